@@ -1,0 +1,218 @@
+"""ctypes bindings to the CPU oracle (oracle/liboracle.so) and to the problem
+library (problems/libproblems.so).  TEST INFRASTRUCTURE: only tests/,
+__graft_entry__.smoke() and bench.py's cpu_baseline leg import this.
+"""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+from libdogleg_amd.ctypes_defs import (Parameters2, CholmodSparse, Trace, TraceBuffer,
+                                       CB_SPARSE, CB_DENSE, CB_PRODUCTS, dptr, iptr)
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_ORACLE = os.path.join(ROOT, "oracle", "liboracle.so")
+_PROBLEMS = os.path.join(ROOT, "problems", "libproblems.so")
+
+
+def build():
+    """gcc-build the oracle and the problem library (seconds)."""
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle")], check=True)
+
+
+def _stale(lib, *srcs):
+    if not os.path.exists(lib):
+        return True
+    t = os.path.getmtime(lib)
+    return any(os.path.exists(s) and os.path.getmtime(s) > t for s in srcs)
+
+
+_libs = {}
+
+
+def oracle():
+    if "o" not in _libs:
+        if _stale(_ORACLE, os.path.join(ROOT, "oracle", "dogleg_oracle.c"),
+                  os.path.join(ROOT, "oracle", "dogleg_oracle.h")):
+            build()
+        L = C.CDLL(_ORACLE)
+        D, I, V = C.POINTER(C.c_double), C.POINTER(C.c_int), C.c_void_p
+        L.orc_optimize_sparse.restype = C.c_double
+        L.orc_optimize_sparse.argtypes = [D, C.c_uint, C.c_uint, C.c_uint, V, V,
+                                          C.POINTER(Parameters2), C.POINTER(Trace)]
+        L.orc_optimize_dense.restype = C.c_double
+        L.orc_optimize_dense.argtypes = [D, C.c_uint, C.c_uint, V, V,
+                                         C.POINTER(Parameters2), C.POINTER(Trace)]
+        L.orc_optimize_dense_products.restype = C.c_double
+        L.orc_optimize_dense_products.argtypes = [D, C.c_uint, V, V,
+                                                  C.POINTER(Parameters2), C.POINTER(Trace)]
+        L.orc_default_parameters.argtypes = [C.POINTER(Parameters2)]
+        L.orc_norm2.restype = C.c_double
+        L.orc_norm2.argtypes = [D, C.c_uint]
+        L.orc_inner.restype = C.c_double
+        L.orc_inner.argtypes = [D, D, C.c_uint]
+        L.orc_spmv_Jt_x.argtypes = [D, C.c_int, C.c_int, I, I, D, D]
+        L.orc_norm2_J_v.restype = C.c_double
+        L.orc_norm2_J_v.argtypes = [C.c_int, I, I, D, D]
+        L.orc_dense_Jt_x.argtypes = [D, D, D, C.c_int, C.c_int]
+        L.orc_dense_norm2_J_v.restype = C.c_double
+        L.orc_dense_norm2_J_v.argtypes = [D, D, C.c_int, C.c_int]
+        L.orc_xt_Apacked_upper_x.restype = C.c_double
+        L.orc_xt_Apacked_upper_x.argtypes = [D, D, C.c_int]
+        L.orc_xt_A_x.restype = C.c_double
+        L.orc_xt_A_x.argtypes = [D, D, C.c_int]
+        L.orc_dense_JtJ_packed_upper.argtypes = [D, D, C.c_int, C.c_int]
+        L.orc_dpptrf_L.restype = C.c_int
+        L.orc_dpptrf_L.argtypes = [C.c_int, D]
+        L.orc_dpptrs_L.argtypes = [C.c_int, D, D]
+        L.orc_dpotrf_L.restype = C.c_int
+        L.orc_dpotrf_L.argtypes = [C.c_int, D, C.c_int]
+        L.orc_dpotrs_L.argtypes = [C.c_int, D, C.c_int, D]
+        L.orc_sparse_analyze.restype = V
+        L.orc_sparse_analyze.argtypes = [C.c_int, C.c_int, I, I]
+        L.orc_sparse_factorize.restype = C.c_long
+        L.orc_sparse_factorize.argtypes = [V, I, I, D, C.c_double]
+        L.orc_sparse_solve.argtypes = [V, D, D]
+        L.orc_sparse_nnzL.restype = C.c_long
+        L.orc_sparse_nnzL.argtypes = [V]
+        L.orc_sparse_flops.restype = C.c_double
+        L.orc_sparse_flops.argtypes = [V]
+        L.orc_sparse_free.argtypes = [V]
+        _libs["o"] = L
+    return _libs["o"]
+
+
+def problems():
+    if "p" not in _libs:
+        if _stale(_PROBLEMS, os.path.join(ROOT, "problems", "problems.c")):
+            build()
+        L = C.CDLL(_PROBLEMS)
+        D, I, V = C.POINTER(C.c_double), C.POINTER(C.c_int), C.c_void_p
+        L.sample_init.argtypes = [D]
+        L.sample_set_measurements.argtypes = [D]
+        L.sample_get_measurements.argtypes = [D]
+        L.synth_ba_create.restype = V
+        L.synth_ba_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64,
+                                      C.c_double, C.c_double, C.c_double, C.c_double, C.c_int]
+        L.synth_dense_create.restype = V
+        L.synth_dense_create.argtypes = [C.c_int, C.c_int, C.c_uint64,
+                                         C.c_double, C.c_double, C.c_double]
+        L.synth_free.argtypes = [V]
+        for f in ("synth_nstate", "synth_nmeas", "synth_nnz", "synth_neval"):
+            getattr(L, f).restype = C.c_int
+            getattr(L, f).argtypes = [V]
+        L.synth_pstar.argtypes = [V, D]
+        L.synth_p0.argtypes = [V, D]
+        L.synth_pattern.argtypes = [V, I, I]
+        L.synth_ba_eval.argtypes = [V, D, D, D]
+        L.synth_cb_dense.argtypes = [D, D, D, V]
+        L.synth_set_products_layout.argtypes = [C.c_int, C.c_int]
+        _libs["p"] = L
+    return _libs["p"]
+
+
+def fn_addr(lib, name):
+    """address of an exported function, as a void* usable as a callback arg."""
+    return C.cast(getattr(lib, name), C.c_void_p)
+
+
+def default_params():
+    p = Parameters2()
+    oracle().orc_default_parameters(C.byref(p))
+    return p
+
+
+class BAProblem:
+    """Synthetic block-arrowhead problem (problems.c, SURVEY.md 8d generator)."""
+
+    def __init__(self, Nc, Np, Nobs, g=6, seed=1, eps=0.3, noise=0.01, p0_spread=0.5,
+                 scale_decades=0.0, n_zero_cols=0):
+        self.lib = problems()
+        self.h = self.lib.synth_ba_create(Nc, Np, Nobs, g, seed, eps, noise, p0_spread,
+                                          scale_decades, n_zero_cols)
+        self.N = self.lib.synth_nstate(self.h)
+        self.M = self.lib.synth_nmeas(self.h)
+        self.nnz = self.lib.synth_nnz(self.h)
+        self.cb = fn_addr(self.lib, "synth_cb_sparse")
+        self.cookie = C.c_void_p(self.h)
+
+    def p0(self):
+        a = np.zeros(self.N)
+        self.lib.synth_p0(self.h, dptr(a))
+        return a
+
+    def pstar(self):
+        a = np.zeros(self.N)
+        self.lib.synth_pstar(self.h, dptr(a))
+        return a
+
+    def pattern(self):
+        Jp = np.zeros(self.M + 1, dtype=np.int32)
+        Ji = np.zeros(self.nnz, dtype=np.int32)
+        self.lib.synth_pattern(self.h, iptr(Jp), iptr(Ji))
+        return Jp, Ji
+
+    def eval(self, p):
+        x = np.zeros(self.M)
+        Jx = np.zeros(self.nnz)
+        self.lib.synth_ba_eval(self.h, dptr(np.ascontiguousarray(p)), dptr(x), dptr(Jx))
+        return x, Jx
+
+    def close(self):
+        if self.h:
+            self.lib.synth_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class DenseProblem:
+    def __init__(self, M, N, seed=1, eps=0.3, noise=0.01, p0_spread=0.5):
+        self.lib = problems()
+        self.h = self.lib.synth_dense_create(M, N, seed, eps, noise, p0_spread)
+        self.M, self.N = M, N
+        self.cb = fn_addr(self.lib, "synth_cb_dense")
+        self.cb_products = fn_addr(self.lib, "synth_cb_products")
+        self.cookie = C.c_void_p(self.h)
+
+    def p0(self):
+        a = np.zeros(self.N)
+        self.lib.synth_p0(self.h, dptr(a))
+        return a
+
+    def eval(self, p):
+        x = np.zeros(self.M)
+        J = np.zeros((self.M, self.N))
+        self.lib.synth_cb_dense(dptr(np.ascontiguousarray(p)), dptr(x), dptr(J), self.h)
+        return x, J
+
+    def close(self):
+        if self.h:
+            self.lib.synth_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def oracle_solve(kind, p0, N, M, nnz, cb, cookie, params=None, capacity=256):
+    """Run the oracle.  kind in {'sparse','dense','products'}.
+    Returns (norm2x, p_final, TraceBuffer)."""
+    L = oracle()
+    p = np.array(p0, dtype=np.float64, copy=True)
+    tr = TraceBuffer(N, capacity)
+    prm = C.byref(params) if params is not None else None
+    if kind == "sparse":
+        r = L.orc_optimize_sparse(dptr(p), N, M, nnz, cb, cookie, prm, tr.byref())
+    elif kind == "dense":
+        r = L.orc_optimize_dense(dptr(p), N, M, cb, cookie, prm, tr.byref())
+    else:
+        r = L.orc_optimize_dense_products(dptr(p), N, cb, cookie, prm, tr.byref())
+    return r, p, tr
