@@ -1,0 +1,163 @@
+/* dlg_backend.h -- the thin C-ABI between the host trust-region driver and the
+ * gfx950 HIP kernels.
+ *
+ * The reference has no seam here: its driver (dogleg.c:1172-1476) calls the
+ * linear-algebra routines (dogleg.c:529-1165) as `static` functions in one
+ * translation unit.  This header is the boundary a reference maintainer would
+ * bind to put those routines on an MI355X; each entry point names the
+ * reference routine it replaces.  Plain C types only: pointers, sizes, ints,
+ * doubles; every function returns DLG_OK (0) or an error code and never
+ * exits the process; dlg_last_error() describes the most recent failure on
+ * the calling thread.
+ *
+ * Data residency: x / J / Jt_x / update vectors / the Cholesky factor live in
+ * HBM for the life of the backend object.  Per trial step only the Jacobian
+ * VALUES and x cross host->device (the user callback runs on the host,
+ * dogleg.c:1016-1022) and p_new plus a few scalars come back.
+ *
+ * Two operating-point slots (0 and 1) mirror ctx->beforeStep / ctx->afterStep
+ * (dogleg.h:178-182); the driver swaps slot ids instead of pointers.
+ */
+#ifndef DLG_BACKEND_H
+#define DLG_BACKEND_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct dlg_backend dlg_backend_t;
+
+enum
+{
+  DLG_OK           = 0,
+  DLG_ERR_HIP      = 1,   /* a HIP runtime call or kernel launch failed      */
+  DLG_ERR_ARG      = 2,   /* bad argument                                    */
+  DLG_ERR_STATE    = 3,   /* op called before its inputs exist               */
+  DLG_ERR_NOMEM    = 4,
+  DLG_ERR_NODEVICE = 5,   /* no usable gfx950 device                         */
+  DLG_ERR_COMM     = 6    /* the all-reduce hook reported failure            */
+};
+
+/* solve types: same values as dogleg_solve_type_t (dogleg.h:158-161) */
+enum { DLG_DENSE = 0, DLG_SPARSE = 1, DLG_DENSE_PRODUCTS = 2 };
+/* flags */
+enum { DLG_FLAG_JTJ_PACKED = 1, DLG_FLAG_JTJ_UPPER = 2 };
+/* step kinds for dlg_make_step (the three branches of dogleg.c:1192-1256) */
+enum { DLG_KIND_CAUCHY_TO_EDGE = 0, DLG_KIND_GAUSSNEWTON = 1, DLG_KIND_INTERPOLATED = 2 };
+/* vectors that can be downloaded from a slot */
+enum
+{
+  DLG_VEC_P = 0, DLG_VEC_X = 1, DLG_VEC_JTX = 2, DLG_VEC_CAUCHY = 3,
+  DLG_VEC_GN = 4, DLG_VEC_STEP = 5, DLG_VEC_J = 6
+};
+
+const char* dlg_last_error(void);
+int         dlg_device_count(void);
+
+/* ---- lifecycle: replaces allocOperatingPoint x2 + factorization storage
+ * (dogleg.c:1479-1562, 1707-1728).  device < 0: current device. ------------- */
+int  dlg_backend_create(dlg_backend_t** out, int solve_type, int Nstate, int Nmeas,
+                        int NJnnz, int flags, int device);
+void dlg_backend_destroy(dlg_backend_t* b);
+/* run on a caller-owned HIP stream (hipStream_t passed as void*) */
+int  dlg_backend_set_stream(dlg_backend_t* b, void* hip_stream);
+void* dlg_backend_get_stream(dlg_backend_t* b);
+
+/* ---- multi-GPU: measurement rows are the sharded unit (every J-dependent
+ * quantity is a sum over rows: dogleg.c:253-260, 269-278, 712-714).  A rank
+ * owns rows [row0,row1) and must be given a sum-all-reduce over `count`
+ * doubles at device address `buf` (RCCL, or torch.distributed through the
+ * Python binding).  Without a hook the backend is single-rank. */
+typedef int (*dlg_allreduce_fn)(void* buf, size_t count, void* cookie);
+int  dlg_backend_set_shard(dlg_backend_t* b, int row0, int row1,
+                           dlg_allreduce_fn fn, void* cookie);
+
+/* ---- sparse pattern: replaces cholmod_analyze (dogleg.c:650-654).  The
+ * pattern is assumed constant for the life of the solve, as the reference
+ * assumes (dogleg.c:648-649).  colptr[Nmeas+1], rowidx[NJnnz] on the host
+ * (the FULL pattern, also on a sharded rank).  Runs the host symbolic phase
+ * (block detection, ordering, supernodes, schedules) and uploads it. */
+int  dlg_sparse_set_pattern(dlg_backend_t* b, const int* colptr, const int* rowidx);
+/* statistics of the symbolic phase; any pointer may be NULL */
+int  dlg_sparse_stats(dlg_backend_t* b, long* nnz_JtJ_lower, long* nnz_L,
+                      int* n_supernodes, int* n_levels, double* factor_flops);
+
+/* ---- operating point inputs (host buffers; the callback's outputs).
+ * K1 = computeCallbackOperatingPoint after the callback (dogleg.c:1024-1082):
+ * Jt_x = Jt*x, norm2_x, and max_i |Jt_x[i]| for the gradient test. --------- */
+int  dlg_point_set_p(dlg_backend_t* b, int slot, const double* p_host);
+int  dlg_point_upload(dlg_backend_t* b, int slot, const double* x_host,
+                      const double* J_host);           /* sparse: values[nnz]; dense: J[M][N] */
+int  dlg_point_upload_products(dlg_backend_t* b, int slot, double norm2x,
+                               const double* Jtx_host, const double* JtJ_host);
+/* device-resident inputs (no PCIe): x and J already in HBM */
+int  dlg_point_bind_device(dlg_backend_t* b, int slot, const double* x_dev,
+                           const double* J_dev);
+int  dlg_point_eval(dlg_backend_t* b, int slot, double* norm2_x, double* Jtx_absmax);
+
+/* ---- K3: compute_updateCauchy (dogleg.c:529-617) -------------------------- */
+int  dlg_cauchy(dlg_backend_t* b, int slot, double* norm2_updateCauchy);
+
+/* ---- K4+K5: one pass of the loop body of dogleg_computeJtJfactorization
+ * (dogleg.c:656-677 / 699-816): assemble JtJ + lambda*I and factorise.
+ * *ok = 1 on success, 0 if not positive definite (the host raises lambda). -- */
+int  dlg_factorize(dlg_backend_t* b, int slot, double lambda, int* ok);
+
+/* ---- K6: compute_updateGN (dogleg.c:822-908): updateGN = -(JtJ)^-1 Jt_x ---- */
+int  dlg_solve_gn(dlg_backend_t* b, int slot, double* norm2_updateGN);
+
+/* ---- K7 + the vector part of takeStepFrom (dogleg.c:1192-1259,1289-1291):
+ * form the step of the given kind from slot `from`, store it as
+ * step_to_here of slot `to`, set p[to] = p[from] + step, copy p[to] to
+ * p_new_host (may be NULL).  norm2_step follows the reference's reporting
+ * (unscaled Cauchy length for DLG_KIND_CAUCHY_TO_EDGE). -------------------- */
+int  dlg_make_step(dlg_backend_t* b, int from, int to, int kind, double trustregion,
+                   double* norm2_step, double* k_cauchy_to_gn, double* step_absmax,
+                   double* p_new_host);
+
+/* ---- K8: computeExpectedImprovement (dogleg.c:1085-1165) for the step held
+ * in slot `to`, evaluated with J / Jt_x of slot `from` ---------------------- */
+int  dlg_expected_improvement(dlg_backend_t* b, int from, int to, double* out);
+
+/* ---- downloads (returnContext, tests) -------------------------------------- */
+int  dlg_point_download(dlg_backend_t* b, int slot, int which, double* host, size_t n);
+/* dense factor in the reference's layout (packed as dpptrf('L') leaves it, or
+ * full N*N for unpacked products): dogleg.h:192-194 */
+int  dlg_factor_download_dense(dlg_backend_t* b, double* host, size_t n);
+/* device address of a slot vector (DLG_VEC_*), for zero-copy harnesses */
+void* dlg_point_device_ptr(dlg_backend_t* b, int slot, int which);
+
+/* ---- stand-alone kernels exposed for parity tests and micro-benchmarks ----
+ * C (n x n, column-major, ldc) lower triangle += A^T-style rank-K update:
+ * C[i,j] += alpha * sum_k A[i + k*lda] * A[j + k*lda]   (i >= j)
+ * with device pointers.  This is the fp64-MFMA kernel behind K4-dense and the
+ * trailing updates of K5-dense. */
+int  dlg_kernel_syrk_lower(void* hip_stream, double* C_dev, int ldc, const double* A_dev,
+                           int lda, int n, int K, double alpha, double* workspace_dev,
+                           size_t workspace_bytes);
+/* in-place blocked Cholesky of the lower triangle (column-major). info_dev: int */
+int  dlg_kernel_potrf_lower(void* hip_stream, double* A_dev, int lda, int n, int* info_dev);
+/* f64 MFMA issue-rate probe: returns achieved TFLOP/s */
+int  dlg_probe_mfma_f64(double* tflops);
+int  dlg_probe_hbm_copy(double* gbytes_per_s);
+
+/* ---- raw device-memory helpers for harnesses that hold inputs in HBM without
+ * a framework (tests, bench): thin wrappers of hipMalloc/hipMemcpy/hipFree --- */
+void* dlg_mem_alloc(size_t bytes);
+void  dlg_mem_free(void* dev);
+int   dlg_mem_upload(void* dev, const void* host, size_t bytes);
+int   dlg_mem_download(void* host, const void* dev, size_t bytes);
+int   dlg_mem_zero(void* dev, size_t bytes);
+int   dlg_device_sync(void);
+
+/* ---- trial trace sink used by the dogleg_optimize* entry points on the
+ * calling thread (include/dlg_trace.h); NULL disables ---------------------- */
+struct dlg_trace_s;
+void dlg_set_trace(void* dlg_trace_t_ptr);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,61 @@
+"""Build libdogleg_amd.so (HIP kernels + C-ABI + host driver) for gfx950.
+
+hipcc cross-compiles without a GPU.  Objects are cached per source under
+libdogleg_amd/csrc/_obj and rebuilt when the source or a header changes.
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(CSRC, "_obj")
+LIB = os.path.join(HERE, "libdogleg_amd.so")
+ARCH = "gfx950"
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall",
+         "-Wno-unused-function", "-Wno-unused-result"]
+
+
+def sources():
+    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
+
+
+def headers():
+    inc = os.path.join(os.path.dirname(HERE), "include")
+    hs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    hs += [os.path.join(inc, f) for f in os.listdir(inc) if f.endswith(".h")]
+    return hs
+
+
+def _compile(src, newest_hdr, verbose):
+    obj = os.path.join(OBJ, os.path.basename(src) + ".o")
+    if os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(src), newest_hdr):
+        return obj
+    cmd = [HIPCC] + FLAGS + ["-c", src, "-o", obj]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+    return obj
+
+
+def build(verbose=False, force=False):
+    os.makedirs(OBJ, exist_ok=True)
+    if force:
+        for f in os.listdir(OBJ):
+            os.remove(os.path.join(OBJ, f))
+    newest_hdr = max(os.path.getmtime(h) for h in headers())
+    srcs = sources()
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        objs = list(ex.map(lambda s: _compile(s, newest_hdr, verbose), srcs))
+    if (not os.path.exists(LIB)) or any(os.path.getmtime(o) > os.path.getmtime(LIB) for o in objs):
+        cmd = [HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB] + objs
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(verbose=True, force="--force" in sys.argv))

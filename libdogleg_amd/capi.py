@@ -1,0 +1,296 @@
+"""ctypes bindings to libdogleg_amd.so: the dogleg.h API (include/dogleg.h) and
+the backend C-ABI (include/dlg_backend.h).  There is no CPU fallback: if the
+HIP library is missing this module raises at load time, and every compute
+entry point fails with DLG_ERR_NODEVICE when no GPU is present.
+"""
+import ctypes as C
+import os
+import numpy as np
+
+from .ctypes_defs import (Parameters2, CholmodSparse, Trace, TraceBuffer,
+                          CB_SPARSE, CB_DENSE, CB_PRODUCTS, dptr, iptr)
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libdogleg_amd.so")
+
+DLG_OK = 0
+DLG_DENSE, DLG_SPARSE, DLG_DENSE_PRODUCTS = 0, 1, 2
+FLAG_PACKED, FLAG_UPPER = 1, 2
+KIND_CAUCHY, KIND_GN, KIND_INTERP = 0, 1, 2
+VEC_P, VEC_X, VEC_JTX, VEC_CAUCHY, VEC_GN, VEC_STEP, VEC_J = range(7)
+
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_size_t, C.c_void_p)
+
+# every symbol include/dlg_backend.h and include/dogleg.h declare
+BACKEND_SYMBOLS = [
+    "dlg_last_error", "dlg_device_count", "dlg_backend_create", "dlg_backend_destroy",
+    "dlg_backend_set_stream", "dlg_backend_get_stream", "dlg_backend_set_shard",
+    "dlg_sparse_set_pattern", "dlg_sparse_stats", "dlg_point_set_p", "dlg_point_upload",
+    "dlg_point_upload_products", "dlg_point_bind_device", "dlg_point_eval", "dlg_cauchy",
+    "dlg_factorize", "dlg_solve_gn", "dlg_make_step", "dlg_expected_improvement",
+    "dlg_point_download", "dlg_factor_download_dense", "dlg_point_device_ptr",
+    "dlg_kernel_syrk_lower", "dlg_kernel_potrf_lower", "dlg_probe_mfma_f64",
+    "dlg_probe_hbm_copy", "dlg_set_trace", "dlg_mem_alloc", "dlg_mem_free", "dlg_mem_upload",
+    "dlg_mem_download", "dlg_mem_zero", "dlg_device_sync",
+]
+DOGLEG_SYMBOLS = [
+    "dogleg_getDefaultParameters", "dogleg_setMaxIterations",
+    "dogleg_setTrustregionUpdateParameters", "dogleg_setDebug", "dogleg_setInitialTrustregion",
+    "dogleg_setThresholds", "dogleg_optimize", "dogleg_optimize2", "dogleg_optimize_dense",
+    "dogleg_optimize_dense2", "dogleg_optimize_dense_products", "dogleg_computeJtJfactorization",
+    "dogleg_freeContext",
+]
+
+_lib = None
+
+
+class DlgError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load libdogleg_amd.so (building it is __graft_entry__.build()'s job)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise DlgError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; "
+                       "g.build()'` (there is no CPU fallback)")
+    L = C.CDLL(LIB_PATH)
+    D, I, V = C.POINTER(C.c_double), C.POINTER(C.c_int), C.c_void_p
+    L.dlg_last_error.restype = C.c_char_p
+    L.dlg_device_count.restype = C.c_int
+    L.dlg_backend_create.argtypes = [C.POINTER(V), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+    L.dlg_backend_destroy.argtypes = [V]
+    L.dlg_backend_destroy.restype = None
+    L.dlg_backend_set_stream.argtypes = [V, V]
+    L.dlg_backend_get_stream.argtypes = [V]
+    L.dlg_backend_get_stream.restype = V
+    L.dlg_backend_set_shard.argtypes = [V, C.c_int, C.c_int, V, V]
+    L.dlg_sparse_set_pattern.argtypes = [V, I, I]
+    L.dlg_sparse_stats.argtypes = [V, C.POINTER(C.c_long), C.POINTER(C.c_long), I, I, D]
+    L.dlg_point_set_p.argtypes = [V, C.c_int, D]
+    L.dlg_point_upload.argtypes = [V, C.c_int, D, D]
+    L.dlg_point_upload_products.argtypes = [V, C.c_int, C.c_double, D, D]
+    L.dlg_point_bind_device.argtypes = [V, C.c_int, V, V]
+    L.dlg_point_eval.argtypes = [V, C.c_int, D, D]
+    L.dlg_cauchy.argtypes = [V, C.c_int, D]
+    L.dlg_factorize.argtypes = [V, C.c_int, C.c_double, I]
+    L.dlg_solve_gn.argtypes = [V, C.c_int, D]
+    L.dlg_make_step.argtypes = [V, C.c_int, C.c_int, C.c_int, C.c_double, D, D, D, D]
+    L.dlg_expected_improvement.argtypes = [V, C.c_int, C.c_int, D]
+    L.dlg_point_download.argtypes = [V, C.c_int, C.c_int, D, C.c_size_t]
+    L.dlg_factor_download_dense.argtypes = [V, D, C.c_size_t]
+    L.dlg_point_device_ptr.argtypes = [V, C.c_int, C.c_int]
+    L.dlg_point_device_ptr.restype = V
+    L.dlg_kernel_syrk_lower.argtypes = [V, V, C.c_int, V, C.c_int, C.c_int, C.c_int, C.c_double, V, C.c_size_t]
+    L.dlg_kernel_potrf_lower.argtypes = [V, V, C.c_int, C.c_int, V]
+    L.dlg_probe_mfma_f64.argtypes = [D]
+    L.dlg_probe_hbm_copy.argtypes = [D]
+    L.dlg_set_trace.argtypes = [V]
+    L.dlg_set_trace.restype = None
+    L.dlg_mem_alloc.argtypes = [C.c_size_t]
+    L.dlg_mem_alloc.restype = V
+    L.dlg_mem_free.argtypes = [V]
+    L.dlg_mem_free.restype = None
+    L.dlg_mem_upload.argtypes = [V, V, C.c_size_t]
+    L.dlg_mem_download.argtypes = [V, V, C.c_size_t]
+    L.dlg_mem_zero.argtypes = [V, C.c_size_t]
+    # dogleg.h
+    PP = C.POINTER(Parameters2)
+    L.dogleg_getDefaultParameters.argtypes = [PP]
+    L.dogleg_getDefaultParameters.restype = None
+    L.dogleg_optimize2.restype = C.c_double
+    L.dogleg_optimize2.argtypes = [D, C.c_uint, C.c_uint, C.c_uint, V, V, PP, V]
+    L.dogleg_optimize.restype = C.c_double
+    L.dogleg_optimize.argtypes = [D, C.c_uint, C.c_uint, C.c_uint, V, V, V]
+    L.dogleg_optimize_dense2.restype = C.c_double
+    L.dogleg_optimize_dense2.argtypes = [D, C.c_uint, C.c_uint, V, V, PP, V]
+    L.dogleg_optimize_dense.restype = C.c_double
+    L.dogleg_optimize_dense.argtypes = [D, C.c_uint, C.c_uint, V, V, V]
+    L.dogleg_optimize_dense_products.restype = C.c_double
+    L.dogleg_optimize_dense_products.argtypes = [D, C.c_uint, V, V, PP, V]
+    L.dogleg_freeContext.argtypes = [V]
+    L.dogleg_freeContext.restype = None
+    L.dogleg_setMaxIterations.argtypes = [C.c_int]
+    L.dogleg_setDebug.argtypes = [C.c_int]
+    L.dogleg_setInitialTrustregion.argtypes = [C.c_double]
+    L.dogleg_setThresholds.argtypes = [C.c_double, C.c_double, C.c_double]
+    L.dogleg_setTrustregionUpdateParameters.argtypes = [C.c_double] * 4
+    _lib = L
+    return L
+
+
+def _ck(rc, what=""):
+    if rc != DLG_OK:
+        raise DlgError(f"{what} failed (code {rc}): {lib().dlg_last_error().decode()}")
+
+
+def default_parameters():
+    p = Parameters2()
+    lib().dogleg_getDefaultParameters(C.byref(p))
+    return p
+
+
+def optimize(kind, p0, N, M, nnz, cb, cookie, params=None, capacity=256):
+    """dogleg_optimize2 / _dense2 / _dense_products with a per-trial trace.
+    kind in {'sparse','dense','products'}; cb is a function address (c_void_p).
+    Returns (norm2x, p_final, TraceBuffer)."""
+    L = lib()
+    p = np.array(p0, dtype=np.float64, copy=True)
+    tr = TraceBuffer(N, capacity)
+    prm = C.byref(params) if params is not None else None
+    L.dlg_set_trace(C.cast(tr.byref(), C.c_void_p))
+    try:
+        if kind == "sparse":
+            r = L.dogleg_optimize2(dptr(p), N, M, nnz, cb, cookie, prm, None)
+        elif kind == "dense":
+            r = L.dogleg_optimize_dense2(dptr(p), N, M, cb, cookie, prm, None)
+        else:
+            r = L.dogleg_optimize_dense_products(dptr(p), N, cb, cookie, prm, None)
+    finally:
+        L.dlg_set_trace(None)
+    return r, p, tr
+
+
+class DeviceArray:
+    """A hipMalloc'ed buffer filled from / read back into numpy (harness helper)."""
+
+    def __init__(self, arr=None, nbytes=None, dtype=np.float64):
+        L = lib()
+        if arr is not None:
+            arr = np.ascontiguousarray(arr)
+            nbytes, dtype = arr.nbytes, arr.dtype
+        self.nbytes, self.dtype = nbytes, np.dtype(dtype)
+        self.ptr = L.dlg_mem_alloc(nbytes)
+        if not self.ptr:
+            raise DlgError(L.dlg_last_error().decode())
+        if arr is not None:
+            _ck(L.dlg_mem_upload(self.ptr, arr.ctypes.data, nbytes), "upload")
+        else:
+            _ck(L.dlg_mem_zero(self.ptr, nbytes), "memset")
+
+    def numpy(self, shape=None):
+        out = np.zeros(self.nbytes // self.dtype.itemsize, dtype=self.dtype)
+        _ck(lib().dlg_mem_download(out.ctypes.data, self.ptr, self.nbytes), "download")
+        return out.reshape(shape) if shape is not None else out
+
+    def free(self):
+        if self.ptr:
+            lib().dlg_mem_free(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Backend:
+    """Thin OO wrapper over the dlg_backend C-ABI (include/dlg_backend.h)."""
+
+    def __init__(self, solve_type, N, M, nnz=0, flags=0, device=-1):
+        self.L = lib()
+        self.h = C.c_void_p()
+        self.N, self.M, self.nnz, self.type = N, M, nnz, solve_type
+        _ck(self.L.dlg_backend_create(C.byref(self.h), solve_type, N, M, nnz, flags, device),
+            "dlg_backend_create")
+        self._keep = []
+
+    def close(self):
+        if self.h:
+            self.L.dlg_backend_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_stream(self, stream_ptr):
+        _ck(self.L.dlg_backend_set_stream(self.h, C.c_void_p(stream_ptr)), "set_stream")
+
+    def set_shard(self, row0, row1, fn=None):
+        cb = ALLREDUCE_FN(fn) if fn is not None else None
+        self._keep.append(cb)
+        _ck(self.L.dlg_backend_set_shard(self.h, row0, row1,
+                                         C.cast(cb, C.c_void_p) if cb else None, None), "set_shard")
+
+    def set_pattern(self, Jp, Ji):
+        Jp = np.ascontiguousarray(Jp, dtype=np.int32)
+        Ji = np.ascontiguousarray(Ji, dtype=np.int32)
+        _ck(self.L.dlg_sparse_set_pattern(self.h, iptr(Jp), iptr(Ji)), "set_pattern")
+
+    def stats(self):
+        a, b = C.c_long(), C.c_long()
+        c, d = C.c_int(), C.c_int()
+        e = C.c_double()
+        _ck(self.L.dlg_sparse_stats(self.h, C.byref(a), C.byref(b), C.byref(c), C.byref(d), C.byref(e)),
+            "stats")
+        return dict(nnz_JtJ_lower=a.value, nnz_L=b.value, n_supernodes=c.value, n_levels=d.value,
+                    factor_flops=e.value)
+
+    def set_p(self, slot, p):
+        p = np.ascontiguousarray(p, dtype=np.float64)
+        _ck(self.L.dlg_point_set_p(self.h, slot, dptr(p)), "set_p")
+
+    def upload(self, slot, x, J):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        J = np.ascontiguousarray(J, dtype=np.float64)
+        self._keep = [x, J]
+        _ck(self.L.dlg_point_upload(self.h, slot, dptr(x), dptr(J)), "upload")
+
+    def upload_products(self, slot, norm2x, Jtx, JtJ):
+        Jtx = np.ascontiguousarray(Jtx, dtype=np.float64)
+        JtJ = np.ascontiguousarray(JtJ, dtype=np.float64)
+        self._keep = [Jtx, JtJ]
+        _ck(self.L.dlg_point_upload_products(self.h, slot, norm2x, dptr(Jtx), dptr(JtJ)), "upload")
+
+    def bind_device(self, slot, x_ptr, J_ptr):
+        _ck(self.L.dlg_point_bind_device(self.h, slot, C.c_void_p(x_ptr), C.c_void_p(J_ptr)), "bind")
+
+    def eval(self, slot):
+        a, b = C.c_double(), C.c_double()
+        _ck(self.L.dlg_point_eval(self.h, slot, C.byref(a), C.byref(b)), "eval")
+        return a.value, b.value
+
+    def cauchy(self, slot):
+        a = C.c_double()
+        _ck(self.L.dlg_cauchy(self.h, slot, C.byref(a)), "cauchy")
+        return a.value
+
+    def factorize(self, slot, lam=0.0):
+        ok = C.c_int()
+        _ck(self.L.dlg_factorize(self.h, slot, lam, C.byref(ok)), "factorize")
+        return bool(ok.value)
+
+    def solve_gn(self, slot):
+        a = C.c_double()
+        _ck(self.L.dlg_solve_gn(self.h, slot, C.byref(a)), "solve_gn")
+        return a.value
+
+    def make_step(self, frm, to, kind, trustregion, want_p=True):
+        n2, k, am = C.c_double(), C.c_double(), C.c_double()
+        pn = np.zeros(self.N) if want_p else None
+        _ck(self.L.dlg_make_step(self.h, frm, to, kind, trustregion, C.byref(n2), C.byref(k),
+                                 C.byref(am), dptr(pn) if want_p else None), "make_step")
+        return n2.value, k.value, am.value, pn
+
+    def expected_improvement(self, frm, to):
+        a = C.c_double()
+        _ck(self.L.dlg_expected_improvement(self.h, frm, to, C.byref(a)), "expected_improvement")
+        return a.value
+
+    def download(self, slot, which, n=None):
+        if n is None:
+            n = self.M if which == VEC_X else self.N
+        out = np.zeros(n)
+        _ck(self.L.dlg_point_download(self.h, slot, which, dptr(out), n), "download")
+        return out
+
+    def factor_dense(self, n):
+        out = np.zeros(n)
+        _ck(self.L.dlg_factor_download_dense(self.h, dptr(out), n), "factor download")
+        return out

@@ -1,0 +1,454 @@
+// backend.hip -- implementation of the C-ABI in include/dlg_backend.h: context
+// lifecycle, operating-point slots, and the per-op orchestration that strings
+// the HIP kernels together.  No CPU arithmetic happens here: every op is a
+// kernel sequence on b->stream followed by one small D2H of result scalars.
+#include "dlg_internal.h"
+
+// ------------------------------------------------------------------ errors --
+static thread_local char g_err[1024] = "";
+void dlg_set_error(const char* fmt, ...)
+{
+  va_list ap; va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+extern "C" const char* dlg_last_error(void) { return g_err; }
+
+extern "C" int dlg_device_count(void)
+{
+  int n = 0;
+  if(hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int dlg_fetch_scalars(dlg_backend* b, int n)
+{
+  DLG_HIP(hipMemcpyAsync(b->h_scal, b->d_scal, sizeof(double)*(size_t)n, hipMemcpyDeviceToHost,
+                         b->stream));
+  DLG_HIP(hipStreamSynchronize(b->stream));
+  return DLG_OK;
+}
+
+static size_t j_doubles(const dlg_backend* b)
+{
+  const size_t N = (size_t)b->N;
+  switch(b->type)
+  {
+  case DLG_DENSE:  return (size_t)b->M*N;
+  case DLG_SPARSE: return (size_t)b->nnz;
+  default:         return (b->flags & DLG_FLAG_JTJ_PACKED) ? N*(N+1)/2 : N*N;
+  }
+}
+
+// ---------------------------------------------------------------- lifecycle --
+extern "C" int dlg_backend_create(dlg_backend_t** out, int solve_type, int Nstate, int Nmeas,
+                                  int NJnnz, int flags, int device)
+{
+  if(!out || Nstate <= 0 || Nmeas < 0 || solve_type < 0 || solve_type > 2)
+  { dlg_set_error("dlg_backend_create: bad arguments"); return DLG_ERR_ARG; }
+  if(solve_type == DLG_SPARSE && NJnnz <= 0)
+  { dlg_set_error("sparse backend needs NJnnz > 0"); return DLG_ERR_ARG; }
+  int ndev = 0;
+  if(hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+  {
+    dlg_set_error("no HIP device available: libdogleg_amd has no CPU fallback");
+    return DLG_ERR_NODEVICE;
+  }
+  if(device >= 0) DLG_HIP(hipSetDevice(device));
+  else            DLG_HIP(hipGetDevice(&device));
+
+  dlg_backend* b = new (std::nothrow) dlg_backend();
+  if(!b) { dlg_set_error("out of host memory"); return DLG_ERR_NOMEM; }
+  b->type = solve_type; b->N = Nstate; b->M = Nmeas; b->nnz = NJnnz; b->flags = flags;
+  b->device = device;
+  b->row0 = 0; b->row1 = Nmeas;
+  *out = nullptr;
+
+  auto fail = [&](int rc) { dlg_backend_destroy(b); return rc; };
+#define TRY_HIP(call) do { hipError_t e_ = (call); if(e_ != hipSuccess) { \
+    dlg_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); \
+    return fail(DLG_ERR_HIP); } } while(0)
+
+  TRY_HIP(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
+  b->own_stream = true;
+  TRY_HIP(hipMalloc(&b->d_scal, sizeof(double)*dlg_backend::NSCAL));
+  TRY_HIP(hipMemsetAsync(b->d_scal, 0, sizeof(double)*dlg_backend::NSCAL, b->stream));
+  TRY_HIP(hipHostMalloc(&b->h_scal, sizeof(double)*dlg_backend::NSCAL));
+  TRY_HIP(hipHostMalloc(&b->h_vec, sizeof(double)*(size_t)Nstate));
+  TRY_HIP(hipMalloc(&b->d_work, sizeof(double)*(size_t)Nstate));
+  const size_t N = (size_t)Nstate, M = (size_t)Nmeas;
+  for(int s = 0; s < 2; s++)
+  {
+    DlgSlot& S = b->slot[s];
+    TRY_HIP(hipMalloc(&S.p,      sizeof(double)*N));
+    TRY_HIP(hipMalloc(&S.Jt_x,   sizeof(double)*N));
+    TRY_HIP(hipMalloc(&S.cauchy, sizeof(double)*N));
+    TRY_HIP(hipMalloc(&S.gn,     sizeof(double)*N));
+    TRY_HIP(hipMalloc(&S.step,   sizeof(double)*N));
+    TRY_HIP(hipMemsetAsync(S.p, 0, sizeof(double)*N, b->stream));
+    TRY_HIP(hipMemsetAsync(S.step, 0, sizeof(double)*N, b->stream));
+    if(solve_type != DLG_DENSE_PRODUCTS && M > 0) TRY_HIP(hipMalloc(&S.x, sizeof(double)*M));
+    TRY_HIP(hipMalloc(&S.J, sizeof(double)*j_doubles(b)));
+  }
+#undef TRY_HIP
+  int rc = (solve_type == DLG_SPARSE) ? sparse_create(b) : dense_create(b);
+  if(rc != DLG_OK) return fail(rc);
+  if(hipStreamSynchronize(b->stream) != hipSuccess)
+  { dlg_set_error("stream sync failed during create"); return fail(DLG_ERR_HIP); }
+  *out = b;
+  return DLG_OK;
+}
+
+extern "C" void dlg_backend_destroy(dlg_backend_t* b)
+{
+  if(!b) return;
+  if(b->stream) (void)hipStreamSynchronize(b->stream);
+  if(b->type == DLG_SPARSE) sparse_destroy(b); else dense_destroy(b);
+  for(int s = 0; s < 2; s++)
+  {
+    DlgSlot& S = b->slot[s];
+    double* v[] = { S.p, S.x, S.J, S.Jt_x, S.cauchy, S.gn, S.step };
+    for(double* q : v) if(q) (void)hipFree(q);
+  }
+  if(b->d_scal) (void)hipFree(b->d_scal);
+  if(b->h_scal) (void)hipHostFree(b->h_scal);
+  if(b->h_vec)  (void)hipHostFree(b->h_vec);
+  if(b->d_part) (void)hipFree(b->d_part);
+  if(b->d_work) (void)hipFree(b->d_work);
+  if(b->d_red)  (void)hipFree(b->d_red);
+  if(b->own_stream && b->stream) (void)hipStreamDestroy(b->stream);
+  delete b;
+}
+
+extern "C" int dlg_backend_set_stream(dlg_backend_t* b, void* hip_stream)
+{
+  if(!b) return DLG_ERR_ARG;
+  if(b->stream) DLG_HIP(hipStreamSynchronize(b->stream));
+  if(b->own_stream && b->stream) (void)hipStreamDestroy(b->stream);
+  b->stream = (hipStream_t)hip_stream;
+  b->own_stream = false;
+  return DLG_OK;
+}
+extern "C" void* dlg_backend_get_stream(dlg_backend_t* b) { return b ? (void*)b->stream : nullptr; }
+
+extern "C" int dlg_backend_set_shard(dlg_backend_t* b, int row0, int row1, dlg_allreduce_fn fn,
+                                     void* cookie)
+{
+  if(!b || row0 < 0 || row1 < row0 || row1 > b->M)
+  { dlg_set_error("dlg_backend_set_shard: bad row range"); return DLG_ERR_ARG; }
+  if(b->type == DLG_DENSE_PRODUCTS)
+  { dlg_set_error("dense-products has no measurement rows to shard"); return DLG_ERR_ARG; }
+  if(b->type == DLG_SPARSE && b->sym)
+  { dlg_set_error("set the shard before dlg_sparse_set_pattern"); return DLG_ERR_STATE; }
+  b->row0 = row0; b->row1 = row1; b->allreduce = fn; b->allreduce_cookie = cookie;
+  return DLG_OK;
+}
+
+// sum-all-reduce `count` doubles at device address buf across ranks (no-op single rank)
+static int allreduce(dlg_backend* b, double* buf, size_t count)
+{
+  if(!b->allreduce) return DLG_OK;
+  DLG_HIP(hipStreamSynchronize(b->stream));
+  if(b->allreduce(buf, count, b->allreduce_cookie) != 0)
+  { dlg_set_error("all-reduce hook failed"); return DLG_ERR_COMM; }
+  return DLG_OK;
+}
+int dlg_allreduce_dev(dlg_backend* b, double* buf, size_t count) { return allreduce(b, buf, count); }
+
+extern "C" int dlg_sparse_set_pattern(dlg_backend_t* b, const int* colptr, const int* rowidx)
+{
+  if(!b || b->type != DLG_SPARSE || !colptr || !rowidx)
+  { dlg_set_error("dlg_sparse_set_pattern: bad arguments"); return DLG_ERR_ARG; }
+  return sparse_set_pattern(b, colptr, rowidx);
+}
+
+// ------------------------------------------------------------------ inputs --
+static int check_slot(dlg_backend* b, int s)
+{
+  if(!b || s < 0 || s > 1) { dlg_set_error("bad backend/slot"); return DLG_ERR_ARG; }
+  return DLG_OK;
+}
+static void invalidate(DlgSlot& S)
+{
+  S.have_Jtx = S.have_cauchy = S.have_gn = false;
+}
+
+extern "C" int dlg_point_set_p(dlg_backend_t* b, int s, const double* p_host)
+{
+  DLG_CHECK(check_slot(b, s));
+  DLG_HIP(hipMemcpyAsync(b->slot[s].p, p_host, sizeof(double)*(size_t)b->N, hipMemcpyHostToDevice,
+                         b->stream));
+  DLG_HIP(hipStreamSynchronize(b->stream));     // p_host may be pageable / reused
+  return DLG_OK;
+}
+
+extern "C" int dlg_point_upload(dlg_backend_t* b, int s, const double* x_host, const double* J_host)
+{
+  DLG_CHECK(check_slot(b, s));
+  if(b->type == DLG_DENSE_PRODUCTS) { dlg_set_error("use dlg_point_upload_products"); return DLG_ERR_ARG; }
+  DlgSlot& S = b->slot[s];
+  S.x_bound = S.J_bound = nullptr;
+  // a sharded rank uploads only its own rows: x[row0:row1] and the J entries of those rows
+  const size_t mloc = (size_t)dlg_mloc(b);
+  if(mloc > 0)
+    DLG_HIP(hipMemcpyAsync(S.x, x_host, sizeof(double)*mloc, hipMemcpyHostToDevice, b->stream));
+  const size_t jn = (b->type == DLG_DENSE) ? mloc*(size_t)b->N : sparse_local_nnz(b);
+  if(jn > 0)
+    DLG_HIP(hipMemcpyAsync(S.J, J_host, sizeof(double)*jn, hipMemcpyHostToDevice, b->stream));
+  S.have_inputs = true;
+  invalidate(S);
+  if(b->factor_slot == s) b->factor_slot = -1;
+  return DLG_OK;
+}
+
+extern "C" int dlg_point_upload_products(dlg_backend_t* b, int s, double norm2x, const double* Jtx_host,
+                                         const double* JtJ_host)
+{
+  DLG_CHECK(check_slot(b, s));
+  if(b->type != DLG_DENSE_PRODUCTS) { dlg_set_error("not a dense-products backend"); return DLG_ERR_ARG; }
+  DlgSlot& S = b->slot[s];
+  S.x_bound = S.J_bound = nullptr;
+  DLG_HIP(hipMemcpyAsync(S.Jt_x, Jtx_host, sizeof(double)*(size_t)b->N, hipMemcpyHostToDevice, b->stream));
+  DLG_HIP(hipMemcpyAsync(S.J, JtJ_host, sizeof(double)*j_doubles(b), hipMemcpyHostToDevice, b->stream));
+  S.norm2_x = norm2x;
+  S.have_inputs = true;
+  invalidate(S);
+  if(b->factor_slot == s) b->factor_slot = -1;
+  return DLG_OK;
+}
+
+extern "C" int dlg_point_bind_device(dlg_backend_t* b, int s, const double* x_dev, const double* J_dev)
+{
+  DLG_CHECK(check_slot(b, s));
+  DlgSlot& S = b->slot[s];
+  S.x_bound = x_dev; S.J_bound = J_dev;
+  S.have_inputs = true;
+  invalidate(S);
+  if(b->factor_slot == s) b->factor_slot = -1;
+  return DLG_OK;
+}
+
+// ---------------------------------------------------------------------- K1 --
+extern "C" int dlg_point_eval(dlg_backend_t* b, int s, double* norm2_x, double* Jtx_absmax)
+{
+  DLG_CHECK(check_slot(b, s));
+  DlgSlot& S = b->slot[s];
+  if(!S.have_inputs) { dlg_set_error("dlg_point_eval: no inputs uploaded for slot %d", s); return DLG_ERR_STATE; }
+  if(b->type == DLG_DENSE_PRODUCTS)
+  {
+    // the callback already reduced over the measurements (dogleg.c:1057-1068)
+    DLG_CHECK(k_norm2_absmax(b, S.Jt_x, b->N, b->d_scal + 2));
+    DLG_CHECK(dlg_fetch_scalars(b, 4));
+  }
+  else
+  {
+    const int mloc = b->row1 - b->row0;
+    if(b->type == DLG_SPARSE) DLG_CHECK(sparse_eval(b, s)); else DLG_CHECK(dense_eval(b, s));
+    // norm2_x over the local rows
+    if(mloc > 0) DLG_CHECK(k_norm2_absmax(b, S.xin(), mloc, b->d_scal));
+    else         DLG_HIP(hipMemsetAsync(b->d_scal, 0, 2*sizeof(double), b->stream));
+    if(b->allreduce)
+    {
+      // fused reduce buffer [Jt_x | norm2_x]
+      if(!b->d_red) DLG_HIP(hipMalloc(&b->d_red, sizeof(double)*((size_t)b->N + 8)));
+      DLG_HIP(hipMemcpyAsync(b->d_red, S.Jt_x, sizeof(double)*(size_t)b->N, hipMemcpyDeviceToDevice, b->stream));
+      DLG_HIP(hipMemcpyAsync(b->d_red + b->N, b->d_scal, sizeof(double), hipMemcpyDeviceToDevice, b->stream));
+      DLG_CHECK(allreduce(b, b->d_red, (size_t)b->N + 1));
+      DLG_HIP(hipMemcpyAsync(S.Jt_x, b->d_red, sizeof(double)*(size_t)b->N, hipMemcpyDeviceToDevice, b->stream));
+      DLG_HIP(hipMemcpyAsync(b->d_scal, b->d_red + b->N, sizeof(double), hipMemcpyDeviceToDevice, b->stream));
+    }
+    DLG_CHECK(k_norm2_absmax(b, S.Jt_x, b->N, b->d_scal + 2));
+    DLG_CHECK(dlg_fetch_scalars(b, 4));
+    S.norm2_x = b->h_scal[0];
+  }
+  S.have_Jtx = true;
+  if(norm2_x) *norm2_x = S.norm2_x;
+  if(Jtx_absmax) *Jtx_absmax = b->h_scal[3];
+  return DLG_OK;
+}
+
+// |J v|^2 into dev scalar `out` (all-reduced over ranks)
+static int norm2_Jv(dlg_backend* b, int s, const double* v, double* out)
+{
+  switch(b->type)
+  {
+  case DLG_SPARSE:  DLG_CHECK(sparse_norm2_Jv(b, s, v, out)); break;
+  case DLG_DENSE:   DLG_CHECK(dense_norm2_Jv(b, s, v, out)); break;
+  default:          return products_quadform(b, s, v, out);
+  }
+  return allreduce(b, out, 1);
+}
+
+// ---------------------------------------------------------------------- K3 --
+extern "C" int dlg_cauchy(dlg_backend_t* b, int s, double* norm2_updateCauchy)
+{
+  DLG_CHECK(check_slot(b, s));
+  DlgSlot& S = b->slot[s];
+  if(!S.have_Jtx) { dlg_set_error("dlg_cauchy needs Jt_x (reference dogleg.c:551-555)"); return DLG_ERR_STATE; }
+  if(!S.have_cauchy)
+  {
+    // d_scal[0] = |g|^2, d_scal[1] = |J g|^2
+    DLG_CHECK(k_norm2_absmax(b, S.Jt_x, b->N, b->d_scal + 4));
+    DLG_HIP(hipMemcpyAsync(b->d_scal, b->d_scal + 4, sizeof(double), hipMemcpyDeviceToDevice, b->stream));
+    DLG_CHECK(norm2_Jv(b, s, S.Jt_x, b->d_scal + 1));
+    DLG_CHECK(k_cauchy_finish(b, S.Jt_x, b->d_scal, S.cauchy, b->N, b->d_scal + 2));
+    DLG_CHECK(dlg_fetch_scalars(b, 3));
+    S.norm2_cauchy = b->h_scal[2];
+    S.have_cauchy = true;
+  }
+  if(norm2_updateCauchy) *norm2_updateCauchy = S.norm2_cauchy;
+  return DLG_OK;
+}
+
+// ----------------------------------------------------------------- K4 + K5 --
+extern "C" int dlg_factorize(dlg_backend_t* b, int s, double lambda, int* ok)
+{
+  DLG_CHECK(check_slot(b, s));
+  DlgSlot& S = b->slot[s];
+  if(!S.have_inputs) { dlg_set_error("dlg_factorize: slot %d has no J/JtJ", s); return DLG_ERR_STATE; }
+  int good = 0;
+  switch(b->type)
+  {
+  case DLG_SPARSE: DLG_CHECK(sparse_factorize(b, s, lambda, &good)); break;
+  case DLG_DENSE:  DLG_CHECK(dense_factorize(b, s, lambda, &good)); break;
+  default:         DLG_CHECK(products_factorize(b, s, lambda, &good)); break;
+  }
+  b->factor_slot = good ? s : -1;
+  if(ok) *ok = good;
+  return DLG_OK;
+}
+
+// ---------------------------------------------------------------------- K6 --
+extern "C" int dlg_solve_gn(dlg_backend_t* b, int s, double* norm2_updateGN)
+{
+  DLG_CHECK(check_slot(b, s));
+  DlgSlot& S = b->slot[s];
+  if(!S.have_Jtx) { dlg_set_error("dlg_solve_gn needs Jt_x"); return DLG_ERR_STATE; }
+  if(b->factor_slot != s) { dlg_set_error("dlg_solve_gn: no factorization of slot %d is held", s); return DLG_ERR_STATE; }
+  if(!S.have_gn)
+  {
+    if(b->type == DLG_SPARSE) DLG_CHECK(sparse_solve(b, S.Jt_x, S.gn));
+    else                      DLG_CHECK(dense_solve(b, S.Jt_x, S.gn));
+    DLG_CHECK(k_negate_norm2(b, S.gn, b->N, b->d_scal));      // dogleg.c:862-865
+    DLG_CHECK(dlg_fetch_scalars(b, 1));
+    S.norm2_gn = b->h_scal[0];
+    S.have_gn = true;
+  }
+  if(norm2_updateGN) *norm2_updateGN = S.norm2_gn;
+  return DLG_OK;
+}
+
+// ---------------------------------------------------------------------- K7 --
+extern "C" int dlg_make_step(dlg_backend_t* b, int from, int to, int kind, double trustregion,
+                             double* norm2_step, double* k_cauchy_to_gn, double* step_absmax,
+                             double* p_new_host)
+{
+  DLG_CHECK(check_slot(b, from)); DLG_CHECK(check_slot(b, to));
+  if(from == to) { dlg_set_error("dlg_make_step: from == to"); return DLG_ERR_ARG; }
+  DlgSlot& F = b->slot[from];
+  DlgSlot& T = b->slot[to];
+  double n2 = 0, kk = NAN, amax = 0;
+  switch(kind)
+  {
+  case DLG_KIND_CAUCHY_TO_EDGE:
+    if(!F.have_cauchy) { dlg_set_error("cauchy step not computed"); return DLG_ERR_STATE; }
+    DLG_CHECK(k_scaled_step(b, F.cauchy, trustregion / sqrt(F.norm2_cauchy), F.p, T.step, T.p, b->N,
+                            b->d_scal));                          // dogleg.c:1204-1207
+    DLG_CHECK(dlg_fetch_scalars(b, 1));
+    n2 = F.norm2_cauchy;                                          // unscaled: dogleg.c:1200
+    amax = b->h_scal[0];
+    break;
+  case DLG_KIND_GAUSSNEWTON:
+    if(!F.have_gn) { dlg_set_error("GN step not computed"); return DLG_ERR_STATE; }
+    DLG_CHECK(k_scaled_step(b, F.gn, 1.0, F.p, T.step, T.p, b->N, b->d_scal));   // dogleg.c:1231
+    DLG_CHECK(dlg_fetch_scalars(b, 1));
+    n2 = F.norm2_gn;
+    amax = b->h_scal[0];
+    break;
+  case DLG_KIND_INTERPOLATED:
+    if(!F.have_cauchy || !F.have_gn) { dlg_set_error("interpolation needs cauchy and GN"); return DLG_ERR_STATE; }
+    DLG_CHECK(k_interpolate(b, F.cauchy, F.gn, F.norm2_cauchy, trustregion, F.p, T.step, T.p, b->N,
+                            b->d_scal));
+    DLG_CHECK(dlg_fetch_scalars(b, 3));
+    n2 = b->h_scal[0]; kk = b->h_scal[1]; amax = b->h_scal[2];
+    break;
+  default:
+    dlg_set_error("dlg_make_step: unknown kind %d", kind);
+    return DLG_ERR_ARG;
+  }
+  if(p_new_host)
+  {
+    DLG_HIP(hipMemcpyAsync(b->h_vec, T.p, sizeof(double)*(size_t)b->N, hipMemcpyDeviceToHost, b->stream));
+    DLG_HIP(hipStreamSynchronize(b->stream));
+    memcpy(p_new_host, b->h_vec, sizeof(double)*(size_t)b->N);
+  }
+  if(norm2_step) *norm2_step = n2;
+  if(k_cauchy_to_gn) *k_cauchy_to_gn = kk;
+  if(step_absmax) *step_absmax = amax;
+  return DLG_OK;
+}
+
+// ---------------------------------------------------------------------- K8 --
+extern "C" int dlg_expected_improvement(dlg_backend_t* b, int from, int to, double* out)
+{
+  DLG_CHECK(check_slot(b, from)); DLG_CHECK(check_slot(b, to));
+  DlgSlot& F = b->slot[from];
+  DlgSlot& T = b->slot[to];
+  if(!F.have_Jtx) { dlg_set_error("expected improvement needs Jt_x"); return DLG_ERR_STATE; }
+  DLG_CHECK(k_inner(b, F.Jt_x, T.step, b->N, b->d_scal));
+  DLG_CHECK(norm2_Jv(b, from, T.step, b->d_scal + 1));
+  DLG_CHECK(dlg_fetch_scalars(b, 2));
+  if(out) *out = -2.0*b->h_scal[0] - b->h_scal[1];               // dogleg.c:1107-1109
+  return DLG_OK;
+}
+
+// ---------------------------------------------------------------- downloads --
+static double* slot_vec(dlg_backend* b, int s, int which, size_t* n)
+{
+  DlgSlot& S = b->slot[s];
+  *n = (size_t)b->N;
+  switch(which)
+  {
+  case DLG_VEC_P:      return S.p;
+  case DLG_VEC_X:      *n = (size_t)b->M; return const_cast<double*>(S.xin());
+  case DLG_VEC_JTX:    return S.Jt_x;
+  case DLG_VEC_CAUCHY: return S.cauchy;
+  case DLG_VEC_GN:     return S.gn;
+  case DLG_VEC_STEP:   return S.step;
+  case DLG_VEC_J:      *n = j_doubles(b); return const_cast<double*>(S.Jin());
+  default:             return nullptr;
+  }
+}
+extern "C" int dlg_point_download(dlg_backend_t* b, int s, int which, double* host, size_t n)
+{
+  DLG_CHECK(check_slot(b, s));
+  size_t have = 0;
+  double* src = slot_vec(b, s, which, &have);
+  if(!src) { dlg_set_error("nothing to download for vector %d", which); return DLG_ERR_ARG; }
+  if(n > have) n = have;
+  DLG_HIP(hipMemcpyAsync(host, src, sizeof(double)*n, hipMemcpyDeviceToHost, b->stream));
+  DLG_HIP(hipStreamSynchronize(b->stream));
+  return DLG_OK;
+}
+extern "C" void* dlg_point_device_ptr(dlg_backend_t* b, int s, int which)
+{
+  if(!b || s < 0 || s > 1) return nullptr;
+  size_t n;
+  return slot_vec(b, s, which, &n);
+}
+
+// ------------------------------------------------------------ raw memory ----
+extern "C" void* dlg_mem_alloc(size_t bytes)
+{
+  void* p = nullptr;
+  if(hipMalloc(&p, bytes ? bytes : 8) != hipSuccess) { dlg_set_error("hipMalloc(%zu) failed", bytes); return nullptr; }
+  return p;
+}
+extern "C" void dlg_mem_free(void* dev) { if(dev) (void)hipFree(dev); }
+extern "C" int dlg_mem_upload(void* dev, const void* host, size_t bytes)
+{ DLG_HIP(hipMemcpy(dev, host, bytes, hipMemcpyHostToDevice)); return DLG_OK; }
+extern "C" int dlg_mem_download(void* host, const void* dev, size_t bytes)
+{ DLG_HIP(hipMemcpy(host, dev, bytes, hipMemcpyDeviceToHost)); return DLG_OK; }
+extern "C" int dlg_mem_zero(void* dev, size_t bytes)
+{ DLG_HIP(hipMemset(dev, 0, bytes)); return DLG_OK; }
+extern "C" int dlg_device_sync(void) { DLG_HIP(hipDeviceSynchronize()); return DLG_OK; }

@@ -1,0 +1,140 @@
+// dlg_internal.h -- shared declarations of the HIP backend (not installed).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <cstdarg>
+#include <cmath>
+#include <vector>
+#include <string>
+#include "../../include/dlg_backend.h"
+
+// ---------------------------------------------------------------- errors ----
+void dlg_set_error(const char* fmt, ...);
+
+#define DLG_HIP(call)                                                              \
+  do {                                                                             \
+    hipError_t e__ = (call);                                                       \
+    if(e__ != hipSuccess) {                                                        \
+      dlg_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #call,                  \
+                    hipGetErrorString(e__));                                       \
+      return DLG_ERR_HIP;                                                          \
+    }                                                                              \
+  } while(0)
+
+#define DLG_CHECK(call)                                                            \
+  do { int rc__ = (call); if(rc__ != DLG_OK) return rc__; } while(0)
+
+#define DLG_LAUNCH_CHECK()  DLG_HIP(hipGetLastError())
+
+// ------------------------------------------------------------- geometry ----
+static inline int dlg_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+struct SparseSym;      // host+device symbolic data of the sparse path (sparse_symbolic.h)
+
+struct DlgSlot
+{
+  double* p      = nullptr;   // [N]
+  double* x      = nullptr;   // [M] (rank-local rows on a sharded rank)
+  double* J      = nullptr;   // dense: [M][N]; sparse: values[nnz]; products: JtJ
+  double* Jt_x   = nullptr;   // [N]
+  double* cauchy = nullptr;   // [N]
+  double* gn     = nullptr;   // [N]
+  double* step   = nullptr;   // [N] step_to_here
+  const double* x_bound = nullptr;   // device-resident inputs (dlg_point_bind_device)
+  const double* J_bound = nullptr;
+  double  norm2_x = 0, norm2_cauchy = 0, norm2_gn = 0;
+  bool    have_inputs = false, have_Jtx = false, have_cauchy = false, have_gn = false;
+  const double* xin() const { return x_bound ? x_bound : x; }
+  const double* Jin() const { return J_bound ? J_bound : J; }
+};
+
+struct dlg_backend
+{
+  int type = 0, N = 0, M = 0, nnz = 0, flags = 0, device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  DlgSlot slot[2];
+
+  // scalar return path: kernels write d_scal, one D2H into pinned h_scal
+  double* d_scal = nullptr;
+  double* h_scal = nullptr;
+  static constexpr int NSCAL = 16;
+
+  // reduction partials
+  double* d_part = nullptr;
+  size_t  part_cap = 0;       // in doubles
+
+  // pinned staging for p_new D2H / uploads of small vectors
+  double* h_vec = nullptr;
+
+  // dense / products
+  double* G = nullptr;        // N x N column-major, lower triangle = factor
+  double* slabs = nullptr;    // split-K partial slabs for the SYRK
+  size_t  slabs_bytes = 0;
+  int*    d_info = nullptr;
+  int*    h_info = nullptr;
+  double* d_work = nullptr;   // N-vector scratch
+
+  // sparse
+  SparseSym* sym = nullptr;
+
+  // sharding
+  int row0 = 0, row1 = 0;     // owned measurement rows
+  dlg_allreduce_fn allreduce = nullptr;
+  void* allreduce_cookie = nullptr;
+  double* d_red = nullptr;    // fused reduce buffer [Jt_x | norm2_x | ...]
+
+  int factor_slot = -1;       // slot whose JtJ the stored factor belongs to (-1: none)
+};
+
+// rows of the measurement vector owned by this rank
+static inline int dlg_mloc(const dlg_backend* b) { return b->row1 - b->row0; }
+// sum-all-reduce over ranks of `count` doubles at device address buf (no-op single rank)
+int dlg_allreduce_dev(dlg_backend* b, double* buf, size_t count);
+
+// fetch the first n scalars of d_scal to the host (synchronises the stream)
+int dlg_fetch_scalars(dlg_backend* b, int n);
+
+// --------------------------------------------------------- kernels_vec.hip --
+// out[0] = sum x[i]^2 ; out[1] = max |x[i]|   (deterministic two-stage)
+int k_norm2_absmax(dlg_backend* b, const double* x, int n, double* out2);
+// out[0] = <x,y>
+int k_inner(dlg_backend* b, const double* x, const double* y, int n, double* out);
+// Cauchy finish: reads g2 = scal_in[0], Jg2 = scal_in[1]; k = -g2/Jg2;
+// cauchy = k*g ; out[0] = k*k*g2
+int k_cauchy_finish(dlg_backend* b, const double* g, const double* scal_in, double* cauchy,
+                    int n, double* out);
+// step = s * v ; p_new = p + step ; out[0] = max|step|
+int k_scaled_step(dlg_backend* b, const double* v, double s, const double* p, double* step,
+                  double* p_new, int n, double* out_absmax);
+// interpolation (dogleg.c:964-987): out = {norm2_step, k, max|step|}
+int k_interpolate(dlg_backend* b, const double* a, const double* bb, double norm2a,
+                  double trustregion, const double* p, double* step, double* p_new, int n,
+                  double* out3);
+// gn = -u ; out[0] = norm2(gn)
+int k_negate_norm2(dlg_backend* b, double* v, int n, double* out);
+// generic deterministic final reduction of `np` partials (sum) into out[0]
+int k_reduce_sum(dlg_backend* b, const double* partials, int np, double* out);
+int dlg_ensure_partials(dlg_backend* b, size_t ndoubles);
+
+// ------------------------------------------------------- kernels_dense.hip --
+int dense_create(dlg_backend* b);
+void dense_destroy(dlg_backend* b);
+int dense_eval(dlg_backend* b, int slot);                       // K1
+int dense_norm2_Jv(dlg_backend* b, int slot, const double* v, double* out_dev); // K3/K8
+int dense_factorize(dlg_backend* b, int slot, double lambda, int* ok);          // K4+K5
+int dense_solve(dlg_backend* b, const double* rhs, double* out);                // K6 (no negate)
+int products_quadform(dlg_backend* b, int slot, const double* v, double* out_dev);
+int products_factorize(dlg_backend* b, int slot, double lambda, int* ok);
+
+// ------------------------------------------------------ kernels_sparse.hip --
+int sparse_create(dlg_backend* b);
+size_t sparse_local_nnz(const dlg_backend* b);   // J values held by this rank
+void sparse_destroy(dlg_backend* b);
+int sparse_set_pattern(dlg_backend* b, const int* colptr, const int* rowidx);
+int sparse_eval(dlg_backend* b, int slot);                      // K1
+int sparse_norm2_Jv(dlg_backend* b, int slot, const double* v, double* out_dev); // K3/K8
+int sparse_factorize(dlg_backend* b, int slot, double lambda, int* ok);          // K4+K5
+int sparse_solve(dlg_backend* b, const double* rhs, double* out);                // K6

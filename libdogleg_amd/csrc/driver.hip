@@ -1,0 +1,662 @@
+// driver.hip -- host trust-region driver behind the dogleg.h API.
+//
+// Restates the reference's control flow (dogleg.c:1172-1476 takeStepFrom /
+// evaluateStep_adjustTrustRegion / runOptimizer, dogleg.c:1633-1818 entry
+// points) on the host; all vector/matrix arithmetic is delegated to the HIP
+// backend through dlg_backend.h.  Comparison senses, the lambda schedule, the
+// un-applied terminal step and the cached-retry behaviour follow SURVEY.md 8a.
+//
+// Host memory handed to user callbacks (x, J, Jt arrays) is pinned
+// (hipHostMalloc) so the per-evaluation upload is a straight DMA.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <cmath>
+#include <new>
+#include "../../include/dogleg.h"
+#include "../../include/dlg_backend.h"
+#include "../../include/dlg_trace.h"
+
+#define MSG(...) do { fprintf(stderr, "libdogleg_amd: " __VA_ARGS__); fputc('\n', stderr); } while(0)
+#define VERBOSE(c, ...) do { if((c)->pub.parameters->debug && !(c)->pub.parameters->debug_vnlog) MSG(__VA_ARGS__); } while(0)
+
+namespace {
+
+constexpr double LAMBDA_INITIAL = 1e-10;       // dogleg.c:138
+
+const dogleg_parameters2_t k_defaults = []{
+  dogleg_parameters2_t q;
+  memset(&q, 0, sizeof(q));
+  q.max_iterations                 = 100;      // dogleg.c:117-128
+  q.trustregion0                   = 1.0e3;
+  q.trustregion_decrease_factor    = 0.1;
+  q.trustregion_decrease_threshold = 0.25;
+  q.trustregion_increase_factor    = 2;
+  q.trustregion_increase_threshold = 0.75;
+  q.Jt_x_threshold                 = 1e-8;
+  q.update_threshold               = 1e-8;
+  q.trustregion_threshold          = 1e-8;
+  return q;
+}();
+dogleg_parameters2_t g_params = k_defaults;    // the legacy process-global set (dogleg.c:131)
+
+thread_local dlg_trace_t* t_trace = nullptr;
+
+struct Driver
+{
+  dogleg_solverContext_t pub;                  // MUST be first: the API hands out &pub
+  dlg_backend_t* be;
+  dogleg_operatingPoint_t* pts[2];             // slot id == index
+  unsigned int nnz;
+  bool pattern_set;
+  cholmod_sparse jt[2];
+  cholmod_dense  gn_dense[2];
+  cholmod_factor factor_handle;
+  void* pinned[2][8];
+  int   npinned[2];
+  // trial record under construction
+  dlg_trial_t cur;
+  int ncallbacks;
+  bool check_pattern;
+  int *pat_p, *pat_i;
+};
+
+inline Driver* D(dogleg_solverContext_t* ctx) { return reinterpret_cast<Driver*>(ctx); }
+inline int slot_of(const Driver* d, const dogleg_operatingPoint_t* pt) { return pt == d->pts[0] ? 0 : 1; }
+
+bool be_ok(int rc, const char* what)
+{
+  if(rc == DLG_OK) return true;
+  MSG("%s failed: %s", what, dlg_last_error());
+  return false;
+}
+
+void* pinned_alloc(Driver* d, int s, size_t bytes)
+{
+  void* p = nullptr;
+  if(bytes == 0) bytes = 8;
+  if(hipHostMalloc(&p, bytes) != hipSuccess) return nullptr;
+  memset(p, 0, bytes);
+  d->pinned[s][d->npinned[s]++] = p;
+  return p;
+}
+
+// ---- vnlog record (dogleg.c:42-113) ---------------------------------------
+void vnlog_legend()
+{
+  printf("# iteration step_accepted norm2x_before norm2x_after step_len_cauchy step_len_gauss_newton "
+         "step_len_interpolated k_cauchy_to_gn step_len step_type step_direction_change_deg "
+         "expected_improvement observed_improvement rho trustregion_before trustregion_after\n");
+}
+void vn(double v) { if(std::isnan(v)) printf("- "); else printf("%g ", v); }
+void vnlog_record(const Driver* d, int iteration, int accepted_flag, double len_interp)
+{
+  const dlg_trial_t& t = d->cur;
+  static const char* names[] = { "cauchy", "gaussnewton", "interpolated" };
+  printf("%d %d ", iteration, accepted_flag);
+  vn(t.norm2x_before); vn(t.norm2x_after);
+  vn(sqrt(t.norm2_cauchy)); vn(sqrt(t.norm2_gn));
+  vn(len_interp); vn(t.k_cauchy_to_gn);
+  vn(sqrt(t.norm2_step));
+  printf("%s ", names[t.step_type]);
+  printf("- ");                                   // direction change: never available
+  vn(t.expected_improvement); vn(t.observed_improvement); vn(t.rho);
+  vn(t.trustregion_before); vn(t.trustregion_after);
+  printf("\n");
+  fflush(stdout);
+}
+
+void cur_reset(Driver* d)
+{
+  memset(&d->cur, 0, sizeof(d->cur));
+  d->cur.norm2x_after = d->cur.norm2_cauchy = d->cur.norm2_gn = d->cur.k_cauchy_to_gn = NAN;
+  d->cur.observed_improvement = d->cur.rho = d->cur.trustregion_after = NAN;
+}
+void emit(Driver* d, int iteration, int accepted)
+{
+  d->cur.iteration = iteration;
+  d->cur.accepted  = accepted;
+  d->cur.lambda    = d->pub.lambda;
+  if(d->pub.parameters->debug_vnlog)
+  {
+    // the terminal record prints the un-clamped expected improvement in the
+    // reference; it is not retained here (trace keeps -1 as the driver sees it)
+    vnlog_record(d, iteration, accepted ? 1 : 0,
+                 d->cur.step_type == DLG_STEP_INTERPOLATED ? sqrt(d->cur.norm2_step) : NAN);
+  }
+  dlg_trace_t* tr = t_trace;
+  if(tr)
+  {
+    if(tr->ntrials < tr->capacity)
+    {
+      const int N = d->pub.Nstate;
+      tr->trials[tr->ntrials] = d->cur;
+      if(tr->p_trial) memcpy(&tr->p_trial[(size_t)tr->ntrials*N], d->pub.afterStep->p, sizeof(double)*(size_t)N);
+      if(tr->step)
+        dlg_point_download(d->be, slot_of(d, d->pub.afterStep), DLG_VEC_STEP,
+                           &tr->step[(size_t)tr->ntrials*N], (size_t)N);
+    }
+    tr->ntrials++;
+  }
+  cur_reset(d);
+}
+
+// ---- operating points ------------------------------------------------------
+// dogleg.c:1479-1562, with the callback-visible arrays pinned
+dogleg_operatingPoint_t* alloc_point(Driver* d, int s)
+{
+  dogleg_operatingPoint_t* pt = (dogleg_operatingPoint_t*)calloc(1, sizeof(*pt));
+  if(!pt) return nullptr;
+  const size_t N = (size_t)d->pub.Nstate, M = (size_t)d->pub.Nmeasurements;
+  const dogleg_solve_type_t type = d->pub.solve_type;
+  pt->p            = (double*)pinned_alloc(d, s, sizeof(double)*N);
+  pt->Jt_x         = (double*)pinned_alloc(d, s, sizeof(double)*N);
+  pt->updateCauchy = (double*)calloc(N, sizeof(double));
+  pt->step_to_here = (double*)calloc(N, sizeof(double));
+  double* gn       = (double*)calloc(N, sizeof(double));
+  if(!pt->p || !pt->Jt_x || !pt->updateCauchy || !pt->step_to_here || !gn) return nullptr;
+  if(type != DOGLEG_DENSE_PRODUCTS)
+  { pt->x = (double*)pinned_alloc(d, s, sizeof(double)*M); if(!pt->x) return nullptr; }
+  if(type == DOGLEG_SPARSE)
+  {
+    cholmod_sparse* A = &d->jt[s];
+    memset(A, 0, sizeof(*A));
+    A->nrow = N; A->ncol = M; A->nzmax = d->nnz;
+    A->p = pinned_alloc(d, s, sizeof(int)*(M + 1));
+    A->i = pinned_alloc(d, s, sizeof(int)*(size_t)d->nnz);
+    A->x = pinned_alloc(d, s, sizeof(double)*(size_t)d->nnz);
+    if(!A->p || !A->i || !A->x) return nullptr;
+    A->stype = 0; A->itype = CHOLMOD_INT; A->xtype = CHOLMOD_REAL; A->dtype = CHOLMOD_DOUBLE;
+    A->sorted = 1; A->packed = 1;
+    pt->Jt = A;
+    cholmod_dense* g = &d->gn_dense[s];
+    memset(g, 0, sizeof(*g));
+    g->nrow = N; g->ncol = 1; g->nzmax = N; g->d = N; g->x = gn;
+    g->xtype = CHOLMOD_REAL; g->dtype = CHOLMOD_DOUBLE;
+    pt->updateGN_cholmoddense = g;
+  }
+  else
+  {
+    if(type == DOGLEG_DENSE)
+    { pt->J_dense = (double*)pinned_alloc(d, s, sizeof(double)*M*N); if(!pt->J_dense) return nullptr; }
+    else
+    {
+      const size_t sz = d->pub.parameters->JtJ_packed ? N*(N+1)/2 : N*N;
+      pt->JtJ = (double*)pinned_alloc(d, s, sizeof(double)*sz);
+      if(!pt->JtJ) return nullptr;
+    }
+    pt->updateGN_dense = gn;
+  }
+  return pt;
+}
+double* gn_host(Driver* d, dogleg_operatingPoint_t* pt)
+{
+  return d->pub.solve_type == DOGLEG_SPARSE ? (double*)pt->updateGN_cholmoddense->x : pt->updateGN_dense;
+}
+void free_point(Driver* d, int s)
+{
+  dogleg_operatingPoint_t* pt = d->pts[s];
+  if(pt)
+  {
+    free(pt->updateCauchy); free(pt->step_to_here);
+    free(d->pub.solve_type == DOGLEG_SPARSE ? d->gn_dense[s].x : (void*)pt->updateGN_dense);
+    free(pt);
+  }
+  for(int i = 0; i < d->npinned[s]; i++) (void)hipHostFree(d->pinned[s][i]);
+  d->npinned[s] = 0;
+  d->pts[s] = nullptr;
+}
+
+// dogleg.c:1004-1083
+bool eval_point(bool* converged, dogleg_operatingPoint_t* pt, Driver* d)
+{
+  dogleg_solverContext_t* ctx = &d->pub;
+  const int s = slot_of(d, pt);
+  pt->norm2_x = -1.;
+  memset(pt->dummy_bits, 0, sizeof(pt->dummy_bits));
+  d->ncallbacks++;
+  double norm2x = 0, absmax = 0;
+  if(ctx->solve_type == DOGLEG_SPARSE)
+  {
+    (*ctx->f)(pt->p, pt->x, pt->Jt, ctx->cookie);
+    const int* cp = (const int*)pt->Jt->p; const int* ri = (const int*)pt->Jt->i;
+    if(!d->pattern_set)
+    {
+      if(!be_ok(dlg_sparse_set_pattern(d->be, cp, ri), "sparse symbolic analysis")) return false;
+      d->pattern_set = true;
+      if(d->check_pattern)
+      {
+        d->pat_p = (int*)malloc(sizeof(int)*((size_t)ctx->Nmeasurements + 1));
+        d->pat_i = (int*)malloc(sizeof(int)*(size_t)d->nnz);
+        memcpy(d->pat_p, cp, sizeof(int)*((size_t)ctx->Nmeasurements + 1));
+        memcpy(d->pat_i, ri, sizeof(int)*(size_t)d->nnz);
+      }
+    }
+    else if(d->check_pattern &&
+            (memcmp(d->pat_p, cp, sizeof(int)*((size_t)ctx->Nmeasurements + 1)) ||
+             memcmp(d->pat_i, ri, sizeof(int)*(size_t)d->nnz)))
+    { MSG("the sparsity pattern of Jt changed between evaluations; it must stay fixed (reference dogleg.c:648-649)"); return false; }
+    if(!be_ok(dlg_point_upload(d->be, s, pt->x, (const double*)pt->Jt->x), "upload")) return false;
+    if(!be_ok(dlg_point_eval(d->be, s, &norm2x, &absmax), "Jt*x")) return false;
+    pt->norm2_x = norm2x;
+    pt->have_x = pt->have_J = pt->have_Jtx = true;
+  }
+  else if(ctx->solve_type == DOGLEG_DENSE)
+  {
+    (*ctx->f_dense)(pt->p, pt->x, pt->J_dense, ctx->cookie);
+    if(!be_ok(dlg_point_upload(d->be, s, pt->x, pt->J_dense), "upload")) return false;
+    if(!be_ok(dlg_point_eval(d->be, s, &norm2x, &absmax), "Jt*x")) return false;
+    pt->norm2_x = norm2x;
+    pt->have_x = pt->have_J = pt->have_Jtx = true;
+  }
+  else
+  {
+    (*ctx->f_dense_products)(pt->p, &pt->norm2_x, pt->Jt_x, pt->JtJ, ctx->cookie);
+    if(!be_ok(dlg_point_upload_products(d->be, s, pt->norm2_x, pt->Jt_x, pt->JtJ), "upload")) return false;
+    if(!be_ok(dlg_point_eval(d->be, s, &norm2x, &absmax), "gradient norm")) return false;
+    pt->have_Jtx = pt->have_JtJ = true;
+  }
+  // dogleg.c:1073-1082: converged unless some |Jt_x[i]| exceeds the threshold
+  *converged = !(absmax > ctx->parameters->Jt_x_threshold);
+  if(*converged) VERBOSE(d, "gradient below threshold everywhere: done");
+  return true;
+}
+
+// dogleg.c:529-617
+bool compute_cauchy(dogleg_operatingPoint_t* pt, Driver* d)
+{
+  if(!pt->have_updateCauchy)
+  {
+    if(!pt->have_Jtx) { MSG("Cauchy step needs Jt_x, which is missing"); return false; }
+    double n2 = 0;
+    if(!be_ok(dlg_cauchy(d->be, slot_of(d, pt), &n2), "Cauchy step")) return false;
+    pt->norm2_updateCauchy = n2;
+    pt->have_updateCauchy = true;
+    VERBOSE(d, "cauchy step length %.6g", sqrt(n2));
+  }
+  d->cur.norm2_cauchy = pt->norm2_updateCauchy;
+  return true;
+}
+
+bool factorize(dogleg_operatingPoint_t* pt, Driver* d)
+{
+  dogleg_solverContext_t* ctx = &d->pub;
+  if(pt->have_factorization) return true;                      // dogleg.c:637
+  if(ctx->solve_type == DOGLEG_DENSE_PRODUCTS ? !pt->have_JtJ : !pt->have_J)
+  { MSG("factorization needs J (or JtJ), which is missing"); return false; }
+  if(ctx->solve_type == DOGLEG_SPARSE && ctx->factorization == nullptr)
+  {
+    d->factor_handle.n = (size_t)ctx->Nstate; d->factor_handle.minor = 0;
+    d->factor_handle.backend = d->be;
+    ctx->factorization = &d->factor_handle;                    // dogleg.c:650-654
+  }
+  while(true)
+  {
+    int ok = 0;
+    if(!be_ok(dlg_factorize(d->be, slot_of(d, pt), ctx->lambda, &ok), "factorization")) return false;
+    if(ok) break;
+    ctx->lambda = (ctx->lambda == 0.0) ? LAMBDA_INITIAL : ctx->lambda*10.0;   // dogleg.c:671-672, 812-813
+    if(!std::isfinite(ctx->lambda)) { MSG("lambda overflowed while regularising a singular JtJ"); return false; }
+    VERBOSE(d, "singular JtJ: adding %g I from now on", ctx->lambda);
+  }
+  if(ctx->solve_type == DOGLEG_SPARSE) d->factor_handle.minor = d->factor_handle.n;
+  pt->have_factorization = true;
+  return true;
+}
+
+// dogleg.c:822-908
+bool compute_gn(dogleg_operatingPoint_t* pt, Driver* d)
+{
+  if(!pt->have_updateGN)
+  {
+    if(!factorize(pt, d)) return false;
+    if(!pt->have_Jtx) { MSG("GN step needs Jt_x, which is missing"); return false; }
+    double n2 = 0;
+    if(!be_ok(dlg_solve_gn(d->be, slot_of(d, pt), &n2), "GN solve")) return false;
+    pt->norm2_updateGN = n2;
+    pt->have_updateGN = true;
+    VERBOSE(d, "gn step length %.6g", sqrt(n2));
+  }
+  d->cur.norm2_gn = pt->norm2_updateGN;
+  return true;
+}
+
+// dogleg.c:1172-1297.  The step vector stays on the device (slot `to`); p_new
+// comes back because the user callback needs it.
+bool take_step(double* expectedImprovement, dogleg_operatingPoint_t* to,
+               dogleg_operatingPoint_t* from, double trustregion, Driver* d)
+{
+  dogleg_solverContext_t* ctx = &d->pub;
+  VERBOSE(d, "taking step with trustregion %.6g", trustregion);
+  d->cur.trustregion_before = trustregion;
+  d->cur.norm2x_before      = from->norm2_x;
+  const int sf = slot_of(d, from), st = slot_of(d, to);
+
+  if(!compute_cauchy(from, d)) return false;
+  int kind;
+  if(from->norm2_updateCauchy >= trustregion*trustregion)
+  {
+    kind = DLG_KIND_CAUCHY_TO_EDGE;
+    d->cur.step_type = DLG_STEP_CAUCHY;
+    from->didStepToEdgeOfTrustRegion = true;
+  }
+  else
+  {
+    if(!compute_gn(from, d)) return false;
+    if(from->norm2_updateGN <= trustregion*trustregion)
+    {
+      kind = DLG_KIND_GAUSSNEWTON;
+      d->cur.step_type = DLG_STEP_GAUSSNEWTON;
+      from->didStepToEdgeOfTrustRegion = false;
+    }
+    else
+    {
+      kind = DLG_KIND_INTERPOLATED;
+      d->cur.step_type = DLG_STEP_INTERPOLATED;
+      from->didStepToEdgeOfTrustRegion = true;
+    }
+  }
+  double n2 = 0, k = NAN, amax = 0;
+  if(!be_ok(dlg_make_step(d->be, sf, st, kind, trustregion, &n2, &k, &amax, to->p), "step")) return false;
+  to->norm2_step_to_here = n2;
+  d->cur.norm2_step = n2;
+  d->cur.k_cauchy_to_gn = k;
+  d->cur.did_step_to_edge = from->didStepToEdgeOfTrustRegion;
+  if(kind == DLG_KIND_INTERPOLATED) VERBOSE(d, "k_cauchy_to_gn %.6g, norm %.6g", k, sqrt(n2));
+
+  if(!be_ok(dlg_expected_improvement(d->be, sf, st, expectedImprovement), "expected improvement")) return false;
+
+  // dogleg.c:1289-1296: every |step_i| <= update_threshold -> signal termination
+  if(!(amax > ctx->parameters->update_threshold))
+  {
+    VERBOSE(d, "update small enough: done");
+    *expectedImprovement = -1.0;
+  }
+  return true;
+}
+
+// dogleg.c:1303-1356
+bool evaluate_step(bool* accept, double* trustregion, const dogleg_operatingPoint_t* before,
+                   const dogleg_operatingPoint_t* after, double expectedImprovement, Driver* d)
+{
+  const dogleg_parameters2_t* prm = d->pub.parameters;
+  const double observed = before->norm2_x - after->norm2_x;
+  const double rho = observed / expectedImprovement;
+  VERBOSE(d, "observed/expected improvement: %.6g/%.6g. rho = %.6g", observed, expectedImprovement, rho);
+  d->cur.observed_improvement = observed;
+  d->cur.rho = rho;
+  if(rho < prm->trustregion_decrease_threshold)
+  {
+    if(!before->didStepToEdgeOfTrustRegion)
+    {
+      if(!before->have_updateGN) { MSG("internal error: GN step missing when shrinking the trust region"); return false; }
+      *trustregion = sqrt(before->norm2_updateGN);
+    }
+    *trustregion *= prm->trustregion_decrease_factor;
+  }
+  else if(rho > prm->trustregion_increase_threshold && before->didStepToEdgeOfTrustRegion)
+    *trustregion *= prm->trustregion_increase_factor;
+  d->cur.trustregion_after = *trustregion;
+  *accept = (rho > 0.0);
+  return true;
+}
+
+// dogleg.c:1359-1476
+int run_optimizer(Driver* d)
+{
+  dogleg_solverContext_t* ctx = &d->pub;
+  double trustregion = ctx->parameters->trustregion0;
+  int stepCount = 0;
+  cur_reset(d);
+
+  bool converged;
+  if(!eval_point(&converged, ctx->beforeStep, d)) return -1;
+  if(converged) return stepCount;
+  VERBOSE(d, "initial operating point has norm2_x %.6g", ctx->beforeStep->norm2_x);
+
+  while(stepCount < ctx->parameters->max_iterations)
+  {
+    VERBOSE(d, "================= step %d", stepCount);
+    while(true)
+    {
+      ctx->afterStep->have_step_to_here = false;
+      double expectedImprovement;
+      if(!take_step(&expectedImprovement, ctx->afterStep, ctx->beforeStep, trustregion, d)) return -1;
+      ctx->afterStep->have_step_to_here = true;
+      d->cur.expected_improvement = expectedImprovement;
+
+      if(expectedImprovement < 0.0)                 // dogleg.c:1403-1408: step NOT applied
+      { emit(d, stepCount, 2); return stepCount; }
+
+      bool afterZeroGradient;
+      if(!eval_point(&afterZeroGradient, ctx->afterStep, d)) return -1;
+      VERBOSE(d, "evaluated operating point with norm2_x %.6g", ctx->afterStep->norm2_x);
+      d->cur.norm2x_after = ctx->afterStep->norm2_x;
+
+      bool accept;
+      if(!evaluate_step(&accept, &trustregion, ctx->beforeStep, ctx->afterStep, expectedImprovement, d))
+        return -1;
+
+      if(accept)
+      {
+        VERBOSE(d, "accepted step");
+        emit(d, stepCount, 1);
+        stepCount++;
+        dogleg_operatingPoint_t* t = ctx->afterStep;
+        ctx->afterStep = ctx->beforeStep;
+        ctx->beforeStep = t;
+        if(afterZeroGradient) { VERBOSE(d, "gradient low enough after an improving step: done"); return stepCount; }
+        break;
+      }
+      VERBOSE(d, "rejected step");
+      emit(d, stepCount, 0);
+      if(trustregion < ctx->parameters->trustregion_threshold)
+      { VERBOSE(d, "trust region below threshold: giving up"); return stepCount; }
+    }
+  }
+  if(stepCount == ctx->parameters->max_iterations) VERBOSE(d, "iteration limit reached");
+  return stepCount;
+}
+
+// bring the host mirrors of a point up to date (returnContext contract,
+// SURVEY.md 3.4): Jt_x, updateCauchy, updateGN, step_to_here
+void sync_point_to_host(Driver* d, dogleg_operatingPoint_t* pt)
+{
+  const int s = slot_of(d, pt);
+  const size_t N = (size_t)d->pub.Nstate;
+  if(pt->have_Jtx && d->pub.solve_type != DOGLEG_DENSE_PRODUCTS)
+    dlg_point_download(d->be, s, DLG_VEC_JTX, pt->Jt_x, N);
+  if(pt->have_updateCauchy) dlg_point_download(d->be, s, DLG_VEC_CAUCHY, pt->updateCauchy, N);
+  if(pt->have_updateGN)     dlg_point_download(d->be, s, DLG_VEC_GN, gn_host(d, pt), N);
+  dlg_point_download(d->be, s, DLG_VEC_STEP, pt->step_to_here, N);
+}
+
+void destroy(Driver* d)
+{
+  if(!d) return;
+  free_point(d, 0); free_point(d, 1);
+  if(d->pub.solve_type != DOGLEG_SPARSE) free(d->pub.factorization_dense);
+  if(d->be) dlg_backend_destroy(d->be);
+  free(d->pat_p); free(d->pat_i);
+  free(d);
+}
+
+// dogleg.c:1633-1753
+double optimize(double* p, unsigned int Nstate, unsigned int Nmeas, unsigned int NJnnz,
+                dogleg_callback_t* f, dogleg_callback_dense_t* f_dense,
+                dogleg_callback_dense_products_t* f_products, void* cookie,
+                const dogleg_parameters2_t* parameters, dogleg_solverContext_t** returnContext)
+{
+  Driver* d = (Driver*)calloc(1, sizeof(Driver));
+  if(!d) { MSG("out of memory"); return -1.0; }
+  dogleg_solverContext_t* ctx = &d->pub;
+  ctx->cookie = cookie;
+  ctx->lambda = 0.0;
+  ctx->Nstate = (int)Nstate;
+  ctx->Nmeasurements = (int)Nmeas;
+  ctx->parameters = parameters ? parameters : &g_params;
+  d->nnz = NJnnz;
+  const char* chk = getenv("DOGLEG_AMD_CHECK_PATTERN");
+  d->check_pattern = chk && chk[0] == '1';
+
+  if(f)
+  {
+    ctx->solve_type = DOGLEG_SPARSE; ctx->f = f;
+    if(NJnnz == 0) { MSG("sparse solves need NJnnz > 0"); free(d); return -1.0; }
+  }
+  else if(f_dense)
+  {
+    ctx->solve_type = DOGLEG_DENSE; ctx->f_dense = f_dense;
+    if(NJnnz > 0) { MSG("dense solves need NJnnz == 0"); free(d); return -1.0; }
+  }
+  else if(f_products)
+  {
+    ctx->solve_type = DOGLEG_DENSE_PRODUCTS; ctx->f_dense_products = f_products;
+    if(NJnnz > 0) { MSG("dense solves need NJnnz == 0"); free(d); return -1.0; }
+  }
+  else { MSG("exactly one of the callbacks must be given"); free(d); return -1.0; }
+
+  if(ctx->parameters->debug_vnlog) vnlog_legend();
+
+  int flags = 0;
+  if(ctx->parameters->JtJ_packed) flags |= DLG_FLAG_JTJ_PACKED;
+  if(ctx->parameters->JtJ_upper)  flags |= DLG_FLAG_JTJ_UPPER;
+  if(dlg_backend_create(&d->be, (int)ctx->solve_type, (int)Nstate, (int)Nmeas, (int)NJnnz, flags, -1) != DLG_OK)
+  { MSG("cannot create the GPU backend: %s", dlg_last_error()); free(d); return -1.0; }
+
+  if(ctx->solve_type != DOGLEG_SPARSE)
+  {
+    const size_t N = Nstate;
+    const size_t sz = (ctx->solve_type == DOGLEG_DENSE || ctx->parameters->JtJ_packed) ? N*(N+1)/2 : N*N;
+    ctx->factorization_dense = (double*)calloc(sz, sizeof(double));          // dogleg.c:1707-1725
+    if(!ctx->factorization_dense) { MSG("out of memory"); destroy(d); return -1.0; }
+  }
+  d->pts[0] = alloc_point(d, 0);
+  d->pts[1] = alloc_point(d, 1);
+  if(!d->pts[0] || !d->pts[1]) { MSG("out of (pinned) host memory"); destroy(d); return -1.0; }
+  ctx->beforeStep = d->pts[0];
+  ctx->afterStep  = d->pts[1];
+
+  memcpy(ctx->beforeStep->p, p, sizeof(double)*Nstate);
+  if(!be_ok(dlg_point_set_p(d->be, 0, ctx->beforeStep->p), "upload of p")) { destroy(d); return -1.0; }
+
+  dlg_trace_t* tr = t_trace;
+  if(tr) { tr->ntrials = 0; tr->ncallbacks = 0; tr->nstate = (int)Nstate; }
+
+  const int numsteps = run_optimizer(d);
+  const double norm2_x = ctx->beforeStep->norm2_x;
+  if(tr) tr->ncallbacks = d->ncallbacks;
+  if(numsteps < 0)
+  {
+    MSG("the solve failed");
+    destroy(d);
+    return -1.0;
+  }
+  memcpy(p, ctx->beforeStep->p, sizeof(double)*Nstate);        // dogleg.c:1745
+  VERBOSE(d, "success: %d iterations", numsteps);
+
+  if(returnContext)
+  {
+    sync_point_to_host(d, ctx->beforeStep);
+    if(ctx->solve_type != DOGLEG_SPARSE && ctx->beforeStep->have_factorization)
+    {
+      const size_t N = Nstate;
+      const size_t sz = (ctx->solve_type == DOGLEG_DENSE || ctx->parameters->JtJ_packed) ? N*(N+1)/2 : N*N;
+      dlg_factor_download_dense(d->be, ctx->factorization_dense, sz);
+    }
+    *returnContext = ctx;
+  }
+  else destroy(d);
+  return norm2_x;
+}
+
+} // namespace
+
+// ============================================================ public API ====
+extern "C" {
+
+void dlg_set_trace(void* tr) { t_trace = (dlg_trace_t*)tr; }
+
+void dogleg_getDefaultParameters(dogleg_parameters2_t* parameters) { *parameters = k_defaults; }
+
+// dogleg.c:140-181
+void dogleg_setDebug(int debug)
+{
+  if(debug == 0)                       { g_params.debug = false; g_params.debug_vnlog = false; }
+  else if(debug & DOGLEG_DEBUG_VNLOG)  { g_params.debug = false; g_params.debug_vnlog = true;  }
+  else                                 { g_params.debug = true;  g_params.debug_vnlog = false; }
+}
+void dogleg_setInitialTrustregion(double t) { g_params.trustregion0 = t; }
+void dogleg_setThresholds(double Jt_x, double update, double trustregion)
+{
+  if(Jt_x > 0.0)        g_params.Jt_x_threshold        = Jt_x;
+  if(update > 0.0)      g_params.update_threshold      = update;
+  if(trustregion > 0.0) g_params.trustregion_threshold = trustregion;
+}
+void dogleg_setMaxIterations(int n) { g_params.max_iterations = n; }
+void dogleg_setTrustregionUpdateParameters(double downFactor, double downThreshold,
+                                           double upFactor, double upThreshold)
+{
+  g_params.trustregion_decrease_factor    = downFactor;
+  g_params.trustregion_decrease_threshold = downThreshold;
+  g_params.trustregion_increase_factor    = upFactor;
+  g_params.trustregion_increase_threshold = upThreshold;
+}
+
+double dogleg_optimize2(double* p, unsigned int Nstate, unsigned int Nmeas, unsigned int NJnnz,
+                        dogleg_callback_t* f, void* cookie,
+                        const dogleg_parameters2_t* parameters,
+                        dogleg_solverContext_t** returnContext)
+{
+  if(NJnnz == 0) { MSG("NJnnz must be > 0, got %u", NJnnz); return -1.0; }      // dogleg.c:1762-1766
+  return optimize(p, Nstate, Nmeas, NJnnz, f, nullptr, nullptr, cookie, parameters, returnContext);
+}
+double dogleg_optimize(double* p, unsigned int Nstate, unsigned int Nmeas, unsigned int NJnnz,
+                       dogleg_callback_t* f, void* cookie, dogleg_solverContext_t** returnContext)
+{
+  return dogleg_optimize2(p, Nstate, Nmeas, NJnnz, f, cookie, nullptr, returnContext);
+}
+double dogleg_optimize_dense2(double* p, unsigned int Nstate, unsigned int Nmeas,
+                              dogleg_callback_dense_t* f, void* cookie,
+                              const dogleg_parameters2_t* parameters,
+                              dogleg_solverContext_t** returnContext)
+{
+  return optimize(p, Nstate, Nmeas, 0, nullptr, f, nullptr, cookie, parameters, returnContext);
+}
+double dogleg_optimize_dense(double* p, unsigned int Nstate, unsigned int Nmeas,
+                             dogleg_callback_dense_t* f, void* cookie,
+                             dogleg_solverContext_t** returnContext)
+{
+  return dogleg_optimize_dense2(p, Nstate, Nmeas, f, cookie, nullptr, returnContext);
+}
+double dogleg_optimize_dense_products(double* p, unsigned int Nstate,
+                                      dogleg_callback_dense_products_t* f, void* cookie,
+                                      const dogleg_parameters2_t* parameters,
+                                      dogleg_solverContext_t** returnContext)
+{
+  return optimize(p, Nstate, 0, 0, nullptr, nullptr, f, cookie, parameters, returnContext);
+}
+
+// dogleg.h:304-310: make sure the factor of JtJ at `point` is held
+bool dogleg_computeJtJfactorization(dogleg_operatingPoint_t* point, dogleg_solverContext_t* ctx)
+{
+  Driver* d = D(ctx);
+  if(!factorize(point, d)) return false;
+  if(ctx->solve_type != DOGLEG_SPARSE)
+  {
+    const size_t N = (size_t)ctx->Nstate;
+    const size_t sz = (ctx->solve_type == DOGLEG_DENSE || ctx->parameters->JtJ_packed) ? N*(N+1)/2 : N*N;
+    if(dlg_factor_download_dense(d->be, ctx->factorization_dense, sz) != DLG_OK) return false;
+  }
+  return true;
+}
+
+void dogleg_freeContext(dogleg_solverContext_t** ctx)
+{
+  if(!ctx || !*ctx) return;
+  destroy(D(*ctx));
+  *ctx = nullptr;
+}
+
+} // extern "C"

@@ -1,0 +1,786 @@
+// kernels_dense.hip -- DOGLEG_DENSE / DOGLEG_DENSE_PRODUCTS hot path on gfx950.
+//
+//   K1-dense  Jt_x = J^T x            replaces mul_matrix_t_densevector (dogleg.c:284-292)
+//   K3/K8     |J v|^2                 replaces norm2_mul_matrix_vector  (dogleg.c:293-306)
+//   K4-dense  JtJ = J^T J (+lambda I) replaces the rank-1 loop          (dogleg.c:709-723)
+//             -> fp64 MFMA SYRK (v_mfma_f64_16x16x4_f64), split over the
+//                measurement rows, lower triangle only
+//   K5-dense  Cholesky                replaces dpptrf_/dpotrf_          (dogleg.c:782-803)
+//             -> blocked right-looking: LDS diagonal block, row-parallel TRSM,
+//                MFMA trailing update (same SYRK kernel)
+//   K6-dense  two triangular solves   replaces dpptrs_/dpotrs_          (dogleg.c:875-891)
+//
+// Storage: the factor lives in G, an N x N column-major array whose LOWER
+// triangle is used.  The reference's "row-major packed upper" triangle is the
+// same matrix as a column-major lower triangle (dogleg.c:788-790); the packed
+// layout exists only at the API edge (dlg_factor_download_dense).
+//
+// J is row-major [M][N]: element (r,c) at r*N + c, i.e. J^T in column-major
+// with leading dimension N.  So "A[i + k*lda]" of the SYRK kernel reads J
+// directly with i = state index, k = measurement row: for a fixed row the 128
+// state entries of a tile are contiguous -> coalesced 512-B wave loads.
+#include "dlg_internal.h"
+
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int TPB = 256;
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+  for(int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  return v;
+}
+
+// ------------------------------------------------------------------ K1 -----
+// partial[chunk][c] = sum_{r in chunk} J[r][c] x[r]
+__global__ void __launch_bounds__(TPB) k_gemvT_part(const double* __restrict__ J,
+                                                    const double* __restrict__ x, int M, int N,
+                                                    int rows_per_chunk, double* __restrict__ part)
+{
+  const int c = blockIdx.x*TPB + threadIdx.x;
+  const int r0 = blockIdx.y*rows_per_chunk;
+  int r1 = r0 + rows_per_chunk; if(r1 > M) r1 = M;
+  if(c >= N) return;
+  double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+  int r = r0;
+  for(; r + 3 < r1; r += 4)
+  {
+    a0 += J[(size_t)(r  )*N + c]*x[r  ];
+    a1 += J[(size_t)(r+1)*N + c]*x[r+1];
+    a2 += J[(size_t)(r+2)*N + c]*x[r+2];
+    a3 += J[(size_t)(r+3)*N + c]*x[r+3];
+  }
+  for(; r < r1; r++) a0 += J[(size_t)r*N + c]*x[r];
+  part[(size_t)blockIdx.y*N + c] = (a0 + a1) + (a2 + a3);
+}
+__global__ void __launch_bounds__(TPB) k_colsum(const double* __restrict__ part, int nchunks, int N,
+                                                double* __restrict__ out)
+{
+  const int c = blockIdx.x*TPB + threadIdx.x;
+  if(c >= N) return;
+  double s = 0;
+  for(int k = 0; k < nchunks; k++) s += part[(size_t)k*N + c];
+  out[c] = s;
+}
+
+// --------------------------------------------------------------- K3 / K8 ---
+// one wave per measurement row: dot(J[r,:], v)^2 accumulated per wave
+__global__ void __launch_bounds__(TPB) k_norm2_Jv_part(const double* __restrict__ J,
+                                                       const double* __restrict__ v, int M, int N,
+                                                       double* __restrict__ part)
+{
+  __shared__ double sh[4];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int wave = blockIdx.x*4 + w, nwaves = gridDim.x*4;
+  double acc = 0;
+  for(int r = wave; r < M; r += nwaves)
+  {
+    const double* Jr = J + (size_t)r*N;
+    double d = 0;
+    for(int c = lane; c < N; c += 64) d += Jr[c]*v[c];
+    d = wave_sum(d);
+    acc += d*d;          // only lane 0 holds the full sum; others add garbage we ignore
+  }
+  if(lane == 0) sh[w] = acc;
+  __syncthreads();
+  if(threadIdx.x == 0) part[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+// ------------------------------------------------------- products helpers ---
+// v' A v with A row-major packed upper (dogleg.c:309-332) or full (335-347)
+__global__ void __launch_bounds__(TPB) k_quadform_part(const double* __restrict__ A,
+                                                       const double* __restrict__ v, int N,
+                                                       int packed_upper, double* __restrict__ part)
+{
+  __shared__ double sh[4];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int wave = blockIdx.x*4 + w, nwaves = gridDim.x*4;
+  double acc = 0;
+  for(int i = wave; i < N; i += nwaves)
+  {
+    double d = 0;
+    if(packed_upper)
+    {
+      const double* row = A + ((size_t)i*N - (size_t)i*(i-1)/2) - i;   // row[j] valid for j>=i
+      for(int j = i + lane; j < N; j += 64) d += (j == i ? 1.0 : 2.0)*row[j]*v[j];
+    }
+    else
+    {
+      const double* row = A + (size_t)i*N;
+      for(int j = lane; j < N; j += 64) d += row[j]*v[j];
+    }
+    d = wave_sum(d);
+    acc += d*v[i];
+  }
+  if(lane == 0) sh[w] = acc;
+  __syncthreads();
+  if(threadIdx.x == 0) part[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+// G (col-major lower, ld N) <- JtJ given as row-major packed upper, or full
+__global__ void __launch_bounds__(TPB) k_unpack_to_G(const double* __restrict__ A, int N,
+                                                     int packed_upper, double lambda,
+                                                     double* __restrict__ G)
+{
+  const size_t t = (size_t)blockIdx.x*TPB + threadIdx.x;
+  if(t >= (size_t)N*N) return;
+  const int i = (int)(t % N), j = (int)(t / N);       // G[i + j*N]
+  if(i < j) return;
+  double v;
+  if(packed_upper) v = A[((size_t)j*N - (size_t)j*(j-1)/2) + (i - j)];
+  else             v = A[(size_t)j*N + i];
+  if(i == j) v += lambda;
+  G[t] = v;
+}
+__global__ void __launch_bounds__(TPB) k_add_diag(double* __restrict__ G, int N, double lambda)
+{
+  const int i = blockIdx.x*TPB + threadIdx.x;
+  if(i < N) G[(size_t)i*N + i] += lambda;
+}
+// packed (as dpptrf('L') leaves it) <- G
+__global__ void __launch_bounds__(TPB) k_pack_from_G(const double* __restrict__ G, int N,
+                                                     double* __restrict__ P)
+{
+  const size_t t = (size_t)blockIdx.x*TPB + threadIdx.x;
+  if(t >= (size_t)N*N) return;
+  const int i = (int)(t % N), j = (int)(t / N);
+  if(i < j) return;
+  P[((size_t)j*N - (size_t)j*(j-1)/2) + (i - j)] = G[t];
+}
+
+// ------------------------------------------------------------- MFMA SYRK ----
+// C[i,j] (i>=j, column-major, ldc) (+)= alpha * sum_{k<K} A[i + k*lda] A[j + k*lda]
+//
+// Workgroup = 4 waves in a 2x2 arrangement; block tile BT x BT with BT = 2*WT;
+// each wave owns WT x WT = (WT/16)^2 MFMA tiles of 16x16 (v_mfma_f64_16x16x4_f64).
+// K is consumed in chunks of KC=16 rows staged through LDS (double-buffered,
+// one barrier per chunk).  LDS rows are padded to BT+16 doubles so that the four
+// k-rows a wave reads in one ds_read_b64 fall in different bank halves.
+// The MFMA is issued "transposed" (operand A <- column index j, operand B <- row
+// index i) so that the 16 lanes of an accumulator register hold 16 consecutive
+// i of one column j: 128-B contiguous stores into column-major C.
+constexpr int KC = 16;
+
+template <int WT>
+__global__ void __launch_bounds__(TPB, 2)
+k_syrk_lower(double* __restrict__ C, int ldc, const double* __restrict__ A, int lda, int n, int K,
+             double alpha, int nsplit, int kper, double* __restrict__ slabs)
+{
+  constexpr int BT = 2*WT;
+  constexpr int LDS_LD = BT + 16;
+  constexpr int NT = WT/16;
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  // layout: [buf][operand][KC][LDS_LD]
+  auto sA = [&](int buf) -> double* { return smem + (size_t)(2*buf    )*KC*LDS_LD; };
+  auto sB = [&](int buf) -> double* { return smem + (size_t)(2*buf + 1)*KC*LDS_LD; };
+
+  // tile index -> (ti >= tj)
+  const int tile  = blockIdx.x / nsplit;
+  const int split = blockIdx.x - tile*nsplit;
+  int ti = (int)((sqrt(8.0*(double)tile + 1.0) - 1.0)*0.5);
+  while((long)ti*(ti+1)/2 > tile) ti--;
+  while((long)(ti+1)*(ti+2)/2 <= tile) ti++;
+  const int tj = tile - (int)((long)ti*(ti+1)/2);
+  const int i0 = ti*BT, j0 = tj*BT;
+  const bool diag = (ti == tj);
+
+  const int k_begin = split*kper;
+  int k_end = k_begin + kper; if(k_end > K) k_end = K;
+  const int nchunks = (k_end > k_begin) ? (k_end - k_begin + KC - 1)/KC : 0;
+
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int wi = (w & 1)*WT, wj = (w >> 1)*WT;     // wave offsets inside the block tile
+
+  // global -> register staging: BT*KC doubles per operand, TPB threads
+  constexpr int PER_T = BT*KC/TPB;                 // 8 (BT=128) or 4 (BT=64)
+  constexpr int ROWS_PER_IT = TPB/BT;              // 2 or 4
+  double ra[PER_T], rb[PER_T];
+  const int li = t % BT, lk = t / BT;
+
+  auto gload = [&](int chunk) {
+    const int kb = k_begin + chunk*KC;
+#pragma unroll
+    for(int it = 0; it < PER_T; it++)
+    {
+      const int k = kb + it*ROWS_PER_IT + lk;
+      const bool kin = k < k_end;
+      ra[it] = (kin && i0 + li < n) ? A[(size_t)k*lda + i0 + li] : 0.0;
+      if(!diag) rb[it] = (kin && j0 + li < n) ? A[(size_t)k*lda + j0 + li] : 0.0;
+    }
+  };
+  auto sstore = [&](int buf) {
+#pragma unroll
+    for(int it = 0; it < PER_T; it++)
+    {
+      const int k = it*ROWS_PER_IT + lk;
+      sA(buf)[k*LDS_LD + li] = ra[it];
+      if(!diag) sB(buf)[k*LDS_LD + li] = rb[it];
+    }
+  };
+
+  double4_t acc[NT][NT];
+#pragma unroll
+  for(int a = 0; a < NT; a++)
+#pragma unroll
+    for(int c = 0; c < NT; c++) acc[a][c] = (double4_t){0.0, 0.0, 0.0, 0.0};
+
+  if(nchunks > 0) { gload(0); sstore(0); }
+  __syncthreads();
+
+  const int fr = lane & 15, fk = lane >> 4;
+  for(int c = 0; c < nchunks; c++)
+  {
+    const int buf = c & 1;
+    if(c + 1 < nchunks) gload(c + 1);
+    const double* pa = sA(buf);
+    const double* pb = diag ? sA(buf) : sB(buf);
+#pragma unroll
+    for(int kk = 0; kk < KC; kk += 4)
+    {
+      double fi[NT], fj[NT];
+#pragma unroll
+      for(int m = 0; m < NT; m++)
+      {
+        fi[m] = pa[(kk + fk)*LDS_LD + wi + m*16 + fr];
+        fj[m] = pb[(kk + fk)*LDS_LD + wj + m*16 + fr];
+      }
+#pragma unroll
+      for(int a = 0; a < NT; a++)          // a: j sub-tile (MFMA rows)
+#pragma unroll
+        for(int bq = 0; bq < NT; bq++)     // bq: i sub-tile (MFMA cols)
+          acc[a][bq] = __builtin_amdgcn_mfma_f64_16x16x4f64(fj[a], fi[bq], acc[a][bq], 0, 0, 0);
+    }
+    if(c + 1 < nchunks) sstore(buf ^ 1);
+    __syncthreads();
+  }
+
+  // epilogue.  acc[a][bq][q]: j = j0+wj+a*16 + (lane>>4) + 4q ; i = i0+wi+bq*16 + (lane&15)
+  if(nsplit == 1)
+  {
+#pragma unroll
+    for(int a = 0; a < NT; a++)
+#pragma unroll
+      for(int bq = 0; bq < NT; bq++)
+#pragma unroll
+        for(int q = 0; q < 4; q++)
+        {
+          const int j = j0 + wj + a*16 + fk + 4*q;
+          const int i = i0 + wi + bq*16 + fr;
+          if(i < n && j < n && i >= j) C[(size_t)j*ldc + i] += alpha*acc[a][bq][q];
+        }
+  }
+  else
+  {
+    double* slab = slabs + ((size_t)split*gridDim.x/nsplit + tile)*(size_t)(BT*BT);
+#pragma unroll
+    for(int a = 0; a < NT; a++)
+#pragma unroll
+      for(int bq = 0; bq < NT; bq++)
+#pragma unroll
+        for(int q = 0; q < 4; q++)
+        {
+          const int jl = wj + a*16 + fk + 4*q;
+          const int il = wi + bq*16 + fr;
+          slab[(size_t)jl*BT + il] = acc[a][bq][q];
+        }
+  }
+}
+
+// C[i,j] = beta*C[i,j] + alpha * sum_s slab[s][tile][jl][il] (+ lambda on the diagonal)
+template <int BT>
+__global__ void __launch_bounds__(TPB) k_syrk_reduce(double* __restrict__ C, int ldc, int n,
+                                                     const double* __restrict__ slabs, int nsplit,
+                                                     int ntiles, double alpha, double beta,
+                                                     double lambda)
+{
+  const int tile = blockIdx.x;
+  int ti = (int)((sqrt(8.0*(double)tile + 1.0) - 1.0)*0.5);
+  while((long)ti*(ti+1)/2 > tile) ti--;
+  while((long)(ti+1)*(ti+2)/2 <= tile) ti++;
+  const int tj = tile - (int)((long)ti*(ti+1)/2);
+  for(int e = threadIdx.x; e < BT*BT; e += TPB)
+  {
+    const int il = e % BT, jl = e / BT;
+    const int i = ti*BT + il, j = tj*BT + jl;
+    if(i >= n || j >= n || i < j) continue;
+    double s = 0;
+    for(int sp = 0; sp < nsplit; sp++) s += slabs[((size_t)sp*ntiles + tile)*(size_t)(BT*BT) + e];
+    double r = alpha*s;
+    if(beta != 0.0) r += beta*C[(size_t)j*ldc + i];
+    if(i == j) r += lambda;
+    C[(size_t)j*ldc + i] = r;
+  }
+}
+
+// --------------------------------------------------------------- potrf ------
+constexpr int NB = 64;
+
+// factor the nb x nb diagonal block at (kb,kb) in LDS; info = first bad pivot (1-based, global)
+__global__ void __launch_bounds__(TPB) k_potrf_diag(double* __restrict__ A, int lda, int kb, int nb,
+                                                    int* __restrict__ info)
+{
+  __shared__ double L[NB][NB + 1];
+  const int t = threadIdx.x;
+  for(int e = t; e < nb*nb; e += TPB)
+  {
+    const int i = e % nb, j = e / nb;
+    L[i][j] = (i >= j) ? A[(size_t)(kb + j)*lda + kb + i] : 0.0;
+  }
+  __syncthreads();
+  for(int j = 0; j < nb; j++)
+  {
+    // column j: pivot
+    const double d = L[j][j];
+    __syncthreads();
+    if(!(d > 0.0))
+    {
+      if(t == 0 && *info == 0) *info = kb + j + 1;
+      // keep going with a harmless pivot so that later kernels do not trap on NaN storms
+    }
+    const double piv = (d > 0.0) ? sqrt(d) : 1.0;
+    const double inv = 1.0/piv;
+    if(t == 0) L[j][j] = piv;
+    for(int i = j + 1 + t; i < nb; i += TPB) L[i][j] *= inv;
+    __syncthreads();
+    // trailing update of the remaining columns (lower part)
+    const int m = nb - j - 1;
+    for(int e = t; e < m*m; e += TPB)
+    {
+      const int ii = j + 1 + e % m, jj = j + 1 + e / m;
+      if(ii >= jj) L[ii][jj] -= L[ii][j]*L[jj][j];
+    }
+    __syncthreads();
+  }
+  for(int e = t; e < nb*nb; e += TPB)
+  {
+    const int i = e % nb, j = e / nb;
+    if(i >= j) A[(size_t)(kb + j)*lda + kb + i] = L[i][j];
+  }
+}
+
+// rows below the diagonal block: X L_kk^T = A_panel, one thread per row.  The
+// block is padded to NB x NB with an identity tail so the substitution is a
+// fully unrolled register-resident loop; L entries are LDS broadcasts.
+__global__ void __launch_bounds__(TPB) k_trsm_panel(double* __restrict__ A, int lda, int kb, int nb,
+                                                    int n)
+{
+  __shared__ double L[NB][NB + 1];
+  const int t = threadIdx.x;
+  for(int e = t; e < NB*NB; e += TPB)
+  {
+    const int i = e % NB, j = e / NB;
+    double v = (i == j) ? 1.0 : 0.0;
+    if(i < nb && j < nb && i >= j) v = A[(size_t)(kb + j)*lda + kb + i];
+    L[i][j] = v;
+  }
+  __syncthreads();
+  const int r = kb + nb + blockIdx.x*TPB + t;
+  if(r >= n) return;
+  double xr[NB];
+#pragma unroll
+  for(int j = 0; j < NB; j++) xr[j] = (j < nb) ? A[(size_t)(kb + j)*lda + r] : 0.0;
+#pragma unroll
+  for(int j = 0; j < NB; j++)
+  {
+    const double xj = xr[j] / L[j][j];
+    xr[j] = xj;
+#pragma unroll
+    for(int k = j + 1; k < NB; k++) xr[k] -= xj*L[k][j];
+  }
+#pragma unroll
+  for(int j = 0; j < NB; j++) if(j < nb) A[(size_t)(kb + j)*lda + r] = xr[j];
+}
+
+// ------------------------------------------------------------- trsv ---------
+// forward: solve the nb x nb diagonal block (single workgroup, serial in LDS)
+__global__ void __launch_bounds__(64) k_trsv_diag_fwd(const double* __restrict__ A, int lda, int kb,
+                                                      int nb, double* __restrict__ y)
+{
+  __shared__ double L[NB][NB + 1];
+  __shared__ double v[NB];
+  const int t = threadIdx.x;
+  for(int e = t; e < nb*nb; e += 64)
+  {
+    const int i = e % nb, j = e / nb;
+    L[i][j] = (i >= j) ? A[(size_t)(kb + j)*lda + kb + i] : 0.0;
+  }
+  if(t < nb) v[t] = y[kb + t];
+  __syncthreads();
+  for(int j = 0; j < nb; j++)
+  {
+    if(t == j) v[j] = v[j] / L[j][j];
+    __syncthreads();
+    if(t > j && t < nb) v[t] -= L[t][j]*v[j];
+    __syncthreads();
+  }
+  if(t < nb) y[kb + t] = v[t];
+}
+// y[i] -= sum_{k in block} L[i,k] y[k]  for i >= kb+nb
+__global__ void __launch_bounds__(TPB) k_trsv_update_fwd(const double* __restrict__ A, int lda,
+                                                         int kb, int nb, int n,
+                                                         double* __restrict__ y)
+{
+  __shared__ double v[NB];
+  if(threadIdx.x < nb) v[threadIdx.x] = y[kb + threadIdx.x];
+  __syncthreads();
+  const int i = kb + nb + blockIdx.x*TPB + threadIdx.x;
+  if(i >= n) return;
+  double s = 0;
+  for(int k = 0; k < nb; k++) s += A[(size_t)(kb + k)*lda + i]*v[k];
+  y[i] -= s;
+}
+// backward: L^T x = y
+__global__ void __launch_bounds__(64) k_trsv_diag_bwd(const double* __restrict__ A, int lda, int kb,
+                                                      int nb, double* __restrict__ y)
+{
+  __shared__ double L[NB][NB + 1];
+  __shared__ double v[NB];
+  const int t = threadIdx.x;
+  for(int e = t; e < nb*nb; e += 64)
+  {
+    const int i = e % nb, j = e / nb;
+    L[i][j] = (i >= j) ? A[(size_t)(kb + j)*lda + kb + i] : 0.0;
+  }
+  if(t < nb) v[t] = y[kb + t];
+  __syncthreads();
+  for(int j = nb - 1; j >= 0; j--)
+  {
+    if(t == j) v[j] = v[j] / L[j][j];
+    __syncthreads();
+    if(t < j) v[t] -= L[j][t]*v[j];
+    __syncthreads();
+  }
+  if(t < nb) y[kb + t] = v[t];
+}
+// x[i] -= sum_{k in block} L[k,i] x[k]  for i < kb   (one wave per i; column i is contiguous)
+__global__ void __launch_bounds__(TPB) k_trsv_update_bwd(const double* __restrict__ A, int lda,
+                                                         int kb, int nb, double* __restrict__ y)
+{
+  __shared__ double v[NB];
+  if(threadIdx.x < nb) v[threadIdx.x] = y[kb + threadIdx.x];
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x*4 + (threadIdx.x >> 6);
+  if(i >= kb) return;
+  double s = (lane < nb) ? A[(size_t)i*lda + kb + lane]*v[lane] : 0.0;
+  s = wave_sum(s);
+  if(lane == 0) y[i] -= s;
+}
+
+// ------------------------------------------------------------ probes --------
+__global__ void __launch_bounds__(TPB) k_probe_mfma(double* out, int iters)
+{
+  double4_t acc[4];
+  for(int a = 0; a < 4; a++) acc[a] = (double4_t){0.0, 0.0, 0.0, 0.0};
+  const double x = 1.0 + threadIdx.x*1e-9, y = 1.0 - threadIdx.x*1e-9;
+  for(int it = 0; it < iters; it++)
+  {
+#pragma unroll
+    for(int a = 0; a < 4; a++) acc[a] = __builtin_amdgcn_mfma_f64_16x16x4f64(x, y, acc[a], 0, 0, 0);
+  }
+  double s = 0;
+  for(int a = 0; a < 4; a++) s += acc[a][0] + acc[a][1] + acc[a][2] + acc[a][3];
+  if(s == 12345.678) out[0] = s;
+}
+__global__ void __launch_bounds__(TPB) k_probe_copy(const double2* __restrict__ in,
+                                                    double2* __restrict__ out, size_t n)
+{
+  for(size_t i = (size_t)blockIdx.x*TPB + threadIdx.x; i < n; i += (size_t)gridDim.x*TPB) out[i] = in[i];
+}
+
+// number of K-splits for a tile count / K (so that ~1536 workgroups exist)
+static int syrk_nsplit(int ntiles, int K)
+{
+  int ns = dlg_cdiv(1536, ntiles);
+  const int maxs = K/(4*KC);
+  if(ns > maxs) ns = maxs;
+  if(ns < 1) ns = 1;
+  return ns;
+}
+
+// overwrite=false: C += alpha*A'A-style update, accumulated in place (one split).
+// overwrite=true : C  = alpha*update + lambda*I through the split-K slabs in `ws`.
+template <int WT>
+int launch_syrk(hipStream_t st, double* C, int ldc, const double* A, int lda, int n, int K,
+                double alpha, double lambda, bool overwrite, double* ws, size_t ws_bytes)
+{
+  constexpr int BT = 2*WT;
+  const int T = dlg_cdiv(n, BT);
+  const int ntiles = T*(T+1)/2;
+  const size_t lds = (size_t)4*KC*(BT + 16)*sizeof(double);
+  static bool attr_set = false;            // per instantiation
+  if(!attr_set)
+  {
+    DLG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_syrk_lower<WT>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  if(!overwrite)
+  {
+    const int kper = dlg_cdiv(K, KC)*KC;
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_syrk_lower<WT>), dim3(ntiles), dim3(TPB), lds, st, C, ldc, A,
+                       lda, n, K, alpha, 1, kper, (double*)nullptr);
+    DLG_LAUNCH_CHECK();
+    return DLG_OK;
+  }
+  int ks = syrk_nsplit(ntiles, K);
+  if(ks < 2) ks = 2;                       // the slab path needs nsplit > 1 (an empty split is fine)
+  const size_t per = (size_t)ntiles*BT*BT*sizeof(double);
+  while(ks > 2 && per*ks > ws_bytes) ks--;
+  if(!ws || per*ks > ws_bytes) { dlg_set_error("syrk workspace too small"); return DLG_ERR_ARG; }
+  int kper = dlg_cdiv(dlg_cdiv(K, ks), KC)*KC;
+  if(kper < KC) kper = KC;
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_syrk_lower<WT>), dim3(ntiles*ks), dim3(TPB), lds, st, C, ldc, A,
+                     lda, n, K, alpha, ks, kper, ws);
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_syrk_reduce<BT>), dim3(ntiles), dim3(TPB), 0, st, C, ldc, n, ws,
+                     ks, ntiles, alpha, 0.0, lambda);
+  DLG_LAUNCH_CHECK();
+  return DLG_OK;
+}
+
+int potrf_lower(hipStream_t st, double* A, int lda, int n, int* info_dev)
+{
+  for(int kb = 0; kb < n; kb += NB)
+  {
+    const int nb = (n - kb < NB) ? n - kb : NB;
+    hipLaunchKernelGGL(k_potrf_diag, dim3(1), dim3(TPB), 0, st, A, lda, kb, nb, info_dev);
+    const int rem = n - kb - nb;
+    if(rem > 0)
+    {
+      hipLaunchKernelGGL(k_trsm_panel, dim3(dlg_cdiv(rem, TPB)), dim3(TPB), 0, st, A, lda, kb, nb, n);
+      // trailing: C = A[kb+nb:, kb+nb:], panel P[i,k] = A[(kb+k)*lda + kb+nb+i]
+      double* Cc = A + (size_t)(kb + nb)*lda + (kb + nb);
+      const double* P = A + (size_t)kb*lda + (kb + nb);
+      int rc;
+      if(rem >= 1024) rc = launch_syrk<64>(st, Cc, lda, P, lda, rem, nb, -1.0, 0.0, false, nullptr, 0);
+      else            rc = launch_syrk<32>(st, Cc, lda, P, lda, rem, nb, -1.0, 0.0, false, nullptr, 0);
+      if(rc != DLG_OK) return rc;
+    }
+  }
+  DLG_LAUNCH_CHECK();
+  return DLG_OK;
+}
+
+} // namespace
+
+// =========================================================== host entry =====
+int dense_create(dlg_backend* b)
+{
+  const size_t N = (size_t)b->N;
+  DLG_HIP(hipMalloc(&b->G, N*N*sizeof(double)));
+  DLG_HIP(hipMemsetAsync(b->G, 0, N*N*sizeof(double), b->stream));
+  if(b->type == DLG_DENSE)
+  {
+    const int T = dlg_cdiv(b->N, 128);
+    const size_t ntiles = (size_t)T*(T+1)/2;
+    size_t ns = (size_t)syrk_nsplit((int)ntiles, b->M);
+    if(ns < 2) ns = 2;
+    b->slabs_bytes = ns*ntiles*128*128*sizeof(double);
+    DLG_HIP(hipMalloc(&b->slabs, b->slabs_bytes));
+  }
+  DLG_HIP(hipMalloc(&b->d_info, sizeof(int)));
+  DLG_HIP(hipHostMalloc(&b->h_info, sizeof(int)));
+  return DLG_OK;
+}
+void dense_destroy(dlg_backend* b)
+{
+  if(b->G) (void)hipFree(b->G);
+  if(b->slabs) (void)hipFree(b->slabs);
+  if(b->d_info) (void)hipFree(b->d_info);
+  if(b->h_info) (void)hipHostFree(b->h_info);
+  b->G = b->slabs = nullptr; b->d_info = nullptr; b->h_info = nullptr;
+}
+
+// K1: Jt_x into slot.Jt_x; d_scal[0] = norm2_x, d_scal[1] = (unused), d_scal[2..3] = norm2/absmax of Jt_x
+int dense_eval(dlg_backend* b, int s)
+{
+  DlgSlot& S = b->slot[s];
+  const int M = dlg_mloc(b), N = b->N;
+  if(M == 0) { DLG_HIP(hipMemsetAsync(S.Jt_x, 0, sizeof(double)*(size_t)N, b->stream)); return DLG_OK; }
+  int rpc = 128;
+  while(rpc > 16 && (long)dlg_cdiv(M, rpc)*dlg_cdiv(N, TPB) < 2048) rpc >>= 1;
+  const int nchunks = dlg_cdiv(M, rpc);
+  DLG_CHECK(dlg_ensure_partials(b, (size_t)nchunks*N + 8192));
+  double* part = b->d_part + 8192;         // first 8192 doubles are used by the vec reductions
+  hipLaunchKernelGGL(k_gemvT_part, dim3(dlg_cdiv(N, TPB), nchunks), dim3(TPB), 0, b->stream, S.Jin(),
+                     S.xin(), M, N, rpc, part);
+  hipLaunchKernelGGL(k_colsum, dim3(dlg_cdiv(N, TPB)), dim3(TPB), 0, b->stream, part, nchunks, N,
+                     S.Jt_x);
+  DLG_LAUNCH_CHECK();
+  return DLG_OK;
+}
+
+int dense_norm2_Jv(dlg_backend* b, int s, const double* v, double* out_dev)
+{
+  DlgSlot& S = b->slot[s];
+  const int M = dlg_mloc(b);
+  int g = dlg_cdiv(M, 4); if(g > 2048) g = 2048; if(g < 1) g = 1;
+  DLG_CHECK(dlg_ensure_partials(b, 8192));
+  double* part = b->d_part + 4096;
+  hipLaunchKernelGGL(k_norm2_Jv_part, dim3(g), dim3(TPB), 0, b->stream, S.Jin(), v, M, b->N, part);
+  DLG_LAUNCH_CHECK();
+  return k_reduce_sum(b, part, g, out_dev);
+}
+
+int products_quadform(dlg_backend* b, int s, const double* v, double* out_dev)
+{
+  DlgSlot& S = b->slot[s];
+  const bool packed = b->flags & DLG_FLAG_JTJ_PACKED, upper = b->flags & DLG_FLAG_JTJ_UPPER;
+  if(packed && !upper)
+  { dlg_set_error("only JtJ unpacked || (packed,upper) is supported (reference dogleg.c:597-601)"); return DLG_ERR_ARG; }
+  int g = dlg_cdiv(b->N, 4); if(g > 2048) g = 2048; if(g < 1) g = 1;
+  DLG_CHECK(dlg_ensure_partials(b, 8192));
+  double* part = b->d_part + 4096;
+  hipLaunchKernelGGL(k_quadform_part, dim3(g), dim3(TPB), 0, b->stream, S.Jin(), v, b->N,
+                     packed ? 1 : 0, part);
+  DLG_LAUNCH_CHECK();
+  return k_reduce_sum(b, part, g, out_dev);
+}
+
+static int finish_potrf(dlg_backend* b, int* ok)
+{
+  DLG_HIP(hipMemcpyAsync(b->h_info, b->d_info, sizeof(int), hipMemcpyDeviceToHost, b->stream));
+  DLG_HIP(hipStreamSynchronize(b->stream));
+  *ok = (*b->h_info == 0);
+  return DLG_OK;
+}
+
+int dense_factorize(dlg_backend* b, int s, double lambda, int* ok)
+{
+  DlgSlot& S = b->slot[s];
+  DLG_HIP(hipMemsetAsync(b->d_info, 0, sizeof(int), b->stream));
+  // K4: G(lower) = J^T J + lambda I   (K = M measurement rows, A = J with lda = N)
+  const bool sharded = b->allreduce != nullptr;
+  DLG_CHECK(launch_syrk<64>(b->stream, b->G, b->N, S.Jin(), b->N, b->N, dlg_mloc(b), 1.0,
+                            sharded ? 0.0 : lambda, true, b->slabs, b->slabs_bytes));
+  if(sharded)
+  {
+    DLG_CHECK(dlg_allreduce_dev(b, b->G, (size_t)b->N*b->N));
+    if(lambda != 0.0)
+      hipLaunchKernelGGL(k_add_diag, dim3(dlg_cdiv(b->N, TPB)), dim3(TPB), 0, b->stream, b->G, b->N, lambda);
+  }
+  // K5
+  DLG_CHECK(potrf_lower(b->stream, b->G, b->N, b->N, b->d_info));
+  return finish_potrf(b, ok);
+}
+
+int products_factorize(dlg_backend* b, int s, double lambda, int* ok)
+{
+  DlgSlot& S = b->slot[s];
+  const bool packed = b->flags & DLG_FLAG_JTJ_PACKED, upper = b->flags & DLG_FLAG_JTJ_UPPER;
+  if(packed && !upper)
+  { dlg_set_error("packed-lower JtJ is not supported (reference dogleg.c:597-601)"); return DLG_ERR_ARG; }
+  DLG_HIP(hipMemsetAsync(b->d_info, 0, sizeof(int), b->stream));
+  const size_t nn = (size_t)b->N*b->N;
+  hipLaunchKernelGGL(k_unpack_to_G, dim3(dlg_cdiv((long)nn, TPB)), dim3(TPB), 0, b->stream, S.Jin(),
+                     b->N, packed ? 1 : 0, lambda, b->G);
+  DLG_LAUNCH_CHECK();
+  DLG_CHECK(potrf_lower(b->stream, b->G, b->N, b->N, b->d_info));
+  return finish_potrf(b, ok);
+}
+
+// out = (L L^T)^-1 rhs
+int dense_solve(dlg_backend* b, const double* rhs, double* out)
+{
+  const int n = b->N;
+  if(out != rhs) DLG_HIP(hipMemcpyAsync(out, rhs, sizeof(double)*(size_t)n, hipMemcpyDeviceToDevice, b->stream));
+  for(int kb = 0; kb < n; kb += NB)
+  {
+    const int nb = (n - kb < NB) ? n - kb : NB;
+    hipLaunchKernelGGL(k_trsv_diag_fwd, dim3(1), dim3(64), 0, b->stream, b->G, n, kb, nb, out);
+    const int rem = n - kb - nb;
+    if(rem > 0)
+      hipLaunchKernelGGL(k_trsv_update_fwd, dim3(dlg_cdiv(rem, TPB)), dim3(TPB), 0, b->stream, b->G, n,
+                         kb, nb, n, out);
+  }
+  const int nblk = dlg_cdiv(n, NB);
+  for(int blk = nblk - 1; blk >= 0; blk--)
+  {
+    const int kb = blk*NB;
+    const int nb = (n - kb < NB) ? n - kb : NB;
+    hipLaunchKernelGGL(k_trsv_diag_bwd, dim3(1), dim3(64), 0, b->stream, b->G, n, kb, nb, out);
+    if(kb > 0)
+      hipLaunchKernelGGL(k_trsv_update_bwd, dim3(dlg_cdiv(kb, 4)), dim3(TPB), 0, b->stream, b->G, n, kb,
+                         nb, out);
+  }
+  DLG_LAUNCH_CHECK();
+  return DLG_OK;
+}
+
+// ------------------------------------------------- stand-alone C-ABI entries
+extern "C" int dlg_kernel_syrk_lower(void* hip_stream, double* C_dev, int ldc, const double* A_dev,
+                                     int lda, int n, int K, double alpha, double* ws,
+                                     size_t ws_bytes)
+{
+  hipStream_t st = (hipStream_t)hip_stream;
+  const bool overwrite = (ws != nullptr);
+  if(n >= 1024) return launch_syrk<64>(st, C_dev, ldc, A_dev, lda, n, K, alpha, 0.0, overwrite, ws, ws_bytes);
+  return launch_syrk<32>(st, C_dev, ldc, A_dev, lda, n, K, alpha, 0.0, overwrite, ws, ws_bytes);
+}
+extern "C" int dlg_kernel_potrf_lower(void* hip_stream, double* A_dev, int lda, int n, int* info_dev)
+{
+  return potrf_lower((hipStream_t)hip_stream, A_dev, lda, n, info_dev);
+}
+extern "C" int dlg_factor_download_dense(dlg_backend_t* b, double* host, size_t n)
+{
+  if(!b || b->type == DLG_SPARSE || !b->G) { dlg_set_error("no dense factor"); return DLG_ERR_STATE; }
+  const size_t N = (size_t)b->N;
+  const bool full = (b->type == DLG_DENSE_PRODUCTS) && !(b->flags & DLG_FLAG_JTJ_PACKED);
+  const size_t need = full ? N*N : N*(N+1)/2;
+  if(n < need) { dlg_set_error("factor buffer too small"); return DLG_ERR_ARG; }
+  if(full)
+  {
+    DLG_HIP(hipMemcpyAsync(host, b->G, need*sizeof(double), hipMemcpyDeviceToHost, b->stream));
+    DLG_HIP(hipStreamSynchronize(b->stream));
+    return DLG_OK;
+  }
+  double* tmp = nullptr;
+  DLG_HIP(hipMalloc(&tmp, need*sizeof(double)));
+  hipLaunchKernelGGL(k_pack_from_G, dim3(dlg_cdiv((long)(N*N), TPB)), dim3(TPB), 0, b->stream, b->G,
+                     b->N, tmp);
+  hipError_t e = hipMemcpyAsync(host, tmp, need*sizeof(double), hipMemcpyDeviceToHost, b->stream);
+  if(e == hipSuccess) e = hipStreamSynchronize(b->stream);
+  (void)hipFree(tmp);
+  if(e != hipSuccess) { dlg_set_error("factor download: %s", hipGetErrorString(e)); return DLG_ERR_HIP; }
+  return DLG_OK;
+}
+
+extern "C" int dlg_probe_mfma_f64(double* tflops)
+{
+  double* d = nullptr;
+  DLG_HIP(hipMalloc(&d, 8));
+  const int iters = 20000, blocks = 256*8;
+  hipEvent_t e0, e1;
+  DLG_HIP(hipEventCreate(&e0)); DLG_HIP(hipEventCreate(&e1));
+  hipLaunchKernelGGL(k_probe_mfma, dim3(blocks), dim3(TPB), 0, 0, d, 100);
+  DLG_HIP(hipEventRecord(e0, 0));
+  hipLaunchKernelGGL(k_probe_mfma, dim3(blocks), dim3(TPB), 0, 0, d, iters);
+  DLG_HIP(hipEventRecord(e1, 0));
+  DLG_HIP(hipEventSynchronize(e1));
+  float ms = 0; DLG_HIP(hipEventElapsedTime(&ms, e0, e1));
+  const double flops = (double)blocks*4 /*waves*/ * iters * 4 /*mfma*/ * 2048.0;
+  *tflops = flops/(ms*1e-3)/1e12;
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipFree(d);
+  return DLG_OK;
+}
+extern "C" int dlg_probe_hbm_copy(double* gbs)
+{
+  const size_t bytes = (size_t)1 << 30;
+  double2 *a = nullptr, *c = nullptr;
+  DLG_HIP(hipMalloc(&a, bytes)); DLG_HIP(hipMalloc(&c, bytes));
+  DLG_HIP(hipMemset(a, 1, bytes));
+  hipEvent_t e0, e1;
+  DLG_HIP(hipEventCreate(&e0)); DLG_HIP(hipEventCreate(&e1));
+  const size_t n = bytes/sizeof(double2);
+  hipLaunchKernelGGL(k_probe_copy, dim3(2048), dim3(TPB), 0, 0, a, c, n);
+  DLG_HIP(hipEventRecord(e0, 0));
+  for(int i = 0; i < 5; i++) hipLaunchKernelGGL(k_probe_copy, dim3(2048), dim3(TPB), 0, 0, a, c, n);
+  DLG_HIP(hipEventRecord(e1, 0));
+  DLG_HIP(hipEventSynchronize(e1));
+  float ms = 0; DLG_HIP(hipEventElapsedTime(&ms, e0, e1));
+  *gbs = 5.0*2.0*(double)bytes/(ms*1e-3)/1e9;
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipFree(a); (void)hipFree(c);
+  return DLG_OK;
+}

@@ -1,0 +1,256 @@
+// kernels_vec.hip -- O(N) vector kernels of the dog-leg step (K7 and the
+// scalar reductions around K1/K3/K6/K8).  All reductions are two-stage and
+// order-deterministic: stage 1 writes one partial per workgroup, stage 2 (one
+// workgroup) combines them in index order, so results are bitwise
+// reproducible run to run.  HBM-bound streaming kernels; 64-wide wavefront
+// shuffles, no atomics.
+//
+// Reference loops replaced: norm2 (dogleg.c:190-196), inner (197-203),
+// vec_copy_scaled (221-226), vec_add (228-233), vec_negate (241-245), the
+// interpolation loops (964-987), the threshold scans (1073-1078, 1289-1291).
+#include "dlg_internal.h"
+
+namespace {
+
+constexpr int TPB = 256;
+constexpr int MAXB = 1024;
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+  for(int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_max(double v)
+{
+#pragma unroll
+  for(int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_down(v, o, 64));
+  return v;
+}
+// block-wide sum/max; result valid in thread 0
+__device__ __forceinline__ double block_sum(double v, double* sh)
+{
+  v = wave_sum(v);
+  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+  __syncthreads();
+  if(l == 0) sh[w] = v;
+  __syncthreads();
+  double r = 0;
+  if(threadIdx.x == 0) for(int i = 0; i < (int)(blockDim.x >> 6); i++) r += sh[i];
+  return r;
+}
+__device__ __forceinline__ double block_max(double v, double* sh)
+{
+  v = wave_max(v);
+  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+  __syncthreads();
+  if(l == 0) sh[w] = v;
+  __syncthreads();
+  double r = 0;
+  if(threadIdx.x == 0) for(int i = 0; i < (int)(blockDim.x >> 6); i++) r = fmax(r, sh[i]);
+  return r;
+}
+
+// partial layout: part[k*nb + blk] for output k
+__global__ void __launch_bounds__(TPB) k_part_norm2_absmax(const double* __restrict__ x, int n,
+                                                           double* __restrict__ part)
+{
+  __shared__ double sh[4];
+  double s = 0, m = 0;
+  for(int i = blockIdx.x*TPB + threadIdx.x; i < n; i += gridDim.x*TPB)
+  { const double v = x[i]; s += v*v; m = fmax(m, fabs(v)); }
+  const double S = block_sum(s, sh);
+  const double Mx = block_max(m, sh);
+  if(threadIdx.x == 0) { part[blockIdx.x] = S; part[gridDim.x + blockIdx.x] = Mx; }
+}
+__global__ void __launch_bounds__(TPB) k_part_inner(const double* __restrict__ x,
+                                                    const double* __restrict__ y, int n,
+                                                    double* __restrict__ part)
+{
+  __shared__ double sh[4];
+  double s = 0;
+  for(int i = blockIdx.x*TPB + threadIdx.x; i < n; i += gridDim.x*TPB) s += x[i]*y[i];
+  const double S = block_sum(s, sh);
+  if(threadIdx.x == 0) part[blockIdx.x] = S;
+}
+// final: nsum sums followed by nmax maxima, each over nb partials
+__global__ void __launch_bounds__(TPB) k_final(const double* __restrict__ part, int nb, int nsum,
+                                               int nmax, double* __restrict__ out)
+{
+  __shared__ double sh[4];
+  for(int k = 0; k < nsum + nmax; k++)
+  {
+    const double* pk = part + (size_t)k*nb;
+    double v = 0;
+    if(k < nsum) { for(int i = threadIdx.x; i < nb; i += TPB) v += pk[i]; v = block_sum(v, sh); }
+    else         { for(int i = threadIdx.x; i < nb; i += TPB) v = fmax(v, pk[i]); v = block_max(v, sh); }
+    if(threadIdx.x == 0) out[k] = v;
+    __syncthreads();
+  }
+}
+
+__global__ void __launch_bounds__(TPB) k_cauchy_scale(const double* __restrict__ g,
+                                                      const double* __restrict__ scal,
+                                                      double* __restrict__ c, int n,
+                                                      double* __restrict__ out)
+{
+  const double g2 = scal[0], Jg2 = scal[1];
+  const double k = -g2 / Jg2;                       // dogleg.c:605
+  for(int i = blockIdx.x*TPB + threadIdx.x; i < n; i += gridDim.x*TPB) c[i] = k*g[i];
+  if(blockIdx.x == 0 && threadIdx.x == 0) out[0] = k*k*g2;   // dogleg.c:607
+}
+
+__global__ void __launch_bounds__(TPB) k_part_scaled_step(const double* __restrict__ v, double s,
+                                                          const double* __restrict__ p,
+                                                          double* __restrict__ step,
+                                                          double* __restrict__ pnew, int n,
+                                                          double* __restrict__ part)
+{
+  __shared__ double sh[4];
+  double m = 0;
+  for(int i = blockIdx.x*TPB + threadIdx.x; i < n; i += gridDim.x*TPB)
+  {
+    const double st = s*v[i];
+    step[i] = st; pnew[i] = p[i] + st; m = fmax(m, fabs(st));
+  }
+  const double Mx = block_max(m, sh);
+  if(threadIdx.x == 0) part[blockIdx.x] = Mx;
+}
+
+// interpolation pass 1: l2 = sum (a-b)^2, neg_c = sum (a-b) a   (dogleg.c:964-972)
+__global__ void __launch_bounds__(TPB) k_part_interp1(const double* __restrict__ a,
+                                                      const double* __restrict__ b, int n,
+                                                      double* __restrict__ part)
+{
+  __shared__ double sh[4];
+  double l2 = 0, nc = 0;
+  for(int i = blockIdx.x*TPB + threadIdx.x; i < n; i += gridDim.x*TPB)
+  { const double d = a[i] - b[i]; l2 += d*d; nc += d*a[i]; }
+  const double L = block_sum(l2, sh);
+  const double Cn = block_sum(nc, sh);
+  if(threadIdx.x == 0) { part[blockIdx.x] = L; part[gridDim.x + blockIdx.x] = Cn; }
+}
+// pass 2: k from the reduced scalars (dogleg.c:974-980), step = a + k (b-a)
+__global__ void __launch_bounds__(TPB) k_part_interp2(const double* __restrict__ a,
+                                                      const double* __restrict__ b,
+                                                      const double* __restrict__ scal,
+                                                      double norm2a, double dsq,
+                                                      const double* __restrict__ p,
+                                                      double* __restrict__ step,
+                                                      double* __restrict__ pnew, int n,
+                                                      double* __restrict__ part,
+                                                      double* __restrict__ kout)
+{
+  __shared__ double sh[4];
+  const double l2 = scal[0], neg_c = scal[1];
+  double disc = neg_c*neg_c - l2*(norm2a - dsq);
+  if(disc < 0.0) disc = 0.0;
+  const double k = (neg_c + sqrt(disc))/l2;
+  double s2 = 0, m = 0;
+  for(int i = blockIdx.x*TPB + threadIdx.x; i < n; i += gridDim.x*TPB)
+  {
+    const double st = a[i] + k*(b[i] - a[i]);
+    step[i] = st; pnew[i] = p[i] + st; s2 += st*st; m = fmax(m, fabs(st));
+  }
+  const double S = block_sum(s2, sh);
+  const double Mx = block_max(m, sh);
+  if(threadIdx.x == 0) { part[blockIdx.x] = S; part[gridDim.x + blockIdx.x] = Mx; }
+  if(blockIdx.x == 0 && threadIdx.x == 0) kout[0] = k;
+}
+
+__global__ void __launch_bounds__(TPB) k_part_negate_norm2(double* __restrict__ v, int n,
+                                                           double* __restrict__ part)
+{
+  __shared__ double sh[4];
+  double s = 0;
+  for(int i = blockIdx.x*TPB + threadIdx.x; i < n; i += gridDim.x*TPB)
+  { const double t = -v[i]; v[i] = t; s += t*t; }
+  const double S = block_sum(s, sh);
+  if(threadIdx.x == 0) part[blockIdx.x] = S;
+}
+
+inline int grid_for(int n) { int g = dlg_cdiv(n, TPB*2); if(g < 1) g = 1; if(g > MAXB) g = MAXB; return g; }
+
+} // namespace
+
+int dlg_ensure_partials(dlg_backend* b, size_t nd)
+{
+  if(nd <= b->part_cap) return DLG_OK;
+  if(b->d_part) DLG_HIP(hipFree(b->d_part));
+  b->d_part = nullptr; b->part_cap = 0;
+  DLG_HIP(hipMalloc(&b->d_part, nd*sizeof(double)));
+  b->part_cap = nd;
+  return DLG_OK;
+}
+
+int k_reduce_sum(dlg_backend* b, const double* partials, int np, double* out)
+{
+  hipLaunchKernelGGL(k_final, dim3(1), dim3(TPB), 0, b->stream, partials, np, 1, 0, out);
+  DLG_LAUNCH_CHECK();
+  return DLG_OK;
+}
+
+int k_norm2_absmax(dlg_backend* b, const double* x, int n, double* out2)
+{
+  const int g = grid_for(n);
+  DLG_CHECK(dlg_ensure_partials(b, 4*MAXB));
+  hipLaunchKernelGGL(k_part_norm2_absmax, dim3(g), dim3(TPB), 0, b->stream, x, n, b->d_part);
+  hipLaunchKernelGGL(k_final, dim3(1), dim3(TPB), 0, b->stream, b->d_part, g, 1, 1, out2);
+  DLG_LAUNCH_CHECK();
+  return DLG_OK;
+}
+int k_inner(dlg_backend* b, const double* x, const double* y, int n, double* out)
+{
+  const int g = grid_for(n);
+  DLG_CHECK(dlg_ensure_partials(b, 4*MAXB));
+  hipLaunchKernelGGL(k_part_inner, dim3(g), dim3(TPB), 0, b->stream, x, y, n, b->d_part);
+  hipLaunchKernelGGL(k_final, dim3(1), dim3(TPB), 0, b->stream, b->d_part, g, 1, 0, out);
+  DLG_LAUNCH_CHECK();
+  return DLG_OK;
+}
+int k_cauchy_finish(dlg_backend* b, const double* g, const double* scal_in, double* cauchy, int n,
+                    double* out)
+{
+  hipLaunchKernelGGL(k_cauchy_scale, dim3(grid_for(n)), dim3(TPB), 0, b->stream, g, scal_in, cauchy,
+                     n, out);
+  DLG_LAUNCH_CHECK();
+  return DLG_OK;
+}
+int k_scaled_step(dlg_backend* b, const double* v, double s, const double* p, double* step,
+                  double* p_new, int n, double* out_absmax)
+{
+  const int g = grid_for(n);
+  DLG_CHECK(dlg_ensure_partials(b, 4*MAXB));
+  hipLaunchKernelGGL(k_part_scaled_step, dim3(g), dim3(TPB), 0, b->stream, v, s, p, step, p_new, n,
+                     b->d_part);
+  hipLaunchKernelGGL(k_final, dim3(1), dim3(TPB), 0, b->stream, b->d_part, g, 0, 1, out_absmax);
+  DLG_LAUNCH_CHECK();
+  return DLG_OK;
+}
+int k_interpolate(dlg_backend* b, const double* a, const double* bb, double norm2a,
+                  double trustregion, const double* p, double* step, double* p_new, int n,
+                  double* out3)
+{
+  const int g = grid_for(n);
+  DLG_CHECK(dlg_ensure_partials(b, 4*MAXB));
+  // out3 = {norm2_step, k, absmax}; l2/neg_c parked in out3[3..4] (d_scal has room)
+  double* tmp = out3 + 3;
+  hipLaunchKernelGGL(k_part_interp1, dim3(g), dim3(TPB), 0, b->stream, a, bb, n, b->d_part);
+  hipLaunchKernelGGL(k_final, dim3(1), dim3(TPB), 0, b->stream, b->d_part, g, 2, 0, tmp);
+  hipLaunchKernelGGL(k_part_interp2, dim3(g), dim3(TPB), 0, b->stream, a, bb, tmp, norm2a,
+                     trustregion*trustregion, p, step, p_new, n, b->d_part, out3 + 1);
+  // sums -> out3[0]; max -> out3[2]: run k_final twice to place them
+  hipLaunchKernelGGL(k_final, dim3(1), dim3(TPB), 0, b->stream, b->d_part, g, 1, 0, out3);
+  hipLaunchKernelGGL(k_final, dim3(1), dim3(TPB), 0, b->stream, b->d_part + g, g, 0, 1, out3 + 2);
+  DLG_LAUNCH_CHECK();
+  return DLG_OK;
+}
+int k_negate_norm2(dlg_backend* b, double* v, int n, double* out)
+{
+  const int g = grid_for(n);
+  DLG_CHECK(dlg_ensure_partials(b, 4*MAXB));
+  hipLaunchKernelGGL(k_part_negate_norm2, dim3(g), dim3(TPB), 0, b->stream, v, n, b->d_part);
+  hipLaunchKernelGGL(k_final, dim3(1), dim3(TPB), 0, b->stream, b->d_part, g, 1, 0, out);
+  DLG_LAUNCH_CHECK();
+  return DLG_OK;
+}
