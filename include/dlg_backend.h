@@ -84,6 +84,14 @@ int  dlg_sparse_set_pattern(dlg_backend_t* b, const int* colptr, const int* rowi
 int  dlg_sparse_stats(dlg_backend_t* b, long* nnz_JtJ_lower, long* nnz_L,
                       int* n_supernodes, int* n_levels, double* factor_flops);
 
+/* host-only symbolic phase on a pattern (no GPU): stats[] = {var-blocks,
+ * supernodes, levels, nnz(tril JtJ), nnz(L), panel doubles, factor flops, max
+ * panel, assembly tasks, update items, relpos entries, output blocks,
+ * contributions, update sub-tasks, solve scratch, Jt*x tasks}; perm_out[N] may
+ * be NULL */
+int  dlg_sparse_symbolic_probe(int N, int M, const int* colptr, const int* rowidx, int row0,
+                               int row1, long* stats, int nstats, int* perm_out);
+
 /* ---- operating point inputs (host buffers; the callback's outputs).
  * K1 = computeCallbackOperatingPoint after the callback (dogleg.c:1024-1082):
  * Jt_x = Jt*x, norm2_x, and max_i |Jt_x[i]| for the gradient test. --------- */

@@ -19,7 +19,7 @@ FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall",
 
 
 def sources():
-    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
+    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".cpp")))
 
 
 def headers():
@@ -33,7 +33,8 @@ def _compile(src, newest_hdr, verbose):
     obj = os.path.join(OBJ, os.path.basename(src) + ".o")
     if os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(src), newest_hdr):
         return obj
-    cmd = [HIPCC] + FLAGS + ["-c", src, "-o", obj]
+    flags = FLAGS if src.endswith(".hip") else [f for f in FLAGS if not f.startswith("--offload-arch")]
+    cmd = [HIPCC] + flags + ["-c", src, "-o", obj]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)

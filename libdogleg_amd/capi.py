@@ -31,7 +31,7 @@ BACKEND_SYMBOLS = [
     "dlg_point_download", "dlg_factor_download_dense", "dlg_point_device_ptr",
     "dlg_kernel_syrk_lower", "dlg_kernel_potrf_lower", "dlg_probe_mfma_f64",
     "dlg_probe_hbm_copy", "dlg_set_trace", "dlg_mem_alloc", "dlg_mem_free", "dlg_mem_upload",
-    "dlg_mem_download", "dlg_mem_zero", "dlg_device_sync",
+    "dlg_mem_download", "dlg_mem_zero", "dlg_device_sync", "dlg_sparse_symbolic_probe",
 ]
 DOGLEG_SYMBOLS = [
     "dogleg_getDefaultParameters", "dogleg_setMaxIterations",
@@ -96,6 +96,8 @@ def lib():
     L.dlg_mem_upload.argtypes = [V, V, C.c_size_t]
     L.dlg_mem_download.argtypes = [V, V, C.c_size_t]
     L.dlg_mem_zero.argtypes = [V, C.c_size_t]
+    L.dlg_sparse_symbolic_probe.argtypes = [C.c_int, C.c_int, I, I, C.c_int, C.c_int,
+                                            C.POINTER(C.c_long), C.c_int, I]
     # dogleg.h
     PP = C.POINTER(Parameters2)
     L.dogleg_getDefaultParameters.argtypes = [PP]
@@ -151,6 +153,25 @@ def optimize(kind, p0, N, M, nnz, cb, cookie, params=None, capacity=256):
     finally:
         L.dlg_set_trace(None)
     return r, p, tr
+
+
+SYM_STAT_NAMES = ["var_blocks", "supernodes", "levels", "nnz_JtJ_lower", "nnz_L", "panel_doubles",
+                  "factor_flops", "max_panel", "asm_tasks", "update_items", "relpos", "out_blocks",
+                  "contribs", "update_subtasks", "solve_scratch", "jtx_tasks"]
+
+
+def symbolic_probe(N, M, Jp, Ji, row0=0, row1=None, want_perm=False):
+    """Host-only symbolic analysis of a Jt pattern: dict of statistics (+ perm)."""
+    L = lib()
+    Jp = np.ascontiguousarray(Jp, dtype=np.int32)
+    Ji = np.ascontiguousarray(Ji, dtype=np.int32)
+    st = (C.c_long * len(SYM_STAT_NAMES))()
+    perm = np.zeros(N, dtype=np.int32) if want_perm else None
+    _ck(L.dlg_sparse_symbolic_probe(N, M, iptr(Jp), iptr(Ji), row0, M if row1 is None else row1,
+                                    st, len(SYM_STAT_NAMES), iptr(perm) if want_perm else None),
+        "symbolic probe")
+    d = {k: st[i] for i, k in enumerate(SYM_STAT_NAMES)}
+    return (d, perm) if want_perm else d
 
 
 class DeviceArray:

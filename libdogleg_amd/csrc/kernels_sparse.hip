@@ -1,11 +1,660 @@
-// placeholder until the sparse path lands
+// kernels_sparse.hip -- DOGLEG_SPARSE hot path on gfx950.
+//
+//   K1  Jt_x = Jt*x            replaces mul_spmatrix_densevector        (dogleg.c:249-261)
+//   K3/K8  |J v|^2             replaces norm2_mul_spmatrix_t_densevector (dogleg.c:262-281)
+//   K4  JtJ assembly           (CHOLMOD forms A*A' internally: dogleg.c:659-664)
+//   K5  supernodal Cholesky    replaces cholmod_factorize[_p]            (dogleg.c:659-664)
+//   K6  triangular solves      replaces cholmod_solve(CHOLMOD_A)         (dogleg.c:853)
+//
+// Everything is gather-based and atomics-free: every output (a JtJ block, a
+// Jt_x block, a panel column range, a right-hand-side row) has exactly one
+// owner wave/workgroup that sums its contributions in a fixed order, so the
+// results are bitwise reproducible run to run.  The schedules come from the
+// host symbolic phase (sparse_symbolic.cpp).
+//
+// HBM layout: Jacobian values stay in the callback's CSC order (one H2D DMA);
+// the factor is a set of dense column-major supernode panels in one buffer Lx;
+// JtJ is assembled straight into those panels (no separate JtJ array).
 #include "dlg_internal.h"
-int sparse_create(dlg_backend*) { return DLG_OK; }
-size_t sparse_local_nnz(const dlg_backend* b) { return (size_t)b->nnz; }
-void sparse_destroy(dlg_backend*) {}
-int sparse_set_pattern(dlg_backend*, const int*, const int*) { dlg_set_error("sparse path not built yet"); return DLG_ERR_STATE; }
-int sparse_eval(dlg_backend*, int) { dlg_set_error("sparse path not built yet"); return DLG_ERR_STATE; }
-int sparse_norm2_Jv(dlg_backend*, int, const double*, double*) { dlg_set_error("sparse path not built yet"); return DLG_ERR_STATE; }
-int sparse_factorize(dlg_backend*, int, double, int*) { dlg_set_error("sparse path not built yet"); return DLG_ERR_STATE; }
-int sparse_solve(dlg_backend*, const double*, double*) { dlg_set_error("sparse path not built yet"); return DLG_ERR_STATE; }
-extern "C" int dlg_sparse_stats(dlg_backend_t*, long*, long*, int*, int*, double*) { return DLG_ERR_STATE; }
+#include "sparse_symbolic.h"
+
+namespace {
+
+constexpr int TPB = 256;
+constexpr int LDS_BUDGET = 147456;      // bytes of dynamic LDS we allow a workgroup
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+  for(int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  return v;
+}
+
+template <class T> int upload(T*& dev, const std::vector<T>& h)
+{
+  dev = nullptr;
+  const size_t bytes = sizeof(T)*(h.size() ? h.size() : 1);
+  DLG_HIP(hipMalloc(&dev, bytes));
+  if(!h.empty()) DLG_HIP(hipMemcpy(dev, h.data(), sizeof(T)*h.size(), hipMemcpyHostToDevice));
+  return DLG_OK;
+}
+
+} // namespace
+
+struct SparseSym
+{
+  SymHost H;
+  // schedules on the device
+  int *sn_c0 = nullptr, *sn_rowptr = nullptr, *sn_rows = nullptr, *sn_scr = nullptr, *lvl_sn = nullptr;
+  int64_t *sn_lx = nullptr, *diagpos = nullptr;
+  int *ui_t = nullptr, *ui_col = nullptr, *ui_nc = nullptr, *ui_ptr = nullptr;
+  int *ut_d = nullptr, *ut_ka = nullptr, *ut_rel = nullptr, *relpos = nullptr;
+  SymOutBlock* oblk = nullptr; SymContrib* contrib = nullptr;
+  SymTask *asm_task = nullptr, *jtx_task = nullptr;
+  int *asm_fin_ptr = nullptr, *asm_fin_blk = nullptr, *jtx_fin_ptr = nullptr, *jtx_fin_blk = nullptr;
+  int *rl_ptr = nullptr, *rl_pos = nullptr, *perm = nullptr;
+  int *Jp = nullptr, *Ji = nullptr;       // rank-local pattern (row pointers rebased to 0)
+  // numeric buffers
+  double *Lx = nullptr, *scr = nullptr, *ywork = nullptr, *asm_part = nullptr, *jtx_part = nullptr;
+  int *d_info = nullptr, *h_info = nullptr;
+  size_t nnz_loc = 0;
+  // per-level launch parameters
+  std::vector<int> fac_lds;     // bytes of LDS for the factor kernel of a level (0: panels stay in HBM)
+  std::vector<int> upd_lds, upd_nw;
+  std::vector<void*> allocs;
+};
+
+namespace {
+
+// ------------------------------------------------------------ K4 assembly ---
+// one wave per task: lane (a,b) of the output block accumulates
+//   sum_{contributions} sum_{rows k} J[k][offI+a] * J[k][offJ+b]
+__global__ void __launch_bounds__(TPB) k_assemble(const SymTask* __restrict__ tasks, int ntasks,
+                                                  const SymOutBlock* __restrict__ oblk,
+                                                  const SymContrib* __restrict__ contrib,
+                                                  const double* __restrict__ vals,
+                                                  double* __restrict__ Lx, double* __restrict__ part)
+{
+  const int wid = __builtin_amdgcn_readfirstlane(blockIdx.x*(TPB/64) + (threadIdx.x >> 6));
+  if(wid >= ntasks) return;
+  const int lane = threadIdx.x & 63;
+  const SymTask T = tasks[wid];
+  const SymOutBlock B = oblk[T.blk];
+  const int nI = B.nI, nJ = B.nJ;
+  const int a = lane % nI, b = lane / nI;
+  const bool active = (b < nJ) && (!B.diag || a >= b);
+  const int bb = active ? b : 0;
+  double acc = 0.0;
+  for(int c = T.c0; c < T.c1; c++)
+  {
+    const SymContrib C = contrib[c];
+    const double* row = vals + C.base;
+    for(int k = 0; k < C.nrows; k++, row += C.len)
+      acc += row[C.offI + a]*row[C.offJ + bb];
+  }
+  if(T.part < 0) { if(active) Lx[B.dest + a + (int64_t)b*B.ld] = acc; }
+  else part[(size_t)T.part*64 + lane] = acc;
+}
+__global__ void __launch_bounds__(TPB) k_assemble_fin(const int* __restrict__ fin_ptr,
+                                                      const int* __restrict__ fin_blk, int nfin,
+                                                      const SymOutBlock* __restrict__ oblk,
+                                                      const double* __restrict__ part,
+                                                      double* __restrict__ Lx)
+{
+  const int wid = blockIdx.x*(TPB/64) + (threadIdx.x >> 6);
+  if(wid >= nfin) return;
+  const int lane = threadIdx.x & 63;
+  const SymOutBlock B = oblk[fin_blk[wid]];
+  const int a = lane % B.nI, b = lane / B.nI;
+  const bool active = (b < B.nJ) && (!B.diag || a >= b);
+  double s = 0.0;
+  for(int p = fin_ptr[wid]; p < fin_ptr[wid+1]; p++) s += part[(size_t)p*64 + lane];
+  if(active) Lx[B.dest + a + (int64_t)b*B.ld] = s;
+}
+__global__ void __launch_bounds__(TPB) k_add_lambda(double* __restrict__ Lx,
+                                                    const int64_t* __restrict__ diagpos, int n,
+                                                    double lambda)
+{
+  const int i = blockIdx.x*TPB + threadIdx.x;
+  if(i < n) Lx[diagpos[i]] += lambda;
+}
+
+// ------------------------------------------------------------------ K1 ------
+// one wave per task over the diagonal block of a var-block I:
+//   Jt_x[I] = sum_{row-blocks containing I} sum_k J[k][offI + a] * x[r0 + k]
+// lanes = (a, j): j strides over the contributions; fixed-order LDS reduction.
+__global__ void __launch_bounds__(TPB) k_jtx(const SymTask* __restrict__ tasks, int ntasks,
+                                             const SymOutBlock* __restrict__ oblk,
+                                             const SymContrib* __restrict__ contrib,
+                                             const double* __restrict__ vals,
+                                             const double* __restrict__ x,
+                                             double* __restrict__ jtx, double* __restrict__ part)
+{
+  __shared__ double sh[TPB];
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wid = blockIdx.x*(TPB/64) + w;
+  double acc = 0.0;
+  int nI = 1, J = 1, a = 0, j = 0;
+  SymTask T = {0, 0, 0, -1};
+  SymOutBlock B; B.nI = 1; B.var0 = 0;
+  const bool live = wid < ntasks;
+  if(live)
+  {
+    T = tasks[wid];
+    B = oblk[T.blk];
+    nI = B.nI; J = 64/nI; a = lane % nI; j = lane / nI;
+    if(j < J)
+      for(int c = T.c0 + j; c < T.c1; c += J)
+      {
+        const SymContrib C = contrib[c];
+        const double* row = vals + C.base + C.offI + a;
+        for(int k = 0; k < C.nrows; k++, row += C.len) acc += row[0]*x[C.r0 + k];
+      }
+  }
+  sh[threadIdx.x] = acc;
+  __syncthreads();
+  if(live && lane < nI)
+  {
+    double s = 0.0;
+    for(int jj = 0; jj < J; jj++) s += sh[w*64 + lane + jj*nI];
+    if(T.part < 0) jtx[B.var0 + lane] = s;
+    else part[(size_t)T.part*8 + lane] = s;
+  }
+}
+__global__ void __launch_bounds__(TPB) k_jtx_fin(const int* __restrict__ fin_ptr,
+                                                 const int* __restrict__ fin_blk, int nfin,
+                                                 const SymOutBlock* __restrict__ oblk,
+                                                 const double* __restrict__ part,
+                                                 double* __restrict__ jtx)
+{
+  const int t = blockIdx.x*TPB + threadIdx.x;
+  const int f = t >> 3, a = t & 7;
+  if(f >= nfin) return;
+  const SymOutBlock B = oblk[fin_blk[f]];
+  if(a >= B.nI) return;
+  double s = 0.0;
+  for(int p = fin_ptr[f]; p < fin_ptr[f+1]; p++) s += part[(size_t)p*8 + a];
+  jtx[B.var0 + a] = s;
+}
+
+// --------------------------------------------------------------- K3 / K8 ---
+// thread per measurement row: (j_r . v)^2, block partial sums
+__global__ void __launch_bounds__(TPB) k_norm2_Jv(const int* __restrict__ Jp,
+                                                  const int* __restrict__ Ji,
+                                                  const double* __restrict__ vals,
+                                                  const double* __restrict__ v, int mloc,
+                                                  double* __restrict__ part)
+{
+  __shared__ double sh[4];
+  double acc = 0.0;
+  for(int r = blockIdx.x*TPB + threadIdx.x; r < mloc; r += gridDim.x*TPB)
+  {
+    double d = 0.0;
+    const int q1 = Jp[r+1];
+    for(int q = Jp[r]; q < q1; q++) d += v[Ji[q]]*vals[q];
+    acc += d*d;
+  }
+  acc = wave_sum(acc);
+  if((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if(threadIdx.x == 0) part[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+// ------------------------------------------------------------------ K5 ------
+// factor one supernode panel per workgroup: dense Cholesky of the w x w diagonal
+// block + triangular solve of the rows below, right-looking, column by column.
+// USE_LDS: the panel is staged in LDS (panels up to PANEL_CAP doubles).
+template <bool USE_LDS>
+__global__ void __launch_bounds__(TPB) k_factor_level(const int* __restrict__ lvl_sn,
+                                                      const int* __restrict__ sn_c0,
+                                                      const int* __restrict__ sn_rowptr,
+                                                      const int64_t* __restrict__ sn_lx,
+                                                      double* __restrict__ Lx, int* __restrict__ info)
+{
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int s = lvl_sn[blockIdx.x];
+  const int w = sn_c0[s+1] - sn_c0[s];
+  const int nrows = sn_rowptr[s+1] - sn_rowptr[s];
+  double* G = Lx + sn_lx[s];
+  const int tid = threadIdx.x;
+  const int total = nrows*w;
+  double* P;
+  if(USE_LDS)
+  {
+    P = lds;
+    for(int e = tid; e < total; e += TPB) P[e] = G[e];
+  }
+  else P = G;
+  __syncthreads();
+  for(int j = 0; j < w; j++)
+  {
+    const double d = P[j + j*nrows];
+    __syncthreads();
+    const bool bad = !(d > 0.0);
+    if(bad && tid == 0) atomicMin(info, sn_c0[s] + j);
+    const double piv = bad ? 1.0 : sqrt(d);
+    const double inv = 1.0/piv;
+    if(tid == 0) P[j + j*nrows] = piv;
+    for(int i = j + 1 + tid; i < nrows; i += TPB) P[i + j*nrows] *= inv;
+    __syncthreads();
+    const int nc = w - j - 1, nr = nrows - j - 1;
+    for(int e = tid; e < nc*nr; e += TPB)
+    {
+      const int cc = e / nr, ii = e - cc*nr;
+      if(ii >= cc)
+      {
+        const int c = j + 1 + cc, i = j + 1 + ii;
+        P[i + c*nrows] -= P[i + j*nrows]*P[c + j*nrows];
+      }
+    }
+    __syncthreads();
+  }
+  if(USE_LDS) for(int e = tid; e < total; e += TPB) G[e] = P[e];
+}
+
+// apply the updates of all source supernodes of one level to their ancestors.
+// One workgroup per item = (target supernode t, one var-block of its columns).
+// NW waves each own a private LDS slab (nrows_t x nc) and process the item's
+// sub-tasks round-robin; the slabs are then summed in wave order and
+// subtracted from the target panel.  NW == 0: slab does not fit LDS; the whole
+// workgroup walks the sub-tasks in order, updating the panel in HBM.
+__global__ void __launch_bounds__(TPB) k_update_level(int item0, const int* __restrict__ ui_t,
+                                                      const int* __restrict__ ui_col,
+                                                      const int* __restrict__ ui_nc,
+                                                      const int* __restrict__ ui_ptr,
+                                                      const int* __restrict__ ut_d,
+                                                      const int* __restrict__ ut_ka,
+                                                      const int* __restrict__ ut_rel,
+                                                      const int* __restrict__ relpos,
+                                                      const int* __restrict__ sn_c0,
+                                                      const int* __restrict__ sn_rowptr,
+                                                      const int64_t* __restrict__ sn_lx,
+                                                      double* __restrict__ Lx, int nw)
+{
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int item = item0 + blockIdx.x;
+  const int t = ui_t[item], col = ui_col[item], nc = ui_nc[item];
+  const int nrows_t = sn_rowptr[t+1] - sn_rowptr[t];
+  double* Lt = Lx + sn_lx[t] + (int64_t)col*nrows_t;
+  const int s0 = ui_ptr[item], s1 = ui_ptr[item+1];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int slab = nrows_t*nc;
+
+  if(nw > 0)
+  {
+    for(int e = tid; e < slab*nw; e += TPB) lds[e] = 0.0;
+    __syncthreads();
+    if(w < nw)
+    {
+      double* acc = lds + (size_t)w*slab;
+      for(int st = s0 + w; st < s1; st += nw)
+      {
+        const int d = ut_d[st], ka = ut_ka[st];
+        const int* rel = relpos + ut_rel[st];
+        const int nrows_d = sn_rowptr[d+1] - sn_rowptr[d];
+        const int wd = sn_c0[d+1] - sn_c0[d];
+        const double* Ld = Lx + sn_lx[d] + ka;
+        const int m = nrows_d - ka;
+        for(int e = lane; e < m*nc; e += 64)
+        {
+          const int c = e / m, i = e - c*m;
+          if(i >= c)
+          {
+            double sacc = 0.0;
+            for(int q = 0; q < wd; q++) sacc += Ld[i + (size_t)q*nrows_d]*Ld[c + (size_t)q*nrows_d];
+            acc[rel[i] + c*nrows_t] += sacc;
+          }
+        }
+      }
+    }
+    __syncthreads();
+    for(int e = tid; e < slab; e += TPB)
+    {
+      double tot = 0.0;
+      for(int k = 0; k < nw; k++) tot += lds[(size_t)k*slab + e];
+      Lt[e] -= tot;
+    }
+  }
+  else
+  {
+    for(int st = s0; st < s1; st++)
+    {
+      const int d = ut_d[st], ka = ut_ka[st];
+      const int* rel = relpos + ut_rel[st];
+      const int nrows_d = sn_rowptr[d+1] - sn_rowptr[d];
+      const int wd = sn_c0[d+1] - sn_c0[d];
+      const double* Ld = Lx + sn_lx[d] + ka;
+      const int m = nrows_d - ka;
+      for(int e = tid; e < m*nc; e += TPB)
+      {
+        const int c = e / m, i = e - c*m;
+        if(i >= c)
+        {
+          double sacc = 0.0;
+          for(int q = 0; q < wd; q++) sacc += Ld[i + (size_t)q*nrows_d]*Ld[c + (size_t)q*nrows_d];
+          Lt[rel[i] + c*nrows_t] -= sacc;
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+// ------------------------------------------------------------------ K6 ------
+// forward: per supernode  y_t = L_tt^-1 (P b - gathered updates);  u_t = L_below y_t
+__global__ void __launch_bounds__(TPB) k_solve_fwd_level(const int* __restrict__ lvl_sn,
+                                                         const int* __restrict__ sn_c0,
+                                                         const int* __restrict__ sn_rowptr,
+                                                         const int64_t* __restrict__ sn_lx,
+                                                         const int* __restrict__ sn_scr,
+                                                         const int* __restrict__ rl_ptr,
+                                                         const int* __restrict__ rl_pos,
+                                                         const int* __restrict__ perm,
+                                                         const double* __restrict__ Lx,
+                                                         const double* __restrict__ rhs,
+                                                         double* __restrict__ scr,
+                                                         double* __restrict__ ywork)
+{
+  __shared__ double y[256];
+  const int s = lvl_sn[blockIdx.x];
+  const int c0 = sn_c0[s], w = sn_c0[s+1] - c0;
+  const int nrows = sn_rowptr[s+1] - sn_rowptr[s];
+  const double* L = Lx + sn_lx[s];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  for(int j = wv; j < w; j += TPB/64)
+  {
+    const int k = c0 + j;
+    double sum = 0.0;
+    for(int e = rl_ptr[k] + lane; e < rl_ptr[k+1]; e += 64) sum += scr[rl_pos[e]];
+    sum = wave_sum(sum);
+    if(lane == 0) y[j] = rhs[perm[k]] - sum;
+  }
+  __syncthreads();
+  for(int j = 0; j < w; j++)
+  {
+    if(tid == 0) y[j] = y[j] / L[j + (size_t)j*nrows];
+    __syncthreads();
+    const double yj = y[j];
+    for(int i = j + 1 + tid; i < w; i += TPB) y[i] -= L[i + (size_t)j*nrows]*yj;
+    __syncthreads();
+  }
+  for(int j = tid; j < w; j += TPB) ywork[c0 + j] = y[j];
+  const int r = nrows - w;
+  double* u = scr + sn_scr[s];
+  for(int i = tid; i < r; i += TPB)
+  {
+    double sum = 0.0;
+    for(int j = 0; j < w; j++) sum += L[w + i + (size_t)j*nrows]*y[j];
+    u[i] = sum;
+  }
+}
+// backward: x_t = L_tt^-T (y_t - L_below^T x[below rows]); out[perm] = x
+__global__ void __launch_bounds__(TPB) k_solve_bwd_level(const int* __restrict__ lvl_sn,
+                                                         const int* __restrict__ sn_c0,
+                                                         const int* __restrict__ sn_rowptr,
+                                                         const int* __restrict__ sn_rows,
+                                                         const int64_t* __restrict__ sn_lx,
+                                                         const int* __restrict__ perm,
+                                                         const double* __restrict__ Lx,
+                                                         double* __restrict__ ywork,
+                                                         double* __restrict__ out)
+{
+  __shared__ double xs[256];
+  const int s = lvl_sn[blockIdx.x];
+  const int c0 = sn_c0[s], w = sn_c0[s+1] - c0;
+  const int nrows = sn_rowptr[s+1] - sn_rowptr[s];
+  const int* rows = sn_rows + sn_rowptr[s];
+  const double* L = Lx + sn_lx[s];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int r = nrows - w;
+  for(int j = wv; j < w; j += TPB/64)
+  {
+    const double* Lj = L + (size_t)j*nrows + w;
+    double sum = 0.0;
+    for(int i = lane; i < r; i += 64) sum += Lj[i]*ywork[rows[w + i]];
+    sum = wave_sum(sum);
+    if(lane == 0) xs[j] = ywork[c0 + j] - sum;
+  }
+  __syncthreads();
+  for(int j = w - 1; j >= 0; j--)
+  {
+    if(tid == 0) xs[j] = xs[j] / L[j + (size_t)j*nrows];
+    __syncthreads();
+    const double xj = xs[j];
+    for(int i = tid; i < j; i += TPB) xs[i] -= L[j + (size_t)i*nrows]*xj;
+    __syncthreads();
+  }
+  for(int j = tid; j < w; j += TPB) { ywork[c0 + j] = xs[j]; out[perm[c0 + j]] = xs[j]; }
+}
+
+} // namespace
+
+// ================================================================ host side ==
+int sparse_create(dlg_backend* b) { (void)b; return DLG_OK; }
+
+size_t sparse_local_nnz(const dlg_backend* b) { return b->sym ? b->sym->nnz_loc : (size_t)b->nnz; }
+
+void sparse_destroy(dlg_backend* b)
+{
+  SparseSym* Y = b->sym;
+  if(!Y) return;
+  for(void* p : Y->allocs) if(p) (void)hipFree(p);
+  if(Y->h_info) (void)hipHostFree(Y->h_info);
+  delete Y;
+  b->sym = nullptr;
+}
+
+#define UP(field) do { DLG_CHECK(upload(Y->field, H.field)); Y->allocs.push_back(Y->field); } while(0)
+
+int sparse_set_pattern(dlg_backend* b, const int* colptr, const int* rowidx)
+{
+  if(b->sym) { dlg_set_error("the sparsity pattern was already set"); return DLG_ERR_STATE; }
+  if(colptr[b->M] != b->nnz)
+  { dlg_set_error("Jt has %d entries but the backend was created for NJnnz = %d", colptr[b->M], b->nnz); return DLG_ERR_ARG; }
+  SparseSym* Y = new (std::nothrow) SparseSym();
+  if(!Y) { dlg_set_error("out of host memory"); return DLG_ERR_NOMEM; }
+  b->sym = Y;
+  char err[512];
+  if(sym_analyze(Y->H, b->N, b->M, colptr, rowidx, b->row0, b->row1, err, sizeof(err)))
+  { dlg_set_error("symbolic analysis: %s", err); return DLG_ERR_ARG; }
+  SymHost& H = Y->H;
+  UP(sn_c0); UP(sn_rowptr); UP(sn_rows); UP(sn_scr); UP(lvl_sn); UP(sn_lx); UP(diagpos);
+  UP(ui_t); UP(ui_col); UP(ui_nc); UP(ui_ptr); UP(ut_d); UP(ut_ka); UP(ut_rel); UP(relpos);
+  UP(oblk); UP(contrib); UP(asm_task); UP(jtx_task);
+  UP(asm_fin_ptr); UP(asm_fin_blk); UP(jtx_fin_ptr); UP(jtx_fin_blk);
+  UP(rl_ptr); UP(rl_pos); UP(perm);
+  // rank-local pattern for the row-wise kernels
+  {
+    const int mloc = b->row1 - b->row0;
+    const int q0 = colptr[b->row0], q1 = colptr[b->row1];
+    Y->nnz_loc = (size_t)(q1 - q0);
+    std::vector<int> jp(mloc + 1), ji(rowidx + q0, rowidx + q1);
+    for(int r = 0; r <= mloc; r++) jp[r] = colptr[b->row0 + r] - q0;
+    DLG_CHECK(upload(Y->Jp, jp)); Y->allocs.push_back(Y->Jp);
+    DLG_CHECK(upload(Y->Ji, ji)); Y->allocs.push_back(Y->Ji);
+  }
+  auto dalloc = [&](double*& p, size_t n) -> int {
+    DLG_HIP(hipMalloc(&p, sizeof(double)*(n ? n : 1))); Y->allocs.push_back(p); return DLG_OK; };
+  DLG_CHECK(dalloc(Y->Lx, (size_t)H.lx_size));
+  DLG_CHECK(dalloc(Y->scr, (size_t)H.scr_size));
+  DLG_CHECK(dalloc(Y->ywork, (size_t)H.N));
+  DLG_CHECK(dalloc(Y->asm_part, (size_t)H.asm_nparts*64));
+  DLG_CHECK(dalloc(Y->jtx_part, (size_t)H.jtx_nparts*8));
+  DLG_HIP(hipMalloc(&Y->d_info, sizeof(int))); Y->allocs.push_back(Y->d_info);
+  DLG_HIP(hipHostMalloc(&Y->h_info, sizeof(int)));
+
+  // per-level launch parameters
+  Y->fac_lds.assign(H.nlevels, 0); Y->upd_lds.assign(H.nlevels, 0); Y->upd_nw.assign(H.nlevels, 0);
+  for(int l = 0; l < H.nlevels; l++)
+  {
+    long maxp = 0;
+    for(int i = H.lvl_ptr[l]; i < H.lvl_ptr[l+1]; i++)
+    {
+      const int s = H.lvl_sn[i];
+      const long p = (long)(H.sn_rowptr[s+1] - H.sn_rowptr[s])*(H.sn_c0[s+1] - H.sn_c0[s]);
+      if(p > maxp) maxp = p;
+    }
+    Y->fac_lds[l] = (maxp*8 <= LDS_BUDGET) ? (int)(maxp*8) : 0;
+    long maxslab = 0;
+    for(int it = H.ui_lvl_ptr[l]; it < H.ui_lvl_ptr[l+1]; it++)
+    {
+      const int t = H.ui_t[it];
+      const long sl = (long)(H.sn_rowptr[t+1] - H.sn_rowptr[t])*H.ui_nc[it];
+      if(sl > maxslab) maxslab = sl;
+    }
+    int nw = 0;
+    if(maxslab > 0) { nw = (int)(LDS_BUDGET/(maxslab*8)); if(nw > 4) nw = 4; }
+    Y->upd_nw[l] = nw;
+    Y->upd_lds[l] = (int)(maxslab*8*nw);
+  }
+  DLG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_factor_level<true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BUDGET));
+  DLG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_update_level),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BUDGET));
+  return DLG_OK;
+}
+
+extern "C" int dlg_sparse_stats(dlg_backend_t* b, long* nnz_JtJ_lower, long* nnz_L, int* n_supernodes,
+                                int* n_levels, double* factor_flops)
+{
+  if(!b || !b->sym) { dlg_set_error("no symbolic analysis yet"); return DLG_ERR_STATE; }
+  const SymHost& H = b->sym->H;
+  if(nnz_JtJ_lower) *nnz_JtJ_lower = (long)H.nnz_JtJ_lower;
+  if(nnz_L) *nnz_L = (long)H.nnz_L;
+  if(n_supernodes) *n_supernodes = H.nsn;
+  if(n_levels) *n_levels = H.nlevels;
+  if(factor_flops) *factor_flops = H.factor_flops;
+  return DLG_OK;
+}
+
+// K1
+int sparse_eval(dlg_backend* b, int s)
+{
+  SparseSym* Y = b->sym;
+  if(!Y) { dlg_set_error("dlg_sparse_set_pattern must be called first"); return DLG_ERR_STATE; }
+  DlgSlot& S = b->slot[s];
+  const SymHost& H = Y->H;
+  DLG_HIP(hipMemsetAsync(S.Jt_x, 0, sizeof(double)*(size_t)b->N, b->stream));
+  const int nt = (int)H.jtx_task.size();
+  if(nt > 0)
+    hipLaunchKernelGGL(k_jtx, dim3(dlg_cdiv(nt, TPB/64)), dim3(TPB), 0, b->stream, Y->jtx_task, nt,
+                       Y->oblk, Y->contrib, S.Jin(), S.xin(), S.Jt_x, Y->jtx_part);
+  const int nf = (int)H.jtx_fin_blk.size();
+  if(nf > 0)
+    hipLaunchKernelGGL(k_jtx_fin, dim3(dlg_cdiv((long)nf*8, TPB)), dim3(TPB), 0, b->stream,
+                       Y->jtx_fin_ptr, Y->jtx_fin_blk, nf, Y->oblk, Y->jtx_part, S.Jt_x);
+  DLG_LAUNCH_CHECK();
+  return DLG_OK;
+}
+
+// K3 / K8
+int sparse_norm2_Jv(dlg_backend* b, int s, const double* v, double* out_dev)
+{
+  SparseSym* Y = b->sym;
+  if(!Y) { dlg_set_error("dlg_sparse_set_pattern must be called first"); return DLG_ERR_STATE; }
+  DlgSlot& S = b->slot[s];
+  const int mloc = dlg_mloc(b);
+  int g = dlg_cdiv(mloc, TPB); if(g > 2048) g = 2048; if(g < 1) g = 1;
+  DLG_CHECK(dlg_ensure_partials(b, 8192));
+  double* part = b->d_part + 4096;
+  hipLaunchKernelGGL(k_norm2_Jv, dim3(g), dim3(TPB), 0, b->stream, Y->Jp, Y->Ji, S.Jin(), v, mloc, part);
+  DLG_LAUNCH_CHECK();
+  return k_reduce_sum(b, part, g, out_dev);
+}
+
+// K4 + K5
+int sparse_factorize(dlg_backend* b, int s, double lambda, int* ok)
+{
+  SparseSym* Y = b->sym;
+  if(!Y) { dlg_set_error("dlg_sparse_set_pattern must be called first"); return DLG_ERR_STATE; }
+  DlgSlot& S = b->slot[s];
+  const SymHost& H = Y->H;
+  hipStream_t st = b->stream;
+  // --- K4: JtJ straight into the supernode panels
+  DLG_HIP(hipMemsetAsync(Y->Lx, 0, sizeof(double)*(size_t)H.lx_size, st));
+  const int nt = (int)H.asm_task.size();
+  if(nt > 0)
+    hipLaunchKernelGGL(k_assemble, dim3(dlg_cdiv(nt, TPB/64)), dim3(TPB), 0, st, Y->asm_task, nt,
+                       Y->oblk, Y->contrib, S.Jin(), Y->Lx, Y->asm_part);
+  const int nf = (int)H.asm_fin_blk.size();
+  if(nf > 0)
+    hipLaunchKernelGGL(k_assemble_fin, dim3(dlg_cdiv(nf, TPB/64)), dim3(TPB), 0, st, Y->asm_fin_ptr,
+                       Y->asm_fin_blk, nf, Y->oblk, Y->asm_part, Y->Lx);
+  DLG_LAUNCH_CHECK();
+  // rows are sharded: sum the partial JtJ of all ranks before factorising
+  DLG_CHECK(dlg_allreduce_dev(b, Y->Lx, (size_t)H.lx_size));
+  if(lambda != 0.0)
+    hipLaunchKernelGGL(k_add_lambda, dim3(dlg_cdiv(H.N, TPB)), dim3(TPB), 0, st, Y->Lx, Y->diagpos, H.N,
+                       lambda);
+  // --- K5: level-scheduled supernodal Cholesky
+  *Y->h_info = 0x7fffffff;
+  DLG_HIP(hipMemcpyAsync(Y->d_info, Y->h_info, sizeof(int), hipMemcpyHostToDevice, st));
+  for(int l = 0; l < H.nlevels; l++)
+  {
+    const int n = H.lvl_ptr[l+1] - H.lvl_ptr[l];
+    if(n > 0)
+    {
+      if(Y->fac_lds[l] > 0)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_factor_level<true>), dim3(n), dim3(TPB), Y->fac_lds[l], st,
+                           Y->lvl_sn + H.lvl_ptr[l], Y->sn_c0, Y->sn_rowptr, Y->sn_lx, Y->Lx, Y->d_info);
+      else
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_factor_level<false>), dim3(n), dim3(TPB), 0, st,
+                           Y->lvl_sn + H.lvl_ptr[l], Y->sn_c0, Y->sn_rowptr, Y->sn_lx, Y->Lx, Y->d_info);
+    }
+    const int ni = H.ui_lvl_ptr[l+1] - H.ui_lvl_ptr[l];
+    if(ni > 0)
+      hipLaunchKernelGGL(k_update_level, dim3(ni), dim3(TPB), Y->upd_lds[l], st, H.ui_lvl_ptr[l],
+                         Y->ui_t, Y->ui_col, Y->ui_nc, Y->ui_ptr, Y->ut_d, Y->ut_ka, Y->ut_rel,
+                         Y->relpos, Y->sn_c0, Y->sn_rowptr, Y->sn_lx, Y->Lx, Y->upd_nw[l]);
+  }
+  DLG_LAUNCH_CHECK();
+  DLG_HIP(hipMemcpyAsync(Y->h_info, Y->d_info, sizeof(int), hipMemcpyDeviceToHost, st));
+  DLG_HIP(hipStreamSynchronize(st));
+  *ok = (*Y->h_info == 0x7fffffff);
+  return DLG_OK;
+}
+
+// K6: out = (L L')^-1 rhs in the original variable order
+int sparse_solve(dlg_backend* b, const double* rhs, double* out)
+{
+  SparseSym* Y = b->sym;
+  if(!Y) { dlg_set_error("dlg_sparse_set_pattern must be called first"); return DLG_ERR_STATE; }
+  const SymHost& H = Y->H;
+  hipStream_t st = b->stream;
+  for(int l = 0; l < H.nlevels; l++)
+  {
+    const int n = H.lvl_ptr[l+1] - H.lvl_ptr[l];
+    if(n > 0)
+      hipLaunchKernelGGL(k_solve_fwd_level, dim3(n), dim3(TPB), 0, st, Y->lvl_sn + H.lvl_ptr[l],
+                         Y->sn_c0, Y->sn_rowptr, Y->sn_lx, Y->sn_scr, Y->rl_ptr, Y->rl_pos, Y->perm,
+                         Y->Lx, rhs, Y->scr, Y->ywork);
+  }
+  for(int l = H.nlevels - 1; l >= 0; l--)
+  {
+    const int n = H.lvl_ptr[l+1] - H.lvl_ptr[l];
+    if(n > 0)
+      hipLaunchKernelGGL(k_solve_bwd_level, dim3(n), dim3(TPB), 0, st, Y->lvl_sn + H.lvl_ptr[l],
+                         Y->sn_c0, Y->sn_rowptr, Y->sn_rows, Y->sn_lx, Y->perm, Y->Lx, Y->ywork, out);
+  }
+  DLG_LAUNCH_CHECK();
+  return DLG_OK;
+}
+
+// host-only: run the symbolic phase on a pattern and report its statistics
+// (no GPU needed; used by the CPU test-suite and by tools/)
+extern "C" int dlg_sparse_symbolic_probe(int N, int M, const int* colptr, const int* rowidx, int row0,
+                                         int row1, long* stats, int nstats, int* perm_out)
+{
+  SymHost H;
+  char err[512];
+  if(sym_analyze(H, N, M, colptr, rowidx, row0, row1, err, sizeof(err)))
+  { dlg_set_error("symbolic analysis: %s", err); return DLG_ERR_ARG; }
+  const long v[] = { (long)H.nvb, (long)H.nsn, (long)H.nlevels, (long)H.nnz_JtJ_lower, (long)H.nnz_L,
+                     (long)H.lx_size, (long)H.factor_flops, (long)H.max_panel, (long)H.asm_task.size(),
+                     (long)H.ui_t.size(), (long)H.relpos.size(), (long)H.oblk.size(),
+                     (long)H.contrib.size(), (long)H.ut_d.size(), (long)H.scr_size,
+                     (long)H.jtx_task.size() };
+  for(int i = 0; i < nstats && i < (int)(sizeof(v)/sizeof(v[0])); i++) stats[i] = v[i];
+  if(perm_out) memcpy(perm_out, H.perm.data(), sizeof(int)*(size_t)N);
+  return DLG_OK;
+}

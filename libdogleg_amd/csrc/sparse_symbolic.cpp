@@ -1,0 +1,742 @@
+// sparse_symbolic.cpp -- see sparse_symbolic.h.  Pure host code (no HIP).
+#include "sparse_symbolic.h"
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <cmath>
+#include <numeric>
+#include <queue>
+
+namespace {
+
+constexpr int VB_MAX   = 8;       // max variables per var-block (<= 64 lanes per 8x8 output block)
+constexpr int RB_MAX   = 8;       // max rows per row-block
+constexpr int CH_ASM   = 64;      // contributions per assembly wave-task
+constexpr int CH_JTX   = 512;     // contributions per Jt*x wave-task
+constexpr int PANEL_CAP = 16384;  // doubles: supernode panels up to this size are factored in LDS
+constexpr int SN_WMAX  = 256;     // max supernode width
+
+int env_int(const char* name, int dflt)
+{
+  const char* s = getenv(name);
+  return (s && *s) ? atoi(s) : dflt;
+}
+
+struct RowBlock { int r0, nrows, len, base, vptr, nvb; bool local; };
+
+// ------------------------------------------------------------------ graph ---
+struct Graph
+{
+  int n = 0;
+  std::vector<int> ptr, adj;      // CSR, no self loops, sorted
+  std::vector<int> w;             // node weights (variables per block)
+  std::vector<long> wdeg;         // weighted degree
+};
+
+// ---------------------------------------------------- nested dissection -----
+struct Orderer
+{
+  const Graph& G;
+  std::vector<char> removed;      // dense nodes and already-ordered separators
+  std::vector<int>  mark;         // generic stamp array
+  int stamp = 0;
+  std::vector<int>  out;          // resulting order (node ids)
+  int leaf_w;
+
+  explicit Orderer(const Graph& g) : G(g), removed(g.n, 0), mark(g.n, 0)
+  { leaf_w = env_int("DOGLEG_AMD_ND_LEAF", 1500); }
+
+  // BFS over `in_set`-stamped nodes from root; fills levels; returns eccentricity
+  int bfs(int root, int setstamp, std::vector<int>& order, std::vector<int>& lvl_start,
+          std::vector<int>& dist)
+  {
+    order.clear(); lvl_start.clear();
+    ++stamp;
+    const int visited = stamp;
+    order.push_back(root); vis[root] = visited; dist[root] = 0;
+    lvl_start.push_back(0);
+    size_t head = 0;
+    int cur = 0;
+    while(head < order.size())
+    {
+      const int u = order[head];
+      if(dist[u] != cur) { cur = dist[u]; lvl_start.push_back((int)head); }
+      head++;
+      for(int e = G.ptr[u]; e < G.ptr[u+1]; e++)
+      {
+        const int v = G.adj[e];
+        if(inset[v] != setstamp || vis[v] == visited) continue;
+        vis[v] = visited; dist[v] = dist[u] + 1; order.push_back(v);
+      }
+    }
+    lvl_start.push_back((int)order.size());
+    return cur;
+  }
+  std::vector<int> inset, vis;
+
+  // exact minimum degree on a small induced subgraph (leaf of the dissection)
+  void order_leaf(const std::vector<int>& nodes)
+  {
+    const int n = (int)nodes.size();
+    if(n > 4000)
+    {
+      std::vector<int> s(nodes);
+      std::sort(s.begin(), s.end(), [&](int a, int b) {
+        if(G.wdeg[a] != G.wdeg[b]) return G.wdeg[a] < G.wdeg[b];
+        return a < b; });
+      out.insert(out.end(), s.begin(), s.end());
+      return;
+    }
+    // local ids
+    ++stamp;
+    std::vector<int> lid_of;           // via mark: store local id in a side map
+    static thread_local std::vector<int> loc;
+    if((int)loc.size() < G.n) loc.assign(G.n, -1);
+    for(int i = 0; i < n; i++) loc[nodes[i]] = i;
+    std::vector<std::vector<int>> adj(n);
+    std::vector<long> ext(n, 0);       // weight of neighbours outside the leaf (static)
+    for(int i = 0; i < n; i++)
+    {
+      const int u = nodes[i];
+      for(int e = G.ptr[u]; e < G.ptr[u+1]; e++)
+      {
+        const int v = G.adj[e];
+        if(loc[v] >= 0 && inset[v] == inset[u] && loc[v] < n && nodes[loc[v]] == v) adj[i].push_back(loc[v]);
+        else ext[i] += G.w[v];
+      }
+      std::sort(adj[i].begin(), adj[i].end());
+    }
+    std::vector<char> gone(n, 0);
+    std::vector<long> deg(n);
+    auto wdeg = [&](int i) { long d = ext[i]; for(int v : adj[i]) d += G.w[nodes[v]]; return d; };
+    for(int i = 0; i < n; i++) deg[i] = wdeg(i);
+    std::vector<int> tmp;
+    for(int it = 0; it < n; it++)
+    {
+      int best = -1;
+      for(int i = 0; i < n; i++)
+        if(!gone[i] && (best < 0 || deg[i] < deg[best] || (deg[i] == deg[best] && nodes[i] < nodes[best]))) best = i;
+      gone[best] = 1;
+      out.push_back(nodes[best]);
+      // neighbours of best become a clique
+      const std::vector<int>& nb = adj[best];
+      for(int v : nb)
+      {
+        tmp.clear();
+        std::set_union(adj[v].begin(), adj[v].end(), nb.begin(), nb.end(), std::back_inserter(tmp));
+        // drop v itself and best
+        std::vector<int> nv; nv.reserve(tmp.size());
+        for(int x : tmp) if(x != v && x != best) nv.push_back(x);
+        adj[v].swap(nv);
+      }
+      // the eliminated node's external weight is inherited by its neighbours' fill only
+      for(int v : nb) deg[v] = wdeg(v);
+      adj[best].clear();
+    }
+    for(int i = 0; i < n; i++) loc[nodes[i]] = -1;
+  }
+
+  void run(const std::vector<int>& all_nodes)
+  {
+    inset.assign(G.n, 0); vis.assign(G.n, 0);
+    std::vector<int> dist(G.n, 0);
+    int setctr = 0;
+    // explicit stack of node sets; a frame with `sep` set flushes a separator
+    struct Frame { std::vector<int> nodes; bool is_sep; };
+    std::vector<Frame> stack;
+    stack.push_back({all_nodes, false});
+    std::vector<int> order, lvl_start, comp;
+    while(!stack.empty())
+    {
+      Frame f = std::move(stack.back());
+      stack.pop_back();
+      if(f.is_sep) { out.insert(out.end(), f.nodes.begin(), f.nodes.end()); continue; }
+      if(f.nodes.empty()) continue;
+      // stamp the set
+      const int setstamp = ++setctr;
+      for(int u : f.nodes) inset[u] = setstamp;
+      // split into connected components; process each
+      std::vector<std::vector<int>> comps;
+      ++stamp;
+      const int cstamp = stamp;
+      for(int u : f.nodes)
+      {
+        if(vis[u] == cstamp) continue;
+        comp.clear(); comp.push_back(u); vis[u] = cstamp;
+        for(size_t h = 0; h < comp.size(); h++)
+        {
+          const int a = comp[h];
+          for(int e = G.ptr[a]; e < G.ptr[a+1]; e++)
+          {
+            const int v = G.adj[e];
+            if(inset[v] == setstamp && vis[v] != cstamp) { vis[v] = cstamp; comp.push_back(v); }
+          }
+        }
+        comps.push_back(comp);
+      }
+      if(comps.size() > 1)
+      {
+        // push in reverse so that the first component is ordered first
+        for(size_t c = comps.size(); c-- > 0;) stack.push_back({std::move(comps[c]), false});
+        continue;
+      }
+      std::vector<int>& nodes = comps[0];
+      long wt = 0; for(int u : nodes) wt += G.w[u];
+      if(wt <= leaf_w || nodes.size() <= 3) { std::sort(nodes.begin(), nodes.end()); order_leaf(nodes); continue; }
+      // pseudo-peripheral root: a few BFS sweeps from the min-degree node
+      int root = nodes[0];
+      for(int u : nodes) if(G.wdeg[u] < G.wdeg[root] || (G.wdeg[u] == G.wdeg[root] && u < root)) root = u;
+      int ecc = bfs(root, setstamp, order, lvl_start, dist);
+      for(int sweep = 0; sweep < 3; sweep++)
+      {
+        // candidate: min-degree node of the last level
+        const int nl = (int)lvl_start.size() - 1;
+        int cand = order[lvl_start[nl-1]];
+        for(int i = lvl_start[nl-1]; i < lvl_start[nl]; i++)
+          if(G.wdeg[order[i]] < G.wdeg[cand]) cand = order[i];
+        std::vector<int> o2, l2;
+        const int e2 = bfs(cand, setstamp, o2, l2, dist);
+        if(e2 > ecc) { ecc = e2; root = cand; order.swap(o2); lvl_start.swap(l2); }
+        else { bfs(root, setstamp, order, lvl_start, dist); break; }
+      }
+      const int nl = (int)lvl_start.size() - 1;
+      if(nl < 3) { std::sort(nodes.begin(), nodes.end()); order_leaf(nodes); continue; }
+      // level weights, choose the lightest level whose prefix weight is within [0.3,0.7]
+      std::vector<long> lw(nl, 0);
+      for(int l = 0; l < nl; l++) for(int i = lvl_start[l]; i < lvl_start[l+1]; i++) lw[l] += G.w[order[i]];
+      long pre = 0; int best = -1; double bestscore = 0;
+      for(int l = 0; l < nl; l++)
+      {
+        const double before = (double)pre/(double)wt, after = (double)(wt - pre - lw[l])/(double)wt;
+        pre += lw[l];
+        if(l == 0 || l == nl-1) continue;
+        if(before < 0.25 || after < 0.25) continue;
+        // score: small separators first, balance as tie-break
+        const double score = (double)lw[l]*(1.0 + 0.5*fabs(before - after));
+        if(best < 0 || score < bestscore) { best = l; bestscore = score; }
+      }
+      if(best < 0)
+      {
+        // no balanced level: take the middle one by weight
+        pre = 0;
+        for(int l = 0; l < nl; l++) { pre += lw[l]; if(2*pre >= wt) { best = l; break; } }
+        if(best <= 0) best = 1;
+        if(best >= nl-1) best = nl-2;
+      }
+      std::vector<int> A(order.begin(), order.begin() + lvl_start[best]);
+      std::vector<int> Sp(order.begin() + lvl_start[best], order.begin() + lvl_start[best+1]);
+      std::vector<int> B(order.begin() + lvl_start[best+1], order.end());
+      if(A.empty() || B.empty()) { std::sort(nodes.begin(), nodes.end()); order_leaf(nodes); continue; }
+      std::sort(Sp.begin(), Sp.end());
+      // order: A ..., B ..., then the separator (stack is LIFO)
+      stack.push_back({std::move(Sp), true});
+      stack.push_back({std::move(B), false});
+      stack.push_back({std::move(A), false});
+    }
+  }
+};
+
+} // namespace
+
+#define SYM_FAIL(...) do { snprintf(err, errlen, __VA_ARGS__); return 1; } while(0)
+
+int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0, int row1,
+                char* err, int errlen)
+{
+  S = SymHost();
+  S.N = N; S.M = M; S.nnz = cp[M]; S.row0 = row0; S.row1 = row1;
+  if(cp[0] != 0) SYM_FAIL("Jt column pointers must start at 0");
+
+  // ---------------------------------------------------------- 1. var-blocks
+  std::vector<char> cut(N + 1, 0);
+  cut[0] = cut[N] = 1;
+  for(int r = 0; r < M; r++)
+  {
+    const int a = cp[r], b = cp[r+1];
+    if(b < a) SYM_FAIL("Jt column pointers must be non-decreasing (row %d)", r);
+    if(b - a > 65535) SYM_FAIL("measurement row %d has %d non-zeros; at most 65535 are supported", r, b - a);
+    for(int q = a; q < b; q++)
+    {
+      const int i = ri[q];
+      if(i < 0 || i >= N) SYM_FAIL("row index %d out of range in measurement %d", i, r);
+      if(q > a && ri[q-1] >= i) SYM_FAIL("row indices of measurement %d are not strictly ascending", r);
+      if(q == a   || ri[q-1] != i-1) cut[i] = 1;
+      if(q == b-1 || ri[q+1] != i+1) cut[i+1] = 1;
+    }
+  }
+  std::vector<int> vb_of(N);
+  {
+    int start = 0;
+    for(int j = 1; j <= N; j++)
+      if(cut[j] || j - start == VB_MAX) { cut[j] = 1; start = j; }
+    S.vb_start.clear();
+    for(int j = 0; j <= N; j++) if(cut[j]) S.vb_start.push_back(j);
+    S.nvb = (int)S.vb_start.size() - 1;
+    for(int v = 0; v < S.nvb; v++) for(int j = S.vb_start[v]; j < S.vb_start[v+1]; j++) vb_of[j] = v;
+  }
+  const int nvb = S.nvb;
+  auto vbw = [&](int v) { return S.vb_start[v+1] - S.vb_start[v]; };
+
+  // ---------------------------------------------------------- 2. row-blocks
+  std::vector<RowBlock> rbs;
+  std::vector<int> rb_vb, rb_off;
+  {
+    int cur = -1;
+    for(int r = 0; r < M; r++)
+    {
+      const int len = cp[r+1] - cp[r];
+      if(len == 0) { cur = -1; continue; }
+      bool fresh = (cur < 0) || r == row0 || r == row1;
+      if(!fresh)
+      {
+        const RowBlock& b = rbs[cur];
+        if(b.len != len || b.nrows == RB_MAX || b.r0 + b.nrows != r ||
+           memcmp(&ri[b.base], &ri[cp[r]], sizeof(int)*(size_t)len) != 0) fresh = true;
+      }
+      if(fresh)
+      {
+        RowBlock b; b.r0 = r; b.nrows = 1; b.len = len; b.base = cp[r]; b.vptr = (int)rb_vb.size();
+        b.local = (r >= row0 && r < row1);
+        int e = 0;
+        while(e < len)
+        {
+          const int v = vb_of[ri[b.base + e]];
+          rb_vb.push_back(v); rb_off.push_back(e);
+          e += S.vb_start[v+1] - ri[b.base + e];     // remainder of the block from this entry
+        }
+        b.nvb = (int)rb_vb.size() - b.vptr;
+        rbs.push_back(b);
+        cur = (int)rbs.size() - 1;
+      }
+      else rbs[cur].nrows++;
+    }
+  }
+  const int nrb = (int)rbs.size();
+
+  // ------------------------------------------------ 3. block graph of JtJ
+  Graph G; G.n = nvb; G.w.resize(nvb);
+  for(int v = 0; v < nvb; v++) G.w[v] = vbw(v);
+  {
+    // inverted index vb -> row-blocks; skip row-blocks with a pattern identical to the previous one
+    std::vector<int> cnt(nvb + 1, 0);
+    std::vector<char> dup(nrb, 0);
+    for(int b = 1; b < nrb; b++)
+      if(rbs[b].nvb == rbs[b-1].nvb &&
+         memcmp(&rb_vb[rbs[b].vptr], &rb_vb[rbs[b-1].vptr], sizeof(int)*(size_t)rbs[b].nvb) == 0) dup[b] = 1;
+    for(int b = 0; b < nrb; b++) if(!dup[b]) for(int k = 0; k < rbs[b].nvb; k++) cnt[rb_vb[rbs[b].vptr + k] + 1]++;
+    for(int v = 0; v < nvb; v++) cnt[v+1] += cnt[v];
+    std::vector<int> inv(cnt[nvb]), nxt(cnt.begin(), cnt.end() - 1);
+    for(int b = 0; b < nrb; b++) if(!dup[b]) for(int k = 0; k < rbs[b].nvb; k++) inv[nxt[rb_vb[rbs[b].vptr + k]]++] = b;
+    std::vector<int> mark(nvb, -1);
+    G.ptr.assign(nvb + 1, 0);
+    std::vector<int> tmp;
+    for(int v = 0; v < nvb; v++)
+    {
+      tmp.clear();
+      mark[v] = v;
+      for(int a = cnt[v]; a < cnt[v+1]; a++)
+      {
+        const RowBlock& b = rbs[inv[a]];
+        for(int k = 0; k < b.nvb; k++)
+        {
+          const int u = rb_vb[b.vptr + k];
+          if(mark[u] != v) { mark[u] = v; tmp.push_back(u); }
+        }
+      }
+      std::sort(tmp.begin(), tmp.end());
+      G.adj.insert(G.adj.end(), tmp.begin(), tmp.end());
+      G.ptr[v+1] = (int)G.adj.size();
+    }
+    G.wdeg.assign(nvb, 0);
+    for(int v = 0; v < nvb; v++) for(int e = G.ptr[v]; e < G.ptr[v+1]; e++) G.wdeg[v] += G.w[G.adj[e]];
+  }
+  // nnz(tril JtJ)
+  S.nnz_JtJ_lower = 0;
+  for(int v = 0; v < nvb; v++)
+  {
+    const long w = G.w[v];
+    S.nnz_JtJ_lower += w*(w+1)/2;
+    for(int e = G.ptr[v]; e < G.ptr[v+1]; e++) if(G.adj[e] > v) S.nnz_JtJ_lower += w*G.w[G.adj[e]];
+  }
+
+  // ------------------------------------------------------------ 4. ordering
+  std::vector<int> border;            // position -> vb
+  {
+    const double dense_thr = std::max(16.0, 10.0*sqrt((double)N));
+    std::vector<int> sparse_nodes, dense_nodes;
+    Graph H;                           // graph without dense nodes
+    std::vector<char> is_dense(nvb, 0);
+    for(int v = 0; v < nvb; v++) if((double)G.wdeg[v] > dense_thr && nvb > 8) is_dense[v] = 1;
+    for(int v = 0; v < nvb; v++) (is_dense[v] ? dense_nodes : sparse_nodes).push_back(v);
+    H.n = nvb; H.w = G.w; H.ptr.assign(nvb + 1, 0);
+    for(int v = 0; v < nvb; v++)
+    {
+      if(!is_dense[v]) for(int e = G.ptr[v]; e < G.ptr[v+1]; e++) if(!is_dense[G.adj[e]]) H.adj.push_back(G.adj[e]);
+      H.ptr[v+1] = (int)H.adj.size();
+    }
+    H.wdeg = G.wdeg;
+    Orderer O(H);
+    O.run(sparse_nodes);
+    border = O.out;
+    // dense nodes last, lightest first
+    std::sort(dense_nodes.begin(), dense_nodes.end(), [&](int a, int b) {
+      if(G.wdeg[a] != G.wdeg[b]) return G.wdeg[a] < G.wdeg[b];
+      return a < b; });
+    border.insert(border.end(), dense_nodes.begin(), dense_nodes.end());
+    if((int)border.size() != nvb) SYM_FAIL("internal error: ordering lost blocks (%zu of %d)", border.size(), nvb);
+  }
+  std::vector<int> bpos(nvb);
+  for(int k = 0; k < nvb; k++) bpos[border[k]] = k;
+
+  // --------------------------------- 5. block-level symbolic factorisation
+  std::vector<std::vector<int>> st(nvb);   // struct of block column (positions > j), sorted
+  std::vector<int> parent(nvb, -1);
+  {
+    std::vector<int> head(nvb, -1), next(nvb, -1), mark(nvb, -1);
+    std::vector<int> tmp;
+    for(int j = 0; j < nvb; j++)
+    {
+      tmp.clear();
+      mark[j] = j;
+      const int v = border[j];
+      for(int e = G.ptr[v]; e < G.ptr[v+1]; e++)
+      {
+        const int q = bpos[G.adj[e]];
+        if(q > j && mark[q] != j) { mark[q] = j; tmp.push_back(q); }
+      }
+      for(int c = head[j]; c >= 0; c = next[c])
+      {
+        for(int q : st[c]) if(q > j && mark[q] != j) { mark[q] = j; tmp.push_back(q); }
+      }
+      std::sort(tmp.begin(), tmp.end());
+      st[j] = tmp;
+      if(!tmp.empty()) { parent[j] = tmp[0]; next[j] = head[tmp[0]]; head[tmp[0]] = j; }
+    }
+  }
+  std::vector<long> stw(nvb, 0);          // scalar weight of struct
+  for(int j = 0; j < nvb; j++) for(int q : st[j]) stw[j] += G.w[border[q]];
+  S.nnz_L = 0; S.factor_flops = 0;
+  for(int j = 0; j < nvb; j++)
+  {
+    const long w = G.w[border[j]];
+    S.nnz_L += w*(w+1)/2 + w*stw[j];
+    for(long a = 0; a < w; a++) { const double c = (double)(w - a + stw[j]); S.factor_flops += c*c; }
+  }
+
+  // ------------------------------------------------------- 6. supernodes
+  std::vector<int> sn_b0;                 // first block position of each supernode (+ sentinel)
+  {
+    const int relax = env_int("DOGLEG_AMD_RELAX_PCT", 25);
+    int a = 0;
+    long W = G.w[border[0]];              // current width
+    long true_nnz = W*stw[0];             // sum_j w_j * |struct_j| (scalar) for columns in the supernode
+    long below_own = 0;                   // helper: sum_j w_j * (own cols after j)
+    sn_b0.push_back(0);
+    for(int j = 0; j + 1 <= nvb; j++)
+    {
+      bool merge = false;
+      if(j + 1 < nvb && parent[j] == j + 1)
+      {
+        const long w1 = G.w[border[j+1]];
+        const long Wn = W + w1, Rn = stw[j+1];
+        // zeros in the rectangular-below + trapezoid-own storage if merged
+        const long tn = true_nnz + w1*stw[j+1];
+        // stored (excluding the dense diagonal block): every column holds Rn below rows + own cols after it
+        long own_after = below_own + W*w1;    // each existing column gains w1 own rows after it
+        const long stored = Wn*Rn + own_after;
+        const long zeros = stored - tn;
+        const bool exact = (st[j].size() == st[j+1].size() + 1);
+        const bool fits = ((Wn + Rn)*Wn <= PANEL_CAP) && Wn <= SN_WMAX;
+        if(fits && (exact || Wn <= 16 || zeros*100 <= (long)relax*(stored + Wn*Wn)))
+        {
+          merge = true;
+          W = Wn; true_nnz = tn; below_own = own_after;
+        }
+      }
+      if(!merge && j + 1 < nvb)
+      {
+        a = j + 1; sn_b0.push_back(a);
+        W = G.w[border[a]]; true_nnz = W*stw[a]; below_own = 0;
+      }
+    }
+    sn_b0.push_back(nvb);
+  }
+  S.nsn = (int)sn_b0.size() - 1;
+  const int nsn = S.nsn;
+
+  // ------------------------------------------- 7. scalar-level layout
+  std::vector<int> colstart(nvb + 1, 0);  // scalar position of block position
+  for(int k = 0; k < nvb; k++) colstart[k+1] = colstart[k] + G.w[border[k]];
+  S.perm.resize(N); S.iperm.resize(N);
+  for(int k = 0; k < nvb; k++)
+    for(int a = 0; a < G.w[border[k]]; a++)
+    { S.perm[colstart[k] + a] = S.vb_start[border[k]] + a; S.iperm[S.vb_start[border[k]] + a] = colstart[k] + a; }
+  std::vector<int> sn_of_b(nvb);
+  S.sn_c0.resize(nsn + 1); S.sn_rowptr.assign(nsn + 1, 0); S.sn_lx.assign(nsn + 1, 0); S.sn_scr.assign(nsn + 1, 0);
+  // block-level below structure of a supernode = struct of its last block column
+  auto sn_last = [&](int s) { return sn_b0[s+1] - 1; };
+  for(int s = 0; s < nsn; s++)
+  {
+    for(int k = sn_b0[s]; k < sn_b0[s+1]; k++) sn_of_b[k] = s;
+    S.sn_c0[s] = colstart[sn_b0[s]];
+  }
+  S.sn_c0[nsn] = N;
+  S.max_panel = 0;
+  for(int s = 0; s < nsn; s++)
+  {
+    const int w = S.sn_c0[s+1] - S.sn_c0[s];
+    const long r = stw[sn_last(s)];
+    const long nrows = w + r;
+    S.sn_rowptr[s+1] = S.sn_rowptr[s] + (int)nrows;
+    S.sn_lx[s+1] = S.sn_lx[s] + nrows*(long)w;
+    S.sn_scr[s+1] = S.sn_scr[s] + (int)r;
+    if(nrows*w > S.max_panel) S.max_panel = (int)(nrows*w);
+  }
+  S.lx_size = S.sn_lx[nsn]; S.scr_size = S.sn_scr[nsn];
+  S.sn_rows.resize(S.sn_rowptr[nsn]);
+  // per supernode: block-level row offsets of the below blocks (for lookups)
+  std::vector<int> belowoff_ptr(nsn + 1, 0);
+  for(int s = 0; s < nsn; s++) belowoff_ptr[s+1] = belowoff_ptr[s] + (int)st[sn_last(s)].size();
+  std::vector<int> belowoff(belowoff_ptr[nsn]);
+  for(int s = 0; s < nsn; s++)
+  {
+    int* rows = &S.sn_rows[S.sn_rowptr[s]];
+    const int w = S.sn_c0[s+1] - S.sn_c0[s];
+    int k = 0;
+    for(; k < w; k++) rows[k] = S.sn_c0[s] + k;
+    int bi = belowoff_ptr[s];
+    for(int q : st[sn_last(s)])
+    {
+      belowoff[bi++] = k;
+      for(int a = 0; a < G.w[border[q]]; a++) rows[k++] = colstart[q] + a;
+    }
+  }
+  S.diagpos.resize(N);
+  for(int s = 0; s < nsn; s++)
+  {
+    const int w = S.sn_c0[s+1] - S.sn_c0[s];
+    const long ld = S.sn_rowptr[s+1] - S.sn_rowptr[s];
+    for(int c = 0; c < w; c++) S.diagpos[S.sn_c0[s] + c] = S.sn_lx[s] + c + c*ld;
+  }
+  // row offset of block position q inside supernode t's row list (-1 if absent)
+  auto rowoff_in = [&](int t, int q) -> int {
+    if(q >= sn_b0[t] && q < sn_b0[t+1]) return colstart[q] - S.sn_c0[t];
+    const std::vector<int>& bl = st[sn_last(t)];
+    auto it = std::lower_bound(bl.begin(), bl.end(), q);
+    if(it == bl.end() || *it != q) return -1;
+    return belowoff[belowoff_ptr[t] + (int)(it - bl.begin())];
+  };
+
+  // levels
+  S.sn_level.assign(nsn, 0);
+  for(int s = 0; s < nsn; s++)
+  {
+    const std::vector<int>& bl = st[sn_last(s)];
+    if(bl.empty()) continue;
+    const int p = sn_of_b[bl[0]];
+    if(S.sn_level[p] < S.sn_level[s] + 1) S.sn_level[p] = S.sn_level[s] + 1;
+  }
+  S.nlevels = 0;
+  for(int s = 0; s < nsn; s++) S.nlevels = std::max(S.nlevels, S.sn_level[s] + 1);
+  S.lvl_ptr.assign(S.nlevels + 1, 0);
+  for(int s = 0; s < nsn; s++) S.lvl_ptr[S.sn_level[s] + 1]++;
+  for(int l = 0; l < S.nlevels; l++) S.lvl_ptr[l+1] += S.lvl_ptr[l];
+  S.lvl_sn.resize(nsn);
+  {
+    std::vector<int> nx(S.lvl_ptr.begin(), S.lvl_ptr.end() - 1);
+    for(int s = 0; s < nsn; s++) S.lvl_sn[nx[S.sn_level[s]]++] = s;
+  }
+
+  // ------------------------------------ 8. factor update schedule
+  {
+    struct Sub { int lvl, t, q, d, ka, rel; };
+    std::vector<Sub> subs;
+    for(int d = 0; d < nsn; d++)
+    {
+      const std::vector<int>& bl = st[sn_last(d)];
+      if(bl.empty()) continue;
+      const int wd = S.sn_c0[d+1] - S.sn_c0[d];
+      const int nrows_d = S.sn_rowptr[d+1] - S.sn_rowptr[d];
+      size_t i = 0;
+      int krow = wd;                       // row index in d of block bl[i]
+      while(i < bl.size())
+      {
+        const int t = sn_of_b[bl[i]];
+        const int k0 = krow;
+        const int relbase = (int)S.relpos.size();
+        // positions of rows k0.. of d inside t: walk the remaining blocks
+        {
+          const std::vector<int>& tl = st[sn_last(t)];
+          size_t tp = 0;
+          for(size_t ii = i; ii < bl.size(); ii++)
+          {
+            const int q = bl[ii];
+            int off;
+            if(q >= sn_b0[t] && q < sn_b0[t+1]) off = colstart[q] - S.sn_c0[t];
+            else
+            {
+              while(tp < tl.size() && tl[tp] < q) tp++;
+              if(tp >= tl.size() || tl[tp] != q)
+                SYM_FAIL("internal error: structure of supernode %d not nested in ancestor %d", d, t);
+              off = belowoff[belowoff_ptr[t] + (int)tp];
+            }
+            for(int a = 0; a < G.w[border[q]]; a++) S.relpos.push_back(off + a);
+          }
+        }
+        if((int)S.relpos.size() - relbase != nrows_d - k0) SYM_FAIL("internal error: relpos size mismatch");
+        // one sub-task per target var-block
+        while(i < bl.size() && sn_of_b[bl[i]] == t)
+        {
+          subs.push_back({S.sn_level[d], t, bl[i], d, krow, relbase + (krow - k0)});
+          krow += G.w[border[bl[i]]];
+          i++;
+        }
+      }
+    }
+    std::sort(subs.begin(), subs.end(), [](const Sub& a, const Sub& b) {
+      if(a.lvl != b.lvl) return a.lvl < b.lvl;
+      if(a.t != b.t) return a.t < b.t;
+      if(a.q != b.q) return a.q < b.q;
+      return a.d < b.d; });
+    S.ui_lvl_ptr.assign(S.nlevels + 1, 0);
+    S.ui_ptr.push_back(0);
+    for(size_t i = 0; i < subs.size(); i++)
+    {
+      const Sub& u = subs[i];
+      const bool newitem = (i == 0) || subs[i-1].lvl != u.lvl || subs[i-1].t != u.t || subs[i-1].q != u.q;
+      if(newitem)
+      {
+        if(i != 0) S.ui_ptr.push_back((int)i);
+        S.ui_t.push_back(u.t);
+        S.ui_col.push_back(colstart[u.q] - S.sn_c0[u.t]);
+        S.ui_nc.push_back(G.w[border[u.q]]);
+        S.ui_lvl_ptr[u.lvl + 1]++;
+      }
+      S.ut_d.push_back(u.d); S.ut_ka.push_back(u.ka); S.ut_rel.push_back(u.rel);
+    }
+    if(!subs.empty()) S.ui_ptr.push_back((int)subs.size());
+    for(int l = 0; l < S.nlevels; l++) S.ui_lvl_ptr[l+1] += S.ui_lvl_ptr[l];
+  }
+
+  // ------------------------------------------- 9. assembly / Jt*x lists
+  {
+    struct Tup { int64_t key; int rb; uint16_t offI, offJ; };
+    std::vector<Tup> tups;
+    size_t ntup = 0;
+    for(const RowBlock& b : rbs) if(b.local) ntup += (size_t)b.nvb*(b.nvb + 1)/2;
+    tups.reserve(ntup);
+    for(int bi = 0; bi < nrb; bi++)
+    {
+      const RowBlock& b = rbs[bi];
+      if(!b.local) continue;
+      for(int x = 0; x < b.nvb; x++)
+        for(int y = 0; y <= x; y++)
+        {
+          int I = rb_vb[b.vptr + x], J = rb_vb[b.vptr + y];
+          int oI = rb_off[b.vptr + x], oJ = rb_off[b.vptr + y];
+          if(I != J && bpos[I] < bpos[J]) { std::swap(I, J); std::swap(oI, oJ); }
+          // diagonal blocks sort first (key = vb id), off-diagonal after
+          const int64_t key = (I == J) ? (int64_t)I : ((int64_t)(bpos[J] + 1) << 32) | (int64_t)bpos[I];
+          tups.push_back({key, bi, (uint16_t)oI, (uint16_t)oJ});
+        }
+    }
+    std::stable_sort(tups.begin(), tups.end(), [](const Tup& a, const Tup& b) { return a.key < b.key; });
+    // diagonal output blocks for every var-block (also those without local contributions)
+    S.oblk.resize(nvb);
+    std::vector<int> blk_c0(nvb + 1, 0);
+    for(int v = 0; v < nvb; v++)
+    {
+      const int q = bpos[v], t = sn_of_b[q];
+      const int ld = S.sn_rowptr[t+1] - S.sn_rowptr[t];
+      const int lc = colstart[q] - S.sn_c0[t];
+      SymOutBlock o; memset(&o, 0, sizeof(o));
+      o.dest = S.sn_lx[t] + lc + (int64_t)lc*ld; o.ld = ld; o.var0 = S.vb_start[v];
+      o.nI = o.nJ = (uint8_t)G.w[v]; o.diag = 1;
+      S.oblk[v] = o;
+    }
+    S.contrib.reserve(tups.size());
+    std::vector<int> cptr;                    // contribution range per output block
+    cptr.assign(nvb + 1, 0);
+    size_t i = 0;
+    // diagonal part
+    for(int v = 0; v < nvb; v++)
+    {
+      cptr[v] = (int)S.contrib.size();
+      while(i < tups.size() && tups[i].key == (int64_t)v)
+      {
+        const RowBlock& b = rbs[tups[i].rb];
+        SymContrib c; c.base = b.base - cp[row0]; c.r0 = b.r0 - row0; c.len = (uint16_t)b.len;
+        c.nrows = (uint8_t)b.nrows; c.pad = 0; c.offI = tups[i].offI; c.offJ = tups[i].offJ;
+        S.contrib.push_back(c); i++;
+      }
+    }
+    cptr[nvb] = (int)S.contrib.size();
+    // off-diagonal part
+    while(i < tups.size())
+    {
+      const int64_t key = tups[i].key;
+      const int qJ = (int)(key >> 32) - 1, qI = (int)(key & 0xffffffff);
+      const int t = sn_of_b[qJ];
+      const int ld = S.sn_rowptr[t+1] - S.sn_rowptr[t];
+      const int lc = colstart[qJ] - S.sn_c0[t];
+      const int ro = rowoff_in(t, qI);
+      if(ro < 0) SYM_FAIL("internal error: JtJ block (%d,%d) missing from the factor structure", qI, qJ);
+      SymOutBlock o; memset(&o, 0, sizeof(o));
+      o.dest = S.sn_lx[t] + ro + (int64_t)lc*ld; o.ld = ld; o.var0 = S.vb_start[border[qI]];
+      o.nI = (uint8_t)G.w[border[qI]]; o.nJ = (uint8_t)G.w[border[qJ]]; o.diag = 0;
+      S.oblk.push_back(o);
+      cptr.back() = (int)S.contrib.size();
+      while(i < tups.size() && tups[i].key == key)
+      {
+        const RowBlock& b = rbs[tups[i].rb];
+        SymContrib c; c.base = b.base - cp[row0]; c.r0 = b.r0 - row0; c.len = (uint16_t)b.len;
+        c.nrows = (uint8_t)b.nrows; c.pad = 0; c.offI = tups[i].offI; c.offJ = tups[i].offJ;
+        S.contrib.push_back(c); i++;
+      }
+      cptr.push_back((int)S.contrib.size());
+    }
+    const int nblk = (int)S.oblk.size();
+    // wave-tasks
+    auto make_tasks = [&](int nb, int chunk, std::vector<SymTask>& tasks, std::vector<int>& fin_ptr,
+                          std::vector<int>& fin_blk, int& nparts) {
+      nparts = 0; fin_ptr.clear(); fin_blk.clear(); fin_ptr.push_back(0);
+      for(int b = 0; b < nb; b++)
+      {
+        const int c0 = cptr[b], c1 = cptr[b+1];
+        if(c1 == c0) continue;
+        const int nch = (c1 - c0 + chunk - 1)/chunk;
+        if(nch == 1) tasks.push_back({b, c0, c1, -1});
+        else
+        {
+          for(int k = 0; k < nch; k++)
+            tasks.push_back({b, c0 + k*chunk, std::min(c1, c0 + (k+1)*chunk), nparts + k});
+          nparts += nch;
+          fin_blk.push_back(b); fin_ptr.push_back(nparts);
+        }
+      }
+    };
+    make_tasks(nblk, CH_ASM, S.asm_task, S.asm_fin_ptr, S.asm_fin_blk, S.asm_nparts);
+    make_tasks(nvb,  CH_JTX, S.jtx_task, S.jtx_fin_ptr, S.jtx_fin_blk, S.jtx_nparts);
+  }
+
+  // --------------------------------------- 10. forward-solve gather lists
+  {
+    S.rl_ptr.assign(N + 1, 0);
+    for(int d = 0; d < nsn; d++)
+    {
+      const int wd = S.sn_c0[d+1] - S.sn_c0[d];
+      for(int k = S.sn_rowptr[d] + wd; k < S.sn_rowptr[d+1]; k++) S.rl_ptr[S.sn_rows[k] + 1]++;
+    }
+    for(int k = 0; k < N; k++) S.rl_ptr[k+1] += S.rl_ptr[k];
+    S.rl_pos.resize(S.rl_ptr[N]);
+    std::vector<int> nx(S.rl_ptr.begin(), S.rl_ptr.end() - 1);
+    for(int d = 0; d < nsn; d++)
+    {
+      const int wd = S.sn_c0[d+1] - S.sn_c0[d];
+      for(int k = S.sn_rowptr[d] + wd, j = 0; k < S.sn_rowptr[d+1]; k++, j++)
+        S.rl_pos[nx[S.sn_rows[k]]++] = S.sn_scr[d] + j;
+    }
+  }
+  return 0;
+}

@@ -1,0 +1,100 @@
+// sparse_symbolic.h -- host-side symbolic phase of the sparse path.  Replaces
+// cholmod_analyze (reference call site dogleg.c:650-654): run once per solve on
+// the constant sparsity pattern of Jt (dogleg.c:648-649).
+//
+// Output = everything the numeric kernels need, as flat arrays that are
+// uploaded verbatim:
+//   * a block-sparse description of J: "var-blocks" (runs of state variables
+//     that always appear together) and "row-blocks" (runs of measurement rows
+//     with identical pattern), so that addresses of Jacobian values are computed
+//     from a few integers per row-block instead of per-entry index lists;
+//   * a fill-reducing, parallelism-exposing elimination order of the var-blocks
+//     (nested dissection by BFS level structures, leaves ordered by degree,
+//     dense blocks last);
+//   * supernodes (block columns with nested structure merged), their dense
+//     column-major panels, the supernodal elimination-tree levels;
+//   * gather lists: which row-blocks contribute to which JtJ block (assembly,
+//     Jt*x), which descendant panels update which target panel columns
+//     (factorisation), which scratch entries feed which row (forward solve).
+#pragma once
+#include <cstdint>
+#include <vector>
+
+// one contribution of a row-block to an output block: 16 bytes, read as int4
+struct SymContrib
+{
+  int32_t  base;     // position of the row-block's first value in the (rank-local) value array
+  int32_t  r0;       // first measurement row of the row-block, rank-local
+  uint16_t len;      // entries per row
+  uint8_t  nrows;    // rows in the row-block
+  uint8_t  pad;
+  uint16_t offI;     // offset of var-block I inside a row
+  uint16_t offJ;     // offset of var-block J inside a row
+};
+static_assert(sizeof(SymContrib) == 16, "SymContrib must be 16 bytes");
+
+// a JtJ output block (I,J), pos(I) >= pos(J) in elimination order
+struct SymOutBlock
+{
+  int64_t dest;      // offset in Lx of element (first row of I, first col of J)
+  int32_t ld;        // leading dimension of the target panel
+  int32_t var0;      // first ORIGINAL variable index of I (used by Jt*x on diagonal blocks)
+  uint8_t nI, nJ, diag, pad;
+  int32_t pad2;
+};
+static_assert(sizeof(SymOutBlock) == 24, "SymOutBlock layout");
+
+// a wave-task: contributions [c0,c1) of block blk; part >= 0: write the partial
+// into slot `part` of the partial buffer instead of the destination
+struct SymTask { int32_t blk, c0, c1, part; };
+
+struct SymHost
+{
+  int N = 0, M = 0, nnz = 0;
+  int row0 = 0, row1 = 0;            // local rows
+  // ---- blocks
+  int nvb = 0;
+  std::vector<int> vb_start;         // [nvb+1] original variable index
+  // ---- ordering
+  std::vector<int> perm;             // [N] perm[k] = original variable at elimination position k
+  std::vector<int> iperm;            // [N]
+  // ---- supernodes
+  int nsn = 0;
+  std::vector<int>     sn_c0;        // [nsn+1] first column (elimination position)
+  std::vector<int>     sn_rowptr;    // [nsn+1] into sn_rows
+  std::vector<int>     sn_rows;      // row structure (elimination positions, ascending; first w = own columns)
+  std::vector<int64_t> sn_lx;        // [nsn+1] panel offsets into Lx (column-major, ld = nrows)
+  std::vector<int>     sn_scr;       // [nsn+1] offsets into the solve scratch (below rows only)
+  std::vector<int>     sn_level;     // [nsn]
+  int nlevels = 0;
+  std::vector<int>     lvl_ptr;      // [nlevels+1]
+  std::vector<int>     lvl_sn;       // [nsn] supernodes sorted by level
+  std::vector<int64_t> diagpos;      // [N] Lx offset of the diagonal entry of column k
+  int64_t lx_size = 0;
+  int     scr_size = 0;
+  int     max_panel = 0;             // max nrows*w over supernodes
+  // ---- factor update schedule (per source level)
+  std::vector<int> ui_lvl_ptr;       // [nlevels+1] into items
+  std::vector<int> ui_t, ui_col, ui_nc, ui_ptr;   // items: target, first local col, #cols, subtask range [ni+1]
+  std::vector<int> ut_d, ut_ka, ut_rel;           // subtasks: source snode, first row index in d, relpos index of row ka
+  std::vector<int> relpos;           // row positions in the target panel
+  // ---- assembly / Jt*x
+  std::vector<SymOutBlock> oblk;     // output blocks (diagonal blocks of every var-block first: [0,nvb))
+  std::vector<SymContrib>  contrib;
+  std::vector<SymTask>     asm_task; // assembly wave-tasks (all blocks)
+  std::vector<SymTask>     jtx_task; // Jt*x wave-tasks (diagonal blocks only)
+  std::vector<int> asm_fin_ptr, asm_fin_blk;   // blocks that need a partial-sum finalize: blk id, partial range
+  std::vector<int> jtx_fin_ptr, jtx_fin_blk;
+  int asm_nparts = 0, jtx_nparts = 0;
+  // ---- forward-solve gather lists
+  std::vector<int> rl_ptr;           // [N+1]
+  std::vector<int> rl_pos;           // scratch positions feeding row k
+  // ---- statistics
+  int64_t nnz_JtJ_lower = 0, nnz_L = 0;
+  double  factor_flops = 0;
+};
+
+// Build everything.  colptr/rowidx: FULL pattern of Jt (CSC, Nstate x Nmeas).
+// Returns 0 on success; on failure returns nonzero and fills err.
+int sym_analyze(SymHost& S, int N, int M, const int* colptr, const int* rowidx, int row0, int row1,
+                char* err, int errlen);

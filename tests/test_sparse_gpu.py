@@ -1,0 +1,136 @@
+"""GPU parity tests of the sparse path (K1, K3/K8, K4+K5, K6 and whole solves)
+against the CPU oracle.  All calls go through the C-ABI."""
+import ctypes as C
+import numpy as np
+import pytest
+
+from libdogleg_amd import capi
+from libdogleg_amd.ctypes_defs import dptr, iptr
+from tests import oracle_api as oa
+from tests.parity import compare_traces
+
+pytestmark = pytest.mark.gpu
+
+
+def test_sample_problem_sparse_matches_oracle(gpu):
+    """reference check.sh:11 (`sample --check sparse`) + trial-by-trial parity"""
+    P = oa.problems()
+    p0 = np.zeros(6)
+    P.sample_init(dptr(p0))
+    prm = oa.default_params()
+    prm.max_iterations = 8
+    cb = oa.fn_addr(P, "sample_cb_sparse")
+    ro, po, tro = oa.oracle_solve("sparse", p0, 6, 100, 600, cb, None, prm)
+    rg, pg, trg = capi.optimize("sparse", p0, 6, 100, 600, cb, None, prm)
+    assert rg >= 0
+    assert np.all(np.abs(pg - np.arange(1, 7)) < 5e-2)          # sample.c:424-458
+    worst = compare_traces(trg, tro)
+    assert np.max(np.abs(pg - po)) <= 1e-10
+    print(f"sample sparse: max |step diff| = {worst:.3e}")
+
+
+def _ops_parity(prob, tol=1e-10):
+    """every sparse op against the oracle primitives at one operating point"""
+    O = oa.oracle()
+    N, M, nnz = prob.N, prob.M, prob.nnz
+    Jp, Ji = prob.pattern()
+    p = prob.p0()
+    x, Jx = prob.eval(p)
+    be = capi.Backend(capi.DLG_SPARSE, N, M, nnz)
+    be.set_pattern(Jp, Ji)
+    st = be.stats()
+    be.set_p(0, p)
+    be.upload(0, x, Jx)
+    # K1
+    norm2x, absmax = be.eval(0)
+    g_ref = np.zeros(N)
+    O.orc_spmv_Jt_x(dptr(g_ref), N, M, iptr(Jp), iptr(Ji), dptr(Jx), dptr(x))
+    g = be.download(0, capi.VEC_JTX)
+    scale = max(1.0, np.max(np.abs(g_ref)))
+    assert np.max(np.abs(g - g_ref)) <= 1e-12 * scale
+    assert abs(norm2x - O.orc_norm2(dptr(x), M)) <= 1e-12 * norm2x
+    assert abs(absmax - np.max(np.abs(g_ref))) <= 1e-12 * scale
+    # K3
+    n2c = be.cauchy(0)
+    g2 = O.orc_norm2(dptr(g_ref), N)
+    Jg2 = O.orc_norm2_J_v(M, iptr(Jp), iptr(Ji), dptr(Jx), dptr(g_ref))
+    k = -g2 / Jg2
+    assert abs(n2c - k * k * g2) <= 1e-11 * n2c
+    # K4 + K5 + K6 against the oracle's sparse Cholesky
+    assert be.factorize(0, 0.0)
+    n2gn = be.solve_gn(0)
+    F = O.orc_sparse_analyze(N, M, iptr(Jp), iptr(Ji))
+    assert O.orc_sparse_factorize(F, iptr(Jp), iptr(Ji), dptr(Jx), 0.0) == N
+    gn_ref = np.zeros(N)
+    O.orc_sparse_solve(F, dptr(g_ref), dptr(gn_ref))
+    O.orc_sparse_free(F)
+    gn_ref *= -1
+    gn = be.download(0, capi.VEC_GN)
+    err = np.linalg.norm(gn - gn_ref)
+    assert err <= tol * max(1.0, np.linalg.norm(gn_ref)), err
+    assert abs(n2gn - gn_ref @ gn_ref) <= 1e-9 * max(1.0, n2gn)
+    # K7 + K8 on an interpolated step
+    tr = 0.5 * (np.sqrt(n2c) + np.sqrt(n2gn))
+    n2s, kk, amax, pnew = be.make_step(0, 1, capi.KIND_INTERP, tr)
+    step = be.download(1, capi.VEC_STEP)
+    ei = be.expected_improvement(0, 1)
+    ei_ref = -2 * (g_ref @ step) - O.orc_norm2_J_v(M, iptr(Jp), iptr(Ji), dptr(Jx), dptr(step))
+    assert abs(ei - ei_ref) <= 1e-10 * abs(ei_ref)
+    assert np.max(np.abs(pnew - (p + step))) <= 1e-13
+    be.close()
+    return st, err
+
+
+def test_ba_tiny_ops(gpu):
+    st, err = _ops_parity(oa.BAProblem(4, 20, 60, seed=2))
+    print("tiny BA:", st, f"|gn diff| = {err:.2e}")
+
+
+def test_ba_medium_ops(gpu):
+    st, err = _ops_parity(oa.BAProblem(49, 900, 10000, seed=3))
+    print("medium BA:", st, f"|gn diff| = {err:.2e}")
+
+
+def test_ba_tiny_solve_matches_oracle(gpu):
+    prob = oa.BAProblem(4, 20, 60, seed=2, eps=0.4, p0_spread=0.8)
+    prm = oa.default_params()
+    prm.max_iterations = 15
+    prm.trustregion0 = 1.0
+    p0 = prob.p0()
+    ro, po, tro = oa.oracle_solve("sparse", p0, prob.N, prob.M, prob.nnz, prob.cb, prob.cookie, prm)
+    rg, pg, trg = capi.optimize("sparse", p0, prob.N, prob.M, prob.nnz, prob.cb, prob.cookie, prm)
+    assert rg >= 0 and ro >= 0
+    worst = compare_traces(trg, tro)
+    assert np.max(np.abs(pg - po)) <= 1e-10
+    print(f"tiny BA solve: trials={trg.ntrials} kinds={sorted({t['step_type'] for t in trg.trials()})} "
+          f"max |step diff|={worst:.3e}")
+
+
+def test_ba_medium_solve_matches_oracle(gpu):
+    prob = oa.BAProblem(49, 900, 10000, seed=5, eps=0.4, p0_spread=0.6)
+    prm = oa.default_params()
+    prm.max_iterations = 10
+    prm.trustregion0 = 5.0
+    p0 = prob.p0()
+    ro, po, tro = oa.oracle_solve("sparse", p0, prob.N, prob.M, prob.nnz, prob.cb, prob.cookie, prm)
+    rg, pg, trg = capi.optimize("sparse", p0, prob.N, prob.M, prob.nnz, prob.cb, prob.cookie, prm)
+    assert rg >= 0 and ro >= 0
+    worst = compare_traces(trg, tro)
+    assert np.max(np.abs(pg - po)) <= 1e-10
+    print(f"medium BA solve: trials={trg.ntrials} kinds={sorted({t['step_type'] for t in trg.trials()})} "
+          f"max |step diff|={worst:.3e}")
+
+
+def test_ba_lambda_path(gpu):
+    """numerically-zero (structurally present) columns: JtJ is singular, the
+    factorisation fails, lambda becomes 1e-10 and sticks (dogleg.c:656-677)"""
+    prob = oa.BAProblem(6, 40, 160, seed=7, n_zero_cols=2)
+    prm = oa.default_params()
+    prm.max_iterations = 6
+    prm.trustregion0 = 100.0
+    p0 = prob.p0()
+    ro, po, tro = oa.oracle_solve("sparse", p0, prob.N, prob.M, prob.nnz, prob.cb, prob.cookie, prm)
+    rg, pg, trg = capi.optimize("sparse", p0, prob.N, prob.M, prob.nnz, prob.cb, prob.cookie, prm)
+    lam = [t["lambda_"] for t in trg.trials()]
+    assert 1e-10 in lam, lam
+    compare_traces(trg, tro, step_tol=1e-7)     # lambda=1e-10 systems are ill-conditioned by design
