@@ -1,0 +1,268 @@
+#!/usr/bin/env python3
+"""bench.py -- trust-region steps/sec (fp64) of the dog-leg hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W [--workload NAME]
+
+A "step" is one full trial step of the hot path on an operating point whose x
+and Jacobian values are already resident in HBM: K1 (Jt*x, |x|^2) -> K3 (Cauchy)
+-> K4+K5 (JtJ assembly + Cholesky) -> K6 (Gauss-Newton solve) -> K7 (dog-leg
+interpolation, p_new back to the host) -> K8 (expected improvement), driven
+through the C-ABI of libdogleg_amd.so exactly as the host trust-region driver
+drives it (including its host<->device scalar round trips).  This is the
+expensive kind of step (refactorisation + interpolation); cached retries after
+a rejection are cheaper.
+
+Workloads (BASELINE.json configs):
+  sparse-1m   (default) config #4: BA-arrowhead 1 000 000 meas x 150 000 params, 15 M nnz
+  sparse-200k config #3: 200 000 x 30 000, 3 M nnz
+  dense-50k   config #2: dense 50 000 x 2 000
+  sparse-5m   config #5: 5 000 000 x 500 001, 75 M nnz, ill-conditioned + lambda path
+
+N > 1 (launched by torch.distributed.run): measurement rows are sharded over the
+ranks; Jt*x / |Jv|^2 / JtJ partials are summed with an RCCL all-reduce
+(torch.distributed, backend nccl) before the replicated factorisation.  The
+problem size is fixed, so scaling is "strong".
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (kind, params)
+    "sparse-1m":   ("sparse", dict(Nc=2499, Np=45000, Nobs=500000)),
+    "sparse-200k": ("sparse", dict(Nc=499, Np=9000, Nobs=100000)),
+    "sparse-5m":   ("sparse", dict(Nc=8333, Np=149999, Nobs=2500000, scale_decades=4.0, n_zero_cols=3)),
+    "dense-50k":   ("dense", dict(M=50000, N=2000)),
+    "sparse-tiny": ("sparse", dict(Nc=49, Np=900, Nobs=10000)),
+    "dense-tiny":  ("dense", dict(M=3000, N=256)),
+}
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+MFMA_F64_PEAK_TFLOPS = 78.6    # public datasheet; the guides carry no fp64 MFMA figure (48 measured)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="sparse-1m", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline sample")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+    use_dist = world > 1 or os.environ.get("DLG_BENCH_FORCE_DIST") == "1"
+
+    torch = dist = None
+    if use_dist:
+        # torch first: libdogleg_amd then binds to the HIP runtime torch ships
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+
+    import numpy as np
+    from libdogleg_amd import capi
+    from tests import oracle_api as oa       # problem generators (+ the oracle for cpu_baseline)
+
+    L = capi.lib()
+    if L.dlg_device_count() <= 0:
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+
+    kind, prm = WORKLOADS[args.workload]
+    t_setup = time.time()
+    if kind == "sparse":
+        prob = oa.BAProblem(**prm, seed=11)
+        N, M, nnz = prob.N, prob.M, prob.nnz
+        Jp, Ji = prob.pattern()
+        p0 = prob.p0()
+        x, Jx = prob.eval(p0)
+        # contiguous row ranges balanced by nnz (rows all have 15 entries here)
+        row0 = (M * rank) // world
+        row1 = (M * (rank + 1)) // world
+        q0, q1 = int(Jp[row0]), int(Jp[row1])
+        x_loc, J_loc = x[row0:row1], Jx[q0:q1]
+        be = capi.Backend(capi.DLG_SPARSE, N, M, nnz, device=local_rank if use_dist else -1)
+    else:
+        prob = oa.DenseProblem(**prm, seed=11)
+        N, M, nnz = prob.N, prob.M, 0
+        p0 = prob.p0()
+        x, J = prob.eval(p0)
+        row0 = (M * rank) // world
+        row1 = (M * (rank + 1)) // world
+        x_loc, J_loc = x[row0:row1], J[row0:row1]
+        be = capi.Backend(capi.DLG_DENSE, N, M, device=local_rank if use_dist else -1)
+
+    hook = None
+    if use_dist:
+        dev = torch.device("cuda", local_rank)
+
+        class _DevPtr:
+            def __init__(self, ptr, n):
+                self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f8",
+                                                 "data": (ptr, False), "version": 3}
+
+        def hook(buf, count, cookie):
+            try:
+                t = torch.as_tensor(_DevPtr(buf, count), device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.SUM)
+                torch.cuda.synchronize()
+                return 0
+            except Exception as e:           # never let an exception cross the C boundary
+                print(f"all-reduce hook failed: {e}", file=sys.stderr)
+                return 1
+        be.set_shard(row0, row1, hook)
+    if kind == "sparse":
+        be.set_pattern(Jp, Ji)
+        sym = be.stats()
+    else:
+        sym = {}
+    d_x = capi.DeviceArray(np.ascontiguousarray(x_loc))
+    d_J = capi.DeviceArray(np.ascontiguousarray(J_loc))
+    be.set_p(0, p0)
+    setup_s = time.time() - t_setup
+
+    def one_step():
+        be.bind_device(0, d_x.ptr, d_J.ptr)          # a fresh operating point: nothing cached
+        norm2x, gmax = be.eval(0)                    # K1
+        n2c = be.cauchy(0)                           # K3
+        ok = be.factorize(0, 0.0)                    # K4 + K5
+        lam = 0.0
+        while not ok:                                # the reference's lambda loop (dogleg.c:656-677)
+            lam = 1e-10 if lam == 0.0 else lam * 10
+            ok = be.factorize(0, lam)
+        n2g = be.solve_gn(0)                         # K6
+        tr = 0.5 * (n2c ** 0.5 + n2g ** 0.5)
+        n2s, k, amax, pnew = be.make_step(0, 1, capi.KIND_INTERP, tr)   # K7 (+ p_new D2H)
+        ei = be.expected_improvement(0, 1)           # K8
+        return norm2x, n2c, n2g, k, n2s, ei, gmax, amax, lam
+
+    def barrier():
+        L.dlg_device_sync()
+        if use_dist:
+            torch.cuda.synchronize()
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        res = one_step()
+    be.set_profiling(True)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = one_step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    prof = be.profile()
+    be.set_profiling(False)
+    if use_dist:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    # ---- roofline of the JtJ assembly kernel (the kernel north_star sets a target for)
+    ms, cnt = prof["K4_kernel"]
+    k4_ms = ms / max(cnt, 1)
+    if kind == "sparse":
+        # 12*nnz + 4*(M+1) + 8*nnz(tril JtJ) bytes per launch (local rows on a shard)
+        nnz_loc = int(J_loc.shape[0])
+        alg_bytes = 12 * nnz_loc + 4 * (row1 - row0 + 1) + 8 * sym["nnz_JtJ_lower"]
+        roof = {"kernel": "k_assemble (K4-sparse JtJ assembly)", "bound": "hbm",
+                "achieved": alg_bytes / (k4_ms * 1e-3) / 1e9 if k4_ms > 0 else None,
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None,
+                "algorithmic_bytes": alg_bytes, "avg_launch_ms": k4_ms, "launches": cnt}
+    else:
+        flops = 2.0 * (row1 - row0) * N * (N + 1) / 2
+        roof = {"kernel": "k_syrk_lower (K4-dense fp64 MFMA SYRK)", "bound": "mfma",
+                "achieved": flops / (k4_ms * 1e-3) / 1e12 if k4_ms > 0 else None,
+                "peak": MFMA_F64_PEAK_TFLOPS, "unit": "TFLOP/s", "traffic": None,
+                "algorithmic_flops": flops, "avg_launch_ms": k4_ms, "launches": cnt}
+    roof["frac"] = (roof["achieved"] / roof["peak"]) if roof["achieved"] else None
+
+    out = None
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        out = {
+            "metric": "trust-region steps/sec (fp64) at fixed (Nmeas,Nstate,nnz)",
+            "value": args.steps / elapsed, "unit": "steps/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": args.workload, "kind": kind, "Nmeas": M, "Nstate": N, "nnz": nnz,
+                       "step": "K1+K3+K4+K5+K6+K7+K8 (refactorise + interpolate), inputs resident in HBM",
+                       "parallelism": f"rows sharded x{world}, all-reduce before factorise" if world > 1 else "1 GPU"},
+            "roofline": roof,
+            "phases_ms_per_step": {k: v[0] / args.steps for k, v in prof.items()},
+            "symbolic": sym, "setup_s": setup_s,
+            "check": {"norm2_x": res[0], "norm2_step": res[4], "expected_improvement": res[5], "lambda": res[8]},
+        }
+
+    # ---- CPU baseline: the oracle's restatement of the same step, host cores, bounded sample
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        O = oa.oracle()
+        from libdogleg_amd.ctypes_defs import dptr, iptr
+        work = np.zeros(5 * N)
+        o8 = np.zeros(8)
+        if kind == "sparse":
+            ta = time.perf_counter()
+            F = O.orc_sparse_analyze(N, M, iptr(Jp), iptr(Ji))
+            t_an = time.perf_counter() - ta
+            n_done, t_cpu = 0, 0.0
+            while n_done < 1 or (t_cpu < args.cpu_seconds and n_done < args.steps):
+                tb = time.perf_counter()
+                rc = O.orc_step_sparse(F, N, M, iptr(Jp), iptr(Ji), dptr(Jx), dptr(x), dptr(p0),
+                                       res[8], dptr(work), dptr(o8))
+                t_cpu += time.perf_counter() - tb
+                n_done += 1
+                assert rc == 0
+            sample = (f"{n_done} full steps of the same workload, single thread "
+                      f"(symbolic analysis {t_an:.1f}s excluded; nnz(L)={O.orc_sparse_nnzL(F)}, "
+                      f"factor flops={O.orc_sparse_flops(F):.3g})")
+            O.orc_sparse_free(F)
+            cpu_val = n_done / t_cpu
+            ocheck = o8.copy()
+        else:
+            # the faithful rank-1 JtJ loop costs ~M*N^2/2 FMAs: time it on a row sample and scale
+            Ms = min(M, max(64, int(args.cpu_seconds * 1.2e9 / (N * N / 2 + 3 * N))))
+            dfac = np.zeros(N * (N + 1) // 2)
+            tb = time.perf_counter()
+            rc = O.orc_step_dense(N, Ms, dptr(J[:Ms]), dptr(x[:Ms]), dptr(p0), 1e-3, dptr(dfac),
+                                  dptr(work), dptr(o8))
+            t_s = time.perf_counter() - tb
+            # split: Cholesky+solve cost does not scale with M; estimate it separately
+            tb = time.perf_counter()
+            O.orc_dpptrf_L(N, dptr(dfac))
+            t_chol = time.perf_counter() - tb
+            t_full = (t_s - t_chol) * (M / Ms) + t_chol
+            cpu_val = 1.0 / t_full
+            sample = (f"1 step on the first {Ms} of {M} rows ({t_s:.1f}s), row-proportional part "
+                      f"scaled to {M} rows; packed Cholesky ({t_chol:.2f}s) not scaled; single thread")
+            ocheck = None
+        out["cpu_baseline"] = {"value": cpu_val, "unit": "steps/s", "cores": 1, "kind": "port",
+                               "sample": sample, "host_cpus": os.cpu_count()}
+        out["speedup_vs_cpu_baseline"] = out["value"] / cpu_val
+        if ocheck is not None:
+            # same inputs -> same numbers: a cheap end-to-end parity check printed with the result
+            out["check"]["oracle_norm2_step"] = float(ocheck[4])
+            out["check"]["oracle_expected_improvement"] = float(ocheck[5])
+            out["check"]["rel_diff_norm2_step"] = abs(float(ocheck[4]) - res[4]) / max(1e-300, abs(res[4]))
+    if rank == 0:
+        print(json.dumps(out))
+    be.close()
+    if use_dist:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -151,6 +151,24 @@ int  dlg_kernel_potrf_lower(void* hip_stream, double* A_dev, int lda, int n, int
 int  dlg_probe_mfma_f64(double* tflops);
 int  dlg_probe_hbm_copy(double* gbytes_per_s);
 
+/* ---- per-phase GPU timing with HIP events on the backend's stream (bench.py's
+ * roofline numbers come from here).  Phases: */
+enum
+{
+  DLG_PROF_K1_JTX = 0,        /* Jt*x kernels                                   */
+  DLG_PROF_K3K8_NORM2JV = 1,  /* |J v|^2 kernels (Cauchy + expected improvement) */
+  DLG_PROF_K4_KERNEL = 2,     /* the JtJ assembly kernel alone (sparse: k_assemble;
+                                 dense: the MFMA SYRK kernel)                    */
+  DLG_PROF_K4_TOTAL = 3,      /* assembly incl. memset / partial-sum finalize    */
+  DLG_PROF_K5_FACTOR = 4,     /* numeric Cholesky                                */
+  DLG_PROF_K6_SOLVE = 5,      /* triangular solves                               */
+  DLG_PROF_K7_STEP = 6,       /* step formation                                  */
+  DLG_PROF_VEC = 7,           /* other O(N) reductions                           */
+  DLG_PROF_COUNT = 8
+};
+int  dlg_backend_set_profiling(dlg_backend_t* b, int on);      /* also clears the counters */
+int  dlg_backend_get_profile(dlg_backend_t* b, double* ms_total, long* launches, int n);
+
 /* ---- raw device-memory helpers for harnesses that hold inputs in HBM without
  * a framework (tests, bench): thin wrappers of hipMalloc/hipMemcpy/hipFree --- */
 void* dlg_mem_alloc(size_t bytes);

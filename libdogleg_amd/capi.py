@@ -32,7 +32,9 @@ BACKEND_SYMBOLS = [
     "dlg_kernel_syrk_lower", "dlg_kernel_potrf_lower", "dlg_probe_mfma_f64",
     "dlg_probe_hbm_copy", "dlg_set_trace", "dlg_mem_alloc", "dlg_mem_free", "dlg_mem_upload",
     "dlg_mem_download", "dlg_mem_zero", "dlg_device_sync", "dlg_sparse_symbolic_probe",
+    "dlg_backend_set_profiling", "dlg_backend_get_profile",
 ]
+PROF_NAMES = ["K1_jtx", "K3K8_norm2Jv", "K4_kernel", "K4_total", "K5_factor", "K6_solve", "K7_step", "vec"]
 DOGLEG_SYMBOLS = [
     "dogleg_getDefaultParameters", "dogleg_setMaxIterations",
     "dogleg_setTrustregionUpdateParameters", "dogleg_setDebug", "dogleg_setInitialTrustregion",
@@ -96,6 +98,8 @@ def lib():
     L.dlg_mem_upload.argtypes = [V, V, C.c_size_t]
     L.dlg_mem_download.argtypes = [V, V, C.c_size_t]
     L.dlg_mem_zero.argtypes = [V, C.c_size_t]
+    L.dlg_backend_set_profiling.argtypes = [V, C.c_int]
+    L.dlg_backend_get_profile.argtypes = [V, D, C.POINTER(C.c_long), C.c_int]
     L.dlg_sparse_symbolic_probe.argtypes = [C.c_int, C.c_int, I, I, C.c_int, C.c_int,
                                             C.POINTER(C.c_long), C.c_int, I]
     # dogleg.h
@@ -229,6 +233,17 @@ class Backend:
             self.close()
         except Exception:
             pass
+
+    def set_profiling(self, on=True):
+        _ck(self.L.dlg_backend_set_profiling(self.h, 1 if on else 0), "set_profiling")
+
+    def profile(self):
+        """{phase: (total_ms, launches)} since set_profiling(True)"""
+        n = len(PROF_NAMES)
+        ms = (C.c_double * n)()
+        cnt = (C.c_long * n)()
+        _ck(self.L.dlg_backend_get_profile(self.h, ms, cnt, n), "get_profile")
+        return {PROF_NAMES[i]: (ms[i], cnt[i]) for i in range(n)}
 
     def set_stream(self, stream_ptr):
         _ck(self.L.dlg_backend_set_stream(self.h, C.c_void_p(stream_ptr)), "set_stream")

@@ -26,6 +26,57 @@ int dlg_fetch_scalars(dlg_backend* b, int n)
   DLG_HIP(hipMemcpyAsync(b->h_scal, b->d_scal, sizeof(double)*(size_t)n, hipMemcpyDeviceToHost,
                          b->stream));
   DLG_HIP(hipStreamSynchronize(b->stream));
+  if(b->profiling) dlg_prof_resolve(b);
+  return DLG_OK;
+}
+
+// ---------------------------------------------------------------- profiling --
+static hipEvent_t prof_event(dlg_backend* b)
+{
+  hipEvent_t e = nullptr;
+  if(!b->prof_pool.empty()) { e = b->prof_pool.back(); b->prof_pool.pop_back(); return e; }
+  if(hipEventCreate(&e) != hipSuccess) return nullptr;
+  return e;
+}
+hipEvent_t dlg_prof_begin(dlg_backend* b)
+{
+  hipEvent_t e = prof_event(b);
+  if(e) (void)hipEventRecord(e, b->stream);
+  return e;
+}
+void dlg_prof_end(dlg_backend* b, int id, hipEvent_t start)
+{
+  hipEvent_t e = prof_event(b);
+  if(!e) { b->prof_pool.push_back(start); return; }
+  (void)hipEventRecord(e, b->stream);
+  b->prof_pending.push_back({start, e, id});
+}
+void dlg_prof_resolve(dlg_backend* b)
+{
+  for(auto& pp : b->prof_pending)
+  {
+    float ms = 0;
+    if(hipEventElapsedTime(&ms, pp.a, pp.b) == hipSuccess) { b->prof_ms[pp.id] += ms; b->prof_n[pp.id]++; }
+    b->prof_pool.push_back(pp.a); b->prof_pool.push_back(pp.b);
+  }
+  b->prof_pending.clear();
+}
+extern "C" int dlg_backend_set_profiling(dlg_backend_t* b, int on)
+{
+  if(!b) return DLG_ERR_ARG;
+  DLG_HIP(hipStreamSynchronize(b->stream));
+  dlg_prof_resolve(b);
+  for(int i = 0; i < DLG_PROF_COUNT; i++) { b->prof_ms[i] = 0; b->prof_n[i] = 0; }
+  b->profiling = on != 0;
+  return DLG_OK;
+}
+extern "C" int dlg_backend_get_profile(dlg_backend_t* b, double* ms_total, long* launches, int n)
+{
+  if(!b) return DLG_ERR_ARG;
+  DLG_HIP(hipStreamSynchronize(b->stream));
+  dlg_prof_resolve(b);
+  for(int i = 0; i < n && i < DLG_PROF_COUNT; i++)
+  { if(ms_total) ms_total[i] = b->prof_ms[i]; if(launches) launches[i] = b->prof_n[i]; }
   return DLG_OK;
 }
 
@@ -116,6 +167,8 @@ extern "C" void dlg_backend_destroy(dlg_backend_t* b)
   if(b->d_part) (void)hipFree(b->d_part);
   if(b->d_work) (void)hipFree(b->d_work);
   if(b->d_red)  (void)hipFree(b->d_red);
+  for(auto& pp : b->prof_pending) { (void)hipEventDestroy(pp.a); (void)hipEventDestroy(pp.b); }
+  for(hipEvent_t e : b->prof_pool) (void)hipEventDestroy(e);
   if(b->own_stream && b->stream) (void)hipStreamDestroy(b->stream);
   delete b;
 }
@@ -243,7 +296,11 @@ extern "C" int dlg_point_eval(dlg_backend_t* b, int s, double* norm2_x, double* 
   else
   {
     const int mloc = b->row1 - b->row0;
-    if(b->type == DLG_SPARSE) DLG_CHECK(sparse_eval(b, s)); else DLG_CHECK(dense_eval(b, s));
+    {
+      DlgProfScope ps(b, DLG_PROF_K1_JTX);
+      if(b->type == DLG_SPARSE) DLG_CHECK(sparse_eval(b, s)); else DLG_CHECK(dense_eval(b, s));
+    }
+    DlgProfScope pv(b, DLG_PROF_VEC);
     // norm2_x over the local rows
     if(mloc > 0) DLG_CHECK(k_norm2_absmax(b, S.xin(), mloc, b->d_scal));
     else         DLG_HIP(hipMemsetAsync(b->d_scal, 0, 2*sizeof(double), b->stream));
@@ -270,6 +327,7 @@ extern "C" int dlg_point_eval(dlg_backend_t* b, int s, double* norm2_x, double* 
 // |J v|^2 into dev scalar `out` (all-reduced over ranks)
 static int norm2_Jv(dlg_backend* b, int s, const double* v, double* out)
 {
+  DlgProfScope ps(b, DLG_PROF_K3K8_NORM2JV);
   switch(b->type)
   {
   case DLG_SPARSE:  DLG_CHECK(sparse_norm2_Jv(b, s, v, out)); break;
@@ -313,6 +371,7 @@ extern "C" int dlg_factorize(dlg_backend_t* b, int s, double lambda, int* ok)
   case DLG_DENSE:  DLG_CHECK(dense_factorize(b, s, lambda, &good)); break;
   default:         DLG_CHECK(products_factorize(b, s, lambda, &good)); break;
   }
+  if(b->profiling) dlg_prof_resolve(b);
   b->factor_slot = good ? s : -1;
   if(ok) *ok = good;
   return DLG_OK;
@@ -327,8 +386,11 @@ extern "C" int dlg_solve_gn(dlg_backend_t* b, int s, double* norm2_updateGN)
   if(b->factor_slot != s) { dlg_set_error("dlg_solve_gn: no factorization of slot %d is held", s); return DLG_ERR_STATE; }
   if(!S.have_gn)
   {
-    if(b->type == DLG_SPARSE) DLG_CHECK(sparse_solve(b, S.Jt_x, S.gn));
-    else                      DLG_CHECK(dense_solve(b, S.Jt_x, S.gn));
+    {
+      DlgProfScope ps(b, DLG_PROF_K6_SOLVE);
+      if(b->type == DLG_SPARSE) DLG_CHECK(sparse_solve(b, S.Jt_x, S.gn));
+      else                      DLG_CHECK(dense_solve(b, S.Jt_x, S.gn));
+    }
     DLG_CHECK(k_negate_norm2(b, S.gn, b->N, b->d_scal));      // dogleg.c:862-865
     DLG_CHECK(dlg_fetch_scalars(b, 1));
     S.norm2_gn = b->h_scal[0];
@@ -348,6 +410,7 @@ extern "C" int dlg_make_step(dlg_backend_t* b, int from, int to, int kind, doubl
   DlgSlot& F = b->slot[from];
   DlgSlot& T = b->slot[to];
   double n2 = 0, kk = NAN, amax = 0;
+  DlgProfScope ps(b, DLG_PROF_K7_STEP);
   switch(kind)
   {
   case DLG_KIND_CAUCHY_TO_EDGE:

@@ -86,7 +86,26 @@ struct dlg_backend
   void* allreduce_cookie = nullptr;
   double* d_red = nullptr;    // fused reduce buffer [Jt_x | norm2_x | ...]
 
+  // optional per-phase timing with HIP events on b->stream (dlg_backend_set_profiling)
+  bool profiling = false;
+  struct ProfPair { hipEvent_t a, b; int id; };
+  std::vector<ProfPair> prof_pending;
+  std::vector<hipEvent_t> prof_pool;
+  double prof_ms[DLG_PROF_COUNT] = {0};
+  long   prof_n[DLG_PROF_COUNT] = {0};
+
   int factor_slot = -1;       // slot whose JtJ the stored factor belongs to (-1: none)
+};
+
+// profiling helpers: bracket a phase with events; resolved at the next stream sync
+hipEvent_t dlg_prof_begin(dlg_backend* b);
+void dlg_prof_end(dlg_backend* b, int id, hipEvent_t start);
+void dlg_prof_resolve(dlg_backend* b);
+struct DlgProfScope
+{
+  dlg_backend* b; int id; hipEvent_t e;
+  DlgProfScope(dlg_backend* b_, int id_) : b(b_), id(id_), e(b_->profiling ? dlg_prof_begin(b_) : nullptr) {}
+  ~DlgProfScope() { if(e) dlg_prof_end(b, id, e); }
 };
 
 // rows of the measurement vector owned by this rank

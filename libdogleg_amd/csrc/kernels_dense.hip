@@ -504,7 +504,8 @@ static int syrk_nsplit(int ntiles, int K)
 // overwrite=true : C  = alpha*update + lambda*I through the split-K slabs in `ws`.
 template <int WT>
 int launch_syrk(hipStream_t st, double* C, int ldc, const double* A, int lda, int n, int K,
-                double alpha, double lambda, bool overwrite, double* ws, size_t ws_bytes)
+                double alpha, double lambda, bool overwrite, double* ws, size_t ws_bytes,
+                dlg_backend* prof = nullptr)
 {
   constexpr int BT = 2*WT;
   const int T = dlg_cdiv(n, BT);
@@ -532,8 +533,12 @@ int launch_syrk(hipStream_t st, double* C, int ldc, const double* A, int lda, in
   if(!ws || per*ks > ws_bytes) { dlg_set_error("syrk workspace too small"); return DLG_ERR_ARG; }
   int kper = dlg_cdiv(dlg_cdiv(K, ks), KC)*KC;
   if(kper < KC) kper = KC;
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_syrk_lower<WT>), dim3(ntiles*ks), dim3(TPB), lds, st, C, ldc, A,
-                     lda, n, K, alpha, ks, kper, ws);
+  {
+    hipEvent_t pe = (prof && prof->profiling) ? dlg_prof_begin(prof) : nullptr;
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_syrk_lower<WT>), dim3(ntiles*ks), dim3(TPB), lds, st, C, ldc, A,
+                       lda, n, K, alpha, ks, kper, ws);
+    if(pe) dlg_prof_end(prof, DLG_PROF_K4_KERNEL, pe);
+  }
   hipLaunchKernelGGL(HIP_KERNEL_NAME(k_syrk_reduce<BT>), dim3(ntiles), dim3(TPB), 0, st, C, ldc, n, ws,
                      ks, ntiles, alpha, 0.0, lambda);
   DLG_LAUNCH_CHECK();
@@ -653,8 +658,11 @@ int dense_factorize(dlg_backend* b, int s, double lambda, int* ok)
   DLG_HIP(hipMemsetAsync(b->d_info, 0, sizeof(int), b->stream));
   // K4: G(lower) = J^T J + lambda I   (K = M measurement rows, A = J with lda = N)
   const bool sharded = b->allreduce != nullptr;
-  DLG_CHECK(launch_syrk<64>(b->stream, b->G, b->N, S.Jin(), b->N, b->N, dlg_mloc(b), 1.0,
-                            sharded ? 0.0 : lambda, true, b->slabs, b->slabs_bytes));
+  {
+    DlgProfScope pt(b, DLG_PROF_K4_TOTAL);
+    DLG_CHECK(launch_syrk<64>(b->stream, b->G, b->N, S.Jin(), b->N, b->N, dlg_mloc(b), 1.0,
+                              sharded ? 0.0 : lambda, true, b->slabs, b->slabs_bytes, b));
+  }
   if(sharded)
   {
     DLG_CHECK(dlg_allreduce_dev(b, b->G, (size_t)b->N*b->N));
@@ -662,7 +670,10 @@ int dense_factorize(dlg_backend* b, int s, double lambda, int* ok)
       hipLaunchKernelGGL(k_add_diag, dim3(dlg_cdiv(b->N, TPB)), dim3(TPB), 0, b->stream, b->G, b->N, lambda);
   }
   // K5
-  DLG_CHECK(potrf_lower(b->stream, b->G, b->N, b->N, b->d_info));
+  {
+    DlgProfScope pf(b, DLG_PROF_K5_FACTOR);
+    DLG_CHECK(potrf_lower(b->stream, b->G, b->N, b->N, b->d_info));
+  }
   return finish_potrf(b, ok);
 }
 

@@ -48,7 +48,10 @@ struct SparseSym
   int *sn_c0 = nullptr, *sn_rowptr = nullptr, *sn_rows = nullptr, *sn_scr = nullptr, *lvl_sn = nullptr;
   int64_t *sn_lx = nullptr, *diagpos = nullptr;
   int *ui_t = nullptr, *ui_col = nullptr, *ui_nc = nullptr, *ui_ptr = nullptr;
-  int *ut_d = nullptr, *ut_ka = nullptr, *ut_rel = nullptr, *relpos = nullptr;
+  SymSub* usub = nullptr; int* relpos = nullptr;
+  int *uw_item = nullptr, *uw_s0 = nullptr, *uw_s1 = nullptr, *uf_item = nullptr, *uf_n = nullptr;
+  int64_t *uw_part = nullptr, *uf_off = nullptr;
+  double* upart = nullptr;
   SymOutBlock* oblk = nullptr; SymContrib* contrib = nullptr;
   SymTask *asm_task = nullptr, *jtx_task = nullptr;
   int *asm_fin_ptr = nullptr, *asm_fin_blk = nullptr, *jtx_fin_ptr = nullptr, *jtx_fin_blk = nullptr;
@@ -60,7 +63,7 @@ struct SparseSym
   size_t nnz_loc = 0;
   // per-level launch parameters
   std::vector<int> fac_lds;     // bytes of LDS for the factor kernel of a level (0: panels stay in HBM)
-  std::vector<int> upd_lds, upd_nw;
+  std::vector<int> upd_lds, upd_nw, slv_lds, fac_nt, upd_coop;
   std::vector<void*> allocs;
 };
 
@@ -95,21 +98,29 @@ __global__ void __launch_bounds__(TPB) k_assemble(const SymTask* __restrict__ ta
   if(T.part < 0) { if(active) Lx[B.dest + a + (int64_t)b*B.ld] = acc; }
   else part[(size_t)T.part*64 + lane] = acc;
 }
-__global__ void __launch_bounds__(TPB) k_assemble_fin(const int* __restrict__ fin_ptr,
-                                                      const int* __restrict__ fin_blk, int nfin,
-                                                      const SymOutBlock* __restrict__ oblk,
-                                                      const double* __restrict__ part,
-                                                      double* __restrict__ Lx)
+// sum the partials of a multi-chunk block: one 1024-thread workgroup per block,
+// 16 groups x 64 lanes stride over the partials, fixed-order LDS reduction
+__global__ void __launch_bounds__(1024) k_assemble_fin(const int* __restrict__ fin_ptr,
+                                                       const int* __restrict__ fin_blk, int nfin,
+                                                       const SymOutBlock* __restrict__ oblk,
+                                                       const double* __restrict__ part,
+                                                       double* __restrict__ Lx)
 {
-  const int wid = blockIdx.x*(TPB/64) + (threadIdx.x >> 6);
-  if(wid >= nfin) return;
-  const int lane = threadIdx.x & 63;
-  const SymOutBlock B = oblk[fin_blk[wid]];
-  const int a = lane % B.nI, b = lane / B.nI;
-  const bool active = (b < B.nJ) && (!B.diag || a >= b);
+  __shared__ double sh[1024];
+  const int f = blockIdx.x;
+  const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const SymOutBlock B = oblk[fin_blk[f]];
   double s = 0.0;
-  for(int p = fin_ptr[wid]; p < fin_ptr[wid+1]; p++) s += part[(size_t)p*64 + lane];
-  if(active) Lx[B.dest + a + (int64_t)b*B.ld] = s;
+  for(int p = fin_ptr[f] + g; p < fin_ptr[f+1]; p += 16) s += part[(size_t)p*64 + lane];
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  if(g == 0)
+  {
+    double tot = 0.0;
+    for(int k = 0; k < 16; k++) tot += sh[k*64 + lane];
+    const int a = lane % B.nI, b = lane / B.nI;
+    if((b < B.nJ) && (!B.diag || a >= b)) Lx[B.dest + a + (int64_t)b*B.ld] = tot;
+  }
 }
 __global__ void __launch_bounds__(TPB) k_add_lambda(double* __restrict__ Lx,
                                                     const int64_t* __restrict__ diagpos, int n,
@@ -161,20 +172,27 @@ __global__ void __launch_bounds__(TPB) k_jtx(const SymTask* __restrict__ tasks, 
     else part[(size_t)T.part*8 + lane] = s;
   }
 }
+// one workgroup per multi-chunk var-block: 32 groups x 8 scalars
 __global__ void __launch_bounds__(TPB) k_jtx_fin(const int* __restrict__ fin_ptr,
                                                  const int* __restrict__ fin_blk, int nfin,
                                                  const SymOutBlock* __restrict__ oblk,
                                                  const double* __restrict__ part,
                                                  double* __restrict__ jtx)
 {
-  const int t = blockIdx.x*TPB + threadIdx.x;
-  const int f = t >> 3, a = t & 7;
-  if(f >= nfin) return;
+  __shared__ double sh[TPB];
+  const int f = blockIdx.x;
+  const int a = threadIdx.x & 7, g = threadIdx.x >> 3;
   const SymOutBlock B = oblk[fin_blk[f]];
-  if(a >= B.nI) return;
   double s = 0.0;
-  for(int p = fin_ptr[f]; p < fin_ptr[f+1]; p++) s += part[(size_t)p*8 + a];
-  jtx[B.var0 + a] = s;
+  for(int p = fin_ptr[f] + g; p < fin_ptr[f+1]; p += 32) s += part[(size_t)p*8 + a];
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  if(g == 0 && a < B.nI)
+  {
+    double tot = 0.0;
+    for(int k = 0; k < 32; k++) tot += sh[k*8 + a];
+    jtx[B.var0 + a] = tot;
+  }
 }
 
 // --------------------------------------------------------------- K3 / K8 ---
@@ -201,15 +219,24 @@ __global__ void __launch_bounds__(TPB) k_norm2_Jv(const int* __restrict__ Jp,
 }
 
 // ------------------------------------------------------------------ K5 ------
-// factor one supernode panel per workgroup: dense Cholesky of the w x w diagonal
-// block + triangular solve of the rows below, right-looking, column by column.
-// USE_LDS: the panel is staged in LDS (panels up to PANEL_CAP doubles).
-template <bool USE_LDS>
-__global__ void __launch_bounds__(TPB) k_factor_level(const int* __restrict__ lvl_sn,
-                                                      const int* __restrict__ sn_c0,
-                                                      const int* __restrict__ sn_rowptr,
-                                                      const int64_t* __restrict__ sn_lx,
-                                                      double* __restrict__ Lx, int* __restrict__ info)
+// factor one supernode panel per workgroup: thread-per-row, left-looking over
+// column blocks of 8.
+//   (1) every thread brings the 8 block-column entries of its row(s) up to date
+//       against all previous columns: per previous column one own LDS read and
+//       the 8 entries of the block rows as 4 broadcast ds_read_b128 -> 8 FMAs;
+//   (2) barrier; every thread factors the 8x8 diagonal block redundantly in
+//       registers (no broadcast step, no extra barrier on the critical path);
+//   (3) barrier; forward substitution of the thread's row against the 8x8 factor.
+// 3 barriers per 8 columns instead of 2 per column, ~1.6 LDS reads per FMA
+// instead of 3.  Panel in LDS with an even leading dimension (16-B aligned
+// broadcast reads).  USE_LDS == false: panels larger than the LDS budget are
+// factored in place in HBM with the same code path (slow, rare).
+template <int NT, bool USE_LDS>
+__global__ void __launch_bounds__(NT) k_factor_level(const int* __restrict__ lvl_sn,
+                                                     const int* __restrict__ sn_c0,
+                                                     const int* __restrict__ sn_rowptr,
+                                                     const int64_t* __restrict__ sn_lx,
+                                                     double* __restrict__ Lx, int* __restrict__ info)
 {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int s = lvl_sn[blockIdx.x];
@@ -217,66 +244,209 @@ __global__ void __launch_bounds__(TPB) k_factor_level(const int* __restrict__ lv
   const int nrows = sn_rowptr[s+1] - sn_rowptr[s];
   double* G = Lx + sn_lx[s];
   const int tid = threadIdx.x;
-  const int total = nrows*w;
-  double* P;
+  const int ldp = USE_LDS ? ((nrows + 1) & ~1) : nrows;
+  double* P = USE_LDS ? lds : G;
   if(USE_LDS)
   {
-    P = lds;
-    for(int e = tid; e < total; e += TPB) P[e] = G[e];
+    for(int j = 0; j < w; j++)
+      for(int i = tid; i < nrows; i += NT) P[i + j*ldp] = G[i + (size_t)j*nrows];
+    __syncthreads();
   }
-  else P = G;
-  __syncthreads();
-  for(int j = 0; j < w; j++)
+  for(int kb = 0; kb < w; kb += 8)
   {
-    const double d = P[j + j*nrows];
-    __syncthreads();
-    const bool bad = !(d > 0.0);
-    if(bad && tid == 0) atomicMin(info, sn_c0[s] + j);
-    const double piv = bad ? 1.0 : sqrt(d);
-    const double inv = 1.0/piv;
-    if(tid == 0) P[j + j*nrows] = piv;
-    for(int i = j + 1 + tid; i < nrows; i += TPB) P[i + j*nrows] *= inv;
-    __syncthreads();
-    const int nc = w - j - 1, nr = nrows - j - 1;
-    for(int e = tid; e < nc*nr; e += TPB)
+    const int nb = (w - kb < 8) ? w - kb : 8;
+    // (1) left-looking update of the block columns
+    for(int r = kb + tid; r < nrows; r += NT)
     {
-      const int cc = e / nr, ii = e - cc*nr;
-      if(ii >= cc)
+      double x[8];
+#pragma unroll
+      for(int c = 0; c < 8; c++) x[c] = (c < nb) ? P[r + (kb + c)*ldp] : 0.0;
+      for(int k = 0; k < kb; k++)
       {
-        const int c = j + 1 + cc, i = j + 1 + ii;
-        P[i + c*nrows] -= P[i + j*nrows]*P[c + j*nrows];
+        const double a = P[r + k*ldp];
+        const double* bp = P + kb + k*ldp;
+        if(USE_LDS)
+        {
+          const double2 b0 = *reinterpret_cast<const double2*>(bp);
+          const double2 b1 = *reinterpret_cast<const double2*>(bp + 2);
+          const double2 b2 = *reinterpret_cast<const double2*>(bp + 4);
+          const double2 b3 = *reinterpret_cast<const double2*>(bp + 6);
+          x[0] -= a*b0.x; x[1] -= a*b0.y; x[2] -= a*b1.x; x[3] -= a*b1.y;
+          x[4] -= a*b2.x; x[5] -= a*b2.y; x[6] -= a*b3.x; x[7] -= a*b3.y;
+        }
+        else
+        {
+#pragma unroll
+          for(int c = 0; c < 8; c++) if(c < nb) x[c] -= a*bp[c];
+        }
+      }
+#pragma unroll
+      for(int c = 0; c < 8; c++) if(c < nb) P[r + (kb + c)*ldp] = x[c];
+    }
+    __syncthreads();
+    // (2) redundant 8x8 Cholesky in registers (identity-padded when nb < 8)
+    double D[8][8];
+#pragma unroll
+    for(int c = 0; c < 8; c++)
+#pragma unroll
+      for(int q = 0; q <= c; q++)
+        D[c][q] = (c < nb) ? P[(kb + c) + (kb + q)*ldp] : ((c == q) ? 1.0 : 0.0);
+    bool bad = false; int badcol = 0;
+#pragma unroll
+    for(int c = 0; c < 8; c++)
+    {
+      double d = D[c][c];
+#pragma unroll
+      for(int q = 0; q < c; q++) d -= D[c][q]*D[c][q];
+      if(!(d > 0.0)) { if(!bad) { bad = true; badcol = c; } d = 1.0; }
+      const double piv = sqrt(d);
+      D[c][c] = piv;
+      const double inv = 1.0/piv;
+#pragma unroll
+      for(int i = c + 1; i < 8; i++)
+      {
+        double v = D[i][c];
+#pragma unroll
+        for(int q = 0; q < c; q++) v -= D[i][q]*D[c][q];
+        D[i][c] = v*inv;
+      }
+    }
+    if(bad && tid == 0) atomicMin(info, sn_c0[s] + kb + badcol);
+    __syncthreads();
+    // (3) rows of the block take the factor; rows below solve against it
+    for(int r = kb + tid; r < nrows; r += NT)
+    {
+      if(r < kb + nb)
+      {
+        const int c = r - kb;
+#pragma unroll
+        for(int cc = 0; cc < 8; cc++)
+#pragma unroll
+          for(int q = 0; q <= cc; q++) if(cc == c) P[r + (kb + q)*ldp] = D[cc][q];
+      }
+      else
+      {
+        double x[8];
+#pragma unroll
+        for(int c = 0; c < 8; c++) x[c] = (c < nb) ? P[r + (kb + c)*ldp] : 0.0;
+#pragma unroll
+        for(int c = 0; c < 8; c++)
+        {
+          double v = x[c];
+#pragma unroll
+          for(int q = 0; q < c; q++) v -= x[q]*D[c][q];
+          x[c] = v/D[c][c];
+        }
+#pragma unroll
+        for(int c = 0; c < 8; c++) if(c < nb) P[r + (kb + c)*ldp] = x[c];
       }
     }
     __syncthreads();
   }
-  if(USE_LDS) for(int e = tid; e < total; e += TPB) G[e] = P[e];
+  if(USE_LDS)
+    for(int j = 0; j < w; j++)
+      for(int i = tid; i < nrows; i += NT) G[i + (size_t)j*nrows] = P[i + j*ldp];
+}
+
+// cooperative variant of the update for heavy sources (wide panels): the whole
+// workgroup works on one sub-task at a time, thread per source row, the nc x wd
+// block of the source rows that sit in the target columns staged in LDS.  The
+// target panel is updated in HBM; a barrier orders consecutive sub-tasks.
+__global__ void __launch_bounds__(TPB) k_update_coop(int unit0, const int* __restrict__ uw_item,
+                                                     const int* __restrict__ uw_s0,
+                                                     const int* __restrict__ uw_s1,
+                                                     const int64_t* __restrict__ uw_part,
+                                                     const int* __restrict__ ui_t,
+                                                     const int* __restrict__ ui_col,
+                                                     const int* __restrict__ ui_nc,
+                                                     const SymSub* __restrict__ usub,
+                                                     const int* __restrict__ relpos,
+                                                     const int* __restrict__ sn_rowptr,
+                                                     const int64_t* __restrict__ sn_lx,
+                                                     double* __restrict__ Lx,
+                                                     double* __restrict__ upart)
+{
+  __shared__ __attribute__((aligned(16))) double Bs[256*8];
+  const int unit = unit0 + blockIdx.x;
+  const int item = uw_item[unit];
+  const int t = ui_t[item], col = ui_col[item], nc = ui_nc[item];
+  const int nrows_t = sn_rowptr[t+1] - sn_rowptr[t];
+  const int s0 = uw_s0[unit], s1 = uw_s1[unit];
+  const int64_t part = uw_part[unit];
+  double* dst = (part < 0) ? (Lx + sn_lx[t] + (int64_t)col*nrows_t) : (upart + part);
+  const double sgn = (part < 0) ? -1.0 : 1.0;
+  const int tid = threadIdx.x;
+  if(part >= 0)
+  {
+    for(int e = tid; e < nrows_t*nc; e += TPB) dst[e] = 0.0;
+    __syncthreads();
+  }
+  for(int st = s0; st < s1; st++)
+  {
+    const SymSub U = usub[st];
+    const double* Ld = Lx + U.src;
+    const int* rel = relpos + U.rel;
+    const int ld = U.nrows_d;
+    for(int e = tid; e < U.wd*8; e += TPB)
+    {
+      const int c = e & 7, q = e >> 3;
+      Bs[e] = (c < nc) ? Ld[c + (size_t)q*ld] : 0.0;
+    }
+    __syncthreads();
+    for(int i = tid; i < U.m; i += TPB)
+    {
+      double sacc[8];
+#pragma unroll
+      for(int c = 0; c < 8; c++) sacc[c] = 0.0;
+      for(int q = 0; q < U.wd; q++)
+      {
+        const double ai = Ld[i + (size_t)q*ld];
+        const double2 b0 = *reinterpret_cast<const double2*>(&Bs[q*8]);
+        const double2 b1 = *reinterpret_cast<const double2*>(&Bs[q*8 + 2]);
+        const double2 b2 = *reinterpret_cast<const double2*>(&Bs[q*8 + 4]);
+        const double2 b3 = *reinterpret_cast<const double2*>(&Bs[q*8 + 6]);
+        sacc[0] += ai*b0.x; sacc[1] += ai*b0.y; sacc[2] += ai*b1.x; sacc[3] += ai*b1.y;
+        sacc[4] += ai*b2.x; sacc[5] += ai*b2.y; sacc[6] += ai*b3.x; sacc[7] += ai*b3.y;
+      }
+      const int cmax = (i < nc - 1) ? i : nc - 1;
+      const int r = rel[i];
+#pragma unroll
+      for(int c = 0; c < 8; c++) if(c <= cmax) dst[r + c*nrows_t] += sgn*sacc[c];
+    }
+    __syncthreads();
+  }
 }
 
 // apply the updates of all source supernodes of one level to their ancestors.
-// One workgroup per item = (target supernode t, one var-block of its columns).
-// NW waves each own a private LDS slab (nrows_t x nc) and process the item's
-// sub-tasks round-robin; the slabs are then summed in wave order and
-// subtracted from the target panel.  NW == 0: slab does not fit LDS; the whole
-// workgroup walks the sub-tasks in order, updating the panel in HBM.
-__global__ void __launch_bounds__(TPB) k_update_level(int item0, const int* __restrict__ ui_t,
+// One workgroup per work unit = a chunk of the sub-tasks of one item
+// (target supernode t, one var-block of its columns).  nw waves each own a
+// private LDS slab (nrows_t x nc) and walk the unit's sub-tasks round-robin;
+// the slabs are summed in wave order.  A single-chunk item subtracts the sum
+// from the target panel; a multi-chunk item (e.g. a dense last block that every
+// supernode updates) stores it as a partial slab for k_update_fin.
+// nw == 0: the slab does not fit LDS; the workgroup accumulates in HBM.
+__global__ void __launch_bounds__(TPB) k_update_level(int unit0, const int* __restrict__ uw_item,
+                                                      const int* __restrict__ uw_s0,
+                                                      const int* __restrict__ uw_s1,
+                                                      const int64_t* __restrict__ uw_part,
+                                                      const int* __restrict__ ui_t,
                                                       const int* __restrict__ ui_col,
                                                       const int* __restrict__ ui_nc,
-                                                      const int* __restrict__ ui_ptr,
-                                                      const int* __restrict__ ut_d,
-                                                      const int* __restrict__ ut_ka,
-                                                      const int* __restrict__ ut_rel,
+                                                      const SymSub* __restrict__ usub,
                                                       const int* __restrict__ relpos,
-                                                      const int* __restrict__ sn_c0,
                                                       const int* __restrict__ sn_rowptr,
                                                       const int64_t* __restrict__ sn_lx,
-                                                      double* __restrict__ Lx, int nw)
+                                                      double* __restrict__ Lx,
+                                                      double* __restrict__ upart, int nw)
 {
   extern __shared__ __attribute__((aligned(16))) double lds[];
-  const int item = item0 + blockIdx.x;
+  const int unit = unit0 + blockIdx.x;
+  const int item = uw_item[unit];
   const int t = ui_t[item], col = ui_col[item], nc = ui_nc[item];
   const int nrows_t = sn_rowptr[t+1] - sn_rowptr[t];
   double* Lt = Lx + sn_lx[t] + (int64_t)col*nrows_t;
-  const int s0 = ui_ptr[item], s1 = ui_ptr[item+1];
+  const int s0 = uw_s0[unit], s1 = uw_s1[unit];
+  const int64_t part = uw_part[unit];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int slab = nrows_t*nc;
 
@@ -284,26 +454,32 @@ __global__ void __launch_bounds__(TPB) k_update_level(int item0, const int* __re
   {
     for(int e = tid; e < slab*nw; e += TPB) lds[e] = 0.0;
     __syncthreads();
-    if(w < nw)
+    if(w < nw && s0 + w < s1)
     {
       double* acc = lds + (size_t)w*slab;
+      SymSub cur = usub[s0 + w];
       for(int st = s0 + w; st < s1; st += nw)
       {
-        const int d = ut_d[st], ka = ut_ka[st];
-        const int* rel = relpos + ut_rel[st];
-        const int nrows_d = sn_rowptr[d+1] - sn_rowptr[d];
-        const int wd = sn_c0[d+1] - sn_c0[d];
-        const double* Ld = Lx + sn_lx[d] + ka;
-        const int m = nrows_d - ka;
-        for(int e = lane; e < m*nc; e += 64)
+        const SymSub U = cur;
+        if(st + nw < s1) cur = usub[st + nw];          // prefetch the next record
+        const double* Ld = Lx + U.src;
+        const int* rel = relpos + U.rel;
+        const int ld = U.nrows_d;
+        for(int i = lane; i < U.m; i += 64)
         {
-          const int c = e / m, i = e - c*m;
-          if(i >= c)
+          const int cmax = (i < nc - 1) ? i : nc - 1;
+          double sacc[8];
+#pragma unroll
+          for(int c = 0; c < 8; c++) sacc[c] = 0.0;
+          for(int q = 0; q < U.wd; q++)
           {
-            double sacc = 0.0;
-            for(int q = 0; q < wd; q++) sacc += Ld[i + (size_t)q*nrows_d]*Ld[c + (size_t)q*nrows_d];
-            acc[rel[i] + c*nrows_t] += sacc;
+            const double ai = Ld[i + (size_t)q*ld];
+#pragma unroll
+            for(int c = 0; c < 8; c++) if(c <= cmax) sacc[c] += ai*Ld[c + (size_t)q*ld];
           }
+          const int r = rel[i];
+#pragma unroll
+          for(int c = 0; c < 8; c++) if(c <= cmax) acc[r + c*nrows_t] += sacc[c];
         }
       }
     }
@@ -312,36 +488,66 @@ __global__ void __launch_bounds__(TPB) k_update_level(int item0, const int* __re
     {
       double tot = 0.0;
       for(int k = 0; k < nw; k++) tot += lds[(size_t)k*slab + e];
-      Lt[e] -= tot;
+      if(part < 0) Lt[e] -= tot; else upart[part + e] = tot;
     }
   }
   else
   {
+    double* dst = (part < 0) ? Lt : upart + part;
+    const double sgn = (part < 0) ? -1.0 : 1.0;
+    if(part >= 0) { for(int e = tid; e < slab; e += TPB) dst[e] = 0.0; __syncthreads(); }
     for(int st = s0; st < s1; st++)
     {
-      const int d = ut_d[st], ka = ut_ka[st];
-      const int* rel = relpos + ut_rel[st];
-      const int nrows_d = sn_rowptr[d+1] - sn_rowptr[d];
-      const int wd = sn_c0[d+1] - sn_c0[d];
-      const double* Ld = Lx + sn_lx[d] + ka;
-      const int m = nrows_d - ka;
-      for(int e = tid; e < m*nc; e += TPB)
+      const SymSub U = usub[st];
+      const double* Ld = Lx + U.src;
+      const int* rel = relpos + U.rel;
+      const int ld = U.nrows_d;
+      for(int i = tid; i < U.m; i += TPB)
       {
-        const int c = e / m, i = e - c*m;
-        if(i >= c)
+        const int cmax = (i < nc - 1) ? i : nc - 1;
+        const int r = rel[i];
+        for(int c = 0; c <= cmax; c++)
         {
           double sacc = 0.0;
-          for(int q = 0; q < wd; q++) sacc += Ld[i + (size_t)q*nrows_d]*Ld[c + (size_t)q*nrows_d];
-          Lt[rel[i] + c*nrows_t] -= sacc;
+          for(int q = 0; q < U.wd; q++) sacc += Ld[i + (size_t)q*ld]*Ld[c + (size_t)q*ld];
+          dst[r + c*nrows_t] += sgn*sacc;
         }
       }
       __syncthreads();
     }
   }
 }
+// sum the partial slabs of a multi-chunk item in chunk order and apply them
+__global__ void __launch_bounds__(TPB) k_update_fin(int f0, const int* __restrict__ uf_item,
+                                                    const int* __restrict__ uf_n,
+                                                    const int64_t* __restrict__ uf_off,
+                                                    const int* __restrict__ ui_t,
+                                                    const int* __restrict__ ui_col,
+                                                    const int* __restrict__ ui_nc,
+                                                    const int* __restrict__ sn_rowptr,
+                                                    const int64_t* __restrict__ sn_lx,
+                                                    double* __restrict__ Lx,
+                                                    const double* __restrict__ upart)
+{
+  const int f = f0 + blockIdx.x;
+  const int item = uf_item[f], n = uf_n[f];
+  const int t = ui_t[item], col = ui_col[item], nc = ui_nc[item];
+  const int nrows_t = sn_rowptr[t+1] - sn_rowptr[t];
+  double* Lt = Lx + sn_lx[t] + (int64_t)col*nrows_t;
+  const int slab = nrows_t*nc;
+  const double* src = upart + uf_off[f];
+  for(int e = threadIdx.x; e < slab; e += TPB)
+  {
+    double tot = 0.0;
+    for(int k = 0; k < n; k++) tot += src[(size_t)k*slab + e];
+    Lt[e] -= tot;
+  }
+}
 
 // ------------------------------------------------------------------ K6 ------
-// forward: per supernode  y_t = L_tt^-1 (P b - gathered updates);  u_t = L_below y_t
+// forward: per supernode  y_t = L_tt^-1 (P b - gathered updates);  u_t = L_below y_t.
+// The diagonal block is staged in LDS (odd leading dimension); the column sweep
+// keeps y_i in a register and needs one barrier per column.
 __global__ void __launch_bounds__(TPB) k_solve_fwd_level(const int* __restrict__ lvl_sn,
                                                          const int* __restrict__ sn_c0,
                                                          const int* __restrict__ sn_rowptr,
@@ -355,29 +561,60 @@ __global__ void __launch_bounds__(TPB) k_solve_fwd_level(const int* __restrict__
                                                          double* __restrict__ scr,
                                                          double* __restrict__ ywork)
 {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
   __shared__ double y[256];
+  __shared__ double red[4];
   const int s = lvl_sn[blockIdx.x];
   const int c0 = sn_c0[s], w = sn_c0[s+1] - c0;
   const int nrows = sn_rowptr[s+1] - sn_rowptr[s];
   const double* L = Lx + sn_lx[s];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  for(int j = wv; j < w; j += TPB/64)
-  {
-    const int k = c0 + j;
-    double sum = 0.0;
-    for(int e = rl_ptr[k] + lane; e < rl_ptr[k+1]; e += 64) sum += scr[rl_pos[e]];
-    sum = wave_sum(sum);
-    if(lane == 0) y[j] = rhs[perm[k]] - sum;
-  }
-  __syncthreads();
+  const int ldp = w | 1;
+  // stage the diagonal block
+  for(int e = tid; e < w*w; e += TPB) { const int i = e % w, j = e / w; lds[i + j*ldp] = L[i + (size_t)j*nrows]; }
+  // gather: long lists (a dense last block is fed by every supernode) use the whole workgroup
   for(int j = 0; j < w; j++)
   {
-    if(tid == 0) y[j] = y[j] / L[j + (size_t)j*nrows];
-    __syncthreads();
-    const double yj = y[j];
-    for(int i = j + 1 + tid; i < w; i += TPB) y[i] -= L[i + (size_t)j*nrows]*yj;
-    __syncthreads();
+    const int k = c0 + j;
+    const int e0 = rl_ptr[k], e1 = rl_ptr[k+1];
+    if(e1 - e0 >= 2048)
+    {
+      double sum = 0.0;
+      int e = e0 + tid;
+      for(; e + 7*TPB < e1; e += 8*TPB)         // 8 independent gathers in flight per thread
+      {
+        int pz[8]; double vz[8];
+#pragma unroll
+        for(int u = 0; u < 8; u++) pz[u] = rl_pos[e + u*TPB];
+#pragma unroll
+        for(int u = 0; u < 8; u++) vz[u] = scr[pz[u]];
+#pragma unroll
+        for(int u = 0; u < 8; u++) sum += vz[u];
+      }
+      for(; e < e1; e += TPB) sum += scr[rl_pos[e]];
+      sum = wave_sum(sum);
+      __syncthreads();
+      if(lane == 0) red[wv] = sum;
+      __syncthreads();
+      if(tid == 0) y[j] = rhs[perm[k]] - ((red[0] + red[1]) + (red[2] + red[3]));
+    }
+    else if((j & 3) == wv)
+    {
+      double sum = 0.0;
+      for(int e = e0 + lane; e < e1; e += 64) sum += scr[rl_pos[e]];
+      sum = wave_sum(sum);
+      if(lane == 0) y[j] = rhs[perm[k]] - sum;
+    }
   }
+  __syncthreads();
+  double yi = (tid < w) ? y[tid] : 0.0;
+  for(int j = 0; j < w; j++)
+  {
+    if(tid == j) y[j] = yi / lds[j + j*ldp];
+    __syncthreads();
+    if(tid > j && tid < w) yi -= lds[tid + j*ldp]*y[j];
+  }
+  __syncthreads();
   for(int j = tid; j < w; j += TPB) ywork[c0 + j] = y[j];
   const int r = nrows - w;
   double* u = scr + sn_scr[s];
@@ -399,6 +636,7 @@ __global__ void __launch_bounds__(TPB) k_solve_bwd_level(const int* __restrict__
                                                          double* __restrict__ ywork,
                                                          double* __restrict__ out)
 {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
   __shared__ double xs[256];
   const int s = lvl_sn[blockIdx.x];
   const int c0 = sn_c0[s], w = sn_c0[s+1] - c0;
@@ -407,6 +645,8 @@ __global__ void __launch_bounds__(TPB) k_solve_bwd_level(const int* __restrict__
   const double* L = Lx + sn_lx[s];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int r = nrows - w;
+  const int ldp = w | 1;
+  for(int e = tid; e < w*w; e += TPB) { const int i = e % w, j = e / w; lds[i + j*ldp] = L[i + (size_t)j*nrows]; }
   for(int j = wv; j < w; j += TPB/64)
   {
     const double* Lj = L + (size_t)j*nrows + w;
@@ -416,14 +656,14 @@ __global__ void __launch_bounds__(TPB) k_solve_bwd_level(const int* __restrict__
     if(lane == 0) xs[j] = ywork[c0 + j] - sum;
   }
   __syncthreads();
+  double xi = (tid < w) ? xs[tid] : 0.0;
   for(int j = w - 1; j >= 0; j--)
   {
-    if(tid == 0) xs[j] = xs[j] / L[j + (size_t)j*nrows];
+    if(tid == j) xs[j] = xi / lds[j + j*ldp];
     __syncthreads();
-    const double xj = xs[j];
-    for(int i = tid; i < j; i += TPB) xs[i] -= L[j + (size_t)i*nrows]*xj;
-    __syncthreads();
+    if(tid < j) xi -= lds[j + tid*ldp]*xs[j];
   }
+  __syncthreads();
   for(int j = tid; j < w; j += TPB) { ywork[c0 + j] = xs[j]; out[perm[c0 + j]] = xs[j]; }
 }
 
@@ -459,7 +699,8 @@ int sparse_set_pattern(dlg_backend* b, const int* colptr, const int* rowidx)
   { dlg_set_error("symbolic analysis: %s", err); return DLG_ERR_ARG; }
   SymHost& H = Y->H;
   UP(sn_c0); UP(sn_rowptr); UP(sn_rows); UP(sn_scr); UP(lvl_sn); UP(sn_lx); UP(diagpos);
-  UP(ui_t); UP(ui_col); UP(ui_nc); UP(ui_ptr); UP(ut_d); UP(ut_ka); UP(ut_rel); UP(relpos);
+  UP(ui_t); UP(ui_col); UP(ui_nc); UP(ui_ptr); UP(usub); UP(relpos);
+  UP(uw_item); UP(uw_s0); UP(uw_s1); UP(uw_part); UP(uf_item); UP(uf_n); UP(uf_off);
   UP(oblk); UP(contrib); UP(asm_task); UP(jtx_task);
   UP(asm_fin_ptr); UP(asm_fin_blk); UP(jtx_fin_ptr); UP(jtx_fin_blk);
   UP(rl_ptr); UP(rl_pos); UP(perm);
@@ -478,6 +719,7 @@ int sparse_set_pattern(dlg_backend* b, const int* colptr, const int* rowidx)
   DLG_CHECK(dalloc(Y->Lx, (size_t)H.lx_size));
   DLG_CHECK(dalloc(Y->scr, (size_t)H.scr_size));
   DLG_CHECK(dalloc(Y->ywork, (size_t)H.N));
+  DLG_CHECK(dalloc(Y->upart, (size_t)H.upart_size));
   DLG_CHECK(dalloc(Y->asm_part, (size_t)H.asm_nparts*64));
   DLG_CHECK(dalloc(Y->jtx_part, (size_t)H.jtx_nparts*8));
   DLG_HIP(hipMalloc(&Y->d_info, sizeof(int))); Y->allocs.push_back(Y->d_info);
@@ -485,16 +727,25 @@ int sparse_set_pattern(dlg_backend* b, const int* colptr, const int* rowidx)
 
   // per-level launch parameters
   Y->fac_lds.assign(H.nlevels, 0); Y->upd_lds.assign(H.nlevels, 0); Y->upd_nw.assign(H.nlevels, 0);
+  Y->slv_lds.assign(H.nlevels, 0); Y->fac_nt.assign(H.nlevels, 512); Y->upd_coop.assign(H.nlevels, 0);
   for(int l = 0; l < H.nlevels; l++)
   {
-    long maxp = 0;
+    long maxp = 0, maxw = 0, maxr = 0;
     for(int i = H.lvl_ptr[l]; i < H.lvl_ptr[l+1]; i++)
     {
       const int s = H.lvl_sn[i];
-      const long p = (long)(H.sn_rowptr[s+1] - H.sn_rowptr[s])*(H.sn_c0[s+1] - H.sn_c0[s]);
+      const long wv = H.sn_c0[s+1] - H.sn_c0[s];
+      const long nr = H.sn_rowptr[s+1] - H.sn_rowptr[s];
+      const long p = ((nr + 1) & ~1L)*wv;        // even leading dimension in LDS
       if(p > maxp) maxp = p;
+      if(wv > maxw) maxw = wv;
+      if(nr > maxr) maxr = nr;
     }
-    Y->fac_lds[l] = (maxp*8 <= LDS_BUDGET) ? (int)(maxp*8) : 0;
+    Y->fac_nt[l] = (maxr <= 128) ? 128 : 512;
+    Y->upd_coop[l] = (maxw > 8) ? 1 : 0;           // heavy sources: cooperative update kernel
+    Y->slv_lds[l] = (int)(maxw*(maxw | 1)*8);
+    if(Y->slv_lds[l] > LDS_BUDGET) { dlg_set_error("supernode of width %ld is too wide for the solve kernels", maxw); return DLG_ERR_ARG; }
+    Y->fac_lds[l] = (maxp*8 <= LDS_BUDGET - 4096) ? (int)(maxp*8) : 0;
     long maxslab = 0;
     for(int it = H.ui_lvl_ptr[l]; it < H.ui_lvl_ptr[l+1]; it++)
     {
@@ -507,9 +758,15 @@ int sparse_set_pattern(dlg_backend* b, const int* colptr, const int* rowidx)
     Y->upd_nw[l] = nw;
     Y->upd_lds[l] = (int)(maxslab*8*nw);
   }
-  DLG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_factor_level<true>),
+  DLG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_factor_level<128, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BUDGET));
+  DLG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_factor_level<512, true>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BUDGET));
   DLG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_update_level),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BUDGET));
+  DLG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_solve_fwd_level),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BUDGET));
+  DLG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_solve_bwd_level),
                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BUDGET));
   return DLG_OK;
 }
@@ -541,7 +798,7 @@ int sparse_eval(dlg_backend* b, int s)
                        Y->oblk, Y->contrib, S.Jin(), S.xin(), S.Jt_x, Y->jtx_part);
   const int nf = (int)H.jtx_fin_blk.size();
   if(nf > 0)
-    hipLaunchKernelGGL(k_jtx_fin, dim3(dlg_cdiv((long)nf*8, TPB)), dim3(TPB), 0, b->stream,
+    hipLaunchKernelGGL(k_jtx_fin, dim3(nf), dim3(TPB), 0, b->stream,
                        Y->jtx_fin_ptr, Y->jtx_fin_blk, nf, Y->oblk, Y->jtx_part, S.Jt_x);
   DLG_LAUNCH_CHECK();
   return DLG_OK;
@@ -571,22 +828,29 @@ int sparse_factorize(dlg_backend* b, int s, double lambda, int* ok)
   const SymHost& H = Y->H;
   hipStream_t st = b->stream;
   // --- K4: JtJ straight into the supernode panels
-  DLG_HIP(hipMemsetAsync(Y->Lx, 0, sizeof(double)*(size_t)H.lx_size, st));
-  const int nt = (int)H.asm_task.size();
-  if(nt > 0)
-    hipLaunchKernelGGL(k_assemble, dim3(dlg_cdiv(nt, TPB/64)), dim3(TPB), 0, st, Y->asm_task, nt,
-                       Y->oblk, Y->contrib, S.Jin(), Y->Lx, Y->asm_part);
-  const int nf = (int)H.asm_fin_blk.size();
-  if(nf > 0)
-    hipLaunchKernelGGL(k_assemble_fin, dim3(dlg_cdiv(nf, TPB/64)), dim3(TPB), 0, st, Y->asm_fin_ptr,
-                       Y->asm_fin_blk, nf, Y->oblk, Y->asm_part, Y->Lx);
-  DLG_LAUNCH_CHECK();
+  {
+    DlgProfScope pt(b, DLG_PROF_K4_TOTAL);
+    DLG_HIP(hipMemsetAsync(Y->Lx, 0, sizeof(double)*(size_t)H.lx_size, st));
+    const int nt = (int)H.asm_task.size();
+    if(nt > 0)
+    {
+      DlgProfScope pk(b, DLG_PROF_K4_KERNEL);
+      hipLaunchKernelGGL(k_assemble, dim3(dlg_cdiv(nt, TPB/64)), dim3(TPB), 0, st, Y->asm_task, nt,
+                         Y->oblk, Y->contrib, S.Jin(), Y->Lx, Y->asm_part);
+    }
+    const int nf = (int)H.asm_fin_blk.size();
+    if(nf > 0)
+      hipLaunchKernelGGL(k_assemble_fin, dim3(nf), dim3(1024), 0, st, Y->asm_fin_ptr,
+                         Y->asm_fin_blk, nf, Y->oblk, Y->asm_part, Y->Lx);
+    DLG_LAUNCH_CHECK();
+  }
   // rows are sharded: sum the partial JtJ of all ranks before factorising
   DLG_CHECK(dlg_allreduce_dev(b, Y->Lx, (size_t)H.lx_size));
   if(lambda != 0.0)
     hipLaunchKernelGGL(k_add_lambda, dim3(dlg_cdiv(H.N, TPB)), dim3(TPB), 0, st, Y->Lx, Y->diagpos, H.N,
                        lambda);
   // --- K5: level-scheduled supernodal Cholesky
+  DlgProfScope pf(b, DLG_PROF_K5_FACTOR);
   *Y->h_info = 0x7fffffff;
   DLG_HIP(hipMemcpyAsync(Y->d_info, Y->h_info, sizeof(int), hipMemcpyHostToDevice, st));
   for(int l = 0; l < H.nlevels; l++)
@@ -594,21 +858,34 @@ int sparse_factorize(dlg_backend* b, int s, double lambda, int* ok)
     const int n = H.lvl_ptr[l+1] - H.lvl_ptr[l];
     if(n > 0)
     {
-      if(Y->fac_lds[l] > 0)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_factor_level<true>), dim3(n), dim3(TPB), Y->fac_lds[l], st,
+      if(Y->fac_lds[l] > 0 && Y->fac_nt[l] == 128)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_factor_level<128, true>), dim3(n), dim3(128), Y->fac_lds[l], st,
+                           Y->lvl_sn + H.lvl_ptr[l], Y->sn_c0, Y->sn_rowptr, Y->sn_lx, Y->Lx, Y->d_info);
+      else if(Y->fac_lds[l] > 0)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_factor_level<512, true>), dim3(n), dim3(512), Y->fac_lds[l], st,
                            Y->lvl_sn + H.lvl_ptr[l], Y->sn_c0, Y->sn_rowptr, Y->sn_lx, Y->Lx, Y->d_info);
       else
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_factor_level<false>), dim3(n), dim3(TPB), 0, st,
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_factor_level<512, false>), dim3(n), dim3(512), 0, st,
                            Y->lvl_sn + H.lvl_ptr[l], Y->sn_c0, Y->sn_rowptr, Y->sn_lx, Y->Lx, Y->d_info);
     }
-    const int ni = H.ui_lvl_ptr[l+1] - H.ui_lvl_ptr[l];
-    if(ni > 0)
-      hipLaunchKernelGGL(k_update_level, dim3(ni), dim3(TPB), Y->upd_lds[l], st, H.ui_lvl_ptr[l],
-                         Y->ui_t, Y->ui_col, Y->ui_nc, Y->ui_ptr, Y->ut_d, Y->ut_ka, Y->ut_rel,
-                         Y->relpos, Y->sn_c0, Y->sn_rowptr, Y->sn_lx, Y->Lx, Y->upd_nw[l]);
+    const int nu = H.uw_lvl_ptr[l+1] - H.uw_lvl_ptr[l];
+    if(nu > 0 && Y->upd_coop[l])
+      hipLaunchKernelGGL(k_update_coop, dim3(nu), dim3(TPB), 0, st, H.uw_lvl_ptr[l],
+                         Y->uw_item, Y->uw_s0, Y->uw_s1, Y->uw_part, Y->ui_t, Y->ui_col, Y->ui_nc,
+                         Y->usub, Y->relpos, Y->sn_rowptr, Y->sn_lx, Y->Lx, Y->upart);
+    else if(nu > 0)
+      hipLaunchKernelGGL(k_update_level, dim3(nu), dim3(TPB), Y->upd_lds[l], st, H.uw_lvl_ptr[l],
+                         Y->uw_item, Y->uw_s0, Y->uw_s1, Y->uw_part, Y->ui_t, Y->ui_col, Y->ui_nc,
+                         Y->usub, Y->relpos, Y->sn_rowptr, Y->sn_lx, Y->Lx, Y->upart, Y->upd_nw[l]);
+    const int nfz = H.uf_lvl_ptr[l+1] - H.uf_lvl_ptr[l];
+    if(nfz > 0)
+      hipLaunchKernelGGL(k_update_fin, dim3(nfz), dim3(TPB), 0, st, H.uf_lvl_ptr[l], Y->uf_item, Y->uf_n,
+                         Y->uf_off, Y->ui_t, Y->ui_col, Y->ui_nc, Y->sn_rowptr, Y->sn_lx, Y->Lx,
+                         Y->upart);
   }
   DLG_LAUNCH_CHECK();
   DLG_HIP(hipMemcpyAsync(Y->h_info, Y->d_info, sizeof(int), hipMemcpyDeviceToHost, st));
+  if(pf.e) { dlg_prof_end(b, pf.id, pf.e); pf.e = nullptr; }
   DLG_HIP(hipStreamSynchronize(st));
   *ok = (*Y->h_info == 0x7fffffff);
   return DLG_OK;
@@ -625,7 +902,7 @@ int sparse_solve(dlg_backend* b, const double* rhs, double* out)
   {
     const int n = H.lvl_ptr[l+1] - H.lvl_ptr[l];
     if(n > 0)
-      hipLaunchKernelGGL(k_solve_fwd_level, dim3(n), dim3(TPB), 0, st, Y->lvl_sn + H.lvl_ptr[l],
+      hipLaunchKernelGGL(k_solve_fwd_level, dim3(n), dim3(TPB), Y->slv_lds[l], st, Y->lvl_sn + H.lvl_ptr[l],
                          Y->sn_c0, Y->sn_rowptr, Y->sn_lx, Y->sn_scr, Y->rl_ptr, Y->rl_pos, Y->perm,
                          Y->Lx, rhs, Y->scr, Y->ywork);
   }
@@ -633,7 +910,7 @@ int sparse_solve(dlg_backend* b, const double* rhs, double* out)
   {
     const int n = H.lvl_ptr[l+1] - H.lvl_ptr[l];
     if(n > 0)
-      hipLaunchKernelGGL(k_solve_bwd_level, dim3(n), dim3(TPB), 0, st, Y->lvl_sn + H.lvl_ptr[l],
+      hipLaunchKernelGGL(k_solve_bwd_level, dim3(n), dim3(TPB), Y->slv_lds[l], st, Y->lvl_sn + H.lvl_ptr[l],
                          Y->sn_c0, Y->sn_rowptr, Y->sn_rows, Y->sn_lx, Y->perm, Y->Lx, Y->ywork, out);
   }
   DLG_LAUNCH_CHECK();
@@ -652,7 +929,7 @@ extern "C" int dlg_sparse_symbolic_probe(int N, int M, const int* colptr, const 
   const long v[] = { (long)H.nvb, (long)H.nsn, (long)H.nlevels, (long)H.nnz_JtJ_lower, (long)H.nnz_L,
                      (long)H.lx_size, (long)H.factor_flops, (long)H.max_panel, (long)H.asm_task.size(),
                      (long)H.ui_t.size(), (long)H.relpos.size(), (long)H.oblk.size(),
-                     (long)H.contrib.size(), (long)H.ut_d.size(), (long)H.scr_size,
+                     (long)H.contrib.size(), (long)H.usub.size(), (long)H.scr_size,
                      (long)H.jtx_task.size() };
   for(int i = 0; i < nstats && i < (int)(sizeof(v)/sizeof(v[0])); i++) stats[i] = v[i];
   if(perm_out) memcpy(perm_out, H.perm.data(), sizeof(int)*(size_t)N);

@@ -12,8 +12,11 @@ namespace {
 
 constexpr int VB_MAX   = 8;       // max variables per var-block (<= 64 lanes per 8x8 output block)
 constexpr int RB_MAX   = 8;       // max rows per row-block
-constexpr int CH_ASM   = 64;      // contributions per assembly wave-task
+constexpr int CH_ASM   = 64;      // contributions per assembly wave-task (more when a list is very long)
 constexpr int CH_JTX   = 512;     // contributions per Jt*x wave-task
+constexpr int MAXCH_ASM = 4096;   // at most this many partials per output block
+constexpr int MAXCH_JTX = 2048;
+constexpr int UCH      = 512;     // update sub-tasks per work unit
 constexpr int PANEL_CAP = 16384;  // doubles: supernode panels up to this size are factored in LDS
 constexpr int SN_WMAX  = 256;     // max supernode width
 
@@ -601,6 +604,7 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
       return a.d < b.d; });
     S.ui_lvl_ptr.assign(S.nlevels + 1, 0);
     S.ui_ptr.push_back(0);
+    std::vector<int> item_lvl;
     for(size_t i = 0; i < subs.size(); i++)
     {
       const Sub& u = subs[i];
@@ -612,11 +616,60 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
         S.ui_col.push_back(colstart[u.q] - S.sn_c0[u.t]);
         S.ui_nc.push_back(G.w[border[u.q]]);
         S.ui_lvl_ptr[u.lvl + 1]++;
+        item_lvl.push_back(u.lvl);
       }
-      S.ut_d.push_back(u.d); S.ut_ka.push_back(u.ka); S.ut_rel.push_back(u.rel);
+      const int nrows_d = S.sn_rowptr[u.d+1] - S.sn_rowptr[u.d];
+      SymSub ss;
+      ss.src = S.sn_lx[u.d] + u.ka; ss.rel = u.rel; ss.nrows_d = nrows_d;
+      ss.wd = S.sn_c0[u.d+1] - S.sn_c0[u.d]; ss.m = nrows_d - u.ka;
+      S.usub.push_back(ss);
     }
     if(!subs.empty()) S.ui_ptr.push_back((int)subs.size());
     for(int l = 0; l < S.nlevels; l++) S.ui_lvl_ptr[l+1] += S.ui_lvl_ptr[l];
+    // work units
+    S.uw_lvl_ptr.assign(S.nlevels + 1, 0); S.uf_lvl_ptr.assign(S.nlevels + 1, 0);
+    S.upart_size = 0;
+    const int nitems = (int)S.ui_t.size();
+    // chunking by estimated cost: a light sub-task (narrow source) counts 1, a
+    // heavy one counts by its thread-iterations; a unit is closed at UNIT_COST
+    const int unit_cost = env_int("DOGLEG_AMD_UNIT_COST", 512);
+    std::vector<int> cuts;
+    for(int it = 0; it < nitems; it++)
+    {
+      const int s0 = S.ui_ptr[it], s1 = S.ui_ptr[it+1];
+      const int lvl = item_lvl[it];
+      const int t = S.ui_t[it];
+      const int64_t slab = (int64_t)(S.sn_rowptr[t+1] - S.sn_rowptr[t])*S.ui_nc[it];
+      cuts.clear(); cuts.push_back(s0);
+      long acc = 0;
+      for(int st = s0; st < s1; st++)
+      {
+        const SymSub& u = S.usub[st];
+        const long c = (u.wd <= 8) ? 1 : 64 + (long)u.wd*((u.m + 255)/256);
+        if(acc > 0 && acc + c > unit_cost) { cuts.push_back(st); acc = 0; }
+        acc += c;
+      }
+      cuts.push_back(s1);
+      const int nch = (int)cuts.size() - 1;
+      if(nch <= 1)
+      {
+        S.uw_item.push_back(it); S.uw_s0.push_back(s0); S.uw_s1.push_back(s1); S.uw_part.push_back(-1);
+        S.uw_lvl_ptr[lvl + 1]++;
+      }
+      else
+      {
+        S.uf_item.push_back(it); S.uf_n.push_back(nch); S.uf_off.push_back(S.upart_size);
+        S.uf_lvl_ptr[lvl + 1]++;
+        for(int k = 0; k < nch; k++)
+        {
+          S.uw_item.push_back(it); S.uw_s0.push_back(cuts[k]); S.uw_s1.push_back(cuts[k+1]);
+          S.uw_part.push_back(S.upart_size + (int64_t)k*slab);
+          S.uw_lvl_ptr[lvl + 1]++;
+        }
+        S.upart_size += (int64_t)nch*slab;
+      }
+    }
+    for(int l = 0; l < S.nlevels; l++) { S.uw_lvl_ptr[l+1] += S.uw_lvl_ptr[l]; S.uf_lvl_ptr[l+1] += S.uf_lvl_ptr[l]; }
   }
 
   // ------------------------------------------- 9. assembly / Jt*x lists
@@ -698,13 +751,15 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
     }
     const int nblk = (int)S.oblk.size();
     // wave-tasks
-    auto make_tasks = [&](int nb, int chunk, std::vector<SymTask>& tasks, std::vector<int>& fin_ptr,
-                          std::vector<int>& fin_blk, int& nparts) {
+    auto make_tasks = [&](int nb, int chunk0, int maxch, std::vector<SymTask>& tasks,
+                          std::vector<int>& fin_ptr, std::vector<int>& fin_blk, int& nparts) {
       nparts = 0; fin_ptr.clear(); fin_blk.clear(); fin_ptr.push_back(0);
       for(int b = 0; b < nb; b++)
       {
         const int c0 = cptr[b], c1 = cptr[b+1];
         if(c1 == c0) continue;
+        int chunk = chunk0;
+        if((c1 - c0 + chunk - 1)/chunk > maxch) chunk = (c1 - c0 + maxch - 1)/maxch;
         const int nch = (c1 - c0 + chunk - 1)/chunk;
         if(nch == 1) tasks.push_back({b, c0, c1, -1});
         else
@@ -716,8 +771,8 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
         }
       }
     };
-    make_tasks(nblk, CH_ASM, S.asm_task, S.asm_fin_ptr, S.asm_fin_blk, S.asm_nparts);
-    make_tasks(nvb,  CH_JTX, S.jtx_task, S.jtx_fin_ptr, S.jtx_fin_blk, S.jtx_nparts);
+    make_tasks(nblk, CH_ASM, MAXCH_ASM, S.asm_task, S.asm_fin_ptr, S.asm_fin_blk, S.asm_nparts);
+    make_tasks(nvb,  CH_JTX, MAXCH_JTX, S.jtx_task, S.jtx_fin_ptr, S.jtx_fin_blk, S.jtx_nparts);
   }
 
   // --------------------------------------- 10. forward-solve gather lists

@@ -44,6 +44,18 @@ struct SymOutBlock
 };
 static_assert(sizeof(SymOutBlock) == 24, "SymOutBlock layout");
 
+// one factor-update sub-task: the rows [ka, nrows_d) of source panel d update
+// one var-block of columns of a target panel
+struct SymSub
+{
+  int64_t src;       // Lx offset of source panel element (row ka, col 0)
+  int32_t rel;       // index into relpos of the entry for row ka
+  int32_t nrows_d;   // leading dimension of the source panel
+  int32_t wd;        // columns of the source panel
+  int32_t m;         // nrows_d - ka
+};
+static_assert(sizeof(SymSub) == 24, "SymSub layout");
+
 // a wave-task: contributions [c0,c1) of block blk; part >= 0: write the partial
 // into slot `part` of the partial buffer instead of the destination
 struct SymTask { int32_t blk, c0, c1, part; };
@@ -76,8 +88,16 @@ struct SymHost
   // ---- factor update schedule (per source level)
   std::vector<int> ui_lvl_ptr;       // [nlevels+1] into items
   std::vector<int> ui_t, ui_col, ui_nc, ui_ptr;   // items: target, first local col, #cols, subtask range [ni+1]
-  std::vector<int> ut_d, ut_ka, ut_rel;           // subtasks: source snode, first row index in d, relpos index of row ka
+  std::vector<SymSub> usub;          // sub-tasks, grouped by item
   std::vector<int> relpos;           // row positions in the target panel
+  // work units = chunks of an item's sub-tasks (long lists, e.g. a dense last block, are split)
+  std::vector<int> uw_lvl_ptr;       // [nlevels+1] into units
+  std::vector<int> uw_item, uw_s0, uw_s1;
+  std::vector<int64_t> uw_part;      // offset into the partial-slab buffer, or -1: apply directly
+  std::vector<int> uf_lvl_ptr;       // [nlevels+1] into finalize entries
+  std::vector<int> uf_item, uf_n;    // item, number of partial slabs
+  std::vector<int64_t> uf_off;       // offset of the first partial slab
+  int64_t upart_size = 0;
   // ---- assembly / Jt*x
   std::vector<SymOutBlock> oblk;     // output blocks (diagonal blocks of every var-block first: [0,nvb))
   std::vector<SymContrib>  contrib;

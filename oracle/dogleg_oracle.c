@@ -917,3 +917,73 @@ double orc_optimize_dense_products(double* p, unsigned int Nstate,
 {
   return optimize_common(p, Nstate, 0, 0, NULL, NULL, f, cookie, parameters, trace);
 }
+
+/* ======================================================================== */
+/* fixed-input trial step (CPU baseline unit for bench.py)                   */
+/* ======================================================================== */
+static void step_tail(int N, const double* g, const double* cauchy, double n2c, double* gn,
+                      const double* p, double* step, double* pnew, double* out)
+{
+  for(int i = 0; i < N; i++) gn[i] *= -1.0;
+  const double n2gn = orc_norm2(gn, N);
+  const double tr = 0.5*(sqrt(n2c) + sqrt(n2gn));
+  const double dsq = tr*tr;
+  double l2 = 0.0, neg_c = 0.0;
+  for(int i = 0; i < N; i++) { const double d = cauchy[i] - gn[i]; l2 += d*d; neg_c += d*cauchy[i]; }
+  double disc = neg_c*neg_c - l2*(n2c - dsq);
+  if(disc < 0.0) disc = 0.0;
+  const double k = (neg_c + sqrt(disc))/l2;
+  double n2s = 0.0, amax = 0.0, gmax = 0.0;
+  for(int i = 0; i < N; i++)
+  {
+    step[i] = cauchy[i] + k*(gn[i] - cauchy[i]);
+    n2s += step[i]*step[i];
+    pnew[i] = p[i] + step[i];
+    if(fabs(step[i]) > amax) amax = fabs(step[i]);
+    if(fabs(g[i]) > gmax) gmax = fabs(g[i]);
+  }
+  out[2] = n2gn; out[3] = k; out[4] = n2s; out[6] = gmax; out[7] = amax;
+}
+
+int orc_step_sparse(orc_sparse_factor_t* F, int N, int M, const int* Jp, const int* Ji,
+                    const double* Jx, const double* x, const double* p, double lambda,
+                    double* work, double* out)
+{
+  double *g = work, *cauchy = work + N, *gn = work + 2*(size_t)N, *step = work + 3*(size_t)N,
+         *pnew = work + 4*(size_t)N;
+  orc_spmv_Jt_x(g, N, M, Jp, Ji, Jx, x);
+  out[0] = orc_norm2(x, M);
+  const double g2 = orc_norm2(g, N);
+  const double Jg2 = orc_norm2_J_v(M, Jp, Ji, Jx, g);
+  const double kc = -g2/Jg2;
+  out[1] = kc*kc*g2;
+  for(int i = 0; i < N; i++) cauchy[i] = kc*g[i];
+  if(orc_sparse_factorize(F, Jp, Ji, Jx, lambda) != N) return 1;
+  orc_sparse_solve(F, g, gn);
+  step_tail(N, g, cauchy, out[1], gn, p, step, pnew, out);
+  out[5] = -2.0*orc_inner(g, step, N) - orc_norm2_J_v(M, Jp, Ji, Jx, step);
+  return 0;
+}
+
+int orc_step_dense(int N, int M, const double* J, const double* x, const double* p, double lambda,
+                   double* dfac, double* work, double* out)
+{
+  double *g = work, *cauchy = work + N, *gn = work + 2*(size_t)N, *step = work + 3*(size_t)N,
+         *pnew = work + 4*(size_t)N;
+  orc_dense_Jt_x(g, J, x, M, N);
+  out[0] = orc_norm2(x, M);
+  const double g2 = orc_norm2(g, N);
+  const double Jg2 = orc_dense_norm2_J_v(J, g, M, N);
+  const double kc = -g2/Jg2;
+  out[1] = kc*kc*g2;
+  for(int i = 0; i < N; i++) cauchy[i] = kc*g[i];
+  memset(dfac, 0, sizeof(double)*(size_t)N*(N+1)/2);
+  orc_dense_JtJ_packed_upper(dfac, J, M, N);
+  if(lambda > 0.0) { size_t k = 0; for(int i1 = 0; i1 < N; i1++) { dfac[k] += lambda; k += N-i1; } }
+  if(orc_dpptrf_L(N, dfac) != 0) return 1;
+  memcpy(gn, g, sizeof(double)*(size_t)N);
+  orc_dpptrs_L(N, dfac, gn);
+  step_tail(N, g, cauchy, out[1], gn, p, step, pnew, out);
+  out[5] = -2.0*orc_inner(g, step, N) - orc_dense_norm2_J_v(J, step, M, N);
+  return 0;
+}

@@ -76,6 +76,21 @@ long   orc_sparse_nnzL(const orc_sparse_factor_t* F);
 double orc_sparse_flops(const orc_sparse_factor_t* F);
 void   orc_sparse_free(orc_sparse_factor_t* F);
 
+/* ---- one full trial step on fixed inputs: the unit bench.py times as the CPU
+ * baseline.  Same op sequence as a step that refactorises and interpolates
+ * (dogleg.c:1025-1027, 529-617, 634-820, 822-908, 927-998, 1259, 1085-1165):
+ * Jt_x, norm2_x, Cauchy, JtJ + Cholesky, GN solve, dog-leg interpolation at
+ * trustregion = mean(|cauchy|,|gn|), p_new, expected improvement.
+ * work: 5*N doubles.  out[8] = {norm2_x, norm2_cauchy, norm2_gn, k, norm2_step,
+ * expected_improvement, max|Jt_x|, max|step|}.  Returns 0, or >0 if JtJ is not
+ * positive definite. */
+int orc_step_sparse(orc_sparse_factor_t* F, int N, int M, const int* Jp, const int* Ji,
+                    const double* Jx, const double* x, const double* p, double lambda,
+                    double* work, double* out);
+/* dense: dfac = N(N+1)/2 doubles scratch */
+int orc_step_dense(int N, int M, const double* J, const double* x, const double* p, double lambda,
+                   double* dfac, double* work, double* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -78,6 +78,10 @@ def oracle():
         L.orc_sparse_flops.restype = C.c_double
         L.orc_sparse_flops.argtypes = [V]
         L.orc_sparse_free.argtypes = [V]
+        L.orc_step_sparse.restype = C.c_int
+        L.orc_step_sparse.argtypes = [V, C.c_int, C.c_int, I, I, D, D, D, C.c_double, D, D]
+        L.orc_step_dense.restype = C.c_int
+        L.orc_step_dense.argtypes = [C.c_int, C.c_int, D, D, D, C.c_double, D, D, D]
         _libs["o"] = L
     return _libs["o"]
 
