@@ -143,6 +143,8 @@ def main():
         lam = 0.0
         while not ok:                                # the reference's lambda loop (dogleg.c:656-677)
             lam = 1e-10 if lam == 0.0 else lam * 10
+            if lam > 1e30:
+                raise SystemExit("factorisation keeps failing: giving up")
             ok = be.factorize(0, lam)
         n2g = be.solve_gn(0)                         # K6
         tr = 0.5 * (n2c ** 0.5 + n2g ** 0.5)

@@ -30,6 +30,22 @@ __device__ __forceinline__ double wave_sum(double v)
   return v;
 }
 
+// copy `total` doubles with U independent global loads in flight per thread before
+// the first dependent store (a plain load->store loop keeps ONE load in flight and
+// pays a full memory latency per iteration)
+template <int NT, int U, class LoadF, class StoreF>
+__device__ __forceinline__ void batched_copy(int total, int tid, LoadF ld, StoreF st)
+{
+  for(int base = 0; base < total; base += U*NT)
+  {
+    double v[U];
+#pragma unroll
+    for(int u = 0; u < U; u++) { const int idx = base + u*NT + tid; v[u] = (idx < total) ? ld(idx) : 0.0; }
+#pragma unroll
+    for(int u = 0; u < U; u++) { const int idx = base + u*NT + tid; if(idx < total) st(idx, v[u]); }
+  }
+}
+
 template <class T> int upload(T*& dev, const std::vector<T>& h)
 {
   dev = nullptr;
@@ -248,8 +264,8 @@ __global__ void __launch_bounds__(NT) k_factor_level(const int* __restrict__ lvl
   double* P = USE_LDS ? lds : G;
   if(USE_LDS)
   {
-    for(int j = 0; j < w; j++)
-      for(int i = tid; i < nrows; i += NT) P[i + j*ldp] = G[i + (size_t)j*nrows];
+    batched_copy<NT, 8>(nrows*w, tid, [&](int e) { return G[e]; },
+                        [&](int e, double v) { const int j = e / nrows; P[e + j*(ldp - nrows)] = v; });
     __syncthreads();
   }
   for(int kb = 0; kb < w; kb += 8)
@@ -344,8 +360,7 @@ __global__ void __launch_bounds__(NT) k_factor_level(const int* __restrict__ lvl
     __syncthreads();
   }
   if(USE_LDS)
-    for(int j = 0; j < w; j++)
-      for(int i = tid; i < nrows; i += NT) G[i + (size_t)j*nrows] = P[i + j*ldp];
+    for(int e = tid; e < nrows*w; e += NT) { const int j = e / nrows; G[e] = P[e + j*(ldp - nrows)]; }
 }
 
 // cooperative variant of the update for heavy sources (wide panels): the whole
@@ -387,17 +402,16 @@ __global__ void __launch_bounds__(TPB) k_update_coop(int unit0, const int* __res
     const double* Ld = Lx + U.src;
     const int* rel = relpos + U.rel;
     const int ld = U.nrows_d;
-    for(int e = tid; e < U.wd*8; e += TPB)
-    {
-      const int c = e & 7, q = e >> 3;
-      Bs[e] = (c < nc) ? Ld[c + (size_t)q*ld] : 0.0;
-    }
+    batched_copy<TPB, 8>(U.wd*8, tid,
+                         [&](int e) { const int c = e & 7, q = e >> 3; return (c < nc) ? Ld[c + (size_t)q*ld] : 0.0; },
+                         [&](int e, double v) { Bs[e] = v; });
     __syncthreads();
     for(int i = tid; i < U.m; i += TPB)
     {
       double sacc[8];
 #pragma unroll
       for(int c = 0; c < 8; c++) sacc[c] = 0.0;
+#pragma unroll 4
       for(int q = 0; q < U.wd; q++)
       {
         const double ai = Ld[i + (size_t)q*ld];
@@ -571,7 +585,8 @@ __global__ void __launch_bounds__(TPB) k_solve_fwd_level(const int* __restrict__
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int ldp = w | 1;
   // stage the diagonal block
-  for(int e = tid; e < w*w; e += TPB) { const int i = e % w, j = e / w; lds[i + j*ldp] = L[i + (size_t)j*nrows]; }
+  batched_copy<TPB, 8>(w*w, tid, [&](int e) { const int j = e / w; return L[(e - j*w) + (size_t)j*nrows]; },
+                       [&](int e, double v) { const int j = e / w; lds[(e - j*w) + j*ldp] = v; });
   // gather: long lists (a dense last block is fed by every supernode) use the whole workgroup
   for(int j = 0; j < w; j++)
   {
@@ -621,6 +636,7 @@ __global__ void __launch_bounds__(TPB) k_solve_fwd_level(const int* __restrict__
   for(int i = tid; i < r; i += TPB)
   {
     double sum = 0.0;
+#pragma unroll 8
     for(int j = 0; j < w; j++) sum += L[w + i + (size_t)j*nrows]*y[j];
     u[i] = sum;
   }
@@ -646,11 +662,13 @@ __global__ void __launch_bounds__(TPB) k_solve_bwd_level(const int* __restrict__
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int r = nrows - w;
   const int ldp = w | 1;
-  for(int e = tid; e < w*w; e += TPB) { const int i = e % w, j = e / w; lds[i + j*ldp] = L[i + (size_t)j*nrows]; }
+  batched_copy<TPB, 8>(w*w, tid, [&](int e) { const int j = e / w; return L[(e - j*w) + (size_t)j*nrows]; },
+                       [&](int e, double v) { const int j = e / w; lds[(e - j*w) + j*ldp] = v; });
   for(int j = wv; j < w; j += TPB/64)
   {
     const double* Lj = L + (size_t)j*nrows + w;
     double sum = 0.0;
+#pragma unroll 4
     for(int i = lane; i < r; i += 64) sum += Lj[i]*ywork[rows[w + i]];
     sum = wave_sum(sum);
     if(lane == 0) xs[j] = ywork[c0 + j] - sum;

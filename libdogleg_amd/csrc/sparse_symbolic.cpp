@@ -395,9 +395,12 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
   // --------------------------------- 5. block-level symbolic factorisation
   std::vector<std::vector<int>> st(nvb);   // struct of block column (positions > j), sorted
   std::vector<int> parent(nvb, -1);
-  {
+  std::vector<int> nchild(nvb, 0);
+  auto symbolic = [&]() {
     std::vector<int> head(nvb, -1), next(nvb, -1), mark(nvb, -1);
     std::vector<int> tmp;
+    std::fill(parent.begin(), parent.end(), -1);
+    std::fill(nchild.begin(), nchild.end(), 0);
     for(int j = 0; j < nvb; j++)
     {
       tmp.clear();
@@ -414,7 +417,51 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
       }
       std::sort(tmp.begin(), tmp.end());
       st[j] = tmp;
-      if(!tmp.empty()) { parent[j] = tmp[0]; next[j] = head[tmp[0]]; head[tmp[0]] = j; }
+      if(!tmp.empty()) { parent[j] = tmp[0]; next[j] = head[tmp[0]]; head[tmp[0]] = j; nchild[tmp[0]]++; }
+    }
+  };
+  symbolic();
+  // Leaves of the elimination tree with IDENTICAL structure (e.g. the points seen by
+  // the same set of cameras) are independent of each other; placed next to each other
+  // they form one supernode with a block-diagonal top -> far fewer, wider panels
+  // (rank-k updates instead of k rank-3 ones).  Moving a leaf earlier is always a
+  // valid elimination order.
+  if(env_int("DOGLEG_AMD_GROUP_LEAVES", 1))
+  {
+    std::vector<int> leaves;
+    for(int j = 0; j < nvb; j++) if(nchild[j] == 0 && !st[j].empty()) leaves.push_back(j);
+    std::sort(leaves.begin(), leaves.end(), [&](int x, int y) {
+      if(st[x] != st[y]) return st[x] < st[y];
+      return x < y; });
+    std::vector<int> group_of(nvb, -1), group_first;
+    std::vector<std::vector<int>> members;
+    for(size_t i = 0; i < leaves.size();)
+    {
+      size_t k = i + 1;
+      while(k < leaves.size() && st[leaves[k]] == st[leaves[i]]) k++;
+      if(k - i > 1)
+      {
+        std::vector<int> m(leaves.begin() + i, leaves.begin() + k);      // ascending positions
+        for(int x : m) group_of[x] = (int)members.size();
+        members.push_back(m);
+      }
+      i = k;
+    }
+    if(!members.empty())
+    {
+      std::vector<int> nb; nb.reserve(nvb);
+      std::vector<char> done(members.size(), 0);
+      for(int j = 0; j < nvb; j++)
+      {
+        const int g = group_of[j];
+        if(g < 0) { nb.push_back(border[j]); continue; }
+        if(done[g]) continue;
+        done[g] = 1;
+        for(int x : members[g]) nb.push_back(border[x]);
+      }
+      border.swap(nb);
+      for(int k = 0; k < nvb; k++) bpos[border[k]] = k;
+      symbolic();
     }
   }
   std::vector<long> stw(nvb, 0);          // scalar weight of struct
@@ -455,6 +502,17 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
         {
           merge = true;
           W = Wn; true_nnz = tn; below_own = own_after;
+        }
+      }
+      if(!merge && j + 1 < nvb && nchild[j] == 0 && nchild[j+1] == 0 && !st[j].empty() && st[j] == st[j+1])
+      {
+        // sibling leaves with identical structure: block-diagonal top, same rows below
+        const long w1 = G.w[border[j+1]];
+        const long Wn = W + w1, Rn = stw[j+1];
+        if(Wn <= 64 && (Wn + Rn)*Wn <= PANEL_CAP)
+        {
+          merge = true;
+          true_nnz += w1*stw[j+1]; below_own += W*w1; W = Wn;
         }
       }
       if(!merge && j + 1 < nvb)
