@@ -71,6 +71,7 @@ struct dlg_backend
 
   // dense / products
   double* G = nullptr;        // N x N column-major, lower triangle = factor
+  double* Linv = nullptr;     // inverses of the 64x64 diagonal blocks of the factor
   double* slabs = nullptr;    // split-K partial slabs for the SYRK
   size_t  slabs_bytes = 0;
   int*    d_info = nullptr;

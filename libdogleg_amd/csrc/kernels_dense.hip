@@ -20,6 +20,7 @@
 // directly with i = state index, k = measurement row: for a fixed row the 128
 // state entries of a tile are contiguous -> coalesced 512-B wave loads.
 #include "dlg_internal.h"
+#include "panel_factor.h"
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
@@ -315,107 +316,99 @@ __global__ void __launch_bounds__(TPB) k_syrk_reduce(double* __restrict__ C, int
 }
 
 // --------------------------------------------------------------- potrf ------
+// Blocked right-looking Cholesky, NB = 64:
+//   k_potrf_diag_inv : one workgroup factors the 64x64 diagonal block in LDS
+//                      (panel_factor.h) and also forms its inverse Linv (64 columns in
+//                      parallel, forward substitution in LDS);
+//   k_trsm_gemm      : the rows below become X = A * Linv^T (a small GEMM, fully
+//                      parallel) instead of a 64-step substitution per row;
+//   k_syrk_lower     : fp64-MFMA trailing update.
+// The Linv blocks are kept (nblk x 64 x 64): the triangular solves of K6 use them as
+// 64x64 mat-vecs, so no kernel on the solve path has a serial 64-step loop either.
 constexpr int NB = 64;
 
-// factor the nb x nb diagonal block at (kb,kb) in LDS; info = first bad pivot (1-based, global)
-__global__ void __launch_bounds__(TPB) k_potrf_diag(double* __restrict__ A, int lda, int kb, int nb,
-                                                    int* __restrict__ info)
+__global__ void __launch_bounds__(TPB) k_potrf_diag_inv(double* __restrict__ A, int lda, int kb,
+                                                        int nb, int* __restrict__ info,
+                                                        double* __restrict__ Linv)
 {
-  __shared__ double L[NB][NB + 1];
+  // rows 0..63: the diagonal block; rows 64..127: the identity.  Factoring the
+  // 128 x 64 panel leaves L in the top block and L^-T in the bottom block (the
+  // row solve X L^T = I), i.e. the inverse comes out of the same sweep.
+  __shared__ __attribute__((aligned(16))) double P[2*NB*NB];
+  __shared__ int sbad;
   const int t = threadIdx.x;
-  for(int e = t; e < nb*nb; e += TPB)
-  {
-    const int i = e % nb, j = e / nb;
-    L[i][j] = (i >= j) ? A[(size_t)(kb + j)*lda + kb + i] : 0.0;
-  }
-  __syncthreads();
-  for(int j = 0; j < nb; j++)
-  {
-    // column j: pivot
-    const double d = L[j][j];
-    __syncthreads();
-    if(!(d > 0.0))
-    {
-      if(t == 0 && *info == 0) *info = kb + j + 1;
-      // keep going with a harmless pivot so that later kernels do not trap on NaN storms
-    }
-    const double piv = (d > 0.0) ? sqrt(d) : 1.0;
-    const double inv = 1.0/piv;
-    if(t == 0) L[j][j] = piv;
-    for(int i = j + 1 + t; i < nb; i += TPB) L[i][j] *= inv;
-    __syncthreads();
-    // trailing update of the remaining columns (lower part)
-    const int m = nb - j - 1;
-    for(int e = t; e < m*m; e += TPB)
-    {
-      const int ii = j + 1 + e % m, jj = j + 1 + e / m;
-      if(ii >= jj) L[ii][jj] -= L[ii][j]*L[jj][j];
-    }
-    __syncthreads();
-  }
-  for(int e = t; e < nb*nb; e += TPB)
-  {
-    const int i = e % nb, j = e / nb;
-    if(i >= j) A[(size_t)(kb + j)*lda + kb + i] = L[i][j];
-  }
-}
-
-// rows below the diagonal block: X L_kk^T = A_panel, one thread per row.  The
-// block is padded to NB x NB with an identity tail so the substitution is a
-// fully unrolled register-resident loop; L entries are LDS broadcasts.
-__global__ void __launch_bounds__(TPB) k_trsm_panel(double* __restrict__ A, int lda, int kb, int nb,
-                                                    int n)
-{
-  __shared__ double L[NB][NB + 1];
-  const int t = threadIdx.x;
+  constexpr int LD = 2*NB;
   for(int e = t; e < NB*NB; e += TPB)
   {
     const int i = e % NB, j = e / NB;
-    double v = (i == j) ? 1.0 : 0.0;
-    if(i < nb && j < nb && i >= j) v = A[(size_t)(kb + j)*lda + kb + i];
-    L[i][j] = v;
+    double v = (i == j) ? 1.0 : 0.0;                          // identity padding of a short last block
+    if(i < nb && j < nb) v = (i >= j) ? A[(size_t)(kb + j)*lda + kb + i] : 0.0;
+    P[i + j*LD] = v;
+    P[NB + i + j*LD] = (i == j) ? 1.0 : 0.0;
+  }
+  if(t == 0) sbad = 0x7fffffff;
+  __syncthreads();
+  panel_factor<TPB, true>(P, LD, 2*NB, NB, t, &sbad, 0);
+  if(t == 0) { const int bad = sbad; if(bad < nb && *info == 0) *info = kb + bad + 1; }
+  for(int e = t; e < NB*NB; e += TPB)
+  {
+    const int i = e % NB, j = e / NB;
+    if(i < nb && j < nb && i >= j) A[(size_t)(kb + j)*lda + kb + i] = P[i + j*LD];
+    Linv[e] = (i >= j) ? P[NB + j + i*LD] : 0.0;              // Linv(i,j) = (L^-T)(j,i)
+  }
+}
+
+// X = A_panel * Linv^T for the rows r >= kb+nb; one workgroup per 64 rows.
+__global__ void __launch_bounds__(TPB) k_trsm_gemm(double* __restrict__ A, int lda, int kb, int nb,
+                                                   int n, const double* __restrict__ Linv)
+{
+  __shared__ double As[NB][NB + 1];      // As[r][k]
+  __shared__ double Ls[NB][NB + 1];      // Ls[c][k] = Linv[c][k]
+  const int t = threadIdx.x;
+  const int r0 = kb + nb + blockIdx.x*NB;
+  for(int e = t; e < NB*NB; e += TPB)
+  {
+    const int i = e % NB, k = e / NB;     // i fastest: coalesced along rows of A and Linv
+    const int r = r0 + i;
+    As[i][k] = (r < n && k < nb) ? A[(size_t)(kb + k)*lda + r] : 0.0;
+    Ls[i][k] = Linv[e];
   }
   __syncthreads();
-  const int r = kb + nb + blockIdx.x*TPB + t;
-  if(r >= n) return;
-  double xr[NB];
+  const int rl = t & 63, cg = t >> 6;
+  const int r = r0 + rl;
+  double out[16];
 #pragma unroll
-  for(int j = 0; j < NB; j++) xr[j] = (j < nb) ? A[(size_t)(kb + j)*lda + r] : 0.0;
-#pragma unroll
-  for(int j = 0; j < NB; j++)
+  for(int cc = 0; cc < 16; cc++)
   {
-    const double xj = xr[j] / L[j][j];
-    xr[j] = xj;
-#pragma unroll
-    for(int k = j + 1; k < NB; k++) xr[k] -= xj*L[k][j];
+    const int c = cg*16 + cc;
+    double sacc = 0.0;
+    for(int k = 0; k <= c; k++) sacc += As[rl][k]*Ls[c][k];
+    out[cc] = sacc;
   }
+  if(r < n)
+  {
 #pragma unroll
-  for(int j = 0; j < NB; j++) if(j < nb) A[(size_t)(kb + j)*lda + r] = xr[j];
+    for(int cc = 0; cc < 16; cc++)
+    {
+      const int c = cg*16 + cc;
+      if(c < nb) A[(size_t)(kb + c)*lda + r] = out[cc];
+    }
+  }
 }
 
 // ------------------------------------------------------------- trsv ---------
-// forward: solve the nb x nb diagonal block (single workgroup, serial in LDS)
-__global__ void __launch_bounds__(64) k_trsv_diag_fwd(const double* __restrict__ A, int lda, int kb,
-                                                      int nb, double* __restrict__ y)
+// forward, diagonal block: y_blk = Linv * b_blk
+__global__ void __launch_bounds__(64) k_trsv_diag_fwd(const double* __restrict__ Linv, int kb, int nb,
+                                                      double* __restrict__ y)
 {
-  __shared__ double L[NB][NB + 1];
   __shared__ double v[NB];
   const int t = threadIdx.x;
-  for(int e = t; e < nb*nb; e += 64)
-  {
-    const int i = e % nb, j = e / nb;
-    L[i][j] = (i >= j) ? A[(size_t)(kb + j)*lda + kb + i] : 0.0;
-  }
-  if(t < nb) v[t] = y[kb + t];
+  v[t] = (t < nb) ? y[kb + t] : 0.0;
   __syncthreads();
-  for(int j = 0; j < nb; j++)
-  {
-    if(t == j) v[j] = v[j] / L[j][j];
-    __syncthreads();
-    if(t > j && t < nb) v[t] -= L[t][j]*v[j];
-    __syncthreads();
-  }
-  if(t < nb) y[kb + t] = v[t];
+  double sacc = 0.0;
+#pragma unroll 8
+  for(int k = 0; k < NB; k++) sacc += Linv[t + k*NB]*v[k];   // Linv is zero above the diagonal
+  if(t < nb) y[kb + t] = sacc;
 }
 // y[i] -= sum_{k in block} L[i,k] y[k]  for i >= kb+nb
 __global__ void __launch_bounds__(TPB) k_trsv_update_fwd(const double* __restrict__ A, int lda,
@@ -428,31 +421,24 @@ __global__ void __launch_bounds__(TPB) k_trsv_update_fwd(const double* __restric
   const int i = kb + nb + blockIdx.x*TPB + threadIdx.x;
   if(i >= n) return;
   double s = 0;
+#pragma unroll 8
   for(int k = 0; k < nb; k++) s += A[(size_t)(kb + k)*lda + i]*v[k];
   y[i] -= s;
 }
-// backward: L^T x = y
-__global__ void __launch_bounds__(64) k_trsv_diag_bwd(const double* __restrict__ A, int lda, int kb,
-                                                      int nb, double* __restrict__ y)
+// backward, diagonal block: x_blk = Linv^T * y_blk
+__global__ void __launch_bounds__(64) k_trsv_diag_bwd(const double* __restrict__ Linv, int kb, int nb,
+                                                      double* __restrict__ y)
 {
-  __shared__ double L[NB][NB + 1];
   __shared__ double v[NB];
+  __shared__ double Ls[NB][NB + 1];
   const int t = threadIdx.x;
-  for(int e = t; e < nb*nb; e += 64)
-  {
-    const int i = e % nb, j = e / nb;
-    L[i][j] = (i >= j) ? A[(size_t)(kb + j)*lda + kb + i] : 0.0;
-  }
-  if(t < nb) v[t] = y[kb + t];
+  v[t] = (t < nb) ? y[kb + t] : 0.0;
+#pragma unroll 8
+  for(int k = 0; k < NB; k++) Ls[t][k] = Linv[t + k*NB];     // Ls[i][k] = Linv[i][k]
   __syncthreads();
-  for(int j = nb - 1; j >= 0; j--)
-  {
-    if(t == j) v[j] = v[j] / L[j][j];
-    __syncthreads();
-    if(t < j) v[t] -= L[j][t]*v[j];
-    __syncthreads();
-  }
-  if(t < nb) y[kb + t] = v[t];
+  double sacc = 0.0;
+  for(int k = 0; k < NB; k++) sacc += Ls[k][t]*v[k];          // (Linv^T)[t][k] = Linv[k][t]
+  if(t < nb) y[kb + t] = sacc;
 }
 // x[i] -= sum_{k in block} L[k,i] x[k]  for i < kb   (one wave per i; column i is contiguous)
 __global__ void __launch_bounds__(TPB) k_trsv_update_bwd(const double* __restrict__ A, int lda,
@@ -545,16 +531,17 @@ int launch_syrk(hipStream_t st, double* C, int ldc, const double* A, int lda, in
   return DLG_OK;
 }
 
-int potrf_lower(hipStream_t st, double* A, int lda, int n, int* info_dev)
+int potrf_lower(hipStream_t st, double* A, int lda, int n, int* info_dev, double* Linv)
 {
-  for(int kb = 0; kb < n; kb += NB)
+  for(int kb = 0, blk = 0; kb < n; kb += NB, blk++)
   {
     const int nb = (n - kb < NB) ? n - kb : NB;
-    hipLaunchKernelGGL(k_potrf_diag, dim3(1), dim3(TPB), 0, st, A, lda, kb, nb, info_dev);
+    double* Li = Linv + (size_t)blk*NB*NB;
+    hipLaunchKernelGGL(k_potrf_diag_inv, dim3(1), dim3(TPB), 0, st, A, lda, kb, nb, info_dev, Li);
     const int rem = n - kb - nb;
     if(rem > 0)
     {
-      hipLaunchKernelGGL(k_trsm_panel, dim3(dlg_cdiv(rem, TPB)), dim3(TPB), 0, st, A, lda, kb, nb, n);
+      hipLaunchKernelGGL(k_trsm_gemm, dim3(dlg_cdiv(rem, NB)), dim3(TPB), 0, st, A, lda, kb, nb, n, Li);
       // trailing: C = A[kb+nb:, kb+nb:], panel P[i,k] = A[(kb+k)*lda + kb+nb+i]
       double* Cc = A + (size_t)(kb + nb)*lda + (kb + nb);
       const double* P = A + (size_t)kb*lda + (kb + nb);
@@ -587,11 +574,14 @@ int dense_create(dlg_backend* b)
   }
   DLG_HIP(hipMalloc(&b->d_info, sizeof(int)));
   DLG_HIP(hipHostMalloc(&b->h_info, sizeof(int)));
+  DLG_HIP(hipMalloc(&b->Linv, sizeof(double)*(size_t)dlg_cdiv(b->N, NB)*NB*NB));
   return DLG_OK;
 }
 void dense_destroy(dlg_backend* b)
 {
   if(b->G) (void)hipFree(b->G);
+  if(b->Linv) (void)hipFree(b->Linv);
+  b->Linv = nullptr;
   if(b->slabs) (void)hipFree(b->slabs);
   if(b->d_info) (void)hipFree(b->d_info);
   if(b->h_info) (void)hipHostFree(b->h_info);
@@ -672,7 +662,7 @@ int dense_factorize(dlg_backend* b, int s, double lambda, int* ok)
   // K5
   {
     DlgProfScope pf(b, DLG_PROF_K5_FACTOR);
-    DLG_CHECK(potrf_lower(b->stream, b->G, b->N, b->N, b->d_info));
+    DLG_CHECK(potrf_lower(b->stream, b->G, b->N, b->N, b->d_info, b->Linv));
   }
   return finish_potrf(b, ok);
 }
@@ -688,7 +678,7 @@ int products_factorize(dlg_backend* b, int s, double lambda, int* ok)
   hipLaunchKernelGGL(k_unpack_to_G, dim3(dlg_cdiv((long)nn, TPB)), dim3(TPB), 0, b->stream, S.Jin(),
                      b->N, packed ? 1 : 0, lambda, b->G);
   DLG_LAUNCH_CHECK();
-  DLG_CHECK(potrf_lower(b->stream, b->G, b->N, b->N, b->d_info));
+  DLG_CHECK(potrf_lower(b->stream, b->G, b->N, b->N, b->d_info, b->Linv));
   return finish_potrf(b, ok);
 }
 
@@ -697,10 +687,10 @@ int dense_solve(dlg_backend* b, const double* rhs, double* out)
 {
   const int n = b->N;
   if(out != rhs) DLG_HIP(hipMemcpyAsync(out, rhs, sizeof(double)*(size_t)n, hipMemcpyDeviceToDevice, b->stream));
-  for(int kb = 0; kb < n; kb += NB)
+  for(int kb = 0, blk = 0; kb < n; kb += NB, blk++)
   {
     const int nb = (n - kb < NB) ? n - kb : NB;
-    hipLaunchKernelGGL(k_trsv_diag_fwd, dim3(1), dim3(64), 0, b->stream, b->G, n, kb, nb, out);
+    hipLaunchKernelGGL(k_trsv_diag_fwd, dim3(1), dim3(64), 0, b->stream, b->Linv + (size_t)blk*NB*NB, kb, nb, out);
     const int rem = n - kb - nb;
     if(rem > 0)
       hipLaunchKernelGGL(k_trsv_update_fwd, dim3(dlg_cdiv(rem, TPB)), dim3(TPB), 0, b->stream, b->G, n,
@@ -711,7 +701,7 @@ int dense_solve(dlg_backend* b, const double* rhs, double* out)
   {
     const int kb = blk*NB;
     const int nb = (n - kb < NB) ? n - kb : NB;
-    hipLaunchKernelGGL(k_trsv_diag_bwd, dim3(1), dim3(64), 0, b->stream, b->G, n, kb, nb, out);
+    hipLaunchKernelGGL(k_trsv_diag_bwd, dim3(1), dim3(64), 0, b->stream, b->Linv + (size_t)blk*NB*NB, kb, nb, out);
     if(kb > 0)
       hipLaunchKernelGGL(k_trsv_update_bwd, dim3(dlg_cdiv(kb, 4)), dim3(TPB), 0, b->stream, b->G, n, kb,
                          nb, out);
@@ -732,7 +722,12 @@ extern "C" int dlg_kernel_syrk_lower(void* hip_stream, double* C_dev, int ldc, c
 }
 extern "C" int dlg_kernel_potrf_lower(void* hip_stream, double* A_dev, int lda, int n, int* info_dev)
 {
-  return potrf_lower((hipStream_t)hip_stream, A_dev, lda, n, info_dev);
+  double* Linv = nullptr;
+  DLG_HIP(hipMalloc(&Linv, sizeof(double)*(size_t)dlg_cdiv(n, NB)*NB*NB));
+  const int rc = potrf_lower((hipStream_t)hip_stream, A_dev, lda, n, info_dev, Linv);
+  (void)hipStreamSynchronize((hipStream_t)hip_stream);
+  (void)hipFree(Linv);
+  return rc;
 }
 extern "C" int dlg_factor_download_dense(dlg_backend_t* b, double* host, size_t n)
 {

@@ -17,6 +17,7 @@
 // JtJ is assembled straight into those panels (no separate JtJ array).
 #include "dlg_internal.h"
 #include "sparse_symbolic.h"
+#include "panel_factor.h"
 
 namespace {
 
@@ -268,97 +269,7 @@ __global__ void __launch_bounds__(NT) k_factor_level(const int* __restrict__ lvl
                         [&](int e, double v) { const int j = e / nrows; P[e + j*(ldp - nrows)] = v; });
     __syncthreads();
   }
-  for(int kb = 0; kb < w; kb += 8)
-  {
-    const int nb = (w - kb < 8) ? w - kb : 8;
-    // (1) left-looking update of the block columns
-    for(int r = kb + tid; r < nrows; r += NT)
-    {
-      double x[8];
-#pragma unroll
-      for(int c = 0; c < 8; c++) x[c] = (c < nb) ? P[r + (kb + c)*ldp] : 0.0;
-      for(int k = 0; k < kb; k++)
-      {
-        const double a = P[r + k*ldp];
-        const double* bp = P + kb + k*ldp;
-        if(USE_LDS)
-        {
-          const double2 b0 = *reinterpret_cast<const double2*>(bp);
-          const double2 b1 = *reinterpret_cast<const double2*>(bp + 2);
-          const double2 b2 = *reinterpret_cast<const double2*>(bp + 4);
-          const double2 b3 = *reinterpret_cast<const double2*>(bp + 6);
-          x[0] -= a*b0.x; x[1] -= a*b0.y; x[2] -= a*b1.x; x[3] -= a*b1.y;
-          x[4] -= a*b2.x; x[5] -= a*b2.y; x[6] -= a*b3.x; x[7] -= a*b3.y;
-        }
-        else
-        {
-#pragma unroll
-          for(int c = 0; c < 8; c++) if(c < nb) x[c] -= a*bp[c];
-        }
-      }
-#pragma unroll
-      for(int c = 0; c < 8; c++) if(c < nb) P[r + (kb + c)*ldp] = x[c];
-    }
-    __syncthreads();
-    // (2) redundant 8x8 Cholesky in registers (identity-padded when nb < 8)
-    double D[8][8];
-#pragma unroll
-    for(int c = 0; c < 8; c++)
-#pragma unroll
-      for(int q = 0; q <= c; q++)
-        D[c][q] = (c < nb) ? P[(kb + c) + (kb + q)*ldp] : ((c == q) ? 1.0 : 0.0);
-    bool bad = false; int badcol = 0;
-#pragma unroll
-    for(int c = 0; c < 8; c++)
-    {
-      double d = D[c][c];
-#pragma unroll
-      for(int q = 0; q < c; q++) d -= D[c][q]*D[c][q];
-      if(!(d > 0.0)) { if(!bad) { bad = true; badcol = c; } d = 1.0; }
-      const double piv = sqrt(d);
-      D[c][c] = piv;
-      const double inv = 1.0/piv;
-#pragma unroll
-      for(int i = c + 1; i < 8; i++)
-      {
-        double v = D[i][c];
-#pragma unroll
-        for(int q = 0; q < c; q++) v -= D[i][q]*D[c][q];
-        D[i][c] = v*inv;
-      }
-    }
-    if(bad && tid == 0) atomicMin(info, sn_c0[s] + kb + badcol);
-    __syncthreads();
-    // (3) rows of the block take the factor; rows below solve against it
-    for(int r = kb + tid; r < nrows; r += NT)
-    {
-      if(r < kb + nb)
-      {
-        const int c = r - kb;
-#pragma unroll
-        for(int cc = 0; cc < 8; cc++)
-#pragma unroll
-          for(int q = 0; q <= cc; q++) if(cc == c) P[r + (kb + q)*ldp] = D[cc][q];
-      }
-      else
-      {
-        double x[8];
-#pragma unroll
-        for(int c = 0; c < 8; c++) x[c] = (c < nb) ? P[r + (kb + c)*ldp] : 0.0;
-#pragma unroll
-        for(int c = 0; c < 8; c++)
-        {
-          double v = x[c];
-#pragma unroll
-          for(int q = 0; q < c; q++) v -= x[q]*D[c][q];
-          x[c] = v/D[c][c];
-        }
-#pragma unroll
-        for(int c = 0; c < 8; c++) if(c < nb) P[r + (kb + c)*ldp] = x[c];
-      }
-    }
-    __syncthreads();
-  }
+  panel_factor<NT, USE_LDS>(P, ldp, nrows, w, tid, info, sn_c0[s]);
   if(USE_LDS)
     for(int e = tid; e < nrows*w; e += NT) { const int j = e / nrows; G[e] = P[e + j*(ldp - nrows)]; }
 }
