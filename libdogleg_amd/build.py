@@ -33,8 +33,10 @@ def _compile(src, newest_hdr, verbose):
     obj = os.path.join(OBJ, os.path.basename(src) + ".o")
     if os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(src), newest_hdr):
         return obj
-    flags = FLAGS if src.endswith(".hip") else [f for f in FLAGS if not f.startswith("--offload-arch")]
-    cmd = [HIPCC] + flags + ["-c", src, "-o", obj]
+    if src.endswith(".hip"):
+        cmd = [HIPCC] + FLAGS + ["-c", src, "-o", obj]
+    else:       # plain host C++
+        cmd = [HIPCC, "-x", "c++"] + [f for f in FLAGS if not f.startswith("--offload-arch")] + ["-c", src, "-o", obj]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)

@@ -70,8 +70,10 @@ struct SparseSym
   int64_t *uw_part = nullptr, *uf_off = nullptr;
   double* upart = nullptr;
   SymOutBlock* oblk = nullptr; SymContrib* contrib = nullptr;
-  SymTask *asm_task = nullptr, *jtx_task = nullptr;
-  int *asm_fin_ptr = nullptr, *asm_fin_blk = nullptr, *jtx_fin_ptr = nullptr, *jtx_fin_blk = nullptr;
+  SymTask *jtx_task = nullptr;
+  int *jtx_fin_ptr = nullptr, *jtx_fin_blk = nullptr;
+  AsmRho* asm_rho = nullptr; AsmPair* asm_pair = nullptr; AsmSlot* asm_slot = nullptr;
+  AsmBatch* asm_batch = nullptr; AsmTask* asm_ctask = nullptr; AsmFin* asm_cfin = nullptr;
   int *rl_ptr = nullptr, *rl_pos = nullptr, *perm = nullptr;
   int *Jp = nullptr, *Ji = nullptr;       // rank-local pattern (row pointers rebased to 0)
   // numeric buffers
@@ -87,56 +89,232 @@ struct SparseSym
 namespace {
 
 // ------------------------------------------------------------ K4 assembly ---
-// one wave per task: lane (a,b) of the output block accumulates
-//   sum_{contributions} sum_{rows k} J[k][offI+a] * J[k][offJ+b]
-__global__ void __launch_bounds__(TPB) k_assemble(const SymTask* __restrict__ tasks, int ntasks,
-                                                  const SymOutBlock* __restrict__ oblk,
-                                                  const SymContrib* __restrict__ contrib,
+// Column-block centric JtJ assembly.  One wave per task; a task owns a group of
+// output blocks (I,J) of one column block J ("slots", accumulated in LDS) and
+// walks the row-blocks containing J in batches.  Per batch the Jacobian rows
+// are staged in LDS once (coalesced segment copies) and every row-block then
+// feeds all its slots at once: lanes = flattened (pair, a, b),
+//     acc[slot(I)][a][b] += sum_k J[k][offI+a] * J[k][offJ+b].
+// Single-task groups store straight into the supernode panels; groups split
+// over several tasks (very long lists: a block every row touches) store
+// partial accumulators that k_assemble_fin adds in task order.
+// Everything a wave shares goes through LDS in program order (same wave), so
+// no barriers are needed and waves of a workgroup are independent.
+constexpr int ASM_STAGE = 512, ASM_ACC = 256, ASM_RHO = 32, ASM_PAIRS = 256;
+
+struct AsmWaveLds
+{
+  double  stage[ASM_STAGE];
+  double  acc[ASM_ACC];
+  AsmRho  rho[ASM_RHO + 1];
+  AsmPair pair[ASM_PAIRS];
+};
+
+__global__ void __launch_bounds__(TPB) k_assemble(const AsmTask* __restrict__ tasks, int ntasks,
+                                                  const AsmBatch* __restrict__ batches,
+                                                  const AsmRho* __restrict__ rho,
+                                                  const AsmPair* __restrict__ pairs,
+                                                  const AsmSlot* __restrict__ slots,
                                                   const double* __restrict__ vals,
                                                   double* __restrict__ Lx, double* __restrict__ part)
 {
-  const int wid = __builtin_amdgcn_readfirstlane(blockIdx.x*(TPB/64) + (threadIdx.x >> 6));
+  __shared__ __attribute__((aligned(16))) AsmWaveLds sh[TPB/64];
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(blockIdx.x*(TPB/64) + w);
   if(wid >= ntasks) return;
-  const int lane = threadIdx.x & 63;
-  const SymTask T = tasks[wid];
-  const SymOutBlock B = oblk[T.blk];
-  const int nI = B.nI, nJ = B.nJ;
-  const int a = lane % nI, b = lane / nI;
-  const bool active = (b < nJ) && (!B.diag || a >= b);
-  const int bb = active ? b : 0;
-  double acc = 0.0;
-  for(int c = T.c0; c < T.c1; c++)
+  AsmWaveLds& S = sh[w];
+  const AsmTask T = tasks[wid];
+  const int nJ = T.nJ;
+  for(int e = lane; e < T.acc_size; e += 64) S.acc[e] = 0.0;
+  // uniform tasks (every row-block has the same sequence of block sizes, <= 128 products):
+  // the lane -> (pair ordinal, a, b) map is computed once for the whole task
+  const bool uniform = T.pad != 0;
+  int uj[2] = {-1, -1}, ua[2] = {0, 0}, ub[2] = {0, 0}, uidx[2] = {0, 0};
+  if(uniform && T.batch0 < T.batch1)
   {
-    const SymContrib C = contrib[c];
-    const double* row = vals + C.base;
-    for(int k = 0; k < C.nrows; k++, row += C.len)
-      acc += row[C.offI + a]*row[C.offJ + bb];
+    const int rfirst = batches[T.batch0].rho0;
+    const int q0 = rho[rfirst].pair0, q1 = rho[rfirst + 1].pair0;
+#pragma unroll
+    for(int u = 0; u < 2; u++)
+    {
+      const int tgt = lane + 64*u;
+      int cum = 0;
+      for(int p = q0; p < q1; p++)
+      {
+        const int ni = (pairs[p].acc_nI >> 12) + 1, n = ni*nJ;
+        if(tgt >= cum && tgt < cum + n)
+        {
+          const int idx = tgt - cum;
+          uj[u] = p - q0; uidx[u] = idx; ub[u] = idx / ni; ua[u] = idx - ub[u]*ni;
+        }
+        cum += n;
+      }
+    }
   }
-  if(T.part < 0) { if(active) Lx[B.dest + a + (int64_t)b*B.ld] = acc; }
-  else part[(size_t)T.part*64 + lane] = acc;
+  for(int bt = T.batch0; bt < T.batch1; bt++)
+  {
+    const AsmBatch B = batches[bt];
+    const int nr = B.rho1 - B.rho0;
+    // (a) the batch's row-block records (+ the one that closes the last pair list): one load
+    if(lane <= nr) S.rho[lane] = rho[B.rho0 + lane];
+    __builtin_amdgcn_wave_barrier();
+    const int P0 = S.rho[0].pair0, np = S.rho[nr].pair0 - P0;
+    // (b) pairs + values of the whole batch, all loads issued before the first LDS store
+    {
+      AsmPair pv[ASM_PAIRS/64];
+#pragma unroll
+      for(int u = 0; u < ASM_PAIRS/64; u++) if(lane + 64*u < np) pv[u] = pairs[P0 + lane + 64*u];
+      for(int rb = 0; rb < nr; rb += 16)
+      {
+        double v[16];
+#pragma unroll
+        for(int u = 0; u < 16; u++)
+        {
+          v[u] = 0.0;
+          if(rb + u < nr)
+          {
+            const AsmRho R = S.rho[rb + u];
+            if(R.stage_off != 0xFFFF && lane < R.nrows*R.len) v[u] = vals[R.base + lane];
+          }
+        }
+#pragma unroll
+        for(int u = 0; u < 16; u++)
+          if(rb + u < nr)
+          {
+            const AsmRho R = S.rho[rb + u];
+            if(R.stage_off != 0xFFFF && lane < R.nrows*R.len) S.stage[R.stage_off + lane] = v[u];
+          }
+      }
+      // segments longer than one wave-load (rare: long rows)
+      for(int r = 0; r < nr; r++)
+      {
+        const AsmRho R = S.rho[r];
+        if(R.stage_off == 0xFFFF) continue;
+        const int cnt = R.nrows*R.len;
+        for(int e = 64 + lane; e < cnt; e += 64) S.stage[R.stage_off + e] = vals[R.base + e];
+      }
+#pragma unroll
+      for(int u = 0; u < ASM_PAIRS/64; u++) if(lane + 64*u < np) S.pair[lane + 64*u] = pv[u];
+    }
+    __builtin_amdgcn_wave_barrier();
+    // (c) every row-block feeds all its slots at once
+    if(uniform)
+    {
+      for(int r = 0; r < nr; r++)
+      {
+        const AsmRho R = S.rho[r];
+        const int p0 = R.pair0 - P0;
+#pragma unroll
+        for(int u = 0; u < 2; u++)
+        {
+          if(uj[u] < 0) continue;
+          const AsmPair P = S.pair[p0 + uj[u]];
+          double sum = 0.0;
+          if(R.stage_off != 0xFFFF)
+          {
+            const double* row = S.stage + R.stage_off;
+            for(int k = 0; k < R.nrows; k++, row += R.len) sum += row[P.offI + ua[u]]*row[R.offJ + ub[u]];
+          }
+          else
+          {
+            const double* row = vals + R.base;
+            for(int k = 0; k < R.nrows; k++, row += R.len) sum += row[P.offI + ua[u]]*row[R.offJ + ub[u]];
+          }
+          S.acc[(P.acc_nI & 0xFFF) + uidx[u]] += sum;
+        }
+      }
+    }
+    else
+    for(int r = 0; r < nr; r++)
+    {
+      const AsmRho R = S.rho[r];
+      const int p0 = R.pair0 - P0, p1 = S.rho[r+1].pair0 - P0;
+      int total = 0;
+      for(int p = p0; p < p1; p++) total += ((S.pair[p].acc_nI >> 12) + 1)*nJ;
+      for(int base = 0; base < total; base += 64)
+      {
+        const int tgt = base + lane;
+        int cum = 0, idx = -1, nI = 1, offI = 0, accoff = 0;
+        for(int p = p0; p < p1; p++)
+        {
+          const AsmPair P = S.pair[p];
+          const int ni = (P.acc_nI >> 12) + 1, n = ni*nJ;
+          if(tgt >= cum && tgt < cum + n) { idx = tgt - cum; nI = ni; offI = P.offI; accoff = P.acc_nI & 0xFFF; }
+          cum += n;
+        }
+        if(idx >= 0)
+        {
+          const int b = idx / nI, a = idx - b*nI;
+          double sum = 0.0;
+          if(R.stage_off != 0xFFFF)
+          {
+            const double* row = S.stage + R.stage_off;
+            for(int k = 0; k < R.nrows; k++, row += R.len) sum += row[offI + a]*row[R.offJ + b];
+          }
+          else
+          {
+            const double* row = vals + R.base;
+            for(int k = 0; k < R.nrows; k++, row += R.len) sum += row[offI + a]*row[R.offJ + b];
+          }
+          S.acc[accoff + idx] += sum;
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  // write out
+  for(int sidx = 0; sidx < T.nslots; sidx++)
+  {
+    const AsmSlot SL = slots[T.slot0 + sidx];
+    const int n = SL.nI*nJ;
+    for(int idx = lane; idx < n; idx += 64)
+    {
+      const double v = S.acc[SL.accoff + idx];
+      if(T.part < 0)
+      {
+        const int b = idx / SL.nI, a = idx - b*SL.nI;
+        if(!SL.diag || a >= b) Lx[SL.dest + a + (int64_t)b*SL.ld] = v;
+      }
+      else part[T.part + SL.accoff + idx] = v;
+    }
+  }
 }
-// sum the partials of a multi-chunk block: one 1024-thread workgroup per block,
-// 16 groups x 64 lanes stride over the partials, fixed-order LDS reduction
-__global__ void __launch_bounds__(1024) k_assemble_fin(const int* __restrict__ fin_ptr,
-                                                       const int* __restrict__ fin_blk, int nfin,
-                                                       const SymOutBlock* __restrict__ oblk,
+// add the partial accumulators of a multi-task group in task order: one 1024-thread
+// workgroup per group, 16 lanes-groups stride over the partials, fixed-order reduce
+__global__ void __launch_bounds__(1024) k_assemble_fin(const AsmFin* __restrict__ fins,
+                                                       const AsmSlot* __restrict__ slots,
                                                        const double* __restrict__ part,
                                                        double* __restrict__ Lx)
 {
   __shared__ double sh[1024];
-  const int f = blockIdx.x;
+  const AsmFin F = fins[blockIdx.x];
   const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
-  const SymOutBlock B = oblk[fin_blk[f]];
-  double s = 0.0;
-  for(int p = fin_ptr[f] + g; p < fin_ptr[f+1]; p += 16) s += part[(size_t)p*64 + lane];
-  sh[threadIdx.x] = s;
-  __syncthreads();
-  if(g == 0)
+  for(int ebase = 0; ebase < F.acc_size; ebase += 64)
   {
-    double tot = 0.0;
-    for(int k = 0; k < 16; k++) tot += sh[k*64 + lane];
-    const int a = lane % B.nI, b = lane / B.nI;
-    if((b < B.nJ) && (!B.diag || a >= b)) Lx[B.dest + a + (int64_t)b*B.ld] = tot;
+    const int e = ebase + lane;
+    double s = 0.0;
+    if(e < F.acc_size)
+      for(int k = g; k < F.nparts; k += 16) s += part[F.part0 + (int64_t)k*F.acc_size + e];
+    __syncthreads();
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    if(g == 0 && e < F.acc_size)
+    {
+      double tot = 0.0;
+      for(int k = 0; k < 16; k++) tot += sh[k*64 + lane];
+      // which slot holds accumulator e?
+      for(int sidx = 0; sidx < F.nslots; sidx++)
+      {
+        const AsmSlot SL = slots[F.slot0 + sidx];
+        const int n = SL.nI*F.nJ;
+        if(e >= SL.accoff && e < SL.accoff + n)
+        {
+          const int idx = e - SL.accoff;
+          const int b = idx / SL.nI, a = idx - b*SL.nI;
+          if(!SL.diag || a >= b) Lx[SL.dest + a + (int64_t)b*SL.ld] = tot;
+        }
+      }
+    }
   }
 }
 __global__ void __launch_bounds__(TPB) k_add_lambda(double* __restrict__ Lx,
@@ -630,8 +808,8 @@ int sparse_set_pattern(dlg_backend* b, const int* colptr, const int* rowidx)
   UP(sn_c0); UP(sn_rowptr); UP(sn_rows); UP(sn_scr); UP(lvl_sn); UP(sn_lx); UP(diagpos);
   UP(ui_t); UP(ui_col); UP(ui_nc); UP(ui_ptr); UP(usub); UP(relpos);
   UP(uw_item); UP(uw_s0); UP(uw_s1); UP(uw_part); UP(uf_item); UP(uf_n); UP(uf_off);
-  UP(oblk); UP(contrib); UP(asm_task); UP(jtx_task);
-  UP(asm_fin_ptr); UP(asm_fin_blk); UP(jtx_fin_ptr); UP(jtx_fin_blk);
+  UP(oblk); UP(contrib); UP(jtx_task); UP(jtx_fin_ptr); UP(jtx_fin_blk);
+  UP(asm_rho); UP(asm_pair); UP(asm_slot); UP(asm_batch); UP(asm_ctask); UP(asm_cfin);
   UP(rl_ptr); UP(rl_pos); UP(perm);
   // rank-local pattern for the row-wise kernels
   {
@@ -649,7 +827,7 @@ int sparse_set_pattern(dlg_backend* b, const int* colptr, const int* rowidx)
   DLG_CHECK(dalloc(Y->scr, (size_t)H.scr_size));
   DLG_CHECK(dalloc(Y->ywork, (size_t)H.N));
   DLG_CHECK(dalloc(Y->upart, (size_t)H.upart_size));
-  DLG_CHECK(dalloc(Y->asm_part, (size_t)H.asm_nparts*64));
+  DLG_CHECK(dalloc(Y->asm_part, (size_t)H.asm_part_size));
   DLG_CHECK(dalloc(Y->jtx_part, (size_t)H.jtx_nparts*8));
   DLG_HIP(hipMalloc(&Y->d_info, sizeof(int))); Y->allocs.push_back(Y->d_info);
   DLG_HIP(hipHostMalloc(&Y->h_info, sizeof(int)));
@@ -760,17 +938,17 @@ int sparse_factorize(dlg_backend* b, int s, double lambda, int* ok)
   {
     DlgProfScope pt(b, DLG_PROF_K4_TOTAL);
     DLG_HIP(hipMemsetAsync(Y->Lx, 0, sizeof(double)*(size_t)H.lx_size, st));
-    const int nt = (int)H.asm_task.size();
+    const int nt = (int)H.asm_ctask.size();
     if(nt > 0)
     {
       DlgProfScope pk(b, DLG_PROF_K4_KERNEL);
-      hipLaunchKernelGGL(k_assemble, dim3(dlg_cdiv(nt, TPB/64)), dim3(TPB), 0, st, Y->asm_task, nt,
-                         Y->oblk, Y->contrib, S.Jin(), Y->Lx, Y->asm_part);
+      hipLaunchKernelGGL(k_assemble, dim3(dlg_cdiv(nt, TPB/64)), dim3(TPB), 0, st, Y->asm_ctask, nt,
+                         Y->asm_batch, Y->asm_rho, Y->asm_pair, Y->asm_slot, S.Jin(), Y->Lx, Y->asm_part);
     }
-    const int nf = (int)H.asm_fin_blk.size();
+    const int nf = (int)H.asm_cfin.size();
     if(nf > 0)
-      hipLaunchKernelGGL(k_assemble_fin, dim3(nf), dim3(1024), 0, st, Y->asm_fin_ptr,
-                         Y->asm_fin_blk, nf, Y->oblk, Y->asm_part, Y->Lx);
+      hipLaunchKernelGGL(k_assemble_fin, dim3(nf), dim3(1024), 0, st, Y->asm_cfin, Y->asm_slot,
+                         Y->asm_part, Y->Lx);
     DLG_LAUNCH_CHECK();
   }
   // rows are sharded: sum the partial JtJ of all ranks before factorising
@@ -856,7 +1034,7 @@ extern "C" int dlg_sparse_symbolic_probe(int N, int M, const int* colptr, const 
   if(sym_analyze(H, N, M, colptr, rowidx, row0, row1, err, sizeof(err)))
   { dlg_set_error("symbolic analysis: %s", err); return DLG_ERR_ARG; }
   const long v[] = { (long)H.nvb, (long)H.nsn, (long)H.nlevels, (long)H.nnz_JtJ_lower, (long)H.nnz_L,
-                     (long)H.lx_size, (long)H.factor_flops, (long)H.max_panel, (long)H.asm_task.size(),
+                     (long)H.lx_size, (long)H.factor_flops, (long)H.max_panel, (long)H.asm_ctask.size(),
                      (long)H.ui_t.size(), (long)H.relpos.size(), (long)H.oblk.size(),
                      (long)H.contrib.size(), (long)H.usub.size(), (long)H.scr_size,
                      (long)H.jtx_task.size() };

@@ -12,11 +12,8 @@ namespace {
 
 constexpr int VB_MAX   = 8;       // max variables per var-block (<= 64 lanes per 8x8 output block)
 constexpr int RB_MAX   = 8;       // max rows per row-block
-constexpr int CH_ASM   = 64;      // contributions per assembly wave-task (more when a list is very long)
 constexpr int CH_JTX   = 512;     // contributions per Jt*x wave-task
-constexpr int MAXCH_ASM = 4096;   // at most this many partials per output block
 constexpr int MAXCH_JTX = 2048;
-constexpr int UCH      = 512;     // update sub-tasks per work unit
 constexpr int PANEL_CAP = 16384;  // doubles: supernode panels up to this size are factored in LDS
 constexpr int SN_WMAX  = 256;     // max supernode width
 
@@ -730,32 +727,26 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
     for(int l = 0; l < S.nlevels; l++) { S.uw_lvl_ptr[l+1] += S.uw_lvl_ptr[l]; S.uf_lvl_ptr[l+1] += S.uf_lvl_ptr[l]; }
   }
 
-  // ------------------------------------------- 9. assembly / Jt*x lists
+  // ------------------------------------------- 9a. Jt*x lists (per var-block)
   {
-    struct Tup { int64_t key; int rb; uint16_t offI, offJ; };
-    std::vector<Tup> tups;
-    size_t ntup = 0;
-    for(const RowBlock& b : rbs) if(b.local) ntup += (size_t)b.nvb*(b.nvb + 1)/2;
-    tups.reserve(ntup);
+    // inverted index: var-block -> local row-blocks containing it (row order)
+    std::vector<int> rptr(nvb + 1, 0);
+    for(const RowBlock& b : rbs) if(b.local) for(int x = 0; x < b.nvb; x++) rptr[rb_vb[b.vptr + x] + 1]++;
+    for(int v = 0; v < nvb; v++) rptr[v+1] += rptr[v];
+    S.oblk.resize(nvb);
+    S.contrib.resize(rptr[nvb]);
+    std::vector<int> nx(rptr.begin(), rptr.end() - 1);
     for(int bi = 0; bi < nrb; bi++)
     {
       const RowBlock& b = rbs[bi];
       if(!b.local) continue;
       for(int x = 0; x < b.nvb; x++)
-        for(int y = 0; y <= x; y++)
-        {
-          int I = rb_vb[b.vptr + x], J = rb_vb[b.vptr + y];
-          int oI = rb_off[b.vptr + x], oJ = rb_off[b.vptr + y];
-          if(I != J && bpos[I] < bpos[J]) { std::swap(I, J); std::swap(oI, oJ); }
-          // diagonal blocks sort first (key = vb id), off-diagonal after
-          const int64_t key = (I == J) ? (int64_t)I : ((int64_t)(bpos[J] + 1) << 32) | (int64_t)bpos[I];
-          tups.push_back({key, bi, (uint16_t)oI, (uint16_t)oJ});
-        }
+      {
+        SymContrib c; c.base = b.base - cp[row0]; c.r0 = b.r0 - row0; c.len = (uint16_t)b.len;
+        c.nrows = (uint8_t)b.nrows; c.pad = 0; c.offI = c.offJ = (uint16_t)rb_off[b.vptr + x];
+        S.contrib[nx[rb_vb[b.vptr + x]]++] = c;
+      }
     }
-    std::stable_sort(tups.begin(), tups.end(), [](const Tup& a, const Tup& b) { return a.key < b.key; });
-    // diagonal output blocks for every var-block (also those without local contributions)
-    S.oblk.resize(nvb);
-    std::vector<int> blk_c0(nvb + 1, 0);
     for(int v = 0; v < nvb; v++)
     {
       const int q = bpos[v], t = sn_of_b[q];
@@ -766,71 +757,172 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
       o.nI = o.nJ = (uint8_t)G.w[v]; o.diag = 1;
       S.oblk[v] = o;
     }
-    S.contrib.reserve(tups.size());
-    std::vector<int> cptr;                    // contribution range per output block
-    cptr.assign(nvb + 1, 0);
-    size_t i = 0;
-    // diagonal part
+    S.jtx_nparts = 0; S.jtx_fin_ptr.assign(1, 0); S.jtx_fin_blk.clear();
     for(int v = 0; v < nvb; v++)
     {
-      cptr[v] = (int)S.contrib.size();
-      while(i < tups.size() && tups[i].key == (int64_t)v)
+      const int c0 = rptr[v], c1 = rptr[v+1];
+      if(c1 == c0) continue;
+      int chunk = CH_JTX;
+      if((c1 - c0 + chunk - 1)/chunk > MAXCH_JTX) chunk = (c1 - c0 + MAXCH_JTX - 1)/MAXCH_JTX;
+      const int nch = (c1 - c0 + chunk - 1)/chunk;
+      if(nch == 1) S.jtx_task.push_back({v, c0, c1, -1});
+      else
       {
-        const RowBlock& b = rbs[tups[i].rb];
-        SymContrib c; c.base = b.base - cp[row0]; c.r0 = b.r0 - row0; c.len = (uint16_t)b.len;
-        c.nrows = (uint8_t)b.nrows; c.pad = 0; c.offI = tups[i].offI; c.offJ = tups[i].offJ;
-        S.contrib.push_back(c); i++;
+        for(int k = 0; k < nch; k++)
+          S.jtx_task.push_back({v, c0 + k*chunk, std::min(c1, c0 + (k+1)*chunk), S.jtx_nparts + k});
+        S.jtx_nparts += nch;
+        S.jtx_fin_blk.push_back(v); S.jtx_fin_ptr.push_back(S.jtx_nparts);
       }
     }
-    cptr[nvb] = (int)S.contrib.size();
-    // off-diagonal part
-    while(i < tups.size())
+  }
+
+  // ------------------------------------------- 9b. JtJ assembly schedule
+  // Column-block centric: a task owns (a group of) the output blocks (I,J) of ONE
+  // column block J and walks the row-blocks that contain J in batches: a batch's
+  // Jacobian rows are staged in LDS once and feed every block of that column.
+  {
+    constexpr int ACC_CAP = 256, SLOT_CAP = 32, STAGE_CAP = 512, TASK_BATCHES = 16;
+    constexpr int RHO_PER_BATCH = 32, PAIRS_PER_BATCH = 256;
+    std::vector<int> rptr(nvb + 1, 0);
+    for(const RowBlock& b : rbs) if(b.local) for(int x = 0; x < b.nvb; x++) rptr[rb_vb[b.vptr + x] + 1]++;
+    for(int v = 0; v < nvb; v++) rptr[v+1] += rptr[v];
+    std::vector<int> rrb(rptr[nvb]), rx(rptr[nvb]);
     {
-      const int64_t key = tups[i].key;
-      const int qJ = (int)(key >> 32) - 1, qI = (int)(key & 0xffffffff);
-      const int t = sn_of_b[qJ];
+      std::vector<int> nx(rptr.begin(), rptr.end() - 1);
+      for(int bi = 0; bi < nrb; bi++)
+      {
+        const RowBlock& b = rbs[bi];
+        if(!b.local) continue;
+        for(int x = 0; x < b.nvb; x++) { const int v = rb_vb[b.vptr + x]; rrb[nx[v]] = bi; rx[nx[v]] = x; nx[v]++; }
+      }
+    }
+    std::vector<int> slot_of(nvb, -1), slot_stamp(nvb, -1);
+    struct SlotTmp { int I; int64_t dest; int nI; int diag; };
+    std::vector<SlotTmp> slots;
+    std::vector<int> grp_of, acc_of;            // per slot: group id, accumulator offset inside the group
+    S.asm_part_size = 0;
+    for(int J = 0; J < nvb; J++)
+    {
+      const int r0 = rptr[J], r1 = rptr[J+1];
+      if(r0 == r1) continue;
+      const int qJ = bpos[J], t = sn_of_b[qJ];
       const int ld = S.sn_rowptr[t+1] - S.sn_rowptr[t];
       const int lc = colstart[qJ] - S.sn_c0[t];
-      const int ro = rowoff_in(t, qI);
-      if(ro < 0) SYM_FAIL("internal error: JtJ block (%d,%d) missing from the factor structure", qI, qJ);
-      SymOutBlock o; memset(&o, 0, sizeof(o));
-      o.dest = S.sn_lx[t] + ro + (int64_t)lc*ld; o.ld = ld; o.var0 = S.vb_start[border[qI]];
-      o.nI = (uint8_t)G.w[border[qI]]; o.nJ = (uint8_t)G.w[border[qJ]]; o.diag = 0;
-      S.oblk.push_back(o);
-      cptr.back() = (int)S.contrib.size();
-      while(i < tups.size() && tups[i].key == key)
+      const int nJ = G.w[J];
+      // distinct I's with pos(I) >= pos(J), in first-seen order
+      slots.clear();
+      for(int e = r0; e < r1; e++)
       {
-        const RowBlock& b = rbs[tups[i].rb];
-        SymContrib c; c.base = b.base - cp[row0]; c.r0 = b.r0 - row0; c.len = (uint16_t)b.len;
-        c.nrows = (uint8_t)b.nrows; c.pad = 0; c.offI = tups[i].offI; c.offJ = tups[i].offJ;
-        S.contrib.push_back(c); i++;
-      }
-      cptr.push_back((int)S.contrib.size());
-    }
-    const int nblk = (int)S.oblk.size();
-    // wave-tasks
-    auto make_tasks = [&](int nb, int chunk0, int maxch, std::vector<SymTask>& tasks,
-                          std::vector<int>& fin_ptr, std::vector<int>& fin_blk, int& nparts) {
-      nparts = 0; fin_ptr.clear(); fin_blk.clear(); fin_ptr.push_back(0);
-      for(int b = 0; b < nb; b++)
-      {
-        const int c0 = cptr[b], c1 = cptr[b+1];
-        if(c1 == c0) continue;
-        int chunk = chunk0;
-        if((c1 - c0 + chunk - 1)/chunk > maxch) chunk = (c1 - c0 + maxch - 1)/maxch;
-        const int nch = (c1 - c0 + chunk - 1)/chunk;
-        if(nch == 1) tasks.push_back({b, c0, c1, -1});
-        else
+        const RowBlock& b = rbs[rrb[e]];
+        for(int x = 0; x < b.nvb; x++)
         {
-          for(int k = 0; k < nch; k++)
-            tasks.push_back({b, c0 + k*chunk, std::min(c1, c0 + (k+1)*chunk), nparts + k});
-          nparts += nch;
-          fin_blk.push_back(b); fin_ptr.push_back(nparts);
+          const int I = rb_vb[b.vptr + x];
+          if(bpos[I] < qJ || slot_stamp[I] == J) continue;
+          slot_stamp[I] = J; slot_of[I] = (int)slots.size();
+          int64_t dest;
+          if(I == J) dest = S.sn_lx[t] + lc + (int64_t)lc*ld;
+          else
+          {
+            const int ro = rowoff_in(t, bpos[I]);
+            if(ro < 0) SYM_FAIL("internal error: JtJ block (%d,%d) missing from the factor structure", bpos[I], qJ);
+            dest = S.sn_lx[t] + ro + (int64_t)lc*ld;
+          }
+          slots.push_back({I, dest, G.w[I], I == J ? 1 : 0});
         }
       }
-    };
-    make_tasks(nblk, CH_ASM, MAXCH_ASM, S.asm_task, S.asm_fin_ptr, S.asm_fin_blk, S.asm_nparts);
-    make_tasks(nvb,  CH_JTX, MAXCH_JTX, S.jtx_task, S.jtx_fin_ptr, S.jtx_fin_blk, S.jtx_nparts);
+      // groups of slots that fit the LDS accumulator
+      grp_of.assign(slots.size(), 0); acc_of.assign(slots.size(), 0);
+      int ngrp = 0;
+      {
+        int acc = 0, cnt = 0;
+        for(size_t k = 0; k < slots.size(); k++)
+        {
+          const int sz = slots[k].nI*nJ;
+          if(cnt > 0 && (acc + sz > ACC_CAP || cnt >= SLOT_CAP)) { ngrp++; acc = 0; cnt = 0; }
+          grp_of[k] = ngrp; acc_of[k] = acc; acc += sz; cnt++;
+        }
+        ngrp++;
+      }
+      for(int g = 0; g < ngrp; g++)
+      {
+        // slot table of the group
+        const int slot0 = (int)S.asm_slot.size();
+        int acc_size = 0, nslots = 0;
+        for(size_t k = 0; k < slots.size(); k++) if(grp_of[k] == g)
+        {
+          AsmSlot sl; sl.dest = slots[k].dest; sl.ld = ld; sl.accoff = (uint16_t)acc_of[k];
+          sl.nI = (uint8_t)slots[k].nI; sl.diag = (uint8_t)slots[k].diag;
+          S.asm_slot.push_back(sl); nslots++; acc_size = acc_of[k] + slots[k].nI*nJ;
+        }
+        // rho records with at least one pair in this group, batched by staged size
+        const int first_task = (int)S.asm_ctask.size();
+        bool task_open = false, batch_open = false;
+        std::vector<int> seq0, seq;
+        int nb_in_task = 0, stage_used = 0, rho_in_batch = 0, pairs_in_batch = 0;
+        auto close_batch = [&]() { if(batch_open) { S.asm_batch.back().rho1 = (int)S.asm_rho.size(); batch_open = false; } };
+        auto close_task = [&]() {
+          close_batch();
+          if(task_open) { S.asm_ctask.back().batch1 = (int)S.asm_batch.size(); task_open = false; } };
+        for(int e = r0; e < r1; e++)
+        {
+          const RowBlock& b = rbs[rrb[e]];
+          int npairs = 0;
+          for(int x = 0; x < b.nvb; x++)
+          { const int I = rb_vb[b.vptr + x]; if(bpos[I] >= qJ && grp_of[slot_of[I]] == g) npairs++; }
+          if(npairs == 0) continue;
+          const int cnt = b.nrows*b.len;
+          const bool direct = cnt > STAGE_CAP;
+          const int need = direct ? 0 : cnt;
+          if(batch_open && (stage_used + need > STAGE_CAP || rho_in_batch >= RHO_PER_BATCH ||
+                            pairs_in_batch + npairs > PAIRS_PER_BATCH)) close_batch();
+          if(!batch_open)
+          {
+            if(!task_open || nb_in_task >= TASK_BATCHES)
+            {
+              close_task();
+              AsmTask T; T.batch0 = (int)S.asm_batch.size(); T.batch1 = -1; T.slot0 = slot0;
+              T.nslots = (uint16_t)nslots; T.nJ = (uint8_t)nJ; T.pad = 0; T.acc_size = acc_size; T.pad2 = 0; T.part = -1;
+              T.pad = 1;                       // uniform until a row-block with another block sequence shows up
+              S.asm_ctask.push_back(T); task_open = true; nb_in_task = 0; seq0.clear();
+            }
+            S.asm_batch.push_back({(int)S.asm_rho.size(), -1}); batch_open = true; stage_used = 0; nb_in_task++;
+            rho_in_batch = 0; pairs_in_batch = 0;
+          }
+          AsmRho R; R.base = b.base - cp[row0]; R.pair0 = (int)S.asm_pair.size(); R.len = (uint16_t)b.len;
+          R.offJ = (uint16_t)rb_off[b.vptr + rx[e]]; R.stage_off = direct ? (uint16_t)0xFFFF : (uint16_t)stage_used;
+          R.nrows = (uint8_t)b.nrows; R.pad = 0;
+          S.asm_rho.push_back(R);
+          stage_used += need; rho_in_batch++; pairs_in_batch += npairs;
+          seq.clear();
+          for(int x = 0; x < b.nvb; x++)
+          { const int I = rb_vb[b.vptr + x]; if(bpos[I] >= qJ && grp_of[slot_of[I]] == g) seq.push_back(G.w[I]); }
+          if(seq0.empty()) { seq0 = seq; int tot = 0; for(int q : seq) tot += q*nJ; if(tot > 128) S.asm_ctask.back().pad = 0; }
+          else if(seq != seq0) S.asm_ctask.back().pad = 0;
+          if(npairs > PAIRS_PER_BATCH) SYM_FAIL("a measurement row touches too many variable blocks (%d)", npairs);
+          for(int x = 0; x < b.nvb; x++)
+          {
+            const int I = rb_vb[b.vptr + x];
+            if(bpos[I] < qJ || grp_of[slot_of[I]] != g) continue;
+            AsmPair P; P.offI = (uint16_t)rb_off[b.vptr + x];
+            P.acc_nI = (uint16_t)(acc_of[slot_of[I]] | ((G.w[I] - 1) << 12));
+            S.asm_pair.push_back(P);
+          }
+        }
+        close_task();
+        // multi-task groups: partial accumulators + finalize entry
+        const int ntask = (int)S.asm_ctask.size() - first_task;
+        if(ntask > 1)
+        {
+          AsmFin F; F.slot0 = slot0; F.nslots = nslots; F.acc_size = acc_size; F.nparts = ntask;
+          F.part0 = S.asm_part_size; F.nJ = nJ;
+          S.asm_cfin.push_back(F);
+          for(int k = 0; k < ntask; k++) S.asm_ctask[first_task + k].part = S.asm_part_size + (int64_t)k*acc_size;
+          S.asm_part_size += (int64_t)ntask*acc_size;
+        }
+      }
+    }
+    // sentinel so that rho[i+1].pair0 closes the pair list of the last rho
+    AsmRho R; memset(&R, 0, sizeof(R)); R.pair0 = (int)S.asm_pair.size(); S.asm_rho.push_back(R);
   }
 
   // --------------------------------------- 10. forward-solve gather lists

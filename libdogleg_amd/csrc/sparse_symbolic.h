@@ -56,6 +56,32 @@ struct SymSub
 };
 static_assert(sizeof(SymSub) == 24, "SymSub layout");
 
+// ---- JtJ assembly schedule (column-block centric, see sparse_symbolic.cpp 9b)
+struct AsmRho                // one row-block inside a task
+{
+  int32_t  base;             // first value of the row-block in the (rank-local) value array
+  int32_t  pair0;            // first pair record; the next AsmRho's pair0 closes the list
+  uint16_t len;              // entries per row
+  uint16_t offJ;             // offset of the task's column block inside a row
+  uint16_t stage_off;        // offset in the LDS staging buffer; 0xFFFF: too big, read from HBM
+  uint8_t  nrows, pad;
+};
+static_assert(sizeof(AsmRho) == 16, "AsmRho layout");
+struct AsmPair { uint16_t offI; uint16_t acc_nI; };   // acc_nI = accumulator offset | (nI-1) << 12
+struct AsmSlot { int64_t dest; int32_t ld; uint16_t accoff; uint8_t nI, diag; };
+static_assert(sizeof(AsmSlot) == 16, "AsmSlot layout");
+struct AsmBatch { int32_t rho0, rho1; };
+struct AsmTask
+{
+  int32_t  batch0, batch1, slot0;
+  uint16_t nslots; uint8_t nJ, pad;
+  int32_t  acc_size, pad2;
+  int64_t  part;             // offset into the partial buffer, or -1: write the panels directly
+};
+static_assert(sizeof(AsmTask) == 32, "AsmTask layout");
+struct AsmFin { int32_t slot0, nslots, acc_size, nparts; int64_t part0; int32_t nJ, pad; };
+static_assert(sizeof(AsmFin) == 32, "AsmFin layout");
+
 // a wave-task: contributions [c0,c1) of block blk; part >= 0: write the partial
 // into slot `part` of the partial buffer instead of the destination
 struct SymTask { int32_t blk, c0, c1, part; };
@@ -99,13 +125,18 @@ struct SymHost
   std::vector<int64_t> uf_off;       // offset of the first partial slab
   int64_t upart_size = 0;
   // ---- assembly / Jt*x
-  std::vector<SymOutBlock> oblk;     // output blocks (diagonal blocks of every var-block first: [0,nvb))
+  std::vector<SymOutBlock> oblk;     // diagonal block of every var-block (Jt*x and lambda use them)
   std::vector<SymContrib>  contrib;
-  std::vector<SymTask>     asm_task; // assembly wave-tasks (all blocks)
   std::vector<SymTask>     jtx_task; // Jt*x wave-tasks (diagonal blocks only)
-  std::vector<int> asm_fin_ptr, asm_fin_blk;   // blocks that need a partial-sum finalize: blk id, partial range
   std::vector<int> jtx_fin_ptr, jtx_fin_blk;
-  int asm_nparts = 0, jtx_nparts = 0;
+  int jtx_nparts = 0;
+  std::vector<AsmRho>   asm_rho;
+  std::vector<AsmPair>  asm_pair;
+  std::vector<AsmSlot>  asm_slot;
+  std::vector<AsmBatch> asm_batch;
+  std::vector<AsmTask>  asm_ctask;
+  std::vector<AsmFin>   asm_cfin;
+  int64_t asm_part_size = 0;
   // ---- forward-solve gather lists
   std::vector<int> rl_ptr;           // [N+1]
   std::vector<int> rl_pos;           // scratch positions feeding row k
