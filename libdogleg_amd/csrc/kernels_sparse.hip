@@ -76,6 +76,7 @@ struct SparseSym
   AsmBatch* asm_batch = nullptr; AsmTask* asm_ctask = nullptr; AsmFin* asm_cfin = nullptr;
   int *rl_ptr = nullptr, *rl_pos = nullptr, *perm = nullptr;
   int *Jp = nullptr, *Ji = nullptr;       // rank-local pattern (row pointers rebased to 0)
+  int *nv_chunk = nullptr; int n_nv_chunks = 0;   // row runs of <= NV_CHUNK non-zeros for |Jv|^2
   // numeric buffers
   double *Lx = nullptr, *scr = nullptr, *ywork = nullptr, *asm_part = nullptr, *jtx_part = nullptr;
   int *d_info = nullptr, *h_info = nullptr;
@@ -391,26 +392,61 @@ __global__ void __launch_bounds__(TPB) k_jtx_fin(const int* __restrict__ fin_ptr
 }
 
 // --------------------------------------------------------------- K3 / K8 ---
-// thread per measurement row: (j_r . v)^2, block partial sums
-__global__ void __launch_bounds__(TPB) k_norm2_Jv(const int* __restrict__ Jp,
+// |J v|^2, "CSR-stream": a workgroup owns a run of consecutive measurement rows
+// holding <= NV_CHUNK non-zeros.  The values and indices of the run are read
+// fully coalesced (a thread-per-row loop strides by the row length and
+// over-fetched 12x in rocprof), the products vals*v[idx] are parked in LDS, and
+// each thread then sums the products of one row.  Deterministic: fixed
+// row->thread map, ordered partials.
+constexpr int NV_CHUNK = 2048;
+
+__global__ void __launch_bounds__(TPB) k_norm2_Jv(const int* __restrict__ chunk_row,
+                                                  const int* __restrict__ Jp,
                                                   const int* __restrict__ Ji,
                                                   const double* __restrict__ vals,
-                                                  const double* __restrict__ v, int mloc,
+                                                  const double* __restrict__ v,
                                                   double* __restrict__ part)
 {
+  __shared__ double prod[NV_CHUNK];
   __shared__ double sh[4];
+  const int r0 = chunk_row[blockIdx.x], r1 = chunk_row[blockIdx.x + 1];
+  const int q0 = Jp[r0], n = Jp[r1] - q0;
+  const int tid = threadIdx.x;
   double acc = 0.0;
-  for(int r = blockIdx.x*TPB + threadIdx.x; r < mloc; r += gridDim.x*TPB)
+  if(n <= NV_CHUNK)
   {
+    for(int base = 0; base < n; base += 8*TPB)
+    {
+      double pv[8]; int pi[8];
+#pragma unroll
+      for(int u = 0; u < 8; u++) { const int e = base + u*TPB + tid; pi[u] = (e < n) ? Ji[q0 + e] : 0; pv[u] = (e < n) ? vals[q0 + e] : 0.0; }
+#pragma unroll
+      for(int u = 0; u < 8; u++) { const int e = base + u*TPB + tid; if(e < n) prod[e] = pv[u]*v[pi[u]]; }
+    }
+    __syncthreads();
+    for(int r = r0 + tid; r < r1; r += TPB)
+    {
+      const int a = Jp[r] - q0, bq = Jp[r+1] - q0;
+      double d = 0.0;
+      for(int q = a; q < bq; q++) d += prod[q];
+      acc += d*d;
+    }
+  }
+  else
+  {
+    // a single row longer than the chunk: the whole workgroup reduces it
     double d = 0.0;
-    const int q1 = Jp[r+1];
-    for(int q = Jp[r]; q < q1; q++) d += v[Ji[q]]*vals[q];
-    acc += d*d;
+    for(int e = tid; e < n; e += TPB) d += vals[q0 + e]*v[Ji[q0 + e]];
+    d = wave_sum(d);
+    if((tid & 63) == 0) sh[tid >> 6] = d;
+    __syncthreads();
+    if(tid == 0) { const double t = (sh[0] + sh[1]) + (sh[2] + sh[3]); acc = t*t; }
+    __syncthreads();
   }
   acc = wave_sum(acc);
-  if((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+  if((tid & 63) == 0) sh[tid >> 6] = acc;
   __syncthreads();
-  if(threadIdx.x == 0) part[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+  if(tid == 0) part[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
 }
 
 // ------------------------------------------------------------------ K5 ------
@@ -820,6 +856,16 @@ int sparse_set_pattern(dlg_backend* b, const int* colptr, const int* rowidx)
     for(int r = 0; r <= mloc; r++) jp[r] = colptr[b->row0 + r] - q0;
     DLG_CHECK(upload(Y->Jp, jp)); Y->allocs.push_back(Y->Jp);
     DLG_CHECK(upload(Y->Ji, ji)); Y->allocs.push_back(Y->Ji);
+    std::vector<int> ch; ch.push_back(0);
+    for(int r = 0; r < mloc;)
+    {
+      int e = r;
+      while(e < mloc && e - r < TPB && jp[e+1] - jp[r] <= NV_CHUNK) e++;
+      if(e == r) e = r + 1;                       // one row longer than a chunk
+      ch.push_back(e); r = e;
+    }
+    Y->n_nv_chunks = (int)ch.size() - 1;
+    DLG_CHECK(upload(Y->nv_chunk, ch)); Y->allocs.push_back(Y->nv_chunk);
   }
   auto dalloc = [&](double*& p, size_t n) -> int {
     DLG_HIP(hipMalloc(&p, sizeof(double)*(n ? n : 1))); Y->allocs.push_back(p); return DLG_OK; };
@@ -917,11 +963,11 @@ int sparse_norm2_Jv(dlg_backend* b, int s, const double* v, double* out_dev)
   SparseSym* Y = b->sym;
   if(!Y) { dlg_set_error("dlg_sparse_set_pattern must be called first"); return DLG_ERR_STATE; }
   DlgSlot& S = b->slot[s];
-  const int mloc = dlg_mloc(b);
-  int g = dlg_cdiv(mloc, TPB); if(g > 2048) g = 2048; if(g < 1) g = 1;
-  DLG_CHECK(dlg_ensure_partials(b, 8192));
+  const int g = Y->n_nv_chunks;
+  if(g == 0) { DLG_HIP(hipMemsetAsync(out_dev, 0, sizeof(double), b->stream)); return DLG_OK; }
+  DLG_CHECK(dlg_ensure_partials(b, 4096 + (size_t)g));
   double* part = b->d_part + 4096;
-  hipLaunchKernelGGL(k_norm2_Jv, dim3(g), dim3(TPB), 0, b->stream, Y->Jp, Y->Ji, S.Jin(), v, mloc, part);
+  hipLaunchKernelGGL(k_norm2_Jv, dim3(g), dim3(TPB), 0, b->stream, Y->nv_chunk, Y->Jp, Y->Ji, S.Jin(), v, part);
   DLG_LAUNCH_CHECK();
   return k_reduce_sum(b, part, g, out_dev);
 }
