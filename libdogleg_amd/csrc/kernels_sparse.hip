@@ -74,7 +74,8 @@ struct SparseSym
   int *jtx_fin_ptr = nullptr, *jtx_fin_blk = nullptr;
   AsmRho* asm_rho = nullptr; AsmPair* asm_pair = nullptr; AsmSlot* asm_slot = nullptr;
   AsmBatch* asm_batch = nullptr; AsmTask* asm_ctask = nullptr; AsmFin* asm_cfin = nullptr;
-  int *rl_ptr = nullptr, *rl_pos = nullptr, *perm = nullptr;
+  int *rl_ptr = nullptr, *rl_pos = nullptr, *perm = nullptr, *col_sn = nullptr;
+  const double* aug_rhs = nullptr;        // rhs the augmented rows of the current factor were built from
   int *Jp = nullptr, *Ji = nullptr;       // rank-local pattern (row pointers rebased to 0)
   int *nv_chunk = nullptr; int n_nv_chunks = 0;   // row runs of <= NV_CHUNK non-zeros for |Jv|^2
   // numeric buffers
@@ -324,6 +325,21 @@ __global__ void __launch_bounds__(TPB) k_add_lambda(double* __restrict__ Lx,
 {
   const int i = blockIdx.x*TPB + threadIdx.x;
   if(i < n) Lx[diagpos[i]] += lambda;
+}
+
+// augmented row: panel(last row, column k) = rhs[perm[k]]
+__global__ void __launch_bounds__(TPB) k_set_aug_row(double* __restrict__ Lx, const int* __restrict__ col_sn,
+                                                     const int* __restrict__ sn_c0,
+                                                     const int* __restrict__ sn_rowptr,
+                                                     const int64_t* __restrict__ sn_lx,
+                                                     const int* __restrict__ perm,
+                                                     const double* __restrict__ rhs, int n)
+{
+  const int k = blockIdx.x*TPB + threadIdx.x;
+  if(k >= n) return;
+  const int s = col_sn[k];
+  const int nrows = sn_rowptr[s+1] - sn_rowptr[s];
+  Lx[sn_lx[s] + (nrows - 1) + (int64_t)(k - sn_c0[s])*nrows] = rhs[perm[k]];
 }
 
 // ------------------------------------------------------------------ K1 ------
@@ -656,7 +672,9 @@ __global__ void __launch_bounds__(TPB) k_update_level(int unit0, const int* __re
     }
   }
 }
-// sum the partial slabs of a multi-chunk item in chunk order and apply them
+// sum the partial slabs of a multi-chunk item and apply them: the slab elements
+// are spread over the lanes, the partials over 256/64 = 4 (or, for small slabs,
+// up to 32) groups; fixed-order LDS reduction keeps the result deterministic
 __global__ void __launch_bounds__(TPB) k_update_fin(int f0, const int* __restrict__ uf_item,
                                                     const int* __restrict__ uf_n,
                                                     const int64_t* __restrict__ uf_off,
@@ -668,6 +686,7 @@ __global__ void __launch_bounds__(TPB) k_update_fin(int f0, const int* __restric
                                                     double* __restrict__ Lx,
                                                     const double* __restrict__ upart)
 {
+  __shared__ double sh[TPB];
   const int f = f0 + blockIdx.x;
   const int item = uf_item[f], n = uf_n[f];
   const int t = ui_t[item], col = ui_col[item], nc = ui_nc[item];
@@ -675,11 +694,24 @@ __global__ void __launch_bounds__(TPB) k_update_fin(int f0, const int* __restric
   double* Lt = Lx + sn_lx[t] + (int64_t)col*nrows_t;
   const int slab = nrows_t*nc;
   const double* src = upart + uf_off[f];
-  for(int e = threadIdx.x; e < slab; e += TPB)
+  // E lanes per element-chunk, G groups over the partials
+  const int E = (slab >= 128) ? 256 : (slab >= 64 ? 64 : (slab >= 32 ? 32 : 8));
+  const int G = TPB/E;
+  const int el = threadIdx.x % E, g = threadIdx.x / E;
+  for(int ebase = 0; ebase < slab; ebase += E)
   {
+    const int e = ebase + el;
     double tot = 0.0;
-    for(int k = 0; k < n; k++) tot += src[(size_t)k*slab + e];
-    Lt[e] -= tot;
+    if(e < slab) for(int k = g; k < n; k += G) tot += src[(size_t)k*slab + e];
+    __syncthreads();
+    sh[threadIdx.x] = tot;
+    __syncthreads();
+    if(g == 0 && e < slab)
+    {
+      double sacc = 0.0;
+      for(int k = 0; k < G; k++) sacc += sh[k*E + el];
+      Lt[e] -= sacc;
+    }
   }
 }
 
@@ -756,7 +788,7 @@ __global__ void __launch_bounds__(TPB) k_solve_fwd_level(const int* __restrict__
   }
   __syncthreads();
   for(int j = tid; j < w; j += TPB) ywork[c0 + j] = y[j];
-  const int r = nrows - w;
+  const int r = nrows - w - 1;            // the augmented row is not part of the solve
   double* u = scr + sn_scr[s];
   for(int i = tid; i < r; i += TPB)
   {
@@ -775,7 +807,7 @@ __global__ void __launch_bounds__(TPB) k_solve_bwd_level(const int* __restrict__
                                                          const int* __restrict__ perm,
                                                          const double* __restrict__ Lx,
                                                          double* __restrict__ ywork,
-                                                         double* __restrict__ out)
+                                                         double* __restrict__ out, int use_aug)
 {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   __shared__ double xs[256];
@@ -785,7 +817,7 @@ __global__ void __launch_bounds__(TPB) k_solve_bwd_level(const int* __restrict__
   const int* rows = sn_rows + sn_rowptr[s];
   const double* L = Lx + sn_lx[s];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int r = nrows - w;
+  const int r = nrows - w - 1;
   const int ldp = w | 1;
   batched_copy<TPB, 8>(w*w, tid, [&](int e) { const int j = e / w; return L[(e - j*w) + (size_t)j*nrows]; },
                        [&](int e, double v) { const int j = e / w; lds[(e - j*w) + j*ldp] = v; });
@@ -796,7 +828,7 @@ __global__ void __launch_bounds__(TPB) k_solve_bwd_level(const int* __restrict__
 #pragma unroll 4
     for(int i = lane; i < r; i += 64) sum += Lj[i]*ywork[rows[w + i]];
     sum = wave_sum(sum);
-    if(lane == 0) xs[j] = ywork[c0 + j] - sum;
+    if(lane == 0) xs[j] = (use_aug ? L[(nrows - 1) + (size_t)j*nrows] : ywork[c0 + j]) - sum;
   }
   __syncthreads();
   double xi = (tid < w) ? xs[tid] : 0.0;
@@ -846,7 +878,7 @@ int sparse_set_pattern(dlg_backend* b, const int* colptr, const int* rowidx)
   UP(uw_item); UP(uw_s0); UP(uw_s1); UP(uw_part); UP(uf_item); UP(uf_n); UP(uf_off);
   UP(oblk); UP(contrib); UP(jtx_task); UP(jtx_fin_ptr); UP(jtx_fin_blk);
   UP(asm_rho); UP(asm_pair); UP(asm_slot); UP(asm_batch); UP(asm_ctask); UP(asm_cfin);
-  UP(rl_ptr); UP(rl_pos); UP(perm);
+  UP(rl_ptr); UP(rl_pos); UP(perm); UP(col_sn);
   // rank-local pattern for the row-wise kernels
   {
     const int mloc = b->row1 - b->row0;
@@ -1002,6 +1034,14 @@ int sparse_factorize(dlg_backend* b, int s, double lambda, int* ok)
   if(lambda != 0.0)
     hipLaunchKernelGGL(k_add_lambda, dim3(dlg_cdiv(H.N, TPB)), dim3(TPB), 0, st, Y->Lx, Y->diagpos, H.N,
                        lambda);
+  // the right-hand side rides along as the last row of every panel: y = L^-1 P Jt_x falls out
+  Y->aug_rhs = nullptr;
+  if(S.have_Jtx)
+  {
+    hipLaunchKernelGGL(k_set_aug_row, dim3(dlg_cdiv(H.N, TPB)), dim3(TPB), 0, st, Y->Lx, Y->col_sn, Y->sn_c0,
+                       Y->sn_rowptr, Y->sn_lx, Y->perm, S.Jt_x, H.N);
+    Y->aug_rhs = S.Jt_x;
+  }
   // --- K5: level-scheduled supernodal Cholesky
   DlgProfScope pf(b, DLG_PROF_K5_FACTOR);
   *Y->h_info = 0x7fffffff;
@@ -1051,7 +1091,8 @@ int sparse_solve(dlg_backend* b, const double* rhs, double* out)
   if(!Y) { dlg_set_error("dlg_sparse_set_pattern must be called first"); return DLG_ERR_STATE; }
   const SymHost& H = Y->H;
   hipStream_t st = b->stream;
-  for(int l = 0; l < H.nlevels; l++)
+  const int use_aug = (Y->aug_rhs != nullptr && Y->aug_rhs == rhs) ? 1 : 0;
+  for(int l = 0; l < H.nlevels && !use_aug; l++)
   {
     const int n = H.lvl_ptr[l+1] - H.lvl_ptr[l];
     if(n > 0)
@@ -1064,7 +1105,7 @@ int sparse_solve(dlg_backend* b, const double* rhs, double* out)
     const int n = H.lvl_ptr[l+1] - H.lvl_ptr[l];
     if(n > 0)
       hipLaunchKernelGGL(k_solve_bwd_level, dim3(n), dim3(TPB), Y->slv_lds[l], st, Y->lvl_sn + H.lvl_ptr[l],
-                         Y->sn_c0, Y->sn_rowptr, Y->sn_rows, Y->sn_lx, Y->perm, Y->Lx, Y->ywork, out);
+                         Y->sn_c0, Y->sn_rowptr, Y->sn_rows, Y->sn_lx, Y->perm, Y->Lx, Y->ywork, out, use_aug);
   }
   DLG_LAUNCH_CHECK();
   return DLG_OK;

@@ -475,6 +475,7 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
   std::vector<int> sn_b0;                 // first block position of each supernode (+ sentinel)
   {
     const int relax = env_int("DOGLEG_AMD_RELAX_PCT", 25);
+    const int sib_w = env_int("DOGLEG_AMD_SIB_W", 64);
     int a = 0;
     long W = G.w[border[0]];              // current width
     long true_nnz = W*stw[0];             // sum_j w_j * |struct_j| (scalar) for columns in the supernode
@@ -494,7 +495,7 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
         const long stored = Wn*Rn + own_after;
         const long zeros = stored - tn;
         const bool exact = (st[j].size() == st[j+1].size() + 1);
-        const bool fits = ((Wn + Rn)*Wn <= PANEL_CAP) && Wn <= SN_WMAX;
+        const bool fits = ((Wn + Rn + 1)*Wn <= PANEL_CAP) && Wn <= SN_WMAX;
         if(fits && (exact || Wn <= 16 || zeros*100 <= (long)relax*(stored + Wn*Wn)))
         {
           merge = true;
@@ -506,7 +507,7 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
         // sibling leaves with identical structure: block-diagonal top, same rows below
         const long w1 = G.w[border[j+1]];
         const long Wn = W + w1, Rn = stw[j+1];
-        if(Wn <= 64 && (Wn + Rn)*Wn <= PANEL_CAP)
+        if(Wn <= sib_w && (Wn + Rn + 1)*Wn <= PANEL_CAP)
         {
           merge = true;
           true_nnz += w1*stw[j+1]; below_own += W*w1; W = Wn;
@@ -545,7 +546,7 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
   {
     const int w = S.sn_c0[s+1] - S.sn_c0[s];
     const long r = stw[sn_last(s)];
-    const long nrows = w + r;
+    const long nrows = w + r + 1;          // + the augmented right-hand-side row (see sparse_symbolic.h)
     S.sn_rowptr[s+1] = S.sn_rowptr[s] + (int)nrows;
     S.sn_lx[s+1] = S.sn_lx[s] + nrows*(long)w;
     S.sn_scr[s+1] = S.sn_scr[s] + (int)r;
@@ -569,13 +570,14 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
       belowoff[bi++] = k;
       for(int a = 0; a < G.w[border[q]]; a++) rows[k++] = colstart[q] + a;
     }
+    rows[k++] = N;                         // augmented row: virtual variable N, present in every panel
   }
-  S.diagpos.resize(N);
+  S.diagpos.resize(N); S.col_sn.resize(N);
   for(int s = 0; s < nsn; s++)
   {
     const int w = S.sn_c0[s+1] - S.sn_c0[s];
     const long ld = S.sn_rowptr[s+1] - S.sn_rowptr[s];
-    for(int c = 0; c < w; c++) S.diagpos[S.sn_c0[s] + c] = S.sn_lx[s] + c + c*ld;
+    for(int c = 0; c < w; c++) { S.diagpos[S.sn_c0[s] + c] = S.sn_lx[s] + c + c*ld; S.col_sn[S.sn_c0[s] + c] = s; }
   }
   // row offset of block position q inside supernode t's row list (-1 if absent)
   auto rowoff_in = [&](int t, int q) -> int {
@@ -642,6 +644,7 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
             for(int a = 0; a < G.w[border[q]]; a++) S.relpos.push_back(off + a);
           }
         }
+        S.relpos.push_back(S.sn_rowptr[t+1] - S.sn_rowptr[t] - 1);      // augmented row -> augmented row
         if((int)S.relpos.size() - relbase != nrows_d - k0) SYM_FAIL("internal error: relpos size mismatch");
         // one sub-task per target var-block
         while(i < bl.size() && sn_of_b[bl[i]] == t)
@@ -931,7 +934,7 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
     for(int d = 0; d < nsn; d++)
     {
       const int wd = S.sn_c0[d+1] - S.sn_c0[d];
-      for(int k = S.sn_rowptr[d] + wd; k < S.sn_rowptr[d+1]; k++) S.rl_ptr[S.sn_rows[k] + 1]++;
+      for(int k = S.sn_rowptr[d] + wd; k < S.sn_rowptr[d+1] - 1; k++) S.rl_ptr[S.sn_rows[k] + 1]++;
     }
     for(int k = 0; k < N; k++) S.rl_ptr[k+1] += S.rl_ptr[k];
     S.rl_pos.resize(S.rl_ptr[N]);
@@ -939,7 +942,7 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
     for(int d = 0; d < nsn; d++)
     {
       const int wd = S.sn_c0[d+1] - S.sn_c0[d];
-      for(int k = S.sn_rowptr[d] + wd, j = 0; k < S.sn_rowptr[d+1]; k++, j++)
+      for(int k = S.sn_rowptr[d] + wd, j = 0; k < S.sn_rowptr[d+1] - 1; k++, j++)
         S.rl_pos[nx[S.sn_rows[k]]++] = S.sn_scr[d] + j;
     }
   }

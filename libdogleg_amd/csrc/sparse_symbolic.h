@@ -13,6 +13,10 @@
 //     dense blocks last);
 //   * supernodes (block columns with nested structure merged), their dense
 //     column-major panels, the supernodal elimination-tree levels;
+//   * every panel carries one extra ("augmented") last row that holds the
+//     right-hand side Jt_x of its columns: the factorisation then produces
+//     y = L^-1 P Jt_x as a by-product (Cholesky of [A b; b' .]), so the
+//     Gauss-Newton solve needs only the backward substitution;
 //   * gather lists: which row-blocks contribute to which JtJ block (assembly,
 //     Jt*x), which descendant panels update which target panel columns
 //     (factorisation), which scratch entries feed which row (forward solve).
@@ -108,6 +112,7 @@ struct SymHost
   std::vector<int>     lvl_ptr;      // [nlevels+1]
   std::vector<int>     lvl_sn;       // [nsn] supernodes sorted by level
   std::vector<int64_t> diagpos;      // [N] Lx offset of the diagonal entry of column k
+  std::vector<int>     col_sn;       // [N] supernode of column k
   int64_t lx_size = 0;
   int     scr_size = 0;
   int     max_panel = 0;             // max nrows*w over supernodes
