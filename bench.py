@@ -192,6 +192,18 @@ def main():
                 "peak": MFMA_F64_PEAK_TFLOPS, "unit": "TFLOP/s", "traffic": None,
                 "algorithmic_flops": flops, "avg_launch_ms": k4_ms, "launches": cnt}
     roof["frac"] = (roof["achieved"] / roof["peak"]) if roof["achieved"] else None
+    # HBM traffic of that kernel from a separate rocprofv3 --pmc pass (FETCH_SIZE, WRITE_SIZE in
+    # their own runs; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950 -- the
+    # factor was re-checked on this repo's 8 B/lane streaming kernels, see profiles/r01_pmc.md).
+    # bench.py cannot collect PMC counters itself; the committed numbers are per launch.
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+        ent = tj.get(args.workload) if world == 1 else None
+        if ent:
+            roof["traffic"] = ent["bytes_per_launch"]
+            roof["traffic_source"] = ent["source"]
+    except Exception:
+        pass
 
     out = None
     if rank == 0:
