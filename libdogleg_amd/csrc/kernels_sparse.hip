@@ -75,6 +75,8 @@ struct SparseSym
   AsmRho* asm_rho = nullptr; AsmPair* asm_pair = nullptr; AsmSlot* asm_slot = nullptr;
   AsmBatch* asm_batch = nullptr; AsmTask* asm_ctask = nullptr; AsmFin* asm_cfin = nullptr;
   int *rl_ptr = nullptr, *rl_pos = nullptr, *perm = nullptr, *col_sn = nullptr;
+  int *fw_sn = nullptr, *fw_r0 = nullptr, *fw_r1 = nullptr, *ms_sn = nullptr; int64_t* sn_top = nullptr;
+  double* top_scr = nullptr;
   const double* aug_rhs = nullptr;        // rhs the augmented rows of the current factor were built from
   int *Jp = nullptr, *Ji = nullptr;       // rank-local pattern (row pointers rebased to 0)
   int *nv_chunk = nullptr; int n_nv_chunks = 0;   // row runs of <= NV_CHUNK non-zeros for |Jv|^2
@@ -478,30 +480,62 @@ __global__ void __launch_bounds__(TPB) k_norm2_Jv(const int* __restrict__ chunk_
 // instead of 3.  Panel in LDS with an even leading dimension (16-B aligned
 // broadcast reads).  USE_LDS == false: panels larger than the LDS budget are
 // factored in place in HBM with the same code path (slow, rare).
-template <int NT, bool USE_LDS>
-__global__ void __launch_bounds__(NT) k_factor_level(const int* __restrict__ lvl_sn,
+// One workgroup per work item = (supernode, slice [r0,r1) of its below rows): the LDS
+// panel holds the w x w top block plus the slice; slices of one supernode factor the top
+// block redundantly (identical arithmetic), slice 0 publishes it.
+template <int NT>
+__global__ void __launch_bounds__(NT) k_factor_level(const int* __restrict__ fw_sn,
+                                                     const int* __restrict__ fw_r0,
+                                                     const int* __restrict__ fw_r1,
                                                      const int* __restrict__ sn_c0,
                                                      const int* __restrict__ sn_rowptr,
                                                      const int64_t* __restrict__ sn_lx,
-                                                     double* __restrict__ Lx, int* __restrict__ info)
+                                                     const int64_t* __restrict__ sn_top,
+                                                     double* __restrict__ Lx,
+                                                     double* __restrict__ top_scr,
+                                                     int* __restrict__ info)
 {
-  extern __shared__ __attribute__((aligned(16))) double lds[];
-  const int s = lvl_sn[blockIdx.x];
+  extern __shared__ __attribute__((aligned(16))) double P[];
+  __shared__ int sbad;
+  const int s = fw_sn[blockIdx.x], r0 = fw_r0[blockIdx.x], r1 = fw_r1[blockIdx.x];
   const int w = sn_c0[s+1] - sn_c0[s];
   const int nrows = sn_rowptr[s+1] - sn_rowptr[s];
   double* G = Lx + sn_lx[s];
   const int tid = threadIdx.x;
-  const int ldp = USE_LDS ? ((nrows + 1) & ~1) : nrows;
-  double* P = USE_LDS ? lds : G;
-  if(USE_LDS)
+  const int nloc = w + (r1 - r0);             // rows held by this workgroup
+  const int ldp = (nloc + 1) & ~1;
+  const int shift = r0;                        // local row i >= w  <->  panel row i + shift
+  if(tid == 0) sbad = 0x7fffffff;
+  batched_copy<NT, 8>(nloc*w, tid,
+                      [&](int e) { const int j = e / nloc, i = e - j*nloc; return G[(i < w ? i : i + shift) + (size_t)j*nrows]; },
+                      [&](int e, double v) { const int j = e / nloc; P[e + j*(ldp - nloc)] = v; });
+  __syncthreads();
+  panel_factor<NT, true>(P, ldp, nloc, w, tid, &sbad, sn_c0[s]);
+  const int64_t top = sn_top[s];
+  if(r0 == 0 && tid == 0 && sbad != 0x7fffffff) atomicMin(info, sbad);
+  for(int e = tid; e < nloc*w; e += NT)
   {
-    batched_copy<NT, 8>(nrows*w, tid, [&](int e) { return G[e]; },
-                        [&](int e, double v) { const int j = e / nrows; P[e + j*(ldp - nrows)] = v; });
-    __syncthreads();
+    const int j = e / nloc, i = e - j*nloc;
+    const double v = P[e + j*(ldp - nloc)];
+    if(i >= w) G[(i + shift) + (size_t)j*nrows] = v;
+    else if(top < 0) G[i + (size_t)j*nrows] = v;
+    else if(r0 == 0) top_scr[top + i + (size_t)j*w] = v;
   }
-  panel_factor<NT, USE_LDS>(P, ldp, nrows, w, tid, info, sn_c0[s]);
-  if(USE_LDS)
-    for(int e = tid; e < nrows*w; e += NT) { const int j = e / nrows; G[e] = P[e + j*(ldp - nrows)]; }
+}
+// publish the top blocks of the multi-slice supernodes
+__global__ void __launch_bounds__(TPB) k_copy_top(const int* __restrict__ ms_sn, const int* __restrict__ sn_c0,
+                                                  const int* __restrict__ sn_rowptr,
+                                                  const int64_t* __restrict__ sn_lx,
+                                                  const int64_t* __restrict__ sn_top,
+                                                  double* __restrict__ Lx,
+                                                  const double* __restrict__ top_scr)
+{
+  const int s = ms_sn[blockIdx.x];
+  const int w = sn_c0[s+1] - sn_c0[s];
+  const int nrows = sn_rowptr[s+1] - sn_rowptr[s];
+  double* G = Lx + sn_lx[s];
+  const double* T = top_scr + sn_top[s];
+  for(int e = threadIdx.x; e < w*w; e += TPB) { const int j = e / w, i = e - j*w; G[i + (size_t)j*nrows] = T[e]; }
 }
 
 // cooperative variant of the update for heavy sources (wide panels): the whole
@@ -878,7 +912,7 @@ int sparse_set_pattern(dlg_backend* b, const int* colptr, const int* rowidx)
   UP(uw_item); UP(uw_s0); UP(uw_s1); UP(uw_part); UP(uf_item); UP(uf_n); UP(uf_off);
   UP(oblk); UP(contrib); UP(jtx_task); UP(jtx_fin_ptr); UP(jtx_fin_blk);
   UP(asm_rho); UP(asm_pair); UP(asm_slot); UP(asm_batch); UP(asm_ctask); UP(asm_cfin);
-  UP(rl_ptr); UP(rl_pos); UP(perm); UP(col_sn);
+  UP(rl_ptr); UP(rl_pos); UP(perm); UP(col_sn); UP(fw_sn); UP(fw_r0); UP(fw_r1); UP(ms_sn); UP(sn_top);
   // rank-local pattern for the row-wise kernels
   {
     const int mloc = b->row1 - b->row0;
@@ -905,6 +939,7 @@ int sparse_set_pattern(dlg_backend* b, const int* colptr, const int* rowidx)
   DLG_CHECK(dalloc(Y->scr, (size_t)H.scr_size));
   DLG_CHECK(dalloc(Y->ywork, (size_t)H.N));
   DLG_CHECK(dalloc(Y->upart, (size_t)H.upart_size));
+  DLG_CHECK(dalloc(Y->top_scr, (size_t)H.top_size));
   DLG_CHECK(dalloc(Y->asm_part, (size_t)H.asm_part_size));
   DLG_CHECK(dalloc(Y->jtx_part, (size_t)H.jtx_nparts*8));
   DLG_HIP(hipMalloc(&Y->d_info, sizeof(int))); Y->allocs.push_back(Y->d_info);
@@ -920,14 +955,21 @@ int sparse_set_pattern(dlg_backend* b, const int* colptr, const int* rowidx)
     {
       const int s = H.lvl_sn[i];
       const long wv = H.sn_c0[s+1] - H.sn_c0[s];
-      const long nr = H.sn_rowptr[s+1] - H.sn_rowptr[s];
-      const long p = ((nr + 1) & ~1L)*wv;        // even leading dimension in LDS
-      if(p > maxp) maxp = p;
       if(wv > maxw) maxw = wv;
-      if(nr > maxr) maxr = nr;
+    }
+    for(int i = H.fw_lvl_ptr[l]; i < H.fw_lvl_ptr[l+1]; i++)
+    {
+      const int s = H.fw_sn[i];
+      const long wv = H.sn_c0[s+1] - H.sn_c0[s];
+      const long nloc = wv + (H.fw_r1[i] - H.fw_r0[i]);
+      const long p = ((nloc + 1) & ~1L)*wv;        // even leading dimension in LDS
+      if(p > maxp) maxp = p;
+      if(nloc > maxr) maxr = nloc;
     }
     Y->fac_nt[l] = (maxr <= 128) ? 128 : 512;
     Y->upd_coop[l] = (maxw > 8) ? 1 : 0;           // heavy sources: cooperative update kernel
+    if(maxp*8 > LDS_BUDGET) { dlg_set_error("internal error: a factor slice does not fit LDS (%ld doubles)", maxp); return DLG_ERR_ARG; }
+    Y->fac_lds[l] = (int)(maxp*8);
     Y->slv_lds[l] = (int)(maxw*(maxw | 1)*8);
     if(Y->slv_lds[l] > LDS_BUDGET) { dlg_set_error("supernode of width %ld is too wide for the solve kernels", maxw); return DLG_ERR_ARG; }
     Y->fac_lds[l] = (maxp*8 <= LDS_BUDGET - 4096) ? (int)(maxp*8) : 0;
@@ -943,9 +985,9 @@ int sparse_set_pattern(dlg_backend* b, const int* colptr, const int* rowidx)
     Y->upd_nw[l] = nw;
     Y->upd_lds[l] = (int)(maxslab*8*nw);
   }
-  DLG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_factor_level<128, true>),
+  DLG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_factor_level<128>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BUDGET));
-  DLG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_factor_level<512, true>),
+  DLG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_factor_level<512>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BUDGET));
   DLG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_update_level),
                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BUDGET));
@@ -1048,18 +1090,18 @@ int sparse_factorize(dlg_backend* b, int s, double lambda, int* ok)
   DLG_HIP(hipMemcpyAsync(Y->d_info, Y->h_info, sizeof(int), hipMemcpyHostToDevice, st));
   for(int l = 0; l < H.nlevels; l++)
   {
-    const int n = H.lvl_ptr[l+1] - H.lvl_ptr[l];
+    const int n = H.fw_lvl_ptr[l+1] - H.fw_lvl_ptr[l];
     if(n > 0)
     {
-      if(Y->fac_lds[l] > 0 && Y->fac_nt[l] == 128)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_factor_level<128, true>), dim3(n), dim3(128), Y->fac_lds[l], st,
-                           Y->lvl_sn + H.lvl_ptr[l], Y->sn_c0, Y->sn_rowptr, Y->sn_lx, Y->Lx, Y->d_info);
-      else if(Y->fac_lds[l] > 0)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_factor_level<512, true>), dim3(n), dim3(512), Y->fac_lds[l], st,
-                           Y->lvl_sn + H.lvl_ptr[l], Y->sn_c0, Y->sn_rowptr, Y->sn_lx, Y->Lx, Y->d_info);
+      const int o = H.fw_lvl_ptr[l];
+      if(Y->fac_nt[l] == 128)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_factor_level<128>), dim3(n), dim3(128), Y->fac_lds[l], st,
+                           Y->fw_sn + o, Y->fw_r0 + o, Y->fw_r1 + o, Y->sn_c0, Y->sn_rowptr, Y->sn_lx,
+                           Y->sn_top, Y->Lx, Y->top_scr, Y->d_info);
       else
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_factor_level<512, false>), dim3(n), dim3(512), 0, st,
-                           Y->lvl_sn + H.lvl_ptr[l], Y->sn_c0, Y->sn_rowptr, Y->sn_lx, Y->Lx, Y->d_info);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_factor_level<512>), dim3(n), dim3(512), Y->fac_lds[l], st,
+                           Y->fw_sn + o, Y->fw_r0 + o, Y->fw_r1 + o, Y->sn_c0, Y->sn_rowptr, Y->sn_lx,
+                           Y->sn_top, Y->Lx, Y->top_scr, Y->d_info);
     }
     const int nu = H.uw_lvl_ptr[l+1] - H.uw_lvl_ptr[l];
     if(nu > 0 && Y->upd_coop[l])
@@ -1076,6 +1118,9 @@ int sparse_factorize(dlg_backend* b, int s, double lambda, int* ok)
                          Y->uf_off, Y->ui_t, Y->ui_col, Y->ui_nc, Y->sn_rowptr, Y->sn_lx, Y->Lx,
                          Y->upart);
   }
+  if(!H.ms_sn.empty())
+    hipLaunchKernelGGL(k_copy_top, dim3((unsigned)H.ms_sn.size()), dim3(TPB), 0, st, Y->ms_sn, Y->sn_c0,
+                       Y->sn_rowptr, Y->sn_lx, Y->sn_top, Y->Lx, Y->top_scr);
   DLG_LAUNCH_CHECK();
   DLG_HIP(hipMemcpyAsync(Y->h_info, Y->d_info, sizeof(int), hipMemcpyDeviceToHost, st));
   if(pf.e) { dlg_prof_end(b, pf.id, pf.e); pf.e = nullptr; }

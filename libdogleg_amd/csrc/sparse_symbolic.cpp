@@ -444,18 +444,48 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
       }
       i = k;
     }
-    if(!members.empty())
+    // New order: every leaf first (grouped by structure, groups and single leaves by
+    // first position), then the remaining nodes in a POSTORDER of the elimination tree
+    // restricted to them.  With the leaves out of the way a chain of the tree (e.g. the
+    // cameras of one dissection leaf, whose other children are all points) becomes a run
+    // of consecutive columns and merges into one supernode.
     {
+      std::vector<char> is_leaf(nvb, 0);
+      for(int j : leaves) is_leaf[j] = 1;
       std::vector<int> nb; nb.reserve(nvb);
       std::vector<char> done(members.size(), 0);
       for(int j = 0; j < nvb; j++)
       {
+        if(!is_leaf[j]) continue;
         const int g = group_of[j];
         if(g < 0) { nb.push_back(border[j]); continue; }
         if(done[g]) continue;
         done[g] = 1;
         for(int x : members[g]) nb.push_back(border[x]);
       }
+      // children lists of the non-leaf forest
+      std::vector<int> chead(nvb, -1), cnext(nvb, -1);
+      std::vector<int> roots;
+      for(int j = nvb - 1; j >= 0; j--)
+      {
+        if(is_leaf[j]) continue;
+        if(parent[j] >= 0) { cnext[j] = chead[parent[j]]; chead[parent[j]] = j; }   // ascending child lists
+        else roots.push_back(j);
+      }
+      std::sort(roots.begin(), roots.end());
+      std::vector<int> stack, it(nvb, -2);
+      for(int r : roots)
+      {
+        stack.push_back(r);
+        while(!stack.empty())
+        {
+          const int u = stack.back();
+          if(it[u] == -2) it[u] = chead[u];
+          if(it[u] >= 0) { const int c = it[u]; it[u] = cnext[c]; stack.push_back(c); }
+          else { nb.push_back(border[u]); stack.pop_back(); }
+        }
+      }
+      if((int)nb.size() != nvb) SYM_FAIL("internal error: postorder lost blocks (%zu of %d)", nb.size(), nvb);
       border.swap(nb);
       for(int k = 0; k < nvb; k++) bpos[border[k]] = k;
       symbolic();
@@ -495,7 +525,8 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
         const long stored = Wn*Rn + own_after;
         const long zeros = stored - tn;
         const bool exact = (st[j].size() == st[j+1].size() + 1);
-        const bool fits = ((Wn + Rn + 1)*Wn <= PANEL_CAP) && Wn <= SN_WMAX;
+        // a panel is factored in row slices (>= 64 rows each) that all carry the w x w top block
+        const bool fits = (Wn*(Wn + 64) <= PANEL_CAP) && Wn <= SN_WMAX;
         if(fits && (exact || Wn <= 16 || zeros*100 <= (long)relax*(stored + Wn*Wn)))
         {
           merge = true;
@@ -606,6 +637,56 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
   {
     std::vector<int> nx(S.lvl_ptr.begin(), S.lvl_ptr.end() - 1);
     for(int s = 0; s < nsn; s++) S.lvl_sn[nx[S.sn_level[s]]++] = s;
+  }
+
+  // factor work list: (supernode, slice of its below rows).  Panels larger than the LDS
+  // budget are cut into row slices; every slice workgroup also holds the w x w top block
+  // and factors it redundantly, only slice 0 publishes it (into top_scr, copied back at
+  // the end: no other kernel of the factorisation reads a top block).
+  {
+    S.fw_lvl_ptr.assign(S.nlevels + 1, 0);
+    S.sn_top.assign(nsn, -1);
+    S.top_size = 0;
+    for(int l = 0; l < S.nlevels; l++)
+    {
+      for(int i = S.lvl_ptr[l]; i < S.lvl_ptr[l+1]; i++)
+      {
+        const int s = S.lvl_sn[i];
+        const int w = S.sn_c0[s+1] - S.sn_c0[s];
+        const int nrows = S.sn_rowptr[s+1] - S.sn_rowptr[s];
+        const int below = nrows - w;
+        int nsl = 1;
+        if((long)nrows*w > PANEL_CAP)
+        {
+          int rpw = PANEL_CAP/w - w; if(rpw < 1) rpw = 1;
+          nsl = (below + rpw - 1)/rpw;
+        }
+        if(nsl > 1) { S.sn_top[s] = S.top_size; S.top_size += (int64_t)w*w; S.ms_sn.push_back(s); }
+        const int per = (below + nsl - 1)/nsl;
+        for(int k = 0; k < nsl; k++)
+        {
+          S.fw_sn.push_back(s); S.fw_r0.push_back(std::min(below, k*per)); S.fw_r1.push_back(std::min(below, (k+1)*per));
+        }
+        S.fw_lvl_ptr[l+1] += nsl;
+      }
+    }
+    for(int l = 0; l < S.nlevels; l++) S.fw_lvl_ptr[l+1] += S.fw_lvl_ptr[l];
+  }
+
+  if(env_int("DOGLEG_AMD_SYM_DEBUG", 0))
+  {
+    for(int l = 0; l < S.nlevels; l++)
+    {
+      long n = 0, wsum = 0, rsum = 0; int wmin = 1 << 30, wmax = 0, rmax = 0;
+      for(int i = S.lvl_ptr[l]; i < S.lvl_ptr[l+1]; i++)
+      {
+        const int s = S.lvl_sn[i];
+        const int w = S.sn_c0[s+1] - S.sn_c0[s], nr = S.sn_rowptr[s+1] - S.sn_rowptr[s];
+        n++; wsum += w; rsum += nr; wmin = std::min(wmin, w); wmax = std::max(wmax, w); rmax = std::max(rmax, nr);
+      }
+      fprintf(stderr, "level %2d: %5ld supernodes  w min/avg/max %d/%.1f/%d  nrows avg/max %.1f/%d  slices %d\n", l, n, wmin,
+              (double)wsum/n, wmax, (double)rsum/n, rmax, S.fw_lvl_ptr[l+1] - S.fw_lvl_ptr[l]);
+    }
   }
 
   // ------------------------------------ 8. factor update schedule

@@ -111,6 +111,10 @@ struct SymHost
   int nlevels = 0;
   std::vector<int>     lvl_ptr;      // [nlevels+1]
   std::vector<int>     lvl_sn;       // [nsn] supernodes sorted by level
+  std::vector<int>     fw_lvl_ptr, fw_sn, fw_r0, fw_r1;   // factor work items: supernode + slice of its below rows
+  std::vector<int64_t> sn_top;       // [nsn] offset of the top-block copy in top_scr for multi-slice supernodes, else -1
+  std::vector<int>     ms_sn;        // the multi-slice supernodes
+  int64_t top_size = 0;
   std::vector<int64_t> diagpos;      // [N] Lx offset of the diagonal entry of column k
   std::vector<int>     col_sn;       // [N] supernode of column k
   int64_t lx_size = 0;
