@@ -76,6 +76,7 @@ struct SparseSym
   AsmBatch* asm_batch = nullptr; AsmTask* asm_ctask = nullptr; AsmFin* asm_cfin = nullptr;
   int *rl_ptr = nullptr, *rl_pos = nullptr, *perm = nullptr, *col_sn = nullptr;
   int *fw_sn = nullptr, *fw_r0 = nullptr, *fw_r1 = nullptr, *ms_sn = nullptr; int64_t* sn_top = nullptr;
+  int *sn_bd_ptr = nullptr, *sn_bd_col = nullptr;
   double* top_scr = nullptr;
   const double* aug_rhs = nullptr;        // rhs the augmented rows of the current factor were built from
   int *Jp = nullptr, *Ji = nullptr;       // rank-local pattern (row pointers rebased to 0)
@@ -491,6 +492,8 @@ __global__ void __launch_bounds__(NT) k_factor_level(const int* __restrict__ fw_
                                                      const int* __restrict__ sn_rowptr,
                                                      const int64_t* __restrict__ sn_lx,
                                                      const int64_t* __restrict__ sn_top,
+                                                     const int* __restrict__ sn_bd_ptr,
+                                                     const int* __restrict__ sn_bd_col,
                                                      double* __restrict__ Lx,
                                                      double* __restrict__ top_scr,
                                                      int* __restrict__ info)
@@ -510,7 +513,9 @@ __global__ void __launch_bounds__(NT) k_factor_level(const int* __restrict__ fw_
                       [&](int e) { const int j = e / nloc, i = e - j*nloc; return G[(i < w ? i : i + shift) + (size_t)j*nrows]; },
                       [&](int e, double v) { const int j = e / nloc; P[e + j*(ldp - nloc)] = v; });
   __syncthreads();
-  panel_factor<NT, true>(P, ldp, nloc, w, tid, &sbad, sn_c0[s]);
+  const int nmem = sn_bd_ptr[s+1] - sn_bd_ptr[s];
+  if(nmem > 0) panel_factor_blockdiag<NT>(P, ldp, nloc, w, tid, sn_bd_col + sn_bd_ptr[s], nmem, &sbad, sn_c0[s]);
+  else         panel_factor<NT, true>(P, ldp, nloc, w, tid, &sbad, sn_c0[s]);
   const int64_t top = sn_top[s];
   if(r0 == 0 && tid == 0 && sbad != 0x7fffffff) atomicMin(info, sbad);
   for(int e = tid; e < nloc*w; e += NT)
@@ -912,7 +917,7 @@ int sparse_set_pattern(dlg_backend* b, const int* colptr, const int* rowidx)
   UP(uw_item); UP(uw_s0); UP(uw_s1); UP(uw_part); UP(uf_item); UP(uf_n); UP(uf_off);
   UP(oblk); UP(contrib); UP(jtx_task); UP(jtx_fin_ptr); UP(jtx_fin_blk);
   UP(asm_rho); UP(asm_pair); UP(asm_slot); UP(asm_batch); UP(asm_ctask); UP(asm_cfin);
-  UP(rl_ptr); UP(rl_pos); UP(perm); UP(col_sn); UP(fw_sn); UP(fw_r0); UP(fw_r1); UP(ms_sn); UP(sn_top);
+  UP(rl_ptr); UP(rl_pos); UP(perm); UP(col_sn); UP(fw_sn); UP(fw_r0); UP(fw_r1); UP(ms_sn); UP(sn_top); UP(sn_bd_ptr); UP(sn_bd_col);
   // rank-local pattern for the row-wise kernels
   {
     const int mloc = b->row1 - b->row0;
@@ -1097,11 +1102,11 @@ int sparse_factorize(dlg_backend* b, int s, double lambda, int* ok)
       if(Y->fac_nt[l] == 128)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_factor_level<128>), dim3(n), dim3(128), Y->fac_lds[l], st,
                            Y->fw_sn + o, Y->fw_r0 + o, Y->fw_r1 + o, Y->sn_c0, Y->sn_rowptr, Y->sn_lx,
-                           Y->sn_top, Y->Lx, Y->top_scr, Y->d_info);
+                           Y->sn_top, Y->sn_bd_ptr, Y->sn_bd_col, Y->Lx, Y->top_scr, Y->d_info);
       else
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_factor_level<512>), dim3(n), dim3(512), Y->fac_lds[l], st,
                            Y->fw_sn + o, Y->fw_r0 + o, Y->fw_r1 + o, Y->sn_c0, Y->sn_rowptr, Y->sn_lx,
-                           Y->sn_top, Y->Lx, Y->top_scr, Y->d_info);
+                           Y->sn_top, Y->sn_bd_ptr, Y->sn_bd_col, Y->Lx, Y->top_scr, Y->d_info);
     }
     const int nu = H.uw_lvl_ptr[l+1] - H.uw_lvl_ptr[l];
     if(nu > 0 && Y->upd_coop[l])

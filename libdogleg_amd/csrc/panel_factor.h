@@ -111,3 +111,75 @@ __device__ __forceinline__ void panel_factor(double* P, int ldp, int nrows, int 
     __syncthreads();
   }
 }
+
+// Panel whose w x w top block is block diagonal (a supernode made of independent
+// sibling leaves, e.g. the points seen by one set of cameras): member m owns columns
+// [mcol[m], mcol[m+1]) (at most 8).  The members do not couple, so there is no sweep:
+//   A: thread m factors the diagonal block of member m in registers (<= 8x8);
+//   B: after one barrier every below row solves against each member's block.
+template <int NT>
+__device__ __forceinline__ void panel_factor_blockdiag(double* P, int ldp, int nrows, int w, int tid,
+                                                       const int* __restrict__ mcol, int nmem,
+                                                       int* __restrict__ info, int col0)
+{
+  for(int m = tid; m < nmem; m += NT)
+  {
+    const int c0 = mcol[m], nb = ((m + 1 < nmem) ? mcol[m+1] : w) - c0;
+    double D[8][8];
+#pragma unroll
+    for(int c = 0; c < 8; c++)
+#pragma unroll
+      for(int q = 0; q <= c; q++)
+        D[c][q] = (c < nb) ? P[(c0 + c) + (c0 + q)*ldp] : ((c == q) ? 1.0 : 0.0);
+    bool bad = false; int badcol = 0;
+#pragma unroll
+    for(int c = 0; c < 8; c++)
+    {
+      double d = D[c][c];
+#pragma unroll
+      for(int q = 0; q < c; q++) d -= D[c][q]*D[c][q];
+      if(!(d > 0.0)) { if(!bad) { bad = true; badcol = c; } d = 1.0; }
+      const double piv = sqrt(d);
+      D[c][c] = piv;
+      const double inv = 1.0/piv;
+#pragma unroll
+      for(int i = c + 1; i < 8; i++)
+      {
+        double v = D[i][c];
+#pragma unroll
+        for(int q = 0; q < c; q++) v -= D[i][q]*D[c][q];
+        D[i][c] = v*inv;
+      }
+    }
+    if(bad) atomicMin(info, col0 + c0 + badcol);
+#pragma unroll
+    for(int c = 0; c < 8; c++)
+#pragma unroll
+      for(int q = 0; q <= c; q++) if(c < nb) P[(c0 + c) + (c0 + q)*ldp] = D[c][q];
+  }
+  __syncthreads();
+  for(int r = w + tid; r < nrows; r += NT)
+  {
+    for(int m = 0; m < nmem; m++)
+    {
+      const int c0 = mcol[m], nb = ((m + 1 < nmem) ? mcol[m+1] : w) - c0;
+      double x[8];
+#pragma unroll
+      for(int c = 0; c < 8; c++) x[c] = (c < nb) ? P[r + (c0 + c)*ldp] : 0.0;
+#pragma unroll
+      for(int c = 0; c < 8; c++)
+      {
+        if(c < nb)
+        {
+          double v = x[c];
+#pragma unroll
+          for(int q = 0; q < c; q++) v -= x[q]*P[(c0 + c) + (c0 + q)*ldp];
+          x[c] = v/P[(c0 + c) + (c0 + c)*ldp];
+        }
+      }
+#pragma unroll
+      for(int c = 0; c < 8; c++) if(c < nb) P[r + (c0 + c)*ldp] = x[c];
+    }
+  }
+  __syncthreads();
+}

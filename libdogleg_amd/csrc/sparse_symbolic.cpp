@@ -503,6 +503,7 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
 
   // ------------------------------------------------------- 6. supernodes
   std::vector<int> sn_b0;                 // first block position of each supernode (+ sentinel)
+  std::vector<char> sn_bd;                // supernode made of sibling leaves only: block-diagonal top
   {
     const int relax = env_int("DOGLEG_AMD_RELAX_PCT", 25);
     const int sib_w = env_int("DOGLEG_AMD_SIB_W", 64);
@@ -511,6 +512,7 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
     long true_nnz = W*stw[0];             // sum_j w_j * |struct_j| (scalar) for columns in the supernode
     long below_own = 0;                   // helper: sum_j w_j * (own cols after j)
     sn_b0.push_back(0);
+    bool sib_only = true; int nmerge = 0;
     for(int j = 0; j + 1 <= nvb; j++)
     {
       bool merge = false;
@@ -529,7 +531,7 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
         const bool fits = (Wn*(Wn + 64) <= PANEL_CAP) && Wn <= SN_WMAX;
         if(fits && (exact || Wn <= 16 || zeros*100 <= (long)relax*(stored + Wn*Wn)))
         {
-          merge = true;
+          merge = true; sib_only = false; nmerge++;
           W = Wn; true_nnz = tn; below_own = own_after;
         }
       }
@@ -540,16 +542,18 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
         const long Wn = W + w1, Rn = stw[j+1];
         if(Wn <= sib_w && (Wn + Rn + 1)*Wn <= PANEL_CAP)
         {
-          merge = true;
+          merge = true; nmerge++;
           true_nnz += w1*stw[j+1]; below_own += W*w1; W = Wn;
         }
       }
       if(!merge && j + 1 < nvb)
       {
+        sn_bd.push_back((sib_only && nmerge > 0) ? 1 : 0); sib_only = true; nmerge = 0;
         a = j + 1; sn_b0.push_back(a);
         W = G.w[border[a]]; true_nnz = W*stw[a]; below_own = 0;
       }
     }
+    sn_bd.push_back((sib_only && nmerge > 0) ? 1 : 0);
     sn_b0.push_back(nvb);
   }
   S.nsn = (int)sn_b0.size() - 1;
@@ -572,6 +576,13 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
     S.sn_c0[s] = colstart[sn_b0[s]];
   }
   S.sn_c0[nsn] = N;
+  // members (var-blocks) of the block-diagonal supernodes
+  S.sn_bd_ptr.assign(nsn + 1, 0);
+  for(int s2 = 0; s2 < nsn; s2++)
+  {
+    if(sn_bd[s2]) for(int k = sn_b0[s2]; k < sn_b0[s2+1]; k++) S.sn_bd_col.push_back(colstart[k] - colstart[sn_b0[s2]]);
+    S.sn_bd_ptr[s2+1] = (int)S.sn_bd_col.size();
+  }
   S.max_panel = 0;
   for(int s = 0; s < nsn; s++)
   {

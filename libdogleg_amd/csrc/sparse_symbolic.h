@@ -111,6 +111,7 @@ struct SymHost
   int nlevels = 0;
   std::vector<int>     lvl_ptr;      // [nlevels+1]
   std::vector<int>     lvl_sn;       // [nsn] supernodes sorted by level
+  std::vector<int>     sn_bd_ptr, sn_bd_col;   // block-diagonal-top supernodes: first column of each member block
   std::vector<int>     fw_lvl_ptr, fw_sn, fw_r0, fw_r1;   // factor work items: supernode + slice of its below rows
   std::vector<int64_t> sn_top;       // [nsn] offset of the top-block copy in top_scr for multi-slice supernodes, else -1
   std::vector<int>     ms_sn;        // the multi-slice supernodes
