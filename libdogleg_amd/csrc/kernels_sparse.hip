@@ -87,7 +87,7 @@ struct SparseSym
   size_t nnz_loc = 0;
   // per-level launch parameters
   std::vector<int> fac_lds;     // bytes of LDS for the factor kernel of a level (0: panels stay in HBM)
-  std::vector<int> upd_lds, upd_nw, slv_lds, fac_nt, upd_coop;
+  std::vector<int> upd_lds, upd_nw, slv_lds, bwd_lds, fac_nt, upd_coop;
   std::vector<void*> allocs;
 };
 
@@ -837,16 +837,19 @@ __global__ void __launch_bounds__(TPB) k_solve_fwd_level(const int* __restrict__
     u[i] = sum;
   }
 }
-// backward: x_t = L_tt^-T (y_t - L_below^T x[below rows]); out[perm] = x
-__global__ void __launch_bounds__(TPB) k_solve_bwd_level(const int* __restrict__ lvl_sn,
-                                                         const int* __restrict__ sn_c0,
-                                                         const int* __restrict__ sn_rowptr,
-                                                         const int* __restrict__ sn_rows,
-                                                         const int64_t* __restrict__ sn_lx,
-                                                         const int* __restrict__ perm,
-                                                         const double* __restrict__ Lx,
-                                                         double* __restrict__ ywork,
-                                                         double* __restrict__ out, int use_aug)
+// backward: x_t = L_tt^-T (y_t - L_below^T x[below rows]); out[perm] = x.
+// x at the below rows is gathered into LDS once (not once per column); 8 waves share the
+// columns of the L_below^T mat-vec; the diagonal block is staged for the column sweep.
+constexpr int BWD_NT = 512;
+__global__ void __launch_bounds__(BWD_NT) k_solve_bwd_level(const int* __restrict__ lvl_sn,
+                                                            const int* __restrict__ sn_c0,
+                                                            const int* __restrict__ sn_rowptr,
+                                                            const int* __restrict__ sn_rows,
+                                                            const int64_t* __restrict__ sn_lx,
+                                                            const int* __restrict__ perm,
+                                                            const double* __restrict__ Lx,
+                                                            double* __restrict__ ywork,
+                                                            double* __restrict__ out, int use_aug)
 {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   __shared__ double xs[256];
@@ -858,14 +861,17 @@ __global__ void __launch_bounds__(TPB) k_solve_bwd_level(const int* __restrict__
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int r = nrows - w - 1;
   const int ldp = w | 1;
-  batched_copy<TPB, 8>(w*w, tid, [&](int e) { const int j = e / w; return L[(e - j*w) + (size_t)j*nrows]; },
-                       [&](int e, double v) { const int j = e / w; lds[(e - j*w) + j*ldp] = v; });
-  for(int j = wv; j < w; j += TPB/64)
+  double* xb = lds + (size_t)w*ldp;
+  batched_copy<BWD_NT, 8>(w*w, tid, [&](int e) { const int j = e / w; return L[(e - j*w) + (size_t)j*nrows]; },
+                          [&](int e, double v) { const int j = e / w; lds[(e - j*w) + j*ldp] = v; });
+  for(int i = tid; i < r; i += BWD_NT) xb[i] = ywork[rows[w + i]];
+  __syncthreads();
+  for(int j = wv; j < w; j += BWD_NT/64)
   {
     const double* Lj = L + (size_t)j*nrows + w;
     double sum = 0.0;
 #pragma unroll 4
-    for(int i = lane; i < r; i += 64) sum += Lj[i]*ywork[rows[w + i]];
+    for(int i = lane; i < r; i += 64) sum += Lj[i]*xb[i];
     sum = wave_sum(sum);
     if(lane == 0) xs[j] = (use_aug ? L[(nrows - 1) + (size_t)j*nrows] : ywork[c0 + j]) - sum;
   }
@@ -878,7 +884,7 @@ __global__ void __launch_bounds__(TPB) k_solve_bwd_level(const int* __restrict__
     if(tid < j) xi -= lds[j + tid*ldp]*xs[j];
   }
   __syncthreads();
-  for(int j = tid; j < w; j += TPB) { ywork[c0 + j] = xs[j]; out[perm[c0 + j]] = xs[j]; }
+  for(int j = tid; j < w; j += BWD_NT) { ywork[c0 + j] = xs[j]; out[perm[c0 + j]] = xs[j]; }
 }
 
 } // namespace
@@ -952,7 +958,7 @@ int sparse_set_pattern(dlg_backend* b, const int* colptr, const int* rowidx)
 
   // per-level launch parameters
   Y->fac_lds.assign(H.nlevels, 0); Y->upd_lds.assign(H.nlevels, 0); Y->upd_nw.assign(H.nlevels, 0);
-  Y->slv_lds.assign(H.nlevels, 0); Y->fac_nt.assign(H.nlevels, 512); Y->upd_coop.assign(H.nlevels, 0);
+  Y->slv_lds.assign(H.nlevels, 0); Y->bwd_lds.assign(H.nlevels, 0); Y->fac_nt.assign(H.nlevels, 512); Y->upd_coop.assign(H.nlevels, 0);
   for(int l = 0; l < H.nlevels; l++)
   {
     long maxp = 0, maxw = 0, maxr = 0;
@@ -976,6 +982,18 @@ int sparse_set_pattern(dlg_backend* b, const int* colptr, const int* rowidx)
     if(maxp*8 > LDS_BUDGET) { dlg_set_error("internal error: a factor slice does not fit LDS (%ld doubles)", maxp); return DLG_ERR_ARG; }
     Y->fac_lds[l] = (int)(maxp*8);
     Y->slv_lds[l] = (int)(maxw*(maxw | 1)*8);
+    {
+      long mb = 0;
+      for(int i = H.lvl_ptr[l]; i < H.lvl_ptr[l+1]; i++)
+      {
+        const int s = H.lvl_sn[i];
+        const long wv = H.sn_c0[s+1] - H.sn_c0[s], nr = H.sn_rowptr[s+1] - H.sn_rowptr[s];
+        const long need = wv*(wv | 1) + (nr - wv);
+        if(need > mb) mb = need;
+      }
+      if(mb*8 > LDS_BUDGET) { dlg_set_error("supernode too large for the backward-solve kernel (%ld doubles)", mb); return DLG_ERR_ARG; }
+      Y->bwd_lds[l] = (int)(mb*8);
+    }
     if(Y->slv_lds[l] > LDS_BUDGET) { dlg_set_error("supernode of width %ld is too wide for the solve kernels", maxw); return DLG_ERR_ARG; }
     Y->fac_lds[l] = (maxp*8 <= LDS_BUDGET - 4096) ? (int)(maxp*8) : 0;
     long maxslab = 0;
@@ -1154,7 +1172,7 @@ int sparse_solve(dlg_backend* b, const double* rhs, double* out)
   {
     const int n = H.lvl_ptr[l+1] - H.lvl_ptr[l];
     if(n > 0)
-      hipLaunchKernelGGL(k_solve_bwd_level, dim3(n), dim3(TPB), Y->slv_lds[l], st, Y->lvl_sn + H.lvl_ptr[l],
+      hipLaunchKernelGGL(k_solve_bwd_level, dim3(n), dim3(BWD_NT), Y->bwd_lds[l], st, Y->lvl_sn + H.lvl_ptr[l],
                          Y->sn_c0, Y->sn_rowptr, Y->sn_rows, Y->sn_lx, Y->perm, Y->Lx, Y->ywork, out, use_aug);
   }
   DLG_LAUNCH_CHECK();
