@@ -977,7 +977,7 @@ int sparse_set_pattern(dlg_backend* b, const int* colptr, const int* rowidx)
       if(p > maxp) maxp = p;
       if(nloc > maxr) maxr = nloc;
     }
-    Y->fac_nt[l] = (maxr <= 128) ? 128 : 512;
+    Y->fac_nt[l] = (maxr <= 128) ? 128 : (maxr <= 256 ? 256 : 512);
     Y->upd_coop[l] = (maxw > 8) ? 1 : 0;           // heavy sources: cooperative update kernel
     if(maxp*8 > LDS_BUDGET) { dlg_set_error("internal error: a factor slice does not fit LDS (%ld doubles)", maxp); return DLG_ERR_ARG; }
     Y->fac_lds[l] = (int)(maxp*8);
@@ -1011,6 +1011,8 @@ int sparse_set_pattern(dlg_backend* b, const int* colptr, const int* rowidx)
   DLG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_factor_level<128>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BUDGET));
   DLG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_factor_level<512>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BUDGET));
+  DLG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_factor_level<256>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BUDGET));
   DLG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_update_level),
                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BUDGET));
@@ -1119,6 +1121,10 @@ int sparse_factorize(dlg_backend* b, int s, double lambda, int* ok)
       const int o = H.fw_lvl_ptr[l];
       if(Y->fac_nt[l] == 128)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_factor_level<128>), dim3(n), dim3(128), Y->fac_lds[l], st,
+                           Y->fw_sn + o, Y->fw_r0 + o, Y->fw_r1 + o, Y->sn_c0, Y->sn_rowptr, Y->sn_lx,
+                           Y->sn_top, Y->sn_bd_ptr, Y->sn_bd_col, Y->Lx, Y->top_scr, Y->d_info);
+      else if(Y->fac_nt[l] == 256)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_factor_level<256>), dim3(n), dim3(256), Y->fac_lds[l], st,
                            Y->fw_sn + o, Y->fw_r0 + o, Y->fw_r1 + o, Y->sn_c0, Y->sn_rowptr, Y->sn_lx,
                            Y->sn_top, Y->sn_bd_ptr, Y->sn_bd_col, Y->Lx, Y->top_scr, Y->d_info);
       else

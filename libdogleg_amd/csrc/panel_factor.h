@@ -17,6 +17,18 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+// 1/sqrt(d) for d > 0: hardware v_rsq_f64 seed (about 1e-8 relative) + two Newton
+// steps (relative error ~1e-16).  The pivot sqrt(d) = d * rsqrt(d) and its reciprocal
+// come out of one short dependency chain instead of an IEEE sqrt followed by an IEEE
+// divide.
+__device__ __forceinline__ double dlg_rsqrt(double d)
+{
+  double y = __builtin_amdgcn_rsq(d);
+  y = y*(1.5 - 0.5*d*y*y);
+  y = y*(1.5 - 0.5*d*y*y);
+  return y;
+}
+
 template <int NT, bool ALIGNED16>
 __device__ __forceinline__ void panel_factor(double* P, int ldp, int nrows, int w, int tid,
                                              int* __restrict__ info, int col0)
@@ -60,6 +72,7 @@ __device__ __forceinline__ void panel_factor(double* P, int ldp, int nrows, int 
       for(int q = 0; q <= c; q++)
         D[c][q] = (c < nb) ? P[(kb + c) + (kb + q)*ldp] : ((c == q) ? 1.0 : 0.0);
     bool bad = false; int badcol = 0;
+    double Dinv[8];
 #pragma unroll
     for(int c = 0; c < 8; c++)
     {
@@ -67,9 +80,9 @@ __device__ __forceinline__ void panel_factor(double* P, int ldp, int nrows, int 
 #pragma unroll
       for(int q = 0; q < c; q++) d -= D[c][q]*D[c][q];
       if(!(d > 0.0)) { if(!bad) { bad = true; badcol = c; } d = 1.0; }
-      const double piv = sqrt(d);
-      D[c][c] = piv;
-      const double inv = 1.0/piv;
+      const double inv = dlg_rsqrt(d);
+      D[c][c] = d*inv;
+      Dinv[c] = inv;
 #pragma unroll
       for(int i = c + 1; i < 8; i++)
       {
@@ -102,7 +115,7 @@ __device__ __forceinline__ void panel_factor(double* P, int ldp, int nrows, int 
           double v = x[c];
 #pragma unroll
           for(int q = 0; q < c; q++) v -= x[q]*D[c][q];
-          x[c] = v/D[c][c];
+          x[c] = v*Dinv[c];
         }
 #pragma unroll
         for(int c = 0; c < 8; c++) if(c < nb) P[r + (kb + c)*ldp] = x[c];
@@ -139,9 +152,9 @@ __device__ __forceinline__ void panel_factor_blockdiag(double* P, int ldp, int n
 #pragma unroll
       for(int q = 0; q < c; q++) d -= D[c][q]*D[c][q];
       if(!(d > 0.0)) { if(!bad) { bad = true; badcol = c; } d = 1.0; }
-      const double piv = sqrt(d);
+      const double inv = dlg_rsqrt(d);
+      const double piv = d*inv;
       D[c][c] = piv;
-      const double inv = 1.0/piv;
 #pragma unroll
       for(int i = c + 1; i < 8; i++)
       {
