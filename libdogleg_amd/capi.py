@@ -161,7 +161,8 @@ def optimize(kind, p0, N, M, nnz, cb, cookie, params=None, capacity=256):
 
 SYM_STAT_NAMES = ["var_blocks", "supernodes", "levels", "nnz_JtJ_lower", "nnz_L", "panel_doubles",
                   "factor_flops", "max_panel", "asm_tasks", "update_items", "relpos", "out_blocks",
-                  "contribs", "update_subtasks", "solve_scratch", "jtx_tasks"]
+                  "contribs", "update_subtasks", "solve_scratch", "jtx_tasks", "asm_mfma_tasks",
+                  "asm_kgroups", "asm_shapes"]
 
 
 def symbolic_probe(N, M, Jp, Ji, row0=0, row1=None, want_perm=False):

@@ -74,6 +74,8 @@ struct SparseSym
   int *jtx_fin_ptr = nullptr, *jtx_fin_blk = nullptr;
   AsmRho* asm_rho = nullptr; AsmPair* asm_pair = nullptr; AsmSlot* asm_slot = nullptr;
   AsmBatch* asm_batch = nullptr; AsmTask* asm_ctask = nullptr; AsmFin* asm_cfin = nullptr;
+  AsmShape* asm_shape = nullptr; AsmKG* asm_kg = nullptr; AsmMTask* asm_mtask = nullptr; int* asm_tdest = nullptr;
+  AsmFin2* asm_fin2 = nullptr; int64_t* asm_fin2_list = nullptr;
   int *rl_ptr = nullptr, *rl_pos = nullptr, *perm = nullptr, *col_sn = nullptr;
   int *fw_sn = nullptr, *fw_r0 = nullptr, *fw_r1 = nullptr, *ms_sn = nullptr; int64_t* sn_top = nullptr;
   int *sn_bd_ptr = nullptr, *sn_bd_col = nullptr;
@@ -282,6 +284,142 @@ __global__ void __launch_bounds__(TPB) k_assemble(const AsmTask* __restrict__ ta
       }
       else part[T.part + SL.accoff + idx] = v;
     }
+  }
+}
+// MFMA assembly of the column blocks whose row-blocks all share one layout (AsmShape).
+// One wave per task, no LDS.  Per k-group (4 Jacobian rows) a lane gathers three values
+// of its row k = lane>>4: the persistent and the transient output row m = lane&15
+// (A operands, A[m][k]) and the column-block entry b = (lane&15) % nJ (B operand,
+// B[k][n]); v_mfma_f64_16x16x4_f64 then gives D[m][n] += sum_k A[m][k] B[k][n].
+//   persistent:  n = b,            every row of the task sums into the same D
+//   transient:   n = slot*nJ + b,  B is masked to the rows of row-block `slot`, so each
+//                row-block of the k-group gets its own columns; D is stored and cleared
+typedef double dlg_v4d __attribute__((ext_vector_type(4)));
+constexpr int ASM_U = 4;
+__global__ void __launch_bounds__(TPB) k_assemble_mfma(const AsmMTask* __restrict__ tasks, int ntasks,
+                                                       const AsmKG* __restrict__ kgs,
+                                                       const AsmShape* __restrict__ shapes,
+                                                       const int* __restrict__ tdest,
+                                                       const AsmSlot* __restrict__ slots,
+                                                       const double* __restrict__ vals,
+                                                       double* __restrict__ Lx, double* __restrict__ part)
+{
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(blockIdx.x*(TPB/64) + (threadIdx.x >> 6));
+  if(wid >= ntasks) return;
+  const AsmMTask T = tasks[wid];
+  const AsmShape* SH = shapes + T.shape;
+  const int m = lane & 15, kq = lane >> 4;
+  const int nJ = SH->nJ, MP = SH->MP, MT = SH->MT, nT = SH->nT;
+  const int pcol = SH->pcol[m], tcol = SH->tcol[m];
+  const int bs = m / nJ, bb = m - bs*nJ;
+  const int bcol = SH->offJ + bb;
+  dlg_v4d accP = {0.0, 0.0, 0.0, 0.0}, accT = {0.0, 0.0, 0.0, 0.0};
+  // transient rows this lane holds in D: m' = kq + 4r
+  int tinfo[4];
+#pragma unroll
+  for(int r = 0; r < 4; r++)
+  {
+    const int mm = kq + 4*r;
+    tinfo[r] = mm < MT ? (SH->tj[mm] | SH->ta[mm] << 8) : -1;
+  }
+  for(int kg = T.kg0; kg < T.kg1; kg += ASM_U)
+  {
+    const int n = min(ASM_U, T.kg1 - kg);
+    double aP[ASM_U], aT[ASM_U], bv[ASM_U];
+    int base[ASM_U];
+#pragma unroll
+    for(int u = 0; u < ASM_U; u++) base[u] = u < n ? kgs[kg + u].base[kq] : -1;
+#pragma unroll
+    for(int u = 0; u < ASM_U; u++)
+    {
+      const bool ok = base[u] >= 0;
+      aP[u] = (ok && pcol >= 0) ? vals[base[u] + pcol] : 0.0;
+      bv[u] = ok ? vals[base[u] + bcol] : 0.0;
+      aT[u] = (ok && tcol >= 0) ? vals[base[u] + tcol] : 0.0;
+    }
+#pragma unroll
+    for(int u = 0; u < ASM_U; u++)
+    {
+      if(u >= n) break;
+      accP = __builtin_amdgcn_mfma_f64_16x16x4f64(aP[u], bs == 0 ? bv[u] : 0.0, accP, 0, 0, 0);
+      if(MT > 0)
+      {
+        const uint32_t meta = kgs[kg + u].meta;
+        const int myslot = (meta >> (2*kq)) & 3;
+        accT = __builtin_amdgcn_mfma_f64_16x16x4f64(aT[u], bs == myslot ? bv[u] : 0.0, accT, 0, 0, 0);
+        if(meta & (1u << 11))
+        {
+          const int nslots = (meta >> 8) & 7;
+          const int tq = kgs[kg + u].tq;
+          if(bs < nslots)
+          {
+#pragma unroll
+            for(int r = 0; r < 4; r++)
+              if(tinfo[r] >= 0)
+              {
+                const int ro = tdest[tq + bs*nT + (tinfo[r] & 0xFF)];
+                Lx[T.panel + ro + (tinfo[r] >> 8) + (int64_t)bb*T.ld] = accT[r];
+              }
+          }
+          accT = (dlg_v4d){0.0, 0.0, 0.0, 0.0};
+        }
+      }
+    }
+  }
+  // persistent blocks
+  if(bs == 0)
+  {
+#pragma unroll
+    for(int r = 0; r < 4; r++)
+    {
+      const int mm = kq + 4*r;
+      if(mm >= MP) continue;
+      const AsmSlot SL = slots[T.slot0 + SH->pslot[mm]];
+      const int a = SH->pa[mm];
+      if(T.part < 0) { if(!SL.diag || a >= bb) Lx[SL.dest + a + (int64_t)bb*SL.ld] = accP[r]; }
+      else part[T.part + SL.accoff + bb*SL.nI + a] = accP[r];
+    }
+  }
+}
+// persistent blocks written by several MFMA tasks: fixed-order sum of the listed partials.
+// k_assemble_fin2_short: one wave per block (lists of <= 32 partials);
+// k_assemble_fin2_long: one 1024-thread workgroup per block, 16 waves stride over the list
+__device__ __forceinline__ void fin2_store(const AsmFin2& F, int e, double v, double* __restrict__ Lx)
+{
+  const int b = e / F.nI, a = e - b*F.nI;
+  if(!F.diag || a >= b) Lx[F.dest + a + (int64_t)b*F.ld] = v;
+}
+__global__ void __launch_bounds__(TPB) k_assemble_fin2_short(const AsmFin2* __restrict__ fins, int nfins,
+                                                             const int64_t* __restrict__ list,
+                                                             const double* __restrict__ part, double* __restrict__ Lx)
+{
+  const int lane = threadIdx.x & 63;
+  const int f = __builtin_amdgcn_readfirstlane(blockIdx.x*(TPB/64) + (threadIdx.x >> 6));
+  if(f >= nfins) return;
+  const AsmFin2 F = fins[f];
+  if(lane >= F.nI*F.nJ) return;
+  double s = 0.0;
+  for(int k = 0; k < F.nlist; k++) s += part[list[F.list0 + k] + lane];
+  fin2_store(F, lane, s, Lx);
+}
+__global__ void __launch_bounds__(1024) k_assemble_fin2_long(const AsmFin2* __restrict__ fins,
+                                                             const int64_t* __restrict__ list,
+                                                             const double* __restrict__ part, double* __restrict__ Lx)
+{
+  __shared__ double sh[1024];
+  const AsmFin2 F = fins[blockIdx.x];
+  const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+  double s = 0.0;
+  if(lane < F.nI*F.nJ)
+    for(int k = g; k < F.nlist; k += 16) s += part[list[F.list0 + k] + lane];
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  if(g == 0 && lane < F.nI*F.nJ)
+  {
+    double tot = 0.0;
+    for(int k = 0; k < 16; k++) tot += sh[k*64 + lane];
+    fin2_store(F, lane, tot, Lx);
   }
 }
 // add the partial accumulators of a multi-task group in task order: one 1024-thread
@@ -923,6 +1061,7 @@ int sparse_set_pattern(dlg_backend* b, const int* colptr, const int* rowidx)
   UP(uw_item); UP(uw_s0); UP(uw_s1); UP(uw_part); UP(uf_item); UP(uf_n); UP(uf_off);
   UP(oblk); UP(contrib); UP(jtx_task); UP(jtx_fin_ptr); UP(jtx_fin_blk);
   UP(asm_rho); UP(asm_pair); UP(asm_slot); UP(asm_batch); UP(asm_ctask); UP(asm_cfin);
+  UP(asm_shape); UP(asm_kg); UP(asm_mtask); UP(asm_tdest); UP(asm_fin2); UP(asm_fin2_list);
   UP(rl_ptr); UP(rl_pos); UP(perm); UP(col_sn); UP(fw_sn); UP(fw_r0); UP(fw_r1); UP(ms_sn); UP(sn_top); UP(sn_bd_ptr); UP(sn_bd_col);
   // rank-local pattern for the row-wise kernels
   {
@@ -1083,13 +1222,24 @@ int sparse_factorize(dlg_backend* b, int s, double lambda, int* ok)
   {
     DlgProfScope pt(b, DLG_PROF_K4_TOTAL);
     DLG_HIP(hipMemsetAsync(Y->Lx, 0, sizeof(double)*(size_t)H.lx_size, st));
-    const int nt = (int)H.asm_ctask.size();
-    if(nt > 0)
+    const int nt = (int)H.asm_ctask.size(), nmt = (int)H.asm_mtask.size();
+    if(nt > 0 || nmt > 0)
     {
       DlgProfScope pk(b, DLG_PROF_K4_KERNEL);
-      hipLaunchKernelGGL(k_assemble, dim3(dlg_cdiv(nt, TPB/64)), dim3(TPB), 0, st, Y->asm_ctask, nt,
-                         Y->asm_batch, Y->asm_rho, Y->asm_pair, Y->asm_slot, S.Jin(), Y->Lx, Y->asm_part);
+      if(nmt > 0)
+        hipLaunchKernelGGL(k_assemble_mfma, dim3(dlg_cdiv(nmt, TPB/64)), dim3(TPB), 0, st, Y->asm_mtask, nmt,
+                           Y->asm_kg, Y->asm_shape, Y->asm_tdest, Y->asm_slot, S.Jin(), Y->Lx, Y->asm_part);
+      if(nt > 0)
+        hipLaunchKernelGGL(k_assemble, dim3(dlg_cdiv(nt, TPB/64)), dim3(TPB), 0, st, Y->asm_ctask, nt,
+                           Y->asm_batch, Y->asm_rho, Y->asm_pair, Y->asm_slot, S.Jin(), Y->Lx, Y->asm_part);
     }
+    const int nf2 = (int)H.asm_fin2.size(), nf2s = H.n_fin2_short;
+    if(nf2s > 0)
+      hipLaunchKernelGGL(k_assemble_fin2_short, dim3(dlg_cdiv(nf2s, TPB/64)), dim3(TPB), 0, st, Y->asm_fin2, nf2s,
+                         Y->asm_fin2_list, Y->asm_part, Y->Lx);
+    if(nf2 > nf2s)
+      hipLaunchKernelGGL(k_assemble_fin2_long, dim3(nf2 - nf2s), dim3(1024), 0, st, Y->asm_fin2 + nf2s,
+                         Y->asm_fin2_list, Y->asm_part, Y->Lx);
     const int nf = (int)H.asm_cfin.size();
     if(nf > 0)
       hipLaunchKernelGGL(k_assemble_fin, dim3(nf), dim3(1024), 0, st, Y->asm_cfin, Y->asm_slot,
@@ -1198,7 +1348,8 @@ extern "C" int dlg_sparse_symbolic_probe(int N, int M, const int* colptr, const 
                      (long)H.lx_size, (long)H.factor_flops, (long)H.max_panel, (long)H.asm_ctask.size(),
                      (long)H.ui_t.size(), (long)H.relpos.size(), (long)H.oblk.size(),
                      (long)H.contrib.size(), (long)H.usub.size(), (long)H.scr_size,
-                     (long)H.jtx_task.size() };
+                     (long)H.jtx_task.size(), (long)H.asm_mtask.size(), (long)H.asm_kg.size(),
+                     (long)H.asm_shape.size() };
   for(int i = 0; i < nstats && i < (int)(sizeof(v)/sizeof(v[0])); i++) stats[i] = v[i];
   if(perm_out) memcpy(perm_out, H.perm.data(), sizeof(int)*(size_t)N);
   return DLG_OK;

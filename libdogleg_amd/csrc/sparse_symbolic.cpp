@@ -4,6 +4,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <cmath>
 #include <numeric>
 #include <queue>
@@ -896,6 +897,221 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
     std::vector<SlotTmp> slots;
     std::vector<int> grp_of, acc_of;            // per slot: group id, accumulator offset inside the group
     S.asm_part_size = 0;
+    // ---- MFMA path.  The row-blocks of a column block J are partitioned into classes of
+    // identical row layout (AsmShape); inside a class every block (I,J) is either persistent
+    // (same I in every row-block) or transient (all I different).  J qualifies when every
+    // transient block receives exactly one contribution overall.
+    const bool use_mfma = env_int("DOGLEG_AMD_ASM_MFMA", 1) != 0;
+    constexpr int KG_PER_TASK_T = 64, KG_PER_TASK_P = 256;
+    std::map<std::vector<int>, int> shape_ids;
+    std::vector<int> tseen(nvb, -1), pseen(nvb, -1), fin_of(nvb, -1);
+    struct Ord { int I, nI, offI; bool P; };
+    struct Cls { std::vector<int> es; std::vector<Ord> ords; int MP, MT, nP, nT, shape, slot0, acc_size; };
+    std::vector<Cls> classes;
+    std::map<std::vector<int>, int> class_ids;
+    std::vector<int> cnt_same, key, last_key;
+    std::vector<std::vector<int64_t>> fin_lists;
+    auto build_mfma = [&](int J, int r0, int r1, int qJ, int t, int ld, int lc, int nJ) -> bool
+    {
+      // 1. classes of identical layout
+      classes.clear(); class_ids.clear();
+      int last_cls = -1;
+      for(int e = r0; e < r1; e++)
+      {
+        const RowBlock& b = rbs[rrb[e]];
+        key.assign(1, rb_off[b.vptr + rx[e]]);
+        for(int x = 0; x < b.nvb; x++)
+        { const int I = rb_vb[b.vptr + x]; if(bpos[I] >= qJ) { key.push_back(G.w[I]); key.push_back(rb_off[b.vptr + x]); } }
+        int c;
+        if(last_cls >= 0 && key == last_key) c = last_cls;
+        else
+        {
+          auto it = class_ids.find(key);
+          if(it != class_ids.end()) c = it->second;
+          else
+          {
+            if(classes.size() >= 64) return false;
+            c = (int)classes.size(); class_ids[key] = c; classes.emplace_back();
+            Cls& C = classes.back();
+            for(int x = 0; x < b.nvb; x++)
+            { const int I = rb_vb[b.vptr + x]; if(bpos[I] >= qJ) C.ords.push_back({I, G.w[I], rb_off[b.vptr + x], true}); }
+          }
+        }
+        classes[c].es.push_back(e); last_cls = c; last_key = key;
+      }
+      // 2. persistent / transient blocks of every class
+      for(Cls& C : classes)
+      {
+        const int nord = (int)C.ords.size();
+        cnt_same.assign(nord, 0);
+        for(int e : C.es)
+        {
+          const RowBlock& b = rbs[rrb[e]];
+          int k = 0;
+          for(int x = 0; x < b.nvb; x++)
+          { const int I = rb_vb[b.vptr + x]; if(bpos[I] < qJ) continue; if(I == C.ords[k].I) cnt_same[k]++; k++; }
+        }
+        C.MP = C.MT = C.nP = C.nT = 0;
+        for(int k = 0; k < nord; k++)
+        {
+          C.ords[k].P = cnt_same[k] == (int)C.es.size();
+          if(C.ords[k].P) { C.MP += C.ords[k].nI; C.nP++; pseen[C.ords[k].I] = J; } else { C.MT += C.ords[k].nI; C.nT++; }
+        }
+        if(C.MP > 16 || C.MT > 16) return false;
+      }
+      for(const Cls& C : classes)
+      {
+        if(C.nT == 0) continue;
+        for(int e : C.es)
+        {
+          const RowBlock& b = rbs[rrb[e]];
+          int k = 0;
+          for(int x = 0; x < b.nvb; x++)
+          {
+            const int I = rb_vb[b.vptr + x];
+            if(bpos[I] < qJ) continue;
+            if(!C.ords[k].P) { if(tseen[I] == J || pseen[I] == J) return false; tseen[I] = J; }
+            k++;
+          }
+        }
+      }
+      // 3. emit
+      const int64_t panel = S.sn_lx[t] + (int64_t)lc*ld;
+      const int first_task = (int)S.asm_mtask.size();
+      const int base0 = cp[row0];
+      for(Cls& C : classes)
+      {
+        const int offJ = rb_off[rbs[rrb[C.es[0]]].vptr + rx[C.es[0]]];
+        key.assign(1, nJ); key.push_back(offJ);
+        for(const Ord& o : C.ords) { key.push_back(o.nI); key.push_back(o.offI); key.push_back(o.P); }
+        auto it = shape_ids.find(key);
+        if(it != shape_ids.end()) C.shape = it->second;
+        else
+        {
+          AsmShape sh; memset(&sh, 0, sizeof(sh));
+          for(int m = 0; m < 16; m++) sh.pcol[m] = sh.tcol[m] = -1;
+          int mp = 0, mt = 0, ip = 0, jt = 0;
+          for(const Ord& o : C.ords)
+          {
+            for(int a = 0; a < o.nI; a++)
+              if(o.P) { sh.pcol[mp] = (int16_t)(o.offI + a); sh.pslot[mp] = (uint8_t)ip; sh.pa[mp] = (uint8_t)a; mp++; }
+              else    { sh.tcol[mt] = (int16_t)(o.offI + a); sh.tj[mt] = (uint8_t)jt; sh.ta[mt] = (uint8_t)a; mt++; }
+            if(o.P) ip++; else jt++;
+          }
+          sh.offJ = (uint16_t)offJ; sh.nJ = (uint8_t)nJ; sh.MP = (uint8_t)C.MP; sh.MT = (uint8_t)C.MT;
+          sh.nT = (uint8_t)C.nT; sh.smax = (uint8_t)std::min(4, 16/nJ);
+          C.shape = (int)S.asm_shape.size(); S.asm_shape.push_back(sh); shape_ids[key] = C.shape;
+        }
+        const int smax = C.nT > 0 ? std::min(4, 16/nJ) : 4;
+        const int kg_cap = C.nT > 0 ? KG_PER_TASK_T : KG_PER_TASK_P;
+        C.slot0 = (int)S.asm_slot.size(); C.acc_size = 0;
+        for(const Ord& o : C.ords) if(o.P)
+        {
+          AsmSlot sl; sl.dest = slots[slot_of[o.I]].dest; sl.ld = ld; sl.accoff = (uint16_t)C.acc_size;
+          sl.nI = (uint8_t)o.nI; sl.diag = (uint8_t)(o.I == J);
+          S.asm_slot.push_back(sl); C.acc_size += o.nI*nJ;
+        }
+        bool task_open = false, kg_open = false;
+        int kg_rows = 0, kg_slots = 0, kg_in_task = 0;
+        auto close_kg = [&]() { if(kg_open) { S.asm_kg.back().meta |= (uint32_t)kg_slots << 8 | 1u << 11; kg_open = false; } };
+        auto close_task = [&]() { close_kg(); if(task_open) { S.asm_mtask.back().kg1 = (int)S.asm_kg.size(); task_open = false; } };
+        auto open_kg = [&]() {
+          AsmKG g; g.base[0] = g.base[1] = g.base[2] = g.base[3] = -1; g.tq = (int)S.asm_tdest.size(); g.meta = 0;
+          S.asm_kg.push_back(g); kg_open = true; kg_rows = 0; kg_slots = 0; kg_in_task++; };
+        for(int e : C.es)
+        {
+          const RowBlock& b = rbs[rrb[e]];
+          const bool fits = kg_open && kg_rows + b.nrows <= 4 && kg_slots < smax;
+          const int need_kg = b.nrows > 4 ? 2 : (fits ? 0 : 1);
+          if(!task_open || kg_in_task + need_kg > kg_cap)
+          {
+            close_task();
+            AsmMTask T; T.kg0 = (int)S.asm_kg.size(); T.kg1 = -1; T.slot0 = C.slot0; T.shape = C.shape; T.ld = ld;
+            T.pad = C.acc_size; T.panel = panel; T.part = -1;
+            S.asm_mtask.push_back(T); task_open = true; kg_in_task = 0;
+          }
+          const int base = b.base - base0;
+          if(b.nrows > 4)
+          {
+            close_kg();
+            const int tq = (int)S.asm_tdest.size();
+            for(int h = 0; h < 2; h++)
+            {
+              open_kg(); S.asm_kg.back().tq = tq;
+              for(int r = 4*h; r < std::min(b.nrows, 4*h + 4); r++) S.asm_kg.back().base[r - 4*h] = base + r*b.len;
+              kg_slots = 1;
+              if(h == 0) { S.asm_kg.back().meta |= 1u << 8; kg_open = false; }    // no store yet: the block continues
+              else close_kg();
+            }
+          }
+          else
+          {
+            if(!(kg_open && kg_rows + b.nrows <= 4 && kg_slots < smax)) { close_kg(); open_kg(); }
+            for(int r = 0; r < b.nrows; r++)
+            {
+              S.asm_kg.back().base[kg_rows] = base + r*b.len;
+              S.asm_kg.back().meta |= (uint32_t)kg_slots << (2*kg_rows);
+              kg_rows++;
+            }
+            kg_slots++;
+          }
+          if(C.nT > 0)
+          {
+            int k = 0;
+            for(int x = 0; x < b.nvb; x++)
+            {
+              const int I = rb_vb[b.vptr + x];
+              if(bpos[I] < qJ) continue;
+              if(!C.ords[k].P) S.asm_tdest.push_back((int)(slots[slot_of[I]].dest - panel));
+              k++;
+            }
+          }
+        }
+        close_task();
+      }
+      // 4. several tasks: persistent blocks go through partials, summed per destination block
+      const int ntask = (int)S.asm_mtask.size() - first_task;
+      if(ntask > 1)
+      {
+        const int fin0 = (int)S.asm_fin2.size();
+        fin_lists.clear();
+        for(int k = first_task; k < first_task + ntask; k++)
+        {
+          AsmMTask& T = S.asm_mtask[k];
+          T.part = S.asm_part_size; S.asm_part_size += T.pad;
+        }
+        for(const Cls& C : classes)
+        {
+          int sidx = 0;
+          for(const Ord& o : C.ords) if(o.P)
+          {
+            const AsmSlot& sl = S.asm_slot[C.slot0 + sidx]; sidx++;
+            int f;
+            if(fin_of[o.I] >= fin0 && fin_of[o.I] < (int)S.asm_fin2.size() && S.asm_fin2[fin_of[o.I]].dest == sl.dest) f = fin_of[o.I];
+            else
+            {
+              f = (int)S.asm_fin2.size(); fin_of[o.I] = f;
+              AsmFin2 F; F.dest = sl.dest; F.ld = ld; F.list0 = 0; F.nlist = 0; F.nI = sl.nI; F.nJ = (uint8_t)nJ;
+              F.diag = sl.diag; F.pad = 0;
+              S.asm_fin2.push_back(F); fin_lists.emplace_back();
+            }
+            for(int k = first_task; k < first_task + ntask; k++)
+            {
+              const AsmMTask& T = S.asm_mtask[k];
+              if(T.slot0 == C.slot0) fin_lists[f - fin0].push_back(T.part + sl.accoff);
+            }
+          }
+        }
+        for(size_t f = 0; f < fin_lists.size(); f++)
+        {
+          S.asm_fin2[fin0 + f].list0 = (int)S.asm_fin2_list.size();
+          S.asm_fin2[fin0 + f].nlist = (int)fin_lists[f].size();
+          S.asm_fin2_list.insert(S.asm_fin2_list.end(), fin_lists[f].begin(), fin_lists[f].end());
+        }
+      }
+      for(int k = first_task; k < first_task + ntask; k++) S.asm_mtask[k].pad = 0;
+      return true;
+    };
     for(int J = 0; J < nvb; J++)
     {
       const int r0 = rptr[J], r1 = rptr[J+1];
@@ -925,6 +1141,7 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
           slots.push_back({I, dest, G.w[I], I == J ? 1 : 0});
         }
       }
+      if(use_mfma && build_mfma(J, r0, r1, qJ, t, ld, lc, nJ)) continue;
       // groups of slots that fit the LDS accumulator
       grp_of.assign(slots.size(), 0); acc_of.assign(slots.size(), 0);
       int ngrp = 0;
@@ -1016,6 +1233,10 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
         }
       }
     }
+    // short partial lists first (one wave each), long ones after (one workgroup each)
+    std::stable_partition(S.asm_fin2.begin(), S.asm_fin2.end(), [](const AsmFin2& f) { return f.nlist <= 32; });
+    S.n_fin2_short = 0;
+    for(const AsmFin2& f : S.asm_fin2) if(f.nlist <= 32) S.n_fin2_short++;
     // sentinel so that rho[i+1].pair0 closes the pair list of the last rho
     AsmRho R; memset(&R, 0, sizeof(R)); R.pair0 = (int)S.asm_pair.size(); S.asm_rho.push_back(R);
   }

@@ -86,6 +86,40 @@ static_assert(sizeof(AsmTask) == 32, "AsmTask layout");
 struct AsmFin { int32_t slot0, nslots, acc_size, nparts; int64_t part0; int32_t nJ, pad; };
 static_assert(sizeof(AsmFin) == 32, "AsmFin layout");
 
+// ---- MFMA assembly path (column blocks whose row-blocks all have the same layout)
+// A "k-group" is 4 Jacobian rows fed to one v_mfma_f64_16x16x4_f64.  The blocks
+// (I,J) of a task's column J are of two kinds: PERSISTENT (the same I in every
+// row-block: the diagonal block, dense columns) accumulate in the MFMA
+// accumulator over the whole task; TRANSIENT (a different I in every row-block,
+// each receiving exactly one contribution) are stored after each k-group.
+struct AsmShape
+{
+  int16_t pcol[16], tcol[16];   // offset inside a row of persistent / transient output row m, -1: none
+  uint8_t pslot[16], pa[16];    // persistent row m: slot ordinal, row inside the block
+  uint8_t tj[16], ta[16];       // transient row m: transient ordinal, row inside the block
+  uint16_t offJ;                // offset of the column block inside a row
+  uint8_t nJ, MP, MT, nT, smax, pad;
+};
+static_assert(sizeof(AsmShape) == 136, "AsmShape layout");
+struct AsmKG
+{
+  int32_t  base[4];             // first value of each of the 4 rows, -1: no row
+  int32_t  tq;                  // first entry in asm_tdest of row-block slot 0 (slot s: + s*nT)
+  uint32_t meta;                // bits 0-7: row-block slot of each row (2 bits each); 8-10: #slots; 11: store transients
+};
+static_assert(sizeof(AsmKG) == 24, "AsmKG layout");
+struct AsmMTask
+{
+  int32_t kg0, kg1, slot0, shape;
+  int32_t ld, pad;
+  int64_t panel;                // Lx offset of (row 0, first column of J) of J's panel
+  int64_t part;                 // offset into the partial buffer, or -1: write the panels directly
+};
+static_assert(sizeof(AsmMTask) == 40, "AsmMTask layout");
+// a persistent block written by several tasks: sum of the listed partials, in list order
+struct AsmFin2 { int64_t dest; int32_t ld, list0, nlist; uint8_t nI, nJ, diag, pad; };
+static_assert(sizeof(AsmFin2) == 24, "AsmFin2 layout");
+
 // a wave-task: contributions [c0,c1) of block blk; part >= 0: write the partial
 // into slot `part` of the partial buffer instead of the destination
 struct SymTask { int32_t blk, c0, c1, part; };
@@ -146,6 +180,13 @@ struct SymHost
   std::vector<AsmBatch> asm_batch;
   std::vector<AsmTask>  asm_ctask;
   std::vector<AsmFin>   asm_cfin;
+  std::vector<AsmShape> asm_shape;
+  std::vector<AsmKG>    asm_kg;
+  std::vector<AsmMTask> asm_mtask;
+  std::vector<AsmFin2>  asm_fin2;     // sorted: the n_fin2_short entries with short lists first
+  std::vector<int64_t>  asm_fin2_list;
+  int n_fin2_short = 0;
+  std::vector<int>      asm_tdest;   // row offset in J's panel of every (row-block, transient ordinal)
   int64_t asm_part_size = 0;
   // ---- forward-solve gather lists
   std::vector<int> rl_ptr;           // [N+1]
