@@ -295,73 +295,89 @@ __global__ void __launch_bounds__(TPB) k_assemble(const AsmTask* __restrict__ ta
 //   transient:   n = slot*nJ + b,  B is masked to the rows of row-block `slot`, so each
 //                row-block of the k-group gets its own columns; D is stored and cleared
 typedef double dlg_v4d __attribute__((ext_vector_type(4)));
-constexpr int ASM_U = 4;
-__global__ void __launch_bounds__(TPB) k_assemble_mfma(const AsmMTask* __restrict__ tasks, int ntasks,
-                                                       const AsmKG* __restrict__ kgs,
-                                                       const AsmShape* __restrict__ shapes,
-                                                       const int* __restrict__ tdest,
-                                                       const AsmSlot* __restrict__ slots,
-                                                       const double* __restrict__ vals,
-                                                       double* __restrict__ Lx, double* __restrict__ part)
+#ifndef DLG_ASM_U
+#define DLG_ASM_U 4
+#endif
+constexpr int ASM_U = DLG_ASM_U;
+// All loads are unconditional with clamped addresses (absent rows / columns read element 0 and
+// are zeroed afterwards): the loop body is straight-line code, the only branches are uniform.
+template <bool HAS_T>
+__device__ __forceinline__ void asm_mfma_task(const AsmMTask& T, const AsmShape* __restrict__ SH,
+                                              const AsmKG* __restrict__ kgs, const int* __restrict__ tdest,
+                                              const AsmSlot* __restrict__ slots, const double* __restrict__ vals,
+                                              double* __restrict__ Lx, double* __restrict__ part, int lane)
 {
-  const int lane = threadIdx.x & 63;
-  const int wid = __builtin_amdgcn_readfirstlane(blockIdx.x*(TPB/64) + (threadIdx.x >> 6));
-  if(wid >= ntasks) return;
-  const AsmMTask T = tasks[wid];
-  const AsmShape* SH = shapes + T.shape;
   const int m = lane & 15, kq = lane >> 4;
   const int nJ = SH->nJ, MP = SH->MP, MT = SH->MT, nT = SH->nT;
-  const int pcol = SH->pcol[m], tcol = SH->tcol[m];
+  const int pcol = SH->pcol[m], tcol = HAS_T ? SH->tcol[m] : -1;
   const int bs = m / nJ, bb = m - bs*nJ;
   const int bcol = SH->offJ + bb;
-  dlg_v4d accP = {0.0, 0.0, 0.0, 0.0}, accT = {0.0, 0.0, 0.0, 0.0};
-  // transient rows this lane holds in D: m' = kq + 4r
-  int tinfo[4];
+  const int pc = max(pcol, 0), tc = max(tcol, 0);
+  int tj[4], ta[4];                       // transient rows this lane holds in D: m' = kq + 4r
 #pragma unroll
-  for(int r = 0; r < 4; r++)
+  for(int r = 0; r < 4; r++) { tj[r] = HAS_T ? SH->tj[kq + 4*r] : 0xFF; ta[r] = HAS_T ? SH->ta[kq + 4*r] : 0; }
+  dlg_v4d accP = {0.0, 0.0, 0.0, 0.0}, accT = {0.0, 0.0, 0.0, 0.0};
+  // k-group records are fetched one iteration ahead of the values they address
+  int base_n[ASM_U], tq_n[ASM_U]; uint32_t meta_n[ASM_U];
+  const int kglast = T.kg1 - 1;
+#pragma unroll
+  for(int u = 0; u < ASM_U; u++)
   {
-    const int mm = kq + 4*r;
-    tinfo[r] = mm < MT ? (SH->tj[mm] | SH->ta[mm] << 8) : -1;
+    const int g = min(T.kg0 + u, kglast);
+    const bool in = T.kg0 + u <= kglast;
+    const int bl = kgs[g].base[kq];
+    base_n[u] = in ? bl : -1; meta_n[u] = in ? kgs[g].meta : 0u; tq_n[u] = HAS_T ? kgs[g].tq : 0;
   }
   for(int kg = T.kg0; kg < T.kg1; kg += ASM_U)
   {
-    const int n = min(ASM_U, T.kg1 - kg);
     double aP[ASM_U], aT[ASM_U], bv[ASM_U];
-    int base[ASM_U];
+    int base[ASM_U], td[ASM_U];
+    uint32_t meta[ASM_U];
 #pragma unroll
-    for(int u = 0; u < ASM_U; u++) base[u] = u < n ? kgs[kg + u].base[kq] : -1;
+    for(int u = 0; u < ASM_U; u++) { base[u] = base_n[u]; meta[u] = meta_n[u]; }
 #pragma unroll
     for(int u = 0; u < ASM_U; u++)
     {
-      const bool ok = base[u] >= 0;
-      aP[u] = (ok && pcol >= 0) ? vals[base[u] + pcol] : 0.0;
-      bv[u] = ok ? vals[base[u] + bcol] : 0.0;
-      aT[u] = (ok && tcol >= 0) ? vals[base[u] + tcol] : 0.0;
+      const int b0 = max(base[u], 0);
+      aP[u] = vals[b0 + pc];
+      bv[u] = vals[b0 + bcol];
+      if(HAS_T)
+      {
+        aT[u] = vals[b0 + tc];
+        // transient destinations of this k-group: entry `lane` of its list (slot-major)
+        const int nent = (int)((meta[u] >> 8) & 7)*nT;
+        td[u] = tdest[lane < nent ? tq_n[u] + lane : 0];
+      }
     }
 #pragma unroll
     for(int u = 0; u < ASM_U; u++)
     {
-      if(u >= n) break;
-      accP = __builtin_amdgcn_mfma_f64_16x16x4f64(aP[u], bs == 0 ? bv[u] : 0.0, accP, 0, 0, 0);
-      if(MT > 0)
-      {
-        const uint32_t meta = kgs[kg + u].meta;
-        const int myslot = (meta >> (2*kq)) & 3;
-        accT = __builtin_amdgcn_mfma_f64_16x16x4f64(aT[u], bs == myslot ? bv[u] : 0.0, accT, 0, 0, 0);
-        if(meta & (1u << 11))
-        {
-          const int nslots = (meta >> 8) & 7;
-          const int tq = kgs[kg + u].tq;
-          if(bs < nslots)
-          {
+      const int g = min(kg + ASM_U + u, kglast);
+      const bool in = kg + ASM_U + u <= kglast;
+      const int bl = kgs[g].base[kq];
+      base_n[u] = in ? bl : -1; meta_n[u] = in ? kgs[g].meta : 0u; tq_n[u] = HAS_T ? kgs[g].tq : 0;
+    }
 #pragma unroll
-            for(int r = 0; r < 4; r++)
-              if(tinfo[r] >= 0)
-              {
-                const int ro = tdest[tq + bs*nT + (tinfo[r] & 0xFF)];
-                Lx[T.panel + ro + (tinfo[r] >> 8) + (int64_t)bb*T.ld] = accT[r];
-              }
-          }
+    for(int u = 0; u < ASM_U; u++)
+    {
+      const bool ok = base[u] >= 0;
+      accP = __builtin_amdgcn_mfma_f64_16x16x4f64((ok && pcol >= 0) ? aP[u] : 0.0, (ok && bs == 0) ? bv[u] : 0.0,
+                                                  accP, 0, 0, 0);
+      if(HAS_T)
+      {
+        const int myslot = (meta[u] >> (2*kq)) & 3;
+        accT = __builtin_amdgcn_mfma_f64_16x16x4f64((ok && tcol >= 0) ? aT[u] : 0.0,
+                                                    (ok && bs == myslot) ? bv[u] : 0.0, accT, 0, 0, 0);
+        if(meta[u] & (1u << 11))
+        {
+          const bool mine = bs < (int)((meta[u] >> 8) & 7);
+#pragma unroll
+          for(int r = 0; r < 4; r++)
+            if(4*r < MT)
+            {
+              const int ro = __builtin_amdgcn_ds_bpermute(4*(bs*nT + tj[r]), td[u]);
+              if(mine && tj[r] != 0xFF) Lx[T.panel + ro + ta[r] + (int64_t)bb*T.ld] = accT[r];
+            }
           accT = (dlg_v4d){0.0, 0.0, 0.0, 0.0};
         }
       }
@@ -381,6 +397,22 @@ __global__ void __launch_bounds__(TPB) k_assemble_mfma(const AsmMTask* __restric
       else part[T.part + SL.accoff + bb*SL.nI + a] = accP[r];
     }
   }
+}
+__global__ void __launch_bounds__(TPB) k_assemble_mfma(const AsmMTask* __restrict__ tasks, int ntasks,
+                                                       const AsmKG* __restrict__ kgs,
+                                                       const AsmShape* __restrict__ shapes,
+                                                       const int* __restrict__ tdest,
+                                                       const AsmSlot* __restrict__ slots,
+                                                       const double* __restrict__ vals,
+                                                       double* __restrict__ Lx, double* __restrict__ part)
+{
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(blockIdx.x*(TPB/64) + (threadIdx.x >> 6));
+  if(wid >= ntasks) return;
+  const AsmMTask T = tasks[wid];
+  const AsmShape* SH = shapes + T.shape;
+  if(SH->MT > 0) asm_mfma_task<true>(T, SH, kgs, tdest, slots, vals, Lx, part, lane);
+  else           asm_mfma_task<false>(T, SH, kgs, tdest, slots, vals, Lx, part, lane);
 }
 // persistent blocks written by several MFMA tasks: fixed-order sum of the listed partials.
 // k_assemble_fin2_short: one wave per block (lists of <= 32 partials);

@@ -989,7 +989,7 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
         else
         {
           AsmShape sh; memset(&sh, 0, sizeof(sh));
-          for(int m = 0; m < 16; m++) sh.pcol[m] = sh.tcol[m] = -1;
+          for(int m = 0; m < 16; m++) { sh.pcol[m] = sh.tcol[m] = -1; sh.tj[m] = 0xFF; }
           int mp = 0, mt = 0, ip = 0, jt = 0;
           for(const Ord& o : C.ords)
           {
