@@ -299,78 +299,97 @@ typedef double dlg_v4d __attribute__((ext_vector_type(4)));
 #define DLG_ASM_U 4
 #endif
 constexpr int ASM_U = DLG_ASM_U;
-// All loads are unconditional with clamped addresses (absent rows / columns read element 0 and
-// are zeroed afterwards): the loop body is straight-line code, the only branches are uniform.
+// Per k-group the wave copies the needed window of its 4 rows into a wave-private LDS tile with
+// one coalesced load (lane = (row, column)), then every lane picks its A/B operands from the
+// tile: the vector-memory pipe sees one load per k-group instead of one per operand.  The
+// k-group records are wave-uniform (scalar loads), fetched one iteration ahead.  All loads are
+// unconditional with clamped addresses (absent rows read element 0 and are zeroed afterwards):
+// the loop body is straight-line code, the only branches are uniform.
 template <bool HAS_T>
 __device__ __forceinline__ void asm_mfma_task(const AsmMTask& T, const AsmShape* __restrict__ SH,
                                               const AsmKG* __restrict__ kgs, const int* __restrict__ tdest,
                                               const AsmSlot* __restrict__ slots, const double* __restrict__ vals,
-                                              double* __restrict__ Lx, double* __restrict__ part, int lane)
+                                              double* __restrict__ Lx, double* __restrict__ part, int lane,
+                                              double* __restrict__ tile, int LEN)
 {
   const int m = lane & 15, kq = lane >> 4;
   const int nJ = SH->nJ, MP = SH->MP, MT = SH->MT, nT = SH->nT;
   const int pcol = SH->pcol[m], tcol = HAS_T ? SH->tcol[m] : -1;
   const int bs = m / nJ, bb = m - bs*nJ;
   const int bcol = SH->offJ + bb;
+  // B column of the persistent product: J's columns, then the rider's (if any)
+  const int nJr = SH->nJr;
+  const int bcolP = m < nJ ? SH->offJ + m : (m < nJ + nJr ? SH->offR + (m - nJ) : (int)SH->offJ);
+  const bool pn = m < nJ + nJr;
   const int pc = max(pcol, 0), tc = max(tcol, 0);
+  const int col0 = SH->col0, ncopy = SH->ncopy;
   int tj[4], ta[4];                       // transient rows this lane holds in D: m' = kq + 4r
 #pragma unroll
   for(int r = 0; r < 4; r++) { tj[r] = HAS_T ? SH->tj[kq + 4*r] : 0xFF; ta[r] = HAS_T ? SH->ta[kq + 4*r] : 0; }
   dlg_v4d accP = {0.0, 0.0, 0.0, 0.0}, accT = {0.0, 0.0, 0.0, 0.0};
-  // k-group records are fetched one iteration ahead of the values they address
-  int base_n[ASM_U], tq_n[ASM_U]; uint32_t meta_n[ASM_U];
+  AsmKG G[ASM_U], Gn[ASM_U];
   const int kglast = T.kg1 - 1;
+  auto fetch = [&](int kg0, AsmKG* R) {
 #pragma unroll
-  for(int u = 0; u < ASM_U; u++)
-  {
-    const int g = min(T.kg0 + u, kglast);
-    const bool in = T.kg0 + u <= kglast;
-    const int bl = kgs[g].base[kq];
-    base_n[u] = in ? bl : -1; meta_n[u] = in ? kgs[g].meta : 0u; tq_n[u] = HAS_T ? kgs[g].tq : 0;
-  }
+    for(int u = 0; u < ASM_U; u++)
+    {
+      R[u] = kgs[min(kg0 + u, kglast)];
+      if(kg0 + u > kglast) { R[u].base[0] = R[u].base[1] = R[u].base[2] = R[u].base[3] = -1; R[u].meta = 0; }
+    }
+  };
+  fetch(T.kg0, Gn);
+  double* myrow = tile + kq*LEN;
   for(int kg = T.kg0; kg < T.kg1; kg += ASM_U)
   {
-    double aP[ASM_U], aT[ASM_U], bv[ASM_U];
-    int base[ASM_U], td[ASM_U];
-    uint32_t meta[ASM_U];
+    int td[ASM_U];
+    bool ok[ASM_U];
 #pragma unroll
-    for(int u = 0; u < ASM_U; u++) { base[u] = base_n[u]; meta[u] = meta_n[u]; }
-#pragma unroll
-    for(int u = 0; u < ASM_U; u++)
+    for(int u = 0; u < ASM_U; u++) G[u] = Gn[u];
+    // (a) one coalesced copy of the rows' windows into the tile
+    for(int c0 = 0; c0 < ncopy; c0 += 16)
     {
-      const int b0 = max(base[u], 0);
-      aP[u] = vals[b0 + pc];
-      bv[u] = vals[b0 + bcol];
-      if(HAS_T)
+      double v[ASM_U];
+#pragma unroll
+      for(int u = 0; u < ASM_U; u++)
       {
-        aT[u] = vals[b0 + tc];
+        const int b = kq == 0 ? G[u].base[0] : kq == 1 ? G[u].base[1] : kq == 2 ? G[u].base[2] : G[u].base[3];
+        ok[u] = b >= 0;
+        v[u] = vals[max(b, 0) + col0 + min(c0 + m, ncopy - 1)];
+      }
+#pragma unroll
+      for(int u = 0; u < ASM_U; u++) myrow[u*4*LEN + c0 + m] = v[u];
+    }
+    if(HAS_T)
+    {
+#pragma unroll
+      for(int u = 0; u < ASM_U; u++)
+      {
         // transient destinations of this k-group: entry `lane` of its list (slot-major)
-        const int nent = (int)((meta[u] >> 8) & 7)*nT;
-        td[u] = tdest[lane < nent ? tq_n[u] + lane : 0];
+        const int nent = (int)((G[u].meta >> 8) & 7)*nT;
+        td[u] = tdest[lane < nent ? G[u].tq + lane : 0];
       }
     }
+    fetch(kg + ASM_U, Gn);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // (b) operands from the tile, products
 #pragma unroll
     for(int u = 0; u < ASM_U; u++)
     {
-      const int g = min(kg + ASM_U + u, kglast);
-      const bool in = kg + ASM_U + u <= kglast;
-      const int bl = kgs[g].base[kq];
-      base_n[u] = in ? bl : -1; meta_n[u] = in ? kgs[g].meta : 0u; tq_n[u] = HAS_T ? kgs[g].tq : 0;
-    }
-#pragma unroll
-    for(int u = 0; u < ASM_U; u++)
-    {
-      const bool ok = base[u] >= 0;
-      accP = __builtin_amdgcn_mfma_f64_16x16x4f64((ok && pcol >= 0) ? aP[u] : 0.0, (ok && bs == 0) ? bv[u] : 0.0,
+      const double* row = myrow + u*4*LEN;
+      const double aP = row[pc], bvP = row[bcolP];
+      accP = __builtin_amdgcn_mfma_f64_16x16x4f64((ok[u] && pcol >= 0) ? aP : 0.0, (ok[u] && pn) ? bvP : 0.0,
                                                   accP, 0, 0, 0);
       if(HAS_T)
       {
-        const int myslot = (meta[u] >> (2*kq)) & 3;
-        accT = __builtin_amdgcn_mfma_f64_16x16x4f64((ok && tcol >= 0) ? aT[u] : 0.0,
-                                                    (ok && bs == myslot) ? bv[u] : 0.0, accT, 0, 0, 0);
-        if(meta[u] & (1u << 11))
+        const double aT = row[tc], bv = row[bcol];
+        const uint32_t meta = G[u].meta;
+        const int myslot = (meta >> (2*kq)) & 3;
+        accT = __builtin_amdgcn_mfma_f64_16x16x4f64((ok[u] && tcol >= 0) ? aT : 0.0,
+                                                    (ok[u] && bs == myslot) ? bv : 0.0, accT, 0, 0, 0);
+        if(meta & (1u << 11))
         {
-          const bool mine = bs < (int)((meta[u] >> 8) & 7);
+          const bool mine = bs < (int)((meta >> 8) & 7);
 #pragma unroll
           for(int r = 0; r < 4; r++)
             if(4*r < MT)
@@ -382,9 +401,11 @@ __device__ __forceinline__ void asm_mfma_task(const AsmMTask& T, const AsmShape*
         }
       }
     }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
   }
   // persistent blocks
-  if(bs == 0)
+  if(m < nJ)
   {
 #pragma unroll
     for(int r = 0; r < 4; r++)
@@ -393,8 +414,17 @@ __device__ __forceinline__ void asm_mfma_task(const AsmMTask& T, const AsmShape*
       if(mm >= MP) continue;
       const AsmSlot SL = slots[T.slot0 + SH->pslot[mm]];
       const int a = SH->pa[mm];
-      if(T.part < 0) { if(!SL.diag || a >= bb) Lx[SL.dest + a + (int64_t)bb*SL.ld] = accP[r]; }
-      else part[T.part + SL.accoff + bb*SL.nI + a] = accP[r];
+      if(T.part < 0) { if(!SL.diag || a >= m) Lx[SL.dest + a + (int64_t)m*SL.ld] = accP[r]; }
+      else part[T.part + SL.accoff + m*SL.nI + a] = accP[r];
+    }
+  }
+  else if(pn)       // the rider's diagonal block: always a partial
+  {
+#pragma unroll
+    for(int r = 0; r < 4; r++)
+    {
+      const int mm = kq + 4*r;
+      if(mm < MP && SH->pslot[mm] == SH->rslot) part[T.rpart + (m - nJ)*nJr + SH->pa[mm]] = accP[r];
     }
   }
 }
@@ -404,27 +434,31 @@ __global__ void __launch_bounds__(TPB) k_assemble_mfma(const AsmMTask* __restric
                                                        const int* __restrict__ tdest,
                                                        const AsmSlot* __restrict__ slots,
                                                        const double* __restrict__ vals,
-                                                       double* __restrict__ Lx, double* __restrict__ part)
+                                                       double* __restrict__ Lx, double* __restrict__ part, int LEN)
 {
+  extern __shared__ double asm_tiles[];
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(blockIdx.x*(TPB/64) + (threadIdx.x >> 6));
   if(wid >= ntasks) return;
   const AsmMTask T = tasks[wid];
   const AsmShape* SH = shapes + T.shape;
-  if(SH->MT > 0) asm_mfma_task<true>(T, SH, kgs, tdest, slots, vals, Lx, part, lane);
-  else           asm_mfma_task<false>(T, SH, kgs, tdest, slots, vals, Lx, part, lane);
+  double* tile = asm_tiles + (threadIdx.x >> 6)*(ASM_U*4*LEN);
+  if(SH->MT > 0) asm_mfma_task<true>(T, SH, kgs, tdest, slots, vals, Lx, part, lane, tile, LEN);
+  else           asm_mfma_task<false>(T, SH, kgs, tdest, slots, vals, Lx, part, lane, tile, LEN);
 }
 // persistent blocks written by several MFMA tasks: fixed-order sum of the listed partials.
 // k_assemble_fin2_short: one wave per block (lists of <= 32 partials);
 // k_assemble_fin2_long: one 1024-thread workgroup per block, 16 waves stride over the list
-__device__ __forceinline__ void fin2_store(const AsmFin2& F, int e, double v, double* __restrict__ Lx)
+__device__ __forceinline__ void fin2_store(const AsmFin2& F, int e, double v, double* __restrict__ Lx,
+                                           double* __restrict__ part)
 {
+  if(F.to_part) { part[F.dest + e] = v; return; }
   const int b = e / F.nI, a = e - b*F.nI;
   if(!F.diag || a >= b) Lx[F.dest + a + (int64_t)b*F.ld] = v;
 }
 __global__ void __launch_bounds__(TPB) k_assemble_fin2_short(const AsmFin2* __restrict__ fins, int nfins,
                                                              const int64_t* __restrict__ list,
-                                                             const double* __restrict__ part, double* __restrict__ Lx)
+                                                             double* part, double* __restrict__ Lx)
 {
   const int lane = threadIdx.x & 63;
   const int f = __builtin_amdgcn_readfirstlane(blockIdx.x*(TPB/64) + (threadIdx.x >> 6));
@@ -433,11 +467,11 @@ __global__ void __launch_bounds__(TPB) k_assemble_fin2_short(const AsmFin2* __re
   if(lane >= F.nI*F.nJ) return;
   double s = 0.0;
   for(int k = 0; k < F.nlist; k++) s += part[list[F.list0 + k] + lane];
-  fin2_store(F, lane, s, Lx);
+  fin2_store(F, lane, s, Lx, part);
 }
 __global__ void __launch_bounds__(1024) k_assemble_fin2_long(const AsmFin2* __restrict__ fins,
                                                              const int64_t* __restrict__ list,
-                                                             const double* __restrict__ part, double* __restrict__ Lx)
+                                                             double* part, double* __restrict__ Lx)
 {
   __shared__ double sh[1024];
   const AsmFin2 F = fins[blockIdx.x];
@@ -451,7 +485,7 @@ __global__ void __launch_bounds__(1024) k_assemble_fin2_long(const AsmFin2* __re
   {
     double tot = 0.0;
     for(int k = 0; k < 16; k++) tot += sh[k*64 + lane];
-    fin2_store(F, lane, tot, Lx);
+    fin2_store(F, lane, tot, Lx, part);
   }
 }
 // add the partial accumulators of a multi-task group in task order: one 1024-thread
@@ -1259,19 +1293,24 @@ int sparse_factorize(dlg_backend* b, int s, double lambda, int* ok)
     {
       DlgProfScope pk(b, DLG_PROF_K4_KERNEL);
       if(nmt > 0)
-        hipLaunchKernelGGL(k_assemble_mfma, dim3(dlg_cdiv(nmt, TPB/64)), dim3(TPB), 0, st, Y->asm_mtask, nmt,
-                           Y->asm_kg, Y->asm_shape, Y->asm_tdest, Y->asm_slot, S.Jin(), Y->Lx, Y->asm_part);
+        hipLaunchKernelGGL(k_assemble_mfma, dim3(dlg_cdiv(nmt, TPB/64)), dim3(TPB),
+                           sizeof(double)*(TPB/64)*ASM_U*4*H.asm_lds_len, st, Y->asm_mtask, nmt,
+                           Y->asm_kg, Y->asm_shape, Y->asm_tdest, Y->asm_slot, S.Jin(), Y->Lx, Y->asm_part,
+                           H.asm_lds_len);
       if(nt > 0)
         hipLaunchKernelGGL(k_assemble, dim3(dlg_cdiv(nt, TPB/64)), dim3(TPB), 0, st, Y->asm_ctask, nt,
                            Y->asm_batch, Y->asm_rho, Y->asm_pair, Y->asm_slot, S.Jin(), Y->Lx, Y->asm_part);
     }
-    const int nf2 = (int)H.asm_fin2.size(), nf2s = H.n_fin2_short;
-    if(nf2s > 0)
-      hipLaunchKernelGGL(k_assemble_fin2_short, dim3(dlg_cdiv(nf2s, TPB/64)), dim3(TPB), 0, st, Y->asm_fin2, nf2s,
-                         Y->asm_fin2_list, Y->asm_part, Y->Lx);
-    if(nf2 > nf2s)
-      hipLaunchKernelGGL(k_assemble_fin2_long, dim3(nf2 - nf2s), dim3(1024), 0, st, Y->asm_fin2 + nf2s,
-                         Y->asm_fin2_list, Y->asm_part, Y->Lx);
+    for(size_t q = 0; q + 2 < H.fin2_stage.size(); q += 3)
+    {
+      const int f0 = H.fin2_stage[q], ns = H.fin2_stage[q+1], nl = H.fin2_stage[q+2];
+      if(ns > 0)
+        hipLaunchKernelGGL(k_assemble_fin2_short, dim3(dlg_cdiv(ns, TPB/64)), dim3(TPB), 0, st, Y->asm_fin2 + f0, ns,
+                           Y->asm_fin2_list, Y->asm_part, Y->Lx);
+      if(nl > 0)
+        hipLaunchKernelGGL(k_assemble_fin2_long, dim3(nl), dim3(1024), 0, st, Y->asm_fin2 + f0 + ns,
+                           Y->asm_fin2_list, Y->asm_part, Y->Lx);
+    }
     const int nf = (int)H.asm_cfin.size();
     if(nf > 0)
       hipLaunchKernelGGL(k_assemble_fin, dim3(nf), dim3(1024), 0, st, Y->asm_cfin, Y->asm_slot,

@@ -902,16 +902,48 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
     // (same I in every row-block) or transient (all I different).  J qualifies when every
     // transient block receives exactly one contribution overall.
     const bool use_mfma = env_int("DOGLEG_AMD_ASM_MFMA", 1) != 0;
-    constexpr int KG_PER_TASK_T = 64, KG_PER_TASK_P = 256;
+    const int KG_PER_TASK_T = env_int("DLG_KGT", 64), KG_PER_TASK_P = env_int("DLG_KGP", 256);
     std::map<std::vector<int>, int> shape_ids;
     std::vector<int> tseen(nvb, -1), pseen(nvb, -1), fin_of(nvb, -1);
     struct Ord { int I, nI, offI; bool P; };
-    struct Cls { std::vector<int> es; std::vector<Ord> ords; int MP, MT, nP, nT, shape, slot0, acc_size; };
+    struct Cls { std::vector<int> es; std::vector<Ord> ords; int MP, MT, nP, nT, shape, slot0, acc_size, rider; };
     std::vector<Cls> classes;
     std::map<std::vector<int>, int> class_ids;
     std::vector<int> cnt_same, key, last_key;
     std::vector<std::vector<int64_t>> fin_lists;
-    auto build_mfma = [&](int J, int r0, int r1, int qJ, int t, int ld, int lc, int nJ) -> bool
+    // riders: dense column blocks whose only output block is their own diagonal
+    std::vector<int> rb_host(nrb, -1), rb_rider(nrb, -1);
+    std::vector<char> is_rider_blk(nvb, 0);
+    std::vector<std::vector<int64_t>> rider_parts(nvb);
+    const int RIDER_MIN = env_int("DOGLEG_AMD_RIDER_MIN", 4096);
+    if(use_mfma && RIDER_MIN > 0)
+      for(int Jr = 0; Jr < nvb; Jr++)
+      {
+        if(rptr[Jr+1] - rptr[Jr] < RIDER_MIN) continue;
+        bool last_everywhere = true;
+        for(int e = rptr[Jr]; e < rptr[Jr+1] && last_everywhere; e++)
+        {
+          const RowBlock& b = rbs[rrb[e]];
+          for(int x = 0; x < b.nvb; x++) if(bpos[rb_vb[b.vptr + x]] > bpos[Jr]) { last_everywhere = false; break; }
+        }
+        if(!last_everywhere) continue;
+        is_rider_blk[Jr] = 1;
+        for(int e = rptr[Jr]; e < rptr[Jr+1]; e++)
+        {
+          const int bi = rrb[e];
+          const RowBlock& b = rbs[bi];
+          int host = -1, best = 0;           // the other block of the row with the longest row list
+          for(int x = 0; x < b.nvb; x++)
+          {
+            const int I = rb_vb[b.vptr + x];
+            if(I == Jr) continue;
+            const int cnt = rptr[I+1] - rptr[I];
+            if(cnt > best || (cnt == best && host >= 0 && bpos[I] < bpos[host])) { best = cnt; host = I; }
+          }
+          rb_host[bi] = host; rb_rider[bi] = host >= 0 ? Jr : -1;
+        }
+      }
+    auto build_mfma = [&](int J, int r0, int r1, int qJ, int t, int ld, int lc, int nJ, bool is_rider) -> bool
     {
       // 1. classes of identical layout
       classes.clear(); class_ids.clear();
@@ -919,7 +951,9 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
       for(int e = r0; e < r1; e++)
       {
         const RowBlock& b = rbs[rrb[e]];
+        if(is_rider && rb_host[rrb[e]] >= 0) continue;         // carried by another column block's tasks
         key.assign(1, rb_off[b.vptr + rx[e]]);
+        key.push_back(rb_host[rrb[e]] == J ? rb_rider[rrb[e]] : -1);
         for(int x = 0; x < b.nvb; x++)
         { const int I = rb_vb[b.vptr + x]; if(bpos[I] >= qJ) { key.push_back(G.w[I]); key.push_back(rb_off[b.vptr + x]); } }
         int c;
@@ -930,9 +964,10 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
           if(it != class_ids.end()) c = it->second;
           else
           {
-            if(classes.size() >= 64) return false;
+            if(classes.size() >= 64 && !is_rider) return false;
             c = (int)classes.size(); class_ids[key] = c; classes.emplace_back();
             Cls& C = classes.back();
+            C.rider = key[1];
             for(int x = 0; x < b.nvb; x++)
             { const int I = rb_vb[b.vptr + x]; if(bpos[I] >= qJ) C.ords.push_back({I, G.w[I], rb_off[b.vptr + x], true}); }
           }
@@ -958,6 +993,11 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
           if(C.ords[k].P) { C.MP += C.ords[k].nI; C.nP++; pseen[C.ords[k].I] = J; } else { C.MT += C.ords[k].nI; C.nT++; }
         }
         if(C.MP > 16 || C.MT > 16) return false;
+        // window of row columns the kernel stages in LDS
+        int lo = rb_off[rbs[rrb[C.es[0]]].vptr + rx[C.es[0]]], hi = lo + nJ;
+        for(const Ord& o : C.ords) { lo = std::min(lo, o.offI); hi = std::max(hi, o.offI + o.nI); }
+        if(hi - lo > 64 && !is_rider) return false;
+        if(hi - lo > 255) return false;
       }
       for(const Cls& C : classes)
       {
@@ -983,7 +1023,7 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
       {
         const int offJ = rb_off[rbs[rrb[C.es[0]]].vptr + rx[C.es[0]]];
         key.assign(1, nJ); key.push_back(offJ);
-        for(const Ord& o : C.ords) { key.push_back(o.nI); key.push_back(o.offI); key.push_back(o.P); }
+        for(const Ord& o : C.ords) { key.push_back(o.nI); key.push_back(o.offI); key.push_back(o.P); key.push_back(o.I == C.rider); }
         auto it = shape_ids.find(key);
         if(it != shape_ids.end()) C.shape = it->second;
         else
@@ -996,9 +1036,16 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
             for(int a = 0; a < o.nI; a++)
               if(o.P) { sh.pcol[mp] = (int16_t)(o.offI + a); sh.pslot[mp] = (uint8_t)ip; sh.pa[mp] = (uint8_t)a; mp++; }
               else    { sh.tcol[mt] = (int16_t)(o.offI + a); sh.tj[mt] = (uint8_t)jt; sh.ta[mt] = (uint8_t)a; mt++; }
+            if(o.P && o.I == C.rider) { sh.offR = (uint16_t)o.offI; sh.nJr = (uint8_t)o.nI; sh.rslot = (uint8_t)ip; }
             if(o.P) ip++; else jt++;
           }
-          sh.offJ = (uint16_t)offJ; sh.nJ = (uint8_t)nJ; sh.MP = (uint8_t)C.MP; sh.MT = (uint8_t)C.MT;
+          int lo = offJ, hi = offJ + nJ;
+          for(const Ord& o : C.ords) { lo = std::min(lo, o.offI); hi = std::max(hi, o.offI + o.nI); }
+          sh.col0 = (uint16_t)lo; sh.ncopy = (uint8_t)(hi - lo);
+          for(int m = 0; m < 16; m++) { if(sh.pcol[m] >= 0) sh.pcol[m] -= lo; if(sh.tcol[m] >= 0) sh.tcol[m] -= lo; }
+          if(sh.nJr > 0) sh.offR -= lo;
+          S.asm_lds_len = std::max(S.asm_lds_len, ((hi - lo + 15)/16)*16 + 2);
+          sh.offJ = (uint16_t)(offJ - lo); sh.nJ = (uint8_t)nJ; sh.MP = (uint8_t)C.MP; sh.MT = (uint8_t)C.MT;
           sh.nT = (uint8_t)C.nT; sh.smax = (uint8_t)std::min(4, 16/nJ);
           C.shape = (int)S.asm_shape.size(); S.asm_shape.push_back(sh); shape_ids[key] = C.shape;
         }
@@ -1027,7 +1074,13 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
           {
             close_task();
             AsmMTask T; T.kg0 = (int)S.asm_kg.size(); T.kg1 = -1; T.slot0 = C.slot0; T.shape = C.shape; T.ld = ld;
-            T.pad = C.acc_size; T.panel = panel; T.part = -1;
+            T.pad = C.acc_size; T.panel = panel; T.part = -1; T.rpart = -1;
+            if(C.rider >= 0)
+            {
+              const int nr = G.w[C.rider];
+              T.rpart = S.asm_part_size; S.asm_part_size += nr*nr;
+              rider_parts[C.rider].push_back(T.rpart);
+            }
             S.asm_mtask.push_back(T); task_open = true; kg_in_task = 0;
           }
           const int base = b.base - base0;
@@ -1071,7 +1124,8 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
       }
       // 4. several tasks: persistent blocks go through partials, summed per destination block
       const int ntask = (int)S.asm_mtask.size() - first_task;
-      if(ntask > 1)
+      const bool carried = is_rider && !rider_parts[J].empty();
+      if(ntask > 1 || carried)
       {
         const int fin0 = (int)S.asm_fin2.size();
         fin_lists.clear();
@@ -1092,7 +1146,7 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
             {
               f = (int)S.asm_fin2.size(); fin_of[o.I] = f;
               AsmFin2 F; F.dest = sl.dest; F.ld = ld; F.list0 = 0; F.nlist = 0; F.nI = sl.nI; F.nJ = (uint8_t)nJ;
-              F.diag = sl.diag; F.pad = 0;
+              F.diag = sl.diag; F.to_part = 0;
               S.asm_fin2.push_back(F); fin_lists.emplace_back();
             }
             for(int k = first_task; k < first_task + ntask; k++)
@@ -1101,6 +1155,16 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
               if(T.slot0 == C.slot0) fin_lists[f - fin0].push_back(T.part + sl.accoff);
             }
           }
+        }
+        if(carried)
+        {
+          if(fin_lists.empty())          // every row of the rider is carried by other tasks
+          {
+            AsmFin2 F; F.dest = S.sn_lx[t] + lc + (int64_t)lc*ld; F.ld = ld; F.list0 = 0; F.nlist = 0;
+            F.nI = F.nJ = (uint8_t)nJ; F.diag = 1; F.to_part = 0;
+            S.asm_fin2.push_back(F); fin_lists.emplace_back();
+          }
+          fin_lists[0].insert(fin_lists[0].begin(), rider_parts[J].begin(), rider_parts[J].end());
         }
         for(size_t f = 0; f < fin_lists.size(); f++)
         {
@@ -1112,10 +1176,11 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
       for(int k = first_task; k < first_task + ntask; k++) S.asm_mtask[k].pad = 0;
       return true;
     };
+    for(int pass = 0; pass < 2; pass++)          // pass 1: the riders (rows nobody carried + the carried partials)
     for(int J = 0; J < nvb; J++)
     {
       const int r0 = rptr[J], r1 = rptr[J+1];
-      if(r0 == r1) continue;
+      if(r0 == r1 || (int)is_rider_blk[J] != pass) continue;
       const int qJ = bpos[J], t = sn_of_b[qJ];
       const int ld = S.sn_rowptr[t+1] - S.sn_rowptr[t];
       const int lc = colstart[qJ] - S.sn_c0[t];
@@ -1141,7 +1206,10 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
           slots.push_back({I, dest, G.w[I], I == J ? 1 : 0});
         }
       }
-      if(use_mfma && build_mfma(J, r0, r1, qJ, t, ld, lc, nJ)) continue;
+      if(use_mfma && build_mfma(J, r0, r1, qJ, t, ld, lc, nJ, pass == 1)) continue;
+      if(pass == 1) SYM_FAIL("internal error: no assembly schedule for dense column block %d", J);
+      // this block falls back to the LDS kernel: the riders it would have carried keep their own tasks
+      for(int e = r0; e < r1; e++) if(rb_host[rrb[e]] == J) { rb_host[rrb[e]] = -2; rb_rider[rrb[e]] = -1; }
       // groups of slots that fit the LDS accumulator
       grp_of.assign(slots.size(), 0); acc_of.assign(slots.size(), 0);
       int ngrp = 0;
@@ -1233,10 +1301,48 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
         }
       }
     }
-    // short partial lists first (one wave each), long ones after (one workgroup each)
-    std::stable_partition(S.asm_fin2.begin(), S.asm_fin2.end(), [](const AsmFin2& f) { return f.nlist <= 32; });
-    S.n_fin2_short = 0;
-    for(const AsmFin2& f : S.asm_fin2) if(f.nlist <= 32) S.n_fin2_short++;
+    // long lists are summed hierarchically: chunks of 64 partials -> intermediate partials.
+    // Stages run in order; inside a stage the entries with <= 64 partials come first
+    // (one wave each), then the longer ones (one workgroup each).
+    {
+      std::vector<AsmFin2> cur; cur.swap(S.asm_fin2);
+      std::vector<int64_t> lst; lst.swap(S.asm_fin2_list);
+      std::vector<std::vector<AsmFin2>> stages;
+      std::vector<AsmFin2> inter;
+      for(int depth = 0; depth < 8; depth++)
+      {
+        inter.clear();
+        for(AsmFin2& F : cur)
+        {
+          if(F.nlist <= 256) continue;
+          const int e = F.nI*F.nJ, nch = (F.nlist + 63)/64;
+          const int new0 = (int)lst.size();
+          std::vector<int64_t> news;
+          for(int c = 0; c < nch; c++)
+          {
+            AsmFin2 X = F; X.to_part = 1; X.dest = S.asm_part_size; S.asm_part_size += e;
+            X.list0 = F.list0 + 64*c; X.nlist = std::min(64, F.nlist - 64*c);
+            inter.push_back(X); news.push_back(X.dest);
+          }
+          lst.insert(lst.end(), news.begin(), news.end());
+          F.list0 = new0; F.nlist = nch;
+        }
+        stages.push_back(cur);
+        if(inter.empty()) break;
+        cur = inter;
+        // the intermediates just created must run BEFORE the entries that consume them
+      }
+      // stages were collected consumer-first: emit them in reverse
+      for(int sidx = (int)stages.size() - 1; sidx >= 0; sidx--)
+      {
+        std::vector<AsmFin2>& st = stages[sidx];
+        std::stable_partition(st.begin(), st.end(), [](const AsmFin2& f) { return f.nlist <= 64; });
+        int ns = 0; for(const AsmFin2& f : st) if(f.nlist <= 64) ns++;
+        S.fin2_stage.push_back((int)S.asm_fin2.size()); S.fin2_stage.push_back(ns); S.fin2_stage.push_back((int)st.size() - ns);
+        S.asm_fin2.insert(S.asm_fin2.end(), st.begin(), st.end());
+      }
+      S.asm_fin2_list.swap(lst);
+    }
     // sentinel so that rho[i+1].pair0 closes the pair list of the last rho
     AsmRho R; memset(&R, 0, sizeof(R)); R.pair0 = (int)S.asm_pair.size(); S.asm_rho.push_back(R);
   }

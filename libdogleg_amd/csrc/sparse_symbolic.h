@@ -99,8 +99,17 @@ struct AsmShape
   uint8_t tj[16], ta[16];       // transient row m: transient ordinal, row inside the block
   uint16_t offJ;                // offset of the column block inside a row
   uint8_t nJ, MP, MT, nT, smax, pad;
+  // "rider": a dense column block J' (its only output is its own diagonal block, every row-block
+  // lists it last) does not get tasks of its own; the tasks of another column block that read
+  // the same rows carry J' as nJr extra B columns and emit a partial of (J',J')
+  uint16_t offR;                // offset of the rider block inside a row
+  uint8_t nJr, rslot;           // rider width (0: none), persistent slot ordinal of the rider's rows
+  // the kernel stages columns [col0, col0 + ncopy) of every row in LDS; pcol/tcol/offJ/offR are
+  // relative to col0
+  uint16_t col0;
+  uint8_t ncopy, pad2;
 };
-static_assert(sizeof(AsmShape) == 136, "AsmShape layout");
+static_assert(sizeof(AsmShape) == 144, "AsmShape layout");
 struct AsmKG
 {
   int32_t  base[4];             // first value of each of the 4 rows, -1: no row
@@ -114,10 +123,12 @@ struct AsmMTask
   int32_t ld, pad;
   int64_t panel;                // Lx offset of (row 0, first column of J) of J's panel
   int64_t part;                 // offset into the partial buffer, or -1: write the panels directly
+  int64_t rpart;                // partial of the rider's diagonal block (shape.nJr > 0)
 };
-static_assert(sizeof(AsmMTask) == 40, "AsmMTask layout");
+static_assert(sizeof(AsmMTask) == 48, "AsmMTask layout");
 // a persistent block written by several tasks: sum of the listed partials, in list order
-struct AsmFin2 { int64_t dest; int32_t ld, list0, nlist; uint8_t nI, nJ, diag, pad; };
+// to_part: an intermediate sum of a long list, written densely to the partial buffer at dest
+struct AsmFin2 { int64_t dest; int32_t ld, list0, nlist; uint8_t nI, nJ, diag, to_part; };
 static_assert(sizeof(AsmFin2) == 24, "AsmFin2 layout");
 
 // a wave-task: contributions [c0,c1) of block blk; part >= 0: write the partial
@@ -183,9 +194,10 @@ struct SymHost
   std::vector<AsmShape> asm_shape;
   std::vector<AsmKG>    asm_kg;
   std::vector<AsmMTask> asm_mtask;
-  std::vector<AsmFin2>  asm_fin2;     // sorted: the n_fin2_short entries with short lists first
+  std::vector<AsmFin2>  asm_fin2;     // grouped in stages (long lists are summed hierarchically)
   std::vector<int64_t>  asm_fin2_list;
-  int n_fin2_short = 0;
+  int asm_lds_len = 0;                // LDS row stride (doubles) of the MFMA assembly kernel
+  std::vector<int>      fin2_stage;   // per stage: first entry, #entries with <= 64 partials, #entries with more
   std::vector<int>      asm_tdest;   // row offset in J's panel of every (row-block, transient ordinal)
   int64_t asm_part_size = 0;
   // ---- forward-solve gather lists
