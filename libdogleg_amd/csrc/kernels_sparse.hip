@@ -75,7 +75,7 @@ struct SparseSym
   AsmRho* asm_rho = nullptr; AsmPair* asm_pair = nullptr; AsmSlot* asm_slot = nullptr;
   AsmBatch* asm_batch = nullptr; AsmTask* asm_ctask = nullptr; AsmFin* asm_cfin = nullptr;
   AsmShape* asm_shape = nullptr; AsmKG* asm_kg = nullptr; AsmMTask* asm_mtask = nullptr; int* asm_tdest = nullptr;
-  AsmFin2* asm_fin2 = nullptr; int64_t* asm_fin2_list = nullptr;
+  AsmFin2* asm_fin2 = nullptr; int64_t* asm_fin2_list = nullptr; AsmRun* asm_run = nullptr; int* asm_pdest = nullptr;
   int *rl_ptr = nullptr, *rl_pos = nullptr, *perm = nullptr, *col_sn = nullptr;
   int *fw_sn = nullptr, *fw_r0 = nullptr, *fw_r1 = nullptr, *ms_sn = nullptr; int64_t* sn_top = nullptr;
   int *sn_bd_ptr = nullptr, *sn_bd_col = nullptr;
@@ -299,6 +299,10 @@ typedef double dlg_v4d __attribute__((ext_vector_type(4)));
 #define DLG_ASM_U 4
 #endif
 constexpr int ASM_U = DLG_ASM_U;
+// One wave per RUN = consecutive tasks of one shape whose k-groups are contiguous: the shape's
+// lane constants are loaded once and the k-group stream is software-pipelined across the
+// task boundaries (bit 12 of a k-group's meta: last of its task -> store the persistent blocks,
+// move on to the next task record, which was fetched ahead).
 // Per k-group the wave copies the needed window of its 4 rows into a wave-private LDS tile with
 // one coalesced load (lane = (row, column)), then every lane picks its A/B operands from the
 // tile: the vector-memory pipe sees one load per k-group instead of one per operand.  The
@@ -306,58 +310,94 @@ constexpr int ASM_U = DLG_ASM_U;
 // unconditional with clamped addresses (absent rows read element 0 and are zeroed afterwards):
 // the loop body is straight-line code, the only branches are uniform.
 template <bool HAS_T>
-__device__ __forceinline__ void asm_mfma_task(const AsmMTask& T, const AsmShape* __restrict__ SH,
-                                              const AsmKG* __restrict__ kgs, const int* __restrict__ tdest,
-                                              const AsmSlot* __restrict__ slots, const double* __restrict__ vals,
-                                              double* __restrict__ Lx, double* __restrict__ part, int lane,
-                                              double* __restrict__ tile, int LEN)
+__device__ __forceinline__ void asm_mfma_run(const AsmRun& R, const AsmMTask* __restrict__ tasks,
+                                             const AsmShape* __restrict__ SH,
+                                             const AsmKG* __restrict__ kgs, const int* __restrict__ tdest,
+                                             const int* __restrict__ pdest, const double* __restrict__ vals,
+                                             double* __restrict__ Lx, double* __restrict__ part, int lane,
+                                             double* __restrict__ tile, int LEN)
 {
   const int m = lane & 15, kq = lane >> 4;
-  const int nJ = SH->nJ, MP = SH->MP, MT = SH->MT, nT = SH->nT;
-  const int pcol = SH->pcol[m], tcol = HAS_T ? SH->tcol[m] : -1;
+  const int nJ = SH->nJ, MP = SH->MP, MT = SH->MT, nT = SH->nT, nJr = SH->nJr;
+  const int col0 = SH->col0, ncopy = SH->ncopy, dslot = SH->dslot, rslot = SH->rslot;
   const int bs = m / nJ, bb = m - bs*nJ;
-  const int bcol = SH->offJ + bb;
-  // B column of the persistent product: J's columns, then the rider's (if any)
-  const int nJr = SH->nJr;
-  const int bcolP = m < nJ ? SH->offJ + m : (m < nJ + nJr ? SH->offR + (m - nJ) : (int)SH->offJ);
+  // Tile columns this lane reads its operands from.  Column ZC of every tile row is zero: lanes
+  // without a persistent / transient row, B columns outside the product and rows of another
+  // row-block slot read it instead of being masked afterwards.
+  const int ZC = LEN - 2;
   const bool pn = m < nJ + nJr;
-  const int pc = max(pcol, 0), tc = max(tcol, 0);
-  const int col0 = SH->col0, ncopy = SH->ncopy;
-  int tj[4], ta[4];                       // transient rows this lane holds in D: m' = kq + 4r
+  int pc = SH->pcol[m];            pc = pc >= 0 ? pc : ZC;
+  int tc = HAS_T ? SH->tcol[m] : -1; tc = tc >= 0 ? tc : ZC;
+  const int bcol = SH->offJ + bb;   // B column of the transient product (this lane's slot only)
+  // B column of the persistent product: J's columns, then the rider's (if any)
+  const int bcolP = m < nJ ? SH->offJ + m : (pn ? SH->offR + (m - nJ) : ZC);
+  // rows m' = kq + 4r of D this lane holds: transient (ordinal, row in block), persistent
+  // (slot ordinal, row in block, offset in a partial, rows of the block)
+  // (packed: these are only needed when something is stored)
+  uint32_t pk1[4], pk2[4];
 #pragma unroll
-  for(int r = 0; r < 4; r++) { tj[r] = HAS_T ? SH->tj[kq + 4*r] : 0xFF; ta[r] = HAS_T ? SH->ta[kq + 4*r] : 0; }
-  dlg_v4d accP = {0.0, 0.0, 0.0, 0.0}, accT = {0.0, 0.0, 0.0, 0.0};
-  AsmKG G[ASM_U], Gn[ASM_U];
-  const int kglast = T.kg1 - 1;
-  auto fetch = [&](int kg0, AsmKG* R) {
-#pragma unroll
-    for(int u = 0; u < ASM_U; u++)
-    {
-      R[u] = kgs[min(kg0 + u, kglast)];
-      if(kg0 + u > kglast) { R[u].base[0] = R[u].base[1] = R[u].base[2] = R[u].base[3] = -1; R[u].meta = 0; }
-    }
-  };
-  fetch(T.kg0, Gn);
-  double* myrow = tile + kq*LEN;
-  for(int kg = T.kg0; kg < T.kg1; kg += ASM_U)
+  for(int r = 0; r < 4; r++)
   {
-    int td[ASM_U];
-    bool ok[ASM_U];
+    const int mm = kq + 4*r;
+    const uint32_t tjv = HAS_T ? SH->tj[mm] : 0xFF, tav = HAS_T ? SH->ta[mm] : 0;
+    const uint32_t psv = mm < MP ? SH->pslot[mm] : 0xFF;
+    pk1[r] = tjv | tav << 8 | psv << 16 | (uint32_t)SH->pa[mm] << 24;
+    pk2[r] = (uint32_t)SH->paccoff[mm] | (uint32_t)SH->pnI[mm] << 8;
+  }
+#define TJ(r)  (int)(pk1[r] & 0xFF)
+#define TA(r)  (int)((pk1[r] >> 8) & 0xFF)
+#define PS(r)  (int)((pk1[r] >> 16) & 0xFF)
+#define PA(r)  (int)(pk1[r] >> 24)
+#define PAO(r) (int)(pk2[r] & 0xFF)
+#define PNI(r) (int)(pk2[r] >> 8)
+  dlg_v4d accP = {0.0, 0.0, 0.0, 0.0}, accT = {0.0, 0.0, 0.0, 0.0};
+  // task records: current + next (fetched ahead, as ONE vector load each: lane l holds dword l of
+  // the record, fields are broadcast with readlane; vector loads return in order, so prefetches
+  // overlap with the rest -- scalar loads would share a counter with the LDS traffic);
+  // persistent destinations of both (16 per task)
+  const int tlast = R.task1 - 1;
+  int tix = R.task0;
+  auto task_fetch = [&](int t) { return reinterpret_cast<const int*>(tasks + min(t, tlast))[min(lane, 11)]; };
+  int tcv = task_fetch(tix), tnv = task_fetch(tix + 1);
+  int pdc = pdest[16*(int64_t)min(tix, tlast) + m], pdn = pdest[16*(int64_t)min(tix + 1, tlast) + m];
+  int64_t Tpart, Trpart, colT, colP;     // current task: partial offsets; Lx offset of this lane's column
+  auto task_unpack = [&](int v) {
+    const int ld = __builtin_amdgcn_readlane(v, 4);
+    const int64_t panel = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readlane(v, 7) << 32) | (uint32_t)__builtin_amdgcn_readlane(v, 6));
+    Tpart  = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readlane(v, 9) << 32) | (uint32_t)__builtin_amdgcn_readlane(v, 8));
+    Trpart = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readlane(v, 11) << 32) | (uint32_t)__builtin_amdgcn_readlane(v, 10));
+    colT = panel + (int64_t)bb*ld; colP = panel + (int64_t)m*ld; };
+  task_unpack(tcv);
+  // k-group records of one iteration: ASM_U*6 dwords, one vector load, prefetched one iteration ahead
+  static_assert(ASM_U*6 <= 64, "k-group records of an iteration must fit one wave load");
+  const int kglast = R.kg1 - 1;
+  const int krec = min(lane, ASM_U*6 - 1)/6, kw = min(lane, ASM_U*6 - 1) - 6*krec;
+  auto kg_fetch = [&](int kg0) { return reinterpret_cast<const int*>(kgs + min(kg0 + krec, kglast))[kw]; };
+  int gnv = kg_fetch(R.kg0);
+  double* myrow = tile + kq*LEN;
 #pragma unroll
-    for(int u = 0; u < ASM_U; u++) G[u] = Gn[u];
-    // (a) one coalesced copy of the rows' windows into the tile
+  for(int u = 0; u < ASM_U; u++) myrow[u*4*LEN + ZC] = 0.0;
+  for(int kg = R.kg0; kg < R.kg1; kg += ASM_U)
+  {
+    const int gv = gnv;
+    uint32_t meta[ASM_U];
+    int td[ASM_U];
+#pragma unroll
+    for(int u = 0; u < ASM_U; u++) meta[u] = kg + u <= kglast ? (uint32_t)__builtin_amdgcn_readlane(gv, 6*u + 5) : 0u;
+    // (a) one coalesced copy of the rows' windows into the tile (absent rows: zeros)
     for(int c0 = 0; c0 < ncopy; c0 += 16)
     {
       double v[ASM_U];
+      int b[ASM_U];
 #pragma unroll
       for(int u = 0; u < ASM_U; u++)
       {
-        const int b = kq == 0 ? G[u].base[0] : kq == 1 ? G[u].base[1] : kq == 2 ? G[u].base[2] : G[u].base[3];
-        ok[u] = b >= 0;
-        v[u] = vals[max(b, 0) + col0 + min(c0 + m, ncopy - 1)];
+        b[u] = __builtin_amdgcn_ds_bpermute(4*(6*u + kq), gv);
+        if(kg + u > kglast) b[u] = -1;
+        v[u] = vals[max(b[u], 0) + col0 + min(c0 + m, ncopy - 1)];
       }
 #pragma unroll
-      for(int u = 0; u < ASM_U; u++) myrow[u*4*LEN + c0 + m] = v[u];
+      for(int u = 0; u < ASM_U; u++) myrow[u*4*LEN + c0 + m] = b[u] >= 0 ? v[u] : 0.0;
     }
     if(HAS_T)
     {
@@ -365,86 +405,90 @@ __device__ __forceinline__ void asm_mfma_task(const AsmMTask& T, const AsmShape*
       for(int u = 0; u < ASM_U; u++)
       {
         // transient destinations of this k-group: entry `lane` of its list (slot-major)
-        const int nent = (int)((G[u].meta >> 8) & 7)*nT;
-        td[u] = tdest[lane < nent ? G[u].tq + lane : 0];
+        const int nent = (int)((meta[u] >> 8) & 7)*nT;
+        td[u] = tdest[lane < nent ? __builtin_amdgcn_readlane(gv, 6*u + 4) + lane : 0];
       }
     }
-    fetch(kg + ASM_U, Gn);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    gnv = kg_fetch(kg + ASM_U);
     __builtin_amdgcn_wave_barrier();
     // (b) operands from the tile, products
 #pragma unroll
     for(int u = 0; u < ASM_U; u++)
     {
       const double* row = myrow + u*4*LEN;
-      const double aP = row[pc], bvP = row[bcolP];
-      accP = __builtin_amdgcn_mfma_f64_16x16x4f64((ok[u] && pcol >= 0) ? aP : 0.0, (ok[u] && pn) ? bvP : 0.0,
-                                                  accP, 0, 0, 0);
+      accP = __builtin_amdgcn_mfma_f64_16x16x4f64(row[pc], row[bcolP], accP, 0, 0, 0);
       if(HAS_T)
       {
-        const double aT = row[tc], bv = row[bcol];
-        const uint32_t meta = G[u].meta;
-        const int myslot = (meta >> (2*kq)) & 3;
-        accT = __builtin_amdgcn_mfma_f64_16x16x4f64((ok[u] && tcol >= 0) ? aT : 0.0,
-                                                    (ok[u] && bs == myslot) ? bv : 0.0, accT, 0, 0, 0);
-        if(meta & (1u << 11))
+        const int myslot = (meta[u] >> (2*kq)) & 3;
+        accT = __builtin_amdgcn_mfma_f64_16x16x4f64(row[tc], row[bs == myslot ? bcol : ZC], accT, 0, 0, 0);
+        if(meta[u] & (1u << 11))
         {
-          const bool mine = bs < (int)((meta >> 8) & 7);
+          const bool mine = bs < (int)((meta[u] >> 8) & 7);
 #pragma unroll
           for(int r = 0; r < 4; r++)
             if(4*r < MT)
             {
-              const int ro = __builtin_amdgcn_ds_bpermute(4*(bs*nT + tj[r]), td[u]);
-              if(mine && tj[r] != 0xFF) Lx[T.panel + ro + ta[r] + (int64_t)bb*T.ld] = accT[r];
+              const int ro = __builtin_amdgcn_ds_bpermute(4*(bs*nT + TJ(r)), td[u]);
+              if(mine && TJ(r) != 0xFF) Lx[colT + (ro + TA(r))] = accT[r];
             }
           accT = (dlg_v4d){0.0, 0.0, 0.0, 0.0};
         }
       }
+      if(meta[u] & (1u << 12))           // end of a task: its persistent blocks
+      {
+#pragma unroll
+        for(int r = 0; r < 4; r++)
+          if(4*r < MP)
+          {
+            const int ro = __builtin_amdgcn_ds_bpermute(4*PS(r), pdc);
+            if(PS(r) != 0xFF)
+            {
+              if(m < nJ)
+              {
+                if(Tpart < 0) { if(PS(r) != dslot || PA(r) >= m) Lx[colP + (ro + PA(r))] = accP[r]; }
+                else part[Tpart + (PAO(r) + m*PNI(r))] = accP[r];
+              }
+              else if(pn && PS(r) == rslot) part[Trpart + ((m - nJ)*nJr + PA(r))] = accP[r];
+            }
+          }
+        accP = (dlg_v4d){0.0, 0.0, 0.0, 0.0};
+        tix++;
+        task_unpack(tnv); pdc = pdn;
+        tnv = task_fetch(tix + 1);
+        pdn = pdest[16*(int64_t)min(tix + 1, tlast) + m];
+      }
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     __builtin_amdgcn_wave_barrier();
   }
-  // persistent blocks
-  if(m < nJ)
-  {
-#pragma unroll
-    for(int r = 0; r < 4; r++)
-    {
-      const int mm = kq + 4*r;
-      if(mm >= MP) continue;
-      const AsmSlot SL = slots[T.slot0 + SH->pslot[mm]];
-      const int a = SH->pa[mm];
-      if(T.part < 0) { if(!SL.diag || a >= m) Lx[SL.dest + a + (int64_t)m*SL.ld] = accP[r]; }
-      else part[T.part + SL.accoff + m*SL.nI + a] = accP[r];
-    }
-  }
-  else if(pn)       // the rider's diagonal block: always a partial
-  {
-#pragma unroll
-    for(int r = 0; r < 4; r++)
-    {
-      const int mm = kq + 4*r;
-      if(mm < MP && SH->pslot[mm] == SH->rslot) part[T.rpart + (m - nJ)*nJr + SH->pa[mm]] = accP[r];
-    }
-  }
+#undef TJ
+#undef TA
+#undef PS
+#undef PA
+#undef PAO
+#undef PNI
 }
-__global__ void __launch_bounds__(TPB) k_assemble_mfma(const AsmMTask* __restrict__ tasks, int ntasks,
+#ifdef DLG_ASM_WPE
+#define ASM_WPE_ATTR __attribute__((amdgpu_waves_per_eu(DLG_ASM_WPE, DLG_ASM_WPE)))
+#else
+#define ASM_WPE_ATTR
+#endif
+__global__ void __launch_bounds__(TPB) ASM_WPE_ATTR k_assemble_mfma(const AsmRun* __restrict__ runs, int nruns,
+                                                       const AsmMTask* __restrict__ tasks,
                                                        const AsmKG* __restrict__ kgs,
                                                        const AsmShape* __restrict__ shapes,
-                                                       const int* __restrict__ tdest,
-                                                       const AsmSlot* __restrict__ slots,
+                                                       const int* __restrict__ tdest, const int* __restrict__ pdest,
                                                        const double* __restrict__ vals,
                                                        double* __restrict__ Lx, double* __restrict__ part, int LEN)
 {
   extern __shared__ double asm_tiles[];
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(blockIdx.x*(TPB/64) + (threadIdx.x >> 6));
-  if(wid >= ntasks) return;
-  const AsmMTask T = tasks[wid];
-  const AsmShape* SH = shapes + T.shape;
+  if(wid >= nruns) return;
+  const AsmRun R = runs[wid];
+  const AsmShape* SH = shapes + tasks[R.task0].shape;
   double* tile = asm_tiles + (threadIdx.x >> 6)*(ASM_U*4*LEN);
-  if(SH->MT > 0) asm_mfma_task<true>(T, SH, kgs, tdest, slots, vals, Lx, part, lane, tile, LEN);
-  else           asm_mfma_task<false>(T, SH, kgs, tdest, slots, vals, Lx, part, lane, tile, LEN);
+  if(SH->MT > 0) asm_mfma_run<true>(R, tasks, SH, kgs, tdest, pdest, vals, Lx, part, lane, tile, LEN);
+  else           asm_mfma_run<false>(R, tasks, SH, kgs, tdest, pdest, vals, Lx, part, lane, tile, LEN);
 }
 // persistent blocks written by several MFMA tasks: fixed-order sum of the listed partials.
 // k_assemble_fin2_short: one wave per block (lists of <= 32 partials);
@@ -1127,7 +1171,7 @@ int sparse_set_pattern(dlg_backend* b, const int* colptr, const int* rowidx)
   UP(uw_item); UP(uw_s0); UP(uw_s1); UP(uw_part); UP(uf_item); UP(uf_n); UP(uf_off);
   UP(oblk); UP(contrib); UP(jtx_task); UP(jtx_fin_ptr); UP(jtx_fin_blk);
   UP(asm_rho); UP(asm_pair); UP(asm_slot); UP(asm_batch); UP(asm_ctask); UP(asm_cfin);
-  UP(asm_shape); UP(asm_kg); UP(asm_mtask); UP(asm_tdest); UP(asm_fin2); UP(asm_fin2_list);
+  UP(asm_shape); UP(asm_kg); UP(asm_mtask); UP(asm_tdest); UP(asm_fin2); UP(asm_fin2_list); UP(asm_run); UP(asm_pdest);
   UP(rl_ptr); UP(rl_pos); UP(perm); UP(col_sn); UP(fw_sn); UP(fw_r0); UP(fw_r1); UP(ms_sn); UP(sn_top); UP(sn_bd_ptr); UP(sn_bd_col);
   // rank-local pattern for the row-wise kernels
   {
@@ -1293,10 +1337,13 @@ int sparse_factorize(dlg_backend* b, int s, double lambda, int* ok)
     {
       DlgProfScope pk(b, DLG_PROF_K4_KERNEL);
       if(nmt > 0)
-        hipLaunchKernelGGL(k_assemble_mfma, dim3(dlg_cdiv(nmt, TPB/64)), dim3(TPB),
-                           sizeof(double)*(TPB/64)*ASM_U*4*H.asm_lds_len, st, Y->asm_mtask, nmt,
-                           Y->asm_kg, Y->asm_shape, Y->asm_tdest, Y->asm_slot, S.Jin(), Y->Lx, Y->asm_part,
+      {
+        const int nruns = (int)H.asm_run.size();
+        hipLaunchKernelGGL(k_assemble_mfma, dim3(dlg_cdiv(nruns, TPB/64)), dim3(TPB),
+                           sizeof(double)*(TPB/64)*ASM_U*4*H.asm_lds_len, st, Y->asm_run, nruns, Y->asm_mtask,
+                           Y->asm_kg, Y->asm_shape, Y->asm_tdest, Y->asm_pdest, S.Jin(), Y->Lx, Y->asm_part,
                            H.asm_lds_len);
+      }
       if(nt > 0)
         hipLaunchKernelGGL(k_assemble, dim3(dlg_cdiv(nt, TPB/64)), dim3(TPB), 0, st, Y->asm_ctask, nt,
                            Y->asm_batch, Y->asm_rho, Y->asm_pair, Y->asm_slot, S.Jin(), Y->Lx, Y->asm_part);

@@ -906,7 +906,8 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
     std::map<std::vector<int>, int> shape_ids;
     std::vector<int> tseen(nvb, -1), pseen(nvb, -1), fin_of(nvb, -1);
     struct Ord { int I, nI, offI; bool P; };
-    struct Cls { std::vector<int> es; std::vector<Ord> ords; int MP, MT, nP, nT, shape, slot0, acc_size, rider; };
+    struct Cls { std::vector<int> es; std::vector<Ord> ords; int MP, MT, nP, nT, shape, slot0, acc_size, rider, pq; };
+    std::vector<int> mtask_acc;          // accumulator size of every MFMA task (parallel to asm_mtask)
     std::vector<Cls> classes;
     std::map<std::vector<int>, int> class_ids;
     std::vector<int> cnt_same, key, last_key;
@@ -1037,8 +1038,12 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
               if(o.P) { sh.pcol[mp] = (int16_t)(o.offI + a); sh.pslot[mp] = (uint8_t)ip; sh.pa[mp] = (uint8_t)a; mp++; }
               else    { sh.tcol[mt] = (int16_t)(o.offI + a); sh.tj[mt] = (uint8_t)jt; sh.ta[mt] = (uint8_t)a; mt++; }
             if(o.P && o.I == C.rider) { sh.offR = (uint16_t)o.offI; sh.nJr = (uint8_t)o.nI; sh.rslot = (uint8_t)ip; }
+            if(o.P && o.I == J) sh.dslot = (uint8_t)ip;
             if(o.P) ip++; else jt++;
           }
+          { int mp2 = 0, acc = 0;
+            for(const Ord& o : C.ords) if(o.P)
+            { for(int a = 0; a < o.nI; a++) { sh.paccoff[mp2] = (uint8_t)(acc + a); sh.pnI[mp2] = (uint8_t)o.nI; mp2++; } acc += o.nI*nJ; } }
           int lo = offJ, hi = offJ + nJ;
           for(const Ord& o : C.ords) { lo = std::min(lo, o.offI); hi = std::max(hi, o.offI + o.nI); }
           sh.col0 = (uint16_t)lo; sh.ncopy = (uint8_t)(hi - lo);
@@ -1058,6 +1063,8 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
           sl.nI = (uint8_t)o.nI; sl.diag = (uint8_t)(o.I == J);
           S.asm_slot.push_back(sl); C.acc_size += o.nI*nJ;
         }
+        C.pq = (int)S.asm_pdest.size();
+        for(const Ord& o : C.ords) if(o.P) S.asm_pdest.push_back((int)(slots[slot_of[o.I]].dest - panel));
         bool task_open = false, kg_open = false;
         int kg_rows = 0, kg_slots = 0, kg_in_task = 0;
         auto close_kg = [&]() { if(kg_open) { S.asm_kg.back().meta |= (uint32_t)kg_slots << 8 | 1u << 11; kg_open = false; } };
@@ -1074,7 +1081,8 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
           {
             close_task();
             AsmMTask T; T.kg0 = (int)S.asm_kg.size(); T.kg1 = -1; T.slot0 = C.slot0; T.shape = C.shape; T.ld = ld;
-            T.pad = C.acc_size; T.panel = panel; T.part = -1; T.rpart = -1;
+            T.pq = C.pq; T.panel = panel; T.part = -1; T.rpart = -1;
+            mtask_acc.push_back(C.acc_size);
             if(C.rider >= 0)
             {
               const int nr = G.w[C.rider];
@@ -1132,7 +1140,7 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
         for(int k = first_task; k < first_task + ntask; k++)
         {
           AsmMTask& T = S.asm_mtask[k];
-          T.part = S.asm_part_size; S.asm_part_size += T.pad;
+          T.part = S.asm_part_size; S.asm_part_size += mtask_acc[k];
         }
         for(const Cls& C : classes)
         {
@@ -1173,7 +1181,6 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
           S.asm_fin2_list.insert(S.asm_fin2_list.end(), fin_lists[f].begin(), fin_lists[f].end());
         }
       }
-      for(int k = first_task; k < first_task + ntask; k++) S.asm_mtask[k].pad = 0;
       return true;
     };
     for(int pass = 0; pass < 2; pass++)          // pass 1: the riders (rows nobody carried + the carried partials)
@@ -1299,6 +1306,46 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
           for(int k = 0; k < ntask; k++) S.asm_ctask[first_task + k].part = S.asm_part_size + (int64_t)k*acc_size;
           S.asm_part_size += (int64_t)ntask*acc_size;
         }
+      }
+    }
+    // group the MFMA tasks by shape (their k-groups move with them) and cut the sequence into
+    // runs: a wave loads the shape's lane constants once and streams the k-groups of several
+    // small tasks back to back
+    {
+      const int nt = (int)S.asm_mtask.size();
+      std::vector<int> order(nt);
+      std::iota(order.begin(), order.end(), 0);
+      std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return S.asm_mtask[a].shape < S.asm_mtask[b].shape; });
+      std::vector<AsmMTask> tasks2; tasks2.reserve(nt);
+      std::vector<AsmKG> kg2; kg2.reserve(S.asm_kg.size());
+      for(int k : order)
+      {
+        AsmMTask T = S.asm_mtask[k];
+        const int k0 = (int)kg2.size();
+        kg2.insert(kg2.end(), S.asm_kg.begin() + T.kg0, S.asm_kg.begin() + T.kg1);
+        kg2.back().meta |= 1u << 12;             // last k-group of its task
+        T.kg0 = k0; T.kg1 = (int)kg2.size();
+        tasks2.push_back(T);
+      }
+      S.asm_mtask.swap(tasks2); S.asm_kg.swap(kg2);
+      // persistent destinations, 16 per task in task order (the kernel prefetches them by task index)
+      {
+        std::vector<int> pd2((size_t)nt*16, 0);
+        for(int k = 0; k < nt; k++)
+          for(int q = 0; q < 16 && S.asm_mtask[k].pq + q < (int)S.asm_pdest.size(); q++)
+            pd2[(size_t)k*16 + q] = S.asm_pdest[S.asm_mtask[k].pq + q];
+        S.asm_pdest.swap(pd2);
+      }
+      const int RUN_KG = env_int("DOGLEG_AMD_RUN_KG", 32);
+      for(int k = 0; k < nt; )
+      {
+        AsmRun R; R.task0 = k; R.kg0 = S.asm_mtask[k].kg0;
+        int nkg = 0;
+        do { nkg += S.asm_mtask[k].kg1 - S.asm_mtask[k].kg0; k++; }
+        while(k < nt && S.asm_mtask[k].shape == S.asm_mtask[R.task0].shape &&
+              nkg + (S.asm_mtask[k].kg1 - S.asm_mtask[k].kg0) <= RUN_KG);
+        R.task1 = k; R.kg1 = S.asm_mtask[k-1].kg1;
+        S.asm_run.push_back(R);
       }
     }
     // long lists are summed hierarchically: chunks of 64 partials -> intermediate partials.

@@ -107,9 +107,10 @@ struct AsmShape
   // the kernel stages columns [col0, col0 + ncopy) of every row in LDS; pcol/tcol/offJ/offR are
   // relative to col0
   uint16_t col0;
-  uint8_t ncopy, pad2;
+  uint8_t ncopy, dslot;         // dslot: persistent slot ordinal of the diagonal block (J,J)
+  uint8_t paccoff[16], pnI[16]; // persistent row m: offset of its block column 0 entry in a partial, rows of its block
 };
-static_assert(sizeof(AsmShape) == 144, "AsmShape layout");
+static_assert(sizeof(AsmShape) == 176, "AsmShape layout");
 struct AsmKG
 {
   int32_t  base[4];             // first value of each of the 4 rows, -1: no row
@@ -120,12 +121,15 @@ static_assert(sizeof(AsmKG) == 24, "AsmKG layout");
 struct AsmMTask
 {
   int32_t kg0, kg1, slot0, shape;
-  int32_t ld, pad;
+  int32_t ld;
+  int32_t pq;                   // first entry in asm_pdest: row offset in J's panel of every persistent block
   int64_t panel;                // Lx offset of (row 0, first column of J) of J's panel
   int64_t part;                 // offset into the partial buffer, or -1: write the panels directly
   int64_t rpart;                // partial of the rider's diagonal block (shape.nJr > 0)
 };
 static_assert(sizeof(AsmMTask) == 48, "AsmMTask layout");
+// a wave's work: consecutive tasks of one shape; their k-groups are contiguous
+struct AsmRun { int32_t task0, task1, kg0, kg1; };
 // a persistent block written by several tasks: sum of the listed partials, in list order
 // to_part: an intermediate sum of a long list, written densely to the partial buffer at dest
 struct AsmFin2 { int64_t dest; int32_t ld, list0, nlist; uint8_t nI, nJ, diag, to_part; };
@@ -198,6 +202,8 @@ struct SymHost
   std::vector<int64_t>  asm_fin2_list;
   int asm_lds_len = 0;                // LDS row stride (doubles) of the MFMA assembly kernel
   std::vector<int>      fin2_stage;   // per stage: first entry, #entries with <= 64 partials, #entries with more
+  std::vector<AsmRun>   asm_run;
+  std::vector<int>      asm_pdest;
   std::vector<int>      asm_tdest;   // row offset in J's panel of every (row-block, transient ordinal)
   int64_t asm_part_size = 0;
   // ---- forward-solve gather lists
