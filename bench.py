@@ -181,7 +181,7 @@ def main():
         # 12*nnz + 4*(M+1) + 8*nnz(tril JtJ) bytes per launch (local rows on a shard)
         nnz_loc = int(J_loc.shape[0])
         alg_bytes = 12 * nnz_loc + 4 * (row1 - row0 + 1) + 8 * sym["nnz_JtJ_lower"]
-        roof = {"kernel": "k_assemble (K4-sparse JtJ assembly)", "bound": "hbm",
+        roof = {"kernel": "k_assemble_mfma (K4-sparse JtJ assembly)", "bound": "hbm",
                 "achieved": alg_bytes / (k4_ms * 1e-3) / 1e9 if k4_ms > 0 else None,
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None,
                 "algorithmic_bytes": alg_bytes, "avg_launch_ms": k4_ms, "launches": cnt}

@@ -23,6 +23,7 @@ namespace {
 
 constexpr int TPB = 256;
 constexpr int LDS_BUDGET = 147456;      // bytes of dynamic LDS we allow a workgroup
+constexpr int FAC_LDS_BUDGET = 163840 - 256;   // the panel factorisation takes (almost) all 160 KB of a CU
 
 __device__ __forceinline__ double wave_sum(double v)
 {
@@ -1228,7 +1229,7 @@ int sparse_set_pattern(dlg_backend* b, const int* colptr, const int* rowidx)
     }
     Y->fac_nt[l] = (maxr <= 128) ? 128 : (maxr <= 256 ? 256 : 512);
     Y->upd_coop[l] = (maxw > 8) ? 1 : 0;           // heavy sources: cooperative update kernel
-    if(maxp*8 > LDS_BUDGET) { dlg_set_error("internal error: a factor slice does not fit LDS (%ld doubles)", maxp); return DLG_ERR_ARG; }
+    if(maxp*8 > FAC_LDS_BUDGET) { dlg_set_error("internal error: a factor slice does not fit LDS (%ld doubles)", maxp); return DLG_ERR_ARG; }
     Y->fac_lds[l] = (int)(maxp*8);
     Y->slv_lds[l] = (int)(maxw*(maxw | 1)*8);
     {
@@ -1244,7 +1245,6 @@ int sparse_set_pattern(dlg_backend* b, const int* colptr, const int* rowidx)
       Y->bwd_lds[l] = (int)(mb*8);
     }
     if(Y->slv_lds[l] > LDS_BUDGET) { dlg_set_error("supernode of width %ld is too wide for the solve kernels", maxw); return DLG_ERR_ARG; }
-    Y->fac_lds[l] = (maxp*8 <= LDS_BUDGET - 4096) ? (int)(maxp*8) : 0;
     long maxslab = 0;
     for(int it = H.ui_lvl_ptr[l]; it < H.ui_lvl_ptr[l+1]; it++)
     {
@@ -1258,11 +1258,11 @@ int sparse_set_pattern(dlg_backend* b, const int* colptr, const int* rowidx)
     Y->upd_lds[l] = (int)(maxslab*8*nw);
   }
   DLG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_factor_level<128>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BUDGET));
+                              hipFuncAttributeMaxDynamicSharedMemorySize, FAC_LDS_BUDGET));
   DLG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_factor_level<512>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BUDGET));
+                              hipFuncAttributeMaxDynamicSharedMemorySize, FAC_LDS_BUDGET));
   DLG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_factor_level<256>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BUDGET));
+                              hipFuncAttributeMaxDynamicSharedMemorySize, FAC_LDS_BUDGET));
   DLG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_update_level),
                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BUDGET));
   DLG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_solve_fwd_level),

@@ -23,6 +23,9 @@ int env_int(const char* name, int dflt)
   const char* s = getenv(name);
   return (s && *s) ? atoi(s) : dflt;
 }
+// doubles: a row slice (top block + its rows) of a larger panel; as much of the 160 KB LDS as a
+// single workgroup can get, so that fewer slices repeat the factorisation of the top block
+static int slice_cap() { static const int v = env_int("DOGLEG_AMD_SLICE_CAP", 20000); return v; }
 
 struct RowBlock { int r0, nrows, len, base, vptr, nvb; bool local; };
 
@@ -670,7 +673,7 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
         int nsl = 1;
         if((long)nrows*w > PANEL_CAP)
         {
-          int rpw = PANEL_CAP/w - w; if(rpw < 1) rpw = 1;
+          int rpw = slice_cap()/w - w - 1; if(rpw < 1) rpw = 1;
           nsl = (below + rpw - 1)/rpw;
         }
         if(nsl > 1) { S.sn_top[s] = S.top_size; S.top_size += (int64_t)w*w; S.ms_sn.push_back(s); }
