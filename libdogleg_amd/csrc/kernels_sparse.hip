@@ -69,7 +69,7 @@ struct SparseSym
   SymSub* usub = nullptr; int* relpos = nullptr;
   int *uw_item = nullptr, *uw_s0 = nullptr, *uw_s1 = nullptr, *uf_item = nullptr, *uf_n = nullptr;
   int64_t *uw_part = nullptr, *uf_off = nullptr;
-  double* upart = nullptr;
+  double* upart = nullptr; double* uscr = nullptr; int64_t *u_off = nullptr, *usub_u = nullptr;
   SymOutBlock* oblk = nullptr; SymContrib* contrib = nullptr;
   SymTask *jtx_task = nullptr;
   int *jtx_fin_ptr = nullptr, *jtx_fin_blk = nullptr;
@@ -90,7 +90,7 @@ struct SparseSym
   size_t nnz_loc = 0;
   // per-level launch parameters
   std::vector<int> fac_lds;     // bytes of LDS for the factor kernel of a level (0: panels stay in HBM)
-  std::vector<int> upd_lds, upd_nw, slv_lds, bwd_lds, fac_nt, upd_coop;
+  std::vector<int> upd_lds, upd_nw, slv_lds, bwd_lds, fac_nt, upd_coop, syrk_lds;
   std::vector<void*> allocs;
 };
 
@@ -860,6 +860,243 @@ __global__ void __launch_bounds__(TPB) k_update_coop(int unit0, const int* __res
   }
 }
 
+// ---- two-phase update of a level with many small sources -------------------------------
+// Phase 1: U_d = B_d B_d' for every source d of the level (B_d = the mb rows below its diagonal
+// block, wd columns), lower triangle, column-major with leading dimension mb, into the scratch.
+// One workgroup per source: B_d is staged in LDS once (k-major, zero padded to whole tiles),
+// the lower 16x16 tiles are produced by v_mfma_f64_16x16x4_f64 with both operands read from
+// LDS; a wave owns whole tile columns so the B operand is read once per k-step.
+__global__ void __launch_bounds__(TPB) k_update_syrk(const int* __restrict__ lvl_sn,
+                                                     const int* __restrict__ sn_c0,
+                                                     const int* __restrict__ sn_rowptr,
+                                                     const int64_t* __restrict__ sn_lx,
+                                                     const int64_t* __restrict__ u_off,
+                                                     const double* __restrict__ Lx,
+                                                     double* __restrict__ uscr)
+{
+  extern __shared__ __attribute__((aligned(16))) double Bs[];
+  const int d = lvl_sn[blockIdx.x];
+  const int wd = sn_c0[d+1] - sn_c0[d], nrows = sn_rowptr[d+1] - sn_rowptr[d], mb = nrows - wd;
+  const double* Ld = Lx + sn_lx[d] + wd;
+  double* U = uscr + u_off[d];
+  const int T = (mb + 15) >> 4, MB16 = T*16;
+  const int LDB = ((mb + 31)/32)*32 + 16, K4 = (wd + 3) & ~3;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  batched_copy<TPB, 8>(K4*MB16, tid,
+                       [&](int e) { const int k = e / MB16, i = e - k*MB16; return (k < wd && i < mb) ? Ld[i + (size_t)k*nrows] : 0.0; },
+                       [&](int e, double v) { const int k = e / MB16, i = e - k*MB16; Bs[k*LDB + i] = v; });
+  __syncthreads();
+  const int jn = lane & 15, kq = lane >> 4;
+  // tile columns dealt out in snake order (0 1 2 3 3 2 1 0 ...): long and short columns pair up
+  for(int round = 0; round*4 < T; round++)
+  {
+    const int tj = (round & 1) ? round*4 + 3 - w : round*4 + w;
+    if(tj >= T) continue;
+    for(int ti0 = tj; ti0 < T; ti0 += 4)
+    {
+      const int nt = min(4, T - ti0);
+      dlg_v4d c4[4];
+#pragma unroll
+      for(int q = 0; q < 4; q++) c4[q] = (dlg_v4d){0.0, 0.0, 0.0, 0.0};
+      const double* bp = Bs + kq*LDB + 16*tj + jn;
+      const double* ap = Bs + kq*LDB + 16*ti0 + jn;
+#pragma unroll 2
+      for(int kk = 0; kk < K4; kk += 4)
+      {
+        const double b = bp[kk*LDB];
+#pragma unroll
+        for(int q = 0; q < 4; q++)
+          if(q < nt) c4[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[kk*LDB + 16*q], b, c4[q], 0, 0, 0);
+      }
+      const int j = 16*tj + jn;
+#pragma unroll
+      for(int q = 0; q < 4; q++)
+        if(q < nt)
+        {
+#pragma unroll
+          for(int r = 0; r < 4; r++)
+          {
+            const int i = 16*(ti0 + q) + kq + 4*r;
+            if(i < mb && j <= i) U[i + (size_t)j*mb] = c4[q][r];
+          }
+        }
+    }
+  }
+}
+// Phase 2: a work unit (chunk of the sub-tasks of one target column block) adds the column
+// blocks of the U_d it is fed from into wave-private LDS slabs (waves take sub-tasks round
+// robin), sums the slabs in wave order and applies / stores the result like the other update
+// kernels.
+__global__ void __launch_bounds__(TPB) k_update_gather(int unit0, const int* __restrict__ uw_item,
+                                                       const int* __restrict__ uw_s0,
+                                                       const int* __restrict__ uw_s1,
+                                                       const int64_t* __restrict__ uw_part,
+                                                       const int* __restrict__ ui_t,
+                                                       const int* __restrict__ ui_col,
+                                                       const int* __restrict__ ui_nc,
+                                                       const SymSub* __restrict__ usub,
+                                                       const int64_t* __restrict__ usub_u,
+                                                       const int* __restrict__ relpos,
+                                                       const int* __restrict__ sn_rowptr,
+                                                       const int64_t* __restrict__ sn_lx,
+                                                       double* __restrict__ Lx,
+                                                       double* __restrict__ upart,
+                                                       const double* __restrict__ uscr, int nw)
+{
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int unit = unit0 + blockIdx.x;
+  const int item = uw_item[unit];
+  const int t = ui_t[item], col = ui_col[item], nc = ui_nc[item];
+  const int nrows_t = sn_rowptr[t+1] - sn_rowptr[t];
+  double* Lt = Lx + sn_lx[t] + (int64_t)col*nrows_t;
+  const int s0 = uw_s0[unit], s1 = uw_s1[unit];
+  const int64_t part = uw_part[unit];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int slab = nrows_t*nc;
+  for(int e = tid; e < slab*nw; e += TPB) lds[e] = 0.0;
+  __syncthreads();
+  if(w < nw)
+  {
+    double* acc = lds + (size_t)w*slab;
+    for(int st = s0 + w; st < s1; st += nw)
+    {
+      const SymSub S = usub[st];
+      const double* U = uscr + usub_u[st];
+      const int* rel = relpos + S.rel;
+      const int mb = S.nrows_d - S.wd;
+      for(int i = lane; i < S.m; i += 64)
+      {
+        const int cmax = (i < nc - 1) ? i : nc - 1;
+        const int r = rel[i];
+        double v[8];
+#pragma unroll
+        for(int c = 0; c < 8; c++) v[c] = (c <= cmax) ? U[i + (size_t)c*mb] : 0.0;
+#pragma unroll
+        for(int c = 0; c < 8; c++) if(c <= cmax) acc[r + c*nrows_t] += v[c];
+      }
+    }
+  }
+  __syncthreads();
+  for(int e = tid; e < slab; e += TPB)
+  {
+    double tot = 0.0;
+    for(int k = 0; k < nw; k++) tot += lds[(size_t)k*slab + e];
+    if(part < 0) Lt[e] -= tot; else upart[part + e] = tot;
+  }
+}
+
+// fp64-MFMA variant of the update for heavy sources.  The unit's work is cut into pieces
+// (sub-task, 16*UPD_TILES source rows); wave w of the nw active waves takes pieces w, w+nw, ... and
+// accumulates into its private LDS slab (nrows_t x nc), so no barrier orders the pieces; the
+// slabs are summed in wave order at the end.  One piece:
+//   C[i][j] = sum_k Ld[i][k] * Ld[j][k],   i = the piece's source rows (MFMA row tiles of 16), j < nc <= 8
+// with v_mfma_f64_16x16x4_f64: A[m][k] = Ld[row tile][4 columns], B[k][n] = Ld[n][4 columns]
+// (n >= nc: zero); both operands are read straight from the source panel (column-major:
+// 16 consecutive rows per column are one 128-byte segment).
+constexpr int UPD_TILES = 6;          // MFMA row tiles (16 source rows each) per piece
+__global__ void __launch_bounds__(TPB) k_update_mfma(int unit0, const int* __restrict__ uw_item,
+                                                     const int* __restrict__ uw_s0,
+                                                     const int* __restrict__ uw_s1,
+                                                     const int64_t* __restrict__ uw_part,
+                                                     const int* __restrict__ ui_t,
+                                                     const int* __restrict__ ui_col,
+                                                     const int* __restrict__ ui_nc,
+                                                     const SymSub* __restrict__ usub,
+                                                     const int* __restrict__ relpos,
+                                                     const int* __restrict__ sn_rowptr,
+                                                     const int64_t* __restrict__ sn_lx,
+                                                     double* __restrict__ Lx,
+                                                     double* __restrict__ upart, int nw)
+{
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int unit = unit0 + blockIdx.x;
+  const int item = uw_item[unit];
+  const int t = ui_t[item], col = ui_col[item], nc = ui_nc[item];
+  const int nrows_t = sn_rowptr[t+1] - sn_rowptr[t];
+  double* Lt = Lx + sn_lx[t] + (int64_t)col*nrows_t;
+  const int s0 = uw_s0[unit], s1 = uw_s1[unit];
+  const int64_t part = uw_part[unit];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int slab = nrows_t*nc;
+  for(int e = tid; e < slab*nw; e += TPB) lds[e] = 0.0;
+  __syncthreads();
+  if(w < nw)
+  {
+    double* acc = lds + (size_t)w*slab;
+    const int jn = lane & 15, kq = lane >> 4;
+    const int jc = min(jn, nc - 1);
+    int piece = 0;
+    for(int st = s0; st < s1; st++)
+    {
+      const SymSub U = usub[st];
+      const double* Ld = Lx + U.src;
+      const int* rel = relpos + U.rel;
+      const int ld = U.nrows_d, wd = U.wd, m = U.m;
+      for(int mt0 = 0; mt0 < m; mt0 += 16*UPD_TILES, piece++)
+      {
+        if(piece % nw != w) continue;
+        const int ntile = min(UPD_TILES, (m - mt0 + 15) >> 4);
+        const int relv0 = rel[min(mt0 + lane, m - 1)], relv1 = rel[min(mt0 + 64 + lane, m - 1)];
+        dlg_v4d c4[UPD_TILES];
+#pragma unroll
+        for(int q = 0; q < UPD_TILES; q++) c4[q] = (dlg_v4d){0.0, 0.0, 0.0, 0.0};
+        int ia[UPD_TILES];
+        bool va[UPD_TILES];
+#pragma unroll
+        for(int q = 0; q < UPD_TILES; q++) { const int i = mt0 + 16*q + jn; va[q] = i < m; ia[q] = min(i, m - 1); }
+        // 16 source columns (4 MFMA k-steps) per round: all loads of a round are issued before
+        // its first product; rows / columns past the end are clamped and zeroed
+        for(int kk = 0; kk < wd; kk += 16)
+        {
+          double a[4][UPD_TILES], b[4];
+#pragma unroll
+          for(int h = 0; h < 4; h++)
+          {
+            const int k = kk + 4*h + kq;
+            const size_t co = (size_t)min(k, wd - 1)*ld;
+            b[h] = Ld[jc + co];
+#pragma unroll
+            for(int q = 0; q < UPD_TILES; q++) a[h][q] = Ld[ia[q] + co];
+          }
+#pragma unroll
+          for(int h = 0; h < 4; h++)
+          {
+            const bool kok = kk + 4*h + kq < wd;
+            const double bv = (kok && jn < nc) ? b[h] : 0.0;
+#pragma unroll
+            for(int q = 0; q < UPD_TILES; q++)
+              if(q < ntile) c4[q] = __builtin_amdgcn_mfma_f64_16x16x4f64((kok && va[q]) ? a[h][q] : 0.0, bv, c4[q], 0, 0, 0);
+          }
+        }
+        // D[i'][j]: this lane holds rows i' = kq + 4r of every tile, column j = jn
+#pragma unroll
+        for(int q = 0; q < UPD_TILES; q++)
+          if(q < ntile)
+          {
+#pragma unroll
+            for(int r = 0; r < 4; r++)
+            {
+              const int il = 16*q + kq + 4*r, i = mt0 + il;
+              const int rr = il < 64 ? __builtin_amdgcn_ds_bpermute(4*il, relv0) : __builtin_amdgcn_ds_bpermute(4*(il - 64), relv1);
+              const int cmax = (i < nc - 1) ? i : nc - 1;
+              if(i < m && jn <= cmax) acc[rr + jn*nrows_t] += c4[q][r];
+            }
+          }
+      }
+    }
+  }
+  __syncthreads();
+  for(int e = tid; e < slab; e += TPB)
+  {
+    double tot = 0.0;
+    for(int k = 0; k < nw; k++) tot += lds[(size_t)k*slab + e];
+    if(part < 0) Lt[e] -= tot; else upart[part + e] = tot;
+  }
+}
+
 // apply the updates of all source supernodes of one level to their ancestors.
 // One workgroup per work unit = a chunk of the sub-tasks of one item
 // (target supernode t, one var-block of its columns).  nw waves each own a
@@ -1168,7 +1405,7 @@ int sparse_set_pattern(dlg_backend* b, const int* colptr, const int* rowidx)
   { dlg_set_error("symbolic analysis: %s", err); return DLG_ERR_ARG; }
   SymHost& H = Y->H;
   UP(sn_c0); UP(sn_rowptr); UP(sn_rows); UP(sn_scr); UP(lvl_sn); UP(sn_lx); UP(diagpos);
-  UP(ui_t); UP(ui_col); UP(ui_nc); UP(ui_ptr); UP(usub); UP(relpos);
+  UP(ui_t); UP(ui_col); UP(ui_nc); UP(ui_ptr); UP(usub); UP(relpos); UP(u_off); UP(usub_u);
   UP(uw_item); UP(uw_s0); UP(uw_s1); UP(uw_part); UP(uf_item); UP(uf_n); UP(uf_off);
   UP(oblk); UP(contrib); UP(jtx_task); UP(jtx_fin_ptr); UP(jtx_fin_blk);
   UP(asm_rho); UP(asm_pair); UP(asm_slot); UP(asm_batch); UP(asm_ctask); UP(asm_cfin);
@@ -1200,6 +1437,7 @@ int sparse_set_pattern(dlg_backend* b, const int* colptr, const int* rowidx)
   DLG_CHECK(dalloc(Y->scr, (size_t)H.scr_size));
   DLG_CHECK(dalloc(Y->ywork, (size_t)H.N));
   DLG_CHECK(dalloc(Y->upart, (size_t)H.upart_size));
+  DLG_CHECK(dalloc(Y->uscr, (size_t)H.uscr_size));
   DLG_CHECK(dalloc(Y->top_scr, (size_t)H.top_size));
   DLG_CHECK(dalloc(Y->asm_part, (size_t)H.asm_part_size));
   DLG_CHECK(dalloc(Y->jtx_part, (size_t)H.jtx_nparts*8));
@@ -1207,7 +1445,7 @@ int sparse_set_pattern(dlg_backend* b, const int* colptr, const int* rowidx)
   DLG_HIP(hipHostMalloc(&Y->h_info, sizeof(int)));
 
   // per-level launch parameters
-  Y->fac_lds.assign(H.nlevels, 0); Y->upd_lds.assign(H.nlevels, 0); Y->upd_nw.assign(H.nlevels, 0);
+  Y->fac_lds.assign(H.nlevels, 0); Y->upd_lds.assign(H.nlevels, 0); Y->upd_nw.assign(H.nlevels, 0); Y->syrk_lds.assign(H.nlevels, 0);
   Y->slv_lds.assign(H.nlevels, 0); Y->bwd_lds.assign(H.nlevels, 0); Y->fac_nt.assign(H.nlevels, 512); Y->upd_coop.assign(H.nlevels, 0);
   for(int l = 0; l < H.nlevels; l++)
   {
@@ -1255,6 +1493,17 @@ int sparse_set_pattern(dlg_backend* b, const int* colptr, const int* rowidx)
     int nw = 0;
     if(maxslab > 0) { nw = (int)(LDS_BUDGET/(maxslab*8)); if(nw > 4) nw = 4; }
     Y->upd_nw[l] = nw;
+    {
+      long mx = 0;
+      if(H.upd_syrk[l])
+        for(int i = H.lvl_ptr[l]; i < H.lvl_ptr[l+1]; i++)
+        {
+          const int d = H.lvl_sn[i];
+          const long wd = H.sn_c0[d+1] - H.sn_c0[d], mb = H.sn_rowptr[d+1] - H.sn_rowptr[d] - wd;
+          mx = std::max(mx, ((wd + 3)/4*4)*(((mb + 31)/32)*32 + 16)*8);
+        }
+      Y->syrk_lds[l] = (int)mx;
+    }
     Y->upd_lds[l] = (int)(maxslab*8*nw);
   }
   DLG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_factor_level<128>),
@@ -1264,6 +1513,12 @@ int sparse_set_pattern(dlg_backend* b, const int* colptr, const int* rowidx)
   DLG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_factor_level<256>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, FAC_LDS_BUDGET));
   DLG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_update_level),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BUDGET));
+  DLG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_update_syrk),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BUDGET));
+  DLG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_update_gather),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BUDGET));
+  DLG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_update_mfma),
                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BUDGET));
   DLG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_solve_fwd_level),
                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BUDGET));
@@ -1401,7 +1656,21 @@ int sparse_factorize(dlg_backend* b, int s, double lambda, int* ok)
                            Y->sn_top, Y->sn_bd_ptr, Y->sn_bd_col, Y->Lx, Y->top_scr, Y->d_info);
     }
     const int nu = H.uw_lvl_ptr[l+1] - H.uw_lvl_ptr[l];
-    if(nu > 0 && Y->upd_coop[l])
+    if(nu > 0 && H.upd_syrk[l] && Y->upd_nw[l] > 0)
+    {
+      const int ns = H.lvl_ptr[l+1] - H.lvl_ptr[l];
+      hipLaunchKernelGGL(k_update_syrk, dim3(ns), dim3(TPB), Y->syrk_lds[l], st, Y->lvl_sn + H.lvl_ptr[l],
+                         Y->sn_c0, Y->sn_rowptr, Y->sn_lx, Y->u_off, Y->Lx, Y->uscr);
+      hipLaunchKernelGGL(k_update_gather, dim3(nu), dim3(TPB), Y->upd_lds[l], st, H.uw_lvl_ptr[l],
+                         Y->uw_item, Y->uw_s0, Y->uw_s1, Y->uw_part, Y->ui_t, Y->ui_col, Y->ui_nc,
+                         Y->usub, Y->usub_u, Y->relpos, Y->sn_rowptr, Y->sn_lx, Y->Lx, Y->upart, Y->uscr,
+                         Y->upd_nw[l]);
+    }
+    else if(nu > 0 && Y->upd_coop[l] && Y->upd_nw[l] > 0 && !getenv("DOGLEG_AMD_NO_UPDATE_MFMA"))
+      hipLaunchKernelGGL(k_update_mfma, dim3(nu), dim3(TPB), Y->upd_lds[l], st, H.uw_lvl_ptr[l],
+                         Y->uw_item, Y->uw_s0, Y->uw_s1, Y->uw_part, Y->ui_t, Y->ui_col, Y->ui_nc,
+                         Y->usub, Y->relpos, Y->sn_rowptr, Y->sn_lx, Y->Lx, Y->upart, Y->upd_nw[l]);
+    else if(nu > 0 && Y->upd_coop[l])
       hipLaunchKernelGGL(k_update_coop, dim3(nu), dim3(TPB), 0, st, H.uw_lvl_ptr[l],
                          Y->uw_item, Y->uw_s0, Y->uw_s1, Y->uw_part, Y->ui_t, Y->ui_col, Y->ui_nc,
                          Y->usub, Y->relpos, Y->sn_rowptr, Y->sn_lx, Y->Lx, Y->upart);

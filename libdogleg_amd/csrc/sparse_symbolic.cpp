@@ -751,6 +751,36 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
         }
       }
     }
+    // levels with many small sources use the two-phase update
+    {
+      S.upd_syrk.assign(S.nlevels, 0); S.u_off.assign(nsn, -1); S.uscr_size = 0;
+      const int syrk_min = env_int("DOGLEG_AMD_SYRK_MIN", 256);
+      for(int l = 0; l < S.nlevels; l++)
+      {
+        const int n = S.lvl_ptr[l+1] - S.lvl_ptr[l];
+        if(syrk_min <= 0 || n < syrk_min) continue;
+        bool ok = true;
+        int64_t tot = 0;
+        for(int i = S.lvl_ptr[l]; i < S.lvl_ptr[l+1] && ok; i++)
+        {
+          const int d = S.lvl_sn[i];
+          const int64_t wd = S.sn_c0[d+1] - S.sn_c0[d], mb = S.sn_rowptr[d+1] - S.sn_rowptr[d] - wd;
+          const int64_t ldb = ((mb + 31)/32)*32 + 16, k4 = (wd + 3)/4*4;
+          if(mb > 128 || wd <= 8 || k4*ldb*8 > 65536) ok = false;
+          tot += mb*mb;
+        }
+        if(!ok) continue;
+        S.upd_syrk[l] = 1;
+        int64_t off = 0;
+        for(int i = S.lvl_ptr[l]; i < S.lvl_ptr[l+1]; i++)
+        {
+          const int d = S.lvl_sn[i];
+          const int64_t mb = S.sn_rowptr[d+1] - S.sn_rowptr[d] - (S.sn_c0[d+1] - S.sn_c0[d]);
+          S.u_off[d] = off; off += mb*mb;
+        }
+        S.uscr_size = std::max(S.uscr_size, off);
+      }
+    }
     std::sort(subs.begin(), subs.end(), [](const Sub& a, const Sub& b) {
       if(a.lvl != b.lvl) return a.lvl < b.lvl;
       if(a.t != b.t) return a.t < b.t;
@@ -777,6 +807,12 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
       ss.src = S.sn_lx[u.d] + u.ka; ss.rel = u.rel; ss.nrows_d = nrows_d;
       ss.wd = S.sn_c0[u.d+1] - S.sn_c0[u.d]; ss.m = nrows_d - u.ka;
       S.usub.push_back(ss);
+      if(S.upd_syrk[u.lvl])
+      {
+        const int64_t mb = nrows_d - ss.wd, k0 = u.ka - ss.wd;
+        S.usub_u.push_back(S.u_off[u.d] + k0 + k0*mb);
+      }
+      else S.usub_u.push_back(-1);
     }
     if(!subs.empty()) S.ui_ptr.push_back((int)subs.size());
     for(int l = 0; l < S.nlevels; l++) S.ui_lvl_ptr[l+1] += S.ui_lvl_ptr[l];
@@ -787,6 +823,7 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
     // chunking by estimated cost: a light sub-task (narrow source) counts 1, a
     // heavy one counts by its thread-iterations; a unit is closed at UNIT_COST
     const int unit_cost = env_int("DOGLEG_AMD_UNIT_COST", 512);
+    const int unit_cost_gather = std::max(1, unit_cost/std::max(1, env_int("DOGLEG_AMD_GATHER_PER_UNIT", 32)));
     std::vector<int> cuts;
     for(int it = 0; it < nitems; it++)
     {
@@ -799,7 +836,7 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
       for(int st = s0; st < s1; st++)
       {
         const SymSub& u = S.usub[st];
-        const long c = (u.wd <= 8) ? 1 : 64 + (long)u.wd*((u.m + 255)/256);
+        const long c = S.upd_syrk[lvl] ? unit_cost_gather : ((u.wd <= 8) ? 1 : 64 + (long)u.wd*((u.m + 255)/256));
         if(acc > 0 && acc + c > unit_cost) { cuts.push_back(st); acc = 0; }
         acc += c;
       }

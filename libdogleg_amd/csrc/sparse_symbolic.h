@@ -183,6 +183,13 @@ struct SymHost
   std::vector<int> uf_item, uf_n;    // item, number of partial slabs
   std::vector<int64_t> uf_off;       // offset of the first partial slab
   int64_t upart_size = 0;
+  // two-phase update of a level (many small sources, e.g. the point leaves of a bundle
+  // adjustment): phase 1 forms U_d = B_d B_d' (B_d: rows below the diagonal block) of every
+  // source once, phase 2 gathers the column blocks of the U_d into the targets
+  std::vector<char>    upd_syrk;     // [nlevels] the level uses the two-phase update
+  std::vector<int64_t> u_off;        // [nsn] offset of U_d in the scratch (two-phase levels only)
+  std::vector<int64_t> usub_u;       // [#sub-tasks] offset of the sub-task's first element in the scratch
+  int64_t uscr_size = 0;
   // ---- assembly / Jt*x
   std::vector<SymOutBlock> oblk;     // diagonal block of every var-block (Jt*x and lambda use them)
   std::vector<SymContrib>  contrib;
