@@ -90,7 +90,7 @@ struct SparseSym
   size_t nnz_loc = 0;
   // per-level launch parameters
   std::vector<int> fac_lds;     // bytes of LDS for the factor kernel of a level (0: panels stay in HBM)
-  std::vector<int> upd_lds, upd_nw, slv_lds, bwd_lds, fac_nt, upd_coop, syrk_lds;
+  std::vector<int> upd_lds, upd_nw, slv_lds, bwd_lds, fac_nt, upd_coop, syrk_lds, syrk_nt, syrk_kc;
   std::vector<void*> allocs;
 };
 
@@ -866,15 +866,17 @@ __global__ void __launch_bounds__(TPB) k_update_coop(int unit0, const int* __res
 // One workgroup per source: B_d is staged in LDS once (k-major, zero padded to whole tiles),
 // the lower 16x16 tiles are produced by v_mfma_f64_16x16x4_f64 with both operands read from
 // LDS; a wave owns whole tile columns so the B operand is read once per k-step.
-__global__ void __launch_bounds__(TPB) k_update_syrk(const int* __restrict__ lvl_sn,
-                                                     const int* __restrict__ sn_c0,
-                                                     const int* __restrict__ sn_rowptr,
-                                                     const int64_t* __restrict__ sn_lx,
-                                                     const int64_t* __restrict__ u_off,
-                                                     const double* __restrict__ Lx,
-                                                     double* __restrict__ uscr)
+template <int NT>
+__global__ void __launch_bounds__(NT) k_update_syrk(const int* __restrict__ lvl_sn,
+                                                    const int* __restrict__ sn_c0,
+                                                    const int* __restrict__ sn_rowptr,
+                                                    const int64_t* __restrict__ sn_lx,
+                                                    const int64_t* __restrict__ u_off,
+                                                    const double* __restrict__ Lx,
+                                                    double* __restrict__ uscr, int KC)
 {
   extern __shared__ __attribute__((aligned(16))) double Bs[];
+  constexpr int NW = NT/64, TPW = 8;            // waves, tiles per wave (kept in registers)
   const int d = lvl_sn[blockIdx.x];
   const int wd = sn_c0[d+1] - sn_c0[d], nrows = sn_rowptr[d+1] - sn_rowptr[d], mb = nrows - wd;
   const double* Ld = Lx + sn_lx[d] + wd;
@@ -883,46 +885,52 @@ __global__ void __launch_bounds__(TPB) k_update_syrk(const int* __restrict__ lvl
   const int LDB = ((mb + 31)/32)*32 + 16, K4 = (wd + 3) & ~3;
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  batched_copy<TPB, 8>(K4*MB16, tid,
-                       [&](int e) { const int k = e / MB16, i = e - k*MB16; return (k < wd && i < mb) ? Ld[i + (size_t)k*nrows] : 0.0; },
-                       [&](int e, double v) { const int k = e / MB16, i = e - k*MB16; Bs[k*LDB + i] = v; });
-  __syncthreads();
   const int jn = lane & 15, kq = lane >> 4;
-  // tile columns dealt out in snake order (0 1 2 3 3 2 1 0 ...): long and short columns pair up
-  for(int round = 0; round*4 < T; round++)
+  // this wave's tiles: flat index over the lower tiles (column by column), round robin
+  const int ntiles = T*(T + 1)/2;
+  int aoff[TPW], boff[TPW];
+#pragma unroll
+  for(int q = 0; q < TPW; q++)
   {
-    const int tj = (round & 1) ? round*4 + 3 - w : round*4 + w;
-    if(tj >= T) continue;
-    for(int ti0 = tj; ti0 < T; ti0 += 4)
-    {
-      const int nt = min(4, T - ti0);
-      dlg_v4d c4[4];
+    int rem = w + q*NW, tj = 0;
+    if(rem < ntiles) { while(rem >= T - tj) { rem -= T - tj; tj++; } }
+    else { rem = 0; tj = 0; }
+    aoff[q] = 16*(tj + rem); boff[q] = 16*tj;
+  }
+  const int nmine = (ntiles - w + NW - 1)/NW;           // tiles of this wave (<= TPW by construction)
+  dlg_v4d c4[TPW];
 #pragma unroll
-      for(int q = 0; q < 4; q++) c4[q] = (dlg_v4d){0.0, 0.0, 0.0, 0.0};
-      const double* bp = Bs + kq*LDB + 16*tj + jn;
-      const double* ap = Bs + kq*LDB + 16*ti0 + jn;
+  for(int q = 0; q < TPW; q++) c4[q] = (dlg_v4d){0.0, 0.0, 0.0, 0.0};
+  for(int k0 = 0; k0 < K4; k0 += KC)
+  {
+    const int kc = min(KC, K4 - k0);
+    if(k0 > 0) __syncthreads();
+    batched_copy<NT, 8>(kc*MB16, tid,
+                        [&](int e) { const int k = k0 + e / MB16, i = e % MB16; return (k < wd && i < mb) ? Ld[i + (size_t)k*nrows] : 0.0; },
+                        [&](int e, double v) { const int k = e / MB16, i = e - k*MB16; Bs[k*LDB + i] = v; });
+    __syncthreads();
+    const double* base = Bs + kq*LDB + jn;
 #pragma unroll 2
-      for(int kk = 0; kk < K4; kk += 4)
-      {
-        const double b = bp[kk*LDB];
+    for(int kk = 0; kk < kc; kk += 4)
+    {
 #pragma unroll
-        for(int q = 0; q < 4; q++)
-          if(q < nt) c4[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[kk*LDB + 16*q], b, c4[q], 0, 0, 0);
-      }
-      const int j = 16*tj + jn;
-#pragma unroll
-      for(int q = 0; q < 4; q++)
-        if(q < nt)
-        {
-#pragma unroll
-          for(int r = 0; r < 4; r++)
-          {
-            const int i = 16*(ti0 + q) + kq + 4*r;
-            if(i < mb && j <= i) U[i + (size_t)j*mb] = c4[q][r];
-          }
-        }
+      for(int q = 0; q < TPW; q++)
+        if(q < nmine)
+          c4[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(base[kk*LDB + aoff[q]], base[kk*LDB + boff[q]], c4[q], 0, 0, 0);
     }
   }
+#pragma unroll
+  for(int q = 0; q < TPW; q++)
+    if(q < nmine)
+    {
+      const int j = boff[q] + jn;
+#pragma unroll
+      for(int r = 0; r < 4; r++)
+      {
+        const int i = aoff[q] + kq + 4*r;
+        if(i < mb && j <= i) U[i + (size_t)j*mb] = c4[q][r];
+      }
+    }
 }
 // Phase 2: a work unit (chunk of the sub-tasks of one target column block) adds the column
 // blocks of the U_d it is fed from into wave-private LDS slabs (waves take sub-tasks round
@@ -1445,7 +1453,7 @@ int sparse_set_pattern(dlg_backend* b, const int* colptr, const int* rowidx)
   DLG_HIP(hipHostMalloc(&Y->h_info, sizeof(int)));
 
   // per-level launch parameters
-  Y->fac_lds.assign(H.nlevels, 0); Y->upd_lds.assign(H.nlevels, 0); Y->upd_nw.assign(H.nlevels, 0); Y->syrk_lds.assign(H.nlevels, 0);
+  Y->fac_lds.assign(H.nlevels, 0); Y->upd_lds.assign(H.nlevels, 0); Y->upd_nw.assign(H.nlevels, 0); Y->syrk_lds.assign(H.nlevels, 0); Y->syrk_nt.assign(H.nlevels, 256); Y->syrk_kc.assign(H.nlevels, 4);
   Y->slv_lds.assign(H.nlevels, 0); Y->bwd_lds.assign(H.nlevels, 0); Y->fac_nt.assign(H.nlevels, 512); Y->upd_coop.assign(H.nlevels, 0);
   for(int l = 0; l < H.nlevels; l++)
   {
@@ -1493,18 +1501,23 @@ int sparse_set_pattern(dlg_backend* b, const int* colptr, const int* rowidx)
     int nw = 0;
     if(maxslab > 0) { nw = (int)(LDS_BUDGET/(maxslab*8)); if(nw > 4) nw = 4; }
     Y->upd_nw[l] = nw;
-    {
-      long mx = 0;
-      if(H.upd_syrk[l])
-        for(int i = H.lvl_ptr[l]; i < H.lvl_ptr[l+1]; i++)
-        {
-          const int d = H.lvl_sn[i];
-          const long wd = H.sn_c0[d+1] - H.sn_c0[d], mb = H.sn_rowptr[d+1] - H.sn_rowptr[d] - wd;
-          mx = std::max(mx, ((wd + 3)/4*4)*(((mb + 31)/32)*32 + 16)*8);
-        }
-      Y->syrk_lds[l] = (int)mx;
-    }
     Y->upd_lds[l] = (int)(maxslab*8*nw);
+    if(H.upd_syrk[l])
+    {
+      long ldbmax = 0, k4max = 0, tmax = 0;
+      for(int i = H.lvl_ptr[l]; i < H.lvl_ptr[l+1]; i++)
+      {
+        const int d = H.lvl_sn[i];
+        const long wd = H.sn_c0[d+1] - H.sn_c0[d], mb = H.sn_rowptr[d+1] - H.sn_rowptr[d] - wd;
+        ldbmax = std::max(ldbmax, ((mb + 31)/32)*32 + 16); k4max = std::max(k4max, (wd + 3)/4*4);
+        tmax = std::max(tmax, (mb + 15)/16);
+      }
+      long kc = (65536/(ldbmax*8)) & ~3L;            // source columns staged per round (<= 64 KB of LDS)
+      if(kc > k4max) kc = k4max;
+      Y->syrk_kc[l] = (int)kc;
+      Y->syrk_lds[l] = (int)(kc*ldbmax*8);
+      Y->syrk_nt[l] = (tmax*(tmax + 1)/2 <= 32) ? 256 : 1024;
+    }
   }
   DLG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_factor_level<128>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, FAC_LDS_BUDGET));
@@ -1514,7 +1527,9 @@ int sparse_set_pattern(dlg_backend* b, const int* colptr, const int* rowidx)
                               hipFuncAttributeMaxDynamicSharedMemorySize, FAC_LDS_BUDGET));
   DLG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_update_level),
                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BUDGET));
-  DLG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_update_syrk),
+  DLG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_update_syrk<256>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BUDGET));
+  DLG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_update_syrk<1024>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BUDGET));
   DLG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_update_gather),
                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BUDGET));
@@ -1659,8 +1674,14 @@ int sparse_factorize(dlg_backend* b, int s, double lambda, int* ok)
     if(nu > 0 && H.upd_syrk[l] && Y->upd_nw[l] > 0)
     {
       const int ns = H.lvl_ptr[l+1] - H.lvl_ptr[l];
-      hipLaunchKernelGGL(k_update_syrk, dim3(ns), dim3(TPB), Y->syrk_lds[l], st, Y->lvl_sn + H.lvl_ptr[l],
-                         Y->sn_c0, Y->sn_rowptr, Y->sn_lx, Y->u_off, Y->Lx, Y->uscr);
+      if(Y->syrk_nt[l] == 256)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_update_syrk<256>), dim3(ns), dim3(256), Y->syrk_lds[l], st,
+                           Y->lvl_sn + H.lvl_ptr[l], Y->sn_c0, Y->sn_rowptr, Y->sn_lx, Y->u_off, Y->Lx, Y->uscr,
+                           Y->syrk_kc[l]);
+      else
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_update_syrk<1024>), dim3(ns), dim3(1024), Y->syrk_lds[l], st,
+                           Y->lvl_sn + H.lvl_ptr[l], Y->sn_c0, Y->sn_rowptr, Y->sn_lx, Y->u_off, Y->Lx, Y->uscr,
+                           Y->syrk_kc[l]);
       hipLaunchKernelGGL(k_update_gather, dim3(nu), dim3(TPB), Y->upd_lds[l], st, H.uw_lvl_ptr[l],
                          Y->uw_item, Y->uw_s0, Y->uw_s1, Y->uw_part, Y->ui_t, Y->ui_col, Y->ui_nc,
                          Y->usub, Y->usub_u, Y->relpos, Y->sn_rowptr, Y->sn_lx, Y->Lx, Y->upart, Y->uscr,

@@ -754,7 +754,7 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
     // levels with many small sources use the two-phase update
     {
       S.upd_syrk.assign(S.nlevels, 0); S.u_off.assign(nsn, -1); S.uscr_size = 0;
-      const int syrk_min = env_int("DOGLEG_AMD_SYRK_MIN", 256);
+      const int syrk_min = env_int("DOGLEG_AMD_SYRK_MIN", 100);
       for(int l = 0; l < S.nlevels; l++)
       {
         const int n = S.lvl_ptr[l+1] - S.lvl_ptr[l];
@@ -765,8 +765,7 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
         {
           const int d = S.lvl_sn[i];
           const int64_t wd = S.sn_c0[d+1] - S.sn_c0[d], mb = S.sn_rowptr[d+1] - S.sn_rowptr[d] - wd;
-          const int64_t ldb = ((mb + 31)/32)*32 + 16, k4 = (wd + 3)/4*4;
-          if(mb > 128 || wd <= 8 || k4*ldb*8 > 65536) ok = false;
+          if(mb > 240 || wd <= 8) ok = false;        // <= 15 x 15 tiles of 16 rows: 8 tiles per wave, 16 waves
           tot += mb*mb;
         }
         if(!ok) continue;
