@@ -764,7 +764,7 @@ __global__ void __launch_bounds__(NT) k_factor_level(const int* __restrict__ fw_
   __syncthreads();
   const int nmem = sn_bd_ptr[s+1] - sn_bd_ptr[s];
   if(nmem > 0) panel_factor_blockdiag<NT>(P, ldp, nloc, w, tid, sn_bd_col + sn_bd_ptr[s], nmem, &sbad, sn_c0[s]);
-  else         panel_factor<NT, true>(P, ldp, nloc, w, tid, &sbad, sn_c0[s]);
+  else         panel_factor<NT, true, true>(P, ldp, nloc, w, tid, &sbad, sn_c0[s]);
   const int64_t top = sn_top[s];
   if(r0 == 0 && tid == 0 && sbad != 0x7fffffff) atomicMin(info, sbad);
   for(int e = tid; e < nloc*w; e += NT)

@@ -17,6 +17,13 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+// phase time stamps for tools/micro/bench_panel.hip (compiled out everywhere else)
+#ifndef DLG_PF_STAMP
+#define DLG_PF_DECL
+#define DLG_PF_STAMP(i)
+#define DLG_PF_DONE
+#endif
+
 // 1/sqrt(d) for d > 0: hardware v_rsq_f64 seed (about 1e-8 relative) + two Newton
 // steps (relative error ~1e-16).  The pivot sqrt(d) = d * rsqrt(d) and its reciprocal
 // come out of one short dependency chain instead of an IEEE sqrt followed by an IEEE
@@ -29,20 +36,76 @@ __device__ __forceinline__ double dlg_rsqrt(double d)
   return y;
 }
 
-template <int NT, bool ALIGNED16>
+// MFMA_SWEEP (LDS panels, NT a multiple of 64): the bulk of step (1) is done by the matrix
+// cores.  Every 16 columns the rows kb.. are cut into tiles of 16, the waves take tiles round
+// robin and form  C[16 x 16] = L[tile rows][0:kb] * L[kb:kb+16][0:kb]'  (v_mfma_f64_16x16x4_f64,
+// both operands read from the LDS panel: 16 consecutive rows of 4 columns) and subtract it in
+// place; the thread-per-row sweep is left with the (at most 8) columns of the current 16-block.
+typedef double dlg_pf_v4d __attribute__((ext_vector_type(4)));
+template <int NT>
+__device__ __forceinline__ void panel_mfma_sweep(double* P, int ldp, int nrows, int kb, int nb, int tid)
+{
+  constexpr int NW = NT/64;
+  const int lane = tid & 63, wv = tid >> 6;
+  const int mm = lane & 15, kq = lane >> 4;
+  const int ntile = (nrows - kb + 15) >> 4;
+  const bool bvalid = mm < nb;
+  const double* bp = P + kb + (bvalid ? mm : 0) + kq*ldp;
+  for(int t = wv; t < ntile; t += 2*NW)
+  {
+    const int r0 = kb + 16*t, r1 = r0 + 16*NW;
+    const bool two = t + NW < ntile;
+    const double* ap0 = P + min(r0 + mm, nrows - 1) + kq*ldp;
+    const double* ap1 = P + min(r1 + mm, nrows - 1) + kq*ldp;
+    dlg_pf_v4d acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+    // 8 panel columns (2 k-steps) per iteration, operands of the next iteration in flight
+    double b0 = bp[0], b1 = bp[4*ldp], a00 = ap0[0], a01 = ap0[4*ldp], a10 = ap1[0], a11 = ap1[4*ldp];
+    for(int k0 = 0; k0 < kb; k0 += 8)
+    {
+      const int kn = (k0 + 8 < kb) ? k0 + 8 : k0;
+      const double nb0 = bp[kn*ldp], nb1 = bp[(kn + 4)*ldp];
+      const double na00 = ap0[kn*ldp], na01 = ap0[(kn + 4)*ldp];
+      const double na10 = ap1[kn*ldp], na11 = ap1[(kn + 4)*ldp];
+      const double vb0 = bvalid ? b0 : 0.0, vb1 = bvalid ? b1 : 0.0;
+      acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a00, vb0, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a10, vb0, acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a01, vb1, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a11, vb1, acc1, 0, 0, 0);
+      b0 = nb0; b1 = nb1; a00 = na00; a01 = na01; a10 = na10; a11 = na11;
+    }
+    if(bvalid)
+    {
+#pragma unroll
+      for(int r = 0; r < 4; r++)
+      {
+        const int row0 = r0 + kq + 4*r, row1 = r1 + kq + 4*r;
+        if(row0 < nrows) P[row0 + (kb + mm)*ldp] -= acc0[r];
+        if(two && row1 < nrows) P[row1 + (kb + mm)*ldp] -= acc1[r];
+      }
+    }
+  }
+  __syncthreads();
+}
+template <int NT, bool ALIGNED16, bool MFMA_SWEEP = false>
 __device__ __forceinline__ void panel_factor(double* P, int ldp, int nrows, int w, int tid,
                                              int* __restrict__ info, int col0)
 {
+  DLG_PF_DECL
   for(int kb = 0; kb < w; kb += 8)
   {
     const int nb = (w - kb < 8) ? w - kb : 8;
+    // first column the thread-per-row sweep still has to apply
+    const int ks = MFMA_SWEEP ? (kb & ~15) : 0;
+    if(MFMA_SWEEP && kb > 0 && (kb & 15) == 0) panel_mfma_sweep<NT>(P, ldp, nrows, kb, min(16, w - kb), tid);
+    if(MFMA_SWEEP && ks == kb) { /* nothing left for the scalar sweep */ }
+    else
     for(int r = kb + tid; r < nrows; r += NT)
     {
       double x[8];
 #pragma unroll
       for(int c = 0; c < 8; c++) x[c] = (c < nb) ? P[r + (kb + c)*ldp] : 0.0;
 #pragma unroll 4
-      for(int k = 0; k < kb; k++)
+      for(int k = ks; k < kb; k++)
       {
         const double a = P[r + k*ldp];
         const double* bp = P + kb + k*ldp;
@@ -65,64 +128,89 @@ __device__ __forceinline__ void panel_factor(double* P, int ldp, int nrows, int 
       for(int c = 0; c < 8; c++) if(c < nb) P[r + (kb + c)*ldp] = x[c];
     }
     __syncthreads();
+    DLG_PF_STAMP(0);
     double D[8][8];
+    if(ALIGNED16)
+    {
+      // column q, rows q..7 of the block: pairs of rows are 16-byte aligned (kb, ldp even)
 #pragma unroll
-    for(int c = 0; c < 8; c++)
+      for(int q = 0; q < 8; q++)
 #pragma unroll
-      for(int q = 0; q <= c; q++)
-        D[c][q] = (c < nb) ? P[(kb + c) + (kb + q)*ldp] : ((c == q) ? 1.0 : 0.0);
+        for(int c2 = (q & ~1); c2 < 8; c2 += 2)
+        {
+          const double2 v = *reinterpret_cast<const double2*>(&P[(kb + c2) + (kb + q)*ldp]);
+          D[c2][q] = v.x; D[c2 + 1][q] = v.y;
+        }
+      if(nb < 8)
+      {
+#pragma unroll
+        for(int c = 0; c < 8; c++)
+#pragma unroll
+          for(int q = 0; q <= c; q++) if(c >= nb) D[c][q] = (c == q) ? 1.0 : 0.0;
+      }
+    }
+    else
+    {
+#pragma unroll
+      for(int c = 0; c < 8; c++)
+#pragma unroll
+        for(int q = 0; q <= c; q++)
+          D[c][q] = (c < nb) ? P[(kb + c) + (kb + q)*ldp] : ((c == q) ? 1.0 : 0.0);
+    }
     bool bad = false; int badcol = 0;
     double Dinv[8];
+    // right-looking: once column c is scaled the trailing block is updated at once, so the next
+    // pivot only waits for one multiply-add after the reciprocal square root
 #pragma unroll
     for(int c = 0; c < 8; c++)
     {
       double d = D[c][c];
-#pragma unroll
-      for(int q = 0; q < c; q++) d -= D[c][q]*D[c][q];
       if(!(d > 0.0)) { if(!bad) { bad = true; badcol = c; } d = 1.0; }
       const double inv = dlg_rsqrt(d);
-      D[c][c] = d*inv;
       Dinv[c] = inv;
 #pragma unroll
-      for(int i = c + 1; i < 8; i++)
-      {
-        double v = D[i][c];
+      for(int i = c + 1; i < 8; i++) D[i][c] *= inv;
 #pragma unroll
-        for(int q = 0; q < c; q++) v -= D[i][q]*D[c][q];
-        D[i][c] = v*inv;
-      }
+      for(int j = c + 1; j < 8; j++)
+#pragma unroll
+        for(int i = j; i < 8; i++) D[i][j] -= D[i][c]*D[j][c];
+      D[c][c] = d*inv;
     }
     if(bad && tid == 0) atomicMin(info, col0 + kb + badcol);
     __syncthreads();
-    for(int r = kb + tid; r < nrows; r += NT)
+    DLG_PF_STAMP(1);
+    // the factored block goes back through the first 64 threads: thread (c, q) keeps element
+    // (c, q) (selected with compile-time indices: D lives in registers)
+    if(tid < 64)
     {
-      if(r < kb + nb)
+      const int c = tid >> 3, q = tid & 7;
+      double v = 0.0;
+#pragma unroll
+      for(int cc = 0; cc < 8; cc++)
+#pragma unroll
+        for(int qq = 0; qq <= cc; qq++) v = (cc == c && qq == q) ? D[cc][qq] : v;
+      if(q <= c && c < nb) P[(kb + c) + (kb + q)*ldp] = v;
+    }
+    for(int r = kb + nb + tid; r < nrows; r += NT)
+    {
+      double x[8];
+#pragma unroll
+      for(int c = 0; c < 8; c++) x[c] = (c < nb) ? P[r + (kb + c)*ldp] : 0.0;
+#pragma unroll
+      for(int c = 0; c < 8; c++)
       {
-        const int c = r - kb;
+        double v = x[c];
 #pragma unroll
-        for(int cc = 0; cc < 8; cc++)
-#pragma unroll
-          for(int q = 0; q <= cc; q++) if(cc == c) P[r + (kb + q)*ldp] = D[cc][q];
+        for(int q = 0; q < c; q++) v -= x[q]*D[c][q];
+        x[c] = v*Dinv[c];
       }
-      else
-      {
-        double x[8];
 #pragma unroll
-        for(int c = 0; c < 8; c++) x[c] = (c < nb) ? P[r + (kb + c)*ldp] : 0.0;
-#pragma unroll
-        for(int c = 0; c < 8; c++)
-        {
-          double v = x[c];
-#pragma unroll
-          for(int q = 0; q < c; q++) v -= x[q]*D[c][q];
-          x[c] = v*Dinv[c];
-        }
-#pragma unroll
-        for(int c = 0; c < 8; c++) if(c < nb) P[r + (kb + c)*ldp] = x[c];
-      }
+      for(int c = 0; c < 8; c++) if(c < nb) P[r + (kb + c)*ldp] = x[c];
     }
     __syncthreads();
+    DLG_PF_STAMP(2);
   }
+  DLG_PF_DONE
 }
 
 // Panel whose w x w top block is block diagonal (a supernode made of independent
