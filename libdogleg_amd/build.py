@@ -29,12 +29,18 @@ def headers():
     return hs
 
 
+# per-source extra flags.  kernels_sparse.hip: its fp64 MFMA loops keep few accumulators; with the
+# default heuristic the compiler parks them in AGPRs and copies all of them to VGPRs and back in
+# every loop iteration, the VGPR form of the instruction avoids that.
+EXTRA = {"kernels_sparse.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
+
+
 def _compile(src, newest_hdr, verbose):
     obj = os.path.join(OBJ, os.path.basename(src) + ".o")
     if os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(src), newest_hdr):
         return obj
     if src.endswith(".hip"):
-        cmd = [HIPCC] + FLAGS + ["-c", src, "-o", obj]
+        cmd = [HIPCC] + FLAGS + EXTRA.get(os.path.basename(src), []) + ["-c", src, "-o", obj]
     else:       # plain host C++
         cmd = [HIPCC, "-x", "c++"] + [f for f in FLAGS if not f.startswith("--offload-arch")] + ["-c", src, "-o", obj]
     if verbose:

@@ -40,10 +40,10 @@ __device__ __forceinline__ double dlg_rsqrt(double d)
 // cores.  Every 16 columns the rows kb.. are cut into tiles of 16, the waves take tiles round
 // robin and form  C[16 x 16] = L[tile rows][0:kb] * L[kb:kb+16][0:kb]'  (v_mfma_f64_16x16x4_f64,
 // both operands read from the LDS panel: 16 consecutive rows of 4 columns) and subtract it in
-// place; the thread-per-row sweep is left with the (at most 8) columns of the current 16-block.
+// place; the second 8-column half of a 16-block is completed the same way against the first.
 typedef double dlg_pf_v4d __attribute__((ext_vector_type(4)));
 template <int NT>
-__device__ __forceinline__ void panel_mfma_sweep(double* P, int ldp, int nrows, int kb, int nb, int tid)
+__device__ __forceinline__ void panel_mfma_sweep(double* P, int ldp, int nrows, int kb, int nb, int kbeg, int tid)
 {
   constexpr int NW = NT/64;
   const int lane = tid & 63, wv = tid >> 6;
@@ -57,34 +57,45 @@ __device__ __forceinline__ void panel_mfma_sweep(double* P, int ldp, int nrows, 
     const bool two = t + NW < ntile;
     const double* ap0 = P + min(r0 + mm, nrows - 1) + kq*ldp;
     const double* ap1 = P + min(r1 + mm, nrows - 1) + kq*ldp;
-    dlg_pf_v4d acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+    // the accumulators start from the current entries and the B operand is negated, so the
+    // result C - L L' only has to be written back
+    double* cp = P + (kb + (bvalid ? mm : 0))*ldp;
+    dlg_pf_v4d acc0, acc1;
+#pragma unroll
+    for(int r = 0; r < 4; r++)
+    {
+      acc0[r] = cp[min(r0 + kq + 4*r, nrows - 1)];
+      acc1[r] = cp[min(r1 + kq + 4*r, nrows - 1)];
+    }
     // 8 panel columns (2 k-steps) per iteration, operands of the next iteration in flight
-    double b0 = bp[0], b1 = bp[4*ldp], a00 = ap0[0], a01 = ap0[4*ldp], a10 = ap1[0], a11 = ap1[4*ldp];
-    for(int k0 = 0; k0 < kb; k0 += 8)
+    double b0 = bp[kbeg*ldp], b1 = bp[(kbeg + 4)*ldp], a00 = ap0[kbeg*ldp], a01 = ap0[(kbeg + 4)*ldp],
+           a10 = ap1[kbeg*ldp], a11 = ap1[(kbeg + 4)*ldp];
+    for(int k0 = kbeg; k0 < kb; k0 += 8)
     {
       const int kn = (k0 + 8 < kb) ? k0 + 8 : k0;
       const double nb0 = bp[kn*ldp], nb1 = bp[(kn + 4)*ldp];
       const double na00 = ap0[kn*ldp], na01 = ap0[(kn + 4)*ldp];
       const double na10 = ap1[kn*ldp], na11 = ap1[(kn + 4)*ldp];
-      const double vb0 = bvalid ? b0 : 0.0, vb1 = bvalid ? b1 : 0.0;
+      __builtin_amdgcn_sched_barrier(0);        // keep the prefetch ahead of the products
+      const double vb0 = bvalid ? -b0 : 0.0, vb1 = bvalid ? -b1 : 0.0;
       acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a00, vb0, acc0, 0, 0, 0);
       acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a10, vb0, acc1, 0, 0, 0);
       acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a01, vb1, acc0, 0, 0, 0);
       acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a11, vb1, acc1, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
       b0 = nb0; b1 = nb1; a00 = na00; a01 = na01; a10 = na10; a11 = na11;
     }
-    if(bvalid)
-    {
 #pragma unroll
-      for(int r = 0; r < 4; r++)
-      {
-        const int row0 = r0 + kq + 4*r, row1 = r1 + kq + 4*r;
-        if(row0 < nrows) P[row0 + (kb + mm)*ldp] -= acc0[r];
-        if(two && row1 < nrows) P[row1 + (kb + mm)*ldp] -= acc1[r];
-      }
+    for(int r = 0; r < 4; r++)
+    {
+      const int row0 = r0 + kq + 4*r, row1 = r1 + kq + 4*r;
+      if(bvalid && row0 < nrows) cp[row0] = acc0[r];
+      if(bvalid && two && row1 < nrows) cp[row1] = acc1[r];
     }
   }
+  DLG_PF_STAMP(0);
   __syncthreads();
+  DLG_PF_STAMP(1);
 }
 template <int NT, bool ALIGNED16, bool MFMA_SWEEP = false>
 __device__ __forceinline__ void panel_factor(double* P, int ldp, int nrows, int w, int tid,
@@ -94,10 +105,17 @@ __device__ __forceinline__ void panel_factor(double* P, int ldp, int nrows, int 
   for(int kb = 0; kb < w; kb += 8)
   {
     const int nb = (w - kb < 8) ? w - kb : 8;
-    // first column the thread-per-row sweep still has to apply
-    const int ks = MFMA_SWEEP ? (kb & ~15) : 0;
-    if(MFMA_SWEEP && kb > 0 && (kb & 15) == 0) panel_mfma_sweep<NT>(P, ldp, nrows, kb, min(16, w - kb), tid);
-    if(MFMA_SWEEP && ks == kb) { /* nothing left for the scalar sweep */ }
+    // MFMA sweep: at the start of a 16-column block both 8-column halves are brought up to date
+    // against all columns before the block; the second half then only lacks the first half
+    constexpr int ks = 0;
+    if(MFMA_SWEEP)
+    {
+      if(kb > 0)
+      {
+        if((kb & 15) == 0) panel_mfma_sweep<NT>(P, ldp, nrows, kb, min(16, w - kb), 0, tid);
+        else               panel_mfma_sweep<NT>(P, ldp, nrows, kb, nb, kb - 8, tid);
+      }
+    }
     else
     for(int r = kb + tid; r < nrows; r += NT)
     {
@@ -127,8 +145,9 @@ __device__ __forceinline__ void panel_factor(double* P, int ldp, int nrows, int 
 #pragma unroll
       for(int c = 0; c < 8; c++) if(c < nb) P[r + (kb + c)*ldp] = x[c];
     }
+    if(!MFMA_SWEEP) { DLG_PF_STAMP(0); }
     __syncthreads();
-    DLG_PF_STAMP(0);
+    DLG_PF_STAMP(1);
     double D[8][8];
     if(ALIGNED16)
     {
@@ -159,6 +178,9 @@ __device__ __forceinline__ void panel_factor(double* P, int ldp, int nrows, int 
     }
     bool bad = false; int badcol = 0;
     double Dinv[8];
+    // waves without rows below the block only keep the barriers (wave 0 writes the block back)
+    const bool need = (tid < 64) || (kb + nb + (tid & ~63) < nrows);
+    if(need)
     // right-looking: once column c is scaled the trailing block is updated at once, so the next
     // pivot only waits for one multiply-add after the reciprocal square root
 #pragma unroll
@@ -177,8 +199,9 @@ __device__ __forceinline__ void panel_factor(double* P, int ldp, int nrows, int 
       D[c][c] = d*inv;
     }
     if(bad && tid == 0) atomicMin(info, col0 + kb + badcol);
+    DLG_PF_STAMP(2);
     __syncthreads();
-    DLG_PF_STAMP(1);
+    DLG_PF_STAMP(3);
     // the factored block goes back through the first 64 threads: thread (c, q) keeps element
     // (c, q) (selected with compile-time indices: D lives in registers)
     if(tid < 64)
@@ -207,8 +230,9 @@ __device__ __forceinline__ void panel_factor(double* P, int ldp, int nrows, int 
 #pragma unroll
       for(int c = 0; c < 8; c++) if(c < nb) P[r + (kb + c)*ldp] = x[c];
     }
+    DLG_PF_STAMP(4);
     __syncthreads();
-    DLG_PF_STAMP(2);
+    DLG_PF_STAMP(5);
   }
   DLG_PF_DONE
 }

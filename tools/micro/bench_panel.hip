@@ -5,11 +5,12 @@
 #include <cstdlib>
 #include <vector>
 #include <cmath>
-// phase stamps: per-thread accumulators, thread 0 of every workgroup publishes them
+// phase stamps: thread 0 accumulates clock deltas in LDS, publishes them at the end
 __device__ long long* g_pf_out = nullptr;
-#define DLG_PF_DECL long long _ph[3] = {0, 0, 0}; long long _t = clock64();
-#define DLG_PF_STAMP(i) do { const long long _n = clock64(); _ph[i] += _n - _t; _t = _n; } while(0)
-#define DLG_PF_DONE if(tid == 0 && g_pf_out) { g_pf_out[0] = _ph[0]; g_pf_out[1] = _ph[1]; g_pf_out[2] = _ph[2]; }
+__shared__ long long s_pf[8];
+#define DLG_PF_DECL if(threadIdx.x == 0) { for(int _i = 0; _i < 6; _i++) s_pf[_i] = 0; s_pf[7] = clock64(); }
+#define DLG_PF_STAMP(i) do { if(threadIdx.x == 0) { const long long _n = clock64(); s_pf[i] += _n - s_pf[7]; s_pf[7] = _n; } } while(0)
+#define DLG_PF_DONE if(threadIdx.x == 0 && g_pf_out) { for(int _i = 0; _i < 6; _i++) g_pf_out[_i] = s_pf[_i]; }
 #include "../../libdogleg_amd/csrc/panel_factor.h"
 
 template <int NT, int MODE>
@@ -51,7 +52,7 @@ void run(int nrows, int w, int G, int iters)
       for(int i = 0; i < nrows; i++)
         h[b*n + i + (size_t)j*nrows] = (i == j) ? (double)(w + 1) : ((i < w && i < j) ? 0.0 : 0.3*sin(0.37*i + 1.3*j));
   double* d; int* info; long long* st;
-  hipMalloc(&d, n*G*8); hipMalloc(&info, 4); hipMalloc(&st, 64);
+  hipMalloc(&d, n*G*8); hipMalloc(&info, 4); hipMalloc(&st, 128);
   const int lds = (int)(((nrows + 1) & ~1)*w*8);
   hipFuncSetAttribute(reinterpret_cast<const void*>(&k_panel<NT, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -71,8 +72,8 @@ void run(int nrows, int w, int G, int iters)
   hipFuncSetAttribute(reinterpret_cast<const void*>(&k_panel<NT, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   hipLaunchKernelGGL(HIP_KERNEL_NAME(k_panel<NT, 1>), dim3(G), dim3(NT), lds, 0, d, nrows, w, info, st);
   hipDeviceSynchronize();
-  long long ph[7]; hipMemcpy(ph, st, 56, hipMemcpyDeviceToHost);
-  printf("      phases (cycles, thread 0): update-sweep %lld  8x8-factor %lld  row-solve %lld\n", ph[4], ph[5], ph[6]);
+  long long ph[10]; hipMemcpy(ph, st, 80, hipMemcpyDeviceToHost);
+  printf("      scalar: sweep %lld +wait %lld | factor %lld +wait %lld | solve %lld +wait %lld\n", ph[4], ph[5], ph[6], ph[7], ph[8], ph[9]);
   hipFuncSetAttribute(reinterpret_cast<const void*>(&k_panel<NT, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   best = 1e9;
   for(int rep = 0; rep < 3; rep++)
@@ -87,8 +88,8 @@ void run(int nrows, int w, int G, int iters)
   hipFuncSetAttribute(reinterpret_cast<const void*>(&k_panel<NT, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   hipLaunchKernelGGL(HIP_KERNEL_NAME(k_panel<NT, 3>), dim3(G), dim3(NT), lds, 0, d, nrows, w, info, st);
   hipDeviceSynchronize();
-  hipMemcpy(ph, st, 56, hipMemcpyDeviceToHost);
-  printf("      MFMA sweep: %.1f us/launch; phases: update-sweep %lld  8x8-factor %lld  row-solve %lld\n", best*1e3/iters, ph[4], ph[5], ph[6]);
+  hipMemcpy(ph, st, 80, hipMemcpyDeviceToHost);
+  printf("      MFMA %.1f us: sweep %lld +wait %lld | factor %lld +wait %lld | solve %lld +wait %lld\n", best*1e3/iters, ph[4], ph[5], ph[6], ph[7], ph[8], ph[9]);
   hipFree(d); hipFree(info); hipFree(st);
 }
 
