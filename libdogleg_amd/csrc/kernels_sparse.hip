@@ -758,22 +758,43 @@ __global__ void __launch_bounds__(NT) k_factor_level(const int* __restrict__ fw_
   const int ldp = (nloc + 1) & ~1;
   const int shift = r0;                        // local row i >= w  <->  panel row i + shift
   if(tid == 0) sbad = 0x7fffffff;
-  batched_copy<NT, 8>(nloc*w, tid,
-                      [&](int e) { const int j = e / nloc, i = e - j*nloc; return G[(i < w ? i : i + shift) + (size_t)j*nrows]; },
-                      [&](int e, double v) { const int j = e / nloc; P[e + j*(ldp - nloc)] = v; });
+  // thread = panel row, 16 columns in flight (no index arithmetic per element)
+  for(int i = tid; i < nloc; i += NT)
+  {
+    const double* gp = G + (i < w ? i : i + shift);
+    for(int j0 = 0; j0 < w; j0 += 16)
+    {
+      double v[16];
+#pragma unroll
+      for(int u = 0; u < 16; u++) v[u] = (j0 + u < w) ? gp[(size_t)(j0 + u)*nrows] : 0.0;
+#pragma unroll
+      for(int u = 0; u < 16; u++) if(j0 + u < w) P[i + (j0 + u)*ldp] = v[u];
+    }
+  }
   __syncthreads();
   const int nmem = sn_bd_ptr[s+1] - sn_bd_ptr[s];
   if(nmem > 0) panel_factor_blockdiag<NT>(P, ldp, nloc, w, tid, sn_bd_col + sn_bd_ptr[s], nmem, &sbad, sn_c0[s]);
+  else if(NT >= 256) panel_factor_mfma<(NT >= 256 ? NT : 256)>(P, ldp, nloc, w, tid, &sbad, sn_c0[s]);
   else         panel_factor<NT, true, true>(P, ldp, nloc, w, tid, &sbad, sn_c0[s]);
   const int64_t top = sn_top[s];
   if(r0 == 0 && tid == 0 && sbad != 0x7fffffff) atomicMin(info, sbad);
-  for(int e = tid; e < nloc*w; e += NT)
+  for(int i = tid; i < nloc; i += NT)
   {
-    const int j = e / nloc, i = e - j*nloc;
-    const double v = P[e + j*(ldp - nloc)];
-    if(i >= w) G[(i + shift) + (size_t)j*nrows] = v;
-    else if(top < 0) G[i + (size_t)j*nrows] = v;
-    else if(r0 == 0) top_scr[top + i + (size_t)j*w] = v;
+    // rows below the top block go back to the panel; the top block too unless the supernode is
+    // cut into slices (then slice 0 parks it in top_scr, see k_copy_top)
+    double* gp; size_t gs;
+    if(i >= w)        { gp = G + (i + shift); gs = (size_t)nrows; }
+    else if(top < 0)  { gp = G + i; gs = (size_t)nrows; }
+    else if(r0 == 0)  { gp = top_scr + top + i; gs = (size_t)w; }
+    else continue;
+    for(int j0 = 0; j0 < w; j0 += 16)
+    {
+      double v[16];
+#pragma unroll
+      for(int u = 0; u < 16; u++) v[u] = (j0 + u < w) ? P[i + (j0 + u)*ldp] : 0.0;
+#pragma unroll
+      for(int u = 0; u < 16; u++) if(j0 + u < w) gp[(size_t)(j0 + u)*gs] = v[u];
+    }
   }
 }
 // publish the top blocks of the multi-slice supernodes

@@ -42,46 +42,47 @@ __device__ __forceinline__ double dlg_rsqrt(double d)
 // both operands read from the LDS panel: 16 consecutive rows of 4 columns) and subtract it in
 // place; the second 8-column half of a 16-block is completed the same way against the first.
 typedef double dlg_pf_v4d __attribute__((ext_vector_type(4)));
-template <int NT>
-__device__ __forceinline__ void panel_mfma_sweep(double* P, int ldp, int nrows, int kb, int nb, int kbeg, int tid)
+// one wave: tiles t0, t0 + ts, t0 + 2 ts, ... (< ntile) of the rows kb.., two at a time if PAIR
+template <bool PAIR>
+__device__ __forceinline__ void panel_mfma_tiles(double* P, int ldp, int nrows, int kb, int nb, int kbeg,
+                                                 int lane, int t0, int ts, int ntile)
 {
-  constexpr int NW = NT/64;
-  const int lane = tid & 63, wv = tid >> 6;
   const int mm = lane & 15, kq = lane >> 4;
-  const int ntile = (nrows - kb + 15) >> 4;
   const bool bvalid = mm < nb;
   const double* bp = P + kb + (bvalid ? mm : 0) + kq*ldp;
-  for(int t = wv; t < ntile; t += 2*NW)
+  double* cp = P + (kb + (bvalid ? mm : 0))*ldp;
+  for(int t = t0; t < ntile; t += (PAIR ? 2 : 1)*ts)
   {
-    const int r0 = kb + 16*t, r1 = r0 + 16*NW;
-    const bool two = t + NW < ntile;
+    const int r0 = kb + 16*t, r1 = r0 + 16*ts;
+    const bool two = PAIR && t + ts < ntile;
     const double* ap0 = P + min(r0 + mm, nrows - 1) + kq*ldp;
     const double* ap1 = P + min(r1 + mm, nrows - 1) + kq*ldp;
     // the accumulators start from the current entries and the B operand is negated, so the
     // result C - L L' only has to be written back
-    double* cp = P + (kb + (bvalid ? mm : 0))*ldp;
     dlg_pf_v4d acc0, acc1;
 #pragma unroll
     for(int r = 0; r < 4; r++)
     {
       acc0[r] = cp[min(r0 + kq + 4*r, nrows - 1)];
-      acc1[r] = cp[min(r1 + kq + 4*r, nrows - 1)];
+      if(PAIR) acc1[r] = cp[min(r1 + kq + 4*r, nrows - 1)];
     }
     // 8 panel columns (2 k-steps) per iteration, operands of the next iteration in flight
-    double b0 = bp[kbeg*ldp], b1 = bp[(kbeg + 4)*ldp], a00 = ap0[kbeg*ldp], a01 = ap0[(kbeg + 4)*ldp],
-           a10 = ap1[kbeg*ldp], a11 = ap1[(kbeg + 4)*ldp];
+    double b0 = bp[kbeg*ldp], b1 = bp[(kbeg + 4)*ldp], a00 = ap0[kbeg*ldp], a01 = ap0[(kbeg + 4)*ldp];
+    double a10 = 0.0, a11 = 0.0;
+    if(PAIR) { a10 = ap1[kbeg*ldp]; a11 = ap1[(kbeg + 4)*ldp]; }
     for(int k0 = kbeg; k0 < kb; k0 += 8)
     {
       const int kn = (k0 + 8 < kb) ? k0 + 8 : k0;
       const double nb0 = bp[kn*ldp], nb1 = bp[(kn + 4)*ldp];
       const double na00 = ap0[kn*ldp], na01 = ap0[(kn + 4)*ldp];
-      const double na10 = ap1[kn*ldp], na11 = ap1[(kn + 4)*ldp];
+      double na10 = 0.0, na11 = 0.0;
+      if(PAIR) { na10 = ap1[kn*ldp]; na11 = ap1[(kn + 4)*ldp]; }
       __builtin_amdgcn_sched_barrier(0);        // keep the prefetch ahead of the products
       const double vb0 = bvalid ? -b0 : 0.0, vb1 = bvalid ? -b1 : 0.0;
       acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a00, vb0, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a10, vb0, acc1, 0, 0, 0);
+      if(PAIR) acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a10, vb0, acc1, 0, 0, 0);
       acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a01, vb1, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a11, vb1, acc1, 0, 0, 0);
+      if(PAIR) acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a11, vb1, acc1, 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
       b0 = nb0; b1 = nb1; a00 = na00; a01 = na01; a10 = na10; a11 = na11;
     }
@@ -90,12 +91,137 @@ __device__ __forceinline__ void panel_mfma_sweep(double* P, int ldp, int nrows, 
     {
       const int row0 = r0 + kq + 4*r, row1 = r1 + kq + 4*r;
       if(bvalid && row0 < nrows) cp[row0] = acc0[r];
-      if(bvalid && two && row1 < nrows) cp[row1] = acc1[r];
+      if(PAIR) if(bvalid && two && row1 < nrows) cp[row1] = acc1[r];
     }
   }
+}
+template <int NT>
+__device__ __forceinline__ void panel_mfma_sweep(double* P, int ldp, int nrows, int kb, int nb, int kbeg, int tid)
+{
+  constexpr int NW = NT/64;
+  panel_mfma_tiles<true>(P, ldp, nrows, kb, nb, kbeg, tid & 63, tid >> 6, NW, (nrows - kb + 15) >> 4);
   DLG_PF_STAMP(0);
   __syncthreads();
   DLG_PF_STAMP(1);
+}
+// ---- pieces of the 8-column step, shared by the variants below
+// the 8x8 diagonal block (lower triangle) from an LDS panel: pairs of rows are 16-byte aligned
+__device__ __forceinline__ void pf_load_block(double (&D)[8][8], const double* P, int ldp, int kb, int nb)
+{
+#pragma unroll
+  for(int q = 0; q < 8; q++)
+#pragma unroll
+    for(int c2 = (q & ~1); c2 < 8; c2 += 2)
+    {
+      const double2 v = *reinterpret_cast<const double2*>(&P[(kb + c2) + (kb + q)*ldp]);
+      D[c2][q] = v.x; D[c2 + 1][q] = v.y;
+    }
+  if(nb < 8)
+  {
+#pragma unroll
+    for(int c = 0; c < 8; c++)
+#pragma unroll
+      for(int q = 0; q <= c; q++) if(c >= nb) D[c][q] = (c == q) ? 1.0 : 0.0;
+  }
+}
+// right-looking Cholesky of the block in registers: once column c is scaled the trailing block
+// is updated at once, so the next pivot only waits for one multiply-add after the reciprocal
+// square root.  Returns the first non-positive pivot (or -1); that pivot is replaced by 1.
+__device__ __forceinline__ int pf_factor_block(double (&D)[8][8], double (&Dinv)[8])
+{
+  int badcol = -1;
+#pragma unroll
+  for(int c = 0; c < 8; c++)
+  {
+    double d = D[c][c];
+    if(!(d > 0.0)) { if(badcol < 0) badcol = c; d = 1.0; }
+    const double inv = dlg_rsqrt(d);
+    Dinv[c] = inv;
+#pragma unroll
+    for(int i = c + 1; i < 8; i++) D[i][c] *= inv;
+#pragma unroll
+    for(int j = c + 1; j < 8; j++)
+#pragma unroll
+      for(int i = j; i < 8; i++) D[i][j] -= D[i][c]*D[j][c];
+    D[c][c] = d*inv;
+  }
+  return badcol;
+}
+// MFMA panel factorisation with a dedicated diagonal wave (LDS panels, NT >= 256).
+// Per 8 columns, two barriers instead of three and the block factorisation off the other
+// waves' path:
+//   wave 0:   MFMA update of the first row tile (it holds the diagonal block), factors the
+//             8x8 block in registers, writes it back and publishes the reciprocal pivots;
+//   waves 1+: MFMA update of the remaining row tiles meanwhile;
+//   barrier;  every thread fetches the factored block and solves its row; barrier.
+template <int NT>
+__device__ __forceinline__ void panel_factor_mfma(double* P, int ldp, int nrows, int w, int tid,
+                                                  int* __restrict__ info, int col0)
+{
+  static_assert(NT >= 256, "panel_factor_mfma needs at least 4 waves");
+  constexpr int NW = NT/64;
+  __shared__ double s_dinv[8];
+  const int lane = tid & 63, wv = tid >> 6;
+  DLG_PF_DECL
+  for(int kb = 0; kb < w; kb += 8)
+  {
+    const int nb = (w - kb < 8) ? w - kb : 8;
+    const int ntile = (nrows - kb + 15) >> 4;
+    const int nb16 = ((kb & 15) == 0) ? min(16, w - kb) : nb, kbeg = ((kb & 15) == 0) ? 0 : kb - 8;
+    double D[8][8], Dinv[8];
+    if(wv == 0)
+    {
+      if(kb > 0) panel_mfma_tiles<false>(P, ldp, nrows, kb, nb16, kbeg, lane, 0, ntile, ntile);
+      pf_load_block(D, P, ldp, kb, nb);
+      const int badcol = pf_factor_block(D, Dinv);
+      if(badcol >= 0 && tid == 0) atomicMin(info, col0 + kb + badcol);
+      // thread (c, q) keeps element (c, q) (compile-time indices: D lives in registers)
+      const int c = tid >> 3, q = tid & 7;
+      double v = 0.0, dv = 0.0;
+#pragma unroll
+      for(int cc = 0; cc < 8; cc++)
+      {
+#pragma unroll
+        for(int qq = 0; qq <= cc; qq++) v = (cc == c && qq == q) ? D[cc][qq] : v;
+        dv = (cc == q) ? Dinv[cc] : dv;
+      }
+      if(q <= c && c < nb) P[(kb + c) + (kb + q)*ldp] = v;
+      if(c == 0) s_dinv[q] = dv;
+    }
+    else if(kb > 0) panel_mfma_tiles<true>(P, ldp, nrows, kb, nb16, kbeg, lane, wv, NW - 1, ntile);
+    DLG_PF_STAMP(0);
+    __syncthreads();
+    DLG_PF_STAMP(1);
+    if(kb + nb + (tid & ~63) < nrows)
+    {
+      if(wv != 0)
+      {
+        pf_load_block(D, P, ldp, kb, nb);
+#pragma unroll
+        for(int c = 0; c < 8; c++) Dinv[c] = s_dinv[c];
+      }
+      for(int r = kb + nb + tid; r < nrows; r += NT)
+      {
+        double x[8];
+#pragma unroll
+        for(int c = 0; c < 8; c++) x[c] = (c < nb) ? P[r + (kb + c)*ldp] : 0.0;
+#pragma unroll
+        for(int c = 0; c < 8; c++)
+        {
+          double v = x[c];
+#pragma unroll
+          for(int q = 0; q < c; q++) v -= x[q]*D[c][q];
+          x[c] = v*Dinv[c];
+        }
+#pragma unroll
+        for(int c = 0; c < 8; c++) if(c < nb) P[r + (kb + c)*ldp] = x[c];
+      }
+    }
+    DLG_PF_STAMP(4);
+    __syncthreads();
+    DLG_PF_STAMP(5);
+  }
+  DLG_PF_DONE
 }
 template <int NT, bool ALIGNED16, bool MFMA_SWEEP = false>
 __device__ __forceinline__ void panel_factor(double* P, int ldp, int nrows, int w, int tid,

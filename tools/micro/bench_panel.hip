@@ -33,8 +33,8 @@ __global__ void __launch_bounds__(NT) k_panel(double* G, int nrows, int w, int* 
   long long t1 = clock64();
   if(MODE == 0) panel_factor<NT, true>(P, ldp, nrows, w, tid, info, 0);
   if(MODE == 1) { if(blockIdx.x == 0 && tid == 0) g_pf_out = stamps + 4; panel_factor<NT, true>(P, ldp, nrows, w, tid, info, 0); }
-  if(MODE == 2) panel_factor<NT, true, true>(P, ldp, nrows, w, tid, info, 0);
-  if(MODE == 3) { if(blockIdx.x == 0 && tid == 0) g_pf_out = stamps + 4; panel_factor<NT, true, true>(P, ldp, nrows, w, tid, info, 0); }
+  if(MODE == 2) { if(NT >= 256) panel_factor_mfma<(NT >= 256 ? NT : 256)>(P, ldp, nrows, w, tid, info, 0); else if(NT >= 256) panel_factor_mfma<(NT >= 256 ? NT : 256)>(P, ldp, nrows, w, tid, info, 0); else panel_factor<NT, true, true>(P, ldp, nrows, w, tid, info, 0); }
+  if(MODE == 3) { if(blockIdx.x == 0 && tid == 0) g_pf_out = stamps + 4; if(NT >= 256) panel_factor_mfma<(NT >= 256 ? NT : 256)>(P, ldp, nrows, w, tid, info, 0); else panel_factor<NT, true, true>(P, ldp, nrows, w, tid, info, 0); }
   __syncthreads();
   long long t2 = clock64();
   for(int e = tid; e < nrows*w; e += NT) { int j = e / nrows; g[e] = P[e + j*(ldp - nrows)]; }
