@@ -1353,8 +1353,12 @@ __global__ void __launch_bounds__(TPB) k_solve_fwd_level(const int* __restrict__
   }
 }
 // backward: x_t = L_tt^-T (y_t - L_below^T x[below rows]); out[perm] = x.
-// x at the below rows is gathered into LDS once (not once per column); 8 waves share the
-// columns of the L_below^T mat-vec; the diagonal block is staged for the column sweep.
+// x at the below rows is gathered into LDS once; 8 waves share the columns of the L_below^T
+// mat-vec.  The triangular solve runs over blocks of 8 columns from the bottom, thread = row:
+// the 8 owners of a block publish their right-hand sides, after ONE barrier every thread
+// solves the 8x8 block itself (the diagonal blocks sit in LDS with reciprocal pivots) and
+// applies the 8 new unknowns to its own row with values of L it fetched a block ahead.
+// w/8 barriers instead of w, no staging of the w x w block.
 constexpr int BWD_NT = 512;
 __global__ void __launch_bounds__(BWD_NT) k_solve_bwd_level(const int* __restrict__ lvl_sn,
                                                             const int* __restrict__ sn_c0,
@@ -1367,7 +1371,6 @@ __global__ void __launch_bounds__(BWD_NT) k_solve_bwd_level(const int* __restric
                                                             double* __restrict__ out, int use_aug)
 {
   extern __shared__ __attribute__((aligned(16))) double lds[];
-  __shared__ double xs[256];
   const int s = lvl_sn[blockIdx.x];
   const int c0 = sn_c0[s], w = sn_c0[s+1] - c0;
   const int nrows = sn_rowptr[s+1] - sn_rowptr[s];
@@ -1375,11 +1378,20 @@ __global__ void __launch_bounds__(BWD_NT) k_solve_bwd_level(const int* __restric
   const double* L = Lx + sn_lx[s];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int r = nrows - w - 1;
-  const int ldp = w | 1;
-  double* xb = lds + (size_t)w*ldp;
-  batched_copy<BWD_NT, 8>(w*w, tid, [&](int e) { const int j = e / w; return L[(e - j*w) + (size_t)j*nrows]; },
-                          [&](int e, double v) { const int j = e / w; lds[(e - j*w) + j*ldp] = v; });
+  const int nblk = (w + 7) >> 3;
+  double* xb = lds;                       // [r]   x at the below rows
+  double* xs = lds + ((r + 1) & ~1);      // [256] right-hand side, then the solution
+  double* T = xs + 256;                   // [nblk][8][8] diagonal blocks (lower), reciprocal pivots
+  double* rhs = T + nblk*64;              // [2][8]
   for(int i = tid; i < r; i += BWD_NT) xb[i] = ywork[rows[w + i]];
+  for(int e = tid; e < nblk*64; e += BWD_NT)
+  {
+    const int j0 = (e >> 6)*8, a = (e >> 3) & 7, b = e & 7;
+    const bool valid = a >= b && j0 + a < w;
+    double v = valid ? L[(j0 + a) + (size_t)(j0 + b)*nrows] : 0.0;
+    if(a == b) v = valid ? 1.0/v : 1.0;
+    T[e] = v;
+  }
   __syncthreads();
   for(int j = wv; j < w; j += BWD_NT/64)
   {
@@ -1392,11 +1404,46 @@ __global__ void __launch_bounds__(BWD_NT) k_solve_bwd_level(const int* __restric
   }
   __syncthreads();
   double xi = (tid < w) ? xs[tid] : 0.0;
-  for(int j = w - 1; j >= 0; j--)
+  const double* Lcol = L + (size_t)min(tid, w - 1)*nrows;      // column tid of L = row tid of L^T
+  double lv[8];
   {
-    if(tid == j) xs[j] = xi / lds[j + j*ldp];
+    const int j0 = 8*(nblk - 1);
+#pragma unroll
+    for(int a = 0; a < 8; a++) lv[a] = (tid < j0 && j0 + a < w) ? Lcol[j0 + a] : 0.0;
+  }
+  for(int blk = nblk - 1; blk >= 0; blk--)
+  {
+    const int j0 = 8*blk;
+    double* rh = rhs + 8*(blk & 1);
+    if(tid >= j0 && tid < j0 + 8) rh[tid - j0] = xi;
+    double ln[8];
+#pragma unroll
+    for(int a = 0; a < 8; a++) ln[a] = (blk > 0 && tid < j0 - 8) ? Lcol[j0 - 8 + a] : 0.0;
     __syncthreads();
-    if(tid < j) xi -= lds[j + tid*ldp]*xs[j];
+    const double* Tb = T + blk*64;
+    double xk[8];
+#pragma unroll
+    for(int a = 7; a >= 0; a--)
+    {
+      double v = rh[a];
+#pragma unroll
+      for(int b = a + 1; b < 8; b++) v -= Tb[b*8 + a]*xk[b];
+      xk[a] = v*Tb[a*8 + a];
+    }
+    if(tid < j0)
+    {
+#pragma unroll
+      for(int a = 0; a < 8; a++) xi -= lv[a]*xk[a];
+    }
+    else if(tid < j0 + 8)
+    {
+      double v = 0.0;
+#pragma unroll
+      for(int a = 0; a < 8; a++) v = (tid - j0 == a) ? xk[a] : v;
+      xs[tid] = v;
+    }
+#pragma unroll
+    for(int a = 0; a < 8; a++) lv[a] = ln[a];
   }
   __syncthreads();
   for(int j = tid; j < w; j += BWD_NT) { ywork[c0 + j] = xs[j]; out[perm[c0 + j]] = xs[j]; }
@@ -1505,7 +1552,7 @@ int sparse_set_pattern(dlg_backend* b, const int* colptr, const int* rowidx)
       {
         const int s = H.lvl_sn[i];
         const long wv = H.sn_c0[s+1] - H.sn_c0[s], nr = H.sn_rowptr[s+1] - H.sn_rowptr[s];
-        const long need = wv*(wv | 1) + (nr - wv);
+        const long need = (nr - wv + 2) + 256 + ((wv + 7)/8)*64 + 16;   // xb, xs, diagonal blocks, rhs
         if(need > mb) mb = need;
       }
       if(mb*8 > LDS_BUDGET) { dlg_set_error("supernode too large for the backward-solve kernel (%ld doubles)", mb); return DLG_ERR_ARG; }
