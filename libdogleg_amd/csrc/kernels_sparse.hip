@@ -90,7 +90,7 @@ struct SparseSym
   size_t nnz_loc = 0;
   // per-level launch parameters
   std::vector<int> fac_lds;     // bytes of LDS for the factor kernel of a level (0: panels stay in HBM)
-  std::vector<int> upd_lds, upd_nw, slv_lds, bwd_lds, fac_nt, upd_coop, syrk_lds, syrk_nt, syrk_kc;
+  std::vector<int> upd_lds, upd_nw, slv_lds, bwd_lds, fac_nt, upd_coop, syrk_lds, syrk_nt, syrk_kc, bwd_nt;
   std::vector<void*> allocs;
 };
 
@@ -1359,7 +1359,7 @@ __global__ void __launch_bounds__(TPB) k_solve_fwd_level(const int* __restrict__
 // solves the 8x8 block itself (the diagonal blocks sit in LDS with reciprocal pivots) and
 // applies the 8 new unknowns to its own row with values of L it fetched a block ahead.
 // w/8 barriers instead of w, no staging of the w x w block.
-constexpr int BWD_NT = 512;
+template <int BWD_NT>
 __global__ void __launch_bounds__(BWD_NT) k_solve_bwd_level(const int* __restrict__ lvl_sn,
                                                             const int* __restrict__ sn_c0,
                                                             const int* __restrict__ sn_rowptr,
@@ -1393,14 +1393,26 @@ __global__ void __launch_bounds__(BWD_NT) k_solve_bwd_level(const int* __restric
     T[e] = v;
   }
   __syncthreads();
-  for(int j = wv; j < w; j += BWD_NT/64)
+  // a wave takes 4 columns at a time: their loads are all in flight together
+  for(int jg = 4*wv; jg < w; jg += 4*(BWD_NT/64))
   {
-    const double* Lj = L + (size_t)j*nrows + w;
-    double sum = 0.0;
-#pragma unroll 4
-    for(int i = lane; i < r; i += 64) sum += Lj[i]*xb[i];
-    sum = wave_sum(sum);
-    if(lane == 0) xs[j] = (use_aug ? L[(nrows - 1) + (size_t)j*nrows] : ywork[c0 + j]) - sum;
+    const double* Lj = L + (size_t)jg*nrows + w;
+    const int nc = min(4, w - jg);
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll 2
+    for(int i = lane; i < r; i += 64)
+    {
+      const double x = xb[i];
+#pragma unroll
+      for(int c = 0; c < 4; c++) acc[c] += ((c < nc) ? Lj[i + (size_t)c*nrows] : 0.0)*x;
+    }
+#pragma unroll
+    for(int c = 0; c < 4; c++)
+    {
+      const double sum = wave_sum(acc[c]);
+      if(lane == 0 && c < nc)
+        xs[jg + c] = (use_aug ? L[(nrows - 1) + (size_t)(jg + c)*nrows] : ywork[c0 + jg + c]) - sum;
+    }
   }
   __syncthreads();
   double xi = (tid < w) ? xs[tid] : 0.0;
@@ -1521,7 +1533,7 @@ int sparse_set_pattern(dlg_backend* b, const int* colptr, const int* rowidx)
   DLG_HIP(hipHostMalloc(&Y->h_info, sizeof(int)));
 
   // per-level launch parameters
-  Y->fac_lds.assign(H.nlevels, 0); Y->upd_lds.assign(H.nlevels, 0); Y->upd_nw.assign(H.nlevels, 0); Y->syrk_lds.assign(H.nlevels, 0); Y->syrk_nt.assign(H.nlevels, 256); Y->syrk_kc.assign(H.nlevels, 4);
+  Y->fac_lds.assign(H.nlevels, 0); Y->upd_lds.assign(H.nlevels, 0); Y->upd_nw.assign(H.nlevels, 0); Y->syrk_lds.assign(H.nlevels, 0); Y->bwd_nt.assign(H.nlevels, 512); Y->syrk_nt.assign(H.nlevels, 256); Y->syrk_kc.assign(H.nlevels, 4);
   Y->slv_lds.assign(H.nlevels, 0); Y->bwd_lds.assign(H.nlevels, 0); Y->fac_nt.assign(H.nlevels, 512); Y->upd_coop.assign(H.nlevels, 0);
   for(int l = 0; l < H.nlevels; l++)
   {
@@ -1557,6 +1569,7 @@ int sparse_set_pattern(dlg_backend* b, const int* colptr, const int* rowidx)
       }
       if(mb*8 > LDS_BUDGET) { dlg_set_error("supernode too large for the backward-solve kernel (%ld doubles)", mb); return DLG_ERR_ARG; }
       Y->bwd_lds[l] = (int)(mb*8);
+      Y->bwd_nt[l] = (maxw <= 128 && H.lvl_ptr[l+1] - H.lvl_ptr[l] >= 512) ? 256 : 512;
     }
     if(Y->slv_lds[l] > LDS_BUDGET) { dlg_set_error("supernode of width %ld is too wide for the solve kernels", maxw); return DLG_ERR_ARG; }
     long maxslab = 0;
@@ -1605,7 +1618,9 @@ int sparse_set_pattern(dlg_backend* b, const int* colptr, const int* rowidx)
                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BUDGET));
   DLG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_solve_fwd_level),
                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BUDGET));
-  DLG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_solve_bwd_level),
+  DLG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_solve_bwd_level<256>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BUDGET));
+  DLG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_solve_bwd_level<512>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BUDGET));
   return DLG_OK;
 }
@@ -1803,9 +1818,16 @@ int sparse_solve(dlg_backend* b, const double* rhs, double* out)
   for(int l = H.nlevels - 1; l >= 0; l--)
   {
     const int n = H.lvl_ptr[l+1] - H.lvl_ptr[l];
-    if(n > 0)
-      hipLaunchKernelGGL(k_solve_bwd_level, dim3(n), dim3(BWD_NT), Y->bwd_lds[l], st, Y->lvl_sn + H.lvl_ptr[l],
-                         Y->sn_c0, Y->sn_rowptr, Y->sn_rows, Y->sn_lx, Y->perm, Y->Lx, Y->ywork, out, use_aug);
+    // thread = row of the diagonal block: 256 threads when every supernode of a populous level is
+    // narrow (more workgroups per CU), else 512
+    if(n > 0 && Y->bwd_nt[l] == 256)
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_solve_bwd_level<256>), dim3(n), dim3(256), Y->bwd_lds[l], st,
+                         Y->lvl_sn + H.lvl_ptr[l], Y->sn_c0, Y->sn_rowptr, Y->sn_rows, Y->sn_lx, Y->perm, Y->Lx,
+                         Y->ywork, out, use_aug);
+    else if(n > 0)
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_solve_bwd_level<512>), dim3(n), dim3(512), Y->bwd_lds[l], st,
+                         Y->lvl_sn + H.lvl_ptr[l], Y->sn_c0, Y->sn_rowptr, Y->sn_rows, Y->sn_lx, Y->perm, Y->Lx,
+                         Y->ywork, out, use_aug);
   }
   DLG_LAUNCH_CHECK();
   return DLG_OK;
