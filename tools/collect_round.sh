@@ -1,0 +1,26 @@
+#!/bin/bash
+# Collect the per-round artifacts on the GPU box: bench JSON lines, rocprofv3 kernel stats,
+# PMC traffic (separate passes), end-to-end rate, probes.  usage: tools/collect_round.sh <tag>
+# Writes under gpurun_out/<tag>/ ; tools/publish_round.py copies the summaries into profiles/.
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+tag=${1:-r01}; out=gpurun_out/$tag; mkdir -p $out
+for wl in sparse-1m sparse-200k dense-50k; do
+  timeout 600 python3 bench.py --workload $wl > $out/bench_$wl.json 2> $out/bench_$wl.err
+done
+timeout 600 python3 bench.py --workload sparse-5m --steps 5 --warmup 2 --no-cpu-baseline > $out/bench_sparse-5m.json 2> $out/bench_sparse-5m.err
+for wl in sparse-1m dense-50k; do
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_$wl -o p -- python3 bench.py --workload $wl --no-cpu-baseline > $out/stats_$wl.log 2>&1
+done
+for wl in sparse-1m dense-50k; do
+  for c in FETCH_SIZE WRITE_SIZE; do
+    timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out/pmc_${wl}_$c -o p -- python3 bench.py --workload $wl --steps 3 --warmup 1 --no-cpu-baseline > $out/pmc_${wl}_$c.log 2>&1
+    python3 tools/pmc_kernel.py $out/pmc_${wl}_$c > $out/pmc_${wl}_$c.txt
+  done
+done
+timeout 600 python3 tools/e2e_bench.py --workload sparse-1m > $out/e2e_sparse1m.json 2> $out/e2e.err
+timeout 300 python3 tools/gpu_probe.py > $out/probe.txt 2>&1
+DLG_BENCH_FORCE_DIST=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29512 RANK=0 LOCAL_RANK=0 WORLD_SIZE=1 timeout 600 python3 bench.py --no-cpu-baseline > $out/bench_dist_world1_rccl.log 2>&1
+# keep the merge small: only summaries travel back
+find $out -name "*kernel_trace.csv" -delete; find $out -name "*counter_collection.csv" -delete
+find $out -name "*agent_info.csv" -delete; find $out -name "*domain_stats.csv" -delete
+ls -la $out

@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""Copy the summaries tools/collect_round.sh produced (gpurun_out/<tag>/) into profiles/ and
+rebuild profiles/traffic.json from the PMC passes.  usage: tools/publish_round.py r01"""
+import json, os, re, shutil, sys
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src, dst = os.path.join(root, "gpurun_out", tag), os.path.join(root, "profiles")
+names = {"sparse-1m": "sparse1m", "sparse-200k": "sparse200k", "dense-50k": "dense50k", "sparse-5m": "sparse5m"}
+for wl, short in names.items():
+    f = os.path.join(src, f"bench_{wl}.json")
+    if os.path.exists(f) and os.path.getsize(f):
+        shutil.copy(f, os.path.join(dst, f"{tag}_bench_{short}.json"))
+    st = os.path.join(src, f"stats_{wl}", "p_kernel_stats.csv")
+    if os.path.exists(st):
+        shutil.copy(st, os.path.join(dst, f"{tag}_{short}_kernel_stats.csv"))
+for a, b in (("e2e_sparse1m.json", f"{tag}_e2e_sparse1m.json"), ("bench_dist_world1_rccl.log", f"{tag}_bench_dist_world1_rccl.log"),
+             ("probe.txt", f"{tag}_probe.txt")):
+    if os.path.exists(os.path.join(src, a)):
+        shutil.copy(os.path.join(src, a), os.path.join(dst, b))
+
+
+def pmc(wl, counter, kernel):
+    f = os.path.join(src, f"pmc_{wl}_{counter}.txt")
+    best = None
+    for line in open(f):
+        if line.startswith(kernel + " ") or (" " + kernel + " ") in (" " + line):
+            m = re.search(r"'%s': ([0-9.]+)" % counter, line)
+            if m:
+                best = float(m.group(1))
+    return best
+
+
+traffic = {}
+# the dense JtJ launch is one of many k_syrk_lower<64> dispatches (the potrf trailing updates use the
+# same kernel): its entry is maintained by hand from the per-dispatch CSV (see the pmc notes)
+for wl, kernel, label in (("sparse-1m", "k_assemble_mfma", "k_assemble_mfma"),):
+    try:
+        f, w = pmc(wl, "FETCH_SIZE", kernel), pmc(wl, "WRITE_SIZE", kernel)
+        if f is None or w is None:
+            continue
+        traffic[wl] = {"kernel": label, "fetch_size_kb": f, "write_size_kb": w, "bytes_per_launch": int((2*f + w)*1024),
+                       "source": f"profiles/{tag}_pmc.md: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs; "
+                                 "bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 FETCH_SIZE counts half of streamed reads)"}
+    except FileNotFoundError:
+        pass
+old = {}
+try:
+    old = json.load(open(os.path.join(dst, "traffic.json")))
+except Exception:
+    pass
+old.update(traffic)
+json.dump(old, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
+for wl in ("sparse-1m", "dense-50k"):
+    for c in ("FETCH_SIZE", "WRITE_SIZE"):
+        f = os.path.join(src, f"pmc_{wl}_{c}.txt")
+        if os.path.exists(f):
+            shutil.copy(f, os.path.join(dst, f"{tag}_pmc_{names[wl]}_{c}.txt"))
+print(json.dumps(traffic, indent=1))
