@@ -23,7 +23,7 @@ namespace {
 
 constexpr int TPB = 256;
 constexpr int LDS_BUDGET = 147456;      // bytes of dynamic LDS we allow a workgroup
-constexpr int FAC_LDS_BUDGET = 163840 - 256;   // the panel factorisation takes (almost) all 160 KB of a CU
+constexpr int FAC_LDS_BUDGET = 163840 - 3584;  // the panel factorisation takes (almost) all 160 KB of a CU; the rest is its static LDS
 
 __device__ __forceinline__ double wave_sum(double v)
 {

@@ -370,50 +370,40 @@ __device__ __forceinline__ void panel_factor(double* P, int ldp, int nrows, int 
 //   B: after one barrier every below row solves against each member's block.
 template <int NT>
 __device__ __forceinline__ void panel_factor_blockdiag(double* P, int ldp, int nrows, int w, int tid,
-                                                       const int* __restrict__ mcol, int nmem,
+                                                       const int* __restrict__ mcol_g, int nmem,
                                                        int* __restrict__ info, int col0)
 {
+  // member boundaries and reciprocal pivots live in LDS: phase B walks them for every row
+  __shared__ int mcol[260];
+  __shared__ double rdiag[256];
+  for(int m = tid; m <= nmem; m += NT) mcol[m] = (m < nmem) ? mcol_g[m] : w;
+  __syncthreads();
   for(int m = tid; m < nmem; m += NT)
   {
-    const int c0 = mcol[m], nb = ((m + 1 < nmem) ? mcol[m+1] : w) - c0;
+    const int c0 = mcol[m], nb = mcol[m+1] - c0;
     double D[8][8];
 #pragma unroll
     for(int c = 0; c < 8; c++)
 #pragma unroll
       for(int q = 0; q <= c; q++)
         D[c][q] = (c < nb) ? P[(c0 + c) + (c0 + q)*ldp] : ((c == q) ? 1.0 : 0.0);
-    bool bad = false; int badcol = 0;
+    double Dinv[8];
+    const int badcol = pf_factor_block(D, Dinv);
+    if(badcol >= 0) atomicMin(info, col0 + c0 + badcol);
 #pragma unroll
     for(int c = 0; c < 8; c++)
     {
-      double d = D[c][c];
-#pragma unroll
-      for(int q = 0; q < c; q++) d -= D[c][q]*D[c][q];
-      if(!(d > 0.0)) { if(!bad) { bad = true; badcol = c; } d = 1.0; }
-      const double inv = dlg_rsqrt(d);
-      const double piv = d*inv;
-      D[c][c] = piv;
-#pragma unroll
-      for(int i = c + 1; i < 8; i++)
-      {
-        double v = D[i][c];
-#pragma unroll
-        for(int q = 0; q < c; q++) v -= D[i][q]*D[c][q];
-        D[i][c] = v*inv;
-      }
-    }
-    if(bad) atomicMin(info, col0 + c0 + badcol);
-#pragma unroll
-    for(int c = 0; c < 8; c++)
+      if(c < nb) rdiag[c0 + c] = Dinv[c];
 #pragma unroll
       for(int q = 0; q <= c; q++) if(c < nb) P[(c0 + c) + (c0 + q)*ldp] = D[c][q];
+    }
   }
   __syncthreads();
   for(int r = w + tid; r < nrows; r += NT)
   {
     for(int m = 0; m < nmem; m++)
     {
-      const int c0 = mcol[m], nb = ((m + 1 < nmem) ? mcol[m+1] : w) - c0;
+      const int c0 = mcol[m], nb = mcol[m+1] - c0;
       double x[8];
 #pragma unroll
       for(int c = 0; c < 8; c++) x[c] = (c < nb) ? P[r + (c0 + c)*ldp] : 0.0;
@@ -425,7 +415,7 @@ __device__ __forceinline__ void panel_factor_blockdiag(double* P, int ldp, int n
           double v = x[c];
 #pragma unroll
           for(int q = 0; q < c; q++) v -= x[q]*P[(c0 + c) + (c0 + q)*ldp];
-          x[c] = v/P[(c0 + c) + (c0 + c)*ldp];
+          x[c] = v*rdiag[c0 + c];
         }
       }
 #pragma unroll
