@@ -368,6 +368,59 @@ __device__ __forceinline__ void panel_factor(double* P, int ldp, int nrows, int 
 // [mcol[m], mcol[m+1]) (at most 8).  The members do not couple, so there is no sweep:
 //   A: thread m factors the diagonal block of member m in registers (<= 8x8);
 //   B: after one barrier every below row solves against each member's block.
+// member block of NB columns (compile-time width: no predicated 8-wide code for 3-wide points)
+template <int NB>
+__device__ __forceinline__ int bd_factor_member(double* P, int ldp, int c0, double* rdiag)
+{
+  double D[NB][NB];
+#pragma unroll
+  for(int c = 0; c < NB; c++)
+#pragma unroll
+    for(int q = 0; q <= c; q++) D[c][q] = P[(c0 + c) + (c0 + q)*ldp];
+  int badcol = -1;
+#pragma unroll
+  for(int c = 0; c < NB; c++)
+  {
+    double d = D[c][c];
+    if(!(d > 0.0)) { if(badcol < 0) badcol = c; d = 1.0; }
+    const double inv = dlg_rsqrt(d);
+    rdiag[c0 + c] = inv;
+#pragma unroll
+    for(int i = c + 1; i < NB; i++) D[i][c] *= inv;
+#pragma unroll
+    for(int j = c + 1; j < NB; j++)
+#pragma unroll
+      for(int i = j; i < NB; i++) D[i][j] -= D[i][c]*D[j][c];
+    D[c][c] = d*inv;
+  }
+#pragma unroll
+  for(int c = 0; c < NB; c++)
+#pragma unroll
+    for(int q = 0; q <= c; q++) P[(c0 + c) + (c0 + q)*ldp] = D[c][q];
+  return badcol;
+}
+template <int NB>
+__device__ __forceinline__ void bd_solve_row(double* P, int ldp, int r, int c0, const double* rdiag)
+{
+  double x[NB], Lm[NB][NB], rd[NB];
+#pragma unroll
+  for(int c = 0; c < NB; c++)
+  {
+    x[c] = P[r + (c0 + c)*ldp]; rd[c] = rdiag[c0 + c];
+#pragma unroll
+    for(int q = 0; q < c; q++) Lm[c][q] = P[(c0 + c) + (c0 + q)*ldp];
+  }
+#pragma unroll
+  for(int c = 0; c < NB; c++)
+  {
+    double v = x[c];
+#pragma unroll
+    for(int q = 0; q < c; q++) v -= x[q]*Lm[c][q];
+    x[c] = v*rd[c];
+  }
+#pragma unroll
+  for(int c = 0; c < NB; c++) P[r + (c0 + c)*ldp] = x[c];
+}
 template <int NT>
 __device__ __forceinline__ void panel_factor_blockdiag(double* P, int ldp, int nrows, int w, int tid,
                                                        const int* __restrict__ mcol_g, int nmem,
@@ -381,45 +434,37 @@ __device__ __forceinline__ void panel_factor_blockdiag(double* P, int ldp, int n
   for(int m = tid; m < nmem; m += NT)
   {
     const int c0 = mcol[m], nb = mcol[m+1] - c0;
-    double D[8][8];
-#pragma unroll
-    for(int c = 0; c < 8; c++)
-#pragma unroll
-      for(int q = 0; q <= c; q++)
-        D[c][q] = (c < nb) ? P[(c0 + c) + (c0 + q)*ldp] : ((c == q) ? 1.0 : 0.0);
-    double Dinv[8];
-    const int badcol = pf_factor_block(D, Dinv);
-    if(badcol >= 0) atomicMin(info, col0 + c0 + badcol);
-#pragma unroll
-    for(int c = 0; c < 8; c++)
+    int badcol;
+    switch(nb)
     {
-      if(c < nb) rdiag[c0 + c] = Dinv[c];
-#pragma unroll
-      for(int q = 0; q <= c; q++) if(c < nb) P[(c0 + c) + (c0 + q)*ldp] = D[c][q];
+      case 1: badcol = bd_factor_member<1>(P, ldp, c0, rdiag); break;
+      case 2: badcol = bd_factor_member<2>(P, ldp, c0, rdiag); break;
+      case 3: badcol = bd_factor_member<3>(P, ldp, c0, rdiag); break;
+      case 4: badcol = bd_factor_member<4>(P, ldp, c0, rdiag); break;
+      case 5: badcol = bd_factor_member<5>(P, ldp, c0, rdiag); break;
+      case 6: badcol = bd_factor_member<6>(P, ldp, c0, rdiag); break;
+      case 7: badcol = bd_factor_member<7>(P, ldp, c0, rdiag); break;
+      default: badcol = bd_factor_member<8>(P, ldp, c0, rdiag); break;
     }
+    if(badcol >= 0) atomicMin(info, col0 + c0 + badcol);
   }
   __syncthreads();
   for(int r = w + tid; r < nrows; r += NT)
   {
     for(int m = 0; m < nmem; m++)
     {
-      const int c0 = mcol[m], nb = mcol[m+1] - c0;
-      double x[8];
-#pragma unroll
-      for(int c = 0; c < 8; c++) x[c] = (c < nb) ? P[r + (c0 + c)*ldp] : 0.0;
-#pragma unroll
-      for(int c = 0; c < 8; c++)
+      const int c0 = mcol[m], nb = mcol[m+1] - c0;        // uniform over the workgroup
+      switch(nb)
       {
-        if(c < nb)
-        {
-          double v = x[c];
-#pragma unroll
-          for(int q = 0; q < c; q++) v -= x[q]*P[(c0 + c) + (c0 + q)*ldp];
-          x[c] = v*rdiag[c0 + c];
-        }
+        case 1: bd_solve_row<1>(P, ldp, r, c0, rdiag); break;
+        case 2: bd_solve_row<2>(P, ldp, r, c0, rdiag); break;
+        case 3: bd_solve_row<3>(P, ldp, r, c0, rdiag); break;
+        case 4: bd_solve_row<4>(P, ldp, r, c0, rdiag); break;
+        case 5: bd_solve_row<5>(P, ldp, r, c0, rdiag); break;
+        case 6: bd_solve_row<6>(P, ldp, r, c0, rdiag); break;
+        case 7: bd_solve_row<7>(P, ldp, r, c0, rdiag); break;
+        default: bd_solve_row<8>(P, ldp, r, c0, rdiag); break;
       }
-#pragma unroll
-      for(int c = 0; c < 8; c++) if(c < nb) P[r + (c0 + c)*ldp] = x[c];
     }
   }
   __syncthreads();

@@ -13,6 +13,7 @@ __shared__ long long s_pf[8];
 #define DLG_PF_DONE if(threadIdx.x == 0 && g_pf_out) { for(int _i = 0; _i < 6; _i++) g_pf_out[_i] = s_pf[_i]; }
 #include "../../libdogleg_amd/csrc/panel_factor.h"
 
+__device__ int g_mcol[256];
 template <int NT, int MODE>
 __global__ void __launch_bounds__(NT) k_panel(double* G, int nrows, int w, int* info, long long* stamps)
 {
@@ -33,6 +34,7 @@ __global__ void __launch_bounds__(NT) k_panel(double* G, int nrows, int w, int* 
   long long t1 = clock64();
   if(MODE == 0) panel_factor<NT, true>(P, ldp, nrows, w, tid, info, 0);
   if(MODE == 1) { if(blockIdx.x == 0 && tid == 0) g_pf_out = stamps + 4; panel_factor<NT, true>(P, ldp, nrows, w, tid, info, 0); }
+  if(MODE == 4) panel_factor_blockdiag<NT>(P, ldp, nrows, w, tid, g_mcol, w/3, info, 0);
   if(MODE == 2) { if(NT >= 256) panel_factor_mfma<(NT >= 256 ? NT : 256)>(P, ldp, nrows, w, tid, info, 0); else if(NT >= 256) panel_factor_mfma<(NT >= 256 ? NT : 256)>(P, ldp, nrows, w, tid, info, 0); else panel_factor<NT, true, true>(P, ldp, nrows, w, tid, info, 0); }
   if(MODE == 3) { if(blockIdx.x == 0 && tid == 0) g_pf_out = stamps + 4; if(NT >= 256) panel_factor_mfma<(NT >= 256 ? NT : 256)>(P, ldp, nrows, w, tid, info, 0); else panel_factor<NT, true, true>(P, ldp, nrows, w, tid, info, 0); }
   __syncthreads();
@@ -93,9 +95,41 @@ void run(int nrows, int w, int G, int iters)
   hipFree(d); hipFree(info); hipFree(st);
 }
 
+template <int NT>
+void run_bd(int nrows, int w, int G, int iters)
+{
+  const size_t n = (size_t)nrows*w;
+  std::vector<double> h(n*G);
+  for(int b = 0; b < G; b++)
+    for(int j = 0; j < w; j++)
+      for(int i = 0; i < nrows; i++)
+        h[b*n + i + (size_t)j*nrows] = (i == j) ? (double)(w + 1) : ((i < w) ? ((i/3 == j/3 && i > j) ? 0.2 : 0.0) : 0.3*sin(0.37*i + 1.3*j));
+  std::vector<int> mc(256); for(int m = 0; m < 256; m++) mc[m] = 3*m;
+  hipMemcpyToSymbol(HIP_SYMBOL(g_mcol), mc.data(), 256*4);
+  double* d; int* info; long long* st;
+  hipMalloc(&d, n*G*8); hipMalloc(&info, 4); hipMalloc(&st, 128);
+  const int lds = (int)(((nrows + 1) & ~1)*w*8);
+  hipFuncSetAttribute(reinterpret_cast<const void*>(&k_panel<NT, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  float best = 1e9;
+  for(int rep = 0; rep < 3; rep++)
+  {
+    hipMemcpy(d, h.data(), n*G*8, hipMemcpyHostToDevice);
+    hipEventRecord(e0);
+    for(int it = 0; it < iters; it++) { hipLaunchKernelGGL(HIP_KERNEL_NAME(k_panel<NT, 4>), dim3(G), dim3(NT), lds, 0, d, nrows, w, info, st); }
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1); if(ms < best) best = ms;
+  }
+  long long hs[3]; hipMemcpy(hs, st, 24, hipMemcpyDeviceToHost);
+  printf("blockdiag NT=%d nrows=%d w=%d G=%d: %.1f us/launch   cycles load %lld factor %lld store %lld\n", NT, nrows, w, G,
+         best*1e3/iters, hs[0], hs[1], hs[2]);
+  hipFree(d); hipFree(info); hipFree(st);
+}
+
 int main(int argc, char** argv)
 {
   const int G = argc > 1 ? atoi(argv[1]) : 64;
+  run_bd<256>(124, 51, G, 20); run_bd<128>(124, 51, G, 20); run_bd<256>(124, 51, 2489, 20); run_bd<128>(124, 51, 2489, 20);
   run<512>(170, 96, G, 20); run<256>(170, 96, G, 20); run<128>(170, 96, G, 20);
   run<256>(128, 64, G, 20); run<256>(250, 48, G, 20); run<128>(100, 24, G, 20);
   return 0;
