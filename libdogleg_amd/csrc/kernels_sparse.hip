@@ -989,21 +989,54 @@ __global__ void __launch_bounds__(TPB) k_update_gather(int unit0, const int* __r
   if(w < nw)
   {
     double* acc = lds + (size_t)w*slab;
-    for(int st = s0 + w; st < s1; st += nw)
+    // the records of this wave's sub-tasks (s0 + w, s0 + w + nw, ...): lane l fetches record l of
+    // the current batch of 64 with one load per field, the loop broadcasts them with readlane;
+    // two sub-tasks are in flight at a time
+    const int nmine = (s1 - s0 - w + nw - 1)/nw;
+    for(int k0 = 0; k0 < nmine; k0 += 64)
     {
-      const SymSub S = usub[st];
-      const double* U = uscr + usub_u[st];
-      const int* rel = relpos + S.rel;
-      const int mb = S.nrows_d - S.wd;
-      for(int i = lane; i < S.m; i += 64)
+      const int stl = s0 + w + (k0 + min(lane, nmine - k0 - 1))*nw;
+      const SymSub R = usub[stl];
+      const int64_t ru = usub_u[stl];
+      const int r_rel = R.rel, r_mb = R.nrows_d - R.wd, r_m = R.m;
+      const int r_ulo = (int)(uint32_t)ru, r_uhi = (int)(ru >> 32);
+      const int nb = min(64, nmine - k0);
+      for(int k = 0; k < nb; k += 2)
       {
-        const int cmax = (i < nc - 1) ? i : nc - 1;
-        const int r = rel[i];
-        double v[8];
+        const int ka = k, kb = min(k + 1, nb - 1);
+        const bool two = k + 1 < nb;
+        const int relA = __builtin_amdgcn_readlane(r_rel, ka), relB = __builtin_amdgcn_readlane(r_rel, kb);
+        const int mbA = __builtin_amdgcn_readlane(r_mb, ka), mbB = __builtin_amdgcn_readlane(r_mb, kb);
+        const int mA = __builtin_amdgcn_readlane(r_m, ka), mB = two ? __builtin_amdgcn_readlane(r_m, kb) : 0;
+        const double* UA = uscr + (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readlane(r_uhi, ka) << 32) | (uint32_t)__builtin_amdgcn_readlane(r_ulo, ka));
+        const double* UB = uscr + (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readlane(r_uhi, kb) << 32) | (uint32_t)__builtin_amdgcn_readlane(r_ulo, kb));
+        for(int i0 = 0; i0 < max(mA, mB); i0 += 64)
+        {
+          const int i = i0 + lane;
+          const int cmax = (i < nc - 1) ? i : nc - 1;
+          const int iA = min(i, mA - 1), iB = min(i, max(mB, 1) - 1);
+          const int rA = relpos[relA + iA], rB = relpos[relB + iB];
+          double vA[8], vB[8];
 #pragma unroll
-        for(int c = 0; c < 8; c++) v[c] = (c <= cmax) ? U[i + (size_t)c*mb] : 0.0;
+          for(int c = 0; c < 8; c++)
+            if(c < nc)
+            {
+              const int cc = min(c, cmax);          // entries above the diagonal are never written
+              vA[c] = UA[iA + (size_t)cc*mbA]; vB[c] = UB[iB + (size_t)cc*mbB];
+            }
 #pragma unroll
-        for(int c = 0; c < 8; c++) if(c <= cmax) acc[r + c*nrows_t] += v[c];
+          for(int c = 0; c < 8; c++)
+            if(c < nc)
+            {
+              if(i < mA && c <= cmax) acc[rA + c*nrows_t] += vA[c];
+            }
+#pragma unroll
+          for(int c = 0; c < 8; c++)
+            if(c < nc)
+            {
+              if(i < mB && c <= cmax) acc[rB + c*nrows_t] += vB[c];
+            }
+        }
       }
     }
   }

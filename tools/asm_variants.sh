@@ -1,5 +1,4 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
-timeout 300 tools/micro/bench_panel 1 | head -4
 timeout 600 python -m pytest tests -x -q -m gpu 2>&1 | tail -3
 for i in 1 2; do timeout 300 python bench.py --no-cpu-baseline --steps 30 --warmup 3 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['phases_ms_per_step'])"; done
