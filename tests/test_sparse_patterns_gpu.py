@@ -133,3 +133,18 @@ def test_block_sizes_around_the_limits(gpu):
     x = rng.standard_normal(M)
     st = _check_pattern(N, M, Jp, Ji, Jx, x, tol=1e-8)
     print("block limits:", st)
+
+
+def test_wide_dense_tail(gpu):
+    """2560 variables that every row touches (rows of 320 variable blocks): target slabs too big
+    for LDS (HBM-accumulating update path), panels cut into many row slices, a long chain of
+    supernodes, the LDS assembly kernel with hundreds of blocks per row"""
+    rng = np.random.default_rng(8)
+    N, M = 2560, 2700
+    Jp = np.arange(0, (M + 1) * N, N, dtype=np.int64).astype(np.int32)
+    Ji = np.tile(np.arange(N, dtype=np.int32), M)
+    Jx = rng.standard_normal(M * N)
+    Jx[::N + 1] += 30.0          # make JtJ comfortably positive definite
+    x = rng.standard_normal(M)
+    st = _check_pattern(N, M, Jp, Ji, Jx, x, tol=1e-7)
+    print("wide dense tail:", st)
