@@ -511,7 +511,18 @@ __global__ void __launch_bounds__(TPB) k_assemble_fin2_short(const AsmFin2* __re
   const AsmFin2 F = fins[f];
   if(lane >= F.nI*F.nJ) return;
   double s = 0.0;
-  for(int k = 0; k < F.nlist; k++) s += part[list[F.list0 + k] + lane];
+  // 8 partials in flight, added in list order
+  for(int k0 = 0; k0 < F.nlist; k0 += 8)
+  {
+    int64_t off[8];
+    double v[8];
+#pragma unroll
+    for(int u = 0; u < 8; u++) off[u] = list[F.list0 + min(k0 + u, F.nlist - 1)];
+#pragma unroll
+    for(int u = 0; u < 8; u++) v[u] = part[off[u] + lane];
+#pragma unroll
+    for(int u = 0; u < 8; u++) if(k0 + u < F.nlist) s += v[u];
+  }
   fin2_store(F, lane, s, Lx, part);
 }
 __global__ void __launch_bounds__(1024) k_assemble_fin2_long(const AsmFin2* __restrict__ fins,
@@ -523,7 +534,17 @@ __global__ void __launch_bounds__(1024) k_assemble_fin2_long(const AsmFin2* __re
   const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
   double s = 0.0;
   if(lane < F.nI*F.nJ)
-    for(int k = g; k < F.nlist; k += 16) s += part[list[F.list0 + k] + lane];
+    for(int k0 = g; k0 < F.nlist; k0 += 64)
+    {
+      int64_t off[4];
+      double v[4];
+#pragma unroll
+      for(int u = 0; u < 4; u++) off[u] = list[F.list0 + min(k0 + 16*u, F.nlist - 1)];
+#pragma unroll
+      for(int u = 0; u < 4; u++) v[u] = part[off[u] + lane];
+#pragma unroll
+      for(int u = 0; u < 4; u++) if(k0 + 16*u < F.nlist) s += v[u];
+    }
   sh[threadIdx.x] = s;
   __syncthreads();
   if(g == 0 && lane < F.nI*F.nJ)
