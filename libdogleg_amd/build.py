@@ -29,10 +29,11 @@ def headers():
     return hs
 
 
-# per-source extra flags.  kernels_sparse.hip: its fp64 MFMA loops keep few accumulators; with the
+# per-source extra flags.  The sparse assembly and factor kernels: their fp64 MFMA loops keep few accumulators; with the
 # default heuristic the compiler parks them in AGPRs and copies all of them to VGPRs and back in
 # every loop iteration, the VGPR form of the instruction avoids that.
-EXTRA = {"kernels_sparse.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
+_VGPR_MFMA = ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]
+EXTRA = {"sparse_assemble.hip": _VGPR_MFMA, "sparse_factor.hip": _VGPR_MFMA}
 
 
 def _compile(src, newest_hdr, verbose):

@@ -149,7 +149,7 @@ int dense_solve(dlg_backend* b, const double* rhs, double* out);                
 int products_quadform(dlg_backend* b, int slot, const double* v, double* out_dev);
 int products_factorize(dlg_backend* b, int slot, double lambda, int* ok);
 
-// ------------------------------------------------------ kernels_sparse.hip --
+// ------------------- sparse_host.hip / sparse_assemble.hip / sparse_solve.hip --
 int sparse_create(dlg_backend* b);
 size_t sparse_local_nnz(const dlg_backend* b);   // J values held by this rank
 void sparse_destroy(dlg_backend* b);

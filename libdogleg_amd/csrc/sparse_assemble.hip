@@ -1,0 +1,745 @@
+// sparse_assemble.hip -- the kernels that read the Jacobian (DOGLEG_SPARSE, gfx950):
+//   K1  Jt_x = Jt*x            replaces mul_spmatrix_densevector        (dogleg.c:249-261)
+//   K3/K8  |J v|^2             replaces norm2_mul_spmatrix_t_densevector (dogleg.c:262-281)
+//   K4  JtJ assembly           (CHOLMOD forms A*A' internally: dogleg.c:659-664)
+// See sparse_internal.h for the layout and the determinism rules.
+#include "sparse_internal.h"
+
+namespace {
+
+// ------------------------------------------------------------ K4 assembly ---
+// Column-block centric JtJ assembly.  One wave per task; a task owns a group of
+// output blocks (I,J) of one column block J ("slots", accumulated in LDS) and
+// walks the row-blocks containing J in batches.  Per batch the Jacobian rows
+// are staged in LDS once (coalesced segment copies) and every row-block then
+// feeds all its slots at once: lanes = flattened (pair, a, b),
+//     acc[slot(I)][a][b] += sum_k J[k][offI+a] * J[k][offJ+b].
+// Single-task groups store straight into the supernode panels; groups split
+// over several tasks (very long lists: a block every row touches) store
+// partial accumulators that k_assemble_fin adds in task order.
+// Everything a wave shares goes through LDS in program order (same wave), so
+// no barriers are needed and waves of a workgroup are independent.
+constexpr int ASM_STAGE = 512, ASM_ACC = 256, ASM_RHO = 32, ASM_PAIRS = 256;
+
+struct AsmWaveLds
+{
+  double  stage[ASM_STAGE];
+  double  acc[ASM_ACC];
+  AsmRho  rho[ASM_RHO + 1];
+  AsmPair pair[ASM_PAIRS];
+};
+
+__global__ void __launch_bounds__(TPB) k_assemble(const AsmTask* __restrict__ tasks, int ntasks,
+                                                  const AsmBatch* __restrict__ batches,
+                                                  const AsmRho* __restrict__ rho,
+                                                  const AsmPair* __restrict__ pairs,
+                                                  const AsmSlot* __restrict__ slots,
+                                                  const double* __restrict__ vals,
+                                                  double* __restrict__ Lx, double* __restrict__ part)
+{
+  __shared__ __attribute__((aligned(16))) AsmWaveLds sh[TPB/64];
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(blockIdx.x*(TPB/64) + w);
+  if(wid >= ntasks) return;
+  AsmWaveLds& S = sh[w];
+  const AsmTask T = tasks[wid];
+  const int nJ = T.nJ;
+  for(int e = lane; e < T.acc_size; e += 64) S.acc[e] = 0.0;
+  // uniform tasks (every row-block has the same sequence of block sizes, <= 128 products):
+  // the lane -> (pair ordinal, a, b) map is computed once for the whole task
+  const bool uniform = T.pad != 0;
+  int uj[2] = {-1, -1}, ua[2] = {0, 0}, ub[2] = {0, 0}, uidx[2] = {0, 0};
+  if(uniform && T.batch0 < T.batch1)
+  {
+    const int rfirst = batches[T.batch0].rho0;
+    const int q0 = rho[rfirst].pair0, q1 = rho[rfirst + 1].pair0;
+#pragma unroll
+    for(int u = 0; u < 2; u++)
+    {
+      const int tgt = lane + 64*u;
+      int cum = 0;
+      for(int p = q0; p < q1; p++)
+      {
+        const int ni = (pairs[p].acc_nI >> 12) + 1, n = ni*nJ;
+        if(tgt >= cum && tgt < cum + n)
+        {
+          const int idx = tgt - cum;
+          uj[u] = p - q0; uidx[u] = idx; ub[u] = idx / ni; ua[u] = idx - ub[u]*ni;
+        }
+        cum += n;
+      }
+    }
+  }
+  for(int bt = T.batch0; bt < T.batch1; bt++)
+  {
+    const AsmBatch B = batches[bt];
+    const int nr = B.rho1 - B.rho0;
+    // (a) the batch's row-block records (+ the one that closes the last pair list): one load
+    if(lane <= nr) S.rho[lane] = rho[B.rho0 + lane];
+    __builtin_amdgcn_wave_barrier();
+    const int P0 = S.rho[0].pair0, np = S.rho[nr].pair0 - P0;
+    // (b) pairs + values of the whole batch, all loads issued before the first LDS store
+    {
+      AsmPair pv[ASM_PAIRS/64];
+#pragma unroll
+      for(int u = 0; u < ASM_PAIRS/64; u++) if(lane + 64*u < np) pv[u] = pairs[P0 + lane + 64*u];
+      for(int rb = 0; rb < nr; rb += 16)
+      {
+        double v[16];
+#pragma unroll
+        for(int u = 0; u < 16; u++)
+        {
+          v[u] = 0.0;
+          if(rb + u < nr)
+          {
+            const AsmRho R = S.rho[rb + u];
+            if(R.stage_off != 0xFFFF && lane < R.nrows*R.len) v[u] = vals[R.base + lane];
+          }
+        }
+#pragma unroll
+        for(int u = 0; u < 16; u++)
+          if(rb + u < nr)
+          {
+            const AsmRho R = S.rho[rb + u];
+            if(R.stage_off != 0xFFFF && lane < R.nrows*R.len) S.stage[R.stage_off + lane] = v[u];
+          }
+      }
+      // segments longer than one wave-load (rare: long rows)
+      for(int r = 0; r < nr; r++)
+      {
+        const AsmRho R = S.rho[r];
+        if(R.stage_off == 0xFFFF) continue;
+        const int cnt = R.nrows*R.len;
+        for(int e = 64 + lane; e < cnt; e += 64) S.stage[R.stage_off + e] = vals[R.base + e];
+      }
+#pragma unroll
+      for(int u = 0; u < ASM_PAIRS/64; u++) if(lane + 64*u < np) S.pair[lane + 64*u] = pv[u];
+    }
+    __builtin_amdgcn_wave_barrier();
+    // (c) every row-block feeds all its slots at once
+    if(uniform)
+    {
+      for(int r = 0; r < nr; r++)
+      {
+        const AsmRho R = S.rho[r];
+        const int p0 = R.pair0 - P0;
+#pragma unroll
+        for(int u = 0; u < 2; u++)
+        {
+          if(uj[u] < 0) continue;
+          const AsmPair P = S.pair[p0 + uj[u]];
+          double sum = 0.0;
+          if(R.stage_off != 0xFFFF)
+          {
+            const double* row = S.stage + R.stage_off;
+            for(int k = 0; k < R.nrows; k++, row += R.len) sum += row[P.offI + ua[u]]*row[R.offJ + ub[u]];
+          }
+          else
+          {
+            const double* row = vals + R.base;
+            for(int k = 0; k < R.nrows; k++, row += R.len) sum += row[P.offI + ua[u]]*row[R.offJ + ub[u]];
+          }
+          S.acc[(P.acc_nI & 0xFFF) + uidx[u]] += sum;
+        }
+      }
+    }
+    else
+    for(int r = 0; r < nr; r++)
+    {
+      const AsmRho R = S.rho[r];
+      const int p0 = R.pair0 - P0, p1 = S.rho[r+1].pair0 - P0;
+      int total = 0;
+      for(int p = p0; p < p1; p++) total += ((S.pair[p].acc_nI >> 12) + 1)*nJ;
+      for(int base = 0; base < total; base += 64)
+      {
+        const int tgt = base + lane;
+        int cum = 0, idx = -1, nI = 1, offI = 0, accoff = 0;
+        for(int p = p0; p < p1; p++)
+        {
+          const AsmPair P = S.pair[p];
+          const int ni = (P.acc_nI >> 12) + 1, n = ni*nJ;
+          if(tgt >= cum && tgt < cum + n) { idx = tgt - cum; nI = ni; offI = P.offI; accoff = P.acc_nI & 0xFFF; }
+          cum += n;
+        }
+        if(idx >= 0)
+        {
+          const int b = idx / nI, a = idx - b*nI;
+          double sum = 0.0;
+          if(R.stage_off != 0xFFFF)
+          {
+            const double* row = S.stage + R.stage_off;
+            for(int k = 0; k < R.nrows; k++, row += R.len) sum += row[offI + a]*row[R.offJ + b];
+          }
+          else
+          {
+            const double* row = vals + R.base;
+            for(int k = 0; k < R.nrows; k++, row += R.len) sum += row[offI + a]*row[R.offJ + b];
+          }
+          S.acc[accoff + idx] += sum;
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  // write out
+  for(int sidx = 0; sidx < T.nslots; sidx++)
+  {
+    const AsmSlot SL = slots[T.slot0 + sidx];
+    const int n = SL.nI*nJ;
+    for(int idx = lane; idx < n; idx += 64)
+    {
+      const double v = S.acc[SL.accoff + idx];
+      if(T.part < 0)
+      {
+        const int b = idx / SL.nI, a = idx - b*SL.nI;
+        if(!SL.diag || a >= b) Lx[SL.dest + a + (int64_t)b*SL.ld] = v;
+      }
+      else part[T.part + SL.accoff + idx] = v;
+    }
+  }
+}
+// MFMA assembly of the column blocks whose row-blocks all share one layout (AsmShape).
+// One wave per task, no LDS.  Per k-group (4 Jacobian rows) a lane gathers three values
+// of its row k = lane>>4: the persistent and the transient output row m = lane&15
+// (A operands, A[m][k]) and the column-block entry b = (lane&15) % nJ (B operand,
+// B[k][n]); v_mfma_f64_16x16x4_f64 then gives D[m][n] += sum_k A[m][k] B[k][n].
+//   persistent:  n = b,            every row of the task sums into the same D
+//   transient:   n = slot*nJ + b,  B is masked to the rows of row-block `slot`, so each
+//                row-block of the k-group gets its own columns; D is stored and cleared
+typedef double dlg_v4d __attribute__((ext_vector_type(4)));
+#ifndef DLG_ASM_U
+#define DLG_ASM_U 4
+#endif
+constexpr int ASM_U = DLG_ASM_U;
+// One wave per RUN = consecutive tasks of one shape whose k-groups are contiguous: the shape's
+// lane constants are loaded once and the k-group stream is software-pipelined across the
+// task boundaries (bit 12 of a k-group's meta: last of its task -> store the persistent blocks,
+// move on to the next task record, which was fetched ahead).
+// Per k-group the wave copies the needed window of its 4 rows into a wave-private LDS tile with
+// one coalesced load (lane = (row, column)), then every lane picks its A/B operands from the
+// tile: the vector-memory pipe sees one load per k-group instead of one per operand.  The
+// k-group records are wave-uniform (scalar loads), fetched one iteration ahead.  All loads are
+// unconditional with clamped addresses (absent rows read element 0 and are zeroed afterwards):
+// the loop body is straight-line code, the only branches are uniform.
+template <bool HAS_T>
+__device__ __forceinline__ void asm_mfma_run(const AsmRun& R, const AsmMTask* __restrict__ tasks,
+                                             const AsmShape* __restrict__ SH,
+                                             const AsmKG* __restrict__ kgs, const int* __restrict__ tdest,
+                                             const int* __restrict__ pdest, const double* __restrict__ vals,
+                                             double* __restrict__ Lx, double* __restrict__ part, int lane,
+                                             double* __restrict__ tile, int LEN)
+{
+  const int m = lane & 15, kq = lane >> 4;
+  const int nJ = SH->nJ, MP = SH->MP, MT = SH->MT, nT = SH->nT, nJr = SH->nJr;
+  const int col0 = SH->col0, ncopy = SH->ncopy, dslot = SH->dslot, rslot = SH->rslot;
+  const int bs = m / nJ, bb = m - bs*nJ;
+  // Tile columns this lane reads its operands from.  Column ZC of every tile row is zero: lanes
+  // without a persistent / transient row, B columns outside the product and rows of another
+  // row-block slot read it instead of being masked afterwards.
+  const int ZC = LEN - 2;
+  const bool pn = m < nJ + nJr;
+  int pc = SH->pcol[m];            pc = pc >= 0 ? pc : ZC;
+  int tc = HAS_T ? SH->tcol[m] : -1; tc = tc >= 0 ? tc : ZC;
+  const int bcol = SH->offJ + bb;   // B column of the transient product (this lane's slot only)
+  // B column of the persistent product: J's columns, then the rider's (if any)
+  const int bcolP = m < nJ ? SH->offJ + m : (pn ? SH->offR + (m - nJ) : ZC);
+  // rows m' = kq + 4r of D this lane holds: transient (ordinal, row in block), persistent
+  // (slot ordinal, row in block, offset in a partial, rows of the block)
+  // (packed: these are only needed when something is stored)
+  uint32_t pk1[4], pk2[4];
+#pragma unroll
+  for(int r = 0; r < 4; r++)
+  {
+    const int mm = kq + 4*r;
+    const uint32_t tjv = HAS_T ? SH->tj[mm] : 0xFF, tav = HAS_T ? SH->ta[mm] : 0;
+    const uint32_t psv = mm < MP ? SH->pslot[mm] : 0xFF;
+    pk1[r] = tjv | tav << 8 | psv << 16 | (uint32_t)SH->pa[mm] << 24;
+    pk2[r] = (uint32_t)SH->paccoff[mm] | (uint32_t)SH->pnI[mm] << 8;
+  }
+#define TJ(r)  (int)(pk1[r] & 0xFF)
+#define TA(r)  (int)((pk1[r] >> 8) & 0xFF)
+#define PS(r)  (int)((pk1[r] >> 16) & 0xFF)
+#define PA(r)  (int)(pk1[r] >> 24)
+#define PAO(r) (int)(pk2[r] & 0xFF)
+#define PNI(r) (int)(pk2[r] >> 8)
+  dlg_v4d accP = {0.0, 0.0, 0.0, 0.0}, accT = {0.0, 0.0, 0.0, 0.0};
+  // task records: current + next (fetched ahead, as ONE vector load each: lane l holds dword l of
+  // the record, fields are broadcast with readlane; vector loads return in order, so prefetches
+  // overlap with the rest -- scalar loads would share a counter with the LDS traffic);
+  // persistent destinations of both (16 per task)
+  const int tlast = R.task1 - 1;
+  int tix = R.task0;
+  auto task_fetch = [&](int t) { return reinterpret_cast<const int*>(tasks + min(t, tlast))[min(lane, 11)]; };
+  int tcv = task_fetch(tix), tnv = task_fetch(tix + 1);
+  int pdc = pdest[16*(int64_t)min(tix, tlast) + m], pdn = pdest[16*(int64_t)min(tix + 1, tlast) + m];
+  int64_t Tpart, Trpart, colT, colP;     // current task: partial offsets; Lx offset of this lane's column
+  auto task_unpack = [&](int v) {
+    const int ld = __builtin_amdgcn_readlane(v, 4);
+    const int64_t panel = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readlane(v, 7) << 32) | (uint32_t)__builtin_amdgcn_readlane(v, 6));
+    Tpart  = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readlane(v, 9) << 32) | (uint32_t)__builtin_amdgcn_readlane(v, 8));
+    Trpart = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readlane(v, 11) << 32) | (uint32_t)__builtin_amdgcn_readlane(v, 10));
+    colT = panel + (int64_t)bb*ld; colP = panel + (int64_t)m*ld; };
+  task_unpack(tcv);
+  // k-group records of one iteration: ASM_U*6 dwords, one vector load, prefetched one iteration ahead
+  static_assert(ASM_U*6 <= 64, "k-group records of an iteration must fit one wave load");
+  const int kglast = R.kg1 - 1;
+  const int krec = min(lane, ASM_U*6 - 1)/6, kw = min(lane, ASM_U*6 - 1) - 6*krec;
+  auto kg_fetch = [&](int kg0) { return reinterpret_cast<const int*>(kgs + min(kg0 + krec, kglast))[kw]; };
+  int gnv = kg_fetch(R.kg0);
+  double* myrow = tile + kq*LEN;
+#pragma unroll
+  for(int u = 0; u < ASM_U; u++) myrow[u*4*LEN + ZC] = 0.0;
+  for(int kg = R.kg0; kg < R.kg1; kg += ASM_U)
+  {
+    const int gv = gnv;
+    uint32_t meta[ASM_U];
+    int td[ASM_U];
+#pragma unroll
+    for(int u = 0; u < ASM_U; u++) meta[u] = kg + u <= kglast ? (uint32_t)__builtin_amdgcn_readlane(gv, 6*u + 5) : 0u;
+    // (a) one coalesced copy of the rows' windows into the tile (absent rows: zeros)
+    for(int c0 = 0; c0 < ncopy; c0 += 16)
+    {
+      double v[ASM_U];
+      int b[ASM_U];
+#pragma unroll
+      for(int u = 0; u < ASM_U; u++)
+      {
+        b[u] = __builtin_amdgcn_ds_bpermute(4*(6*u + kq), gv);
+        if(kg + u > kglast) b[u] = -1;
+        v[u] = vals[max(b[u], 0) + col0 + min(c0 + m, ncopy - 1)];
+      }
+#pragma unroll
+      for(int u = 0; u < ASM_U; u++) myrow[u*4*LEN + c0 + m] = b[u] >= 0 ? v[u] : 0.0;
+    }
+    if(HAS_T)
+    {
+#pragma unroll
+      for(int u = 0; u < ASM_U; u++)
+      {
+        // transient destinations of this k-group: entry `lane` of its list (slot-major)
+        const int nent = (int)((meta[u] >> 8) & 7)*nT;
+        td[u] = tdest[lane < nent ? __builtin_amdgcn_readlane(gv, 6*u + 4) + lane : 0];
+      }
+    }
+    gnv = kg_fetch(kg + ASM_U);
+    __builtin_amdgcn_wave_barrier();
+    // (b) operands from the tile, products
+#pragma unroll
+    for(int u = 0; u < ASM_U; u++)
+    {
+      const double* row = myrow + u*4*LEN;
+      accP = __builtin_amdgcn_mfma_f64_16x16x4f64(row[pc], row[bcolP], accP, 0, 0, 0);
+      if(HAS_T)
+      {
+        const int myslot = (meta[u] >> (2*kq)) & 3;
+        accT = __builtin_amdgcn_mfma_f64_16x16x4f64(row[tc], row[bs == myslot ? bcol : ZC], accT, 0, 0, 0);
+        if(meta[u] & (1u << 11))
+        {
+          const bool mine = bs < (int)((meta[u] >> 8) & 7);
+#pragma unroll
+          for(int r = 0; r < 4; r++)
+            if(4*r < MT)
+            {
+              const int ro = __builtin_amdgcn_ds_bpermute(4*(bs*nT + TJ(r)), td[u]);
+              if(mine && TJ(r) != 0xFF) Lx[colT + (ro + TA(r))] = accT[r];
+            }
+          accT = (dlg_v4d){0.0, 0.0, 0.0, 0.0};
+        }
+      }
+      if(meta[u] & (1u << 12))           // end of a task: its persistent blocks
+      {
+#pragma unroll
+        for(int r = 0; r < 4; r++)
+          if(4*r < MP)
+          {
+            const int ro = __builtin_amdgcn_ds_bpermute(4*PS(r), pdc);
+            if(PS(r) != 0xFF)
+            {
+              if(m < nJ)
+              {
+                if(Tpart < 0) { if(PS(r) != dslot || PA(r) >= m) Lx[colP + (ro + PA(r))] = accP[r]; }
+                else part[Tpart + (PAO(r) + m*PNI(r))] = accP[r];
+              }
+              else if(pn && PS(r) == rslot) part[Trpart + ((m - nJ)*nJr + PA(r))] = accP[r];
+            }
+          }
+        accP = (dlg_v4d){0.0, 0.0, 0.0, 0.0};
+        tix++;
+        task_unpack(tnv); pdc = pdn;
+        tnv = task_fetch(tix + 1);
+        pdn = pdest[16*(int64_t)min(tix + 1, tlast) + m];
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+#undef TJ
+#undef TA
+#undef PS
+#undef PA
+#undef PAO
+#undef PNI
+}
+#ifdef DLG_ASM_WPE
+#define ASM_WPE_ATTR __attribute__((amdgpu_waves_per_eu(DLG_ASM_WPE, DLG_ASM_WPE)))
+#else
+#define ASM_WPE_ATTR
+#endif
+__global__ void __launch_bounds__(TPB) ASM_WPE_ATTR k_assemble_mfma(const AsmRun* __restrict__ runs, int nruns,
+                                                       const AsmMTask* __restrict__ tasks,
+                                                       const AsmKG* __restrict__ kgs,
+                                                       const AsmShape* __restrict__ shapes,
+                                                       const int* __restrict__ tdest, const int* __restrict__ pdest,
+                                                       const double* __restrict__ vals,
+                                                       double* __restrict__ Lx, double* __restrict__ part, int LEN)
+{
+  extern __shared__ double asm_tiles[];
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(blockIdx.x*(TPB/64) + (threadIdx.x >> 6));
+  if(wid >= nruns) return;
+  const AsmRun R = runs[wid];
+  const AsmShape* SH = shapes + tasks[R.task0].shape;
+  double* tile = asm_tiles + (threadIdx.x >> 6)*(ASM_U*4*LEN);
+  if(SH->MT > 0) asm_mfma_run<true>(R, tasks, SH, kgs, tdest, pdest, vals, Lx, part, lane, tile, LEN);
+  else           asm_mfma_run<false>(R, tasks, SH, kgs, tdest, pdest, vals, Lx, part, lane, tile, LEN);
+}
+// persistent blocks written by several MFMA tasks: fixed-order sum of the listed partials.
+// k_assemble_fin2_short: one wave per block (lists of <= 32 partials);
+// k_assemble_fin2_long: one 1024-thread workgroup per block, 16 waves stride over the list
+__device__ __forceinline__ void fin2_store(const AsmFin2& F, int e, double v, double* __restrict__ Lx,
+                                           double* __restrict__ part)
+{
+  if(F.to_part) { part[F.dest + e] = v; return; }
+  const int b = e / F.nI, a = e - b*F.nI;
+  if(!F.diag || a >= b) Lx[F.dest + a + (int64_t)b*F.ld] = v;
+}
+__global__ void __launch_bounds__(TPB) k_assemble_fin2_short(const AsmFin2* __restrict__ fins, int nfins,
+                                                             const int64_t* __restrict__ list,
+                                                             double* part, double* __restrict__ Lx)
+{
+  const int lane = threadIdx.x & 63;
+  const int f = __builtin_amdgcn_readfirstlane(blockIdx.x*(TPB/64) + (threadIdx.x >> 6));
+  if(f >= nfins) return;
+  const AsmFin2 F = fins[f];
+  if(lane >= F.nI*F.nJ) return;
+  double s = 0.0;
+  // 8 partials in flight, added in list order
+  for(int k0 = 0; k0 < F.nlist; k0 += 8)
+  {
+    int64_t off[8];
+    double v[8];
+#pragma unroll
+    for(int u = 0; u < 8; u++) off[u] = list[F.list0 + min(k0 + u, F.nlist - 1)];
+#pragma unroll
+    for(int u = 0; u < 8; u++) v[u] = part[off[u] + lane];
+#pragma unroll
+    for(int u = 0; u < 8; u++) if(k0 + u < F.nlist) s += v[u];
+  }
+  fin2_store(F, lane, s, Lx, part);
+}
+__global__ void __launch_bounds__(1024) k_assemble_fin2_long(const AsmFin2* __restrict__ fins,
+                                                             const int64_t* __restrict__ list,
+                                                             double* part, double* __restrict__ Lx)
+{
+  __shared__ double sh[1024];
+  const AsmFin2 F = fins[blockIdx.x];
+  const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+  double s = 0.0;
+  if(lane < F.nI*F.nJ)
+    for(int k0 = g; k0 < F.nlist; k0 += 64)
+    {
+      int64_t off[4];
+      double v[4];
+#pragma unroll
+      for(int u = 0; u < 4; u++) off[u] = list[F.list0 + min(k0 + 16*u, F.nlist - 1)];
+#pragma unroll
+      for(int u = 0; u < 4; u++) v[u] = part[off[u] + lane];
+#pragma unroll
+      for(int u = 0; u < 4; u++) if(k0 + 16*u < F.nlist) s += v[u];
+    }
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  if(g == 0 && lane < F.nI*F.nJ)
+  {
+    double tot = 0.0;
+    for(int k = 0; k < 16; k++) tot += sh[k*64 + lane];
+    fin2_store(F, lane, tot, Lx, part);
+  }
+}
+// add the partial accumulators of a multi-task group in task order: one 1024-thread
+// workgroup per group, 16 lanes-groups stride over the partials, fixed-order reduce
+__global__ void __launch_bounds__(1024) k_assemble_fin(const AsmFin* __restrict__ fins,
+                                                       const AsmSlot* __restrict__ slots,
+                                                       const double* __restrict__ part,
+                                                       double* __restrict__ Lx)
+{
+  __shared__ double sh[1024];
+  const AsmFin F = fins[blockIdx.x];
+  const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+  for(int ebase = 0; ebase < F.acc_size; ebase += 64)
+  {
+    const int e = ebase + lane;
+    double s = 0.0;
+    if(e < F.acc_size)
+      for(int k = g; k < F.nparts; k += 16) s += part[F.part0 + (int64_t)k*F.acc_size + e];
+    __syncthreads();
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    if(g == 0 && e < F.acc_size)
+    {
+      double tot = 0.0;
+      for(int k = 0; k < 16; k++) tot += sh[k*64 + lane];
+      // which slot holds accumulator e?
+      for(int sidx = 0; sidx < F.nslots; sidx++)
+      {
+        const AsmSlot SL = slots[F.slot0 + sidx];
+        const int n = SL.nI*F.nJ;
+        if(e >= SL.accoff && e < SL.accoff + n)
+        {
+          const int idx = e - SL.accoff;
+          const int b = idx / SL.nI, a = idx - b*SL.nI;
+          if(!SL.diag || a >= b) Lx[SL.dest + a + (int64_t)b*SL.ld] = tot;
+        }
+      }
+    }
+  }
+}
+__global__ void __launch_bounds__(TPB) k_add_lambda(double* __restrict__ Lx,
+                                                    const int64_t* __restrict__ diagpos, int n,
+                                                    double lambda)
+{
+  const int i = blockIdx.x*TPB + threadIdx.x;
+  if(i < n) Lx[diagpos[i]] += lambda;
+}
+
+// augmented row: panel(last row, column k) = rhs[perm[k]]
+__global__ void __launch_bounds__(TPB) k_set_aug_row(double* __restrict__ Lx, const int* __restrict__ col_sn,
+                                                     const int* __restrict__ sn_c0,
+                                                     const int* __restrict__ sn_rowptr,
+                                                     const int64_t* __restrict__ sn_lx,
+                                                     const int* __restrict__ perm,
+                                                     const double* __restrict__ rhs, int n)
+{
+  const int k = blockIdx.x*TPB + threadIdx.x;
+  if(k >= n) return;
+  const int s = col_sn[k];
+  const int nrows = sn_rowptr[s+1] - sn_rowptr[s];
+  Lx[sn_lx[s] + (nrows - 1) + (int64_t)(k - sn_c0[s])*nrows] = rhs[perm[k]];
+}
+
+// ------------------------------------------------------------------ K1 ------
+// one wave per task over the diagonal block of a var-block I:
+//   Jt_x[I] = sum_{row-blocks containing I} sum_k J[k][offI + a] * x[r0 + k]
+// lanes = (a, j): j strides over the contributions; fixed-order LDS reduction.
+__global__ void __launch_bounds__(TPB) k_jtx(const SymTask* __restrict__ tasks, int ntasks,
+                                             const SymOutBlock* __restrict__ oblk,
+                                             const SymContrib* __restrict__ contrib,
+                                             const double* __restrict__ vals,
+                                             const double* __restrict__ x,
+                                             double* __restrict__ jtx, double* __restrict__ part)
+{
+  __shared__ double sh[TPB];
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wid = blockIdx.x*(TPB/64) + w;
+  double acc = 0.0;
+  int nI = 1, J = 1, a = 0, j = 0;
+  SymTask T = {0, 0, 0, -1};
+  SymOutBlock B; B.nI = 1; B.var0 = 0;
+  const bool live = wid < ntasks;
+  if(live)
+  {
+    T = tasks[wid];
+    B = oblk[T.blk];
+    nI = B.nI; J = 64/nI; a = lane % nI; j = lane / nI;
+    if(j < J)
+      for(int c = T.c0 + j; c < T.c1; c += J)
+      {
+        const SymContrib C = contrib[c];
+        const double* row = vals + C.base + C.offI + a;
+        for(int k = 0; k < C.nrows; k++, row += C.len) acc += row[0]*x[C.r0 + k];
+      }
+  }
+  sh[threadIdx.x] = acc;
+  __syncthreads();
+  if(live && lane < nI)
+  {
+    double s = 0.0;
+    for(int jj = 0; jj < J; jj++) s += sh[w*64 + lane + jj*nI];
+    if(T.part < 0) jtx[B.var0 + lane] = s;
+    else part[(size_t)T.part*8 + lane] = s;
+  }
+}
+// one workgroup per multi-chunk var-block: 32 groups x 8 scalars
+__global__ void __launch_bounds__(TPB) k_jtx_fin(const int* __restrict__ fin_ptr,
+                                                 const int* __restrict__ fin_blk, int nfin,
+                                                 const SymOutBlock* __restrict__ oblk,
+                                                 const double* __restrict__ part,
+                                                 double* __restrict__ jtx)
+{
+  __shared__ double sh[TPB];
+  const int f = blockIdx.x;
+  const int a = threadIdx.x & 7, g = threadIdx.x >> 3;
+  const SymOutBlock B = oblk[fin_blk[f]];
+  double s = 0.0;
+  for(int p = fin_ptr[f] + g; p < fin_ptr[f+1]; p += 32) s += part[(size_t)p*8 + a];
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  if(g == 0 && a < B.nI)
+  {
+    double tot = 0.0;
+    for(int k = 0; k < 32; k++) tot += sh[k*8 + a];
+    jtx[B.var0 + a] = tot;
+  }
+}
+
+// --------------------------------------------------------------- K3 / K8 ---
+// |J v|^2, "CSR-stream": a workgroup owns a run of consecutive measurement rows
+// holding <= NV_CHUNK non-zeros.  The values and indices of the run are read
+// fully coalesced (a thread-per-row loop strides by the row length and
+// over-fetched 12x in rocprof), the products vals*v[idx] are parked in LDS, and
+// each thread then sums the products of one row.  Deterministic: fixed
+// row->thread map, ordered partials.
+
+__global__ void __launch_bounds__(TPB) k_norm2_Jv(const int* __restrict__ chunk_row,
+                                                  const int* __restrict__ Jp,
+                                                  const int* __restrict__ Ji,
+                                                  const double* __restrict__ vals,
+                                                  const double* __restrict__ v,
+                                                  double* __restrict__ part)
+{
+  __shared__ double prod[NV_CHUNK];
+  __shared__ double sh[4];
+  const int r0 = chunk_row[blockIdx.x], r1 = chunk_row[blockIdx.x + 1];
+  const int q0 = Jp[r0], n = Jp[r1] - q0;
+  const int tid = threadIdx.x;
+  double acc = 0.0;
+  if(n <= NV_CHUNK)
+  {
+    for(int base = 0; base < n; base += 8*TPB)
+    {
+      double pv[8]; int pi[8];
+#pragma unroll
+      for(int u = 0; u < 8; u++) { const int e = base + u*TPB + tid; pi[u] = (e < n) ? Ji[q0 + e] : 0; pv[u] = (e < n) ? vals[q0 + e] : 0.0; }
+#pragma unroll
+      for(int u = 0; u < 8; u++) { const int e = base + u*TPB + tid; if(e < n) prod[e] = pv[u]*v[pi[u]]; }
+    }
+    __syncthreads();
+    for(int r = r0 + tid; r < r1; r += TPB)
+    {
+      const int a = Jp[r] - q0, bq = Jp[r+1] - q0;
+      double d = 0.0;
+      for(int q = a; q < bq; q++) d += prod[q];
+      acc += d*d;
+    }
+  }
+  else
+  {
+    // a single row longer than the chunk: the whole workgroup reduces it
+    double d = 0.0;
+    for(int e = tid; e < n; e += TPB) d += vals[q0 + e]*v[Ji[q0 + e]];
+    d = wave_sum(d);
+    if((tid & 63) == 0) sh[tid >> 6] = d;
+    __syncthreads();
+    if(tid == 0) { const double t = (sh[0] + sh[1]) + (sh[2] + sh[3]); acc = t*t; }
+    __syncthreads();
+  }
+  acc = wave_sum(acc);
+  if((tid & 63) == 0) sh[tid >> 6] = acc;
+  __syncthreads();
+  if(tid == 0) part[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+} // namespace
+
+// K1
+int sparse_eval(dlg_backend* b, int s)
+{
+  SparseSym* Y = b->sym;
+  if(!Y) { dlg_set_error("dlg_sparse_set_pattern must be called first"); return DLG_ERR_STATE; }
+  DlgSlot& S = b->slot[s];
+  const SymHost& H = Y->H;
+  DLG_HIP(hipMemsetAsync(S.Jt_x, 0, sizeof(double)*(size_t)b->N, b->stream));
+  const int nt = (int)H.jtx_task.size();
+  if(nt > 0)
+    hipLaunchKernelGGL(k_jtx, dim3(dlg_cdiv(nt, TPB/64)), dim3(TPB), 0, b->stream, Y->jtx_task, nt,
+                       Y->oblk, Y->contrib, S.Jin(), S.xin(), S.Jt_x, Y->jtx_part);
+  const int nf = (int)H.jtx_fin_blk.size();
+  if(nf > 0)
+    hipLaunchKernelGGL(k_jtx_fin, dim3(nf), dim3(TPB), 0, b->stream,
+                       Y->jtx_fin_ptr, Y->jtx_fin_blk, nf, Y->oblk, Y->jtx_part, S.Jt_x);
+  DLG_LAUNCH_CHECK();
+  return DLG_OK;
+}
+
+// K3 / K8
+int sparse_norm2_Jv(dlg_backend* b, int s, const double* v, double* out_dev)
+{
+  SparseSym* Y = b->sym;
+  if(!Y) { dlg_set_error("dlg_sparse_set_pattern must be called first"); return DLG_ERR_STATE; }
+  DlgSlot& S = b->slot[s];
+  const int g = Y->n_nv_chunks;
+  if(g == 0) { DLG_HIP(hipMemsetAsync(out_dev, 0, sizeof(double), b->stream)); return DLG_OK; }
+  DLG_CHECK(dlg_ensure_partials(b, 4096 + (size_t)g));
+  double* part = b->d_part + 4096;
+  hipLaunchKernelGGL(k_norm2_Jv, dim3(g), dim3(TPB), 0, b->stream, Y->nv_chunk, Y->Jp, Y->Ji, S.Jin(), v, part);
+  DLG_LAUNCH_CHECK();
+  return k_reduce_sum(b, part, g, out_dev);
+}
+
+// K4: JtJ straight into the supernode panels, summed over the ranks, + lambda, + augmented row
+int sparse_assemble(dlg_backend* b, int s, double lambda)
+{
+  SparseSym* Y = b->sym;
+  DlgSlot& S = b->slot[s];
+  const SymHost& H = Y->H;
+  hipStream_t st = b->stream;
+  {
+    DlgProfScope pt(b, DLG_PROF_K4_TOTAL);
+    DLG_HIP(hipMemsetAsync(Y->Lx, 0, sizeof(double)*(size_t)H.lx_size, st));
+    const int nt = (int)H.asm_ctask.size(), nmt = (int)H.asm_mtask.size();
+    if(nt > 0 || nmt > 0)
+    {
+      DlgProfScope pk(b, DLG_PROF_K4_KERNEL);
+      if(nmt > 0)
+      {
+        const int nruns = (int)H.asm_run.size();
+        hipLaunchKernelGGL(k_assemble_mfma, dim3(dlg_cdiv(nruns, TPB/64)), dim3(TPB),
+                           sizeof(double)*(TPB/64)*ASM_U*4*H.asm_lds_len, st, Y->asm_run, nruns, Y->asm_mtask,
+                           Y->asm_kg, Y->asm_shape, Y->asm_tdest, Y->asm_pdest, S.Jin(), Y->Lx, Y->asm_part,
+                           H.asm_lds_len);
+      }
+      if(nt > 0)
+        hipLaunchKernelGGL(k_assemble, dim3(dlg_cdiv(nt, TPB/64)), dim3(TPB), 0, st, Y->asm_ctask, nt,
+                           Y->asm_batch, Y->asm_rho, Y->asm_pair, Y->asm_slot, S.Jin(), Y->Lx, Y->asm_part);
+    }
+    for(size_t q = 0; q + 2 < H.fin2_stage.size(); q += 3)
+    {
+      const int f0 = H.fin2_stage[q], ns = H.fin2_stage[q+1], nl = H.fin2_stage[q+2];
+      if(ns > 0)
+        hipLaunchKernelGGL(k_assemble_fin2_short, dim3(dlg_cdiv(ns, TPB/64)), dim3(TPB), 0, st, Y->asm_fin2 + f0, ns,
+                           Y->asm_fin2_list, Y->asm_part, Y->Lx);
+      if(nl > 0)
+        hipLaunchKernelGGL(k_assemble_fin2_long, dim3(nl), dim3(1024), 0, st, Y->asm_fin2 + f0 + ns,
+                           Y->asm_fin2_list, Y->asm_part, Y->Lx);
+    }
+    const int nf = (int)H.asm_cfin.size();
+    if(nf > 0)
+      hipLaunchKernelGGL(k_assemble_fin, dim3(nf), dim3(1024), 0, st, Y->asm_cfin, Y->asm_slot,
+                         Y->asm_part, Y->Lx);
+    DLG_LAUNCH_CHECK();
+  }
+  // rows are sharded: sum the partial JtJ of all ranks before factorising
+  DLG_CHECK(dlg_allreduce_dev(b, Y->Lx, (size_t)H.lx_size));
+  if(lambda != 0.0)
+    hipLaunchKernelGGL(k_add_lambda, dim3(dlg_cdiv(H.N, TPB)), dim3(TPB), 0, st, Y->Lx, Y->diagpos, H.N,
+                       lambda);
+  // the right-hand side rides along as the last row of every panel: y = L^-1 P Jt_x falls out
+  Y->aug_rhs = nullptr;
+  if(S.have_Jtx)
+  {
+    hipLaunchKernelGGL(k_set_aug_row, dim3(dlg_cdiv(H.N, TPB)), dim3(TPB), 0, st, Y->Lx, Y->col_sn, Y->sn_c0,
+                       Y->sn_rowptr, Y->sn_lx, Y->perm, S.Jt_x, H.N);
+    Y->aug_rhs = S.Jt_x;
+  }
+  DLG_LAUNCH_CHECK();
+  return DLG_OK;
+}

@@ -1,0 +1,101 @@
+// sparse_internal.h -- shared by the DOGLEG_SPARSE translation units:
+//   sparse_assemble.hip   K1 Jt*x, K3/K8 |Jv|^2, K4 JtJ assembly into the supernode panels
+//   sparse_factor.hip     K5 level-scheduled supernodal Cholesky (panel factorisation + updates)
+//   sparse_solve.hip      K6 triangular solves
+//   sparse_host.hip       pattern set-up (symbolic phase, uploads, buffers), orchestration
+// Kernels are launched from the file that defines them (no relocatable device code).
+//
+// Everything is gather-based and atomics-free: every output (a JtJ block, a
+// Jt_x block, a panel column range, a right-hand-side row) has exactly one
+// owner wave/workgroup that sums its contributions in a fixed order, so the
+// results are bitwise reproducible run to run.  The schedules come from the
+// host symbolic phase (sparse_symbolic.cpp).
+//
+// HBM layout: Jacobian values stay in the callback's CSC order (one H2D DMA);
+// the factor is a set of dense column-major supernode panels in one buffer Lx;
+// JtJ is assembled straight into those panels (no separate JtJ array).
+#pragma once
+#include "dlg_internal.h"
+#include "sparse_symbolic.h"
+
+namespace {
+constexpr int NV_CHUNK = 2048;          // non-zeros per workgroup of the |Jv|^2 kernel
+
+constexpr int TPB = 256;
+constexpr int LDS_BUDGET = 147456;      // bytes of dynamic LDS we allow a workgroup
+constexpr int FAC_LDS_BUDGET = 163840 - 3584;  // the panel factorisation takes (almost) all 160 KB of a CU; the rest is its static LDS
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+  for(int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  return v;
+}
+
+// copy `total` doubles with U independent global loads in flight per thread before
+// the first dependent store (a plain load->store loop keeps ONE load in flight and
+// pays a full memory latency per iteration)
+template <int NT, int U, class LoadF, class StoreF>
+__device__ __forceinline__ void batched_copy(int total, int tid, LoadF ld, StoreF st)
+{
+  for(int base = 0; base < total; base += U*NT)
+  {
+    double v[U];
+#pragma unroll
+    for(int u = 0; u < U; u++) { const int idx = base + u*NT + tid; v[u] = (idx < total) ? ld(idx) : 0.0; }
+#pragma unroll
+    for(int u = 0; u < U; u++) { const int idx = base + u*NT + tid; if(idx < total) st(idx, v[u]); }
+  }
+}
+
+template <class T> int upload(T*& dev, const std::vector<T>& h)
+{
+  dev = nullptr;
+  const size_t bytes = sizeof(T)*(h.size() ? h.size() : 1);
+  DLG_HIP(hipMalloc(&dev, bytes));
+  if(!h.empty()) DLG_HIP(hipMemcpy(dev, h.data(), sizeof(T)*h.size(), hipMemcpyHostToDevice));
+  return DLG_OK;
+}
+
+} // namespace
+
+struct SparseSym
+{
+  SymHost H;
+  // schedules on the device
+  int *sn_c0 = nullptr, *sn_rowptr = nullptr, *sn_rows = nullptr, *sn_scr = nullptr, *lvl_sn = nullptr;
+  int64_t *sn_lx = nullptr, *diagpos = nullptr;
+  int *ui_t = nullptr, *ui_col = nullptr, *ui_nc = nullptr, *ui_ptr = nullptr;
+  SymSub* usub = nullptr; int* relpos = nullptr;
+  int *uw_item = nullptr, *uw_s0 = nullptr, *uw_s1 = nullptr, *uf_item = nullptr, *uf_n = nullptr;
+  int64_t *uw_part = nullptr, *uf_off = nullptr;
+  double* upart = nullptr; double* uscr = nullptr; int64_t *u_off = nullptr, *usub_u = nullptr;
+  SymOutBlock* oblk = nullptr; SymContrib* contrib = nullptr;
+  SymTask *jtx_task = nullptr;
+  int *jtx_fin_ptr = nullptr, *jtx_fin_blk = nullptr;
+  AsmRho* asm_rho = nullptr; AsmPair* asm_pair = nullptr; AsmSlot* asm_slot = nullptr;
+  AsmBatch* asm_batch = nullptr; AsmTask* asm_ctask = nullptr; AsmFin* asm_cfin = nullptr;
+  AsmShape* asm_shape = nullptr; AsmKG* asm_kg = nullptr; AsmMTask* asm_mtask = nullptr; int* asm_tdest = nullptr;
+  AsmFin2* asm_fin2 = nullptr; int64_t* asm_fin2_list = nullptr; AsmRun* asm_run = nullptr; int* asm_pdest = nullptr;
+  int *rl_ptr = nullptr, *rl_pos = nullptr, *perm = nullptr, *col_sn = nullptr;
+  int *fw_sn = nullptr, *fw_r0 = nullptr, *fw_r1 = nullptr, *ms_sn = nullptr; int64_t* sn_top = nullptr;
+  int *sn_bd_ptr = nullptr, *sn_bd_col = nullptr;
+  double* top_scr = nullptr;
+  const double* aug_rhs = nullptr;        // rhs the augmented rows of the current factor were built from
+  int *Jp = nullptr, *Ji = nullptr;       // rank-local pattern (row pointers rebased to 0)
+  int *nv_chunk = nullptr; int n_nv_chunks = 0;   // row runs of <= NV_CHUNK non-zeros for |Jv|^2
+  // numeric buffers
+  double *Lx = nullptr, *scr = nullptr, *ywork = nullptr, *asm_part = nullptr, *jtx_part = nullptr;
+  int *d_info = nullptr, *h_info = nullptr;
+  size_t nnz_loc = 0;
+  // per-level launch parameters
+  std::vector<int> fac_lds;     // bytes of LDS for the factor kernel of a level (0: panels stay in HBM)
+  std::vector<int> upd_lds, upd_nw, slv_lds, bwd_lds, fac_nt, upd_coop, syrk_lds, syrk_nt, syrk_kc, bwd_nt;
+  std::vector<void*> allocs;
+};
+
+// ---- per-file host entry points
+int sparse_assemble(dlg_backend* b, int s, double lambda);   // K4 (+ all-reduce, lambda, augmented row)
+int sparse_factor_setup(dlg_backend* b);                     // per-level launch parameters of K5
+int sparse_factor_levels(dlg_backend* b);                    // K5 launches (no synchronisation)
+int sparse_solve_setup(dlg_backend* b);                      // per-level launch parameters of K6
