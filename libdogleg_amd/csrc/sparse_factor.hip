@@ -8,21 +8,18 @@ namespace {
 typedef double dlg_v4d __attribute__((ext_vector_type(4)));
 
 // ------------------------------------------------------------------ K5 ------
-// factor one supernode panel per workgroup: thread-per-row, left-looking over
-// column blocks of 8.
-//   (1) every thread brings the 8 block-column entries of its row(s) up to date
-//       against all previous columns: per previous column one own LDS read and
-//       the 8 entries of the block rows as 4 broadcast ds_read_b128 -> 8 FMAs;
-//   (2) barrier; every thread factors the 8x8 diagonal block redundantly in
-//       registers (no broadcast step, no extra barrier on the critical path);
-//   (3) barrier; forward substitution of the thread's row against the 8x8 factor.
-// 3 barriers per 8 columns instead of 2 per column, ~1.6 LDS reads per FMA
-// instead of 3.  Panel in LDS with an even leading dimension (16-B aligned
-// broadcast reads).  USE_LDS == false: panels larger than the LDS budget are
-// factored in place in HBM with the same code path (slow, rare).
-// One workgroup per work item = (supernode, slice [r0,r1) of its below rows): the LDS
-// panel holds the w x w top block plus the slice; slices of one supernode factor the top
-// block redundantly (identical arithmetic), slice 0 publishes it.
+// factor one supernode panel per workgroup in LDS (column-major, even leading dimension).
+// One workgroup per work item = (supernode, slice [r0,r1) of its below rows): the LDS panel
+// holds the w x w top block plus the slice (up to ~160 KB); slices of one supernode factor the
+// top block redundantly (identical arithmetic), slice 0 publishes it (top_scr, k_copy_top).
+// The arithmetic is in panel_factor.h:
+//   * regular panels, >= 256 threads: panel_factor_mfma -- per 8 columns wave 0 brings the
+//     diagonal row tile up to date on the matrix cores, factors the 8x8 block in registers and
+//     publishes it while the other waves update the remaining row tiles; barrier; every thread
+//     solves its row; barrier;
+//   * 128 threads: panel_factor (same steps, all waves factor the block redundantly);
+//   * sibling-merged leaves (block-diagonal top): panel_factor_blockdiag, no sweep at all.
+// The panel is copied in and out thread-per-row, 16 columns in flight.
 template <int NT>
 __global__ void __launch_bounds__(NT) k_factor_level(const int* __restrict__ fw_sn,
                                                      const int* __restrict__ fw_r0,
