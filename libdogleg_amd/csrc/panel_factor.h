@@ -3,14 +3,17 @@
 // solved against it.  Shared by the sparse supernode kernel and the dense
 // blocked potrf (diagonal blocks).
 //
-// Thread-per-row, left-looking over column blocks of 8:
-//   (1) every thread brings the 8 block-column entries of its row(s) up to date
-//       against all previous columns: per previous column one own read and the
-//       8 entries of the block rows as 4 broadcast 16-byte reads -> 8 FMAs;
-//   (2) barrier; every thread factors the 8x8 diagonal block redundantly in
-//       registers (no broadcast step);
-//   (3) barrier; forward substitution of the thread's row against the 8x8 factor.
-// 3 barriers per 8 columns, ~0.6 LDS reads per FMA.
+// Three variants, all left-looking over column blocks of 8 with thread = panel row:
+//   panel_factor            (1) every thread brings the 8 block-column entries of its row(s) up
+//                           to date against all previous columns (own read + the 8 block-row
+//                           entries as 4 broadcast 16-byte reads -> 8 FMAs; with MFMA_SWEEP the
+//                           matrix cores do this step, see panel_mfma_tiles); (2) barrier; every
+//                           thread factors the 8x8 diagonal block redundantly in registers
+//                           (right-looking, reciprocal square roots); (3) barrier; forward
+//                           substitution of the thread's row against the 8x8 factor.
+//   panel_factor_mfma       the same steps with a dedicated diagonal wave (>= 4 waves): the
+//                           block factorisation leaves the other waves' path, 2 barriers.
+//   panel_factor_blockdiag  block-diagonal top (merged sibling leaves): no sweep at all.
 // ALIGNED16: P is 16-byte aligned and ldp is even (LDS panels) -> double2 reads.
 // On a non-positive pivot the column index (col0 + j) is min-reduced into *info
 // and the pivot is replaced by 1 so that the sweep finishes without NaN storms.
