@@ -511,6 +511,7 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
   {
     const int relax = env_int("DOGLEG_AMD_RELAX_PCT", 25);
     const int sib_w = env_int("DOGLEG_AMD_SIB_W", 64);
+    const long chain_cap = env_int("DOGLEG_AMD_CHAIN_CAP", PANEL_CAP);   // width cap of chain supernodes: W*(W+64)
     int a = 0;
     long W = G.w[border[0]];              // current width
     long true_nnz = W*stw[0];             // sum_j w_j * |struct_j| (scalar) for columns in the supernode
@@ -532,7 +533,7 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
         const long zeros = stored - tn;
         const bool exact = (st[j].size() == st[j+1].size() + 1);
         // a panel is factored in row slices (>= 64 rows each) that all carry the w x w top block
-        const bool fits = (Wn*(Wn + 64) <= PANEL_CAP) && Wn <= SN_WMAX;
+        const bool fits = (Wn*(Wn + 64) <= chain_cap) && Wn <= SN_WMAX;
         if(fits && (exact || Wn <= 16 || zeros*100 <= (long)relax*(stored + Wn*Wn)))
         {
           merge = true; sib_only = false; nmerge++;
@@ -671,7 +672,7 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
         const int nrows = S.sn_rowptr[s+1] - S.sn_rowptr[s];
         const int below = nrows - w;
         int nsl = 1;
-        if((long)nrows*w > PANEL_CAP)
+        if((long)((nrows + 1) & ~1)*w > slice_cap())
         {
           int rpw = slice_cap()/w - w - 1; if(rpw < 1) rpw = 1;
           nsl = (below + rpw - 1)/rpw;
