@@ -176,6 +176,10 @@ void  dlg_mem_free(void* dev);
 int   dlg_mem_upload(void* dev, const void* host, size_t bytes);
 int   dlg_mem_download(void* host, const void* dev, size_t bytes);
 int   dlg_mem_zero(void* dev, size_t bytes);
+/* page-locked host memory (hipHostMalloc): a p_new_host / download destination allocated here is
+ * written by the DMA engine directly, pageable memory goes through a staging buffer */
+void* dlg_host_alloc(size_t bytes);
+void  dlg_host_free(void* host);
 int   dlg_device_sync(void);
 
 /* ---- trial trace sink used by the dogleg_optimize* entry points on the

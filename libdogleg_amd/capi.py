@@ -30,7 +30,8 @@ BACKEND_SYMBOLS = [
     "dlg_factorize", "dlg_solve_gn", "dlg_make_step", "dlg_expected_improvement",
     "dlg_point_download", "dlg_factor_download_dense", "dlg_point_device_ptr",
     "dlg_kernel_syrk_lower", "dlg_kernel_potrf_lower", "dlg_probe_mfma_f64",
-    "dlg_probe_hbm_copy", "dlg_set_trace", "dlg_mem_alloc", "dlg_mem_free", "dlg_mem_upload",
+    "dlg_probe_hbm_copy", "dlg_set_trace", "dlg_mem_alloc", "dlg_mem_free", "dlg_host_alloc",
+    "dlg_host_free", "dlg_mem_upload",
     "dlg_mem_download", "dlg_mem_zero", "dlg_device_sync", "dlg_sparse_symbolic_probe",
     "dlg_backend_set_profiling", "dlg_backend_get_profile",
 ]
@@ -95,6 +96,10 @@ def lib():
     L.dlg_mem_alloc.restype = V
     L.dlg_mem_free.argtypes = [V]
     L.dlg_mem_free.restype = None
+    L.dlg_host_alloc.argtypes = [C.c_size_t]
+    L.dlg_host_alloc.restype = V
+    L.dlg_host_free.argtypes = [V]
+    L.dlg_host_free.restype = None
     L.dlg_mem_upload.argtypes = [V, V, C.c_size_t]
     L.dlg_mem_download.argtypes = [V, V, C.c_size_t]
     L.dlg_mem_zero.argtypes = [V, C.c_size_t]
@@ -223,11 +228,16 @@ class Backend:
         _ck(self.L.dlg_backend_create(C.byref(self.h), solve_type, N, M, nnz, flags, device),
             "dlg_backend_create")
         self._keep = []
+        self._pnew_ptr = None
+        self._pnew = None
 
     def close(self):
         if self.h:
             self.L.dlg_backend_destroy(self.h)
             self.h = C.c_void_p()
+        if self._pnew_ptr:
+            self.L.dlg_host_free(self._pnew_ptr)
+            self._pnew_ptr, self._pnew = None, None
 
     def __del__(self):
         try:
@@ -309,11 +319,17 @@ class Backend:
         return a.value
 
     def make_step(self, frm, to, kind, trustregion, want_p=True):
+        """p_new comes back in a page-locked buffer owned by this object (as the driver's operating
+        points are): it is overwritten by the next call -- copy it to keep it."""
         n2, k, am = C.c_double(), C.c_double(), C.c_double()
-        pn = np.zeros(self.N) if want_p else None
+        if want_p and self._pnew is None:
+            self._pnew_ptr = self.L.dlg_host_alloc(8 * self.N)
+            if not self._pnew_ptr:
+                raise DlgError(self.L.dlg_last_error().decode())
+            self._pnew = np.ctypeslib.as_array(C.cast(self._pnew_ptr, C.POINTER(C.c_double)), shape=(self.N,))
         _ck(self.L.dlg_make_step(self.h, frm, to, kind, trustregion, C.byref(n2), C.byref(k),
-                                 C.byref(am), dptr(pn) if want_p else None), "make_step")
-        return n2.value, k.value, am.value, pn
+                                 C.byref(am), dptr(self._pnew) if want_p else None), "make_step")
+        return n2.value, k.value, am.value, (self._pnew if want_p else None)
 
     def expected_improvement(self, frm, to):
         a = C.c_double()

@@ -441,9 +441,15 @@ extern "C" int dlg_make_step(dlg_backend_t* b, int from, int to, int kind, doubl
   }
   if(p_new_host)
   {
-    DLG_HIP(hipMemcpyAsync(b->h_vec, T.p, sizeof(double)*(size_t)b->N, hipMemcpyDeviceToHost, b->stream));
+    // page-locked destination (the driver's operating points, dlg_host_alloc): straight DMA;
+    // pageable: through the backend's pinned staging vector
+    hipPointerAttribute_t attr;
+    const bool pinned = hipPointerGetAttributes(&attr, p_new_host) == hipSuccess && attr.type == hipMemoryTypeHost;
+    if(!pinned) (void)hipGetLastError();
+    double* dst = pinned ? p_new_host : b->h_vec;
+    DLG_HIP(hipMemcpyAsync(dst, T.p, sizeof(double)*(size_t)b->N, hipMemcpyDeviceToHost, b->stream));
     DLG_HIP(hipStreamSynchronize(b->stream));
-    memcpy(p_new_host, b->h_vec, sizeof(double)*(size_t)b->N);
+    if(!pinned) memcpy(p_new_host, b->h_vec, sizeof(double)*(size_t)b->N);
   }
   if(norm2_step) *norm2_step = n2;
   if(k_cauchy_to_gn) *k_cauchy_to_gn = kk;
@@ -508,6 +514,13 @@ extern "C" void* dlg_mem_alloc(size_t bytes)
   return p;
 }
 extern "C" void dlg_mem_free(void* dev) { if(dev) (void)hipFree(dev); }
+extern "C" void* dlg_host_alloc(size_t bytes)
+{
+  void* p = nullptr;
+  if(hipHostMalloc(&p, bytes ? bytes : 8) != hipSuccess) { dlg_set_error("hipHostMalloc(%zu) failed", bytes); return nullptr; }
+  return p;
+}
+extern "C" void dlg_host_free(void* host) { if(host) (void)hipHostFree(host); }
 extern "C" int dlg_mem_upload(void* dev, const void* host, size_t bytes)
 { DLG_HIP(hipMemcpy(dev, host, bytes, hipMemcpyHostToDevice)); return DLG_OK; }
 extern "C" int dlg_mem_download(void* host, const void* dev, size_t bytes)
