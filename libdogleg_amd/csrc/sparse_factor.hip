@@ -32,7 +32,9 @@ __global__ void __launch_bounds__(NT) k_factor_level(const int* __restrict__ fw_
                                                      const int* __restrict__ sn_bd_col,
                                                      double* __restrict__ Lx,
                                                      double* __restrict__ top_scr,
-                                                     int* __restrict__ info)
+                                                     int* __restrict__ info,
+                                                     const int64_t* __restrict__ u_off,
+                                                     double* __restrict__ uscr, int fuse_syrk)
 {
   extern __shared__ __attribute__((aligned(16))) double P[];
   __shared__ int sbad;
@@ -65,6 +67,41 @@ __global__ void __launch_bounds__(NT) k_factor_level(const int* __restrict__ fw_
   else         panel_factor<NT, true, true>(P, ldp, nloc, w, tid, &sbad, sn_c0[s]);
   const int64_t top = sn_top[s];
   if(r0 == 0 && tid == 0 && sbad != 0x7fffffff) atomicMin(info, sbad);
+  // two-phase update, phase 1 fused: this workgroup holds all the below rows of the (unsliced)
+  // panel in LDS, so U = B B' (B = rows w.. of the factored panel) comes straight out of it:
+  // lower 16x16 tiles round robin over the waves, both MFMA operands read from the panel
+  if(fuse_syrk && top < 0)
+  {
+    const int mb = nloc - w, T = (mb + 15) >> 4, ntiles = T*(T + 1)/2;
+    double* U = uscr + u_off[s];
+    const int lane = tid & 63, wv = tid >> 6;
+    const int jn = lane & 15, kq = lane >> 4;
+    for(int idx = wv; idx < ntiles; idx += NT/64)
+    {
+      int rem = idx, tj = 0;
+      while(rem >= T - tj) { rem -= T - tj; tj++; }
+      const int ti = tj + rem;
+      const int ra = w + min(16*ti + jn, mb - 1), rb = w + min(16*tj + jn, mb - 1);
+      const bool va = 16*ti + jn < mb, vb = 16*tj + jn < mb;
+      dlg_v4d c4 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll 2
+      for(int kk = 0; kk < w; kk += 4)
+      {
+        const int k = kk + kq;
+        const bool kok = k < w;
+        const int kc = kok ? k : w - 1;
+        const double a = P[ra + kc*ldp], bv = P[rb + kc*ldp];
+        c4 = __builtin_amdgcn_mfma_f64_16x16x4f64((kok && va) ? a : 0.0, (kok && vb) ? bv : 0.0, c4, 0, 0, 0);
+      }
+      const int j = 16*tj + jn;
+#pragma unroll
+      for(int r = 0; r < 4; r++)
+      {
+        const int i = 16*ti + kq + 4*r;
+        if(i < mb && j <= i) U[i + (size_t)j*mb] = c4[r];
+      }
+    }
+  }
   for(int i = tid; i < nloc; i += NT)
   {
     // rows below the top block go back to the panel; the top block too unless the supernode is
@@ -599,6 +636,7 @@ int sparse_factor_setup(dlg_backend* b)
   Y->fac_lds.assign(H.nlevels, 0); Y->fac_nt.assign(H.nlevels, 512); Y->upd_coop.assign(H.nlevels, 0);
   Y->upd_lds.assign(H.nlevels, 0); Y->upd_nw.assign(H.nlevels, 0);
   Y->syrk_lds.assign(H.nlevels, 0); Y->syrk_nt.assign(H.nlevels, 256); Y->syrk_kc.assign(H.nlevels, 4);
+  Y->syrk_fused.assign(H.nlevels, 0);
   for(int l = 0; l < H.nlevels; l++)
   {
     long maxp = 0, maxw = 0, maxr = 0;
@@ -647,6 +685,10 @@ int sparse_factor_setup(dlg_backend* b)
       Y->syrk_kc[l] = (int)kc;
       Y->syrk_lds[l] = (int)(kc*ldbmax*8);
       Y->syrk_nt[l] = (tmax*(tmax + 1)/2 <= 32) ? 256 : 1024;
+      // no supernode of the level is cut into slices: the factor kernel forms the U_d itself
+      bool unsliced = true;
+      for(int i = H.lvl_ptr[l]; i < H.lvl_ptr[l+1]; i++) if(H.sn_top[H.lvl_sn[i]] >= 0) unsliced = false;
+      Y->syrk_fused[l] = (unsliced && nw > 0 && !getenv("DOGLEG_AMD_NO_SYRK_FUSE")) ? 1 : 0;
     }
   }
   DLG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_factor_level<128>),
@@ -683,21 +725,25 @@ int sparse_factor_levels(dlg_backend* b)
       if(Y->fac_nt[l] == 128)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_factor_level<128>), dim3(n), dim3(128), Y->fac_lds[l], st,
                            Y->fw_sn + o, Y->fw_r0 + o, Y->fw_r1 + o, Y->sn_c0, Y->sn_rowptr, Y->sn_lx,
-                           Y->sn_top, Y->sn_bd_ptr, Y->sn_bd_col, Y->Lx, Y->top_scr, Y->d_info);
+                           Y->sn_top, Y->sn_bd_ptr, Y->sn_bd_col, Y->Lx, Y->top_scr, Y->d_info,
+                           Y->u_off, Y->uscr, Y->syrk_fused[l]);
       else if(Y->fac_nt[l] == 256)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_factor_level<256>), dim3(n), dim3(256), Y->fac_lds[l], st,
                            Y->fw_sn + o, Y->fw_r0 + o, Y->fw_r1 + o, Y->sn_c0, Y->sn_rowptr, Y->sn_lx,
-                           Y->sn_top, Y->sn_bd_ptr, Y->sn_bd_col, Y->Lx, Y->top_scr, Y->d_info);
+                           Y->sn_top, Y->sn_bd_ptr, Y->sn_bd_col, Y->Lx, Y->top_scr, Y->d_info,
+                           Y->u_off, Y->uscr, Y->syrk_fused[l]);
       else
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_factor_level<512>), dim3(n), dim3(512), Y->fac_lds[l], st,
                            Y->fw_sn + o, Y->fw_r0 + o, Y->fw_r1 + o, Y->sn_c0, Y->sn_rowptr, Y->sn_lx,
-                           Y->sn_top, Y->sn_bd_ptr, Y->sn_bd_col, Y->Lx, Y->top_scr, Y->d_info);
+                           Y->sn_top, Y->sn_bd_ptr, Y->sn_bd_col, Y->Lx, Y->top_scr, Y->d_info,
+                           Y->u_off, Y->uscr, Y->syrk_fused[l]);
     }
     const int nu = H.uw_lvl_ptr[l+1] - H.uw_lvl_ptr[l];
     if(nu > 0 && H.upd_syrk[l] && Y->upd_nw[l] > 0)
     {
       const int ns = H.lvl_ptr[l+1] - H.lvl_ptr[l];
-      if(Y->syrk_nt[l] == 256)
+      if(Y->syrk_fused[l]) { /* phase 1 was done by the factor kernel */ }
+      else if(Y->syrk_nt[l] == 256)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_update_syrk<256>), dim3(ns), dim3(256), Y->syrk_lds[l], st,
                            Y->lvl_sn + H.lvl_ptr[l], Y->sn_c0, Y->sn_rowptr, Y->sn_lx, Y->u_off, Y->Lx, Y->uscr,
                            Y->syrk_kc[l]);
