@@ -141,6 +141,8 @@ int dlg_ensure_partials(dlg_backend* b, size_t ndoubles);
 
 // ------------------------------------------------------- kernels_dense.hip --
 int dense_create(dlg_backend* b);
+// dense_diag.hip: factor the 64x64 diagonal block at kb and form its inverse (one workgroup)
+void dense_launch_potrf_diag(hipStream_t st, double* A, int lda, int kb, int nb, int* info_dev, double* Linv);
 void dense_destroy(dlg_backend* b);
 int dense_eval(dlg_backend* b, int slot);                       // K1
 int dense_norm2_Jv(dlg_backend* b, int slot, const double* v, double* out_dev); // K3/K8

@@ -327,37 +327,6 @@ __global__ void __launch_bounds__(TPB) k_syrk_reduce(double* __restrict__ C, int
 // 64x64 mat-vecs, so no kernel on the solve path has a serial 64-step loop either.
 constexpr int NB = 64;
 
-__global__ void __launch_bounds__(TPB) k_potrf_diag_inv(double* __restrict__ A, int lda, int kb,
-                                                        int nb, int* __restrict__ info,
-                                                        double* __restrict__ Linv)
-{
-  // rows 0..63: the diagonal block; rows 64..127: the identity.  Factoring the
-  // 128 x 64 panel leaves L in the top block and L^-T in the bottom block (the
-  // row solve X L^T = I), i.e. the inverse comes out of the same sweep.
-  __shared__ __attribute__((aligned(16))) double P[2*NB*NB];
-  __shared__ int sbad;
-  const int t = threadIdx.x;
-  constexpr int LD = 2*NB;
-  for(int e = t; e < NB*NB; e += TPB)
-  {
-    const int i = e % NB, j = e / NB;
-    double v = (i == j) ? 1.0 : 0.0;                          // identity padding of a short last block
-    if(i < nb && j < nb) v = (i >= j) ? A[(size_t)(kb + j)*lda + kb + i] : 0.0;
-    P[i + j*LD] = v;
-    P[NB + i + j*LD] = (i == j) ? 1.0 : 0.0;
-  }
-  if(t == 0) sbad = 0x7fffffff;
-  __syncthreads();
-  panel_factor<TPB, true>(P, LD, 2*NB, NB, t, &sbad, 0);
-  if(t == 0) { const int bad = sbad; if(bad < nb && *info == 0) *info = kb + bad + 1; }
-  for(int e = t; e < NB*NB; e += TPB)
-  {
-    const int i = e % NB, j = e / NB;
-    if(i < nb && j < nb && i >= j) A[(size_t)(kb + j)*lda + kb + i] = P[i + j*LD];
-    Linv[e] = (i >= j) ? P[NB + j + i*LD] : 0.0;              // Linv(i,j) = (L^-T)(j,i)
-  }
-}
-
 // X = A_panel * Linv^T for the rows r >= kb+nb; one workgroup per 64 rows.
 __global__ void __launch_bounds__(TPB) k_trsm_gemm(double* __restrict__ A, int lda, int kb, int nb,
                                                    int n, const double* __restrict__ Linv)
@@ -537,7 +506,7 @@ int potrf_lower(hipStream_t st, double* A, int lda, int n, int* info_dev, double
   {
     const int nb = (n - kb < NB) ? n - kb : NB;
     double* Li = Linv + (size_t)blk*NB*NB;
-    hipLaunchKernelGGL(k_potrf_diag_inv, dim3(1), dim3(TPB), 0, st, A, lda, kb, nb, info_dev, Li);
+    dense_launch_potrf_diag(st, A, lda, kb, nb, info_dev, Li);
     const int rem = n - kb - nb;
     if(rem > 0)
     {
