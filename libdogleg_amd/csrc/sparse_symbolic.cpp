@@ -4,6 +4,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
 #include <map>
 #include <cmath>
 #include <numeric>
@@ -248,10 +249,25 @@ struct Orderer
 int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0, int row1,
                 char* err, int errlen)
 {
+  // DOGLEG_AMD_SYM_DEBUG >= 2: wall time of every step on stderr
+  const bool sym_time = env_int("DOGLEG_AMD_SYM_DEBUG", 0) >= 2;
+  auto sym_t0 = std::chrono::steady_clock::now();
+  const char* sym_what = "setup";
+  auto sym_tick = [&](const char* next) {
+    if(sym_time)
+    {
+      const auto t1 = std::chrono::steady_clock::now();
+      fprintf(stderr, "sym_analyze: %-40s %8.1f ms\n", sym_what, std::chrono::duration<double, std::milli>(t1 - sym_t0).count());
+      sym_t0 = t1;
+    }
+    sym_what = next; };
+#define SYM_TICK(name) sym_tick(name)
+
   S = SymHost();
   S.N = N; S.M = M; S.nnz = cp[M]; S.row0 = row0; S.row1 = row1;
   if(cp[0] != 0) SYM_FAIL("Jt column pointers must start at 0");
 
+  SYM_TICK("1 var-blocks");
   // ---------------------------------------------------------- 1. var-blocks
   std::vector<char> cut(N + 1, 0);
   cut[0] = cut[N] = 1;
@@ -282,6 +298,7 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
   const int nvb = S.nvb;
   auto vbw = [&](int v) { return S.vb_start[v+1] - S.vb_start[v]; };
 
+  SYM_TICK("2 row-blocks");
   // ---------------------------------------------------------- 2. row-blocks
   std::vector<RowBlock> rbs;
   std::vector<int> rb_vb, rb_off;
@@ -318,6 +335,7 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
   }
   const int nrb = (int)rbs.size();
 
+  SYM_TICK("3 block graph of JtJ");
   // ------------------------------------------------ 3. block graph of JtJ
   Graph G; G.n = nvb; G.w.resize(nvb);
   for(int v = 0; v < nvb; v++) G.w[v] = vbw(v);
@@ -364,6 +382,7 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
     for(int e = G.ptr[v]; e < G.ptr[v+1]; e++) if(G.adj[e] > v) S.nnz_JtJ_lower += w*G.w[G.adj[e]];
   }
 
+  SYM_TICK("4 ordering");
   // ------------------------------------------------------------ 4. ordering
   std::vector<int> border;            // position -> vb
   {
@@ -393,6 +412,7 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
   std::vector<int> bpos(nvb);
   for(int k = 0; k < nvb; k++) bpos[border[k]] = k;
 
+  SYM_TICK("5 block-level symbolic factorisation");
   // --------------------------------- 5. block-level symbolic factorisation
   std::vector<std::vector<int>> st(nvb);   // struct of block column (positions > j), sorted
   std::vector<int> parent(nvb, -1);
@@ -505,6 +525,7 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
     for(long a = 0; a < w; a++) { const double c = (double)(w - a + stw[j]); S.factor_flops += c*c; }
   }
 
+  SYM_TICK("6 supernodes");
   // ------------------------------------------------------- 6. supernodes
   std::vector<int> sn_b0;                 // first block position of each supernode (+ sentinel)
   std::vector<char> sn_bd;                // supernode made of sibling leaves only: block-diagonal top
@@ -564,6 +585,7 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
   S.nsn = (int)sn_b0.size() - 1;
   const int nsn = S.nsn;
 
+  SYM_TICK("7 scalar-level layout");
   // ------------------------------------------- 7. scalar-level layout
   std::vector<int> colstart(nvb + 1, 0);  // scalar position of block position
   for(int k = 0; k < nvb; k++) colstart[k+1] = colstart[k] + G.w[border[k]];
@@ -705,6 +727,7 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
     }
   }
 
+  SYM_TICK("8 factor update schedule");
   // ------------------------------------ 8. factor update schedule
   {
     struct Sub { int lvl, t, q, d, ka, rel; };
@@ -863,6 +886,7 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
     for(int l = 0; l < S.nlevels; l++) { S.uw_lvl_ptr[l+1] += S.uw_lvl_ptr[l]; S.uf_lvl_ptr[l+1] += S.uf_lvl_ptr[l]; }
   }
 
+  SYM_TICK("9a Jt*x lists (per var-block)");
   // ------------------------------------------- 9a. Jt*x lists (per var-block)
   {
     // inverted index: var-block -> local row-blocks containing it (row order)
@@ -912,6 +936,7 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
     }
   }
 
+  SYM_TICK("9b JtJ assembly schedule");
   // ------------------------------------------- 9b. JtJ assembly schedule
   // Column-block centric: a task owns (a group of) the output blocks (I,J) of ONE
   // column block J and walks the row-blocks that contain J in batches: a batch's
@@ -946,12 +971,30 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
     std::map<std::vector<int>, int> shape_ids;
     std::vector<int> tseen(nvb, -1), pseen(nvb, -1), fin_of(nvb, -1);
     struct Ord { int I, nI, offI; bool P; };
-    struct Cls { std::vector<int> es; std::vector<Ord> ords; int MP, MT, nP, nT, shape, slot0, acc_size, rider, pq; };
+    struct Cls { std::vector<int> es; std::vector<Ord> ords; int MP, MT, nP, nT, shape, slot0, acc_size, rider, pq;
+                 int lay, xJ; uint64_t mask; };
+    // layout id of every row-block: number of blocks, their widths and offsets inside a row
+    std::vector<int> rb_layout(nrb, -1);
+    {
+      std::map<std::vector<int>, int> ids;
+      std::vector<int> k, kprev;
+      int prev = -1;
+      for(int bi = 0; bi < nrb; bi++)
+      {
+        const RowBlock& b = rbs[bi];
+        k.clear();
+        for(int x = 0; x < b.nvb; x++) { k.push_back(G.w[rb_vb[b.vptr + x]]); k.push_back(rb_off[b.vptr + x]); }
+        if(prev >= 0 && k == kprev) { rb_layout[bi] = prev; continue; }
+        auto it = ids.find(k);
+        if(it == ids.end()) it = ids.emplace(k, (int)ids.size()).first;
+        rb_layout[bi] = prev = it->second; kprev = k;
+      }
+    }
     std::vector<int> mtask_acc;          // accumulator size of every MFMA task (parallel to asm_mtask)
     std::vector<Cls> classes;
-    std::map<std::vector<int>, int> class_ids;
-    std::vector<int> cnt_same, key, last_key;
+    std::vector<int> cnt_same, key;
     std::vector<std::vector<int64_t>> fin_lists;
+    SYM_TICK("9b.1 riders");
     // riders: dense column blocks whose only output block is their own diagonal
     std::vector<int> rb_host(nrb, -1), rb_rider(nrb, -1);
     std::vector<char> is_rider_blk(nvb, 0);
@@ -986,34 +1029,40 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
       }
     auto build_mfma = [&](int J, int r0, int r1, int qJ, int t, int ld, int lc, int nJ, bool is_rider) -> bool
     {
-      // 1. classes of identical layout
-      classes.clear(); class_ids.clear();
+      // 1. classes of identical layout: same row layout id, same position of J in the row, same set
+      //    of blocks eliminated after J, same rider
+      classes.clear();
       int last_cls = -1;
       for(int e = r0; e < r1; e++)
       {
-        const RowBlock& b = rbs[rrb[e]];
-        if(is_rider && rb_host[rrb[e]] >= 0) continue;         // carried by another column block's tasks
-        key.assign(1, rb_off[b.vptr + rx[e]]);
-        key.push_back(rb_host[rrb[e]] == J ? rb_rider[rrb[e]] : -1);
-        for(int x = 0; x < b.nvb; x++)
-        { const int I = rb_vb[b.vptr + x]; if(bpos[I] >= qJ) { key.push_back(G.w[I]); key.push_back(rb_off[b.vptr + x]); } }
-        int c;
-        if(last_cls >= 0 && key == last_key) c = last_cls;
+        const int bi = rrb[e];
+        const RowBlock& b = rbs[bi];
+        if(is_rider && rb_host[bi] >= 0) continue;             // carried by another column block's tasks
+        uint64_t mask = 0;
+        if(is_rider) mask = 1;                                  // a rider is the last block of its rows
         else
         {
-          auto it = class_ids.find(key);
-          if(it != class_ids.end()) c = it->second;
-          else
-          {
-            if(classes.size() >= 64 && !is_rider) return false;
-            c = (int)classes.size(); class_ids[key] = c; classes.emplace_back();
-            Cls& C = classes.back();
-            C.rider = key[1];
-            for(int x = 0; x < b.nvb; x++)
-            { const int I = rb_vb[b.vptr + x]; if(bpos[I] >= qJ) C.ords.push_back({I, G.w[I], rb_off[b.vptr + x], true}); }
-          }
+          if(b.nvb > 64) return false;
+          for(int x = 0; x < b.nvb; x++) if(bpos[rb_vb[b.vptr + x]] >= qJ) mask |= 1ull << x;
         }
-        classes[c].es.push_back(e); last_cls = c; last_key = key;
+        const int rider = rb_host[bi] == J ? rb_rider[bi] : -1;
+        const int lay = rb_layout[bi], xJ = rx[e];
+        int c = -1;
+        if(last_cls >= 0 && classes[last_cls].lay == lay && classes[last_cls].xJ == xJ &&
+           classes[last_cls].mask == mask && classes[last_cls].rider == rider) c = last_cls;
+        else
+          for(size_t q = 0; q < classes.size(); q++)
+            if(classes[q].lay == lay && classes[q].xJ == xJ && classes[q].mask == mask && classes[q].rider == rider) { c = (int)q; break; }
+        if(c < 0)
+        {
+          if(classes.size() >= 64) return false;
+          c = (int)classes.size(); classes.emplace_back();
+          Cls& C = classes.back();
+          C.lay = lay; C.xJ = xJ; C.mask = mask; C.rider = rider;
+          for(int x = 0; x < b.nvb; x++)
+          { const int I = rb_vb[b.vptr + x]; if(bpos[I] >= qJ) C.ords.push_back({I, G.w[I], rb_off[b.vptr + x], true}); }
+        }
+        classes[c].es.push_back(e); last_cls = c;
       }
       // 2. persistent / transient blocks of every class
       for(Cls& C : classes)
@@ -1223,6 +1272,7 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
       }
       return true;
     };
+    SYM_TICK("9b.2 column blocks");
     for(int pass = 0; pass < 2; pass++)          // pass 1: the riders (rows nobody carried + the carried partials)
     for(int J = 0; J < nvb; J++)
     {
@@ -1348,6 +1398,7 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
         }
       }
     }
+    SYM_TICK("9b.3 sort tasks, runs");
     // group the MFMA tasks by shape (their k-groups move with them) and cut the sequence into
     // runs: a wave loads the shape's lane constants once and streams the k-groups of several
     // small tasks back to back
@@ -1388,6 +1439,7 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
         S.asm_run.push_back(R);
       }
     }
+    SYM_TICK("9b.4 partial-sum stages");
     // long lists are summed hierarchically: chunks of 64 partials -> intermediate partials.
     // Stages run in order; inside a stage the entries with <= 64 partials come first
     // (one wave each), then the longer ones (one workgroup each).
@@ -1430,10 +1482,12 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
       }
       S.asm_fin2_list.swap(lst);
     }
+    SYM_TICK("9b.5 sentinel");
     // sentinel so that rho[i+1].pair0 closes the pair list of the last rho
     AsmRho R; memset(&R, 0, sizeof(R)); R.pair0 = (int)S.asm_pair.size(); S.asm_rho.push_back(R);
   }
 
+  SYM_TICK("10 forward-solve gather lists");
   // --------------------------------------- 10. forward-solve gather lists
   {
     S.rl_ptr.assign(N + 1, 0);
@@ -1452,5 +1506,6 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
         S.rl_pos[nx[S.sn_rows[k]]++] = S.sn_scr[d] + j;
     }
   }
+  SYM_TICK("done");
   return 0;
 }
