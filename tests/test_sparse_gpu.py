@@ -134,3 +134,20 @@ def test_ba_lambda_path(gpu):
     lam = [t["lambda_"] for t in trg.trials()]
     assert 1e-10 in lam, lam
     compare_traces(trg, tro, step_tol=1e-7)     # lambda=1e-10 systems are ill-conditioned by design
+
+
+@pytest.mark.parametrize("env", [
+    {"DOGLEG_AMD_ASM_MFMA": "0"},                                   # LDS assembly kernel k_assemble for every column block
+    {"DOGLEG_AMD_SYRK_MIN": "0", "DOGLEG_AMD_NO_UPDATE_MFMA": "1"},  # k_update_coop instead of SYRK+gather / MFMA updates
+    {"DOGLEG_AMD_SYRK_MIN": "0"},                                   # k_update_mfma at every level
+    {"DOGLEG_AMD_SYRK_MIN": "1", "DOGLEG_AMD_NO_SYRK_FUSE": "1"},    # stand-alone SYRK kernel at every level
+    {"DOGLEG_AMD_RIDER_MIN": "0"},                                  # the dense block keeps tasks of its own
+    {"DOGLEG_AMD_SLICE_CAP": "6000"},                               # many row slices per panel
+], ids=["lds-assembly", "coop-update", "mfma-update", "syrk-unfused", "no-rider", "small-slices"])
+def test_fallback_kernels_match_oracle(gpu, env, monkeypatch):
+    """the kernels the default schedule does not pick on a bundle-adjustment pattern stay correct:
+    the schedule knobs are read when the pattern is set"""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    st, err = _ops_parity(oa.BAProblem(49, 900, 10000, seed=5))
+    print(env, st, f"|gn diff| = {err:.2e}")
