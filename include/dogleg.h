@@ -9,7 +9,7 @@
  * gfx950 through the C-ABI declared in dlg_backend.h.
  *
  * What is NOT provided (out of the hot-path scope):
- * dogleg_testGradient*, the experimental outlier API.
+ * the experimental outlier / confidence API.
  *
  * Binary layout note: like the reference (dogleg.h:166-210) the context embeds
  * a cholmod_common by value as its first member, so the *binary* layout
@@ -207,6 +207,19 @@ bool dogleg_computeJtJfactorization(dogleg_operatingPoint_t* point,
                                     dogleg_solverContext_t* ctx);
 
 void dogleg_freeContext(dogleg_solverContext_t** ctx);
+
+/* gradient check of a callback (reference dogleg.h:312-322): prints, for variable `var`, the
+ * reported d x[i] / d p[var] next to a central difference, one line per measurement, as a
+ * vnlog-style table on stdout.  Host only. */
+void dogleg_testGradient(unsigned int var, const double* p0,
+                         unsigned int Nstate, unsigned int Nmeas, unsigned int NJnnz,
+                         dogleg_callback_t* f, void* cookie);
+void dogleg_testGradient_dense(unsigned int var, const double* p0,
+                               unsigned int Nstate, unsigned int Nmeas,
+                               dogleg_callback_dense_t* f, void* cookie);
+void dogleg_testGradient_dense_products(unsigned int var, const double* p0,
+                                        unsigned int Nstate, unsigned int Nmeas,
+                                        dogleg_callback_dense_products_t* f, void* cookie);
 
 #ifdef __cplusplus
 }

@@ -41,7 +41,8 @@ DOGLEG_SYMBOLS = [
     "dogleg_setTrustregionUpdateParameters", "dogleg_setDebug", "dogleg_setInitialTrustregion",
     "dogleg_setThresholds", "dogleg_optimize", "dogleg_optimize2", "dogleg_optimize_dense",
     "dogleg_optimize_dense2", "dogleg_optimize_dense_products", "dogleg_computeJtJfactorization",
-    "dogleg_freeContext",
+    "dogleg_freeContext", "dogleg_testGradient", "dogleg_testGradient_dense",
+    "dogleg_testGradient_dense_products",
 ]
 
 _lib = None

@@ -207,3 +207,50 @@ def test_row_sharding_with_gloo_world_size_2():
         p.join(timeout=120)
         assert p.exitcode == 0
     assert q.get(timeout=5) is True
+
+
+def _capture_stdout(fn):
+    """run fn() and return what the C library printed on stdout (fd 1)"""
+    import tempfile
+    C.CDLL(None).fflush(None)
+    saved = os.dup(1)
+    with tempfile.TemporaryFile(mode="w+b") as tmp:
+        os.dup2(tmp.fileno(), 1)
+        try:
+            fn()
+            C.CDLL(None).fflush(None)
+        finally:
+            os.dup2(saved, 1)
+            os.close(saved)
+        tmp.seek(0)
+        return tmp.read().decode()
+
+
+@pytest.mark.parametrize("mode", ["sparse", "dense"])
+def test_gradient_check_tool_on_the_sample_problem(mode):
+    """dogleg_testGradient{,_dense} (reference dogleg.h:312-322; sample.c runs it with --test-gradient):
+    the table has one row per measurement and the sample problem's analytic gradients agree with
+    central differences; host only, no GPU"""
+    L, P = capi.lib(), oa.problems()
+    p0 = np.zeros(6)
+    P.sample_init(dptr(p0))
+    var = 2
+    U = C.c_uint
+    if mode == "sparse":
+        L.dogleg_testGradient.argtypes = [U, C.POINTER(C.c_double), U, U, U, C.c_void_p, C.c_void_p]
+        L.dogleg_testGradient.restype = None
+        out = _capture_stdout(lambda: L.dogleg_testGradient(var, dptr(p0), 6, 100, 600,
+                                                            oa.fn_addr(P, "sample_cb_sparse"), None))
+    else:
+        L.dogleg_testGradient_dense.argtypes = [U, C.POINTER(C.c_double), U, U, C.c_void_p, C.c_void_p]
+        L.dogleg_testGradient_dense.restype = None
+        out = _capture_stdout(lambda: L.dogleg_testGradient_dense(var, dptr(p0), 6, 100,
+                                                                  oa.fn_addr(P, "sample_cb_dense"), None))
+    lines = out.strip().splitlines()
+    assert lines[0] == "# ivar imeasurement gradient_reported gradient_observed error error_relative"
+    rows = [l.split() for l in lines[1:]]
+    assert len(rows) == 100
+    assert [int(r[0]) for r in rows] == [var] * 100 and [int(r[1]) for r in rows] == list(range(100))
+    rep = np.array([float(r[2]) for r in rows]); obs = np.array([float(r[3]) for r in rows])
+    assert np.max(np.abs(rep)) > 0
+    assert np.max(np.abs(rep - obs)) <= 1e-4 * max(1.0, np.max(np.abs(rep)))
