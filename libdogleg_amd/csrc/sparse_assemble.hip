@@ -221,14 +221,17 @@ constexpr int ASM_U = DLG_ASM_U;
 // k-group records are wave-uniform (scalar loads), fetched one iteration ahead.  All loads are
 // unconditional with clamped addresses (absent rows read element 0 and are zeroed afterwards):
 // the loop body is straight-line code, the only branches are uniform.
-template <bool HAS_T>
+template <bool HAS_T, int CLEN>
 __device__ __forceinline__ void asm_mfma_run(const AsmRun& R, const AsmMTask* __restrict__ tasks,
                                              const AsmShape* __restrict__ SH,
                                              const AsmKG* __restrict__ kgs, const int* __restrict__ tdest,
                                              const int* __restrict__ pdest, const double* __restrict__ vals,
                                              double* __restrict__ Lx, double* __restrict__ part, int lane,
-                                             double* __restrict__ tile, int LEN)
+                                             double* __restrict__ tile, int LEN_rt)
 {
+  // CLEN > 0: the tile row stride is a compile-time constant (the usual 16-column window), so the
+  // LDS offsets of the unrolled k-groups become instruction immediates
+  const int LEN = CLEN > 0 ? CLEN : LEN_rt;
   const int m = lane & 15, kq = lane >> 4;
   const int nJ = SH->nJ, MP = SH->MP, MT = SH->MT, nT = SH->nT, nJr = SH->nJr;
   const int col0 = SH->col0, ncopy = SH->ncopy, dslot = SH->dslot, rslot = SH->rslot;
@@ -384,6 +387,7 @@ __device__ __forceinline__ void asm_mfma_run(const AsmRun& R, const AsmMTask* __
 #else
 #define ASM_WPE_ATTR
 #endif
+template <int CLEN>
 __global__ void __launch_bounds__(TPB) ASM_WPE_ATTR k_assemble_mfma(const AsmRun* __restrict__ runs, int nruns,
                                                        const AsmMTask* __restrict__ tasks,
                                                        const AsmKG* __restrict__ kgs,
@@ -399,8 +403,8 @@ __global__ void __launch_bounds__(TPB) ASM_WPE_ATTR k_assemble_mfma(const AsmRun
   const AsmRun R = runs[wid];
   const AsmShape* SH = shapes + tasks[R.task0].shape;
   double* tile = asm_tiles + (threadIdx.x >> 6)*(ASM_U*4*LEN);
-  if(SH->MT > 0) asm_mfma_run<true>(R, tasks, SH, kgs, tdest, pdest, vals, Lx, part, lane, tile, LEN);
-  else           asm_mfma_run<false>(R, tasks, SH, kgs, tdest, pdest, vals, Lx, part, lane, tile, LEN);
+  if(SH->MT > 0) asm_mfma_run<true, CLEN>(R, tasks, SH, kgs, tdest, pdest, vals, Lx, part, lane, tile, LEN);
+  else           asm_mfma_run<false, CLEN>(R, tasks, SH, kgs, tdest, pdest, vals, Lx, part, lane, tile, LEN);
 }
 // persistent blocks written by several MFMA tasks: fixed-order sum of the listed partials.
 // k_assemble_fin2_short: one wave per block (lists of <= 32 partials);
@@ -702,10 +706,15 @@ int sparse_assemble(dlg_backend* b, int s, double lambda)
       if(nmt > 0)
       {
         const int nruns = (int)H.asm_run.size();
-        hipLaunchKernelGGL(k_assemble_mfma, dim3(dlg_cdiv(nruns, TPB/64)), dim3(TPB),
-                           sizeof(double)*(TPB/64)*ASM_U*4*H.asm_lds_len, st, Y->asm_run, nruns, Y->asm_mtask,
-                           Y->asm_kg, Y->asm_shape, Y->asm_tdest, Y->asm_pdest, S.Jin(), Y->Lx, Y->asm_part,
-                           H.asm_lds_len);
+        if(H.asm_lds_len == 18)
+          hipLaunchKernelGGL(HIP_KERNEL_NAME(k_assemble_mfma<18>), dim3(dlg_cdiv(nruns, TPB/64)), dim3(TPB),
+                             sizeof(double)*(TPB/64)*ASM_U*4*18, st, Y->asm_run, nruns, Y->asm_mtask,
+                             Y->asm_kg, Y->asm_shape, Y->asm_tdest, Y->asm_pdest, S.Jin(), Y->Lx, Y->asm_part, 18);
+        else
+          hipLaunchKernelGGL(HIP_KERNEL_NAME(k_assemble_mfma<0>), dim3(dlg_cdiv(nruns, TPB/64)), dim3(TPB),
+                             sizeof(double)*(TPB/64)*ASM_U*4*H.asm_lds_len, st, Y->asm_run, nruns, Y->asm_mtask,
+                             Y->asm_kg, Y->asm_shape, Y->asm_tdest, Y->asm_pdest, S.Jin(), Y->Lx, Y->asm_part,
+                             H.asm_lds_len);
       }
       if(nt > 0)
         hipLaunchKernelGGL(k_assemble, dim3(dlg_cdiv(nt, TPB/64)), dim3(TPB), 0, st, Y->asm_ctask, nt,
