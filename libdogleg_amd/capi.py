@@ -262,7 +262,7 @@ class Backend:
 
     def set_shard(self, row0, row1, fn=None):
         cb = ALLREDUCE_FN(fn) if fn is not None else None
-        self._keep.append(cb)
+        self._allreduce_cb = cb                 # must outlive the backend: the C side keeps the pointer
         _ck(self.L.dlg_backend_set_shard(self.h, row0, row1,
                                          C.cast(cb, C.c_void_p) if cb else None, None), "set_shard")
 

@@ -1,0 +1,117 @@
+"""Row sharding on the GPU with k logical ranks on ONE device (gpurun boxes have a single
+GPU): every rank is a backend of its own with dlg_backend_set_shard, driven by its own host thread;
+the all-reduce hook is an in-process sum (download, barrier, add in rank order, upload) standing in
+for RCCL.  Every rank must end up with the oracle's step."""
+import ctypes as C
+import threading
+import numpy as np
+import pytest
+
+from libdogleg_amd import capi
+from libdogleg_amd.ctypes_defs import dptr, iptr
+from tests import oracle_api as oa
+
+pytestmark = pytest.mark.gpu
+
+
+class _InProcessAllReduce:
+    def __init__(self, world):
+        self.world, self.slots = world, [None] * world
+        self.bar = threading.Barrier(world)
+        self.L = capi.lib()
+
+    def hook(self, rank):
+        def fn(buf, count, cookie):
+            try:
+                host = np.empty(count)
+                if self.L.dlg_mem_download(host.ctypes.data, buf, 8 * count) != 0:
+                    return 1
+                self.slots[rank] = host
+                self.bar.wait(timeout=120)
+                total = self.slots[0].copy()
+                for r in range(1, self.world):          # fixed order: every rank gets the same bits
+                    total += self.slots[r]
+                self.bar.wait(timeout=120)
+                return 0 if self.L.dlg_mem_upload(buf, total.ctypes.data, 8 * count) == 0 else 1
+            except Exception as e:                       # never let an exception cross the C boundary
+                print("in-process all-reduce failed:", e)
+                return 1
+        return fn
+
+
+def _sharded_step(kind, N, M, nnz, pattern, x, Jvals, p, cuts, row_slice):
+    world = len(cuts) - 1
+    ar = _InProcessAllReduce(world)
+    out, errs = [None] * world, []
+
+    def run(rank):
+        try:
+            r0, r1 = cuts[rank], cuts[rank + 1]
+            be = capi.Backend(kind, N, M, nnz)
+            be.set_shard(r0, r1, ar.hook(rank))
+            if pattern is not None:
+                be.set_pattern(*pattern)
+            be.set_p(0, p)
+            be.upload(0, x[r0:r1], row_slice(r0, r1))
+            n2x, gmax = be.eval(0)
+            n2c = be.cauchy(0)
+            assert be.factorize(0, 0.0)
+            n2g = be.solve_gn(0)
+            tr = 0.5 * (np.sqrt(n2c) + np.sqrt(n2g))
+            n2s, k, amax, pnew = be.make_step(0, 1, capi.KIND_INTERP, tr)
+            ei = be.expected_improvement(0, 1)
+            out[rank] = dict(n2x=n2x, n2c=n2c, n2g=n2g, k=k, ei=ei, step=be.download(1, capi.VEC_STEP),
+                             gn=be.download(0, capi.VEC_GN))
+            be.close()
+        except Exception as e:
+            errs.append((rank, repr(e)))
+            try:
+                ar.bar.abort()
+            except Exception:
+                pass
+
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    [t.start() for t in th]
+    [t.join(timeout=300) for t in th]
+    assert not errs, errs
+    return out
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sparse_rows_sharded_over_logical_ranks(gpu, world):
+    O = oa.oracle()
+    prob = oa.BAProblem(49, 900, 10000, seed=7)
+    N, M, nnz = prob.N, prob.M, prob.nnz
+    Jp, Ji = prob.pattern()
+    p = prob.p0()
+    x, Jx = prob.eval(p)
+    # uneven cuts, one of them inside an observation's pair of rows
+    cuts = [0] + [int(M * (i + 1) / world) + (1 if i == 0 else 0) for i in range(world - 1)] + [M]
+    res = _sharded_step(capi.DLG_SPARSE, N, M, nnz, (Jp, Ji), x, Jx, p, cuts, lambda a, b: Jx[Jp[a]:Jp[b]])
+    # the oracle's step on the full problem
+    F = O.orc_sparse_analyze(N, M, iptr(Jp), iptr(Ji))
+    work, o8 = np.zeros(5 * N), np.zeros(8)
+    assert O.orc_step_sparse(F, N, M, iptr(Jp), iptr(Ji), dptr(Jx), dptr(x), dptr(p), 0.0, dptr(work), dptr(o8)) == 0
+    O.orc_sparse_free(F)
+    step_ref = work[3 * N:4 * N]
+    for r in res:
+        assert np.linalg.norm(r["step"] - step_ref) <= 1e-10          # tolerance of the parity bar
+        assert abs(r["n2x"] - o8[0]) <= 1e-12 * o8[0]
+        assert abs(r["ei"] - o8[5]) <= 1e-9 * abs(o8[5])
+    for r in res[1:]:                                                  # replicated factor: identical bits
+        assert np.array_equal(r["step"], res[0]["step"]) and r["k"] == res[0]["k"]
+
+
+def test_dense_rows_sharded_over_two_logical_ranks(gpu):
+    prob = oa.DenseProblem(3000, 256, seed=5)
+    M, N = prob.M, prob.N
+    p = prob.p0()
+    x, J = prob.eval(p)
+    J = np.ascontiguousarray(J).reshape(-1)
+    cuts = [0, 1301, M]
+    res = _sharded_step(capi.DLG_DENSE, N, M, 0, None, x, J, p, cuts, lambda a, b: J[a * N:b * N])
+    full = _sharded_step(capi.DLG_DENSE, N, M, 0, None, x, J, p, [0, M], lambda a, b: J[a * N:b * N])[0]
+    for r in res:
+        assert np.linalg.norm(r["step"] - full["step"]) <= 1e-10
+        assert abs(r["n2x"] - full["n2x"]) <= 1e-12 * full["n2x"]
+    assert np.array_equal(res[0]["step"], res[1]["step"])
