@@ -1,0 +1,110 @@
+"""Edge cases of the drop-in API on the GPU against the oracle: one variable, one measurement,
+under-determined systems (singular JtJ -> the lambda schedule), a start that is already converged,
+a huge initial trust region (several rejections), max_iterations = 0/1."""
+import ctypes as C
+import numpy as np
+import pytest
+
+from libdogleg_amd import capi
+from libdogleg_amd.ctypes_defs import CholmodSparse
+from tests import oracle_api as oa
+from tests.parity import compare_traces
+
+pytestmark = pytest.mark.gpu
+
+
+def _dense_cb(J0, xs, M, N, nonlin=0.0):
+    @capi.CB_DENSE
+    def cb(p, x, J, cookie):
+        pv = np.ctypeslib.as_array(p, shape=(N,)).copy()
+        r = J0 @ pv - xs
+        np.ctypeslib.as_array(x, shape=(M,))[:] = r + nonlin * np.sin(r)
+        Jv = J0 * (1.0 + nonlin * np.cos(r))[:, None]
+        np.ctypeslib.as_array(J, shape=(M * N,))[:] = Jv.ravel()
+    return cb
+
+
+def _sparse_cb(J0, xs, M, N, nonlin=0.0):
+    """every row lists all N variables (values may be zero)"""
+    @capi.CB_SPARSE
+    def cb(p, x, Jt, cookie):
+        pv = np.ctypeslib.as_array(p, shape=(N,)).copy()
+        r = J0 @ pv - xs
+        np.ctypeslib.as_array(x, shape=(M,))[:] = r + nonlin * np.sin(r)
+        A = Jt.contents
+        cp = np.ctypeslib.as_array(C.cast(A.p, C.POINTER(C.c_int)), shape=(M + 1,))
+        ri = np.ctypeslib.as_array(C.cast(A.i, C.POINTER(C.c_int)), shape=(M * N,))
+        vx = np.ctypeslib.as_array(C.cast(A.x, C.POINTER(C.c_double)), shape=(M * N,))
+        cp[:] = np.arange(0, (M + 1) * N, N)
+        ri[:] = np.tile(np.arange(N), M)
+        vx[:] = (J0 * (1.0 + nonlin * np.cos(r))[:, None]).ravel()
+    return cb
+
+
+def _both(kind, cb, p0, N, M, prm, tol=1e-10):
+    addr = C.cast(cb, C.c_void_p)
+    nnz = M * N if kind == "sparse" else 0
+    ro, po, tro = oa.oracle_solve(kind, p0, N, M, nnz, addr, None, prm)
+    rg, pg, trg = capi.optimize(kind, p0, N, M, nnz, addr, None, prm)
+    assert (rg < 0) == (ro < 0)
+    if ro >= 0:
+        compare_traces(trg, tro, step_tol=tol)
+        assert np.max(np.abs(pg - po)) <= tol
+        assert abs(rg - ro) <= 1e-10 * max(1.0, abs(ro))
+    return trg, tro
+
+
+@pytest.mark.parametrize("kind", ["dense", "sparse"])
+def test_one_variable_and_one_measurement(gpu, kind):
+    rng = np.random.default_rng(1)
+    mk = _dense_cb if kind == "dense" else _sparse_cb
+    prm = oa.default_params()
+    prm.max_iterations = 10
+    for (M, N) in ((5, 1), (1, 1), (7, 2)):
+        J0 = rng.standard_normal((M, N)) + 0.5
+        xs = rng.standard_normal(M)
+        _both(kind, mk(J0, xs, M, N, 0.2), np.full(N, 0.3), N, M, prm)
+
+
+@pytest.mark.parametrize("kind", ["dense", "sparse"])
+def test_underdetermined_system_takes_the_lambda_path(gpu, kind):
+    """M < N: JtJ is singular, the factorisation fails until lambda makes it positive definite"""
+    rng = np.random.default_rng(2)
+    M, N = 6, 10
+    J0, xs = rng.standard_normal((M, N)), rng.standard_normal(M)
+    mk = _dense_cb if kind == "dense" else _sparse_cb
+    prm = oa.default_params()
+    prm.max_iterations = 6
+    # cond(JtJ + 1e-10 I) ~ 1e11: the two Cholesky factorisations agree to ~1e-5 at best
+    trg, tro = _both(kind, mk(J0, xs, M, N), np.zeros(N), N, M, prm, tol=1e-3)
+    assert [t["lambda_"] for t in trg.trials()] == [t["lambda_"] for t in tro.trials()]
+    assert any(t["lambda_"] > 0 for t in trg.trials())
+
+
+@pytest.mark.parametrize("kind", ["dense", "sparse"])
+def test_converged_start_and_iteration_limits(gpu, kind):
+    rng = np.random.default_rng(3)
+    M, N = 30, 4
+    J0 = rng.standard_normal((M, N))
+    pstar = rng.standard_normal(N)
+    xs = J0 @ pstar
+    mk = _dense_cb if kind == "dense" else _sparse_cb
+    prm = oa.default_params()
+    prm.max_iterations = 10
+    trg, tro = _both(kind, mk(J0, xs, M, N), pstar.copy(), N, M, prm)     # Jt_x = 0 at the start
+    assert trg.ncallbacks == tro.ncallbacks == 1 and trg.ntrials == 0
+    for it in (0, 1):
+        prm2 = oa.default_params()
+        prm2.max_iterations = it
+        _both(kind, mk(J0, xs + 0.1, M, N, 0.3), np.zeros(N), N, M, prm2)
+
+
+def test_huge_trust_region_is_cut_down_by_rejections(gpu):
+    rng = np.random.default_rng(4)
+    M, N = 60, 5
+    J0, xs = rng.standard_normal((M, N)), 3.0 * rng.standard_normal(M)
+    prm = oa.default_params()
+    prm.max_iterations = 25
+    prm.trustregion0 = 1e6
+    trg, tro = _both("dense", _dense_cb(J0, xs, M, N, 2.5), np.full(N, 4.0), N, M, prm, tol=1e-9)
+    assert any(not t["accepted"] for t in trg.trials())
