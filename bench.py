@@ -139,14 +139,9 @@ def main():
         be.bind_device(0, d_x.ptr, d_J.ptr)          # a fresh operating point: nothing cached
         norm2x, gmax = be.eval(0)                    # K1
         n2c = be.cauchy(0)                           # K3
-        ok = be.factorize(0, 0.0)                    # K4 + K5
-        lam = 0.0
-        while not ok:                                # the reference's lambda loop (dogleg.c:656-677)
-            lam = 1e-10 if lam == 0.0 else lam * 10
-            if lam > 1e30:
-                raise SystemExit("factorisation keeps failing: giving up")
-            ok = be.factorize(0, lam)
-        n2g = be.solve_gn(0)                         # K6
+        # K4 + K5 + K6: compute_updateGN as the driver issues it (factorise from lambda = 0 with the
+        # reference's lambda loop, dogleg.c:656-677, then solve; one synchronisation per attempt)
+        lam, n2g = be.gauss_newton(0, 0.0)
         tr = 0.5 * (n2c ** 0.5 + n2g ** 0.5)
         n2s, k, amax, pnew = be.make_step(0, 1, capi.KIND_INTERP, tr)   # K7 (+ p_new D2H)
         ei = be.expected_improvement(0, 1)           # K8

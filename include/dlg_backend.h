@@ -116,6 +116,13 @@ int  dlg_factorize(dlg_backend_t* b, int slot, double lambda, int* ok);
 /* ---- K6: compute_updateGN (dogleg.c:822-908): updateGN = -(JtJ)^-1 Jt_x ---- */
 int  dlg_solve_gn(dlg_backend_t* b, int slot, double* norm2_updateGN);
 
+/* ---- K4+K5+K6 fused: compute_updateGN as the reference runs it (dogleg.c:822-908 calls
+ * dogleg_computeJtJfactorization first, dogleg.c:825): factorise with *lambda_io, raising it by the
+ * reference's schedule (0 -> 1e-10 -> x10, dogleg.c:138,671-672,812-813) until the factorisation
+ * succeeds, and solve.  One host synchronisation per attempt instead of two (dlg_factorize +
+ * dlg_solve_gn).  On return *lambda_io is the lambda that worked. ---------------------------- */
+int  dlg_gauss_newton(dlg_backend_t* b, int slot, double* lambda_io, double* norm2_updateGN);
+
 /* ---- K7 + the vector part of takeStepFrom (dogleg.c:1192-1259,1289-1291):
  * form the step of the given kind from slot `from`, store it as
  * step_to_here of slot `to`, set p[to] = p[from] + step, copy p[to] to

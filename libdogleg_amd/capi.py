@@ -27,7 +27,7 @@ BACKEND_SYMBOLS = [
     "dlg_backend_set_stream", "dlg_backend_get_stream", "dlg_backend_set_shard",
     "dlg_sparse_set_pattern", "dlg_sparse_stats", "dlg_point_set_p", "dlg_point_upload",
     "dlg_point_upload_products", "dlg_point_bind_device", "dlg_point_eval", "dlg_cauchy",
-    "dlg_factorize", "dlg_solve_gn", "dlg_make_step", "dlg_expected_improvement",
+    "dlg_factorize", "dlg_solve_gn", "dlg_gauss_newton", "dlg_make_step", "dlg_expected_improvement",
     "dlg_point_download", "dlg_factor_download_dense", "dlg_point_device_ptr",
     "dlg_kernel_syrk_lower", "dlg_kernel_potrf_lower", "dlg_probe_mfma_f64",
     "dlg_probe_hbm_copy", "dlg_set_trace", "dlg_mem_alloc", "dlg_mem_free", "dlg_host_alloc",
@@ -81,6 +81,7 @@ def lib():
     L.dlg_cauchy.argtypes = [V, C.c_int, D]
     L.dlg_factorize.argtypes = [V, C.c_int, C.c_double, I]
     L.dlg_solve_gn.argtypes = [V, C.c_int, D]
+    L.dlg_gauss_newton.argtypes = [V, C.c_int, D, D]
     L.dlg_make_step.argtypes = [V, C.c_int, C.c_int, C.c_int, C.c_double, D, D, D, D]
     L.dlg_expected_improvement.argtypes = [V, C.c_int, C.c_int, D]
     L.dlg_point_download.argtypes = [V, C.c_int, C.c_int, D, C.c_size_t]
@@ -318,6 +319,12 @@ class Backend:
         a = C.c_double()
         _ck(self.L.dlg_solve_gn(self.h, slot, C.byref(a)), "solve_gn")
         return a.value
+
+    def gauss_newton(self, slot, lam=0.0):
+        """factorise (raising lambda as the reference does) + solve: returns (lambda, |gn|^2)"""
+        l, a = C.c_double(lam), C.c_double()
+        _ck(self.L.dlg_gauss_newton(self.h, slot, C.byref(l), C.byref(a)), "gauss_newton")
+        return l.value, a.value
 
     def make_step(self, frm, to, kind, trustregion, want_p=True):
         """p_new comes back in a page-locked buffer owned by this object (as the driver's operating

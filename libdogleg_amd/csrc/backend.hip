@@ -400,6 +400,59 @@ extern "C" int dlg_solve_gn(dlg_backend_t* b, int s, double* norm2_updateGN)
   return DLG_OK;
 }
 
+// ------------------------------------------------------------- K4+K5+K6 ----
+// The reference's compute_updateGN (dogleg.c:822-908) starts with the factorisation
+// (dogleg.c:825 -> 634-820, including the lambda loop 656-677 / 806-815) and solves right after it.
+// Fused here so that one attempt costs ONE host synchronisation: the factorisation is enqueued,
+// the solve is enqueued behind it, and the pivot flag is read together with |gn|^2 (a failed
+// factorisation replaces its bad pivots by 1, so the speculative solve cannot fault).
+extern "C" int dlg_gauss_newton(dlg_backend_t* b, int s, double* lambda_io, double* norm2_updateGN)
+{
+  DLG_CHECK(check_slot(b, s));
+  if(!lambda_io) { dlg_set_error("dlg_gauss_newton: lambda_io is NULL"); return DLG_ERR_ARG; }
+  DlgSlot& S = b->slot[s];
+  if(!S.have_inputs) { dlg_set_error("dlg_gauss_newton: slot %d has no J/JtJ", s); return DLG_ERR_STATE; }
+  if(!S.have_Jtx) { dlg_set_error("dlg_gauss_newton needs Jt_x"); return DLG_ERR_STATE; }
+  if(b->factor_slot == s && S.have_gn)                       // both cached (dogleg.c:637, 825)
+  { if(norm2_updateGN) *norm2_updateGN = S.norm2_gn; return DLG_OK; }
+  double lam = *lambda_io;
+  for(;;)
+  {
+    int good = 0, rc;
+    if(b->factor_slot != s)
+    {
+      b->defer_factor_sync = true;
+      switch(b->type)
+      {
+      case DLG_SPARSE: rc = sparse_factorize(b, s, lam, &good); break;
+      case DLG_DENSE:  rc = dense_factorize(b, s, lam, &good); break;
+      default:         rc = products_factorize(b, s, lam, &good); break;
+      }
+      b->defer_factor_sync = false;
+      DLG_CHECK(rc);
+    }
+    {
+      DlgProfScope ps(b, DLG_PROF_K6_SOLVE);
+      if(b->type == DLG_SPARSE) DLG_CHECK(sparse_solve(b, S.Jt_x, S.gn));
+      else                      DLG_CHECK(dense_solve(b, S.Jt_x, S.gn));
+    }
+    DLG_CHECK(k_negate_norm2(b, S.gn, b->N, b->d_scal));      // dogleg.c:862-865
+    DLG_CHECK(dlg_fetch_scalars(b, 1));                       // the one synchronisation
+    if(b->profiling) dlg_prof_resolve(b);
+    good = (b->factor_slot == s) ? 1 : (b->type == DLG_SPARSE ? sparse_factor_ok(b) : dense_factor_ok(b));
+    if(good) break;
+    b->factor_slot = -1;
+    lam = (lam == 0.0) ? 1e-10 : lam*10.0;                    // dogleg.c:138, 671-672, 812-813
+    if(!(lam < 1e300)) { dlg_set_error("lambda overflowed while regularising a singular JtJ"); return DLG_ERR_STATE; }
+  }
+  b->factor_slot = s;
+  S.norm2_gn = b->h_scal[0];
+  S.have_gn = true;
+  *lambda_io = lam;
+  if(norm2_updateGN) *norm2_updateGN = S.norm2_gn;
+  return DLG_OK;
+}
+
 // ---------------------------------------------------------------------- K7 --
 extern "C" int dlg_make_step(dlg_backend_t* b, int from, int to, int kind, double trustregion,
                              double* norm2_step, double* k_cauchy_to_gn, double* step_absmax,

@@ -76,6 +76,8 @@ struct dlg_backend
   size_t  slabs_bytes = 0;
   int*    d_info = nullptr;
   int*    h_info = nullptr;
+  bool    defer_factor_sync = false;   // dlg_gauss_newton: the *_factorize calls enqueue only; the pivot
+                                       // flag is read after the solve's synchronisation
   double* d_work = nullptr;   // N-vector scratch
 
   // sparse
@@ -147,6 +149,7 @@ void dense_destroy(dlg_backend* b);
 int dense_eval(dlg_backend* b, int slot);                       // K1
 int dense_norm2_Jv(dlg_backend* b, int slot, const double* v, double* out_dev); // K3/K8
 int dense_factorize(dlg_backend* b, int slot, double lambda, int* ok);          // K4+K5
+bool dense_factor_ok(const dlg_backend* b);      // pivot flag of the last factorisation (after a sync)
 int dense_solve(dlg_backend* b, const double* rhs, double* out);                // K6 (no negate)
 int products_quadform(dlg_backend* b, int slot, const double* v, double* out_dev);
 int products_factorize(dlg_backend* b, int slot, double lambda, int* ok);
@@ -159,4 +162,5 @@ int sparse_set_pattern(dlg_backend* b, const int* colptr, const int* rowidx);
 int sparse_eval(dlg_backend* b, int slot);                      // K1
 int sparse_norm2_Jv(dlg_backend* b, int slot, const double* v, double* out_dev); // K3/K8
 int sparse_factorize(dlg_backend* b, int slot, double lambda, int* ok);          // K4+K5
+bool sparse_factor_ok(const dlg_backend* b);     // pivot flag of the last factorisation (after a sync)
 int sparse_solve(dlg_backend* b, const double* rhs, double* out);                // K6

@@ -310,10 +310,28 @@ bool compute_gn(dogleg_operatingPoint_t* pt, Driver* d)
 {
   if(!pt->have_updateGN)
   {
-    if(!factorize(pt, d)) return false;
     if(!pt->have_Jtx) { MSG("GN step needs Jt_x, which is missing"); return false; }
     double n2 = 0;
-    if(!be_ok(dlg_solve_gn(d->be, slot_of(d, pt), &n2), "GN solve")) return false;
+    if(!pt->have_factorization)
+    {
+      // factorisation (with the lambda loop, dogleg.c:656-677 / 806-815) and solve in one backend op:
+      // one host synchronisation per attempt
+      dogleg_solverContext_t* ctx = &d->pub;
+      if(ctx->solve_type == DOGLEG_DENSE_PRODUCTS ? !pt->have_JtJ : !pt->have_J)
+      { MSG("factorization needs J (or JtJ), which is missing"); return false; }
+      if(ctx->solve_type == DOGLEG_SPARSE && ctx->factorization == nullptr)
+      {
+        d->factor_handle.n = (size_t)ctx->Nstate; d->factor_handle.minor = 0;
+        d->factor_handle.backend = d->be;
+        ctx->factorization = &d->factor_handle;                  // dogleg.c:650-654
+      }
+      const double lambda_before = ctx->lambda;
+      if(!be_ok(dlg_gauss_newton(d->be, slot_of(d, pt), &ctx->lambda, &n2), "factorization + GN solve")) return false;
+      if(ctx->lambda != lambda_before) VERBOSE(d, "singular JtJ: adding %g I from now on", ctx->lambda);
+      if(ctx->solve_type == DOGLEG_SPARSE) d->factor_handle.minor = d->factor_handle.n;
+      pt->have_factorization = true;
+    }
+    else if(!be_ok(dlg_solve_gn(d->be, slot_of(d, pt), &n2), "GN solve")) return false;
     pt->norm2_updateGN = n2;
     pt->have_updateGN = true;
     VERBOSE(d, "gn step length %.6g", sqrt(n2));

@@ -606,6 +606,7 @@ int products_quadform(dlg_backend* b, int s, const double* v, double* out_dev)
 static int finish_potrf(dlg_backend* b, int* ok)
 {
   DLG_HIP(hipMemcpyAsync(b->h_info, b->d_info, sizeof(int), hipMemcpyDeviceToHost, b->stream));
+  if(b->defer_factor_sync) { *ok = 1; return DLG_OK; }        // the caller reads dense_factor_ok() later
   DLG_HIP(hipStreamSynchronize(b->stream));
   *ok = (*b->h_info == 0);
   return DLG_OK;
@@ -759,3 +760,5 @@ extern "C" int dlg_probe_hbm_copy(double* gbs)
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipFree(a); (void)hipFree(c);
   return DLG_OK;
 }
+
+bool dense_factor_ok(const dlg_backend* b) { return *b->h_info == 0; }

@@ -102,10 +102,12 @@ int sparse_factorize(dlg_backend* b, int s, double lambda, int* ok)
   DLG_CHECK(sparse_factor_levels(b));
   DLG_HIP(hipMemcpyAsync(Y->h_info, Y->d_info, sizeof(int), hipMemcpyDeviceToHost, st));
   if(pf.e) { dlg_prof_end(b, pf.id, pf.e); pf.e = nullptr; }
+  if(b->defer_factor_sync) { *ok = 1; return DLG_OK; }        // the caller reads sparse_factor_ok() later
   DLG_HIP(hipStreamSynchronize(st));
-  *ok = (*Y->h_info == 0x7fffffff);
+  *ok = sparse_factor_ok(b);
   return DLG_OK;
 }
+bool sparse_factor_ok(const dlg_backend* b) { return *b->sym->h_info == 0x7fffffff; }
 
 // host-only: run the symbolic phase on a pattern and report its statistics
 // (no GPU needed; used by the CPU test-suite and by tools/)
