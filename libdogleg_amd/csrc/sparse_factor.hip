@@ -281,6 +281,7 @@ __global__ void __launch_bounds__(NT) k_update_syrk(const int* __restrict__ lvl_
 // blocks of the U_d it is fed from into wave-private LDS slabs (waves take sub-tasks round
 // robin), sums the slabs in wave order and applies / stores the result like the other update
 // kernels.
+constexpr int GATHER_FLIGHT = 4;        // sub-tasks whose loads are in flight together
 __global__ void __launch_bounds__(TPB) k_update_gather(int unit0, const int* __restrict__ uw_item,
                                                        const int* __restrict__ uw_s0,
                                                        const int* __restrict__ uw_s1,
@@ -315,7 +316,7 @@ __global__ void __launch_bounds__(TPB) k_update_gather(int unit0, const int* __r
     double* acc = lds + (size_t)w*slab;
     // the records of this wave's sub-tasks (s0 + w, s0 + w + nw, ...): lane l fetches record l of
     // the current batch of 64 with one load per field, the loop broadcasts them with readlane;
-    // two sub-tasks are in flight at a time
+    // GATHER_FLIGHT sub-tasks are in flight at a time
     const int nmine = (s1 - s0 - w + nw - 1)/nw;
     for(int k0 = 0; k0 < nmine; k0 += 64)
     {
@@ -325,41 +326,38 @@ __global__ void __launch_bounds__(TPB) k_update_gather(int unit0, const int* __r
       const int r_rel = R.rel, r_mb = R.nrows_d - R.wd, r_m = R.m;
       const int r_ulo = (int)(uint32_t)ru, r_uhi = (int)(ru >> 32);
       const int nb = min(64, nmine - k0);
-      for(int k = 0; k < nb; k += 2)
+      for(int k = 0; k < nb; k += GATHER_FLIGHT)
       {
-        const int ka = k, kb = min(k + 1, nb - 1);
-        const bool two = k + 1 < nb;
-        const int relA = __builtin_amdgcn_readlane(r_rel, ka), relB = __builtin_amdgcn_readlane(r_rel, kb);
-        const int mbA = __builtin_amdgcn_readlane(r_mb, ka), mbB = __builtin_amdgcn_readlane(r_mb, kb);
-        const int mA = __builtin_amdgcn_readlane(r_m, ka), mB = two ? __builtin_amdgcn_readlane(r_m, kb) : 0;
-        const double* UA = uscr + (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readlane(r_uhi, ka) << 32) | (uint32_t)__builtin_amdgcn_readlane(r_ulo, ka));
-        const double* UB = uscr + (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readlane(r_uhi, kb) << 32) | (uint32_t)__builtin_amdgcn_readlane(r_ulo, kb));
-        for(int i0 = 0; i0 < max(mA, mB); i0 += 64)
+        int relv[GATHER_FLIGHT], mbv[GATHER_FLIGHT], mv[GATHER_FLIGHT], mmax = 0;
+        const double* Uv[GATHER_FLIGHT];
+#pragma unroll
+        for(int g = 0; g < GATHER_FLIGHT; g++)
+        {
+          const int kg = min(k + g, nb - 1);
+          relv[g] = __builtin_amdgcn_readlane(r_rel, kg);
+          mbv[g] = __builtin_amdgcn_readlane(r_mb, kg);
+          mv[g] = (k + g < nb) ? __builtin_amdgcn_readlane(r_m, kg) : 0;
+          Uv[g] = uscr + (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readlane(r_uhi, kg) << 32) | (uint32_t)__builtin_amdgcn_readlane(r_ulo, kg));
+          mmax = max(mmax, mv[g]);
+        }
+        for(int i0 = 0; i0 < mmax; i0 += 64)
         {
           const int i = i0 + lane;
           const int cmax = (i < nc - 1) ? i : nc - 1;
-          const int iA = min(i, mA - 1), iB = min(i, max(mB, 1) - 1);
-          const int rA = relpos[relA + iA], rB = relpos[relB + iB];
-          double vA[8], vB[8];
+          int ig[GATHER_FLIGHT], rg[GATHER_FLIGHT];
+          double v[GATHER_FLIGHT][8];
 #pragma unroll
-          for(int c = 0; c < 8; c++)
-            if(c < nc)
-            {
-              const int cc = min(c, cmax);          // entries above the diagonal are never written
-              vA[c] = UA[iA + (size_t)cc*mbA]; vB[c] = UB[iB + (size_t)cc*mbB];
-            }
+          for(int g = 0; g < GATHER_FLIGHT; g++) { ig[g] = min(i, max(mv[g], 1) - 1); rg[g] = relpos[relv[g] + ig[g]]; }
 #pragma unroll
-          for(int c = 0; c < 8; c++)
-            if(c < nc)
-            {
-              if(i < mA && c <= cmax) acc[rA + c*nrows_t] += vA[c];
-            }
+          for(int g = 0; g < GATHER_FLIGHT; g++)
 #pragma unroll
-          for(int c = 0; c < 8; c++)
-            if(c < nc)
-            {
-              if(i < mB && c <= cmax) acc[rB + c*nrows_t] += vB[c];
-            }
+            for(int c = 0; c < 8; c++)
+              if(c < nc) v[g][c] = Uv[g][ig[g] + (size_t)min(c, cmax)*mbv[g]];   // entries above the diagonal are never written
+#pragma unroll
+          for(int g = 0; g < GATHER_FLIGHT; g++)
+#pragma unroll
+            for(int c = 0; c < 8; c++)
+              if(c < nc) { if(i < mv[g] && c <= cmax) acc[rg[g] + c*nrows_t] += v[g][c]; }
         }
       }
     }
