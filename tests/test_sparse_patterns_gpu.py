@@ -148,3 +148,55 @@ def test_wide_dense_tail(gpu):
     x = rng.standard_normal(M)
     st = _check_pattern(N, M, Jp, Ji, Jx, x, tol=1e-7)
     print("wide dense tail:", st)
+
+
+def _random_structured_pattern(rng):
+    """variable blocks of random widths, a few of them 'dense' (touched by every row), rows drawn
+    from a small set of templates and repeated 1..10 times (row-blocks), random values"""
+    nblk = int(rng.integers(6, 40))
+    widths = rng.integers(1, 10, size=nblk)
+    starts = np.concatenate([[0], np.cumsum(widths)])
+    N = int(starts[-1])
+    ndense = int(rng.integers(0, 3))
+    dense_blocks = list(rng.choice(nblk, size=ndense, replace=False)) if ndense else []
+    templates = []
+    for _ in range(int(rng.integers(3, 60))):
+        k = int(rng.integers(1, min(5, nblk) + 1))
+        blks = set(rng.choice(nblk, size=k, replace=False).tolist()) | set(dense_blocks)
+        templates.append(sorted(blks))
+    rows = []
+    target = int(rng.integers(N + 20, 6 * N + 200))
+    while len(rows) < target:
+        t = templates[int(rng.integers(0, len(templates)))]
+        idx = np.concatenate([np.arange(starts[b], starts[b + 1]) for b in t])
+        for _ in range(int(rng.integers(1, 11))):
+            rows.append(idx)
+    # every block gets as many rows of its own as it is wide, so that J has full column rank
+    # (the values of these rows are boosted by the caller)
+    ntail = 0
+    for b in range(nblk):
+        for _ in range(int(widths[b])):
+            rows.append(np.arange(starts[b], starts[b + 1]))
+            ntail += int(widths[b])
+    return N, rows, ntail
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_structured_patterns(gpu, seed, monkeypatch):
+    """stress of the symbolic phase and the schedules (layout classes, riders with a low threshold,
+    partial-sum stages, slices, every update path) on randomly structured problems"""
+    rng = np.random.default_rng(1000 + seed)
+    if seed % 3 == 0:
+        monkeypatch.setenv("DOGLEG_AMD_RIDER_MIN", "16")       # riders even on small problems
+    if seed % 4 == 1:
+        monkeypatch.setenv("DOGLEG_AMD_SYRK_MIN", "2")         # two-phase updates at small levels
+    if seed % 5 == 2:
+        monkeypatch.setenv("DOGLEG_AMD_SLICE_CAP", "3000")     # sliced panels
+    N, rows, ntail = _random_structured_pattern(rng)
+    Jp, Ji = _rows_to_csc(rows, N)
+    M = len(rows)
+    Jx = rng.standard_normal(Jp[-1])
+    tail = Jp[-1] - ntail
+    Jx[tail:] *= 4.0                                           # JtJ comfortably positive definite
+    x = rng.standard_normal(M)
+    _check_pattern(N, M, Jp, Ji, Jx, x, tol=1e-8)
