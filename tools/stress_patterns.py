@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""Hunt for rare schedule bugs: many random structured patterns (tests/test_sparse_patterns_gpu.py's
+generator) with the schedule knobs varied, each checked against the oracle.  usage: stress_patterns.py [n] [seed0]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from tests.test_sparse_patterns_gpu import _random_structured_pattern, _rows_to_csc, _check_pattern
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 5000
+knobs = ["DOGLEG_AMD_RIDER_MIN", "DOGLEG_AMD_SYRK_MIN", "DOGLEG_AMD_SLICE_CAP", "DOGLEG_AMD_ASM_MFMA",
+         "DOGLEG_AMD_RUN_KG", "DOGLEG_AMD_UNIT_COST", "DOGLEG_AMD_ND_LEAF", "DOGLEG_AMD_SIB_W"]
+bad = 0
+for s in range(seed0, seed0 + n):
+    rng = np.random.default_rng(s)
+    for k in knobs:
+        os.environ.pop(k, None)
+    cfg = {}
+    if rng.random() < 0.5: cfg["DOGLEG_AMD_RIDER_MIN"] = str(int(rng.choice([0, 8, 16, 64])))
+    if rng.random() < 0.5: cfg["DOGLEG_AMD_SYRK_MIN"] = str(int(rng.choice([0, 1, 2, 4])))
+    if rng.random() < 0.4: cfg["DOGLEG_AMD_SLICE_CAP"] = str(int(rng.choice([1500, 3000, 6000])))
+    if rng.random() < 0.15: cfg["DOGLEG_AMD_ASM_MFMA"] = "0"
+    if rng.random() < 0.3: cfg["DOGLEG_AMD_RUN_KG"] = str(int(rng.choice([4, 8, 64])))
+    if rng.random() < 0.3: cfg["DOGLEG_AMD_UNIT_COST"] = str(int(rng.choice([64, 128, 2048])))
+    if rng.random() < 0.3: cfg["DOGLEG_AMD_ND_LEAF"] = str(int(rng.choice([8, 40, 200])))
+    if rng.random() < 0.3: cfg["DOGLEG_AMD_SIB_W"] = str(int(rng.choice([0, 16, 64])))
+    os.environ.update(cfg)
+    N, rows, ntail = _random_structured_pattern(rng)
+    Jp, Ji = _rows_to_csc(rows, N)
+    M = len(rows)
+    Jx = rng.standard_normal(Jp[-1])
+    Jx[Jp[-1] - ntail:] *= 4.0
+    x = rng.standard_normal(M)
+    try:
+        _check_pattern(N, M, Jp, Ji, Jx, x, tol=1e-8)
+    except Exception as e:
+        bad += 1
+        print("FAIL seed", s, cfg, "N", N, "M", M, repr(e)[:300], flush=True)
+print(f"{n - bad} of {n} passed")
+sys.exit(1 if bad else 0)
