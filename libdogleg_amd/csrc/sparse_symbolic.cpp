@@ -1046,7 +1046,9 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
           for(int x = 0; x < b.nvb; x++) if(bpos[rb_vb[b.vptr + x]] >= qJ) mask |= 1ull << x;
         }
         const int rider = rb_host[bi] == J ? rb_rider[bi] : -1;
-        const int lay = rb_layout[bi], xJ = rx[e];
+        // a rider only reads its own block: rows with the same offset of that block are one class,
+        // whatever else they contain
+        const int lay = is_rider ? rb_off[b.vptr + rx[e]] : rb_layout[bi], xJ = is_rider ? 0 : rx[e];
         int c = -1;
         if(last_cls >= 0 && classes[last_cls].lay == lay && classes[last_cls].xJ == xJ &&
            classes[last_cls].mask == mask && classes[last_cls].rider == rider) c = last_cls;
@@ -1055,7 +1057,7 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
             if(classes[q].lay == lay && classes[q].xJ == xJ && classes[q].mask == mask && classes[q].rider == rider) { c = (int)q; break; }
         if(c < 0)
         {
-          if(classes.size() >= 64) return false;
+          if(classes.size() >= (is_rider ? 4096u : 64u)) return false;
           c = (int)classes.size(); classes.emplace_back();
           Cls& C = classes.back();
           C.lay = lay; C.xJ = xJ; C.mask = mask; C.rider = rider;

@@ -150,17 +150,17 @@ def test_wide_dense_tail(gpu):
     print("wide dense tail:", st)
 
 
-def _random_structured_pattern(rng):
+def _random_structured_pattern(rng, scale=1):
     """variable blocks of random widths, a few of them 'dense' (touched by every row), rows drawn
     from a small set of templates and repeated 1..10 times (row-blocks), random values"""
-    nblk = int(rng.integers(6, 40))
+    nblk = int(rng.integers(6, 40))*scale
     widths = rng.integers(1, 10, size=nblk)
     starts = np.concatenate([[0], np.cumsum(widths)])
     N = int(starts[-1])
     ndense = int(rng.integers(0, 3))
     dense_blocks = list(rng.choice(nblk, size=ndense, replace=False)) if ndense else []
     templates = []
-    for _ in range(int(rng.integers(3, 60))):
+    for _ in range(int(rng.integers(3, 60))*scale):
         k = int(rng.integers(1, min(5, nblk) + 1))
         blks = set(rng.choice(nblk, size=k, replace=False).tolist()) | set(dense_blocks)
         templates.append(sorted(blks))
@@ -200,3 +200,18 @@ def test_random_structured_patterns(gpu, seed, monkeypatch):
     Jx[tail:] *= 4.0                                           # JtJ comfortably positive definite
     x = rng.standard_normal(M)
     _check_pattern(N, M, Jp, Ji, Jx, x, tol=1e-8)
+
+
+@pytest.mark.parametrize("seed", [9026, 9030, 9052])
+def test_dense_block_with_many_row_layouts(gpu, seed, monkeypatch):
+    """regression: a dense column block (no tasks of its own, carried by other column blocks) whose
+    left-over rows come in more than 64 different layouts used to have no assembly schedule"""
+    monkeypatch.setenv("DOGLEG_AMD_RIDER_MIN", "8")
+    rng = np.random.default_rng(seed)
+    N, rows, ntail = _random_structured_pattern(rng, scale=20)
+    Jp, Ji = _rows_to_csc(rows, N)
+    M = len(rows)
+    Jx = rng.standard_normal(Jp[-1])
+    Jx[Jp[-1] - ntail:] *= 4.0
+    x = rng.standard_normal(M)
+    _check_pattern(N, M, Jp, Ji, Jx, x, tol=1e-6)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Hunt for rare schedule bugs: many random structured patterns (tests/test_sparse_patterns_gpu.py's
-generator) with the schedule knobs varied, each checked against the oracle.  usage: stress_patterns.py [n] [seed0]"""
+generator) with the schedule knobs varied, each checked against the oracle.  usage: stress_patterns.py [n] [seed0] [scale]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -8,6 +8,7 @@ from tests.test_sparse_patterns_gpu import _random_structured_pattern, _rows_to_
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 5000
+scale = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 knobs = ["DOGLEG_AMD_RIDER_MIN", "DOGLEG_AMD_SYRK_MIN", "DOGLEG_AMD_SLICE_CAP", "DOGLEG_AMD_ASM_MFMA",
          "DOGLEG_AMD_RUN_KG", "DOGLEG_AMD_UNIT_COST", "DOGLEG_AMD_ND_LEAF", "DOGLEG_AMD_SIB_W"]
 bad = 0
@@ -25,7 +26,7 @@ for s in range(seed0, seed0 + n):
     if rng.random() < 0.3: cfg["DOGLEG_AMD_ND_LEAF"] = str(int(rng.choice([8, 40, 200])))
     if rng.random() < 0.3: cfg["DOGLEG_AMD_SIB_W"] = str(int(rng.choice([0, 16, 64])))
     os.environ.update(cfg)
-    N, rows, ntail = _random_structured_pattern(rng)
+    N, rows, ntail = _random_structured_pattern(rng, scale)
     Jp, Ji = _rows_to_csc(rows, N)
     M = len(rows)
     Jx = rng.standard_normal(Jp[-1])
