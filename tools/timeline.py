@@ -2,7 +2,7 @@
 """Print the kernel timeline of the last bench step from a rocprofv3 kernel trace."""
 import csv, glob, sys
 rows = list(csv.DictReader(open(glob.glob(sys.argv[1] + '/**/*kernel_trace.csv', recursive=True)[0])))
-idx = [i for i, r in enumerate(rows) if ('k_assemble(' in r['Kernel_Name'] or 'k_assemble_mfma(' in r['Kernel_Name'])]
+idx = [i for i, r in enumerate(rows) if ('k_assemble(' in r['Kernel_Name'] or 'k_assemble_mfma' in r['Kernel_Name'])]
 start = idx[-1]
 seq = []
 for r in rows[start:]:
