@@ -668,6 +668,9 @@ int sparse_factor_setup(dlg_backend* b)
     if(maxslab > 0) { nw = (int)(LDS_BUDGET/(maxslab*8)); if(nw > 4) nw = 4; }
     Y->upd_nw[l] = nw;
     Y->upd_lds[l] = (int)(maxslab*8*nw);
+    // heavy sources: 2 = matrix-core update kernel (needs the target slabs in LDS), 1 = cooperative
+    // kernel accumulating in HBM (also selectable with DOGLEG_AMD_NO_UPDATE_MFMA for testing)
+    if(Y->upd_coop[l] && nw > 0 && !getenv("DOGLEG_AMD_NO_UPDATE_MFMA")) Y->upd_coop[l] = 2;
     if(H.upd_syrk[l])
     {
       long ldbmax = 0, k4max = 0, tmax = 0;
@@ -754,7 +757,7 @@ int sparse_factor_levels(dlg_backend* b)
                          Y->usub, Y->usub_u, Y->relpos, Y->sn_rowptr, Y->sn_lx, Y->Lx, Y->upart, Y->uscr,
                          Y->upd_nw[l]);
     }
-    else if(nu > 0 && Y->upd_coop[l] && Y->upd_nw[l] > 0 && !getenv("DOGLEG_AMD_NO_UPDATE_MFMA"))
+    else if(nu > 0 && Y->upd_coop[l] == 2)
       hipLaunchKernelGGL(k_update_mfma, dim3(nu), dim3(TPB), Y->upd_lds[l], st, H.uw_lvl_ptr[l],
                          Y->uw_item, Y->uw_s0, Y->uw_s1, Y->uw_part, Y->ui_t, Y->ui_col, Y->ui_nc,
                          Y->usub, Y->relpos, Y->sn_rowptr, Y->sn_lx, Y->Lx, Y->upart, Y->upd_nw[l]);
