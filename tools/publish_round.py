@@ -23,7 +23,7 @@ def pmc(wl, counter, kernel):
     f = os.path.join(src, f"pmc_{wl}_{counter}.txt")
     best = None
     for line in open(f):
-        if line.startswith(kernel + " ") or (" " + kernel + " ") in (" " + line):
+        if kernel in line.split(" dispatches")[0]:
             m = re.search(r"'%s': ([0-9.]+)" % counter, line)
             if m:
                 best = float(m.group(1))
