@@ -103,7 +103,9 @@ __global__ void __launch_bounds__(BWD_NT) k_solve_bwd_level(const int* __restric
                                                             const int* __restrict__ perm,
                                                             const double* __restrict__ Lx,
                                                             double* __restrict__ ywork,
-                                                            double* __restrict__ out, int use_aug)
+                                                            double* __restrict__ out, int use_aug,
+                                                            const int* __restrict__ sn_bd_ptr,
+                                                            const int* __restrict__ sn_bd_col)
 {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int s = lvl_sn[blockIdx.x];
@@ -118,8 +120,11 @@ __global__ void __launch_bounds__(BWD_NT) k_solve_bwd_level(const int* __restric
   double* xs = lds + ((r + 1) & ~1);      // [256] right-hand side, then the solution
   double* T = xs + 256;                   // [nblk][8][8] diagonal blocks (lower), reciprocal pivots
   double* rhs = T + nblk*64;              // [2][8]
+  // block-diagonal top (merged sibling leaves): the members do not couple, every member is a
+  // little triangular system of its own -- no sweep over the columns at all
+  const int nmem = sn_bd_ptr[s+1] - sn_bd_ptr[s];
   for(int i = tid; i < r; i += BWD_NT) xb[i] = ywork[rows[w + i]];
-  for(int e = tid; e < nblk*64; e += BWD_NT)
+  for(int e = tid; e < (nmem > 0 ? 0 : nblk*64); e += BWD_NT)
   {
     const int j0 = (e >> 6)*8, a = (e >> 3) & 7, b = e & 7;
     const bool valid = a >= b && j0 + a < w;
@@ -150,6 +155,32 @@ __global__ void __launch_bounds__(BWD_NT) k_solve_bwd_level(const int* __restric
     }
   }
   __syncthreads();
+  if(nmem > 0)
+  {
+    const int* mcol = sn_bd_col + sn_bd_ptr[s];
+    for(int m = tid; m < nmem; m += BWD_NT)
+    {
+      const int m0 = mcol[m], nb = ((m + 1 < nmem) ? mcol[m+1] : w) - m0;
+      double Lm[8][8], xk[8];
+#pragma unroll
+      for(int a = 0; a < 8; a++)
+#pragma unroll
+        for(int b = 0; b <= a; b++) Lm[a][b] = (a < nb) ? L[(m0 + a) + (size_t)(m0 + b)*nrows] : (a == b ? 1.0 : 0.0);
+#pragma unroll
+      for(int a = 7; a >= 0; a--)
+      {
+        double v = (a < nb) ? xs[m0 + a] : 0.0;
+#pragma unroll
+        for(int b = a + 1; b < 8; b++) v -= Lm[b][a]*xk[b];
+        xk[a] = v/Lm[a][a];
+      }
+#pragma unroll
+      for(int a = 0; a < 8; a++) if(a < nb) xs[m0 + a] = xk[a];
+    }
+    __syncthreads();
+    for(int j = tid; j < w; j += BWD_NT) { ywork[c0 + j] = xs[j]; out[perm[c0 + j]] = xs[j]; }
+    return;
+  }
   double xi = (tid < w) ? xs[tid] : 0.0;
   const double* Lcol = L + (size_t)min(tid, w - 1)*nrows;      // column tid of L = row tid of L^T
   double lv[8];
@@ -256,11 +287,11 @@ int sparse_solve(dlg_backend* b, const double* rhs, double* out)
     if(n > 0 && Y->bwd_nt[l] == 256)
       hipLaunchKernelGGL(HIP_KERNEL_NAME(k_solve_bwd_level<256>), dim3(n), dim3(256), Y->bwd_lds[l], st,
                          Y->lvl_sn + H.lvl_ptr[l], Y->sn_c0, Y->sn_rowptr, Y->sn_rows, Y->sn_lx, Y->perm, Y->Lx,
-                         Y->ywork, out, use_aug);
+                         Y->ywork, out, use_aug, Y->sn_bd_ptr, Y->sn_bd_col);
     else if(n > 0)
       hipLaunchKernelGGL(HIP_KERNEL_NAME(k_solve_bwd_level<512>), dim3(n), dim3(512), Y->bwd_lds[l], st,
                          Y->lvl_sn + H.lvl_ptr[l], Y->sn_c0, Y->sn_rowptr, Y->sn_rows, Y->sn_lx, Y->perm, Y->Lx,
-                         Y->ywork, out, use_aug);
+                         Y->ywork, out, use_aug, Y->sn_bd_ptr, Y->sn_bd_col);
   }
   DLG_LAUNCH_CHECK();
   return DLG_OK;
