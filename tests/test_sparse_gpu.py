@@ -151,3 +151,38 @@ def test_fallback_kernels_match_oracle(gpu, env, monkeypatch):
         monkeypatch.setenv(k, v)
     st, err = _ops_parity(oa.BAProblem(49, 900, 10000, seed=5))
     print(env, st, f"|gn diff| = {err:.2e}")
+
+
+def test_no_device_memory_leak_over_create_solve_destroy_cycles(gpu):
+    """dlg_backend_destroy / dogleg_optimize2 give back everything they allocated"""
+    hip = C.CDLL("libamdhip64.so")
+
+    def free_bytes():
+        a, b = C.c_size_t(), C.c_size_t()
+        assert hip.hipMemGetInfo(C.byref(a), C.byref(b)) == 0
+        return a.value
+
+    prob = oa.BAProblem(49, 900, 10000, seed=3)
+    Jp, Ji = prob.pattern()
+    p = prob.p0()
+    x, Jx = prob.eval(p)
+    prm = oa.default_params()
+    prm.max_iterations = 2
+
+    def cycle():
+        be = capi.Backend(capi.DLG_SPARSE, prob.N, prob.M, prob.nnz)
+        be.set_pattern(Jp, Ji)
+        be.set_p(0, p)
+        be.upload(0, x, Jx)
+        be.eval(0)
+        be.cauchy(0)
+        be.gauss_newton(0, 0.0)
+        be.make_step(0, 1, capi.KIND_INTERP, 1.0)
+        be.close()
+        capi.optimize("sparse", prob.p0(), prob.N, prob.M, prob.nnz, prob.cb, prob.cookie, prm)
+
+    cycle()                                  # one-off allocations of the runtime (code objects, pools)
+    before = free_bytes()
+    for _ in range(10):
+        cycle()
+    assert before - free_bytes() <= (1 << 20), "device memory is not returned"
