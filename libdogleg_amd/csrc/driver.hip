@@ -384,6 +384,9 @@ bool take_step(double* expectedImprovement, dogleg_operatingPoint_t* to,
   if(kind == DLG_KIND_INTERPOLATED) VERBOSE(d, "k_cauchy_to_gn %.6g, norm %.6g", k, sqrt(n2));
 
   if(!be_ok(dlg_expected_improvement(d->be, sf, st, expectedImprovement), "expected improvement")) return false;
+  // the diagnostics record the computed value, also for the terminal step whose return value is
+  // replaced by -1 below (dogleg.c:1267-1269 comes before 1289-1296)
+  d->cur.expected_improvement = *expectedImprovement;
 
   // dogleg.c:1289-1296: every |step_i| <= update_threshold -> signal termination
   if(!(amax > ctx->parameters->update_threshold))
@@ -442,7 +445,6 @@ int run_optimizer(Driver* d)
       double expectedImprovement;
       if(!take_step(&expectedImprovement, ctx->afterStep, ctx->beforeStep, trustregion, d)) return -1;
       ctx->afterStep->have_step_to_here = true;
-      d->cur.expected_improvement = expectedImprovement;
 
       if(expectedImprovement < 0.0)                 // dogleg.c:1403-1408: step NOT applied
       { emit(d, stepCount, 2); return stepCount; }

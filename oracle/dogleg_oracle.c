@@ -757,6 +757,9 @@ static int take_step(double* expectedImprovement, double* p_new, double* step,
   }
   for(int i = 0; i < c->N; i++) p_new[i] = from->p[i] + step[i];
   if(!expected_improvement(expectedImprovement, step, from, c)) return 0;
+  /* the diagnostics record the computed value (dogleg.c:1267-1269), also for the terminal step
+     whose return value is replaced by -1 below (dogleg.c:1289-1296) */
+  c->cur.expected_improvement = *expectedImprovement;
   c->cur.norm2_step = *norm2_step;
   c->cur.did_step_to_edge = from->didStepToEdge;
 
@@ -836,7 +839,6 @@ static int run_optimizer(orc_ctx_t* c)
                     &c->after->norm2_step_to_here, c->before, trustregion, c))
         return -1;
       c->after->have_step_to_here = 1;
-      c->cur.expected_improvement = expectedImprovement;
 
       if(expectedImprovement < 0.0) { trace_emit(c, stepCount, 2); return stepCount; }   /* :1403-1408 */
 
