@@ -49,7 +49,7 @@ def test_reference_sample_check_passes_on_the_gpu(gpu, mode):
 
 @needs_bins
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["sparse", "dense"])
+@pytest.mark.parametrize("mode", MODES)
 def test_reference_sample_vnlog_stream_matches_the_golden_trace(gpu, mode):
     """`sample --diag vnlog <mode>`: the vnlog records the driver prints for the reference's program are
     those of SURVEY.md Appendix B (tests/golden/sample_trace.json), field by field at %g precision"""
