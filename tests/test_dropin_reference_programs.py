@@ -69,3 +69,24 @@ def test_reference_sample_vnlog_stream_matches_the_golden_trace(gpu, mode):
                 # tiny terms (4 digits)
                 rel = 1e-4 if (want is t["vnlog"][-1]) else 2e-5
                 assert math.isclose(float(g), float(w), rel_tol=rel, abs_tol=1e-300), (got, want)
+
+
+@needs_bins
+@pytest.mark.parametrize("mode", ["sparse", "dense"])
+def test_reference_sample_gradient_tables(mode):
+    """`sample --test-gradients <mode>` (sample.c:392-405): the reference's program drives
+    dogleg_testGradient{,_dense} for every variable and returns; host only.  6 tables of 100 rows,
+    reported and observed gradients agree."""
+    r = subprocess.run([SAMPLE, "--test-gradients", mode], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = r.stdout.splitlines()
+    assert sum(1 for l in lines if l.startswith("# ivar imeasurement")) == 6
+    rows = [l.split() for l in lines if l and l[0].isdigit()]
+    assert len(rows) == 600
+    for ivar in range(6):
+        sub = [x for x in rows if int(x[0]) == ivar]
+        assert [int(x[1]) for x in sub] == list(range(100))
+        rep = [float(x[2]) for x in sub]
+        obs = [float(x[3]) for x in sub]
+        scale = max(1.0, max(abs(v) for v in rep))
+        assert max(abs(a - b) for a, b in zip(rep, obs)) <= 1e-4 * scale
