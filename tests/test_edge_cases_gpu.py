@@ -108,3 +108,55 @@ def test_huge_trust_region_is_cut_down_by_rejections(gpu):
     prm.trustregion0 = 1e6
     trg, tro = _both("dense", _dense_cb(J0, xs, M, N, 2.5), np.full(N, 4.0), N, M, prm, tol=1e-9)
     assert any(not t["accepted"] for t in trg.trials())
+
+
+def test_legacy_entry_points_use_the_global_parameters(gpu):
+    """dogleg_optimize / dogleg_optimize_dense (reference dogleg.h:278-292) read the process-global
+    parameters edited by dogleg_setMaxIterations, dogleg_setInitialTrustregion,
+    dogleg_setTrustregionUpdateParameters, dogleg_setThresholds, dogleg_setDebug (dogleg.h:216-257,
+    dogleg.c:131-181): a solve through them equals dogleg_optimize*2 with the same values in a struct"""
+    L = capi.lib()
+    D, U, V = C.POINTER(C.c_double), C.c_uint, C.c_void_p
+    L.dogleg_optimize.restype = C.c_double
+    L.dogleg_optimize.argtypes = [D, U, U, U, V, V, V]
+    L.dogleg_optimize_dense.restype = C.c_double
+    L.dogleg_optimize_dense.argtypes = [D, U, U, V, V, V]
+    L.dogleg_setMaxIterations.argtypes = [C.c_int]
+    L.dogleg_setInitialTrustregion.argtypes = [C.c_double]
+    L.dogleg_setTrustregionUpdateParameters.argtypes = [C.c_double] * 4
+    L.dogleg_setThresholds.argtypes = [C.c_double] * 3
+    L.dogleg_setDebug.argtypes = [C.c_int]
+    rng = np.random.default_rng(9)
+    M, N = 40, 5
+    J0, xs = rng.standard_normal((M, N)), 2.0 * rng.standard_normal(M)
+    prm = oa.default_params()
+    prm.max_iterations = 7
+    prm.trustregion0 = 0.37
+    prm.trustregion_decrease_factor, prm.trustregion_decrease_threshold = 0.2, 0.3
+    prm.trustregion_increase_factor, prm.trustregion_increase_threshold = 3.0, 0.7
+    prm.Jt_x_threshold, prm.update_threshold, prm.trustregion_threshold = 1e-7, 1e-7, 1e-7
+    L.dogleg_setMaxIterations(7)
+    L.dogleg_setInitialTrustregion(0.37)
+    L.dogleg_setTrustregionUpdateParameters(0.2, 0.3, 3.0, 0.7)
+    L.dogleg_setThresholds(1e-7, 1e-7, 1e-7)
+    L.dogleg_setDebug(0)
+    try:
+        for kind in ("dense", "sparse"):
+            cb = (_dense_cb if kind == "dense" else _sparse_cb)(J0, xs, M, N, 1.2)
+            addr = C.cast(cb, C.c_void_p)
+            p2 = np.full(N, 0.5)
+            r2, p2o, tr2 = capi.optimize(kind, p2, N, M, M * N if kind == "sparse" else 0, addr, None, prm)
+            p1 = np.full(N, 0.5)
+            if kind == "dense":
+                r1 = L.dogleg_optimize_dense(p1.ctypes.data_as(D), N, M, addr, None, None)
+            else:
+                r1 = L.dogleg_optimize(p1.ctypes.data_as(D), N, M, M * N, addr, None, None)
+            assert r1 == r2 and np.array_equal(p1, p2o), (kind, r1, r2)
+            assert tr2.ntrials >= 3
+    finally:                                               # back to the defaults (dogleg.c:117-128)
+        d = oa.default_params()
+        L.dogleg_setMaxIterations(d.max_iterations)
+        L.dogleg_setInitialTrustregion(d.trustregion0)
+        L.dogleg_setTrustregionUpdateParameters(d.trustregion_decrease_factor, d.trustregion_decrease_threshold,
+                                                d.trustregion_increase_factor, d.trustregion_increase_threshold)
+        L.dogleg_setThresholds(d.Jt_x_threshold, d.update_threshold, d.trustregion_threshold)
