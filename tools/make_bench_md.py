@@ -13,6 +13,10 @@ s1, d5 = stats("sparse-1m", 23, 18), stats("dense-50k", 11, 12)
 e2e = json.load(open(os.path.join(P, f"{tag}_e2e_sparse1m.json")))
 t = json.load(open(os.path.join(P, "traffic.json")))["sparse-1m"]
 r, rd = B["sparse1m"]["roofline"], B["dense50k"]["roofline"]
+sy = B["sparse1m"]["symbolic"]
+k5b = 8.0*(sy["nnz_JtJ_lower"] + sy["nnz_L"]); k5f = sy["factor_flops"]; k5t = B["sparse1m"]["phases_ms_per_step"]["K5_factor"]
+k6b = 16.0*sy["nnz_L"] + 32.0*B["sparse1m"]["config"]["Nstate"]; k6t = B["sparse1m"]["phases_ms_per_step"]["K6_solve"]
+nlev = sy["n_levels"]
 def row(k, label):
     b = B[k]; c = b.get("cpu_baseline")
     if c:
@@ -56,6 +60,10 @@ Roofline of the JtJ assembly kernel:
   TFLOP/s datasheet fp64-matrix peak, 89 % of the 48 TFLOP/s a register-only
   v_mfma_f64_16x16x4_f64 loop sustains on this box (`tools/gpu_probe.py`, {tag}_probe.txt).
 * sparse `k_norm2_Jv` (K3/K8): 192 MB / 56 us = 3.4 TB/s = 43 % of 8 TB/s; traffic 203 MB (1.06x).
+* K5-sparse and K6-sparse are latency / critical-path bound (SURVEY 8d says to expect low fractions and to
+  say so): sparse-1m K5 = {k5b/1e6:.0f} MB algorithmic (`8 nnz(tril JtJ) + 8 nnz(L)`) and {k5f/1e9:.2f} GFLOP in {k5t:.2f} ms
+  = {k5b/k5t/1e6:.0f} GB/s ({100*k5b/k5t/1e6/8000:.1f} % of HBM), {k5f/k5t/1e9:.2f} TFLOP/s; K6 = {k6b/1e6:.0f} MB (`16 nnz(L) + 32 N`) in {k6t:.2f} ms
+  = {k6b/k6t/1e6:.0f} GB/s ({100*k6b/k6t/1e6/8000:.1f} %).  {nlev} elimination-tree levels, about 110 us each above the leaves.
 
 rocprofv3 --stats, sparse-1m (20 timed + 3 warm-up steps; ms/step = total/23):
 ```
