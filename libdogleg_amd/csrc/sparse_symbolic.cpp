@@ -50,7 +50,7 @@ struct Orderer
   int leaf_w;
 
   explicit Orderer(const Graph& g) : G(g), removed(g.n, 0), mark(g.n, 0)
-  { leaf_w = env_int("DOGLEG_AMD_ND_LEAF", 1500); }
+  { leaf_w = env_int("DOGLEG_AMD_ND_LEAF", 300); }
 
   // BFS over `in_set`-stamped nodes from root; fills levels; returns eccentricity
   int bfs(int root, int setstamp, std::vector<int>& order, std::vector<int>& lvl_start,
