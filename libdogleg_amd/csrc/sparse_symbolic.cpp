@@ -533,6 +533,15 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
     const int relax = env_int("DOGLEG_AMD_RELAX_PCT", 25);
     const int sib_w = env_int("DOGLEG_AMD_SIB_W", 64);
     const long chain_cap = env_int("DOGLEG_AMD_CHAIN_CAP", PANEL_CAP);   // width cap of chain supernodes: W*(W+64)
+    // width of the fundamental supernode (maximal chain of exactly nested block columns) starting at j:
+    // a relaxed merge across a structure change takes that whole run or nothing -- stopping in the
+    // middle of it at the width cap leaves fragments that cost an elimination-tree level each
+    std::vector<long> run_w(nvb + 1, 0);
+    for(int j = nvb - 1; j >= 0; j--)
+    {
+      const bool exact_next = j + 1 < nvb && parent[j] == j + 1 && st[j].size() == st[j+1].size() + 1;
+      run_w[j] = G.w[border[j]] + (exact_next ? run_w[j+1] : 0);
+    }
     int a = 0;
     long W = G.w[border[0]];              // current width
     long true_nnz = W*stw[0];             // sum_j w_j * |struct_j| (scalar) for columns in the supernode
@@ -555,7 +564,9 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
         const bool exact = (st[j].size() == st[j+1].size() + 1);
         // a panel is factored in row slices (>= 64 rows each) that all carry the w x w top block
         const bool fits = (Wn*(Wn + 64) <= chain_cap) && Wn <= SN_WMAX;
-        if(fits && (exact || Wn <= 16 || zeros*100 <= (long)relax*(stored + Wn*Wn)))
+        const long Wrun = W + run_w[j+1];
+        const bool run_fits = (Wrun*(Wrun + 64) <= chain_cap) && Wrun <= SN_WMAX;
+        if(fits && (exact || (run_fits && (Wn <= 16 || zeros*100 <= (long)relax*(stored + Wn*Wn)))))
         {
           merge = true; sib_only = false; nmerge++;
           W = Wn; true_nnz = tn; below_own = own_after;
