@@ -856,8 +856,8 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
     const int nitems = (int)S.ui_t.size();
     // chunking by estimated cost: a light sub-task (narrow source) counts 1, a
     // heavy one counts by its thread-iterations; a unit is closed at UNIT_COST
-    const int unit_cost = env_int("DOGLEG_AMD_UNIT_COST", 512);
-    const int unit_cost_gather = std::max(1, unit_cost/std::max(1, env_int("DOGLEG_AMD_GATHER_PER_UNIT", 32)));
+    const int unit_cost = env_int("DOGLEG_AMD_UNIT_COST", 1024);
+    const int unit_cost_gather = std::max(1, unit_cost/std::max(1, env_int("DOGLEG_AMD_GATHER_PER_UNIT", 64)));
     std::vector<int> cuts;
     for(int it = 0; it < nitems; it++)
     {
