@@ -6,12 +6,81 @@
 
 namespace {
 typedef double dlg_v4d __attribute__((ext_vector_type(4)));
+// -DDLG_FL_PROFILE: phase clocks of workgroup 0 of every factor launch (tools only)
+#ifdef DLG_FL_PROFILE
+__device__ long long g_fl_prof[64*8];
+#define FL_STAMP(k) do { if(threadIdx.x == 0 && blockIdx.x == 0) g_fl_prof[(prof_lvl & 63)*8 + (k)] = clock64(); } while(0)
+#else
+#define FL_STAMP(k)
+#endif
 
 // ------------------------------------------------------------------ K5 ------
+// Update matrices (U = B B' of a supernode, B = the mb rows below its diagonal block, plus in
+// the multifrontal region what its children left over) are stored as packed lower triangles,
+// column-major: element (i, j), i >= j, at  j*mb - j*(j-1)/2 + (i - j).
+__device__ __forceinline__ int tri_col(int j, int mb) { return j*mb - j*(j - 1)/2 - j; }   // (i, j) at tri_col + i
+
+// multifrontal region: add the update matrices of the children of a supernode into its LDS
+// panel P (entries whose column is one of the supernode's own columns) and into its own update
+// matrix Wt (the others; zeroed here).  The region stores NEGATED update matrices W = -U, so
+// both destinations are plain additions.  The symbolic phase lists the destination of every
+// entry of every child (mf_dst: element offset from P; bit 15: offset into a Wt kept in HBM),
+// padded to whole batches with a scratch slot, so the kernel is a pure stream: a low-occupancy
+// wave pays ~4 cycles per instruction of any kind, and a dependent global load costs
+// microseconds up here -- all loads of a batch (MF_SLOTS entries per thread) are issued
+// together.  One child at a time: inside a child no two entries share a destination, so the
+// sums are in child order.
+template <int NT, bool UT_LDS>
+__device__ __forceinline__ void mf_add_children(double* P, double* Wt, int ntri, int nch, int ch0,
+                                                MfChild rc, const MfChild* __restrict__ mf_rec,
+                                                const double* uscr, const uint16_t* __restrict__ mf_dst, int tid)
+{
+  constexpr int MF_SLOTS = 16;
+  const int lane = tid & 63;
+  for(int e = tid; e < ntri; e += NT) Wt[e] = 0.0;
+  __syncthreads();
+  for(int k = 0; k < nch; k++)
+  {
+    if(k > 0 && (k & 63) == 0) rc = mf_rec[ch0 + k + min(lane, nch - k - 1)];
+    const int npad = __builtin_amdgcn_readlane(rc.npad, k & 63);
+    const int64_t uo = ((int64_t)__builtin_amdgcn_readlane((int)(rc.u_off >> 32), k & 63) << 32) |
+                       (uint32_t)__builtin_amdgcn_readlane((int)rc.u_off, k & 63);
+    const int64_t dof = ((int64_t)__builtin_amdgcn_readlane((int)(rc.dst_off >> 32), k & 63) << 32) |
+                        (uint32_t)__builtin_amdgcn_readlane((int)rc.dst_off, k & 63);
+    const double* Wc = uscr + uo + tid;
+    const uint16_t* D = mf_dst + dof + tid;
+    for(int e0 = 0; e0 < npad; e0 += NT*MF_SLOTS)      // npad is a multiple of 1024: whole rounds of NT
+    {
+      double v[MF_SLOTS], old[MF_SLOTS];
+      unsigned d[MF_SLOTS];
+#pragma unroll
+      for(int u = 0; u < MF_SLOTS; u++)
+        if(e0 + u*NT < npad) { v[u] = Wc[e0 + u*NT]; d[u] = D[e0 + u*NT]; }
+      if(UT_LDS)
+      {
+#pragma unroll
+        for(int u = 0; u < MF_SLOTS; u++) if(e0 + u*NT < npad) old[u] = P[d[u]];
+#pragma unroll
+        for(int u = 0; u < MF_SLOTS; u++) if(e0 + u*NT < npad) P[d[u]] = old[u] + v[u];
+      }
+      else
+      {
+#pragma unroll
+        for(int u = 0; u < MF_SLOTS; u++)
+          if(e0 + u*NT < npad) old[u] = (d[u] & 0x8000) ? Wt[d[u] & 0x7fff] : P[d[u]];
+#pragma unroll
+        for(int u = 0; u < MF_SLOTS; u++)
+          if(e0 + u*NT < npad) { if(d[u] & 0x8000) Wt[d[u] & 0x7fff] = old[u] + v[u]; else P[d[u]] = old[u] + v[u]; }
+      }
+    }
+    __syncthreads();
+  }
+}
+
 // factor one supernode panel per workgroup in LDS (column-major, even leading dimension).
-// One workgroup per work item = (supernode, slice [r0,r1) of its below rows): the LDS panel
-// holds the w x w top block plus the slice (up to ~160 KB); slices of one supernode factor the
-// top block redundantly (identical arithmetic), slice 0 publishes it (top_scr, k_copy_top).
+// One workgroup per work item (FwItem) = (supernode, slice [r0,r1) of its below rows): the LDS
+// panel holds the w x w top block plus the slice (up to ~160 KB); slices of one supernode factor
+// the top block redundantly (identical arithmetic), slice 0 publishes it (top_scr, k_copy_top).
 // The arithmetic is in panel_factor.h:
 //   * regular panels, >= 256 threads: panel_factor_mfma -- per 8 columns wave 0 brings the
 //     diagonal row tile up to date on the matrix cores, factors the 8x8 block in registers and
@@ -19,90 +88,189 @@ typedef double dlg_v4d __attribute__((ext_vector_type(4)));
 //     solves its row; barrier;
 //   * 128 threads: panel_factor (same steps, all waves factor the block redundantly);
 //   * sibling-merged leaves (block-diagonal top): panel_factor_blockdiag, no sweep at all.
-// The panel is copied in and out thread-per-row, 16 columns in flight.
+// mode 1 / 2: the (unsliced) panel's update matrix U = B B' comes straight out of LDS afterwards;
+// mode 2 (multifrontal region) first adds the children's update matrices (mf_add_children), leaves
+// them in U as well and stores W = -U.  U is staged behind the panel in LDS when both fit.
+// The panel is copied in and out thread = (row, column group), CP_FLIGHT columns in flight.
 template <int NT>
-__global__ void __launch_bounds__(NT) k_factor_level(const int* __restrict__ fw_sn,
-                                                     const int* __restrict__ fw_r0,
-                                                     const int* __restrict__ fw_r1,
-                                                     const int* __restrict__ sn_c0,
-                                                     const int* __restrict__ sn_rowptr,
-                                                     const int64_t* __restrict__ sn_lx,
-                                                     const int64_t* __restrict__ sn_top,
-                                                     const int* __restrict__ sn_bd_ptr,
+__global__ void __launch_bounds__(NT) k_factor_level(const FwItem* __restrict__ items,
+                                                     const MfChild* __restrict__ mf_rec,
                                                      const int* __restrict__ sn_bd_col,
+                                                     const uint16_t* __restrict__ mf_dst,
                                                      double* __restrict__ Lx,
                                                      double* __restrict__ top_scr,
                                                      int* __restrict__ info,
-                                                     const int64_t* __restrict__ u_off,
-                                                     double* __restrict__ uscr, int fuse_syrk)
+                                                     double* uscr, int mode)
 {
   extern __shared__ __attribute__((aligned(16))) double P[];
   __shared__ int sbad;
-  const int s = fw_sn[blockIdx.x], r0 = fw_r0[blockIdx.x], r1 = fw_r1[blockIdx.x];
-  const int w = sn_c0[s+1] - sn_c0[s];
-  const int nrows = sn_rowptr[s+1] - sn_rowptr[s];
-  double* G = Lx + sn_lx[s];
-  const int tid = threadIdx.x;
-  const int nloc = w + (r1 - r0);             // rows held by this workgroup
+  constexpr int CP_FLIGHT = 32;
+#ifdef DLG_FL_PROFILE
+  const int prof_lvl = mode >> 8;
+  if(threadIdx.x == 0 && blockIdx.x == 0) g_fl_prof[(prof_lvl & 63)*8] = clock64();
+#endif
+  const bool stage_leaf_u = (mode & 4) != 0;    // childless supernodes may stage U in LDS too (host: no occupancy loss)
+  mode &= 3;
+  const FwItem it = items[blockIdx.x];
+  const int r0 = it.r0, w = it.w, nrows = it.nrows;
+  double* G = Lx + it.lx;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int nloc = w + (it.r1 - r0);          // rows held by this workgroup
   const int ldp = (nloc + 1) & ~1;
   const int shift = r0;                        // local row i >= w  <->  panel row i + shift
+  const int64_t top = it.top;
+  const int mb = nloc - w, ntri = mb*(mb + 1)/2;
+  const bool has_u = mode != 0 && top < 0;
+  const bool u_lds = has_u && (it.nch > 0 || stage_leaf_u) &&
+                     (size_t)(ldp*w + ntri + 1)*sizeof(double) <= (size_t)FAC_LDS_BUDGET;   // + the scratch slot of mf_dst
+  double* Ug = has_u ? uscr + it.u_off : nullptr;
+  double* Us = P + ldp*w;
+  MfChild rc = {0, 0, 0, 0};
+  const bool mf_acc = mode == 2 && it.nch > 0;
+  if(mf_acc) rc = mf_rec[it.ch0 + min(lane, it.nch - 1)];     // on its way during the panel copy
   if(tid == 0) sbad = 0x7fffffff;
-  // thread = panel row, 16 columns in flight (no index arithmetic per element)
-  for(int i = tid; i < nloc; i += NT)
+  // thread = (panel row, column group): rows padded to whole waves, the remaining threads take
+  // further columns
+  const int cp_rows = min(NT, (nloc + 63) & ~63), cp_ng = NT/cp_rows, cp_g = tid/cp_rows;
+  for(int i = tid - cp_g*cp_rows; i < nloc && cp_g < cp_ng; i += cp_rows)
   {
     const double* gp = G + (i < w ? i : i + shift);
-    for(int j0 = 0; j0 < w; j0 += 16)
+    for(int j0 = cp_g; j0 < w; j0 += CP_FLIGHT*cp_ng)
     {
-      double v[16];
+      double v[CP_FLIGHT];
 #pragma unroll
-      for(int u = 0; u < 16; u++) v[u] = (j0 + u < w) ? gp[(size_t)(j0 + u)*nrows] : 0.0;
+      for(int u = 0; u < CP_FLIGHT; u++) v[u] = (j0 + u*cp_ng < w) ? gp[(size_t)(j0 + u*cp_ng)*nrows] : 0.0;
 #pragma unroll
-      for(int u = 0; u < 16; u++) if(j0 + u < w) P[i + (j0 + u)*ldp] = v[u];
+      for(int u = 0; u < CP_FLIGHT; u++) if(j0 + u*cp_ng < w) P[i + (j0 + u*cp_ng)*ldp] = v[u];
     }
   }
   __syncthreads();
-  const int nmem = sn_bd_ptr[s+1] - sn_bd_ptr[s];
-  if(nmem > 0) panel_factor_blockdiag<NT>(P, ldp, nloc, w, tid, sn_bd_col + sn_bd_ptr[s], nmem, &sbad, sn_c0[s]);
-  else if(NT >= 256) panel_factor_mfma<(NT >= 256 ? NT : 256)>(P, ldp, nloc, w, tid, &sbad, sn_c0[s]);
-  else         panel_factor<NT, true, true>(P, ldp, nloc, w, tid, &sbad, sn_c0[s]);
-  const int64_t top = sn_top[s];
-  if(r0 == 0 && tid == 0 && sbad != 0x7fffffff) atomicMin(info, sbad);
-  // two-phase update, phase 1 fused: this workgroup holds all the below rows of the (unsliced)
-  // panel in LDS, so U = B B' (B = rows w.. of the factored panel) comes straight out of it:
-  // lower 16x16 tiles round robin over the waves, both MFMA operands read from the panel
-  if(fuse_syrk && top < 0)
+  FL_STAMP(1);
+  if(mf_acc)
   {
-    const int mb = nloc - w, T = (mb + 15) >> 4, ntiles = T*(T + 1)/2;
-    double* U = uscr + u_off[s];
-    const int lane = tid & 63, wv = tid >> 6;
-    const int jn = lane & 15, kq = lane >> 4;
-    for(int idx = wv; idx < ntiles; idx += NT/64)
-    {
-      int rem = idx, tj = 0;
-      while(rem >= T - tj) { rem -= T - tj; tj++; }
-      const int ti = tj + rem;
-      const int ra = w + min(16*ti + jn, mb - 1), rb = w + min(16*tj + jn, mb - 1);
-      const bool va = 16*ti + jn < mb, vb = 16*tj + jn < mb;
-      dlg_v4d c4 = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll 2
-      for(int kk = 0; kk < w; kk += 4)
-      {
-        const int k = kk + kq;
-        const bool kok = k < w;
-        const int kc = kok ? k : w - 1;
-        const double a = P[ra + kc*ldp], bv = P[rb + kc*ldp];
-        c4 = __builtin_amdgcn_mfma_f64_16x16x4f64((kok && va) ? a : 0.0, (kok && vb) ? bv : 0.0, c4, 0, 0, 0);
-      }
-      const int j = 16*tj + jn;
-#pragma unroll
-      for(int r = 0; r < 4; r++)
-      {
-        const int i = 16*ti + kq + 4*r;
-        if(i < mb && j <= i) U[i + (size_t)j*mb] = c4[r];
-      }
-    }
+    if(u_lds) mf_add_children<NT, true >(P, Us, ntri, it.nch, it.ch0, rc, mf_rec, uscr, mf_dst, tid);
+    else      mf_add_children<NT, false>(P, Ug, ntri, it.nch, it.ch0, rc, mf_rec, uscr, mf_dst, tid);
   }
-  for(int i = tid; i < nloc; i += NT)
+  FL_STAMP(2);
+  if(it.nbd > 0) panel_factor_blockdiag<NT>(P, ldp, nloc, w, tid, sn_bd_col + it.bd0, it.nbd, &sbad, it.col0);
+  else if(NT >= 256) panel_factor_mfma<(NT >= 256 ? NT : 256)>(P, ldp, nloc, w, tid, &sbad, it.col0);
+  else         panel_factor<NT, true, true>(P, ldp, nloc, w, tid, &sbad, it.col0);
+  FL_STAMP(3);
+  if(r0 == 0 && tid == 0 && sbad != 0x7fffffff) atomicMin(info, sbad);
+  // U = B B' (mode 2: W = children's sum - B B'): lower 16x16 tiles, both MFMA operands read from
+  // the panel.  Work item = up to SY_G consecutive row tiles of one tile column: the B operand is
+  // shared, the SY_G accumulator chains keep the matrix core busy.  Rows / columns past the end are
+  // clamped (their results are never written); two k-steps per iteration with their own operand
+  // registers, so the loads of one are in flight during the products of the other.
+  if(has_u)
+  {
+    const int T = (mb + 15) >> 4;
+    const int wv = tid >> 6, jn = lane & 15, kq = lane >> 4;
+    double* Ud = u_lds ? Us : Ug;              // in place behind the panel, or straight to the scratch
+    constexpr int SY_G = 4;
+    int nitems = 0;
+    for(int tj = 0; tj < T; tj++) nitems += (T - tj + SY_G - 1)/SY_G;
+    const int w4 = w & ~3;
+    for(int item = wv; item < nitems; item += NT/64)
+    {
+      int rem = item, tj = 0;
+      while(rem >= (T - tj + SY_G - 1)/SY_G) { rem -= (T - tj + SY_G - 1)/SY_G; tj++; }
+      const int ti0 = tj + SY_G*rem, nt = min(SY_G, T - ti0);
+      const int j = 16*tj + jn;
+      // element offsets into P of this lane's operands at k-step 0 (row tiles past the item's
+      // last one repeat it: their products are computed and dropped)
+      int ob = w + min(j, mb - 1) + kq*ldp;
+      int oa[SY_G];
+      dlg_v4d c4[SY_G];
+#pragma unroll
+      for(int q = 0; q < SY_G; q++)
+      {
+        oa[q] = w + min(16*(ti0 + min(q, nt - 1)) + jn, mb - 1) + kq*ldp;
+        c4[q] = (dlg_v4d){0.0, 0.0, 0.0, 0.0};
+      }
+      const int st = 4*ldp;
+      double a0[SY_G], a1[SY_G], b0 = 0.0, b1;
+#pragma unroll
+      for(int q = 0; q < SY_G; q++) a0[q] = 0.0;
+      int kk = 0;
+      if(w4 >= 4)
+      {
+        b0 = P[ob];
+#pragma unroll
+        for(int q = 0; q < SY_G; q++) a0[q] = P[oa[q]];
+      }
+      for(; kk + 8 <= w4; kk += 8)
+      {
+        b1 = P[ob + st];
+#pragma unroll
+        for(int q = 0; q < SY_G; q++) a1[q] = P[oa[q] + st];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for(int q = 0; q < SY_G; q++) c4[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[q], b0, c4[q], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        ob += 2*st;
+#pragma unroll
+        for(int q = 0; q < SY_G; q++) oa[q] += 2*st;
+        // the k-step after next (clamped to the last whole one: a harmless re-read at the end)
+        const int back = (kk + 12 <= w4) ? 0 : 2*st;
+        b0 = P[ob - back];
+#pragma unroll
+        for(int q = 0; q < SY_G; q++) a0[q] = P[oa[q] - back];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for(int q = 0; q < SY_G; q++) c4[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[q], b1, c4[q], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if(kk + 4 <= w4)
+      {
+        // odd number of whole k-steps: the last one
+        if(kk > 0)
+        {
+          b0 = P[ob];
+#pragma unroll
+          for(int q = 0; q < SY_G; q++) a0[q] = P[oa[q]];
+        }
+#pragma unroll
+        for(int q = 0; q < SY_G; q++) c4[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[q], b0, c4[q], 0, 0, 0);
+        kk += 4; ob += st;
+#pragma unroll
+        for(int q = 0; q < SY_G; q++) oa[q] += st;
+      }
+      if(kk < w)
+      {
+        // the last, partial k-step: columns past the end contribute zeros
+        const bool kok = kk + kq < w;
+        const int back = kok ? 0 : (kk + kq - (w - 1))*ldp;
+        const double bz = kok ? P[ob - back] : 0.0;
+#pragma unroll
+        for(int q = 0; q < SY_G; q++)
+        {
+          const double az = kok ? P[oa[q] - back] : 0.0;
+          c4[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(az, bz, c4[q], 0, 0, 0);
+        }
+      }
+      const int jtri = tri_col(j, mb);
+#pragma unroll
+      for(int q = 0; q < SY_G; q++)
+        if(q < nt)
+        {
+#pragma unroll
+          for(int r = 0; r < 4; r++)
+          {
+            const int i = 16*(ti0 + q) + kq + 4*r;
+            if(i < mb && j <= i)
+            {
+              if(mode == 2) Ud[jtri + i] = (mf_acc ? Ud[jtri + i] : 0.0) - c4[q][r];     // the region keeps W = -U
+              else Ud[jtri + i] = c4[q][r];
+            }
+          }
+        }
+    }
+    if(u_lds) __syncthreads();
+  }
+  FL_STAMP(4);
+  if(u_lds) for(int e = tid; e < ntri; e += NT) Ug[e] = Us[e];
+  for(int i = tid - cp_g*cp_rows; i < nloc && cp_g < cp_ng; i += cp_rows)
   {
     // rows below the top block go back to the panel; the top block too unless the supernode is
     // cut into slices (then slice 0 parks it in top_scr, see k_copy_top)
@@ -111,15 +279,16 @@ __global__ void __launch_bounds__(NT) k_factor_level(const int* __restrict__ fw_
     else if(top < 0)  { gp = G + i; gs = (size_t)nrows; }
     else if(r0 == 0)  { gp = top_scr + top + i; gs = (size_t)w; }
     else continue;
-    for(int j0 = 0; j0 < w; j0 += 16)
+    for(int j0 = cp_g; j0 < w; j0 += 16*cp_ng)
     {
       double v[16];
 #pragma unroll
-      for(int u = 0; u < 16; u++) v[u] = (j0 + u < w) ? P[i + (j0 + u)*ldp] : 0.0;
+      for(int u = 0; u < 16; u++) v[u] = (j0 + u*cp_ng < w) ? P[i + (j0 + u*cp_ng)*ldp] : 0.0;
 #pragma unroll
-      for(int u = 0; u < 16; u++) if(j0 + u < w) gp[(size_t)(j0 + u)*gs] = v[u];
+      for(int u = 0; u < 16; u++) if(j0 + u*cp_ng < w) gp[(size_t)(j0 + u*cp_ng)*gs] = v[u];
     }
   }
+  FL_STAMP(5);
 }
 // publish the top blocks of the multi-slice supernodes
 __global__ void __launch_bounds__(TPB) k_copy_top(const int* __restrict__ ms_sn, const int* __restrict__ sn_c0,
@@ -273,7 +442,7 @@ __global__ void __launch_bounds__(NT) k_update_syrk(const int* __restrict__ lvl_
       for(int r = 0; r < 4; r++)
       {
         const int i = aoff[q] + kq + 4*r;
-        if(i < mb && j <= i) U[i + (size_t)j*mb] = c4[q][r];
+        if(i < mb && j <= i) U[tri_col(j, mb) + i] = c4[q][r];
       }
     }
 }
@@ -340,6 +509,9 @@ __global__ void __launch_bounds__(TPB) k_update_gather(int unit0, const int* __r
           Uv[g] = uscr + (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readlane(r_uhi, kg) << 32) | (uint32_t)__builtin_amdgcn_readlane(r_ulo, kg));
           mmax = max(mmax, mv[g]);
         }
+        int mv2[GATHER_FLIGHT];          // rows of the sub-block (>= 1), also its packed column stride
+#pragma unroll
+        for(int g = 0; g < GATHER_FLIGHT; g++) mv2[g] = max(mv[g], 1);
         for(int i0 = 0; i0 < mmax; i0 += 64)
         {
           const int i = i0 + lane;
@@ -352,7 +524,7 @@ __global__ void __launch_bounds__(TPB) k_update_gather(int unit0, const int* __r
           for(int g = 0; g < GATHER_FLIGHT; g++)
 #pragma unroll
             for(int c = 0; c < 8; c++)
-              if(c < nc) v[g][c] = Uv[g][ig[g] + (size_t)min(c, cmax)*mbv[g]];   // entries above the diagonal are never written
+              if(c < nc) { const int cc = min(min(c, cmax), ig[g]); v[g][c] = Uv[g][ig[g] + cc*(mv2[g] - 1) - cc*(cc - 1)/2]; }   // packed lower triangle, column cc of the sub-block
 #pragma unroll
           for(int g = 0; g < GATHER_FLIGHT; g++)
 #pragma unroll
@@ -581,9 +753,10 @@ __global__ void __launch_bounds__(TPB) k_update_level(int unit0, const int* __re
     }
   }
 }
-// sum the partial slabs of a multi-chunk item and apply them: the slab elements
-// are spread over the lanes, the partials over 256/64 = 4 (or, for small slabs,
-// up to 32) groups; fixed-order LDS reduction keeps the result deterministic
+// sum the partial slabs of a multi-chunk item and apply them.  grid.y workgroups share the
+// elements of a slab in chunks of E; within a workgroup the partials are dealt to G = 256/E
+// thread groups, each keeping four loads in flight.  The summation order is fixed by (G, n)
+// alone, so the result is deterministic.
 __global__ void __launch_bounds__(TPB) k_update_fin(int f0, const int* __restrict__ uf_item,
                                                     const int* __restrict__ uf_n,
                                                     const int64_t* __restrict__ uf_off,
@@ -603,17 +776,26 @@ __global__ void __launch_bounds__(TPB) k_update_fin(int f0, const int* __restric
   double* Lt = Lx + sn_lx[t] + (int64_t)col*nrows_t;
   const int slab = nrows_t*nc;
   const double* src = upart + uf_off[f];
-  // E lanes per element-chunk, G groups over the partials
-  const int E = (slab >= 128) ? 256 : (slab >= 64 ? 64 : (slab >= 32 ? 32 : 8));
+  const int E = (slab >= 32) ? 32 : 8;
   const int G = TPB/E;
   const int el = threadIdx.x % E, g = threadIdx.x / E;
-  for(int ebase = 0; ebase < slab; ebase += E)
+  for(int ebase = blockIdx.y*E; ebase < slab; ebase += gridDim.y*E)
   {
     const int e = ebase + el;
-    double tot = 0.0;
-    if(e < slab) for(int k = g; k < n; k += G) tot += src[(size_t)k*slab + e];
+    double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
+    if(e < slab)
+    {
+      const double* q = src + e;
+      int k = g;
+      for(; k + 3*G < n; k += 4*G)
+      {
+        t0 += q[(size_t)k*slab];         t1 += q[(size_t)(k + G)*slab];
+        t2 += q[(size_t)(k + 2*G)*slab]; t3 += q[(size_t)(k + 3*G)*slab];
+      }
+      for(; k < n; k += G) t0 += q[(size_t)k*slab];
+    }
     __syncthreads();
-    sh[threadIdx.x] = tot;
+    sh[threadIdx.x] = (t0 + t1) + (t2 + t3);
     __syncthreads();
     if(g == 0 && e < slab)
     {
@@ -626,6 +808,7 @@ __global__ void __launch_bounds__(TPB) k_update_fin(int f0, const int* __restric
 
 } // namespace
 
+static int env_int_host(const char* n, int d) { const char* v = getenv(n); return v ? atoi(v) : d; }
 // per-level launch parameters of the factor and update kernels
 int sparse_factor_setup(dlg_backend* b)
 {
@@ -634,7 +817,7 @@ int sparse_factor_setup(dlg_backend* b)
   Y->fac_lds.assign(H.nlevels, 0); Y->fac_nt.assign(H.nlevels, 512); Y->upd_coop.assign(H.nlevels, 0);
   Y->upd_lds.assign(H.nlevels, 0); Y->upd_nw.assign(H.nlevels, 0);
   Y->syrk_lds.assign(H.nlevels, 0); Y->syrk_nt.assign(H.nlevels, 256); Y->syrk_kc.assign(H.nlevels, 4);
-  Y->syrk_fused.assign(H.nlevels, 0);
+  Y->syrk_fused.assign(H.nlevels, 0); Y->fin_ny.assign(H.nlevels, 1); Y->fac_stage.assign(H.nlevels, 0);
   for(int l = 0; l < H.nlevels; l++)
   {
     long maxp = 0, maxw = 0, maxr = 0;
@@ -654,6 +837,7 @@ int sparse_factor_setup(dlg_backend* b)
       if(nloc > maxr) maxr = nloc;
     }
     Y->fac_nt[l] = (maxr <= 128) ? 128 : (maxr <= 256 ? 256 : 512);
+    if(l >= H.mf_level0) Y->fac_nt[l] = env_int_host("DOGLEG_AMD_MF_NT", 512);
     Y->upd_coop[l] = (maxw > 8) ? 1 : 0;           // heavy sources: matrix-core / cooperative update kernels
     if(maxp*8 > FAC_LDS_BUDGET) { dlg_set_error("internal error: a factor slice does not fit LDS (%ld doubles)", maxp); return DLG_ERR_ARG; }
     Y->fac_lds[l] = (int)(maxp*8);
@@ -664,6 +848,13 @@ int sparse_factor_setup(dlg_backend* b)
       const long sl = (long)(H.sn_rowptr[t+1] - H.sn_rowptr[t])*H.ui_nc[it];
       if(sl > maxslab) maxslab = sl;
     }
+    long finslab = 0;
+    for(int f = H.uf_lvl_ptr[l]; f < H.uf_lvl_ptr[l+1]; f++)
+    {
+      const int it = H.uf_item[f], t = H.ui_t[it];
+      finslab = std::max(finslab, (long)(H.sn_rowptr[t+1] - H.sn_rowptr[t])*H.ui_nc[it]);
+    }
+    Y->fin_ny[l] = (int)std::min(64L, std::max(1L, (finslab + 31)/32));
     int nw = 0;
     if(maxslab > 0) { nw = (int)(LDS_BUDGET/(maxslab*8)); if(nw > 4) nw = 4; }
     Y->upd_nw[l] = nw;
@@ -691,6 +882,27 @@ int sparse_factor_setup(dlg_backend* b)
       for(int i = H.lvl_ptr[l]; i < H.lvl_ptr[l+1]; i++) if(H.sn_top[H.lvl_sn[i]] >= 0) unsliced = false;
       Y->syrk_fused[l] = (unsliced && nw > 0 && !getenv("DOGLEG_AMD_NO_SYRK_FUSE")) ? 1 : 0;
     }
+    if(l >= H.mf_level0 || Y->syrk_fused[l])
+    {
+      // room for the update matrix behind the panel where both fit (same rule as the kernel and,
+      // for supernodes with children, as the symbolic phase).  Childless supernodes only stage it
+      // if that does not cost the level a resident workgroup per CU.
+      long with_children = Y->fac_lds[l], leaves = Y->fac_lds[l];
+      for(int i = H.lvl_ptr[l]; i < H.lvl_ptr[l+1]; i++)
+      {
+        const int s = H.lvl_sn[i];
+        const long wv = H.sn_c0[s+1] - H.sn_c0[s], nr = H.sn_rowptr[s+1] - H.sn_rowptr[s], mb = nr - wv;
+        const long need = (((nr + 1) & ~1L)*wv + mb*(mb + 1)/2 + 1)*8;
+        const long need0 = (((nr + 1) & ~1L)*wv + 1)*8;          // at least the scratch slot behind the panel
+        const long want = (need <= FAC_LDS_BUDGET) ? need : need0;
+        const bool has_children = l >= H.mf_level0 && H.mf_cptr[s+1] > H.mf_cptr[s];
+        if(has_children) with_children = std::max(with_children, want); else leaves = std::max(leaves, want);
+      }
+      const long base = std::max((long)Y->fac_lds[l], with_children);
+      const long per_cu0 = 163840/(base + 3584), per_cu1 = 163840/(std::max(base, leaves) + 3584);
+      Y->fac_stage[l] = (per_cu1 == per_cu0) ? 1 : 0;
+      Y->fac_lds[l] = (int)(Y->fac_stage[l] ? std::max(base, leaves) : base);
+    }
   }
   DLG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_factor_level<128>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, FAC_LDS_BUDGET));
@@ -711,6 +923,17 @@ int sparse_factor_setup(dlg_backend* b)
   return DLG_OK;
 }
 
+#ifdef DLG_FL_PROFILE
+extern "C" void dlg_fl_profile_dump(int nlevels)
+{
+  long long h[64*8];
+  hipDeviceSynchronize();
+  hipMemcpyFromSymbol(h, HIP_SYMBOL(g_fl_prof), sizeof(h));
+  for(int l = 0; l < nlevels && l < 64; l++)
+    fprintf(stderr, "level %2d: load %6lld  add %6lld  factor %6lld  tail %6lld  store %6lld cycles\n", l,
+            h[l*8+1] - h[l*8], h[l*8+2] - h[l*8+1], h[l*8+3] - h[l*8+2], h[l*8+4] - h[l*8+3], h[l*8+5] - h[l*8+4]);
+}
+#endif
 // K5: level-scheduled supernodal Cholesky (launches only; the caller reads the pivot flag)
 int sparse_factor_levels(dlg_backend* b)
 {
@@ -723,21 +946,16 @@ int sparse_factor_levels(dlg_backend* b)
     if(n > 0)
     {
       const int o = H.fw_lvl_ptr[l];
+      const int fmode = ((l >= H.mf_level0) ? 2 : Y->syrk_fused[l]) + 4*Y->fac_stage[l] + 256*l;
       if(Y->fac_nt[l] == 128)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_factor_level<128>), dim3(n), dim3(128), Y->fac_lds[l], st,
-                           Y->fw_sn + o, Y->fw_r0 + o, Y->fw_r1 + o, Y->sn_c0, Y->sn_rowptr, Y->sn_lx,
-                           Y->sn_top, Y->sn_bd_ptr, Y->sn_bd_col, Y->Lx, Y->top_scr, Y->d_info,
-                           Y->u_off, Y->uscr, Y->syrk_fused[l]);
+                           Y->fw_item + o, Y->mf_rec, Y->sn_bd_col, Y->mf_dst, Y->Lx, Y->top_scr, Y->d_info, Y->uscr, fmode);
       else if(Y->fac_nt[l] == 256)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_factor_level<256>), dim3(n), dim3(256), Y->fac_lds[l], st,
-                           Y->fw_sn + o, Y->fw_r0 + o, Y->fw_r1 + o, Y->sn_c0, Y->sn_rowptr, Y->sn_lx,
-                           Y->sn_top, Y->sn_bd_ptr, Y->sn_bd_col, Y->Lx, Y->top_scr, Y->d_info,
-                           Y->u_off, Y->uscr, Y->syrk_fused[l]);
+                           Y->fw_item + o, Y->mf_rec, Y->sn_bd_col, Y->mf_dst, Y->Lx, Y->top_scr, Y->d_info, Y->uscr, fmode);
       else
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_factor_level<512>), dim3(n), dim3(512), Y->fac_lds[l], st,
-                           Y->fw_sn + o, Y->fw_r0 + o, Y->fw_r1 + o, Y->sn_c0, Y->sn_rowptr, Y->sn_lx,
-                           Y->sn_top, Y->sn_bd_ptr, Y->sn_bd_col, Y->Lx, Y->top_scr, Y->d_info,
-                           Y->u_off, Y->uscr, Y->syrk_fused[l]);
+                           Y->fw_item + o, Y->mf_rec, Y->sn_bd_col, Y->mf_dst, Y->Lx, Y->top_scr, Y->d_info, Y->uscr, fmode);
     }
     const int nu = H.uw_lvl_ptr[l+1] - H.uw_lvl_ptr[l];
     if(nu > 0 && H.upd_syrk[l] && Y->upd_nw[l] > 0)
@@ -771,7 +989,7 @@ int sparse_factor_levels(dlg_backend* b)
                          Y->usub, Y->relpos, Y->sn_rowptr, Y->sn_lx, Y->Lx, Y->upart, Y->upd_nw[l]);
     const int nfz = H.uf_lvl_ptr[l+1] - H.uf_lvl_ptr[l];
     if(nfz > 0)
-      hipLaunchKernelGGL(k_update_fin, dim3(nfz), dim3(TPB), 0, st, H.uf_lvl_ptr[l], Y->uf_item, Y->uf_n,
+      hipLaunchKernelGGL(k_update_fin, dim3(nfz, Y->fin_ny[l]), dim3(TPB), 0, st, H.uf_lvl_ptr[l], Y->uf_item, Y->uf_n,
                          Y->uf_off, Y->ui_t, Y->ui_col, Y->ui_nc, Y->sn_rowptr, Y->sn_lx, Y->Lx,
                          Y->upart);
   }

@@ -23,7 +23,7 @@ constexpr int NV_CHUNK = 2048;          // non-zeros per workgroup of the |Jv|^2
 
 constexpr int TPB = 256;
 constexpr int LDS_BUDGET = 147456;      // bytes of dynamic LDS we allow a workgroup
-constexpr int FAC_LDS_BUDGET = 163840 - 3584;  // the panel factorisation takes (almost) all 160 KB of a CU; the rest is its static LDS
+constexpr int FAC_LDS_BUDGET = SYM_FAC_LDS_BUDGET;  // the panel factorisation takes (almost) all 160 KB of a CU; the rest is its static LDS
 
 __device__ __forceinline__ double wave_sum(double v)
 {
@@ -70,6 +70,7 @@ struct SparseSym
   int *uw_item = nullptr, *uw_s0 = nullptr, *uw_s1 = nullptr, *uf_item = nullptr, *uf_n = nullptr;
   int64_t *uw_part = nullptr, *uf_off = nullptr;
   double* upart = nullptr; double* uscr = nullptr; int64_t *u_off = nullptr, *usub_u = nullptr;
+  FwItem* fw_item = nullptr; MfChild* mf_rec = nullptr; uint16_t* mf_dst = nullptr;
   SymOutBlock* oblk = nullptr; SymContrib* contrib = nullptr;
   SymTask *jtx_task = nullptr;
   int *jtx_fin_ptr = nullptr, *jtx_fin_blk = nullptr;
@@ -90,7 +91,7 @@ struct SparseSym
   size_t nnz_loc = 0;
   // per-level launch parameters
   std::vector<int> fac_lds;     // bytes of LDS for the factor kernel of a level (0: panels stay in HBM)
-  std::vector<int> upd_lds, upd_nw, slv_lds, bwd_lds, fac_nt, upd_coop, syrk_lds, syrk_nt, syrk_kc, bwd_nt, syrk_fused;
+  std::vector<int> upd_lds, upd_nw, slv_lds, bwd_lds, fac_nt, upd_coop, syrk_lds, syrk_nt, syrk_kc, bwd_nt, syrk_fused, fin_ny, fac_stage;
   std::vector<void*> allocs;
 };
 

@@ -743,10 +743,33 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
   {
     struct Sub { int lvl, t, q, d, ka, rel; };
     std::vector<Sub> subs;
+    // multifrontal region: the levels from mf_level0 up, provided none of their supernodes is
+    // cut into slices or has more than MF_MAXM rows below its diagonal block (one workgroup
+    // adds a child's whole update matrix).  DOGLEG_AMD_MF_LEVEL: lowest level allowed in the
+    // region, < 0 turns it off.
+    S.mf_level0 = S.nlevels;
+    {
+      const int mf_req = env_int("DOGLEG_AMD_MF_LEVEL", 1), mf_maxm = std::min(255, env_int("DOGLEG_AMD_MF_MAXM", 255));
+      for(int l = S.nlevels - 1; mf_req >= 0 && l >= mf_req; l--)
+      {
+        bool ok = true;
+        for(int i = S.lvl_ptr[l]; i < S.lvl_ptr[l+1] && ok; i++)
+        {
+          const int d = S.lvl_sn[i];
+          const int mb = S.sn_rowptr[d+1] - S.sn_rowptr[d] - (S.sn_c0[d+1] - S.sn_c0[d]);
+          if(S.sn_top[d] >= 0 || mb > mf_maxm) ok = false;
+        }
+        if(!ok) break;
+        S.mf_level0 = l;
+      }
+    }
+    S.sn_prel.assign(nsn, -1);
+    std::vector<int> sn_parent(nsn, -1);
     for(int d = 0; d < nsn; d++)
     {
       const std::vector<int>& bl = st[sn_last(d)];
       if(bl.empty()) continue;
+      const bool mf_src = S.sn_level[d] >= S.mf_level0;
       const int wd = S.sn_c0[d+1] - S.sn_c0[d];
       const int nrows_d = S.sn_rowptr[d+1] - S.sn_rowptr[d];
       size_t i = 0;
@@ -777,6 +800,13 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
         }
         S.relpos.push_back(S.sn_rowptr[t+1] - S.sn_rowptr[t] - 1);      // augmented row -> augmented row
         if((int)S.relpos.size() - relbase != nrows_d - k0) SYM_FAIL("internal error: relpos size mismatch");
+        if(k0 == wd) { sn_parent[d] = t; S.sn_prel[d] = relbase; }
+        if(mf_src)
+        {
+          // only the map into the parent is needed: the update travels up the tree from there
+          while(i < bl.size() && sn_of_b[bl[i]] == t) { krow += G.w[border[bl[i]]]; i++; }
+          break;
+        }
         // one sub-task per target var-block
         while(i < bl.size() && sn_of_b[bl[i]] == t)
         {
@@ -790,7 +820,7 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
     {
       S.upd_syrk.assign(S.nlevels, 0); S.u_off.assign(nsn, -1); S.uscr_size = 0;
       const int syrk_min = env_int("DOGLEG_AMD_SYRK_MIN", 100);
-      for(int l = 0; l < S.nlevels; l++)
+      for(int l = 0; l < S.mf_level0; l++)
       {
         const int n = S.lvl_ptr[l+1] - S.lvl_ptr[l];
         if(syrk_min <= 0 || n < syrk_min) continue;
@@ -813,6 +843,63 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
           S.u_off[d] = off; off += mb*mb;
         }
         S.uscr_size = std::max(S.uscr_size, off);
+      }
+      // the update matrices of the multifrontal region live until the parent has read them
+      S.mf_cptr.assign(nsn + 1, 0);
+      for(int d = 0; d < nsn; d++)
+        if(S.sn_level[d] >= S.mf_level0)
+        {
+          const int64_t mb = S.sn_rowptr[d+1] - S.sn_rowptr[d] - (S.sn_c0[d+1] - S.sn_c0[d]);
+          S.u_off[d] = S.uscr_size; S.uscr_size += mb*(mb + 1)/2;
+          if(sn_parent[d] >= 0) S.mf_cptr[sn_parent[d] + 1]++;
+        }
+      for(int t = 0; t < nsn; t++) S.mf_cptr[t+1] += S.mf_cptr[t];
+      S.mf_child.resize(S.mf_cptr[nsn]);
+      {
+        std::vector<int> nx(S.mf_cptr.begin(), S.mf_cptr.end() - 1);
+        for(int d = 0; d < nsn; d++)
+          if(S.sn_level[d] >= S.mf_level0 && sn_parent[d] >= 0) S.mf_child[nx[sn_parent[d]]++] = d;
+      }
+      S.mf_rec.resize(S.mf_child.size());
+      for(int t = 0; t < nsn; t++)
+      {
+        if(S.mf_cptr[t+1] == S.mf_cptr[t]) continue;
+        // layout of t's factor workgroup (k_factor_level): panel with an even leading dimension,
+        // the update matrix behind it when both (and one scratch double) fit in LDS
+        const int w = S.sn_c0[t+1] - S.sn_c0[t], nrows = S.sn_rowptr[t+1] - S.sn_rowptr[t], mb = nrows - w;
+        const int ldp = (nrows + 1) & ~1, ntri = mb*(mb + 1)/2;
+        const bool u_lds = (size_t)(ldp*w + ntri + 1)*sizeof(double) <= (size_t)SYM_FAC_LDS_BUDGET;
+        const int wt_off = u_lds ? ldp*w : 0x8000, trash = u_lds ? ldp*w + ntri : ldp*w;
+        for(int k = S.mf_cptr[t]; k < S.mf_cptr[t+1]; k++)
+        {
+          const int c = S.mf_child[k];
+          const int mc = S.sn_rowptr[c+1] - S.sn_rowptr[c] - (S.sn_c0[c+1] - S.sn_c0[c]);
+          const int* map = &S.relpos[S.sn_prel[c]];
+          const int nc = mc*(mc + 1)/2, npad = (nc + 1023) & ~1023;
+          S.mf_rec[k].u_off = S.u_off[c]; S.mf_rec[k].dst_off = (int64_t)S.mf_dst.size();
+          S.mf_rec[k].npad = npad; S.mf_rec[k].rsv = 0;
+          S.mf_dst.reserve(S.mf_dst.size() + npad);
+          for(int j = 0; j < mc; j++)
+            for(int i = j; i < mc; i++)
+            {
+              const int fi = map[i], fj = map[j];
+              const int d = (fj < w) ? fi + fj*ldp : wt_off + (fj - w)*mb - (fj - w)*(fj - w - 1)/2 + (fi - fj);
+              S.mf_dst.push_back((uint16_t)d);
+            }
+          for(int e = nc; e < npad; e++) S.mf_dst.push_back((uint16_t)trash);
+        }
+      }
+      S.uscr_size += 1024;                 // the padded tail of the last child is read (and dropped)
+      S.fw_item.resize(S.fw_sn.size());
+      for(size_t k = 0; k < S.fw_sn.size(); k++)
+      {
+        const int s2 = S.fw_sn[k];
+        FwItem& it = S.fw_item[k];
+        it.s = s2; it.r0 = S.fw_r0[k]; it.r1 = S.fw_r1[k]; it.w = S.sn_c0[s2+1] - S.sn_c0[s2];
+        it.nrows = S.sn_rowptr[s2+1] - S.sn_rowptr[s2]; it.col0 = S.sn_c0[s2];
+        it.bd0 = S.sn_bd_ptr[s2]; it.nbd = S.sn_bd_ptr[s2+1] - S.sn_bd_ptr[s2];
+        it.lx = S.sn_lx[s2]; it.top = S.sn_top[s2]; it.u_off = S.u_off[s2];
+        it.ch0 = S.mf_cptr[s2]; it.nch = S.mf_cptr[s2+1] - S.mf_cptr[s2];
       }
     }
     std::sort(subs.begin(), subs.end(), [](const Sub& a, const Sub& b) {
@@ -844,7 +931,7 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
       if(S.upd_syrk[u.lvl])
       {
         const int64_t mb = nrows_d - ss.wd, k0 = u.ka - ss.wd;
-        S.usub_u.push_back(S.u_off[u.d] + k0 + k0*mb);
+        S.usub_u.push_back(S.u_off[u.d] + k0*mb - k0*(k0 - 1)/2);      // packed lower triangle: diagonal of column k0
       }
       else S.usub_u.push_back(-1);
     }

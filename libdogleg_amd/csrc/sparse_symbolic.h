@@ -139,6 +139,22 @@ static_assert(sizeof(AsmFin2) == 24, "AsmFin2 layout");
 // into slot `part` of the partial buffer instead of the destination
 struct SymTask { int32_t blk, c0, c1, part; };
 
+// LDS bytes a factor workgroup may use: (almost) all 160 KB of a CU, the rest is its static LDS
+constexpr int SYM_FAC_LDS_BUDGET = 163840 - 3584;
+
+// one factor work item (supernode, slice of its below rows)
+struct FwItem
+{
+  int s, r0, r1, w;            // supernode, slice [r0, r1) of the below rows, width
+  int nrows, col0;             // rows of the panel, first column (elimination position)
+  int bd0, nbd;                // block-diagonal top: members in sn_bd_col[bd0 .. bd0 + nbd)
+  int64_t lx, top, u_off;      // panel offset, top-block copy (or -1), update-matrix offset (or -1)
+  int ch0, nch;                // multifrontal children: mf_rec[ch0 .. ch0 + nch)
+};
+// one child of a supernode of the multifrontal region: its update matrix and, entry by entry
+// (packed order, padded to a multiple of 1024 with a scratch slot), where each entry goes
+struct MfChild { int64_t u_off, dst_off; int npad, rsv; };
+
 struct SymHost
 {
   int N = 0, M = 0, nnz = 0;
@@ -190,6 +206,19 @@ struct SymHost
   std::vector<int64_t> u_off;        // [nsn] offset of U_d in the scratch (two-phase levels only)
   std::vector<int64_t> usub_u;       // [#sub-tasks] offset of the sub-task's first element in the scratch
   int64_t uscr_size = 0;
+  // multifrontal top of the tree (levels >= mf_level0; == nlevels: none): a supernode of the
+  // region does not update its ancestors one by one, it hands its whole update matrix
+  // U = (children's leftovers) + B B' (packed lower triangle, column-major) to its parent, whose
+  // factor workgroup adds it into its panel / its own U before factorising (k_factor_level)
+  int mf_level0 = 0;
+  std::vector<int> mf_cptr, mf_child;   // [nsn+1], children inside the region (ascending)
+  std::vector<int> sn_prel;             // [nsn] relpos offset of "below rows of s -> rows of parent(s)", -1: root
+  // flat records for k_factor_level: everything a workgroup needs in one load (a dependent
+  // global load costs microseconds at the top of the tree, where little else is going on)
+  std::vector<FwItem>  fw_item;         // per factor work item, same order as fw_sn
+  std::vector<MfChild> mf_rec;          // children of the multifrontal region, grouped by parent
+  std::vector<uint16_t> mf_dst;         // destination of every entry of every child: element offset in the parent's
+                                        // LDS panel / update matrix; bit 15: offset into an update matrix kept in HBM
   // ---- assembly / Jt*x
   std::vector<SymOutBlock> oblk;     // diagonal block of every var-block (Jt*x and lambda use them)
   std::vector<SymContrib>  contrib;

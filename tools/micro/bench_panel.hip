@@ -129,6 +129,7 @@ void run_bd(int nrows, int w, int G, int iters)
 int main(int argc, char** argv)
 {
   const int G = argc > 1 ? atoi(argv[1]) : 64;
+  if(argc > 3) { run<256>(atoi(argv[2]), atoi(argv[3]), G, 20); return 0; }
   run_bd<256>(124, 51, G, 20); run_bd<128>(124, 51, G, 20); run_bd<256>(124, 51, 2489, 20); run_bd<128>(124, 51, 2489, 20);
   run<512>(170, 96, G, 20); run<256>(170, 96, G, 20); run<128>(170, 96, G, 20);
   run<256>(128, 64, G, 20); run<256>(250, 48, G, 20); run<128>(100, 24, G, 20);
