@@ -59,6 +59,9 @@ template <class T> int upload(T*& dev, const std::vector<T>& h)
 
 } // namespace
 
+// flat record of a supernode for the backward solve (same order as lvl_sn)
+struct SolveItem { int c0, w, nrows, rowoff; int64_t lx; int bd0, nbd; };
+
 struct SparseSym
 {
   SymHost H;
@@ -70,7 +73,7 @@ struct SparseSym
   int *uw_item = nullptr, *uw_s0 = nullptr, *uw_s1 = nullptr, *uf_item = nullptr, *uf_n = nullptr;
   int64_t *uw_part = nullptr, *uf_off = nullptr;
   double* upart = nullptr; double* uscr = nullptr; int64_t *u_off = nullptr, *usub_u = nullptr;
-  FwItem* fw_item = nullptr; MfChild* mf_rec = nullptr; uint16_t* mf_dst = nullptr;
+  SolveItem* slv_item = nullptr; FwItem* fw_item = nullptr; MfChild* mf_rec = nullptr; uint16_t* mf_dst = nullptr;
   SymOutBlock* oblk = nullptr; SymContrib* contrib = nullptr;
   SymTask *jtx_task = nullptr;
   int *jtx_fin_ptr = nullptr, *jtx_fin_blk = nullptr;
@@ -91,7 +94,7 @@ struct SparseSym
   size_t nnz_loc = 0;
   // per-level launch parameters
   std::vector<int> fac_lds;     // bytes of LDS for the factor kernel of a level (0: panels stay in HBM)
-  std::vector<int> upd_lds, upd_nw, slv_lds, bwd_lds, fac_nt, upd_coop, syrk_lds, syrk_nt, syrk_kc, bwd_nt, syrk_fused, fin_ny, fac_stage;
+  std::vector<int> upd_lds, upd_nw, slv_lds, bwd_lds, fac_nt, upd_coop, syrk_lds, syrk_nt, syrk_kc, bwd_nt, syrk_fused, fin_ny, fac_stage, bwd_top;
   std::vector<void*> allocs;
 };
 

@@ -3,6 +3,13 @@
 #include "sparse_internal.h"
 
 namespace {
+// -DDLG_FL_PROFILE: phase clocks of workgroup 0 of every backward-solve launch (tools only)
+#ifdef DLG_FL_PROFILE
+__device__ long long g_bw_prof[64*8];
+#define BW_STAMP(k) do { if(threadIdx.x == 0 && blockIdx.x == 0) g_bw_prof[(prof_lvl & 63)*8 + (k)] = clock64(); } while(0)
+#else
+#define BW_STAMP(k)
+#endif
 
 // ------------------------------------------------------------------ K6 ------
 // forward: per supernode  y_t = L_tt^-1 (P b - gathered updates);  u_t = L_below y_t.
@@ -88,42 +95,66 @@ __global__ void __launch_bounds__(TPB) k_solve_fwd_level(const int* __restrict__
   }
 }
 // backward: x_t = L_tt^-T (y_t - L_below^T x[below rows]); out[perm] = x.
-// x at the below rows is gathered into LDS once; 8 waves share the columns of the L_below^T
-// mat-vec.  The triangular solve runs over blocks of 8 columns from the bottom, thread = row:
-// the 8 owners of a block publish their right-hand sides, after ONE barrier every thread
-// solves the 8x8 block itself (the diagonal blocks sit in LDS with reciprocal pivots) and
-// applies the 8 new unknowns to its own row with values of L it fetched a block ahead.
-// w/8 barriers instead of w, no staging of the w x w block.
+// A dependent global load costs microseconds at the top of the tree, so the kernel is built in
+// three rounds of loads: (1) the supernode's flat record (SolveItem); (2) everything that only
+// needs the record -- the indices of the below rows, the right-hand side, the operands of the
+// L_below^T mat-vec (up to two passes of 16 values per thread, in registers), the diagonal
+// blocks and, when it fits, the whole top block into LDS; (3) x at the below rows.  Then the
+// waves share the columns of the mat-vec, and the triangular solve runs over blocks of 8
+// columns from the bottom, thread = row: the 8 owners of a block publish their right-hand
+// sides, after ONE barrier every thread solves the 8x8 block itself (diagonal blocks in LDS
+// with reciprocal pivots) and applies the 8 new unknowns to its own row with the values of L
+// from the LDS copy (or, for wide supernodes, fetched a block ahead from HBM).
 template <int BWD_NT>
-__global__ void __launch_bounds__(BWD_NT) k_solve_bwd_level(const int* __restrict__ lvl_sn,
-                                                            const int* __restrict__ sn_c0,
-                                                            const int* __restrict__ sn_rowptr,
+__global__ void __launch_bounds__(BWD_NT) k_solve_bwd_level(const SolveItem* __restrict__ items,
                                                             const int* __restrict__ sn_rows,
-                                                            const int64_t* __restrict__ sn_lx,
                                                             const int* __restrict__ perm,
                                                             const double* __restrict__ Lx,
                                                             double* __restrict__ ywork,
                                                             double* __restrict__ out, int use_aug,
-                                                            const int* __restrict__ sn_bd_ptr,
-                                                            const int* __restrict__ sn_bd_col)
+                                                            const int* __restrict__ sn_bd_col, int top_lds)
 {
   extern __shared__ __attribute__((aligned(16))) double lds[];
-  const int s = lvl_sn[blockIdx.x];
-  const int c0 = sn_c0[s], w = sn_c0[s+1] - c0;
-  const int nrows = sn_rowptr[s+1] - sn_rowptr[s];
-  const int* rows = sn_rows + sn_rowptr[s];
-  const double* L = Lx + sn_lx[s];
+  constexpr int NW = BWD_NT/64, MV_PRE = 2;
+  const int prof_lvl = top_lds >> 8; (void)prof_lvl; top_lds &= 1;
+  BW_STAMP(0);
+  const SolveItem it = items[blockIdx.x];
+  const int c0 = it.c0, w = it.w, nrows = it.nrows;
+  const int* rows = sn_rows + it.rowoff;
+  const double* L = Lx + it.lx;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int r = nrows - w - 1;
   const int nblk = (w + 7) >> 3;
   double* xb = lds;                       // [r]   x at the below rows
-  double* xs = lds + ((r + 1) & ~1);      // [256] right-hand side, then the solution
+  double* xs = lds + ((r + 1) & ~1);      // [256] -(L_below^T x), then the solution
   double* T = xs + 256;                   // [nblk][8][8] diagonal blocks (lower), reciprocal pivots
   double* rhs = T + nblk*64;              // [2][8]
+  double* xp = rhs + 16;                  // [parts][256] partial sums of the mat-vec
+  double* Lt = xp + 8*256;                // [w][ldt] top block (top_lds)
+  const int ldt = w | 1;
   // block-diagonal top (merged sibling leaves): the members do not couple, every member is a
   // little triangular system of its own -- no sweep over the columns at all
-  const int nmem = sn_bd_ptr[s+1] - sn_bd_ptr[s];
-  for(int i = tid; i < r; i += BWD_NT) xb[i] = ywork[rows[w + i]];
+  const int nmem = it.nbd;
+  // ---- round 2
+  const int myrow = (tid < r) ? rows[w + tid] : 0;
+  double myrhs = 0.0; int myperm = 0;
+  if(tid < w) { myrhs = use_aug ? L[(nrows - 1) + (size_t)tid*nrows] : ywork[c0 + tid]; myperm = perm[c0 + tid]; }
+  // L_below^T x: thread = (column j, part of the below rows); MV_SLOTS consecutive rows per pass,
+  // the first pass in flight from here on
+  // 256 threads = populous levels of narrow supernodes: latency is hidden by resident workgroups,
+  // so registers are kept low there (fewer values in flight, the member blocks fetched late)
+  constexpr bool LEAN = BWD_NT == 256;
+  constexpr int MV_SLOTS = LEAN ? 20 : 24;
+  const int mv_cols = min(BWD_NT, (w + 63) & ~63), mv_parts = BWD_NT/mv_cols;
+  const int mv_j = tid % mv_cols, mv_p = tid/mv_cols;
+  const int mv_len = (r + mv_parts - 1)/mv_parts;           // rows per part
+  const int mv_i0 = mv_p*mv_len, mv_i1 = min(r, mv_i0 + mv_len);
+  const bool mv_thread = mv_len <= MV_SLOTS;                 // else: long columns, the waves stream them (below)
+  const bool mv_on = mv_thread && mv_j < w && mv_p < mv_parts;
+  const double* mv_L = L + (size_t)min(mv_j, w - 1)*nrows + w;
+  double mv[MV_SLOTS];
+#pragma unroll
+  for(int q = 0; q < MV_SLOTS; q++) mv[q] = (mv_on && mv_i0 + q < mv_i1) ? mv_L[mv_i0 + q] : 0.0;
   for(int e = tid; e < (nmem > 0 ? 0 : nblk*64); e += BWD_NT)
   {
     const int j0 = (e >> 6)*8, a = (e >> 3) & 7, b = e & 7;
@@ -132,58 +163,129 @@ __global__ void __launch_bounds__(BWD_NT) k_solve_bwd_level(const int* __restric
     if(a == b) v = valid ? 1.0/v : 1.0;
     T[e] = v;
   }
-  __syncthreads();
-  // a wave takes 4 columns at a time: their loads are all in flight together
-  for(int jg = 4*wv; jg < w; jg += 4*(BWD_NT/64))
+  if(top_lds && nmem == 0)
   {
-    const double* Lj = L + (size_t)jg*nrows + w;
-    const int nc = min(4, w - jg);
-    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    // thread = (row, column group), lower triangle only
+    const int cp_rows = min(BWD_NT, (w + 63) & ~63), cp_ng = BWD_NT/cp_rows, cp_g = tid/cp_rows;
+    for(int i = tid - cp_g*cp_rows; i < w && cp_g < cp_ng; i += cp_rows)
+      for(int j0 = cp_g; j0 <= i; j0 += 16*cp_ng)
+      {
+        double v[16];
+#pragma unroll
+        for(int u = 0; u < 16; u++) v[u] = (j0 + u*cp_ng <= i) ? L[i + (size_t)(j0 + u*cp_ng)*nrows] : 0.0;
+#pragma unroll
+        for(int u = 0; u < 16; u++) if(j0 + u*cp_ng <= i) Lt[i + (j0 + u*cp_ng)*ldt] = v[u];
+      }
+  }
+  // members of a block-diagonal top: thread = member, its little block in registers
+  double Lm[8][8];
+  int m0 = 0, nbm = 0;
+  if(nmem > 0 && tid < nmem)
+  {
+    const int* mcol = sn_bd_col + it.bd0;
+    m0 = mcol[tid]; nbm = ((tid + 1 < nmem) ? mcol[tid + 1] : w) - m0;
+  }
+  if(nmem > 0)
+  {
+#pragma unroll
+    for(int a = 0; a < 8; a++)
+#pragma unroll
+      for(int b = 0; b <= a; b++) Lm[a][b] = (a < nbm) ? L[(m0 + a) + (size_t)(m0 + b)*nrows] : (a == b ? 1.0 : 0.0);
+  }
+  BW_STAMP(1);
+  // ---- round 3
+  if(tid < 256) xs[tid] = 0.0;            // columns without below rows (a root) get no mat-vec pass
+  if(tid < r) xb[tid] = ywork[myrow];
+  for(int i = tid + BWD_NT; i < r; i += BWD_NT) xb[i] = ywork[rows[w + i]];
+  __syncthreads();
+  BW_STAMP(2);
+  if(mv_thread)
+  {
+    // partial sums of the mat-vec into xp[part][column]; thread j < w adds them up below
+    double acc = 0.0;
+#pragma unroll
+    for(int q = 0; q < MV_SLOTS; q++) acc += mv[q]*((mv_i0 + q < mv_i1) ? xb[mv_i0 + q] : 0.0);
+    if(mv_on) xp[mv_p*256 + mv_j] = acc;
+  }
+  else
+  {
+    // many below rows: a wave takes 4 columns at a time, lanes over the rows, all loads of a
+    // round in flight together; the sums land in part 0
+    for(int e = 256 + tid; e < mv_parts*256; e += BWD_NT) xp[e] = 0.0;     // (part 0 is written in full)
+    for(int jg = 4*wv; jg < w; jg += 4*NW)
+    {
+      const double* Lj = L + (size_t)jg*nrows + w;
+      const int nc = min(4, w - jg);
+      double acc[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll 2
-    for(int i = lane; i < r; i += 64)
-    {
-      const double x = xb[i];
+      for(int i = lane; i < r; i += 64)
+      {
+        const double x = xb[i];
 #pragma unroll
-      for(int c = 0; c < 4; c++) acc[c] += ((c < nc) ? Lj[i + (size_t)c*nrows] : 0.0)*x;
-    }
+        for(int c = 0; c < 4; c++) acc[c] += ((c < nc) ? Lj[i + (size_t)c*nrows] : 0.0)*x;
+      }
 #pragma unroll
-    for(int c = 0; c < 4; c++)
-    {
-      const double sum = wave_sum(acc[c]);
-      if(lane == 0 && c < nc)
-        xs[jg + c] = (use_aug ? L[(nrows - 1) + (size_t)(jg + c)*nrows] : ywork[c0 + jg + c]) - sum;
+      for(int c = 0; c < 4; c++)
+      {
+        const double sum = wave_sum(acc[c]);
+        if(lane == 0 && c < nc) xp[jg + c] = sum;
+      }
     }
   }
   __syncthreads();
+  BW_STAMP(3);
   if(nmem > 0)
   {
-    const int* mcol = sn_bd_col + sn_bd_ptr[s];
-    for(int m = tid; m < nmem; m += BWD_NT)
+    // (nmem <= BWD_NT: a member has at least one column and w <= 256)
+    if(tid < w)
     {
-      const int m0 = mcol[m], nb = ((m + 1 < nmem) ? mcol[m+1] : w) - m0;
-      double Lm[8][8], xk[8];
-#pragma unroll
-      for(int a = 0; a < 8; a++)
-#pragma unroll
-        for(int b = 0; b <= a; b++) Lm[a][b] = (a < nb) ? L[(m0 + a) + (size_t)(m0 + b)*nrows] : (a == b ? 1.0 : 0.0);
+      double sum = 0.0;
+      for(int p = 0; p < mv_parts; p++) sum += xp[p*256 + tid];
+      xs[tid] = myrhs - sum;
+    }
+    __syncthreads();
+    if(LEAN)
+    {
+      // rolled loops, the solved unknowns stay in xs: few registers, the latency is hidden by the
+      // other workgroups of the CU
+      if(tid < nmem)
+        for(int a = nbm - 1; a >= 0; a--)
+        {
+          const double* Lc = L + (size_t)(m0 + a)*nrows + m0;
+          double v = xs[m0 + a];
+          for(int b = a + 1; b < nbm; b++) v -= Lc[b]*xs[m0 + b];
+          xs[m0 + a] = v/Lc[a];
+        }
+    }
+    else if(tid < nmem)
+    {
+      double xk[8];
 #pragma unroll
       for(int a = 7; a >= 0; a--)
       {
-        double v = (a < nb) ? xs[m0 + a] : 0.0;
+        double v = (a < nbm) ? xs[m0 + a] : 0.0;
 #pragma unroll
         for(int b = a + 1; b < 8; b++) v -= Lm[b][a]*xk[b];
         xk[a] = v/Lm[a][a];
       }
 #pragma unroll
-      for(int a = 0; a < 8; a++) if(a < nb) xs[m0 + a] = xk[a];
+      for(int a = 0; a < 8; a++) if(a < nbm) xs[m0 + a] = xk[a];
     }
     __syncthreads();
-    for(int j = tid; j < w; j += BWD_NT) { ywork[c0 + j] = xs[j]; out[perm[c0 + j]] = xs[j]; }
+    if(tid < w) { ywork[c0 + tid] = xs[tid]; out[myperm] = xs[tid]; }
     return;
   }
-  double xi = (tid < w) ? xs[tid] : 0.0;
+  double xi = 0.0;
+  if(tid < w)
+  {
+    double sum = 0.0;
+    for(int p = 0; p < mv_parts; p++) sum += xp[p*256 + tid];
+    xi = myrhs - sum;
+  }
   const double* Lcol = L + (size_t)min(tid, w - 1)*nrows;      // column tid of L = row tid of L^T
+  const double* Ltc = Lt + min(tid, w - 1)*ldt;
   double lv[8];
+  if(!top_lds)
   {
     const int j0 = 8*(nblk - 1);
 #pragma unroll
@@ -195,8 +297,16 @@ __global__ void __launch_bounds__(BWD_NT) k_solve_bwd_level(const int* __restric
     double* rh = rhs + 8*(blk & 1);
     if(tid >= j0 && tid < j0 + 8) rh[tid - j0] = xi;
     double ln[8];
+    if(top_lds)
+    {
 #pragma unroll
-    for(int a = 0; a < 8; a++) ln[a] = (blk > 0 && tid < j0 - 8) ? Lcol[j0 - 8 + a] : 0.0;
+      for(int a = 0; a < 8; a++) lv[a] = (tid < j0 && j0 + a < w) ? Ltc[j0 + a] : 0.0;
+    }
+    else
+    {
+#pragma unroll
+      for(int a = 0; a < 8; a++) ln[a] = (blk > 0 && tid < j0 - 8) ? Lcol[j0 - 8 + a] : 0.0;
+    }
     __syncthreads();
     const double* Tb = T + blk*64;
     double xk[8];
@@ -218,41 +328,74 @@ __global__ void __launch_bounds__(BWD_NT) k_solve_bwd_level(const int* __restric
       double v = 0.0;
 #pragma unroll
       for(int a = 0; a < 8; a++) v = (tid - j0 == a) ? xk[a] : v;
-      xs[tid] = v;
+      xi = v;
     }
+    if(!top_lds)
+    {
 #pragma unroll
-    for(int a = 0; a < 8; a++) lv[a] = ln[a];
+      for(int a = 0; a < 8; a++) lv[a] = ln[a];
+    }
   }
-  __syncthreads();
-  for(int j = tid; j < w; j += BWD_NT) { ywork[c0 + j] = xs[j]; out[perm[c0 + j]] = xs[j]; }
+  BW_STAMP(4);
+  if(tid < w) { ywork[c0 + tid] = xi; out[myperm] = xi; }
+  BW_STAMP(5);
 }
 
 } // namespace
 
 // per-level launch parameters of the solve kernels
+#ifdef DLG_FL_PROFILE
+extern "C" void dlg_bw_profile_dump(int nlevels)
+{
+  long long h[64*8];
+  hipDeviceSynchronize();
+  hipMemcpyFromSymbol(h, HIP_SYMBOL(g_bw_prof), sizeof(h));
+  for(int l = 0; l < nlevels && l < 64; l++)
+    fprintf(stderr, "bwd level %2d: issue %6lld  gather+barrier %6lld  matvec %6lld  solve %6lld  store %6lld cycles\n", l,
+            h[l*8+1] - h[l*8], h[l*8+2] - h[l*8+1], h[l*8+3] - h[l*8+2], h[l*8+4] - h[l*8+3], h[l*8+5] - h[l*8+4]);
+}
+#endif
 int sparse_solve_setup(dlg_backend* b)
 {
   SparseSym* Y = b->sym;
   const SymHost& H = Y->H;
-  Y->slv_lds.assign(H.nlevels, 0); Y->bwd_lds.assign(H.nlevels, 0); Y->bwd_nt.assign(H.nlevels, 512);
+  Y->slv_lds.assign(H.nlevels, 0); Y->bwd_lds.assign(H.nlevels, 0); Y->bwd_nt.assign(H.nlevels, 512); Y->bwd_top.assign(H.nlevels, 0);
   for(int l = 0; l < H.nlevels; l++)
   {
-    long maxw = 0, mb = 0;
+    long maxw = 0, mb = 0, mbt = 0, wmax_all = 0;
     for(int i = H.lvl_ptr[l]; i < H.lvl_ptr[l+1]; i++)
     {
       const int s = H.lvl_sn[i];
       const long wv = H.sn_c0[s+1] - H.sn_c0[s], nr = H.sn_rowptr[s+1] - H.sn_rowptr[s];
       if(wv > maxw) maxw = wv;
-      const long need = (nr - wv + 2) + 256 + ((wv + 7)/8)*64 + 16;   // xb, xs, diagonal blocks, rhs
+      wmax_all = std::max(wmax_all, wv);
+      const long need = (nr - wv + 2) + 256 + ((wv + 7)/8)*64 + 16 + 8*256;   // xb, xs, diagonal blocks, rhs, mat-vec partial sums
       if(need > mb) mb = need;
+      // + the top block, for the supernodes that read it (not the block-diagonal ones)
+      if(H.sn_bd_ptr[s+1] == H.sn_bd_ptr[s]) mbt = std::max(mbt, need + wv*(wv | 1));
     }
+    mbt = std::max(mbt, mb);
+    if(wmax_all > 256) { dlg_set_error("supernode of width %ld is too wide for the backward-solve kernel", wmax_all); return DLG_ERR_ARG; }
     Y->slv_lds[l] = (int)(maxw*(maxw | 1)*8);
     if(Y->slv_lds[l] > LDS_BUDGET) { dlg_set_error("supernode of width %ld is too wide for the solve kernels", maxw); return DLG_ERR_ARG; }
     if(mb*8 > LDS_BUDGET) { dlg_set_error("supernode too large for the backward-solve kernel (%ld doubles)", mb); return DLG_ERR_ARG; }
-    Y->bwd_lds[l] = (int)(mb*8);
+    // the top block rides in LDS when every supernode of the level has room for it
+    Y->bwd_top[l] = (mbt*8 <= LDS_BUDGET && getenv("DOGLEG_AMD_BWD_TOP")) ? 1 : 0;     // measured slower than the prefetch from HBM: off unless asked for
+    Y->bwd_lds[l] = (int)((Y->bwd_top[l] ? mbt : mb)*8);
     // thread = row of the diagonal block: 256 threads when every supernode of a populous level is
     // narrow (more workgroups per CU), else 512
     Y->bwd_nt[l] = (maxw <= 128 && H.lvl_ptr[l+1] - H.lvl_ptr[l] >= 512) ? 256 : 512;
+  }
+  {
+    std::vector<SolveItem> items(H.nsn);
+    for(int k = 0; k < H.nsn; k++)
+    {
+      const int s = H.lvl_sn[k];
+      SolveItem& it = items[k];
+      it.c0 = H.sn_c0[s]; it.w = H.sn_c0[s+1] - H.sn_c0[s]; it.nrows = H.sn_rowptr[s+1] - H.sn_rowptr[s];
+      it.rowoff = H.sn_rowptr[s]; it.lx = H.sn_lx[s]; it.bd0 = H.sn_bd_ptr[s]; it.nbd = H.sn_bd_ptr[s+1] - H.sn_bd_ptr[s];
+    }
+    DLG_CHECK(upload(Y->slv_item, items)); Y->allocs.push_back(Y->slv_item);
   }
   DLG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_solve_fwd_level),
                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BUDGET));
@@ -286,12 +429,12 @@ int sparse_solve(dlg_backend* b, const double* rhs, double* out)
     // narrow (more workgroups per CU), else 512
     if(n > 0 && Y->bwd_nt[l] == 256)
       hipLaunchKernelGGL(HIP_KERNEL_NAME(k_solve_bwd_level<256>), dim3(n), dim3(256), Y->bwd_lds[l], st,
-                         Y->lvl_sn + H.lvl_ptr[l], Y->sn_c0, Y->sn_rowptr, Y->sn_rows, Y->sn_lx, Y->perm, Y->Lx,
-                         Y->ywork, out, use_aug, Y->sn_bd_ptr, Y->sn_bd_col);
+                         Y->slv_item + H.lvl_ptr[l], Y->sn_rows, Y->perm, Y->Lx, Y->ywork, out, use_aug, Y->sn_bd_col,
+                         Y->bwd_top[l] + 256*l);
     else if(n > 0)
       hipLaunchKernelGGL(HIP_KERNEL_NAME(k_solve_bwd_level<512>), dim3(n), dim3(512), Y->bwd_lds[l], st,
-                         Y->lvl_sn + H.lvl_ptr[l], Y->sn_c0, Y->sn_rowptr, Y->sn_rows, Y->sn_lx, Y->perm, Y->Lx,
-                         Y->ywork, out, use_aug, Y->sn_bd_ptr, Y->sn_bd_col);
+                         Y->slv_item + H.lvl_ptr[l], Y->sn_rows, Y->perm, Y->Lx, Y->ywork, out, use_aug, Y->sn_bd_col,
+                         Y->bwd_top[l] + 256*l);
   }
   DLG_LAUNCH_CHECK();
   return DLG_OK;

@@ -7,8 +7,10 @@ if [ "$1" = build ]; then
   python3 -c "import __graft_entry__ as g; g.build()" >/dev/null 2>&1
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -mllvm -amdgpu-mfma-vgpr-form=1 -DDLG_FL_PROFILE \
     -Iinclude -c libdogleg_amd/csrc/sparse_factor.hip -o /tmp/sparse_factor_prof.o 2>/dev/null || exit 1
-  objs=$(ls libdogleg_amd/csrc/_obj/*.o | grep -v sparse_factor.hip.o)
-  /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o tools/micro/libprof.so $objs /tmp/sparse_factor_prof.o
+  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -DDLG_FL_PROFILE \
+    -Iinclude -c libdogleg_amd/csrc/sparse_solve.hip -o /tmp/sparse_solve_prof.o 2>/dev/null || exit 1
+  objs=$(ls libdogleg_amd/csrc/_obj/*.o | grep -v sparse_factor.hip.o | grep -v sparse_solve.hip.o)
+  /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o tools/micro/libprof.so $objs /tmp/sparse_factor_prof.o /tmp/sparse_solve_prof.o
   exit $?
 fi
 shift
@@ -22,4 +24,5 @@ buf = io.StringIO()
 with contextlib.redirect_stdout(buf):
     bench.main()
 capi.lib().dlg_fl_profile_dump(16)
+capi.lib().dlg_bw_profile_dump(16)
 PY
