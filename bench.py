@@ -138,13 +138,13 @@ def main():
     def one_step():
         be.bind_device(0, d_x.ptr, d_J.ptr)          # a fresh operating point: nothing cached
         norm2x, gmax = be.eval(0)                    # K1
-        n2c = be.cauchy(0)                           # K3
-        # K4 + K5 + K6: compute_updateGN as the driver issues it (factorise from lambda = 0 with the
-        # reference's lambda loop, dogleg.c:656-677, then solve; one synchronisation per attempt)
-        lam, n2g = be.gauss_newton(0, 0.0)
+        # K3 + K4 + K5 + K6 as the driver issues them once steps leave the trust region's edge behind
+        # (driver.hip take_step): Cauchy step, then compute_updateGN (factorise from lambda = 0 with the
+        # reference's lambda loop, dogleg.c:656-677, and solve), one synchronisation per attempt
+        lam, n2c, n2g = be.cauchy_gauss_newton(0, 0.0)
         tr = 0.5 * (n2c ** 0.5 + n2g ** 0.5)
-        n2s, k, amax, pnew = be.make_step(0, 1, capi.KIND_INTERP, tr)   # K7 (+ p_new D2H)
-        ei = be.expected_improvement(0, 1)           # K8
+        # K7 + K8 (+ p_new D2H): the step and its expected improvement, one synchronisation
+        n2s, k, amax, ei, pnew = be.step(0, 1, capi.KIND_INTERP, tr)
         return norm2x, n2c, n2g, k, n2s, ei, gmax, amax, lam
 
     def barrier():
@@ -173,8 +173,7 @@ def main():
         tr_retry = 0.5 * (res[1] ** 0.5 + res[2] ** 0.5)
 
         def one_retry(shrink):
-            be.make_step(0, 1, capi.KIND_INTERP, tr_retry * shrink)
-            be.expected_improvement(0, 1)
+            be.step(0, 1, capi.KIND_INTERP, tr_retry * shrink)
             be.bind_device(1, d_x.ptr, d_J.ptr)
             be.eval(1)
         one_retry(0.99)

@@ -123,6 +123,13 @@ int  dlg_solve_gn(dlg_backend_t* b, int slot, double* norm2_updateGN);
  * dlg_solve_gn).  On return *lambda_io is the lambda that worked. ---------------------------- */
 int  dlg_gauss_newton(dlg_backend_t* b, int slot, double* lambda_io, double* norm2_updateGN);
 
+/* ---- K3 + K4+K5+K6 behind one synchronisation: dlg_cauchy issued in front of dlg_gauss_newton.
+ * takeStepFrom (dogleg.c:1186-1256) needs the Cauchy step first and the Gauss-Newton step whenever
+ * the Cauchy step ends inside the trust region; a caller that expects that (the driver does once a
+ * step needed both) saves a host round trip.  Same results as the two calls. ------------------- */
+int  dlg_cauchy_gauss_newton(dlg_backend_t* b, int slot, double* lambda_io, double* norm2_updateCauchy,
+                             double* norm2_updateGN);
+
 /* ---- K7 + the vector part of takeStepFrom (dogleg.c:1192-1259,1289-1291):
  * form the step of the given kind from slot `from`, store it as
  * step_to_here of slot `to`, set p[to] = p[from] + step, copy p[to] to
@@ -135,6 +142,12 @@ int  dlg_make_step(dlg_backend_t* b, int from, int to, int kind, double trustreg
 /* ---- K8: computeExpectedImprovement (dogleg.c:1085-1165) for the step held
  * in slot `to`, evaluated with J / Jt_x of slot `from` ---------------------- */
 int  dlg_expected_improvement(dlg_backend_t* b, int from, int to, double* out);
+
+/* ---- K7 + K8 behind one synchronisation: dlg_make_step followed by dlg_expected_improvement,
+ * as takeStepFrom issues them back to back (dogleg.c:1192-1269) ------------------------------- */
+int  dlg_step(dlg_backend_t* b, int from, int to, int kind, double trustregion,
+              double* norm2_step, double* k_cauchy_to_gn, double* step_absmax,
+              double* expected_improvement, double* p_new_host);
 
 /* ---- downloads (returnContext, tests) -------------------------------------- */
 int  dlg_point_download(dlg_backend_t* b, int slot, int which, double* host, size_t n);

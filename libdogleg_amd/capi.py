@@ -27,7 +27,8 @@ BACKEND_SYMBOLS = [
     "dlg_backend_set_stream", "dlg_backend_get_stream", "dlg_backend_set_shard",
     "dlg_sparse_set_pattern", "dlg_sparse_stats", "dlg_point_set_p", "dlg_point_upload",
     "dlg_point_upload_products", "dlg_point_bind_device", "dlg_point_eval", "dlg_cauchy",
-    "dlg_factorize", "dlg_solve_gn", "dlg_gauss_newton", "dlg_make_step", "dlg_expected_improvement",
+    "dlg_factorize", "dlg_solve_gn", "dlg_gauss_newton", "dlg_cauchy_gauss_newton", "dlg_make_step",
+    "dlg_expected_improvement", "dlg_step",
     "dlg_point_download", "dlg_factor_download_dense", "dlg_point_device_ptr",
     "dlg_kernel_syrk_lower", "dlg_kernel_potrf_lower", "dlg_probe_mfma_f64",
     "dlg_probe_hbm_copy", "dlg_set_trace", "dlg_mem_alloc", "dlg_mem_free", "dlg_host_alloc",
@@ -82,7 +83,9 @@ def lib():
     L.dlg_factorize.argtypes = [V, C.c_int, C.c_double, I]
     L.dlg_solve_gn.argtypes = [V, C.c_int, D]
     L.dlg_gauss_newton.argtypes = [V, C.c_int, D, D]
+    L.dlg_cauchy_gauss_newton.argtypes = [V, C.c_int, D, D, D]
     L.dlg_make_step.argtypes = [V, C.c_int, C.c_int, C.c_int, C.c_double, D, D, D, D]
+    L.dlg_step.argtypes = [V, C.c_int, C.c_int, C.c_int, C.c_double, D, D, D, D, D]
     L.dlg_expected_improvement.argtypes = [V, C.c_int, C.c_int, D]
     L.dlg_point_download.argtypes = [V, C.c_int, C.c_int, D, C.c_size_t]
     L.dlg_factor_download_dense.argtypes = [V, D, C.c_size_t]
@@ -325,6 +328,30 @@ class Backend:
         l, a = C.c_double(lam), C.c_double()
         _ck(self.L.dlg_gauss_newton(self.h, slot, C.byref(l), C.byref(a)), "gauss_newton")
         return l.value, a.value
+
+    def cauchy_gauss_newton(self, slot, lam=0.0):
+        """Cauchy step + gauss_newton behind one synchronisation: (lambda, |cauchy|^2, |gn|^2)"""
+        l, c, a = C.c_double(lam), C.c_double(), C.c_double()
+        _ck(self.L.dlg_cauchy_gauss_newton(self.h, slot, C.byref(l), C.byref(c), C.byref(a)), "cauchy_gauss_newton")
+        return l.value, c.value, a.value
+
+    def _pnew_buffer(self):
+        if self._pnew is None:
+            self._pnew_ptr = self.L.dlg_host_alloc(8 * self.N)
+            if not self._pnew_ptr:
+                raise DlgError(self.L.dlg_last_error().decode())
+            self._pnew = np.ctypeslib.as_array(C.cast(self._pnew_ptr, C.POINTER(C.c_double)), shape=(self.N,))
+        return self._pnew
+
+    def step(self, frm, to, kind, trustregion, want_p=True):
+        """make_step + expected_improvement behind one synchronisation:
+        (|step|^2, k, max|step|, expected improvement, p_new); p_new as in make_step"""
+        n2, k, am, ei = C.c_double(), C.c_double(), C.c_double(), C.c_double()
+        if want_p:
+            self._pnew_buffer()
+        _ck(self.L.dlg_step(self.h, frm, to, kind, trustregion, C.byref(n2), C.byref(k), C.byref(am),
+                            C.byref(ei), dptr(self._pnew) if want_p else None), "step")
+        return n2.value, k.value, am.value, ei.value, (self._pnew if want_p else None)
 
     def make_step(self, frm, to, kind, trustregion, want_p=True):
         """p_new comes back in a page-locked buffer owned by this object (as the driver's operating

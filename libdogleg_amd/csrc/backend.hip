@@ -338,6 +338,15 @@ static int norm2_Jv(dlg_backend* b, int s, const double* v, double* out)
 }
 
 // ---------------------------------------------------------------------- K3 --
+// launches only: sc[0] = |g|^2, sc[1] = |J g|^2, sc[2] = |cauchy|^2 (device scalars)
+static int cauchy_enqueue(dlg_backend* b, int s, double* sc)
+{
+  DlgSlot& S = b->slot[s];
+  DLG_CHECK(k_norm2_absmax(b, S.Jt_x, b->N, sc));               // also writes sc[1], replaced next
+  DLG_CHECK(norm2_Jv(b, s, S.Jt_x, sc + 1));
+  DLG_CHECK(k_cauchy_finish(b, S.Jt_x, sc, S.cauchy, b->N, sc + 2));
+  return DLG_OK;
+}
 extern "C" int dlg_cauchy(dlg_backend_t* b, int s, double* norm2_updateCauchy)
 {
   DLG_CHECK(check_slot(b, s));
@@ -345,11 +354,7 @@ extern "C" int dlg_cauchy(dlg_backend_t* b, int s, double* norm2_updateCauchy)
   if(!S.have_Jtx) { dlg_set_error("dlg_cauchy needs Jt_x (reference dogleg.c:551-555)"); return DLG_ERR_STATE; }
   if(!S.have_cauchy)
   {
-    // d_scal[0] = |g|^2, d_scal[1] = |J g|^2
-    DLG_CHECK(k_norm2_absmax(b, S.Jt_x, b->N, b->d_scal + 4));
-    DLG_HIP(hipMemcpyAsync(b->d_scal, b->d_scal + 4, sizeof(double), hipMemcpyDeviceToDevice, b->stream));
-    DLG_CHECK(norm2_Jv(b, s, S.Jt_x, b->d_scal + 1));
-    DLG_CHECK(k_cauchy_finish(b, S.Jt_x, b->d_scal, S.cauchy, b->N, b->d_scal + 2));
+    DLG_CHECK(cauchy_enqueue(b, s, b->d_scal));
     DLG_CHECK(dlg_fetch_scalars(b, 3));
     S.norm2_cauchy = b->h_scal[2];
     S.have_cauchy = true;
@@ -406,19 +411,31 @@ extern "C" int dlg_solve_gn(dlg_backend_t* b, int s, double* norm2_updateGN)
 // Fused here so that one attempt costs ONE host synchronisation: the factorisation is enqueued,
 // the solve is enqueued behind it, and the pivot flag is read together with |gn|^2 (a failed
 // factorisation replaces its bad pivots by 1, so the speculative solve cannot fault).
-extern "C" int dlg_gauss_newton(dlg_backend_t* b, int s, double* lambda_io, double* norm2_updateGN)
+static int gauss_newton_impl(dlg_backend_t* b, int s, double* lambda_io, double* norm2_updateGN,
+                            bool with_cauchy, double* norm2_updateCauchy)
 {
   DLG_CHECK(check_slot(b, s));
   if(!lambda_io) { dlg_set_error("dlg_gauss_newton: lambda_io is NULL"); return DLG_ERR_ARG; }
   DlgSlot& S = b->slot[s];
   if(!S.have_inputs) { dlg_set_error("dlg_gauss_newton: slot %d has no J/JtJ", s); return DLG_ERR_STATE; }
   if(!S.have_Jtx) { dlg_set_error("dlg_gauss_newton needs Jt_x"); return DLG_ERR_STATE; }
+  bool cauchy_pending = false;
   if(b->factor_slot == s && S.have_gn)                       // both cached (dogleg.c:637, 825)
-  { if(norm2_updateGN) *norm2_updateGN = S.norm2_gn; return DLG_OK; }
+  {
+    if(with_cauchy) DLG_CHECK(dlg_cauchy(b, s, norm2_updateCauchy));
+    if(norm2_updateGN) *norm2_updateGN = S.norm2_gn;
+    return DLG_OK;
+  }
   double lam = *lambda_io;
   for(;;)
   {
     int good = 0, rc;
+    if(with_cauchy && !S.have_cauchy && !cauchy_pending)
+    {
+      // the Cauchy step rides along: its scalars come back with the same synchronisation
+      DLG_CHECK(cauchy_enqueue(b, s, b->d_scal + 4));
+      cauchy_pending = true;
+    }
     if(b->factor_slot != s)
     {
       b->defer_factor_sync = true;
@@ -437,8 +454,9 @@ extern "C" int dlg_gauss_newton(dlg_backend_t* b, int s, double* lambda_io, doub
       else                      DLG_CHECK(dense_solve(b, S.Jt_x, S.gn));
     }
     DLG_CHECK(k_negate_norm2(b, S.gn, b->N, b->d_scal));      // dogleg.c:862-865
-    DLG_CHECK(dlg_fetch_scalars(b, 1));                       // the one synchronisation
+    DLG_CHECK(dlg_fetch_scalars(b, cauchy_pending ? 7 : 1));  // the one synchronisation
     if(b->profiling) dlg_prof_resolve(b);
+    if(cauchy_pending && !S.have_cauchy) { S.norm2_cauchy = b->h_scal[6]; S.have_cauchy = true; }
     good = (b->factor_slot == s) ? 1 : (b->type == DLG_SPARSE ? sparse_factor_ok(b) : dense_factor_ok(b));
     if(good) break;
     b->factor_slot = -1;
@@ -450,19 +468,24 @@ extern "C" int dlg_gauss_newton(dlg_backend_t* b, int s, double* lambda_io, doub
   S.have_gn = true;
   *lambda_io = lam;
   if(norm2_updateGN) *norm2_updateGN = S.norm2_gn;
+  if(with_cauchy && norm2_updateCauchy) *norm2_updateCauchy = S.norm2_cauchy;
   return DLG_OK;
 }
+extern "C" int dlg_gauss_newton(dlg_backend_t* b, int s, double* lambda_io, double* norm2_updateGN)
+{ return gauss_newton_impl(b, s, lambda_io, norm2_updateGN, false, nullptr); }
+// K3 + K4 + K5 + K6 behind one synchronisation: the Cauchy step (dogleg.c:529-617) is issued in
+// front of the Gauss-Newton work of dlg_gauss_newton.  For callers that expect to need both (the
+// driver does once a step has left the trust region's edge behind).
+extern "C" int dlg_cauchy_gauss_newton(dlg_backend_t* b, int s, double* lambda_io, double* norm2_updateCauchy,
+                                       double* norm2_updateGN)
+{ return gauss_newton_impl(b, s, lambda_io, norm2_updateGN, true, norm2_updateCauchy); }
 
 // ---------------------------------------------------------------------- K7 --
-extern "C" int dlg_make_step(dlg_backend_t* b, int from, int to, int kind, double trustregion,
-                             double* norm2_step, double* k_cauchy_to_gn, double* step_absmax,
-                             double* p_new_host)
+// launches the step kernel (its scalars land in d_scal[0..2]); nscal = how many to fetch
+static int make_step_enqueue(dlg_backend* b, int from, int to, int kind, double trustregion, int* nscal)
 {
-  DLG_CHECK(check_slot(b, from)); DLG_CHECK(check_slot(b, to));
-  if(from == to) { dlg_set_error("dlg_make_step: from == to"); return DLG_ERR_ARG; }
   DlgSlot& F = b->slot[from];
   DlgSlot& T = b->slot[to];
-  double n2 = 0, kk = NAN, amax = 0;
   DlgProfScope ps(b, DLG_PROF_K7_STEP);
   switch(kind)
   {
@@ -470,40 +493,67 @@ extern "C" int dlg_make_step(dlg_backend_t* b, int from, int to, int kind, doubl
     if(!F.have_cauchy) { dlg_set_error("cauchy step not computed"); return DLG_ERR_STATE; }
     DLG_CHECK(k_scaled_step(b, F.cauchy, trustregion / sqrt(F.norm2_cauchy), F.p, T.step, T.p, b->N,
                             b->d_scal));                          // dogleg.c:1204-1207
-    DLG_CHECK(dlg_fetch_scalars(b, 1));
-    n2 = F.norm2_cauchy;                                          // unscaled: dogleg.c:1200
-    amax = b->h_scal[0];
+    *nscal = 1;
     break;
   case DLG_KIND_GAUSSNEWTON:
     if(!F.have_gn) { dlg_set_error("GN step not computed"); return DLG_ERR_STATE; }
     DLG_CHECK(k_scaled_step(b, F.gn, 1.0, F.p, T.step, T.p, b->N, b->d_scal));   // dogleg.c:1231
-    DLG_CHECK(dlg_fetch_scalars(b, 1));
-    n2 = F.norm2_gn;
-    amax = b->h_scal[0];
+    *nscal = 1;
     break;
   case DLG_KIND_INTERPOLATED:
     if(!F.have_cauchy || !F.have_gn) { dlg_set_error("interpolation needs cauchy and GN"); return DLG_ERR_STATE; }
     DLG_CHECK(k_interpolate(b, F.cauchy, F.gn, F.norm2_cauchy, trustregion, F.p, T.step, T.p, b->N,
                             b->d_scal));
-    DLG_CHECK(dlg_fetch_scalars(b, 3));
-    n2 = b->h_scal[0]; kk = b->h_scal[1]; amax = b->h_scal[2];
+    *nscal = 3;
     break;
   default:
     dlg_set_error("dlg_make_step: unknown kind %d", kind);
     return DLG_ERR_ARG;
   }
+  return DLG_OK;
+}
+static void make_step_read(dlg_backend* b, int from, int kind, double* n2, double* kk, double* amax)
+{
+  DlgSlot& F = b->slot[from];
+  *kk = NAN;
+  switch(kind)
+  {
+  case DLG_KIND_CAUCHY_TO_EDGE: *n2 = F.norm2_cauchy; *amax = b->h_scal[0]; break;   // unscaled: dogleg.c:1200
+  case DLG_KIND_GAUSSNEWTON:    *n2 = F.norm2_gn;     *amax = b->h_scal[0]; break;
+  default:                      *n2 = b->h_scal[0]; *kk = b->h_scal[1]; *amax = b->h_scal[2]; break;
+  }
+}
+// scalars and (optionally) p_new back to the host behind ONE synchronisation
+static int step_finish(dlg_backend* b, int to, int nscal, double* p_new_host)
+{
+  DlgSlot& T = b->slot[to];
+  DLG_HIP(hipMemcpyAsync(b->h_scal, b->d_scal, sizeof(double)*(size_t)nscal, hipMemcpyDeviceToHost, b->stream));
+  bool pinned = true;
   if(p_new_host)
   {
     // page-locked destination (the driver's operating points, dlg_host_alloc): straight DMA;
     // pageable: through the backend's pinned staging vector
     hipPointerAttribute_t attr;
-    const bool pinned = hipPointerGetAttributes(&attr, p_new_host) == hipSuccess && attr.type == hipMemoryTypeHost;
+    pinned = hipPointerGetAttributes(&attr, p_new_host) == hipSuccess && attr.type == hipMemoryTypeHost;
     if(!pinned) (void)hipGetLastError();
     double* dst = pinned ? p_new_host : b->h_vec;
     DLG_HIP(hipMemcpyAsync(dst, T.p, sizeof(double)*(size_t)b->N, hipMemcpyDeviceToHost, b->stream));
-    DLG_HIP(hipStreamSynchronize(b->stream));
-    if(!pinned) memcpy(p_new_host, b->h_vec, sizeof(double)*(size_t)b->N);
   }
+  DLG_HIP(hipStreamSynchronize(b->stream));
+  if(p_new_host && !pinned) memcpy(p_new_host, b->h_vec, sizeof(double)*(size_t)b->N);
+  return DLG_OK;
+}
+extern "C" int dlg_make_step(dlg_backend_t* b, int from, int to, int kind, double trustregion,
+                             double* norm2_step, double* k_cauchy_to_gn, double* step_absmax,
+                             double* p_new_host)
+{
+  DLG_CHECK(check_slot(b, from)); DLG_CHECK(check_slot(b, to));
+  if(from == to) { dlg_set_error("dlg_make_step: from == to"); return DLG_ERR_ARG; }
+  double n2 = 0, kk = NAN, amax = 0;
+  int nscal = 0;
+  DLG_CHECK(make_step_enqueue(b, from, to, kind, trustregion, &nscal));
+  DLG_CHECK(step_finish(b, to, nscal, p_new_host));
+  make_step_read(b, from, kind, &n2, &kk, &amax);
   if(norm2_step) *norm2_step = n2;
   if(k_cauchy_to_gn) *k_cauchy_to_gn = kk;
   if(step_absmax) *step_absmax = amax;
@@ -511,16 +561,41 @@ extern "C" int dlg_make_step(dlg_backend_t* b, int from, int to, int kind, doubl
 }
 
 // ---------------------------------------------------------------------- K8 --
-extern "C" int dlg_expected_improvement(dlg_backend_t* b, int from, int to, double* out)
+static int expected_improvement_enqueue(dlg_backend* b, int from, int to, double* sc)
 {
-  DLG_CHECK(check_slot(b, from)); DLG_CHECK(check_slot(b, to));
   DlgSlot& F = b->slot[from];
   DlgSlot& T = b->slot[to];
   if(!F.have_Jtx) { dlg_set_error("expected improvement needs Jt_x"); return DLG_ERR_STATE; }
-  DLG_CHECK(k_inner(b, F.Jt_x, T.step, b->N, b->d_scal));
-  DLG_CHECK(norm2_Jv(b, from, T.step, b->d_scal + 1));
+  DLG_CHECK(k_inner(b, F.Jt_x, T.step, b->N, sc));
+  DLG_CHECK(norm2_Jv(b, from, T.step, sc + 1));
+  return DLG_OK;
+}
+extern "C" int dlg_expected_improvement(dlg_backend_t* b, int from, int to, double* out)
+{
+  DLG_CHECK(check_slot(b, from)); DLG_CHECK(check_slot(b, to));
+  DLG_CHECK(expected_improvement_enqueue(b, from, to, b->d_scal));
   DLG_CHECK(dlg_fetch_scalars(b, 2));
   if(out) *out = -2.0*b->h_scal[0] - b->h_scal[1];               // dogleg.c:1107-1109
+  return DLG_OK;
+}
+// K7 + K8 behind one synchronisation: the step (dlg_make_step), its expected improvement
+// (dlg_expected_improvement, dogleg.c:1258-1269 computes it right after the step) and p_new
+extern "C" int dlg_step(dlg_backend_t* b, int from, int to, int kind, double trustregion,
+                        double* norm2_step, double* k_cauchy_to_gn, double* step_absmax,
+                        double* expected_improvement, double* p_new_host)
+{
+  DLG_CHECK(check_slot(b, from)); DLG_CHECK(check_slot(b, to));
+  if(from == to) { dlg_set_error("dlg_step: from == to"); return DLG_ERR_ARG; }
+  double n2 = 0, kk = NAN, amax = 0;
+  int nscal = 0;
+  DLG_CHECK(make_step_enqueue(b, from, to, kind, trustregion, &nscal));
+  DLG_CHECK(expected_improvement_enqueue(b, from, to, b->d_scal + 4));
+  DLG_CHECK(step_finish(b, to, 6, p_new_host));
+  make_step_read(b, from, kind, &n2, &kk, &amax);
+  if(norm2_step) *norm2_step = n2;
+  if(k_cauchy_to_gn) *k_cauchy_to_gn = kk;
+  if(step_absmax) *step_absmax = amax;
+  if(expected_improvement) *expected_improvement = -2.0*b->h_scal[4] - b->h_scal[5];
   return DLG_OK;
 }
 

@@ -60,6 +60,7 @@ struct Driver
   int ncallbacks;
   bool check_pattern;
   int *pat_p, *pat_i;
+  bool expect_gn;                              // the last step needed the Gauss-Newton step: issue it with the Cauchy step
 };
 
 inline Driver* D(dogleg_solverContext_t* ctx) { return reinterpret_cast<Driver*>(ctx); }
@@ -340,6 +341,31 @@ bool compute_gn(dogleg_operatingPoint_t* pt, Driver* d)
   return true;
 }
 
+// Cauchy + Gauss-Newton of a fresh point behind one synchronisation (see take_step)
+bool compute_cauchy_gn(dogleg_operatingPoint_t* pt, Driver* d)
+{
+  dogleg_solverContext_t* ctx = &d->pub;
+  if(!pt->have_Jtx) { MSG("Cauchy step needs Jt_x, which is missing"); return false; }
+  if(ctx->solve_type == DOGLEG_DENSE_PRODUCTS ? !pt->have_JtJ : !pt->have_J)
+  { MSG("factorization needs J (or JtJ), which is missing"); return false; }
+  if(ctx->solve_type == DOGLEG_SPARSE && ctx->factorization == nullptr)
+  {
+    d->factor_handle.n = (size_t)ctx->Nstate; d->factor_handle.minor = 0;
+    d->factor_handle.backend = d->be;
+    ctx->factorization = &d->factor_handle;                    // dogleg.c:650-654
+  }
+  double n2c = 0, n2g = 0;
+  const double lambda_before = ctx->lambda;
+  if(!be_ok(dlg_cauchy_gauss_newton(d->be, slot_of(d, pt), &ctx->lambda, &n2c, &n2g), "Cauchy + GN step")) return false;
+  if(ctx->lambda != lambda_before) VERBOSE(d, "singular JtJ: adding %g I from now on", ctx->lambda);
+  if(ctx->solve_type == DOGLEG_SPARSE) d->factor_handle.minor = d->factor_handle.n;
+  pt->norm2_updateCauchy = n2c; pt->have_updateCauchy = true;
+  pt->norm2_updateGN = n2g; pt->have_updateGN = true; pt->have_factorization = true;
+  VERBOSE(d, "cauchy step length %.6g", sqrt(n2c));
+  d->cur.norm2_cauchy = n2c;
+  return true;
+}
+
 // dogleg.c:1172-1297.  The step vector stays on the device (slot `to`); p_new
 // comes back because the user callback needs it.
 bool take_step(double* expectedImprovement, dogleg_operatingPoint_t* to,
@@ -351,17 +377,25 @@ bool take_step(double* expectedImprovement, dogleg_operatingPoint_t* to,
   d->cur.norm2x_before      = from->norm2_x;
   const int sf = slot_of(d, from), st = slot_of(d, to);
 
-  if(!compute_cauchy(from, d)) return false;
+  // The reference computes the Cauchy step, and the Gauss-Newton step only if the Cauchy step ends
+  // inside the trust region (dogleg.c:1186-1211).  Once a step has needed both, the next point's
+  // pair is issued behind one host synchronisation; the values are the same, and a Gauss-Newton
+  // step the reference would not have computed is simply not used (nor reported).
+  if(d->expect_gn && !from->have_updateCauchy && !from->have_updateGN && !from->have_factorization)
+  { if(!compute_cauchy_gn(from, d)) return false; }
+  else if(!compute_cauchy(from, d)) return false;
   int kind;
   if(from->norm2_updateCauchy >= trustregion*trustregion)
   {
     kind = DLG_KIND_CAUCHY_TO_EDGE;
     d->cur.step_type = DLG_STEP_CAUCHY;
     from->didStepToEdgeOfTrustRegion = true;
+    d->expect_gn = false;
   }
   else
   {
     if(!compute_gn(from, d)) return false;
+    d->expect_gn = true;
     if(from->norm2_updateGN <= trustregion*trustregion)
     {
       kind = DLG_KIND_GAUSSNEWTON;
@@ -376,14 +410,14 @@ bool take_step(double* expectedImprovement, dogleg_operatingPoint_t* to,
     }
   }
   double n2 = 0, k = NAN, amax = 0;
-  if(!be_ok(dlg_make_step(d->be, sf, st, kind, trustregion, &n2, &k, &amax, to->p), "step")) return false;
+  // step, its expected improvement and p_new: one backend op, one host synchronisation
+  if(!be_ok(dlg_step(d->be, sf, st, kind, trustregion, &n2, &k, &amax, expectedImprovement, to->p), "step")) return false;
   to->norm2_step_to_here = n2;
   d->cur.norm2_step = n2;
   d->cur.k_cauchy_to_gn = k;
   d->cur.did_step_to_edge = from->didStepToEdgeOfTrustRegion;
   if(kind == DLG_KIND_INTERPOLATED) VERBOSE(d, "k_cauchy_to_gn %.6g, norm %.6g", k, sqrt(n2));
 
-  if(!be_ok(dlg_expected_improvement(d->be, sf, st, expectedImprovement), "expected improvement")) return false;
   // the diagnostics record the computed value, also for the terminal step whose return value is
   // replaced by -1 below (dogleg.c:1267-1269 comes before 1289-1296)
   d->cur.expected_improvement = *expectedImprovement;

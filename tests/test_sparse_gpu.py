@@ -186,3 +186,44 @@ def test_no_device_memory_leak_over_create_solve_destroy_cycles(gpu):
     for _ in range(10):
         cycle()
     assert before - free_bytes() <= (1 << 20), "device memory is not returned"
+
+
+@pytest.mark.parametrize("kind", ["sparse", "dense"])
+def test_fused_backend_ops_match_the_separate_calls(gpu, kind):
+    """dlg_cauchy_gauss_newton and dlg_step only save host round trips: their numbers are those of
+    dlg_cauchy + dlg_gauss_newton and dlg_make_step + dlg_expected_improvement, bit for bit"""
+    if kind == "sparse":
+        prob = oa.BAProblem(6, 60, 400, seed=5)
+        p = prob.p0()
+        x, J = prob.eval(p)
+        Jp, Ji = prob.pattern()
+        mk = lambda: capi.Backend(capi.DLG_SPARSE, prob.N, prob.M, prob.nnz)
+    else:
+        prob = oa.DenseProblem(M=500, N=40, seed=5)
+        p = prob.p0()
+        x, J = prob.eval(p)
+        mk = lambda: capi.Backend(capi.DLG_DENSE, prob.N, prob.M)
+    out = []
+    for fused in (False, True):
+        be = mk()
+        if kind == "sparse":
+            be.set_pattern(Jp, Ji)
+        be.set_p(0, p)
+        be.upload(0, x, J)
+        be.eval(0)
+        if fused:
+            lam, n2c, n2g = be.cauchy_gauss_newton(0, 0.0)
+        else:
+            n2c = be.cauchy(0)
+            lam, n2g = be.gauss_newton(0, 0.0)
+        tr = 0.5 * (np.sqrt(n2c) + np.sqrt(n2g))
+        if fused:
+            n2s, k, amax, ei, pnew = be.step(0, 1, capi.KIND_INTERP, tr)
+        else:
+            n2s, k, amax, pnew = be.make_step(0, 1, capi.KIND_INTERP, tr)
+            ei = be.expected_improvement(0, 1)
+        out.append((lam, n2c, n2g, n2s, k, amax, ei, pnew.copy(), be.download(1, capi.VEC_STEP)))
+    a, b = out
+    for u, v in zip(a[:7], b[:7]):
+        assert u == v
+    assert np.array_equal(a[7], b[7]) and np.array_equal(a[8], b[8])
