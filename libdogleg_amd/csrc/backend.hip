@@ -319,6 +319,7 @@ extern "C" int dlg_point_eval(dlg_backend_t* b, int s, double* norm2_x, double* 
     S.norm2_x = b->h_scal[0];
   }
   S.have_Jtx = true;
+  S.norm2_jtx = b->h_scal[2];
   if(norm2_x) *norm2_x = S.norm2_x;
   if(Jtx_absmax) *Jtx_absmax = b->h_scal[3];
   return DLG_OK;
@@ -338,13 +339,12 @@ static int norm2_Jv(dlg_backend* b, int s, const double* v, double* out)
 }
 
 // ---------------------------------------------------------------------- K3 --
-// launches only: sc[0] = |g|^2, sc[1] = |J g|^2, sc[2] = |cauchy|^2 (device scalars)
+// launches only: sc[1] = |J g|^2, sc[2] = |cauchy|^2 (device scalars)
 static int cauchy_enqueue(dlg_backend* b, int s, double* sc)
 {
   DlgSlot& S = b->slot[s];
-  DLG_CHECK(k_norm2_absmax(b, S.Jt_x, b->N, sc));               // also writes sc[1], replaced next
   DLG_CHECK(norm2_Jv(b, s, S.Jt_x, sc + 1));
-  DLG_CHECK(k_cauchy_finish(b, S.Jt_x, sc, S.cauchy, b->N, sc + 2));
+  DLG_CHECK(k_cauchy_finish(b, S.Jt_x, S.norm2_jtx, sc + 1, S.cauchy, b->N, sc + 2));    // |g|^2: from dlg_point_eval
   return DLG_OK;
 }
 extern "C" int dlg_cauchy(dlg_backend_t* b, int s, double* norm2_updateCauchy)
@@ -454,7 +454,7 @@ static int gauss_newton_impl(dlg_backend_t* b, int s, double* lambda_io, double*
       else                      DLG_CHECK(dense_solve(b, S.Jt_x, S.gn));
     }
     DLG_CHECK(k_negate_norm2(b, S.gn, b->N, b->d_scal));      // dogleg.c:862-865
-    DLG_CHECK(dlg_fetch_scalars(b, cauchy_pending ? 7 : 1));  // the one synchronisation
+    DLG_CHECK(dlg_fetch_scalars(b, dlg_backend::NSCAL));      // the one synchronisation (the sparse pivot flag rides in the last slot)
     if(b->profiling) dlg_prof_resolve(b);
     if(cauchy_pending && !S.have_cauchy) { S.norm2_cauchy = b->h_scal[6]; S.have_cauchy = true; }
     good = (b->factor_slot == s) ? 1 : (b->type == DLG_SPARSE ? sparse_factor_ok(b) : dense_factor_ok(b));

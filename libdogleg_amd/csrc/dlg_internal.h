@@ -44,7 +44,7 @@ struct DlgSlot
   double* step   = nullptr;   // [N] step_to_here
   const double* x_bound = nullptr;   // device-resident inputs (dlg_point_bind_device)
   const double* J_bound = nullptr;
-  double  norm2_x = 0, norm2_cauchy = 0, norm2_gn = 0;
+  double  norm2_x = 0, norm2_cauchy = 0, norm2_gn = 0, norm2_jtx = 0;
   bool    have_inputs = false, have_Jtx = false, have_cauchy = false, have_gn = false;
   const double* xin() const { return x_bound ? x_bound : x; }
   const double* Jin() const { return J_bound ? J_bound : J; }
@@ -124,9 +124,9 @@ int dlg_fetch_scalars(dlg_backend* b, int n);
 int k_norm2_absmax(dlg_backend* b, const double* x, int n, double* out2);
 // out[0] = <x,y>
 int k_inner(dlg_backend* b, const double* x, const double* y, int n, double* out);
-// Cauchy finish: reads g2 = scal_in[0], Jg2 = scal_in[1]; k = -g2/Jg2;
+// Cauchy finish: g2 = |g|^2 (host), Jg2 = *Jg2_dev; k = -g2/Jg2;
 // cauchy = k*g ; out[0] = k*k*g2
-int k_cauchy_finish(dlg_backend* b, const double* g, const double* scal_in, double* cauchy,
+int k_cauchy_finish(dlg_backend* b, const double* g, double g2, const double* Jg2_dev, double* cauchy,
                     int n, double* out);
 // step = s * v ; p_new = p + step ; out[0] = max|step|
 int k_scaled_step(dlg_backend* b, const double* v, double s, const double* p, double* step,

@@ -75,7 +75,7 @@ __global__ void __launch_bounds__(TPB) k_part_inner(const double* __restrict__ x
 }
 // final: nsum sums followed by nmax maxima, each over nb partials
 __global__ void __launch_bounds__(TPB) k_final(const double* __restrict__ part, int nb, int nsum,
-                                               int nmax, double* __restrict__ out)
+                                               int nmax, double* __restrict__ out, int ostride)
 {
   __shared__ double sh[4];
   for(int k = 0; k < nsum + nmax; k++)
@@ -84,17 +84,17 @@ __global__ void __launch_bounds__(TPB) k_final(const double* __restrict__ part, 
     double v = 0;
     if(k < nsum) { for(int i = threadIdx.x; i < nb; i += TPB) v += pk[i]; v = block_sum(v, sh); }
     else         { for(int i = threadIdx.x; i < nb; i += TPB) v = fmax(v, pk[i]); v = block_max(v, sh); }
-    if(threadIdx.x == 0) out[k] = v;
+    if(threadIdx.x == 0) out[k*ostride] = v;
     __syncthreads();
   }
 }
 
-__global__ void __launch_bounds__(TPB) k_cauchy_scale(const double* __restrict__ g,
-                                                      const double* __restrict__ scal,
+__global__ void __launch_bounds__(TPB) k_cauchy_scale(const double* __restrict__ g, double g2,
+                                                      const double* __restrict__ Jg2p,
                                                       double* __restrict__ c, int n,
                                                       double* __restrict__ out)
 {
-  const double g2 = scal[0], Jg2 = scal[1];
+  const double Jg2 = Jg2p[0];
   const double k = -g2 / Jg2;                       // dogleg.c:605
   for(int i = blockIdx.x*TPB + threadIdx.x; i < n; i += gridDim.x*TPB) c[i] = k*g[i];
   if(blockIdx.x == 0 && threadIdx.x == 0) out[0] = k*k*g2;   // dogleg.c:607
@@ -185,7 +185,7 @@ int dlg_ensure_partials(dlg_backend* b, size_t nd)
 
 int k_reduce_sum(dlg_backend* b, const double* partials, int np, double* out)
 {
-  hipLaunchKernelGGL(k_final, dim3(1), dim3(TPB), 0, b->stream, partials, np, 1, 0, out);
+  hipLaunchKernelGGL(k_final, dim3(1), dim3(TPB), 0, b->stream, partials, np, 1, 0, out, 1);
   DLG_LAUNCH_CHECK();
   return DLG_OK;
 }
@@ -195,7 +195,7 @@ int k_norm2_absmax(dlg_backend* b, const double* x, int n, double* out2)
   const int g = grid_for(n);
   DLG_CHECK(dlg_ensure_partials(b, 4*MAXB));
   hipLaunchKernelGGL(k_part_norm2_absmax, dim3(g), dim3(TPB), 0, b->stream, x, n, b->d_part);
-  hipLaunchKernelGGL(k_final, dim3(1), dim3(TPB), 0, b->stream, b->d_part, g, 1, 1, out2);
+  hipLaunchKernelGGL(k_final, dim3(1), dim3(TPB), 0, b->stream, b->d_part, g, 1, 1, out2, 1);
   DLG_LAUNCH_CHECK();
   return DLG_OK;
 }
@@ -204,14 +204,14 @@ int k_inner(dlg_backend* b, const double* x, const double* y, int n, double* out
   const int g = grid_for(n);
   DLG_CHECK(dlg_ensure_partials(b, 4*MAXB));
   hipLaunchKernelGGL(k_part_inner, dim3(g), dim3(TPB), 0, b->stream, x, y, n, b->d_part);
-  hipLaunchKernelGGL(k_final, dim3(1), dim3(TPB), 0, b->stream, b->d_part, g, 1, 0, out);
+  hipLaunchKernelGGL(k_final, dim3(1), dim3(TPB), 0, b->stream, b->d_part, g, 1, 0, out, 1);
   DLG_LAUNCH_CHECK();
   return DLG_OK;
 }
-int k_cauchy_finish(dlg_backend* b, const double* g, const double* scal_in, double* cauchy, int n,
+int k_cauchy_finish(dlg_backend* b, const double* g, double g2, const double* Jg2_dev, double* cauchy, int n,
                     double* out)
 {
-  hipLaunchKernelGGL(k_cauchy_scale, dim3(grid_for(n)), dim3(TPB), 0, b->stream, g, scal_in, cauchy,
+  hipLaunchKernelGGL(k_cauchy_scale, dim3(grid_for(n)), dim3(TPB), 0, b->stream, g, g2, Jg2_dev, cauchy,
                      n, out);
   DLG_LAUNCH_CHECK();
   return DLG_OK;
@@ -223,7 +223,7 @@ int k_scaled_step(dlg_backend* b, const double* v, double s, const double* p, do
   DLG_CHECK(dlg_ensure_partials(b, 4*MAXB));
   hipLaunchKernelGGL(k_part_scaled_step, dim3(g), dim3(TPB), 0, b->stream, v, s, p, step, p_new, n,
                      b->d_part);
-  hipLaunchKernelGGL(k_final, dim3(1), dim3(TPB), 0, b->stream, b->d_part, g, 0, 1, out_absmax);
+  hipLaunchKernelGGL(k_final, dim3(1), dim3(TPB), 0, b->stream, b->d_part, g, 0, 1, out_absmax, 1);
   DLG_LAUNCH_CHECK();
   return DLG_OK;
 }
@@ -236,12 +236,11 @@ int k_interpolate(dlg_backend* b, const double* a, const double* bb, double norm
   // out3 = {norm2_step, k, absmax}; l2/neg_c parked in out3[3..4] (d_scal has room)
   double* tmp = out3 + 3;
   hipLaunchKernelGGL(k_part_interp1, dim3(g), dim3(TPB), 0, b->stream, a, bb, n, b->d_part);
-  hipLaunchKernelGGL(k_final, dim3(1), dim3(TPB), 0, b->stream, b->d_part, g, 2, 0, tmp);
+  hipLaunchKernelGGL(k_final, dim3(1), dim3(TPB), 0, b->stream, b->d_part, g, 2, 0, tmp, 1);
   hipLaunchKernelGGL(k_part_interp2, dim3(g), dim3(TPB), 0, b->stream, a, bb, tmp, norm2a,
                      trustregion*trustregion, p, step, p_new, n, b->d_part, out3 + 1);
-  // sums -> out3[0]; max -> out3[2]: run k_final twice to place them
-  hipLaunchKernelGGL(k_final, dim3(1), dim3(TPB), 0, b->stream, b->d_part, g, 1, 0, out3);
-  hipLaunchKernelGGL(k_final, dim3(1), dim3(TPB), 0, b->stream, b->d_part + g, g, 0, 1, out3 + 2);
+  // sum -> out3[0]; max -> out3[2]
+  hipLaunchKernelGGL(k_final, dim3(1), dim3(TPB), 0, b->stream, b->d_part, g, 1, 1, out3, 2);
   DLG_LAUNCH_CHECK();
   return DLG_OK;
 }
@@ -250,7 +249,7 @@ int k_negate_norm2(dlg_backend* b, double* v, int n, double* out)
   const int g = grid_for(n);
   DLG_CHECK(dlg_ensure_partials(b, 4*MAXB));
   hipLaunchKernelGGL(k_part_negate_norm2, dim3(g), dim3(TPB), 0, b->stream, v, n, b->d_part);
-  hipLaunchKernelGGL(k_final, dim3(1), dim3(TPB), 0, b->stream, b->d_part, g, 1, 0, out);
+  hipLaunchKernelGGL(k_final, dim3(1), dim3(TPB), 0, b->stream, b->d_part, g, 1, 0, out, 1);
   DLG_LAUNCH_CHECK();
   return DLG_OK;
 }

@@ -521,9 +521,11 @@ __global__ void __launch_bounds__(TPB) k_set_aug_row(double* __restrict__ Lx, co
                                                      const int* __restrict__ sn_rowptr,
                                                      const int64_t* __restrict__ sn_lx,
                                                      const int* __restrict__ perm,
-                                                     const double* __restrict__ rhs, int n)
+                                                     const double* __restrict__ rhs, int n,
+                                                     int* __restrict__ info)
 {
   const int k = blockIdx.x*TPB + threadIdx.x;
+  if(k == 0) *info = 0x7fffffff;          // re-arm the pivot flag of the factorisation that follows
   if(k >= n) return;
   const int s = col_sn[k];
   const int nrows = sn_rowptr[s+1] - sn_rowptr[s];
@@ -743,11 +745,13 @@ int sparse_assemble(dlg_backend* b, int s, double lambda)
                        lambda);
   // the right-hand side rides along as the last row of every panel: y = L^-1 P Jt_x falls out
   Y->aug_rhs = nullptr;
+  Y->info_armed = false;
   if(S.have_Jtx)
   {
     hipLaunchKernelGGL(k_set_aug_row, dim3(dlg_cdiv(H.N, TPB)), dim3(TPB), 0, st, Y->Lx, Y->col_sn, Y->sn_c0,
-                       Y->sn_rowptr, Y->sn_lx, Y->perm, S.Jt_x, H.N);
+                       Y->sn_rowptr, Y->sn_lx, Y->perm, S.Jt_x, H.N, Y->d_info);
     Y->aug_rhs = S.Jt_x;
+    Y->info_armed = true;
   }
   DLG_LAUNCH_CHECK();
   return DLG_OK;

@@ -12,7 +12,6 @@ void sparse_destroy(dlg_backend* b)
   SparseSym* Y = b->sym;
   if(!Y) return;
   for(void* p : Y->allocs) if(p) (void)hipFree(p);
-  if(Y->h_info) (void)hipHostFree(Y->h_info);
   delete Y;
   b->sym = nullptr;
 }
@@ -68,8 +67,10 @@ int sparse_set_pattern(dlg_backend* b, const int* colptr, const int* rowidx)
   DLG_CHECK(dalloc(Y->top_scr, (size_t)H.top_size));
   DLG_CHECK(dalloc(Y->asm_part, (size_t)H.asm_part_size));
   DLG_CHECK(dalloc(Y->jtx_part, (size_t)H.jtx_nparts*8));
-  DLG_HIP(hipMalloc(&Y->d_info, sizeof(int))); Y->allocs.push_back(Y->d_info);
-  DLG_HIP(hipHostMalloc(&Y->h_info, sizeof(int)));
+  // the pivot flag of the factorisation shares the backend's scalar block (last slot): it comes back
+  // to the host with the scalars of the step, and the kernel that sets the augmented row re-arms it
+  Y->d_info = reinterpret_cast<int*>(b->d_scal + (dlg_backend::NSCAL - 1));
+  Y->h_info = reinterpret_cast<int*>(b->h_scal + (dlg_backend::NSCAL - 1));
 
   DLG_CHECK(sparse_factor_setup(b));
   DLG_CHECK(sparse_solve_setup(b));
@@ -97,12 +98,17 @@ int sparse_factorize(dlg_backend* b, int s, double lambda, int* ok)
   hipStream_t st = b->stream;
   DLG_CHECK(sparse_assemble(b, s, lambda));
   DlgProfScope pf(b, DLG_PROF_K5_FACTOR);
-  *Y->h_info = 0x7fffffff;
-  DLG_HIP(hipMemcpyAsync(Y->d_info, Y->h_info, sizeof(int), hipMemcpyHostToDevice, st));
+  if(!Y->info_armed)
+  {
+    // (no augmented row this time: arm the flag with a copy; the source must outlive the copy)
+    static const int k_armed = 0x7fffffff;
+    DLG_HIP(hipMemcpyAsync(Y->d_info, &k_armed, sizeof(int), hipMemcpyHostToDevice, st));
+  }
   DLG_CHECK(sparse_factor_levels(b));
-  DLG_HIP(hipMemcpyAsync(Y->h_info, Y->d_info, sizeof(int), hipMemcpyDeviceToHost, st));
   if(pf.e) { dlg_prof_end(b, pf.id, pf.e); pf.e = nullptr; }
-  if(b->defer_factor_sync) { *ok = 1; return DLG_OK; }        // the caller reads sparse_factor_ok() later
+  // the caller's dlg_fetch_scalars(b, NSCAL) brings the flag along; sparse_factor_ok() reads it then
+  if(b->defer_factor_sync) { *ok = 1; return DLG_OK; }
+  DLG_HIP(hipMemcpyAsync(Y->h_info, Y->d_info, sizeof(int), hipMemcpyDeviceToHost, st));
   DLG_HIP(hipStreamSynchronize(st));
   *ok = sparse_factor_ok(b);
   return DLG_OK;

@@ -90,7 +90,8 @@ struct SparseSym
   int *nv_chunk = nullptr; int n_nv_chunks = 0;   // row runs of <= NV_CHUNK non-zeros for |Jv|^2
   // numeric buffers
   double *Lx = nullptr, *scr = nullptr, *ywork = nullptr, *asm_part = nullptr, *jtx_part = nullptr;
-  int *d_info = nullptr, *h_info = nullptr;
+  int *d_info = nullptr, *h_info = nullptr;   // pivot flag: inside the backend's scalar block (device / pinned host)
+  bool info_armed = false;                    // the assembly re-armed the flag (k_set_aug_row)
   size_t nnz_loc = 0;
   // per-level launch parameters
   std::vector<int> fac_lds;     // bytes of LDS for the factor kernel of a level (0: panels stay in HBM)

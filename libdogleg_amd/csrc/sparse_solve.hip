@@ -115,7 +115,7 @@ __global__ void __launch_bounds__(BWD_NT) k_solve_bwd_level(const SolveItem* __r
                                                             const int* __restrict__ sn_bd_col, int top_lds)
 {
   extern __shared__ __attribute__((aligned(16))) double lds[];
-  constexpr int NW = BWD_NT/64, MV_PRE = 2;
+  constexpr int NW = BWD_NT/64;
   const int prof_lvl = top_lds >> 8; (void)prof_lvl; top_lds &= 1;
   BW_STAMP(0);
   const SolveItem it = items[blockIdx.x];
