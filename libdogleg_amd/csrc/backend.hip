@@ -26,6 +26,7 @@ int dlg_fetch_scalars(dlg_backend* b, int n)
   DLG_HIP(hipMemcpyAsync(b->h_scal, b->d_scal, sizeof(double)*(size_t)n, hipMemcpyDeviceToHost,
                          b->stream));
   DLG_HIP(hipStreamSynchronize(b->stream));
+  dlg_resolve_pending(b);
   if(b->profiling) dlg_prof_resolve(b);
   return DLG_OK;
 }
@@ -125,6 +126,8 @@ extern "C" int dlg_backend_create(dlg_backend_t** out, int solve_type, int Nstat
   TRY_HIP(hipMalloc(&b->d_scal, sizeof(double)*dlg_backend::NSCAL));
   TRY_HIP(hipMemsetAsync(b->d_scal, 0, sizeof(double)*dlg_backend::NSCAL, b->stream));
   TRY_HIP(hipHostMalloc(&b->h_scal, sizeof(double)*dlg_backend::NSCAL));
+  TRY_HIP(hipHostMalloc(&b->h_part, sizeof(double)*dlg_backend::HPART_CAP));
+  b->host_finals = getenv("DOGLEG_AMD_DEVICE_FINALS") == nullptr;
   TRY_HIP(hipHostMalloc(&b->h_vec, sizeof(double)*(size_t)Nstate));
   TRY_HIP(hipMalloc(&b->d_work, sizeof(double)*(size_t)Nstate));
   const size_t N = (size_t)Nstate, M = (size_t)Nmeas;
@@ -163,6 +166,7 @@ extern "C" void dlg_backend_destroy(dlg_backend_t* b)
   }
   if(b->d_scal) (void)hipFree(b->d_scal);
   if(b->h_scal) (void)hipHostFree(b->h_scal);
+  if(b->h_part) (void)hipHostFree(b->h_part);
   if(b->h_vec)  (void)hipHostFree(b->h_vec);
   if(b->d_part) (void)hipFree(b->d_part);
   if(b->d_work) (void)hipFree(b->d_work);
@@ -194,6 +198,7 @@ extern "C" int dlg_backend_set_shard(dlg_backend_t* b, int row0, int row1, dlg_a
   if(b->type == DLG_SPARSE && b->sym)
   { dlg_set_error("set the shard before dlg_sparse_set_pattern"); return DLG_ERR_STATE; }
   b->row0 = row0; b->row1 = row1; b->allreduce = fn; b->allreduce_cookie = cookie;
+  if(fn) b->host_finals = false;          // the hook sums device scalars: they must be final on the device
   return DLG_OK;
 }
 
@@ -540,6 +545,7 @@ static int step_finish(dlg_backend* b, int to, int nscal, double* p_new_host)
     DLG_HIP(hipMemcpyAsync(dst, T.p, sizeof(double)*(size_t)b->N, hipMemcpyDeviceToHost, b->stream));
   }
   DLG_HIP(hipStreamSynchronize(b->stream));
+  dlg_resolve_pending(b);
   if(p_new_host && !pinned) memcpy(p_new_host, b->h_vec, sizeof(double)*(size_t)b->N);
   return DLG_OK;
 }

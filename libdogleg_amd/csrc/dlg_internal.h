@@ -65,6 +65,16 @@ struct dlg_backend
   // reduction partials
   double* d_part = nullptr;
   size_t  part_cap = 0;       // in doubles
+  // Reductions whose result only the host reads skip their one-workgroup second stage: the
+  // partials are written straight into page-locked host memory and summed (in index order) by
+  // dlg_resolve_pending() after the synchronisation that the host needs anyway.  Off when an
+  // all-reduce hook wants the results on the device.
+  struct PendingFinal { size_t off; int nb, nsum, nmax, dst, stride; };
+  static constexpr size_t HPART_CAP = 16384;
+  double* h_part = nullptr;
+  size_t  h_part_used = 0;
+  std::vector<PendingFinal> pending;
+  bool    host_finals = true;
 
   // pinned staging for p_new D2H / uploads of small vectors
   double* h_vec = nullptr;
@@ -139,6 +149,10 @@ int k_interpolate(dlg_backend* b, const double* a, const double* bb, double norm
 int k_negate_norm2(dlg_backend* b, double* v, int n, double* out);
 // generic deterministic final reduction of `np` partials (sum) into out[0]
 int k_reduce_sum(dlg_backend* b, const double* partials, int np, double* out);
+// region of b->h_part for (nsum + nmax) x nb partials whose results go to h_scal[out - d_scal + k*stride],
+// or nullptr: the result is wanted on the device / no room -> the caller launches the second stage
+double* dlg_host_partials(dlg_backend* b, const double* out, int nb, int nsum, int nmax, int stride);
+void dlg_resolve_pending(dlg_backend* b);
 int dlg_ensure_partials(dlg_backend* b, size_t ndoubles);
 
 // ------------------------------------------------------- kernels_dense.hip --

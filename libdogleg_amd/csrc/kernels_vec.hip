@@ -133,7 +133,7 @@ __global__ void __launch_bounds__(TPB) k_part_interp1(const double* __restrict__
 // pass 2: k from the reduced scalars (dogleg.c:974-980), step = a + k (b-a)
 __global__ void __launch_bounds__(TPB) k_part_interp2(const double* __restrict__ a,
                                                       const double* __restrict__ b,
-                                                      const double* __restrict__ scal,
+                                                      const double* __restrict__ part1, int nb1,
                                                       double norm2a, double dsq,
                                                       const double* __restrict__ p,
                                                       double* __restrict__ step,
@@ -142,7 +142,17 @@ __global__ void __launch_bounds__(TPB) k_part_interp2(const double* __restrict__
                                                       double* __restrict__ kout)
 {
   __shared__ double sh[4];
-  const double l2 = scal[0], neg_c = scal[1];
+  __shared__ double s_l2, s_negc;
+  {
+    // second stage of pass 1, redone by every workgroup in the same (index) order: no launch for it
+    double v0 = 0, v1 = 0;
+    for(int i = threadIdx.x; i < nb1; i += TPB) { v0 += part1[i]; v1 += part1[nb1 + i]; }
+    v0 = block_sum(v0, sh); __syncthreads();
+    v1 = block_sum(v1, sh);
+    if(threadIdx.x == 0) { s_l2 = v0; s_negc = v1; }
+    __syncthreads();
+  }
+  const double l2 = s_l2, neg_c = s_negc;
   double disc = neg_c*neg_c - l2*(norm2a - dsq);
   if(disc < 0.0) disc = 0.0;
   const double k = (neg_c + sqrt(disc))/l2;
@@ -173,6 +183,32 @@ inline int grid_for(int n) { int g = dlg_cdiv(n, TPB*2); if(g < 1) g = 1; if(g >
 
 } // namespace
 
+double* dlg_host_partials(dlg_backend* b, const double* out, int nb, int nsum, int nmax, int stride)
+{
+  if(!b->host_finals || !b->h_part) return nullptr;
+  if(out < b->d_scal || out >= b->d_scal + dlg_backend::NSCAL) return nullptr;
+  const size_t need = (size_t)(nsum + nmax)*nb;
+  if(b->h_part_used + need > dlg_backend::HPART_CAP) return nullptr;
+  double* region = b->h_part + b->h_part_used;
+  b->pending.push_back({b->h_part_used, nb, nsum, nmax, (int)(out - b->d_scal), stride});
+  b->h_part_used += need;
+  return region;
+}
+void dlg_resolve_pending(dlg_backend* b)
+{
+  for(const dlg_backend::PendingFinal& f : b->pending)
+    for(int k = 0; k < f.nsum + f.nmax; k++)
+    {
+      const double* pk = b->h_part + f.off + (size_t)k*f.nb;
+      double v = 0;
+      if(k < f.nsum) for(int i = 0; i < f.nb; i++) v += pk[i];
+      else           for(int i = 0; i < f.nb; i++) v = fmax(v, pk[i]);
+      b->h_scal[f.dst + k*f.stride] = v;
+    }
+  b->pending.clear();
+  b->h_part_used = 0;
+}
+
 int dlg_ensure_partials(dlg_backend* b, size_t nd)
 {
   if(nd <= b->part_cap) return DLG_OK;
@@ -194,6 +230,8 @@ int k_norm2_absmax(dlg_backend* b, const double* x, int n, double* out2)
 {
   const int g = grid_for(n);
   DLG_CHECK(dlg_ensure_partials(b, 4*MAXB));
+  if(double* hp = dlg_host_partials(b, out2, g, 1, 1, 1))
+  { hipLaunchKernelGGL(k_part_norm2_absmax, dim3(g), dim3(TPB), 0, b->stream, x, n, hp); DLG_LAUNCH_CHECK(); return DLG_OK; }
   hipLaunchKernelGGL(k_part_norm2_absmax, dim3(g), dim3(TPB), 0, b->stream, x, n, b->d_part);
   hipLaunchKernelGGL(k_final, dim3(1), dim3(TPB), 0, b->stream, b->d_part, g, 1, 1, out2, 1);
   DLG_LAUNCH_CHECK();
@@ -203,6 +241,8 @@ int k_inner(dlg_backend* b, const double* x, const double* y, int n, double* out
 {
   const int g = grid_for(n);
   DLG_CHECK(dlg_ensure_partials(b, 4*MAXB));
+  if(double* hp = dlg_host_partials(b, out, g, 1, 0, 1))
+  { hipLaunchKernelGGL(k_part_inner, dim3(g), dim3(TPB), 0, b->stream, x, y, n, hp); DLG_LAUNCH_CHECK(); return DLG_OK; }
   hipLaunchKernelGGL(k_part_inner, dim3(g), dim3(TPB), 0, b->stream, x, y, n, b->d_part);
   hipLaunchKernelGGL(k_final, dim3(1), dim3(TPB), 0, b->stream, b->d_part, g, 1, 0, out, 1);
   DLG_LAUNCH_CHECK();
@@ -221,6 +261,12 @@ int k_scaled_step(dlg_backend* b, const double* v, double s, const double* p, do
 {
   const int g = grid_for(n);
   DLG_CHECK(dlg_ensure_partials(b, 4*MAXB));
+  if(double* hp = dlg_host_partials(b, out_absmax, g, 0, 1, 1))
+  {
+    hipLaunchKernelGGL(k_part_scaled_step, dim3(g), dim3(TPB), 0, b->stream, v, s, p, step, p_new, n, hp);
+    DLG_LAUNCH_CHECK();
+    return DLG_OK;
+  }
   hipLaunchKernelGGL(k_part_scaled_step, dim3(g), dim3(TPB), 0, b->stream, v, s, p, step, p_new, n,
                      b->d_part);
   hipLaunchKernelGGL(k_final, dim3(1), dim3(TPB), 0, b->stream, b->d_part, g, 0, 1, out_absmax, 1);
@@ -233,14 +279,14 @@ int k_interpolate(dlg_backend* b, const double* a, const double* bb, double norm
 {
   const int g = grid_for(n);
   DLG_CHECK(dlg_ensure_partials(b, 4*MAXB));
-  // out3 = {norm2_step, k, absmax}; l2/neg_c parked in out3[3..4] (d_scal has room)
-  double* tmp = out3 + 3;
+  // out3 = {norm2_step, k, absmax}.  Pass 1 leaves its partials in d_part[0 .. 2g); pass 2 sums them
+  // itself and writes its own partials behind them (or into host memory: sum -> out3[0], max -> out3[2])
   hipLaunchKernelGGL(k_part_interp1, dim3(g), dim3(TPB), 0, b->stream, a, bb, n, b->d_part);
-  hipLaunchKernelGGL(k_final, dim3(1), dim3(TPB), 0, b->stream, b->d_part, g, 2, 0, tmp, 1);
-  hipLaunchKernelGGL(k_part_interp2, dim3(g), dim3(TPB), 0, b->stream, a, bb, tmp, norm2a,
-                     trustregion*trustregion, p, step, p_new, n, b->d_part, out3 + 1);
-  // sum -> out3[0]; max -> out3[2]
-  hipLaunchKernelGGL(k_final, dim3(1), dim3(TPB), 0, b->stream, b->d_part, g, 1, 1, out3, 2);
+  double* part2 = b->d_part + 2*g;
+  double* hp = dlg_host_partials(b, out3, g, 1, 1, 2);
+  hipLaunchKernelGGL(k_part_interp2, dim3(g), dim3(TPB), 0, b->stream, a, bb, b->d_part, g, norm2a,
+                     trustregion*trustregion, p, step, p_new, n, hp ? hp : part2, out3 + 1);
+  if(!hp) hipLaunchKernelGGL(k_final, dim3(1), dim3(TPB), 0, b->stream, part2, g, 1, 1, out3, 2);
   DLG_LAUNCH_CHECK();
   return DLG_OK;
 }
@@ -248,6 +294,8 @@ int k_negate_norm2(dlg_backend* b, double* v, int n, double* out)
 {
   const int g = grid_for(n);
   DLG_CHECK(dlg_ensure_partials(b, 4*MAXB));
+  if(double* hp = dlg_host_partials(b, out, g, 1, 0, 1))
+  { hipLaunchKernelGGL(k_part_negate_norm2, dim3(g), dim3(TPB), 0, b->stream, v, n, hp); DLG_LAUNCH_CHECK(); return DLG_OK; }
   hipLaunchKernelGGL(k_part_negate_norm2, dim3(g), dim3(TPB), 0, b->stream, v, n, b->d_part);
   hipLaunchKernelGGL(k_final, dim3(1), dim3(TPB), 0, b->stream, b->d_part, g, 1, 0, out, 1);
   DLG_LAUNCH_CHECK();
