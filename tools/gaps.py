@@ -4,7 +4,7 @@ the K1 kernel k_jtx / dense equivalent) the wall span, the kernel-busy time and 
 import csv, glob, sys
 rows = list(csv.DictReader(open(glob.glob(sys.argv[1] + '/**/*kernel_trace.csv', recursive=True)[0])))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
-starts = [i for i, r in enumerate(rows) if 'k_jtx(' in r['Kernel_Name']]
+starts = [i for i, r in enumerate(rows) if ('k_jtx(' in r['Kernel_Name'] or 'k_jtx_rows(' in r['Kernel_Name'])]
 def short(n):
     n = n.replace('(anonymous namespace)::', '').replace('void ', '')
     return n.split('(')[0][:30]
