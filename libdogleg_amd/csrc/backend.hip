@@ -123,6 +123,9 @@ extern "C" int dlg_backend_create(dlg_backend_t** out, int solve_type, int Nstat
 
   TRY_HIP(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
   b->own_stream = true;
+  TRY_HIP(hipStreamCreateWithFlags(&b->copy_stream, hipStreamNonBlocking));
+  TRY_HIP(hipEventCreateWithFlags(&b->ev_step, hipEventDisableTiming));
+  TRY_HIP(hipEventCreateWithFlags(&b->ev_copy, hipEventDisableTiming));
   TRY_HIP(hipMalloc(&b->d_scal, sizeof(double)*dlg_backend::NSCAL));
   TRY_HIP(hipMemsetAsync(b->d_scal, 0, sizeof(double)*dlg_backend::NSCAL, b->stream));
   TRY_HIP(hipHostMalloc(&b->h_scal, sizeof(double)*dlg_backend::NSCAL));
@@ -173,6 +176,9 @@ extern "C" void dlg_backend_destroy(dlg_backend_t* b)
   if(b->d_red)  (void)hipFree(b->d_red);
   for(auto& pp : b->prof_pending) { (void)hipEventDestroy(pp.a); (void)hipEventDestroy(pp.b); }
   for(hipEvent_t e : b->prof_pool) (void)hipEventDestroy(e);
+  if(b->copy_stream) { (void)hipStreamSynchronize(b->copy_stream); (void)hipStreamDestroy(b->copy_stream); b->copy_stream = nullptr; }
+  if(b->ev_step) { (void)hipEventDestroy(b->ev_step); b->ev_step = nullptr; }
+  if(b->ev_copy) { (void)hipEventDestroy(b->ev_copy); b->ev_copy = nullptr; }
   if(b->own_stream && b->stream) (void)hipStreamDestroy(b->stream);
   delete b;
 }
@@ -595,8 +601,26 @@ extern "C" int dlg_step(dlg_backend_t* b, int from, int to, int kind, double tru
   double n2 = 0, kk = NAN, amax = 0;
   int nscal = 0;
   DLG_CHECK(make_step_enqueue(b, from, to, kind, trustregion, &nscal));
+  // p_new is final here: it travels to the host on the side stream while K8 runs (a page-locked
+  // destination; a pageable one goes through step_finish's staging copy afterwards)
+  bool side_copy = false;
+  if(p_new_host && b->copy_stream)
+  {
+    hipPointerAttribute_t attr;
+    const bool pinned = hipPointerGetAttributes(&attr, p_new_host) == hipSuccess && attr.type == hipMemoryTypeHost;
+    if(!pinned) (void)hipGetLastError();
+    if(pinned)
+    {
+      DLG_HIP(hipEventRecord(b->ev_step, b->stream));
+      DLG_HIP(hipStreamWaitEvent(b->copy_stream, b->ev_step, 0));
+      DLG_HIP(hipMemcpyAsync(p_new_host, b->slot[to].p, sizeof(double)*(size_t)b->N, hipMemcpyDeviceToHost, b->copy_stream));
+      DLG_HIP(hipEventRecord(b->ev_copy, b->copy_stream));
+      side_copy = true;
+    }
+  }
   DLG_CHECK(expected_improvement_enqueue(b, from, to, b->d_scal + 4));
-  DLG_CHECK(step_finish(b, to, 6, p_new_host));
+  DLG_CHECK(step_finish(b, to, 6, side_copy ? nullptr : p_new_host));
+  if(side_copy) DLG_HIP(hipEventSynchronize(b->ev_copy));
   make_step_read(b, from, kind, &n2, &kk, &amax);
   if(norm2_step) *norm2_step = n2;
   if(k_cauchy_to_gn) *k_cauchy_to_gn = kk;

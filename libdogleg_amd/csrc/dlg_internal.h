@@ -55,6 +55,9 @@ struct dlg_backend
   int type = 0, N = 0, M = 0, nnz = 0, flags = 0, device = 0;
   hipStream_t stream = nullptr;
   bool own_stream = false;
+  // side stream + events: p_new travels to the host while the expected improvement is computed (dlg_step)
+  hipStream_t copy_stream = nullptr;
+  hipEvent_t  ev_step = nullptr, ev_copy = nullptr;
   DlgSlot slot[2];
 
   // scalar return path: kernels write d_scal, one D2H into pinned h_scal
