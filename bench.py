@@ -135,16 +135,25 @@ def main():
     be.set_p(0, p0)
     setup_s = time.time() - t_setup
 
+    state = {"tr": None}
+
     def one_step():
         be.bind_device(0, d_x.ptr, d_J.ptr)          # a fresh operating point: nothing cached
         norm2x, gmax = be.eval(0)                    # K1
-        # K3 + K4 + K5 + K6 as the driver issues them once steps leave the trust region's edge behind
-        # (driver.hip take_step): Cauchy step, then compute_updateGN (factorise from lambda = 0 with the
-        # reference's lambda loop, dogleg.c:656-677, and solve), one synchronisation per attempt
-        lam, n2c, n2g = be.cauchy_gauss_newton(0, 0.0)
-        tr = 0.5 * (n2c ** 0.5 + n2g ** 0.5)
-        # K7 + K8 (+ p_new D2H): the step and its expected improvement, one synchronisation
-        n2s, k, amax, ei, pnew = be.step(0, 1, capi.KIND_INTERP, tr)
+        # K3..K8 as the driver issues them for a fresh point once steps leave the trust region's edge
+        # behind (driver.hip take_step -> dlg_take_step): Cauchy step, compute_updateGN (factorise from
+        # lambda = 0 with the reference's lambda loop, dogleg.c:656-677, and solve), the choice of the kind
+        # of step, the step, its expected improvement, p_new D2H -- one synchronisation per attempt.
+        # The trust region is known before the step, as in the driver (state["tr"], from the first step).
+        if use_dist or state["tr"] is None:
+            lam, n2c, n2g = be.cauchy_gauss_newton(0, 0.0)
+            tr = 0.5 * (n2c ** 0.5 + n2g ** 0.5)
+            n2s, k, amax, ei, pnew = be.step(0, 1, capi.KIND_INTERP, tr)
+            state["tr"] = tr
+        else:
+            lam, r, pnew = be.take_step(0, 1, state["tr"], 0.0)
+            assert r["kind"] == capi.KIND_INTERP
+            n2c, n2g, n2s, k, amax, ei = r["n2c"], r["n2g"], r["n2s"], r["k"], r["amax"], r["ei"]
         return norm2x, n2c, n2g, k, n2s, ei, gmax, amax, lam
 
     def barrier():

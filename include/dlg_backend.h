@@ -149,6 +149,16 @@ int  dlg_step(dlg_backend_t* b, int from, int to, int kind, double trustregion,
               double* norm2_step, double* k_cauchy_to_gn, double* step_absmax,
               double* expected_improvement, double* p_new_host);
 
+/* ---- K3 .. K8 behind ONE synchronisation: takeStepFrom (dogleg.c:1172-1297) for a point with
+ * nothing cached -- Cauchy step, factorise + solve (lambda loop as in dlg_gauss_newton), the choice
+ * of the kind of step (made on the device with the reference's comparisons, dogleg.c:1192-1256),
+ * the step, its expected improvement and p_new.
+ * out7 = {|cauchy|^2, |gn|^2, kind, |step|^2 (reference reporting), k_cauchy_to_gn, max|step|,
+ * expected improvement}.  Computes the Gauss-Newton step even when the Cauchy step is taken.
+ * Not available with row sharding (the all-reduce hooks need the host in between). --------- */
+int  dlg_take_step(dlg_backend_t* b, int from, int to, double trustregion, double* lambda_io,
+                   double* out7, double* p_new_host);
+
 /* ---- downloads (returnContext, tests) -------------------------------------- */
 int  dlg_point_download(dlg_backend_t* b, int slot, int which, double* host, size_t n);
 /* dense factor in the reference's layout (packed as dpptrf('L') leaves it, or

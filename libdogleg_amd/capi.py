@@ -28,7 +28,7 @@ BACKEND_SYMBOLS = [
     "dlg_sparse_set_pattern", "dlg_sparse_stats", "dlg_point_set_p", "dlg_point_upload",
     "dlg_point_upload_products", "dlg_point_bind_device", "dlg_point_eval", "dlg_cauchy",
     "dlg_factorize", "dlg_solve_gn", "dlg_gauss_newton", "dlg_cauchy_gauss_newton", "dlg_make_step",
-    "dlg_expected_improvement", "dlg_step",
+    "dlg_expected_improvement", "dlg_step", "dlg_take_step",
     "dlg_point_download", "dlg_factor_download_dense", "dlg_point_device_ptr",
     "dlg_kernel_syrk_lower", "dlg_kernel_potrf_lower", "dlg_probe_mfma_f64",
     "dlg_probe_hbm_copy", "dlg_set_trace", "dlg_mem_alloc", "dlg_mem_free", "dlg_host_alloc",
@@ -86,6 +86,7 @@ def lib():
     L.dlg_cauchy_gauss_newton.argtypes = [V, C.c_int, D, D, D]
     L.dlg_make_step.argtypes = [V, C.c_int, C.c_int, C.c_int, C.c_double, D, D, D, D]
     L.dlg_step.argtypes = [V, C.c_int, C.c_int, C.c_int, C.c_double, D, D, D, D, D]
+    L.dlg_take_step.argtypes = [V, C.c_int, C.c_int, C.c_double, D, D, D]
     L.dlg_expected_improvement.argtypes = [V, C.c_int, C.c_int, D]
     L.dlg_point_download.argtypes = [V, C.c_int, C.c_int, D, C.c_size_t]
     L.dlg_factor_download_dense.argtypes = [V, D, C.c_size_t]
@@ -352,6 +353,20 @@ class Backend:
         _ck(self.L.dlg_step(self.h, frm, to, kind, trustregion, C.byref(n2), C.byref(k), C.byref(am),
                             C.byref(ei), dptr(self._pnew) if want_p else None), "step")
         return n2.value, k.value, am.value, ei.value, (self._pnew if want_p else None)
+
+    def take_step(self, frm, to, trustregion, lam=0.0, want_p=True):
+        """Cauchy + Gauss-Newton + the choice of step + step + expected improvement behind one
+        synchronisation: (lambda, dict(n2c, n2g, kind, n2s, k, amax, ei), p_new)"""
+        l = C.c_double(lam)
+        out = (C.c_double * 7)()
+        if want_p:
+            self._pnew_buffer()
+        _ck(self.L.dlg_take_step(self.h, frm, to, trustregion, C.byref(l), out,
+                                 dptr(self._pnew) if want_p else None), "take_step")
+        keys = ("n2c", "n2g", "kind", "n2s", "k", "amax", "ei")
+        r = dict(zip(keys, [float(v) for v in out]))
+        r["kind"] = int(r["kind"])
+        return l.value, r, (self._pnew if want_p else None)
 
     def make_step(self, frm, to, kind, trustregion, want_p=True):
         """p_new comes back in a page-locked buffer owned by this object (as the driver's operating

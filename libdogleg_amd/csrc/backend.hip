@@ -172,6 +172,7 @@ extern "C" void dlg_backend_destroy(dlg_backend_t* b)
   if(b->h_part) (void)hipHostFree(b->h_part);
   if(b->h_vec)  (void)hipHostFree(b->h_vec);
   if(b->d_part) (void)hipFree(b->d_part);
+  if(b->d_gnpart) (void)hipFree(b->d_gnpart);
   if(b->d_work) (void)hipFree(b->d_work);
   if(b->d_red)  (void)hipFree(b->d_red);
   for(auto& pp : b->prof_pending) { (void)hipEventDestroy(pp.a); (void)hipEventDestroy(pp.b); }
@@ -626,6 +627,96 @@ extern "C" int dlg_step(dlg_backend_t* b, int from, int to, int kind, double tru
   if(k_cauchy_to_gn) *k_cauchy_to_gn = kk;
   if(step_absmax) *step_absmax = amax;
   if(expected_improvement) *expected_improvement = -2.0*b->h_scal[4] - b->h_scal[5];
+  return DLG_OK;
+}
+
+// ------------------------------------------------ K3 .. K8, one round trip ----
+// takeStepFrom (dogleg.c:1172-1297) for a point with nothing cached, behind ONE host synchronisation:
+// Cauchy step, factorise + solve (lambda loop as in dlg_gauss_newton), the choice between the three
+// kinds of step made on the device (k_take_step), the step, its expected improvement, p_new.
+// out = {|cauchy|^2, |gn|^2, kind, |step|^2 as the reference reports it, k_cauchy_to_gn, max|step|,
+// expected improvement}.  The Gauss-Newton step is computed even when the Cauchy step is the one
+// taken: for callers that expect to need it (the driver, once a step has needed it).
+extern "C" int dlg_take_step(dlg_backend_t* b, int from, int to, double trustregion, double* lambda_io,
+                             double* out7, double* p_new_host)
+{
+  DLG_CHECK(check_slot(b, from)); DLG_CHECK(check_slot(b, to));
+  if(from == to) { dlg_set_error("dlg_take_step: from == to"); return DLG_ERR_ARG; }
+  if(!lambda_io || !out7) { dlg_set_error("dlg_take_step: NULL argument"); return DLG_ERR_ARG; }
+  DlgSlot& F = b->slot[from];
+  DlgSlot& T = b->slot[to];
+  if(!F.have_inputs) { dlg_set_error("dlg_take_step: slot %d has no J/JtJ", from); return DLG_ERR_STATE; }
+  if(!F.have_Jtx) { dlg_set_error("dlg_take_step needs Jt_x"); return DLG_ERR_STATE; }
+  if(b->allreduce) { dlg_set_error("dlg_take_step is not available with row sharding"); return DLG_ERR_STATE; }
+  if(!b->d_gnpart) DLG_HIP(hipMalloc(&b->d_gnpart, sizeof(double)*1024));
+  double lam = *lambda_io;
+  bool side_copy = false;
+  for(;;)
+  {
+    int good = 0, rc;
+    double* n2c_dev = b->d_scal + 6;
+    if(!F.have_cauchy) DLG_CHECK(cauchy_enqueue(b, from, b->d_scal + 4));
+    else DLG_HIP(hipMemcpyAsync(n2c_dev, &F.norm2_cauchy, sizeof(double), hipMemcpyHostToDevice, b->stream));
+    if(b->factor_slot != from)
+    {
+      b->defer_factor_sync = true;
+      switch(b->type)
+      {
+      case DLG_SPARSE: rc = sparse_factorize(b, from, lam, &good); break;
+      case DLG_DENSE:  rc = dense_factorize(b, from, lam, &good); break;
+      default:         rc = products_factorize(b, from, lam, &good); break;
+      }
+      b->defer_factor_sync = false;
+      DLG_CHECK(rc);
+    }
+    {
+      DlgProfScope ps(b, DLG_PROF_K6_SOLVE);
+      if(b->type == DLG_SPARSE) DLG_CHECK(sparse_solve(b, F.Jt_x, F.gn));
+      else                      DLG_CHECK(dense_solve(b, F.Jt_x, F.gn));
+    }
+    int nbg = 0;
+    DLG_CHECK(k_negate_norm2_partials(b, F.gn, b->N, b->d_gnpart, &nbg));          // dogleg.c:862-865
+    {
+      DlgProfScope ps(b, DLG_PROF_K7_STEP);
+      DLG_CHECK(k_take_step(b, F.cauchy, F.gn, b->d_gnpart, nbg, n2c_dev, trustregion, F.p, T.step, T.p, b->N,
+                            b->d_scal, b->d_scal + 8));
+    }
+    side_copy = false;
+    if(p_new_host && b->copy_stream)
+    {
+      hipPointerAttribute_t attr;
+      const bool pinned = hipPointerGetAttributes(&attr, p_new_host) == hipSuccess && attr.type == hipMemoryTypeHost;
+      if(!pinned) (void)hipGetLastError();
+      if(pinned)
+      {
+        DLG_HIP(hipEventRecord(b->ev_step, b->stream));
+        DLG_HIP(hipStreamWaitEvent(b->copy_stream, b->ev_step, 0));
+        DLG_HIP(hipMemcpyAsync(p_new_host, T.p, sizeof(double)*(size_t)b->N, hipMemcpyDeviceToHost, b->copy_stream));
+        DLG_HIP(hipEventRecord(b->ev_copy, b->copy_stream));
+        side_copy = true;
+      }
+    }
+    DLG_CHECK(expected_improvement_enqueue(b, from, to, b->d_scal + 11));
+    DLG_CHECK(step_finish(b, to, dlg_backend::NSCAL, side_copy ? nullptr : p_new_host));   // the one synchronisation
+    if(side_copy) DLG_HIP(hipEventSynchronize(b->ev_copy));
+    if(b->profiling) dlg_prof_resolve(b);
+    if(!F.have_cauchy) { F.norm2_cauchy = b->h_scal[6]; F.have_cauchy = true; }
+    good = (b->factor_slot == from) ? 1 : (b->type == DLG_SPARSE ? sparse_factor_ok(b) : dense_factor_ok(b));
+    if(good) break;
+    b->factor_slot = -1;
+    lam = (lam == 0.0) ? 1e-10 : lam*10.0;                    // dogleg.c:138, 671-672, 812-813
+    if(!(lam < 1e300)) { dlg_set_error("lambda overflowed while regularising a singular JtJ"); return DLG_ERR_STATE; }
+  }
+  b->factor_slot = from;
+  F.norm2_gn = b->h_scal[10];
+  F.have_gn = true;
+  *lambda_io = lam;
+  const int kind = (int)b->h_scal[8];
+  out7[0] = F.norm2_cauchy; out7[1] = F.norm2_gn; out7[2] = (double)kind;
+  out7[3] = (kind == DLG_KIND_CAUCHY_TO_EDGE) ? F.norm2_cauchy : (kind == DLG_KIND_GAUSSNEWTON ? F.norm2_gn : b->h_scal[0]);
+  out7[4] = b->h_scal[9];
+  out7[5] = b->h_scal[2];
+  out7[6] = -2.0*b->h_scal[11] - b->h_scal[12];               // dogleg.c:1107-1109
   return DLG_OK;
 }
 

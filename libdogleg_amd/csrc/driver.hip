@@ -61,6 +61,7 @@ struct Driver
   bool check_pattern;
   int *pat_p, *pat_i;
   bool expect_gn;                              // the last step needed the Gauss-Newton step: issue it with the Cauchy step
+  bool sharded;                                // an all-reduce hook is installed: the host sits between the ops
 };
 
 inline Driver* D(dogleg_solverContext_t* ctx) { return reinterpret_cast<Driver*>(ctx); }
@@ -341,31 +342,6 @@ bool compute_gn(dogleg_operatingPoint_t* pt, Driver* d)
   return true;
 }
 
-// Cauchy + Gauss-Newton of a fresh point behind one synchronisation (see take_step)
-bool compute_cauchy_gn(dogleg_operatingPoint_t* pt, Driver* d)
-{
-  dogleg_solverContext_t* ctx = &d->pub;
-  if(!pt->have_Jtx) { MSG("Cauchy step needs Jt_x, which is missing"); return false; }
-  if(ctx->solve_type == DOGLEG_DENSE_PRODUCTS ? !pt->have_JtJ : !pt->have_J)
-  { MSG("factorization needs J (or JtJ), which is missing"); return false; }
-  if(ctx->solve_type == DOGLEG_SPARSE && ctx->factorization == nullptr)
-  {
-    d->factor_handle.n = (size_t)ctx->Nstate; d->factor_handle.minor = 0;
-    d->factor_handle.backend = d->be;
-    ctx->factorization = &d->factor_handle;                    // dogleg.c:650-654
-  }
-  double n2c = 0, n2g = 0;
-  const double lambda_before = ctx->lambda;
-  if(!be_ok(dlg_cauchy_gauss_newton(d->be, slot_of(d, pt), &ctx->lambda, &n2c, &n2g), "Cauchy + GN step")) return false;
-  if(ctx->lambda != lambda_before) VERBOSE(d, "singular JtJ: adding %g I from now on", ctx->lambda);
-  if(ctx->solve_type == DOGLEG_SPARSE) d->factor_handle.minor = d->factor_handle.n;
-  pt->norm2_updateCauchy = n2c; pt->have_updateCauchy = true;
-  pt->norm2_updateGN = n2g; pt->have_updateGN = true; pt->have_factorization = true;
-  VERBOSE(d, "cauchy step length %.6g", sqrt(n2c));
-  d->cur.norm2_cauchy = n2c;
-  return true;
-}
-
 // dogleg.c:1172-1297.  The step vector stays on the device (slot `to`); p_new
 // comes back because the user callback needs it.
 bool take_step(double* expectedImprovement, dogleg_operatingPoint_t* to,
@@ -378,13 +354,43 @@ bool take_step(double* expectedImprovement, dogleg_operatingPoint_t* to,
   const int sf = slot_of(d, from), st = slot_of(d, to);
 
   // The reference computes the Cauchy step, and the Gauss-Newton step only if the Cauchy step ends
-  // inside the trust region (dogleg.c:1186-1211).  Once a step has needed both, the next point's
-  // pair is issued behind one host synchronisation; the values are the same, and a Gauss-Newton
-  // step the reference would not have computed is simply not used (nor reported).
-  if(d->expect_gn && !from->have_updateCauchy && !from->have_updateGN && !from->have_factorization)
-  { if(!compute_cauchy_gn(from, d)) return false; }
-  else if(!compute_cauchy(from, d)) return false;
+  // inside the trust region (dogleg.c:1186-1211).  Once a step has needed both, the whole of
+  // takeStepFrom for a fresh point -- both steps, the choice between them (same comparisons, made
+  // on the device), the step, its expected improvement, p_new -- is ONE backend op behind one host
+  // synchronisation; the values are the same, and a Gauss-Newton step the reference would not have
+  // computed is simply not used (nor reported).
   int kind;
+  double n2 = 0, k = NAN, amax = 0;
+  const bool fresh = !from->have_updateCauchy && !from->have_updateGN && !from->have_factorization;
+  if(d->expect_gn && fresh && !d->sharded)
+  {
+    if(!from->have_Jtx) { MSG("Cauchy step needs Jt_x, which is missing"); return false; }
+    if(ctx->solve_type == DOGLEG_DENSE_PRODUCTS ? !from->have_JtJ : !from->have_J)
+    { MSG("factorization needs J (or JtJ), which is missing"); return false; }
+    if(ctx->solve_type == DOGLEG_SPARSE && ctx->factorization == nullptr)
+    {
+      d->factor_handle.n = (size_t)ctx->Nstate; d->factor_handle.minor = 0;
+      d->factor_handle.backend = d->be;
+      ctx->factorization = &d->factor_handle;                    // dogleg.c:650-654
+    }
+    double o[7];
+    const double lambda_before = ctx->lambda;
+    if(!be_ok(dlg_take_step(d->be, sf, st, trustregion, &ctx->lambda, o, to->p), "step")) return false;
+    if(ctx->lambda != lambda_before) VERBOSE(d, "singular JtJ: adding %g I from now on", ctx->lambda);
+    if(ctx->solve_type == DOGLEG_SPARSE) d->factor_handle.minor = d->factor_handle.n;
+    from->norm2_updateCauchy = o[0]; from->have_updateCauchy = true;
+    from->norm2_updateGN = o[1]; from->have_updateGN = true; from->have_factorization = true;
+    d->cur.norm2_cauchy = o[0];
+    VERBOSE(d, "cauchy step length %.6g", sqrt(o[0]));
+    kind = (int)o[2]; n2 = o[3]; k = o[4]; amax = o[5]; *expectedImprovement = o[6];
+    if(kind != DLG_KIND_CAUCHY_TO_EDGE) { d->cur.norm2_gn = o[1]; VERBOSE(d, "gn step length %.6g", sqrt(o[1])); }
+    d->cur.step_type = (kind == DLG_KIND_CAUCHY_TO_EDGE) ? DLG_STEP_CAUCHY : (kind == DLG_KIND_GAUSSNEWTON ? DLG_STEP_GAUSSNEWTON : DLG_STEP_INTERPOLATED);
+    from->didStepToEdgeOfTrustRegion = (kind != DLG_KIND_GAUSSNEWTON);
+    d->expect_gn = (kind != DLG_KIND_CAUCHY_TO_EDGE);
+  }
+  else
+  {
+  if(!compute_cauchy(from, d)) return false;
   if(from->norm2_updateCauchy >= trustregion*trustregion)
   {
     kind = DLG_KIND_CAUCHY_TO_EDGE;
@@ -409,9 +415,9 @@ bool take_step(double* expectedImprovement, dogleg_operatingPoint_t* to,
       from->didStepToEdgeOfTrustRegion = true;
     }
   }
-  double n2 = 0, k = NAN, amax = 0;
   // step, its expected improvement and p_new: one backend op, one host synchronisation
   if(!be_ok(dlg_step(d->be, sf, st, kind, trustregion, &n2, &k, &amax, expectedImprovement, to->p), "step")) return false;
+  }
   to->norm2_step_to_here = n2;
   d->cur.norm2_step = n2;
   d->cur.k_cauchy_to_gn = k;

@@ -168,6 +168,64 @@ __global__ void __launch_bounds__(TPB) k_part_interp2(const double* __restrict__
   if(blockIdx.x == 0 && threadIdx.x == 0) kout[0] = k;
 }
 
+// takeStepFrom's choice of step (dogleg.c:1192-1256) made on the device, so that the Cauchy step,
+// the Gauss-Newton step and the step itself can be issued behind ONE host synchronisation:
+//   |cauchy|^2 >= D^2 -> cauchy scaled to the edge; else |gn|^2 <= D^2 -> gn; else interpolate.
+// |gn|^2 = the partials of k_part_negate_norm2 summed in index order (as the host would);
+// l2 / neg_c = the partials of k_part_interp1 (as k_part_interp2 sums them).
+// out3 = {kind, k, |gn|^2}; the step's own partials (|step|^2, max|step|) go to `part`.
+__global__ void __launch_bounds__(TPB) k_part_take_step(const double* __restrict__ a,
+                                                        const double* __restrict__ b,
+                                                        const double* __restrict__ part1, int nb1,
+                                                        const double* __restrict__ gnpart, int nbg,
+                                                        const double* __restrict__ n2c_dev, double trustregion,
+                                                        const double* __restrict__ p,
+                                                        double* __restrict__ step,
+                                                        double* __restrict__ pnew, int n,
+                                                        double* __restrict__ part,
+                                                        double* __restrict__ out3)
+{
+  __shared__ double sh[4];
+  __shared__ double s_l2, s_negc, s_n2g;
+  __shared__ double s_gn[MAXB];
+  {
+    double v0 = 0, v1 = 0;
+    for(int i = threadIdx.x; i < nb1; i += TPB) { v0 += part1[i]; v1 += part1[nb1 + i]; }
+    for(int i = threadIdx.x; i < nbg; i += TPB) s_gn[i] = gnpart[i];      // one round of loads, summed in order below
+    v0 = block_sum(v0, sh); __syncthreads();
+    v1 = block_sum(v1, sh);
+    if(threadIdx.x == 0)
+    {
+      s_l2 = v0; s_negc = v1;
+      double g2 = 0;
+      for(int i = 0; i < nbg; i++) g2 += s_gn[i];
+      s_n2g = g2;
+    }
+    __syncthreads();
+  }
+  const double n2c = n2c_dev[0], n2g = s_n2g, dsq = trustregion*trustregion;
+  const int kind = (n2c >= dsq) ? 0 : ((n2g <= dsq) ? 1 : 2);
+  double k = 0.0, sc = 0.0;
+  if(kind == 0) sc = trustregion / sqrt(n2c);                  // dogleg.c:1204-1207
+  else if(kind == 2)
+  {
+    const double l2 = s_l2, neg_c = s_negc;                     // dogleg.c:974-980
+    double disc = neg_c*neg_c - l2*(n2c - dsq);
+    if(disc < 0.0) disc = 0.0;
+    k = (neg_c + sqrt(disc))/l2;
+  }
+  double s2 = 0, m = 0;
+  for(int i = blockIdx.x*TPB + threadIdx.x; i < n; i += gridDim.x*TPB)
+  {
+    const double st = (kind == 0) ? sc*a[i] : ((kind == 1) ? b[i] : a[i] + k*(b[i] - a[i]));
+    step[i] = st; pnew[i] = p[i] + st; s2 += st*st; m = fmax(m, fabs(st));
+  }
+  const double S = block_sum(s2, sh);
+  const double Mx = block_max(m, sh);
+  if(threadIdx.x == 0) { part[blockIdx.x] = S; part[gridDim.x + blockIdx.x] = Mx; }
+  if(blockIdx.x == 0 && threadIdx.x == 0) { out3[0] = (double)kind; out3[1] = (kind == 2) ? k : NAN; out3[2] = n2g; }
+}
+
 __global__ void __launch_bounds__(TPB) k_part_negate_norm2(double* __restrict__ v, int n,
                                                            double* __restrict__ part)
 {
@@ -287,6 +345,30 @@ int k_interpolate(dlg_backend* b, const double* a, const double* bb, double norm
   hipLaunchKernelGGL(k_part_interp2, dim3(g), dim3(TPB), 0, b->stream, a, bb, b->d_part, g, norm2a,
                      trustregion*trustregion, p, step, p_new, n, hp ? hp : part2, out3 + 1);
   if(!hp) hipLaunchKernelGGL(k_final, dim3(1), dim3(TPB), 0, b->stream, part2, g, 1, 1, out3, 2);
+  DLG_LAUNCH_CHECK();
+  return DLG_OK;
+}
+// gn = -u, the partials of |gn|^2 left on the device (gnpart, *nb of them) for k_take_step
+int k_negate_norm2_partials(dlg_backend* b, double* v, int n, double* gnpart, int* nb)
+{
+  const int g = grid_for(n);
+  hipLaunchKernelGGL(k_part_negate_norm2, dim3(g), dim3(TPB), 0, b->stream, v, n, gnpart);
+  DLG_LAUNCH_CHECK();
+  *nb = g;
+  return DLG_OK;
+}
+int k_take_step(dlg_backend* b, const double* cauchy, const double* gn, const double* gnpart, int nbg,
+                const double* n2c_dev, double trustregion, const double* p, double* step, double* p_new, int n,
+                double* out_n2_max, double* out3)
+{
+  const int g = grid_for(n);
+  DLG_CHECK(dlg_ensure_partials(b, 4*MAXB));
+  hipLaunchKernelGGL(k_part_interp1, dim3(g), dim3(TPB), 0, b->stream, cauchy, gn, n, b->d_part);
+  double* part2 = b->d_part + 2*g;
+  double* hp = dlg_host_partials(b, out_n2_max, g, 1, 1, 2);
+  hipLaunchKernelGGL(k_part_take_step, dim3(g), dim3(TPB), 0, b->stream, cauchy, gn, b->d_part, g, gnpart, nbg,
+                     n2c_dev, trustregion, p, step, p_new, n, hp ? hp : part2, out3);
+  if(!hp) hipLaunchKernelGGL(k_final, dim3(1), dim3(TPB), 0, b->stream, part2, g, 1, 1, out_n2_max, 2);
   DLG_LAUNCH_CHECK();
   return DLG_OK;
 }

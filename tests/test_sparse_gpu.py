@@ -227,3 +227,46 @@ def test_fused_backend_ops_match_the_separate_calls(gpu, kind):
     for u, v in zip(a[:7], b[:7]):
         assert u == v
     assert np.array_equal(a[7], b[7]) and np.array_equal(a[8], b[8])
+
+
+@pytest.mark.parametrize("kind", ["sparse", "dense"])
+@pytest.mark.parametrize("which", ["cauchy", "gn", "interp"])
+def test_take_step_matches_the_separate_calls(gpu, kind, which):
+    """dlg_take_step = Cauchy + GN + the choice of step (made on the device) + step + expected
+    improvement behind one synchronisation: the same numbers as the separate calls, bit for bit"""
+    if kind == "sparse":
+        prob = oa.BAProblem(6, 60, 400, seed=7)
+        p = prob.p0()
+        x, J = prob.eval(p)
+        Jp, Ji = prob.pattern()
+        mk = lambda: capi.Backend(capi.DLG_SPARSE, prob.N, prob.M, prob.nnz)
+    else:
+        prob = oa.DenseProblem(M=500, N=40, seed=7)
+        p = prob.p0()
+        x, J = prob.eval(p)
+        mk = lambda: capi.Backend(capi.DLG_DENSE, prob.N, prob.M)
+
+    def fresh():
+        be = mk()
+        if kind == "sparse":
+            be.set_pattern(Jp, Ji)
+        be.set_p(0, p)
+        be.upload(0, x, J)
+        be.eval(0)
+        return be
+    be = fresh()
+    n2c = be.cauchy(0)
+    lam, n2g = be.gauss_newton(0, 0.0)
+    lo, hi = sorted((np.sqrt(n2c), np.sqrt(n2g)))
+    assert np.sqrt(n2c) < np.sqrt(n2g)
+    tr = {"cauchy": 0.5 * lo, "interp": 0.5 * (lo + hi), "gn": 2.0 * hi}[which]
+    want_kind = {"cauchy": capi.KIND_CAUCHY, "interp": capi.KIND_INTERP, "gn": capi.KIND_GN}[which]
+    n2s, k, amax, ei, pnew = be.step(0, 1, want_kind, tr)
+    ref = (lam, n2c, n2g, n2s, amax, ei, pnew.copy(), be.download(1, capi.VEC_STEP))
+    be2 = fresh()
+    lam2, r, pnew2 = be2.take_step(0, 1, tr, 0.0)
+    assert r["kind"] == want_kind
+    assert (lam2, r["n2c"], r["n2g"], r["n2s"], r["amax"], r["ei"]) == ref[:6]
+    if which == "interp":
+        assert r["k"] == k
+    assert np.array_equal(pnew2, ref[6]) and np.array_equal(be2.download(1, capi.VEC_STEP), ref[7])
