@@ -65,12 +65,18 @@ __device__ __forceinline__ void mf_add_children(double* P, double* Wt, int ntri,
       }
       else
       {
+        // the update matrix lives in HBM: each of its entries gets an atomic add (fire and forget,
+        // no read round trip).  A child adds to an address at most once and the barrier orders the
+        // children, so the sums are still in child order.
+#pragma unroll
+        for(int u = 0; u < MF_SLOTS; u++) if(e0 + u*NT < npad) old[u] = P[(d[u] & 0x8000) ? 0 : d[u]];
 #pragma unroll
         for(int u = 0; u < MF_SLOTS; u++)
-          if(e0 + u*NT < npad) old[u] = (d[u] & 0x8000) ? Wt[d[u] & 0x7fff] : P[d[u]];
-#pragma unroll
-        for(int u = 0; u < MF_SLOTS; u++)
-          if(e0 + u*NT < npad) { if(d[u] & 0x8000) Wt[d[u] & 0x7fff] = old[u] + v[u]; else P[d[u]] = old[u] + v[u]; }
+          if(e0 + u*NT < npad)
+          {
+            if(d[u] & 0x8000) unsafeAtomicAdd(Wt + (d[u] & 0x7fff), v[u]);
+            else P[d[u]] = old[u] + v[u];
+          }
       }
     }
     __syncthreads();
@@ -188,6 +194,22 @@ __global__ void __launch_bounds__(NT) k_factor_level(const FwItem* __restrict__ 
         oa[q] = w + min(16*(ti0 + min(q, nt - 1)) + jn, mb - 1) + kq*ldp;
         c4[q] = (dlg_v4d){0.0, 0.0, 0.0, 0.0};
       }
+      // an update matrix kept in HBM: the children's sums of this item's tiles, on their way during
+      // the products (read around L1: they were formed by atomics in L2)
+      double w0[SY_G][4];
+      const bool w_hbm = mf_acc && !u_lds;
+      if(w_hbm)
+      {
+        const int jt0 = tri_col(j, mb);
+#pragma unroll
+        for(int q = 0; q < SY_G; q++)
+#pragma unroll
+          for(int r = 0; r < 4; r++)
+          {
+            const int i = 16*(ti0 + q) + kq + 4*r;
+            w0[q][r] = (q < nt && i < mb && j <= i) ? __hip_atomic_load(Ud + jt0 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+          }
+      }
       const int st = 4*ldp;
       double a0[SY_G], a1[SY_G], b0 = 0.0, b1;
 #pragma unroll
@@ -260,7 +282,7 @@ __global__ void __launch_bounds__(NT) k_factor_level(const FwItem* __restrict__ 
             const int i = 16*(ti0 + q) + kq + 4*r;
             if(i < mb && j <= i)
             {
-              if(mode == 2) Ud[jtri + i] = (mf_acc ? Ud[jtri + i] : 0.0) - c4[q][r];     // the region keeps W = -U
+              if(mode == 2) Ud[jtri + i] = (w_hbm ? w0[q][r] : (mf_acc ? Ud[jtri + i] : 0.0)) - c4[q][r];     // the region keeps W = -U
               else Ud[jtri + i] = c4[q][r];
             }
           }

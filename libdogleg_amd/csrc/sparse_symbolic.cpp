@@ -726,15 +726,17 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
   {
     for(int l = 0; l < S.nlevels; l++)
     {
-      long n = 0, wsum = 0, rsum = 0; int wmin = 1 << 30, wmax = 0, rmax = 0;
+      long n = 0, wsum = 0, rsum = 0, nofit = 0; int wmin = 1 << 30, wmax = 0, rmax = 0;
       for(int i = S.lvl_ptr[l]; i < S.lvl_ptr[l+1]; i++)
       {
         const int s = S.lvl_sn[i];
         const int w = S.sn_c0[s+1] - S.sn_c0[s], nr = S.sn_rowptr[s+1] - S.sn_rowptr[s];
         n++; wsum += w; rsum += nr; wmin = std::min(wmin, w); wmax = std::max(wmax, w); rmax = std::max(rmax, nr);
+        const long mb = nr - w;
+        if((((nr + 1) & ~1L)*w + mb*(mb + 1)/2 + 1)*8 > SYM_FAC_LDS_BUDGET) nofit++;
       }
-      fprintf(stderr, "level %2d: %5ld supernodes  w min/avg/max %d/%.1f/%d  nrows avg/max %.1f/%d  slices %d\n", l, n, wmin,
-              (double)wsum/n, wmax, (double)rsum/n, rmax, S.fw_lvl_ptr[l+1] - S.fw_lvl_ptr[l]);
+      fprintf(stderr, "level %2d: %5ld supernodes  w min/avg/max %d/%.1f/%d  nrows avg/max %.1f/%d  slices %d  update matrix not in LDS: %ld\n", l, n, wmin,
+              (double)wsum/n, wmax, (double)rsum/n, rmax, S.fw_lvl_ptr[l+1] - S.fw_lvl_ptr[l], nofit);
     }
   }
 
