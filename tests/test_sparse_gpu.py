@@ -143,7 +143,14 @@ def test_ba_lambda_path(gpu):
     {"DOGLEG_AMD_SYRK_MIN": "1", "DOGLEG_AMD_NO_SYRK_FUSE": "1"},    # stand-alone SYRK kernel at every level
     {"DOGLEG_AMD_RIDER_MIN": "0"},                                  # the dense block keeps tasks of its own
     {"DOGLEG_AMD_SLICE_CAP": "6000"},                               # many row slices per panel
-], ids=["lds-assembly", "coop-update", "mfma-update", "syrk-unfused", "no-rider", "small-slices"])
+    {"DOGLEG_AMD_MF_LEVEL": "-1"},                                  # no multifrontal region: every level pushes its updates
+    {"DOGLEG_AMD_MF_LEVEL": "0"},                                   # multifrontal from the leaves up (parents with many children)
+    {"DOGLEG_AMD_MF_LEVEL": "0", "DOGLEG_AMD_MF_NT": "128", "DOGLEG_AMD_ND_LEAF": "40"},   # 128-thread factor workgroups in the region
+    {"DOGLEG_AMD_MF_LEVEL": "0", "DOGLEG_AMD_MF_NT": "256", "DOGLEG_AMD_SIB_W": "0"},     # 256 threads, no sibling-merged leaves
+    {"DOGLEG_AMD_MF_MAXM": "60"},                                   # the region ends below the big fronts
+    {"DOGLEG_AMD_DEVICE_FINALS": "1"},                              # second stage of every reduction on the device
+], ids=["lds-assembly", "coop-update", "mfma-update", "syrk-unfused", "no-rider", "small-slices", "no-multifrontal",
+        "multifrontal-from-leaves", "multifrontal-128", "multifrontal-256", "multifrontal-small-fronts", "device-finals"])
 def test_fallback_kernels_match_oracle(gpu, env, monkeypatch):
     """the kernels the default schedule does not pick on a bundle-adjustment pattern stay correct:
     the schedule knobs are read when the pattern is set"""
