@@ -275,6 +275,9 @@ __global__ void __launch_bounds__(BWD_NT) k_solve_bwd_level(const SolveItem* __r
     if(tid < w) { ywork[c0 + tid] = xs[tid]; out[myperm] = xs[tid]; }
     return;
   }
+  // only the waves that hold a row of the diagonal block take part in the substitution: the others
+  // leave, and the barriers below (one per 8 columns) are among one or two waves instead of all
+  if(tid >= ((8*nblk + 63) & ~63)) return;
   double xi = 0.0;
   if(tid < w)
   {
