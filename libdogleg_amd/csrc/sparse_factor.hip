@@ -164,83 +164,85 @@ __global__ void __launch_bounds__(NT) k_factor_level(const FwItem* __restrict__ 
   FL_STAMP(3);
   if(r0 == 0 && tid == 0 && sbad != 0x7fffffff) atomicMin(info, sbad);
   // U = B B' (mode 2: W = children's sum - B B'): lower 16x16 tiles, both MFMA operands read from
-  // the panel.  Work item = up to SY_G consecutive row tiles of one tile column: the B operand is
-  // shared, the SY_G accumulator chains keep the matrix core busy.  Rows / columns past the end are
-  // clamped (their results are never written); two k-steps per iteration with their own operand
-  // registers, so the loads of one are in flight during the products of the other.
+  // the panel.  SY_G accumulator chains per wave keep the matrix core busy.  Rows / columns past the
+  // end are clamped (their results are never written); two k-steps per iteration with their own
+  // operand registers, so the loads of one are in flight during the products of the other.
   if(has_u)
   {
     const int T = (mb + 15) >> 4;
     const int wv = tid >> 6, jn = lane & 15, kq = lane >> 4;
     double* Ud = u_lds ? Us : Ug;              // in place behind the panel, or straight to the scratch
-    constexpr int SY_G = 4;
-    int nitems = 0;
-    for(int tj = 0; tj < T; tj++) nitems += (T - tj + SY_G - 1)/SY_G;
+    // work item = SY_G consecutive lower tiles in column-major tile order (they may span two tile
+    // columns, so every chain has its own B operand): the triangle is dealt out evenly, a wave of
+    // the upper levels (512 threads, 8 x 8 tiles) and of the leaves (256 threads, 5 x 5) gets one item
+    constexpr int SY_G = (NT >= 512) ? 6 : 4;
+    const int ntiles = T*(T + 1)/2, nitems = (ntiles + SY_G - 1)/SY_G;
     const int w4 = w & ~3;
+    const bool w_hbm = mf_acc && !u_lds;
     for(int item = wv; item < nitems; item += NT/64)
     {
-      int rem = item, tj = 0;
-      while(rem >= (T - tj + SY_G - 1)/SY_G) { rem -= (T - tj + SY_G - 1)/SY_G; tj++; }
-      const int ti0 = tj + SY_G*rem, nt = min(SY_G, T - ti0);
-      const int j = 16*tj + jn;
-      // element offsets into P of this lane's operands at k-step 0 (row tiles past the item's
-      // last one repeat it: their products are computed and dropped)
-      int ob = w + min(j, mb - 1) + kq*ldp;
-      int oa[SY_G];
+      // tile (ti, tj) of chain q; chains past the last tile repeat it (computed and dropped)
+      int ti[SY_G], tjq[SY_G], oa[SY_G], ob[SY_G];
+      bool on[SY_G];
       dlg_v4d c4[SY_G];
-#pragma unroll
-      for(int q = 0; q < SY_G; q++)
       {
-        oa[q] = w + min(16*(ti0 + min(q, nt - 1)) + jn, mb - 1) + kq*ldp;
-        c4[q] = (dlg_v4d){0.0, 0.0, 0.0, 0.0};
+        int rem = item*SY_G, tj = 0;
+        while(rem >= T - tj) { rem -= T - tj; tj++; }
+        int tcur = tj + rem;
+#pragma unroll
+        for(int q = 0; q < SY_G; q++)
+        {
+          on[q] = item*SY_G + q < ntiles;
+          ti[q] = tcur; tjq[q] = tj;
+          if(on[q] && item*SY_G + q + 1 < ntiles) { tcur++; if(tcur >= T) { tj++; tcur = tj; } }
+          oa[q] = w + min(16*ti[q] + jn, mb - 1) + kq*ldp;
+          ob[q] = w + min(16*tjq[q] + jn, mb - 1) + kq*ldp;
+          c4[q] = (dlg_v4d){0.0, 0.0, 0.0, 0.0};
+        }
       }
       // an update matrix kept in HBM: the children's sums of this item's tiles, on their way during
       // the products (read around L1: they were formed by atomics in L2)
       double w0[SY_G][4];
-      const bool w_hbm = mf_acc && !u_lds;
       if(w_hbm)
       {
-        const int jt0 = tri_col(j, mb);
 #pragma unroll
         for(int q = 0; q < SY_G; q++)
+        {
+          const int j = 16*tjq[q] + jn, jt0 = tri_col(j, mb);
 #pragma unroll
           for(int r = 0; r < 4; r++)
           {
-            const int i = 16*(ti0 + q) + kq + 4*r;
-            w0[q][r] = (q < nt && i < mb && j <= i) ? __hip_atomic_load(Ud + jt0 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+            const int i = 16*ti[q] + kq + 4*r;
+            w0[q][r] = (on[q] && i < mb && j <= i) ? __hip_atomic_load(Ud + jt0 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
           }
+        }
       }
       const int st = 4*ldp;
-      double a0[SY_G], a1[SY_G], b0 = 0.0, b1;
+      double a0[SY_G], a1[SY_G], b0[SY_G], b1[SY_G];
 #pragma unroll
-      for(int q = 0; q < SY_G; q++) a0[q] = 0.0;
-      int kk = 0;
+      for(int q = 0; q < SY_G; q++) { a0[q] = 0.0; b0[q] = 0.0; }
+      int kk = 0, ko = 0;                      // ko: element offset of k-step kk
       if(w4 >= 4)
       {
-        b0 = P[ob];
 #pragma unroll
-        for(int q = 0; q < SY_G; q++) a0[q] = P[oa[q]];
+        for(int q = 0; q < SY_G; q++) { a0[q] = P[oa[q]]; b0[q] = P[ob[q]]; }
       }
       for(; kk + 8 <= w4; kk += 8)
       {
-        b1 = P[ob + st];
 #pragma unroll
-        for(int q = 0; q < SY_G; q++) a1[q] = P[oa[q] + st];
+        for(int q = 0; q < SY_G; q++) { a1[q] = P[oa[q] + ko + st]; b1[q] = P[ob[q] + ko + st]; }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for(int q = 0; q < SY_G; q++) c4[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[q], b0, c4[q], 0, 0, 0);
+        for(int q = 0; q < SY_G; q++) c4[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[q], b0[q], c4[q], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
-        ob += 2*st;
-#pragma unroll
-        for(int q = 0; q < SY_G; q++) oa[q] += 2*st;
+        ko += 2*st;
         // the k-step after next (clamped to the last whole one: a harmless re-read at the end)
-        const int back = (kk + 12 <= w4) ? 0 : 2*st;
-        b0 = P[ob - back];
+        const int kn = (kk + 12 <= w4) ? ko : ko - 2*st;
 #pragma unroll
-        for(int q = 0; q < SY_G; q++) a0[q] = P[oa[q] - back];
+        for(int q = 0; q < SY_G; q++) { a0[q] = P[oa[q] + kn]; b0[q] = P[ob[q] + kn]; }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for(int q = 0; q < SY_G; q++) c4[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[q], b1, c4[q], 0, 0, 0);
+        for(int q = 0; q < SY_G; q++) c4[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[q], b1[q], c4[q], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
       }
       if(kk + 4 <= w4)
@@ -248,38 +250,34 @@ __global__ void __launch_bounds__(NT) k_factor_level(const FwItem* __restrict__ 
         // odd number of whole k-steps: the last one
         if(kk > 0)
         {
-          b0 = P[ob];
 #pragma unroll
-          for(int q = 0; q < SY_G; q++) a0[q] = P[oa[q]];
+          for(int q = 0; q < SY_G; q++) { a0[q] = P[oa[q] + ko]; b0[q] = P[ob[q] + ko]; }
         }
 #pragma unroll
-        for(int q = 0; q < SY_G; q++) c4[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[q], b0, c4[q], 0, 0, 0);
-        kk += 4; ob += st;
-#pragma unroll
-        for(int q = 0; q < SY_G; q++) oa[q] += st;
+        for(int q = 0; q < SY_G; q++) c4[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[q], b0[q], c4[q], 0, 0, 0);
+        kk += 4; ko += st;
       }
       if(kk < w)
       {
         // the last, partial k-step: columns past the end contribute zeros
         const bool kok = kk + kq < w;
-        const int back = kok ? 0 : (kk + kq - (w - 1))*ldp;
-        const double bz = kok ? P[ob - back] : 0.0;
+        const int kz = ko - (kok ? 0 : (kk + kq - (w - 1))*ldp);
 #pragma unroll
         for(int q = 0; q < SY_G; q++)
         {
-          const double az = kok ? P[oa[q] - back] : 0.0;
+          const double az = kok ? P[oa[q] + kz] : 0.0, bz = kok ? P[ob[q] + kz] : 0.0;
           c4[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(az, bz, c4[q], 0, 0, 0);
         }
       }
-      const int jtri = tri_col(j, mb);
 #pragma unroll
       for(int q = 0; q < SY_G; q++)
-        if(q < nt)
+        if(on[q])
         {
+          const int j = 16*tjq[q] + jn, jtri = tri_col(j, mb);
 #pragma unroll
           for(int r = 0; r < 4; r++)
           {
-            const int i = 16*(ti0 + q) + kq + 4*r;
+            const int i = 16*ti[q] + kq + 4*r;
             if(i < mb && j <= i)
             {
               if(mode == 2) Ud[jtri + i] = (w_hbm ? w0[q][r] : (mf_acc ? Ud[jtri + i] : 0.0)) - c4[q][r];     // the region keeps W = -U
@@ -860,6 +858,7 @@ int sparse_factor_setup(dlg_backend* b)
     }
     Y->fac_nt[l] = (maxr <= 128) ? 128 : (maxr <= 256 ? 256 : 512);
     if(l >= H.mf_level0) Y->fac_nt[l] = env_int_host("DOGLEG_AMD_MF_NT", 512);
+    else if(getenv("DOGLEG_AMD_FAC_NT")) Y->fac_nt[l] = env_int_host("DOGLEG_AMD_FAC_NT", 256);
     Y->upd_coop[l] = (maxw > 8) ? 1 : 0;           // heavy sources: matrix-core / cooperative update kernels
     if(maxp*8 > FAC_LDS_BUDGET) { dlg_set_error("internal error: a factor slice does not fit LDS (%ld doubles)", maxp); return DLG_ERR_ARG; }
     Y->fac_lds[l] = (int)(maxp*8);
