@@ -427,11 +427,11 @@ __device__ __forceinline__ void bd_solve_row(double* P, int ldp, int r, int c0, 
 template <int NT>
 __device__ __forceinline__ void panel_factor_blockdiag(double* P, int ldp, int nrows, int w, int tid,
                                                        const int* __restrict__ mcol_g, int nmem,
-                                                       int* __restrict__ info, int col0)
+                                                       int* __restrict__ info, int col0,
+                                                       int* mcol, double* rdiag)
 {
-  // member boundaries and reciprocal pivots live in LDS: phase B walks them for every row
-  __shared__ int mcol[260];
-  __shared__ double rdiag[256];
+  // member boundaries and reciprocal pivots live in LDS (mcol[260], rdiag[256], the caller's):
+  // phase B walks them for every row
   for(int m = tid; m <= nmem; m += NT) mcol[m] = (m < nmem) ? mcol_g[m] : w;
   __syncthreads();
   for(int m = tid; m < nmem; m += NT)
@@ -472,3 +472,116 @@ __device__ __forceinline__ void panel_factor_blockdiag(double* P, int ldp, int n
   }
   __syncthreads();
 }
+
+// ---- compact variant for unsliced block-diagonal panels (the merged point leaves) -------------
+// The top block of such a panel is block diagonal, i.e. almost all zeros: it is never staged.
+// LDS holds the rows below it only (Pb[i + j*ldp] for i >= w: Pb = base - w) plus the factored
+// member blocks (Dg[(c0 + c)*8 + q]); a member's thread reads its little block straight from the
+// panel in HBM (G, leading dimension ldg), factors it in registers and writes it back.
+template <int NB>
+__device__ __forceinline__ int bd_factor_member_g(double* __restrict__ G, int ldg, int c0, double* rdiag,
+                                                  double* __restrict__ Dg)
+{
+  double D[NB][NB];
+#pragma unroll
+  for(int c = 0; c < NB; c++)
+#pragma unroll
+    for(int q = 0; q <= c; q++) D[c][q] = G[(c0 + c) + (size_t)(c0 + q)*ldg];
+  int badcol = -1;
+#pragma unroll
+  for(int c = 0; c < NB; c++)
+  {
+    double d = D[c][c];
+    if(!(d > 0.0)) { if(badcol < 0) badcol = c; d = 1.0; }
+    const double inv = dlg_rsqrt(d);
+    rdiag[c0 + c] = inv;
+#pragma unroll
+    for(int i = c + 1; i < NB; i++) D[i][c] *= inv;
+#pragma unroll
+    for(int j = c + 1; j < NB; j++)
+#pragma unroll
+      for(int i = j; i < NB; i++) D[i][j] -= D[i][c]*D[j][c];
+    D[c][c] = d*inv;
+  }
+#pragma unroll
+  for(int c = 0; c < NB; c++)
+#pragma unroll
+    for(int q = 0; q <= c; q++) { G[(c0 + c) + (size_t)(c0 + q)*ldg] = D[c][q]; Dg[(c0 + c)*8 + q] = D[c][q]; }
+  return badcol;
+}
+template <int NB>
+__device__ __forceinline__ void bd_solve_row_c(double* Pb, int ldp, int r, int c0, const double* rdiag,
+                                               const double* __restrict__ Dg)
+{
+  double x[NB], Lm[NB][NB], rd[NB];
+#pragma unroll
+  for(int c = 0; c < NB; c++)
+  {
+    x[c] = Pb[r + (c0 + c)*ldp]; rd[c] = rdiag[c0 + c];
+#pragma unroll
+    for(int q = 0; q < c; q++) Lm[c][q] = Dg[(c0 + c)*8 + q];
+  }
+#pragma unroll
+  for(int c = 0; c < NB; c++)
+  {
+    double v = x[c];
+#pragma unroll
+    for(int q = 0; q < c; q++) v -= x[q]*Lm[c][q];
+    x[c] = v*rd[c];
+  }
+#pragma unroll
+  for(int c = 0; c < NB; c++) Pb[r + (c0 + c)*ldp] = x[c];
+}
+// members first (their global loads are on their way while the caller copies the rows below into
+// LDS: call bd_compact_members before that copy's barrier), then the rows
+template <int NT>
+__device__ __forceinline__ void bd_compact_members(double* __restrict__ G, int ldg, int w, int tid,
+                                                   const int* __restrict__ mcol_g, int nmem, int bdw,
+                                                   int* mcol, double* rdiag, double* __restrict__ Dg,
+                                                   int* __restrict__ info, int col0)
+{
+  for(int m = tid; m <= nmem; m += NT) mcol[m] = (m < nmem) ? (bdw > 0 ? m*bdw : mcol_g[m]) : w;
+  for(int m = tid; m < nmem; m += NT)
+  {
+    const int c0 = bdw > 0 ? m*bdw : mcol_g[m];
+    const int nb = (m + 1 < nmem ? (bdw > 0 ? (m + 1)*bdw : mcol_g[m + 1]) : w) - c0;
+    int badcol;
+    switch(nb)
+    {
+      case 1: badcol = bd_factor_member_g<1>(G, ldg, c0, rdiag, Dg); break;
+      case 2: badcol = bd_factor_member_g<2>(G, ldg, c0, rdiag, Dg); break;
+      case 3: badcol = bd_factor_member_g<3>(G, ldg, c0, rdiag, Dg); break;
+      case 4: badcol = bd_factor_member_g<4>(G, ldg, c0, rdiag, Dg); break;
+      case 5: badcol = bd_factor_member_g<5>(G, ldg, c0, rdiag, Dg); break;
+      case 6: badcol = bd_factor_member_g<6>(G, ldg, c0, rdiag, Dg); break;
+      case 7: badcol = bd_factor_member_g<7>(G, ldg, c0, rdiag, Dg); break;
+      default: badcol = bd_factor_member_g<8>(G, ldg, c0, rdiag, Dg); break;
+    }
+    if(badcol >= 0) atomicMin(info, col0 + c0 + badcol);
+  }
+}
+template <int NT>
+__device__ __forceinline__ void bd_compact_rows(double* Pb, int ldp, int nrows, int w, int tid, int nmem,
+                                                const int* mcol, const double* rdiag, const double* __restrict__ Dg)
+{
+  for(int r = w + tid; r < nrows; r += NT)
+  {
+    for(int m = 0; m < nmem; m++)
+    {
+      const int c0 = mcol[m], nb = mcol[m+1] - c0;        // uniform over the workgroup
+      switch(nb)
+      {
+        case 1: bd_solve_row_c<1>(Pb, ldp, r, c0, rdiag, Dg); break;
+        case 2: bd_solve_row_c<2>(Pb, ldp, r, c0, rdiag, Dg); break;
+        case 3: bd_solve_row_c<3>(Pb, ldp, r, c0, rdiag, Dg); break;
+        case 4: bd_solve_row_c<4>(Pb, ldp, r, c0, rdiag, Dg); break;
+        case 5: bd_solve_row_c<5>(Pb, ldp, r, c0, rdiag, Dg); break;
+        case 6: bd_solve_row_c<6>(Pb, ldp, r, c0, rdiag, Dg); break;
+        case 7: bd_solve_row_c<7>(Pb, ldp, r, c0, rdiag, Dg); break;
+        default: bd_solve_row_c<8>(Pb, ldp, r, c0, rdiag, Dg); break;
+      }
+    }
+  }
+  __syncthreads();
+}
+

@@ -122,23 +122,37 @@ __global__ void __launch_bounds__(NT) k_factor_level(const FwItem* __restrict__ 
   double* G = Lx + it.lx;
   const int tid = threadIdx.x, lane = tid & 63;
   const int nloc = w + (it.r1 - r0);          // rows held by this workgroup
-  const int ldp = (nloc + 1) & ~1;
   const int shift = r0;                        // local row i >= w  <->  panel row i + shift
   const int64_t top = it.top;
   const int mb = nloc - w, ntri = mb*(mb + 1)/2;
+  // compact layout for unsliced block-diagonal panels (the merged point leaves): the top block is
+  // almost all zeros and is never staged -- LDS holds the rows below it (Pb[i + j*ldp], i >= w) and
+  // the factored member blocks (Dg), see panel_factor.h
+  const bool cmp = it.nbd > 0 && top < 0;
+  const int ldp = cmp ? ((mb + 1) & ~1) : ((nloc + 1) & ~1);
+  double* Pb = cmp ? P - w : P;
+  const int row0c = cmp ? w : 0;               // first row that is staged
   const bool has_u = mode != 0 && top < 0;
   const bool u_lds = has_u && (it.nch > 0 || stage_leaf_u) &&
-                     (size_t)(ldp*w + ntri + 1)*sizeof(double) <= (size_t)FAC_LDS_BUDGET;   // + the scratch slot of mf_dst
+                     (size_t)(ldp*w + ntri + 1 + (cmp ? 8*w : 0))*sizeof(double) <= (size_t)FAC_LDS_BUDGET;   // + the scratch slot of mf_dst
   double* Ug = has_u ? uscr + it.u_off : nullptr;
   double* Us = P + ldp*w;
+  double* Dg = Us + (u_lds ? ntri + 1 : 0);
+  __shared__ int s_mcol[260];
+  __shared__ double s_rdiag[256];
   MfChild rc = {0, 0, 0, 0};
   const bool mf_acc = mode == 2 && it.nch > 0;
   if(mf_acc) rc = mf_rec[it.ch0 + min(lane, it.nch - 1)];     // on its way during the panel copy
   if(tid == 0) sbad = 0x7fffffff;
+  if(cmp)
+  {
+    __syncthreads();
+    bd_compact_members<NT>(G, nrows, w, tid, sn_bd_col + it.bd0, it.nbd, it.bdw, s_mcol, s_rdiag, Dg, &sbad, it.col0);
+  }
   // thread = (panel row, column group): rows padded to whole waves, the remaining threads take
   // further columns
-  const int cp_rows = min(NT, (nloc + 63) & ~63), cp_ng = NT/cp_rows, cp_g = tid/cp_rows;
-  for(int i = tid - cp_g*cp_rows; i < nloc && cp_g < cp_ng; i += cp_rows)
+  const int cp_rows = min(NT, (nloc - row0c + 63) & ~63), cp_ng = NT/cp_rows, cp_g = tid/cp_rows;
+  for(int i = row0c + tid - cp_g*cp_rows; i < nloc && cp_g < cp_ng; i += cp_rows)
   {
     const double* gp = G + (i < w ? i : i + shift);
     for(int j0 = cp_g; j0 < w; j0 += CP_FLIGHT*cp_ng)
@@ -147,7 +161,7 @@ __global__ void __launch_bounds__(NT) k_factor_level(const FwItem* __restrict__ 
 #pragma unroll
       for(int u = 0; u < CP_FLIGHT; u++) v[u] = (j0 + u*cp_ng < w) ? gp[(size_t)(j0 + u*cp_ng)*nrows] : 0.0;
 #pragma unroll
-      for(int u = 0; u < CP_FLIGHT; u++) if(j0 + u*cp_ng < w) P[i + (j0 + u*cp_ng)*ldp] = v[u];
+      for(int u = 0; u < CP_FLIGHT; u++) if(j0 + u*cp_ng < w) Pb[i + (j0 + u*cp_ng)*ldp] = v[u];
     }
   }
   __syncthreads();
@@ -158,7 +172,8 @@ __global__ void __launch_bounds__(NT) k_factor_level(const FwItem* __restrict__ 
     else      mf_add_children<NT, false>(P, Ug, ntri, it.nch, it.ch0, rc, mf_rec, uscr, mf_dst, tid);
   }
   FL_STAMP(2);
-  if(it.nbd > 0) panel_factor_blockdiag<NT>(P, ldp, nloc, w, tid, sn_bd_col + it.bd0, it.nbd, &sbad, it.col0);
+  if(cmp) bd_compact_rows<NT>(Pb, ldp, nloc, w, tid, it.nbd, s_mcol, s_rdiag, Dg);
+  else if(it.nbd > 0) panel_factor_blockdiag<NT>(P, ldp, nloc, w, tid, sn_bd_col + it.bd0, it.nbd, &sbad, it.col0, s_mcol, s_rdiag);
   else if(NT >= 256) panel_factor_mfma<(NT >= 256 ? NT : 256)>(P, ldp, nloc, w, tid, &sbad, it.col0);
   else         panel_factor<NT, true, true>(P, ldp, nloc, w, tid, &sbad, it.col0);
   FL_STAMP(3);
@@ -225,12 +240,12 @@ __global__ void __launch_bounds__(NT) k_factor_level(const FwItem* __restrict__ 
       if(w4 >= 4)
       {
 #pragma unroll
-        for(int q = 0; q < SY_G; q++) { a0[q] = P[oa[q]]; b0[q] = P[ob[q]]; }
+        for(int q = 0; q < SY_G; q++) { a0[q] = Pb[oa[q]]; b0[q] = Pb[ob[q]]; }
       }
       for(; kk + 8 <= w4; kk += 8)
       {
 #pragma unroll
-        for(int q = 0; q < SY_G; q++) { a1[q] = P[oa[q] + ko + st]; b1[q] = P[ob[q] + ko + st]; }
+        for(int q = 0; q < SY_G; q++) { a1[q] = Pb[oa[q] + ko + st]; b1[q] = Pb[ob[q] + ko + st]; }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for(int q = 0; q < SY_G; q++) c4[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[q], b0[q], c4[q], 0, 0, 0);
@@ -239,7 +254,7 @@ __global__ void __launch_bounds__(NT) k_factor_level(const FwItem* __restrict__ 
         // the k-step after next (clamped to the last whole one: a harmless re-read at the end)
         const int kn = (kk + 12 <= w4) ? ko : ko - 2*st;
 #pragma unroll
-        for(int q = 0; q < SY_G; q++) { a0[q] = P[oa[q] + kn]; b0[q] = P[ob[q] + kn]; }
+        for(int q = 0; q < SY_G; q++) { a0[q] = Pb[oa[q] + kn]; b0[q] = Pb[ob[q] + kn]; }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for(int q = 0; q < SY_G; q++) c4[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[q], b1[q], c4[q], 0, 0, 0);
@@ -251,7 +266,7 @@ __global__ void __launch_bounds__(NT) k_factor_level(const FwItem* __restrict__ 
         if(kk > 0)
         {
 #pragma unroll
-          for(int q = 0; q < SY_G; q++) { a0[q] = P[oa[q] + ko]; b0[q] = P[ob[q] + ko]; }
+          for(int q = 0; q < SY_G; q++) { a0[q] = Pb[oa[q] + ko]; b0[q] = Pb[ob[q] + ko]; }
         }
 #pragma unroll
         for(int q = 0; q < SY_G; q++) c4[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[q], b0[q], c4[q], 0, 0, 0);
@@ -265,7 +280,7 @@ __global__ void __launch_bounds__(NT) k_factor_level(const FwItem* __restrict__ 
 #pragma unroll
         for(int q = 0; q < SY_G; q++)
         {
-          const double az = kok ? P[oa[q] + kz] : 0.0, bz = kok ? P[ob[q] + kz] : 0.0;
+          const double az = kok ? Pb[oa[q] + kz] : 0.0, bz = kok ? Pb[ob[q] + kz] : 0.0;
           c4[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(az, bz, c4[q], 0, 0, 0);
         }
       }
@@ -290,10 +305,10 @@ __global__ void __launch_bounds__(NT) k_factor_level(const FwItem* __restrict__ 
   }
   FL_STAMP(4);
   if(u_lds) for(int e = tid; e < ntri; e += NT) Ug[e] = Us[e];
-  for(int i = tid - cp_g*cp_rows; i < nloc && cp_g < cp_ng; i += cp_rows)
+  for(int i = row0c + tid - cp_g*cp_rows; i < nloc && cp_g < cp_ng; i += cp_rows)
   {
     // rows below the top block go back to the panel; the top block too unless the supernode is
-    // cut into slices (then slice 0 parks it in top_scr, see k_copy_top)
+    // cut into slices (then slice 0 parks it in top_scr, see k_copy_top) or it was never staged
     double* gp; size_t gs;
     if(i >= w)        { gp = G + (i + shift); gs = (size_t)nrows; }
     else if(top < 0)  { gp = G + i; gs = (size_t)nrows; }
@@ -303,7 +318,7 @@ __global__ void __launch_bounds__(NT) k_factor_level(const FwItem* __restrict__ 
     {
       double v[16];
 #pragma unroll
-      for(int u = 0; u < 16; u++) v[u] = (j0 + u*cp_ng < w) ? P[i + (j0 + u*cp_ng)*ldp] : 0.0;
+      for(int u = 0; u < 16; u++) v[u] = (j0 + u*cp_ng < w) ? Pb[i + (j0 + u*cp_ng)*ldp] : 0.0;
 #pragma unroll
       for(int u = 0; u < 16; u++) if(j0 + u*cp_ng < w) gp[(size_t)(j0 + u*cp_ng)*gs] = v[u];
     }
@@ -913,8 +928,10 @@ int sparse_factor_setup(dlg_backend* b)
       {
         const int s = H.lvl_sn[i];
         const long wv = H.sn_c0[s+1] - H.sn_c0[s], nr = H.sn_rowptr[s+1] - H.sn_rowptr[s], mb = nr - wv;
-        const long need = (((nr + 1) & ~1L)*wv + mb*(mb + 1)/2 + 1)*8;
-        const long need0 = (((nr + 1) & ~1L)*wv + 1)*8;          // at least the scratch slot behind the panel
+        const bool cmp = H.sn_bd_ptr[s+1] > H.sn_bd_ptr[s] && H.sn_top[s] < 0;
+        const long pan = cmp ? ((mb + 1) & ~1L)*wv + 8*wv : ((nr + 1) & ~1L)*wv;
+        const long need = (pan + mb*(mb + 1)/2 + 1)*8;
+        const long need0 = (pan + 1)*8;          // at least the scratch slot behind the panel
         const long want = (need <= FAC_LDS_BUDGET) ? need : need0;
         const bool has_children = l >= H.mf_level0 && H.mf_cptr[s+1] > H.mf_cptr[s];
         if(has_children) with_children = std::max(with_children, want); else leaves = std::max(leaves, want);

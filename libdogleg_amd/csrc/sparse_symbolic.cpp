@@ -902,6 +902,16 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
         it.bd0 = S.sn_bd_ptr[s2]; it.nbd = S.sn_bd_ptr[s2+1] - S.sn_bd_ptr[s2];
         it.lx = S.sn_lx[s2]; it.top = S.sn_top[s2]; it.u_off = S.u_off[s2];
         it.ch0 = S.mf_cptr[s2]; it.nch = S.mf_cptr[s2+1] - S.mf_cptr[s2];
+        it.bdw = 0; it.rsv = 0;
+        if(it.nbd > 0)
+        {
+          // members of equal width (the usual case: points): no list lookup in the kernel
+          const int* mc = &S.sn_bd_col[it.bd0];
+          const int wd0 = (it.nbd > 1 ? mc[1] : it.w) - mc[0];
+          bool same = mc[0] == 0;
+          for(int m = 0; m < it.nbd && same; m++) if(((m + 1 < it.nbd) ? mc[m+1] : it.w) - mc[m] != wd0) same = false;
+          if(same) it.bdw = wd0;
+        }
       }
     }
     std::sort(subs.begin(), subs.end(), [](const Sub& a, const Sub& b) {

@@ -150,6 +150,7 @@ struct FwItem
   int bd0, nbd;                // block-diagonal top: members in sn_bd_col[bd0 .. bd0 + nbd)
   int64_t lx, top, u_off;      // panel offset, top-block copy (or -1), update-matrix offset (or -1)
   int ch0, nch;                // multifrontal children: mf_rec[ch0 .. ch0 + nch)
+  int bdw, rsv;                // block-diagonal top: the common width of the members, 0 if they differ
 };
 // one child of a supernode of the multifrontal region: its update matrix and, entry by entry
 // (packed order, padded to a multiple of 1024 with a scratch slot), where each entry goes
