@@ -95,7 +95,7 @@ struct SparseSym
   size_t nnz_loc = 0;
   // per-level launch parameters
   std::vector<int> fac_lds;     // bytes of LDS for the factor kernel of a level (0: panels stay in HBM)
-  std::vector<int> upd_lds, upd_nw, slv_lds, bwd_lds, fac_nt, upd_coop, syrk_lds, syrk_nt, syrk_kc, bwd_nt, syrk_fused, fin_ny, fac_stage, bwd_top;
+  std::vector<int> upd_lds, upd_nw, slv_lds, bwd_lds, fac_nt, upd_coop, syrk_lds, syrk_nt, syrk_kc, bwd_nt, syrk_fused, fin_ny, fac_stage, bwd_top, bwd_bd;
   std::vector<void*> allocs;
 };
 

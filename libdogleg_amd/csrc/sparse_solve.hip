@@ -105,8 +105,8 @@ __global__ void __launch_bounds__(TPB) k_solve_fwd_level(const int* __restrict__
 // sides, after ONE barrier every thread solves the 8x8 block itself (diagonal blocks in LDS
 // with reciprocal pivots) and applies the 8 new unknowns to its own row with the values of L
 // from the LDS copy (or, for wide supernodes, fetched a block ahead from HBM).
-template <int BWD_NT>
-__global__ void __launch_bounds__(BWD_NT) k_solve_bwd_level(const SolveItem* __restrict__ items,
+template <int BWD_NT, bool BD_ONLY>
+__global__ void __launch_bounds__(BWD_NT, BD_ONLY ? 4 : 1) k_solve_bwd_level(const SolveItem* __restrict__ items,
                                                             const int* __restrict__ sn_rows,
                                                             const int* __restrict__ perm,
                                                             const double* __restrict__ Lx,
@@ -134,7 +134,7 @@ __global__ void __launch_bounds__(BWD_NT) k_solve_bwd_level(const SolveItem* __r
   const int ldt = w | 1;
   // block-diagonal top (merged sibling leaves): the members do not couple, every member is a
   // little triangular system of its own -- no sweep over the columns at all
-  const int nmem = it.nbd;
+  const int nmem = BD_ONLY ? max(it.nbd, 1) : it.nbd;      // BD_ONLY: every supernode of the launch has a block-diagonal top
   // ---- round 2
   const int myrow = (tid < r) ? rows[w + tid] : 0;
   double myrhs = 0.0; int myperm = 0;
@@ -155,6 +155,7 @@ __global__ void __launch_bounds__(BWD_NT) k_solve_bwd_level(const SolveItem* __r
   double mv[MV_SLOTS];
 #pragma unroll
   for(int q = 0; q < MV_SLOTS; q++) mv[q] = (mv_on && mv_i0 + q < mv_i1) ? mv_L[mv_i0 + q] : 0.0;
+  if(!BD_ONLY)
   for(int e = tid; e < (nmem > 0 ? 0 : nblk*64); e += BWD_NT)
   {
     const int j0 = (e >> 6)*8, a = (e >> 3) & 7, b = e & 7;
@@ -163,7 +164,7 @@ __global__ void __launch_bounds__(BWD_NT) k_solve_bwd_level(const SolveItem* __r
     if(a == b) v = valid ? 1.0/v : 1.0;
     T[e] = v;
   }
-  if(top_lds && nmem == 0)
+  if(!BD_ONLY && top_lds && nmem == 0)
   {
     // thread = (row, column group), lower triangle only
     const int cp_rows = min(BWD_NT, (w + 63) & ~63), cp_ng = BWD_NT/cp_rows, cp_g = tid/cp_rows;
@@ -275,6 +276,7 @@ __global__ void __launch_bounds__(BWD_NT) k_solve_bwd_level(const SolveItem* __r
     if(tid < w) { ywork[c0 + tid] = xs[tid]; out[myperm] = xs[tid]; }
     return;
   }
+  if(BD_ONLY) return;
   // only the waves that hold a row of the diagonal block take part in the substitution: the others
   // leave, and the barriers below (one per 8 columns) are among one or two waves instead of all
   if(tid >= ((8*nblk + 63) & ~63)) return;
@@ -362,7 +364,7 @@ int sparse_solve_setup(dlg_backend* b)
 {
   SparseSym* Y = b->sym;
   const SymHost& H = Y->H;
-  Y->slv_lds.assign(H.nlevels, 0); Y->bwd_lds.assign(H.nlevels, 0); Y->bwd_nt.assign(H.nlevels, 512); Y->bwd_top.assign(H.nlevels, 0);
+  Y->slv_lds.assign(H.nlevels, 0); Y->bwd_lds.assign(H.nlevels, 0); Y->bwd_nt.assign(H.nlevels, 512); Y->bwd_top.assign(H.nlevels, 0); Y->bwd_bd.assign(H.nlevels, 0);
   for(int l = 0; l < H.nlevels; l++)
   {
     long maxw = 0, mb = 0, mbt = 0, wmax_all = 0;
@@ -388,6 +390,10 @@ int sparse_solve_setup(dlg_backend* b)
     // thread = row of the diagonal block: 256 threads when every supernode of a populous level is
     // narrow (more workgroups per CU), else 512
     Y->bwd_nt[l] = (maxw <= 128 && H.lvl_ptr[l+1] - H.lvl_ptr[l] >= 512) ? 256 : 512;
+    // every supernode of the level has a block-diagonal top: the leaner kernel variant
+    bool allbd = true;
+    for(int i = H.lvl_ptr[l]; i < H.lvl_ptr[l+1]; i++) { const int s = H.lvl_sn[i]; if(H.sn_bd_ptr[s+1] == H.sn_bd_ptr[s]) allbd = false; }
+    Y->bwd_bd[l] = allbd ? 1 : 0;
   }
   {
     std::vector<SolveItem> items(H.nsn);
@@ -402,9 +408,11 @@ int sparse_solve_setup(dlg_backend* b)
   }
   DLG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_solve_fwd_level),
                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BUDGET));
-  DLG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_solve_bwd_level<256>),
+  DLG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_solve_bwd_level<256, false>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BUDGET));
-  DLG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_solve_bwd_level<512>),
+  DLG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_solve_bwd_level<256, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BUDGET));
+  DLG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_solve_bwd_level<512, false>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BUDGET));
   return DLG_OK;
 }
@@ -430,12 +438,16 @@ int sparse_solve(dlg_backend* b, const double* rhs, double* out)
     const int n = H.lvl_ptr[l+1] - H.lvl_ptr[l];
     // thread = row of the diagonal block: 256 threads when every supernode of a populous level is
     // narrow (more workgroups per CU), else 512
-    if(n > 0 && Y->bwd_nt[l] == 256)
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_solve_bwd_level<256>), dim3(n), dim3(256), Y->bwd_lds[l], st,
+    if(n > 0 && Y->bwd_nt[l] == 256 && Y->bwd_bd[l])
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_solve_bwd_level<256, true>), dim3(n), dim3(256), Y->bwd_lds[l], st,
+                         Y->slv_item + H.lvl_ptr[l], Y->sn_rows, Y->perm, Y->Lx, Y->ywork, out, use_aug, Y->sn_bd_col,
+                         Y->bwd_top[l] + 256*l);
+    else if(n > 0 && Y->bwd_nt[l] == 256)
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_solve_bwd_level<256, false>), dim3(n), dim3(256), Y->bwd_lds[l], st,
                          Y->slv_item + H.lvl_ptr[l], Y->sn_rows, Y->perm, Y->Lx, Y->ywork, out, use_aug, Y->sn_bd_col,
                          Y->bwd_top[l] + 256*l);
     else if(n > 0)
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_solve_bwd_level<512>), dim3(n), dim3(512), Y->bwd_lds[l], st,
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_solve_bwd_level<512, false>), dim3(n), dim3(512), Y->bwd_lds[l], st,
                          Y->slv_item + H.lvl_ptr[l], Y->sn_rows, Y->perm, Y->Lx, Y->ywork, out, use_aug, Y->sn_bd_col,
                          Y->bwd_top[l] + 256*l);
   }
