@@ -3,7 +3,7 @@
 // solved against it.  Shared by the sparse supernode kernel and the dense
 // blocked potrf (diagonal blocks).
 //
-// Three variants, all left-looking over column blocks of 8 with thread = panel row:
+// Variants, all left-looking over column blocks of 8 with thread = panel row:
 //   panel_factor            (1) every thread brings the 8 block-column entries of its row(s) up
 //                           to date against all previous columns (own read + the 8 block-row
 //                           entries as 4 broadcast 16-byte reads -> 8 FMAs; with MFMA_SWEEP the
@@ -13,7 +13,8 @@
 //                           substitution of the thread's row against the 8x8 factor.
 //   panel_factor_mfma       the same steps with a dedicated diagonal wave (>= 4 waves): the
 //                           block factorisation leaves the other waves' path, 2 barriers.
-//   panel_factor_blockdiag  block-diagonal top (merged sibling leaves): no sweep at all.
+//   panel_factor_blockdiag  block-diagonal top (merged sibling leaves): no sweep at all;
+//   bd_compact_members/rows the same for unsliced panels without staging the top block (end of file).
 // ALIGNED16: P is 16-byte aligned and ldp is even (LDS panels) -> double2 reads.
 // On a non-positive pivot the column index (col0 + j) is min-reduced into *info
 // and the pivot is replaced by 1 so that the sweep finishes without NaN storms.

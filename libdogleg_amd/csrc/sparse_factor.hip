@@ -93,7 +93,9 @@ __device__ __forceinline__ void mf_add_children(double* P, double* Wt, int ntri,
 //     publishes it while the other waves update the remaining row tiles; barrier; every thread
 //     solves its row; barrier;
 //   * 128 threads: panel_factor (same steps, all waves factor the block redundantly);
-//   * sibling-merged leaves (block-diagonal top): panel_factor_blockdiag, no sweep at all.
+//   * sibling-merged leaves (block-diagonal top): no sweep at all; unsliced ones in a compact
+//     layout that never stages the (almost empty) top block (bd_compact_*), sliced ones through
+//     panel_factor_blockdiag.
 // mode 1 / 2: the (unsliced) panel's update matrix U = B B' comes straight out of LDS afterwards;
 // mode 2 (multifrontal region) first adds the children's update matrices (mf_add_children), leaves
 // them in U as well and stores W = -U.  U is staged behind the panel in LDS when both fit.
