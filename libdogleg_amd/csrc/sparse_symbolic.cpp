@@ -14,7 +14,7 @@ namespace {
 
 constexpr int VB_MAX   = 8;       // max variables per var-block (<= 64 lanes per 8x8 output block)
 constexpr int RB_MAX   = 8;       // max rows per row-block
-constexpr int CH_JTX   = 512;     // contributions per Jt*x wave-task
+constexpr int CH_JTX   = 128;     // contributions per Jt*x wave-task (long lists are latency chains: keep them short)
 constexpr int MAXCH_JTX = 2048;
 constexpr int PANEL_CAP = 16384;  // doubles: supernode panels up to this size are factored in LDS
 constexpr int SN_WMAX  = 256;     // max supernode width
@@ -1032,7 +1032,7 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
     {
       const int c0 = rptr[v], c1 = rptr[v+1];
       if(c1 == c0) continue;
-      int chunk = CH_JTX;
+      int chunk = env_int("DOGLEG_AMD_CH_JTX", CH_JTX);
       if((c1 - c0 + chunk - 1)/chunk > MAXCH_JTX) chunk = (c1 - c0 + MAXCH_JTX - 1)/MAXCH_JTX;
       const int nch = (c1 - c0 + chunk - 1)/chunk;
       if(nch == 1) S.jtx_task.push_back({v, c0, c1, -1});
