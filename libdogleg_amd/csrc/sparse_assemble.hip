@@ -548,14 +548,12 @@ __global__ void __launch_bounds__(TPB) k_jtx(const SymTask* __restrict__ tasks, 
   const int wid = blockIdx.x*(TPB/64) + w;
   double acc = 0.0;
   int nI = 1, J = 1, a = 0, j = 0;
-  SymTask T = {0, 0, 0, -1};
-  SymOutBlock B; B.nI = 1; B.var0 = 0;
+  SymTask T = {0, 0, 0, -1, 0, 1};
   const bool live = wid < ntasks;
   if(live)
   {
     T = tasks[wid];
-    B = oblk[T.blk];
-    nI = B.nI; J = 64/nI; a = lane % nI; j = lane / nI;
+    nI = T.nI; J = 64/nI; a = lane % nI; j = lane / nI;
     if(j < J)
       for(int c = T.c0 + j; c < T.c1; c += J)
       {
@@ -570,7 +568,7 @@ __global__ void __launch_bounds__(TPB) k_jtx(const SymTask* __restrict__ tasks, 
   {
     double s = 0.0;
     for(int jj = 0; jj < J; jj++) s += sh[w*64 + lane + jj*nI];
-    if(T.part < 0) jtx[B.var0 + lane] = s;
+    if(T.part < 0) jtx[T.var0 + lane] = s;
     else part[(size_t)T.part*8 + lane] = s;
   }
 }

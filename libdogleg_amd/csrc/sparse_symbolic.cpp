@@ -1035,11 +1035,11 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
       int chunk = env_int("DOGLEG_AMD_CH_JTX", CH_JTX);
       if((c1 - c0 + chunk - 1)/chunk > MAXCH_JTX) chunk = (c1 - c0 + MAXCH_JTX - 1)/MAXCH_JTX;
       const int nch = (c1 - c0 + chunk - 1)/chunk;
-      if(nch == 1) S.jtx_task.push_back({v, c0, c1, -1});
+      if(nch == 1) S.jtx_task.push_back({v, c0, c1, -1, S.vb_start[v], G.w[v]});
       else
       {
         for(int k = 0; k < nch; k++)
-          S.jtx_task.push_back({v, c0 + k*chunk, std::min(c1, c0 + (k+1)*chunk), S.jtx_nparts + k});
+          S.jtx_task.push_back({v, c0 + k*chunk, std::min(c1, c0 + (k+1)*chunk), S.jtx_nparts + k, S.vb_start[v], G.w[v]});
         S.jtx_nparts += nch;
         S.jtx_fin_blk.push_back(v); S.jtx_fin_ptr.push_back(S.jtx_nparts);
       }

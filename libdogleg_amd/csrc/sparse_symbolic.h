@@ -137,7 +137,7 @@ static_assert(sizeof(AsmFin2) == 24, "AsmFin2 layout");
 
 // a wave-task: contributions [c0,c1) of block blk; part >= 0: write the partial
 // into slot `part` of the partial buffer instead of the destination
-struct SymTask { int32_t blk, c0, c1, part; };
+struct SymTask { int32_t blk, c0, c1, part, var0, nI; };   // var0 / nI: copied from the out-block (one dependent load less)
 
 // LDS bytes a factor workgroup may use: (almost) all 160 KB of a CU, the rest is its static LDS
 constexpr int SYM_FAC_LDS_BUDGET = 163840 - 3584;
