@@ -675,11 +675,11 @@ extern "C" int dlg_take_step(dlg_backend_t* b, int from, int to, double trustreg
       else                      DLG_CHECK(dense_solve(b, F.Jt_x, F.gn));
     }
     int nbg = 0;
-    DLG_CHECK(k_negate_norm2_partials(b, F.gn, b->N, b->d_gnpart, &nbg));          // dogleg.c:862-865
     {
       DlgProfScope ps(b, DLG_PROF_K7_STEP);
+      DLG_CHECK(k_negate_interp1(b, F.gn, F.cauchy, b->N, b->d_gnpart, &nbg));      // dogleg.c:862-865, 964-972
       DLG_CHECK(k_take_step(b, F.cauchy, F.gn, b->d_gnpart, nbg, n2c_dev, trustregion, F.p, T.step, T.p, b->N,
-                            b->d_scal, b->d_scal + 8));
+                            b->d_scal, b->d_scal + 8, F.Jt_x, b->d_scal + 11));
     }
     side_copy = false;
     if(p_new_host && b->copy_stream)
@@ -696,7 +696,7 @@ extern "C" int dlg_take_step(dlg_backend_t* b, int from, int to, double trustreg
         side_copy = true;
       }
     }
-    DLG_CHECK(expected_improvement_enqueue(b, from, to, b->d_scal + 11));
+    DLG_CHECK(norm2_Jv(b, from, T.step, b->d_scal + 12));          // the other half of the expected improvement
     DLG_CHECK(step_finish(b, to, dlg_backend::NSCAL, side_copy ? nullptr : p_new_host));   // the one synchronisation
     if(side_copy) DLG_HIP(hipEventSynchronize(b->ev_copy));
     if(b->profiling) dlg_prof_resolve(b);

@@ -151,11 +151,11 @@ int k_interpolate(dlg_backend* b, const double* a, const double* bb, double norm
                   double* out3);
 // gn = -u ; out[0] = norm2(gn)
 int k_negate_norm2(dlg_backend* b, double* v, int n, double* out);
-int k_negate_norm2_partials(dlg_backend* b, double* v, int n, double* gnpart, int* nb);
 // step chosen on the device (dogleg.c:1192-1256): out_n2_max[0] = |step|^2, [2] = max|step|; out3 = {kind, k, |gn|^2}
+int k_negate_interp1(dlg_backend* b, double* gn, const double* cauchy, int n, double* gnpart, int* nb);
 int k_take_step(dlg_backend* b, const double* cauchy, const double* gn, const double* gnpart, int nbg,
                 const double* n2c_dev, double trustregion, const double* p, double* step, double* p_new, int n,
-                double* out_n2_max, double* out3);
+                double* out_n2_max, double* out3, const double* Jtx, double* out_inner);
 // generic deterministic final reduction of `np` partials (sum) into out[0]
 int k_reduce_sum(dlg_backend* b, const double* partials, int np, double* out);
 // region of b->h_part for (nsum + nmax) x nb partials whose results go to h_scal[out - d_scal + k*stride],

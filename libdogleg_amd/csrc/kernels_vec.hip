@@ -183,7 +183,9 @@ __global__ void __launch_bounds__(TPB) k_part_take_step(const double* __restrict
                                                         double* __restrict__ step,
                                                         double* __restrict__ pnew, int n,
                                                         double* __restrict__ part,
-                                                        double* __restrict__ out3)
+                                                        double* __restrict__ out3,
+                                                        const double* __restrict__ g,
+                                                        double* __restrict__ gpart)
 {
   __shared__ double sh[4];
   __shared__ double s_l2, s_negc, s_n2g;
@@ -214,18 +216,40 @@ __global__ void __launch_bounds__(TPB) k_part_take_step(const double* __restrict
     if(disc < 0.0) disc = 0.0;
     k = (neg_c + sqrt(disc))/l2;
   }
-  double s2 = 0, m = 0;
+  double s2 = 0, m = 0, gs = 0;
   for(int i = blockIdx.x*TPB + threadIdx.x; i < n; i += gridDim.x*TPB)
   {
     const double st = (kind == 0) ? sc*a[i] : ((kind == 1) ? b[i] : a[i] + k*(b[i] - a[i]));
     step[i] = st; pnew[i] = p[i] + st; s2 += st*st; m = fmax(m, fabs(st));
+    gs += g[i]*st;                                               // <Jt x, step> for the expected improvement
   }
   const double S = block_sum(s2, sh);
   const double Mx = block_max(m, sh);
-  if(threadIdx.x == 0) { part[blockIdx.x] = S; part[gridDim.x + blockIdx.x] = Mx; }
+  __syncthreads();
+  const double Gs = block_sum(gs, sh);
+  if(threadIdx.x == 0) { part[blockIdx.x] = S; part[gridDim.x + blockIdx.x] = Mx; gpart[blockIdx.x] = Gs; }
   if(blockIdx.x == 0 && threadIdx.x == 0) { out3[0] = (double)kind; out3[1] = (kind == 2) ? k : NAN; out3[2] = n2g; }
 }
 
+// gn = -u with the partials of |gn|^2, and pass 1 of the interpolation (l2, neg_c of cauchy vs. gn)
+// in the same sweep: what dlg_take_step needs before it can choose the step
+__global__ void __launch_bounds__(TPB) k_part_negate_interp1(double* __restrict__ v,
+                                                             const double* __restrict__ a, int n,
+                                                             double* __restrict__ gnpart,
+                                                             double* __restrict__ part1)
+{
+  __shared__ double sh[4];
+  double s = 0, l2 = 0, nc = 0;
+  for(int i = blockIdx.x*TPB + threadIdx.x; i < n; i += gridDim.x*TPB)
+  {
+    const double t = -v[i]; v[i] = t; s += t*t;
+    const double ai = a[i], d = ai - t; l2 += d*d; nc += d*ai;
+  }
+  const double S = block_sum(s, sh); __syncthreads();
+  const double L = block_sum(l2, sh); __syncthreads();
+  const double Cn = block_sum(nc, sh);
+  if(threadIdx.x == 0) { gnpart[blockIdx.x] = S; part1[blockIdx.x] = L; part1[gridDim.x + blockIdx.x] = Cn; }
+}
 __global__ void __launch_bounds__(TPB) k_part_negate_norm2(double* __restrict__ v, int n,
                                                            double* __restrict__ part)
 {
@@ -348,27 +372,31 @@ int k_interpolate(dlg_backend* b, const double* a, const double* bb, double norm
   DLG_LAUNCH_CHECK();
   return DLG_OK;
 }
-// gn = -u, the partials of |gn|^2 left on the device (gnpart, *nb of them) for k_take_step
-int k_negate_norm2_partials(dlg_backend* b, double* v, int n, double* gnpart, int* nb)
+// gn = -u (in place); its |.|^2 partials -> gnpart, the interpolation's pass-1 partials -> d_part[0 .. 2g)
+int k_negate_interp1(dlg_backend* b, double* gn, const double* cauchy, int n, double* gnpart, int* nb)
 {
   const int g = grid_for(n);
-  hipLaunchKernelGGL(k_part_negate_norm2, dim3(g), dim3(TPB), 0, b->stream, v, n, gnpart);
+  DLG_CHECK(dlg_ensure_partials(b, 4*MAXB));
+  hipLaunchKernelGGL(k_part_negate_interp1, dim3(g), dim3(TPB), 0, b->stream, gn, cauchy, n, gnpart, b->d_part);
   DLG_LAUNCH_CHECK();
   *nb = g;
   return DLG_OK;
 }
+// after k_negate_interp1: the step (kind chosen on the device) and <Jtx, step> -> out_inner
 int k_take_step(dlg_backend* b, const double* cauchy, const double* gn, const double* gnpart, int nbg,
                 const double* n2c_dev, double trustregion, const double* p, double* step, double* p_new, int n,
-                double* out_n2_max, double* out3)
+                double* out_n2_max, double* out3, const double* Jtx, double* out_inner)
 {
   const int g = grid_for(n);
   DLG_CHECK(dlg_ensure_partials(b, 4*MAXB));
-  hipLaunchKernelGGL(k_part_interp1, dim3(g), dim3(TPB), 0, b->stream, cauchy, gn, n, b->d_part);
   double* part2 = b->d_part + 2*g;
   double* hp = dlg_host_partials(b, out_n2_max, g, 1, 1, 2);
+  double* hg = hp ? dlg_host_partials(b, out_inner, g, 1, 0, 1) : nullptr;
+  double* gp = hg ? hg : b->d_part + 3*MAXB;
   hipLaunchKernelGGL(k_part_take_step, dim3(g), dim3(TPB), 0, b->stream, cauchy, gn, b->d_part, g, gnpart, nbg,
-                     n2c_dev, trustregion, p, step, p_new, n, hp ? hp : part2, out3);
+                     n2c_dev, trustregion, p, step, p_new, n, hp ? hp : part2, out3, Jtx, gp);
   if(!hp) hipLaunchKernelGGL(k_final, dim3(1), dim3(TPB), 0, b->stream, part2, g, 1, 1, out_n2_max, 2);
+  if(!hg) hipLaunchKernelGGL(k_final, dim3(1), dim3(TPB), 0, b->stream, gp, g, 1, 0, out_inner, 1);
   DLG_LAUNCH_CHECK();
   return DLG_OK;
 }
