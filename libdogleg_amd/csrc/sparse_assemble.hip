@@ -661,7 +661,7 @@ int sparse_eval(dlg_backend* b, int s)
   if(!Y) { dlg_set_error("dlg_sparse_set_pattern must be called first"); return DLG_ERR_STATE; }
   DlgSlot& S = b->slot[s];
   const SymHost& H = Y->H;
-  DLG_HIP(hipMemsetAsync(S.Jt_x, 0, sizeof(double)*(size_t)b->N, b->stream));
+  if(!H.jtx_covers_all) DLG_HIP(hipMemsetAsync(S.Jt_x, 0, sizeof(double)*(size_t)b->N, b->stream));   // var-blocks without rows
   const int nt = (int)H.jtx_task.size();
   if(nt > 0)
     hipLaunchKernelGGL(k_jtx, dim3(dlg_cdiv(nt, TPB/64)), dim3(TPB), 0, b->stream, Y->jtx_task, nt,

@@ -1028,10 +1028,11 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
       S.oblk[v] = o;
     }
     S.jtx_nparts = 0; S.jtx_fin_ptr.assign(1, 0); S.jtx_fin_blk.clear();
+    S.jtx_covers_all = true;
     for(int v = 0; v < nvb; v++)
     {
       const int c0 = rptr[v], c1 = rptr[v+1];
-      if(c1 == c0) continue;
+      if(c1 == c0) { S.jtx_covers_all = false; continue; }
       int chunk = env_int("DOGLEG_AMD_CH_JTX", CH_JTX);
       if((c1 - c0 + chunk - 1)/chunk > MAXCH_JTX) chunk = (c1 - c0 + MAXCH_JTX - 1)/MAXCH_JTX;
       const int nch = (c1 - c0 + chunk - 1)/chunk;

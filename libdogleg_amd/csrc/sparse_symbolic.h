@@ -226,6 +226,7 @@ struct SymHost
   std::vector<SymTask>     jtx_task; // Jt*x wave-tasks (diagonal blocks only)
   std::vector<int> jtx_fin_ptr, jtx_fin_blk;
   int jtx_nparts = 0;
+  bool jtx_covers_all = false;       // every var-block has a (local) contribution: k_jtx writes all of Jt_x
   std::vector<AsmRho>   asm_rho;
   std::vector<AsmPair>  asm_pair;
   std::vector<AsmSlot>  asm_slot;
