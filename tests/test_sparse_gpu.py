@@ -277,3 +277,33 @@ def test_take_step_matches_the_separate_calls(gpu, kind, which):
     if which == "interp":
         assert r["k"] == k
     assert np.array_equal(pnew2, ref[6]) and np.array_equal(be2.download(1, capi.VEC_STEP), ref[7])
+
+
+def test_take_step_runs_the_lambda_loop(gpu):
+    """a singular JtJ (numerically-zero columns): dlg_take_step raises lambda like dlg_gauss_newton
+    (dogleg.c:656-677) and returns the numbers of the separate calls"""
+    prob = oa.BAProblem(6, 40, 160, seed=7, n_zero_cols=2)
+    p = prob.p0()
+    x, J = prob.eval(p)
+    Jp, Ji = prob.pattern()
+
+    def fresh():
+        be = capi.Backend(capi.DLG_SPARSE, prob.N, prob.M, prob.nnz)
+        be.set_pattern(Jp, Ji)
+        be.set_p(0, p)
+        be.upload(0, x, J)
+        be.eval(0)
+        return be
+    be = fresh()
+    n2c = be.cauchy(0)
+    lam, n2g = be.gauss_newton(0, 0.0)
+    assert lam == 1e-10
+    tr = 0.5 * (np.sqrt(n2c) + np.sqrt(n2g))
+    kind = capi.KIND_INTERP if n2c < tr * tr < n2g else (capi.KIND_CAUCHY if n2c >= tr * tr else capi.KIND_GN)
+    n2s, k, amax, ei, pnew = be.step(0, 1, kind, tr)
+    ref = (lam, n2c, n2g, n2s, amax, ei, pnew.copy())
+    be2 = fresh()
+    lam2, r, pnew2 = be2.take_step(0, 1, tr, 0.0)
+    assert r["kind"] == kind
+    assert (lam2, r["n2c"], r["n2g"], r["n2s"], r["amax"], r["ei"]) == ref[:6]
+    assert np.array_equal(pnew2, ref[6])
