@@ -63,7 +63,7 @@ Roofline of the JtJ assembly kernel:
 * K5-sparse and K6-sparse are latency / critical-path bound (SURVEY 8d says to expect low fractions and to
   say so): sparse-1m K5 = {k5b/1e6:.0f} MB algorithmic (`8 nnz(tril JtJ) + 8 nnz(L)`) and {k5f/1e9:.2f} GFLOP in {k5t:.2f} ms
   = {k5b/k5t/1e6:.0f} GB/s ({100*k5b/k5t/1e6/8000:.1f} % of HBM), {k5f/k5t/1e9:.2f} TFLOP/s; K6 = {k6b/1e6:.0f} MB (`16 nnz(L) + 32 N`) in {k6t:.2f} ms
-  = {k6b/k6t/1e6:.0f} GB/s ({100*k6b/k6t/1e6/8000:.1f} %).  {nlev} elimination-tree levels, roughly 100 us each above the leaves (factor + update + backward solve).
+  = {k6b/k6t/1e6:.0f} GB/s ({100*k6b/k6t/1e6/8000:.1f} %).  {nlev} elimination-tree levels, roughly 60-80 us each above the leaves (one factor kernel that also pulls the children's update matrices, one backward-solve kernel).
 
 rocprofv3 --stats, sparse-1m (20 timed + 3 warm-up steps; ms/step = total/23):
 ```
