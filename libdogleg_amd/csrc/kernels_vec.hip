@@ -301,8 +301,27 @@ int dlg_ensure_partials(dlg_backend* b, size_t nd)
   return DLG_OK;
 }
 
+// long lists (the thousands of row-run partials of |J v|^2): 1024 threads, four loads in flight
+__global__ void __launch_bounds__(1024) k_final_sum_long(const double* __restrict__ part, int nb, double* __restrict__ out)
+{
+  __shared__ double sh[16];
+  double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+  int i = threadIdx.x;
+  for(; i + 3072 < nb; i += 4096) { s0 += part[i]; s1 += part[i + 1024]; s2 += part[i + 2048]; s3 += part[i + 3072]; }
+  for(; i < nb; i += 1024) s0 += part[i];
+  double v = wave_sum((s0 + s1) + (s2 + s3));
+  if((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if(threadIdx.x == 0) { double r = 0; for(int k = 0; k < 16; k++) r += sh[k]; out[0] = r; }
+}
 int k_reduce_sum(dlg_backend* b, const double* partials, int np, double* out)
 {
+  if(np > 2048)
+  {
+    hipLaunchKernelGGL(k_final_sum_long, dim3(1), dim3(1024), 0, b->stream, partials, np, out);
+    DLG_LAUNCH_CHECK();
+    return DLG_OK;
+  }
   hipLaunchKernelGGL(k_final, dim3(1), dim3(TPB), 0, b->stream, partials, np, 1, 0, out, 1);
   DLG_LAUNCH_CHECK();
   return DLG_OK;
