@@ -572,33 +572,37 @@ __global__ void __launch_bounds__(TPB) k_jtx(const SymTask* __restrict__ tasks, 
     else part[(size_t)T.part*8 + lane] = s;
   }
 }
-// one workgroup (1024 threads) per multi-chunk var-block: 128 groups x 8 scalars, four loads in
-// flight per thread (a dense block that every row touches has thousands of partials)
-__global__ void __launch_bounds__(1024) k_jtx_fin(const int* __restrict__ fin_ptr,
-                                                  const int* __restrict__ fin_blk, int nfin,
-                                                  const SymOutBlock* __restrict__ oblk,
-                                                  const double* __restrict__ part,
-                                                  double* __restrict__ jtx)
+// one workgroup per multi-chunk var-block: NT/8 groups x 8 scalars, four loads in flight per
+// thread; 256 threads for the usual lists, 1024 for the few long ones (a dense block that every
+// row touches has thousands of partials)
+template <int NT>
+__global__ void __launch_bounds__(NT) k_jtx_fin(const int* __restrict__ flist,
+                                                const int* __restrict__ fin_ptr,
+                                                const int* __restrict__ fin_blk,
+                                                const SymOutBlock* __restrict__ oblk,
+                                                const double* __restrict__ part,
+                                                double* __restrict__ jtx)
 {
-  __shared__ double sh[1024];
-  const int f = blockIdx.x;
+  constexpr int G = NT/8;
+  __shared__ double sh[NT];
+  const int f = flist[blockIdx.x];
   const int a = threadIdx.x & 7, g = threadIdx.x >> 3;
   const SymOutBlock B = oblk[fin_blk[f]];
   const int p1 = fin_ptr[f+1];
   double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
   int p = fin_ptr[f] + g;
-  for(; p + 384 < p1; p += 512)
+  for(; p + 3*G < p1; p += 4*G)
   {
-    s0 += part[(size_t)p*8 + a]; s1 += part[(size_t)(p + 128)*8 + a];
-    s2 += part[(size_t)(p + 256)*8 + a]; s3 += part[(size_t)(p + 384)*8 + a];
+    s0 += part[(size_t)p*8 + a]; s1 += part[(size_t)(p + G)*8 + a];
+    s2 += part[(size_t)(p + 2*G)*8 + a]; s3 += part[(size_t)(p + 3*G)*8 + a];
   }
-  for(; p < p1; p += 128) s0 += part[(size_t)p*8 + a];
+  for(; p < p1; p += G) s0 += part[(size_t)p*8 + a];
   sh[threadIdx.x] = (s0 + s1) + (s2 + s3);
   __syncthreads();
   if(g == 0 && a < B.nI)
   {
     double tot = 0.0;
-    for(int k = 0; k < 128; k++) tot += sh[k*8 + a];
+    for(int k = 0; k < G; k++) tot += sh[k*8 + a];
     jtx[B.var0 + a] = tot;
   }
 }
@@ -674,10 +678,12 @@ int sparse_eval(dlg_backend* b, int s)
   if(nt > 0)
     hipLaunchKernelGGL(k_jtx, dim3(dlg_cdiv(nt, TPB/64)), dim3(TPB), 0, b->stream, Y->jtx_task, nt,
                        Y->oblk, Y->contrib, S.Jin(), S.xin(), S.Jt_x, Y->jtx_part);
-  const int nf = (int)H.jtx_fin_blk.size();
-  if(nf > 0)
-    hipLaunchKernelGGL(k_jtx_fin, dim3(nf), dim3(1024), 0, b->stream,
-                       Y->jtx_fin_ptr, Y->jtx_fin_blk, nf, Y->oblk, Y->jtx_part, S.Jt_x);
+  if(Y->n_fin_short > 0)
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_jtx_fin<256>), dim3(Y->n_fin_short), dim3(256), 0, b->stream, Y->jtx_fin_short,
+                       Y->jtx_fin_ptr, Y->jtx_fin_blk, Y->oblk, Y->jtx_part, S.Jt_x);
+  if(Y->n_fin_long > 0)
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_jtx_fin<1024>), dim3(Y->n_fin_long), dim3(1024), 0, b->stream, Y->jtx_fin_long,
+                       Y->jtx_fin_ptr, Y->jtx_fin_blk, Y->oblk, Y->jtx_part, S.Jt_x);
   DLG_LAUNCH_CHECK();
   return DLG_OK;
 }

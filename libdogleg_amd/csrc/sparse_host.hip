@@ -37,6 +37,15 @@ int sparse_set_pattern(dlg_backend* b, const int* colptr, const int* rowidx)
   UP(asm_rho); UP(asm_pair); UP(asm_slot); UP(asm_batch); UP(asm_ctask); UP(asm_cfin);
   UP(asm_shape); UP(asm_kg); UP(asm_mtask); UP(asm_tdest); UP(asm_fin2); UP(asm_fin2_list); UP(asm_run); UP(asm_pdest);
   UP(rl_ptr); UP(rl_pos); UP(perm); UP(col_sn); UP(fw_sn); UP(fw_r0); UP(fw_r1); UP(ms_sn); UP(sn_top); UP(sn_bd_ptr); UP(sn_bd_col);
+  {
+    // Jt*x partial lists: the few long ones (a dense block that every row touches) get a big workgroup each
+    std::vector<int> fs, fl;
+    for(int f = 0; f + 1 < (int)H.jtx_fin_ptr.size(); f++)
+      (H.jtx_fin_ptr[f+1] - H.jtx_fin_ptr[f] > 256 ? fl : fs).push_back(f);
+    Y->n_fin_short = (int)fs.size(); Y->n_fin_long = (int)fl.size();
+    DLG_CHECK(upload(Y->jtx_fin_short, fs)); Y->allocs.push_back(Y->jtx_fin_short);
+    DLG_CHECK(upload(Y->jtx_fin_long, fl)); Y->allocs.push_back(Y->jtx_fin_long);
+  }
   // rank-local pattern for the row-wise kernels
   {
     const int mloc = b->row1 - b->row0;

@@ -77,6 +77,7 @@ struct SparseSym
   SymOutBlock* oblk = nullptr; SymContrib* contrib = nullptr;
   SymTask *jtx_task = nullptr;
   int *jtx_fin_ptr = nullptr, *jtx_fin_blk = nullptr;
+  int *jtx_fin_short = nullptr, *jtx_fin_long = nullptr; int n_fin_short = 0, n_fin_long = 0;   // entries by list length
   AsmRho* asm_rho = nullptr; AsmPair* asm_pair = nullptr; AsmSlot* asm_slot = nullptr;
   AsmBatch* asm_batch = nullptr; AsmTask* asm_ctask = nullptr; AsmFin* asm_cfin = nullptr;
   AsmShape* asm_shape = nullptr; AsmKG* asm_kg = nullptr; AsmMTask* asm_mtask = nullptr; int* asm_tdest = nullptr;
