@@ -413,7 +413,7 @@ __global__ void __launch_bounds__(TPB) k_update_coop(int unit0, const int* __res
 
 // ---- two-phase update of a level with many small sources -------------------------------
 // Phase 1: U_d = B_d B_d' for every source d of the level (B_d = the mb rows below its diagonal
-// block, wd columns), lower triangle, column-major with leading dimension mb, into the scratch.
+// block, wd columns), packed lower triangle (tri_col), into the scratch.
 // One workgroup per source: B_d is staged in LDS once (k-major, zero padded to whole tiles),
 // the lower 16x16 tiles are produced by v_mfma_f64_16x16x4_f64 with both operands read from
 // LDS; a wave owns whole tile columns so the B operand is read once per k-step.

@@ -827,13 +827,11 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
         const int n = S.lvl_ptr[l+1] - S.lvl_ptr[l];
         if(syrk_min <= 0 || n < syrk_min) continue;
         bool ok = true;
-        int64_t tot = 0;
         for(int i = S.lvl_ptr[l]; i < S.lvl_ptr[l+1] && ok; i++)
         {
           const int d = S.lvl_sn[i];
           const int64_t wd = S.sn_c0[d+1] - S.sn_c0[d], mb = S.sn_rowptr[d+1] - S.sn_rowptr[d] - wd;
           if(mb > 240 || wd <= 8) ok = false;        // <= 15 x 15 tiles of 16 rows: 8 tiles per wave, 16 waves
-          tot += mb*mb;
         }
         if(!ok) continue;
         S.upd_syrk[l] = 1;
