@@ -159,6 +159,13 @@ int  dlg_step(dlg_backend_t* b, int from, int to, int kind, double trustregion,
 int  dlg_take_step(dlg_backend_t* b, int from, int to, double trustregion, double* lambda_io,
                    double* out7, double* p_new_host);
 
+/* ---- post-solve reuse of the factor: (JtJ + lambda I) u = rhs for nrhs right-hand
+ * sides (host, N doubles each, one after the other) with the factorisation held for `slot` -- what a
+ * libdogleg user does with cholmod_solve / dpotrs on ctx->factorization (dogleg.h:304-310; the
+ * reference's own user is its outlier / confidence code, dogleg.c:1831-1921).  The factor stays on
+ * the device. --------------------------------------------------------------------------------- */
+int  dlg_solve_with_factor(dlg_backend_t* b, int slot, const double* rhs_host, double* out_host, int nrhs);
+
 /* ---- downloads (returnContext, tests) -------------------------------------- */
 int  dlg_point_download(dlg_backend_t* b, int slot, int which, double* host, size_t n);
 /* dense factor in the reference's layout (packed as dpptrf('L') leaves it, or

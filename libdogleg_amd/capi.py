@@ -28,7 +28,7 @@ BACKEND_SYMBOLS = [
     "dlg_sparse_set_pattern", "dlg_sparse_stats", "dlg_point_set_p", "dlg_point_upload",
     "dlg_point_upload_products", "dlg_point_bind_device", "dlg_point_eval", "dlg_cauchy",
     "dlg_factorize", "dlg_solve_gn", "dlg_gauss_newton", "dlg_cauchy_gauss_newton", "dlg_make_step",
-    "dlg_expected_improvement", "dlg_step", "dlg_take_step",
+    "dlg_expected_improvement", "dlg_step", "dlg_take_step", "dlg_solve_with_factor",
     "dlg_point_download", "dlg_factor_download_dense", "dlg_point_device_ptr",
     "dlg_kernel_syrk_lower", "dlg_kernel_potrf_lower", "dlg_probe_mfma_f64",
     "dlg_probe_hbm_copy", "dlg_set_trace", "dlg_mem_alloc", "dlg_mem_free", "dlg_host_alloc",
@@ -87,6 +87,7 @@ def lib():
     L.dlg_make_step.argtypes = [V, C.c_int, C.c_int, C.c_int, C.c_double, D, D, D, D]
     L.dlg_step.argtypes = [V, C.c_int, C.c_int, C.c_int, C.c_double, D, D, D, D, D]
     L.dlg_take_step.argtypes = [V, C.c_int, C.c_int, C.c_double, D, D, D]
+    L.dlg_solve_with_factor.argtypes = [V, C.c_int, D, D, C.c_int]
     L.dlg_expected_improvement.argtypes = [V, C.c_int, C.c_int, D]
     L.dlg_point_download.argtypes = [V, C.c_int, C.c_int, D, C.c_size_t]
     L.dlg_factor_download_dense.argtypes = [V, D, C.c_size_t]
@@ -367,6 +368,13 @@ class Backend:
         r = dict(zip(keys, [float(v) for v in out]))
         r["kind"] = int(r["kind"])
         return l.value, r, (self._pnew if want_p else None)
+
+    def solve_with_factor(self, slot, rhs):
+        """(JtJ + lambda I) u = rhs with the factor held for `slot`; rhs: (N,) or (nrhs, N) rows"""
+        r = np.ascontiguousarray(np.atleast_2d(rhs), dtype=np.float64)
+        out = np.zeros_like(r)
+        _ck(self.L.dlg_solve_with_factor(self.h, slot, dptr(r), dptr(out), r.shape[0]), "solve_with_factor")
+        return out if np.ndim(rhs) == 2 else out[0]
 
     def make_step(self, frm, to, kind, trustregion, want_p=True):
         """p_new comes back in a page-locked buffer owned by this object (as the driver's operating

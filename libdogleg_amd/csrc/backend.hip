@@ -720,6 +720,34 @@ extern "C" int dlg_take_step(dlg_backend_t* b, int from, int to, double trustreg
   return DLG_OK;
 }
 
+// ------------------------------------------------- solves with the resident factor
+// (JtJ + lambda I) u = rhs for nrhs right-hand sides (host, column after column, N each) with the
+// factorisation held for `slot` (dlg_factorize / dlg_gauss_newton / dlg_take_step): what the
+// reference does with cholmod_solve / dpotrs on ctx->factorization after the solve (dogleg.h:304-310
+// hands the factor out for exactly that; its outlier / confidence code is the in-tree user,
+// dogleg.c:1831-1921).  The factor stays on the device; only the vectors travel.
+extern "C" int dlg_solve_with_factor(dlg_backend_t* b, int s, const double* rhs_host, double* out_host, int nrhs)
+{
+  DLG_CHECK(check_slot(b, s));
+  if(!rhs_host || !out_host || nrhs < 0) { dlg_set_error("dlg_solve_with_factor: bad argument"); return DLG_ERR_ARG; }
+  if(b->factor_slot != s) { dlg_set_error("dlg_solve_with_factor: no factorization of slot %d is held", s); return DLG_ERR_STATE; }
+  double* d_out = nullptr;
+  DLG_HIP(hipMalloc(&d_out, sizeof(double)*(size_t)b->N));
+  int rc = DLG_OK;
+  for(int k = 0; k < nrhs && rc == DLG_OK; k++)
+  {
+    if(hipMemcpyAsync(b->d_work, rhs_host + (size_t)k*b->N, sizeof(double)*(size_t)b->N, hipMemcpyHostToDevice, b->stream) != hipSuccess)
+    { dlg_set_error("dlg_solve_with_factor: upload failed"); rc = DLG_ERR_HIP; break; }
+    rc = (b->type == DLG_SPARSE) ? sparse_solve(b, b->d_work, d_out) : dense_solve(b, b->d_work, d_out);
+    if(rc != DLG_OK) break;
+    if(hipMemcpyAsync(out_host + (size_t)k*b->N, d_out, sizeof(double)*(size_t)b->N, hipMemcpyDeviceToHost, b->stream) != hipSuccess ||
+       hipStreamSynchronize(b->stream) != hipSuccess)
+    { dlg_set_error("dlg_solve_with_factor: download failed"); rc = DLG_ERR_HIP; }
+  }
+  (void)hipFree(d_out);
+  return rc;
+}
+
 // ---------------------------------------------------------------- downloads --
 static double* slot_vec(dlg_backend* b, int s, int which, size_t* n)
 {

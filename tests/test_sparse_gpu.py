@@ -307,3 +307,38 @@ def test_take_step_runs_the_lambda_loop(gpu):
     assert r["kind"] == kind
     assert (lam2, r["n2c"], r["n2g"], r["n2s"], r["amax"], r["ei"]) == ref[:6]
     assert np.array_equal(pnew2, ref[6])
+
+
+@pytest.mark.parametrize("kind", ["sparse", "dense"])
+def test_solve_with_the_resident_factor(gpu, kind):
+    """post-solve reuse of the factor -- (JtJ + lambda I) u = rhs for several right-hand
+    sides against numpy's dense solve"""
+    rng = np.random.default_rng(3)
+    if kind == "sparse":
+        prob = oa.BAProblem(5, 40, 300, seed=11)
+        p = prob.p0()
+        x, Jx = prob.eval(p)
+        Jp, Ji = prob.pattern()
+        be = capi.Backend(capi.DLG_SPARSE, prob.N, prob.M, prob.nnz)
+        be.set_pattern(Jp, Ji)
+        J = np.zeros((prob.M, prob.N))
+        for r in range(prob.M):
+            J[r, Ji[Jp[r]:Jp[r+1]]] = Jx[Jp[r]:Jp[r+1]]
+    else:
+        prob = oa.DenseProblem(M=400, N=50, seed=11)
+        p = prob.p0()
+        x, J = prob.eval(p)
+        Jx = J
+        be = capi.Backend(capi.DLG_DENSE, prob.N, prob.M)
+    be.set_p(0, p)
+    be.upload(0, x, Jx)
+    be.eval(0)
+    lam = 1e-3
+    assert be.factorize(0, lam)
+    rhs = rng.standard_normal((4, prob.N))
+    u = be.solve_with_factor(0, rhs)
+    A = J.T @ J + lam * np.eye(prob.N)
+    ref = np.linalg.solve(A, rhs.T).T
+    # tolerance: relative 1e-9 times cond is far above what double precision delivers here
+    assert np.max(np.abs(u - ref)) <= 1e-9 * np.max(np.abs(ref)) * max(1.0, np.linalg.cond(A) * 1e-6)
+    assert np.allclose(be.solve_with_factor(0, rhs[1]), u[1], rtol=0, atol=0)
