@@ -703,6 +703,105 @@ int sparse_norm2_Jv(dlg_backend* b, int s, const double* v, double* out_dev)
   return k_reduce_sum(b, part, g, out_dev);
 }
 
+// the assembly launches: JtJ of the local rows (values Jv) into the zeroed panel buffer
+static int assemble_launch(dlg_backend* b, const double* Jv)
+{
+  SparseSym* Y = b->sym;
+  const SymHost& H = Y->H;
+  hipStream_t st = b->stream;
+  DLG_HIP(hipMemsetAsync(Y->Lx, 0, sizeof(double)*(size_t)H.lx_size, st));
+  const int nt = (int)H.asm_ctask.size(), nmt = (int)H.asm_mtask.size();
+  if(nt > 0 || nmt > 0)
+  {
+    DlgProfScope pk(b, DLG_PROF_K4_KERNEL);
+    if(nmt > 0)
+    {
+      const int nruns = (int)H.asm_run.size();
+      if(H.asm_lds_len == 18)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_assemble_mfma<18>), dim3(dlg_cdiv(nruns, TPB/64)), dim3(TPB),
+                           sizeof(double)*(TPB/64)*ASM_U*4*18, st, Y->asm_run, nruns, Y->asm_mtask,
+                           Y->asm_kg, Y->asm_shape, Y->asm_tdest, Y->asm_pdest, Jv, Y->Lx, Y->asm_part, 18);
+      else
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_assemble_mfma<0>), dim3(dlg_cdiv(nruns, TPB/64)), dim3(TPB),
+                           sizeof(double)*(TPB/64)*ASM_U*4*H.asm_lds_len, st, Y->asm_run, nruns, Y->asm_mtask,
+                           Y->asm_kg, Y->asm_shape, Y->asm_tdest, Y->asm_pdest, Jv, Y->Lx, Y->asm_part,
+                           H.asm_lds_len);
+    }
+    if(nt > 0)
+      hipLaunchKernelGGL(k_assemble, dim3(dlg_cdiv(nt, TPB/64)), dim3(TPB), 0, st, Y->asm_ctask, nt,
+                         Y->asm_batch, Y->asm_rho, Y->asm_pair, Y->asm_slot, Jv, Y->Lx, Y->asm_part);
+  }
+  for(size_t q = 0; q + 2 < H.fin2_stage.size(); q += 3)
+  {
+    const int f0 = H.fin2_stage[q], ns = H.fin2_stage[q+1], nl = H.fin2_stage[q+2];
+    if(ns > 0)
+      hipLaunchKernelGGL(k_assemble_fin2_short, dim3(dlg_cdiv(ns, TPB/64)), dim3(TPB), 0, st, Y->asm_fin2 + f0, ns,
+                         Y->asm_fin2_list, Y->asm_part, Y->Lx);
+    if(nl > 0)
+      hipLaunchKernelGGL(k_assemble_fin2_long, dim3(nl), dim3(1024), 0, st, Y->asm_fin2 + f0 + ns,
+                         Y->asm_fin2_list, Y->asm_part, Y->Lx);
+  }
+  const int nf = (int)H.asm_cfin.size();
+  if(nf > 0)
+    hipLaunchKernelGGL(k_assemble_fin, dim3(nf), dim3(1024), 0, st, Y->asm_cfin, Y->asm_slot,
+                       Y->asm_part, Y->Lx);
+  DLG_LAUNCH_CHECK();
+  return DLG_OK;
+}
+
+// Sharded rows: the partial JtJ of all ranks are summed before the factorisation.  Only the
+// structural non-zeros of JtJ travel (half of the panel buffer is fill and padding): the first
+// call finds them -- the assembly of an all-ones Jacobian, summed over the ranks once, is non-zero
+// exactly there on every rank -- and from then on the entries are packed, all-reduced, unpacked.
+namespace {
+__global__ void __launch_bounds__(TPB) k_fill(double* __restrict__ a, size_t n, double v)
+{ for(size_t i = blockIdx.x*(size_t)TPB + threadIdx.x; i < n; i += (size_t)gridDim.x*TPB) a[i] = v; }
+__global__ void __launch_bounds__(TPB) k_pack(const double* __restrict__ Lx, const uint32_t* __restrict__ idx, size_t n,
+                                              double* __restrict__ buf)
+{ for(size_t i = blockIdx.x*(size_t)TPB + threadIdx.x; i < n; i += (size_t)gridDim.x*TPB) buf[i] = Lx[idx[i]]; }
+__global__ void __launch_bounds__(TPB) k_unpack(double* __restrict__ Lx, const uint32_t* __restrict__ idx, size_t n,
+                                                const double* __restrict__ buf)
+{ for(size_t i = blockIdx.x*(size_t)TPB + threadIdx.x; i < n; i += (size_t)gridDim.x*TPB) Lx[idx[i]] = buf[i]; }
+}
+static int allreduce_panels(dlg_backend* b)
+{
+  SparseSym* Y = b->sym;
+  const SymHost& H = Y->H;
+  hipStream_t st = b->stream;
+  if(!b->allreduce) return DLG_OK;
+  if((size_t)H.lx_size >= ((size_t)1 << 32) || getenv("DOGLEG_AMD_ALLREDUCE_FULL"))
+    return dlg_allreduce_dev(b, Y->Lx, (size_t)H.lx_size);
+  if(!Y->ar_idx)
+  {
+    // (the caller's assembled panels are overwritten here: it assembles again afterwards)
+    double* ones = nullptr;
+    const size_t nv = Y->nnz_loc ? Y->nnz_loc : 1;
+    DLG_HIP(hipMalloc(&ones, sizeof(double)*nv));
+    hipLaunchKernelGGL(k_fill, dim3(1024), dim3(TPB), 0, st, ones, nv, 1.0);
+    int rc = assemble_launch(b, ones);
+    if(rc == DLG_OK) rc = dlg_allreduce_dev(b, Y->Lx, (size_t)H.lx_size);
+    std::vector<double> h((size_t)H.lx_size);
+    if(rc == DLG_OK && (hipMemcpyAsync(h.data(), Y->Lx, sizeof(double)*h.size(), hipMemcpyDeviceToHost, st) != hipSuccess ||
+                        hipStreamSynchronize(st) != hipSuccess))
+    { dlg_set_error("all-reduce index: download failed"); rc = DLG_ERR_HIP; }
+    (void)hipFree(ones);
+    DLG_CHECK(rc);
+    std::vector<uint32_t> idx;
+    idx.reserve((size_t)H.nnz_JtJ_lower + 16);
+    for(size_t i = 0; i < h.size(); i++) if(h[i] != 0.0) idx.push_back((uint32_t)i);
+    Y->ar_n = idx.size();
+    DLG_CHECK(upload(Y->ar_idx, idx)); Y->allocs.push_back(Y->ar_idx);
+    DLG_HIP(hipMalloc(&Y->ar_buf, sizeof(double)*(Y->ar_n ? Y->ar_n : 1))); Y->allocs.push_back(Y->ar_buf);
+    return 1;                                   // tell the caller to assemble again
+  }
+  hipLaunchKernelGGL(k_pack, dim3(2048), dim3(TPB), 0, st, Y->Lx, Y->ar_idx, Y->ar_n, Y->ar_buf);
+  DLG_LAUNCH_CHECK();
+  DLG_CHECK(dlg_allreduce_dev(b, Y->ar_buf, Y->ar_n));
+  hipLaunchKernelGGL(k_unpack, dim3(2048), dim3(TPB), 0, st, Y->Lx, Y->ar_idx, Y->ar_n, Y->ar_buf);
+  DLG_LAUNCH_CHECK();
+  return DLG_OK;
+}
+
 // K4: JtJ straight into the supernode panels, summed over the ranks, + lambda, + augmented row
 int sparse_assemble(dlg_backend* b, int s, double lambda)
 {
@@ -712,46 +811,18 @@ int sparse_assemble(dlg_backend* b, int s, double lambda)
   hipStream_t st = b->stream;
   {
     DlgProfScope pt(b, DLG_PROF_K4_TOTAL);
-    DLG_HIP(hipMemsetAsync(Y->Lx, 0, sizeof(double)*(size_t)H.lx_size, st));
-    const int nt = (int)H.asm_ctask.size(), nmt = (int)H.asm_mtask.size();
-    if(nt > 0 || nmt > 0)
-    {
-      DlgProfScope pk(b, DLG_PROF_K4_KERNEL);
-      if(nmt > 0)
-      {
-        const int nruns = (int)H.asm_run.size();
-        if(H.asm_lds_len == 18)
-          hipLaunchKernelGGL(HIP_KERNEL_NAME(k_assemble_mfma<18>), dim3(dlg_cdiv(nruns, TPB/64)), dim3(TPB),
-                             sizeof(double)*(TPB/64)*ASM_U*4*18, st, Y->asm_run, nruns, Y->asm_mtask,
-                             Y->asm_kg, Y->asm_shape, Y->asm_tdest, Y->asm_pdest, S.Jin(), Y->Lx, Y->asm_part, 18);
-        else
-          hipLaunchKernelGGL(HIP_KERNEL_NAME(k_assemble_mfma<0>), dim3(dlg_cdiv(nruns, TPB/64)), dim3(TPB),
-                             sizeof(double)*(TPB/64)*ASM_U*4*H.asm_lds_len, st, Y->asm_run, nruns, Y->asm_mtask,
-                             Y->asm_kg, Y->asm_shape, Y->asm_tdest, Y->asm_pdest, S.Jin(), Y->Lx, Y->asm_part,
-                             H.asm_lds_len);
-      }
-      if(nt > 0)
-        hipLaunchKernelGGL(k_assemble, dim3(dlg_cdiv(nt, TPB/64)), dim3(TPB), 0, st, Y->asm_ctask, nt,
-                           Y->asm_batch, Y->asm_rho, Y->asm_pair, Y->asm_slot, S.Jin(), Y->Lx, Y->asm_part);
-    }
-    for(size_t q = 0; q + 2 < H.fin2_stage.size(); q += 3)
-    {
-      const int f0 = H.fin2_stage[q], ns = H.fin2_stage[q+1], nl = H.fin2_stage[q+2];
-      if(ns > 0)
-        hipLaunchKernelGGL(k_assemble_fin2_short, dim3(dlg_cdiv(ns, TPB/64)), dim3(TPB), 0, st, Y->asm_fin2 + f0, ns,
-                           Y->asm_fin2_list, Y->asm_part, Y->Lx);
-      if(nl > 0)
-        hipLaunchKernelGGL(k_assemble_fin2_long, dim3(nl), dim3(1024), 0, st, Y->asm_fin2 + f0 + ns,
-                           Y->asm_fin2_list, Y->asm_part, Y->Lx);
-    }
-    const int nf = (int)H.asm_cfin.size();
-    if(nf > 0)
-      hipLaunchKernelGGL(k_assemble_fin, dim3(nf), dim3(1024), 0, st, Y->asm_cfin, Y->asm_slot,
-                         Y->asm_part, Y->Lx);
-    DLG_LAUNCH_CHECK();
+    DLG_CHECK(assemble_launch(b, S.Jin()));
   }
   // rows are sharded: sum the partial JtJ of all ranks before factorising
-  DLG_CHECK(dlg_allreduce_dev(b, Y->Lx, (size_t)H.lx_size));
+  {
+    const int rc = allreduce_panels(b);
+    if(rc == 1)
+    {
+      DLG_CHECK(assemble_launch(b, S.Jin()));
+      DLG_CHECK(allreduce_panels(b));
+    }
+    else DLG_CHECK(rc);
+  }
   if(lambda != 0.0)
     hipLaunchKernelGGL(k_add_lambda, dim3(dlg_cdiv(H.N, TPB)), dim3(TPB), 0, st, Y->Lx, Y->diagpos, H.N,
                        lambda);

@@ -94,6 +94,8 @@ struct SparseSym
   int *d_info = nullptr, *h_info = nullptr;   // pivot flag: inside the backend's scalar block (device / pinned host)
   bool info_armed = false;                    // the assembly re-armed the flag (k_set_aug_row)
   size_t nnz_loc = 0;
+  // sharded rows: positions of the structural non-zeros of JtJ in Lx (what the all-reduce carries)
+  uint32_t* ar_idx = nullptr; double* ar_buf = nullptr; size_t ar_n = 0;
   // per-level launch parameters
   std::vector<int> fac_lds;     // bytes of LDS for the factor kernel of a level (0: panels stay in HBM)
   std::vector<int> upd_lds, upd_nw, slv_lds, bwd_lds, fac_nt, upd_coop, syrk_lds, syrk_nt, syrk_kc, bwd_nt, syrk_fused, fin_ny, fac_stage, bwd_top, bwd_bd;
