@@ -115,9 +115,13 @@ def main():
                 self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f8",
                                                  "data": (ptr, False), "version": 3}
 
+        views = {}                            # (device pointer, count) -> tensor view: the buffers are few and fixed
+
         def hook(buf, count, cookie):
             try:
-                t = torch.as_tensor(_DevPtr(buf, count), device=dev)
+                t = views.get((buf, count))
+                if t is None:
+                    t = views[(buf, count)] = torch.as_tensor(_DevPtr(buf, count), device=dev)
                 dist.all_reduce(t, op=dist.ReduceOp.SUM)
                 torch.cuda.synchronize()
                 return 0
