@@ -50,7 +50,10 @@ enum { DLG_KIND_CAUCHY_TO_EDGE = 0, DLG_KIND_GAUSSNEWTON = 1, DLG_KIND_INTERPOLA
 enum
 {
   DLG_VEC_P = 0, DLG_VEC_X = 1, DLG_VEC_JTX = 2, DLG_VEC_CAUCHY = 3,
-  DLG_VEC_GN = 4, DLG_VEC_STEP = 5, DLG_VEC_J = 6
+  DLG_VEC_GN = 4, DLG_VEC_STEP = 5, DLG_VEC_J = 6,
+  /* dlg_point_device_ptr only: the slot's OWN x / J buffers (what a device-side evaluation writes
+   * before dlg_point_bind_device), whatever is bound at the moment */
+  DLG_VEC_X_OWN = 7, DLG_VEC_J_OWN = 8
 };
 
 const char* dlg_last_error(void);
@@ -154,8 +157,10 @@ int  dlg_step(dlg_backend_t* b, int from, int to, int kind, double trustregion,
  * of the kind of step (made on the device with the reference's comparisons, dogleg.c:1192-1256),
  * the step, its expected improvement and p_new.
  * out7 = {|cauchy|^2, |gn|^2, kind, |step|^2 (reference reporting), k_cauchy_to_gn, max|step|,
- * expected improvement}.  Computes the Gauss-Newton step even when the Cauchy step is taken.
- * Not available with row sharding (the all-reduce hooks need the host in between). --------- */
+ * expected improvement}.  The Gauss-Newton step is computed speculatively; if the Cauchy step is the
+ * one taken (kind == DLG_KIND_CAUCHY_TO_EDGE) it is discarded with its factorisation, *lambda_io is
+ * NOT modified (the reference does not factorise on that branch, dogleg.c:1192-1211) and
+ * out7[1] = NaN. --------------------------------------------------------------------------- */
 int  dlg_take_step(dlg_backend_t* b, int from, int to, double trustregion, double* lambda_io,
                    double* out7, double* p_new_host);
 

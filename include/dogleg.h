@@ -208,6 +208,44 @@ bool dogleg_computeJtJfactorization(dogleg_operatingPoint_t* point,
 
 void dogleg_freeContext(dogleg_solverContext_t** ctx);
 
+/* ---- extensions of this implementation (nothing below exists in the reference) -------------
+ *
+ * Device-side evaluation.  The reference evaluates the user's model on the host at
+ * every trial point (computeCallbackOperatingPoint, dogleg.c:1016-1022); here that means the
+ * Jacobian values cross PCIe once per evaluation, which is the end-to-end bottleneck once the
+ * kernels are fast.  A model that already lives on the GPU supplies a device callback instead:
+ *   p_dev     in : Nstate doubles, device memory
+ *   x_dev     out: Nmeas doubles, device memory (library-owned)
+ *   J_dev     out: sparse: the NJnnz values of Jt in the order of the pattern (column r of Jt =
+ *                  gradient of measurement r); dense: J[Nmeas][Nstate] row-major.  Device memory.
+ *   hip_stream   : the hipStream_t (as void*) the callback must enqueue its kernels on; the
+ *                  library orders its own work behind it on the same stream and the callback
+ *                  must not synchronise.
+ * dogleg_optimize_device2: the sparsity pattern of Jt is constant over a solve (as the reference
+ * assumes, dogleg.c:648-649), so it is given once, on the host (Jt_colptr[Nmeas+1],
+ * Jt_rowidx[NJnnz], row indices ascending within a column).  NJnnz == 0 and NULL pattern
+ * pointers select the dense path.  Everything else -- p in/out on the host, return value, the
+ * iterate sequence, returnContext -- is as dogleg_optimize2 / dogleg_optimize_dense2, except that
+ * the Jacobian values of a returned context stay on the device (point->Jt->x / J_dense == NULL;
+ * dlg_point_download(dogleg_amd_backend(ctx), slot, DLG_VEC_J, ...) fetches them). */
+typedef void (dogleg_callback_device_t)(const double* p_dev, double* x_dev, double* J_dev,
+                                        void* hip_stream, void* cookie);
+double dogleg_optimize_device2(double* p, unsigned int Nstate,
+                               unsigned int Nmeas, unsigned int NJnnz,
+                               const int* Jt_colptr, const int* Jt_rowidx,
+                               dogleg_callback_device_t* f, void* cookie,
+                               const dogleg_parameters2_t* parameters,
+                               dogleg_solverContext_t** returnContext);
+
+/* the device backend (include/dlg_backend.h) behind a returned context, and the backend slot of
+ * one of its operating points: what dlg_solve_with_factor / dlg_solve_multi /
+ * dlg_pseudoinverse_chunk / dlg_point_download need to work with the factor and the vectors that
+ * stay on the device after a solve (the reference hands out a cholmod_factor / LAPACK factor
+ * for the same purpose, dogleg.h:185-194) */
+struct dlg_backend;
+struct dlg_backend* dogleg_amd_backend(dogleg_solverContext_t* ctx);
+int dogleg_amd_point_slot(dogleg_solverContext_t* ctx, const dogleg_operatingPoint_t* point);
+
 /* gradient check of a callback (reference dogleg.h:312-322): prints, for variable `var`, the
  * reported d x[i] / d p[var] next to a central difference, one line per measurement, as a
  * vnlog-style table on stdout.  Host only. */

@@ -17,7 +17,7 @@ DLG_OK = 0
 DLG_DENSE, DLG_SPARSE, DLG_DENSE_PRODUCTS = 0, 1, 2
 FLAG_PACKED, FLAG_UPPER = 1, 2
 KIND_CAUCHY, KIND_GN, KIND_INTERP = 0, 1, 2
-VEC_P, VEC_X, VEC_JTX, VEC_CAUCHY, VEC_GN, VEC_STEP, VEC_J = range(7)
+VEC_P, VEC_X, VEC_JTX, VEC_CAUCHY, VEC_GN, VEC_STEP, VEC_J, VEC_X_OWN, VEC_J_OWN = range(9)
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_size_t, C.c_void_p)
 
@@ -44,6 +44,7 @@ DOGLEG_SYMBOLS = [
     "dogleg_optimize_dense2", "dogleg_optimize_dense_products", "dogleg_computeJtJfactorization",
     "dogleg_freeContext", "dogleg_testGradient", "dogleg_testGradient_dense",
     "dogleg_testGradient_dense_products",
+    "dogleg_optimize_device2", "dogleg_amd_backend", "dogleg_amd_point_slot",
 ]
 
 _lib = None
@@ -130,6 +131,12 @@ def lib():
     L.dogleg_optimize_dense_products.argtypes = [D, C.c_uint, V, V, PP, V]
     L.dogleg_freeContext.argtypes = [V]
     L.dogleg_freeContext.restype = None
+    L.dogleg_optimize_device2.restype = C.c_double
+    L.dogleg_optimize_device2.argtypes = [D, C.c_uint, C.c_uint, C.c_uint, I, I, V, V, PP, V]
+    L.dogleg_amd_backend.restype = V
+    L.dogleg_amd_backend.argtypes = [V]
+    L.dogleg_amd_point_slot.restype = C.c_int
+    L.dogleg_amd_point_slot.argtypes = [V, V]
     L.dogleg_setMaxIterations.argtypes = [C.c_int]
     L.dogleg_setDebug.argtypes = [C.c_int]
     L.dogleg_setInitialTrustregion.argtypes = [C.c_double]
@@ -166,6 +173,25 @@ def optimize(kind, p0, N, M, nnz, cb, cookie, params=None, capacity=256):
             r = L.dogleg_optimize_dense2(dptr(p), N, M, cb, cookie, prm, None)
         else:
             r = L.dogleg_optimize_dense_products(dptr(p), N, cb, cookie, prm, None)
+    finally:
+        L.dlg_set_trace(None)
+    return r, p, tr
+
+
+def optimize_device(p0, N, M, nnz, Jp, Ji, cb, cookie, params=None, capacity=256):
+    """dogleg_optimize_device2 (device-side evaluation) with a per-trial trace.  nnz == 0: dense
+    (Jp, Ji ignored).  cb: address of a dogleg_callback_device_t.  Returns (norm2x, p_final, TraceBuffer)."""
+    L = lib()
+    p = np.array(p0, dtype=np.float64, copy=True)
+    tr = TraceBuffer(N, capacity)
+    prm = C.byref(params) if params is not None else None
+    if nnz > 0:
+        Jp = np.ascontiguousarray(Jp, dtype=np.int32)
+        Ji = np.ascontiguousarray(Ji, dtype=np.int32)
+    L.dlg_set_trace(C.cast(tr.byref(), C.c_void_p))
+    try:
+        r = L.dogleg_optimize_device2(dptr(p), N, M, nnz, iptr(Jp) if nnz > 0 else None,
+                                      iptr(Ji) if nnz > 0 else None, cb, cookie, prm, None)
     finally:
         L.dlg_set_trace(None)
     return r, p, tr

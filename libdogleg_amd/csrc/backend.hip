@@ -635,8 +635,10 @@ extern "C" int dlg_step(dlg_backend_t* b, int from, int to, int kind, double tru
 // Cauchy step, factorise + solve (lambda loop as in dlg_gauss_newton), the choice between the three
 // kinds of step made on the device (k_take_step), the step, its expected improvement, p_new.
 // out = {|cauchy|^2, |gn|^2, kind, |step|^2 as the reference reports it, k_cauchy_to_gn, max|step|,
-// expected improvement}.  The Gauss-Newton step is computed even when the Cauchy step is the one
-// taken: for callers that expect to need it (the driver, once a step has needed it).
+// expected improvement}.  The Gauss-Newton step is computed speculatively (for callers that expect
+// to need it: the driver, once a step has needed it); when the Cauchy step turns out to be the one
+// taken it is discarded together with its factorisation and *lambda_io is left alone, as in the
+// reference, which does not factorise on that branch (|gn|^2 is then reported as NaN).
 extern "C" int dlg_take_step(dlg_backend_t* b, int from, int to, double trustregion, double* lambda_io,
                              double* out7, double* p_new_host)
 {
@@ -701,6 +703,21 @@ extern "C" int dlg_take_step(dlg_backend_t* b, int from, int to, double trustreg
     if(side_copy) DLG_HIP(hipEventSynchronize(b->ev_copy));
     if(b->profiling) dlg_prof_resolve(b);
     if(!F.have_cauchy) { F.norm2_cauchy = b->h_scal[6]; F.have_cauchy = true; }
+    if((int)b->h_scal[8] == DLG_KIND_CAUCHY_TO_EDGE)
+    {
+      // The Cauchy step was the one taken: the reference never factorises on this branch
+      // (dogleg.c:1192-1211), so the speculative Gauss-Newton work is dropped -- no cached factor,
+      // no cached GN step, and above all no change of the (sticky) lambda, whether or not the
+      // speculative factorisation succeeded.
+      b->factor_slot = -1;
+      F.have_gn = false;
+      out7[0] = F.norm2_cauchy; out7[1] = NAN; out7[2] = (double)DLG_KIND_CAUCHY_TO_EDGE;
+      out7[3] = F.norm2_cauchy;                                 // unscaled: dogleg.c:1200
+      out7[4] = NAN;
+      out7[5] = b->h_scal[2];
+      out7[6] = -2.0*b->h_scal[11] - b->h_scal[12];             // dogleg.c:1107-1109
+      return DLG_OK;
+    }
     good = (b->factor_slot == from) ? 1 : (b->type == DLG_SPARSE ? sparse_factor_ok(b) : dense_factor_ok(b));
     if(good) break;
     b->factor_slot = -1;
@@ -762,6 +779,8 @@ static double* slot_vec(dlg_backend* b, int s, int which, size_t* n)
   case DLG_VEC_GN:     return S.gn;
   case DLG_VEC_STEP:   return S.step;
   case DLG_VEC_J:      *n = j_doubles(b); return const_cast<double*>(S.Jin());
+  case DLG_VEC_X_OWN:  *n = (size_t)b->M; return S.x;
+  case DLG_VEC_J_OWN:  *n = j_doubles(b); return S.J;
   default:             return nullptr;
   }
 }

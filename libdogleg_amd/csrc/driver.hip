@@ -52,7 +52,8 @@ struct Driver
   bool pattern_set;
   cholmod_sparse jt[2];
   cholmod_dense  gn_dense[2];
-  cholmod_factor factor_handle;
+  cholmod_factor* factor_handle;               // opaque handle handed out as ctx->factorization (heap: never a by-value
+                                               // cholmod_factor, only its public fields n / minor are written)
   void* pinned[2][8];
   int   npinned[2];
   // trial record under construction
@@ -62,6 +63,9 @@ struct Driver
   int *pat_p, *pat_i;
   bool expect_gn;                              // the last step needed the Gauss-Newton step: issue it with the Cauchy step
   bool sharded;                                // an all-reduce hook is installed: the host sits between the ops
+  // device-side evaluation (dogleg_optimize_device2): the model runs on the GPU, x / J never cross PCIe
+  dogleg_callback_device_t* f_device;
+  const int *dev_cp, *dev_ri;                  // the caller's pattern (host), valid during the call
 };
 
 inline Driver* D(dogleg_solverContext_t* ctx) { return reinterpret_cast<Driver*>(ctx); }
@@ -167,8 +171,18 @@ dogleg_operatingPoint_t* alloc_point(Driver* d, int s)
     A->nrow = N; A->ncol = M; A->nzmax = d->nnz;
     A->p = pinned_alloc(d, s, sizeof(int)*(M + 1));
     A->i = pinned_alloc(d, s, sizeof(int)*(size_t)d->nnz);
-    A->x = pinned_alloc(d, s, sizeof(double)*(size_t)d->nnz);
-    if(!A->p || !A->i || !A->x) return nullptr;
+    if(!A->p || !A->i) return nullptr;
+    if(d->f_device)
+    {
+      // the values stay on the device; the pattern is the caller's
+      memcpy(A->p, d->dev_cp, sizeof(int)*(M + 1));
+      memcpy(A->i, d->dev_ri, sizeof(int)*(size_t)d->nnz);
+    }
+    else
+    {
+      A->x = pinned_alloc(d, s, sizeof(double)*(size_t)d->nnz);
+      if(!A->x) return nullptr;
+    }
     A->stype = 0; A->itype = CHOLMOD_INT; A->xtype = CHOLMOD_REAL; A->dtype = CHOLMOD_DOUBLE;
     A->sorted = 1; A->packed = 1;
     pt->Jt = A;
@@ -181,7 +195,9 @@ dogleg_operatingPoint_t* alloc_point(Driver* d, int s)
   else
   {
     if(type == DOGLEG_DENSE)
-    { pt->J_dense = (double*)pinned_alloc(d, s, sizeof(double)*M*N); if(!pt->J_dense) return nullptr; }
+    {
+      if(!d->f_device) { pt->J_dense = (double*)pinned_alloc(d, s, sizeof(double)*M*N); if(!pt->J_dense) return nullptr; }
+    }
     else
     {
       const size_t sz = d->pub.parameters->JtJ_packed ? N*(N+1)/2 : N*N;
@@ -219,7 +235,25 @@ bool eval_point(bool* converged, dogleg_operatingPoint_t* pt, Driver* d)
   memset(pt->dummy_bits, 0, sizeof(pt->dummy_bits));
   d->ncallbacks++;
   double norm2x = 0, absmax = 0;
-  if(ctx->solve_type == DOGLEG_SPARSE)
+  if(d->f_device)
+  {
+    // dogleg.c:1016-1022 with the model on the device: the callback writes x and the Jacobian
+    // values straight into the slot's HBM buffers, ordered on the backend's stream
+    if(ctx->solve_type == DOGLEG_SPARSE && !d->pattern_set)
+    {
+      if(!be_ok(dlg_sparse_set_pattern(d->be, d->dev_cp, d->dev_ri), "sparse symbolic analysis")) return false;
+      d->pattern_set = true;
+    }
+    const double* p_dev = (const double*)dlg_point_device_ptr(d->be, s, DLG_VEC_P);
+    double* x_dev = (double*)dlg_point_device_ptr(d->be, s, DLG_VEC_X_OWN);
+    double* J_dev = (double*)dlg_point_device_ptr(d->be, s, DLG_VEC_J_OWN);
+    (*d->f_device)(p_dev, x_dev, J_dev, dlg_backend_get_stream(d->be), ctx->cookie);
+    if(!be_ok(dlg_point_bind_device(d->be, s, x_dev, J_dev), "bind")) return false;
+    if(!be_ok(dlg_point_eval(d->be, s, &norm2x, &absmax), "Jt*x")) return false;
+    pt->norm2_x = norm2x;
+    pt->have_x = pt->have_J = pt->have_Jtx = true;
+  }
+  else if(ctx->solve_type == DOGLEG_SPARSE)
   {
     (*ctx->f)(pt->p, pt->x, pt->Jt, ctx->cookie);
     const int* cp = (const int*)pt->Jt->p; const int* ri = (const int*)pt->Jt->i;
@@ -281,18 +315,32 @@ bool compute_cauchy(dogleg_operatingPoint_t* pt, Driver* d)
   return true;
 }
 
+// ctx->factorization of a sparse solve (dogleg.h:185-190; the reference gets it from
+// cholmod_analyze, dogleg.c:650-654): an opaque, zero-filled cholmod_factor of which only the public
+// fields n and minor are maintained (minor == n <=> the last factorisation succeeded, dogleg.c:667).
+// The factor itself lives on the device; dogleg_amd_backend(ctx) + dlg_solve_with_factor use it.
+bool publish_factor_handle(Driver* d)
+{
+  dogleg_solverContext_t* ctx = &d->pub;
+  if(ctx->solve_type != DOGLEG_SPARSE || ctx->factorization) return true;
+  if(!d->factor_handle) d->factor_handle = (cholmod_factor*)calloc(1, sizeof(cholmod_factor));
+  if(!d->factor_handle) { MSG("out of memory"); return false; }
+  d->factor_handle->n = (size_t)ctx->Nstate; d->factor_handle->minor = 0;
+  ctx->factorization = d->factor_handle;
+  return true;
+}
+void factor_handle_ok(Driver* d)
+{
+  if(d->pub.solve_type == DOGLEG_SPARSE && d->factor_handle) d->factor_handle->minor = d->factor_handle->n;
+}
+
 bool factorize(dogleg_operatingPoint_t* pt, Driver* d)
 {
   dogleg_solverContext_t* ctx = &d->pub;
   if(pt->have_factorization) return true;                      // dogleg.c:637
   if(ctx->solve_type == DOGLEG_DENSE_PRODUCTS ? !pt->have_JtJ : !pt->have_J)
   { MSG("factorization needs J (or JtJ), which is missing"); return false; }
-  if(ctx->solve_type == DOGLEG_SPARSE && ctx->factorization == nullptr)
-  {
-    d->factor_handle.n = (size_t)ctx->Nstate; d->factor_handle.minor = 0;
-    d->factor_handle.backend = d->be;
-    ctx->factorization = &d->factor_handle;                    // dogleg.c:650-654
-  }
+  if(!publish_factor_handle(d)) return false;                  // dogleg.c:650-654
   while(true)
   {
     int ok = 0;
@@ -302,7 +350,7 @@ bool factorize(dogleg_operatingPoint_t* pt, Driver* d)
     if(!std::isfinite(ctx->lambda)) { MSG("lambda overflowed while regularising a singular JtJ"); return false; }
     VERBOSE(d, "singular JtJ: adding %g I from now on", ctx->lambda);
   }
-  if(ctx->solve_type == DOGLEG_SPARSE) d->factor_handle.minor = d->factor_handle.n;
+  factor_handle_ok(d);
   pt->have_factorization = true;
   return true;
 }
@@ -321,16 +369,11 @@ bool compute_gn(dogleg_operatingPoint_t* pt, Driver* d)
       dogleg_solverContext_t* ctx = &d->pub;
       if(ctx->solve_type == DOGLEG_DENSE_PRODUCTS ? !pt->have_JtJ : !pt->have_J)
       { MSG("factorization needs J (or JtJ), which is missing"); return false; }
-      if(ctx->solve_type == DOGLEG_SPARSE && ctx->factorization == nullptr)
-      {
-        d->factor_handle.n = (size_t)ctx->Nstate; d->factor_handle.minor = 0;
-        d->factor_handle.backend = d->be;
-        ctx->factorization = &d->factor_handle;                  // dogleg.c:650-654
-      }
+      if(!publish_factor_handle(d)) return false;                // dogleg.c:650-654
       const double lambda_before = ctx->lambda;
       if(!be_ok(dlg_gauss_newton(d->be, slot_of(d, pt), &ctx->lambda, &n2), "factorization + GN solve")) return false;
       if(ctx->lambda != lambda_before) VERBOSE(d, "singular JtJ: adding %g I from now on", ctx->lambda);
-      if(ctx->solve_type == DOGLEG_SPARSE) d->factor_handle.minor = d->factor_handle.n;
+      factor_handle_ok(d);
       pt->have_factorization = true;
     }
     else if(!be_ok(dlg_solve_gn(d->be, slot_of(d, pt), &n2), "GN solve")) return false;
@@ -358,7 +401,7 @@ bool take_step(double* expectedImprovement, dogleg_operatingPoint_t* to,
   // takeStepFrom for a fresh point -- both steps, the choice between them (same comparisons, made
   // on the device), the step, its expected improvement, p_new -- is ONE backend op behind one host
   // synchronisation; the values are the same, and a Gauss-Newton step the reference would not have
-  // computed is simply not used (nor reported).
+  // computed is discarded by the backend: neither cached nor reported, and lambda keeps its value.
   int kind;
   double n2 = 0, k = NAN, amax = 0;
   const bool fresh = !from->have_updateCauchy && !from->have_updateGN && !from->have_factorization;
@@ -367,23 +410,23 @@ bool take_step(double* expectedImprovement, dogleg_operatingPoint_t* to,
     if(!from->have_Jtx) { MSG("Cauchy step needs Jt_x, which is missing"); return false; }
     if(ctx->solve_type == DOGLEG_DENSE_PRODUCTS ? !from->have_JtJ : !from->have_J)
     { MSG("factorization needs J (or JtJ), which is missing"); return false; }
-    if(ctx->solve_type == DOGLEG_SPARSE && ctx->factorization == nullptr)
-    {
-      d->factor_handle.n = (size_t)ctx->Nstate; d->factor_handle.minor = 0;
-      d->factor_handle.backend = d->be;
-      ctx->factorization = &d->factor_handle;                    // dogleg.c:650-654
-    }
     double o[7];
     const double lambda_before = ctx->lambda;
     if(!be_ok(dlg_take_step(d->be, sf, st, trustregion, &ctx->lambda, o, to->p), "step")) return false;
     if(ctx->lambda != lambda_before) VERBOSE(d, "singular JtJ: adding %g I from now on", ctx->lambda);
-    if(ctx->solve_type == DOGLEG_SPARSE) d->factor_handle.minor = d->factor_handle.n;
     from->norm2_updateCauchy = o[0]; from->have_updateCauchy = true;
-    from->norm2_updateGN = o[1]; from->have_updateGN = true; from->have_factorization = true;
     d->cur.norm2_cauchy = o[0];
     VERBOSE(d, "cauchy step length %.6g", sqrt(o[0]));
     kind = (int)o[2]; n2 = o[3]; k = o[4]; amax = o[5]; *expectedImprovement = o[6];
-    if(kind != DLG_KIND_CAUCHY_TO_EDGE) { d->cur.norm2_gn = o[1]; VERBOSE(d, "gn step length %.6g", sqrt(o[1])); }
+    if(kind != DLG_KIND_CAUCHY_TO_EDGE)
+    {
+      // (on the Cauchy branch the backend dropped its speculative factor and GN step and left
+      // lambda alone: dogleg.c:1192-1211 never gets to compute_updateGN)
+      if(!publish_factor_handle(d)) return false;                // dogleg.c:650-654
+      factor_handle_ok(d);
+      from->norm2_updateGN = o[1]; from->have_updateGN = true; from->have_factorization = true;
+      d->cur.norm2_gn = o[1]; VERBOSE(d, "gn step length %.6g", sqrt(o[1]));
+    }
     d->cur.step_type = (kind == DLG_KIND_CAUCHY_TO_EDGE) ? DLG_STEP_CAUCHY : (kind == DLG_KIND_GAUSSNEWTON ? DLG_STEP_GAUSSNEWTON : DLG_STEP_INTERPOLATED);
     from->didStepToEdgeOfTrustRegion = (kind != DLG_KIND_GAUSSNEWTON);
     d->expect_gn = (kind != DLG_KIND_CAUCHY_TO_EDGE);
@@ -530,6 +573,7 @@ void sync_point_to_host(Driver* d, dogleg_operatingPoint_t* pt)
   if(pt->have_updateCauchy) dlg_point_download(d->be, s, DLG_VEC_CAUCHY, pt->updateCauchy, N);
   if(pt->have_updateGN)     dlg_point_download(d->be, s, DLG_VEC_GN, gn_host(d, pt), N);
   dlg_point_download(d->be, s, DLG_VEC_STEP, pt->step_to_here, N);
+  if(d->f_device && pt->have_x) dlg_point_download(d->be, s, DLG_VEC_X, pt->x, (size_t)d->pub.Nmeasurements);
 }
 
 void destroy(Driver* d)
@@ -538,6 +582,7 @@ void destroy(Driver* d)
   free_point(d, 0); free_point(d, 1);
   if(d->pub.solve_type != DOGLEG_SPARSE) free(d->pub.factorization_dense);
   if(d->be) dlg_backend_destroy(d->be);
+  free(d->factor_handle);
   free(d->pat_p); free(d->pat_i);
   free(d);
 }
@@ -546,10 +591,13 @@ void destroy(Driver* d)
 double optimize(double* p, unsigned int Nstate, unsigned int Nmeas, unsigned int NJnnz,
                 dogleg_callback_t* f, dogleg_callback_dense_t* f_dense,
                 dogleg_callback_dense_products_t* f_products, void* cookie,
-                const dogleg_parameters2_t* parameters, dogleg_solverContext_t** returnContext)
+                const dogleg_parameters2_t* parameters, dogleg_solverContext_t** returnContext,
+                dogleg_callback_device_t* f_device = nullptr, const int* dev_cp = nullptr,
+                const int* dev_ri = nullptr)
 {
   Driver* d = (Driver*)calloc(1, sizeof(Driver));
   if(!d) { MSG("out of memory"); return -1.0; }
+  d->f_device = f_device; d->dev_cp = dev_cp; d->dev_ri = dev_ri;
   dogleg_solverContext_t* ctx = &d->pub;
   ctx->cookie = cookie;
   ctx->lambda = 0.0;
@@ -560,7 +608,19 @@ double optimize(double* p, unsigned int Nstate, unsigned int Nmeas, unsigned int
   const char* chk = getenv("DOGLEG_AMD_CHECK_PATTERN");
   d->check_pattern = chk && chk[0] == '1';
 
-  if(f)
+  if(f_device)
+  {
+    // ctx->f stays NULL: the device callback has another signature and lives in the driver
+    if(NJnnz > 0)
+    {
+      ctx->solve_type = DOGLEG_SPARSE;
+      if(!dev_cp || !dev_ri) { MSG("a sparse device solve needs the pattern of Jt"); free(d); return -1.0; }
+      if(dev_cp[0] != 0 || dev_cp[Nmeas] != (int)NJnnz)
+      { MSG("the pattern has %d entries, NJnnz says %u", dev_cp[Nmeas], NJnnz); free(d); return -1.0; }
+    }
+    else ctx->solve_type = DOGLEG_DENSE;
+  }
+  else if(f)
   {
     ctx->solve_type = DOGLEG_SPARSE; ctx->f = f;
     if(NJnnz == 0) { MSG("sparse solves need NJnnz > 0"); free(d); return -1.0; }
@@ -690,6 +750,16 @@ double dogleg_optimize_dense(double* p, unsigned int Nstate, unsigned int Nmeas,
 {
   return dogleg_optimize_dense2(p, Nstate, Nmeas, f, cookie, nullptr, returnContext);
 }
+double dogleg_optimize_device2(double* p, unsigned int Nstate, unsigned int Nmeas, unsigned int NJnnz,
+                               const int* Jt_colptr, const int* Jt_rowidx,
+                               dogleg_callback_device_t* f, void* cookie,
+                               const dogleg_parameters2_t* parameters,
+                               dogleg_solverContext_t** returnContext)
+{
+  if(!f) { MSG("dogleg_optimize_device2 needs a device callback"); return -1.0; }
+  return optimize(p, Nstate, Nmeas, NJnnz, nullptr, nullptr, nullptr, cookie, parameters, returnContext,
+                  f, Jt_colptr, Jt_rowidx);
+}
 double dogleg_optimize_dense_products(double* p, unsigned int Nstate,
                                       dogleg_callback_dense_products_t* f, void* cookie,
                                       const dogleg_parameters2_t* parameters,
@@ -711,6 +781,12 @@ bool dogleg_computeJtJfactorization(dogleg_operatingPoint_t* point, dogleg_solve
   }
   return true;
 }
+
+// extension (not in the reference): the device backend behind a returned context, for
+// dlg_solve_with_factor / dlg_point_download on the resident factor and vectors
+dlg_backend_t* dogleg_amd_backend(dogleg_solverContext_t* ctx) { return ctx ? D(ctx)->be : nullptr; }
+int dogleg_amd_point_slot(dogleg_solverContext_t* ctx, const dogleg_operatingPoint_t* point)
+{ return (ctx && point) ? slot_of(D(ctx), point) : -1; }
 
 void dogleg_freeContext(dogleg_solverContext_t** ctx)
 {

@@ -395,7 +395,7 @@ int k_interpolate(dlg_backend* b, const double* a, const double* bb, double norm
 int k_negate_interp1(dlg_backend* b, double* gn, const double* cauchy, int n, double* gnpart, int* nb)
 {
   const int g = grid_for(n);
-  DLG_CHECK(dlg_ensure_partials(b, 4*MAXB));
+  DLG_CHECK(dlg_ensure_partials(b, 5*MAXB));      // k_take_step's layout: no reallocation between the two
   hipLaunchKernelGGL(k_part_negate_interp1, dim3(g), dim3(TPB), 0, b->stream, gn, cauchy, n, gnpart, b->d_part);
   DLG_LAUNCH_CHECK();
   *nb = g;
@@ -407,11 +407,13 @@ int k_take_step(dlg_backend* b, const double* cauchy, const double* gn, const do
                 double* out_n2_max, double* out3, const double* Jtx, double* out_inner)
 {
   const int g = grid_for(n);
-  DLG_CHECK(dlg_ensure_partials(b, 4*MAXB));
+  // d_part: [0, 2g) pass-1 partials (k_negate_interp1), [2g, 4g) |step|^2 and max|step|, and the
+  // <Jt x, step> partials in a region of their own behind 4*MAXB (g can be MAXB)
+  DLG_CHECK(dlg_ensure_partials(b, 5*MAXB));
   double* part2 = b->d_part + 2*g;
   double* hp = dlg_host_partials(b, out_n2_max, g, 1, 1, 2);
   double* hg = hp ? dlg_host_partials(b, out_inner, g, 1, 0, 1) : nullptr;
-  double* gp = hg ? hg : b->d_part + 3*MAXB;
+  double* gp = hg ? hg : b->d_part + 4*MAXB;
   hipLaunchKernelGGL(k_part_take_step, dim3(g), dim3(TPB), 0, b->stream, cauchy, gn, b->d_part, g, gnpart, nbg,
                      n2c_dev, trustregion, p, step, p_new, n, hp ? hp : part2, out3, Jtx, gp);
   if(!hp) hipLaunchKernelGGL(k_final, dim3(1), dim3(TPB), 0, b->stream, part2, g, 1, 1, out_n2_max, 2);

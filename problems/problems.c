@@ -269,6 +269,10 @@ void synth_p0    (const synth_t* S, double* out)
   for(int j = 0; j < S->N; j++)
     out[j] = S->pstar[j] + S->p0_spread * urand(S->seed, 4, (uint64_t)j);
 }
+/* the coefficients a[nnz] of a ba problem (for the device twin, problems/device_problems.hip) */
+void synth_coefs(const synth_t* S, double* out) { memcpy(out, S->a, sizeof(double)*(size_t)S->nnz); }
+void synth_model(const synth_t* S, double* eps_noise2, uint64_t* seed)
+{ eps_noise2[0] = S->eps; eps_noise2[1] = S->noise; *seed = S->seed; }
 void synth_pattern(const synth_t* S, int* Jp, int* Ji)
 {
   memcpy(Jp, S->Jp, sizeof(int)*((size_t)S->M+1));

@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/splu_config3_step.json: one full trial step of BASELINE.json
+config #3 (200k measurements x 30k parameters, 3M non-zeros; problems.c generator, seed 11)
+computed WITHOUT the oracle and without the product -- numpy + scipy's SuperLU with extended
+precision iterative refinement (tests/independent.py).  Both the oracle (CPU test) and the HIP
+path (-m gpu test) are compared with it at the 1e-10 parity bar: an independent pin of the sparse
+factor / solve arithmetic that the reference delegates to CHOLMOD.
+
+Data only: hex floats of the Gauss-Newton step, the Cauchy scalars and the interpolated step.
+Run here (scipy 1.15.3):  python tests/golden/make_independent_goldens.py   (about a minute)
+"""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import numpy as np
+import scipy
+from tests import oracle_api as oa          # only for the PROBLEM generator (problems.c); no oracle call
+from tests import independent as ind
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def hexlist(a):
+    return [float(v).hex() for v in np.asarray(a).ravel()]
+
+
+def main():
+    args = dict(Nc=499, Np=9000, Nobs=100000, seed=11)
+    prob = oa.BAProblem(args["Nc"], args["Np"], args["Nobs"], seed=args["seed"])
+    Jp, Ji = prob.pattern()
+    p = prob.p0()
+    x, Jx = prob.eval(p)
+    J = ind.csr_from_pattern(prob.M, prob.N, Jp, Ji, Jx)
+    g = np.asarray(J.T @ x).ravel()
+    gn = ind.gn_sparse_splu(J, g, 0.0, refine=3)
+    # the same trust region bench.py / orc_step_sparse use: mean(|cauchy|, |gn|) -> interpolation
+    Jg = np.asarray(J @ g).ravel()
+    kc = -float(g @ g) / float(Jg @ Jg)
+    n2c = kc * kc * float(g @ g)
+    tr = 0.5 * (np.sqrt(n2c) + np.sqrt(float(gn @ gn)))
+    st = ind.trial_step(J, x, tr, 0.0)
+    # residual of the refined solve, in extended precision: how exact the fixture is
+    A = (J.T @ J).tocoo()
+    res = g.astype(np.longdouble).copy()
+    np.add.at(res, A.row, A.data.astype(np.longdouble) * gn.astype(np.longdouble)[A.col])
+    out = {
+        "_generator": "tests/golden/make_independent_goldens.py: numpy %s + scipy %s SuperLU (MMD_AT_PLUS_A, symmetric mode) "
+                      "+ 3 rounds of long-double iterative refinement; problem = problems.c BAProblem(%d,%d,%d,seed=%d) at p0"
+                      % (np.__version__, scipy.__version__, args["Nc"], args["Np"], args["Nobs"], args["seed"]),
+        "problem": args, "N": prob.N, "M": prob.M, "nnz": prob.nnz,
+        "norm2_x": float(x @ x).hex(),
+        "norm2_cauchy": float(n2c).hex(),
+        "norm2_gn": float(gn @ gn).hex(),
+        "trustregion": float(tr).hex(),
+        "kind": int(st["kind"]), "k": float(st["k"]).hex(),
+        "expected_improvement": float(st["expected_improvement"]).hex(),
+        "relative_residual_of_gn": float(np.sqrt(float(res @ res)) / np.linalg.norm(g)),
+        "gn_hex": hexlist(gn),
+        "step_hex": hexlist(st["step"]),
+    }
+    json.dump(out, open(os.path.join(HERE, "splu_config3_step.json"), "w"), indent=0)
+    print("written; relative residual of the refined GN solve:", out["relative_residual_of_gn"])
+
+
+if __name__ == "__main__":
+    main()

@@ -13,6 +13,7 @@ from libdogleg_amd.ctypes_defs import (Parameters2, CholmodSparse, Trace, TraceB
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 _ORACLE = os.path.join(ROOT, "oracle", "liboracle.so")
 _PROBLEMS = os.path.join(ROOT, "problems", "libproblems.so")
+_PROBLEMS_DEV = os.path.join(ROOT, "problems", "libproblems_dev.so")
 
 
 def build():
@@ -111,8 +112,67 @@ def problems():
         L.synth_ba_eval.argtypes = [V, D, D, D]
         L.synth_cb_dense.argtypes = [D, D, D, V]
         L.synth_set_products_layout.argtypes = [C.c_int, C.c_int]
+        L.synth_coefs.argtypes = [V, D]
+        L.synth_model.argtypes = [V, D, C.POINTER(C.c_uint64)]
         _libs["p"] = L
     return _libs["p"]
+
+
+def device_problems():
+    """problems/libproblems_dev.so: the synthetic problems evaluated on the GPU
+    (dogleg_callback_device_t).  Needs a HIP device at call time, not at load time."""
+    if "d" not in _libs:
+        if _stale(_PROBLEMS_DEV, os.path.join(ROOT, "problems", "device_problems.hip")):
+            build()
+        L = C.CDLL(_PROBLEMS_DEV)
+        D, I, V = C.POINTER(C.c_double), C.POINTER(C.c_int), C.c_void_p
+        L.synth_dev_create_ba.restype = V
+        L.synth_dev_create_ba.argtypes = [C.c_int, C.c_int, C.c_int, I, I, D, D, C.c_double, C.c_double, C.c_uint64]
+        L.synth_dev_create_dense.restype = V
+        L.synth_dev_create_dense.argtypes = [C.c_int, C.c_int, D, C.c_double, C.c_double, C.c_uint64]
+        L.synth_dev_free.argtypes = [V]
+        L.synth_dev_neval.argtypes = [V]
+        L.synth_dev_neval.restype = C.c_int
+        _libs["d"] = L
+    return _libs["d"]
+
+
+class DeviceTwin:
+    """The GPU-resident twin of a BAProblem / DenseProblem: same model, evaluated by a
+    dogleg_callback_device_t (problems/device_problems.hip)."""
+
+    def __init__(self, prob):
+        self.lib = device_problems()
+        en = np.zeros(2)
+        seed = C.c_uint64()
+        prob.lib.synth_model(prob.h, dptr(en), C.byref(seed))
+        pstar = np.zeros(prob.N)
+        prob.lib.synth_pstar(prob.h, dptr(pstar))
+        if isinstance(prob, BAProblem):
+            Jp, Ji = prob.pattern()
+            a = np.zeros(prob.nnz)
+            prob.lib.synth_coefs(prob.h, dptr(a))
+            self.h = self.lib.synth_dev_create_ba(prob.N, prob.M, prob.nnz, iptr(Jp), iptr(Ji), dptr(a),
+                                                  dptr(pstar), en[0], en[1], seed.value)
+        else:
+            self.h = self.lib.synth_dev_create_dense(prob.N, prob.M, dptr(pstar), en[0], en[1], seed.value)
+        assert self.h, "device problem creation failed"
+        self.cb = fn_addr(self.lib, "synth_cb_device")
+        self.cookie = C.c_void_p(self.h)
+
+    def neval(self):
+        return self.lib.synth_dev_neval(self.h)
+
+    def close(self):
+        if self.h:
+            self.lib.synth_dev_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def fn_addr(lib, name):

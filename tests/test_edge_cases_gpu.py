@@ -160,3 +160,80 @@ def test_legacy_entry_points_use_the_global_parameters(gpu):
         L.dogleg_setTrustregionUpdateParameters(d.trustregion_decrease_factor, d.trustregion_decrease_threshold,
                                                 d.trustregion_increase_factor, d.trustregion_increase_threshold)
         L.dogleg_setThresholds(d.Jt_x_threshold, d.update_threshold, d.trustregion_threshold)
+
+
+@pytest.mark.parametrize("kind", ["dense", "sparse"])
+def test_cauchy_step_at_a_singular_point_leaves_lambda_alone(gpu, kind):
+    """dogleg.c:1192-1211: when the Cauchy step reaches the edge of the trust region the reference
+    never factorises, so a JtJ that is singular only at such a point must not raise the (sticky)
+    lambda.  The driver's one-round-trip path factorises speculatively once a step has needed the
+    Gauss-Newton step; it has to drop that work -- the lambda column of the trace and every later
+    Gauss-Newton step must equal the oracle's.
+
+    The callback keys the Jacobian on the evaluation count: evaluation `sing` returns a tiny J
+    (=> a huge Cauchy step, far outside the trust region) with an exactly-zero column."""
+    rng = np.random.default_rng(11)
+    M, N = 40, 6
+    J0 = rng.standard_normal((M, N))
+    J0[:, 0] *= 30.0                      # ill-scaled: |cauchy| << |gn| => rejected GN, then interpolation
+    xs = rng.standard_normal(M) * 5.0
+    state = {"n": 0, "sing": -1}
+
+    def model(pv):
+        r = J0 @ pv - xs
+        x = r + 0.4 * np.sin(r)
+        J = J0 * (1.0 + 0.4 * np.cos(r))[:, None]
+        if state["n"] == state["sing"]:
+            J = J * 1e-4
+            J[:, N - 1] = 0.0
+        state["n"] += 1
+        return x, J
+
+    if kind == "dense":
+        @capi.CB_DENSE
+        def cb(p, x, J, cookie):
+            xv, Jv = model(np.ctypeslib.as_array(p, shape=(N,)).copy())
+            np.ctypeslib.as_array(x, shape=(M,))[:] = xv
+            np.ctypeslib.as_array(J, shape=(M * N,))[:] = Jv.ravel()
+    else:
+        @capi.CB_SPARSE
+        def cb(p, x, Jt, cookie):
+            xv, Jv = model(np.ctypeslib.as_array(p, shape=(N,)).copy())
+            np.ctypeslib.as_array(x, shape=(M,))[:] = xv
+            A = Jt.contents
+            np.ctypeslib.as_array(C.cast(A.p, C.POINTER(C.c_int)), shape=(M + 1,))[:] = np.arange(0, (M + 1) * N, N)
+            np.ctypeslib.as_array(C.cast(A.i, C.POINTER(C.c_int)), shape=(M * N,))[:] = np.tile(np.arange(N), M)
+            np.ctypeslib.as_array(C.cast(A.x, C.POINTER(C.c_double)), shape=(M * N,))[:] = Jv.ravel()
+    addr = C.cast(cb, C.c_void_p)
+    nnz = M * N if kind == "sparse" else 0
+    prm = oa.default_params()
+    prm.max_iterations = 12
+    p0 = np.full(N, 2.0)
+
+    # find an evaluation at which the oracle (a) has already taken a step that needed the GN step
+    # and (b) takes a Cauchy step from the point evaluated there
+    hit = None
+    for sing in range(1, 8):
+        state.update(n=0, sing=sing)
+        ro, po, tro = oa.oracle_solve(kind, p0, N, M, nnz, addr, None, prm)
+        tt = tro.trials()
+        # trial t is taken from the point of the last accepted evaluation before it; evaluation e+1
+        # is made by trial e
+        seen_gn = False
+        for e, t in enumerate(tt):
+            if e + 1 == sing and t["accepted"] == 1 and seen_gn and e + 1 < len(tt) and tt[e + 1]["step_type"] == 0:
+                hit = sing
+            if t["step_type"] != 0:
+                seen_gn = True
+        if hit:
+            break
+    assert hit is not None, "the test problem no longer produces a Cauchy step after a Gauss-Newton one"
+    assert all(t["lambda_"] == 0.0 for t in tt[:hit + 1]), "the oracle must not have factorised at the singular point"
+
+    state.update(n=0, sing=hit)
+    ro, po, tro = oa.oracle_solve(kind, p0, N, M, nnz, addr, None, prm)
+    state.update(n=0, sing=hit)
+    rg, pg, trg = capi.optimize(kind, p0, N, M, nnz, addr, None, prm)
+    assert [t["lambda_"] for t in trg.trials()] == [t["lambda_"] for t in tro.trials()]
+    compare_traces(trg, tro, step_tol=1e-9)          # the tiny-J point makes one huge, clipped Cauchy step
+    assert np.max(np.abs(pg - po)) <= 1e-9

@@ -194,3 +194,115 @@ def test_committed_oracle_goldens_are_current():
     assert tr.ntrials == len(g["trials"])
     for i, t in enumerate(g["trials"]):
         assert [float(v).hex() for v in tr.step[i]] == t["step_hex"]
+
+
+# ---------------------------------------------------------------------------------------------
+# Pinning at the 1e-10 bar with an independent leg (tests/independent.py): the REAL LAPACK
+# routines the reference calls (scipy.linalg.lapack.dpptrf/dpptrs/dpotrf/dpotrs = dogleg.c:782,
+# 875, 801, 889) on the dense paths, scipy's SuperLU with extended-precision refinement where the
+# reference calls CHOLMOD (dogleg.c:659-664, 853).  Every trial step of an oracle trace is
+# re-derived from the problem's x and J with numpy + those libraries only.
+from tests import independent as ind
+
+
+def _rederive_trace(tr, eval_at, sparse_pattern=None, step_tol=1e-10, dense_packed=True):
+    """eval_at(p) -> (x, J) with J dense (M,N) or the CSC values of Jt.  Returns the worst
+    |step_oracle - step_independent|_2 over the trials."""
+    worst = 0.0
+    for i, t in enumerate(tr.trials()):
+        p_from = tr.p_trial[i] - tr.step[i]
+        x, J = eval_at(p_from)
+        if sparse_pattern is not None:
+            Jp, Ji, M, N = sparse_pattern
+            J = ind.csr_from_pattern(M, N, Jp, Ji, J)
+        st = ind.trial_step(J, x, t["trustregion_before"], t["lambda_"], dense_packed)
+        assert st["kind"] == t["step_type"], f"trial {i}: step kind {t['step_type']} vs independent {st['kind']}"
+        d = float(np.linalg.norm(st["step"] - tr.step[i]))
+        worst = max(worst, d)
+        assert d <= step_tol, f"trial {i}: |step - independent| = {d:.3e}"
+        ei = t["expected_improvement"]
+        assert abs(st["expected_improvement"] - ei) <= 1e-9 * max(1.0, abs(ei)), f"trial {i}: expected improvement"
+        # step lengths: relative, with the absolute parity bar as the floor (a converged solve ends
+        # with steps of 1e-10 and below, made of rounding noise of the gradient)
+        close = lambda u, v: abs(math.sqrt(u) - math.sqrt(v)) <= 1e-10 + 1e-9 * math.sqrt(v)
+        assert close(st["norm2_cauchy"], t["norm2_cauchy"])
+        if st["kind"] != 0:
+            assert close(st["norm2_gn"], t["norm2_gn"])
+    return worst
+
+
+@pytest.mark.parametrize("kind", ["dense", "sparse", "products_packed_upper", "products_unpacked"])
+def test_oracle_sample_trace_rederived_with_real_lapack(kind):
+    """config #1 (the reference's bundled problem), all four modes of check.sh: every trial of the
+    oracle's solve against LAPACK dpptrf/dpptrs (dpotrf/dpotrs for unpacked products, as
+    dogleg.c:801,889) on the same x, J"""
+    P, p0, prm, cookie, cb, k = _sample_setup(kind)
+    r, p, tr = oa.oracle_solve(k, p0, 6, 100, 600 if kind == "sparse" else 0, cb, cookie, prm)
+    assert r >= 0 and tr.ntrials == 8
+
+    def eval_at(pv):
+        x = np.zeros(100)
+        J = np.zeros((100, 6))
+        P.sample_cb_dense(dptr(np.ascontiguousarray(pv)), dptr(x), dptr(J), None)
+        return x, J
+    w = _rederive_trace(tr, eval_at, dense_packed=(kind != "products_unpacked"))
+    print(f"sample {kind}: {tr.ntrials} trials, worst |step - LAPACK re-derivation| = {w:.2e}")
+
+
+def test_oracle_dense_trace_rederived_with_real_lapack():
+    dp = oa.DenseProblem(M=300, N=24, seed=9, eps=0.4, p0_spread=0.8)
+    prm = oa.default_params()
+    prm.max_iterations = 12
+    prm.trustregion0 = 0.5
+    r, p, tr = oa.oracle_solve("dense", dp.p0(), dp.N, dp.M, 0, dp.cb, dp.cookie, prm)
+    assert {t["step_type"] for t in tr.trials()} >= {1, 2} or tr.ntrials > 3
+    w = _rederive_trace(tr, dp.eval)
+    print(f"dense 300x24: {tr.ntrials} trials, worst = {w:.2e}")
+
+
+@pytest.mark.parametrize("args,prmset", [
+    (dict(Nc=4, Np=20, Nobs=60, seed=2, eps=0.4, p0_spread=0.8), dict(max_iterations=15, trustregion0=1.0)),
+    (dict(Nc=12, Np=120, Nobs=720, seed=4, eps=0.4, p0_spread=0.6), dict(max_iterations=10, trustregion0=3.0)),
+    (dict(Nc=49, Np=900, Nobs=10000, seed=3), dict(max_iterations=6)),
+], ids=["ba-tiny", "ba-small", "ba-medium"])
+def test_oracle_sparse_trace_rederived_with_superlu(args, prmset):
+    """the oracle's sparse Cholesky (the CHOLMOD stand-in) against SuperLU + refinement, trial by trial"""
+    prob = oa.BAProblem(args.pop("Nc"), args.pop("Np"), args.pop("Nobs"), **args)
+    prm = oa.default_params()
+    for k, v in prmset.items():
+        setattr(prm, k, v)
+    r, p, tr = oa.oracle_solve("sparse", prob.p0(), prob.N, prob.M, prob.nnz, prob.cb, prob.cookie, prm)
+    assert r >= 0
+    Jp, Ji = prob.pattern()
+    w = _rederive_trace(tr, prob.eval, sparse_pattern=(Jp, Ji, prob.M, prob.N))
+    print(f"BA {prob.N} vars: {tr.ntrials} trials, kinds {sorted({t['step_type'] for t in tr.trials()})}, worst = {w:.2e}")
+
+
+def test_oracle_matches_the_independent_config3_fixture():
+    """BASELINE.json config #3 at full size: the oracle's sparse step against the committed
+    SuperLU fixture (tests/golden/splu_config3_step.json, make_independent_goldens.py)"""
+    O = oa.oracle()
+    g = json.load(open(os.path.join(GOLD, "splu_config3_step.json")))
+    a = g["problem"]
+    prob = oa.BAProblem(a["Nc"], a["Np"], a["Nobs"], seed=a["seed"])
+    assert (prob.N, prob.M, prob.nnz) == (g["N"], g["M"], g["nnz"])
+    N, M = prob.N, prob.M
+    Jp, Ji = prob.pattern()
+    p = prob.p0()
+    x, Jx = prob.eval(p)
+    F = O.orc_sparse_analyze(N, M, iptr(Jp), iptr(Ji))
+    work = np.zeros(5 * N)
+    o8 = np.zeros(8)
+    assert O.orc_step_sparse(F, N, M, iptr(Jp), iptr(Ji), dptr(Jx), dptr(x), dptr(p), 0.0, dptr(work), dptr(o8)) == 0
+    O.orc_sparse_free(F)
+    gn_ref = np.array([float.fromhex(v) for v in g["gn_hex"]])
+    step_ref = np.array([float.fromhex(v) for v in g["step_hex"]])
+    dgn = np.linalg.norm(work[2*N:3*N] - gn_ref)
+    dst = np.linalg.norm(work[3*N:4*N] - step_ref)
+    print(f"config #3 oracle vs SuperLU fixture: |gn diff| = {dgn:.2e}, |step diff| = {dst:.2e}")
+    assert dgn <= 1e-10 and dst <= 1e-10
+    assert abs(o8[0] - float.fromhex(g["norm2_x"])) <= 1e-12 * o8[0]
+    assert abs(o8[1] - float.fromhex(g["norm2_cauchy"])) <= 1e-11 * o8[1]
+    assert abs(o8[2] - float.fromhex(g["norm2_gn"])) <= 1e-11 * o8[2]
+    assert abs(o8[3] - float.fromhex(g["k"])) <= 1e-10
+    assert abs(o8[5] - float.fromhex(g["expected_improvement"])) <= 1e-10 * abs(o8[5])

@@ -169,3 +169,172 @@ def test_dense_config2_shape_downscaled(gpu):
     # linearity property of the solve: (JtJ) gn == -g
     assert np.linalg.norm(A @ gn + g) <= 1e-9 * np.linalg.norm(g)
     be.close()
+
+
+def test_gpu_matches_the_independent_config3_fixture(gpu):
+    """BASELINE.json config #3 at full size against the committed SuperLU fixture
+    (tests/golden/splu_config3_step.json: numpy + scipy only, no oracle, no product): the pin of
+    the supernodal factor + solve that the reference delegates to CHOLMOD"""
+    g = json.load(open(os.path.join(GOLD, "splu_config3_step.json")))
+    a = g["problem"]
+    prob = oa.BAProblem(a["Nc"], a["Np"], a["Nobs"], seed=a["seed"])
+    N, M, nnz = prob.N, prob.M, prob.nnz
+    assert (N, M, nnz) == (g["N"], g["M"], g["nnz"])
+    Jp, Ji = prob.pattern()
+    p = prob.p0()
+    x, Jx = prob.eval(p)
+    be = capi.Backend(capi.DLG_SPARSE, N, M, nnz)
+    be.set_pattern(Jp, Ji)
+    be.set_p(0, p)
+    be.upload(0, x, Jx)
+    n2x, _ = be.eval(0)
+    tr = float.fromhex(g["trustregion"])
+    lam, r, pnew = be.take_step(0, 1, tr, 0.0)
+    assert lam == 0.0 and r["kind"] == g["kind"] == capi.KIND_INTERP
+    gn = be.download(0, capi.VEC_GN)
+    step = be.download(1, capi.VEC_STEP)
+    dgn = np.linalg.norm(gn - _unhex(g["gn_hex"]))
+    dst = np.linalg.norm(step - _unhex(g["step_hex"]))
+    print(f"config #3 GPU vs SuperLU fixture: |gn diff| = {dgn:.2e}, |step diff| = {dst:.2e}")
+    assert dgn <= 1e-10 and dst <= 1e-10
+    assert abs(n2x - float.fromhex(g["norm2_x"])) <= 1e-12 * n2x
+    assert abs(r["n2c"] - float.fromhex(g["norm2_cauchy"])) <= 1e-11 * r["n2c"]
+    assert abs(r["n2g"] - float.fromhex(g["norm2_gn"])) <= 1e-11 * r["n2g"]
+    assert abs(r["k"] - float.fromhex(g["k"])) <= 1e-10
+    assert abs(r["ei"] - float.fromhex(g["expected_improvement"])) <= 1e-10 * abs(r["ei"])
+    be.close()
+
+
+def test_config5_sparse_5m_ill_conditioned_full_size(gpu):
+    """BASELINE.json configs[4] at FULL size on one GPU: 5M measurements x 500 001 parameters,
+    75M non-zeros, column scales over 4 decades and exactly-zero columns => the factorisation fails
+    at lambda = 0 and succeeds at 1e-10 (dogleg.c:656-677).  One full step against orc_step_sparse.
+    The separators of this size class are cut into row slices and stay outside the multifrontal
+    region: a path the smaller tests do not reach."""
+    prob = oa.BAProblem(8333, 149999, 2500000, seed=13, scale_decades=4.0, n_zero_cols=3)
+    assert (prob.M, prob.N, prob.nnz) == (5000000, 500001, 75000000)
+    # tolerance: cond(JtJ + 1e-10 I) is ~1e13 along the zeroed columns' neighbours; the down-scaled
+    # variant of this test (test_ill_conditioned_lambda_step_parity) uses the same bar
+    d, lam = _step_parity(prob, tol=1e-6)
+    assert lam == 1e-10
+    print(f"config #5 full size: lambda={lam:g} |step_gpu - step_oracle| = {d:.3e}")
+
+
+def test_dense_config2_full_size(gpu):
+    """BASELINE.json configs[1] at FULL size: 50 000 measurements x 2 000 parameters (J = 800 MB).
+    The SYRK runs split-K over the measurement rows here (slabs + ordered reduce), which the
+    down-scaled cases do not reach.
+      * K1 / K3 against the oracle's loops at full size (they are O(M N));
+      * JtJ against BLAS (numpy J.T @ J) -- the oracle's rank-1 loop is 1e11 scalar FMAs, a minute;
+      * the factor + solve against the ORACLE's dpptrf / dpptrs restatement on that JtJ;
+      * the oracle's rank-1 assembly itself on a row sample of the same J (orc_step_dense), with the
+        GPU run on the same sample."""
+    O = oa.oracle()
+    M, N = 50000, 2000
+    dp = oa.DenseProblem(M=M, N=N, seed=2)
+    p = dp.p0()
+    x, J = dp.eval(p)
+    be = capi.Backend(capi.DLG_DENSE, N, M)
+    be.set_p(0, p)
+    be.upload(0, x, J)
+    n2x, gmax = be.eval(0)
+    g_gpu = be.download(0, capi.VEC_JTX)
+    n2c = be.cauchy(0)
+    assert be.factorize(0, 0.0)
+    n2g = be.solve_gn(0)
+    gn = be.download(0, capi.VEC_GN)
+    # K1 / K3 against the oracle's own loops
+    g = np.zeros(N)
+    O.orc_dense_Jt_x(dptr(g), dptr(J), dptr(x), M, N)
+    assert np.linalg.norm(g_gpu - g) <= 1e-12 * np.linalg.norm(g)
+    assert abs(n2x - O.orc_norm2(dptr(x), M)) <= 1e-12 * n2x
+    g2 = O.orc_norm2(dptr(g), N)
+    kc = -g2 / O.orc_dense_norm2_J_v(dptr(J), dptr(g), M, N)
+    assert abs(n2c - kc * kc * g2) <= 1e-10 * n2c
+    # K4 against BLAS, K5 + K6 against the oracle's LAPACK restatement
+    A = J.T @ J
+    ap = np.ascontiguousarray(A[np.triu_indices(N)])           # row-major packed upper (dogleg.c:214-220)
+    assert O.orc_dpptrf_L(N, dptr(ap)) == 0
+    sol = g.copy()
+    O.orc_dpptrs_L(N, dptr(ap), dptr(sol))
+    d = np.linalg.norm(gn + sol)
+    print(f"config #2 full size: |gn_gpu - gn(oracle dpptrf/dpptrs on BLAS JtJ)| = {d:.3e}, |gn| = {np.sqrt(n2g):.3e}")
+    assert d <= 1e-10
+    # the factor handed out at the API edge (ctx->factorization_dense layout) against the oracle's
+    fac = be.factor_dense(N * (N + 1) // 2)
+    assert np.max(np.abs(fac - ap)) <= 1e-10 * np.max(np.abs(ap))
+    # size-independent: (JtJ) gn == -g
+    assert np.linalg.norm(A @ gn + g) <= 1e-9 * np.linalg.norm(g)
+    # one interpolated step + expected improvement against numpy on the full J
+    trr = 0.5 * (np.sqrt(n2c) + np.sqrt(n2g))
+    n2s, k, amax, ei, pnew = be.step(0, 1, capi.KIND_INTERP, trr)
+    step = be.download(1, capi.VEC_STEP)
+    assert abs(np.sqrt(n2s) - trr) <= 1e-9 * trr
+    ei_ref = -2.0 * O.orc_inner(dptr(g), dptr(step), N) - O.orc_dense_norm2_J_v(dptr(J), dptr(step), M, N)
+    assert abs(ei - ei_ref) <= 1e-10 * abs(ei_ref)
+    be.close()
+    # the oracle's rank-1 JtJ loop + everything else on a row sample (every 20th row)
+    Js = np.ascontiguousarray(J[::20])
+    xs = np.ascontiguousarray(x[::20])
+    Ms = Js.shape[0]
+    bs = capi.Backend(capi.DLG_DENSE, N, Ms)
+    bs.set_p(0, p)
+    bs.upload(0, xs, Js)
+    bs.eval(0)
+    c2 = bs.cauchy(0)
+    assert bs.factorize(0, 0.0)
+    g2n = bs.solve_gn(0)
+    trs = 0.5 * (np.sqrt(c2) + np.sqrt(g2n))
+    bs.make_step(0, 1, capi.KIND_INTERP, trs)
+    step_s = bs.download(1, capi.VEC_STEP)
+    dfac = np.zeros(N * (N + 1) // 2)
+    work = np.zeros(5 * N)
+    o8 = np.zeros(8)
+    assert O.orc_step_dense(N, Ms, dptr(Js), dptr(xs), dptr(p), 0.0, dptr(dfac), dptr(work), dptr(o8)) == 0
+    ds = np.linalg.norm(step_s - work[3*N:4*N])
+    print(f"config #2 row sample ({Ms} rows): |step_gpu - step_oracle| = {ds:.3e}")
+    assert ds <= 1e-10
+    bs.close()
+
+
+def test_take_step_with_device_side_finals_at_large_n(gpu, monkeypatch):
+    """N > 393k makes the step kernels run with the maximum of 1024 workgroups: the partial sums of
+    |step|^2, max|step| and <Jt x, step> must not share storage (they once did: max|step| came back
+    as 0 and the driver stopped with 'update small enough').  Device-side second stages
+    (DOGLEG_AMD_DEVICE_FINALS, the mode an all-reduce hook needs) against the host-side ones."""
+    prob = oa.BAProblem(40, 190000, 400000, seed=5)
+    assert prob.N > 524288
+    Jp, Ji = prob.pattern()
+    p = prob.p0()
+    x, Jx = prob.eval(p)
+    res = []
+    for dev_finals in (False, True):
+        if dev_finals:
+            monkeypatch.setenv("DOGLEG_AMD_DEVICE_FINALS", "1")
+        be = capi.Backend(capi.DLG_SPARSE, prob.N, prob.M, prob.nnz)
+        be.set_pattern(Jp, Ji)
+        be.set_p(0, p)
+        be.upload(0, x, Jx)
+        be.eval(0)
+        n2c = be.cauchy(0)
+        lam, n2g = be.gauss_newton(0, 0.0)
+        trr = 0.5 * (np.sqrt(n2c) + np.sqrt(n2g))
+        n2s, k, amax, ei, pnew = be.step(0, 1, capi.KIND_INTERP, trr)
+        ref = (n2s, amax, ei)
+        be.close()
+        be = capi.Backend(capi.DLG_SPARSE, prob.N, prob.M, prob.nnz)
+        be.set_pattern(Jp, Ji)
+        be.set_p(0, p)
+        be.upload(0, x, Jx)
+        be.eval(0)
+        lam2, r, pnew2 = be.take_step(0, 1, trr, 0.0)
+        step = be.download(1, capi.VEC_STEP)
+        be.close()
+        assert r["kind"] == capi.KIND_INTERP
+        assert r["amax"] > 0 and r["amax"] == np.max(np.abs(step))
+        assert abs(r["n2s"] - float(step @ step)) <= 1e-12 * r["n2s"]
+        assert abs(r["n2s"] - ref[0]) <= 1e-12 * ref[0] and r["amax"] == ref[1]
+        assert abs(r["ei"] - ref[2]) <= 1e-12 * abs(ref[2])
+        res.append((r["n2s"], r["amax"], r["ei"]))
+    assert res[0][1] == res[1][1]
+    assert abs(res[0][0] - res[1][0]) <= 1e-12 * res[0][0] and abs(res[0][2] - res[1][2]) <= 1e-12 * abs(res[0][2])

@@ -273,7 +273,13 @@ def test_take_step_matches_the_separate_calls(gpu, kind, which):
     be2 = fresh()
     lam2, r, pnew2 = be2.take_step(0, 1, tr, 0.0)
     assert r["kind"] == want_kind
-    assert (lam2, r["n2c"], r["n2g"], r["n2s"], r["amax"], r["ei"]) == ref[:6]
+    if which == "cauchy":
+        # the reference never factorises on the Cauchy branch (dogleg.c:1192-1211): the speculative
+        # Gauss-Newton step is dropped, not reported, not cached
+        assert np.isnan(r["n2g"])
+        assert (lam2, r["n2c"], r["n2s"], r["amax"], r["ei"]) == (ref[0], ref[1], ref[3], ref[4], ref[5])
+    else:
+        assert (lam2, r["n2c"], r["n2g"], r["n2s"], r["amax"], r["ei"]) == ref[:6]
     if which == "interp":
         assert r["k"] == k
     assert np.array_equal(pnew2, ref[6]) and np.array_equal(be2.download(1, capi.VEC_STEP), ref[7])
