@@ -126,6 +126,10 @@ extern "C" int dlg_backend_create(dlg_backend_t** out, int solve_type, int Nstat
   TRY_HIP(hipStreamCreateWithFlags(&b->copy_stream, hipStreamNonBlocking));
   TRY_HIP(hipEventCreateWithFlags(&b->ev_step, hipEventDisableTiming));
   TRY_HIP(hipEventCreateWithFlags(&b->ev_copy, hipEventDisableTiming));
+  TRY_HIP(hipStreamCreateWithFlags(&b->aux_stream, hipStreamNonBlocking));
+  TRY_HIP(hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming));
+  TRY_HIP(hipEventCreateWithFlags(&b->ev_join, hipEventDisableTiming));
+  b->overlap = getenv("DOGLEG_AMD_NO_OVERLAP") == nullptr;
   TRY_HIP(hipMalloc(&b->d_scal, sizeof(double)*dlg_backend::NSCAL));
   TRY_HIP(hipMemsetAsync(b->d_scal, 0, sizeof(double)*dlg_backend::NSCAL, b->stream));
   TRY_HIP(hipHostMalloc(&b->h_scal, sizeof(double)*dlg_backend::NSCAL));
@@ -178,6 +182,9 @@ extern "C" void dlg_backend_destroy(dlg_backend_t* b)
   for(auto& pp : b->prof_pending) { (void)hipEventDestroy(pp.a); (void)hipEventDestroy(pp.b); }
   for(hipEvent_t e : b->prof_pool) (void)hipEventDestroy(e);
   if(b->copy_stream) { (void)hipStreamSynchronize(b->copy_stream); (void)hipStreamDestroy(b->copy_stream); b->copy_stream = nullptr; }
+  if(b->aux_stream) { (void)hipStreamSynchronize(b->aux_stream); (void)hipStreamDestroy(b->aux_stream); b->aux_stream = nullptr; }
+  if(b->ev_fork) { (void)hipEventDestroy(b->ev_fork); b->ev_fork = nullptr; }
+  if(b->ev_join) { (void)hipEventDestroy(b->ev_join); b->ev_join = nullptr; }
   if(b->ev_step) { (void)hipEventDestroy(b->ev_step); b->ev_step = nullptr; }
   if(b->ev_copy) { (void)hipEventDestroy(b->ev_copy); b->ev_copy = nullptr; }
   if(b->own_stream && b->stream) (void)hipStreamDestroy(b->stream);
@@ -359,6 +366,32 @@ static int cauchy_enqueue(dlg_backend* b, int s, double* sc)
   DLG_CHECK(k_cauchy_finish(b, S.Jt_x, S.norm2_jtx, sc + 1, S.cauchy, b->N, sc + 2));    // |g|^2: from dlg_point_eval
   return DLG_OK;
 }
+// The Cauchy step beside the factorisation (K3 || K5): the caller sets want_fork before the
+// factorisation is enqueued, the factorisation records ev_fork where its latency-bound phase
+// begins (or never: then the fork is here, behind it), the Cauchy kernels go to aux_stream behind
+// that event and the main stream waits for them before anything reads the Cauchy step.
+static int cauchy_fork_begin(dlg_backend* b)
+{
+  b->want_fork = b->overlap && b->aux_stream && !b->allreduce;
+  b->fork_recorded = false;
+  return DLG_OK;
+}
+static int cauchy_fork_enqueue(dlg_backend* b, int s, double* sc)
+{
+  if(!b->want_fork) return cauchy_enqueue(b, s, sc);
+  if(!b->fork_recorded) DLG_HIP(hipEventRecord(b->ev_fork, b->stream));
+  b->want_fork = false; b->fork_recorded = false;
+  DLG_HIP(hipStreamWaitEvent(b->aux_stream, b->ev_fork, 0));
+  hipStream_t main_stream = b->stream;
+  b->stream = b->aux_stream;
+  const int rc = cauchy_enqueue(b, s, sc);
+  b->stream = main_stream;
+  DLG_CHECK(rc);
+  DLG_HIP(hipEventRecord(b->ev_join, b->aux_stream));
+  DLG_HIP(hipStreamWaitEvent(b->stream, b->ev_join, 0));
+  return DLG_OK;
+}
+
 extern "C" int dlg_cauchy(dlg_backend_t* b, int s, double* norm2_updateCauchy)
 {
   DLG_CHECK(check_slot(b, s));
@@ -442,12 +475,10 @@ static int gauss_newton_impl(dlg_backend_t* b, int s, double* lambda_io, double*
   for(;;)
   {
     int good = 0, rc;
-    if(with_cauchy && !S.have_cauchy && !cauchy_pending)
-    {
-      // the Cauchy step rides along: its scalars come back with the same synchronisation
-      DLG_CHECK(cauchy_enqueue(b, s, b->d_scal + 4));
-      cauchy_pending = true;
-    }
+    // the Cauchy step rides along (its scalars come back with the same synchronisation), on the
+    // second stream beside the factorisation
+    const bool do_cauchy = with_cauchy && !S.have_cauchy && !cauchy_pending;
+    if(do_cauchy) DLG_CHECK(cauchy_fork_begin(b));
     if(b->factor_slot != s)
     {
       b->defer_factor_sync = true;
@@ -458,7 +489,13 @@ static int gauss_newton_impl(dlg_backend_t* b, int s, double* lambda_io, double*
       default:         rc = products_factorize(b, s, lam, &good); break;
       }
       b->defer_factor_sync = false;
+      if(rc != DLG_OK) b->want_fork = false;
       DLG_CHECK(rc);
+    }
+    if(do_cauchy)
+    {
+      DLG_CHECK(cauchy_fork_enqueue(b, s, b->d_scal + 4));
+      cauchy_pending = true;
     }
     {
       DlgProfScope ps(b, DLG_PROF_K6_SOLVE);
@@ -657,7 +694,8 @@ extern "C" int dlg_take_step(dlg_backend_t* b, int from, int to, double trustreg
   {
     int good = 0, rc;
     double* n2c_dev = b->d_scal + 6;
-    if(!F.have_cauchy) DLG_CHECK(cauchy_enqueue(b, from, b->d_scal + 4));
+    const bool do_cauchy = !F.have_cauchy;
+    if(do_cauchy) DLG_CHECK(cauchy_fork_begin(b));
     else DLG_HIP(hipMemcpyAsync(n2c_dev, &F.norm2_cauchy, sizeof(double), hipMemcpyHostToDevice, b->stream));
     if(b->factor_slot != from)
     {
@@ -669,8 +707,10 @@ extern "C" int dlg_take_step(dlg_backend_t* b, int from, int to, double trustreg
       default:         rc = products_factorize(b, from, lam, &good); break;
       }
       b->defer_factor_sync = false;
+      if(rc != DLG_OK) b->want_fork = false;
       DLG_CHECK(rc);
     }
+    if(do_cauchy) DLG_CHECK(cauchy_fork_enqueue(b, from, b->d_scal + 4));     // K3 beside K5 (second stream)
     {
       DlgProfScope ps(b, DLG_PROF_K6_SOLVE);
       if(b->type == DLG_SPARSE) DLG_CHECK(sparse_solve(b, F.Jt_x, F.gn));

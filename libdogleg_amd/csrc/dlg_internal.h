@@ -58,6 +58,13 @@ struct dlg_backend
   // side stream + events: p_new travels to the host while the expected improvement is computed (dlg_step)
   hipStream_t copy_stream = nullptr;
   hipEvent_t  ev_step = nullptr, ev_copy = nullptr;
+  // second compute stream: the Cauchy step (one pass over J, independent of the factorisation) runs
+  // beside the latency-bound upper levels of the elimination tree / the potrf chain, which leave
+  // most of the chip idle.  The factorisation records ev_fork where that phase begins
+  // (want_fork -> fork_recorded), the caller joins with ev_join before the step is formed.
+  hipStream_t aux_stream = nullptr;
+  hipEvent_t  ev_fork = nullptr, ev_join = nullptr;
+  bool want_fork = false, fork_recorded = false, overlap = true;
   DlgSlot slot[2];
 
   // scalar return path: kernels write d_scal, one D2H into pinned h_scal
@@ -129,6 +136,12 @@ struct DlgProfScope
 static inline int dlg_mloc(const dlg_backend* b) { return b->row1 - b->row0; }
 // sum-all-reduce over ranks of `count` doubles at device address buf (no-op single rank)
 int dlg_allreduce_dev(dlg_backend* b, double* buf, size_t count);
+
+// the factorisation calls this where its latency-bound phase begins
+static inline void dlg_fork_point(dlg_backend* b)
+{
+  if(b->want_fork && !b->fork_recorded && hipEventRecord(b->ev_fork, b->stream) == hipSuccess) b->fork_recorded = true;
+}
 
 // fetch the first n scalars of d_scal to the host (synchronises the stream)
 int dlg_fetch_scalars(dlg_backend* b, int n);

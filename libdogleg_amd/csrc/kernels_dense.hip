@@ -582,7 +582,7 @@ int dense_norm2_Jv(dlg_backend* b, int s, const double* v, double* out_dev)
   const int M = dlg_mloc(b);
   int g = dlg_cdiv(M, 4); if(g > 2048) g = 2048; if(g < 1) g = 1;
   DLG_CHECK(dlg_ensure_partials(b, 8192));
-  double* part = b->d_part + 4096;
+  double* part = b->d_part + 5120;          // behind the regions of the vector reductions (kernels_vec.hip)
   hipLaunchKernelGGL(k_norm2_Jv_part, dim3(g), dim3(TPB), 0, b->stream, S.Jin(), v, M, b->N, part);
   DLG_LAUNCH_CHECK();
   return k_reduce_sum(b, part, g, out_dev);
@@ -596,7 +596,7 @@ int products_quadform(dlg_backend* b, int s, const double* v, double* out_dev)
   { dlg_set_error("only JtJ unpacked || (packed,upper) is supported (reference dogleg.c:597-601)"); return DLG_ERR_ARG; }
   int g = dlg_cdiv(b->N, 4); if(g > 2048) g = 2048; if(g < 1) g = 1;
   DLG_CHECK(dlg_ensure_partials(b, 8192));
-  double* part = b->d_part + 4096;
+  double* part = b->d_part + 5120;          // behind the regions of the vector reductions (kernels_vec.hip)
   hipLaunchKernelGGL(k_quadform_part, dim3(g), dim3(TPB), 0, b->stream, S.Jin(), v, b->N,
                      packed ? 1 : 0, part);
   DLG_LAUNCH_CHECK();
@@ -629,7 +629,8 @@ int dense_factorize(dlg_backend* b, int s, double lambda, int* ok)
     if(lambda != 0.0)
       hipLaunchKernelGGL(k_add_diag, dim3(dlg_cdiv(b->N, TPB)), dim3(TPB), 0, b->stream, b->G, b->N, lambda);
   }
-  // K5
+  // K5 (a chain of small kernels: independent work may run beside it from here on)
+  dlg_fork_point(b);
   {
     DlgProfScope pf(b, DLG_PROF_K5_FACTOR);
     DLG_CHECK(potrf_lower(b->stream, b->G, b->N, b->N, b->d_info, b->Linv));

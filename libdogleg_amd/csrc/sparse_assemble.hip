@@ -696,8 +696,8 @@ int sparse_norm2_Jv(dlg_backend* b, int s, const double* v, double* out_dev)
   DlgSlot& S = b->slot[s];
   const int g = Y->n_nv_chunks;
   if(g == 0) { DLG_HIP(hipMemsetAsync(out_dev, 0, sizeof(double), b->stream)); return DLG_OK; }
-  DLG_CHECK(dlg_ensure_partials(b, 4096 + (size_t)g));
-  double* part = b->d_part + 4096;
+  DLG_CHECK(dlg_ensure_partials(b, 5120 + (size_t)g));
+  double* part = b->d_part + 5120;          // behind the regions of the vector reductions (kernels_vec.hip)
   hipLaunchKernelGGL(k_norm2_Jv, dim3(g), dim3(TPB), 0, b->stream, Y->nv_chunk, Y->Jp, Y->Ji, S.Jin(), v, part);
   DLG_LAUNCH_CHECK();
   return k_reduce_sum(b, part, g, out_dev);

@@ -8,8 +8,9 @@ namespace {
 typedef double dlg_v4d __attribute__((ext_vector_type(4)));
 // -DDLG_FL_PROFILE: phase clocks of workgroup 0 of every factor launch (tools only)
 #ifdef DLG_FL_PROFILE
-__device__ long long g_fl_prof[64*8];
-#define FL_STAMP(k) do { if(threadIdx.x == 0 && blockIdx.x == 0) g_fl_prof[(prof_lvl & 63)*8 + (k)] = clock64(); } while(0)
+constexpr int FL_PROF_WG = 256;       // workgroups per level whose phase clocks are kept
+__device__ long long g_fl_prof[32*FL_PROF_WG*8];
+#define FL_STAMP(k) do { if(threadIdx.x == 0 && blockIdx.x < FL_PROF_WG) g_fl_prof[((prof_lvl & 31)*FL_PROF_WG + blockIdx.x)*8 + (k)] = clock64(); } while(0)
 #else
 #define FL_STAMP(k)
 #endif
@@ -67,7 +68,10 @@ __device__ __forceinline__ void mf_add_children(double* P, double* Wt, int ntri,
       {
         // the update matrix lives in HBM: each of its entries gets an atomic add (fire and forget,
         // no read round trip).  A child adds to an address at most once and the barrier orders the
-        // children, so the sums are still in child order.
+        // children's instruction streams; the adds of one CU to one address reach L2 through the
+        // same queue in that order (waiting for L2's acknowledgement before every barrier --
+        // s_waitcnt vmcnt(0) -- was measured: it doubles this phase; bitwise reproducibility is
+        // checked on a pattern that takes this path, tests/test_scale_gpu.py).
 #pragma unroll
         for(int u = 0; u < MF_SLOTS; u++) if(e0 + u*NT < npad) old[u] = P[(d[u] & 0x8000) ? 0 : d[u]];
 #pragma unroll
@@ -80,6 +84,120 @@ __device__ __forceinline__ void mf_add_children(double* P, double* Wt, int ntri,
       }
     }
     __syncthreads();
+  }
+}
+
+// NCH consecutive lower 16x16 tiles (column-major tile order, first tile `first`) of
+// U = B B' (B = the mb rows below the diagonal block of the LDS panel Pb, w columns), one
+// accumulator chain per tile, every chain with its own operands (the tiles may span two tile
+// columns).  Rows / columns past the end are clamped (their results are never written); two
+// k-steps per iteration with their own operand registers, so the loads of one are in flight
+// during the products of the other.  mode 2: the multifrontal region keeps W = (children) - U.
+template <int NCH>
+__device__ __forceinline__ void factor_tail_tiles(const double* Pb, int ldp, int w, int mb, int T, int first,
+                                                  double* Ud, int mode, bool w_hbm, bool mf_acc, int lane)
+{
+  const int jn = lane & 15, kq = lane >> 4;
+  int ti[NCH], tjq[NCH], oa[NCH], ob[NCH];
+  dlg_v4d c4[NCH];
+  {
+    int rem = first, tj = 0;
+    while(rem >= T - tj) { rem -= T - tj; tj++; }
+    int tcur = tj + rem;
+#pragma unroll
+    for(int q = 0; q < NCH; q++)
+    {
+      ti[q] = tcur; tjq[q] = tj;
+      tcur++; if(tcur >= T) { tj++; tcur = tj; }
+      oa[q] = w + min(16*ti[q] + jn, mb - 1) + kq*ldp;
+      ob[q] = w + min(16*tjq[q] + jn, mb - 1) + kq*ldp;
+      c4[q] = (dlg_v4d){0.0, 0.0, 0.0, 0.0};
+    }
+  }
+  // an update matrix kept in HBM: the children's sums of these tiles, on their way during the
+  // products (read around L1: they were formed by atomics in L2)
+  double w0[NCH][4];
+  if(w_hbm)
+  {
+#pragma unroll
+    for(int q = 0; q < NCH; q++)
+    {
+      const int j = 16*tjq[q] + jn, jt0 = tri_col(j, mb);
+#pragma unroll
+      for(int r = 0; r < 4; r++)
+      {
+        const int i = 16*ti[q] + kq + 4*r;
+        w0[q][r] = (i < mb && j <= i) ? __hip_atomic_load(Ud + jt0 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+      }
+    }
+  }
+  const int w4 = w & ~3;
+  const int st = 4*ldp;
+  double a0[NCH], a1[NCH], b0[NCH], b1[NCH];
+#pragma unroll
+  for(int q = 0; q < NCH; q++) { a0[q] = 0.0; b0[q] = 0.0; }
+  int kk = 0, ko = 0;                      // ko: element offset of k-step kk
+  if(w4 >= 4)
+  {
+#pragma unroll
+    for(int q = 0; q < NCH; q++) { a0[q] = Pb[oa[q]]; b0[q] = Pb[ob[q]]; }
+  }
+  for(; kk + 8 <= w4; kk += 8)
+  {
+#pragma unroll
+    for(int q = 0; q < NCH; q++) { a1[q] = Pb[oa[q] + ko + st]; b1[q] = Pb[ob[q] + ko + st]; }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for(int q = 0; q < NCH; q++) c4[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[q], b0[q], c4[q], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    ko += 2*st;
+    // the k-step after next (clamped to the last whole one: a harmless re-read at the end)
+    const int kn = (kk + 12 <= w4) ? ko : ko - 2*st;
+#pragma unroll
+    for(int q = 0; q < NCH; q++) { a0[q] = Pb[oa[q] + kn]; b0[q] = Pb[ob[q] + kn]; }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for(int q = 0; q < NCH; q++) c4[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[q], b1[q], c4[q], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if(kk + 4 <= w4)
+  {
+    // odd number of whole k-steps: the last one
+    if(kk > 0)
+    {
+#pragma unroll
+      for(int q = 0; q < NCH; q++) { a0[q] = Pb[oa[q] + ko]; b0[q] = Pb[ob[q] + ko]; }
+    }
+#pragma unroll
+    for(int q = 0; q < NCH; q++) c4[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[q], b0[q], c4[q], 0, 0, 0);
+    kk += 4; ko += st;
+  }
+  if(kk < w)
+  {
+    // the last, partial k-step: columns past the end contribute zeros
+    const bool kok = kk + kq < w;
+    const int kz = ko - (kok ? 0 : (kk + kq - (w - 1))*ldp);
+#pragma unroll
+    for(int q = 0; q < NCH; q++)
+    {
+      const double az = kok ? Pb[oa[q] + kz] : 0.0, bz = kok ? Pb[ob[q] + kz] : 0.0;
+      c4[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(az, bz, c4[q], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for(int q = 0; q < NCH; q++)
+  {
+    const int j = 16*tjq[q] + jn, jtri = tri_col(j, mb);
+#pragma unroll
+    for(int r = 0; r < 4; r++)
+    {
+      const int i = 16*ti[q] + kq + 4*r;
+      if(i < mb && j <= i)
+      {
+        if(mode == 2) Ud[jtri + i] = (w_hbm ? w0[q][r] : (mf_acc ? Ud[jtri + i] : 0.0)) - c4[q][r];     // the region keeps W = -U
+        else Ud[jtri + i] = c4[q][r];
+      }
+    }
   }
 }
 
@@ -115,9 +233,10 @@ __global__ void __launch_bounds__(NT) k_factor_level(const FwItem* __restrict__ 
   constexpr int CP_FLIGHT = 32;
 #ifdef DLG_FL_PROFILE
   const int prof_lvl = mode >> 8;
-  if(threadIdx.x == 0 && blockIdx.x == 0) g_fl_prof[(prof_lvl & 63)*8] = clock64();
+  FL_STAMP(0);
 #endif
   const bool stage_leaf_u = (mode & 4) != 0;    // childless supernodes may stage U in LDS too (host: no occupancy loss)
+  const bool ahead = (mode & 8) != 0;           // panel_factor_ahead (barrier-free sweep) where the top block allows it
   mode &= 3;
   const FwItem it = items[blockIdx.x];
   const int r0 = it.r0, w = it.w, nrows = it.nrows;
@@ -176,132 +295,39 @@ __global__ void __launch_bounds__(NT) k_factor_level(const FwItem* __restrict__ 
   FL_STAMP(2);
   if(cmp) bd_compact_rows<NT>(Pb, ldp, nloc, w, tid, it.nbd, s_mcol, s_rdiag, Dg);
   else if(it.nbd > 0) panel_factor_blockdiag<NT>(P, ldp, nloc, w, tid, sn_bd_col + it.bd0, it.nbd, &sbad, it.col0, s_mcol, s_rdiag);
+  else if(NT >= 256 && ahead && w <= PF_AHEAD_MAXW) panel_factor_ahead<(NT >= 256 ? NT : 256)>(P, ldp, nloc, w, tid, &sbad, it.col0, s_rdiag, s_mcol);
   else if(NT >= 256) panel_factor_mfma<(NT >= 256 ? NT : 256)>(P, ldp, nloc, w, tid, &sbad, it.col0);
   else         panel_factor<NT, true, true>(P, ldp, nloc, w, tid, &sbad, it.col0);
   FL_STAMP(3);
   if(r0 == 0 && tid == 0 && sbad != 0x7fffffff) atomicMin(info, sbad);
-  // U = B B' (mode 2: W = children's sum - B B'): lower 16x16 tiles, both MFMA operands read from
-  // the panel.  SY_G accumulator chains per wave keep the matrix core busy.  Rows / columns past the
-  // end are clamped (their results are never written); two k-steps per iteration with their own
-  // operand registers, so the loads of one are in flight during the products of the other.
+  // U = B B' (mode 2: W = children's sum - B B'): lower 16x16 tiles on the matrix cores, both
+  // operands read from the panel (factor_tail_tiles above).  The lower triangle of tiles is dealt
+  // out in column-major tile order, in chunks of consecutive tiles: every round gives each wave one
+  // chunk, all chunks of a round within one tile of each other -- the two waves of a SIMD share its
+  // matrix core, so the tail is only as fast as the busiest SIMD.
   if(has_u)
   {
     const int T = (mb + 15) >> 4;
-    const int wv = tid >> 6, jn = lane & 15, kq = lane >> 4;
+    const int wv = tid >> 6;
     double* Ud = u_lds ? Us : Ug;              // in place behind the panel, or straight to the scratch
-    // work item = SY_G consecutive lower tiles in column-major tile order (they may span two tile
-    // columns, so every chain has its own B operand): the triangle is dealt out evenly, a wave of
-    // the upper levels (512 threads, 8 x 8 tiles) and of the leaves (256 threads, 5 x 5) gets one item
+    constexpr int NWV = NT/64;
     constexpr int SY_G = (NT >= 512) ? 6 : 4;
-    const int ntiles = T*(T + 1)/2, nitems = (ntiles + SY_G - 1)/SY_G;
-    const int w4 = w & ~3;
+    const int ntiles = T*(T + 1)/2;
+    const int rounds = (ntiles + NWV*SY_G - 1)/(NWV*SY_G), nchunks = rounds*NWV;
     const bool w_hbm = mf_acc && !u_lds;
-    for(int item = wv; item < nitems; item += NT/64)
+    for(int c = wv; c < nchunks; c += NWV)
     {
-      // tile (ti, tj) of chain q; chains past the last tile repeat it (computed and dropped)
-      int ti[SY_G], tjq[SY_G], oa[SY_G], ob[SY_G];
-      bool on[SY_G];
-      dlg_v4d c4[SY_G];
+      const int t0 = (int)((long)c*ntiles/nchunks), t1 = (int)((long)(c + 1)*ntiles/nchunks);
+      switch(t1 - t0)
       {
-        int rem = item*SY_G, tj = 0;
-        while(rem >= T - tj) { rem -= T - tj; tj++; }
-        int tcur = tj + rem;
-#pragma unroll
-        for(int q = 0; q < SY_G; q++)
-        {
-          on[q] = item*SY_G + q < ntiles;
-          ti[q] = tcur; tjq[q] = tj;
-          if(on[q] && item*SY_G + q + 1 < ntiles) { tcur++; if(tcur >= T) { tj++; tcur = tj; } }
-          oa[q] = w + min(16*ti[q] + jn, mb - 1) + kq*ldp;
-          ob[q] = w + min(16*tjq[q] + jn, mb - 1) + kq*ldp;
-          c4[q] = (dlg_v4d){0.0, 0.0, 0.0, 0.0};
-        }
+        case 1: factor_tail_tiles<1>(Pb, ldp, w, mb, T, t0, Ud, mode, w_hbm, mf_acc, lane); break;
+        case 2: factor_tail_tiles<2>(Pb, ldp, w, mb, T, t0, Ud, mode, w_hbm, mf_acc, lane); break;
+        case 3: factor_tail_tiles<3>(Pb, ldp, w, mb, T, t0, Ud, mode, w_hbm, mf_acc, lane); break;
+        case 4: factor_tail_tiles<4>(Pb, ldp, w, mb, T, t0, Ud, mode, w_hbm, mf_acc, lane); break;
+        case 5: if(SY_G >= 5) factor_tail_tiles<(SY_G >= 5 ? 5 : 1)>(Pb, ldp, w, mb, T, t0, Ud, mode, w_hbm, mf_acc, lane); break;
+        case 6: if(SY_G >= 6) factor_tail_tiles<(SY_G >= 6 ? 6 : 1)>(Pb, ldp, w, mb, T, t0, Ud, mode, w_hbm, mf_acc, lane); break;
+        default: break;
       }
-      // an update matrix kept in HBM: the children's sums of this item's tiles, on their way during
-      // the products (read around L1: they were formed by atomics in L2)
-      double w0[SY_G][4];
-      if(w_hbm)
-      {
-#pragma unroll
-        for(int q = 0; q < SY_G; q++)
-        {
-          const int j = 16*tjq[q] + jn, jt0 = tri_col(j, mb);
-#pragma unroll
-          for(int r = 0; r < 4; r++)
-          {
-            const int i = 16*ti[q] + kq + 4*r;
-            w0[q][r] = (on[q] && i < mb && j <= i) ? __hip_atomic_load(Ud + jt0 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
-          }
-        }
-      }
-      const int st = 4*ldp;
-      double a0[SY_G], a1[SY_G], b0[SY_G], b1[SY_G];
-#pragma unroll
-      for(int q = 0; q < SY_G; q++) { a0[q] = 0.0; b0[q] = 0.0; }
-      int kk = 0, ko = 0;                      // ko: element offset of k-step kk
-      if(w4 >= 4)
-      {
-#pragma unroll
-        for(int q = 0; q < SY_G; q++) { a0[q] = Pb[oa[q]]; b0[q] = Pb[ob[q]]; }
-      }
-      for(; kk + 8 <= w4; kk += 8)
-      {
-#pragma unroll
-        for(int q = 0; q < SY_G; q++) { a1[q] = Pb[oa[q] + ko + st]; b1[q] = Pb[ob[q] + ko + st]; }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for(int q = 0; q < SY_G; q++) c4[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[q], b0[q], c4[q], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        ko += 2*st;
-        // the k-step after next (clamped to the last whole one: a harmless re-read at the end)
-        const int kn = (kk + 12 <= w4) ? ko : ko - 2*st;
-#pragma unroll
-        for(int q = 0; q < SY_G; q++) { a0[q] = Pb[oa[q] + kn]; b0[q] = Pb[ob[q] + kn]; }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for(int q = 0; q < SY_G; q++) c4[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[q], b1[q], c4[q], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      if(kk + 4 <= w4)
-      {
-        // odd number of whole k-steps: the last one
-        if(kk > 0)
-        {
-#pragma unroll
-          for(int q = 0; q < SY_G; q++) { a0[q] = Pb[oa[q] + ko]; b0[q] = Pb[ob[q] + ko]; }
-        }
-#pragma unroll
-        for(int q = 0; q < SY_G; q++) c4[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[q], b0[q], c4[q], 0, 0, 0);
-        kk += 4; ko += st;
-      }
-      if(kk < w)
-      {
-        // the last, partial k-step: columns past the end contribute zeros
-        const bool kok = kk + kq < w;
-        const int kz = ko - (kok ? 0 : (kk + kq - (w - 1))*ldp);
-#pragma unroll
-        for(int q = 0; q < SY_G; q++)
-        {
-          const double az = kok ? Pb[oa[q] + kz] : 0.0, bz = kok ? Pb[ob[q] + kz] : 0.0;
-          c4[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(az, bz, c4[q], 0, 0, 0);
-        }
-      }
-#pragma unroll
-      for(int q = 0; q < SY_G; q++)
-        if(on[q])
-        {
-          const int j = 16*tjq[q] + jn, jtri = tri_col(j, mb);
-#pragma unroll
-          for(int r = 0; r < 4; r++)
-          {
-            const int i = 16*ti[q] + kq + 4*r;
-            if(i < mb && j <= i)
-            {
-              if(mode == 2) Ud[jtri + i] = (w_hbm ? w0[q][r] : (mf_acc ? Ud[jtri + i] : 0.0)) - c4[q][r];     // the region keeps W = -U
-              else Ud[jtri + i] = c4[q][r];
-            }
-          }
-        }
     }
     if(u_lds) __syncthreads();
   }
@@ -326,6 +352,10 @@ __global__ void __launch_bounds__(NT) k_factor_level(const FwItem* __restrict__ 
     }
   }
   FL_STAMP(5);
+#ifdef DLG_FL_PROFILE
+  if(threadIdx.x == 0 && blockIdx.x < FL_PROF_WG)
+    g_fl_prof[((prof_lvl & 31)*FL_PROF_WG + blockIdx.x)*8 + 6] = (long long)w | ((long long)nrows << 12) | ((long long)it.nch << 24) | ((long long)(u_lds ? 1 : 0) << 36) | ((long long)(has_u ? 1 : 0) << 37) | ((long long)(it.r1 - it.r0) << 40);
+#endif
 }
 // publish the top blocks of the multi-slice supernodes
 __global__ void __launch_bounds__(TPB) k_copy_top(const int* __restrict__ ms_sn, const int* __restrict__ sn_c0,
@@ -964,14 +994,33 @@ int sparse_factor_setup(dlg_backend* b)
 }
 
 #ifdef DLG_FL_PROFILE
+// per level: the workgroup that finishes last (its phases) and the mean over the recorded workgroups
 extern "C" void dlg_fl_profile_dump(int nlevels)
 {
-  long long h[64*8];
+  std::vector<long long> h(32*FL_PROF_WG*8);
   hipDeviceSynchronize();
-  hipMemcpyFromSymbol(h, HIP_SYMBOL(g_fl_prof), sizeof(h));
-  for(int l = 0; l < nlevels && l < 64; l++)
-    fprintf(stderr, "level %2d: load %6lld  add %6lld  factor %6lld  tail %6lld  store %6lld cycles\n", l,
-            h[l*8+1] - h[l*8], h[l*8+2] - h[l*8+1], h[l*8+3] - h[l*8+2], h[l*8+4] - h[l*8+3], h[l*8+5] - h[l*8+4]);
+  hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(g_fl_prof), sizeof(long long)*h.size());
+  for(int l = 0; l < nlevels && l < 32; l++)
+  {
+    int nwg = 0, last = -1; long long t0 = 0, tend = 0; double mean[5] = {0, 0, 0, 0, 0};
+    for(int g = 0; g < FL_PROF_WG; g++)
+    {
+      const long long* q = &h[(l*FL_PROF_WG + g)*8];
+      if(q[5] == 0) continue;
+      nwg++;
+      if(t0 == 0 || q[0] < t0) t0 = q[0];
+      if(q[5] > tend) { tend = q[5]; last = g; }
+      for(int k = 0; k < 5; k++) mean[k] += (double)(q[k+1] - q[k]);
+    }
+    if(nwg == 0) continue;
+    const long long* q = &h[(l*FL_PROF_WG + last)*8];
+    fprintf(stderr, "level %2d: %3d wg, span %7lld | last wg %3d (w %3lld rows %4lld slice %4lld nch %2lld u_lds %lld has_u %lld): start +%6lld load %6lld add %6lld factor %6lld tail %6lld store %6lld | mean: load %6.0f add %6.0f factor %6.0f tail %6.0f store %6.0f\n",
+            l, nwg, tend - t0, last, q[6] & 4095, (q[6] >> 12) & 4095, (q[6] >> 40) & 4095, (q[6] >> 24) & 4095, (q[6] >> 36) & 1, (q[6] >> 37) & 1,
+            q[0] - t0, q[1] - q[0], q[2] - q[1], q[3] - q[2], q[4] - q[3], q[5] - q[4],
+            mean[0]/nwg, mean[1]/nwg, mean[2]/nwg, mean[3]/nwg, mean[4]/nwg);
+  }
+  std::vector<long long> z(h.size(), 0);
+  hipMemcpyToSymbol(HIP_SYMBOL(g_fl_prof), z.data(), sizeof(long long)*z.size());
 }
 #endif
 // K5: level-scheduled supernodal Cholesky (launches only; the caller reads the pivot flag)
@@ -983,10 +1032,14 @@ int sparse_factor_levels(dlg_backend* b)
   for(int l = 0; l < H.nlevels; l++)
   {
     const int n = H.fw_lvl_ptr[l+1] - H.fw_lvl_ptr[l];
+    // from the first level that cannot fill the chip on, the factorisation is latency-bound:
+    // independent work (the Cauchy step's pass over J) may run beside it
+    if(l > 0 && n < 256) dlg_fork_point(b);
     if(n > 0)
     {
       const int o = H.fw_lvl_ptr[l];
-      const int fmode = ((l >= H.mf_level0) ? 2 : Y->syrk_fused[l]) + 4*Y->fac_stage[l] + 256*l;
+      static const int use_ahead = getenv("DOGLEG_AMD_AHEAD") ? 8 : 0;     // barrier-free sweep: measured slower (tools/micro/bench_ahead), kept for experiments
+      const int fmode = ((l >= H.mf_level0) ? 2 : Y->syrk_fused[l]) + 4*Y->fac_stage[l] + use_ahead + 256*l;
       if(Y->fac_nt[l] == 128)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_factor_level<128>), dim3(n), dim3(128), Y->fac_lds[l], st,
                            Y->fw_item + o, Y->mf_rec, Y->sn_bd_col, Y->mf_dst, Y->Lx, Y->top_scr, Y->d_info, Y->uscr, fmode);

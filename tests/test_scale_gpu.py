@@ -148,6 +148,29 @@ def test_run_to_run_bitwise_reproducible(gpu):
     assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
 
 
+def test_run_to_run_bitwise_reproducible_config4(gpu):
+    """config #4: one supernode in eight of the multifrontal region keeps its update matrix in HBM
+    and adds its children's entries with fire-and-forget atomics, ordered by workgroup barriers
+    (sparse_factor.hip, mf_add_children): repeated factorisations of the same input must still
+    agree bit for bit"""
+    prob = oa.BAProblem(2499, 45000, 500000, seed=11)
+    Jp, Ji = prob.pattern()
+    p = prob.p0()
+    x, Jx = prob.eval(p)
+    be = capi.Backend(capi.DLG_SPARSE, prob.N, prob.M, prob.nnz)
+    be.set_pattern(Jp, Ji)
+    be.set_p(0, p)
+    outs = []
+    for _ in range(4):
+        be.upload(0, x, Jx)
+        be.eval(0)
+        lam, n2g = be.gauss_newton(0, 0.0)
+        outs.append((n2g, be.download(0, capi.VEC_GN)))
+    be.close()
+    for n2g, gn in outs[1:]:
+        assert n2g == outs[0][0] and np.array_equal(gn, outs[0][1])
+
+
 def test_dense_config2_shape_downscaled(gpu):
     """configs[1] shape at 1/10 rows: dense 5000 x 2000 ops vs the oracle"""
     O = oa.oracle()
@@ -336,5 +359,6 @@ def test_take_step_with_device_side_finals_at_large_n(gpu, monkeypatch):
         assert abs(r["n2s"] - ref[0]) <= 1e-12 * ref[0] and r["amax"] == ref[1]
         assert abs(r["ei"] - ref[2]) <= 1e-12 * abs(ref[2])
         res.append((r["n2s"], r["amax"], r["ei"]))
-    assert res[0][1] == res[1][1]
+    # (the two modes sum their partials in different orders: k, hence the step, may differ by an ulp)
+    assert abs(res[0][1] - res[1][1]) <= 1e-12 * res[0][1]
     assert abs(res[0][0] - res[1][0]) <= 1e-12 * res[0][0] and abs(res[0][2] - res[1][2]) <= 1e-12 * abs(res[0][2])
