@@ -881,6 +881,7 @@ int sparse_factor_setup(dlg_backend* b)
 {
   SparseSym* Y = b->sym;
   const SymHost& H = Y->H;
+  Y->fac_ahead = getenv("DOGLEG_AMD_AHEAD") != nullptr;
   Y->fac_lds.assign(H.nlevels, 0); Y->fac_nt.assign(H.nlevels, 512); Y->upd_coop.assign(H.nlevels, 0);
   Y->upd_lds.assign(H.nlevels, 0); Y->upd_nw.assign(H.nlevels, 0);
   Y->syrk_lds.assign(H.nlevels, 0); Y->syrk_nt.assign(H.nlevels, 256); Y->syrk_kc.assign(H.nlevels, 4);
@@ -1038,7 +1039,7 @@ int sparse_factor_levels(dlg_backend* b)
     if(n > 0)
     {
       const int o = H.fw_lvl_ptr[l];
-      static const int use_ahead = getenv("DOGLEG_AMD_AHEAD") ? 8 : 0;     // barrier-free sweep: measured slower (tools/micro/bench_ahead), kept for experiments
+      const int use_ahead = Y->fac_ahead ? 8 : 0;     // barrier-free sweep: measured slower (tools/micro/bench_ahead), kept for experiments
       const int fmode = ((l >= H.mf_level0) ? 2 : Y->syrk_fused[l]) + 4*Y->fac_stage[l] + use_ahead + 256*l;
       if(Y->fac_nt[l] == 128)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_factor_level<128>), dim3(n), dim3(128), Y->fac_lds[l], st,

@@ -112,7 +112,7 @@ __global__ void __launch_bounds__(BWD_NT, BD_ONLY ? 4 : 1) k_solve_bwd_level(con
                                                             const double* __restrict__ Lx,
                                                             double* __restrict__ ywork,
                                                             double* __restrict__ out, int use_aug,
-                                                            const int* __restrict__ sn_bd_col, int top_lds)
+                                                            const int* __restrict__ sn_bd_col, int top_lds, int xb_cap)
 {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   constexpr int NW = BWD_NT/64;
@@ -125,8 +125,12 @@ __global__ void __launch_bounds__(BWD_NT, BD_ONLY ? 4 : 1) k_solve_bwd_level(con
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int r = nrows - w - 1;
   const int nblk = (w + 7) >> 3;
+  // x at the below rows is staged in LDS -- unless the supernode has more below rows than the level's
+  // LDS allows (xb_cap; e.g. the first supernode of a wide dense tail): then the mat-vec gathers x
+  // from HBM as it streams the columns
+  const bool xb_lds = r <= xb_cap;
   double* xb = lds;                       // [r]   x at the below rows
-  double* xs = lds + ((r + 1) & ~1);      // [256] -(L_below^T x), then the solution
+  double* xs = lds + (xb_lds ? ((r + 1) & ~1) : 0);      // [256] -(L_below^T x), then the solution
   double* T = xs + 256;                   // [nblk][8][8] diagonal blocks (lower), reciprocal pivots
   double* rhs = T + nblk*64;              // [2][8]
   double* xp = rhs + 16;                  // [parts][256] partial sums of the mat-vec
@@ -149,7 +153,7 @@ __global__ void __launch_bounds__(BWD_NT, BD_ONLY ? 4 : 1) k_solve_bwd_level(con
   const int mv_j = tid % mv_cols, mv_p = tid/mv_cols;
   const int mv_len = (r + mv_parts - 1)/mv_parts;           // rows per part
   const int mv_i0 = mv_p*mv_len, mv_i1 = min(r, mv_i0 + mv_len);
-  const bool mv_thread = mv_len <= MV_SLOTS;                 // else: long columns, the waves stream them (below)
+  const bool mv_thread = mv_len <= MV_SLOTS && xb_lds;       // else: long columns, the waves stream them (below)
   const bool mv_on = mv_thread && mv_j < w && mv_p < mv_parts;
   const double* mv_L = L + (size_t)min(mv_j, w - 1)*nrows + w;
   double mv[MV_SLOTS];
@@ -196,8 +200,11 @@ __global__ void __launch_bounds__(BWD_NT, BD_ONLY ? 4 : 1) k_solve_bwd_level(con
   BW_STAMP(1);
   // ---- round 3
   if(tid < 256) xs[tid] = 0.0;            // columns without below rows (a root) get no mat-vec pass
-  if(tid < r) xb[tid] = ywork[myrow];
-  for(int i = tid + BWD_NT; i < r; i += BWD_NT) xb[i] = ywork[rows[w + i]];
+  if(xb_lds)
+  {
+    if(tid < r) xb[tid] = ywork[myrow];
+    for(int i = tid + BWD_NT; i < r; i += BWD_NT) xb[i] = ywork[rows[w + i]];
+  }
   __syncthreads();
   BW_STAMP(2);
   if(mv_thread)
@@ -221,7 +228,7 @@ __global__ void __launch_bounds__(BWD_NT, BD_ONLY ? 4 : 1) k_solve_bwd_level(con
 #pragma unroll 2
       for(int i = lane; i < r; i += 64)
       {
-        const double x = xb[i];
+        const double x = xb_lds ? xb[i] : ywork[rows[w + i]];
 #pragma unroll
         for(int c = 0; c < 4; c++) acc[c] += ((c < nc) ? Lj[i + (size_t)c*nrows] : 0.0)*x;
       }
@@ -349,6 +356,7 @@ __global__ void __launch_bounds__(BWD_NT, BD_ONLY ? 4 : 1) k_solve_bwd_level(con
 } // namespace
 
 // per-level launch parameters of the solve kernels
+static long env_int_solve(const char* n, long d) { const char* v = getenv(n); return v ? atol(v) : d; }
 #ifdef DLG_FL_PROFILE
 extern "C" void dlg_bw_profile_dump(int nlevels)
 {
@@ -364,6 +372,9 @@ int sparse_solve_setup(dlg_backend* b)
 {
   SparseSym* Y = b->sym;
   const SymHost& H = Y->H;
+  // below rows of a supernode that the backward solve stages in LDS (96 KB of x); beyond that it gathers x from HBM
+  const long xb_cap = env_int_solve("DOGLEG_AMD_BWD_XB_CAP", 12288);
+  Y->bwd_xb_cap = (int)xb_cap;
   Y->slv_lds.assign(H.nlevels, 0); Y->bwd_lds.assign(H.nlevels, 0); Y->bwd_nt.assign(H.nlevels, 512); Y->bwd_top.assign(H.nlevels, 0); Y->bwd_bd.assign(H.nlevels, 0);
   for(int l = 0; l < H.nlevels; l++)
   {
@@ -374,7 +385,10 @@ int sparse_solve_setup(dlg_backend* b)
       const long wv = H.sn_c0[s+1] - H.sn_c0[s], nr = H.sn_rowptr[s+1] - H.sn_rowptr[s];
       if(wv > maxw) maxw = wv;
       wmax_all = std::max(wmax_all, wv);
-      const long need = (nr - wv + 2) + 256 + ((wv + 7)/8)*64 + 16 + 8*256;   // xb, xs, diagonal blocks, rhs, mat-vec partial sums
+      // xb (x at the below rows, unless there are more of them than xb_cap: those supernodes gather x
+      // from HBM), xs, diagonal blocks, rhs, mat-vec partial sums
+      const long rb = nr - wv - 1;
+      const long need = (rb <= xb_cap ? rb + 3 : 0) + 256 + ((wv + 7)/8)*64 + 16 + 8*256;
       if(need > mb) mb = need;
       // + the top block, for the supernodes that read it (not the block-diagonal ones)
       if(H.sn_bd_ptr[s+1] == H.sn_bd_ptr[s]) mbt = std::max(mbt, need + wv*(wv | 1));
@@ -441,15 +455,15 @@ int sparse_solve(dlg_backend* b, const double* rhs, double* out)
     if(n > 0 && Y->bwd_nt[l] == 256 && Y->bwd_bd[l])
       hipLaunchKernelGGL(HIP_KERNEL_NAME(k_solve_bwd_level<256, true>), dim3(n), dim3(256), Y->bwd_lds[l], st,
                          Y->slv_item + H.lvl_ptr[l], Y->sn_rows, Y->perm, Y->Lx, Y->ywork, out, use_aug, Y->sn_bd_col,
-                         Y->bwd_top[l] + 256*l);
+                         Y->bwd_top[l] + 256*l, Y->bwd_xb_cap);
     else if(n > 0 && Y->bwd_nt[l] == 256)
       hipLaunchKernelGGL(HIP_KERNEL_NAME(k_solve_bwd_level<256, false>), dim3(n), dim3(256), Y->bwd_lds[l], st,
                          Y->slv_item + H.lvl_ptr[l], Y->sn_rows, Y->perm, Y->Lx, Y->ywork, out, use_aug, Y->sn_bd_col,
-                         Y->bwd_top[l] + 256*l);
+                         Y->bwd_top[l] + 256*l, Y->bwd_xb_cap);
     else if(n > 0)
       hipLaunchKernelGGL(HIP_KERNEL_NAME(k_solve_bwd_level<512, false>), dim3(n), dim3(512), Y->bwd_lds[l], st,
                          Y->slv_item + H.lvl_ptr[l], Y->sn_rows, Y->perm, Y->Lx, Y->ywork, out, use_aug, Y->sn_bd_col,
-                         Y->bwd_top[l] + 256*l);
+                         Y->bwd_top[l] + 256*l, Y->bwd_xb_cap);
   }
   DLG_LAUNCH_CHECK();
   return DLG_OK;

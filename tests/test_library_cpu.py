@@ -4,6 +4,7 @@ and the row-sharding arithmetic under a 2-rank gloo group."""
 import ctypes as C
 import os
 import re
+import subprocess
 import numpy as np
 import pytest
 
@@ -254,3 +255,24 @@ def test_gradient_check_tool_on_the_sample_problem(mode):
     rep = np.array([float(r[2]) for r in rows]); obs = np.array([float(r[3]) for r in rows])
     assert np.max(np.abs(rep)) > 0
     assert np.max(np.abs(rep - obs)) <= 1e-4 * max(1.0, np.max(np.abs(rep)))
+
+
+def test_host_side_compiles_against_a_real_cholmod_header(tmp_path):
+    """VERDICT r1 item 8 / INTEGRATION.md: where SuiteSparse is installed <cholmod.h> is used instead
+    of include/dogleg_cholmod_compat.h.  The driver (host pass of driver.hip) and a user translation
+    unit must compile against CHOLMOD's public struct shapes: no by-value cholmod_factor with
+    compat-only fields, the backend pointer lives in the driver."""
+    inc = os.path.join(ROOT, "tests", "c", "cholmod_shape")
+    hipcc = "/opt/rocm/bin/hipcc"
+    drv = os.path.join(ROOT, "libdogleg_amd", "csrc", "driver.hip")
+    r = subprocess.run([hipcc, "-std=c++17", "--offload-arch=gfx950", "--cuda-host-only", "-fsyntax-only",
+                        "-I", inc, drv], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-I", inc,
+                        os.path.join(ROOT, "tests", "c", "real_cholmod_host.cpp")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    # and with the compat header forced the same user code still compiles (the default in this image)
+    r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-DDOGLEG_FORCE_CHOLMOD_COMPAT",
+                        "-I", inc, "-include", os.path.join(ROOT, "include", "dogleg.h"), "-x", "c++", "/dev/null"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]

@@ -149,8 +149,12 @@ def test_ba_lambda_path(gpu):
     {"DOGLEG_AMD_MF_LEVEL": "0", "DOGLEG_AMD_MF_NT": "256", "DOGLEG_AMD_SIB_W": "0"},     # 256 threads, no sibling-merged leaves
     {"DOGLEG_AMD_MF_MAXM": "60"},                                   # the region ends below the big fronts
     {"DOGLEG_AMD_DEVICE_FINALS": "1"},                              # second stage of every reduction on the device
+    {"DOGLEG_AMD_BWD_XB_CAP": "40"},                                # backward solve: x of the below rows gathered from HBM
+    {"DOGLEG_AMD_AHEAD": "1"},                                      # barrier-free panel sweep (diagonal wave runs ahead)
+    {"DOGLEG_AMD_NO_OVERLAP": "1"},                                 # Cauchy step on the main stream
 ], ids=["lds-assembly", "coop-update", "mfma-update", "syrk-unfused", "no-rider", "small-slices", "no-multifrontal",
-        "multifrontal-from-leaves", "multifrontal-128", "multifrontal-256", "multifrontal-small-fronts", "device-finals"])
+        "multifrontal-from-leaves", "multifrontal-128", "multifrontal-256", "multifrontal-small-fronts", "device-finals",
+        "bwd-x-from-hbm", "panel-ahead", "no-overlap"])
 def test_fallback_kernels_match_oracle(gpu, env, monkeypatch):
     """the kernels the default schedule does not pick on a bundle-adjustment pattern stay correct:
     the schedule knobs are read when the pattern is set"""
