@@ -68,14 +68,50 @@ void dlg_backend_destroy(dlg_backend_t* b);
 int  dlg_backend_set_stream(dlg_backend_t* b, void* hip_stream);
 void* dlg_backend_get_stream(dlg_backend_t* b);
 
-/* ---- multi-GPU: measurement rows are the sharded unit (every J-dependent
- * quantity is a sum over rows: dogleg.c:253-260, 269-278, 712-714).  A rank
- * owns rows [row0,row1) and must be given a sum-all-reduce over `count`
- * doubles at device address `buf` (RCCL, or torch.distributed through the
- * Python binding).  Without a hook the backend is single-rank. */
+/* ---- multi-GPU: measurement rows are the sharded unit (every J-dependent quantity is a sum over
+ * rows: dogleg.c:253-260, 269-278, 712-714).  One backend per rank (= per GPU).
+ *
+ * Who holds which rows:
+ *   dlg_backend_set_partition(rank, nranks)   sparse: the SUBTREE PARTITION.  dlg_sparse_set_pattern
+ *       (given the FULL pattern on every rank) cuts the elimination tree above the highest level with
+ *       >= nranks supernodes; every subtree below the cut belongs to one rank, which holds the rows
+ *       whose first-eliminated variable lies in it (dlg_partition_rows) and assembles, factors and
+ *       solves that subtree alone.  Per factorisation only the panels above the cut and the update
+ *       matrices crossing it are summed over the ranks (dlg_partition_stats: a few MB on the
+ *       bundle-adjustment configurations, against the whole JtJ), the solution is completed by one
+ *       sum over N doubles.  The replicated top of the tree is computed identically on every rank.
+ *   dlg_backend_set_shard(row0, row1, fn, cookie)   contiguous rows [row0, row1): the dense path (JtJ
+ *       summed, factorisation replicated) and the simple sparse variant (the whole assembled JtJ
+ *       summed, every rank factors everything).  fn may be NULL when RCCL is used.
+ * How the sums over the ranks are made:
+ *   dlg_backend_init_rccl / dlg_backend_set_rccl   RCCL (ncclAllReduce, fp64 sum) enqueued on the
+ *       backend's own stream: no host synchronisation per collective, every op of this header keeps
+ *       its number of synchronisations.  librccl.so is loaded on demand.
+ *   the hook (dlg_backend_set_shard / dlg_backend_set_allreduce)   a sum-all-reduce over `count`
+ *       doubles at device address `buf` supplied by the caller (MPI, torch.distributed ...); the
+ *       backend synchronises its stream before every call.  Fallback, and what the single-GPU tests
+ *       use to run several logical ranks on one device. */
 typedef int (*dlg_allreduce_fn)(void* buf, size_t count, void* cookie);
 int  dlg_backend_set_shard(dlg_backend_t* b, int row0, int row1,
                            dlg_allreduce_fn fn, void* cookie);
+int  dlg_backend_set_allreduce(dlg_backend_t* b, dlg_allreduce_fn fn, void* cookie);
+int  dlg_backend_set_partition(dlg_backend_t* b, int rank, int nranks);   /* before dlg_sparse_set_pattern */
+/* after dlg_sparse_set_pattern: the measurement rows this rank holds (ascending); dlg_point_upload /
+ * dlg_point_bind_device expect x and the values of Jt for exactly these rows, in this order */
+int  dlg_partition_rows(dlg_backend_t* b, int* nrows, const int** rows);
+/* stats[] = {cut level, supernodes above the cut, supernodes of this rank, rows of this rank,
+ * doubles summed per factorisation (panels above the cut + update matrices crossing it),
+ * doubles of the whole panel buffer, non-zeros of this rank} */
+int  dlg_partition_stats(dlg_backend_t* b, long* stats, int nstats);
+/* host-only (no GPU): the partition of a pattern over nranks ranks as rank `rank` sees it.
+ * row_owner[M] (may be NULL) receives 1 for the rows of this rank, 0 otherwise; stats as above */
+int  dlg_sparse_partition_probe(int N, int M, const int* colptr, const int* rowidx, int rank, int nranks,
+                                long* stats, int nstats, char* row_owner);
+/* RCCL: rank 0 creates the id (128 bytes) and distributes it by any means; every rank then joins */
+int  dlg_rccl_unique_id(void* out128);
+int  dlg_backend_init_rccl(dlg_backend_t* b, int rank, int nranks, const void* unique_id128);
+int  dlg_backend_set_rccl(dlg_backend_t* b, void* nccl_comm);            /* adopt a caller-owned ncclComm_t */
+int  dlg_backend_comm_size(dlg_backend_t* b, int* nranks);               /* what RCCL reports (1 without RCCL) */
 
 /* ---- sparse pattern: replaces cholmod_analyze (dogleg.c:650-654).  The
  * pattern is assumed constant for the life of the solve, as the reference

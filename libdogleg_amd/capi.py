@@ -35,6 +35,9 @@ BACKEND_SYMBOLS = [
     "dlg_host_free", "dlg_mem_upload",
     "dlg_mem_download", "dlg_mem_zero", "dlg_device_sync", "dlg_sparse_symbolic_probe",
     "dlg_backend_set_profiling", "dlg_backend_get_profile",
+    "dlg_backend_set_allreduce", "dlg_backend_set_partition", "dlg_partition_rows", "dlg_partition_stats",
+    "dlg_sparse_partition_probe", "dlg_rccl_unique_id", "dlg_backend_init_rccl", "dlg_backend_set_rccl",
+    "dlg_backend_comm_size",
 ]
 PROF_NAMES = ["K1_jtx", "K3K8_norm2Jv", "K4_kernel", "K4_total", "K5_factor", "K6_solve", "K7_step", "vec"]
 DOGLEG_SYMBOLS = [
@@ -73,6 +76,15 @@ def lib():
     L.dlg_backend_get_stream.argtypes = [V]
     L.dlg_backend_get_stream.restype = V
     L.dlg_backend_set_shard.argtypes = [V, C.c_int, C.c_int, V, V]
+    L.dlg_backend_set_allreduce.argtypes = [V, V, V]
+    L.dlg_backend_set_partition.argtypes = [V, C.c_int, C.c_int]
+    L.dlg_partition_rows.argtypes = [V, I, C.POINTER(I)]
+    L.dlg_partition_stats.argtypes = [V, C.POINTER(C.c_long), C.c_int]
+    L.dlg_sparse_partition_probe.argtypes = [C.c_int, C.c_int, I, I, C.c_int, C.c_int, C.POINTER(C.c_long), C.c_int, C.c_char_p]
+    L.dlg_rccl_unique_id.argtypes = [V]
+    L.dlg_backend_init_rccl.argtypes = [V, C.c_int, C.c_int, V]
+    L.dlg_backend_set_rccl.argtypes = [V, V]
+    L.dlg_backend_comm_size.argtypes = [V, I]
     L.dlg_sparse_set_pattern.argtypes = [V, I, I]
     L.dlg_sparse_stats.argtypes = [V, C.POINTER(C.c_long), C.POINTER(C.c_long), I, I, D]
     L.dlg_point_set_p.argtypes = [V, C.c_int, D]
@@ -217,6 +229,30 @@ def symbolic_probe(N, M, Jp, Ji, row0=0, row1=None, want_perm=False):
     return (d, perm) if want_perm else d
 
 
+PART_STAT_NAMES = ["cut_level", "supernodes_above_cut", "supernodes_mine", "rows_mine", "reduced_doubles",
+                   "panel_doubles", "nnz_mine"]
+
+
+def partition_probe(N, M, Jp, Ji, rank, nranks):
+    """Host-only: the subtree partition of a Jt pattern as rank `rank` of `nranks` sees it.
+    Returns (dict of statistics, bool array row_is_mine[M])."""
+    L = lib()
+    Jp = np.ascontiguousarray(Jp, dtype=np.int32)
+    Ji = np.ascontiguousarray(Ji, dtype=np.int32)
+    st = (C.c_long * len(PART_STAT_NAMES))()
+    own = np.zeros(M, dtype=np.uint8)
+    _ck(L.dlg_sparse_partition_probe(N, M, iptr(Jp), iptr(Ji), rank, nranks, st, len(PART_STAT_NAMES),
+                                     own.ctypes.data_as(C.c_char_p)), "partition probe")
+    return {k: st[i] for i, k in enumerate(PART_STAT_NAMES)}, own.astype(bool)
+
+
+def rccl_unique_id():
+    """128 bytes from ncclGetUniqueId (rank 0 creates it and hands it to the others)"""
+    buf = (C.c_char * 128)()
+    _ck(lib().dlg_rccl_unique_id(C.cast(buf, C.c_void_p)), "rccl_unique_id")
+    return bytes(buf)
+
+
 class DeviceArray:
     """A hipMalloc'ed buffer filled from / read back into numpy (harness helper)."""
 
@@ -297,6 +333,38 @@ class Backend:
         self._allreduce_cb = cb                 # must outlive the backend: the C side keeps the pointer
         _ck(self.L.dlg_backend_set_shard(self.h, row0, row1,
                                          C.cast(cb, C.c_void_p) if cb else None, None), "set_shard")
+
+    def set_allreduce(self, fn):
+        """host-synchronous sum-all-reduce hook (fallback / logical ranks on one device)"""
+        cb = ALLREDUCE_FN(fn) if fn is not None else None
+        self._allreduce_cb = cb
+        _ck(self.L.dlg_backend_set_allreduce(self.h, C.cast(cb, C.c_void_p) if cb else None, None), "set_allreduce")
+
+    def set_partition(self, rank, nranks):
+        """sparse: subtree partition over nranks ranks (before set_pattern)"""
+        _ck(self.L.dlg_backend_set_partition(self.h, rank, nranks), "set_partition")
+
+    def partition_rows(self):
+        """the measurement rows this rank holds (ascending); x / J values are uploaded for these"""
+        n = C.c_int()
+        rows = C.POINTER(C.c_int)()
+        _ck(self.L.dlg_partition_rows(self.h, C.byref(n), C.byref(rows)), "partition_rows")
+        return np.ctypeslib.as_array(rows, shape=(n.value,)).copy() if n.value else np.zeros(0, dtype=np.int32)
+
+    def partition_stats(self):
+        st = (C.c_long * len(PART_STAT_NAMES))()
+        _ck(self.L.dlg_partition_stats(self.h, st, len(PART_STAT_NAMES)), "partition_stats")
+        return {k: st[i] for i, k in enumerate(PART_STAT_NAMES)}
+
+    def init_rccl(self, rank, nranks, unique_id):
+        """join an RCCL communicator: collectives run on the backend's stream, no host in between"""
+        buf = C.create_string_buffer(unique_id, 128)
+        _ck(self.L.dlg_backend_init_rccl(self.h, rank, nranks, C.cast(buf, C.c_void_p)), "init_rccl")
+
+    def comm_size(self):
+        n = C.c_int()
+        _ck(self.L.dlg_backend_comm_size(self.h, C.byref(n)), "comm_size")
+        return n.value
 
     def set_pattern(self, Jp, Ji):
         Jp = np.ascontiguousarray(Jp, dtype=np.int32)

@@ -93,6 +93,7 @@ static size_t j_doubles(const dlg_backend* b)
 }
 
 // ---------------------------------------------------------------- lifecycle --
+static void rccl_release(dlg_backend* b);
 extern "C" int dlg_backend_create(dlg_backend_t** out, int solve_type, int Nstate, int Nmeas,
                                   int NJnnz, int flags, int device)
 {
@@ -113,7 +114,7 @@ extern "C" int dlg_backend_create(dlg_backend_t** out, int solve_type, int Nstat
   if(!b) { dlg_set_error("out of host memory"); return DLG_ERR_NOMEM; }
   b->type = solve_type; b->N = Nstate; b->M = Nmeas; b->nnz = NJnnz; b->flags = flags;
   b->device = device;
-  b->row0 = 0; b->row1 = Nmeas;
+  b->row0 = 0; b->row1 = Nmeas; b->mloc = Nmeas;
   *out = nullptr;
 
   auto fail = [&](int rc) { dlg_backend_destroy(b); return rc; };
@@ -165,6 +166,7 @@ extern "C" void dlg_backend_destroy(dlg_backend_t* b)
   if(!b) return;
   if(b->stream) (void)hipStreamSynchronize(b->stream);
   if(b->type == DLG_SPARSE) sparse_destroy(b); else dense_destroy(b);
+  rccl_release(b);
   for(int s = 0; s < 2; s++)
   {
     DlgSlot& S = b->slot[s];
@@ -211,14 +213,129 @@ extern "C" int dlg_backend_set_shard(dlg_backend_t* b, int row0, int row1, dlg_a
   { dlg_set_error("dense-products has no measurement rows to shard"); return DLG_ERR_ARG; }
   if(b->type == DLG_SPARSE && b->sym)
   { dlg_set_error("set the shard before dlg_sparse_set_pattern"); return DLG_ERR_STATE; }
-  b->row0 = row0; b->row1 = row1; b->allreduce = fn; b->allreduce_cookie = cookie;
-  if(fn) b->host_finals = false;          // the hook sums device scalars: they must be final on the device
+  b->row0 = row0; b->row1 = row1; b->mloc = row1 - row0;
+  if(fn) { b->allreduce = fn; b->allreduce_cookie = cookie; }
+  if(b->sharded()) b->host_finals = false;          // sums over the ranks act on device scalars: they must be final on the device
   return DLG_OK;
 }
 
-// sum-all-reduce `count` doubles at device address buf across ranks (no-op single rank)
+extern "C" int dlg_backend_set_allreduce(dlg_backend_t* b, dlg_allreduce_fn fn, void* cookie)
+{
+  if(!b) return DLG_ERR_ARG;
+  b->allreduce = fn; b->allreduce_cookie = cookie;
+  if(b->sharded()) b->host_finals = false;
+  return DLG_OK;
+}
+
+extern "C" int dlg_backend_set_partition(dlg_backend_t* b, int rank, int nranks)
+{
+  if(!b || nranks < 1 || rank < 0 || rank >= nranks)
+  { dlg_set_error("dlg_backend_set_partition: bad rank %d of %d", rank, nranks); return DLG_ERR_ARG; }
+  if(b->type != DLG_SPARSE)
+  { dlg_set_error("the subtree partition is a property of the sparse path (dense: dlg_backend_set_shard)"); return DLG_ERR_ARG; }
+  if(b->sym) { dlg_set_error("set the partition before dlg_sparse_set_pattern"); return DLG_ERR_STATE; }
+  b->part_rank = rank; b->part_nranks = nranks;
+  return DLG_OK;
+}
+
+// ---- RCCL, loaded on demand: the library itself does not depend on librccl.so ----------------
+#include <dlfcn.h>
+namespace {
+struct dlg_nccl_id { char internal[128]; };        // ncclUniqueId
+struct RcclApi
+{
+  void* lib = nullptr;
+  int (*GetUniqueId)(dlg_nccl_id*) = nullptr;
+  int (*CommInitRank)(void**, int, dlg_nccl_id, int) = nullptr;
+  int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  int (*CommDestroy)(void*) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+  int (*CommCount)(void*, int*) = nullptr;
+};
+RcclApi g_rccl;
+int rccl_load()
+{
+  if(g_rccl.lib) return DLG_OK;
+  const char* names[] = { "librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so" };
+  void* h = nullptr;
+  for(const char* n : names) { h = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if(h) break; }
+  if(!h) { dlg_set_error("cannot load librccl.so: %s", dlerror()); return DLG_ERR_COMM; }
+  RcclApi a; a.lib = h;
+  a.GetUniqueId  = (int (*)(dlg_nccl_id*))dlsym(h, "ncclGetUniqueId");
+  a.CommInitRank = (int (*)(void**, int, dlg_nccl_id, int))dlsym(h, "ncclCommInitRank");
+  a.AllReduce    = (int (*)(const void*, void*, size_t, int, int, void*, hipStream_t))dlsym(h, "ncclAllReduce");
+  a.CommDestroy  = (int (*)(void*))dlsym(h, "ncclCommDestroy");
+  a.GetErrorString = (const char* (*)(int))dlsym(h, "ncclGetErrorString");
+  a.CommCount    = (int (*)(void*, int*))dlsym(h, "ncclCommCount");
+  if(!a.GetUniqueId || !a.CommInitRank || !a.AllReduce || !a.CommDestroy)
+  { dlg_set_error("librccl.so lacks the NCCL entry points"); dlclose(h); return DLG_ERR_COMM; }
+  g_rccl = a;
+  return DLG_OK;
+}
+const char* rccl_err(int rc) { return g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "RCCL error"; }
+constexpr int DLG_NCCL_FLOAT64 = 8, DLG_NCCL_SUM = 0;
+}
+
+extern "C" int dlg_rccl_unique_id(void* out128)
+{
+  if(!out128) return DLG_ERR_ARG;
+  DLG_CHECK(rccl_load());
+  dlg_nccl_id id;
+  const int rc = g_rccl.GetUniqueId(&id);
+  if(rc != 0) { dlg_set_error("ncclGetUniqueId: %s", rccl_err(rc)); return DLG_ERR_COMM; }
+  memcpy(out128, &id, sizeof(id));
+  return DLG_OK;
+}
+extern "C" int dlg_backend_init_rccl(dlg_backend_t* b, int rank, int nranks, const void* unique_id128)
+{
+  if(!b || !unique_id128 || nranks < 1 || rank < 0 || rank >= nranks)
+  { dlg_set_error("dlg_backend_init_rccl: bad arguments"); return DLG_ERR_ARG; }
+  if(b->rccl_comm) { dlg_set_error("the backend already has a communicator"); return DLG_ERR_STATE; }
+  DLG_CHECK(rccl_load());
+  DLG_HIP(hipSetDevice(b->device));
+  dlg_nccl_id id; memcpy(&id, unique_id128, sizeof(id));
+  void* comm = nullptr;
+  const int rc = g_rccl.CommInitRank(&comm, nranks, id, rank);
+  if(rc != 0) { dlg_set_error("ncclCommInitRank(rank %d of %d): %s", rank, nranks, rccl_err(rc)); return DLG_ERR_COMM; }
+  b->rccl_comm = comm; b->rccl_owned = true;
+  b->host_finals = false;
+  return DLG_OK;
+}
+extern "C" int dlg_backend_set_rccl(dlg_backend_t* b, void* nccl_comm)
+{
+  if(!b || !nccl_comm) { dlg_set_error("dlg_backend_set_rccl: bad arguments"); return DLG_ERR_ARG; }
+  DLG_CHECK(rccl_load());
+  b->rccl_comm = nccl_comm; b->rccl_owned = false;
+  b->host_finals = false;
+  return DLG_OK;
+}
+extern "C" int dlg_backend_comm_size(dlg_backend_t* b, int* nranks)
+{
+  if(!b || !nranks) return DLG_ERR_ARG;
+  *nranks = 1;
+  if(b->rccl_comm && g_rccl.CommCount)
+  {
+    const int rc = g_rccl.CommCount(b->rccl_comm, nranks);
+    if(rc != 0) { dlg_set_error("ncclCommCount: %s", rccl_err(rc)); return DLG_ERR_COMM; }
+  }
+  return DLG_OK;
+}
+static void rccl_release(dlg_backend* b)
+{
+  if(b->rccl_comm && b->rccl_owned && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(b->rccl_comm);
+  b->rccl_comm = nullptr;
+}
+
+// sum-all-reduce `count` doubles at device address buf across ranks (no-op single rank): RCCL on the
+// backend's stream -- nothing for the host to wait for --, or the caller's hook behind a synchronisation
 static int allreduce(dlg_backend* b, double* buf, size_t count)
 {
+  if(b->rccl_comm)
+  {
+    const int rc = g_rccl.AllReduce(buf, buf, count, DLG_NCCL_FLOAT64, DLG_NCCL_SUM, b->rccl_comm, b->stream);
+    if(rc != 0) { dlg_set_error("ncclAllReduce(%zu doubles): %s", count, rccl_err(rc)); return DLG_ERR_COMM; }
+    return DLG_OK;
+  }
   if(!b->allreduce) return DLG_OK;
   DLG_HIP(hipStreamSynchronize(b->stream));
   if(b->allreduce(buf, count, b->allreduce_cookie) != 0)
@@ -314,7 +431,7 @@ extern "C" int dlg_point_eval(dlg_backend_t* b, int s, double* norm2_x, double* 
   }
   else
   {
-    const int mloc = b->row1 - b->row0;
+    const int mloc = dlg_mloc(b);
     {
       DlgProfScope ps(b, DLG_PROF_K1_JTX);
       if(b->type == DLG_SPARSE) DLG_CHECK(sparse_eval(b, s)); else DLG_CHECK(dense_eval(b, s));
@@ -323,7 +440,7 @@ extern "C" int dlg_point_eval(dlg_backend_t* b, int s, double* norm2_x, double* 
     // norm2_x over the local rows
     if(mloc > 0) DLG_CHECK(k_norm2_absmax(b, S.xin(), mloc, b->d_scal));
     else         DLG_HIP(hipMemsetAsync(b->d_scal, 0, 2*sizeof(double), b->stream));
-    if(b->allreduce)
+    if(b->sharded())
     {
       // fused reduce buffer [Jt_x | norm2_x]
       if(!b->d_red) DLG_HIP(hipMalloc(&b->d_red, sizeof(double)*((size_t)b->N + 8)));
@@ -372,7 +489,7 @@ static int cauchy_enqueue(dlg_backend* b, int s, double* sc)
 // that event and the main stream waits for them before anything reads the Cauchy step.
 static int cauchy_fork_begin(dlg_backend* b)
 {
-  b->want_fork = b->overlap && b->aux_stream && !b->allreduce;
+  b->want_fork = b->overlap && b->aux_stream && !b->sharded();    // (one communicator: its collectives stay on one stream)
   b->fork_recorded = false;
   return DLG_OK;
 }
@@ -686,7 +803,6 @@ extern "C" int dlg_take_step(dlg_backend_t* b, int from, int to, double trustreg
   DlgSlot& T = b->slot[to];
   if(!F.have_inputs) { dlg_set_error("dlg_take_step: slot %d has no J/JtJ", from); return DLG_ERR_STATE; }
   if(!F.have_Jtx) { dlg_set_error("dlg_take_step needs Jt_x"); return DLG_ERR_STATE; }
-  if(b->allreduce) { dlg_set_error("dlg_take_step is not available with row sharding"); return DLG_ERR_STATE; }
   if(!b->d_gnpart) DLG_HIP(hipMalloc(&b->d_gnpart, sizeof(double)*1024));
   double lam = *lambda_io;
   bool side_copy = false;

@@ -104,11 +104,20 @@ struct dlg_backend
   // sparse
   SparseSym* sym = nullptr;
 
-  // sharding
-  int row0 = 0, row1 = 0;     // owned measurement rows
+  // multi-GPU: measurement rows are the sharded unit.  Contiguous rows [row0, row1) (dense; sparse
+  // "row sharding": every rank factors everything, the whole JtJ is summed), or the subtree
+  // partition of the sparse path (part_nranks > 1: the rank's rows are chosen by the symbolic phase,
+  // only the top of the elimination tree is summed).  Sums over the ranks: RCCL on the backend's
+  // stream (rccl_comm: no host in between), or the caller's hook (host-synchronous fallback).
+  int row0 = 0, row1 = 0;     // owned measurement rows (contiguous mode)
+  int mloc = 0;               // measurement rows held by this rank
+  int part_rank = 0, part_nranks = 1;
   dlg_allreduce_fn allreduce = nullptr;
   void* allreduce_cookie = nullptr;
+  void* rccl_comm = nullptr;  // ncclComm_t
+  bool  rccl_owned = false;
   double* d_red = nullptr;    // fused reduce buffer [Jt_x | norm2_x | ...]
+  bool sharded() const { return allreduce != nullptr || rccl_comm != nullptr; }
 
   // optional per-phase timing with HIP events on b->stream (dlg_backend_set_profiling)
   bool profiling = false;
@@ -133,7 +142,7 @@ struct DlgProfScope
 };
 
 // rows of the measurement vector owned by this rank
-static inline int dlg_mloc(const dlg_backend* b) { return b->row1 - b->row0; }
+static inline int dlg_mloc(const dlg_backend* b) { return b->mloc; }
 // sum-all-reduce over ranks of `count` doubles at device address buf (no-op single rank)
 int dlg_allreduce_dev(dlg_backend* b, double* buf, size_t count);
 

@@ -617,7 +617,7 @@ int dense_factorize(dlg_backend* b, int s, double lambda, int* ok)
   DlgSlot& S = b->slot[s];
   DLG_HIP(hipMemsetAsync(b->d_info, 0, sizeof(int), b->stream));
   // K4: G(lower) = J^T J + lambda I   (K = M measurement rows, A = J with lda = N)
-  const bool sharded = b->allreduce != nullptr;
+  const bool sharded = b->sharded();
   {
     DlgProfScope pt(b, DLG_PROF_K4_TOTAL);
     DLG_CHECK(launch_syrk<64>(b->stream, b->G, b->N, S.Jin(), b->N, b->N, dlg_mloc(b), 1.0,

@@ -507,29 +507,37 @@ __global__ void __launch_bounds__(1024) k_assemble_fin(const AsmFin* __restrict_
     }
   }
 }
+// `phase` selects the columns by the owner of their supernode (subtree partition): -1 all of them,
+// 0 the columns of supernodes below the cut, 1 the columns of the replicated supernodes above it
+__device__ __forceinline__ bool phase_has(const int* __restrict__ sn_owner, int s, int phase)
+{ return phase < 0 || (phase == 0) == (sn_owner[s] >= 0); }
 __global__ void __launch_bounds__(TPB) k_add_lambda(double* __restrict__ Lx,
                                                     const int64_t* __restrict__ diagpos, int n,
-                                                    double lambda)
+                                                    double lambda, const int* __restrict__ col_sn,
+                                                    const int* __restrict__ sn_owner, int phase)
 {
   const int i = blockIdx.x*TPB + threadIdx.x;
-  if(i < n) Lx[diagpos[i]] += lambda;
+  if(i < n && phase_has(sn_owner, col_sn[i], phase)) Lx[diagpos[i]] += lambda;
 }
 
-// augmented row: panel(last row, column k) = rhs[perm[k]]
+// augmented row: panel(last row, column k) += rhs[perm[k]]   (the row is zero after the assembly;
+// above the cut of a subtree partition it already carries the updates from below)
 __global__ void __launch_bounds__(TPB) k_set_aug_row(double* __restrict__ Lx, const int* __restrict__ col_sn,
                                                      const int* __restrict__ sn_c0,
                                                      const int* __restrict__ sn_rowptr,
                                                      const int64_t* __restrict__ sn_lx,
                                                      const int* __restrict__ perm,
                                                      const double* __restrict__ rhs, int n,
-                                                     int* __restrict__ info)
+                                                     int* __restrict__ info,
+                                                     const int* __restrict__ sn_owner, int phase)
 {
   const int k = blockIdx.x*TPB + threadIdx.x;
-  if(k == 0) *info = 0x7fffffff;          // re-arm the pivot flag of the factorisation that follows
+  if(k == 0 && phase <= 0) *info = 0x7fffffff;          // re-arm the pivot flag of the factorisation that follows
   if(k >= n) return;
   const int s = col_sn[k];
+  if(!phase_has(sn_owner, s, phase)) return;
   const int nrows = sn_rowptr[s+1] - sn_rowptr[s];
-  Lx[sn_lx[s] + (nrows - 1) + (int64_t)(k - sn_c0[s])*nrows] = rhs[perm[k]];
+  Lx[sn_lx[s] + (nrows - 1) + (int64_t)(k - sn_c0[s])*nrows] += rhs[perm[k]];
 }
 
 // ------------------------------------------------------------------ K1 ------
@@ -763,12 +771,13 @@ __global__ void __launch_bounds__(TPB) k_unpack(double* __restrict__ Lx, const u
                                                 const double* __restrict__ buf)
 { for(size_t i = blockIdx.x*(size_t)TPB + threadIdx.x; i < n; i += (size_t)gridDim.x*TPB) Lx[idx[i]] = buf[i]; }
 }
-static int allreduce_panels(dlg_backend* b)
+static int allreduce_panels(dlg_backend* b, bool* again)
 {
+  *again = false;
   SparseSym* Y = b->sym;
   const SymHost& H = Y->H;
   hipStream_t st = b->stream;
-  if(!b->allreduce) return DLG_OK;
+  if(!b->sharded() || H.part_nranks > 1) return DLG_OK;      // (subtree partition: sparse_partition_reduce, at the cut)
   if((size_t)H.lx_size >= ((size_t)1 << 32) || getenv("DOGLEG_AMD_ALLREDUCE_FULL"))
     return dlg_allreduce_dev(b, Y->Lx, (size_t)H.lx_size);
   if(!Y->ar_idx)
@@ -792,7 +801,8 @@ static int allreduce_panels(dlg_backend* b)
     Y->ar_n = idx.size();
     DLG_CHECK(upload(Y->ar_idx, idx)); Y->allocs.push_back(Y->ar_idx);
     DLG_HIP(hipMalloc(&Y->ar_buf, sizeof(double)*(Y->ar_n ? Y->ar_n : 1))); Y->allocs.push_back(Y->ar_buf);
-    return 1;                                   // tell the caller to assemble again
+    *again = true;                              // tell the caller to assemble again
+    return DLG_OK;
   }
   hipLaunchKernelGGL(k_pack, dim3(2048), dim3(TPB), 0, st, Y->Lx, Y->ar_idx, Y->ar_n, Y->ar_buf);
   DLG_LAUNCH_CHECK();
@@ -813,29 +823,91 @@ int sparse_assemble(dlg_backend* b, int s, double lambda)
     DlgProfScope pt(b, DLG_PROF_K4_TOTAL);
     DLG_CHECK(assemble_launch(b, S.Jin()));
   }
-  // rows are sharded: sum the partial JtJ of all ranks before factorising
+  // contiguous row sharding: sum the partial JtJ of all ranks before factorising
   {
-    const int rc = allreduce_panels(b);
-    if(rc == 1)
+    bool again = false;
+    DLG_CHECK(allreduce_panels(b, &again));
+    if(again)
     {
       DLG_CHECK(assemble_launch(b, S.Jin()));
-      DLG_CHECK(allreduce_panels(b));
+      DLG_CHECK(allreduce_panels(b, &again));
     }
-    else DLG_CHECK(rc);
   }
+  // subtree partition: the replicated panels above the cut get lambda and their right-hand side after
+  // the sum over the ranks (sparse_partition_reduce); everything else here
+  const int phase = H.part_nranks > 1 ? 0 : -1;
   if(lambda != 0.0)
     hipLaunchKernelGGL(k_add_lambda, dim3(dlg_cdiv(H.N, TPB)), dim3(TPB), 0, st, Y->Lx, Y->diagpos, H.N,
-                       lambda);
+                       lambda, Y->col_sn, Y->sn_owner, phase);
   // the right-hand side rides along as the last row of every panel: y = L^-1 P Jt_x falls out
   Y->aug_rhs = nullptr;
   Y->info_armed = false;
   if(S.have_Jtx)
   {
     hipLaunchKernelGGL(k_set_aug_row, dim3(dlg_cdiv(H.N, TPB)), dim3(TPB), 0, st, Y->Lx, Y->col_sn, Y->sn_c0,
-                       Y->sn_rowptr, Y->sn_lx, Y->perm, S.Jt_x, H.N, Y->d_info);
+                       Y->sn_rowptr, Y->sn_lx, Y->perm, S.Jt_x, H.N, Y->d_info, Y->sn_owner, phase);
     Y->aug_rhs = S.Jt_x;
     Y->info_armed = true;
   }
+  DLG_LAUNCH_CHECK();
+  return DLG_OK;
+}
+
+// ---- subtree partition: the one sum over the ranks inside a factorisation ----------------------
+// Between the last level below the cut and the first one above it: the panels of the replicated
+// supernodes (assembled entries of every rank's rows + the updates of every rank's subtrees, all
+// partial sums) and the update matrices that cross the cut are packed, summed (RCCL on the stream,
+// or the hook) and unpacked; then the replicated panels get lambda and their right-hand side, once.
+namespace {
+__global__ void __launch_bounds__(TPB) k_red_pack(const int64_t* __restrict__ off, const int* __restrict__ len,
+                                                  const int* __restrict__ kind, const int64_t* __restrict__ dst,
+                                                  const double* __restrict__ Lx, const double* __restrict__ uscr,
+                                                  double* __restrict__ buf, size_t total, const int* __restrict__ info)
+{
+  const int sg = blockIdx.y;
+  const double* src = (kind[sg] == 0 ? Lx : uscr) + off[sg];
+  double* d = buf + dst[sg];
+  const int n = len[sg];
+  const bool zero = kind[sg] == 2;              // another rank's update matrix: nothing from here
+  for(int i = blockIdx.x*TPB + threadIdx.x; i < n; i += gridDim.x*TPB) d[i] = zero ? 0.0 : src[i];
+  // the pivot flag of the levels below the cut rides along: a rank sees only its own subtrees' pivots,
+  // but every rank must take the same decision (and raise lambda together)
+  if(sg == 0 && blockIdx.x == 0 && threadIdx.x == 0) buf[total] = (*info != 0x7fffffff) ? 1.0 : 0.0;
+}
+__global__ void __launch_bounds__(TPB) k_red_unpack(const int64_t* __restrict__ off, const int* __restrict__ len,
+                                                    const int* __restrict__ kind, const int64_t* __restrict__ dst,
+                                                    double* __restrict__ Lx, double* __restrict__ uscr,
+                                                    const double* __restrict__ buf, size_t total, int* __restrict__ info)
+{
+  const int sg = blockIdx.y;
+  double* d = (kind[sg] == 0 ? Lx : uscr) + off[sg];
+  const double* src = buf + dst[sg];
+  const int n = len[sg];
+  for(int i = blockIdx.x*TPB + threadIdx.x; i < n; i += gridDim.x*TPB) d[i] = src[i];
+  if(sg == 0 && blockIdx.x == 0 && threadIdx.x == 0 && buf[total] > 0.0) atomicMin(info, 0);
+}
+}
+int sparse_partition_reduce(dlg_backend* b)
+{
+  SparseSym* Y = b->sym;
+  const SymHost& H = Y->H;
+  hipStream_t st = b->stream;
+  if(H.part_nranks <= 1) return DLG_OK;
+  if(Y->n_red_seg > 0)
+  {
+    hipLaunchKernelGGL(k_red_pack, dim3(16, Y->n_red_seg), dim3(TPB), 0, st, Y->red_off, Y->red_len, Y->red_kind,
+                       Y->red_dst, Y->Lx, Y->uscr, Y->red_buf, Y->red_n, Y->d_info);
+    DLG_LAUNCH_CHECK();
+    DLG_CHECK(dlg_allreduce_dev(b, Y->red_buf, Y->red_n + 1));
+    hipLaunchKernelGGL(k_red_unpack, dim3(16, Y->n_red_seg), dim3(TPB), 0, st, Y->red_off, Y->red_len, Y->red_kind,
+                       Y->red_dst, Y->Lx, Y->uscr, Y->red_buf, Y->red_n, Y->d_info);
+  }
+  if(Y->cur_lambda != 0.0)
+    hipLaunchKernelGGL(k_add_lambda, dim3(dlg_cdiv(H.N, TPB)), dim3(TPB), 0, st, Y->Lx, Y->diagpos, H.N,
+                       Y->cur_lambda, Y->col_sn, Y->sn_owner, 1);
+  if(Y->aug_rhs)
+    hipLaunchKernelGGL(k_set_aug_row, dim3(dlg_cdiv(H.N, TPB)), dim3(TPB), 0, st, Y->Lx, Y->col_sn, Y->sn_c0,
+                       Y->sn_rowptr, Y->sn_lx, Y->perm, Y->aug_rhs, H.N, Y->d_info, Y->sn_owner, 1);
   DLG_LAUNCH_CHECK();
   return DLG_OK;
 }

@@ -1030,6 +1030,7 @@ int sparse_factor_levels(dlg_backend* b)
   SparseSym* Y = b->sym;
   const SymHost& H = Y->H;
   hipStream_t st = b->stream;
+  if(H.part_nranks > 1 && H.cut_level < 0) DLG_CHECK(sparse_partition_reduce(b));     // nothing below the cut
   for(int l = 0; l < H.nlevels; l++)
   {
     const int n = H.fw_lvl_ptr[l+1] - H.fw_lvl_ptr[l];
@@ -1054,15 +1055,15 @@ int sparse_factor_levels(dlg_backend* b)
     const int nu = H.uw_lvl_ptr[l+1] - H.uw_lvl_ptr[l];
     if(nu > 0 && H.upd_syrk[l] && Y->upd_nw[l] > 0)
     {
-      const int ns = H.lvl_ptr[l+1] - H.lvl_ptr[l];
-      if(Y->syrk_fused[l]) { /* phase 1 was done by the factor kernel */ }
+      const int ns = H.xl_ptr[l+1] - H.xl_ptr[l];
+      if(Y->syrk_fused[l] || ns == 0) { /* phase 1 was done by the factor kernel */ }
       else if(Y->syrk_nt[l] == 256)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_update_syrk<256>), dim3(ns), dim3(256), Y->syrk_lds[l], st,
-                           Y->lvl_sn + H.lvl_ptr[l], Y->sn_c0, Y->sn_rowptr, Y->sn_lx, Y->u_off, Y->Lx, Y->uscr,
+                           Y->xl_sn + H.xl_ptr[l], Y->sn_c0, Y->sn_rowptr, Y->sn_lx, Y->u_off, Y->Lx, Y->uscr,
                            Y->syrk_kc[l]);
       else
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_update_syrk<1024>), dim3(ns), dim3(1024), Y->syrk_lds[l], st,
-                           Y->lvl_sn + H.lvl_ptr[l], Y->sn_c0, Y->sn_rowptr, Y->sn_lx, Y->u_off, Y->Lx, Y->uscr,
+                           Y->xl_sn + H.xl_ptr[l], Y->sn_c0, Y->sn_rowptr, Y->sn_lx, Y->u_off, Y->Lx, Y->uscr,
                            Y->syrk_kc[l]);
       hipLaunchKernelGGL(k_update_gather, dim3(nu), dim3(TPB), Y->upd_lds[l], st, H.uw_lvl_ptr[l],
                          Y->uw_item, Y->uw_s0, Y->uw_s1, Y->uw_part, Y->ui_t, Y->ui_col, Y->ui_nc,
@@ -1086,6 +1087,8 @@ int sparse_factor_levels(dlg_backend* b)
       hipLaunchKernelGGL(k_update_fin, dim3(nfz, Y->fin_ny[l]), dim3(TPB), 0, st, H.uf_lvl_ptr[l], Y->uf_item, Y->uf_n,
                          Y->uf_off, Y->ui_t, Y->ui_col, Y->ui_nc, Y->sn_rowptr, Y->sn_lx, Y->Lx,
                          Y->upart);
+    // subtree partition: everything below the cut is done -- the sum over the ranks, then the replicated top
+    if(H.part_nranks > 1 && l == H.cut_level) { DLG_LAUNCH_CHECK(); DLG_CHECK(sparse_partition_reduce(b)); }
   }
   if(!H.ms_sn.empty())
     hipLaunchKernelGGL(k_copy_top, dim3((unsigned)H.ms_sn.size()), dim3(TPB), 0, st, Y->ms_sn, Y->sn_c0,

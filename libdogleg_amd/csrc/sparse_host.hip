@@ -27,16 +27,18 @@ int sparse_set_pattern(dlg_backend* b, const int* colptr, const int* rowidx)
   if(!Y) { dlg_set_error("out of host memory"); return DLG_ERR_NOMEM; }
   b->sym = Y;
   char err[512];
-  if(sym_analyze(Y->H, b->N, b->M, colptr, rowidx, b->row0, b->row1, err, sizeof(err)))
+  if(sym_analyze(Y->H, b->N, b->M, colptr, rowidx, b->row0, b->row1, err, sizeof(err), b->part_rank, b->part_nranks))
   { dlg_set_error("symbolic analysis: %s", err); return DLG_ERR_ARG; }
   SymHost& H = Y->H;
+  const bool partition = H.part_nranks > 1;
+  if(partition) b->mloc = (int)H.part_rows.size();
   UP(sn_c0); UP(sn_rowptr); UP(sn_rows); UP(sn_scr); UP(lvl_sn); UP(sn_lx); UP(diagpos);
   UP(ui_t); UP(ui_col); UP(ui_nc); UP(ui_ptr); UP(usub); UP(relpos); UP(u_off); UP(usub_u); UP(fw_item); UP(mf_rec); UP(mf_dst);
   UP(uw_item); UP(uw_s0); UP(uw_s1); UP(uw_part); UP(uf_item); UP(uf_n); UP(uf_off);
   UP(oblk); UP(contrib); UP(jtx_task); UP(jtx_fin_ptr); UP(jtx_fin_blk);
   UP(asm_rho); UP(asm_pair); UP(asm_slot); UP(asm_batch); UP(asm_ctask); UP(asm_cfin);
   UP(asm_shape); UP(asm_kg); UP(asm_mtask); UP(asm_tdest); UP(asm_fin2); UP(asm_fin2_list); UP(asm_run); UP(asm_pdest);
-  UP(rl_ptr); UP(rl_pos); UP(perm); UP(col_sn); UP(fw_sn); UP(fw_r0); UP(fw_r1); UP(ms_sn); UP(sn_top); UP(sn_bd_ptr); UP(sn_bd_col);
+  UP(rl_ptr); UP(rl_pos); UP(perm); UP(col_sn); UP(sn_owner); UP(xl_sn); UP(fw_sn); UP(fw_r0); UP(fw_r1); UP(ms_sn); UP(sn_top); UP(sn_bd_ptr); UP(sn_bd_col);
   {
     // Jt*x partial lists: the few long ones (a dense block that every row touches) get a big workgroup each
     std::vector<int> fs, fl;
@@ -48,11 +50,24 @@ int sparse_set_pattern(dlg_backend* b, const int* colptr, const int* rowidx)
   }
   // rank-local pattern for the row-wise kernels
   {
-    const int mloc = b->row1 - b->row0;
-    const int q0 = colptr[b->row0], q1 = colptr[b->row1];
-    Y->nnz_loc = (size_t)(q1 - q0);
-    std::vector<int> jp(mloc + 1), ji(rowidx + q0, rowidx + q1);
-    for(int r = 0; r <= mloc; r++) jp[r] = colptr[b->row0 + r] - q0;
+    const int mloc = dlg_mloc(b);
+    std::vector<int> jp(mloc + 1), ji;
+    if(partition)
+    {
+      // the rank's rows are scattered: its local pattern is their concatenation
+      jp[0] = 0;
+      for(int k = 0; k < mloc; k++) { const int r = H.part_rows[k]; jp[k+1] = jp[k] + (colptr[r+1] - colptr[r]); }
+      ji.resize((size_t)jp[mloc]);
+      for(int k = 0; k < mloc; k++) { const int r = H.part_rows[k]; memcpy(&ji[jp[k]], rowidx + colptr[r], sizeof(int)*(size_t)(colptr[r+1] - colptr[r])); }
+      Y->nnz_loc = (size_t)jp[mloc];
+    }
+    else
+    {
+      const int q0 = colptr[b->row0], q1 = colptr[b->row1];
+      Y->nnz_loc = (size_t)(q1 - q0);
+      ji.assign(rowidx + q0, rowidx + q1);
+      for(int r = 0; r <= mloc; r++) jp[r] = colptr[b->row0 + r] - q0;
+    }
     DLG_CHECK(upload(Y->Jp, jp)); Y->allocs.push_back(Y->Jp);
     DLG_CHECK(upload(Y->Ji, ji)); Y->allocs.push_back(Y->Ji);
     std::vector<int> ch; ch.push_back(0);
@@ -81,8 +96,98 @@ int sparse_set_pattern(dlg_backend* b, const int* colptr, const int* rowidx)
   Y->d_info = reinterpret_cast<int*>(b->d_scal + (dlg_backend::NSCAL - 1));
   Y->h_info = reinterpret_cast<int*>(b->h_scal + (dlg_backend::NSCAL - 1));
 
+  if(partition)
+  {
+    // what crosses the ranks at the cut: the panels of the replicated supernodes (kind 0: every rank
+    // holds a partial sum) and the update matrices of the multifrontal region whose parent is
+    // replicated and whose owner is one rank (kind 1: mine, kind 2: another rank's -- zeros from here)
+    std::vector<int64_t> off, dst; std::vector<int> len, kind;
+    int64_t n = 0;
+    auto seg = [&](int64_t o, int64_t l, int k) {
+      while(l > 0) { const int64_t c = std::min<int64_t>(l, 1 << 30); off.push_back(o); len.push_back((int)c); kind.push_back(k); dst.push_back(n); n += c; o += c; l -= c; } };
+    std::vector<int> parent(H.nsn, -1);
+    for(int t = 0; t < H.nsn; t++) for(int k = H.mf_cptr[t]; k < H.mf_cptr[t+1]; k++) parent[H.mf_child[k]] = t;
+    for(int s2 = 0; s2 < H.nsn; s2++)
+    {
+      if(H.sn_owner[s2] < 0) seg(H.sn_lx[s2], H.sn_lx[s2+1] - H.sn_lx[s2], 0);
+      else if(H.sn_level[s2] >= H.mf_level0 && parent[s2] >= 0 && H.sn_owner[parent[s2]] < 0)
+      {
+        const int64_t mb = (H.sn_rowptr[s2+1] - H.sn_rowptr[s2]) - (H.sn_c0[s2+1] - H.sn_c0[s2]);
+        seg(H.u_off[s2], mb*(mb + 1)/2, H.sn_owner[s2] == H.part_rank ? 1 : 2);
+      }
+    }
+    Y->n_red_seg = (int)off.size(); Y->red_n = (size_t)n;
+    DLG_CHECK(upload(Y->red_off, off)); Y->allocs.push_back(Y->red_off);
+    DLG_CHECK(upload(Y->red_len, len)); Y->allocs.push_back(Y->red_len);
+    DLG_CHECK(upload(Y->red_kind, kind)); Y->allocs.push_back(Y->red_kind);
+    DLG_CHECK(upload(Y->red_dst, dst)); Y->allocs.push_back(Y->red_dst);
+    DLG_CHECK(dalloc(Y->red_buf, Y->red_n + 8));
+    // the solution is completed by a sum over the ranks: every variable counts on exactly one rank
+    std::vector<double> mask((size_t)H.N, 0.0);
+    for(int k = 0; k < H.N; k++)
+    {
+      const int o = H.sn_owner[H.col_sn[k]];
+      if(o == H.part_rank || (o < 0 && H.part_rank == 0)) mask[H.perm[k]] = 1.0;
+    }
+    DLG_CHECK(upload(Y->colmask, mask)); Y->allocs.push_back(Y->colmask);
+  }
   DLG_CHECK(sparse_factor_setup(b));
   DLG_CHECK(sparse_solve_setup(b));
+  return DLG_OK;
+}
+
+extern "C" int dlg_partition_rows(dlg_backend_t* b, int* nrows, const int** rows)
+{
+  if(!b || !b->sym) { dlg_set_error("no symbolic analysis yet"); return DLG_ERR_STATE; }
+  SymHost& H = b->sym->H;
+  if(H.part_nranks <= 1 && H.part_rows.empty())         // not partitioned: the contiguous range of the backend
+    for(int r = b->row0; r < b->row1; r++) H.part_rows.push_back(r);
+  if(nrows) *nrows = (int)H.part_rows.size();
+  if(rows) *rows = H.part_rows.data();
+  return DLG_OK;
+}
+static void partition_stats(const SymHost& H, long* stats, int nstats)
+{
+  long ntop = 0, nmine = 0, red = 0;
+  std::vector<int> parent(H.nsn, -1);
+  for(int t = 0; t < H.nsn; t++) for(int k = H.mf_cptr[t]; k < H.mf_cptr[t+1]; k++) parent[H.mf_child[k]] = t;
+  for(int s2 = 0; s2 < H.nsn; s2++)
+  {
+    if(H.sn_owner[s2] < 0) { ntop++; red += (long)(H.sn_lx[s2+1] - H.sn_lx[s2]); }
+    else
+    {
+      if(H.sn_owner[s2] == H.part_rank) nmine++;
+      if(H.sn_level[s2] >= H.mf_level0 && parent[s2] >= 0 && H.sn_owner[parent[s2]] < 0)
+      { const long mb = (H.sn_rowptr[s2+1] - H.sn_rowptr[s2]) - (H.sn_c0[s2+1] - H.sn_c0[s2]); red += mb*(mb + 1)/2; }
+    }
+  }
+  long nnz_loc = 0;
+  const long v[] = { (long)H.cut_level, ntop, nmine, (long)H.part_rows.size(), red, (long)H.lx_size, nnz_loc };
+  for(int i = 0; i < nstats && i < (int)(sizeof(v)/sizeof(v[0])); i++) stats[i] = v[i];
+}
+extern "C" int dlg_partition_stats(dlg_backend_t* b, long* stats, int nstats)
+{
+  if(!b || !b->sym || !stats) { dlg_set_error("no symbolic analysis yet"); return DLG_ERR_STATE; }
+  partition_stats(b->sym->H, stats, nstats);
+  if(nstats > 6) stats[6] = (long)b->sym->nnz_loc;
+  return DLG_OK;
+}
+extern "C" int dlg_sparse_partition_probe(int N, int M, const int* colptr, const int* rowidx, int rank, int nranks,
+                                          long* stats, int nstats, char* row_owner)
+{
+  if(nranks < 1 || rank < 0 || rank >= nranks) { dlg_set_error("bad rank %d of %d", rank, nranks); return DLG_ERR_ARG; }
+  SymHost H;
+  char err[512];
+  if(sym_analyze(H, N, M, colptr, rowidx, 0, M, err, sizeof(err), rank, nranks))
+  { dlg_set_error("symbolic analysis: %s", err); return DLG_ERR_ARG; }
+  if(stats) partition_stats(H, stats, nstats);
+  if(stats && nstats > 6)
+  { long z = 0; for(int r : H.part_rows) z += colptr[r+1] - colptr[r]; stats[6] = nranks > 1 ? z : (long)colptr[M]; }
+  if(row_owner)
+  {
+    memset(row_owner, nranks > 1 ? 0 : 1, (size_t)M);
+    for(int r : H.part_rows) row_owner[r] = 1;
+  }
   return DLG_OK;
 }
 
@@ -105,6 +210,7 @@ int sparse_factorize(dlg_backend* b, int s, double lambda, int* ok)
   SparseSym* Y = b->sym;
   if(!Y) { dlg_set_error("dlg_sparse_set_pattern must be called first"); return DLG_ERR_STATE; }
   hipStream_t st = b->stream;
+  Y->cur_lambda = lambda;
   DLG_CHECK(sparse_assemble(b, s, lambda));
   DlgProfScope pf(b, DLG_PROF_K5_FACTOR);
   if(!Y->info_armed)

@@ -99,6 +99,15 @@ struct SparseSym
   // per-level launch parameters
   std::vector<int> fac_lds;     // bytes of LDS for the factor kernel of a level (0: panels stay in HBM)
   std::vector<int> upd_lds, upd_nw, slv_lds, bwd_lds, fac_nt, upd_coop, syrk_lds, syrk_nt, syrk_kc, bwd_nt, syrk_fused, fin_ny, fac_stage, bwd_top, bwd_bd;
+  // subtree partition (part_nranks > 1): what is summed over the ranks between the last level below
+  // the cut and the first one above it -- segments of Lx (panels above the cut) and of uscr (update
+  // matrices that cross the cut), packed into red_buf --, and the 0/1 mask that makes the solution
+  // a sum over the ranks (own subtrees everywhere, the replicated top on rank 0 only)
+  int64_t* red_off = nullptr; int* red_len = nullptr; int* red_kind = nullptr; int64_t* red_dst = nullptr;
+  int n_red_seg = 0; size_t red_n = 0; double* red_buf = nullptr;
+  double* colmask = nullptr; int* sn_owner = nullptr;
+  int *xl_sn = nullptr;
+  double cur_lambda = 0.0;              // of the factorisation being enqueued (the top panels get it after the sum)
   bool fac_ahead = false;       // panel_factor_ahead instead of panel_factor_mfma (DOGLEG_AMD_AHEAD)
   int bwd_xb_cap = 12288;       // below rows of a supernode staged in LDS by the backward solve
   std::vector<void*> allocs;
@@ -106,6 +115,7 @@ struct SparseSym
 
 // ---- per-file host entry points
 int sparse_assemble(dlg_backend* b, int s, double lambda);   // K4 (+ all-reduce, lambda, augmented row)
+int sparse_partition_reduce(dlg_backend* b);                 // subtree partition: the sum over the ranks at the cut
 int sparse_factor_setup(dlg_backend* b);                     // per-level launch parameters of K5
 int sparse_factor_levels(dlg_backend* b);                    // K5 launches (no synchronisation)
 int sparse_solve_setup(dlg_backend* b);                      // per-level launch parameters of K6

@@ -353,6 +353,12 @@ __global__ void __launch_bounds__(BWD_NT, BD_ONLY ? 4 : 1) k_solve_bwd_level(con
   BW_STAMP(5);
 }
 
+__global__ void __launch_bounds__(TPB) k_mask_vec(double* __restrict__ v, const double* __restrict__ mask, int n)
+{
+  const int i = blockIdx.x*TPB + threadIdx.x;
+  if(i < n) v[i] *= mask[i];
+}
+
 } // namespace
 
 // per-level launch parameters of the solve kernels
@@ -410,10 +416,11 @@ int sparse_solve_setup(dlg_backend* b)
     Y->bwd_bd[l] = allbd ? 1 : 0;
   }
   {
-    std::vector<SolveItem> items(H.nsn);
-    for(int k = 0; k < H.nsn; k++)
+    // (the supernodes this rank works on: all of them, or its subtrees + the replicated top)
+    std::vector<SolveItem> items(H.xl_sn.size());
+    for(int k = 0; k < (int)H.xl_sn.size(); k++)
     {
-      const int s = H.lvl_sn[k];
+      const int s = H.xl_sn[k];
       SolveItem& it = items[k];
       it.c0 = H.sn_c0[s]; it.w = H.sn_c0[s+1] - H.sn_c0[s]; it.nrows = H.sn_rowptr[s+1] - H.sn_rowptr[s];
       it.rowoff = H.sn_rowptr[s]; it.lx = H.sn_lx[s]; it.bd0 = H.sn_bd_ptr[s]; it.nbd = H.sn_bd_ptr[s+1] - H.sn_bd_ptr[s];
@@ -439,33 +446,44 @@ int sparse_solve(dlg_backend* b, const double* rhs, double* out)
   const SymHost& H = Y->H;
   hipStream_t st = b->stream;
   const int use_aug = (Y->aug_rhs != nullptr && Y->aug_rhs == rhs) ? 1 : 0;
+  if(H.part_nranks > 1 && !use_aug)
+  { dlg_set_error("with a subtree partition only the right-hand side that rode along with the factorisation (Jt x) can be solved for"); return DLG_ERR_STATE; }
   for(int l = 0; l < H.nlevels && !use_aug; l++)
   {
-    const int n = H.lvl_ptr[l+1] - H.lvl_ptr[l];
+    const int n = H.xl_ptr[l+1] - H.xl_ptr[l];
     if(n > 0)
-      hipLaunchKernelGGL(k_solve_fwd_level, dim3(n), dim3(TPB), Y->slv_lds[l], st, Y->lvl_sn + H.lvl_ptr[l],
+      hipLaunchKernelGGL(k_solve_fwd_level, dim3(n), dim3(TPB), Y->slv_lds[l], st, Y->xl_sn + H.xl_ptr[l],
                          Y->sn_c0, Y->sn_rowptr, Y->sn_lx, Y->sn_scr, Y->rl_ptr, Y->rl_pos, Y->perm,
                          Y->Lx, rhs, Y->scr, Y->ywork);
   }
+  // subtree partition: the entries of the other ranks' variables are zero here, and the replicated
+  // ones count on rank 0 only: the solution is the sum over the ranks
+  if(H.part_nranks > 1) DLG_HIP(hipMemsetAsync(out, 0, sizeof(double)*(size_t)H.N, st));
   for(int l = H.nlevels - 1; l >= 0; l--)
   {
-    const int n = H.lvl_ptr[l+1] - H.lvl_ptr[l];
+    const int n = H.xl_ptr[l+1] - H.xl_ptr[l];
     // thread = row of the diagonal block: 256 threads when every supernode of a populous level is
     // narrow (more workgroups per CU), else 512
     if(n > 0 && Y->bwd_nt[l] == 256 && Y->bwd_bd[l])
       hipLaunchKernelGGL(HIP_KERNEL_NAME(k_solve_bwd_level<256, true>), dim3(n), dim3(256), Y->bwd_lds[l], st,
-                         Y->slv_item + H.lvl_ptr[l], Y->sn_rows, Y->perm, Y->Lx, Y->ywork, out, use_aug, Y->sn_bd_col,
+                         Y->slv_item + H.xl_ptr[l], Y->sn_rows, Y->perm, Y->Lx, Y->ywork, out, use_aug, Y->sn_bd_col,
                          Y->bwd_top[l] + 256*l, Y->bwd_xb_cap);
     else if(n > 0 && Y->bwd_nt[l] == 256)
       hipLaunchKernelGGL(HIP_KERNEL_NAME(k_solve_bwd_level<256, false>), dim3(n), dim3(256), Y->bwd_lds[l], st,
-                         Y->slv_item + H.lvl_ptr[l], Y->sn_rows, Y->perm, Y->Lx, Y->ywork, out, use_aug, Y->sn_bd_col,
+                         Y->slv_item + H.xl_ptr[l], Y->sn_rows, Y->perm, Y->Lx, Y->ywork, out, use_aug, Y->sn_bd_col,
                          Y->bwd_top[l] + 256*l, Y->bwd_xb_cap);
     else if(n > 0)
       hipLaunchKernelGGL(HIP_KERNEL_NAME(k_solve_bwd_level<512, false>), dim3(n), dim3(512), Y->bwd_lds[l], st,
-                         Y->slv_item + H.lvl_ptr[l], Y->sn_rows, Y->perm, Y->Lx, Y->ywork, out, use_aug, Y->sn_bd_col,
+                         Y->slv_item + H.xl_ptr[l], Y->sn_rows, Y->perm, Y->Lx, Y->ywork, out, use_aug, Y->sn_bd_col,
                          Y->bwd_top[l] + 256*l, Y->bwd_xb_cap);
   }
   DLG_LAUNCH_CHECK();
+  if(H.part_nranks > 1)
+  {
+    hipLaunchKernelGGL(k_mask_vec, dim3(dlg_cdiv(H.N, TPB)), dim3(TPB), 0, st, out, Y->colmask, H.N);
+    DLG_LAUNCH_CHECK();
+    DLG_CHECK(dlg_allreduce_dev(b, out, (size_t)H.N));
+  }
   return DLG_OK;
 }
 

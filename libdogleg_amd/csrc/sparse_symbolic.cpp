@@ -28,7 +28,7 @@ int env_int(const char* name, int dflt)
 // single workgroup can get, so that fewer slices repeat the factorisation of the top block
 static int slice_cap() { return env_int("DOGLEG_AMD_SLICE_CAP", 20000); }
 
-struct RowBlock { int r0, nrows, len, base, vptr, nvb; bool local; };
+struct RowBlock { int r0, nrows, len, base, vptr, nvb; bool local; int lbase, lr0; };   // lbase / lr0: first value / first row in the rank-local arrays
 
 // ------------------------------------------------------------------ graph ---
 struct Graph
@@ -247,8 +247,10 @@ struct Orderer
 #define SYM_FAIL(...) do { snprintf(err, errlen, __VA_ARGS__); return 1; } while(0)
 
 int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0, int row1,
-                char* err, int errlen)
+                char* err, int errlen, int part_rank, int part_nranks)
 {
+  const bool partition = part_nranks > 1;
+  if(partition) { row0 = 0; row1 = M; }           // the rows of a rank are chosen below, not given
   // DOGLEG_AMD_SYM_DEBUG >= 2: wall time of every step on stderr
   const bool sym_time = env_int("DOGLEG_AMD_SYM_DEBUG", 0) >= 2;
   auto sym_t0 = std::chrono::steady_clock::now();
@@ -265,6 +267,7 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
 
   S = SymHost();
   S.N = N; S.M = M; S.nnz = cp[M]; S.row0 = row0; S.row1 = row1;
+  S.part_rank = partition ? part_rank : 0; S.part_nranks = partition ? part_nranks : 1;
   if(cp[0] != 0) SYM_FAIL("Jt column pointers must start at 0");
 
   SYM_TICK("1 var-blocks");
@@ -319,6 +322,7 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
       {
         RowBlock b; b.r0 = r; b.nrows = 1; b.len = len; b.base = cp[r]; b.vptr = (int)rb_vb.size();
         b.local = (r >= row0 && r < row1);
+        b.lbase = b.base - cp[row0]; b.lr0 = r - row0;
         int e = 0;
         while(e < len)
         {
@@ -688,6 +692,70 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
     for(int s = 0; s < nsn; s++) S.lvl_sn[nx[S.sn_level[s]]++] = s;
   }
 
+  // ---- subtree partition (multi-GPU, SURVEY 8e "point ownership"): the elimination tree is cut
+  // above level `cut_level`; every subtree below the cut belongs to ONE rank, which holds the
+  // measurement rows whose first-eliminated variable lies in it, assembles, factors and solves it
+  // alone -- a row's variables are a clique of JtJ, so they all sit on one root path and a subtree's
+  // panels receive contributions from its owner's rows only.  The supernodes above the cut are
+  // replicated: their panels (assembled entries + the owners' updates, both partial sums) and the
+  // update matrices handed up across the cut are summed over the ranks once per factorisation.
+  std::vector<int> sn_parent0(nsn, -1);
+  for(int d = 0; d < nsn; d++) { const std::vector<int>& bl = st[sn_last(d)]; if(!bl.empty()) sn_parent0[d] = sn_of_b[bl[0]]; }
+  S.sn_owner.assign(nsn, -1);
+  S.cut_level = -1;
+  if(partition)
+  {
+    const int oversub = std::max(1, env_int("DOGLEG_AMD_PART_OVERSUB", 1));
+    for(int l = S.nlevels - 1; l >= 0; l--)
+      if(S.lvl_ptr[l+1] - S.lvl_ptr[l] >= part_nranks*oversub) { S.cut_level = l; break; }
+    if(env_int("DOGLEG_AMD_PART_CUT", -2) >= -1) S.cut_level = std::min(S.nlevels - 1, env_int("DOGLEG_AMD_PART_CUT", -1));
+    const int Lc = S.cut_level;
+    // weight of a subtree: panel entries (a proxy for its assembly, factorisation and solve work)
+    std::vector<double> wt(nsn, 0.0);
+    for(int d = 0; d < nsn; d++)
+    {
+      wt[d] += (double)(S.sn_rowptr[d+1] - S.sn_rowptr[d])*(S.sn_c0[d+1] - S.sn_c0[d]);
+      if(sn_parent0[d] >= 0 && S.sn_level[sn_parent0[d]] <= Lc) wt[sn_parent0[d]] += wt[d];     // parents come later
+    }
+    std::vector<int> roots;
+    for(int d = 0; d < nsn; d++)
+      if(S.sn_level[d] <= Lc && (sn_parent0[d] < 0 || S.sn_level[sn_parent0[d]] > Lc)) roots.push_back(d);
+    std::sort(roots.begin(), roots.end(), [&](int a, int b) { if(wt[a] != wt[b]) return wt[a] > wt[b]; return a < b; });
+    std::vector<double> load(part_nranks, 0.0);
+    for(int d : roots)
+    {
+      int best = 0;
+      for(int r = 1; r < part_nranks; r++) if(load[r] < load[best]) best = r;
+      S.sn_owner[d] = best; load[best] += wt[d];
+    }
+    for(int d = nsn - 1; d >= 0; d--)
+      if(S.sn_level[d] <= Lc && S.sn_owner[d] < 0) S.sn_owner[d] = S.sn_owner[sn_parent0[d]];
+    // rows: the row-blocks whose first-eliminated variable lies in one of this rank's subtrees; rows
+    // that only touch replicated variables are dealt out in turn
+    int lb = 0, lr = 0, turn = 0;
+    S.part_rows.clear();
+    for(int bi = 0; bi < nrb; bi++)
+    {
+      RowBlock& b = rbs[bi];
+      int qmin = nvb;
+      for(int x = 0; x < b.nvb; x++) qmin = std::min(qmin, bpos[rb_vb[b.vptr + x]]);
+      int own = S.sn_owner[sn_of_b[qmin]];
+      if(own < 0) own = (turn++) % part_nranks;
+      b.local = own == part_rank;
+      b.lbase = lb; b.lr0 = lr;
+      if(b.local) { lb += b.nrows*b.len; lr += b.nrows; for(int r = 0; r < b.nrows; r++) S.part_rows.push_back(b.r0 + r); }
+    }
+  }
+  auto mine = [&](int s) { return S.sn_owner[s] < 0 || S.sn_owner[s] == part_rank; };
+  // the supernodes this rank works on, by level (all of them on a single rank)
+  S.xl_ptr.assign(S.nlevels + 1, 0);
+  S.xl_sn.clear();
+  for(int l = 0; l < S.nlevels; l++)
+  {
+    for(int i = S.lvl_ptr[l]; i < S.lvl_ptr[l+1]; i++) if(mine(S.lvl_sn[i])) S.xl_sn.push_back(S.lvl_sn[i]);
+    S.xl_ptr[l+1] = (int)S.xl_sn.size();
+  }
+
   // factor work list: (supernode, slice of its below rows).  Panels larger than the LDS
   // budget are cut into row slices; every slice workgroup also holds the w x w top block
   // and factors it redundantly, only slice 0 publishes it (into top_scr, copied back at
@@ -710,7 +778,10 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
           int rpw = slice_cap()/w - w - 1; if(rpw < 1) rpw = 1;
           nsl = (below + rpw - 1)/rpw;
         }
-        if(nsl > 1) { S.sn_top[s] = S.top_size; S.top_size += (int64_t)w*w; S.ms_sn.push_back(s); }
+        // (the slicing of every supernode is recorded -- it decides where the multifrontal region
+        // starts, identically on every rank --, work items only for this rank's supernodes)
+        if(nsl > 1) { S.sn_top[s] = S.top_size; S.top_size += (int64_t)w*w; if(mine(s)) S.ms_sn.push_back(s); }
+        if(!mine(s)) continue;
         const int per = (below + nsl - 1)/nsl;
         for(int k = 0; k < nsl; k++)
         {
@@ -809,10 +880,10 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
           while(i < bl.size() && sn_of_b[bl[i]] == t) { krow += G.w[border[bl[i]]]; i++; }
           break;
         }
-        // one sub-task per target var-block
+        // one sub-task per target var-block (another rank's supernode is not a source here)
         while(i < bl.size() && sn_of_b[bl[i]] == t)
         {
-          subs.push_back({S.sn_level[d], t, bl[i], d, krow, relbase + (krow - k0)});
+          if(mine(d)) subs.push_back({S.sn_level[d], t, bl[i], d, krow, relbase + (krow - k0)});
           krow += G.w[border[bl[i]]];
           i++;
         }
@@ -1010,7 +1081,7 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
       if(!b.local) continue;
       for(int x = 0; x < b.nvb; x++)
       {
-        SymContrib c; c.base = b.base - cp[row0]; c.r0 = b.r0 - row0; c.len = (uint16_t)b.len;
+        SymContrib c; c.base = b.lbase; c.r0 = b.lr0; c.len = (uint16_t)b.len;
         c.nrows = (uint8_t)b.nrows; c.pad = 0; c.offI = c.offJ = (uint16_t)rb_off[b.vptr + x];
         S.contrib[nx[rb_vb[b.vptr + x]]++] = c;
       }
@@ -1219,7 +1290,6 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
       // 3. emit
       const int64_t panel = S.sn_lx[t] + (int64_t)lc*ld;
       const int first_task = (int)S.asm_mtask.size();
-      const int base0 = cp[row0];
       for(Cls& C : classes)
       {
         const int offJ = rb_off[rbs[rrb[C.es[0]]].vptr + rx[C.es[0]]];
@@ -1291,7 +1361,7 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
             }
             S.asm_mtask.push_back(T); task_open = true; kg_in_task = 0;
           }
-          const int base = b.base - base0;
+          const int base = b.lbase;
           if(b.nrows > 4)
           {
             close_kg();
@@ -1476,7 +1546,7 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
             S.asm_batch.push_back({(int)S.asm_rho.size(), -1}); batch_open = true; stage_used = 0; nb_in_task++;
             rho_in_batch = 0; pairs_in_batch = 0;
           }
-          AsmRho R; R.base = b.base - cp[row0]; R.pair0 = (int)S.asm_pair.size(); R.len = (uint16_t)b.len;
+          AsmRho R; R.base = b.lbase; R.pair0 = (int)S.asm_pair.size(); R.len = (uint16_t)b.len;
           R.offJ = (uint16_t)rb_off[b.vptr + rx[e]]; R.stage_off = direct ? (uint16_t)0xFFFF : (uint16_t)stage_used;
           R.nrows = (uint8_t)b.nrows; R.pad = 0;
           S.asm_rho.push_back(R);

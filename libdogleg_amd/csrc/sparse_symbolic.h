@@ -159,7 +159,12 @@ struct MfChild { int64_t u_off, dst_off; int npad, rsv; };
 struct SymHost
 {
   int N = 0, M = 0, nnz = 0;
-  int row0 = 0, row1 = 0;            // local rows
+  int row0 = 0, row1 = 0;            // local rows (contiguous row sharding)
+  // subtree partition (multi-GPU): owner rank of every supernode, -1 = above the cut (replicated on
+  // every rank); the supernodes this rank works on by level (xl_*: all of them on a single rank);
+  // the measurement rows this rank holds, in the order of its local x / J value arrays
+  int part_rank = 0, part_nranks = 1, cut_level = -1;
+  std::vector<int> sn_owner, xl_ptr, xl_sn, part_rows;
   // ---- blocks
   int nvb = 0;
   std::vector<int> vb_start;         // [nvb+1] original variable index
@@ -254,5 +259,7 @@ struct SymHost
 
 // Build everything.  colptr/rowidx: FULL pattern of Jt (CSC, Nstate x Nmeas).
 // Returns 0 on success; on failure returns nonzero and fills err.
+// part_nranks > 1: subtree partition -- the rank's rows are chosen by the analysis (S.part_rows),
+// row0 / row1 are ignored.
 int sym_analyze(SymHost& S, int N, int M, const int* colptr, const int* rowidx, int row0, int row1,
-                char* err, int errlen);
+                char* err, int errlen, int part_rank = 0, int part_nranks = 1);

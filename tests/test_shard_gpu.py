@@ -115,3 +115,139 @@ def test_dense_rows_sharded_over_two_logical_ranks(gpu):
         assert np.linalg.norm(r["step"] - full["step"]) <= 1e-10
         assert abs(r["n2x"] - full["n2x"]) <= 1e-12 * full["n2x"]
     assert np.array_equal(res[0]["step"], res[1]["step"])
+
+
+# ------------------------------------------------------------ subtree partition -------
+def _partition_step(prob, world, use_take_step=False, lam0=0.0):
+    """every logical rank: backend with dlg_backend_set_partition + the in-process sum as the
+    all-reduce hook; x / J of the rows the symbolic phase gave it; one full trial step"""
+    N, M, nnz = prob.N, prob.M, prob.nnz
+    Jp, Ji = prob.pattern()
+    p = prob.p0()
+    x, Jx = prob.eval(p)
+    ar = _InProcessAllReduce(world)
+    out, errs = [None] * world, []
+
+    def run(rank):
+        try:
+            be = capi.Backend(capi.DLG_SPARSE, N, M, nnz)
+            be.set_partition(rank, world)
+            be.set_allreduce(ar.hook(rank))
+            be.set_pattern(Jp, Ji)
+            rows = be.partition_rows()
+            st = be.partition_stats()
+            Jloc = np.concatenate([Jx[Jp[r]:Jp[r+1]] for r in rows]) if len(rows) else np.zeros(0)
+            be.set_p(0, p)
+            be.upload(0, np.ascontiguousarray(x[rows]), Jloc)
+            n2x, gmax = be.eval(0)
+            if use_take_step:
+                # the one-synchronisation op of the driver, sharded: first a plain step to learn the trust region
+                lam, n2c, n2g = be.cauchy_gauss_newton(0, lam0)
+                tr = 0.5 * (np.sqrt(n2c) + np.sqrt(n2g))
+                be.upload(0, np.ascontiguousarray(x[rows]), Jloc)
+                be.eval(0)
+                lam, r, pnew = be.take_step(0, 1, tr, lam0)
+                n2c, n2g, k, ei = r["n2c"], r["n2g"], r["k"], r["ei"]
+            else:
+                n2c = be.cauchy(0)
+                lam, n2g = be.gauss_newton(0, lam0)
+                tr = 0.5 * (np.sqrt(n2c) + np.sqrt(n2g))
+                n2s, k, amax, pnew = be.make_step(0, 1, capi.KIND_INTERP, tr)
+                ei = be.expected_improvement(0, 1)
+            out[rank] = dict(n2x=n2x, n2c=n2c, n2g=n2g, k=k, ei=ei, lam=lam, step=be.download(1, capi.VEC_STEP),
+                             gn=be.download(0, capi.VEC_GN), g=be.download(0, capi.VEC_JTX), rows=rows, stats=st)
+            be.close()
+        except Exception as e:
+            errs.append((rank, repr(e)))
+            try:
+                ar.bar.abort()
+            except Exception:
+                pass
+
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    [t.start() for t in th]
+    [t.join(timeout=600) for t in th]
+    assert not errs, errs
+    return out, (N, M, Jp, Ji, x, Jx, p)
+
+
+def _check_partition_against_oracle(res, data, lam=0.0, tol=1e-10):
+    O = oa.oracle()
+    N, M, Jp, Ji, x, Jx, p = data
+    F = O.orc_sparse_analyze(N, M, iptr(Jp), iptr(Ji))
+    work, o8 = np.zeros(5 * N), np.zeros(8)
+    assert O.orc_step_sparse(F, N, M, iptr(Jp), iptr(Ji), dptr(Jx), dptr(x), dptr(p), lam, dptr(work), dptr(o8)) == 0
+    O.orc_sparse_free(F)
+    step_ref, gn_ref = work[3 * N:4 * N], work[2 * N:3 * N]
+    # the rows of the ranks are a partition of the measurements
+    allrows = np.sort(np.concatenate([r["rows"] for r in res]))
+    assert np.array_equal(allrows, np.arange(M))
+    worst = 0.0
+    for r in res:
+        d = np.linalg.norm(r["step"] - step_ref)
+        worst = max(worst, d)
+        assert d <= tol, d
+        assert np.linalg.norm(r["gn"] - gn_ref) <= tol
+        assert abs(r["n2x"] - o8[0]) <= 1e-12 * o8[0]
+        assert abs(r["n2c"] - o8[1]) <= 1e-10 * o8[1]
+        assert abs(r["ei"] - o8[5]) <= 1e-9 * abs(o8[5])
+    for r in res[1:]:          # the top of the tree is replicated and every sum is the same on every rank: identical bits
+        assert np.array_equal(r["step"], res[0]["step"]) and np.array_equal(r["gn"], res[0]["gn"]) and r["k"] == res[0]["k"]
+        assert np.array_equal(r["g"], res[0]["g"])
+    return worst
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_subtree_partition_medium(gpu, world):
+    prob = oa.BAProblem(49, 900, 10000, seed=7)
+    res, data = _partition_step(prob, world)
+    w = _check_partition_against_oracle(res, data)
+    st = res[0]["stats"]
+    print(f"world={world}: cut above level {st['cut_level']}, rows/rank {[len(r['rows']) for r in res]}, "
+          f"{st['reduced_doubles']*8/1e3:.0f} KB summed per factorisation, |step - oracle| = {w:.2e}")
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_subtree_partition_config3_200k_rows(gpu, world):
+    """BASELINE.json config #3 (200 000 measurement rows) on logical ranks: every rank's step equals
+    the oracle's within the parity bar, and all ranks hold identical bits"""
+    prob = oa.BAProblem(499, 9000, 100000, seed=11)
+    res, data = _partition_step(prob, world)
+    w = _check_partition_against_oracle(res, data)
+    st = res[0]["stats"]
+    assert st["reduced_doubles"] * 8 < 8e6                     # a few MB, against 16 MB of JtJ
+    print(f"config #3, world={world}: cut above level {st['cut_level']}, {st['supernodes_above_cut']} replicated supernodes, "
+          f"rows/rank {[len(r['rows']) for r in res]}, {st['reduced_doubles']*8/1e6:.2f} MB summed, |step - oracle| = {w:.2e}")
+
+
+def test_subtree_partition_take_step_one_synchronisation(gpu):
+    """dlg_take_step (K3..K8 behind one host synchronisation) works on a partitioned backend: same
+    numbers as the separate calls on a single rank"""
+    prob = oa.BAProblem(49, 900, 10000, seed=7)
+    res, data = _partition_step(prob, 4, use_take_step=True)
+    _check_partition_against_oracle(res, data)
+
+
+def test_subtree_partition_lambda_loop_agrees_across_ranks(gpu):
+    """numerically-zero columns: the non-positive pivot shows up in ONE rank's subtree, but every rank
+    must see the failed factorisation and raise lambda together (dogleg.c:656-677)"""
+    prob = oa.BAProblem(49, 900, 10000, seed=9, n_zero_cols=2)
+    res, data = _partition_step(prob, 4)
+    assert all(r["lam"] == 1e-10 for r in res)
+    _check_partition_against_oracle(res, data, lam=1e-10, tol=1e-6)
+
+
+def test_subtree_partition_single_rank_is_the_plain_path(gpu):
+    """nranks = 1: the partitioned backend is the ordinary one, bit for bit"""
+    prob = oa.BAProblem(12, 120, 720, seed=4)
+    res, data = _partition_step(prob, 1)
+    N, M, Jp, Ji, x, Jx, p = data
+    be = capi.Backend(capi.DLG_SPARSE, N, M, prob.nnz)
+    be.set_pattern(Jp, Ji)
+    be.set_p(0, p)
+    be.upload(0, x, Jx)
+    be.eval(0)
+    be.cauchy(0)
+    lam, n2g = be.gauss_newton(0, 0.0)
+    assert np.array_equal(be.download(0, capi.VEC_GN), res[0]["gn"])
+    be.close()
