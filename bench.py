@@ -18,10 +18,13 @@ Workloads (BASELINE.json configs):
   dense-50k   config #2: dense 50 000 x 2 000
   sparse-5m   config #5: 5 000 000 x 500 001, 75 M nnz, ill-conditioned + lambda path
 
-N > 1 (launched by torch.distributed.run): measurement rows are sharded over the
-ranks; Jt*x / |Jv|^2 / JtJ partials are summed with an RCCL all-reduce
-(torch.distributed, backend nccl) before the replicated factorisation.  The
-problem size is fixed, so scaling is "strong".
+N > 1 (launched by torch.distributed.run, one process per GPU): sparse workloads use the SUBTREE
+PARTITION of the elimination tree (include/dlg_backend.h: every rank holds the measurement rows of
+its subtrees, assembles / factors / solves them alone; per step the ranks sum Jt*x, one small buffer
+at the cut of the tree -- 1.2 MB on config #4 over 8 ranks --, the solution and two scalars); the
+dense workload shards contiguous rows and sums JtJ.  The sums are RCCL all-reduces enqueued by the
+library on its own stream (dlg_backend_init_rccl; torch.distributed only hands out the unique id,
+the barrier and the max over ranks of the elapsed time).  The problem size is fixed: "strong".
 
 Prints ONE JSON line on rank 0.
 """
@@ -57,6 +60,7 @@ def main():
     ap.add_argument("--workload", default="sparse-1m", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline sample")
+    ap.add_argument("--copies", type=int, default=3, help="resident copies of (x, J) the timed loop rotates over")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -68,7 +72,8 @@ def main():
 
     torch = dist = None
     if use_dist:
-        # torch first: libdogleg_amd then binds to the HIP runtime torch ships
+        # torch.distributed (backend nccl = RCCL) before any GPU call of this process; libdogleg_amd
+        # then binds to the HIP runtime torch ships
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
@@ -84,72 +89,75 @@ def main():
 
     kind, prm = WORKLOADS[args.workload]
     t_setup = time.time()
+    rccl_ranks = None
     if kind == "sparse":
         prob = oa.BAProblem(**prm, seed=11)
         N, M, nnz = prob.N, prob.M, prob.nnz
         Jp, Ji = prob.pattern()
         p0 = prob.p0()
         x, Jx = prob.eval(p0)
-        # contiguous row ranges balanced by nnz (rows all have 15 entries here)
-        row0 = (M * rank) // world
-        row1 = (M * (rank + 1)) // world
-        q0, q1 = int(Jp[row0]), int(Jp[row1])
-        x_loc, J_loc = x[row0:row1], Jx[q0:q1]
         be = capi.Backend(capi.DLG_SPARSE, N, M, nnz, device=local_rank if use_dist else -1)
     else:
         prob = oa.DenseProblem(**prm, seed=11)
         N, M, nnz = prob.N, prob.M, 0
         p0 = prob.p0()
         x, J = prob.eval(p0)
+        be = capi.Backend(capi.DLG_DENSE, N, M, device=local_rank if use_dist else -1)
+    if use_dist:
+        # the library's own RCCL communicator: rank 0 creates the id, torch.distributed hands it out
+        idt = torch.zeros(128, dtype=torch.uint8, device=torch.device("cuda", local_rank))
+        if rank == 0:
+            idt.copy_(torch.frombuffer(bytearray(capi.rccl_unique_id()), dtype=torch.uint8))
+        dist.broadcast(idt, 0)
+        be.init_rccl(rank, world, bytes(idt.cpu().numpy().tobytes()))
+        rccl_ranks = be.comm_size()
+        assert rccl_ranks == world, f"RCCL reports {rccl_ranks} ranks, expected {world}"
+    part = None
+    if kind == "sparse":
+        if use_dist:
+            be.set_partition(rank, world)
+        be.set_pattern(Jp, Ji)
+        sym = be.stats()
+        if use_dist:
+            rows = be.partition_rows()
+            part = be.partition_stats()
+            x_loc = x[rows]
+            J_loc = np.concatenate([Jx[Jp[r]:Jp[r+1]] for r in rows]) if len(rows) else np.zeros(0)
+            row0, row1 = 0, len(rows)
+        else:
+            row0, row1 = 0, M
+            x_loc, J_loc = x, Jx
+    else:
+        sym = {}
+        # contiguous row ranges
         row0 = (M * rank) // world
         row1 = (M * (rank + 1)) // world
         x_loc, J_loc = x[row0:row1], J[row0:row1]
-        be = capi.Backend(capi.DLG_DENSE, N, M, device=local_rank if use_dist else -1)
-
-    hook = None
-    if use_dist:
-        dev = torch.device("cuda", local_rank)
-
-        class _DevPtr:
-            def __init__(self, ptr, n):
-                self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f8",
-                                                 "data": (ptr, False), "version": 3}
-
-        views = {}                            # (device pointer, count) -> tensor view: the buffers are few and fixed
-
-        def hook(buf, count, cookie):
-            try:
-                t = views.get((buf, count))
-                if t is None:
-                    t = views[(buf, count)] = torch.as_tensor(_DevPtr(buf, count), device=dev)
-                dist.all_reduce(t, op=dist.ReduceOp.SUM)
-                torch.cuda.synchronize()
-                return 0
-            except Exception as e:           # never let an exception cross the C boundary
-                print(f"all-reduce hook failed: {e}", file=sys.stderr)
-                return 1
-        be.set_shard(row0, row1, hook)
-    if kind == "sparse":
-        be.set_pattern(Jp, Ji)
-        sym = be.stats()
-    else:
-        sym = {}
-    d_x = capi.DeviceArray(np.ascontiguousarray(x_loc))
-    d_J = capi.DeviceArray(np.ascontiguousarray(J_loc))
+        if use_dist:
+            be.set_shard(row0, row1, None)
+    # The timed loop rotates over NCOPY resident copies of (x, J): one unchanging J of 120 MB (config #4)
+    # would sit in the 256 MiB Infinity Cache between steps and flatter every "HBM" fraction
+    # (MI355X_MICROARCH.md: scale past L3 before reading bandwidth numbers); 3 copies = 360 MB+ do not.
+    ncopy = max(1, args.copies)
+    xh, Jh = np.ascontiguousarray(x_loc), np.ascontiguousarray(J_loc)
+    d_x = [capi.DeviceArray(xh) for _ in range(ncopy)]
+    d_J = [capi.DeviceArray(Jh) for _ in range(ncopy)]
     be.set_p(0, p0)
     setup_s = time.time() - t_setup
 
-    state = {"tr": None}
+    state = {"tr": None, "i": 0}
 
     def one_step():
-        be.bind_device(0, d_x.ptr, d_J.ptr)          # a fresh operating point: nothing cached
+        c = state["i"] % ncopy
+        state["i"] += 1
+        be.bind_device(0, d_x[c].ptr, d_J[c].ptr)    # a fresh operating point: nothing cached
         norm2x, gmax = be.eval(0)                    # K1
         # K3..K8 as the driver issues them for a fresh point once steps leave the trust region's edge
         # behind (driver.hip take_step -> dlg_take_step): Cauchy step, compute_updateGN (factorise from
         # lambda = 0 with the reference's lambda loop, dogleg.c:656-677, and solve), the choice of the kind
         # of step, the step, its expected improvement, p_new D2H -- one synchronisation per attempt.
         # The trust region is known before the step, as in the driver (state["tr"], from the first step).
-        if use_dist or state["tr"] is None:
+        if state["tr"] is None:
             lam, n2c, n2g = be.cauchy_gauss_newton(0, 0.0)
             tr = 0.5 * (n2c ** 0.5 + n2g ** 0.5)
             n2s, k, amax, ei, pnew = be.step(0, 1, capi.KIND_INTERP, tr)
@@ -187,7 +195,9 @@ def main():
 
         def one_retry(shrink):
             be.step(0, 1, capi.KIND_INTERP, tr_retry * shrink)
-            be.bind_device(1, d_x.ptr, d_J.ptr)
+            c = state["i"] % ncopy
+            state["i"] += 1
+            be.bind_device(1, d_x[c].ptr, d_J[c].ptr)
             be.eval(1)
         one_retry(0.99)
         barrier()
@@ -197,6 +207,7 @@ def main():
         barrier()
         retry_ms = (time.perf_counter() - tr0) / args.steps * 1e3
     if use_dist:
+        dev = torch.device("cuda", local_rank)
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -232,6 +243,43 @@ def main():
     except Exception:
         pass
 
+    # the other phases against their own bounds (SURVEY 8d formulas): the factorisation and the
+    # triangular solves are latency / critical-path bound -- low fractions are expected, they are
+    # printed so that they can be watched
+    others = {}
+    def per_launch(name):
+        ms_, cnt_ = prof[name]
+        return ms_ / max(cnt_, 1)
+    if kind == "sparse":
+        k5_ms, k6_ms = per_launch("K5_factor"), per_launch("K6_solve")
+        k5_bytes = 8 * sym["nnz_JtJ_lower"] + 8 * sym["nnz_L"]
+        k6_bytes = 16 * sym["nnz_L"] + 32 * N
+        jv_ms = per_launch("K3K8_norm2Jv")
+        jv_bytes = 12 * int(J_loc.shape[0]) + 4 * (row1 - row0) + 8 * N
+        others = {
+            "K5_sparse_cholesky": {"bound": "latency (critical path of the elimination tree)", "ms": k5_ms,
+                                   "algorithmic_bytes": k5_bytes, "GBps": k5_bytes / (k5_ms * 1e-3) / 1e9 if k5_ms > 0 else None,
+                                   "frac_hbm": k5_bytes / (k5_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if k5_ms > 0 else None,
+                                   "flops": sym["factor_flops"], "TFLOPps": sym["factor_flops"] / (k5_ms * 1e-3) / 1e12 if k5_ms > 0 else None,
+                                   "frac_mfma": sym["factor_flops"] / (k5_ms * 1e-3) / 1e12 / MFMA_F64_PEAK_TFLOPS if k5_ms > 0 else None,
+                                   "levels": sym["n_levels"]},
+            "K6_sparse_solve": {"bound": "latency", "ms": k6_ms, "algorithmic_bytes": k6_bytes,
+                                "GBps": k6_bytes / (k6_ms * 1e-3) / 1e9 if k6_ms > 0 else None,
+                                "frac_hbm": k6_bytes / (k6_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if k6_ms > 0 else None},
+            "K3K8_norm2_Jv": {"bound": "hbm", "ms": jv_ms, "algorithmic_bytes": jv_bytes,
+                              "GBps": jv_bytes / (jv_ms * 1e-3) / 1e9 if jv_ms > 0 else None,
+                              "frac_hbm": jv_bytes / (jv_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if jv_ms > 0 else None},
+        }
+    else:
+        k5_ms, k6_ms = per_launch("K5_factor"), per_launch("K6_solve")
+        others = {
+            "K5_dense_potrf": {"bound": "mfma / launch chain", "ms": k5_ms, "flops": N**3 / 3.0,
+                               "TFLOPps": N**3 / 3.0 / (k5_ms * 1e-3) / 1e12 if k5_ms > 0 else None,
+                               "frac_mfma": N**3 / 3.0 / (k5_ms * 1e-3) / 1e12 / MFMA_F64_PEAK_TFLOPS if k5_ms > 0 else None},
+            "K6_dense_potrs": {"bound": "hbm / latency", "ms": k6_ms, "algorithmic_bytes": 2 * 8 * N * (N + 1) // 2,
+                               "GBps": 8.0 * N * (N + 1) / (k6_ms * 1e-3) / 1e9 if k6_ms > 0 else None},
+        }
+
     out = None
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -242,13 +290,19 @@ def main():
             "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": args.workload, "kind": kind, "Nmeas": M, "Nstate": N, "nnz": nnz,
                        "step": "K1+K3+K4+K5+K6+K7+K8 (refactorise + interpolate), inputs resident in HBM",
-                       "parallelism": f"rows sharded x{world}, all-reduce before factorise" if world > 1 else "1 GPU"},
+                       "parallelism": (("subtree partition" if kind == "sparse" else "row sharding") + f" x{world}, RCCL in-stream") if use_dist else "1 GPU"},
             "roofline": roof,
+            "other_kernels": others,
+            "inputs": {"resident_copies": ncopy, "bytes_per_copy": int(xh.nbytes + Jh.nbytes),
+                       "note": "the timed loop rotates over the copies: past the 256 MiB Infinity Cache"},
             "phases_ms_per_step": {k: v[0] / args.steps for k, v in prof.items()},
             "cached_retry_step": ({"ms_per_step": retry_ms, "steps_per_s": 1e3 / retry_ms,
                                    "what": "K7 + K8 + K1 of the new point, cached Cauchy/GN/factor"}
                                   if retry_ms else None),
-            "symbolic": sym, "setup_s": setup_s,
+            "symbolic": sym, "setup_s": setup_s, "rccl_ranks": rccl_ranks,
+            "partition": ({"cut_above_level": part["cut_level"], "replicated_supernodes": part["supernodes_above_cut"],
+                           "rows_rank0": part["rows_mine"], "bytes_summed_per_factorisation": 8 * part["reduced_doubles"],
+                           "bytes_panel_buffer": 8 * part["panel_doubles"]} if part else None),
             "check": {"norm2_x": res[0], "norm2_step": res[4], "expected_improvement": res[5], "lambda": res[8]},
         }
 
@@ -270,8 +324,9 @@ def main():
                 t_cpu += time.perf_counter() - tb
                 n_done += 1
                 assert rc == 0
-            sample = (f"{n_done} full steps of the same workload, single thread "
-                      f"(symbolic analysis {t_an:.1f}s excluded; nnz(L)={O.orc_sparse_nnzL(F)}, "
+            sample = (f"{n_done} full steps of the same workload, single thread; sparse Cholesky = up-looking simplicial, "
+                      f"static minimum-degree ordering (a CHOLMOD-simplicial stand-in; symbolic analysis {t_an:.1f}s excluded; "
+                      f"nnz(L)={O.orc_sparse_nnzL(F)} against {sym['nnz_L']} of the GPU's nested dissection, "
                       f"factor flops={O.orc_sparse_flops(F):.3g})")
             O.orc_sparse_free(F)
             cpu_val = n_done / t_cpu

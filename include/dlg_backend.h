@@ -206,6 +206,14 @@ int  dlg_take_step(dlg_backend_t* b, int from, int to, double trustregion, doubl
  * reference's own user is its outlier / confidence code, dogleg.c:1831-1921).  The factor stays on
  * the device. --------------------------------------------------------------------------------- */
 int  dlg_solve_with_factor(dlg_backend_t* b, int slot, const double* rhs_host, double* out_host, int nrhs);
+/* the same, BLOCKED: 16 right-hand sides per pass over the factor (the factor is read once per block,
+ * the products with its off-diagonal part run on the matrix cores): cholmod_solve / dpptrs with a
+ * block of right-hand sides.  rhs / out: N x nrhs column-major (ld = N), host. */
+int  dlg_solve_multi(dlg_backend_t* b, int slot, const double* rhs_host, double* out_host, int nrhs);
+/* out (N x (row1 - row0), column-major, host) = inv(JtJ + lambda I) * Jt[:, row0:row1] with the factor held
+ * for `slot` and the slot's Jacobian on the device: pseudoinverse_J_dense / pseudoinverse_J_sparse of
+ * the reference (dogleg.c:1831-1921), built on the blocked solve */
+int  dlg_pseudoinverse_chunk(dlg_backend_t* b, int slot, int row0, int row1, double* out_host);
 
 /* ---- downloads (returnContext, tests) -------------------------------------- */
 int  dlg_point_download(dlg_backend_t* b, int slot, int which, double* host, size_t n);

@@ -37,7 +37,7 @@ BACKEND_SYMBOLS = [
     "dlg_backend_set_profiling", "dlg_backend_get_profile",
     "dlg_backend_set_allreduce", "dlg_backend_set_partition", "dlg_partition_rows", "dlg_partition_stats",
     "dlg_sparse_partition_probe", "dlg_rccl_unique_id", "dlg_backend_init_rccl", "dlg_backend_set_rccl",
-    "dlg_backend_comm_size",
+    "dlg_backend_comm_size", "dlg_solve_multi", "dlg_pseudoinverse_chunk",
 ]
 PROF_NAMES = ["K1_jtx", "K3K8_norm2Jv", "K4_kernel", "K4_total", "K5_factor", "K6_solve", "K7_step", "vec"]
 DOGLEG_SYMBOLS = [
@@ -101,6 +101,8 @@ def lib():
     L.dlg_step.argtypes = [V, C.c_int, C.c_int, C.c_int, C.c_double, D, D, D, D, D]
     L.dlg_take_step.argtypes = [V, C.c_int, C.c_int, C.c_double, D, D, D]
     L.dlg_solve_with_factor.argtypes = [V, C.c_int, D, D, C.c_int]
+    L.dlg_solve_multi.argtypes = [V, C.c_int, D, D, C.c_int]
+    L.dlg_pseudoinverse_chunk.argtypes = [V, C.c_int, C.c_int, C.c_int, D]
     L.dlg_expected_improvement.argtypes = [V, C.c_int, C.c_int, D]
     L.dlg_point_download.argtypes = [V, C.c_int, C.c_int, D, C.c_size_t]
     L.dlg_factor_download_dense.argtypes = [V, D, C.c_size_t]
@@ -469,6 +471,19 @@ class Backend:
         out = np.zeros_like(r)
         _ck(self.L.dlg_solve_with_factor(self.h, slot, dptr(r), dptr(out), r.shape[0]), "solve_with_factor")
         return out if np.ndim(rhs) == 2 else out[0]
+
+    def solve_multi(self, slot, rhs):
+        """blocked variant of solve_with_factor: rhs (nrhs, N) rows = right-hand sides; 16 per pass over the factor"""
+        r = np.ascontiguousarray(np.atleast_2d(rhs), dtype=np.float64)
+        out = np.zeros_like(r)
+        _ck(self.L.dlg_solve_multi(self.h, slot, dptr(r), dptr(out), r.shape[0]), "solve_multi")
+        return out
+
+    def pseudoinverse_chunk(self, slot, row0, row1):
+        """inv(JtJ + lambda I) Jt[:, row0:row1] as (row1 - row0, N): row i = the column of measurement row0 + i"""
+        out = np.zeros((row1 - row0, self.N))
+        _ck(self.L.dlg_pseudoinverse_chunk(self.h, slot, row0, row1, dptr(out)), "pseudoinverse_chunk")
+        return out
 
     def make_step(self, frm, to, kind, trustregion, want_p=True):
         """p_new comes back in a page-locked buffer owned by this object (as the driver's operating

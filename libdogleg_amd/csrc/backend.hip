@@ -234,7 +234,7 @@ extern "C" int dlg_backend_set_partition(dlg_backend_t* b, int rank, int nranks)
   if(b->type != DLG_SPARSE)
   { dlg_set_error("the subtree partition is a property of the sparse path (dense: dlg_backend_set_shard)"); return DLG_ERR_ARG; }
   if(b->sym) { dlg_set_error("set the partition before dlg_sparse_set_pattern"); return DLG_ERR_STATE; }
-  b->part_rank = rank; b->part_nranks = nranks;
+  b->part_rank = rank; b->part_nranks = nranks; b->part_requested = true;
   return DLG_OK;
 }
 
@@ -918,6 +918,78 @@ extern "C" int dlg_solve_with_factor(dlg_backend_t* b, int s, const double* rhs_
     { dlg_set_error("dlg_solve_with_factor: download failed"); rc = DLG_ERR_HIP; }
   }
   (void)hipFree(d_out);
+  return rc;
+}
+
+// ---- blocked multi-right-hand-side solves ---------------------------------------
+// 16 right-hand sides per pass over the factor (sparse_multi.hip / kernels_dense.hip); a sparse
+// pattern with a supernode wider than the blocked kernels take falls back to one pass per column.
+static int solve_block_dev(dlg_backend* b, double* d_il)
+{
+  return b->type == DLG_SPARSE ? sparse_solve_multi(b, d_il) : dense_solve_multi(b, d_il);
+}
+static bool multi_ok(dlg_backend* b) { return b->type != DLG_SPARSE || sparse_multi_width_ok(b); }
+extern "C" int dlg_solve_multi(dlg_backend_t* b, int s, const double* rhs_host, double* out_host, int nrhs)
+{
+  DLG_CHECK(check_slot(b, s));
+  if(!rhs_host || !out_host || nrhs < 0) { dlg_set_error("dlg_solve_multi: bad argument"); return DLG_ERR_ARG; }
+  if(b->factor_slot != s) { dlg_set_error("dlg_solve_multi: no factorization of slot %d is held", s); return DLG_ERR_STATE; }
+  if(b->part_nranks > 1) { dlg_set_error("dlg_solve_multi is not available on a partitioned backend"); return DLG_ERR_STATE; }
+  if(!multi_ok(b)) return dlg_solve_with_factor(b, s, rhs_host, out_host, nrhs);
+  const int MRB = sparse_multi_rhs();
+  const size_t N = (size_t)b->N;
+  double *d_cols = nullptr, *d_il = nullptr;
+  DLG_HIP(hipMalloc(&d_cols, sizeof(double)*N*MRB));
+  if(hipMalloc(&d_il, sizeof(double)*N*MRB) != hipSuccess) { (void)hipFree(d_cols); dlg_set_error("out of device memory"); return DLG_ERR_NOMEM; }
+  int rc = DLG_OK;
+  for(int c0 = 0; c0 < nrhs && rc == DLG_OK; c0 += MRB)
+  {
+    const int nc = (nrhs - c0 < MRB) ? nrhs - c0 : MRB;
+    if(hipMemcpyAsync(d_cols, rhs_host + (size_t)c0*N, sizeof(double)*N*nc, hipMemcpyHostToDevice, b->stream) != hipSuccess)
+    { dlg_set_error("dlg_solve_multi: upload failed"); rc = DLG_ERR_HIP; break; }
+    rc = multi_cols_to_interleaved(b, d_cols, nc, d_il);
+    if(rc == DLG_OK) rc = solve_block_dev(b, d_il);
+    if(rc == DLG_OK) rc = multi_interleaved_to_cols(b, d_il, nc, d_cols);
+    if(rc == DLG_OK && (hipMemcpyAsync(out_host + (size_t)c0*N, d_cols, sizeof(double)*N*nc, hipMemcpyDeviceToHost, b->stream) != hipSuccess ||
+                        hipStreamSynchronize(b->stream) != hipSuccess))
+    { dlg_set_error("dlg_solve_multi: download failed"); rc = DLG_ERR_HIP; }
+  }
+  (void)hipFree(d_cols); (void)hipFree(d_il);
+  return rc;
+}
+// out (N x (row1 - row0), column-major, host) = inv(JtJ + lambda I) * Jt[:, row0:row1]: the building block
+// of the reference's pseudoinverse_J_dense / pseudoinverse_J_sparse (dogleg.c:1831-1921); Jt is taken
+// from the slot's Jacobian on the device, nothing but the result crosses PCIe
+extern "C" int dlg_pseudoinverse_chunk(dlg_backend_t* b, int s, int row0, int row1, double* out_host)
+{
+  DLG_CHECK(check_slot(b, s));
+  if(!out_host || row0 < 0 || row1 < row0 || row1 > b->M) { dlg_set_error("dlg_pseudoinverse_chunk: bad row range"); return DLG_ERR_ARG; }
+  if(b->type == DLG_DENSE_PRODUCTS) { dlg_set_error("dense-products keeps no Jacobian"); return DLG_ERR_STATE; }
+  if(!b->slot[s].have_inputs) { dlg_set_error("dlg_pseudoinverse_chunk needs J (reference dogleg.c:1838-1842)"); return DLG_ERR_STATE; }
+  if(b->factor_slot != s) { dlg_set_error("dlg_pseudoinverse_chunk: no factorization of slot %d is held", s); return DLG_ERR_STATE; }
+  if(b->sharded() || b->part_nranks > 1) { dlg_set_error("dlg_pseudoinverse_chunk is not available on a sharded backend"); return DLG_ERR_STATE; }
+  const int MRB = sparse_multi_rhs();
+  const size_t N = (size_t)b->N;
+  double *d_cols = nullptr, *d_il = nullptr;
+  DLG_HIP(hipMalloc(&d_cols, sizeof(double)*N*MRB));
+  if(hipMalloc(&d_il, sizeof(double)*N*MRB) != hipSuccess) { (void)hipFree(d_cols); dlg_set_error("out of device memory"); return DLG_ERR_NOMEM; }
+  int rc = DLG_OK;
+  const bool blocked = multi_ok(b);
+  for(int r = row0; r < row1 && rc == DLG_OK; r += MRB)
+  {
+    const int nc = (row1 - r < MRB) ? row1 - r : MRB;
+    rc = b->type == DLG_SPARSE ? sparse_jt_chunk_interleaved(b, s, r, nc, d_il) : dense_jt_chunk_interleaved(b, s, r, nc, d_il);
+    if(rc != DLG_OK) break;
+    if(blocked) rc = solve_block_dev(b, d_il);
+    if(rc == DLG_OK) rc = multi_interleaved_to_cols(b, d_il, nc, d_cols);
+    if(rc == DLG_OK && !blocked)
+      for(int c = 0; c < nc && rc == DLG_OK; c++)          // (a supernode too wide for the blocked kernels: column by column)
+        rc = sparse_solve(b, d_cols + (size_t)c*N, d_cols + (size_t)c*N);
+    if(rc == DLG_OK && (hipMemcpyAsync(out_host + (size_t)(r - row0)*N, d_cols, sizeof(double)*N*nc, hipMemcpyDeviceToHost, b->stream) != hipSuccess ||
+                        hipStreamSynchronize(b->stream) != hipSuccess))
+    { dlg_set_error("dlg_pseudoinverse_chunk: download failed"); rc = DLG_ERR_HIP; }
+  }
+  (void)hipFree(d_cols); (void)hipFree(d_il);
   return rc;
 }
 

@@ -112,6 +112,7 @@ struct dlg_backend
   int row0 = 0, row1 = 0;     // owned measurement rows (contiguous mode)
   int mloc = 0;               // measurement rows held by this rank
   int part_rank = 0, part_nranks = 1;
+  bool part_requested = false;          // dlg_backend_set_partition was called (also with nranks == 1)
   dlg_allreduce_fn allreduce = nullptr;
   void* allreduce_cookie = nullptr;
   void* rccl_comm = nullptr;  // ncclComm_t
@@ -209,3 +210,13 @@ int sparse_norm2_Jv(dlg_backend* b, int slot, const double* v, double* out_dev);
 int sparse_factorize(dlg_backend* b, int slot, double lambda, int* ok);          // K4+K5
 bool sparse_factor_ok(const dlg_backend* b);     // pivot flag of the last factorisation (after a sync)
 int sparse_solve(dlg_backend* b, const double* rhs, double* out);                // K6
+// blocked multi-right-hand-side solves (sparse_multi.hip / kernels_dense.hip): MR = 16 right-hand sides
+// interleaved [N][MR] (element (variable k, rhs c) at k*MR + c), solved in place, original order
+int sparse_multi_width_ok(const dlg_backend* b);
+int sparse_multi_rhs();
+int sparse_solve_multi(dlg_backend* b, double* d_il);
+int dense_solve_multi(dlg_backend* b, double* d_il);
+int multi_cols_to_interleaved(dlg_backend* b, const double* d_cols, int ncols, double* d_il);
+int multi_interleaved_to_cols(dlg_backend* b, const double* d_il, int ncols, double* d_cols);
+int sparse_jt_chunk_interleaved(dlg_backend* b, int s, int row0, int ncols, double* d_il);
+int dense_jt_chunk_interleaved(dlg_backend* b, int s, int row0, int ncols, double* d_il);

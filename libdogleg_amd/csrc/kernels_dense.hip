@@ -424,6 +424,83 @@ __global__ void __launch_bounds__(TPB) k_trsv_update_bwd(const double* __restric
   if(lane == 0) y[i] -= s;
 }
 
+// ---- blocked multi-right-hand-side triangular solves (dpptrs / dpotrs with nrhs > 1:
+// reference pseudoinverse_J_dense, dogleg.c:1831-1855).  MR = 16 right-hand sides interleaved
+// [n][MR]; per 64-column block of the factor: the diagonal block is a product with its stored
+// inverse, the rest of the block column is applied to all 16 right-hand sides on the matrix cores
+// (v_mfma_f64_16x16x4_f64: A = a 16-row tile of L, B = the 64 x 16 block of solved unknowns in
+// LDS) -- the factor is read once per 16 right-hand sides.
+constexpr int DMR = 16;
+// X_blk = Linv_blk * Y_blk (forward) or Linv_blk^T * Y_blk (backward)
+__global__ void __launch_bounds__(TPB) k_trsm_diag_m(const double* __restrict__ Linv, int kb, int nb,
+                                                     double* __restrict__ y, int transpose)
+{
+  __shared__ double v[NB*DMR];
+  __shared__ double Ls[NB][NB + 1];
+  const int tid = threadIdx.x, c = tid & (DMR - 1), tg = tid >> 4;
+  for(int e = tid; e < NB*DMR; e += TPB) { const int k = e / DMR; v[e] = (k < nb) ? y[(size_t)(kb + k)*DMR + (e - k*DMR)] : 0.0; }
+  for(int e = tid; e < NB*NB; e += TPB) { const int k = e / NB, t = e - k*NB; Ls[t][k] = Linv[e]; }    // Ls[i][k] = Linv[i][k]
+  __syncthreads();
+  for(int t = tg; t < nb; t += TPB/DMR)
+  {
+    double sacc = 0.0;
+    if(!transpose) { for(int k = 0; k <= t; k++) sacc += Ls[t][k]*v[k*DMR + c]; }
+    else           { for(int k = t; k < NB; k++) sacc += Ls[k][t]*v[k*DMR + c]; }
+    y[(size_t)(kb + t)*DMR + c] = sacc;
+  }
+}
+// forward: Y[i][:] -= L[i, kb:kb+nb] X[kb:kb+nb][:] for the rows i >= kb + nb; a wave per 16 rows
+__global__ void __launch_bounds__(TPB) k_trsm_update_fwd_m(const double* __restrict__ A, int lda, int kb, int nb,
+                                                           int n, double* __restrict__ y)
+{
+  __shared__ double v[NB*DMR];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, mm = lane & 15, kq = lane >> 4;
+  for(int e = tid; e < NB*DMR; e += TPB) { const int k = e / DMR; v[e] = (k < nb) ? y[(size_t)(kb + k)*DMR + (e - k*DMR)] : 0.0; }
+  __syncthreads();
+  const int i0 = kb + nb + 16*(blockIdx.x*(TPB/64) + wv);
+  if(i0 >= n) return;
+  const int row = min(i0 + mm, n - 1);
+  double4_t acc = {0.0, 0.0, 0.0, 0.0};
+  for(int k4 = 0; k4 < NB; k4 += 4)
+  {
+    const int k = k4 + kq;
+    const double a = (k < nb) ? A[(size_t)(kb + k)*lda + row] : 0.0;
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, v[k*DMR + mm], acc, 0, 0, 0);
+  }
+#pragma unroll
+  for(int q = 0; q < 4; q++) { const int i = i0 + kq + 4*q; if(i < n) y[(size_t)i*DMR + mm] -= acc[q]; }
+}
+// backward: Y[i][:] -= L[kb:kb+nb, i]^T X[kb:kb+nb][:] for the rows i < kb
+__global__ void __launch_bounds__(TPB) k_trsm_update_bwd_m(const double* __restrict__ A, int lda, int kb, int nb,
+                                                           double* __restrict__ y)
+{
+  __shared__ double v[NB*DMR];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, mm = lane & 15, kq = lane >> 4;
+  for(int e = tid; e < NB*DMR; e += TPB) { const int k = e / DMR; v[e] = (k < nb) ? y[(size_t)(kb + k)*DMR + (e - k*DMR)] : 0.0; }
+  __syncthreads();
+  const int i0 = 16*(blockIdx.x*(TPB/64) + wv);
+  if(i0 >= kb) return;
+  const int col = min(i0 + mm, kb - 1);
+  double4_t acc = {0.0, 0.0, 0.0, 0.0};
+  for(int k4 = 0; k4 < NB; k4 += 4)
+  {
+    const int k = k4 + kq;
+    const double a = (k < nb) ? A[(size_t)col*lda + kb + k] : 0.0;          // (L^T)[i][k] = L[kb + k][i]
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, v[k*DMR + mm], acc, 0, 0, 0);
+  }
+#pragma unroll
+  for(int q = 0; q < 4; q++) { const int i = i0 + kq + 4*q; if(i < kb) y[(size_t)i*DMR + mm] -= acc[q]; }
+}
+// interleaved block of Jt[:, row0 : row0 + ncols] of the dense J (row-major [M][N]): element (k, c) = J[row0 + c][k]
+__global__ void __launch_bounds__(TPB) k_jt_chunk_dense(const double* __restrict__ J, int N, int row0, int ncols,
+                                                        double* __restrict__ il)
+{
+  const size_t e = (size_t)blockIdx.x*TPB + threadIdx.x;
+  if(e >= (size_t)N*DMR) return;
+  const int k = (int)(e / DMR), c = (int)(e % DMR);
+  il[e] = (c < ncols) ? J[(size_t)(row0 + c)*N + k] : 0.0;
+}
+
 // ------------------------------------------------------------ probes --------
 __global__ void __launch_bounds__(TPB) k_probe_mfma(double* out, int iters)
 {
@@ -677,6 +754,39 @@ int dense_solve(dlg_backend* b, const double* rhs, double* out)
       hipLaunchKernelGGL(k_trsv_update_bwd, dim3(dlg_cdiv(kb, 4)), dim3(TPB), 0, b->stream, b->G, n, kb,
                          nb, out);
   }
+  DLG_LAUNCH_CHECK();
+  return DLG_OK;
+}
+
+// (L L^T) X = B for 16 interleaved right-hand sides [n][16], in place
+int dense_solve_multi(dlg_backend* b, double* d_il)
+{
+  const int n = b->N;
+  hipStream_t st = b->stream;
+  for(int kb = 0, blk = 0; kb < n; kb += NB, blk++)
+  {
+    const int nb = (n - kb < NB) ? n - kb : NB;
+    hipLaunchKernelGGL(k_trsm_diag_m, dim3(1), dim3(TPB), 0, st, b->Linv + (size_t)blk*NB*NB, kb, nb, d_il, 0);
+    const int rem = n - kb - nb;
+    if(rem > 0)
+      hipLaunchKernelGGL(k_trsm_update_fwd_m, dim3(dlg_cdiv(rem, 16*(TPB/64))), dim3(TPB), 0, st, b->G, n, kb, nb, n, d_il);
+  }
+  const int nblk = dlg_cdiv(n, NB);
+  for(int blk = nblk - 1; blk >= 0; blk--)
+  {
+    const int kb = blk*NB;
+    const int nb = (n - kb < NB) ? n - kb : NB;
+    hipLaunchKernelGGL(k_trsm_diag_m, dim3(1), dim3(TPB), 0, st, b->Linv + (size_t)blk*NB*NB, kb, nb, d_il, 1);
+    if(kb > 0)
+      hipLaunchKernelGGL(k_trsm_update_bwd_m, dim3(dlg_cdiv(kb, 16*(TPB/64))), dim3(TPB), 0, st, b->G, n, kb, nb, d_il);
+  }
+  DLG_LAUNCH_CHECK();
+  return DLG_OK;
+}
+int dense_jt_chunk_interleaved(dlg_backend* b, int s, int row0, int ncols, double* d_il)
+{
+  hipLaunchKernelGGL(k_jt_chunk_dense, dim3(dlg_cdiv((long)b->N*DMR, TPB)), dim3(TPB), 0, b->stream, b->slot[s].Jin(), b->N,
+                     row0, ncols, d_il);
   DLG_LAUNCH_CHECK();
   return DLG_OK;
 }

@@ -108,6 +108,7 @@ struct SparseSym
   double* colmask = nullptr; int* sn_owner = nullptr;
   int *xl_sn = nullptr;
   double cur_lambda = 0.0;              // of the factorisation being enqueued (the top panels get it after the sum)
+  double *ms_scr = nullptr, *ms_y = nullptr; int ms_lds_f = 0, ms_lds_b = 0;     // multi-right-hand-side solves (sparse_multi.hip)
   bool fac_ahead = false;       // panel_factor_ahead instead of panel_factor_mfma (DOGLEG_AMD_AHEAD)
   int bwd_xb_cap = 12288;       // below rows of a supernode staged in LDS by the backward solve
   std::vector<void*> allocs;
