@@ -489,7 +489,8 @@ static int cauchy_enqueue(dlg_backend* b, int s, double* sc)
 // that event and the main stream waits for them before anything reads the Cauchy step.
 static int cauchy_fork_begin(dlg_backend* b)
 {
-  b->want_fork = b->overlap && b->aux_stream && !b->sharded();    // (one communicator: its collectives stay on one stream)
+  const bool no_k3_fork = getenv("DOGLEG_AMD_NO_K3_FORK") != nullptr;
+  b->want_fork = b->overlap && b->aux_stream && !b->sharded() && !no_k3_fork;    // (one communicator: its collectives stay on one stream)
   b->fork_recorded = false;
   return DLG_OK;
 }

@@ -67,6 +67,23 @@ __global__ void __launch_bounds__(TPB) k_colsum(const double* __restrict__ part,
   out[c] = s;
 }
 
+// first stage of the column sums for long lists of partials: slice y adds its share of the chunks
+// (in chunk order), k_colsum then adds the slices (in slice order): deterministic, and S times more
+// workgroups than one column-sum pass over all chunks
+__global__ void __launch_bounds__(TPB) k_colsum_slices(const double* __restrict__ part, int nchunks, int N,
+                                                       double* __restrict__ part2)
+{
+  const int c = blockIdx.x*TPB + threadIdx.x;
+  if(c >= N) return;
+  const int S = gridDim.y, y = blockIdx.y;
+  const int k0 = (int)((long)y*nchunks/S), k1 = (int)((long)(y + 1)*nchunks/S);
+  double s0 = 0, s1 = 0;
+  int k = k0;
+  for(; k + 1 < k1; k += 2) { s0 += part[(size_t)k*N + c]; s1 += part[(size_t)(k + 1)*N + c]; }
+  if(k < k1) s0 += part[(size_t)k*N + c];
+  part2[(size_t)y*N + c] = s0 + s1;
+}
+
 // --------------------------------------------------------------- K3 / K8 ---
 // one wave per measurement row: dot(J[r,:], v)^2 accumulated per wave
 __global__ void __launch_bounds__(TPB) k_norm2_Jv_part(const double* __restrict__ J,
@@ -577,8 +594,90 @@ int launch_syrk(hipStream_t st, double* C, int ldc, const double* A, int lda, in
   return DLG_OK;
 }
 
-int potrf_lower(hipStream_t st, double* A, int lda, int n, int* info_dev, double* Linv)
+// look-ahead part of the trailing update: only the NEXT panel's columns [c0, c0 + nc) of the
+// trailing matrix, C[i][j] -= sum_k X[i][k] X[j][k] for the rows i >= c0 (X = the panel just solved,
+// columns kb .. kb + nb).  A wave per 16 rows x 64 columns on the matrix cores; the 64 x 64 block of
+// X at the next panel's own rows sits in LDS as the B operand.
+__global__ void __launch_bounds__(TPB) k_panel_update(double* __restrict__ A, int lda, int kb, int nb, int c0, int nc, int n)
 {
+  __shared__ double Xt[NB][NB + 1];      // Xt[j][k] = X[c0 + j][k]
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6, mm = lane & 15, kq = lane >> 4;
+  for(int e = t; e < NB*NB; e += TPB)
+  {
+    const int j = e % NB, k = e / NB;
+    Xt[j][k] = (j < nc && k < nb) ? A[(size_t)(kb + k)*lda + c0 + j] : 0.0;
+  }
+  __syncthreads();
+  const int i0 = c0 + 16*(blockIdx.x*(TPB/64) + wv);
+  if(i0 >= n) return;
+  const int row = min(i0 + mm, n - 1);
+  double4_t acc[4];
+#pragma unroll
+  for(int jt = 0; jt < 4; jt++) acc[jt] = (double4_t){0.0, 0.0, 0.0, 0.0};
+  for(int k4 = 0; k4 < NB; k4 += 4)
+  {
+    const int k = k4 + kq;
+    const double a = (k < nb) ? A[(size_t)(kb + k)*lda + row] : 0.0;
+#pragma unroll
+    for(int jt = 0; jt < 4; jt++) acc[jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Xt[16*jt + mm][k], acc[jt], 0, 0, 0);
+  }
+#pragma unroll
+  for(int jt = 0; jt < 4; jt++)
+#pragma unroll
+    for(int q = 0; q < 4; q++)
+    {
+      const int i = i0 + kq + 4*q, j = 16*jt + mm;
+      if(i < n && j < nc && i >= c0 + j) A[(size_t)(c0 + j)*lda + i] -= acc[jt][q];
+    }
+}
+
+// blocked right-looking Cholesky with LOOK-AHEAD over two streams: after the panel of step k is solved
+// (diagonal block + triangular solve), only the next panel's columns are updated on the main stream
+// (k_panel_update), so the next diagonal block and solve can start; the rest of the trailing matrix is
+// updated by the fp64-MFMA SYRK on the second stream meanwhile.  st2 == nullptr: everything in order
+// on one stream (the default, see below).
+int potrf_lower(hipStream_t st, double* A, int lda, int n, int* info_dev, double* Linv,
+                hipStream_t st2 = nullptr, hipEvent_t ev_panel = nullptr, hipEvent_t ev_trail = nullptr)
+{
+  // measured on config #2 (N = 2000): 2.23 ms with look-ahead against 2.15 without -- the three stream
+  // dependencies per step cost more than the overlapped SYRK saves -- so it is opt-in (DOGLEG_AMD_LOOKAHEAD)
+  const bool lookahead = getenv("DOGLEG_AMD_LOOKAHEAD") != nullptr;
+  if(st2 && ev_panel && ev_trail && n > 4*NB && lookahead)
+  {
+    bool trail_pending = false;
+    for(int kb = 0, blk = 0; kb < n; kb += NB, blk++)
+    {
+      const int nb = (n - kb < NB) ? n - kb : NB;
+      double* Li = Linv + (size_t)blk*NB*NB;
+      dense_launch_potrf_diag(st, A, lda, kb, nb, info_dev, Li);
+      const int rem = n - kb - nb;
+      if(rem <= 0) break;
+      hipLaunchKernelGGL(k_trsm_gemm, dim3(dlg_cdiv(rem, NB)), dim3(TPB), 0, st, A, lda, kb, nb, n, Li);
+      DLG_HIP(hipEventRecord(ev_panel, st));
+      // the previous step's trailing update also wrote the next panel's columns: it must be done
+      // before this step's share is subtracted from them
+      if(trail_pending) DLG_HIP(hipStreamWaitEvent(st, ev_trail, 0));
+      const int c0 = kb + nb, nc = (rem < NB) ? rem : NB;
+      hipLaunchKernelGGL(k_panel_update, dim3(dlg_cdiv(rem, 16*(TPB/64))), dim3(TPB), 0, st, A, lda, kb, nb, c0, nc, n);
+      const int rem2 = rem - nc;
+      trail_pending = false;
+      if(rem2 > 0)
+      {
+        DLG_HIP(hipStreamWaitEvent(st2, ev_panel, 0));
+        double* Cc = A + (size_t)(c0 + nc)*lda + (c0 + nc);
+        const double* P = A + (size_t)kb*lda + (c0 + nc);
+        int rc;
+        if(rem2 >= 1024) rc = launch_syrk<64>(st2, Cc, lda, P, lda, rem2, nb, -1.0, 0.0, false, nullptr, 0);
+        else             rc = launch_syrk<32>(st2, Cc, lda, P, lda, rem2, nb, -1.0, 0.0, false, nullptr, 0);
+        if(rc != DLG_OK) return rc;
+        DLG_HIP(hipEventRecord(ev_trail, st2));
+        trail_pending = true;
+      }
+    }
+    if(trail_pending) DLG_HIP(hipStreamWaitEvent(st, ev_trail, 0));
+    DLG_LAUNCH_CHECK();
+    return DLG_OK;
+  }
   for(int kb = 0, blk = 0; kb < n; kb += NB, blk++)
   {
     const int nb = (n - kb < NB) ? n - kb : NB;
@@ -643,12 +742,20 @@ int dense_eval(dlg_backend* b, int s)
   int rpc = 128;
   while(rpc > 16 && (long)dlg_cdiv(M, rpc)*dlg_cdiv(N, TPB) < 2048) rpc >>= 1;
   const int nchunks = dlg_cdiv(M, rpc);
-  DLG_CHECK(dlg_ensure_partials(b, (size_t)nchunks*N + 8192));
+  const int nsl = (nchunks >= 64) ? 32 : 0;      // long lists: column sums in two stages
+  DLG_CHECK(dlg_ensure_partials(b, (size_t)(nchunks + nsl)*N + 8192));
   double* part = b->d_part + 8192;         // first 8192 doubles are used by the vec reductions
   hipLaunchKernelGGL(k_gemvT_part, dim3(dlg_cdiv(N, TPB), nchunks), dim3(TPB), 0, b->stream, S.Jin(),
                      S.xin(), M, N, rpc, part);
-  hipLaunchKernelGGL(k_colsum, dim3(dlg_cdiv(N, TPB)), dim3(TPB), 0, b->stream, part, nchunks, N,
-                     S.Jt_x);
+  if(nsl > 0)
+  {
+    double* part2 = part + (size_t)nchunks*N;
+    hipLaunchKernelGGL(k_colsum_slices, dim3(dlg_cdiv(N, TPB), nsl), dim3(TPB), 0, b->stream, part, nchunks, N, part2);
+    hipLaunchKernelGGL(k_colsum, dim3(dlg_cdiv(N, TPB)), dim3(TPB), 0, b->stream, part2, nsl, N, S.Jt_x);
+  }
+  else
+    hipLaunchKernelGGL(k_colsum, dim3(dlg_cdiv(N, TPB)), dim3(TPB), 0, b->stream, part, nchunks, N,
+                       S.Jt_x);
   DLG_LAUNCH_CHECK();
   return DLG_OK;
 }
@@ -710,7 +817,8 @@ int dense_factorize(dlg_backend* b, int s, double lambda, int* ok)
   dlg_fork_point(b);
   {
     DlgProfScope pf(b, DLG_PROF_K5_FACTOR);
-    DLG_CHECK(potrf_lower(b->stream, b->G, b->N, b->N, b->d_info, b->Linv));
+    DLG_CHECK(potrf_lower(b->stream, b->G, b->N, b->N, b->d_info, b->Linv,
+                          b->overlap ? b->copy_stream : nullptr, b->ev_step, b->ev_copy));
   }
   return finish_potrf(b, ok);
 }
@@ -726,7 +834,8 @@ int products_factorize(dlg_backend* b, int s, double lambda, int* ok)
   hipLaunchKernelGGL(k_unpack_to_G, dim3(dlg_cdiv((long)nn, TPB)), dim3(TPB), 0, b->stream, S.Jin(),
                      b->N, packed ? 1 : 0, lambda, b->G);
   DLG_LAUNCH_CHECK();
-  DLG_CHECK(potrf_lower(b->stream, b->G, b->N, b->N, b->d_info, b->Linv));
+  DLG_CHECK(potrf_lower(b->stream, b->G, b->N, b->N, b->d_info, b->Linv,
+                        b->overlap ? b->copy_stream : nullptr, b->ev_step, b->ev_copy));
   return finish_potrf(b, ok);
 }
 

@@ -176,3 +176,28 @@ def test_syrk_and_potrf_kernels(gpu):
         Lg = np.tril(dS.numpy((n, n)).T)
         Lref = np.linalg.cholesky(Sm)
         assert np.max(np.abs(Lg - Lref)) <= 1e-11 * np.max(np.abs(Lref)), n
+
+
+@pytest.mark.parametrize("env", [{"DOGLEG_AMD_LOOKAHEAD": "1"}, {"DOGLEG_AMD_NO_OVERLAP": "1"}, {"DOGLEG_AMD_NO_K3_FORK": "1"}],
+                         ids=["potrf-lookahead", "no-overlap", "no-k3-fork"])
+def test_dense_stream_variants_match_oracle(gpu, env, monkeypatch):
+    """the two-stream variants of the dense path (look-ahead potrf, Cauchy step beside the factorisation)
+    and their single-stream forms give the oracle's Gauss-Newton step"""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    O = oa.oracle()
+    dp = oa.DenseProblem(M=2500, N=521, seed=4)
+    p = dp.p0()
+    x, J = dp.eval(p)
+    be = capi.Backend(capi.DLG_DENSE, dp.N, dp.M)
+    be.set_p(0, p)
+    be.upload(0, x, J)
+    be.eval(0)
+    lam, n2c, n2g = be.cauchy_gauss_newton(0, 0.0)
+    gn = be.download(0, capi.VEC_GN)
+    N, M = dp.N, dp.M
+    dfac, work, o8 = np.zeros(N * (N + 1) // 2), np.zeros(5 * N), np.zeros(8)
+    assert O.orc_step_dense(N, M, dptr(J), dptr(x), dptr(p), 0.0, dptr(dfac), dptr(work), dptr(o8)) == 0
+    assert np.linalg.norm(gn - work[2*N:3*N]) <= 1e-10
+    assert abs(n2c - o8[1]) <= 1e-10 * o8[1]
+    be.close()
