@@ -37,7 +37,7 @@ BACKEND_SYMBOLS = [
     "dlg_backend_set_profiling", "dlg_backend_get_profile",
     "dlg_backend_set_allreduce", "dlg_backend_set_partition", "dlg_partition_rows", "dlg_partition_stats",
     "dlg_sparse_partition_probe", "dlg_rccl_unique_id", "dlg_backend_init_rccl", "dlg_backend_set_rccl",
-    "dlg_backend_comm_size", "dlg_solve_multi", "dlg_pseudoinverse_chunk",
+    "dlg_backend_comm_size", "dlg_solve_multi", "dlg_pseudoinverse_chunk", "dlg_backend_set_speculation",
 ]
 PROF_NAMES = ["K1_jtx", "K3K8_norm2Jv", "K4_kernel", "K4_total", "K5_factor", "K6_solve", "K7_step", "vec"]
 DOGLEG_SYMBOLS = [
@@ -77,6 +77,7 @@ def lib():
     L.dlg_backend_get_stream.restype = V
     L.dlg_backend_set_shard.argtypes = [V, C.c_int, C.c_int, V, V]
     L.dlg_backend_set_allreduce.argtypes = [V, V, V]
+    L.dlg_backend_set_speculation.argtypes = [V, C.c_int]
     L.dlg_backend_set_partition.argtypes = [V, C.c_int, C.c_int]
     L.dlg_partition_rows.argtypes = [V, I, C.POINTER(I)]
     L.dlg_partition_stats.argtypes = [V, C.POINTER(C.c_long), C.c_int]
@@ -335,6 +336,10 @@ class Backend:
         self._allreduce_cb = cb                 # must outlive the backend: the C side keeps the pointer
         _ck(self.L.dlg_backend_set_shard(self.h, row0, row1,
                                          C.cast(cb, C.c_void_p) if cb else None, None), "set_shard")
+
+    def set_speculation(self, on=True):
+        """assemble JtJ beside Jt*x at every eval (for callers that expect to factorise the point)"""
+        _ck(self.L.dlg_backend_set_speculation(self.h, 1 if on else 0), "set_speculation")
 
     def set_allreduce(self, fn):
         """host-synchronous sum-all-reduce hook (fallback / logical ranks on one device)"""

@@ -57,6 +57,7 @@ void dlg_prof_resolve(dlg_backend* b)
   for(auto& pp : b->prof_pending)
   {
     float ms = 0;
+    (void)hipEventSynchronize(pp.b);          // (a phase on the second stream may still be running)
     if(hipEventElapsedTime(&ms, pp.a, pp.b) == hipSuccess) { b->prof_ms[pp.id] += ms; b->prof_n[pp.id]++; }
     b->prof_pool.push_back(pp.a); b->prof_pool.push_back(pp.b);
   }
@@ -216,6 +217,13 @@ extern "C" int dlg_backend_set_shard(dlg_backend_t* b, int row0, int row1, dlg_a
   b->row0 = row0; b->row1 = row1; b->mloc = row1 - row0;
   if(fn) { b->allreduce = fn; b->allreduce_cookie = cookie; }
   if(b->sharded()) b->host_finals = false;          // sums over the ranks act on device scalars: they must be final on the device
+  return DLG_OK;
+}
+
+extern "C" int dlg_backend_set_speculation(dlg_backend_t* b, int on)
+{
+  if(!b) return DLG_ERR_ARG;
+  b->speculate = on != 0;
   return DLG_OK;
 }
 
@@ -387,6 +395,7 @@ extern "C" int dlg_point_upload(dlg_backend_t* b, int s, const double* x_host, c
   S.have_inputs = true;
   invalidate(S);
   if(b->factor_slot == s) b->factor_slot = -1;
+  if(b->type == DLG_SPARSE) sparse_spec_invalidate(b, s);
   return DLG_OK;
 }
 
@@ -414,6 +423,7 @@ extern "C" int dlg_point_bind_device(dlg_backend_t* b, int s, const double* x_de
   S.have_inputs = true;
   invalidate(S);
   if(b->factor_slot == s) b->factor_slot = -1;
+  if(b->type == DLG_SPARSE) sparse_spec_invalidate(b, s);
   return DLG_OK;
 }
 
@@ -432,6 +442,8 @@ extern "C" int dlg_point_eval(dlg_backend_t* b, int s, double* norm2_x, double* 
   else
   {
     const int mloc = dlg_mloc(b);
+    // the caller expects to factorise this point: its JtJ is assembled on the second stream meanwhile
+    if(b->type == DLG_SPARSE && b->speculate && b->overlap) DLG_CHECK(sparse_assemble_speculative(b, s));
     {
       DlgProfScope ps(b, DLG_PROF_K1_JTX);
       if(b->type == DLG_SPARSE) DLG_CHECK(sparse_eval(b, s)); else DLG_CHECK(dense_eval(b, s));

@@ -65,6 +65,7 @@ struct dlg_backend
   hipStream_t aux_stream = nullptr;
   hipEvent_t  ev_fork = nullptr, ev_join = nullptr;
   bool want_fork = false, fork_recorded = false, overlap = true;
+  bool speculate = false;     // dlg_backend_set_speculation: assemble JtJ beside Jt*x at every dlg_point_eval
   DlgSlot slot[2];
 
   // scalar return path: kernels write d_scal, one D2H into pinned h_scal
@@ -206,6 +207,8 @@ size_t sparse_local_nnz(const dlg_backend* b);   // J values held by this rank
 void sparse_destroy(dlg_backend* b);
 int sparse_set_pattern(dlg_backend* b, const int* colptr, const int* rowidx);
 int sparse_eval(dlg_backend* b, int slot);                      // K1
+int sparse_assemble_speculative(dlg_backend* b, int s);         // K4 beside K1 (second stream, second panel buffer)
+void sparse_spec_invalidate(dlg_backend* b, int s);
 int sparse_norm2_Jv(dlg_backend* b, int slot, const double* v, double* out_dev); // K3/K8
 int sparse_factorize(dlg_backend* b, int slot, double lambda, int* ok);          // K4+K5
 bool sparse_factor_ok(const dlg_backend* b);     // pivot flag of the last factorisation (after a sync)

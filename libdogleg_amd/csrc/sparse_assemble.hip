@@ -712,12 +712,13 @@ int sparse_norm2_Jv(dlg_backend* b, int s, const double* v, double* out_dev)
 }
 
 // the assembly launches: JtJ of the local rows (values Jv) into the zeroed panel buffer
-static int assemble_launch(dlg_backend* b, const double* Jv)
+static int assemble_launch(dlg_backend* b, const double* Jv, double* Lx = nullptr)
 {
   SparseSym* Y = b->sym;
   const SymHost& H = Y->H;
   hipStream_t st = b->stream;
-  DLG_HIP(hipMemsetAsync(Y->Lx, 0, sizeof(double)*(size_t)H.lx_size, st));
+  if(!Lx) Lx = Y->Lx;
+  DLG_HIP(hipMemsetAsync(Lx, 0, sizeof(double)*(size_t)H.lx_size, st));
   const int nt = (int)H.asm_ctask.size(), nmt = (int)H.asm_mtask.size();
   if(nt > 0 || nmt > 0)
   {
@@ -728,31 +729,31 @@ static int assemble_launch(dlg_backend* b, const double* Jv)
       if(H.asm_lds_len == 18)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_assemble_mfma<18>), dim3(dlg_cdiv(nruns, TPB/64)), dim3(TPB),
                            sizeof(double)*(TPB/64)*ASM_U*4*18, st, Y->asm_run, nruns, Y->asm_mtask,
-                           Y->asm_kg, Y->asm_shape, Y->asm_tdest, Y->asm_pdest, Jv, Y->Lx, Y->asm_part, 18);
+                           Y->asm_kg, Y->asm_shape, Y->asm_tdest, Y->asm_pdest, Jv, Lx, Y->asm_part, 18);
       else
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_assemble_mfma<0>), dim3(dlg_cdiv(nruns, TPB/64)), dim3(TPB),
                            sizeof(double)*(TPB/64)*ASM_U*4*H.asm_lds_len, st, Y->asm_run, nruns, Y->asm_mtask,
-                           Y->asm_kg, Y->asm_shape, Y->asm_tdest, Y->asm_pdest, Jv, Y->Lx, Y->asm_part,
+                           Y->asm_kg, Y->asm_shape, Y->asm_tdest, Y->asm_pdest, Jv, Lx, Y->asm_part,
                            H.asm_lds_len);
     }
     if(nt > 0)
       hipLaunchKernelGGL(k_assemble, dim3(dlg_cdiv(nt, TPB/64)), dim3(TPB), 0, st, Y->asm_ctask, nt,
-                         Y->asm_batch, Y->asm_rho, Y->asm_pair, Y->asm_slot, Jv, Y->Lx, Y->asm_part);
+                         Y->asm_batch, Y->asm_rho, Y->asm_pair, Y->asm_slot, Jv, Lx, Y->asm_part);
   }
   for(size_t q = 0; q + 2 < H.fin2_stage.size(); q += 3)
   {
     const int f0 = H.fin2_stage[q], ns = H.fin2_stage[q+1], nl = H.fin2_stage[q+2];
     if(ns > 0)
       hipLaunchKernelGGL(k_assemble_fin2_short, dim3(dlg_cdiv(ns, TPB/64)), dim3(TPB), 0, st, Y->asm_fin2 + f0, ns,
-                         Y->asm_fin2_list, Y->asm_part, Y->Lx);
+                         Y->asm_fin2_list, Y->asm_part, Lx);
     if(nl > 0)
       hipLaunchKernelGGL(k_assemble_fin2_long, dim3(nl), dim3(1024), 0, st, Y->asm_fin2 + f0 + ns,
-                         Y->asm_fin2_list, Y->asm_part, Y->Lx);
+                         Y->asm_fin2_list, Y->asm_part, Lx);
   }
   const int nf = (int)H.asm_cfin.size();
   if(nf > 0)
     hipLaunchKernelGGL(k_assemble_fin, dim3(nf), dim3(1024), 0, st, Y->asm_cfin, Y->asm_slot,
-                       Y->asm_part, Y->Lx);
+                       Y->asm_part, Lx);
   DLG_LAUNCH_CHECK();
   return DLG_OK;
 }
@@ -819,6 +820,19 @@ int sparse_assemble(dlg_backend* b, int s, double lambda)
   DlgSlot& S = b->slot[s];
   const SymHost& H = Y->H;
   hipStream_t st = b->stream;
+  // a speculative assembly may be in flight on the second stream (sparse_assemble_speculative): it
+  // shares the partial-sum buffers with any other assembly and, if it is this slot's, it IS the assembly
+  if(Y->spec_inflight)
+  {
+    DLG_HIP(hipStreamWaitEvent(st, Y->ev_spec, 0));
+    Y->spec_inflight = false;
+  }
+  if(Y->spec_valid && Y->spec_slot == s && Y->spec_J == S.Jin())
+  {
+    std::swap(Y->Lx, Y->Lx_spec);           // the panels assembled beside K1 become the factor's panels
+    Y->spec_valid = false;
+  }
+  else
   {
     DlgProfScope pt(b, DLG_PROF_K4_TOTAL);
     DLG_CHECK(assemble_launch(b, S.Jin()));
@@ -910,4 +924,46 @@ int sparse_partition_reduce(dlg_backend* b)
                        Y->sn_rowptr, Y->sn_lx, Y->perm, Y->aug_rhs, H.N, Y->d_info, Y->sn_owner, 1);
   DLG_LAUNCH_CHECK();
   return DLG_OK;
+}
+
+// ---- speculative assembly (K4 beside K1) -----------------------------------------------------------
+// The assembly needs nothing but J, so it can start as soon as J is on the device: when the caller of
+// dlg_point_eval expects the point to be factorised (the driver does once steps need the
+// Gauss-Newton step), the assembly of the slot's J runs on the second stream, into a second panel
+// buffer, while Jt*x and the norms run on the main stream and the host looks at the gradient.  A
+// later sparse_assemble of the same slot adopts the buffer (pointer swap); an unused one is
+// dropped.  Same kernels, same sums: the panels are bit-identical to the in-line assembly.
+int sparse_assemble_speculative(dlg_backend* b, int s)
+{
+  SparseSym* Y = b->sym;
+  if(!Y || !b->aux_stream || b->sharded() || Y->H.part_nranks > 1) return DLG_OK;
+  const SymHost& H = Y->H;
+  DlgSlot& S = b->slot[s];
+  if(!Y->Lx_spec)
+  {
+    DLG_HIP(hipMalloc(&Y->Lx_spec, sizeof(double)*(size_t)(H.lx_size ? H.lx_size : 1))); Y->allocs.push_back(Y->Lx_spec);
+    DLG_HIP(hipEventCreateWithFlags(&Y->ev_spec, hipEventDisableTiming));
+    DLG_HIP(hipEventCreateWithFlags(&Y->ev_spec_fork, hipEventDisableTiming));
+  }
+  // behind everything enqueued so far on the main stream (the upload of J, a factorisation that still
+  // reads the partial-sum buffers), and behind an earlier speculative assembly (same stream)
+  DLG_HIP(hipEventRecord(Y->ev_spec_fork, b->stream));
+  DLG_HIP(hipStreamWaitEvent(b->aux_stream, Y->ev_spec_fork, 0));
+  hipStream_t main_stream = b->stream;
+  b->stream = b->aux_stream;
+  int rc;
+  {
+    DlgProfScope pt(b, DLG_PROF_K4_TOTAL);
+    rc = assemble_launch(b, S.Jin(), Y->Lx_spec);
+  }
+  b->stream = main_stream;
+  DLG_CHECK(rc);
+  DLG_HIP(hipEventRecord(Y->ev_spec, b->aux_stream));
+  Y->spec_inflight = true; Y->spec_valid = true; Y->spec_slot = s; Y->spec_J = S.Jin();
+  return DLG_OK;
+}
+void sparse_spec_invalidate(dlg_backend* b, int s)
+{
+  SparseSym* Y = b->sym;
+  if(Y && Y->spec_valid && Y->spec_slot == s) Y->spec_valid = false;
 }

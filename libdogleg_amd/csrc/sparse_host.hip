@@ -11,6 +11,9 @@ void sparse_destroy(dlg_backend* b)
 {
   SparseSym* Y = b->sym;
   if(!Y) return;
+  if(b->aux_stream) (void)hipStreamSynchronize(b->aux_stream);
+  if(Y->ev_spec) (void)hipEventDestroy(Y->ev_spec);
+  if(Y->ev_spec_fork) (void)hipEventDestroy(Y->ev_spec_fork);
   for(void* p : Y->allocs) if(p) (void)hipFree(p);
   delete Y;
   b->sym = nullptr;

@@ -109,6 +109,9 @@ struct SparseSym
   int *xl_sn = nullptr;
   double cur_lambda = 0.0;              // of the factorisation being enqueued (the top panels get it after the sum)
   double *ms_scr = nullptr, *ms_y = nullptr; int ms_lds_f = 0, ms_lds_b = 0;     // multi-right-hand-side solves (sparse_multi.hip)
+  // speculative assembly beside K1 (sparse_assemble_speculative): second panel buffer, its state
+  double* Lx_spec = nullptr; hipEvent_t ev_spec = nullptr, ev_spec_fork = nullptr;
+  bool spec_inflight = false, spec_valid = false; int spec_slot = -1; const double* spec_J = nullptr;
   bool fac_ahead = false;       // panel_factor_ahead instead of panel_factor_mfma (DOGLEG_AMD_AHEAD)
   int bwd_xb_cap = 12288;       // below rows of a supernode staged in LDS by the backward solve
   std::vector<void*> allocs;
@@ -116,7 +119,9 @@ struct SparseSym
 
 // ---- per-file host entry points
 int sparse_assemble(dlg_backend* b, int s, double lambda);   // K4 (+ all-reduce, lambda, augmented row)
-int sparse_partition_reduce(dlg_backend* b);                 // subtree partition: the sum over the ranks at the cut
+int sparse_partition_reduce(dlg_backend* b);
+int sparse_assemble_speculative(dlg_backend* b, int s);     // K4 on the second stream, beside K1
+void sparse_spec_invalidate(dlg_backend* b, int s);                 // subtree partition: the sum over the ranks at the cut
 int sparse_factor_setup(dlg_backend* b);                     // per-level launch parameters of K5
 int sparse_factor_levels(dlg_backend* b);                    // K5 launches (no synchronisation)
 int sparse_solve_setup(dlg_backend* b);                      // per-level launch parameters of K6

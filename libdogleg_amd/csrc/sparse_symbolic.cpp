@@ -1619,6 +1619,12 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
         R.task1 = k; R.kg1 = S.asm_mtask[k-1].kg1;
         S.asm_run.push_back(R);
       }
+      // (Tried: an XCD-aware launch order -- runs sorted by the position in J of the first row they
+      // read, the sorted list cut into 8 segments laid out on the workgroups s, s + 8, ..., so that the
+      // two readers of a stretch of J, its points' tasks and its cameras' tasks, meet in one XCD's L2.
+      // Measured slower: 120.7 us against 112.6 on config #4, 1.17 ms against 1.07 on config #5 -- the
+      // kernel is bound by instruction issue around the K = 4 MFMAs, not by the second pass over J, and
+      // the shape-sorted order balances the long camera runs better.)
     }
     SYM_TICK("9b.4 partial-sum stages");
     // long lists are summed hierarchically: chunks of 64 partials -> intermediate partials.

@@ -352,3 +352,38 @@ def test_solve_with_the_resident_factor(gpu, kind):
     # tolerance: relative 1e-9 times cond is far above what double precision delivers here
     assert np.max(np.abs(u - ref)) <= 1e-9 * np.max(np.abs(ref)) * max(1.0, np.linalg.cond(A) * 1e-6)
     assert np.allclose(be.solve_with_factor(0, rhs[1]), u[1], rtol=0, atol=0)
+
+
+def test_speculative_assembly_changes_no_bit(gpu):
+    """dlg_backend_set_speculation: JtJ assembled on the second stream beside Jt*x, adopted by the
+    factorisation that follows -- the Gauss-Newton step is bit-identical to the in-line assembly; new
+    inputs, another slot or a second factorisation never pick up a stale assembly"""
+    prob = oa.BAProblem(49, 900, 10000, seed=3)
+    Jp, Ji = prob.pattern()
+    p = prob.p0()
+    x, Jx = prob.eval(p)
+    x2, Jx2 = prob.eval(p + 0.01)
+    out = {}
+    for spec in (False, True):
+        be = capi.Backend(capi.DLG_SPARSE, prob.N, prob.M, prob.nnz)
+        be.set_pattern(Jp, Ji)
+        be.set_speculation(spec)
+        be.set_p(0, p)
+        res = []
+        be.upload(0, x, Jx)
+        be.eval(0)
+        lam, n2g = be.gauss_newton(0, 0.0)                 # adopts the speculative assembly of slot 0
+        res.append((n2g, be.download(0, capi.VEC_GN)))
+        be.upload(0, x2, Jx2)                               # new inputs in the same slot
+        be.eval(0)
+        be.upload(1, x, Jx)                                 # ... and another evaluation in the other slot, unused
+        be.eval(1)
+        lam, n2g = be.gauss_newton(0, 1e-3)                 # slot 0 again: the last speculative assembly was slot 1's
+        res.append((n2g, be.download(0, capi.VEC_GN)))
+        lam, n2g = be.gauss_newton(1, 0.0)
+        res.append((n2g, be.download(1, capi.VEC_GN)))
+        out[spec] = res
+        be.close()
+    for a, b in zip(out[False], out[True]):
+        assert a[0] == b[0] and np.array_equal(a[1], b[1])
+    assert np.array_equal(out[True][0][1], out[True][2][1])      # same inputs, other slot: same step
