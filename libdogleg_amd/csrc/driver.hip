@@ -14,6 +14,7 @@
 #include <cstring>
 #include <cmath>
 #include <new>
+#include <chrono>
 #include "../../include/dogleg.h"
 #include "../../include/dlg_backend.h"
 #include "../../include/dlg_trace.h"
@@ -169,19 +170,22 @@ dogleg_operatingPoint_t* alloc_point(Driver* d, int s)
     cholmod_sparse* A = &d->jt[s];
     memset(A, 0, sizeof(*A));
     A->nrow = N; A->ncol = M; A->nzmax = d->nnz;
-    A->p = pinned_alloc(d, s, sizeof(int)*(M + 1));
-    A->i = pinned_alloc(d, s, sizeof(int)*(size_t)d->nnz);
-    if(!A->p || !A->i) return nullptr;
     if(d->f_device)
     {
-      // the values stay on the device; the pattern is the caller's
+      // the values stay on the device and the pattern never travels from here: plain host memory,
+      // a copy of the caller's pattern (page-locking 64 MB per point costs tens of milliseconds)
+      A->p = malloc(sizeof(int)*(M + 1));
+      A->i = malloc(sizeof(int)*(size_t)(d->nnz ? d->nnz : 1));
+      if(!A->p || !A->i) return nullptr;
       memcpy(A->p, d->dev_cp, sizeof(int)*(M + 1));
       memcpy(A->i, d->dev_ri, sizeof(int)*(size_t)d->nnz);
     }
     else
     {
+      A->p = pinned_alloc(d, s, sizeof(int)*(M + 1));
+      A->i = pinned_alloc(d, s, sizeof(int)*(size_t)d->nnz);
       A->x = pinned_alloc(d, s, sizeof(double)*(size_t)d->nnz);
-      if(!A->x) return nullptr;
+      if(!A->p || !A->i || !A->x) return nullptr;
     }
     A->stype = 0; A->itype = CHOLMOD_INT; A->xtype = CHOLMOD_REAL; A->dtype = CHOLMOD_DOUBLE;
     A->sorted = 1; A->packed = 1;
@@ -219,6 +223,7 @@ void free_point(Driver* d, int s)
   {
     free(pt->updateCauchy); free(pt->step_to_here);
     free(d->pub.solve_type == DOGLEG_SPARSE ? d->gn_dense[s].x : (void*)pt->updateGN_dense);
+    if(d->f_device && d->pub.solve_type == DOGLEG_SPARSE) { free(d->jt[s].p); free(d->jt[s].i); }
     free(pt);
   }
   for(int i = 0; i < d->npinned[s]; i++) (void)hipHostFree(d->pinned[s][i]);
@@ -642,12 +647,22 @@ double optimize(double* p, unsigned int Nstate, unsigned int Nmeas, unsigned int
   else { MSG("exactly one of the callbacks must be given"); free(d); return -1.0; }
 
   if(ctx->parameters->debug_vnlog) vnlog_legend();
+  // DOGLEG_AMD_TIMING=1: wall time of the phases of a solve on stderr (where an end-to-end call spends its time)
+  const bool timing = getenv("DOGLEG_AMD_TIMING") != nullptr;
+  const auto t_begin = std::chrono::steady_clock::now();
+  auto t_last = t_begin;
+  auto lap = [&](const char* what) {
+    if(!timing) return;
+    const auto now = std::chrono::steady_clock::now();
+    MSG("timing: %-34s %8.2f ms", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+    t_last = now; };
 
   int flags = 0;
   if(ctx->parameters->JtJ_packed) flags |= DLG_FLAG_JTJ_PACKED;
   if(ctx->parameters->JtJ_upper)  flags |= DLG_FLAG_JTJ_UPPER;
   if(dlg_backend_create(&d->be, (int)ctx->solve_type, (int)Nstate, (int)Nmeas, (int)NJnnz, flags, -1) != DLG_OK)
   { MSG("cannot create the GPU backend: %s", dlg_last_error()); free(d); return -1.0; }
+  lap("backend create (device buffers)");
 
   if(ctx->solve_type != DOGLEG_SPARSE)
   {
@@ -661,6 +676,7 @@ double optimize(double* p, unsigned int Nstate, unsigned int Nmeas, unsigned int
   if(!d->pts[0] || !d->pts[1]) { MSG("out of (pinned) host memory"); destroy(d); return -1.0; }
   ctx->beforeStep = d->pts[0];
   ctx->afterStep  = d->pts[1];
+  lap("operating points (pinned host)");
 
   memcpy(ctx->beforeStep->p, p, sizeof(double)*Nstate);
   if(!be_ok(dlg_point_set_p(d->be, 0, ctx->beforeStep->p), "upload of p")) { destroy(d); return -1.0; }
@@ -669,6 +685,7 @@ double optimize(double* p, unsigned int Nstate, unsigned int Nmeas, unsigned int
   if(tr) { tr->ntrials = 0; tr->ncallbacks = 0; tr->nstate = (int)Nstate; }
 
   const int numsteps = run_optimizer(d);
+  lap("run_optimizer (incl. symbolic phase)");
   const double norm2_x = ctx->beforeStep->norm2_x;
   if(tr) tr->ncallbacks = d->ncallbacks;
   if(numsteps < 0)
@@ -692,6 +709,7 @@ double optimize(double* p, unsigned int Nstate, unsigned int Nmeas, unsigned int
     *returnContext = ctx;
   }
   else destroy(d);
+  lap("teardown");
   return norm2_x;
 }
 

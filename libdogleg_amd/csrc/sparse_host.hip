@@ -2,6 +2,7 @@
 // numeric buffers) and the K4 + K5 orchestration.  The kernels live in sparse_assemble.hip,
 // sparse_factor.hip and sparse_solve.hip.
 #include "sparse_internal.h"
+#include <chrono>
 
 int sparse_create(dlg_backend* b) { (void)b; return DLG_OK; }
 
@@ -29,10 +30,18 @@ int sparse_set_pattern(dlg_backend* b, const int* colptr, const int* rowidx)
   SparseSym* Y = new (std::nothrow) SparseSym();
   if(!Y) { dlg_set_error("out of host memory"); return DLG_ERR_NOMEM; }
   b->sym = Y;
+  const bool timing = getenv("DOGLEG_AMD_TIMING") != nullptr;
+  auto t_last = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what) {
+    if(!timing) return;
+    const auto now = std::chrono::steady_clock::now();
+    fprintf(stderr, "libdogleg_amd: timing:   %-32s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+    t_last = now; };
   char err[512];
   if(sym_analyze(Y->H, b->N, b->M, colptr, rowidx, b->row0, b->row1, err, sizeof(err), b->part_rank, b->part_nranks))
   { dlg_set_error("symbolic analysis: %s", err); return DLG_ERR_ARG; }
   SymHost& H = Y->H;
+  lap("symbolic analysis (host)");
   const bool partition = H.part_nranks > 1;
   if(partition) b->mloc = (int)H.part_rows.size();
   UP(sn_c0); UP(sn_rowptr); UP(sn_rows); UP(sn_scr); UP(lvl_sn); UP(sn_lx); UP(diagpos);
@@ -84,6 +93,7 @@ int sparse_set_pattern(dlg_backend* b, const int* colptr, const int* rowidx)
     Y->n_nv_chunks = (int)ch.size() - 1;
     DLG_CHECK(upload(Y->nv_chunk, ch)); Y->allocs.push_back(Y->nv_chunk);
   }
+  lap("schedule uploads");
   auto dalloc = [&](double*& p, size_t n) -> int {
     DLG_HIP(hipMalloc(&p, sizeof(double)*(n ? n : 1))); Y->allocs.push_back(p); return DLG_OK; };
   DLG_CHECK(dalloc(Y->Lx, (size_t)H.lx_size));
@@ -134,8 +144,10 @@ int sparse_set_pattern(dlg_backend* b, const int* colptr, const int* rowidx)
     }
     DLG_CHECK(upload(Y->colmask, mask)); Y->allocs.push_back(Y->colmask);
   }
+  lap("numeric buffers");
   DLG_CHECK(sparse_factor_setup(b));
   DLG_CHECK(sparse_solve_setup(b));
+  lap("kernel set-up");
   return DLG_OK;
 }
 

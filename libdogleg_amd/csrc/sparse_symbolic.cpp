@@ -5,6 +5,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <chrono>
+#include <thread>
 #include <map>
 #include <cmath>
 #include <numeric>
@@ -255,7 +256,9 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
   const bool sym_time = env_int("DOGLEG_AMD_SYM_DEBUG", 0) >= 2;
   auto sym_t0 = std::chrono::steady_clock::now();
   const char* sym_what = "setup";
+  bool sym_parallel = false;                 // inside the threaded section: the step clock is not kept
   auto sym_tick = [&](const char* next) {
+    if(sym_parallel) return;
     if(sym_time)
     {
       const auto t1 = std::chrono::steady_clock::now();
@@ -811,7 +814,9 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
     }
   }
 
-  SYM_TICK("8 factor update schedule");
+  // (steps 8, 9a, 9b and 10 only read what the steps before them built and write disjoint parts of S:
+  // they run on four threads, see below)
+  auto step8 = [&](char* err, int errlen) -> int {
   // ------------------------------------ 8. factor update schedule
   {
     struct Sub { int lvl, t, q, d, ka, rel; };
@@ -1065,7 +1070,8 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
     for(int l = 0; l < S.nlevels; l++) { S.uw_lvl_ptr[l+1] += S.uw_lvl_ptr[l]; S.uf_lvl_ptr[l+1] += S.uf_lvl_ptr[l]; }
   }
 
-  SYM_TICK("9a Jt*x lists (per var-block)");
+  return 0; };
+  auto step9a = [&](char* err, int errlen) -> int {
   // ------------------------------------------- 9a. Jt*x lists (per var-block)
   {
     // inverted index: var-block -> local row-blocks containing it (row order)
@@ -1116,7 +1122,8 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
     }
   }
 
-  SYM_TICK("9b JtJ assembly schedule");
+  return 0; };
+  auto step9b = [&](char* err, int errlen) -> int {
   // ------------------------------------------- 9b. JtJ assembly schedule
   // Column-block centric: a task owns (a group of) the output blocks (I,J) of ONE
   // column block J and walks the row-blocks that contain J in batches: a batch's
@@ -1674,7 +1681,8 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
     AsmRho R; memset(&R, 0, sizeof(R)); R.pair0 = (int)S.asm_pair.size(); S.asm_rho.push_back(R);
   }
 
-  SYM_TICK("10 forward-solve gather lists");
+  return 0; };
+  auto step10 = [&](char* err, int errlen) -> int {
   // --------------------------------------- 10. forward-solve gather lists
   {
     S.rl_ptr.assign(N + 1, 0);
@@ -1692,6 +1700,25 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
       for(int k = S.sn_rowptr[d] + wd, j = 0; k < S.sn_rowptr[d+1] - 1; k++, j++)
         S.rl_pos[nx[S.sn_rows[k]]++] = S.sn_scr[d] + j;
     }
+  }
+  return 0; };
+  SYM_TICK("8-10 schedules (4 threads)");
+  {
+    char e8[256] = "", e9a[256] = "", e9b[256] = "", e10[256] = "";
+    int r8 = 0, r9a = 0, r9b = 0, r10 = 0;
+    if(env_int("DOGLEG_AMD_SYM_THREADS", 1))
+    {
+      sym_parallel = true;
+      std::thread t8([&] { r8 = step8(e8, sizeof(e8)); });
+      std::thread t9a([&] { r9a = step9a(e9a, sizeof(e9a)); });
+      std::thread t10([&] { r10 = step10(e10, sizeof(e10)); });
+      r9b = step9b(e9b, sizeof(e9b));
+      t8.join(); t9a.join(); t10.join();
+      sym_parallel = false;
+    }
+    else { r8 = step8(e8, sizeof(e8)); r9a = step9a(e9a, sizeof(e9a)); r9b = step9b(e9b, sizeof(e9b)); r10 = step10(e10, sizeof(e10)); }
+    const char* em = r8 ? e8 : (r9a ? e9a : (r9b ? e9b : (r10 ? e10 : nullptr)));
+    if(em) SYM_FAIL("%s", em);
   }
   SYM_TICK("done");
   return 0;
