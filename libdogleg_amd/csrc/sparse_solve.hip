@@ -207,6 +207,30 @@ __global__ void __launch_bounds__(BWD_NT, BD_ONLY ? 4 : 1) k_solve_bwd_level(con
   }
   __syncthreads();
   BW_STAMP(2);
+  // The 8x8 diagonal blocks are inverted once, all of them in parallel (thread = (block, column),
+  // forward substitution in registers), so that the sequential sweep over the blocks below is eight
+  // independent dot products per block instead of a 36-step substitution chain.  The column is
+  // written back behind the next barrier (every thread has read the original block by then).
+  double tinv[8];
+  const bool tinv_on = !BD_ONLY && nmem == 0 && tid < 8*nblk;
+  if(tinv_on)
+  {
+    const double* Tb = T + (tid >> 3)*64;
+    const int c = tid & 7;
+    double Lb[8][8];
+#pragma unroll
+    for(int a = 0; a < 8; a++)
+#pragma unroll
+      for(int b = 0; b <= a; b++) Lb[a][b] = Tb[a*8 + b];        // diagonal entries are reciprocals already
+#pragma unroll
+    for(int i = 0; i < 8; i++)
+    {
+      double v = 0.0;
+#pragma unroll
+      for(int k = 0; k < i; k++) v -= (k >= c) ? Lb[i][k]*tinv[k] : 0.0;
+      tinv[i] = (i == c) ? Lb[i][i] : ((i > c) ? v*Lb[i][i] : 0.0);
+    }
+  }
   if(mv_thread)
   {
     // partial sums of the mat-vec into xp[part][column]; thread j < w adds them up below
@@ -242,6 +266,13 @@ __global__ void __launch_bounds__(BWD_NT, BD_ONLY ? 4 : 1) k_solve_bwd_level(con
   }
   __syncthreads();
   BW_STAMP(3);
+  if(tinv_on)
+  {
+    double* Tb = T + (tid >> 3)*64;
+    const int c = tid & 7;
+#pragma unroll
+    for(int i = 0; i < 8; i++) if(i >= c) Tb[i*8 + c] = tinv[i];       // Tb = (diagonal block)^-1, lower triangle
+  }
   if(nmem > 0)
   {
     // (nmem <= BWD_NT: a member has at least one column and w <= 256)
@@ -294,60 +325,73 @@ __global__ void __launch_bounds__(BWD_NT, BD_ONLY ? 4 : 1) k_solve_bwd_level(con
     for(int p = 0; p < mv_parts; p++) sum += xp[p*256 + tid];
     xi = myrhs - sum;
   }
+  // The sweep over the blocks is bound by instruction issue (one or two waves, ~4.5 cycles per
+  // instruction): the body is kept branch-free and short.  Operands come from the LDS copy of the
+  // top block when the level has room for it, else from HBM two blocks ahead with clamped,
+  // unconditional loads; every thread computes the 8 unknowns of a block itself (dot products with
+  // the inverted diagonal block) and ONE thread parks them in xs -- the owners pick them up at the end.
   const double* Lcol = L + (size_t)min(tid, w - 1)*nrows;      // column tid of L = row tid of L^T
   const double* Ltc = Lt + min(tid, w - 1)*ldt;
-  double lv[8];
+  const int wlast = w - 1;
+  double lv[8], ln[8];
+#pragma unroll
+  for(int a = 0; a < 8; a++) { lv[a] = 0.0; ln[a] = 0.0; }
   if(!top_lds)
   {
-    const int j0 = 8*(nblk - 1);
+    const int j0 = 8*(nblk - 1), j1 = max(j0 - 8, 0);
 #pragma unroll
-    for(int a = 0; a < 8; a++) lv[a] = (tid < j0 && j0 + a < w) ? Lcol[j0 + a] : 0.0;
+    for(int a = 0; a < 8; a++) { lv[a] = Lcol[min(j0 + a, wlast)]; ln[a] = Lcol[min(j1 + a, wlast)]; }
   }
   for(int blk = nblk - 1; blk >= 0; blk--)
   {
     const int j0 = 8*blk;
     double* rh = rhs + 8*(blk & 1);
     if(tid >= j0 && tid < j0 + 8) rh[tid - j0] = xi;
-    double ln[8];
+    double lf[8];                          // two blocks ahead (HBM path)
     if(top_lds)
     {
 #pragma unroll
-      for(int a = 0; a < 8; a++) lv[a] = (tid < j0 && j0 + a < w) ? Ltc[j0 + a] : 0.0;
+      for(int a = 0; a < 8; a++) lv[a] = Ltc[min(j0 + a, wlast)];
     }
     else
     {
+      const int j2 = max(j0 - 16, 0);
 #pragma unroll
-      for(int a = 0; a < 8; a++) ln[a] = (blk > 0 && tid < j0 - 8) ? Lcol[j0 - 8 + a] : 0.0;
+      for(int a = 0; a < 8; a++) lf[a] = Lcol[min(j2 + a, wlast)];
     }
-    __syncthreads();
+    // the barrier only has to publish rh (LDS): __syncthreads() would also wait for the global loads
+    // in flight for the blocks ahead (s_waitcnt vmcnt(0)), i.e. pay a memory latency per block
+    if(blk == nblk - 1) BW_STAMP(6);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if(blk == nblk - 1) BW_STAMP(7);
     const double* Tb = T + blk*64;
     double xk[8];
+    // x_blk = (block^-1)' rhs: eight independent dot products (rows past the end: rh = 0 -> 0)
 #pragma unroll
-    for(int a = 7; a >= 0; a--)
+    for(int a = 0; a < 8; a++)
     {
-      double v = rh[a];
+      double v = Tb[a*8 + a]*rh[a];
 #pragma unroll
-      for(int b = a + 1; b < 8; b++) v -= Tb[b*8 + a]*xk[b];
-      xk[a] = v*Tb[a*8 + a];
+      for(int b = a + 1; b < 8; b++) v += Tb[b*8 + a]*rh[b];
+      xk[a] = v;
     }
-    if(tid < j0)
+    if(tid == j0)
     {
 #pragma unroll
-      for(int a = 0; a < 8; a++) xi -= lv[a]*xk[a];
+      for(int a = 0; a < 8; a++) xs[min(j0 + a, 255)] = xk[a];
     }
-    else if(tid < j0 + 8)
-    {
-      double v = 0.0;
+    double upd = 0.0;
 #pragma unroll
-      for(int a = 0; a < 8; a++) v = (tid - j0 == a) ? xk[a] : v;
-      xi = v;
-    }
+    for(int a = 0; a < 8; a++) upd += lv[a]*xk[a];
+    xi -= (tid < j0) ? upd : 0.0;
     if(!top_lds)
     {
 #pragma unroll
-      for(int a = 0; a < 8; a++) lv[a] = ln[a];
+      for(int a = 0; a < 8; a++) { lv[a] = ln[a]; ln[a] = lf[a]; }
     }
   }
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  if(tid < w) xi = xs[tid];
   BW_STAMP(4);
   if(tid < w) { ywork[c0 + tid] = xi; out[myperm] = xi; }
   BW_STAMP(5);
@@ -370,8 +414,9 @@ extern "C" void dlg_bw_profile_dump(int nlevels)
   hipDeviceSynchronize();
   hipMemcpyFromSymbol(h, HIP_SYMBOL(g_bw_prof), sizeof(h));
   for(int l = 0; l < nlevels && l < 64; l++)
-    fprintf(stderr, "bwd level %2d: issue %6lld  gather+barrier %6lld  matvec %6lld  solve %6lld  store %6lld cycles\n", l,
-            h[l*8+1] - h[l*8], h[l*8+2] - h[l*8+1], h[l*8+3] - h[l*8+2], h[l*8+4] - h[l*8+3], h[l*8+5] - h[l*8+4]);
+    fprintf(stderr, "bwd level %2d: issue %6lld  gather+barrier %6lld  matvec %6lld  solve %6lld  store %6lld cycles | to first barrier %6lld, in it %6lld, rest of the loop %6lld\n", l,
+            h[l*8+1] - h[l*8], h[l*8+2] - h[l*8+1], h[l*8+3] - h[l*8+2], h[l*8+4] - h[l*8+3], h[l*8+5] - h[l*8+4],
+            h[l*8+6] - h[l*8+3], h[l*8+7] - h[l*8+6], h[l*8+4] - h[l*8+7]);
 }
 #endif
 int sparse_solve_setup(dlg_backend* b)
