@@ -192,7 +192,14 @@ __device__ __forceinline__ void panel_factor_mfma(double* P, int ldp, int nrows,
       if(q <= c && c < nb) P[(kb + c) + (kb + q)*ldp] = v;
       if(c == 0) s_dinv[q] = dv;
     }
-    else if(kb > 0) panel_mfma_tiles<true>(P, ldp, nrows, kb, nb16, kbeg, lane, wv, NW - 1, ntile);
+    else if(kb > 0)
+    {
+      // with 8 waves, wave 4 shares its SIMD with the diagonal wave and the two contend for instruction
+      // issue: it stays out of the tile updates, the diagonal wave's chain has SIMD 0 to itself
+      // (tools/micro/bench_ahead: 52.8k -> 50.1k cycles for a 187 x 60 panel)
+      if(NW == 8) { if(wv != 4) panel_mfma_tiles<true>(P, ldp, nrows, kb, nb16, kbeg, lane, wv < 4 ? wv : wv - 1, NW - 2, ntile); }
+      else panel_mfma_tiles<true>(P, ldp, nrows, kb, nb16, kbeg, lane, wv, NW - 1, ntile);
+    }
     DLG_PF_STAMP(0);
     __syncthreads();
     DLG_PF_STAMP(1);
