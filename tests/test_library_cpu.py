@@ -407,3 +407,19 @@ def test_subtree_partition_with_gloo_world_size_2():
         p.join(timeout=120)
         assert p.exitcode == 0
     assert q.get(timeout=5) is True
+
+
+def test_documented_limits_are_reported_cleanly():
+    """DESIGN.md section 3, "Limits": a pattern outside them makes dlg_sparse_set_pattern (here: the
+    host-only probe of the same symbolic phase) return an error with a message -- no crash, no exit"""
+    N, M = 70010, 3
+    Jp = np.array([0, 70000, 70001, 70002], dtype=np.int32)
+    Ji = np.concatenate([np.arange(70000), [5], [7]]).astype(np.int32)
+    with pytest.raises(capi.DlgError, match="at most 65535"):
+        capi.symbolic_probe(N, M, Jp, Ji)
+    # a row touching 300 separate var-blocks is within the limits of the symbolic phase
+    rows = [np.arange(0, 3000, 10)] + [np.array([10 * k, 10 * k + 1]) for k in range(300)]
+    Jp = np.cumsum([0] + [len(r) for r in rows]).astype(np.int32)
+    Ji = np.concatenate(rows).astype(np.int32)
+    st = capi.symbolic_probe(3000, len(rows), Jp, Ji)
+    assert st["supernodes"] > 0
