@@ -9,7 +9,8 @@ def ph(k, n): return "%.3f" % B[k]["phases_ms_per_step"][n]
 def stats(wl, steps, rows):
     return subprocess.check_output([sys.executable, os.path.join(root, "tools", "prof_summary.py"),
                                     os.path.join(root, "gpurun_out", tag, f"stats_{wl}"), str(steps), str(rows)]).decode().rstrip()
-s1, d5 = stats("sparse-1m", 23, 18), stats("dense-50k", 11, 12)
+nst = lambda k: B[k]["steps"]*2 + B[k]["warmup"] + 3
+s1, d5 = stats("sparse-1m", nst("sparse1m"), 18), stats("dense-50k", B["dense50k"]["steps"] + B["dense50k"]["warmup"] + 1, 12)
 e2e = json.load(open(os.path.join(P, f"{tag}_e2e_sparse1m.json")))
 t = json.load(open(os.path.join(P, "traffic.json")))["sparse-1m"]
 r, rd = B["sparse1m"]["roofline"], B["dense50k"]["roofline"]
@@ -22,23 +23,34 @@ def row(k, label):
     if c:
         return f"| {label} | {b['value']:.1f} | {b['ms_per_step']:.2f} | {c['value']:.4g} | {b['value']/c['value']:.0f}x |"
     return f"| {label} | {b['value']:.1f} | {b['ms_per_step']:.2f} | not timed | |"
-md = f"""# Round 1 — measurements on one MI355X (gpurun box, ROCm 7.2, hipcc gfx950)
+def spec(k):
+    sp = B[k].get("speculative_assembly")
+    return f"{sp['steps_per_s']:.1f}" if sp else "-"
+def row2(k, label):
+    b = B[k]; c = b.get("cpu_baseline")
+    cpu = f"{c['value']:.4g} | {b['value']/c['value']:.0f}x" if c else "not timed | "
+    return f"| {label} | {b['value']:.1f} | {b['ms_per_step']:.2f} | {spec(k)} | {cpu} |"
+ok = B["sparse1m"]["other_kernels"]
+hc, dc = e2e["host_callback"], e2e["device_callback"]
+md = f"""# Round {int(tag[1:])} -- measurements on one MI355X (gpurun box, ROCm 7.2, hipcc gfx950)
 
 All numbers from `python bench.py` (JSON lines committed next to this file) and
 `rocprofv3 --kernel-trace --stats` of the same command (`{tag}_*_kernel_stats.csv`); collected by
 `tools/collect_round.sh`, copied here by `tools/publish_round.py`, this file by `tools/make_bench_md.py`.
-A "step" = K1+K3+K4+K5+K6+K7+K8 on inputs resident in HBM (refactorise + interpolate).
+A "step" = K1+K3+K4+K5+K6+K7+K8 on inputs resident in HBM (refactorise + interpolate).  The timed loop
+rotates over {B['sparse1m']['inputs']['resident_copies']} resident copies of (x, J) ({B['sparse1m']['inputs']['bytes_per_copy']/1e6:.0f} MB each on sparse-1m): past the 256 MiB
+Infinity Cache.  `value` = every kernel alone on the chip; "speculative" = the same step with JtJ
+assembled beside Jt*x on a second stream, as `dogleg_optimize*` runs once steps need Gauss-Newton.
 
-| workload (BASELINE.json config) | GPU steps/s | ms/step | CPU oracle steps/s (1 thread, same box) | ratio |
-|---|---|---|---|---|
-{row('sparse1m', 'sparse-1m (#4: 1M x 150k, 15M nnz)')}
-{row('sparse200k', 'sparse-200k (#3: 200k x 30k, 3M nnz)')}
-{row('dense50k', 'dense-50k (#2: 50k x 2k; CPU row-sampled, see JSON)')}
-{row('sparse5m', 'sparse-5m (#5: 5M x 500k, 75M nnz, 2 factorisations per step: lambda path)')}
+| workload (BASELINE.json config) | GPU steps/s (`value`) | ms/step | speculative steps/s | CPU oracle steps/s (1 thread, same box) | ratio |
+|---|---|---|---|---|---|
+{row2('sparse1m', 'sparse-1m (#4: 1M x 150k, 15M nnz)')}
+{row2('sparse200k', 'sparse-200k (#3: 200k x 30k, 3M nnz)')}
+{row2('dense50k', 'dense-50k (#2: 50k x 2k; CPU row-sampled, see JSON)')}
+{row2('sparse5m', 'sparse-5m (#5: 5M x 500k, 75M nnz, 2 factorisations per step: lambda path)')}
 
-(The round started at 26 steps/s on sparse-1m; the trajectory is in DESIGN.md section 6.)
-
-Per-phase GPU time (HIP events on the backend stream, ms per step):
+Per-phase GPU time (HIP events on the stream the phase runs on, ms per step; K3 runs on the second
+stream beside K5, so the phases add up to more than the step):
 
 | phase | sparse-1m | sparse-200k | dense-50k |
 |---|---|---|---|
@@ -50,39 +62,35 @@ Per-phase GPU time (HIP events on the backend stream, ms per step):
 | K6 solve (sparse: backward only, forward rides in the factor) | {ph('sparse1m','K6_solve')} | {ph('sparse200k','K6_solve')} | {ph('dense50k','K6_solve')} |
 | K7 step | {ph('sparse1m','K7_step')} | {ph('sparse200k','K7_step')} | {ph('dense50k','K7_step')} |
 
-Roofline of the JtJ assembly kernel:
-* sparse-1m `k_assemble_mfma`: {r['algorithmic_bytes']/1e6:.1f} MB algorithmic / {r['avg_launch_ms']:.3f} ms = **{r['achieved']:.0f} GB/s = {100*r['frac']:.1f} % of 8 TB/s**
-  (target in BASELINE.json: 40 %; the LDS kernel this round started with reached 6.5 %).  Measured HBM
-  traffic {t['bytes_per_launch']/1e6:.0f} MB per launch ({tag}_pmc.md): {t['bytes_per_launch']/r['algorithmic_bytes']:.2f}x the algorithmic bytes -- J is
-  walked twice (once by the point column blocks, once by the camera column blocks that also carry the
-  dense global block), plus the k-group records.
-* dense-50k `k_syrk_lower<64>`: {rd['algorithmic_flops']:.3e} flop / {rd['avg_launch_ms']:.3f} ms = **{rd['achieved']:.1f} TFLOP/s** = {100*rd['frac']:.0f} % of the 78.6
-  TFLOP/s datasheet fp64-matrix peak, 89 % of the 48 TFLOP/s a register-only
-  v_mfma_f64_16x16x4_f64 loop sustains on this box (`tools/gpu_probe.py`, {tag}_probe.txt).
-* sparse `k_norm2_Jv` (K3/K8): 192 MB / 56 us = 3.4 TB/s = 43 % of 8 TB/s; traffic 203 MB (1.06x).
+Rooflines:
+* sparse-1m `k_assemble_mfma` (K4): {r['algorithmic_bytes']/1e6:.1f} MB algorithmic / {r['avg_launch_ms']:.3f} ms = **{r['achieved']:.0f} GB/s = {100*r['frac']:.1f} % of 8 TB/s**
+  (target in BASELINE.json: 40 %).  Counter traffic {t['bytes_per_launch']/1e6:.0f} MB per launch ({tag}_pmc.md): {t['bytes_per_launch']/r['algorithmic_bytes']:.2f}x the
+  algorithmic bytes (J is walked twice).  The kernel is bound by instruction issue around the K = 4 fp64 MFMAs.
+* dense-50k `k_syrk_lower<64>` (K4): {rd['algorithmic_flops']:.3e} flop / {rd['avg_launch_ms']:.3f} ms = **{rd['achieved']:.1f} TFLOP/s** = {100*rd['frac']:.0f} % of the 78.6
+  TFLOP/s datasheet fp64-matrix peak (48 TFLOP/s is what a register-only v_mfma_f64_16x16x4_f64 loop sustains here).
+* sparse-1m `k_norm2_Jv` (K3/K8): {ok['K3K8_norm2_Jv']['algorithmic_bytes']/1e6:.0f} MB / {1e3*ok['K3K8_norm2_Jv']['ms']:.0f} us = {ok['K3K8_norm2_Jv']['GBps']:.0f} GB/s = {100*ok['K3K8_norm2_Jv']['frac_hbm']:.0f} % of HBM (J past the Infinity Cache).
 * K5-sparse and K6-sparse are latency / critical-path bound (SURVEY 8d says to expect low fractions and to
-  say so): sparse-1m K5 = {k5b/1e6:.0f} MB algorithmic (`8 nnz(tril JtJ) + 8 nnz(L)`) and {k5f/1e9:.2f} GFLOP in {k5t:.2f} ms
-  = {k5b/k5t/1e6:.0f} GB/s ({100*k5b/k5t/1e6/8000:.1f} % of HBM), {k5f/k5t/1e9:.2f} TFLOP/s; K6 = {k6b/1e6:.0f} MB (`16 nnz(L) + 32 N`) in {k6t:.2f} ms
-  = {k6b/k6t/1e6:.0f} GB/s ({100*k6b/k6t/1e6/8000:.1f} %).  {nlev} elimination-tree levels, roughly 60-80 us each above the leaves (one factor kernel that also pulls the children's update matrices, one backward-solve kernel).
+  say so): K5 = {k5b/1e6:.0f} MB (`8 nnz(tril JtJ) + 8 nnz(L)`) and {k5f/1e9:.2f} GFLOP in {k5t:.2f} ms = {k5b/k5t/1e6:.0f} GB/s
+  ({100*k5b/k5t/1e6/8000:.1f} % of HBM), {k5f/k5t/1e9:.2f} TFLOP/s ({100*k5f/k5t/1e9/78.6:.1f} % of the fp64 peak); K6 = {k6b/1e6:.0f} MB (`16 nnz(L) + 32 N`) in {k6t:.2f} ms
+  = {k6b/k6t/1e6:.0f} GB/s ({100*k6b/k6t/1e6/8000:.1f} %).  {nlev} elimination-tree levels: nine upper levels of ~50 us (factor) + ~15 us
+  (backward solve) each; per-workgroup phase clocks of a level in DESIGN.md section 6.
 
-rocprofv3 --stats, sparse-1m (20 timed + 3 warm-up steps; ms/step = total/23):
+rocprofv3 --stats, sparse-1m (bench.py default run; ms/step = total / steps issued):
 ```
 {s1}
 ```
-rocprofv3 --stats, dense-50k (10 timed + 1 warm-up; ms/step = total/11):
+rocprofv3 --stats, dense-50k:
 ```
 {d5}
 ```
 
-End to end through `dogleg_optimize2` with the host callback (PCIe-inclusive, `tools/e2e_bench.py`,
-sparse-1m): {e2e['trials']} trials + {e2e['callbacks']} callback evaluations in {e2e['total_s']:.2f} s including the one-off symbolic
-analysis and pinned allocations ({e2e['end_to_end_steps_per_s']:.1f} steps/s; {e2e['steps_per_s_excluding_callback']:.1f} without the host callback time); each
-evaluation moves 128 MB host->device.  This is NOT bench.py's value.
+End to end (`tools/e2e_bench.py`, sparse-1m, {e2e['trials']} trials + {e2e['callbacks']} evaluations; NOT bench.py's value):
+host callback {hc['second_call_s']:.2f} s per solve ({hc['steps_per_s']:.1f} steps/s; callback {1e3*hc['callback_s_each']:.0f} ms per evaluation, {hc['h2d_bytes_per_eval']/1e6:.0f} MB host->device per
+evaluation), **device callback {dc['second_call_s']:.2f} s per solve ({dc['steps_per_s']:.1f} steps/s; no H2D of J, {dc['d2h_bytes_per_trial']/1e6:.1f} MB device->host per trial)**;
+symbolic analysis {e2e['symbolic_analysis_s']:.2f} s of each; final p of the two differs by {e2e['max_abs_p_diff_device_vs_host']:.1e}.
 
-RCCL plumbing check (1 rank, backend nccl, all-reduce hook installed, torch's HIP runtime):
-`{tag}_bench_dist_world1_rccl.log` — same check values as the single-process run.
-
-Probes ({tag}_probe.txt): fp64 MFMA issue rate 48 TFLOP/s; HBM copy 4.88 TB/s (read+write bytes).
+RCCL in-stream path at world size 1 (the library's own communicator, `dlg_backend_init_rccl`):
+`{tag}_bench_dist_world1_rccl.log`.  Probes ({tag}_probe.txt): fp64 MFMA issue rate 48 TFLOP/s; HBM copy 4.9 TB/s.
 """
 open(os.path.join(P, f"{tag}_bench.md"), "w").write(md)
 print(md[:1500])
