@@ -396,21 +396,86 @@ __global__ void __launch_bounds__(64) k_trsv_diag_fwd(const double* __restrict__
   for(int k = 0; k < NB; k++) sacc += Linv[t + k*NB]*v[k];   // Linv is zero above the diagonal
   if(t < nb) y[kb + t] = sacc;
 }
-// y[i] -= sum_{k in block} L[i,k] y[k]  for i >= kb+nb
-__global__ void __launch_bounds__(TPB) k_trsv_update_fwd(const double* __restrict__ A, int lda,
-                                                         int kb, int nb, int n,
-                                                         double* __restrict__ y)
+// forward, fused: y[i] -= sum_k L[i, kb+k] y[kb+k] for the rows below block column kb and -- by workgroup 0, whose
+// rows are the NEXT diagonal block's -- the next block's y = Linv_next * y right behind it: one
+// launch per block column instead of two.  Workgroup 0 covers rows kb+nb .. kb+nb+TPB-1 >= the 64
+// rows of the next block.
+__global__ void __launch_bounds__(TPB) k_trsv_step_fwd(const double* __restrict__ A, int lda,
+                                                       int kb, int nb, int n,
+                                                       const double* __restrict__ Linv_next, int nb_next,
+                                                       double* __restrict__ y)
 {
   __shared__ double v[NB];
+  __shared__ double w[NB];
   if(threadIdx.x < nb) v[threadIdx.x] = y[kb + threadIdx.x];
   __syncthreads();
   const int i = kb + nb + blockIdx.x*TPB + threadIdx.x;
-  if(i >= n) return;
-  double s = 0;
+  double yi = 0.0;
+  if(i < n)
+  {
+    double s = 0;
 #pragma unroll 8
-  for(int k = 0; k < nb; k++) s += A[(size_t)(kb + k)*lda + i]*v[k];
-  y[i] -= s;
+    for(int k = 0; k < nb; k++) s += A[(size_t)(kb + k)*lda + i]*v[k];
+    yi = y[i] - s;
+    if(blockIdx.x > 0 || threadIdx.x >= NB) y[i] = yi;         // the next block's rows are written below, solved
+  }
+  if(blockIdx.x == 0)
+  {
+    if(threadIdx.x < NB) w[threadIdx.x] = (threadIdx.x < nb_next) ? yi : 0.0;
+    __syncthreads();
+    if(threadIdx.x < NB)
+    {
+      const int t = threadIdx.x;
+      double sacc = 0.0;
+#pragma unroll 8
+      for(int k = 0; k < NB; k++) sacc += Linv_next[t + k*NB]*w[k];   // Linv is zero above the diagonal
+      if(t < nb_next) y[kb + nb + t] = sacc;
+    }
+  }
 }
+// backward, fused: x[i] -= sum_k L[kb+k, i] x[kb+k] for the rows i < kb of block column kb, and -- by
+// workgroup 0, which takes the 64 rows of the PREVIOUS diagonal block (thread = (row, quarter of k)) --
+// that block's x = Linv_prev^T * (updated rows) right behind it.  The other workgroups: one wave per row
+// (column i of L is contiguous: a coalesced read, a wave reduction).
+__global__ void __launch_bounds__(TPB) k_trsv_step_bwd(const double* __restrict__ A, int lda, int kb, int nb,
+                                                       const double* __restrict__ Linv_prev,
+                                                       double* __restrict__ y)
+{
+  __shared__ double v[NB];
+  __shared__ double part[4][NB];
+  __shared__ double w[NB];
+  if(threadIdx.x < NB) v[threadIdx.x] = (threadIdx.x < nb) ? y[kb + threadIdx.x] : 0.0;
+  __syncthreads();
+  if(blockIdx.x == 0)
+  {
+    const int r = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int i = kb - NB + r;                     // kb >= NB: the previous block is a full one
+    const double* Ai = A + (size_t)i*lda + kb + 16*g;
+    double s = 0.0;
+#pragma unroll
+    for(int k = 0; k < 16; k++) s += (16*g + k < nb) ? Ai[k]*v[16*g + k] : 0.0;
+    part[g][r] = s;
+    __syncthreads();
+    if(threadIdx.x < NB) w[r] = y[i] - ((part[0][r] + part[1][r]) + (part[2][r] + part[3][r]));
+    __syncthreads();
+    if(threadIdx.x < NB)
+    {
+      const double* Lc = Linv_prev + (size_t)r*NB;     // (Linv^T)[r][k] = Linv[k][r] = Linv[k + r*NB]
+      double sacc = 0.0;
+#pragma unroll 8
+      for(int k = r; k < NB; k++) sacc += Lc[k]*w[k];
+      y[i] = sacc;
+    }
+    return;
+  }
+  const int lane = threadIdx.x & 63;
+  const int i = (blockIdx.x - 1)*4 + (threadIdx.x >> 6);
+  if(i >= kb - NB) return;
+  double s = (lane < nb) ? A[(size_t)i*lda + kb + lane]*v[lane] : 0.0;
+  s = wave_sum(s);
+  if(lane == 0) y[i] -= s;
+}
+
 // backward, diagonal block: x_blk = Linv^T * y_blk
 __global__ void __launch_bounds__(64) k_trsv_diag_bwd(const double* __restrict__ Linv, int kb, int nb,
                                                       double* __restrict__ y)
@@ -426,21 +491,6 @@ __global__ void __launch_bounds__(64) k_trsv_diag_bwd(const double* __restrict__
   for(int k = 0; k < NB; k++) sacc += Ls[k][t]*v[k];          // (Linv^T)[t][k] = Linv[k][t]
   if(t < nb) y[kb + t] = sacc;
 }
-// x[i] -= sum_{k in block} L[k,i] x[k]  for i < kb   (one wave per i; column i is contiguous)
-__global__ void __launch_bounds__(TPB) k_trsv_update_bwd(const double* __restrict__ A, int lda,
-                                                         int kb, int nb, double* __restrict__ y)
-{
-  __shared__ double v[NB];
-  if(threadIdx.x < nb) v[threadIdx.x] = y[kb + threadIdx.x];
-  __syncthreads();
-  const int lane = threadIdx.x & 63;
-  const int i = blockIdx.x*4 + (threadIdx.x >> 6);
-  if(i >= kb) return;
-  double s = (lane < nb) ? A[(size_t)i*lda + kb + lane]*v[lane] : 0.0;
-  s = wave_sum(s);
-  if(lane == 0) y[i] -= s;
-}
-
 // ---- blocked multi-right-hand-side triangular solves (dpptrs / dpotrs with nrhs > 1:
 // reference pseudoinverse_J_dense, dogleg.c:1831-1855).  MR = 16 right-hand sides interleaved
 // [n][MR]; per 64-column block of the factor: the diagonal block is a product with its stored
@@ -844,24 +894,28 @@ int dense_solve(dlg_backend* b, const double* rhs, double* out)
 {
   const int n = b->N;
   if(out != rhs) DLG_HIP(hipMemcpyAsync(out, rhs, sizeof(double)*(size_t)n, hipMemcpyDeviceToDevice, b->stream));
+  // forward: the first diagonal block, then one fused launch per block column (update + next diagonal block)
+  hipLaunchKernelGGL(k_trsv_diag_fwd, dim3(1), dim3(64), 0, b->stream, b->Linv, 0, (n < NB) ? n : NB, out);
   for(int kb = 0, blk = 0; kb < n; kb += NB, blk++)
   {
     const int nb = (n - kb < NB) ? n - kb : NB;
-    hipLaunchKernelGGL(k_trsv_diag_fwd, dim3(1), dim3(64), 0, b->stream, b->Linv + (size_t)blk*NB*NB, kb, nb, out);
     const int rem = n - kb - nb;
     if(rem > 0)
-      hipLaunchKernelGGL(k_trsv_update_fwd, dim3(dlg_cdiv(rem, TPB)), dim3(TPB), 0, b->stream, b->G, n,
-                         kb, nb, n, out);
+      hipLaunchKernelGGL(k_trsv_step_fwd, dim3(dlg_cdiv(rem, TPB)), dim3(TPB), 0, b->stream, b->G, n,
+                         kb, nb, n, b->Linv + (size_t)(blk + 1)*NB*NB, (rem < NB) ? rem : NB, out);
   }
   const int nblk = dlg_cdiv(n, NB);
-  for(int blk = nblk - 1; blk >= 0; blk--)
+  // backward: the last diagonal block, then one fused launch per block column (update + previous diagonal block)
+  {
+    const int kb = (nblk - 1)*NB;
+    hipLaunchKernelGGL(k_trsv_diag_bwd, dim3(1), dim3(64), 0, b->stream, b->Linv + (size_t)(nblk - 1)*NB*NB, kb, n - kb, out);
+  }
+  for(int blk = nblk - 1; blk >= 1; blk--)
   {
     const int kb = blk*NB;
     const int nb = (n - kb < NB) ? n - kb : NB;
-    hipLaunchKernelGGL(k_trsv_diag_bwd, dim3(1), dim3(64), 0, b->stream, b->Linv + (size_t)blk*NB*NB, kb, nb, out);
-    if(kb > 0)
-      hipLaunchKernelGGL(k_trsv_update_bwd, dim3(dlg_cdiv(kb, 4)), dim3(TPB), 0, b->stream, b->G, n, kb,
-                         nb, out);
+    hipLaunchKernelGGL(k_trsv_step_bwd, dim3(1 + dlg_cdiv(kb - NB, 4)), dim3(TPB), 0, b->stream, b->G, n, kb, nb,
+                       b->Linv + (size_t)(blk - 1)*NB*NB, out);
   }
   DLG_LAUNCH_CHECK();
   return DLG_OK;
