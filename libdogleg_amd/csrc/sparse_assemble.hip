@@ -521,11 +521,10 @@ __global__ void __launch_bounds__(TPB) k_add_lambda(double* __restrict__ Lx,
 }
 
 // augmented row: panel(last row, column k) += rhs[perm[k]]   (the row is zero after the assembly;
-// above the cut of a subtree partition it already carries the updates from below)
+// above the cut of a subtree partition it already carries the updates from below).  augpos[k] = the
+// entry's offset in Lx (precomputed: one dependent load instead of five)
 __global__ void __launch_bounds__(TPB) k_set_aug_row(double* __restrict__ Lx, const int* __restrict__ col_sn,
-                                                     const int* __restrict__ sn_c0,
-                                                     const int* __restrict__ sn_rowptr,
-                                                     const int64_t* __restrict__ sn_lx,
+                                                     const int64_t* __restrict__ augpos,
                                                      const int* __restrict__ perm,
                                                      const double* __restrict__ rhs, int n,
                                                      int* __restrict__ info,
@@ -534,10 +533,8 @@ __global__ void __launch_bounds__(TPB) k_set_aug_row(double* __restrict__ Lx, co
   const int k = blockIdx.x*TPB + threadIdx.x;
   if(k == 0 && phase <= 0) *info = 0x7fffffff;          // re-arm the pivot flag of the factorisation that follows
   if(k >= n) return;
-  const int s = col_sn[k];
-  if(!phase_has(sn_owner, s, phase)) return;
-  const int nrows = sn_rowptr[s+1] - sn_rowptr[s];
-  Lx[sn_lx[s] + (nrows - 1) + (int64_t)(k - sn_c0[s])*nrows] += rhs[perm[k]];
+  if(phase >= 0 && !phase_has(sn_owner, col_sn[k], phase)) return;
+  Lx[augpos[k]] += rhs[perm[k]];
 }
 
 // ------------------------------------------------------------------ K1 ------
@@ -858,8 +855,8 @@ int sparse_assemble(dlg_backend* b, int s, double lambda)
   Y->info_armed = false;
   if(S.have_Jtx)
   {
-    hipLaunchKernelGGL(k_set_aug_row, dim3(dlg_cdiv(H.N, TPB)), dim3(TPB), 0, st, Y->Lx, Y->col_sn, Y->sn_c0,
-                       Y->sn_rowptr, Y->sn_lx, Y->perm, S.Jt_x, H.N, Y->d_info, Y->sn_owner, phase);
+    hipLaunchKernelGGL(k_set_aug_row, dim3(dlg_cdiv(H.N, TPB)), dim3(TPB), 0, st, Y->Lx, Y->col_sn, Y->augpos,
+                       Y->perm, S.Jt_x, H.N, Y->d_info, Y->sn_owner, phase);
     Y->aug_rhs = S.Jt_x;
     Y->info_armed = true;
   }
@@ -920,8 +917,8 @@ int sparse_partition_reduce(dlg_backend* b)
     hipLaunchKernelGGL(k_add_lambda, dim3(dlg_cdiv(H.N, TPB)), dim3(TPB), 0, st, Y->Lx, Y->diagpos, H.N,
                        Y->cur_lambda, Y->col_sn, Y->sn_owner, 1);
   if(Y->aug_rhs)
-    hipLaunchKernelGGL(k_set_aug_row, dim3(dlg_cdiv(H.N, TPB)), dim3(TPB), 0, st, Y->Lx, Y->col_sn, Y->sn_c0,
-                       Y->sn_rowptr, Y->sn_lx, Y->perm, Y->aug_rhs, H.N, Y->d_info, Y->sn_owner, 1);
+    hipLaunchKernelGGL(k_set_aug_row, dim3(dlg_cdiv(H.N, TPB)), dim3(TPB), 0, st, Y->Lx, Y->col_sn, Y->augpos,
+                       Y->perm, Y->aug_rhs, H.N, Y->d_info, Y->sn_owner, 1);
   DLG_LAUNCH_CHECK();
   return DLG_OK;
 }

@@ -52,6 +52,16 @@ int sparse_set_pattern(dlg_backend* b, const int* colptr, const int* rowidx)
   UP(asm_shape); UP(asm_kg); UP(asm_mtask); UP(asm_tdest); UP(asm_fin2); UP(asm_fin2_list); UP(asm_run); UP(asm_pdest);
   UP(rl_ptr); UP(rl_pos); UP(perm); UP(col_sn); UP(sn_owner); UP(xl_sn); UP(fw_sn); UP(fw_r0); UP(fw_r1); UP(ms_sn); UP(sn_top); UP(sn_bd_ptr); UP(sn_bd_col);
   {
+    std::vector<int64_t> ap((size_t)H.N);
+    for(int k = 0; k < H.N; k++)
+    {
+      const int s2 = H.col_sn[k];
+      const int64_t nrows = H.sn_rowptr[s2+1] - H.sn_rowptr[s2];
+      ap[k] = H.sn_lx[s2] + (nrows - 1) + (int64_t)(k - H.sn_c0[s2])*nrows;
+    }
+    DLG_CHECK(upload(Y->augpos, ap)); Y->allocs.push_back(Y->augpos);
+  }
+  {
     // Jt*x partial lists: the few long ones (a dense block that every row touches) get a big workgroup each
     std::vector<int> fs, fl;
     for(int f = 0; f + 1 < (int)H.jtx_fin_ptr.size(); f++)

@@ -106,6 +106,7 @@ struct SparseSym
   int64_t* red_off = nullptr; int* red_len = nullptr; int* red_kind = nullptr; int64_t* red_dst = nullptr;
   int n_red_seg = 0; size_t red_n = 0; double* red_buf = nullptr;
   double* colmask = nullptr; int* sn_owner = nullptr;
+  int64_t* augpos = nullptr;            // Lx offset of the augmented-row entry of every column
   int *xl_sn = nullptr;
   double cur_lambda = 0.0;              // of the factorisation being enqueued (the top panels get it after the sum)
   double *ms_scr = nullptr, *ms_y = nullptr; int ms_lds_f = 0, ms_lds_b = 0;     // multi-right-hand-side solves (sparse_multi.hip)
