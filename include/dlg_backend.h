@@ -123,6 +123,12 @@ int  dlg_sparse_set_pattern(dlg_backend_t* b, const int* colptr, const int* rowi
 int  dlg_sparse_stats(dlg_backend_t* b, long* nnz_JtJ_lower, long* nnz_L,
                       int* n_supernodes, int* n_levels, double* factor_flops);
 
+/* launch schedule of the factorisation: the number of levels of the supernodal
+ * elimination tree; the first level of the persistent top region (all levels from
+ * there on are ONE launch whose workgroups hand their update matrices to their
+ * parents through flags) or -1 if there is none; the workgroups of that launch */
+int  dlg_sparse_schedule(dlg_backend_t* b, int* n_levels, int* persist_level0, int* persist_items);
+
 /* host-only symbolic phase on a pattern (no GPU): stats[] = {var-blocks,
  * supernodes, levels, nnz(tril JtJ), nnz(L), panel doubles, factor flops, max
  * panel, assembly tasks, update items, relpos entries, output blocks,

@@ -25,7 +25,7 @@ ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_size_t, C.c_void_p)
 BACKEND_SYMBOLS = [
     "dlg_last_error", "dlg_device_count", "dlg_backend_create", "dlg_backend_destroy",
     "dlg_backend_set_stream", "dlg_backend_get_stream", "dlg_backend_set_shard",
-    "dlg_sparse_set_pattern", "dlg_sparse_stats", "dlg_point_set_p", "dlg_point_upload",
+    "dlg_sparse_set_pattern", "dlg_sparse_stats", "dlg_sparse_schedule", "dlg_point_set_p", "dlg_point_upload",
     "dlg_point_upload_products", "dlg_point_bind_device", "dlg_point_eval", "dlg_cauchy",
     "dlg_factorize", "dlg_solve_gn", "dlg_gauss_newton", "dlg_cauchy_gauss_newton", "dlg_make_step",
     "dlg_expected_improvement", "dlg_step", "dlg_take_step", "dlg_solve_with_factor",
@@ -88,6 +88,7 @@ def lib():
     L.dlg_backend_comm_size.argtypes = [V, I]
     L.dlg_sparse_set_pattern.argtypes = [V, I, I]
     L.dlg_sparse_stats.argtypes = [V, C.POINTER(C.c_long), C.POINTER(C.c_long), I, I, D]
+    L.dlg_sparse_schedule.argtypes = [V, I, I, I]
     L.dlg_point_set_p.argtypes = [V, C.c_int, D]
     L.dlg_point_upload.argtypes = [V, C.c_int, D, D]
     L.dlg_point_upload_products.argtypes = [V, C.c_int, C.c_double, D, D]
@@ -386,6 +387,11 @@ class Backend:
             "stats")
         return dict(nnz_JtJ_lower=a.value, nnz_L=b.value, n_supernodes=c.value, n_levels=d.value,
                     factor_flops=e.value)
+
+    def schedule(self):
+        a, b, c = C.c_int(), C.c_int(), C.c_int()
+        _ck(self.L.dlg_sparse_schedule(self.h, C.byref(a), C.byref(b), C.byref(c)), "schedule")
+        return dict(n_levels=a.value, persist_level0=b.value, persist_items=c.value)
 
     def set_p(self, slot, p):
         p = np.ascontiguousarray(p, dtype=np.float64)

@@ -6,11 +6,12 @@
 
 namespace {
 typedef double dlg_v4d __attribute__((ext_vector_type(4)));
+typedef double dlg_v2d __attribute__((ext_vector_type(2)));
 // -DDLG_FL_PROFILE: phase clocks of workgroup 0 of every factor launch (tools only)
 #ifdef DLG_FL_PROFILE
 constexpr int FL_PROF_WG = 256;       // workgroups per level whose phase clocks are kept
 __device__ long long g_fl_prof[32*FL_PROF_WG*8];
-#define FL_STAMP(k) do { if(threadIdx.x == 0 && blockIdx.x < FL_PROF_WG) g_fl_prof[((prof_lvl & 31)*FL_PROF_WG + blockIdx.x)*8 + (k)] = clock64(); } while(0)
+#define FL_STAMP(k) do { if(threadIdx.x == 0 && blockIdx.x < FL_PROF_WG) g_fl_prof[((prof_lvl & 31)*FL_PROF_WG + blockIdx.x)*8 + (k)] = wall_clock64(); } while(0)      // 100 MHz, one clock for the chip
 #else
 #define FL_STAMP(k)
 #endif
@@ -31,7 +32,7 @@ __device__ __forceinline__ int tri_col(int j, int mb) { return j*mb - j*(j - 1)/
 // microseconds up here -- all loads of a batch (MF_SLOTS entries per thread) are issued
 // together.  One child at a time: inside a child no two entries share a destination, so the
 // sums are in child order.
-template <int NT, bool UT_LDS>
+template <int NT, bool UT_LDS, bool HANDOFF = false>
 __device__ __forceinline__ void mf_add_children(double* P, double* Wt, int ntri, int nch, int ch0,
                                                 MfChild rc, const MfChild* __restrict__ mf_rec,
                                                 const double* uscr, const uint16_t* __restrict__ mf_dst, int tid)
@@ -56,7 +57,15 @@ __device__ __forceinline__ void mf_add_children(double* P, double* Wt, int ntri,
       unsigned d[MF_SLOTS];
 #pragma unroll
       for(int u = 0; u < MF_SLOTS; u++)
-        if(e0 + u*NT < npad) { v[u] = Wc[e0 + u*NT]; d[u] = D[e0 + u*NT]; }
+        if(e0 + u*NT < npad)
+        {
+          // persistent top region: the child wrote these bytes in this launch (write-through stores,
+          // see k_factor_level) -- read them around this CU's L1
+          // (a global_ load: the hand-off is not measured for flat_ ones)
+          typedef const __attribute__((address_space(1))) double* gptr_t;
+          v[u] = HANDOFF ? __hip_atomic_load((gptr_t)(Wc + e0 + u*NT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : Wc[e0 + u*NT];
+          d[u] = D[e0 + u*NT];
+        }
       if(UT_LDS)
       {
 #pragma unroll
@@ -95,7 +104,8 @@ __device__ __forceinline__ void mf_add_children(double* P, double* Wt, int ntri,
 // during the products of the other.  mode 2: the multifrontal region keeps W = (children) - U.
 template <int NCH>
 __device__ __forceinline__ void factor_tail_tiles(const double* Pb, int ldp, int w, int mb, int T, int first,
-                                                  double* Ud, int mode, bool w_hbm, bool mf_acc, int lane)
+                                                  double* Ud, int mode, bool w_hbm, bool mf_acc, int lane,
+                                                  int64_t acc_shift, bool st_wt)
 {
   const int jn = lane & 15, kq = lane >> 4;
   int ti[NCH], tjq[NCH], oa[NCH], ob[NCH];
@@ -127,7 +137,7 @@ __device__ __forceinline__ void factor_tail_tiles(const double* Pb, int ldp, int
       for(int r = 0; r < 4; r++)
       {
         const int i = 16*ti[q] + kq + 4*r;
-        w0[q][r] = (i < mb && j <= i) ? __hip_atomic_load(Ud + jt0 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+        w0[q][r] = (i < mb && j <= i) ? __hip_atomic_load(Ud + acc_shift + jt0 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
       }
     }
   }
@@ -194,7 +204,15 @@ __device__ __forceinline__ void factor_tail_tiles(const double* Pb, int ldp, int
       const int i = 16*ti[q] + kq + 4*r;
       if(i < mb && j <= i)
       {
-        if(mode == 2) Ud[jtri + i] = (w_hbm ? w0[q][r] : (mf_acc ? Ud[jtri + i] : 0.0)) - c4[q][r];     // the region keeps W = -U
+        if(st_wt)
+        {
+          // persistent top region, update matrix not staged in LDS: the parent reads it in this launch --
+          // write-through stores into a slot no plain store or atomic ever touches (the children's
+          // sums were formed in the shadow slot at acc_shift)
+          typedef __attribute__((address_space(1))) double* gwptr_t;
+          __hip_atomic_store((gwptr_t)(Ud + jtri + i), (w_hbm ? w0[q][r] : 0.0) - c4[q][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        else if(mode == 2) Ud[jtri + i] = (w_hbm ? w0[q][r] : (mf_acc ? Ud[jtri + i] : 0.0)) - c4[q][r];     // the region keeps W = -U
         else Ud[jtri + i] = c4[q][r];
       }
     }
@@ -226,7 +244,8 @@ __global__ void __launch_bounds__(NT) k_factor_level(const FwItem* __restrict__ 
                                                      double* __restrict__ Lx,
                                                      double* __restrict__ top_scr,
                                                      int* __restrict__ info,
-                                                     double* uscr, int mode)
+                                                     double* uscr, int mode,
+                                                     int* pr_flag, int pr_epoch, int pr_item0, int64_t pr_acc)
 {
   extern __shared__ __attribute__((aligned(16))) double P[];
   __shared__ int sbad;
@@ -285,12 +304,32 @@ __global__ void __launch_bounds__(NT) k_factor_level(const FwItem* __restrict__ 
       for(int u = 0; u < CP_FLIGHT; u++) if(j0 + u*cp_ng < w) Pb[i + (j0 + u*cp_ng)*ldp] = v[u];
     }
   }
+  if(pr_flag && mf_acc && tid < 64)
+  {
+    // persistent top region (one launch for all its levels, workgroups in level order): the panel
+    // is in LDS already; wave 0 waits for the flags of the children that are part of this launch
+    // (the others finished with the launch before), the barrier below holds the other waves
+    for(int k = lane; k < it.nch; k += 64)
+    {
+      const int ci = (k < 64) ? rc.rsv : mf_rec[it.ch0 + k].rsv;
+      if(ci < pr_item0) continue;
+      int spins = 0;
+      while(__hip_atomic_load(pr_flag + ci, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != pr_epoch)
+      {
+        __builtin_amdgcn_s_sleep(1);
+        if(++spins > (1 << 21)) { atomicMin(info, 0); break; }      // a child that never arrives: report, do not hang
+      }
+    }
+    FL_STAMP(7);
+  }
   __syncthreads();
   FL_STAMP(1);
   if(mf_acc)
   {
-    if(u_lds) mf_add_children<NT, true >(P, Us, ntri, it.nch, it.ch0, rc, mf_rec, uscr, mf_dst, tid);
-    else      mf_add_children<NT, false>(P, Ug, ntri, it.nch, it.ch0, rc, mf_rec, uscr, mf_dst, tid);
+    if(pr_flag && u_lds) mf_add_children<NT, true, true>(P, Us, ntri, it.nch, it.ch0, rc, mf_rec, uscr, mf_dst, tid);
+    else if(pr_flag)     mf_add_children<NT, false, true>(P, Ug + pr_acc, ntri, it.nch, it.ch0, rc, mf_rec, uscr, mf_dst, tid);
+    else if(u_lds)  mf_add_children<NT, true >(P, Us, ntri, it.nch, it.ch0, rc, mf_rec, uscr, mf_dst, tid);
+    else            mf_add_children<NT, false>(P, Ug, ntri, it.nch, it.ch0, rc, mf_rec, uscr, mf_dst, tid);
   }
   FL_STAMP(2);
   if(cmp) bd_compact_rows<NT>(Pb, ldp, nloc, w, tid, it.nbd, s_mcol, s_rdiag, Dg);
@@ -315,24 +354,42 @@ __global__ void __launch_bounds__(NT) k_factor_level(const FwItem* __restrict__ 
     const int ntiles = T*(T + 1)/2;
     const int rounds = (ntiles + NWV*SY_G - 1)/(NWV*SY_G), nchunks = rounds*NWV;
     const bool w_hbm = mf_acc && !u_lds;
+    const bool st_wt = pr_flag != nullptr && !u_lds;
+    const int64_t acc_shift = st_wt ? pr_acc : 0;
     for(int c = wv; c < nchunks; c += NWV)
     {
       const int t0 = (int)((long)c*ntiles/nchunks), t1 = (int)((long)(c + 1)*ntiles/nchunks);
       switch(t1 - t0)
       {
-        case 1: factor_tail_tiles<1>(Pb, ldp, w, mb, T, t0, Ud, mode, w_hbm, mf_acc, lane); break;
-        case 2: factor_tail_tiles<2>(Pb, ldp, w, mb, T, t0, Ud, mode, w_hbm, mf_acc, lane); break;
-        case 3: factor_tail_tiles<3>(Pb, ldp, w, mb, T, t0, Ud, mode, w_hbm, mf_acc, lane); break;
-        case 4: factor_tail_tiles<4>(Pb, ldp, w, mb, T, t0, Ud, mode, w_hbm, mf_acc, lane); break;
-        case 5: if(SY_G >= 5) factor_tail_tiles<(SY_G >= 5 ? 5 : 1)>(Pb, ldp, w, mb, T, t0, Ud, mode, w_hbm, mf_acc, lane); break;
-        case 6: if(SY_G >= 6) factor_tail_tiles<(SY_G >= 6 ? 6 : 1)>(Pb, ldp, w, mb, T, t0, Ud, mode, w_hbm, mf_acc, lane); break;
+        case 1: factor_tail_tiles<1>(Pb, ldp, w, mb, T, t0, Ud, mode, w_hbm, mf_acc, lane, acc_shift, st_wt); break;
+        case 2: factor_tail_tiles<2>(Pb, ldp, w, mb, T, t0, Ud, mode, w_hbm, mf_acc, lane, acc_shift, st_wt); break;
+        case 3: factor_tail_tiles<3>(Pb, ldp, w, mb, T, t0, Ud, mode, w_hbm, mf_acc, lane, acc_shift, st_wt); break;
+        case 4: factor_tail_tiles<4>(Pb, ldp, w, mb, T, t0, Ud, mode, w_hbm, mf_acc, lane, acc_shift, st_wt); break;
+        case 5: if(SY_G >= 5) factor_tail_tiles<(SY_G >= 5 ? 5 : 1)>(Pb, ldp, w, mb, T, t0, Ud, mode, w_hbm, mf_acc, lane, acc_shift, st_wt); break;
+        case 6: if(SY_G >= 6) factor_tail_tiles<(SY_G >= 6 ? 6 : 1)>(Pb, ldp, w, mb, T, t0, Ud, mode, w_hbm, mf_acc, lane, acc_shift, st_wt); break;
         default: break;
       }
     }
     if(u_lds) __syncthreads();
   }
   FL_STAMP(4);
-  if(u_lds) for(int e = tid; e < ntri; e += NT) Ug[e] = Us[e];
+  if(u_lds && pr_flag)
+  {
+    // the parent reads W in this same launch: 16-byte write-through stores (the slots are 16-byte
+    // aligned and padded to an even length), drained by every wave before the flag goes up
+    for(int e = 2*tid; e < ntri; e += 2*NT)
+    {
+      const dlg_v2d v2 = *reinterpret_cast<const dlg_v2d*>(Us + e);
+      asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(Ug + e), "v"(v2) : "memory");
+    }
+  }
+  else if(u_lds) for(int e = tid; e < ntri; e += NT) Ug[e] = Us[e];
+  if(pr_flag)
+  {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if(tid == 0) __hip_atomic_store(pr_flag + pr_item0 + blockIdx.x, pr_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
   for(int i = row0c + tid - cp_g*cp_rows; i < nloc && cp_g < cp_ng; i += cp_rows)
   {
     // rows below the top block go back to the panel; the top block too unless the supernode is
@@ -975,6 +1032,71 @@ int sparse_factor_setup(dlg_backend* b)
       Y->fac_lds[l] = (int)(Y->fac_stage[l] ? std::max(base, leaves) : base);
     }
   }
+  // Persistent top region: the last levels of the multifrontal region hold a few supernodes each and
+  // every one of them waits for the one before -- each kernel boundary costs the launch gap, a cold
+  // panel load and the store of the panel before the next level may start.  They go out as ONE
+  // launch, workgroups in level order (a workgroup only ever waits for lower-numbered ones, so
+  // in-order dispatch cannot deadlock): a workgroup stages its panel at once, waits for its
+  // children's flags, and raises its own flag as soon as its update matrix is out -- before its
+  // panel goes back to HBM.  Conditions: unsliced supernodes, update matrices staged in LDS (their
+  // hand-off is the write-through store of that LDS copy), one block size, no update units, above
+  // the cut of a subtree partition.
+  Y->pr_level0 = H.nlevels;
+  if(!getenv("DOGLEG_AMD_NO_PERSIST") && H.nlevels >= 2)
+  {
+    // (a workgroup of the region fills a CU; more of them than CUs would only queue behind waiting ones)
+    int ncu = 256;
+    { int dev = 0; if(hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev); }
+    const int cap = env_int_host("DOGLEG_AMD_PERSIST_MAX", ncu);
+    int total = 0, l0 = H.nlevels, lds = 0, stage = 1;
+    bool acc = false;
+    const int nt = Y->fac_nt[H.nlevels - 1];
+    const bool dbg = getenv("DOGLEG_AMD_TIMING") != nullptr;
+    for(int l = H.nlevels - 1; l >= 1; l--)
+    {
+      const int n = H.fw_lvl_ptr[l+1] - H.fw_lvl_ptr[l];
+      if(l < H.mf_level0 || (H.part_nranks > 1 && l <= H.cut_level)) break;
+      if(n == 0 || total + n > cap || Y->fac_nt[l] != nt || Y->fac_lds[l] <= 0) break;
+      if(H.uw_lvl_ptr[l+1] > H.uw_lvl_ptr[l] || H.uf_lvl_ptr[l+1] > H.uf_lvl_ptr[l]) break;
+      bool ok = true;
+      for(int i = H.fw_lvl_ptr[l]; i < H.fw_lvl_ptr[l+1] && ok; i++)
+      {
+        const FwItem& it = H.fw_item[i];
+        if(it.top >= 0 || it.r0 != 0 || it.nbd > 0) ok = false;
+      }
+      if(!ok) break;
+      stage = stage && Y->fac_stage[l]; total += n; l0 = l; lds = std::max(lds, Y->fac_lds[l]);
+    }
+    if(H.nlevels - l0 >= 2)
+    {
+      Y->pr_level0 = l0; Y->pr_lds = lds; Y->pr_stage = stage;
+      for(int i = H.fw_lvl_ptr[l0]; i < H.fw_lvl_ptr[H.nlevels]; i++)
+      {
+        // the kernel's rule for staging the update matrix behind the panel
+        const FwItem& it = H.fw_item[i];
+        const long nloc = it.w + (it.r1 - it.r0), mb = nloc - it.w, ldp = (nloc + 1) & ~1L, ntri = mb*(mb + 1)/2;
+        const bool fits = (size_t)(ldp*it.w + ntri + 1)*sizeof(double) <= (size_t)FAC_LDS_BUDGET;
+        if(mb > 0 && it.nch > 0 && !fits) acc = true;
+      }
+    }
+    if(dbg)
+      fprintf(stderr, "libdogleg_amd: persistent top region: levels %d..%d of %d (%d workgroups, %d bytes of LDS, multifrontal from level %d)\n",
+              l0, H.nlevels - 1, H.nlevels, total, lds, H.mf_level0);
+    // update matrices of the region that do not fit LDS are summed (atomics) in a shadow of the scratch,
+    // so that the slot the parent reads only ever sees write-through stores
+    if(acc && !Y->pr_acc)
+    {
+      DLG_HIP(hipMalloc(&Y->pr_acc, sizeof(double)*(size_t)std::max<int64_t>(1, H.uscr_size)));
+      Y->allocs.push_back(Y->pr_acc);
+    }
+  }
+  if(Y->pr_level0 < H.nlevels && !Y->fac_flag)
+  {
+    DLG_HIP(hipMalloc(&Y->fac_flag, sizeof(int)*std::max<size_t>(1, H.fw_item.size())));
+    Y->allocs.push_back(Y->fac_flag);
+    DLG_HIP(hipMemsetAsync(Y->fac_flag, 0, sizeof(int)*std::max<size_t>(1, H.fw_item.size()), b->stream));
+    Y->fac_epoch = 0;
+  }
   DLG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_factor_level<128>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, FAC_LDS_BUDGET));
   DLG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_factor_level<256>),
@@ -1014,6 +1136,15 @@ extern "C" void dlg_fl_profile_dump(int nlevels)
       for(int k = 0; k < 5; k++) mean[k] += (double)(q[k+1] - q[k]);
     }
     if(nwg == 0) continue;
+    // a persistent launch: the timeline of its last workgroups (the top of the tree), 10 ns units
+    for(int g = FL_PROF_WG - 1, shown = 0; g >= 0 && shown < (getenv("DLG_FL_DUMP_ALL") ? 256 : 20); g--)
+    {
+      const long long* q = &h[(l*FL_PROF_WG + g)*8];
+      if(q[5] == 0 || q[7] == 0) continue;
+      shown++;
+      fprintf(stderr, "   wg %3d (w %3lld rows %4lld nch %lld u_lds %lld): start %6lld children there %6lld panel in %6lld added %6lld factored %6lld tail %6lld flag+stored %6lld\n",
+              g, q[6] & 4095, (q[6] >> 12) & 4095, (q[6] >> 24) & 4095, (q[6] >> 36) & 1, q[0] - t0, q[7] - t0, q[1] - t0, q[2] - t0, q[3] - t0, q[4] - t0, q[5] - t0);
+    }
     const long long* q = &h[(l*FL_PROF_WG + last)*8];
     fprintf(stderr, "level %2d: %3d wg, span %7lld | last wg %3d (w %3lld rows %4lld slice %4lld nch %2lld u_lds %lld has_u %lld): start +%6lld load %6lld add %6lld factor %6lld tail %6lld store %6lld | mean: load %6.0f add %6.0f factor %6.0f tail %6.0f store %6.0f\n",
             l, nwg, tend - t0, last, q[6] & 4095, (q[6] >> 12) & 4095, (q[6] >> 40) & 4095, (q[6] >> 24) & 4095, (q[6] >> 36) & 1, (q[6] >> 37) & 1,
@@ -1037,6 +1168,24 @@ int sparse_factor_levels(dlg_backend* b)
     // from the first level that cannot fill the chip on, the factorisation is latency-bound:
     // independent work (the Cauchy step's pass over J) may run beside it
     if(l > 0 && n < 256) dlg_fork_point(b);
+    if(l == Y->pr_level0)
+    {
+      // the persistent top region: every remaining level in one launch (sparse_factor_setup)
+      const int o = H.fw_lvl_ptr[l], np = H.fw_lvl_ptr[H.nlevels] - o;
+      const int fmode = 2 + 4*Y->pr_stage + (Y->fac_ahead ? 8 : 0) + 256*l;
+      int* fl = Y->fac_flag; const int ep = ++Y->fac_epoch;
+      const int64_t pacc = Y->pr_acc ? (int64_t)(Y->pr_acc - Y->uscr) : 0;
+      if(Y->fac_nt[l] == 128)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_factor_level<128>), dim3(np), dim3(128), Y->pr_lds, st,
+                           Y->fw_item + o, Y->mf_rec, Y->sn_bd_col, Y->mf_dst, Y->Lx, Y->top_scr, Y->d_info, Y->uscr, fmode, fl, ep, o, pacc);
+      else if(Y->fac_nt[l] == 256)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_factor_level<256>), dim3(np), dim3(256), Y->pr_lds, st,
+                           Y->fw_item + o, Y->mf_rec, Y->sn_bd_col, Y->mf_dst, Y->Lx, Y->top_scr, Y->d_info, Y->uscr, fmode, fl, ep, o, pacc);
+      else
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_factor_level<512>), dim3(np), dim3(512), Y->pr_lds, st,
+                           Y->fw_item + o, Y->mf_rec, Y->sn_bd_col, Y->mf_dst, Y->Lx, Y->top_scr, Y->d_info, Y->uscr, fmode, fl, ep, o, pacc);
+      break;
+    }
     if(n > 0)
     {
       const int o = H.fw_lvl_ptr[l];
@@ -1044,13 +1193,13 @@ int sparse_factor_levels(dlg_backend* b)
       const int fmode = ((l >= H.mf_level0) ? 2 : Y->syrk_fused[l]) + 4*Y->fac_stage[l] + use_ahead + 256*l;
       if(Y->fac_nt[l] == 128)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_factor_level<128>), dim3(n), dim3(128), Y->fac_lds[l], st,
-                           Y->fw_item + o, Y->mf_rec, Y->sn_bd_col, Y->mf_dst, Y->Lx, Y->top_scr, Y->d_info, Y->uscr, fmode);
+                           Y->fw_item + o, Y->mf_rec, Y->sn_bd_col, Y->mf_dst, Y->Lx, Y->top_scr, Y->d_info, Y->uscr, fmode, (int*)nullptr, 0, 0, (int64_t)0);
       else if(Y->fac_nt[l] == 256)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_factor_level<256>), dim3(n), dim3(256), Y->fac_lds[l], st,
-                           Y->fw_item + o, Y->mf_rec, Y->sn_bd_col, Y->mf_dst, Y->Lx, Y->top_scr, Y->d_info, Y->uscr, fmode);
+                           Y->fw_item + o, Y->mf_rec, Y->sn_bd_col, Y->mf_dst, Y->Lx, Y->top_scr, Y->d_info, Y->uscr, fmode, (int*)nullptr, 0, 0, (int64_t)0);
       else
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_factor_level<512>), dim3(n), dim3(512), Y->fac_lds[l], st,
-                           Y->fw_item + o, Y->mf_rec, Y->sn_bd_col, Y->mf_dst, Y->Lx, Y->top_scr, Y->d_info, Y->uscr, fmode);
+                           Y->fw_item + o, Y->mf_rec, Y->sn_bd_col, Y->mf_dst, Y->Lx, Y->top_scr, Y->d_info, Y->uscr, fmode, (int*)nullptr, 0, 0, (int64_t)0);
     }
     const int nu = H.uw_lvl_ptr[l+1] - H.uw_lvl_ptr[l];
     if(nu > 0 && H.upd_syrk[l] && Y->upd_nw[l] > 0)

@@ -229,6 +229,17 @@ extern "C" int dlg_sparse_stats(dlg_backend_t* b, long* nnz_JtJ_lower, long* nnz
   return DLG_OK;
 }
 
+extern "C" int dlg_sparse_schedule(dlg_backend_t* b, int* n_levels, int* persist_level0, int* persist_items)
+{
+  if(!b || !b->sym) { dlg_set_error("no symbolic analysis yet"); return DLG_ERR_STATE; }
+  const SparseSym* Y = b->sym; const SymHost& H = Y->H;
+  const bool on = Y->pr_level0 < H.nlevels;
+  if(n_levels) *n_levels = H.nlevels;
+  if(persist_level0) *persist_level0 = on ? Y->pr_level0 : -1;
+  if(persist_items) *persist_items = on ? H.fw_lvl_ptr[H.nlevels] - H.fw_lvl_ptr[Y->pr_level0] : 0;
+  return DLG_OK;
+}
+
 // K4 + K5
 int sparse_factorize(dlg_backend* b, int s, double lambda, int* ok)
 {

@@ -60,7 +60,7 @@ template <class T> int upload(T*& dev, const std::vector<T>& h)
 } // namespace
 
 // flat record of a supernode for the backward solve (same order as lvl_sn)
-struct SolveItem { int c0, w, nrows, rowoff; int64_t lx; int bd0, nbd; };
+struct SolveItem { int c0, w, nrows, rowoff; int64_t lx; int bd0, nbd; int pflag, rsv; };    // pflag: the parent's workgroup in the persistent backward launch (-1: none)
 
 struct SparseSym
 {
@@ -113,6 +113,11 @@ struct SparseSym
   // speculative assembly beside K1 (sparse_assemble_speculative): second panel buffer, its state
   double* Lx_spec = nullptr; hipEvent_t ev_spec = nullptr, ev_spec_fork = nullptr;
   bool spec_inflight = false, spec_valid = false; int spec_slot = -1; const double* spec_J = nullptr;
+  int bw_level0 = 1 << 30, bw_lds = 0, bw_n = 0;   // persistent top region of the backward solve (sparse_solve_setup)
+  SolveItem* slv_item_pr = nullptr; int* bwd_flag = nullptr; int bwd_epoch = 0;
+  int pr_stage = 0; double* pr_acc = nullptr;   // ... childless supernodes stage their update matrix; shadow scratch for the ones kept in HBM
+  int pr_level0 = 1 << 30, pr_lds = 0;   // persistent top region of the factorisation: first level, LDS bytes (sparse_factor_setup)
+  int* fac_flag = nullptr; int fac_epoch = 0;   // one flag per work item: the epoch of the launch that finished it
   bool fac_ahead = false;       // panel_factor_ahead instead of panel_factor_mfma (DOGLEG_AMD_AHEAD)
   int bwd_xb_cap = 12288;       // below rows of a supernode staged in LDS by the backward solve
   std::vector<void*> allocs;

@@ -112,10 +112,18 @@ __global__ void __launch_bounds__(BWD_NT, BD_ONLY ? 4 : 1) k_solve_bwd_level(con
                                                             const double* __restrict__ Lx,
                                                             double* __restrict__ ywork,
                                                             double* __restrict__ out, int use_aug,
-                                                            const int* __restrict__ sn_bd_col, int top_lds, int xb_cap)
+                                                            const int* __restrict__ sn_bd_col, int top_lds, int xb_cap,
+                                                            int* pr_flag, int pr_epoch)
 {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   constexpr int NW = BWD_NT/64;
+  // persistent top region (pr_flag != null): ONE launch for the last levels of the tree, workgroups
+  // from the root down; x of the ancestors was written in this very launch -- write-through stores,
+  // loads around L1 (global_ ... sc1), a flag per supernode carrying the epoch of the launch
+  typedef const __attribute__((address_space(1))) double* gcd_t;
+  typedef __attribute__((address_space(1))) double* gd_t;
+  auto ldx = [&](const double* p) -> double { return pr_flag ? __hip_atomic_load((gcd_t)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p; };
+
   const int prof_lvl = top_lds >> 8; (void)prof_lvl; top_lds &= 1;
   BW_STAMP(0);
   const SolveItem it = items[blockIdx.x];
@@ -200,10 +208,25 @@ __global__ void __launch_bounds__(BWD_NT, BD_ONLY ? 4 : 1) k_solve_bwd_level(con
   BW_STAMP(1);
   // ---- round 3
   if(tid < 256) xs[tid] = 0.0;            // columns without below rows (a root) get no mat-vec pass
+  if(pr_flag)
+  {
+    // everything that does not depend on the ancestors is on its way; now wait for the parent (it
+    // waited for its own: all ancestors are done)
+    if(tid == 0 && it.pflag >= 0)
+    {
+      int spins = 0;
+      while(__hip_atomic_load(pr_flag + it.pflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != pr_epoch)
+      {
+        __builtin_amdgcn_s_sleep(1);
+        if(++spins > (1 << 21)) break;          // never hang (the parent is always dispatched first)
+      }
+    }
+    __syncthreads();
+  }
   if(xb_lds)
   {
-    if(tid < r) xb[tid] = ywork[myrow];
-    for(int i = tid + BWD_NT; i < r; i += BWD_NT) xb[i] = ywork[rows[w + i]];
+    if(tid < r) xb[tid] = ldx(ywork + myrow);
+    for(int i = tid + BWD_NT; i < r; i += BWD_NT) xb[i] = ldx(ywork + rows[w + i]);
   }
   __syncthreads();
   BW_STAMP(2);
@@ -252,7 +275,7 @@ __global__ void __launch_bounds__(BWD_NT, BD_ONLY ? 4 : 1) k_solve_bwd_level(con
 #pragma unroll 2
       for(int i = lane; i < r; i += 64)
       {
-        const double x = xb_lds ? xb[i] : ywork[rows[w + i]];
+        const double x = xb_lds ? xb[i] : ldx(ywork + rows[w + i]);
 #pragma unroll
         for(int c = 0; c < 4; c++) acc[c] += ((c < nc) ? Lj[i + (size_t)c*nrows] : 0.0)*x;
       }
@@ -311,7 +334,18 @@ __global__ void __launch_bounds__(BWD_NT, BD_ONLY ? 4 : 1) k_solve_bwd_level(con
       for(int a = 0; a < 8; a++) if(a < nbm) xs[m0 + a] = xk[a];
     }
     __syncthreads();
-    if(tid < w) { ywork[c0 + tid] = xs[tid]; out[myperm] = xs[tid]; }
+    if(tid < w)
+    {
+      if(pr_flag) __hip_atomic_store((gd_t)(ywork + c0 + tid), xs[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      else ywork[c0 + tid] = xs[tid];
+      out[myperm] = xs[tid];
+    }
+    if(pr_flag)
+    {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if(tid == 0) __hip_atomic_store(pr_flag + blockIdx.x, pr_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     return;
   }
   if(BD_ONLY) return;
@@ -393,7 +427,19 @@ __global__ void __launch_bounds__(BWD_NT, BD_ONLY ? 4 : 1) k_solve_bwd_level(con
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
   if(tid < w) xi = xs[tid];
   BW_STAMP(4);
-  if(tid < w) { ywork[c0 + tid] = xi; out[myperm] = xi; }
+  if(tid < w)
+  {
+    if(pr_flag) __hip_atomic_store((gd_t)(ywork + c0 + tid), xi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else ywork[c0 + tid] = xi;
+    out[myperm] = xi;
+  }
+  if(pr_flag)
+  {
+    // every storing wave drains its stores, then (behind a barrier of the waves still here) the flag
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if(tid == 0) __hip_atomic_store(pr_flag + blockIdx.x, pr_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
   BW_STAMP(5);
 }
 
@@ -469,8 +515,58 @@ int sparse_solve_setup(dlg_backend* b)
       SolveItem& it = items[k];
       it.c0 = H.sn_c0[s]; it.w = H.sn_c0[s+1] - H.sn_c0[s]; it.nrows = H.sn_rowptr[s+1] - H.sn_rowptr[s];
       it.rowoff = H.sn_rowptr[s]; it.lx = H.sn_lx[s]; it.bd0 = H.sn_bd_ptr[s]; it.nbd = H.sn_bd_ptr[s+1] - H.sn_bd_ptr[s];
+      it.pflag = -1; it.rsv = 0;
     }
     DLG_CHECK(upload(Y->slv_item, items)); Y->allocs.push_back(Y->slv_item);
+  }
+  // Persistent top region of the backward solve: the last levels of the tree hold a few supernodes each
+  // and every level waits for the one above.  They go out as ONE launch, workgroups ordered from the
+  // root down (a workgroup only waits for a lower-numbered one): a workgroup pulls its part of L
+  // while it waits for its parent's flag, and raises its own as soon as its x is out.  One workgroup
+  // per CU (the hand-off through write-through stores and loads around L1 is measured for that):
+  // the launch asks for more than half of the LDS.
+  Y->bw_level0 = H.nlevels; Y->bw_n = 0;
+  if(!getenv("DOGLEG_AMD_NO_PERSIST") && H.nlevels >= 2)
+  {
+    int ncu = 256;
+    { int dev = 0; if(hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev); }
+    const int cap = (int)env_int_solve("DOGLEG_AMD_PERSIST_MAX", ncu);
+    int total = 0, l0 = H.nlevels, ldsb = 0;
+    for(int l = H.nlevels - 1; l >= 1; l--)
+    {
+      const int n = H.xl_ptr[l+1] - H.xl_ptr[l];
+      if(n == 0 || total + n > cap || Y->bwd_nt[l] != 512 || Y->bwd_bd[l] || Y->bwd_top[l]) break;
+      total += n; l0 = l; ldsb = std::max(ldsb, Y->bwd_lds[l]);
+    }
+    if(H.nlevels - l0 >= 2)
+    {
+      std::vector<SolveItem> items;
+      std::vector<int> pos(H.nsn, -1);
+      for(int l = H.nlevels - 1; l >= l0; l--)
+        for(int k = H.xl_ptr[l]; k < H.xl_ptr[l+1]; k++)
+        {
+          const int s = H.xl_sn[k];
+          SolveItem it;
+          it.c0 = H.sn_c0[s]; it.w = H.sn_c0[s+1] - H.sn_c0[s]; it.nrows = H.sn_rowptr[s+1] - H.sn_rowptr[s];
+          it.rowoff = H.sn_rowptr[s]; it.lx = H.sn_lx[s]; it.bd0 = H.sn_bd_ptr[s]; it.nbd = H.sn_bd_ptr[s+1] - H.sn_bd_ptr[s];
+          it.rsv = 0; it.pflag = -1;
+          // the parent: the supernode of the first below row (the last row is the augmented one)
+          if(it.nrows - it.w - 1 > 0)
+          {
+            const int prow = H.sn_rows[H.sn_rowptr[s] + it.w];
+            const int ps = H.col_sn[prow];
+            it.pflag = pos[ps];
+            if(it.pflag < 0) { dlg_set_error("internal error: the parent of supernode %d is not part of the persistent backward launch", s); return DLG_ERR_ARG; }
+          }
+          pos[s] = (int)items.size();
+          items.push_back(it);
+        }
+      Y->bw_level0 = l0; Y->bw_n = (int)items.size(); Y->bw_lds = std::max(ldsb, 84*1024);
+      DLG_CHECK(upload(Y->slv_item_pr, items)); Y->allocs.push_back(Y->slv_item_pr);
+      DLG_HIP(hipMalloc(&Y->bwd_flag, sizeof(int)*items.size())); Y->allocs.push_back(Y->bwd_flag);
+      DLG_HIP(hipMemsetAsync(Y->bwd_flag, 0, sizeof(int)*items.size(), b->stream));
+      Y->bwd_epoch = 0;
+    }
   }
   DLG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_solve_fwd_level),
                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BUDGET));
@@ -504,7 +600,16 @@ int sparse_solve(dlg_backend* b, const double* rhs, double* out)
   // subtree partition: the entries of the other ranks' variables are zero here, and the replicated
   // ones count on rank 0 only: the solution is the sum over the ranks
   if(H.part_nranks > 1) DLG_HIP(hipMemsetAsync(out, 0, sizeof(double)*(size_t)H.N, st));
-  for(int l = H.nlevels - 1; l >= 0; l--)
+  int ltop = H.nlevels - 1;
+  if(Y->bw_level0 < H.nlevels)
+  {
+    // the persistent top region: its levels in one launch, workgroups from the root down (sparse_solve_setup)
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_solve_bwd_level<512, false>), dim3(Y->bw_n), dim3(512), Y->bw_lds, st,
+                       Y->slv_item_pr, Y->sn_rows, Y->perm, Y->Lx, Y->ywork, out, use_aug, Y->sn_bd_col,
+                       256*Y->bw_level0, Y->bwd_xb_cap, Y->bwd_flag, ++Y->bwd_epoch);
+    ltop = Y->bw_level0 - 1;
+  }
+  for(int l = ltop; l >= 0; l--)
   {
     const int n = H.xl_ptr[l+1] - H.xl_ptr[l];
     // thread = row of the diagonal block: 256 threads when every supernode of a populous level is
@@ -512,15 +617,15 @@ int sparse_solve(dlg_backend* b, const double* rhs, double* out)
     if(n > 0 && Y->bwd_nt[l] == 256 && Y->bwd_bd[l])
       hipLaunchKernelGGL(HIP_KERNEL_NAME(k_solve_bwd_level<256, true>), dim3(n), dim3(256), Y->bwd_lds[l], st,
                          Y->slv_item + H.xl_ptr[l], Y->sn_rows, Y->perm, Y->Lx, Y->ywork, out, use_aug, Y->sn_bd_col,
-                         Y->bwd_top[l] + 256*l, Y->bwd_xb_cap);
+                         Y->bwd_top[l] + 256*l, Y->bwd_xb_cap, (int*)nullptr, 0);
     else if(n > 0 && Y->bwd_nt[l] == 256)
       hipLaunchKernelGGL(HIP_KERNEL_NAME(k_solve_bwd_level<256, false>), dim3(n), dim3(256), Y->bwd_lds[l], st,
                          Y->slv_item + H.xl_ptr[l], Y->sn_rows, Y->perm, Y->Lx, Y->ywork, out, use_aug, Y->sn_bd_col,
-                         Y->bwd_top[l] + 256*l, Y->bwd_xb_cap);
+                         Y->bwd_top[l] + 256*l, Y->bwd_xb_cap, (int*)nullptr, 0);
     else if(n > 0)
       hipLaunchKernelGGL(HIP_KERNEL_NAME(k_solve_bwd_level<512, false>), dim3(n), dim3(512), Y->bwd_lds[l], st,
                          Y->slv_item + H.xl_ptr[l], Y->sn_rows, Y->perm, Y->Lx, Y->ywork, out, use_aug, Y->sn_bd_col,
-                         Y->bwd_top[l] + 256*l, Y->bwd_xb_cap);
+                         Y->bwd_top[l] + 256*l, Y->bwd_xb_cap, (int*)nullptr, 0);
   }
   DLG_LAUNCH_CHECK();
   if(H.part_nranks > 1)

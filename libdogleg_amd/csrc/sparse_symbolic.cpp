@@ -926,7 +926,7 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
         if(S.sn_level[d] >= S.mf_level0)
         {
           const int64_t mb = S.sn_rowptr[d+1] - S.sn_rowptr[d] - (S.sn_c0[d+1] - S.sn_c0[d]);
-          S.u_off[d] = S.uscr_size; S.uscr_size += mb*(mb + 1)/2;
+          S.u_off[d] = S.uscr_size; S.uscr_size += (mb*(mb + 1)/2 + 1) & ~(int64_t)1;     // 16-byte aligned slots
           if(sn_parent[d] >= 0) S.mf_cptr[sn_parent[d] + 1]++;
         }
       for(int t = 0; t < nsn; t++) S.mf_cptr[t+1] += S.mf_cptr[t];
@@ -967,6 +967,12 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
       }
       S.uscr_size += 1024;                 // the padded tail of the last child is read (and dropped)
       S.fw_item.resize(S.fw_sn.size());
+      // the work item of every child (persistent top region of the factorisation: its flag); -1: none here
+      {
+        std::vector<int> sn_item(nsn, -1);
+        for(size_t k = 0; k < S.fw_sn.size(); k++) if(sn_item[S.fw_sn[k]] < 0) sn_item[S.fw_sn[k]] = (int)k;
+        for(size_t k = 0; k < S.mf_rec.size(); k++) S.mf_rec[k].rsv = sn_item[S.mf_child[k]];
+      }
       for(size_t k = 0; k < S.fw_sn.size(); k++)
       {
         const int s2 = S.fw_sn[k];

@@ -154,7 +154,7 @@ struct FwItem
 };
 // one child of a supernode of the multifrontal region: its update matrix and, entry by entry
 // (packed order, padded to a multiple of 1024 with a scratch slot), where each entry goes
-struct MfChild { int64_t u_off, dst_off; int npad, rsv; };
+struct MfChild { int64_t u_off, dst_off; int npad, rsv; };     // rsv: the child's work item (index into fw_item), -1 if it has none on this rank
 
 struct SymHost
 {

@@ -152,9 +152,11 @@ def test_ba_lambda_path(gpu):
     {"DOGLEG_AMD_BWD_XB_CAP": "40"},                                # backward solve: x of the below rows gathered from HBM
     {"DOGLEG_AMD_AHEAD": "1"},                                      # barrier-free panel sweep (diagonal wave runs ahead)
     {"DOGLEG_AMD_NO_OVERLAP": "1"},                                 # Cauchy step on the main stream
+    {"DOGLEG_AMD_NO_PERSIST": "1"},                                 # one launch per level all the way up
+    {"DOGLEG_AMD_PERSIST_MAX": "100000"},                           # the persistent top region as deep as it can go
 ], ids=["lds-assembly", "coop-update", "mfma-update", "syrk-unfused", "no-rider", "small-slices", "no-multifrontal",
         "multifrontal-from-leaves", "multifrontal-128", "multifrontal-256", "multifrontal-small-fronts", "device-finals",
-        "bwd-x-from-hbm", "panel-ahead", "no-overlap"])
+        "bwd-x-from-hbm", "panel-ahead", "no-overlap", "no-persistent-top", "deep-persistent-top"])
 def test_fallback_kernels_match_oracle(gpu, env, monkeypatch):
     """the kernels the default schedule does not pick on a bundle-adjustment pattern stay correct:
     the schedule knobs are read when the pattern is set"""
@@ -387,3 +389,43 @@ def test_speculative_assembly_changes_no_bit(gpu):
     for a, b in zip(out[False], out[True]):
         assert a[0] == b[0] and np.array_equal(a[1], b[1])
     assert np.array_equal(out[True][0][1], out[True][2][1])      # same inputs, other slot: same step
+
+
+@pytest.mark.parametrize("shape", [(49, 900, 10000), (199, 3600, 40000)])
+def test_persistent_top_region_changes_no_bit(gpu, shape, monkeypatch):
+    """the last levels of the elimination tree factored by ONE launch (children hand their update
+    matrices to the parent's workgroup through flags, sparse_factor_setup) give the same bits as one
+    launch per level -- over repeated factorisations (every launch has its own flag epoch), with the
+    region at its default depth and as deep as the conditions allow"""
+    prob = oa.BAProblem(*shape, seed=4)
+    Jp, Ji = prob.pattern()
+    p = prob.p0()
+    evals = [prob.eval(p + 0.003*k) for k in range(3)]
+    out, sched = {}, {}
+    for mode in ("off", "default", "deep"):
+        monkeypatch.delenv("DOGLEG_AMD_NO_PERSIST", raising=False)
+        monkeypatch.delenv("DOGLEG_AMD_PERSIST_MAX", raising=False)
+        if mode == "off":
+            monkeypatch.setenv("DOGLEG_AMD_NO_PERSIST", "1")
+        if mode == "deep":
+            monkeypatch.setenv("DOGLEG_AMD_PERSIST_MAX", "100000")
+        be = capi.Backend(capi.DLG_SPARSE, prob.N, prob.M, prob.nnz)
+        be.set_pattern(Jp, Ji)
+        sched[mode] = be.schedule()
+        be.set_p(0, p)
+        res = []
+        for rep in range(4):
+            for x, Jx in evals:
+                be.upload(0, x, Jx)
+                be.eval(0)
+                lam, n2g = be.gauss_newton(0, 0.0 if rep % 2 == 0 else 1e-4)
+                res.append((lam, n2g, be.download(0, capi.VEC_GN)))
+        out[mode] = res
+        be.close()
+    print(sched)
+    assert sched["off"]["persist_level0"] == -1
+    assert sched["default"]["persist_level0"] >= 1 and sched["default"]["persist_items"] >= 2
+    assert sched["deep"]["persist_level0"] <= sched["default"]["persist_level0"]
+    for mode in ("default", "deep"):
+        for a, b in zip(out["off"], out[mode]):
+            assert a[0] == b[0] and a[1] == b[1] and np.array_equal(a[2], b[2]), mode
