@@ -6,7 +6,9 @@ namespace {
 // -DDLG_FL_PROFILE: phase clocks of workgroup 0 of every backward-solve launch (tools only)
 #ifdef DLG_FL_PROFILE
 __device__ long long g_bw_prof[64*8];
-#define BW_STAMP(k) do { if(threadIdx.x == 0 && blockIdx.x == 0) g_bw_prof[(prof_lvl & 63)*8 + (k)] = clock64(); } while(0)
+__device__ long long g_bw_chain[256*8];      // the persistent launch: every workgroup, 100 MHz clock
+#define BW_STAMP(k) do { if(threadIdx.x == 0 && blockIdx.x == 0) g_bw_prof[(prof_lvl & 63)*8 + (k)] = clock64(); \
+                         if(threadIdx.x == 0 && pr_flag && blockIdx.x < 256) g_bw_chain[blockIdx.x*8 + (k)] = wall_clock64(); } while(0)
 #else
 #define BW_STAMP(k)
 #endif
@@ -157,7 +159,9 @@ __global__ void __launch_bounds__(BWD_NT, BD_ONLY ? 4 : 1) k_solve_bwd_level(con
   // so registers are kept low there (fewer values in flight, the member blocks fetched late)
   constexpr bool LEAN = BWD_NT == 256;
   constexpr int MV_SLOTS = LEAN ? 20 : 24;
-  const int mv_cols = min(BWD_NT, (w + 63) & ~63), mv_parts = BWD_NT/mv_cols;
+  // (a thread reads its own stretch of a column: nothing is gained from a power-of-two column count,
+  // and 66 columns are 7 parts of the rows, not 4; at most 8 parts -- xp)
+  const int mv_cols = min(BWD_NT, max(w, 64)), mv_parts = BWD_NT/mv_cols;
   const int mv_j = tid % mv_cols, mv_p = tid/mv_cols;
   const int mv_len = (r + mv_parts - 1)/mv_parts;           // rows per part
   const int mv_i0 = mv_p*mv_len, mv_i1 = min(r, mv_i0 + mv_len);
@@ -458,6 +462,19 @@ extern "C" void dlg_bw_profile_dump(int nlevels)
 {
   long long h[64*8];
   hipDeviceSynchronize();
+  {
+    std::vector<long long> c(256*8);
+    hipMemcpyFromSymbol(c.data(), HIP_SYMBOL(g_bw_chain), sizeof(long long)*c.size());
+    long long t0 = 0;
+    for(int g = 0; g < 256; g++) if(c[g*8] && (t0 == 0 || c[g*8] < t0)) t0 = c[g*8];
+    for(int g = 0; g < 256 && g < (getenv("DLG_FL_DUMP_ALL") ? 256 : 24); g++)
+    {
+      const long long* q = &c[g*8];
+      if(q[5] == 0) continue;
+      fprintf(stderr, "   bwd wg %3d: start %6lld loads issued %6lld parent there + x gathered %6lld mat-vec %6lld sweep %6lld published %6lld (10 ns)\n",
+              g, q[0] - t0, q[1] - t0, q[2] - t0, q[3] - t0, q[4] - t0, q[5] - t0);
+    }
+  }
   hipMemcpyFromSymbol(h, HIP_SYMBOL(g_bw_prof), sizeof(h));
   for(int l = 0; l < nlevels && l < 64; l++)
     fprintf(stderr, "bwd level %2d: issue %6lld  gather+barrier %6lld  matvec %6lld  solve %6lld  store %6lld cycles | to first barrier %6lld, in it %6lld, rest of the loop %6lld\n", l,
