@@ -94,7 +94,8 @@ __device__ __forceinline__ void panel_mfma_tiles(double* P, int ldp, int nrows, 
     for(int r = 0; r < 4; r++)
     {
       const int row0 = r0 + kq + 4*r, row1 = r1 + kq + 4*r;
-      if(bvalid && row0 < nrows) cp[row0] = acc0[r];
+      // (never the strict upper triangle: the factor kernel may keep part of an update matrix there)
+      if(bvalid && row0 < nrows && row0 >= kb + mm) cp[row0] = acc0[r];
       if(PAIR) if(bvalid && two && row1 < nrows) cp[row1] = acc1[r];
     }
   }
@@ -298,7 +299,7 @@ __device__ __forceinline__ void pf_tile_pair_at(double* P, int ldp, int nrows, i
   for(int r = 0; r < 4; r++)
   {
     const int row0 = r0 + kq + 4*r, row1 = r1 + kq + 4*r;
-    if(bvalid && row0 < nrows) cp[row0] = acc0[r];
+    if(bvalid && row0 < nrows && row0 >= kb + mm) cp[row0] = acc0[r];
     if(bvalid && two && row1 < nrows) cp[row1] = acc1[r];
   }
 }

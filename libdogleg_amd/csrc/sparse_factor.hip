@@ -37,7 +37,7 @@ __device__ __forceinline__ void mf_add_children(double* P, double* Wt, int ntri,
                                                 MfChild rc, const MfChild* __restrict__ mf_rec,
                                                 const double* uscr, const uint16_t* __restrict__ mf_dst, int tid)
 {
-  constexpr int MF_SLOTS = 16;
+  constexpr int MF_SLOTS = (NT >= 512) ? 20 : 16;      // 512 threads: up to 10240 entries (a 139-row update matrix) in one round
   const int lane = tid & 63;
   for(int e = tid; e < ntri; e += NT) Wt[e] = 0.0;
   __syncthreads();
@@ -105,7 +105,7 @@ __device__ __forceinline__ void mf_add_children(double* P, double* Wt, int ntri,
 template <int NCH>
 __device__ __forceinline__ void factor_tail_tiles(const double* Pb, int ldp, int w, int mb, int T, int first,
                                                   double* Ud, int mode, bool w_hbm, bool mf_acc, int lane,
-                                                  int64_t acc_shift, bool st_wt)
+                                                  int64_t acc_shift, bool st_wt, int usp, double* Pgap)
 {
   const int jn = lane & 15, kq = lane >> 4;
   int ti[NCH], tjq[NCH], oa[NCH], ob[NCH];
@@ -198,6 +198,8 @@ __device__ __forceinline__ void factor_tail_tiles(const double* Pb, int ldp, int
   for(int q = 0; q < NCH; q++)
   {
     const int j = 16*tjq[q] + jn, jtri = tri_col(j, mb);
+    // columns from usp on live in the strict upper triangle of the panel's top block (sym_w_split)
+    double* Uc = (j >= usp) ? Pgap + (mb - j)*ldp - j : Ud + jtri;
 #pragma unroll
     for(int r = 0; r < 4; r++)
     {
@@ -212,8 +214,8 @@ __device__ __forceinline__ void factor_tail_tiles(const double* Pb, int ldp, int
           typedef __attribute__((address_space(1))) double* gwptr_t;
           __hip_atomic_store((gwptr_t)(Ud + jtri + i), (w_hbm ? w0[q][r] : 0.0) - c4[q][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        else if(mode == 2) Ud[jtri + i] = (w_hbm ? w0[q][r] : (mf_acc ? Ud[jtri + i] : 0.0)) - c4[q][r];     // the region keeps W = -U
-        else Ud[jtri + i] = c4[q][r];
+        else if(mode == 2) Uc[i] = (w_hbm ? w0[q][r] : (mf_acc ? Uc[i] : 0.0)) - c4[q][r];     // the region keeps W = -U
+        else Uc[i] = c4[q][r];
       }
     }
   }
@@ -273,11 +275,15 @@ __global__ void __launch_bounds__(NT) k_factor_level(const FwItem* __restrict__ 
   double* Pb = cmp ? P - w : P;
   const int row0c = cmp ? w : 0;               // first row that is staged
   const bool has_u = mode != 0 && top < 0;
+  // the update matrix is staged in LDS where it fits: behind the panel, its last columns in the unused
+  // strict upper triangle of the top block if need be (it.jsp, sym_w_split)
   const bool u_lds = has_u && (it.nch > 0 || stage_leaf_u) &&
-                     (size_t)(ldp*w + ntri + 1 + (cmp ? 8*w : 0))*sizeof(double) <= (size_t)FAC_LDS_BUDGET;   // + the scratch slot of mf_dst
+                     (cmp ? (size_t)(ldp*w + ntri + 1 + 8*w)*sizeof(double) <= (size_t)FAC_LDS_BUDGET : it.jsp >= 0);   // + the scratch slot of mf_dst
+  const int usp = (u_lds && !cmp) ? it.jsp : mb;          // first column kept up there (mb: none)
+  const int nlin = usp*mb - usp*(usp - 1)/2;              // doubles behind the panel
   double* Ug = has_u ? uscr + it.u_off : nullptr;
   double* Us = P + ldp*w;
-  double* Dg = Us + (u_lds ? ntri + 1 : 0);
+  double* Dg = Us + (u_lds ? nlin + 1 : 0);
   __shared__ int s_mcol[260];
   __shared__ double s_rdiag[256];
   MfChild rc = {0, 0, 0, 0};
@@ -324,11 +330,14 @@ __global__ void __launch_bounds__(NT) k_factor_level(const FwItem* __restrict__ 
   }
   __syncthreads();
   FL_STAMP(1);
+  if(mf_acc && usp < mb)
+    for(int jw = usp + (tid >> 6); jw < mb; jw += NT/64)
+      for(int i = lane; i < mb - jw; i += 64) P[(mb - jw)*ldp + i] = 0.0;      // (the barrier is in mf_add_children)
   if(mf_acc)
   {
-    if(pr_flag && u_lds) mf_add_children<NT, true, true>(P, Us, ntri, it.nch, it.ch0, rc, mf_rec, uscr, mf_dst, tid);
+    if(pr_flag && u_lds) mf_add_children<NT, true, true>(P, Us, nlin, it.nch, it.ch0, rc, mf_rec, uscr, mf_dst, tid);
     else if(pr_flag)     mf_add_children<NT, false, true>(P, Ug + pr_acc, ntri, it.nch, it.ch0, rc, mf_rec, uscr, mf_dst, tid);
-    else if(u_lds)  mf_add_children<NT, true >(P, Us, ntri, it.nch, it.ch0, rc, mf_rec, uscr, mf_dst, tid);
+    else if(u_lds)  mf_add_children<NT, true >(P, Us, nlin, it.nch, it.ch0, rc, mf_rec, uscr, mf_dst, tid);
     else            mf_add_children<NT, false>(P, Ug, ntri, it.nch, it.ch0, rc, mf_rec, uscr, mf_dst, tid);
   }
   FL_STAMP(2);
@@ -361,29 +370,47 @@ __global__ void __launch_bounds__(NT) k_factor_level(const FwItem* __restrict__ 
       const int t0 = (int)((long)c*ntiles/nchunks), t1 = (int)((long)(c + 1)*ntiles/nchunks);
       switch(t1 - t0)
       {
-        case 1: factor_tail_tiles<1>(Pb, ldp, w, mb, T, t0, Ud, mode, w_hbm, mf_acc, lane, acc_shift, st_wt); break;
-        case 2: factor_tail_tiles<2>(Pb, ldp, w, mb, T, t0, Ud, mode, w_hbm, mf_acc, lane, acc_shift, st_wt); break;
-        case 3: factor_tail_tiles<3>(Pb, ldp, w, mb, T, t0, Ud, mode, w_hbm, mf_acc, lane, acc_shift, st_wt); break;
-        case 4: factor_tail_tiles<4>(Pb, ldp, w, mb, T, t0, Ud, mode, w_hbm, mf_acc, lane, acc_shift, st_wt); break;
-        case 5: if(SY_G >= 5) factor_tail_tiles<(SY_G >= 5 ? 5 : 1)>(Pb, ldp, w, mb, T, t0, Ud, mode, w_hbm, mf_acc, lane, acc_shift, st_wt); break;
-        case 6: if(SY_G >= 6) factor_tail_tiles<(SY_G >= 6 ? 6 : 1)>(Pb, ldp, w, mb, T, t0, Ud, mode, w_hbm, mf_acc, lane, acc_shift, st_wt); break;
+        case 1: factor_tail_tiles<1>(Pb, ldp, w, mb, T, t0, Ud, mode, w_hbm, mf_acc, lane, acc_shift, st_wt, usp, P); break;
+        case 2: factor_tail_tiles<2>(Pb, ldp, w, mb, T, t0, Ud, mode, w_hbm, mf_acc, lane, acc_shift, st_wt, usp, P); break;
+        case 3: factor_tail_tiles<3>(Pb, ldp, w, mb, T, t0, Ud, mode, w_hbm, mf_acc, lane, acc_shift, st_wt, usp, P); break;
+        case 4: factor_tail_tiles<4>(Pb, ldp, w, mb, T, t0, Ud, mode, w_hbm, mf_acc, lane, acc_shift, st_wt, usp, P); break;
+        case 5: if(SY_G >= 5) factor_tail_tiles<(SY_G >= 5 ? 5 : 1)>(Pb, ldp, w, mb, T, t0, Ud, mode, w_hbm, mf_acc, lane, acc_shift, st_wt, usp, P); break;
+        case 6: if(SY_G >= 6) factor_tail_tiles<(SY_G >= 6 ? 6 : 1)>(Pb, ldp, w, mb, T, t0, Ud, mode, w_hbm, mf_acc, lane, acc_shift, st_wt, usp, P); break;
         default: break;
       }
     }
     if(u_lds) __syncthreads();
   }
   FL_STAMP(4);
-  if(u_lds && pr_flag)
+  if(u_lds)
   {
-    // the parent reads W in this same launch: 16-byte write-through stores (the slots are 16-byte
-    // aligned and padded to an even length), drained by every wave before the flag goes up
-    for(int e = 2*tid; e < ntri; e += 2*NT)
+    typedef __attribute__((address_space(1))) double* gwptr_t;
+    // the part behind the panel.  Persistent top region: the parent reads W in this same launch --
+    // 16-byte write-through stores (the slots are 16-byte aligned and padded to an even length),
+    // drained by every wave before the flag goes up
+    const int npair = (usp == mb) ? (nlin + 1) & ~1 : nlin & ~1;
+    if(pr_flag)
     {
-      const dlg_v2d v2 = *reinterpret_cast<const dlg_v2d*>(Us + e);
-      asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(Ug + e), "v"(v2) : "memory");
+      for(int e = 2*tid; e < npair; e += 2*NT)
+      {
+        const dlg_v2d v2 = *reinterpret_cast<const dlg_v2d*>(Us + e);
+        asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(Ug + e), "v"(v2) : "memory");
+      }
+      if(tid == 0 && npair < nlin) __hip_atomic_store((gwptr_t)(Ug + npair), Us[npair], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    else for(int e = tid; e < nlin; e += NT) Ug[e] = Us[e];
+    // the columns kept in the top block's upper triangle
+    for(int jw = usp + (tid >> 6); jw < mb; jw += NT/64)
+    {
+      const double* src = P + (mb - jw)*ldp;
+      double* dst = Ug + tri_col(jw, mb) + jw;
+      for(int i = lane; i < mb - jw; i += 64)
+      {
+        if(pr_flag) __hip_atomic_store((gwptr_t)(dst + i), src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else dst[i] = src[i];
+      }
     }
   }
-  else if(u_lds) for(int e = tid; e < ntri; e += NT) Ug[e] = Us[e];
   if(pr_flag)
   {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -399,13 +426,15 @@ __global__ void __launch_bounds__(NT) k_factor_level(const FwItem* __restrict__ 
     else if(top < 0)  { gp = G + i; gs = (size_t)nrows; }
     else if(r0 == 0)  { gp = top_scr + top + i; gs = (size_t)w; }
     else continue;
-    for(int j0 = cp_g; j0 < w; j0 += 16*cp_ng)
+    // (where the top block's upper triangle held part of W, only its lower triangle goes back)
+    const int jend = (usp < mb && i < w) ? i + 1 : w;
+    for(int j0 = cp_g; j0 < jend; j0 += 16*cp_ng)
     {
       double v[16];
 #pragma unroll
-      for(int u = 0; u < 16; u++) v[u] = (j0 + u*cp_ng < w) ? Pb[i + (j0 + u*cp_ng)*ldp] : 0.0;
+      for(int u = 0; u < 16; u++) v[u] = (j0 + u*cp_ng < jend) ? Pb[i + (j0 + u*cp_ng)*ldp] : 0.0;
 #pragma unroll
-      for(int u = 0; u < 16; u++) if(j0 + u*cp_ng < w) gp[(size_t)(j0 + u*cp_ng)*gs] = v[u];
+      for(int u = 0; u < 16; u++) if(j0 + u*cp_ng < jend) gp[(size_t)(j0 + u*cp_ng)*gs] = v[u];
     }
   }
   FL_STAMP(5);
@@ -1020,9 +1049,10 @@ int sparse_factor_setup(dlg_backend* b)
         const long wv = H.sn_c0[s+1] - H.sn_c0[s], nr = H.sn_rowptr[s+1] - H.sn_rowptr[s], mb = nr - wv;
         const bool cmp = H.sn_bd_ptr[s+1] > H.sn_bd_ptr[s] && H.sn_top[s] < 0;
         const long pan = cmp ? ((mb + 1) & ~1L)*wv + 8*wv : ((nr + 1) & ~1L)*wv;
-        const long need = (pan + mb*(mb + 1)/2 + 1)*8;
+        const int jsp = cmp ? (int)mb : sym_w_split(wv, nr);      // the kernel's rule (sym_w_split: part of W may sit in the top block's upper triangle)
+        const long need = (pan + (jsp >= 0 ? sym_w_linear(mb, jsp) : mb*(mb + 1)/2) + 1)*8;
         const long need0 = (pan + 1)*8;          // at least the scratch slot behind the panel
-        const long want = (need <= FAC_LDS_BUDGET) ? need : need0;
+        const long want = (need <= FAC_LDS_BUDGET && jsp >= 0) ? need : need0;
         const bool has_children = l >= H.mf_level0 && H.mf_cptr[s+1] > H.mf_cptr[s];
         if(has_children) with_children = std::max(with_children, want); else leaves = std::max(leaves, want);
       }
@@ -1074,9 +1104,8 @@ int sparse_factor_setup(dlg_backend* b)
       {
         // the kernel's rule for staging the update matrix behind the panel
         const FwItem& it = H.fw_item[i];
-        const long nloc = it.w + (it.r1 - it.r0), mb = nloc - it.w, ldp = (nloc + 1) & ~1L, ntri = mb*(mb + 1)/2;
-        const bool fits = (size_t)(ldp*it.w + ntri + 1)*sizeof(double) <= (size_t)FAC_LDS_BUDGET;
-        if(mb > 0 && it.nch > 0 && !fits) acc = true;
+        const long mb = it.nrows - it.w;
+        if(mb > 0 && it.nch > 0 && it.jsp < 0) acc = true;
       }
     }
     if(dbg)

@@ -807,7 +807,8 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
         const int w = S.sn_c0[s+1] - S.sn_c0[s], nr = S.sn_rowptr[s+1] - S.sn_rowptr[s];
         n++; wsum += w; rsum += nr; wmin = std::min(wmin, w); wmax = std::max(wmax, w); rmax = std::max(rmax, nr);
         const long mb = nr - w;
-        if((((nr + 1) & ~1L)*w + mb*(mb + 1)/2 + 1)*8 > SYM_FAC_LDS_BUDGET) nofit++;
+        (void)mb;
+        if(sym_w_split(w, nr) < 0) nofit++;
       }
       fprintf(stderr, "level %2d: %5ld supernodes  w min/avg/max %d/%.1f/%d  nrows avg/max %.1f/%d  slices %d  update matrix not in LDS: %ld\n", l, n, wmin,
               (double)wsum/n, wmax, (double)rsum/n, rmax, S.fw_lvl_ptr[l+1] - S.fw_lvl_ptr[l], nofit);
@@ -943,9 +944,11 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
         // layout of t's factor workgroup (k_factor_level): panel with an even leading dimension,
         // the update matrix behind it when both (and one scratch double) fit in LDS
         const int w = S.sn_c0[t+1] - S.sn_c0[t], nrows = S.sn_rowptr[t+1] - S.sn_rowptr[t], mb = nrows - w;
-        const int ldp = (nrows + 1) & ~1, ntri = mb*(mb + 1)/2;
-        const bool u_lds = (size_t)(ldp*w + ntri + 1)*sizeof(double) <= (size_t)SYM_FAC_LDS_BUDGET;
-        const int wt_off = u_lds ? ldp*w : 0x8000, trash = u_lds ? ldp*w + ntri : ldp*w;
+        const int ldp = (nrows + 1) & ~1;
+        const int jsp = sym_w_split(w, nrows);            // -1: the update matrix stays in HBM
+        const bool u_lds = jsp >= 0;
+        const int nlin = u_lds ? (int)sym_w_linear(mb, jsp) : 0;
+        const int wt_off = u_lds ? ldp*w : 0x8000, trash = ldp*w + nlin;
         for(int k = S.mf_cptr[t]; k < S.mf_cptr[t+1]; k++)
         {
           const int c = S.mf_child[k];
@@ -959,7 +962,10 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
             for(int i = j; i < mc; i++)
             {
               const int fi = map[i], fj = map[j];
-              const int d = (fj < w) ? fi + fj*ldp : wt_off + (fj - w)*mb - (fj - w)*(fj - w - 1)/2 + (fi - fj);
+              const int jw = fj - w;
+              const int d = (fj < w) ? fi + fj*ldp
+                          : (u_lds && jw >= jsp) ? (mb - jw)*ldp + (fi - fj)          // in the top block's upper triangle
+                          : wt_off + jw*mb - jw*(jw - 1)/2 + (fi - fj);
               S.mf_dst.push_back((uint16_t)d);
             }
           for(int e = nc; e < npad; e++) S.mf_dst.push_back((uint16_t)trash);
@@ -982,7 +988,7 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
         it.bd0 = S.sn_bd_ptr[s2]; it.nbd = S.sn_bd_ptr[s2+1] - S.sn_bd_ptr[s2];
         it.lx = S.sn_lx[s2]; it.top = S.sn_top[s2]; it.u_off = S.u_off[s2];
         it.ch0 = S.mf_cptr[s2]; it.nch = S.mf_cptr[s2+1] - S.mf_cptr[s2];
-        it.bdw = 0; it.rsv = 0;
+        it.bdw = 0; it.jsp = sym_w_split(it.w, it.nrows);
         if(it.nbd > 0)
         {
           // members of equal width (the usual case: points): no list lookup in the kernel

@@ -142,6 +142,22 @@ struct SymTask { int32_t blk, c0, c1, part, var0, nI; };   // var0 / nI: copied 
 // LDS bytes a factor workgroup may use: (almost) all 160 KB of a CU, the rest is its static LDS
 constexpr int SYM_FAC_LDS_BUDGET = 163840 - 3584;
 
+// Where the update matrix W (mb x mb, packed lower triangle) of an unsliced supernode lives while its
+// factor workgroup runs: behind the panel in LDS if both fit; else its last columns move into the
+// unused strict upper triangle of the panel's top block -- column jw of W (length mb - jw) fills
+// exactly the mb - jw free slots at the head of panel column mb - jw -- which is possible for the
+// columns jw >= mb - w + 1.  Returns the first column that lives up there (mb: none, everything is
+// behind the panel; -1: W does not fit either way and stays in HBM).
+inline int sym_w_split(long w, long nrows)
+{
+  const long mb = nrows - w, ldp = (nrows + 1) & ~1L, ntri = mb*(mb + 1)/2, room = SYM_FAC_LDS_BUDGET/8 - ldp*w - 1;
+  if(ntri <= room) return (int)mb;
+  const long jsp = mb - w + 1 > 0 ? mb - w + 1 : 0;
+  if(jsp*mb - jsp*(jsp - 1)/2 <= room) return (int)jsp;
+  return -1;
+}
+inline long sym_w_linear(long mb, long jsp) { return jsp*mb - jsp*(jsp - 1)/2; }    // doubles behind the panel
+
 // one factor work item (supernode, slice of its below rows)
 struct FwItem
 {
@@ -150,7 +166,7 @@ struct FwItem
   int bd0, nbd;                // block-diagonal top: members in sn_bd_col[bd0 .. bd0 + nbd)
   int64_t lx, top, u_off;      // panel offset, top-block copy (or -1), update-matrix offset (or -1)
   int ch0, nch;                // multifrontal children: mf_rec[ch0 .. ch0 + nch)
-  int bdw, rsv;                // block-diagonal top: the common width of the members, 0 if they differ
+  int bdw, jsp;                // block-diagonal top: the common width of the members, 0 if they differ; sym_w_split of the supernode
 };
 // one child of a supernode of the multifrontal region: its update matrix and, entry by entry
 // (packed order, padded to a multiple of 1024 with a scratch slot), where each entry goes
