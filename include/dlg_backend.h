@@ -265,7 +265,9 @@ enum
   DLG_PROF_VEC = 7,           /* other O(N) reductions                           */
   DLG_PROF_COUNT = 8
 };
-int  dlg_backend_set_profiling(dlg_backend_t* b, int on);      /* also clears the counters */
+/* on = 0: off; 1: every phase; else: only the phases p with bit (p + 1) of `on` set, e.g.
+ * 2 << DLG_PROF_K4_KERNEL (two event records per step instead of twenty).  Clears the counters. */
+int  dlg_backend_set_profiling(dlg_backend_t* b, int on);
 int  dlg_backend_get_profile(dlg_backend_t* b, double* ms_total, long* launches, int n);
 
 /* ---- raw device-memory helpers for harnesses that hold inputs in HBM without

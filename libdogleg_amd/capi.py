@@ -318,8 +318,10 @@ class Backend:
         except Exception:
             pass
 
-    def set_profiling(self, on=True):
-        _ck(self.L.dlg_backend_set_profiling(self.h, 1 if on else 0), "set_profiling")
+    def set_profiling(self, on=True, only=None):
+        """only: names of the phases to time (PROF_NAMES); default all"""
+        v = (1 if on else 0) if only is None else sum(2 << PROF_NAMES.index(n) for n in only)
+        _ck(self.L.dlg_backend_set_profiling(self.h, v), "set_profiling")
 
     def profile(self):
         """{phase: (total_ms, launches)} since set_profiling(True)"""

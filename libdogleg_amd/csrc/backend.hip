@@ -70,6 +70,7 @@ extern "C" int dlg_backend_set_profiling(dlg_backend_t* b, int on)
   dlg_prof_resolve(b);
   for(int i = 0; i < DLG_PROF_COUNT; i++) { b->prof_ms[i] = 0; b->prof_n[i] = 0; }
   b->profiling = on != 0;
+  b->prof_mask = on == 0 ? 0u : (on == 1 ? ~0u : (unsigned)on >> 1);
   return DLG_OK;
 }
 extern "C" int dlg_backend_get_profile(dlg_backend_t* b, double* ms_total, long* launches, int n)
@@ -132,6 +133,7 @@ extern "C" int dlg_backend_create(dlg_backend_t** out, int solve_type, int Nstat
   TRY_HIP(hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming));
   TRY_HIP(hipEventCreateWithFlags(&b->ev_join, hipEventDisableTiming));
   b->overlap = getenv("DOGLEG_AMD_NO_OVERLAP") == nullptr;
+  b->fuse_eval = getenv("DOGLEG_AMD_NO_FUSED_EVAL") == nullptr;
   TRY_HIP(hipMalloc(&b->d_scal, sizeof(double)*dlg_backend::NSCAL));
   TRY_HIP(hipMemsetAsync(b->d_scal, 0, sizeof(double)*dlg_backend::NSCAL, b->stream));
   TRY_HIP(hipHostMalloc(&b->h_scal, sizeof(double)*dlg_backend::NSCAL));
@@ -442,9 +444,13 @@ extern "C" int dlg_point_eval(dlg_backend_t* b, int s, double* norm2_x, double* 
   else
   {
     const int mloc = dlg_mloc(b);
-    // the caller expects to factorise this point: its JtJ is assembled on the second stream meanwhile
-    if(b->type == DLG_SPARSE && b->speculate && b->overlap) DLG_CHECK(sparse_assemble_speculative(b, s));
+    // the caller expects to factorise this point: JtJ is assembled in the same pass over J that forms
+    // Jt*x (sparse_eval_assemble) or, where that schedule is not available, on the second stream meanwhile
+    int fused = 0;
+    if(b->type == DLG_SPARSE && b->speculate && b->fuse_eval) DLG_CHECK(sparse_eval_assemble(b, s, &fused));
+    if(!fused)
     {
+      if(b->type == DLG_SPARSE && b->speculate && b->overlap) DLG_CHECK(sparse_assemble_speculative(b, s));
       DlgProfScope ps(b, DLG_PROF_K1_JTX);
       if(b->type == DLG_SPARSE) DLG_CHECK(sparse_eval(b, s)); else DLG_CHECK(dense_eval(b, s));
     }

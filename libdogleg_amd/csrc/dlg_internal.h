@@ -65,6 +65,7 @@ struct dlg_backend
   hipStream_t aux_stream = nullptr;
   hipEvent_t  ev_fork = nullptr, ev_join = nullptr;
   bool want_fork = false, fork_recorded = false, overlap = true;
+  bool fuse_eval = true;      // ... in the pass that forms Jt*x where the schedule allows (DOGLEG_AMD_NO_FUSED_EVAL: second stream instead)
   bool speculate = false;     // dlg_backend_set_speculation: assemble JtJ beside Jt*x at every dlg_point_eval
   DlgSlot slot[2];
 
@@ -123,6 +124,7 @@ struct dlg_backend
 
   // optional per-phase timing with HIP events on b->stream (dlg_backend_set_profiling)
   bool profiling = false;
+  unsigned prof_mask = 0;     // the phases that are timed (bit = DLG_PROF_*)
   struct ProfPair { hipEvent_t a, b; int id; };
   std::vector<ProfPair> prof_pending;
   std::vector<hipEvent_t> prof_pool;
@@ -139,7 +141,7 @@ void dlg_prof_resolve(dlg_backend* b);
 struct DlgProfScope
 {
   dlg_backend* b; int id; hipEvent_t e;
-  DlgProfScope(dlg_backend* b_, int id_) : b(b_), id(id_), e(b_->profiling ? dlg_prof_begin(b_) : nullptr) {}
+  DlgProfScope(dlg_backend* b_, int id_) : b(b_), id(id_), e((b_->prof_mask >> id_ & 1u) ? dlg_prof_begin(b_) : nullptr) {}
   ~DlgProfScope() { if(e) dlg_prof_end(b, id, e); }
 };
 
@@ -208,6 +210,7 @@ void sparse_destroy(dlg_backend* b);
 int sparse_set_pattern(dlg_backend* b, const int* colptr, const int* rowidx);
 int sparse_eval(dlg_backend* b, int slot);                      // K1
 int sparse_assemble_speculative(dlg_backend* b, int s);         // K4 beside K1 (second stream, second panel buffer)
+int sparse_eval_assemble(dlg_backend* b, int s, int* done);      // K1 + K4 in one pass over J (the assembly kernel forms Jt*x too)
 void sparse_spec_invalidate(dlg_backend* b, int s);
 int sparse_norm2_Jv(dlg_backend* b, int slot, const double* v, double* out_dev); // K3/K8
 int sparse_factorize(dlg_backend* b, int slot, double lambda, int* ok);          // K4+K5

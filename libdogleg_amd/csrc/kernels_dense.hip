@@ -633,7 +633,7 @@ int launch_syrk(hipStream_t st, double* C, int ldc, const double* A, int lda, in
   int kper = dlg_cdiv(dlg_cdiv(K, ks), KC)*KC;
   if(kper < KC) kper = KC;
   {
-    hipEvent_t pe = (prof && prof->profiling) ? dlg_prof_begin(prof) : nullptr;
+    hipEvent_t pe = (prof && (prof->prof_mask >> DLG_PROF_K4_KERNEL & 1u)) ? dlg_prof_begin(prof) : nullptr;
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_syrk_lower<WT>), dim3(ntiles*ks), dim3(TPB), lds, st, C, ldc, A,
                        lda, n, K, alpha, ks, kper, ws);
     if(pe) dlg_prof_end(prof, DLG_PROF_K4_KERNEL, pe);

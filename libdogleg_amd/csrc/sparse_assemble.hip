@@ -221,14 +221,21 @@ constexpr int ASM_U = DLG_ASM_U;
 // k-group records are wave-uniform (scalar loads), fetched one iteration ahead.  All loads are
 // unconditional with clamped addresses (absent rows read element 0 and are zeroed afterwards):
 // the loop body is straight-line code, the only branches are uniform.
-template <bool HAS_T, int CLEN>
+// JTX: the wave also forms Jt*x of its tasks' rows -- the B operand of the persistent product IS
+// J(row, column of the task's block / of the rider), so one multiply-add per k-group with x(row)
+// gives the task's share of (Jt x)[block]; it leaves a 16-double record per task (jtp), summed per
+// var-block by k_jtx_fin2_* in task order.  K1's own pass over J is not needed then.
+template <bool HAS_T, int CLEN, bool JTX>
 __device__ __forceinline__ void asm_mfma_run(const AsmRun& R, const AsmMTask* __restrict__ tasks,
                                              const AsmShape* __restrict__ SH,
                                              const AsmKG* __restrict__ kgs, const int* __restrict__ tdest,
                                              const int* __restrict__ pdest, const double* __restrict__ vals,
                                              double* __restrict__ Lx, double* __restrict__ part, int lane,
-                                             double* __restrict__ tile, int LEN_rt)
+                                             double* __restrict__ tile, int LEN_rt,
+                                             const double* __restrict__ xvec, double* __restrict__ jtp,
+                                             double* __restrict__ jtx_out)
 {
+  constexpr int KD = ASM_KG_DW;
   // CLEN > 0: the tile row stride is a compile-time constant (the usual 16-column window), so the
   // LDS offsets of the unrolled k-groups become instruction immediates
   const int LEN = CLEN > 0 ? CLEN : LEN_rt;
@@ -272,21 +279,24 @@ __device__ __forceinline__ void asm_mfma_run(const AsmRun& R, const AsmMTask* __
   // persistent destinations of both (16 per task)
   const int tlast = R.task1 - 1;
   int tix = R.task0;
-  auto task_fetch = [&](int t) { return reinterpret_cast<const int*>(tasks + min(t, tlast))[min(lane, 11)]; };
+  auto task_fetch = [&](int t) { return reinterpret_cast<const int*>(tasks + min(t, tlast))[min(lane, ASM_MTASK_DW - 1)]; };
   int tcv = task_fetch(tix), tnv = task_fetch(tix + 1);
   int pdc = pdest[16*(int64_t)min(tix, tlast) + m], pdn = pdest[16*(int64_t)min(tix + 1, tlast) + m];
   int64_t Tpart, Trpart, colT, colP;     // current task: partial offsets; Lx offset of this lane's column
+  int Tjvar = -1;                        // ... first variable of J if the task writes Jt*x itself
   auto task_unpack = [&](int v) {
+    if(JTX) Tjvar = __builtin_amdgcn_readlane(v, 12);
     const int ld = __builtin_amdgcn_readlane(v, 4);
     const int64_t panel = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readlane(v, 7) << 32) | (uint32_t)__builtin_amdgcn_readlane(v, 6));
     Tpart  = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readlane(v, 9) << 32) | (uint32_t)__builtin_amdgcn_readlane(v, 8));
     Trpart = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readlane(v, 11) << 32) | (uint32_t)__builtin_amdgcn_readlane(v, 10));
     colT = panel + (int64_t)bb*ld; colP = panel + (int64_t)m*ld; };
   task_unpack(tcv);
-  // k-group records of one iteration: ASM_U*6 dwords, one vector load, prefetched one iteration ahead
-  static_assert(ASM_U*6 <= 64, "k-group records of an iteration must fit one wave load");
+  // k-group records of one iteration: ASM_U*KD dwords, one vector load, prefetched one iteration ahead
+  static_assert(ASM_U*KD <= 64, "k-group records of an iteration must fit one wave load");
   const int kglast = R.kg1 - 1;
-  const int krec = min(lane, ASM_U*6 - 1)/6, kw = min(lane, ASM_U*6 - 1) - 6*krec;
+  const int krec = min(lane, ASM_U*KD - 1)/KD, kw = min(lane, ASM_U*KD - 1) - KD*krec;
+  double jacc = 0.0;
   auto kg_fetch = [&](int kg0) { return reinterpret_cast<const int*>(kgs + min(kg0 + krec, kglast))[kw]; };
   int gnv = kg_fetch(R.kg0);
   double* myrow = tile + kq*LEN;
@@ -298,7 +308,13 @@ __device__ __forceinline__ void asm_mfma_run(const AsmRun& R, const AsmMTask* __
     uint32_t meta[ASM_U];
     int td[ASM_U];
 #pragma unroll
-    for(int u = 0; u < ASM_U; u++) meta[u] = kg + u <= kglast ? (uint32_t)__builtin_amdgcn_readlane(gv, 6*u + 5) : 0u;
+    for(int u = 0; u < ASM_U; u++) meta[u] = kg + u <= kglast ? (uint32_t)__builtin_amdgcn_readlane(gv, KD*u + 5) : 0u;
+    double xv[ASM_U];
+    if(JTX)
+    {
+#pragma unroll
+      for(int u = 0; u < ASM_U; u++) xv[u] = xvec[__builtin_amdgcn_ds_bpermute(4*(KD*u + 6 + kq), gv)];    // (rows past the end: row 0, times zeros)
+    }
     // (a) one coalesced copy of the rows' windows into the tile (absent rows: zeros)
     for(int c0 = 0; c0 < ncopy; c0 += 16)
     {
@@ -307,7 +323,7 @@ __device__ __forceinline__ void asm_mfma_run(const AsmRun& R, const AsmMTask* __
 #pragma unroll
       for(int u = 0; u < ASM_U; u++)
       {
-        b[u] = __builtin_amdgcn_ds_bpermute(4*(6*u + kq), gv);
+        b[u] = __builtin_amdgcn_ds_bpermute(4*(KD*u + kq), gv);
         if(kg + u > kglast) b[u] = -1;
         v[u] = vals[max(b[u], 0) + col0 + min(c0 + m, ncopy - 1)];
       }
@@ -321,7 +337,7 @@ __device__ __forceinline__ void asm_mfma_run(const AsmRun& R, const AsmMTask* __
       {
         // transient destinations of this k-group: entry `lane` of its list (slot-major)
         const int nent = (int)((meta[u] >> 8) & 7)*nT;
-        td[u] = tdest[lane < nent ? __builtin_amdgcn_readlane(gv, 6*u + 4) + lane : 0];
+        td[u] = tdest[lane < nent ? __builtin_amdgcn_readlane(gv, KD*u + 4) + lane : 0];
       }
     }
     gnv = kg_fetch(kg + ASM_U);
@@ -331,7 +347,9 @@ __device__ __forceinline__ void asm_mfma_run(const AsmRun& R, const AsmMTask* __
     for(int u = 0; u < ASM_U; u++)
     {
       const double* row = myrow + u*4*LEN;
-      accP = __builtin_amdgcn_mfma_f64_16x16x4f64(row[pc], row[bcolP], accP, 0, 0, 0);
+      const double bP = row[bcolP];
+      accP = __builtin_amdgcn_mfma_f64_16x16x4f64(row[pc], bP, accP, 0, 0, 0);
+      if(JTX) jacc += xv[u]*bP;
       if(HAS_T)
       {
         const int myslot = (meta[u] >> (2*kq)) & 3;
@@ -367,6 +385,18 @@ __device__ __forceinline__ void asm_mfma_run(const AsmRun& R, const AsmMTask* __
             }
           }
         accP = (dlg_v4d){0.0, 0.0, 0.0, 0.0};
+        if(JTX)
+        {
+          // the four rows of the k-groups sit in the four lane groups: (0 + 1) + (2 + 3)
+          double t = jacc + __shfl_xor(jacc, 16);
+          t += __shfl_xor(t, 32);
+          if(kq == 0)
+          {
+            if(Tjvar >= 0 && m < nJ) jtx_out[Tjvar + m] = t;     // the only task of its block: (Jt x)[J] is complete
+            else jtp[16*(int64_t)tix + m] = t;                   // (a rider on board still leaves its part of the record)
+          }
+          jacc = 0.0;
+        }
         tix++;
         task_unpack(tnv); pdc = pdn;
         tnv = task_fetch(tix + 1);
@@ -387,14 +417,16 @@ __device__ __forceinline__ void asm_mfma_run(const AsmRun& R, const AsmMTask* __
 #else
 #define ASM_WPE_ATTR
 #endif
-template <int CLEN>
+template <int CLEN, bool JTX>
 __global__ void __launch_bounds__(TPB) ASM_WPE_ATTR k_assemble_mfma(const AsmRun* __restrict__ runs, int nruns,
                                                        const AsmMTask* __restrict__ tasks,
                                                        const AsmKG* __restrict__ kgs,
                                                        const AsmShape* __restrict__ shapes,
                                                        const int* __restrict__ tdest, const int* __restrict__ pdest,
                                                        const double* __restrict__ vals,
-                                                       double* __restrict__ Lx, double* __restrict__ part, int LEN)
+                                                       double* __restrict__ Lx, double* __restrict__ part, int LEN,
+                                                       const double* __restrict__ xvec, double* __restrict__ jtp,
+                                                       double* __restrict__ jtx_out)
 {
   extern __shared__ double asm_tiles[];
   const int lane = threadIdx.x & 63;
@@ -403,8 +435,54 @@ __global__ void __launch_bounds__(TPB) ASM_WPE_ATTR k_assemble_mfma(const AsmRun
   const AsmRun R = runs[wid];
   const AsmShape* SH = shapes + tasks[R.task0].shape;
   double* tile = asm_tiles + (threadIdx.x >> 6)*(ASM_U*4*LEN);
-  if(SH->MT > 0) asm_mfma_run<true, CLEN>(R, tasks, SH, kgs, tdest, pdest, vals, Lx, part, lane, tile, LEN);
-  else           asm_mfma_run<false, CLEN>(R, tasks, SH, kgs, tdest, pdest, vals, Lx, part, lane, tile, LEN);
+  if(SH->MT > 0) asm_mfma_run<true, CLEN, JTX>(R, tasks, SH, kgs, tdest, pdest, vals, Lx, part, lane, tile, LEN, xvec, jtp, jtx_out);
+  else           asm_mfma_run<false, CLEN, JTX>(R, tasks, SH, kgs, tdest, pdest, vals, Lx, part, lane, tile, LEN, xvec, jtp, jtx_out);
+}
+// Jt*x from the records the assembly kernel left (JTX): var-block v = blks[...] sums its list in order.
+// short lists: 16 threads per var-block (thread = entry of the block); long ones (a dense block that
+// every task carries as a rider): a workgroup per var-block, 64 strided sub-sums, then those in order.
+__global__ void __launch_bounds__(TPB) k_jtx_fin2_short(const int* __restrict__ blks, int nblk,
+                                                        const int* __restrict__ jf_ptr, const int* __restrict__ jf_ent,
+                                                        const int* __restrict__ var0, const int* __restrict__ wv,
+                                                        const double* __restrict__ jtp, double* __restrict__ Jt_x)
+{
+  const int g = blockIdx.x*(TPB/16) + (threadIdx.x >> 4), a = threadIdx.x & 15;
+  if(g >= nblk) return;
+  const int v = blks[g];
+  if(a >= wv[v]) return;
+  double sum = 0.0;
+  for(int e = jf_ptr[v]; e < jf_ptr[v+1]; e++) sum += jtp[jf_ent[e] + a];
+  Jt_x[var0[v] + a] = sum;
+}
+__global__ void __launch_bounds__(1024) k_jtx_fin2_long(const int* __restrict__ blks,
+                                                        const int* __restrict__ jf_ptr, const int* __restrict__ jf_ent,
+                                                        const int* __restrict__ var0, const int* __restrict__ wv,
+                                                        const double* __restrict__ jtp, double* __restrict__ Jt_x)
+{
+  __shared__ double sh[64*16];
+  const int v = blks[blockIdx.x], a = threadIdx.x & 15, g = threadIdx.x >> 4;
+  const int e0 = jf_ptr[v], e1 = jf_ptr[v+1];
+  double sum = 0.0;
+  if(a < wv[v])
+    for(int e = e0 + g; e < e1; e += 64*16)
+    {
+      // sixteen records in flight (their indices first), added in list order
+      int ix[16]; double t[16];
+#pragma unroll
+      for(int u = 0; u < 16; u++) ix[u] = jf_ent[min(e + 64*u, e1 - 1)];
+#pragma unroll
+      for(int u = 0; u < 16; u++) t[u] = jtp[ix[u] + a];
+#pragma unroll
+      for(int u = 0; u < 16; u++) sum += (e + 64*u < e1) ? t[u] : 0.0;
+    }
+  sh[g*16 + a] = sum;
+  __syncthreads();
+  if(g == 0 && a < wv[v])
+  {
+    double tot = 0.0;
+    for(int k = 0; k < 64; k++) tot += sh[k*16 + a];
+    Jt_x[var0[v] + a] = tot;
+  }
 }
 // persistent blocks written by several MFMA tasks: fixed-order sum of the listed partials.
 // k_assemble_fin2_short: one wave per block (lists of <= 32 partials);
@@ -709,7 +787,7 @@ int sparse_norm2_Jv(dlg_backend* b, int s, const double* v, double* out_dev)
 }
 
 // the assembly launches: JtJ of the local rows (values Jv) into the zeroed panel buffer
-static int assemble_launch(dlg_backend* b, const double* Jv, double* Lx = nullptr)
+static int assemble_launch(dlg_backend* b, const double* Jv, double* Lx = nullptr, const double* xvec = nullptr, double* Jt_x = nullptr)
 {
   SparseSym* Y = b->sym;
   const SymHost& H = Y->H;
@@ -723,19 +801,40 @@ static int assemble_launch(dlg_backend* b, const double* Jv, double* Lx = nullpt
     if(nmt > 0)
     {
       const int nruns = (int)H.asm_run.size();
-      if(H.asm_lds_len == 18)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_assemble_mfma<18>), dim3(dlg_cdiv(nruns, TPB/64)), dim3(TPB),
+      const double* nox = nullptr; double* nojt = nullptr;
+      if(H.asm_lds_len == 18 && xvec)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_assemble_mfma<18, true>), dim3(dlg_cdiv(nruns, TPB/64)), dim3(TPB),
                            sizeof(double)*(TPB/64)*ASM_U*4*18, st, Y->asm_run, nruns, Y->asm_mtask,
-                           Y->asm_kg, Y->asm_shape, Y->asm_tdest, Y->asm_pdest, Jv, Lx, Y->asm_part, 18);
-      else
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_assemble_mfma<0>), dim3(dlg_cdiv(nruns, TPB/64)), dim3(TPB),
+                           Y->asm_kg, Y->asm_shape, Y->asm_tdest, Y->asm_pdest, Jv, Lx, Y->asm_part, 18, xvec, Y->jtp, Jt_x);
+      else if(xvec)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_assemble_mfma<0, true>), dim3(dlg_cdiv(nruns, TPB/64)), dim3(TPB),
                            sizeof(double)*(TPB/64)*ASM_U*4*H.asm_lds_len, st, Y->asm_run, nruns, Y->asm_mtask,
                            Y->asm_kg, Y->asm_shape, Y->asm_tdest, Y->asm_pdest, Jv, Lx, Y->asm_part,
-                           H.asm_lds_len);
+                           H.asm_lds_len, xvec, Y->jtp, Jt_x);
+      else if(H.asm_lds_len == 18)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_assemble_mfma<18, false>), dim3(dlg_cdiv(nruns, TPB/64)), dim3(TPB),
+                           sizeof(double)*(TPB/64)*ASM_U*4*18, st, Y->asm_run, nruns, Y->asm_mtask,
+                           Y->asm_kg, Y->asm_shape, Y->asm_tdest, Y->asm_pdest, Jv, Lx, Y->asm_part, 18, nox, nojt, nojt);
+      else
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_assemble_mfma<0, false>), dim3(dlg_cdiv(nruns, TPB/64)), dim3(TPB),
+                           sizeof(double)*(TPB/64)*ASM_U*4*H.asm_lds_len, st, Y->asm_run, nruns, Y->asm_mtask,
+                           Y->asm_kg, Y->asm_shape, Y->asm_tdest, Y->asm_pdest, Jv, Lx, Y->asm_part,
+                           H.asm_lds_len, nox, nojt, nojt);
     }
     if(nt > 0)
       hipLaunchKernelGGL(k_assemble, dim3(dlg_cdiv(nt, TPB/64)), dim3(TPB), 0, st, Y->asm_ctask, nt,
                          Y->asm_batch, Y->asm_rho, Y->asm_pair, Y->asm_slot, Jv, Lx, Y->asm_part);
+  }
+  if(xvec)
+  {
+    // Jt*x from the task records (first: it is what the caller waits for)
+    const int ns = (int)H.jf_short.size(), nl = (int)H.jf_long.size();
+    if(ns > 0)
+      hipLaunchKernelGGL(k_jtx_fin2_short, dim3(dlg_cdiv(ns, TPB/16)), dim3(TPB), 0, st, Y->jf_short, ns, Y->jf_ptr,
+                         Y->jf_ent, Y->jf_var0, Y->jf_w, Y->jtp, Jt_x);
+    if(nl > 0)
+      hipLaunchKernelGGL(k_jtx_fin2_long, dim3(nl), dim3(1024), 0, st, Y->jf_long, Y->jf_ptr, Y->jf_ent,
+                         Y->jf_var0, Y->jf_w, Y->jtp, Jt_x);
   }
   for(size_t q = 0; q + 2 < H.fin2_stage.size(); q += 3)
   {
@@ -957,6 +1056,36 @@ int sparse_assemble_speculative(dlg_backend* b, int s)
   DLG_CHECK(rc);
   DLG_HIP(hipEventRecord(Y->ev_spec, b->aux_stream));
   Y->spec_inflight = true; Y->spec_valid = true; Y->spec_slot = s; Y->spec_J = S.Jin();
+  return DLG_OK;
+}
+// K1 + K4 in one pass over J: the assembly kernel forms Jt*x of its rows as a by-product (JTX), the
+// panels go to the second panel buffer and are adopted by the factorisation of this slot's point
+// (sparse_assemble) like a speculative assembly -- only that nothing is speculative about the pass
+// over J: the gradient is needed at every evaluation.  *done = 0 if the schedule cannot (a column
+// block assembled by the LDS kernel, sharded rows): the caller runs K1.
+int sparse_eval_assemble(dlg_backend* b, int s, int* done)
+{
+  *done = 0;
+  SparseSym* Y = b->sym;
+  if(!Y) { dlg_set_error("dlg_sparse_set_pattern must be called first"); return DLG_ERR_STATE; }
+  const SymHost& H = Y->H;
+  if(!H.asm_jtx_ok || !Y->jtp || b->sharded() || H.part_nranks > 1) return DLG_OK;
+  DlgSlot& S = b->slot[s];
+  hipStream_t st = b->stream;
+  if(!Y->Lx_spec)
+  {
+    DLG_HIP(hipMalloc(&Y->Lx_spec, sizeof(double)*(size_t)(H.lx_size ? H.lx_size : 1))); Y->allocs.push_back(Y->Lx_spec);
+    DLG_HIP(hipEventCreateWithFlags(&Y->ev_spec, hipEventDisableTiming));
+    DLG_HIP(hipEventCreateWithFlags(&Y->ev_spec_fork, hipEventDisableTiming));
+  }
+  if(Y->spec_inflight) { DLG_HIP(hipStreamWaitEvent(st, Y->ev_spec, 0)); Y->spec_inflight = false; }    // (shares the partial-sum buffers)
+  if(!H.jtx_covers_all) DLG_HIP(hipMemsetAsync(S.Jt_x, 0, sizeof(double)*(size_t)b->N, st));          // var-blocks without rows
+  {
+    DlgProfScope pt(b, DLG_PROF_K4_TOTAL);
+    DLG_CHECK(assemble_launch(b, S.Jin(), Y->Lx_spec, S.xin(), S.Jt_x));
+  }
+  Y->spec_valid = true; Y->spec_slot = s; Y->spec_J = S.Jin();
+  *done = 1;
   return DLG_OK;
 }
 void sparse_spec_invalidate(dlg_backend* b, int s)

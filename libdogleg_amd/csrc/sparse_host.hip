@@ -49,6 +49,11 @@ int sparse_set_pattern(dlg_backend* b, const int* colptr, const int* rowidx)
   UP(uw_item); UP(uw_s0); UP(uw_s1); UP(uw_part); UP(uf_item); UP(uf_n); UP(uf_off);
   UP(oblk); UP(contrib); UP(jtx_task); UP(jtx_fin_ptr); UP(jtx_fin_blk);
   UP(asm_rho); UP(asm_pair); UP(asm_slot); UP(asm_batch); UP(asm_ctask); UP(asm_cfin);
+  if(H.asm_jtx_ok)
+  {
+    UP(jf_ptr); UP(jf_ent); UP(jf_var0); UP(jf_w); UP(jf_short); UP(jf_long);
+    DLG_HIP(hipMalloc(&Y->jtp, sizeof(double)*16*std::max<size_t>(1, H.asm_mtask.size()))); Y->allocs.push_back(Y->jtp);
+  }
   UP(asm_shape); UP(asm_kg); UP(asm_mtask); UP(asm_tdest); UP(asm_fin2); UP(asm_fin2_list); UP(asm_run); UP(asm_pdest);
   UP(rl_ptr); UP(rl_pos); UP(perm); UP(col_sn); UP(sn_owner); UP(xl_sn); UP(fw_sn); UP(fw_r0); UP(fw_r1); UP(ms_sn); UP(sn_top); UP(sn_bd_ptr); UP(sn_bd_col);
   {

@@ -81,6 +81,8 @@ struct SparseSym
   AsmRho* asm_rho = nullptr; AsmPair* asm_pair = nullptr; AsmSlot* asm_slot = nullptr;
   AsmBatch* asm_batch = nullptr; AsmTask* asm_ctask = nullptr; AsmFin* asm_cfin = nullptr;
   AsmShape* asm_shape = nullptr; AsmKG* asm_kg = nullptr; AsmMTask* asm_mtask = nullptr; int* asm_tdest = nullptr;
+  int *jf_ptr = nullptr, *jf_ent = nullptr, *jf_var0 = nullptr, *jf_w = nullptr, *jf_short = nullptr, *jf_long = nullptr;
+  double* jtp = nullptr;        // [16 per MFMA task] Jt*x records of the assembly kernel (sparse_eval_assemble)
   AsmFin2* asm_fin2 = nullptr; int64_t* asm_fin2_list = nullptr; AsmRun* asm_run = nullptr; int* asm_pdest = nullptr;
   int *rl_ptr = nullptr, *rl_pos = nullptr, *perm = nullptr, *col_sn = nullptr;
   int *fw_sn = nullptr, *fw_r0 = nullptr, *fw_r1 = nullptr, *ms_sn = nullptr; int64_t* sn_top = nullptr;
@@ -127,6 +129,7 @@ struct SparseSym
 int sparse_assemble(dlg_backend* b, int s, double lambda);   // K4 (+ all-reduce, lambda, augmented row)
 int sparse_partition_reduce(dlg_backend* b);
 int sparse_assemble_speculative(dlg_backend* b, int s);     // K4 on the second stream, beside K1
+int sparse_eval_assemble(dlg_backend* b, int s, int* done);   // K1 + K4 in one pass over J
 void sparse_spec_invalidate(dlg_backend* b, int s);                 // subtree partition: the sum over the ranks at the cut
 int sparse_factor_setup(dlg_backend* b);                     // per-level launch parameters of K5
 int sparse_factor_levels(dlg_backend* b);                    // K5 launches (no synchronisation)

@@ -1190,6 +1190,7 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
       }
     }
     std::vector<int> mtask_acc;          // accumulator size of every MFMA task (parallel to asm_mtask)
+    std::vector<int> mtask_blk, mtask_rider;   // ... its column block, the rider it carries (-1: none)
     std::vector<Cls> classes;
     std::vector<int> cnt_same, key;
     std::vector<std::vector<int64_t>> fin_lists;
@@ -1360,6 +1361,7 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
         auto close_task = [&]() { close_kg(); if(task_open) { S.asm_mtask.back().kg1 = (int)S.asm_kg.size(); task_open = false; } };
         auto open_kg = [&]() {
           AsmKG g; g.base[0] = g.base[1] = g.base[2] = g.base[3] = -1; g.tq = (int)S.asm_tdest.size(); g.meta = 0;
+          g.xr[0] = g.xr[1] = g.xr[2] = g.xr[3] = 0;
           S.asm_kg.push_back(g); kg_open = true; kg_rows = 0; kg_slots = 0; kg_in_task++; };
         for(int e : C.es)
         {
@@ -1370,8 +1372,8 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
           {
             close_task();
             AsmMTask T; T.kg0 = (int)S.asm_kg.size(); T.kg1 = -1; T.slot0 = C.slot0; T.shape = C.shape; T.ld = ld;
-            T.pq = C.pq; T.panel = panel; T.part = -1; T.rpart = -1;
-            mtask_acc.push_back(C.acc_size);
+            T.pq = C.pq; T.panel = panel; T.part = -1; T.rpart = -1; T.jvar = -1; T.pad = 0;
+            mtask_acc.push_back(C.acc_size); mtask_blk.push_back(J); mtask_rider.push_back(C.rider);
             if(C.rider >= 0)
             {
               const int nr = G.w[C.rider];
@@ -1388,7 +1390,8 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
             for(int h = 0; h < 2; h++)
             {
               open_kg(); S.asm_kg.back().tq = tq;
-              for(int r = 4*h; r < std::min(b.nrows, 4*h + 4); r++) S.asm_kg.back().base[r - 4*h] = base + r*b.len;
+              for(int r = 4*h; r < std::min(b.nrows, 4*h + 4); r++)
+              { S.asm_kg.back().base[r - 4*h] = base + r*b.len; S.asm_kg.back().xr[r - 4*h] = b.lr0 + r; }
               kg_slots = 1;
               if(h == 0) { S.asm_kg.back().meta |= 1u << 8; kg_open = false; }    // no store yet: the block continues
               else close_kg();
@@ -1399,7 +1402,7 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
             if(!(kg_open && kg_rows + b.nrows <= 4 && kg_slots < smax)) { close_kg(); open_kg(); }
             for(int r = 0; r < b.nrows; r++)
             {
-              S.asm_kg.back().base[kg_rows] = base + r*b.len;
+              S.asm_kg.back().base[kg_rows] = base + r*b.len; S.asm_kg.back().xr[kg_rows] = b.lr0 + r;
               S.asm_kg.back().meta |= (uint32_t)kg_slots << (2*kg_rows);
               kg_rows++;
             }
@@ -1619,6 +1622,31 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
         tasks2.push_back(T);
       }
       S.asm_mtask.swap(tasks2); S.asm_kg.swap(kg2);
+      // Jt*x beside JtJ: which task records every var-block sums (task order)
+      {
+        std::vector<std::vector<int>> ent(nvb);
+        for(int kk = 0; kk < nt; kk++)
+        {
+          const int k = order[kk], J = mtask_blk[k], R = mtask_rider[k];
+          ent[J].push_back(16*kk);
+          if(R >= 0) ent[R].push_back(16*kk + G.w[J]);
+        }
+        S.asm_jtx_ok = use_mfma && S.asm_ctask.empty() && nt > 0;
+        S.jf_ptr.assign(1, 0); S.jf_ent.clear(); S.jf_var0.resize(nvb); S.jf_w.resize(nvb);
+        S.jf_short.clear(); S.jf_long.clear();
+        for(int v = 0; v < nvb; v++)
+        {
+          S.jf_ent.insert(S.jf_ent.end(), ent[v].begin(), ent[v].end());
+          S.jf_ptr.push_back((int)S.jf_ent.size());
+          S.jf_var0[v] = S.vb_start[v]; S.jf_w[v] = G.w[v];
+          if(G.w[v] > 16 || (ent[v].empty() && rptr[v+1] > rptr[v])) S.asm_jtx_ok = false;
+          if(ent[v].empty()) continue;                 // no rows: its entries of Jt*x stay zero
+          // a single record that is the block's own task (not a ride on another block's): the kernel
+          // writes Jt*x itself
+          if(ent[v].size() == 1 && (ent[v][0] & 15) == 0) { S.asm_mtask[ent[v][0] >> 4].jvar = S.vb_start[v]; continue; }
+          if(ent[v].size() <= 64) S.jf_short.push_back(v); else S.jf_long.push_back(v);
+        }
+      }
       // persistent destinations, 16 per task in task order (the kernel prefetches them by task index)
       {
         std::vector<int> pd2((size_t)nt*16, 0);

@@ -116,8 +116,11 @@ struct AsmKG
   int32_t  base[4];             // first value of each of the 4 rows, -1: no row
   int32_t  tq;                  // first entry in asm_tdest of row-block slot 0 (slot s: + s*nT)
   uint32_t meta;                // bits 0-7: row-block slot of each row (2 bits each); 8-10: #slots; 11: store transients
+  int32_t  xr[4];               // the rows themselves (index into the rank's x), 0 where there is none: the
+                                // kernel can form Jt*x beside JtJ (it holds every J(row, column of J) anyway)
 };
-static_assert(sizeof(AsmKG) == 24, "AsmKG layout");
+static_assert(sizeof(AsmKG) == 40, "AsmKG layout");
+constexpr int ASM_KG_DW = 10;   // dwords per record
 struct AsmMTask
 {
   int32_t kg0, kg1, slot0, shape;
@@ -126,8 +129,11 @@ struct AsmMTask
   int64_t panel;                // Lx offset of (row 0, first column of J) of J's panel
   int64_t part;                 // offset into the partial buffer, or -1: write the panels directly
   int64_t rpart;                // partial of the rider's diagonal block (shape.nJr > 0)
+  int32_t jvar;                 // Jt*x beside JtJ: first variable of J if this is the ONLY task of J (the kernel
+  int32_t pad;                  // writes (Jt x)[J] itself), else -1 (its record is summed by k_jtx_fin2_*)
 };
-static_assert(sizeof(AsmMTask) == 48, "AsmMTask layout");
+static_assert(sizeof(AsmMTask) == 56, "AsmMTask layout");
+constexpr int ASM_MTASK_DW = 14;
 // a wave's work: consecutive tasks of one shape; their k-groups are contiguous
 struct AsmRun { int32_t task0, task1, kg0, kg1; };
 // a persistent block written by several tasks: sum of the listed partials, in list order
@@ -260,6 +266,11 @@ struct SymHost
   std::vector<AsmFin2>  asm_fin2;     // grouped in stages (long lists are summed hierarchically)
   std::vector<int64_t>  asm_fin2_list;
   int asm_lds_len = 0;                // LDS row stride (doubles) of the MFMA assembly kernel
+  // Jt*x out of the assembly kernel: every MFMA task leaves a 16-double record (lanes 0..nJ-1: its own
+  // column block, nJ..: the rider it carries); var-block v sums the records jf_ent[jf_ptr[v] .. jf_ptr[v+1])
+  // (entry = 16*task + first lane) in that order.  asm_jtx_ok: every var-block with rows is covered.
+  bool asm_jtx_ok = false;
+  std::vector<int> jf_ptr, jf_ent, jf_var0, jf_w, jf_short, jf_long;
   std::vector<int>      fin2_stage;   // per stage: first entry, #entries with <= 64 partials, #entries with more
   std::vector<AsmRun>   asm_run;
   std::vector<int>      asm_pdest;

@@ -356,10 +356,12 @@ def test_solve_with_the_resident_factor(gpu, kind):
     assert np.allclose(be.solve_with_factor(0, rhs[1]), u[1], rtol=0, atol=0)
 
 
-def test_speculative_assembly_changes_no_bit(gpu):
+def test_speculative_assembly_changes_no_bit(gpu, monkeypatch):
     """dlg_backend_set_speculation: JtJ assembled on the second stream beside Jt*x, adopted by the
     factorisation that follows -- the Gauss-Newton step is bit-identical to the in-line assembly; new
-    inputs, another slot or a second factorisation never pick up a stale assembly"""
+    inputs, another slot or a second factorisation never pick up a stale assembly.  (The one-pass
+    variant, which also changes how Jt*x is summed, is switched off here: next test.)"""
+    monkeypatch.setenv("DOGLEG_AMD_NO_FUSED_EVAL", "1")
     prob = oa.BAProblem(49, 900, 10000, seed=3)
     Jp, Ji = prob.pattern()
     p = prob.p0()
@@ -429,3 +431,44 @@ def test_persistent_top_region_changes_no_bit(gpu, shape, monkeypatch):
     for mode in ("default", "deep"):
         for a, b in zip(out["off"], out[mode]):
             assert a[0] == b[0] and a[1] == b[1] and np.array_equal(a[2], b[2]), mode
+
+
+@pytest.mark.parametrize("shape,kw", [((49, 900, 10000), {}), ((6, 60, 400), {}), ((30, 500, 4000), dict(n_zero_cols=2))])
+def test_gradient_out_of_the_assembly_pass(gpu, shape, kw):
+    """JtJ assembled in the pass over J that forms Jt*x (sparse_eval_assemble: the assembly kernel's B
+    operand times x): Jt*x agrees with K1's own pass to rounding (another summation order) and with
+    the host's product; the panels are those of the separate assembly bit for bit -- the same
+    right-hand side through both gives the same step; stale assemblies are never adopted"""
+    prob = oa.BAProblem(*shape, seed=3, **kw)
+    Jp, Ji = prob.pattern()
+    p = prob.p0()
+    x, Jx = prob.eval(p)
+    x2, Jx2 = prob.eval(p + 0.01)
+    import scipy.sparse as sp
+    Jt = sp.csc_matrix((Jx, Ji, Jp), shape=(prob.N, prob.M))
+    ref = Jt @ x
+    bound = 2e-12*(abs(Jt) @ np.abs(x)) + 1e-300          # a few thousand terms per entry, any summation order
+    out = {}
+    for fused in (False, True):
+        be = capi.Backend(capi.DLG_SPARSE, prob.N, prob.M, prob.nnz)
+        be.set_pattern(Jp, Ji)
+        be.set_speculation(fused)
+        be.set_p(0, p)
+        be.upload(0, x, Jx)
+        be.eval(0)
+        jtx = be.download(0, capi.VEC_JTX)
+        lam, n2g = be.gauss_newton(0, 0.0)
+        gn = be.download(0, capi.VEC_GN)
+        be.upload(0, x2, Jx2)                  # new inputs: the panels of the first evaluation must not be adopted
+        be.eval(0)
+        be.upload(1, x, Jx)
+        be.eval(1)                             # ... nor slot 1's for slot 0
+        lam2, n2g2 = be.gauss_newton(0, 1e-3)
+        gn2 = be.download(0, capi.VEC_GN)
+        out[fused] = (jtx, lam, n2g, gn, lam2, n2g2, gn2)
+        be.close()
+    a, b = out[False], out[True]
+    assert np.all(np.abs(b[0] - ref) <= bound) and np.all(np.abs(a[0] - ref) <= bound)
+    assert a[1] == b[1] and a[4] == b[4]
+    for k in (3, 6):
+        assert np.max(np.abs(a[k] - b[k])) <= 1e-11*max(1.0, np.max(np.abs(a[k])))
