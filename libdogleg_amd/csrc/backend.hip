@@ -192,6 +192,7 @@ extern "C" void dlg_backend_destroy(dlg_backend_t* b)
   if(b->ev_join) { (void)hipEventDestroy(b->ev_join); b->ev_join = nullptr; }
   if(b->ev_step) { (void)hipEventDestroy(b->ev_step); b->ev_step = nullptr; }
   if(b->ev_copy) { (void)hipEventDestroy(b->ev_copy); b->ev_copy = nullptr; }
+  if(b->ev_fetch) { (void)hipEventDestroy(b->ev_fetch); b->ev_fetch = nullptr; }
   if(b->own_stream && b->stream) (void)hipStreamDestroy(b->stream);
   delete b;
 }
@@ -469,7 +470,17 @@ extern "C" int dlg_point_eval(dlg_backend_t* b, int s, double* norm2_x, double* 
       DLG_HIP(hipMemcpyAsync(b->d_scal, b->d_red + b->N, sizeof(double), hipMemcpyDeviceToDevice, b->stream));
     }
     DLG_CHECK(k_norm2_absmax(b, S.Jt_x, b->N, b->d_scal + 2));
-    DLG_CHECK(dlg_fetch_scalars(b, 4));
+    if(fused)
+    {
+      // the scalars go to the host first; the partial-sum stages of JtJ run while the host gets them
+      if(!b->ev_fetch) DLG_HIP(hipEventCreateWithFlags(&b->ev_fetch, hipEventDisableTiming));
+      DLG_HIP(hipMemcpyAsync(b->h_scal, b->d_scal, sizeof(double)*4, hipMemcpyDeviceToHost, b->stream));
+      DLG_HIP(hipEventRecord(b->ev_fetch, b->stream));
+      DLG_CHECK(sparse_assemble_finish(b));
+      DLG_HIP(hipEventSynchronize(b->ev_fetch));
+      dlg_resolve_pending(b);
+    }
+    else DLG_CHECK(dlg_fetch_scalars(b, 4));
     S.norm2_x = b->h_scal[0];
   }
   S.have_Jtx = true;
@@ -633,6 +644,7 @@ static int gauss_newton_impl(dlg_backend_t* b, int s, double* lambda_io, double*
       DLG_CHECK(cauchy_fork_enqueue(b, s, b->d_scal + 4));
       cauchy_pending = true;
     }
+    if(b->type == DLG_SPARSE) DLG_CHECK(sparse_zero_spare(b));
     {
       DlgProfScope ps(b, DLG_PROF_K6_SOLVE);
       if(b->type == DLG_SPARSE) DLG_CHECK(sparse_solve(b, S.Jt_x, S.gn));
@@ -846,6 +858,7 @@ extern "C" int dlg_take_step(dlg_backend_t* b, int from, int to, double trustreg
       DLG_CHECK(rc);
     }
     if(do_cauchy) DLG_CHECK(cauchy_fork_enqueue(b, from, b->d_scal + 4));     // K3 beside K5 (second stream)
+    if(b->type == DLG_SPARSE) DLG_CHECK(sparse_zero_spare(b));
     {
       DlgProfScope ps(b, DLG_PROF_K6_SOLVE);
       if(b->type == DLG_SPARSE) DLG_CHECK(sparse_solve(b, F.Jt_x, F.gn));

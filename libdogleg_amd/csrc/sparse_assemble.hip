@@ -787,13 +787,25 @@ int sparse_norm2_Jv(dlg_backend* b, int s, const double* v, double* out_dev)
 }
 
 // the assembly launches: JtJ of the local rows (values Jv) into the zeroed panel buffer
-static int assemble_launch(dlg_backend* b, const double* Jv, double* Lx = nullptr, const double* xvec = nullptr, double* Jt_x = nullptr)
+static int assemble_fin_launch(dlg_backend* b, double* Lx);
+// the partial-sum stages of an assembly whose caller wanted Jt*x first (assemble_launch, defer_fin)
+int sparse_assemble_finish(dlg_backend* b)
+{
+  SparseSym* Y = b->sym;
+  if(!Y || !Y->fin_pending_Lx) return DLG_OK;
+  double* Lx = Y->fin_pending_Lx;
+  Y->fin_pending_Lx = nullptr;
+  return assemble_fin_launch(b, Lx);
+}
+static int assemble_launch(dlg_backend* b, const double* Jv, double* Lx = nullptr, const double* xvec = nullptr, double* Jt_x = nullptr,
+                           bool zeroed = false, bool defer_fin = false)
 {
   SparseSym* Y = b->sym;
   const SymHost& H = Y->H;
   hipStream_t st = b->stream;
+  DLG_CHECK(sparse_assemble_finish(b));             // (an earlier assembly's partial sums live in the buffers this one fills)
   if(!Lx) Lx = Y->Lx;
-  DLG_HIP(hipMemsetAsync(Lx, 0, sizeof(double)*(size_t)H.lx_size, st));
+  if(!zeroed) DLG_HIP(hipMemsetAsync(Lx, 0, sizeof(double)*(size_t)H.lx_size, st));
   const int nt = (int)H.asm_ctask.size(), nmt = (int)H.asm_mtask.size();
   if(nt > 0 || nmt > 0)
   {
@@ -836,6 +848,14 @@ static int assemble_launch(dlg_backend* b, const double* Jv, double* Lx = nullpt
       hipLaunchKernelGGL(k_jtx_fin2_long, dim3(nl), dim3(1024), 0, st, Y->jf_long, Y->jf_ptr, Y->jf_ent,
                          Y->jf_var0, Y->jf_w, Y->jtp, Jt_x);
   }
+  if(defer_fin) { Y->fin_pending_Lx = Lx; DLG_LAUNCH_CHECK(); return DLG_OK; }
+  return assemble_fin_launch(b, Lx);
+}
+static int assemble_fin_launch(dlg_backend* b, double* Lx)
+{
+  SparseSym* Y = b->sym;
+  const SymHost& H = Y->H;
+  hipStream_t st = b->stream;
   for(size_t q = 0; q + 2 < H.fin2_stage.size(); q += 3)
   {
     const int f0 = H.fin2_stage[q], ns = H.fin2_stage[q+1], nl = H.fin2_stage[q+2];
@@ -923,10 +943,15 @@ int sparse_assemble(dlg_backend* b, int s, double lambda)
     DLG_HIP(hipStreamWaitEvent(st, Y->ev_spec, 0));
     Y->spec_inflight = false;
   }
+  DLG_CHECK(sparse_assemble_finish(b));
   if(Y->spec_valid && Y->spec_slot == s && Y->spec_J == S.Jin())
   {
     std::swap(Y->Lx, Y->Lx_spec);           // the panels assembled beside K1 become the factor's panels
     Y->spec_valid = false;
+    // the other buffer (the previous factor) is free from here on: sparse_zero_spare clears it on the
+    // second stream while the factorisation is latency-bound, the next evaluation finds it zeroed
+    Y->spare_zeroed = false;
+    if(b->aux_stream && Y->ev_swap && hipEventRecord(Y->ev_swap, st) == hipSuccess) Y->spare_dirty = true;
   }
   else
   {
@@ -1050,6 +1075,7 @@ int sparse_assemble_speculative(dlg_backend* b, int s)
   int rc;
   {
     DlgProfScope pt(b, DLG_PROF_K4_TOTAL);
+    Y->spare_zeroed = false; Y->spare_dirty = false;
     rc = assemble_launch(b, S.Jin(), Y->Lx_spec);
   }
   b->stream = main_stream;
@@ -1078,14 +1104,36 @@ int sparse_eval_assemble(dlg_backend* b, int s, int* done)
     DLG_HIP(hipEventCreateWithFlags(&Y->ev_spec, hipEventDisableTiming));
     DLG_HIP(hipEventCreateWithFlags(&Y->ev_spec_fork, hipEventDisableTiming));
   }
+  if(!Y->ev_swap)
+  {
+    DLG_HIP(hipEventCreateWithFlags(&Y->ev_swap, hipEventDisableTiming));
+    DLG_HIP(hipEventCreateWithFlags(&Y->ev_zero, hipEventDisableTiming));
+  }
   if(Y->spec_inflight) { DLG_HIP(hipStreamWaitEvent(st, Y->ev_spec, 0)); Y->spec_inflight = false; }    // (shares the partial-sum buffers)
   if(!H.jtx_covers_all) DLG_HIP(hipMemsetAsync(S.Jt_x, 0, sizeof(double)*(size_t)b->N, st));          // var-blocks without rows
+  const bool zeroed = Y->spare_zeroed;
+  if(zeroed) DLG_HIP(hipStreamWaitEvent(st, Y->ev_zero, 0));
+  Y->spare_zeroed = false; Y->spare_dirty = false;
   {
     DlgProfScope pt(b, DLG_PROF_K4_TOTAL);
-    DLG_CHECK(assemble_launch(b, S.Jin(), Y->Lx_spec, S.xin(), S.Jt_x));
+    // (the partial-sum stages of JtJ wait until the caller has Jt*x on its way to the host: sparse_assemble_finish)
+    DLG_CHECK(assemble_launch(b, S.Jin(), Y->Lx_spec, S.xin(), S.Jt_x, zeroed, true));
   }
   Y->spec_valid = true; Y->spec_slot = s; Y->spec_J = S.Jin();
   *done = 1;
+  return DLG_OK;
+}
+// the panel buffer that a factorisation just left behind (sparse_assemble swapped it out) is cleared on
+// the second stream, behind the Cauchy step's pass over J if there is one: off the critical path
+int sparse_zero_spare(dlg_backend* b)
+{
+  SparseSym* Y = b->sym;
+  if(!Y || !Y->spare_dirty || !b->aux_stream || !b->overlap || !Y->Lx_spec) return DLG_OK;
+  Y->spare_dirty = false;
+  DLG_HIP(hipStreamWaitEvent(b->aux_stream, Y->ev_swap, 0));
+  DLG_HIP(hipMemsetAsync(Y->Lx_spec, 0, sizeof(double)*(size_t)Y->H.lx_size, b->aux_stream));
+  DLG_HIP(hipEventRecord(Y->ev_zero, b->aux_stream));
+  Y->spare_zeroed = true;
   return DLG_OK;
 }
 void sparse_spec_invalidate(dlg_backend* b, int s)

@@ -15,6 +15,8 @@ void sparse_destroy(dlg_backend* b)
   if(b->aux_stream) (void)hipStreamSynchronize(b->aux_stream);
   if(Y->ev_spec) (void)hipEventDestroy(Y->ev_spec);
   if(Y->ev_spec_fork) (void)hipEventDestroy(Y->ev_spec_fork);
+  if(Y->ev_swap) (void)hipEventDestroy(Y->ev_swap);
+  if(Y->ev_zero) (void)hipEventDestroy(Y->ev_zero);
   for(void* p : Y->allocs) if(p) (void)hipFree(p);
   delete Y;
   b->sym = nullptr;
