@@ -986,7 +986,11 @@ int sparse_factor_setup(dlg_backend* b)
       const int s = H.fw_sn[i];
       const long wv = H.sn_c0[s+1] - H.sn_c0[s];
       const long nloc = wv + (H.fw_r1[i] - H.fw_r0[i]);
-      const long p = ((nloc + 1) & ~1L)*wv;        // even leading dimension in LDS
+      // even leading dimension in LDS; unsliced block-diagonal tops (merged leaves) use the compact
+      // layout that never stages the top block (k_factor_level: cmp)
+      const bool cmp = H.sn_bd_ptr[s+1] > H.sn_bd_ptr[s] && H.sn_top[s] < 0;
+      const long mbl = nloc - wv;
+      const long p = (cmp && !getenv("DOGLEG_AMD_LEAF_LDS_FULL")) ? ((mbl + 1) & ~1L)*wv + 8*wv + 1 : ((nloc + 1) & ~1L)*wv;
       if(p > maxp) maxp = p;
       if(nloc > maxr) maxr = nloc;
     }
