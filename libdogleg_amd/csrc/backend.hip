@@ -193,6 +193,8 @@ extern "C" void dlg_backend_destroy(dlg_backend_t* b)
   if(b->ev_step) { (void)hipEventDestroy(b->ev_step); b->ev_step = nullptr; }
   if(b->ev_copy) { (void)hipEventDestroy(b->ev_copy); b->ev_copy = nullptr; }
   if(b->ev_fetch) { (void)hipEventDestroy(b->ev_fetch); b->ev_fetch = nullptr; }
+  if(b->ev_evalfork) { (void)hipEventDestroy(b->ev_evalfork); b->ev_evalfork = nullptr; }
+  if(b->ev_evaljoin) { (void)hipEventDestroy(b->ev_evaljoin); b->ev_evaljoin = nullptr; }
   if(b->own_stream && b->stream) (void)hipStreamDestroy(b->stream);
   delete b;
 }
@@ -448,6 +450,25 @@ extern "C" int dlg_point_eval(dlg_backend_t* b, int s, double* norm2_x, double* 
     // the caller expects to factorise this point: JtJ is assembled in the same pass over J that forms
     // Jt*x (sparse_eval_assemble) or, where that schedule is not available, on the second stream meanwhile
     int fused = 0;
+    bool x_norm_aux = false;
+    if(b->type == DLG_SPARSE && b->speculate && b->fuse_eval && b->overlap && b->aux_stream && !b->sharded() && mloc > 0 && b->host_finals && b->h_part)
+    {
+      // |x|^2 needs nothing but x: on the second stream, beside the pass over J
+      if(!b->ev_evalfork)
+      {
+        DLG_HIP(hipEventCreateWithFlags(&b->ev_evalfork, hipEventDisableTiming));
+        DLG_HIP(hipEventCreateWithFlags(&b->ev_evaljoin, hipEventDisableTiming));
+      }
+      DLG_HIP(hipEventRecord(b->ev_evalfork, b->stream));
+      DLG_HIP(hipStreamWaitEvent(b->aux_stream, b->ev_evalfork, 0));
+      hipStream_t main_stream = b->stream;
+      b->stream = b->aux_stream;
+      const int rc = k_norm2_absmax(b, S.xin(), mloc, b->d_scal);
+      b->stream = main_stream;
+      DLG_CHECK(rc);
+      DLG_HIP(hipEventRecord(b->ev_evaljoin, b->aux_stream));
+      x_norm_aux = true;
+    }
     if(b->type == DLG_SPARSE && b->speculate && b->fuse_eval) DLG_CHECK(sparse_eval_assemble(b, s, &fused));
     if(!fused)
     {
@@ -457,7 +478,8 @@ extern "C" int dlg_point_eval(dlg_backend_t* b, int s, double* norm2_x, double* 
     }
     DlgProfScope pv(b, DLG_PROF_VEC);
     // norm2_x over the local rows
-    if(mloc > 0) DLG_CHECK(k_norm2_absmax(b, S.xin(), mloc, b->d_scal));
+    if(x_norm_aux) DLG_HIP(hipStreamWaitEvent(b->stream, b->ev_evaljoin, 0));
+    else if(mloc > 0) DLG_CHECK(k_norm2_absmax(b, S.xin(), mloc, b->d_scal));
     else         DLG_HIP(hipMemsetAsync(b->d_scal, 0, 2*sizeof(double), b->stream));
     if(b->sharded())
     {
@@ -644,7 +666,6 @@ static int gauss_newton_impl(dlg_backend_t* b, int s, double* lambda_io, double*
       DLG_CHECK(cauchy_fork_enqueue(b, s, b->d_scal + 4));
       cauchy_pending = true;
     }
-    if(b->type == DLG_SPARSE) DLG_CHECK(sparse_zero_spare(b));
     {
       DlgProfScope ps(b, DLG_PROF_K6_SOLVE);
       if(b->type == DLG_SPARSE) DLG_CHECK(sparse_solve(b, S.Jt_x, S.gn));
@@ -736,7 +757,13 @@ static int step_finish(dlg_backend* b, int to, int nscal, double* p_new_host)
     double* dst = pinned ? p_new_host : b->h_vec;
     DLG_HIP(hipMemcpyAsync(dst, T.p, sizeof(double)*(size_t)b->N, hipMemcpyDeviceToHost, b->stream));
   }
-  DLG_HIP(hipStreamSynchronize(b->stream));
+  // The host only waits for what it reads.  Behind that point the stream clears the panel buffer a
+  // factorisation left behind (sparse_zero_spare): the GPU does it while the host digests the step and
+  // evaluates the next point, and that point's assembly finds the buffer zeroed.
+  if(!b->ev_fetch) DLG_HIP(hipEventCreateWithFlags(&b->ev_fetch, hipEventDisableTiming));
+  DLG_HIP(hipEventRecord(b->ev_fetch, b->stream));
+  if(b->type == DLG_SPARSE) DLG_CHECK(sparse_zero_spare(b));
+  DLG_HIP(hipEventSynchronize(b->ev_fetch));
   dlg_resolve_pending(b);
   if(p_new_host && !pinned) memcpy(p_new_host, b->h_vec, sizeof(double)*(size_t)b->N);
   return DLG_OK;
@@ -858,7 +885,6 @@ extern "C" int dlg_take_step(dlg_backend_t* b, int from, int to, double trustreg
       DLG_CHECK(rc);
     }
     if(do_cauchy) DLG_CHECK(cauchy_fork_enqueue(b, from, b->d_scal + 4));     // K3 beside K5 (second stream)
-    if(b->type == DLG_SPARSE) DLG_CHECK(sparse_zero_spare(b));
     {
       DlgProfScope ps(b, DLG_PROF_K6_SOLVE);
       if(b->type == DLG_SPARSE) DLG_CHECK(sparse_solve(b, F.Jt_x, F.gn));

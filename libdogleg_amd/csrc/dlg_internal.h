@@ -57,7 +57,7 @@ struct dlg_backend
   bool own_stream = false;
   // side stream + events: p_new travels to the host while the expected improvement is computed (dlg_step)
   hipStream_t copy_stream = nullptr;
-  hipEvent_t  ev_step = nullptr, ev_copy = nullptr, ev_fetch = nullptr;
+  hipEvent_t  ev_step = nullptr, ev_copy = nullptr, ev_fetch = nullptr, ev_evalfork = nullptr, ev_evaljoin = nullptr;
   // second compute stream: the Cauchy step (one pass over J, independent of the factorisation) runs
   // beside the latency-bound upper levels of the elimination tree / the potrf chain, which leave
   // most of the chip idle.  The factorisation records ev_fork where that phase begins
@@ -212,7 +212,7 @@ int sparse_eval(dlg_backend* b, int slot);                      // K1
 int sparse_assemble_speculative(dlg_backend* b, int s);         // K4 beside K1 (second stream, second panel buffer)
 int sparse_eval_assemble(dlg_backend* b, int s, int* done);      // K1 + K4 in one pass over J (the assembly kernel forms Jt*x too)
 int sparse_assemble_finish(dlg_backend* b);                      // ... the deferred partial-sum stages of that JtJ
-int sparse_zero_spare(dlg_backend* b);                           // second stream: clear the panel buffer the factorisation left behind
+int sparse_zero_spare(dlg_backend* b);                           // clear the panel buffer the factorisation left behind (behind the step's fetch)
 void sparse_spec_invalidate(dlg_backend* b, int s);
 int sparse_norm2_Jv(dlg_backend* b, int slot, const double* v, double* out_dev); // K3/K8
 int sparse_factorize(dlg_backend* b, int slot, double lambda, int* ok);          // K4+K5

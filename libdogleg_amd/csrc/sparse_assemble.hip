@@ -795,7 +795,20 @@ int sparse_assemble_finish(dlg_backend* b)
   if(!Y || !Y->fin_pending_Lx) return DLG_OK;
   double* Lx = Y->fin_pending_Lx;
   Y->fin_pending_Lx = nullptr;
-  return assemble_fin_launch(b, Lx);
+  DLG_CHECK(assemble_fin_launch(b, Lx));
+  if(Y->fin_pending_rhs)
+  {
+    // the right-hand side of the Gauss-Newton system (Jt*x of the point just evaluated) goes into the
+    // augmented row now, and the pivot flag is re-armed: one launch less between the caller's decision
+    // to factorise and the first factor kernel
+    const SymHost& H = Y->H;
+    hipLaunchKernelGGL(k_set_aug_row, dim3(dlg_cdiv(H.N, TPB)), dim3(TPB), 0, b->stream, Lx, Y->col_sn, Y->augpos,
+                       Y->perm, Y->fin_pending_rhs, H.N, Y->d_info, Y->sn_owner, -1);
+    DLG_LAUNCH_CHECK();
+    Y->spec_aug_rhs = Y->fin_pending_rhs; Y->info_clean = true;
+    Y->fin_pending_rhs = nullptr;
+  }
+  return DLG_OK;
 }
 static int assemble_launch(dlg_backend* b, const double* Jv, double* Lx = nullptr, const double* xvec = nullptr, double* Jt_x = nullptr,
                            bool zeroed = false, bool defer_fin = false)
@@ -848,7 +861,7 @@ static int assemble_launch(dlg_backend* b, const double* Jv, double* Lx = nullpt
       hipLaunchKernelGGL(k_jtx_fin2_long, dim3(nl), dim3(1024), 0, st, Y->jf_long, Y->jf_ptr, Y->jf_ent,
                          Y->jf_var0, Y->jf_w, Y->jtp, Jt_x);
   }
-  if(defer_fin) { Y->fin_pending_Lx = Lx; DLG_LAUNCH_CHECK(); return DLG_OK; }
+  if(defer_fin) { Y->fin_pending_Lx = Lx; Y->fin_pending_rhs = Jt_x; DLG_LAUNCH_CHECK(); return DLG_OK; }
   return assemble_fin_launch(b, Lx);
 }
 static int assemble_fin_launch(dlg_backend* b, double* Lx)
@@ -944,14 +957,15 @@ int sparse_assemble(dlg_backend* b, int s, double lambda)
     Y->spec_inflight = false;
   }
   DLG_CHECK(sparse_assemble_finish(b));
+  bool adopted = false;
   if(Y->spec_valid && Y->spec_slot == s && Y->spec_J == S.Jin())
   {
     std::swap(Y->Lx, Y->Lx_spec);           // the panels assembled beside K1 become the factor's panels
     Y->spec_valid = false;
+    adopted = true;
     // the other buffer (the previous factor) is free from here on: sparse_zero_spare clears it on the
     // second stream while the factorisation is latency-bound, the next evaluation finds it zeroed
-    Y->spare_zeroed = false;
-    if(b->aux_stream && Y->ev_swap && hipEventRecord(Y->ev_swap, st) == hipSuccess) Y->spare_dirty = true;
+    Y->spare_zeroed = false; Y->spare_dirty = true;
   }
   else
   {
@@ -977,7 +991,13 @@ int sparse_assemble(dlg_backend* b, int s, double lambda)
   // the right-hand side rides along as the last row of every panel: y = L^-1 P Jt_x falls out
   Y->aug_rhs = nullptr;
   Y->info_armed = false;
-  if(S.have_Jtx)
+  if(S.have_Jtx && adopted && Y->spec_aug_rhs == S.Jt_x)
+  {
+    // the adopted panels carry their right-hand side already (sparse_assemble_finish)
+    Y->aug_rhs = S.Jt_x;
+    Y->info_armed = Y->info_clean;
+  }
+  else if(S.have_Jtx)
   {
     hipLaunchKernelGGL(k_set_aug_row, dim3(dlg_cdiv(H.N, TPB)), dim3(TPB), 0, st, Y->Lx, Y->col_sn, Y->augpos,
                        Y->perm, S.Jt_x, H.N, Y->d_info, Y->sn_owner, phase);
@@ -1075,7 +1095,7 @@ int sparse_assemble_speculative(dlg_backend* b, int s)
   int rc;
   {
     DlgProfScope pt(b, DLG_PROF_K4_TOTAL);
-    Y->spare_zeroed = false; Y->spare_dirty = false;
+    Y->spare_zeroed = false; Y->spare_dirty = false; Y->spec_aug_rhs = nullptr;
     rc = assemble_launch(b, S.Jin(), Y->Lx_spec);
   }
   b->stream = main_stream;
@@ -1104,36 +1124,28 @@ int sparse_eval_assemble(dlg_backend* b, int s, int* done)
     DLG_HIP(hipEventCreateWithFlags(&Y->ev_spec, hipEventDisableTiming));
     DLG_HIP(hipEventCreateWithFlags(&Y->ev_spec_fork, hipEventDisableTiming));
   }
-  if(!Y->ev_swap)
-  {
-    DLG_HIP(hipEventCreateWithFlags(&Y->ev_swap, hipEventDisableTiming));
-    DLG_HIP(hipEventCreateWithFlags(&Y->ev_zero, hipEventDisableTiming));
-  }
   if(Y->spec_inflight) { DLG_HIP(hipStreamWaitEvent(st, Y->ev_spec, 0)); Y->spec_inflight = false; }    // (shares the partial-sum buffers)
   if(!H.jtx_covers_all) DLG_HIP(hipMemsetAsync(S.Jt_x, 0, sizeof(double)*(size_t)b->N, st));          // var-blocks without rows
-  const bool zeroed = Y->spare_zeroed;
-  if(zeroed) DLG_HIP(hipStreamWaitEvent(st, Y->ev_zero, 0));
+  const bool zeroed = Y->spare_zeroed && Y->spare_stream == st;      // (cleared on this very stream: sparse_zero_spare)
   Y->spare_zeroed = false; Y->spare_dirty = false;
   {
     DlgProfScope pt(b, DLG_PROF_K4_TOTAL);
     // (the partial-sum stages of JtJ wait until the caller has Jt*x on its way to the host: sparse_assemble_finish)
     DLG_CHECK(assemble_launch(b, S.Jin(), Y->Lx_spec, S.xin(), S.Jt_x, zeroed, true));
   }
-  Y->spec_valid = true; Y->spec_slot = s; Y->spec_J = S.Jin();
+  Y->spec_valid = true; Y->spec_slot = s; Y->spec_J = S.Jin(); Y->spec_aug_rhs = nullptr;
   *done = 1;
   return DLG_OK;
 }
-// the panel buffer that a factorisation just left behind (sparse_assemble swapped it out) is cleared on
-// the second stream, behind the Cauchy step's pass over J if there is one: off the critical path
+// the panel buffer that a factorisation just left behind (sparse_assemble swapped it out) is cleared
+// behind the point the host waits for (step_finish): in stream order before the next assembly
 int sparse_zero_spare(dlg_backend* b)
 {
   SparseSym* Y = b->sym;
-  if(!Y || !Y->spare_dirty || !b->aux_stream || !b->overlap || !Y->Lx_spec) return DLG_OK;
+  if(!Y || !Y->spare_dirty || !Y->Lx_spec) return DLG_OK;
   Y->spare_dirty = false;
-  DLG_HIP(hipStreamWaitEvent(b->aux_stream, Y->ev_swap, 0));
-  DLG_HIP(hipMemsetAsync(Y->Lx_spec, 0, sizeof(double)*(size_t)Y->H.lx_size, b->aux_stream));
-  DLG_HIP(hipEventRecord(Y->ev_zero, b->aux_stream));
-  Y->spare_zeroed = true;
+  DLG_HIP(hipMemsetAsync(Y->Lx_spec, 0, sizeof(double)*(size_t)Y->H.lx_size, b->stream));
+  Y->spare_zeroed = true; Y->spare_stream = b->stream;
   return DLG_OK;
 }
 void sparse_spec_invalidate(dlg_backend* b, int s)

@@ -15,8 +15,6 @@ void sparse_destroy(dlg_backend* b)
   if(b->aux_stream) (void)hipStreamSynchronize(b->aux_stream);
   if(Y->ev_spec) (void)hipEventDestroy(Y->ev_spec);
   if(Y->ev_spec_fork) (void)hipEventDestroy(Y->ev_spec_fork);
-  if(Y->ev_swap) (void)hipEventDestroy(Y->ev_swap);
-  if(Y->ev_zero) (void)hipEventDestroy(Y->ev_zero);
   for(void* p : Y->allocs) if(p) (void)hipFree(p);
   delete Y;
   b->sym = nullptr;
@@ -262,6 +260,7 @@ int sparse_factorize(dlg_backend* b, int s, double lambda, int* ok)
     static const int k_armed = 0x7fffffff;
     DLG_HIP(hipMemcpyAsync(Y->d_info, &k_armed, sizeof(int), hipMemcpyHostToDevice, st));
   }
+  Y->info_clean = false;
   DLG_CHECK(sparse_factor_levels(b));
   if(pf.e) { dlg_prof_end(b, pf.id, pf.e); pf.e = nullptr; }
   // the caller's dlg_fetch_scalars(b, NSCAL) brings the flag along; sparse_factor_ok() reads it then

@@ -82,8 +82,9 @@ struct SparseSym
   AsmBatch* asm_batch = nullptr; AsmTask* asm_ctask = nullptr; AsmFin* asm_cfin = nullptr;
   AsmShape* asm_shape = nullptr; AsmKG* asm_kg = nullptr; AsmMTask* asm_mtask = nullptr; int* asm_tdest = nullptr;
   int *jf_ptr = nullptr, *jf_ent = nullptr, *jf_var0 = nullptr, *jf_w = nullptr, *jf_short = nullptr, *jf_long = nullptr;
+  const double* fin_pending_rhs = nullptr; const double* spec_aug_rhs = nullptr; bool info_clean = false;   // augmented row set at evaluation time
   double* fin_pending_Lx = nullptr;      // assembly whose partial-sum stages are still to be launched
-  bool spare_dirty = false, spare_zeroed = false; hipEvent_t ev_swap = nullptr, ev_zero = nullptr;   // sparse_zero_spare
+  bool spare_dirty = false, spare_zeroed = false; hipStream_t spare_stream = nullptr;   // sparse_zero_spare
   double* jtp = nullptr;        // [16 per MFMA task] Jt*x records of the assembly kernel (sparse_eval_assemble)
   AsmFin2* asm_fin2 = nullptr; int64_t* asm_fin2_list = nullptr; AsmRun* asm_run = nullptr; int* asm_pdest = nullptr;
   int *rl_ptr = nullptr, *rl_pos = nullptr, *perm = nullptr, *col_sn = nullptr;
@@ -133,7 +134,7 @@ int sparse_partition_reduce(dlg_backend* b);
 int sparse_assemble_speculative(dlg_backend* b, int s);     // K4 on the second stream, beside K1
 int sparse_eval_assemble(dlg_backend* b, int s, int* done);   // K1 + K4 in one pass over J
 int sparse_assemble_finish(dlg_backend* b);                   // ... its JtJ partial-sum stages (deferred behind the fetch of Jt*x)
-int sparse_zero_spare(dlg_backend* b);                        // clear the swapped-out panel buffer on the second stream
+int sparse_zero_spare(dlg_backend* b);                        // clear the swapped-out panel buffer behind the step's fetch
 void sparse_spec_invalidate(dlg_backend* b, int s);                 // subtree partition: the sum over the ranks at the cut
 int sparse_factor_setup(dlg_backend* b);                     // per-level launch parameters of K5
 int sparse_factor_levels(dlg_backend* b);                    // K5 launches (no synchronisation)
