@@ -24,7 +24,7 @@ def row(k, label):
         return f"| {label} | {b['value']:.1f} | {b['ms_per_step']:.2f} | {c['value']:.4g} | {b['value']/c['value']:.0f}x |"
     return f"| {label} | {b['value']:.1f} | {b['ms_per_step']:.2f} | not timed | |"
 def spec(k):
-    sp = B[k].get("speculative_assembly")
+    sp = B[k].get("separate_passes")
     return f"{sp['steps_per_s']:.1f}" if sp else "-"
 def row2(k, label):
     b = B[k]; c = b.get("cpu_baseline")
@@ -39,10 +39,12 @@ All numbers from `python bench.py` (JSON lines committed next to this file) and
 `tools/collect_round.sh`, copied here by `tools/publish_round.py`, this file by `tools/make_bench_md.py`.
 A "step" = K1+K3+K4+K5+K6+K7+K8 on inputs resident in HBM (refactorise + interpolate).  The timed loop
 rotates over {B['sparse1m']['inputs']['resident_copies']} resident copies of (x, J) ({B['sparse1m']['inputs']['bytes_per_copy']/1e6:.0f} MB each on sparse-1m): past the 256 MiB
-Infinity Cache.  `value` = every kernel alone on the chip; "speculative" = the same step with JtJ
-assembled beside Jt*x on a second stream, as `dogleg_optimize*` runs once steps need Gauss-Newton.
+Infinity Cache.  Sparse workloads: `value` = the step with Jt*x (K1) and JtJ (K4) formed in ONE pass over J at
+the evaluation of the point (`dlg_backend_set_speculation`, what `dogleg_optimize*` does once steps need
+Gauss-Newton); "two passes" = the same step with K1 and K4 apart (how rounds 1-2 quoted `value`).  In the
+timed loop only the roofline kernel carries HIP events; the phase table is from a second loop.
 
-| workload (BASELINE.json config) | GPU steps/s (`value`) | ms/step | speculative steps/s | CPU oracle steps/s (1 thread, same box) | ratio |
+| workload (BASELINE.json config) | GPU steps/s (`value`) | ms/step | two passes, steps/s | CPU oracle steps/s (1 thread, same box) | ratio |
 |---|---|---|---|---|---|
 {row2('sparse1m', 'sparse-1m (#4: 1M x 150k, 15M nnz)')}
 {row2('sparse200k', 'sparse-200k (#3: 200k x 30k, 3M nnz)')}
@@ -54,7 +56,7 @@ stream beside K5, so the phases add up to more than the step):
 
 | phase | sparse-1m | sparse-200k | dense-50k |
 |---|---|---|---|
-| K1 Jt*x | {ph('sparse1m','K1_jtx')} | {ph('sparse200k','K1_jtx')} | {ph('dense50k','K1_jtx')} |
+| K1 Jt*x (sparse: 0 = inside the K4 kernel) | {ph('sparse1m','K1_jtx')} | {ph('sparse200k','K1_jtx')} | {ph('dense50k','K1_jtx')} |
 | K3+K8 two \\|Jv\\|^2 passes | {ph('sparse1m','K3K8_norm2Jv')} | {ph('sparse200k','K3K8_norm2Jv')} | {ph('dense50k','K3K8_norm2Jv')} |
 | K4 JtJ assembly (kernel alone) | {ph('sparse1m','K4_kernel')} | {ph('sparse200k','K4_kernel')} | {ph('dense50k','K4_kernel')} |
 | K4 total (memset, partial sums / slab reduce) | {ph('sparse1m','K4_total')} | {ph('sparse200k','K4_total')} | {ph('dense50k','K4_total')} |
@@ -63,17 +65,18 @@ stream beside K5, so the phases add up to more than the step):
 | K7 step | {ph('sparse1m','K7_step')} | {ph('sparse200k','K7_step')} | {ph('dense50k','K7_step')} |
 
 Rooflines:
-* sparse-1m `k_assemble_mfma` (K4): {r['algorithmic_bytes']/1e6:.1f} MB algorithmic / {r['avg_launch_ms']:.3f} ms = **{r['achieved']:.0f} GB/s = {100*r['frac']:.1f} % of 8 TB/s**
+* sparse-1m `k_assemble_mfma<18, true>` (K1+K4: JtJ and Jt*x in one pass): {r['algorithmic_bytes']/1e6:.1f} MB algorithmic / {r['avg_launch_ms']:.3f} ms = **{r['achieved']:.0f} GB/s = {100*r['frac']:.1f} % of 8 TB/s**
   (target in BASELINE.json: 40 %).  Counter traffic {t['bytes_per_launch']/1e6:.0f} MB per launch ({tag}_pmc.md): {t['bytes_per_launch']/r['algorithmic_bytes']:.2f}x the
-  algorithmic bytes (J is walked twice).  The kernel is bound by instruction issue around the K = 4 fp64 MFMAs.
+  algorithmic bytes (J is walked twice: by the tasks of its points' columns and of its cameras').  The kernel is bound by
+  instruction issue around the K = 4 fp64 MFMAs; K1's own pass over J (0.08 ms, 2.2x its bytes) is gone.
 * dense-50k `k_syrk_lower<64>` (K4): {rd['algorithmic_flops']:.3e} flop / {rd['avg_launch_ms']:.3f} ms = **{rd['achieved']:.1f} TFLOP/s** = {100*rd['frac']:.0f} % of the 78.6
   TFLOP/s datasheet fp64-matrix peak (48 TFLOP/s is what a register-only v_mfma_f64_16x16x4_f64 loop sustains here).
 * sparse-1m `k_norm2_Jv` (K3/K8): {ok['K3K8_norm2_Jv']['algorithmic_bytes']/1e6:.0f} MB / {1e3*ok['K3K8_norm2_Jv']['ms']:.0f} us = {ok['K3K8_norm2_Jv']['GBps']:.0f} GB/s = {100*ok['K3K8_norm2_Jv']['frac_hbm']:.0f} % of HBM (J past the Infinity Cache).
 * K5-sparse and K6-sparse are latency / critical-path bound (SURVEY 8d says to expect low fractions and to
   say so): K5 = {k5b/1e6:.0f} MB (`8 nnz(tril JtJ) + 8 nnz(L)`) and {k5f/1e9:.2f} GFLOP in {k5t:.2f} ms = {k5b/k5t/1e6:.0f} GB/s
   ({100*k5b/k5t/1e6/8000:.1f} % of HBM), {k5f/k5t/1e9:.2f} TFLOP/s ({100*k5f/k5t/1e9/78.6:.1f} % of the fp64 peak); K6 = {k6b/1e6:.0f} MB (`16 nnz(L) + 32 N`) in {k6t:.2f} ms
-  = {k6b/k6t/1e6:.0f} GB/s ({100*k6b/k6t/1e6/8000:.1f} %).  {nlev} elimination-tree levels: nine upper levels of ~50 us (factor) + ~15 us
-  (backward solve) each; per-workgroup phase clocks of a level in DESIGN.md section 6.
+  = {k6b/k6t/1e6:.0f} GB/s ({100*k6b/k6t/1e6/8000:.1f} %).  {nlev} elimination-tree levels: the nine upper ones are ONE launch each way
+  (workgroups hand over through flags): ~40 us (factor) + ~9 us (backward solve) a level; timelines in DESIGN.md section 6.
 
 rocprofv3 --stats, sparse-1m (bench.py default run; ms/step = total / steps issued):
 ```

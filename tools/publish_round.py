@@ -33,7 +33,7 @@ def pmc(wl, counter, kernel):
 traffic = {}
 # the dense JtJ launch is one of many k_syrk_lower<64> dispatches (the potrf trailing updates use the
 # same kernel): its entry is maintained by hand from the per-dispatch CSV (see the pmc notes)
-for wl, kernel, label in (("sparse-1m", "k_assemble_mfma", "k_assemble_mfma"),):
+for wl, kernel, label in (("sparse-1m", "k_assemble_mfma<18, true>", "k_assemble_mfma<18, true> (K1+K4 in one pass)"),):
     try:
         f, w = pmc(wl, "FETCH_SIZE", kernel), pmc(wl, "WRITE_SIZE", kernel)
         if f is None or w is None:
