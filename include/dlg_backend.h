@@ -149,12 +149,15 @@ int  dlg_point_upload_products(dlg_backend_t* b, int slot, double norm2x,
 int  dlg_point_bind_device(dlg_backend_t* b, int slot, const double* x_dev,
                            const double* J_dev);
 int  dlg_point_eval(dlg_backend_t* b, int slot, double* norm2_x, double* Jtx_absmax);
-/* Speculation (sparse): while it is on, every dlg_point_eval also starts the assembly of the slot's
- * JtJ -- on a second stream, into a second panel buffer, beside Jt*x --, and a following
+/* Assembly at evaluation time (sparse): while it is on, every dlg_point_eval also assembles the
+ * slot's JtJ into a second panel buffer -- in the SAME pass over J that forms Jt*x where the
+ * assembly schedule allows (the assembly kernel's B operand times x; DOGLEG_AMD_NO_FUSED_EVAL or
+ * an irregular pattern: on a second stream beside the Jt*x kernel) --, and a following
  * dlg_factorize / dlg_gauss_newton / dlg_take_step of the same slot and inputs adopts it instead of
  * assembling again.  For callers that expect the evaluated point to be factorised (the driver turns
- * it on once a step has needed the Gauss-Newton step: an accepted point is factorised next).  The
- * numbers do not change (same kernels, same sums); an assembly that is not used is dropped. */
+ * it on once a step has needed the Gauss-Newton step: an accepted point is factorised next).  JtJ
+ * is the same bit for bit; in the one-pass form Jt*x is summed in another (fixed) order, i.e. it
+ * differs from the stand-alone kernel's by rounding.  An assembly that is not used is dropped. */
 int  dlg_backend_set_speculation(dlg_backend_t* b, int on);
 
 /* ---- K3: compute_updateCauchy (dogleg.c:529-617) -------------------------- */

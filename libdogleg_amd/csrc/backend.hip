@@ -193,8 +193,6 @@ extern "C" void dlg_backend_destroy(dlg_backend_t* b)
   if(b->ev_step) { (void)hipEventDestroy(b->ev_step); b->ev_step = nullptr; }
   if(b->ev_copy) { (void)hipEventDestroy(b->ev_copy); b->ev_copy = nullptr; }
   if(b->ev_fetch) { (void)hipEventDestroy(b->ev_fetch); b->ev_fetch = nullptr; }
-  if(b->ev_evalfork) { (void)hipEventDestroy(b->ev_evalfork); b->ev_evalfork = nullptr; }
-  if(b->ev_evaljoin) { (void)hipEventDestroy(b->ev_evaljoin); b->ev_evaljoin = nullptr; }
   if(b->own_stream && b->stream) (void)hipStreamDestroy(b->stream);
   delete b;
 }
@@ -450,25 +448,6 @@ extern "C" int dlg_point_eval(dlg_backend_t* b, int s, double* norm2_x, double* 
     // the caller expects to factorise this point: JtJ is assembled in the same pass over J that forms
     // Jt*x (sparse_eval_assemble) or, where that schedule is not available, on the second stream meanwhile
     int fused = 0;
-    bool x_norm_aux = false;
-    if(b->type == DLG_SPARSE && b->speculate && b->fuse_eval && b->overlap && b->aux_stream && !b->sharded() && mloc > 0 && b->host_finals && b->h_part)
-    {
-      // |x|^2 needs nothing but x: on the second stream, beside the pass over J
-      if(!b->ev_evalfork)
-      {
-        DLG_HIP(hipEventCreateWithFlags(&b->ev_evalfork, hipEventDisableTiming));
-        DLG_HIP(hipEventCreateWithFlags(&b->ev_evaljoin, hipEventDisableTiming));
-      }
-      DLG_HIP(hipEventRecord(b->ev_evalfork, b->stream));
-      DLG_HIP(hipStreamWaitEvent(b->aux_stream, b->ev_evalfork, 0));
-      hipStream_t main_stream = b->stream;
-      b->stream = b->aux_stream;
-      const int rc = k_norm2_absmax(b, S.xin(), mloc, b->d_scal);
-      b->stream = main_stream;
-      DLG_CHECK(rc);
-      DLG_HIP(hipEventRecord(b->ev_evaljoin, b->aux_stream));
-      x_norm_aux = true;
-    }
     if(b->type == DLG_SPARSE && b->speculate && b->fuse_eval) DLG_CHECK(sparse_eval_assemble(b, s, &fused));
     if(!fused)
     {
@@ -477,8 +456,9 @@ extern "C" int dlg_point_eval(dlg_backend_t* b, int s, double* norm2_x, double* 
       if(b->type == DLG_SPARSE) DLG_CHECK(sparse_eval(b, s)); else DLG_CHECK(dense_eval(b, s));
     }
     DlgProfScope pv(b, DLG_PROF_VEC);
-    // norm2_x over the local rows
-    if(x_norm_aux) DLG_HIP(hipStreamWaitEvent(b->stream, b->ev_evaljoin, 0));
+    // norm2_x over the local rows (one-pass evaluation: together with the norms of Jt_x, one launch)
+    const bool pair = fused && mloc > 0 && !b->sharded();
+    if(pair) { /* below */ }
     else if(mloc > 0) DLG_CHECK(k_norm2_absmax(b, S.xin(), mloc, b->d_scal));
     else         DLG_HIP(hipMemsetAsync(b->d_scal, 0, 2*sizeof(double), b->stream));
     if(b->sharded())
@@ -491,7 +471,8 @@ extern "C" int dlg_point_eval(dlg_backend_t* b, int s, double* norm2_x, double* 
       DLG_HIP(hipMemcpyAsync(S.Jt_x, b->d_red, sizeof(double)*(size_t)b->N, hipMemcpyDeviceToDevice, b->stream));
       DLG_HIP(hipMemcpyAsync(b->d_scal, b->d_red + b->N, sizeof(double), hipMemcpyDeviceToDevice, b->stream));
     }
-    DLG_CHECK(k_norm2_absmax(b, S.Jt_x, b->N, b->d_scal + 2));
+    if(pair) DLG_CHECK(k_norm2_absmax_pair(b, S.Jt_x, b->N, b->d_scal + 2, S.xin(), mloc, b->d_scal));
+    else     DLG_CHECK(k_norm2_absmax(b, S.Jt_x, b->N, b->d_scal + 2));
     if(fused)
     {
       // the scalars go to the host first; the partial-sum stages of JtJ run while the host gets them

@@ -57,7 +57,7 @@ struct dlg_backend
   bool own_stream = false;
   // side stream + events: p_new travels to the host while the expected improvement is computed (dlg_step)
   hipStream_t copy_stream = nullptr;
-  hipEvent_t  ev_step = nullptr, ev_copy = nullptr, ev_fetch = nullptr, ev_evalfork = nullptr, ev_evaljoin = nullptr;
+  hipEvent_t  ev_step = nullptr, ev_copy = nullptr, ev_fetch = nullptr;
   // second compute stream: the Cauchy step (one pass over J, independent of the factorisation) runs
   // beside the latency-bound upper levels of the elimination tree / the potrf chain, which leave
   // most of the chip idle.  The factorisation records ev_fork where that phase begins
@@ -162,6 +162,8 @@ int dlg_fetch_scalars(dlg_backend* b, int n);
 // --------------------------------------------------------- kernels_vec.hip --
 // out[0] = sum x[i]^2 ; out[1] = max |x[i]|   (deterministic two-stage)
 int k_norm2_absmax(dlg_backend* b, const double* x, int n, double* out2);
+// ... of two vectors behind one launch
+int k_norm2_absmax_pair(dlg_backend* b, const double* x1, int n1, double* out1, const double* x2, int n2, double* out2);
 // out[0] = <x,y>
 int k_inner(dlg_backend* b, const double* x, const double* y, int n, double* out);
 // Cauchy finish: g2 = |g|^2 (host), Jg2 = *Jg2_dev; k = -g2/Jg2;

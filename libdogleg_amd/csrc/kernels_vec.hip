@@ -63,6 +63,23 @@ __global__ void __launch_bounds__(TPB) k_part_norm2_absmax(const double* __restr
   const double Mx = block_max(m, sh);
   if(threadIdx.x == 0) { part[blockIdx.x] = S; part[gridDim.x + blockIdx.x] = Mx; }
 }
+// the same for two vectors in one launch: blocks [0, g1) take x1, the rest x2 -- each half sums exactly as
+// a launch of its own would (same grid-stride order), one launch latency instead of two
+__global__ void __launch_bounds__(TPB) k_part_norm2_absmax2(const double* __restrict__ x1, int n1, double* __restrict__ part1, int g1,
+                                                            const double* __restrict__ x2, int n2, double* __restrict__ part2)
+{
+  __shared__ double sh[4];
+  const bool first = (int)blockIdx.x < g1;
+  const double* x = first ? x1 : x2;
+  const int n = first ? n1 : n2, g = first ? g1 : (int)gridDim.x - g1, blk = first ? (int)blockIdx.x : (int)blockIdx.x - g1;
+  double* part = first ? part1 : part2;
+  double s = 0, m = 0;
+  for(int i = blk*TPB + threadIdx.x; i < n; i += g*TPB)
+  { const double v = x[i]; s += v*v; m = fmax(m, fabs(v)); }
+  const double S = block_sum(s, sh);
+  const double Mx = block_max(m, sh);
+  if(threadIdx.x == 0) { part[blk] = S; part[g + blk] = Mx; }
+}
 __global__ void __launch_bounds__(TPB) k_part_inner(const double* __restrict__ x,
                                                     const double* __restrict__ y, int n,
                                                     double* __restrict__ part)
@@ -337,6 +354,26 @@ int k_norm2_absmax(dlg_backend* b, const double* x, int n, double* out2)
   hipLaunchKernelGGL(k_final, dim3(1), dim3(TPB), 0, b->stream, b->d_part, g, 1, 1, out2, 1);
   DLG_LAUNCH_CHECK();
   return DLG_OK;
+}
+// (|x1|^2, max|x1|) -> out1[0..1] and (|x2|^2, max|x2|) -> out2[0..1] behind one launch where the second
+// stages run on the host (dlg_host_partials); else two calls of k_norm2_absmax
+int k_norm2_absmax_pair(dlg_backend* b, const double* x1, int n1, double* out1, const double* x2, int n2, double* out2)
+{
+  const int g1 = grid_for(n1), g2 = grid_for(n2);
+  if(b->host_finals && b->h_part && b->h_part_used + 2*(size_t)(g1 + g2) <= dlg_backend::HPART_CAP)
+  {
+    double* hp1 = dlg_host_partials(b, out1, g1, 1, 1, 1);
+    double* hp2 = hp1 ? dlg_host_partials(b, out2, g2, 1, 1, 1) : nullptr;
+    if(hp1 && hp2)
+    {
+      hipLaunchKernelGGL(k_part_norm2_absmax2, dim3(g1 + g2), dim3(TPB), 0, b->stream, x1, n1, hp1, g1, x2, n2, hp2);
+      DLG_LAUNCH_CHECK();
+      return DLG_OK;
+    }
+    if(hp1) { hipLaunchKernelGGL(k_part_norm2_absmax, dim3(g1), dim3(TPB), 0, b->stream, x1, n1, hp1); DLG_LAUNCH_CHECK(); return k_norm2_absmax(b, x2, n2, out2); }
+  }
+  DLG_CHECK(k_norm2_absmax(b, x1, n1, out1));
+  return k_norm2_absmax(b, x2, n2, out2);
 }
 int k_inner(dlg_backend* b, const double* x, const double* y, int n, double* out)
 {
