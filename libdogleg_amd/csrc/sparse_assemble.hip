@@ -459,28 +459,31 @@ __global__ void __launch_bounds__(1024) k_jtx_fin2_long(const int* __restrict__ 
                                                         const int* __restrict__ var0, const int* __restrict__ wv,
                                                         const double* __restrict__ jtp, double* __restrict__ Jt_x)
 {
-  __shared__ double sh[64*16];
-  const int v = blks[blockIdx.x], a = threadIdx.x & 15, g = threadIdx.x >> 4;
+  __shared__ double sh[128*16];
+  const int v = blks[blockIdx.x], w = wv[v];
+  // groups of 8 lanes for blocks of up to 8 variables (128 sub-sums), of 16 otherwise (64)
+  const int gw = (w <= 8) ? 8 : 16, ng = 1024/gw;
+  const int a = threadIdx.x & (gw - 1), g = threadIdx.x/gw;
   const int e0 = jf_ptr[v], e1 = jf_ptr[v+1];
   double sum = 0.0;
-  if(a < wv[v])
-    for(int e = e0 + g; e < e1; e += 64*16)
+  if(a < w)
+    for(int e = e0 + g; e < e1; e += ng*16)
     {
       // sixteen records in flight (their indices first), added in list order
       int ix[16]; double t[16];
 #pragma unroll
-      for(int u = 0; u < 16; u++) ix[u] = jf_ent[min(e + 64*u, e1 - 1)];
+      for(int u = 0; u < 16; u++) ix[u] = jf_ent[min(e + ng*u, e1 - 1)];
 #pragma unroll
       for(int u = 0; u < 16; u++) t[u] = jtp[ix[u] + a];
 #pragma unroll
-      for(int u = 0; u < 16; u++) sum += (e + 64*u < e1) ? t[u] : 0.0;
+      for(int u = 0; u < 16; u++) sum += (e + ng*u < e1) ? t[u] : 0.0;
     }
   sh[g*16 + a] = sum;
   __syncthreads();
-  if(g == 0 && a < wv[v])
+  if(g == 0 && a < w)
   {
     double tot = 0.0;
-    for(int k = 0; k < 64; k++) tot += sh[k*16 + a];
+    for(int k = 0; k < ng; k++) tot += sh[k*16 + a];
     Jt_x[var0[v] + a] = tot;
   }
 }
