@@ -178,7 +178,7 @@ def main():
     # runs once steps need the Gauss-Newton step: sparse_eval_assemble, the assembly kernel's B operand
     # times x); the factorisation of the step adopts those panels.  All of K1..K8 is inside the timed
     # loop either way; the same loop with the two passes apart is reported as "separate_passes".
-    one_pass = kind == "sparse" and not use_dist
+    one_pass = kind == "sparse"
     if one_pass:
         be.set_speculation(True)
     for _ in range(args.warmup):

@@ -254,7 +254,7 @@ bool eval_point(bool* converged, dogleg_operatingPoint_t* pt, Driver* d)
     double* J_dev = (double*)dlg_point_device_ptr(d->be, s, DLG_VEC_J_OWN);
     (*d->f_device)(p_dev, x_dev, J_dev, dlg_backend_get_stream(d->be), ctx->cookie);
     if(!be_ok(dlg_point_bind_device(d->be, s, x_dev, J_dev), "bind")) return false;
-    if(ctx->solve_type == DOGLEG_SPARSE) dlg_backend_set_speculation(d->be, d->expect_gn && !d->sharded);
+    if(ctx->solve_type == DOGLEG_SPARSE) dlg_backend_set_speculation(d->be, d->expect_gn);
     if(!be_ok(dlg_point_eval(d->be, s, &norm2x, &absmax), "Jt*x")) return false;
     pt->norm2_x = norm2x;
     pt->have_x = pt->have_J = pt->have_Jtx = true;
@@ -282,7 +282,7 @@ bool eval_point(bool* converged, dogleg_operatingPoint_t* pt, Driver* d)
     if(!be_ok(dlg_point_upload(d->be, s, pt->x, (const double*)pt->Jt->x), "upload")) return false;
     // once steps need the Gauss-Newton step an accepted point is factorised next: its JtJ is assembled
     // beside Jt*x (an unused assembly -- a rejected point -- is simply dropped; no number changes)
-    dlg_backend_set_speculation(d->be, d->expect_gn && !d->sharded);
+    dlg_backend_set_speculation(d->be, d->expect_gn);
     if(!be_ok(dlg_point_eval(d->be, s, &norm2x, &absmax), "Jt*x")) return false;
     pt->norm2_x = norm2x;
     pt->have_x = pt->have_J = pt->have_Jtx = true;

@@ -1118,7 +1118,9 @@ int sparse_eval_assemble(dlg_backend* b, int s, int* done)
   SparseSym* Y = b->sym;
   if(!Y) { dlg_set_error("dlg_sparse_set_pattern must be called first"); return DLG_ERR_STATE; }
   const SymHost& H = Y->H;
-  if(!H.asm_jtx_ok || !Y->jtp || b->sharded() || H.part_nranks > 1) return DLG_OK;
+  if(!H.asm_jtx_ok || !Y->jtp) return DLG_OK;
+  // (sharded rows / subtree partition: the rank's rows give its share of Jt*x and of JtJ as the separate
+  // kernels would; the sums over the ranks follow where they always did)
   DlgSlot& S = b->slot[s];
   hipStream_t st = b->stream;
   if(!Y->Lx_spec)
@@ -1135,6 +1137,7 @@ int sparse_eval_assemble(dlg_backend* b, int s, int* done)
     DlgProfScope pt(b, DLG_PROF_K4_TOTAL);
     // (the partial-sum stages of JtJ wait until the caller has Jt*x on its way to the host: sparse_assemble_finish)
     DLG_CHECK(assemble_launch(b, S.Jin(), Y->Lx_spec, S.xin(), S.Jt_x, zeroed, true));
+    if(b->sharded()) Y->fin_pending_rhs = nullptr;     // Jt*x is not summed over the ranks yet: the augmented row waits for the factorisation
   }
   Y->spec_valid = true; Y->spec_slot = s; Y->spec_J = S.Jin(); Y->spec_aug_rhs = nullptr;
   *done = 1;

@@ -39,7 +39,7 @@ class _InProcessAllReduce:
         return fn
 
 
-def _sharded_step(kind, N, M, nnz, pattern, x, Jvals, p, cuts, row_slice):
+def _sharded_step(kind, N, M, nnz, pattern, x, Jvals, p, cuts, row_slice, one_pass=False):
     world = len(cuts) - 1
     ar = _InProcessAllReduce(world)
     out, errs = [None] * world, []
@@ -51,6 +51,7 @@ def _sharded_step(kind, N, M, nnz, pattern, x, Jvals, p, cuts, row_slice):
             be.set_shard(r0, r1, ar.hook(rank))
             if pattern is not None:
                 be.set_pattern(*pattern)
+                be.set_speculation(one_pass)
             be.set_p(0, p)
             be.upload(0, x[r0:r1], row_slice(r0, r1))
             n2x, gmax = be.eval(0)
@@ -118,7 +119,7 @@ def test_dense_rows_sharded_over_two_logical_ranks(gpu):
 
 
 # ------------------------------------------------------------ subtree partition -------
-def _partition_step(prob, world, use_take_step=False, lam0=0.0):
+def _partition_step(prob, world, use_take_step=False, lam0=0.0, one_pass=False):
     """every logical rank: backend with dlg_backend_set_partition + the in-process sum as the
     all-reduce hook; x / J of the rows the symbolic phase gave it; one full trial step"""
     N, M, nnz = prob.N, prob.M, prob.nnz
@@ -134,6 +135,7 @@ def _partition_step(prob, world, use_take_step=False, lam0=0.0):
             be.set_partition(rank, world)
             be.set_allreduce(ar.hook(rank))
             be.set_pattern(Jp, Ji)
+            be.set_speculation(one_pass)       # JtJ assembled in the pass over the rank's rows that forms its share of Jt*x
             rows = be.partition_rows()
             st = be.partition_stats()
             Jloc = np.concatenate([Jx[Jp[r]:Jp[r+1]] for r in rows]) if len(rows) else np.zeros(0)
@@ -218,6 +220,31 @@ def test_subtree_partition_config3_200k_rows(gpu, world):
     assert st["reduced_doubles"] * 8 < 8e6                     # a few MB, against 16 MB of JtJ
     print(f"config #3, world={world}: cut above level {st['cut_level']}, {st['supernodes_above_cut']} replicated supernodes, "
           f"rows/rank {[len(r['rows']) for r in res]}, {st['reduced_doubles']*8/1e6:.2f} MB summed, |step - oracle| = {w:.2e}")
+
+
+@pytest.mark.parametrize("world,take", [(2, False), (3, True), (8, True)])
+def test_subtree_partition_with_one_pass_evaluation(gpu, world, take):
+    """dlg_backend_set_speculation on a partitioned backend: every rank assembles its rows' JtJ in the pass
+    that forms its share of Jt*x (sparse_eval_assemble), the sums over the ranks follow where they always
+    did -- the oracle's step within the parity bar on every rank, identical bits across ranks"""
+    prob = oa.BAProblem(49, 900, 10000, seed=7)
+    res, data = _partition_step(prob, world, use_take_step=take, one_pass=True)
+    _check_partition_against_oracle(res, data)
+
+
+def test_sparse_rows_sharded_with_one_pass_evaluation(gpu):
+    prob = oa.BAProblem(49, 900, 10000, seed=7)
+    N, M, nnz = prob.N, prob.M, prob.nnz
+    Jp, Ji = prob.pattern()
+    p = prob.p0()
+    x, Jx = prob.eval(p)
+    cuts = [0, M // 3 + 1, M]
+    a = _sharded_step(capi.DLG_SPARSE, N, M, nnz, (Jp, Ji), x, Jx, p, cuts, lambda a, b: Jx[Jp[a]:Jp[b]], one_pass=True)
+    b = _sharded_step(capi.DLG_SPARSE, N, M, nnz, (Jp, Ji), x, Jx, p, cuts, lambda a, b: Jx[Jp[a]:Jp[b]], one_pass=False)
+    for ra, rb in zip(a, b):
+        assert np.linalg.norm(ra["step"] - rb["step"]) <= 1e-11 * max(1.0, np.linalg.norm(rb["step"]))
+        assert abs(ra["n2x"] - rb["n2x"]) <= 1e-13 * rb["n2x"]
+    assert np.array_equal(a[0]["step"], a[1]["step"])
 
 
 def test_subtree_partition_take_step_one_synchronisation(gpu):
