@@ -539,6 +539,7 @@ static int cauchy_fork_enqueue(dlg_backend* b, int s, double* sc)
   DLG_CHECK(rc);
   DLG_HIP(hipEventRecord(b->ev_join, b->aux_stream));
   DLG_HIP(hipStreamWaitEvent(b->stream, b->ev_join, 0));
+  if(b->type == DLG_SPARSE) DLG_CHECK(sparse_touch_factor(b, b->aux_stream));     // (behind the join: a hint nobody waits for)
   return DLG_OK;
 }
 

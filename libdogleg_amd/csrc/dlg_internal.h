@@ -214,6 +214,7 @@ int sparse_eval(dlg_backend* b, int slot);                      // K1
 int sparse_assemble_speculative(dlg_backend* b, int s);         // K4 beside K1 (second stream, second panel buffer)
 int sparse_eval_assemble(dlg_backend* b, int s, int* done);      // K1 + K4 in one pass over J (the assembly kernel forms Jt*x too)
 int sparse_assemble_finish(dlg_backend* b);                      // ... the deferred partial-sum stages of that JtJ
+int sparse_touch_factor(dlg_backend* b, hipStream_t st);         // second stream: pull the leaf panels into the Infinity Cache
 int sparse_zero_spare(dlg_backend* b);                           // clear the panel buffer the factorisation left behind (behind the step's fetch)
 void sparse_spec_invalidate(dlg_backend* b, int s);
 int sparse_norm2_Jv(dlg_backend* b, int slot, const double* v, double* out_dev); // K3/K8

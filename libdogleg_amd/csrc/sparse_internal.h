@@ -118,6 +118,7 @@ struct SparseSym
   // speculative assembly beside K1 (sparse_assemble_speculative): second panel buffer, its state
   double* Lx_spec = nullptr; hipEvent_t ev_spec = nullptr, ev_spec_fork = nullptr;
   bool spec_inflight = false, spec_valid = false; int spec_slot = -1; const double* spec_J = nullptr;
+  int64_t touch_off = 0, touch_n = 0;    // stretch of Lx with the leaf panels (sparse_touch_factor)
   int bw_level0 = 1 << 30, bw_lds = 0, bw_n = 0;   // persistent top region of the backward solve (sparse_solve_setup)
   SolveItem* slv_item_pr = nullptr; int* bwd_flag = nullptr; int bwd_epoch = 0;
   int pr_stage = 0; double* pr_acc = nullptr;   // ... childless supernodes stage their update matrix; shadow scratch for the ones kept in HBM
