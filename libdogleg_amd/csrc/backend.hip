@@ -494,12 +494,12 @@ extern "C" int dlg_point_eval(dlg_backend_t* b, int s, double* norm2_x, double* 
 }
 
 // |J v|^2 into dev scalar `out` (all-reduced over ranks)
-static int norm2_Jv(dlg_backend* b, int s, const double* v, double* out)
+static int norm2_Jv(dlg_backend* b, int s, const double* v, double* out, const double* kind_if_factor_failed = nullptr)
 {
   DlgProfScope ps(b, DLG_PROF_K3K8_NORM2JV);
   switch(b->type)
   {
-  case DLG_SPARSE:  DLG_CHECK(sparse_norm2_Jv(b, s, v, out)); break;
+  case DLG_SPARSE:  DLG_CHECK(sparse_norm2_Jv(b, s, v, out, kind_if_factor_failed)); break;
   case DLG_DENSE:   DLG_CHECK(dense_norm2_Jv(b, s, v, out)); break;
   default:          return products_quadform(b, s, v, out);
   }
@@ -894,7 +894,7 @@ extern "C" int dlg_take_step(dlg_backend_t* b, int from, int to, double trustreg
         side_copy = true;
       }
     }
-    DLG_CHECK(norm2_Jv(b, from, T.step, b->d_scal + 12));          // the other half of the expected improvement
+    DLG_CHECK(norm2_Jv(b, from, T.step, b->d_scal + 12, b->d_scal + 8));    // the other half of the expected improvement
     DLG_CHECK(step_finish(b, to, dlg_backend::NSCAL, side_copy ? nullptr : p_new_host));   // the one synchronisation
     if(side_copy) DLG_HIP(hipEventSynchronize(b->ev_copy));
     if(b->profiling) dlg_prof_resolve(b);

@@ -217,7 +217,9 @@ int sparse_assemble_finish(dlg_backend* b);                      // ... the defe
 int sparse_touch_factor(dlg_backend* b, hipStream_t st);         // second stream: pull the leaf panels into the Infinity Cache
 int sparse_zero_spare(dlg_backend* b);                           // clear the panel buffer the factorisation left behind (behind the step's fetch)
 void sparse_spec_invalidate(dlg_backend* b, int s);
-int sparse_norm2_Jv(dlg_backend* b, int slot, const double* v, double* out_dev); // K3/K8
+// K3/K8; kind_if_factor_failed (device scalar holding the kind of step, or null): the pass is skipped when the
+// factorisation on the stream failed and the step is not the Cauchy step to the edge
+int sparse_norm2_Jv(dlg_backend* b, int slot, const double* v, double* out_dev, const double* kind_if_factor_failed = nullptr);
 int sparse_factorize(dlg_backend* b, int slot, double lambda, int* ok);          // K4+K5
 bool sparse_factor_ok(const dlg_backend* b);     // pivot flag of the last factorisation (after a sync)
 int sparse_solve(dlg_backend* b, const double* rhs, double* out);                // K6

@@ -706,10 +706,14 @@ __global__ void __launch_bounds__(TPB) k_norm2_Jv(const int* __restrict__ chunk_
                                                   const int* __restrict__ Ji,
                                                   const double* __restrict__ vals,
                                                   const double* __restrict__ v,
-                                                  double* __restrict__ part)
+                                                  double* __restrict__ part, const int* __restrict__ info,
+                                                  const double* __restrict__ kind)
 {
   __shared__ double prod[NV_CHUNK];
   __shared__ double sh[4];
+  // K8 behind a speculative factorisation (dlg_take_step): a step built on a failed factorisation is
+  // never used -- unless it is the Cauchy step to the edge of the trust region, which needs no factor
+  if(info && *info != 0x7fffffff && (int)*kind != DLG_KIND_CAUCHY_TO_EDGE) { if(threadIdx.x == 0) part[blockIdx.x] = 0.0; return; }
   const int r0 = chunk_row[blockIdx.x], r1 = chunk_row[blockIdx.x + 1];
   const int q0 = Jp[r0], n = Jp[r1] - q0;
   const int tid = threadIdx.x;
@@ -775,7 +779,7 @@ int sparse_eval(dlg_backend* b, int s)
 }
 
 // K3 / K8
-int sparse_norm2_Jv(dlg_backend* b, int s, const double* v, double* out_dev)
+int sparse_norm2_Jv(dlg_backend* b, int s, const double* v, double* out_dev, const double* kind_if_factor_failed)
 {
   SparseSym* Y = b->sym;
   if(!Y) { dlg_set_error("dlg_sparse_set_pattern must be called first"); return DLG_ERR_STATE; }
@@ -784,7 +788,8 @@ int sparse_norm2_Jv(dlg_backend* b, int s, const double* v, double* out_dev)
   if(g == 0) { DLG_HIP(hipMemsetAsync(out_dev, 0, sizeof(double), b->stream)); return DLG_OK; }
   DLG_CHECK(dlg_ensure_partials(b, 5120 + (size_t)g));
   double* part = b->d_part + 5120;          // behind the regions of the vector reductions (kernels_vec.hip)
-  hipLaunchKernelGGL(k_norm2_Jv, dim3(g), dim3(TPB), 0, b->stream, Y->nv_chunk, Y->Jp, Y->Ji, S.Jin(), v, part);
+  hipLaunchKernelGGL(k_norm2_Jv, dim3(g), dim3(TPB), 0, b->stream, Y->nv_chunk, Y->Jp, Y->Ji, S.Jin(), v, part,
+                     kind_if_factor_failed ? (const int*)Y->d_info : (const int*)nullptr, kind_if_factor_failed);
   DLG_LAUNCH_CHECK();
   return k_reduce_sum(b, part, g, out_dev);
 }

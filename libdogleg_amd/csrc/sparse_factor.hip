@@ -250,7 +250,7 @@ __global__ void __launch_bounds__(NT) k_factor_level(const FwItem* __restrict__ 
                                                      int* pr_flag, int pr_epoch, int pr_item0, int64_t pr_acc)
 {
   extern __shared__ __attribute__((aligned(16))) double P[];
-  __shared__ int sbad;
+  __shared__ int sbad, s_skip;
   constexpr int CP_FLIGHT = 32;
 #ifdef DLG_FL_PROFILE
   const int prof_lvl = mode >> 8;
@@ -289,7 +289,9 @@ __global__ void __launch_bounds__(NT) k_factor_level(const FwItem* __restrict__ 
   MfChild rc = {0, 0, 0, 0};
   const bool mf_acc = mode == 2 && it.nch > 0;
   if(mf_acc) rc = mf_rec[it.ch0 + min(lane, it.nch - 1)];     // on its way during the panel copy
-  if(tid == 0) sbad = 0x7fffffff;
+  // (s_skip: a launch before this one found a non-positive pivot -- the factorisation is going to be
+  // thrown away by the lambda loop, dogleg.c:656-677: nothing to do here but to let the parent go on)
+  if(tid == 0) { sbad = 0x7fffffff; s_skip = __hip_atomic_load(info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0x7fffffff; }
   if(cmp)
   {
     __syncthreads();
@@ -330,6 +332,11 @@ __global__ void __launch_bounds__(NT) k_factor_level(const FwItem* __restrict__ 
   }
   __syncthreads();
   FL_STAMP(1);
+  if(s_skip)
+  {
+    if(pr_flag && tid == 0) __hip_atomic_store(pr_flag + pr_item0 + blockIdx.x, pr_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return;
+  }
   if(mf_acc && usp < mb)
     for(int jw = usp + (tid >> 6); jw < mb; jw += NT/64)
       for(int i = lane; i < mb - jw; i += 64) P[(mb - jw)*ldp + i] = 0.0;      // (the barrier is in mf_add_children)
@@ -619,9 +626,12 @@ __global__ void __launch_bounds__(NT) k_update_gather(int unit0, const int* __re
                                                        const int64_t* __restrict__ sn_lx,
                                                        double* __restrict__ Lx,
                                                        double* __restrict__ upart,
-                                                       const double* __restrict__ uscr, int nw)
+                                                       const double* __restrict__ uscr, int nw,
+                                                       const int* __restrict__ info)
 {
   extern __shared__ __attribute__((aligned(16))) double lds[];
+  __shared__ int s_skip;
+  if(threadIdx.x == 0) s_skip = *info != 0x7fffffff;      // a failed factorisation is not worth finishing
   const int unit = unit0 + blockIdx.x;
   const int item = uw_item[unit];
   const int t = ui_t[item], col = ui_col[item], nc = ui_nc[item];
@@ -634,6 +644,7 @@ __global__ void __launch_bounds__(NT) k_update_gather(int unit0, const int* __re
   const int slab = nrows_t*nc;
   for(int e = tid; e < slab*nw; e += NT) lds[e] = 0.0;
   __syncthreads();
+  if(s_skip) return;
   if(w < nw)
   {
     double* acc = lds + (size_t)w*slab;
@@ -1263,7 +1274,7 @@ int sparse_factor_levels(dlg_backend* b)
       hipLaunchKernelGGL(HIP_KERNEL_NAME(k_update_gather<TPB>), dim3(nu), dim3(TPB), Y->upd_lds[l], st, H.uw_lvl_ptr[l],
                          Y->uw_item, Y->uw_s0, Y->uw_s1, Y->uw_part, Y->ui_t, Y->ui_col, Y->ui_nc,
                          Y->usub, Y->usub_u, Y->relpos, Y->sn_rowptr, Y->sn_lx, Y->Lx, Y->upart, Y->uscr,
-                         Y->upd_nw[l]);
+                         Y->upd_nw[l], Y->d_info);
     }
     else if(nu > 0 && Y->upd_coop[l] == 2)
       hipLaunchKernelGGL(k_update_mfma, dim3(nu), dim3(TPB), Y->upd_lds[l], st, H.uw_lvl_ptr[l],

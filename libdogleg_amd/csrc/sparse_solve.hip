@@ -115,9 +115,11 @@ __global__ void __launch_bounds__(BWD_NT, BD_ONLY ? 4 : 1) k_solve_bwd_level(con
                                                             double* __restrict__ ywork,
                                                             double* __restrict__ out, int use_aug,
                                                             const int* __restrict__ sn_bd_col, int top_lds, int xb_cap,
-                                                            int* pr_flag, int pr_epoch)
+                                                            int* pr_flag, int pr_epoch, const int* __restrict__ info)
 {
   extern __shared__ __attribute__((aligned(16))) double lds[];
+  __shared__ int s_skip;
+  if(threadIdx.x == 0) s_skip = *info != 0x7fffffff;      // the factor is that of a failed factorisation: its solution is never used
   constexpr int NW = BWD_NT/64;
   // persistent top region (pr_flag != null): ONE launch for the last levels of the tree, workgroups
   // from the root down; x of the ancestors was written in this very launch -- write-through stores,
@@ -233,6 +235,11 @@ __global__ void __launch_bounds__(BWD_NT, BD_ONLY ? 4 : 1) k_solve_bwd_level(con
     for(int i = tid + BWD_NT; i < r; i += BWD_NT) xb[i] = ldx(ywork + rows[w + i]);
   }
   __syncthreads();
+  if(s_skip)
+  {
+    if(pr_flag && tid == 0) __hip_atomic_store(pr_flag + blockIdx.x, pr_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return;
+  }
   BW_STAMP(2);
   // The 8x8 diagonal blocks are inverted once, all of them in parallel (thread = (block, column),
   // forward substitution in registers), so that the sequential sweep over the blocks below is eight
@@ -659,7 +666,7 @@ int sparse_solve(dlg_backend* b, const double* rhs, double* out)
     // the persistent top region: its levels in one launch, workgroups from the root down (sparse_solve_setup)
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_solve_bwd_level<512, false>), dim3(Y->bw_n), dim3(512), Y->bw_lds, st,
                        Y->slv_item_pr, Y->sn_rows, Y->perm, Y->Lx, Y->ywork, out, use_aug, Y->sn_bd_col,
-                       256*Y->bw_level0, Y->bwd_xb_cap, Y->bwd_flag, ++Y->bwd_epoch);
+                       256*Y->bw_level0, Y->bwd_xb_cap, Y->bwd_flag, ++Y->bwd_epoch, Y->d_info);
     ltop = Y->bw_level0 - 1;
   }
   for(int l = ltop; l >= 0; l--)
@@ -670,15 +677,15 @@ int sparse_solve(dlg_backend* b, const double* rhs, double* out)
     if(n > 0 && Y->bwd_nt[l] == 256 && Y->bwd_bd[l])
       hipLaunchKernelGGL(HIP_KERNEL_NAME(k_solve_bwd_level<256, true>), dim3(n), dim3(256), Y->bwd_lds[l], st,
                          Y->slv_item + H.xl_ptr[l], Y->sn_rows, Y->perm, Y->Lx, Y->ywork, out, use_aug, Y->sn_bd_col,
-                         Y->bwd_top[l] + 256*l, Y->bwd_xb_cap, (int*)nullptr, 0);
+                         Y->bwd_top[l] + 256*l, Y->bwd_xb_cap, (int*)nullptr, 0, Y->d_info);
     else if(n > 0 && Y->bwd_nt[l] == 256)
       hipLaunchKernelGGL(HIP_KERNEL_NAME(k_solve_bwd_level<256, false>), dim3(n), dim3(256), Y->bwd_lds[l], st,
                          Y->slv_item + H.xl_ptr[l], Y->sn_rows, Y->perm, Y->Lx, Y->ywork, out, use_aug, Y->sn_bd_col,
-                         Y->bwd_top[l] + 256*l, Y->bwd_xb_cap, (int*)nullptr, 0);
+                         Y->bwd_top[l] + 256*l, Y->bwd_xb_cap, (int*)nullptr, 0, Y->d_info);
     else if(n > 0)
       hipLaunchKernelGGL(HIP_KERNEL_NAME(k_solve_bwd_level<512, false>), dim3(n), dim3(512), Y->bwd_lds[l], st,
                          Y->slv_item + H.xl_ptr[l], Y->sn_rows, Y->perm, Y->Lx, Y->ywork, out, use_aug, Y->sn_bd_col,
-                         Y->bwd_top[l] + 256*l, Y->bwd_xb_cap, (int*)nullptr, 0);
+                         Y->bwd_top[l] + 256*l, Y->bwd_xb_cap, (int*)nullptr, 0, Y->d_info);
   }
   DLG_LAUNCH_CHECK();
   if(H.part_nranks > 1)
