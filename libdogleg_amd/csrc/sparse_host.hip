@@ -2,6 +2,11 @@
 // numeric buffers) and the K4 + K5 orchestration.  The kernels live in sparse_assemble.hip,
 // sparse_factor.hip and sparse_solve.hip.
 #include "sparse_internal.h"
+#include <mutex>
+#include <memory>
+#include <string>
+#include <algorithm>
+#include <cstring>
 #include <chrono>
 
 int sparse_create(dlg_backend* b) { (void)b; return DLG_OK; }
@@ -22,6 +27,44 @@ void sparse_destroy(dlg_backend* b)
 
 #define UP(field) do { DLG_CHECK(upload(Y->field, H.field)); Y->allocs.push_back(Y->field); } while(0)
 
+// ---- the last symbolic analysis of the process is kept ------------------------------------------
+// A program that solves many problems of ONE sparsity pattern (the usual case: the same scene, new
+// measurements) pays the host-side symbolic phase once: the next dlg_sparse_set_pattern with the same
+// (sizes, rows of the rank, partition, pattern, schedule knobs in the environment) copies the schedules
+// instead of deriving them (0.14 s -> a few ms for config #4).  The pattern itself is kept and compared
+// (memcmp) behind a 64-bit hash, so a hit is exact.  DOGLEG_AMD_NO_SYM_CACHE turns it off.
+namespace {
+struct SymCacheEntry
+{
+  uint64_t key = 0;
+  int N = 0, M = 0, nnz = 0, row0 = 0, row1 = 0, part_rank = 0, part_nranks = 1;
+  std::vector<int> cp, ri;
+  SymHost H;
+};
+std::mutex g_sym_mu;
+std::unique_ptr<SymCacheEntry> g_sym_cache;
+inline uint64_t mix64(uint64_t h, uint64_t v) { h ^= v; h *= 0x9E3779B97F4A7C15ull; h ^= h >> 29; return h; }
+uint64_t hash_ints(uint64_t h, const int* p, size_t n)
+{
+  size_t i = 0;
+  for(; i + 1 < n; i += 2) { uint64_t v; memcpy(&v, p + i, 8); h = mix64(h, v); }
+  if(i < n) h = mix64(h, (uint64_t)(uint32_t)p[i]);
+  return h;
+}
+extern "C" char** environ;
+uint64_t hash_env_knobs()
+{
+  // every DOGLEG_AMD_* / DLG_* variable may steer the schedules (the tests force kernels through them)
+  std::vector<std::string> v;
+  for(char** e = environ; e && *e; e++)
+    if(!strncmp(*e, "DOGLEG_AMD_", 11) || !strncmp(*e, "DLG_", 4)) v.emplace_back(*e);
+  std::sort(v.begin(), v.end());
+  uint64_t h = 0x1234567ull;
+  for(const std::string& t : v) for(char c : t) h = mix64(h, (uint64_t)(unsigned char)c);
+  return h;
+}
+}
+
 int sparse_set_pattern(dlg_backend* b, const int* colptr, const int* rowidx)
 {
   if(b->sym) { dlg_set_error("the sparsity pattern was already set"); return DLG_ERR_STATE; }
@@ -38,10 +81,43 @@ int sparse_set_pattern(dlg_backend* b, const int* colptr, const int* rowidx)
     fprintf(stderr, "libdogleg_amd: timing:   %-32s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
     t_last = now; };
   char err[512];
-  if(sym_analyze(Y->H, b->N, b->M, colptr, rowidx, b->row0, b->row1, err, sizeof(err), b->part_rank, b->part_nranks))
-  { dlg_set_error("symbolic analysis: %s", err); return DLG_ERR_ARG; }
+  bool cached = false;
+  const bool use_cache = getenv("DOGLEG_AMD_NO_SYM_CACHE") == nullptr;
+  uint64_t key = 0;
+  if(use_cache)
+  {
+    key = hash_env_knobs();
+    const int hdr[8] = { b->N, b->M, b->nnz, b->row0, b->row1, b->part_rank, b->part_nranks, 0 };
+    key = hash_ints(key, hdr, 8);
+    key = hash_ints(key, colptr, (size_t)b->M + 1);
+    key = hash_ints(key, rowidx, (size_t)b->nnz);
+    std::lock_guard<std::mutex> lk(g_sym_mu);
+    const SymCacheEntry* c = g_sym_cache.get();
+    if(c && c->key == key && c->N == b->N && c->M == b->M && c->nnz == b->nnz && c->row0 == b->row0 && c->row1 == b->row1 &&
+       c->part_rank == b->part_rank && c->part_nranks == b->part_nranks &&
+       !memcmp(c->cp.data(), colptr, sizeof(int)*((size_t)b->M + 1)) && !memcmp(c->ri.data(), rowidx, sizeof(int)*(size_t)b->nnz))
+    { Y->H = c->H; cached = true; }
+  }
+  if(!cached)
+  {
+    if(sym_analyze(Y->H, b->N, b->M, colptr, rowidx, b->row0, b->row1, err, sizeof(err), b->part_rank, b->part_nranks))
+    { dlg_set_error("symbolic analysis: %s", err); return DLG_ERR_ARG; }
+    if(use_cache)
+    {
+      std::unique_ptr<SymCacheEntry> e(new (std::nothrow) SymCacheEntry());
+      if(e)
+      {
+        e->key = key; e->N = b->N; e->M = b->M; e->nnz = b->nnz; e->row0 = b->row0; e->row1 = b->row1;
+        e->part_rank = b->part_rank; e->part_nranks = b->part_nranks;
+        e->cp.assign(colptr, colptr + b->M + 1); e->ri.assign(rowidx, rowidx + b->nnz);
+        e->H = Y->H;
+        std::lock_guard<std::mutex> lk(g_sym_mu);
+        g_sym_cache = std::move(e);
+      }
+    }
+  }
   SymHost& H = Y->H;
-  lap("symbolic analysis (host)");
+  lap(cached ? "symbolic analysis (copied: same pattern as the last one)" : "symbolic analysis (host)");
   const bool partition = H.part_nranks > 1;
   if(partition) b->mloc = (int)H.part_rows.size();
   UP(sn_c0); UP(sn_rowptr); UP(sn_rows); UP(sn_scr); UP(lvl_sn); UP(sn_lx); UP(diagpos);

@@ -476,3 +476,36 @@ def test_gradient_out_of_the_assembly_pass(gpu, shape, kw):
     assert a[1] == b[1] and a[4] == b[4]
     for k in (3, 6):
         assert np.max(np.abs(a[k] - b[k])) <= 1e-11*max(1.0, np.max(np.abs(a[k])))
+
+
+def test_symbolic_analysis_is_copied_for_a_repeated_pattern(gpu, monkeypatch):
+    """the library keeps the last symbolic analysis: a second backend with the same pattern copies it
+    (same schedules: bit-identical steps), a different pattern or different schedule knobs do not hit"""
+    prob = oa.BAProblem(49, 900, 10000, seed=3)
+    other = oa.BAProblem(49, 900, 9000, seed=3)
+    p = prob.p0()
+    x, Jx = prob.eval(p)
+
+    def gn(pr, xx, JJ, pp):
+        be = capi.Backend(capi.DLG_SPARSE, pr.N, pr.M, pr.nnz)
+        be.set_pattern(*pr.pattern())
+        be.set_p(0, pp)
+        be.upload(0, xx, JJ)
+        be.eval(0)
+        lam, n2g = be.gauss_newton(0, 0.0)
+        out = (n2g, be.download(0, capi.VEC_GN), be.stats(), be.schedule())
+        be.close()
+        return out
+
+    a = gn(prob, x, Jx, p)
+    b = gn(prob, x, Jx, p)                          # hit
+    assert a[0] == b[0] and np.array_equal(a[1], b[1]) and a[2] == b[2] and a[3] == b[3]
+    xo, Jo = other.eval(other.p0())
+    c = gn(other, xo, Jo, other.p0())               # another pattern in between
+    assert c[2]["nnz_JtJ_lower"] != a[2]["nnz_JtJ_lower"]
+    monkeypatch.setenv("DOGLEG_AMD_NO_PERSIST", "1")
+    d = gn(prob, x, Jx, p)                          # same pattern, other knobs: analysed again
+    assert d[3]["persist_level0"] == -1 and np.array_equal(a[1], d[1])
+    monkeypatch.setenv("DOGLEG_AMD_NO_SYM_CACHE", "1")
+    e = gn(prob, x, Jx, p)
+    assert np.array_equal(d[1], e[1])

@@ -7,9 +7,10 @@
   device callback  dogleg_optimize_device2: the model is evaluated on the GPU, nothing
                    but p_new (N doubles) and a few scalars crosses PCIe per trial.
 
-For both: the first call (pays the one-off symbolic analysis of the pattern, allocations, the lazy
-loading of code objects) and a second call of the same solve (steady state of a process that solves
-many problems of one shape ... the symbolic analysis is still redone: it belongs to a solve)."""
+For both: the first call (pays the symbolic analysis of the pattern, allocations, the lazy loading of
+code objects) and a second call of the same solve (steady state of a process that solves many
+problems of one shape: the library keeps the last symbolic analysis and copies it when the pattern
+is the same -- sparse_set_pattern)."""
 import argparse
 import json
 import os
@@ -60,10 +61,8 @@ out = {"workload": a.workload, "Nmeas": prob.M, "Nstate": prob.N, "nnz": prob.nn
        "trials": trh.ntrials, "callbacks": trh.ncallbacks, "symbolic_analysis_s": t_sym,
        "host_callback": {"first_call_s": th1, "second_call_s": th2, "callback_s_each": t_cb,
                          "steps_per_s": trh.ntrials / th2,
-                         "steps_per_s_excluding_callback_and_symbolic": trh.ntrials / max(1e-9, th2 - t_cb * trh.ncallbacks - t_sym),
                          "h2d_bytes_per_eval": 8 * (prob.nnz + prob.M)},
        "device_callback": {"first_call_s": td1, "second_call_s": td2, "steps_per_s": trd.ntrials / td2,
-                           "steps_per_s_excluding_symbolic": trd.ntrials / max(1e-9, td2 - t_sym),
                            "h2d_bytes_per_eval": 0, "d2h_bytes_per_trial": 8 * prob.N,
                            "trials": trd.ntrials, "evaluations_on_device": twin.neval()},
        "max_abs_p_diff_device_vs_host": float(np.max(np.abs(pd - ph))),

@@ -90,7 +90,8 @@ rocprofv3 --stats, dense-50k:
 End to end (`tools/e2e_bench.py`, sparse-1m, {e2e['trials']} trials + {e2e['callbacks']} evaluations; NOT bench.py's value):
 host callback {hc['second_call_s']:.2f} s per solve ({hc['steps_per_s']:.1f} steps/s; callback {1e3*hc['callback_s_each']:.0f} ms per evaluation, {hc['h2d_bytes_per_eval']/1e6:.0f} MB host->device per
 evaluation), **device callback {dc['second_call_s']:.2f} s per solve ({dc['steps_per_s']:.1f} steps/s; no H2D of J, {dc['d2h_bytes_per_trial']/1e6:.1f} MB device->host per trial)**;
-symbolic analysis {e2e['symbolic_analysis_s']:.2f} s of each; final p of the two differs by {e2e['max_abs_p_diff_device_vs_host']:.1e}.
+symbolic analysis {e2e['symbolic_analysis_s']:.2f} s in the first solve of a pattern (that call: {hc['first_call_s']:.2f} s), copied from the previous solve
+of the same pattern afterwards (15 ms); final p of the two differs by {e2e['max_abs_p_diff_device_vs_host']:.1e}.
 
 RCCL in-stream path at world size 1 (the library's own communicator, `dlg_backend_init_rccl`):
 `{tag}_bench_dist_world1_rccl.log`.  Probes ({tag}_probe.txt): fp64 MFMA issue rate 48 TFLOP/s; HBM copy 4.9 TB/s.
