@@ -420,7 +420,7 @@ def test_persistent_top_region_changes_no_bit(gpu, shape, monkeypatch):
         sched[mode] = be.schedule()
         be.set_p(0, p)
         res = []
-        for rep in range(4):
+        for rep in range(16 if shape[0] < 100 else 6):
             for x, Jx in evals:
                 be.upload(0, x, Jx)
                 be.eval(0)
