@@ -128,7 +128,8 @@ __global__ void __launch_bounds__(BWD_NT, BD_ONLY ? 4 : 1) k_solve_bwd_level(con
   typedef __attribute__((address_space(1))) double* gd_t;
   auto ldx = [&](const double* p) -> double { return pr_flag ? __hip_atomic_load((gcd_t)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p; };
 
-  const int prof_lvl = top_lds >> 8; (void)prof_lvl; top_lds &= 1;
+  const int prof_lvl = top_lds >> 8; (void)prof_lvl;
+  top_lds &= 1;
   BW_STAMP(0);
   const SolveItem it = items[blockIdx.x];
   const int c0 = it.c0, w = it.w, nrows = it.nrows;
@@ -148,6 +149,14 @@ __global__ void __launch_bounds__(BWD_NT, BD_ONLY ? 4 : 1) k_solve_bwd_level(con
   double* xp = rhs + 16;                  // [parts][256] partial sums of the mat-vec
   double* Lt = xp + 8*256;                // [w][ldt] top block (top_lds)
   const int ldt = w | 1;
+  // Pre-multiplied sweep (premul): the sweep over the 8-column blocks needs, per block and thread,
+  // upd = sum_a L(j0+a, tid) * x_blk(a) with x_blk = inv(block)' rh.  Written as sum_b rh(b) * m(b),
+  // m(b) = sum_{a<=b} inv(block)(b,a) * L(j0+a, tid), the m's depend on the factor alone: they are
+  // formed for ALL blocks before x of the ancestors is there (in the one-launch region: while the
+  // workgroup waits for its parent), and the serial sweep shrinks to 8 multiply-adds per block and
+  // thread plus one 8-term dot product in the 8 threads that own the block.
+  const int MW = (w + 15) & ~15;
+  double* Mx = Lt + (top_lds ? w*ldt : 0); // [nblk][8][MW]
   // block-diagonal top (merged sibling leaves): the members do not couple, every member is a
   // little triangular system of its own -- no sweep over the columns at all
   const int nmem = BD_ONLY ? max(it.nbd, 1) : it.nbd;      // BD_ONLY: every supernode of the launch has a block-diagonal top
@@ -212,6 +221,66 @@ __global__ void __launch_bounds__(BWD_NT, BD_ONLY ? 4 : 1) k_solve_bwd_level(con
       for(int b = 0; b <= a; b++) Lm[a][b] = (a < nbm) ? L[(m0 + a) + (size_t)(m0 + b)*nrows] : (a == b ? 1.0 : 0.0);
   }
   BW_STAMP(1);
+  const bool premul = it.rsv != 0 && !BD_ONLY && nmem == 0;     // (rsv: the supernode's level has LDS room for it, sparse_solve_setup)
+  if(premul)
+  {
+    // diagonal blocks -> their inverses (in place), then the m's of every block below this thread's own
+    __syncthreads();
+    double ti[8];
+    const bool ton = tid < 8*nblk;
+    if(ton)
+    {
+      const double* Tb = T + (tid >> 3)*64;
+      const int c = tid & 7;
+      double Lb[8][8];
+#pragma unroll
+      for(int a = 0; a < 8; a++)
+#pragma unroll
+        for(int b2 = 0; b2 <= a; b2++) Lb[a][b2] = Tb[a*8 + b2];
+#pragma unroll
+      for(int i = 0; i < 8; i++)
+      {
+        double v = 0.0;
+#pragma unroll
+        for(int k = 0; k < i; k++) v -= (k >= c) ? Lb[i][k]*ti[k] : 0.0;
+        ti[i] = (i == c) ? Lb[i][i] : ((i > c) ? v*Lb[i][i] : 0.0);
+      }
+    }
+    __syncthreads();
+    if(ton)
+    {
+      double* Tb = T + (tid >> 3)*64;
+      const int c = tid & 7;
+#pragma unroll
+      for(int i = 0; i < 8; i++) if(i >= c) Tb[i*8 + c] = ti[i];
+    }
+    __syncthreads();
+    if(tid < w)
+    {
+      const double* Lc = L + (size_t)tid*nrows;            // column tid of L = row tid of L'
+      const int wl = w - 1, b0 = (tid >> 3) + 1;           // first block strictly below this thread's row
+      double cur[8], nxt[8];
+#pragma unroll
+      for(int a = 0; a < 8; a++) { cur[a] = Lc[min(8*min(b0, nblk - 1) + a, wl)]; nxt[a] = Lc[min(8*min(b0 + 1, nblk - 1) + a, wl)]; }
+      for(int blk = b0; blk < nblk; blk++)
+      {
+        double far[8];
+#pragma unroll
+        for(int a = 0; a < 8; a++) far[a] = Lc[min(8*min(blk + 2, nblk - 1) + a, wl)];
+        const double* Tb = T + blk*64;
+#pragma unroll
+        for(int b2 = 0; b2 < 8; b2++)
+        {
+          double m = Tb[b2*8]*cur[0];
+#pragma unroll
+          for(int a = 1; a <= b2; a++) m += Tb[b2*8 + a]*cur[a];
+          Mx[(blk*8 + b2)*MW + tid] = m;
+        }
+#pragma unroll
+        for(int a = 0; a < 8; a++) { cur[a] = nxt[a]; nxt[a] = far[a]; }
+      }
+    }
+  }
   // ---- round 3
   if(tid < 256) xs[tid] = 0.0;            // columns without below rows (a root) get no mat-vec pass
   if(pr_flag)
@@ -246,7 +315,7 @@ __global__ void __launch_bounds__(BWD_NT, BD_ONLY ? 4 : 1) k_solve_bwd_level(con
   // independent dot products per block instead of a 36-step substitution chain.  The column is
   // written back behind the next barrier (every thread has read the original block by then).
   double tinv[8];
-  const bool tinv_on = !BD_ONLY && nmem == 0 && tid < 8*nblk;
+  const bool tinv_on = !BD_ONLY && nmem == 0 && tid < 8*nblk && !premul;
   if(tinv_on)
   {
     const double* Tb = T + (tid >> 3)*64;
@@ -375,6 +444,54 @@ __global__ void __launch_bounds__(BWD_NT, BD_ONLY ? 4 : 1) k_solve_bwd_level(con
   // top block when the level has room for it, else from HBM two blocks ahead with clamped,
   // unconditional loads; every thread computes the 8 unknowns of a block itself (dot products with
   // the inverted diagonal block) and ONE thread parks them in xs -- the owners pick them up at the end.
+  if(premul)
+  {
+    const int own = tid & 7;
+    for(int blk = nblk - 1; blk >= 0; blk--)
+    {
+      const int j0 = 8*blk;
+      double* rh = rhs + 8*(blk & 1);
+      if(tid >= j0 && tid < j0 + 8) rh[tid - j0] = xi;
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      double r8[8];
+#pragma unroll
+      for(int b2 = 0; b2 < 8; b2++) r8[b2] = rh[b2];
+      if(tid < j0)
+      {
+        const double* Mb = Mx + (size_t)blk*8*MW + tid;
+        double upd = Mb[0]*r8[0];
+#pragma unroll
+        for(int b2 = 1; b2 < 8; b2++) upd += Mb[b2*MW]*r8[b2];
+        xi -= upd;
+      }
+      else if(tid < j0 + 8)
+      {
+        // an owner: its unknown of this block, x(j0 + own) = sum_b inv(b, own) rh(b) (zeros above the diagonal)
+        const double* Tb = T + blk*64 + own;
+        double v = Tb[0]*r8[0];
+#pragma unroll
+        for(int b2 = 1; b2 < 8; b2++) v += Tb[b2*8]*r8[b2];
+        xs[min(tid, 255)] = v;
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if(tid < w) xi = xs[tid];
+    BW_STAMP(4);
+    if(tid < w)
+    {
+      if(pr_flag) __hip_atomic_store((gd_t)(ywork + c0 + tid), xi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      else ywork[c0 + tid] = xi;
+      out[myperm] = xi;
+    }
+    if(pr_flag)
+    {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if(tid == 0) __hip_atomic_store(pr_flag + blockIdx.x, pr_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    BW_STAMP(5);
+    return;
+  }
   const double* Lcol = L + (size_t)min(tid, w - 1)*nrows;      // column tid of L = row tid of L^T
   const double* Ltc = Lt + min(tid, w - 1)*ldt;
   const int wlast = w - 1;
@@ -518,7 +635,7 @@ int sparse_solve_setup(dlg_backend* b)
   // below rows of a supernode that the backward solve stages in LDS (96 KB of x); beyond that it gathers x from HBM
   const long xb_cap = env_int_solve("DOGLEG_AMD_BWD_XB_CAP", 12288);
   Y->bwd_xb_cap = (int)xb_cap;
-  Y->slv_lds.assign(H.nlevels, 0); Y->bwd_lds.assign(H.nlevels, 0); Y->bwd_nt.assign(H.nlevels, 512); Y->bwd_top.assign(H.nlevels, 0); Y->bwd_bd.assign(H.nlevels, 0);
+  Y->slv_lds.assign(H.nlevels, 0); Y->bwd_lds.assign(H.nlevels, 0); Y->bwd_nt.assign(H.nlevels, 512); Y->bwd_top.assign(H.nlevels, 0); Y->bwd_bd.assign(H.nlevels, 0); Y->bwd_pmx.assign(H.nlevels, 0);
   for(int l = 0; l < H.nlevels; l++)
   {
     long maxw = 0, mb = 0, mbt = 0, wmax_all = 0;
@@ -544,6 +661,18 @@ int sparse_solve_setup(dlg_backend* b)
     // the top block rides in LDS when every supernode of the level has room for it
     Y->bwd_top[l] = (mbt*8 <= LDS_BUDGET && getenv("DOGLEG_AMD_BWD_TOP")) ? 1 : 0;     // measured slower than the prefetch from HBM: off unless asked for
     Y->bwd_lds[l] = (int)((Y->bwd_top[l] ? mbt : mb)*8);
+    Y->bwd_pmx[l] = 0;
+    {
+      // room for the pre-multiplied operands of the block sweep (k_solve_bwd_level: premul), [nblk][8][w16] per supernode
+      long pm = 0;
+      for(int i = H.lvl_ptr[l]; i < H.lvl_ptr[l+1]; i++)
+      {
+        const int s = H.lvl_sn[i];
+        const long wv = H.sn_c0[s+1] - H.sn_c0[s];
+        if(H.sn_bd_ptr[s+1] == H.sn_bd_ptr[s]) pm = std::max(pm, ((wv + 7)/8)*8*((wv + 15) & ~15L));
+      }
+      if(pm > 0 && !getenv("DOGLEG_AMD_NO_PREMUL") && (long)Y->bwd_lds[l] + pm*8 <= LDS_BUDGET) Y->bwd_pmx[l] = (int)(pm*8);
+    }
     // thread = row of the diagonal block: 256 threads when every supernode of a populous level is
     // narrow (more workgroups per CU), else 512
     Y->bwd_nt[l] = (maxw <= 128 && H.lvl_ptr[l+1] - H.lvl_ptr[l] >= 512) ? 256 : 512;
@@ -551,6 +680,8 @@ int sparse_solve_setup(dlg_backend* b)
     bool allbd = true;
     for(int i = H.lvl_ptr[l]; i < H.lvl_ptr[l+1]; i++) { const int s = H.lvl_sn[i]; if(H.sn_bd_ptr[s+1] == H.sn_bd_ptr[s]) allbd = false; }
     Y->bwd_bd[l] = allbd ? 1 : 0;
+    if(Y->bwd_nt[l] != 512 || Y->bwd_bd[l]) Y->bwd_pmx[l] = 0;
+    Y->bwd_lds[l] += Y->bwd_pmx[l];
   }
   {
     // (the supernodes this rank works on: all of them, or its subtrees + the replicated top)
@@ -561,7 +692,7 @@ int sparse_solve_setup(dlg_backend* b)
       SolveItem& it = items[k];
       it.c0 = H.sn_c0[s]; it.w = H.sn_c0[s+1] - H.sn_c0[s]; it.nrows = H.sn_rowptr[s+1] - H.sn_rowptr[s];
       it.rowoff = H.sn_rowptr[s]; it.lx = H.sn_lx[s]; it.bd0 = H.sn_bd_ptr[s]; it.nbd = H.sn_bd_ptr[s+1] - H.sn_bd_ptr[s];
-      it.pflag = -1; it.rsv = 0;
+      it.pflag = -1; it.rsv = Y->bwd_pmx[H.sn_level[s]] ? 1 : 0;
     }
     DLG_CHECK(upload(Y->slv_item, items)); Y->allocs.push_back(Y->slv_item);
   }
@@ -598,6 +729,7 @@ int sparse_solve_setup(dlg_backend* b)
       if(n == 0 || total + n > cap || Y->bwd_nt[l] != 512 || Y->bwd_bd[l] || Y->bwd_top[l]) break;
       total += n; l0 = l; ldsb = std::max(ldsb, Y->bwd_lds[l]);
     }
+
     if(H.nlevels - l0 >= 2)
     {
       std::vector<SolveItem> items;
@@ -609,7 +741,7 @@ int sparse_solve_setup(dlg_backend* b)
           SolveItem it;
           it.c0 = H.sn_c0[s]; it.w = H.sn_c0[s+1] - H.sn_c0[s]; it.nrows = H.sn_rowptr[s+1] - H.sn_rowptr[s];
           it.rowoff = H.sn_rowptr[s]; it.lx = H.sn_lx[s]; it.bd0 = H.sn_bd_ptr[s]; it.nbd = H.sn_bd_ptr[s+1] - H.sn_bd_ptr[s];
-          it.rsv = 0; it.pflag = -1;
+          it.rsv = Y->bwd_pmx[l] ? 1 : 0; it.pflag = -1;
           // the parent: the supernode of the first below row (the last row is the augmented one)
           if(it.nrows - it.w - 1 > 0)
           {
