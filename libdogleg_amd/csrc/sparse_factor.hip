@@ -238,8 +238,11 @@ __device__ __forceinline__ void factor_tail_tiles(const double* Pb, int ldp, int
 // mode 2 (multifrontal region) first adds the children's update matrices (mf_add_children), leaves
 // them in U as well and stores W = -U.  U is staged behind the panel in LDS when both fit.
 // The panel is copied in and out thread = (row, column group), CP_FLIGHT columns in flight.
-template <int NT>
-__global__ void __launch_bounds__(NT) k_factor_level(const FwItem* __restrict__ items,
+// LEAF: every work item of the launch is an unsliced block-diagonal panel in the compact layout (a level
+// of merged leaves) -- the paths of the other kinds of panel are compiled out, which brings the kernel
+// under 128 registers: 4 workgroups per CU instead of 3.
+template <int NT, bool LEAF = false>
+__global__ void __launch_bounds__(NT, LEAF ? 4 : 1) k_factor_level(const FwItem* __restrict__ items,
                                                      const MfChild* __restrict__ mf_rec,
                                                      const int* __restrict__ sn_bd_col,
                                                      const uint16_t* __restrict__ mf_dst,
@@ -251,7 +254,7 @@ __global__ void __launch_bounds__(NT) k_factor_level(const FwItem* __restrict__ 
 {
   extern __shared__ __attribute__((aligned(16))) double P[];
   __shared__ int sbad, s_skip;
-  constexpr int CP_FLIGHT = 32;
+  constexpr int CP_FLIGHT = LEAF ? 16 : 32;
 #ifdef DLG_FL_PROFILE
   const int prof_lvl = mode >> 8;
   FL_STAMP(0);
@@ -287,7 +290,7 @@ __global__ void __launch_bounds__(NT) k_factor_level(const FwItem* __restrict__ 
   __shared__ int s_mcol[260];
   __shared__ double s_rdiag[256];
   MfChild rc = {0, 0, 0, 0};
-  const bool mf_acc = mode == 2 && it.nch > 0;
+  const bool mf_acc = !LEAF && mode == 2 && it.nch > 0;
   if(mf_acc) rc = mf_rec[it.ch0 + min(lane, it.nch - 1)];     // on its way during the panel copy
   // (s_skip: a launch before this one found a non-positive pivot -- the factorisation is going to be
   // thrown away by the lambda loop, dogleg.c:656-677: nothing to do here but to let the parent go on)
@@ -349,6 +352,7 @@ __global__ void __launch_bounds__(NT) k_factor_level(const FwItem* __restrict__ 
   }
   FL_STAMP(2);
   if(cmp) bd_compact_rows<NT>(Pb, ldp, nloc, w, tid, it.nbd, s_mcol, s_rdiag, Dg);
+  else if(LEAF) { }
   else if(it.nbd > 0) panel_factor_blockdiag<NT>(P, ldp, nloc, w, tid, sn_bd_col + it.bd0, it.nbd, &sbad, it.col0, s_mcol, s_rdiag);
   else if(NT >= 256 && ahead && w <= PF_AHEAD_MAXW) panel_factor_ahead<(NT >= 256 ? NT : 256)>(P, ldp, nloc, w, tid, &sbad, it.col0, s_rdiag, s_mcol);
   else if(NT >= 256) panel_factor_mfma<(NT >= 256 ? NT : 256)>(P, ldp, nloc, w, tid, &sbad, it.col0);
@@ -1156,6 +1160,18 @@ int sparse_factor_setup(dlg_backend* b)
                               hipFuncAttributeMaxDynamicSharedMemorySize, FAC_LDS_BUDGET));
   DLG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_factor_level<256>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, FAC_LDS_BUDGET));
+  DLG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_factor_level<256, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, FAC_LDS_BUDGET));
+  // levels whose work items are all unsliced block-diagonal panels (merged leaves) outside the
+  // multifrontal region: the lean instantiation
+  Y->fac_leaf.assign(H.nlevels, 0);
+  for(int l = 0; l < H.nlevels && !getenv("DOGLEG_AMD_NO_LEAF_KERNEL"); l++)
+  {
+    bool all = H.fw_lvl_ptr[l+1] > H.fw_lvl_ptr[l] && l < H.mf_level0;
+    for(int i = H.fw_lvl_ptr[l]; i < H.fw_lvl_ptr[l+1] && all; i++)
+    { const FwItem& it = H.fw_item[i]; if(!(it.nbd > 0 && it.top < 0)) all = false; }
+    Y->fac_leaf[l] = all ? 1 : 0;
+  }
   DLG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_factor_level<512>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, FAC_LDS_BUDGET));
   DLG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_update_level),
@@ -1248,6 +1264,9 @@ int sparse_factor_levels(dlg_backend* b)
       const int fmode = ((l >= H.mf_level0) ? 2 : Y->syrk_fused[l]) + 4*Y->fac_stage[l] + use_ahead + 256*l;
       if(Y->fac_nt[l] == 128)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_factor_level<128>), dim3(n), dim3(128), Y->fac_lds[l], st,
+                           Y->fw_item + o, Y->mf_rec, Y->sn_bd_col, Y->mf_dst, Y->Lx, Y->top_scr, Y->d_info, Y->uscr, fmode, (int*)nullptr, 0, 0, (int64_t)0);
+      else if(Y->fac_nt[l] == 256 && Y->fac_leaf[l])
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_factor_level<256, true>), dim3(n), dim3(256), Y->fac_lds[l], st,
                            Y->fw_item + o, Y->mf_rec, Y->sn_bd_col, Y->mf_dst, Y->Lx, Y->top_scr, Y->d_info, Y->uscr, fmode, (int*)nullptr, 0, 0, (int64_t)0);
       else if(Y->fac_nt[l] == 256)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_factor_level<256>), dim3(n), dim3(256), Y->fac_lds[l], st,

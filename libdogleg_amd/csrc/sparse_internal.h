@@ -103,7 +103,7 @@ struct SparseSym
   uint32_t* ar_idx = nullptr; double* ar_buf = nullptr; size_t ar_n = 0;
   // per-level launch parameters
   std::vector<int> fac_lds;     // bytes of LDS for the factor kernel of a level (0: panels stay in HBM)
-  std::vector<int> upd_lds, upd_nw, slv_lds, bwd_lds, fac_nt, upd_coop, syrk_lds, syrk_nt, syrk_kc, bwd_nt, syrk_fused, fin_ny, fac_stage, bwd_top, bwd_bd, bwd_pmx;
+  std::vector<int> upd_lds, upd_nw, slv_lds, bwd_lds, fac_nt, upd_coop, syrk_lds, syrk_nt, syrk_kc, bwd_nt, syrk_fused, fin_ny, fac_stage, bwd_top, bwd_bd, bwd_pmx, fac_leaf;
   // subtree partition (part_nranks > 1): what is summed over the ranks between the last level below
   // the cut and the first one above it -- segments of Lx (panels above the cut) and of uscr (update
   // matrices that cross the cut), packed into red_buf --, and the 0/1 mask that makes the solution

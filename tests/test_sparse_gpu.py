@@ -158,10 +158,11 @@ def test_ba_lambda_path(gpu):
     {"DOGLEG_AMD_NO_FUSED_EVAL": "1"},                              # Jt*x by its own pass over J (k_jtx)
     {"DOGLEG_AMD_NO_TOUCH": "1"},                                   # no cache hint for the leaf panels
     {"DOGLEG_AMD_NO_PREMUL": "1"},                                  # backward block sweep with the operands multiplied in the loop
+    {"DOGLEG_AMD_NO_LEAF_KERNEL": "1"},                             # merged leaves through the general factor kernel
 ], ids=["lds-assembly", "coop-update", "mfma-update", "syrk-unfused", "no-rider", "small-slices", "no-multifrontal",
         "multifrontal-from-leaves", "multifrontal-128", "multifrontal-256", "multifrontal-small-fronts", "device-finals",
         "bwd-x-from-hbm", "panel-ahead", "no-overlap", "no-persistent-top", "deep-persistent-top",
-        "leaf-lds-full", "separate-jtx", "no-touch", "no-premul"])
+        "leaf-lds-full", "separate-jtx", "no-touch", "no-premul", "no-leaf-kernel"])
 def test_fallback_kernels_match_oracle(gpu, env, monkeypatch):
     """the kernels the default schedule does not pick on a bundle-adjustment pattern stay correct:
     the schedule knobs are read when the pattern is set"""
