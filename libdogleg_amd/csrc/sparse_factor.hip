@@ -35,7 +35,8 @@ __device__ __forceinline__ int tri_col(int j, int mb) { return j*mb - j*(j - 1)/
 template <int NT, bool UT_LDS, bool HANDOFF = false>
 __device__ __forceinline__ void mf_add_children(double* P, double* Wt, int ntri, int nch, int ch0,
                                                 MfChild rc, const MfChild* __restrict__ mf_rec,
-                                                const double* uscr, const uint16_t* __restrict__ mf_dst, int tid)
+                                                const double* uscr, const uint16_t* __restrict__ mf_dst, int tid,
+                                                int* pr_flag = nullptr, int pr_epoch = 0, int pr_item0 = 0, int* info = nullptr)
 {
   constexpr int MF_SLOTS = (NT >= 512) ? 20 : 16;      // 512 threads: up to 10240 entries (a 139-row update matrix) in one round
   const int lane = tid & 63;
@@ -44,6 +45,24 @@ __device__ __forceinline__ void mf_add_children(double* P, double* Wt, int ntri,
   for(int k = 0; k < nch; k++)
   {
     if(k > 0 && (k & 63) == 0) rc = mf_rec[ch0 + k + min(lane, nch - k - 1)];
+    if(HANDOFF)
+    {
+      // persistent top region: wait for THIS child's flag only (the children of this launch; the others
+      // finished with the launch before).  The symbolic phase lists the children by expected time of
+      // arrival, the latest last: the early ones are added while the late one is still at work, and the
+      // order of the sums stays what the list says.
+      const int ci = __builtin_amdgcn_readlane(rc.rsv, k & 63);
+      if(tid == 0 && ci >= pr_item0)
+      {
+        int spins = 0;
+        while(__hip_atomic_load(pr_flag + ci, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != pr_epoch)
+        {
+          __builtin_amdgcn_s_sleep(1);
+          if(++spins > (1 << 21)) { atomicMin(info, 0); break; }      // a child that never arrives: report, do not hang
+        }
+      }
+      __syncthreads();
+    }
     const int npad = __builtin_amdgcn_readlane(rc.npad, k & 63);
     const int64_t uo = ((int64_t)__builtin_amdgcn_readlane((int)(rc.u_off >> 32), k & 63) << 32) |
                        (uint32_t)__builtin_amdgcn_readlane((int)rc.u_off, k & 63);
@@ -315,24 +334,8 @@ __global__ void __launch_bounds__(NT, LEAF ? 4 : 1) k_factor_level(const FwItem*
       for(int u = 0; u < CP_FLIGHT; u++) if(j0 + u*cp_ng < w) Pb[i + (j0 + u*cp_ng)*ldp] = v[u];
     }
   }
-  if(pr_flag && mf_acc && tid < 64)
-  {
-    // persistent top region (one launch for all its levels, workgroups in level order): the panel
-    // is in LDS already; wave 0 waits for the flags of the children that are part of this launch
-    // (the others finished with the launch before), the barrier below holds the other waves
-    for(int k = lane; k < it.nch; k += 64)
-    {
-      const int ci = (k < 64) ? rc.rsv : mf_rec[it.ch0 + k].rsv;
-      if(ci < pr_item0) continue;
-      int spins = 0;
-      while(__hip_atomic_load(pr_flag + ci, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != pr_epoch)
-      {
-        __builtin_amdgcn_s_sleep(1);
-        if(++spins > (1 << 21)) { atomicMin(info, 0); break; }      // a child that never arrives: report, do not hang
-      }
-    }
-    FL_STAMP(7);
-  }
+  // (persistent top region: the panel is in LDS already; the children's flags are awaited one by one in
+  // mf_add_children)
   __syncthreads();
   FL_STAMP(1);
   if(s_skip)
@@ -345,11 +348,12 @@ __global__ void __launch_bounds__(NT, LEAF ? 4 : 1) k_factor_level(const FwItem*
       for(int i = lane; i < mb - jw; i += 64) P[(mb - jw)*ldp + i] = 0.0;      // (the barrier is in mf_add_children)
   if(mf_acc)
   {
-    if(pr_flag && u_lds) mf_add_children<NT, true, true>(P, Us, nlin, it.nch, it.ch0, rc, mf_rec, uscr, mf_dst, tid);
-    else if(pr_flag)     mf_add_children<NT, false, true>(P, Ug + pr_acc, ntri, it.nch, it.ch0, rc, mf_rec, uscr, mf_dst, tid);
+    if(pr_flag && u_lds) mf_add_children<NT, true, true>(P, Us, nlin, it.nch, it.ch0, rc, mf_rec, uscr, mf_dst, tid, pr_flag, pr_epoch, pr_item0, info);
+    else if(pr_flag)     mf_add_children<NT, false, true>(P, Ug + pr_acc, ntri, it.nch, it.ch0, rc, mf_rec, uscr, mf_dst, tid, pr_flag, pr_epoch, pr_item0, info);
     else if(u_lds)  mf_add_children<NT, true >(P, Us, nlin, it.nch, it.ch0, rc, mf_rec, uscr, mf_dst, tid);
     else            mf_add_children<NT, false>(P, Ug, ntri, it.nch, it.ch0, rc, mf_rec, uscr, mf_dst, tid);
   }
+  FL_STAMP(7);
   FL_STAMP(2);
   if(cmp) bd_compact_rows<NT>(Pb, ldp, nloc, w, tid, it.nbd, s_mcol, s_rdiag, Dg);
   else if(LEAF) { }

@@ -937,6 +937,23 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
         for(int d = 0; d < nsn; d++)
           if(S.sn_level[d] >= S.mf_level0 && sn_parent[d] >= 0) S.mf_child[nx[sn_parent[d]]++] = d;
       }
+      // children in the order of their expected time of arrival, the latest last: a parent adds the early
+      // ones while the late one is still at work (k_factor_level, one-launch region).  The estimate: the
+      // longest chain below (and including) a supernode, a supernode counting panel rows x columns.
+      {
+        std::vector<double> chain(nsn, 0.0);
+        for(int l = 0; l < S.nlevels; l++)
+          for(int i = S.lvl_ptr[l]; i < S.lvl_ptr[l+1]; i++)
+          {
+            const int t = S.lvl_sn[i];
+            double below = 0.0;
+            for(int k = S.mf_cptr[t]; k < S.mf_cptr[t+1]; k++) below = std::max(below, chain[S.mf_child[k]]);
+            chain[t] = below + (double)(S.sn_rowptr[t+1] - S.sn_rowptr[t])*(S.sn_c0[t+1] - S.sn_c0[t]);
+          }
+        for(int t = 0; t < nsn; t++)
+          std::stable_sort(S.mf_child.begin() + S.mf_cptr[t], S.mf_child.begin() + S.mf_cptr[t+1],
+                           [&](int a, int b) { return chain[a] < chain[b]; });
+      }
       S.mf_rec.resize(S.mf_child.size());
       for(int t = 0; t < nsn; t++)
       {
