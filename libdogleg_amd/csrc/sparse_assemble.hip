@@ -971,8 +971,8 @@ int sparse_assemble(dlg_backend* b, int s, double lambda)
     std::swap(Y->Lx, Y->Lx_spec);           // the panels assembled beside K1 become the factor's panels
     Y->spec_valid = false;
     adopted = true;
-    // the other buffer (the previous factor) is free from here on: sparse_zero_spare clears it on the
-    // second stream while the factorisation is latency-bound, the next evaluation finds it zeroed
+    // the other buffer (the previous factor) is free from here on: sparse_zero_spare clears it behind the
+    // step's last fetch (step_finish), the next evaluation finds it zeroed
     Y->spare_zeroed = false; Y->spare_dirty = true;
   }
   else
