@@ -210,8 +210,14 @@ __global__ void __launch_bounds__(BWD_NT, BD_ONLY ? 4 : 1) k_solve_bwd_level(con
   int m0 = 0, nbm = 0;
   if(nmem > 0 && tid < nmem)
   {
-    const int* mcol = sn_bd_col + it.bd0;
-    m0 = mcol[tid]; nbm = ((tid + 1 < nmem) ? mcol[tid + 1] : w) - m0;
+    // (rsv of a block-diagonal supernode: the common width of its members, 0 if they differ -- no list
+    // lookup, i.e. no dependent load in front of the members' loads)
+    if(it.rsv > 0) { m0 = tid*it.rsv; nbm = it.rsv; }
+    else
+    {
+      const int* mcol = sn_bd_col + it.bd0;
+      m0 = mcol[tid]; nbm = ((tid + 1 < nmem) ? mcol[tid + 1] : w) - m0;
+    }
   }
   if(nmem > 0)
   {
@@ -697,6 +703,15 @@ int sparse_solve_setup(dlg_backend* b)
       it.c0 = H.sn_c0[s]; it.w = H.sn_c0[s+1] - H.sn_c0[s]; it.nrows = H.sn_rowptr[s+1] - H.sn_rowptr[s];
       it.rowoff = H.sn_rowptr[s]; it.lx = H.sn_lx[s]; it.bd0 = H.sn_bd_ptr[s]; it.nbd = H.sn_bd_ptr[s+1] - H.sn_bd_ptr[s];
       it.pflag = -1; it.rsv = Y->bwd_pmx[H.sn_level[s]] ? 1 : 0;
+      if(it.nbd > 0)
+      {
+        // block-diagonal top: rsv = the common width of the members (0: they differ)
+        const int* mc = &H.sn_bd_col[it.bd0];
+        const int wd0 = (it.nbd > 1 ? mc[1] : it.w) - mc[0];
+        bool same = mc[0] == 0;
+        for(int m = 0; m < it.nbd && same; m++) if(((m + 1 < it.nbd) ? mc[m+1] : it.w) - mc[m] != wd0 || mc[m] != m*wd0) same = false;
+        it.rsv = same ? wd0 : 0;
+      }
     }
     DLG_CHECK(upload(Y->slv_item, items)); Y->allocs.push_back(Y->slv_item);
   }
@@ -746,6 +761,7 @@ int sparse_solve_setup(dlg_backend* b)
           it.c0 = H.sn_c0[s]; it.w = H.sn_c0[s+1] - H.sn_c0[s]; it.nrows = H.sn_rowptr[s+1] - H.sn_rowptr[s];
           it.rowoff = H.sn_rowptr[s]; it.lx = H.sn_lx[s]; it.bd0 = H.sn_bd_ptr[s]; it.nbd = H.sn_bd_ptr[s+1] - H.sn_bd_ptr[s];
           it.rsv = Y->bwd_pmx[l] ? 1 : 0; it.pflag = -1;
+          if(it.nbd > 0) it.rsv = 0;          // (a block-diagonal top in the region: rsv would mean the members' width; 0 = look it up)
           // the parent: the supernode of the first below row (the last row is the augmented one)
           if(it.nrows - it.w - 1 > 0)
           {
