@@ -620,18 +620,10 @@ __global__ void __launch_bounds__(NT) k_update_syrk(const int* __restrict__ lvl_
 // kernels.
 constexpr int GATHER_FLIGHT = 4;        // sub-tasks whose loads are in flight together
 template <int NT>
-__global__ void __launch_bounds__(NT) k_update_gather(int unit0, const int* __restrict__ uw_item,
-                                                       const int* __restrict__ uw_s0,
-                                                       const int* __restrict__ uw_s1,
-                                                       const int64_t* __restrict__ uw_part,
-                                                       const int* __restrict__ ui_t,
-                                                       const int* __restrict__ ui_col,
-                                                       const int* __restrict__ ui_nc,
+__global__ void __launch_bounds__(NT) k_update_gather(int unit0, const GatherUnit* __restrict__ units,
                                                        const SymSub* __restrict__ usub,
                                                        const int64_t* __restrict__ usub_u,
                                                        const int* __restrict__ relpos,
-                                                       const int* __restrict__ sn_rowptr,
-                                                       const int64_t* __restrict__ sn_lx,
                                                        double* __restrict__ Lx,
                                                        double* __restrict__ upart,
                                                        const double* __restrict__ uscr, int nw,
@@ -640,13 +632,12 @@ __global__ void __launch_bounds__(NT) k_update_gather(int unit0, const int* __re
   extern __shared__ __attribute__((aligned(16))) double lds[];
   __shared__ int s_skip;
   if(threadIdx.x == 0) s_skip = *info != 0x7fffffff;      // a failed factorisation is not worth finishing
-  const int unit = unit0 + blockIdx.x;
-  const int item = uw_item[unit];
-  const int t = ui_t[item], col = ui_col[item], nc = ui_nc[item];
-  const int nrows_t = sn_rowptr[t+1] - sn_rowptr[t];
-  double* Lt = Lx + sn_lx[t] + (int64_t)col*nrows_t;
-  const int s0 = uw_s0[unit], s1 = uw_s1[unit];
-  const int64_t part = uw_part[unit];
+  // (one flat record: the chain unit -> item -> target supernode -> its rows cost three dependent loads
+  // in front of the first barrier)
+  const GatherUnit U0 = units[unit0 + blockIdx.x];
+  const int nc = U0.nc, nrows_t = U0.nrows_t, s0 = U0.s0, s1 = U0.s1;
+  double* Lt = Lx + U0.lt;
+  const int64_t part = U0.part;
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int slab = nrows_t*nc;
@@ -1096,6 +1087,18 @@ int sparse_factor_setup(dlg_backend* b)
       Y->fac_lds[l] = (int)(Y->fac_stage[l] ? std::max(base, leaves) : base);
     }
   }
+  if(!Y->uw_flat && !H.uw_item.empty())
+  {
+    std::vector<GatherUnit> fl(H.uw_item.size());
+    for(size_t u = 0; u < fl.size(); u++)
+    {
+      const int item = H.uw_item[u], t = H.ui_t[item];
+      const int nr = H.sn_rowptr[t+1] - H.sn_rowptr[t];
+      fl[u].lt = H.sn_lx[t] + (int64_t)H.ui_col[item]*nr; fl[u].part = H.uw_part[u];
+      fl[u].s0 = H.uw_s0[u]; fl[u].s1 = H.uw_s1[u]; fl[u].nrows_t = nr; fl[u].nc = H.ui_nc[item];
+    }
+    DLG_CHECK(upload(Y->uw_flat, fl)); Y->allocs.push_back(Y->uw_flat);
+  }
   // Persistent top region: the last levels of the multifrontal region hold a few supernodes each and
   // every one of them waits for the one before -- each kernel boundary costs the launch gap, a cold
   // panel load and the store of the panel before the next level may start.  They go out as ONE
@@ -1295,8 +1298,7 @@ int sparse_factor_levels(dlg_backend* b)
       // (one wave per unit, all units resident at once, was measured: 78 us against 48 with up to four
       // waves sharing a unit's sub-tasks)
       hipLaunchKernelGGL(HIP_KERNEL_NAME(k_update_gather<TPB>), dim3(nu), dim3(TPB), Y->upd_lds[l], st, H.uw_lvl_ptr[l],
-                         Y->uw_item, Y->uw_s0, Y->uw_s1, Y->uw_part, Y->ui_t, Y->ui_col, Y->ui_nc,
-                         Y->usub, Y->usub_u, Y->relpos, Y->sn_rowptr, Y->sn_lx, Y->Lx, Y->upart, Y->uscr,
+                         Y->uw_flat, Y->usub, Y->usub_u, Y->relpos, Y->Lx, Y->upart, Y->uscr,
                          Y->upd_nw[l], Y->d_info);
     }
     else if(nu > 0 && Y->upd_coop[l] == 2)

@@ -60,6 +60,8 @@ template <class T> int upload(T*& dev, const std::vector<T>& h)
 } // namespace
 
 // flat record of a supernode for the backward solve (same order as lvl_sn)
+// one work unit of k_update_gather, flat (everything the kernel needs before its first barrier behind ONE load)
+struct GatherUnit { int64_t lt, part; int s0, s1, nrows_t, nc; };
 struct SolveItem { int c0, w, nrows, rowoff; int64_t lx; int bd0, nbd; int pflag, rsv; };    // pflag: the parent's workgroup in the persistent backward launch (-1: none); rsv: pre-multiplied block sweep
 
 struct SparseSym
@@ -72,6 +74,7 @@ struct SparseSym
   SymSub* usub = nullptr; int* relpos = nullptr;
   int *uw_item = nullptr, *uw_s0 = nullptr, *uw_s1 = nullptr, *uf_item = nullptr, *uf_n = nullptr;
   int64_t *uw_part = nullptr, *uf_off = nullptr;
+  GatherUnit* uw_flat = nullptr;          // [work units] flat records for k_update_gather
   double* upart = nullptr; double* uscr = nullptr; int64_t *u_off = nullptr, *usub_u = nullptr;
   SolveItem* slv_item = nullptr; FwItem* fw_item = nullptr; MfChild* mf_rec = nullptr; uint16_t* mf_dst = nullptr;
   SymOutBlock* oblk = nullptr; SymContrib* contrib = nullptr;
