@@ -460,11 +460,13 @@ __global__ void __launch_bounds__(1024) k_jtx_fin2_long(const int* __restrict__ 
                                                         const double* __restrict__ jtp, double* __restrict__ Jt_x)
 {
   __shared__ double sh[128*16];
-  const int v = blks[blockIdx.x], w = wv[v];
+  // (blks: flat records {list begin, list end, first variable, width} -- sparse_set_pattern)
+  const int4 rec = reinterpret_cast<const int4*>(blks)[blockIdx.x];
+  const int w = rec.w;
   // groups of 8 lanes for blocks of up to 8 variables (128 sub-sums), of 16 otherwise (64)
   const int gw = (w <= 8) ? 8 : 16, ng = 1024/gw;
   const int a = threadIdx.x & (gw - 1), g = threadIdx.x/gw;
-  const int e0 = jf_ptr[v], e1 = jf_ptr[v+1];
+  const int e0 = rec.x, e1 = rec.y;
   double sum = 0.0;
   if(a < w)
     for(int e = e0 + g; e < e1; e += ng*16)
@@ -484,7 +486,7 @@ __global__ void __launch_bounds__(1024) k_jtx_fin2_long(const int* __restrict__ 
   {
     double tot = 0.0;
     for(int k = 0; k < ng; k++) tot += sh[k*16 + a];
-    Jt_x[var0[v] + a] = tot;
+    Jt_x[rec.z + a] = tot;
   }
 }
 // persistent blocks written by several MFMA tasks: fixed-order sum of the listed partials.
@@ -714,8 +716,8 @@ __global__ void __launch_bounds__(TPB) k_norm2_Jv(const int* __restrict__ chunk_
   // K8 behind a speculative factorisation (dlg_take_step): a step built on a failed factorisation is
   // never used -- unless it is the Cauchy step to the edge of the trust region, which needs no factor
   if(info && *info != 0x7fffffff && (int)*kind != DLG_KIND_CAUCHY_TO_EDGE) { if(threadIdx.x == 0) part[blockIdx.x] = 0.0; return; }
-  const int r0 = chunk_row[blockIdx.x], r1 = chunk_row[blockIdx.x + 1];
-  const int q0 = Jp[r0], n = Jp[r1] - q0;
+  const int4 rec = reinterpret_cast<const int4*>(chunk_row)[blockIdx.x];      // {r0, r1, q0, n}
+  const int r0 = rec.x, r1 = rec.y, q0 = rec.z, n = rec.w;
   const int tid = threadIdx.x;
   double acc = 0.0;
   if(n <= NV_CHUNK)

@@ -127,7 +127,14 @@ int sparse_set_pattern(dlg_backend* b, const int* colptr, const int* rowidx)
   UP(asm_rho); UP(asm_pair); UP(asm_slot); UP(asm_batch); UP(asm_ctask); UP(asm_cfin);
   if(H.asm_jtx_ok)
   {
-    UP(jf_ptr); UP(jf_ent); UP(jf_var0); UP(jf_w); UP(jf_short); UP(jf_long);
+    UP(jf_ptr); UP(jf_ent); UP(jf_var0); UP(jf_w); UP(jf_short);
+    {
+      // long lists: flat records {list begin, list end, first variable, width}
+      std::vector<int> rec(4*H.jf_long.size());
+      for(size_t k = 0; k < H.jf_long.size(); k++)
+      { const int v = H.jf_long[k]; rec[4*k] = H.jf_ptr[v]; rec[4*k+1] = H.jf_ptr[v+1]; rec[4*k+2] = H.jf_var0[v]; rec[4*k+3] = H.jf_w[v]; }
+      DLG_CHECK(upload(Y->jf_long, rec)); Y->allocs.push_back(Y->jf_long);
+    }
     DLG_HIP(hipMalloc(&Y->jtp, sizeof(double)*16*std::max<size_t>(1, H.asm_mtask.size()))); Y->allocs.push_back(Y->jtp);
   }
   UP(asm_shape); UP(asm_kg); UP(asm_mtask); UP(asm_tdest); UP(asm_fin2); UP(asm_fin2_list); UP(asm_run); UP(asm_pdest);
@@ -182,7 +189,12 @@ int sparse_set_pattern(dlg_backend* b, const int* colptr, const int* rowidx)
       ch.push_back(e); r = e;
     }
     Y->n_nv_chunks = (int)ch.size() - 1;
-    DLG_CHECK(upload(Y->nv_chunk, ch)); Y->allocs.push_back(Y->nv_chunk);
+    // flat records {first row, last row + 1, first value, values}: no dependent look-up of the row
+    // pointers in front of the kernel's loads
+    std::vector<int> rec(4*(size_t)Y->n_nv_chunks);
+    for(int c = 0; c < Y->n_nv_chunks; c++)
+    { rec[4*c] = ch[c]; rec[4*c+1] = ch[c+1]; rec[4*c+2] = jp[ch[c]]; rec[4*c+3] = jp[ch[c+1]] - jp[ch[c]]; }
+    DLG_CHECK(upload(Y->nv_chunk, rec)); Y->allocs.push_back(Y->nv_chunk);
   }
   lap("schedule uploads");
   auto dalloc = [&](double*& p, size_t n) -> int {
