@@ -662,7 +662,8 @@ __device__ __forceinline__ void panel_factor_blockdiag(double* P, int ldp, int n
 // LDS holds the rows below it only (Pb[i + j*ldp] for i >= w: Pb = base - w) plus the factored
 // member blocks (Dg[(c0 + c)*8 + q]); a member's thread reads its little block straight from the
 // panel in HBM (G, leading dimension ldg), factors it in registers and writes it back.
-template <int NB>
+// (DS: doubles kept per column of the factored member blocks in Dg: 8, or 4 where no member is wider than 4)
+template <int NB, int DS = 8>
 __device__ __forceinline__ int bd_factor_member_g(double* __restrict__ G, int ldg, int c0, double* rdiag,
                                                   double* __restrict__ Dg)
 {
@@ -690,10 +691,10 @@ __device__ __forceinline__ int bd_factor_member_g(double* __restrict__ G, int ld
 #pragma unroll
   for(int c = 0; c < NB; c++)
 #pragma unroll
-    for(int q = 0; q <= c; q++) { G[(c0 + c) + (size_t)(c0 + q)*ldg] = D[c][q]; Dg[(c0 + c)*8 + q] = D[c][q]; }
+    for(int q = 0; q <= c; q++) { G[(c0 + c) + (size_t)(c0 + q)*ldg] = D[c][q]; if(q < DS) Dg[(c0 + c)*DS + q] = D[c][q]; }
   return badcol;
 }
-template <int NB>
+template <int NB, int DS = 8>
 __device__ __forceinline__ void bd_solve_row_c(double* Pb, int ldp, int r, int c0, const double* rdiag,
                                                const double* __restrict__ Dg)
 {
@@ -703,7 +704,7 @@ __device__ __forceinline__ void bd_solve_row_c(double* Pb, int ldp, int r, int c
   {
     x[c] = Pb[r + (c0 + c)*ldp]; rd[c] = rdiag[c0 + c];
 #pragma unroll
-    for(int q = 0; q < c; q++) Lm[c][q] = Dg[(c0 + c)*8 + q];
+    for(int q = 0; q < c; q++) Lm[c][q] = Dg[(c0 + c)*DS + q];
   }
 #pragma unroll
   for(int c = 0; c < NB; c++)
@@ -718,7 +719,7 @@ __device__ __forceinline__ void bd_solve_row_c(double* Pb, int ldp, int r, int c
 }
 // members first (their global loads are on their way while the caller copies the rows below into
 // LDS: call bd_compact_members before that copy's barrier), then the rows
-template <int NT>
+template <int NT, int DS = 8>
 __device__ __forceinline__ void bd_compact_members(double* __restrict__ G, int ldg, int w, int tid,
                                                    const int* __restrict__ mcol_g, int nmem, int bdw,
                                                    int* mcol, double* rdiag, double* __restrict__ Dg,
@@ -732,19 +733,19 @@ __device__ __forceinline__ void bd_compact_members(double* __restrict__ G, int l
     int badcol;
     switch(nb)
     {
-      case 1: badcol = bd_factor_member_g<1>(G, ldg, c0, rdiag, Dg); break;
-      case 2: badcol = bd_factor_member_g<2>(G, ldg, c0, rdiag, Dg); break;
-      case 3: badcol = bd_factor_member_g<3>(G, ldg, c0, rdiag, Dg); break;
-      case 4: badcol = bd_factor_member_g<4>(G, ldg, c0, rdiag, Dg); break;
-      case 5: badcol = bd_factor_member_g<5>(G, ldg, c0, rdiag, Dg); break;
-      case 6: badcol = bd_factor_member_g<6>(G, ldg, c0, rdiag, Dg); break;
-      case 7: badcol = bd_factor_member_g<7>(G, ldg, c0, rdiag, Dg); break;
-      default: badcol = bd_factor_member_g<8>(G, ldg, c0, rdiag, Dg); break;
+      case 1: badcol = bd_factor_member_g<1, DS>(G, ldg, c0, rdiag, Dg); break;
+      case 2: badcol = bd_factor_member_g<2, DS>(G, ldg, c0, rdiag, Dg); break;
+      case 3: badcol = bd_factor_member_g<3, DS>(G, ldg, c0, rdiag, Dg); break;
+      case 4: badcol = bd_factor_member_g<4, DS>(G, ldg, c0, rdiag, Dg); break;
+      case 5: badcol = bd_factor_member_g<5, DS>(G, ldg, c0, rdiag, Dg); break;
+      case 6: badcol = bd_factor_member_g<6, DS>(G, ldg, c0, rdiag, Dg); break;
+      case 7: badcol = bd_factor_member_g<7, DS>(G, ldg, c0, rdiag, Dg); break;
+      default: badcol = bd_factor_member_g<8, DS>(G, ldg, c0, rdiag, Dg); break;
     }
     if(badcol >= 0) atomicMin(info, col0 + c0 + badcol);
   }
 }
-template <int NT>
+template <int NT, int DS = 8>
 __device__ __forceinline__ void bd_compact_rows(double* Pb, int ldp, int nrows, int w, int tid, int nmem,
                                                 const int* mcol, const double* rdiag, const double* __restrict__ Dg)
 {
@@ -755,14 +756,14 @@ __device__ __forceinline__ void bd_compact_rows(double* Pb, int ldp, int nrows, 
       const int c0 = mcol[m], nb = mcol[m+1] - c0;        // uniform over the workgroup
       switch(nb)
       {
-        case 1: bd_solve_row_c<1>(Pb, ldp, r, c0, rdiag, Dg); break;
-        case 2: bd_solve_row_c<2>(Pb, ldp, r, c0, rdiag, Dg); break;
-        case 3: bd_solve_row_c<3>(Pb, ldp, r, c0, rdiag, Dg); break;
-        case 4: bd_solve_row_c<4>(Pb, ldp, r, c0, rdiag, Dg); break;
-        case 5: bd_solve_row_c<5>(Pb, ldp, r, c0, rdiag, Dg); break;
-        case 6: bd_solve_row_c<6>(Pb, ldp, r, c0, rdiag, Dg); break;
-        case 7: bd_solve_row_c<7>(Pb, ldp, r, c0, rdiag, Dg); break;
-        default: bd_solve_row_c<8>(Pb, ldp, r, c0, rdiag, Dg); break;
+        case 1: bd_solve_row_c<1, DS>(Pb, ldp, r, c0, rdiag, Dg); break;
+        case 2: bd_solve_row_c<2, DS>(Pb, ldp, r, c0, rdiag, Dg); break;
+        case 3: bd_solve_row_c<3, DS>(Pb, ldp, r, c0, rdiag, Dg); break;
+        case 4: bd_solve_row_c<4, DS>(Pb, ldp, r, c0, rdiag, Dg); break;
+        case 5: bd_solve_row_c<5, DS>(Pb, ldp, r, c0, rdiag, Dg); break;
+        case 6: bd_solve_row_c<6, DS>(Pb, ldp, r, c0, rdiag, Dg); break;
+        case 7: bd_solve_row_c<7, DS>(Pb, ldp, r, c0, rdiag, Dg); break;
+        default: bd_solve_row_c<8, DS>(Pb, ldp, r, c0, rdiag, Dg); break;
       }
     }
   }

@@ -273,6 +273,7 @@ __global__ void __launch_bounds__(NT, LEAF ? 4 : 1) k_factor_level(const FwItem*
 {
   extern __shared__ __attribute__((aligned(16))) double P[];
   __shared__ int sbad, s_skip;
+  constexpr int DS = LEAF ? 4 : 8;             // doubles per column of the factored member blocks (compact layout)
   constexpr int CP_FLIGHT = LEAF ? 16 : 32;
 #ifdef DLG_FL_PROFILE
   const int prof_lvl = mode >> 8;
@@ -300,14 +301,16 @@ __global__ void __launch_bounds__(NT, LEAF ? 4 : 1) k_factor_level(const FwItem*
   // the update matrix is staged in LDS where it fits: behind the panel, its last columns in the unused
   // strict upper triangle of the top block if need be (it.jsp, sym_w_split)
   const bool u_lds = has_u && (it.nch > 0 || stage_leaf_u) &&
-                     (cmp ? (size_t)(ldp*w + ntri + 1 + 8*w)*sizeof(double) <= (size_t)FAC_LDS_BUDGET : it.jsp >= 0);   // + the scratch slot of mf_dst
+                     (cmp ? (size_t)(ldp*w + ntri + 1 + DS*w)*sizeof(double) <= (size_t)FAC_LDS_BUDGET : it.jsp >= 0);   // + the scratch slot of mf_dst
   const int usp = (u_lds && !cmp) ? it.jsp : mb;          // first column kept up there (mb: none)
   const int nlin = usp*mb - usp*(usp - 1)/2;              // doubles behind the panel
   double* Ug = has_u ? uscr + it.u_off : nullptr;
   double* Us = P + ldp*w;
   double* Dg = Us + (u_lds ? nlin + 1 : 0);
-  __shared__ int s_mcol[260];
-  __shared__ double s_rdiag[256];
+  // (LEAF: members of at most 4 columns, supernodes of at most 64 -- sparse_factor_setup: less LDS per
+  // workgroup, which is what lets a fourth one onto the CU)
+  __shared__ int s_mcol[LEAF ? 68 : 260];
+  __shared__ double s_rdiag[LEAF ? 64 : 256];
   MfChild rc = {0, 0, 0, 0};
   const bool mf_acc = !LEAF && mode == 2 && it.nch > 0;
   if(mf_acc) rc = mf_rec[it.ch0 + min(lane, it.nch - 1)];     // on its way during the panel copy
@@ -317,7 +320,7 @@ __global__ void __launch_bounds__(NT, LEAF ? 4 : 1) k_factor_level(const FwItem*
   if(cmp)
   {
     __syncthreads();
-    bd_compact_members<NT>(G, nrows, w, tid, sn_bd_col + it.bd0, it.nbd, it.bdw, s_mcol, s_rdiag, Dg, &sbad, it.col0);
+    bd_compact_members<NT, DS>(G, nrows, w, tid, sn_bd_col + it.bd0, it.nbd, it.bdw, s_mcol, s_rdiag, Dg, &sbad, it.col0);
   }
   // thread = (panel row, column group): rows padded to whole waves, the remaining threads take
   // further columns
@@ -355,7 +358,7 @@ __global__ void __launch_bounds__(NT, LEAF ? 4 : 1) k_factor_level(const FwItem*
   }
   FL_STAMP(7);
   FL_STAMP(2);
-  if(cmp) bd_compact_rows<NT>(Pb, ldp, nloc, w, tid, it.nbd, s_mcol, s_rdiag, Dg);
+  if(cmp) bd_compact_rows<NT, DS>(Pb, ldp, nloc, w, tid, it.nbd, s_mcol, s_rdiag, Dg);
   else if(LEAF) { }
   else if(it.nbd > 0) panel_factor_blockdiag<NT>(P, ldp, nloc, w, tid, sn_bd_col + it.bd0, it.nbd, &sbad, it.col0, s_mcol, s_rdiag);
   else if(NT >= 256 && ahead && w <= PF_AHEAD_MAXW) panel_factor_ahead<(NT >= 256 ? NT : 256)>(P, ldp, nloc, w, tid, &sbad, it.col0, s_rdiag, s_mcol);
@@ -993,6 +996,24 @@ int sparse_factor_setup(dlg_backend* b)
   Y->upd_lds.assign(H.nlevels, 0); Y->upd_nw.assign(H.nlevels, 0);
   Y->syrk_lds.assign(H.nlevels, 0); Y->syrk_nt.assign(H.nlevels, 256); Y->syrk_kc.assign(H.nlevels, 4);
   Y->syrk_fused.assign(H.nlevels, 0); Y->fin_ny.assign(H.nlevels, 1); Y->fac_stage.assign(H.nlevels, 0);
+  // levels whose work items are all unsliced block-diagonal panels (merged leaves) outside the
+  // multifrontal region, with members of at most 4 columns and at most 64 columns in all: the lean
+  // instantiation (k_factor_level<256, true>)
+  Y->fac_leaf.assign(H.nlevels, 0);
+  for(int l = 0; l < H.nlevels && !getenv("DOGLEG_AMD_NO_LEAF_KERNEL"); l++)
+  {
+    bool all = H.fw_lvl_ptr[l+1] > H.fw_lvl_ptr[l] && l < H.mf_level0;
+    long maxr = 0;
+    for(int i = H.fw_lvl_ptr[l]; i < H.fw_lvl_ptr[l+1] && all; i++)
+    {
+      const FwItem& it = H.fw_item[i];
+      if(!(it.nbd > 0 && it.top < 0 && it.bdw > 0 && it.bdw <= 4 && it.w <= 64)) all = false;
+      maxr = std::max(maxr, (long)it.w + (it.r1 - it.r0));
+    }
+    // (the instantiation exists for 256 threads: the block size the level gets below)
+    const int nt = getenv("DOGLEG_AMD_FAC_NT") ? env_int_host("DOGLEG_AMD_FAC_NT", 256) : ((maxr <= 128) ? 128 : (maxr <= 256 ? 256 : 512));
+    Y->fac_leaf[l] = (all && nt == 256) ? 1 : 0;
+  }
   for(int l = 0; l < H.nlevels; l++)
   {
     long maxp = 0, maxw = 0, maxr = 0;
@@ -1011,7 +1032,7 @@ int sparse_factor_setup(dlg_backend* b)
       // layout that never stages the top block (k_factor_level: cmp)
       const bool cmp = H.sn_bd_ptr[s+1] > H.sn_bd_ptr[s] && H.sn_top[s] < 0;
       const long mbl = nloc - wv;
-      const long p = (cmp && !getenv("DOGLEG_AMD_LEAF_LDS_FULL")) ? ((mbl + 1) & ~1L)*wv + 8*wv + 1 : ((nloc + 1) & ~1L)*wv;
+      const long p = (cmp && !getenv("DOGLEG_AMD_LEAF_LDS_FULL")) ? ((mbl + 1) & ~1L)*wv + (Y->fac_leaf[l] ? 4 : 8)*wv + 1 : ((nloc + 1) & ~1L)*wv;
       if(p > maxp) maxp = p;
       if(nloc > maxr) maxr = nloc;
     }
@@ -1073,7 +1094,7 @@ int sparse_factor_setup(dlg_backend* b)
         const int s = H.lvl_sn[i];
         const long wv = H.sn_c0[s+1] - H.sn_c0[s], nr = H.sn_rowptr[s+1] - H.sn_rowptr[s], mb = nr - wv;
         const bool cmp = H.sn_bd_ptr[s+1] > H.sn_bd_ptr[s] && H.sn_top[s] < 0;
-        const long pan = cmp ? ((mb + 1) & ~1L)*wv + 8*wv : ((nr + 1) & ~1L)*wv;
+        const long pan = cmp ? ((mb + 1) & ~1L)*wv + (Y->fac_leaf[l] ? 4 : 8)*wv : ((nr + 1) & ~1L)*wv;
         const int jsp = cmp ? (int)mb : sym_w_split(wv, nr);      // the kernel's rule (sym_w_split: part of W may sit in the top block's upper triangle)
         const long need = (pan + (jsp >= 0 ? sym_w_linear(mb, jsp) : mb*(mb + 1)/2) + 1)*8;
         const long need0 = (pan + 1)*8;          // at least the scratch slot behind the panel
@@ -1169,16 +1190,88 @@ int sparse_factor_setup(dlg_backend* b)
                               hipFuncAttributeMaxDynamicSharedMemorySize, FAC_LDS_BUDGET));
   DLG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_factor_level<256, true>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, FAC_LDS_BUDGET));
-  // levels whose work items are all unsliced block-diagonal panels (merged leaves) outside the
-  // multifrontal region: the lean instantiation
-  Y->fac_leaf.assign(H.nlevels, 0);
-  for(int l = 0; l < H.nlevels && !getenv("DOGLEG_AMD_NO_LEAF_KERNEL"); l++)
+  if(!Y->uw_flat && !H.uw_item.empty())
   {
-    bool all = H.fw_lvl_ptr[l+1] > H.fw_lvl_ptr[l] && l < H.mf_level0;
-    for(int i = H.fw_lvl_ptr[l]; i < H.fw_lvl_ptr[l+1] && all; i++)
-    { const FwItem& it = H.fw_item[i]; if(!(it.nbd > 0 && it.top < 0)) all = false; }
-    Y->fac_leaf[l] = all ? 1 : 0;
+    std::vector<GatherUnit> fl(H.uw_item.size());
+    for(size_t u = 0; u < fl.size(); u++)
+    {
+      const int item = H.uw_item[u], t = H.ui_t[item];
+      const int nr = H.sn_rowptr[t+1] - H.sn_rowptr[t];
+      fl[u].lt = H.sn_lx[t] + (int64_t)H.ui_col[item]*nr; fl[u].part = H.uw_part[u];
+      fl[u].s0 = H.uw_s0[u]; fl[u].s1 = H.uw_s1[u]; fl[u].nrows_t = nr; fl[u].nc = H.ui_nc[item];
+    }
+    DLG_CHECK(upload(Y->uw_flat, fl)); Y->allocs.push_back(Y->uw_flat);
   }
+  // Persistent top region: the last levels of the multifrontal region hold a few supernodes each and
+  // every one of them waits for the one before -- each kernel boundary costs the launch gap, a cold
+  // panel load and the store of the panel before the next level may start.  They go out as ONE
+  // launch, workgroups in level order (a workgroup only ever waits for lower-numbered ones, so
+  // in-order dispatch cannot deadlock): a workgroup stages its panel at once, waits for its
+  // children's flags, and raises its own flag as soon as its update matrix is out -- before its
+  // panel goes back to HBM.  Conditions: unsliced supernodes, update matrices staged in LDS (their
+  // hand-off is the write-through store of that LDS copy), one block size, no update units, above
+  // the cut of a subtree partition.
+  Y->pr_level0 = H.nlevels;
+  if(!getenv("DOGLEG_AMD_NO_PERSIST") && H.nlevels >= 2)
+  {
+    // (a workgroup of the region fills a CU; more of them than CUs would only queue behind waiting ones)
+    int ncu = 256;
+    { int dev = 0; if(hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev); }
+    const int cap = env_int_host("DOGLEG_AMD_PERSIST_MAX", ncu);
+    int total = 0, l0 = H.nlevels, lds = 0, stage = 1;
+    bool acc = false;
+    const int nt = Y->fac_nt[H.nlevels - 1];
+    const bool dbg = getenv("DOGLEG_AMD_TIMING") != nullptr;
+    for(int l = H.nlevels - 1; l >= 1; l--)
+    {
+      const int n = H.fw_lvl_ptr[l+1] - H.fw_lvl_ptr[l];
+      if(l < H.mf_level0 || (H.part_nranks > 1 && l <= H.cut_level)) break;
+      if(n == 0 || total + n > cap || Y->fac_nt[l] != nt || Y->fac_lds[l] <= 0) break;
+      if(H.uw_lvl_ptr[l+1] > H.uw_lvl_ptr[l] || H.uf_lvl_ptr[l+1] > H.uf_lvl_ptr[l]) break;
+      bool ok = true;
+      for(int i = H.fw_lvl_ptr[l]; i < H.fw_lvl_ptr[l+1] && ok; i++)
+      {
+        const FwItem& it = H.fw_item[i];
+        if(it.top >= 0 || it.r0 != 0 || it.nbd > 0) ok = false;
+      }
+      if(!ok) break;
+      stage = stage && Y->fac_stage[l]; total += n; l0 = l; lds = std::max(lds, Y->fac_lds[l]);
+    }
+    if(H.nlevels - l0 >= 2)
+    {
+      Y->pr_level0 = l0; Y->pr_lds = lds; Y->pr_stage = stage;
+      for(int i = H.fw_lvl_ptr[l0]; i < H.fw_lvl_ptr[H.nlevels]; i++)
+      {
+        // the kernel's rule for staging the update matrix behind the panel
+        const FwItem& it = H.fw_item[i];
+        const long mb = it.nrows - it.w;
+        if(mb > 0 && it.nch > 0 && it.jsp < 0) acc = true;
+      }
+    }
+    if(dbg)
+      fprintf(stderr, "libdogleg_amd: persistent top region: levels %d..%d of %d (%d workgroups, %d bytes of LDS, multifrontal from level %d)\n",
+              l0, H.nlevels - 1, H.nlevels, total, lds, H.mf_level0);
+    // update matrices of the region that do not fit LDS are summed (atomics) in a shadow of the scratch,
+    // so that the slot the parent reads only ever sees write-through stores
+    if(acc && !Y->pr_acc)
+    {
+      DLG_HIP(hipMalloc(&Y->pr_acc, sizeof(double)*(size_t)std::max<int64_t>(1, H.uscr_size)));
+      Y->allocs.push_back(Y->pr_acc);
+    }
+  }
+  if(Y->pr_level0 < H.nlevels && !Y->fac_flag)
+  {
+    DLG_HIP(hipMalloc(&Y->fac_flag, sizeof(int)*std::max<size_t>(1, H.fw_item.size())));
+    Y->allocs.push_back(Y->fac_flag);
+    DLG_HIP(hipMemsetAsync(Y->fac_flag, 0, sizeof(int)*std::max<size_t>(1, H.fw_item.size()), b->stream));
+    Y->fac_epoch = 0;
+  }
+  DLG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_factor_level<128>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, FAC_LDS_BUDGET));
+  DLG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_factor_level<256>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, FAC_LDS_BUDGET));
+  DLG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_factor_level<256, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, FAC_LDS_BUDGET));
   DLG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_factor_level<512>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, FAC_LDS_BUDGET));
   DLG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_update_level),
