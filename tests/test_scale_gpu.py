@@ -362,3 +362,37 @@ def test_take_step_with_device_side_finals_at_large_n(gpu, monkeypatch):
     # (the two modes sum their partials in different orders: k, hence the step, may differ by an ulp)
     assert abs(res[0][1] - res[1][1]) <= 1e-12 * res[0][1]
     assert abs(res[0][0] - res[1][0]) <= 1e-12 * res[0][0] and abs(res[0][2] - res[1][2]) <= 1e-12 * abs(res[0][2])
+
+
+def test_thousand_steps_reproduce_their_bits(gpu):
+    """config #3, the step of bench.py a thousand times over, alternating between two inputs: every
+    repetition of an input gives the bits of its first time -- a stale read in one of the one-launch
+    regions (flags with an epoch per launch, write-through hand-offs) would not (tools/soak_steps.py
+    is the long form: 6 000 steps of config #4, 20 000 of config #3)"""
+    prob = oa.BAProblem(499, 9000, 100000, seed=11, eps=0.4, p0_spread=0.6)
+    Jp, Ji = prob.pattern()
+    p = prob.p0()
+    inputs = [prob.eval(p), prob.eval(p + 0.01)]
+    be = capi.Backend(capi.DLG_SPARSE, prob.N, prob.M, prob.nnz)
+    be.set_pattern(Jp, Ji)
+    be.set_speculation(True)
+    be.set_p(0, p)
+    dev = [(capi.DeviceArray(np.ascontiguousarray(x)), capi.DeviceArray(np.ascontiguousarray(J))) for x, J in inputs]
+    ref, tr, bad = [None, None], None, 0
+    for k in range(1000):
+        c = k & 1
+        be.bind_device(0, dev[c][0].ptr, dev[c][1].ptr)
+        n2x, gmax = be.eval(0)
+        if tr is None:
+            lam, n2c, n2g = be.cauchy_gauss_newton(0, 0.0)
+            tr = 0.5*(n2c**0.5 + n2g**0.5)
+            be.step(0, 1, capi.KIND_INTERP, tr)
+            continue
+        lam, r, pnew = be.take_step(0, 1, tr, 0.0)
+        sig = (n2x, gmax, r["n2c"], r["n2g"], r["n2s"], r["k"], r["ei"], float(pnew[0]), float(pnew[-1]), float(np.sum(pnew)))
+        if ref[c] is None:
+            ref[c] = sig
+        else:
+            bad += sig != ref[c]
+    be.close()
+    assert bad == 0

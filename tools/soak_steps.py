@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""tools only: the same trust-region step of a config-#4-sized problem many thousand times (fresh
+binding every time: nothing cached), alternating between two different inputs -- every repetition of
+an input must reproduce its numbers bit for bit.  A stale read in one of the one-launch regions (a
+workgroup reading an update matrix or x of an earlier launch) would show up as a different bit
+pattern.  usage: soak_steps.py [steps] [workload]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from libdogleg_amd import capi
+from tests import oracle_api as oa
+
+steps = int(sys.argv[1]) if len(sys.argv) > 1 else 4000
+shape = {"sparse-1m": (2499, 45000, 500000), "sparse-200k": (499, 9000, 100000)}[sys.argv[2] if len(sys.argv) > 2 else "sparse-1m"]
+prob = oa.BAProblem(*shape, seed=11, eps=0.4, p0_spread=0.6)
+Jp, Ji = prob.pattern()
+p = prob.p0()
+inputs = [prob.eval(p), prob.eval(p + 0.01)]
+be = capi.Backend(capi.DLG_SPARSE, prob.N, prob.M, prob.nnz)
+be.set_pattern(Jp, Ji)
+be.set_speculation(True)
+be.set_p(0, p)
+dev = [(capi.DeviceArray(np.ascontiguousarray(x)), capi.DeviceArray(np.ascontiguousarray(J))) for x, J in inputs]
+ref, tr = [None, None], None
+bad = 0
+for k in range(steps):
+    c = k & 1
+    be.bind_device(0, dev[c][0].ptr, dev[c][1].ptr)
+    n2x, gmax = be.eval(0)
+    if tr is None:
+        lam, n2c, n2g = be.cauchy_gauss_newton(0, 0.0)
+        tr = 0.5*(n2c**0.5 + n2g**0.5)
+        be.step(0, 1, capi.KIND_INTERP, tr)
+        continue
+    lam, r, pnew = be.take_step(0, 1, tr, 0.0)
+    sig = (n2x, gmax, r["n2c"], r["n2g"], r["n2s"], r["k"], r["ei"], float(pnew[0]), float(pnew[-1]), float(np.sum(pnew)))
+    if ref[c] is None:
+        ref[c] = sig
+    elif sig != ref[c]:
+        bad += 1
+        if bad < 5:
+            print("step", k, "input", c, "differs:", sig, "vs", ref[c], flush=True)
+print(f"{steps} steps, {bad} deviations from the first result of their input")
+sys.exit(1 if bad else 0)
