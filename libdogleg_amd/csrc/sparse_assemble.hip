@@ -788,6 +788,16 @@ int sparse_norm2_Jv(dlg_backend* b, int s, const double* v, double* out_dev, con
   DlgSlot& S = b->slot[s];
   const int g = Y->n_nv_chunks;
   if(g == 0) { DLG_HIP(hipMemsetAsync(out_dev, 0, sizeof(double), b->stream)); return DLG_OK; }
+  // K8 inside dlg_take_step: only the host reads the sum -- the workgroups' partial sums go straight to
+  // pinned host memory and are added there behind the step's one synchronisation (no second-stage launch)
+  if(kind_if_factor_failed)
+    if(double* hp = dlg_host_partials(b, out_dev, g, 1, 0, 1))
+    {
+      hipLaunchKernelGGL(k_norm2_Jv, dim3(g), dim3(TPB), 0, b->stream, Y->nv_chunk, Y->Jp, Y->Ji, S.Jin(), v, hp,
+                         (const int*)Y->d_info, kind_if_factor_failed);
+      DLG_LAUNCH_CHECK();
+      return DLG_OK;
+    }
   DLG_CHECK(dlg_ensure_partials(b, 5120 + (size_t)g));
   double* part = b->d_part + 5120;          // behind the regions of the vector reductions (kernels_vec.hip)
   hipLaunchKernelGGL(k_norm2_Jv, dim3(g), dim3(TPB), 0, b->stream, Y->nv_chunk, Y->Jp, Y->Ji, S.Jin(), v, part,
