@@ -148,6 +148,7 @@ struct Orderer
     inset.assign(G.n, 0); vis.assign(G.n, 0);
     std::vector<int> dist(G.n, 0);
     int setctr = 0;
+    const long nd_debug = env_int("DOGLEG_AMD_ND_DEBUG", 0);      // print the separators of sets heavier than this
     // explicit stack of node sets; a frame with `sep` set flushes a separator
     struct Frame { std::vector<int> nodes; bool is_sep; };
     std::vector<Frame> stack;
@@ -229,6 +230,13 @@ struct Orderer
         for(int l = 0; l < nl; l++) { pre += lw[l]; if(2*pre >= wt) { best = l; break; } }
         if(best <= 0) best = 1;
         if(best >= nl-1) best = nl-2;
+      }
+      if(nd_debug && wt > nd_debug)
+      {
+        fprintf(stderr, "nd: set of %zu nodes (weight %ld): %d BFS levels, separator = level %d (weight %ld, %d nodes)  level weights around it:",
+                nodes.size(), wt, nl, best, lw[best], lvl_start[best+1] - lvl_start[best]);
+        for(int l = std::max(0, best - 3); l < std::min(nl, best + 4); l++) fprintf(stderr, " %ld", lw[l]);
+        fprintf(stderr, "\n");
       }
       std::vector<int> A(order.begin(), order.begin() + lvl_start[best]);
       std::vector<int> Sp(order.begin() + lvl_start[best], order.begin() + lvl_start[best+1]);
