@@ -687,7 +687,8 @@ __global__ void __launch_bounds__(TPB) k_panel_update(double* __restrict__ A, in
 // updated by the fp64-MFMA SYRK on the second stream meanwhile.  st2 == nullptr: everything in order
 // on one stream (the default, see below).
 int potrf_lower(hipStream_t st, double* A, int lda, int n, int* info_dev, double* Linv,
-                hipStream_t st2 = nullptr, hipEvent_t ev_panel = nullptr, hipEvent_t ev_trail = nullptr)
+                hipStream_t st2 = nullptr, hipEvent_t ev_panel = nullptr, hipEvent_t ev_trail = nullptr,
+                int* flag = nullptr, int* epoch = nullptr)
 {
   // measured on config #2 (N = 2000): 2.23 ms with look-ahead against 2.15 without -- the three stream
   // dependencies per step cost more than the overlapped SYRK saves -- so it is opt-in (DOGLEG_AMD_LOOKAHEAD)
@@ -732,11 +733,13 @@ int potrf_lower(hipStream_t st, double* A, int lda, int n, int* info_dev, double
   {
     const int nb = (n - kb < NB) ? n - kb : NB;
     double* Li = Linv + (size_t)blk*NB*NB;
-    dense_launch_potrf_diag(st, A, lda, kb, nb, info_dev, Li);
     const int rem = n - kb - nb;
+    const bool fused = flag && epoch && rem > 0 && !getenv("DOGLEG_AMD_NO_POTRF_FUSE");
+    if(fused) dense_launch_potrf_diag_trsm(st, A, lda, kb, nb, n, info_dev, Li, flag, ++*epoch);
+    else dense_launch_potrf_diag(st, A, lda, kb, nb, info_dev, Li);
     if(rem > 0)
     {
-      hipLaunchKernelGGL(k_trsm_gemm, dim3(dlg_cdiv(rem, NB)), dim3(TPB), 0, st, A, lda, kb, nb, n, Li);
+      if(!fused) hipLaunchKernelGGL(k_trsm_gemm, dim3(dlg_cdiv(rem, NB)), dim3(TPB), 0, st, A, lda, kb, nb, n, Li);
       // trailing: C = A[kb+nb:, kb+nb:], panel P[i,k] = A[(kb+k)*lda + kb+nb+i]
       double* Cc = A + (size_t)(kb + nb)*lda + (kb + nb);
       const double* P = A + (size_t)kb*lda + (kb + nb);
@@ -779,6 +782,7 @@ void dense_destroy(dlg_backend* b)
   b->Linv = nullptr;
   if(b->slabs) (void)hipFree(b->slabs);
   if(b->d_info) (void)hipFree(b->d_info);
+  if(b->potrf_flag) { (void)hipFree(b->potrf_flag); b->potrf_flag = nullptr; }
   if(b->h_info) (void)hipHostFree(b->h_info);
   b->G = b->slabs = nullptr; b->d_info = nullptr; b->h_info = nullptr;
 }
@@ -867,8 +871,9 @@ int dense_factorize(dlg_backend* b, int s, double lambda, int* ok)
   dlg_fork_point(b);
   {
     DlgProfScope pf(b, DLG_PROF_K5_FACTOR);
+    if(!b->potrf_flag) { DLG_HIP(hipMalloc(&b->potrf_flag, sizeof(int))); DLG_HIP(hipMemsetAsync(b->potrf_flag, 0, sizeof(int), b->stream)); }
     DLG_CHECK(potrf_lower(b->stream, b->G, b->N, b->N, b->d_info, b->Linv,
-                          b->overlap ? b->copy_stream : nullptr, b->ev_step, b->ev_copy));
+                          b->overlap ? b->copy_stream : nullptr, b->ev_step, b->ev_copy, b->potrf_flag, &b->potrf_epoch));
   }
   return finish_potrf(b, ok);
 }
