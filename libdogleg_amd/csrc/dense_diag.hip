@@ -129,7 +129,166 @@ __global__ void __launch_bounds__(TPB) k_potrf_diag_trsm(double* __restrict__ A,
   }
 }
 
+// ---- the whole factorisation in ONE launch: a workgroup per 64 x 64 tile of the lower triangle ------
+// Left-looking, owner computes: the owner of tile (i, j) keeps it in MFMA accumulators and subtracts
+// L(i,k) L(j,k)' for k = 0 .. j-1 as those blocks of L appear (one flag per block, carrying the epoch
+// of the launch); then the owner of a diagonal tile factors it (panel_factor_mfma on [A; I]: L and
+// its inverse) and publishes the inverse, the owner of an off-diagonal tile multiplies with that
+// inverse and publishes its block of L.  Workgroups are numbered column by column, the diagonal tile
+// first: a workgroup only waits for lower-numbered ones, so in-order dispatch cannot deadlock.  The
+// step-by-step form pays three launches per 64 columns (96 for N = 2000) and every one of them waits
+// for the one before; here the critical path is factor -> one multiply -> one update per 64 columns.
+// Hand-offs as in the sparse one-launch regions: write-through stores, drained, then the flag;
+// consumers poll and read around L1; one workgroup per CU.
+typedef double dd_v4d __attribute__((ext_vector_type(4)));
+__global__ void __launch_bounds__(TPB) k_potrf_tiles(double* A, int lda, int n, int T, int* __restrict__ info,
+                                                     double* Linv, int* flags, int epoch)
+{
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  __shared__ int sbad;
+  typedef __attribute__((address_space(1))) double* gd_t;
+  typedef const __attribute__((address_space(1))) double* gcd_t;
+  constexpr int LDT = NB + 1;
+  double (*Li)[LDT] = reinterpret_cast<double (*)[LDT]>(sm);                // [row][k]
+  double (*Lj)[LDT] = reinterpret_cast<double (*)[LDT]>(sm + NB*LDT);
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  const int jn = lane & 15, kq = lane >> 4;
+  // tile of this workgroup: column by column, the diagonal tile of a column first
+  int rem = blockIdx.x, tj = 0;
+  while(rem >= T - tj) { rem -= T - tj; tj++; }
+  const int ti = tj + rem;
+  const int row0 = NB*ti, col0 = NB*tj;
+  // the tile in accumulators: wave wv holds rows 16 wv .. 16 wv + 15, four 16-column pieces;
+  // lane (jn, kq): column jn of a piece, rows kq + 4 r
+  dd_v4d acc[4];
+#pragma unroll
+  for(int ct = 0; ct < 4; ct++)
+#pragma unroll
+    for(int r = 0; r < 4; r++)
+    {
+      const int row = row0 + 16*wv + kq + 4*r, col = col0 + 16*ct + jn;
+      double v = (row == col) ? 1.0 : 0.0;                      // identity padding past the end
+      if(row < n && col < n) v = (row >= col) ? A[(size_t)col*lda + row] : 0.0;
+      acc[ct][r] = v;
+    }
+  auto wait_flag = [&](int fi, int fj) {
+    int spins = 0;
+    while(__hip_atomic_load(flags + fi*T + fj, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch)
+    { __builtin_amdgcn_s_sleep(1); if(++spins > (1 << 22)) { atomicMax(info, n + 1); break; } }
+  };
+  // a published 64 x 64 block of L (rows r0.., columns c0..) into LDS, read around L1; past the end: zeros
+  auto stage = [&](double (*D)[LDT], int r0, int c0) {
+    for(int e = t; e < NB*NB; e += TPB)
+    {
+      const int i = e % NB, k = e / NB;
+      const int row = r0 + i, col = c0 + k;
+      D[i][k] = (row < n && col < n) ? __hip_atomic_load((gcd_t)(A + (size_t)col*lda + row), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+    }
+  };
+  for(int k = 0; k < tj; k++)
+  {
+    if(t == 0) wait_flag(ti, k);
+    if(t == 64 && ti != tj) wait_flag(tj, k);
+    __syncthreads();
+    stage(Li, row0, NB*k);
+    if(ti != tj) stage(Lj, col0, NB*k);
+    __syncthreads();
+    double (*Lb)[LDT] = (ti != tj) ? Lj : Li;
+#pragma unroll 4
+    for(int kk = 0; kk < NB; kk += 4)
+    {
+      const double a = Li[16*wv + jn][kk + kq];
+#pragma unroll
+      for(int ct = 0; ct < 4; ct++)
+        acc[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, -Lb[16*ct + jn][kk + kq], acc[ct], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  if(ti == tj)
+  {
+    // the diagonal tile: [A; I] -> [L; L^-T] in one panel sweep (as k_potrf_diag_inv)
+    double* P = sm;
+    constexpr int LD = 2*NB;
+#pragma unroll
+    for(int ct = 0; ct < 4; ct++)
+#pragma unroll
+      for(int r = 0; r < 4; r++)
+      {
+        const int i = 16*wv + kq + 4*r, j = 16*ct + jn;
+        P[i + j*LD] = (i >= j) ? acc[ct][r] : 0.0;
+      }
+    for(int e = t; e < NB*NB; e += TPB) { const int i = e % NB, j = e / NB; P[NB + i + j*LD] = (i == j) ? 1.0 : 0.0; }
+    if(t == 0) sbad = 0x7fffffff;
+    __syncthreads();
+    panel_factor_mfma<TPB>(P, LD, 2*NB, NB, t, &sbad, 0);
+    const int nb = min(NB, n - col0);
+    if(t == 0) { const int bad = sbad; if(bad < nb) atomicCAS(info, 0, col0 + bad + 1); }
+    double* Lv = Linv + (size_t)tj*NB*NB;
+    for(int e = t; e < NB*NB; e += TPB)
+    {
+      const int i = e % NB, j = e / NB;
+      __hip_atomic_store((gd_t)(Lv + e), (i >= j) ? P[NB + j + i*LD] : 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if(t == 0) __hip_atomic_store(flags + tj*T + tj, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for(int e = t; e < NB*NB; e += TPB)
+    {
+      const int i = e % NB, j = e / NB;
+      if(i >= j && row0 + i < n && col0 + j < n) A[(size_t)(col0 + j)*lda + row0 + i] = P[i + j*LD];
+    }
+    return;
+  }
+  // an off-diagonal tile: X = tile * inv(L(j,j))'
+  if(t == 0) wait_flag(tj, tj);
+  __syncthreads();
+  {
+    const double* Lv = Linv + (size_t)tj*NB*NB;
+    for(int e = t; e < NB*NB; e += TPB)
+    {
+      const int i = e % NB, k = e / NB;                                 // Linv(i, k), zero above the diagonal
+      Lj[i][k] = __hip_atomic_load((gcd_t)(Lv + e), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+#pragma unroll
+    for(int ct = 0; ct < 4; ct++)
+#pragma unroll
+      for(int r = 0; r < 4; r++) Li[16*wv + kq + 4*r][16*ct + jn] = acc[ct][r];
+  }
+  __syncthreads();
+  dd_v4d x[4];
+#pragma unroll
+  for(int ct = 0; ct < 4; ct++) x[ct] = (dd_v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
+  for(int kk = 0; kk < NB; kk += 4)
+  {
+    const double a = Li[16*wv + jn][kk + kq];
+#pragma unroll
+    for(int ct = 0; ct < 4; ct++)
+      x[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Lj[16*ct + jn][kk + kq], x[ct], 0, 0, 0);
+  }
+#pragma unroll
+  for(int ct = 0; ct < 4; ct++)
+#pragma unroll
+    for(int r = 0; r < 4; r++)
+    {
+      const int row = row0 + 16*wv + kq + 4*r, col = col0 + 16*ct + jn;
+      if(row < n && col < n) __hip_atomic_store((gd_t)(A + (size_t)col*lda + row), x[ct][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if(t == 0) __hip_atomic_store(flags + ti*T + tj, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 } // namespace
+
+void dense_launch_potrf_tiles(hipStream_t st, double* A, int lda, int n, int* info_dev, double* Linv, int* flags, int epoch)
+{
+  static bool attr = false;
+  constexpr int LDSB = 88*1024;           // > half of the CU's LDS: one workgroup per CU
+  if(!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_potrf_tiles), hipFuncAttributeMaxDynamicSharedMemorySize, LDSB); attr = true; }
+  const int T = (n + NB - 1)/NB;
+  hipLaunchKernelGGL(k_potrf_tiles, dim3(T*(T + 1)/2), dim3(TPB), LDSB, st, A, lda, n, T, info_dev, Linv, flags, epoch);
+}
 
 void dense_launch_potrf_diag_trsm(hipStream_t st, double* A, int lda, int kb, int nb, int n, int* info_dev, double* Linv,
                                   int* flag, int epoch)

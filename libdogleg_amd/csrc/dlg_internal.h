@@ -95,7 +95,7 @@ struct dlg_backend
   // dense / products
   double* G = nullptr;        // N x N column-major, lower triangle = factor
   double* Linv = nullptr;     // inverses of the 64x64 diagonal blocks of the factor
-  int* potrf_flag = nullptr; int potrf_epoch = 0;   // hand-off flag of the fused diagonal-block + rows-below launch
+  int* potrf_flag = nullptr; int potrf_epoch = 0;   // hand-off flags of the one-launch factorisation ([T*T] + 1 for the step form)
   double* slabs = nullptr;    // split-K partial slabs for the SYRK
   size_t  slabs_bytes = 0;
   int*    d_info = nullptr;
@@ -198,6 +198,8 @@ int dense_create(dlg_backend* b);
 // dense_diag.hip: factor the 64x64 diagonal block at kb and form its inverse (one workgroup)
 void dense_launch_potrf_diag(hipStream_t st, double* A, int lda, int kb, int nb, int* info_dev, double* Linv);
 // ... and the rows below it in the same launch (flag: one device int, epoch: a value no earlier launch used)
+// the whole dense factorisation in one launch (a workgroup per 64 x 64 tile; flags: T*T device ints, T = ceil(n/64))
+void dense_launch_potrf_tiles(hipStream_t st, double* A, int lda, int n, int* info_dev, double* Linv, int* flags, int epoch);
 void dense_launch_potrf_diag_trsm(hipStream_t st, double* A, int lda, int kb, int nb, int n, int* info_dev, double* Linv,
                                   int* flag, int epoch);
 void dense_destroy(dlg_backend* b);

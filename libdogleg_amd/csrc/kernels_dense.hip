@@ -871,9 +871,22 @@ int dense_factorize(dlg_backend* b, int s, double lambda, int* ok)
   dlg_fork_point(b);
   {
     DlgProfScope pf(b, DLG_PROF_K5_FACTOR);
-    if(!b->potrf_flag) { DLG_HIP(hipMalloc(&b->potrf_flag, sizeof(int))); DLG_HIP(hipMemsetAsync(b->potrf_flag, 0, sizeof(int), b->stream)); }
+    const int T = dlg_cdiv(b->N, NB);
+    if(!b->potrf_flag)
+    {
+      DLG_HIP(hipMalloc(&b->potrf_flag, sizeof(int)*((size_t)T*T + 1)));
+      DLG_HIP(hipMemsetAsync(b->potrf_flag, 0, sizeof(int)*((size_t)T*T + 1), b->stream));
+    }
+    // one launch for the whole factorisation (dense_diag.hip: k_potrf_tiles); DOGLEG_AMD_POTRF_STEPS: the
+    // step-by-step form (its fused diagonal + rows launch uses the last flag)
+    if(!getenv("DOGLEG_AMD_POTRF_STEPS") && T >= 2)
+    {
+      dense_launch_potrf_tiles(b->stream, b->G, b->N, b->N, b->d_info, b->Linv, b->potrf_flag, ++b->potrf_epoch);
+      DLG_LAUNCH_CHECK();
+    }
+    else
     DLG_CHECK(potrf_lower(b->stream, b->G, b->N, b->N, b->d_info, b->Linv,
-                          b->overlap ? b->copy_stream : nullptr, b->ev_step, b->ev_copy, b->potrf_flag, &b->potrf_epoch));
+                          b->overlap ? b->copy_stream : nullptr, b->ev_step, b->ev_copy, b->potrf_flag + (size_t)T*T, &b->potrf_epoch));
   }
   return finish_potrf(b, ok);
 }

@@ -179,8 +179,8 @@ def test_syrk_and_potrf_kernels(gpu):
 
 
 @pytest.mark.parametrize("env", [{"DOGLEG_AMD_LOOKAHEAD": "1"}, {"DOGLEG_AMD_NO_OVERLAP": "1"}, {"DOGLEG_AMD_NO_K3_FORK": "1"},
-                                 {"DOGLEG_AMD_NO_POTRF_FUSE": "1"}],
-                         ids=["potrf-lookahead", "no-overlap", "no-k3-fork", "potrf-unfused"])
+                                 {"DOGLEG_AMD_POTRF_STEPS": "1"}, {"DOGLEG_AMD_POTRF_STEPS": "1", "DOGLEG_AMD_NO_POTRF_FUSE": "1"}],
+                         ids=["potrf-lookahead", "no-overlap", "no-k3-fork", "potrf-steps", "potrf-steps-unfused"])
 def test_dense_stream_variants_match_oracle(gpu, env, monkeypatch):
     """the two-stream variants of the dense path (look-ahead potrf, Cauchy step beside the factorisation)
     and their single-stream forms give the oracle's Gauss-Newton step"""
@@ -208,6 +208,7 @@ def test_fused_diagonal_block_launch_changes_no_bit(gpu, monkeypatch):
     """the diagonal block of a potrf step and the rows below it in one launch (the inverse of the block
     handed over through a flag, dense_diag.hip) leave the same factor as the two launches, bit for bit,
     over repeated factorisations"""
+    monkeypatch.setenv("DOGLEG_AMD_POTRF_STEPS", "1")        # (the step-by-step form; the one-launch form: next test)
     dp = oa.DenseProblem(M=2500, N=521, seed=4)
     p = dp.p0()
     evals = [dp.eval(p + 0.01*k) for k in range(3)]
@@ -229,3 +230,37 @@ def test_fused_diagonal_block_launch_changes_no_bit(gpu, monkeypatch):
         be.close()
     for a, b in zip(out[True], out[False]):
         assert a[0] == b[0] and np.array_equal(a[1], b[1])
+
+
+@pytest.mark.parametrize("N", [130, 521, 1000])
+def test_one_launch_potrf_matches_the_step_form_and_reproduces_its_bits(gpu, N, monkeypatch):
+    """the whole dense factorisation in one launch (a workgroup per 64 x 64 tile, blocks of L handed over
+    through flags: k_potrf_tiles): the Gauss-Newton step agrees with the step-by-step form to rounding
+    and with numpy's Cholesky solve; a hundred repetitions over two inputs reproduce their bits"""
+    dp = oa.DenseProblem(M=3*N, N=N, seed=5)
+    p = dp.p0()
+    evals = [dp.eval(p), dp.eval(p + 0.01)]
+    out = {}
+    for mode in ("tiles", "steps"):
+        monkeypatch.delenv("DOGLEG_AMD_POTRF_STEPS", raising=False)
+        if mode == "steps":
+            monkeypatch.setenv("DOGLEG_AMD_POTRF_STEPS", "1")
+        be = capi.Backend(capi.DLG_DENSE, dp.N, dp.M)
+        be.set_p(0, p)
+        res = []
+        for rep in range(100 if mode == "tiles" else 1):
+            for x, J in evals:
+                be.upload(0, x, J)
+                be.eval(0)
+                lam, n2g = be.gauss_newton(0, 0.0)
+                res.append((n2g, be.download(0, capi.VEC_GN)))
+        out[mode] = res
+        be.close()
+    for k, (n2g, gn) in enumerate(out["tiles"]):
+        assert n2g == out["tiles"][k & 1][0] and np.array_equal(gn, out["tiles"][k & 1][1])
+    for k in range(2):
+        x, J = evals[k]
+        ref = -np.linalg.solve(J.reshape(dp.M, dp.N).T @ J.reshape(dp.M, dp.N), J.reshape(dp.M, dp.N).T @ x)
+        scale = max(1.0, np.max(np.abs(ref)))
+        assert np.max(np.abs(out["tiles"][k][1] - out["steps"][k][1])) <= 1e-11*scale
+        assert np.max(np.abs(out["tiles"][k][1] - ref)) <= 1e-9*scale
