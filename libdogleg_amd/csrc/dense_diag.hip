@@ -279,7 +279,126 @@ __global__ void __launch_bounds__(TPB) k_potrf_tiles(double* A, int lda, int n, 
   if(t == 0) __hip_atomic_store(flags + ti*T + tj, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// ---- both triangular solves in ONE launch: a workgroup per 64 rows -------------------------------
+// forward  y_i = Linv_i (b_i - sum_{k<i} L(i,k) y_k), backward  x_i = Linv_i' (y_i - sum_{k>i} L(k,i)' x_k).
+// Workgroup i waits for y_k (k < i) going down and for x_k (k > i) coming back up: flags with the
+// epoch of the launch, vectors handed over with write-through stores / loads around L1.  The tile of
+// L a product needs does not depend on the vector it waits for: it is on its way (forward: in
+// registers, backward: staged in LDS) before the flag is polled.  All T workgroups must be resident
+// (they wait for higher-numbered ones on the way back): T <= the number of CUs, one per CU.
+__global__ void __launch_bounds__(TPB) k_trsv_tiles(const double* __restrict__ A, int lda, int n, int T,
+                                                    const double* __restrict__ Linv, const double* __restrict__ rhs,
+                                                    double* Y, double* X, int* flags, int epoch)
+{
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  typedef __attribute__((address_space(1))) double* gd_t;
+  typedef const __attribute__((address_space(1))) double* gcd_t;
+  constexpr int LDT = NB + 1;
+  double (*Lt)[LDT] = reinterpret_cast<double (*)[LDT]>(sm);                 // a tile of L: Lt[row][col]
+  double* Li = sm + NB*LDT;                                                  // [NB*NB] this block's inverse, Li[r + c*NB] = Linv(r, c)
+  double* v = Li + NB*NB;                                                    // [NB]  the vector waited for
+  double* part = v + NB;                                                     // [4][NB] partial sums
+  const int t = threadIdx.x, r = t & 63, g = t >> 6;
+  const int i = blockIdx.x, row0 = NB*i;
+  int* fy = flags; int* fx = flags + T;
+  auto wait_flag = [&](int* f) {
+    int spins = 0;
+    while(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch)
+    { __builtin_amdgcn_s_sleep(1); if(++spins > (1 << 22)) break; }
+  };
+  for(int e = t; e < NB*NB; e += TPB) Li[e] = Linv[(size_t)i*NB*NB + e];
+  // ---- forward: thread (row r, column group g) keeps 16 values of the tile in registers
+  double acc = 0.0;
+  double cur[16];
+  auto load_row_tile = [&](int k, double (&d)[16]) {
+#pragma unroll
+    for(int c = 0; c < 16; c++)
+    {
+      const int row = row0 + r, col = NB*k + 16*g + c;
+      d[c] = (row < n && k < i) ? A[(size_t)col*lda + row] : 0.0;
+    }
+  };
+  load_row_tile(0, cur);
+  for(int k = 0; k < i; k++)
+  {
+    double nxt[16];
+    load_row_tile(k + 1, nxt);                       // (k + 1 == i: zeros, no loads)
+    if(t == 0) wait_flag(fy + k);
+    __syncthreads();
+    if(t < NB) v[t] = __hip_atomic_load((gcd_t)(Y + NB*k + t), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+#pragma unroll
+    for(int c = 0; c < 16; c++) acc += cur[c]*v[16*g + c];
+#pragma unroll
+    for(int c = 0; c < 16; c++) cur[c] = nxt[c];
+  }
+  part[g*NB + r] = acc;
+  __syncthreads();
+  if(t < NB)
+  {
+    const double s = (part[t] + part[NB + t]) + (part[2*NB + t] + part[3*NB + t]);
+    v[t] = (row0 + t < n) ? rhs[row0 + t] - s : 0.0;
+  }
+  __syncthreads();
+  double yi = 0.0;
+  if(t < NB)
+  {
+#pragma unroll 8
+    for(int k = 0; k < NB; k++) yi += Li[t + k*NB]*v[k];          // Linv is zero above the diagonal
+    if(row0 + t < n) __hip_atomic_store((gd_t)(Y + row0 + t), yi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if(t == 0) __hip_atomic_store(fy + i, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // ---- backward: the tile L(k, i) goes through LDS (thread = column afterwards)
+  double bacc = 0.0;
+  for(int k = T - 1; k > i; k--)
+  {
+    for(int e = t; e < NB*NB; e += TPB)
+    {
+      const int rr = e % NB, cc = e / NB;
+      const int row = NB*k + rr, col = row0 + cc;
+      Lt[rr][cc] = (row < n && col < n) ? A[(size_t)col*lda + row] : 0.0;
+    }
+    if(t == 0) wait_flag(fx + k);
+    __syncthreads();
+    if(t < NB) v[t] = (NB*k + t < n) ? __hip_atomic_load((gcd_t)(X + NB*k + t), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+    __syncthreads();
+#pragma unroll
+    for(int q = 0; q < 16; q++) bacc += Lt[16*g + q][r]*v[16*g + q];      // thread (column r, row group g)
+    __syncthreads();
+  }
+  part[g*NB + r] = bacc;
+  __syncthreads();
+  if(t < NB)
+  {
+    const double s = (part[t] + part[NB + t]) + (part[2*NB + t] + part[3*NB + t]);
+    v[t] = yi - s;                                   // (rows past the end: yi = 0, s = 0)
+  }
+  __syncthreads();
+  if(t < NB)
+  {
+    double xi = 0.0;
+#pragma unroll 8
+    for(int k = 0; k < NB; k++) xi += Li[k + t*NB]*v[k];          // Linv' : column t of Linv
+    if(row0 + t < n) __hip_atomic_store((gd_t)(X + row0 + t), xi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if(t == 0) __hip_atomic_store(fx + i, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 } // namespace
+
+void dense_launch_trsv_tiles(hipStream_t st, const double* A, int lda, int n, const double* Linv, const double* rhs,
+                             double* Y, double* X, int* flags, int epoch)
+{
+  static bool attr = false;
+  constexpr int LDSB = 88*1024;           // > half of the CU's LDS: one workgroup per CU
+  if(!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trsv_tiles), hipFuncAttributeMaxDynamicSharedMemorySize, LDSB); attr = true; }
+  const int T = (n + NB - 1)/NB;
+  hipLaunchKernelGGL(k_trsv_tiles, dim3(T), dim3(TPB), LDSB, st, A, lda, n, T, Linv, rhs, Y, X, flags, epoch);
+}
 
 void dense_launch_potrf_tiles(hipStream_t st, double* A, int lda, int n, int* info_dev, double* Linv, int* flags, int epoch)
 {

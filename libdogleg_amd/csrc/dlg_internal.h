@@ -95,7 +95,7 @@ struct dlg_backend
   // dense / products
   double* G = nullptr;        // N x N column-major, lower triangle = factor
   double* Linv = nullptr;     // inverses of the 64x64 diagonal blocks of the factor
-  int* potrf_flag = nullptr; int potrf_epoch = 0;   // hand-off flags of the one-launch factorisation ([T*T] + 1 for the step form)
+  int* potrf_flag = nullptr; int potrf_epoch = 0; int* trsv_flag = nullptr; double* trsv_y = nullptr;   // hand-off flags of the one-launch factorisation ([T*T] + 1 for the step form)
   double* slabs = nullptr;    // split-K partial slabs for the SYRK
   size_t  slabs_bytes = 0;
   int*    d_info = nullptr;
@@ -200,6 +200,9 @@ void dense_launch_potrf_diag(hipStream_t st, double* A, int lda, int kb, int nb,
 // ... and the rows below it in the same launch (flag: one device int, epoch: a value no earlier launch used)
 // the whole dense factorisation in one launch (a workgroup per 64 x 64 tile; flags: T*T device ints, T = ceil(n/64))
 void dense_launch_potrf_tiles(hipStream_t st, double* A, int lda, int n, int* info_dev, double* Linv, int* flags, int epoch);
+// both triangular solves of (L L') x = rhs in one launch (a workgroup per 64 rows; flags: 2*T device ints; Y: n doubles of scratch)
+void dense_launch_trsv_tiles(hipStream_t st, const double* A, int lda, int n, const double* Linv, const double* rhs,
+                             double* Y, double* X, int* flags, int epoch);
 void dense_launch_potrf_diag_trsm(hipStream_t st, double* A, int lda, int kb, int nb, int n, int* info_dev, double* Linv,
                                   int* flag, int epoch);
 void dense_destroy(dlg_backend* b);

@@ -783,6 +783,8 @@ void dense_destroy(dlg_backend* b)
   if(b->slabs) (void)hipFree(b->slabs);
   if(b->d_info) (void)hipFree(b->d_info);
   if(b->potrf_flag) { (void)hipFree(b->potrf_flag); b->potrf_flag = nullptr; }
+  if(b->trsv_flag) { (void)hipFree(b->trsv_flag); b->trsv_flag = nullptr; }
+  if(b->trsv_y) { (void)hipFree(b->trsv_y); b->trsv_y = nullptr; }
   if(b->h_info) (void)hipHostFree(b->h_info);
   b->G = b->slabs = nullptr; b->d_info = nullptr; b->h_info = nullptr;
 }
@@ -911,6 +913,25 @@ int products_factorize(dlg_backend* b, int s, double lambda, int* ok)
 int dense_solve(dlg_backend* b, const double* rhs, double* out)
 {
   const int n = b->N;
+  {
+    // one launch for both sweeps where every block row gets a CU of its own (dense_diag.hip: k_trsv_tiles);
+    // DOGLEG_AMD_TRSV_STEPS: a launch per block column and sweep
+    const int T = dlg_cdiv(n, NB);
+    static int ncu = 0;
+    if(!ncu) { int dev = 0; ncu = 256; if(hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev); }
+    if(T >= 2 && T <= ncu && !getenv("DOGLEG_AMD_TRSV_STEPS"))
+    {
+      if(!b->trsv_flag)
+      {
+        DLG_HIP(hipMalloc(&b->trsv_flag, sizeof(int)*2*(size_t)T));
+        DLG_HIP(hipMemsetAsync(b->trsv_flag, 0, sizeof(int)*2*(size_t)T, b->stream));
+        DLG_HIP(hipMalloc(&b->trsv_y, sizeof(double)*(size_t)n));
+      }
+      dense_launch_trsv_tiles(b->stream, b->G, n, n, b->Linv, rhs, b->trsv_y, out, b->trsv_flag, ++b->potrf_epoch);
+      DLG_LAUNCH_CHECK();
+      return DLG_OK;
+    }
+  }
   if(out != rhs) DLG_HIP(hipMemcpyAsync(out, rhs, sizeof(double)*(size_t)n, hipMemcpyDeviceToDevice, b->stream));
   // forward: the first diagonal block, then one fused launch per block column (update + next diagonal block)
   hipLaunchKernelGGL(k_trsv_diag_fwd, dim3(1), dim3(64), 0, b->stream, b->Linv, 0, (n < NB) ? n : NB, out);

@@ -179,8 +179,9 @@ def test_syrk_and_potrf_kernels(gpu):
 
 
 @pytest.mark.parametrize("env", [{"DOGLEG_AMD_LOOKAHEAD": "1"}, {"DOGLEG_AMD_NO_OVERLAP": "1"}, {"DOGLEG_AMD_NO_K3_FORK": "1"},
-                                 {"DOGLEG_AMD_POTRF_STEPS": "1"}, {"DOGLEG_AMD_POTRF_STEPS": "1", "DOGLEG_AMD_NO_POTRF_FUSE": "1"}],
-                         ids=["potrf-lookahead", "no-overlap", "no-k3-fork", "potrf-steps", "potrf-steps-unfused"])
+                                 {"DOGLEG_AMD_POTRF_STEPS": "1"}, {"DOGLEG_AMD_POTRF_STEPS": "1", "DOGLEG_AMD_NO_POTRF_FUSE": "1"},
+                                 {"DOGLEG_AMD_TRSV_STEPS": "1"}],
+                         ids=["potrf-lookahead", "no-overlap", "no-k3-fork", "potrf-steps", "potrf-steps-unfused", "trsv-steps"])
 def test_dense_stream_variants_match_oracle(gpu, env, monkeypatch):
     """the two-stream variants of the dense path (look-ahead potrf, Cauchy step beside the factorisation)
     and their single-stream forms give the oracle's Gauss-Newton step"""
@@ -235,7 +236,8 @@ def test_fused_diagonal_block_launch_changes_no_bit(gpu, monkeypatch):
 @pytest.mark.parametrize("N", [130, 521, 1000])
 def test_one_launch_potrf_matches_the_step_form_and_reproduces_its_bits(gpu, N, monkeypatch):
     """the whole dense factorisation in one launch (a workgroup per 64 x 64 tile, blocks of L handed over
-    through flags: k_potrf_tiles): the Gauss-Newton step agrees with the step-by-step form to rounding
+    through flags: k_potrf_tiles) and both triangular solves in another (k_trsv_tiles): the Gauss-Newton
+    step agrees with the step-by-step forms to rounding
     and with numpy's Cholesky solve; a hundred repetitions over two inputs reproduce their bits"""
     dp = oa.DenseProblem(M=3*N, N=N, seed=5)
     p = dp.p0()
@@ -243,8 +245,10 @@ def test_one_launch_potrf_matches_the_step_form_and_reproduces_its_bits(gpu, N, 
     out = {}
     for mode in ("tiles", "steps"):
         monkeypatch.delenv("DOGLEG_AMD_POTRF_STEPS", raising=False)
+        monkeypatch.delenv("DOGLEG_AMD_TRSV_STEPS", raising=False)
         if mode == "steps":
             monkeypatch.setenv("DOGLEG_AMD_POTRF_STEPS", "1")
+            monkeypatch.setenv("DOGLEG_AMD_TRSV_STEPS", "1")
         be = capi.Backend(capi.DLG_DENSE, dp.N, dp.M)
         be.set_p(0, p)
         res = []
