@@ -304,10 +304,10 @@ def main():
     else:
         k5_ms, k6_ms = per_launch("K5_factor"), per_launch("K6_solve")
         others = {
-            "K5_dense_potrf": {"bound": "mfma / launch chain", "ms": k5_ms, "flops": N**3 / 3.0,
+            "K5_dense_potrf": {"bound": "latency (one launch; critical path = the diagonal tiles' panel sweeps)", "ms": k5_ms, "flops": N**3 / 3.0,
                                "TFLOPps": N**3 / 3.0 / (k5_ms * 1e-3) / 1e12 if k5_ms > 0 else None,
                                "frac_mfma": N**3 / 3.0 / (k5_ms * 1e-3) / 1e12 / MFMA_F64_PEAK_TFLOPS if k5_ms > 0 else None},
-            "K6_dense_potrs": {"bound": "hbm / latency", "ms": k6_ms, "algorithmic_bytes": 2 * 8 * N * (N + 1) // 2,
+            "K6_dense_potrs": {"bound": "latency (one launch; hand-off per 64 rows and sweep)", "ms": k6_ms, "algorithmic_bytes": 2 * 8 * N * (N + 1) // 2,
                                "GBps": 8.0 * N * (N + 1) / (k6_ms * 1e-3) / 1e9 if k6_ms > 0 else None},
         }
 
