@@ -843,6 +843,27 @@ int products_quadform(dlg_backend* b, int s, const double* v, double* out_dev)
   return k_reduce_sum(b, part, g, out_dev);
 }
 
+// K5-dense on b->G: the one-launch form, or the step-by-step one
+static int run_potrf(dlg_backend* b)
+{
+  const int T = dlg_cdiv(b->N, NB);
+  if(!b->potrf_flag)
+  {
+    DLG_HIP(hipMalloc(&b->potrf_flag, sizeof(int)*((size_t)T*T + 1)));
+    DLG_HIP(hipMemsetAsync(b->potrf_flag, 0, sizeof(int)*((size_t)T*T + 1), b->stream));
+  }
+  // one launch for the whole factorisation (dense_diag.hip: k_potrf_tiles); DOGLEG_AMD_POTRF_STEPS: the
+  // step-by-step form (its fused diagonal + rows launch uses the last flag)
+  if(!getenv("DOGLEG_AMD_POTRF_STEPS") && T >= 2)
+  {
+    dense_launch_potrf_tiles(b->stream, b->G, b->N, b->N, b->d_info, b->Linv, b->potrf_flag, ++b->potrf_epoch);
+    DLG_LAUNCH_CHECK();
+    return DLG_OK;
+  }
+  return potrf_lower(b->stream, b->G, b->N, b->N, b->d_info, b->Linv,
+                     b->overlap ? b->copy_stream : nullptr, b->ev_step, b->ev_copy, b->potrf_flag + (size_t)T*T, &b->potrf_epoch);
+}
+
 static int finish_potrf(dlg_backend* b, int* ok)
 {
   DLG_HIP(hipMemcpyAsync(b->h_info, b->d_info, sizeof(int), hipMemcpyDeviceToHost, b->stream));
@@ -873,22 +894,7 @@ int dense_factorize(dlg_backend* b, int s, double lambda, int* ok)
   dlg_fork_point(b);
   {
     DlgProfScope pf(b, DLG_PROF_K5_FACTOR);
-    const int T = dlg_cdiv(b->N, NB);
-    if(!b->potrf_flag)
-    {
-      DLG_HIP(hipMalloc(&b->potrf_flag, sizeof(int)*((size_t)T*T + 1)));
-      DLG_HIP(hipMemsetAsync(b->potrf_flag, 0, sizeof(int)*((size_t)T*T + 1), b->stream));
-    }
-    // one launch for the whole factorisation (dense_diag.hip: k_potrf_tiles); DOGLEG_AMD_POTRF_STEPS: the
-    // step-by-step form (its fused diagonal + rows launch uses the last flag)
-    if(!getenv("DOGLEG_AMD_POTRF_STEPS") && T >= 2)
-    {
-      dense_launch_potrf_tiles(b->stream, b->G, b->N, b->N, b->d_info, b->Linv, b->potrf_flag, ++b->potrf_epoch);
-      DLG_LAUNCH_CHECK();
-    }
-    else
-    DLG_CHECK(potrf_lower(b->stream, b->G, b->N, b->N, b->d_info, b->Linv,
-                          b->overlap ? b->copy_stream : nullptr, b->ev_step, b->ev_copy, b->potrf_flag + (size_t)T*T, &b->potrf_epoch));
+    DLG_CHECK(run_potrf(b));
   }
   return finish_potrf(b, ok);
 }
@@ -904,8 +910,7 @@ int products_factorize(dlg_backend* b, int s, double lambda, int* ok)
   hipLaunchKernelGGL(k_unpack_to_G, dim3(dlg_cdiv((long)nn, TPB)), dim3(TPB), 0, b->stream, S.Jin(),
                      b->N, packed ? 1 : 0, lambda, b->G);
   DLG_LAUNCH_CHECK();
-  DLG_CHECK(potrf_lower(b->stream, b->G, b->N, b->N, b->d_info, b->Linv,
-                        b->overlap ? b->copy_stream : nullptr, b->ev_step, b->ev_copy));
+  DLG_CHECK(run_potrf(b));
   return finish_potrf(b, ok);
 }
 
