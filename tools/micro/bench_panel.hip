@@ -34,7 +34,7 @@ __global__ void __launch_bounds__(NT) k_panel(double* G, int nrows, int w, int* 
   long long t1 = clock64();
   if(MODE == 0) panel_factor<NT, true>(P, ldp, nrows, w, tid, info, 0);
   if(MODE == 1) { if(blockIdx.x == 0 && tid == 0) g_pf_out = stamps + 4; panel_factor<NT, true>(P, ldp, nrows, w, tid, info, 0); }
-  if(MODE == 4) panel_factor_blockdiag<NT>(P, ldp, nrows, w, tid, g_mcol, w/3, info, 0);
+  if(MODE == 4) { __shared__ int s_mcol[260]; __shared__ double s_rdiag[256]; panel_factor_blockdiag<NT>(P, ldp, nrows, w, tid, g_mcol, w/3, info, 0, s_mcol, s_rdiag); }
   if(MODE == 2) { if(NT >= 256) panel_factor_mfma<(NT >= 256 ? NT : 256)>(P, ldp, nrows, w, tid, info, 0); else if(NT >= 256) panel_factor_mfma<(NT >= 256 ? NT : 256)>(P, ldp, nrows, w, tid, info, 0); else panel_factor<NT, true, true>(P, ldp, nrows, w, tid, info, 0); }
   if(MODE == 3) { if(blockIdx.x == 0 && tid == 0) g_pf_out = stamps + 4; if(NT >= 256) panel_factor_mfma<(NT >= 256 ? NT : 256)>(P, ldp, nrows, w, tid, info, 0); else panel_factor<NT, true, true>(P, ldp, nrows, w, tid, info, 0); }
   __syncthreads();
@@ -129,6 +129,7 @@ void run_bd(int nrows, int w, int G, int iters)
 int main(int argc, char** argv)
 {
   const int G = argc > 1 ? atoi(argv[1]) : 64;
+  if(argc > 4) { run<512>(atoi(argv[2]), atoi(argv[3]), G, 20); return 0; }      // G nrows w 512
   if(argc > 3) { run<256>(atoi(argv[2]), atoi(argv[3]), G, 20); return 0; }
   run_bd<256>(124, 51, G, 20); run_bd<128>(124, 51, G, 20); run_bd<256>(124, 51, 2489, 20); run_bd<128>(124, 51, 2489, 20);
   run<512>(170, 96, G, 20); run<256>(170, 96, G, 20); run<128>(170, 96, G, 20);
