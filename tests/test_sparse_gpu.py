@@ -201,10 +201,17 @@ def test_no_device_memory_leak_over_create_solve_destroy_cycles(gpu):
         capi.optimize("sparse", prob.p0(), prob.N, prob.M, prob.nnz, prob.cb, prob.cookie, prm)
 
     cycle()                                  # one-off allocations of the runtime (code objects, pools)
-    before = free_bytes()
-    for _ in range(10):
-        cycle()
-    assert before - free_bytes() <= (1 << 20), "device memory is not returned"
+    # a leak loses memory in every batch of cycles; the HIP runtime's own pools (signals, kernel
+    # arguments) grow once, whenever the timing first needs them, so one clean batch is the proof
+    lost = []
+    for _ in range(3):
+        before = free_bytes()
+        for _ in range(10):
+            cycle()
+        lost.append(before - free_bytes())
+        if lost[-1] <= (1 << 20):
+            break
+    assert lost[-1] <= (1 << 20), f"device memory is not returned: {lost} bytes per 10 cycles"
 
 
 @pytest.mark.parametrize("kind", ["sparse", "dense"])
