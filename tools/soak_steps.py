@@ -3,7 +3,7 @@
 binding every time: nothing cached), alternating between two different inputs -- every repetition of
 an input must reproduce its numbers bit for bit.  A stale read in one of the one-launch regions (a
 workgroup reading an update matrix or x of an earlier launch) would show up as a different bit
-pattern.  usage: soak_steps.py [steps] [workload]"""
+pattern.  usage: soak_steps.py [steps] [sparse-1m|sparse-200k|dense-50k|dense-8k]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -11,14 +11,22 @@ from libdogleg_amd import capi
 from tests import oracle_api as oa
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 4000
-shape = {"sparse-1m": (2499, 45000, 500000), "sparse-200k": (499, 9000, 100000)}[sys.argv[2] if len(sys.argv) > 2 else "sparse-1m"]
-prob = oa.BAProblem(*shape, seed=11, eps=0.4, p0_spread=0.6)
-Jp, Ji = prob.pattern()
-p = prob.p0()
-inputs = [prob.eval(p), prob.eval(p + 0.01)]
-be = capi.Backend(capi.DLG_SPARSE, prob.N, prob.M, prob.nnz)
-be.set_pattern(Jp, Ji)
-be.set_speculation(True)
+workload = sys.argv[2] if len(sys.argv) > 2 else "sparse-1m"
+if workload.startswith("dense"):
+    # the one-launch dense factorisation and triangular solves (tile flags carry a per-launch epoch)
+    prob = oa.DenseProblem({"dense-50k": 50000, "dense-8k": 8000}[workload], {"dense-50k": 2000, "dense-8k": 1000}[workload], seed=11)
+    p = prob.p0()
+    inputs = [prob.eval(p), prob.eval(p + 0.01)]
+    be = capi.Backend(capi.DLG_DENSE, prob.N, prob.M)
+else:
+    shape = {"sparse-1m": (2499, 45000, 500000), "sparse-200k": (499, 9000, 100000)}[workload]
+    prob = oa.BAProblem(*shape, seed=11, eps=0.4, p0_spread=0.6)
+    Jp, Ji = prob.pattern()
+    p = prob.p0()
+    inputs = [prob.eval(p), prob.eval(p + 0.01)]
+    be = capi.Backend(capi.DLG_SPARSE, prob.N, prob.M, prob.nnz)
+    be.set_pattern(Jp, Ji)
+    be.set_speculation(True)
 be.set_p(0, p)
 dev = [(capi.DeviceArray(np.ascontiguousarray(x)), capi.DeviceArray(np.ascontiguousarray(J))) for x, J in inputs]
 ref, tr = [None, None], None
