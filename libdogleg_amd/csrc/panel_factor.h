@@ -177,8 +177,11 @@ __device__ __forceinline__ void panel_factor_mfma(double* P, int ldp, int nrows,
     if(wv == 0)
     {
       if(kb > 0) panel_mfma_tiles<false>(P, ldp, nrows, kb, nb16, kbeg, lane, 0, ntile, ntile);
+      DLG_PF_STAMP(2);
       pf_load_block(D, P, ldp, kb, nb);
+      DLG_PF_STAMP(3);
       const int badcol = pf_factor_block(D, Dinv);
+      DLG_PF_STAMP(6);
       if(badcol >= 0 && tid == 0) atomicMin(info, col0 + kb + badcol);
       // thread (c, q) keeps element (c, q) (compile-time indices: D lives in registers)
       const int c = tid >> 3, q = tid & 7;
