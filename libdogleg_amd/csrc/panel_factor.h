@@ -25,6 +25,7 @@
 #ifndef DLG_PF_STAMP
 #define DLG_PF_DECL
 #define DLG_PF_STAMP(i)
+#define DLG_PF_PIN(x)
 #define DLG_PF_DONE
 #endif
 
@@ -152,6 +153,147 @@ __device__ __forceinline__ int pf_factor_block(double (&D)[8][8], double (&Dinv)
   }
   return badcol;
 }
+// The diagonal wave holds the factored block in EVERY lane (the factorisation is the same instruction
+// stream in all of them).  Write-back without a select chain: element e of the 44 (see pf_block_lane_addr)
+// is moved into lane e of one register with only that lane enabled -- 44 x (s_mov exec + v_mov_b64) --
+// and one ds_write_b64 of 44 lanes stores them all.  (The select chain it replaces kept 36 lane-index
+// compares in spilled SGPRs, ~1400 clocks per block; 44 single-lane LDS stores cost as much: a lone
+// wave issues an LDS store every ~30 clocks.  tools/micro/bench_pfchain.)  exec is restored inside the asm.
+__device__ __forceinline__ double pf_block_to_lanes(const double (&D)[8][8], const double (&Dinv)[8])
+{
+  unsigned long long sv;
+  double t = 0.0;
+  asm volatile(
+    "s_mov_b64 %[sv], exec\n\t"
+    "s_mov_b32 exec_hi, 0\n\t"
+    "s_mov_b32 exec_lo, 0x1\n\t"
+    "v_mov_b64 %[t], %[d0]\n\t"
+    "s_mov_b32 exec_lo, 0x2\n\t"
+    "v_mov_b64 %[t], %[d1]\n\t"
+    "s_mov_b32 exec_lo, 0x4\n\t"
+    "v_mov_b64 %[t], %[d2]\n\t"
+    "s_mov_b32 exec_lo, 0x8\n\t"
+    "v_mov_b64 %[t], %[d3]\n\t"
+    "s_mov_b32 exec_lo, 0x10\n\t"
+    "v_mov_b64 %[t], %[d4]\n\t"
+    "s_mov_b32 exec_lo, 0x20\n\t"
+    "v_mov_b64 %[t], %[d5]\n\t"
+    "s_mov_b32 exec_lo, 0x40\n\t"
+    "v_mov_b64 %[t], %[d6]\n\t"
+    "s_mov_b32 exec_lo, 0x80\n\t"
+    "v_mov_b64 %[t], %[d7]\n\t"
+    "s_mov_b32 exec_lo, 0x100\n\t"
+    "v_mov_b64 %[t], %[d8]\n\t"
+    "s_mov_b32 exec_lo, 0x200\n\t"
+    "v_mov_b64 %[t], %[d9]\n\t"
+    "s_mov_b32 exec_lo, 0x400\n\t"
+    "v_mov_b64 %[t], %[d10]\n\t"
+    "s_mov_b32 exec_lo, 0x800\n\t"
+    "v_mov_b64 %[t], %[d11]\n\t"
+    "s_mov_b32 exec_lo, 0x1000\n\t"
+    "v_mov_b64 %[t], %[d12]\n\t"
+    "s_mov_b32 exec_lo, 0x2000\n\t"
+    "v_mov_b64 %[t], %[d13]\n\t"
+    "s_mov_b32 exec_lo, 0x4000\n\t"
+    "v_mov_b64 %[t], %[d14]\n\t"
+    "s_mov_b32 exec_lo, 0x8000\n\t"
+    "v_mov_b64 %[t], %[d15]\n\t"
+    "s_mov_b32 exec_lo, 0x10000\n\t"
+    "v_mov_b64 %[t], %[d16]\n\t"
+    "s_mov_b32 exec_lo, 0x20000\n\t"
+    "v_mov_b64 %[t], %[d17]\n\t"
+    "s_mov_b32 exec_lo, 0x40000\n\t"
+    "v_mov_b64 %[t], %[d18]\n\t"
+    "s_mov_b32 exec_lo, 0x80000\n\t"
+    "v_mov_b64 %[t], %[d19]\n\t"
+    "s_mov_b32 exec_lo, 0x100000\n\t"
+    "v_mov_b64 %[t], %[d20]\n\t"
+    "s_mov_b32 exec_lo, 0x200000\n\t"
+    "v_mov_b64 %[t], %[d21]\n\t"
+    "s_mov_b32 exec_lo, 0x400000\n\t"
+    "v_mov_b64 %[t], %[d22]\n\t"
+    "s_mov_b32 exec_lo, 0x800000\n\t"
+    "v_mov_b64 %[t], %[d23]\n\t"
+    "s_mov_b32 exec_lo, 0x1000000\n\t"
+    "v_mov_b64 %[t], %[d24]\n\t"
+    "s_mov_b32 exec_lo, 0x2000000\n\t"
+    "v_mov_b64 %[t], %[d25]\n\t"
+    "s_mov_b32 exec_lo, 0x4000000\n\t"
+    "v_mov_b64 %[t], %[d26]\n\t"
+    "s_mov_b32 exec_lo, 0x8000000\n\t"
+    "v_mov_b64 %[t], %[d27]\n\t"
+    "s_mov_b64 exec, %[sv]"
+    : [sv] "=&s"(sv), [t] "+v"(t)
+    : [d0] "v"(D[0][0]), [d1] "v"(D[1][0]), [d2] "v"(D[1][1]), [d3] "v"(D[2][0]), [d4] "v"(D[2][1]), [d5] "v"(D[2][2]), [d6] "v"(D[3][0]), [d7] "v"(D[3][1]), [d8] "v"(D[3][2]), [d9] "v"(D[3][3]), [d10] "v"(D[4][0]), [d11] "v"(D[4][1]), [d12] "v"(D[4][2]), [d13] "v"(D[4][3]), [d14] "v"(D[4][4]), [d15] "v"(D[5][0]), [d16] "v"(D[5][1]), [d17] "v"(D[5][2]), [d18] "v"(D[5][3]), [d19] "v"(D[5][4]), [d20] "v"(D[5][5]), [d21] "v"(D[6][0]), [d22] "v"(D[6][1]), [d23] "v"(D[6][2]), [d24] "v"(D[6][3]), [d25] "v"(D[6][4]), [d26] "v"(D[6][5]), [d27] "v"(D[6][6]));
+  asm volatile(
+    "s_mov_b64 %[sv], exec\n\t"
+    "s_mov_b32 exec_hi, 0\n\t"
+    "s_mov_b32 exec_lo, 0x10000000\n\t"
+    "v_mov_b64 %[t], %[d0]\n\t"
+    "s_mov_b32 exec_lo, 0x20000000\n\t"
+    "v_mov_b64 %[t], %[d1]\n\t"
+    "s_mov_b32 exec_lo, 0x40000000\n\t"
+    "v_mov_b64 %[t], %[d2]\n\t"
+    "s_mov_b32 exec_lo, 0x80000000\n\t"
+    "v_mov_b64 %[t], %[d3]\n\t"
+    "s_mov_b32 exec_lo, 0\n\t"
+    "s_mov_b32 exec_hi, 0x1\n\t"
+    "v_mov_b64 %[t], %[d4]\n\t"
+    "s_mov_b32 exec_hi, 0x2\n\t"
+    "v_mov_b64 %[t], %[d5]\n\t"
+    "s_mov_b32 exec_hi, 0x4\n\t"
+    "v_mov_b64 %[t], %[d6]\n\t"
+    "s_mov_b32 exec_hi, 0x8\n\t"
+    "v_mov_b64 %[t], %[d7]\n\t"
+    "s_mov_b32 exec_hi, 0x10\n\t"
+    "v_mov_b64 %[t], %[d8]\n\t"
+    "s_mov_b32 exec_hi, 0x20\n\t"
+    "v_mov_b64 %[t], %[d9]\n\t"
+    "s_mov_b32 exec_hi, 0x40\n\t"
+    "v_mov_b64 %[t], %[d10]\n\t"
+    "s_mov_b32 exec_hi, 0x80\n\t"
+    "v_mov_b64 %[t], %[d11]\n\t"
+    "s_mov_b32 exec_hi, 0x100\n\t"
+    "v_mov_b64 %[t], %[d12]\n\t"
+    "s_mov_b32 exec_hi, 0x200\n\t"
+    "v_mov_b64 %[t], %[d13]\n\t"
+    "s_mov_b32 exec_hi, 0x400\n\t"
+    "v_mov_b64 %[t], %[d14]\n\t"
+    "s_mov_b32 exec_hi, 0x800\n\t"
+    "v_mov_b64 %[t], %[d15]\n\t"
+    "s_mov_b64 exec, %[sv]"
+    : [sv] "=&s"(sv), [t] "+v"(t)
+    : [d0] "v"(D[7][0]), [d1] "v"(D[7][1]), [d2] "v"(D[7][2]), [d3] "v"(D[7][3]), [d4] "v"(D[7][4]), [d5] "v"(D[7][5]), [d6] "v"(D[7][6]), [d7] "v"(D[7][7]), [d8] "v"(Dinv[0]), [d9] "v"(Dinv[1]), [d10] "v"(Dinv[2]), [d11] "v"(Dinv[3]), [d12] "v"(Dinv[4]), [d13] "v"(Dinv[5]), [d14] "v"(Dinv[6]), [d15] "v"(Dinv[7]));
+  return t;
+}
+// LDS byte address of the element lane `lane` holds after pf_block_to_lanes: (c, q), q <= c, in row-major
+// order of the lower triangle for lanes 0..35, the reciprocal pivots dinv[0..7] for lanes 36..43
+__device__ __forceinline__ unsigned pf_block_lane_addr(const double* P, int ldp, int kb, const double* dinv, int lane)
+{
+  const int c = (lane >= 1) + (lane >= 3) + (lane >= 6) + (lane >= 10) + (lane >= 15) + (lane >= 21) + (lane >= 28);
+  const int q = lane - ((c*(c + 1)) >> 1);
+  const double* p = (lane < 36) ? P + (kb + c) + (kb + q)*ldp : dinv + ((lane - 36) & 7);
+  return (unsigned)(size_t)(const __attribute__((address_space(3))) double*)p;
+}
+// row r below a factored 8x8 block: x <- x * inv(D)' in place (same operations, same order, for FULL or not)
+template <bool FULL>
+__device__ __forceinline__ void pf_solve_row_lds(double* P, int ldp, int r, int kb, int nb, const double (&D)[8][8],
+                                                 const double (&Dinv)[8])
+{
+  double x[8];
+#pragma unroll
+  for(int c = 0; c < 8; c++) x[c] = (FULL || c < nb) ? P[r + (kb + c)*ldp] : 0.0;
+#pragma unroll
+  for(int c = 0; c < 8; c++)
+  {
+    double v = x[c];
+#pragma unroll
+    for(int q = 0; q < c; q++) v -= x[q]*D[c][q];
+    x[c] = v*Dinv[c];
+  }
+#pragma unroll
+  for(int c = 0; c < 8; c++) if(FULL || c < nb) P[r + (kb + c)*ldp] = x[c];
+}
 // MFMA panel factorisation with a dedicated diagonal wave (LDS panels, NT >= 256).
 // Per 8 columns, two barriers instead of three and the block factorisation off the other
 // waves' path:
@@ -181,28 +323,41 @@ __device__ __forceinline__ void panel_factor_mfma(double* P, int ldp, int nrows,
       pf_load_block(D, P, ldp, kb, nb);
       DLG_PF_STAMP(3);
       const int badcol = pf_factor_block(D, Dinv);
+      DLG_PF_PIN(D[7][7]); DLG_PF_PIN(D[7][6]); DLG_PF_PIN(Dinv[7]);
       DLG_PF_STAMP(6);
       if(badcol >= 0 && tid == 0) atomicMin(info, col0 + kb + badcol);
-      // thread (c, q) keeps element (c, q) (compile-time indices: D lives in registers)
-      const int c = tid >> 3, q = tid & 7;
-      double v = 0.0, dv = 0.0;
-#pragma unroll
-      for(int cc = 0; cc < 8; cc++)
+      if(nb == 8)
       {
-#pragma unroll
-        for(int qq = 0; qq <= cc; qq++) v = (cc == c && qq == q) ? D[cc][qq] : v;
-        dv = (cc == q) ? Dinv[cc] : dv;
+        const double t = pf_block_to_lanes(D, Dinv);
+        if(lane < 44) *(__attribute__((address_space(3))) double*)(size_t)pf_block_lane_addr(P, ldp, kb, s_dinv, lane) = t;
       }
-      if(q <= c && c < nb) P[(kb + c) + (kb + q)*ldp] = v;
-      if(c == 0) s_dinv[q] = dv;
+      else
+      {
+        // the last, partial block: thread (c, q) keeps element (c, q) (compile-time indices: D lives in registers)
+        const int c = tid >> 3, q = tid & 7;
+        double v = 0.0, dv = 0.0;
+#pragma unroll
+        for(int cc = 0; cc < 8; cc++)
+        {
+#pragma unroll
+          for(int qq = 0; qq <= cc; qq++) v = (cc == c && qq == q) ? D[cc][qq] : v;
+          dv = (cc == q) ? Dinv[cc] : dv;
+        }
+        if(q <= c && c < nb) P[(kb + c) + (kb + q)*ldp] = v;
+        if(c == 0) s_dinv[q] = dv;
+      }
     }
     else if(kb > 0)
     {
       // with 8 waves, wave 4 shares its SIMD with the diagonal wave and the two contend for instruction
       // issue: it stays out of the tile updates, the diagonal wave's chain has SIMD 0 to itself
       // (tools/micro/bench_ahead: 52.8k -> 50.1k cycles for a 187 x 60 panel)
+#ifdef DLG_PF_EXPERIMENT_TILE_WAVES   // tools/micro only: 0 = nobody updates (timing of the diagonal wave alone), 3 = waves 1-3
+      if(DLG_PF_EXPERIMENT_TILE_WAVES == 3) { if(wv < 4) panel_mfma_tiles<true>(P, ldp, nrows, kb, nb16, kbeg, lane, wv, 3, ntile); }
+#else
       if(NW == 8) { if(wv != 4) panel_mfma_tiles<true>(P, ldp, nrows, kb, nb16, kbeg, lane, wv < 4 ? wv : wv - 1, NW - 2, ntile); }
       else panel_mfma_tiles<true>(P, ldp, nrows, kb, nb16, kbeg, lane, wv, NW - 1, ntile);
+#endif
     }
     DLG_PF_STAMP(0);
     __syncthreads();
@@ -215,22 +370,12 @@ __device__ __forceinline__ void panel_factor_mfma(double* P, int ldp, int nrows,
 #pragma unroll
         for(int c = 0; c < 8; c++) Dinv[c] = s_dinv[c];
       }
-      for(int r = kb + nb + tid; r < nrows; r += NT)
-      {
-        double x[8];
-#pragma unroll
-        for(int c = 0; c < 8; c++) x[c] = (c < nb) ? P[r + (kb + c)*ldp] : 0.0;
-#pragma unroll
-        for(int c = 0; c < 8; c++)
-        {
-          double v = x[c];
-#pragma unroll
-          for(int q = 0; q < c; q++) v -= x[q]*D[c][q];
-          x[c] = v*Dinv[c];
-        }
-#pragma unroll
-        for(int c = 0; c < 8; c++) if(c < nb) P[r + (kb + c)*ldp] = x[c];
-      }
+      // a full block of 8 columns (all but the last of a panel) is straight-line code: 8 loads, the
+      // 36-operation chain, 8 stores; the partial one tests every column against nb
+      if(nb == 8)
+        for(int r = kb + 8 + tid; r < nrows; r += NT) pf_solve_row_lds<true>(P, ldp, r, kb, 8, D, Dinv);
+      else
+        for(int r = kb + nb + tid; r < nrows; r += NT) pf_solve_row_lds<false>(P, ldp, r, kb, nb, D, Dinv);
     }
     DLG_PF_STAMP(4);
     __syncthreads();

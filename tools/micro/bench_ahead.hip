@@ -8,6 +8,7 @@ __device__ long long* g_pf_out = nullptr;
 __shared__ long long s_pf[8];
 #define DLG_PF_DECL if(threadIdx.x == 0) { for(int _i = 0; _i < 6; _i++) s_pf[_i] = 0; s_pf[7] = clock64(); }
 #define DLG_PF_STAMP(i) do { if(threadIdx.x == 0) { const long long _n = clock64(); s_pf[i] += _n - s_pf[7]; s_pf[7] = _n; } } while(0)
+#define DLG_PF_PIN(x) asm volatile("" :: "v"(x))
 #define DLG_PF_DONE if(threadIdx.x == 0 && g_pf_out) { for(int _i = 0; _i < 6; _i++) g_pf_out[_i] = s_pf[_i]; }
 #include "../../libdogleg_amd/csrc/panel_factor.h"
 
