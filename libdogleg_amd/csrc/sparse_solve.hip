@@ -462,27 +462,27 @@ __global__ void __launch_bounds__(BWD_NT, BD_ONLY ? 4 : 1) k_solve_bwd_level(con
       const int j0 = 8*blk;
       double* rh = rhs + 8*(blk & 1);
       if(tid >= j0 && tid < j0 + 8) rh[tid - j0] = xi;
+      // the thread's eight operands do not depend on rh: their loads are in flight while rh is published
+      // (a thread above the block: its pre-multiplied column; an owner -- and, harmlessly, a thread whose
+      // unknown is already out -- column `own` of the inverted diagonal block, zeros above the diagonal)
+      const double* Mb = (tid < j0) ? Mx + (size_t)blk*8*MW + tid : T + blk*64 + own;
+      const int mst = (tid < j0) ? MW : 8;
+      double mb[8];
+#pragma unroll
+      for(int b2 = 0; b2 < 8; b2++) mb[b2] = Mb[b2*mst];
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
       double r8[8];
 #pragma unroll
-      for(int b2 = 0; b2 < 8; b2++) r8[b2] = rh[b2];
-      if(tid < j0)
+      for(int b2 = 0; b2 < 8; b2 += 2)
       {
-        const double* Mb = Mx + (size_t)blk*8*MW + tid;
-        double upd = Mb[0]*r8[0];
-#pragma unroll
-        for(int b2 = 1; b2 < 8; b2++) upd += Mb[b2*MW]*r8[b2];
-        xi -= upd;
+        const double2 rr = *reinterpret_cast<const double2*>(rh + b2);
+        r8[b2] = rr.x; r8[b2 + 1] = rr.y;
       }
-      else if(tid < j0 + 8)
-      {
-        // an owner: its unknown of this block, x(j0 + own) = sum_b inv(b, own) rh(b) (zeros above the diagonal)
-        const double* Tb = T + blk*64 + own;
-        double v = Tb[0]*r8[0];
+      double v = mb[0]*r8[0];
 #pragma unroll
-        for(int b2 = 1; b2 < 8; b2++) v += Tb[b2*8]*r8[b2];
-        xs[min(tid, 255)] = v;
-      }
+      for(int b2 = 1; b2 < 8; b2++) v += mb[b2]*r8[b2];
+      if(tid < j0) xi -= v;
+      else if(tid < j0 + 8) xs[min(tid, 255)] = v;   // an owner: x(j0 + own) = sum_b inv(b, own) rh(b)
     }
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     if(tid < w) xi = xs[tid];
