@@ -216,8 +216,19 @@ __global__ void __launch_bounds__(TPB) k_part_take_step(const double* __restrict
     if(threadIdx.x == 0)
     {
       s_l2 = v0; s_negc = v1;
+      // in index order, as the host sums them -- sixteen LDS reads in flight per trip: one read per add
+      // (a dependent LDS round trip each) made this prologue most of the kernel
       double g2 = 0;
-      for(int i = 0; i < nbg; i++) g2 += s_gn[i];
+      int i = 0;
+      for(; i + 16 <= nbg; i += 16)
+      {
+        double t[16];
+#pragma unroll
+        for(int u = 0; u < 16; u++) t[u] = s_gn[i + u];
+#pragma unroll
+        for(int u = 0; u < 16; u++) g2 += t[u];
+      }
+      for(; i < nbg; i++) g2 += s_gn[i];
       s_n2g = g2;
     }
     __syncthreads();

@@ -499,10 +499,21 @@ __device__ __forceinline__ void fin2_store(const AsmFin2& F, int e, double v, do
   const int b = e / F.nI, a = e - b*F.nI;
   if(!F.diag || a >= b) Lx[F.dest + a + (int64_t)b*F.ld] = v;
 }
+// (the blocks past the fins' own, if any: the augmented row of the point just evaluated, k_set_aug_row's
+// work riding in this launch -- it touches the last row of the panels only, the fins never do)
+struct AugRowArgs { const int64_t* augpos; const int* perm; const double* rhs; int n; int* info; };
 __global__ void __launch_bounds__(TPB) k_assemble_fin2_short(const AsmFin2* __restrict__ fins, int nfins,
                                                              const int64_t* __restrict__ list,
-                                                             double* part, double* __restrict__ Lx)
+                                                             double* part, double* __restrict__ Lx, AugRowArgs aug)
 {
+  const int nfb = (nfins + TPB/64 - 1)/(TPB/64);
+  if((int)blockIdx.x >= nfb)
+  {
+    const int k = (blockIdx.x - nfb)*TPB + threadIdx.x;
+    if(k == 0) *aug.info = 0x7fffffff;                  // re-arm the pivot flag of the factorisation that follows
+    if(k < aug.n) Lx[aug.augpos[k]] += aug.rhs[aug.perm[k]];
+    return;
+  }
   const int lane = threadIdx.x & 63;
   const int f = __builtin_amdgcn_readfirstlane(blockIdx.x*(TPB/64) + (threadIdx.x >> 6));
   if(f >= nfins) return;
@@ -709,9 +720,9 @@ __global__ void __launch_bounds__(TPB) k_norm2_Jv(const int* __restrict__ chunk_
                                                   const double* __restrict__ vals,
                                                   const double* __restrict__ v,
                                                   double* __restrict__ part, const int* __restrict__ info,
-                                                  const double* __restrict__ kind)
+                                                  const double* __restrict__ kind, int nnz)
 {
-  __shared__ double prod[NV_CHUNK];
+  __shared__ __attribute__((aligned(16))) double prod[NV_CHUNK + 4];
   __shared__ double sh[4];
   // K8 behind a speculative factorisation (dlg_take_step): a step built on a failed factorisation is
   // never used -- unless it is the Cauchy step to the edge of the trust region, which needs no factor
@@ -722,18 +733,43 @@ __global__ void __launch_bounds__(TPB) k_norm2_Jv(const int* __restrict__ chunk_
   double acc = 0.0;
   if(n <= NV_CHUNK)
   {
-    for(int base = 0; base < n; base += 8*TPB)
+    // the run from the 4-element boundary below its start, four non-zeros per thread and load: one 16-byte
+    // load of indices, two of values (the up to three elements in front belong to the row before: their
+    // products are formed and never summed; past the end of the arrays the last thread goes one by one)
+    const int pad = q0 & 3, qa = q0 - pad, nn = n + pad;
+    for(int base = 0; base < nn; base += 8*TPB)
     {
-      double pv[8]; int pi[8];
+      int4 ix[2]; double2 va[2], vb[2];
 #pragma unroll
-      for(int u = 0; u < 8; u++) { const int e = base + u*TPB + tid; pi[u] = (e < n) ? Ji[q0 + e] : 0; pv[u] = (e < n) ? vals[q0 + e] : 0.0; }
+      for(int u = 0; u < 2; u++)
+      {
+        const int e = base + 4*(tid + u*TPB);
+        const bool whole = e < nn && qa + e + 4 <= nnz;
+        ix[u] = whole ? *reinterpret_cast<const int4*>(Ji + qa + e) : make_int4(0, 0, 0, 0);
+        va[u] = whole ? *reinterpret_cast<const double2*>(vals + qa + e) : make_double2(0.0, 0.0);
+        vb[u] = whole ? *reinterpret_cast<const double2*>(vals + qa + e + 2) : make_double2(0.0, 0.0);
+      }
 #pragma unroll
-      for(int u = 0; u < 8; u++) { const int e = base + u*TPB + tid; if(e < n) prod[e] = pv[u]*v[pi[u]]; }
+      for(int u = 0; u < 2; u++)
+      {
+        const int e = base + 4*(tid + u*TPB);
+        if(e < nn)
+        {
+          if(qa + e + 4 <= nnz)
+          {
+            const double p0 = va[u].x*v[ix[u].x], p1 = va[u].y*v[ix[u].y], p2 = vb[u].x*v[ix[u].z], p3 = vb[u].y*v[ix[u].w];
+            *reinterpret_cast<double2*>(prod + e) = make_double2(p0, p1);
+            *reinterpret_cast<double2*>(prod + e + 2) = make_double2(p2, p3);
+          }
+          else
+            for(int k = 0; k < 4; k++) if(qa + e + k < nnz) prod[e + k] = vals[qa + e + k]*v[Ji[qa + e + k]];
+        }
+      }
     }
     __syncthreads();
     for(int r = r0 + tid; r < r1; r += TPB)
     {
-      const int a = Jp[r] - q0, bq = Jp[r+1] - q0;
+      const int a = Jp[r] - qa, bq = Jp[r+1] - qa;
       double d = 0.0;
       for(int q = a; q < bq; q++) d += prod[q];
       acc += d*d;
@@ -794,20 +830,20 @@ int sparse_norm2_Jv(dlg_backend* b, int s, const double* v, double* out_dev, con
     if(double* hp = dlg_host_partials(b, out_dev, g, 1, 0, 1))
     {
       hipLaunchKernelGGL(k_norm2_Jv, dim3(g), dim3(TPB), 0, b->stream, Y->nv_chunk, Y->Jp, Y->Ji, S.Jin(), v, hp,
-                         (const int*)Y->d_info, kind_if_factor_failed);
+                         (const int*)Y->d_info, kind_if_factor_failed, (int)Y->nnz_loc);
       DLG_LAUNCH_CHECK();
       return DLG_OK;
     }
   DLG_CHECK(dlg_ensure_partials(b, 5120 + (size_t)g));
   double* part = b->d_part + 5120;          // behind the regions of the vector reductions (kernels_vec.hip)
   hipLaunchKernelGGL(k_norm2_Jv, dim3(g), dim3(TPB), 0, b->stream, Y->nv_chunk, Y->Jp, Y->Ji, S.Jin(), v, part,
-                     kind_if_factor_failed ? (const int*)Y->d_info : (const int*)nullptr, kind_if_factor_failed);
+                     kind_if_factor_failed ? (const int*)Y->d_info : (const int*)nullptr, kind_if_factor_failed, (int)Y->nnz_loc);
   DLG_LAUNCH_CHECK();
   return k_reduce_sum(b, part, g, out_dev);
 }
 
 // the assembly launches: JtJ of the local rows (values Jv) into the zeroed panel buffer
-static int assemble_fin_launch(dlg_backend* b, double* Lx);
+static int assemble_fin_launch(dlg_backend* b, double* Lx, const double* aug_rhs = nullptr, bool* aug_done = nullptr);
 // the partial-sum stages of an assembly whose caller wanted Jt*x first (assemble_launch, defer_fin)
 int sparse_assemble_finish(dlg_backend* b)
 {
@@ -815,15 +851,17 @@ int sparse_assemble_finish(dlg_backend* b)
   if(!Y || !Y->fin_pending_Lx) return DLG_OK;
   double* Lx = Y->fin_pending_Lx;
   Y->fin_pending_Lx = nullptr;
-  DLG_CHECK(assemble_fin_launch(b, Lx));
+  // the right-hand side of the Gauss-Newton system (Jt*x of the point just evaluated) goes into the
+  // augmented row now, and the pivot flag is re-armed: nothing left to launch between the caller's
+  // decision to factorise and the first factor kernel.  It rides in the first partial-sum launch.
+  bool aug_done = false;
+  DLG_CHECK(assemble_fin_launch(b, Lx, Y->fin_pending_rhs, &aug_done));
   if(Y->fin_pending_rhs)
   {
-    // the right-hand side of the Gauss-Newton system (Jt*x of the point just evaluated) goes into the
-    // augmented row now, and the pivot flag is re-armed: one launch less between the caller's decision
-    // to factorise and the first factor kernel
     const SymHost& H = Y->H;
-    hipLaunchKernelGGL(k_set_aug_row, dim3(dlg_cdiv(H.N, TPB)), dim3(TPB), 0, b->stream, Lx, Y->col_sn, Y->augpos,
-                       Y->perm, Y->fin_pending_rhs, H.N, Y->d_info, Y->sn_owner, -1);
+    if(!aug_done)
+      hipLaunchKernelGGL(k_set_aug_row, dim3(dlg_cdiv(H.N, TPB)), dim3(TPB), 0, b->stream, Lx, Y->col_sn, Y->augpos,
+                         Y->perm, Y->fin_pending_rhs, H.N, Y->d_info, Y->sn_owner, -1);
     DLG_LAUNCH_CHECK();
     Y->spec_aug_rhs = Y->fin_pending_rhs; Y->info_clean = true;
     Y->fin_pending_rhs = nullptr;
@@ -884,17 +922,28 @@ static int assemble_launch(dlg_backend* b, const double* Jv, double* Lx = nullpt
   if(defer_fin) { Y->fin_pending_Lx = Lx; Y->fin_pending_rhs = Jt_x; DLG_LAUNCH_CHECK(); return DLG_OK; }
   return assemble_fin_launch(b, Lx);
 }
-static int assemble_fin_launch(dlg_backend* b, double* Lx)
+static int assemble_fin_launch(dlg_backend* b, double* Lx, const double* aug_rhs, bool* aug_done)
 {
   SparseSym* Y = b->sym;
   const SymHost& H = Y->H;
   hipStream_t st = b->stream;
+  if(aug_done) *aug_done = false;
   for(size_t q = 0; q + 2 < H.fin2_stage.size(); q += 3)
   {
     const int f0 = H.fin2_stage[q], ns = H.fin2_stage[q+1], nl = H.fin2_stage[q+2];
     if(ns > 0)
-      hipLaunchKernelGGL(k_assemble_fin2_short, dim3(dlg_cdiv(ns, TPB/64)), dim3(TPB), 0, st, Y->asm_fin2 + f0, ns,
-                         Y->asm_fin2_list, Y->asm_part, Lx);
+    {
+      // the first launch of short lists also sets the augmented row, if the caller has one to set
+      AugRowArgs aug = {nullptr, nullptr, nullptr, 0, nullptr};
+      int gaug = 0;
+      if(aug_rhs && aug_done && !*aug_done)
+      {
+        aug = AugRowArgs{Y->augpos, Y->perm, aug_rhs, H.N, Y->d_info};
+        gaug = dlg_cdiv(H.N, TPB); *aug_done = true;
+      }
+      hipLaunchKernelGGL(k_assemble_fin2_short, dim3(dlg_cdiv(ns, TPB/64) + gaug), dim3(TPB), 0, st, Y->asm_fin2 + f0, ns,
+                         Y->asm_fin2_list, Y->asm_part, Lx, aug);
+    }
     if(nl > 0)
       hipLaunchKernelGGL(k_assemble_fin2_long, dim3(nl), dim3(1024), 0, st, Y->asm_fin2 + f0 + ns,
                          Y->asm_fin2_list, Y->asm_part, Lx);
