@@ -94,11 +94,24 @@ __global__ void __launch_bounds__(TPB) k_norm2_Jv_part(const double* __restrict_
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int wave = blockIdx.x*4 + w, nwaves = gridDim.x*4;
   double acc = 0;
+  // (rows of an even length from a 16-byte aligned base start on 16-byte boundaries)
+  const bool pairs = (N & 1) == 0 && (((size_t)J | (size_t)v) & 15) == 0;
   for(int r = wave; r < M; r += nwaves)
   {
     const double* Jr = J + (size_t)r*N;
     double d = 0;
-    for(int c = lane; c < N; c += 64) d += Jr[c]*v[c];
+    if(pairs)
+    {
+      // 16-byte loads: a lane takes columns 2*lane, 2*lane + 1, then 128 further on (four loads in flight)
+#pragma unroll 4
+      for(int c = 2*lane; c < N; c += 128)
+      {
+        const double2 jv = *reinterpret_cast<const double2*>(Jr + c), vv = *reinterpret_cast<const double2*>(v + c);
+        d += jv.x*vv.x; d += jv.y*vv.y;
+      }
+    }
+    else
+      for(int c = lane; c < N; c += 64) d += Jr[c]*v[c];
     d = wave_sum(d);
     acc += d*d;          // only lane 0 holds the full sum; others add garbage we ignore
   }
