@@ -320,28 +320,50 @@ k_syrk_lower(double* __restrict__ C, int ldc, const double* __restrict__ A, int 
 }
 
 // C[i,j] = beta*C[i,j] + alpha * sum_s slab[s][tile][jl][il] (+ lambda on the diagonal)
+// (SYRK_RSUB workgroups per tile, a thread sums a PAIR of rows over the splits in split order -- 16-byte
+// loads, several splits in flight: as one workgroup per tile with 8-byte loads and one dependent load per
+// add this pass read its 214 MB (config #2: 12 splits) at 0.7 TB/s)
+constexpr int SYRK_RSUB = 8;
 template <int BT>
 __global__ void __launch_bounds__(TPB) k_syrk_reduce(double* __restrict__ C, int ldc, int n,
                                                      const double* __restrict__ slabs, int nsplit,
                                                      int ntiles, double alpha, double beta,
                                                      double lambda)
 {
-  const int tile = blockIdx.x;
+  static_assert((BT*BT) % (2*SYRK_RSUB*TPB) == 0, "a tile is a whole number of rounds");
+  const int tile = blockIdx.x / SYRK_RSUB, sub = blockIdx.x % SYRK_RSUB;
   int ti = (int)((sqrt(8.0*(double)tile + 1.0) - 1.0)*0.5);
   while((long)ti*(ti+1)/2 > tile) ti--;
   while((long)(ti+1)*(ti+2)/2 <= tile) ti++;
   const int tj = tile - (int)((long)ti*(ti+1)/2);
-  for(int e = threadIdx.x; e < BT*BT; e += TPB)
+  const size_t tsz = (size_t)BT*BT, sstride = (size_t)ntiles*tsz;
+  const double* base = slabs + (size_t)tile*tsz;
+  for(int e = 2*(sub*TPB + threadIdx.x); e < BT*BT; e += 2*SYRK_RSUB*TPB)
   {
-    const int il = e % BT, jl = e / BT;
+    const int il = e % BT, jl = e / BT;        // il is even: rows i, i + 1 of column j
     const int i = ti*BT + il, j = tj*BT + jl;
-    if(i >= n || j >= n || i < j) continue;
-    double s = 0;
-    for(int sp = 0; sp < nsplit; sp++) s += slabs[((size_t)sp*ntiles + tile)*(size_t)(BT*BT) + e];
-    double r = alpha*s;
-    if(beta != 0.0) r += beta*C[(size_t)j*ldc + i];
-    if(i == j) r += lambda;
-    C[(size_t)j*ldc + i] = r;
+    if(i >= n || j >= n || i + 1 < j) continue;
+    double s0 = 0, s1 = 0;
+#pragma unroll 4
+    for(int sp = 0; sp < nsplit; sp++)
+    {
+      const double2 t = *reinterpret_cast<const double2*>(base + (size_t)sp*sstride + e);
+      s0 += t.x; s1 += t.y;
+    }
+    if(i >= j)
+    {
+      double r = alpha*s0;
+      if(beta != 0.0) r += beta*C[(size_t)j*ldc + i];
+      if(i == j) r += lambda;
+      C[(size_t)j*ldc + i] = r;
+    }
+    if(i + 1 < n)
+    {
+      double r = alpha*s1;
+      if(beta != 0.0) r += beta*C[(size_t)j*ldc + i + 1];
+      if(i + 1 == j) r += lambda;
+      C[(size_t)j*ldc + i + 1] = r;
+    }
   }
 }
 
@@ -651,7 +673,7 @@ int launch_syrk(hipStream_t st, double* C, int ldc, const double* A, int lda, in
                        lda, n, K, alpha, ks, kper, ws);
     if(pe) dlg_prof_end(prof, DLG_PROF_K4_KERNEL, pe);
   }
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_syrk_reduce<BT>), dim3(ntiles), dim3(TPB), 0, st, C, ldc, n, ws,
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_syrk_reduce<BT>), dim3(ntiles*SYRK_RSUB), dim3(TPB), 0, st, C, ldc, n, ws,
                      ks, ntiles, alpha, 0.0, lambda);
   DLG_LAUNCH_CHECK();
   return DLG_OK;
