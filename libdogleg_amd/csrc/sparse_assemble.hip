@@ -457,16 +457,23 @@ __global__ void __launch_bounds__(TPB) k_jtx_fin2_short(const int* __restrict__ 
 __global__ void __launch_bounds__(1024) k_jtx_fin2_long(const int* __restrict__ blks,
                                                         const int* __restrict__ jf_ptr, const int* __restrict__ jf_ent,
                                                         const int* __restrict__ var0, const int* __restrict__ wv,
-                                                        const double* __restrict__ jtp, double* __restrict__ Jt_x)
+                                                        const double* __restrict__ jtp, double* __restrict__ Jt_x,
+                                                        double* __restrict__ segpart, int* __restrict__ segcnt)
 {
   __shared__ double sh[128*16];
+  __shared__ int s_last;
   // (blks: flat records {list begin, list end, first variable, width} -- sparse_set_pattern)
-  const int4 rec = reinterpret_cast<const int4*>(blks)[blockIdx.x];
+  // JFL_SEG workgroups per list, each sums a contiguous segment (one workgroup read the 60 000 records of
+  // config #4's dense block at 0.6 TB/s: 11 us on the path of every evaluation); the last one to arrive
+  // adds the segment sums in segment order -- the order of the sums does not depend on who that is.
+  const int blk = blockIdx.x / JFL_SEG, seg = blockIdx.x % JFL_SEG;
+  const int4 rec = reinterpret_cast<const int4*>(blks)[blk];
   const int w = rec.w;
   // groups of 8 lanes for blocks of up to 8 variables (128 sub-sums), of 16 otherwise (64)
   const int gw = (w <= 8) ? 8 : 16, ng = 1024/gw;
   const int a = threadIdx.x & (gw - 1), g = threadIdx.x/gw;
-  const int e0 = rec.x, e1 = rec.y;
+  const int len = rec.y - rec.x;
+  const int e0 = rec.x + (int)((long)len*seg/JFL_SEG), e1 = rec.x + (int)((long)len*(seg + 1)/JFL_SEG);
   double sum = 0.0;
   if(a < w)
     for(int e = e0 + g; e < e1; e += ng*16)
@@ -482,12 +489,28 @@ __global__ void __launch_bounds__(1024) k_jtx_fin2_long(const int* __restrict__ 
     }
   sh[g*16 + a] = sum;
   __syncthreads();
+  typedef __attribute__((address_space(1))) double* gdp_t;
+  double* mine = segpart + ((size_t)blk*JFL_SEG + seg)*16;
   if(g == 0 && a < w)
   {
     double tot = 0.0;
     for(int k = 0; k < ng; k++) tot += sh[k*16 + a];
-    Jt_x[rec.z + a] = tot;
+    // the hand-off of MI355X_MICROARCH.md: write-through payload, drained, then the counter
+    __hip_atomic_store((gdp_t)(mine + a), tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if(threadIdx.x == 0) s_last = (atomicAdd(segcnt + blk, 1) == JFL_SEG - 1);
+  __syncthreads();
+  if(!s_last) return;
+  if(threadIdx.x < w)
+  {
+    double tot = 0.0;
+    for(int k = 0; k < JFL_SEG; k++)
+      tot += __hip_atomic_load((gdp_t)(segpart + ((size_t)blk*JFL_SEG + k)*16 + threadIdx.x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    Jt_x[rec.z + threadIdx.x] = tot;
+  }
+  if(threadIdx.x == 0) __hip_atomic_store(segcnt + blk, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // for the next launch (stream order)
 }
 // persistent blocks written by several MFMA tasks: fixed-order sum of the listed partials.
 // k_assemble_fin2_short: one wave per block (lists of <= 32 partials);
@@ -916,8 +939,8 @@ static int assemble_launch(dlg_backend* b, const double* Jv, double* Lx = nullpt
       hipLaunchKernelGGL(k_jtx_fin2_short, dim3(dlg_cdiv(ns, TPB/16)), dim3(TPB), 0, st, Y->jf_short, ns, Y->jf_ptr,
                          Y->jf_ent, Y->jf_var0, Y->jf_w, Y->jtp, Jt_x);
     if(nl > 0)
-      hipLaunchKernelGGL(k_jtx_fin2_long, dim3(nl), dim3(1024), 0, st, Y->jf_long, Y->jf_ptr, Y->jf_ent,
-                         Y->jf_var0, Y->jf_w, Y->jtp, Jt_x);
+      hipLaunchKernelGGL(k_jtx_fin2_long, dim3(nl*JFL_SEG), dim3(1024), 0, st, Y->jf_long, Y->jf_ptr, Y->jf_ent,
+                         Y->jf_var0, Y->jf_w, Y->jtp, Jt_x, Y->jf_lpart, Y->jf_lcnt);
   }
   if(defer_fin) { Y->fin_pending_Lx = Lx; Y->fin_pending_rhs = Jt_x; DLG_LAUNCH_CHECK(); return DLG_OK; }
   return assemble_fin_launch(b, Lx);

@@ -134,6 +134,10 @@ int sparse_set_pattern(dlg_backend* b, const int* colptr, const int* rowidx)
       for(size_t k = 0; k < H.jf_long.size(); k++)
       { const int v = H.jf_long[k]; rec[4*k] = H.jf_ptr[v]; rec[4*k+1] = H.jf_ptr[v+1]; rec[4*k+2] = H.jf_var0[v]; rec[4*k+3] = H.jf_w[v]; }
       DLG_CHECK(upload(Y->jf_long, rec)); Y->allocs.push_back(Y->jf_long);
+      const size_t nl = std::max<size_t>(1, H.jf_long.size());
+      DLG_HIP(hipMalloc(&Y->jf_lpart, sizeof(double)*16*JFL_SEG*nl)); Y->allocs.push_back(Y->jf_lpart);
+      DLG_HIP(hipMalloc(&Y->jf_lcnt, sizeof(int)*nl)); Y->allocs.push_back(Y->jf_lcnt);
+      DLG_HIP(hipMemset(Y->jf_lcnt, 0, sizeof(int)*nl));
     }
     DLG_HIP(hipMalloc(&Y->jtp, sizeof(double)*16*std::max<size_t>(1, H.asm_mtask.size()))); Y->allocs.push_back(Y->jtp);
   }

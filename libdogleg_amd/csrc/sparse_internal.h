@@ -19,6 +19,7 @@
 #include "sparse_symbolic.h"
 
 namespace {
+constexpr int JFL_SEG = 16;             // workgroups per long Jt*x list (k_jtx_fin2_long)
 constexpr int NV_CHUNK = 2048;          // non-zeros per workgroup of the |Jv|^2 kernel
 
 constexpr int TPB = 256;
@@ -85,6 +86,7 @@ struct SparseSym
   AsmBatch* asm_batch = nullptr; AsmTask* asm_ctask = nullptr; AsmFin* asm_cfin = nullptr;
   AsmShape* asm_shape = nullptr; AsmKG* asm_kg = nullptr; AsmMTask* asm_mtask = nullptr; int* asm_tdest = nullptr;
   int *jf_ptr = nullptr, *jf_ent = nullptr, *jf_var0 = nullptr, *jf_w = nullptr, *jf_short = nullptr, *jf_long = nullptr;
+  double* jf_lpart = nullptr; int* jf_lcnt = nullptr;      // k_jtx_fin2_long: [long block][JFL_SEG][16] segment sums, arrival counters
   const double* fin_pending_rhs = nullptr; const double* spec_aug_rhs = nullptr; bool info_clean = false;   // augmented row set at evaluation time
   double* fin_pending_Lx = nullptr;      // assembly whose partial-sum stages are still to be launched
   bool spare_dirty = false, spare_zeroed = false; hipStream_t spare_stream = nullptr;   // sparse_zero_spare
