@@ -1,3 +1,5 @@
+"""tools only: host time per backend call of one steady-state step of config #4 (bind / eval / take_step):
+what the host adds to the kernels' span (rocprofv3 inflates it: measure without the profiler)."""
 import os, sys, time
 sys.path.insert(0, os.getcwd())
 import numpy as np
