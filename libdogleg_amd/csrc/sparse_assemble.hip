@@ -207,6 +207,10 @@ __global__ void __launch_bounds__(TPB) k_assemble(const AsmTask* __restrict__ ta
 //   transient:   n = slot*nJ + b,  B is masked to the rows of row-block `slot`, so each
 //                row-block of the k-group gets its own columns; D is stored and cleared
 typedef double dlg_v4d __attribute__((ext_vector_type(4)));
+// (-DDLG_ASM_NO_PREFETCH: the values of an iteration's rows fetched inside it -- tools/variant_lib.sh A/B)
+#ifndef DLG_ASM_NO_PREFETCH
+#define DLG_ASM_PREFETCH 1
+#endif
 #ifndef DLG_ASM_U
 #define DLG_ASM_U 4
 #endif
@@ -299,6 +303,21 @@ __device__ __forceinline__ void asm_mfma_run(const AsmRun& R, const AsmMTask* __
   double jacc = 0.0;
   auto kg_fetch = [&](int kg0) { return reinterpret_cast<const int*>(kgs + min(kg0 + krec, kglast))[kw]; };
   int gnv = kg_fetch(R.kg0);
+#ifdef DLG_ASM_PREFETCH
+  // the values of the first 16 columns of an iteration's rows are fetched one iteration ahead (their
+  // records two ahead): the copy into the tile finds them in registers
+  int gnn = kg_fetch(R.kg0 + ASM_U);
+  double vpre[ASM_U]; int bpre[ASM_U];
+  auto vals_fetch = [&](int rec, int kgi) {
+#pragma unroll
+    for(int u = 0; u < ASM_U; u++)
+    {
+      bpre[u] = __builtin_amdgcn_ds_bpermute(4*(KD*u + kq), rec);
+      if(kgi + u > kglast) bpre[u] = -1;
+      vpre[u] = vals[max(bpre[u], 0) + col0 + min(m, ncopy - 1)];
+    } };
+  vals_fetch(gnv, R.kg0);
+#endif
   double* myrow = tile + kq*LEN;
 #pragma unroll
   for(int u = 0; u < ASM_U; u++) myrow[u*4*LEN + ZC] = 0.0;
@@ -316,7 +335,19 @@ __device__ __forceinline__ void asm_mfma_run(const AsmRun& R, const AsmMTask* __
       for(int u = 0; u < ASM_U; u++) xv[u] = xvec[__builtin_amdgcn_ds_bpermute(4*(KD*u + 6 + kq), gv)];    // (rows past the end: row 0, times zeros)
     }
     // (a) one coalesced copy of the rows' windows into the tile (absent rows: zeros)
+#ifdef DLG_ASM_PREFETCH
+    {
+      double v[ASM_U]; int b[ASM_U];
+#pragma unroll
+      for(int u = 0; u < ASM_U; u++) { v[u] = vpre[u]; b[u] = bpre[u]; }
+      vals_fetch(gnn, kg + ASM_U);                    // the next iteration's, on their way during this one
+#pragma unroll
+      for(int u = 0; u < ASM_U; u++) myrow[u*4*LEN + m] = b[u] >= 0 ? v[u] : 0.0;
+    }
+    for(int c0 = 16; c0 < ncopy; c0 += 16)
+#else
     for(int c0 = 0; c0 < ncopy; c0 += 16)
+#endif
     {
       double v[ASM_U];
       int b[ASM_U];
@@ -340,7 +371,11 @@ __device__ __forceinline__ void asm_mfma_run(const AsmRun& R, const AsmMTask* __
         td[u] = tdest[lane < nent ? __builtin_amdgcn_readlane(gv, KD*u + 4) + lane : 0];
       }
     }
+#ifdef DLG_ASM_PREFETCH
+    gnv = gnn; gnn = kg_fetch(kg + 2*ASM_U);
+#else
     gnv = kg_fetch(kg + ASM_U);
+#endif
     __builtin_amdgcn_wave_barrier();
     // (b) operands from the tile, products
 #pragma unroll
