@@ -215,3 +215,19 @@ def test_dense_block_with_many_row_layouts(gpu, seed, monkeypatch):
     Jx[Jp[-1] - ntail:] *= 4.0
     x = rng.standard_normal(M)
     _check_pattern(N, M, Jp, Ji, Jx, x, tol=1e-6)
+
+
+@pytest.mark.parametrize("seed", [21, 22, 23, 24])
+def test_ragged_rows_with_every_alignment_of_the_value_runs(gpu, seed):
+    """K3/K8 read four non-zeros per 16-byte load from the 4-element boundary below a run's first value:
+    rows of 1..9 entries put the runs of the workgroups at every offset, the total count at every
+    remainder (the last thread goes element by element past the end of the arrays)"""
+    rng = np.random.default_rng(seed)
+    N = 120
+    M = 3000 + seed          # several runs of <= 2048 values
+    rows = [rng.choice(N, size=rng.integers(1, 10), replace=False) for _ in range(M)]
+    rows[-1] = rows[-1][:1 + seed % 3]
+    Jp, Ji = _rows_to_csc(rows, N)
+    Jx = rng.standard_normal(Jp[-1])
+    x = rng.standard_normal(M)
+    _check_pattern(N, M, Jp, Ji, Jx, x)
