@@ -471,13 +471,16 @@ extern "C" int dlg_point_eval(dlg_backend_t* b, int s, double* norm2_x, double* 
       DLG_HIP(hipMemcpyAsync(S.Jt_x, b->d_red, sizeof(double)*(size_t)b->N, hipMemcpyDeviceToDevice, b->stream));
       DLG_HIP(hipMemcpyAsync(b->d_scal, b->d_red + b->N, sizeof(double), hipMemcpyDeviceToDevice, b->stream));
     }
-    if(pair) DLG_CHECK(k_norm2_absmax_pair(b, S.Jt_x, b->N, b->d_scal + 2, S.xin(), mloc, b->d_scal));
+    bool norms_on_host = false;
+    if(pair) DLG_CHECK(k_norm2_absmax_pair(b, S.Jt_x, b->N, b->d_scal + 2, S.xin(), mloc, b->d_scal, &norms_on_host));
     else     DLG_CHECK(k_norm2_absmax(b, S.Jt_x, b->N, b->d_scal + 2));
     if(fused)
     {
       // the scalars go to the host first; the partial-sum stages of JtJ run while the host gets them
       if(!b->ev_fetch) DLG_HIP(hipEventCreateWithFlags(&b->ev_fetch, hipEventDisableTiming));
-      DLG_HIP(hipMemcpyAsync(b->h_scal, b->d_scal, sizeof(double)*4, hipMemcpyDeviceToHost, b->stream));
+      // (the workgroups of the norm kernel wrote their partial sums to page-locked host memory and the host
+      // adds them: nothing to copy then -- the event alone is the point the host waits for)
+      if(!norms_on_host) DLG_HIP(hipMemcpyAsync(b->h_scal, b->d_scal, sizeof(double)*4, hipMemcpyDeviceToHost, b->stream));
       DLG_HIP(hipEventRecord(b->ev_fetch, b->stream));
       DLG_CHECK(sparse_assemble_finish(b));
       DLG_HIP(hipEventSynchronize(b->ev_fetch));

@@ -164,7 +164,8 @@ int dlg_fetch_scalars(dlg_backend* b, int n);
 // out[0] = sum x[i]^2 ; out[1] = max |x[i]|   (deterministic two-stage)
 int k_norm2_absmax(dlg_backend* b, const double* x, int n, double* out2);
 // ... of two vectors behind one launch
-int k_norm2_absmax_pair(dlg_backend* b, const double* x1, int n1, double* out1, const double* x2, int n2, double* out2);
+int k_norm2_absmax_pair(dlg_backend* b, const double* x1, int n1, double* out1, const double* x2, int n2, double* out2,
+                        bool* on_host = nullptr);
 // out[0] = <x,y>
 int k_inner(dlg_backend* b, const double* x, const double* y, int n, double* out);
 // Cauchy finish: g2 = |g|^2 (host), Jg2 = *Jg2_dev; k = -g2/Jg2;

@@ -368,8 +368,10 @@ int k_norm2_absmax(dlg_backend* b, const double* x, int n, double* out2)
 }
 // (|x1|^2, max|x1|) -> out1[0..1] and (|x2|^2, max|x2|) -> out2[0..1] behind one launch where the second
 // stages run on the host (dlg_host_partials); else two calls of k_norm2_absmax
-int k_norm2_absmax_pair(dlg_backend* b, const double* x1, int n1, double* out1, const double* x2, int n2, double* out2)
+int k_norm2_absmax_pair(dlg_backend* b, const double* x1, int n1, double* out1, const double* x2, int n2, double* out2,
+                        bool* on_host)
 {
+  if(on_host) *on_host = false;
   const int g1 = grid_for(n1), g2 = grid_for(n2);
   if(b->host_finals && b->h_part && b->h_part_used + 2*(size_t)(g1 + g2) <= dlg_backend::HPART_CAP)
   {
@@ -379,6 +381,7 @@ int k_norm2_absmax_pair(dlg_backend* b, const double* x1, int n1, double* out1, 
     {
       hipLaunchKernelGGL(k_part_norm2_absmax2, dim3(g1 + g2), dim3(TPB), 0, b->stream, x1, n1, hp1, g1, x2, n2, hp2);
       DLG_LAUNCH_CHECK();
+      if(on_host) *on_host = true;             // all four scalars are summed on the host (dlg_resolve_pending)
       return DLG_OK;
     }
     if(hp1) { hipLaunchKernelGGL(k_part_norm2_absmax, dim3(g1), dim3(TPB), 0, b->stream, x1, n1, hp1); DLG_LAUNCH_CHECK(); return k_norm2_absmax(b, x2, n2, out2); }
