@@ -730,7 +730,9 @@ static void make_step_read(dlg_backend* b, int from, int kind, double* n2, doubl
 static int step_finish(dlg_backend* b, int to, int nscal, double* p_new_host)
 {
   DlgSlot& T = b->slot[to];
-  DLG_HIP(hipMemcpyAsync(b->h_scal, b->d_scal, sizeof(double)*(size_t)nscal, hipMemcpyDeviceToHost, b->stream));
+  // (unless the step's last kernel has written them to the page-locked h_scal itself: sparse_norm2_Jv)
+  if(!b->scal_copied) DLG_HIP(hipMemcpyAsync(b->h_scal, b->d_scal, sizeof(double)*(size_t)nscal, hipMemcpyDeviceToHost, b->stream));
+  b->scal_copied = false;
   bool pinned = true;
   if(p_new_host)
   {
@@ -897,7 +899,10 @@ extern "C" int dlg_take_step(dlg_backend_t* b, int from, int to, double trustreg
         side_copy = true;
       }
     }
-    DLG_CHECK(norm2_Jv(b, from, T.step, b->d_scal + 12, b->d_scal + 8));    // the other half of the expected improvement
+    b->fold_scal = dlg_backend::NSCAL;       // (the last kernel of the step: it takes the scalars to the host with it)
+    const int rc8 = norm2_Jv(b, from, T.step, b->d_scal + 12, b->d_scal + 8);    // the other half of the expected improvement
+    b->fold_scal = 0;
+    DLG_CHECK(rc8);
     DLG_CHECK(step_finish(b, to, dlg_backend::NSCAL, side_copy ? nullptr : p_new_host));   // the one synchronisation
     if(side_copy) DLG_HIP(hipEventSynchronize(b->ev_copy));
     if(b->profiling) dlg_prof_resolve(b);

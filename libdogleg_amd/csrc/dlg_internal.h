@@ -72,6 +72,7 @@ struct dlg_backend
   // scalar return path: kernels write d_scal, one D2H into pinned h_scal
   double* d_scal = nullptr;
   double* h_scal = nullptr;
+  int fold_scal = 0; bool scal_copied = false;   // dlg_take_step: its last kernel (K8-sparse) copies d_scal to h_scal itself
   static constexpr int NSCAL = 16;
 
   // reduction partials
