@@ -885,12 +885,20 @@ extern "C" int dlg_take_step(dlg_backend_t* b, int from, int to, double trustreg
                             b->d_scal, b->d_scal + 8, F.Jt_x, b->d_scal + 11));
     }
     side_copy = false;
+    b->fold_p_src = nullptr; b->p_copied = false;
     if(p_new_host && b->copy_stream)
     {
       hipPointerAttribute_t attr;
       const bool pinned = hipPointerGetAttributes(&attr, p_new_host) == hipSuccess && attr.type == hipMemoryTypeHost;
       if(!pinned) (void)hipGetLastError();
-      if(pinned)
+      static const bool side_only = getenv("DOGLEG_AMD_P_SIDE_COPY") != nullptr;
+      if(pinned && b->type == DLG_SPARSE && b->host_finals && !b->sharded() && attr.devicePointer && !side_only)
+      {
+        // page-locked destination: the step's last kernel (K8) writes p_new there itself, a slice per
+        // workgroup -- no event between the step kernel and K8 for a copy on the side stream to wait on
+        b->fold_p_src = T.p; b->fold_p_dst = (double*)attr.devicePointer;
+      }
+      else if(pinned)
       {
         DLG_HIP(hipEventRecord(b->ev_step, b->stream));
         DLG_HIP(hipStreamWaitEvent(b->copy_stream, b->ev_step, 0));
@@ -902,8 +910,10 @@ extern "C" int dlg_take_step(dlg_backend_t* b, int from, int to, double trustreg
     b->fold_scal = dlg_backend::NSCAL;       // (the last kernel of the step: it takes the scalars to the host with it)
     const int rc8 = norm2_Jv(b, from, T.step, b->d_scal + 12, b->d_scal + 8);    // the other half of the expected improvement
     b->fold_scal = 0;
+    const bool p_done = b->p_copied;
+    b->fold_p_src = nullptr; b->p_copied = false;
     DLG_CHECK(rc8);
-    DLG_CHECK(step_finish(b, to, dlg_backend::NSCAL, side_copy ? nullptr : p_new_host));   // the one synchronisation
+    DLG_CHECK(step_finish(b, to, dlg_backend::NSCAL, (side_copy || p_done) ? nullptr : p_new_host));   // the one synchronisation
     if(side_copy) DLG_HIP(hipEventSynchronize(b->ev_copy));
     if(b->profiling) dlg_prof_resolve(b);
     if(!F.have_cauchy) { F.norm2_cauchy = b->h_scal[6]; F.have_cauchy = true; }

@@ -72,6 +72,7 @@ struct dlg_backend
   // scalar return path: kernels write d_scal, one D2H into pinned h_scal
   double* d_scal = nullptr;
   double* h_scal = nullptr;
+  const double* fold_p_src = nullptr; double* fold_p_dst = nullptr; bool p_copied = false;   // ... and p_new to a page-locked destination
   int fold_scal = 0; bool scal_copied = false;   // dlg_take_step: its last kernel (K8-sparse) copies d_scal to h_scal itself
   static constexpr int NSCAL = 16;
 

@@ -779,13 +779,20 @@ __global__ void __launch_bounds__(TPB) k_norm2_Jv(const int* __restrict__ chunk_
                                                   const double* __restrict__ v,
                                                   double* __restrict__ part, const int* __restrict__ info,
                                                   const double* __restrict__ kind, int nnz,
-                                                  const double* __restrict__ dsc, double* __restrict__ hsc, int nsc)
+                                                  const double* __restrict__ dsc, double* __restrict__ hsc, int nsc,
+                                                  const double* __restrict__ psrc, double* __restrict__ pdst, int pn)
 {
   __shared__ __attribute__((aligned(16))) double prod[NV_CHUNK + 4];
   __shared__ double sh[4];
   // the last kernel of dlg_take_step: the device scalars of the step (written by the kernels before this
   // one) go to the page-locked host array with it -- no copy kernel behind it
   if(dsc && blockIdx.x == 0 && (int)threadIdx.x < nsc) hsc[threadIdx.x] = dsc[threadIdx.x];
+  // ... and p_new, a slice per workgroup, to its page-locked destination (dlg_take_step)
+  if(psrc)
+  {
+    const int per = (pn + (int)gridDim.x - 1)/(int)gridDim.x, i0 = (int)blockIdx.x*per, i1 = min(i0 + per, pn);
+    for(int i = i0 + (int)threadIdx.x; i < i1; i += TPB) pdst[i] = psrc[i];
+  }
   // K8 behind a speculative factorisation (dlg_take_step): a step built on a failed factorisation is
   // never used -- unless it is the Cauchy step to the edge of the trust region, which needs no factor
   if(info && *info != 0x7fffffff && (int)*kind != DLG_KIND_CAUCHY_TO_EDGE) { if(threadIdx.x == 0) part[blockIdx.x] = 0.0; return; }
@@ -894,16 +901,17 @@ int sparse_norm2_Jv(dlg_backend* b, int s, const double* v, double* out_dev, con
       const bool fold = b->fold_scal > 0 && b->fold_scal <= TPB && b->h_scal;
       hipLaunchKernelGGL(k_norm2_Jv, dim3(g), dim3(TPB), 0, b->stream, Y->nv_chunk, Y->Jp, Y->Ji, S.Jin(), v, hp,
                          (const int*)Y->d_info, kind_if_factor_failed, (int)Y->nnz_loc,
-                         fold ? (const double*)b->d_scal : (const double*)nullptr, b->h_scal, b->fold_scal);
+                         fold ? (const double*)b->d_scal : (const double*)nullptr, b->h_scal, b->fold_scal,
+                         fold ? b->fold_p_src : (const double*)nullptr, b->fold_p_dst, b->N);
       DLG_LAUNCH_CHECK();
-      if(fold) b->scal_copied = true;
+      if(fold) { b->scal_copied = true; b->p_copied = b->fold_p_src != nullptr; }
       return DLG_OK;
     }
   DLG_CHECK(dlg_ensure_partials(b, 5120 + (size_t)g));
   double* part = b->d_part + 5120;          // behind the regions of the vector reductions (kernels_vec.hip)
   hipLaunchKernelGGL(k_norm2_Jv, dim3(g), dim3(TPB), 0, b->stream, Y->nv_chunk, Y->Jp, Y->Ji, S.Jin(), v, part,
                      kind_if_factor_failed ? (const int*)Y->d_info : (const int*)nullptr, kind_if_factor_failed, (int)Y->nnz_loc,
-                     (const double*)nullptr, (double*)nullptr, 0);
+                     (const double*)nullptr, (double*)nullptr, 0, (const double*)nullptr, (double*)nullptr, 0);
   DLG_LAUNCH_CHECK();
   return k_reduce_sum(b, part, g, out_dev);
 }
