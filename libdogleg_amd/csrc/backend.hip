@@ -526,15 +526,30 @@ static int cauchy_fork_begin(dlg_backend* b)
 {
   const bool no_k3_fork = getenv("DOGLEG_AMD_NO_K3_FORK") != nullptr;
   b->want_fork = b->overlap && b->aux_stream && !b->sharded() && !no_k3_fork;    // (one communicator: its collectives stay on one stream)
-  b->fork_recorded = false;
+  b->fork_recorded = false; b->fork_gate = nullptr;
   return DLG_OK;
+}
+// holds the second stream until the one-launch region of the factorisation is on the chip (dlg_fork_gate)
+__global__ void k_gate_wait(const int* gate, int epoch)
+{
+  if(threadIdx.x != 0) return;
+  int spins = 0;
+  while(__hip_atomic_load(gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch)
+  {
+    __builtin_amdgcn_s_sleep(8);
+    if(++spins > (1 << 21)) break;            // (a launch that never comes: go on, it is only timing)
+  }
 }
 static int cauchy_fork_enqueue(dlg_backend* b, int s, double* sc)
 {
   if(!b->want_fork) return cauchy_enqueue(b, s, sc);
+  int* gate = b->fork_recorded ? b->fork_gate : nullptr;
+  const int gate_epoch = b->fork_gate_epoch;
+  b->fork_gate = nullptr;
   if(!b->fork_recorded) DLG_HIP(hipEventRecord(b->ev_fork, b->stream));
   b->want_fork = false; b->fork_recorded = false;
-  DLG_HIP(hipStreamWaitEvent(b->aux_stream, b->ev_fork, 0));
+  if(gate) hipLaunchKernelGGL(k_gate_wait, dim3(1), dim3(64), 0, b->aux_stream, (const int*)gate, gate_epoch);
+  else     DLG_HIP(hipStreamWaitEvent(b->aux_stream, b->ev_fork, 0));
   hipStream_t main_stream = b->stream;
   b->stream = b->aux_stream;
   const int rc = cauchy_enqueue(b, s, sc);

@@ -73,6 +73,7 @@ struct dlg_backend
   double* d_scal = nullptr;
   double* h_scal = nullptr;
   const double* fold_p_src = nullptr; double* fold_p_dst = nullptr; bool p_copied = false;   // ... and p_new to a page-locked destination
+  int* fork_gate = nullptr; int fork_gate_epoch = 0;      // dlg_fork_gate
   int fold_scal = 0; bool scal_copied = false;   // dlg_take_step: its last kernel (K8-sparse) copies d_scal to h_scal itself
   static constexpr int NSCAL = 16;
 
@@ -157,6 +158,13 @@ int dlg_allreduce_dev(dlg_backend* b, double* buf, size_t count);
 static inline void dlg_fork_point(dlg_backend* b)
 {
   if(b->want_fork && !b->fork_recorded && hipEventRecord(b->ev_fork, b->stream) == hipSuccess) b->fork_recorded = true;
+}
+
+// ... or, where that phase is ONE launch: the word that launch sets to `epoch` once all its workgroups are
+// dispatched (no event on the main stream; the second stream holds a waiting kernel in front of its work)
+static inline void dlg_fork_gate(dlg_backend* b, int* gate, int epoch)
+{
+  if(b->want_fork && !b->fork_recorded) { b->fork_gate = gate; b->fork_gate_epoch = epoch; b->fork_recorded = true; }
 }
 
 // fetch the first n scalars of d_scal to the host (synchronises the stream)

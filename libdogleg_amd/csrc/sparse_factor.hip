@@ -317,6 +317,11 @@ __global__ void __launch_bounds__(NT, LEAF ? 4 : 1) k_factor_level(const FwItem*
   // (s_skip: a launch before this one found a non-positive pivot -- the factorisation is going to be
   // thrown away by the lambda loop, dogleg.c:656-677: nothing to do here but to let the parent go on)
   if(tid == 0) { sbad = 0x7fffffff; s_skip = __hip_atomic_load(info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0x7fffffff; }
+  // one-launch region: its last workgroup (dispatched last: all of them are on their CUs) opens the gate
+  // behind which the second stream holds the Cauchy step's pass over J (the word behind the items' flags;
+  // a matter of timing only -- that pass depends on nothing this launch computes)
+  if(pr_flag && tid == 0 && blockIdx.x == gridDim.x - 1)
+    __hip_atomic_store(pr_flag + pr_item0 + gridDim.x, pr_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if(cmp)
   {
     __syncthreads();
@@ -1179,9 +1184,9 @@ int sparse_factor_setup(dlg_backend* b)
   }
   if(Y->pr_level0 < H.nlevels && !Y->fac_flag)
   {
-    DLG_HIP(hipMalloc(&Y->fac_flag, sizeof(int)*std::max<size_t>(1, H.fw_item.size())));
+    DLG_HIP(hipMalloc(&Y->fac_flag, sizeof(int)*(H.fw_item.size() + 1)));
     Y->allocs.push_back(Y->fac_flag);
-    DLG_HIP(hipMemsetAsync(Y->fac_flag, 0, sizeof(int)*std::max<size_t>(1, H.fw_item.size()), b->stream));
+    DLG_HIP(hipMemsetAsync(Y->fac_flag, 0, sizeof(int)*(H.fw_item.size() + 1), b->stream));
     Y->fac_epoch = 0;
   }
   DLG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_factor_level<128>),
@@ -1261,9 +1266,9 @@ int sparse_factor_setup(dlg_backend* b)
   }
   if(Y->pr_level0 < H.nlevels && !Y->fac_flag)
   {
-    DLG_HIP(hipMalloc(&Y->fac_flag, sizeof(int)*std::max<size_t>(1, H.fw_item.size())));
+    DLG_HIP(hipMalloc(&Y->fac_flag, sizeof(int)*(H.fw_item.size() + 1)));
     Y->allocs.push_back(Y->fac_flag);
-    DLG_HIP(hipMemsetAsync(Y->fac_flag, 0, sizeof(int)*std::max<size_t>(1, H.fw_item.size()), b->stream));
+    DLG_HIP(hipMemsetAsync(Y->fac_flag, 0, sizeof(int)*(H.fw_item.size() + 1), b->stream));
     Y->fac_epoch = 0;
   }
   DLG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_factor_level<128>),
@@ -1338,13 +1343,16 @@ int sparse_factor_levels(dlg_backend* b)
     const int n = H.fw_lvl_ptr[l+1] - H.fw_lvl_ptr[l];
     // from the first level that cannot fill the chip on, the factorisation is latency-bound:
     // independent work (the Cauchy step's pass over J) may run beside it
-    if(l > 0 && n < 256) dlg_fork_point(b);
+    static const bool no_gate = getenv("DOGLEG_AMD_NO_FORK_GATE") != nullptr;
+    const bool gate_here = l == Y->pr_level0 && Y->fac_flag && !no_gate;      // (no event on this stream: the launch opens a gate)
+    if(l > 0 && n < 256 && !gate_here) dlg_fork_point(b);
     if(l == Y->pr_level0)
     {
       // the persistent top region: every remaining level in one launch (sparse_factor_setup)
       const int o = H.fw_lvl_ptr[l], np = H.fw_lvl_ptr[H.nlevels] - o;
       const int fmode = 2 + 4*Y->pr_stage + (Y->fac_ahead ? 8 : 0) + 256*l;
       int* fl = Y->fac_flag; const int ep = ++Y->fac_epoch;
+      if(gate_here && l > 0 && n < 256) dlg_fork_gate(b, fl + H.fw_lvl_ptr[H.nlevels], ep);
       const int64_t pacc = Y->pr_acc ? (int64_t)(Y->pr_acc - Y->uscr) : 0;
       if(Y->fac_nt[l] == 128)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_factor_level<128>), dim3(np), dim3(128), Y->pr_lds, st,
