@@ -180,8 +180,17 @@ __global__ void __launch_bounds__(BWD_NT, BD_ONLY ? 4 : 1) k_solve_bwd_level(con
   const bool mv_on = mv_thread && mv_j < w && mv_p < mv_parts;
   const double* mv_L = L + (size_t)min(mv_j, w - 1)*nrows + w;
   double mv[MV_SLOTS];
+  // (a thread's stretch of its column in 16-byte loads: 8-byte aligned pairs; K6 0.098 -> 0.090 ms on config #4)
+  {
+    typedef double bw_v2d __attribute__((ext_vector_type(2)));
+    typedef bw_v2d bw_v2d_u __attribute__((aligned(8)));
 #pragma unroll
-  for(int q = 0; q < MV_SLOTS; q++) mv[q] = (mv_on && mv_i0 + q < mv_i1) ? mv_L[mv_i0 + q] : 0.0;
+    for(int q = 0; q < MV_SLOTS; q += 2)
+    {
+      if(mv_on && mv_i0 + q + 1 < mv_i1) { const bw_v2d t = *reinterpret_cast<const bw_v2d_u*>(mv_L + mv_i0 + q); mv[q] = t.x; mv[q + 1] = t.y; }
+      else { mv[q] = (mv_on && mv_i0 + q < mv_i1) ? mv_L[mv_i0 + q] : 0.0; mv[q + 1] = 0.0; }
+    }
+  }
   if(!BD_ONLY)
   for(int e = tid; e < (nmem > 0 ? 0 : nblk*64); e += BWD_NT)
   {
