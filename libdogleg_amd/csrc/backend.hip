@@ -906,7 +906,7 @@ extern "C" int dlg_take_step(dlg_backend_t* b, int from, int to, double trustreg
       hipPointerAttribute_t attr;
       const bool pinned = hipPointerGetAttributes(&attr, p_new_host) == hipSuccess && attr.type == hipMemoryTypeHost;
       if(!pinned) (void)hipGetLastError();
-      static const bool side_only = getenv("DOGLEG_AMD_P_SIDE_COPY") != nullptr;
+      const bool side_only = getenv("DOGLEG_AMD_P_SIDE_COPY") != nullptr;      // (read per call: the tests switch it)
       if(pinned && b->type == DLG_SPARSE && b->host_finals && !b->sharded() && attr.devicePointer && !side_only)
       {
         // page-locked destination: the step's last kernel (K8) writes p_new there itself, a slice per

@@ -1343,7 +1343,7 @@ int sparse_factor_levels(dlg_backend* b)
     const int n = H.fw_lvl_ptr[l+1] - H.fw_lvl_ptr[l];
     // from the first level that cannot fill the chip on, the factorisation is latency-bound:
     // independent work (the Cauchy step's pass over J) may run beside it
-    static const bool no_gate = getenv("DOGLEG_AMD_NO_FORK_GATE") != nullptr;
+    const bool no_gate = l == Y->pr_level0 && getenv("DOGLEG_AMD_NO_FORK_GATE") != nullptr;      // (read per factorisation: the tests switch it)
     const bool gate_here = l == Y->pr_level0 && Y->fac_flag && !no_gate;      // (no event on this stream: the launch opens a gate)
     if(l > 0 && n < 256 && !gate_here) dlg_fork_point(b);
     if(l == Y->pr_level0)

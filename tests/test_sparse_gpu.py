@@ -255,6 +255,37 @@ def test_fused_backend_ops_match_the_separate_calls(gpu, kind):
     assert np.array_equal(a[7], b[7]) and np.array_equal(a[8], b[8])
 
 
+@pytest.mark.parametrize("env", ["DOGLEG_AMD_NO_FORK_GATE", "DOGLEG_AMD_P_SIDE_COPY"])
+def test_take_step_with_the_event_based_fork_and_side_copy(gpu, env, monkeypatch):
+    """the paths the one-launch schedule replaced -- an event where the Cauchy step forks off, p_new copied on
+    the side stream -- still give dlg_take_step's numbers bit for bit"""
+    prob = oa.BAProblem(49, 900, 10000, seed=9)
+    p = prob.p0()
+    x, J = prob.eval(p)
+    Jp, Ji = prob.pattern()
+
+    def run():
+        be = capi.Backend(capi.DLG_SPARSE, prob.N, prob.M, prob.nnz)
+        be.set_pattern(Jp, Ji)
+        be.set_speculation(True)
+        be.set_p(0, p)
+        be.upload(0, x, J)
+        be.eval(0)
+        lam, n2c, n2g = be.cauchy_gauss_newton(0, 0.0)
+        tr = 0.5 * (np.sqrt(n2c) + np.sqrt(n2g))
+        be.set_p(0, p)
+        be.upload(0, x, J)
+        be.eval(0)
+        lam, r, pnew = be.take_step(0, 1, tr, 0.0)
+        out = (lam, tuple(sorted(r.items())), pnew.copy())
+        be.close()
+        return out
+    ref = run()
+    monkeypatch.setenv(env, "1")
+    alt = run()
+    assert ref[0] == alt[0] and ref[1] == alt[1] and np.array_equal(ref[2], alt[2])
+
+
 @pytest.mark.parametrize("kind", ["sparse", "dense"])
 @pytest.mark.parametrize("which", ["cauchy", "gn", "interp"])
 def test_take_step_matches_the_separate_calls(gpu, kind, which):
