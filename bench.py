@@ -81,7 +81,7 @@ def main():
 
     import numpy as np
     from libdogleg_amd import capi
-    from tests import oracle_api as oa       # problem generators (+ the oracle for cpu_baseline)
+    import problems as oa                    # the synthetic problem generators (problems/); the oracle is loaded by the cpu_baseline leg only
 
     L = capi.lib()
     if L.dlg_device_count() <= 0:
@@ -343,7 +343,8 @@ def main():
 
     # ---- CPU baseline: the oracle's restatement of the same step, host cores, bounded sample
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        O = oa.oracle()
+        from tests import oracle_api         # (the CPU oracle: this leg and nothing else in bench.py)
+        O = oracle_api.oracle()
         from libdogleg_amd.ctypes_defs import dptr, iptr
         work = np.zeros(5 * N)
         o8 = np.zeros(8)

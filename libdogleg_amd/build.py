@@ -12,6 +12,11 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libdogleg_amd.so")
+# The reference builds libdogleg.so.2 (Makefile:7, ABI_VERSION := 2).  The library carries that SONAME and
+# the two names a linker / loader looks for sit next to it, so `-ldogleg` and binaries that were linked
+# against the reference's library resolve to this one once the directory is on the library path.
+SONAME = "libdogleg.so.2"
+LINKS = ["libdogleg.so.2", "libdogleg.so"]
 ARCH = "gfx950"
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall",
@@ -60,11 +65,23 @@ def build(verbose=False, force=False):
     with ThreadPoolExecutor(max_workers=4) as ex:
         objs = list(ex.map(lambda s: _compile(s, newest_hdr, verbose), srcs))
     if (not os.path.exists(LIB)) or any(os.path.getmtime(o) > os.path.getmtime(LIB) for o in objs):
-        cmd = [HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB] + objs
+        cmd = [HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", f"-Wl,-soname,{SONAME}", "-o", LIB] + objs
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
+    ensure_links()
     return LIB
+
+
+def ensure_links():
+    """libdogleg.so.2 and libdogleg.so -> libdogleg_amd.so (relative symlinks, re-made if missing)"""
+    for name in LINKS:
+        path = os.path.join(HERE, name)
+        if os.path.islink(path) and os.readlink(path) == os.path.basename(LIB):
+            continue
+        if os.path.lexists(path):
+            os.remove(path)
+        os.symlink(os.path.basename(LIB), path)
 
 
 if __name__ == "__main__":

@@ -23,12 +23,31 @@ extern "C" int dlg_device_count(void)
 
 int dlg_fetch_scalars(dlg_backend* b, int n)
 {
-  DLG_HIP(hipMemcpyAsync(b->h_scal, b->d_scal, sizeof(double)*(size_t)n, hipMemcpyDeviceToHost,
+  // (always the whole block, 128 bytes: the hand-off status word of the one-launch regions rides in it)
+  (void)n;
+  DLG_HIP(hipMemcpyAsync(b->h_scal, b->d_scal, sizeof(double)*(size_t)dlg_backend::NSCAL, hipMemcpyDeviceToHost,
                          b->stream));
   DLG_HIP(hipStreamSynchronize(b->stream));
   dlg_resolve_pending(b);
   if(b->profiling) dlg_prof_resolve(b);
-  return DLG_OK;
+  return dlg_check_handoff(b);
+}
+// A wait inside a one-launch region (sparse factorisation / backward solve, dense potrf / trsv) gave up:
+// whatever that launch computed is not to be used.  The status word is cleared for the next attempt.
+int dlg_check_handoff(dlg_backend* b)
+{
+  const int st = *reinterpret_cast<const int*>(b->h_scal + (dlg_backend::NSCAL - 2));
+  if(st == 0) return DLG_OK;
+  *reinterpret_cast<int*>(b->h_scal + (dlg_backend::NSCAL - 2)) = 0;
+  (void)hipMemsetAsync(b->d_scal + (dlg_backend::NSCAL - 2), 0, sizeof(double), b->stream);
+  b->factor_slot = -1;
+  for(int s = 0; s < 2; s++) b->slot[s].have_gn = false;
+  dlg_set_error("a hand-off between workgroups timed out (status 0x%x:%s%s%s%s%s): the GPU is shared with work that keeps "
+                "the waiting workgroups' partners off the chip, or a launch failed", st,
+                (st & DLG_HANDOFF_FACTOR) ? " sparse factorisation" : "", (st & DLG_HANDOFF_SOLVE) ? " sparse backward solve" : "",
+                (st & DLG_HANDOFF_POTRF) ? " dense potrf" : "", (st & DLG_HANDOFF_TRSV) ? " dense trsv" : "",
+                (st & DLG_HANDOFF_TRSM) ? " dense potrf step" : "");
+  return DLG_ERR_STATE;
 }
 
 // ---------------------------------------------------------------- profiling --
@@ -139,6 +158,23 @@ extern "C" int dlg_backend_create(dlg_backend_t** out, int solve_type, int Nstat
   TRY_HIP(hipHostMalloc(&b->h_scal, sizeof(double)*dlg_backend::NSCAL));
   TRY_HIP(hipHostMalloc(&b->h_part, sizeof(double)*dlg_backend::HPART_CAP));
   b->host_finals = getenv("DOGLEG_AMD_DEVICE_FINALS") == nullptr;
+  {
+    dlg_backend::Knobs& k = b->knobs;
+    k.no_k3_fork = getenv("DOGLEG_AMD_NO_K3_FORK") != nullptr;
+    k.p_side_copy = getenv("DOGLEG_AMD_P_SIDE_COPY") != nullptr;
+    k.lookahead = getenv("DOGLEG_AMD_LOOKAHEAD") != nullptr;
+    k.no_potrf_fuse = getenv("DOGLEG_AMD_NO_POTRF_FUSE") != nullptr;
+    k.potrf_steps = getenv("DOGLEG_AMD_POTRF_STEPS") != nullptr;
+    k.trsv_steps = getenv("DOGLEG_AMD_TRSV_STEPS") != nullptr;
+    k.no_fork_gate = getenv("DOGLEG_AMD_NO_FORK_GATE") != nullptr;
+    k.no_touch = getenv("DOGLEG_AMD_NO_TOUCH") != nullptr;
+    if(const char* v = getenv("DOGLEG_AMD_TOUCH_WG")) k.touch_wg = atoi(v);
+    // test hook of the hand-off time-outs: the waits of the one-launch regions look for an epoch that never
+    // comes and give up after a few hundred polls
+    if(getenv("DOGLEG_AMD_DEBUG_HANDOFF_TIMEOUT")) { b->handoff_skew = 1; b->handoff_spins = 256; }
+    (void)hipDeviceGetAttribute(&b->ncu, hipDeviceAttributeMultiprocessorCount, device);
+    if(b->ncu <= 0) b->ncu = 256;
+  }
   TRY_HIP(hipHostMalloc(&b->h_vec, sizeof(double)*(size_t)Nstate));
   TRY_HIP(hipMalloc(&b->d_work, sizeof(double)*(size_t)Nstate));
   const size_t N = (size_t)Nstate, M = (size_t)Nmeas;
@@ -524,8 +560,7 @@ static int cauchy_enqueue(dlg_backend* b, int s, double* sc)
 // that event and the main stream waits for them before anything reads the Cauchy step.
 static int cauchy_fork_begin(dlg_backend* b)
 {
-  const bool no_k3_fork = getenv("DOGLEG_AMD_NO_K3_FORK") != nullptr;
-  b->want_fork = b->overlap && b->aux_stream && !b->sharded() && !no_k3_fork;    // (one communicator: its collectives stay on one stream)
+  b->want_fork = b->overlap && b->aux_stream && !b->sharded() && !b->knobs.no_k3_fork;    // (one communicator: its collectives stay on one stream)
   b->fork_recorded = false; b->fork_gate = nullptr;
   return DLG_OK;
 }
@@ -768,7 +803,7 @@ static int step_finish(dlg_backend* b, int to, int nscal, double* p_new_host)
   DLG_HIP(hipEventSynchronize(b->ev_fetch));
   dlg_resolve_pending(b);
   if(p_new_host && !pinned) memcpy(p_new_host, b->h_vec, sizeof(double)*(size_t)b->N);
-  return DLG_OK;
+  return nscal >= dlg_backend::NSCAL ? dlg_check_handoff(b) : DLG_OK;
 }
 extern "C" int dlg_make_step(dlg_backend_t* b, int from, int to, int kind, double trustregion,
                              double* norm2_step, double* k_cauchy_to_gn, double* step_absmax,
@@ -906,7 +941,7 @@ extern "C" int dlg_take_step(dlg_backend_t* b, int from, int to, double trustreg
       hipPointerAttribute_t attr;
       const bool pinned = hipPointerGetAttributes(&attr, p_new_host) == hipSuccess && attr.type == hipMemoryTypeHost;
       if(!pinned) (void)hipGetLastError();
-      const bool side_only = getenv("DOGLEG_AMD_P_SIDE_COPY") != nullptr;      // (read per call: the tests switch it)
+      const bool side_only = b->knobs.p_side_copy;
       if(pinned && b->type == DLG_SPARSE && b->host_finals && !b->sharded() && attr.devicePointer && !side_only)
       {
         // page-locked destination: the step's last kernel (K8) writes p_new there itself, a slice per
@@ -991,6 +1026,7 @@ extern "C" int dlg_solve_with_factor(dlg_backend_t* b, int s, const double* rhs_
     { dlg_set_error("dlg_solve_with_factor: download failed"); rc = DLG_ERR_HIP; }
   }
   (void)hipFree(d_out);
+  if(rc == DLG_OK) rc = dlg_fetch_scalars(b, dlg_backend::NSCAL);      // the hand-off status of the solves' one-launch regions
   return rc;
 }
 

@@ -47,7 +47,7 @@ __global__ void __launch_bounds__(TPB) k_potrf_diag_inv(double* __restrict__ A, 
 // asks for more than half of the LDS): the form the hand-off is measured in (MI355X_MICROARCH.md).
 __global__ void __launch_bounds__(TPB) k_potrf_diag_trsm(double* __restrict__ A, int lda, int kb, int nb, int n,
                                                          int* __restrict__ info, double* Linv,
-                                                         int* flag, int epoch)
+                                                         int* flag, int epoch, DlgHandoff ho)
 {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   __shared__ int sbad;
@@ -97,8 +97,8 @@ __global__ void __launch_bounds__(TPB) k_potrf_diag_trsm(double* __restrict__ A,
   if(t == 0)
   {
     int spins = 0;
-    while(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch)
-    { __builtin_amdgcn_s_sleep(1); if(++spins > (1 << 21)) break; }
+    while(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch + ho.skew)
+    { __builtin_amdgcn_s_sleep(1); if(++spins > ho.spins) { atomicOr(ho.status, DLG_HANDOFF_TRSM); break; } }      // report, never hang
   }
   __syncthreads();
   for(int e = t; e < NB*NB; e += TPB)
@@ -142,7 +142,7 @@ __global__ void __launch_bounds__(TPB) k_potrf_diag_trsm(double* __restrict__ A,
 // consumers poll and read around L1; one workgroup per CU.
 typedef double dd_v4d __attribute__((ext_vector_type(4)));
 __global__ void __launch_bounds__(TPB) k_potrf_tiles(double* A, int lda, int n, int T, int* __restrict__ info,
-                                                     double* Linv, int* flags, int epoch)
+                                                     double* Linv, int* flags, int epoch, DlgHandoff ho)
 {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   __shared__ int sbad;
@@ -173,8 +173,8 @@ __global__ void __launch_bounds__(TPB) k_potrf_tiles(double* A, int lda, int n, 
     }
   auto wait_flag = [&](int fi, int fj) {
     int spins = 0;
-    while(__hip_atomic_load(flags + fi*T + fj, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch)
-    { __builtin_amdgcn_s_sleep(1); if(++spins > (1 << 22)) { atomicMax(info, n + 1); break; } }
+    while(__hip_atomic_load(flags + fi*T + fj, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch + ho.skew)
+    { __builtin_amdgcn_s_sleep(1); if(++spins > ho.spins) { atomicOr(ho.status, DLG_HANDOFF_POTRF); break; } }     // its own status word: not a pivot
   };
   // a published 64 x 64 block of L (rows r0.., columns c0..) into LDS, read around L1; past the end: zeros
   auto stage = [&](double (*D)[LDT], int r0, int c0) {
@@ -288,7 +288,7 @@ __global__ void __launch_bounds__(TPB) k_potrf_tiles(double* A, int lda, int n, 
 // (they wait for higher-numbered ones on the way back): T <= the number of CUs, one per CU.
 __global__ void __launch_bounds__(TPB) k_trsv_tiles(const double* __restrict__ A, int lda, int n, int T,
                                                     const double* __restrict__ Linv, const double* __restrict__ rhs,
-                                                    double* Y, double* X, int* flags, int epoch)
+                                                    double* Y, double* X, int* flags, int epoch, DlgHandoff ho)
 {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   typedef __attribute__((address_space(1))) double* gd_t;
@@ -303,8 +303,8 @@ __global__ void __launch_bounds__(TPB) k_trsv_tiles(const double* __restrict__ A
   int* fy = flags; int* fx = flags + T;
   auto wait_flag = [&](int* f) {
     int spins = 0;
-    while(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch)
-    { __builtin_amdgcn_s_sleep(1); if(++spins > (1 << 22)) break; }
+    while(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch + ho.skew)
+    { __builtin_amdgcn_s_sleep(1); if(++spins > ho.spins) { atomicOr(ho.status, DLG_HANDOFF_TRSV); break; } }
   };
   for(int e = t; e < NB*NB; e += TPB) Li[e] = Linv[(size_t)i*NB*NB + e];
   // ---- forward: thread (row r, column group g) keeps 16 values of the tile in registers
@@ -390,33 +390,46 @@ __global__ void __launch_bounds__(TPB) k_trsv_tiles(const double* __restrict__ A
 
 } // namespace
 
-void dense_launch_trsv_tiles(hipStream_t st, const double* A, int lda, int n, const double* Linv, const double* rhs,
-                             double* Y, double* X, int* flags, int epoch)
+// the dynamic-LDS limit of a kernel, set once per device (a failure is left for the launch to report)
+constexpr int DLG_MAX_DEV = 64;
+static void dlg_func_lds_once(bool (&done)[DLG_MAX_DEV], const void* fn, int bytes)
 {
-  static bool attr = false;
-  constexpr int LDSB = 88*1024;           // > half of the CU's LDS: one workgroup per CU
-  if(!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trsv_tiles), hipFuncAttributeMaxDynamicSharedMemorySize, LDSB); attr = true; }
-  const int T = (n + NB - 1)/NB;
-  hipLaunchKernelGGL(k_trsv_tiles, dim3(T), dim3(TPB), LDSB, st, A, lda, n, T, Linv, rhs, Y, X, flags, epoch);
+  int dev = 0;
+  if(hipGetDevice(&dev) != hipSuccess) return;
+  dev &= DLG_MAX_DEV - 1;
+  if(done[dev]) return;
+  if(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess)
+  { dlg_set_error("hipFuncSetAttribute(%d bytes of dynamic LDS) failed on device %d", bytes, dev); return; }
+  done[dev] = true;
 }
 
-void dense_launch_potrf_tiles(hipStream_t st, double* A, int lda, int n, int* info_dev, double* Linv, int* flags, int epoch)
+void dense_launch_trsv_tiles(hipStream_t st, const double* A, int lda, int n, const double* Linv, const double* rhs,
+                             double* Y, double* X, int* flags, int epoch, const DlgHandoff& ho)
 {
-  static bool attr = false;
+  static bool attr[DLG_MAX_DEV] = {};       // a function attribute is a property of (function, device)
   constexpr int LDSB = 88*1024;           // > half of the CU's LDS: one workgroup per CU
-  if(!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_potrf_tiles), hipFuncAttributeMaxDynamicSharedMemorySize, LDSB); attr = true; }
+  dlg_func_lds_once(attr, reinterpret_cast<const void*>(&k_trsv_tiles), LDSB);
   const int T = (n + NB - 1)/NB;
-  hipLaunchKernelGGL(k_potrf_tiles, dim3(T*(T + 1)/2), dim3(TPB), LDSB, st, A, lda, n, T, info_dev, Linv, flags, epoch);
+  hipLaunchKernelGGL(k_trsv_tiles, dim3(T), dim3(TPB), LDSB, st, A, lda, n, T, Linv, rhs, Y, X, flags, epoch, ho);
+}
+
+void dense_launch_potrf_tiles(hipStream_t st, double* A, int lda, int n, int* info_dev, double* Linv, int* flags, int epoch, const DlgHandoff& ho)
+{
+  static bool attr[DLG_MAX_DEV] = {};       // a function attribute is a property of (function, device)
+  constexpr int LDSB = 88*1024;           // > half of the CU's LDS: one workgroup per CU
+  dlg_func_lds_once(attr, reinterpret_cast<const void*>(&k_potrf_tiles), LDSB);
+  const int T = (n + NB - 1)/NB;
+  hipLaunchKernelGGL(k_potrf_tiles, dim3(T*(T + 1)/2), dim3(TPB), LDSB, st, A, lda, n, T, info_dev, Linv, flags, epoch, ho);
 }
 
 void dense_launch_potrf_diag_trsm(hipStream_t st, double* A, int lda, int kb, int nb, int n, int* info_dev, double* Linv,
-                                  int* flag, int epoch)
+                                  int* flag, int epoch, const DlgHandoff& ho)
 {
-  static bool attr = false;
+  static bool attr[DLG_MAX_DEV] = {};       // a function attribute is a property of (function, device)
   constexpr int LDSB = 88*1024;           // > half of the CU's LDS: one workgroup per CU
-  if(!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_potrf_diag_trsm), hipFuncAttributeMaxDynamicSharedMemorySize, LDSB); attr = true; }
+  dlg_func_lds_once(attr, reinterpret_cast<const void*>(&k_potrf_diag_trsm), LDSB);
   const int ntr = (n - kb - nb + NB - 1)/NB;
-  hipLaunchKernelGGL(k_potrf_diag_trsm, dim3(1 + ntr), dim3(TPB), LDSB, st, A, lda, kb, nb, n, info_dev, Linv, flag, epoch);
+  hipLaunchKernelGGL(k_potrf_diag_trsm, dim3(1 + ntr), dim3(TPB), LDSB, st, A, lda, kb, nb, n, info_dev, Linv, flag, epoch, ho);
 }
 
 void dense_launch_potrf_diag(hipStream_t st, double* A, int lda, int kb, int nb, int* info_dev, double* Linv)

@@ -76,6 +76,19 @@ struct dlg_backend
   int* fork_gate = nullptr; int fork_gate_epoch = 0;      // dlg_fork_gate
   int fold_scal = 0; bool scal_copied = false;   // dlg_take_step: its last kernel (K8-sparse) copies d_scal to h_scal itself
   static constexpr int NSCAL = 16;
+  // hand-offs inside the one-launch regions (flags between workgroups): a wait that gives up raises a bit in
+  // the status word (slot NSCAL - 2 of the scalar block, so it travels with every fetch of the scalars);
+  // the host turns it into DLG_ERR_STATE (dlg_check_handoff).  handoff_skew != 0 (DOGLEG_AMD_DEBUG_HANDOFF_TIMEOUT,
+  // read at create time): the waits look for an epoch that never comes -- the test hook of that path.
+  int handoff_spins = 0, handoff_skew = 0;
+  // environment knobs that steer per-step paths, read ONCE when the backend is created (dlg_backend_create)
+  struct Knobs
+  {
+    bool no_k3_fork = false, p_side_copy = false, lookahead = false, no_potrf_fuse = false, potrf_steps = false,
+         trsv_steps = false, no_fork_gate = false, no_touch = false;
+    int touch_wg = 128;
+  } knobs;
+  int ncu = 256;              // compute units of b->device
 
   // reduction partials
   double* d_part = nullptr;
@@ -170,6 +183,19 @@ static inline void dlg_fork_gate(dlg_backend* b, int* gate, int epoch)
 // fetch the first n scalars of d_scal to the host (synchronises the stream)
 int dlg_fetch_scalars(dlg_backend* b, int n);
 
+// what a kernel of a one-launch region needs to report a wait that gave up
+struct DlgHandoff { int* status; int spins; int skew; };
+enum { DLG_HANDOFF_FACTOR = 1, DLG_HANDOFF_SOLVE = 2, DLG_HANDOFF_POTRF = 4, DLG_HANDOFF_TRSV = 8, DLG_HANDOFF_TRSM = 16 };
+static inline DlgHandoff dlg_handoff(const dlg_backend* b, int spins)
+{
+  DlgHandoff h;
+  h.status = reinterpret_cast<int*>(b->d_scal + (dlg_backend::NSCAL - 2));
+  h.spins = b->handoff_spins > 0 ? b->handoff_spins : spins; h.skew = b->handoff_skew;
+  return h;
+}
+// after a synchronisation that brought the scalar block to the host: DLG_ERR_STATE if a hand-off timed out
+int dlg_check_handoff(dlg_backend* b);
+
 // --------------------------------------------------------- kernels_vec.hip --
 // out[0] = sum x[i]^2 ; out[1] = max |x[i]|   (deterministic two-stage)
 int k_norm2_absmax(dlg_backend* b, const double* x, int n, double* out2);
@@ -210,12 +236,12 @@ int dense_create(dlg_backend* b);
 void dense_launch_potrf_diag(hipStream_t st, double* A, int lda, int kb, int nb, int* info_dev, double* Linv);
 // ... and the rows below it in the same launch (flag: one device int, epoch: a value no earlier launch used)
 // the whole dense factorisation in one launch (a workgroup per 64 x 64 tile; flags: T*T device ints, T = ceil(n/64))
-void dense_launch_potrf_tiles(hipStream_t st, double* A, int lda, int n, int* info_dev, double* Linv, int* flags, int epoch);
+void dense_launch_potrf_tiles(hipStream_t st, double* A, int lda, int n, int* info_dev, double* Linv, int* flags, int epoch, const DlgHandoff& ho);
 // both triangular solves of (L L') x = rhs in one launch (a workgroup per 64 rows; flags: 2*T device ints; Y: n doubles of scratch)
 void dense_launch_trsv_tiles(hipStream_t st, const double* A, int lda, int n, const double* Linv, const double* rhs,
-                             double* Y, double* X, int* flags, int epoch);
+                             double* Y, double* X, int* flags, int epoch, const DlgHandoff& ho);
 void dense_launch_potrf_diag_trsm(hipStream_t st, double* A, int lda, int kb, int nb, int n, int* info_dev, double* Linv,
-                                  int* flag, int epoch);
+                                  int* flag, int epoch, const DlgHandoff& ho);
 void dense_destroy(dlg_backend* b);
 int dense_eval(dlg_backend* b, int slot);                       // K1
 int dense_norm2_Jv(dlg_backend* b, int slot, const double* v, double* out_dev); // K3/K8

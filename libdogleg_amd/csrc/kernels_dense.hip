@@ -723,11 +723,11 @@ __global__ void __launch_bounds__(TPB) k_panel_update(double* __restrict__ A, in
 // on one stream (the default, see below).
 int potrf_lower(hipStream_t st, double* A, int lda, int n, int* info_dev, double* Linv,
                 hipStream_t st2 = nullptr, hipEvent_t ev_panel = nullptr, hipEvent_t ev_trail = nullptr,
-                int* flag = nullptr, int* epoch = nullptr)
+                int* flag = nullptr, int* epoch = nullptr, bool lookahead = false, bool fuse = false,
+                const DlgHandoff* ho = nullptr)
 {
   // measured on config #2 (N = 2000): 2.23 ms with look-ahead against 2.15 without -- the three stream
   // dependencies per step cost more than the overlapped SYRK saves -- so it is opt-in (DOGLEG_AMD_LOOKAHEAD)
-  const bool lookahead = getenv("DOGLEG_AMD_LOOKAHEAD") != nullptr;
   if(st2 && ev_panel && ev_trail && n > 4*NB && lookahead)
   {
     bool trail_pending = false;
@@ -769,8 +769,8 @@ int potrf_lower(hipStream_t st, double* A, int lda, int n, int* info_dev, double
     const int nb = (n - kb < NB) ? n - kb : NB;
     double* Li = Linv + (size_t)blk*NB*NB;
     const int rem = n - kb - nb;
-    const bool fused = flag && epoch && rem > 0 && !getenv("DOGLEG_AMD_NO_POTRF_FUSE");
-    if(fused) dense_launch_potrf_diag_trsm(st, A, lda, kb, nb, n, info_dev, Li, flag, ++*epoch);
+    const bool fused = flag && epoch && ho && rem > 0 && fuse;
+    if(fused) dense_launch_potrf_diag_trsm(st, A, lda, kb, nb, n, info_dev, Li, flag, ++*epoch, *ho);
     else dense_launch_potrf_diag(st, A, lda, kb, nb, info_dev, Li);
     if(rem > 0)
     {
@@ -889,14 +889,16 @@ static int run_potrf(dlg_backend* b)
   }
   // one launch for the whole factorisation (dense_diag.hip: k_potrf_tiles); DOGLEG_AMD_POTRF_STEPS: the
   // step-by-step form (its fused diagonal + rows launch uses the last flag)
-  if(!getenv("DOGLEG_AMD_POTRF_STEPS") && T >= 2)
+  const DlgHandoff ho = dlg_handoff(b, 1 << 22);
+  if(!b->knobs.potrf_steps && T >= 2)
   {
-    dense_launch_potrf_tiles(b->stream, b->G, b->N, b->N, b->d_info, b->Linv, b->potrf_flag, ++b->potrf_epoch);
+    dense_launch_potrf_tiles(b->stream, b->G, b->N, b->N, b->d_info, b->Linv, b->potrf_flag, ++b->potrf_epoch, ho);
     DLG_LAUNCH_CHECK();
     return DLG_OK;
   }
   return potrf_lower(b->stream, b->G, b->N, b->N, b->d_info, b->Linv,
-                     b->overlap ? b->copy_stream : nullptr, b->ev_step, b->ev_copy, b->potrf_flag + (size_t)T*T, &b->potrf_epoch);
+                     b->overlap ? b->copy_stream : nullptr, b->ev_step, b->ev_copy, b->potrf_flag + (size_t)T*T, &b->potrf_epoch,
+                     b->knobs.lookahead, !b->knobs.no_potrf_fuse, &ho);
 }
 
 static int finish_potrf(dlg_backend* b, int* ok)
@@ -957,9 +959,9 @@ int dense_solve(dlg_backend* b, const double* rhs, double* out)
     // one launch for both sweeps where every block row gets a CU of its own (dense_diag.hip: k_trsv_tiles);
     // DOGLEG_AMD_TRSV_STEPS: a launch per block column and sweep
     const int T = dlg_cdiv(n, NB);
-    static int ncu = 0;
-    if(!ncu) { int dev = 0; ncu = 256; if(hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev); }
-    if(T >= 2 && T <= ncu && !getenv("DOGLEG_AMD_TRSV_STEPS"))
+    // (every block row needs a CU of its own at the same time -- the sweep back waits for higher-numbered
+    // workgroups --: half the chip at most, so that the pass over J on the second stream does not matter)
+    if(T >= 2 && T <= b->ncu/2 && !b->knobs.trsv_steps)
     {
       if(!b->trsv_flag)
       {
@@ -967,7 +969,7 @@ int dense_solve(dlg_backend* b, const double* rhs, double* out)
         DLG_HIP(hipMemsetAsync(b->trsv_flag, 0, sizeof(int)*2*(size_t)T, b->stream));
         DLG_HIP(hipMalloc(&b->trsv_y, sizeof(double)*(size_t)n));
       }
-      dense_launch_trsv_tiles(b->stream, b->G, n, n, b->Linv, rhs, b->trsv_y, out, b->trsv_flag, ++b->potrf_epoch);
+      dense_launch_trsv_tiles(b->stream, b->G, n, n, b->Linv, rhs, b->trsv_y, out, b->trsv_flag, ++b->potrf_epoch, dlg_handoff(b, 1 << 22));
       DLG_LAUNCH_CHECK();
       return DLG_OK;
     }

@@ -36,7 +36,7 @@ template <int NT, bool UT_LDS, bool HANDOFF = false>
 __device__ __forceinline__ void mf_add_children(double* P, double* Wt, int ntri, int nch, int ch0,
                                                 MfChild rc, const MfChild* __restrict__ mf_rec,
                                                 const double* uscr, const uint16_t* __restrict__ mf_dst, int tid,
-                                                int* pr_flag = nullptr, int pr_epoch = 0, int pr_item0 = 0, int* info = nullptr)
+                                                int* pr_flag = nullptr, int pr_epoch = 0, DlgHandoff ho = DlgHandoff{nullptr, 0, 0})
 {
   constexpr int MF_SLOTS = (NT >= 512) ? 20 : 16;      // 512 threads: up to 10240 entries (a 139-row update matrix) in one round
   const int lane = tid & 63;
@@ -47,18 +47,20 @@ __device__ __forceinline__ void mf_add_children(double* P, double* Wt, int ntri,
     if(k > 0 && (k & 63) == 0) rc = mf_rec[ch0 + k + min(lane, nch - k - 1)];
     if(HANDOFF)
     {
-      // persistent top region: wait for THIS child's flag only (the children of this launch; the others
-      // finished with the launch before).  The symbolic phase lists the children by expected time of
+      // persistent top region: wait for THIS child's flags only (the children of this launch; the others
+      // finished with the launch before) -- one flag per replica of the child, each of which hands over its
+      // tile columns of the update matrix.  The symbolic phase lists the children by expected time of
       // arrival, the latest last: the early ones are added while the late one is still at work, and the
       // order of the sums stays what the list says.
-      const int ci = __builtin_amdgcn_readlane(rc.rsv, k & 63);
-      if(tid == 0 && ci >= pr_item0)
+      const int cr = __builtin_amdgcn_readlane(rc.rsv, k & 63);
+      const int ci = cr & 0xfffff, cn = cr >> 20;          // (cr < 0: not in this launch, cn < 0)
+      if(tid < cn)
       {
         int spins = 0;
-        while(__hip_atomic_load(pr_flag + ci, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != pr_epoch)
+        while(__hip_atomic_load(pr_flag + ci + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != pr_epoch + ho.skew)
         {
           __builtin_amdgcn_s_sleep(1);
-          if(++spins > (1 << 21)) { atomicMin(info, 0); break; }      // a child that never arrives: report, do not hang
+          if(++spins > ho.spins) { atomicOr(ho.status, DLG_HANDOFF_FACTOR); break; }      // a child that never arrives: report (its own status word: not a pivot), do not hang
         }
       }
       __syncthreads();
@@ -269,7 +271,7 @@ __global__ void __launch_bounds__(NT, LEAF ? 4 : 1) k_factor_level(const FwItem*
                                                      double* __restrict__ top_scr,
                                                      int* __restrict__ info,
                                                      double* uscr, int mode,
-                                                     int* pr_flag, int pr_epoch, int pr_item0, int64_t pr_acc)
+                                                     int* pr_flag, int pr_epoch, DlgHandoff ho, int64_t pr_acc)
 {
   extern __shared__ __attribute__((aligned(16))) double P[];
   __shared__ int sbad, s_skip;
@@ -321,7 +323,7 @@ __global__ void __launch_bounds__(NT, LEAF ? 4 : 1) k_factor_level(const FwItem*
   // behind which the second stream holds the Cauchy step's pass over J (the word behind the items' flags;
   // a matter of timing only -- that pass depends on nothing this launch computes)
   if(pr_flag && tid == 0 && blockIdx.x == gridDim.x - 1)
-    __hip_atomic_store(pr_flag + pr_item0 + gridDim.x, pr_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(pr_flag + gridDim.x, pr_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if(cmp)
   {
     __syncthreads();
@@ -348,7 +350,7 @@ __global__ void __launch_bounds__(NT, LEAF ? 4 : 1) k_factor_level(const FwItem*
   FL_STAMP(1);
   if(s_skip)
   {
-    if(pr_flag && tid == 0) __hip_atomic_store(pr_flag + pr_item0 + blockIdx.x, pr_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if(pr_flag && tid == 0) __hip_atomic_store(pr_flag + blockIdx.x, pr_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return;
   }
   if(mf_acc && usp < mb)
@@ -356,8 +358,8 @@ __global__ void __launch_bounds__(NT, LEAF ? 4 : 1) k_factor_level(const FwItem*
       for(int i = lane; i < mb - jw; i += 64) P[(mb - jw)*ldp + i] = 0.0;      // (the barrier is in mf_add_children)
   if(mf_acc)
   {
-    if(pr_flag && u_lds) mf_add_children<NT, true, true>(P, Us, nlin, it.nch, it.ch0, rc, mf_rec, uscr, mf_dst, tid, pr_flag, pr_epoch, pr_item0, info);
-    else if(pr_flag)     mf_add_children<NT, false, true>(P, Ug + pr_acc, ntri, it.nch, it.ch0, rc, mf_rec, uscr, mf_dst, tid, pr_flag, pr_epoch, pr_item0, info);
+    if(pr_flag && u_lds) mf_add_children<NT, true, true>(P, Us, nlin, it.nch, it.ch0, rc, mf_rec, uscr, mf_dst, tid, pr_flag, pr_epoch, ho);
+    else if(pr_flag)     mf_add_children<NT, false, true>(P, Ug + pr_acc, ntri, it.nch, it.ch0, rc, mf_rec, uscr, mf_dst, tid, pr_flag, pr_epoch, ho);
     else if(u_lds)  mf_add_children<NT, true >(P, Us, nlin, it.nch, it.ch0, rc, mf_rec, uscr, mf_dst, tid);
     else            mf_add_children<NT, false>(P, Ug, ntri, it.nch, it.ch0, rc, mf_rec, uscr, mf_dst, tid);
   }
@@ -370,7 +372,7 @@ __global__ void __launch_bounds__(NT, LEAF ? 4 : 1) k_factor_level(const FwItem*
   else if(NT >= 256) panel_factor_mfma<(NT >= 256 ? NT : 256)>(P, ldp, nloc, w, tid, &sbad, it.col0);
   else         panel_factor<NT, true, true>(P, ldp, nloc, w, tid, &sbad, it.col0);
   FL_STAMP(3);
-  if(r0 == 0 && tid == 0 && sbad != 0x7fffffff) atomicMin(info, sbad);
+  if(r0 == 0 && it.rep == 0 && tid == 0 && sbad != 0x7fffffff) atomicMin(info, sbad);
   // U = B B' (mode 2: W = children's sum - B B'): lower 16x16 tiles on the matrix cores, both
   // operands read from the panel (factor_tail_tiles above).  The lower triangle of tiles is dealt
   // out in column-major tile order, in chunks of consecutive tiles: every round gives each wave one
@@ -383,14 +385,18 @@ __global__ void __launch_bounds__(NT, LEAF ? 4 : 1) k_factor_level(const FwItem*
     double* Ud = u_lds ? Us : Ug;              // in place behind the panel, or straight to the scratch
     constexpr int NWV = NT/64;
     constexpr int SY_G = (NT >= 512) ? 6 : 4;
-    const int ntiles = T*(T + 1)/2;
+    // (a replica of the one-launch region forms the tile columns [tj0, tj1) only: tiles [tlo, thi) in
+    // column-major tile order; every tile has its own accumulator chain, so who forms it changes no bit)
+    const int tjA = min(it.tj0, T), tjB = min(it.tj1, T);
+    const int tlo = tjA*T - tjA*(tjA - 1)/2, thi = tjB*T - tjB*(tjB - 1)/2;
+    const int ntiles = thi - tlo;
     const int rounds = (ntiles + NWV*SY_G - 1)/(NWV*SY_G), nchunks = rounds*NWV;
     const bool w_hbm = mf_acc && !u_lds;
     const bool st_wt = pr_flag != nullptr && !u_lds;
     const int64_t acc_shift = st_wt ? pr_acc : 0;
     for(int c = wv; c < nchunks; c += NWV)
     {
-      const int t0 = (int)((long)c*ntiles/nchunks), t1 = (int)((long)(c + 1)*ntiles/nchunks);
+      const int t0 = tlo + (int)((long)c*ntiles/nchunks), t1 = tlo + (int)((long)(c + 1)*ntiles/nchunks);
       switch(t1 - t0)
       {
         case 1: factor_tail_tiles<1>(Pb, ldp, w, mb, T, t0, Ud, mode, w_hbm, mf_acc, lane, acc_shift, st_wt, usp, P); break;
@@ -411,19 +417,24 @@ __global__ void __launch_bounds__(NT, LEAF ? 4 : 1) k_factor_level(const FwItem*
     // the part behind the panel.  Persistent top region: the parent reads W in this same launch --
     // 16-byte write-through stores (the slots are 16-byte aligned and padded to an even length),
     // drained by every wave before the flag goes up
-    const int npair = (usp == mb) ? (nlin + 1) & ~1 : nlin & ~1;
+    // (a replica: the columns [jA, jB) of its tile columns -- a contiguous stretch [eA, eB) of the packed triangle)
+    const int jA = min(16*it.tj0, mb), jB = min(it.tj1, 1 << 20) >= ((mb + 15) >> 4) ? mb : 16*it.tj1;
+    const int jAl = min(jA, usp), jBl = min(jB, usp);
+    const int eA = jAl*mb - jAl*(jAl - 1)/2, eB = jBl*mb - jBl*(jBl - 1)/2;
     if(pr_flag)
     {
-      for(int e = 2*tid; e < npair; e += 2*NT)
+      const int eA2 = (eA + 1) & ~1, eB2 = eB & ~1;
+      for(int e = eA2 + 2*tid; e < eB2; e += 2*NT)
       {
         const dlg_v2d v2 = *reinterpret_cast<const dlg_v2d*>(Us + e);
         asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(Ug + e), "v"(v2) : "memory");
       }
-      if(tid == 0 && npair < nlin) __hip_atomic_store((gwptr_t)(Ug + npair), Us[npair], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if(tid == 0 && eA < eA2 && eA < eB) __hip_atomic_store((gwptr_t)(Ug + eA), Us[eA], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if(tid == 1 && eB2 < eB && eB2 >= eA2) __hip_atomic_store((gwptr_t)(Ug + eB2), Us[eB2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    else for(int e = tid; e < nlin; e += NT) Ug[e] = Us[e];
+    else for(int e = eA + tid; e < eB; e += NT) Ug[e] = Us[e];
     // the columns kept in the top block's upper triangle
-    for(int jw = usp + (tid >> 6); jw < mb; jw += NT/64)
+    for(int jw = max(usp, jA) + (tid >> 6); jw < jB; jw += NT/64)
     {
       const double* src = P + (mb - jw)*ldp;
       double* dst = Ug + tri_col(jw, mb) + jw;
@@ -438,8 +449,9 @@ __global__ void __launch_bounds__(NT, LEAF ? 4 : 1) k_factor_level(const FwItem*
   {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if(tid == 0) __hip_atomic_store(pr_flag + pr_item0 + blockIdx.x, pr_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if(tid == 0) __hip_atomic_store(pr_flag + blockIdx.x, pr_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
+  if(it.rep != 0) { FL_STAMP(5); return; }        // the panel is replica 0's to store
   for(int i = row0c + tid - cp_g*cp_rows; i < nloc && cp_g < cp_ng; i += cp_rows)
   {
     // rows below the top block go back to the panel; the top block too unless the supernode is
@@ -1138,8 +1150,7 @@ int sparse_factor_setup(dlg_backend* b)
   if(!getenv("DOGLEG_AMD_NO_PERSIST") && H.nlevels >= 2)
   {
     // (a workgroup of the region fills a CU; more of them than CUs would only queue behind waiting ones)
-    int ncu = 256;
-    { int dev = 0; if(hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev); }
+    const int ncu = b->ncu;
     const int cap = env_int_host("DOGLEG_AMD_PERSIST_MAX", ncu);
     int total = 0, l0 = H.nlevels, lds = 0, stage = 1;
     bool acc = false;
@@ -1171,9 +1182,62 @@ int sparse_factor_setup(dlg_backend* b)
         if(mb > 0 && it.nch > 0 && it.jsp < 0) acc = true;
       }
     }
+    // Replicas: the upper levels hold fewer supernodes than the chip has CUs, and behind the panel sweep of a
+    // supernode sits its update matrix W = (children) - B B', a third of the level's critical path on ONE CU.
+    // A supernode of such a level is given to several workgroups: each stages the panel, adds the children
+    // and runs the sweep -- the same instructions on the same data, so the same bits, and nothing to hand
+    // over between them --, then forms and publishes only its share of W's tile columns; the parent waits
+    // for all of them.  A level gets replicas while it and its neighbour level still fit the chip together
+    // (a workgroup that finds no CU starts late and pays its panel load on the critical path).
+    Y->pr_nwg = 0;
+    if(Y->pr_level0 < H.nlevels)
+    {
+      const int rmax = std::max(1, std::min(8, env_int_host("DOGLEG_AMD_FRONT_REPLICAS", 4)));
+      const int fill = env_int_host("DOGLEG_AMD_FRONT_FILL", ncu/2);
+      std::vector<FwItem> items;
+      std::vector<int> first(H.fw_item.size(), -1), count(H.fw_item.size(), 0);
+      for(int l = Y->pr_level0; l < H.nlevels; l++)
+      {
+        const int n = H.fw_lvl_ptr[l+1] - H.fw_lvl_ptr[l];
+        const int rl = std::max(1, std::min(rmax, fill/std::max(n, 1)));
+        for(int i = H.fw_lvl_ptr[l]; i < H.fw_lvl_ptr[l+1]; i++)
+        {
+          FwItem it = H.fw_item[i];
+          const int mb = it.nrows - it.w, T = (mb + 15) >> 4;
+          // (an update matrix that is summed in HBM -- it.jsp < 0 -- is one workgroup's: atomics)
+          int want = (mb > 0 && it.jsp >= 0 && it.u_off >= 0) ? std::min(rl, T) : 1;
+          // contiguous tile columns, tile counts T - t, the largest share as small as possible
+          std::vector<int> cut;
+          for(int cap = (T*(T + 1)/2 + want - 1)/std::max(want, 1); ; cap++)
+          {
+            cut.assign(1, 0);
+            int load = 0;
+            for(int t = 0; t < T; t++)
+            {
+              if(load > 0 && load + (T - t) > cap) { cut.push_back(t); load = 0; }
+              load += T - t;
+            }
+            cut.push_back(T);
+            if((int)cut.size() - 1 <= want) break;
+          }
+          const int nrep = std::max(1, (int)cut.size() - 1);
+          first[i] = (int)items.size(); count[i] = nrep;
+          for(int r = 0; r < nrep; r++)
+          {
+            it.rep = r; it.tj0 = (nrep == 1) ? 0 : cut[r]; it.tj1 = (nrep == 1 || r == nrep - 1) ? (1 << 20) : cut[r+1];
+            items.push_back(it);
+          }
+        }
+      }
+      std::vector<MfChild> rec(H.mf_rec);
+      for(auto& r : rec) r.rsv = (r.rsv >= 0 && first[r.rsv] >= 0) ? (first[r.rsv] | (count[r.rsv] << 20)) : -1;
+      Y->pr_nwg = (int)items.size();
+      if(!Y->pr_item) { DLG_CHECK(upload(Y->pr_item, items)); Y->allocs.push_back(Y->pr_item); }
+      if(!Y->pr_rec)  { DLG_CHECK(upload(Y->pr_rec, rec));   Y->allocs.push_back(Y->pr_rec); }
+    }
     if(dbg)
-      fprintf(stderr, "libdogleg_amd: persistent top region: levels %d..%d of %d (%d workgroups, %d bytes of LDS, multifrontal from level %d)\n",
-              l0, H.nlevels - 1, H.nlevels, total, lds, H.mf_level0);
+      fprintf(stderr, "libdogleg_amd: persistent top region: levels %d..%d of %d (%d supernodes, %d workgroups, %d bytes of LDS, multifrontal from level %d)\n",
+              l0, H.nlevels - 1, H.nlevels, total, Y->pr_nwg, lds, H.mf_level0);
     // update matrices of the region that do not fit LDS are summed (atomics) in a shadow of the scratch,
     // so that the slot the parent reads only ever sees write-through stores
     if(acc && !Y->pr_acc)
@@ -1184,91 +1248,9 @@ int sparse_factor_setup(dlg_backend* b)
   }
   if(Y->pr_level0 < H.nlevels && !Y->fac_flag)
   {
-    DLG_HIP(hipMalloc(&Y->fac_flag, sizeof(int)*(H.fw_item.size() + 1)));
+    DLG_HIP(hipMalloc(&Y->fac_flag, sizeof(int)*((size_t)Y->pr_nwg + 1)));         // one per workgroup of the region + the fork gate
     Y->allocs.push_back(Y->fac_flag);
-    DLG_HIP(hipMemsetAsync(Y->fac_flag, 0, sizeof(int)*(H.fw_item.size() + 1), b->stream));
-    Y->fac_epoch = 0;
-  }
-  DLG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_factor_level<128>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, FAC_LDS_BUDGET));
-  DLG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_factor_level<256>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, FAC_LDS_BUDGET));
-  DLG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_factor_level<256, true>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, FAC_LDS_BUDGET));
-  if(!Y->uw_flat && !H.uw_item.empty())
-  {
-    std::vector<GatherUnit> fl(H.uw_item.size());
-    for(size_t u = 0; u < fl.size(); u++)
-    {
-      const int item = H.uw_item[u], t = H.ui_t[item];
-      const int nr = H.sn_rowptr[t+1] - H.sn_rowptr[t];
-      fl[u].lt = H.sn_lx[t] + (int64_t)H.ui_col[item]*nr; fl[u].part = H.uw_part[u];
-      fl[u].s0 = H.uw_s0[u]; fl[u].s1 = H.uw_s1[u]; fl[u].nrows_t = nr; fl[u].nc = H.ui_nc[item];
-    }
-    DLG_CHECK(upload(Y->uw_flat, fl)); Y->allocs.push_back(Y->uw_flat);
-  }
-  // Persistent top region: the last levels of the multifrontal region hold a few supernodes each and
-  // every one of them waits for the one before -- each kernel boundary costs the launch gap, a cold
-  // panel load and the store of the panel before the next level may start.  They go out as ONE
-  // launch, workgroups in level order (a workgroup only ever waits for lower-numbered ones, so
-  // in-order dispatch cannot deadlock): a workgroup stages its panel at once, waits for its
-  // children's flags, and raises its own flag as soon as its update matrix is out -- before its
-  // panel goes back to HBM.  Conditions: unsliced supernodes, update matrices staged in LDS (their
-  // hand-off is the write-through store of that LDS copy), one block size, no update units, above
-  // the cut of a subtree partition.
-  Y->pr_level0 = H.nlevels;
-  if(!getenv("DOGLEG_AMD_NO_PERSIST") && H.nlevels >= 2)
-  {
-    // (a workgroup of the region fills a CU; more of them than CUs would only queue behind waiting ones)
-    int ncu = 256;
-    { int dev = 0; if(hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev); }
-    const int cap = env_int_host("DOGLEG_AMD_PERSIST_MAX", ncu);
-    int total = 0, l0 = H.nlevels, lds = 0, stage = 1;
-    bool acc = false;
-    const int nt = Y->fac_nt[H.nlevels - 1];
-    const bool dbg = getenv("DOGLEG_AMD_TIMING") != nullptr;
-    for(int l = H.nlevels - 1; l >= 1; l--)
-    {
-      const int n = H.fw_lvl_ptr[l+1] - H.fw_lvl_ptr[l];
-      if(l < H.mf_level0 || (H.part_nranks > 1 && l <= H.cut_level)) break;
-      if(n == 0 || total + n > cap || Y->fac_nt[l] != nt || Y->fac_lds[l] <= 0) break;
-      if(H.uw_lvl_ptr[l+1] > H.uw_lvl_ptr[l] || H.uf_lvl_ptr[l+1] > H.uf_lvl_ptr[l]) break;
-      bool ok = true;
-      for(int i = H.fw_lvl_ptr[l]; i < H.fw_lvl_ptr[l+1] && ok; i++)
-      {
-        const FwItem& it = H.fw_item[i];
-        if(it.top >= 0 || it.r0 != 0 || it.nbd > 0) ok = false;
-      }
-      if(!ok) break;
-      stage = stage && Y->fac_stage[l]; total += n; l0 = l; lds = std::max(lds, Y->fac_lds[l]);
-    }
-    if(H.nlevels - l0 >= 2)
-    {
-      Y->pr_level0 = l0; Y->pr_lds = lds; Y->pr_stage = stage;
-      for(int i = H.fw_lvl_ptr[l0]; i < H.fw_lvl_ptr[H.nlevels]; i++)
-      {
-        // the kernel's rule for staging the update matrix behind the panel
-        const FwItem& it = H.fw_item[i];
-        const long mb = it.nrows - it.w;
-        if(mb > 0 && it.nch > 0 && it.jsp < 0) acc = true;
-      }
-    }
-    if(dbg)
-      fprintf(stderr, "libdogleg_amd: persistent top region: levels %d..%d of %d (%d workgroups, %d bytes of LDS, multifrontal from level %d)\n",
-              l0, H.nlevels - 1, H.nlevels, total, lds, H.mf_level0);
-    // update matrices of the region that do not fit LDS are summed (atomics) in a shadow of the scratch,
-    // so that the slot the parent reads only ever sees write-through stores
-    if(acc && !Y->pr_acc)
-    {
-      DLG_HIP(hipMalloc(&Y->pr_acc, sizeof(double)*(size_t)std::max<int64_t>(1, H.uscr_size)));
-      Y->allocs.push_back(Y->pr_acc);
-    }
-  }
-  if(Y->pr_level0 < H.nlevels && !Y->fac_flag)
-  {
-    DLG_HIP(hipMalloc(&Y->fac_flag, sizeof(int)*(H.fw_item.size() + 1)));
-    Y->allocs.push_back(Y->fac_flag);
-    DLG_HIP(hipMemsetAsync(Y->fac_flag, 0, sizeof(int)*(H.fw_item.size() + 1), b->stream));
+    DLG_HIP(hipMemsetAsync(Y->fac_flag, 0, sizeof(int)*((size_t)Y->pr_nwg + 1), b->stream));
     Y->fac_epoch = 0;
   }
   DLG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_factor_level<128>),
@@ -1343,26 +1325,27 @@ int sparse_factor_levels(dlg_backend* b)
     const int n = H.fw_lvl_ptr[l+1] - H.fw_lvl_ptr[l];
     // from the first level that cannot fill the chip on, the factorisation is latency-bound:
     // independent work (the Cauchy step's pass over J) may run beside it
-    const bool no_gate = l == Y->pr_level0 && getenv("DOGLEG_AMD_NO_FORK_GATE") != nullptr;      // (read per factorisation: the tests switch it)
+    const bool no_gate = l == Y->pr_level0 && b->knobs.no_fork_gate;
     const bool gate_here = l == Y->pr_level0 && Y->fac_flag && !no_gate;      // (no event on this stream: the launch opens a gate)
     if(l > 0 && n < 256 && !gate_here) dlg_fork_point(b);
     if(l == Y->pr_level0)
     {
       // the persistent top region: every remaining level in one launch (sparse_factor_setup)
-      const int o = H.fw_lvl_ptr[l], np = H.fw_lvl_ptr[H.nlevels] - o;
+      const int np = Y->pr_nwg;           // the region's own work items (replicas) and children records
       const int fmode = 2 + 4*Y->pr_stage + (Y->fac_ahead ? 8 : 0) + 256*l;
       int* fl = Y->fac_flag; const int ep = ++Y->fac_epoch;
-      if(gate_here && l > 0 && n < 256) dlg_fork_gate(b, fl + H.fw_lvl_ptr[H.nlevels], ep);
+      if(gate_here && l > 0 && n < 256) dlg_fork_gate(b, fl + np, ep);
       const int64_t pacc = Y->pr_acc ? (int64_t)(Y->pr_acc - Y->uscr) : 0;
+      const DlgHandoff ho = dlg_handoff(b, 1 << 21);
       if(Y->fac_nt[l] == 128)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_factor_level<128>), dim3(np), dim3(128), Y->pr_lds, st,
-                           Y->fw_item + o, Y->mf_rec, Y->sn_bd_col, Y->mf_dst, Y->Lx, Y->top_scr, Y->d_info, Y->uscr, fmode, fl, ep, o, pacc);
+                           Y->pr_item, Y->pr_rec, Y->sn_bd_col, Y->mf_dst, Y->Lx, Y->top_scr, Y->d_info, Y->uscr, fmode, fl, ep, ho, pacc);
       else if(Y->fac_nt[l] == 256)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_factor_level<256>), dim3(np), dim3(256), Y->pr_lds, st,
-                           Y->fw_item + o, Y->mf_rec, Y->sn_bd_col, Y->mf_dst, Y->Lx, Y->top_scr, Y->d_info, Y->uscr, fmode, fl, ep, o, pacc);
+                           Y->pr_item, Y->pr_rec, Y->sn_bd_col, Y->mf_dst, Y->Lx, Y->top_scr, Y->d_info, Y->uscr, fmode, fl, ep, ho, pacc);
       else
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_factor_level<512>), dim3(np), dim3(512), Y->pr_lds, st,
-                           Y->fw_item + o, Y->mf_rec, Y->sn_bd_col, Y->mf_dst, Y->Lx, Y->top_scr, Y->d_info, Y->uscr, fmode, fl, ep, o, pacc);
+                           Y->pr_item, Y->pr_rec, Y->sn_bd_col, Y->mf_dst, Y->Lx, Y->top_scr, Y->d_info, Y->uscr, fmode, fl, ep, ho, pacc);
       break;
     }
     if(n > 0)
@@ -1372,16 +1355,16 @@ int sparse_factor_levels(dlg_backend* b)
       const int fmode = ((l >= H.mf_level0) ? 2 : Y->syrk_fused[l]) + 4*Y->fac_stage[l] + use_ahead + 256*l;
       if(Y->fac_nt[l] == 128)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_factor_level<128>), dim3(n), dim3(128), Y->fac_lds[l], st,
-                           Y->fw_item + o, Y->mf_rec, Y->sn_bd_col, Y->mf_dst, Y->Lx, Y->top_scr, Y->d_info, Y->uscr, fmode, (int*)nullptr, 0, 0, (int64_t)0);
+                           Y->fw_item + o, Y->mf_rec, Y->sn_bd_col, Y->mf_dst, Y->Lx, Y->top_scr, Y->d_info, Y->uscr, fmode, (int*)nullptr, 0, DlgHandoff{nullptr, 0, 0}, (int64_t)0);
       else if(Y->fac_nt[l] == 256 && Y->fac_leaf[l])
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_factor_level<256, true>), dim3(n), dim3(256), Y->fac_lds[l], st,
-                           Y->fw_item + o, Y->mf_rec, Y->sn_bd_col, Y->mf_dst, Y->Lx, Y->top_scr, Y->d_info, Y->uscr, fmode, (int*)nullptr, 0, 0, (int64_t)0);
+                           Y->fw_item + o, Y->mf_rec, Y->sn_bd_col, Y->mf_dst, Y->Lx, Y->top_scr, Y->d_info, Y->uscr, fmode, (int*)nullptr, 0, DlgHandoff{nullptr, 0, 0}, (int64_t)0);
       else if(Y->fac_nt[l] == 256)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_factor_level<256>), dim3(n), dim3(256), Y->fac_lds[l], st,
-                           Y->fw_item + o, Y->mf_rec, Y->sn_bd_col, Y->mf_dst, Y->Lx, Y->top_scr, Y->d_info, Y->uscr, fmode, (int*)nullptr, 0, 0, (int64_t)0);
+                           Y->fw_item + o, Y->mf_rec, Y->sn_bd_col, Y->mf_dst, Y->Lx, Y->top_scr, Y->d_info, Y->uscr, fmode, (int*)nullptr, 0, DlgHandoff{nullptr, 0, 0}, (int64_t)0);
       else
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_factor_level<512>), dim3(n), dim3(512), Y->fac_lds[l], st,
-                           Y->fw_item + o, Y->mf_rec, Y->sn_bd_col, Y->mf_dst, Y->Lx, Y->top_scr, Y->d_info, Y->uscr, fmode, (int*)nullptr, 0, 0, (int64_t)0);
+                           Y->fw_item + o, Y->mf_rec, Y->sn_bd_col, Y->mf_dst, Y->Lx, Y->top_scr, Y->d_info, Y->uscr, fmode, (int*)nullptr, 0, DlgHandoff{nullptr, 0, 0}, (int64_t)0);
     }
     const int nu = H.uw_lvl_ptr[l+1] - H.uw_lvl_ptr[l];
     if(nu > 0 && H.upd_syrk[l] && Y->upd_nw[l] > 0)

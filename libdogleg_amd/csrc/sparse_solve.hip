@@ -115,7 +115,7 @@ __global__ void __launch_bounds__(BWD_NT, BD_ONLY ? 4 : 1) k_solve_bwd_level(con
                                                             double* __restrict__ ywork,
                                                             double* __restrict__ out, int use_aug,
                                                             const int* __restrict__ sn_bd_col, int top_lds, int xb_cap,
-                                                            int* pr_flag, int pr_epoch, const int* __restrict__ info)
+                                                            int* pr_flag, int pr_epoch, const int* __restrict__ info, DlgHandoff ho)
 {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   __shared__ int s_skip;
@@ -309,10 +309,10 @@ __global__ void __launch_bounds__(BWD_NT, BD_ONLY ? 4 : 1) k_solve_bwd_level(con
     if(tid == 0 && it.pflag >= 0)
     {
       int spins = 0;
-      while(__hip_atomic_load(pr_flag + it.pflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != pr_epoch)
+      while(__hip_atomic_load(pr_flag + it.pflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != pr_epoch + ho.skew)
       {
         __builtin_amdgcn_s_sleep(1);
-        if(++spins > (1 << 21)) break;          // never hang (the parent is always dispatched first)
+        if(++spins > ho.spins) { atomicOr(ho.status, DLG_HANDOFF_SOLVE); break; }    // never hang (the parent is always dispatched first), but say so: x of the ancestors is not there
       }
     }
     __syncthreads();
@@ -640,8 +640,8 @@ extern "C" void dlg_bw_profile_dump(int nlevels)
 int sparse_touch_factor(dlg_backend* b, hipStream_t st)
 {
   SparseSym* Y = b->sym;
-  if(!Y || !Y->touch_n || getenv("DOGLEG_AMD_NO_TOUCH")) return DLG_OK;
-  static const int nwg = [] { const char* v = getenv("DOGLEG_AMD_TOUCH_WG"); return v ? atoi(v) : 128; }();   // (1024: 9 us more in the factorisation; 16: still running when the next step needs the stream)
+  if(!Y || !Y->touch_n || b->knobs.no_touch) return DLG_OK;
+  const int nwg = b->knobs.touch_wg;   // (1024: 9 us more in the factorisation; 16: still running when the next step needs the stream)
   hipLaunchKernelGGL(k_touch, dim3(nwg), dim3(TPB), 0, st, reinterpret_cast<const double2*>(Y->Lx + Y->touch_off),
                      (size_t)Y->touch_n/2, Y->ywork);
   DLG_LAUNCH_CHECK();
@@ -827,7 +827,7 @@ int sparse_solve(dlg_backend* b, const double* rhs, double* out)
     // the persistent top region: its levels in one launch, workgroups from the root down (sparse_solve_setup)
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_solve_bwd_level<512, false>), dim3(Y->bw_n), dim3(512), Y->bw_lds, st,
                        Y->slv_item_pr, Y->sn_rows, Y->perm, Y->Lx, Y->ywork, out, use_aug, Y->sn_bd_col,
-                       256*Y->bw_level0, Y->bwd_xb_cap, Y->bwd_flag, ++Y->bwd_epoch, Y->d_info);
+                       256*Y->bw_level0, Y->bwd_xb_cap, Y->bwd_flag, ++Y->bwd_epoch, Y->d_info, dlg_handoff(b, 1 << 21));
     ltop = Y->bw_level0 - 1;
   }
   for(int l = ltop; l >= 0; l--)
@@ -838,15 +838,15 @@ int sparse_solve(dlg_backend* b, const double* rhs, double* out)
     if(n > 0 && Y->bwd_nt[l] == 256 && Y->bwd_bd[l])
       hipLaunchKernelGGL(HIP_KERNEL_NAME(k_solve_bwd_level<256, true>), dim3(n), dim3(256), Y->bwd_lds[l], st,
                          Y->slv_item + H.xl_ptr[l], Y->sn_rows, Y->perm, Y->Lx, Y->ywork, out, use_aug, Y->sn_bd_col,
-                         Y->bwd_top[l] + 256*l, Y->bwd_xb_cap, (int*)nullptr, 0, Y->d_info);
+                         Y->bwd_top[l] + 256*l, Y->bwd_xb_cap, (int*)nullptr, 0, Y->d_info, dlg_handoff(b, 1 << 21));
     else if(n > 0 && Y->bwd_nt[l] == 256)
       hipLaunchKernelGGL(HIP_KERNEL_NAME(k_solve_bwd_level<256, false>), dim3(n), dim3(256), Y->bwd_lds[l], st,
                          Y->slv_item + H.xl_ptr[l], Y->sn_rows, Y->perm, Y->Lx, Y->ywork, out, use_aug, Y->sn_bd_col,
-                         Y->bwd_top[l] + 256*l, Y->bwd_xb_cap, (int*)nullptr, 0, Y->d_info);
+                         Y->bwd_top[l] + 256*l, Y->bwd_xb_cap, (int*)nullptr, 0, Y->d_info, dlg_handoff(b, 1 << 21));
     else if(n > 0)
       hipLaunchKernelGGL(HIP_KERNEL_NAME(k_solve_bwd_level<512, false>), dim3(n), dim3(512), Y->bwd_lds[l], st,
                          Y->slv_item + H.xl_ptr[l], Y->sn_rows, Y->perm, Y->Lx, Y->ywork, out, use_aug, Y->sn_bd_col,
-                         Y->bwd_top[l] + 256*l, Y->bwd_xb_cap, (int*)nullptr, 0, Y->d_info);
+                         Y->bwd_top[l] + 256*l, Y->bwd_xb_cap, (int*)nullptr, 0, Y->d_info, dlg_handoff(b, 1 << 21));
   }
   DLG_LAUNCH_CHECK();
   if(H.part_nranks > 1)

@@ -173,10 +173,15 @@ struct FwItem
   int64_t lx, top, u_off;      // panel offset, top-block copy (or -1), update-matrix offset (or -1)
   int ch0, nch;                // multifrontal children: mf_rec[ch0 .. ch0 + nch)
   int bdw, jsp;                // block-diagonal top: the common width of the members, 0 if they differ; sym_w_split of the supernode
+  // one-launch region of the factorisation (sparse_factor_setup): a supernode may be factored by several
+  // workgroups ("replicas": identical arithmetic on the whole panel), each of which forms and hands over
+  // the 16-column tile columns [tj0, tj1) of the update matrix; replica 0 stores the panel
+  int rep, tj0, tj1, pad;
 };
 // one child of a supernode of the multifrontal region: its update matrix and, entry by entry
 // (packed order, padded to a multiple of 1024 with a scratch slot), where each entry goes
-struct MfChild { int64_t u_off, dst_off; int npad, rsv; };     // rsv: the child's work item (index into fw_item), -1 if it has none on this rank
+struct MfChild { int64_t u_off, dst_off; int npad, rsv; };     // rsv: the child's work item (index into fw_item), -1 if it has none on this rank;
+                                                               // in the one-launch region's copy: first workgroup of the child | its replicas << 20, -1: not in the launch
 
 struct SymHost
 {

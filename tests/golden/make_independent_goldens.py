@@ -6,8 +6,11 @@ precision iterative refinement (tests/independent.py).  Both the oracle (CPU tes
 path (-m gpu test) are compared with it at the 1e-10 parity bar: an independent pin of the sparse
 factor / solve arithmetic that the reference delegates to CHOLMOD.
 
+The same for config #4 (1M x 150k, 15M non-zeros) -> splu_config4_step.json, every 16th entry of the
+vectors plus their norms and sums, to keep the file small.
+
 Data only: hex floats of the Gauss-Newton step, the Cauchy scalars and the interpolated step.
-Run here (scipy 1.15.3):  python tests/golden/make_independent_goldens.py   (about a minute)
+Run here (scipy 1.15.3):  python tests/golden/make_independent_goldens.py [3] [4]   (config #3: about a minute)
 """
 import json
 import os
@@ -27,8 +30,8 @@ def hexlist(a):
     return [float(v).hex() for v in np.asarray(a).ravel()]
 
 
-def main():
-    args = dict(Nc=499, Np=9000, Nobs=100000, seed=11)
+def make(args, fname, stride):
+    """stride > 1: every stride-th entry of the vectors (+ their norms): a small file for a large problem"""
     prob = oa.BAProblem(args["Nc"], args["Np"], args["Nobs"], seed=args["seed"])
     Jp, Ji = prob.pattern()
     p = prob.p0()
@@ -58,12 +61,20 @@ def main():
         "kind": int(st["kind"]), "k": float(st["k"]).hex(),
         "expected_improvement": float(st["expected_improvement"]).hex(),
         "relative_residual_of_gn": float(np.sqrt(float(res @ res)) / np.linalg.norm(g)),
-        "gn_hex": hexlist(gn),
-        "step_hex": hexlist(st["step"]),
+        "stride": stride,
+        "norm2_step": float(st["step"] @ st["step"]).hex(),
+        "sum_gn": float(np.sum(gn)).hex(), "sum_step": float(np.sum(st["step"])).hex(),
+        "gn_hex": hexlist(gn[::stride]),
+        "step_hex": hexlist(st["step"][::stride]),
     }
-    json.dump(out, open(os.path.join(HERE, "splu_config3_step.json"), "w"), indent=0)
-    print("written; relative residual of the refined GN solve:", out["relative_residual_of_gn"])
+    json.dump(out, open(os.path.join(HERE, fname), "w"), indent=0)
+    print(fname, "written; relative residual of the refined GN solve:", out["relative_residual_of_gn"])
 
 
 if __name__ == "__main__":
-    main()
+    which = sys.argv[1:] or ["3", "4"]
+    if "3" in which:
+        make(dict(Nc=499, Np=9000, Nobs=100000, seed=11), "splu_config3_step.json", 1)
+    if "4" in which:
+        # BASELINE.json config #4 (1M x 150k, 15M nnz): every 16th entry of the vectors + norms and sums
+        make(dict(Nc=2499, Np=45000, Nobs=500000, seed=11), "splu_config4_step.json", 16)

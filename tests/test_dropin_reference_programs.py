@@ -12,11 +12,26 @@ import subprocess
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+from libdogleg_amd import build as _build
+_build.ensure_links()          # libdogleg.so.2 / libdogleg.so next to libdogleg_amd.so (symlinks may not have travelled)
 SAMPLE = os.path.join(ROOT, "oracle", "_ref", "sample_dropin")
 MISC = os.path.join(ROOT, "oracle", "_ref", "test_misc_dropin")
 MODES = ["sparse", "dense", "dense-products-packed-upper", "dense-products-unpacked"]
 needs_bins = pytest.mark.skipif(not (os.path.exists(SAMPLE) and os.path.exists(MISC)),
                                 reason="oracle/_ref not built (no /root/reference at build time)")
+
+
+def test_library_carries_the_reference_soname():
+    """reference Makefile:7 (ABI_VERSION := 2): the shared library is libdogleg.so.2; ours carries that
+    SONAME and the names `-ldogleg` / the loader look for resolve to it"""
+    lib = os.path.join(ROOT, "libdogleg_amd", "libdogleg_amd.so")
+    r = subprocess.run(["readelf", "-d", lib], capture_output=True, text=True)
+    assert "soname: [libdogleg.so.2]" in r.stdout
+    for name in ("libdogleg.so.2", "libdogleg.so"):
+        assert os.path.realpath(os.path.join(ROOT, "libdogleg_amd", name)) == os.path.realpath(lib)
+    if os.path.exists(SAMPLE):
+        r = subprocess.run(["readelf", "-d", SAMPLE], capture_output=True, text=True)
+        assert "[libdogleg.so.2]" in r.stdout          # the reference's program asks for the reference's library name
 
 
 @needs_bins

@@ -237,3 +237,49 @@ def test_cauchy_step_at_a_singular_point_leaves_lambda_alone(gpu, kind):
     assert [t["lambda_"] for t in trg.trials()] == [t["lambda_"] for t in tro.trials()]
     compare_traces(trg, tro, step_tol=1e-9)          # the tiny-J point makes one huge, clipped Cauchy step
     assert np.max(np.abs(pg - po)) <= 1e-9
+
+
+def test_a_hand_off_that_times_out_is_an_error_not_a_wrong_answer(gpu, monkeypatch):
+    """The one-launch regions (top of the sparse elimination tree both ways, dense potrf / trsv) hand data
+    from workgroup to workgroup through flags; a wait that gives up raises a status word that the host turns
+    into DLG_ERR_STATE -- dogleg_optimize* then returns -1.0 -- instead of going on with data that was never
+    published.  DOGLEG_AMD_DEBUG_HANDOFF_TIMEOUT (read when the backend is created) makes every wait look for
+    an epoch that never comes."""
+    prob = oa.BAProblem(49, 900, 10000, seed=9)
+    p = prob.p0()
+    x, J = prob.eval(p)
+    Jp, Ji = prob.pattern()
+    dp = oa.DenseProblem(M=1500, N=521, seed=4)
+    xd, Jd = dp.eval(dp.p0())
+
+    def sparse_gn():
+        be = capi.Backend(capi.DLG_SPARSE, prob.N, prob.M, prob.nnz)
+        try:
+            be.set_pattern(Jp, Ji)
+            assert be.schedule()["persist_level0"] >= 0, "the pattern must have a one-launch region"
+            be.set_p(0, p); be.upload(0, x, J); be.eval(0)
+            return be.gauss_newton(0, 0.0)
+        finally:
+            be.close()
+
+    def dense_gn():
+        be = capi.Backend(capi.DLG_DENSE, dp.N, dp.M)
+        try:
+            be.set_p(0, dp.p0()); be.upload(0, xd, Jd); be.eval(0)
+            return be.gauss_newton(0, 0.0)
+        finally:
+            be.close()
+    ref_s, ref_d = sparse_gn(), dense_gn()
+    monkeypatch.setenv("DOGLEG_AMD_DEBUG_HANDOFF_TIMEOUT", "1")
+    with pytest.raises(capi.DlgError, match="hand-off"):
+        sparse_gn()
+    with pytest.raises(capi.DlgError, match="hand-off"):
+        dense_gn()
+    prm = oa.default_params()
+    prm.max_iterations = 5
+    r, _, _ = capi.optimize("sparse", p, prob.N, prob.M, prob.nnz, prob.cb, prob.cookie, prm)
+    assert r == -1.0
+    r, _, _ = capi.optimize("dense", dp.p0(), dp.N, dp.M, 0, dp.cb, dp.cookie, prm)
+    assert r == -1.0
+    monkeypatch.delenv("DOGLEG_AMD_DEBUG_HANDOFF_TIMEOUT")
+    assert sparse_gn() == ref_s and dense_gn() == ref_d          # and nothing sticks to the library
