@@ -99,6 +99,11 @@ int  dlg_backend_set_partition(dlg_backend_t* b, int rank, int nranks);   /* bef
 /* after dlg_sparse_set_pattern: the measurement rows this rank holds (ascending); dlg_point_upload /
  * dlg_point_bind_device expect x and the values of Jt for exactly these rows, in this order */
 int  dlg_partition_rows(dlg_backend_t* b, int* nrows, const int** rows);
+/* x and the values of Jt for ALL rows are on the device (a model evaluated there, colptr = the full pattern's
+ * column pointers on the host): gather this rank's rows into the slot's own buffers, in the order of
+ * dlg_partition_rows, and bind them as the slot's inputs (a kernel on the backend's stream, no host copy) */
+int  dlg_point_gather_device(dlg_backend_t* b, int slot, const double* x_full_dev, const double* J_full_dev,
+                             const int* colptr_host);
 /* stats[] = {cut level, supernodes above the cut, supernodes of this rank, rows of this rank,
  * doubles summed per factorisation (panels above the cut + update matrices crossing it),
  * doubles of the whole panel buffer, non-zeros of this rank} */
@@ -111,6 +116,7 @@ int  dlg_sparse_partition_probe(int N, int M, const int* colptr, const int* rowi
 int  dlg_rccl_unique_id(void* out128);
 int  dlg_backend_init_rccl(dlg_backend_t* b, int rank, int nranks, const void* unique_id128);
 int  dlg_backend_set_rccl(dlg_backend_t* b, void* nccl_comm);            /* adopt a caller-owned ncclComm_t */
+int  dlg_backend_share_rccl(dlg_backend_t* b, dlg_backend_t* owner);     /* ... the one another backend of this process made (it keeps owning it) */
 int  dlg_backend_comm_size(dlg_backend_t* b, int* nranks);               /* what RCCL reports (1 without RCCL) */
 
 /* ---- sparse pattern: replaces cholmod_analyze (dogleg.c:650-654).  The

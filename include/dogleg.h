@@ -237,6 +237,36 @@ double dogleg_optimize_device2(double* p, unsigned int Nstate,
                                const dogleg_parameters2_t* parameters,
                                dogleg_solverContext_t** returnContext);
 
+/* Multi-GPU (the reference is single-threaded CPU code; its row sums dogleg.c:253-260, 269-278, 712-714 are
+ * what is split).  One process per GPU; EVERY rank calls dogleg_optimize* / dogleg_optimize_device2 with the
+ * same arguments and the same callback.  The callback keeps its contract -- it evaluates ALL measurement
+ * rows at the p it is given (every rank sees the same p: the sums over the ranks leave identical bits
+ * everywhere) --; the library takes from it the rows of its rank (sparse: those the subtree partition of
+ * the elimination tree assigns, include/dlg_backend.h; dense: a contiguous slice), assembles / factors /
+ * solves its share and sums Jt*x, the top of the tree (dense: JtJ), the solution and two scalars per step
+ * over the ranks.  p, the return value, the iterate sequence and a returned context are the same on every
+ * rank (the vectors of a returned context are complete; dogleg_amd_rank tells a rank which one it is).
+ * dense-products solves have no rows to split: every rank does all of it (replicas).
+ *
+ * How a solve finds its communicator, in this order:
+ *   dogleg_amd_set_communicator   per calling thread, before the solve: rank, ranks, the GPU (device index,
+ *       -1: the current one) and the 128-byte RCCL id rank 0 made with dogleg_amd_rccl_unique_id and handed
+ *       to the others by any means (MPI_Bcast, a file ...).  The sums are ncclAllReduce calls on the
+ *       solve's own stream.
+ *   dogleg_amd_set_allreduce      ... with the caller's sum-all-reduce over `count` doubles at a device
+ *       address instead of RCCL (MPI, or the in-process sum the single-GPU tests use); host-synchronous.
+ *   the environment               DOGLEG_AMD_WORLD_SIZE > 1, DOGLEG_AMD_RANK, DOGLEG_AMD_LOCAL_RANK (the GPU,
+ *       default: the rank), DOGLEG_AMD_RCCL_ID_FILE (a path all ranks see: rank 0 writes the id there,
+ *       the others wait for it): a program that was only re-linked against this library, started once
+ *       per GPU by a launcher, needs no source change.  The communicator is made once per process.
+ * All return 0 on success, -1 on bad arguments. */
+typedef int (*dogleg_amd_allreduce_t)(void* buf_dev, size_t count, void* cookie);
+int  dogleg_amd_set_communicator(int rank, int nranks, int device, const void* rccl_unique_id128);
+int  dogleg_amd_set_allreduce(int rank, int nranks, int device, dogleg_amd_allreduce_t fn, void* cookie);
+void dogleg_amd_clear_communicator(void);
+int  dogleg_amd_rccl_unique_id(void* out128);
+int  dogleg_amd_rank(const dogleg_solverContext_t* ctx, int* nranks);
+
 /* the device backend (include/dlg_backend.h) behind a returned context, and the backend slot of
  * one of its operating points: what dlg_solve_with_factor / dlg_solve_multi /
  * dlg_pseudoinverse_chunk / dlg_point_download need to work with the factor and the vectors that

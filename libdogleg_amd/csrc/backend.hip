@@ -184,7 +184,7 @@ extern "C" int dlg_backend_create(dlg_backend_t** out, int solve_type, int Nstat
     TRY_HIP(hipMalloc(&S.p,      sizeof(double)*N));
     TRY_HIP(hipMalloc(&S.Jt_x,   sizeof(double)*N));
     TRY_HIP(hipMalloc(&S.cauchy, sizeof(double)*N));
-    TRY_HIP(hipMalloc(&S.gn,     sizeof(double)*N));
+    TRY_HIP(hipMalloc(&S.gn,     sizeof(double)*(N + 8)));      // (+ room for a scalar behind the vector: sparse_solve, fold_scalar)
     TRY_HIP(hipMalloc(&S.step,   sizeof(double)*N));
     TRY_HIP(hipMemsetAsync(S.p, 0, sizeof(double)*N, b->stream));
     TRY_HIP(hipMemsetAsync(S.step, 0, sizeof(double)*N, b->stream));
@@ -254,8 +254,8 @@ extern "C" int dlg_backend_set_shard(dlg_backend_t* b, int row0, int row1, dlg_a
   if(b->type == DLG_SPARSE && b->sym)
   { dlg_set_error("set the shard before dlg_sparse_set_pattern"); return DLG_ERR_STATE; }
   b->row0 = row0; b->row1 = row1; b->mloc = row1 - row0;
-  if(fn) { b->allreduce = fn; b->allreduce_cookie = cookie; }
-  if(b->sharded()) b->host_finals = false;          // sums over the ranks act on device scalars: they must be final on the device
+  b->allreduce = fn; b->allreduce_cookie = fn ? cookie : nullptr;      // (fn == NULL: no hook -- RCCL, or a single rank again)
+  b->host_finals = b->sharded() ? false : getenv("DOGLEG_AMD_DEVICE_FINALS") == nullptr;   // sums over the ranks act on device scalars: they must be final on the device
   return DLG_OK;
 }
 
@@ -287,6 +287,7 @@ extern "C" int dlg_backend_set_partition(dlg_backend_t* b, int rank, int nranks)
 
 // ---- RCCL, loaded on demand: the library itself does not depend on librccl.so ----------------
 #include <dlfcn.h>
+#include <mutex>
 namespace {
 struct dlg_nccl_id { char internal[128]; };        // ncclUniqueId
 struct RcclApi
@@ -300,8 +301,10 @@ struct RcclApi
   int (*CommCount)(void*, int*) = nullptr;
 };
 RcclApi g_rccl;
+std::mutex g_rccl_mu;
 int rccl_load()
 {
+  std::lock_guard<std::mutex> lk(g_rccl_mu);       // backends on several threads may ask at once
   if(g_rccl.lib) return DLG_OK;
   const char* names[] = { "librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so" };
   void* h = nullptr;
@@ -352,9 +355,16 @@ extern "C" int dlg_backend_set_rccl(dlg_backend_t* b, void* nccl_comm)
 {
   if(!b || !nccl_comm) { dlg_set_error("dlg_backend_set_rccl: bad arguments"); return DLG_ERR_ARG; }
   DLG_CHECK(rccl_load());
+  rccl_release(b);                                  // a communicator the backend made itself is not leaked
   b->rccl_comm = nccl_comm; b->rccl_owned = false;
   b->host_finals = false;
   return DLG_OK;
+}
+// the communicator of another backend of this process (which keeps owning it and must outlive b)
+extern "C" int dlg_backend_share_rccl(dlg_backend_t* b, dlg_backend_t* owner)
+{
+  if(!b || !owner || !owner->rccl_comm) { dlg_set_error("dlg_backend_share_rccl: the owner has no communicator"); return DLG_ERR_ARG; }
+  return dlg_backend_set_rccl(b, owner->rccl_comm);
 }
 extern "C" int dlg_backend_comm_size(dlg_backend_t* b, int* nranks)
 {
@@ -560,7 +570,11 @@ static int cauchy_enqueue(dlg_backend* b, int s, double* sc)
 // that event and the main stream waits for them before anything reads the Cauchy step.
 static int cauchy_fork_begin(dlg_backend* b)
 {
-  b->want_fork = b->overlap && b->aux_stream && !b->sharded() && !b->knobs.no_k3_fork;    // (one communicator: its collectives stay on one stream)
+  // (one communicator: its collectives stay on ONE stream.  Subtree partition: the pass over J forks off, its
+  // scalar is summed over the ranks with the solution on the main stream -- cauchy_fork_enqueue; the other
+  // sharded forms keep the Cauchy step in line)
+  const bool part = b->type == DLG_SPARSE && b->part_nranks > 1;
+  b->want_fork = b->overlap && b->aux_stream && (!b->sharded() || part) && !b->knobs.no_k3_fork;
   b->fork_recorded = false; b->fork_gate = nullptr;
   return DLG_OK;
 }
@@ -587,13 +601,43 @@ static int cauchy_fork_enqueue(dlg_backend* b, int s, double* sc)
   else     DLG_HIP(hipStreamWaitEvent(b->aux_stream, b->ev_fork, 0));
   hipStream_t main_stream = b->stream;
   b->stream = b->aux_stream;
-  const int rc = cauchy_enqueue(b, s, sc);
+  int rc;
+  if(b->sharded())
+  {
+    // the rank's share of |J g|^2 only; its sum over the ranks rides with the solution (sparse_solve), the rest
+    // of the Cauchy step follows there (cauchy_deferred_finish)
+    DlgProfScope ps(b, DLG_PROF_K3K8_NORM2JV);
+    rc = sparse_norm2_Jv(b, s, b->slot[s].Jt_x, sc + 1);
+    b->fold_scalar = sc + 1; b->fold_result = nullptr; b->fold_cauchy_out = sc + 2;
+  }
+  else rc = cauchy_enqueue(b, s, sc);
   b->stream = main_stream;
   DLG_CHECK(rc);
   DLG_HIP(hipEventRecord(b->ev_join, b->aux_stream));
   DLG_HIP(hipStreamWaitEvent(b->stream, b->ev_join, 0));
   if(b->type == DLG_SPARSE) DLG_CHECK(sparse_touch_factor(b, b->aux_stream));     // (behind the join: a hint nobody waits for)
   return DLG_OK;
+}
+
+// behind the solve that carried the Cauchy step's scalar through its sum over the ranks
+static int cauchy_deferred_finish(dlg_backend* b, int s)
+{
+  if(!b->fold_cauchy_out) return DLG_OK;
+  double* out = b->fold_cauchy_out;
+  b->fold_cauchy_out = nullptr;
+  const double* jg2 = b->fold_result;
+  if(!jg2)
+  {
+    // (the solve had no sum over the ranks to offer: the scalar gets its own)
+    double* own = const_cast<double*>(b->fold_scalar);
+    b->fold_scalar = nullptr;
+    if(!own) { dlg_set_error("internal error: the Cauchy step's scalar was lost"); return DLG_ERR_STATE; }
+    DLG_CHECK(dlg_allreduce_dev(b, own, 1));
+    jg2 = own;
+  }
+  b->fold_result = nullptr;
+  DlgSlot& S = b->slot[s];
+  return k_cauchy_finish(b, S.Jt_x, S.norm2_jtx, jg2, S.cauchy, b->N, out);
 }
 
 extern "C" int dlg_cauchy(dlg_backend_t* b, int s, double* norm2_updateCauchy)
@@ -706,6 +750,7 @@ static int gauss_newton_impl(dlg_backend_t* b, int s, double* lambda_io, double*
       if(b->type == DLG_SPARSE) DLG_CHECK(sparse_solve(b, S.Jt_x, S.gn));
       else                      DLG_CHECK(dense_solve(b, S.Jt_x, S.gn));
     }
+    DLG_CHECK(cauchy_deferred_finish(b, s));
     DLG_CHECK(k_negate_norm2(b, S.gn, b->N, b->d_scal));      // dogleg.c:862-865
     DLG_CHECK(dlg_fetch_scalars(b, dlg_backend::NSCAL));      // the one synchronisation (the sparse pivot flag rides in the last slot)
     if(b->profiling) dlg_prof_resolve(b);
@@ -927,6 +972,7 @@ extern "C" int dlg_take_step(dlg_backend_t* b, int from, int to, double trustreg
       if(b->type == DLG_SPARSE) DLG_CHECK(sparse_solve(b, F.Jt_x, F.gn));
       else                      DLG_CHECK(dense_solve(b, F.Jt_x, F.gn));
     }
+    DLG_CHECK(cauchy_deferred_finish(b, from));
     int nbg = 0;
     {
       DlgProfScope ps(b, DLG_PROF_K7_STEP);

@@ -137,6 +137,10 @@ struct dlg_backend
   void* rccl_comm = nullptr;  // ncclComm_t
   bool  rccl_owned = false;
   double* d_red = nullptr;    // fused reduce buffer [Jt_x | norm2_x | ...]
+  // subtree partition: the Cauchy step's pass over the rank's rows runs on the second stream beside the
+  // factorisation and leaves |J g|^2 of those rows in fold_scalar; the sum over the ranks is made together
+  // with the solution's (sparse_solve -> fold_result = where the sum is), k_cauchy_finish follows on the main stream
+  const double* fold_scalar = nullptr; const double* fold_result = nullptr; double* fold_cauchy_out = nullptr;
   bool sharded() const { return allreduce != nullptr || rccl_comm != nullptr; }
 
   // optional per-phase timing with HIP events on b->stream (dlg_backend_set_profiling)

@@ -15,6 +15,8 @@
 #include <cmath>
 #include <new>
 #include <chrono>
+#include <string>
+#include <time.h>
 #include "../../include/dogleg.h"
 #include "../../include/dlg_backend.h"
 #include "../../include/dlg_trace.h"
@@ -44,6 +46,22 @@ dogleg_parameters2_t g_params = k_defaults;    // the legacy process-global set 
 
 thread_local dlg_trace_t* t_trace = nullptr;
 
+// ---- multi-GPU behind dogleg.h (include/dogleg.h, "multi-GPU"): one process -- or, in the single-GPU
+// tests, one host thread -- per rank calls dogleg_optimize* with the same arguments; the communicator a
+// solve uses is the calling thread's (dogleg_amd_set_communicator / _set_allreduce) or comes from the
+// environment (DOGLEG_AMD_WORLD_SIZE ...: a re-linked libdogleg program under a launcher, no source change).
+struct Comm
+{
+  int rank = 0, nranks = 1, device = -1;
+  bool have_id = false; unsigned char id[128];
+  dlg_allreduce_fn fn = nullptr; void* cookie = nullptr;
+  bool set = false;
+};
+thread_local Comm t_comm;
+// the environment contract: the RCCL communicator is made once per process and adopted by every solve
+struct EnvComm { bool tried = false, ok = false; int rank = 0, nranks = 1, device = -1; dlg_backend_t* holder = nullptr; };
+EnvComm g_env_comm;
+
 struct Driver
 {
   dogleg_solverContext_t pub;                  // MUST be first: the API hands out &pub
@@ -63,7 +81,11 @@ struct Driver
   bool check_pattern;
   int *pat_p, *pat_i;
   bool expect_gn;                              // the last step needed the Gauss-Newton step: issue it with the Cauchy step
-  bool sharded;                                // an all-reduce hook is installed: the host sits between the ops
+  bool sharded;                                // this solve is one rank of several (subtree partition / row shard + all-reduces)
+  int rank, nranks, row0, row1;                // its rank; dense: the contiguous rows it holds
+  const int* part_rows; int part_nrows;        // sparse: the measurement rows the partition gave this rank (dlg_partition_rows)
+  double *x_loc, *J_loc;                       // page-locked staging of the rank's rows of x / values of Jt (host callback)
+  double *x_full_dev, *J_full_dev;             // sparse device callback on a rank: it evaluates ALL rows here, the rank's are gathered
   // device-side evaluation (dogleg_optimize_device2): the model runs on the GPU, x / J never cross PCIe
   dogleg_callback_device_t* f_device;
   const int *dev_cp, *dev_ri;                  // the caller's pattern (host), valid during the call
@@ -231,6 +253,22 @@ void free_point(Driver* d, int s)
   d->pts[s] = nullptr;
 }
 
+// sparse, one rank of several: the rows the subtree partition gave this rank (known once the pattern is set)
+// and the page-locked staging for them
+bool rank_rows(Driver* d, const int* cp)
+{
+  if(!d->sharded || d->pub.solve_type != DOGLEG_SPARSE || d->part_rows) return true;
+  if(!be_ok(dlg_partition_rows(d->be, &d->part_nrows, &d->part_rows), "partition rows")) return false;
+  if(!d->part_rows) { static const int none = 0; d->part_rows = &none; }
+  if(d->f_device) return true;
+  size_t nv = 0;
+  for(int i = 0; i < d->part_nrows; i++) nv += (size_t)(cp[d->part_rows[i] + 1] - cp[d->part_rows[i]]);
+  d->x_loc = (double*)dlg_host_alloc(sizeof(double)*(size_t)(d->part_nrows ? d->part_nrows : 1));
+  d->J_loc = (double*)dlg_host_alloc(sizeof(double)*(nv ? nv : 1));
+  if(!d->x_loc || !d->J_loc) { MSG("out of (pinned) host memory"); return false; }
+  return true;
+}
+
 // dogleg.c:1004-1083
 bool eval_point(bool* converged, dogleg_operatingPoint_t* pt, Driver* d)
 {
@@ -249,11 +287,30 @@ bool eval_point(bool* converged, dogleg_operatingPoint_t* pt, Driver* d)
       if(!be_ok(dlg_sparse_set_pattern(d->be, d->dev_cp, d->dev_ri), "sparse symbolic analysis")) return false;
       d->pattern_set = true;
     }
+    if(!rank_rows(d, d->dev_cp)) return false;
     const double* p_dev = (const double*)dlg_point_device_ptr(d->be, s, DLG_VEC_P);
     double* x_dev = (double*)dlg_point_device_ptr(d->be, s, DLG_VEC_X_OWN);
     double* J_dev = (double*)dlg_point_device_ptr(d->be, s, DLG_VEC_J_OWN);
-    (*d->f_device)(p_dev, x_dev, J_dev, dlg_backend_get_stream(d->be), ctx->cookie);
-    if(!be_ok(dlg_point_bind_device(d->be, s, x_dev, J_dev), "bind")) return false;
+    if(d->sharded && ctx->solve_type == DOGLEG_SPARSE)
+    {
+      // one rank of several: the callback evaluates ALL rows (its contract does not know about ranks) into
+      // buffers of the full size, the rank's rows are gathered on the device
+      if(!d->x_full_dev)
+      {
+        d->x_full_dev = (double*)dlg_mem_alloc(sizeof(double)*(size_t)ctx->Nmeasurements);
+        d->J_full_dev = (double*)dlg_mem_alloc(sizeof(double)*(size_t)d->nnz);
+        if(!d->x_full_dev || !d->J_full_dev) { MSG("out of device memory"); return false; }
+      }
+      (*d->f_device)(p_dev, d->x_full_dev, d->J_full_dev, dlg_backend_get_stream(d->be), ctx->cookie);
+      if(!be_ok(dlg_point_gather_device(d->be, s, d->x_full_dev, d->J_full_dev, d->dev_cp), "gather of the rank's rows")) return false;
+    }
+    else
+    {
+      (*d->f_device)(p_dev, x_dev, J_dev, dlg_backend_get_stream(d->be), ctx->cookie);
+      // (dense on a rank: its rows are a contiguous slice of what the callback wrote)
+      const size_t r0 = d->sharded ? (size_t)d->row0 : 0;
+      if(!be_ok(dlg_point_bind_device(d->be, s, x_dev + r0, J_dev + r0*(size_t)ctx->Nstate), "bind")) return false;
+    }
     if(ctx->solve_type == DOGLEG_SPARSE) dlg_backend_set_speculation(d->be, d->expect_gn);
     if(!be_ok(dlg_point_eval(d->be, s, &norm2x, &absmax), "Jt*x")) return false;
     pt->norm2_x = norm2x;
@@ -279,6 +336,24 @@ bool eval_point(bool* converged, dogleg_operatingPoint_t* pt, Driver* d)
             (memcmp(d->pat_p, cp, sizeof(int)*((size_t)ctx->Nmeasurements + 1)) ||
              memcmp(d->pat_i, ri, sizeof(int)*(size_t)d->nnz)))
     { MSG("the sparsity pattern of Jt changed between evaluations; it must stay fixed (reference dogleg.c:648-649)"); return false; }
+    if(!rank_rows(d, cp)) return false;
+    if(d->sharded)
+    {
+      // one rank of several: the callback evaluated all rows (its contract does not know about ranks); the
+      // rank's rows -- those the subtree partition gave it, in that order -- go to the device
+      const double* Jv = (const double*)pt->Jt->x;
+      size_t q = 0;
+      for(int i = 0; i < d->part_nrows; i++)
+      {
+        const int r = d->part_rows[i];
+        d->x_loc[i] = pt->x[r];
+        const size_t n = (size_t)(cp[r+1] - cp[r]);
+        memcpy(d->J_loc + q, Jv + cp[r], sizeof(double)*n);
+        q += n;
+      }
+      if(!be_ok(dlg_point_upload(d->be, s, d->x_loc, d->J_loc), "upload")) return false;
+    }
+    else
     if(!be_ok(dlg_point_upload(d->be, s, pt->x, (const double*)pt->Jt->x), "upload")) return false;
     // once steps need the Gauss-Newton step an accepted point is factorised next: its JtJ is assembled
     // beside Jt*x (an unused assembly -- a rejected point -- is simply dropped; no number changes)
@@ -290,7 +365,9 @@ bool eval_point(bool* converged, dogleg_operatingPoint_t* pt, Driver* d)
   else if(ctx->solve_type == DOGLEG_DENSE)
   {
     (*ctx->f_dense)(pt->p, pt->x, pt->J_dense, ctx->cookie);
-    if(!be_ok(dlg_point_upload(d->be, s, pt->x, pt->J_dense), "upload")) return false;
+    // (a rank of several: its contiguous rows of what the callback wrote)
+    const size_t r0 = d->sharded ? (size_t)d->row0 : 0;
+    if(!be_ok(dlg_point_upload(d->be, s, pt->x + r0, pt->J_dense + r0*(size_t)ctx->Nstate), "upload")) return false;
     if(!be_ok(dlg_point_eval(d->be, s, &norm2x, &absmax), "Jt*x")) return false;
     pt->norm2_x = norm2x;
     pt->have_x = pt->have_J = pt->have_Jtx = true;
@@ -414,7 +491,7 @@ bool take_step(double* expectedImprovement, dogleg_operatingPoint_t* to,
   int kind;
   double n2 = 0, k = NAN, amax = 0;
   const bool fresh = !from->have_updateCauchy && !from->have_updateGN && !from->have_factorization;
-  if(d->expect_gn && fresh && !d->sharded)
+  if(d->expect_gn && fresh)
   {
     if(!from->have_Jtx) { MSG("Cauchy step needs Jt_x, which is missing"); return false; }
     if(ctx->solve_type == DOGLEG_DENSE_PRODUCTS ? !from->have_JtJ : !from->have_J)
@@ -590,10 +667,65 @@ void destroy(Driver* d)
   if(!d) return;
   free_point(d, 0); free_point(d, 1);
   if(d->pub.solve_type != DOGLEG_SPARSE) free(d->pub.factorization_dense);
+  if(d->x_full_dev) dlg_mem_free(d->x_full_dev);
+  if(d->J_full_dev) dlg_mem_free(d->J_full_dev);
+  if(d->x_loc) dlg_host_free(d->x_loc);
+  if(d->J_loc) dlg_host_free(d->J_loc);
   if(d->be) dlg_backend_destroy(d->be);
   free(d->factor_handle);
   free(d->pat_p); free(d->pat_i);
   free(d);
+}
+
+// DOGLEG_AMD_WORLD_SIZE (> 1), DOGLEG_AMD_RANK, DOGLEG_AMD_LOCAL_RANK (the GPU; default: the rank),
+// DOGLEG_AMD_RCCL_ID_FILE: rank 0 writes the 128-byte RCCL id there (tmp + rename), the others wait for it.
+// The communicator is made once per process -- a backend that only holds it -- and shared by every solve.
+bool env_communicator(Comm* cm)
+{
+  EnvComm& E = g_env_comm;
+  if(!E.tried)
+  {
+    E.tried = true;
+    const char* ws = getenv("DOGLEG_AMD_WORLD_SIZE");
+    const int n = ws ? atoi(ws) : 1;
+    if(n > 1 || (ws && getenv("DOGLEG_AMD_FORCE_COMM")))
+    {
+      const char* rk = getenv("DOGLEG_AMD_RANK"); const char* lr = getenv("DOGLEG_AMD_LOCAL_RANK");
+      const char* idf = getenv("DOGLEG_AMD_RCCL_ID_FILE");
+      if(!rk || !idf) { MSG("DOGLEG_AMD_WORLD_SIZE=%d needs DOGLEG_AMD_RANK and DOGLEG_AMD_RCCL_ID_FILE", n); return false; }
+      E.rank = atoi(rk); E.nranks = n; E.device = lr ? atoi(lr) : E.rank;
+      if(E.rank < 0 || E.rank >= n) { MSG("DOGLEG_AMD_RANK=%d of %d", E.rank, n); return false; }
+      unsigned char id[128];
+      std::string tmp = std::string(idf) + ".tmp";
+      if(E.rank == 0)
+      {
+        if(dlg_rccl_unique_id(id) != DLG_OK) { MSG("RCCL id: %s", dlg_last_error()); return false; }
+        FILE* f = fopen(tmp.c_str(), "wb");
+        if(!f || fwrite(id, 1, 128, f) != 128) { MSG("cannot write %s", tmp.c_str()); if(f) fclose(f); return false; }
+        fclose(f);
+        if(rename(tmp.c_str(), idf) != 0) { MSG("cannot rename %s", tmp.c_str()); return false; }
+      }
+      else
+      {
+        bool got = false;
+        for(int tries = 0; tries < 1200 && !got; tries++)          // up to 2 minutes
+        {
+          FILE* f = fopen(idf, "rb");
+          if(f) { got = fread(id, 1, 128, f) == 128; fclose(f); }
+          if(!got) { struct timespec ts = {0, 100000000}; nanosleep(&ts, nullptr); }
+        }
+        if(!got) { MSG("rank %d: no RCCL id in %s after 2 minutes", E.rank, idf); return false; }
+      }
+      // (a backend with nothing in it but the communicator: dlg_backend_share_rccl hands it to the solves)
+      if(dlg_backend_create(&E.holder, DLG_DENSE_PRODUCTS, 1, 0, 0, 0, E.device) != DLG_OK ||
+         dlg_backend_init_rccl(E.holder, E.rank, E.nranks, id) != DLG_OK)
+      { MSG("cannot make the process's RCCL communicator: %s", dlg_last_error()); return false; }
+      E.ok = true;
+    }
+  }
+  if(E.tried && !E.ok && getenv("DOGLEG_AMD_WORLD_SIZE") && atoi(getenv("DOGLEG_AMD_WORLD_SIZE")) > 1) return false;
+  if(E.ok) { cm->rank = E.rank; cm->nranks = E.nranks; cm->device = E.device; cm->set = true; }
+  return true;
 }
 
 // dogleg.c:1633-1753
@@ -660,9 +792,34 @@ double optimize(double* p, unsigned int Nstate, unsigned int Nmeas, unsigned int
   int flags = 0;
   if(ctx->parameters->JtJ_packed) flags |= DLG_FLAG_JTJ_PACKED;
   if(ctx->parameters->JtJ_upper)  flags |= DLG_FLAG_JTJ_UPPER;
-  if(dlg_backend_create(&d->be, (int)ctx->solve_type, (int)Nstate, (int)Nmeas, (int)NJnnz, flags, -1) != DLG_OK)
+  // this solve's communicator: the calling thread's, else the environment's, else none (one GPU)
+  Comm cm = t_comm;
+  if(!cm.set && !env_communicator(&cm)) { free(d); return -1.0; }
+  if(dlg_backend_create(&d->be, (int)ctx->solve_type, (int)Nstate, (int)Nmeas, (int)NJnnz, flags, cm.device) != DLG_OK)
   { MSG("cannot create the GPU backend: %s", dlg_last_error()); free(d); return -1.0; }
   lap("backend create (device buffers)");
+  d->rank = cm.rank; d->nranks = cm.nranks; d->row0 = 0; d->row1 = (int)Nmeas;
+  if(cm.set && ctx->solve_type != DOGLEG_DENSE_PRODUCTS)
+  {
+    // Measurement rows are the sharded unit (dogleg.c:253-260, 269-278, 712-714).  Sparse: the subtree
+    // partition of the elimination tree; dense: contiguous rows, JtJ summed.  (dense-products: the
+    // callback has already summed over the rows -- every rank does the same work: replicas.)
+    bool ok = true;
+    if(ctx->solve_type == DOGLEG_SPARSE) ok = be_ok(dlg_backend_set_partition(d->be, cm.rank, cm.nranks), "subtree partition");
+    else
+    {
+      d->row0 = (int)((long)Nmeas*cm.rank/cm.nranks); d->row1 = (int)((long)Nmeas*(cm.rank + 1)/cm.nranks);
+      ok = be_ok(dlg_backend_set_shard(d->be, d->row0, d->row1, nullptr, nullptr), "row shard");
+    }
+    if(ok && g_env_comm.ok && g_env_comm.holder && !cm.have_id && !cm.fn)
+      ok = be_ok(dlg_backend_share_rccl(d->be, g_env_comm.holder), "RCCL communicator of the process");
+    else if(ok && cm.have_id) ok = be_ok(dlg_backend_init_rccl(d->be, cm.rank, cm.nranks, cm.id), "RCCL communicator");
+    else if(ok && cm.fn)      ok = be_ok(dlg_backend_set_allreduce(d->be, cm.fn, cm.cookie), "all-reduce hook");
+    else if(ok) { MSG("a communicator of %d ranks needs an RCCL id or an all-reduce hook", cm.nranks); ok = false; }
+    if(!ok) { destroy(d); return -1.0; }
+    d->sharded = true;
+    lap("communicator");
+  }
 
   if(ctx->solve_type != DOGLEG_SPARSE)
   {
@@ -802,6 +959,31 @@ bool dogleg_computeJtJfactorization(dogleg_operatingPoint_t* point, dogleg_solve
     if(dlg_factor_download_dense(d->be, ctx->factorization_dense, sz) != DLG_OK) return false;
   }
   return true;
+}
+
+// ---- extension (not in the reference): multi-GPU.  See include/dogleg.h.
+int dogleg_amd_set_communicator(int rank, int nranks, int device, const void* rccl_unique_id128)
+{
+  if(nranks < 1 || rank < 0 || rank >= nranks || !rccl_unique_id128) { MSG("dogleg_amd_set_communicator: bad arguments"); return -1; }
+  Comm c; c.rank = rank; c.nranks = nranks; c.device = device; c.have_id = true; memcpy(c.id, rccl_unique_id128, 128); c.set = true;
+  t_comm = c;
+  return 0;
+}
+int dogleg_amd_set_allreduce(int rank, int nranks, int device, dogleg_amd_allreduce_t fn, void* cookie)
+{
+  if(nranks < 1 || rank < 0 || rank >= nranks || !fn) { MSG("dogleg_amd_set_allreduce: bad arguments"); return -1; }
+  Comm c; c.rank = rank; c.nranks = nranks; c.device = device; c.fn = fn; c.cookie = cookie; c.set = true;
+  t_comm = c;
+  return 0;
+}
+void dogleg_amd_clear_communicator(void) { t_comm = Comm(); }
+int dogleg_amd_rccl_unique_id(void* out128) { return dlg_rccl_unique_id(out128) == DLG_OK ? 0 : -1; }
+int dogleg_amd_rank(const dogleg_solverContext_t* ctx, int* nranks)
+{
+  const Driver* d = reinterpret_cast<const Driver*>(ctx);
+  if(!d) return -1;
+  if(nranks) *nranks = d->sharded ? d->nranks : 1;
+  return d->sharded ? d->rank : 0;
 }
 
 // extension (not in the reference): the device backend behind a returned context, for

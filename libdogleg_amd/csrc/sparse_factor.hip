@@ -9,7 +9,7 @@ typedef double dlg_v4d __attribute__((ext_vector_type(4)));
 typedef double dlg_v2d __attribute__((ext_vector_type(2)));
 // -DDLG_FL_PROFILE: phase clocks of workgroup 0 of every factor launch (tools only)
 #ifdef DLG_FL_PROFILE
-constexpr int FL_PROF_WG = 256;       // workgroups per level whose phase clocks are kept
+constexpr int FL_PROF_WG = 1024;       // workgroups per level whose phase clocks are kept
 __device__ long long g_fl_prof[32*FL_PROF_WG*8];
 #define FL_STAMP(k) do { if(threadIdx.x == 0 && blockIdx.x < FL_PROF_WG) g_fl_prof[((prof_lvl & 31)*FL_PROF_WG + blockIdx.x)*8 + (k)] = wall_clock64(); } while(0)      // 100 MHz, one clock for the chip
 #else
@@ -363,7 +363,6 @@ __global__ void __launch_bounds__(NT, LEAF ? 4 : 1) k_factor_level(const FwItem*
     else if(u_lds)  mf_add_children<NT, true >(P, Us, nlin, it.nch, it.ch0, rc, mf_rec, uscr, mf_dst, tid);
     else            mf_add_children<NT, false>(P, Ug, ntri, it.nch, it.ch0, rc, mf_rec, uscr, mf_dst, tid);
   }
-  FL_STAMP(7);
   FL_STAMP(2);
   if(cmp) bd_compact_rows<NT, DS>(Pb, ldp, nloc, w, tid, it.nbd, s_mcol, s_rdiag, Dg);
   else if(LEAF) { }
@@ -451,8 +450,9 @@ __global__ void __launch_bounds__(NT, LEAF ? 4 : 1) k_factor_level(const FwItem*
     __syncthreads();
     if(tid == 0) __hip_atomic_store(pr_flag + blockIdx.x, pr_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-  if(it.rep != 0) { FL_STAMP(5); return; }        // the panel is replica 0's to store
-  for(int i = row0c + tid - cp_g*cp_rows; i < nloc && cp_g < cp_ng; i += cp_rows)
+  FL_STAMP(7);
+  const bool store_panel = it.rep == 0;             // the panel is replica 0's to store
+  for(int i = row0c + tid - cp_g*cp_rows; i < nloc && cp_g < cp_ng && store_panel; i += cp_rows)
   {
     // rows below the top block go back to the panel; the top block too unless the supernode is
     // cut into slices (then slice 0 parks it in top_scr, see k_copy_top) or it was never staged
@@ -475,7 +475,7 @@ __global__ void __launch_bounds__(NT, LEAF ? 4 : 1) k_factor_level(const FwItem*
   FL_STAMP(5);
 #ifdef DLG_FL_PROFILE
   if(threadIdx.x == 0 && blockIdx.x < FL_PROF_WG)
-    g_fl_prof[((prof_lvl & 31)*FL_PROF_WG + blockIdx.x)*8 + 6] = (long long)w | ((long long)nrows << 12) | ((long long)it.nch << 24) | ((long long)(u_lds ? 1 : 0) << 36) | ((long long)(has_u ? 1 : 0) << 37) | ((long long)(it.r1 - it.r0) << 40);
+    g_fl_prof[((prof_lvl & 31)*FL_PROF_WG + blockIdx.x)*8 + 6] = (long long)w | ((long long)nrows << 12) | ((long long)it.nch << 24) | ((long long)(u_lds ? 1 : 0) << 36) | ((long long)(has_u ? 1 : 0) << 37) | ((long long)(it.r1 - it.r0) << 40) | ((long long)(it.rep & 15) << 52) | ((long long)(it.pad & 63) << 56);
 #endif
 }
 // publish the top blocks of the multi-slice supernodes
@@ -1225,6 +1225,7 @@ int sparse_factor_setup(dlg_backend* b)
           for(int r = 0; r < nrep; r++)
           {
             it.rep = r; it.tj0 = (nrep == 1) ? 0 : cut[r]; it.tj1 = (nrep == 1 || r == nrep - 1) ? (1 << 20) : cut[r+1];
+            it.pad = l;          // (the level: for the profile build's dump)
             items.push_back(it);
           }
         }
@@ -1295,13 +1296,13 @@ extern "C" void dlg_fl_profile_dump(int nlevels)
     }
     if(nwg == 0) continue;
     // a persistent launch: the timeline of its last workgroups (the top of the tree), 10 ns units
-    for(int g = FL_PROF_WG - 1, shown = 0; g >= 0 && shown < (getenv("DLG_FL_DUMP_ALL") ? 256 : 20); g--)
+    for(int g = FL_PROF_WG - 1, shown = 0; g >= 0 && shown < (getenv("DLG_FL_DUMP_ALL") ? FL_PROF_WG : 20); g--)
     {
       const long long* q = &h[(l*FL_PROF_WG + g)*8];
       if(q[5] == 0 || q[7] == 0) continue;
       shown++;
-      fprintf(stderr, "   wg %3d (w %3lld rows %4lld nch %lld u_lds %lld): start %6lld children there %6lld panel in %6lld added %6lld factored %6lld tail %6lld flag+stored %6lld\n",
-              g, q[6] & 4095, (q[6] >> 12) & 4095, (q[6] >> 24) & 4095, (q[6] >> 36) & 1, q[0] - t0, q[7] - t0, q[1] - t0, q[2] - t0, q[3] - t0, q[4] - t0, q[5] - t0);
+      fprintf(stderr, "   wg %3d (w %3lld rows %4lld nch %lld u_lds %lld lvl %lld rep %lld): start %6lld flag up %6lld panel in %6lld added %6lld factored %6lld tail %6lld flag+stored %6lld\n",
+              g, q[6] & 4095, (q[6] >> 12) & 4095, (q[6] >> 24) & 4095, (q[6] >> 36) & 1, (q[6] >> 56) & 63, (q[6] >> 52) & 15, q[0] - t0, q[7] - t0, q[1] - t0, q[2] - t0, q[3] - t0, q[4] - t0, q[5] - t0);
     }
     const long long* q = &h[(l*FL_PROF_WG + last)*8];
     fprintf(stderr, "level %2d: %3d wg, span %7lld | last wg %3d (w %3lld rows %4lld slice %4lld nch %2lld u_lds %lld has_u %lld): start +%6lld load %6lld add %6lld factor %6lld tail %6lld store %6lld | mean: load %6.0f add %6.0f factor %6.0f tail %6.0f store %6.0f\n",

@@ -268,6 +268,49 @@ extern "C" int dlg_partition_rows(dlg_backend_t* b, int* nrows, const int** rows
   if(rows) *rows = H.part_rows.data();
   return DLG_OK;
 }
+// A model evaluated on the device for ALL measurement rows (dogleg_optimize_device2 on a rank of a
+// multi-GPU solve): the rank's rows of x and of the values of Jt are gathered, on the device, into the
+// slot's own buffers -- the order dlg_partition_rows reports -- and bound as the slot's inputs.
+namespace {
+__global__ void __launch_bounds__(TPB) k_gather_rows(int mloc, const int* __restrict__ rows, const int* __restrict__ src_off,
+                                                     const int* __restrict__ jp_loc, const double* __restrict__ x_full,
+                                                     const double* __restrict__ J_full, double* __restrict__ x_loc,
+                                                     double* __restrict__ J_loc)
+{
+  // a wave per row: its values are a short contiguous run
+  const int lane = threadIdx.x & 63;
+  for(int i = blockIdx.x*(TPB/64) + (threadIdx.x >> 6); i < mloc; i += gridDim.x*(TPB/64))
+  {
+    const int q0 = jp_loc[i], n = jp_loc[i+1] - q0, so = src_off[i];
+    if(lane == 0) x_loc[i] = x_full[rows[i]];
+    for(int k = lane; k < n; k += 64) J_loc[q0 + k] = J_full[so + k];
+  }
+}
+}
+extern "C" int dlg_point_gather_device(dlg_backend_t* b, int s, const double* x_full_dev, const double* J_full_dev,
+                                       const int* colptr_host)
+{
+  if(!b || s < 0 || s > 1 || !x_full_dev || !J_full_dev || !colptr_host) { dlg_set_error("dlg_point_gather_device: bad arguments"); return DLG_ERR_ARG; }
+  if(b->type != DLG_SPARSE || !b->sym) { dlg_set_error("dlg_point_gather_device: a sparse backend with its pattern set"); return DLG_ERR_STATE; }
+  SparseSym* Y = b->sym; SymHost& H = Y->H;
+  int mloc = 0; const int* rows = nullptr;
+  DLG_CHECK(dlg_partition_rows(b, &mloc, &rows));
+  if(!Y->gat_rows)
+  {
+    std::vector<int> r(rows, rows + mloc), so((size_t)mloc);
+    for(int i = 0; i < mloc; i++) so[i] = colptr_host[rows[i]];
+    DLG_CHECK(upload(Y->gat_rows, r)); Y->allocs.push_back(Y->gat_rows);
+    DLG_CHECK(upload(Y->gat_src, so)); Y->allocs.push_back(Y->gat_src);
+  }
+  (void)H;
+  DlgSlot& S = b->slot[s];
+  if(mloc > 0)
+    hipLaunchKernelGGL(k_gather_rows, dim3(std::min(4096, dlg_cdiv(mloc, TPB/64))), dim3(TPB), 0, b->stream, mloc,
+                       Y->gat_rows, Y->gat_src, Y->Jp, x_full_dev, J_full_dev, S.x, S.J);
+  DLG_LAUNCH_CHECK();
+  return dlg_point_bind_device(b, s, S.x, S.J);
+}
+
 static void partition_stats(const SymHost& H, long* stats, int nstats)
 {
   long ntop = 0, nmine = 0, red = 0;

@@ -98,6 +98,7 @@ struct SparseSym
   double* top_scr = nullptr;
   const double* aug_rhs = nullptr;        // rhs the augmented rows of the current factor were built from
   int *Jp = nullptr, *Ji = nullptr;       // rank-local pattern (row pointers rebased to 0)
+  int *gat_rows = nullptr, *gat_src = nullptr;   // dlg_point_gather_device: the rank's rows, first value of each in the full value array
   int *nv_chunk = nullptr; int n_nv_chunks = 0;   // row runs of <= NV_CHUNK non-zeros for |Jv|^2
   // numeric buffers
   double *Lx = nullptr, *scr = nullptr, *ywork = nullptr, *asm_part = nullptr, *jtx_part = nullptr;

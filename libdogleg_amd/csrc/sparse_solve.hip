@@ -599,10 +599,13 @@ __global__ void __launch_bounds__(TPB) k_touch(const double2* __restrict__ p, si
   { const double2 v = p[i]; acc += v.x + v.y; }
   if(acc == 1.2345678e300) sink[0] = acc;          // (never: keeps the loads)
 }
-__global__ void __launch_bounds__(TPB) k_mask_vec(double* __restrict__ v, const double* __restrict__ mask, int n)
+// (extra: a device scalar that rides behind the vector, at v[n], through the sum over the ranks)
+__global__ void __launch_bounds__(TPB) k_mask_vec(double* __restrict__ v, const double* __restrict__ mask, int n,
+                                                  const double* __restrict__ extra)
 {
   const int i = blockIdx.x*TPB + threadIdx.x;
   if(i < n) v[i] *= mask[i];
+  if(extra && i == 0) v[n] = *extra;
 }
 
 } // namespace
@@ -851,9 +854,15 @@ int sparse_solve(dlg_backend* b, const double* rhs, double* out)
   DLG_LAUNCH_CHECK();
   if(H.part_nranks > 1)
   {
-    hipLaunchKernelGGL(k_mask_vec, dim3(dlg_cdiv(H.N, TPB)), dim3(TPB), 0, st, out, Y->colmask, H.N);
+    // a scalar the caller wants summed over the ranks (the Cauchy step's |J g|^2 of the rank's rows, formed on the
+    // second stream beside the factorisation) rides behind the solution: one collective less per step.
+    // (only into the Gauss-Newton vectors of the slots: they have room behind their N entries)
+    const bool room = out == b->slot[0].gn || out == b->slot[1].gn;
+    const double* extra = room ? b->fold_scalar : nullptr;
+    hipLaunchKernelGGL(k_mask_vec, dim3(dlg_cdiv(H.N, TPB)), dim3(TPB), 0, st, out, Y->colmask, H.N, extra);
     DLG_LAUNCH_CHECK();
-    DLG_CHECK(dlg_allreduce_dev(b, out, (size_t)H.N));
+    DLG_CHECK(dlg_allreduce_dev(b, out, (size_t)H.N + (extra ? 1 : 0)));
+    if(extra) { b->fold_result = out + H.N; b->fold_scalar = nullptr; }
   }
   return DLG_OK;
 }
