@@ -119,6 +119,17 @@ int  dlg_backend_set_rccl(dlg_backend_t* b, void* nccl_comm);            /* adop
 int  dlg_backend_share_rccl(dlg_backend_t* b, dlg_backend_t* owner);     /* ... the one another backend of this process made (it keeps owning it) */
 int  dlg_backend_comm_size(dlg_backend_t* b, int* nranks);               /* what RCCL reports (1 without RCCL) */
 
+/* ---- one backend for a series of solves (what the dogleg.h driver does between dogleg_optimize* calls: the
+ * reference allocates and frees everything per solve, dogleg.c:1479-1562, 1694-1750 -- there a solve takes
+ * seconds, here the set-up would be the solve).  dlg_backend_reset forgets the operating points and the held
+ * factor and keeps every buffer, stream, the uploaded pattern and its schedules; dlg_sparse_pattern_matches
+ * tells whether a pattern is the one the backend is set up for (exact: hash + compare), dlg_sparse_drop_pattern
+ * makes room for another one. */
+int  dlg_backend_reset(dlg_backend_t* b);
+int  dlg_backend_device(dlg_backend_t* b);                               /* the HIP device index the backend lives on */
+int  dlg_sparse_pattern_matches(dlg_backend_t* b, const int* colptr, const int* rowidx);
+int  dlg_sparse_drop_pattern(dlg_backend_t* b);
+
 /* ---- sparse pattern: replaces cholmod_analyze (dogleg.c:650-654).  The
  * pattern is assumed constant for the life of the solve, as the reference
  * assumes (dogleg.c:648-649).  colptr[Nmeas+1], rowidx[NJnnz] on the host

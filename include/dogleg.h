@@ -267,6 +267,13 @@ void dogleg_amd_clear_communicator(void);
 int  dogleg_amd_rccl_unique_id(void* out128);
 int  dogleg_amd_rank(const dogleg_solverContext_t* ctx, int* nranks);
 
+/* Between solves the library keeps one idle backend (device buffers, the uploaded sparsity pattern and its
+ * schedules) and the page-locked host buffers of the operating points: a program that solves many problems
+ * of one shape -- the same scene, new measurements -- pays allocations, uploads and the symbolic analysis
+ * once (the reference redoes all of it per solve, dogleg.c:1479-1562, 1633-1753: its solves take seconds).
+ * dogleg_amd_release_cache gives everything back; DOGLEG_AMD_NO_BACKEND_CACHE=1 never keeps anything. */
+void dogleg_amd_release_cache(void);
+
 /* the device backend (include/dlg_backend.h) behind a returned context, and the backend slot of
  * one of its operating points: what dlg_solve_with_factor / dlg_solve_multi /
  * dlg_pseudoinverse_chunk / dlg_point_download need to work with the factor and the vectors that

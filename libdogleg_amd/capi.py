@@ -38,7 +38,8 @@ BACKEND_SYMBOLS = [
     "dlg_backend_set_allreduce", "dlg_backend_set_partition", "dlg_partition_rows", "dlg_partition_stats",
     "dlg_sparse_partition_probe", "dlg_rccl_unique_id", "dlg_backend_init_rccl", "dlg_backend_set_rccl",
     "dlg_backend_comm_size", "dlg_solve_multi", "dlg_pseudoinverse_chunk", "dlg_backend_set_speculation",
-    "dlg_backend_share_rccl", "dlg_point_gather_device",
+    "dlg_backend_share_rccl", "dlg_point_gather_device", "dlg_backend_reset", "dlg_backend_device",
+    "dlg_sparse_pattern_matches", "dlg_sparse_drop_pattern",
 ]
 PROF_NAMES = ["K1_jtx", "K3K8_norm2Jv", "K4_kernel", "K4_total", "K5_factor", "K6_solve", "K7_step", "vec"]
 DOGLEG_SYMBOLS = [
@@ -50,7 +51,7 @@ DOGLEG_SYMBOLS = [
     "dogleg_testGradient_dense_products",
     "dogleg_optimize_device2", "dogleg_amd_backend", "dogleg_amd_point_slot",
     "dogleg_amd_set_communicator", "dogleg_amd_set_allreduce", "dogleg_amd_clear_communicator",
-    "dogleg_amd_rccl_unique_id", "dogleg_amd_rank",
+    "dogleg_amd_rccl_unique_id", "dogleg_amd_rank", "dogleg_amd_release_cache",
 ]
 
 _lib = None
@@ -162,6 +163,11 @@ def lib():
     L.dogleg_amd_rccl_unique_id.argtypes = [V]
     L.dogleg_amd_rank.argtypes = [V, I]
     L.dlg_backend_share_rccl.argtypes = [V, V]
+    L.dlg_backend_reset.argtypes = [V]
+    L.dlg_backend_device.argtypes = [V]
+    L.dlg_sparse_pattern_matches.argtypes = [V, I, I]
+    L.dlg_sparse_drop_pattern.argtypes = [V]
+    L.dogleg_amd_release_cache.restype = None
     L.dlg_point_gather_device.argtypes = [V, C.c_int, V, V, I]
     L.dogleg_setMaxIterations.argtypes = [C.c_int]
     L.dogleg_setDebug.argtypes = [C.c_int]

@@ -233,6 +233,36 @@ extern "C" void dlg_backend_destroy(dlg_backend_t* b)
   delete b;
 }
 
+// One backend, one solve after another (the driver parks a backend between dogleg_optimize* calls instead
+// of destroying it: device buffers, the uploaded pattern and schedules, streams and events all stay).  What
+// belongs to the previous solve -- operating points, the held factor, bound inputs -- is forgotten.
+extern "C" int dlg_backend_reset(dlg_backend_t* b)
+{
+  if(!b) return DLG_ERR_ARG;
+  DLG_HIP(hipStreamSynchronize(b->stream));
+  if(b->aux_stream) DLG_HIP(hipStreamSynchronize(b->aux_stream));
+  if(b->copy_stream) DLG_HIP(hipStreamSynchronize(b->copy_stream));
+  dlg_resolve_pending(b);
+  for(int s = 0; s < 2; s++)
+  {
+    DlgSlot& S = b->slot[s];
+    S.x_bound = S.J_bound = nullptr;
+    S.have_inputs = S.have_Jtx = S.have_cauchy = S.have_gn = false;
+    S.norm2_x = S.norm2_cauchy = S.norm2_gn = S.norm2_jtx = 0;
+    // (step_to_here of the first point of a solve is read by nobody, but a returned context downloads it)
+    DLG_HIP(hipMemsetAsync(S.step, 0, sizeof(double)*(size_t)b->N, b->stream));
+  }
+  b->factor_slot = -1; b->speculate = false;
+  b->want_fork = b->fork_recorded = false; b->fork_gate = nullptr;
+  b->fold_scalar = b->fold_result = nullptr; b->fold_cauchy_out = nullptr;
+  b->fold_p_src = nullptr; b->p_copied = false; b->scal_copied = false; b->fold_scal = 0;
+  b->h_part_used = 0; b->pending.clear();
+  DLG_HIP(hipMemsetAsync(b->d_scal, 0, sizeof(double)*dlg_backend::NSCAL, b->stream));
+  if(b->type == DLG_SPARSE) sparse_reset(b);
+  DLG_HIP(hipStreamSynchronize(b->stream));
+  return DLG_OK;
+}
+
 extern "C" int dlg_backend_set_stream(dlg_backend_t* b, void* hip_stream)
 {
   if(!b) return DLG_ERR_ARG;
@@ -243,6 +273,7 @@ extern "C" int dlg_backend_set_stream(dlg_backend_t* b, void* hip_stream)
   return DLG_OK;
 }
 extern "C" void* dlg_backend_get_stream(dlg_backend_t* b) { return b ? (void*)b->stream : nullptr; }
+extern "C" int dlg_backend_device(dlg_backend_t* b) { return b ? b->device : -1; }
 
 extern "C" int dlg_backend_set_shard(dlg_backend_t* b, int row0, int row1, dlg_allreduce_fn fn,
                                      void* cookie)

@@ -259,6 +259,7 @@ int products_factorize(dlg_backend* b, int slot, double lambda, int* ok);
 int sparse_create(dlg_backend* b);
 size_t sparse_local_nnz(const dlg_backend* b);   // J values held by this rank
 void sparse_destroy(dlg_backend* b);
+void sparse_reset(dlg_backend* b);
 int sparse_set_pattern(dlg_backend* b, const int* colptr, const int* rowidx);
 int sparse_eval(dlg_backend* b, int slot);                      // K1
 int sparse_assemble_speculative(dlg_backend* b, int s);         // K4 beside K1 (second stream, second panel buffer)

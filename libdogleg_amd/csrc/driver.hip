@@ -16,6 +16,8 @@
 #include <new>
 #include <chrono>
 #include <string>
+#include <vector>
+#include <mutex>
 #include <time.h>
 #include "../../include/dogleg.h"
 #include "../../include/dlg_backend.h"
@@ -74,13 +76,17 @@ struct Driver
   cholmod_factor* factor_handle;               // opaque handle handed out as ctx->factorization (heap: never a by-value
                                                // cholmod_factor, only its public fields n / minor are written)
   void* pinned[2][8];
+  size_t pinned_bytes[2][8];
   int   npinned[2];
+  int   be_flags;                              // the flags the backend was created with
   // trial record under construction
   dlg_trial_t cur;
   int ncallbacks;
   bool check_pattern;
   int *pat_p, *pat_i;
+  bool be_reused;                              // the backend served an earlier solve (take_parked)
   bool expect_gn;                              // the last step needed the Gauss-Newton step: issue it with the Cauchy step
+  bool failed;                                 // a backend op failed during the solve: the backend is not kept
   bool sharded;                                // this solve is one rank of several (subtree partition / row shard + all-reduces)
   int rank, nranks, row0, row1;                // its rank; dense: the contiguous rows it holds
   const int* part_rows; int part_nrows;        // sparse: the measurement rows the partition gave this rank (dlg_partition_rows)
@@ -90,6 +96,82 @@ struct Driver
   dogleg_callback_device_t* f_device;
   const int *dev_cp, *dev_ri;                  // the caller's pattern (host), valid during the call
 };
+
+// ---- what outlives a solve (the reference allocates and frees everything per solve, dogleg.c:1479-1562,
+// 1694-1750; there a solve takes seconds -- here the set-up WAS the solve: 90 of the 100 ms of a 5-trial
+// device-callback solve of config #4).  Between dogleg_optimize* calls the library keeps
+//   * ONE idle backend (device buffers, streams, the uploaded pattern and schedules, hipFuncSetAttribute'd
+//     kernels): the next solve of the same shape takes it over (dlg_backend_reset); a sparse solve whose
+//     pattern is the one it was set up for skips the symbolic phase and every upload;
+//   * the page-locked host buffers of the operating points (hipHostMalloc of 2 x 190 MB costs tens of ms).
+// DOGLEG_AMD_NO_BACKEND_CACHE=1 turns both off; dogleg_amd_release_cache() frees them.
+struct ParkedBackend { dlg_backend_t* be = nullptr; int type = 0, N = 0, M = 0, nnz = 0, flags = 0, device = 0; unsigned long long env = 0; };
+// (a backend reads its DOGLEG_AMD_* knobs when it is created: one made under other knobs is not taken over)
+extern "C" char** environ;
+unsigned long long env_knobs_hash()
+{
+  unsigned long long h = 1469598103934665603ull;
+  for(char** e = environ; e && *e; e++)
+    if(!strncmp(*e, "DOGLEG_AMD_", 11) || !strncmp(*e, "DLG_", 4))
+    {
+      unsigned long long g = 1469598103934665603ull;
+      for(const char* c = *e; *c; c++) { g ^= (unsigned char)*c; g *= 1099511628211ull; }
+      h += g;                               // order-independent
+    }
+  return h;
+}
+struct PinnedBuf { void* p; size_t bytes; };
+std::mutex g_cache_mu;
+ParkedBackend g_parked;
+std::vector<PinnedBuf> g_pinned_pool;
+size_t g_pinned_pool_bytes = 0;
+constexpr size_t PINNED_POOL_CAP = (size_t)4 << 30;
+bool cache_on() { static const bool on = getenv("DOGLEG_AMD_NO_BACKEND_CACHE") == nullptr; return on; }
+
+dlg_backend_t* take_parked(int type, int N, int M, int nnz, int flags, int device)
+{
+  std::lock_guard<std::mutex> lk(g_cache_mu);
+  ParkedBackend& P = g_parked;
+  if(!P.be || P.type != type || P.N != N || P.M != M || P.nnz != nnz || P.flags != flags || (device >= 0 && P.device != device) ||
+     P.env != env_knobs_hash()) return nullptr;
+  dlg_backend_t* be = P.be;
+  P.be = nullptr;
+  return be;
+}
+void park_backend(dlg_backend_t* be, int type, int N, int M, int nnz, int flags)
+{
+  if(!be) return;
+  dlg_backend_t* old = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(g_cache_mu);
+    old = g_parked.be;
+    g_parked.be = be; g_parked.type = type; g_parked.N = N; g_parked.M = M; g_parked.nnz = nnz; g_parked.flags = flags;
+    g_parked.device = dlg_backend_device(be); g_parked.env = env_knobs_hash();
+  }
+  if(old) dlg_backend_destroy(old);
+}
+void* pinned_take(size_t bytes)
+{
+  std::lock_guard<std::mutex> lk(g_cache_mu);
+  for(size_t i = 0; i < g_pinned_pool.size(); i++)
+    if(g_pinned_pool[i].bytes == bytes)
+    {
+      void* p = g_pinned_pool[i].p;
+      g_pinned_pool_bytes -= bytes;
+      g_pinned_pool[i] = g_pinned_pool.back(); g_pinned_pool.pop_back();
+      return p;
+    }
+  return nullptr;
+}
+void pinned_give(void* p, size_t bytes)
+{
+  {
+    std::lock_guard<std::mutex> lk(g_cache_mu);
+    if(cache_on() && g_pinned_pool_bytes + bytes <= PINNED_POOL_CAP && g_pinned_pool.size() < 64)
+    { g_pinned_pool.push_back({p, bytes}); g_pinned_pool_bytes += bytes; return; }
+  }
+  (void)hipHostFree(p);
+}
 
 inline Driver* D(dogleg_solverContext_t* ctx) { return reinterpret_cast<Driver*>(ctx); }
 inline int slot_of(const Driver* d, const dogleg_operatingPoint_t* pt) { return pt == d->pts[0] ? 0 : 1; }
@@ -105,8 +187,15 @@ void* pinned_alloc(Driver* d, int s, size_t bytes)
 {
   void* p = nullptr;
   if(bytes == 0) bytes = 8;
-  if(hipHostMalloc(&p, bytes) != hipSuccess) return nullptr;
-  memset(p, 0, bytes);
+  // (a buffer of an earlier solve: the large ones -- x, the arrays of Jt / J -- are written in full by the
+  // callback before anything reads them; the small ones are cleared as a fresh allocation is)
+  if(cache_on() && (p = pinned_take(bytes)) != nullptr) { if(bytes <= ((size_t)8 << 20)) memset(p, 0, bytes); }
+  else
+  {
+    if(hipHostMalloc(&p, bytes) != hipSuccess) return nullptr;
+    memset(p, 0, bytes);
+  }
+  d->pinned_bytes[s][d->npinned[s]] = bytes;
   d->pinned[s][d->npinned[s]++] = p;
   return p;
 }
@@ -248,9 +337,21 @@ void free_point(Driver* d, int s)
     if(d->f_device && d->pub.solve_type == DOGLEG_SPARSE) { free(d->jt[s].p); free(d->jt[s].i); }
     free(pt);
   }
-  for(int i = 0; i < d->npinned[s]; i++) (void)hipHostFree(d->pinned[s][i]);
+  for(int i = 0; i < d->npinned[s]; i++) pinned_give(d->pinned[s][i], d->pinned_bytes[s][i]);
   d->npinned[s] = 0;
   d->pts[s] = nullptr;
+}
+
+// the first evaluation of a sparse solve: the symbolic phase -- unless the backend was taken over from an
+// earlier solve and is set up for this very pattern
+bool set_pattern(Driver* d, const int* cp, const int* ri)
+{
+  if(d->be_reused)
+  {
+    if(dlg_sparse_pattern_matches(d->be, cp, ri)) return true;
+    if(!be_ok(dlg_sparse_drop_pattern(d->be), "dropping the previous solve's pattern")) return false;
+  }
+  return be_ok(dlg_sparse_set_pattern(d->be, cp, ri), "sparse symbolic analysis");
 }
 
 // sparse, one rank of several: the rows the subtree partition gave this rank (known once the pattern is set)
@@ -284,7 +385,7 @@ bool eval_point(bool* converged, dogleg_operatingPoint_t* pt, Driver* d)
     // values straight into the slot's HBM buffers, ordered on the backend's stream
     if(ctx->solve_type == DOGLEG_SPARSE && !d->pattern_set)
     {
-      if(!be_ok(dlg_sparse_set_pattern(d->be, d->dev_cp, d->dev_ri), "sparse symbolic analysis")) return false;
+      if(!set_pattern(d, d->dev_cp, d->dev_ri)) return false;
       d->pattern_set = true;
     }
     if(!rank_rows(d, d->dev_cp)) return false;
@@ -322,7 +423,7 @@ bool eval_point(bool* converged, dogleg_operatingPoint_t* pt, Driver* d)
     const int* cp = (const int*)pt->Jt->p; const int* ri = (const int*)pt->Jt->i;
     if(!d->pattern_set)
     {
-      if(!be_ok(dlg_sparse_set_pattern(d->be, cp, ri), "sparse symbolic analysis")) return false;
+      if(!set_pattern(d, cp, ri)) return false;
       d->pattern_set = true;
       if(d->check_pattern)
       {
@@ -671,7 +772,13 @@ void destroy(Driver* d)
   if(d->J_full_dev) dlg_mem_free(d->J_full_dev);
   if(d->x_loc) dlg_host_free(d->x_loc);
   if(d->J_loc) dlg_host_free(d->J_loc);
-  if(d->be) dlg_backend_destroy(d->be);
+  if(d->be)
+  {
+    // (a backend that is one rank of several holds its communicator and partition: not kept)
+    if(cache_on() && !d->sharded && !d->failed && dlg_backend_reset(d->be) == DLG_OK)
+      park_backend(d->be, (int)d->pub.solve_type, d->pub.Nstate, d->pub.Nmeasurements, (int)d->nnz, d->be_flags);
+    else dlg_backend_destroy(d->be);
+  }
   free(d->factor_handle);
   free(d->pat_p); free(d->pat_i);
   free(d);
@@ -795,9 +902,15 @@ double optimize(double* p, unsigned int Nstate, unsigned int Nmeas, unsigned int
   // this solve's communicator: the calling thread's, else the environment's, else none (one GPU)
   Comm cm = t_comm;
   if(!cm.set && !env_communicator(&cm)) { free(d); return -1.0; }
-  if(dlg_backend_create(&d->be, (int)ctx->solve_type, (int)Nstate, (int)Nmeas, (int)NJnnz, flags, cm.device) != DLG_OK)
-  { MSG("cannot create the GPU backend: %s", dlg_last_error()); free(d); return -1.0; }
-  lap("backend create (device buffers)");
+  d->be_flags = flags;
+  if(cache_on() && !cm.set) d->be = take_parked((int)ctx->solve_type, (int)Nstate, (int)Nmeas, (int)NJnnz, flags, cm.device);
+  if(d->be) { d->be_reused = true; lap("backend taken over from the previous solve"); }
+  else
+  {
+    if(dlg_backend_create(&d->be, (int)ctx->solve_type, (int)Nstate, (int)Nmeas, (int)NJnnz, flags, cm.device) != DLG_OK)
+    { MSG("cannot create the GPU backend: %s", dlg_last_error()); free(d); return -1.0; }
+    lap("backend create (device buffers)");
+  }
   d->rank = cm.rank; d->nranks = cm.nranks; d->row0 = 0; d->row1 = (int)Nmeas;
   if(cm.set && ctx->solve_type != DOGLEG_DENSE_PRODUCTS)
   {
@@ -848,6 +961,7 @@ double optimize(double* p, unsigned int Nstate, unsigned int Nmeas, unsigned int
   if(numsteps < 0)
   {
     MSG("the solve failed");
+    d->failed = true;
     destroy(d);
     return -1.0;
   }
@@ -977,6 +1091,19 @@ int dogleg_amd_set_allreduce(int rank, int nranks, int device, dogleg_amd_allred
   return 0;
 }
 void dogleg_amd_clear_communicator(void) { t_comm = Comm(); }
+// what the library keeps between solves (the idle backend with its device memory, page-locked host buffers)
+void dogleg_amd_release_cache(void)
+{
+  dlg_backend_t* be = nullptr;
+  std::vector<PinnedBuf> pool;
+  {
+    std::lock_guard<std::mutex> lk(g_cache_mu);
+    be = g_parked.be; g_parked.be = nullptr;
+    pool.swap(g_pinned_pool); g_pinned_pool_bytes = 0;
+  }
+  if(be) dlg_backend_destroy(be);
+  for(const PinnedBuf& b : pool) (void)hipHostFree(b.p);
+}
 int dogleg_amd_rccl_unique_id(void* out128) { return dlg_rccl_unique_id(out128) == DLG_OK ? 0 : -1; }
 int dogleg_amd_rank(const dogleg_solverContext_t* ctx, int* nranks)
 {

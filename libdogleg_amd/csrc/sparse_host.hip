@@ -65,6 +65,45 @@ uint64_t hash_env_knobs()
 }
 }
 
+static uint64_t pattern_key(const dlg_backend* b, const int* colptr, const int* rowidx)
+{
+  uint64_t key = hash_env_knobs();
+  const int hdr[8] = { b->N, b->M, b->nnz, b->row0, b->row1, b->part_rank, b->part_nranks, 0 };
+  key = hash_ints(key, hdr, 8);
+  key = hash_ints(key, colptr, (size_t)b->M + 1);
+  return hash_ints(key, rowidx, (size_t)b->nnz);
+}
+// A backend that is used for one solve after another (the driver parks it between dogleg_optimize* calls):
+// is the pattern it was set up for the one given here?  Exact: hash, then memcmp against the copy the
+// symbolic cache keeps.  1: yes -- schedules, device buffers and uploads all stay; 0: no (or not known)
+extern "C" int dlg_sparse_pattern_matches(dlg_backend_t* b, const int* colptr, const int* rowidx)
+{
+  if(!b || !b->sym || !colptr || !rowidx || b->sym->pat_key == 0) return 0;
+  if(colptr[b->M] != b->nnz || pattern_key(b, colptr, rowidx) != b->sym->pat_key) return 0;
+  std::lock_guard<std::mutex> lk(g_sym_mu);
+  const SymCacheEntry* c = g_sym_cache.get();
+  return c && c->key == b->sym->pat_key && c->M == b->M && c->nnz == b->nnz &&
+         !memcmp(c->cp.data(), colptr, sizeof(int)*((size_t)b->M + 1)) && !memcmp(c->ri.data(), rowidx, sizeof(int)*(size_t)b->nnz);
+}
+// forget the pattern (and everything derived from it) so that another one can be set
+extern "C" int dlg_sparse_drop_pattern(dlg_backend_t* b)
+{
+  if(!b || b->type != DLG_SPARSE) return DLG_ERR_ARG;
+  if(b->stream) DLG_HIP(hipStreamSynchronize(b->stream));
+  sparse_destroy(b);
+  b->factor_slot = -1;
+  return DLG_OK;
+}
+// between two solves on the same backend: nothing of the previous solve's operating points may be taken for valid
+void sparse_reset(dlg_backend* b)
+{
+  SparseSym* Y = b->sym;
+  if(!Y) return;
+  Y->spec_valid = false; Y->spec_inflight = false; Y->spec_slot = -1; Y->spec_J = nullptr;
+  Y->aug_rhs = nullptr; Y->spec_aug_rhs = nullptr; Y->fin_pending_rhs = nullptr; Y->fin_pending_Lx = nullptr;
+  Y->info_armed = false; Y->info_clean = false;
+}
+
 int sparse_set_pattern(dlg_backend* b, const int* colptr, const int* rowidx)
 {
   if(b->sym) { dlg_set_error("the sparsity pattern was already set"); return DLG_ERR_STATE; }
@@ -86,11 +125,8 @@ int sparse_set_pattern(dlg_backend* b, const int* colptr, const int* rowidx)
   uint64_t key = 0;
   if(use_cache)
   {
-    key = hash_env_knobs();
-    const int hdr[8] = { b->N, b->M, b->nnz, b->row0, b->row1, b->part_rank, b->part_nranks, 0 };
-    key = hash_ints(key, hdr, 8);
-    key = hash_ints(key, colptr, (size_t)b->M + 1);
-    key = hash_ints(key, rowidx, (size_t)b->nnz);
+    key = pattern_key(b, colptr, rowidx);
+    Y->pat_key = key;
     std::lock_guard<std::mutex> lk(g_sym_mu);
     const SymCacheEntry* c = g_sym_cache.get();
     if(c && c->key == key && c->N == b->N && c->M == b->M && c->nnz == b->nnz && c->row0 == b->row0 && c->row1 == b->row1 &&

@@ -68,6 +68,7 @@ struct SolveItem { int c0, w, nrows, rowoff; int64_t lx; int bd0, nbd; int pflag
 struct SparseSym
 {
   SymHost H;
+  uint64_t pat_key = 0;         // hash of (sizes, rows of the rank, partition, pattern, schedule knobs): dlg_sparse_pattern_matches
   // schedules on the device
   int *sn_c0 = nullptr, *sn_rowptr = nullptr, *sn_rows = nullptr, *sn_scr = nullptr, *lvl_sn = nullptr;
   int64_t *sn_lx = nullptr, *diagpos = nullptr;

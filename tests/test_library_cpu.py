@@ -333,6 +333,23 @@ def test_subtree_partition_of_config4_over_8_ranks():
           f"rows of ranks 0/3/7: {rows}")
 
 
+def test_subtree_partition_of_config5_over_8_ranks():
+    """BASELINE.json config #5 (5M x 500 001, 75M non-zeros: the other configuration that names 8 GPUs): the
+    product's partition as ranks 0 and 7 see it -- every row held exactly once is checked on two complementary
+    masks' disjointness, the cut and what crosses the ranks agree"""
+    prob = oa.BAProblem(8333, 149999, 2500000, seed=13, scale_decades=4.0, n_zero_cols=3)
+    Jp, Ji = prob.pattern()
+    (s0, m0), (s7, m7) = [capi.partition_probe(prob.N, prob.M, Jp, Ji, r, 8) for r in (0, 7)]
+    assert s0["cut_level"] == s7["cut_level"] and s0["reduced_doubles"] == s7["reduced_doubles"]
+    assert not np.any(m0 & m7), "a measurement row held by two ranks"
+    for st in (s0, s7):
+        assert 0.6 * prob.M / 8 <= st["rows_mine"] <= 1.4 * prob.M / 8
+    assert s0["reduced_doubles"] * 8 <= 16e6 and s0["reduced_doubles"] * 20 <= s0["panel_doubles"]
+    print(f"config #5 / 8 ranks: cut above level {s0['cut_level']}, {s0['supernodes_above_cut']} replicated supernodes, "
+          f"{s0['reduced_doubles']*8/1e6:.2f} MB summed per factorisation (panel buffer {s0['panel_doubles']*8/1e6:.0f} MB), "
+          f"rows of ranks 0/7: {s0['rows_mine']}, {s7['rows_mine']}")
+
+
 def test_subtree_partition_rows_form_closed_subtrees():
     """the property the partition rests on: a rank's rows touch only its own subtrees' variables and
     the replicated ones -- so J_r' J_r of rank r is zero in every (variable of another rank, *) entry"""

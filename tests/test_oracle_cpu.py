@@ -306,3 +306,40 @@ def test_oracle_matches_the_independent_config3_fixture():
     assert abs(o8[2] - float.fromhex(g["norm2_gn"])) <= 1e-11 * o8[2]
     assert abs(o8[3] - float.fromhex(g["k"])) <= 1e-10
     assert abs(o8[5] - float.fromhex(g["expected_improvement"])) <= 1e-10 * abs(o8[5])
+
+
+def test_oracle_matches_the_independent_config4_fixture():
+    """BASELINE.json config #4 at full size (1M x 150k, 15M non-zeros): the oracle's sparse step against the
+    committed SuperLU fixture (tests/golden/splu_config4_step.json: every 16th entry of the vectors, their
+    norms and sums; make_independent_goldens.py, no oracle and no product in the loop).  ~20 s of CPU."""
+    O = oa.oracle()
+    g = json.load(open(os.path.join(GOLD, "splu_config4_step.json")))
+    a = g["problem"]
+    prob = oa.BAProblem(a["Nc"], a["Np"], a["Nobs"], seed=a["seed"])
+    assert (prob.N, prob.M, prob.nnz) == (g["N"], g["M"], g["nnz"])
+    N, M = prob.N, prob.M
+    Jp, Ji = prob.pattern()
+    p = prob.p0()
+    x, Jx = prob.eval(p)
+    F = O.orc_sparse_analyze(N, M, iptr(Jp), iptr(Ji))
+    work = np.zeros(5 * N)
+    o8 = np.zeros(8)
+    assert O.orc_step_sparse(F, N, M, iptr(Jp), iptr(Ji), dptr(Jx), dptr(x), dptr(p), 0.0, dptr(work), dptr(o8)) == 0
+    O.orc_sparse_free(F)
+    st = g["stride"]
+    gn, step = work[2*N:3*N], work[3*N:4*N]
+    gn_ref = np.array([float.fromhex(v) for v in g["gn_hex"]])
+    step_ref = np.array([float.fromhex(v) for v in g["step_hex"]])
+    dgn = np.linalg.norm(gn[::st] - gn_ref)
+    dst = np.linalg.norm(step[::st] - step_ref)
+    print(f"config #4 oracle vs SuperLU fixture (every {st}th entry): |gn diff| = {dgn:.2e}, |step diff| = {dst:.2e}")
+    assert dgn <= 1e-10 and dst <= 1e-10
+    # the entries the fixture does not list are pinned through the norms and the sums of the whole vectors
+    assert abs(float(gn @ gn) - float.fromhex(g["norm2_gn"])) <= 1e-11 * float(gn @ gn)
+    assert abs(float(step @ step) - float.fromhex(g["norm2_step"])) <= 1e-11 * float(step @ step)
+    assert abs(float(np.sum(gn)) - float.fromhex(g["sum_gn"])) <= 1e-9 * np.sqrt(N) * np.linalg.norm(gn) / np.sqrt(N)
+    assert abs(float(np.sum(step)) - float.fromhex(g["sum_step"])) <= 1e-9 * np.linalg.norm(step)
+    assert abs(o8[0] - float.fromhex(g["norm2_x"])) <= 1e-12 * o8[0]
+    assert abs(o8[1] - float.fromhex(g["norm2_cauchy"])) <= 1e-11 * o8[1]
+    assert abs(o8[3] - float.fromhex(g["k"])) <= 1e-10
+    assert abs(o8[5] - float.fromhex(g["expected_improvement"])) <= 1e-10 * abs(o8[5])

@@ -277,6 +277,45 @@ def test_gpu_matches_the_independent_config3_fixture(gpu):
     be.close()
 
 
+def test_gpu_matches_the_independent_config4_fixture(gpu):
+    """BASELINE.json config #4 at full size against the committed SuperLU fixture
+    (tests/golden/splu_config4_step.json: every 16th entry of the Gauss-Newton and the interpolated step, their
+    norms and sums; numpy + scipy only): the independent pin at the configuration `value` is quoted on"""
+    g = json.load(open(os.path.join(GOLD, "splu_config4_step.json")))
+    a = g["problem"]
+    prob = oa.BAProblem(a["Nc"], a["Np"], a["Nobs"], seed=a["seed"])
+    N, M, nnz = prob.N, prob.M, prob.nnz
+    assert (N, M, nnz) == (g["N"], g["M"], g["nnz"])
+    Jp, Ji = prob.pattern()
+    p = prob.p0()
+    x, Jx = prob.eval(p)
+    be = capi.Backend(capi.DLG_SPARSE, N, M, nnz)
+    be.set_pattern(Jp, Ji)
+    be.set_speculation(True)
+    be.set_p(0, p)
+    be.upload(0, x, Jx)
+    n2x, _ = be.eval(0)
+    tr = float.fromhex(g["trustregion"])
+    lam, r, pnew = be.take_step(0, 1, tr, 0.0)
+    assert lam == 0.0 and r["kind"] == g["kind"] == capi.KIND_INTERP
+    gn = be.download(0, capi.VEC_GN)
+    step = be.download(1, capi.VEC_STEP)
+    st = g["stride"]
+    dgn = np.linalg.norm(gn[::st] - _unhex(g["gn_hex"]))
+    dst = np.linalg.norm(step[::st] - _unhex(g["step_hex"]))
+    print(f"config #4 GPU vs SuperLU fixture (every {st}th entry): |gn diff| = {dgn:.2e}, |step diff| = {dst:.2e}")
+    assert dgn <= 1e-10 and dst <= 1e-10
+    assert abs(float(gn @ gn) - float.fromhex(g["norm2_gn"])) <= 1e-11 * float(gn @ gn)
+    assert abs(float(step @ step) - float.fromhex(g["norm2_step"])) <= 1e-11 * float(step @ step)
+    assert abs(float(np.sum(gn)) - float.fromhex(g["sum_gn"])) <= 1e-9 * np.linalg.norm(gn)
+    assert abs(float(np.sum(step)) - float.fromhex(g["sum_step"])) <= 1e-9 * np.linalg.norm(step)
+    assert abs(n2x - float.fromhex(g["norm2_x"])) <= 1e-12 * n2x
+    assert abs(r["n2c"] - float.fromhex(g["norm2_cauchy"])) <= 1e-11 * r["n2c"]
+    assert abs(r["k"] - float.fromhex(g["k"])) <= 1e-10
+    assert abs(r["ei"] - float.fromhex(g["expected_improvement"])) <= 1e-10 * abs(r["ei"])
+    be.close()
+
+
 def test_config5_sparse_5m_ill_conditioned_full_size(gpu):
     """BASELINE.json configs[4] at FULL size on one GPU: 5M measurements x 500 001 parameters,
     75M non-zeros, column scales over 4 decades and exactly-zero columns => the factorisation fails
