@@ -302,12 +302,17 @@ __global__ void __launch_bounds__(NT, LEAF ? 4 : 1) k_factor_level(const FwItem*
   const bool has_u = mode != 0 && top < 0;
   // the update matrix is staged in LDS where it fits: behind the panel, its last columns in the unused
   // strict upper triangle of the top block if need be (it.jsp, sym_w_split)
-  const bool u_lds = has_u && (it.nch > 0 || stage_leaf_u) &&
-                     (cmp ? (size_t)(ldp*w + ntri + 1 + DS*w)*sizeof(double) <= (size_t)FAC_LDS_BUDGET : it.jsp >= 0);   // + the scratch slot of mf_dst
-  const int usp = (u_lds && !cmp) ? it.jsp : mb;          // first column kept up there (mb: none)
-  const int nlin = usp*mb - usp*(usp - 1)/2;              // doubles behind the panel
+  // (sliced: a replica of the one-launch region that keeps only its own columns of the update matrix -- the
+  // packed entries [eA, eB) -- behind the panel; the host sized the LDS for it)
+  const bool sliced = !LEAF && it.sliced != 0;
+  const bool u_lds = has_u && (sliced || ((it.nch > 0 || stage_leaf_u) &&
+                     (cmp ? (size_t)(ldp*w + ntri + 1 + DS*w)*sizeof(double) <= (size_t)FAC_LDS_BUDGET : it.jsp >= 0)));   // + the scratch slot of mf_dst
+  const int usp = (u_lds && !cmp && !sliced) ? it.jsp : mb;          // first column kept up there (mb: none)
+  const int sl_pad = sliced ? (it.eA & 1) : 0;            // (keeps packed index and LDS index of one parity: 16-byte copies)
+  const int nlin = sliced ? it.eB - it.eA + sl_pad : usp*mb - usp*(usp - 1)/2;              // doubles behind the panel
   double* Ug = has_u ? uscr + it.u_off : nullptr;
-  double* Us = P + ldp*w;
+  double* Us = P + ldp*w;                                 // what is behind the panel ...
+  double* Ub = sliced ? Us + sl_pad - it.eA : Us;         // ... addressed by packed index
   double* Dg = Us + (u_lds ? nlin + 1 : 0);
   // (LEAF: members of at most 4 columns, supernodes of at most 64 -- sparse_factor_setup: less LDS per
   // workgroup, which is what lets a fourth one onto the CU)
@@ -381,7 +386,7 @@ __global__ void __launch_bounds__(NT, LEAF ? 4 : 1) k_factor_level(const FwItem*
   {
     const int T = (mb + 15) >> 4;
     const int wv = tid >> 6;
-    double* Ud = u_lds ? Us : Ug;              // in place behind the panel, or straight to the scratch
+    double* Ud = u_lds ? Ub : Ug;              // in place behind the panel, or straight to the scratch
     constexpr int NWV = NT/64;
     constexpr int SY_G = (NT >= 512) ? 6 : 4;
     // (a replica of the one-launch region forms the tile columns [tj0, tj1) only: tiles [tlo, thi) in
@@ -425,13 +430,13 @@ __global__ void __launch_bounds__(NT, LEAF ? 4 : 1) k_factor_level(const FwItem*
       const int eA2 = (eA + 1) & ~1, eB2 = eB & ~1;
       for(int e = eA2 + 2*tid; e < eB2; e += 2*NT)
       {
-        const dlg_v2d v2 = *reinterpret_cast<const dlg_v2d*>(Us + e);
+        const dlg_v2d v2 = *reinterpret_cast<const dlg_v2d*>(Ub + e);
         asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(Ug + e), "v"(v2) : "memory");
       }
-      if(tid == 0 && eA < eA2 && eA < eB) __hip_atomic_store((gwptr_t)(Ug + eA), Us[eA], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if(tid == 1 && eB2 < eB && eB2 >= eA2) __hip_atomic_store((gwptr_t)(Ug + eB2), Us[eB2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if(tid == 0 && eA < eA2 && eA < eB) __hip_atomic_store((gwptr_t)(Ug + eA), Ub[eA], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if(tid == 1 && eB2 < eB && eB2 >= eA2) __hip_atomic_store((gwptr_t)(Ug + eB2), Ub[eB2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    else for(int e = eA + tid; e < eB; e += NT) Ug[e] = Us[e];
+    else for(int e = eA + tid; e < eB; e += NT) Ug[e] = Ub[e];
     // the columns kept in the top block's upper triangle
     for(int jw = max(usp, jA) + (tid >> 6); jw < jB; jw += NT/64)
     {
@@ -1194,8 +1199,16 @@ int sparse_factor_setup(dlg_backend* b)
     {
       const int rmax = std::max(1, std::min(8, env_int_host("DOGLEG_AMD_FRONT_REPLICAS", 4)));
       const int fill = env_int_host("DOGLEG_AMD_FRONT_FILL", ncu/2);
+      const bool slice_ok = !getenv("DOGLEG_AMD_NO_FRONT_SLICES");
       std::vector<FwItem> items;
       std::vector<int> first(H.fw_item.size(), -1), count(H.fw_item.size(), 0);
+      // the region's own children records and destination lists: those of the symbolic phase (whole update
+      // matrix behind the panel), and behind them the lists of the replicas that keep a slice of it
+      std::vector<MfChild> rec(H.mf_rec);
+      std::vector<uint16_t> dst(H.mf_dst);
+      auto lin = [](long j, long mb) { return j*mb - j*(j - 1)/2; };       // packed index of (j, j)
+      long lds_need = lds;
+      acc = false;
       for(int l = Y->pr_level0; l < H.nlevels; l++)
       {
         const int n = H.fw_lvl_ptr[l+1] - H.fw_lvl_ptr[l];
@@ -1204,37 +1217,94 @@ int sparse_factor_setup(dlg_backend* b)
         {
           FwItem it = H.fw_item[i];
           const int mb = it.nrows - it.w, T = (mb + 15) >> 4;
-          // (an update matrix that is summed in HBM -- it.jsp < 0 -- is one workgroup's: atomics)
-          int want = (mb > 0 && it.jsp >= 0 && it.u_off >= 0) ? std::min(rl, T) : 1;
-          // contiguous tile columns, tile counts T - t, the largest share as small as possible
+          const long ldp = (it.nrows + 1) & ~1L, pan = ldp*it.w, room = FAC_LDS_BUDGET/8 - pan - 2;
+          const bool has_w = mb > 0 && it.u_off >= 0;
+          // an update matrix that does not fit LDS whole (it.jsp < 0) fits in slices: two replicas at least
+          int want = has_w ? std::min(rl, T) : 1;
+          if(has_w && it.jsp < 0 && slice_ok) want = std::max(want, std::min(2, T));
           std::vector<int> cut;
-          for(int cap = (T*(T + 1)/2 + want - 1)/std::max(want, 1); ; cap++)
+          int nrep = 1;
+          for(; want <= std::min(8, std::max(T, 1)); want++)
           {
-            cut.assign(1, 0);
-            int load = 0;
-            for(int t = 0; t < T; t++)
+            // contiguous tile columns, tile counts T - t, the largest share as small as possible
+            for(int cap = (T*(T + 1)/2 + want - 1)/std::max(want, 1); ; cap++)
             {
-              if(load > 0 && load + (T - t) > cap) { cut.push_back(t); load = 0; }
-              load += T - t;
+              cut.assign(1, 0);
+              int load = 0;
+              for(int t = 0; t < T; t++)
+              {
+                if(load > 0 && load + (T - t) > cap) { cut.push_back(t); load = 0; }
+                load += T - t;
+              }
+              cut.push_back(T);
+              if((int)cut.size() - 1 <= want) break;
             }
-            cut.push_back(T);
-            if((int)cut.size() - 1 <= want) break;
+            nrep = std::max(1, (int)cut.size() - 1);
+            if(nrep == 1 || !slice_ok) break;
+            bool fits = true;
+            for(int r = 0; r < nrep; r++)
+            {
+              const long jA = std::min<long>(16L*cut[r], mb), jB = std::min<long>(16L*cut[r+1], mb);
+              if(lin(jB, mb) - lin(jA, mb) + 1 > room) fits = false;
+            }
+            if(fits) break;
+            nrep = 1;                                   // (more, narrower slices)
           }
-          const int nrep = std::max(1, (int)cut.size() - 1);
+          if(nrep == 1 || !slice_ok)
+          {
+            // one workgroup (or replicas that each stage the whole update matrix: DOGLEG_AMD_NO_FRONT_SLICES)
+            if(it.jsp < 0) { nrep = 1; if(has_w && it.nch > 0) acc = true; }
+            else if(nrep > 1) { /* whole-W replicas: the kernel's column-range copy-out */ }
+          }
           first[i] = (int)items.size(); count[i] = nrep;
           for(int r = 0; r < nrep; r++)
           {
+            it = H.fw_item[i];
             it.rep = r; it.tj0 = (nrep == 1) ? 0 : cut[r]; it.tj1 = (nrep == 1 || r == nrep - 1) ? (1 << 20) : cut[r+1];
             it.pad = l;          // (the level: for the profile build's dump)
+            if(nrep > 1 && slice_ok)
+            {
+              const long jA = std::min<long>(16L*it.tj0, mb), jB = (r == nrep - 1) ? mb : std::min<long>(16L*it.tj1, mb);
+              const long eA = lin(jA, mb), eB = lin(jB, mb), slp = eA & 1;
+              it.sliced = 1; it.eA = (int)eA; it.eB = (int)eB;
+              lds_need = std::max(lds_need, (pan + slp + (eB - eA) + 2)*8);
+              const long wt = pan + slp, trash = wt + (eB - eA);
+              const int ch0_new = (int)rec.size();
+              for(int k = 0; k < it.nch; k++)
+              {
+                MfChild rc = H.mf_rec[it.ch0 + k];
+                const int c = H.mf_child[it.ch0 + k];
+                const int mc = (H.sn_rowptr[c+1] - H.sn_rowptr[c]) - (H.sn_c0[c+1] - H.sn_c0[c]);
+                const int* map = &H.relpos[H.sn_prel[c]];
+                const int nc = mc*(mc + 1)/2;
+                rc.dst_off = (int64_t)dst.size();
+                rc.rsv = (rc.rsv >= 0 && first[rc.rsv] >= 0) ? (first[rc.rsv] | (count[rc.rsv] << 20)) : -1;
+                dst.reserve(dst.size() + rc.npad);
+                for(int j = 0; j < mc; j++)
+                  for(int q = j; q < mc; q++)
+                  {
+                    const long fi = map[q], fj = map[j], jw = fj - it.w;
+                    const long d = (fj < it.w) ? fi + fj*ldp
+                                 : (jw >= jA && jw < jB) ? wt + (lin(jw, mb) - eA) + (fi - fj) : trash;
+                    dst.push_back((uint16_t)d);
+                  }
+                for(int e = nc; e < rc.npad; e++) dst.push_back((uint16_t)trash);
+                rec.push_back(rc);
+              }
+              it.ch0 = ch0_new;
+            }
             items.push_back(it);
           }
         }
       }
-      std::vector<MfChild> rec(H.mf_rec);
-      for(auto& r : rec) r.rsv = (r.rsv >= 0 && first[r.rsv] >= 0) ? (first[r.rsv] | (count[r.rsv] << 20)) : -1;
+      // (the records of the symbolic phase: the children's workgroups in this launch)
+      for(size_t k = 0; k < H.mf_rec.size(); k++)
+        rec[k].rsv = (rec[k].rsv >= 0 && first[rec[k].rsv] >= 0) ? (first[rec[k].rsv] | (count[rec[k].rsv] << 20)) : -1;
       Y->pr_nwg = (int)items.size();
+      Y->pr_lds = (int)std::max<long>(Y->pr_lds, lds_need);
       if(!Y->pr_item) { DLG_CHECK(upload(Y->pr_item, items)); Y->allocs.push_back(Y->pr_item); }
       if(!Y->pr_rec)  { DLG_CHECK(upload(Y->pr_rec, rec));   Y->allocs.push_back(Y->pr_rec); }
+      if(!Y->pr_dst)  { DLG_CHECK(upload(Y->pr_dst, dst));   Y->allocs.push_back(Y->pr_dst); }
     }
     if(dbg)
       fprintf(stderr, "libdogleg_amd: persistent top region: levels %d..%d of %d (%d supernodes, %d workgroups, %d bytes of LDS, multifrontal from level %d)\n",
@@ -1340,13 +1410,13 @@ int sparse_factor_levels(dlg_backend* b)
       const DlgHandoff ho = dlg_handoff(b, 1 << 21);
       if(Y->fac_nt[l] == 128)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_factor_level<128>), dim3(np), dim3(128), Y->pr_lds, st,
-                           Y->pr_item, Y->pr_rec, Y->sn_bd_col, Y->mf_dst, Y->Lx, Y->top_scr, Y->d_info, Y->uscr, fmode, fl, ep, ho, pacc);
+                           Y->pr_item, Y->pr_rec, Y->sn_bd_col, Y->pr_dst, Y->Lx, Y->top_scr, Y->d_info, Y->uscr, fmode, fl, ep, ho, pacc);
       else if(Y->fac_nt[l] == 256)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_factor_level<256>), dim3(np), dim3(256), Y->pr_lds, st,
-                           Y->pr_item, Y->pr_rec, Y->sn_bd_col, Y->mf_dst, Y->Lx, Y->top_scr, Y->d_info, Y->uscr, fmode, fl, ep, ho, pacc);
+                           Y->pr_item, Y->pr_rec, Y->sn_bd_col, Y->pr_dst, Y->Lx, Y->top_scr, Y->d_info, Y->uscr, fmode, fl, ep, ho, pacc);
       else
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_factor_level<512>), dim3(np), dim3(512), Y->pr_lds, st,
-                           Y->pr_item, Y->pr_rec, Y->sn_bd_col, Y->mf_dst, Y->Lx, Y->top_scr, Y->d_info, Y->uscr, fmode, fl, ep, ho, pacc);
+                           Y->pr_item, Y->pr_rec, Y->sn_bd_col, Y->pr_dst, Y->Lx, Y->top_scr, Y->d_info, Y->uscr, fmode, fl, ep, ho, pacc);
       break;
     }
     if(n > 0)

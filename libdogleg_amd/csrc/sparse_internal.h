@@ -131,7 +131,7 @@ struct SparseSym
   int pr_stage = 0; double* pr_acc = nullptr;   // ... childless supernodes stage their update matrix; shadow scratch for the ones kept in HBM
   int pr_level0 = 1 << 30, pr_lds = 0;   // persistent top region of the factorisation: first level, LDS bytes (sparse_factor_setup)
   int* fac_flag = nullptr; int fac_epoch = 0;   // one flag per workgroup of the region: the epoch of the launch that finished it
-  FwItem* pr_item = nullptr; MfChild* pr_rec = nullptr; int pr_nwg = 0;   // the region's work items (supernode x replica) and its copy of the children records
+  FwItem* pr_item = nullptr; MfChild* pr_rec = nullptr; uint16_t* pr_dst = nullptr; int pr_nwg = 0;   // the region's work items (supernode x replica) and its copy of the children records
   bool fac_ahead = false;       // panel_factor_ahead instead of panel_factor_mfma (DOGLEG_AMD_AHEAD)
   int bwd_xb_cap = 12288;       // below rows of a supernode staged in LDS by the backward solve
   std::vector<void*> allocs;

@@ -1014,7 +1014,7 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
         it.lx = S.sn_lx[s2]; it.top = S.sn_top[s2]; it.u_off = S.u_off[s2];
         it.ch0 = S.mf_cptr[s2]; it.nch = S.mf_cptr[s2+1] - S.mf_cptr[s2];
         it.bdw = 0; it.jsp = sym_w_split(it.w, it.nrows);
-        it.rep = 0; it.tj0 = 0; it.tj1 = 1 << 20; it.pad = 0;
+        it.rep = 0; it.tj0 = 0; it.tj1 = 1 << 20; it.pad = 0; it.sliced = 0; it.eA = 0; it.eB = 0; it.rsv2 = 0;
         if(it.nbd > 0)
         {
           // members of equal width (the usual case: points): no list lookup in the kernel

@@ -176,7 +176,12 @@ struct FwItem
   // one-launch region of the factorisation (sparse_factor_setup): a supernode may be factored by several
   // workgroups ("replicas": identical arithmetic on the whole panel), each of which forms and hands over
   // the 16-column tile columns [tj0, tj1) of the update matrix; replica 0 stores the panel
-  int rep, tj0, tj1, pad;
+  int rep, tj0, tj1, pad;      // pad: the level (profile build's dump)
+  // a replica that keeps only ITS columns of the update matrix in LDS (sliced != 0): the packed entries
+  // [eA, eB) -- columns [16 tj0, 16 tj1) -- sit behind the panel, everything else of the children's update
+  // matrices that is not a panel entry is dropped by its destination lists.  An update matrix that does
+  // not fit LDS whole (a 66-column separator with 139 rows below: 106 KB of panel + 76 KB) fits in slices.
+  int sliced, eA, eB, rsv2;
 };
 // one child of a supernode of the multifrontal region: its update matrix and, entry by entry
 // (packed order, padded to a multiple of 1024 with a scratch slot), where each entry goes
