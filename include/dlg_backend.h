@@ -140,6 +140,13 @@ int  dlg_sparse_set_pattern(dlg_backend_t* b, const int* colptr, const int* rowi
 int  dlg_sparse_stats(dlg_backend_t* b, long* nnz_JtJ_lower, long* nnz_L,
                       int* n_supernodes, int* n_levels, double* factor_flops);
 
+/* host-only (no GPU): the schedule of the one-launch region of the factorisation as a chip with `ncu` compute
+ * units would get it, checked for everything the kernel takes on trust (destinations inside LDS, replicas'
+ * slices covering an update matrix exactly once, children before parents).  stats[] = {first level of the
+ * region, supernodes, workgroups, LDS bytes, workgroups that keep a slice of their update matrix, supernodes
+ * whose update matrix is summed in HBM} */
+int  dlg_sparse_region_probe(int N, int M, const int* colptr, const int* rowidx, int ncu, long* stats, int nstats);
+
 /* launch schedule of the factorisation: the number of levels of the supernodal
  * elimination tree; the first level of the persistent top region (all levels from
  * there on are ONE launch whose workgroups hand their update matrices to their

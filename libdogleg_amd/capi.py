@@ -39,7 +39,7 @@ BACKEND_SYMBOLS = [
     "dlg_sparse_partition_probe", "dlg_rccl_unique_id", "dlg_backend_init_rccl", "dlg_backend_set_rccl",
     "dlg_backend_comm_size", "dlg_solve_multi", "dlg_pseudoinverse_chunk", "dlg_backend_set_speculation",
     "dlg_backend_share_rccl", "dlg_point_gather_device", "dlg_backend_reset", "dlg_backend_device",
-    "dlg_sparse_pattern_matches", "dlg_sparse_drop_pattern",
+    "dlg_sparse_pattern_matches", "dlg_sparse_drop_pattern", "dlg_sparse_region_probe",
 ]
 PROF_NAMES = ["K1_jtx", "K3K8_norm2Jv", "K4_kernel", "K4_total", "K5_factor", "K6_solve", "K7_step", "vec"]
 DOGLEG_SYMBOLS = [
@@ -163,6 +163,7 @@ def lib():
     L.dogleg_amd_rccl_unique_id.argtypes = [V]
     L.dogleg_amd_rank.argtypes = [V, I]
     L.dlg_backend_share_rccl.argtypes = [V, V]
+    L.dlg_sparse_region_probe.argtypes = [C.c_int, C.c_int, I, I, C.c_int, C.POINTER(C.c_long), C.c_int]
     L.dlg_backend_reset.argtypes = [V]
     L.dlg_backend_device.argtypes = [V]
     L.dlg_sparse_pattern_matches.argtypes = [V, I, I]
@@ -264,6 +265,20 @@ def partition_probe(N, M, Jp, Ji, rank, nranks):
     _ck(L.dlg_sparse_partition_probe(N, M, iptr(Jp), iptr(Ji), rank, nranks, st, len(PART_STAT_NAMES),
                                      own.ctypes.data_as(C.c_char_p)), "partition probe")
     return {k: st[i] for i, k in enumerate(PART_STAT_NAMES)}, own.astype(bool)
+
+
+REGION_STAT_NAMES = ["level0", "supernodes", "workgroups", "lds_bytes", "sliced_workgroups", "hbm_update_matrices"]
+
+
+def region_probe(N, M, Jp, Ji, ncu=256):
+    """Host-only: the one-launch region of the factorisation of a pattern on a chip with `ncu` CUs, checked
+    (raises DlgError on a violated invariant).  Returns a dict of REGION_STAT_NAMES."""
+    L = lib()
+    Jp = np.ascontiguousarray(Jp, dtype=np.int32)
+    Ji = np.ascontiguousarray(Ji, dtype=np.int32)
+    st = (C.c_long * len(REGION_STAT_NAMES))()
+    _ck(L.dlg_sparse_region_probe(N, M, iptr(Jp), iptr(Ji), ncu, st, len(REGION_STAT_NAMES)), "region probe")
+    return {k: st[i] for i, k in enumerate(REGION_STAT_NAMES)}
 
 
 def rccl_unique_id():

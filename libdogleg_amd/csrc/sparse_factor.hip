@@ -126,7 +126,7 @@ __device__ __forceinline__ void mf_add_children(double* P, double* Wt, int ntri,
 template <int NCH>
 __device__ __forceinline__ void factor_tail_tiles(const double* Pb, int ldp, int w, int mb, int T, int first,
                                                   double* Ud, int mode, bool w_hbm, bool mf_acc, int lane,
-                                                  int64_t acc_shift, bool st_wt, int usp, double* Pgap)
+                                                  int64_t acc_shift, bool st_wt, int usp, double* Pgap, int ush)
 {
   const int jn = lane & 15, kq = lane >> 4;
   int ti[NCH], tjq[NCH], oa[NCH], ob[NCH];
@@ -220,7 +220,8 @@ __device__ __forceinline__ void factor_tail_tiles(const double* Pb, int ldp, int
   {
     const int j = 16*tjq[q] + jn, jtri = tri_col(j, mb);
     // columns from usp on live in the strict upper triangle of the panel's top block (sym_w_split)
-    double* Uc = (j >= usp) ? Pgap + (mb - j)*ldp - j : Ud + jtri;
+    // (ush: a slice of the update matrix behind the panel starts at packed index -ush)
+    double* Uc = (j >= usp) ? Pgap + (mb - j)*ldp - j : Ud + (jtri + ush);
 #pragma unroll
     for(int r = 0; r < 4; r++)
     {
@@ -312,7 +313,7 @@ __global__ void __launch_bounds__(NT, LEAF ? 4 : 1) k_factor_level(const FwItem*
   const int nlin = sliced ? it.eB - it.eA + sl_pad : usp*mb - usp*(usp - 1)/2;              // doubles behind the panel
   double* Ug = has_u ? uscr + it.u_off : nullptr;
   double* Us = P + ldp*w;                                 // what is behind the panel ...
-  double* Ub = sliced ? Us + sl_pad - it.eA : Us;         // ... addressed by packed index
+  const int ush = sliced ? sl_pad - it.eA : 0;            // ... holds packed index e at Us[e + ush]
   double* Dg = Us + (u_lds ? nlin + 1 : 0);
   // (LEAF: members of at most 4 columns, supernodes of at most 64 -- sparse_factor_setup: less LDS per
   // workgroup, which is what lets a fourth one onto the CU)
@@ -386,7 +387,7 @@ __global__ void __launch_bounds__(NT, LEAF ? 4 : 1) k_factor_level(const FwItem*
   {
     const int T = (mb + 15) >> 4;
     const int wv = tid >> 6;
-    double* Ud = u_lds ? Ub : Ug;              // in place behind the panel, or straight to the scratch
+    double* Ud = u_lds ? Us : Ug;              // in place behind the panel (+ ush), or straight to the scratch
     constexpr int NWV = NT/64;
     constexpr int SY_G = (NT >= 512) ? 6 : 4;
     // (a replica of the one-launch region forms the tile columns [tj0, tj1) only: tiles [tlo, thi) in
@@ -397,18 +398,19 @@ __global__ void __launch_bounds__(NT, LEAF ? 4 : 1) k_factor_level(const FwItem*
     const int rounds = (ntiles + NWV*SY_G - 1)/(NWV*SY_G), nchunks = rounds*NWV;
     const bool w_hbm = mf_acc && !u_lds;
     const bool st_wt = pr_flag != nullptr && !u_lds;
+    const int ush_t = u_lds ? ush : 0;
     const int64_t acc_shift = st_wt ? pr_acc : 0;
     for(int c = wv; c < nchunks; c += NWV)
     {
       const int t0 = tlo + (int)((long)c*ntiles/nchunks), t1 = tlo + (int)((long)(c + 1)*ntiles/nchunks);
       switch(t1 - t0)
       {
-        case 1: factor_tail_tiles<1>(Pb, ldp, w, mb, T, t0, Ud, mode, w_hbm, mf_acc, lane, acc_shift, st_wt, usp, P); break;
-        case 2: factor_tail_tiles<2>(Pb, ldp, w, mb, T, t0, Ud, mode, w_hbm, mf_acc, lane, acc_shift, st_wt, usp, P); break;
-        case 3: factor_tail_tiles<3>(Pb, ldp, w, mb, T, t0, Ud, mode, w_hbm, mf_acc, lane, acc_shift, st_wt, usp, P); break;
-        case 4: factor_tail_tiles<4>(Pb, ldp, w, mb, T, t0, Ud, mode, w_hbm, mf_acc, lane, acc_shift, st_wt, usp, P); break;
-        case 5: if(SY_G >= 5) factor_tail_tiles<(SY_G >= 5 ? 5 : 1)>(Pb, ldp, w, mb, T, t0, Ud, mode, w_hbm, mf_acc, lane, acc_shift, st_wt, usp, P); break;
-        case 6: if(SY_G >= 6) factor_tail_tiles<(SY_G >= 6 ? 6 : 1)>(Pb, ldp, w, mb, T, t0, Ud, mode, w_hbm, mf_acc, lane, acc_shift, st_wt, usp, P); break;
+        case 1: factor_tail_tiles<1>(Pb, ldp, w, mb, T, t0, Ud, mode, w_hbm, mf_acc, lane, acc_shift, st_wt, usp, P, ush_t); break;
+        case 2: factor_tail_tiles<2>(Pb, ldp, w, mb, T, t0, Ud, mode, w_hbm, mf_acc, lane, acc_shift, st_wt, usp, P, ush_t); break;
+        case 3: factor_tail_tiles<3>(Pb, ldp, w, mb, T, t0, Ud, mode, w_hbm, mf_acc, lane, acc_shift, st_wt, usp, P, ush_t); break;
+        case 4: factor_tail_tiles<4>(Pb, ldp, w, mb, T, t0, Ud, mode, w_hbm, mf_acc, lane, acc_shift, st_wt, usp, P, ush_t); break;
+        case 5: if(SY_G >= 5) factor_tail_tiles<(SY_G >= 5 ? 5 : 1)>(Pb, ldp, w, mb, T, t0, Ud, mode, w_hbm, mf_acc, lane, acc_shift, st_wt, usp, P, ush_t); break;
+        case 6: if(SY_G >= 6) factor_tail_tiles<(SY_G >= 6 ? 6 : 1)>(Pb, ldp, w, mb, T, t0, Ud, mode, w_hbm, mf_acc, lane, acc_shift, st_wt, usp, P, ush_t); break;
         default: break;
       }
     }
@@ -430,13 +432,13 @@ __global__ void __launch_bounds__(NT, LEAF ? 4 : 1) k_factor_level(const FwItem*
       const int eA2 = (eA + 1) & ~1, eB2 = eB & ~1;
       for(int e = eA2 + 2*tid; e < eB2; e += 2*NT)
       {
-        const dlg_v2d v2 = *reinterpret_cast<const dlg_v2d*>(Ub + e);
+        const dlg_v2d v2 = *reinterpret_cast<const dlg_v2d*>(Us + (e + ush));
         asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(Ug + e), "v"(v2) : "memory");
       }
-      if(tid == 0 && eA < eA2 && eA < eB) __hip_atomic_store((gwptr_t)(Ug + eA), Ub[eA], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if(tid == 1 && eB2 < eB && eB2 >= eA2) __hip_atomic_store((gwptr_t)(Ug + eB2), Ub[eB2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if(tid == 0 && eA < eA2 && eA < eB) __hip_atomic_store((gwptr_t)(Ug + eA), Us[eA + ush], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if(tid == 1 && eB2 < eB && eB2 >= eA2) __hip_atomic_store((gwptr_t)(Ug + eB2), Us[eB2 + ush], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    else for(int e = eA + tid; e < eB; e += NT) Ug[e] = Ub[e];
+    else for(int e = eA + tid; e < eB; e += NT) Ug[e] = Us[e + ush];
     // the columns kept in the top block's upper triangle
     for(int jw = max(usp, jA) + (tid >> 6); jw < jB; jw += NT/64)
     {
@@ -1009,7 +1011,9 @@ __global__ void __launch_bounds__(TPB) k_update_fin(int f0, const int* __restric
 
 static int env_int_host(const char* n, int d) { const char* v = getenv(n); return v ? atoi(v) : d; }
 // per-level launch parameters of the factor and update kernels
-int sparse_factor_setup(dlg_backend* b)
+// plan_only: everything but the HIP calls (uploads, allocations, function attributes) -- the schedule of the
+// one-launch region is left in Y->pr_*_h for dlg_sparse_region_probe (host-only checks, no GPU)
+int sparse_factor_setup(dlg_backend* b, bool plan_only)
 {
   SparseSym* Y = b->sym;
   const SymHost& H = Y->H;
@@ -1130,7 +1134,7 @@ int sparse_factor_setup(dlg_backend* b)
       Y->fac_lds[l] = (int)(Y->fac_stage[l] ? std::max(base, leaves) : base);
     }
   }
-  if(!Y->uw_flat && !H.uw_item.empty())
+  if(!Y->uw_flat && !H.uw_item.empty() && !plan_only)
   {
     std::vector<GatherUnit> fl(H.uw_item.size());
     for(size_t u = 0; u < fl.size(); u++)
@@ -1222,6 +1226,7 @@ int sparse_factor_setup(dlg_backend* b)
           // an update matrix that does not fit LDS whole (it.jsp < 0) fits in slices: two replicas at least
           int want = has_w ? std::min(rl, T) : 1;
           if(has_w && it.jsp < 0 && slice_ok) want = std::max(want, std::min(2, T));
+          else if(getenv("DOGLEG_AMD_SLICE_ONLY_IF_NEEDED")) want = 1;
           std::vector<int> cut;
           int nrep = 1;
           for(; want <= std::min(8, std::max(T, 1)); want++)
@@ -1302,21 +1307,26 @@ int sparse_factor_setup(dlg_backend* b)
         rec[k].rsv = (rec[k].rsv >= 0 && first[rec[k].rsv] >= 0) ? (first[rec[k].rsv] | (count[rec[k].rsv] << 20)) : -1;
       Y->pr_nwg = (int)items.size();
       Y->pr_lds = (int)std::max<long>(Y->pr_lds, lds_need);
-      if(!Y->pr_item) { DLG_CHECK(upload(Y->pr_item, items)); Y->allocs.push_back(Y->pr_item); }
-      if(!Y->pr_rec)  { DLG_CHECK(upload(Y->pr_rec, rec));   Y->allocs.push_back(Y->pr_rec); }
-      if(!Y->pr_dst)  { DLG_CHECK(upload(Y->pr_dst, dst));   Y->allocs.push_back(Y->pr_dst); }
+      if(plan_only) { Y->pr_item_h.swap(items); Y->pr_rec_h.swap(rec); Y->pr_dst_h.swap(dst); }
+      else
+      {
+        if(!Y->pr_item) { DLG_CHECK(upload(Y->pr_item, items)); Y->allocs.push_back(Y->pr_item); }
+        if(!Y->pr_rec)  { DLG_CHECK(upload(Y->pr_rec, rec));   Y->allocs.push_back(Y->pr_rec); }
+        if(!Y->pr_dst)  { DLG_CHECK(upload(Y->pr_dst, dst));   Y->allocs.push_back(Y->pr_dst); }
+      }
     }
     if(dbg)
       fprintf(stderr, "libdogleg_amd: persistent top region: levels %d..%d of %d (%d supernodes, %d workgroups, %d bytes of LDS, multifrontal from level %d)\n",
               l0, H.nlevels - 1, H.nlevels, total, Y->pr_nwg, lds, H.mf_level0);
     // update matrices of the region that do not fit LDS are summed (atomics) in a shadow of the scratch,
     // so that the slot the parent reads only ever sees write-through stores
-    if(acc && !Y->pr_acc)
+    if(acc && !Y->pr_acc && !plan_only)
     {
       DLG_HIP(hipMalloc(&Y->pr_acc, sizeof(double)*(size_t)std::max<int64_t>(1, H.uscr_size)));
       Y->allocs.push_back(Y->pr_acc);
     }
   }
+  if(plan_only) return DLG_OK;
   if(Y->pr_level0 < H.nlevels && !Y->fac_flag)
   {
     DLG_HIP(hipMalloc(&Y->fac_flag, sizeof(int)*((size_t)Y->pr_nwg + 1)));         // one per workgroup of the region + the fork gate
@@ -1408,6 +1418,8 @@ int sparse_factor_levels(dlg_backend* b)
       if(gate_here && l > 0 && n < 256) dlg_fork_gate(b, fl + np, ep);
       const int64_t pacc = Y->pr_acc ? (int64_t)(Y->pr_acc - Y->uscr) : 0;
       const DlgHandoff ho = dlg_handoff(b, 1 << 21);
+      static const bool dbg_sync = getenv("DOGLEG_AMD_DEBUG_SYNC") != nullptr;     // tools: which launch faults
+      if(dbg_sync) { fprintf(stderr, "libdogleg_amd: before the one-launch region: %s\n", hipGetErrorString(hipStreamSynchronize(st))); fflush(stderr); }
       if(Y->fac_nt[l] == 128)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_factor_level<128>), dim3(np), dim3(128), Y->pr_lds, st,
                            Y->pr_item, Y->pr_rec, Y->sn_bd_col, Y->pr_dst, Y->Lx, Y->top_scr, Y->d_info, Y->uscr, fmode, fl, ep, ho, pacc);
@@ -1417,6 +1429,7 @@ int sparse_factor_levels(dlg_backend* b)
       else
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_factor_level<512>), dim3(np), dim3(512), Y->pr_lds, st,
                            Y->pr_item, Y->pr_rec, Y->sn_bd_col, Y->pr_dst, Y->Lx, Y->top_scr, Y->d_info, Y->uscr, fmode, fl, ep, ho, pacc);
+      if(dbg_sync) { fprintf(stderr, "libdogleg_amd: after the one-launch region (%d workgroups): %s\n", np, hipGetErrorString(hipStreamSynchronize(st))); fflush(stderr); }
       break;
     }
     if(n > 0)
@@ -1480,5 +1493,75 @@ int sparse_factor_levels(dlg_backend* b)
     hipLaunchKernelGGL(k_copy_top, dim3((unsigned)H.ms_sn.size()), dim3(TPB), 0, st, Y->ms_sn, Y->sn_c0,
                        Y->sn_rowptr, Y->sn_lx, Y->sn_top, Y->Lx, Y->top_scr);
   DLG_LAUNCH_CHECK();
+  return DLG_OK;
+}
+
+// Host only (no GPU): the schedule of the one-launch region of the factorisation for a pattern as a chip with
+// `ncu` compute units would get it -- and a check of everything the kernel takes on trust: every destination
+// inside the workgroup's LDS, the slices of a supernode's replicas covering its update matrix exactly once,
+// children listed before their parents.  stats = {first level, supernodes, workgroups, LDS bytes, sliced
+// workgroups, supernodes whose update matrix stays in HBM}.  Returns DLG_ERR_STATE with a message on a violation.
+extern "C" int dlg_sparse_region_probe(int N, int M, const int* colptr, const int* rowidx, int ncu, long* stats, int nstats)
+{
+  dlg_backend b;
+  b.type = DLG_SPARSE; b.N = N; b.M = M; b.nnz = colptr[M]; b.ncu = ncu; b.row0 = 0; b.row1 = M; b.mloc = M;
+  SparseSym Y;
+  b.sym = &Y;
+  char err[512];
+  if(sym_analyze(Y.H, N, M, colptr, rowidx, 0, M, err, sizeof(err))) { b.sym = nullptr; dlg_set_error("symbolic analysis: %s", err); return DLG_ERR_ARG; }
+  const int rc = sparse_factor_setup(&b, true);
+  b.sym = nullptr;
+  if(rc != DLG_OK) return rc;
+  const SymHost& H = Y.H;
+  long nsliced = 0, nhbm = 0;
+  auto fail = [&](const char* what, size_t g) { dlg_set_error("one-launch region: %s (workgroup %zu)", what, g); return DLG_ERR_STATE; };
+  std::vector<long> covered;
+  for(size_t g = 0; g < Y.pr_item_h.size(); g++)
+  {
+    const FwItem& it = Y.pr_item_h[g];
+    const long mb = it.nrows - it.w, ldp = (it.nrows + 1) & ~1L, pan = ldp*it.w, ntri = mb*(mb + 1)/2;
+    const long T = (mb + 15) >> 4;
+    if(it.rep == 0) covered.assign((size_t)std::max<long>(T, 1), 0);
+    for(long t = std::min<long>(it.tj0, T); t < std::min<long>(it.tj1, T); t++) covered[(size_t)t]++;
+    long lds_end;
+    if(it.sliced)
+    {
+      nsliced++;
+      const long jA = std::min<long>(16L*it.tj0, mb), jB = it.tj1 >= T ? mb : std::min<long>(16L*it.tj1, mb);
+      if(it.eA != jA*mb - jA*(jA - 1)/2 || it.eB != jB*mb - jB*(jB - 1)/2) return fail("slice bounds do not match its tile columns", g);
+      lds_end = pan + (it.eA & 1) + (it.eB - it.eA) + 1;             // + the scratch slot
+    }
+    else
+    {
+      if(it.jsp < 0 && mb > 0 && it.u_off >= 0) { if(it.rep == 0) nhbm++; if(it.tj0 != 0 || it.tj1 < T) return fail("replicas of an update matrix that is summed in HBM", g); }
+      lds_end = pan + (it.jsp >= 0 ? sym_w_linear(mb, it.jsp) : 0) + 1;
+    }
+    if(lds_end*8 > Y.pr_lds) return fail("its LDS need exceeds the launch's", g);
+    if(Y.pr_lds > FAC_LDS_BUDGET) return fail("the launch's LDS exceeds the budget", g);
+    for(int k = 0; k < it.nch; k++)
+    {
+      if((size_t)(it.ch0 + k) >= Y.pr_rec_h.size()) return fail("children record out of range", g);
+      const MfChild& rc2 = Y.pr_rec_h[it.ch0 + k];
+      if(rc2.rsv >= 0)
+      {
+        const long ci = rc2.rsv & 0xfffff, cn = rc2.rsv >> 20;
+        if(cn < 1 || ci + cn > (long)g) return fail("a child's workgroups do not precede their parent", g);
+      }
+      if(rc2.dst_off < 0 || (size_t)(rc2.dst_off + rc2.npad) > Y.pr_dst_h.size()) return fail("destination list out of range", g);
+      if(rc2.u_off < 0 || rc2.u_off + rc2.npad > H.uscr_size) return fail("a child's update matrix outside the scratch", g);
+      for(long e = 0; e < rc2.npad; e++)
+      {
+        const long d = Y.pr_dst_h[(size_t)(rc2.dst_off + e)];
+        if(it.sliced || it.jsp >= 0) { if(d >= lds_end) return fail("a destination behind the workgroup's LDS", g); }
+        else if(!(d & 0x8000) ? d >= pan + 1 : (d & 0x7fff) > ntri) return fail("a destination outside panel / update matrix", g);
+      }
+    }
+    const bool last = g + 1 == Y.pr_item_h.size() || Y.pr_item_h[g + 1].rep == 0;
+    if(last && mb > 0 && it.u_off >= 0)
+      for(long t = 0; t < T; t++) if(covered[(size_t)t] != 1) return fail("a tile column of the update matrix is not formed exactly once", g);
+  }
+  const long v[] = { (long)Y.pr_level0, (long)(H.fw_lvl_ptr[H.nlevels] - (Y.pr_level0 < H.nlevels ? H.fw_lvl_ptr[Y.pr_level0] : H.fw_lvl_ptr[H.nlevels])),
+                     (long)Y.pr_nwg, (long)Y.pr_lds, nsliced, nhbm };
+  for(int i = 0; i < nstats && i < 6; i++) stats[i] = v[i];
   return DLG_OK;
 }

@@ -131,7 +131,8 @@ struct SparseSym
   int pr_stage = 0; double* pr_acc = nullptr;   // ... childless supernodes stage their update matrix; shadow scratch for the ones kept in HBM
   int pr_level0 = 1 << 30, pr_lds = 0;   // persistent top region of the factorisation: first level, LDS bytes (sparse_factor_setup)
   int* fac_flag = nullptr; int fac_epoch = 0;   // one flag per workgroup of the region: the epoch of the launch that finished it
-  FwItem* pr_item = nullptr; MfChild* pr_rec = nullptr; uint16_t* pr_dst = nullptr; int pr_nwg = 0;   // the region's work items (supernode x replica) and its copy of the children records
+  FwItem* pr_item = nullptr; MfChild* pr_rec = nullptr; uint16_t* pr_dst = nullptr; int pr_nwg = 0;
+  std::vector<FwItem> pr_item_h; std::vector<MfChild> pr_rec_h; std::vector<uint16_t> pr_dst_h;   // ... on the host (plan-only set-up: dlg_sparse_region_probe)   // the region's work items (supernode x replica) and its copy of the children records
   bool fac_ahead = false;       // panel_factor_ahead instead of panel_factor_mfma (DOGLEG_AMD_AHEAD)
   int bwd_xb_cap = 12288;       // below rows of a supernode staged in LDS by the backward solve
   std::vector<void*> allocs;
@@ -145,6 +146,6 @@ int sparse_eval_assemble(dlg_backend* b, int s, int* done);   // K1 + K4 in one 
 int sparse_assemble_finish(dlg_backend* b);                   // ... its JtJ partial-sum stages (deferred behind the fetch of Jt*x)
 int sparse_zero_spare(dlg_backend* b);                        // clear the swapped-out panel buffer behind the step's fetch
 void sparse_spec_invalidate(dlg_backend* b, int s);                 // subtree partition: the sum over the ranks at the cut
-int sparse_factor_setup(dlg_backend* b);                     // per-level launch parameters of K5
+int sparse_factor_setup(dlg_backend* b, bool plan_only = false);   // per-level launch parameters of K5
 int sparse_factor_levels(dlg_backend* b);                    // K5 launches (no synchronisation)
 int sparse_solve_setup(dlg_backend* b);                      // per-level launch parameters of K6
