@@ -1202,7 +1202,7 @@ int sparse_factor_setup(dlg_backend* b, bool plan_only)
     if(Y->pr_level0 < H.nlevels)
     {
       const int rmax = std::max(1, std::min(8, env_int_host("DOGLEG_AMD_FRONT_REPLICAS", 4)));
-      const int fill = env_int_host("DOGLEG_AMD_FRONT_FILL", ncu/2);
+      const int fill = env_int_host("DOGLEG_AMD_FRONT_FILL", ncu/2), fill0 = env_int_host("DOGLEG_AMD_FRONT_FILL0", ncu/2);
       const bool slice_ok = !getenv("DOGLEG_AMD_NO_FRONT_SLICES");
       std::vector<FwItem> items;
       std::vector<int> first(H.fw_item.size(), -1), count(H.fw_item.size(), 0);
@@ -1216,7 +1216,9 @@ int sparse_factor_setup(dlg_backend* b, bool plan_only)
       for(int l = Y->pr_level0; l < H.nlevels; l++)
       {
         const int n = H.fw_lvl_ptr[l+1] - H.fw_lvl_ptr[l];
-        const int rl = std::max(1, std::min(rmax, fill/std::max(n, 1)));
+        // (the first level of the region is its most populous one, and the Cauchy step's pass over J runs beside
+        // it: replicas there cost more in CUs than they save -- only what does not fit LDS whole is sliced)
+        const int rl = std::max(1, std::min(rmax, (l == Y->pr_level0 ? fill0 : fill)/std::max(n, 1)));
         for(int i = H.fw_lvl_ptr[l]; i < H.fw_lvl_ptr[l+1]; i++)
         {
           FwItem it = H.fw_item[i];
@@ -1560,6 +1562,17 @@ extern "C" int dlg_sparse_region_probe(int N, int M, const int* colptr, const in
     if(last && mb > 0 && it.u_off >= 0)
       for(long t = 0; t < T; t++) if(covered[(size_t)t] != 1) return fail("a tile column of the update matrix is not formed exactly once", g);
   }
+  if(getenv("DLG_REGION_DUMP"))
+    for(int l = std::max(0, H.nlevels - atoi(getenv("DLG_REGION_DUMP"))); l < H.nlevels; l++)
+      for(int i = H.fw_lvl_ptr[l]; i < H.fw_lvl_ptr[l+1]; i++)
+      {
+        const FwItem& it = H.fw_item[i];
+        fprintf(stderr, "level %d: supernode %d cols [%d, %d) w %d rows %d nbd %d children:", l, it.s, it.col0, it.col0 + it.w, it.w, it.nrows, it.nbd);
+        for(int k = H.mf_cptr[it.s]; k < H.mf_cptr[it.s+1]; k++) fprintf(stderr, " %d(w %d)", H.mf_child[k], H.sn_c0[H.mf_child[k]+1] - H.sn_c0[H.mf_child[k]]);
+        fprintf(stderr, "  first below rows:");
+        for(int r = it.w; r < std::min(it.nrows, it.w + 4); r++) fprintf(stderr, " %d", H.sn_rows[H.sn_rowptr[it.s] + r]);
+        fprintf(stderr, " ... last %d\n", H.sn_rows[H.sn_rowptr[it.s] + it.nrows - 1]);
+      }
   const long v[] = { (long)Y.pr_level0, (long)(H.fw_lvl_ptr[H.nlevels] - (Y.pr_level0 < H.nlevels ? H.fw_lvl_ptr[Y.pr_level0] : H.fw_lvl_ptr[H.nlevels])),
                      (long)Y.pr_nwg, (long)Y.pr_lds, nsliced, nhbm };
   for(int i = 0; i < nstats && i < 6; i++) stats[i] = v[i];

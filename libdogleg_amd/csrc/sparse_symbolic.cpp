@@ -547,6 +547,7 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
   {
     const int relax = env_int("DOGLEG_AMD_RELAX_PCT", 25);
     const int sib_w = env_int("DOGLEG_AMD_SIB_W", 64);
+    const int split_w = env_int("DOGLEG_AMD_SPLIT_W", 32);   // columns from which a run stays a supernode of its own beside its parent's other children
     const long chain_cap = env_int("DOGLEG_AMD_CHAIN_CAP", PANEL_CAP);   // width cap of chain supernodes: W*(W+64)
     // width of the fundamental supernode (maximal chain of exactly nested block columns) starting at j:
     // a relaxed merge across a structure change takes that whole run or nothing -- stopping in the
@@ -556,6 +557,18 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
     {
       const bool exact_next = j + 1 < nvb && parent[j] == j + 1 && st[j].size() == st[j+1].size() + 1;
       run_w[j] = G.w[border[j]] + (exact_next ? run_w[j+1] : 0);
+    }
+    // children lists and the longest chain of columns below (and including) every block column
+    std::vector<int> kid_head(nvb, -1), kid_next(nvb, -1);
+    std::vector<long> crit(nvb, 0);
+    for(int j = 0; j < nvb; j++)
+    {
+      crit[j] += G.w[border[j]];
+      if(parent[j] >= 0)
+      {
+        kid_next[j] = kid_head[parent[j]]; kid_head[parent[j]] = j;
+        crit[parent[j]] = std::max(crit[parent[j]], crit[j]);
+      }
     }
     int a = 0;
     long W = G.w[border[0]];              // current width
@@ -578,10 +591,24 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
         const long zeros = stored - tn;
         const bool exact = (st[j].size() == st[j+1].size() + 1);
         // a panel is factored in row slices (>= 64 rows each) that all carry the w x w top block
-        const bool fits = (Wn*(Wn + 64) <= chain_cap) && Wn <= SN_WMAX;
+        // (... unless it has fewer rows below than that: the root of the tree, whose panel is its top block)
+        const long below = std::min<long>(64, Rn);
+        const bool fits = (Wn*(Wn + below) <= chain_cap) && Wn <= SN_WMAX;
         const long Wrun = W + run_w[j+1];
-        const bool run_fits = (Wrun*(Wrun + 64) <= chain_cap) && Wrun <= SN_WMAX;
-        if(fits && (exact || (run_fits && (Wn <= 16 || zeros*100 <= (long)relax*(stored + Wn*Wn)))))
+        const bool run_fits = (Wrun*(Wrun + below) <= chain_cap) && Wrun <= SN_WMAX;
+        // A wide run of columns is NOT merged into a parent that has other children: merged, it is eliminated
+        // after all of them (the merged supernode waits for every child); on its own it is eliminated beside
+        // them.  The top of a nested dissection: the separator of one half and the root separator -- 60
+        // columns less on the critical path of config #4.
+        // Costs in columns on the critical path (crit[c]: the longest chain of columns ending with block c):
+        // merged, the supernode starts when ALL children are done -- max(crit[j], sib + W) to its end --, apart
+        // the run ends at crit[j] and the parent starts at max(crit[j], sib) plus one more hand-off (~split_w
+        // columns' worth).  Siblings that are leaves (points) never make it worth it.
+        long sib = 0;
+        if(nchild[j+1] >= 2)
+          for(int c = kid_head[j+1]; c >= 0; c = kid_next[c]) if(c != j) sib = std::max(sib, crit[c]);
+        const bool beside_siblings = nchild[j+1] >= 2 && std::min<long>(W, sib + W - crit[j]) > split_w;
+        if(fits && !beside_siblings && (exact || (run_fits && (Wn <= 16 || zeros*100 <= (long)relax*(stored + Wn*Wn)))))
         {
           merge = true; sib_only = false; nmerge++;
           W = Wn; true_nnz = tn; below_own = own_after;

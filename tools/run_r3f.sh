@@ -1,0 +1,11 @@
+#!/bin/bash
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+out=gpurun_out/r3f; mkdir -p $out
+timeout 1500 python3 -m pytest tests -m gpu -x -q > $out/tests.log 2>&1; echo "rc=$?" >> $out/tests.log
+tail -6 $out/tests.log
+for wl in sparse-1m sparse-200k; do
+timeout 300 python3 bench.py --workload $wl --no-cpu-baseline --steps 100 --warmup 10 > $out/bench_$wl.json 2> $out/bench_$wl.err; python3 tools/pj.py < $out/bench_$wl.json
+DOGLEG_AMD_SPLIT_W=100000 timeout 300 python3 bench.py --workload $wl --no-cpu-baseline --steps 100 --warmup 10 > $out/bench_nosplit_$wl.json 2> $out/bench_nosplit_$wl.err; python3 tools/pj.py < $out/bench_nosplit_$wl.json
+done
+bash tools/run_prof.sh r3f/prof env
+timeout 300 python3 bench.py --workload sparse-5m --steps 5 --warmup 2 --no-cpu-baseline > $out/bench_5m.json 2> $out/bench_5m.err; python3 tools/pj.py < $out/bench_5m.json
