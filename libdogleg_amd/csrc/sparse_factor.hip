@@ -1562,6 +1562,14 @@ extern "C" int dlg_sparse_region_probe(int N, int M, const int* colptr, const in
     if(last && mb > 0 && it.u_off >= 0)
       for(long t = 0; t < T; t++) if(covered[(size_t)t] != 1) return fail("a tile column of the update matrix is not formed exactly once", g);
   }
+  if(getenv("DLG_REGION_WG_DUMP"))
+    for(size_t g = 0; g < Y.pr_item_h.size(); g++)
+    {
+      const FwItem& it = Y.pr_item_h[g];
+      fprintf(stderr, "rwg %zu s %d lvl %d rep %d w %d rows %d kids", g, it.s, it.pad, it.rep, it.w, it.nrows);
+      for(int k = 0; k < it.nch; k++) { const int r = Y.pr_rec_h[it.ch0 + k].rsv; fprintf(stderr, " %d:%d", r < 0 ? -1 : (r & 0xfffff), r < 0 ? 0 : (r >> 20)); }
+      fprintf(stderr, "\n");
+    }
   if(getenv("DLG_REGION_DUMP"))
     for(int l = std::max(0, H.nlevels - atoi(getenv("DLG_REGION_DUMP"))); l < H.nlevels; l++)
       for(int i = H.fw_lvl_ptr[l]; i < H.fw_lvl_ptr[l+1]; i++)
