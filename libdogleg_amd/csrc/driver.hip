@@ -84,6 +84,7 @@ struct Driver
   int ncallbacks;
   bool check_pattern;
   int *pat_p, *pat_i;
+  bool pattern_owned;                          // device solve: Jt->p / Jt->i of the points are copies (a returned context), not the caller's arrays
   bool be_reused;                              // the backend served an earlier solve (take_parked)
   bool expect_gn;                              // the last step needed the Gauss-Newton step: issue it with the Cauchy step
   bool failed;                                 // a backend op failed during the solve: the backend is not kept
@@ -283,13 +284,11 @@ dogleg_operatingPoint_t* alloc_point(Driver* d, int s)
     A->nrow = N; A->ncol = M; A->nzmax = d->nnz;
     if(d->f_device)
     {
-      // the values stay on the device and the pattern never travels from here: plain host memory,
-      // a copy of the caller's pattern (page-locking 64 MB per point costs tens of milliseconds)
-      A->p = malloc(sizeof(int)*(M + 1));
-      A->i = malloc(sizeof(int)*(size_t)(d->nnz ? d->nnz : 1));
-      if(!A->p || !A->i) return nullptr;
-      memcpy(A->p, d->dev_cp, sizeof(int)*(M + 1));
-      memcpy(A->i, d->dev_ri, sizeof(int)*(size_t)d->nnz);
+      // the values stay on the device and the pattern never travels from here: during the solve Jt->p / Jt->i
+      // ARE the caller's arrays (copying 64 MB per point costs 10 ms each on config #4); a context that is
+      // handed back gets copies of its own then (own_pattern_copies)
+      A->p = const_cast<int*>(d->dev_cp);
+      A->i = const_cast<int*>(d->dev_ri);
     }
     else
     {
@@ -334,7 +333,7 @@ void free_point(Driver* d, int s)
   {
     free(pt->updateCauchy); free(pt->step_to_here);
     free(d->pub.solve_type == DOGLEG_SPARSE ? d->gn_dense[s].x : (void*)pt->updateGN_dense);
-    if(d->f_device && d->pub.solve_type == DOGLEG_SPARSE) { free(d->jt[s].p); free(d->jt[s].i); }
+    if(d->f_device && d->pub.solve_type == DOGLEG_SPARSE && d->pattern_owned) { free(d->jt[s].p); free(d->jt[s].i); }
     free(pt);
   }
   for(int i = 0; i < d->npinned[s]; i++) pinned_give(d->pinned[s][i], d->pinned_bytes[s][i]);
@@ -763,6 +762,26 @@ void sync_point_to_host(Driver* d, dogleg_operatingPoint_t* pt)
   if(d->f_device && pt->have_x) dlg_point_download(d->be, s, DLG_VEC_X, pt->x, (size_t)d->pub.Nmeasurements);
 }
 
+// a device solve whose context outlives the call: the points' Jt->p / Jt->i must not point into the caller's arrays
+bool own_pattern_copies(Driver* d)
+{
+  if(d->pattern_owned) return true;
+  const size_t M = (size_t)d->pub.Nmeasurements;
+  int* cp[2] = {nullptr, nullptr}; int* ri[2] = {nullptr, nullptr};
+  for(int s = 0; s < 2; s++)
+  {
+    cp[s] = (int*)malloc(sizeof(int)*(M + 1));
+    ri[s] = (int*)malloc(sizeof(int)*(size_t)(d->nnz ? d->nnz : 1));
+    if(!cp[s] || !ri[s]) { for(int k = 0; k <= s; k++) { free(cp[k]); free(ri[k]); } return false; }
+    memcpy(cp[s], d->dev_cp, sizeof(int)*(M + 1));
+    memcpy(ri[s], d->dev_ri, sizeof(int)*(size_t)d->nnz);
+  }
+  for(int s = 0; s < 2; s++) { d->jt[s].p = cp[s]; d->jt[s].i = ri[s]; }
+  d->pattern_owned = true;
+  d->dev_cp = d->dev_ri = nullptr;
+  return true;
+}
+
 void destroy(Driver* d)
 {
   if(!d) return;
@@ -970,6 +989,7 @@ double optimize(double* p, unsigned int Nstate, unsigned int Nmeas, unsigned int
 
   if(returnContext)
   {
+    if(d->f_device && ctx->solve_type == DOGLEG_SPARSE && !own_pattern_copies(d)) { MSG("out of memory"); destroy(d); return -1.0; }
     sync_point_to_host(d, ctx->beforeStep);
     if(ctx->solve_type != DOGLEG_SPARSE && ctx->beforeStep->have_factorization)
     {

@@ -2,6 +2,7 @@
 // numeric buffers) and the K4 + K5 orchestration.  The kernels live in sparse_assemble.hip,
 // sparse_factor.hip and sparse_solve.hip.
 #include "sparse_internal.h"
+#include <thread>
 #include <mutex>
 #include <memory>
 #include <string>
@@ -79,11 +80,21 @@ static uint64_t pattern_key(const dlg_backend* b, const int* colptr, const int* 
 extern "C" int dlg_sparse_pattern_matches(dlg_backend_t* b, const int* colptr, const int* rowidx)
 {
   if(!b || !b->sym || !colptr || !rowidx || b->sym->pat_key == 0) return 0;
-  if(colptr[b->M] != b->nnz || pattern_key(b, colptr, rowidx) != b->sym->pat_key) return 0;
+  if(colptr[b->M] != b->nnz) return 0;
+  // (no hash here: the comparison itself is the cheaper pass over the 64 MB of config #4 -- four threads, ~2 ms)
   std::lock_guard<std::mutex> lk(g_sym_mu);
   const SymCacheEntry* c = g_sym_cache.get();
-  return c && c->key == b->sym->pat_key && c->M == b->M && c->nnz == b->nnz &&
-         !memcmp(c->cp.data(), colptr, sizeof(int)*((size_t)b->M + 1)) && !memcmp(c->ri.data(), rowidx, sizeof(int)*(size_t)b->nnz);
+  if(!c || c->key != b->sym->pat_key || c->N != b->N || c->M != b->M || c->nnz != b->nnz || c->row0 != b->row0 || c->row1 != b->row1 ||
+     c->part_rank != b->part_rank || c->part_nranks != b->part_nranks) return 0;
+  if(memcmp(c->cp.data(), colptr, sizeof(int)*((size_t)b->M + 1))) return 0;
+  const size_t n = (size_t)b->nnz;
+  constexpr int NTH = 4;
+  int same[NTH] = {1, 1, 1, 1};
+  std::thread th[NTH];
+  for(int t = 0; t < NTH; t++)
+    th[t] = std::thread([&, t] { const size_t a0 = n*t/NTH, a1 = n*(t + 1)/NTH; same[t] = !memcmp(c->ri.data() + a0, rowidx + a0, sizeof(int)*(a1 - a0)); });
+  for(int t = 0; t < NTH; t++) th[t].join();
+  return same[0] && same[1] && same[2] && same[3];
 }
 // forget the pattern (and everything derived from it) so that another one can be set
 extern "C" int dlg_sparse_drop_pattern(dlg_backend_t* b)
