@@ -229,7 +229,7 @@ constexpr int ASM_U = DLG_ASM_U;
 // J(row, column of the task's block / of the rider), so one multiply-add per k-group with x(row)
 // gives the task's share of (Jt x)[block]; it leaves a 16-double record per task (jtp), summed per
 // var-block by k_jtx_fin2_* in task order.  K1's own pass over J is not needed then.
-template <bool HAS_T, int CLEN, bool JTX>
+template <bool HAS_T, int CLEN, bool JTX, bool XT = false>
 __device__ __forceinline__ void asm_mfma_run(const AsmRun& R, const AsmMTask* __restrict__ tasks,
                                              const AsmShape* __restrict__ SH,
                                              const AsmKG* __restrict__ kgs, const int* __restrict__ tdest,
@@ -303,18 +303,34 @@ __device__ __forceinline__ void asm_mfma_run(const AsmRun& R, const AsmMTask* __
   double jacc = 0.0;
   auto kg_fetch = [&](int kg0) { return reinterpret_cast<const int*>(kgs + min(kg0 + krec, kglast))[kw]; };
   int gnv = kg_fetch(R.kg0);
+  // (XT: every shape of the schedule has a window of at most 15 columns -- the host checks --, so that x of a
+  // row can ride in column 15 of its tile row)
+#ifdef DLG_ASM_PREFETCH
+  constexpr bool x_in_tile = JTX && CLEN == 18 && XT;
+#else
+  constexpr bool x_in_tile = false;
+#endif
 #ifdef DLG_ASM_PREFETCH
   // the values of the first 16 columns of an iteration's rows are fetched one iteration ahead (their
   // records two ahead): the copy into the tile finds them in registers
   int gnn = kg_fetch(R.kg0 + ASM_U);
   double vpre[ASM_U]; int bpre[ASM_U];
+  // (JTX, a window of at most 15 columns: lane 15 of every row fetches x(row) instead of a duplicate of the
+  // window's last column -- it lands in column 15 of the tile row, and the Jt*x product reads it from there:
+  // no gather of x between the records and the products, no load of its own)
   auto vals_fetch = [&](int rec, int kgi) {
 #pragma unroll
     for(int u = 0; u < ASM_U; u++)
     {
       bpre[u] = __builtin_amdgcn_ds_bpermute(4*(KD*u + kq), rec);
       if(kgi + u > kglast) bpre[u] = -1;
-      vpre[u] = vals[max(bpre[u], 0) + col0 + min(m, ncopy - 1)];
+      const double* src = vals + (max(bpre[u], 0) + col0 + min(m, ncopy - 1));
+      if(x_in_tile)
+      {
+        const int xrow = __builtin_amdgcn_ds_bpermute(4*(KD*u + 6 + kq), rec);
+        if(m == 15) src = xvec + xrow;
+      }
+      vpre[u] = *src;
     } };
   vals_fetch(gnv, R.kg0);
 #endif
@@ -329,7 +345,7 @@ __device__ __forceinline__ void asm_mfma_run(const AsmRun& R, const AsmMTask* __
 #pragma unroll
     for(int u = 0; u < ASM_U; u++) meta[u] = kg + u <= kglast ? (uint32_t)__builtin_amdgcn_readlane(gv, KD*u + 5) : 0u;
     double xv[ASM_U];
-    if(JTX)
+    if(JTX && !x_in_tile)
     {
 #pragma unroll
       for(int u = 0; u < ASM_U; u++) xv[u] = xvec[__builtin_amdgcn_ds_bpermute(4*(KD*u + 6 + kq), gv)];    // (rows past the end: row 0, times zeros)
@@ -367,8 +383,11 @@ __device__ __forceinline__ void asm_mfma_run(const AsmRun& R, const AsmMTask* __
       for(int u = 0; u < ASM_U; u++)
       {
         // transient destinations of this k-group: entry `lane` of its list (slot-major)
+        // (at most two destinations: they came with the record)
         const int nent = (int)((meta[u] >> 8) & 7)*nT;
-        td[u] = tdest[lane < nent ? __builtin_amdgcn_readlane(gv, KD*u + 4) + lane : 0];
+        // (only in the instantiation that has the registers for both forms)
+        if(XT && (meta[u] & (1u << 13))) td[u] = __builtin_amdgcn_ds_bpermute(4*(KD*u + 10 + min(lane, 1)), gv);
+        else td[u] = tdest[lane < nent ? __builtin_amdgcn_readlane(gv, KD*u + 4) + lane : 0];
       }
     }
 #ifdef DLG_ASM_PREFETCH
@@ -384,7 +403,7 @@ __device__ __forceinline__ void asm_mfma_run(const AsmRun& R, const AsmMTask* __
       const double* row = myrow + u*4*LEN;
       const double bP = row[bcolP];
       accP = __builtin_amdgcn_mfma_f64_16x16x4f64(row[pc], bP, accP, 0, 0, 0);
-      if(JTX) jacc += xv[u]*bP;
+      if(JTX) jacc += (x_in_tile ? row[15] : xv[u])*bP;
       if(HAS_T)
       {
         const int myslot = (meta[u] >> (2*kq)) & 3;
@@ -452,7 +471,7 @@ __device__ __forceinline__ void asm_mfma_run(const AsmRun& R, const AsmMTask* __
 #else
 #define ASM_WPE_ATTR
 #endif
-template <int CLEN, bool JTX>
+template <int CLEN, bool JTX, bool XT = false>
 __global__ void __launch_bounds__(TPB) ASM_WPE_ATTR k_assemble_mfma(const AsmRun* __restrict__ runs, int nruns,
                                                        const AsmMTask* __restrict__ tasks,
                                                        const AsmKG* __restrict__ kgs,
@@ -461,17 +480,18 @@ __global__ void __launch_bounds__(TPB) ASM_WPE_ATTR k_assemble_mfma(const AsmRun
                                                        const double* __restrict__ vals,
                                                        double* __restrict__ Lx, double* __restrict__ part, int LEN,
                                                        const double* __restrict__ xvec, double* __restrict__ jtp,
-                                                       double* __restrict__ jtx_out)
+                                                       double* __restrict__ jtx_out, int only_shape)
 {
   extern __shared__ double asm_tiles[];
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(blockIdx.x*(TPB/64) + (threadIdx.x >> 6));
   if(wid >= nruns) return;
   const AsmRun R = runs[wid];
+  if(only_shape >= 0 && tasks[R.task0].shape != only_shape) return;      // (tools/k4_split.py: the time of one kind of task)
   const AsmShape* SH = shapes + tasks[R.task0].shape;
   double* tile = asm_tiles + (threadIdx.x >> 6)*(ASM_U*4*LEN);
-  if(SH->MT > 0) asm_mfma_run<true, CLEN, JTX>(R, tasks, SH, kgs, tdest, pdest, vals, Lx, part, lane, tile, LEN, xvec, jtp, jtx_out);
-  else           asm_mfma_run<false, CLEN, JTX>(R, tasks, SH, kgs, tdest, pdest, vals, Lx, part, lane, tile, LEN, xvec, jtp, jtx_out);
+  if(SH->MT > 0) asm_mfma_run<true, CLEN, JTX, XT>(R, tasks, SH, kgs, tdest, pdest, vals, Lx, part, lane, tile, LEN, xvec, jtp, jtx_out);
+  else           asm_mfma_run<false, CLEN, JTX, XT>(R, tasks, SH, kgs, tdest, pdest, vals, Lx, part, lane, tile, LEN, xvec, jtp, jtx_out);
 }
 // Jt*x from the records the assembly kernel left (JTX): var-block v = blks[...] sums its list in order.
 // short lists: 16 threads per var-block (thread = entry of the block); long ones (a dense block that
@@ -959,24 +979,32 @@ static int assemble_launch(dlg_backend* b, const double* Jv, double* Lx = nullpt
     {
       const int nruns = (int)H.asm_run.size();
       const double* nox = nullptr; double* nojt = nullptr;
-      if(H.asm_lds_len == 18 && xvec)
+      static const int only_shape = getenv("DLG_ASM_ONLY_SHAPE") ? atoi(getenv("DLG_ASM_ONLY_SHAPE")) : -1;    // tools only
+      // (x rides in the tile rows where every shape leaves column 15 free)
+      bool xt = H.asm_lds_len == 18;
+      for(const AsmShape& sh : H.asm_shape) if(sh.ncopy > 15) xt = false;
+      if(H.asm_lds_len == 18 && xvec && xt)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_assemble_mfma<18, true, true>), dim3(dlg_cdiv(nruns, TPB/64)), dim3(TPB),
+                           sizeof(double)*(TPB/64)*ASM_U*4*18, st, Y->asm_run, nruns, Y->asm_mtask,
+                           Y->asm_kg, Y->asm_shape, Y->asm_tdest, Y->asm_pdest, Jv, Lx, Y->asm_part, 18, xvec, Y->jtp, Jt_x, only_shape);
+      else if(H.asm_lds_len == 18 && xvec)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_assemble_mfma<18, true>), dim3(dlg_cdiv(nruns, TPB/64)), dim3(TPB),
                            sizeof(double)*(TPB/64)*ASM_U*4*18, st, Y->asm_run, nruns, Y->asm_mtask,
-                           Y->asm_kg, Y->asm_shape, Y->asm_tdest, Y->asm_pdest, Jv, Lx, Y->asm_part, 18, xvec, Y->jtp, Jt_x);
+                           Y->asm_kg, Y->asm_shape, Y->asm_tdest, Y->asm_pdest, Jv, Lx, Y->asm_part, 18, xvec, Y->jtp, Jt_x, only_shape);
       else if(xvec)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_assemble_mfma<0, true>), dim3(dlg_cdiv(nruns, TPB/64)), dim3(TPB),
                            sizeof(double)*(TPB/64)*ASM_U*4*H.asm_lds_len, st, Y->asm_run, nruns, Y->asm_mtask,
                            Y->asm_kg, Y->asm_shape, Y->asm_tdest, Y->asm_pdest, Jv, Lx, Y->asm_part,
-                           H.asm_lds_len, xvec, Y->jtp, Jt_x);
+                           H.asm_lds_len, xvec, Y->jtp, Jt_x, only_shape);
       else if(H.asm_lds_len == 18)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_assemble_mfma<18, false>), dim3(dlg_cdiv(nruns, TPB/64)), dim3(TPB),
                            sizeof(double)*(TPB/64)*ASM_U*4*18, st, Y->asm_run, nruns, Y->asm_mtask,
-                           Y->asm_kg, Y->asm_shape, Y->asm_tdest, Y->asm_pdest, Jv, Lx, Y->asm_part, 18, nox, nojt, nojt);
+                           Y->asm_kg, Y->asm_shape, Y->asm_tdest, Y->asm_pdest, Jv, Lx, Y->asm_part, 18, nox, nojt, nojt, only_shape);
       else
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_assemble_mfma<0, false>), dim3(dlg_cdiv(nruns, TPB/64)), dim3(TPB),
                            sizeof(double)*(TPB/64)*ASM_U*4*H.asm_lds_len, st, Y->asm_run, nruns, Y->asm_mtask,
                            Y->asm_kg, Y->asm_shape, Y->asm_tdest, Y->asm_pdest, Jv, Lx, Y->asm_part,
-                           H.asm_lds_len, nox, nojt, nojt);
+                           H.asm_lds_len, nox, nojt, nojt, only_shape);
     }
     if(nt > 0)
       hipLaunchKernelGGL(k_assemble, dim3(dlg_cdiv(nt, TPB/64)), dim3(TPB), 0, st, Y->asm_ctask, nt,

@@ -1410,11 +1410,19 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
         for(const Ord& o : C.ords) if(o.P) S.asm_pdest.push_back((int)(slots[slot_of[o.I]].dest - panel));
         bool task_open = false, kg_open = false;
         int kg_rows = 0, kg_slots = 0, kg_in_task = 0;
-        auto close_kg = [&]() { if(kg_open) { S.asm_kg.back().meta |= (uint32_t)kg_slots << 8 | 1u << 11; kg_open = false; } };
+        auto close_kg = [&]() {
+          if(!kg_open) return;
+          AsmKG& g = S.asm_kg.back();
+          g.meta |= (uint32_t)kg_slots << 8 | 1u << 11; kg_open = false;
+          // at most two transient destinations: they ride in the record
+          const int nent = kg_slots*C.nT;
+          if(C.nT > 0 && nent <= 2 && g.tq + nent <= (int)S.asm_tdest.size())
+          { for(int q = 0; q < nent; q++) g.td[q] = S.asm_tdest[g.tq + q]; g.meta |= 1u << 13; } };
         auto close_task = [&]() { close_kg(); if(task_open) { S.asm_mtask.back().kg1 = (int)S.asm_kg.size(); task_open = false; } };
         auto open_kg = [&]() {
           AsmKG g; g.base[0] = g.base[1] = g.base[2] = g.base[3] = -1; g.tq = (int)S.asm_tdest.size(); g.meta = 0;
           g.xr[0] = g.xr[1] = g.xr[2] = g.xr[3] = 0;
+          g.td[0] = g.td[1] = 0;
           S.asm_kg.push_back(g); kg_open = true; kg_rows = 0; kg_slots = 0; kg_in_task++; };
         for(int e : C.es)
         {

@@ -115,12 +115,14 @@ struct AsmKG
 {
   int32_t  base[4];             // first value of each of the 4 rows, -1: no row
   int32_t  tq;                  // first entry in asm_tdest of row-block slot 0 (slot s: + s*nT)
-  uint32_t meta;                // bits 0-7: row-block slot of each row (2 bits each); 8-10: #slots; 11: store transients
+  uint32_t meta;                // bits 0-7: row-block slot of each row (2 bits each); 8-10: #slots; 11: store transients; 13: td[] holds the destinations
   int32_t  xr[4];               // the rows themselves (index into the rank's x), 0 where there is none: the
                                 // kernel can form Jt*x beside JtJ (it holds every J(row, column of J) anyway)
+  int32_t  td[2];               // meta bit 13: the k-group has at most two transient destinations and they are
+                                // HERE (no dependent load of asm_tdest between the record and the stores)
 };
-static_assert(sizeof(AsmKG) == 40, "AsmKG layout");
-constexpr int ASM_KG_DW = 10;   // dwords per record
+static_assert(sizeof(AsmKG) == 48, "AsmKG layout");
+constexpr int ASM_KG_DW = 12;   // dwords per record
 struct AsmMTask
 {
   int32_t kg0, kg1, slot0, shape;

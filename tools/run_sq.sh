@@ -1,0 +1,16 @@
+#!/bin/bash
+# SQ counters of the assembly kernel (rocprofv3 --pmc, counters only: no trace domains beside --kernel-trace)
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+out=gpurun_out/${1:-sq}; mkdir -p $out
+rocprofv3 -L 2>/dev/null | grep -o "SQ_[A-Z_0-9]*" | sort -u > $out/sq_counters.txt
+wc -l $out/sq_counters.txt
+grep -E "MFMA|INSTS_VALU$|INSTS_SALU|INSTS_LDS|INSTS_VMEM|INSTS_SMEM|WAIT|ACTIVE_INST|BUSY_CY|WAVE_CYCLES|WAVES$|LDS_BANK|LDS_IDX" $out/sq_counters.txt | tr '\n' ' '; echo
+p=1
+for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU" \
+           "SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS" \
+           "SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_MISC"; do
+  timeout 600 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $out/pass$p -o p -- python3 tools/k4_split.py > $out/pass$p.log 2>&1
+  python3 tools/pmc_kernel.py $out/pass$p k_assemble_mfma | tee -a $out/sq_k4.txt
+  p=$((p+1))
+done
+find $out -name "*kernel_trace.csv" -delete; find $out -name "*agent_info.csv" -delete
