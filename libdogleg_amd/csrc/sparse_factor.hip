@@ -45,6 +45,18 @@ __device__ __forceinline__ void mf_add_children(double* P, double* Wt, int ntri,
   for(int k = 0; k < nch; k++)
   {
     if(k > 0 && (k & 63) == 0) rc = mf_rec[ch0 + k + min(lane, nch - k - 1)];
+    const int npad = __builtin_amdgcn_readlane(rc.npad, k & 63);
+    const int64_t uo = ((int64_t)__builtin_amdgcn_readlane((int)(rc.u_off >> 32), k & 63) << 32) |
+                       (uint32_t)__builtin_amdgcn_readlane((int)rc.u_off, k & 63);
+    const int64_t dof = ((int64_t)__builtin_amdgcn_readlane((int)(rc.dst_off >> 32), k & 63) << 32) |
+                        (uint32_t)__builtin_amdgcn_readlane((int)rc.dst_off, k & 63);
+    const double* Wc = uscr + uo + tid;
+    const uint16_t* D = mf_dst + dof + tid;
+    // the destinations of the first round are static data (cold in HBM, ~2 us away): on their way BEFORE the
+    // wait for the child, so that behind its flag only the update matrix itself is fetched
+    unsigned d[MF_SLOTS];
+#pragma unroll
+    for(int u = 0; u < MF_SLOTS; u++) d[u] = (u*NT < npad) ? D[u*NT] : 0u;
     if(HANDOFF)
     {
       // persistent top region: wait for THIS child's flags only (the children of this launch; the others
@@ -65,17 +77,14 @@ __device__ __forceinline__ void mf_add_children(double* P, double* Wt, int ntri,
       }
       __syncthreads();
     }
-    const int npad = __builtin_amdgcn_readlane(rc.npad, k & 63);
-    const int64_t uo = ((int64_t)__builtin_amdgcn_readlane((int)(rc.u_off >> 32), k & 63) << 32) |
-                       (uint32_t)__builtin_amdgcn_readlane((int)rc.u_off, k & 63);
-    const int64_t dof = ((int64_t)__builtin_amdgcn_readlane((int)(rc.dst_off >> 32), k & 63) << 32) |
-                        (uint32_t)__builtin_amdgcn_readlane((int)rc.dst_off, k & 63);
-    const double* Wc = uscr + uo + tid;
-    const uint16_t* D = mf_dst + dof + tid;
     for(int e0 = 0; e0 < npad; e0 += NT*MF_SLOTS)      // npad is a multiple of 1024: whole rounds of NT
     {
       double v[MF_SLOTS], old[MF_SLOTS];
-      unsigned d[MF_SLOTS];
+      if(e0 > 0)
+      {
+#pragma unroll
+        for(int u = 0; u < MF_SLOTS; u++) if(e0 + u*NT < npad) d[u] = D[e0 + u*NT];
+      }
 #pragma unroll
       for(int u = 0; u < MF_SLOTS; u++)
         if(e0 + u*NT < npad)
@@ -85,7 +94,6 @@ __device__ __forceinline__ void mf_add_children(double* P, double* Wt, int ntri,
           // (a global_ load: the hand-off is not measured for flat_ ones)
           typedef const __attribute__((address_space(1))) double* gptr_t;
           v[u] = HANDOFF ? __hip_atomic_load((gptr_t)(Wc + e0 + u*NT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : Wc[e0 + u*NT];
-          d[u] = D[e0 + u*NT];
         }
       if(UT_LDS)
       {
