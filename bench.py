@@ -168,6 +168,20 @@ def main():
             n2c, n2g, n2s, k, amax, ei = r["n2c"], r["n2g"], r["n2s"], r["k"], r["amax"], r["ei"]
         return norm2x, n2c, n2g, k, n2s, ei, gmax, amax, lam
 
+    def run_steps(n):
+        """n steps as ONE call into the library (dlg_run_steps: the same bind / eval / take_step sequence, the
+        host side in C as in the library's own driver): the timed loop does not carry the interpreter's
+        overhead per entry point (~25 us of a 0.73 ms step on config #4)"""
+        if state["tr"] is None:
+            one_step()
+            n -= 1
+        if n <= 0:
+            return None
+        r, kind = be.run_steps(0, 1, n, [d.ptr for d in d_x], [d.ptr for d in d_J], state["i"] % ncopy, state["tr"], 0.0)
+        state["i"] += n
+        assert kind == capi.KIND_INTERP
+        return r["n2x"], r["n2c"], r["n2g"], r["k"], r["n2s"], r["ei"], r["gmax"], r["amax"], r["lam"]
+
     def barrier():
         L.dlg_device_sync()
         if use_dist:
@@ -181,6 +195,7 @@ def main():
     one_pass = kind == "sparse"
     if one_pass:
         be.set_speculation(True)
+    res = one_step()
     for _ in range(args.warmup):
         res = one_step()
     # in the timed loop only the roofline kernel is bracketed by events (two records per step); the table
@@ -188,14 +203,12 @@ def main():
     be.set_profiling(True, only=["K4_kernel"])
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        res = one_step()
+    res = run_steps(args.steps) or res
     barrier()
     elapsed = time.perf_counter() - t0
     prof_k4 = be.profile()
     be.set_profiling(True)
-    for _ in range(args.steps):
-        one_step()
+    run_steps(args.steps)
     barrier()
     prof = be.profile()
     prof["K4_kernel"] = prof_k4["K4_kernel"]
@@ -228,8 +241,7 @@ def main():
         one_step()
         barrier()
         ts0 = time.perf_counter()
-        for _ in range(args.steps):
-            res_s = one_step()
+        res_s = run_steps(args.steps)
         barrier()
         sep_ms = (time.perf_counter() - ts0) / args.steps * 1e3
         be.set_speculation(True)

@@ -119,6 +119,15 @@ int  dlg_backend_set_rccl(dlg_backend_t* b, void* nccl_comm);            /* adop
 int  dlg_backend_share_rccl(dlg_backend_t* b, dlg_backend_t* owner);     /* ... the one another backend of this process made (it keeps owning it) */
 int  dlg_backend_comm_size(dlg_backend_t* b, int* nranks);               /* what RCCL reports (1 without RCCL) */
 
+/* ---- nsteps trial steps of a fresh operating point in one call: bind resident inputs (ncopy copies of (x, J)
+ * on the device, rotated from first_copy), dlg_point_eval, dlg_take_step from lambda0 -- the sequence of the
+ * driver's takeStepFrom for a point with nothing cached, with the driver's host overhead and its two host
+ * synchronisations per step (what bench.py times).  out9 (may be NULL): {|x|^2, |cauchy|^2, |gn|^2, k,
+ * |step|^2, expected improvement, max|Jt x|, max|step|, lambda} of the last step; kind_out: its DLG_KIND_*. */
+int  dlg_run_steps(dlg_backend_t* b, int from, int to, int nsteps, int ncopy, const double* const* x_dev,
+                   const double* const* J_dev, int first_copy, double trustregion, double lambda0,
+                   double* out9, int* kind_out);
+
 /* ---- one backend for a series of solves (what the dogleg.h driver does between dogleg_optimize* calls: the
  * reference allocates and frees everything per solve, dogleg.c:1479-1562, 1694-1750 -- there a solve takes
  * seconds, here the set-up would be the solve).  dlg_backend_reset forgets the operating points and the held

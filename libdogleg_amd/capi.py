@@ -39,7 +39,7 @@ BACKEND_SYMBOLS = [
     "dlg_sparse_partition_probe", "dlg_rccl_unique_id", "dlg_backend_init_rccl", "dlg_backend_set_rccl",
     "dlg_backend_comm_size", "dlg_solve_multi", "dlg_pseudoinverse_chunk", "dlg_backend_set_speculation",
     "dlg_backend_share_rccl", "dlg_point_gather_device", "dlg_backend_reset", "dlg_backend_device",
-    "dlg_sparse_pattern_matches", "dlg_sparse_drop_pattern", "dlg_sparse_region_probe",
+    "dlg_sparse_pattern_matches", "dlg_sparse_drop_pattern", "dlg_sparse_region_probe", "dlg_run_steps",
 ]
 PROF_NAMES = ["K1_jtx", "K3K8_norm2Jv", "K4_kernel", "K4_total", "K5_factor", "K6_solve", "K7_step", "vec"]
 DOGLEG_SYMBOLS = [
@@ -164,6 +164,7 @@ def lib():
     L.dogleg_amd_rank.argtypes = [V, I]
     L.dlg_backend_share_rccl.argtypes = [V, V]
     L.dlg_sparse_region_probe.argtypes = [C.c_int, C.c_int, I, I, C.c_int, C.POINTER(C.c_long), C.c_int]
+    L.dlg_run_steps.argtypes = [V, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(V), C.POINTER(V), C.c_int, C.c_double, C.c_double, D, I]
     L.dlg_backend_reset.argtypes = [V]
     L.dlg_backend_device.argtypes = [V]
     L.dlg_sparse_pattern_matches.argtypes = [V, I, I]
@@ -508,6 +509,19 @@ class Backend:
         r = dict(zip(keys, [float(v) for v in out]))
         r["kind"] = int(r["kind"])
         return l.value, r, (self._pnew if want_p else None)
+
+    def run_steps(self, frm, to, nsteps, x_ptrs, J_ptrs, first_copy, trustregion, lam0=0.0):
+        """nsteps x (bind the next resident copy, eval, take_step) in one C call (dlg_run_steps): returns
+        (dict of the last step's scalars, kind of step)"""
+        n = len(x_ptrs)
+        xa = (C.c_void_p * n)(*x_ptrs)
+        ja = (C.c_void_p * n)(*J_ptrs)
+        out = (C.c_double * 9)()
+        kind = C.c_int()
+        _ck(self.L.dlg_run_steps(self.h, frm, to, nsteps, n, xa, ja, first_copy, trustregion, lam0, out, C.byref(kind)),
+            "run_steps")
+        keys = ("n2x", "n2c", "n2g", "k", "n2s", "ei", "gmax", "amax", "lam")
+        return dict(zip(keys, [float(v) for v in out])), kind.value
 
     def solve_with_factor(self, slot, rhs):
         """(JtJ + lambda I) u = rhs with the factor held for `slot`; rhs: (N,) or (nrhs, N) rows"""

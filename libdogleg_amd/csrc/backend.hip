@@ -1078,6 +1078,32 @@ extern "C" int dlg_take_step(dlg_backend_t* b, int from, int to, double trustreg
   return DLG_OK;
 }
 
+// ---- the hot path of one trial step, nsteps times: what driver.hip does for a fresh operating point once steps
+// need the Gauss-Newton step -- inputs bound (here: resident copies of (x, J), rotated), dlg_point_eval,
+// dlg_take_step from lambda0 -- as ONE C call, so that a timed loop carries the host overhead of the C driver
+// and not that of an interpreter calling the three entry points (bench.py).  Same entry points, same two host
+// synchronisations per step.  out9 (may be NULL) = {|x|^2, |cauchy|^2, |gn|^2, k, |step|^2, expected
+// improvement, max|Jt x|, max|step|, lambda} of the last step; *kind_out its kind of step.
+extern "C" int dlg_run_steps(dlg_backend_t* b, int from, int to, int nsteps, int ncopy, const double* const* x_dev,
+                             const double* const* J_dev, int first_copy, double trustregion, double lambda0,
+                             double* out9, int* kind_out)
+{
+  DLG_CHECK(check_slot(b, from)); DLG_CHECK(check_slot(b, to));
+  if(nsteps < 0 || ncopy < 1 || !x_dev || !J_dev) { dlg_set_error("dlg_run_steps: bad arguments"); return DLG_ERR_ARG; }
+  double n2x = 0, gmax = 0, lam = lambda0, o[7] = {0, 0, 0, 0, 0, 0, 0};
+  for(int i = 0; i < nsteps; i++)
+  {
+    const int c = (first_copy + i) % ncopy;
+    DLG_CHECK(dlg_point_bind_device(b, from, x_dev[c], J_dev[c]));
+    DLG_CHECK(dlg_point_eval(b, from, &n2x, &gmax));
+    lam = lambda0;
+    DLG_CHECK(dlg_take_step(b, from, to, trustregion, &lam, o, b->h_vec));      // p_new travels to the host (page-locked), as for the driver
+  }
+  if(out9) { out9[0] = n2x; out9[1] = o[0]; out9[2] = o[1]; out9[3] = o[4]; out9[4] = o[3]; out9[5] = o[6]; out9[6] = gmax; out9[7] = o[5]; out9[8] = lam; }
+  if(kind_out) *kind_out = (int)o[2];
+  return DLG_OK;
+}
+
 // ------------------------------------------------- solves with the resident factor
 // (JtJ + lambda I) u = rhs for nrhs right-hand sides (host, column after column, N each) with the
 // factorisation held for `slot` (dlg_factorize / dlg_gauss_newton / dlg_take_step): what the

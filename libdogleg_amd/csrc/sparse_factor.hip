@@ -11,9 +11,12 @@ typedef double dlg_v2d __attribute__((ext_vector_type(2)));
 #ifdef DLG_FL_PROFILE
 constexpr int FL_PROF_WG = 1024;       // workgroups per level whose phase clocks are kept
 __device__ long long g_fl_prof[32*FL_PROF_WG*8];
+__device__ long long g_fl_add[FL_PROF_WG*4];          // the children's adds of the one-launch region: see mf_add_children
+#define FL_ADD_STAMP(k) do { if(HANDOFF && threadIdx.x == 0 && blockIdx.x < FL_PROF_WG) g_fl_add[blockIdx.x*4 + (k)] = wall_clock64(); } while(0)
 #define FL_STAMP(k) do { if(threadIdx.x == 0 && blockIdx.x < FL_PROF_WG) g_fl_prof[((prof_lvl & 31)*FL_PROF_WG + blockIdx.x)*8 + (k)] = wall_clock64(); } while(0)      // 100 MHz, one clock for the chip
 #else
 #define FL_STAMP(k)
+#define FL_ADD_STAMP(k)
 #endif
 
 // ------------------------------------------------------------------ K5 ------
@@ -76,6 +79,8 @@ __device__ __forceinline__ void mf_add_children(double* P, double* Wt, int ntri,
         }
       }
       __syncthreads();
+      if(k == 0) FL_ADD_STAMP(0);
+      if(k == nch - 1) FL_ADD_STAMP(2);
     }
     for(int e0 = 0; e0 < npad; e0 += NT*MF_SLOTS)      // npad is a multiple of 1024: whole rounds of NT
     {
@@ -122,6 +127,7 @@ __device__ __forceinline__ void mf_add_children(double* P, double* Wt, int ntri,
       }
     }
     __syncthreads();
+    if(k == 0) FL_ADD_STAMP(1);
   }
 }
 
@@ -1391,6 +1397,12 @@ extern "C" void dlg_fl_profile_dump(int nlevels)
       const long long* q = &h[(l*FL_PROF_WG + g)*8];
       if(q[5] == 0 || q[7] == 0) continue;
       shown++;
+      {
+        std::vector<long long> ha(FL_PROF_WG*4);
+        static bool got = false; static std::vector<long long> hadd;
+        if(!got) { hadd.resize(FL_PROF_WG*4); hipMemcpyFromSymbol(hadd.data(), HIP_SYMBOL(g_fl_add), sizeof(long long)*hadd.size()); got = true; }
+        if(hadd[g*4 + 0]) fprintf(stderr, "   add %3d: child0 seen %6lld child0 added %6lld last child seen %6lld\n", g, hadd[g*4] - t0, hadd[g*4 + 1] - t0, hadd[g*4 + 2] - t0);
+      }
       fprintf(stderr, "   wg %3d (w %3lld rows %4lld nch %lld u_lds %lld lvl %lld rep %lld): start %6lld flag up %6lld panel in %6lld added %6lld factored %6lld tail %6lld flag+stored %6lld\n",
               g, q[6] & 4095, (q[6] >> 12) & 4095, (q[6] >> 24) & 4095, (q[6] >> 36) & 1, (q[6] >> 56) & 63, (q[6] >> 52) & 15, q[0] - t0, q[7] - t0, q[1] - t0, q[2] - t0, q[3] - t0, q[4] - t0, q[5] - t0);
     }

@@ -17,7 +17,12 @@ for wl in sparse-1m dense-50k; do
     python3 tools/pmc_kernel.py $out/pmc_${wl}_$c > $out/pmc_${wl}_$c.txt
   done
 done
-timeout 600 python3 tools/e2e_bench.py --workload sparse-1m > $out/e2e_sparse1m.json 2> $out/e2e.err
+DOGLEG_AMD_TIMING=1 timeout 600 python3 tools/e2e_bench.py --workload sparse-1m > $out/e2e_sparse1m.json 2> $out/e2e.err
+# SQ counters of the assembly kernel (three passes of eight), the per-workgroup timeline of the one-launch factor region
+bash tools/run_sq.sh $tag/sq > $out/sq.log 2>&1
+cp gpurun_out/$tag/sq/sq_k4.txt $out/sq_k4.txt 2>/dev/null
+bash tools/run_prof.sh $tag/prof env > $out/top_of_tree_levels.txt 2>&1
+python3 tools/k4_split.py > $out/k4_split.txt 2>&1; DLG_ASM_ONLY_SHAPE=0 python3 tools/k4_split.py >> $out/k4_split.txt 2>&1; DLG_ASM_ONLY_SHAPE=1 python3 tools/k4_split.py >> $out/k4_split.txt 2>&1
 timeout 300 python3 tools/gpu_probe.py > $out/probe.txt 2>&1
 DLG_BENCH_FORCE_DIST=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29512 RANK=0 LOCAL_RANK=0 WORLD_SIZE=1 timeout 600 python3 bench.py --no-cpu-baseline > $out/bench_dist_world1_rccl.log 2>&1
 # keep the merge small: only summaries travel back

@@ -57,6 +57,11 @@ th1, (rh, ph, trh) = timed(host)
 th2, _ = timed(host)
 td1, (rd, pd, trd) = timed(dev)
 td2, _ = timed(dev)
+# a longer solve of the same shape (20 iterations allowed): what the fixed cost per solve is against
+prm.max_iterations = 20
+td20, (rd20, pd20, trd20) = timed(dev)
+th20, (rh20, ph20, trh20) = timed(host)
+prm.max_iterations = a.iters
 out = {"workload": a.workload, "Nmeas": prob.M, "Nstate": prob.N, "nnz": prob.nnz,
        "trials": trh.ntrials, "callbacks": trh.ncallbacks, "symbolic_analysis_s": t_sym,
        "host_callback": {"first_call_s": th1, "second_call_s": th2, "callback_s_each": t_cb,
@@ -65,6 +70,8 @@ out = {"workload": a.workload, "Nmeas": prob.M, "Nstate": prob.N, "nnz": prob.nn
        "device_callback": {"first_call_s": td1, "second_call_s": td2, "steps_per_s": trd.ntrials / td2,
                            "h2d_bytes_per_eval": 0, "d2h_bytes_per_trial": 8 * prob.N,
                            "trials": trd.ntrials, "evaluations_on_device": twin.neval()},
+       "device_callback_20_iterations": {"solve_s": td20, "trials": trd20.ntrials, "steps_per_s": trd20.ntrials / td20},
+       "host_callback_20_iterations": {"solve_s": th20, "trials": trh20.ntrials, "steps_per_s": trh20.ntrials / th20},
        "max_abs_p_diff_device_vs_host": float(np.max(np.abs(pd - ph))),
        "norm2x": rh, "step_types": [t["step_type"] for t in trh.trials()]}
 if a.oracle:
