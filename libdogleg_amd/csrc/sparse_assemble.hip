@@ -385,8 +385,10 @@ __device__ __forceinline__ void asm_mfma_run(const AsmRun& R, const AsmMTask* __
         // transient destinations of this k-group: entry `lane` of its list (slot-major)
         // (at most two destinations: they came with the record)
         const int nent = (int)((meta[u] >> 8) & 7)*nT;
-        // (only in the instantiation that has the registers for both forms)
-        if(XT && (meta[u] & (1u << 13))) td[u] = __builtin_amdgcn_ds_bpermute(4*(KD*u + 10 + min(lane, 1)), gv);
+        // (XT: the host found every k-group's destinations in its record -- no load of asm_tdest at all, so that
+        // nothing between the products and the stores waits on the memory counter: a wait there drains the value
+        // prefetch of the next iteration, the loads complete in order)
+        if(XT) td[u] = __builtin_amdgcn_ds_bpermute(4*(KD*u + 10 + min(lane, 1)), gv);
         else td[u] = tdest[lane < nent ? __builtin_amdgcn_readlane(gv, KD*u + 4) + lane : 0];
       }
     }
@@ -416,7 +418,11 @@ __device__ __forceinline__ void asm_mfma_run(const AsmRun& R, const AsmMTask* __
             if(4*r < MT)
             {
               const int ro = __builtin_amdgcn_ds_bpermute(4*(bs*nT + TJ(r)), td[u]);
+#ifndef DLG_ASM_NO_TSTORE                     // (tools/variant_lib.sh: the kernel without its transient stores)
               if(mine && TJ(r) != 0xFF) Lx[colT + (ro + TA(r))] = accT[r];
+#else
+              if(mine && TJ(r) != 0xFF && accT[r] == 1.2345e300) Lx[colT + (ro + TA(r))] = accT[r];
+#endif
             }
           accT = (dlg_v4d){0.0, 0.0, 0.0, 0.0};
         }
@@ -983,6 +989,7 @@ static int assemble_launch(dlg_backend* b, const double* Jv, double* Lx = nullpt
       // (x rides in the tile rows where every shape leaves column 15 free)
       bool xt = H.asm_lds_len == 18;
       for(const AsmShape& sh : H.asm_shape) if(sh.ncopy > 15) xt = false;
+      if(xt) xt = H.asm_td_inline;                  // ... and every k-group carries its transient destinations
       if(H.asm_lds_len == 18 && xvec && xt)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_assemble_mfma<18, true, true>), dim3(dlg_cdiv(nruns, TPB/64)), dim3(TPB),
                            sizeof(double)*(TPB/64)*ASM_U*4*18, st, Y->asm_run, nruns, Y->asm_mtask,

@@ -1716,6 +1716,12 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
             pd2[(size_t)k*16 + q] = S.asm_pdest[S.asm_mtask[k].pq + q];
         S.asm_pdest.swap(pd2);
       }
+      // (do all k-groups that store transient blocks carry the destinations themselves?)
+      S.asm_td_inline = true;
+      for(const AsmMTask& T : S.asm_mtask)
+        if(S.asm_shape[T.shape].MT > 0)
+          for(int g = T.kg0; g < T.kg1; g++)
+            if(((S.asm_kg[g].meta >> 8) & 7) > 0 && !(S.asm_kg[g].meta & (1u << 13))) S.asm_td_inline = false;
       const int RUN_KG = env_int("DOGLEG_AMD_RUN_KG", 32);
       for(int k = 0; k < nt; )
       {

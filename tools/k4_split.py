@@ -7,6 +7,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from libdogleg_amd import capi
 import problems as pb
+if os.environ.get("DLG_LIB"):
+    capi.LIB_PATH = os.path.abspath(os.environ["DLG_LIB"])
 prob = pb.BAProblem(2499, 45000, 500000, seed=11)
 Jp, Ji = prob.pattern()
 p = prob.p0()

@@ -14,7 +14,8 @@ for wl, short in names.items():
     if os.path.exists(st):
         shutil.copy(st, os.path.join(dst, f"{tag}_{short}_kernel_stats.csv"))
 for a, b in (("e2e_sparse1m.json", f"{tag}_e2e_sparse1m.json"), ("bench_dist_world1_rccl.log", f"{tag}_bench_dist_world1_rccl.log"),
-             ("probe.txt", f"{tag}_probe.txt")):
+             ("probe.txt", f"{tag}_probe.txt"), ("sq_k4.txt", f"{tag}_sq_k_assemble_mfma.txt"), ("k4_split.txt", f"{tag}_k4_split.txt"),
+             ("top_of_tree_levels.txt", f"{tag}_top_of_tree_levels.txt"), ("e2e.err", f"{tag}_e2e_timing.txt")):
     if os.path.exists(os.path.join(src, a)):
         shutil.copy(os.path.join(src, a), os.path.join(dst, b))
 
@@ -33,7 +34,7 @@ def pmc(wl, counter, kernel):
 traffic = {}
 # the dense JtJ launch is one of many k_syrk_lower<64> dispatches (the potrf trailing updates use the
 # same kernel): its entry is maintained by hand from the per-dispatch CSV (see the pmc notes)
-for wl, kernel, label in (("sparse-1m", "k_assemble_mfma<18, true>", "k_assemble_mfma<18, true> (K1+K4 in one pass)"),):
+for wl, kernel, label in (("sparse-1m", "k_assemble_mfma<18, true, true>", "k_assemble_mfma<18, true, true> (K1+K4 in one pass)"),):
     try:
         f, w = pmc(wl, "FETCH_SIZE", kernel), pmc(wl, "WRITE_SIZE", kernel)
         if f is None or w is None:
@@ -43,6 +44,18 @@ for wl, kernel, label in (("sparse-1m", "k_assemble_mfma<18, true>", "k_assemble
                                  "bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 FETCH_SIZE counts half of streamed reads)"}
     except FileNotFoundError:
         pass
+# dense: since the factorisation is one launch of its own (k_potrf_tiles), every k_syrk_lower<64> dispatch is a JtJ launch
+try:
+    f, w = pmc("dense-50k", "FETCH_SIZE", "k_syrk_lower<64>"), pmc("dense-50k", "WRITE_SIZE", "k_syrk_lower<64>")
+    fr, wr = pmc("dense-50k", "FETCH_SIZE", "k_syrk_reduce<128>"), pmc("dense-50k", "WRITE_SIZE", "k_syrk_reduce<128>")
+    if f is not None and w is not None:
+        traffic["dense-50k"] = {"kernel": "k_syrk_lower<64> (JtJ launch, split-K slabs)", "fetch_size_kb": f, "write_size_kb": w,
+                                "bytes_per_launch": int((2*f + w)*1024),
+                                "k_syrk_reduce_bytes_per_launch": int((2*(fr or 0) + (wr or 0))*1024),
+                                "source": f"profiles/{tag}_pmc.md: as above; every k_syrk_lower<64> dispatch of the run is a JtJ launch "
+                                          "(the factorisation is k_potrf_tiles); FETCH_SIZE counts L2-to-fabric requests, Infinity-Cache hits included"}
+except FileNotFoundError:
+    pass
 old = {}
 try:
     old = json.load(open(os.path.join(dst, "traffic.json")))
