@@ -1556,7 +1556,10 @@ extern "C" int dlg_sparse_region_probe(int N, int M, const int* colptr, const in
     else
     {
       if(it.jsp < 0 && mb > 0 && it.u_off >= 0) { if(it.rep == 0) nhbm++; if(it.tj0 != 0 || it.tj1 < T) return fail("replicas of an update matrix that is summed in HBM", g); }
-      lds_end = pan + (it.jsp >= 0 ? sym_w_linear(mb, it.jsp) : 0) + 1;
+      // (the kernel stages the whole update matrix behind the panel when the supernode has children, or -- childless --
+      // when the launch stages those too)
+      const bool staged = it.jsp >= 0 && mb > 0 && it.u_off >= 0 && (it.nch > 0 || Y.pr_stage);
+      lds_end = pan + (staged ? sym_w_linear(mb, it.jsp) : 0) + 1;
     }
     if(lds_end*8 > Y.pr_lds) return fail("its LDS need exceeds the launch's", g);
     if(Y.pr_lds > FAC_LDS_BUDGET) return fail("the launch's LDS exceeds the budget", g);
@@ -1574,7 +1577,7 @@ extern "C" int dlg_sparse_region_probe(int N, int M, const int* colptr, const in
       for(long e = 0; e < rc2.npad; e++)
       {
         const long d = Y.pr_dst_h[(size_t)(rc2.dst_off + e)];
-        if(it.sliced || it.jsp >= 0) { if(d >= lds_end) return fail("a destination behind the workgroup's LDS", g); }
+        if(it.sliced || it.jsp >= 0) { if(d >= pan + (it.sliced ? (it.eA & 1) + (it.eB - it.eA) : sym_w_linear(mb, it.jsp)) + 1) return fail("a destination behind the workgroup's LDS", g); }
         else if(!(d & 0x8000) ? d >= pan + 1 : (d & 0x7fff) > ntri) return fail("a destination outside panel / update matrix", g);
       }
     }

@@ -350,6 +350,28 @@ def test_subtree_partition_of_config5_over_8_ranks():
           f"rows of ranks 0/7: {s0['rows_mine']}, {s7['rows_mine']}")
 
 
+@pytest.mark.parametrize("shape,ncu", [((49, 900, 10000), 256), ((499, 9000, 100000), 256), ((2499, 45000, 500000), 256),
+                                       ((2499, 45000, 500000), 64)])
+def test_one_launch_region_schedule_invariants(shape, ncu, monkeypatch):
+    """The top of the elimination tree is factored by ONE launch whose workgroups trust their schedule blindly:
+    replicas of a supernode that each form a slice of its update matrix, destination lists into LDS, children
+    that must come before their parents.  dlg_sparse_region_probe builds that schedule with the library's own
+    set-up code (no GPU) and checks every destination against the workgroup's LDS, the slices against the update
+    matrix (every tile column formed exactly once), the order of the workgroups."""
+    prob = oa.BAProblem(*shape, seed=11)
+    Jp, Ji = prob.pattern()
+    st = capi.region_probe(prob.N, prob.M, Jp, Ji, ncu)
+    assert st["workgroups"] >= st["supernodes"] > 0 and st["lds_bytes"] <= 160 * 1024
+    if shape[0] == 2499 and ncu == 256:
+        # config #4: every update matrix of the region is staged in LDS (whole or in slices), none summed in HBM
+        assert st["hbm_update_matrices"] == 0 and st["sliced_workgroups"] > 0 and st["level0"] == 1
+    for knob, val in (("DOGLEG_AMD_FRONT_REPLICAS", "1"), ("DOGLEG_AMD_FRONT_REPLICAS", "8"), ("DOGLEG_AMD_NO_FRONT_SLICES", "1")):
+        monkeypatch.setenv(knob, val)
+        st2 = capi.region_probe(prob.N, prob.M, Jp, Ji, ncu)
+        assert st2["supernodes"] == st["supernodes"]
+        monkeypatch.delenv(knob)
+
+
 def test_subtree_partition_rows_form_closed_subtrees():
     """the property the partition rests on: a rank's rows touch only its own subtrees' variables and
     the replicated ones -- so J_r' J_r of rank r is zero in every (variable of another rank, *) entry"""

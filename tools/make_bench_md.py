@@ -68,15 +68,17 @@ Rooflines:
 * sparse-1m `k_assemble_mfma<18, true>` (K1+K4: JtJ and Jt*x in one pass): {r['algorithmic_bytes']/1e6:.1f} MB algorithmic / {r['avg_launch_ms']:.3f} ms = **{r['achieved']:.0f} GB/s = {100*r['frac']:.1f} % of 8 TB/s**
   (target in BASELINE.json: 40 %).  Counter traffic {t['bytes_per_launch']/1e6:.0f} MB per launch ({tag}_pmc.md): {t['bytes_per_launch']/r['algorithmic_bytes']:.2f}x the
   algorithmic bytes (J is walked twice: by the tasks of its points' columns and of its cameras').  The kernel is bound by
-  instruction issue around the K = 4 fp64 MFMAs; K1's own pass over J (0.08 ms, 2.2x its bytes) is gone.
+  memory latency exposed per wave ({tag}_pmc.md: 60 % of the wave cycles in s_waitcnt, matrix cores 18 % busy); K1's own
+  pass over J is gone.
 * dense-50k `k_syrk_lower<64>` (K4): {rd['algorithmic_flops']:.3e} flop / {rd['avg_launch_ms']:.3f} ms = **{rd['achieved']:.1f} TFLOP/s** = {100*rd['frac']:.0f} % of the 78.6
   TFLOP/s datasheet fp64-matrix peak (48 TFLOP/s is what a register-only v_mfma_f64_16x16x4_f64 loop sustains here).
 * sparse-1m `k_norm2_Jv` (K3/K8): {ok['K3K8_norm2_Jv']['algorithmic_bytes']/1e6:.0f} MB / {1e3*ok['K3K8_norm2_Jv']['ms']:.0f} us = {ok['K3K8_norm2_Jv']['GBps']:.0f} GB/s = {100*ok['K3K8_norm2_Jv']['frac_hbm']:.0f} % of HBM (J past the Infinity Cache).
 * K5-sparse and K6-sparse are latency / critical-path bound (SURVEY 8d says to expect low fractions and to
   say so): K5 = {k5b/1e6:.0f} MB (`8 nnz(tril JtJ) + 8 nnz(L)`) and {k5f/1e9:.2f} GFLOP in {k5t:.2f} ms = {k5b/k5t/1e6:.0f} GB/s
   ({100*k5b/k5t/1e6/8000:.1f} % of HBM), {k5f/k5t/1e9:.2f} TFLOP/s ({100*k5f/k5t/1e9/78.6:.1f} % of the fp64 peak); K6 = {k6b/1e6:.0f} MB (`16 nnz(L) + 32 N`) in {k6t:.2f} ms
-  = {k6b/k6t/1e6:.0f} GB/s ({100*k6b/k6t/1e6/8000:.1f} %).  {nlev} elimination-tree levels: the nine upper ones are ONE launch each way
-  (workgroups hand over through flags): ~40 us (factor) + ~9 us (backward solve) a level; timelines in DESIGN.md section 6.
+  = {k6b/k6t/1e6:.0f} GB/s ({100*k6b/k6t/1e6/8000:.1f} %).  {nlev} elimination-tree levels: the upper ones are ONE launch each way
+  (workgroups hand over through flags; round 3: a supernode of the factor launch is shared by up to four workgroups, each
+  forming a slice of its update matrix): ~25-35 us (factor) + ~6 us (backward solve) a level; {tag}_top_of_tree_levels.txt, DESIGN.md section 6.
 
 rocprofv3 --stats, sparse-1m (bench.py default run; ms/step = total / steps issued):
 ```
