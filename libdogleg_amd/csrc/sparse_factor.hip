@@ -131,6 +131,112 @@ __device__ __forceinline__ void mf_add_children(double* P, double* Wt, int ntri,
   }
 }
 
+// The usual case of the one-launch region -- two children, each update matrix one round of loads, everything
+// staged in LDS -- with the second child's loads on their way while the first is being added.  Both children of
+// a supernode on the critical chain arrive together; added one after the other they cost two memory round trips
+// and a poll in between (2.5 + 1.3 + 2.4 us measured).  Here every thread, once the first child's loads are out,
+// reads the second child's flags itself: if they are up (a thread's own finding: its loads come after its own
+// look at the flags, nobody else's), its half of that child's entries is fetched while it adds the first child's.
+// The order of the sums is the list's, as before: first child, workgroup barrier, second child.
+template <int NT>
+__device__ __forceinline__ void mf_add_two_pipelined(double* P, double* Wt, int nzero, MfChild rc, const double* uscr,
+                                                     const uint16_t* __restrict__ mf_dst, int tid,
+                                                     int* pr_flag, int pr_epoch, DlgHandoff ho)
+{
+  constexpr int H = 10;                    // entries per thread and half (two halves = one round of 20*NT)
+  constexpr bool HANDOFF = true;           // (the profile build's stamps ask)
+  (void)HANDOFF;
+  typedef const __attribute__((address_space(1))) double* gptr_t;
+  for(int e = tid; e < nzero; e += NT) Wt[e] = 0.0;
+  const int npA = __builtin_amdgcn_readlane(rc.npad, 0), npB = __builtin_amdgcn_readlane(rc.npad, 1);
+  auto rl64 = [&](int64_t v, int l) { return ((int64_t)__builtin_amdgcn_readlane((int)(v >> 32), l) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)v, l); };
+  const double* WA = uscr + rl64(rc.u_off, 0) + tid; const double* WB = uscr + rl64(rc.u_off, 1) + tid;
+  const uint16_t* DA = mf_dst + rl64(rc.dst_off, 0) + tid; const uint16_t* DB = mf_dst + rl64(rc.dst_off, 1) + tid;
+  const int crA = __builtin_amdgcn_readlane(rc.rsv, 0), crB = __builtin_amdgcn_readlane(rc.rsv, 1);
+  const int ciA = crA & 0xfffff, cnA = crA >> 20, ciB = crB & 0xfffff, cnB = crB >> 20;
+  const int want = pr_epoch + ho.skew;
+  auto wait_flags = [&](int ci, int cn) {
+    if(tid < cn)
+    {
+      int spins = 0;
+      while(__hip_atomic_load(pr_flag + ci + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != want)
+      {
+        __builtin_amdgcn_s_sleep(1);
+        if(++spins > ho.spins) { atomicOr(ho.status, DLG_HANDOFF_FACTOR); break; }
+      }
+    } };
+  // destinations of both children: static data, on their way before any wait
+  unsigned dA[2*H], dB[2*H];
+#pragma unroll
+  for(int u = 0; u < 2*H; u++) { dA[u] = (u*NT < npA) ? DA[u*NT] : 0u; dB[u] = (u*NT < npB) ? DB[u*NT] : 0u; }
+  wait_flags(ciA, cnA);
+  __syncthreads();                         // (also: Wt is zero everywhere)
+  FL_ADD_STAMP(0);
+  double vX[H], vY[H];
+#pragma unroll
+  for(int u = 0; u < H; u++) { vX[u] = (u*NT < npA) ? __hip_atomic_load((gptr_t)(WA + u*NT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0; }
+#pragma unroll
+  for(int u = 0; u < H; u++) { vY[u] = ((H + u)*NT < npA) ? __hip_atomic_load((gptr_t)(WA + (H + u)*NT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0; }
+  // first child, first half (its values are the first to arrive: ~2 us after the flag)
+  {
+    double old[H];
+#pragma unroll
+    for(int u = 0; u < H; u++) old[u] = P[dA[u]];
+#pragma unroll
+    for(int u = 0; u < H; u++) if(u*NT < npA) P[dA[u]] = old[u] + vX[u];
+  }
+  // this thread's own look at the second child's flags, as late as it is of use (cn <= 8 of them; a child
+  // outside the launch is there)
+  int fl[8];
+#pragma unroll
+  for(int q = 0; q < 8; q++) fl[q] = (q < cnB) ? __hip_atomic_load(pr_flag + ciB + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : want;
+  // first child, second half
+  {
+    double old[H];
+#pragma unroll
+    for(int u = 0; u < H; u++) old[u] = P[dA[H + u]];
+#pragma unroll
+    for(int u = 0; u < H; u++) if((H + u)*NT < npA) P[dA[H + u]] = old[u] + vY[u];
+  }
+  bool bup = true;
+#pragma unroll
+  for(int q = 0; q < 8; q++) bup = bup && fl[q] == want;
+  if(bup)
+  {
+#pragma unroll
+    for(int u = 0; u < H; u++) vX[u] = (u*NT < npB) ? __hip_atomic_load((gptr_t)(WB + u*NT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+#pragma unroll
+    for(int u = 0; u < H; u++) vY[u] = ((H + u)*NT < npB) ? __hip_atomic_load((gptr_t)(WB + (H + u)*NT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+  }
+  __syncthreads();                         // the first child is in, in every thread's entries
+  FL_ADD_STAMP(1);
+#ifdef DLG_FL_PROFILE
+  if(threadIdx.x == 0 && blockIdx.x < FL_PROF_WG) g_fl_add[blockIdx.x*4 + 3] = 1000 + (bup ? 1 : 0) + 10*cnB + 100*(fl[0] == want);
+#endif
+  if(!bup) wait_flags(ciB, cnB);           // (a polling lane that saw them up itself has nothing to wait for)
+  __syncthreads();
+  FL_ADD_STAMP(2);
+  if(!bup)
+  {
+#pragma unroll
+    for(int u = 0; u < H; u++) vX[u] = (u*NT < npB) ? __hip_atomic_load((gptr_t)(WB + u*NT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+#pragma unroll
+    for(int u = 0; u < H; u++) vY[u] = ((H + u)*NT < npB) ? __hip_atomic_load((gptr_t)(WB + (H + u)*NT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+  }
+  {
+    double old[H];
+#pragma unroll
+    for(int u = 0; u < H; u++) old[u] = P[dB[u]];
+#pragma unroll
+    for(int u = 0; u < H; u++) if(u*NT < npB) P[dB[u]] = old[u] + vX[u];
+#pragma unroll
+    for(int u = 0; u < H; u++) old[u] = P[dB[H + u]];
+#pragma unroll
+    for(int u = 0; u < H; u++) if((H + u)*NT < npB) P[dB[H + u]] = old[u] + vY[u];
+  }
+  __syncthreads();
+}
+
 // NCH consecutive lower 16x16 tiles (column-major tile order, first tile `first`) of
 // U = B B' (B = the mb rows below the diagonal block of the LDS panel Pb, w columns), one
 // accumulator chain per tile, every chain with its own operands (the tiles may span two tile
@@ -378,7 +484,11 @@ __global__ void __launch_bounds__(NT, LEAF ? 4 : 1) k_factor_level(const FwItem*
       for(int i = lane; i < mb - jw; i += 64) P[(mb - jw)*ldp + i] = 0.0;      // (the barrier is in mf_add_children)
   if(mf_acc)
   {
-    if(pr_flag && u_lds) mf_add_children<NT, true, true>(P, Us, nlin, it.nch, it.ch0, rc, mf_rec, uscr, mf_dst, tid, pr_flag, pr_epoch, ho);
+    // (two children, one round of loads each: the second child's loads overlap the first child's adds)
+    const bool two = NT >= 512 && it.nch == 2 && __builtin_amdgcn_readlane(rc.npad, 0) <= 20*NT && __builtin_amdgcn_readlane(rc.npad, 1) <= 20*NT &&
+                     (__builtin_amdgcn_readlane(rc.rsv, 0) >> 20) <= 8 && (__builtin_amdgcn_readlane(rc.rsv, 1) >> 20) <= 8;
+    if(pr_flag && u_lds && two) mf_add_two_pipelined<NT>(P, Us, nlin, rc, uscr, mf_dst, tid, pr_flag, pr_epoch, ho);
+    else if(pr_flag && u_lds) mf_add_children<NT, true, true>(P, Us, nlin, it.nch, it.ch0, rc, mf_rec, uscr, mf_dst, tid, pr_flag, pr_epoch, ho);
     else if(pr_flag)     mf_add_children<NT, false, true>(P, Ug + pr_acc, ntri, it.nch, it.ch0, rc, mf_rec, uscr, mf_dst, tid, pr_flag, pr_epoch, ho);
     else if(u_lds)  mf_add_children<NT, true >(P, Us, nlin, it.nch, it.ch0, rc, mf_rec, uscr, mf_dst, tid);
     else            mf_add_children<NT, false>(P, Ug, ntri, it.nch, it.ch0, rc, mf_rec, uscr, mf_dst, tid);
@@ -1401,7 +1511,7 @@ extern "C" void dlg_fl_profile_dump(int nlevels)
         std::vector<long long> ha(FL_PROF_WG*4);
         static bool got = false; static std::vector<long long> hadd;
         if(!got) { hadd.resize(FL_PROF_WG*4); hipMemcpyFromSymbol(hadd.data(), HIP_SYMBOL(g_fl_add), sizeof(long long)*hadd.size()); got = true; }
-        if(hadd[g*4 + 0]) fprintf(stderr, "   add %3d: child0 seen %6lld child0 added %6lld last child seen %6lld\n", g, hadd[g*4] - t0, hadd[g*4 + 1] - t0, hadd[g*4 + 2] - t0);
+        if(hadd[g*4 + 0]) fprintf(stderr, "   add %3d: child0 seen %6lld child0 added %6lld last child seen %6lld dbg %lld\n", g, hadd[g*4] - t0, hadd[g*4 + 1] - t0, hadd[g*4 + 2] - t0, hadd[g*4 + 3]);
       }
       fprintf(stderr, "   wg %3d (w %3lld rows %4lld nch %lld u_lds %lld lvl %lld rep %lld): start %6lld flag up %6lld panel in %6lld added %6lld factored %6lld tail %6lld flag+stored %6lld\n",
               g, q[6] & 4095, (q[6] >> 12) & 4095, (q[6] >> 24) & 4095, (q[6] >> 36) & 1, (q[6] >> 56) & 63, (q[6] >> 52) & 15, q[0] - t0, q[7] - t0, q[1] - t0, q[2] - t0, q[3] - t0, q[4] - t0, q[5] - t0);

@@ -6,7 +6,7 @@ cd "$(dirname "$0")/.."
 if [ "$1" = build ]; then
   python3 -c "import __graft_entry__ as g; g.build()" >/dev/null 2>&1
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -mllvm -amdgpu-mfma-vgpr-form=1 -DDLG_FL_PROFILE \
-    -Iinclude -c libdogleg_amd/csrc/sparse_factor.hip -o /tmp/sparse_factor_prof.o 2>/dev/null || exit 1
+    -Iinclude -c libdogleg_amd/csrc/sparse_factor.hip -o /tmp/sparse_factor_prof.o 2>/tmp/prof_build.err || exit 1
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -DDLG_FL_PROFILE \
     -Iinclude -c libdogleg_amd/csrc/sparse_solve.hip -o /tmp/sparse_solve_prof.o 2>/dev/null || exit 1
   objs=$(ls libdogleg_amd/csrc/_obj/*.o | grep -v sparse_factor.hip.o | grep -v sparse_solve.hip.o)
