@@ -234,7 +234,7 @@ def optimize_device(p0, N, M, nnz, Jp, Ji, cb, cookie, params=None, capacity=256
 SYM_STAT_NAMES = ["var_blocks", "supernodes", "levels", "nnz_JtJ_lower", "nnz_L", "panel_doubles",
                   "factor_flops", "max_panel", "asm_tasks", "update_items", "relpos", "out_blocks",
                   "contribs", "update_subtasks", "solve_scratch", "jtx_tasks", "asm_mfma_tasks",
-                  "asm_kgroups", "asm_shapes"]
+                  "asm_kgroups", "asm_shapes", "leaf_fronts", "lf_leaves", "lf_lds", "lf_blob_bytes", "lf_jtx_record"]
 
 
 def symbolic_probe(N, M, Jp, Ji, row0=0, row1=None, want_perm=False):

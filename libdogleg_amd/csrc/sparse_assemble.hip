@@ -692,10 +692,11 @@ __device__ __forceinline__ bool phase_has(const int* __restrict__ sn_owner, int 
 __global__ void __launch_bounds__(TPB) k_add_lambda(double* __restrict__ Lx,
                                                     const int64_t* __restrict__ diagpos, int n,
                                                     double lambda, const int* __restrict__ col_sn,
-                                                    const int* __restrict__ sn_owner, int phase)
+                                                    const int* __restrict__ sn_owner, int phase,
+                                                    const char* __restrict__ skip)
 {
   const int i = blockIdx.x*TPB + threadIdx.x;
-  if(i < n && phase_has(sn_owner, col_sn[i], phase)) Lx[diagpos[i]] += lambda;
+  if(i < n && phase_has(sn_owner, col_sn[i], phase) && !(skip && skip[i])) Lx[diagpos[i]] += lambda;      // (skip: columns of the leaf fronts, which took lambda themselves)
 }
 
 // augmented row: panel(last row, column k) += rhs[perm[k]]   (the row is zero after the assembly;
@@ -706,12 +707,14 @@ __global__ void __launch_bounds__(TPB) k_set_aug_row(double* __restrict__ Lx, co
                                                      const int* __restrict__ perm,
                                                      const double* __restrict__ rhs, int n,
                                                      int* __restrict__ info,
-                                                     const int* __restrict__ sn_owner, int phase)
+                                                     const int* __restrict__ sn_owner, int phase,
+                                                     const char* __restrict__ skip)
 {
   const int k = blockIdx.x*TPB + threadIdx.x;
   if(k == 0 && phase <= 0) *info = 0x7fffffff;          // re-arm the pivot flag of the factorisation that follows
   if(k >= n) return;
   if(phase >= 0 && !phase_has(sn_owner, col_sn[k], phase)) return;
+  if(skip && skip[k]) return;                           // (a column of a leaf front: its right-hand side went in with the front)
   Lx[augpos[k]] += rhs[perm[k]];
 }
 
@@ -955,13 +958,13 @@ int sparse_assemble_finish(dlg_backend* b)
   // augmented row now, and the pivot flag is re-armed: nothing left to launch between the caller's
   // decision to factorise and the first factor kernel.  It rides in the first partial-sum launch.
   bool aug_done = false;
-  DLG_CHECK(assemble_fin_launch(b, Lx, Y->fin_pending_rhs, &aug_done));
+  if(!Y->lf_on) DLG_CHECK(assemble_fin_launch(b, Lx, Y->fin_pending_rhs, &aug_done));     // (leaf fronts: no partial sums, the fronts ARE the assembly)
   if(Y->fin_pending_rhs)
   {
     const SymHost& H = Y->H;
     if(!aug_done)
       hipLaunchKernelGGL(k_set_aug_row, dim3(dlg_cdiv(H.N, TPB)), dim3(TPB), 0, b->stream, Lx, Y->col_sn, Y->augpos,
-                         Y->perm, Y->fin_pending_rhs, H.N, Y->d_info, Y->sn_owner, -1);
+                         Y->perm, Y->fin_pending_rhs, H.N, Y->d_info, Y->sn_owner, -1, Y->lf_on ? Y->lf_col : (const char*)nullptr);
     DLG_LAUNCH_CHECK();
     Y->spec_aug_rhs = Y->fin_pending_rhs; Y->info_clean = true;
     Y->fin_pending_rhs = nullptr;
@@ -969,14 +972,37 @@ int sparse_assemble_finish(dlg_backend* b)
   return DLG_OK;
 }
 static int assemble_launch(dlg_backend* b, const double* Jv, double* Lx = nullptr, const double* xvec = nullptr, double* Jt_x = nullptr,
-                           bool zeroed = false, bool defer_fin = false)
+                           bool zeroed = false, bool defer_fin = false, const double* lf_rhs = nullptr, double lf_lambda = 0.0)
 {
   SparseSym* Y = b->sym;
   const SymHost& H = Y->H;
   hipStream_t st = b->stream;
   DLG_CHECK(sparse_assemble_finish(b));             // (an earlier assembly's partial sums live in the buffers this one fills)
   if(!Lx) Lx = Y->Lx;
-  if(!zeroed) DLG_HIP(hipMemsetAsync(Lx, 0, sizeof(double)*(size_t)H.lx_size, st));
+  if(!zeroed) DLG_HIP(hipMemsetAsync(Lx, 0, sizeof(double)*((size_t)H.lx_size + 8), st));
+  if(Y->lf_on)
+  {
+    // leaf fronts: JtJ, Jt*x and the leaves' factorisation in one pass over J (sparse_leaf.hip); the panels of the
+    // ancestors stay zero until the update gather brings them everything
+    {
+      DlgProfScope pk(b, DLG_PROF_K4_KERNEL);
+      DLG_CHECK(sparse_leaf_front(b, Jv, Lx, xvec, Jt_x, xvec ? nullptr : lf_rhs, lf_lambda));
+    }
+    Y->lf_gen++;
+    if(xvec)
+    {
+      const int ns = (int)H.lf_jf_short.size(), nl = (int)H.lf_jf_long.size();
+      if(ns > 0)
+        hipLaunchKernelGGL(k_jtx_fin2_short, dim3(dlg_cdiv(ns, TPB/16)), dim3(TPB), 0, st, Y->lf_jf_short, ns, Y->lf_jf_ptr,
+                           Y->lf_jf_ent, Y->lf_jf_var0, Y->lf_jf_w, Y->lf_jtp, Jt_x);
+      if(nl > 0)
+        hipLaunchKernelGGL(k_jtx_fin2_long, dim3(nl*JFL_SEG), dim3(1024), 0, st, Y->lf_jf_long, Y->lf_jf_ptr, Y->lf_jf_ent,
+                           Y->lf_jf_var0, Y->lf_jf_w, Y->lf_jtp, Jt_x, Y->lf_jf_lpart, Y->lf_jf_lcnt);
+    }
+    if(defer_fin) { Y->fin_pending_Lx = Lx; Y->fin_pending_rhs = Jt_x; }
+    DLG_LAUNCH_CHECK();
+    return DLG_OK;
+  }
   const int nt = (int)H.asm_ctask.size(), nmt = (int)H.asm_mtask.size();
   if(nt > 0 || nmt > 0)
   {
@@ -1136,7 +1162,10 @@ int sparse_assemble(dlg_backend* b, int s, double lambda)
   }
   DLG_CHECK(sparse_assemble_finish(b));
   bool adopted = false;
-  if(Y->spec_valid && Y->spec_slot == s && Y->spec_J == S.Jin())
+  // (leaf fronts: the second buffer holds FACTORED leaf panels -- they are this factorisation's only if they were
+  // formed at this lambda and the leaves' update matrices in the scratch are still that launch's)
+  const bool lf_fits = !Y->lf_on || (Y->spec_lambda == lambda && Y->spec_gen == Y->lf_gen);
+  if(Y->spec_valid && Y->spec_slot == s && Y->spec_J == S.Jin() && lf_fits)
   {
     std::swap(Y->Lx, Y->Lx_spec);           // the panels assembled beside K1 become the factor's panels
     Y->spec_valid = false;
@@ -1148,7 +1177,8 @@ int sparse_assemble(dlg_backend* b, int s, double lambda)
   else
   {
     DlgProfScope pt(b, DLG_PROF_K4_TOTAL);
-    DLG_CHECK(assemble_launch(b, S.Jin()));
+    Y->spec_valid = Y->spec_valid && !(Y->spec_slot == s);      // (a second buffer that did not fit is of no further use)
+    DLG_CHECK(assemble_launch(b, S.Jin(), nullptr, nullptr, nullptr, false, false, S.have_Jtx ? S.Jt_x : (const double*)nullptr, lambda));
   }
   // contiguous row sharding: sum the partial JtJ of all ranks before factorising
   {
@@ -1165,7 +1195,7 @@ int sparse_assemble(dlg_backend* b, int s, double lambda)
   const int phase = H.part_nranks > 1 ? 0 : -1;
   if(lambda != 0.0)
     hipLaunchKernelGGL(k_add_lambda, dim3(dlg_cdiv(H.N, TPB)), dim3(TPB), 0, st, Y->Lx, Y->diagpos, H.N,
-                       lambda, Y->col_sn, Y->sn_owner, phase);
+                       lambda, Y->col_sn, Y->sn_owner, phase, Y->lf_on ? Y->lf_col : (const char*)nullptr);
   // the right-hand side rides along as the last row of every panel: y = L^-1 P Jt_x falls out
   Y->aug_rhs = nullptr;
   Y->info_armed = false;
@@ -1178,7 +1208,7 @@ int sparse_assemble(dlg_backend* b, int s, double lambda)
   else if(S.have_Jtx)
   {
     hipLaunchKernelGGL(k_set_aug_row, dim3(dlg_cdiv(H.N, TPB)), dim3(TPB), 0, st, Y->Lx, Y->col_sn, Y->augpos,
-                       Y->perm, S.Jt_x, H.N, Y->d_info, Y->sn_owner, phase);
+                       Y->perm, S.Jt_x, H.N, Y->d_info, Y->sn_owner, phase, Y->lf_on ? Y->lf_col : (const char*)nullptr);
     Y->aug_rhs = S.Jt_x;
     Y->info_armed = true;
   }
@@ -1237,10 +1267,10 @@ int sparse_partition_reduce(dlg_backend* b)
   }
   if(Y->cur_lambda != 0.0)
     hipLaunchKernelGGL(k_add_lambda, dim3(dlg_cdiv(H.N, TPB)), dim3(TPB), 0, st, Y->Lx, Y->diagpos, H.N,
-                       Y->cur_lambda, Y->col_sn, Y->sn_owner, 1);
+                       Y->cur_lambda, Y->col_sn, Y->sn_owner, 1, (const char*)nullptr);
   if(Y->aug_rhs)
     hipLaunchKernelGGL(k_set_aug_row, dim3(dlg_cdiv(H.N, TPB)), dim3(TPB), 0, st, Y->Lx, Y->col_sn, Y->augpos,
-                       Y->perm, Y->aug_rhs, H.N, Y->d_info, Y->sn_owner, 1);
+                       Y->perm, Y->aug_rhs, H.N, Y->d_info, Y->sn_owner, 1, (const char*)nullptr);
   DLG_LAUNCH_CHECK();
   return DLG_OK;
 }
@@ -1255,12 +1285,12 @@ int sparse_partition_reduce(dlg_backend* b)
 int sparse_assemble_speculative(dlg_backend* b, int s)
 {
   SparseSym* Y = b->sym;
-  if(!Y || !b->aux_stream || b->sharded() || Y->H.part_nranks > 1) return DLG_OK;
+  if(!Y || !b->aux_stream || b->sharded() || Y->H.part_nranks > 1 || Y->lf_on) return DLG_OK;
   const SymHost& H = Y->H;
   DlgSlot& S = b->slot[s];
   if(!Y->Lx_spec)
   {
-    DLG_HIP(hipMalloc(&Y->Lx_spec, sizeof(double)*(size_t)(H.lx_size ? H.lx_size : 1))); Y->allocs.push_back(Y->Lx_spec);
+    DLG_HIP(hipMalloc(&Y->Lx_spec, sizeof(double)*((size_t)H.lx_size + 8))); Y->allocs.push_back(Y->Lx_spec);
     DLG_HIP(hipEventCreateWithFlags(&Y->ev_spec, hipEventDisableTiming));
     DLG_HIP(hipEventCreateWithFlags(&Y->ev_spec_fork, hipEventDisableTiming));
   }
@@ -1293,14 +1323,14 @@ int sparse_eval_assemble(dlg_backend* b, int s, int* done)
   SparseSym* Y = b->sym;
   if(!Y) { dlg_set_error("dlg_sparse_set_pattern must be called first"); return DLG_ERR_STATE; }
   const SymHost& H = Y->H;
-  if(!H.asm_jtx_ok || !Y->jtp) return DLG_OK;
+  if(!Y->lf_on && (!H.asm_jtx_ok || !Y->jtp)) return DLG_OK;
   // (sharded rows / subtree partition: the rank's rows give its share of Jt*x and of JtJ as the separate
   // kernels would; the sums over the ranks follow where they always did)
   DlgSlot& S = b->slot[s];
   hipStream_t st = b->stream;
   if(!Y->Lx_spec)
   {
-    DLG_HIP(hipMalloc(&Y->Lx_spec, sizeof(double)*(size_t)(H.lx_size ? H.lx_size : 1))); Y->allocs.push_back(Y->Lx_spec);
+    DLG_HIP(hipMalloc(&Y->Lx_spec, sizeof(double)*((size_t)H.lx_size + 8))); Y->allocs.push_back(Y->Lx_spec);
     DLG_HIP(hipEventCreateWithFlags(&Y->ev_spec, hipEventDisableTiming));
     DLG_HIP(hipEventCreateWithFlags(&Y->ev_spec_fork, hipEventDisableTiming));
   }
@@ -1311,7 +1341,10 @@ int sparse_eval_assemble(dlg_backend* b, int s, int* done)
   {
     DlgProfScope pt(b, DLG_PROF_K4_TOTAL);
     // (the partial-sum stages of JtJ wait until the caller has Jt*x on its way to the host: sparse_assemble_finish)
-    DLG_CHECK(assemble_launch(b, S.Jin(), Y->Lx_spec, S.xin(), S.Jt_x, zeroed, true));
+    // (leaf fronts: the leaves are factored in this pass, at the lambda of the last factorisation -- the driver's
+    // lambda only ever changes when a factorisation fails, and then the point is assembled again)
+    DLG_CHECK(assemble_launch(b, S.Jin(), Y->Lx_spec, S.xin(), S.Jt_x, zeroed, true, nullptr, Y->cur_lambda));
+    Y->spec_lambda = Y->cur_lambda; Y->spec_gen = Y->lf_gen;
     if(b->sharded()) Y->fin_pending_rhs = nullptr;     // Jt*x is not summed over the ranks yet: the augmented row waits for the factorisation
   }
   Y->spec_valid = true; Y->spec_slot = s; Y->spec_J = S.Jin(); Y->spec_aug_rhs = nullptr;
@@ -1325,7 +1358,7 @@ int sparse_zero_spare(dlg_backend* b)
   SparseSym* Y = b->sym;
   if(!Y || !Y->spare_dirty || !Y->Lx_spec) return DLG_OK;
   Y->spare_dirty = false;
-  DLG_HIP(hipMemsetAsync(Y->Lx_spec, 0, sizeof(double)*(size_t)Y->H.lx_size, b->stream));
+  DLG_HIP(hipMemsetAsync(Y->Lx_spec, 0, sizeof(double)*((size_t)Y->H.lx_size + 8), b->stream));
   Y->spare_zeroed = true; Y->spare_stream = b->stream;
   return DLG_OK;
 }

@@ -3,10 +3,9 @@
 // factorisation (k_factor_level), then the updates of the ancestors by the level's panels.
 #include "sparse_internal.h"
 #include "panel_factor.h"
+#include "factor_tail.h"
 
 namespace {
-typedef double dlg_v4d __attribute__((ext_vector_type(4)));
-typedef double dlg_v2d __attribute__((ext_vector_type(2)));
 // -DDLG_FL_PROFILE: phase clocks of workgroup 0 of every factor launch (tools only)
 #ifdef DLG_FL_PROFILE
 constexpr int FL_PROF_WG = 1024;       // workgroups per level whose phase clocks are kept
@@ -18,12 +17,6 @@ __device__ long long g_fl_add[FL_PROF_WG*4];          // the children's adds of 
 #define FL_STAMP(k)
 #define FL_ADD_STAMP(k)
 #endif
-
-// ------------------------------------------------------------------ K5 ------
-// Update matrices (U = B B' of a supernode, B = the mb rows below its diagonal block, plus in
-// the multifrontal region what its children left over) are stored as packed lower triangles,
-// column-major: element (i, j), i >= j, at  j*mb - j*(j-1)/2 + (i - j).
-__device__ __forceinline__ int tri_col(int j, int mb) { return j*mb - j*(j - 1)/2 - j; }   // (i, j) at tri_col + i
 
 // multifrontal region: add the update matrices of the children of a supernode into its LDS
 // panel P (entries whose column is one of the supernode's own columns) and into its own update
@@ -237,132 +230,6 @@ __device__ __forceinline__ void mf_add_two_pipelined(double* P, double* Wt, int 
   __syncthreads();
 }
 
-// NCH consecutive lower 16x16 tiles (column-major tile order, first tile `first`) of
-// U = B B' (B = the mb rows below the diagonal block of the LDS panel Pb, w columns), one
-// accumulator chain per tile, every chain with its own operands (the tiles may span two tile
-// columns).  Rows / columns past the end are clamped (their results are never written); two
-// k-steps per iteration with their own operand registers, so the loads of one are in flight
-// during the products of the other.  mode 2: the multifrontal region keeps W = (children) - U.
-template <int NCH>
-__device__ __forceinline__ void factor_tail_tiles(const double* Pb, int ldp, int w, int mb, int T, int first,
-                                                  double* Ud, int mode, bool w_hbm, bool mf_acc, int lane,
-                                                  int64_t acc_shift, bool st_wt, int usp, double* Pgap, int ush)
-{
-  const int jn = lane & 15, kq = lane >> 4;
-  int ti[NCH], tjq[NCH], oa[NCH], ob[NCH];
-  dlg_v4d c4[NCH];
-  {
-    int rem = first, tj = 0;
-    while(rem >= T - tj) { rem -= T - tj; tj++; }
-    int tcur = tj + rem;
-#pragma unroll
-    for(int q = 0; q < NCH; q++)
-    {
-      ti[q] = tcur; tjq[q] = tj;
-      tcur++; if(tcur >= T) { tj++; tcur = tj; }
-      oa[q] = w + min(16*ti[q] + jn, mb - 1) + kq*ldp;
-      ob[q] = w + min(16*tjq[q] + jn, mb - 1) + kq*ldp;
-      c4[q] = (dlg_v4d){0.0, 0.0, 0.0, 0.0};
-    }
-  }
-  // an update matrix kept in HBM: the children's sums of these tiles, on their way during the
-  // products (read around L1: they were formed by atomics in L2)
-  double w0[NCH][4];
-  if(w_hbm)
-  {
-#pragma unroll
-    for(int q = 0; q < NCH; q++)
-    {
-      const int j = 16*tjq[q] + jn, jt0 = tri_col(j, mb);
-#pragma unroll
-      for(int r = 0; r < 4; r++)
-      {
-        const int i = 16*ti[q] + kq + 4*r;
-        w0[q][r] = (i < mb && j <= i) ? __hip_atomic_load(Ud + acc_shift + jt0 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
-      }
-    }
-  }
-  const int w4 = w & ~3;
-  const int st = 4*ldp;
-  double a0[NCH], a1[NCH], b0[NCH], b1[NCH];
-#pragma unroll
-  for(int q = 0; q < NCH; q++) { a0[q] = 0.0; b0[q] = 0.0; }
-  int kk = 0, ko = 0;                      // ko: element offset of k-step kk
-  if(w4 >= 4)
-  {
-#pragma unroll
-    for(int q = 0; q < NCH; q++) { a0[q] = Pb[oa[q]]; b0[q] = Pb[ob[q]]; }
-  }
-  for(; kk + 8 <= w4; kk += 8)
-  {
-#pragma unroll
-    for(int q = 0; q < NCH; q++) { a1[q] = Pb[oa[q] + ko + st]; b1[q] = Pb[ob[q] + ko + st]; }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for(int q = 0; q < NCH; q++) c4[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[q], b0[q], c4[q], 0, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    ko += 2*st;
-    // the k-step after next (clamped to the last whole one: a harmless re-read at the end)
-    const int kn = (kk + 12 <= w4) ? ko : ko - 2*st;
-#pragma unroll
-    for(int q = 0; q < NCH; q++) { a0[q] = Pb[oa[q] + kn]; b0[q] = Pb[ob[q] + kn]; }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for(int q = 0; q < NCH; q++) c4[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[q], b1[q], c4[q], 0, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-  }
-  if(kk + 4 <= w4)
-  {
-    // odd number of whole k-steps: the last one
-    if(kk > 0)
-    {
-#pragma unroll
-      for(int q = 0; q < NCH; q++) { a0[q] = Pb[oa[q] + ko]; b0[q] = Pb[ob[q] + ko]; }
-    }
-#pragma unroll
-    for(int q = 0; q < NCH; q++) c4[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[q], b0[q], c4[q], 0, 0, 0);
-    kk += 4; ko += st;
-  }
-  if(kk < w)
-  {
-    // the last, partial k-step: columns past the end contribute zeros
-    const bool kok = kk + kq < w;
-    const int kz = ko - (kok ? 0 : (kk + kq - (w - 1))*ldp);
-#pragma unroll
-    for(int q = 0; q < NCH; q++)
-    {
-      const double az = kok ? Pb[oa[q] + kz] : 0.0, bz = kok ? Pb[ob[q] + kz] : 0.0;
-      c4[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(az, bz, c4[q], 0, 0, 0);
-    }
-  }
-#pragma unroll
-  for(int q = 0; q < NCH; q++)
-  {
-    const int j = 16*tjq[q] + jn, jtri = tri_col(j, mb);
-    // columns from usp on live in the strict upper triangle of the panel's top block (sym_w_split)
-    // (ush: a slice of the update matrix behind the panel starts at packed index -ush)
-    double* Uc = (j >= usp) ? Pgap + (mb - j)*ldp - j : Ud + (jtri + ush);
-#pragma unroll
-    for(int r = 0; r < 4; r++)
-    {
-      const int i = 16*ti[q] + kq + 4*r;
-      if(i < mb && j <= i)
-      {
-        if(st_wt)
-        {
-          // persistent top region, update matrix not staged in LDS: the parent reads it in this launch --
-          // write-through stores into a slot no plain store or atomic ever touches (the children's
-          // sums were formed in the shadow slot at acc_shift)
-          typedef __attribute__((address_space(1))) double* gwptr_t;
-          __hip_atomic_store((gwptr_t)(Ud + jtri + i), (w_hbm ? w0[q][r] : 0.0) - c4[q][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        else if(mode == 2) Uc[i] = (w_hbm ? w0[q][r] : (mf_acc ? Uc[i] : 0.0)) - c4[q][r];     // the region keeps W = -U
-        else Uc[i] = c4[q][r];
-      }
-    }
-  }
-}
-
 // factor one supernode panel per workgroup in LDS (column-major, even leading dimension).
 // One workgroup per work item (FwItem) = (supernode, slice [r0,r1) of its below rows): the LDS
 // panel holds the w x w top block plus the slice (up to ~160 KB); slices of one supernode factor
@@ -526,7 +393,8 @@ __global__ void __launch_bounds__(NT, LEAF ? 4 : 1) k_factor_level(const FwItem*
     const int64_t acc_shift = st_wt ? pr_acc : 0;
     for(int c = wv; c < nchunks; c += NWV)
     {
-      const int t0 = tlo + (int)((long)c*ntiles/nchunks), t1 = tlo + (int)((long)(c + 1)*ntiles/nchunks);
+      // (32-bit: c*ntiles < 2^31 by far; a 64-bit division is some hundred instructions in front of the products)
+      const int t0 = tlo + (int)((unsigned)(c*ntiles)/(unsigned)nchunks), t1 = tlo + (int)((unsigned)((c + 1)*ntiles)/(unsigned)nchunks);
       switch(t1 - t0)
       {
         case 1: factor_tail_tiles<1>(Pb, ldp, w, mb, T, t0, Ud, mode, w_hbm, mf_acc, lane, acc_shift, st_wt, usp, P, ush_t); break;
@@ -778,11 +646,18 @@ __global__ void __launch_bounds__(NT) k_update_gather(int unit0, const GatherUni
                                                        double* __restrict__ Lx,
                                                        double* __restrict__ upart,
                                                        const double* __restrict__ uscr, int nw,
-                                                       const int* __restrict__ info)
+                                                       int* __restrict__ info, const int* __restrict__ lf_word)
 {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   __shared__ int s_skip;
-  if(threadIdx.x == 0) s_skip = *info != 0x7fffffff;      // a failed factorisation is not worth finishing
+  if(threadIdx.x == 0)
+  {
+    // (leaf fronts: the leaves were factored with the assembly, their pivot word sits behind the panels -- zero
+    // if every pivot was positive; it joins the factorisation's flag here, in front of the levels above)
+    const int lw = lf_word ? *lf_word : 0;
+    if(lw != 0 && blockIdx.x == 0) atomicMin(info, 0x7fffffff - lw);
+    s_skip = *info != 0x7fffffff || lw != 0;      // a failed factorisation is not worth finishing
+  }
   // (one flat record: the chain unit -> item -> target supernode -> its rows cost three dependent loads
   // in front of the first barrier)
   const GatherUnit U0 = units[unit0 + blockIdx.x];
@@ -1564,7 +1439,7 @@ int sparse_factor_levels(dlg_backend* b)
       if(dbg_sync) { fprintf(stderr, "libdogleg_amd: after the one-launch region (%d workgroups): %s\n", np, hipGetErrorString(hipStreamSynchronize(st))); fflush(stderr); }
       break;
     }
-    if(n > 0)
+    if(n > 0 && !(l == 0 && Y->lf_on))      // (leaf fronts: level 0 was factored with the assembly, sparse_leaf.hip)
     {
       const int o = H.fw_lvl_ptr[l];
       const int use_ahead = Y->fac_ahead ? 8 : 0;     // barrier-free sweep: measured slower (tools/micro/bench_ahead), kept for experiments
@@ -1599,7 +1474,7 @@ int sparse_factor_levels(dlg_backend* b)
       // waves sharing a unit's sub-tasks)
       hipLaunchKernelGGL(HIP_KERNEL_NAME(k_update_gather<TPB>), dim3(nu), dim3(TPB), Y->upd_lds[l], st, H.uw_lvl_ptr[l],
                          Y->uw_flat, Y->usub, Y->usub_u, Y->relpos, Y->Lx, Y->upart, Y->uscr,
-                         Y->upd_nw[l], Y->d_info);
+                         Y->upd_nw[l], Y->d_info, (l == 0 && Y->lf_on) ? reinterpret_cast<const int*>(Y->Lx + H.lx_size) : (const int*)nullptr);
     }
     else if(nu > 0 && Y->upd_coop[l] == 2)
       hipLaunchKernelGGL(k_update_mfma, dim3(nu), dim3(TPB), Y->upd_lds[l], st, H.uw_lvl_ptr[l],

@@ -112,7 +112,7 @@ void sparse_reset(dlg_backend* b)
   if(!Y) return;
   Y->spec_valid = false; Y->spec_inflight = false; Y->spec_slot = -1; Y->spec_J = nullptr;
   Y->aug_rhs = nullptr; Y->spec_aug_rhs = nullptr; Y->fin_pending_rhs = nullptr; Y->fin_pending_Lx = nullptr;
-  Y->info_armed = false; Y->info_clean = false;
+  Y->info_armed = false; Y->info_clean = false; Y->spec_gen = -1;
 }
 
 int sparse_set_pattern(dlg_backend* b, const int* colptr, const int* rowidx)
@@ -250,7 +250,7 @@ int sparse_set_pattern(dlg_backend* b, const int* colptr, const int* rowidx)
   lap("schedule uploads");
   auto dalloc = [&](double*& p, size_t n) -> int {
     DLG_HIP(hipMalloc(&p, sizeof(double)*(n ? n : 1))); Y->allocs.push_back(p); return DLG_OK; };
-  DLG_CHECK(dalloc(Y->Lx, (size_t)H.lx_size));
+  DLG_CHECK(dalloc(Y->Lx, (size_t)H.lx_size + 8));       // (+ the leaf fronts' pivot word behind the panels)
   DLG_CHECK(dalloc(Y->scr, (size_t)H.scr_size));
   DLG_CHECK(dalloc(Y->ywork, (size_t)H.N));
   DLG_CHECK(dalloc(Y->upart, (size_t)H.upart_size));
@@ -300,6 +300,7 @@ int sparse_set_pattern(dlg_backend* b, const int* colptr, const int* rowidx)
   }
   lap("numeric buffers");
   DLG_CHECK(sparse_factor_setup(b));
+  DLG_CHECK(sparse_leaf_setup(b));
   DLG_CHECK(sparse_solve_setup(b));
   lap("kernel set-up");
   return DLG_OK;
@@ -468,7 +469,8 @@ extern "C" int dlg_sparse_symbolic_probe(int N, int M, const int* colptr, const 
                      (long)H.ui_t.size(), (long)H.relpos.size(), (long)H.oblk.size(),
                      (long)H.contrib.size(), (long)H.usub.size(), (long)H.scr_size,
                      (long)H.jtx_task.size(), (long)H.asm_mtask.size(), (long)H.asm_kg.size(),
-                     (long)H.asm_shape.size() };
+                     (long)H.asm_shape.size(), (long)H.lf_ok, (long)H.lf_leaf.size(), (long)H.lf_lds, (long)H.lf_blob.size(), (long)H.lf_jtp_size };
+  if(!H.lf_ok && getenv("DOGLEG_AMD_SYM_DEBUG")) fprintf(stderr, "leaf fronts off: %s\n", H.lf_why);
   for(int i = 0; i < nstats && i < (int)(sizeof(v)/sizeof(v[0])); i++) stats[i] = v[i];
   if(perm_out) memcpy(perm_out, H.perm.data(), sizeof(int)*(size_t)N);
   return DLG_OK;

@@ -134,6 +134,14 @@ struct SparseSym
   FwItem* pr_item = nullptr; MfChild* pr_rec = nullptr; uint16_t* pr_dst = nullptr; int pr_nwg = 0;
   std::vector<FwItem> pr_item_h; std::vector<MfChild> pr_rec_h; std::vector<uint16_t> pr_dst_h;   // ... on the host (plan-only set-up: dlg_sparse_region_probe)   // the region's work items (supernode x replica) and its copy of the children records
   bool fac_ahead = false;       // panel_factor_ahead instead of panel_factor_mfma (DOGLEG_AMD_AHEAD)
+  // leaf fronts (sparse_leaf.hip): assembly + Jt*x + the leaves' factorisation in one kernel
+  bool lf_on = false;
+  LfLeaf* lf_leaf = nullptr; uint8_t* lf_blob = nullptr; double* lf_jtp = nullptr; char* lf_col = nullptr;
+  int *lf_jf_ptr = nullptr, *lf_jf_ent = nullptr, *lf_jf_var0 = nullptr, *lf_jf_w = nullptr, *lf_jf_short = nullptr, *lf_jf_long = nullptr;
+  double* lf_jf_lpart = nullptr; int* lf_jf_lcnt = nullptr;
+  // the leaves' update matrices in uscr belong to ONE assembly: lf_gen counts the launches, spec_gen / spec_lambda
+  // say which launch (at which lambda) filled the second panel buffer
+  long lf_gen = 0, spec_gen = -1; double spec_lambda = 0.0;
   int bwd_xb_cap = 12288;       // below rows of a supernode staged in LDS by the backward solve
   std::vector<void*> allocs;
 };
@@ -147,5 +155,7 @@ int sparse_assemble_finish(dlg_backend* b);                   // ... its JtJ par
 int sparse_zero_spare(dlg_backend* b);                        // clear the swapped-out panel buffer behind the step's fetch
 void sparse_spec_invalidate(dlg_backend* b, int s);                 // subtree partition: the sum over the ranks at the cut
 int sparse_factor_setup(dlg_backend* b, bool plan_only = false);   // per-level launch parameters of K5
+int sparse_leaf_setup(dlg_backend* b);                       // leaf fronts: uploads (after sparse_factor_setup)
+int sparse_leaf_front(dlg_backend* b, const double* Jv, double* Lx, const double* x, double* Jt_x, const double* rhs, double lambda);
 int sparse_factor_levels(dlg_backend* b);                    // K5 launches (no synchronisation)
 int sparse_solve_setup(dlg_backend* b);                      // per-level launch parameters of K6
