@@ -44,13 +44,15 @@ __device__ long long g_lf_wave[16*64];      // workgroup 300: per wave, cycle st
 // member block of NB columns from its accumulated entries in Dg (row c, column q at Dg[(c0 + c)*4 + q]):
 // factored in registers, left in Dg for the rows' solves and written to the panel's top block
 template <int NB>
-__device__ __forceinline__ int lf_factor_member(double* Dg, int c0, double* rdiag, double* __restrict__ G, int ldg)
+__device__ __forceinline__ int lf_factor_member(double* Dg, int c0, double* rdiag, double* __restrict__ G, int ldg, double lambda)
 {
   double D[NB][NB];
 #pragma unroll
   for(int c = 0; c < NB; c++)
 #pragma unroll
     for(int q = 0; q <= c; q++) D[c][q] = Dg[(c0 + c)*4 + q];
+#pragma unroll
+  for(int c = 0; c < NB; c++) D[c][c] += lambda;
   int badcol = -1;
 #pragma unroll
   for(int c = 0; c < NB; c++)
@@ -103,7 +105,7 @@ __device__ __forceinline__ void lf_barrier() { asm volatile("s_waitcnt lgkmcnt(0
 // leaf i + (number of workgroups) is fetched (during the strip tasks) and then its rows (during the elimination) --
 // the three dependent global round trips of a leaf (record -> table -> rows, ~5 us) disappear behind the work.
 __global__ void __launch_bounds__(LF_NT, 1) k_leaf_front(const LfLeaf* __restrict__ leaves, int nleaf,
-                                                         const uint8_t* __restrict__ blob_g,
+                                                         const uint8_t* __restrict__ blob_g, int b_stride, int b_smax, int b_tb,
                                                          const int* __restrict__ perm,
                                                          const double* __restrict__ Jv,
                                                          const double* __restrict__ x,
@@ -124,17 +126,22 @@ __global__ void __launch_bounds__(LF_NT, 1) k_leaf_front(const LfLeaf* __restric
   // (per row one word: lanes 0..14 the first value of the row | its entries << 28, lane 15 the row itself (for x))
   int n_w[LF_Q], n_sd[LF_Q], n_sd2[LF_Q/2], n_pvar = 0;      // (n_sd: as loaded; packed in pairs once they have arrived)
   double n_v[LF_Q];
-  auto load_table = [&](const LfLeaf& L) {
-    const int32_t* svg = reinterpret_cast<const int32_t*>(blob_g + L.blob);
-    const uint16_t* sdg = reinterpret_cast<const uint16_t*>(svg + 2*L.nslots);
-    const int32_t* wg = (k16 == 15) ? svg + L.nslots : svg;
+  // (b_stride > 0: every blob at leaf*b_stride, its table padded to b_smax rows -- no field of the leaf's record is
+  // needed to find it, the loads go out beside the load of the record)
+  auto load_table_at = [&](const uint8_t* blob, int smax, int nsl) {
+    const int32_t* svg = reinterpret_cast<const int32_t*>(blob);
+    const uint16_t* sdg = reinterpret_cast<const uint16_t*>(svg + 2*smax);
+    const int32_t* wg = (k16 == 15) ? svg + smax : svg;
 #pragma unroll
     for(int q = 0; q < LF_Q; q++)
     {
-      const int g = min((tid >> 4) + (NT/16)*q, L.nslots - 1);
+      const int g = min((tid >> 4) + (NT/16)*q, nsl - 1);
       n_w[q] = wg[g];
       n_sd[q] = sdg[g];
     }
+  };
+  auto load_table = [&](const LfLeaf& L) {
+    load_table_at(blob_g + L.blob, b_stride > 0 ? b_smax : L.nslots, b_stride > 0 ? b_smax : L.nslots);
     if(tid >= NT - 64 && tid - (NT - 64) < L.w) n_pvar = perm[L.col0 + tid - (NT - 64)];      // (the last wave sets the right-hand side row)
   };
   auto load_values = [&](const LfLeaf& L) {
@@ -143,11 +150,14 @@ __global__ void __launch_bounds__(LF_NT, 1) k_leaf_front(const LfLeaf* __restric
     {
       const int len = (int)((unsigned)n_w[q] >> 28), off = n_w[q] & 0xfffffff;
       const bool isx = k16 == 15;
-      const double* src = isx ? (x ? x + n_w[q] : Jv) : Jv + ((size_t)off + min(k16, len - 1));
+      const double* src = isx ? (x ? x + n_w[q] : Jv) : Jv + ((size_t)off + max(min(k16, len - 1), 0));
       n_v[q] = *src;                              // (as loaded: nothing here may wait for it; masked when it goes to LDS)
     }
+    if(LF_PREFETCH)
+    {
 #pragma unroll
-    for(int q = 0; q < LF_Q/2; q++) n_sd2[q] = n_sd[2*q] | (n_sd[2*q + 1] << 16);
+      for(int q = 0; q < LF_Q/2; q++) n_sd2[q] = n_sd[2*q] | (n_sd[2*q + 1] << 16);
+    }
   };
   if(LF_PREFETCH)
   {
@@ -156,12 +166,26 @@ __global__ void __launch_bounds__(LF_NT, 1) k_leaf_front(const LfLeaf* __restric
     load_table(L0);
     load_values(L0);
   }
-  for(int leaf = blockIdx.x; leaf < nleaf; leaf += gridDim.x)
+  int leaf = blockIdx.x;
+  do        // (a workgroup per leaf unless LF_PREFETCH)
   {
   LF_STAMP(0);
+  uint4 bl0 = {0u, 0u, 0u, 0u};
+  if(!LF_PREFETCH && b_stride > 0)
+  {
+    // table and schedule from the leaf's index alone (beside the load of its record)
+    const uint8_t* blob = blob_g + (size_t)leaf*b_stride;
+    load_table_at(blob, b_smax, b_smax);
+    bl0 = reinterpret_cast<const uint4*>(blob + b_tb)[tid];      // (the stride covers a whole pass of the workgroup?  see the launch)
+  }
   const LfLeaf lf = leaves[leaf];
   const bool more = LF_PREFETCH && leaf + (int)gridDim.x < nleaf;
-  if(!LF_PREFETCH) { load_table(lf); load_values(lf); }
+  if(!LF_PREFETCH)
+  {
+    if(b_stride > 0) { if(tid >= NT - 64 && tid - (NT - 64) < lf.w) n_pvar = perm[lf.col0 + tid - (NT - 64)]; }
+    else load_table(lf);
+    load_values(lf);
+  }
   const int w = lf.w, nrows = lf.nrows, mb = nrows - w, ldp = (mb + 1) & ~1, ntri = mb*(mb + 1)/2;
   const int nslots = lf.nslots;
   double* Us = P + ldp*w;                         // the packed update matrix (direct contributions, then U - them)
@@ -176,7 +200,7 @@ __global__ void __launch_bounds__(LF_NT, 1) k_leaf_front(const LfLeaf* __restric
   {
     // (the schedule: fetched here, stored at the end of this phase -- four registers held across a leaf were spilled,
     // and the spill of a load in flight waits for it; phase 4 of the leaf before touched its cache lines)
-    const uint4 bl = reinterpret_cast<const uint4*>(bg + lf.o_lds)[min(tid, (lf.lds_bytes >> 4) - 1)];
+    const uint4 bl = (!LF_PREFETCH && b_stride > 0) ? bl0 : reinterpret_cast<const uint4*>(bg + lf.o_lds)[min(tid, (lf.lds_bytes >> 4) - 1)];
     const int nz = (int)(R - P) >> 1;
     for(int c = tid; c < nz; c += NT) reinterpret_cast<dlg_v2d*>(P)[c] = (dlg_v2d){0.0, 0.0};
     if(tid < LF_RS) R[nslots*LF_RS + tid] = 0.0;
@@ -186,7 +210,7 @@ __global__ void __launch_bounds__(LF_NT, 1) k_leaf_front(const LfLeaf* __restric
     for(int q = 0; q < LF_Q; q++)
     {
       const int g = (tid >> 4) + (NT/16)*q;
-      const int sd = (q & 1) ? (int)((unsigned)n_sd2[q >> 1] >> 16) : (n_sd2[q >> 1] & 0xFFFF);
+      const int sd = !LF_PREFETCH ? n_sd[q] : (q & 1) ? (int)((unsigned)n_sd2[q >> 1] >> 16) : (n_sd2[q >> 1] & 0xFFFF);
       // (positions past the row's entries hold whatever followed the row in J: no strip keeps a product with them;
       // position 15 without x: zero)
       if(g < nslots) R[sd*LF_RS + k16] = (k16 == 15 && !x) ? 0.0 : n_v[q];
@@ -447,23 +471,23 @@ __global__ void __launch_bounds__(LF_NT, 1) k_leaf_front(const LfLeaf* __restric
     const int c = tid - (NT - 64);
     if(x) { if(Jt_x) Jt_x[pvar] = P[(mb - 1) + c*ldp]; }
     else if(rhs) P[(mb - 1) + c*ldp] = rhs[pvar];
-    if(lambda != 0.0) Dg[c*4 + (c % lf.bdw)] += lambda;
   }
+  // the members beside them (a wave of their own: the diagonal blocks were complete with the strip tasks)
   for(int m = tid; m <= lf.nbd; m += NT) s_mcol[m] = (m < lf.nbd) ? m*lf.bdw : w;
-  lf_barrier();
-  for(int m = tid; m < lf.nbd; m += NT)
-  {
-    const int c0 = m*lf.bdw;
-    int badcol;
-    switch(lf.bdw)
+  if(tid >= NT/2 && tid - NT/2 < 64)
+    for(int m = tid - NT/2; m < lf.nbd; m += 64)
     {
-      case 1: badcol = lf_factor_member<1>(Dg, c0, s_rdiag, G, nrows); break;
-      case 2: badcol = lf_factor_member<2>(Dg, c0, s_rdiag, G, nrows); break;
-      case 3: badcol = lf_factor_member<3>(Dg, c0, s_rdiag, G, nrows); break;
-      default: badcol = lf_factor_member<4>(Dg, c0, s_rdiag, G, nrows); break;
+      const int c0 = m*lf.bdw;
+      int badcol;
+      switch(lf.bdw)
+      {
+        case 1: badcol = lf_factor_member<1>(Dg, c0, s_rdiag, G, nrows, lambda); break;
+        case 2: badcol = lf_factor_member<2>(Dg, c0, s_rdiag, G, nrows, lambda); break;
+        case 3: badcol = lf_factor_member<3>(Dg, c0, s_rdiag, G, nrows, lambda); break;
+        default: badcol = lf_factor_member<4>(Dg, c0, s_rdiag, G, nrows, lambda); break;
+      }
+      if(badcol >= 0) atomicMin(&sbad, lf.col0 + c0 + badcol);
     }
-    if(badcol >= 0) atomicMin(&sbad, lf.col0 + c0 + badcol);
-  }
   lf_barrier();
   LF_STAMP(3);
   if(tid == 0 && sbad != 0x7fffffff) atomicMax(lf_word, 0x7fffffff - sbad);       // (0: every pivot of every leaf was positive)
@@ -525,7 +549,8 @@ __global__ void __launch_bounds__(LF_NT, 1) k_leaf_front(const LfLeaf* __restric
   }
   LF_STAMP(6);
   lf_barrier();                                   // (every wave is done with the LDS: the next leaf may have it)
-  }
+  leaf += gridDim.x;
+  } while(LF_PREFETCH && leaf < nleaf);
 }
 } // namespace
 
@@ -541,7 +566,12 @@ int sparse_leaf_setup(dlg_backend* b)
   if((int)H.lf_leaf.size() != H.fw_lvl_ptr[1] - H.fw_lvl_ptr[0]) return DLG_OK;
   if(!(H.uw_lvl_ptr[1] - H.uw_lvl_ptr[0] > 0 && H.upd_syrk[0] && Y->upd_nw[0] > 0)) return DLG_OK;     // (the update gather carries the leaves' pivot word)
   DLG_CHECK(upload(Y->lf_leaf, H.lf_leaf)); Y->allocs.push_back(Y->lf_leaf);
-  DLG_CHECK(upload(Y->lf_blob, H.lf_blob)); Y->allocs.push_back(Y->lf_blob);
+  {
+    // (+ a pass of the workgroup behind the last blob: its threads read 16 bytes each from the schedule's start, whatever its size)
+    std::vector<uint8_t> bl(H.lf_blob);
+    bl.resize(bl.size() + 16*LF_NT, 0);
+    DLG_CHECK(upload(Y->lf_blob, bl)); Y->allocs.push_back(Y->lf_blob);
+  }
   DLG_HIP(hipMalloc(&Y->lf_jtp, sizeof(double)*(size_t)std::max<int64_t>(1, H.lf_jtp_size))); Y->allocs.push_back(Y->lf_jtp);
   DLG_CHECK(upload(Y->lf_jf_ptr, H.lf_jf_ptr)); Y->allocs.push_back(Y->lf_jf_ptr);
   DLG_CHECK(upload(Y->lf_jf_ent, H.lf_jf_ent)); Y->allocs.push_back(Y->lf_jf_ent);
@@ -577,7 +607,7 @@ int sparse_leaf_front(dlg_backend* b, const double* Jv, double* Lx, const double
   // (persistent: one workgroup per CU takes leaves g, g + #workgroups, ...)
   static const int wg_env = getenv("DOGLEG_AMD_LF_WGS") ? atoi(getenv("DOGLEG_AMD_LF_WGS")) : 0;
   const int nwg = std::max(1, std::min(n, wg_env > 0 ? wg_env : (LF_PREFETCH ? b->ncu : n)));
-  hipLaunchKernelGGL(k_leaf_front, dim3(nwg), dim3(LF_NT), H.lf_lds, b->stream, Y->lf_leaf, n, Y->lf_blob, Y->perm, Jv, x, rhs, lambda,
+  hipLaunchKernelGGL(k_leaf_front, dim3(nwg), dim3(LF_NT), H.lf_lds, b->stream, Y->lf_leaf, n, Y->lf_blob, H.lf_stride, H.lf_smax, H.lf_tb, Y->perm, Jv, x, rhs, lambda,
                      Lx, Y->uscr, Jt_x, Y->lf_jtp, reinterpret_cast<int*>(Lx + H.lx_size));
   DLG_LAUNCH_CHECK();
   return DLG_OK;

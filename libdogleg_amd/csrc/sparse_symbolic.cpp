@@ -1837,7 +1837,8 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
     S.lf_jf_ptr.clear(); S.lf_jf_ent.clear(); S.lf_jf_var0.clear(); S.lf_jf_w.clear(); S.lf_jf_short.clear(); S.lf_jf_long.clear();
     auto why = [&](const char* fmt, long a = 0, long b = 0) { snprintf(S.lf_why, sizeof(S.lf_why), fmt, a, b); return false; };
     auto build = [&]() -> bool {
-      if(env_int("DOGLEG_AMD_NO_LEAF_FRONT", 0)) return why("switched off (DOGLEG_AMD_NO_LEAF_FRONT)");
+      // (opt-in: on config #4 the one kernel takes what the two it replaces take -- DESIGN.md section 6, round 3)
+      if(!env_int("DOGLEG_AMD_LEAF_FRONT", 0)) return why("not switched on (DOGLEG_AMD_LEAF_FRONT=1)");
       if(partition || row0 != 0 || row1 != M) return why("the rows are shared between ranks");
       if(cp[M] >= (1 << 28)) return why("more than 2^28 non-zeros");
       if(S.nlevels < 2 || S.mf_level0 < 1 || S.upd_syrk.empty() || !S.upd_syrk[0]) return why("no two-phase leaf level");
@@ -2178,6 +2179,30 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
         for(int c = 0; c < w; c++) S.lf_col[it.col0 + c] = 1;
       }
       if(S.lf_lds > SYM_FAC_LDS_BUDGET) return why("a leaf front needs %ld bytes of LDS", S.lf_lds);
+      // one stride for all blobs (see lf_stride), unless a few large leaves would blow the buffer up
+      {
+        int smax = 1, lmax = 16;
+        for(const LfLeaf& L : S.lf_leaf) { smax = std::max(smax, L.nslots); lmax = std::max(lmax, L.lds_bytes); }
+        const size_t tb = ((size_t)10*smax + 15) & ~(size_t)15, stride = tb + (size_t)lmax;
+        S.lf_stride = S.lf_smax = S.lf_tb = 0;
+        if(stride*S.lf_leaf.size() <= 2*S.lf_blob.size() + (1u << 20) && stride*S.lf_leaf.size() < ((size_t)1 << 31) - 65536 && !env_int("DOGLEG_AMD_LF_NO_STRIDE", 0))
+        {
+          std::vector<uint8_t> nb(stride*S.lf_leaf.size(), 0);
+          for(size_t i = 0; i < S.lf_leaf.size(); i++)
+          {
+            LfLeaf& L = S.lf_leaf[i];
+            const uint8_t* src = &S.lf_blob[(size_t)L.blob];
+            uint8_t* dst = &nb[i*stride];
+            memcpy(dst, src, 4*(size_t)L.nslots);
+            memcpy(dst + 4*(size_t)smax, src + 4*(size_t)L.nslots, 4*(size_t)L.nslots);
+            memcpy(dst + 8*(size_t)smax, src + 8*(size_t)L.nslots, 2*(size_t)L.nslots);
+            memcpy(dst + tb, src + L.o_lds, (size_t)L.lds_bytes);
+            L.blob = (int32_t)(i*stride); L.o_lds = (int32_t)tb; L.blob_bytes = (int32_t)stride;
+          }
+          S.lf_blob.swap(nb);
+          S.lf_stride = (int)stride; S.lf_smax = smax; S.lf_tb = (int)tb;
+        }
+      }
       // Jt*x of the ancestors' blocks
       S.lf_jf_ptr.assign(1, 0);
       for(int v = 0; v < nvb; v++)
@@ -2191,7 +2216,7 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
       }
       return true; };
     S.lf_ok = build();
-    if(!S.lf_ok) { S.lf_leaf.clear(); S.lf_blob.clear(); S.lf_jtp_size = 0; S.lf_lds = 0; std::fill(S.lf_col.begin(), S.lf_col.end(), 0); }
+    if(!S.lf_ok) { S.lf_leaf.clear(); S.lf_blob.clear(); S.lf_jtp_size = 0; S.lf_lds = 0; S.lf_stride = 0; std::fill(S.lf_col.begin(), S.lf_col.end(), 0); }
     if(env_int("DOGLEG_AMD_SYM_DEBUG", 0) >= 1)
     {
       size_t naff = 0, nt = 0;

@@ -353,6 +353,9 @@ struct SymHost
   std::vector<uint8_t> lf_blob;
   int64_t lf_jtp_size = 0;
   int lf_lds = 0;                     // bytes of LDS of the largest leaf
+  // the blobs at one stride, their staging tables padded to lf_smax rows and their LDS parts at offset lf_tb: a workgroup
+  // finds its table and its schedule from its index alone -- the loads do not wait for the leaf's record (0: not so)
+  int lf_stride = 0, lf_smax = 0, lf_tb = 0;
   // Jt*x of the ancestors' blocks: block i (first variable lf_jf_var0[i], lf_jf_w[i] of them) sums the leaves' records
   // lf_jf_ent[lf_jf_ptr[i] .. lf_jf_ptr[i+1]) (first entry in the record buffer) in that order; short / long lists
   std::vector<int> lf_jf_ptr, lf_jf_ent, lf_jf_var0, lf_jf_w, lf_jf_short, lf_jf_long;

@@ -19,9 +19,9 @@ print("leaf fronts:", {k: v for k, v in capi.symbolic_probe(P.N, P.M, Jp, Ji).it
 
 def run(off):
     if off:
-        os.environ["DOGLEG_AMD_NO_LEAF_FRONT"] = "1"
+        os.environ.pop("DOGLEG_AMD_LEAF_FRONT", None)
     else:
-        os.environ.pop("DOGLEG_AMD_NO_LEAF_FRONT", None)
+        os.environ["DOGLEG_AMD_LEAF_FRONT"] = "1"
     be = capi.Backend(capi.DLG_SPARSE, P.N, P.M, P.nnz)
     be.set_pattern(Jp, Ji)
     if spec:
