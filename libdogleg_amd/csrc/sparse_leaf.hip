@@ -23,11 +23,6 @@
 
 namespace {
 constexpr int LF_NT = 1024;
-// the next leaf's table and rows fetched under the current leaf's work (a workgroup per CU, leaf after leaf): measured
-// SLOWER than a workgroup per leaf -- at 1024 threads the registers that hold the loads in flight are spilled, and a
-// spill or reload anywhere in a phase waits for every load issued before it; at 512 threads the strip tasks take
-// half as many waves (10.5 us against 6.5).  Kept for experiments.
-constexpr bool LF_PREFETCH = false;
 constexpr int LF_RS = 16;          // doubles per staged row: the row's entries (<= 15), x of the row at 15
 constexpr int LF_Q = 8;            // rows per thread group and staging pass (64 rows per pass and workgroup)
 
@@ -44,7 +39,7 @@ __device__ long long g_lf_wave[16*64];      // workgroup 300: per wave, cycle st
 // member block of NB columns from its accumulated entries in Dg (row c, column q at Dg[(c0 + c)*4 + q]):
 // factored in registers, left in Dg for the rows' solves and written to the panel's top block
 template <int NB>
-__device__ __forceinline__ int lf_factor_member(double* Dg, int c0, double* rdiag, double* __restrict__ G, int ldg, double lambda)
+__device__ __forceinline__ int lf_factor_member(double* Dg, int c0, double* rdiag, double lambda)
 {
   double D[NB][NB];
 #pragma unroll
@@ -72,7 +67,7 @@ __device__ __forceinline__ int lf_factor_member(double* Dg, int c0, double* rdia
 #pragma unroll
   for(int c = 0; c < NB; c++)
 #pragma unroll
-    for(int q = 0; q <= c; q++) { G[(c0 + c) + (size_t)(c0 + q)*ldg] = D[c][q]; Dg[(c0 + c)*4 + q] = D[c][q]; }
+    for(int q = 0; q <= c; q++) Dg[(c0 + c)*4 + q] = D[c][q];       // (to the panel's top block with the rows below: k_leaf_front, part 5)
   return badcol;
 }
 
@@ -97,15 +92,39 @@ __device__ __forceinline__ void lf_put(double acc, int kind, int pdk, int k, int
   }
 }
 
-// all of a workgroup's LDS traffic done, then the barrier -- WITHOUT waiting for its global loads (the next leaf's
+// all of a workgroup's LDS traffic done, then the barrier -- WITHOUT waiting for its global loads (PF: the next leaf's
 // rows are on their way across the phases of this one; __syncthreads would wait for them at every barrier)
 __device__ __forceinline__ void lf_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-// One workgroup per CU, a leaf after the other: while leaf i is being formed and eliminated, the staging table of
-// leaf i + (number of workgroups) is fetched (during the strip tasks) and then its rows (during the elimination) --
-// the three dependent global round trips of a leaf (record -> table -> rows, ~5 us) disappear behind the work.
+// gfx950's 16-byte copy from memory straight into LDS (buffer_load_dwordx4 ... lds): every lane fetches 16 bytes at
+// its own offset into the buffer (out of range: zeros), the wave's 64 x 16 bytes land lane after lane behind the LDS
+// address in M0.  No destination registers, nothing for the compiler to wait for or to spill: the issuing code
+// decides when to wait (s_waitcnt vmcnt).  Checked on its own in tools/micro/test_lds_dma.hip.
+typedef int lf_v4i __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ lf_v4i lf_rsrc(const void* base, unsigned bytes)
+{
+  const uint64_t a = (uint64_t)base;
+  return (lf_v4i){ (int)(uint32_t)a, (int)(uint32_t)((a >> 32) & 0xffff), (int)bytes, 0x00020000 };
+}
+__device__ __forceinline__ void lf_dma16(lf_v4i rsrc, unsigned lds_addr, unsigned voff)
+{
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" :: "s"(lds_addr), "v"(voff), "s"(rsrc) : "memory", "m0");
+}
+__device__ __forceinline__ unsigned lf_lds_addr(const void* p) { return (unsigned)(size_t)(const __attribute__((address_space(3))) char*)p; }
+
+// PF = false: a workgroup per leaf; record, staging table and schedule are fetched at once (the schedules lie at one
+// stride), the rows behind the table: two dependent round trips to memory in front of the first barrier, 5 us of the
+// 19 a leaf takes (and every CU fetches at the same time: the chip's memory idles while they all compute).
+// PF = true: one workgroup per CU, leaf after leaf; while leaf i is eliminated the rows and the schedule of leaf
+// i + (number of workgroups) are COPIED INTO LDS by the copy engine of the texture path (lf_dma16) -- the rows' part of
+// LDS is free from the end of the strip tasks on, the schedule's from the end of the riders' sums.  One LDS layout for all
+// leaves (sizes from the symbolic phase).  The table of the next leaf (where its rows are) is fetched during the strip
+// tasks into four registers a lane.  x of the rows (position 15 of a slot) cannot come with the copy (16-byte granules
+// land lane after lane): one register a thread, stored at the top of the next round.
+template <bool PF>
 __global__ void __launch_bounds__(LF_NT, 1) k_leaf_front(const LfLeaf* __restrict__ leaves, int nleaf,
                                                          const uint8_t* __restrict__ blob_g, int b_stride, int b_smax, int b_tb,
+                                                         int pf_b, int pf_pud, unsigned jv_bytes, unsigned blob_bytes,
                                                          const int* __restrict__ perm,
                                                          const double* __restrict__ Jv,
                                                          const double* __restrict__ x,
@@ -114,21 +133,56 @@ __global__ void __launch_bounds__(LF_NT, 1) k_leaf_front(const LfLeaf* __restric
                                                          double* __restrict__ Jt_x, double* __restrict__ jtp,
                                                          int* __restrict__ lf_word)
 {
-  extern __shared__ __attribute__((aligned(16))) double P[];
+  extern __shared__ __attribute__((aligned(16))) double LDS0[];
   __shared__ int s_mcol[68];
   __shared__ double s_rdiag[64];
   __shared__ int sbad;
+  __shared__ double s_jo[64];                        // Jt*x of the leaf's own columns (the right-hand side row before it is solved)
+  __shared__ double s_jt[240];                      // the leaf's shares of Jt*x of the ancestors' variables (out with the panel)
   constexpr int NT = LF_NT, NW = NT/64;
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int k16 = tid & 15;
-  // the staged rows of a leaf, in the order they have in J: thread = (row of the pass, position); every load
-  // unconditional (a branch around a load costs its whole latency again), all of a thread's loads in flight at once
+  const int tid0 = threadIdx.x;
+  double* const P = PF ? LDS0 + (pf_b >> 3) : LDS0;
+  // ---- PF: what is fetched ahead for the next leaf
+  int n_w[4] = {0, 0, 0, 0}, n_xr = 0, n_pvar = 0, n_nsl = 0, n_lb = 0;      // (n_nsl, n_lb: its rows and the bytes of its schedule)
+  double n_x = 0.0;
+  const int o_s = (10*b_smax + 3) & ~3;                       // the by-slot tables inside a blob
+  auto pf_table = [&](int li, int tid, int lane, int wv) {
+    const uint8_t* blob = blob_g + (size_t)li*b_stride;
+    const int32_t* svs = reinterpret_cast<const int32_t*>(blob + o_s);
+#pragma unroll
+    for(int q = 0; q < 4; q++) n_w[q] = svs[min(8*(wv + NW*q) + (lane >> 3), b_smax - 1)];
+    n_xr = svs[b_smax + min(tid, b_smax - 1)];
+    const int wn = leaves[li].w, c0n = leaves[li].col0;
+    n_nsl = leaves[li].nslots; n_lb = leaves[li].lds_bytes;
+    if(tid >= NT - 64 && tid - (NT - 64) < wn) n_pvar = perm[c0n + tid - (NT - 64)];
+  };
+  auto pf_issue = [&](int li, int tid, int lane, int wv) {
+    const int nsl = n_nsl, lb = n_lb;                 // (fetched with the table: a scalar load here would be waited for)
+    const lf_v4i rj = lf_rsrc(Jv, jv_bytes), rb = lf_rsrc(blob_g, blob_bytes);
+    double* Rn = P + pf_pud;
+    // (x first: its address waits for the table, and the compiler counts only the loads it knows -- behind the copies
+    // that wait would be for them)
+    n_x = (x && tid < nsl) ? x[n_xr] : 0.0;
+#pragma unroll
+    for(int q = 0; q < 4; q++)
+    {
+      const int s0 = 8*(wv + NW*q);
+      if(s0 < nsl)
+      {
+        const int sl = s0 + (lane >> 3);
+        const unsigned voff = (sl < nsl) ? ((unsigned)(n_w[q] & 0xfffffff) << 3) + 16u*(lane & 7) : 0xfffffff0u;
+        lf_dma16(rj, lf_sgpr((int)lf_lds_addr(Rn + s0*LF_RS)), voff);
+      }
+    }
+    if(1024*wv < lb)
+      lf_dma16(rb, lf_sgpr((int)lf_lds_addr(reinterpret_cast<uint8_t*>(LDS0) + 1024*wv)), (unsigned)li*(unsigned)b_stride + (unsigned)b_tb + 16u*tid);
+  };
+  // ---- PF = false: the staged rows of a leaf, in the order they have in J: thread = (row of the pass, position); every
+  // load unconditional (a branch around a load costs its whole latency again), all of a thread's loads in flight at once
   // (per row one word: lanes 0..14 the first value of the row | its entries << 28, lane 15 the row itself (for x))
-  int n_w[LF_Q], n_sd[LF_Q], n_sd2[LF_Q/2], n_pvar = 0;      // (n_sd: as loaded; packed in pairs once they have arrived)
-  double n_v[LF_Q];
-  // (b_stride > 0: every blob at leaf*b_stride, its table padded to b_smax rows -- no field of the leaf's record is
-  // needed to find it, the loads go out beside the load of the record)
-  auto load_table_at = [&](const uint8_t* blob, int smax, int nsl) {
+  int g_w[LF_Q], g_sd[LF_Q];
+  double g_v[LF_Q];
+  auto load_table_at = [&](const uint8_t* blob, int smax, int nsl, int tid, int k16) {
     const int32_t* svg = reinterpret_cast<const int32_t*>(blob);
     const uint16_t* sdg = reinterpret_cast<const uint16_t*>(svg + 2*smax);
     const int32_t* wg = (k16 == 15) ? svg + smax : svg;
@@ -136,71 +190,80 @@ __global__ void __launch_bounds__(LF_NT, 1) k_leaf_front(const LfLeaf* __restric
     for(int q = 0; q < LF_Q; q++)
     {
       const int g = min((tid >> 4) + (NT/16)*q, nsl - 1);
-      n_w[q] = wg[g];
-      n_sd[q] = sdg[g];
+      g_w[q] = wg[g];
+      g_sd[q] = sdg[g];
     }
   };
-  auto load_table = [&](const LfLeaf& L) {
-    load_table_at(blob_g + L.blob, b_stride > 0 ? b_smax : L.nslots, b_stride > 0 ? b_smax : L.nslots);
-    if(tid >= NT - 64 && tid - (NT - 64) < L.w) n_pvar = perm[L.col0 + tid - (NT - 64)];      // (the last wave sets the right-hand side row)
-  };
-  auto load_values = [&](const LfLeaf& L) {
+  auto load_values = [&](int k16) {
 #pragma unroll
     for(int q = 0; q < LF_Q; q++)
     {
-      const int len = (int)((unsigned)n_w[q] >> 28), off = n_w[q] & 0xfffffff;
+      const int len = (int)((unsigned)g_w[q] >> 28), off = g_w[q] & 0xfffffff;
       const bool isx = k16 == 15;
-      const double* src = isx ? (x ? x + n_w[q] : Jv) : Jv + ((size_t)off + max(min(k16, len - 1), 0));
-      n_v[q] = *src;                              // (as loaded: nothing here may wait for it; masked when it goes to LDS)
-    }
-    if(LF_PREFETCH)
-    {
-#pragma unroll
-      for(int q = 0; q < LF_Q/2; q++) n_sd2[q] = n_sd[2*q] | (n_sd[2*q + 1] << 16);
+      const double* src = isx ? (x ? x + g_w[q] : Jv) : Jv + ((size_t)off + max(min(k16, len - 1), 0));
+      g_v[q] = *src;
     }
   };
-  if(LF_PREFETCH)
-  {
-    // the first leaf: nothing to hide its loads behind
-    const LfLeaf L0 = leaves[blockIdx.x];
-    load_table(L0);
-    load_values(L0);
-  }
   int leaf = blockIdx.x;
-  do        // (a workgroup per leaf unless LF_PREFETCH)
+  if(PF)
   {
+    // the first leaf of this workgroup: nothing to hide its fetch behind
+    pf_table(leaf, tid0, tid0 & 63, tid0 >> 6);
+    pf_issue(leaf, tid0, tid0 & 63, tid0 >> 6);
+  }
+  do        // (PF = false: once)
+  {
+  // (PF: the thread's index through an empty asm, so that nothing derived from it counts as invariant of the loop -- hoisted
+  // out, those few dozen values took the registers the kernel has at 1024 threads, and ONE spilled value reloaded
+  // between two copies waits for the first copy to land)
+  int tid = tid0;
+  if(PF) asm volatile("" : "+v"(tid));
+  const int lane = tid & 63, wv = tid >> 6, k16 = tid & 15;
   LF_STAMP(0);
   uint4 bl0 = {0u, 0u, 0u, 0u};
-  if(!LF_PREFETCH && b_stride > 0)
+  if(!PF && b_stride > 0)
   {
     // table and schedule from the leaf's index alone (beside the load of its record)
     const uint8_t* blob = blob_g + (size_t)leaf*b_stride;
-    load_table_at(blob, b_smax, b_smax);
-    bl0 = reinterpret_cast<const uint4*>(blob + b_tb)[tid];      // (the stride covers a whole pass of the workgroup?  see the launch)
+    load_table_at(blob, b_smax, b_smax, tid, k16);
+    bl0 = reinterpret_cast<const uint4*>(blob + b_tb)[tid];      // (the upload is padded by a pass of the workgroup)
   }
   const LfLeaf lf = leaves[leaf];
-  const bool more = LF_PREFETCH && leaf + (int)gridDim.x < nleaf;
-  if(!LF_PREFETCH)
+  const bool more = PF && leaf + (int)gridDim.x < nleaf;
+  if(!PF)
   {
     if(b_stride > 0) { if(tid >= NT - 64 && tid - (NT - 64) < lf.w) n_pvar = perm[lf.col0 + tid - (NT - 64)]; }
-    else load_table(lf);
-    load_values(lf);
+    else
+    {
+      load_table_at(blob_g + lf.blob, lf.nslots, lf.nslots, tid, k16);
+      if(tid >= NT - 64 && tid - (NT - 64) < lf.w) n_pvar = perm[lf.col0 + tid - (NT - 64)];
+    }
+    load_values(k16);
   }
   const int w = lf.w, nrows = lf.nrows, mb = nrows - w, ldp = (mb + 1) & ~1, ntri = mb*(mb + 1)/2;
   const int nslots = lf.nslots;
   double* Us = P + ldp*w;                         // the packed update matrix (direct contributions, then U - them)
   double* Dg = Us + ((ntri + 2) & ~1);            // member blocks
-  double* R  = Dg + ((4*w + 1) & ~1);             // staged rows (+ a row of zeros: slot nslots)
-  double* Sc = R + LF_RS*(nslots + 1);            // partial strips of split tasks / the riders' shares
-  uint8_t* B = reinterpret_cast<uint8_t*>(Sc + 128*lf.nscr);   // the schedule
+  double* R  = PF ? P + pf_pud : Dg + ((4*w + 1) & ~1);             // staged rows (+ a row of zeros: slot nslots)
+  double* Sc = R + LF_RS*((PF ? b_smax : nslots) + 1);              // partial strips of split tasks / the riders' shares
+  uint8_t* B = PF ? reinterpret_cast<uint8_t*>(LDS0) : reinterpret_cast<uint8_t*>(Sc + 128*lf.nscr);   // the schedule
   const uint8_t* bg = blob_g + lf.blob;
   double* G = Lx + lf.lx;
   if(tid == 0) sbad = 0x7fffffff;
-  // ---- 1. what was fetched for this leaf goes to LDS: zeros, the schedule, the rows
+  // ---- 1. zeros where the front is formed; the rows and the schedule of this leaf in LDS
+  if(PF)
   {
-    // (the schedule: fetched here, stored at the end of this phase -- four registers held across a leaf were spilled,
-    // and the spill of a load in flight waits for it; phase 4 of the leaf before touched its cache lines)
-    const uint4 bl = (!LF_PREFETCH && b_stride > 0) ? bl0 : reinterpret_cast<const uint4*>(bg + lf.o_lds)[min(tid, (lf.lds_bytes >> 4) - 1)];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this wave's copies have landed ...
+    lf_barrier();                                               // ... everybody's
+    if(tid < nslots) R[tid*LF_RS + 15] = n_x;                   // x of the rows (whatever followed a row in J lay there)
+    if(tid < LF_RS) R[nslots*LF_RS + tid] = 0.0;
+    const int nz = (int)((Dg + ((4*w + 1) & ~1)) - P) >> 1;
+    for(int c = tid; c < nz; c += NT) reinterpret_cast<dlg_v2d*>(P)[c] = (dlg_v2d){0.0, 0.0};
+  }
+  else
+  {
+    // (the schedule: fetched at the top, stored at the end of this phase)
+    const uint4 bl = (b_stride > 0) ? bl0 : reinterpret_cast<const uint4*>(bg + lf.o_lds)[min(tid, (lf.lds_bytes >> 4) - 1)];
     const int nz = (int)(R - P) >> 1;
     for(int c = tid; c < nz; c += NT) reinterpret_cast<dlg_v2d*>(P)[c] = (dlg_v2d){0.0, 0.0};
     if(tid < LF_RS) R[nslots*LF_RS + tid] = 0.0;
@@ -210,23 +273,23 @@ __global__ void __launch_bounds__(LF_NT, 1) k_leaf_front(const LfLeaf* __restric
     for(int q = 0; q < LF_Q; q++)
     {
       const int g = (tid >> 4) + (NT/16)*q;
-      const int sd = !LF_PREFETCH ? n_sd[q] : (q & 1) ? (int)((unsigned)n_sd2[q >> 1] >> 16) : (n_sd2[q >> 1] & 0xFFFF);
       // (positions past the row's entries hold whatever followed the row in J: no strip keeps a product with them;
       // position 15 without x: zero)
-      if(g < nslots) R[sd*LF_RS + k16] = (k16 == 15 && !x) ? 0.0 : n_v[q];
+      if(g < nslots) R[g_sd[q]*LF_RS + k16] = (k16 == 15 && !x) ? 0.0 : g_v[q];
     }
     // (a leaf with more rows than one pass of the workgroup holds: the rest now, at full latency)
     if(nslots > (NT/16)*LF_Q)
     {
+      const int smx = b_stride > 0 ? b_smax : nslots;
       const int32_t* svg = reinterpret_cast<const int32_t*>(bg);
-      const int32_t* srg = svg + nslots;
-      const uint16_t* sdg = reinterpret_cast<const uint16_t*>(srg + nslots);
+      const int32_t* srg = svg + smx;
+      const uint16_t* sdg = reinterpret_cast<const uint16_t*>(srg + smx);
       for(int g = (NT/16)*LF_Q + (tid >> 4); g < nslots; g += NT/16)
       {
         const int wd = (k16 == 15) ? srg[g] : svg[g], sd = sdg[g];
         const int len = (int)((unsigned)wd >> 28), off = wd & 0xfffffff;
         const bool isx = k16 == 15;
-        const double t = isx ? (x ? x[wd] : 0.0) : Jv[(size_t)off + min(k16, len - 1)];
+        const double t = isx ? (x ? x[wd] : 0.0) : Jv[(size_t)off + max(min(k16, len - 1), 0)];
         R[sd*LF_RS + k16] = (isx || k16 < len) ? t : 0.0;
       }
     }
@@ -235,14 +298,16 @@ __global__ void __launch_bounds__(LF_NT, 1) k_leaf_front(const LfLeaf* __restric
   const int pvar = n_pvar;
   lf_barrier();
   LF_STAMP(1);
-  // (the next leaf's table: on its way during the strip tasks)
-  if(more) load_table(leaves[leaf + gridDim.x]);
+  // (PF: where the next leaf's rows are -- on its way during the strip tasks)
+  if(more) pf_table(leaf + gridDim.x, tid, lane, wv);
   // ---- 2. strip tasks, one wave each
   const LfTask* tk = reinterpret_cast<const LfTask*>(B + lf.o_task);
   const uint32_t* rbh = reinterpret_cast<const uint32_t*>(B + lf.o_rbh);
   const uint8_t* fib = B + lf.o_fi;
   const uint16_t* l16 = reinterpret_cast<const uint16_t*>(B);
-  double* jtp_rec = (x && jtp) ? jtp + lf.jtp : nullptr;
+  // (no global store between the fetch of the next leaf's table and its use: the compiler's wait for those loads would
+  // be a wait for the stores behind them -- the Jt*x shares go to LDS first, out with the panel)
+  double* jtp_rec = (x && jtp) ? s_jt : nullptr;
 #ifdef DLG_LF_PROFILE
   int wslot = 0;
 #endif
@@ -275,13 +340,14 @@ __global__ void __launch_bounds__(LF_NT, 1) k_leaf_front(const LfLeaf* __restric
       double acc0 = 0.0, acc1 = 0.0;
       const int npair = (nprow + 1 - par) >> 1;                 // rows par, par + 2, ...
       int i = 0;
-      for(; i + 4 <= npair; i += 4)
+      constexpr int UM = 4;
+      for(; i + UM <= npair; i += UM)
       {
-        double a[4], b0[4], b1[4];
+        double a[UM], b0[UM], b1[UM];
 #pragma unroll
-        for(int u = 0; u < 4; u++) { a[u] = pa[(2*(i + u))*LF_RS]; b0[u] = pb[(2*(i + u))*LF_RS]; b1[u] = pb[(2*(i + u))*LF_RS + 2]; }
+        for(int u = 0; u < UM; u++) { a[u] = pa[(2*(i + u))*LF_RS]; b0[u] = pb[(2*(i + u))*LF_RS]; b1[u] = pb[(2*(i + u))*LF_RS + 2]; }
 #pragma unroll
-        for(int u = 0; u < 4; u++) { acc0 = fma(a[u], b0[u], acc0); acc1 = fma(a[u], b1[u], acc1); }
+        for(int u = 0; u < UM; u++) { acc0 = fma(a[u], b0[u], acc0); acc1 = fma(a[u], b1[u], acc1); }
       }
       for(; i < npair; i++)
       {
@@ -353,18 +419,19 @@ __global__ void __launch_bounds__(LF_NT, 1) k_leaf_front(const LfLeaf* __restric
           if((a_nin & 3) == 0) { if(r >= a_nin) { r -= a_nin; o++; } }
           else { while(r >= a_nin) { r -= a_nin; o++; } } };
         int g = 0;
-        for(; g + 4 <= ngr; g += 4)
+        constexpr int UG = 4;                     // (groups of rows whose operands are in flight together; PF: registers)
+        for(; g + UG <= ngr; g += UG)
         {
-          double a[4], bq[4];
+          double a[UG], bq[UG];
 #pragma unroll
-          for(int u = 0; u < 4; u++)
+          for(int u = 0; u < UG; u++)
           {
             const int sl = slot_now(4*(g + u) + kq);
             a[u] = ra[sl]; bq[u] = rb[sl];
             step();
           }
 #pragma unroll
-          for(int u = 0; u < 4; u++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], bval ? bq[u] : 0.0, acc, 0, 0, 0);
+          for(int u = 0; u < UG; u++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], bval ? bq[u] : 0.0, acc, 0, 0, 0);
         }
         for(; g < ngr; g++)
         {
@@ -440,12 +507,6 @@ __global__ void __launch_bounds__(LF_NT, 1) k_leaf_front(const LfLeaf* __restric
   lf_barrier();
   LF_WSTAMP(7);
   LF_STAMP(2);
-  // (the next leaf's rows: on their way during the elimination of this one)
-  if(more)
-  {
-    const LfLeaf Ln = leaves[leaf + gridDim.x];
-    load_values(Ln);
-  }
   // split strips / a rider's shares: the partial strips in order (update matrix and Jt*x record only); beside them the
   // right-hand side row and lambda (panel, member blocks)
   if(lf.ncomb > 0)
@@ -469,7 +530,7 @@ __global__ void __launch_bounds__(LF_NT, 1) k_leaf_front(const LfLeaf* __restric
   if(tid >= NT - 64 && tid - (NT - 64) < w)
   {
     const int c = tid - (NT - 64);
-    if(x) { if(Jt_x) Jt_x[pvar] = P[(mb - 1) + c*ldp]; }
+    if(x) s_jo[c] = P[(mb - 1) + c*ldp];             // (Jt*x of the leaf's own columns: stored with the panel)
     else if(rhs) P[(mb - 1) + c*ldp] = rhs[pvar];
   }
   // the members beside them (a wave of their own: the diagonal blocks were complete with the strip tasks)
@@ -481,15 +542,17 @@ __global__ void __launch_bounds__(LF_NT, 1) k_leaf_front(const LfLeaf* __restric
       int badcol;
       switch(lf.bdw)
       {
-        case 1: badcol = lf_factor_member<1>(Dg, c0, s_rdiag, G, nrows, lambda); break;
-        case 2: badcol = lf_factor_member<2>(Dg, c0, s_rdiag, G, nrows, lambda); break;
-        case 3: badcol = lf_factor_member<3>(Dg, c0, s_rdiag, G, nrows, lambda); break;
-        default: badcol = lf_factor_member<4>(Dg, c0, s_rdiag, G, nrows, lambda); break;
+        case 1: badcol = lf_factor_member<1>(Dg, c0, s_rdiag, lambda); break;
+        case 2: badcol = lf_factor_member<2>(Dg, c0, s_rdiag, lambda); break;
+        case 3: badcol = lf_factor_member<3>(Dg, c0, s_rdiag, lambda); break;
+        default: badcol = lf_factor_member<4>(Dg, c0, s_rdiag, lambda); break;
       }
       if(badcol >= 0) atomicMin(&sbad, lf.col0 + c0 + badcol);
     }
   lf_barrier();
   LF_STAMP(3);
+  // (PF: rows, scratch and schedule are done with -- the next leaf's rows and schedule into their place, under the rest)
+  if(more) pf_issue(leaf + gridDim.x, tid, lane, wv);
   if(tid == 0 && sbad != 0x7fffffff) atomicMax(lf_word, 0x7fffffff - sbad);       // (0: every pivot of every leaf was positive)
   // the rows below against every member's block: thread = (row, group of members) -- the members do not couple
   double* Pb = P - w;
@@ -531,6 +594,14 @@ __global__ void __launch_bounds__(LF_NT, 1) k_leaf_front(const LfLeaf* __restric
   LF_STAMP(5);
   // ---- 5. out: the update matrix, the rows below the member blocks
   {
+    if(x && Jt_x && tid >= NT - 64 && tid - (NT - 64) < w) Jt_x[pvar] = s_jo[tid - (NT - 64)];
+    // the factored member blocks (lower triangles) into the panel's top block
+    for(int e = tid; e < w*lf.bdw; e += NT)
+    {
+      const int c = e/lf.bdw, q = e - c*lf.bdw, cm = c % lf.bdw;       // column c of the leaf, entry q of its row in the block
+      if(q <= cm) G[c + (size_t)(c - cm + q)*nrows] = Dg[c*4 + q];
+    }
+    if(x && jtp) for(int e = tid; e < mb - 1; e += NT) jtp[lf.jtp + e] = s_jt[e];
     double* Ug = uscr + lf.u_off;
     for(int e = tid; e < ntri; e += NT) Ug[e] = Us[e];
     const int cp_rows = min(NT, (mb + 63) & ~63), cp_ng = NT/cp_rows, cp_g = tid/cp_rows;
@@ -550,7 +621,7 @@ __global__ void __launch_bounds__(LF_NT, 1) k_leaf_front(const LfLeaf* __restric
   LF_STAMP(6);
   lf_barrier();                                   // (every wave is done with the LDS: the next leaf may have it)
   leaf += gridDim.x;
-  } while(LF_PREFETCH && leaf < nleaf);
+  } while(PF && leaf < nleaf);
 }
 } // namespace
 
@@ -592,7 +663,9 @@ int sparse_leaf_setup(dlg_backend* b)
     std::vector<char> col(H.lf_col.begin(), H.lf_col.end());
     DLG_CHECK(upload(Y->lf_col, col)); Y->allocs.push_back(Y->lf_col);
   }
-  DLG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_leaf_front), hipFuncAttributeMaxDynamicSharedMemorySize, H.lf_lds));
+  DLG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_leaf_front<false>), hipFuncAttributeMaxDynamicSharedMemorySize, H.lf_lds));
+  if(H.lf_pf_lds > 0)
+    DLG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_leaf_front<true>), hipFuncAttributeMaxDynamicSharedMemorySize, H.lf_pf_lds));
   Y->lf_on = true;
   return DLG_OK;
 }
@@ -604,11 +677,22 @@ int sparse_leaf_front(dlg_backend* b, const double* Jv, double* Lx, const double
   SparseSym* Y = b->sym;
   const SymHost& H = Y->H;
   const int n = (int)H.lf_leaf.size();
-  // (persistent: one workgroup per CU takes leaves g, g + #workgroups, ...)
+  // (the persistent form -- a workgroup per CU, the next leaf copied into LDS under the current one -- where its one LDS
+  // layout fits and the copy engine's 32-bit offsets reach; DOGLEG_AMD_LF_NO_PF=1: a workgroup per leaf)
+  static const bool no_pf = getenv("DOGLEG_AMD_LF_NO_PF") != nullptr;
   static const int wg_env = getenv("DOGLEG_AMD_LF_WGS") ? atoi(getenv("DOGLEG_AMD_LF_WGS")) : 0;
-  const int nwg = std::max(1, std::min(n, wg_env > 0 ? wg_env : (LF_PREFETCH ? b->ncu : n)));
-  hipLaunchKernelGGL(k_leaf_front, dim3(nwg), dim3(LF_NT), H.lf_lds, b->stream, Y->lf_leaf, n, Y->lf_blob, H.lf_stride, H.lf_smax, H.lf_tb, Y->perm, Jv, x, rhs, lambda,
-                     Lx, Y->uscr, Jt_x, Y->lf_jtp, reinterpret_cast<int*>(Lx + H.lx_size));
+  const size_t jvb = (size_t)Y->nnz_loc*8, blb = H.lf_blob.size() + 16*LF_NT;
+  const int nwg_pf = std::max(1, wg_env > 0 ? wg_env : b->ncu);
+  const bool pf = !no_pf && H.lf_pf_lds > 0 && H.lf_stride > 0 && jvb < ((size_t)1 << 32) - 65536 && blb < ((size_t)1 << 32) - 65536 && n > nwg_pf;      // (more leaves than workgroups: something to fetch ahead)
+  int* word = reinterpret_cast<int*>(Lx + H.lx_size);
+  if(pf)
+  {
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_leaf_front<true>), dim3(nwg_pf), dim3(LF_NT), H.lf_pf_lds, b->stream, Y->lf_leaf, n, Y->lf_blob, H.lf_stride, H.lf_smax, H.lf_tb,
+                       H.lf_pf_b, H.lf_pf_pud, (unsigned)jvb, (unsigned)blb, Y->perm, Jv, x, rhs, lambda, Lx, Y->uscr, Jt_x, Y->lf_jtp, word);
+  }
+  else
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_leaf_front<false>), dim3(n), dim3(LF_NT), H.lf_lds, b->stream, Y->lf_leaf, n, Y->lf_blob, H.lf_stride, H.lf_smax, H.lf_tb,
+                       0, 0, 0u, 0u, Y->perm, Jv, x, rhs, lambda, Lx, Y->uscr, Jt_x, Y->lf_jtp, word);
   DLG_LAUNCH_CHECK();
   return DLG_OK;
 }

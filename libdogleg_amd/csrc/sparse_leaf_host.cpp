@@ -38,6 +38,11 @@ extern "C" int dlg_sparse_leaf_probe(int N, int M, const int* colptr, const int*
     const int32_t* sr = sv + smax;
     const uint16_t* sd = reinterpret_cast<const uint16_t*>(sv + 2*smax);
     const uint8_t* B = blob + L.o_lds;
+    // (the same table by slot, for the form of the kernel that copies a leaf's rows into LDS in slot order)
+    const int32_t* svs = reinterpret_cast<const int32_t*>(blob + (((size_t)10*smax + 3) & ~(size_t)3));
+    const int32_t* srs = svs + smax;
+    for(int g = 0; g < L.nslots; g++)
+      if(sd[g] >= L.nslots || svs[sd[g]] != sv[g] || srs[sd[g]] != sr[g]) { dlg_set_error("leaf %zu: the by-slot table disagrees with the by-row one at %d", li, g); return 1; }
     // ---- staging
     std::vector<double> R((size_t)16*(L.nslots + 1), 0.0);
     std::vector<char> filled(L.nslots, 0);

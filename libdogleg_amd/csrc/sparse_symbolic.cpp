@@ -2135,6 +2135,11 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
           std::vector<int32_t> sv(nslots), sr(nslots); std::vector<uint16_t> sd(nslots);
           for(int g = 0; g < nslots; g++) { sv[g] = st[g][0]; sr[g] = st[g][1]; sd[g] = (uint16_t)st[g][2]; }
           put(sv.data(), 4*(size_t)nslots); put(sr.data(), 4*(size_t)nslots); put(sd.data(), 2*(size_t)nslots);
+          // ... and by slot
+          std::vector<int32_t> svs(nslots), srs(nslots);
+          for(int g = 0; g < nslots; g++) { svs[sd[g]] = sv[g]; srs[sd[g]] = sr[g]; }
+          align(4);
+          put(svs.data(), 4*(size_t)nslots); put(srs.data(), 4*(size_t)nslots);
         }
         align(16);
         const size_t l0 = S.lf_blob.size();                 // the part that goes to LDS
@@ -2183,7 +2188,8 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
       {
         int smax = 1, lmax = 16;
         for(const LfLeaf& L : S.lf_leaf) { smax = std::max(smax, L.nslots); lmax = std::max(lmax, L.lds_bytes); }
-        const size_t tb = ((size_t)10*smax + 15) & ~(size_t)15, stride = tb + (size_t)lmax;
+        const size_t o_s = ((size_t)10*smax + 3) & ~(size_t)3;                  // the by-slot tables behind the three by-row ones
+        const size_t tb = (o_s + (size_t)8*smax + 15) & ~(size_t)15, stride = tb + (size_t)lmax;
         S.lf_stride = S.lf_smax = S.lf_tb = 0;
         if(stride*S.lf_leaf.size() <= 2*S.lf_blob.size() + (1u << 20) && stride*S.lf_leaf.size() < ((size_t)1 << 31) - 65536 && !env_int("DOGLEG_AMD_LF_NO_STRIDE", 0))
         {
@@ -2196,11 +2202,28 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
             memcpy(dst, src, 4*(size_t)L.nslots);
             memcpy(dst + 4*(size_t)smax, src + 4*(size_t)L.nslots, 4*(size_t)L.nslots);
             memcpy(dst + 8*(size_t)smax, src + 8*(size_t)L.nslots, 2*(size_t)L.nslots);
+            const size_t so = ((size_t)10*L.nslots + 3) & ~(size_t)3;
+            memcpy(dst + o_s, src + so, 4*(size_t)L.nslots);
+            memcpy(dst + o_s + 4*(size_t)smax, src + so + 4*(size_t)L.nslots, 4*(size_t)L.nslots);
             memcpy(dst + tb, src + L.o_lds, (size_t)L.lds_bytes);
             L.blob = (int32_t)(i*stride); L.o_lds = (int32_t)tb; L.blob_bytes = (int32_t)stride;
           }
           S.lf_blob.swap(nb);
           S.lf_stride = (int)stride; S.lf_smax = smax; S.lf_tb = (int)tb;
+          // the persistent form's LDS: one layout for all leaves
+          long pud = 0; int scr = 0;
+          for(size_t i = 0; i < S.lf_leaf.size(); i++)
+          {
+            const LfLeaf& L = S.lf_leaf[i];
+            const long mb = L.nrows - L.w, ldp = (mb + 1) & ~1L, ntri = mb*(mb + 1)/2;
+            pud = std::max(pud, ldp*L.w + ((ntri + 2) & ~1L) + ((4L*L.w + 1) & ~1L));
+            scr = std::max(scr, L.nscr);
+          }
+          const long lmaxk = ((long)lmax + 1023) & ~1023L;                     // (a wave copies a kilobyte of schedule at a time)
+          const long bytes = lmaxk + 8*(pud + 16L*(smax + 1) + 128L*scr) + 64;
+          S.lf_pf_lds = 0;
+          if(bytes <= SYM_FAC_LDS_BUDGET && smax <= 512 && lmax <= 16384)
+          { S.lf_pf_lds = (int)bytes; S.lf_pf_b = (int)lmaxk; S.lf_pf_pud = (int)pud; S.lf_pf_scr = scr; }
         }
       }
       // Jt*x of the ancestors' blocks
@@ -2216,7 +2239,7 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
       }
       return true; };
     S.lf_ok = build();
-    if(!S.lf_ok) { S.lf_leaf.clear(); S.lf_blob.clear(); S.lf_jtp_size = 0; S.lf_lds = 0; S.lf_stride = 0; std::fill(S.lf_col.begin(), S.lf_col.end(), 0); }
+    if(!S.lf_ok) { S.lf_leaf.clear(); S.lf_blob.clear(); S.lf_jtp_size = 0; S.lf_lds = 0; S.lf_stride = 0; S.lf_pf_lds = 0; std::fill(S.lf_col.begin(), S.lf_col.end(), 0); }
     if(env_int("DOGLEG_AMD_SYM_DEBUG", 0) >= 1)
     {
       size_t naff = 0, nt = 0;

@@ -199,7 +199,8 @@ struct MfChild { int64_t u_off, dst_off; int npad, rsv; };     // rsv: the child
 // usually an arithmetic pattern of slots (a member's: consecutive; a camera's: one row-block per member at a
 // constant stride) and need no list.  The schedule of a leaf is one blob:
 //   staging table (read from HBM only), in the order of the rows in J (coalesced loads):
-//     int32 sval[nslots] (first value | entries << 28), srow[nslots], uint16 sdst[nslots] (the slot)
+//     int32 sval[nslots] (first value | entries << 28), srow[nslots], uint16 sdst[nslots] (the slot);
+//     the same by slot (the persistent form copies a leaf's rows in the order of their slots): int32 sval_s[nslots], srow_s[nslots]
 //   the part copied to LDS verbatim:
 //     LfTask task[ntask + ncomb]       strip tasks in the order the waves take them (wave v: v, v + #waves, ...),
 //                                      then the records of the split strips (where their sum goes)
@@ -356,6 +357,10 @@ struct SymHost
   // the blobs at one stride, their staging tables padded to lf_smax rows and their LDS parts at offset lf_tb: a workgroup
   // finds its table and its schedule from its index alone -- the loads do not wait for the leaf's record (0: not so)
   int lf_stride = 0, lf_smax = 0, lf_tb = 0;
+  // the persistent form of the kernel (a workgroup per CU, the next leaf's rows copied into LDS under the current
+  // leaf's elimination): one LDS layout for all leaves -- schedule (lf_pf_b bytes), then panel / update matrix / member
+  // blocks (lf_pf_pud doubles), rows (lf_smax + 1 of them), scratch (lf_pf_scr slots); lf_pf_lds bytes, 0: not available
+  int lf_pf_lds = 0, lf_pf_b = 0, lf_pf_pud = 0, lf_pf_scr = 0;
   // Jt*x of the ancestors' blocks: block i (first variable lf_jf_var0[i], lf_jf_w[i] of them) sums the leaves' records
   // lf_jf_ent[lf_jf_ptr[i] .. lf_jf_ptr[i+1]) (first entry in the record buffer) in that order; short / long lists
   std::vector<int> lf_jf_ptr, lf_jf_ent, lf_jf_var0, lf_jf_w, lf_jf_short, lf_jf_long;

@@ -18,6 +18,9 @@ VARIANTS = {
     "row-lists": {"DOGLEG_AMD_LF_LISTS": "1"},          # every strip reads its rows through a list (no arithmetic patterns)
     "no-rider": {"DOGLEG_AMD_LF_NO_RIDER": "1"},        # the global block keeps (split) strips of its own
     "no-stride": {"DOGLEG_AMD_LF_NO_STRIDE": "1"},      # schedules packed back to back (found through the leaf's record)
+    "persistent": {"DOGLEG_AMD_LF_WGS": "7"},           # 7 workgroups take the 50 leaves in turn, the next leaf's rows copied into LDS ahead
+    "persistent-1": {"DOGLEG_AMD_LF_WGS": "1"},         # one workgroup for all of them
+    "per-leaf": {"DOGLEG_AMD_LF_NO_PF": "1"},           # a workgroup per leaf
 }
 
 
