@@ -1,6 +1,6 @@
 #!/bin/bash
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-out=gpurun_out/r3l; mkdir -p $out
+out=gpurun_out/${1:-check}; mkdir -p $out
 timeout 1500 python3 -m pytest tests -m gpu -x -q > $out/tests.log 2>&1; echo "rc=$?" >> $out/tests.log
 tail -6 $out/tests.log
 for wl in sparse-1m sparse-200k; do
