@@ -281,32 +281,50 @@ __global__ void __launch_bounds__(TPB) k_potrf_tiles(double* A, int lda, int n, 
 
 // ---- both triangular solves in ONE launch: a workgroup per 64 rows -------------------------------
 // forward  y_i = Linv_i (b_i - sum_{k<i} L(i,k) y_k), backward  x_i = Linv_i' (y_i - sum_{k>i} L(k,i)' x_k).
-// Workgroup i waits for y_k (k < i) going down and for x_k (k > i) coming back up: flags with the
-// epoch of the launch, vectors handed over with write-through stores / loads around L1.  The tile of
-// L a product needs does not depend on the vector it waits for: it is on its way (forward: in
-// registers, backward: staged in LDS) before the flag is polled.  All T workgroups must be resident
-// (they wait for higher-numbered ones on the way back): T <= the number of CUs, one per CU.
+// Workgroup i waits for y_k (k < i) going down and for x_k (k > i) coming back up.  The vectors ARE the signal: a
+// block of y (x) is handed over in a buffer that holds a sentinel (a NaN no computation produces) until its owner
+// stores the values -- write-through, 8 bytes a lane --, and the 64 lanes that need a block each poll their own
+// element until it is not the sentinel: one trip through L2 per block instead of flag, barrier, load of the
+// block (and no drain + barrier + flag store on the owner's side): 3.5 -> 2 us a block, 32 + 32 of them in a row
+// on config #2.  Two sets of buffers, used by launches of even / odd epoch; a launch re-arms the set of the NEXT
+// launch (the launch before this one, which used it, is over).  The tile of L a product needs does not depend on
+// the vector it waits for: it is on its way (forward: in registers, backward: staged in LDS) before the poll.
+// All T workgroups must be resident (they wait for higher-numbered ones on the way back): T <= #CUs / 2.
+constexpr unsigned long long TRSV_EMPTY = 0x7FF8DEADBEEF0001ull;
 __global__ void __launch_bounds__(TPB) k_trsv_tiles(const double* __restrict__ A, int lda, int n, int T,
                                                     const double* __restrict__ Linv, const double* __restrict__ rhs,
-                                                    double* Y, double* X, int* flags, int epoch, DlgHandoff ho)
+                                                    double* Yh, double* X, double* Xh, int epoch, DlgHandoff ho)
 {
   extern __shared__ __attribute__((aligned(16))) double sm[];
-  typedef __attribute__((address_space(1))) double* gd_t;
-  typedef const __attribute__((address_space(1))) double* gcd_t;
+  typedef __attribute__((address_space(1))) unsigned long long* gu_t;
   constexpr int LDT = NB + 1;
   double (*Lt)[LDT] = reinterpret_cast<double (*)[LDT]>(sm);                 // a tile of L: Lt[row][col]
-  double* Li = sm + NB*LDT;                                                  // [NB*NB] this block's inverse, Li[r + c*NB] = Linv(r, c)
-  double* v = Li + NB*NB;                                                    // [NB]  the vector waited for
+  double* Li = sm + NB*LDT;                                                  // [NB*LDT] this block's inverse, Li[r + c*LDT] = Linv(r, c) (padded: its transpose is read too)
+  double* v = Li + NB*LDT;                                                    // [NB]  the vector waited for
   double* part = v + NB;                                                     // [4][NB] partial sums
   const int t = threadIdx.x, r = t & 63, g = t >> 6;
   const int i = blockIdx.x, row0 = NB*i;
-  int* fy = flags; int* fx = flags + T;
-  auto wait_flag = [&](int* f) {
-    int spins = 0;
-    while(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch + ho.skew)
-    { __builtin_amdgcn_s_sleep(1); if(++spins > ho.spins) { atomicOr(ho.status, DLG_HANDOFF_TRSV); break; } }
+  const int npad = T*NB, par = epoch & 1;
+  unsigned long long* ycur = reinterpret_cast<unsigned long long*>(Yh) + (size_t)par*npad;
+  unsigned long long* xcur = reinterpret_cast<unsigned long long*>(Xh) + (size_t)par*npad;
+  // (ho.skew != 0, the tests' forced time-out: the consumers look at a third set that nobody ever fills)
+  unsigned long long* ytake = ho.skew ? reinterpret_cast<unsigned long long*>(Yh) + (size_t)2*npad : ycur;
+  unsigned long long* xtake = ho.skew ? reinterpret_cast<unsigned long long*>(Xh) + (size_t)2*npad : xcur;
+  // the next launch's set, this block's part
+  if(t < NB)
+  {
+    reinterpret_cast<unsigned long long*>(Yh)[(size_t)(1 - (epoch & 1))*npad + row0 + t] = TRSV_EMPTY;
+    reinterpret_cast<unsigned long long*>(Xh)[(size_t)(1 - (epoch & 1))*npad + row0 + t] = TRSV_EMPTY;
+  }
+  // (lanes 0..NB-1: element t of block k, once it is there)
+  auto take = [&](unsigned long long* buf, int k) -> double {
+    unsigned long long u; int spins = 0;
+    while((u = __hip_atomic_load((gu_t)(buf + NB*k + t), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == TRSV_EMPTY)
+    { __builtin_amdgcn_s_sleep(1); if(++spins > ho.spins) { atomicOr(ho.status, DLG_HANDOFF_TRSV); u = 0; break; } }
+    return __longlong_as_double((long long)u);
   };
-  for(int e = t; e < NB*NB; e += TPB) Li[e] = Linv[(size_t)i*NB*NB + e];
+  for(int e = t; e < NB*NB; e += TPB) Li[(e & (NB - 1)) + (e/NB)*LDT] = Linv[(size_t)i*NB*NB + e];
+  const double rhs_t = (t < NB && row0 + t < n) ? rhs[row0 + t] : 0.0;      // (fetched now: behind the last block of y it would sit on everybody's path)
   // ---- forward: thread (row r, column group g) keeps 16 values of the tile in registers
   double acc = 0.0;
   double cur[16];
@@ -323,51 +341,56 @@ __global__ void __launch_bounds__(TPB) k_trsv_tiles(const double* __restrict__ A
   {
     double nxt[16];
     load_row_tile(k + 1, nxt);                       // (k + 1 == i: zeros, no loads)
-    if(t == 0) wait_flag(fy + k);
-    __syncthreads();
-    if(t < NB) v[t] = __hip_atomic_load((gcd_t)(Y + NB*k + t), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();                                 // (v of the step before is done with)
+    if(t < NB) v[t] = take(ytake, k);
     __syncthreads();
 #pragma unroll
     for(int c = 0; c < 16; c++) acc += cur[c]*v[16*g + c];
 #pragma unroll
     for(int c = 0; c < 16; c++) cur[c] = nxt[c];
   }
+  __syncthreads();
   part[g*NB + r] = acc;
   __syncthreads();
   if(t < NB)
   {
     const double s = (part[t] + part[NB + t]) + (part[2*NB + t] + part[3*NB + t]);
-    v[t] = (row0 + t < n) ? rhs[row0 + t] - s : 0.0;
+    v[t] = (row0 + t < n) ? rhs_t - s : 0.0;
+  }
+  __syncthreads();
+  // y_i = Linv * v: every thread a quarter of a row's 64 terms (a chain of 16, not 64, on everybody's path), then the
+  // four quarters in a fixed order
+  {
+    double q4 = 0.0;
+#pragma unroll
+    for(int k = 0; k < 16; k++) q4 += Li[r + (16*g + k)*LDT]*v[16*g + k];          // Linv is zero above the diagonal
+    part[g*NB + r] = q4;
   }
   __syncthreads();
   double yi = 0.0;
   if(t < NB)
   {
-#pragma unroll 8
-    for(int k = 0; k < NB; k++) yi += Li[t + k*NB]*v[k];          // Linv is zero above the diagonal
-    if(row0 + t < n) __hip_atomic_store((gd_t)(Y + row0 + t), yi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    yi = (part[t] + part[NB + t]) + (part[2*NB + t] + part[3*NB + t]);
+    // (rows past the end hand over zeros: a block is NB values, and none of them may stay the sentinel)
+    __hip_atomic_store((gu_t)(ycur + row0 + t), (unsigned long long)__double_as_longlong(row0 + t < n ? yi : 0.0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if(t == 0) __hip_atomic_store(fy + i, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   // ---- backward: the tile L(k, i) goes through LDS (thread = column afterwards)
   double bacc = 0.0;
   for(int k = T - 1; k > i; k--)
   {
+    __syncthreads();
     for(int e = t; e < NB*NB; e += TPB)
     {
       const int rr = e % NB, cc = e / NB;
       const int row = NB*k + rr, col = row0 + cc;
       Lt[rr][cc] = (row < n && col < n) ? A[(size_t)col*lda + row] : 0.0;
     }
-    if(t == 0) wait_flag(fx + k);
-    __syncthreads();
-    if(t < NB) v[t] = (NB*k + t < n) ? __hip_atomic_load((gcd_t)(X + NB*k + t), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+    if(t < NB) v[t] = take(xtake, k);
     __syncthreads();
 #pragma unroll
     for(int q = 0; q < 16; q++) bacc += Lt[16*g + q][r]*v[16*g + q];      // thread (column r, row group g)
-    __syncthreads();
   }
+  __syncthreads();
   part[g*NB + r] = bacc;
   __syncthreads();
   if(t < NB)
@@ -376,16 +399,19 @@ __global__ void __launch_bounds__(TPB) k_trsv_tiles(const double* __restrict__ A
     v[t] = yi - s;                                   // (rows past the end: yi = 0, s = 0)
   }
   __syncthreads();
+  {
+    double q4 = 0.0;
+#pragma unroll
+    for(int k = 0; k < 16; k++) q4 += Li[(16*g + k) + r*LDT]*v[16*g + k];         // Linv' : column r of Linv
+    part[g*NB + r] = q4;
+  }
+  __syncthreads();
   if(t < NB)
   {
-    double xi = 0.0;
-#pragma unroll 8
-    for(int k = 0; k < NB; k++) xi += Li[k + t*NB]*v[k];          // Linv' : column t of Linv
-    if(row0 + t < n) __hip_atomic_store((gd_t)(X + row0 + t), xi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const double xi = (part[t] + part[NB + t]) + (part[2*NB + t] + part[3*NB + t]);
+    if(row0 + t < n) X[row0 + t] = xi;
+    __hip_atomic_store((gu_t)(xcur + row0 + t), (unsigned long long)__double_as_longlong(row0 + t < n ? xi : 0.0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if(t == 0) __hip_atomic_store(fx + i, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 } // namespace
@@ -404,13 +430,20 @@ static void dlg_func_lds_once(bool (&done)[DLG_MAX_DEV], const void* fn, int byt
 }
 
 void dense_launch_trsv_tiles(hipStream_t st, const double* A, int lda, int n, const double* Linv, const double* rhs,
-                             double* Y, double* X, int* flags, int epoch, const DlgHandoff& ho)
+                             double* Yh, double* X, double* Xh, int epoch, const DlgHandoff& ho)
 {
   static bool attr[DLG_MAX_DEV] = {};       // a function attribute is a property of (function, device)
   constexpr int LDSB = 88*1024;           // > half of the CU's LDS: one workgroup per CU
   dlg_func_lds_once(attr, reinterpret_cast<const void*>(&k_trsv_tiles), LDSB);
   const int T = (n + NB - 1)/NB;
-  hipLaunchKernelGGL(k_trsv_tiles, dim3(T), dim3(TPB), LDSB, st, A, lda, n, T, Linv, rhs, Y, X, flags, epoch, ho);
+  hipLaunchKernelGGL(k_trsv_tiles, dim3(T), dim3(TPB), LDSB, st, A, lda, n, T, Linv, rhs, Yh, X, Xh, epoch, ho);
+}
+// (both sets of hand-off buffers empty: before the first launch)
+namespace { __global__ void k_trsv_arm(unsigned long long* a, size_t n) { for(size_t i = blockIdx.x*(size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x*blockDim.x) a[i] = TRSV_EMPTY; } }
+void dense_trsv_arm(hipStream_t st, double* Yh, double* Xh, size_t n_each)
+{
+  hipLaunchKernelGGL(k_trsv_arm, dim3(64), dim3(256), 0, st, reinterpret_cast<unsigned long long*>(Yh), n_each);
+  hipLaunchKernelGGL(k_trsv_arm, dim3(64), dim3(256), 0, st, reinterpret_cast<unsigned long long*>(Xh), n_each);
 }
 
 void dense_launch_potrf_tiles(hipStream_t st, double* A, int lda, int n, int* info_dev, double* Linv, int* flags, int epoch, const DlgHandoff& ho)

@@ -111,7 +111,7 @@ struct dlg_backend
   // dense / products
   double* G = nullptr;        // N x N column-major, lower triangle = factor
   double* Linv = nullptr;     // inverses of the 64x64 diagonal blocks of the factor
-  int* potrf_flag = nullptr; int potrf_epoch = 0; int* trsv_flag = nullptr; double* trsv_y = nullptr;   // hand-off flags of the one-launch factorisation ([T*T] + 1 for the step form)
+  int* potrf_flag = nullptr; int potrf_epoch = 0; int* trsv_flag = nullptr; double* trsv_y = nullptr; double* trsv_x = nullptr; int trsv_epoch = 0;   // hand-off flags of the one-launch factorisation ([T*T] + 1 for the step form)
   double* slabs = nullptr;    // split-K partial slabs for the SYRK
   size_t  slabs_bytes = 0;
   int*    d_info = nullptr;
@@ -243,7 +243,8 @@ void dense_launch_potrf_diag(hipStream_t st, double* A, int lda, int kb, int nb,
 void dense_launch_potrf_tiles(hipStream_t st, double* A, int lda, int n, int* info_dev, double* Linv, int* flags, int epoch, const DlgHandoff& ho);
 // both triangular solves of (L L') x = rhs in one launch (a workgroup per 64 rows; flags: 2*T device ints; Y: n doubles of scratch)
 void dense_launch_trsv_tiles(hipStream_t st, const double* A, int lda, int n, const double* Linv, const double* rhs,
-                             double* Y, double* X, int* flags, int epoch, const DlgHandoff& ho);
+                             double* Yh, double* X, double* Xh, int epoch, const DlgHandoff& ho);
+void dense_trsv_arm(hipStream_t st, double* Yh, double* Xh, size_t n_each);
 void dense_launch_potrf_diag_trsm(hipStream_t st, double* A, int lda, int kb, int nb, int n, int* info_dev, double* Linv,
                                   int* flag, int epoch, const DlgHandoff& ho);
 void dense_destroy(dlg_backend* b);

@@ -820,6 +820,7 @@ void dense_destroy(dlg_backend* b)
   if(b->potrf_flag) { (void)hipFree(b->potrf_flag); b->potrf_flag = nullptr; }
   if(b->trsv_flag) { (void)hipFree(b->trsv_flag); b->trsv_flag = nullptr; }
   if(b->trsv_y) { (void)hipFree(b->trsv_y); b->trsv_y = nullptr; }
+  if(b->trsv_x) { (void)hipFree(b->trsv_x); b->trsv_x = nullptr; }
   if(b->h_info) (void)hipHostFree(b->h_info);
   b->G = b->slabs = nullptr; b->d_info = nullptr; b->h_info = nullptr;
 }
@@ -963,13 +964,15 @@ int dense_solve(dlg_backend* b, const double* rhs, double* out)
     // workgroups --: half the chip at most, so that the pass over J on the second stream does not matter)
     if(T >= 2 && T <= b->ncu/2 && !b->knobs.trsv_steps)
     {
-      if(!b->trsv_flag)
+      if(!b->trsv_y)
       {
-        DLG_HIP(hipMalloc(&b->trsv_flag, sizeof(int)*2*(size_t)T));
-        DLG_HIP(hipMemsetAsync(b->trsv_flag, 0, sizeof(int)*2*(size_t)T, b->stream));
-        DLG_HIP(hipMalloc(&b->trsv_y, sizeof(double)*(size_t)n));
+        // two sets of hand-off buffers (even / odd launches), every element a sentinel until its owner stores it
+        const size_t ne = 3*(size_t)T*NB;         // (+ a set that stays empty: the forced time-out of the tests)
+        DLG_HIP(hipMalloc(&b->trsv_y, sizeof(double)*ne));
+        DLG_HIP(hipMalloc(&b->trsv_x, sizeof(double)*ne));
+        dense_trsv_arm(b->stream, b->trsv_y, b->trsv_x, ne);
       }
-      dense_launch_trsv_tiles(b->stream, b->G, n, n, b->Linv, rhs, b->trsv_y, out, b->trsv_flag, ++b->potrf_epoch, dlg_handoff(b, 1 << 22));
+      dense_launch_trsv_tiles(b->stream, b->G, n, n, b->Linv, rhs, b->trsv_y, out, b->trsv_x, ++b->trsv_epoch, dlg_handoff(b, 1 << 22));
       DLG_LAUNCH_CHECK();
       return DLG_OK;
     }
