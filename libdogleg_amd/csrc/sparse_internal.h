@@ -127,7 +127,7 @@ struct SparseSym
   bool spec_inflight = false, spec_valid = false; int spec_slot = -1; const double* spec_J = nullptr;
   int64_t touch_off = 0, touch_n = 0;    // stretch of Lx with the leaf panels (sparse_touch_factor)
   int bw_level0 = 1 << 30, bw_lds = 0, bw_n = 0;   // persistent top region of the backward solve (sparse_solve_setup)
-  SolveItem* slv_item_pr = nullptr; int* bwd_flag = nullptr; int bwd_epoch = 0;
+  SolveItem* slv_item_pr = nullptr; int* bwd_flag = nullptr; int bwd_epoch = 0; double* bwd_xh = nullptr;   // (bwd_xh: x of the region as its own arrival signal, two sets)
   int pr_stage = 0; double* pr_acc = nullptr;   // ... childless supernodes stage their update matrix; shadow scratch for the ones kept in HBM
   int pr_level0 = 1 << 30, pr_lds = 0;   // persistent top region of the factorisation: first level, LDS bytes (sparse_factor_setup)
   int* fac_flag = nullptr; int fac_epoch = 0;   // one flag per workgroup of the region: the epoch of the launch that finished it

@@ -115,7 +115,8 @@ __global__ void __launch_bounds__(BWD_NT, BD_ONLY ? 4 : 1) k_solve_bwd_level(con
                                                             double* __restrict__ ywork,
                                                             double* __restrict__ out, int use_aug,
                                                             const int* __restrict__ sn_bd_col, int top_lds, int xb_cap,
-                                                            int* pr_flag, int pr_epoch, const int* __restrict__ info, DlgHandoff ho)
+                                                            int* pr_flag, int pr_epoch, const int* __restrict__ info, DlgHandoff ho,
+                                                            double* xh, int xh_n)
 {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   __shared__ int s_skip;
@@ -127,12 +128,30 @@ __global__ void __launch_bounds__(BWD_NT, BD_ONLY ? 4 : 1) k_solve_bwd_level(con
   typedef const __attribute__((address_space(1))) double* gcd_t;
   typedef __attribute__((address_space(1))) double* gd_t;
   auto ldx = [&](const double* p) -> double { return pr_flag ? __hip_atomic_load((gcd_t)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p; };
+  // One-launch region, x of the ancestors staged in LDS: x IS the signal.  A copy of the region's part of x (xh, two
+  // sets for launches of even / odd epoch) holds a sentinel -- a NaN no solve produces -- until a supernode stores its
+  // solution there; a workgroup polls the entries of its below rows themselves, every lane its own, instead of flag,
+  // barrier, gather (one trip through L2 a level instead of two, and the parent's drain + barrier + flag store are
+  // off the children's path).  A launch re-arms the set of the next launch.  (The forced time-out of the tests and
+  // supernodes whose below rows do not fit LDS keep the flags, which are raised as before.)
+  constexpr unsigned long long X_EMPTY = 0x7FF8DEADBEEF0002ull;
+  typedef __attribute__((address_space(1))) unsigned long long* gu_t;
+  const bool xh_on = pr_flag != nullptr && xh != nullptr && ho.skew == 0;
+  unsigned long long* xcur = reinterpret_cast<unsigned long long*>(xh) + (size_t)(pr_epoch & 1)*xh_n;
+  auto put_xh = [&](int col, double v) {
+    if(xh_on) __hip_atomic_store((gu_t)(xcur + col), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+  auto take_xh = [&](int col) -> double {
+    unsigned long long u; int spins = 0;
+    while((u = __hip_atomic_load((gu_t)(xcur + col), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == X_EMPTY)
+    { __builtin_amdgcn_s_sleep(1); if(++spins > ho.spins) { atomicOr(ho.status, DLG_HANDOFF_SOLVE); u = 0; break; } }
+    return __longlong_as_double((long long)u); };
 
   const int prof_lvl = top_lds >> 8; (void)prof_lvl;
   top_lds &= 1;
   BW_STAMP(0);
   const SolveItem it = items[blockIdx.x];
   const int c0 = it.c0, w = it.w, nrows = it.nrows;
+  if(xh_on && (int)threadIdx.x < w) reinterpret_cast<unsigned long long*>(xh)[(size_t)(1 - (pr_epoch & 1))*xh_n + c0 + threadIdx.x] = X_EMPTY;
   const int* rows = sn_rows + it.rowoff;
   const double* L = Lx + it.lx;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -302,7 +321,8 @@ __global__ void __launch_bounds__(BWD_NT, BD_ONLY ? 4 : 1) k_solve_bwd_level(con
   }
   // ---- round 3
   if(tid < 256) xs[tid] = 0.0;            // columns without below rows (a root) get no mat-vec pass
-  if(pr_flag)
+  const bool by_value = xh_on && xb_lds;          // x of the below rows polled entry by entry (see xh above)
+  if(pr_flag && !by_value)
   {
     // everything that does not depend on the ancestors is on its way; now wait for the parent (it
     // waited for its own: all ancestors are done)
@@ -317,7 +337,12 @@ __global__ void __launch_bounds__(BWD_NT, BD_ONLY ? 4 : 1) k_solve_bwd_level(con
     }
     __syncthreads();
   }
-  if(xb_lds)
+  if(by_value)
+  {
+    if(tid < r) xb[tid] = take_xh(myrow);
+    for(int i = tid + BWD_NT; i < r; i += BWD_NT) xb[i] = take_xh(rows[w + i]);
+  }
+  else if(xb_lds)
   {
     if(tid < r) xb[tid] = ldx(ywork + myrow);
     for(int i = tid + BWD_NT; i < r; i += BWD_NT) xb[i] = ldx(ywork + rows[w + i]);
@@ -325,6 +350,7 @@ __global__ void __launch_bounds__(BWD_NT, BD_ONLY ? 4 : 1) k_solve_bwd_level(con
   __syncthreads();
   if(s_skip)
   {
+    if(tid < w) put_xh(c0 + tid, 0.0);              // (the children must not wait for values that never come)
     if(pr_flag && tid == 0) __hip_atomic_store(pr_flag + blockIdx.x, pr_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return;
   }
@@ -435,6 +461,7 @@ __global__ void __launch_bounds__(BWD_NT, BD_ONLY ? 4 : 1) k_solve_bwd_level(con
     __syncthreads();
     if(tid < w)
     {
+      put_xh(c0 + tid, xs[tid]);
       if(pr_flag) __hip_atomic_store((gd_t)(ywork + c0 + tid), xs[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       else ywork[c0 + tid] = xs[tid];
       out[myperm] = xs[tid];
@@ -498,6 +525,7 @@ __global__ void __launch_bounds__(BWD_NT, BD_ONLY ? 4 : 1) k_solve_bwd_level(con
     BW_STAMP(4);
     if(tid < w)
     {
+      put_xh(c0 + tid, xi);
       if(pr_flag) __hip_atomic_store((gd_t)(ywork + c0 + tid), xi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       else ywork[c0 + tid] = xi;
       out[myperm] = xi;
@@ -576,6 +604,7 @@ __global__ void __launch_bounds__(BWD_NT, BD_ONLY ? 4 : 1) k_solve_bwd_level(con
   BW_STAMP(4);
   if(tid < w)
   {
+    put_xh(c0 + tid, xi);
     if(pr_flag) __hip_atomic_store((gd_t)(ywork + c0 + tid), xi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     else ywork[c0 + tid] = xi;
     out[myperm] = xi;
@@ -787,6 +816,13 @@ int sparse_solve_setup(dlg_backend* b)
         }
       Y->bw_level0 = l0; Y->bw_n = (int)items.size(); Y->bw_lds = std::max(ldsb, 84*1024);
       DLG_CHECK(upload(Y->slv_item_pr, items)); Y->allocs.push_back(Y->slv_item_pr);
+      // x of the region as its own signal (k_solve_bwd_level, xh): two sets, every entry a sentinel until it is stored
+      if(!getenv("DOGLEG_AMD_BWD_FLAGS"))
+      {
+        std::vector<unsigned long long> empty(2*(size_t)H.N, 0x7FF8DEADBEEF0002ull);
+        DLG_HIP(hipMalloc(&Y->bwd_xh, sizeof(double)*empty.size())); Y->allocs.push_back(Y->bwd_xh);
+        DLG_HIP(hipMemcpy(Y->bwd_xh, empty.data(), sizeof(double)*empty.size(), hipMemcpyHostToDevice));
+      }
       DLG_HIP(hipMalloc(&Y->bwd_flag, sizeof(int)*items.size())); Y->allocs.push_back(Y->bwd_flag);
       DLG_HIP(hipMemsetAsync(Y->bwd_flag, 0, sizeof(int)*items.size(), b->stream));
       Y->bwd_epoch = 0;
@@ -830,7 +866,7 @@ int sparse_solve(dlg_backend* b, const double* rhs, double* out)
     // the persistent top region: its levels in one launch, workgroups from the root down (sparse_solve_setup)
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_solve_bwd_level<512, false>), dim3(Y->bw_n), dim3(512), Y->bw_lds, st,
                        Y->slv_item_pr, Y->sn_rows, Y->perm, Y->Lx, Y->ywork, out, use_aug, Y->sn_bd_col,
-                       256*Y->bw_level0, Y->bwd_xb_cap, Y->bwd_flag, ++Y->bwd_epoch, Y->d_info, dlg_handoff(b, 1 << 21));
+                       256*Y->bw_level0, Y->bwd_xb_cap, Y->bwd_flag, ++Y->bwd_epoch, Y->d_info, dlg_handoff(b, 1 << 21), Y->bwd_xh, H.N);
     ltop = Y->bw_level0 - 1;
   }
   for(int l = ltop; l >= 0; l--)
@@ -841,15 +877,15 @@ int sparse_solve(dlg_backend* b, const double* rhs, double* out)
     if(n > 0 && Y->bwd_nt[l] == 256 && Y->bwd_bd[l])
       hipLaunchKernelGGL(HIP_KERNEL_NAME(k_solve_bwd_level<256, true>), dim3(n), dim3(256), Y->bwd_lds[l], st,
                          Y->slv_item + H.xl_ptr[l], Y->sn_rows, Y->perm, Y->Lx, Y->ywork, out, use_aug, Y->sn_bd_col,
-                         Y->bwd_top[l] + 256*l, Y->bwd_xb_cap, (int*)nullptr, 0, Y->d_info, dlg_handoff(b, 1 << 21));
+                         Y->bwd_top[l] + 256*l, Y->bwd_xb_cap, (int*)nullptr, 0, Y->d_info, dlg_handoff(b, 1 << 21), (double*)nullptr, 0);
     else if(n > 0 && Y->bwd_nt[l] == 256)
       hipLaunchKernelGGL(HIP_KERNEL_NAME(k_solve_bwd_level<256, false>), dim3(n), dim3(256), Y->bwd_lds[l], st,
                          Y->slv_item + H.xl_ptr[l], Y->sn_rows, Y->perm, Y->Lx, Y->ywork, out, use_aug, Y->sn_bd_col,
-                         Y->bwd_top[l] + 256*l, Y->bwd_xb_cap, (int*)nullptr, 0, Y->d_info, dlg_handoff(b, 1 << 21));
+                         Y->bwd_top[l] + 256*l, Y->bwd_xb_cap, (int*)nullptr, 0, Y->d_info, dlg_handoff(b, 1 << 21), (double*)nullptr, 0);
     else if(n > 0)
       hipLaunchKernelGGL(HIP_KERNEL_NAME(k_solve_bwd_level<512, false>), dim3(n), dim3(512), Y->bwd_lds[l], st,
                          Y->slv_item + H.xl_ptr[l], Y->sn_rows, Y->perm, Y->Lx, Y->ywork, out, use_aug, Y->sn_bd_col,
-                         Y->bwd_top[l] + 256*l, Y->bwd_xb_cap, (int*)nullptr, 0, Y->d_info, dlg_handoff(b, 1 << 21));
+                         Y->bwd_top[l] + 256*l, Y->bwd_xb_cap, (int*)nullptr, 0, Y->d_info, dlg_handoff(b, 1 << 21), (double*)nullptr, 0);
   }
   DLG_LAUNCH_CHECK();
   if(H.part_nranks > 1)
