@@ -71,6 +71,14 @@ void dlg_prof_end(dlg_backend* b, int id, hipEvent_t start)
   (void)hipEventRecord(e, b->stream);
   b->prof_pending.push_back({start, e, id});
 }
+bool dlg_prof_pair(dlg_backend* b, int id, hipEvent_t* e0, hipEvent_t* e1)
+{
+  if(!(b->prof_mask >> id & 1u) || !b->ext_events) return false;
+  *e0 = prof_event(b); *e1 = prof_event(b);
+  if(!*e0 || !*e1) { if(*e0) b->prof_pool.push_back(*e0); if(*e1) b->prof_pool.push_back(*e1); return false; }
+  b->prof_pending.push_back({*e0, *e1, id});
+  return true;
+}
 void dlg_prof_resolve(dlg_backend* b)
 {
   for(auto& pp : b->prof_pending)
@@ -153,6 +161,7 @@ extern "C" int dlg_backend_create(dlg_backend_t** out, int solve_type, int Nstat
   TRY_HIP(hipEventCreateWithFlags(&b->ev_join, hipEventDisableTiming));
   b->overlap = getenv("DOGLEG_AMD_NO_OVERLAP") == nullptr;
   b->fuse_eval = getenv("DOGLEG_AMD_NO_FUSED_EVAL") == nullptr;
+  b->ext_events = getenv("DOGLEG_AMD_NO_EXT_EVENTS") == nullptr;
   TRY_HIP(hipMalloc(&b->d_scal, sizeof(double)*dlg_backend::NSCAL));
   TRY_HIP(hipMemsetAsync(b->d_scal, 0, sizeof(double)*dlg_backend::NSCAL, b->stream));
   TRY_HIP(hipHostMalloc(&b->h_scal, sizeof(double)*dlg_backend::NSCAL));
@@ -252,7 +261,7 @@ extern "C" int dlg_backend_reset(dlg_backend_t* b)
     // (step_to_here of the first point of a solve is read by nobody, but a returned context downloads it)
     DLG_HIP(hipMemsetAsync(S.step, 0, sizeof(double)*(size_t)b->N, b->stream));
   }
-  b->factor_slot = -1; b->speculate = false;
+  b->factor_slot = -1; b->speculate = false; b->presolve = false; b->pre_slot = -1; b->pre_held = -1;
   b->want_fork = b->fork_recorded = false; b->fork_gate = nullptr;
   b->fold_scalar = b->fold_result = nullptr; b->fold_cauchy_out = nullptr;
   b->fold_p_src = nullptr; b->p_copied = false; b->scal_copied = false; b->fold_scal = 0;
@@ -294,6 +303,7 @@ extern "C" int dlg_backend_set_speculation(dlg_backend_t* b, int on)
 {
   if(!b) return DLG_ERR_ARG;
   b->speculate = on != 0;
+  b->presolve = b->speculate && getenv("DOGLEG_AMD_NO_PRESOLVE") == nullptr;
   return DLG_OK;
 }
 
@@ -440,6 +450,7 @@ extern "C" int dlg_sparse_set_pattern(dlg_backend_t* b, const int* colptr, const
 }
 
 // ------------------------------------------------------------------ inputs --
+static int step_unprepare(dlg_backend* b);
 static int check_slot(dlg_backend* b, int s)
 {
   if(!b || s < 0 || s > 1) { dlg_set_error("bad backend/slot"); return DLG_ERR_ARG; }
@@ -462,6 +473,7 @@ extern "C" int dlg_point_set_p(dlg_backend_t* b, int s, const double* p_host)
 extern "C" int dlg_point_upload(dlg_backend_t* b, int s, const double* x_host, const double* J_host)
 {
   DLG_CHECK(check_slot(b, s));
+  DLG_CHECK(step_unprepare(b));
   if(b->type == DLG_DENSE_PRODUCTS) { dlg_set_error("use dlg_point_upload_products"); return DLG_ERR_ARG; }
   DlgSlot& S = b->slot[s];
   S.x_bound = S.J_bound = nullptr;
@@ -483,6 +495,7 @@ extern "C" int dlg_point_upload_products(dlg_backend_t* b, int s, double norm2x,
                                          const double* JtJ_host)
 {
   DLG_CHECK(check_slot(b, s));
+  DLG_CHECK(step_unprepare(b));
   if(b->type != DLG_DENSE_PRODUCTS) { dlg_set_error("not a dense-products backend"); return DLG_ERR_ARG; }
   DlgSlot& S = b->slot[s];
   S.x_bound = S.J_bound = nullptr;
@@ -498,6 +511,7 @@ extern "C" int dlg_point_upload_products(dlg_backend_t* b, int s, double norm2x,
 extern "C" int dlg_point_bind_device(dlg_backend_t* b, int s, const double* x_dev, const double* J_dev)
 {
   DLG_CHECK(check_slot(b, s));
+  DLG_CHECK(step_unprepare(b));
   DlgSlot& S = b->slot[s];
   S.x_bound = x_dev; S.J_bound = J_dev;
   S.have_inputs = true;
@@ -507,10 +521,53 @@ extern "C" int dlg_point_bind_device(dlg_backend_t* b, int s, const double* x_de
   return DLG_OK;
 }
 
+static int cauchy_fork_begin(dlg_backend* b);
+// what step_prepare enqueued is not going to be used: the factor it displaced is the held one again
+static int step_unprepare(dlg_backend* b)
+{
+  if(b->pre_slot < 0) return DLG_OK;
+  b->pre_slot = -1;
+  b->want_fork = b->fork_recorded = false; b->fork_gate = nullptr;
+  const int held = b->pre_held;
+  b->pre_held = -1;
+  if(held < 0 || b->type != DLG_SPARSE) return DLG_OK;
+  bool restored = false;
+  DLG_CHECK(sparse_restore_factor(b, &restored));
+  b->factor_slot = restored ? held : -1;
+  return DLG_OK;
+}
+// K5 + K6 of slot s enqueued ahead of the caller's decision to step from it (dlg_point_eval, one-pass form:
+// the panels are the ones assembled beside Jt*x), at the lambda of the last factorisation.  dlg_take_step
+// picks them up if it is called for this slot at this lambda (pre_slot / pre_lambda); any other use of the
+// slot factorises again.  Nothing is fetched here: the pivot flag comes back with the step's scalars.
+static int step_prepare(dlg_backend* b, int s)
+{
+  DlgSlot& S = b->slot[s];
+  const double lam = sparse_current_lambda(b);
+  b->pre_held = (b->factor_slot >= 0 && b->factor_slot != s) ? b->factor_slot : -1;
+  sparse_hold_factor(b);
+  b->factor_slot = -1;
+  S.have_Jtx = true;                                           // (enqueued: the panels carry it as their right-hand side)
+  DLG_CHECK(cauchy_fork_begin(b));
+  int good = 0;
+  b->defer_factor_sync = true;
+  const int rc = sparse_factorize(b, s, lam, &good);
+  b->defer_factor_sync = false;
+  if(rc != DLG_OK) b->want_fork = false;
+  DLG_CHECK(rc);
+  {
+    DlgProfScope ps(b, DLG_PROF_K6_SOLVE);
+    DLG_CHECK(sparse_solve(b, S.Jt_x, S.gn));
+  }
+  b->pre_slot = s; b->pre_lambda = lam;
+  return DLG_OK;
+}
+
 // ---------------------------------------------------------------------- K1 --
 extern "C" int dlg_point_eval(dlg_backend_t* b, int s, double* norm2_x, double* Jtx_absmax)
 {
   DLG_CHECK(check_slot(b, s));
+  DLG_CHECK(step_unprepare(b));
   DlgSlot& S = b->slot[s];
   if(!S.have_inputs) { dlg_set_error("dlg_point_eval: no inputs uploaded for slot %d", s); return DLG_ERR_STATE; }
   if(b->type == DLG_DENSE_PRODUCTS)
@@ -549,7 +606,15 @@ extern "C" int dlg_point_eval(dlg_backend_t* b, int s, double* norm2_x, double* 
       DLG_HIP(hipMemcpyAsync(b->d_scal, b->d_red + b->N, sizeof(double), hipMemcpyDeviceToDevice, b->stream));
     }
     bool norms_on_host = false;
-    if(pair) DLG_CHECK(k_norm2_absmax_pair(b, S.Jt_x, b->N, b->d_scal + 2, S.xin(), mloc, b->d_scal, &norms_on_host));
+    if(pair)
+    {
+      // (the event the host waits for rides on the norm kernel where that is the last thing the host reads)
+      if(!b->ev_fetch) DLG_HIP(hipEventCreateWithFlags(&b->ev_fetch, hipEventDisableTiming));
+      b->attach_stop = b->ext_events ? b->ev_fetch : nullptr; b->stop_attached = false;
+      const int rcn = k_norm2_absmax_pair(b, S.Jt_x, b->N, b->d_scal + 2, S.xin(), mloc, b->d_scal, &norms_on_host);
+      b->attach_stop = nullptr;
+      DLG_CHECK(rcn);
+    }
     else     DLG_CHECK(k_norm2_absmax(b, S.Jt_x, b->N, b->d_scal + 2));
     if(fused)
     {
@@ -558,8 +623,12 @@ extern "C" int dlg_point_eval(dlg_backend_t* b, int s, double* norm2_x, double* 
       // (the workgroups of the norm kernel wrote their partial sums to page-locked host memory and the host
       // adds them: nothing to copy then -- the event alone is the point the host waits for)
       if(!norms_on_host) DLG_HIP(hipMemcpyAsync(b->h_scal, b->d_scal, sizeof(double)*4, hipMemcpyDeviceToHost, b->stream));
-      DLG_HIP(hipEventRecord(b->ev_fetch, b->stream));
+      if(!(norms_on_host && b->stop_attached)) DLG_HIP(hipEventRecord(b->ev_fetch, b->stream));
+      b->stop_attached = false;
       DLG_CHECK(sparse_assemble_finish(b));
+      // the factorisation and the Gauss-Newton solve follow at once (dlg_take_step finds them enqueued): the
+      // chip works on them while the host fetches the norms and decides
+      if(b->presolve && !b->sharded() && b->part_nranks <= 1) DLG_CHECK(step_prepare(b, s));
       DLG_HIP(hipEventSynchronize(b->ev_fetch));
       dlg_resolve_pending(b);
     }
@@ -691,6 +760,7 @@ extern "C" int dlg_cauchy(dlg_backend_t* b, int s, double* norm2_updateCauchy)
 extern "C" int dlg_factorize(dlg_backend_t* b, int s, double lambda, int* ok)
 {
   DLG_CHECK(check_slot(b, s));
+  DLG_CHECK(step_unprepare(b));
   DlgSlot& S = b->slot[s];
   if(!S.have_inputs) { dlg_set_error("dlg_factorize: slot %d has no J/JtJ", s); return DLG_ERR_STATE; }
   int good = 0;
@@ -710,6 +780,7 @@ extern "C" int dlg_factorize(dlg_backend_t* b, int s, double lambda, int* ok)
 extern "C" int dlg_solve_gn(dlg_backend_t* b, int s, double* norm2_updateGN)
 {
   DLG_CHECK(check_slot(b, s));
+  DLG_CHECK(step_unprepare(b));
   DlgSlot& S = b->slot[s];
   if(!S.have_Jtx) { dlg_set_error("dlg_solve_gn needs Jt_x"); return DLG_ERR_STATE; }
   if(b->factor_slot != s) { dlg_set_error("dlg_solve_gn: no factorization of slot %d is held", s); return DLG_ERR_STATE; }
@@ -739,6 +810,7 @@ static int gauss_newton_impl(dlg_backend_t* b, int s, double* lambda_io, double*
                             bool with_cauchy, double* norm2_updateCauchy)
 {
   DLG_CHECK(check_slot(b, s));
+  DLG_CHECK(step_unprepare(b));
   if(!lambda_io) { dlg_set_error("dlg_gauss_newton: lambda_io is NULL"); return DLG_ERR_ARG; }
   DlgSlot& S = b->slot[s];
   if(!S.have_inputs) { dlg_set_error("dlg_gauss_newton: slot %d has no J/JtJ", s); return DLG_ERR_STATE; }
@@ -857,6 +929,8 @@ static int step_finish(dlg_backend* b, int to, int nscal, double* p_new_host)
 {
   DlgSlot& T = b->slot[to];
   // (unless the step's last kernel has written them to the page-locked h_scal itself: sparse_norm2_Jv)
+  bool attached = b->stop_attached && b->scal_copied && !p_new_host;      // (the step's last kernel carries ev_fetch)
+  b->stop_attached = false;
   if(!b->scal_copied) DLG_HIP(hipMemcpyAsync(b->h_scal, b->d_scal, sizeof(double)*(size_t)nscal, hipMemcpyDeviceToHost, b->stream));
   b->scal_copied = false;
   bool pinned = true;
@@ -874,7 +948,7 @@ static int step_finish(dlg_backend* b, int to, int nscal, double* p_new_host)
   // factorisation left behind (sparse_zero_spare): the GPU does it while the host digests the step and
   // evaluates the next point, and that point's assembly finds the buffer zeroed.
   if(!b->ev_fetch) DLG_HIP(hipEventCreateWithFlags(&b->ev_fetch, hipEventDisableTiming));
-  DLG_HIP(hipEventRecord(b->ev_fetch, b->stream));
+  if(!attached) DLG_HIP(hipEventRecord(b->ev_fetch, b->stream));
   if(b->type == DLG_SPARSE) DLG_CHECK(sparse_zero_spare(b));
   DLG_HIP(hipEventSynchronize(b->ev_fetch));
   dlg_resolve_pending(b);
@@ -977,14 +1051,24 @@ extern "C" int dlg_take_step(dlg_backend_t* b, int from, int to, double trustreg
   if(!b->d_gnpart) DLG_HIP(hipMalloc(&b->d_gnpart, sizeof(double)*1024));
   double lam = *lambda_io;
   bool side_copy = false;
+  // (the factorisation and the solve enqueued by dlg_point_eval -- step_prepare -- are this step's if the
+  // lambda is the one they were formed at; they are used once)
+  const bool prepared_here = b->pre_slot == from && b->pre_lambda == lam;
+  if(prepared_here) { b->pre_slot = -1; b->pre_held = -1; } else DLG_CHECK(step_unprepare(b));
+  bool prepared = prepared_here;
   for(;;)
   {
     int good = 0, rc;
     double* n2c_dev = b->d_scal + 6;
     const bool do_cauchy = !F.have_cauchy;
-    if(do_cauchy) DLG_CHECK(cauchy_fork_begin(b));
-    else DLG_HIP(hipMemcpyAsync(n2c_dev, &F.norm2_cauchy, sizeof(double), hipMemcpyHostToDevice, b->stream));
-    if(b->factor_slot != from)
+    if(do_cauchy) { if(!prepared) DLG_CHECK(cauchy_fork_begin(b)); }
+    else
+    {
+      b->want_fork = b->fork_recorded = false; b->fork_gate = nullptr;
+      DLG_HIP(hipMemcpyAsync(n2c_dev, &F.norm2_cauchy, sizeof(double), hipMemcpyHostToDevice, b->stream));
+    }
+    if(prepared) { /* K5 is on the stream already */ }
+    else if(b->factor_slot != from)
     {
       b->defer_factor_sync = true;
       switch(b->type)
@@ -998,11 +1082,13 @@ extern "C" int dlg_take_step(dlg_backend_t* b, int from, int to, double trustreg
       DLG_CHECK(rc);
     }
     if(do_cauchy) DLG_CHECK(cauchy_fork_enqueue(b, from, b->d_scal + 4));     // K3 beside K5 (second stream)
+    if(!prepared)
     {
       DlgProfScope ps(b, DLG_PROF_K6_SOLVE);
       if(b->type == DLG_SPARSE) DLG_CHECK(sparse_solve(b, F.Jt_x, F.gn));
       else                      DLG_CHECK(dense_solve(b, F.Jt_x, F.gn));
     }
+    prepared = false;
     DLG_CHECK(cauchy_deferred_finish(b, from));
     int nbg = 0;
     {
@@ -1035,7 +1121,10 @@ extern "C" int dlg_take_step(dlg_backend_t* b, int from, int to, double trustreg
       }
     }
     b->fold_scal = dlg_backend::NSCAL;       // (the last kernel of the step: it takes the scalars to the host with it)
+    if(!b->ev_fetch) DLG_HIP(hipEventCreateWithFlags(&b->ev_fetch, hipEventDisableTiming));
+    b->attach_stop = (b->ext_events && !side_copy && !(b->prof_mask >> DLG_PROF_K3K8_NORM2JV & 1u)) ? b->ev_fetch : nullptr; b->stop_attached = false;   // ... and the event the host waits for
     const int rc8 = norm2_Jv(b, from, T.step, b->d_scal + 12, b->d_scal + 8);    // the other half of the expected improvement
+    b->attach_stop = nullptr;
     b->fold_scal = 0;
     const bool p_done = b->p_copied;
     b->fold_p_src = nullptr; b->p_copied = false;
@@ -1113,6 +1202,7 @@ extern "C" int dlg_run_steps(dlg_backend_t* b, int from, int to, int nsteps, int
 extern "C" int dlg_solve_with_factor(dlg_backend_t* b, int s, const double* rhs_host, double* out_host, int nrhs)
 {
   DLG_CHECK(check_slot(b, s));
+  DLG_CHECK(step_unprepare(b));
   if(!rhs_host || !out_host || nrhs < 0) { dlg_set_error("dlg_solve_with_factor: bad argument"); return DLG_ERR_ARG; }
   if(b->factor_slot != s) { dlg_set_error("dlg_solve_with_factor: no factorization of slot %d is held", s); return DLG_ERR_STATE; }
   double* d_out = nullptr;
@@ -1144,6 +1234,7 @@ static bool multi_ok(dlg_backend* b) { return b->type != DLG_SPARSE || sparse_mu
 extern "C" int dlg_solve_multi(dlg_backend_t* b, int s, const double* rhs_host, double* out_host, int nrhs)
 {
   DLG_CHECK(check_slot(b, s));
+  DLG_CHECK(step_unprepare(b));
   if(!rhs_host || !out_host || nrhs < 0) { dlg_set_error("dlg_solve_multi: bad argument"); return DLG_ERR_ARG; }
   if(b->factor_slot != s) { dlg_set_error("dlg_solve_multi: no factorization of slot %d is held", s); return DLG_ERR_STATE; }
   if(b->part_nranks > 1) { dlg_set_error("dlg_solve_multi is not available on a partitioned backend"); return DLG_ERR_STATE; }
@@ -1175,6 +1266,7 @@ extern "C" int dlg_solve_multi(dlg_backend_t* b, int s, const double* rhs_host, 
 extern "C" int dlg_pseudoinverse_chunk(dlg_backend_t* b, int s, int row0, int row1, double* out_host)
 {
   DLG_CHECK(check_slot(b, s));
+  DLG_CHECK(step_unprepare(b));
   if(!out_host || row0 < 0 || row1 < row0 || row1 > b->M) { dlg_set_error("dlg_pseudoinverse_chunk: bad row range"); return DLG_ERR_ARG; }
   if(b->type == DLG_DENSE_PRODUCTS) { dlg_set_error("dense-products keeps no Jacobian"); return DLG_ERR_STATE; }
   if(!b->slot[s].have_inputs) { dlg_set_error("dlg_pseudoinverse_chunk needs J (reference dogleg.c:1838-1842)"); return DLG_ERR_STATE; }

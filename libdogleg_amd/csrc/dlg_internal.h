@@ -1,6 +1,7 @@
 // dlg_internal.h -- shared declarations of the HIP backend (not installed).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -67,6 +68,8 @@ struct dlg_backend
   bool want_fork = false, fork_recorded = false, overlap = true;
   bool fuse_eval = true;      // ... in the pass that forms Jt*x where the schedule allows (DOGLEG_AMD_NO_FUSED_EVAL: second stream instead)
   bool speculate = false;     // dlg_backend_set_speculation: assemble JtJ beside Jt*x at every dlg_point_eval
+  bool presolve = false;      // ... and enqueue K5 + K6 behind it (step_prepare) for dlg_take_step to pick up
+  int  pre_slot = -1, pre_held = -1; double pre_lambda = 0.0;   // prepared slot; slot whose factor it displaced
   DlgSlot slot[2];
 
   // scalar return path: kernels write d_scal, one D2H into pinned h_scal
@@ -145,6 +148,7 @@ struct dlg_backend
 
   // optional per-phase timing with HIP events on b->stream (dlg_backend_set_profiling)
   bool profiling = false;
+  hipEvent_t attach_stop = nullptr; bool stop_attached = false, ext_events = true;      // DLG_LAUNCH_LAST
   unsigned prof_mask = 0;     // the phases that are timed (bit = DLG_PROF_*)
   struct ProfPair { hipEvent_t a, b; int id; };
   std::vector<ProfPair> prof_pending;
@@ -162,9 +166,21 @@ void dlg_prof_resolve(dlg_backend* b);
 struct DlgProfScope
 {
   dlg_backend* b; int id; hipEvent_t e;
-  DlgProfScope(dlg_backend* b_, int id_) : b(b_), id(id_), e((b_->prof_mask >> id_ & 1u) ? dlg_prof_begin(b_) : nullptr) {}
+  DlgProfScope(dlg_backend* b_, int id_, bool enable = true) : b(b_), id(id_), e((enable && (b_->prof_mask >> id_ & 1u)) ? dlg_prof_begin(b_) : nullptr) {}
   ~DlgProfScope() { if(e) dlg_prof_end(b, id, e); }
 };
+// One kernel as a timed phase: the two events ride on the launch itself (hipExtLaunchKernelGGL: the dispatch's own
+// start / end time stamps) -- no event records, i.e. no barrier packets and no idle microseconds, around it.
+bool dlg_prof_pair(dlg_backend* b, int id, hipEvent_t* e0, hipEvent_t* e1);
+#define DLG_LAUNCH_TIMED(b_, id_, kernel, grid, block, shm, st, ...) \
+  do { hipEvent_t dlg_e0 = nullptr, dlg_e1 = nullptr; \
+       if(dlg_prof_pair(b_, id_, &dlg_e0, &dlg_e1)) hipExtLaunchKernelGGL(kernel, grid, block, shm, st, dlg_e0, dlg_e1, 0, __VA_ARGS__); \
+       else hipLaunchKernelGGL(kernel, grid, block, shm, st, __VA_ARGS__); } while(0)
+// The event the host is going to wait for, attached to the last kernel of what it waits for (attach_stop set by the
+// caller around the launch; stop_attached: the launch took it): no record behind the kernel.
+#define DLG_LAUNCH_LAST(b_, kernel, grid, block, shm, st, ...) \
+  do { if((b_)->attach_stop) { hipExtLaunchKernelGGL(kernel, grid, block, shm, st, (hipEvent_t)nullptr, (b_)->attach_stop, 0, __VA_ARGS__); (b_)->stop_attached = true; } \
+       else hipLaunchKernelGGL(kernel, grid, block, shm, st, __VA_ARGS__); } while(0)
 
 // rows of the measurement vector owned by this rank
 static inline int dlg_mloc(const dlg_backend* b) { return b->mloc; }
@@ -275,6 +291,9 @@ int sparse_norm2_Jv(dlg_backend* b, int slot, const double* v, double* out_dev, 
 int sparse_factorize(dlg_backend* b, int slot, double lambda, int* ok);          // K4+K5
 bool sparse_factor_ok(const dlg_backend* b);     // pivot flag of the last factorisation (after a sync)
 int sparse_solve(dlg_backend* b, const double* rhs, double* out);                // K6
+void sparse_hold_factor(dlg_backend* b);
+int sparse_restore_factor(dlg_backend* b, bool* restored);
+double sparse_current_lambda(const dlg_backend* b);                                 // of the last factorisation enqueued
 // blocked multi-right-hand-side solves (sparse_multi.hip / kernels_dense.hip): MR = 16 right-hand sides
 // interleaved [N][MR] (element (variable k, rhs c) at k*MR + c), solved in place, original order
 int sparse_multi_width_ok(const dlg_backend* b);

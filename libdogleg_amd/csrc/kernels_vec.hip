@@ -379,7 +379,7 @@ int k_norm2_absmax_pair(dlg_backend* b, const double* x1, int n1, double* out1, 
     double* hp2 = hp1 ? dlg_host_partials(b, out2, g2, 1, 1, 1) : nullptr;
     if(hp1 && hp2)
     {
-      hipLaunchKernelGGL(k_part_norm2_absmax2, dim3(g1 + g2), dim3(TPB), 0, b->stream, x1, n1, hp1, g1, x2, n2, hp2);
+      DLG_LAUNCH_LAST(b, k_part_norm2_absmax2, dim3(g1 + g2), dim3(TPB), 0, b->stream, x1, n1, hp1, g1, x2, n2, hp2);
       DLG_LAUNCH_CHECK();
       if(on_host) *on_host = true;             // all four scalars are summed on the host (dlg_resolve_pending)
       return DLG_OK;

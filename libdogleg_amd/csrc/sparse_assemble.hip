@@ -928,10 +928,11 @@ int sparse_norm2_Jv(dlg_backend* b, int s, const double* v, double* out_dev, con
     if(double* hp = dlg_host_partials(b, out_dev, g, 1, 0, 1))
     {
       const bool fold = b->fold_scal > 0 && b->fold_scal <= TPB && b->h_scal;
-      hipLaunchKernelGGL(k_norm2_Jv, dim3(g), dim3(TPB), 0, b->stream, Y->nv_chunk, Y->Jp, Y->Ji, S.Jin(), v, hp,
-                         (const int*)Y->d_info, kind_if_factor_failed, (int)Y->nnz_loc,
-                         fold ? (const double*)b->d_scal : (const double*)nullptr, b->h_scal, b->fold_scal,
-                         fold ? b->fold_p_src : (const double*)nullptr, b->fold_p_dst, b->N);
+      if(!fold) b->attach_stop = nullptr;
+      DLG_LAUNCH_LAST(b, k_norm2_Jv, dim3(g), dim3(TPB), 0, b->stream, Y->nv_chunk, Y->Jp, Y->Ji, S.Jin(), v, hp,
+                      (const int*)Y->d_info, kind_if_factor_failed, (int)Y->nnz_loc,
+                      fold ? (const double*)b->d_scal : (const double*)nullptr, b->h_scal, (int)b->fold_scal,
+                      fold ? b->fold_p_src : (const double*)nullptr, b->fold_p_dst, (int)b->N);
       DLG_LAUNCH_CHECK();
       if(fold) { b->scal_copied = true; b->p_copied = b->fold_p_src != nullptr; }
       return DLG_OK;
@@ -971,6 +972,10 @@ int sparse_assemble_finish(dlg_backend* b)
   }
   return DLG_OK;
 }
+#define ASM_LAUNCH(kernel, grid, block, shm, st, ...) \
+  do { hipEvent_t e0 = nullptr, e1 = nullptr; \
+       if(timed_single && dlg_prof_pair(b, DLG_PROF_K4_KERNEL, &e0, &e1)) hipExtLaunchKernelGGL(kernel, grid, block, shm, st, e0, e1, 0, __VA_ARGS__); \
+       else { DlgProfScope pk1(b, DLG_PROF_K4_KERNEL, timed_single); hipLaunchKernelGGL(kernel, grid, block, shm, st, __VA_ARGS__); } } while(0)
 static int assemble_launch(dlg_backend* b, const double* Jv, double* Lx = nullptr, const double* xvec = nullptr, double* Jt_x = nullptr,
                            bool zeroed = false, bool defer_fin = false, const double* lf_rhs = nullptr, double lf_lambda = 0.0)
 {
@@ -1006,7 +1011,9 @@ static int assemble_launch(dlg_backend* b, const double* Jv, double* Lx = nullpt
   const int nt = (int)H.asm_ctask.size(), nmt = (int)H.asm_mtask.size();
   if(nt > 0 || nmt > 0)
   {
-    DlgProfScope pk(b, DLG_PROF_K4_KERNEL);
+    // (one kernel: its time stamps ride on the launch)
+    const bool timed_single = nmt > 0 && nt == 0;
+    DlgProfScope pk(b, DLG_PROF_K4_KERNEL, !timed_single);
     if(nmt > 0)
     {
       const int nruns = (int)H.asm_run.size();
@@ -1017,24 +1024,24 @@ static int assemble_launch(dlg_backend* b, const double* Jv, double* Lx = nullpt
       for(const AsmShape& sh : H.asm_shape) if(sh.ncopy > 15) xt = false;
       if(xt) xt = H.asm_td_inline;                  // ... and every k-group carries its transient destinations
       if(H.asm_lds_len == 18 && xvec && xt)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_assemble_mfma<18, true, true>), dim3(dlg_cdiv(nruns, TPB/64)), dim3(TPB),
+        ASM_LAUNCH((k_assemble_mfma<18, true, true>), dim3(dlg_cdiv(nruns, TPB/64)), dim3(TPB),
                            sizeof(double)*(TPB/64)*ASM_U*4*18, st, Y->asm_run, nruns, Y->asm_mtask,
                            Y->asm_kg, Y->asm_shape, Y->asm_tdest, Y->asm_pdest, Jv, Lx, Y->asm_part, 18, xvec, Y->jtp, Jt_x, only_shape);
       else if(H.asm_lds_len == 18 && xvec)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_assemble_mfma<18, true>), dim3(dlg_cdiv(nruns, TPB/64)), dim3(TPB),
+        ASM_LAUNCH((k_assemble_mfma<18, true>), dim3(dlg_cdiv(nruns, TPB/64)), dim3(TPB),
                            sizeof(double)*(TPB/64)*ASM_U*4*18, st, Y->asm_run, nruns, Y->asm_mtask,
                            Y->asm_kg, Y->asm_shape, Y->asm_tdest, Y->asm_pdest, Jv, Lx, Y->asm_part, 18, xvec, Y->jtp, Jt_x, only_shape);
       else if(xvec)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_assemble_mfma<0, true>), dim3(dlg_cdiv(nruns, TPB/64)), dim3(TPB),
+        ASM_LAUNCH((k_assemble_mfma<0, true>), dim3(dlg_cdiv(nruns, TPB/64)), dim3(TPB),
                            sizeof(double)*(TPB/64)*ASM_U*4*H.asm_lds_len, st, Y->asm_run, nruns, Y->asm_mtask,
                            Y->asm_kg, Y->asm_shape, Y->asm_tdest, Y->asm_pdest, Jv, Lx, Y->asm_part,
                            H.asm_lds_len, xvec, Y->jtp, Jt_x, only_shape);
       else if(H.asm_lds_len == 18)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_assemble_mfma<18, false>), dim3(dlg_cdiv(nruns, TPB/64)), dim3(TPB),
+        ASM_LAUNCH((k_assemble_mfma<18, false>), dim3(dlg_cdiv(nruns, TPB/64)), dim3(TPB),
                            sizeof(double)*(TPB/64)*ASM_U*4*18, st, Y->asm_run, nruns, Y->asm_mtask,
                            Y->asm_kg, Y->asm_shape, Y->asm_tdest, Y->asm_pdest, Jv, Lx, Y->asm_part, 18, nox, nojt, nojt, only_shape);
       else
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_assemble_mfma<0, false>), dim3(dlg_cdiv(nruns, TPB/64)), dim3(TPB),
+        ASM_LAUNCH((k_assemble_mfma<0, false>), dim3(dlg_cdiv(nruns, TPB/64)), dim3(TPB),
                            sizeof(double)*(TPB/64)*ASM_U*4*H.asm_lds_len, st, Y->asm_run, nruns, Y->asm_mtask,
                            Y->asm_kg, Y->asm_shape, Y->asm_tdest, Y->asm_pdest, Jv, Lx, Y->asm_part,
                            H.asm_lds_len, nox, nojt, nojt, only_shape);

@@ -453,6 +453,29 @@ int sparse_factorize(dlg_backend* b, int s, double lambda, int* ok)
   *ok = sparse_factor_ok(b);
   return DLG_OK;
 }
+double sparse_current_lambda(const dlg_backend* b) { return b->sym ? b->sym->cur_lambda : 0.0; }
+// A factorisation enqueued ahead of the caller's decision (backend.hip, step_prepare) takes the place of the held
+// one: the held panels stay in the other buffer (sparse_assemble swaps, the buffer is cleared only behind the
+// next step) and come back if the caller turns to the held factor after all (a rejected trial point).
+void sparse_hold_factor(dlg_backend* b)
+{
+  SparseSym* Y = b->sym;
+  Y->held_Lx = Y->Lx; Y->held_aug = Y->aug_rhs; Y->held_lambda = Y->cur_lambda;
+}
+int sparse_restore_factor(dlg_backend* b, bool* restored)
+{
+  SparseSym* Y = b->sym;
+  *restored = false;
+  if(!Y->held_Lx || Y->held_Lx != Y->Lx_spec) { Y->held_Lx = nullptr; return DLG_OK; }      // (assembled in place: gone)
+  std::swap(Y->Lx, Y->Lx_spec);
+  Y->spare_zeroed = false; Y->spare_dirty = true;                // the dropped factor: cleared behind the next step
+  Y->aug_rhs = Y->held_aug; Y->cur_lambda = Y->held_lambda; Y->held_Lx = nullptr;
+  static const int k_armed = 0x7fffffff;                         // (the held factor was a good one)
+  DLG_HIP(hipMemcpyAsync(Y->d_info, &k_armed, sizeof(int), hipMemcpyHostToDevice, b->stream));
+  Y->info_clean = false; Y->info_armed = false;
+  *restored = true;
+  return DLG_OK;
+}
 bool sparse_factor_ok(const dlg_backend* b) { return *b->sym->h_info == 0x7fffffff; }
 
 // host-only: run the symbolic phase on a pattern and report its statistics

@@ -120,6 +120,7 @@ struct SparseSym
   double* colmask = nullptr; int* sn_owner = nullptr;
   int64_t* augpos = nullptr;            // Lx offset of the augmented-row entry of every column
   int *xl_sn = nullptr;
+  double* held_Lx = nullptr; const double* held_aug = nullptr; double held_lambda = 0.0;   // sparse_hold_factor
   double cur_lambda = 0.0;              // of the factorisation being enqueued (the top panels get it after the sum)
   double *ms_scr = nullptr, *ms_y = nullptr; int ms_lds_f = 0, ms_lds_b = 0;     // multi-right-hand-side solves (sparse_multi.hip)
   // speculative assembly beside K1 (sparse_assemble_speculative): second panel buffer, its state

@@ -583,3 +583,74 @@ def test_premultiplied_block_sweep_agrees_to_rounding(gpu, shape, monkeypatch):
         be.close()
     assert res["premul"][0] == res["premul-again"][0] and np.array_equal(res["premul"][1], res["premul-again"][1])
     assert np.max(np.abs(res["premul"][1] - res["plain"][1])) <= 1e-12*max(1.0, np.max(np.abs(res["plain"][1])))
+
+
+@pytest.mark.parametrize("lf", [False, True])
+def test_factor_and_solve_ahead_of_the_decision_change_no_bit(gpu, lf, monkeypatch):
+    """dlg_point_eval (one-pass form) enqueues the factorisation and the Gauss-Newton solve of the point it
+    evaluated; dlg_take_step from that point picks them up.  A step from the OTHER point (the trial point was
+    rejected) gets the displaced factor back, and so does every other user of the held factor.  All numbers
+    as without (DOGLEG_AMD_NO_PRESOLVE), bit for bit."""
+    if lf:
+        monkeypatch.setenv("DOGLEG_AMD_LEAF_FRONT", "1")
+    prob = oa.BAProblem(49, 900, 10000, seed=5)
+    Jp, Ji = prob.pattern()
+    pA = prob.p0()
+    xA, JA = prob.eval(pA)
+
+    def run(script):
+        be = capi.Backend(capi.DLG_SPARSE, prob.N, prob.M, prob.nnz)
+        be.set_pattern(Jp, Ji)
+        be.set_speculation(True)
+        be.set_p(0, pA)
+        be.upload(0, xA, JA)
+        be.eval(0)
+        lam, n2c, n2g = be.cauchy_gauss_newton(0, 0.0)
+        tr = 0.7 * np.sqrt(n2g)
+        be.upload(0, xA, JA)
+        be.eval(0)                                         # (prepared: nothing was held)
+        lam, r, pB = be.take_step(0, 1, tr, 0.0)           # A -> B, picks the prepared work up
+        res = [tuple(sorted(r.items())), pB.copy()]
+        xB, JB = prob.eval(pB)
+        be.upload(1, xB, JB)
+        be.eval(1)                                         # prepared: B; A's factor displaced
+        if script == "accept":
+            lam, r, pC = be.take_step(1, 0, tr, 0.0)
+            res += [tuple(sorted(r.items())), pC.copy(), be.download(1, capi.VEC_GN)]
+        elif script == "reject":
+            lam, r, pB2 = be.take_step(0, 1, 0.25 * tr, 0.0)      # from A again, smaller trust region
+            res += [tuple(sorted(r.items())), pB2.copy()]
+            xB2, JB2 = prob.eval(pB2)
+            be.upload(1, xB2, JB2)
+            be.eval(1)
+            lam, r, pC = be.take_step(1, 0, tr, 0.0)
+            res += [tuple(sorted(r.items())), pC.copy()]
+        elif script == "held":
+            rhs = np.linspace(-1.0, 1.0, prob.N)
+            res += [be.solve_with_factor(0, rhs)]          # A's factor is still the held one
+            lam, r, pC = be.take_step(1, 0, tr, 0.0)       # B: factorised in line now
+            res += [tuple(sorted(r.items())), pC.copy()]
+        elif script == "lambda":
+            lam, r, pC = be.take_step(1, 0, tr, 1e-3)      # another lambda than the prepared one
+            res += [lam, tuple(sorted(r.items())), pC.copy()]
+            be.upload(1, xB, JB)
+            be.eval(1)                                     # prepared at 1e-3 now
+            lam, r, pC = be.take_step(1, 0, tr, 1e-3)
+            res += [lam, tuple(sorted(r.items())), pC.copy()]
+        be.close()
+        return res
+
+    def same(a, b):
+        if isinstance(a, np.ndarray):
+            return np.array_equal(a, b)
+        if isinstance(a, tuple):
+            return all(ka == kb and (va == vb or (va != va and vb != vb)) for (ka, va), (kb, vb) in zip(a, b))
+        return a == b
+    for script in ("accept", "reject", "held", "lambda"):
+        monkeypatch.delenv("DOGLEG_AMD_NO_PRESOLVE", raising=False)
+        got = run(script)
+        monkeypatch.setenv("DOGLEG_AMD_NO_PRESOLVE", "1")
+        want = run(script)
+        assert len(got) == len(want)
+        for i, (a, b) in enumerate(zip(got, want)):
+            assert same(a, b), (script, i)

@@ -8,7 +8,8 @@ def short(n):
     return n.split('(')[0][:34]
 # steps delimited by the assembly kernel
 idx = [i for i, r in enumerate(rows) if 'k_assemble_mfma' in r['Kernel_Name'] or 'k_leaf_front' in r['Kernel_Name']]
-a, b = idx[-3], idx[-2]
+k = int(sys.argv[2]) if len(sys.argv) > 2 else -3
+a, b = idx[k], idx[k+1]
 seg = rows[a:b]
 # keep the stream (queue) of the assembly kernel
 q = seg[0].get('Queue_Id') or seg[0].get('Stream_Id')
