@@ -261,7 +261,7 @@ extern "C" int dlg_backend_reset(dlg_backend_t* b)
     // (step_to_here of the first point of a solve is read by nobody, but a returned context downloads it)
     DLG_HIP(hipMemsetAsync(S.step, 0, sizeof(double)*(size_t)b->N, b->stream));
   }
-  b->factor_slot = -1; b->speculate = false; b->presolve = false; b->pre_slot = -1; b->pre_held = -1;
+  b->factor_slot = -1; b->speculate = false; b->presolve = false; b->pre_slot = -1; b->pre_held = -1; b->pre_hint_valid = false; b->pre_hint_input = false;
   b->want_fork = b->fork_recorded = false; b->fork_gate = nullptr;
   b->fold_scalar = b->fold_result = nullptr; b->fold_cauchy_out = nullptr;
   b->fold_p_src = nullptr; b->p_copied = false; b->scal_copied = false; b->fold_scal = 0;
@@ -543,7 +543,9 @@ static int step_unprepare(dlg_backend* b)
 static int step_prepare(dlg_backend* b, int s)
 {
   DlgSlot& S = b->slot[s];
-  const double lam = sparse_current_lambda(b);
+  // the lambda the next step is expected to ask for: the one the last step ended with (the reference's lambda is
+  // sticky, dogleg.c:138, 671-672) -- or, for a caller that was seen to start over from its own value, the one it passed
+  const double lam = b->pre_hint_valid ? b->pre_hint : sparse_current_lambda(b);
   b->pre_held = (b->factor_slot >= 0 && b->factor_slot != s) ? b->factor_slot : -1;
   sparse_hold_factor(b);
   b->factor_slot = -1;
@@ -1053,6 +1055,8 @@ extern "C" int dlg_take_step(dlg_backend_t* b, int from, int to, double trustreg
   bool side_copy = false;
   // (the factorisation and the solve enqueued by dlg_point_eval -- step_prepare -- are this step's if the
   // lambda is the one they were formed at; they are used once)
+  const double lam_in = lam;
+  if(b->pre_slot == from && b->pre_lambda != lam) b->pre_hint_input = true;      // (the guess was wrong: this caller does not keep lambda)
   const bool prepared_here = b->pre_slot == from && b->pre_lambda == lam;
   if(prepared_here) { b->pre_slot = -1; b->pre_held = -1; } else DLG_CHECK(step_unprepare(b));
   bool prepared = prepared_here;
@@ -1158,6 +1162,7 @@ extern "C" int dlg_take_step(dlg_backend_t* b, int from, int to, double trustreg
   F.norm2_gn = b->h_scal[10];
   F.have_gn = true;
   *lambda_io = lam;
+  b->pre_hint = b->pre_hint_input ? lam_in : lam; b->pre_hint_valid = true;
   const int kind = (int)b->h_scal[8];
   out7[0] = F.norm2_cauchy; out7[1] = F.norm2_gn; out7[2] = (double)kind;
   out7[3] = (kind == DLG_KIND_CAUCHY_TO_EDGE) ? F.norm2_cauchy : (kind == DLG_KIND_GAUSSNEWTON ? F.norm2_gn : b->h_scal[0]);

@@ -69,7 +69,7 @@ struct dlg_backend
   bool fuse_eval = true;      // ... in the pass that forms Jt*x where the schedule allows (DOGLEG_AMD_NO_FUSED_EVAL: second stream instead)
   bool speculate = false;     // dlg_backend_set_speculation: assemble JtJ beside Jt*x at every dlg_point_eval
   bool presolve = false;      // ... and enqueue K5 + K6 behind it (step_prepare) for dlg_take_step to pick up
-  int  pre_slot = -1, pre_held = -1; double pre_lambda = 0.0;   // prepared slot; slot whose factor it displaced
+  int  pre_slot = -1, pre_held = -1; double pre_lambda = 0.0, pre_hint = 0.0; bool pre_hint_valid = false, pre_hint_input = false;   // prepared slot; slot whose factor it displaced
   DlgSlot slot[2];
 
   // scalar return path: kernels write d_scal, one D2H into pinned h_scal

@@ -397,7 +397,12 @@ __device__ __forceinline__ void panel_factor_mfma(double* P, int ldp, int nrows,
 constexpr int PF_AHEAD_MAXW = 128;
 __device__ __forceinline__ void pf_wait(int* flag, int need)
 {
+#ifdef DLG_PF_BOUNDED_WAIT      // tools/micro: a protocol error shows as wrong numbers, not as a hung GPU
+  int spins = 0;
+  while(__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < need && ++spins < (1 << 20)) __builtin_amdgcn_s_sleep(1);
+#else
   while(__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < need) __builtin_amdgcn_s_sleep(1);
+#endif
 }
 // order the LDS traffic of ONE wave across a hand-over between its lanes (no instruction: LDS
 // operations of a wave are executed in order; this only stops the compiler from moving them)
@@ -552,6 +557,254 @@ __device__ __forceinline__ void panel_factor_ahead(double* P, int ldp, int nrows
           if(r < nrows) pf_solve_row(P, ldp, r, kb, nb, D, Dinv);
         }
         pf_wave_sync();
+      }
+    }
+  }
+  __syncthreads();
+  DLG_PF_DONE
+}
+// ---- panel factorisation by blocks of 16 columns, the diagonal tile in registers (LDS panels, NT >= 256) -------
+// The sweeps above pay, per 8 columns, a chain of dependent steps that each cross LDS: tile update -> block load ->
+// 8x8 factorisation in every lane -> write-back -> barrier -> row solves -> barrier (about 6.2k clocks on a 100 x 66
+// panel, tools/micro/bench_panel).  Here wave 0 keeps the 16 x 16 diagonal tile T in the accumulators of
+// v_mfma_f64_16x16x4 and never leaves its registers inside a block:
+//   * T is symmetric, so register s of the tile (rows 4s .. 4s + 3 in the C/D layout) is at the same time
+//     "lane (j, k) = T[j][4s + k]", the A/B operand layout of the four columns 4s .. 4s + 3;
+//   * step s: the 4 x 4 pivot block comes out of the tile by v_readlane, is factored and inverted in uniform
+//     registers (M = D^-1, 4 reciprocal square roots in a row -- the only serial part);
+//   * X' = M * src'  -- ONE MFMA with M (padded) as A and the source register as B -- leaves the four finished
+//     columns of L for all 16 rows of the tile in register 0 of the result, again in the operand layout;
+//   * T -= X X'  (one MFMA, both operands that register) brings the remaining columns up to date;
+//   * the rows of L_JJ^-1 fall out the same way from an identity tile that rides along (two more MFMAs, off the chain)
+//     and are published in LDS.
+// The other waves own the row tiles below (tile t -> wave 1 + (t - 1) mod (NW - 1)): per block they bring their tile
+// up to date against all columns before the block (left-looking, as in the sweeps above, but TRANSPOSED so that the
+// accumulators are at once the B operands of the next product), wait for L_JJ^-1 and multiply with it: four MFMAs, no
+// row-by-row substitution.  Hand-offs are LDS words (wdone: blocks whose inverse is published; tdone[t]: blocks row
+// tile t has finished), no workgroup barrier inside the sweep.  The diagonal tile of the next block belongs to the
+// wave that finishes first in every block (the tiles are taken in increasing order).
+constexpr int PF_B16_WS = 17;          // row stride of the published inverse (doubles; 16 would put a column on one bank)
+constexpr int PF_B16_MAXT = 32;        // row tiles: nrows <= 512
+// W: L_JJ^-1 of the last two blocks; A / E: the NEXT diagonal tile's rows, brought up to date by their wave and handed
+// to wave 0 (A: the 16 columns of the current block, transposed; E: the diagonal tile itself against all columns before
+// the block); wdone / adone / tdone: the hand-off words
+struct pf_b16_lds { double W[2][16*PF_B16_WS]; double A[4*64]; double E[4*64]; int wdone; int adone; int tdone[PF_B16_MAXT]; };
+
+__device__ __forceinline__ double pf_readlane64(double v, int l)
+{
+  const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)u, l), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u >> 32), l);
+  return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+// the diagonal tile of the block at kb (nb columns) as the panel holds it: both triangles from the lower one, identity
+// where the block is short; register r, lane (n, kq) = T[kq + 4 r][n]
+__device__ __forceinline__ dlg_pf_v4d pf_b16_diag_tile(const double* P, int ldp, int kb, int nb, int mm, int kq)
+{
+  dlg_pf_v4d U;
+#pragma unroll
+  for(int r = 0; r < 4; r++)
+  {
+    const int row = kq + 4*r, hi = max(row, mm), lo = min(row, mm);
+    const bool valid = hi < nb;
+    const double v = P[(kb + (valid ? hi : 0)) + (kb + (valid ? lo : 0))*ldp];
+    U[r] = valid ? v : (row == mm ? 1.0 : 0.0);
+  }
+  return U;
+}
+template <int NT>
+__device__ __forceinline__ void panel_factor_b16(double* P, int ldp, int nrows, int w, int tid,
+                                                 int* __restrict__ info, int col0)
+{
+  static_assert(NT >= 256, "panel_factor_b16 needs at least 4 waves");
+  // (with 8 waves, wave 4 shares its SIMD with wave 0: an fp64 MFMA holds the SIMD for its 64 clocks, so that wave
+  // takes no tiles -- wave 0's chain has SIMD 0 to itself)
+  constexpr int NW = NT/64, NH = (NW == 8) ? 6 : NW - 1;
+  __shared__ pf_b16_lds S;
+  const int lane = tid & 63, wv = tid >> 6;
+  const int mm = lane & 15, kq = lane >> 4;
+  const int ntr = (nrows + 15) >> 4, nblk = (w + 15) >> 4;
+  if(tid == 0) { S.wdone = 0; S.adone = 0; }
+  if(tid < PF_B16_MAXT) S.tdone[tid] = 0;
+  __syncthreads();
+  DLG_PF_DECL
+  const dlg_pf_v4d zero4 = {0.0, 0.0, 0.0, 0.0};
+  if(wv == 0)
+  {
+    int bad = 0x7fffffff;
+    dlg_pf_v4d U = pf_b16_diag_tile(P, ldp, 0, min(16, w), mm, kq);
+    for(int J = 0; J < nblk; J++)
+    {
+      const int kb = 16*J, nb = min(16, w - kb);
+      dlg_pf_v4d G;
+#pragma unroll
+      for(int r = 0; r < 4; r++) G[r] = (kq + 4*r == mm) ? 1.0 : 0.0;
+      if(J >= 2)
+      {
+        // the buffer of the inverse published two blocks ago is written again: every tile must be done with it
+        for(int spins = 0; spins < (1 << 20); spins++)          // (bounded: a wave that never reports shows as a wrong factor)
+        {
+          const bool mine = lane < ntr && lane > J - 2;
+          const int v = mine ? __hip_atomic_load(&S.tdone[mine ? lane : 0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) : 0x7fffffff;
+          if(__all(v >= J - 1)) break;
+          __builtin_amdgcn_s_sleep(1);
+        }
+      }
+      DLG_PF_STAMP(0);
+      double* Wb = S.W[J & 1];
+#pragma unroll
+      for(int s = 0; s < 4; s++)
+      {
+        if(4*s >= nb)
+        {
+          Wb[(4*s + kq)*PF_B16_WS + mm] = (4*s + kq == mm) ? 1.0 : 0.0;
+          continue;
+        }
+        const double src = U[s];
+        // the 4 x 4 pivot block: T[4s + q][4s + k] sits in lane (j = 4s + q, k) = 16 k + 4 s + q
+        const double a00 = pf_readlane64(src, 4*s), a10 = pf_readlane64(src, 4*s + 1), a20 = pf_readlane64(src, 4*s + 2), a30 = pf_readlane64(src, 4*s + 3);
+        const double a11 = pf_readlane64(src, 16 + 4*s + 1), a21 = pf_readlane64(src, 16 + 4*s + 2), a31 = pf_readlane64(src, 16 + 4*s + 3);
+        const double a22 = pf_readlane64(src, 32 + 4*s + 2), a32 = pf_readlane64(src, 32 + 4*s + 3), a33 = pf_readlane64(src, 48 + 4*s + 3);
+        double d0 = a00; if(!(d0 > 0.0)) { bad = min(bad, kb + 4*s); d0 = 1.0; }
+        const double i0 = dlg_rsqrt(d0);
+        const double l10 = a10*i0, l20 = a20*i0, l30 = a30*i0;
+        double d1 = a11 - l10*l10; if(!(d1 > 0.0)) { bad = min(bad, kb + 4*s + 1); d1 = 1.0; }
+        const double i1 = dlg_rsqrt(d1);
+        const double l21 = (a21 - l20*l10)*i1, l31 = (a31 - l30*l10)*i1;
+        double d2 = a22 - l20*l20 - l21*l21; if(!(d2 > 0.0)) { bad = min(bad, kb + 4*s + 2); d2 = 1.0; }
+        const double i2 = dlg_rsqrt(d2);
+        const double l32 = (a32 - l30*l20 - l31*l21)*i2;
+        double d3 = a33 - l30*l30 - l31*l31 - l32*l32; if(!(d3 > 0.0)) { bad = min(bad, kb + 4*s + 3); d3 = 1.0; }
+        const double i3 = dlg_rsqrt(d3);
+        // M = D^-1 (lower)
+        const double m10 = -(l10*i0)*i1, m21 = -(l21*i1)*i2, m32 = -(l32*i2)*i3;
+        const double m20 = -(l20*i0 + l21*m10)*i2, m31 = -(l31*i1 + l32*m21)*i3;
+        const double m30 = -(l30*i0 + l31*m10 + l32*m20)*i3;
+        // A operand: lane (i, k) = M[i][k] (rows 4 .. 15 of the operand are zero)
+        double aop = 0.0;
+        aop = (lane == 0) ? i0 : aop;   aop = (lane == 1) ? m10 : aop;  aop = (lane == 2) ? m20 : aop;  aop = (lane == 3) ? m30 : aop;
+        aop = (lane == 17) ? i1 : aop;  aop = (lane == 18) ? m21 : aop; aop = (lane == 19) ? m31 : aop;
+        aop = (lane == 34) ? i2 : aop;  aop = (lane == 35) ? m32 : aop; aop = (lane == 51) ? i3 : aop;
+        const dlg_pf_v4d Xv = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, src, zero4, 0, 0, 0);
+        const double X0 = Xv[0];                    // lane (j, k) = L[kb + j][kb + 4s + k]
+        if(s < 3) U = __builtin_amdgcn_mfma_f64_16x16x4f64(X0, -X0, U, 0, 0, 0);
+        if(mm >= 4*s + kq && mm < nb && 4*s + kq < nb) P[(kb + mm) + (kb + 4*s + kq)*ldp] = X0;
+        // the rows 4s .. 4s + 3 of L_JJ^-1 from the identity tile
+        const dlg_pf_v4d Wv = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, G[s], zero4, 0, 0, 0);
+        const double W0 = Wv[0];                    // lane (j, k) = W[4s + k][j]
+        Wb[(4*s + kq)*PF_B16_WS + mm] = W0;
+        if(s < 3) G = __builtin_amdgcn_mfma_f64_16x16x4f64(X0, -W0, G, 0, 0, 0);
+      }
+      pf_wave_sync();
+      if(lane == 0) __hip_atomic_store(&S.wdone, J + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+      DLG_PF_STAMP(1);
+      if(J + 1 < nblk)
+      {
+        // the next diagonal tile: its rows in the columns of this block times L_JJ^-T, here, in registers -- the
+        // product IS the operand of the tile's own update
+        const int r1 = kb + 16, nb1 = min(16, w - r1);
+        const double* Wr = Wb + mm*PF_B16_WS + kq;
+        const double w0 = Wr[0], w1 = Wr[4], w2 = Wr[8], w3 = Wr[12];
+        pf_wait(&S.adone, J + 1);
+        DLG_PF_STAMP(3);
+        const double s0 = S.A[lane], s1 = S.A[64 + lane], s2 = S.A[128 + lane], s3 = S.A[192 + lane];
+#pragma unroll
+        for(int r = 0; r < 4; r++) U[r] = S.E[64*r + lane];
+        dlg_pf_v4d y0 = __builtin_amdgcn_mfma_f64_16x16x4f64(w0, s0, zero4, 0, 0, 0);
+        dlg_pf_v4d y1 = __builtin_amdgcn_mfma_f64_16x16x4f64(w2, s2, zero4, 0, 0, 0);
+        y0 = __builtin_amdgcn_mfma_f64_16x16x4f64(w1, s1, y0, 0, 0, 0);
+        y1 = __builtin_amdgcn_mfma_f64_16x16x4f64(w3, s3, y1, 0, 0, 0);
+        double yv[4];
+#pragma unroll
+        for(int r = 0; r < 4; r++)
+        {
+          yv[r] = y0[r] + y1[r];                  // lane (n, kq) = L[r1 + n][kb + 4 r + kq]
+          if(r1 + mm < nrows) P[(r1 + mm) + (kb + kq + 4*r)*ldp] = yv[r];
+          yv[r] = (mm < nb1) ? yv[r] : 0.0;       // (rows below the top block are not part of the next diagonal tile)
+        }
+        dlg_pf_v4d U2 = __builtin_amdgcn_mfma_f64_16x16x4f64(yv[2], -yv[2], zero4, 0, 0, 0);
+        U = __builtin_amdgcn_mfma_f64_16x16x4f64(yv[0], -yv[0], U, 0, 0, 0);
+        U2 = __builtin_amdgcn_mfma_f64_16x16x4f64(yv[3], -yv[3], U2, 0, 0, 0);
+        U = __builtin_amdgcn_mfma_f64_16x16x4f64(yv[1], -yv[1], U, 0, 0, 0);
+        U += U2;
+        pf_wave_sync();
+        if(lane == 0) __hip_atomic_store(&S.tdone[J + 1], J + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+      DLG_PF_STAMP(2);
+    }
+    if(bad != 0x7fffffff && lane == 0) atomicMin(info, col0 + bad);
+  }
+  else if(!(NW == 8 && wv == 4))
+  {
+    const int h = (NW == 8 && wv > 4) ? wv - 2 : wv - 1;
+    for(int J = 0; J < nblk; J++)
+    {
+      const int kb = 16*J, nb = min(16, w - kb);
+      for(int t = (h + 1) % NH; t < ntr; t += NH)
+      {
+        // tiles below the block; in a short (last) block also the rows of the block's own tile below the top block
+        const bool own = t == J && nb < 16 && nrows > kb + nb;
+        if(t < J || (t == J && !own)) continue;
+        const bool next = t == J + 1 && J + 1 < nblk;        // the next diagonal tile: wave 0 finishes it
+        const int r0 = 16*t, rowc = min(r0 + mm, nrows - 1);
+        const int nb1 = min(16, w - r0);
+        // the tile TRANSPOSED: register r, lane (n, kq) = S[r0 + n][kb + kq + 4 r]
+        dlg_pf_v4d acc, E = zero4;
+#pragma unroll
+        for(int r = 0; r < 4; r++)
+        {
+          const int col = kq + 4*r;
+          const double v = P[rowc + (kb + (col < nb ? col : 0))*ldp];
+          acc[r] = (col < nb) ? v : 0.0;
+        }
+        if(next) E = pf_b16_diag_tile(P, ldp, r0, nb1, mm, kq);
+        if(J > 0)
+        {
+          pf_wait(&S.tdone[J], J);
+          const double* ap = P + kb + (mm < nb ? mm : 0) + kq*ldp;        // rows of the diagonal tile
+          const double* bp = P + rowc + kq*ldp;                           // rows of this tile
+          double a0 = ap[0], b0 = bp[0], a1 = ap[4*ldp], b1 = bp[4*ldp];
+          for(int k0 = 0; k0 < kb; k0 += 8)
+          {
+            const int kn = (k0 + 8 < kb) ? k0 + 8 : k0;
+            const double na0 = ap[kn*ldp], nb0 = bp[kn*ldp], na1 = ap[(kn + 4)*ldp], nb1v = bp[(kn + 4)*ldp];
+            __builtin_amdgcn_sched_barrier(0);
+            const double va0 = (mm < nb) ? -a0 : 0.0, va1 = (mm < nb) ? -a1 : 0.0;
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(va0, b0, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(va1, b1, acc, 0, 0, 0);
+            if(next)
+            {
+              const double e0 = (mm < nb1) ? b0 : 0.0, e1 = (mm < nb1) ? b1 : 0.0;
+              E = __builtin_amdgcn_mfma_f64_16x16x4f64(e0, -e0, E, 0, 0, 0);
+              E = __builtin_amdgcn_mfma_f64_16x16x4f64(e1, -e1, E, 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            a0 = na0; b0 = nb0; a1 = na1; b1 = nb1v;
+          }
+        }
+        if(next)
+        {
+#pragma unroll
+          for(int r = 0; r < 4; r++) { S.A[64*r + lane] = acc[r]; S.E[64*r + lane] = E[r]; }
+          pf_wave_sync();
+          if(lane == 0) __hip_atomic_store(&S.adone, J + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+          continue;
+        }
+        // times L_JJ^-T: Y'[i][j] = sum_c W[i][c] S[r0 + j][kb + c]
+        pf_wait(&S.wdone, J + 1);
+        const double* Wr = S.W[J & 1] + mm*PF_B16_WS + kq;
+        const double w0 = Wr[0], w1 = Wr[4], w2 = Wr[8], w3 = Wr[12];
+        dlg_pf_v4d y0 = __builtin_amdgcn_mfma_f64_16x16x4f64(w0, acc[0], zero4, 0, 0, 0);
+        dlg_pf_v4d y1 = __builtin_amdgcn_mfma_f64_16x16x4f64(w2, acc[2], zero4, 0, 0, 0);
+        y0 = __builtin_amdgcn_mfma_f64_16x16x4f64(w1, acc[1], y0, 0, 0, 0);
+        y1 = __builtin_amdgcn_mfma_f64_16x16x4f64(w3, acc[3], y1, 0, 0, 0);
+#pragma unroll
+        for(int r = 0; r < 4; r++)
+        {
+          const int col = kq + 4*r;
+          if(r0 + mm < nrows && col < nb && (!own || r0 + mm >= kb + nb)) P[(r0 + mm) + (kb + col)*ldp] = y0[r] + y1[r];
+        }
+        pf_wave_sync();
+        if(lane == 0 && !own) __hip_atomic_store(&S.tdone[t], J + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
       }
     }
   }

@@ -271,6 +271,8 @@ __global__ void __launch_bounds__(NT, LEAF ? 4 : 1) k_factor_level(const FwItem*
 #endif
   const bool stage_leaf_u = (mode & 4) != 0;    // childless supernodes may stage U in LDS too (host: no occupancy loss)
   const bool ahead = (mode & 8) != 0;           // panel_factor_ahead (barrier-free sweep) where the top block allows it
+  const bool b16 = (mode & 16) != 0;            // panel_factor_b16 (blocks of 16, the diagonal tile in registers)
+  const int b16_maxw = (mode >> 5) & 7 ? 64*((mode >> 5) & 7) : 1 << 20;      // ... for top blocks up to this width (tools: DOGLEG_AMD_B16_MAXW)
   mode &= 3;
   const FwItem it = items[blockIdx.x];
   const int r0 = it.r0, w = it.w, nrows = it.nrows;
@@ -364,6 +366,7 @@ __global__ void __launch_bounds__(NT, LEAF ? 4 : 1) k_factor_level(const FwItem*
   if(cmp) bd_compact_rows<NT, DS>(Pb, ldp, nloc, w, tid, it.nbd, s_mcol, s_rdiag, Dg);
   else if(LEAF) { }
   else if(it.nbd > 0) panel_factor_blockdiag<NT>(P, ldp, nloc, w, tid, sn_bd_col + it.bd0, it.nbd, &sbad, it.col0, s_mcol, s_rdiag);
+  else if(NT >= 256 && b16 && nloc <= 16*PF_B16_MAXT && w <= b16_maxw) panel_factor_b16<(NT >= 256 ? NT : 256)>(P, ldp, nloc, w, tid, &sbad, it.col0);
   else if(NT >= 256 && ahead && w <= PF_AHEAD_MAXW) panel_factor_ahead<(NT >= 256 ? NT : 256)>(P, ldp, nloc, w, tid, &sbad, it.col0, s_rdiag, s_mcol);
   else if(NT >= 256) panel_factor_mfma<(NT >= 256 ? NT : 256)>(P, ldp, nloc, w, tid, &sbad, it.col0);
   else         panel_factor<NT, true, true>(P, ldp, nloc, w, tid, &sbad, it.col0);
@@ -1017,6 +1020,8 @@ int sparse_factor_setup(dlg_backend* b, bool plan_only)
   SparseSym* Y = b->sym;
   const SymHost& H = Y->H;
   Y->fac_ahead = getenv("DOGLEG_AMD_AHEAD") != nullptr;
+  Y->fac_b16 = getenv("DOGLEG_AMD_NO_B16") == nullptr;
+  Y->fac_b16_maxw = getenv("DOGLEG_AMD_B16_MAXW") ? atoi(getenv("DOGLEG_AMD_B16_MAXW"))/64 & 7 : 0;
   Y->fac_lds.assign(H.nlevels, 0); Y->fac_nt.assign(H.nlevels, 512); Y->upd_coop.assign(H.nlevels, 0);
   Y->upd_lds.assign(H.nlevels, 0); Y->upd_nw.assign(H.nlevels, 0);
   Y->syrk_lds.assign(H.nlevels, 0); Y->syrk_nt.assign(H.nlevels, 256); Y->syrk_kc.assign(H.nlevels, 4);
@@ -1420,7 +1425,7 @@ int sparse_factor_levels(dlg_backend* b)
     {
       // the persistent top region: every remaining level in one launch (sparse_factor_setup)
       const int np = Y->pr_nwg;           // the region's own work items (replicas) and children records
-      const int fmode = 2 + 4*Y->pr_stage + (Y->fac_ahead ? 8 : 0) + 256*l;
+      const int fmode = 2 + 4*Y->pr_stage + (Y->fac_ahead ? 8 : 0) + (Y->fac_b16 ? 16 + 32*Y->fac_b16_maxw : 0) + 256*l;
       int* fl = Y->fac_flag; const int ep = ++Y->fac_epoch;
       if(gate_here && l > 0 && n < 256) dlg_fork_gate(b, fl + np, ep);
       const int64_t pacc = Y->pr_acc ? (int64_t)(Y->pr_acc - Y->uscr) : 0;
@@ -1442,7 +1447,7 @@ int sparse_factor_levels(dlg_backend* b)
     if(n > 0 && !(l == 0 && Y->lf_on))      // (leaf fronts: level 0 was factored with the assembly, sparse_leaf.hip)
     {
       const int o = H.fw_lvl_ptr[l];
-      const int use_ahead = Y->fac_ahead ? 8 : 0;     // barrier-free sweep: measured slower (tools/micro/bench_ahead), kept for experiments
+      const int use_ahead = (Y->fac_ahead ? 8 : 0) + (Y->fac_b16 ? 16 + 32*Y->fac_b16_maxw : 0);     // barrier-free sweep: measured slower (tools/micro/bench_ahead), kept for experiments
       const int fmode = ((l >= H.mf_level0) ? 2 : Y->syrk_fused[l]) + 4*Y->fac_stage[l] + use_ahead + 256*l;
       if(Y->fac_nt[l] == 128)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_factor_level<128>), dim3(n), dim3(128), Y->fac_lds[l], st,

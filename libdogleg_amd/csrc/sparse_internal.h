@@ -134,6 +134,8 @@ struct SparseSym
   int* fac_flag = nullptr; int fac_epoch = 0;   // one flag per workgroup of the region: the epoch of the launch that finished it
   FwItem* pr_item = nullptr; MfChild* pr_rec = nullptr; uint16_t* pr_dst = nullptr; int pr_nwg = 0;
   std::vector<FwItem> pr_item_h; std::vector<MfChild> pr_rec_h; std::vector<uint16_t> pr_dst_h;   // ... on the host (plan-only set-up: dlg_sparse_region_probe)   // the region's work items (supernode x replica) and its copy of the children records
+  int fac_b16_maxw = 0;
+  bool fac_b16 = false;         // panel_factor_b16 (DOGLEG_AMD_B16)
   bool fac_ahead = false;       // panel_factor_ahead instead of panel_factor_mfma (DOGLEG_AMD_AHEAD)
   // leaf fronts (sparse_leaf.hip): assembly + Jt*x + the leaves' factorisation in one kernel
   bool lf_on = false;

@@ -28,7 +28,7 @@ int env_int(const char* name, int dflt)
 }
 // doubles: a row slice (top block + its rows) of a larger panel; as much of the 160 KB LDS as a
 // single workgroup can get, so that fewer slices repeat the factorisation of the top block
-static int slice_cap() { return env_int("DOGLEG_AMD_SLICE_CAP", 20000); }
+static int slice_cap() { return env_int("DOGLEG_AMD_SLICE_CAP", SYM_FAC_LDS_BUDGET/8 - 40); }
 
 struct RowBlock { int r0, nrows, len, base, vptr, nvb; bool local; int lbase, lr0; };   // lbase / lr0: first value / first row in the rank-local arrays
 

@@ -148,7 +148,7 @@ static_assert(sizeof(AsmFin2) == 24, "AsmFin2 layout");
 struct SymTask { int32_t blk, c0, c1, part, var0, nI; };   // var0 / nI: copied from the out-block (one dependent load less)
 
 // LDS bytes a factor workgroup may use: (almost) all 160 KB of a CU, the rest is its static LDS
-constexpr int SYM_FAC_LDS_BUDGET = 163840 - 3584;
+constexpr int SYM_FAC_LDS_BUDGET = 163840 - 3584 - 8704;      // (static LDS of the factor kernel: its own words + panel_factor_b16's hand-off buffers)
 
 // Where the update matrix W (mb x mb, packed lower triangle) of an unsliced supernode lives while its
 // factor workgroup runs: behind the panel in LDS if both fit; else its last columns move into the

@@ -336,7 +336,10 @@ def test_take_step_matches_the_separate_calls(gpu, kind, which):
         assert np.isnan(r["n2g"])
         assert (lam2, r["n2c"], r["n2s"], r["amax"], r["ei"]) == (ref[0], ref[1], ref[3], ref[4], ref[5])
     else:
-        assert (lam2, r["n2c"], r["n2g"], r["n2s"], r["amax"], r["ei"]) == ref[:6]
+        assert (lam2, r["n2c"], r["n2g"], r["n2s"], r["amax"]) == ref[:5]
+        # (the expected improvement is summed over the workgroups' partial sums in another order by the one-call
+        # form -- on the host instead of in a second launch: equal to rounding)
+        assert abs(r["ei"] - ref[5]) <= 4e-16 * abs(ref[5]) * 8
     if which == "interp":
         assert r["k"] == k
     assert np.array_equal(pnew2, ref[6]) and np.array_equal(be2.download(1, capi.VEC_STEP), ref[7])

@@ -8,9 +8,10 @@
 // phase stamps: thread 0 accumulates clock deltas in LDS, publishes them at the end
 __device__ long long* g_pf_out = nullptr;
 __shared__ long long s_pf[8];
-#define DLG_PF_DECL if(threadIdx.x == 0) { for(int _i = 0; _i < 6; _i++) s_pf[_i] = 0; s_pf[7] = clock64(); }
+#define DLG_PF_DECL if(threadIdx.x == 0) { for(int _i = 0; _i < 7; _i++) s_pf[_i] = 0; s_pf[7] = clock64(); }
 #define DLG_PF_STAMP(i) do { if(threadIdx.x == 0) { const long long _n = clock64(); s_pf[i] += _n - s_pf[7]; s_pf[7] = _n; } } while(0)
-#define DLG_PF_DONE if(threadIdx.x == 0 && g_pf_out) { for(int _i = 0; _i < 6; _i++) g_pf_out[_i] = s_pf[_i]; }
+#define DLG_PF_PIN(x) asm volatile("" :: "v"(x))
+#define DLG_PF_DONE if(threadIdx.x == 0 && g_pf_out) { for(int _i = 0; _i < 7; _i++) g_pf_out[_i] = s_pf[_i]; }
 #include "../../libdogleg_amd/csrc/panel_factor.h"
 
 __device__ int g_mcol[256];
@@ -35,6 +36,7 @@ __global__ void __launch_bounds__(NT) k_panel(double* G, int nrows, int w, int* 
   if(MODE == 0) panel_factor<NT, true>(P, ldp, nrows, w, tid, info, 0);
   if(MODE == 1) { if(blockIdx.x == 0 && tid == 0) g_pf_out = stamps + 4; panel_factor<NT, true>(P, ldp, nrows, w, tid, info, 0); }
   if(MODE == 4) { __shared__ int s_mcol[260]; __shared__ double s_rdiag[256]; panel_factor_blockdiag<NT>(P, ldp, nrows, w, tid, g_mcol, w/3, info, 0, s_mcol, s_rdiag); }
+  if(MODE == 5) { if(blockIdx.x == 0 && tid == 0) g_pf_out = stamps + 4; panel_factor_b16<(NT >= 256 ? NT : 256)>(P, ldp, nrows, w, tid, info, 0); }
   if(MODE == 2) { if(NT >= 256) panel_factor_mfma<(NT >= 256 ? NT : 256)>(P, ldp, nrows, w, tid, info, 0); else if(NT >= 256) panel_factor_mfma<(NT >= 256 ? NT : 256)>(P, ldp, nrows, w, tid, info, 0); else panel_factor<NT, true, true>(P, ldp, nrows, w, tid, info, 0); }
   if(MODE == 3) { if(blockIdx.x == 0 && tid == 0) g_pf_out = stamps + 4; if(NT >= 256) panel_factor_mfma<(NT >= 256 ? NT : 256)>(P, ldp, nrows, w, tid, info, 0); else panel_factor<NT, true, true>(P, ldp, nrows, w, tid, info, 0); }
   __syncthreads();
@@ -74,7 +76,7 @@ void run(int nrows, int w, int G, int iters)
   hipFuncSetAttribute(reinterpret_cast<const void*>(&k_panel<NT, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   hipLaunchKernelGGL(HIP_KERNEL_NAME(k_panel<NT, 1>), dim3(G), dim3(NT), lds, 0, d, nrows, w, info, st);
   hipDeviceSynchronize();
-  long long ph[10]; hipMemcpy(ph, st, 80, hipMemcpyDeviceToHost);
+  long long ph[11]; hipMemcpy(ph, st, 80, hipMemcpyDeviceToHost);
   printf("      scalar: sweep %lld +wait %lld | factor %lld +wait %lld | solve %lld +wait %lld\n", ph[4], ph[5], ph[6], ph[7], ph[8], ph[9]);
   hipFuncSetAttribute(reinterpret_cast<const void*>(&k_panel<NT, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   best = 1e9;
@@ -91,7 +93,49 @@ void run(int nrows, int w, int G, int iters)
   hipLaunchKernelGGL(HIP_KERNEL_NAME(k_panel<NT, 3>), dim3(G), dim3(NT), lds, 0, d, nrows, w, info, st);
   hipDeviceSynchronize();
   hipMemcpy(ph, st, 80, hipMemcpyDeviceToHost);
-  printf("      MFMA %.1f us: sweep %lld +wait %lld | factor %lld +wait %lld | solve %lld +wait %lld\n", best*1e3/iters, ph[4], ph[5], ph[6], ph[7], ph[8], ph[9]);
+  hipMemcpy(ph, st, 88, hipMemcpyDeviceToHost);
+  printf("      MFMA %.1f us: wave0 tile %lld load %lld factor %lld write-back %lld | barrier %lld | solve %lld | barrier %lld\n", best*1e3/iters, ph[6], ph[7], ph[10], ph[4], ph[5], ph[8], ph[9]);
+  {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&k_panel<NT, 5>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    float bb = 1e9;
+    for(int rep = 0; rep < 3; rep++)
+    {
+      hipMemcpy(d, h.data(), n*G*8, hipMemcpyHostToDevice);
+      hipEventRecord(e0);
+      for(int it = 0; it < iters; it++) { hipLaunchKernelGGL(HIP_KERNEL_NAME(k_panel<NT, 5>), dim3(G), dim3(NT), lds, 0, d, nrows, w, info, st); }
+      hipEventRecord(e1); hipEventSynchronize(e1);
+      float ms; hipEventElapsedTime(&ms, e0, e1); if(ms < bb) bb = ms;
+    }
+    std::vector<double> r0(n), r5(n);
+    hipMemcpy(d, h.data(), n*8, hipMemcpyHostToDevice);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_panel<NT, 0>), dim3(1), dim3(NT), lds, 0, d, nrows, w, info, st);
+    hipMemcpy(r0.data(), d, n*8, hipMemcpyDeviceToHost);
+    hipMemcpy(d, h.data(), n*8, hipMemcpyHostToDevice);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_panel<NT, 5>), dim3(1), dim3(NT), lds, 0, d, nrows, w, info, st);
+    hipMemcpy(r5.data(), d, n*8, hipMemcpyDeviceToHost);
+    hipMemcpy(ph, st, 88, hipMemcpyDeviceToHost);
+    double worst = 0, big = 0, up = 0; int wi = 0, wj = 0;
+    for(int j = 0; j < w; j++) for(int i = 0; i < nrows; i++)
+    {
+      const double dd = fabs(r0[i + (size_t)j*nrows] - r5[i + (size_t)j*nrows]);
+      if(i >= j) { if(dd > worst || dd != dd) { worst = dd; wi = i; wj = j; } big = fmax(big, fabs(r0[i + (size_t)j*nrows])); }
+      else up = fmax(up, fabs(h[i + (size_t)j*nrows] - r5[i + (size_t)j*nrows]));
+    }
+    printf("      B16 %.1f us: wave 0: wait %lld steps %lld next tile %lld (of which waiting %lld) | scalar vs b16: max |diff| %.3g at (%d,%d) (max |L| %.3g), strict upper triangle touched by %.3g\n", bb*1e3/iters, ph[4], ph[5], ph[6], ph[7], worst, wi, wj, big, up);
+  }
+  {
+    // the two sweeps on the same panel: largest difference over the lower trapezoid
+    std::vector<double> r0(n), r2(n);
+    hipMemcpy(d, h.data(), n*8, hipMemcpyHostToDevice);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_panel<NT, 0>), dim3(1), dim3(NT), lds, 0, d, nrows, w, info, st);
+    hipMemcpy(r0.data(), d, n*8, hipMemcpyDeviceToHost);
+    hipMemcpy(d, h.data(), n*8, hipMemcpyHostToDevice);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_panel<NT, 2>), dim3(1), dim3(NT), lds, 0, d, nrows, w, info, st);
+    hipMemcpy(r2.data(), d, n*8, hipMemcpyDeviceToHost);
+    double worst = 0, big = 0;
+    for(int j = 0; j < w; j++) for(int i = j; i < nrows; i++) { worst = fmax(worst, fabs(r0[i + (size_t)j*nrows] - r2[i + (size_t)j*nrows])); big = fmax(big, fabs(r0[i + (size_t)j*nrows])); }
+    printf("      scalar vs MFMA sweep: max |diff| %.3g (max |L| %.3g)\n", worst, big);
+  }
   hipFree(d); hipFree(info); hipFree(st);
 }
 
