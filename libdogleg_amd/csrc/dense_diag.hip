@@ -29,7 +29,7 @@ __global__ void __launch_bounds__(TPB) k_potrf_diag_inv(double* __restrict__ A, 
   }
   if(t == 0) sbad = 0x7fffffff;
   __syncthreads();
-  panel_factor_mfma<TPB>(P, LD, 2*NB, NB, t, &sbad, 0);
+  panel_factor_b16<TPB>(P, LD, 2*NB, NB, t, &sbad, 0);
   if(t == 0) { const int bad = sbad; if(bad < nb && *info == 0) *info = kb + bad + 1; }
   for(int e = t; e < NB*NB; e += TPB)
   {
@@ -68,7 +68,7 @@ __global__ void __launch_bounds__(TPB) k_potrf_diag_trsm(double* __restrict__ A,
     }
     if(t == 0) sbad = 0x7fffffff;
     __syncthreads();
-    panel_factor_mfma<TPB>(P, LD, 2*NB, NB, t, &sbad, 0);
+    panel_factor_b16<TPB>(P, LD, 2*NB, NB, t, &sbad, 0);
     if(t == 0) { const int bad = sbad; if(bad < nb && *info == 0) *info = kb + bad + 1; }
     for(int e = t; e < NB*NB; e += TPB)
     {
@@ -220,7 +220,7 @@ __global__ void __launch_bounds__(TPB) k_potrf_tiles(double* A, int lda, int n, 
     for(int e = t; e < NB*NB; e += TPB) { const int i = e % NB, j = e / NB; P[NB + i + j*LD] = (i == j) ? 1.0 : 0.0; }
     if(t == 0) sbad = 0x7fffffff;
     __syncthreads();
-    panel_factor_mfma<TPB>(P, LD, 2*NB, NB, t, &sbad, 0);
+    panel_factor_b16<TPB>(P, LD, 2*NB, NB, t, &sbad, 0);
     const int nb = min(NB, n - col0);
     if(t == 0) { const int bad = sbad; if(bad < nb) atomicCAS(info, 0, col0 + bad + 1); }
     double* Lv = Linv + (size_t)tj*NB*NB;

@@ -611,6 +611,15 @@ __device__ __forceinline__ dlg_pf_v4d pf_b16_diag_tile(const double* P, int ldp,
   }
   return U;
 }
+// 1/sqrt(d) on the pivot chain: v_rsq_f64 seed and ONE third-order step  y (1 + e/2 + 3 e^2/8),  e = 1 - d y^2  (five
+// dependent operations instead of the six of two Newton steps; the seed's 2^-23 goes to ~1e-21 before rounding)
+__device__ __forceinline__ double pf_rsqrt3(double d)
+{
+  const double y = __builtin_amdgcn_rsq(d);
+  const double e = __builtin_fma(-(d*y), y, 1.0);
+  const double q = __builtin_fma(0.375, e, 0.5)*e;
+  return __builtin_fma(y, q, y);
+}
 template <int NT>
 __device__ __forceinline__ void panel_factor_b16(double* P, int ldp, int nrows, int w, int tid,
                                                  int* __restrict__ info, int col0)
@@ -632,6 +641,7 @@ __device__ __forceinline__ void panel_factor_b16(double* P, int ldp, int nrows, 
   {
     int bad = 0x7fffffff;
     dlg_pf_v4d U = pf_b16_diag_tile(P, ldp, 0, min(16, w), mm, kq);
+    int tv_ahead = 0;
     for(int J = 0; J < nblk; J++)
     {
       const int kb = 16*J, nb = min(16, w - kb);
@@ -640,14 +650,16 @@ __device__ __forceinline__ void panel_factor_b16(double* P, int ldp, int nrows, 
       for(int r = 0; r < 4; r++) G[r] = (kq + 4*r == mm) ? 1.0 : 0.0;
       if(J >= 2)
       {
-        // the buffer of the inverse published two blocks ago is written again: every tile must be done with it
-        for(int spins = 0; spins < (1 << 20); spins++)          // (bounded: a wave that never reports shows as a wrong factor)
-        {
-          const bool mine = lane < ntr && lane > J - 2;
-          const int v = mine ? __hip_atomic_load(&S.tdone[mine ? lane : 0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) : 0x7fffffff;
-          if(__all(v >= J - 1)) break;
-          __builtin_amdgcn_s_sleep(1);
-        }
+        // the buffer of the inverse published two blocks ago is written again: every tile must be done with it (the
+        // words were fetched at the end of the last block; only a tile that was late then is polled)
+        if(!__all(tv_ahead >= J - 1))
+          for(int spins = 0; spins < (1 << 20); spins++)          // (bounded: a wave that never reports shows as a wrong factor)
+          {
+            const bool mine = lane < ntr && lane > J - 2;
+            const int v = mine ? __hip_atomic_load(&S.tdone[mine ? lane : 0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) : 0x7fffffff;
+            if(__all(v >= J - 1)) break;
+            __builtin_amdgcn_s_sleep(1);
+          }
       }
       DLG_PF_STAMP(0);
       double* Wb = S.W[J & 1];
@@ -665,25 +677,25 @@ __device__ __forceinline__ void panel_factor_b16(double* P, int ldp, int nrows, 
         const double a11 = pf_readlane64(src, 16 + 4*s + 1), a21 = pf_readlane64(src, 16 + 4*s + 2), a31 = pf_readlane64(src, 16 + 4*s + 3);
         const double a22 = pf_readlane64(src, 32 + 4*s + 2), a32 = pf_readlane64(src, 32 + 4*s + 3), a33 = pf_readlane64(src, 48 + 4*s + 3);
         double d0 = a00; if(!(d0 > 0.0)) { bad = min(bad, kb + 4*s); d0 = 1.0; }
-        const double i0 = dlg_rsqrt(d0);
+        const double i0 = pf_rsqrt3(d0);
         const double l10 = a10*i0, l20 = a20*i0, l30 = a30*i0;
         double d1 = a11 - l10*l10; if(!(d1 > 0.0)) { bad = min(bad, kb + 4*s + 1); d1 = 1.0; }
-        const double i1 = dlg_rsqrt(d1);
+        const double i1 = pf_rsqrt3(d1);
         const double l21 = (a21 - l20*l10)*i1, l31 = (a31 - l30*l10)*i1;
         double d2 = a22 - l20*l20 - l21*l21; if(!(d2 > 0.0)) { bad = min(bad, kb + 4*s + 2); d2 = 1.0; }
-        const double i2 = dlg_rsqrt(d2);
+        const double i2 = pf_rsqrt3(d2);
         const double l32 = (a32 - l30*l20 - l31*l21)*i2;
         double d3 = a33 - l30*l30 - l31*l31 - l32*l32; if(!(d3 > 0.0)) { bad = min(bad, kb + 4*s + 3); d3 = 1.0; }
-        const double i3 = dlg_rsqrt(d3);
+        const double i3 = pf_rsqrt3(d3);
         // M = D^-1 (lower)
         const double m10 = -(l10*i0)*i1, m21 = -(l21*i1)*i2, m32 = -(l32*i2)*i3;
         const double m20 = -(l20*i0 + l21*m10)*i2, m31 = -(l31*i1 + l32*m21)*i3;
         const double m30 = -(l30*i0 + l31*m10 + l32*m20)*i3;
         // A operand: lane (i, k) = M[i][k] (rows 4 .. 15 of the operand are zero)
-        double aop = 0.0;
-        aop = (lane == 0) ? i0 : aop;   aop = (lane == 1) ? m10 : aop;  aop = (lane == 2) ? m20 : aop;  aop = (lane == 3) ? m30 : aop;
-        aop = (lane == 17) ? i1 : aop;  aop = (lane == 18) ? m21 : aop; aop = (lane == 19) ? m31 : aop;
-        aop = (lane == 34) ? i2 : aop;  aop = (lane == 35) ? m32 : aop; aop = (lane == 51) ? i3 : aop;
+        double aop = 0.0;       // (the values that come out last go in last)
+        aop = (lane == 0) ? i0 : aop;   aop = (lane == 1) ? m10 : aop;  aop = (lane == 17) ? i1 : aop;
+        aop = (lane == 2) ? m20 : aop;  aop = (lane == 18) ? m21 : aop; aop = (lane == 34) ? i2 : aop;
+        aop = (lane == 3) ? m30 : aop;  aop = (lane == 19) ? m31 : aop; aop = (lane == 35) ? m32 : aop; aop = (lane == 51) ? i3 : aop;
         const dlg_pf_v4d Xv = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, src, zero4, 0, 0, 0);
         const double X0 = Xv[0];                    // lane (j, k) = L[kb + j][kb + 4s + k]
         if(s < 3) U = __builtin_amdgcn_mfma_f64_16x16x4f64(X0, -X0, U, 0, 0, 0);
@@ -709,25 +721,23 @@ __device__ __forceinline__ void panel_factor_b16(double* P, int ldp, int nrows, 
         const double s0 = S.A[lane], s1 = S.A[64 + lane], s2 = S.A[128 + lane], s3 = S.A[192 + lane];
 #pragma unroll
         for(int r = 0; r < 4; r++) U[r] = S.E[64*r + lane];
+        // (an fp64 MFMA is issue-bound, 72 clocks apiece whatever the dependences: one chain each)
         dlg_pf_v4d y0 = __builtin_amdgcn_mfma_f64_16x16x4f64(w0, s0, zero4, 0, 0, 0);
-        dlg_pf_v4d y1 = __builtin_amdgcn_mfma_f64_16x16x4f64(w2, s2, zero4, 0, 0, 0);
         y0 = __builtin_amdgcn_mfma_f64_16x16x4f64(w1, s1, y0, 0, 0, 0);
-        y1 = __builtin_amdgcn_mfma_f64_16x16x4f64(w3, s3, y1, 0, 0, 0);
-        double yv[4];
+        y0 = __builtin_amdgcn_mfma_f64_16x16x4f64(w2, s2, y0, 0, 0, 0);
+        y0 = __builtin_amdgcn_mfma_f64_16x16x4f64(w3, s3, y0, 0, 0, 0);
 #pragma unroll
         for(int r = 0; r < 4; r++)
         {
-          yv[r] = y0[r] + y1[r];                  // lane (n, kq) = L[r1 + n][kb + 4 r + kq]
-          if(r1 + mm < nrows) P[(r1 + mm) + (kb + kq + 4*r)*ldp] = yv[r];
-          yv[r] = (mm < nb1) ? yv[r] : 0.0;       // (rows below the top block are not part of the next diagonal tile)
+          const double yr = y0[r];                // lane (n, kq) = L[r1 + n][kb + 4 r + kq]
+          if(r1 + mm < nrows) P[(r1 + mm) + (kb + kq + 4*r)*ldp] = yr;
+          const double ym = (mm < nb1) ? yr : 0.0;          // (rows below the top block are not part of the next diagonal tile)
+          U = __builtin_amdgcn_mfma_f64_16x16x4f64(ym, -ym, U, 0, 0, 0);
         }
-        dlg_pf_v4d U2 = __builtin_amdgcn_mfma_f64_16x16x4f64(yv[2], -yv[2], zero4, 0, 0, 0);
-        U = __builtin_amdgcn_mfma_f64_16x16x4f64(yv[0], -yv[0], U, 0, 0, 0);
-        U2 = __builtin_amdgcn_mfma_f64_16x16x4f64(yv[3], -yv[3], U2, 0, 0, 0);
-        U = __builtin_amdgcn_mfma_f64_16x16x4f64(yv[1], -yv[1], U, 0, 0, 0);
-        U += U2;
         pf_wave_sync();
         if(lane == 0) __hip_atomic_store(&S.tdone[J + 1], J + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        // (for the check in front of the next block's first store into the other buffer: tiles > J - 1 at >= J)
+        tv_ahead = (lane < ntr && lane > J - 1) ? __hip_atomic_load(&S.tdone[lane], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) : 0x7fffffff;
       }
       DLG_PF_STAMP(2);
     }
