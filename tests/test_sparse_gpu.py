@@ -657,3 +657,61 @@ def test_factor_and_solve_ahead_of_the_decision_change_no_bit(gpu, lf, monkeypat
         assert len(got) == len(want)
         for i, (a, b) in enumerate(zip(got, want)):
             assert same(a, b), (script, i)
+
+
+@pytest.mark.parametrize("shape", [(49, 900, 10000), (199, 3600, 40000), (40, 800, 8777)])
+def test_sweep_by_blocks_of_16_agrees_with_the_column_block_sweep(gpu, shape, monkeypatch):
+    """panel_factor_b16 (the diagonal tile in MFMA accumulators, row tiles times the published inverse) against the
+    sweep by blocks of 8 columns with row-by-row substitution (DOGLEG_AMD_NO_B16): other sums, the same factor --
+    the Gauss-Newton step agrees to rounding; run to run the bits are the same (the hand-offs between the waves
+    carry no race)"""
+    prob = oa.BAProblem(*shape, seed=11)
+    Jp, Ji = prob.pattern()
+    p = prob.p0()
+    x, Jx = prob.eval(p)
+    res = {}
+    for mode in ("b16", "b16-again", "b8"):
+        monkeypatch.delenv("DOGLEG_AMD_NO_B16", raising=False)
+        if mode == "b8":
+            monkeypatch.setenv("DOGLEG_AMD_NO_B16", "1")
+        be = capi.Backend(capi.DLG_SPARSE, prob.N, prob.M, prob.nnz)
+        be.set_pattern(Jp, Ji)
+        be.set_p(0, p)
+        be.upload(0, x, Jx)
+        be.eval(0)
+        lam, n2g = be.gauss_newton(0, 1e-6)
+        rhs = np.cos(np.arange(prob.N) * 0.37)
+        res[mode] = (lam, n2g, be.download(0, capi.VEC_GN), be.solve_with_factor(0, rhs))
+        be.close()
+    assert res["b16"][0] == res["b8"][0] == 1e-6
+    assert res["b16"][1] == res["b16-again"][1]
+    assert np.array_equal(res["b16"][2], res["b16-again"][2]) and np.array_equal(res["b16"][3], res["b16-again"][3])
+    for k in (2, 3):
+        assert np.max(np.abs(res["b16"][k] - res["b8"][k])) <= 1e-11 * max(1.0, np.max(np.abs(res["b8"][k])))
+
+
+def test_sweep_by_blocks_of_16_reports_a_bad_pivot(gpu, monkeypatch):
+    """numerically-zero columns: the block sweep flags the non-positive pivot (the 4 x 4 pivot block counts it as 1
+    and goes on), lambda is raised exactly as with the column-block sweep"""
+    prob = oa.BAProblem(30, 500, 5000, seed=3, n_zero_cols=3)
+    Jp, Ji = prob.pattern()
+    p = prob.p0()
+    x, Jx = prob.eval(p)
+    out = {}
+    for mode in ("b16", "b8"):
+        monkeypatch.delenv("DOGLEG_AMD_NO_B16", raising=False)
+        if mode == "b8":
+            monkeypatch.setenv("DOGLEG_AMD_NO_B16", "1")
+        be = capi.Backend(capi.DLG_SPARSE, prob.N, prob.M, prob.nnz)
+        be.set_pattern(Jp, Ji)
+        be.set_p(0, p)
+        be.upload(0, x, Jx)
+        be.eval(0)
+        ok = be.factorize(0, 0.0)
+        lam, n2g = be.gauss_newton(0, 0.0)
+        out[mode] = (ok, lam, n2g, be.download(0, capi.VEC_GN))
+        be.close()
+    assert out["b16"][0] == out["b8"][0]
+    assert out["b16"][1] == out["b8"][1] and out["b16"][1] > 0.0
+    assert np.isfinite(out["b16"][3]).all()
+    assert np.max(np.abs(out["b16"][3] - out["b8"][3])) <= 1e-6 * max(1.0, np.max(np.abs(out["b8"][3])))
