@@ -28,6 +28,9 @@
 #define DLG_PF_PIN(x)
 #define DLG_PF_DONE
 #endif
+#ifndef DLG_PF_EVT           // tools/micro/bench_panel: time stamps of the hand-overs between the waves of panel_factor_b16
+#define DLG_PF_EVT(J, e)
+#endif
 
 // 1/sqrt(d) for d > 0: hardware v_rsq_f64 seed (about 1e-8 relative) + two Newton
 // steps (relative error ~1e-16).  The pivot sqrt(d) = d * rsqrt(d) and its reciprocal
@@ -662,6 +665,7 @@ __device__ __forceinline__ void panel_factor_b16(double* P, int ldp, int nrows, 
           }
       }
       DLG_PF_STAMP(0);
+      DLG_PF_EVT(J, 0);
       double* Wb = S.W[J & 1];
 #pragma unroll
       for(int s = 0; s < 4; s++)
@@ -709,6 +713,7 @@ __device__ __forceinline__ void panel_factor_b16(double* P, int ldp, int nrows, 
       pf_wave_sync();
       if(lane == 0) __hip_atomic_store(&S.wdone, J + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
       DLG_PF_STAMP(1);
+      DLG_PF_EVT(J, 1);
       if(J + 1 < nblk)
       {
         // the next diagonal tile: its rows in the columns of this block times L_JJ^-T, here, in registers -- the
@@ -718,6 +723,7 @@ __device__ __forceinline__ void panel_factor_b16(double* P, int ldp, int nrows, 
         const double w0 = Wr[0], w1 = Wr[4], w2 = Wr[8], w3 = Wr[12];
         pf_wait(&S.adone, J + 1);
         DLG_PF_STAMP(3);
+        DLG_PF_EVT(J, 2);
         const double s0 = S.A[lane], s1 = S.A[64 + lane], s2 = S.A[128 + lane], s3 = S.A[192 + lane];
 #pragma unroll
         for(int r = 0; r < 4; r++) U[r] = S.E[64*r + lane];
@@ -736,6 +742,7 @@ __device__ __forceinline__ void panel_factor_b16(double* P, int ldp, int nrows, 
         }
         pf_wave_sync();
         if(lane == 0) __hip_atomic_store(&S.tdone[J + 1], J + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        DLG_PF_EVT(J, 3);
         // (for the check in front of the next block's first store into the other buffer: tiles > J - 1 at >= J)
         tv_ahead = (lane < ntr && lane > J - 1) ? __hip_atomic_load(&S.tdone[lane], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) : 0x7fffffff;
       }
@@ -757,6 +764,7 @@ __device__ __forceinline__ void panel_factor_b16(double* P, int ldp, int nrows, 
         const bool next = t == J + 1 && J + 1 < nblk;        // the next diagonal tile: wave 0 finishes it
         const int r0 = 16*t, rowc = min(r0 + mm, nrows - 1);
         const int nb1 = min(16, w - r0);
+        if(next) { DLG_PF_EVT(J, 4); }
         // the tile TRANSPOSED: register r, lane (n, kq) = S[r0 + n][kb + kq + 4 r]
         dlg_pf_v4d acc, E = zero4;
 #pragma unroll
@@ -770,6 +778,7 @@ __device__ __forceinline__ void panel_factor_b16(double* P, int ldp, int nrows, 
         if(J > 0)
         {
           pf_wait(&S.tdone[J], J);
+          if(next) { DLG_PF_EVT(J, 5); }
           const double* ap = P + kb + (mm < nb ? mm : 0) + kq*ldp;        // rows of the diagonal tile
           const double* bp = P + rowc + kq*ldp;                           // rows of this tile
           double a0 = ap[0], b0 = bp[0], a1 = ap[4*ldp], b1 = bp[4*ldp];
@@ -797,6 +806,7 @@ __device__ __forceinline__ void panel_factor_b16(double* P, int ldp, int nrows, 
           for(int r = 0; r < 4; r++) { S.A[64*r + lane] = acc[r]; S.E[64*r + lane] = E[r]; }
           pf_wave_sync();
           if(lane == 0) __hip_atomic_store(&S.adone, J + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+          DLG_PF_EVT(J, 6);
           continue;
         }
         // times L_JJ^-T: Y'[i][j] = sum_c W[i][c] S[r0 + j][kb + c]

@@ -12,6 +12,8 @@ __shared__ long long s_pf[8];
 #define DLG_PF_STAMP(i) do { if(threadIdx.x == 0) { const long long _n = clock64(); s_pf[i] += _n - s_pf[7]; s_pf[7] = _n; } } while(0)
 #define DLG_PF_PIN(x) asm volatile("" :: "v"(x))
 #define DLG_PF_DONE if(threadIdx.x == 0 && g_pf_out) { for(int _i = 0; _i < 7; _i++) g_pf_out[_i] = s_pf[_i]; }
+__device__ long long g_evt[64*8];
+#define DLG_PF_EVT(J, e) do { if((threadIdx.x & 63) == 0 && blockIdx.x == 0) g_evt[(J)*8 + (e)] = clock64(); } while(0)
 #include "../../libdogleg_amd/csrc/panel_factor.h"
 
 __device__ int g_mcol[256];
@@ -120,6 +122,14 @@ void run(int nrows, int w, int G, int iters)
       const double dd = fabs(r0[i + (size_t)j*nrows] - r5[i + (size_t)j*nrows]);
       if(i >= j) { if(dd > worst || dd != dd) { worst = dd; wi = i; wj = j; } big = fmax(big, fabs(r0[i + (size_t)j*nrows])); }
       else up = fmax(up, fabs(h[i + (size_t)j*nrows] - r5[i + (size_t)j*nrows]));
+    }
+    if(getenv("DLG_PF_EVENTS"))
+    {
+      long long ev[64*8]; hipMemcpyFromSymbol(ev, HIP_SYMBOL(g_evt), sizeof(ev));
+      const int nblk = (w + 15)/16;
+      for(int J = 0; J + 1 < nblk; J++)
+        printf("        block %d: steps %lld .. %lld | next tile's wave: at the tile %+lld, diagonal rows seen %+lld, handed over %+lld | wave 0: hand-over seen %+lld, tile ready %+lld (all relative to the inverse being out)\n", J,
+               ev[J*8] - ev[0], ev[J*8+1] - ev[0], ev[J*8+4] - ev[J*8+1], ev[J*8+5] - ev[J*8+1], ev[J*8+6] - ev[J*8+1], ev[J*8+2] - ev[J*8+1], ev[J*8+3] - ev[J*8+1]);
     }
     printf("      B16 %.1f us: wave 0: wait %lld steps %lld next tile %lld (of which waiting %lld) | scalar vs b16: max |diff| %.3g at (%d,%d) (max |L| %.3g), strict upper triangle touched by %.3g\n", bb*1e3/iters, ph[4], ph[5], ph[6], ph[7], worst, wi, wj, big, up);
   }
