@@ -312,7 +312,9 @@ enum
   DLG_PROF_COUNT = 8
 };
 /* on = 0: off; 1: every phase; else: only the phases p with bit (p + 1) of `on` set, e.g.
- * 2 << DLG_PROF_K4_KERNEL (two event records per step instead of twenty).  Clears the counters. */
+ * 2 << DLG_PROF_K4_KERNEL (two event records per step instead of twenty).  Bits 16-23, if not zero: only every
+ * n-th occurrence of a phase carries events (a kernel whose completion somebody listens to holds the next
+ * dispatch back by ~5 us: sampling keeps the timed loop close to the untimed one).  Clears the counters. */
 int  dlg_backend_set_profiling(dlg_backend_t* b, int on);
 int  dlg_backend_get_profile(dlg_backend_t* b, double* ms_total, long* launches, int n);
 

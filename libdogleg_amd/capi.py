@@ -371,9 +371,11 @@ class Backend:
         except Exception:
             pass
 
-    def set_profiling(self, on=True, only=None):
-        """only: names of the phases to time (PROF_NAMES); default all"""
+    def set_profiling(self, on=True, only=None, every=1):
+        """only: names of the phases to time (PROF_NAMES), default all; every: time every n-th occurrence only"""
         v = (1 if on else 0) if only is None else sum(2 << PROF_NAMES.index(n) for n in only)
+        if v and every > 1:
+            v |= min(int(every), 255) << 16
         _ck(self.L.dlg_backend_set_profiling(self.h, v), "set_profiling")
 
     def profile(self):

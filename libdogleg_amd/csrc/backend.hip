@@ -74,6 +74,7 @@ void dlg_prof_end(dlg_backend* b, int id, hipEvent_t start)
 bool dlg_prof_pair(dlg_backend* b, int id, hipEvent_t* e0, hipEvent_t* e1)
 {
   if(!(b->prof_mask >> id & 1u) || !b->ext_events) return false;
+  if(b->prof_tick[id]++ % b->prof_every != 0) return false;
   *e0 = prof_event(b); *e1 = prof_event(b);
   if(!*e0 || !*e1) { if(*e0) b->prof_pool.push_back(*e0); if(*e1) b->prof_pool.push_back(*e1); return false; }
   b->prof_pending.push_back({*e0, *e1, id});
@@ -96,8 +97,11 @@ extern "C" int dlg_backend_set_profiling(dlg_backend_t* b, int on)
   DLG_HIP(hipStreamSynchronize(b->stream));
   dlg_prof_resolve(b);
   for(int i = 0; i < DLG_PROF_COUNT; i++) { b->prof_ms[i] = 0; b->prof_n[i] = 0; }
-  b->profiling = on != 0;
-  b->prof_mask = on == 0 ? 0u : (on == 1 ? ~0u : (unsigned)on >> 1);
+  const int every = (on >> 16) & 0xff, sel = on & 0xffff;
+  b->profiling = sel != 0;
+  b->prof_mask = sel == 0 ? 0u : (sel == 1 ? ~0u : (unsigned)sel >> 1);
+  b->prof_every = every > 0 ? every : 1;
+  for(int i = 0; i < DLG_PROF_COUNT; i++) b->prof_tick[i] = 0;
   return DLG_OK;
 }
 extern "C" int dlg_backend_get_profile(dlg_backend_t* b, double* ms_total, long* launches, int n)

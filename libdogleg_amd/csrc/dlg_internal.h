@@ -149,6 +149,7 @@ struct dlg_backend
   // optional per-phase timing with HIP events on b->stream (dlg_backend_set_profiling)
   bool profiling = false;
   hipEvent_t attach_stop = nullptr; bool stop_attached = false, ext_events = true;      // DLG_LAUNCH_LAST
+  int prof_every = 1; unsigned prof_tick[DLG_PROF_COUNT] = {};      // every n-th occurrence of a timed phase carries events
   unsigned prof_mask = 0;     // the phases that are timed (bit = DLG_PROF_*)
   struct ProfPair { hipEvent_t a, b; int id; };
   std::vector<ProfPair> prof_pending;
@@ -166,7 +167,7 @@ void dlg_prof_resolve(dlg_backend* b);
 struct DlgProfScope
 {
   dlg_backend* b; int id; hipEvent_t e;
-  DlgProfScope(dlg_backend* b_, int id_, bool enable = true) : b(b_), id(id_), e((enable && (b_->prof_mask >> id_ & 1u)) ? dlg_prof_begin(b_) : nullptr) {}
+  DlgProfScope(dlg_backend* b_, int id_, bool enable = true) : b(b_), id(id_), e((enable && (b_->prof_mask >> id_ & 1u) && b_->prof_tick[id_]++ % b_->prof_every == 0) ? dlg_prof_begin(b_) : nullptr) {}
   ~DlgProfScope() { if(e) dlg_prof_end(b, id, e); }
 };
 // One kernel as a timed phase: the two events ride on the launch itself (hipExtLaunchKernelGGL: the dispatch's own

@@ -588,6 +588,7 @@ __device__ __forceinline__ void panel_factor_ahead(double* P, int ldp, int nrows
 // wave that finishes first in every block (the tiles are taken in increasing order).
 constexpr int PF_B16_WS = 17;          // row stride of the published inverse (doubles; 16 would put a column on one bank)
 constexpr int PF_B16_MAXT = 32;        // row tiles: nrows <= 512
+#define PF_NEG_A 1                     // v_mfma_f64: the BLGP field holds the NEG bits, bit 0 negates A (no VALU negation between the products)
 // W: L_JJ^-1 of the last two blocks; A / E: the NEXT diagonal tile's rows, brought up to date by their wave and handed
 // to wave 0 (A: the 16 columns of the current block, transposed; E: the diagonal tile itself against all columns before
 // the block); wdone / adone / tdone: the hand-off words
@@ -702,13 +703,13 @@ __device__ __forceinline__ void panel_factor_b16(double* P, int ldp, int nrows, 
         aop = (lane == 3) ? m30 : aop;  aop = (lane == 19) ? m31 : aop; aop = (lane == 35) ? m32 : aop; aop = (lane == 51) ? i3 : aop;
         const dlg_pf_v4d Xv = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, src, zero4, 0, 0, 0);
         const double X0 = Xv[0];                    // lane (j, k) = L[kb + j][kb + 4s + k]
-        if(s < 3) U = __builtin_amdgcn_mfma_f64_16x16x4f64(X0, -X0, U, 0, 0, 0);
+        if(s < 3) U = __builtin_amdgcn_mfma_f64_16x16x4f64(X0, X0, U, 0, 0, PF_NEG_A);
         if(mm >= 4*s + kq && mm < nb && 4*s + kq < nb) P[(kb + mm) + (kb + 4*s + kq)*ldp] = X0;
         // the rows 4s .. 4s + 3 of L_JJ^-1 from the identity tile
         const dlg_pf_v4d Wv = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, G[s], zero4, 0, 0, 0);
         const double W0 = Wv[0];                    // lane (j, k) = W[4s + k][j]
         Wb[(4*s + kq)*PF_B16_WS + mm] = W0;
-        if(s < 3) G = __builtin_amdgcn_mfma_f64_16x16x4f64(X0, -W0, G, 0, 0, 0);
+        if(s < 3) G = __builtin_amdgcn_mfma_f64_16x16x4f64(X0, W0, G, 0, 0, PF_NEG_A);
       }
       pf_wave_sync();
       if(lane == 0) __hip_atomic_store(&S.wdone, J + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -738,7 +739,7 @@ __device__ __forceinline__ void panel_factor_b16(double* P, int ldp, int nrows, 
           const double yr = y0[r];                // lane (n, kq) = L[r1 + n][kb + 4 r + kq]
           if(r1 + mm < nrows) P[(r1 + mm) + (kb + kq + 4*r)*ldp] = yr;
           const double ym = (mm < nb1) ? yr : 0.0;          // (rows below the top block are not part of the next diagonal tile)
-          U = __builtin_amdgcn_mfma_f64_16x16x4f64(ym, -ym, U, 0, 0, 0);
+          U = __builtin_amdgcn_mfma_f64_16x16x4f64(ym, ym, U, 0, 0, PF_NEG_A);
         }
         pf_wave_sync();
         if(lane == 0) __hip_atomic_store(&S.tdone[J + 1], J + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -787,14 +788,14 @@ __device__ __forceinline__ void panel_factor_b16(double* P, int ldp, int nrows, 
             const int kn = (k0 + 8 < kb) ? k0 + 8 : k0;
             const double na0 = ap[kn*ldp], nb0 = bp[kn*ldp], na1 = ap[(kn + 4)*ldp], nb1v = bp[(kn + 4)*ldp];
             __builtin_amdgcn_sched_barrier(0);
-            const double va0 = (mm < nb) ? -a0 : 0.0, va1 = (mm < nb) ? -a1 : 0.0;
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(va0, b0, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(va1, b1, acc, 0, 0, 0);
+            const double va0 = (mm < nb) ? a0 : 0.0, va1 = (mm < nb) ? a1 : 0.0;
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(va0, b0, acc, 0, 0, PF_NEG_A);
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(va1, b1, acc, 0, 0, PF_NEG_A);
             if(next)
             {
               const double e0 = (mm < nb1) ? b0 : 0.0, e1 = (mm < nb1) ? b1 : 0.0;
-              E = __builtin_amdgcn_mfma_f64_16x16x4f64(e0, -e0, E, 0, 0, 0);
-              E = __builtin_amdgcn_mfma_f64_16x16x4f64(e1, -e1, E, 0, 0, 0);
+              E = __builtin_amdgcn_mfma_f64_16x16x4f64(e0, e0, E, 0, 0, PF_NEG_A);
+              E = __builtin_amdgcn_mfma_f64_16x16x4f64(e1, e1, E, 0, 0, PF_NEG_A);
             }
             __builtin_amdgcn_sched_barrier(0);
             a0 = na0; b0 = nb0; a1 = na1; b1 = nb1v;
