@@ -23,6 +23,6 @@ import bench, io, contextlib
 buf = io.StringIO()
 with contextlib.redirect_stdout(buf):
     bench.main()
-capi.lib().dlg_fl_profile_dump(16)
+capi.lib().dlg_fl_profile_dump(int(os.environ.get("DLG_FL_DUMP_N", "16")))
 capi.lib().dlg_bw_profile_dump(16)
 PY
