@@ -200,7 +200,14 @@ int  dlg_point_eval(dlg_backend_t* b, int slot, double* norm2_x, double* Jtx_abs
  * assembling again.  For callers that expect the evaluated point to be factorised (the driver turns
  * it on once a step has needed the Gauss-Newton step: an accepted point is factorised next).  JtJ
  * is the same bit for bit; in the one-pass form Jt*x is summed in another (fixed) order, i.e. it
- * differs from the stand-alone kernel's by rounding.  An assembly that is not used is dropped. */
+ * differs from the stand-alone kernel's by rounding.  An assembly that is not used is dropped.
+ * In the one-pass form (single rank) the evaluation also ENQUEUES the factorisation and the Gauss-Newton
+ * solve of the slot, at the lambda the next step is expected to ask for (the one the last step ended with;
+ * a caller that was seen to start over from its own value: that value), behind the point the host waits
+ * for: dlg_take_step from that slot at that lambda picks them up.  Any other use leaves every result as
+ * it would have been: a step from the other slot, or any call that uses the factor held before, gets
+ * that factor back (its panels stay in the second buffer until the next step), another lambda
+ * factorises again.  DOGLEG_AMD_NO_PRESOLVE=1 keeps the evaluation to the assembly. */
 int  dlg_backend_set_speculation(dlg_backend_t* b, int on);
 
 /* ---- K3: compute_updateCauchy (dogleg.c:529-617) -------------------------- */

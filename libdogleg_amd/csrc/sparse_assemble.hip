@@ -975,7 +975,7 @@ int sparse_assemble_finish(dlg_backend* b)
 #define ASM_LAUNCH(kernel, grid, block, shm, st, ...) \
   do { hipEvent_t e0 = nullptr, e1 = nullptr; \
        if(timed_single && dlg_prof_pair(b, DLG_PROF_K4_KERNEL, &e0, &e1)) hipExtLaunchKernelGGL(kernel, grid, block, shm, st, e0, e1, 0, __VA_ARGS__); \
-       else { DlgProfScope pk1(b, DLG_PROF_K4_KERNEL, timed_single); hipLaunchKernelGGL(kernel, grid, block, shm, st, __VA_ARGS__); } } while(0)
+       else { DlgProfScope pk1(b, DLG_PROF_K4_KERNEL, timed_single && !b->ext_events); hipLaunchKernelGGL(kernel, grid, block, shm, st, __VA_ARGS__); } } while(0)
 static int assemble_launch(dlg_backend* b, const double* Jv, double* Lx = nullptr, const double* xvec = nullptr, double* Jt_x = nullptr,
                            bool zeroed = false, bool defer_fin = false, const double* lf_rhs = nullptr, double lf_lambda = 0.0)
 {

@@ -715,3 +715,28 @@ def test_sweep_by_blocks_of_16_reports_a_bad_pivot(gpu, monkeypatch):
     assert out["b16"][1] == out["b8"][1] and out["b16"][1] > 0.0
     assert np.isfinite(out["b16"][3]).all()
     assert np.max(np.abs(out["b16"][3] - out["b8"][3])) <= 1e-6 * max(1.0, np.max(np.abs(out["b8"][3])))
+
+
+def test_profiling_can_sample_every_nth_occurrence(gpu):
+    """dlg_backend_set_profiling: bits 16-23 of `on` = time every n-th occurrence of a phase only (a kernel somebody
+    listens to holds the next dispatch back; sampling keeps a timed loop close to the untimed one)"""
+    prob = oa.BAProblem(49, 900, 10000, seed=2)
+    Jp, Ji = prob.pattern()
+    p = prob.p0()
+    x, Jx = prob.eval(p)
+    be = capi.Backend(capi.DLG_SPARSE, prob.N, prob.M, prob.nnz)
+    be.set_pattern(Jp, Ji)
+    be.set_p(0, p)
+    counts = {}
+    for every in (1, 4):
+        be.set_profiling(True, only=["K4_kernel"], every=every)
+        for _ in range(8):
+            be.upload(0, x, Jx)
+            be.eval(0)
+            be.factorize(0, 1e-6)
+        prof = be.profile()
+        counts[every] = prof["K4_kernel"][1]
+        assert prof["K4_kernel"][0] > 0.0 and prof["K5_factor"][1] == 0
+    be.set_profiling(False)
+    be.close()
+    assert counts[1] == 8 and counts[4] == 2
