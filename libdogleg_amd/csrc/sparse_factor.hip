@@ -1223,14 +1223,21 @@ int sparse_factor_setup(dlg_backend* b, bool plan_only)
         // (the first level of the region is its most populous one, and the Cauchy step's pass over J runs beside
         // it: replicas there cost more in CUs than they save -- only what does not fit LDS whole is sliced)
         const int rl = std::max(1, std::min(rmax, (l == Y->pr_level0 ? fill0 : fill)/std::max(n, 1)));
+        // (DOGLEG_AMD_L1_REP=percent, 0 = off -- the first level's supernodes whose panel is at least that share of the
+        // level's largest get a second workgroup for their update matrix, while CUs are left)
+        const int l1_pct = (l == Y->pr_level0 && rl == 1) ? env_int_host("DOGLEG_AMD_L1_REP", 70) : 0;
+        long l1_max = 0; int l1_left = std::max(0, ncu - n);
+        if(l1_pct > 0) for(int i = H.fw_lvl_ptr[l]; i < H.fw_lvl_ptr[l+1]; i++) l1_max = std::max(l1_max, (long)H.fw_item[i].nrows*H.fw_item[i].w);
         for(int i = H.fw_lvl_ptr[l]; i < H.fw_lvl_ptr[l+1]; i++)
         {
           FwItem it = H.fw_item[i];
           const int mb = it.nrows - it.w, T = (mb + 15) >> 4;
+          int rl_i = rl;
+          if(l1_pct > 0 && l1_left > 0 && (long)it.nrows*it.w*100 >= l1_max*l1_pct) { rl_i = 2; l1_left--; }
           const long ldp = (it.nrows + 1) & ~1L, pan = ldp*it.w, room = FAC_LDS_BUDGET/8 - pan - 2;
           const bool has_w = mb > 0 && it.u_off >= 0;
           // an update matrix that does not fit LDS whole (it.jsp < 0) fits in slices: two replicas at least
-          int want = has_w ? std::min(rl, T) : 1;
+          int want = has_w ? std::min(rl_i, T) : 1;
           if(has_w && it.jsp < 0 && slice_ok) want = std::max(want, std::min(2, T));
           else if(getenv("DOGLEG_AMD_SLICE_ONLY_IF_NEEDED")) want = 1;
           std::vector<int> cut;
