@@ -89,7 +89,7 @@ struct dlg_backend
   {
     bool no_k3_fork = false, p_side_copy = false, lookahead = false, no_potrf_fuse = false, potrf_steps = false,
          trsv_steps = false, no_fork_gate = false, no_touch = false;
-    int touch_wg = 128;
+    int touch_wg = 512;
   } knobs;
   int ncu = 256;              // compute units of b->device
 

@@ -1205,7 +1205,7 @@ int sparse_factor_setup(dlg_backend* b, bool plan_only)
     Y->pr_nwg = 0;
     if(Y->pr_level0 < H.nlevels)
     {
-      const int rmax = std::max(1, std::min(8, env_int_host("DOGLEG_AMD_FRONT_REPLICAS", 4)));
+      const int rmax = std::max(1, std::min(8, env_int_host("DOGLEG_AMD_FRONT_REPLICAS", 8)));
       const int fill = env_int_host("DOGLEG_AMD_FRONT_FILL", ncu/2), fill0 = env_int_host("DOGLEG_AMD_FRONT_FILL0", ncu/2);
       const bool slice_ok = !getenv("DOGLEG_AMD_NO_FRONT_SLICES");
       std::vector<FwItem> items;
