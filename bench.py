@@ -212,6 +212,10 @@ def main():
     barrier()
     prof = be.profile()
     prof["K4_kernel"] = prof_k4["K4_kernel"]
+    # launches that returned after their first barrier behind a failed factorisation (the lambda path of config #5:
+    # what is left of K5, K6 and K8 of the attempt at lambda = 0) are NOT in `prof`: per-launch averages below are
+    # over launches that ran in full
+    prof_early = be.profile_early()
     be.set_profiling(False)
     # the cheaper kind of trial step, reported beside `value`: after a rejected step the
     # reference re-uses the cached Cauchy/GN steps and the factor (dogleg.c:533-535, 637, 825), so a
@@ -339,7 +343,9 @@ def main():
             "other_kernels": others,
             "inputs": {"resident_copies": ncopy, "bytes_per_copy": int(xh.nbytes + Jh.nbytes),
                        "note": "the timed loop rotates over the copies: past the 256 MiB Infinity Cache"},
-            "phases_ms_per_step": {k: v[0] / args.steps for k, v in prof.items()},
+            "phases_ms_per_step": {k: (v[0] + prof_early[k][0]) / args.steps for k, v in prof.items()},
+            "early_return_launches": ({k: {"launches": v[1], "ms_per_launch": v[0] / v[1]} for k, v in prof_early.items() if v[1] > 0}
+                                      or None),
             "cached_retry_step": ({"ms_per_step": retry_ms, "steps_per_s": 1e3 / retry_ms,
                                    "what": "K7 + K8 + evaluation of the new point (K1, with K4 in the same pass where `value` has it), cached Cauchy/GN/factor"}
                                   if retry_ms else None),

@@ -118,6 +118,7 @@ int  dlg_backend_init_rccl(dlg_backend_t* b, int rank, int nranks, const void* u
 int  dlg_backend_set_rccl(dlg_backend_t* b, void* nccl_comm);            /* adopt a caller-owned ncclComm_t */
 int  dlg_backend_share_rccl(dlg_backend_t* b, dlg_backend_t* owner);     /* ... the one another backend of this process made (it keeps owning it) */
 int  dlg_backend_comm_size(dlg_backend_t* b, int* nranks);               /* what RCCL reports (1 without RCCL) */
+int  dlg_backend_has_rccl(dlg_backend_t* b);                             /* 1: the sums over the ranks are ncclAllReduce calls on the backend's stream */
 
 /* ---- nsteps trial steps of a fresh operating point in one call: bind resident inputs (ncopy copies of (x, J)
  * on the device, rotated from first_copy), dlg_point_eval, dlg_take_step from lambda0 -- the sequence of the
@@ -324,6 +325,10 @@ enum
  * dispatch back by ~5 us: sampling keeps the timed loop close to the untimed one).  Clears the counters. */
 int  dlg_backend_set_profiling(dlg_backend_t* b, int on);
 int  dlg_backend_get_profile(dlg_backend_t* b, double* ms_total, long* launches, int n);
+/* the launches that returned after their first barrier because the factorisation they belong to had failed (the
+ * lambda path, dogleg.c:670-673: what is left of K5, K6, K8 of the attempt that is thrown away) -- counted
+ * here and NOT in dlg_backend_get_profile, whose per-launch averages are over launches that ran in full */
+int  dlg_backend_get_profile_early(dlg_backend_t* b, double* ms_total, long* launches, int n);
 
 /* ---- raw device-memory helpers for harnesses that hold inputs in HBM without
  * a framework (tests, bench): thin wrappers of hipMalloc/hipMemcpy/hipFree --- */

@@ -257,7 +257,7 @@ double dogleg_optimize_device2(double* p, unsigned int Nstate,
  *       address instead of RCCL (MPI, or the in-process sum the single-GPU tests use); host-synchronous.
  *   the environment               DOGLEG_AMD_WORLD_SIZE > 1, DOGLEG_AMD_RANK, DOGLEG_AMD_LOCAL_RANK (the GPU,
  *       default: the rank), DOGLEG_AMD_RCCL_ID_FILE (a path all ranks see: rank 0 writes the id there,
- *       the others wait for it): a program that was only re-linked against this library, started once
+ *       the others wait for it; DOGLEG_AMD_RUN_ID names the launch, see dogleg_amd_id_file_publish): a program that was only re-linked against this library, started once
  *       per GPU by a launcher, needs no source change.  The communicator is made once per process.
  * All return 0 on success, -1 on bad arguments. */
 typedef int (*dogleg_amd_allreduce_t)(void* buf_dev, size_t count, void* cookie);
@@ -266,6 +266,13 @@ int  dogleg_amd_set_allreduce(int rank, int nranks, int device, dogleg_amd_allre
 void dogleg_amd_clear_communicator(void);
 int  dogleg_amd_rccl_unique_id(void* out128);
 int  dogleg_amd_rank(const dogleg_solverContext_t* ctx, int* nranks);
+/* The id file of the environment contract, for launchers that hand the id round themselves: rank 0 publishes
+ * the 128-byte id (tmp + rename: never seen half-written), the others wait for a complete file that carries
+ * the same run id (any string that names the launch; the environment contract uses DOGLEG_AMD_RUN_ID, else
+ * TORCHELASTIC_RUN_ID, else ""), so that a file an earlier launch left at the path is not taken for this
+ * launch's.  Under one run id the path must be fresh for each launch.  Host only, no GPU call.  0 / -1. */
+int  dogleg_amd_id_file_publish(const char* path, const void* id128, const char* run_id);
+int  dogleg_amd_id_file_wait(const char* path, void* id128_out, const char* run_id, int timeout_ms);
 
 /* Between solves the library keeps one idle backend (device buffers, the uploaded sparsity pattern and its
  * schedules) and the page-locked host buffers of the operating points: a program that solves many problems

@@ -34,10 +34,10 @@ BACKEND_SYMBOLS = [
     "dlg_probe_hbm_copy", "dlg_set_trace", "dlg_mem_alloc", "dlg_mem_free", "dlg_host_alloc",
     "dlg_host_free", "dlg_mem_upload",
     "dlg_mem_download", "dlg_mem_zero", "dlg_device_sync", "dlg_sparse_symbolic_probe", "dlg_sparse_leaf_probe",
-    "dlg_backend_set_profiling", "dlg_backend_get_profile",
+    "dlg_backend_set_profiling", "dlg_backend_get_profile", "dlg_backend_get_profile_early",
     "dlg_backend_set_allreduce", "dlg_backend_set_partition", "dlg_partition_rows", "dlg_partition_stats",
     "dlg_sparse_partition_probe", "dlg_rccl_unique_id", "dlg_backend_init_rccl", "dlg_backend_set_rccl",
-    "dlg_backend_comm_size", "dlg_solve_multi", "dlg_pseudoinverse_chunk", "dlg_backend_set_speculation",
+    "dlg_backend_comm_size", "dlg_backend_has_rccl", "dlg_solve_multi", "dlg_pseudoinverse_chunk", "dlg_backend_set_speculation",
     "dlg_backend_share_rccl", "dlg_point_gather_device", "dlg_backend_reset", "dlg_backend_device",
     "dlg_sparse_pattern_matches", "dlg_sparse_drop_pattern", "dlg_sparse_region_probe", "dlg_run_steps",
 ]
@@ -52,6 +52,7 @@ DOGLEG_SYMBOLS = [
     "dogleg_optimize_device2", "dogleg_amd_backend", "dogleg_amd_point_slot",
     "dogleg_amd_set_communicator", "dogleg_amd_set_allreduce", "dogleg_amd_clear_communicator",
     "dogleg_amd_rccl_unique_id", "dogleg_amd_rank", "dogleg_amd_release_cache",
+    "dogleg_amd_id_file_publish", "dogleg_amd_id_file_wait",
 ]
 
 _lib = None
@@ -90,6 +91,8 @@ def lib():
     L.dlg_backend_init_rccl.argtypes = [V, C.c_int, C.c_int, V]
     L.dlg_backend_set_rccl.argtypes = [V, V]
     L.dlg_backend_comm_size.argtypes = [V, I]
+    L.dlg_backend_has_rccl.argtypes = [V]
+    L.dlg_backend_get_profile_early.argtypes = [V, D, C.POINTER(C.c_long), C.c_int]
     L.dlg_sparse_set_pattern.argtypes = [V, I, I]
     L.dlg_sparse_stats.argtypes = [V, C.POINTER(C.c_long), C.POINTER(C.c_long), I, I, D]
     L.dlg_sparse_schedule.argtypes = [V, I, I, I]
@@ -163,6 +166,8 @@ def lib():
     L.dogleg_amd_clear_communicator.restype = None
     L.dogleg_amd_rccl_unique_id.argtypes = [V]
     L.dogleg_amd_rank.argtypes = [V, I]
+    L.dogleg_amd_id_file_publish.argtypes = [C.c_char_p, V, C.c_char_p]
+    L.dogleg_amd_id_file_wait.argtypes = [C.c_char_p, V, C.c_char_p, C.c_int]
     L.dlg_backend_share_rccl.argtypes = [V, V]
     L.dlg_sparse_region_probe.argtypes = [C.c_int, C.c_int, I, I, C.c_int, C.POINTER(C.c_long), C.c_int]
     L.dlg_run_steps.argtypes = [V, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(V), C.POINTER(V), C.c_int, C.c_double, C.c_double, D, I]
@@ -384,6 +389,14 @@ class Backend:
         ms = (C.c_double * n)()
         cnt = (C.c_long * n)()
         _ck(self.L.dlg_backend_get_profile(self.h, ms, cnt, n), "get_profile")
+        return {PROF_NAMES[i]: (ms[i], cnt[i]) for i in range(n)}
+
+    def profile_early(self):
+        """{phase: (total_ms, launches)} of the launches that returned early behind a failed factorisation"""
+        n = len(PROF_NAMES)
+        ms = (C.c_double * n)()
+        cnt = (C.c_long * n)()
+        _ck(self.L.dlg_backend_get_profile_early(self.h, ms, cnt, n), "get_profile_early")
         return {PROF_NAMES[i]: (ms[i], cnt[i]) for i in range(n)}
 
     def set_stream(self, stream_ptr):

@@ -58,6 +58,9 @@ static hipEvent_t prof_event(dlg_backend* b)
   if(hipEventCreate(&e) != hipSuccess) return nullptr;
   return e;
 }
+// (only the phases whose kernels look at the pivot flag: the assembly of a retried attempt runs in full)
+static bool prof_is_cond(const dlg_backend* b, int id)
+{ return b->prof_cond && (id == DLG_PROF_K5_FACTOR || id == DLG_PROF_K6_SOLVE || id == DLG_PROF_K3K8_NORM2JV); }
 hipEvent_t dlg_prof_begin(dlg_backend* b)
 {
   hipEvent_t e = prof_event(b);
@@ -69,7 +72,7 @@ void dlg_prof_end(dlg_backend* b, int id, hipEvent_t start)
   hipEvent_t e = prof_event(b);
   if(!e) { b->prof_pool.push_back(start); return; }
   (void)hipEventRecord(e, b->stream);
-  b->prof_pending.push_back({start, e, id});
+  b->prof_pending.push_back({start, e, id, prof_is_cond(b, id)});
 }
 bool dlg_prof_pair(dlg_backend* b, int id, hipEvent_t* e0, hipEvent_t* e1)
 {
@@ -77,7 +80,7 @@ bool dlg_prof_pair(dlg_backend* b, int id, hipEvent_t* e0, hipEvent_t* e1)
   if(b->prof_tick[id]++ % b->prof_every != 0) return false;
   *e0 = prof_event(b); *e1 = prof_event(b);
   if(!*e0 || !*e1) { if(*e0) b->prof_pool.push_back(*e0); if(*e1) b->prof_pool.push_back(*e1); return false; }
-  b->prof_pending.push_back({*e0, *e1, id});
+  b->prof_pending.push_back({*e0, *e1, id, prof_is_cond(b, id)});
   return true;
 }
 void dlg_prof_resolve(dlg_backend* b)
@@ -86,17 +89,31 @@ void dlg_prof_resolve(dlg_backend* b)
   {
     float ms = 0;
     (void)hipEventSynchronize(pp.b);          // (a phase on the second stream may still be running)
-    if(hipEventElapsedTime(&ms, pp.a, pp.b) == hipSuccess) { b->prof_ms[pp.id] += ms; b->prof_n[pp.id]++; }
+    if(hipEventElapsedTime(&ms, pp.a, pp.b) == hipSuccess)
+    {
+      if(pp.cond) { b->prof_att_ms[pp.id] += ms; b->prof_att_n[pp.id]++; }
+      else        { b->prof_ms[pp.id] += ms; b->prof_n[pp.id]++; }
+    }
     b->prof_pool.push_back(pp.a); b->prof_pool.push_back(pp.b);
   }
   b->prof_pending.clear();
+}
+// the outcome of the attempt the conditionally timed launches belong to is known
+void dlg_prof_commit(dlg_backend* b, bool attempt_succeeded)
+{
+  for(int i = 0; i < DLG_PROF_COUNT; i++)
+  {
+    if(attempt_succeeded) { b->prof_ms[i] += b->prof_att_ms[i]; b->prof_n[i] += b->prof_att_n[i]; }
+    else                  { b->prof_early_ms[i] += b->prof_att_ms[i]; b->prof_early_n[i] += b->prof_att_n[i]; }
+    b->prof_att_ms[i] = 0; b->prof_att_n[i] = 0;
+  }
 }
 extern "C" int dlg_backend_set_profiling(dlg_backend_t* b, int on)
 {
   if(!b) return DLG_ERR_ARG;
   DLG_HIP(hipStreamSynchronize(b->stream));
   dlg_prof_resolve(b);
-  for(int i = 0; i < DLG_PROF_COUNT; i++) { b->prof_ms[i] = 0; b->prof_n[i] = 0; }
+  for(int i = 0; i < DLG_PROF_COUNT; i++) { b->prof_ms[i] = 0; b->prof_n[i] = 0; b->prof_att_ms[i] = 0; b->prof_att_n[i] = 0; b->prof_early_ms[i] = 0; b->prof_early_n[i] = 0; }
   const int every = (on >> 16) & 0xff, sel = on & 0xffff;
   b->profiling = sel != 0;
   b->prof_mask = sel == 0 ? 0u : (sel == 1 ? ~0u : (unsigned)sel >> 1);
@@ -109,8 +126,19 @@ extern "C" int dlg_backend_get_profile(dlg_backend_t* b, double* ms_total, long*
   if(!b) return DLG_ERR_ARG;
   DLG_HIP(hipStreamSynchronize(b->stream));
   dlg_prof_resolve(b);
+  dlg_prof_commit(b, true);                  // (an attempt nobody reported on: its launches ran in full)
   for(int i = 0; i < n && i < DLG_PROF_COUNT; i++)
   { if(ms_total) ms_total[i] = b->prof_ms[i]; if(launches) launches[i] = b->prof_n[i]; }
+  return DLG_OK;
+}
+// the launches that returned early behind a failed factorisation (the lambda path), kept out of dlg_backend_get_profile
+extern "C" int dlg_backend_get_profile_early(dlg_backend_t* b, double* ms_total, long* launches, int n)
+{
+  if(!b) return DLG_ERR_ARG;
+  DLG_HIP(hipStreamSynchronize(b->stream));
+  dlg_prof_resolve(b);
+  for(int i = 0; i < n && i < DLG_PROF_COUNT; i++)
+  { if(ms_total) ms_total[i] = b->prof_early_ms[i]; if(launches) launches[i] = b->prof_early_n[i]; }
   return DLG_OK;
 }
 
@@ -422,6 +450,7 @@ extern "C" int dlg_backend_comm_size(dlg_backend_t* b, int* nranks)
   }
   return DLG_OK;
 }
+extern "C" int dlg_backend_has_rccl(dlg_backend_t* b) { return (b && b->rccl_comm) ? 1 : 0; }
 static void rccl_release(dlg_backend* b)
 {
   if(b->rccl_comm && b->rccl_owned && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(b->rccl_comm);
@@ -534,7 +563,8 @@ static int step_unprepare(dlg_backend* b)
   b->want_fork = b->fork_recorded = false; b->fork_gate = nullptr;
   const int held = b->pre_held;
   b->pre_held = -1;
-  if(held < 0 || b->type != DLG_SPARSE) return DLG_OK;
+  if(b->type != DLG_SPARSE) return DLG_OK;
+  if(held < 0) { sparse_release_held(b); return DLG_OK; }
   bool restored = false;
   DLG_CHECK(sparse_restore_factor(b, &restored));
   b->factor_slot = restored ? held : -1;
@@ -556,6 +586,7 @@ static int step_prepare(dlg_backend* b, int s)
   S.have_Jtx = true;                                           // (enqueued: the panels carry it as their right-hand side)
   DLG_CHECK(cauchy_fork_begin(b));
   int good = 0;
+  DlgProfCond pc(b);
   b->defer_factor_sync = true;
   const int rc = sparse_factorize(b, s, lam, &good);
   b->defer_factor_sync = false;
@@ -838,6 +869,7 @@ static int gauss_newton_impl(dlg_backend_t* b, int s, double* lambda_io, double*
     if(do_cauchy) DLG_CHECK(cauchy_fork_begin(b));
     if(b->factor_slot != s)
     {
+      DlgProfCond pc(b);
       b->defer_factor_sync = true;
       switch(b->type)
       {
@@ -855,6 +887,7 @@ static int gauss_newton_impl(dlg_backend_t* b, int s, double* lambda_io, double*
       cauchy_pending = true;
     }
     {
+      DlgProfCond pc(b);
       DlgProfScope ps(b, DLG_PROF_K6_SOLVE);
       if(b->type == DLG_SPARSE) DLG_CHECK(sparse_solve(b, S.Jt_x, S.gn));
       else                      DLG_CHECK(dense_solve(b, S.Jt_x, S.gn));
@@ -865,6 +898,7 @@ static int gauss_newton_impl(dlg_backend_t* b, int s, double* lambda_io, double*
     if(b->profiling) dlg_prof_resolve(b);
     if(cauchy_pending && !S.have_cauchy) { S.norm2_cauchy = b->h_scal[6]; S.have_cauchy = true; }
     good = (b->factor_slot == s) ? 1 : (b->type == DLG_SPARSE ? sparse_factor_ok(b) : dense_factor_ok(b));
+    if(b->profiling) dlg_prof_commit(b, good != 0);
     if(good) break;
     b->factor_slot = -1;
     lam = (lam == 0.0) ? 1e-10 : lam*10.0;                    // dogleg.c:138, 671-672, 812-813
@@ -967,6 +1001,10 @@ extern "C" int dlg_make_step(dlg_backend_t* b, int from, int to, int kind, doubl
 {
   DLG_CHECK(check_slot(b, from)); DLG_CHECK(check_slot(b, to));
   if(from == to) { dlg_set_error("dlg_make_step: from == to"); return DLG_ERR_ARG; }
+  // (a step from the cached vectors of `from` after the trial point was rejected: what dlg_point_eval enqueued for
+  // the trial point is dropped and the factor it displaced is the held one again BEFORE step_finish clears the
+  // spare panel buffer -- which is where the displaced factor lives)
+  DLG_CHECK(step_unprepare(b));
   double n2 = 0, kk = NAN, amax = 0;
   int nscal = 0;
   DLG_CHECK(make_step_enqueue(b, from, to, kind, trustregion, &nscal));
@@ -1004,6 +1042,7 @@ extern "C" int dlg_step(dlg_backend_t* b, int from, int to, int kind, double tru
 {
   DLG_CHECK(check_slot(b, from)); DLG_CHECK(check_slot(b, to));
   if(from == to) { dlg_set_error("dlg_step: from == to"); return DLG_ERR_ARG; }
+  DLG_CHECK(step_unprepare(b));                 // (as in dlg_make_step: the driver's retry after a rejected trial point)
   double n2 = 0, kk = NAN, amax = 0;
   int nscal = 0;
   DLG_CHECK(make_step_enqueue(b, from, to, kind, trustregion, &nscal));
@@ -1062,7 +1101,7 @@ extern "C" int dlg_take_step(dlg_backend_t* b, int from, int to, double trustreg
   const double lam_in = lam;
   if(b->pre_slot == from && b->pre_lambda != lam) b->pre_hint_input = true;      // (the guess was wrong: this caller does not keep lambda)
   const bool prepared_here = b->pre_slot == from && b->pre_lambda == lam;
-  if(prepared_here) { b->pre_slot = -1; b->pre_held = -1; } else DLG_CHECK(step_unprepare(b));
+  if(prepared_here) { b->pre_slot = -1; b->pre_held = -1; if(b->type == DLG_SPARSE) sparse_release_held(b); } else DLG_CHECK(step_unprepare(b));
   bool prepared = prepared_here;
   for(;;)
   {
@@ -1078,6 +1117,7 @@ extern "C" int dlg_take_step(dlg_backend_t* b, int from, int to, double trustreg
     if(prepared) { /* K5 is on the stream already */ }
     else if(b->factor_slot != from)
     {
+      DlgProfCond pc(b);
       b->defer_factor_sync = true;
       switch(b->type)
       {
@@ -1092,6 +1132,7 @@ extern "C" int dlg_take_step(dlg_backend_t* b, int from, int to, double trustreg
     if(do_cauchy) DLG_CHECK(cauchy_fork_enqueue(b, from, b->d_scal + 4));     // K3 beside K5 (second stream)
     if(!prepared)
     {
+      DlgProfCond pc(b);
       DlgProfScope ps(b, DLG_PROF_K6_SOLVE);
       if(b->type == DLG_SPARSE) DLG_CHECK(sparse_solve(b, F.Jt_x, F.gn));
       else                      DLG_CHECK(dense_solve(b, F.Jt_x, F.gn));
@@ -1131,7 +1172,8 @@ extern "C" int dlg_take_step(dlg_backend_t* b, int from, int to, double trustreg
     b->fold_scal = dlg_backend::NSCAL;       // (the last kernel of the step: it takes the scalars to the host with it)
     if(!b->ev_fetch) DLG_HIP(hipEventCreateWithFlags(&b->ev_fetch, hipEventDisableTiming));
     b->attach_stop = (b->ext_events && !side_copy && !(b->prof_mask >> DLG_PROF_K3K8_NORM2JV & 1u)) ? b->ev_fetch : nullptr; b->stop_attached = false;   // ... and the event the host waits for
-    const int rc8 = norm2_Jv(b, from, T.step, b->d_scal + 12, b->d_scal + 8);    // the other half of the expected improvement
+    int rc8;
+    { DlgProfCond pc(b); rc8 = norm2_Jv(b, from, T.step, b->d_scal + 12, b->d_scal + 8); }   // the other half of the expected improvement (returns early behind a failed factorisation unless the step is the Cauchy step)
     b->attach_stop = nullptr;
     b->fold_scal = 0;
     const bool p_done = b->p_copied;
@@ -1154,9 +1196,11 @@ extern "C" int dlg_take_step(dlg_backend_t* b, int from, int to, double trustreg
       out7[4] = NAN;
       out7[5] = b->h_scal[2];
       out7[6] = -2.0*b->h_scal[11] - b->h_scal[12];             // dogleg.c:1107-1109
+      if(b->profiling) dlg_prof_commit(b, b->type == DLG_SPARSE ? sparse_factor_ok(b) : dense_factor_ok(b));
       return DLG_OK;
     }
     good = (b->factor_slot == from) ? 1 : (b->type == DLG_SPARSE ? sparse_factor_ok(b) : dense_factor_ok(b));
+    if(b->profiling) dlg_prof_commit(b, good != 0);
     if(good) break;
     b->factor_slot = -1;
     lam = (lam == 0.0) ? 1e-10 : lam*10.0;                    // dogleg.c:138, 671-672, 812-813

@@ -151,11 +151,19 @@ struct dlg_backend
   hipEvent_t attach_stop = nullptr; bool stop_attached = false, ext_events = true;      // DLG_LAUNCH_LAST
   int prof_every = 1; unsigned prof_tick[DLG_PROF_COUNT] = {};      // every n-th occurrence of a timed phase carries events
   unsigned prof_mask = 0;     // the phases that are timed (bit = DLG_PROF_*)
-  struct ProfPair { hipEvent_t a, b; int id; };
+  struct ProfPair { hipEvent_t a, b; int id; bool cond; };
   std::vector<ProfPair> prof_pending;
   std::vector<hipEvent_t> prof_pool;
   double prof_ms[DLG_PROF_COUNT] = {0};
   long   prof_n[DLG_PROF_COUNT] = {0};
+  // Launches that return after their first barrier when the factorisation they belong to has failed (the lambda
+  // path: the rest of K5, K6, K8) are timed "conditionally" (prof_cond set by the caller around them): their
+  // times wait in prof_att_* until the attempt's outcome is known (dlg_prof_commit) and are then counted as
+  // full launches (prof_ms / prof_n) or as early returns (prof_early_*) -- a per-launch average over both
+  // would report bandwidths no kernel reaches (7 TB/s on config #5).
+  bool   prof_cond = false;
+  double prof_att_ms[DLG_PROF_COUNT] = {0};   long prof_att_n[DLG_PROF_COUNT] = {0};
+  double prof_early_ms[DLG_PROF_COUNT] = {0}; long prof_early_n[DLG_PROF_COUNT] = {0};
 
   int factor_slot = -1;       // slot whose JtJ the stored factor belongs to (-1: none)
 };
@@ -164,6 +172,13 @@ struct dlg_backend
 hipEvent_t dlg_prof_begin(dlg_backend* b);
 void dlg_prof_end(dlg_backend* b, int id, hipEvent_t start);
 void dlg_prof_resolve(dlg_backend* b);
+void dlg_prof_commit(dlg_backend* b, bool attempt_succeeded);
+struct DlgProfCond       // launches inside the scope return early if the factorisation of this attempt fails
+{
+  dlg_backend* b; bool was;
+  explicit DlgProfCond(dlg_backend* b_) : b(b_), was(b_->prof_cond) { b_->prof_cond = true; }
+  ~DlgProfCond() { b->prof_cond = was; }
+};
 struct DlgProfScope
 {
   dlg_backend* b; int id; hipEvent_t e;
@@ -293,6 +308,7 @@ int sparse_factorize(dlg_backend* b, int slot, double lambda, int* ok);         
 bool sparse_factor_ok(const dlg_backend* b);     // pivot flag of the last factorisation (after a sync)
 int sparse_solve(dlg_backend* b, const double* rhs, double* out);                // K6
 void sparse_hold_factor(dlg_backend* b);
+void sparse_release_held(dlg_backend* b);
 int sparse_restore_factor(dlg_backend* b, bool* restored);
 double sparse_current_lambda(const dlg_backend* b);                                 // of the last factorisation enqueued
 // blocked multi-right-hand-side solves (sparse_multi.hip / kernels_dense.hip): MR = 16 right-hand sides

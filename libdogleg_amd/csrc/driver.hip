@@ -131,9 +131,12 @@ bool cache_on() { static const bool on = getenv("DOGLEG_AMD_NO_BACKEND_CACHE") =
 
 dlg_backend_t* take_parked(int type, int N, int M, int nnz, int flags, int device)
 {
+  // (device -1 = the calling thread's current GPU, as dlg_backend_create resolves it: a backend parked on
+  // another GPU is not this solve's -- a device callback would get pointers and a stream of the wrong device)
+  if(device < 0 && hipGetDevice(&device) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
   std::lock_guard<std::mutex> lk(g_cache_mu);
   ParkedBackend& P = g_parked;
-  if(!P.be || P.type != type || P.N != N || P.M != M || P.nnz != nnz || P.flags != flags || (device >= 0 && P.device != device) ||
+  if(!P.be || P.type != type || P.N != N || P.M != M || P.nnz != nnz || P.flags != flags || P.device != device ||
      P.env != env_knobs_hash()) return nullptr;
   dlg_backend_t* be = P.be;
   P.be = nullptr;
@@ -803,11 +806,72 @@ void destroy(Driver* d)
   free(d);
 }
 
+// ---- the id file of the environment contract.  144 bytes: the 128-byte RCCL id, the tag "DLGAMD01", and the
+// 64-bit FNV-1a hash of the launch's run id (DOGLEG_AMD_RUN_ID, else TORCHELASTIC_RUN_ID, else empty).  A reader takes
+// only a complete file whose run id is its own: a file an earlier launch left at the path under another run id is
+// skipped (under the SAME run id -- or none -- the path has to be fresh for each launch; rank 0 removes what it finds
+// before it makes the id, which narrows that window, it cannot close it).  Written as tmp + rename: never seen half.
+unsigned long long run_id_hash(const char* run_id)
+{
+  unsigned long long g = 1469598103934665603ull;
+  for(const char* c = run_id ? run_id : ""; *c; c++) { g ^= (unsigned char)*c; g *= 1099511628211ull; }
+  return g;
+}
+const char* env_run_id()
+{
+  const char* r = getenv("DOGLEG_AMD_RUN_ID");
+  if(!r) r = getenv("TORCHELASTIC_RUN_ID");
+  return r ? r : "";
+}
+constexpr size_t ID_FILE_BYTES = 144;
+} // namespace
+extern "C" int dogleg_amd_id_file_publish(const char* path, const void* id128, const char* run_id)
+{
+  if(!path || !id128) { MSG("dogleg_amd_id_file_publish: bad arguments"); return -1; }
+  unsigned char rec[ID_FILE_BYTES];
+  memcpy(rec, id128, 128); memcpy(rec + 128, "DLGAMD01", 8);
+  const unsigned long long h = run_id_hash(run_id);
+  memcpy(rec + 136, &h, 8);
+  const std::string tmp = std::string(path) + ".tmp";
+  FILE* f = fopen(tmp.c_str(), "wb");
+  if(!f || fwrite(rec, 1, ID_FILE_BYTES, f) != ID_FILE_BYTES) { MSG("cannot write %s", tmp.c_str()); if(f) fclose(f); return -1; }
+  if(fclose(f) != 0) { MSG("cannot write %s", tmp.c_str()); return -1; }
+  if(rename(tmp.c_str(), path) != 0) { MSG("cannot rename %s to %s", tmp.c_str(), path); return -1; }
+  return 0;
+}
+extern "C" int dogleg_amd_id_file_wait(const char* path, void* id128_out, const char* run_id, int timeout_ms)
+{
+  if(!path || !id128_out) { MSG("dogleg_amd_id_file_wait: bad arguments"); return -1; }
+  const unsigned long long want = run_id_hash(run_id);
+  const auto t0 = std::chrono::steady_clock::now();
+  for(;;)
+  {
+    unsigned char rec[ID_FILE_BYTES + 1];
+    FILE* f = fopen(path, "rb");
+    if(f)
+    {
+      const size_t n = fread(rec, 1, sizeof(rec), f);
+      fclose(f);
+      unsigned long long h = 0;
+      if(n == ID_FILE_BYTES) memcpy(&h, rec + 136, 8);
+      if(n == ID_FILE_BYTES && !memcmp(rec + 128, "DLGAMD01", 8) && h == want) { memcpy(id128_out, rec, 128); return 0; }
+    }
+    if(std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() >= (double)timeout_ms) break;
+    struct timespec ts = {0, 20000000}; nanosleep(&ts, nullptr);
+  }
+  MSG("no RCCL id of this launch in %s after %d ms", path, timeout_ms);
+  return -1;
+}
+namespace {
+
 // DOGLEG_AMD_WORLD_SIZE (> 1), DOGLEG_AMD_RANK, DOGLEG_AMD_LOCAL_RANK (the GPU; default: the rank),
-// DOGLEG_AMD_RCCL_ID_FILE: rank 0 writes the 128-byte RCCL id there (tmp + rename), the others wait for it.
-// The communicator is made once per process -- a backend that only holds it -- and shared by every solve.
+// DOGLEG_AMD_RCCL_ID_FILE: rank 0 writes the RCCL id there (dogleg_amd_id_file_publish), the others wait for it
+// (dogleg_amd_id_file_wait, two minutes; DOGLEG_AMD_RUN_ID names the launch).  The communicator is made once per
+// process -- a backend that only holds it -- and shared by every solve; solves may start on several threads.
+std::mutex g_env_comm_mu;
 bool env_communicator(Comm* cm)
 {
+  std::lock_guard<std::mutex> lk(g_env_comm_mu);
   EnvComm& E = g_env_comm;
   if(!E.tried)
   {
@@ -822,26 +886,13 @@ bool env_communicator(Comm* cm)
       E.rank = atoi(rk); E.nranks = n; E.device = lr ? atoi(lr) : E.rank;
       if(E.rank < 0 || E.rank >= n) { MSG("DOGLEG_AMD_RANK=%d of %d", E.rank, n); return false; }
       unsigned char id[128];
-      std::string tmp = std::string(idf) + ".tmp";
       if(E.rank == 0)
       {
+        (void)remove(idf);                          // (what an earlier launch left there)
         if(dlg_rccl_unique_id(id) != DLG_OK) { MSG("RCCL id: %s", dlg_last_error()); return false; }
-        FILE* f = fopen(tmp.c_str(), "wb");
-        if(!f || fwrite(id, 1, 128, f) != 128) { MSG("cannot write %s", tmp.c_str()); if(f) fclose(f); return false; }
-        fclose(f);
-        if(rename(tmp.c_str(), idf) != 0) { MSG("cannot rename %s", tmp.c_str()); return false; }
+        if(dogleg_amd_id_file_publish(idf, id, env_run_id()) != 0) return false;
       }
-      else
-      {
-        bool got = false;
-        for(int tries = 0; tries < 1200 && !got; tries++)          // up to 2 minutes
-        {
-          FILE* f = fopen(idf, "rb");
-          if(f) { got = fread(id, 1, 128, f) == 128; fclose(f); }
-          if(!got) { struct timespec ts = {0, 100000000}; nanosleep(&ts, nullptr); }
-        }
-        if(!got) { MSG("rank %d: no RCCL id in %s after 2 minutes", E.rank, idf); return false; }
-      }
+      else if(dogleg_amd_id_file_wait(idf, id, env_run_id(), 120000) != 0) return false;
       // (a backend with nothing in it but the communicator: dlg_backend_share_rccl hands it to the solves)
       if(dlg_backend_create(&E.holder, DLG_DENSE_PRODUCTS, 1, 0, 0, 0, E.device) != DLG_OK ||
          dlg_backend_init_rccl(E.holder, E.rank, E.nranks, id) != DLG_OK)

@@ -1364,6 +1364,9 @@ int sparse_zero_spare(dlg_backend* b)
 {
   SparseSym* Y = b->sym;
   if(!Y || !Y->spare_dirty || !Y->Lx_spec) return DLG_OK;
+  // the spare buffer holds a factor somebody may still turn to (sparse_hold_factor: the one a factorisation
+  // enqueued ahead of the caller's decision displaced): it is cleared once that question is settled
+  if(Y->held_Lx && Y->held_Lx == Y->Lx_spec) return DLG_OK;
   Y->spare_dirty = false;
   DLG_HIP(hipMemsetAsync(Y->Lx_spec, 0, sizeof(double)*((size_t)Y->H.lx_size + 8), b->stream));
   Y->spare_zeroed = true; Y->spare_stream = b->stream;

@@ -106,8 +106,10 @@ __device__ __forceinline__ void mf_add_children(double* P, double* Wt, int ntri,
         // no read round trip).  A child adds to an address at most once and the barrier orders the
         // children's instruction streams; the adds of one CU to one address reach L2 through the
         // same queue in that order (waiting for L2's acknowledgement before every barrier --
-        // s_waitcnt vmcnt(0) -- was measured: it doubles this phase; bitwise reproducibility is
-        // checked on a pattern that takes this path, tests/test_scale_gpu.py).
+        // s_waitcnt vmcnt(0) -- was measured: it doubles this phase).  With sliced fronts no supernode of
+        // config #4 comes here any more; the run-to-run bit tests that pin this path are
+        // tests/test_scale_gpu.py::test_update_matrices_summed_in_hbm_are_bitwise_reproducible_config4
+        // (slices off: 23 update matrices of the region summed here) and ..._config5.
 #pragma unroll
         for(int u = 0; u < MF_SLOTS; u++) if(e0 + u*NT < npad) old[u] = P[(d[u] & 0x8000) ? 0 : d[u]];
 #pragma unroll

@@ -113,6 +113,7 @@ void sparse_reset(dlg_backend* b)
   Y->spec_valid = false; Y->spec_inflight = false; Y->spec_slot = -1; Y->spec_J = nullptr;
   Y->aug_rhs = nullptr; Y->spec_aug_rhs = nullptr; Y->fin_pending_rhs = nullptr; Y->fin_pending_Lx = nullptr;
   Y->info_armed = false; Y->info_clean = false; Y->spec_gen = -1;
+  Y->held_Lx = nullptr;
 }
 
 int sparse_set_pattern(dlg_backend* b, const int* colptr, const int* rowidx)
@@ -462,6 +463,8 @@ void sparse_hold_factor(dlg_backend* b)
   SparseSym* Y = b->sym;
   Y->held_Lx = Y->Lx; Y->held_aug = Y->aug_rhs; Y->held_lambda = Y->cur_lambda;
 }
+// the enqueued factorisation is the one the caller went on with: the displaced factor is nobody's any more
+void sparse_release_held(dlg_backend* b) { if(b->sym) b->sym->held_Lx = nullptr; }
 int sparse_restore_factor(dlg_backend* b, bool* restored)
 {
   SparseSym* Y = b->sym;

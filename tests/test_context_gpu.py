@@ -73,3 +73,64 @@ def test_sparse_context(gpu, tmp_path):
     assert abs(float.fromhex(o["norm2_x"][0]) - x @ x) <= 1e-12 * (x @ x)
     assert np.array_equal(_f(o["p"]), _f(o["p_out"]))
     assert o["have_factorization"][0] == "1"
+
+
+@pytest.mark.parametrize("presolve", [True, False])
+def test_factor_of_a_returned_context_survives_rejected_trials(gpu, presolve, monkeypatch):
+    """A sparse solve that ends after SEVERAL rejected trial points (every trial point is made worse than the
+    start, the trust region collapses: dogleg.c:1462-1466) hands back a context whose beforeStep reports
+    have_factorization; the factor behind it must be the start point's.  The evaluation of a trial point enqueues
+    that point's factorisation in the held factor's place (step_prepare), the driver's retry after the rejection
+    is dlg_step from the start point's cached vectors: the held factor has to come back BEFORE the step's tail
+    clears the spare panel buffer (ADVICE r3 -- it was zeroed there, and solves with the returned factor gave
+    garbage).  Checked against the oracle's factorisation of the start point."""
+    import ctypes as C
+    from libdogleg_amd import capi
+    from libdogleg_amd.ctypes_defs import dptr, iptr
+    from tests import oracle_api as oa
+    if not presolve:
+        monkeypatch.setenv("DOGLEG_AMD_NO_PRESOLVE", "1")
+    monkeypatch.setenv("DOGLEG_AMD_NO_BACKEND_CACHE", "1")
+    prob = oa.BAProblem(12, 120, 720, seed=4, eps=0.4, p0_spread=0.6)
+    p0 = prob.p0()
+    inner = capi.CB_SPARSE(prob.cb.value)
+    nevals = [0]
+
+    @capi.CB_SPARSE
+    def cb(p, x, Jt, cookie):
+        inner(p, x, Jt, cookie)
+        nevals[0] += 1
+        if nevals[0] > 1:                       # every trial point: much worse than the start -> rho < 0, rejected
+            xv = np.ctypeslib.as_array(x, shape=(prob.M,))
+            xv *= 50.0
+    L = capi.lib()
+    prm = oa.default_params()
+    prm.max_iterations = 10
+    prm.trustregion0 = 1e3
+    prm.trustregion_threshold = 1e-4
+    p = p0.copy()
+    ctx = C.c_void_p()
+    r = L.dogleg_optimize2(dptr(p), prob.N, prob.M, prob.nnz, C.cast(cb, C.c_void_p), prob.cookie, C.byref(prm),
+                           C.byref(ctx))
+    assert r >= 0 and ctx.value
+    assert nevals[0] >= 4, "the scenario needs at least three rejected trial points"
+    assert np.array_equal(p, p0)                # nothing was accepted
+    be = L.dogleg_amd_backend(ctx)
+    rhs = np.cos(0.3 * np.arange(prob.N))
+    got, ok = None, 0
+    for slot in (0, 1):
+        out = np.zeros(prob.N)
+        if L.dlg_solve_with_factor(be, slot, dptr(rhs), dptr(out), 1) == 0:
+            got, ok = out, ok + 1
+    assert ok == 1, "exactly one point holds the factor"
+    x0, J0 = prob.eval(p0)
+    Jp, Ji = prob.pattern()
+    O = oa.oracle()
+    F = O.orc_sparse_analyze(prob.N, prob.M, iptr(Jp), iptr(Ji))
+    assert O.orc_sparse_factorize(F, iptr(Jp), iptr(Ji), dptr(J0), 0.0) == prob.N
+    ref = np.zeros(prob.N)
+    O.orc_sparse_solve(F, dptr(rhs), dptr(ref))
+    O.orc_sparse_free(F)
+    assert np.all(np.isfinite(got))
+    assert np.linalg.norm(got - ref) <= 1e-10 * np.linalg.norm(ref)
+    L.dogleg_freeContext(C.byref(ctx))

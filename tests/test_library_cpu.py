@@ -505,3 +505,47 @@ def test_documented_limits_are_reported_cleanly():
     Ji = np.concatenate(rows).astype(np.int32)
     st = capi.symbolic_probe(3000, len(rows), Jp, Ji)
     assert st["supernodes"] > 0
+
+
+def _id_file_reader(path, run_id, q):
+    import ctypes as C
+    from libdogleg_amd import capi
+    L = capi.lib()
+    out = (C.c_ubyte * 128)()
+    rc = L.dogleg_amd_id_file_wait(path.encode(), out, run_id.encode(), 20000)
+    q.put((rc, bytes(out)))
+
+
+def test_id_file_rendezvous_between_two_processes(tmp_path):
+    """the id file of the environment contract (DOGLEG_AMD_RCCL_ID_FILE; reference interface behind it:
+    dogleg.h:278-302): a reader process waits while the path holds nothing, a half-written file, a file of an
+    EARLIER launch (other run id) -- and takes this launch's 128 bytes once rank 0 has published them.  No GPU
+    call on either side."""
+    import multiprocessing as mp
+    import time
+    L = capi.lib()
+    path = str(tmp_path / "id")
+    stale = bytes(range(128))
+    assert L.dogleg_amd_id_file_publish(path.encode(), stale, b"launch-1") == 0
+    assert os.path.getsize(path) == 144
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    pr = ctx.Process(target=_id_file_reader, args=(path, "launch-2", q))
+    pr.start()
+    time.sleep(1.0)
+    assert q.empty(), "the reader took the id of another launch"
+    open(path, "wb").write(b"\x01" * 77)                       # a torn file is not an id either
+    time.sleep(0.5)
+    assert q.empty()
+    fresh = bytes((7 * i + 3) % 256 for i in range(128))
+    assert L.dogleg_amd_id_file_publish(path.encode(), fresh, b"launch-2") == 0
+    rc, got = q.get(timeout=30)
+    pr.join(30)
+    assert rc == 0 and got == fresh
+    assert not os.path.exists(path + ".tmp")
+    # a reader whose launch never publishes gives up with -1 (and says so), it does not hang
+    out = (C.c_ubyte * 128)()
+    t0 = time.time()
+    assert L.dogleg_amd_id_file_wait(path.encode(), out, b"launch-3", 300) == -1
+    assert time.time() - t0 < 5
+    assert L.dogleg_amd_id_file_wait(None, out, b"", 10) == -1

@@ -168,6 +168,54 @@ def test_bench_loop_matches_the_oracle_step_config4(gpu):
     print(f"bench loop, config #4: max |step_gpu - step_oracle| over 7 steps = {worst:.3e}")
 
 
+def test_run_steps_entry_matches_the_oracle_step_config4(gpu):
+    """dlg_run_steps -- the ONE C call bench.py's timed region is (backend.hip; bind the next resident copy,
+    dlg_point_eval, dlg_take_step, K times) -- on config #4 at full size with three rotating copies that hold
+    DIFFERENT inputs (the model evaluated at three points): after 1, 2, 3 and 5 steps the step vector (VEC_STEP)
+    and p_new left by the LAST step against orc_step_sparse on that copy's inputs (<= 1e-10), and its scalars."""
+    O = oa.oracle()
+    prob = oa.BAProblem(2499, 45000, 500000, seed=11)
+    N, M, nnz = prob.N, prob.M, prob.nnz
+    Jp, Ji = prob.pattern()
+    p = prob.p0()
+    rng = np.random.default_rng(5)
+    inputs = [prob.eval(p + 0.02 * c * rng.standard_normal(N)) for c in range(3)]
+    F = O.orc_sparse_analyze(N, M, iptr(Jp), iptr(Ji))
+    refs = []
+    for x, Jx in inputs:
+        work = np.zeros(5 * N)
+        o8 = np.zeros(8)
+        assert O.orc_step_sparse(F, N, M, iptr(Jp), iptr(Ji), dptr(Jx), dptr(x), dptr(p), 0.0, dptr(work), dptr(o8)) == 0
+        refs.append((work[3*N:4*N].copy(), work[4*N:5*N].copy(), o8.copy()))
+    O.orc_sparse_free(F)
+    # one trust region that makes every copy's step an interpolated one (what orc_step_sparse takes)
+    tr = None
+    be = capi.Backend(capi.DLG_SPARSE, N, M, nnz)
+    be.set_pattern(Jp, Ji)
+    be.set_speculation(True)
+    be.set_p(0, p)
+    d_x = [capi.DeviceArray(x) for x, _ in inputs]
+    d_J = [capi.DeviceArray(Jx) for _, Jx in inputs]
+    worst = 0.0
+    for nsteps in (1, 2, 3, 5):
+        c = (nsteps - 1) % 3
+        step_ref, pnew_ref, o8 = refs[c]
+        tr = 0.5 * (o8[1] ** 0.5 + o8[2] ** 0.5)          # the oracle's own choice: midway between the two steps
+        r, kind = be.run_steps(0, 1, nsteps, [a.ptr for a in d_x], [a.ptr for a in d_J], 0, tr, 0.0)
+        assert kind == capi.KIND_INTERP and r["lam"] == 0.0
+        step = be.download(1, capi.VEC_STEP)
+        pnew = be.download(1, capi.VEC_P)
+        d = np.linalg.norm(step - step_ref)
+        worst = max(worst, d)
+        assert d <= 1e-10, (nsteps, d)
+        assert np.max(np.abs(pnew - pnew_ref)) <= 1e-10
+        assert abs(r["n2x"] - o8[0]) <= 1e-12 * o8[0]
+        assert abs(r["n2c"] - o8[1]) <= 1e-10 * o8[1] and abs(r["n2g"] - o8[2]) <= 1e-9 * o8[2]
+        assert abs(r["k"] - o8[3]) <= 1e-9 and abs(r["ei"] - o8[5]) <= 1e-9 * abs(o8[5])
+    be.close()
+    print(f"dlg_run_steps, config #4, three different resident copies: max |step_gpu - step_oracle| = {worst:.3e}")
+
+
 def test_ill_conditioned_lambda_step_parity(gpu):
     """configs[4] shape, down-scaled: column scales over 4 decades + exactly-zero columns"""
     # (bar: 1e-9 -- round 2 measured 6.5e-11 at full size; cond(JtJ + 1e-10 I) ~ 1e13 along the zeroed columns)
@@ -218,6 +266,53 @@ def test_run_to_run_bitwise_reproducible_config4(gpu):
     be.close()
     for n2g, gn in outs[1:]:
         assert n2g == outs[0][0] and np.array_equal(gn, outs[0][1])
+
+
+def _repeat_gn(prob, n, lam0=0.0):
+    Jp, Ji = prob.pattern()
+    p = prob.p0()
+    x, Jx = prob.eval(p)
+    be = capi.Backend(capi.DLG_SPARSE, prob.N, prob.M, prob.nnz)
+    be.set_pattern(Jp, Ji)
+    be.set_p(0, p)
+    outs = []
+    for _ in range(n):
+        be.upload(0, x, Jx)
+        be.eval(0)
+        lam, n2g = be.gauss_newton(0, lam0)
+        outs.append((lam, n2g, be.download(0, capi.VEC_GN)))
+    be.close()
+    return outs, capi.region_probe(prob.N, prob.M, Jp, Ji)
+
+
+def test_update_matrices_summed_in_hbm_are_bitwise_reproducible_config4(gpu, monkeypatch):
+    """The one path of the numeric phase that relies on HBM atomics (sparse_factor.hip, mf_add_children: an update
+    matrix that does not fit LDS is summed in HBM by fire-and-forget adds, children separated by workgroup
+    barriers).  With sliced fronts no supernode of config #4 takes it any more, so the slices are switched off
+    (DOGLEG_AMD_NO_FRONT_SLICES: the 66-column separators keep their update matrices in HBM again): four
+    factorisations of the same input, the same bits -- and the same Gauss-Newton step as the default schedule's
+    to rounding."""
+    prob = oa.BAProblem(2499, 45000, 500000, seed=11)
+    ref, _ = _repeat_gn(prob, 1)
+    monkeypatch.setenv("DOGLEG_AMD_NO_FRONT_SLICES", "1")
+    monkeypatch.setenv("DOGLEG_AMD_NO_SYM_CACHE", "1")
+    outs, reg = _repeat_gn(prob, 4)
+    print("one-launch region without slices:", reg)
+    assert reg["hbm_update_matrices"] > 0, "the schedule under test sums no update matrix in HBM: the test pins nothing"
+    for lam, n2g, gn in outs[1:]:
+        assert n2g == outs[0][1] and np.array_equal(gn, outs[0][2])
+    assert np.linalg.norm(outs[0][2] - ref[0][2]) <= 1e-10 * max(1.0, np.linalg.norm(ref[0][2]))
+
+
+def test_update_matrices_summed_in_hbm_are_bitwise_reproducible_config5(gpu):
+    """config #5 at full size: its wide separators (96 columns, 289 rows) take the HBM-summed path by default;
+    four times the whole lambda path (the factorisation at 0 fails, at 1e-10 it stands), the same bits"""
+    prob = oa.BAProblem(8333, 149999, 2500000, seed=11, scale_decades=4.0, n_zero_cols=3)
+    outs, reg = _repeat_gn(prob, 4)
+    print("one-launch region of config #5:", reg)
+    assert outs[0][0] >= 1e-10
+    for lam, n2g, gn in outs[1:]:
+        assert lam == outs[0][0] and n2g == outs[0][1] and np.array_equal(gn, outs[0][2])
 
 
 def test_dense_config2_shape_downscaled(gpu):

@@ -628,6 +628,21 @@ def test_factor_and_solve_ahead_of_the_decision_change_no_bit(gpu, lf, monkeypat
             be.eval(1)
             lam, r, pC = be.take_step(1, 0, tr, 0.0)
             res += [tuple(sorted(r.items())), pC.copy()]
+        elif script == "driver-retry":
+            # what driver.hip does after a rejected trial point: the step from A again out of A's CACHED vectors
+            # (dlg_step, not dlg_take_step), while B's factorisation sits enqueued in A's place -- A's factor must
+            # come back before the step's tail clears the spare panel buffer (it was zeroed there)
+            n2, k, amax, ei, pB2 = be.step(0, 1, capi.KIND_GN, 0.25 * tr)
+            rhs = np.linspace(-1.0, 1.0, prob.N)
+            res += [n2, k, amax, ei, pB2.copy(), be.solve_with_factor(0, rhs)]
+            n2, k, amax, pB3 = be.make_step(0, 1, capi.KIND_CAUCHY, 0.125 * tr)
+            res += [n2, k, amax, pB3.copy(), be.solve_with_factor(0, rhs)]
+            xB2, JB2 = prob.eval(pB2)
+            be.upload(1, xB2, JB2)
+            be.eval(1)                                     # prepared again, A's factor displaced again
+            n2, k, amax, ei, pB4 = be.step(0, 1, capi.KIND_GN, 0.0625 * tr)
+            res += [n2, ei, pB4.copy(), be.solve_with_factor(0, rhs)]
+            assert np.all(np.isfinite(res[-1])) and np.max(np.abs(res[-1])) > 0
         elif script == "held":
             rhs = np.linspace(-1.0, 1.0, prob.N)
             res += [be.solve_with_factor(0, rhs)]          # A's factor is still the held one
@@ -648,8 +663,8 @@ def test_factor_and_solve_ahead_of_the_decision_change_no_bit(gpu, lf, monkeypat
             return np.array_equal(a, b)
         if isinstance(a, tuple):
             return all(ka == kb and (va == vb or (va != va and vb != vb)) for (ka, va), (kb, vb) in zip(a, b))
-        return a == b
-    for script in ("accept", "reject", "held", "lambda"):
+        return a == b or (a != a and b != b)
+    for script in ("accept", "reject", "driver-retry", "held", "lambda"):
         monkeypatch.delenv("DOGLEG_AMD_NO_PRESOLVE", raising=False)
         got = run(script)
         monkeypatch.setenv("DOGLEG_AMD_NO_PRESOLVE", "1")
