@@ -1434,7 +1434,7 @@ int sparse_factor_levels(dlg_backend* b)
     {
       // the persistent top region: every remaining level in one launch (sparse_factor_setup)
       const int np = Y->pr_nwg;           // the region's own work items (replicas) and children records
-      const int fmode = 2 + 4*Y->pr_stage + (Y->fac_ahead ? 8 : 0) + (Y->fac_b16 ? 16 + 32*Y->fac_b16_maxw : 0) + 256*l;
+      const int fmode = 2 + 4*Y->pr_stage + (Y->fac_ahead ? 8 : 0) + (Y->fac_b16 ? 16 + 32*Y->fac_b16_maxw : 0) + 256*(l & 31);
       int* fl = Y->fac_flag; const int ep = ++Y->fac_epoch;
       if(gate_here && l > 0 && n < 256) dlg_fork_gate(b, fl + np, ep);
       const int64_t pacc = Y->pr_acc ? (int64_t)(Y->pr_acc - Y->uscr) : 0;
@@ -1457,7 +1457,7 @@ int sparse_factor_levels(dlg_backend* b)
     {
       const int o = H.fw_lvl_ptr[l];
       const int use_ahead = (Y->fac_ahead ? 8 : 0) + (Y->fac_b16 ? 16 + 32*Y->fac_b16_maxw : 0);     // barrier-free sweep: measured slower (tools/micro/bench_ahead), kept for experiments
-      const int fmode = ((l >= H.mf_level0) ? 2 : Y->syrk_fused[l]) + 4*Y->fac_stage[l] + use_ahead + 256*l;
+      const int fmode = ((l >= H.mf_level0) ? 2 : Y->syrk_fused[l]) + 4*Y->fac_stage[l] + use_ahead + 256*(l & 31);
       if(Y->fac_nt[l] == 128)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_factor_level<128>), dim3(n), dim3(128), Y->fac_lds[l], st,
                            Y->fw_item + o, Y->mf_rec, Y->sn_bd_col, Y->mf_dst, Y->Lx, Y->top_scr, Y->d_info, Y->uscr, fmode, (int*)nullptr, 0, DlgHandoff{nullptr, 0, 0}, (int64_t)0);
