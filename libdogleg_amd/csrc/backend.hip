@@ -643,6 +643,12 @@ extern "C" int dlg_point_eval(dlg_backend_t* b, int s, double* norm2_x, double* 
       DLG_HIP(hipMemcpyAsync(b->d_scal, b->d_red + b->N, sizeof(double), hipMemcpyDeviceToDevice, b->stream));
     }
     bool norms_on_host = false;
+    // The partial-sum stages of JtJ and the norm kernel the host waits for leave the critical stream where the
+    // factorisation of this point is going to follow at once (step_prepare): the main stream goes from Jt*x
+    // straight to the augmented row and the leaf level, the second stream does norms and stages meanwhile.
+    const bool side = pair && fused && b->presolve && b->host_finals && b->part_nranks <= 1 && sparse_fin_side_ok(b);
+    struct SideGuard { dlg_backend* b; ~SideGuard() { (void)sparse_fin_side_end(b); } } side_guard{b};     // (an error on the way: the main stream is b->stream again)
+    if(side) DLG_CHECK(sparse_fin_side_begin(b));
     if(pair)
     {
       // (the event the host waits for rides on the norm kernel where that is the last thing the host reads)
@@ -663,6 +669,7 @@ extern "C" int dlg_point_eval(dlg_backend_t* b, int s, double* norm2_x, double* 
       if(!(norms_on_host && b->stop_attached)) DLG_HIP(hipEventRecord(b->ev_fetch, b->stream));
       b->stop_attached = false;
       DLG_CHECK(sparse_assemble_finish(b));
+      if(side) DLG_CHECK(sparse_fin_side_end(b));
       // the factorisation and the Gauss-Newton solve follow at once (dlg_take_step finds them enqueued): the
       // chip works on them while the host fetches the norms and decides
       if(b->presolve && !b->sharded() && b->part_nranks <= 1) DLG_CHECK(step_prepare(b, s));
@@ -716,15 +723,28 @@ static int cauchy_fork_begin(dlg_backend* b)
   return DLG_OK;
 }
 // holds the second stream until the one-launch region of the factorisation is on the chip (dlg_fork_gate)
-__global__ void k_gate_wait(const int* gate, int epoch)
+__global__ void k_gate_wait(const int* gate, int epoch, int* status = nullptr)
 {
   if(threadIdx.x != 0) return;
   int spins = 0;
-  while(__hip_atomic_load(gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch)
+  while(__hip_atomic_load(gate, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != epoch)
   {
     __builtin_amdgcn_s_sleep(8);
-    if(++spins > (1 << 21)) break;            // (a launch that never comes: go on, it is only timing)
+    if(++spins > (1 << 21))
+    {
+      // (a launch that never comes.  status == NULL: go on, it is only timing; else the wait ORDERS work and the
+      // caller must not use what follows: reported like a hand-off that timed out)
+      if(status) atomicOr(status, DLG_HANDOFF_FACTOR);
+      break;
+    }
   }
+}
+int dlg_gate_wait(dlg_backend* b, hipStream_t st, const int* gate, int epoch, bool report)
+{
+  hipLaunchKernelGGL(k_gate_wait, dim3(1), dim3(64), 0, st, gate, epoch,
+                     report ? reinterpret_cast<int*>(b->d_scal + (dlg_backend::NSCAL - 2)) : (int*)nullptr);
+  DLG_LAUNCH_CHECK();
+  return DLG_OK;
 }
 static int cauchy_fork_enqueue(dlg_backend* b, int s, double* sc)
 {
@@ -734,7 +754,7 @@ static int cauchy_fork_enqueue(dlg_backend* b, int s, double* sc)
   b->fork_gate = nullptr;
   if(!b->fork_recorded) DLG_HIP(hipEventRecord(b->ev_fork, b->stream));
   b->want_fork = false; b->fork_recorded = false;
-  if(gate) hipLaunchKernelGGL(k_gate_wait, dim3(1), dim3(64), 0, b->aux_stream, (const int*)gate, gate_epoch);
+  if(gate) hipLaunchKernelGGL(k_gate_wait, dim3(1), dim3(64), 0, b->aux_stream, (const int*)gate, gate_epoch, (int*)nullptr);
   else     DLG_HIP(hipStreamWaitEvent(b->aux_stream, b->ev_fork, 0));
   hipStream_t main_stream = b->stream;
   b->stream = b->aux_stream;

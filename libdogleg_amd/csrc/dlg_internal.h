@@ -308,6 +308,14 @@ int sparse_factorize(dlg_backend* b, int slot, double lambda, int* ok);         
 bool sparse_factor_ok(const dlg_backend* b);     // pivot flag of the last factorisation (after a sync)
 int sparse_solve(dlg_backend* b, const double* rhs, double* out);                // K6
 void sparse_hold_factor(dlg_backend* b);
+// the partial-sum stages of an evaluation-time assembly on the SECOND stream (sparse_assemble.hip, "fin on the side")
+bool sparse_fin_side_ok(const dlg_backend* b);
+int  sparse_fin_side_begin(dlg_backend* b);      // main: augmented row + flag A; second stream: waits for flag A; b->stream := second stream
+int  sparse_fin_side_end(dlg_backend* b);        // second stream: flag B behind the partial-sum stages; b->stream := main stream
+int  sparse_fin_side_gate(dlg_backend* b);       // main: wait for flag B if stages are still owed (no-op otherwise)
+// one wave that holds stream `st` until *gate == epoch (bounded: it is a matter of ordering work the chip has
+// long finished in every measured case; a gate that never opens is reported through the hand-off status word)
+int  dlg_gate_wait(dlg_backend* b, hipStream_t st, const int* gate, int epoch, bool report);
 void sparse_release_held(dlg_backend* b);
 int sparse_restore_factor(dlg_backend* b, bool* restored);
 double sparse_current_lambda(const dlg_backend* b);                                 // of the last factorisation enqueued

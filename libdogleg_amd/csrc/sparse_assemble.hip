@@ -708,9 +708,11 @@ __global__ void __launch_bounds__(TPB) k_set_aug_row(double* __restrict__ Lx, co
                                                      const double* __restrict__ rhs, int n,
                                                      int* __restrict__ info,
                                                      const int* __restrict__ sn_owner, int phase,
-                                                     const char* __restrict__ skip)
+                                                     const char* __restrict__ skip, int* flag = nullptr, int flag_epoch = 0)
 {
   const int k = blockIdx.x*TPB + threadIdx.x;
+  // (fin on the side: this kernel runs behind the sums of rhs = Jt*x in stream order -- the second stream may read them)
+  if(k == 0 && flag) __hip_atomic_store(flag, flag_epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
   if(k == 0 && phase <= 0) *info = 0x7fffffff;          // re-arm the pivot flag of the factorisation that follows
   if(k >= n) return;
   if(phase >= 0 && !phase_has(sn_owner, col_sn[k], phase)) return;
@@ -972,6 +974,66 @@ int sparse_assemble_finish(dlg_backend* b)
   }
   return DLG_OK;
 }
+// ---- fin on the side ------------------------------------------------------------------------------------------
+// An evaluation whose point is factorised at once (backend.hip, step_prepare) had, between the assembly kernel and the
+// leaf level of the factorisation, on ONE stream: the Jt*x record sums, the norm kernel the host waits for, a gap behind
+// it (a kernel somebody listens to holds the next dispatch back), and the two partial-sum stages of JtJ -- 35 us of
+// small kernels of which the leaf level needs only Jt*x (for the augmented row).  The stages write blocks of the
+// ANCESTORS' panels only (checked when the schedules are set up: every block a stage stores lies in a supernode above
+// level 0), so they and the norm kernel go to the second stream:
+//   main stream:    ... Jt*x sums | augmented row (+ flag A) | leaf level | [gate: flag B] update gather | region ...
+//   second stream:  gate: flag A | norms (the host's event rides on them) | stage 1 | stage 2 | flag B
+// The gates are one-wave kernels polling a word (no event packets on the critical stream: an event between two
+// kernels costs 5 - 8 us there); flag B is long up when the main stream asks.  Whoever touches the ancestors' panels
+// or the partial-sum buffers next on the main stream asks first (sparse_fin_side_gate: lambda on the diagonal, the
+// first update kernel, another assembly).  Same kernels, same sums, same bits.
+__global__ void k_fin_flag(int* flag, int epoch)
+{
+  if(threadIdx.x == 0) __hip_atomic_store(flag, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+bool sparse_fin_side_ok(const dlg_backend* b)
+{
+  const SparseSym* Y = b->sym;
+  return Y && Y->fin_side_sched_ok && Y->fin_flag && b->aux_stream && !Y->lf_on && Y->fin_pending_Lx && Y->fin_pending_rhs &&
+         !Y->fin_main && b->stream != b->aux_stream;
+}
+int sparse_fin_side_begin(dlg_backend* b)
+{
+  SparseSym* Y = b->sym;
+  const SymHost& H = Y->H;
+  DLG_CHECK(sparse_fin_side_gate(b));                  // (stages of an evaluation nobody factorised: done with the buffers first)
+  const int ep = ++Y->fin_epoch;
+  // main stream, behind the Jt*x sums: the augmented row of every panel (the stages never touch a last row), the pivot
+  // flag re-armed -- and the word that tells the second stream that Jt*x is final
+  hipLaunchKernelGGL(k_set_aug_row, dim3(dlg_cdiv(H.N, TPB)), dim3(TPB), 0, b->stream, Y->fin_pending_Lx, Y->col_sn, Y->augpos,
+                     Y->perm, Y->fin_pending_rhs, H.N, Y->d_info, Y->sn_owner, -1, (const char*)nullptr, Y->fin_flag, ep);
+  DLG_LAUNCH_CHECK();
+  Y->spec_aug_rhs = Y->fin_pending_rhs; Y->info_clean = true;
+  Y->fin_pending_rhs = nullptr;                        // (sparse_assemble_finish: the stages only)
+  DLG_CHECK(dlg_gate_wait(b, b->aux_stream, Y->fin_flag, ep, true));
+  Y->fin_main = b->stream;
+  b->stream = b->aux_stream;
+  return DLG_OK;
+}
+int sparse_fin_side_end(dlg_backend* b)
+{
+  SparseSym* Y = b->sym;
+  if(!Y || !Y->fin_main) return DLG_OK;
+  hipStream_t side = b->stream;
+  b->stream = Y->fin_main; Y->fin_main = nullptr;
+  hipLaunchKernelGGL(k_fin_flag, dim3(1), dim3(64), 0, side, Y->fin_flag + 1, Y->fin_epoch);
+  Y->fin_side_owed = Y->fin_epoch;
+  DLG_LAUNCH_CHECK();
+  return DLG_OK;
+}
+int sparse_fin_side_gate(dlg_backend* b)
+{
+  SparseSym* Y = b->sym;
+  if(!Y || !Y->fin_side_owed) return DLG_OK;
+  const int ep = Y->fin_side_owed;
+  Y->fin_side_owed = 0;
+  return dlg_gate_wait(b, Y->fin_main ? Y->fin_main : b->stream, Y->fin_flag + 1, ep, true);
+}
 #define ASM_LAUNCH(kernel, grid, block, shm, st, ...) \
   do { hipEvent_t e0 = nullptr, e1 = nullptr; \
        if(timed_single && dlg_prof_pair(b, DLG_PROF_K4_KERNEL, &e0, &e1)) hipExtLaunchKernelGGL(kernel, grid, block, shm, st, e0, e1, 0, __VA_ARGS__); \
@@ -983,6 +1045,7 @@ static int assemble_launch(dlg_backend* b, const double* Jv, double* Lx = nullpt
   const SymHost& H = Y->H;
   hipStream_t st = b->stream;
   DLG_CHECK(sparse_assemble_finish(b));             // (an earlier assembly's partial sums live in the buffers this one fills)
+  DLG_CHECK(sparse_fin_side_gate(b));               // (... and stages still running on the second stream read them)
   if(!Lx) Lx = Y->Lx;
   if(!zeroed) DLG_HIP(hipMemsetAsync(Lx, 0, sizeof(double)*((size_t)H.lx_size + 8), st));
   if(Y->lf_on)
@@ -1200,6 +1263,7 @@ int sparse_assemble(dlg_backend* b, int s, double lambda)
   // subtree partition: the replicated panels above the cut get lambda and their right-hand side after
   // the sum over the ranks (sparse_partition_reduce); everything else here
   const int phase = H.part_nranks > 1 ? 0 : -1;
+  if(lambda != 0.0) DLG_CHECK(sparse_fin_side_gate(b));      // (lambda goes onto diagonal entries the stages on the second stream store)
   if(lambda != 0.0)
     hipLaunchKernelGGL(k_add_lambda, dim3(dlg_cdiv(H.N, TPB)), dim3(TPB), 0, st, Y->Lx, Y->diagpos, H.N,
                        lambda, Y->col_sn, Y->sn_owner, phase, Y->lf_on ? Y->lf_col : (const char*)nullptr);

@@ -1422,8 +1422,12 @@ int sparse_factor_levels(dlg_backend* b)
   const SymHost& H = Y->H;
   hipStream_t st = b->stream;
   if(H.part_nranks > 1 && H.cut_level < 0) DLG_CHECK(sparse_partition_reduce(b));     // nothing below the cut
+  // (fin on the side, sparse_assemble.hip: the partial-sum stages of the ancestors' panels may still be on the second
+  // stream -- level 0 does not touch those panels; whatever follows it does)
+  if(Y->pr_level0 == 0 || Y->lf_on || H.nlevels < 2) DLG_CHECK(sparse_fin_side_gate(b));
   for(int l = 0; l < H.nlevels; l++)
   {
+
     const int n = H.fw_lvl_ptr[l+1] - H.fw_lvl_ptr[l];
     // from the first level that cannot fill the chip on, the factorisation is latency-bound:
     // independent work (the Cauchy step's pass over J) may run beside it
@@ -1471,6 +1475,7 @@ int sparse_factor_levels(dlg_backend* b)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_factor_level<512>), dim3(n), dim3(512), Y->fac_lds[l], st,
                            Y->fw_item + o, Y->mf_rec, Y->sn_bd_col, Y->mf_dst, Y->Lx, Y->top_scr, Y->d_info, Y->uscr, fmode, (int*)nullptr, 0, DlgHandoff{nullptr, 0, 0}, (int64_t)0);
     }
+    if(l == 0) DLG_CHECK(sparse_fin_side_gate(b));       // (behind the leaf level's factor kernel, in front of its updates)
     const int nu = H.uw_lvl_ptr[l+1] - H.uw_lvl_ptr[l];
     if(nu > 0 && H.upd_syrk[l] && Y->upd_nw[l] > 0)
     {

@@ -114,6 +114,7 @@ void sparse_reset(dlg_backend* b)
   Y->aug_rhs = nullptr; Y->spec_aug_rhs = nullptr; Y->fin_pending_rhs = nullptr; Y->fin_pending_Lx = nullptr;
   Y->info_armed = false; Y->info_clean = false; Y->spec_gen = -1;
   Y->held_Lx = nullptr;
+  Y->fin_side_owed = 0; Y->fin_main = nullptr;            // (dlg_backend_reset waits for both streams first)
 }
 
 int sparse_set_pattern(dlg_backend* b, const int* colptr, const int* rowidx)
@@ -190,6 +191,26 @@ int sparse_set_pattern(dlg_backend* b, const int* colptr, const int* rowidx)
     DLG_HIP(hipMalloc(&Y->jtp, sizeof(double)*16*std::max<size_t>(1, H.asm_mtask.size()))); Y->allocs.push_back(Y->jtp);
   }
   UP(asm_shape); UP(asm_kg); UP(asm_mtask); UP(asm_tdest); UP(asm_fin2); UP(asm_fin2_list); UP(asm_run); UP(asm_pdest);
+  {
+    // fin on the side (sparse_assemble.hip): allowed where every block the partial-sum stages store lies in a panel
+    // above level 0 (the leaf level's factor kernel runs beside them) and no LDS-kernel group has partial sums
+    std::vector<std::pair<int64_t, int>> by_lx((size_t)H.nsn);
+    for(int s2 = 0; s2 < H.nsn; s2++) by_lx[(size_t)s2] = { H.sn_lx[s2], s2 };
+    std::sort(by_lx.begin(), by_lx.end());
+    bool ok = H.asm_cfin.empty() && H.nlevels >= 2 && !getenv("DOGLEG_AMD_NO_FIN_SIDE");
+    for(const AsmFin2& F : H.asm_fin2)
+    {
+      if(!ok) break;
+      if(F.to_part) continue;
+      auto it2 = std::upper_bound(by_lx.begin(), by_lx.end(), std::make_pair(F.dest, 0x7fffffff));
+      if(it2 == by_lx.begin()) { ok = false; break; }
+      const int s2 = (it2 - 1)->second;
+      if(H.sn_level[s2] < 1) ok = false;
+    }
+    Y->fin_side_sched_ok = ok;
+    DLG_HIP(hipMalloc(&Y->fin_flag, sizeof(int)*2)); Y->allocs.push_back(Y->fin_flag);
+    DLG_HIP(hipMemsetAsync(Y->fin_flag, 0, sizeof(int)*2, b->stream));
+  }
   UP(rl_ptr); UP(rl_pos); UP(perm); UP(col_sn); UP(sn_owner); UP(xl_sn); UP(fw_sn); UP(fw_r0); UP(fw_r1); UP(ms_sn); UP(sn_top); UP(sn_bd_ptr); UP(sn_bd_col);
   {
     std::vector<int64_t> ap((size_t)H.N);
