@@ -200,7 +200,10 @@ def main():
         res = one_step()
     # in the timed loop only the roofline kernel is bracketed by events (two records per step); the table
     # of all phases comes from a second loop: twenty event records per step cost ~6 % of a 1.1 ms step
-    be.set_profiling(True, only=["K4_kernel"])
+    # (... and only every fourth launch of it: a kernel whose completion somebody listens to holds the next dispatch
+    # back by ~5 us -- an artefact of measuring that sat inside `value` in every step; the average below is over the
+    # sampled launches of the timed region)
+    be.set_profiling(True, only=["K4_kernel"], every=4 if args.steps >= 8 else 1)
     barrier()
     t0 = time.perf_counter()
     res = run_steps(args.steps) or res

@@ -708,16 +708,30 @@ __global__ void __launch_bounds__(TPB) k_set_aug_row(double* __restrict__ Lx, co
                                                      const double* __restrict__ rhs, int n,
                                                      int* __restrict__ info,
                                                      const int* __restrict__ sn_owner, int phase,
-                                                     const char* __restrict__ skip, int* flag = nullptr, int flag_epoch = 0)
+                                                     const char* __restrict__ skip)
 {
   const int k = blockIdx.x*TPB + threadIdx.x;
-  // (fin on the side: this kernel runs behind the sums of rhs = Jt*x in stream order -- the second stream may read them)
-  if(k == 0 && flag) __hip_atomic_store(flag, flag_epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
   if(k == 0 && phase <= 0) *info = 0x7fffffff;          // re-arm the pivot flag of the factorisation that follows
   if(k >= n) return;
   if(phase >= 0 && !phase_has(sn_owner, col_sn[k], phase)) return;
   if(skip && skip[k]) return;                           // (a column of a leaf front: its right-hand side went in with the front)
   Lx[augpos[k]] += rhs[perm[k]];
+}
+
+// the same for a freshly cleared buffer whose last rows nothing has touched (fin on the side: this kernel sits on the
+// critical stream between the Jt*x sums and the leaf level): plain stores, two columns a thread, their loads in flight
+// together -- two dependent round trips instead of three
+__global__ void __launch_bounds__(TPB) k_store_aug_row(double* __restrict__ Lx, const int64_t* __restrict__ augpos,
+                                                       const int* __restrict__ perm, const double* __restrict__ rhs, int n,
+                                                       int* __restrict__ info, int* flag, int flag_epoch)
+{
+  const int k = blockIdx.x*TPB + threadIdx.x, k2 = k + gridDim.x*TPB;
+  if(k == 0) { __hip_atomic_store(flag, flag_epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); *info = 0x7fffffff; }
+  const int p0 = perm[min(k, n - 1)], p1 = perm[min(k2, n - 1)];
+  const int64_t a0 = augpos[min(k, n - 1)], a1 = augpos[min(k2, n - 1)];
+  const double v0 = rhs[p0], v1 = rhs[p1];
+  if(k < n) Lx[a0] = v0;
+  if(k2 < n) Lx[a1] = v1;
 }
 
 // ------------------------------------------------------------------ K1 ------
@@ -1005,8 +1019,8 @@ int sparse_fin_side_begin(dlg_backend* b)
   const int ep = ++Y->fin_epoch;
   // main stream, behind the Jt*x sums: the augmented row of every panel (the stages never touch a last row), the pivot
   // flag re-armed -- and the word that tells the second stream that Jt*x is final
-  hipLaunchKernelGGL(k_set_aug_row, dim3(dlg_cdiv(H.N, TPB)), dim3(TPB), 0, b->stream, Y->fin_pending_Lx, Y->col_sn, Y->augpos,
-                     Y->perm, Y->fin_pending_rhs, H.N, Y->d_info, Y->sn_owner, -1, (const char*)nullptr, Y->fin_flag, ep);
+  hipLaunchKernelGGL(k_store_aug_row, dim3(dlg_cdiv(H.N, 2*TPB)), dim3(TPB), 0, b->stream, Y->fin_pending_Lx, Y->augpos,
+                     Y->perm, Y->fin_pending_rhs, H.N, Y->d_info, Y->fin_flag, ep);
   DLG_LAUNCH_CHECK();
   Y->spec_aug_rhs = Y->fin_pending_rhs; Y->info_clean = true;
   Y->fin_pending_rhs = nullptr;                        // (sparse_assemble_finish: the stages only)

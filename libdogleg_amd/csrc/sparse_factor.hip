@@ -651,10 +651,15 @@ __global__ void __launch_bounds__(NT) k_update_gather(int unit0, const GatherUni
                                                        double* __restrict__ Lx,
                                                        double* __restrict__ upart,
                                                        const double* __restrict__ uscr, int nw,
-                                                       int* __restrict__ info, const int* __restrict__ lf_word)
+                                                       int* __restrict__ info, const int* __restrict__ lf_word,
+                                                       const int* __restrict__ fin_gate = nullptr, int fin_epoch = 0, int* fin_status = nullptr)
 {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   __shared__ int s_skip;
+  // (fin on the side, sparse_assemble.hip: the partial-sum stages of the target panels may still run on the second
+  // stream -- the word is fetched now and looked at in front of the first access to a target panel)
+  int fin_seen = fin_epoch;
+  if(fin_gate && threadIdx.x == 0) fin_seen = __hip_atomic_load(fin_gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if(threadIdx.x == 0)
   {
     // (leaf fronts: the leaves were factored with the assembly, their pivot word sits behind the panels -- zero
@@ -729,6 +734,13 @@ __global__ void __launch_bounds__(NT) k_update_gather(int unit0, const GatherUni
       }
     }
   }
+  if(fin_gate && tid == 0)
+    for(int spins = 0; fin_seen != fin_epoch; spins++)
+    {
+      if(spins > (1 << 21)) { atomicOr(fin_status, DLG_HANDOFF_FACTOR); break; }       // (never in order: reported, not hung)
+      __builtin_amdgcn_s_sleep(8);
+      fin_seen = __hip_atomic_load(fin_gate, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+    }
   __syncthreads();
   // the slab goes out eight entries per thread at a time: the reads of the panel are in flight together
   for(int e0 = tid; e0 < slab; e0 += 8*NT)
@@ -1475,9 +1487,14 @@ int sparse_factor_levels(dlg_backend* b)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_factor_level<512>), dim3(n), dim3(512), Y->fac_lds[l], st,
                            Y->fw_item + o, Y->mf_rec, Y->sn_bd_col, Y->mf_dst, Y->Lx, Y->top_scr, Y->d_info, Y->uscr, fmode, (int*)nullptr, 0, DlgHandoff{nullptr, 0, 0}, (int64_t)0);
     }
-    if(l == 0) DLG_CHECK(sparse_fin_side_gate(b));       // (behind the leaf level's factor kernel, in front of its updates)
+    // (behind the leaf level's factor kernel, in front of its updates: the gather kernel looks at the word itself,
+    // in front of anything else a one-wave kernel waits for it)
     const int nu = H.uw_lvl_ptr[l+1] - H.uw_lvl_ptr[l];
-    if(nu > 0 && H.upd_syrk[l] && Y->upd_nw[l] > 0)
+    const bool gather_next = nu > 0 && H.upd_syrk[l] && Y->upd_nw[l] > 0;
+    const int fin_ep = (l == 0 && gather_next) ? Y->fin_side_owed : 0;
+    if(fin_ep) Y->fin_side_owed = 0;
+    if(l == 0) DLG_CHECK(sparse_fin_side_gate(b));
+    if(gather_next)
     {
       const int ns = H.xl_ptr[l+1] - H.xl_ptr[l];
       if(Y->syrk_fused[l] || ns == 0) { /* phase 1 was done by the factor kernel */ }
@@ -1493,7 +1510,9 @@ int sparse_factor_levels(dlg_backend* b)
       // waves sharing a unit's sub-tasks)
       hipLaunchKernelGGL(HIP_KERNEL_NAME(k_update_gather<TPB>), dim3(nu), dim3(TPB), Y->upd_lds[l], st, H.uw_lvl_ptr[l],
                          Y->uw_flat, Y->usub, Y->usub_u, Y->relpos, Y->Lx, Y->upart, Y->uscr,
-                         Y->upd_nw[l], Y->d_info, (l == 0 && Y->lf_on) ? reinterpret_cast<const int*>(Y->Lx + H.lx_size) : (const int*)nullptr);
+                         Y->upd_nw[l], Y->d_info, (l == 0 && Y->lf_on) ? reinterpret_cast<const int*>(Y->Lx + H.lx_size) : (const int*)nullptr,
+                         fin_ep ? (const int*)(Y->fin_flag + 1) : (const int*)nullptr, fin_ep,
+                         reinterpret_cast<int*>(b->d_scal + (dlg_backend::NSCAL - 2)));
     }
     else if(nu > 0 && Y->upd_coop[l] == 2)
       hipLaunchKernelGGL(k_update_mfma, dim3(nu), dim3(TPB), Y->upd_lds[l], st, H.uw_lvl_ptr[l],
