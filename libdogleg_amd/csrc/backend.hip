@@ -681,6 +681,8 @@ extern "C" int dlg_point_eval(dlg_backend_t* b, int s, double* norm2_x, double* 
   }
   S.have_Jtx = true;
   S.norm2_jtx = b->h_scal[2];
+  // (values that are not numbers may have reached the panels: no partial clear relies on what they hold)
+  if(b->type == DLG_SPARSE && !(std::isfinite(S.norm2_x) && std::isfinite(S.norm2_jtx) && std::isfinite(b->h_scal[3]))) sparse_mark_unclean(b);
   if(norm2_x) *norm2_x = S.norm2_x;
   if(Jtx_absmax) *Jtx_absmax = b->h_scal[3];
   return DLG_OK;
@@ -920,6 +922,7 @@ static int gauss_newton_impl(dlg_backend_t* b, int s, double* lambda_io, double*
     good = (b->factor_slot == s) ? 1 : (b->type == DLG_SPARSE ? sparse_factor_ok(b) : dense_factor_ok(b));
     if(b->profiling) dlg_prof_commit(b, good != 0);
     if(good) break;
+    if(b->type == DLG_SPARSE) sparse_mark_unclean(b);          // (a factorisation that broke down: full clears next)
     b->factor_slot = -1;
     lam = (lam == 0.0) ? 1e-10 : lam*10.0;                    // dogleg.c:138, 671-672, 812-813
     if(!(lam < 1e300)) { dlg_set_error("lambda overflowed while regularising a singular JtJ"); return DLG_ERR_STATE; }
@@ -1222,6 +1225,7 @@ extern "C" int dlg_take_step(dlg_backend_t* b, int from, int to, double trustreg
     good = (b->factor_slot == from) ? 1 : (b->type == DLG_SPARSE ? sparse_factor_ok(b) : dense_factor_ok(b));
     if(b->profiling) dlg_prof_commit(b, good != 0);
     if(good) break;
+    if(b->type == DLG_SPARSE) sparse_mark_unclean(b);          // (a factorisation that broke down: full clears next)
     b->factor_slot = -1;
     lam = (lam == 0.0) ? 1e-10 : lam*10.0;                    // dogleg.c:138, 671-672, 812-813
     if(!(lam < 1e300)) { dlg_set_error("lambda overflowed while regularising a singular JtJ"); return DLG_ERR_STATE; }

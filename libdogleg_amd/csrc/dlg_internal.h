@@ -308,6 +308,7 @@ int sparse_factorize(dlg_backend* b, int slot, double lambda, int* ok);         
 bool sparse_factor_ok(const dlg_backend* b);     // pivot flag of the last factorisation (after a sync)
 int sparse_solve(dlg_backend* b, const double* rhs, double* out);                // K6
 void sparse_hold_factor(dlg_backend* b);
+void sparse_mark_unclean(dlg_backend* b);             // the next clear of either panel buffer is a full one (clear_panels)
 // the partial-sum stages of an evaluation-time assembly on the SECOND stream (sparse_assemble.hip, "fin on the side")
 bool sparse_fin_side_ok(const dlg_backend* b);
 int  sparse_fin_side_begin(dlg_backend* b);      // main: augmented row + flag A; second stream: waits for flag A; b->stream := second stream

@@ -595,7 +595,7 @@ __global__ void __launch_bounds__(TPB) k_assemble_fin2_short(const AsmFin2* __re
   {
     const int k = (blockIdx.x - nfb)*TPB + threadIdx.x;
     if(k == 0) *aug.info = 0x7fffffff;                  // re-arm the pivot flag of the factorisation that follows
-    if(k < aug.n) Lx[aug.augpos[k]] += aug.rhs[aug.perm[k]];
+    if(k < aug.n) Lx[aug.augpos[k]] = aug.rhs[aug.perm[k]];       // (a store: see k_set_aug_row; this launch carries it on a single rank only)
     return;
   }
   const int lane = threadIdx.x & 63;
@@ -715,7 +715,9 @@ __global__ void __launch_bounds__(TPB) k_set_aug_row(double* __restrict__ Lx, co
   if(k >= n) return;
   if(phase >= 0 && !phase_has(sn_owner, col_sn[k], phase)) return;
   if(skip && skip[k]) return;                           // (a column of a leaf front: its right-hand side went in with the front)
-  Lx[augpos[k]] += rhs[perm[k]];
+  // (single rank: nothing but this kernel ever writes a last row between two assemblies, and a partially cleared
+  // buffer -- clear_panels -- holds the previous factorisation's there; the phases of a partition add behind the sum over the ranks)
+  if(phase < 0) Lx[augpos[k]] = rhs[perm[k]]; else Lx[augpos[k]] += rhs[perm[k]];
 }
 
 // the same for a freshly cleared buffer whose last rows nothing has touched (fin on the side: this kernel sits on the
@@ -1048,6 +1050,37 @@ int sparse_fin_side_gate(dlg_backend* b)
   Y->fin_side_owed = 0;
   return dlg_gate_wait(b, Y->fin_main ? Y->fin_main : b->stream, Y->fin_flag + 1, ep, true);
 }
+// ---- clearing a panel buffer in front of an assembly: all of it, or (sparse_host.hip, clr_partial_ok) only what is
+// not a merged leaf's panel once the buffer's leaves are known to be clean
+__global__ void __launch_bounds__(TPB) k_clear_ranges(double* __restrict__ Lx, const int64_t* __restrict__ off,
+                                                      const int64_t* __restrict__ len)
+{
+  double* d = Lx + off[blockIdx.y];
+  const int64_t n = len[blockIdx.y];
+  // (16-byte stores where the range allows: the head up to an even index one by one)
+  const int64_t head = ((reinterpret_cast<uintptr_t>(d) >> 3) & 1) ? 1 : 0;
+  if(blockIdx.x == 0 && threadIdx.x == 0 && head && n > 0) d[0] = 0.0;
+  double2* d2 = reinterpret_cast<double2*>(d + head);
+  const int64_t n2 = (n - head) >> 1;
+  for(int64_t i = blockIdx.x*(int64_t)TPB + threadIdx.x; i < n2; i += (int64_t)gridDim.x*TPB) d2[i] = make_double2(0.0, 0.0);
+  if(blockIdx.x == 0 && threadIdx.x == 0 && ((n - head) & 1)) d[n - 1] = 0.0;
+}
+void sparse_mark_unclean(dlg_backend* b) { if(b->sym) b->sym->lz_ok[0] = b->sym->lz_ok[1] = nullptr; }
+static int clear_panels(dlg_backend* b, double* Lx, hipStream_t st)
+{
+  SparseSym* Y = b->sym;
+  const SymHost& H = Y->H;
+  const bool known = Lx == Y->lz_ok[0] || Lx == Y->lz_ok[1];
+  if(known && Y->clr_partial_ok && !Y->lf_on && !b->sharded() && H.part_nranks <= 1)
+  {
+    hipLaunchKernelGGL(k_clear_ranges, dim3(64, Y->n_clr), dim3(TPB), 0, st, Lx, Y->clr_off, Y->clr_len);
+    DLG_LAUNCH_CHECK();
+    return DLG_OK;
+  }
+  DLG_HIP(hipMemsetAsync(Lx, 0, sizeof(double)*((size_t)H.lx_size + 8), st));
+  if(!known) { if(!Y->lz_ok[0]) Y->lz_ok[0] = Lx; else if(!Y->lz_ok[1]) Y->lz_ok[1] = Lx; else { Y->lz_ok[0] = Lx; Y->lz_ok[1] = nullptr; } }
+  return DLG_OK;
+}
 #define ASM_LAUNCH(kernel, grid, block, shm, st, ...) \
   do { hipEvent_t e0 = nullptr, e1 = nullptr; \
        if(timed_single && dlg_prof_pair(b, DLG_PROF_K4_KERNEL, &e0, &e1)) hipExtLaunchKernelGGL(kernel, grid, block, shm, st, e0, e1, 0, __VA_ARGS__); \
@@ -1061,7 +1094,7 @@ static int assemble_launch(dlg_backend* b, const double* Jv, double* Lx = nullpt
   DLG_CHECK(sparse_assemble_finish(b));             // (an earlier assembly's partial sums live in the buffers this one fills)
   DLG_CHECK(sparse_fin_side_gate(b));               // (... and stages still running on the second stream read them)
   if(!Lx) Lx = Y->Lx;
-  if(!zeroed) DLG_HIP(hipMemsetAsync(Lx, 0, sizeof(double)*((size_t)H.lx_size + 8), st));
+  if(!zeroed) DLG_CHECK(clear_panels(b, Lx, st));
   if(Y->lf_on)
   {
     // leaf fronts: JtJ, Jt*x and the leaves' factorisation in one pass over J (sparse_leaf.hip); the panels of the
@@ -1297,6 +1330,7 @@ int sparse_assemble(dlg_backend* b, int s, double lambda)
     Y->aug_rhs = S.Jt_x;
     Y->info_armed = true;
   }
+  else sparse_mark_unclean(b);       // (no right-hand side: the leaves' last rows keep what they held -- not something to build on)
   DLG_LAUNCH_CHECK();
   return DLG_OK;
 }
@@ -1446,7 +1480,7 @@ int sparse_zero_spare(dlg_backend* b)
   // enqueued ahead of the caller's decision displaced): it is cleared once that question is settled
   if(Y->held_Lx && Y->held_Lx == Y->Lx_spec) return DLG_OK;
   Y->spare_dirty = false;
-  DLG_HIP(hipMemsetAsync(Y->Lx_spec, 0, sizeof(double)*((size_t)Y->H.lx_size + 8), b->stream));
+  DLG_CHECK(clear_panels(b, Y->Lx_spec, b->stream));
   Y->spare_zeroed = true; Y->spare_stream = b->stream;
   return DLG_OK;
 }

@@ -208,6 +208,31 @@ int sparse_set_pattern(dlg_backend* b, const int* colptr, const int* rowidx)
       if(H.sn_level[s2] < 1) ok = false;
     }
     Y->fin_side_sched_ok = ok;
+    // Partial clears (sparse_assemble.hip, clear_panels).  The panel of a merged leaf (block-diagonal members, their
+    // common rows below, no children) has NO fill: a row's block under a member is (JtJ block) * (member block)^-T, zero
+    // where JtJ is zero; the assembly STORES every structural entry of JtJ (persistent, transient and summed blocks
+    // alike, never an addition into the panel), the leaf kernel rewrites exactly the rows below and the member blocks,
+    // the augmented row is stored.  So once such a panel was cleared, everything outside the structure stays zero
+    // from step to step and only the other panels -- update matrices and fill land there -- are cleared per step.
+    {
+      std::vector<int64_t> off, len;
+      int64_t kept = 0;
+      for(int s2 = 0; s2 < H.nsn; s2++)
+      {
+        const bool keep = H.sn_level[s2] == 0 && H.sn_bd_ptr[s2+1] > H.sn_bd_ptr[s2] && H.sn_top[s2] < 0 && H.nlevels >= 2;
+        if(keep) { kept += H.sn_lx[s2+1] - H.sn_lx[s2]; continue; }
+        if(!off.empty() && off.back() + len.back() == H.sn_lx[s2]) len.back() += H.sn_lx[s2+1] - H.sn_lx[s2];
+        else { off.push_back(H.sn_lx[s2]); len.push_back(H.sn_lx[s2+1] - H.sn_lx[s2]); }
+      }
+      if(!off.empty() && off.back() + len.back() == H.lx_size) len.back() += 8;      // (+ the words behind the panels)
+      else { off.push_back(H.lx_size); len.push_back(8); }
+      Y->n_clr = (int)off.size();
+      // (worth it where most of the buffer is kept and the ranges are few enough for one launch; LDS-kernel groups sum
+      // into the panels: not with them)
+      Y->clr_partial_ok = kept*2 > H.lx_size && Y->n_clr <= 65535 && H.asm_cfin.empty() && H.asm_ctask.empty() && !getenv("DOGLEG_AMD_FULL_CLEAR");
+      DLG_CHECK(upload(Y->clr_off, off)); Y->allocs.push_back(Y->clr_off);
+      DLG_CHECK(upload(Y->clr_len, len)); Y->allocs.push_back(Y->clr_len);
+    }
     DLG_HIP(hipMalloc(&Y->fin_flag, sizeof(int)*2)); Y->allocs.push_back(Y->fin_flag);
     DLG_HIP(hipMemsetAsync(Y->fin_flag, 0, sizeof(int)*2, b->stream));
   }

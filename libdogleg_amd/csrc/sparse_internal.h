@@ -137,6 +137,9 @@ struct SparseSym
   int fac_b16_maxw = 0;
   // fin on the side: flags [A: Jt*x final / augmented row on its way, B: partial-sum stages done], their epoch, the
   // epoch the main stream still has to wait for (0: nothing owed), whether the schedule allows it at all
+  // partial clears (sparse_assemble.hip, clear_panels): the ranges of a panel buffer outside the merged leaves' panels,
+  // and the buffers whose leaves are known to hold nothing but zeros outside the structure of JtJ
+  int64_t* clr_off = nullptr; int64_t* clr_len = nullptr; int n_clr = 0; bool clr_partial_ok = false; double* lz_ok[2] = {nullptr, nullptr};
   int* fin_flag = nullptr; int fin_epoch = 0, fin_side_owed = 0; bool fin_side_sched_ok = false; hipStream_t fin_main = nullptr;
   bool fac_b16 = false;         // panel_factor_b16 (DOGLEG_AMD_B16)
   bool fac_ahead = false;       // panel_factor_ahead instead of panel_factor_mfma (DOGLEG_AMD_AHEAD)

@@ -755,3 +755,81 @@ def test_profiling_can_sample_every_nth_occurrence(gpu):
     be.set_profiling(False)
     be.close()
     assert counts[1] == 8 and counts[4] == 2
+
+
+def _steps_script(prob, inputs, poison=None):
+    """eval + take_step over `inputs` (speculation on: the one-pass evaluation, panels adopted by the factorisation),
+    then a blocked multi-right-hand-side solve with the last factor (it reads the leaves' whole top blocks)"""
+    Jp, Ji = prob.pattern()
+    be = capi.Backend(capi.DLG_SPARSE, prob.N, prob.M, prob.nnz)
+    be.set_pattern(Jp, Ji)
+    be.set_speculation(True)
+    be.set_p(0, prob.p0())
+    out, tr = [], None
+    for i, (x, Jx) in enumerate(inputs):
+        if poison is not None and i == poison:
+            Jbad = Jx.copy()
+            Jbad[::97] = np.nan
+            be.upload(0, x, Jbad)
+            try:
+                be.eval(0)
+                be.take_step(0, 1, tr, 0.0)
+            except capi.DlgError:
+                pass
+        be.upload(0, x, Jx)
+        n2x, gmax = be.eval(0)
+        if tr is None:
+            lam, n2c, n2g = be.cauchy_gauss_newton(0, 0.0)
+            tr = 0.5 * (n2c ** 0.5 + n2g ** 0.5)
+            be.upload(0, x, Jx)
+            be.eval(0)
+        lam, r, pnew = be.take_step(0, 1, tr, 0.0)
+        out.append((n2x, gmax, lam, tuple(sorted(r.items())), pnew.copy(), be.download(0, capi.VEC_GN)))
+    rhs = np.cos(0.01 * np.arange(3 * prob.N)).reshape(3, prob.N)
+    out.append(be.solve_multi(0, rhs))
+    be.close()
+    return out
+
+
+def _same_runs(a, b):
+    assert len(a) == len(b)
+    for i, (u, v) in enumerate(zip(a, b)):
+        if isinstance(u, np.ndarray):
+            assert np.array_equal(u, v), i
+            continue
+        for k, (p, q) in enumerate(zip(u, v)):
+            if isinstance(p, np.ndarray):
+                assert np.array_equal(p, q), (i, k)
+            elif isinstance(p, tuple):
+                assert all(x == y or (x != x and y != y) for (_, x), (_, y) in zip(p, q)), (i, k)
+            else:
+                assert p == q or (p != p and q != q), (i, k)
+
+
+@pytest.mark.parametrize("shape", [(49, 900, 10000), (199, 3600, 40000)])
+def test_partial_clears_change_no_bit(gpu, shape, monkeypatch):
+    """Between two assemblies only the panels above the merged leaves are cleared (clear_panels: a leaf's panel has no
+    fill, the assembly stores every structural entry, the last row is stored): eight steps over three different inputs
+    give the bits of the same steps with full clears (DOGLEG_AMD_FULL_CLEAR), and so does a blocked solve with the last
+    factor, which reads the leaves' whole top blocks"""
+    prob = oa.BAProblem(*shape, seed=6, eps=0.4, p0_spread=0.6)
+    rng = np.random.default_rng(2)
+    pts = [prob.p0() + 0.05 * c * rng.standard_normal(prob.N) for c in range(3)]
+    inputs = [prob.eval(pts[i % 3]) for i in range(8)]
+    got = _steps_script(prob, inputs)
+    monkeypatch.setenv("DOGLEG_AMD_FULL_CLEAR", "1")
+    want = _steps_script(prob, inputs)
+    _same_runs(got, want)
+
+
+def test_partial_clears_do_not_outlive_values_that_are_not_numbers(gpu):
+    """a Jacobian with NaNs in it (a user callback gone wrong) between good evaluations: the step at the bad point is
+    whatever it is, the steps AFTER it have the bits they have without the bad point in between -- nothing the bad
+    values left in a panel survives into a later factorisation"""
+    prob = oa.BAProblem(49, 900, 10000, seed=6, eps=0.4, p0_spread=0.6)
+    rng = np.random.default_rng(2)
+    pts = [prob.p0() + 0.05 * c * rng.standard_normal(prob.N) for c in range(3)]
+    inputs = [prob.eval(pts[i % 3]) for i in range(6)]
+    want = _steps_script(prob, inputs)
+    got = _steps_script(prob, inputs, poison=3)
+    _same_runs(got, want)
