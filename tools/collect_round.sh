@@ -2,7 +2,7 @@
 # Collect the per-round artifacts on the GPU box: bench JSON lines, rocprofv3 kernel stats,
 # PMC traffic (separate passes), end-to-end rate, probes.  usage: tools/collect_round.sh <tag>
 # Writes under gpurun_out/<tag>/ ; tools/publish_round.py copies the summaries into profiles/.
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+export TMPDIR=/tmp; cd "$(dirname "$0")/.." || exit 1
 tag=${1:-r01}; out=gpurun_out/$tag; mkdir -p $out
 for wl in sparse-1m sparse-200k dense-50k; do
   timeout 600 python3 bench.py --workload $wl > $out/bench_$wl.json 2> $out/bench_$wl.err

@@ -1,6 +1,6 @@
 #!/bin/bash
 # usage: tools/pmc_run2.sh <outdir-under-gpurun_out> <kernel-pattern> ; SQ counter groups, separate passes
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+export TMPDIR=/tmp; cd "$(dirname "$0")/.." || exit 1
 out=gpurun_out/$1; pat=$2
 i=0
 for c in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES" "SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_WAIT_INST_ANY" "SQ_INSTS_MFMA SQ_INSTS_SMEM SQ_INST_CYCLES_VMEM" "GRBM_GUI_ACTIVE TA_BUSY_avr TCP_PENDING_STALL_CYCLES_sum" ; do

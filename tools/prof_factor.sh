@@ -2,7 +2,7 @@
 # tools only: per-phase clocks of workgroup 0 of every k_factor_level launch.
 # Build (in the container):  tools/prof_factor.sh build   -> gpurun_out is not used; tools/micro/libprof.so
 # Run (on the GPU box):      tools/prof_factor.sh run [bench args]
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/.." || exit 1
 if [ "$1" = build ]; then
   python3 -c "import __graft_entry__ as g; g.build()" >/dev/null 2>&1
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -mllvm -amdgpu-mfma-vgpr-form=1 -DDLG_FL_PROFILE \

@@ -2,7 +2,7 @@
 # tools only: phase clocks of the leaf-front workgroups (sparse_leaf.hip, -DDLG_LF_PROFILE).
 # Build (in the container):  tools/prof_leaf.sh build   -> tools/micro/liblfprof.so
 # Run (on the GPU box):      tools/prof_leaf.sh run [bench args]
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/.." || exit 1
 if [ "$1" = build ]; then
   python3 -c "import __graft_entry__ as g; g.build()" >/dev/null 2>&1
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -mllvm -amdgpu-mfma-vgpr-form=1 -DDLG_LF_PROFILE \

@@ -1,6 +1,6 @@
 #!/bin/bash
 # tools only: kernel statistics of config #5 (sparse-5m)
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+export TMPDIR=/tmp; cd "$(dirname "$0")/.." || exit 1
 O=gpurun_out/s5m; rm -rf $O; mkdir -p $O
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o p -- python3 bench.py --workload sparse-5m --steps 10 --warmup 2 --no-cpu-baseline > $O/log.txt 2>&1
 python3 - <<'PY'

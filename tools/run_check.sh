@@ -1,5 +1,5 @@
 #!/bin/bash
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+export TMPDIR=/tmp; cd "$(dirname "$0")/.." || exit 1
 out=gpurun_out/${1:-check}; mkdir -p $out
 timeout 1500 python3 -m pytest tests -m gpu -x -q > $out/tests.log 2>&1; echo "rc=$?" >> $out/tests.log
 tail -6 $out/tests.log

@@ -1,6 +1,6 @@
 #!/bin/bash
 # tools only: kernel trace of a short bench run -> one step's critical-queue timeline (tools/step_gaps.py), then bench lines
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/.." || exit 1
 export TMPDIR=/tmp
 O=gpurun_out/gaps; rm -rf $O; mkdir -p $O
 timeout 600 rocprofv3 --kernel-trace --output-format csv -d $O/tr_on -o t -- python3 bench.py --no-cpu-baseline --steps 30 --warmup 5 > $O/bench_tr.json 2>$O/err_on.txt

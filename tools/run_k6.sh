@@ -1,6 +1,6 @@
 #!/bin/bash
 # tools only: the backward solve after a change: the GPU suite, the backward region's per-workgroup clocks, bench lines
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/.." || exit 1
 O=gpurun_out/k6; rm -rf $O; mkdir -p $O
 timeout 2400 python3 -m pytest tests -x -q -m gpu > $O/tests.txt 2>&1; tail -3 $O/tests.txt
 timeout 300 bash tools/prof_factor.sh run > $O/levels.txt 2>&1; grep -E "bwd wg +[0-9]:" $O/levels.txt | head -4

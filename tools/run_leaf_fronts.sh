@@ -1,5 +1,5 @@
 #!/bin/bash
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+export TMPDIR=/tmp; cd "$(dirname "$0")/.." || exit 1
 out=gpurun_out/${1:-lf18}; mkdir -p $out
 for a in "tiny" "tiny spec" "200k spec"; do
   echo "== $a"; timeout 300 python3 tools/lf_check.py $a 2>&1 | grep -v "^level" | tail -4 | head -3

@@ -1,6 +1,6 @@
 #!/bin/bash
 # per-workgroup timeline of the one-launch factor region (profile build made by tools/prof_factor.sh build)
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+export TMPDIR=/tmp; cd "$(dirname "$0")/.." || exit 1
 out=gpurun_out/${1:-prof}; mkdir -p $out
 shift
 DLG_FL_DUMP_ALL=1 "$@" bash tools/prof_factor.sh run > $out/raw.txt 2>&1

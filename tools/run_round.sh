@@ -1,6 +1,6 @@
 #!/bin/bash
 # tools only: the new sweep tests, the micro numbers of the panel sweeps, then the round's artifacts
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/.." || exit 1
 mkdir -p gpurun_out/r03
 timeout 900 python3 -m pytest tests/test_sparse_gpu.py -x -q -m gpu -k "blocks_of_16" 2>&1 | tail -3
 {

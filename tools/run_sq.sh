@@ -1,6 +1,6 @@
 #!/bin/bash
 # SQ counters of the assembly kernel (rocprofv3 --pmc, counters only: no trace domains beside --kernel-trace)
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+export TMPDIR=/tmp; cd "$(dirname "$0")/.." || exit 1
 out=gpurun_out/${1:-sq}; mkdir -p $out
 rocprofv3 -L 2>/dev/null | grep -o "SQ_[A-Z_0-9]*" | sort -u > $out/sq_counters.txt
 wc -l $out/sq_counters.txt

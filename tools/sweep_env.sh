@@ -1,6 +1,6 @@
 #!/bin/bash
 # usage: tools/sweep_env.sh VAR v1 v2 ...   (one bench line per value; scratch helper for gpurun)
-cd $GRAFT_REPO_ROOT
+cd "$(dirname "$0")/.." || exit 1
 var=$1; shift
 for v in "$@"; do
   export $var=$v

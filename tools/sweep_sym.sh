@@ -1,6 +1,6 @@
 #!/bin/bash
 # tools only: knobs of the symbolic phase against steps/s (config #4)
-cd $GRAFT_REPO_ROOT
+cd "$(dirname "$0")/.." || exit 1
 export DOGLEG_AMD_NO_SYM_CACHE=1
 bash tools/sweep_env.sh DOGLEG_AMD_ND_LEAF 200 300 400 600
 unset DOGLEG_AMD_ND_LEAF

@@ -2,7 +2,7 @@
 # tools only: A/B a compile-time variant of ONE source file of the library.
 #   tools/variant_lib.sh build sparse_assemble.hip -DDLG_ASM_PREFETCH     (in the container) -> tools/micro/libvar.so
 #   tools/variant_lib.sh run [bench args]                                  (on the GPU box): bench.py with that library
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/.." || exit 1
 if [ "$1" = build ]; then
   src=$2; shift 2
   python3 -c "import __graft_entry__ as g; g.build()" >/dev/null 2>&1
