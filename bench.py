@@ -61,6 +61,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline sample")
     ap.add_argument("--copies", type=int, default=3, help="resident copies of (x, J) the timed loop rotates over")
+    # a PROJECTION input, not a bench line: rank --rank of a partition over --logical-ranks ranks on this one device, every
+    # sum over the ranks skipped (dlg_backend_set_noop_comm) -- the rank's compute time per phase
+    ap.add_argument("--logical-ranks", type=int, default=1)
+    ap.add_argument("--rank", type=int, default=0)
+    ap.add_argument("--lambda0", type=float, default=None, help="lambda of every step (logical ranks: 1.0, the partial top of the tree must stay positive definite)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -69,6 +74,9 @@ def main():
     if world != args.gpus and world > 1:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
     use_dist = world > 1 or os.environ.get("DLG_BENCH_FORCE_DIST") == "1"
+    logical = args.logical_ranks > 1 and not use_dist
+    prank, pworld = (args.rank, args.logical_ranks) if logical else (rank, world)
+    lam0 = args.lambda0 if args.lambda0 is not None else (1.0 if logical else 0.0)
 
     torch = dist = None
     if use_dist:
@@ -113,12 +121,14 @@ def main():
         rccl_ranks = be.comm_size()
         assert rccl_ranks == world, f"RCCL reports {rccl_ranks} ranks, expected {world}"
     part = None
+    if logical:
+        be.set_noop_comm(True)
     if kind == "sparse":
-        if use_dist:
-            be.set_partition(rank, world)
+        if use_dist or logical:
+            be.set_partition(prank, pworld)
         be.set_pattern(Jp, Ji)
         sym = be.stats()
-        if use_dist:
+        if use_dist or logical:
             rows = be.partition_rows()
             part = be.partition_stats()
             x_loc = x[rows]
@@ -130,10 +140,10 @@ def main():
     else:
         sym = {}
         # contiguous row ranges
-        row0 = (M * rank) // world
-        row1 = (M * (rank + 1)) // world
+        row0 = (M * prank) // pworld
+        row1 = (M * (prank + 1)) // pworld
         x_loc, J_loc = x[row0:row1], J[row0:row1]
-        if use_dist:
+        if use_dist or logical:
             be.set_shard(row0, row1, None)
     # The timed loop rotates over NCOPY resident copies of (x, J): one unchanging J of 120 MB (config #4)
     # would sit in the 256 MiB Infinity Cache between steps and flatter every "HBM" fraction
@@ -158,13 +168,13 @@ def main():
         # of step, the step, its expected improvement, p_new D2H -- one synchronisation per attempt.
         # The trust region is known before the step, as in the driver (state["tr"], from the first step).
         if state["tr"] is None:
-            lam, n2c, n2g = be.cauchy_gauss_newton(0, 0.0)
+            lam, n2c, n2g = be.cauchy_gauss_newton(0, lam0)
             tr = 0.5 * (n2c ** 0.5 + n2g ** 0.5)
             n2s, k, amax, ei, pnew = be.step(0, 1, capi.KIND_INTERP, tr)
             state["tr"] = tr
         else:
-            lam, r, pnew = be.take_step(0, 1, state["tr"], 0.0)
-            assert r["kind"] == capi.KIND_INTERP
+            lam, r, pnew = be.take_step(0, 1, state["tr"], lam0)
+            assert logical or r["kind"] == capi.KIND_INTERP
             n2c, n2g, n2s, k, amax, ei = r["n2c"], r["n2g"], r["n2s"], r["k"], r["amax"], r["ei"]
         return norm2x, n2c, n2g, k, n2s, ei, gmax, amax, lam
 
@@ -177,9 +187,9 @@ def main():
             n -= 1
         if n <= 0:
             return None
-        r, kind = be.run_steps(0, 1, n, [d.ptr for d in d_x], [d.ptr for d in d_J], state["i"] % ncopy, state["tr"], 0.0)
+        r, kind = be.run_steps(0, 1, n, [d.ptr for d in d_x], [d.ptr for d in d_J], state["i"] % ncopy, state["tr"], lam0)
         state["i"] += n
-        assert kind == capi.KIND_INTERP
+        assert logical or kind == capi.KIND_INTERP
         return r["n2x"], r["n2c"], r["n2g"], r["k"], r["n2s"], r["ei"], r["gmax"], r["amax"], r["lam"]
 
     def barrier():
@@ -225,7 +235,7 @@ def main():
     # retry is only step formation (K7), expected improvement (K8) and the evaluation of the new
     # point (K1).  Not part of `value`.
     retry_ms = None
-    if not use_dist:
+    if not use_dist and not logical:
         tr_retry = 0.5 * (res[1] ** 0.5 + res[2] ** 0.5)
 
         def one_retry(shrink):
@@ -243,7 +253,7 @@ def main():
         retry_ms = (time.perf_counter() - tr0) / args.steps * 1e3
     # the same step with K1 and K4 as two passes over J (how rounds 1-2 reported `value`)
     sep_ms = None
-    if one_pass:
+    if one_pass and not logical:
         be.set_speculation(False)
         one_step()
         barrier()
@@ -341,7 +351,8 @@ def main():
             "config": {"workload": args.workload, "kind": kind, "Nmeas": M, "Nstate": N, "nnz": nnz,
                        "step": "K1+K3+K4+K5+K6+K7+K8 (refactorise + interpolate), inputs resident in HBM"
                                + ("; K1 and K4 share one pass over J" if one_pass else ""),
-                       "parallelism": (("subtree partition" if kind == "sparse" else "row sharding") + f" x{world}, RCCL in-stream") if use_dist else "1 GPU"},
+                       "parallelism": (("subtree partition" if kind == "sparse" else "row sharding") + f" x{world}, RCCL in-stream") if use_dist else
+                                      (f"rank {prank} of {pworld} LOGICAL ranks on one device, every sum over the ranks skipped: per-rank compute time for a projection, not a throughput" if logical else "1 GPU")},
             "roofline": roof,
             "other_kernels": others,
             "inputs": {"resident_copies": ncopy, "bytes_per_copy": int(xh.nbytes + Jh.nbytes),
@@ -363,7 +374,7 @@ def main():
         }
 
     # ---- CPU baseline: the oracle's restatement of the same step, host cores, bounded sample
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not logical:
         from tests import oracle_api         # (the CPU oracle: this leg and nothing else in bench.py)
         O = oracle_api.oracle()
         from libdogleg_amd.ctypes_defs import dptr, iptr
@@ -414,6 +425,10 @@ def main():
             out["check"]["oracle_expected_improvement"] = float(ocheck[5])
             out["check"]["rel_diff_norm2_step"] = abs(float(ocheck[4]) - res[4]) / max(1e-300, abs(res[4]))
     if rank == 0:
+        if logical:
+            out["metric"] = "per-rank compute time of one partitioned step (projection input; NOT trust-region steps/sec)"
+            out["value"] = None
+            out["logical_rank"] = {"rank": prank, "ranks": pworld, "lambda0": lam0, "rows": int(row1 - row0)}
         print(json.dumps(out))
     be.close()
     if use_dist:

@@ -118,7 +118,10 @@ int  dlg_backend_init_rccl(dlg_backend_t* b, int rank, int nranks, const void* u
 int  dlg_backend_set_rccl(dlg_backend_t* b, void* nccl_comm);            /* adopt a caller-owned ncclComm_t */
 int  dlg_backend_share_rccl(dlg_backend_t* b, dlg_backend_t* owner);     /* ... the one another backend of this process made (it keeps owning it) */
 int  dlg_backend_comm_size(dlg_backend_t* b, int* nranks);               /* what RCCL reports (1 without RCCL) */
-int  dlg_backend_has_rccl(dlg_backend_t* b);                             /* 1: the sums over the ranks are ncclAllReduce calls on the backend's stream */
+int  dlg_backend_has_rccl(dlg_backend_t* b);
+/* MEASUREMENT ONLY (bench.py --logical-ranks): one rank of a partition on a device of its own with every sum over
+ * the ranks skipped -- the rank's compute time per phase, its numbers meaningless (partial sums). */
+int  dlg_backend_set_noop_comm(dlg_backend_t* b, int on);                             /* 1: the sums over the ranks are ncclAllReduce calls on the backend's stream */
 
 /* ---- nsteps trial steps of a fresh operating point in one call: bind resident inputs (ncopy copies of (x, J)
  * on the device, rotated from first_copy), dlg_point_eval, dlg_take_step from lambda0 -- the sequence of the

@@ -37,7 +37,7 @@ BACKEND_SYMBOLS = [
     "dlg_backend_set_profiling", "dlg_backend_get_profile", "dlg_backend_get_profile_early",
     "dlg_backend_set_allreduce", "dlg_backend_set_partition", "dlg_partition_rows", "dlg_partition_stats",
     "dlg_sparse_partition_probe", "dlg_rccl_unique_id", "dlg_backend_init_rccl", "dlg_backend_set_rccl",
-    "dlg_backend_comm_size", "dlg_backend_has_rccl", "dlg_solve_multi", "dlg_pseudoinverse_chunk", "dlg_backend_set_speculation",
+    "dlg_backend_comm_size", "dlg_backend_has_rccl", "dlg_backend_set_noop_comm", "dlg_solve_multi", "dlg_pseudoinverse_chunk", "dlg_backend_set_speculation",
     "dlg_backend_share_rccl", "dlg_point_gather_device", "dlg_backend_reset", "dlg_backend_device",
     "dlg_sparse_pattern_matches", "dlg_sparse_drop_pattern", "dlg_sparse_region_probe", "dlg_run_steps",
 ]
@@ -92,6 +92,7 @@ def lib():
     L.dlg_backend_set_rccl.argtypes = [V, V]
     L.dlg_backend_comm_size.argtypes = [V, I]
     L.dlg_backend_has_rccl.argtypes = [V]
+    L.dlg_backend_set_noop_comm.argtypes = [V, C.c_int]
     L.dlg_backend_get_profile_early.argtypes = [V, D, C.POINTER(C.c_long), C.c_int]
     L.dlg_sparse_set_pattern.argtypes = [V, I, I]
     L.dlg_sparse_stats.argtypes = [V, C.POINTER(C.c_long), C.POINTER(C.c_long), I, I, D]
@@ -438,6 +439,10 @@ class Backend:
         """join an RCCL communicator: collectives run on the backend's stream, no host in between"""
         buf = C.create_string_buffer(unique_id, 128)
         _ck(self.L.dlg_backend_init_rccl(self.h, rank, nranks, C.cast(buf, C.c_void_p)), "init_rccl")
+
+    def set_noop_comm(self, on=True):
+        """measurement only: one rank of a partition with every sum over the ranks skipped"""
+        _ck(self.L.dlg_backend_set_noop_comm(self.h, 1 if on else 0), "set_noop_comm")
 
     def comm_size(self):
         n = C.c_int()

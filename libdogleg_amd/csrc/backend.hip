@@ -339,6 +339,17 @@ extern "C" int dlg_backend_set_speculation(dlg_backend_t* b, int on)
   return DLG_OK;
 }
 
+// MEASUREMENT ONLY: the per-rank compute time of a partitioned step on ONE device, for a scaling projection where no
+// multi-GPU node is at hand (bench.py --logical-ranks).  Every sum over the ranks is skipped, so a rank sees only its
+// own contributions: the caller adds a lambda that keeps the partial top of the tree positive definite, and uses
+// nothing but the clocks.
+extern "C" int dlg_backend_set_noop_comm(dlg_backend_t* b, int on)
+{
+  if(!b) return DLG_ERR_ARG;
+  b->noop_comm = on != 0;
+  if(b->noop_comm) b->host_finals = false;
+  return DLG_OK;
+}
 extern "C" int dlg_backend_set_allreduce(dlg_backend_t* b, dlg_allreduce_fn fn, void* cookie)
 {
   if(!b) return DLG_ERR_ARG;
@@ -461,6 +472,7 @@ static void rccl_release(dlg_backend* b)
 // backend's stream -- nothing for the host to wait for --, or the caller's hook behind a synchronisation
 static int allreduce(dlg_backend* b, double* buf, size_t count)
 {
+  if(b->noop_comm) return DLG_OK;
   if(b->rccl_comm)
   {
     const int rc = g_rccl.AllReduce(buf, buf, count, DLG_NCCL_FLOAT64, DLG_NCCL_SUM, b->rccl_comm, b->stream);

@@ -144,7 +144,11 @@ struct dlg_backend
   // factorisation and leaves |J g|^2 of those rows in fold_scalar; the sum over the ranks is made together
   // with the solution's (sparse_solve -> fold_result = where the sum is), k_cauchy_finish follows on the main stream
   const double* fold_scalar = nullptr; const double* fold_result = nullptr; double* fold_cauchy_out = nullptr;
-  bool sharded() const { return allreduce != nullptr || rccl_comm != nullptr; }
+  // measurement only (dlg_backend_set_noop_comm): the backend behaves as one rank of several -- partition, reduce
+  // buffers, device-side finals, every collective's place in the stream -- but a sum over the ranks returns at once
+  // (the numbers are this rank's partial sums: timing, not results)
+  bool noop_comm = false;
+  bool sharded() const { return allreduce != nullptr || rccl_comm != nullptr || noop_comm; }
 
   // optional per-phase timing with HIP events on b->stream (dlg_backend_set_profiling)
   bool profiling = false;
