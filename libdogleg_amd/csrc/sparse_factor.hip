@@ -275,7 +275,6 @@ __global__ void __launch_bounds__(NT, LEAF ? 4 : 1) k_factor_level(const FwItem*
   const bool ahead = (mode & 8) != 0;           // panel_factor_ahead (barrier-free sweep) where the top block allows it
   const bool b16 = (mode & 16) != 0;            // panel_factor_b16 (blocks of 16, the diagonal tile in registers)
   const int b16_maxw = (mode >> 5) & 7 ? 64*((mode >> 5) & 7) : 1 << 20;      // ... for top blocks up to this width (tools: DOGLEG_AMD_B16_MAXW)
-  const bool leaf_dma = (mode & (1 << 14)) == 0;  // LEAF: the rows below the members by memory -> LDS copies (off: DOGLEG_AMD_NO_LEAF_DMA)
   mode &= 3;
   const FwItem it = items[blockIdx.x];
   const int r0 = it.r0, w = it.w, nrows = it.nrows;
@@ -322,30 +321,6 @@ __global__ void __launch_bounds__(NT, LEAF ? 4 : 1) k_factor_level(const FwItem*
   // a matter of timing only -- that pass depends on nothing this launch computes)
   if(pr_flag && tid == 0 && blockIdx.x == gridDim.x - 1)
     __hip_atomic_store(pr_flag + gridDim.x, pr_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  // LEAF (compact layout, rows below the members only): the rows come in by the copy engine of the texture path,
-  // memory -> LDS without registers (buffer_load_dword ... lds: 64 consecutive dwords of the LDS image per wave and
-  // instruction, every lane fetches the dword that belongs there -- column j = image dword / (2 ldp), the padding
-  // behind a column's rows reads out of range: zeros).  ALL of the panel's loads are in flight at once; through
-  // registers a thread had 16 of its 27 columns in flight and the phase cost two round trips under load (10 us of the
-  // 27 a leaf workgroup takes).
-  if(LEAF && leaf_dma)
-  {
-    const int twol = 2*ldp, nq = twol*w, mb2 = 2*mb;
-    const uint64_t ga = (uint64_t)(G + w);                       // first row below the members, column 0
-    typedef int v4i_t __attribute__((ext_vector_type(4)));
-    const v4i_t rsrc = { (int)(uint32_t)ga, (int)(uint32_t)((ga >> 32) & 0xffff), (int)(((unsigned)nrows*(unsigned)(w - 1) + (unsigned)mb)*8u), 0x00020000 };
-    const unsigned lds0 = (unsigned)(size_t)(const __attribute__((address_space(3))) char*)P;
-    int q = tid, j = q/twol, r = q - j*twol;
-    for(int q0 = (tid & ~63); q0 < nq; q0 += NT)
-    {
-      const unsigned voff = (q < nq && r < mb2) ? (unsigned)(j*2*nrows + r)*4u : 0xfffffff0u;
-      const unsigned m0v = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + 4u*(unsigned)q0));
-      // (lanes past the image are off: behind it lie the member blocks)
-      if(q < nq) asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, 0 offen lds" :: "s"(m0v), "v"(voff), "s"(rsrc) : "memory", "m0");
-      q += NT; r += NT;
-      while(r >= twol) { r -= twol; j++; }
-    }
-  }
   if(cmp)
   {
     __syncthreads();
@@ -354,8 +329,6 @@ __global__ void __launch_bounds__(NT, LEAF ? 4 : 1) k_factor_level(const FwItem*
   // thread = (panel row, column group): rows padded to whole waves, the remaining threads take
   // further columns
   const int cp_rows = min(NT, (nloc - row0c + 63) & ~63), cp_ng = NT/cp_rows, cp_g = tid/cp_rows;
-  if(LEAF && leaf_dma) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the copies issued in front of the member blocks have landed)
-  else
   for(int i = row0c + tid - cp_g*cp_rows; i < nloc && cp_g < cp_ng; i += cp_rows)
   {
     const double* gp = G + (i < w ? i : i + shift);
@@ -1063,7 +1036,6 @@ int sparse_factor_setup(dlg_backend* b, bool plan_only)
   Y->fac_ahead = getenv("DOGLEG_AMD_AHEAD") != nullptr;
   Y->fac_b16 = getenv("DOGLEG_AMD_NO_B16") == nullptr;
   Y->fac_b16_maxw = getenv("DOGLEG_AMD_B16_MAXW") ? atoi(getenv("DOGLEG_AMD_B16_MAXW"))/64 & 7 : 0;
-  Y->fac_no_leaf_dma = getenv("DOGLEG_AMD_NO_LEAF_DMA") != nullptr;
   Y->fac_lds.assign(H.nlevels, 0); Y->fac_nt.assign(H.nlevels, 512); Y->upd_coop.assign(H.nlevels, 0);
   Y->upd_lds.assign(H.nlevels, 0); Y->upd_nw.assign(H.nlevels, 0);
   Y->syrk_lds.assign(H.nlevels, 0); Y->syrk_nt.assign(H.nlevels, 256); Y->syrk_kc.assign(H.nlevels, 4);
@@ -1501,7 +1473,7 @@ int sparse_factor_levels(dlg_backend* b)
     {
       const int o = H.fw_lvl_ptr[l];
       const int use_ahead = (Y->fac_ahead ? 8 : 0) + (Y->fac_b16 ? 16 + 32*Y->fac_b16_maxw : 0);     // barrier-free sweep: measured slower (tools/micro/bench_ahead), kept for experiments
-      const int fmode = ((l >= H.mf_level0) ? 2 : Y->syrk_fused[l]) + 4*Y->fac_stage[l] + use_ahead + 256*(l & 31) + (Y->fac_no_leaf_dma ? (1 << 14) : 0);
+      const int fmode = ((l >= H.mf_level0) ? 2 : Y->syrk_fused[l]) + 4*Y->fac_stage[l] + use_ahead + 256*(l & 31);
       if(Y->fac_nt[l] == 128)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_factor_level<128>), dim3(n), dim3(128), Y->fac_lds[l], st,
                            Y->fw_item + o, Y->mf_rec, Y->sn_bd_col, Y->mf_dst, Y->Lx, Y->top_scr, Y->d_info, Y->uscr, fmode, (int*)nullptr, 0, DlgHandoff{nullptr, 0, 0}, (int64_t)0);

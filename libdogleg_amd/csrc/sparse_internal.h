@@ -135,7 +135,6 @@ struct SparseSym
   FwItem* pr_item = nullptr; MfChild* pr_rec = nullptr; uint16_t* pr_dst = nullptr; int pr_nwg = 0;
   std::vector<FwItem> pr_item_h; std::vector<MfChild> pr_rec_h; std::vector<uint16_t> pr_dst_h;   // ... on the host (plan-only set-up: dlg_sparse_region_probe)   // the region's work items (supernode x replica) and its copy of the children records
   int fac_b16_maxw = 0;
-  bool fac_no_leaf_dma = false;                              // DOGLEG_AMD_NO_LEAF_DMA: the leaf kernel's panel rows through registers
   // fin on the side: flags [A: Jt*x final / augmented row on its way, B: partial-sum stages done], their epoch, the
   // epoch the main stream still has to wait for (0: nothing owed), whether the schedule allows it at all
   // partial clears (sparse_assemble.hip, clear_panels): the ranges of a panel buffer outside the merged leaves' panels,
