@@ -305,6 +305,7 @@ int  dlg_kernel_syrk_lower(void* hip_stream, double* C_dev, int ldc, const doubl
 int  dlg_kernel_potrf_lower(void* hip_stream, double* A_dev, int lda, int n, int* info_dev);
 /* f64 MFMA issue-rate probe: returns achieved TFLOP/s */
 int  dlg_probe_mfma_f64(double* tflops);
+int  dlg_probe_mfma_f64_clock(double* tflops, double* clock3);   /* + {shader MHz during the loop, clocks per MFMA and wave, per SIMD} */
 int  dlg_probe_hbm_copy(double* gbytes_per_s);
 
 /* ---- per-phase GPU timing with HIP events on the backend's stream (bench.py's

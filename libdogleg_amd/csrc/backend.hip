@@ -202,14 +202,10 @@ extern "C" int dlg_backend_create(dlg_backend_t** out, int solve_type, int Nstat
   {
     dlg_backend::Knobs& k = b->knobs;
     k.no_k3_fork = getenv("DOGLEG_AMD_NO_K3_FORK") != nullptr;
-    k.p_side_copy = getenv("DOGLEG_AMD_P_SIDE_COPY") != nullptr;
-    k.lookahead = getenv("DOGLEG_AMD_LOOKAHEAD") != nullptr;
     k.no_potrf_fuse = getenv("DOGLEG_AMD_NO_POTRF_FUSE") != nullptr;
     k.potrf_steps = getenv("DOGLEG_AMD_POTRF_STEPS") != nullptr;
     k.trsv_steps = getenv("DOGLEG_AMD_TRSV_STEPS") != nullptr;
-    k.no_fork_gate = getenv("DOGLEG_AMD_NO_FORK_GATE") != nullptr;
     k.no_touch = getenv("DOGLEG_AMD_NO_TOUCH") != nullptr;
-    if(const char* v = getenv("DOGLEG_AMD_TOUCH_WG")) k.touch_wg = atoi(v);
     // test hook of the hand-off time-outs: the waits of the one-launch regions look for an epoch that never
     // comes and give up after a few hundred polls
     if(getenv("DOGLEG_AMD_DEBUG_HANDOFF_TIMEOUT")) { b->handoff_skew = 1; b->handoff_spins = 256; }
@@ -1188,8 +1184,7 @@ extern "C" int dlg_take_step(dlg_backend_t* b, int from, int to, double trustreg
       hipPointerAttribute_t attr;
       const bool pinned = hipPointerGetAttributes(&attr, p_new_host) == hipSuccess && attr.type == hipMemoryTypeHost;
       if(!pinned) (void)hipGetLastError();
-      const bool side_only = b->knobs.p_side_copy;
-      if(pinned && b->type == DLG_SPARSE && b->host_finals && !b->sharded() && attr.devicePointer && !side_only)
+      if(pinned && b->type == DLG_SPARSE && b->host_finals && !b->sharded() && attr.devicePointer)
       {
         // page-locked destination: the step's last kernel (K8) writes p_new there itself, a slice per
         // workgroup -- no event between the step kernel and K8 for a copy on the side stream to wait on

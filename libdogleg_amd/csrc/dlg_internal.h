@@ -87,8 +87,8 @@ struct dlg_backend
   // environment knobs that steer per-step paths, read ONCE when the backend is created (dlg_backend_create)
   struct Knobs
   {
-    bool no_k3_fork = false, p_side_copy = false, lookahead = false, no_potrf_fuse = false, potrf_steps = false,
-         trsv_steps = false, no_fork_gate = false, no_touch = false;
+    bool no_k3_fork = false, no_potrf_fuse = false, potrf_steps = false,
+         trsv_steps = false, no_touch = false;
     int touch_wg = 512;
   } knobs;
   int ncu = 256;              // compute units of b->device

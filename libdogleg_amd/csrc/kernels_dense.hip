@@ -609,6 +609,11 @@ __global__ void __launch_bounds__(TPB) k_probe_mfma(double* out, int iters)
   double4_t acc[4];
   for(int a = 0; a < 4; a++) acc[a] = (double4_t){0.0, 0.0, 0.0, 0.0};
   const double x = 1.0 + threadIdx.x*1e-9, y = 1.0 - threadIdx.x*1e-9;
+  // (a workgroup in the middle of the grid: the shader clock's count against the constant 100 MHz counter over its loop
+  // = the clock the matrix cores actually ran at while the whole chip did nothing but fp64 MFMAs)
+  const bool stamp = blockIdx.x == gridDim.x/2 && threadIdx.x == 0;
+  long long c0 = 0, w0 = 0;
+  if(stamp) { c0 = clock64(); w0 = wall_clock64(); }
   for(int it = 0; it < iters; it++)
   {
 #pragma unroll
@@ -616,6 +621,7 @@ __global__ void __launch_bounds__(TPB) k_probe_mfma(double* out, int iters)
   }
   double s = 0;
   for(int a = 0; a < 4; a++) s += acc[a][0] + acc[a][1] + acc[a][2] + acc[a][3];
+  if(stamp) { asm volatile("" :: "v"(s)); out[1] = (double)(clock64() - c0); out[2] = (double)(wall_clock64() - w0); }
   if(s == 12345.678) out[0] = s;
 }
 __global__ void __launch_bounds__(TPB) k_probe_copy(const double2* __restrict__ in,
@@ -679,91 +685,14 @@ int launch_syrk(hipStream_t st, double* C, int ldc, const double* A, int lda, in
   return DLG_OK;
 }
 
-// look-ahead part of the trailing update: only the NEXT panel's columns [c0, c0 + nc) of the
-// trailing matrix, C[i][j] -= sum_k X[i][k] X[j][k] for the rows i >= c0 (X = the panel just solved,
-// columns kb .. kb + nb).  A wave per 16 rows x 64 columns on the matrix cores; the 64 x 64 block of
-// X at the next panel's own rows sits in LDS as the B operand.
-__global__ void __launch_bounds__(TPB) k_panel_update(double* __restrict__ A, int lda, int kb, int nb, int c0, int nc, int n)
-{
-  __shared__ double Xt[NB][NB + 1];      // Xt[j][k] = X[c0 + j][k]
-  const int t = threadIdx.x, lane = t & 63, wv = t >> 6, mm = lane & 15, kq = lane >> 4;
-  for(int e = t; e < NB*NB; e += TPB)
-  {
-    const int j = e % NB, k = e / NB;
-    Xt[j][k] = (j < nc && k < nb) ? A[(size_t)(kb + k)*lda + c0 + j] : 0.0;
-  }
-  __syncthreads();
-  const int i0 = c0 + 16*(blockIdx.x*(TPB/64) + wv);
-  if(i0 >= n) return;
-  const int row = min(i0 + mm, n - 1);
-  double4_t acc[4];
-#pragma unroll
-  for(int jt = 0; jt < 4; jt++) acc[jt] = (double4_t){0.0, 0.0, 0.0, 0.0};
-  for(int k4 = 0; k4 < NB; k4 += 4)
-  {
-    const int k = k4 + kq;
-    const double a = (k < nb) ? A[(size_t)(kb + k)*lda + row] : 0.0;
-#pragma unroll
-    for(int jt = 0; jt < 4; jt++) acc[jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Xt[16*jt + mm][k], acc[jt], 0, 0, 0);
-  }
-#pragma unroll
-  for(int jt = 0; jt < 4; jt++)
-#pragma unroll
-    for(int q = 0; q < 4; q++)
-    {
-      const int i = i0 + kq + 4*q, j = 16*jt + mm;
-      if(i < n && j < nc && i >= c0 + j) A[(size_t)(c0 + j)*lda + i] -= acc[jt][q];
-    }
-}
-
-// blocked right-looking Cholesky with LOOK-AHEAD over two streams: after the panel of step k is solved
-// (diagonal block + triangular solve), only the next panel's columns are updated on the main stream
-// (k_panel_update), so the next diagonal block and solve can start; the rest of the trailing matrix is
-// updated by the fp64-MFMA SYRK on the second stream meanwhile.  st2 == nullptr: everything in order
-// on one stream (the default, see below).
+// blocked right-looking Cholesky, one launch chain per 64 columns (the step form; the default is the one-launch
+// k_potrf_tiles, dense_launch_potrf_tiles): diagonal block + triangular solve (one launch where `fuse`), then the
+// trailing update on the matrix cores.  (A look-ahead variant over two streams -- the next panel's columns first, the
+// rest of the trailing update beside the next diagonal block -- was measured slower, 2.23 ms against 2.15 on config #2:
+// three stream dependencies per step cost more than the overlapped SYRK saves; removed in round 4.)
 int potrf_lower(hipStream_t st, double* A, int lda, int n, int* info_dev, double* Linv,
-                hipStream_t st2 = nullptr, hipEvent_t ev_panel = nullptr, hipEvent_t ev_trail = nullptr,
-                int* flag = nullptr, int* epoch = nullptr, bool lookahead = false, bool fuse = false,
-                const DlgHandoff* ho = nullptr)
+                int* flag = nullptr, int* epoch = nullptr, bool fuse = false, const DlgHandoff* ho = nullptr)
 {
-  // measured on config #2 (N = 2000): 2.23 ms with look-ahead against 2.15 without -- the three stream
-  // dependencies per step cost more than the overlapped SYRK saves -- so it is opt-in (DOGLEG_AMD_LOOKAHEAD)
-  if(st2 && ev_panel && ev_trail && n > 4*NB && lookahead)
-  {
-    bool trail_pending = false;
-    for(int kb = 0, blk = 0; kb < n; kb += NB, blk++)
-    {
-      const int nb = (n - kb < NB) ? n - kb : NB;
-      double* Li = Linv + (size_t)blk*NB*NB;
-      dense_launch_potrf_diag(st, A, lda, kb, nb, info_dev, Li);
-      const int rem = n - kb - nb;
-      if(rem <= 0) break;
-      hipLaunchKernelGGL(k_trsm_gemm, dim3(dlg_cdiv(rem, NB)), dim3(TPB), 0, st, A, lda, kb, nb, n, Li);
-      DLG_HIP(hipEventRecord(ev_panel, st));
-      // the previous step's trailing update also wrote the next panel's columns: it must be done
-      // before this step's share is subtracted from them
-      if(trail_pending) DLG_HIP(hipStreamWaitEvent(st, ev_trail, 0));
-      const int c0 = kb + nb, nc = (rem < NB) ? rem : NB;
-      hipLaunchKernelGGL(k_panel_update, dim3(dlg_cdiv(rem, 16*(TPB/64))), dim3(TPB), 0, st, A, lda, kb, nb, c0, nc, n);
-      const int rem2 = rem - nc;
-      trail_pending = false;
-      if(rem2 > 0)
-      {
-        DLG_HIP(hipStreamWaitEvent(st2, ev_panel, 0));
-        double* Cc = A + (size_t)(c0 + nc)*lda + (c0 + nc);
-        const double* P = A + (size_t)kb*lda + (c0 + nc);
-        int rc;
-        if(rem2 >= 1024) rc = launch_syrk<64>(st2, Cc, lda, P, lda, rem2, nb, -1.0, 0.0, false, nullptr, 0);
-        else             rc = launch_syrk<32>(st2, Cc, lda, P, lda, rem2, nb, -1.0, 0.0, false, nullptr, 0);
-        if(rc != DLG_OK) return rc;
-        DLG_HIP(hipEventRecord(ev_trail, st2));
-        trail_pending = true;
-      }
-    }
-    if(trail_pending) DLG_HIP(hipStreamWaitEvent(st, ev_trail, 0));
-    DLG_LAUNCH_CHECK();
-    return DLG_OK;
-  }
   for(int kb = 0, blk = 0; kb < n; kb += NB, blk++)
   {
     const int nb = (n - kb < NB) ? n - kb : NB;
@@ -897,9 +826,8 @@ static int run_potrf(dlg_backend* b)
     DLG_LAUNCH_CHECK();
     return DLG_OK;
   }
-  return potrf_lower(b->stream, b->G, b->N, b->N, b->d_info, b->Linv,
-                     b->overlap ? b->copy_stream : nullptr, b->ev_step, b->ev_copy, b->potrf_flag + (size_t)T*T, &b->potrf_epoch,
-                     b->knobs.lookahead, !b->knobs.no_potrf_fuse, &ho);
+  return potrf_lower(b->stream, b->G, b->N, b->N, b->d_info, b->Linv, b->potrf_flag + (size_t)T*T, &b->potrf_epoch,
+                     !b->knobs.no_potrf_fuse, &ho);
 }
 
 static int finish_potrf(dlg_backend* b, int* ok)
@@ -1081,11 +1009,18 @@ extern "C" int dlg_factor_download_dense(dlg_backend_t* b, double* host, size_t 
   return DLG_OK;
 }
 
-extern "C" int dlg_probe_mfma_f64(double* tflops)
+// tflops: sustained fp64 MFMA rate of the whole chip (8 waves a CU, four independent accumulators a wave);
+// clock3 (may be NULL): {shader clock in MHz during the loop, clocks per MFMA and wave, clocks per MFMA and SIMD}
+extern "C" int dlg_probe_mfma_f64_clock(double* tflops, double* clock3)
 {
   double* d = nullptr;
-  DLG_HIP(hipMalloc(&d, 8));
-  const int iters = 20000, blocks = 256*8;
+  DLG_HIP(hipMalloc(&d, 32));
+  // ONE resident round: 4 workgroups of 4 waves on every CU (4 waves a SIMD).  (Until round 4 the grid was 2048
+  // workgroups: 8 a CU do not fit -- the accumulators' registers --, so a second, partly filled round ran behind the
+  // first and the "sustained" rate read 48 TFLOP/s; the stamps of one wave gave it away: 71 clocks per MFMA and SIMD.)
+  int ncu = 256;
+  { int dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev); if(ncu <= 0) ncu = 256; }
+  const int iters = 20000, wg_per_cu = 4, blocks = ncu*wg_per_cu;
   hipEvent_t e0, e1;
   DLG_HIP(hipEventCreate(&e0)); DLG_HIP(hipEventCreate(&e1));
   hipLaunchKernelGGL(k_probe_mfma, dim3(blocks), dim3(TPB), 0, 0, d, 100);
@@ -1096,9 +1031,19 @@ extern "C" int dlg_probe_mfma_f64(double* tflops)
   float ms = 0; DLG_HIP(hipEventElapsedTime(&ms, e0, e1));
   const double flops = (double)blocks*4 /*waves*/ * iters * 4 /*mfma*/ * 2048.0;
   *tflops = flops/(ms*1e-3)/1e12;
+  if(clock3)
+  {
+    double h[4] = {0, 0, 0, 0};
+    DLG_HIP(hipMemcpy(h, d, 32, hipMemcpyDeviceToHost));
+    const double cyc = h[1], ticks = h[2];                        // ticks: 100 MHz
+    clock3[0] = ticks > 0 ? cyc/(ticks/100.0) : 0.0;             // MHz
+    clock3[1] = cyc/((double)iters*4.0);                          // one wave issues iters * 4 MFMAs
+    clock3[2] = clock3[1]/(double)wg_per_cu;                      // wg_per_cu waves share a SIMD (4 waves a workgroup, one per SIMD)
+  }
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipFree(d);
   return DLG_OK;
 }
+extern "C" int dlg_probe_mfma_f64(double* tflops) { return dlg_probe_mfma_f64_clock(tflops, nullptr); }
 extern "C" int dlg_probe_hbm_copy(double* gbs)
 {
   const size_t bytes = (size_t)1 << 30;

@@ -386,18 +386,7 @@ __device__ __forceinline__ void panel_factor_mfma(double* P, int ldp, int nrows,
   }
   DLG_PF_DONE
 }
-// ---- panel factorisation with a diagonal wave that runs AHEAD (LDS panels, NT >= 256) -----------
-// panel_factor_mfma pays two workgroup barriers per 8 columns and its diagonal wave waits at both.
-// Here the top block (the w x w triangle, w <= PF_AHEAD_MAXW) belongs to wave 0 alone: it brings
-// its row tiles up to date on the matrix cores, factors the 8x8 block in registers and solves the
-// top-block rows below it -- all inside one wave, so nothing but program order (LDS operations of
-// a wave complete in order) synchronises those steps -- and publishes its progress in an LDS word.
-// The other waves own the rows below the top block in chunks of 64 (four MFMA row tiles, thread =
-// row for the solves) and trail behind: before the MFMA update of a block they wait for the
-// top-block rows it reads, before the row solves for the factored 8x8 block.  The dependency is
-// one-way (wave 0 never waits), there is no barrier inside the sweep, and the critical path is
-// wave 0's chain alone.
-constexpr int PF_AHEAD_MAXW = 128;
+// ---- hand-overs between the waves of a workgroup inside a sweep (panel_factor_b16) ----------------------------
 __device__ __forceinline__ void pf_wait(int* flag, int need)
 {
 #ifdef DLG_PF_BOUNDED_WAIT      // tools/micro: a protocol error shows as wrong numbers, not as a hung GPU
@@ -414,157 +403,6 @@ __device__ __forceinline__ void pf_wave_sync()
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-// two row tiles at absolute rows r0 and r0 + 16 (rows >= nrows are clamped / masked): columns
-// [kb, kb + nb) -= L[rows][kbeg:kb] * L[kb:kb+nb][kbeg:kb]'
-__device__ __forceinline__ void pf_tile_pair_at(double* P, int ldp, int nrows, int r0, int kb, int nb, int kbeg, int lane)
-{
-  const int mm = lane & 15, kq = lane >> 4;
-  const bool bvalid = mm < nb;
-  const double* bp = P + kb + (bvalid ? mm : 0) + kq*ldp;
-  double* cp = P + (kb + (bvalid ? mm : 0))*ldp;
-  const int r1 = r0 + 16;
-  const bool two = r1 < nrows;
-  const double* ap0 = P + min(r0 + mm, nrows - 1) + kq*ldp;
-  const double* ap1 = P + min(r1 + mm, nrows - 1) + kq*ldp;
-  dlg_pf_v4d acc0, acc1;
-#pragma unroll
-  for(int r = 0; r < 4; r++)
-  {
-    acc0[r] = cp[min(r0 + kq + 4*r, nrows - 1)];
-    acc1[r] = cp[min(r1 + kq + 4*r, nrows - 1)];
-  }
-  double b0 = bp[kbeg*ldp], b1 = bp[(kbeg + 4)*ldp], a00 = ap0[kbeg*ldp], a01 = ap0[(kbeg + 4)*ldp];
-  double a10 = ap1[kbeg*ldp], a11 = ap1[(kbeg + 4)*ldp];
-  for(int k0 = kbeg; k0 < kb; k0 += 8)
-  {
-    const int kn = (k0 + 8 < kb) ? k0 + 8 : k0;
-    const double nb0 = bp[kn*ldp], nb1 = bp[(kn + 4)*ldp];
-    const double na00 = ap0[kn*ldp], na01 = ap0[(kn + 4)*ldp];
-    const double na10 = ap1[kn*ldp], na11 = ap1[(kn + 4)*ldp];
-    __builtin_amdgcn_sched_barrier(0);
-    const double vb0 = bvalid ? -b0 : 0.0, vb1 = bvalid ? -b1 : 0.0;
-    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a00, vb0, acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a10, vb0, acc1, 0, 0, 0);
-    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a01, vb1, acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a11, vb1, acc1, 0, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    b0 = nb0; b1 = nb1; a00 = na00; a01 = na01; a10 = na10; a11 = na11;
-  }
-#pragma unroll
-  for(int r = 0; r < 4; r++)
-  {
-    const int row0 = r0 + kq + 4*r, row1 = r1 + kq + 4*r;
-    if(bvalid && row0 < nrows && row0 >= kb + mm) cp[row0] = acc0[r];
-    if(bvalid && two && row1 < nrows) cp[row1] = acc1[r];
-  }
-}
-// forward substitution of panel row r against the factored 8x8 block at kb (D, Dinv in registers)
-__device__ __forceinline__ void pf_solve_row(double* P, int ldp, int r, int kb, int nb, const double (&D)[8][8], const double (&Dinv)[8])
-{
-  double x[8];
-#pragma unroll
-  for(int c = 0; c < 8; c++) x[c] = (c < nb) ? P[r + (kb + c)*ldp] : 0.0;
-#pragma unroll
-  for(int c = 0; c < 8; c++)
-  {
-    double v = x[c];
-#pragma unroll
-    for(int q = 0; q < c; q++) v -= x[q]*D[c][q];
-    x[c] = v*Dinv[c];
-  }
-#pragma unroll
-  for(int c = 0; c < 8; c++) if(c < nb) P[r + (kb + c)*ldp] = x[c];
-}
-// s_dinv_all: PF_AHEAD_MAXW doubles of LDS (reciprocal pivots of every column), s_done_p: one int
-// of LDS (8-column blocks wave 0 has finished) -- the caller's, so that the kernel's static LDS
-// does not grow
-template <int NT>
-__device__ __forceinline__ void panel_factor_ahead(double* P, int ldp, int nrows, int w, int tid,
-                                                   int* __restrict__ info, int col0, double* s_dinv_all, int* s_done_p)
-{
-  static_assert(NT >= 256, "panel_factor_ahead needs at least 4 waves");
-  constexpr int NW = NT/64;
-  int& s_done = *s_done_p;
-  const int lane = tid & 63, wv = tid >> 6;
-  if(tid == 0) s_done = 0;
-  __syncthreads();
-  DLG_PF_DECL
-  if(wv == 0)
-  {
-    int b = 0;
-    for(int kb = 0; kb < w; kb += 8, b++)
-    {
-      const int nb = (w - kb < 8) ? w - kb : 8;
-      const int nb16 = ((kb & 15) == 0) ? min(16, w - kb) : nb, kbeg = ((kb & 15) == 0) ? 0 : kb - 8;
-      // the top-block row tiles from the diagonal down, two at a time
-      if(kb > 0)
-        for(int r0 = kb; r0 < w; r0 += 32) pf_tile_pair_at(P, ldp, w, r0, kb, nb16, kbeg, lane);
-      pf_wave_sync();
-      DLG_PF_STAMP(0);
-      double D[8][8], Dinv[8];
-      pf_load_block(D, P, ldp, kb, nb);
-      DLG_PF_STAMP(1);
-      const int badcol = pf_factor_block(D, Dinv);
-      DLG_PF_STAMP(2);
-      if(badcol >= 0 && lane == 0) atomicMin(info, col0 + kb + badcol);
-      {
-        const int c = lane >> 3, q = lane & 7;
-        double v = 0.0, dv = 0.0;
-#pragma unroll
-        for(int cc = 0; cc < 8; cc++)
-        {
-#pragma unroll
-          for(int qq = 0; qq <= cc; qq++) v = (cc == c && qq == q) ? D[cc][qq] : v;
-          dv = (cc == q) ? Dinv[cc] : dv;
-        }
-        if(q <= c && c < nb) P[(kb + c) + (kb + q)*ldp] = v;
-        if(c == 0) s_dinv_all[kb + q] = dv;
-      }
-      DLG_PF_STAMP(3);
-      for(int r = kb + nb + lane; r < w; r += 64) pf_solve_row(P, ldp, r, kb, nb, D, Dinv);
-      pf_wave_sync();
-      if(lane == 0) __hip_atomic_store(&s_done, b + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-      DLG_PF_STAMP(4);
-    }
-  }
-  else
-  {
-    const int mb = nrows - w;
-    const int c0 = wv - 1;                           // this wave's chunks: c0, c0 + (NW - 1), ... (64 rows each)
-    if(c0*64 < mb)
-    {
-      int b = 0;
-      for(int kb = 0; kb < w; kb += 8, b++)
-      {
-        const int nb = (w - kb < 8) ? w - kb : 8;
-        const int nb16 = ((kb & 15) == 0) ? min(16, w - kb) : nb, kbeg = ((kb & 15) == 0) ? 0 : kb - 8;
-        if(kb > 0)
-        {
-          // the update reads the top-block rows kb .. kb + nb16 in the columns before kb: final once
-          // wave 0 has finished block b - 1
-          pf_wait(&s_done, b);
-          for(int ch = c0; ch*64 < mb; ch += NW - 1)
-            for(int r0 = w + 64*ch; r0 < min(nrows, w + 64*ch + 64); r0 += 32)
-              pf_tile_pair_at(P, ldp, nrows, r0, kb, nb16, kbeg, lane);
-          pf_wave_sync();
-        }
-        pf_wait(&s_done, b + 1);
-        double D[8][8], Dinv[8];
-        pf_load_block(D, P, ldp, kb, nb);
-#pragma unroll
-        for(int c = 0; c < 8; c++) Dinv[c] = s_dinv_all[kb + c];
-        for(int ch = c0; ch*64 < mb; ch += NW - 1)
-        {
-          const int r = w + 64*ch + lane;
-          if(r < nrows) pf_solve_row(P, ldp, r, kb, nb, D, Dinv);
-        }
-        pf_wave_sync();
-      }
-    }
-  }
-  __syncthreads();
-  DLG_PF_DONE
 }
 // ---- panel factorisation by blocks of 16 columns, the diagonal tile in registers (LDS panels, NT >= 256) -------
 // The sweeps above pay, per 8 columns, a chain of dependent steps that each cross LDS: tile update -> block load ->

@@ -1229,7 +1229,7 @@ static int allreduce_panels(dlg_backend* b, bool* again)
   const SymHost& H = Y->H;
   hipStream_t st = b->stream;
   if(!b->sharded() || b->part_requested) return DLG_OK;      // (subtree partition: sparse_partition_reduce, at the cut)
-  if((size_t)H.lx_size >= ((size_t)1 << 32) || getenv("DOGLEG_AMD_ALLREDUCE_FULL"))
+  if((size_t)H.lx_size >= ((size_t)1 << 32))
     return dlg_allreduce_dev(b, Y->Lx, (size_t)H.lx_size);
   if(!Y->ar_idx)
   {

@@ -272,9 +272,7 @@ __global__ void __launch_bounds__(NT, LEAF ? 4 : 1) k_factor_level(const FwItem*
   FL_STAMP(0);
 #endif
   const bool stage_leaf_u = (mode & 4) != 0;    // childless supernodes may stage U in LDS too (host: no occupancy loss)
-  const bool ahead = (mode & 8) != 0;           // panel_factor_ahead (barrier-free sweep) where the top block allows it
   const bool b16 = (mode & 16) != 0;            // panel_factor_b16 (blocks of 16, the diagonal tile in registers)
-  const int b16_maxw = (mode >> 5) & 7 ? 64*((mode >> 5) & 7) : 1 << 20;      // ... for top blocks up to this width (tools: DOGLEG_AMD_B16_MAXW)
   mode &= 3;
   const FwItem it = items[blockIdx.x];
   const int r0 = it.r0, w = it.w, nrows = it.nrows;
@@ -368,8 +366,7 @@ __global__ void __launch_bounds__(NT, LEAF ? 4 : 1) k_factor_level(const FwItem*
   if(cmp) bd_compact_rows<NT, DS>(Pb, ldp, nloc, w, tid, it.nbd, s_mcol, s_rdiag, Dg);
   else if(LEAF) { }
   else if(it.nbd > 0) panel_factor_blockdiag<NT>(P, ldp, nloc, w, tid, sn_bd_col + it.bd0, it.nbd, &sbad, it.col0, s_mcol, s_rdiag);
-  else if(NT >= 256 && b16 && nloc <= 16*PF_B16_MAXT && w <= b16_maxw) panel_factor_b16<(NT >= 256 ? NT : 256)>(P, ldp, nloc, w, tid, &sbad, it.col0);
-  else if(NT >= 256 && ahead && w <= PF_AHEAD_MAXW) panel_factor_ahead<(NT >= 256 ? NT : 256)>(P, ldp, nloc, w, tid, &sbad, it.col0, s_rdiag, s_mcol);
+  else if(NT >= 256 && b16 && nloc <= 16*PF_B16_MAXT) panel_factor_b16<(NT >= 256 ? NT : 256)>(P, ldp, nloc, w, tid, &sbad, it.col0);
   else if(NT >= 256) panel_factor_mfma<(NT >= 256 ? NT : 256)>(P, ldp, nloc, w, tid, &sbad, it.col0);
   else         panel_factor<NT, true, true>(P, ldp, nloc, w, tid, &sbad, it.col0);
   FL_STAMP(3);
@@ -1033,9 +1030,7 @@ int sparse_factor_setup(dlg_backend* b, bool plan_only)
 {
   SparseSym* Y = b->sym;
   const SymHost& H = Y->H;
-  Y->fac_ahead = getenv("DOGLEG_AMD_AHEAD") != nullptr;
   Y->fac_b16 = getenv("DOGLEG_AMD_NO_B16") == nullptr;
-  Y->fac_b16_maxw = getenv("DOGLEG_AMD_B16_MAXW") ? atoi(getenv("DOGLEG_AMD_B16_MAXW"))/64 & 7 : 0;
   Y->fac_lds.assign(H.nlevels, 0); Y->fac_nt.assign(H.nlevels, 512); Y->upd_coop.assign(H.nlevels, 0);
   Y->upd_lds.assign(H.nlevels, 0); Y->upd_nw.assign(H.nlevels, 0);
   Y->syrk_lds.assign(H.nlevels, 0); Y->syrk_nt.assign(H.nlevels, 256); Y->syrk_kc.assign(H.nlevels, 4);
@@ -1055,7 +1050,7 @@ int sparse_factor_setup(dlg_backend* b, bool plan_only)
       maxr = std::max(maxr, (long)it.w + (it.r1 - it.r0));
     }
     // (the instantiation exists for 256 threads: the block size the level gets below)
-    const int nt = getenv("DOGLEG_AMD_FAC_NT") ? env_int_host("DOGLEG_AMD_FAC_NT", 256) : ((maxr <= 128) ? 128 : (maxr <= 256 ? 256 : 512));
+    const int nt = (maxr <= 128) ? 128 : (maxr <= 256 ? 256 : 512);
     Y->fac_leaf[l] = (all && nt == 256) ? 1 : 0;
   }
   for(int l = 0; l < H.nlevels; l++)
@@ -1082,7 +1077,6 @@ int sparse_factor_setup(dlg_backend* b, bool plan_only)
     }
     Y->fac_nt[l] = (maxr <= 128) ? 128 : (maxr <= 256 ? 256 : 512);
     if(l >= H.mf_level0) Y->fac_nt[l] = env_int_host("DOGLEG_AMD_MF_NT", 512);
-    else if(getenv("DOGLEG_AMD_FAC_NT")) Y->fac_nt[l] = env_int_host("DOGLEG_AMD_FAC_NT", 256);
     Y->upd_coop[l] = (maxw > 8) ? 1 : 0;           // heavy sources: matrix-core / cooperative update kernels
     if(maxp*8 > FAC_LDS_BUDGET) { dlg_set_error("internal error: a factor slice does not fit LDS (%ld doubles)", maxp); return DLG_ERR_ARG; }
     Y->fac_lds[l] = (int)(maxp*8);
@@ -1220,7 +1214,7 @@ int sparse_factor_setup(dlg_backend* b, bool plan_only)
     if(Y->pr_level0 < H.nlevels)
     {
       const int rmax = std::max(1, std::min(8, env_int_host("DOGLEG_AMD_FRONT_REPLICAS", 8)));
-      const int fill = env_int_host("DOGLEG_AMD_FRONT_FILL", ncu/2), fill0 = env_int_host("DOGLEG_AMD_FRONT_FILL0", ncu/2);
+      const int fill = env_int_host("DOGLEG_AMD_FRONT_FILL", ncu/2), fill0 = ncu/2;
       const bool slice_ok = !getenv("DOGLEG_AMD_NO_FRONT_SLICES");
       std::vector<FwItem> items;
       std::vector<int> first(H.fw_item.size(), -1), count(H.fw_item.size(), 0);
@@ -1237,9 +1231,9 @@ int sparse_factor_setup(dlg_backend* b, bool plan_only)
         // (the first level of the region is its most populous one, and the Cauchy step's pass over J runs beside
         // it: replicas there cost more in CUs than they save -- only what does not fit LDS whole is sliced)
         const int rl = std::max(1, std::min(rmax, (l == Y->pr_level0 ? fill0 : fill)/std::max(n, 1)));
-        // (DOGLEG_AMD_L1_REP=percent, 0 = off -- the first level's supernodes whose panel is at least that share of the
+        // (the first level's supernodes whose panel is at least 70 % of the
         // level's largest get a second workgroup for their update matrix, while CUs are left)
-        const int l1_pct = (l == Y->pr_level0 && rl == 1) ? env_int_host("DOGLEG_AMD_L1_REP", 70) : 0;
+        const int l1_pct = (l == Y->pr_level0 && rl == 1) ? 70 : 0;
         long l1_max = 0; int l1_left = std::max(0, ncu - n);
         if(l1_pct > 0) for(int i = H.fw_lvl_ptr[l]; i < H.fw_lvl_ptr[l+1]; i++) l1_max = std::max(l1_max, (long)H.fw_item[i].nrows*H.fw_item[i].w);
         for(int i = H.fw_lvl_ptr[l]; i < H.fw_lvl_ptr[l+1]; i++)
@@ -1253,7 +1247,6 @@ int sparse_factor_setup(dlg_backend* b, bool plan_only)
           // an update matrix that does not fit LDS whole (it.jsp < 0) fits in slices: two replicas at least
           int want = has_w ? std::min(rl_i, T) : 1;
           if(has_w && it.jsp < 0 && slice_ok) want = std::max(want, std::min(2, T));
-          else if(getenv("DOGLEG_AMD_SLICE_ONLY_IF_NEEDED")) want = 1;
           std::vector<int> cut;
           int nrep = 1;
           for(; want <= std::min(8, std::max(T, 1)); want++)
@@ -1443,20 +1436,17 @@ int sparse_factor_levels(dlg_backend* b)
     const int n = H.fw_lvl_ptr[l+1] - H.fw_lvl_ptr[l];
     // from the first level that cannot fill the chip on, the factorisation is latency-bound:
     // independent work (the Cauchy step's pass over J) may run beside it
-    const bool no_gate = l == Y->pr_level0 && b->knobs.no_fork_gate;
-    const bool gate_here = l == Y->pr_level0 && Y->fac_flag && !no_gate;      // (no event on this stream: the launch opens a gate)
+    const bool gate_here = l == Y->pr_level0 && Y->fac_flag;      // (no event on this stream: the launch opens a gate)
     if(l > 0 && n < 256 && !gate_here) dlg_fork_point(b);
     if(l == Y->pr_level0)
     {
       // the persistent top region: every remaining level in one launch (sparse_factor_setup)
       const int np = Y->pr_nwg;           // the region's own work items (replicas) and children records
-      const int fmode = 2 + 4*Y->pr_stage + (Y->fac_ahead ? 8 : 0) + (Y->fac_b16 ? 16 + 32*Y->fac_b16_maxw : 0) + 256*(l & 31);
+      const int fmode = 2 + 4*Y->pr_stage + (Y->fac_b16 ? 16 : 0) + 256*(l & 31);
       int* fl = Y->fac_flag; const int ep = ++Y->fac_epoch;
       if(gate_here && l > 0 && n < 256) dlg_fork_gate(b, fl + np, ep);
       const int64_t pacc = Y->pr_acc ? (int64_t)(Y->pr_acc - Y->uscr) : 0;
       const DlgHandoff ho = dlg_handoff(b, 1 << 21);
-      static const bool dbg_sync = getenv("DOGLEG_AMD_DEBUG_SYNC") != nullptr;     // tools: which launch faults
-      if(dbg_sync) { fprintf(stderr, "libdogleg_amd: before the one-launch region: %s\n", hipGetErrorString(hipStreamSynchronize(st))); fflush(stderr); }
       if(Y->fac_nt[l] == 128)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_factor_level<128>), dim3(np), dim3(128), Y->pr_lds, st,
                            Y->pr_item, Y->pr_rec, Y->sn_bd_col, Y->pr_dst, Y->Lx, Y->top_scr, Y->d_info, Y->uscr, fmode, fl, ep, ho, pacc);
@@ -1466,14 +1456,13 @@ int sparse_factor_levels(dlg_backend* b)
       else
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_factor_level<512>), dim3(np), dim3(512), Y->pr_lds, st,
                            Y->pr_item, Y->pr_rec, Y->sn_bd_col, Y->pr_dst, Y->Lx, Y->top_scr, Y->d_info, Y->uscr, fmode, fl, ep, ho, pacc);
-      if(dbg_sync) { fprintf(stderr, "libdogleg_amd: after the one-launch region (%d workgroups): %s\n", np, hipGetErrorString(hipStreamSynchronize(st))); fflush(stderr); }
       break;
     }
     if(n > 0 && !(l == 0 && Y->lf_on))      // (leaf fronts: level 0 was factored with the assembly, sparse_leaf.hip)
     {
       const int o = H.fw_lvl_ptr[l];
-      const int use_ahead = (Y->fac_ahead ? 8 : 0) + (Y->fac_b16 ? 16 + 32*Y->fac_b16_maxw : 0);     // barrier-free sweep: measured slower (tools/micro/bench_ahead), kept for experiments
-      const int fmode = ((l >= H.mf_level0) ? 2 : Y->syrk_fused[l]) + 4*Y->fac_stage[l] + use_ahead + 256*(l & 31);
+      const int sweep_bits = (Y->fac_b16 ? 16 : 0);
+      const int fmode = ((l >= H.mf_level0) ? 2 : Y->syrk_fused[l]) + 4*Y->fac_stage[l] + sweep_bits + 256*(l & 31);
       if(Y->fac_nt[l] == 128)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_factor_level<128>), dim3(n), dim3(128), Y->fac_lds[l], st,
                            Y->fw_item + o, Y->mf_rec, Y->sn_bd_col, Y->mf_dst, Y->Lx, Y->top_scr, Y->d_info, Y->uscr, fmode, (int*)nullptr, 0, DlgHandoff{nullptr, 0, 0}, (int64_t)0);
@@ -1608,25 +1597,6 @@ extern "C" int dlg_sparse_region_probe(int N, int M, const int* colptr, const in
     if(last && mb > 0 && it.u_off >= 0)
       for(long t = 0; t < T; t++) if(covered[(size_t)t] != 1) return fail("a tile column of the update matrix is not formed exactly once", g);
   }
-  if(getenv("DLG_REGION_WG_DUMP"))
-    for(size_t g = 0; g < Y.pr_item_h.size(); g++)
-    {
-      const FwItem& it = Y.pr_item_h[g];
-      fprintf(stderr, "rwg %zu s %d lvl %d rep %d w %d rows %d kids", g, it.s, it.pad, it.rep, it.w, it.nrows);
-      for(int k = 0; k < it.nch; k++) { const int r = Y.pr_rec_h[it.ch0 + k].rsv; fprintf(stderr, " %d:%d", r < 0 ? -1 : (r & 0xfffff), r < 0 ? 0 : (r >> 20)); }
-      fprintf(stderr, "\n");
-    }
-  if(getenv("DLG_REGION_DUMP"))
-    for(int l = std::max(0, H.nlevels - atoi(getenv("DLG_REGION_DUMP"))); l < H.nlevels; l++)
-      for(int i = H.fw_lvl_ptr[l]; i < H.fw_lvl_ptr[l+1]; i++)
-      {
-        const FwItem& it = H.fw_item[i];
-        fprintf(stderr, "level %d: supernode %d cols [%d, %d) w %d rows %d nbd %d children:", l, it.s, it.col0, it.col0 + it.w, it.w, it.nrows, it.nbd);
-        for(int k = H.mf_cptr[it.s]; k < H.mf_cptr[it.s+1]; k++) fprintf(stderr, " %d(w %d)", H.mf_child[k], H.sn_c0[H.mf_child[k]+1] - H.sn_c0[H.mf_child[k]]);
-        fprintf(stderr, "  first below rows:");
-        for(int r = it.w; r < std::min(it.nrows, it.w + 4); r++) fprintf(stderr, " %d", H.sn_rows[H.sn_rowptr[it.s] + r]);
-        fprintf(stderr, " ... last %d\n", H.sn_rows[H.sn_rowptr[it.s] + it.nrows - 1]);
-      }
   const long v[] = { (long)Y.pr_level0, (long)(H.fw_lvl_ptr[H.nlevels] - (Y.pr_level0 < H.nlevels ? H.fw_lvl_ptr[Y.pr_level0] : H.fw_lvl_ptr[H.nlevels])),
                      (long)Y.pr_nwg, (long)Y.pr_lds, nsliced, nhbm };
   for(int i = 0; i < nstats && i < 6; i++) stats[i] = v[i];

@@ -134,7 +134,6 @@ struct SparseSym
   int* fac_flag = nullptr; int fac_epoch = 0;   // one flag per workgroup of the region: the epoch of the launch that finished it
   FwItem* pr_item = nullptr; MfChild* pr_rec = nullptr; uint16_t* pr_dst = nullptr; int pr_nwg = 0;
   std::vector<FwItem> pr_item_h; std::vector<MfChild> pr_rec_h; std::vector<uint16_t> pr_dst_h;   // ... on the host (plan-only set-up: dlg_sparse_region_probe)   // the region's work items (supernode x replica) and its copy of the children records
-  int fac_b16_maxw = 0;
   // fin on the side: flags [A: Jt*x final / augmented row on its way, B: partial-sum stages done], their epoch, the
   // epoch the main stream still has to wait for (0: nothing owed), whether the schedule allows it at all
   // partial clears (sparse_assemble.hip, clear_panels): the ranges of a panel buffer outside the merged leaves' panels,
@@ -142,7 +141,6 @@ struct SparseSym
   int64_t* clr_off = nullptr; int64_t* clr_len = nullptr; int n_clr = 0; bool clr_partial_ok = false; double* lz_ok[2] = {nullptr, nullptr};
   int* fin_flag = nullptr; int fin_epoch = 0, fin_side_owed = 0; bool fin_side_sched_ok = false; hipStream_t fin_main = nullptr;
   bool fac_b16 = false;         // panel_factor_b16 (DOGLEG_AMD_B16)
-  bool fac_ahead = false;       // panel_factor_ahead instead of panel_factor_mfma (DOGLEG_AMD_AHEAD)
   // leaf fronts (sparse_leaf.hip): assembly + Jt*x + the leaves' factorisation in one kernel
   bool lf_on = false;
   LfLeaf* lf_leaf = nullptr; uint8_t* lf_blob = nullptr; double* lf_jtp = nullptr; char* lf_col = nullptr;

@@ -149,7 +149,6 @@ struct Orderer
     inset.assign(G.n, 0); vis.assign(G.n, 0);
     std::vector<int> dist(G.n, 0);
     int setctr = 0;
-    const long nd_debug = env_int("DOGLEG_AMD_ND_DEBUG", 0);      // print the separators of sets heavier than this
     // explicit stack of node sets; a frame with `sep` set flushes a separator
     struct Frame { std::vector<int> nodes; bool is_sep; };
     std::vector<Frame> stack;
@@ -231,13 +230,6 @@ struct Orderer
         for(int l = 0; l < nl; l++) { pre += lw[l]; if(2*pre >= wt) { best = l; break; } }
         if(best <= 0) best = 1;
         if(best >= nl-1) best = nl-2;
-      }
-      if(nd_debug && wt > nd_debug)
-      {
-        fprintf(stderr, "nd: set of %zu nodes (weight %ld): %d BFS levels, separator = level %d (weight %ld, %d nodes)  level weights around it:",
-                nodes.size(), wt, nl, best, lw[best], lvl_start[best+1] - lvl_start[best]);
-        for(int l = std::max(0, best - 3); l < std::min(nl, best + 4); l++) fprintf(stderr, " %ld", lw[l]);
-        fprintf(stderr, "\n");
       }
       std::vector<int> A(order.begin(), order.begin() + lvl_start[best]);
       std::vector<int> Sp(order.begin() + lvl_start[best], order.begin() + lvl_start[best+1]);
@@ -463,7 +455,7 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
   // they form one supernode with a block-diagonal top -> far fewer, wider panels
   // (rank-k updates instead of k rank-3 ones).  Moving a leaf earlier is always a
   // valid elimination order.
-  if(env_int("DOGLEG_AMD_GROUP_LEAVES", 1))
+  if(true)
   {
     std::vector<int> leaves;
     for(int j = 0; j < nvb; j++) if(nchild[j] == 0 && !st[j].empty()) leaves.push_back(j);
@@ -549,7 +541,7 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
     const int relax = env_int("DOGLEG_AMD_RELAX_PCT", 25);
     const int sib_w = env_int("DOGLEG_AMD_SIB_W", 64);
     const int split_w = env_int("DOGLEG_AMD_SPLIT_W", 32);   // columns from which a run stays a supernode of its own beside its parent's other children
-    const long chain_cap = env_int("DOGLEG_AMD_CHAIN_CAP", PANEL_CAP);   // width cap of chain supernodes: W*(W+64)
+    const long chain_cap = PANEL_CAP;   // width cap of chain supernodes: W*(W+64)
     // width of the fundamental supernode (maximal chain of exactly nested block columns) starting at j:
     // a relaxed merge across a structure change takes that whole run or nothing -- stopping in the
     // middle of it at the width cap leaves fragments that cost an elimination-tree level each
@@ -744,10 +736,9 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
   S.cut_level = -1;
   if(partition)
   {
-    const int oversub = std::max(1, env_int("DOGLEG_AMD_PART_OVERSUB", 1));
+    const int oversub = 1;
     for(int l = S.nlevels - 1; l >= 0; l--)
       if(S.lvl_ptr[l+1] - S.lvl_ptr[l] >= part_nranks*oversub) { S.cut_level = l; break; }
-    if(env_int("DOGLEG_AMD_PART_CUT", -2) >= -1) S.cut_level = std::min(S.nlevels - 1, env_int("DOGLEG_AMD_PART_CUT", -1));
     const int Lc = S.cut_level;
     // weight of a subtree: panel entries (a proxy for its assembly, factorisation and solve work)
     std::vector<double> wt(nsn, 0.0);
@@ -1096,7 +1087,7 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
     // chunking by estimated cost: a light sub-task (narrow source) counts 1, a
     // heavy one counts by its thread-iterations; a unit is closed at UNIT_COST
     const int unit_cost = env_int("DOGLEG_AMD_UNIT_COST", 1024);
-    const int unit_cost_gather = std::max(1, unit_cost/std::max(1, env_int("DOGLEG_AMD_GATHER_PER_UNIT", 64)));
+    const int unit_cost_gather = std::max(1, unit_cost/64);
     std::vector<int> cuts;
     for(int it = 0; it < nitems; it++)
     {
@@ -1174,7 +1165,7 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
     {
       const int c0 = rptr[v], c1 = rptr[v+1];
       if(c1 == c0) { S.jtx_covers_all = false; continue; }
-      int chunk = env_int("DOGLEG_AMD_CH_JTX", CH_JTX);
+      int chunk = CH_JTX;
       if((c1 - c0 + chunk - 1)/chunk > MAXCH_JTX) chunk = (c1 - c0 + MAXCH_JTX - 1)/MAXCH_JTX;
       const int nch = (c1 - c0 + chunk - 1)/chunk;
       if(nch == 1) S.jtx_task.push_back({v, c0, c1, -1, S.vb_start[v], G.w[v]});
@@ -1220,7 +1211,7 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
     // (same I in every row-block) or transient (all I different).  J qualifies when every
     // transient block receives exactly one contribution overall.
     const bool use_mfma = env_int("DOGLEG_AMD_ASM_MFMA", 1) != 0;
-    const int KG_PER_TASK_T = env_int("DLG_KGT", 64), KG_PER_TASK_P = env_int("DLG_KGP", 256);
+    const int KG_PER_TASK_T = 64, KG_PER_TASK_P = 256;
     std::map<std::vector<int>, int> shape_ids;
     std::vector<int> tseen(nvb, -1), pseen(nvb, -1), fin_of(nvb, -1);
     struct Ord { int I, nI, offI; bool P; };
@@ -1814,7 +1805,7 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
   {
     char e8[256] = "", e9a[256] = "", e9b[256] = "", e10[256] = "";
     int r8 = 0, r9a = 0, r9b = 0, r10 = 0;
-    if(env_int("DOGLEG_AMD_SYM_THREADS", 1))
+    if(true)
     {
       sym_parallel = true;
       std::thread t8([&] { r8 = step8(e8, sizeof(e8)); });

@@ -178,12 +178,12 @@ def test_syrk_and_potrf_kernels(gpu):
         assert np.max(np.abs(Lg - Lref)) <= 1e-11 * np.max(np.abs(Lref)), n
 
 
-@pytest.mark.parametrize("env", [{"DOGLEG_AMD_LOOKAHEAD": "1"}, {"DOGLEG_AMD_NO_OVERLAP": "1"}, {"DOGLEG_AMD_NO_K3_FORK": "1"},
+@pytest.mark.parametrize("env", [{"DOGLEG_AMD_NO_OVERLAP": "1"}, {"DOGLEG_AMD_NO_K3_FORK": "1"},
                                  {"DOGLEG_AMD_POTRF_STEPS": "1"}, {"DOGLEG_AMD_POTRF_STEPS": "1", "DOGLEG_AMD_NO_POTRF_FUSE": "1"},
                                  {"DOGLEG_AMD_TRSV_STEPS": "1"}],
-                         ids=["potrf-lookahead", "no-overlap", "no-k3-fork", "potrf-steps", "potrf-steps-unfused", "trsv-steps"])
+                         ids=["no-overlap", "no-k3-fork", "potrf-steps", "potrf-steps-unfused", "trsv-steps"])
 def test_dense_stream_variants_match_oracle(gpu, env, monkeypatch):
-    """the two-stream variants of the dense path (look-ahead potrf, Cauchy step beside the factorisation)
+    """the two-stream variant of the dense path (the Cauchy step beside the factorisation), the step forms of potrf / trsv
     and their single-stream forms give the oracle's Gauss-Newton step"""
     for k, v in env.items():
         monkeypatch.setenv(k, v)

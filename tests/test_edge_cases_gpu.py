@@ -283,3 +283,31 @@ def test_a_hand_off_that_times_out_is_an_error_not_a_wrong_answer(gpu, monkeypat
     assert r == -1.0
     monkeypatch.delenv("DOGLEG_AMD_DEBUG_HANDOFF_TIMEOUT")
     assert sparse_gn() == ref_s and dense_gn() == ref_d          # and nothing sticks to the library
+
+
+def test_a_pattern_that_changes_between_evaluations_is_refused_when_checked(gpu, monkeypatch):
+    """the reference assumes a fixed pattern of Jt (dogleg.c:648-649: analysed once); DOGLEG_AMD_CHECK_PATTERN=1 compares
+    every evaluation's pattern with the first one's: the same pattern solves as without the check, a callback that moves
+    an entry gets -1.0 instead of a factorisation with a stale schedule"""
+    monkeypatch.setenv("DOGLEG_AMD_CHECK_PATTERN", "1")
+    monkeypatch.setenv("DOGLEG_AMD_NO_BACKEND_CACHE", "1")
+    rng = np.random.default_rng(3)
+    M, N = 40, 4
+    J0, xs = rng.standard_normal((M, N)), rng.standard_normal(M)
+    prm = oa.default_params()
+    prm.max_iterations = 6
+    cb = _sparse_cb(J0, xs, M, N, 0.3)
+    trg, tro = _both("sparse", cb, np.full(N, 1.0), N, M, prm)
+    assert trg.ntrials >= 2
+    calls = [0]
+
+    @capi.CB_SPARSE
+    def moving(p, x, Jt, cookie):
+        cb(p, x, Jt, cookie)
+        calls[0] += 1
+        if calls[0] >= 2:
+            A = Jt.contents
+            ri = np.ctypeslib.as_array(C.cast(A.i, C.POINTER(C.c_int)), shape=(M * N,))
+            ri[0], ri[1] = 1, 0                       # the first row lists its variables in another order
+    r, p, tr = capi.optimize("sparse", np.full(N, 1.0), N, M, M * N, C.cast(moving, C.c_void_p), None, prm)
+    assert r == -1.0 and calls[0] == 2

@@ -150,7 +150,6 @@ def test_ba_lambda_path(gpu):
     {"DOGLEG_AMD_MF_MAXM": "60"},                                   # the region ends below the big fronts
     {"DOGLEG_AMD_DEVICE_FINALS": "1"},                              # second stage of every reduction on the device
     {"DOGLEG_AMD_BWD_XB_CAP": "40"},                                # backward solve: x of the below rows gathered from HBM
-    {"DOGLEG_AMD_AHEAD": "1"},                                      # barrier-free panel sweep (diagonal wave runs ahead)
     {"DOGLEG_AMD_NO_OVERLAP": "1"},                                 # Cauchy step on the main stream
     {"DOGLEG_AMD_NO_PERSIST": "1"},                                 # one launch per level all the way up
     {"DOGLEG_AMD_PERSIST_MAX": "100000"},                           # the persistent top region as deep as it can go
@@ -159,10 +158,17 @@ def test_ba_lambda_path(gpu):
     {"DOGLEG_AMD_NO_TOUCH": "1"},                                   # no cache hint for the leaf panels
     {"DOGLEG_AMD_NO_PREMUL": "1"},                                  # backward block sweep with the operands multiplied in the loop
     {"DOGLEG_AMD_NO_LEAF_KERNEL": "1"},                             # merged leaves through the general factor kernel
+    {"DOGLEG_AMD_BWD_TOP": "1"},                                    # backward solve: the top block staged in LDS (measured slower: off by default)
+    {"DOGLEG_AMD_BWD_FLAGS": "1"},                                  # backward region: flags instead of the sentinel-armed copy of x
+    {"DOGLEG_AMD_NO_EXT_EVENTS": "1"},                              # events recorded behind the kernels instead of riding on the launches
+    {"DOGLEG_AMD_FRONT_FILL": "16", "DOGLEG_AMD_FRONT_REPLICAS": "3"},   # other replica counts in the one-launch region
+    {"DOGLEG_AMD_SPLIT_W": "1000", "DOGLEG_AMD_RELAX_PCT": "0"},    # supernodes: no run kept beside its siblings, no relaxed merging
+    {"DOGLEG_AMD_UNIT_COST": "128", "DOGLEG_AMD_RUN_KG": "8"},      # small update units, short assembly runs
 ], ids=["lds-assembly", "coop-update", "mfma-update", "syrk-unfused", "no-rider", "small-slices", "no-multifrontal",
         "multifrontal-from-leaves", "multifrontal-128", "multifrontal-256", "multifrontal-small-fronts", "device-finals",
-        "bwd-x-from-hbm", "panel-ahead", "no-overlap", "no-persistent-top", "deep-persistent-top",
-        "leaf-lds-full", "separate-jtx", "no-touch", "no-premul", "no-leaf-kernel"])
+        "bwd-x-from-hbm", "no-overlap", "no-persistent-top", "deep-persistent-top",
+        "leaf-lds-full", "separate-jtx", "no-touch", "no-premul", "no-leaf-kernel", "bwd-top-lds", "bwd-flags", "no-ext-events",
+        "replica-counts", "supernode-rules", "small-units"])
 def test_fallback_kernels_match_oracle(gpu, env, monkeypatch):
     """the kernels the default schedule does not pick on a bundle-adjustment pattern stay correct:
     the schedule knobs are read when the pattern is set"""
@@ -260,37 +266,6 @@ def test_fused_backend_ops_match_the_separate_calls(gpu, kind):
     for u, v in zip(a[:7], b[:7]):
         assert u == v
     assert np.array_equal(a[7], b[7]) and np.array_equal(a[8], b[8])
-
-
-@pytest.mark.parametrize("env", ["DOGLEG_AMD_NO_FORK_GATE", "DOGLEG_AMD_P_SIDE_COPY"])
-def test_take_step_with_the_event_based_fork_and_side_copy(gpu, env, monkeypatch):
-    """the paths the one-launch schedule replaced -- an event where the Cauchy step forks off, p_new copied on
-    the side stream -- still give dlg_take_step's numbers bit for bit"""
-    prob = oa.BAProblem(49, 900, 10000, seed=9)
-    p = prob.p0()
-    x, J = prob.eval(p)
-    Jp, Ji = prob.pattern()
-
-    def run():
-        be = capi.Backend(capi.DLG_SPARSE, prob.N, prob.M, prob.nnz)
-        be.set_pattern(Jp, Ji)
-        be.set_speculation(True)
-        be.set_p(0, p)
-        be.upload(0, x, J)
-        be.eval(0)
-        lam, n2c, n2g = be.cauchy_gauss_newton(0, 0.0)
-        tr = 0.5 * (np.sqrt(n2c) + np.sqrt(n2g))
-        be.set_p(0, p)
-        be.upload(0, x, J)
-        be.eval(0)
-        lam, r, pnew = be.take_step(0, 1, tr, 0.0)
-        out = (lam, tuple(sorted(r.items())), pnew.copy())
-        be.close()
-        return out
-    ref = run()
-    monkeypatch.setenv(env, "1")
-    alt = run()
-    assert ref[0] == alt[0] and ref[1] == alt[1] and np.array_equal(ref[2], alt[2])
 
 
 @pytest.mark.parametrize("kind", ["sparse", "dense"])
