@@ -306,6 +306,7 @@ int  dlg_kernel_potrf_lower(void* hip_stream, double* A_dev, int lda, int n, int
 /* f64 MFMA issue-rate probe: returns achieved TFLOP/s */
 int  dlg_probe_mfma_f64(double* tflops);
 int  dlg_probe_mfma_f64_clock(double* tflops, double* clock3);   /* + {shader MHz during the loop, clocks per MFMA and wave, per SIMD} */
+int  dlg_probe_mfma_f64_waves(int waves_per_simd, double* tflops, double* clock3);   /* the same with 1 .. 8 waves a SIMD, one resident round */
 int  dlg_probe_hbm_copy(double* gbytes_per_s);
 
 /* ---- per-phase GPU timing with HIP events on the backend's stream (bench.py's

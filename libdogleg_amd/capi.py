@@ -30,7 +30,7 @@ BACKEND_SYMBOLS = [
     "dlg_factorize", "dlg_solve_gn", "dlg_gauss_newton", "dlg_cauchy_gauss_newton", "dlg_make_step",
     "dlg_expected_improvement", "dlg_step", "dlg_take_step", "dlg_solve_with_factor",
     "dlg_point_download", "dlg_factor_download_dense", "dlg_point_device_ptr",
-    "dlg_kernel_syrk_lower", "dlg_kernel_potrf_lower", "dlg_probe_mfma_f64", "dlg_probe_mfma_f64_clock",
+    "dlg_kernel_syrk_lower", "dlg_kernel_potrf_lower", "dlg_probe_mfma_f64", "dlg_probe_mfma_f64_clock", "dlg_probe_mfma_f64_waves",
     "dlg_probe_hbm_copy", "dlg_set_trace", "dlg_mem_alloc", "dlg_mem_free", "dlg_host_alloc",
     "dlg_host_free", "dlg_mem_upload",
     "dlg_mem_download", "dlg_mem_zero", "dlg_device_sync", "dlg_sparse_symbolic_probe", "dlg_sparse_leaf_probe",

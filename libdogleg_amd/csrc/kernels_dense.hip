@@ -604,7 +604,7 @@ __global__ void __launch_bounds__(TPB) k_jt_chunk_dense(const double* __restrict
 }
 
 // ------------------------------------------------------------ probes --------
-__global__ void __launch_bounds__(TPB) k_probe_mfma(double* out, int iters)
+__global__ void __launch_bounds__(TPB, 8) k_probe_mfma(double* out, int iters)
 {
   double4_t acc[4];
   for(int a = 0; a < 4; a++) acc[a] = (double4_t){0.0, 0.0, 0.0, 0.0};
@@ -630,14 +630,23 @@ __global__ void __launch_bounds__(TPB) k_probe_copy(const double2* __restrict__ 
   for(size_t i = (size_t)blockIdx.x*TPB + threadIdx.x; i < n; i += (size_t)gridDim.x*TPB) out[i] = in[i];
 }
 
-// number of K-splits for a tile count / K (so that ~1536 workgroups exist)
-static int syrk_nsplit(int ntiles, int K)
+// number of K-splits for a tile count / K: about 1536 workgroups, and -- two workgroups of the SYRK kernel are resident on a
+// CU -- a number of them that fills its LAST round of 2 * #CUs too.  Config #2: 136 tiles x 12 splits = 1632 workgroups are
+// 3.19 rounds of 512, i.e. four rounds with the last one a fifth full; measured (profiles/r04_experiments.md) 4.46 ms with
+// 12 splits, 4.08 with 11 (2.92 rounds), 4.09 with 15 (3.98), 4.67 with 13.  Among the split counts from two thirds of
+// the nominal one to 1.5 times it: the smallest whose rounds are filled to within 3 % of the best.
+static int syrk_nsplit(int ntiles, int K, int resident = 512)
 {
-  int ns = dlg_cdiv(1536, ntiles);
+  int nom = dlg_cdiv(1536, ntiles);
   const int maxs = K/(4*KC);
-  if(ns > maxs) ns = maxs;
-  if(ns < 1) ns = 1;
-  return ns;
+  if(nom > maxs) nom = maxs;
+  if(nom < 1) nom = 1;
+  const int lo = std::max(1, 2*nom/3), hi = std::max(lo, std::min(std::max(maxs, 1), nom + nom/2 + 1));
+  auto eff = [&](int ns) { const double r = (double)ntiles*ns/resident; return r/std::ceil(r); };
+  double beff = 0.0;
+  for(int ns = lo; ns <= hi; ns++) beff = std::max(beff, eff(ns));
+  for(int ns = lo; ns <= hi; ns++) if(eff(ns) >= beff - 0.03) return ns;
+  return nom;
 }
 
 // overwrite=false: C += alpha*A'A-style update, accumulated in place (one split).
@@ -1009,18 +1018,19 @@ extern "C" int dlg_factor_download_dense(dlg_backend_t* b, double* host, size_t 
   return DLG_OK;
 }
 
-// tflops: sustained fp64 MFMA rate of the whole chip (8 waves a CU, four independent accumulators a wave);
-// clock3 (may be NULL): {shader clock in MHz during the loop, clocks per MFMA and wave, clocks per MFMA and SIMD}
-extern "C" int dlg_probe_mfma_f64_clock(double* tflops, double* clock3)
+// tflops: sustained fp64 MFMA rate of the whole chip, ONE resident round of `waves_per_simd` workgroups of 4 waves on
+// every CU, four independent accumulators a wave; clock3 (may be NULL): {shader clock in MHz during the loop, clocks per
+// MFMA and wave, clocks per MFMA and SIMD}.  (Rounds 1-3 read 48 TFLOP/s here: the probe kernel was compiled without a
+// bound on its registers -- its accumulators travelled between AGPRs and VGPRs in every iteration -- and its grid
+// of 2048 workgroups ran a second, partly filled round behind the first.  profiles/r04_probe.txt.)
+extern "C" int dlg_probe_mfma_f64_waves(int waves_per_simd, double* tflops, double* clock3)
 {
+  if(waves_per_simd < 1 || waves_per_simd > 8 || !tflops) return DLG_ERR_ARG;
   double* d = nullptr;
   DLG_HIP(hipMalloc(&d, 32));
-  // ONE resident round: 4 workgroups of 4 waves on every CU (4 waves a SIMD).  (Until round 4 the grid was 2048
-  // workgroups: 8 a CU do not fit -- the accumulators' registers --, so a second, partly filled round ran behind the
-  // first and the "sustained" rate read 48 TFLOP/s; the stamps of one wave gave it away: 71 clocks per MFMA and SIMD.)
   int ncu = 256;
   { int dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev); if(ncu <= 0) ncu = 256; }
-  const int iters = 20000, wg_per_cu = 4, blocks = ncu*wg_per_cu;
+  const int iters = 20000, blocks = ncu*waves_per_simd;
   hipEvent_t e0, e1;
   DLG_HIP(hipEventCreate(&e0)); DLG_HIP(hipEventCreate(&e1));
   hipLaunchKernelGGL(k_probe_mfma, dim3(blocks), dim3(TPB), 0, 0, d, 100);
@@ -1038,11 +1048,12 @@ extern "C" int dlg_probe_mfma_f64_clock(double* tflops, double* clock3)
     const double cyc = h[1], ticks = h[2];                        // ticks: 100 MHz
     clock3[0] = ticks > 0 ? cyc/(ticks/100.0) : 0.0;             // MHz
     clock3[1] = cyc/((double)iters*4.0);                          // one wave issues iters * 4 MFMAs
-    clock3[2] = clock3[1]/(double)wg_per_cu;                      // wg_per_cu waves share a SIMD (4 waves a workgroup, one per SIMD)
+    clock3[2] = clock3[1]/(double)waves_per_simd;
   }
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipFree(d);
   return DLG_OK;
 }
+extern "C" int dlg_probe_mfma_f64_clock(double* tflops, double* clock3) { return dlg_probe_mfma_f64_waves(2, tflops, clock3); }
 extern "C" int dlg_probe_mfma_f64(double* tflops) { return dlg_probe_mfma_f64_clock(tflops, nullptr); }
 extern "C" int dlg_probe_hbm_copy(double* gbs)
 {

@@ -1165,22 +1165,28 @@ int sparse_factor_setup(dlg_backend* b, bool plan_only)
   // in-order dispatch cannot deadlock): a workgroup stages its panel at once, waits for its
   // children's flags, and raises its own flag as soon as its update matrix is out -- before its
   // panel goes back to HBM.  Conditions: unsliced supernodes, update matrices staged in LDS (their
-  // hand-off is the write-through store of that LDS copy), one block size, no update units, above
-  // the cut of a subtree partition.
-  Y->pr_level0 = H.nlevels;
-  if(!getenv("DOGLEG_AMD_NO_PERSIST") && H.nlevels >= 2)
+  // hand-off is the write-through store of that LDS copy), one block size, no update units.
+  // A subtree partition has TWO such regions (round 4): the levels of the rank's own subtrees up to the cut
+  // (PrRegion lo: measured per level launch they cost a rank 35 - 40 us a level, profiles/r04_scaling_projection.md)
+  // and, behind the sum over the ranks, the replicated levels above it (PrRegion top, as on one rank).
+  Y->pr_level0 = H.nlevels; Y->pr2_level0 = H.nlevels; Y->pr2_level1 = -1;
+  const bool dbg = getenv("DOGLEG_AMD_TIMING") != nullptr;
+  bool acc_any = false;
+  // levels [lo, hi] (as far down from hi as the conditions hold) -> region R; returns its first level (> hi: none)
+  auto build_region = [&](int lo_min, int hi, int& r_level0, int& r_lds, int& r_stage, int& r_nwg,
+                          std::vector<FwItem>& items, std::vector<MfChild>& rec, std::vector<uint16_t>& dst) -> int
   {
+    r_level0 = H.nlevels; r_nwg = 0;
+    if(getenv("DOGLEG_AMD_NO_PERSIST") || H.nlevels < 2 || hi < lo_min) return DLG_OK;
     // (a workgroup of the region fills a CU; more of them than CUs would only queue behind waiting ones)
     const int ncu = b->ncu;
     const int cap = env_int_host("DOGLEG_AMD_PERSIST_MAX", ncu);
-    int total = 0, l0 = H.nlevels, lds = 0, stage = 1;
-    bool acc = false;
-    const int nt = Y->fac_nt[H.nlevels - 1];
-    const bool dbg = getenv("DOGLEG_AMD_TIMING") != nullptr;
-    for(int l = H.nlevels - 1; l >= 1; l--)
+    int total = 0, l0 = hi + 1, lds = 0, stage = 1;
+    const int nt = Y->fac_nt[hi];
+    for(int l = hi; l >= std::max(1, lo_min); l--)
     {
       const int n = H.fw_lvl_ptr[l+1] - H.fw_lvl_ptr[l];
-      if(l < H.mf_level0 || (H.part_nranks > 1 && l <= H.cut_level)) break;
+      if(l < H.mf_level0) break;
       if(n == 0 || total + n > cap || Y->fac_nt[l] != nt || Y->fac_lds[l] <= 0) break;
       if(H.uw_lvl_ptr[l+1] > H.uw_lvl_ptr[l] || H.uf_lvl_ptr[l+1] > H.uf_lvl_ptr[l]) break;
       bool ok = true;
@@ -1192,17 +1198,8 @@ int sparse_factor_setup(dlg_backend* b, bool plan_only)
       if(!ok) break;
       stage = stage && Y->fac_stage[l]; total += n; l0 = l; lds = std::max(lds, Y->fac_lds[l]);
     }
-    if(H.nlevels - l0 >= 2)
-    {
-      Y->pr_level0 = l0; Y->pr_lds = lds; Y->pr_stage = stage;
-      for(int i = H.fw_lvl_ptr[l0]; i < H.fw_lvl_ptr[H.nlevels]; i++)
-      {
-        // the kernel's rule for staging the update matrix behind the panel
-        const FwItem& it = H.fw_item[i];
-        const long mb = it.nrows - it.w;
-        if(mb > 0 && it.nch > 0 && it.jsp < 0) acc = true;
-      }
-    }
+    if(hi + 1 - l0 < 2) return DLG_OK;
+    r_level0 = l0; r_lds = lds; r_stage = stage;
     // Replicas: the upper levels hold fewer supernodes than the chip has CUs, and behind the panel sweep of a
     // supernode sits its update matrix W = (children) - B B', a third of the level's critical path on ONE CU.
     // A supernode of such a level is given to several workgroups: each stages the panel, adds the children
@@ -1210,30 +1207,25 @@ int sparse_factor_setup(dlg_backend* b, bool plan_only)
     // over between them --, then forms and publishes only its share of W's tile columns; the parent waits
     // for all of them.  A level gets replicas while it and its neighbour level still fit the chip together
     // (a workgroup that finds no CU starts late and pays its panel load on the critical path).
-    Y->pr_nwg = 0;
-    if(Y->pr_level0 < H.nlevels)
     {
       const int rmax = std::max(1, std::min(8, env_int_host("DOGLEG_AMD_FRONT_REPLICAS", 8)));
       const int fill = env_int_host("DOGLEG_AMD_FRONT_FILL", ncu/2), fill0 = ncu/2;
       const bool slice_ok = !getenv("DOGLEG_AMD_NO_FRONT_SLICES");
-      std::vector<FwItem> items;
       std::vector<int> first(H.fw_item.size(), -1), count(H.fw_item.size(), 0);
       // the region's own children records and destination lists: those of the symbolic phase (whole update
       // matrix behind the panel), and behind them the lists of the replicas that keep a slice of it
-      std::vector<MfChild> rec(H.mf_rec);
-      std::vector<uint16_t> dst(H.mf_dst);
+      rec = H.mf_rec; dst = H.mf_dst;
       auto lin = [](long j, long mb) { return j*mb - j*(j - 1)/2; };       // packed index of (j, j)
       long lds_need = lds;
-      acc = false;
-      for(int l = Y->pr_level0; l < H.nlevels; l++)
+      for(int l = r_level0; l <= hi; l++)
       {
         const int n = H.fw_lvl_ptr[l+1] - H.fw_lvl_ptr[l];
         // (the first level of the region is its most populous one, and the Cauchy step's pass over J runs beside
         // it: replicas there cost more in CUs than they save -- only what does not fit LDS whole is sliced)
-        const int rl = std::max(1, std::min(rmax, (l == Y->pr_level0 ? fill0 : fill)/std::max(n, 1)));
+        const int rl = std::max(1, std::min(rmax, (l == r_level0 ? fill0 : fill)/std::max(n, 1)));
         // (the first level's supernodes whose panel is at least 70 % of the
         // level's largest get a second workgroup for their update matrix, while CUs are left)
-        const int l1_pct = (l == Y->pr_level0 && rl == 1) ? 70 : 0;
+        const int l1_pct = (l == r_level0 && rl == 1) ? 70 : 0;
         long l1_max = 0; int l1_left = std::max(0, ncu - n);
         if(l1_pct > 0) for(int i = H.fw_lvl_ptr[l]; i < H.fw_lvl_ptr[l+1]; i++) l1_max = std::max(l1_max, (long)H.fw_item[i].nrows*H.fw_item[i].w);
         for(int i = H.fw_lvl_ptr[l]; i < H.fw_lvl_ptr[l+1]; i++)
@@ -1252,13 +1244,13 @@ int sparse_factor_setup(dlg_backend* b, bool plan_only)
           for(; want <= std::min(8, std::max(T, 1)); want++)
           {
             // contiguous tile columns, tile counts T - t, the largest share as small as possible
-            for(int cap = (T*(T + 1)/2 + want - 1)/std::max(want, 1); ; cap++)
+            for(int cap2 = (T*(T + 1)/2 + want - 1)/std::max(want, 1); ; cap2++)
             {
               cut.assign(1, 0);
               int load = 0;
               for(int t = 0; t < T; t++)
               {
-                if(load > 0 && load + (T - t) > cap) { cut.push_back(t); load = 0; }
+                if(load > 0 && load + (T - t) > cap2) { cut.push_back(t); load = 0; }
                 load += T - t;
               }
               cut.push_back(T);
@@ -1278,7 +1270,7 @@ int sparse_factor_setup(dlg_backend* b, bool plan_only)
           if(nrep == 1 || !slice_ok)
           {
             // one workgroup (or replicas that each stage the whole update matrix: DOGLEG_AMD_NO_FRONT_SLICES)
-            if(it.jsp < 0) { nrep = 1; if(has_w && it.nch > 0) acc = true; }
+            if(it.jsp < 0) { nrep = 1; if(has_w && it.nch > 0) acc_any = true; }
             else if(nrep > 1) { /* whole-W replicas: the kernel's column-range copy-out */ }
           }
           first[i] = (int)items.size(); count[i] = nrep;
@@ -1325,8 +1317,20 @@ int sparse_factor_setup(dlg_backend* b, bool plan_only)
       // (the records of the symbolic phase: the children's workgroups in this launch)
       for(size_t k = 0; k < H.mf_rec.size(); k++)
         rec[k].rsv = (rec[k].rsv >= 0 && first[rec[k].rsv] >= 0) ? (first[rec[k].rsv] | (count[rec[k].rsv] << 20)) : -1;
-      Y->pr_nwg = (int)items.size();
-      Y->pr_lds = (int)std::max<long>(Y->pr_lds, lds_need);
+      r_nwg = (int)items.size();
+      r_lds = (int)std::max<long>(r_lds, lds_need);
+    }
+    if(dbg)
+      fprintf(stderr, "libdogleg_amd: one-launch region of the factorisation: levels %d..%d of %d (%d supernodes, %d workgroups, %d bytes of LDS, multifrontal from level %d)\n",
+              r_level0, hi, H.nlevels, total, r_nwg, r_lds, H.mf_level0);
+    return DLG_OK;
+  };
+  {
+    const bool part = H.part_nranks > 1;
+    std::vector<FwItem> items; std::vector<MfChild> rec; std::vector<uint16_t> dst;
+    DLG_CHECK(build_region(part ? H.cut_level + 1 : 1, H.nlevels - 1, Y->pr_level0, Y->pr_lds, Y->pr_stage, Y->pr_nwg, items, rec, dst));
+    if(Y->pr_level0 < H.nlevels)
+    {
       if(plan_only) { Y->pr_item_h.swap(items); Y->pr_rec_h.swap(rec); Y->pr_dst_h.swap(dst); }
       else
       {
@@ -1335,12 +1339,23 @@ int sparse_factor_setup(dlg_backend* b, bool plan_only)
         if(!Y->pr_dst)  { DLG_CHECK(upload(Y->pr_dst, dst));   Y->allocs.push_back(Y->pr_dst); }
       }
     }
-    if(dbg)
-      fprintf(stderr, "libdogleg_amd: persistent top region: levels %d..%d of %d (%d supernodes, %d workgroups, %d bytes of LDS, multifrontal from level %d)\n",
-              l0, H.nlevels - 1, H.nlevels, total, Y->pr_nwg, lds, H.mf_level0);
-    // update matrices of the region that do not fit LDS are summed (atomics) in a shadow of the scratch,
+    // the rank's own levels up to the cut (a partition whose cut leaves at least two multifrontal levels below it)
+    if(part && H.cut_level >= 2 && !plan_only)
+    {
+      std::vector<FwItem> items2; std::vector<MfChild> rec2; std::vector<uint16_t> dst2;
+      DLG_CHECK(build_region(1, H.cut_level, Y->pr2_level0, Y->pr2_lds, Y->pr2_stage, Y->pr2_nwg, items2, rec2, dst2));
+      if(Y->pr2_level0 <= H.cut_level)
+      {
+        Y->pr2_level1 = H.cut_level;
+        if(!Y->pr2_item) { DLG_CHECK(upload(Y->pr2_item, items2)); Y->allocs.push_back(Y->pr2_item); }
+        if(!Y->pr2_rec)  { DLG_CHECK(upload(Y->pr2_rec, rec2));   Y->allocs.push_back(Y->pr2_rec); }
+        if(!Y->pr2_dst)  { DLG_CHECK(upload(Y->pr2_dst, dst2));   Y->allocs.push_back(Y->pr2_dst); }
+      }
+      else Y->pr2_level0 = H.nlevels;
+    }
+    // update matrices of a region that do not fit LDS are summed (atomics) in a shadow of the scratch,
     // so that the slot the parent reads only ever sees write-through stores
-    if(acc && !Y->pr_acc && !plan_only)
+    if(acc_any && !Y->pr_acc && !plan_only)
     {
       DLG_HIP(hipMalloc(&Y->pr_acc, sizeof(double)*(size_t)std::max<int64_t>(1, H.uscr_size)));
       Y->allocs.push_back(Y->pr_acc);
@@ -1353,6 +1368,13 @@ int sparse_factor_setup(dlg_backend* b, bool plan_only)
     Y->allocs.push_back(Y->fac_flag);
     DLG_HIP(hipMemsetAsync(Y->fac_flag, 0, sizeof(int)*((size_t)Y->pr_nwg + 1), b->stream));
     Y->fac_epoch = 0;
+  }
+  if(Y->pr2_level0 < H.nlevels && !Y->fac2_flag)
+  {
+    DLG_HIP(hipMalloc(&Y->fac2_flag, sizeof(int)*((size_t)Y->pr2_nwg + 1)));
+    Y->allocs.push_back(Y->fac2_flag);
+    DLG_HIP(hipMemsetAsync(Y->fac2_flag, 0, sizeof(int)*((size_t)Y->pr2_nwg + 1), b->stream));
+    Y->fac2_epoch = 0;
   }
   DLG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_factor_level<128>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, FAC_LDS_BUDGET));
@@ -1436,8 +1458,30 @@ int sparse_factor_levels(dlg_backend* b)
     const int n = H.fw_lvl_ptr[l+1] - H.fw_lvl_ptr[l];
     // from the first level that cannot fill the chip on, the factorisation is latency-bound:
     // independent work (the Cauchy step's pass over J) may run beside it
-    const bool gate_here = l == Y->pr_level0 && Y->fac_flag;      // (no event on this stream: the launch opens a gate)
+    const bool gate_here = (l == Y->pr_level0 && Y->fac_flag) || (l == Y->pr2_level0 && Y->fac2_flag);      // (no event on this stream: the launch opens a gate)
     if(l > 0 && n < 256 && !gate_here) dlg_fork_point(b);
+    if(l == Y->pr2_level0 && Y->fac2_flag)
+    {
+      // a subtree partition: the rank's own levels up to the cut in one launch (sparse_factor_setup, region "lo")
+      const int np = Y->pr2_nwg;
+      const int fmode = 2 + 4*Y->pr2_stage + (Y->fac_b16 ? 16 : 0) + 256*(l & 31);
+      int* fl = Y->fac2_flag; const int ep = ++Y->fac2_epoch;
+      if(l > 0 && n < 256) dlg_fork_gate(b, fl + np, ep);
+      const int64_t pacc = Y->pr_acc ? (int64_t)(Y->pr_acc - Y->uscr) : 0;
+      const DlgHandoff ho = dlg_handoff(b, 1 << 21);
+      if(Y->fac_nt[l] == 128)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_factor_level<128>), dim3(np), dim3(128), Y->pr2_lds, st,
+                           Y->pr2_item, Y->pr2_rec, Y->sn_bd_col, Y->pr2_dst, Y->Lx, Y->top_scr, Y->d_info, Y->uscr, fmode, fl, ep, ho, pacc);
+      else if(Y->fac_nt[l] == 256)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_factor_level<256>), dim3(np), dim3(256), Y->pr2_lds, st,
+                           Y->pr2_item, Y->pr2_rec, Y->sn_bd_col, Y->pr2_dst, Y->Lx, Y->top_scr, Y->d_info, Y->uscr, fmode, fl, ep, ho, pacc);
+      else
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_factor_level<512>), dim3(np), dim3(512), Y->pr2_lds, st,
+                           Y->pr2_item, Y->pr2_rec, Y->sn_bd_col, Y->pr2_dst, Y->Lx, Y->top_scr, Y->d_info, Y->uscr, fmode, fl, ep, ho, pacc);
+      l = Y->pr2_level1;                                 // (= the cut: everything below it is done)
+      if(H.part_nranks > 1 && l == H.cut_level) { DLG_LAUNCH_CHECK(); DLG_CHECK(sparse_partition_reduce(b)); }
+      continue;
+    }
     if(l == Y->pr_level0)
     {
       // the persistent top region: every remaining level in one launch (sparse_factor_setup)

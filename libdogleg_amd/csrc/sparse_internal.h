@@ -133,6 +133,9 @@ struct SparseSym
   int pr_level0 = 1 << 30, pr_lds = 0;   // persistent top region of the factorisation: first level, LDS bytes (sparse_factor_setup)
   int* fac_flag = nullptr; int fac_epoch = 0;   // one flag per workgroup of the region: the epoch of the launch that finished it
   FwItem* pr_item = nullptr; MfChild* pr_rec = nullptr; uint16_t* pr_dst = nullptr; int pr_nwg = 0;
+  // a subtree partition's second one-launch region: the rank's own levels pr2_level0 .. pr2_level1 (= the cut)
+  int pr2_level0 = 1 << 30, pr2_level1 = -1, pr2_lds = 0, pr2_stage = 0, pr2_nwg = 0; int* fac2_flag = nullptr; int fac2_epoch = 0;
+  FwItem* pr2_item = nullptr; MfChild* pr2_rec = nullptr; uint16_t* pr2_dst = nullptr;
   std::vector<FwItem> pr_item_h; std::vector<MfChild> pr_rec_h; std::vector<uint16_t> pr_dst_h;   // ... on the host (plan-only set-up: dlg_sparse_region_probe)   // the region's work items (supernode x replica) and its copy of the children records
   // fin on the side: flags [A: Jt*x final / augmented row on its way, B: partial-sum stages done], their epoch, the
   // epoch the main stream still has to wait for (0: nothing owed), whether the schedule allows it at all
