@@ -515,14 +515,27 @@ __global__ void __launch_bounds__(TPB) k_jtx_fin2_short(const int* __restrict__ 
   for(int e = jf_ptr[v]; e < jf_ptr[v+1]; e++) sum += jtp[jf_ent[e] + a];
   Jt_x[var0[v] + a] = sum;
 }
+struct JfAug { double* Lx; const int64_t* augpos; const int* perm; const int64_t* aug_of_var; const char* listed; int n; int* info;
+               int* flag; int flag_epoch; int nlist_blocks; };
 __global__ void __launch_bounds__(1024) k_jtx_fin2_long(const int* __restrict__ blks,
                                                         const int* __restrict__ jf_ptr, const int* __restrict__ jf_ent,
                                                         const int* __restrict__ var0, const int* __restrict__ wv,
                                                         const double* __restrict__ jtp, double* __restrict__ Jt_x,
-                                                        double* __restrict__ segpart, int* __restrict__ segcnt)
+                                                        double* __restrict__ segpart, int* __restrict__ segcnt, JfAug aug)
 {
   __shared__ double sh[128*16];
   __shared__ int s_last;
+  // (aug.Lx: the launch also sets the augmented row of every panel -- the right-hand side Jt*x of the point just
+  // evaluated -- and re-arms the pivot flag: the blocks behind the lists' store the columns whose Jt*x the assembly kernel
+  // wrote itself, the workgroup that finishes the one list the columns of its block; it then raises the word that tells
+  // the second stream that Jt*x is final.  One kernel less between the assembly and the leaf level.)
+  if((int)blockIdx.x >= aug.nlist_blocks)
+  {
+    const int k = ((int)blockIdx.x - aug.nlist_blocks)*1024 + (int)threadIdx.x;
+    if(k == 0) *aug.info = 0x7fffffff;
+    if(k < aug.n) { const int var = aug.perm[k]; if(!aug.listed[var]) aug.Lx[aug.augpos[k]] = Jt_x[var]; }
+    return;
+  }
   // (blks: flat records {list begin, list end, first variable, width} -- sparse_set_pattern)
   // JFL_SEG workgroups per list, each sums a contiguous segment (one workgroup read the 60 000 records of
   // config #4's dense block at 0.6 TB/s: 11 us on the path of every evaluation); the last one to arrive
@@ -570,8 +583,15 @@ __global__ void __launch_bounds__(1024) k_jtx_fin2_long(const int* __restrict__ 
     for(int k = 0; k < JFL_SEG; k++)
       tot += __hip_atomic_load((gdp_t)(segpart + ((size_t)blk*JFL_SEG + k)*16 + threadIdx.x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     Jt_x[rec.z + threadIdx.x] = tot;
+    if(aug.Lx) aug.Lx[aug.aug_of_var[rec.z + threadIdx.x]] = tot;
   }
   if(threadIdx.x == 0) __hip_atomic_store(segcnt + blk, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // for the next launch (stream order)
+  if(aug.flag)
+  {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if(threadIdx.x == 0) __hip_atomic_store(aug.flag, aug.flag_epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  }
 }
 // persistent blocks written by several MFMA tasks: fixed-order sum of the listed partials.
 // k_assemble_fin2_short: one wave per block (lists of <= 32 partials);
@@ -1010,7 +1030,7 @@ __global__ void k_fin_flag(int* flag, int epoch)
 bool sparse_fin_side_ok(const dlg_backend* b)
 {
   const SparseSym* Y = b->sym;
-  return Y && Y->fin_side_sched_ok && Y->fin_flag && b->aux_stream && !Y->lf_on && Y->fin_pending_Lx && Y->fin_pending_rhs &&
+  return Y && Y->fin_side_sched_ok && Y->fin_flag && b->aux_stream && !Y->lf_on && Y->fin_pending_Lx && (Y->fin_pending_rhs || Y->aug_fused_epoch) &&
          !Y->fin_main && b->stream != b->aux_stream;
 }
 int sparse_fin_side_begin(dlg_backend* b)
@@ -1018,6 +1038,16 @@ int sparse_fin_side_begin(dlg_backend* b)
   SparseSym* Y = b->sym;
   const SymHost& H = Y->H;
   DLG_CHECK(sparse_fin_side_gate(b));                  // (stages of an evaluation nobody factorised: done with the buffers first)
+  if(Y->aug_fused_epoch)
+  {
+    // the Jt*x sums set the augmented rows and raise the word themselves (assemble_launch): nothing to launch here
+    const int ep = Y->aug_fused_epoch;
+    Y->aug_fused_epoch = 0;
+    DLG_CHECK(dlg_gate_wait(b, b->aux_stream, Y->fin_flag, ep, true));
+    Y->fin_main = b->stream;
+    b->stream = b->aux_stream;
+    return DLG_OK;
+  }
   const int ep = ++Y->fin_epoch;
   // main stream, behind the Jt*x sums: the augmented row of every panel (the stages never touch a last row), the pivot
   // flag re-armed -- and the word that tells the second stream that Jt*x is final
@@ -1112,7 +1142,8 @@ static int assemble_launch(dlg_backend* b, const double* Jv, double* Lx = nullpt
                            Y->lf_jf_ent, Y->lf_jf_var0, Y->lf_jf_w, Y->lf_jtp, Jt_x);
       if(nl > 0)
         hipLaunchKernelGGL(k_jtx_fin2_long, dim3(nl*JFL_SEG), dim3(1024), 0, st, Y->lf_jf_long, Y->lf_jf_ptr, Y->lf_jf_ent,
-                           Y->lf_jf_var0, Y->lf_jf_w, Y->lf_jtp, Jt_x, Y->lf_jf_lpart, Y->lf_jf_lcnt);
+                           Y->lf_jf_var0, Y->lf_jf_w, Y->lf_jtp, Jt_x, Y->lf_jf_lpart, Y->lf_jf_lcnt,
+                           JfAug{nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, 0, nl*JFL_SEG});
     }
     if(defer_fin) { Y->fin_pending_Lx = Lx; Y->fin_pending_rhs = Jt_x; }
     DLG_LAUNCH_CHECK();
@@ -1167,9 +1198,30 @@ static int assemble_launch(dlg_backend* b, const double* Jv, double* Lx = nullpt
     if(ns > 0)
       hipLaunchKernelGGL(k_jtx_fin2_short, dim3(dlg_cdiv(ns, TPB/16)), dim3(TPB), 0, st, Y->jf_short, ns, Y->jf_ptr,
                          Y->jf_ent, Y->jf_var0, Y->jf_w, Y->jtp, Jt_x);
+    // (an evaluation whose point may be factorised at once: the one long list's launch also sets the augmented rows,
+    // re-arms the pivot flag and raises the word for the second stream -- fin on the side needs no kernel of its own)
+    const bool fuse_aug = defer_fin && ns == 0 && nl == 1 && Y->aug_of_var && Y->fin_flag && !b->sharded() && H.part_nranks <= 1;
+    Y->aug_fused_epoch = 0;
     if(nl > 0)
-      hipLaunchKernelGGL(k_jtx_fin2_long, dim3(nl*JFL_SEG), dim3(1024), 0, st, Y->jf_long, Y->jf_ptr, Y->jf_ent,
-                         Y->jf_var0, Y->jf_w, Y->jtp, Jt_x, Y->jf_lpart, Y->jf_lcnt);
+    {
+      JfAug ja{nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, 0, nl*JFL_SEG};
+      int extra = 0;
+      if(fuse_aug)
+      {
+        Y->aug_fused_epoch = ++Y->fin_epoch;
+        ja = JfAug{Lx, Y->augpos, Y->perm, Y->aug_of_var, Y->jf_listed, H.N, Y->d_info, Y->fin_flag, Y->aug_fused_epoch, nl*JFL_SEG};
+        extra = dlg_cdiv(H.N, 1024);
+      }
+      hipLaunchKernelGGL(k_jtx_fin2_long, dim3(nl*JFL_SEG + extra), dim3(1024), 0, st, Y->jf_long, Y->jf_ptr, Y->jf_ent,
+                         Y->jf_var0, Y->jf_w, Y->jtp, Jt_x, Y->jf_lpart, Y->jf_lcnt, ja);
+    }
+    if(fuse_aug)
+    {
+      Y->fin_pending_Lx = Lx; Y->fin_pending_rhs = nullptr;      // (the stages only: the augmented row is set ...)
+      Y->spec_aug_fused = Jt_x;                                   // (... sparse_eval_assemble records that behind this call)
+      DLG_LAUNCH_CHECK();
+      return DLG_OK;
+    }
   }
   if(defer_fin) { Y->fin_pending_Lx = Lx; Y->fin_pending_rhs = Jt_x; DLG_LAUNCH_CHECK(); return DLG_OK; }
   return assemble_fin_launch(b, Lx);
@@ -1467,6 +1519,7 @@ int sparse_eval_assemble(dlg_backend* b, int s, int* done)
     if(b->sharded()) Y->fin_pending_rhs = nullptr;     // Jt*x is not summed over the ranks yet: the augmented row waits for the factorisation
   }
   Y->spec_valid = true; Y->spec_slot = s; Y->spec_J = S.Jin(); Y->spec_aug_rhs = nullptr;
+  if(Y->spec_aug_fused) { Y->spec_aug_rhs = Y->spec_aug_fused; Y->info_clean = true; Y->spec_aug_fused = nullptr; }    // (set with the Jt*x sums: assemble_launch)
   *done = 1;
   return DLG_OK;
 }

@@ -246,6 +246,16 @@ int sparse_set_pattern(dlg_backend* b, const int* colptr, const int* rowidx)
       ap[k] = H.sn_lx[s2] + (nrows - 1) + (int64_t)(k - H.sn_c0[s2])*nrows;
     }
     DLG_CHECK(upload(Y->augpos, ap)); Y->allocs.push_back(Y->augpos);
+    // by variable (the Jt*x sums that also set the augmented rows, sparse_assemble.hip): its entry's place, and
+    // whether its Jt*x is summed from a record list (then the list's workgroup stores the entry)
+    std::vector<int64_t> av((size_t)H.N);
+    for(int k = 0; k < H.N; k++) av[(size_t)H.perm[k]] = ap[k];
+    std::vector<char> listed((size_t)H.N, 0);
+    for(int pass = 0; pass < 2; pass++)
+      for(int v : (pass ? H.jf_long : H.jf_short))
+        for(int q = 0; q < H.jf_w[v]; q++) listed[(size_t)H.jf_var0[v] + q] = 1;
+    DLG_CHECK(upload(Y->aug_of_var, av)); Y->allocs.push_back(Y->aug_of_var);
+    DLG_CHECK(upload(Y->jf_listed, listed)); Y->allocs.push_back(Y->jf_listed);
   }
   {
     // Jt*x partial lists: the few long ones (a dense block that every row touches) get a big workgroup each

@@ -142,6 +142,8 @@ struct SparseSym
   // partial clears (sparse_assemble.hip, clear_panels): the ranges of a panel buffer outside the merged leaves' panels,
   // and the buffers whose leaves are known to hold nothing but zeros outside the structure of JtJ
   int64_t* clr_off = nullptr; int64_t* clr_len = nullptr; int n_clr = 0; bool clr_partial_ok = false; double* lz_ok[2] = {nullptr, nullptr};
+  int64_t* aug_of_var = nullptr; char* jf_listed = nullptr;      // by variable: where its augmented-row entry lies; its Jt*x comes from a record list
+  int aug_fused_epoch = 0; const double* spec_aug_fused = nullptr;   // the Jt*x sums of the last evaluation set the augmented rows (epoch of their word)
   int* fin_flag = nullptr; int fin_epoch = 0, fin_side_owed = 0; bool fin_side_sched_ok = false; hipStream_t fin_main = nullptr;
   bool fac_b16 = false;         // panel_factor_b16 (DOGLEG_AMD_B16)
   // leaf fronts (sparse_leaf.hip): assembly + Jt*x + the leaves' factorisation in one kernel
