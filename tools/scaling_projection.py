@@ -52,7 +52,11 @@ print("|---|---|---|---|")
 for lat in (15e-3, 30e-3, 50e-3):
     t = slow + 4*lat
     print(f"| {lat*1e3:.0f} us | {t:.4f} | {1e3/t:.0f} | {one['ms_per_step']/t:.2f} x |")
+k5_1, k5_r = p1.get("K5_factor", 0), max(d["phases_ms_per_step"].get("K5_factor", 0) for d in rows)
 print(f"\nSlowest rank {slow:.4f} ms against {one['ms_per_step']:.4f} ms on one GPU: {one['ms_per_step']/slow:.2f} x is the ceiling the partition's compute "
-      "leaves before any collective is paid for -- the levels between the leaves and the cut keep their per-level latency and the top of the")
-print("tree is replicated (DESIGN §7).  The north star's 3.5 x at 8 GPUs is out of reach for this configuration with this algorithm; config #5, whose")
-print("step is dominated by the passes over J and the leaf level, is where the partition pays.")
+      "leaves before any collective is paid for.  The passes over J and the leaf level shrink with the rank's rows; the factorisation does not")
+print(f"(K5 {k5_1:.3f} ms on one GPU, {k5_r:.3f} ms on the slowest rank): the levels between the leaves and the cut keep their per-level latency -- since round 4 as ONE")
+print("launch with replicas (`sparse_factor_setup`, region \"lo\"; before, one launch per level: 0.37 - 0.43 ms a rank, a rank's share took as long as the")
+print("whole problem on one GPU) --, then come pack / sum / unpack of the cut buffer and the replicated top of the tree.  The north star's 3.5 x at")
+print("8 GPUs is out of reach for this configuration with this algorithm: sharding rows does not shorten the elimination tree's critical path.")
+print("Config #5, whose step is dominated by the passes over J and the leaf level, is where the partition pays.")
