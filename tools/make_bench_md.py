@@ -32,6 +32,12 @@ def row2(k, label):
     return f"| {label} | {b['value']:.1f} | {b['ms_per_step']:.2f} | {spec(k)} | {cpu} |"
 ok = B["sparse1m"]["other_kernels"]
 hc, dc = e2e["host_callback"], e2e["device_callback"]
+import re as _re
+_pt = open(os.path.join(P, f"{tag}_probe.txt")).read() if os.path.exists(os.path.join(P, f"{tag}_probe.txt")) else ""
+_m = _re.search(r"best of the above\): ([0-9.]+) TFLOP/s", _pt) or _re.search(r"([0-9.]+) TFLOP/s", _pt)
+probe_mfma = _m.group(1) if _m else "n/a"
+_m = _re.search(r"HBM copy[^:]*: ([0-9.]+) GB/s", _pt)
+probe_hbm = _m.group(1) if _m else "n/a"
 md = f"""# Round {int(tag[1:])} -- measurements on one MI355X (gpurun box, ROCm 7.2, hipcc gfx950)
 
 All numbers from `python bench.py` (JSON lines committed next to this file) and
@@ -71,7 +77,7 @@ Rooflines:
   memory latency exposed per wave ({tag}_pmc.md: 60 % of the wave cycles in s_waitcnt, matrix cores 18 % busy); K1's own
   pass over J is gone.
 * dense-50k `k_syrk_lower<64>` (K4): {rd['algorithmic_flops']:.3e} flop / {rd['avg_launch_ms']:.3f} ms = **{rd['achieved']:.1f} TFLOP/s** = {100*rd['frac']:.0f} % of the 78.6
-  TFLOP/s datasheet fp64-matrix peak (48 TFLOP/s is what a register-only v_mfma_f64_16x16x4_f64 loop sustains here).
+  TFLOP/s datasheet fp64-matrix peak, which a register-only v_mfma_f64_16x16x4_f64 loop does sustain here ({probe_mfma} TFLOP/s, {tag}_probe.txt; the 48 of rounds 1-3 was a faulty probe: {tag}_probe_notes.md).
 * sparse-1m `k_norm2_Jv` (K3/K8): {ok['K3K8_norm2_Jv']['algorithmic_bytes']/1e6:.0f} MB / {1e3*ok['K3K8_norm2_Jv']['ms']:.0f} us = {ok['K3K8_norm2_Jv']['GBps']:.0f} GB/s = {100*ok['K3K8_norm2_Jv']['frac_hbm']:.0f} % of HBM (J past the Infinity Cache).
 * K5-sparse and K6-sparse are latency / critical-path bound (SURVEY 8d says to expect low fractions and to
   say so): K5 = {k5b/1e6:.0f} MB (`8 nnz(tril JtJ) + 8 nnz(L)`) and {k5f/1e9:.2f} GFLOP in {k5t:.2f} ms = {k5b/k5t/1e6:.0f} GB/s
@@ -96,7 +102,7 @@ symbolic analysis {e2e['symbolic_analysis_s']:.2f} s in the first solve of a pat
 of the same pattern afterwards (15 ms); final p of the two differs by {e2e['max_abs_p_diff_device_vs_host']:.1e}.
 
 RCCL in-stream path at world size 1 (the library's own communicator, `dlg_backend_init_rccl`):
-`{tag}_bench_dist_world1_rccl.log`.  Probes ({tag}_probe.txt): fp64 MFMA issue rate 48 TFLOP/s; HBM copy 4.9 TB/s.
+`{tag}_bench_dist_world1_rccl.log`.  Probes ({tag}_probe.txt): fp64 MFMA sustained {probe_mfma} TFLOP/s; HBM copy {probe_hbm} GB/s.
 """
 open(os.path.join(P, f"{tag}_bench.md"), "w").write(md)
 print(md[:1500])
