@@ -1145,6 +1145,9 @@ int sparse_factor_setup(dlg_backend* b, bool plan_only)
       Y->fac_stage[l] = (per_cu1 == per_cu0) ? 1 : 0;
       Y->fac_lds[l] = (int)(Y->fac_stage[l] ? std::max(base, leaves) : base);
     }
+    if(getenv("DOGLEG_AMD_SYM_DEBUG"))
+      fprintf(stderr, "factor level %d: %d supernodes, dynamic LDS %d bytes, update matrices staged %d, leaf instantiation %d, gather: %d waves, %d bytes\n",
+              l, H.lvl_ptr[l+1] - H.lvl_ptr[l], Y->fac_lds[l], (int)Y->fac_stage[l], (int)Y->fac_leaf[l], Y->upd_nw[l], Y->upd_lds[l]);
   }
   if(!Y->uw_flat && !H.uw_item.empty() && !plan_only)
   {

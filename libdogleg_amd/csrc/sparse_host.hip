@@ -553,6 +553,20 @@ extern "C" int dlg_sparse_symbolic_probe(int N, int M, const int* colptr, const 
                      (long)H.jtx_task.size(), (long)H.asm_mtask.size(), (long)H.asm_kg.size(),
                      (long)H.asm_shape.size(), (long)H.lf_ok, (long)H.lf_leaf.size(), (long)H.lf_lds, (long)H.lf_blob.size(), (long)H.lf_jtp_size };
   if(!H.lf_ok && getenv("DOGLEG_AMD_SYM_DEBUG")) fprintf(stderr, "leaf fronts off: %s\n", H.lf_why);
+  if(getenv("DOGLEG_AMD_SYM_DEBUG"))
+    for(int l = 0; l + 1 < (int)H.uw_lvl_ptr.size(); l++)
+    {
+      long nu = 0, direct = 0, part = 0, subs = 0;
+      for(int u = H.uw_lvl_ptr[l]; u < H.uw_lvl_ptr[l+1]; u++)
+      {
+        const int item = H.uw_item[u], t = H.ui_t[item];
+        const long slab = (long)(H.sn_rowptr[t+1] - H.sn_rowptr[t])*H.ui_nc[item];
+        nu++; subs += H.uw_s1[u] - H.uw_s0[u];
+        (H.uw_part[u] < 0 ? direct : part) += slab;
+      }
+      if(nu) fprintf(stderr, "update level %d: %ld units, %ld sub-tasks, slabs applied directly %ld doubles, partial slabs %ld doubles, U scratch %ld doubles, two-phase %d\n",
+                     l, nu, subs, direct, part, (long)H.uscr_size, (int)H.upd_syrk[l]);
+    }
   for(int i = 0; i < nstats && i < (int)(sizeof(v)/sizeof(v[0])); i++) stats[i] = v[i];
   if(perm_out) memcpy(perm_out, H.perm.data(), sizeof(int)*(size_t)N);
   return DLG_OK;
