@@ -276,7 +276,7 @@ __device__ __forceinline__ void asm_mfma_run(const AsmRun& R, const AsmMTask* __
 #define PA(r)  (int)(pk1[r] >> 24)
 #define PAO(r) (int)(pk2[r] & 0xFF)
 #define PNI(r) (int)(pk2[r] >> 8)
-  dlg_v4d accP = {0.0, 0.0, 0.0, 0.0}, accT = {0.0, 0.0, 0.0, 0.0};
+  dlg_v4d accP = {0.0, 0.0, 0.0, 0.0};
   // task records: current + next (fetched ahead, as ONE vector load each: lane l holds dword l of
   // the record, fields are broadcast with readlane; vector loads return in order, so prefetches
   // overlap with the rest -- scalar loads would share a counter with the LDS traffic);
@@ -330,7 +330,11 @@ __device__ __forceinline__ void asm_mfma_run(const AsmRun& R, const AsmMTask* __
         const int xrow = __builtin_amdgcn_ds_bpermute(4*(KD*u + 6 + kq), rec);
         if(m == 15) src = xvec + xrow;
       }
+#ifdef DLG_ASM_NO_VLOAD
+      vpre[u] = (double)(((long)src >> 3) & 7);
+#else
       vpre[u] = *src;
+#endif
     } };
   vals_fetch(gnv, R.kg0);
 #endif
@@ -408,23 +412,28 @@ __device__ __forceinline__ void asm_mfma_run(const AsmRun& R, const AsmMTask* __
       if(JTX) jacc += (x_in_tile ? row[15] : xv[u])*bP;
       if(HAS_T)
       {
+        // (every k-group of the schedule closes its row-blocks -- sparse_symbolic.cpp, close_kg --: the transient
+        // product starts from zero and is stored at once; a k-group past the end has no slot, so nothing is `mine`.
+        // The four row offsets are fetched together, in front of the product: one LDS round trip, not four behind it)
         const int myslot = (meta[u] >> (2*kq)) & 3;
-        accT = __builtin_amdgcn_mfma_f64_16x16x4f64(row[tc], row[bs == myslot ? bcol : ZC], accT, 0, 0, 0);
-        if(meta[u] & (1u << 11))
-        {
-          const bool mine = bs < (int)((meta[u] >> 8) & 7);
+        const bool mine = bs < (int)((meta[u] >> 8) & 7);
+        int ro[4];
 #pragma unroll
-          for(int r = 0; r < 4; r++)
-            if(4*r < MT)
-            {
-              const int ro = __builtin_amdgcn_ds_bpermute(4*(bs*nT + TJ(r)), td[u]);
+        for(int r = 0; r < 4; r++) ro[r] = __builtin_amdgcn_ds_bpermute(4*(bs*nT + TJ(r)), td[u]);
+        const dlg_v4d t4 = __builtin_amdgcn_mfma_f64_16x16x4f64(row[tc], row[bs == myslot ? bcol : ZC], (dlg_v4d){0.0, 0.0, 0.0, 0.0}, 0, 0, 0);
+#pragma unroll
+        for(int r = 0; r < 4; r++)
+        {
 #ifndef DLG_ASM_NO_TSTORE                     // (tools/variant_lib.sh: the kernel without its transient stores)
-              if(mine && TJ(r) != 0xFF) Lx[colT + (ro + TA(r))] = accT[r];
+          if(mine && TJ(r) != 0xFF)
 #else
-              if(mine && TJ(r) != 0xFF && accT[r] == 1.2345e300) Lx[colT + (ro + TA(r))] = accT[r];
+          if(mine && TJ(r) != 0xFF && t4[r] == 1.2345e300)
 #endif
-            }
-          accT = (dlg_v4d){0.0, 0.0, 0.0, 0.0};
+          {
+            // (XT: the host checked that the panels end below 4 GB -- 32-bit offsets from the scalar base)
+            if(XT) *reinterpret_cast<double*>(reinterpret_cast<char*>(Lx) + (((uint32_t)colT + (uint32_t)(ro[r] + TA(r))) << 3)) = t4[r];
+            else Lx[colT + (ro[r] + TA(r))] = t4[r];
+          }
         }
       }
       if(meta[u] & (1u << 12))           // end of a task: its persistent blocks
@@ -1164,6 +1173,7 @@ static int assemble_launch(dlg_backend* b, const double* Jv, double* Lx = nullpt
       bool xt = H.asm_lds_len == 18;
       for(const AsmShape& sh : H.asm_shape) if(sh.ncopy > 15) xt = false;
       if(xt) xt = H.asm_td_inline;                  // ... and every k-group carries its transient destinations
+      if(xt) xt = (uint64_t)H.lx_size + (1u << 20) < (1ull << 29);      // ... and the panels end below 4 GB (32-bit store offsets)
       if(H.asm_lds_len == 18 && xvec && xt)
         ASM_LAUNCH((k_assemble_mfma<18, true, true>), dim3(dlg_cdiv(nruns, TPB/64)), dim3(TPB),
                            sizeof(double)*(TPB/64)*ASM_U*4*18, st, Y->asm_run, nruns, Y->asm_mtask,
