@@ -276,7 +276,7 @@ __device__ __forceinline__ void asm_mfma_run(const AsmRun& R, const AsmMTask* __
 #define PA(r)  (int)(pk1[r] >> 24)
 #define PAO(r) (int)(pk2[r] & 0xFF)
 #define PNI(r) (int)(pk2[r] >> 8)
-  dlg_v4d accP = {0.0, 0.0, 0.0, 0.0};
+  dlg_v4d accP = {0.0, 0.0, 0.0, 0.0}, accT = {0.0, 0.0, 0.0, 0.0};
   // task records: current + next (fetched ahead, as ONE vector load each: lane l holds dword l of
   // the record, fields are broadcast with readlane; vector loads return in order, so prefetches
   // overlap with the rest -- scalar loads would share a counter with the LDS traffic);
@@ -410,11 +410,12 @@ __device__ __forceinline__ void asm_mfma_run(const AsmRun& R, const AsmMTask* __
       const double bP = row[bcolP];
       accP = __builtin_amdgcn_mfma_f64_16x16x4f64(row[pc], bP, accP, 0, 0, 0);
       if(JTX) jacc += (x_in_tile ? row[15] : xv[u])*bP;
-      if(HAS_T)
+      if(HAS_T && XT)
       {
-        // (every k-group of the schedule closes its row-blocks -- sparse_symbolic.cpp, close_kg --: the transient
+        // (XT: every k-group with row-block slots closes them -- the host checked, asm_td_inline --: the transient
         // product starts from zero and is stored at once; a k-group past the end has no slot, so nothing is `mine`.
-        // The four row offsets are fetched together, in front of the product: one LDS round trip, not four behind it)
+        // The four row offsets are fetched together, in front of the product: one LDS round trip, not four behind it;
+        // the panels end below 4 GB (checked too): 32-bit offsets from the scalar base)
         const int myslot = (meta[u] >> (2*kq)) & 3;
         const bool mine = bs < (int)((meta[u] >> 8) & 7);
         int ro[4];
@@ -429,11 +430,25 @@ __device__ __forceinline__ void asm_mfma_run(const AsmRun& R, const AsmMTask* __
 #else
           if(mine && TJ(r) != 0xFF && t4[r] == 1.2345e300)
 #endif
-          {
-            // (XT: the host checked that the panels end below 4 GB -- 32-bit offsets from the scalar base)
-            if(XT) *reinterpret_cast<double*>(reinterpret_cast<char*>(Lx) + (((uint32_t)colT + (uint32_t)(ro[r] + TA(r))) << 3)) = t4[r];
-            else Lx[colT + (ro[r] + TA(r))] = t4[r];
-          }
+            *reinterpret_cast<double*>(reinterpret_cast<char*>(Lx) + (((uint32_t)colT + (uint32_t)(ro[r] + TA(r))) << 3)) = t4[r];
+        }
+      }
+      else if(HAS_T)
+      {
+        // (the general form: a row-block of more than four rows spans two k-groups, the first of which stores nothing)
+        const int myslot = (meta[u] >> (2*kq)) & 3;
+        accT = __builtin_amdgcn_mfma_f64_16x16x4f64(row[tc], row[bs == myslot ? bcol : ZC], accT, 0, 0, 0);
+        if(meta[u] & (1u << 11))
+        {
+          const bool mine = bs < (int)((meta[u] >> 8) & 7);
+#pragma unroll
+          for(int r = 0; r < 4; r++)
+            if(4*r < MT)
+            {
+              const int ro = __builtin_amdgcn_ds_bpermute(4*(bs*nT + TJ(r)), td[u]);
+              if(mine && TJ(r) != 0xFF) Lx[colT + (ro + TA(r))] = accT[r];
+            }
+          accT = (dlg_v4d){0.0, 0.0, 0.0, 0.0};
         }
       }
       if(meta[u] & (1u << 12))           // end of a task: its persistent blocks

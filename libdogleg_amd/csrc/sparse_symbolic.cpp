@@ -1713,7 +1713,7 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
       for(const AsmMTask& T : S.asm_mtask)
         if(S.asm_shape[T.shape].MT > 0)
           for(int g = T.kg0; g < T.kg1; g++)
-            if(((S.asm_kg[g].meta >> 8) & 7) > 0 && !(S.asm_kg[g].meta & (1u << 13))) S.asm_td_inline = false;
+            if(((S.asm_kg[g].meta >> 8) & 7) > 0 && (!(S.asm_kg[g].meta & (1u << 13)) || !(S.asm_kg[g].meta & (1u << 11)))) S.asm_td_inline = false;     // (... and stores them: no row-block of more than four rows)
       const int RUN_KG = env_int("DOGLEG_AMD_RUN_KG", 32);
       for(int k = 0; k < nt; )
       {
