@@ -207,13 +207,38 @@ k_syrk_lower(double* __restrict__ C, int ldc, const double* __restrict__ A, int 
   auto sA = [&](int buf) -> double* { return smem + (size_t)(2*buf    )*KC*LDS_LD; };
   auto sB = [&](int buf) -> double* { return smem + (size_t)(2*buf + 1)*KC*LDS_LD; };
 
-  // tile index -> (ti >= tj)
-  const int tile  = blockIdx.x / nsplit;
-  const int split = blockIdx.x - tile*nsplit;
-  int ti = (int)((sqrt(8.0*(double)tile + 1.0) - 1.0)*0.5);
-  while((long)ti*(ti+1)/2 > tile) ti--;
-  while((long)(ti+1)*(ti+2)/2 <= tile) ti++;
-  const int tj = tile - (int)((long)ti*(ti+1)/2);
+  // (split-major: the workgroups resident at a time are the tiles of ONE range of rows, marching through it together --
+  // the rows a chunk needs, 16 x N doubles, are shared by all of them in L2; tile-major, every resident workgroup read
+  // rows of its own and 11.9 GB crossed the fabric per launch for 0.8 GB of J, profiles/r04_pmc.md)
+  const int ntl   = gridDim.x / nsplit;
+  const int split = blockIdx.x / ntl;
+  const int pos   = blockIdx.x - split*ntl;
+  // ... and XCD-aware: consecutive workgroups go to consecutive XCDs, each with an L2 of its own -- the positions
+  // pos = r (mod 8) of a split, which share an XCD, get a CONTIGUOUS stretch of the tiles listed by 4 x 4 super-tiles,
+  // i.e. about one super-tile: 8 of the 16 column blocks of J instead of all of them through that L2
+  int ti, tj;
+  {
+    const int T = (int)((sqrt(8.0*(double)ntl + 1.0) - 1.0)*0.5 + 0.5);      // ntl = T (T + 1) / 2
+    const int r = pos & 7, q = pos >> 3;
+    int idx = q;
+    for(int x = 0; x < r; x++) idx += (ntl - x + 7) >> 3;                    // positions of the groups in front
+    constexpr int S = 4;
+    const int TS = (T + S - 1)/S;
+    ti = tj = 0;
+    bool found = false;
+    for(int a = 0; a < TS && !found; a++)
+      for(int bq = 0; bq <= a && !found; bq++)
+      {
+        const int ra = min(S, T - a*S), rb = min(S, T - bq*S);
+        const int cnt = (a == bq) ? ra*(ra + 1)/2 : ra*rb;
+        if(idx >= cnt) { idx -= cnt; continue; }
+        int li, lj;
+        if(a != bq) { li = idx / rb; lj = idx - li*rb; }
+        else { li = 0; while(idx > li) { idx -= li + 1; li++; } lj = idx; }
+        ti = a*S + li; tj = bq*S + lj; found = true;
+      }
+  }
+  const int tile = ti*(ti + 1)/2 + tj;
   const int i0 = ti*BT, j0 = tj*BT;
   const bool diag = (ti == tj);
 
@@ -237,8 +262,13 @@ k_syrk_lower(double* __restrict__ C, int ldc, const double* __restrict__ A, int 
     {
       const int k = kb + it*ROWS_PER_IT + lk;
       const bool kin = k < k_end;
+#ifdef DLG_SYRK_NO_GLOAD                      // (tools/variant_lib.sh: the kernel without its loads of J)
+      ra[it] = (kin && i0 + li < n) ? (double)((k + li) & 7) : 0.0;
+      if(!diag) rb[it] = (kin && j0 + li < n) ? (double)((k - li) & 7) : 0.0;
+#else
       ra[it] = (kin && i0 + li < n) ? A[(size_t)k*lda + i0 + li] : 0.0;
       if(!diag) rb[it] = (kin && j0 + li < n) ? A[(size_t)k*lda + j0 + li] : 0.0;
+#endif
     }
   };
   auto sstore = [&](int buf) {
@@ -304,7 +334,7 @@ k_syrk_lower(double* __restrict__ C, int ldc, const double* __restrict__ A, int 
   }
   else
   {
-    double* slab = slabs + ((size_t)split*gridDim.x/nsplit + tile)*(size_t)(BT*BT);
+    double* slab = slabs + ((size_t)split*ntl + tile)*(size_t)(BT*BT);
 #pragma unroll
     for(int a = 0; a < NT; a++)
 #pragma unroll

@@ -6,7 +6,7 @@ cd "$(dirname "$0")/.." || exit 1
 if [ "$1" = build ]; then
   src=$2; shift 2
   python3 -c "import __graft_entry__ as g; g.build()" >/dev/null 2>&1
-  extra=""; case $src in sparse_assemble.hip|sparse_factor.hip|dense_diag.hip) extra="-mllvm -amdgpu-mfma-vgpr-form=1";; esac
+  extra=""; case $src in sparse_assemble.hip|sparse_factor.hip|dense_diag.hip|sparse_leaf.hip) extra="-mllvm -amdgpu-mfma-vgpr-form=1";; esac
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 $extra "$@" -Iinclude -c libdogleg_amd/csrc/$src -o /tmp/var_$src.o || exit 1
   objs=$(ls libdogleg_amd/csrc/_obj/*.o | grep -v "/$src.o")
   /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o tools/micro/libvar.so $objs /tmp/var_$src.o
