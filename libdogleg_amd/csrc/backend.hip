@@ -191,6 +191,8 @@ extern "C" int dlg_backend_create(dlg_backend_t** out, int solve_type, int Nstat
   TRY_HIP(hipStreamCreateWithFlags(&b->aux_stream, hipStreamNonBlocking));
   TRY_HIP(hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming));
   TRY_HIP(hipEventCreateWithFlags(&b->ev_join, hipEventDisableTiming));
+  TRY_HIP(hipMalloc(&b->d_join, sizeof(int)*2));
+  TRY_HIP(hipMemsetAsync(b->d_join, 0, sizeof(int)*2, b->stream));
   b->overlap = getenv("DOGLEG_AMD_NO_OVERLAP") == nullptr;
   b->fuse_eval = getenv("DOGLEG_AMD_NO_FUSED_EVAL") == nullptr;
   b->ext_events = getenv("DOGLEG_AMD_NO_EXT_EVENTS") == nullptr;
@@ -202,6 +204,7 @@ extern "C" int dlg_backend_create(dlg_backend_t** out, int solve_type, int Nstat
   {
     dlg_backend::Knobs& k = b->knobs;
     k.no_k3_fork = getenv("DOGLEG_AMD_NO_K3_FORK") != nullptr;
+    k.join_event = getenv("DOGLEG_AMD_JOIN_EVENT") != nullptr;
     k.no_potrf_fuse = getenv("DOGLEG_AMD_NO_POTRF_FUSE") != nullptr;
     k.potrf_steps = getenv("DOGLEG_AMD_POTRF_STEPS") != nullptr;
     k.trsv_steps = getenv("DOGLEG_AMD_TRSV_STEPS") != nullptr;
@@ -263,6 +266,7 @@ extern "C" void dlg_backend_destroy(dlg_backend_t* b)
   if(b->aux_stream) { (void)hipStreamSynchronize(b->aux_stream); (void)hipStreamDestroy(b->aux_stream); b->aux_stream = nullptr; }
   if(b->ev_fork) { (void)hipEventDestroy(b->ev_fork); b->ev_fork = nullptr; }
   if(b->ev_join) { (void)hipEventDestroy(b->ev_join); b->ev_join = nullptr; }
+  if(b->d_join) { (void)hipFree(b->d_join); b->d_join = nullptr; }
   if(b->ev_step) { (void)hipEventDestroy(b->ev_step); b->ev_step = nullptr; }
   if(b->ev_copy) { (void)hipEventDestroy(b->ev_copy); b->ev_copy = nullptr; }
   if(b->ev_fetch) { (void)hipEventDestroy(b->ev_fetch); b->ev_fetch = nullptr; }
@@ -291,6 +295,7 @@ extern "C" int dlg_backend_reset(dlg_backend_t* b)
   }
   b->factor_slot = -1; b->speculate = false; b->presolve = false; b->pre_slot = -1; b->pre_held = -1; b->pre_hint_valid = false; b->pre_hint_input = false;
   b->want_fork = b->fork_recorded = false; b->fork_gate = nullptr;
+  b->join_pending = 0;
   b->fold_scalar = b->fold_result = nullptr; b->fold_cauchy_out = nullptr;
   b->fold_p_src = nullptr; b->p_copied = false; b->scal_copied = false; b->fold_scal = 0;
   b->h_part_used = 0; b->pending.clear();
@@ -749,6 +754,10 @@ __global__ void k_gate_wait(const int* gate, int epoch, int* status = nullptr)
     }
   }
 }
+__global__ void k_raise_word(int* word, int epoch)
+{
+  if(threadIdx.x == 0) __hip_atomic_store(word, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
 int dlg_gate_wait(dlg_backend* b, hipStream_t st, const int* gate, int epoch, bool report)
 {
   hipLaunchKernelGGL(k_gate_wait, dim3(1), dim3(64), 0, st, gate, epoch,
@@ -780,8 +789,18 @@ static int cauchy_fork_enqueue(dlg_backend* b, int s, double* sc)
   else rc = cauchy_enqueue(b, s, sc);
   b->stream = main_stream;
   DLG_CHECK(rc);
-  DLG_HIP(hipEventRecord(b->ev_join, b->aux_stream));
-  DLG_HIP(hipStreamWaitEvent(b->stream, b->ev_join, 0));
+  if(b->d_join && !b->knobs.join_event && !b->sharded())
+  {
+    // (no event: the word goes up behind the Cauchy step, k_negate_interp1 polls it)
+    hipLaunchKernelGGL(k_raise_word, dim3(1), dim3(64), 0, b->aux_stream, b->d_join, ++b->join_epoch);
+    DLG_LAUNCH_CHECK();
+    b->join_pending = b->join_epoch;
+  }
+  else
+  {
+    DLG_HIP(hipEventRecord(b->ev_join, b->aux_stream));
+    DLG_HIP(hipStreamWaitEvent(b->stream, b->ev_join, 0));
+  }
   if(b->type == DLG_SPARSE) DLG_CHECK(sparse_touch_factor(b, b->aux_stream));     // (behind the join: a hint nobody waits for)
   return DLG_OK;
 }

@@ -65,6 +65,10 @@ struct dlg_backend
   // (want_fork -> fork_recorded), the caller joins with ev_join before the step is formed.
   hipStream_t aux_stream = nullptr;
   hipEvent_t  ev_fork = nullptr, ev_join = nullptr;
+  // the join without an event: the second stream raises d_join to join_epoch behind the Cauchy step, the first kernel of the
+  // main stream that reads that step (k_negate_interp1) polls the word itself -- a wait for an event of another stream costs
+  // the main stream ~6 us between two kernels even when the event is long complete (DOGLEG_AMD_JOIN_EVENT: the event)
+  int* d_join = nullptr; int join_epoch = 0, join_pending = 0;
   bool want_fork = false, fork_recorded = false, overlap = true;
   bool fuse_eval = true;      // ... in the pass that forms Jt*x where the schedule allows (DOGLEG_AMD_NO_FUSED_EVAL: second stream instead)
   bool speculate = false;     // dlg_backend_set_speculation: assemble JtJ beside Jt*x at every dlg_point_eval
@@ -87,6 +91,7 @@ struct dlg_backend
   // environment knobs that steer per-step paths, read ONCE when the backend is created (dlg_backend_create)
   struct Knobs
   {
+    bool join_event = false;
     bool no_k3_fork = false, no_potrf_fuse = false, potrf_steps = false,
          trsv_steps = false, no_touch = false;
     int touch_wg = 512;

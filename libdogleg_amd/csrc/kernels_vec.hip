@@ -264,9 +264,22 @@ __global__ void __launch_bounds__(TPB) k_part_take_step(const double* __restrict
 __global__ void __launch_bounds__(TPB) k_part_negate_interp1(double* __restrict__ v,
                                                              const double* __restrict__ a, int n,
                                                              double* __restrict__ gnpart,
-                                                             double* __restrict__ part1)
+                                                             double* __restrict__ part1,
+                                                             const int* __restrict__ gate, int epoch, int* __restrict__ status)
 {
   __shared__ double sh[4];
+  // (the Cauchy step a comes from the second stream: its word instead of an event between two kernels of this stream,
+  // dlg_backend::d_join)
+  if(gate)
+  {
+    if(threadIdx.x == 0)
+      for(int spins = 0; __hip_atomic_load(gate, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - epoch < 0; spins++)
+      {
+        if(spins > (1 << 21)) { atomicOr(status, DLG_HANDOFF_FACTOR); break; }       // (never in order: reported, not hung)
+        __builtin_amdgcn_s_sleep(8);
+      }
+    __syncthreads();
+  }
   double s = 0, l2 = 0, nc = 0;
   for(int i = blockIdx.x*TPB + threadIdx.x; i < n; i += gridDim.x*TPB)
   {
@@ -447,7 +460,10 @@ int k_negate_interp1(dlg_backend* b, double* gn, const double* cauchy, int n, do
 {
   const int g = grid_for(n);
   DLG_CHECK(dlg_ensure_partials(b, 5*MAXB));      // k_take_step's layout: no reallocation between the two
-  hipLaunchKernelGGL(k_part_negate_interp1, dim3(g), dim3(TPB), 0, b->stream, gn, cauchy, n, gnpart, b->d_part);
+  const int ep = b->join_pending;
+  b->join_pending = 0;
+  hipLaunchKernelGGL(k_part_negate_interp1, dim3(g), dim3(TPB), 0, b->stream, gn, cauchy, n, gnpart, b->d_part,
+                     ep ? (const int*)b->d_join : (const int*)nullptr, ep, reinterpret_cast<int*>(b->d_scal + (dlg_backend::NSCAL - 2)));
   DLG_LAUNCH_CHECK();
   *nb = g;
   return DLG_OK;

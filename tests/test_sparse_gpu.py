@@ -164,11 +164,12 @@ def test_ba_lambda_path(gpu):
     {"DOGLEG_AMD_FRONT_FILL": "16", "DOGLEG_AMD_FRONT_REPLICAS": "3"},   # other replica counts in the one-launch region
     {"DOGLEG_AMD_SPLIT_W": "1000", "DOGLEG_AMD_RELAX_PCT": "0"},    # supernodes: no run kept beside its siblings, no relaxed merging
     {"DOGLEG_AMD_UNIT_COST": "128", "DOGLEG_AMD_RUN_KG": "8"},      # small update units, short assembly runs
+    {"DOGLEG_AMD_JOIN_EVENT": "1"},                                 # the Cauchy step joined by an event instead of its word
 ], ids=["lds-assembly", "coop-update", "mfma-update", "syrk-unfused", "no-rider", "small-slices", "no-multifrontal",
         "multifrontal-from-leaves", "multifrontal-128", "multifrontal-256", "multifrontal-small-fronts", "device-finals",
         "bwd-x-from-hbm", "no-overlap", "no-persistent-top", "deep-persistent-top",
         "leaf-lds-full", "separate-jtx", "no-touch", "no-premul", "no-leaf-kernel", "bwd-top-lds", "bwd-flags", "no-ext-events",
-        "replica-counts", "supernode-rules", "small-units"])
+        "replica-counts", "supernode-rules", "small-units", "join-event"])
 def test_fallback_kernels_match_oracle(gpu, env, monkeypatch):
     """the kernels the default schedule does not pick on a bundle-adjustment pattern stay correct:
     the schedule knobs are read when the pattern is set"""
