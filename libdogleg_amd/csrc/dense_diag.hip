@@ -142,7 +142,7 @@ __global__ void __launch_bounds__(TPB) k_potrf_diag_trsm(double* __restrict__ A,
 // consumers poll and read around L1; one workgroup per CU.
 typedef double dd_v4d __attribute__((ext_vector_type(4)));
 __global__ void __launch_bounds__(TPB) k_potrf_tiles(double* A, int lda, int n, int T, int* __restrict__ info,
-                                                     double* Linv, int* flags, int epoch, DlgHandoff ho)
+                                                     double* Linv, int* flags, int epoch, DlgHandoff ho, int self_x)
 {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   __shared__ int sbad;
@@ -185,13 +185,33 @@ __global__ void __launch_bounds__(TPB) k_potrf_tiles(double* A, int lda, int n, 
       D[i][k] = (row < n && col < n) ? __hip_atomic_load((gcd_t)(A + (size_t)col*lda + row), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
     }
   };
-  for(int k = 0; k < tj; k++)
+  // self_x: the owner of a diagonal tile (j, j) also keeps the tile to its left, (j, j - 1), up to date and forms
+  // L(j, j-1) = tile * inv(L(j-1, j-1))' ITSELF once that inverse is published -- what lies between the factorisation of
+  // one diagonal tile and the next is then inverse -> one product -> one update in ONE workgroup, not the neighbour's
+  // product, its stores, their drain, its flag, this workgroup's poll and a 32 KB load (the neighbour still publishes the
+  // block for the tiles below)
+  const bool selfx = self_x && ti == tj && tj > 0;
+  dd_v4d acc2[4];
+  if(selfx)
+  {
+#pragma unroll
+    for(int ct = 0; ct < 4; ct++)
+#pragma unroll
+      for(int r = 0; r < 4; r++)
+      {
+        const int row = row0 + 16*wv + kq + 4*r, col = col0 - NB + 16*ct + jn;
+        acc2[ct][r] = (row < n) ? A[(size_t)col*lda + row] : 0.0;
+      }
+  }
+  for(int k = 0; k < (selfx ? tj - 1 : tj); k++)
   {
     if(t == 0) wait_flag(ti, k);
     if(t == 64 && ti != tj) wait_flag(tj, k);
+    if(t == 64 && selfx) wait_flag(tj - 1, k);
     __syncthreads();
     stage(Li, row0, NB*k);
     if(ti != tj) stage(Lj, col0, NB*k);
+    if(selfx) stage(Lj, col0 - NB, NB*k);
     __syncthreads();
     double (*Lb)[LDT] = (ti != tj) ? Lj : Li;
 #pragma unroll 4
@@ -201,6 +221,57 @@ __global__ void __launch_bounds__(TPB) k_potrf_tiles(double* A, int lda, int n, 
 #pragma unroll
       for(int ct = 0; ct < 4; ct++)
         acc[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, -Lb[16*ct + jn][kk + kq], acc[ct], 0, 0, 0);
+      if(selfx)
+      {
+#pragma unroll
+        for(int ct = 0; ct < 4; ct++)
+          acc2[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, -Lj[16*ct + jn][kk + kq], acc2[ct], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+  if(selfx)
+  {
+    // L(j, j-1) from the tile kept here and the inverse of the diagonal block to the left, then this tile's last update
+    if(t == 0) wait_flag(tj - 1, tj - 1);
+    __syncthreads();
+    {
+      const double* Lv = Linv + (size_t)(tj - 1)*NB*NB;
+      for(int e = t; e < NB*NB; e += TPB)
+      {
+        const int i = e % NB, k = e / NB;
+        Lj[i][k] = __hip_atomic_load((gcd_t)(Lv + e), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+#pragma unroll
+      for(int ct = 0; ct < 4; ct++)
+#pragma unroll
+        for(int r = 0; r < 4; r++) Li[16*wv + kq + 4*r][16*ct + jn] = acc2[ct][r];
+    }
+    __syncthreads();
+    dd_v4d x[4];
+#pragma unroll
+    for(int ct = 0; ct < 4; ct++) x[ct] = (dd_v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
+    for(int kk = 0; kk < NB; kk += 4)
+    {
+      const double a = Li[16*wv + jn][kk + kq];
+#pragma unroll
+      for(int ct = 0; ct < 4; ct++)
+        x[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Lj[16*ct + jn][kk + kq], x[ct], 0, 0, 0);
+    }
+    __syncthreads();
+#pragma unroll
+    for(int ct = 0; ct < 4; ct++)
+#pragma unroll
+      for(int r = 0; r < 4; r++) Li[16*wv + kq + 4*r][16*ct + jn] = x[ct][r];
+    __syncthreads();
+#pragma unroll 4
+    for(int kk = 0; kk < NB; kk += 4)
+    {
+      const double a = Li[16*wv + jn][kk + kq];
+#pragma unroll
+      for(int ct = 0; ct < 4; ct++)
+        acc[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, -Li[16*ct + jn][kk + kq], acc[ct], 0, 0, 0);
     }
     __syncthreads();
   }
@@ -452,7 +523,8 @@ void dense_launch_potrf_tiles(hipStream_t st, double* A, int lda, int n, int* in
   constexpr int LDSB = 88*1024;           // > half of the CU's LDS: one workgroup per CU
   dlg_func_lds_once(attr, reinterpret_cast<const void*>(&k_potrf_tiles), LDSB);
   const int T = (n + NB - 1)/NB;
-  hipLaunchKernelGGL(k_potrf_tiles, dim3(T*(T + 1)/2), dim3(TPB), LDSB, st, A, lda, n, T, info_dev, Linv, flags, epoch, ho);
+  const int self_x = getenv("DOGLEG_AMD_NO_POTRF_SELF") ? 0 : 1;      // (the form of rounds 2 - 3: every block of L comes from its owner)
+  hipLaunchKernelGGL(k_potrf_tiles, dim3(T*(T + 1)/2), dim3(TPB), LDSB, st, A, lda, n, T, info_dev, Linv, flags, epoch, ho, self_x);
 }
 
 void dense_launch_potrf_diag_trsm(hipStream_t st, double* A, int lda, int kb, int nb, int n, int* info_dev, double* Linv,

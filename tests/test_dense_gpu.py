@@ -180,8 +180,8 @@ def test_syrk_and_potrf_kernels(gpu):
 
 @pytest.mark.parametrize("env", [{"DOGLEG_AMD_NO_OVERLAP": "1"}, {"DOGLEG_AMD_NO_K3_FORK": "1"},
                                  {"DOGLEG_AMD_POTRF_STEPS": "1"}, {"DOGLEG_AMD_POTRF_STEPS": "1", "DOGLEG_AMD_NO_POTRF_FUSE": "1"},
-                                 {"DOGLEG_AMD_TRSV_STEPS": "1"}],
-                         ids=["no-overlap", "no-k3-fork", "potrf-steps", "potrf-steps-unfused", "trsv-steps"])
+                                 {"DOGLEG_AMD_TRSV_STEPS": "1"}, {"DOGLEG_AMD_NO_POTRF_SELF": "1"}],
+                         ids=["no-overlap", "no-k3-fork", "potrf-steps", "potrf-steps-unfused", "trsv-steps", "potrf-blocks-from-owners"])
 def test_dense_stream_variants_match_oracle(gpu, env, monkeypatch):
     """the two-stream variant of the dense path (the Cauchy step beside the factorisation), the step forms of potrf / trsv
     and their single-stream forms give the oracle's Gauss-Newton step"""
