@@ -208,6 +208,16 @@ def main():
     res = one_step()
     for _ in range(args.warmup):
         res = one_step()
+    # Untimed steps until the device has worked for a quarter of a second (at least 30 steps): the first steps behind
+    # the allocations run 5 - 10 % slower whatever W is, and the first process on a fresh box was once seen at 0.72 ms a
+    # step for a whole timed region with every phase at its usual time.  Not part of the K steps.
+    presteps, t_pre = 0, time.perf_counter()
+    while presteps < 30 or time.perf_counter() - t_pre < 0.25:
+        n_pre = 30 if kind == "sparse" else 10
+        run_steps(n_pre)
+        presteps += n_pre
+        if presteps >= 3000:
+            break
     # in the timed loop only the roofline kernel is bracketed by events (two records per step); the table
     # of all phases comes from a second loop: twenty event records per step cost ~6 % of a 1.1 ms step
     # (... and only every fourth launch of it: a kernel whose completion somebody listens to holds the next dispatch
@@ -355,6 +365,7 @@ def main():
                                       (f"rank {prank} of {pworld} LOGICAL ranks on one device, every sum over the ranks skipped: per-rank compute time for a projection, not a throughput" if logical else "1 GPU")},
             "roofline": roof,
             "other_kernels": others,
+            "untimed_presteps": presteps,
             "inputs": {"resident_copies": ncopy, "bytes_per_copy": int(xh.nbytes + Jh.nbytes),
                        "note": "the timed loop rotates over the copies: past the 256 MiB Infinity Cache"},
             "phases_ms_per_step": {k: (v[0] + prof_early[k][0]) / args.steps for k, v in prof.items()},
