@@ -343,6 +343,12 @@ __global__ void __launch_bounds__(NT, LEAF ? 4 : 1) k_factor_level(const FwItem*
   // mf_add_children)
   __syncthreads();
   FL_STAMP(1);
+  // Replicas of a supernode all read its panel from HBM and ONE of them writes the factored panel back: the last one
+  // (highest workgroup index: the others were dispatched before it), and only after every other replica has said that
+  // its copy is in LDS -- a replica that finds no CU until late (a chip shared with other launches) would otherwise
+  // read a panel that is factored already.  The word: -epoch = "panel read", epoch = "done" (what the parent waits for).
+  const int nrep = (pr_flag && it.rsv2 > 1) ? it.rsv2 : 1;
+  if(nrep > 1 && it.rep < nrep - 1 && tid == 0) __hip_atomic_store(pr_flag + blockIdx.x, -pr_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if(s_skip)
   {
     if(pr_flag && tid == 0) __hip_atomic_store(pr_flag + blockIdx.x, pr_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -452,7 +458,22 @@ __global__ void __launch_bounds__(NT, LEAF ? 4 : 1) k_factor_level(const FwItem*
     if(tid == 0) __hip_atomic_store(pr_flag + blockIdx.x, pr_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   FL_STAMP(7);
-  const bool store_panel = it.rep == 0;             // the panel is replica 0's to store
+  const bool store_panel = it.rep == nrep - 1;       // the panel is the last replica's to store
+  if(nrep > 1 && store_panel)
+  {
+    if(tid < nrep - 1)
+    {
+      int spins = 0;
+      for(;;)
+      {
+        const int v = __hip_atomic_load(pr_flag + ((int)blockIdx.x - (nrep - 1) + tid), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if(v == pr_epoch || v == -pr_epoch) break;
+        __builtin_amdgcn_s_sleep(1);
+        if(++spins > ho.spins) { atomicOr(ho.status, DLG_HANDOFF_FACTOR); break; }
+      }
+    }
+    __syncthreads();
+  }
   for(int i = row0c + tid - cp_g*cp_rows; i < nloc && cp_g < cp_ng && store_panel; i += cp_rows)
   {
     // rows below the top block go back to the panel; the top block too unless the supernode is
@@ -1281,6 +1302,7 @@ int sparse_factor_setup(dlg_backend* b, bool plan_only)
           {
             it = H.fw_item[i];
             it.rep = r; it.tj0 = (nrep == 1) ? 0 : cut[r]; it.tj1 = (nrep == 1 || r == nrep - 1) ? (1 << 20) : cut[r+1];
+            it.rsv2 = nrep;      // (the LAST replica stores the panel, once the others have read it: k_factor_level)
             it.pad = l;          // (the level: for the profile build's dump)
             if(nrep > 1 && slice_ok)
             {
@@ -1343,7 +1365,7 @@ int sparse_factor_setup(dlg_backend* b, bool plan_only)
       }
     }
     // the rank's own levels up to the cut (a partition whose cut leaves at least two multifrontal levels below it)
-    if(part && H.cut_level >= 2 && !plan_only)
+    if(part && H.cut_level >= 2 && !plan_only && !getenv("DOGLEG_AMD_NO_LOWER_REGION"))
     {
       std::vector<FwItem> items2; std::vector<MfChild> rec2; std::vector<uint16_t> dst2;
       DLG_CHECK(build_region(1, H.cut_level, Y->pr2_level0, Y->pr2_lds, Y->pr2_stage, Y->pr2_nwg, items2, rec2, dst2));

@@ -542,6 +542,8 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
     const int sib_w = env_int("DOGLEG_AMD_SIB_W", 64);
     const int split_w = env_int("DOGLEG_AMD_SPLIT_W", 32);   // columns from which a run stays a supernode of its own beside its parent's other children
     const long chain_cap = PANEL_CAP;   // width cap of chain supernodes: W*(W+64)
+    const bool lds_split = env_int("DOGLEG_AMD_LDS_SPLIT", 1) != 0;
+    const long lds_split_minw = 32;
     // width of the fundamental supernode (maximal chain of exactly nested block columns) starting at j:
     // a relaxed merge across a structure change takes that whole run or nothing -- stopping in the
     // middle of it at the width cap leaves fragments that cost an elimination-tree level each
@@ -601,7 +603,13 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
         if(nchild[j+1] >= 2)
           for(int c = kid_head[j+1]; c >= 0; c = kid_next[c]) if(c != j) sib = std::max(sib, crit[c]);
         const bool beside_siblings = nchild[j+1] >= 2 && std::min<long>(W, sib + W - crit[j]) > split_w;
-        if(fits && !beside_siblings && (exact || (run_fits && (Wn <= 16 || zeros*100 <= (long)relax*(stored + Wn*Wn)))))
+        // A chain whose panel would not fit LDS whole is cut where it still does, once it is wide enough to be worth a
+        // workgroup (config #5: separators of 96 columns with 194 rows below, 222 KB -- as one supernode they are cut into
+        // ROW slices, which keeps every level above the leaves out of the multifrontal one-launch region; as 64 + 32
+        // columns both panels fit and the whole top of the tree is one launch).  DOGLEG_AMD_LDS_SPLIT=0: rounds 1 - 3.
+        const long pan_n = ((Wn + Rn + 1 + 1) & ~1L)*Wn;
+        const bool lds_cut = lds_split && W >= lds_split_minw && pan_n > slice_cap() && Rn + 1 <= 255;
+        if(fits && !beside_siblings && !lds_cut && (exact || (run_fits && (Wn <= 16 || zeros*100 <= (long)relax*(stored + Wn*Wn)))))
         {
           merge = true; sib_only = false; nmerge++;
           W = Wn; true_nnz = tn; below_own = own_after;

@@ -386,3 +386,20 @@ def test_subtree_partition_config4_on_8_logical_ranks(gpu):
     assert st["reduced_doubles"] * 8 < 4e6
     print(f"config #4, 8 logical ranks: cut above level {st['cut_level']}, rows/rank {[len(r['rows']) for r in res]}, "
           f"{st['reduced_doubles']*8/1e6:.2f} MB summed per factorisation, |step - oracle| = {w:.2e}")
+
+
+def test_replicas_of_a_supernode_do_not_race_for_its_panel(gpu):
+    """regression (round 4): eight logical ranks run their one-launch regions on ONE device at the same time -- more
+    workgroups than CUs, so some replicas of a supernode start late.  Every replica reads the supernode's panel and one
+    of them writes the factored panel back: that one used to be the first, and a late replica then read a panel that
+    was factored already (a wrong step in 4 runs of 10).  Now the last replica stores, after the others have said that
+    their copy is in LDS.  Six rounds, each against the oracle and bit-identical to the first."""
+    prob = oa.BAProblem(2499, 45000, 500000, seed=11)
+    first = None
+    for it in range(6):
+        res, data = _partition_step(prob, 8, use_take_step=True, one_pass=True)
+        _check_partition_against_oracle(res, data)
+        if first is None:
+            first = res[0]["step"].copy()
+        assert np.array_equal(res[0]["step"], first), it
+
