@@ -153,10 +153,27 @@ __global__ void __launch_bounds__(TPB) k_potrf_tiles(double* A, int lda, int n, 
   double (*Lj)[LDT] = reinterpret_cast<double (*)[LDT]>(sm + NB*LDT);
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
   const int jn = lane & 15, kq = lane >> 4;
-  // tile of this workgroup: column by column, the diagonal tile of a column first
-  int rem = blockIdx.x, tj = 0;
-  while(rem >= T - tj) { rem -= T - tj; tj++; }
-  const int ti = tj + rem;
+  // tile of this workgroup: column by column, the diagonal tile of a column first.  self_x: the diagonal tile of the NEXT
+  // column comes right behind this column's diagonal tile, in front of its left neighbour -- the neighbour overwrites
+  // tile (j, j-1) with L(j, j-1) in place and may only do so once the diagonal owner (j, j) has read the original, and a
+  // workgroup only ever waits for lower-numbered ones: (0,0) | (1,1) (1,0) (2,0) ... | (2,2) (2,1) (3,1) ... | ...
+  int ti, tj;
+  if(self_x)
+  {
+    if(blockIdx.x == 0) { ti = tj = 0; }
+    else
+    {
+      int rem = (int)blockIdx.x - 1; tj = 0;
+      while(rem >= T - tj) { rem -= T - tj; tj++; }
+      if(rem == 0) { ti = tj = tj + 1; } else ti = tj + rem;
+    }
+  }
+  else
+  {
+    int rem = blockIdx.x; tj = 0;
+    while(rem >= T - tj) { rem -= T - tj; tj++; }
+    ti = tj + rem;
+  }
   const int row0 = NB*ti, col0 = NB*tj;
   // the tile in accumulators: wave wv holds rows 16 wv .. 16 wv + 15, four 16-column pieces;
   // lane (jn, kq): column jn of a piece, rows kq + 4 r
@@ -202,6 +219,10 @@ __global__ void __launch_bounds__(TPB) k_potrf_tiles(double* A, int lda, int n, 
         const int row = row0 + 16*wv + kq + 4*r, col = col0 - NB + 16*ct + jn;
         acc2[ct][r] = (row < n) ? A[(size_t)col*lda + row] : 0.0;
       }
+    // (the original tile is in registers: its owner may overwrite it -- the word in the unused upper triangle of the flags)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if(t == 0) __hip_atomic_store(flags + (tj - 1)*T + tj, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   for(int k = 0; k < (selfx ? tj - 1 : tj); k++)
   {
@@ -336,6 +357,12 @@ __global__ void __launch_bounds__(TPB) k_potrf_tiles(double* A, int lda, int n, 
 #pragma unroll
     for(int ct = 0; ct < 4; ct++)
       x[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Lj[16*ct + jn][kk + kq], x[ct], 0, 0, 0);
+  }
+  // (the diagonal owner of this block row keeps the original of this tile up to date itself, self_x: it must have read it)
+  if(self_x && ti == tj + 1)
+  {
+    if(t == 0) wait_flag(tj, ti);
+    __syncthreads();
   }
 #pragma unroll
   for(int ct = 0; ct < 4; ct++)
