@@ -1202,9 +1202,10 @@ int sparse_factor_setup(dlg_backend* b, bool plan_only)
   {
     r_level0 = H.nlevels; r_nwg = 0;
     if(getenv("DOGLEG_AMD_NO_PERSIST") || H.nlevels < 2 || hi < lo_min) return DLG_OK;
-    // (a workgroup of the region fills a CU; more of them than CUs would only queue behind waiting ones)
+    // (a workgroup of the region fills a CU; the cap counts SUPERNODES: twice the CUs -- with replicas the launch holds more
+    // workgroups than the chip has CUs anyway, they are dispatched in order and only wait for lower-numbered ones)
     const int ncu = b->ncu;
-    const int cap = env_int_host("DOGLEG_AMD_PERSIST_MAX", ncu);
+    const int cap = env_int_host("DOGLEG_AMD_PERSIST_MAX", 2*ncu);     // (supernodes; since the replicas of round 4 a region holds more workgroups than the chip has CUs anyway)
     int total = 0, l0 = hi + 1, lds = 0, stage = 1;
     const int nt = Y->fac_nt[hi];
     for(int l = hi; l >= std::max(1, lo_min); l--)

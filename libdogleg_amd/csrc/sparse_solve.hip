@@ -781,7 +781,7 @@ int sparse_solve_setup(dlg_backend* b)
   {
     int ncu = 256;
     { int dev = 0; if(hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev); }
-    const int cap = (int)env_int_solve("DOGLEG_AMD_PERSIST_MAX", ncu);
+    const int cap = (int)env_int_solve("DOGLEG_AMD_PERSIST_MAX", 2*ncu);
     int total = 0, l0 = H.nlevels, ldsb = 0;
     for(int l = H.nlevels - 1; l >= 1; l--)
     {
