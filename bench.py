@@ -211,9 +211,10 @@ def main():
     # Untimed steps until the device has worked for a quarter of a second (at least 30 steps): the first steps behind
     # the allocations run 5 - 10 % slower whatever W is, and the first process on a fresh box was once seen at 0.72 ms a
     # step for a whole timed region with every phase at its usual time.  Not part of the K steps.
+    # (N > 1: every rank must run the SAME number of steps -- the steps hold collectives --, so the count is fixed there)
     presteps, t_pre = 0, time.perf_counter()
-    while presteps < 30 or time.perf_counter() - t_pre < 0.25:
-        n_pre = 30 if kind == "sparse" else 10
+    n_pre = 30 if kind == "sparse" else 10
+    while presteps < 30 or (not use_dist and time.perf_counter() - t_pre < 0.25) or (use_dist and presteps < 6 * n_pre):
         run_steps(n_pre)
         presteps += n_pre
         if presteps >= 3000:
