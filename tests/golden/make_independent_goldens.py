@@ -10,7 +10,7 @@ The same for config #4 (1M x 150k, 15M non-zeros) -> splu_config4_step.json, eve
 vectors plus their norms and sums, to keep the file small.
 
 Data only: hex floats of the Gauss-Newton step, the Cauchy scalars and the interpolated step.
-Run here (scipy 1.15.3):  python tests/golden/make_independent_goldens.py [3] [4]   (config #3: about a minute)
+Run here (scipy 1.15.3):  python tests/golden/make_independent_goldens.py [2] [3] [4]   (config #3: about a minute)\nConfig #2 (dense 50 000 x 2 000) -> lapack_config2_step.json: BLAS J'J + the image's LAPACK dpptrf / dpptrs.
 """
 import json
 import os
@@ -71,8 +71,39 @@ def make(args, fname, stride):
     print(fname, "written; relative residual of the refined GN solve:", out["relative_residual_of_gn"])
 
 
+def make_dense(args, fname):
+    """BASELINE.json config #2 (dense 50 000 x 2 000): JtJ by BLAS, dpptrf_ / dpptrs_ of the image's LAPACK (the entry points
+    the reference links, dogleg.c:782,875) through tests/independent.py -- no oracle, no product"""
+    dp = oa.DenseProblem(M=args["M"], N=args["N"], seed=args["seed"])
+    p = dp.p0()
+    x, J = dp.eval(p)
+    g = J.T @ x
+    gn, info = ind.gn_dense_lapack(J, g, 0.0, packed=True)
+    assert info == 0
+    Jg = J @ g
+    kc = -float(g @ g) / float(Jg @ Jg)
+    n2c = kc * kc * float(g @ g)
+    tr = 0.5 * (np.sqrt(n2c) + np.sqrt(float(gn @ gn)))
+    st = ind.trial_step(J, x, tr, 0.0)
+    A = J.T @ J
+    res = np.linalg.norm(A.astype(np.longdouble) @ gn.astype(np.longdouble) + g.astype(np.longdouble))
+    out = {
+        "_generator": "tests/golden/make_independent_goldens.py: numpy %s (BLAS J'J) + scipy %s LAPACK dpptrf/dpptrs; "
+                      "problem = problems.c DenseProblem(M=%d, N=%d, seed=%d) at p0" % (np.__version__, scipy.__version__, args["M"], args["N"], args["seed"]),
+        "problem": args, "norm2_x": float(x @ x).hex(), "norm2_cauchy": float(n2c).hex(), "norm2_gn": float(gn @ gn).hex(),
+        "trustregion": float(tr).hex(), "kind": int(st["kind"]), "k": float(st["k"]).hex(),
+        "expected_improvement": float(st["expected_improvement"]).hex(),
+        "relative_residual_of_gn": float(res / np.linalg.norm(g)),
+        "gn_hex": hexlist(gn), "step_hex": hexlist(st["step"]),
+    }
+    json.dump(out, open(os.path.join(HERE, fname), "w"), indent=0)
+    print(fname, "written; relative residual of the GN solve:", out["relative_residual_of_gn"])
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["3", "4"]
+    if "2" in which:
+        make_dense(dict(M=50000, N=2000, seed=2), "lapack_config2_step.json")
     if "3" in which:
         make(dict(Nc=499, Np=9000, Nobs=100000, seed=11), "splu_config3_step.json", 1)
     if "4" in which:

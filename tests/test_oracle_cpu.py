@@ -308,6 +308,31 @@ def test_oracle_matches_the_independent_config3_fixture():
     assert abs(o8[5] - float.fromhex(g["expected_improvement"])) <= 1e-10 * abs(o8[5])
 
 
+def test_oracle_dense_solve_matches_the_independent_config2_fixture():
+    """BASELINE.json config #2 at full size (dense 50 000 x 2 000): the oracle's dpptrf / dpptrs restatement on BLAS's J'J
+    and its Jt*x loop against the committed LAPACK fixture (tests/golden/lapack_config2_step.json) -- the oracle's own
+    rank-1 assembly of J'J at this size is 1e11 scalar multiply-adds, a minute: it is pinned on the smaller fixtures"""
+    O = oa.oracle()
+    g = json.load(open(os.path.join(GOLD, "lapack_config2_step.json")))
+    a = g["problem"]
+    dp = oa.DenseProblem(M=a["M"], N=a["N"], seed=a["seed"])
+    M, N = dp.M, dp.N
+    p = dp.p0()
+    x, J = dp.eval(p)
+    gvec = np.zeros(N)
+    O.orc_dense_Jt_x(dptr(gvec), dptr(J), dptr(x), M, N)
+    A = J.T @ J
+    ap = np.ascontiguousarray(A[np.triu_indices(N)])           # row-major packed upper (dogleg.c:214-220)
+    assert O.orc_dpptrf_L(N, dptr(ap)) == 0
+    sol = gvec.copy()
+    O.orc_dpptrs_L(N, dptr(ap), dptr(sol))
+    gn_ref = np.array([float.fromhex(v) for v in g["gn_hex"]])
+    d = np.linalg.norm(-sol - gn_ref)
+    print(f"config #2 oracle (dpptrf/dpptrs restatement) vs LAPACK fixture: |gn diff| = {d:.2e}")
+    assert d <= 1e-10
+    assert abs(O.orc_norm2(dptr(x), M) - float.fromhex(g["norm2_x"])) <= 1e-12 * float.fromhex(g["norm2_x"])
+
+
 def test_oracle_matches_the_independent_config4_fixture():
     """BASELINE.json config #4 at full size (1M x 150k, 15M non-zeros): the oracle's sparse step against the
     committed SuperLU fixture (tests/golden/splu_config4_step.json: every 16th entry of the vectors, their

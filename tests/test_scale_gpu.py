@@ -372,6 +372,36 @@ def test_gpu_matches_the_independent_config3_fixture(gpu):
     be.close()
 
 
+def test_gpu_matches_the_independent_config2_fixture(gpu):
+    """BASELINE.json config #2 at FULL size (dense 50 000 x 2 000) against the committed LAPACK fixture
+    (tests/golden/lapack_config2_step.json: BLAS J'J + the image's dpptrf / dpptrs, numpy only -- no oracle, no product):
+    Gauss-Newton step, the interpolated step and its scalars of dlg_take_step at the fixture's trust region"""
+    g = json.load(open(os.path.join(GOLD, "lapack_config2_step.json")))
+    a = g["problem"]
+    dp = oa.DenseProblem(M=a["M"], N=a["N"], seed=a["seed"])
+    p = dp.p0()
+    x, J = dp.eval(p)
+    be = capi.Backend(capi.DLG_DENSE, dp.N, dp.M)
+    be.set_p(0, p)
+    be.upload(0, x, J)
+    n2x, _ = be.eval(0)
+    tr = float.fromhex(g["trustregion"])
+    lam, r, pnew = be.take_step(0, 1, tr, 0.0)
+    assert lam == 0.0 and r["kind"] == g["kind"] == capi.KIND_INTERP
+    gn = be.download(0, capi.VEC_GN)
+    step = be.download(1, capi.VEC_STEP)
+    dgn = np.linalg.norm(gn - _unhex(g["gn_hex"]))
+    dst = np.linalg.norm(step - _unhex(g["step_hex"]))
+    print(f"config #2 GPU vs LAPACK fixture: |gn diff| = {dgn:.2e}, |step diff| = {dst:.2e}")
+    assert dgn <= 1e-10 and dst <= 1e-10
+    assert abs(n2x - float.fromhex(g["norm2_x"])) <= 1e-12 * n2x
+    assert abs(r["n2c"] - float.fromhex(g["norm2_cauchy"])) <= 1e-11 * r["n2c"]
+    assert abs(r["n2g"] - float.fromhex(g["norm2_gn"])) <= 1e-11 * r["n2g"]
+    assert abs(r["k"] - float.fromhex(g["k"])) <= 1e-10
+    assert abs(r["ei"] - float.fromhex(g["expected_improvement"])) <= 1e-10 * abs(r["ei"])
+    be.close()
+
+
 def test_gpu_matches_the_independent_config4_fixture(gpu):
     """BASELINE.json config #4 at full size against the committed SuperLU fixture
     (tests/golden/splu_config4_step.json: every 16th entry of the Gauss-Newton and the interpolated step, their
