@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 4: A/B of one knob: tools/run_r4e.sh KNOB [pytest -k expr]
+# round 4: A/B of one knob: tools/ab_knob.sh KNOB [pytest -k expr]
 cd "$(dirname "$0")/.." || exit 1
 K=$1; mkdir -p gpurun_out/r4e
 timeout 1500 python3 -m pytest tests/test_sparse_gpu.py tests/test_sparse_patterns_gpu.py tests/test_scale_gpu.py -x -q -m gpu 2>&1 | tail -4
