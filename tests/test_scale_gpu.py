@@ -441,12 +441,15 @@ def test_gpu_matches_the_independent_config4_fixture(gpu):
     be.close()
 
 
-def test_config5_sparse_5m_ill_conditioned_full_size(gpu):
+@pytest.mark.parametrize("lds_split", ["1", "0"], ids=["chains-cut-to-fit-lds", "row-sliced-separators"])
+def test_config5_sparse_5m_ill_conditioned_full_size(gpu, lds_split, monkeypatch):
     """BASELINE.json configs[4] at FULL size on one GPU: 5M measurements x 500 001 parameters,
     75M non-zeros, column scales over 4 decades and exactly-zero columns => the factorisation fails
     at lambda = 0 and succeeds at 1e-10 (dogleg.c:656-677).  One full step against orc_step_sparse.
-    The separators of this size class are cut into row slices and stay outside the multifrontal
-    region: a path the smaller tests do not reach."""
+    The separators of this size class (96 columns, 194 rows below) do not fit LDS: by default (round 4) they are
+    chains of two supernodes that do, and the whole top of the tree is multifrontal; with DOGLEG_AMD_LDS_SPLIT=0
+    they are cut into row slices and stay outside the multifrontal region -- a path the smaller tests do not reach."""
+    monkeypatch.setenv("DOGLEG_AMD_LDS_SPLIT", lds_split)
     prob = oa.BAProblem(8333, 149999, 2500000, seed=13, scale_decades=4.0, n_zero_cols=3)
     assert (prob.M, prob.N, prob.nnz) == (5000000, 500001, 75000000)
     # tolerance: cond(JtJ + 1e-10 I) is ~1e13 along the zeroed columns' neighbours -- 1e-9 (measured:
