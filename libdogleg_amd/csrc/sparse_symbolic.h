@@ -177,7 +177,7 @@ struct FwItem
   int bdw, jsp;                // block-diagonal top: the common width of the members, 0 if they differ; sym_w_split of the supernode
   // one-launch region of the factorisation (sparse_factor_setup): a supernode may be factored by several
   // workgroups ("replicas": identical arithmetic on the whole panel), each of which forms and hands over
-  // the 16-column tile columns [tj0, tj1) of the update matrix; replica 0 stores the panel
+  // the 16-column tile columns [tj0, tj1) of the update matrix; the LAST replica stores the panel, once the others have read it (rsv2 = number of replicas)
   int rep, tj0, tj1, pad;      // pad: the level (profile build's dump)
   // a replica that keeps only ITS columns of the update matrix in LDS (sliced != 0): the packed entries
   // [eA, eB) -- columns [16 tj0, 16 tj1) -- sit behind the panel, everything else of the children's update
