@@ -9,6 +9,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--workload", default="sparse-1m")
 ap.add_argument("--ranks", type=int, default=8)
 ap.add_argument("--steps", type=int, default=50)
+ap.add_argument("--lambda0", type=float, default=None, help="lambda of the one-GPU run too (config #5: 1.0, so that both sides factorise once)")
 a = ap.parse_args()
 
 
@@ -21,7 +22,7 @@ def run(extra):
     raise SystemExit("bench.py gave no line:\n" + r.stderr[-2000:])
 
 
-one = run([])
+one = run(["--lambda0", str(a.lambda0)] if a.lambda0 is not None else [])
 rows = []
 for r in range(a.ranks):
     d = run(["--logical-ranks", str(a.ranks), "--rank", str(r)])
@@ -44,19 +45,24 @@ slow = max(d["ms_per_step"] for d in rows)
 part = rows[0].get("partition") or {}
 print(f"\nPartition: cut above level {part.get('cut_above_level')}, {part.get('replicated_supernodes')} replicated supernodes, "
       f"{part.get('bytes_summed_per_factorisation', 0)/1e6:.2f} MB summed per factorisation.\n")
-print("Collectives per step (DESIGN §7): Jt*x + |x|^2 (N + 1 doubles) at the evaluation; the cut buffer inside the factorisation; the")
-print("solution + the Cauchy step's scalar (N + 1); |J step|^2 (1).  Four all-reduces of at most 1.2 MB: latency-bound on xGMI.  RCCL's")
-print("small-message all-reduce latency on 8 GPUs is not in the guides and was never measured here (one GPU per box): three assumptions.\n")
+N1 = one["config"]["Nstate"] + 1
+big = max(8.0*N1, float(part.get("bytes_summed_per_factorisation", 0)))
+print(f"Collectives per step (DESIGN §7): Jt*x + |x|^2 (N + 1 doubles = {8*N1/1e6:.2f} MB) at the evaluation; the cut buffer inside the factorisation; the")
+print("solution + the Cauchy step's scalar (N + 1); |J step|^2 (1).  RCCL's all-reduce on 8 GPUs over xGMI was never measured here (one GPU per")
+print("box) and its small-message latency is not in the guides: each all-reduce is ASSUMED to cost a latency plus 2 (R - 1) / R x bytes at 100 GB/s")
+print("(a ring over point-to-point links of ~153 GB/s each).\n")
 print("| assumed latency per all-reduce | projected ms / step | projected steps/s | against one GPU |")
 print("|---|---|---|---|")
+R = a.ranks
+bw_ms = lambda nbytes: 2.0*(R - 1)/R*nbytes/100e9*1e3
+wire = 2*bw_ms(8.0*N1) + bw_ms(float(part.get("bytes_summed_per_factorisation", 0))) + bw_ms(8.0)
 for lat in (15e-3, 30e-3, 50e-3):
-    t = slow + 4*lat
+    t = slow + 4*lat + wire
     print(f"| {lat*1e3:.0f} us | {t:.4f} | {1e3/t:.0f} | {one['ms_per_step']/t:.2f} x |")
 k5_1, k5_r = p1.get("K5_factor", 0), max(d["phases_ms_per_step"].get("K5_factor", 0) for d in rows)
 print(f"\nSlowest rank {slow:.4f} ms against {one['ms_per_step']:.4f} ms on one GPU: {one['ms_per_step']/slow:.2f} x is the ceiling the partition's compute "
-      "leaves before any collective is paid for.  The passes over J and the leaf level shrink with the rank's rows; the factorisation does not")
-print(f"(K5 {k5_1:.3f} ms on one GPU, {k5_r:.3f} ms on the slowest rank): the levels between the leaves and the cut keep their per-level latency -- since round 4 as ONE")
-print("launch with replicas (`sparse_factor_setup`, region \"lo\"; before, one launch per level: 0.37 - 0.43 ms a rank, a rank's share took as long as the")
-print("whole problem on one GPU) --, then come pack / sum / unpack of the cut buffer and the replicated top of the tree.  The north star's 3.5 x at")
-print("8 GPUs is out of reach for this configuration with this algorithm: sharding rows does not shorten the elimination tree's critical path.")
-print("Config #5, whose step is dominated by the passes over J and the leaf level, is where the partition pays.")
+      f"leaves before any collective is paid for ({wire*1e3:.0f} us of the projection are bytes on the wire).  The passes over J and the leaf level shrink with the")
+print(f"rank's rows; the factorisation less so (K5 {k5_1:.3f} ms on one GPU, {k5_r:.3f} ms on the slowest rank): the levels between the leaves and the cut keep their")
+print("per-level latency (one launch with replicas, `sparse_factor_setup`, region \"lo\"), then come pack / sum / unpack of the cut buffer and the replicated top")
+print("of the tree.  Sharding rows does not shorten the elimination tree's critical path: a configuration whose step is mostly that path (config #4) gains")
+print("nothing, one whose step is mostly passes over J and leaves (config #5) gains what those were.")
