@@ -26,6 +26,7 @@ python3 tools/k4_split.py > $out/k4_split.txt 2>&1; DLG_ASM_ONLY_SHAPE=0 python3
 timeout 300 python3 tools/gpu_probe.py > $out/probe.txt 2>&1
 DLG_BENCH_FORCE_DIST=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29512 RANK=0 LOCAL_RANK=0 WORLD_SIZE=1 timeout 600 python3 bench.py --no-cpu-baseline > $out/bench_dist_world1_rccl.log 2>&1
 timeout 1500 python3 tools/scaling_projection.py --workload sparse-1m --ranks 8 > $out/scaling_projection.md 2> $out/scaling_projection.err
+timeout 2400 python3 tools/scaling_projection.py --workload sparse-5m --ranks 8 --steps 8 --lambda0 1.0 > $out/scaling_projection_sparse5m.md 2>> $out/scaling_projection.err
 bash tools/run_trace.sh $tag/trace > $out/step_trace.txt 2>&1
 # keep the merge small: only summaries travel back
 find $out -name "*kernel_trace.csv" -delete; find $out -name "*counter_collection.csv" -delete

@@ -16,7 +16,7 @@ for wl, short in names.items():
 for a, b in (("e2e_sparse1m.json", f"{tag}_e2e_sparse1m.json"), ("bench_dist_world1_rccl.log", f"{tag}_bench_dist_world1_rccl.log"),
              ("probe.txt", f"{tag}_probe.txt"), ("sq_k4.txt", f"{tag}_sq_k_assemble_mfma.txt"), ("k4_split.txt", f"{tag}_k4_split.txt"),
              ("top_of_tree_levels.txt", f"{tag}_top_of_tree_levels.txt"), ("e2e.err", f"{tag}_e2e_timing.txt"),
-             ("scaling_projection.md", f"{tag}_scaling_projection.md"), ("step_trace.txt", f"{tag}_step_trace.txt")):
+             ("scaling_projection.md", f"{tag}_scaling_projection.md"), ("scaling_projection_sparse5m.md", f"{tag}_scaling_projection_sparse5m.md"), ("step_trace.txt", f"{tag}_step_trace.txt")):
     if os.path.exists(os.path.join(src, a)):
         shutil.copy(os.path.join(src, a), os.path.join(dst, b))
 
