@@ -73,9 +73,10 @@ stream beside K5, so the phases add up to more than the step):
 Rooflines:
 * sparse-1m `k_assemble_mfma<18, true>` (K1+K4: JtJ and Jt*x in one pass): {r['algorithmic_bytes']/1e6:.1f} MB algorithmic / {r['avg_launch_ms']:.3f} ms = **{r['achieved']:.0f} GB/s = {100*r['frac']:.1f} % of 8 TB/s**
   (target in BASELINE.json: 40 %).  Counter traffic {t['bytes_per_launch']/1e6:.0f} MB per launch ({tag}_pmc.md): {t['bytes_per_launch']/r['algorithmic_bytes']:.2f}x the
-  algorithmic bytes (J is walked twice: by the tasks of its points' columns and of its cameras').  The kernel is bound by
-  memory latency exposed per wave ({tag}_pmc.md: 60 % of the wave cycles in s_waitcnt, matrix cores 18 % busy); K1's own
-  pass over J is gone.
+  algorithmic bytes (J is walked twice: by the tasks of its points' columns and of its cameras').  What bounds it is not that
+  traffic: with no value of J loaded and no transient block stored the kernel still takes 83 of its ~104 us ({tag}_experiments.md,
+  ablations) -- ~80 instructions a k-group of 4 rows on 4 waves a SIMD ({tag}_pmc.md: 60 % of the wave cycles in s_waitcnt,
+  matrix cores 18 % busy).  K1's own pass over J is gone.
 * dense-50k `k_syrk_lower<64>` (K4): {rd['algorithmic_flops']:.3e} flop / {rd['avg_launch_ms']:.3f} ms = **{rd['achieved']:.1f} TFLOP/s** = {100*rd['frac']:.0f} % of the 78.6
   TFLOP/s datasheet fp64-matrix peak, which a register-only v_mfma_f64_16x16x4_f64 loop does sustain here ({probe_mfma} TFLOP/s, {tag}_probe.txt; the 48 of rounds 1-3 was a faulty probe: {tag}_probe_notes.md).
 * sparse-1m `k_norm2_Jv` (K3/K8): {ok['K3K8_norm2_Jv']['algorithmic_bytes']/1e6:.0f} MB / {1e3*ok['K3K8_norm2_Jv']['ms']:.0f} us = {ok['K3K8_norm2_Jv']['GBps']:.0f} GB/s = {100*ok['K3K8_norm2_Jv']['frac_hbm']:.0f} % of HBM (J past the Infinity Cache).
@@ -83,7 +84,7 @@ Rooflines:
   say so): K5 = {k5b/1e6:.0f} MB (`8 nnz(tril JtJ) + 8 nnz(L)`) and {k5f/1e9:.2f} GFLOP in {k5t:.2f} ms = {k5b/k5t/1e6:.0f} GB/s
   ({100*k5b/k5t/1e6/8000:.1f} % of HBM), {k5f/k5t/1e9:.2f} TFLOP/s ({100*k5f/k5t/1e9/78.6:.1f} % of the fp64 peak); K6 = {k6b/1e6:.0f} MB (`16 nnz(L) + 32 N`) in {k6t:.2f} ms
   = {k6b/k6t/1e6:.0f} GB/s ({100*k6b/k6t/1e6/8000:.1f} %).  {nlev} elimination-tree levels: the upper ones are ONE launch each way
-  (workgroups hand over through flags; round 3: a supernode of the factor launch is shared by up to four workgroups, each
+  (workgroups hand over through flags; a supernode of the factor launch is shared by up to eight workgroups, each
   forming a slice of its update matrix): ~25-35 us (factor) + ~6 us (backward solve) a level; {tag}_top_of_tree_levels.txt, DESIGN.md section 6.
 
 rocprofv3 --stats, sparse-1m (bench.py default run; ms/step = total / steps issued):
