@@ -6,6 +6,39 @@
 
 // ------------------------------------------------------------------ errors --
 static thread_local char g_err[1024] = "";
+#include <atomic>
+#include <mutex>
+namespace {
+constexpr int DLG_TURN_DEV = 64;
+std::mutex g_turn_mu;
+std::atomic<int> g_turn_live[DLG_TURN_DEV];
+hipEvent_t g_turn_ev[DLG_TURN_DEV];
+dlg_backend* g_turn_owner[DLG_TURN_DEV];
+}
+DlgRegionTurn::DlgRegionTurn(dlg_backend* b_) : b(b_), on(false)
+{
+  const int d = b->device & (DLG_TURN_DEV - 1);
+  if(g_turn_live[d].load(std::memory_order_relaxed) <= 1 || !b->ev_region) return;
+  on = true;
+  g_turn_mu.lock();
+  // (the launch before this one on the device, if it was another backend's: over before this one goes out)
+  if(g_turn_owner[d] && g_turn_owner[d] != b && g_turn_ev[d]) (void)hipEventSynchronize(g_turn_ev[d]);
+}
+DlgRegionTurn::~DlgRegionTurn()
+{
+  if(!on) return;
+  const int d = b->device & (DLG_TURN_DEV - 1);
+  if(hipEventRecord(b->ev_region, b->stream) == hipSuccess) { g_turn_ev[d] = b->ev_region; g_turn_owner[d] = b; }
+  g_turn_mu.unlock();
+}
+static void turn_register(dlg_backend* b) { g_turn_live[b->device & (DLG_TURN_DEV - 1)].fetch_add(1); }
+static void turn_unregister(dlg_backend* b)
+{
+  const int d = b->device & (DLG_TURN_DEV - 1);
+  std::lock_guard<std::mutex> lk(g_turn_mu);
+  if(g_turn_owner[d] == b) { if(g_turn_ev[d]) (void)hipEventSynchronize(g_turn_ev[d]); g_turn_owner[d] = nullptr; g_turn_ev[d] = nullptr; }
+  g_turn_live[d].fetch_sub(1);
+}
 void dlg_set_error(const char* fmt, ...)
 {
   va_list ap; va_start(ap, fmt);
@@ -191,6 +224,8 @@ extern "C" int dlg_backend_create(dlg_backend_t** out, int solve_type, int Nstat
   TRY_HIP(hipStreamCreateWithFlags(&b->aux_stream, hipStreamNonBlocking));
   TRY_HIP(hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming));
   TRY_HIP(hipEventCreateWithFlags(&b->ev_join, hipEventDisableTiming));
+  TRY_HIP(hipEventCreateWithFlags(&b->ev_region, hipEventDisableTiming));
+  turn_register(b); b->turn_registered = true;
   TRY_HIP(hipMalloc(&b->d_join, sizeof(int)*2));
   TRY_HIP(hipMemsetAsync(b->d_join, 0, sizeof(int)*2, b->stream));
   b->overlap = getenv("DOGLEG_AMD_NO_OVERLAP") == nullptr;
@@ -266,6 +301,8 @@ extern "C" void dlg_backend_destroy(dlg_backend_t* b)
   if(b->aux_stream) { (void)hipStreamSynchronize(b->aux_stream); (void)hipStreamDestroy(b->aux_stream); b->aux_stream = nullptr; }
   if(b->ev_fork) { (void)hipEventDestroy(b->ev_fork); b->ev_fork = nullptr; }
   if(b->ev_join) { (void)hipEventDestroy(b->ev_join); b->ev_join = nullptr; }
+  if(b->turn_registered) { turn_unregister(b); b->turn_registered = false; }
+  if(b->ev_region) { (void)hipEventDestroy(b->ev_region); b->ev_region = nullptr; }
   if(b->d_join) { (void)hipFree(b->d_join); b->d_join = nullptr; }
   if(b->ev_step) { (void)hipEventDestroy(b->ev_step); b->ev_step = nullptr; }
   if(b->ev_copy) { (void)hipEventDestroy(b->ev_copy); b->ev_copy = nullptr; }

@@ -69,6 +69,8 @@ struct dlg_backend
   // main stream that reads that step (k_negate_interp1) polls the word itself -- a wait for an event of another stream costs
   // the main stream ~6 us between two kernels even when the event is long complete (DOGLEG_AMD_JOIN_EVENT: the event)
   int* d_join = nullptr; int join_epoch = 0, join_pending = 0;
+  hipEvent_t ev_region = nullptr;    // behind this backend's last one-launch region (DlgRegionTurn)
+  bool turn_registered = false;
   bool want_fork = false, fork_recorded = false, overlap = true;
   bool fuse_eval = true;      // ... in the pass that forms Jt*x where the schedule allows (DOGLEG_AMD_NO_FUSED_EVAL: second stream instead)
   bool speculate = false;     // dlg_backend_set_speculation: assemble JtJ beside Jt*x at every dlg_point_eval
@@ -238,6 +240,12 @@ static inline DlgHandoff dlg_handoff(const dlg_backend* b, int spins)
   h.spins = b->handoff_spins > 0 ? b->handoff_spins : spins; h.skew = b->handoff_skew;
   return h;
 }
+// One-launch regions (workgroups that wait for each other inside a launch) of DIFFERENT backends on one device take
+// turns: two such launches at once can hold each other's CUs with waiting workgroups whose partners find no room --
+// every one of them gives up after its 2^21 polls and the step fails with DLG_ERR_STATE (tools/stress_concurrent.py).
+// With one backend on the device (one process per GPU: the rule) this is one atomic load.  Around the launch:
+//   { DlgRegionTurn turn(b); hipLaunchKernelGGL(...region...); }
+struct DlgRegionTurn { dlg_backend* b; bool on; explicit DlgRegionTurn(dlg_backend* b); ~DlgRegionTurn(); };
 // after a synchronisation that brought the scalar block to the host: DLG_ERR_STATE if a hand-off timed out
 int dlg_check_handoff(dlg_backend* b);
 

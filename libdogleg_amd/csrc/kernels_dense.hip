@@ -861,6 +861,7 @@ static int run_potrf(dlg_backend* b)
   const DlgHandoff ho = dlg_handoff(b, 1 << 22);
   if(!b->knobs.potrf_steps && T >= 2)
   {
+    DlgRegionTurn turn(b);
     dense_launch_potrf_tiles(b->stream, b->G, b->N, b->N, b->d_info, b->Linv, b->potrf_flag, ++b->potrf_epoch, ho);
     DLG_LAUNCH_CHECK();
     return DLG_OK;
@@ -939,6 +940,7 @@ int dense_solve(dlg_backend* b, const double* rhs, double* out)
         DLG_HIP(hipMalloc(&b->trsv_x, sizeof(double)*ne));
         dense_trsv_arm(b->stream, b->trsv_y, b->trsv_x, ne);
       }
+      DlgRegionTurn turn(b);
       dense_launch_trsv_tiles(b->stream, b->G, n, n, b->Linv, rhs, b->trsv_y, out, b->trsv_x, ++b->trsv_epoch, dlg_handoff(b, 1 << 22));
       DLG_LAUNCH_CHECK();
       return DLG_OK;

@@ -1495,15 +1495,18 @@ int sparse_factor_levels(dlg_backend* b)
       if(l > 0 && n < 256) dlg_fork_gate(b, fl + np, ep);
       const int64_t pacc = Y->pr_acc ? (int64_t)(Y->pr_acc - Y->uscr) : 0;
       const DlgHandoff ho = dlg_handoff(b, 1 << 21);
-      if(Y->fac_nt[l] == 128)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_factor_level<128>), dim3(np), dim3(128), Y->pr2_lds, st,
-                           Y->pr2_item, Y->pr2_rec, Y->sn_bd_col, Y->pr2_dst, Y->Lx, Y->top_scr, Y->d_info, Y->uscr, fmode, fl, ep, ho, pacc);
-      else if(Y->fac_nt[l] == 256)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_factor_level<256>), dim3(np), dim3(256), Y->pr2_lds, st,
-                           Y->pr2_item, Y->pr2_rec, Y->sn_bd_col, Y->pr2_dst, Y->Lx, Y->top_scr, Y->d_info, Y->uscr, fmode, fl, ep, ho, pacc);
-      else
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_factor_level<512>), dim3(np), dim3(512), Y->pr2_lds, st,
-                           Y->pr2_item, Y->pr2_rec, Y->sn_bd_col, Y->pr2_dst, Y->Lx, Y->top_scr, Y->d_info, Y->uscr, fmode, fl, ep, ho, pacc);
+      {
+        DlgRegionTurn turn(b);            // (held for the launch only: the sum over the ranks behind it blocks in the caller's hook)
+        if(Y->fac_nt[l] == 128)
+          hipLaunchKernelGGL(HIP_KERNEL_NAME(k_factor_level<128>), dim3(np), dim3(128), Y->pr2_lds, st,
+                             Y->pr2_item, Y->pr2_rec, Y->sn_bd_col, Y->pr2_dst, Y->Lx, Y->top_scr, Y->d_info, Y->uscr, fmode, fl, ep, ho, pacc);
+        else if(Y->fac_nt[l] == 256)
+          hipLaunchKernelGGL(HIP_KERNEL_NAME(k_factor_level<256>), dim3(np), dim3(256), Y->pr2_lds, st,
+                             Y->pr2_item, Y->pr2_rec, Y->sn_bd_col, Y->pr2_dst, Y->Lx, Y->top_scr, Y->d_info, Y->uscr, fmode, fl, ep, ho, pacc);
+        else
+          hipLaunchKernelGGL(HIP_KERNEL_NAME(k_factor_level<512>), dim3(np), dim3(512), Y->pr2_lds, st,
+                             Y->pr2_item, Y->pr2_rec, Y->sn_bd_col, Y->pr2_dst, Y->Lx, Y->top_scr, Y->d_info, Y->uscr, fmode, fl, ep, ho, pacc);
+      }
       l = Y->pr2_level1;                                 // (= the cut: everything below it is done)
       if(H.part_nranks > 1 && l == H.cut_level) { DLG_LAUNCH_CHECK(); DLG_CHECK(sparse_partition_reduce(b)); }
       continue;
@@ -1517,6 +1520,7 @@ int sparse_factor_levels(dlg_backend* b)
       if(gate_here && l > 0 && n < 256) dlg_fork_gate(b, fl + np, ep);
       const int64_t pacc = Y->pr_acc ? (int64_t)(Y->pr_acc - Y->uscr) : 0;
       const DlgHandoff ho = dlg_handoff(b, 1 << 21);
+      DlgRegionTurn turn(b);
       if(Y->fac_nt[l] == 128)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_factor_level<128>), dim3(np), dim3(128), Y->pr_lds, st,
                            Y->pr_item, Y->pr_rec, Y->sn_bd_col, Y->pr_dst, Y->Lx, Y->top_scr, Y->d_info, Y->uscr, fmode, fl, ep, ho, pacc);

@@ -864,6 +864,7 @@ int sparse_solve(dlg_backend* b, const double* rhs, double* out)
   if(Y->bw_level0 < H.nlevels)
   {
     // the persistent top region: its levels in one launch, workgroups from the root down (sparse_solve_setup)
+    DlgRegionTurn turn(b);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_solve_bwd_level<512, false>), dim3(Y->bw_n), dim3(512), Y->bw_lds, st,
                        Y->slv_item_pr, Y->sn_rows, Y->perm, Y->Lx, Y->ywork, out, use_aug, Y->sn_bd_col,
                        256*Y->bw_level0, Y->bwd_xb_cap, Y->bwd_flag, ++Y->bwd_epoch, Y->d_info, dlg_handoff(b, 1 << 21), Y->bwd_xh, H.N);
