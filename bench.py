@@ -49,7 +49,7 @@ WORKLOADS = {
 }
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
-MFMA_F64_PEAK_TFLOPS = 78.6    # public datasheet; the guides carry no fp64 MFMA figure (48 measured)
+MFMA_F64_PEAK_TFLOPS = 78.6    # public datasheet; a register-only v_mfma_f64_16x16x4_f64 loop sustains 72 - 78 here (profiles/r04_probe.txt)
 
 
 def main():
@@ -245,7 +245,7 @@ def main():
     # reference re-uses the cached Cauchy/GN steps and the factor (dogleg.c:533-535, 637, 825), so a
     # retry is only step formation (K7), expected improvement (K8) and the evaluation of the new
     # point (K1).  Not part of `value`.
-    retry_ms = None
+    retry_ms = first_retry_ms = None
     if not use_dist and not logical:
         tr_retry = 0.5 * (res[1] ** 0.5 + res[2] ** 0.5)
 
@@ -262,6 +262,23 @@ def main():
             one_retry(0.98 - 1e-4 * i)
         barrier()
         retry_ms = (time.perf_counter() - tr0) / args.steps * 1e3
+        # ... and the FIRST retry behind an accepted step: the evaluation of the trial point had enqueued the leaf level of
+        # its factorisation ahead (step_prepare), the rejection abandons it (sparse_abandon_enqueued); the retries of a
+        # run of rejections (above) find nothing enqueued
+        t_first = 0.0
+        n_first = max(8, args.steps // 4)
+        for i in range(n_first + 2):
+            one_step()
+            c = state["i"] % ncopy
+            state["i"] += 1
+            be.bind_device(1, d_x[c].ptr, d_J[c].ptr)
+            be.eval(1)
+            ta = time.perf_counter()
+            one_retry(0.98 - 1e-4 * i)
+            if i >= 2:
+                t_first += time.perf_counter() - ta
+        first_retry_ms = t_first / n_first * 1e3
+        one_step()
     # the same step with K1 and K4 as two passes over J (how rounds 1-2 reported `value`)
     sep_ms = None
     if one_pass and not logical:
@@ -373,7 +390,10 @@ def main():
             "early_return_launches": ({k: {"launches": v[1], "ms_per_launch": v[0] / v[1]} for k, v in prof_early.items() if v[1] > 0}
                                       or None),
             "cached_retry_step": ({"ms_per_step": retry_ms, "steps_per_s": 1e3 / retry_ms,
-                                   "what": "K7 + K8 + evaluation of the new point (K1, with K4 in the same pass where `value` has it), cached Cauchy/GN/factor"}
+                                   "first_retry_after_an_accepted_step_ms": first_retry_ms,
+                                   "what": "K7 + K8 + evaluation of the new point (K1, with K4 in the same pass where `value` has it), cached Cauchy/GN/factor; "
+                                           "ms_per_step: inside a run of rejections (nothing enqueued ahead); first_retry...: the retry right behind an accepted "
+                                           "step, whose trial point's leaf-level factorisation had been enqueued ahead and is abandoned"}
                                   if retry_ms else None),
             "separate_passes": ({"ms_per_step": sep_ms, "steps_per_s": 1e3 / sep_ms,
                                  "what": "same step with Jt*x (K1) and the JtJ assembly (K4) as two passes over J: `value` of rounds 1-2"}

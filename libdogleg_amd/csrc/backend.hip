@@ -105,7 +105,7 @@ void dlg_prof_end(dlg_backend* b, int id, hipEvent_t start)
   hipEvent_t e = prof_event(b);
   if(!e) { b->prof_pool.push_back(start); return; }
   (void)hipEventRecord(e, b->stream);
-  b->prof_pending.push_back({start, e, id, prof_is_cond(b, id)});
+  b->prof_pending.push_back({start, e, id, prof_is_cond(b, id), b->prof_cont});
 }
 bool dlg_prof_pair(dlg_backend* b, int id, hipEvent_t* e0, hipEvent_t* e1)
 {
@@ -124,8 +124,9 @@ void dlg_prof_resolve(dlg_backend* b)
     (void)hipEventSynchronize(pp.b);          // (a phase on the second stream may still be running)
     if(hipEventElapsedTime(&ms, pp.a, pp.b) == hipSuccess)
     {
-      if(pp.cond) { b->prof_att_ms[pp.id] += ms; b->prof_att_n[pp.id]++; }
-      else        { b->prof_ms[pp.id] += ms; b->prof_n[pp.id]++; }
+      // (cont: the second part of a phase that was counted with its first part -- a factorisation enqueued in two pieces)
+      if(pp.cond) { b->prof_att_ms[pp.id] += ms; b->prof_att_n[pp.id] += pp.cont ? 0 : 1; }
+      else        { b->prof_ms[pp.id] += ms; b->prof_n[pp.id] += pp.cont ? 0 : 1; }
     }
     b->prof_pool.push_back(pp.a); b->prof_pool.push_back(pp.b);
   }
@@ -244,6 +245,9 @@ extern "C" int dlg_backend_create(dlg_backend_t** out, int solve_type, int Nstat
     k.potrf_steps = getenv("DOGLEG_AMD_POTRF_STEPS") != nullptr;
     k.trsv_steps = getenv("DOGLEG_AMD_TRSV_STEPS") != nullptr;
     k.no_touch = getenv("DOGLEG_AMD_NO_TOUCH") != nullptr;
+    k.no_abandon = getenv("DOGLEG_AMD_NO_ABANDON") != nullptr;
+    k.no_split = getenv("DOGLEG_AMD_NO_SPLIT_PRESOLVE") != nullptr;
+    k.no_reject_run = getenv("DOGLEG_AMD_NO_REJECT_RUN") != nullptr;
     // test hook of the hand-off time-outs: the waits of the one-launch regions look for an epoch that never
     // comes and give up after a few hundred polls
     if(getenv("DOGLEG_AMD_DEBUG_HANDOFF_TIMEOUT")) { b->handoff_skew = 1; b->handoff_spins = 256; }
@@ -330,7 +334,7 @@ extern "C" int dlg_backend_reset(dlg_backend_t* b)
     // (step_to_here of the first point of a solve is read by nobody, but a returned context downloads it)
     DLG_HIP(hipMemsetAsync(S.step, 0, sizeof(double)*(size_t)b->N, b->stream));
   }
-  b->factor_slot = -1; b->speculate = false; b->presolve = false; b->pre_slot = -1; b->pre_held = -1; b->pre_hint_valid = false; b->pre_hint_input = false;
+  b->factor_slot = -1; b->speculate = false; b->presolve = false; b->pre_slot = -1; b->pre_held = -1; b->pre_hint_valid = false; b->pre_hint_input = false; b->pre_rejected = false; b->pre_split = false;
   b->want_fork = b->fork_recorded = false; b->fork_gate = nullptr;
   b->join_pending = 0;
   b->fold_scalar = b->fold_result = nullptr; b->fold_cauchy_out = nullptr;
@@ -614,9 +618,17 @@ static int step_unprepare(dlg_backend* b)
   const int held = b->pre_held;
   b->pre_held = -1;
   if(b->type != DLG_SPARSE) return DLG_OK;
+  // (a rejected trial point, dogleg.c:1455-1468: whatever of its K5 + K6 has not started yet is not worth starting --
+  // the retry from the cached vectors of the other point, README.pod:49, is behind them on this stream)
+  if(!b->knobs.no_abandon) DLG_CHECK(sparse_abandon_enqueued(b));
+  b->pre_split = false;
+  // ... and the next trial point is expected to go the same way (rejections come in runs while the trust region
+  // shrinks, dogleg.c:1455-1468): its evaluation enqueues nothing ahead -- a retry then costs what the reference's
+  // does, K7 + K8 + the evaluation -- until a step is taken from a fresh point again (dlg_take_step)
+  b->pre_rejected = !b->knobs.no_reject_run;
   if(held < 0) { sparse_release_held(b); return DLG_OK; }
   bool restored = false;
-  DLG_CHECK(sparse_restore_factor(b, &restored));
+  DLG_CHECK(sparse_restore_factor(b, &restored, b->knobs.no_abandon));      // (the abandon re-armed the pivot flag)
   b->factor_slot = restored ? held : -1;
   return DLG_OK;
 }
@@ -637,11 +649,16 @@ static int step_prepare(dlg_backend* b, int s)
   DLG_CHECK(cauchy_fork_begin(b));
   int good = 0;
   DlgProfCond pc(b);
-  b->defer_factor_sync = true;
+  // Only what covers the host's round trip goes onto the stream now -- the leaf level (88 us on config #4 against ~45 us
+  // until the host has its norms and ~15 us until it is back) --; dlg_take_step enqueues the levels above and the solve
+  // behind it, back to back.  A rejected point (step_unprepare) then has one kernel to abandon, not K5 + K6.
+  b->defer_factor_sync = true; b->factor_ahead = !b->knobs.no_split;
   const int rc = sparse_factorize(b, s, lam, &good);
-  b->defer_factor_sync = false;
+  b->defer_factor_sync = false; b->factor_ahead = false;
   if(rc != DLG_OK) b->want_fork = false;
   DLG_CHECK(rc);
+  b->pre_split = sparse_factor_pending(b);
+  if(!b->pre_split)
   {
     DlgProfScope ps(b, DLG_PROF_K6_SOLVE);
     DLG_CHECK(sparse_solve(b, S.Jt_x, S.gn));
@@ -696,7 +713,8 @@ extern "C" int dlg_point_eval(dlg_backend_t* b, int s, double* norm2_x, double* 
     // The partial-sum stages of JtJ and the norm kernel the host waits for leave the critical stream where the
     // factorisation of this point is going to follow at once (step_prepare): the main stream goes from Jt*x
     // straight to the augmented row and the leaf level, the second stream does norms and stages meanwhile.
-    const bool side = pair && fused && b->presolve && b->host_finals && b->part_nranks <= 1 && sparse_fin_side_ok(b);
+    const bool ahead = b->presolve && !b->pre_rejected;
+    const bool side = pair && fused && ahead && b->host_finals && b->part_nranks <= 1 && sparse_fin_side_ok(b);
     struct SideGuard { dlg_backend* b; ~SideGuard() { (void)sparse_fin_side_end(b); } } side_guard{b};     // (an error on the way: the main stream is b->stream again)
     if(side) DLG_CHECK(sparse_fin_side_begin(b));
     if(pair)
@@ -722,7 +740,7 @@ extern "C" int dlg_point_eval(dlg_backend_t* b, int s, double* norm2_x, double* 
       if(side) DLG_CHECK(sparse_fin_side_end(b));
       // the factorisation and the Gauss-Newton solve follow at once (dlg_take_step finds them enqueued): the
       // chip works on them while the host fetches the norms and decides
-      if(b->presolve && !b->sharded() && b->part_nranks <= 1) DLG_CHECK(step_prepare(b, s));
+      if(ahead && !b->sharded() && b->part_nranks <= 1) DLG_CHECK(step_prepare(b, s));
       DLG_HIP(hipEventSynchronize(b->ev_fetch));
       dlg_resolve_pending(b);
     }
@@ -1188,8 +1206,10 @@ extern "C" int dlg_take_step(dlg_backend_t* b, int from, int to, double trustreg
   const double lam_in = lam;
   if(b->pre_slot == from && b->pre_lambda != lam) b->pre_hint_input = true;      // (the guess was wrong: this caller does not keep lambda)
   const bool prepared_here = b->pre_slot == from && b->pre_lambda == lam;
-  if(prepared_here) { b->pre_slot = -1; b->pre_held = -1; if(b->type == DLG_SPARSE) sparse_release_held(b); } else DLG_CHECK(step_unprepare(b));
+  bool pre_split = prepared_here && b->pre_split;          // (the prepared factorisation stopped behind its leaf level: the rest is enqueued here)
+  if(prepared_here) { b->pre_slot = -1; b->pre_held = -1; b->pre_split = false; if(b->type == DLG_SPARSE) sparse_release_held(b); } else DLG_CHECK(step_unprepare(b));
   bool prepared = prepared_here;
+  b->pre_rejected = false;                     // (a step from a fresh point: the point before it was accepted)
   for(;;)
   {
     int good = 0, rc;
@@ -1201,7 +1221,18 @@ extern "C" int dlg_take_step(dlg_backend_t* b, int from, int to, double trustreg
       b->want_fork = b->fork_recorded = false; b->fork_gate = nullptr;
       DLG_HIP(hipMemcpyAsync(n2c_dev, &F.norm2_cauchy, sizeof(double), hipMemcpyHostToDevice, b->stream));
     }
-    if(prepared) { /* K5 is on the stream already */ }
+    if(prepared)
+    {
+      // K5 is on the stream already -- or its leaf level is, and the levels above follow here
+      if(pre_split)
+      {
+        DlgProfCond pc(b);
+        bool was = false;
+        const int rcr = sparse_factorize_rest(b, &was);
+        if(rcr != DLG_OK) b->want_fork = false;
+        DLG_CHECK(rcr);
+      }
+    }
     else if(b->factor_slot != from)
     {
       DlgProfCond pc(b);
@@ -1217,14 +1248,14 @@ extern "C" int dlg_take_step(dlg_backend_t* b, int from, int to, double trustreg
       DLG_CHECK(rc);
     }
     if(do_cauchy) DLG_CHECK(cauchy_fork_enqueue(b, from, b->d_scal + 4));     // K3 beside K5 (second stream)
-    if(!prepared)
+    if(!prepared || pre_split)
     {
       DlgProfCond pc(b);
       DlgProfScope ps(b, DLG_PROF_K6_SOLVE);
       if(b->type == DLG_SPARSE) DLG_CHECK(sparse_solve(b, F.Jt_x, F.gn));
       else                      DLG_CHECK(dense_solve(b, F.Jt_x, F.gn));
     }
-    prepared = false;
+    prepared = false; pre_split = false;
     DLG_CHECK(cauchy_deferred_finish(b, from));
     int nbg = 0;
     {

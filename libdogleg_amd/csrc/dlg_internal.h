@@ -75,6 +75,10 @@ struct dlg_backend
   bool fuse_eval = true;      // ... in the pass that forms Jt*x where the schedule allows (DOGLEG_AMD_NO_FUSED_EVAL: second stream instead)
   bool speculate = false;     // dlg_backend_set_speculation: assemble JtJ beside Jt*x at every dlg_point_eval
   bool presolve = false;      // ... and enqueue K5 + K6 behind it (step_prepare) for dlg_take_step to pick up
+  bool pre_rejected = false;  // the last point whose factorisation was enqueued ahead was rejected: the next evaluation enqueues nothing ahead (a step taken from a fresh point clears it)
+  bool factor_ahead = false;  // (around sparse_factorize in step_prepare) only what covers the host's round trip: the leaf level
+  bool pre_split = false;     // the prepared factorisation stopped behind its leaf level: dlg_take_step enqueues the rest and the solve
+  bool prof_cont = false;     // the next timed scope continues a phase that was counted already (a factorisation in two parts)
   int  pre_slot = -1, pre_held = -1; double pre_lambda = 0.0, pre_hint = 0.0; bool pre_hint_valid = false, pre_hint_input = false;   // prepared slot; slot whose factor it displaced
   DlgSlot slot[2];
 
@@ -95,7 +99,7 @@ struct dlg_backend
   {
     bool join_event = false;
     bool no_k3_fork = false, no_potrf_fuse = false, potrf_steps = false,
-         trsv_steps = false, no_touch = false;
+         trsv_steps = false, no_touch = false, no_abandon = false, no_split = false, no_reject_run = false;
     int touch_wg = 512;
   } knobs;
   int ncu = 256;              // compute units of b->device
@@ -162,7 +166,7 @@ struct dlg_backend
   hipEvent_t attach_stop = nullptr; bool stop_attached = false, ext_events = true;      // DLG_LAUNCH_LAST
   int prof_every = 1; unsigned prof_tick[DLG_PROF_COUNT] = {};      // every n-th occurrence of a timed phase carries events
   unsigned prof_mask = 0;     // the phases that are timed (bit = DLG_PROF_*)
-  struct ProfPair { hipEvent_t a, b; int id; bool cond; };
+  struct ProfPair { hipEvent_t a, b; int id; bool cond; bool cont = false; };
   std::vector<ProfPair> prof_pending;
   std::vector<hipEvent_t> prof_pool;
   double prof_ms[DLG_PROF_COUNT] = {0};
@@ -317,11 +321,14 @@ int sparse_eval_assemble(dlg_backend* b, int s, int* done);      // K1 + K4 in o
 int sparse_assemble_finish(dlg_backend* b);                      // ... the deferred partial-sum stages of that JtJ
 int sparse_touch_factor(dlg_backend* b, hipStream_t st);         // second stream: pull the leaf panels into the Infinity Cache
 int sparse_zero_spare(dlg_backend* b);                           // clear the panel buffer the factorisation left behind (behind the step's fetch)
+int sparse_abandon_enqueued(dlg_backend* b);                     // the launches of a factorisation + solve enqueued ahead (step_prepare) return early from here on
 void sparse_spec_invalidate(dlg_backend* b, int s);
 // K3/K8; kind_if_factor_failed (device scalar holding the kind of step, or null): the pass is skipped when the
 // factorisation on the stream failed and the step is not the Cauchy step to the edge
 int sparse_norm2_Jv(dlg_backend* b, int slot, const double* v, double* out_dev, const double* kind_if_factor_failed = nullptr);
-int sparse_factorize(dlg_backend* b, int slot, double lambda, int* ok);          // K4+K5
+int sparse_factorize(dlg_backend* b, int slot, double lambda, int* ok);          // K4+K5 (b->factor_ahead: K5 up to the leaf level only, sparse_factorize_rest owes the rest)
+int sparse_factorize_rest(dlg_backend* b, bool* was_pending);
+bool sparse_factor_pending(const dlg_backend* b);                     // the levels above the leaves of a factorisation enqueued ahead
 bool sparse_factor_ok(const dlg_backend* b);     // pivot flag of the last factorisation (after a sync)
 int sparse_solve(dlg_backend* b, const double* rhs, double* out);                // K6
 void sparse_hold_factor(dlg_backend* b);
@@ -335,7 +342,7 @@ int  sparse_fin_side_gate(dlg_backend* b);       // main: wait for flag B if sta
 // long finished in every measured case; a gate that never opens is reported through the hand-off status word)
 int  dlg_gate_wait(dlg_backend* b, hipStream_t st, const int* gate, int epoch, bool report);
 void sparse_release_held(dlg_backend* b);
-int sparse_restore_factor(dlg_backend* b, bool* restored);
+int sparse_restore_factor(dlg_backend* b, bool* restored, bool rearm = true);
 double sparse_current_lambda(const dlg_backend* b);                                 // of the last factorisation enqueued
 // blocked multi-right-hand-side solves (sparse_multi.hip / kernels_dense.hip): MR = 16 right-hand sides
 // interleaved [N][MR] (element (variable k, rhs c) at k*MR + c), solved in place, original order

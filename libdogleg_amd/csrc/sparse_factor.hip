@@ -322,6 +322,9 @@ __global__ void __launch_bounds__(NT, LEAF ? 4 : 1) k_factor_level(const FwItem*
   if(cmp)
   {
     __syncthreads();
+    // (a level of merged leaves is nobody's child inside its launch: a workgroup of a factorisation that is not going to
+    // be used -- failed pivot in an earlier launch, or abandoned: sparse_abandon_enqueued -- leaves before it loads anything)
+    if(LEAF && s_skip) return;
     bd_compact_members<NT, DS>(G, nrows, w, tid, sn_bd_col + it.bd0, it.nbd, it.bdw, s_mcol, s_rdiag, Dg, &sbad, it.col0);
   }
   // thread = (panel row, column group): rows padded to whole waves, the remaining threads take
@@ -1469,17 +1472,26 @@ extern "C" void dlg_fl_profile_dump(int nlevels)
 }
 #endif
 // K5: level-scheduled supernodal Cholesky (launches only; the caller reads the pivot flag)
-int sparse_factor_levels(dlg_backend* b)
+int sparse_factor_levels(dlg_backend* b, int part)
 {
   SparseSym* Y = b->sym;
   const SymHost& H = Y->H;
   hipStream_t st = b->stream;
+  // A factorisation enqueued ahead of the caller's decision (backend.hip, step_prepare) comes in two parts where its
+  // first launch is a level of its own: part 1 = that launch (the leaf level), part 2 = everything behind it.  Same
+  // launches in the same order on the same stream as part 0.
+  const bool split = Y->pr_level0 > 0 && !Y->lf_on && H.nlevels >= 2 && H.part_nranks <= 1 && H.fw_lvl_ptr[1] > H.fw_lvl_ptr[0];
+  if(part == 2 && !split) return DLG_OK;
+  if(part != 2)
+  {
   if(H.part_nranks > 1 && H.cut_level < 0) DLG_CHECK(sparse_partition_reduce(b));     // nothing below the cut
   // (fin on the side, sparse_assemble.hip: the partial-sum stages of the ancestors' panels may still be on the second
   // stream -- level 0 does not touch those panels; whatever follows it does)
   if(Y->pr_level0 == 0 || Y->lf_on || H.nlevels < 2) DLG_CHECK(sparse_fin_side_gate(b));
+  }
   for(int l = 0; l < H.nlevels; l++)
   {
+    const bool launched_before = part == 2 && l == 0;      // (the level's factor launch is on the stream: part 1)
 
     const int n = H.fw_lvl_ptr[l+1] - H.fw_lvl_ptr[l];
     // from the first level that cannot fill the chip on, the factorisation is latency-bound:
@@ -1532,7 +1544,7 @@ int sparse_factor_levels(dlg_backend* b)
                            Y->pr_item, Y->pr_rec, Y->sn_bd_col, Y->pr_dst, Y->Lx, Y->top_scr, Y->d_info, Y->uscr, fmode, fl, ep, ho, pacc);
       break;
     }
-    if(n > 0 && !(l == 0 && Y->lf_on))      // (leaf fronts: level 0 was factored with the assembly, sparse_leaf.hip)
+    if(n > 0 && !(l == 0 && Y->lf_on) && !launched_before)      // (leaf fronts: level 0 was factored with the assembly, sparse_leaf.hip)
     {
       const int o = H.fw_lvl_ptr[l];
       const int sweep_bits = (Y->fac_b16 ? 16 : 0);
@@ -1550,6 +1562,7 @@ int sparse_factor_levels(dlg_backend* b)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_factor_level<512>), dim3(n), dim3(512), Y->fac_lds[l], st,
                            Y->fw_item + o, Y->mf_rec, Y->sn_bd_col, Y->mf_dst, Y->Lx, Y->top_scr, Y->d_info, Y->uscr, fmode, (int*)nullptr, 0, DlgHandoff{nullptr, 0, 0}, (int64_t)0);
     }
+    if(part == 1 && split && l == 0) { Y->fac_pending = true; DLG_LAUNCH_CHECK(); return DLG_OK; }
     // (behind the leaf level's factor kernel, in front of its updates: the gather kernel looks at the word itself,
     // in front of anything else a one-wave kernel waits for it)
     const int nu = H.uw_lvl_ptr[l+1] - H.uw_lvl_ptr[l];

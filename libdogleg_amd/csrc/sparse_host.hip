@@ -501,7 +501,8 @@ int sparse_factorize(dlg_backend* b, int s, double lambda, int* ok)
     DLG_HIP(hipMemcpyAsync(Y->d_info, &k_armed, sizeof(int), hipMemcpyHostToDevice, st));
   }
   Y->info_clean = false;
-  DLG_CHECK(sparse_factor_levels(b));
+  Y->fac_pending = false;
+  DLG_CHECK(sparse_factor_levels(b, b->factor_ahead ? 1 : 0));
   if(pf.e) { dlg_prof_end(b, pf.id, pf.e); pf.e = nullptr; }
   // the caller's dlg_fetch_scalars(b, NSCAL) brings the flag along; sparse_factor_ok() reads it then
   if(b->defer_factor_sync) { *ok = 1; return DLG_OK; }
@@ -509,6 +510,19 @@ int sparse_factorize(dlg_backend* b, int s, double lambda, int* ok)
   DLG_HIP(hipStreamSynchronize(st));
   *ok = sparse_factor_ok(b);
   return DLG_OK;
+}
+bool sparse_factor_pending(const dlg_backend* b) { return b->sym && b->sym->fac_pending; }
+// the levels above the leaves of a factorisation whose leaf level was enqueued ahead (sparse_factor_levels(b, 1))
+int sparse_factorize_rest(dlg_backend* b, bool* was_pending)
+{
+  SparseSym* Y = b->sym;
+  *was_pending = Y && Y->fac_pending;
+  if(!*was_pending) return DLG_OK;
+  Y->fac_pending = false;
+  b->prof_cont = true;
+  struct Cont { dlg_backend* b; ~Cont() { b->prof_cont = false; } } cont{b};
+  DlgProfScope pf(b, DLG_PROF_K5_FACTOR);
+  return sparse_factor_levels(b, 2);
 }
 double sparse_current_lambda(const dlg_backend* b) { return b->sym ? b->sym->cur_lambda : 0.0; }
 // A factorisation enqueued ahead of the caller's decision (backend.hip, step_prepare) takes the place of the held
@@ -521,21 +535,46 @@ void sparse_hold_factor(dlg_backend* b)
 }
 // the enqueued factorisation is the one the caller went on with: the displaced factor is nobody's any more
 void sparse_release_held(dlg_backend* b) { if(b->sym) b->sym->held_Lx = nullptr; }
-int sparse_restore_factor(dlg_backend* b, bool* restored)
+int sparse_restore_factor(dlg_backend* b, bool* restored, bool rearm)
 {
   SparseSym* Y = b->sym;
   *restored = false;
+  Y->fac_pending = false;
   if(!Y->held_Lx || Y->held_Lx != Y->Lx_spec) { Y->held_Lx = nullptr; return DLG_OK; }      // (assembled in place: gone)
   std::swap(Y->Lx, Y->Lx_spec);
   Y->spare_zeroed = false; Y->spare_dirty = true;                // the dropped factor: cleared behind the next step
   Y->aug_rhs = Y->held_aug; Y->cur_lambda = Y->held_lambda; Y->held_Lx = nullptr;
   static const int k_armed = 0x7fffffff;                         // (the held factor was a good one)
-  DLG_HIP(hipMemcpyAsync(Y->d_info, &k_armed, sizeof(int), hipMemcpyHostToDevice, b->stream));
+  if(rearm) DLG_HIP(hipMemcpyAsync(Y->d_info, &k_armed, sizeof(int), hipMemcpyHostToDevice, b->stream));
   Y->info_clean = false; Y->info_armed = false;
   *restored = true;
   return DLG_OK;
 }
 bool sparse_factor_ok(const dlg_backend* b) { return *b->sym->h_info == 0x7fffffff; }
+// The factorisation and the solve enqueued ahead of the caller's decision (backend.hip, step_prepare) are not going to
+// be used -- the trial point was rejected: their launches that have not started yet return behind their first
+// barrier, exactly as they do behind a failed pivot (k_factor_level, k_update_*, k_solve_bwd_level look at the
+// pivot flag; the one-launch regions still raise their flags, nothing waits for a workgroup that gave up).  The
+// word is lowered from the side (the copy stream is idle here; the main stream is where those launches queue) and
+// the main stream re-arms it behind them: an event orders the two writes, at the price of one barrier packet on a
+// path that has just saved 0.4 ms.  What the buffers hold afterwards is what a finished factorisation leaves in
+// the same places or what the assembly stored there (structural entries of the leaves' panels; everything above
+// is cleared before its next use), so partial clears stay valid (tests/test_sparse_gpu.py, the reject scripts
+// against DOGLEG_AMD_NO_ABANDON bit for bit).
+namespace { __global__ void k_lower_word(int* word, int v) { if(threadIdx.x == 0) __hip_atomic_store(word, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } }
+int sparse_abandon_enqueued(dlg_backend* b)
+{
+  SparseSym* Y = b->sym;
+  if(!Y || !Y->d_info || !b->copy_stream || !b->ev_copy) return DLG_OK;
+  hipLaunchKernelGGL(k_lower_word, dim3(1), dim3(64), 0, b->copy_stream, Y->d_info, 0);
+  DLG_LAUNCH_CHECK();
+  DLG_HIP(hipEventRecord(b->ev_copy, b->copy_stream));
+  DLG_HIP(hipStreamWaitEvent(b->stream, b->ev_copy, 0));
+  hipLaunchKernelGGL(k_lower_word, dim3(1), dim3(64), 0, b->stream, Y->d_info, 0x7fffffff);      // (armed again behind what was abandoned)
+  DLG_LAUNCH_CHECK();
+  Y->info_clean = false; Y->info_armed = false; Y->fac_pending = false;
+  return DLG_OK;
+}
 
 // host-only: run the symbolic phase on a pattern and report its statistics
 // (no GPU needed; used by the CPU test-suite and by tools/)

@@ -105,6 +105,7 @@ struct SparseSym
   double *Lx = nullptr, *scr = nullptr, *ywork = nullptr, *asm_part = nullptr, *jtx_part = nullptr;
   int *d_info = nullptr, *h_info = nullptr;   // pivot flag: inside the backend's scalar block (device / pinned host)
   bool info_armed = false;                    // the assembly re-armed the flag (k_set_aug_row)
+  bool fac_pending = false;                   // sparse_factor_levels(b, 1) launched the leaf level only: part 2 is owed (backend.hip, step_prepare)
   size_t nnz_loc = 0;
   // sharded rows: positions of the structural non-zeros of JtJ in Lx (what the all-reduce carries)
   uint32_t* ar_idx = nullptr; double* ar_buf = nullptr; size_t ar_n = 0;
@@ -169,5 +170,5 @@ void sparse_spec_invalidate(dlg_backend* b, int s);                 // subtree p
 int sparse_factor_setup(dlg_backend* b, bool plan_only = false);   // per-level launch parameters of K5
 int sparse_leaf_setup(dlg_backend* b);                       // leaf fronts: uploads (after sparse_factor_setup)
 int sparse_leaf_front(dlg_backend* b, const double* Jv, double* Lx, const double* x, double* Jt_x, const double* rhs, double lambda);
-int sparse_factor_levels(dlg_backend* b);                    // K5 launches (no synchronisation)
+int sparse_factor_levels(dlg_backend* b, int part = 0);      // K5 launches (no synchronisation); part 1: the leaf level only where the rest can follow later (fac_pending), part 2: that rest
 int sparse_solve_setup(dlg_backend* b);                      // per-level launch parameters of K6

@@ -42,28 +42,97 @@ def gn_dense_lapack(J, g, lam=0.0, packed=True):
     return -sol, 0
 
 
-def gn_sparse_splu(Jcsr, g, lam=0.0, refine=2):
+def gn_sparse_splu(Jcsr, g, lam=0.0, refine=2, perm=None):
     """-(JtJ + lam I)^-1 g with SuperLU, then `refine` rounds of iterative refinement with the
     residual accumulated in extended precision (np.longdouble): the result is accurate far below
-    the 1e-10 parity bar, whatever the conditioning of the fixtures in use."""
+    the 1e-10 parity bar, whatever the conditioning of the fixtures in use.
+    perm (optional): a fill-reducing elimination order supplied by the caller -- position k eliminates variable
+    perm[k]; SuperLU then factors P A P' in its NATURAL order.  (A permutation is not arithmetic: config #5's JtJ,
+    500 001 x 500 001 with 97.6 M non-zeros, runs SuperLU's own minimum-degree ordering out of memory in this
+    container; with the nested-dissection order of the product's symbolic phase nnz(L) is 60 M.)"""
     N = Jcsr.shape[1]
     A = (Jcsr.T @ Jcsr).tocsc()
     if lam:
         A = A + lam * sp.identity(N, format="csc")
-    lu = spla.splu(A, permc_spec="MMD_AT_PLUS_A", diag_pivot_thresh=0.0,
-                   options=dict(SymmetricMode=True))
-    u = lu.solve(g)
+    if perm is None:
+        lu = spla.splu(A, permc_spec="MMD_AT_PLUS_A", diag_pivot_thresh=0.0,
+                       options=dict(SymmetricMode=True))
+        solve = lu.solve
+    else:
+        perm = np.asarray(perm, dtype=np.int64)
+        Ap = A[perm][:, perm].tocsc()
+        lu = spla.splu(Ap, permc_spec="NATURAL", diag_pivot_thresh=0.0, options=dict(SymmetricMode=True))
+        del Ap
+
+        def solve(b):
+            out = np.empty_like(b)
+            out[perm] = lu.solve(np.ascontiguousarray(b[perm]))
+            return out
+    u = solve(g)
     if refine:
         Ac = A.tocoo()
         r_, c_, v_ = Ac.row, Ac.col, Ac.data.astype(np.longdouble)
         for _ in range(refine):
             res = g.astype(np.longdouble).copy()
             np.subtract.at(res, r_, v_ * u.astype(np.longdouble)[c_])
-            u = u + lu.solve(res.astype(np.float64))
+            u = u + solve(res.astype(np.float64))
     return -u
 
 
-def trial_step(J, x, trustregion, lam=0.0, dense_packed=True):
+def gn_ba_schur(Jcsr, g, lam, n_lead, blk, refine=8, tol=1e-14, log=None):
+    """-(JtJ + lam I)^-1 g for a block-arrowhead J whose last columns are independent blocks of `blk` columns (no
+    measurement row touches two of them: the points of a bundle adjustment; the first n_lead columns are the rest):
+    block elimination -- the reduced system  S = Jc'Jc + lam I - E' (D + lam I)^-1 E  (E = Jp'Jc, D = Jp'Jp, block
+    diagonal) factored by SuperLU, the blocks by numpy's batched LAPACK inverse -- as the INNER solver of an iterative
+    refinement whose residual  g - (J'(J u) + lam u)  is accumulated in extended precision (np.longdouble).  The
+    fixed point of the refinement is the solution of the system itself, whatever the inner solver's rounding; the
+    loop runs until the correction is below tol |u| (the caller records the last corrections and the residual).
+    For config #5's JtJ (500 001 x 500 001, 97.6 M non-zeros) scipy's SuperLU gives up on the whole matrix in this
+    container (32-bit fill estimate / memory), on the reduced system (50 004 x 50 004) it does not."""
+    M, N = Jcsr.shape
+    nb = (N - n_lead) // blk
+    assert n_lead + nb * blk == N
+    Jc = Jcsr[:, :n_lead].tocsr()
+    Jp = Jcsr[:, n_lead:].tocsr()
+    D = (Jp.T @ Jp).tobsr(blocksize=(blk, blk))
+    D.sort_indices()
+    assert D.nnz == nb * blk * blk and np.array_equal(D.indices, np.arange(nb)), "the trailing blocks are coupled"
+    Dinv = np.linalg.inv(D.data + lam * np.eye(blk)[None, :, :])
+    Dinv = sp.bsr_matrix((Dinv, np.arange(nb), np.arange(nb + 1)), shape=(nb * blk, nb * blk)).tocsr()
+    E = (Jp.T @ Jc).tocsr()
+    S = (Jc.T @ Jc) + lam * sp.identity(n_lead, format="csr") - E.T @ (Dinv @ E)
+    lu = spla.splu(S.tocsc(), permc_spec="MMD_AT_PLUS_A", diag_pivot_thresh=0.0, options=dict(SymmetricMode=True))
+    del S
+
+    def inner(b):
+        bp = Dinv @ b[n_lead:]
+        yc = lu.solve(b[:n_lead] - E.T @ bp)
+        return np.concatenate([yc, bp - Dinv @ (E @ yc)])
+    Jcoo = Jcsr.tocoo()
+    rr, cc, vv = Jcoo.row, Jcoo.col, Jcoo.data.astype(np.longdouble)
+
+    def residual(u):
+        ul = u.astype(np.longdouble)
+        y = np.zeros(M, dtype=np.longdouble)
+        np.add.at(y, rr, vv * ul[cc])
+        res = g.astype(np.longdouble) - np.longdouble(lam) * ul
+        np.subtract.at(res, cc, vv * y[rr])
+        return res
+    u = inner(g)
+    hist = []
+    for it in range(refine):
+        res = residual(u)
+        du = inner(res.astype(np.float64))
+        u = u + du
+        hist.append((float(np.linalg.norm(du) / np.linalg.norm(u)), float(np.sqrt(float(res @ res)) / np.linalg.norm(g))))
+        if log:
+            log(f"refinement {it}: |du|/|u| = {hist[-1][0]:.3e}, |res|/|g| = {hist[-1][1]:.3e}")
+        if hist[-1][0] < tol:
+            break
+    return -u, hist, residual(u)
+
+
+def trial_step(J, x, trustregion, lam=0.0, dense_packed=True, gn=None):
     """One step of takeStepFrom from a fresh point.  J: dense ndarray or scipy.sparse matrix.
     Returns dict(step, kind, norm2_cauchy, norm2_gn, k, expected_improvement, g).  kind: 0 Cauchy to
     the edge, 1 Gauss-Newton, 2 interpolated."""
@@ -80,7 +149,8 @@ def trial_step(J, x, trustregion, lam=0.0, dense_packed=True):
         step = cauchy * (trustregion / np.sqrt(n2c))
         kind = 0
     else:
-        gn = gn_sparse_splu(J.tocsr(), g, lam) if sparse else gn_dense_lapack(J, g, lam, dense_packed)[0]
+        if gn is None:         # (a caller that has the Gauss-Newton step already -- config #5's fixture -- passes it in)
+            gn = gn_sparse_splu(J.tocsr(), g, lam) if sparse else gn_dense_lapack(J, g, lam, dense_packed)[0]
         n2g = float(gn @ gn)
         out["norm2_gn"] = n2g
         if n2g <= dsq:                                          # dogleg.c:1220

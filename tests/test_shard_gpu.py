@@ -403,3 +403,19 @@ def test_replicas_of_a_supernode_do_not_race_for_its_panel(gpu):
             first = res[0]["step"].copy()
         assert np.array_equal(res[0]["step"], first), it
 
+
+
+@pytest.mark.parametrize("shape,world", [((199, 3600, 40000), 4), ((499, 9000, 100000), 8)])
+def test_lower_region_of_a_partition_changes_no_bit(gpu, shape, world, monkeypatch):
+    """Round 4's second one-launch region -- a rank's own levels from the first multifrontal one up to the cut as ONE
+    launch with replicas -- against one launch per level (DOGLEG_AMD_NO_LOWER_REGION): the same step, bit for bit,
+    on every rank (INTEGRATION.md says so; VERDICT r4: nothing checked it)."""
+    prob = oa.BAProblem(*shape, seed=7)
+    monkeypatch.delenv("DOGLEG_AMD_NO_LOWER_REGION", raising=False)
+    res, data = _partition_step(prob, world, use_take_step=True, one_pass=True)
+    _check_partition_against_oracle(res, data)
+    monkeypatch.setenv("DOGLEG_AMD_NO_LOWER_REGION", "1")
+    ref, _ = _partition_step(prob, world, use_take_step=True, one_pass=True)
+    for a, b in zip(res, ref):
+        assert np.array_equal(a["step"], b["step"]) and np.array_equal(a["gn"], b["gn"]) and np.array_equal(a["g"], b["g"])
+        assert a["k"] == b["k"] and a["ei"] == b["ei"] and a["n2c"] == b["n2c"] and a["n2g"] == b["n2g"]

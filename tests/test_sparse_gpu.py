@@ -564,14 +564,17 @@ def test_premultiplied_block_sweep_agrees_to_rounding(gpu, shape, monkeypatch):
     assert np.max(np.abs(res["premul"][1] - res["plain"][1])) <= 1e-12*max(1.0, np.max(np.abs(res["plain"][1])))
 
 
-@pytest.mark.parametrize("lf", [False, True])
-def test_factor_and_solve_ahead_of_the_decision_change_no_bit(gpu, lf, monkeypatch):
+@pytest.mark.parametrize("lf,whole", [(False, False), (True, False), (False, True)])
+def test_factor_and_solve_ahead_of_the_decision_change_no_bit(gpu, lf, whole, monkeypatch):
     """dlg_point_eval (one-pass form) enqueues the factorisation and the Gauss-Newton solve of the point it
     evaluated; dlg_take_step from that point picks them up.  A step from the OTHER point (the trial point was
     rejected) gets the displaced factor back, and so does every other user of the held factor.  All numbers
     as without (DOGLEG_AMD_NO_PRESOLVE), bit for bit."""
     if lf:
         monkeypatch.setenv("DOGLEG_AMD_LEAF_FRONT", "1")
+    if whole:       # (round 5: by default only the leaf level goes ahead, the rest follows in dlg_take_step; here all of K5 + K6)
+        monkeypatch.setenv("DOGLEG_AMD_NO_SPLIT_PRESOLVE", "1")
+        monkeypatch.setenv("DOGLEG_AMD_NO_REJECT_RUN", "1")
     prob = oa.BAProblem(49, 900, 10000, seed=5)
     Jp, Ji = prob.pattern()
     pA = prob.p0()
@@ -809,3 +812,141 @@ def test_partial_clears_do_not_outlive_values_that_are_not_numbers(gpu):
     want = _steps_script(prob, inputs)
     got = _steps_script(prob, inputs, poison=3)
     _same_runs(got, want)
+
+
+@pytest.mark.parametrize("knob", [None, "DOGLEG_AMD_NO_ABANDON", "DOGLEG_AMD_NO_REJECT_RUN", "DOGLEG_AMD_NO_SPLIT_PRESOLVE"])
+def test_consecutive_rejections_match_the_oracle(gpu, knob, monkeypatch):
+    """A solve with runs of THREE and more rejected trial points in the middle of accepted ones (the callback makes
+    chosen evaluations much worse than they are; the oracle sees the same callback): every retry is the reference's
+    cheap one (dogleg.c:1455-1468 with the caches of 533-535, 637, 825: no refactorisation), and the factorisation +
+    solve that dlg_point_eval had enqueued for the rejected point is abandoned (sparse_abandon_enqueued; only its leaf
+    level is on the stream at that time, and inside a run of rejections nothing is enqueued ahead at all) -- the
+    trace is the oracle's trial for trial, also with each of these switched off (DOGLEG_AMD_NO_ABANDON: the enqueued
+    work runs to its end; _NO_REJECT_RUN: every evaluation enqueues ahead; _NO_SPLIT_PRESOLVE: all of K5 + K6 ahead)."""
+    if knob:
+        monkeypatch.setenv(knob, "1")
+    monkeypatch.setenv("DOGLEG_AMD_NO_BACKEND_CACHE", "1")
+    prob = oa.BAProblem(49, 900, 10000, seed=5, eps=0.4, p0_spread=0.6)
+    inner = capi.CB_SPARSE(prob.cb.value)
+    worse = {3, 4, 5, 8, 9, 10, 11}
+    count = [0]
+
+    @capi.CB_SPARSE
+    def cb(p, x, Jt, cookie):
+        inner(p, x, Jt, cookie)
+        count[0] += 1
+        if count[0] in worse:
+            np.ctypeslib.as_array(x, shape=(prob.M,))[:] *= 30.0
+    cbp = C.cast(cb, C.c_void_p)
+    prm = oa.default_params()
+    prm.max_iterations = 14
+    prm.trustregion0 = 5.0
+    p0 = prob.p0()
+    count[0] = 0
+    ro, po, tro = oa.oracle_solve("sparse", p0, prob.N, prob.M, prob.nnz, cbp, prob.cookie, prm)
+    count[0] = 0
+    rg, pg, trg = capi.optimize("sparse", p0, prob.N, prob.M, prob.nnz, cbp, prob.cookie, prm)
+    assert rg >= 0 and ro >= 0
+    acc = [t["accepted"] for t in trg.trials()]
+    runs = "".join("a" if a else "r" for a in acc)
+    assert "rrr" in runs and "a" in runs.split("rrr", 1)[1], runs     # three in a row, and accepted steps after them
+    worst = compare_traces(trg, tro)
+    assert np.max(np.abs(pg - po)) <= 1e-10
+    print(f"rejections: {runs} kinds={[t['step_type'] for t in trg.trials()]} max |step diff|={worst:.3e}")
+
+
+def test_a_retry_after_a_rejection_costs_less_than_half_a_step(gpu):
+    """README.pod:49 of the reference: "a matrix inversion isn't needed to retry a rejected step".  Here the evaluation of
+    a trial point enqueues that point's factorisation and solve; when the point is rejected they are abandoned, so a
+    retry (step from the cached vectors + evaluation of the new trial point, inputs resident in HBM) stays under
+    half a full step (config #3: 200k x 30k)."""
+    import time
+    prob = oa.BAProblem(499, 9000, 100000, seed=11)
+    Jp, Ji = prob.pattern()
+    p = prob.p0()
+    x, Jx = prob.eval(p)
+    be = capi.Backend(capi.DLG_SPARSE, prob.N, prob.M, prob.nnz)
+    be.set_pattern(Jp, Ji)
+    be.set_speculation(True)
+    be.set_p(0, p)
+    d_x = [capi.DeviceArray(np.ascontiguousarray(x)) for _ in range(3)]
+    d_J = [capi.DeviceArray(np.ascontiguousarray(Jx)) for _ in range(3)]
+    k = [0]
+
+    def bind(slot):
+        c = k[0] % 3
+        k[0] += 1
+        be.bind_device(slot, d_x[c].ptr, d_J[c].ptr)
+
+    def full(tr=1e30):
+        bind(0)
+        be.eval(0)
+        return be.take_step(0, 1, tr, 0.0)
+    lam, r, pn = full()
+    tr = 0.5 * (np.sqrt(r["n2c"]) + np.sqrt(r["n2g"]))
+
+    def retry(i):
+        be.step(0, 1, capi.KIND_INTERP, tr * (0.98 - 1e-4 * i))
+        bind(1)
+        be.eval(1)
+    for i in range(20):
+        full(tr)
+    n = 60
+    capi.lib().dlg_device_sync()
+    t0 = time.perf_counter()
+    for i in range(n):
+        full(tr)
+    capi.lib().dlg_device_sync()
+    t_full = (time.perf_counter() - t0) / n
+    full(tr)
+    bind(1)
+    be.eval(1)
+    for i in range(20):
+        retry(i)
+    capi.lib().dlg_device_sync()
+    t0 = time.perf_counter()
+    for i in range(n):
+        retry(i)
+    capi.lib().dlg_device_sync()
+    t_retry = (time.perf_counter() - t0) / n
+    be.close()
+    print(f"full step {t_full*1e3:.3f} ms, retry {t_retry*1e3:.3f} ms")
+    assert t_retry < 0.5 * t_full, (t_retry, t_full)
+
+
+@pytest.mark.parametrize("shape", [(49, 900, 10000), (199, 3600, 40000)])
+def test_fin_on_the_side_changes_no_bit(gpu, shape, monkeypatch):
+    """Round 4's "fin on the side" -- the partial-sum stages of JtJ and the norm kernel on the second stream while the
+    leaf level runs, gated by words -- against the same kernels in line on the main stream (DOGLEG_AMD_NO_FIN_SIDE):
+    every number of the bench's step sequence (evaluation, prepared factorisation, dlg_take_step) bit for bit, over
+    several steps with changing inputs (INTEGRATION.md says so; VERDICT r4: nothing checked it)."""
+    prob = oa.BAProblem(*shape, seed=6)
+    Jp, Ji = prob.pattern()
+    p = prob.p0()
+    evals = [prob.eval(p + 0.002*k) for k in range(3)]
+
+    def run():
+        be = capi.Backend(capi.DLG_SPARSE, prob.N, prob.M, prob.nnz)
+        be.set_pattern(Jp, Ji)
+        be.set_speculation(True)
+        be.set_p(0, p)
+        be.upload(0, *evals[0])
+        be.eval(0)
+        lam, n2c, n2g = be.cauchy_gauss_newton(0, 0.0)
+        tr = 0.6 * (np.sqrt(n2c) + np.sqrt(n2g))
+        res = []
+        for rep in range(9):
+            be.upload(0, *evals[rep % 3])
+            n2x, gmax = be.eval(0)
+            lam, r, pn = be.take_step(0, 1, tr, 0.0)
+            res.append((n2x, gmax, tuple(sorted(r.items())), pn.copy(), be.download(0, capi.VEC_GN), be.download(0, capi.VEC_JTX)))
+        be.close()
+        return res
+    monkeypatch.delenv("DOGLEG_AMD_NO_FIN_SIDE", raising=False)
+    got = run()
+    monkeypatch.setenv("DOGLEG_AMD_NO_FIN_SIDE", "1")
+    want = run()
+    for a, b in zip(got, want):
+        assert a[0] == b[0] and a[1] == b[1]
+        assert all(ka == kb and (va == vb or (va != va and vb != vb)) for (ka, va), (kb, vb) in zip(a[2], b[2]))
+        assert np.array_equal(a[3], b[3]) and np.array_equal(a[4], b[4]) and np.array_equal(a[5], b[5])

@@ -18,6 +18,11 @@ for a, b in (("e2e_sparse1m.json", f"{tag}_e2e_sparse1m.json"), ("bench_dist_wor
              ("top_of_tree_levels.txt", f"{tag}_top_of_tree_levels.txt"), ("e2e.err", f"{tag}_e2e_timing.txt"),
              ("scaling_projection.md", f"{tag}_scaling_projection.md"), ("scaling_projection_sparse5m.md", f"{tag}_scaling_projection_sparse5m.md"), ("step_trace.txt", f"{tag}_step_trace.txt")):
     if os.path.exists(os.path.join(src, a)):
+        # (profiles/r04_sq_k_assemble_mfma.txt was published EMPTY and a text computed from it -- an empty source
+        # is a failed collection step, not an artifact)
+        if os.path.getsize(os.path.join(src, a)) == 0:
+            sys.exit(f"publish_round: {os.path.join(src, a)} is empty -- the step of tools/collect_round.sh that writes it failed; "
+                     "re-collect (or delete the file if the round does not carry it)")
         shutil.copy(os.path.join(src, a), os.path.join(dst, b))
 
 
