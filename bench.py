@@ -279,6 +279,22 @@ def main():
                 t_first += time.perf_counter() - ta
         first_retry_ms = t_first / n_first * 1e3
         one_step()
+    # A workload whose factorisation breaks down at lambda = 0 (config #5: exactly-zero columns): `value` restarts every step
+    # from lambda0 = 0 -- K4 + the failed K5 of the first attempt are paid every time, the worst case.  The reference's lambda is
+    # sticky (dogleg.c:138, 670-673): after the first failure a real solve starts every later step at the lambda that worked.
+    sticky = None
+    if kind == "sparse" and not use_dist and not logical and res[8] != lam0:
+        lam_s = res[8]
+        rs0 = be.run_steps(0, 1, max(3, args.warmup), [d.ptr for d in d_x], [d.ptr for d in d_J], state["i"] % ncopy, state["tr"], lam_s)
+        barrier()
+        tq0 = time.perf_counter()
+        rs, kd = be.run_steps(0, 1, args.steps, [d.ptr for d in d_x], [d.ptr for d in d_J], state["i"] % ncopy, state["tr"], lam_s)
+        barrier()
+        sticky_ms = (time.perf_counter() - tq0) / args.steps * 1e3
+        assert rs["lam"] == lam_s and abs(rs["n2s"] - res[4]) <= 1e-9 * abs(res[4])
+        sticky = {"ms_per_step": sticky_ms, "steps_per_s": 1e3 / sticky_ms, "lambda": lam_s,
+                  "what": "the same step started at the lambda the first step ended with (the reference's sticky lambda): one factorisation a step; "
+                          "`value` starts every step at lambda0 and pays the failed attempt again"}
     # the same step with K1 and K4 as two passes over J (how rounds 1-2 reported `value`)
     sep_ms = None
     if one_pass and not logical:
@@ -395,6 +411,7 @@ def main():
                                            "ms_per_step: inside a run of rejections (nothing enqueued ahead); first_retry...: the retry right behind an accepted "
                                            "step, whose trial point's leaf-level factorisation had been enqueued ahead and is abandoned"}
                                   if retry_ms else None),
+            "sticky_lambda_step": sticky,
             "separate_passes": ({"ms_per_step": sep_ms, "steps_per_s": 1e3 / sep_ms,
                                  "what": "same step with Jt*x (K1) and the JtJ assembly (K4) as two passes over J: `value` of rounds 1-2"}
                                 if sep_ms else None),

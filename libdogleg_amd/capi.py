@@ -11,7 +11,7 @@ from .ctypes_defs import (Parameters2, CholmodSparse, Trace, TraceBuffer,
                           CB_SPARSE, CB_DENSE, CB_PRODUCTS, dptr, iptr)
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libdogleg_amd.so")
+LIB_PATH = os.environ.get("DLG_TEST_LIB") or os.path.join(HERE, "libdogleg_amd.so")      # (DLG_TEST_LIB: tools only -- the test suite against a variant build, tools/variant_lib.sh)
 
 DLG_OK = 0
 DLG_DENSE, DLG_SPARSE, DLG_DENSE_PRODUCTS = 0, 1, 2

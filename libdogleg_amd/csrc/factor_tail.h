@@ -16,11 +16,11 @@ __device__ __forceinline__ int tri_col(int j, int mb) { return j*mb - j*(j - 1)/
 // NCH consecutive lower 16x16 tiles (column-major tile order, first tile `first`) of
 // U = B B' (B = the mb rows below the diagonal block of the LDS panel Pb, w columns), one
 // accumulator chain per tile, every chain with its own operands (the tiles may span two tile
-// columns).  Rows / columns past the end are clamped (their results are never written); two
-// k-steps per iteration with their own operand registers, so the loads of one are in flight
-// during the products of the other.  mode 2: the multifrontal region keeps W = (children) - U;
+// columns).  Rows / columns past the end are clamped (their results are never written);
+// KD k-steps with their own operand registers, so the loads of the next ones are in flight
+// during the products of one.  mode 2: the multifrontal region keeps W = (children) - U;
 // mode 3 (leaf fronts): U - (what Ud holds).
-template <int NCH>
+template <int NCH, int KD = 4>
 __device__ __forceinline__ void factor_tail_tiles(const double* Pb, int ldp, int w, int mb, int T, int first,
                                                   double* Ud, int mode, bool w_hbm, bool mf_acc, int lane,
                                                   int64_t acc_shift, bool st_wt, int usp, double* Pgap, int ush)
@@ -61,45 +61,44 @@ __device__ __forceinline__ void factor_tail_tiles(const double* Pb, int ldp, int
   }
   const int w4 = w & ~3;
   const int st = 4*ldp;
-  double a0[NCH], a1[NCH], b0[NCH], b1[NCH];
+  // Whole k-steps, four of them in flight: a wave has one to six accumulator chains and a tile's k-loop is 15 - 17 steps --
+  // with the operands of only the next step on their way (rounds 1 - 4) every step waited out most of an LDS round trip
+  // (~200 clocks at this occupancy against ~80 for the product): 3 - 4 us of a level of the one-launch region for what is
+  // 1.3 us of products.  Same products in the same order: the same bits.
+  // (KD = 2 for the lean leaf instantiation of k_factor_level: 128 registers, four workgroups a CU)
+  const int nk = w4 >> 2;
+  double a[KD][NCH], b[KD][NCH];
 #pragma unroll
-  for(int q = 0; q < NCH; q++) { a0[q] = 0.0; b0[q] = 0.0; }
-  int kk = 0, ko = 0;                      // ko: element offset of k-step kk
-  if(w4 >= 4)
+  for(int u = 0; u < KD; u++)
   {
+    const int ku = min(u, max(nk - 1, 0))*st;
 #pragma unroll
-    for(int q = 0; q < NCH; q++) { a0[q] = Pb[oa[q]]; b0[q] = Pb[ob[q]]; }
+    for(int q = 0; q < NCH; q++) { a[u][q] = (nk > 0) ? Pb[oa[q] + ku] : 0.0; b[u][q] = (nk > 0) ? Pb[ob[q] + ku] : 0.0; }
   }
-  for(; kk + 8 <= w4; kk += 8)
+  int ks = 0;
+  for(; ks + KD <= nk; ks += KD)
   {
 #pragma unroll
-    for(int q = 0; q < NCH; q++) { a1[q] = Pb[oa[q] + ko + st]; b1[q] = Pb[ob[q] + ko + st]; }
-    __builtin_amdgcn_sched_barrier(0);
+    for(int u = 0; u < KD; u++)
+    {
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for(int q = 0; q < NCH; q++) c4[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[q], b0[q], c4[q], 0, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    ko += 2*st;
-    // the k-step after next (clamped to the last whole one: a harmless re-read at the end)
-    const int kn = (kk + 12 <= w4) ? ko : ko - 2*st;
+      for(int q = 0; q < NCH; q++) c4[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u][q], b[u][q], c4[q], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      // the step KD ahead takes this one's registers (clamped to the last whole one: a harmless re-read at the end)
+      const int kn = min(ks + KD + u, nk - 1)*st;
 #pragma unroll
-    for(int q = 0; q < NCH; q++) { a0[q] = Pb[oa[q] + kn]; b0[q] = Pb[ob[q] + kn]; }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for(int q = 0; q < NCH; q++) c4[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[q], b1[q], c4[q], 0, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
+      for(int q = 0; q < NCH; q++) { a[u][q] = Pb[oa[q] + kn]; b[u][q] = Pb[ob[q] + kn]; }
+    }
   }
-  if(kk + 4 <= w4)
-  {
-    // odd number of whole k-steps: the last one
-    if(kk > 0)
+#pragma unroll
+  for(int u = 0; u < KD; u++)
+    if(ks + u < nk)
     {
 #pragma unroll
-      for(int q = 0; q < NCH; q++) { a0[q] = Pb[oa[q] + ko]; b0[q] = Pb[ob[q] + ko]; }
+      for(int q = 0; q < NCH; q++) c4[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u][q], b[u][q], c4[q], 0, 0, 0);
     }
-#pragma unroll
-    for(int q = 0; q < NCH; q++) c4[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[q], b0[q], c4[q], 0, 0, 0);
-    kk += 4; ko += st;
-  }
+  const int kk = w4, ko = nk*st;
   if(kk < w)
   {
     // the last, partial k-step: columns past the end contribute zeros

@@ -462,11 +462,154 @@ __device__ __forceinline__ double pf_rsqrt3(double d)
   const double q = __builtin_fma(0.375, e, 0.5)*e;
   return __builtin_fma(y, q, y);
 }
+// A panel whose width is a few columns past a multiple of 16 (the 66-column separators of config #4: 4 x 16 + 2) used to
+// pay a whole block step for those columns -- every row tile brought up to date against all columns before them on the
+// matrix cores (16 products a tile for 2 of 16 columns), the next diagonal tile handed to wave 0 and back: 5.6 us of a
+// 17.5 us sweep (profiles/r05_top_of_tree_levels.txt, 193 x 66 against 187 x 60).  They are finished on the vector pipe
+// instead, by ALL threads, behind the sweep over the whole blocks (which treats their rows as rows below): thread =
+// panel row, one pass over the row's finished entries -- own entry (consecutive lanes, consecutive addresses) times the
+// pivot rows' entries (one 16-byte broadcast read for two of them) --, the little diagonal block factored by every
+// thread from the pivot rows' sums (LDS, one barrier), then the row's own solve.  Columns finished that way:
+constexpr int PF_VFIN_MAX = 4;
+constexpr int PF_VFIN_SCR = 2*16*PF_B16_WS + 2*4*64;       // doubles of pf_b16_lds the finish may use (W, A, E: free behind the sweep)
+// The waves share the pass two ways: a wave = (group of 64 rows, slice of the finished columns) -- 193 x 66: three groups x
+// two slices --, every thread with two accumulator chains a column; the slices' partial sums meet in LDS (slice 0 adds
+// them in slice order: the bits do not depend on who was first).  With one wave per row group and one chain the pass was a
+// chain of 64 dependent multiply-adds behind their loads (5000 - 6600 clocks, tools/micro/bench_panel).
+template <int NT, int NF>
+__device__ __forceinline__ void pf_b16_vector_finish(double* P, int ldp, int nrows, int wm, int tid, double* scr,
+                                                     int* __restrict__ info, int col0)
+{
+  // (the caller's barrier is behind us: every entry left of column wm is final; at most 512 rows: PF_B16_MAXT)
+  constexpr int NWV = NT/64;
+  constexpr int NFP = (NF <= 2) ? 2 : 4;                        // accumulators kept per row (16-byte reads of the pivot rows)
+  const int lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nlive = nrows - wm, G = (nlive + 63) >> 6;          // row groups (G <= NWV: the caller's condition)
+  // slices of the columns: 1, 2 or 4 (shifts and compares only: an integer division costs more than a slice saves here)
+  int ls = 0;
+#ifndef DLG_VFIN_NOSLICE
+  while(ls < 2 && (G << (ls + 1)) <= NWV && ((2 << ls) - 1)*G*64*NFP <= PF_VFIN_SCR - 4*NF*NF && (wm >> (ls + 1)) >= 8) ls++;
+#endif
+  const int S = 1 << ls;
+  double* pivs = scr;                                           // [4][NF][NF]: the pivot rows' partial sums, slice by slice
+  double* part = scr + 4*NF*NF;                                 // [S - 1][G*64][NFP]
+  int g = wv, sl = 0;
+  while(g >= G) { g -= G; sl++; }
+  const bool in_pass = sl < S;
+  const int i = wm + 64*g + lane;
+  const bool live = i < nrows;
+  double acc[NFP];
+#pragma unroll
+  for(int c = 0; c < NFP; c++) acc[c] = 0.0;
+  if(in_pass)
+  {
+    const int ic = live ? i : nrows - 1;
+    const int k0 = sl*(wm >> ls), k1 = k0 + (wm >> ls);
+    const double* own = P + ic;
+    const double* piv = P + wm;                  // rows wm .. wm + NF - 1 (wm is a multiple of 16, ldp even: 16-byte aligned pairs)
+    double a0[NFP], a1[NFP];
+#pragma unroll
+    for(int c = 0; c < NFP; c++) { a0[c] = (sl == 0 && c < NF) ? P[ic + (wm + (c < NF ? c : 0))*ldp] : 0.0; a1[c] = 0.0; }
+#pragma unroll 8
+    for(int k = k0; k < k1; k += 2)
+    {
+      const double x0 = own[k*ldp], x1 = own[(k + 1)*ldp];
+#pragma unroll
+      for(int c = 0; c < NFP; c += 2)
+      {
+        const double2 b0 = *reinterpret_cast<const double2*>(piv + k*ldp + c), b1 = *reinterpret_cast<const double2*>(piv + (k + 1)*ldp + c);
+        a0[c] = __builtin_fma(-x0, b0.x, a0[c]); a0[c + 1] = __builtin_fma(-x0, b0.y, a0[c + 1]);
+        a1[c] = __builtin_fma(-x1, b1.x, a1[c]); a1[c + 1] = __builtin_fma(-x1, b1.y, a1[c + 1]);
+      }
+    }
+#pragma unroll
+    for(int c = 0; c < NFP; c++) acc[c] = a0[c] + a1[c];
+    if(sl > 0)
+    {
+#pragma unroll
+      for(int c = 0; c < NFP; c++) part[((sl - 1)*G*64 + g*64 + lane)*NFP + c] = acc[c];
+    }
+    // the pivot rows' sums, slice by slice: row wm + r holds the r-th row of the little diagonal block (its lower triangle counts)
+    if(g == 0 && lane < NF)
+    {
+#pragma unroll
+      for(int c = 0; c < NF; c++) pivs[(sl*NF + lane)*NF + c] = acc[c];
+    }
+  }
+  DLG_PF_STAMP(6);
+  __syncthreads();
+  DLG_PF_STAMP(7);
+  if(in_pass && sl == 0)
+  {
+    // the other slices' shares, in slice order -- for the thread's own row and for the pivot rows (every thread forms
+    // the little block's sums itself: the same additions in the same order as the pivot rows' own threads)
+    double d[NF][NF];
+#pragma unroll
+    for(int r = 0; r < NF; r++)
+#pragma unroll
+      for(int c = 0; c < NF; c++) d[r][c] = (c <= r) ? pivs[r*NF + c] : 0.0;
+#pragma unroll
+    for(int q = 1; q < 4; q++)
+      if(q < S)
+      {
+#pragma unroll
+        for(int c = 0; c < NFP; c++) acc[c] += part[((q - 1)*G*64 + g*64 + lane)*NFP + c];
+#pragma unroll
+        for(int r = 0; r < NF; r++)
+#pragma unroll
+          for(int c = 0; c < NF; c++) if(c <= r) d[r][c] += pivs[(q*NF + r)*NF + c];
+      }
+    DLG_PF_STAMP(8);
+    // every thread of slice 0 factors the little block itself (at most four reciprocal square roots in a row) ...
+    double inv[NF];
+    int bad = 0x7fffffff;
+#pragma unroll
+    for(int c = 0; c < NF; c++)
+    {
+      double dd = d[c][c];
+#pragma unroll
+      for(int q = 0; q < c; q++) dd = __builtin_fma(-d[c][q], d[c][q], dd);
+      if(!(dd > 0.0)) { bad = min(bad, wm + c); dd = 1.0; }
+      inv[c] = pf_rsqrt3(dd);
+#pragma unroll
+      for(int r = c + 1; r < NF; r++)
+      {
+        double v = d[r][c];
+#pragma unroll
+        for(int q = 0; q < c; q++) v = __builtin_fma(-d[r][q], d[c][q], v);
+        d[r][c] = v*inv[c];
+      }
+    }
+    DLG_PF_STAMP(9);
+    // ... and solves its own row against it (a pivot row: its entries up to the diagonal, which is 1 / inv)
+    double x[NF];
+#pragma unroll
+    for(int c = 0; c < NF; c++)
+    {
+      double v = acc[c];
+#pragma unroll
+      for(int q = 0; q < c; q++) v = __builtin_fma(-x[q], d[c][q], v);
+      x[c] = v*inv[c];
+      if(live && i >= wm + c) P[i + (wm + c)*ldp] = x[c];          // (never above the diagonal: part of an update matrix may live there)
+    }
+    if(tid == 0 && bad != 0x7fffffff) atomicMin(info, col0 + bad);
+    DLG_PF_STAMP(10);
+  }
+  __syncthreads();
+  DLG_PF_STAMP(11);
+}
 template <int NT>
-__device__ __forceinline__ void panel_factor_b16(double* P, int ldp, int nrows, int w, int tid,
+__device__ __forceinline__ void panel_factor_b16(double* P, int ldp, int nrows, int w_all, int tid,
                                                  int* __restrict__ info, int col0)
 {
   static_assert(NT >= 256, "panel_factor_b16 needs at least 4 waves");
+  // (a short last block goes to the vector pipe: the sweep below sees a panel of w columns whose other columns' rows are rows below)
+#ifdef DLG_PF_NO_VFIN
+  const int nfin = 0;
+#else
+  const int nfin = ((w_all & 15) != 0 && (w_all & 15) <= PF_VFIN_MAX && w_all > 16 && (nrows - (w_all & ~15) + 63)/64 <= NT/64) ? (w_all & 15) : 0;
+#endif
+  const int w = w_all - nfin;
   // (with 8 waves, wave 4 shares its SIMD with wave 0: an fp64 MFMA holds the SIMD for its 64 clocks, so that wave
   // takes no tiles -- wave 0's chain has SIMD 0 to itself)
   constexpr int NW = NT/64, NH = (NW == 8) ? 6 : NW - 1;
@@ -668,6 +811,15 @@ __device__ __forceinline__ void panel_factor_b16(double* P, int ldp, int nrows, 
     }
   }
   __syncthreads();
+  DLG_PF_STAMP(5);
+  switch(nfin)
+  {
+    case 1: pf_b16_vector_finish<NT, 1>(P, ldp, nrows, w, tid, &S.W[0][0], info, col0); break;
+    case 2: pf_b16_vector_finish<NT, 2>(P, ldp, nrows, w, tid, &S.W[0][0], info, col0); break;
+    case 3: pf_b16_vector_finish<NT, 3>(P, ldp, nrows, w, tid, &S.W[0][0], info, col0); break;
+    case 4: pf_b16_vector_finish<NT, 4>(P, ldp, nrows, w, tid, &S.W[0][0], info, col0); break;
+    default: break;
+  }
   DLG_PF_DONE
 }
 template <int NT, bool ALIGNED16, bool MFMA_SWEEP = false>

@@ -160,49 +160,88 @@ __device__ __forceinline__ void mf_add_two_pipelined(double* P, double* Wt, int 
         if(++spins > ho.spins) { atomicOr(ho.status, DLG_HANDOFF_FACTOR); break; }
       }
     } };
+  auto load_child = [&](const double* W, int np, double (&x)[H], double (&y)[H]) {
+#pragma unroll
+    for(int u = 0; u < H; u++) x[u] = (u*NT < np) ? __hip_atomic_load((gptr_t)(W + u*NT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+#pragma unroll
+    for(int u = 0; u < H; u++) y[u] = ((H + u)*NT < np) ? __hip_atomic_load((gptr_t)(W + (H + u)*NT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+  };
+  auto add_half = [&](const unsigned* d, int np, int u0, const double (&v)[H]) {
+    double old[H];
+#pragma unroll
+    for(int u = 0; u < H; u++) old[u] = P[d[u0 + u]];
+#pragma unroll
+    for(int u = 0; u < H; u++) if((u0 + u)*NT < np) P[d[u0 + u]] = old[u] + v[u];
+  };
   // destinations of both children: static data, on their way before any wait
   unsigned dA[2*H], dB[2*H];
 #pragma unroll
   for(int u = 0; u < 2*H; u++) { dA[u] = (u*NT < npA) ? DA[u*NT] : 0u; dB[u] = (u*NT < npB) ? DB[u*NT] : 0u; }
-  wait_flags(ciA, cnA);
+  // Wave 0 waits for the first child and looks at the second child's flags in the same loads (lanes 8 ..): where BOTH are
+  // up when the first one is -- or one more look later: the children of a balanced tree finish together, and since the
+  // short last blocks of the 66-column separators went to the vector pipe that is the rule at the top of config #4 --
+  // all entries of both update matrices are fetched in ONE round of loads; one behind the other they are two round trips
+  // (8 - 9 us from the last flag to "children added" at the root, profiles/r05_top_of_tree_levels.txt).  The sums keep
+  // their order either way: first child, barrier, second child.
+  __shared__ int s_both;
+  if(tid < 64)
+  {
+    int spins = 0;
+    const bool la = tid < cnA, lb = tid >= 8 && tid < 8 + cnB;
+    bool ball = false;
+    for(;;)
+    {
+      const int va = la ? __hip_atomic_load(pr_flag + ciA + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : want;
+      const int vb = lb ? __hip_atomic_load(pr_flag + ciB + (tid - 8), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : want;
+      ball = __all(vb == want);
+      if(__all(va == want)) break;
+      __builtin_amdgcn_s_sleep(1);
+      if(++spins > ho.spins) { if(tid == 0) atomicOr(ho.status, DLG_HANDOFF_FACTOR); ball = false; break; }
+    }
+#ifndef DLG_ADD_NO_GRACE
+    if(!ball && cnB > 0 && spins <= ho.spins)
+    {
+      // (one more look: a second child a few hundred nanoseconds behind the first is worth that wait -- it saves a round trip)
+      const int vb = lb ? __hip_atomic_load(pr_flag + ciB + (tid - 8), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : want;
+      ball = __all(vb == want);
+    }
+#endif
+#ifdef DLG_ADD_NO_BOTH
+    ball = false;
+#endif
+    if(tid == 0) s_both = (ball && cnB > 0) ? 1 : 0;
+  }
   __syncthreads();                         // (also: Wt is zero everywhere)
   FL_ADD_STAMP(0);
-  double vX[H], vY[H];
-#pragma unroll
-  for(int u = 0; u < H; u++) { vX[u] = (u*NT < npA) ? __hip_atomic_load((gptr_t)(WA + u*NT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0; }
-#pragma unroll
-  for(int u = 0; u < H; u++) { vY[u] = ((H + u)*NT < npA) ? __hip_atomic_load((gptr_t)(WA + (H + u)*NT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0; }
-  // first child, first half (its values are the first to arrive: ~2 us after the flag)
+  double vX[H], vY[H], bX[H], bY[H];
+  if(s_both)
   {
-    double old[H];
-#pragma unroll
-    for(int u = 0; u < H; u++) old[u] = P[dA[u]];
-#pragma unroll
-    for(int u = 0; u < H; u++) if(u*NT < npA) P[dA[u]] = old[u] + vX[u];
+    load_child(WA, npA, vX, vY);
+    load_child(WB, npB, bX, bY);
+    add_half(dA, npA, 0, vX); add_half(dA, npA, H, vY);
+    __syncthreads();                       // the first child is in, in every thread's entries
+    FL_ADD_STAMP(1);
+    FL_ADD_STAMP(2);
+#ifdef DLG_FL_PROFILE
+    if(threadIdx.x == 0 && blockIdx.x < FL_PROF_WG) g_fl_add[blockIdx.x*4 + 3] = 2000 + 10*cnB;
+#endif
+    add_half(dB, npB, 0, bX); add_half(dB, npB, H, bY);
+    __syncthreads();
+    return;
   }
-  // this thread's own look at the second child's flags, as late as it is of use (cn <= 8 of them; a child
-  // outside the launch is there)
+  // The second child is still at work: the first child's entries, and behind their first half every thread's own look at
+  // the second child's flags -- if they are up (a thread's own finding: its loads come after its own look at the flags,
+  // nobody else's), its half of that child's entries is fetched while it adds the first child's second half.
+  load_child(WA, npA, vX, vY);
+  add_half(dA, npA, 0, vX);
   int fl[8];
 #pragma unroll
   for(int q = 0; q < 8; q++) fl[q] = (q < cnB) ? __hip_atomic_load(pr_flag + ciB + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : want;
-  // first child, second half
-  {
-    double old[H];
-#pragma unroll
-    for(int u = 0; u < H; u++) old[u] = P[dA[H + u]];
-#pragma unroll
-    for(int u = 0; u < H; u++) if((H + u)*NT < npA) P[dA[H + u]] = old[u] + vY[u];
-  }
+  add_half(dA, npA, H, vY);
   bool bup = true;
 #pragma unroll
   for(int q = 0; q < 8; q++) bup = bup && fl[q] == want;
-  if(bup)
-  {
-#pragma unroll
-    for(int u = 0; u < H; u++) vX[u] = (u*NT < npB) ? __hip_atomic_load((gptr_t)(WB + u*NT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
-#pragma unroll
-    for(int u = 0; u < H; u++) vY[u] = ((H + u)*NT < npB) ? __hip_atomic_load((gptr_t)(WB + (H + u)*NT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
-  }
+  if(bup) load_child(WB, npB, bX, bY);
   __syncthreads();                         // the first child is in, in every thread's entries
   FL_ADD_STAMP(1);
 #ifdef DLG_FL_PROFILE
@@ -211,24 +250,8 @@ __device__ __forceinline__ void mf_add_two_pipelined(double* P, double* Wt, int 
   if(!bup) wait_flags(ciB, cnB);           // (a polling lane that saw them up itself has nothing to wait for)
   __syncthreads();
   FL_ADD_STAMP(2);
-  if(!bup)
-  {
-#pragma unroll
-    for(int u = 0; u < H; u++) vX[u] = (u*NT < npB) ? __hip_atomic_load((gptr_t)(WB + u*NT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
-#pragma unroll
-    for(int u = 0; u < H; u++) vY[u] = ((H + u)*NT < npB) ? __hip_atomic_load((gptr_t)(WB + (H + u)*NT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
-  }
-  {
-    double old[H];
-#pragma unroll
-    for(int u = 0; u < H; u++) old[u] = P[dB[u]];
-#pragma unroll
-    for(int u = 0; u < H; u++) if(u*NT < npB) P[dB[u]] = old[u] + vX[u];
-#pragma unroll
-    for(int u = 0; u < H; u++) old[u] = P[dB[H + u]];
-#pragma unroll
-    for(int u = 0; u < H; u++) if((H + u)*NT < npB) P[dB[H + u]] = old[u] + vY[u];
-  }
+  if(!bup) load_child(WB, npB, bX, bY);
+  add_half(dB, npB, 0, bX); add_half(dB, npB, H, bY);
   __syncthreads();
 }
 
@@ -392,6 +415,7 @@ __global__ void __launch_bounds__(NT, LEAF ? 4 : 1) k_factor_level(const FwItem*
     double* Ud = u_lds ? Us : Ug;              // in place behind the panel (+ ush), or straight to the scratch
     constexpr int NWV = NT/64;
     constexpr int SY_G = (NT >= 512) ? 6 : 4;
+    constexpr int TKD = LEAF ? 2 : 4;          // k-steps of operands in flight (factor_tail.h; the leaf instantiation has 128 registers)
     // (a replica of the one-launch region forms the tile columns [tj0, tj1) only: tiles [tlo, thi) in
     // column-major tile order; every tile has its own accumulator chain, so who forms it changes no bit)
     const int tjA = min(it.tj0, T), tjB = min(it.tj1, T);
@@ -408,12 +432,12 @@ __global__ void __launch_bounds__(NT, LEAF ? 4 : 1) k_factor_level(const FwItem*
       const int t0 = tlo + (int)((unsigned)(c*ntiles)/(unsigned)nchunks), t1 = tlo + (int)((unsigned)((c + 1)*ntiles)/(unsigned)nchunks);
       switch(t1 - t0)
       {
-        case 1: factor_tail_tiles<1>(Pb, ldp, w, mb, T, t0, Ud, mode, w_hbm, mf_acc, lane, acc_shift, st_wt, usp, P, ush_t); break;
-        case 2: factor_tail_tiles<2>(Pb, ldp, w, mb, T, t0, Ud, mode, w_hbm, mf_acc, lane, acc_shift, st_wt, usp, P, ush_t); break;
-        case 3: factor_tail_tiles<3>(Pb, ldp, w, mb, T, t0, Ud, mode, w_hbm, mf_acc, lane, acc_shift, st_wt, usp, P, ush_t); break;
-        case 4: factor_tail_tiles<4>(Pb, ldp, w, mb, T, t0, Ud, mode, w_hbm, mf_acc, lane, acc_shift, st_wt, usp, P, ush_t); break;
-        case 5: if(SY_G >= 5) factor_tail_tiles<(SY_G >= 5 ? 5 : 1)>(Pb, ldp, w, mb, T, t0, Ud, mode, w_hbm, mf_acc, lane, acc_shift, st_wt, usp, P, ush_t); break;
-        case 6: if(SY_G >= 6) factor_tail_tiles<(SY_G >= 6 ? 6 : 1)>(Pb, ldp, w, mb, T, t0, Ud, mode, w_hbm, mf_acc, lane, acc_shift, st_wt, usp, P, ush_t); break;
+        case 1: factor_tail_tiles<1, TKD>(Pb, ldp, w, mb, T, t0, Ud, mode, w_hbm, mf_acc, lane, acc_shift, st_wt, usp, P, ush_t); break;
+        case 2: factor_tail_tiles<2, TKD>(Pb, ldp, w, mb, T, t0, Ud, mode, w_hbm, mf_acc, lane, acc_shift, st_wt, usp, P, ush_t); break;
+        case 3: factor_tail_tiles<3, TKD>(Pb, ldp, w, mb, T, t0, Ud, mode, w_hbm, mf_acc, lane, acc_shift, st_wt, usp, P, ush_t); break;
+        case 4: factor_tail_tiles<4, TKD>(Pb, ldp, w, mb, T, t0, Ud, mode, w_hbm, mf_acc, lane, acc_shift, st_wt, usp, P, ush_t); break;
+        case 5: if(SY_G >= 5) factor_tail_tiles<(SY_G >= 5 ? 5 : 1), TKD>(Pb, ldp, w, mb, T, t0, Ud, mode, w_hbm, mf_acc, lane, acc_shift, st_wt, usp, P, ush_t); break;
+        case 6: if(SY_G >= 6) factor_tail_tiles<(SY_G >= 6 ? 6 : 1), TKD>(Pb, ldp, w, mb, T, t0, Ud, mode, w_hbm, mf_acc, lane, acc_shift, st_wt, usp, P, ush_t); break;
         default: break;
       }
     }
@@ -1245,9 +1269,30 @@ int sparse_factor_setup(dlg_backend* b, bool plan_only)
       rec = H.mf_rec; dst = H.mf_dst;
       auto lin = [](long j, long mb) { return j*mb - j*(j - 1)/2; };       // packed index of (j, j)
       long lds_need = lds;
+      // Workgroups are dispatched in index order and a level holds more of them than CUs are free when its turn comes
+      // (config #4: 230 + 134 + 128 + ... on 256 CUs): the ones that find a CU late should be the ones with slack.  A
+      // level's supernodes are listed by the estimated time their subtree is done, the latest first (a static estimate:
+      // columns swept in blocks of 16, rows, a constant for the children's sum and the hand-off) -- a parent whose
+      // children are the level's slowest is on its CU, panel staged, when they arrive.  Levels stay in order (a
+      // workgroup only waits for lower-numbered ones); no arithmetic depends on the order.
+      std::vector<double> est(H.fw_item.size(), 0.0);
+      std::vector<int> item_of_sn(H.nsn, -1);
+      const bool by_est = !getenv("DOGLEG_AMD_REGION_INDEX_ORDER");
+      for(int l = r_level0; l <= hi; l++)
+        for(int i = H.fw_lvl_ptr[l]; i < H.fw_lvl_ptr[l+1]; i++) item_of_sn[H.fw_sn[i]] = i;
       for(int l = r_level0; l <= hi; l++)
       {
         const int n = H.fw_lvl_ptr[l+1] - H.fw_lvl_ptr[l];
+        std::vector<int> order(n);
+        for(int k = 0; k < n; k++) order[k] = H.fw_lvl_ptr[l] + k;
+        for(int i : order)
+        {
+          const FwItem& fi = H.fw_item[i];
+          double e0 = 0.0;
+          for(int k = 0; k < fi.nch; k++) { const int ci = item_of_sn[H.mf_child[fi.ch0 + k]]; if(ci >= 0) e0 = std::max(e0, est[ci]); }
+          est[i] = e0 + 3.0*((fi.w + 15)/16) + 0.02*fi.nrows + 9.0;
+        }
+        if(by_est) std::stable_sort(order.begin(), order.end(), [&](int a, int b2) { return est[a] > est[b2]; });
         // (the first level of the region is its most populous one, and the Cauchy step's pass over J runs beside
         // it: replicas there cost more in CUs than they save -- only what does not fit LDS whole is sliced)
         const int rl = std::max(1, std::min(rmax, (l == r_level0 ? fill0 : fill)/std::max(n, 1)));
@@ -1256,7 +1301,7 @@ int sparse_factor_setup(dlg_backend* b, bool plan_only)
         const int l1_pct = (l == r_level0 && rl == 1) ? 70 : 0;
         long l1_max = 0; int l1_left = std::max(0, ncu - n);
         if(l1_pct > 0) for(int i = H.fw_lvl_ptr[l]; i < H.fw_lvl_ptr[l+1]; i++) l1_max = std::max(l1_max, (long)H.fw_item[i].nrows*H.fw_item[i].w);
-        for(int i = H.fw_lvl_ptr[l]; i < H.fw_lvl_ptr[l+1]; i++)
+        for(int i : order)
         {
           FwItem it = H.fw_item[i];
           const int mb = it.nrows - it.w, T = (mb + 15) >> 4;

@@ -368,3 +368,39 @@ def test_oracle_matches_the_independent_config4_fixture():
     assert abs(o8[1] - float.fromhex(g["norm2_cauchy"])) <= 1e-11 * o8[1]
     assert abs(o8[3] - float.fromhex(g["k"])) <= 1e-10
     assert abs(o8[5] - float.fromhex(g["expected_improvement"])) <= 1e-10 * abs(o8[5])
+
+
+def test_oracle_matches_the_independent_config5_fixture():
+    """BASELINE.json config #5 at FULL size (5M x 500 001, lambda = 1e-10, cond ~ 1e13): one oracle step against the
+    committed independent fixture (tests/golden/splu_config5_step.json, round 5: block elimination of the points +
+    SuperLU on the reduced system + iterative refinement with long-double residuals; every 64th entry) -- the oracle's
+    sparse Cholesky pinned at the 1e-10 bar on the ill-conditioned configuration too (about 40 s, 3 GB)."""
+    g = json.load(open(os.path.join(GOLD, "splu_config5_step.json")))
+    a = g["problem"]
+    prob = oa.BAProblem(a["Nc"], a["Np"], a["Nobs"], seed=a["seed"], scale_decades=a["scale_decades"], n_zero_cols=a["n_zero_cols"])
+    N, M = prob.N, prob.M
+    assert (N, M, prob.nnz) == (g["N"], g["M"], g["nnz"])
+    Jp, Ji = prob.pattern()
+    p = prob.p0()
+    x, Jx = prob.eval(p)
+    O = oa.oracle()
+    lam = float.fromhex(g["lambda"])
+    F = O.orc_sparse_analyze(N, M, iptr(Jp), iptr(Ji))
+    # (the factorisation at lambda = 0 breaks down on the exactly-zero columns, dogleg.c:667: that is why the step is at 1e-10)
+    assert O.orc_sparse_factorize(F, iptr(Jp), iptr(Ji), dptr(Jx), 0.0) != N
+    work, o8 = np.zeros(5 * N), np.zeros(8)
+    assert O.orc_step_sparse(F, N, M, iptr(Jp), iptr(Ji), dptr(Jx), dptr(x), dptr(p), lam, dptr(work), dptr(o8)) == 0
+    O.orc_sparse_free(F)
+    gn, step = work[2 * N:3 * N], work[3 * N:4 * N]
+    st = g["stride"]
+    unhex = lambda lst: np.array([float.fromhex(v) for v in lst])
+    dgn = np.linalg.norm(gn[::st] - unhex(g["gn_hex"]))
+    dst = np.linalg.norm(step[::st] - unhex(g["step_hex"]))
+    print(f"config #5 oracle vs the independent fixture (every {st}th entry): |gn diff| = {dgn:.2e}, |step diff| = {dst:.2e}")
+    assert dgn <= 1e-10 and dst <= 1e-10
+    assert abs(float(gn @ gn) - float.fromhex(g["norm2_gn"])) <= 1e-11 * float(gn @ gn)
+    assert abs(float(step @ step) - float.fromhex(g["norm2_step"])) <= 1e-11 * float(step @ step)
+    assert abs(o8[0] - float.fromhex(g["norm2_x"])) <= 1e-12 * o8[0]
+    assert abs(o8[1] - float.fromhex(g["norm2_cauchy"])) <= 1e-11 * o8[1]
+    assert abs(o8[3] - float.fromhex(g["k"])) <= 1e-10
+    assert abs(o8[5] - float.fromhex(g["expected_improvement"])) <= 1e-10 * abs(o8[5])

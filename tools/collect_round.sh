@@ -7,7 +7,7 @@ tag=${1:-r01}; out=gpurun_out/$tag; mkdir -p $out
 for wl in sparse-1m sparse-200k dense-50k; do
   timeout 600 python3 bench.py --workload $wl > $out/bench_$wl.json 2> $out/bench_$wl.err
 done
-timeout 600 python3 bench.py --workload sparse-5m --steps 5 --warmup 2 --no-cpu-baseline > $out/bench_sparse-5m.json 2> $out/bench_sparse-5m.err
+timeout 900 python3 bench.py --workload sparse-5m --steps 5 --warmup 2 --cpu-seconds 5 > $out/bench_sparse-5m.json 2> $out/bench_sparse-5m.err
 for wl in sparse-1m dense-50k; do
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_$wl -o p -- python3 bench.py --workload $wl --no-cpu-baseline > $out/stats_$wl.log 2>&1
 done

@@ -7,11 +7,11 @@
 #include <cmath>
 // phase stamps: thread 0 accumulates clock deltas in LDS, publishes them at the end
 __device__ long long* g_pf_out = nullptr;
-__shared__ long long s_pf[8];
-#define DLG_PF_DECL if(threadIdx.x == 0) { for(int _i = 0; _i < 7; _i++) s_pf[_i] = 0; s_pf[7] = clock64(); }
-#define DLG_PF_STAMP(i) do { if(threadIdx.x == 0) { const long long _n = clock64(); s_pf[i] += _n - s_pf[7]; s_pf[7] = _n; } } while(0)
+__shared__ long long s_pf[16];
+#define DLG_PF_DECL if(threadIdx.x == 0) { for(int _i = 0; _i < 15; _i++) s_pf[_i] = 0; s_pf[15] = clock64(); }
+#define DLG_PF_STAMP(i) do { if(threadIdx.x == 0) { const long long _n = clock64(); s_pf[i] += _n - s_pf[15]; s_pf[15] = _n; } } while(0)
 #define DLG_PF_PIN(x) asm volatile("" :: "v"(x))
-#define DLG_PF_DONE if(threadIdx.x == 0 && g_pf_out) { for(int _i = 0; _i < 7; _i++) g_pf_out[_i] = s_pf[_i]; }
+#define DLG_PF_DONE if(threadIdx.x == 0 && g_pf_out) { for(int _i = 0; _i < 12; _i++) g_pf_out[_i] = s_pf[_i]; }
 __device__ long long g_evt[64*8];
 #define DLG_PF_EVT(J, e) do { if((threadIdx.x & 63) == 0 && blockIdx.x == 0) g_evt[(J)*8 + (e)] = clock64(); } while(0)
 #include "../../libdogleg_amd/csrc/panel_factor.h"
@@ -56,9 +56,9 @@ void run(int nrows, int w, int G, int iters)
   for(int b = 0; b < G; b++)
     for(int j = 0; j < w; j++)
       for(int i = 0; i < nrows; i++)
-        h[b*n + i + (size_t)j*nrows] = (i == j) ? (double)(w + 1) : ((i < w && i < j) ? 0.0 : 0.3*sin(0.37*i + 1.3*j));
+        h[b*n + i + (size_t)j*nrows] = (i == j) ? (double)(w + 1) : ((i < w && i < j) ? (getenv("DLG_PF_UPPER_NAN") ? NAN : 0.0) : 0.3*sin(0.37*i + 1.3*j));
   double* d; int* info; long long* st;
-  hipMalloc(&d, n*G*8); hipMalloc(&info, 4); hipMalloc(&st, 128);
+  hipMalloc(&d, n*G*8); hipMalloc(&info, 4); hipMalloc(&st, 256);
   const int lds = (int)(((nrows + 1) & ~1)*w*8);
   hipFuncSetAttribute(reinterpret_cast<const void*>(&k_panel<NT, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -115,6 +115,8 @@ void run(int nrows, int w, int G, int iters)
     hipMemcpy(d, h.data(), n*8, hipMemcpyHostToDevice);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_panel<NT, 5>), dim3(1), dim3(NT), lds, 0, d, nrows, w, info, st);
     hipMemcpy(r5.data(), d, n*8, hipMemcpyDeviceToHost);
+    long long ph2[16]; hipMemcpy(ph2, st, 128, hipMemcpyDeviceToHost);
+    printf("      vfin phases: pass %lld | barrier %lld | partials+pivot sums %lld | factor %lld | solve+store %lld | barrier %lld\n", ph2[4+6], ph2[4+7], ph2[4+8], ph2[4+9], ph2[4+10], ph2[4+11]);
     hipMemcpy(ph, st, 88, hipMemcpyDeviceToHost);
     double worst = 0, big = 0, up = 0; int wi = 0, wj = 0;
     for(int j = 0; j < w; j++) for(int i = 0; i < nrows; i++)
@@ -131,6 +133,7 @@ void run(int nrows, int w, int G, int iters)
         printf("        block %d: steps %lld .. %lld | next tile's wave: at the tile %+lld, diagonal rows seen %+lld, handed over %+lld | wave 0: hand-over seen %+lld, tile ready %+lld (all relative to the inverse being out)\n", J,
                ev[J*8] - ev[0], ev[J*8+1] - ev[0], ev[J*8+4] - ev[J*8+1], ev[J*8+5] - ev[J*8+1], ev[J*8+6] - ev[J*8+1], ev[J*8+2] - ev[J*8+1], ev[J*8+3] - ev[J*8+1]);
     }
+    printf("      B16 tail: to the end of the sweep %lld clocks\n", ph[9]);
     printf("      B16 %.1f us: wave 0: wait %lld steps %lld next tile %lld (of which waiting %lld) | scalar vs b16: max |diff| %.3g at (%d,%d) (max |L| %.3g), strict upper triangle touched by %.3g\n", bb*1e3/iters, ph[4], ph[5], ph[6], ph[7], worst, wi, wj, big, up);
   }
   {
@@ -161,7 +164,7 @@ void run_bd(int nrows, int w, int G, int iters)
   std::vector<int> mc(256); for(int m = 0; m < 256; m++) mc[m] = 3*m;
   hipMemcpyToSymbol(HIP_SYMBOL(g_mcol), mc.data(), 256*4);
   double* d; int* info; long long* st;
-  hipMalloc(&d, n*G*8); hipMalloc(&info, 4); hipMalloc(&st, 128);
+  hipMalloc(&d, n*G*8); hipMalloc(&info, 4); hipMalloc(&st, 256);
   const int lds = (int)(((nrows + 1) & ~1)*w*8);
   hipFuncSetAttribute(reinterpret_cast<const void*>(&k_panel<NT, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
