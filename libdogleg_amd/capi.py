@@ -219,17 +219,19 @@ def optimize(kind, p0, N, M, nnz, cb, cookie, params=None, capacity=256):
     return r, p, tr
 
 
-def optimize_device(p0, N, M, nnz, Jp, Ji, cb, cookie, params=None, capacity=256):
+def optimize_device(p0, N, M, nnz, Jp, Ji, cb, cookie, params=None, capacity=256, trace=True):
     """dogleg_optimize_device2 (device-side evaluation) with a per-trial trace.  nnz == 0: dense
-    (Jp, Ji ignored).  cb: address of a dogleg_callback_device_t.  Returns (norm2x, p_final, TraceBuffer)."""
+    (Jp, Ji ignored).  cb: address of a dogleg_callback_device_t.  Returns (norm2x, p_final, TraceBuffer).
+    trace=False: no per-trial record (every record downloads the step vector: a test feature that costs a
+    synchronisation a trial) -- what a user's call does; the third value is None then."""
     L = lib()
     p = np.array(p0, dtype=np.float64, copy=True)
-    tr = TraceBuffer(N, capacity)
+    tr = TraceBuffer(N, capacity) if trace else None
     prm = C.byref(params) if params is not None else None
     if nnz > 0:
         Jp = np.ascontiguousarray(Jp, dtype=np.int32)
         Ji = np.ascontiguousarray(Ji, dtype=np.int32)
-    L.dlg_set_trace(C.cast(tr.byref(), C.c_void_p))
+    L.dlg_set_trace(C.cast(tr.byref(), C.c_void_p) if trace else None)
     try:
         r = L.dogleg_optimize_device2(dptr(p), N, M, nnz, iptr(Jp) if nnz > 0 else None,
                                       iptr(Ji) if nnz > 0 else None, cb, cookie, prm, None)

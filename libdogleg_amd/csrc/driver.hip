@@ -96,6 +96,19 @@ struct Driver
   // device-side evaluation (dogleg_optimize_device2): the model runs on the GPU, x / J never cross PCIe
   dogleg_callback_device_t* f_device;
   const int *dev_cp, *dev_ri;                  // the caller's pattern (host), valid during the call
+  // DOGLEG_AMD_TIMING=1: where the wall time of run_optimizer goes (host clock around the driver's own calls)
+  bool timing;
+  double tm_ms[8]; int tm_n[8];
+};
+enum { TM_PATTERN, TM_CALLBACK, TM_UPLOAD, TM_EVAL, TM_STEP, TM_TRACE, TM_COUNT };
+const char* const k_tm_names[TM_COUNT] = { "pattern (symbolic phase or comparison with the parked one)", "model callback (host: evaluation; device: enqueue)",
+                                           "inputs to the backend (upload / bind / gather)", "dlg_point_eval (K1 [+ K4, leaf level ahead], norms fetched)",
+                                           "dlg_take_step / dlg_step (K3 .. K8, p_new fetched)", "trace / vnlog records (test harness, debug)" };
+struct Tick
+{
+  Driver* d; int k; std::chrono::steady_clock::time_point t0;
+  Tick(Driver* d_, int k_) : d(d_), k(k_) { if(d->timing) t0 = std::chrono::steady_clock::now(); }
+  ~Tick() { if(d->timing) { d->tm_ms[k] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); d->tm_n[k]++; } }
 };
 
 // ---- what outlives a solve (the reference allocates and frees everything per solve, dogleg.c:1479-1562,
@@ -237,6 +250,7 @@ void cur_reset(Driver* d)
 }
 void emit(Driver* d, int iteration, int accepted)
 {
+  Tick tt(d, TM_TRACE);
   d->cur.iteration = iteration;
   d->cur.accepted  = accepted;
   d->cur.lambda    = d->pub.lambda;
@@ -387,6 +401,7 @@ bool eval_point(bool* converged, dogleg_operatingPoint_t* pt, Driver* d)
     // values straight into the slot's HBM buffers, ordered on the backend's stream
     if(ctx->solve_type == DOGLEG_SPARSE && !d->pattern_set)
     {
+      Tick tk(d, TM_PATTERN);
       if(!set_pattern(d, d->dev_cp, d->dev_ri)) return false;
       d->pattern_set = true;
     }
@@ -404,27 +419,30 @@ bool eval_point(bool* converged, dogleg_operatingPoint_t* pt, Driver* d)
         d->J_full_dev = (double*)dlg_mem_alloc(sizeof(double)*(size_t)d->nnz);
         if(!d->x_full_dev || !d->J_full_dev) { MSG("out of device memory"); return false; }
       }
-      (*d->f_device)(p_dev, d->x_full_dev, d->J_full_dev, dlg_backend_get_stream(d->be), ctx->cookie);
+      { Tick tk(d, TM_CALLBACK); (*d->f_device)(p_dev, d->x_full_dev, d->J_full_dev, dlg_backend_get_stream(d->be), ctx->cookie); }
+      Tick tu(d, TM_UPLOAD);
       if(!be_ok(dlg_point_gather_device(d->be, s, d->x_full_dev, d->J_full_dev, d->dev_cp), "gather of the rank's rows")) return false;
     }
     else
     {
-      (*d->f_device)(p_dev, x_dev, J_dev, dlg_backend_get_stream(d->be), ctx->cookie);
+      { Tick tk(d, TM_CALLBACK); (*d->f_device)(p_dev, x_dev, J_dev, dlg_backend_get_stream(d->be), ctx->cookie); }
       // (dense on a rank: its rows are a contiguous slice of what the callback wrote)
       const size_t r0 = d->sharded ? (size_t)d->row0 : 0;
+      Tick tu(d, TM_UPLOAD);
       if(!be_ok(dlg_point_bind_device(d->be, s, x_dev + r0, J_dev + r0*(size_t)ctx->Nstate), "bind")) return false;
     }
     if(ctx->solve_type == DOGLEG_SPARSE) dlg_backend_set_speculation(d->be, d->expect_gn);
-    if(!be_ok(dlg_point_eval(d->be, s, &norm2x, &absmax), "Jt*x")) return false;
+    { Tick te(d, TM_EVAL); if(!be_ok(dlg_point_eval(d->be, s, &norm2x, &absmax), "Jt*x")) return false; }
     pt->norm2_x = norm2x;
     pt->have_x = pt->have_J = pt->have_Jtx = true;
   }
   else if(ctx->solve_type == DOGLEG_SPARSE)
   {
-    (*ctx->f)(pt->p, pt->x, pt->Jt, ctx->cookie);
+    { Tick tk(d, TM_CALLBACK); (*ctx->f)(pt->p, pt->x, pt->Jt, ctx->cookie); }
     const int* cp = (const int*)pt->Jt->p; const int* ri = (const int*)pt->Jt->i;
     if(!d->pattern_set)
     {
+      Tick tk(d, TM_PATTERN);
       if(!set_pattern(d, cp, ri)) return false;
       d->pattern_set = true;
       if(d->check_pattern)
@@ -454,31 +472,34 @@ bool eval_point(bool* converged, dogleg_operatingPoint_t* pt, Driver* d)
         memcpy(d->J_loc + q, Jv + cp[r], sizeof(double)*n);
         q += n;
       }
+      Tick tu(d, TM_UPLOAD);
       if(!be_ok(dlg_point_upload(d->be, s, d->x_loc, d->J_loc), "upload")) return false;
     }
     else
-    if(!be_ok(dlg_point_upload(d->be, s, pt->x, (const double*)pt->Jt->x), "upload")) return false;
+    { Tick tu(d, TM_UPLOAD); if(!be_ok(dlg_point_upload(d->be, s, pt->x, (const double*)pt->Jt->x), "upload")) return false; }
     // once steps need the Gauss-Newton step an accepted point is factorised next: its JtJ is assembled
     // beside Jt*x (an unused assembly -- a rejected point -- is simply dropped; no number changes)
     dlg_backend_set_speculation(d->be, d->expect_gn);
-    if(!be_ok(dlg_point_eval(d->be, s, &norm2x, &absmax), "Jt*x")) return false;
+    { Tick te(d, TM_EVAL); if(!be_ok(dlg_point_eval(d->be, s, &norm2x, &absmax), "Jt*x")) return false; }
     pt->norm2_x = norm2x;
     pt->have_x = pt->have_J = pt->have_Jtx = true;
   }
   else if(ctx->solve_type == DOGLEG_DENSE)
   {
-    (*ctx->f_dense)(pt->p, pt->x, pt->J_dense, ctx->cookie);
+    { Tick tk(d, TM_CALLBACK); (*ctx->f_dense)(pt->p, pt->x, pt->J_dense, ctx->cookie); }
     // (a rank of several: its contiguous rows of what the callback wrote)
     const size_t r0 = d->sharded ? (size_t)d->row0 : 0;
-    if(!be_ok(dlg_point_upload(d->be, s, pt->x + r0, pt->J_dense + r0*(size_t)ctx->Nstate), "upload")) return false;
+    { Tick tu(d, TM_UPLOAD); if(!be_ok(dlg_point_upload(d->be, s, pt->x + r0, pt->J_dense + r0*(size_t)ctx->Nstate), "upload")) return false; }
+    Tick te(d, TM_EVAL);
     if(!be_ok(dlg_point_eval(d->be, s, &norm2x, &absmax), "Jt*x")) return false;
     pt->norm2_x = norm2x;
     pt->have_x = pt->have_J = pt->have_Jtx = true;
   }
   else
   {
-    (*ctx->f_dense_products)(pt->p, &pt->norm2_x, pt->Jt_x, pt->JtJ, ctx->cookie);
-    if(!be_ok(dlg_point_upload_products(d->be, s, pt->norm2_x, pt->Jt_x, pt->JtJ), "upload")) return false;
+    { Tick tk(d, TM_CALLBACK); (*ctx->f_dense_products)(pt->p, &pt->norm2_x, pt->Jt_x, pt->JtJ, ctx->cookie); }
+    { Tick tu(d, TM_UPLOAD); if(!be_ok(dlg_point_upload_products(d->be, s, pt->norm2_x, pt->Jt_x, pt->JtJ), "upload")) return false; }
+    Tick te(d, TM_EVAL);
     if(!be_ok(dlg_point_eval(d->be, s, &norm2x, &absmax), "gradient norm")) return false;
     pt->have_Jtx = pt->have_JtJ = true;
   }
@@ -580,6 +601,7 @@ bool take_step(double* expectedImprovement, dogleg_operatingPoint_t* to,
                dogleg_operatingPoint_t* from, double trustregion, Driver* d)
 {
   dogleg_solverContext_t* ctx = &d->pub;
+  Tick tstep(d, TM_STEP);
   VERBOSE(d, "taking step with trustregion %.6g", trustregion);
   d->cur.trustregion_before = trustregion;
   d->cur.norm2x_before      = from->norm2_x;
@@ -958,6 +980,7 @@ double optimize(double* p, unsigned int Nstate, unsigned int Nmeas, unsigned int
   if(ctx->parameters->debug_vnlog) vnlog_legend();
   // DOGLEG_AMD_TIMING=1: wall time of the phases of a solve on stderr (where an end-to-end call spends its time)
   const bool timing = getenv("DOGLEG_AMD_TIMING") != nullptr;
+  d->timing = timing;
   const auto t_begin = std::chrono::steady_clock::now();
   auto t_last = t_begin;
   auto lap = [&](const char* what) {
@@ -1024,7 +1047,20 @@ double optimize(double* p, unsigned int Nstate, unsigned int Nmeas, unsigned int
   dlg_trace_t* tr = t_trace;
   if(tr) { tr->ntrials = 0; tr->ncallbacks = 0; tr->nstate = (int)Nstate; }
 
+  const auto t_run = std::chrono::steady_clock::now();
   const int numsteps = run_optimizer(d);
+  if(timing)
+  {
+    // where run_optimizer's wall time went: the driver's own calls, host clock (one line for all of it hid 6 ms)
+    const double run_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_run).count();
+    double acc = 0;
+    for(int k = 0; k < TM_COUNT; k++)
+    {
+      if(d->tm_n[k]) MSG("timing:   %-62s %8.3f ms in %2d calls (%7.3f ms each)", k_tm_names[k], d->tm_ms[k], d->tm_n[k], d->tm_ms[k]/d->tm_n[k]);
+      acc += d->tm_ms[k];
+    }
+    MSG("timing:   %-62s %8.3f ms", "host logic between them (trust region, bookkeeping)", run_ms - acc);
+  }
   lap("run_optimizer (incl. symbolic phase)");
   const double norm2_x = ctx->beforeStep->norm2_x;
   if(tr) tr->ncallbacks = d->ncallbacks;

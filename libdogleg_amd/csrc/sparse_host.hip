@@ -81,20 +81,23 @@ extern "C" int dlg_sparse_pattern_matches(dlg_backend_t* b, const int* colptr, c
 {
   if(!b || !b->sym || !colptr || !rowidx || b->sym->pat_key == 0) return 0;
   if(colptr[b->M] != b->nnz) return 0;
-  // (no hash here: the comparison itself is the cheaper pass over the 64 MB of config #4 -- four threads, ~2 ms)
+  // (no hash here: the comparison itself is the cheaper pass over the 64 MB of config #4 -- eight threads, 0.3 - 0.5 ms;
+  // four took 0.5 - 1.9 ms of a 7.7 ms device-callback solve, profiles/r05_e2e.md)
   std::lock_guard<std::mutex> lk(g_sym_mu);
   const SymCacheEntry* c = g_sym_cache.get();
   if(!c || c->key != b->sym->pat_key || c->N != b->N || c->M != b->M || c->nnz != b->nnz || c->row0 != b->row0 || c->row1 != b->row1 ||
      c->part_rank != b->part_rank || c->part_nranks != b->part_nranks) return 0;
   if(memcmp(c->cp.data(), colptr, sizeof(int)*((size_t)b->M + 1))) return 0;
   const size_t n = (size_t)b->nnz;
-  constexpr int NTH = 4;
-  int same[NTH] = {1, 1, 1, 1};
+  constexpr int NTH = 8;
+  int same[NTH] = {1, 1, 1, 1, 1, 1, 1, 1};
   std::thread th[NTH];
   for(int t = 0; t < NTH; t++)
     th[t] = std::thread([&, t] { const size_t a0 = n*t/NTH, a1 = n*(t + 1)/NTH; same[t] = !memcmp(c->ri.data() + a0, rowidx + a0, sizeof(int)*(a1 - a0)); });
   for(int t = 0; t < NTH; t++) th[t].join();
-  return same[0] && same[1] && same[2] && same[3];
+  int all = 1;
+  for(int t = 0; t < NTH; t++) all = all && same[t];
+  return all;
 }
 // forget the pattern (and everything derived from it) so that another one can be set
 extern "C" int dlg_sparse_drop_pattern(dlg_backend_t* b)

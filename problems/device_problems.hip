@@ -38,20 +38,55 @@ struct DevProblem
   int neval;
 };
 
-// one thread per measurement row; a row's entries are summed in index order (as the host does)
+// A workgroup takes BA_RPB consecutive rows: their entries are one contiguous run of Jt's arrays, read with lane = entry
+// (the products a_t (p[i_t] - p*[i_t]) and the coefficients parked in LDS), then one thread per row sums ITS products in index
+// order -- the order of the host's loop, so the bits are the host's -- and leaves the row's factor behind for the second
+// coalesced pass that writes the Jacobian values.  (One thread per row with a row's 15 entries 120 bytes apart read
+// 300 MB at 0.5 TB/s: 0.65 ms an evaluation, more than a whole trial step of the solver: profiles/r05_e2e.md.)
+constexpr int BA_RPB = 64, BA_CAP = 2048;
 __global__ void __launch_bounds__(256) k_ba_eval(int M, const int* __restrict__ Jp, const int* __restrict__ Ji,
                                                  const double* __restrict__ a, const double* __restrict__ pstar,
                                                  const double* __restrict__ p, double eps, double noise,
                                                  uint64_t seed, double* __restrict__ x, double* __restrict__ Jx)
 {
-  const int r = blockIdx.x*256 + threadIdx.x;
-  if(r >= M) return;
-  const int t0 = Jp[r], t1 = Jp[r+1];
-  double u = 0.0;
-  for(int t = t0; t < t1; t++) { const int j = Ji[t]; u += a[t]*(p[j] - pstar[j]); }
-  x[r] = u + eps*sin(u) - noise*urand(seed, 5, (uint64_t)r);
-  const double d = 1.0 + eps*cos(u);
-  for(int t = t0; t < t1; t++) Jx[t] = a[t]*d;
+  __shared__ double s_prod[BA_CAP], s_a[BA_CAP];
+  const int r0 = blockIdx.x*BA_RPB, r1 = min(M, r0 + BA_RPB);
+  const int e0 = Jp[r0], e1 = Jp[r1], n = e1 - e0;
+  if(n > BA_CAP)
+  {
+    // (rows too long for the staging buffers: one thread per row)
+    const int r = r0 + threadIdx.x;
+    if(threadIdx.x < BA_RPB && r < r1)
+    {
+      const int t0 = Jp[r], t1 = Jp[r+1];
+      double u = 0.0;
+      for(int t = t0; t < t1; t++) { const int j = Ji[t]; u += a[t]*(p[j] - pstar[j]); }
+      x[r] = u + eps*sin(u) - noise*urand(seed, 5, (uint64_t)r);
+      const double d = 1.0 + eps*cos(u);
+      for(int t = t0; t < t1; t++) Jx[t] = a[t]*d;
+    }
+    return;
+  }
+  for(int e = threadIdx.x; e < n; e += 256)
+  {
+    const int j = Ji[e0 + e];
+    const double av = a[e0 + e];
+    s_a[e] = av;
+    s_prod[e] = av*(p[j] - pstar[j]);
+  }
+  __syncthreads();
+  const int r = r0 + threadIdx.x;
+  if(threadIdx.x < BA_RPB && r < r1)
+  {
+    const int t0 = Jp[r] - e0, t1 = Jp[r+1] - e0;
+    double u = 0.0;
+    for(int t = t0; t < t1; t++) u += s_prod[t];
+    x[r] = u + eps*sin(u) - noise*urand(seed, 5, (uint64_t)r);
+    const double d = 1.0 + eps*cos(u);
+    for(int t = t0; t < t1; t++) s_prod[t] = d;
+  }
+  __syncthreads();
+  for(int e = threadIdx.x; e < n; e += 256) Jx[e0 + e] = s_a[e]*s_prod[e];
 }
 // one workgroup per row; the coefficients are generated in parallel, u is summed in index order
 __global__ void __launch_bounds__(256) k_dense_eval(int M, int N, const double* __restrict__ pstar,
@@ -129,7 +164,7 @@ void synth_cb_device(const double* p_dev, double* x_dev, double* J_dev, void* hi
   hipStream_t st = (hipStream_t)hip_stream;
   P->neval++;
   if(P->kind == 0)
-    hipLaunchKernelGGL(k_ba_eval, dim3((P->M + 255)/256), dim3(256), 0, st, P->M, P->Jp, P->Ji, P->a, P->pstar,
+    hipLaunchKernelGGL(k_ba_eval, dim3((P->M + BA_RPB - 1)/BA_RPB), dim3(256), 0, st, P->M, P->Jp, P->Ji, P->a, P->pstar,
                        p_dev, P->eps, P->noise, P->seed, x_dev, J_dev);
   else
     hipLaunchKernelGGL(k_dense_eval, dim3(P->M), dim3(256), sizeof(double)*((size_t)P->N + 1), st, P->M, P->N,

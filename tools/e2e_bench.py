@@ -55,8 +55,14 @@ host = lambda: capi.optimize("sparse", p0, prob.N, prob.M, prob.nnz, prob.cb, pr
 dev = lambda: capi.optimize_device(p0, prob.N, prob.M, prob.nnz, Jp, Ji, twin.cb, twin.cookie, prm)
 th1, (rh, ph, trh) = timed(host)
 th2, _ = timed(host)
+n0 = twin.neval()
 td1, (rd, pd, trd) = timed(dev)
+evals_per_solve = twin.neval() - n0
 td2, _ = timed(dev)
+# ... and as a user calls it: no per-trial trace (every trace record downloads the step vector behind a synchronisation of
+# its own -- a test feature); the best and the median of five
+dev_plain = lambda: capi.optimize_device(p0, prob.N, prob.M, prob.nnz, Jp, Ji, twin.cb, twin.cookie, prm, trace=False)
+tdp = sorted(timed(dev_plain)[0] for _ in range(5))
 # a longer solve of the same shape (20 iterations allowed): what the fixed cost per solve is against
 prm.max_iterations = 20
 td20, (rd20, pd20, trd20) = timed(dev)
@@ -69,7 +75,9 @@ out = {"workload": a.workload, "Nmeas": prob.M, "Nstate": prob.N, "nnz": prob.nn
                          "h2d_bytes_per_eval": 8 * (prob.nnz + prob.M)},
        "device_callback": {"first_call_s": td1, "second_call_s": td2, "steps_per_s": trd.ntrials / td2,
                            "h2d_bytes_per_eval": 0, "d2h_bytes_per_trial": 8 * prob.N,
-                           "trials": trd.ntrials, "evaluations_on_device": twin.neval()},
+                           "trials": trd.ntrials, "evaluations_per_solve": evals_per_solve,
+                           "untraced_solve_s_best": tdp[0], "untraced_solve_s_median": tdp[2],
+                           "untraced_steps_per_s": trd.ntrials / tdp[2]},
        "device_callback_20_iterations": {"solve_s": td20, "trials": trd20.ntrials, "steps_per_s": trd20.ntrials / td20},
        "host_callback_20_iterations": {"solve_s": th20, "trials": trh20.ntrials, "steps_per_s": trh20.ntrials / th20},
        "max_abs_p_diff_device_vs_host": float(np.max(np.abs(pd - ph))),
