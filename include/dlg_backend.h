@@ -213,6 +213,9 @@ int  dlg_point_eval(dlg_backend_t* b, int slot, double* norm2_x, double* Jtx_abs
  * that factor back (its panels stay in the second buffer until the next step), another lambda
  * factorises again.  DOGLEG_AMD_NO_PRESOLVE=1 keeps the evaluation to the assembly. */
 int  dlg_backend_set_speculation(dlg_backend_t* b, int on);
+/* measurement only (tools/rccl_floor.py): average enqueue-to-completion time, in microseconds, of `iters` all-reduces of
+ * `count` doubles on the backend's stream through the communicator it holds */
+int  dlg_backend_time_allreduce(dlg_backend_t* b, size_t count, int iters, double* us_each);
 
 /* ---- K3: compute_updateCauchy (dogleg.c:529-617) -------------------------- */
 int  dlg_cauchy(dlg_backend_t* b, int slot, double* norm2_updateCauchy);

@@ -39,7 +39,7 @@ BACKEND_SYMBOLS = [
     "dlg_sparse_partition_probe", "dlg_rccl_unique_id", "dlg_backend_init_rccl", "dlg_backend_set_rccl",
     "dlg_backend_comm_size", "dlg_backend_has_rccl", "dlg_backend_set_noop_comm", "dlg_solve_multi", "dlg_pseudoinverse_chunk", "dlg_backend_set_speculation",
     "dlg_backend_share_rccl", "dlg_point_gather_device", "dlg_backend_reset", "dlg_backend_device",
-    "dlg_sparse_pattern_matches", "dlg_sparse_drop_pattern", "dlg_sparse_region_probe", "dlg_run_steps",
+    "dlg_sparse_pattern_matches", "dlg_sparse_drop_pattern", "dlg_sparse_region_probe", "dlg_run_steps", "dlg_backend_time_allreduce",
 ]
 PROF_NAMES = ["K1_jtx", "K3K8_norm2Jv", "K4_kernel", "K4_total", "K5_factor", "K6_solve", "K7_step", "vec"]
 DOGLEG_SYMBOLS = [

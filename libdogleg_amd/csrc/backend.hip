@@ -6,6 +6,7 @@
 
 // ------------------------------------------------------------------ errors --
 static thread_local char g_err[1024] = "";
+#include <chrono>
 #include <atomic>
 #include <mutex>
 namespace {
@@ -261,7 +262,7 @@ extern "C" int dlg_backend_create(dlg_backend_t** out, int solve_type, int Nstat
   {
     DlgSlot& S = b->slot[s];
     TRY_HIP(hipMalloc(&S.p,      sizeof(double)*N));
-    TRY_HIP(hipMalloc(&S.Jt_x,   sizeof(double)*N));
+    TRY_HIP(hipMalloc(&S.Jt_x,   sizeof(double)*(N + 8)));      // (+ room for |x|^2 behind the vector: the sum over the ranks is made in place, dlg_point_eval)
     TRY_HIP(hipMalloc(&S.cauchy, sizeof(double)*N));
     TRY_HIP(hipMalloc(&S.gn,     sizeof(double)*(N + 8)));      // (+ room for a scalar behind the vector: sparse_solve, fold_scalar)
     TRY_HIP(hipMalloc(&S.step,   sizeof(double)*N));
@@ -536,6 +537,33 @@ extern "C" int dlg_sparse_set_pattern(dlg_backend_t* b, const int* colptr, const
   return sparse_set_pattern(b, colptr, rowidx);
 }
 
+// measurement only: enqueue-to-completion time of `iters` all-reduces of `count` doubles each on the backend's stream,
+// through whatever communicator the backend holds (RCCL at world size 1 on a one-GPU box: the floor of what a
+// collective costs the step -- tools/rccl_floor.py, tools/scaling_projection.py).  us_each = average, microseconds.
+extern "C" int dlg_backend_time_allreduce(dlg_backend_t* b, size_t count, int iters, double* us_each)
+{
+  if(!b || count == 0 || iters <= 0 || !us_each) { dlg_set_error("dlg_backend_time_allreduce: bad arguments"); return DLG_ERR_ARG; }
+  double* buf = nullptr;
+  DLG_HIP(hipMalloc(&buf, sizeof(double)*count));
+  DLG_HIP(hipMemsetAsync(buf, 0, sizeof(double)*count, b->stream));
+  hipEvent_t e0, e1;
+  DLG_HIP(hipEventCreate(&e0)); DLG_HIP(hipEventCreate(&e1));
+  int rc = DLG_OK;
+  for(int i = 0; i < 3 && rc == DLG_OK; i++) rc = allreduce(b, buf, count);          // warm-up
+  DLG_HIP(hipStreamSynchronize(b->stream));
+  const auto t0 = std::chrono::steady_clock::now();
+  DLG_HIP(hipEventRecord(e0, b->stream));
+  for(int i = 0; i < iters && rc == DLG_OK; i++) rc = allreduce(b, buf, count);
+  DLG_HIP(hipEventRecord(e1, b->stream));
+  DLG_HIP(hipStreamSynchronize(b->stream));
+  const double wall_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+  float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1);
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipFree(buf);
+  // (back to back on one stream: the larger of the device time between the events and the host's wall time)
+  *us_each = std::max((double)ms*1e3, wall_us)/iters;
+  return rc;
+}
+
 // ------------------------------------------------------------------ inputs --
 static int step_unprepare(dlg_backend* b);
 static int check_slot(dlg_backend* b, int s)
@@ -696,18 +724,17 @@ extern "C" int dlg_point_eval(dlg_backend_t* b, int s, double* norm2_x, double* 
     DlgProfScope pv(b, DLG_PROF_VEC);
     // norm2_x over the local rows (one-pass evaluation: together with the norms of Jt_x, one launch)
     const bool pair = fused && mloc > 0 && !b->sharded();
+    // (a rank of several: |x|^2 of its rows goes straight behind its share of Jt*x -- [Jt_x | |x|^2] is summed over the
+    // ranks in place, one collective, no staging copies: rounds 1 - 4 copied N doubles into a reduce buffer and back around
+    // the all-reduce, two 1.2 MB copies on the critical stream of every evaluation of config #4)
+    double* n2x_dev = b->sharded() ? S.Jt_x + b->N : b->d_scal;
     if(pair) { /* below */ }
-    else if(mloc > 0) DLG_CHECK(k_norm2_absmax(b, S.xin(), mloc, b->d_scal));
-    else         DLG_HIP(hipMemsetAsync(b->d_scal, 0, 2*sizeof(double), b->stream));
+    else if(mloc > 0) DLG_CHECK(k_norm2_absmax(b, S.xin(), mloc, n2x_dev));
+    else         DLG_HIP(hipMemsetAsync(n2x_dev, 0, 2*sizeof(double), b->stream));
     if(b->sharded())
     {
-      // fused reduce buffer [Jt_x | norm2_x]
-      if(!b->d_red) DLG_HIP(hipMalloc(&b->d_red, sizeof(double)*((size_t)b->N + 8)));
-      DLG_HIP(hipMemcpyAsync(b->d_red, S.Jt_x, sizeof(double)*(size_t)b->N, hipMemcpyDeviceToDevice, b->stream));
-      DLG_HIP(hipMemcpyAsync(b->d_red + b->N, b->d_scal, sizeof(double), hipMemcpyDeviceToDevice, b->stream));
-      DLG_CHECK(allreduce(b, b->d_red, (size_t)b->N + 1));
-      DLG_HIP(hipMemcpyAsync(S.Jt_x, b->d_red, sizeof(double)*(size_t)b->N, hipMemcpyDeviceToDevice, b->stream));
-      DLG_HIP(hipMemcpyAsync(b->d_scal, b->d_red + b->N, sizeof(double), hipMemcpyDeviceToDevice, b->stream));
+      DLG_CHECK(allreduce(b, S.Jt_x, (size_t)b->N + 1));
+      DLG_HIP(hipMemcpyAsync(b->d_scal, S.Jt_x + b->N, sizeof(double), hipMemcpyDeviceToDevice, b->stream));
     }
     bool norms_on_host = false;
     // The partial-sum stages of JtJ and the norm kernel the host waits for leave the critical stream where the

@@ -1232,7 +1232,11 @@ int sparse_factor_setup(dlg_backend* b, bool plan_only)
     // (a workgroup of the region fills a CU; the cap counts SUPERNODES: twice the CUs -- with replicas the launch holds more
     // workgroups than the chip has CUs anyway, they are dispatched in order and only wait for lower-numbered ones)
     const int ncu = b->ncu;
-    const int cap = env_int_host("DOGLEG_AMD_PERSIST_MAX", 2*ncu);     // (supernodes; since the replicas of round 4 a region holds more workgroups than the chip has CUs anyway)
+    // (supernodes; since the replicas of round 3 a region holds more workgroups than the chip has CUs anyway.  Round 5: five
+    // times the CUs -- config #5's levels 1 - 3 (269 + 251 + 128 supernodes) were one launch each in front of a region of
+    // 406: K5 2.33 -> 2.07 ms with all of them in it, 227 -> 234 steps/s.  The backward solve keeps twice the CUs: its
+    // region runs from the root DOWN, the populous levels last, and those are faster as launches of their own.)
+    const int cap = env_int_host("DOGLEG_AMD_PERSIST_MAX", 5*ncu);
     int total = 0, l0 = hi + 1, lds = 0, stage = 1;
     const int nt = Y->fac_nt[hi];
     for(int l = hi; l >= std::max(1, lo_min); l--)

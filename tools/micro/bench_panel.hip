@@ -34,7 +34,7 @@ __global__ void __launch_bounds__(NT) k_panel(double* G, int nrows, int w, int* 
     for(int u = 0; u < 8; u++) { int e = base + u*NT + tid; if(e < nrows*w) { int j = e / nrows; P[e + j*(ldp - nrows)] = v[u]; } }
   }
   __syncthreads();
-  long long t1 = clock64();
+  long long t1 = clock64(); long long w1 = wall_clock64();
   if(MODE == 0) panel_factor<NT, true>(P, ldp, nrows, w, tid, info, 0);
   if(MODE == 1) { if(blockIdx.x == 0 && tid == 0) g_pf_out = stamps + 4; panel_factor<NT, true>(P, ldp, nrows, w, tid, info, 0); }
   if(MODE == 4) { __shared__ int s_mcol[260]; __shared__ double s_rdiag[256]; panel_factor_blockdiag<NT>(P, ldp, nrows, w, tid, g_mcol, w/3, info, 0, s_mcol, s_rdiag); }
@@ -42,10 +42,10 @@ __global__ void __launch_bounds__(NT) k_panel(double* G, int nrows, int w, int* 
   if(MODE == 2) { if(NT >= 256) panel_factor_mfma<(NT >= 256 ? NT : 256)>(P, ldp, nrows, w, tid, info, 0); else if(NT >= 256) panel_factor_mfma<(NT >= 256 ? NT : 256)>(P, ldp, nrows, w, tid, info, 0); else panel_factor<NT, true, true>(P, ldp, nrows, w, tid, info, 0); }
   if(MODE == 3) { if(blockIdx.x == 0 && tid == 0) g_pf_out = stamps + 4; if(NT >= 256) panel_factor_mfma<(NT >= 256 ? NT : 256)>(P, ldp, nrows, w, tid, info, 0); else panel_factor<NT, true, true>(P, ldp, nrows, w, tid, info, 0); }
   __syncthreads();
-  long long t2 = clock64();
+  long long t2 = clock64(); long long w2 = wall_clock64();
   for(int e = tid; e < nrows*w; e += NT) { int j = e / nrows; g[e] = P[e + j*(ldp - nrows)]; }
   long long t3 = clock64();
-  if(tid == 0 && blockIdx.x == 0) { stamps[0] = t1 - t0; stamps[1] = t2 - t1; stamps[2] = t3 - t2; }
+  if(tid == 0 && blockIdx.x == 0) { stamps[0] = t1 - t0; stamps[1] = t2 - t1; stamps[2] = t3 - t2; stamps[3] = w2 - w1; }
 }
 
 template <int NT>
@@ -134,6 +134,7 @@ void run(int nrows, int w, int G, int iters)
                ev[J*8] - ev[0], ev[J*8+1] - ev[0], ev[J*8+4] - ev[J*8+1], ev[J*8+5] - ev[J*8+1], ev[J*8+6] - ev[J*8+1], ev[J*8+2] - ev[J*8+1], ev[J*8+3] - ev[J*8+1]);
     }
     printf("      B16 tail: to the end of the sweep %lld clocks\n", ph[9]);
+    { long long hs5[4]; hipMemcpy(hs5, st, 32, hipMemcpyDeviceToHost); printf("      B16 factor phase: %lld shader clocks in %lld x 10 ns of wall clock = %.2f GHz\n", hs5[1], hs5[3], hs5[3] > 0 ? (double)hs5[1]/(10.0*hs5[3]) : 0.0); }
     printf("      B16 %.1f us: wave 0: wait %lld steps %lld next tile %lld (of which waiting %lld) | scalar vs b16: max |diff| %.3g at (%d,%d) (max |L| %.3g), strict upper triangle touched by %.3g\n", bb*1e3/iters, ph[4], ph[5], ph[6], ph[7], worst, wi, wj, big, up);
   }
   {

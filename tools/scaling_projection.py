@@ -10,6 +10,7 @@ ap.add_argument("--workload", default="sparse-1m")
 ap.add_argument("--ranks", type=int, default=8)
 ap.add_argument("--steps", type=int, default=50)
 ap.add_argument("--lambda0", type=float, default=None, help="lambda of the one-GPU run too (config #5: 1.0, so that both sides factorise once)")
+ap.add_argument("--rccl-floor", default=None, help="JSON of tools/rccl_floor.py: RCCL's measured cost per all-reduce at world size 1 on this box -- the first row of the table")
 a = ap.parse_args()
 
 
@@ -56,9 +57,19 @@ print("|---|---|---|---|")
 R = a.ranks
 bw_ms = lambda nbytes: 2.0*(R - 1)/R*nbytes/100e9*1e3
 wire = 2*bw_ms(8.0*N1) + bw_ms(float(part.get("bytes_summed_per_factorisation", 0))) + bw_ms(8.0)
+floor = None
+if a.rccl_floor and os.path.exists(a.rccl_floor):
+    try:
+        fl = json.load(open(a.rccl_floor))
+        # two vectors of N + 1, the cut buffer, one scalar: what RCCL itself costs this stream with ONE rank (no wire, no peer)
+        floor = (2*fl["N_plus_1_doubles_1.2MB"] + fl["cut_buffer_1.18MB"] + fl["1_double_8B"])*1e-3
+        t = slow + floor
+        print(f"| **measured floor**: RCCL at world size 1 on this box ({fl['N_plus_1_doubles_1.2MB']:.0f} / {fl['cut_buffer_1.18MB']:.0f} / {fl['1_double_8B']:.0f} us for 1.2 MB / the cut buffer / 8 bytes; no wire, no peer) | {t:.4f} | {1e3/t:.0f} | {one['ms_per_step']/t:.2f} x |")
+    except Exception as ex:
+        print(f"| (no usable {a.rccl_floor}: {ex}) | | | |")
 for lat in (15e-3, 30e-3, 50e-3):
     t = slow + 4*lat + wire
-    print(f"| {lat*1e3:.0f} us | {t:.4f} | {1e3/t:.0f} | {one['ms_per_step']/t:.2f} x |")
+    print(f"| {lat*1e3:.0f} us (assumed) + bytes at 100 GB/s | {t:.4f} | {1e3/t:.0f} | {one['ms_per_step']/t:.2f} x |")
 k5_1, k5_r = p1.get("K5_factor", 0), max(d["phases_ms_per_step"].get("K5_factor", 0) for d in rows)
 print(f"\nSlowest rank {slow:.4f} ms against {one['ms_per_step']:.4f} ms on one GPU: {one['ms_per_step']/slow:.2f} x is the ceiling the partition's compute "
       f"leaves before any collective is paid for ({wire*1e3:.0f} us of the projection are bytes on the wire).  The passes over J and the leaf level shrink with the")
