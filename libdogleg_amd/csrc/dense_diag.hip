@@ -389,7 +389,7 @@ __global__ void __launch_bounds__(TPB) k_potrf_tiles(double* A, int lda, int n, 
 // the vector it waits for: it is on its way (forward: in registers, backward: staged in LDS) before the poll.
 // All T workgroups must be resident (they wait for higher-numbered ones on the way back): T <= #CUs / 2.
 constexpr unsigned long long TRSV_EMPTY = 0x7FF8DEADBEEF0001ull;
-__global__ void __launch_bounds__(TPB) k_trsv_tiles(const double* __restrict__ A, int lda, int n, int T,
+__global__ void __launch_bounds__(TPB) k_trsv_tiles_plain(const double* __restrict__ A, int lda, int n, int T,
                                                     const double* __restrict__ Linv, const double* __restrict__ rhs,
                                                     double* Yh, double* X, double* Xh, int epoch, DlgHandoff ho)
 {
@@ -512,6 +512,282 @@ __global__ void __launch_bounds__(TPB) k_trsv_tiles(const double* __restrict__ A
   }
 }
 
+
+#ifdef DLG_TRSV_PROFILE
+__device__ long long g_trsv_dbg[64*8];
+#define TRSV_STAMP(k) do { if(threadIdx.x == 0 && blockIdx.x < 64) g_trsv_dbg[blockIdx.x*8 + (k)] = wall_clock64(); } while(0)
+#else
+#define TRSV_STAMP(k)
+#endif
+// ---- the same two sweeps with the last TWO blocks a workgroup waits for folded into products formed ahead (round 5) ----
+// y_i = Linv_i (b_i - sum_{k<i} L(i,k) y_k).  Measured per workgroup (tools/trsv_prof.py): the way down ran at 1.4 us a
+// hop although a block of y crosses in 0.36 us -- behind the arrival of y_{i-2} sat the tile product, its four-way sum,
+// the product with Linv_i and its sum (six barriers), longer than a hop --, and the way back at 4.5 us a hop: every
+// workgroup staged its T - 1 - i tiles through LDS one after the other, a 32 KB load each that nothing covered.  Now
+//   * with  M1 = Linv_i L(i, i-1),  M2 = Linv_i L(i, i-2)  (64 x 64 x 64 products on the matrix cores while the workgroup
+//     waits; a thread keeps ITS 16 entries of each in registers) and  z = Linv_i (b_i - sum_{k<i-2} L(i,k) y_k),
+//     y_i = z - M2 y_{i-2} - M1 y_{i-1}:  behind the arrival of y_{i-1} there is one product of 16 terms a thread and one
+//     four-way sum; what depends on y_{i-3} (the sums, z) has two hops to finish in;
+//   * the way back the same with  Linv_i' L(i+1, i)',  Linv_i' L(i+2, i)',  and the tiles L(k, i), k > i + 2, come
+//     straight into registers (a thread: 16 consecutive rows of its column), four tiles ahead of their use.
+__global__ void __launch_bounds__(TPB) k_trsv_tiles(const double* __restrict__ A, int lda, int n, int T,
+                                                    const double* __restrict__ Linv, const double* __restrict__ rhs,
+                                                    double* Yh, double* X, double* Xh, int epoch, DlgHandoff ho)
+{
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  typedef __attribute__((address_space(1))) unsigned long long* gu_t;
+  constexpr int LDT = NB + 1;
+  double (*Lt)[LDT] = reinterpret_cast<double (*)[LDT]>(sm);                 // a tile of L: Lt[row][col]
+  double* Li = sm + NB*LDT;                                                  // Li[r + c*LDT] = Linv(r, c)
+  double* Ms = Li + NB*LDT;                                                  // scratch: a product on its way into registers, Ms[r + c*LDT]
+  double* v = Ms + NB*LDT;                                                   // [NB]  the vector waited for
+  double* part = v + NB;                                                     // [4][NB] partial sums
+  double* part2 = part + 4*NB;                                               // [4][NB] the second set (a product read from the first)
+  double* vb = part2 + 4*NB;                                                 // [NB] b_i, then y_i
+  const int t = threadIdx.x, r = t & 63, g = t >> 6;
+  const int lane = t & 63, wv = t >> 6, jn = lane & 15, kq = lane >> 4;
+  const int i = blockIdx.x, row0 = NB*i;
+  const int npad = T*NB, par = epoch & 1;
+  unsigned long long* ycur = reinterpret_cast<unsigned long long*>(Yh) + (size_t)par*npad;
+  unsigned long long* xcur = reinterpret_cast<unsigned long long*>(Xh) + (size_t)par*npad;
+  unsigned long long* ytake = ho.skew ? reinterpret_cast<unsigned long long*>(Yh) + (size_t)2*npad : ycur;
+  unsigned long long* xtake = ho.skew ? reinterpret_cast<unsigned long long*>(Xh) + (size_t)2*npad : xcur;
+  if(t < NB)
+  {
+    reinterpret_cast<unsigned long long*>(Yh)[(size_t)(1 - (epoch & 1))*npad + row0 + t] = TRSV_EMPTY;
+    reinterpret_cast<unsigned long long*>(Xh)[(size_t)(1 - (epoch & 1))*npad + row0 + t] = TRSV_EMPTY;
+  }
+  auto take = [&](unsigned long long* buf, int k) -> double {
+    unsigned long long u; int spins = 0;
+    while((u = __hip_atomic_load((gu_t)(buf + NB*k + t), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == TRSV_EMPTY)
+    { __builtin_amdgcn_s_sleep(1); if(++spins > ho.spins) { atomicOr(ho.status, DLG_HANDOFF_TRSV); u = 0; break; } }
+    return __longlong_as_double((long long)u);
+  };
+  // a tile of L into Lt (rows of block kr, columns of block kc; zeros past the end)
+  auto stage_tile = [&](int kr, int kc) {
+    for(int e = t; e < NB*NB; e += TPB)
+    {
+      const int rr = e % NB, cc = e / NB;
+      const int row = NB*kr + rr, col = NB*kc + cc;
+      Lt[rr][cc] = (row < n && col < n) ? A[(size_t)col*lda + row] : 0.0;
+    }
+  };
+  // Ms(row, col) = sum_k Aop(row, k) Bop(col, k) on the matrix cores, wave w the rows 16 w .. 16 w + 15; then this
+  // thread's 16 entries of it: m[c] = Ms(r, 16 g + c)
+  auto mm64 = [&](auto Aop, auto Bop, double (&m)[16]) {
+    dd_v4d x[4];
+#pragma unroll
+    for(int ct = 0; ct < 4; ct++) x[ct] = (dd_v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
+    for(int kk = 0; kk < NB; kk += 4)
+    {
+      const double a = Aop(16*wv + jn, kk + kq);
+#pragma unroll
+      for(int ct = 0; ct < 4; ct++) x[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Bop(16*ct + jn, kk + kq), x[ct], 0, 0, 0);
+    }
+#pragma unroll
+    for(int ct = 0; ct < 4; ct++)
+#pragma unroll
+      for(int q = 0; q < 4; q++) Ms[(16*wv + kq + 4*q) + (16*ct + jn)*LDT] = x[ct][q];
+    __syncthreads();
+#pragma unroll
+    for(int c = 0; c < 16; c++) m[c] = Ms[r + (16*g + c)*LDT];
+    __syncthreads();
+  };
+  // (forward products: Linv_i times the tile; backward: Linv_i' times the tile's transpose)
+  auto fold_fwd = [&](int k, double (&m)[16]) {
+    stage_tile(i, k);
+    __syncthreads();
+    mm64([&](int row, int kk) { return Li[row + kk*LDT]; }, [&](int col, int kk) { return Lt[kk][col]; }, m);
+  };
+  auto fold_bwd = [&](int k, double (&m)[16]) {
+    stage_tile(k, i);
+    __syncthreads();
+    mm64([&](int row, int kk) { return Li[kk + row*LDT]; }, [&](int col, int kk) { return Lt[col][kk]; }, m);
+  };
+  auto dot16 = [&](const double (&m)[16]) { double q4 = 0.0;
+#pragma unroll
+    for(int c = 0; c < 16; c++) q4 += m[c]*v[16*g + c];
+    return q4; };
+  auto sum4 = [&]() { return (part[t] + part[NB + t]) + (part[2*NB + t] + part[3*NB + t]); };      // (t < NB)
+  TRSV_STAMP(0);
+  for(int e = t; e < NB*NB; e += TPB) Li[(e & (NB - 1)) + (e/NB)*LDT] = Linv[(size_t)i*NB*NB + e];
+  if(t < NB) vb[t] = (row0 + t < n) ? rhs[row0 + t] : 0.0;
+  __syncthreads();
+  double M1[16], M2[16], B1[16], B2[16];
+#pragma unroll
+  for(int c = 0; c < 16; c++) { M1[c] = 0.0; M2[c] = 0.0; B1[c] = 0.0; B2[c] = 0.0; }
+  // (the first block rows are needed before two products would be done: they take their tiles the plain way)
+  const bool ffold = i >= 8;
+  if(ffold) fold_fwd(i - 1, M1);
+  if(ffold) fold_fwd(i - 2, M2);
+  // the products of the way back: behind the departure of y_i where the turn-round leaves the time (2 (T - 1 - i) hops
+  // until x_{i+1} is there; two products take ~12 us), now for the last block rows -- they have the whole way down to wait
+  const bool b_early = T - 1 - i < 8;
+  if(b_early && i + 1 < T) fold_bwd(i + 1, B1);
+  if(b_early && i + 2 < T) fold_bwd(i + 2, B2);
+  TRSV_STAMP(1);
+  // ---- forward: thread (row r, column group g) keeps 16 values of a tile in registers; blocks 0 .. i - 3
+  const int nf = ffold ? i - 2 : i;                  // tiles of the loop
+  double acc = 0.0;
+  double cur[16];
+  auto load_row_tile = [&](int k, double (&d)[16]) {
+#pragma unroll
+    for(int c = 0; c < 16; c++)
+    {
+      const int row = row0 + r, col = NB*k + 16*g + c;
+      d[c] = (row < n && k < nf) ? A[(size_t)col*lda + row] : 0.0;
+    }
+  };
+  auto fstep = [&](int k, const double (&d)[16]) {
+    __syncthreads();                                 // (v of the step before is done with)
+    if(t < NB) v[t] = take(ytake, k);
+    __syncthreads();
+#pragma unroll
+    for(int c = 0; c < 16; c++) acc += d[c]*v[16*g + c];
+  };
+  {
+    // (three tiles on their way: a block row near the end starts its loop late -- its products of the way back come first --
+    // and has to catch up with blocks of y that are all there)
+    double f1[16], f2[16];
+    load_row_tile(0, cur); load_row_tile(1, f1); load_row_tile(2, f2);
+    for(int k = 0; k < nf; k += 3)
+    {
+      fstep(k, cur); load_row_tile(k + 3, cur);
+      if(k + 1 < nf) { fstep(k + 1, f1); load_row_tile(k + 4, f1); }
+      if(k + 2 < nf) { fstep(k + 2, f2); load_row_tile(k + 5, f2); }
+    }
+  }
+  __syncthreads();
+  part[g*NB + r] = acc;
+  __syncthreads();
+  // z = Linv (b - s): every thread a quarter of a row's 64 terms, the four partial sums of s taken in as it goes (no
+  // pass of its own for s: one barrier less on the path), then the four quarters in a fixed order
+  {
+    double q4 = 0.0;
+#pragma unroll
+    for(int k = 0; k < 16; k++)
+    {
+      const int c = 16*g + k;
+      const double sv = (part[c] + part[NB + c]) + (part[2*NB + c] + part[3*NB + c]);
+      q4 += Li[r + c*LDT]*(vb[c] - sv);                              // Linv is zero above the diagonal; vb: b_i (zeros past the end)
+    }
+    part2[g*NB + r] = q4;
+  }
+  __syncthreads();
+  double yi = (t < NB) ? (part2[t] + part2[NB + t]) + (part2[2*NB + t] + part2[3*NB + t]) : 0.0;
+  double pq = 0.0;                                   // this thread's quarter of  M2 y_{i-2} + M1 y_{i-1}
+  if(ffold)
+  {
+    __syncthreads();
+    if(t < NB) v[t] = take(ytake, i - 2);
+    __syncthreads();
+    pq = dot16(M2);
+  }
+  if(ffold)
+  {
+    // the one block on everybody's path: y_{i-1}
+    __syncthreads();
+    TRSV_STAMP(2);
+    if(t < NB) v[t] = take(ytake, i - 1);
+    __syncthreads();
+    TRSV_STAMP(3);
+    pq += dot16(M1);
+    part[g*NB + r] = pq;
+    __syncthreads();
+    if(t < NB) yi -= sum4();
+  }
+  if(t < NB)
+  {
+    __hip_atomic_store((gu_t)(ycur + row0 + t), (unsigned long long)__double_as_longlong(row0 + t < n ? yi : 0.0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    vb[t] = (row0 + t < n) ? yi : 0.0;               // (for the way back: x_i = Linv_i' (y_i - ...))
+  }
+  TRSV_STAMP(4);
+  if(!b_early)
+  {
+    __syncthreads();
+    if(i + 1 < T) fold_bwd(i + 1, B1);
+    if(i + 2 < T) fold_bwd(i + 2, B2);
+  }
+  // ---- backward: the tiles L(k, i), k = T - 1 .. i + 3, three of them on their way in registers -- fetched with
+  // lane = row (whole lines; a thread = 16 consecutive rows of its column asked for 64 lines an instruction and could not
+  // keep up with the blocks of x: 2.2 us a hop) -- and turned through LDS when their block of x is there: thread (column r,
+  // row group g) then
+  auto load_tile_rows = [&](int k, double (&d)[16]) {
+    const bool on = k > i + 2 && k < T;
+#pragma unroll
+    for(int j = 0; j < 16; j++)
+    {
+      const int rr = t & 63, cc = (t >> 6) + 4*j;
+      const int row = NB*k + rr, col = row0 + cc;
+      d[j] = (on && row < n && col < n) ? A[(size_t)col*lda + row] : 0.0;
+    }
+  };
+  double bacc = 0.0;
+  auto bstep = [&](int k, const double (&d)[16]) {
+    __syncthreads();                                 // (v and Lt of the step before are done with)
+#pragma unroll
+    for(int j = 0; j < 16; j++) Lt[t & 63][(t >> 6) + 4*j] = d[j];
+    if(t < NB) v[t] = take(xtake, k);
+    __syncthreads();
+#pragma unroll
+    for(int q = 0; q < 16; q++) bacc += Lt[16*g + q][r]*v[16*g + q];
+  };
+  {
+    double t0[16], t1[16], t2[16];
+    int k = T - 1;
+    load_tile_rows(k, t0); load_tile_rows(k - 1, t1); load_tile_rows(k - 2, t2);
+    for(; k > i + 2; k -= 3)
+    {
+      bstep(k, t0); load_tile_rows(k - 3, t0);
+      if(k - 1 > i + 2) { bstep(k - 1, t1); load_tile_rows(k - 4, t1); }
+      if(k - 2 > i + 2) { bstep(k - 2, t2); load_tile_rows(k - 5, t2); }
+    }
+  }
+  __syncthreads();
+  part[g*NB + r] = bacc;
+  __syncthreads();
+  {
+    double q4 = 0.0;
+#pragma unroll
+    for(int k = 0; k < 16; k++)
+    {
+      const int c = 16*g + k;
+      const double sv = (part[c] + part[NB + c]) + (part[2*NB + c] + part[3*NB + c]);
+      q4 += Li[c + r*LDT]*(vb[c] - sv);                              // Linv' : column r of Linv; vb: y_i
+    }
+    part2[g*NB + r] = q4;
+  }
+  __syncthreads();
+  double xi = (t < NB) ? (part2[t] + part2[NB + t]) + (part2[2*NB + t] + part2[3*NB + t]) : 0.0;
+  pq = 0.0;
+  if(i + 2 < T)
+  {
+    __syncthreads();
+    if(t < NB) v[t] = take(xtake, i + 2);
+    __syncthreads();
+    pq = dot16(B2);
+  }
+  if(i + 1 < T)
+  {
+    __syncthreads();
+    TRSV_STAMP(5);
+    if(t < NB) v[t] = take(xtake, i + 1);
+    __syncthreads();
+    TRSV_STAMP(6);
+    pq += dot16(B1);
+    part[g*NB + r] = pq;
+    __syncthreads();
+    if(t < NB) xi -= sum4();
+  }
+  if(t < NB)
+  {
+    if(row0 + t < n) X[row0 + t] = xi;
+    __hip_atomic_store((gu_t)(xcur + row0 + t), (unsigned long long)__double_as_longlong(row0 + t < n ? xi : 0.0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  TRSV_STAMP(7);
+}
+
 } // namespace
 
 // the dynamic-LDS limit of a kernel, set once per device (a failure is left for the launch to report)
@@ -530,12 +806,31 @@ static void dlg_func_lds_once(bool (&done)[DLG_MAX_DEV], const void* fn, int byt
 void dense_launch_trsv_tiles(hipStream_t st, const double* A, int lda, int n, const double* Linv, const double* rhs,
                              double* Yh, double* X, double* Xh, int epoch, const DlgHandoff& ho)
 {
-  static bool attr[DLG_MAX_DEV] = {};       // a function attribute is a property of (function, device)
-  constexpr int LDSB = 88*1024;           // > half of the CU's LDS: one workgroup per CU
-  dlg_func_lds_once(attr, reinterpret_cast<const void*>(&k_trsv_tiles), LDSB);
+  static bool attr[DLG_MAX_DEV] = {}, attr_plain[DLG_MAX_DEV] = {};       // a function attribute is a property of (function, device)
   const int T = (n + NB - 1)/NB;
+  static const bool plain = getenv("DOGLEG_AMD_TRSV_PLAIN") != nullptr;      // (the form of rounds 2b - 4: two products a hop; tests)
+  if(plain)
+  {
+    constexpr int LDSB = 88*1024;           // > half of the CU's LDS: one workgroup per CU
+    dlg_func_lds_once(attr_plain, reinterpret_cast<const void*>(&k_trsv_tiles_plain), LDSB);
+    hipLaunchKernelGGL(k_trsv_tiles_plain, dim3(T), dim3(TPB), LDSB, st, A, lda, n, T, Linv, rhs, Yh, X, Xh, epoch, ho);
+    return;
+  }
+  constexpr int LDSB = (3*NB*(NB + 1) + 10*NB + 16)*(int)sizeof(double);           // three 64 x 65 tiles + the vectors: 102 KB, one workgroup per CU
+  dlg_func_lds_once(attr, reinterpret_cast<const void*>(&k_trsv_tiles), LDSB);
   hipLaunchKernelGGL(k_trsv_tiles, dim3(T), dim3(TPB), LDSB, st, A, lda, n, T, Linv, rhs, Yh, X, Xh, epoch, ho);
 }
+#ifdef DLG_TRSV_PROFILE
+extern "C" void dlg_trsv_profile_dump(int T)
+{
+  long long h[64*8];
+  if(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_trsv_dbg), sizeof(h)) != hipSuccess) return;
+  const long long t0 = h[0];
+  for(int i = 0; i < T && i < 64; i++)
+    fprintf(stderr, "  trsv wg %2d: start %6lld set-up done %6lld | waits for y(i-1) at %6lld, has it at %6lld, y(i) out %6lld | waits for x(i+1) at %6lld, has it %6lld, x(i) out %6lld\n",
+            i, h[i*8] - t0, h[i*8+1] - t0, h[i*8+2] - t0, h[i*8+3] - t0, h[i*8+4] - t0, h[i*8+5] - t0, h[i*8+6] - t0, h[i*8+7] - t0);
+}
+#endif
 // (both sets of hand-off buffers empty: before the first launch)
 namespace { __global__ void k_trsv_arm(unsigned long long* a, size_t n) { for(size_t i = blockIdx.x*(size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x*blockDim.x) a[i] = TRSV_EMPTY; } }
 void dense_trsv_arm(hipStream_t st, double* Yh, double* Xh, size_t n_each)
