@@ -470,7 +470,7 @@ __device__ __forceinline__ double pf_rsqrt3(double d)
 // panel row, one pass over the row's finished entries -- own entry (consecutive lanes, consecutive addresses) times the
 // pivot rows' entries (one 16-byte broadcast read for two of them) --, the little diagonal block factored by every
 // thread from the pivot rows' sums (LDS, one barrier), then the row's own solve.  Columns finished that way:
-constexpr int PF_VFIN_MAX = 4;
+constexpr int PF_VFIN_MAX = 4;          // (5 .. 8 columns: measured 0.4 - 0.7 us faster on 54 / 70 / 72-column panels, 0.6 us slower on a 40-column one: left to the matrix cores)
 constexpr int PF_VFIN_SCR = 2*16*PF_B16_WS + 2*4*64;       // doubles of pf_b16_lds the finish may use (W, A, E: free behind the sweep)
 // The waves share the pass two ways: a wave = (group of 64 rows, slice of the finished columns) -- 193 x 66: three groups x
 // two slices --, every thread with two accumulator chains a column; the slices' partial sums meet in LDS (slice 0 adds
@@ -482,7 +482,7 @@ __device__ __forceinline__ void pf_b16_vector_finish(double* P, int ldp, int nro
 {
   // (the caller's barrier is behind us: every entry left of column wm is final; at most 512 rows: PF_B16_MAXT)
   constexpr int NWV = NT/64;
-  constexpr int NFP = (NF <= 2) ? 2 : 4;                        // accumulators kept per row (16-byte reads of the pivot rows)
+  constexpr int NFP = (NF + 1) & ~1;                            // accumulators kept per row (16-byte reads of the pivot rows)
   const int lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nlive = nrows - wm, G = (nlive + 63) >> 6;          // row groups (G <= NWV: the caller's condition)
   // slices of the columns: 1, 2 or 4 (shifts and compares only: an integer division costs more than a slice saves here)

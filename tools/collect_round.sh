@@ -24,8 +24,17 @@ cp gpurun_out/$tag/sq/sq_k4.txt $out/sq_k4.txt 2>/dev/null
 bash tools/run_prof.sh $tag/prof env > $out/top_of_tree_levels.txt 2>&1
 python3 tools/k4_split.py > $out/k4_split.txt 2>&1; DLG_ASM_ONLY_SHAPE=0 python3 tools/k4_split.py >> $out/k4_split.txt 2>&1; DLG_ASM_ONLY_SHAPE=1 python3 tools/k4_split.py >> $out/k4_split.txt 2>&1
 timeout 300 python3 tools/gpu_probe.py > $out/probe.txt 2>&1
+# round 5: RCCL's cost per all-reduce at world size 1 (a process of its own), the dense triangular solves' hop timeline, the
+# panel sweeps with and without the vector finish of a short last block, where workgroups land (XCDs) and what a hand-off costs
+timeout 300 python3 tools/rccl_floor.py > $out/rccl_floor.json 2> $out/rccl_floor.err
+if [ -f tools/micro/libtrsvprof.so ]; then DLG_PROF_LIB=tools/micro/libtrsvprof.so timeout 300 python3 tools/trsv_prof.py 2>&1 | grep "trsv wg" > $out/trsv_hops.txt; fi
+{
+  echo "# tools/micro/bench_panel (one workgroup of 512 threads, panel in LDS; us per launch include ~5 us of load / store); second line of a pair: -DDLG_PF_NO_VFIN (the short last block on the matrix cores)"
+  for a in "187 60" "193 66" "199 66" "205 66" "211 72" "127 126" "100 66" "163 36"; do echo "== nrows w = $a"; timeout 60 tools/micro/bench_panel 1 $a 512 | grep -E "B16 [0-9]|vfin phases"; timeout 60 tools/micro/bench_panel_novfin 1 $a 512 | grep -E "B16 [0-9]"; done
+} > $out/panel_sweep.txt 2>&1
+timeout 120 tools/micro/xcd_probe > $out/xcd_probe.txt 2>&1
 DLG_BENCH_FORCE_DIST=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29512 RANK=0 LOCAL_RANK=0 WORLD_SIZE=1 timeout 600 python3 bench.py --no-cpu-baseline > $out/bench_dist_world1_rccl.log 2>&1
-timeout 1500 python3 tools/scaling_projection.py --workload sparse-1m --ranks 8 > $out/scaling_projection.md 2> $out/scaling_projection.err
+timeout 1500 python3 tools/scaling_projection.py --workload sparse-1m --ranks 8 --rccl-floor $out/rccl_floor.json > $out/scaling_projection.md 2> $out/scaling_projection.err
 timeout 2400 python3 tools/scaling_projection.py --workload sparse-5m --ranks 8 --steps 8 --lambda0 1.0 > $out/scaling_projection_sparse5m.md 2>> $out/scaling_projection.err
 bash tools/run_trace.sh $tag/trace > $out/step_trace.txt 2>&1
 # keep the merge small: only summaries travel back

@@ -10,13 +10,19 @@ for l in open(sys.argv[1]):
                  r"panel in\s+(\d+) added\s+(\d+) factored\s+(\d+) tail\s+(\d+) flag\+stored\s+(\d+)", l)
     if m:
         v = tuple(int(x) for x in m.groups())
-        rows[v[0]] = v          # (the dump may hold several launches: keep the last record of every workgroup)
+        # (the dump may hold several launches: keep the last record of every workgroup -- of the one-launch region, levels >= 1,
+        # and of the leaf-level launch, level 0, apart: until round 5 they shared the key, and what was printed as "level 0:
+        # 321 supernodes" were the leaf launch's workgroups 703 .. 1023 that no region workgroup had overwritten)
+        rows[(v[5] == 0, v[0])] = v
 lv = {}
 for v in rows.values():
     lv.setdefault(v[5], []).append(v)
 prev = None
 for l in sorted(lv):
     g = lv[l]
+    if l == 0:
+        print(f"(level 0 is the leaf level's own launch, k_factor_level<256, true>: {len(g)} of its workgroups recorded; the one-launch region is levels 1 and up)")
+        continue
     nrep = max(v[6] for v in g) + 1
     late = max(g, key=lambda v: v[8])
     wdone = [v[8] for v in g]            # flag up
