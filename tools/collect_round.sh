@@ -26,7 +26,7 @@ python3 tools/k4_split.py > $out/k4_split.txt 2>&1; DLG_ASM_ONLY_SHAPE=0 python3
 timeout 300 python3 tools/gpu_probe.py > $out/probe.txt 2>&1
 # round 5: RCCL's cost per all-reduce at world size 1 (a process of its own), the dense triangular solves' hop timeline, the
 # panel sweeps with and without the vector finish of a short last block, where workgroups land (XCDs) and what a hand-off costs
-timeout 300 python3 tools/rccl_floor.py > $out/rccl_floor.json 2> $out/rccl_floor.err
+timeout 300 python3 tools/rccl_floor.py 2> $out/rccl_floor.err | grep '^{' > $out/rccl_floor.json
 if [ -f tools/micro/libtrsvprof.so ]; then DLG_PROF_LIB=tools/micro/libtrsvprof.so timeout 300 python3 tools/trsv_prof.py 2>&1 | grep "trsv wg" > $out/trsv_hops.txt; fi
 {
   echo "# tools/micro/bench_panel (one workgroup of 512 threads, panel in LDS; us per launch include ~5 us of load / store); second line of a pair: -DDLG_PF_NO_VFIN (the short last block on the matrix cores)"

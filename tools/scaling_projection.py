@@ -60,7 +60,7 @@ wire = 2*bw_ms(8.0*N1) + bw_ms(float(part.get("bytes_summed_per_factorisation", 
 floor = None
 if a.rccl_floor and os.path.exists(a.rccl_floor):
     try:
-        fl = json.load(open(a.rccl_floor))
+        fl = json.loads([l for l in open(a.rccl_floor) if l.startswith("{")][0])      # (librccl prints its banner on stdout too)
         # two vectors of N + 1, the cut buffer, one scalar: what RCCL itself costs this stream with ONE rank (no wire, no peer)
         floor = (2*fl["N_plus_1_doubles_1.2MB"] + fl["cut_buffer_1.18MB"] + fl["1_double_8B"])*1e-3
         t = slow + floor
