@@ -205,6 +205,12 @@ def main():
     one_pass = kind == "sparse"
     if one_pass:
         be.set_speculation(True)
+        # ... and the expected improvement's pass over J (K8) behind the decision point (dlg_backend_set_defer_tail, as the
+        # driver runs device-callback solves): the reference uses the value behind the NEXT evaluation (dogleg.c:1427), so
+        # K8 of step i runs beside the evaluation of step i + 1 and dlg_run_steps fetches it there (dlg_step_tail);
+        # the last step's tail is waited for inside the timed region.  DOGLEG_AMD_NO_DEFER_TAIL=1: K8 in line, as in rounds 1-4
+        if not use_dist and not logical:
+            be.set_defer_tail(True)
     res = one_step()
     for _ in range(args.warmup):
         res = one_step()

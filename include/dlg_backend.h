@@ -213,6 +213,18 @@ int  dlg_point_eval(dlg_backend_t* b, int slot, double* norm2_x, double* Jtx_abs
  * that factor back (its panels stay in the second buffer until the next step), another lambda
  * factorises again.  DOGLEG_AMD_NO_PRESOLVE=1 keeps the evaluation to the assembly. */
 int  dlg_backend_set_speculation(dlg_backend_t* b, int on);
+/* The expected improvement behind the decision point.  takeStepFrom (dogleg.c:1172-1297) computes the expected improvement
+ * with the step, but the reference first USES the value behind the evaluation of the trial point (dogleg.c:1410-1427;
+ * "done" is decided on max|step|, 1289-1296).  With this on (sparse, single rank), dlg_take_step returns NaN in its place
+ * (out7[6]) as soon as the step's scalars are on the host; the pass over J that forms |J step|^2 (K8) is on the backend's
+ * stream behind the step, running while the host is on its way back and enqueues what comes next -- the model's kernels,
+ * the evaluation of the trial point --, and dlg_step_tail waits for it and returns the value (bit for bit the one
+ * dlg_take_step would have returned).  A page-locked
+ * p_new_host is complete when dlg_step_tail returns, not before.  Until then the caller leaves the J arrays of the slot
+ * the step was taken from alone (binding other arrays to the slot is fine).  dlg_step_tail with nothing outstanding
+ * returns the last value.  DOGLEG_AMD_NO_DEFER_TAIL=1: the switch does nothing. */
+int  dlg_backend_set_defer_tail(dlg_backend_t* b, int on);
+int  dlg_step_tail(dlg_backend_t* b, double* expected_improvement);
 /* measurement only (tools/rccl_floor.py): average enqueue-to-completion time, in microseconds, of `iters` all-reduces of
  * `count` doubles on the backend's stream through the communicator it holds */
 int  dlg_backend_time_allreduce(dlg_backend_t* b, size_t count, int iters, double* us_each);

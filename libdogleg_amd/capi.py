@@ -37,7 +37,7 @@ BACKEND_SYMBOLS = [
     "dlg_backend_set_profiling", "dlg_backend_get_profile", "dlg_backend_get_profile_early",
     "dlg_backend_set_allreduce", "dlg_backend_set_partition", "dlg_partition_rows", "dlg_partition_stats",
     "dlg_sparse_partition_probe", "dlg_rccl_unique_id", "dlg_backend_init_rccl", "dlg_backend_set_rccl",
-    "dlg_backend_comm_size", "dlg_backend_has_rccl", "dlg_backend_set_noop_comm", "dlg_solve_multi", "dlg_pseudoinverse_chunk", "dlg_backend_set_speculation",
+    "dlg_backend_comm_size", "dlg_backend_has_rccl", "dlg_backend_set_noop_comm", "dlg_solve_multi", "dlg_pseudoinverse_chunk", "dlg_backend_set_speculation", "dlg_backend_set_defer_tail", "dlg_step_tail",
     "dlg_backend_share_rccl", "dlg_point_gather_device", "dlg_backend_reset", "dlg_backend_device",
     "dlg_sparse_pattern_matches", "dlg_sparse_drop_pattern", "dlg_sparse_region_probe", "dlg_run_steps", "dlg_backend_time_allreduce",
 ]
@@ -83,6 +83,8 @@ def lib():
     L.dlg_backend_set_shard.argtypes = [V, C.c_int, C.c_int, V, V]
     L.dlg_backend_set_allreduce.argtypes = [V, V, V]
     L.dlg_backend_set_speculation.argtypes = [V, C.c_int]
+    L.dlg_backend_set_defer_tail.argtypes = [V, C.c_int]
+    L.dlg_step_tail.argtypes = [V, C.POINTER(C.c_double)]
     L.dlg_backend_set_partition.argtypes = [V, C.c_int, C.c_int]
     L.dlg_partition_rows.argtypes = [V, I, C.POINTER(I)]
     L.dlg_partition_stats.argtypes = [V, C.POINTER(C.c_long), C.c_int]
@@ -415,6 +417,16 @@ class Backend:
         """assemble JtJ beside Jt*x at every eval (for callers that expect to factorise the point)"""
         _ck(self.L.dlg_backend_set_speculation(self.h, 1 if on else 0), "set_speculation")
 
+    def set_defer_tail(self, on=True):
+        """dlg_take_step returns before the expected improvement's pass over J (K8): step_tail() has the value"""
+        _ck(self.L.dlg_backend_set_defer_tail(self.h, 1 if on else 0), "set_defer_tail")
+
+    def step_tail(self):
+        """the expected improvement of the last step taken with set_defer_tail (and its p_new complete)"""
+        v = C.c_double()
+        _ck(self.L.dlg_step_tail(self.h, C.byref(v)), "step_tail")
+        return v.value
+
     def set_allreduce(self, fn):
         """host-synchronous sum-all-reduce hook (fallback / logical ranks on one device)"""
         cb = ALLREDUCE_FN(fn) if fn is not None else None
@@ -539,7 +551,7 @@ class Backend:
                             C.byref(ei), dptr(self._pnew) if want_p else None), "step")
         return n2.value, k.value, am.value, ei.value, (self._pnew if want_p else None)
 
-    def take_step(self, frm, to, trustregion, lam=0.0, want_p=True):
+    def take_step(self, frm, to, trustregion, lam=0.0, want_p=True, tail=True):
         """Cauchy + Gauss-Newton + the choice of step + step + expected improvement behind one
         synchronisation: (lambda, dict(n2c, n2g, kind, n2s, k, amax, ei), p_new)"""
         l = C.c_double(lam)
@@ -551,6 +563,8 @@ class Backend:
         keys = ("n2c", "n2g", "kind", "n2s", "k", "amax", "ei")
         r = dict(zip(keys, [float(v) for v in out]))
         r["kind"] = int(r["kind"])
+        if tail and r["ei"] != r["ei"]:
+            r["ei"] = self.step_tail()          # set_defer_tail: the value (and a page-locked p_new) complete here
         return l.value, r, (self._pnew if want_p else None)
 
     def run_steps(self, frm, to, nsteps, x_ptrs, J_ptrs, first_copy, trustregion, lam0=0.0):

@@ -62,6 +62,7 @@ int dlg_fetch_scalars(dlg_backend* b, int n)
   DLG_HIP(hipMemcpyAsync(b->h_scal, b->d_scal, sizeof(double)*(size_t)dlg_backend::NSCAL, hipMemcpyDeviceToHost,
                          b->stream));
   DLG_HIP(hipStreamSynchronize(b->stream));
+  b->sync_mark++;
   dlg_resolve_pending(b);
   if(b->profiling) dlg_prof_resolve(b);
   return dlg_check_handoff(b);
@@ -241,6 +242,7 @@ extern "C" int dlg_backend_create(dlg_backend_t** out, int solve_type, int Nstat
   {
     dlg_backend::Knobs& k = b->knobs;
     k.no_k3_fork = getenv("DOGLEG_AMD_NO_K3_FORK") != nullptr;
+    k.no_defer_tail = getenv("DOGLEG_AMD_NO_DEFER_TAIL") != nullptr;
     k.join_event = getenv("DOGLEG_AMD_JOIN_EVENT") != nullptr;
     k.no_potrf_fuse = getenv("DOGLEG_AMD_NO_POTRF_FUSE") != nullptr;
     k.potrf_steps = getenv("DOGLEG_AMD_POTRF_STEPS") != nullptr;
@@ -295,6 +297,7 @@ extern "C" void dlg_backend_destroy(dlg_backend_t* b)
   if(b->d_scal) (void)hipFree(b->d_scal);
   if(b->h_scal) (void)hipHostFree(b->h_scal);
   if(b->h_part) (void)hipHostFree(b->h_part);
+  if(b->h_tail) (void)hipHostFree(b->h_tail);
   if(b->h_vec)  (void)hipHostFree(b->h_vec);
   if(b->d_part) (void)hipFree(b->d_part);
   if(b->d_gnpart) (void)hipFree(b->d_gnpart);
@@ -341,6 +344,8 @@ extern "C" int dlg_backend_reset(dlg_backend_t* b)
   b->fold_scalar = b->fold_result = nullptr; b->fold_cauchy_out = nullptr;
   b->fold_p_src = nullptr; b->p_copied = false; b->scal_copied = false; b->fold_scal = 0;
   b->h_part_used = 0; b->pending.clear();
+  if(b->tail_pending) DLG_HIP(hipStreamSynchronize(b->stream));
+  b->tail_pending = false; b->defer_tail = false; b->tail_mode = false; b->fold_scal_k7 = 0;
   DLG_HIP(hipMemsetAsync(b->d_scal, 0, sizeof(double)*dlg_backend::NSCAL, b->stream));
   if(b->type == DLG_SPARSE) sparse_reset(b);
   DLG_HIP(hipStreamSynchronize(b->stream));
@@ -379,6 +384,36 @@ extern "C" int dlg_backend_set_speculation(dlg_backend_t* b, int on)
   if(!b) return DLG_ERR_ARG;
   b->speculate = on != 0;
   b->presolve = b->speculate && getenv("DOGLEG_AMD_NO_PRESOLVE") == nullptr;
+  return DLG_OK;
+}
+
+// dlg_take_step / dlg_step return without the expected improvement (NaN in its place) and, for a page-locked p_new_host,
+// possibly without p_new: both are complete when dlg_step_tail returns.  The reference uses the value only after the
+// NEXT evaluation (dogleg.c:1427; "done" is decided on max|step|, 1289-1296): the pass over J that forms |J step|^2 runs
+// while the host is on its way back and enqueues what comes next (the model's kernels, the next evaluation) instead of
+// in front of the synchronisation the host decides behind.  Until dlg_step_tail the caller must leave J of the slot the
+// step was taken from alone (binding other arrays to the slot is fine: the bound ones are only read).
+extern "C" int dlg_backend_set_defer_tail(dlg_backend_t* b, int on)
+{
+  if(!b) return DLG_ERR_ARG;
+  b->defer_tail = on != 0 && !b->knobs.no_defer_tail;
+  return DLG_OK;
+}
+// Before anything overwrites what a tail that is still out reads (the step vector, p_new, J of its slot): the tail is a
+// launch on the backend's own stream, so whatever is enqueued there is behind it already.
+static int tail_guard(dlg_backend*) { return DLG_OK; }
+extern "C" int dlg_step_tail(dlg_backend_t* b, double* expected_improvement)
+{
+  if(!b) return DLG_ERR_ARG;
+  if(b->tail_pending)
+  {
+    if(b->tail_mark == b->sync_mark) DLG_HIP(hipStreamSynchronize(b->stream));      // (nobody has waited for anything behind K8 yet)
+    double v = 0.0;
+    for(int i = 0; i < b->tail_nb; i++) v += b->h_tail[i];          // in index order, as dlg_resolve_pending adds them
+    b->tail_value = -2.0*b->tail_inner - v;                          // dogleg.c:1107-1109
+    b->tail_pending = false;
+  }
+  if(expected_improvement) *expected_improvement = b->tail_value;
   return DLG_OK;
 }
 
@@ -576,9 +611,11 @@ static void invalidate(DlgSlot& S)
   S.have_Jtx = S.have_cauchy = S.have_gn = false;
 }
 
+static int tail_guard(dlg_backend* b);
 extern "C" int dlg_point_set_p(dlg_backend_t* b, int s, const double* p_host)
 {
   DLG_CHECK(check_slot(b, s));
+  DLG_CHECK(tail_guard(b));
   DLG_HIP(hipMemcpyAsync(b->slot[s].p, p_host, sizeof(double)*(size_t)b->N, hipMemcpyHostToDevice,
                          b->stream));
   DLG_HIP(hipStreamSynchronize(b->stream));     // p_host may be pageable / reused
@@ -590,6 +627,7 @@ extern "C" int dlg_point_upload(dlg_backend_t* b, int s, const double* x_host, c
   DLG_CHECK(check_slot(b, s));
   DLG_CHECK(step_unprepare(b));
   if(b->type == DLG_DENSE_PRODUCTS) { dlg_set_error("use dlg_point_upload_products"); return DLG_ERR_ARG; }
+  DLG_CHECK(tail_guard(b));                     // (a K8 behind the decision point may still be reading this slot's J)
   DlgSlot& S = b->slot[s];
   S.x_bound = S.J_bound = nullptr;
   // a sharded rank uploads only its own rows: x[row0:row1] and the J entries of those rows
@@ -769,6 +807,7 @@ extern "C" int dlg_point_eval(dlg_backend_t* b, int s, double* norm2_x, double* 
       // chip works on them while the host fetches the norms and decides
       if(ahead && !b->sharded() && b->part_nranks <= 1) DLG_CHECK(step_prepare(b, s));
       DLG_HIP(hipEventSynchronize(b->ev_fetch));
+      b->sync_mark++;       // (the host has waited for something enqueued behind everything that was on the main stream before this call)
       dlg_resolve_pending(b);
     }
     else DLG_CHECK(dlg_fetch_scalars(b, 4));
@@ -1033,6 +1072,7 @@ static int gauss_newton_impl(dlg_backend_t* b, int s, double* lambda_io, double*
     if(good) break;
     if(b->type == DLG_SPARSE) sparse_mark_unclean(b);          // (a factorisation that broke down: full clears next)
     b->factor_slot = -1;
+    if(b->tail_pending) { DLG_CHECK(tail_guard(b)); b->tail_pending = false; }     // (that attempt's K8 returned at its first look at the pivot flag)
     lam = (lam == 0.0) ? 1e-10 : lam*10.0;                    // dogleg.c:138, 671-672, 812-813
     if(!(lam < 1e300)) { dlg_set_error("lambda overflowed while regularising a singular JtJ"); return DLG_ERR_STATE; }
   }
@@ -1123,6 +1163,7 @@ static int step_finish(dlg_backend* b, int to, int nscal, double* p_new_host)
   if(!attached) DLG_HIP(hipEventRecord(b->ev_fetch, b->stream));
   if(b->type == DLG_SPARSE) DLG_CHECK(sparse_zero_spare(b));
   DLG_HIP(hipEventSynchronize(b->ev_fetch));
+  b->sync_mark++;
   dlg_resolve_pending(b);
   if(p_new_host && !pinned) memcpy(p_new_host, b->h_vec, sizeof(double)*(size_t)b->N);
   return nscal >= dlg_backend::NSCAL ? dlg_check_handoff(b) : DLG_OK;
@@ -1137,6 +1178,7 @@ extern "C" int dlg_make_step(dlg_backend_t* b, int from, int to, int kind, doubl
   // the trial point is dropped and the factor it displaced is the held one again BEFORE step_finish clears the
   // spare panel buffer -- which is where the displaced factor lives)
   DLG_CHECK(step_unprepare(b));
+  DLG_CHECK(tail_guard(b)); b->tail_pending = false;
   double n2 = 0, kk = NAN, amax = 0;
   int nscal = 0;
   DLG_CHECK(make_step_enqueue(b, from, to, kind, trustregion, &nscal));
@@ -1175,6 +1217,7 @@ extern "C" int dlg_step(dlg_backend_t* b, int from, int to, int kind, double tru
   DLG_CHECK(check_slot(b, from)); DLG_CHECK(check_slot(b, to));
   if(from == to) { dlg_set_error("dlg_step: from == to"); return DLG_ERR_ARG; }
   DLG_CHECK(step_unprepare(b));                 // (as in dlg_make_step: the driver's retry after a rejected trial point)
+  DLG_CHECK(tail_guard(b)); b->tail_pending = false;
   double n2 = 0, kk = NAN, amax = 0;
   int nscal = 0;
   DLG_CHECK(make_step_enqueue(b, from, to, kind, trustregion, &nscal));
@@ -1237,6 +1280,17 @@ extern "C" int dlg_take_step(dlg_backend_t* b, int from, int to, double trustreg
   if(prepared_here) { b->pre_slot = -1; b->pre_held = -1; b->pre_split = false; if(b->type == DLG_SPARSE) sparse_release_held(b); } else DLG_CHECK(step_unprepare(b));
   bool prepared = prepared_here;
   b->pre_rejected = false;                     // (a step from a fresh point: the point before it was accepted)
+  DLG_CHECK(tail_guard(b));
+  b->tail_pending = false;
+  // Where p_new goes: a page-locked destination is written by the step's pass over J itself (K8, a slice per workgroup)
+  hipPointerAttribute_t p_attr;
+  const bool p_pinned = p_new_host && b->copy_stream && hipPointerGetAttributes(&p_attr, p_new_host) == hipSuccess && p_attr.type == hipMemoryTypeHost;
+  if(p_new_host && b->copy_stream && !p_pinned) (void)hipGetLastError();
+  const bool p_fold = p_pinned && b->type == DLG_SPARSE && b->host_finals && !b->sharded() && p_attr.devicePointer;
+  // K8 behind the decision point (dlg_backend_set_defer_tail): the step kernel is what the host waits for
+  const bool defer = b->defer_tail && b->type == DLG_SPARSE && b->host_finals && !b->sharded() &&
+                     (!p_new_host || p_fold) && !(b->prof_mask >> DLG_PROF_K3K8_NORM2JV & 1u) &&
+                     sparse_norm2_chunks(b) > 0 && dlg_tail_partials(b, sparse_norm2_chunks(b)) != nullptr;
   for(;;)
   {
     int good = 0, rc;
@@ -1285,20 +1339,52 @@ extern "C" int dlg_take_step(dlg_backend_t* b, int from, int to, double trustreg
     prepared = false; pre_split = false;
     DLG_CHECK(cauchy_deferred_finish(b, from));
     int nbg = 0;
+    if(!b->ev_fetch) DLG_HIP(hipEventCreateWithFlags(&b->ev_fetch, hipEventDisableTiming));
     {
       DlgProfScope ps(b, DLG_PROF_K7_STEP);
       DLG_CHECK(k_negate_interp1(b, F.gn, F.cauchy, b->N, b->d_gnpart, &nbg));      // dogleg.c:862-865, 964-972
-      DLG_CHECK(k_take_step(b, F.cauchy, F.gn, b->d_gnpart, nbg, n2c_dev, trustregion, F.p, T.step, T.p, b->N,
-                            b->d_scal, b->d_scal + 8, F.Jt_x, b->d_scal + 11));
+      if(defer)
+      {
+        // (the last kernel on the main stream: it takes the scalars to the host and carries the event the host waits for)
+        b->fold_scal_k7 = dlg_backend::NSCAL;
+        b->attach_stop = (b->ext_events && !(b->prof_mask >> DLG_PROF_K7_STEP & 1u)) ? b->ev_fetch : nullptr; b->stop_attached = false;
+      }
+      const int rc7 = k_take_step(b, F.cauchy, F.gn, b->d_gnpart, nbg, n2c_dev, trustregion, F.p, T.step, T.p, b->N,
+                                  b->d_scal, b->d_scal + 8, F.Jt_x, b->d_scal + 11);
+      b->fold_scal_k7 = 0; b->attach_stop = nullptr;
+      DLG_CHECK(rc7);
     }
     side_copy = false;
     b->fold_p_src = nullptr; b->p_copied = false;
+    if(defer && !b->scal_copied) { dlg_set_error("internal error: the step kernel did not take the scalars along"); return DLG_ERR_STATE; }
+    if(defer)
+    {
+      // K8 right behind the step kernel on the same stream -- but the host is already on its way back when it runs: its
+      // partial sums and p_new land in page-locked memory, the event rides on the launch (dlg_step_tail waits for it).
+      // (On the second stream beside the next evaluation it gained nothing: that evaluation's pass over J is bound by HBM
+      // as K8 is -- 131 + 0 us against 98 + 38 -- and the wait for the event between the queues cost 18 us.)
+      const bool k7_attached = b->stop_attached;
+      if(p_fold) { b->fold_p_src = T.p; b->fold_p_dst = (double*)p_attr.devicePointer; }
+      // No event of its own (a launch somebody listens to holds the next dispatch back by ~5 us): the evaluation that
+      // follows is waited for on this stream behind it -- dlg_step_tail only waits itself if nothing was (sync_mark).
+      b->tail_mode = true; b->fold_scal = 0; b->attach_stop = nullptr; b->stop_attached = false;
+      const int rct = sparse_norm2_Jv(b, from, T.step, b->d_scal + 12, b->d_scal + 8);
+      b->tail_mode = false;
+      b->fold_p_src = nullptr; b->p_copied = false;
+      DLG_CHECK(rct);
+      b->tail_pending = true;
+      b->stop_attached = k7_attached; b->scal_copied = true;
+      DLG_CHECK(step_finish(b, to, dlg_backend::NSCAL, nullptr));
+      b->tail_mark = b->sync_mark;              // (that wait was for the step kernel, in front of K8)
+      b->tail_inner = b->h_scal[11];
+    }
+    else
+    {
     if(p_new_host && b->copy_stream)
     {
-      hipPointerAttribute_t attr;
-      const bool pinned = hipPointerGetAttributes(&attr, p_new_host) == hipSuccess && attr.type == hipMemoryTypeHost;
-      if(!pinned) (void)hipGetLastError();
-      if(pinned && b->type == DLG_SPARSE && b->host_finals && !b->sharded() && attr.devicePointer)
+      const hipPointerAttribute_t& attr = p_attr;
+      const bool pinned = p_pinned;
+      if(p_fold)
       {
         // page-locked destination: the step's last kernel (K8) writes p_new there itself, a slice per
         // workgroup -- no event between the step kernel and K8 for a copy on the side stream to wait on
@@ -1314,7 +1400,6 @@ extern "C" int dlg_take_step(dlg_backend_t* b, int from, int to, double trustreg
       }
     }
     b->fold_scal = dlg_backend::NSCAL;       // (the last kernel of the step: it takes the scalars to the host with it)
-    if(!b->ev_fetch) DLG_HIP(hipEventCreateWithFlags(&b->ev_fetch, hipEventDisableTiming));
     b->attach_stop = (b->ext_events && !side_copy && !(b->prof_mask >> DLG_PROF_K3K8_NORM2JV & 1u)) ? b->ev_fetch : nullptr; b->stop_attached = false;   // ... and the event the host waits for
     int rc8;
     { DlgProfCond pc(b); rc8 = norm2_Jv(b, from, T.step, b->d_scal + 12, b->d_scal + 8); }   // the other half of the expected improvement (returns early behind a failed factorisation unless the step is the Cauchy step)
@@ -1325,6 +1410,7 @@ extern "C" int dlg_take_step(dlg_backend_t* b, int from, int to, double trustreg
     DLG_CHECK(rc8);
     DLG_CHECK(step_finish(b, to, dlg_backend::NSCAL, (side_copy || p_done) ? nullptr : p_new_host));   // the one synchronisation
     if(side_copy) DLG_HIP(hipEventSynchronize(b->ev_copy));
+    }
     if(b->profiling) dlg_prof_resolve(b);
     if(!F.have_cauchy) { F.norm2_cauchy = b->h_scal[6]; F.have_cauchy = true; }
     if((int)b->h_scal[8] == DLG_KIND_CAUCHY_TO_EDGE)
@@ -1339,7 +1425,7 @@ extern "C" int dlg_take_step(dlg_backend_t* b, int from, int to, double trustreg
       out7[3] = F.norm2_cauchy;                                 // unscaled: dogleg.c:1200
       out7[4] = NAN;
       out7[5] = b->h_scal[2];
-      out7[6] = -2.0*b->h_scal[11] - b->h_scal[12];             // dogleg.c:1107-1109
+      out7[6] = defer ? NAN : -2.0*b->h_scal[11] - b->h_scal[12];             // dogleg.c:1107-1109 (NaN: dlg_step_tail has it)
       if(b->profiling) dlg_prof_commit(b, b->type == DLG_SPARSE ? sparse_factor_ok(b) : dense_factor_ok(b));
       return DLG_OK;
     }
@@ -1361,7 +1447,7 @@ extern "C" int dlg_take_step(dlg_backend_t* b, int from, int to, double trustreg
   out7[3] = (kind == DLG_KIND_CAUCHY_TO_EDGE) ? F.norm2_cauchy : (kind == DLG_KIND_GAUSSNEWTON ? F.norm2_gn : b->h_scal[0]);
   out7[4] = b->h_scal[9];
   out7[5] = b->h_scal[2];
-  out7[6] = -2.0*b->h_scal[11] - b->h_scal[12];               // dogleg.c:1107-1109
+  out7[6] = defer ? NAN : -2.0*b->h_scal[11] - b->h_scal[12];               // dogleg.c:1107-1109 (NaN: dlg_step_tail has it)
   return DLG_OK;
 }
 
@@ -1377,15 +1463,19 @@ extern "C" int dlg_run_steps(dlg_backend_t* b, int from, int to, int nsteps, int
 {
   DLG_CHECK(check_slot(b, from)); DLG_CHECK(check_slot(b, to));
   if(nsteps < 0 || ncopy < 1 || !x_dev || !J_dev) { dlg_set_error("dlg_run_steps: bad arguments"); return DLG_ERR_ARG; }
-  double n2x = 0, gmax = 0, lam = lambda0, o[7] = {0, 0, 0, 0, 0, 0, 0};
+  double n2x = 0, gmax = 0, lam = lambda0, tail = 0, o[7] = {0, 0, 0, 0, 0, 0, 0};
   for(int i = 0; i < nsteps; i++)
   {
     const int c = (first_copy + i) % ncopy;
     DLG_CHECK(dlg_point_bind_device(b, from, x_dev[c], J_dev[c]));
     DLG_CHECK(dlg_point_eval(b, from, &n2x, &gmax));
+    // (dlg_backend_set_defer_tail: the expected improvement of the step before is fetched where the driver needs it --
+    // behind the evaluation of the trial point, dogleg.c:1410-1427; its pass over J ran beside that evaluation)
+    DLG_CHECK(dlg_step_tail(b, &tail));
     lam = lambda0;
     DLG_CHECK(dlg_take_step(b, from, to, trustregion, &lam, o, b->h_vec));      // p_new travels to the host (page-locked), as for the driver
   }
+  if(b->defer_tail && nsteps > 0) { DLG_CHECK(dlg_step_tail(b, &tail)); if(std::isnan(o[6])) o[6] = tail; }
   if(out9) { out9[0] = n2x; out9[1] = o[0]; out9[2] = o[1]; out9[3] = o[4]; out9[4] = o[3]; out9[5] = o[6]; out9[6] = gmax; out9[7] = o[5]; out9[8] = lam; }
   if(kind_out) *kind_out = (int)o[2];
   return DLG_OK;

@@ -141,6 +141,13 @@ __global__ void __launch_bounds__(TPB) k_potrf_diag_trsm(double* __restrict__ A,
 // Hand-offs as in the sparse one-launch regions: write-through stores, drained, then the flag;
 // consumers poll and read around L1; one workgroup per CU.
 typedef double dd_v4d __attribute__((ext_vector_type(4)));
+#ifdef DLG_POTRF_PROFILE
+// tools/potrf_prof.py: the diagonal owners' time line (tile (j, j) -> slot j)
+__device__ long long g_potrf_dbg[64*8];
+#define POTRF_STAMP(k) do { if(threadIdx.x == 0 && ti == tj && tj < 64) g_potrf_dbg[tj*8 + (k)] = wall_clock64(); } while(0)
+#else
+#define POTRF_STAMP(k)
+#endif
 __global__ void __launch_bounds__(TPB) k_potrf_tiles(double* A, int lda, int n, int T, int* __restrict__ info,
                                                      double* Linv, int* flags, int epoch, DlgHandoff ho, int self_x)
 {
@@ -175,6 +182,7 @@ __global__ void __launch_bounds__(TPB) k_potrf_tiles(double* A, int lda, int n, 
     ti = tj + rem;
   }
   const int row0 = NB*ti, col0 = NB*tj;
+  POTRF_STAMP(0);
   // the tile in accumulators: wave wv holds rows 16 wv .. 16 wv + 15, four 16-column pieces;
   // lane (jn, kq): column jn of a piece, rows kq + 4 r
   dd_v4d acc[4];
@@ -254,8 +262,10 @@ __global__ void __launch_bounds__(TPB) k_potrf_tiles(double* A, int lda, int n, 
   if(selfx)
   {
     // L(j, j-1) from the tile kept here and the inverse of the diagonal block to the left, then this tile's last update
+    POTRF_STAMP(1);
     if(t == 0) wait_flag(tj - 1, tj - 1);
     __syncthreads();
+    POTRF_STAMP(2);
     {
       const double* Lv = Linv + (size_t)(tj - 1)*NB*NB;
       for(int e = t; e < NB*NB; e += TPB)
@@ -269,6 +279,7 @@ __global__ void __launch_bounds__(TPB) k_potrf_tiles(double* A, int lda, int n, 
         for(int r = 0; r < 4; r++) Li[16*wv + kq + 4*r][16*ct + jn] = acc2[ct][r];
     }
     __syncthreads();
+    POTRF_STAMP(3);
     dd_v4d x[4];
 #pragma unroll
     for(int ct = 0; ct < 4; ct++) x[ct] = (dd_v4d){0.0, 0.0, 0.0, 0.0};
@@ -286,6 +297,7 @@ __global__ void __launch_bounds__(TPB) k_potrf_tiles(double* A, int lda, int n, 
 #pragma unroll
       for(int r = 0; r < 4; r++) Li[16*wv + kq + 4*r][16*ct + jn] = x[ct][r];
     __syncthreads();
+    POTRF_STAMP(4);
 #pragma unroll 4
     for(int kk = 0; kk < NB; kk += 4)
     {
@@ -312,7 +324,9 @@ __global__ void __launch_bounds__(TPB) k_potrf_tiles(double* A, int lda, int n, 
     for(int e = t; e < NB*NB; e += TPB) { const int i = e % NB, j = e / NB; P[NB + i + j*LD] = (i == j) ? 1.0 : 0.0; }
     if(t == 0) sbad = 0x7fffffff;
     __syncthreads();
+    POTRF_STAMP(5);
     panel_factor_b16<TPB>(P, LD, 2*NB, NB, t, &sbad, 0);
+    POTRF_STAMP(6);
     const int nb = min(NB, n - col0);
     if(t == 0) { const int bad = sbad; if(bad < nb) atomicCAS(info, 0, col0 + bad + 1); }
     double* Lv = Linv + (size_t)tj*NB*NB;
@@ -324,6 +338,7 @@ __global__ void __launch_bounds__(TPB) k_potrf_tiles(double* A, int lda, int n, 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if(t == 0) __hip_atomic_store(flags + tj*T + tj, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    POTRF_STAMP(7);
     for(int e = t; e < NB*NB; e += TPB)
     {
       const int i = e % NB, j = e / NB;
@@ -820,6 +835,17 @@ void dense_launch_trsv_tiles(hipStream_t st, const double* A, int lda, int n, co
   dlg_func_lds_once(attr, reinterpret_cast<const void*>(&k_trsv_tiles), LDSB);
   hipLaunchKernelGGL(k_trsv_tiles, dim3(T), dim3(TPB), LDSB, st, A, lda, n, T, Linv, rhs, Yh, X, Xh, epoch, ho);
 }
+#ifdef DLG_POTRF_PROFILE
+extern "C" void dlg_potrf_profile_dump(int T)
+{
+  long long h[64*8];
+  if(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_potrf_dbg), sizeof(h)) != hipSuccess) return;
+  const long long t0 = h[0];
+  for(int i = 0; i < T && i < 64; i++)
+    fprintf(stderr, "  potrf diag %2d: start %6lld | updates k < j-1 done, waits for inv(j-1) at %6lld, has it %6lld, staged %6lld, L(j,j-1) formed %6lld | sweep from %6lld to %6lld, inverse published %6lld\n",
+            i, h[i*8] - t0, h[i*8+1] - t0, h[i*8+2] - t0, h[i*8+3] - t0, h[i*8+4] - t0, h[i*8+5] - t0, h[i*8+6] - t0, h[i*8+7] - t0);
+}
+#endif
 #ifdef DLG_TRSV_PROFILE
 extern "C" void dlg_trsv_profile_dump(int T)
 {

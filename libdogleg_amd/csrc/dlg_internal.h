@@ -88,6 +88,17 @@ struct dlg_backend
   const double* fold_p_src = nullptr; double* fold_p_dst = nullptr; bool p_copied = false;   // ... and p_new to a page-locked destination
   int* fork_gate = nullptr; int fork_gate_epoch = 0;      // dlg_fork_gate
   int fold_scal = 0; bool scal_copied = false;   // dlg_take_step: its last kernel (K8-sparse) copies d_scal to h_scal itself
+  // The expected improvement's pass over J (K8) behind the host's decision point (dlg_backend_set_defer_tail): the value is
+  // first used after the NEXT evaluation (dogleg.c:1427 -- takeStepFrom only needs max|step| to tell "done", 1289-1296), so
+  // dlg_take_step's synchronisation rides on the step kernel (fold_scal_k7: it takes the scalars to the host), K8 follows on
+  // the same stream while the host is on its way back, its partial sums (and p_new) land in page-locked memory and
+  // dlg_step_tail adds them up -- behind a wait of its own only if the host has not waited for anything enqueued behind K8
+  // since (sync_mark against tail_mark: the evaluation of the trial point is such a wait).
+  bool defer_tail = false, tail_pending = false, tail_mode = false;
+  int fold_scal_k7 = 0, tail_nb = 0;
+  double tail_inner = 0.0, tail_value = 0.0;
+  double* h_tail = nullptr; int h_tail_cap = 0;
+  unsigned long sync_mark = 0, tail_mark = 0;
   static constexpr int NSCAL = 16;
   // hand-offs inside the one-launch regions (flags between workgroups): a wait that gives up raises a bit in
   // the status word (slot NSCAL - 2 of the scalar block, so it travels with every fetch of the scalars);
@@ -99,7 +110,7 @@ struct dlg_backend
   {
     bool join_event = false;
     bool no_k3_fork = false, no_potrf_fuse = false, potrf_steps = false,
-         trsv_steps = false, no_touch = false, no_abandon = false, no_split = false, no_reject_run = false;
+         trsv_steps = false, no_touch = false, no_abandon = false, no_split = false, no_reject_run = false, no_defer_tail = false;
     int touch_wg = 512;
   } knobs;
   int ncu = 256;              // compute units of b->device
@@ -284,6 +295,7 @@ int k_reduce_sum(dlg_backend* b, const double* partials, int np, double* out);
 // region of b->h_part for (nsum + nmax) x nb partials whose results go to h_scal[out - d_scal + k*stride],
 // or nullptr: the result is wanted on the device / no room -> the caller launches the second stage
 double* dlg_host_partials(dlg_backend* b, const double* out, int nb, int nsum, int nmax, int stride);
+double* dlg_tail_partials(dlg_backend* b, int nb);      // page-locked room for the partial sums of a K8 behind the decision point (dlg_step_tail adds them)
 void dlg_resolve_pending(dlg_backend* b);
 int dlg_ensure_partials(dlg_backend* b, size_t ndoubles);
 
@@ -329,6 +341,7 @@ int sparse_norm2_Jv(dlg_backend* b, int slot, const double* v, double* out_dev, 
 int sparse_factorize(dlg_backend* b, int slot, double lambda, int* ok);          // K4+K5 (b->factor_ahead: K5 up to the leaf level only, sparse_factorize_rest owes the rest)
 int sparse_factorize_rest(dlg_backend* b, bool* was_pending);
 bool sparse_factor_pending(const dlg_backend* b);                     // the levels above the leaves of a factorisation enqueued ahead
+int sparse_norm2_chunks(const dlg_backend* b);
 bool sparse_factor_ok(const dlg_backend* b);     // pivot flag of the last factorisation (after a sync)
 int sparse_solve(dlg_backend* b, const double* rhs, double* out);                // K6
 void sparse_hold_factor(dlg_backend* b);

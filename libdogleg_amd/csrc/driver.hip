@@ -87,6 +87,7 @@ struct Driver
   bool pattern_owned;                          // device solve: Jt->p / Jt->i of the points are copies (a returned context), not the caller's arrays
   bool be_reused;                              // the backend served an earlier solve (take_parked)
   bool expect_gn;                              // the last step needed the Gauss-Newton step: issue it with the Cauchy step
+  bool tail_out;                               // the expected improvement of the step just taken is still on its way (dlg_step_tail)
   bool failed;                                 // a backend op failed during the solve: the backend is not kept
   bool sharded;                                // this solve is one rank of several (subtree partition / row shard + all-reduces)
   int rank, nranks, row0, row1;                // its rank; dense: the contiguous rows it holds
@@ -432,6 +433,9 @@ bool eval_point(bool* converged, dogleg_operatingPoint_t* pt, Driver* d)
       if(!be_ok(dlg_point_bind_device(d->be, s, x_dev + r0, J_dev + r0*(size_t)ctx->Nstate), "bind")) return false;
     }
     if(ctx->solve_type == DOGLEG_SPARSE) dlg_backend_set_speculation(d->be, d->expect_gn);
+    // the model lives on the device: nothing on the host waits for p_new, and the expected improvement of a step is first
+    // used behind the evaluation of its trial point (dogleg.c:1427) -- its pass over J runs beside this evaluation
+    if(ctx->solve_type == DOGLEG_SPARSE && !d->sharded) dlg_backend_set_defer_tail(d->be, 1);
     { Tick te(d, TM_EVAL); if(!be_ok(dlg_point_eval(d->be, s, &norm2x, &absmax), "Jt*x")) return false; }
     pt->norm2_x = norm2x;
     pt->have_x = pt->have_J = pt->have_Jtx = true;
@@ -629,6 +633,7 @@ bool take_step(double* expectedImprovement, dogleg_operatingPoint_t* to,
     d->cur.norm2_cauchy = o[0];
     VERBOSE(d, "cauchy step length %.6g", sqrt(o[0]));
     kind = (int)o[2]; n2 = o[3]; k = o[4]; amax = o[5]; *expectedImprovement = o[6];
+    d->tail_out = std::isnan(o[6]);          // (dlg_backend_set_defer_tail: run_optimizer fetches it behind the evaluation)
     if(kind != DLG_KIND_CAUCHY_TO_EDGE)
     {
       // (on the Cauchy branch the backend dropped its speculative factor and GN step and left
@@ -685,6 +690,13 @@ bool take_step(double* expectedImprovement, dogleg_operatingPoint_t* to,
   // dogleg.c:1289-1296: every |step_i| <= update_threshold -> signal termination
   if(!(amax > ctx->parameters->update_threshold))
   {
+    if(d->tail_out)
+    {
+      // (no evaluation follows: the record of the terminal step still carries the computed value)
+      d->tail_out = false;
+      if(!be_ok(dlg_step_tail(d->be, expectedImprovement), "expected improvement")) return false;
+      d->cur.expected_improvement = *expectedImprovement;
+    }
     VERBOSE(d, "update small enough: done");
     *expectedImprovement = -1.0;
   }
@@ -747,6 +759,13 @@ int run_optimizer(Driver* d)
       if(!eval_point(&afterZeroGradient, ctx->afterStep, d)) return -1;
       VERBOSE(d, "evaluated operating point with norm2_x %.6g", ctx->afterStep->norm2_x);
       d->cur.norm2x_after = ctx->afterStep->norm2_x;
+      if(d->tail_out)
+      {
+        d->tail_out = false;
+        Tick tt(d, TM_STEP);
+        if(!be_ok(dlg_step_tail(d->be, &expectedImprovement), "expected improvement")) return -1;
+        d->cur.expected_improvement = expectedImprovement;
+      }
 
       bool accept;
       if(!evaluate_step(&accept, &trustregion, ctx->beforeStep, ctx->afterStep, expectedImprovement, d))

@@ -202,7 +202,8 @@ __global__ void __launch_bounds__(TPB) k_part_take_step(const double* __restrict
                                                         double* __restrict__ part,
                                                         double* __restrict__ out3,
                                                         const double* __restrict__ g,
-                                                        double* __restrict__ gpart)
+                                                        double* __restrict__ gpart,
+                                                        const double* __restrict__ dsc, double* __restrict__ hsc, int nsc)
 {
   __shared__ double sh[4];
   __shared__ double s_l2, s_negc, s_n2g;
@@ -257,6 +258,14 @@ __global__ void __launch_bounds__(TPB) k_part_take_step(const double* __restrict
   const double Gs = block_sum(gs, sh);
   if(threadIdx.x == 0) { part[blockIdx.x] = S; part[gridDim.x + blockIdx.x] = Mx; gpart[blockIdx.x] = Gs; }
   if(blockIdx.x == 0 && threadIdx.x == 0) { out3[0] = (double)kind; out3[1] = (kind == 2) ? k : NAN; out3[2] = n2g; }
+  // the step's last kernel on the main stream (K8 follows on the second one, dlg_step_tail): the device scalars of the
+  // step -- written by the kernels before this one, and out3 from here -- go to the page-locked host array with it
+  if(dsc && blockIdx.x == 0 && (int)threadIdx.x < nsc)
+  {
+    const double* o3 = out3;
+    const int t = threadIdx.x, d = (int)(o3 - dsc);
+    hsc[t] = (t == d) ? (double)kind : (t == d + 1) ? ((kind == 2) ? k : NAN) : (t == d + 2) ? n2g : dsc[t];
+  }
 }
 
 // gn = -u with the partials of |gn|^2, and pass 1 of the interpolation (l2, neg_c of cauchy vs. gn)
@@ -316,6 +325,18 @@ double* dlg_host_partials(dlg_backend* b, const double* out, int nb, int nsum, i
   b->pending.push_back({b->h_part_used, nb, nsum, nmax, (int)(out - b->d_scal), stride});
   b->h_part_used += need;
   return region;
+}
+double* dlg_tail_partials(dlg_backend* b, int nb)
+{
+  if(nb > b->h_tail_cap)
+  {
+    if(b->h_tail) (void)hipHostFree(b->h_tail);
+    b->h_tail = nullptr; b->h_tail_cap = 0;
+    if(hipHostMalloc((void**)&b->h_tail, sizeof(double)*(size_t)nb, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    b->h_tail_cap = nb;
+  }
+  b->tail_nb = nb;
+  return b->h_tail;
 }
 void dlg_resolve_pending(dlg_backend* b)
 {
@@ -481,8 +502,13 @@ int k_take_step(dlg_backend* b, const double* cauchy, const double* gn, const do
   double* hp = dlg_host_partials(b, out_n2_max, g, 1, 1, 2);
   double* hg = hp ? dlg_host_partials(b, out_inner, g, 1, 0, 1) : nullptr;
   double* gp = hg ? hg : b->d_part + 4*MAXB;
-  hipLaunchKernelGGL(k_part_take_step, dim3(g), dim3(TPB), 0, b->stream, cauchy, gn, b->d_part, g, gnpart, nbg,
-                     n2c_dev, trustregion, p, step, p_new, n, hp ? hp : part2, out3, Jtx, gp);
+  // (fold_scal_k7: this is the launch the host waits for -- it takes the scalars along and carries the event)
+  const bool fold = hp && hg && b->fold_scal_k7 > 0 && b->fold_scal_k7 <= TPB && b->h_scal && out3 >= b->d_scal && out3 + 3 <= b->d_scal + b->fold_scal_k7;
+  if(!fold) b->attach_stop = nullptr;
+  DLG_LAUNCH_LAST(b, k_part_take_step, dim3(g), dim3(TPB), 0, b->stream, cauchy, gn, (const double*)b->d_part, g, gnpart, nbg,
+                  n2c_dev, trustregion, p, step, p_new, n, hp ? hp : part2, out3, Jtx, gp,
+                  fold ? (const double*)b->d_scal : (const double*)nullptr, b->h_scal, fold ? b->fold_scal_k7 : 0);
+  if(fold) b->scal_copied = true;
   if(!hp) hipLaunchKernelGGL(k_final, dim3(1), dim3(TPB), 0, b->stream, part2, g, 1, 1, out_n2_max, 2);
   if(!hg) hipLaunchKernelGGL(k_final, dim3(1), dim3(TPB), 0, b->stream, gp, g, 1, 0, out_inner, 1);
   DLG_LAUNCH_CHECK();

@@ -987,16 +987,17 @@ int sparse_norm2_Jv(dlg_backend* b, int s, const double* v, double* out_dev, con
   // K8 inside dlg_take_step: only the host reads the sum -- the workgroups' partial sums go straight to
   // pinned host memory and are added there behind the step's one synchronisation (no second-stage launch)
   if(kind_if_factor_failed)
-    if(double* hp = dlg_host_partials(b, out_dev, g, 1, 0, 1))
+    if(double* hp = b->tail_mode ? dlg_tail_partials(b, g) : dlg_host_partials(b, out_dev, g, 1, 0, 1))
     {
       const bool fold = b->fold_scal > 0 && b->fold_scal <= TPB && b->h_scal;
       if(!fold) b->attach_stop = nullptr;
       DLG_LAUNCH_LAST(b, k_norm2_Jv, dim3(g), dim3(TPB), 0, b->stream, Y->nv_chunk, Y->Jp, Y->Ji, S.Jin(), v, hp,
                       (const int*)Y->d_info, kind_if_factor_failed, (int)Y->nnz_loc,
                       fold ? (const double*)b->d_scal : (const double*)nullptr, b->h_scal, (int)b->fold_scal,
-                      fold ? b->fold_p_src : (const double*)nullptr, b->fold_p_dst, (int)b->N);
+                      (fold || b->tail_mode) ? b->fold_p_src : (const double*)nullptr, b->fold_p_dst, (int)b->N);
       DLG_LAUNCH_CHECK();
-      if(fold) { b->scal_copied = true; b->p_copied = b->fold_p_src != nullptr; }
+      if(fold) b->scal_copied = true;
+      if(fold || b->tail_mode) b->p_copied = b->fold_p_src != nullptr;
       return DLG_OK;
     }
   DLG_CHECK(dlg_ensure_partials(b, 5120 + (size_t)g));

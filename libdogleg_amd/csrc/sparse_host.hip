@@ -515,6 +515,7 @@ int sparse_factorize(dlg_backend* b, int s, double lambda, int* ok)
   return DLG_OK;
 }
 bool sparse_factor_pending(const dlg_backend* b) { return b->sym && b->sym->fac_pending; }
+int sparse_norm2_chunks(const dlg_backend* b) { return b->sym ? b->sym->n_nv_chunks : 0; }      // workgroups (= partial sums) of K3 / K8
 // the levels above the leaves of a factorisation whose leaf level was enqueued ahead (sparse_factor_levels(b, 1))
 int sparse_factorize_rest(dlg_backend* b, bool* was_pending)
 {

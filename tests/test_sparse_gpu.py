@@ -950,3 +950,69 @@ def test_fin_on_the_side_changes_no_bit(gpu, shape, monkeypatch):
         assert a[0] == b[0] and a[1] == b[1]
         assert all(ka == kb and (va == vb or (va != va and vb != vb)) for (ka, va), (kb, vb) in zip(a[2], b[2]))
         assert np.array_equal(a[3], b[3]) and np.array_equal(a[4], b[4]) and np.array_equal(a[5], b[5])
+
+
+@pytest.mark.parametrize("shape,trf", [((49, 900, 10000), 0.6), ((199, 3600, 40000), 0.6), ((49, 900, 10000), 1e-3), ((49, 900, 10000), 1e3)])
+def test_the_expected_improvement_behind_the_decision_point_is_the_same_number(gpu, shape, trf):
+    """dlg_backend_set_defer_tail: dlg_take_step returns before the pass over J that forms |J step|^2 (NaN in the place of
+    the expected improvement), the pass runs on the second stream beside the next evaluation and dlg_step_tail hands the
+    value out -- the reference first uses it behind the evaluation of the trial point (dogleg.c:1410-1427).  Same
+    partial sums in the same order: the value, p_new and everything else of the step bit for bit the in-line form's,
+    for interpolated steps, Cauchy steps to the edge (trf small) and Gauss-Newton steps (trf large); the tail fetched at
+    once, behind the next evaluation (as the driver does), and through dlg_run_steps."""
+    prob = oa.BAProblem(*shape, seed=8)
+    Jp, Ji = prob.pattern()
+    p = prob.p0()
+    evals = [prob.eval(p + 0.002*k) for k in range(3)]
+
+    def run(defer, late):
+        be = capi.Backend(capi.DLG_SPARSE, prob.N, prob.M, prob.nnz)
+        be.set_pattern(Jp, Ji)
+        be.set_speculation(True)
+        be.set_p(0, p)
+        be.upload(0, *evals[0])
+        be.eval(0)
+        lam, n2c, n2g = be.cauchy_gauss_newton(0, 0.0)
+        tr = trf * (np.sqrt(n2c) + np.sqrt(n2g))
+        be.set_defer_tail(defer)
+        res = []
+        d_x = [capi.DeviceArray(np.ascontiguousarray(e[0])) for e in evals]
+        d_J = [capi.DeviceArray(np.ascontiguousarray(e[1])) for e in evals]
+        pend = None
+        for rep in range(9):
+            be.bind_device(0, d_x[rep % 3].ptr, d_J[rep % 3].ptr)
+            n2x, gmax = be.eval(0)
+            if pend is not None:
+                pend["ei"] = be.step_tail()           # (behind the next evaluation: where the driver needs it)
+                pend = None
+            lam, r, pn = be.take_step(0, 1, tr, 0.0, tail=not late)
+            if defer and late:
+                assert r["ei"] != r["ei"]
+                pend = r
+            # (the page-locked p_new buffer is one per backend and complete behind the tail: in the late form only the last
+            # step's is looked at)
+            res.append([n2x, gmax, r, None if (defer and late) else pn.copy(), be.download(1, capi.VEC_STEP)])
+        if pend is not None:
+            pend["ei"] = be.step_tail()
+            res[-1][3] = pn.copy()
+        rs, kd = be.run_steps(0, 1, 4, [d.ptr for d in d_x], [d.ptr for d in d_J], 0, tr, 0.0)
+        be.close()
+        return res, rs, kd
+    want, rs_w, kd_w = run(False, False)
+    kinds = {q[2]["kind"] for q in want}
+    for late in (False, True):
+        got, rs_g, kd_g = run(True, late)
+        for i, (a, b) in enumerate(zip(got, want)):
+            assert a[0] == b[0] and a[1] == b[1]
+            assert a[2].keys() == b[2].keys()
+            for k in a[2]:
+                va, vb = a[2][k], b[2][k]
+                assert va == vb or (va != va and vb != vb), (late, i, k, va, vb)
+            assert np.isfinite(a[2]["ei"])
+            assert np.array_equal(a[4], b[4])
+            if not late or i == len(want) - 1:
+                assert np.array_equal(a[3], b[3])
+        assert kd_g == kd_w
+        for k in rs_w:
+            assert rs_g[k] == rs_w[k] or (rs_g[k] != rs_g[k] and rs_w[k] != rs_w[k]), (k, rs_g[k], rs_w[k])
+    print("kinds of step seen:", kinds)
