@@ -183,6 +183,12 @@ __global__ void __launch_bounds__(TPB) k_potrf_tiles(double* A, int lda, int n, 
   }
   const int row0 = NB*ti, col0 = NB*tj;
   POTRF_STAMP(0);
+  // (the panel [A; I] of a diagonal tile's sweep has LDS of its own behind the two staging tiles: its identity half is
+  // written here, long before the tile is complete, and the tile goes there straight from the accumulators)
+  double* P = sm + 2*NB*LDT;
+  constexpr int LD = 2*NB;
+  if(ti == tj)
+    for(int e = t; e < NB*NB; e += TPB) { const int i = e % NB, j = e / NB; P[NB + i + j*LD] = (i == j) ? 1.0 : 0.0; }
   // the tile in accumulators: wave wv holds rows 16 wv .. 16 wv + 15, four 16-column pieces;
   // lane (jn, kq): column jn of a piece, rows kq + 4 r
   dd_v4d acc[4];
@@ -202,13 +208,31 @@ __global__ void __launch_bounds__(TPB) k_potrf_tiles(double* A, int lda, int n, 
     { __builtin_amdgcn_s_sleep(1); if(++spins > ho.spins) { atomicOr(ho.status, DLG_HANDOFF_POTRF); break; } }     // its own status word: not a pivot
   };
   // a published 64 x 64 block of L (rows r0.., columns c0..) into LDS, read around L1; past the end: zeros
+  // (thread t: row t % 64 of the columns t / 64 + 4 u -- all sixteen loads on their way before the first is used)
   auto stage = [&](double (*D)[LDT], int r0, int c0) {
-    for(int e = t; e < NB*NB; e += TPB)
+    const int i = t & (NB - 1), row = r0 + i;
+    double v[NB*NB/TPB];
+#pragma unroll
+    for(int u = 0; u < NB*NB/TPB; u++)
     {
-      const int i = e % NB, k = e / NB;
-      const int row = r0 + i, col = c0 + k;
-      D[i][k] = (row < n && col < n) ? __hip_atomic_load((gcd_t)(A + (size_t)col*lda + row), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+      const int col = c0 + (t >> 6) + (TPB/NB)*u;
+      v[u] = (row < n && col < n) ? __hip_atomic_load((gcd_t)(A + (size_t)col*lda + row), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
     }
+#pragma unroll
+    for(int u = 0; u < NB*NB/TPB; u++) D[i][(t >> 6) + (TPB/NB)*u] = v[u];
+  };
+  // the published inverse of a diagonal block (lower triangular: only that half travels)
+  auto stage_inv = [&](double (*D)[LDT], const double* Lv) {
+    const int i = t & (NB - 1);
+    double v[NB*NB/TPB];
+#pragma unroll
+    for(int u = 0; u < NB*NB/TPB; u++)
+    {
+      const int k = (t >> 6) + (TPB/NB)*u;
+      v[u] = (i >= k) ? __hip_atomic_load((gcd_t)(Lv + k*NB + i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+    }
+#pragma unroll
+    for(int u = 0; u < NB*NB/TPB; u++) D[i][(t >> 6) + (TPB/NB)*u] = v[u];
   };
   // self_x: the owner of a diagonal tile (j, j) also keeps the tile to its left, (j, j - 1), up to date and forms
   // L(j, j-1) = tile * inv(L(j-1, j-1))' ITSELF once that inverse is published -- what lies between the factorisation of
@@ -267,12 +291,7 @@ __global__ void __launch_bounds__(TPB) k_potrf_tiles(double* A, int lda, int n, 
     __syncthreads();
     POTRF_STAMP(2);
     {
-      const double* Lv = Linv + (size_t)(tj - 1)*NB*NB;
-      for(int e = t; e < NB*NB; e += TPB)
-      {
-        const int i = e % NB, k = e / NB;
-        Lj[i][k] = __hip_atomic_load((gcd_t)(Lv + e), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
+      stage_inv(Lj, Linv + (size_t)(tj - 1)*NB*NB);
 #pragma unroll
       for(int ct = 0; ct < 4; ct++)
 #pragma unroll
@@ -283,13 +302,14 @@ __global__ void __launch_bounds__(TPB) k_potrf_tiles(double* A, int lda, int n, 
     dd_v4d x[4];
 #pragma unroll
     for(int ct = 0; ct < 4; ct++) x[ct] = (dd_v4d){0.0, 0.0, 0.0, 0.0};
-#pragma unroll 4
+    // (the inverse is lower triangular: columns 16 ct .. of the product take k < 16 (ct + 1) only -- 40 products, not 64)
+#pragma unroll
     for(int kk = 0; kk < NB; kk += 4)
     {
       const double a = Li[16*wv + jn][kk + kq];
 #pragma unroll
       for(int ct = 0; ct < 4; ct++)
-        x[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Lj[16*ct + jn][kk + kq], x[ct], 0, 0, 0);
+        if(kk < 16*(ct + 1)) x[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Lj[16*ct + jn][kk + kq], x[ct], 0, 0, 0);
     }
     __syncthreads();
 #pragma unroll
@@ -306,13 +326,10 @@ __global__ void __launch_bounds__(TPB) k_potrf_tiles(double* A, int lda, int n, 
       for(int ct = 0; ct < 4; ct++)
         acc[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, -Li[16*ct + jn][kk + kq], acc[ct], 0, 0, 0);
     }
-    __syncthreads();
   }
   if(ti == tj)
   {
     // the diagonal tile: [A; I] -> [L; L^-T] in one panel sweep (as k_potrf_diag_inv)
-    double* P = sm;
-    constexpr int LD = 2*NB;
 #pragma unroll
     for(int ct = 0; ct < 4; ct++)
 #pragma unroll
@@ -321,7 +338,6 @@ __global__ void __launch_bounds__(TPB) k_potrf_tiles(double* A, int lda, int n, 
         const int i = 16*wv + kq + 4*r, j = 16*ct + jn;
         P[i + j*LD] = (i >= j) ? acc[ct][r] : 0.0;
       }
-    for(int e = t; e < NB*NB; e += TPB) { const int i = e % NB, j = e / NB; P[NB + i + j*LD] = (i == j) ? 1.0 : 0.0; }
     if(t == 0) sbad = 0x7fffffff;
     __syncthreads();
     POTRF_STAMP(5);
@@ -330,10 +346,20 @@ __global__ void __launch_bounds__(TPB) k_potrf_tiles(double* A, int lda, int n, 
     const int nb = min(NB, n - col0);
     if(t == 0) { const int bad = sbad; if(bad < nb) atomicCAS(info, 0, col0 + bad + 1); }
     double* Lv = Linv + (size_t)tj*NB*NB;
-    for(int e = t; e < NB*NB; e += TPB)
+    // Linv(i, j) = P[NB + j + i*LD]: a row of the inverse is a column of the panel.  Read along the panel's columns
+    // (lanes over j: no bank conflict; lanes over i, LD = 128 apart, all hit ONE bank) into a staging tile, stored from
+    // there with lanes over i (coalesced).  Above the diagonal the buffer holds zeros from its allocation on.
     {
-      const int i = e % NB, j = e / NB;
-      __hip_atomic_store((gd_t)(Lv + e), (i >= j) ? P[NB + j + i*LD] : 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int l = t & (NB - 1);
+#pragma unroll
+      for(int u = 0; u < NB*NB/TPB; u++) { const int i = (t >> 6) + (TPB/NB)*u; Li[l][i] = P[NB + l + i*LD]; }      // Li[j][i] = Linv(i, j)
+      __syncthreads();
+#pragma unroll
+      for(int u = 0; u < NB*NB/TPB; u++)
+      {
+        const int j = (t >> 6) + (TPB/NB)*u;
+        if(l >= j) __hip_atomic_store((gd_t)(Lv + j*NB + l), Li[j][l], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -350,12 +376,7 @@ __global__ void __launch_bounds__(TPB) k_potrf_tiles(double* A, int lda, int n, 
   if(t == 0) wait_flag(tj, tj);
   __syncthreads();
   {
-    const double* Lv = Linv + (size_t)tj*NB*NB;
-    for(int e = t; e < NB*NB; e += TPB)
-    {
-      const int i = e % NB, k = e / NB;                                 // Linv(i, k), zero above the diagonal
-      Lj[i][k] = __hip_atomic_load((gcd_t)(Lv + e), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    stage_inv(Lj, Linv + (size_t)tj*NB*NB);
 #pragma unroll
     for(int ct = 0; ct < 4; ct++)
 #pragma unroll
@@ -365,13 +386,13 @@ __global__ void __launch_bounds__(TPB) k_potrf_tiles(double* A, int lda, int n, 
   dd_v4d x[4];
 #pragma unroll
   for(int ct = 0; ct < 4; ct++) x[ct] = (dd_v4d){0.0, 0.0, 0.0, 0.0};
-#pragma unroll 4
+#pragma unroll
   for(int kk = 0; kk < NB; kk += 4)
   {
     const double a = Li[16*wv + jn][kk + kq];
 #pragma unroll
     for(int ct = 0; ct < 4; ct++)
-      x[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Lj[16*ct + jn][kk + kq], x[ct], 0, 0, 0);
+      if(kk < 16*(ct + 1)) x[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Lj[16*ct + jn][kk + kq], x[ct], 0, 0, 0);
   }
   // (the diagonal owner of this block row keeps the original of this tile up to date itself, self_x: it must have read it)
   if(self_x && ti == tj + 1)
@@ -868,7 +889,7 @@ void dense_trsv_arm(hipStream_t st, double* Yh, double* Xh, size_t n_each)
 void dense_launch_potrf_tiles(hipStream_t st, double* A, int lda, int n, int* info_dev, double* Linv, int* flags, int epoch, const DlgHandoff& ho)
 {
   static bool attr[DLG_MAX_DEV] = {};       // a function attribute is a property of (function, device)
-  constexpr int LDSB = 88*1024;           // > half of the CU's LDS: one workgroup per CU
+  constexpr int LDSB = (2*NB*(NB + 1) + 2*NB*NB)*8;      // two staging tiles + the panel [A; I] of a diagonal tile (130 KB: one workgroup per CU)
   dlg_func_lds_once(attr, reinterpret_cast<const void*>(&k_potrf_tiles), LDSB);
   const int T = (n + NB - 1)/NB;
   const int self_x = getenv("DOGLEG_AMD_NO_POTRF_SELF") ? 0 : 1;      // (the form of rounds 2 - 3: every block of L comes from its owner)

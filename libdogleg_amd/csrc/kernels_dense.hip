@@ -776,6 +776,7 @@ int dense_create(dlg_backend* b)
   DLG_HIP(hipMalloc(&b->d_info, sizeof(int)));
   DLG_HIP(hipHostMalloc(&b->h_info, sizeof(int)));
   DLG_HIP(hipMalloc(&b->Linv, sizeof(double)*(size_t)dlg_cdiv(b->N, NB)*NB*NB));
+  DLG_HIP(hipMemset(b->Linv, 0, sizeof(double)*(size_t)dlg_cdiv(b->N, NB)*NB*NB));      // (k_potrf_tiles stores the lower triangles only)
   return DLG_OK;
 }
 void dense_destroy(dlg_backend* b)

@@ -14,6 +14,9 @@ __shared__ long long s_pf[16];
 #define DLG_PF_DONE if(threadIdx.x == 0 && g_pf_out) { for(int _i = 0; _i < 12; _i++) g_pf_out[_i] = s_pf[_i]; }
 __device__ long long g_evt[64*8];
 #define DLG_PF_EVT(J, e) do { if((threadIdx.x & 63) == 0 && blockIdx.x == 0) g_evt[(J)*8 + (e)] = clock64(); } while(0)
+#ifndef BP_LDP_EXTRA
+#define BP_LDP_EXTRA 0      // -DBP_LDP_EXTRA=16: the leading dimension of the LDS panel padded (bank layout experiments)
+#endif
 #include "../../libdogleg_amd/csrc/panel_factor.h"
 
 __device__ int g_mcol[256];
@@ -23,7 +26,7 @@ __global__ void __launch_bounds__(NT) k_panel(double* G, int nrows, int w, int* 
   extern __shared__ __attribute__((aligned(16))) double P[];
   double* g = G + (size_t)blockIdx.x*nrows*w;
   const int tid = threadIdx.x;
-  const int ldp = (nrows + 1) & ~1;
+  const int ldp = ((nrows + 1) & ~1) + BP_LDP_EXTRA;
   long long t0 = clock64();
   for(int base = 0; base < nrows*w; base += 8*NT)
   {
@@ -59,7 +62,7 @@ void run(int nrows, int w, int G, int iters)
         h[b*n + i + (size_t)j*nrows] = (i == j) ? (double)(w + 1) : ((i < w && i < j) ? (getenv("DLG_PF_UPPER_NAN") ? NAN : 0.0) : 0.3*sin(0.37*i + 1.3*j));
   double* d; int* info; long long* st;
   hipMalloc(&d, n*G*8); hipMalloc(&info, 4); hipMalloc(&st, 256);
-  const int lds = (int)(((nrows + 1) & ~1)*w*8);
+  const int lds = (int)((((nrows + 1) & ~1) + BP_LDP_EXTRA)*w*8);
   hipFuncSetAttribute(reinterpret_cast<const void*>(&k_panel<NT, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   float best = 1e9;
