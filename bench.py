@@ -211,6 +211,8 @@ def main():
         # the last step's tail is waited for inside the timed region.  DOGLEG_AMD_NO_DEFER_TAIL=1: K8 in line, as in rounds 1-4
         if not use_dist and not logical:
             be.set_defer_tail(True)
+    elif kind == "dense" and not use_dist and not logical:
+        be.set_defer_tail(True)         # (the same for the dense pass: K8 and p_new behind the step kernel the host waits for)
     res = one_step()
     for _ in range(args.warmup):
         res = one_step()

@@ -1286,11 +1286,14 @@ extern "C" int dlg_take_step(dlg_backend_t* b, int from, int to, double trustreg
   hipPointerAttribute_t p_attr;
   const bool p_pinned = p_new_host && b->copy_stream && hipPointerGetAttributes(&p_attr, p_new_host) == hipSuccess && p_attr.type == hipMemoryTypeHost;
   if(p_new_host && b->copy_stream && !p_pinned) (void)hipGetLastError();
-  const bool p_fold = p_pinned && b->type == DLG_SPARSE && b->host_finals && !b->sharded() && p_attr.devicePointer;
+  const bool p_foldable = p_pinned && b->host_finals && !b->sharded() && p_attr.devicePointer;
   // K8 behind the decision point (dlg_backend_set_defer_tail): the step kernel is what the host waits for
-  const bool defer = b->defer_tail && b->type == DLG_SPARSE && b->host_finals && !b->sharded() &&
-                     (!p_new_host || p_fold) && !(b->prof_mask >> DLG_PROF_K3K8_NORM2JV & 1u) &&
-                     sparse_norm2_chunks(b) > 0 && dlg_tail_partials(b, sparse_norm2_chunks(b)) != nullptr;
+  const int tail_chunks = b->type == DLG_SPARSE ? sparse_norm2_chunks(b) : (b->type == DLG_DENSE ? dense_norm2_chunks(b) : 0);
+  const bool defer = b->defer_tail && b->host_finals && !b->sharded() &&
+                     (!p_new_host || p_foldable) && !(b->prof_mask >> DLG_PROF_K3K8_NORM2JV & 1u) &&
+                     tail_chunks > 0 && dlg_tail_partials(b, tail_chunks) != nullptr;
+  // (the dense pass over J takes p_new along only in that form)
+  const bool p_fold = p_foldable && (b->type == DLG_SPARSE || (b->type == DLG_DENSE && defer));
   for(;;)
   {
     int good = 0, rc;
@@ -1368,7 +1371,8 @@ extern "C" int dlg_take_step(dlg_backend_t* b, int from, int to, double trustreg
       // No event of its own (a launch somebody listens to holds the next dispatch back by ~5 us): the evaluation that
       // follows is waited for on this stream behind it -- dlg_step_tail only waits itself if nothing was (sync_mark).
       b->tail_mode = true; b->fold_scal = 0; b->attach_stop = nullptr; b->stop_attached = false;
-      const int rct = sparse_norm2_Jv(b, from, T.step, b->d_scal + 12, b->d_scal + 8);
+      const int rct = b->type == DLG_SPARSE ? sparse_norm2_Jv(b, from, T.step, b->d_scal + 12, b->d_scal + 8)
+                                            : dense_norm2_Jv(b, from, T.step, b->d_scal + 12);
       b->tail_mode = false;
       b->fold_p_src = nullptr; b->p_copied = false;
       DLG_CHECK(rct);

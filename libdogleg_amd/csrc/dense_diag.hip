@@ -149,10 +149,17 @@ __device__ long long g_potrf_dbg[64*8];
 #define POTRF_STAMP(k)
 #endif
 __global__ void __launch_bounds__(TPB) k_potrf_tiles(double* A, int lda, int n, int T, int* __restrict__ info,
-                                                     double* Linv, int* flags, int epoch, DlgHandoff ho, int self_x)
+                                                     double* Linv, int* flags, int epoch, DlgHandoff ho, int self_x, int* gate)
 {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   __shared__ int sbad;
+  // the first workgroup -- in front of every pivot of the launch -- clears the pivot word (write-through: a plain store
+  // could reach memory behind another XCD's atomic) and tells the second stream that the factorisation is on the chip
+  if(blockIdx.x == 0 && threadIdx.x == 0)
+  {
+    __hip_atomic_store(info, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if(gate) __hip_atomic_store(gate, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  }
   typedef __attribute__((address_space(1))) double* gd_t;
   typedef const __attribute__((address_space(1))) double* gcd_t;
   constexpr int LDT = NB + 1;
@@ -886,14 +893,14 @@ void dense_trsv_arm(hipStream_t st, double* Yh, double* Xh, size_t n_each)
   hipLaunchKernelGGL(k_trsv_arm, dim3(64), dim3(256), 0, st, reinterpret_cast<unsigned long long*>(Xh), n_each);
 }
 
-void dense_launch_potrf_tiles(hipStream_t st, double* A, int lda, int n, int* info_dev, double* Linv, int* flags, int epoch, const DlgHandoff& ho)
+void dense_launch_potrf_tiles(hipStream_t st, double* A, int lda, int n, int* info_dev, double* Linv, int* flags, int epoch, const DlgHandoff& ho, int* gate)
 {
   static bool attr[DLG_MAX_DEV] = {};       // a function attribute is a property of (function, device)
   constexpr int LDSB = (2*NB*(NB + 1) + 2*NB*NB)*8;      // two staging tiles + the panel [A; I] of a diagonal tile (130 KB: one workgroup per CU)
   dlg_func_lds_once(attr, reinterpret_cast<const void*>(&k_potrf_tiles), LDSB);
   const int T = (n + NB - 1)/NB;
   const int self_x = getenv("DOGLEG_AMD_NO_POTRF_SELF") ? 0 : 1;      // (the form of rounds 2 - 3: every block of L comes from its owner)
-  hipLaunchKernelGGL(k_potrf_tiles, dim3(T*(T + 1)/2), dim3(TPB), LDSB, st, A, lda, n, T, info_dev, Linv, flags, epoch, ho, self_x);
+  hipLaunchKernelGGL(k_potrf_tiles, dim3(T*(T + 1)/2), dim3(TPB), LDSB, st, A, lda, n, T, info_dev, Linv, flags, epoch, ho, self_x, gate);
 }
 
 void dense_launch_potrf_diag_trsm(hipStream_t st, double* A, int lda, int kb, int nb, int n, int* info_dev, double* Linv,

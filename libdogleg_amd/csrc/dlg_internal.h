@@ -305,7 +305,7 @@ int dense_create(dlg_backend* b);
 void dense_launch_potrf_diag(hipStream_t st, double* A, int lda, int kb, int nb, int* info_dev, double* Linv);
 // ... and the rows below it in the same launch (flag: one device int, epoch: a value no earlier launch used)
 // the whole dense factorisation in one launch (a workgroup per 64 x 64 tile; flags: T*T device ints, T = ceil(n/64))
-void dense_launch_potrf_tiles(hipStream_t st, double* A, int lda, int n, int* info_dev, double* Linv, int* flags, int epoch, const DlgHandoff& ho);
+void dense_launch_potrf_tiles(hipStream_t st, double* A, int lda, int n, int* info_dev, double* Linv, int* flags, int epoch, const DlgHandoff& ho, int* gate = nullptr);
 // both triangular solves of (L L') x = rhs in one launch (a workgroup per 64 rows; flags: 2*T device ints; Y: n doubles of scratch)
 void dense_launch_trsv_tiles(hipStream_t st, const double* A, int lda, int n, const double* Linv, const double* rhs,
                              double* Yh, double* X, double* Xh, int epoch, const DlgHandoff& ho);
@@ -342,6 +342,7 @@ int sparse_factorize(dlg_backend* b, int slot, double lambda, int* ok);         
 int sparse_factorize_rest(dlg_backend* b, bool* was_pending);
 bool sparse_factor_pending(const dlg_backend* b);                     // the levels above the leaves of a factorisation enqueued ahead
 int sparse_norm2_chunks(const dlg_backend* b);
+int dense_norm2_chunks(const dlg_backend* b);
 bool sparse_factor_ok(const dlg_backend* b);     // pivot flag of the last factorisation (after a sync)
 int sparse_solve(dlg_backend* b, const double* rhs, double* out);                // K6
 void sparse_hold_factor(dlg_backend* b);

@@ -435,7 +435,7 @@ bool eval_point(bool* converged, dogleg_operatingPoint_t* pt, Driver* d)
     if(ctx->solve_type == DOGLEG_SPARSE) dlg_backend_set_speculation(d->be, d->expect_gn);
     // the model lives on the device: nothing on the host waits for p_new, and the expected improvement of a step is first
     // used behind the evaluation of its trial point (dogleg.c:1427) -- its pass over J runs beside this evaluation
-    if(ctx->solve_type == DOGLEG_SPARSE && !d->sharded) dlg_backend_set_defer_tail(d->be, 1);
+    if((ctx->solve_type == DOGLEG_SPARSE || ctx->solve_type == DOGLEG_DENSE) && !d->sharded) dlg_backend_set_defer_tail(d->be, 1);
     { Tick te(d, TM_EVAL); if(!be_ok(dlg_point_eval(d->be, s, &norm2x, &absmax), "Jt*x")) return false; }
     pt->norm2_x = norm2x;
     pt->have_x = pt->have_J = pt->have_Jtx = true;

@@ -88,9 +88,16 @@ __global__ void __launch_bounds__(TPB) k_colsum_slices(const double* __restrict_
 // one wave per measurement row: dot(J[r,:], v)^2 accumulated per wave
 __global__ void __launch_bounds__(TPB) k_norm2_Jv_part(const double* __restrict__ J,
                                                        const double* __restrict__ v, int M, int N,
-                                                       double* __restrict__ part)
+                                                       double* __restrict__ part,
+                                                       const double* __restrict__ psrc, double* __restrict__ pdst, int pn)
 {
   __shared__ double sh[4];
+  // (behind the decision point, dlg_take_step: p_new goes to its page-locked destination with this pass, a slice a workgroup)
+  if(psrc)
+  {
+    const int per = (pn + (int)gridDim.x - 1)/(int)gridDim.x, i0 = (int)blockIdx.x*per, i1 = min(i0 + per, pn);
+    for(int i = i0 + (int)threadIdx.x; i < i1; i += TPB) pdst[i] = psrc[i];
+  }
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int wave = blockIdx.x*4 + w, nwaves = gridDim.x*4;
   double acc = 0;
@@ -773,8 +780,10 @@ int dense_create(dlg_backend* b)
     b->slabs_bytes = ns*ntiles*128*128*sizeof(double);
     DLG_HIP(hipMalloc(&b->slabs, b->slabs_bytes));
   }
-  DLG_HIP(hipMalloc(&b->d_info, sizeof(int)));
-  DLG_HIP(hipHostMalloc(&b->h_info, sizeof(int)));
+  // the pivot word rides in the last slot of the scalar block (as the sparse one does): whatever fetches the step's
+  // scalars brings it along -- no copy of its own on the critical stream between the factorisation and the solve
+  b->d_info = reinterpret_cast<int*>(b->d_scal + (dlg_backend::NSCAL - 1));
+  b->h_info = reinterpret_cast<int*>(b->h_scal + (dlg_backend::NSCAL - 1));
   DLG_HIP(hipMalloc(&b->Linv, sizeof(double)*(size_t)dlg_cdiv(b->N, NB)*NB*NB));
   DLG_HIP(hipMemset(b->Linv, 0, sizeof(double)*(size_t)dlg_cdiv(b->N, NB)*NB*NB));      // (k_potrf_tiles stores the lower triangles only)
   return DLG_OK;
@@ -785,12 +794,10 @@ void dense_destroy(dlg_backend* b)
   if(b->Linv) (void)hipFree(b->Linv);
   b->Linv = nullptr;
   if(b->slabs) (void)hipFree(b->slabs);
-  if(b->d_info) (void)hipFree(b->d_info);
   if(b->potrf_flag) { (void)hipFree(b->potrf_flag); b->potrf_flag = nullptr; }
   if(b->trsv_flag) { (void)hipFree(b->trsv_flag); b->trsv_flag = nullptr; }
   if(b->trsv_y) { (void)hipFree(b->trsv_y); b->trsv_y = nullptr; }
   if(b->trsv_x) { (void)hipFree(b->trsv_x); b->trsv_x = nullptr; }
-  if(b->h_info) (void)hipHostFree(b->h_info);
   b->G = b->slabs = nullptr; b->d_info = nullptr; b->h_info = nullptr;
 }
 
@@ -826,12 +833,25 @@ int dense_norm2_Jv(dlg_backend* b, int s, const double* v, double* out_dev)
   DlgSlot& S = b->slot[s];
   const int M = dlg_mloc(b);
   int g = dlg_cdiv(M, 4); if(g > 2048) g = 2048; if(g < 1) g = 1;
+  // K8 behind the decision point (dlg_take_step, dlg_backend_set_defer_tail): the partial sums go to page-locked memory,
+  // dlg_step_tail adds them; p_new rides along
+  if(b->tail_mode)
+    if(double* hp = dlg_tail_partials(b, g))
+    {
+      hipLaunchKernelGGL(k_norm2_Jv_part, dim3(g), dim3(TPB), 0, b->stream, S.Jin(), v, M, b->N, hp,
+                         b->fold_p_src, b->fold_p_dst, (int)b->N);
+      DLG_LAUNCH_CHECK();
+      b->p_copied = b->fold_p_src != nullptr;
+      return DLG_OK;
+    }
   DLG_CHECK(dlg_ensure_partials(b, 8192));
   double* part = b->d_part + 5120;          // behind the regions of the vector reductions (kernels_vec.hip)
-  hipLaunchKernelGGL(k_norm2_Jv_part, dim3(g), dim3(TPB), 0, b->stream, S.Jin(), v, M, b->N, part);
+  hipLaunchKernelGGL(k_norm2_Jv_part, dim3(g), dim3(TPB), 0, b->stream, S.Jin(), v, M, b->N, part,
+                     (const double*)nullptr, (double*)nullptr, 0);
   DLG_LAUNCH_CHECK();
   return k_reduce_sum(b, part, g, out_dev);
 }
+int dense_norm2_chunks(const dlg_backend* b) { int g = dlg_cdiv(dlg_mloc(b), 4); if(g > 2048) g = 2048; if(g < 1) g = 1; return g; }
 
 int products_quadform(dlg_backend* b, int s, const double* v, double* out_dev)
 {
@@ -854,8 +874,8 @@ static int run_potrf(dlg_backend* b)
   const int T = dlg_cdiv(b->N, NB);
   if(!b->potrf_flag)
   {
-    DLG_HIP(hipMalloc(&b->potrf_flag, sizeof(int)*((size_t)T*T + 1)));
-    DLG_HIP(hipMemsetAsync(b->potrf_flag, 0, sizeof(int)*((size_t)T*T + 1), b->stream));
+    DLG_HIP(hipMalloc(&b->potrf_flag, sizeof(int)*((size_t)T*T + 2)));      // (+ the step form's flag, + the word for the second stream)
+    DLG_HIP(hipMemsetAsync(b->potrf_flag, 0, sizeof(int)*((size_t)T*T + 2), b->stream));
   }
   // one launch for the whole factorisation (dense_diag.hip: k_potrf_tiles); DOGLEG_AMD_POTRF_STEPS: the
   // step-by-step form (its fused diagonal + rows launch uses the last flag)
@@ -863,8 +883,10 @@ static int run_potrf(dlg_backend* b)
   if(!b->knobs.potrf_steps && T >= 2)
   {
     DlgRegionTurn turn(b);
-    dense_launch_potrf_tiles(b->stream, b->G, b->N, b->N, b->d_info, b->Linv, b->potrf_flag, ++b->potrf_epoch, ho);
+    int* gate = b->potrf_flag + (size_t)T*T + 1;
+    dense_launch_potrf_tiles(b->stream, b->G, b->N, b->N, b->d_info, b->Linv, b->potrf_flag, ++b->potrf_epoch, ho, gate);
     DLG_LAUNCH_CHECK();
+    dlg_fork_gate(b, gate, b->potrf_epoch);
     return DLG_OK;
   }
   return potrf_lower(b->stream, b->G, b->N, b->N, b->d_info, b->Linv, b->potrf_flag + (size_t)T*T, &b->potrf_epoch,
@@ -873,17 +895,20 @@ static int run_potrf(dlg_backend* b)
 
 static int finish_potrf(dlg_backend* b, int* ok)
 {
+  if(b->defer_factor_sync) { *ok = 1; return DLG_OK; }        // the caller reads dense_factor_ok() behind its fetch of the scalars
   DLG_HIP(hipMemcpyAsync(b->h_info, b->d_info, sizeof(int), hipMemcpyDeviceToHost, b->stream));
-  if(b->defer_factor_sync) { *ok = 1; return DLG_OK; }        // the caller reads dense_factor_ok() later
   DLG_HIP(hipStreamSynchronize(b->stream));
   *ok = (*b->h_info == 0);
   return DLG_OK;
 }
 
+// (the one-launch factorisation clears the pivot word itself -- its first workgroup, in front of every pivot: no fill
+// kernel in front of the SYRK)
+static bool potrf_clears_info(const dlg_backend* b) { return !b->knobs.potrf_steps && dlg_cdiv(b->N, NB) >= 2; }
 int dense_factorize(dlg_backend* b, int s, double lambda, int* ok)
 {
   DlgSlot& S = b->slot[s];
-  DLG_HIP(hipMemsetAsync(b->d_info, 0, sizeof(int), b->stream));
+  if(!potrf_clears_info(b)) DLG_HIP(hipMemsetAsync(b->d_info, 0, sizeof(int), b->stream));
   // K4: G(lower) = J^T J + lambda I   (K = M measurement rows, A = J with lda = N)
   const bool sharded = b->sharded();
   {
@@ -897,8 +922,9 @@ int dense_factorize(dlg_backend* b, int s, double lambda, int* ok)
     if(lambda != 0.0)
       hipLaunchKernelGGL(k_add_diag, dim3(dlg_cdiv(b->N, TPB)), dim3(TPB), 0, b->stream, b->G, b->N, lambda);
   }
-  // K5 (a chain of small kernels: independent work may run beside it from here on)
-  dlg_fork_point(b);
+  // K5: independent work may run beside it from here on (the one-launch form raises a word for the second stream
+  // itself: no event between the SYRK's reduce and the factorisation; the chain of small kernels: an event)
+  if(!potrf_clears_info(b)) dlg_fork_point(b);
   {
     DlgProfScope pf(b, DLG_PROF_K5_FACTOR);
     DLG_CHECK(run_potrf(b));
@@ -912,7 +938,7 @@ int products_factorize(dlg_backend* b, int s, double lambda, int* ok)
   const bool packed = b->flags & DLG_FLAG_JTJ_PACKED, upper = b->flags & DLG_FLAG_JTJ_UPPER;
   if(packed && !upper)
   { dlg_set_error("packed-lower JtJ is not supported (reference dogleg.c:597-601)"); return DLG_ERR_ARG; }
-  DLG_HIP(hipMemsetAsync(b->d_info, 0, sizeof(int), b->stream));
+  if(!potrf_clears_info(b)) DLG_HIP(hipMemsetAsync(b->d_info, 0, sizeof(int), b->stream));
   const size_t nn = (size_t)b->N*b->N;
   hipLaunchKernelGGL(k_unpack_to_G, dim3(dlg_cdiv((long)nn, TPB)), dim3(TPB), 0, b->stream, S.Jin(),
                      b->N, packed ? 1 : 0, lambda, b->G);

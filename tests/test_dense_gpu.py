@@ -268,3 +268,54 @@ def test_one_launch_potrf_matches_the_step_form_and_reproduces_its_bits(gpu, N, 
         scale = max(1.0, np.max(np.abs(ref)))
         assert np.max(np.abs(out["tiles"][k][1] - out["steps"][k][1])) <= 1e-11*scale
         assert np.max(np.abs(out["tiles"][k][1] - ref)) <= 1e-9*scale
+
+
+@pytest.mark.parametrize("trf", [0.5, 1e-3, 1e3])
+def test_dense_expected_improvement_behind_the_decision_point(gpu, trf):
+    """dlg_backend_set_defer_tail on the dense path: dlg_take_step returns behind the step kernel, the pass over J that forms
+    |J step|^2 and the copy of p_new follow on the stream, dlg_step_tail hands the value out (dogleg.c:1427 first uses it
+    behind the evaluation of the trial point).  Same kernel, same partial sums -- added in index order on the host where the
+    in-line form adds them with k_final's tree: the value agrees to rounding (1e-13 relative asserted), p_new and the step
+    bit for bit -- interpolated, Cauchy-to-the-edge and Gauss-Newton steps; the tail fetched at once and behind the next
+    evaluation."""
+    prob = oa.DenseProblem(M=1500, N=200, seed=7)
+    p = prob.p0()
+    evals = [prob.eval(p + 0.003*k) for k in range(3)]
+
+    def run(defer, late):
+        be = capi.Backend(capi.DLG_DENSE, prob.N, prob.M)
+        be.set_p(0, p)
+        be.upload(0, *evals[0])
+        be.eval(0)
+        lam, n2c, n2g = be.cauchy_gauss_newton(0, 0.0)
+        tr = trf * (np.sqrt(n2c) + np.sqrt(n2g))
+        be.set_defer_tail(defer)
+        res, pend, pn = [], None, None
+        for rep in range(6):
+            be.upload(0, *evals[rep % 3])
+            n2x, gmax = be.eval(0)
+            if pend is not None:
+                pend["ei"] = be.step_tail()
+                pend = None
+            lam, r, pn = be.take_step(0, 1, tr, 0.0, tail=not late)
+            if defer and late:
+                assert r["ei"] != r["ei"]
+                pend = r
+            res.append([n2x, gmax, r, None if (defer and late) else pn.copy(), be.download(1, capi.VEC_STEP)])
+        if pend is not None:
+            pend["ei"] = be.step_tail()
+            res[-1][3] = pn.copy()
+        be.close()
+        return res
+    want = run(False, False)
+    for late in (False, True):
+        got = run(True, late)
+        for i, (a, b) in enumerate(zip(got, want)):
+            assert a[0] == b[0] and a[1] == b[1]
+            for k in a[2]:
+                va, vb = a[2][k], b[2][k]
+                assert va == vb or (va != va and vb != vb) or (k == "ei" and abs(va - vb) <= 1e-13 * abs(vb)), (late, i, k, va, vb)
+            assert np.isfinite(a[2]["ei"]) and np.array_equal(a[4], b[4])
+            if a[3] is not None:
+                assert np.array_equal(a[3], b[3])
+    print("kinds of step seen:", {q[2]["kind"] for q in want})
