@@ -420,6 +420,13 @@ def main():
                                            "step, whose trial point's leaf-level factorisation had been enqueued ahead and is abandoned"}
                                   if retry_ms else None),
             "sticky_lambda_step": sticky,
+            "expected_improvement": ({"placement": "behind the decision point",
+                                      "what": "dlg_backend_set_defer_tail (as the library's device-callback solves run): every step's K8 -- the pass over J that forms "
+                                              "|J step|^2 -- and its p_new copy are INSIDE the timed region, enqueued behind the step kernel the host waits for; "
+                                              "the value is fetched where the reference first uses it, behind the next evaluation (dogleg.c:1427; the last step's "
+                                              "inside the region too).  DOGLEG_AMD_NO_DEFER_TAIL=1: K8 in front of the synchronisation, as in rounds 1-4"}
+                                     if (not use_dist and not logical and os.environ.get("DOGLEG_AMD_NO_DEFER_TAIL") is None and kind in ("sparse", "dense"))
+                                     else {"placement": "in front of the step's synchronisation"}),
             "separate_passes": ({"ms_per_step": sep_ms, "steps_per_s": 1e3 / sep_ms,
                                  "what": "same step with Jt*x (K1) and the JtJ assembly (K4) as two passes over J: `value` of rounds 1-2"}
                                 if sep_ms else None),

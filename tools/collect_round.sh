@@ -28,6 +28,7 @@ timeout 300 python3 tools/gpu_probe.py > $out/probe.txt 2>&1
 # panel sweeps with and without the vector finish of a short last block, where workgroups land (XCDs) and what a hand-off costs
 timeout 300 python3 tools/rccl_floor.py 2> $out/rccl_floor.err | grep '^{' > $out/rccl_floor.json
 if [ -f tools/micro/libtrsvprof.so ]; then DLG_PROF_LIB=tools/micro/libtrsvprof.so timeout 300 python3 tools/trsv_prof.py 2>&1 | grep "trsv wg" > $out/trsv_hops.txt; fi
+if [ -f tools/micro/libpotrfprof.so ]; then DLG_PROF_LIB=tools/micro/libpotrfprof.so timeout 300 python3 tools/potrf_prof.py 2>&1 | grep "potrf diag" > $out/potrf_diag.txt; fi
 {
   echo "# tools/micro/bench_panel (one workgroup of 512 threads, panel in LDS; us per launch include ~5 us of load / store); second line of a pair: -DDLG_PF_NO_VFIN (the short last block on the matrix cores)"
   for a in "187 60" "193 66" "199 66" "205 66" "211 72" "127 126" "100 66" "163 36"; do echo "== nrows w = $a"; timeout 60 tools/micro/bench_panel 1 $a 512 | grep -E "B16 [0-9]|vfin phases"; timeout 60 tools/micro/bench_panel_novfin 1 $a 512 | grep -E "B16 [0-9]"; done
