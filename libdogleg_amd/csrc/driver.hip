@@ -18,6 +18,7 @@
 #include <string>
 #include <vector>
 #include <mutex>
+#include <future>
 #include <time.h>
 #include "../../include/dogleg.h"
 #include "../../include/dlg_backend.h"
@@ -88,6 +89,7 @@ struct Driver
   bool be_reused;                              // the backend served an earlier solve (take_parked)
   bool expect_gn;                              // the last step needed the Gauss-Newton step: issue it with the Cauchy step
   bool tail_out;                               // the expected improvement of the step just taken is still on its way (dlg_step_tail)
+  std::future<int>* pat_check;                 // the comparison of the caller's pattern with the taken-over backend's, running beside the first evaluation
   bool failed;                                 // a backend op failed during the solve: the backend is not kept
   bool sharded;                                // this solve is one rank of several (subtree partition / row shard + all-reduces)
   int rank, nranks, row0, row1;                // its rank; dense: the contiguous rows it holds
@@ -403,7 +405,18 @@ bool eval_point(bool* converged, dogleg_operatingPoint_t* pt, Driver* d)
     if(ctx->solve_type == DOGLEG_SPARSE && !d->pattern_set)
     {
       Tick tk(d, TM_PATTERN);
-      if(!set_pattern(d, d->dev_cp, d->dev_ri)) return false;
+      if(d->be_reused && !d->sharded && !d->check_pattern && getenv("DOGLEG_AMD_NO_PATTERN_OVERLAP") == nullptr)
+      {
+        // A backend taken over from the previous solve: whether its pattern is the caller's is 64 MB of comparison on
+        // config #4 (1 ms of a 5 ms solve).  It runs on a thread of its own beside the first evaluation, which is made with
+        // the backend's schedules -- if the patterns turn out to differ (below), that evaluation is thrown away: the callback's
+        // x and J stay where they are, the pattern is analysed and the evaluation made again.  (Same shape, so every index the
+        // stale schedules hold is inside the arrays.)
+        dlg_backend_t* be = d->be; const int* cp = d->dev_cp; const int* ri = d->dev_ri;
+        d->pat_check = new(std::nothrow) std::future<int>(std::async(std::launch::async, [be, cp, ri] { return dlg_sparse_pattern_matches(be, cp, ri); }));
+        if(!d->pat_check) { MSG("out of memory"); return false; }
+      }
+      else if(!set_pattern(d, d->dev_cp, d->dev_ri)) return false;
       d->pattern_set = true;
     }
     if(!rank_rows(d, d->dev_cp)) return false;
@@ -436,7 +449,26 @@ bool eval_point(bool* converged, dogleg_operatingPoint_t* pt, Driver* d)
     // the model lives on the device: nothing on the host waits for p_new, and the expected improvement of a step is first
     // used behind the evaluation of its trial point (dogleg.c:1427) -- its pass over J runs beside this evaluation
     if((ctx->solve_type == DOGLEG_SPARSE || ctx->solve_type == DOGLEG_DENSE) && !d->sharded) dlg_backend_set_defer_tail(d->be, 1);
-    { Tick te(d, TM_EVAL); if(!be_ok(dlg_point_eval(d->be, s, &norm2x, &absmax), "Jt*x")) return false; }
+    int rc_eval;
+    { Tick te(d, TM_EVAL); rc_eval = dlg_point_eval(d->be, s, &norm2x, &absmax); }
+    if(d->pat_check)
+    {
+      int same;
+      { Tick tk(d, TM_PATTERN); same = d->pat_check->get(); delete d->pat_check; d->pat_check = nullptr; }
+      if(!same)
+      {
+        // another pattern of the same shape: what was just evaluated is void
+        { Tick tk(d, TM_PATTERN);
+          if(!be_ok(dlg_sparse_drop_pattern(d->be), "dropping the previous solve's pattern")) return false;
+          if(!be_ok(dlg_sparse_set_pattern(d->be, d->dev_cp, d->dev_ri), "sparse symbolic analysis")) return false; }
+        { Tick tu(d, TM_UPLOAD); if(!be_ok(dlg_point_bind_device(d->be, s, x_dev, J_dev), "bind")) return false; }
+        dlg_backend_set_speculation(d->be, d->expect_gn);
+        dlg_backend_set_defer_tail(d->be, 1);
+        Tick te(d, TM_EVAL);
+        rc_eval = dlg_point_eval(d->be, s, &norm2x, &absmax);
+      }
+    }
+    if(!be_ok(rc_eval, "Jt*x")) return false;
     pt->norm2_x = norm2x;
     pt->have_x = pt->have_J = pt->have_Jtx = true;
   }
@@ -829,6 +861,7 @@ bool own_pattern_copies(Driver* d)
 void destroy(Driver* d)
 {
   if(!d) return;
+  if(d->pat_check) { (void)d->pat_check->get(); delete d->pat_check; d->pat_check = nullptr; }      // (it reads the backend's pattern)
   free_point(d, 0); free_point(d, 1);
   if(d->pub.solve_type != DOGLEG_SPARSE) free(d->pub.factorization_dense);
   if(d->x_full_dev) dlg_mem_free(d->x_full_dev);

@@ -119,3 +119,35 @@ def test_returned_context_of_a_device_solve(gpu):
     assert min(got) <= 1e-13 * max(1.0, np.max(np.abs(Jx)))
     L.dogleg_freeContext(C.byref(ctx))
     assert not ctx.value
+
+
+@pytest.mark.parametrize("overlap", [True, False], ids=["comparison beside the evaluation", "comparison first"])
+def test_a_backend_taken_over_serves_the_same_and_another_pattern_of_its_shape(gpu, overlap, monkeypatch):
+    """Between solves the library keeps one idle backend with its pattern and schedules (driver.hip: park / take over).  The
+    next solve of the SAME shape compares its pattern with the backend's -- on a thread of its own, beside the first
+    evaluation, which is made with the backend's schedules (round 5; DOGLEG_AMD_NO_PATTERN_OVERLAP: first, as before).
+    Three solves in a row, same (N, M, nnz): pattern A, A again (taken over as it is), then B (another pattern: the
+    evaluation made with A's schedules is thrown away, B analysed, the evaluation made again) -- every one the oracle's
+    trace, every callback count the oracle's (the model is not evaluated a second time for the thrown-away evaluation)."""
+    if overlap:
+        monkeypatch.delenv("DOGLEG_AMD_NO_PATTERN_OVERLAP", raising=False)
+    else:
+        monkeypatch.setenv("DOGLEG_AMD_NO_PATTERN_OVERLAP", "1")
+    # (one camera less, two points more: the same number of variables, rows and non-zeros, another pattern)
+    probs = [oa.BAProblem(23, 400, 3000, seed=21, eps=0.4, p0_spread=0.5), oa.BAProblem(23, 400, 3000, seed=21, eps=0.4, p0_spread=0.5),
+             oa.BAProblem(22, 402, 3000, seed=22, eps=0.4, p0_spread=0.5)]
+    assert probs[0].nnz == probs[2].nnz and probs[0].M == probs[2].M and probs[0].N == probs[2].N
+    assert not np.array_equal(probs[0].pattern()[1], probs[2].pattern()[1])
+    prm = oa.default_params()
+    prm.max_iterations = 8
+    prm.trustregion0 = 3.0
+    for k, prob in enumerate(probs):
+        twin = oa.DeviceTwin(prob)
+        Jp, Ji = prob.pattern()
+        p0 = prob.p0()
+        ro, po, tro = oa.oracle_solve("sparse", p0, prob.N, prob.M, prob.nnz, prob.cb, prob.cookie, prm)
+        rg, pg, trg = capi.optimize_device(p0, prob.N, prob.M, prob.nnz, Jp, Ji, twin.cb, twin.cookie, prm)
+        assert rg >= 0, k
+        compare_traces(trg, tro)
+        assert np.max(np.abs(pg - po)) <= 1e-10, k
+        assert twin.neval() == tro.ncallbacks, (k, twin.neval(), tro.ncallbacks)
