@@ -1289,11 +1289,11 @@ extern "C" int dlg_take_step(dlg_backend_t* b, int from, int to, double trustreg
   const bool p_foldable = p_pinned && b->host_finals && !b->sharded() && p_attr.devicePointer;
   // K8 behind the decision point (dlg_backend_set_defer_tail): the step kernel is what the host waits for
   const int tail_chunks = b->type == DLG_SPARSE ? sparse_norm2_chunks(b) : (b->type == DLG_DENSE ? dense_norm2_chunks(b) : 0);
-  const bool defer = b->defer_tail && b->host_finals && !b->sharded() &&
+  bool defer = b->defer_tail && b->host_finals && !b->sharded() &&
                      (!p_new_host || p_foldable) && !(b->prof_mask >> DLG_PROF_K3K8_NORM2JV & 1u) &&
                      tail_chunks > 0 && dlg_tail_partials(b, tail_chunks) != nullptr;
   // (the dense pass over J takes p_new along only in that form)
-  const bool p_fold = p_foldable && (b->type == DLG_SPARSE || (b->type == DLG_DENSE && defer));
+  bool p_fold = p_foldable && (b->type == DLG_SPARSE || (b->type == DLG_DENSE && defer));
   for(;;)
   {
     int good = 0, rc;
@@ -1359,7 +1359,14 @@ extern "C" int dlg_take_step(dlg_backend_t* b, int from, int to, double trustreg
     }
     side_copy = false;
     b->fold_p_src = nullptr; b->p_copied = false;
-    if(defer && !b->scal_copied) { dlg_set_error("internal error: the step kernel did not take the scalars along"); return DLG_ERR_STATE; }
+    if(defer && !b->scal_copied)
+    {
+      // (the step kernel could not take the scalars along -- no room left for its partial sums in page-locked memory --:
+      // this step in the in-line form, K8 in front of the synchronisation)
+      defer = false;
+      p_fold = p_foldable && b->type == DLG_SPARSE;
+      b->stop_attached = false;
+    }
     if(defer)
     {
       // K8 right behind the step kernel on the same stream -- but the host is already on its way back when it runs: its
