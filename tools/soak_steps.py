@@ -28,6 +28,12 @@ else:
     be.set_pattern(Jp, Ji)
     be.set_speculation(True)
 be.set_p(0, p)
+# DLG_SOAK_DEFER=1: the expected improvement behind the decision point (dlg_backend_set_defer_tail), fetched at once;
+# DLG_SOAK_DEFER=late: fetched behind the next evaluation, as the driver and dlg_run_steps do
+defer = os.environ.get("DLG_SOAK_DEFER", "")
+if defer:
+    be.set_defer_tail(True)
+pend = None
 dev = [(capi.DeviceArray(np.ascontiguousarray(x)), capi.DeviceArray(np.ascontiguousarray(J))) for x, J in inputs]
 ref, tr = [None, None], None
 bad = 0
@@ -35,13 +41,27 @@ for k in range(steps):
     c = k & 1
     be.bind_device(0, dev[c][0].ptr, dev[c][1].ptr)
     n2x, gmax = be.eval(0)
+    if pend is not None:
+        pc, psig, pv = pend
+        ei = be.step_tail()                     # (... and p_new of that step is complete now)
+        psig = psig[:6] + (ei, float(pv[0]), float(pv[-1]), float(np.sum(pv)))
+        pend = None
+        if ref[pc] is None:
+            ref[pc] = psig
+        elif psig != ref[pc]:
+            bad += 1
+            if bad < 5:
+                print("step", k - 1, "input", pc, "differs:", psig, "vs", ref[pc], flush=True)
     if tr is None:
         lam, n2c, n2g = be.cauchy_gauss_newton(0, 0.0)
         tr = 0.5*(n2c**0.5 + n2g**0.5)
         be.step(0, 1, capi.KIND_INTERP, tr)
         continue
-    lam, r, pnew = be.take_step(0, 1, tr, 0.0)
+    lam, r, pnew = be.take_step(0, 1, tr, 0.0, tail=(defer != "late"))
     sig = (n2x, gmax, r["n2c"], r["n2g"], r["n2s"], r["k"], r["ei"], float(pnew[0]), float(pnew[-1]), float(np.sum(pnew)))
+    if defer == "late":
+        pend = (c, sig, pnew)                   # (p_new of this step is complete behind the tail: looked at there)
+        continue
     if ref[c] is None:
         ref[c] = sig
     elif sig != ref[c]:
