@@ -258,11 +258,13 @@ def main():
         tr_retry = 0.5 * (res[1] ** 0.5 + res[2] ** 0.5)
 
         def one_retry(shrink):
-            be.step(0, 1, capi.KIND_INTERP, tr_retry * shrink)
+            # (the expected improvement is fetched where the driver needs it: behind the evaluation of the new trial point)
+            be.step(0, 1, capi.KIND_INTERP, tr_retry * shrink, tail=False)
             c = state["i"] % ncopy
             state["i"] += 1
             be.bind_device(1, d_x[c].ptr, d_J[c].ptr)
             be.eval(1)
+            be.step_tail()
         one_retry(0.99)
         barrier()
         tr0 = time.perf_counter()

@@ -541,7 +541,7 @@ class Backend:
             self._pnew = np.ctypeslib.as_array(C.cast(self._pnew_ptr, C.POINTER(C.c_double)), shape=(self.N,))
         return self._pnew
 
-    def step(self, frm, to, kind, trustregion, want_p=True):
+    def step(self, frm, to, kind, trustregion, want_p=True, tail=True):
         """make_step + expected_improvement behind one synchronisation:
         (|step|^2, k, max|step|, expected improvement, p_new); p_new as in make_step"""
         n2, k, am, ei = C.c_double(), C.c_double(), C.c_double(), C.c_double()
@@ -549,7 +549,10 @@ class Backend:
             self._pnew_buffer()
         _ck(self.L.dlg_step(self.h, frm, to, kind, trustregion, C.byref(n2), C.byref(k), C.byref(am),
                             C.byref(ei), dptr(self._pnew) if want_p else None), "step")
-        return n2.value, k.value, am.value, ei.value, (self._pnew if want_p else None)
+        e = ei.value
+        if tail and e != e:
+            e = self.step_tail()                # set_defer_tail: the value (and a page-locked p_new) complete here
+        return n2.value, k.value, am.value, e, (self._pnew if want_p else None)
 
     def take_step(self, frm, to, trustregion, lam=0.0, want_p=True, tail=True):
         """Cauchy + Gauss-Newton + the choice of step + step + expected improvement behind one

@@ -1220,6 +1220,56 @@ extern "C" int dlg_step(dlg_backend_t* b, int from, int to, int kind, double tru
   DLG_CHECK(tail_guard(b)); b->tail_pending = false;
   double n2 = 0, kk = NAN, amax = 0;
   int nscal = 0;
+  // K8 behind the decision point (dlg_backend_set_defer_tail), as in dlg_take_step: the host waits for the kernel that
+  // forms <Jt x, step> -- every scalar of the step reaches it through page-locked partial sums, nothing is copied --,
+  // the pass over J and p_new follow on the stream, dlg_step_tail has the value
+  {
+    hipPointerAttribute_t pa;
+    const bool pin = p_new_host && hipPointerGetAttributes(&pa, p_new_host) == hipSuccess && pa.type == hipMemoryTypeHost && pa.devicePointer;
+    if(p_new_host && !pin) (void)hipGetLastError();
+    const int chunks = b->type == DLG_SPARSE ? sparse_norm2_chunks(b) : (b->type == DLG_DENSE ? dense_norm2_chunks(b) : 0);
+    const bool defer = b->defer_tail && expected_improvement && b->host_finals && b->h_part && !b->sharded() && (!p_new_host || pin) &&
+                       !(b->prof_mask >> DLG_PROF_K3K8_NORM2JV & 1u) && !(b->prof_mask >> DLG_PROF_K7_STEP & 1u) && b->ext_events &&
+                       chunks > 0 && b->slot[from].have_Jtx && b->h_part_used + 4096 <= dlg_backend::HPART_CAP &&      // (room for the step's partial sums: 4 x 1024 at most)
+                       dlg_tail_partials(b, chunks) != nullptr;
+    if(defer)
+    {
+      DlgSlot& F = b->slot[from];
+      DlgSlot& T = b->slot[to];
+      b->kout_host = true;
+      const int rcm = make_step_enqueue(b, from, to, kind, trustregion, &nscal);
+      b->kout_host = false;
+      DLG_CHECK(rcm);
+      if(!b->ev_fetch) DLG_HIP(hipEventCreateWithFlags(&b->ev_fetch, hipEventDisableTiming));
+      b->attach_stop = b->ev_fetch; b->stop_attached = false;
+      const int rci = k_inner(b, F.Jt_x, T.step, b->N, b->d_scal + 4);
+      const bool attached = b->stop_attached;
+      b->attach_stop = nullptr; b->stop_attached = false;
+      DLG_CHECK(rci);
+      if(attached)
+      {
+        if(pin) { b->fold_p_src = T.p; b->fold_p_dst = (double*)pa.devicePointer; }
+        b->tail_mode = true; b->fold_scal = 0;
+        const int rct = b->type == DLG_SPARSE ? sparse_norm2_Jv(b, from, T.step, b->d_scal + 5, nullptr) : dense_norm2_Jv(b, from, T.step, b->d_scal + 5);
+        b->tail_mode = false;
+        b->fold_p_src = nullptr; b->p_copied = false;
+        DLG_CHECK(rct);
+        b->tail_pending = true;
+        b->stop_attached = true; b->scal_copied = true;          // (nothing to copy: every scalar is a sum of page-locked partials)
+        DLG_CHECK(step_finish(b, to, 0, nullptr));
+        b->tail_mark = b->sync_mark;
+        b->tail_inner = b->h_scal[4];
+        make_step_read(b, from, kind, &n2, &kk, &amax);
+        if(norm2_step) *norm2_step = n2;
+        if(k_cauchy_to_gn) *k_cauchy_to_gn = kk;
+        if(step_absmax) *step_absmax = amax;
+        *expected_improvement = NAN;                             // (dlg_step_tail has it)
+        return DLG_OK;
+      }
+      dlg_set_error("internal error: the step's partial sums found no room in page-locked memory");
+      return DLG_ERR_STATE;
+    }
+  }
   DLG_CHECK(make_step_enqueue(b, from, to, kind, trustregion, &nscal));
   // p_new is final here: it travels to the host on the side stream while K8 runs (a page-locked
   // destination; a pageable one goes through step_finish's staging copy afterwards)

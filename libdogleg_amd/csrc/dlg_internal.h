@@ -99,6 +99,7 @@ struct dlg_backend
   double tail_inner = 0.0, tail_value = 0.0;
   double* h_tail = nullptr; int h_tail_cap = 0;
   unsigned long sync_mark = 0, tail_mark = 0;
+  bool kout_host = false;     // (dlg_step behind the decision point: k_interpolate's k straight into the page-locked scalars)
   static constexpr int NSCAL = 16;
   // hand-offs inside the one-launch regions (flags between workgroups): a wait that gives up raises a bit in
   // the status word (slot NSCAL - 2 of the scalar block, so it travels with every fetch of the scalars);

@@ -708,6 +708,7 @@ bool take_step(double* expectedImprovement, dogleg_operatingPoint_t* to,
   }
   // step, its expected improvement and p_new: one backend op, one host synchronisation
   if(!be_ok(dlg_step(d->be, sf, st, kind, trustregion, &n2, &k, &amax, expectedImprovement, to->p), "step")) return false;
+  d->tail_out = std::isnan(*expectedImprovement);      // (dlg_backend_set_defer_tail: run_optimizer fetches it behind the evaluation)
   }
   to->norm2_step_to_here = n2;
   d->cur.norm2_step = n2;

@@ -428,7 +428,8 @@ int k_inner(dlg_backend* b, const double* x, const double* y, int n, double* out
   const int g = grid_for(n);
   DLG_CHECK(dlg_ensure_partials(b, 4*MAXB));
   if(double* hp = dlg_host_partials(b, out, g, 1, 0, 1))
-  { hipLaunchKernelGGL(k_part_inner, dim3(g), dim3(TPB), 0, b->stream, x, y, n, hp); DLG_LAUNCH_CHECK(); return DLG_OK; }
+  { DLG_LAUNCH_LAST(b, k_part_inner, dim3(g), dim3(TPB), 0, b->stream, x, y, n, hp); DLG_LAUNCH_CHECK(); return DLG_OK; }      // (attach_stop: the launch the host waits for, dlg_step)
+  b->attach_stop = nullptr;
   hipLaunchKernelGGL(k_part_inner, dim3(g), dim3(TPB), 0, b->stream, x, y, n, b->d_part);
   hipLaunchKernelGGL(k_final, dim3(1), dim3(TPB), 0, b->stream, b->d_part, g, 1, 0, out, 1);
   DLG_LAUNCH_CHECK();
@@ -470,8 +471,11 @@ int k_interpolate(dlg_backend* b, const double* a, const double* bb, double norm
   hipLaunchKernelGGL(k_part_interp1, dim3(g), dim3(TPB), 0, b->stream, a, bb, n, b->d_part);
   double* part2 = b->d_part + 2*g;
   double* hp = dlg_host_partials(b, out3, g, 1, 1, 2);
+  // (kout_host: the caller fetches no device scalars behind this step -- dlg_step with K8 behind the decision point --: k goes
+  // straight to its place in the page-locked block)
+  double* kout = (b->kout_host && hp && out3 >= b->d_scal && out3 + 3 <= b->d_scal + dlg_backend::NSCAL) ? b->h_scal + ((out3 + 1) - b->d_scal) : out3 + 1;
   hipLaunchKernelGGL(k_part_interp2, dim3(g), dim3(TPB), 0, b->stream, a, bb, b->d_part, g, norm2a,
-                     trustregion*trustregion, p, step, p_new, n, hp ? hp : part2, out3 + 1);
+                     trustregion*trustregion, p, step, p_new, n, hp ? hp : part2, kout);
   if(!hp) hipLaunchKernelGGL(k_final, dim3(1), dim3(TPB), 0, b->stream, part2, g, 1, 1, out3, 2);
   DLG_LAUNCH_CHECK();
   return DLG_OK;

@@ -986,13 +986,14 @@ int sparse_norm2_Jv(dlg_backend* b, int s, const double* v, double* out_dev, con
   if(g == 0) { DLG_HIP(hipMemsetAsync(out_dev, 0, sizeof(double), b->stream)); return DLG_OK; }
   // K8 inside dlg_take_step: only the host reads the sum -- the workgroups' partial sums go straight to
   // pinned host memory and are added there behind the step's one synchronisation (no second-stage launch)
-  if(kind_if_factor_failed)
+  // (tail_mode without a kind: K8 of a step from cached vectors, dlg_step -- no factorisation of this call to look at)
+  if(kind_if_factor_failed || b->tail_mode)
     if(double* hp = b->tail_mode ? dlg_tail_partials(b, g) : dlg_host_partials(b, out_dev, g, 1, 0, 1))
     {
       const bool fold = b->fold_scal > 0 && b->fold_scal <= TPB && b->h_scal;
       if(!fold) b->attach_stop = nullptr;
       DLG_LAUNCH_LAST(b, k_norm2_Jv, dim3(g), dim3(TPB), 0, b->stream, Y->nv_chunk, Y->Jp, Y->Ji, S.Jin(), v, hp,
-                      (const int*)Y->d_info, kind_if_factor_failed, (int)Y->nnz_loc,
+                      kind_if_factor_failed ? (const int*)Y->d_info : (const int*)nullptr, kind_if_factor_failed, (int)Y->nnz_loc,
                       fold ? (const double*)b->d_scal : (const double*)nullptr, b->h_scal, (int)b->fold_scal,
                       (fold || b->tail_mode) ? b->fold_p_src : (const double*)nullptr, b->fold_p_dst, (int)b->N);
       DLG_LAUNCH_CHECK();

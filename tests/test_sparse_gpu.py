@@ -1016,3 +1016,56 @@ def test_the_expected_improvement_behind_the_decision_point_is_the_same_number(g
         for k in rs_w:
             assert rs_g[k] == rs_w[k] or (rs_g[k] != rs_g[k] and rs_w[k] != rs_w[k]), (k, rs_g[k], rs_w[k])
     print("kinds of step seen:", kinds)
+
+
+@pytest.mark.parametrize("dense", [False, True], ids=["sparse", "dense"])
+def test_a_retry_with_the_expected_improvement_behind_the_decision_point(gpu, dense):
+    """dlg_step -- the driver's retry of a rejected trial point from the cached vectors (dogleg.c:1455-1468) -- with
+    dlg_backend_set_defer_tail: the host waits for the kernel that forms <Jt x, step>, K8 and p_new follow, dlg_step_tail has
+    the value.  All three kinds of step, the value fetched at once and behind the evaluation of the new trial point:
+    |step|^2, k, max|step|, p_new and the step vector bit for bit the in-line form's, the value to 1e-13 (the in-line dlg_step
+    adds K8's partial sums with k_final's tree, the tail in index order on the host)."""
+    if dense:
+        prob = oa.DenseProblem(M=1500, N=200, seed=9)
+        mk = lambda: capi.Backend(capi.DLG_DENSE, prob.N, prob.M)
+    else:
+        prob = oa.BAProblem(49, 900, 10000, seed=9)
+        Jp, Ji = prob.pattern()
+
+        def mk():
+            be = capi.Backend(capi.DLG_SPARSE, prob.N, prob.M, prob.nnz)
+            be.set_pattern(Jp, Ji)
+            be.set_speculation(True)
+            return be
+    p = prob.p0()
+    ev = [prob.eval(p), prob.eval(p + 0.002)]
+
+    def run(defer, late):
+        be = mk()
+        be.set_p(0, p)
+        be.upload(0, *ev[0])
+        be.eval(0)
+        lam, n2c, n2g = be.cauchy_gauss_newton(0, 0.0)
+        be.set_defer_tail(defer)
+        res, pend, pn = [], None, None
+        trs = [(capi.KIND_INTERP, 0.5*(np.sqrt(n2c) + np.sqrt(n2g))), (capi.KIND_INTERP, 0.45*(np.sqrt(n2c) + np.sqrt(n2g))),
+               (capi.KIND_CAUCHY, 0.5*np.sqrt(n2c)), (capi.KIND_GN, 2.0*np.sqrt(n2g)), (capi.KIND_INTERP, 0.4*(np.sqrt(n2c) + np.sqrt(n2g)))]
+        for kind, tr in trs:
+            n2s, k, amax, ei, pn = be.step(0, 1, kind, tr, tail=not late)
+            rec = [n2s, k, amax, ei, None if (defer and late) else pn.copy(), be.download(1, capi.VEC_STEP)]
+            be.upload(1, *ev[1])
+            be.eval(1)                              # the evaluation of the trial point (rejected: the next retry follows)
+            if defer and late:
+                assert rec[3] != rec[3]
+                rec[3] = be.step_tail()
+                rec[4] = pn.copy()
+            res.append(rec)
+        be.close()
+        return res
+    want = run(False, False)
+    for late in (False, True):
+        got = run(True, late)
+        for i, (a, b) in enumerate(zip(got, want)):
+            assert a[0] == b[0] and (a[1] == b[1] or (a[1] != a[1] and b[1] != b[1])) and a[2] == b[2], (late, i, a[:3], b[:3])
+            assert abs(a[3] - b[3]) <= 1e-13*abs(b[3]), (late, i, a[3], b[3])
+            assert np.array_equal(a[4], b[4]) and np.array_equal(a[5], b[5]), (late, i)
