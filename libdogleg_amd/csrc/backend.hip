@@ -708,6 +708,9 @@ static int step_prepare(dlg_backend* b, int s)
   // the lambda the next step is expected to ask for: the one the last step ended with (the reference's lambda is
   // sticky, dogleg.c:138, 671-672) -- or, for a caller that was seen to start over from its own value, the one it passed
   const double lam = b->pre_hint_valid ? b->pre_hint : sparse_current_lambda(b);
+  // (a factorisation that would ask the host about its diagonal first -- lambda = 0 on a backend that has broken down there
+  // before -- is not enqueued ahead: dlg_take_step's loop makes it, and most likely goes on to the next lambda at once)
+  if(sparse_would_look(b, lam)) return DLG_OK;
   b->pre_held = (b->factor_slot >= 0 && b->factor_slot != s) ? b->factor_slot : -1;
   sparse_hold_factor(b);
   b->factor_slot = -1;
@@ -979,6 +982,8 @@ extern "C" int dlg_factorize(dlg_backend_t* b, int s, double lambda, int* ok)
   }
   if(b->profiling) dlg_prof_resolve(b);
   b->factor_slot = good ? s : -1;
+  if(b->factor_doomed) b->factor_doomed = false;            // (sparse_factorize noted the breakdown itself)
+  else if(!good && b->type == DLG_SPARSE) (void)sparse_note_breakdown(b);
   if(ok) *ok = good;
   return DLG_OK;
 }
@@ -1050,6 +1055,15 @@ static int gauss_newton_impl(dlg_backend_t* b, int s, double* lambda_io, double*
       b->defer_factor_sync = false;
       if(rc != DLG_OK) b->want_fork = false;
       DLG_CHECK(rc);
+      if(b->factor_doomed)
+      {
+        // (found doomed at the diagonal, in front of every launch -- sparse_factorize: the next lambda at once)
+        b->factor_doomed = false; b->want_fork = false; b->factor_slot = -1;
+        if(b->profiling) { dlg_prof_resolve(b); dlg_prof_commit(b, false); }
+        lam = (lam == 0.0) ? 1e-10 : lam*10.0;                    // dogleg.c:138, 671-672, 812-813
+        if(!(lam < 1e300)) { dlg_set_error("lambda overflowed while regularising a singular JtJ"); return DLG_ERR_STATE; }
+        continue;
+      }
     }
     if(do_cauchy)
     {
@@ -1070,7 +1084,7 @@ static int gauss_newton_impl(dlg_backend_t* b, int s, double* lambda_io, double*
     good = (b->factor_slot == s) ? 1 : (b->type == DLG_SPARSE ? sparse_factor_ok(b) : dense_factor_ok(b));
     if(b->profiling) dlg_prof_commit(b, good != 0);
     if(good) break;
-    if(b->type == DLG_SPARSE) sparse_mark_unclean(b);          // (a factorisation that broke down: full clears next)
+    if(b->type == DLG_SPARSE && !sparse_note_breakdown(b)) sparse_mark_unclean(b);          // (a factorisation that broke down: full clears next -- unless nothing of it ran)
     b->factor_slot = -1;
     if(b->tail_pending) { DLG_CHECK(tail_guard(b)); b->tail_pending = false; }     // (that attempt's K8 returned at its first look at the pivot flag)
     lam = (lam == 0.0) ? 1e-10 : lam*10.0;                    // dogleg.c:138, 671-672, 812-813
@@ -1380,6 +1394,15 @@ extern "C" int dlg_take_step(dlg_backend_t* b, int from, int to, double trustreg
       b->defer_factor_sync = false;
       if(rc != DLG_OK) b->want_fork = false;
       DLG_CHECK(rc);
+      if(b->factor_doomed)
+      {
+        // (found doomed at the diagonal, in front of every launch -- sparse_factorize: the next lambda at once)
+        b->factor_doomed = false; b->want_fork = false; b->factor_slot = -1;
+        if(b->profiling) { dlg_prof_resolve(b); dlg_prof_commit(b, false); }
+        lam = (lam == 0.0) ? 1e-10 : lam*10.0;                    // dogleg.c:138, 671-672, 812-813
+        if(!(lam < 1e300)) { dlg_set_error("lambda overflowed while regularising a singular JtJ"); return DLG_ERR_STATE; }
+        continue;
+      }
     }
     if(do_cauchy) DLG_CHECK(cauchy_fork_enqueue(b, from, b->d_scal + 4));     // K3 beside K5 (second stream)
     if(!prepared || pre_split)
@@ -1493,7 +1516,7 @@ extern "C" int dlg_take_step(dlg_backend_t* b, int from, int to, double trustreg
     good = (b->factor_slot == from) ? 1 : (b->type == DLG_SPARSE ? sparse_factor_ok(b) : dense_factor_ok(b));
     if(b->profiling) dlg_prof_commit(b, good != 0);
     if(good) break;
-    if(b->type == DLG_SPARSE) sparse_mark_unclean(b);          // (a factorisation that broke down: full clears next)
+    if(b->type == DLG_SPARSE && !sparse_note_breakdown(b)) sparse_mark_unclean(b);          // (a factorisation that broke down: full clears next -- unless nothing of it ran)
     b->factor_slot = -1;
     lam = (lam == 0.0) ? 1e-10 : lam*10.0;                    // dogleg.c:138, 671-672, 812-813
     if(!(lam < 1e300)) { dlg_set_error("lambda overflowed while regularising a singular JtJ"); return DLG_ERR_STATE; }

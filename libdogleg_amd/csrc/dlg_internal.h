@@ -99,6 +99,7 @@ struct dlg_backend
   double tail_inner = 0.0, tail_value = 0.0;
   double* h_tail = nullptr; int h_tail_cap = 0;
   unsigned long sync_mark = 0, tail_mark = 0;
+  bool factor_doomed = false; // sparse_factorize found the factorisation doomed at its look at the diagonal and enqueued nothing else (the lambda loops go on at once)
   bool kout_host = false;     // (dlg_step behind the decision point: k_interpolate's k straight into the page-locked scalars)
   static constexpr int NSCAL = 16;
   // hand-offs inside the one-launch regions (flags between workgroups): a wait that gives up raises a bit in
@@ -347,6 +348,8 @@ int dense_norm2_chunks(const dlg_backend* b);
 bool sparse_factor_ok(const dlg_backend* b);     // pivot flag of the last factorisation (after a sync)
 int sparse_solve(dlg_backend* b, const double* rhs, double* out);                // K6
 void sparse_hold_factor(dlg_backend* b);
+bool sparse_would_look(const dlg_backend* b, double lambda);      // sparse_factorize(lambda) would look at the diagonal first (and ask the host at once)
+bool sparse_note_breakdown(dlg_backend* b);           // a factorisation broke down (the host knows): sparse_factorize looks at the diagonal first from now on (lambda = 0); true: stopped by that look, the panels are the assembly's still
 void sparse_mark_unclean(dlg_backend* b);             // the next clear of either panel buffer is a full one (clear_panels)
 // the partial-sum stages of an evaluation-time assembly on the SECOND stream (sparse_assemble.hip, "fin on the side")
 bool sparse_fin_side_ok(const dlg_backend* b);

@@ -1357,6 +1357,24 @@ int sparse_assemble(dlg_backend* b, int s, double lambda)
     Y->spec_inflight = false;
   }
   DLG_CHECK(sparse_assemble_finish(b));
+  // The attempt before this one was stopped by the look at the diagonal (sparse_host.hip, sparse_note_breakdown): its panels
+  // are the assembly's still -- same slot, same inputs: they get the difference of the lambdas, nothing is assembled.
+  if(Y->intact_Lx && Y->intact_Lx == Y->Lx && Y->intact_slot == s && Y->intact_J == S.Jin() && S.have_Jtx && Y->aug_rhs == S.Jt_x &&
+     !b->sharded() && H.part_nranks <= 1)
+  {
+    const double dl = lambda - Y->intact_lambda;
+    Y->intact_Lx = nullptr;
+    if(dl != 0.0)
+    {
+      DLG_CHECK(sparse_fin_side_gate(b));
+      hipLaunchKernelGGL(k_add_lambda, dim3(dlg_cdiv(H.N, TPB)), dim3(TPB), 0, st, Y->Lx, Y->diagpos, H.N,
+                         dl, Y->col_sn, Y->sn_owner, -1, (const char*)nullptr);
+      DLG_LAUNCH_CHECK();
+    }
+    Y->info_armed = false;            // (sparse_factorize arms the pivot word with a copy)
+    return DLG_OK;
+  }
+  Y->intact_Lx = nullptr;
   bool adopted = false;
   // (leaf fronts: the second buffer holds FACTORED leaf panels -- they are this factorisation's only if they were
   // formed at this lambda and the leaves' update matrices in the scratch are still that launch's)
@@ -1568,4 +1586,5 @@ void sparse_spec_invalidate(dlg_backend* b, int s)
 {
   SparseSym* Y = b->sym;
   if(Y && Y->spec_valid && Y->spec_slot == s) Y->spec_valid = false;
+  if(Y && Y->intact_slot == s) Y->intact_Lx = nullptr;      // (new inputs: panels assembled from the old ones are nobody's)
 }

@@ -345,9 +345,14 @@ __global__ void __launch_bounds__(NT, LEAF ? 4 : 1) k_factor_level(const FwItem*
   if(cmp)
   {
     __syncthreads();
-    // (a level of merged leaves is nobody's child inside its launch: a workgroup of a factorisation that is not going to
-    // be used -- failed pivot in an earlier launch, or abandoned: sparse_abandon_enqueued -- leaves before it loads anything)
-    if(LEAF && s_skip) return;
+    // (a workgroup of a factorisation that is not going to be used -- failed pivot in an earlier launch, abandoned
+    // (sparse_abandon_enqueued), or found doomed by the look at the diagonal (sparse_factorize) -- leaves before it loads
+    // anything and, above all, before the members are factored IN PLACE below: the panels stay the assembly's)
+    if(s_skip)
+    {
+      if(pr_flag && tid == 0) __hip_atomic_store(pr_flag + blockIdx.x, pr_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return;
+    }
     bd_compact_members<NT, DS>(G, nrows, w, tid, sn_bd_col + it.bd0, it.nbd, it.bdw, s_mcol, s_rdiag, Dg, &sbad, it.col0);
   }
   // thread = (panel row, column group): rows padded to whole waves, the remaining threads take
@@ -533,8 +538,11 @@ __global__ void __launch_bounds__(TPB) k_copy_top(const int* __restrict__ ms_sn,
                                                   const int64_t* __restrict__ sn_lx,
                                                   const int64_t* __restrict__ sn_top,
                                                   double* __restrict__ Lx,
-                                                  const double* __restrict__ top_scr)
+                                                  const double* __restrict__ top_scr, const int* __restrict__ info)
 {
+  // (a factorisation that broke down or was found doomed: the scratch holds an EARLIER factorisation's top blocks -- they
+  // must not land in panels that sparse_assemble may take over as the assembly left them)
+  if(*info != 0x7fffffff) return;
   const int s = ms_sn[blockIdx.x];
   const int w = sn_c0[s+1] - sn_c0[s];
   const int nrows = sn_rowptr[s+1] - sn_rowptr[s];
@@ -559,8 +567,12 @@ __global__ void __launch_bounds__(TPB) k_update_coop(int unit0, const int* __res
                                                      const int* __restrict__ sn_rowptr,
                                                      const int64_t* __restrict__ sn_lx,
                                                      double* __restrict__ Lx,
-                                                     double* __restrict__ upart)
+                                                     double* __restrict__ upart, const int* __restrict__ info)
 {
+  // (a factorisation that has broken down -- or was found doomed by the look at the diagonal, sparse_host.hip -- is not
+  // worth finishing, and the panels stay what the assembly left: sparse_assemble takes them over for the next lambda)
+  if(*info != 0x7fffffff) return;
+
   __shared__ __attribute__((aligned(16))) double Bs[256*8];
   const int unit = unit0 + blockIdx.x;
   const int item = uw_item[unit];
@@ -826,9 +838,13 @@ __global__ void __launch_bounds__(TPB) k_update_mfma(int unit0, const int* __res
                                                      const int* __restrict__ sn_rowptr,
                                                      const int64_t* __restrict__ sn_lx,
                                                      double* __restrict__ Lx,
-                                                     double* __restrict__ upart, int nw)
+                                                     double* __restrict__ upart, int nw, const int* __restrict__ info)
 {
   extern __shared__ __attribute__((aligned(16))) double lds[];
+  // (a factorisation that has broken down -- or was found doomed by the look at the diagonal, sparse_host.hip -- is not
+  // worth finishing, and the panels stay what the assembly left: sparse_assemble takes them over for the next lambda)
+  if(*info != 0x7fffffff) return;
+
   const int unit = unit0 + blockIdx.x;
   const int item = uw_item[unit];
   const int t = ui_t[item], col = ui_col[item], nc = ui_nc[item];
@@ -935,9 +951,13 @@ __global__ void __launch_bounds__(TPB) k_update_level(int unit0, const int* __re
                                                       const int* __restrict__ sn_rowptr,
                                                       const int64_t* __restrict__ sn_lx,
                                                       double* __restrict__ Lx,
-                                                      double* __restrict__ upart, int nw)
+                                                      double* __restrict__ upart, int nw, const int* __restrict__ info)
 {
   extern __shared__ __attribute__((aligned(16))) double lds[];
+  // (a factorisation that has broken down -- or was found doomed by the look at the diagonal, sparse_host.hip -- is not
+  // worth finishing, and the panels stay what the assembly left: sparse_assemble takes them over for the next lambda)
+  if(*info != 0x7fffffff) return;
+
   const int unit = unit0 + blockIdx.x;
   const int item = uw_item[unit];
   const int t = ui_t[item], col = ui_col[item], nc = ui_nc[item];
@@ -1028,9 +1048,13 @@ __global__ void __launch_bounds__(TPB) k_update_fin(int f0, const int* __restric
                                                     const int* __restrict__ sn_rowptr,
                                                     const int64_t* __restrict__ sn_lx,
                                                     double* __restrict__ Lx,
-                                                    const double* __restrict__ upart)
+                                                    const double* __restrict__ upart, const int* __restrict__ info)
 {
   __shared__ double sh[TPB];
+  // (a factorisation that has broken down -- or was found doomed by the look at the diagonal, sparse_host.hip -- is not
+  // worth finishing, and the panels stay what the assembly left: sparse_assemble takes them over for the next lambda)
+  if(*info != 0x7fffffff) return;
+
   const int f = f0 + blockIdx.x;
   const int item = uf_item[f], n = uf_n[f];
   const int t = ui_t[item], col = ui_col[item], nc = ui_nc[item];
@@ -1642,26 +1666,26 @@ int sparse_factor_levels(dlg_backend* b, int part)
     else if(nu > 0 && Y->upd_coop[l] == 2)
       hipLaunchKernelGGL(k_update_mfma, dim3(nu), dim3(TPB), Y->upd_lds[l], st, H.uw_lvl_ptr[l],
                          Y->uw_item, Y->uw_s0, Y->uw_s1, Y->uw_part, Y->ui_t, Y->ui_col, Y->ui_nc,
-                         Y->usub, Y->relpos, Y->sn_rowptr, Y->sn_lx, Y->Lx, Y->upart, Y->upd_nw[l]);
+                         Y->usub, Y->relpos, Y->sn_rowptr, Y->sn_lx, Y->Lx, Y->upart, Y->upd_nw[l], (const int*)Y->d_info);
     else if(nu > 0 && Y->upd_coop[l])
       hipLaunchKernelGGL(k_update_coop, dim3(nu), dim3(TPB), 0, st, H.uw_lvl_ptr[l],
                          Y->uw_item, Y->uw_s0, Y->uw_s1, Y->uw_part, Y->ui_t, Y->ui_col, Y->ui_nc,
-                         Y->usub, Y->relpos, Y->sn_rowptr, Y->sn_lx, Y->Lx, Y->upart);
+                         Y->usub, Y->relpos, Y->sn_rowptr, Y->sn_lx, Y->Lx, Y->upart, (const int*)Y->d_info);
     else if(nu > 0)
       hipLaunchKernelGGL(k_update_level, dim3(nu), dim3(TPB), Y->upd_lds[l], st, H.uw_lvl_ptr[l],
                          Y->uw_item, Y->uw_s0, Y->uw_s1, Y->uw_part, Y->ui_t, Y->ui_col, Y->ui_nc,
-                         Y->usub, Y->relpos, Y->sn_rowptr, Y->sn_lx, Y->Lx, Y->upart, Y->upd_nw[l]);
+                         Y->usub, Y->relpos, Y->sn_rowptr, Y->sn_lx, Y->Lx, Y->upart, Y->upd_nw[l], (const int*)Y->d_info);
     const int nfz = H.uf_lvl_ptr[l+1] - H.uf_lvl_ptr[l];
     if(nfz > 0)
       hipLaunchKernelGGL(k_update_fin, dim3(nfz, Y->fin_ny[l]), dim3(TPB), 0, st, H.uf_lvl_ptr[l], Y->uf_item, Y->uf_n,
                          Y->uf_off, Y->ui_t, Y->ui_col, Y->ui_nc, Y->sn_rowptr, Y->sn_lx, Y->Lx,
-                         Y->upart);
+                         Y->upart, (const int*)Y->d_info);
     // subtree partition: everything below the cut is done -- the sum over the ranks, then the replicated top
     if(H.part_nranks > 1 && l == H.cut_level) { DLG_LAUNCH_CHECK(); DLG_CHECK(sparse_partition_reduce(b)); }
   }
   if(!H.ms_sn.empty())
     hipLaunchKernelGGL(k_copy_top, dim3((unsigned)H.ms_sn.size()), dim3(TPB), 0, st, Y->ms_sn, Y->sn_c0,
-                       Y->sn_rowptr, Y->sn_lx, Y->sn_top, Y->Lx, Y->top_scr);
+                       Y->sn_rowptr, Y->sn_lx, Y->sn_top, Y->Lx, Y->top_scr, (const int*)Y->d_info);
   DLG_LAUNCH_CHECK();
   return DLG_OK;
 }

@@ -236,6 +236,17 @@ int sparse_set_pattern(dlg_backend* b, const int* colptr, const int* rowidx)
       DLG_CHECK(upload(Y->clr_off, off)); Y->allocs.push_back(Y->clr_off);
       DLG_CHECK(upload(Y->clr_len, len)); Y->allocs.push_back(Y->clr_len);
     }
+    {
+      // the diagonal entries of the level-0 columns (sparse_factorize: the look at the diagonal in front of a factorisation at lambda = 0)
+      std::vector<int64_t> dp; std::vector<int> dc;
+      for(int k = 0; k < H.N; k++) if(H.sn_level[H.col_sn[k]] == 0) { dp.push_back(H.diagpos[k]); dc.push_back(k); }
+      Y->n_leaf_diag = (int)dp.size();
+      if(Y->n_leaf_diag > 0)
+      {
+        DLG_CHECK(upload(Y->leaf_diag, dp)); Y->allocs.push_back(Y->leaf_diag);
+        DLG_CHECK(upload(Y->leaf_diag_col, dc)); Y->allocs.push_back(Y->leaf_diag_col);
+      }
+    }
     DLG_HIP(hipMalloc(&Y->fin_flag, sizeof(int)*2)); Y->allocs.push_back(Y->fin_flag);
     DLG_HIP(hipMemsetAsync(Y->fin_flag, 0, sizeof(int)*2, b->stream));
   }
@@ -489,6 +500,35 @@ extern "C" int dlg_sparse_schedule(dlg_backend_t* b, int* n_levels, int* persist
 }
 
 // K4 + K5
+namespace {
+__global__ void __launch_bounds__(TPB) k_diag_look(const double* __restrict__ Lx, const int64_t* __restrict__ pos, const int* __restrict__ col, int n, int* __restrict__ info)
+{
+  for(int i = blockIdx.x*TPB + threadIdx.x; i < n; i += gridDim.x*TPB)
+    if(!(Lx[pos[i]] > 0.0)) atomicMin(info, -2 - col[i]);      // (negative: found here, in front of every launch of the factorisation)
+}
+}
+bool sparse_would_look(const dlg_backend* b, double lambda)
+{
+  const SparseSym* Y = b->sym;
+  return Y && lambda == 0.0 && Y->zero_fail_seen && Y->n_leaf_diag > 0 && !Y->lf_on && Y->H.part_nranks <= 1 && !b->sharded() && !getenv("DOGLEG_AMD_NO_DIAG_LOOK");
+}
+// The host has learnt that a factorisation broke down.  At lambda = 0 the next ones look at the diagonal first.  Returns
+// true if THIS one was stopped by that look (a negative pivot word): no launch of it stored anything -- every kernel of the
+// factorisation returns at its first look at the word --, the panels hold what the assembly left (JtJ + lambda I, the
+// right-hand side rows), and the next attempt of the lambda loop takes them over (sparse_assemble) instead of assembling again.
+bool sparse_note_breakdown(dlg_backend* b)
+{
+  SparseSym* Y = b->sym;
+  if(!Y) return false;
+  if(Y->cur_lambda == 0.0) Y->zero_fail_seen = true;
+  Y->intact_Lx = nullptr;
+  if(*Y->h_info < 0 && Y->fac_J && !Y->lf_on && !getenv("DOGLEG_AMD_NO_INTACT"))
+  {
+    Y->intact_Lx = Y->Lx; Y->intact_slot = Y->fac_slot; Y->intact_J = Y->fac_J; Y->intact_lambda = Y->cur_lambda;
+    return true;
+  }
+  return false;
+}
 int sparse_factorize(dlg_backend* b, int s, double lambda, int* ok)
 {
   SparseSym* Y = b->sym;
@@ -496,6 +536,7 @@ int sparse_factorize(dlg_backend* b, int s, double lambda, int* ok)
   hipStream_t st = b->stream;
   Y->cur_lambda = lambda;
   DLG_CHECK(sparse_assemble(b, s, lambda));
+  Y->fac_slot = s; Y->fac_J = b->slot[s].Jin();
   DlgProfScope pf(b, DLG_PROF_K5_FACTOR);
   if(!Y->info_armed)
   {
@@ -505,6 +546,24 @@ int sparse_factorize(dlg_backend* b, int s, double lambda, int* ok)
   }
   Y->info_clean = false;
   Y->fac_pending = false;
+  if(sparse_would_look(b, lambda))
+  {
+    hipLaunchKernelGGL(k_diag_look, dim3(dlg_cdiv(Y->n_leaf_diag, 4*TPB)), dim3(TPB), 0, st, (const double*)Y->Lx, Y->leaf_diag, Y->leaf_diag_col, Y->n_leaf_diag, Y->d_info);
+    DLG_LAUNCH_CHECK();
+    // The host asks at once (this backend HAS broken down at lambda = 0 before: a synchronisation of ~20 us against the
+    // launches of a whole doomed attempt -- K5's levels, K6, K7, K8, each returning at its first look at the word: 0.4 ms on
+    // config #5): doomed -> nothing else is enqueued, the caller's lambda loop goes on with panels that are the assembly's.
+    DLG_HIP(hipMemcpyAsync(Y->h_info, Y->d_info, sizeof(int), hipMemcpyDeviceToHost, st));
+    DLG_HIP(hipStreamSynchronize(st));
+    if(*Y->h_info < 0)
+    {
+      if(pf.e) { dlg_prof_end(b, pf.id, pf.e); pf.e = nullptr; }
+      (void)sparse_note_breakdown(b);
+      b->factor_doomed = true;
+      *ok = 0;
+      return DLG_OK;
+    }
+  }
   DLG_CHECK(sparse_factor_levels(b, b->factor_ahead ? 1 : 0));
   if(pf.e) { dlg_prof_end(b, pf.id, pf.e); pf.e = nullptr; }
   // the caller's dlg_fetch_scalars(b, NSCAL) brings the flag along; sparse_factor_ok() reads it then

@@ -105,6 +105,15 @@ struct SparseSym
   double *Lx = nullptr, *scr = nullptr, *ywork = nullptr, *asm_part = nullptr, *jtx_part = nullptr;
   int *d_info = nullptr, *h_info = nullptr;   // pivot flag: inside the backend's scalar block (device / pinned host)
   bool info_armed = false;                    // the assembly re-armed the flag (k_set_aug_row)
+  // A factorisation at lambda = 0 that broke down before (the reference's lambda loop, dogleg.c:656-677; its lambda is sticky, a
+  // caller that starts over from 0 every step pays the failed attempt every step): from then on a factorisation at lambda = 0
+  // looks at the diagonal entries of the leaves' columns first (final once the assembly kernel is through) -- one that is not
+  // positive is a pivot that is not (pivot <= diagonal entry), the doomed launches find the pivot word lowered and return.
+  bool zero_fail_seen = false; int64_t* leaf_diag = nullptr; int* leaf_diag_col = nullptr; int n_leaf_diag = 0;
+  // ... and a factorisation stopped by that look has stored nothing: its panels (intact_Lx, of slot intact_slot's inputs
+  // intact_J, assembled with intact_lambda) are what the next attempt of the lambda loop factors (sparse_assemble)
+  double* intact_Lx = nullptr; const double* intact_J = nullptr; int intact_slot = -1; double intact_lambda = 0.0;
+  const double* fac_J = nullptr; int fac_slot = -1;      // the inputs of the last sparse_factorize
   bool fac_pending = false;                   // sparse_factor_levels(b, 1) launched the leaf level only: part 2 is owed (backend.hip, step_prepare)
   size_t nnz_loc = 0;
   // sharded rows: positions of the structural non-zeros of JtJ in Lx (what the all-reduce carries)

@@ -1069,3 +1069,45 @@ def test_a_retry_with_the_expected_improvement_behind_the_decision_point(gpu, de
             assert a[0] == b[0] and (a[1] == b[1] or (a[1] != a[1] and b[1] != b[1])) and a[2] == b[2], (late, i, a[:3], b[:3])
             assert abs(a[3] - b[3]) <= 1e-13*abs(b[3]), (late, i, a[3], b[3])
             assert np.array_equal(a[4], b[4]) and np.array_equal(a[5], b[5]), (late, i)
+
+
+@pytest.mark.parametrize("shape", [(49, 900, 10000), (199, 3600, 40000)])
+def test_a_breakdown_seen_before_is_found_at_the_diagonal_and_costs_no_second_assembly(gpu, shape, monkeypatch):
+    """The reference's lambda loop (dogleg.c:656-677) on a problem with exactly-zero columns, every step started over from
+    lambda = 0 (what bench.py's `value` does on config #5): the first factorisation breaks down at a pivot; from then on a
+    factorisation at lambda = 0 looks at the diagonal of the leaves' columns first (a diagonal entry that is not positive is
+    a pivot that is not), every launch of the doomed attempt returns at its first look at the pivot word, and the next
+    attempt of the loop takes the untouched panels over -- lambda onto the diagonal, nothing assembled again.  Against the
+    same steps with DOGLEG_AMD_NO_DIAG_LOOK (the attempt runs into the pivot, the panels are assembled again): lambda, every
+    scalar, the step and p_new bit for bit; and against the oracle's step."""
+    prob = oa.BAProblem(*shape, seed=13, scale_decades=2.0, n_zero_cols=3)
+    Jp, Ji = prob.pattern()
+    p = prob.p0()
+    evals = [prob.eval(p + 0.002*k) for k in range(3)]
+
+    def run():
+        be = capi.Backend(capi.DLG_SPARSE, prob.N, prob.M, prob.nnz)
+        be.set_pattern(Jp, Ji)
+        be.set_speculation(True)
+        be.set_p(0, p)
+        be.upload(0, *evals[0])
+        be.eval(0)
+        lam, n2c, n2g = be.cauchy_gauss_newton(0, 0.0)
+        assert lam > 0.0
+        tr = 0.6 * (np.sqrt(n2c) + np.sqrt(n2g))
+        res = []
+        for rep in range(6):
+            be.upload(0, *evals[rep % 3])
+            n2x, gmax = be.eval(0)
+            lam, r, pn = be.take_step(0, 1, tr, 0.0)           # from lambda = 0 every time
+            res.append((lam, n2x, gmax, tuple(sorted(r.items())), pn.copy(), be.download(1, capi.VEC_STEP), be.download(0, capi.VEC_GN)))
+        be.close()
+        return res
+    monkeypatch.delenv("DOGLEG_AMD_NO_DIAG_LOOK", raising=False)
+    got = run()
+    monkeypatch.setenv("DOGLEG_AMD_NO_DIAG_LOOK", "1")
+    want = run()
+    for i, (a, b) in enumerate(zip(got, want)):
+        assert a[0] == b[0] and a[0] > 0.0 and a[1] == b[1] and a[2] == b[2], i
+        assert all(ka == kb and (va == vb or (va != va and vb != vb)) for (ka, va), (kb, vb) in zip(a[3], b[3])), (i, a[3], b[3])
+        assert np.array_equal(a[4], b[4]) and np.array_equal(a[5], b[5]) and np.array_equal(a[6], b[6]), i
