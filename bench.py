@@ -290,7 +290,8 @@ def main():
         first_retry_ms = t_first / n_first * 1e3
         one_step()
     # A workload whose factorisation breaks down at lambda = 0 (config #5: exactly-zero columns): `value` restarts every step
-    # from lambda0 = 0 -- K4 + the failed K5 of the first attempt are paid every time, the worst case.  The reference's lambda is
+    # from lambda0 = 0 -- the worst case (rounds 1-4: K4 + the failed K5 of the first attempt paid every time; round 5: a look at
+    # the diagonal in front of the attempt, sparse_host.hip).  The reference's lambda is
     # sticky (dogleg.c:138, 670-673): after the first failure a real solve starts every later step at the lambda that worked.
     sticky = None
     if kind == "sparse" and not use_dist and not logical and res[8] != lam0:
@@ -304,7 +305,8 @@ def main():
         assert rs["lam"] == lam_s and abs(rs["n2s"] - res[4]) <= 1e-9 * abs(res[4])
         sticky = {"ms_per_step": sticky_ms, "steps_per_s": 1e3 / sticky_ms, "lambda": lam_s,
                   "what": "the same step started at the lambda the first step ended with (the reference's sticky lambda): one factorisation a step; "
-                          "`value` starts every step at lambda0 and pays the failed attempt again"}
+                          "`value` starts every step at lambda0: since round 5 that costs a look at the diagonal and one more host "
+                          "synchronisation (the doomed attempt enqueues nothing, its panels are factored at the next lambda: no second assembly)"}
     # the same step with K1 and K4 as two passes over J (how rounds 1-2 reported `value`)
     sep_ms = None
     if one_pass and not logical:
