@@ -55,7 +55,7 @@ timed loop only the roofline kernel carries HIP events; the phase table is from 
 {row2('sparse1m', 'sparse-1m (#4: 1M x 150k, 15M nnz)')}
 {row2('sparse200k', 'sparse-200k (#3: 200k x 30k, 3M nnz)')}
 {row2('dense50k', 'dense-50k (#2: 50k x 2k; CPU row-sampled, see JSON)')}
-{row2('sparse5m', 'sparse-5m (#5: 5M x 500k, 75M nnz, 2 factorisations per step: lambda path)')}
+{row2('sparse5m', 'sparse-5m (#5: 5M x 500k, 75M nnz, every step restarted at lambda = 0: the lambda loop)')}
 
 Per-phase GPU time (HIP events on the stream the phase runs on, ms per step; K3 runs on the second
 stream beside K5, so the phases add up to more than the step):
