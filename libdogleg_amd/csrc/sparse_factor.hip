@@ -8,7 +8,7 @@
 namespace {
 // -DDLG_FL_PROFILE: phase clocks of workgroup 0 of every factor launch (tools only)
 #ifdef DLG_FL_PROFILE
-constexpr int FL_PROF_WG = 1024;       // workgroups per level whose phase clocks are kept
+constexpr int FL_PROF_WG = 4096;       // workgroups per level whose phase clocks are kept
 __device__ long long g_fl_prof[32*FL_PROF_WG*8];
 __device__ long long g_fl_add[FL_PROF_WG*4];          // the children's adds of the one-launch region: see mf_add_children
 #define FL_ADD_STAMP(k) do { if(HANDOFF && threadIdx.x == 0 && blockIdx.x < FL_PROF_WG) g_fl_add[blockIdx.x*4 + (k)] = wall_clock64(); } while(0)
