@@ -214,16 +214,32 @@ int  dlg_point_eval(dlg_backend_t* b, int slot, double* norm2_x, double* Jtx_abs
  * factorises again.  DOGLEG_AMD_NO_PRESOLVE=1 keeps the evaluation to the assembly. */
 int  dlg_backend_set_speculation(dlg_backend_t* b, int on);
 /* The expected improvement behind the decision point.  takeStepFrom (dogleg.c:1172-1297) computes the expected improvement
- * with the step, but the reference first USES the value behind the evaluation of the trial point (dogleg.c:1410-1427;
- * "done" is decided on max|step|, 1289-1296).  With this on (sparse, single rank), dlg_take_step returns NaN in its place
- * (out7[6]) as soon as the step's scalars are on the host; the pass over J that forms |J step|^2 (K8) is on the backend's
- * stream behind the step, running while the host is on its way back and enqueues what comes next -- the model's kernels,
- * the evaluation of the trial point --, and dlg_step_tail waits for it and returns the value (bit for bit the one
- * dlg_take_step would have returned).  A page-locked
- * p_new_host is complete when dlg_step_tail returns, not before.  Until then the caller leaves the J arrays of the slot
- * the step was taken from alone (binding other arrays to the slot is fine).  dlg_step_tail with nothing outstanding
- * returns the last value.  DOGLEG_AMD_NO_DEFER_TAIL=1: the switch does nothing. */
+ * with the step (1258-1269); runOptimizer looks at it twice: `expectedImprovement < 0.0` in front of the evaluation of the trial
+ * point (dogleg.c:1403-1408: stop, the step is not applied; takeStepFrom's own -1 for max|step| below the threshold, 1289-1296,
+ * is the usual way there) and as rho's denominator behind it (1410-1427).  With this on (single rank), dlg_take_step returns
+ * NaN in its place (out7[6]) as soon as the step's scalars are on the host; the pass over J that forms |J step|^2 (K8) is on
+ * the backend's stream behind the step, running while the host is on its way back and enqueues what comes next -- the model's
+ * kernels, the evaluation of the trial point --, and dlg_step_tail waits for it and returns the value (sparse: bit for bit the
+ * one dlg_take_step would have returned; dense: to rounding, the host adds the partial sums in index order).  A caller that
+ * defers the value evaluates the trial point BEFORE it can make the first of the two tests, and makes it then (driver.hip,
+ * run_optimizer: a computed value below zero still stops the solve with the step not applied; the one extra evaluation is
+ * discarded).  A page-locked p_new_host is complete when dlg_step_tail returns, not before.  Until then the caller leaves
+ * the J arrays of the slot the step was taken from alone (binding other arrays to the slot is fine).  dlg_step_tail with
+ * nothing outstanding returns the value of the last step, whichever way it was formed; dlg_step_tail_pending says whether a
+ * value is outstanding (NaN in out7[6] is how dlg_take_step says so, but a computed NaN looks the same).
+ * DOGLEG_AMD_NO_DEFER_TAIL=1: the switch does nothing.
+ *
+ * The value itself needs no pass over J where the Gauss-Newton system was solved at lambda = 0 with a factor whose pivots
+ * span less than 212x ((max L_ii / min L_ii)^2 eps <= 1e-11): |J gn|^2 = -<Jt x, gn>, <J cauchy, J gn> = -<cauchy, Jt x>,
+ * |J cauchy|^2 is the Cauchy step's own scalar (backend.hip: ident_norm2_Jstep; to rounding the number of
+ * computeExpectedImprovement, dogleg.c:1085-1165).  The step kernel decides on the device, the pass over J that is on the
+ * stream returns at once.  Any lambda > 0, a wider pivot range, several ranks: the pass over J, as before.
+ * DOGLEG_AMD_EI_JPASS=1: always the pass over J. */
 int  dlg_backend_set_defer_tail(dlg_backend_t* b, int on);
+int  dlg_step_tail_pending(dlg_backend_t* b);
+/* how the last expected improvement handed out was formed: *from_solved_system = 1 without a pass over J; *pivot_ratio =
+ * max L_ii / min L_ii of the factor behind the last dlg_take_step (NaN: not looked at -- dense, several ranks, the knob) */
+int  dlg_backend_ei_source(dlg_backend_t* b, int* from_solved_system, double* pivot_ratio);
 int  dlg_step_tail(dlg_backend_t* b, double* expected_improvement);
 /* measurement only (tools/rccl_floor.py): average enqueue-to-completion time, in microseconds, of `iters` all-reduces of
  * `count` doubles on the backend's stream through the communicator it holds */

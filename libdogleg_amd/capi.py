@@ -38,6 +38,7 @@ BACKEND_SYMBOLS = [
     "dlg_backend_set_allreduce", "dlg_backend_set_partition", "dlg_partition_rows", "dlg_partition_stats",
     "dlg_sparse_partition_probe", "dlg_rccl_unique_id", "dlg_backend_init_rccl", "dlg_backend_set_rccl",
     "dlg_backend_comm_size", "dlg_backend_has_rccl", "dlg_backend_set_noop_comm", "dlg_solve_multi", "dlg_pseudoinverse_chunk", "dlg_backend_set_speculation", "dlg_backend_set_defer_tail", "dlg_step_tail",
+    "dlg_step_tail_pending", "dlg_backend_ei_source",
     "dlg_backend_share_rccl", "dlg_point_gather_device", "dlg_backend_reset", "dlg_backend_device",
     "dlg_sparse_pattern_matches", "dlg_sparse_drop_pattern", "dlg_sparse_region_probe", "dlg_run_steps", "dlg_backend_time_allreduce",
 ]
@@ -85,6 +86,8 @@ def lib():
     L.dlg_backend_set_speculation.argtypes = [V, C.c_int]
     L.dlg_backend_set_defer_tail.argtypes = [V, C.c_int]
     L.dlg_step_tail.argtypes = [V, C.POINTER(C.c_double)]
+    L.dlg_step_tail_pending.argtypes = [V]
+    L.dlg_backend_ei_source.argtypes = [V, I, D]
     L.dlg_backend_set_partition.argtypes = [V, C.c_int, C.c_int]
     L.dlg_partition_rows.argtypes = [V, I, C.POINTER(I)]
     L.dlg_partition_stats.argtypes = [V, C.POINTER(C.c_long), C.c_int]
@@ -427,6 +430,15 @@ class Backend:
         _ck(self.L.dlg_step_tail(self.h, C.byref(v)), "step_tail")
         return v.value
 
+    def step_tail_pending(self):
+        return bool(self.L.dlg_step_tail_pending(self.h))
+
+    def ei_source(self):
+        """(the last expected improvement came from the solved system -- no pass over J --, pivot ratio of the factor)"""
+        f, r = C.c_int(), C.c_double()
+        _ck(self.L.dlg_backend_ei_source(self.h, C.byref(f), C.byref(r)), "ei_source")
+        return bool(f.value), r.value
+
     def set_allreduce(self, fn):
         """host-synchronous sum-all-reduce hook (fallback / logical ranks on one device)"""
         cb = ALLREDUCE_FN(fn) if fn is not None else None
@@ -550,7 +562,7 @@ class Backend:
         _ck(self.L.dlg_step(self.h, frm, to, kind, trustregion, C.byref(n2), C.byref(k), C.byref(am),
                             C.byref(ei), dptr(self._pnew) if want_p else None), "step")
         e = ei.value
-        if tail and e != e:
+        if tail and self.step_tail_pending():
             e = self.step_tail()                # set_defer_tail: the value (and a page-locked p_new) complete here
         return n2.value, k.value, am.value, e, (self._pnew if want_p else None)
 
@@ -566,7 +578,7 @@ class Backend:
         keys = ("n2c", "n2g", "kind", "n2s", "k", "amax", "ei")
         r = dict(zip(keys, [float(v) for v in out]))
         r["kind"] = int(r["kind"])
-        if tail and r["ei"] != r["ei"]:
+        if tail and self.step_tail_pending():
             r["ei"] = self.step_tail()          # set_defer_tail: the value (and a page-locked p_new) complete here
         return l.value, r, (self._pnew if want_p else None)
 

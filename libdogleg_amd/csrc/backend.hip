@@ -251,6 +251,10 @@ extern "C" int dlg_backend_create(dlg_backend_t** out, int solve_type, int Nstat
     k.no_abandon = getenv("DOGLEG_AMD_NO_ABANDON") != nullptr;
     k.no_split = getenv("DOGLEG_AMD_NO_SPLIT_PRESOLVE") != nullptr;
     k.no_reject_run = getenv("DOGLEG_AMD_NO_REJECT_RUN") != nullptr;
+    k.ei_jpass = getenv("DOGLEG_AMD_EI_JPASS") != nullptr;
+    // test hook of the driver's `expected improvement < 0` stop (dogleg.c:1403-1408; exact arithmetic never gets there: the
+    // value is a positive definite form of Jt x for all three kinds of step): the n-th value this backend hands out is negated
+    if(const char* e = getenv("DOGLEG_AMD_DEBUG_EI_FLIP")) b->ei_flip = atoi(e);
     // test hook of the hand-off time-outs: the waits of the one-launch regions look for an epoch that never
     // comes and give up after a few hundred polls
     if(getenv("DOGLEG_AMD_DEBUG_HANDOFF_TIMEOUT")) { b->handoff_skew = 1; b->handoff_spins = 256; }
@@ -401,6 +405,11 @@ extern "C" int dlg_backend_set_defer_tail(dlg_backend_t* b, int on)
 }
 // Before anything overwrites what a tail that is still out reads (the step vector, p_new, J of its slot): the tail is a
 // launch on the backend's own stream, so whatever is enqueued there is behind it already.
+static double ei_out(dlg_backend* b, double v)
+{
+  if(b->ei_flip > 0 && ++b->ei_count == b->ei_flip) return -fabs(v);
+  return v;
+}
 static int tail_guard(dlg_backend*) { return DLG_OK; }
 extern "C" int dlg_step_tail(dlg_backend_t* b, double* expected_improvement)
 {
@@ -409,11 +418,21 @@ extern "C" int dlg_step_tail(dlg_backend_t* b, double* expected_improvement)
   {
     if(b->tail_mark == b->sync_mark) DLG_HIP(hipStreamSynchronize(b->stream));      // (nobody has waited for anything behind K8 yet)
     double v = 0.0;
-    for(int i = 0; i < b->tail_nb; i++) v += b->h_tail[i];          // in index order, as dlg_resolve_pending adds them
-    b->tail_value = -2.0*b->tail_inner - v;                          // dogleg.c:1107-1109
-    b->tail_pending = false;
+    if(b->tail_ident) v = b->tail_nJs;                                // (from the solved system: that K8 returned at once)
+    else for(int i = 0; i < b->tail_nb; i++) v += b->h_tail[i];     // in index order, as dlg_resolve_pending adds them
+    b->tail_value = ei_out(b, -2.0*b->tail_inner - v);               // dogleg.c:1107-1109
+    b->ei_from_system = b->tail_ident;
+    b->tail_pending = false; b->tail_ident = false;
   }
   if(expected_improvement) *expected_improvement = b->tail_value;
+  return DLG_OK;
+}
+extern "C" int dlg_step_tail_pending(dlg_backend_t* b) { return (b && b->tail_pending) ? 1 : 0; }
+extern "C" int dlg_backend_ei_source(dlg_backend_t* b, int* from_solved_system, double* pivot_ratio)
+{
+  if(!b) return DLG_ERR_ARG;
+  if(from_solved_system) *from_solved_system = b->ei_from_system ? 1 : 0;
+  if(pivot_ratio) *pivot_ratio = b->pivot_ratio;
   return DLG_OK;
 }
 
@@ -609,6 +628,25 @@ static int check_slot(dlg_backend* b, int s)
 static void invalidate(DlgSlot& S)
 {
   S.have_Jtx = S.have_cauchy = S.have_gn = false;
+  S.ident_ok = false;
+}
+
+// |J step|^2 without a pass over J.  The Cauchy step is a = kappa g with kappa = -|g|^2 / |J g|^2 (dogleg.c:605): |J a|^2 =
+// kappa^2 |J g|^2, K3's own scalar.  The Gauss-Newton step b solves (JtJ + lambda I) b = -g, so at lambda = 0
+// |J b|^2 = b' JtJ b = -<g, b> and <J a, J b> = a' JtJ b = -<a, g> = -kappa |g|^2; the interpolated step is
+// (1 - k) a + k b (dogleg.c:964-987).  The error of the last two against the pass over J is b' r with r the residual of
+// the solve, i.e. eps * cond(JtJ) relative: the caller uses them only where the factor's pivot ratio says cond is small
+// (k_part_take_step) -- the value agrees with computeExpectedImprovement (dogleg.c:1085-1165) to rounding there.
+static double ident_norm2_Jstep(int kind, double k, double trustregion, double g2, double Jg2, double n2c, double g_dot_gn)
+{
+  const double kappa = -g2/Jg2;
+  const double Ja2 = kappa*kappa*Jg2;
+  switch(kind)
+  {
+  case DLG_KIND_CAUCHY_TO_EDGE: { const double sc = trustregion/sqrt(n2c); return sc*sc*Ja2; }      // dogleg.c:1204-1207
+  case DLG_KIND_GAUSSNEWTON:    return -g_dot_gn;
+  default:                      return (1.0 - k)*(1.0 - k)*Ja2 - 2.0*k*(1.0 - k)*kappa*g2 - k*k*g_dot_gn;
+  }
 }
 
 static int tail_guard(dlg_backend* b);
@@ -960,6 +998,7 @@ extern "C" int dlg_cauchy(dlg_backend_t* b, int s, double* norm2_updateCauchy)
     DLG_CHECK(cauchy_enqueue(b, s, b->d_scal));
     DLG_CHECK(dlg_fetch_scalars(b, 3));
     S.norm2_cauchy = b->h_scal[2];
+    S.Jg2 = b->sharded() ? 0.0 : b->h_scal[1];       // (|J Jt_x|^2: ident_norm2_Jstep; a rank of several holds a partial sum there)
     S.have_cauchy = true;
   }
   if(norm2_updateCauchy) *norm2_updateCauchy = S.norm2_cauchy;
@@ -1006,7 +1045,7 @@ extern "C" int dlg_solve_gn(dlg_backend_t* b, int s, double* norm2_updateGN)
     DLG_CHECK(k_negate_norm2(b, S.gn, b->N, b->d_scal));      // dogleg.c:862-865
     DLG_CHECK(dlg_fetch_scalars(b, 1));
     S.norm2_gn = b->h_scal[0];
-    S.have_gn = true;
+    S.have_gn = true; S.ident_ok = false;
   }
   if(norm2_updateGN) *norm2_updateGN = S.norm2_gn;
   return DLG_OK;
@@ -1080,7 +1119,7 @@ static int gauss_newton_impl(dlg_backend_t* b, int s, double* lambda_io, double*
     DLG_CHECK(k_negate_norm2(b, S.gn, b->N, b->d_scal));      // dogleg.c:862-865
     DLG_CHECK(dlg_fetch_scalars(b, dlg_backend::NSCAL));      // the one synchronisation (the sparse pivot flag rides in the last slot)
     if(b->profiling) dlg_prof_resolve(b);
-    if(cauchy_pending && !S.have_cauchy) { S.norm2_cauchy = b->h_scal[6]; S.have_cauchy = true; }
+    if(cauchy_pending && !S.have_cauchy) { S.norm2_cauchy = b->h_scal[6]; S.Jg2 = b->sharded() ? 0.0 : b->h_scal[5]; S.have_cauchy = true; }
     good = (b->factor_slot == s) ? 1 : (b->type == DLG_SPARSE ? sparse_factor_ok(b) : dense_factor_ok(b));
     if(b->profiling) dlg_prof_commit(b, good != 0);
     if(good) break;
@@ -1092,7 +1131,7 @@ static int gauss_newton_impl(dlg_backend_t* b, int s, double* lambda_io, double*
   }
   b->factor_slot = s;
   S.norm2_gn = b->h_scal[0];
-  S.have_gn = true;
+  S.have_gn = true; S.ident_ok = false;        // (<Jt x, gn> is formed by dlg_take_step only)
   *lambda_io = lam;
   if(norm2_updateGN) *norm2_updateGN = S.norm2_gn;
   if(with_cauchy && norm2_updateCauchy) *norm2_updateCauchy = S.norm2_cauchy;
@@ -1219,7 +1258,7 @@ extern "C" int dlg_expected_improvement(dlg_backend_t* b, int from, int to, doub
   DLG_CHECK(check_slot(b, from)); DLG_CHECK(check_slot(b, to));
   DLG_CHECK(expected_improvement_enqueue(b, from, to, b->d_scal));
   DLG_CHECK(dlg_fetch_scalars(b, 2));
-  if(out) *out = -2.0*b->h_scal[0] - b->h_scal[1];               // dogleg.c:1107-1109
+  if(out) { *out = ei_out(b, -2.0*b->h_scal[0] - b->h_scal[1]); b->tail_value = *out; b->ei_from_system = false; }              // dogleg.c:1107-1109
   return DLG_OK;
 }
 // K7 + K8 behind one synchronisation: the step (dlg_make_step), its expected improvement
@@ -1234,6 +1273,29 @@ extern "C" int dlg_step(dlg_backend_t* b, int from, int to, int kind, double tru
   DLG_CHECK(tail_guard(b)); b->tail_pending = false;
   double n2 = 0, kk = NAN, amax = 0;
   int nscal = 0;
+  // The expected improvement from the solved system (ident_norm2_Jstep): a step from the cached vectors of a point whose
+  // dlg_take_step left <Jt x, gn> and the factor's verdict behind -- or the Cauchy step, which needs K3's scalar only --
+  // has no pass over J at all: step, <Jt x, step>, one synchronisation, the value at once (nothing deferred)
+  {
+    DlgSlot& F = b->slot[from];
+    const bool ident = expected_improvement && !b->knobs.ei_jpass && b->host_finals && !b->sharded() && b->part_nranks <= 1 &&
+                       b->type != DLG_DENSE_PRODUCTS && F.have_Jtx && F.have_cauchy && F.Jg2 > 0.0 &&
+                       (kind == DLG_KIND_CAUCHY_TO_EDGE || (F.ident_ok && F.have_gn));
+    if(ident)
+    {
+      DLG_CHECK(make_step_enqueue(b, from, to, kind, trustregion, &nscal));
+      if(!b->ev_fetch) DLG_HIP(hipEventCreateWithFlags(&b->ev_fetch, hipEventDisableTiming));
+      DLG_CHECK(k_inner(b, F.Jt_x, b->slot[to].step, b->N, b->d_scal + 4));
+      DLG_CHECK(step_finish(b, to, 6, p_new_host));
+      make_step_read(b, from, kind, &n2, &kk, &amax);
+      if(norm2_step) *norm2_step = n2;
+      if(k_cauchy_to_gn) *k_cauchy_to_gn = kk;
+      if(step_absmax) *step_absmax = amax;
+      *expected_improvement = ei_out(b, -2.0*b->h_scal[4] - ident_norm2_Jstep(kind, kk, trustregion, F.norm2_jtx, F.Jg2, F.norm2_cauchy, F.g_dot_gn));
+      b->tail_value = *expected_improvement; b->ei_from_system = true;
+      return DLG_OK;
+    }
+  }
   // K8 behind the decision point (dlg_backend_set_defer_tail), as in dlg_take_step: the host waits for the kernel that
   // forms <Jt x, step> -- every scalar of the step reaches it through page-locked partial sums, nothing is copied --,
   // the pass over J and p_new follow on the stream, dlg_step_tail has the value
@@ -1280,8 +1342,25 @@ extern "C" int dlg_step(dlg_backend_t* b, int from, int to, int kind, double tru
         *expected_improvement = NAN;                             // (dlg_step_tail has it)
         return DLG_OK;
       }
-      dlg_set_error("internal error: the step's partial sums found no room in page-locked memory");
-      return DLG_ERR_STATE;
+      // (the sum <Jt x, step> found no room for its partial sums in page-locked memory -- k_inner ran with a second stage on
+      // the device instead and took no event along: the step is formed, the rest follows in the in-line form, as in dlg_take_step)
+      b->stop_attached = false; b->scal_copied = false;
+      DLG_CHECK(norm2_Jv(b, from, T.step, b->d_scal + 5));
+      // (kout_host: an interpolation whose partial sums DID find room has written k to the page-locked block itself)
+      bool k_on_host = false;
+      for(const dlg_backend::PendingFinal& f : b->pending) if(f.dst == 0 && f.stride == 2) k_on_host = true;
+      if(k_on_host && kind == DLG_KIND_INTERPOLATED)
+      {
+        DLG_HIP(hipMemcpyAsync(b->h_scal + 2, b->d_scal + 2, sizeof(double)*4, hipMemcpyDeviceToHost, b->stream));
+        b->scal_copied = true;
+      }
+      DLG_CHECK(step_finish(b, to, 6, p_new_host));
+      make_step_read(b, from, kind, &n2, &kk, &amax);
+      if(norm2_step) *norm2_step = n2;
+      if(k_cauchy_to_gn) *k_cauchy_to_gn = kk;
+      if(step_absmax) *step_absmax = amax;
+      *expected_improvement = ei_out(b, -2.0*b->h_scal[4] - b->h_scal[5]); b->tail_value = *expected_improvement; b->ei_from_system = false;
+      return DLG_OK;
     }
   }
   DLG_CHECK(make_step_enqueue(b, from, to, kind, trustregion, &nscal));
@@ -1309,7 +1388,7 @@ extern "C" int dlg_step(dlg_backend_t* b, int from, int to, int kind, double tru
   if(norm2_step) *norm2_step = n2;
   if(k_cauchy_to_gn) *k_cauchy_to_gn = kk;
   if(step_absmax) *step_absmax = amax;
-  if(expected_improvement) *expected_improvement = -2.0*b->h_scal[4] - b->h_scal[5];
+  if(expected_improvement) { *expected_improvement = ei_out(b, -2.0*b->h_scal[4] - b->h_scal[5]); b->tail_value = *expected_improvement; b->ei_from_system = false; }
   return DLG_OK;
 }
 
@@ -1332,9 +1411,10 @@ extern "C" int dlg_take_step(dlg_backend_t* b, int from, int to, double trustreg
   DlgSlot& T = b->slot[to];
   if(!F.have_inputs) { dlg_set_error("dlg_take_step: slot %d has no J/JtJ", from); return DLG_ERR_STATE; }
   if(!F.have_Jtx) { dlg_set_error("dlg_take_step needs Jt_x"); return DLG_ERR_STATE; }
-  if(!b->d_gnpart) DLG_HIP(hipMalloc(&b->d_gnpart, sizeof(double)*1024));
+  if(!b->d_gnpart) DLG_HIP(hipMalloc(&b->d_gnpart, sizeof(double)*4096));      // |gn|^2 partials, then the pivots' partial minima / maxima (k_negate_interp1)
   double lam = *lambda_io;
-  bool side_copy = false;
+  bool side_copy = false, ident_used = false;
+  double ident_nJs = 0.0;
   // (the factorisation and the solve enqueued by dlg_point_eval -- step_prepare -- are this step's if the
   // lambda is the one they were formed at; they are used once)
   const double lam_in = lam;
@@ -1358,6 +1438,14 @@ extern "C" int dlg_take_step(dlg_backend_t* b, int from, int to, double trustreg
                      tail_chunks > 0 && dlg_tail_partials(b, tail_chunks) != nullptr;
   // (the dense pass over J takes p_new along only in that form)
   bool p_fold = p_foldable && (b->type == DLG_SPARSE || (b->type == DLG_DENSE && defer));
+  // The expected improvement from the solved system instead of a pass over J (ident_norm2_Jstep): one rank, the host adds the
+  // partial sums; the sparse backward solve leaves the factor's pivots' minima / maxima per supernode for the step kernel
+  const bool ident_try = !b->knobs.ei_jpass && b->host_finals && !b->sharded() && b->part_nranks <= 1 && b->type != DLG_DENSE_PRODUCTS &&
+                         (!F.have_cauchy || F.Jg2 > 0.0);
+  int ident_nmm = 0; long ident_stride = 2;
+  const double* ident_mm = (ident_try && b->type == DLG_SPARSE) ? sparse_pivot_minmax(b, &ident_nmm) : nullptr;
+  if(ident_try && b->type == DLG_DENSE && b->G) { ident_mm = b->G; ident_nmm = b->N; ident_stride = (long)b->N + 1; }      // (the diagonal of the dense factor)
+  b->ident_launched = false;
   for(;;)
   {
     int good = 0, rc;
@@ -1418,7 +1506,7 @@ extern "C" int dlg_take_step(dlg_backend_t* b, int from, int to, double trustreg
     if(!b->ev_fetch) DLG_HIP(hipEventCreateWithFlags(&b->ev_fetch, hipEventDisableTiming));
     {
       DlgProfScope ps(b, DLG_PROF_K7_STEP);
-      DLG_CHECK(k_negate_interp1(b, F.gn, F.cauchy, b->N, b->d_gnpart, &nbg));      // dogleg.c:862-865, 964-972
+      DLG_CHECK(k_negate_interp1(b, F.gn, F.cauchy, b->N, b->d_gnpart, &nbg, ident_mm, ident_nmm, ident_stride));      // dogleg.c:862-865, 964-972
       if(defer)
       {
         // (the last kernel on the main stream: it takes the scalars to the host and carries the event the host waits for)
@@ -1426,7 +1514,10 @@ extern "C" int dlg_take_step(dlg_backend_t* b, int from, int to, double trustreg
         b->attach_stop = (b->ext_events && !(b->prof_mask >> DLG_PROF_K7_STEP & 1u)) ? b->ev_fetch : nullptr; b->stop_attached = false;
       }
       const int rc7 = k_take_step(b, F.cauchy, F.gn, b->d_gnpart, nbg, n2c_dev, trustregion, F.p, T.step, T.p, b->N,
-                                  b->d_scal, b->d_scal + 8, F.Jt_x, b->d_scal + 11);
+                                  b->d_scal, b->d_scal + 8, F.Jt_x, b->d_scal + 11,
+                                  ident_try ? b->d_scal + dlg_backend::GB_SLOT : (double*)nullptr,
+                                  ident_try ? b->d_scal + dlg_backend::IDENT_SLOT : (double*)nullptr,
+                                  ident_mm != nullptr, lam == 0.0, dlg_backend::IDENT_RATIO_MAX);
       b->fold_scal_k7 = 0; b->attach_stop = nullptr;
       DLG_CHECK(rc7);
     }
@@ -1451,9 +1542,10 @@ extern "C" int dlg_take_step(dlg_backend_t* b, int from, int to, double trustreg
       // No event of its own (a launch somebody listens to holds the next dispatch back by ~5 us): the evaluation that
       // follows is waited for on this stream behind it -- dlg_step_tail only waits itself if nothing was (sync_mark).
       b->tail_mode = true; b->fold_scal = 0; b->attach_stop = nullptr; b->stop_attached = false;
+      b->k8_skip = b->ident_launched ? b->d_scal + dlg_backend::IDENT_SLOT : nullptr;
       const int rct = b->type == DLG_SPARSE ? sparse_norm2_Jv(b, from, T.step, b->d_scal + 12, b->d_scal + 8)
                                             : dense_norm2_Jv(b, from, T.step, b->d_scal + 12);
-      b->tail_mode = false;
+      b->tail_mode = false; b->k8_skip = nullptr;
       b->fold_p_src = nullptr; b->p_copied = false;
       DLG_CHECK(rct);
       b->tail_pending = true;
@@ -1486,8 +1578,9 @@ extern "C" int dlg_take_step(dlg_backend_t* b, int from, int to, double trustreg
     b->fold_scal = dlg_backend::NSCAL;       // (the last kernel of the step: it takes the scalars to the host with it)
     b->attach_stop = (b->ext_events && !side_copy && !(b->prof_mask >> DLG_PROF_K3K8_NORM2JV & 1u)) ? b->ev_fetch : nullptr; b->stop_attached = false;   // ... and the event the host waits for
     int rc8;
+    b->k8_skip = b->ident_launched ? b->d_scal + dlg_backend::IDENT_SLOT : nullptr;
     { DlgProfCond pc(b); rc8 = norm2_Jv(b, from, T.step, b->d_scal + 12, b->d_scal + 8); }   // the other half of the expected improvement (returns early behind a failed factorisation unless the step is the Cauchy step)
-    b->attach_stop = nullptr;
+    b->attach_stop = nullptr; b->k8_skip = nullptr;
     b->fold_scal = 0;
     const bool p_done = b->p_copied;
     b->fold_p_src = nullptr; b->p_copied = false;
@@ -1496,7 +1589,14 @@ extern "C" int dlg_take_step(dlg_backend_t* b, int from, int to, double trustreg
     if(side_copy) DLG_HIP(hipEventSynchronize(b->ev_copy));
     }
     if(b->profiling) dlg_prof_resolve(b);
-    if(!F.have_cauchy) { F.norm2_cauchy = b->h_scal[6]; F.have_cauchy = true; }
+    if(!F.have_cauchy) { F.norm2_cauchy = b->h_scal[6]; F.Jg2 = b->h_scal[5]; F.have_cauchy = true; }
+    // the step kernel let the pass over J return at once: |J step|^2 from the solved system
+    ident_used = b->ident_launched && b->h_scal[dlg_backend::IDENT_SLOT] != 0.0 && F.Jg2 > 0.0;
+    if(b->ident_launched && !ident_used && b->h_scal[dlg_backend::IDENT_SLOT] != 0.0)
+    { dlg_set_error("internal error: the expected improvement's pass over J was skipped without |J Jt_x|^2 at hand"); return DLG_ERR_STATE; }
+    if(ident_used)
+      ident_nJs = ident_norm2_Jstep((int)b->h_scal[8], b->h_scal[9], trustregion, F.norm2_jtx, F.Jg2, F.norm2_cauchy, b->h_scal[dlg_backend::GB_SLOT]);
+    if(defer) { b->tail_ident = ident_used; b->tail_nJs = ident_nJs; }
     if((int)b->h_scal[8] == DLG_KIND_CAUCHY_TO_EDGE)
     {
       // The Cauchy step was the one taken: the reference never factorises on this branch
@@ -1509,7 +1609,8 @@ extern "C" int dlg_take_step(dlg_backend_t* b, int from, int to, double trustreg
       out7[3] = F.norm2_cauchy;                                 // unscaled: dogleg.c:1200
       out7[4] = NAN;
       out7[5] = b->h_scal[2];
-      out7[6] = defer ? NAN : -2.0*b->h_scal[11] - b->h_scal[12];             // dogleg.c:1107-1109 (NaN: dlg_step_tail has it)
+      out7[6] = defer ? NAN : ei_out(b, -2.0*b->h_scal[11] - (ident_used ? ident_nJs : b->h_scal[12]));             // dogleg.c:1107-1109 (NaN: dlg_step_tail has it)
+      if(!defer) { b->tail_value = out7[6]; b->ei_from_system = ident_used; }
       if(b->profiling) dlg_prof_commit(b, b->type == DLG_SPARSE ? sparse_factor_ok(b) : dense_factor_ok(b));
       return DLG_OK;
     }
@@ -1531,7 +1632,12 @@ extern "C" int dlg_take_step(dlg_backend_t* b, int from, int to, double trustreg
   out7[3] = (kind == DLG_KIND_CAUCHY_TO_EDGE) ? F.norm2_cauchy : (kind == DLG_KIND_GAUSSNEWTON ? F.norm2_gn : b->h_scal[0]);
   out7[4] = b->h_scal[9];
   out7[5] = b->h_scal[2];
-  out7[6] = defer ? NAN : -2.0*b->h_scal[11] - b->h_scal[12];               // dogleg.c:1107-1109 (NaN: dlg_step_tail has it)
+  out7[6] = defer ? NAN : ei_out(b, -2.0*b->h_scal[11] - (ident_used ? ident_nJs : b->h_scal[12]));               // dogleg.c:1107-1109 (NaN: dlg_step_tail has it)
+  if(!defer) { b->tail_value = out7[6]; b->ei_from_system = ident_used; }
+  b->pivot_ratio = b->ident_launched ? b->h_scal[dlg_backend::IDENT_SLOT + 1] : NAN;
+  // (a retry from the cached vectors of this point, dlg_step, takes the same route: <Jt x, gn> and the factor's verdict)
+  F.g_dot_gn = b->h_scal[dlg_backend::GB_SLOT];
+  F.ident_ok = b->ident_launched && lam == 0.0 && ident_mm != nullptr && b->h_scal[dlg_backend::IDENT_SLOT + 1] <= dlg_backend::IDENT_RATIO_MAX;
   return DLG_OK;
 }
 

@@ -46,6 +46,9 @@ struct DlgSlot
   const double* x_bound = nullptr;   // device-resident inputs (dlg_point_bind_device)
   const double* J_bound = nullptr;
   double  norm2_x = 0, norm2_cauchy = 0, norm2_gn = 0, norm2_jtx = 0;
+  // the expected improvement from the solved system (backend.hip, ident_norm2_Jstep): |J Jt_x|^2 of the Cauchy step, <Jt_x, gn>,
+  // and whether the factor the Gauss-Newton step came from allows it (lambda == 0, pivot ratio)
+  double  Jg2 = 0, g_dot_gn = 0; bool ident_ok = false;
   bool    have_inputs = false, have_Jtx = false, have_cauchy = false, have_gn = false;
   const double* xin() const { return x_bound ? x_bound : x; }
   const double* Jin() const { return J_bound ? J_bound : J; }
@@ -101,6 +104,18 @@ struct dlg_backend
   unsigned long sync_mark = 0, tail_mark = 0;
   bool factor_doomed = false; // sparse_factorize found the factorisation doomed at its look at the diagonal and enqueued nothing else (the lambda loops go on at once)
   bool kout_host = false;     // (dlg_step behind the decision point: k_interpolate's k straight into the page-locked scalars)
+  // The expected improvement WITHOUT its pass over J (K8): with (JtJ + lambda I) gn = -Jt_x solved, |J step|^2 of all three
+  // kinds of step is a combination of N-vector dot products (ident_norm2_Jstep).  The step kernel decides on the device
+  // (lambda == 0 and the factor's pivot ratio small enough -- d_scal[IDENT_SLOT] = 1, [IDENT_SLOT + 1] = the ratio) and the
+  // pass over J that is on the stream behind it returns at once (k8_skip); the host reads the same word and forms the value.
+  // DOGLEG_AMD_EI_JPASS=1: always the pass over J.
+  static constexpr int IDENT_SLOT = 3, GB_SLOT = 13;     // free slots of dlg_take_step's scalar block
+  static constexpr double IDENT_RATIO_MAX = 212.0;       // (max L_ii / min L_ii)^2 * 2.2e-16 <= 1e-11
+  bool ident_launched = false; const double* k8_skip = nullptr;
+  bool ei_from_system = false; double pivot_ratio = NAN;   // dlg_backend_ei_source: how the last value handed out was formed
+  int ei_flip = 0, ei_count = 0;                           // DOGLEG_AMD_DEBUG_EI_FLIP (test hook)
+  bool tail_ident = false; double tail_nJs = 0.0;
+  bool p_side_pending = false;          // p_new of a step behind the decision point is on its way on the copy stream (ev_copy)
   static constexpr int NSCAL = 16;
   // hand-offs inside the one-launch regions (flags between workgroups): a wait that gives up raises a bit in
   // the status word (slot NSCAL - 2 of the scalar block, so it travels with every fetch of the scalars);
@@ -112,7 +127,7 @@ struct dlg_backend
   {
     bool join_event = false;
     bool no_k3_fork = false, no_potrf_fuse = false, potrf_steps = false,
-         trsv_steps = false, no_touch = false, no_abandon = false, no_split = false, no_reject_run = false, no_defer_tail = false;
+         trsv_steps = false, no_touch = false, no_abandon = false, no_split = false, no_reject_run = false, no_defer_tail = false, ei_jpass = false;
     int touch_wg = 512;
   } knobs;
   int ncu = 256;              // compute units of b->device
@@ -288,10 +303,11 @@ int k_interpolate(dlg_backend* b, const double* a, const double* bb, double norm
 // gn = -u ; out[0] = norm2(gn)
 int k_negate_norm2(dlg_backend* b, double* v, int n, double* out);
 // step chosen on the device (dogleg.c:1192-1256): out_n2_max[0] = |step|^2, [2] = max|step|; out3 = {kind, k, |gn|^2}
-int k_negate_interp1(dlg_backend* b, double* gn, const double* cauchy, int n, double* gnpart, int* nb);
+int k_negate_interp1(dlg_backend* b, double* gn, const double* cauchy, int n, double* gnpart, int* nb, const double* mm = nullptr, int nmm = 0, long mm_stride = 2);
 int k_take_step(dlg_backend* b, const double* cauchy, const double* gn, const double* gnpart, int nbg,
                 const double* n2c_dev, double trustregion, const double* p, double* step, double* p_new, int n,
-                double* out_n2_max, double* out3, const double* Jtx, double* out_inner);
+                double* out_n2_max, double* out3, const double* Jtx, double* out_inner,
+                double* out_gb = nullptr, double* ident_out = nullptr, bool have_mm = false, bool ident_gn = false, double ratio_max = 0.0);
 // generic deterministic final reduction of `np` partials (sum) into out[0]
 int k_reduce_sum(dlg_backend* b, const double* partials, int np, double* out);
 // region of b->h_part for (nsum + nmax) x nb partials whose results go to h_scal[out - d_scal + k*stride],
@@ -362,6 +378,7 @@ int  dlg_gate_wait(dlg_backend* b, hipStream_t st, const int* gate, int epoch, b
 void sparse_release_held(dlg_backend* b);
 int sparse_restore_factor(dlg_backend* b, bool* restored, bool rearm = true);
 double sparse_current_lambda(const dlg_backend* b);                                 // of the last factorisation enqueued
+const double* sparse_pivot_minmax(const dlg_backend* b, int* n);                    // [supernode][min, max] of diag(L) left by the last backward solve
 // blocked multi-right-hand-side solves (sparse_multi.hip / kernels_dense.hip): MR = 16 right-hand sides
 // interleaved [N][MR] (element (variable k, rhs c) at k*MR + c), solved in place, original order
 int sparse_multi_width_ok(const dlg_backend* b);

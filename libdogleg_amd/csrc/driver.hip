@@ -413,8 +413,10 @@ bool eval_point(bool* converged, dogleg_operatingPoint_t* pt, Driver* d)
         // x and J stay where they are, the pattern is analysed and the evaluation made again.  (Same shape, so every index the
         // stale schedules hold is inside the arrays.)
         dlg_backend_t* be = d->be; const int* cp = d->dev_cp; const int* ri = d->dev_ri;
-        d->pat_check = new(std::nothrow) std::future<int>(std::async(std::launch::async, [be, cp, ri] { return dlg_sparse_pattern_matches(be, cp, ri); }));
-        if(!d->pat_check) { MSG("out of memory"); return false; }
+        // (a thread that cannot be started throws: then the comparison is made in line, as without the overlap)
+        try { d->pat_check = new std::future<int>(std::async(std::launch::async, [be, cp, ri] { return dlg_sparse_pattern_matches(be, cp, ri); })); }
+        catch(...) { d->pat_check = nullptr; }
+        if(!d->pat_check && !set_pattern(d, d->dev_cp, d->dev_ri)) return false;
       }
       else if(!set_pattern(d, d->dev_cp, d->dev_ri)) return false;
       d->pattern_set = true;
@@ -446,8 +448,9 @@ bool eval_point(bool* converged, dogleg_operatingPoint_t* pt, Driver* d)
       if(!be_ok(dlg_point_bind_device(d->be, s, x_dev + r0, J_dev + r0*(size_t)ctx->Nstate), "bind")) return false;
     }
     if(ctx->solve_type == DOGLEG_SPARSE) dlg_backend_set_speculation(d->be, d->expect_gn);
-    // the model lives on the device: nothing on the host waits for p_new, and the expected improvement of a step is first
-    // used behind the evaluation of its trial point (dogleg.c:1427) -- its pass over J runs beside this evaluation
+    // the model lives on the device: nothing on the host waits for p_new, and the expected improvement of a step is needed as
+    // rho's denominator behind the evaluation of its trial point (dogleg.c:1410-1427; the `< 0` stop of 1403-1408 is made
+    // there too, run_optimizer) -- its pass over J, if it needs one, runs beside this evaluation
     if((ctx->solve_type == DOGLEG_SPARSE || ctx->solve_type == DOGLEG_DENSE) && !d->sharded) dlg_backend_set_defer_tail(d->be, 1);
     int rc_eval;
     { Tick te(d, TM_EVAL); rc_eval = dlg_point_eval(d->be, s, &norm2x, &absmax); }
@@ -665,7 +668,7 @@ bool take_step(double* expectedImprovement, dogleg_operatingPoint_t* to,
     d->cur.norm2_cauchy = o[0];
     VERBOSE(d, "cauchy step length %.6g", sqrt(o[0]));
     kind = (int)o[2]; n2 = o[3]; k = o[4]; amax = o[5]; *expectedImprovement = o[6];
-    d->tail_out = std::isnan(o[6]);          // (dlg_backend_set_defer_tail: run_optimizer fetches it behind the evaluation)
+    d->tail_out = dlg_step_tail_pending(d->be) != 0;          // (dlg_backend_set_defer_tail: run_optimizer fetches it behind the evaluation)
     if(kind != DLG_KIND_CAUCHY_TO_EDGE)
     {
       // (on the Cauchy branch the backend dropped its speculative factor and GN step and left
@@ -708,7 +711,7 @@ bool take_step(double* expectedImprovement, dogleg_operatingPoint_t* to,
   }
   // step, its expected improvement and p_new: one backend op, one host synchronisation
   if(!be_ok(dlg_step(d->be, sf, st, kind, trustregion, &n2, &k, &amax, expectedImprovement, to->p), "step")) return false;
-  d->tail_out = std::isnan(*expectedImprovement);      // (dlg_backend_set_defer_tail: run_optimizer fetches it behind the evaluation)
+  d->tail_out = dlg_step_tail_pending(d->be) != 0;      // (dlg_backend_set_defer_tail: run_optimizer fetches it behind the evaluation)
   }
   to->norm2_step_to_here = n2;
   d->cur.norm2_step = n2;
@@ -798,6 +801,10 @@ int run_optimizer(Driver* d)
         Tick tt(d, TM_STEP);
         if(!be_ok(dlg_step_tail(d->be, &expectedImprovement), "expected improvement")) return -1;
         d->cur.expected_improvement = expectedImprovement;
+        // dogleg.c:1403-1408, made where the value is first at hand: the reference tests it in FRONT of the evaluation and
+        // stops with the step not applied; here the trial point has been evaluated meanwhile (one callback more than the
+        // reference makes) and is discarded -- evaluate_step must never divide by a negative expected improvement
+        if(expectedImprovement < 0.0) { emit(d, stepCount, 2); return stepCount; }
       }
 
       bool accept;

@@ -89,7 +89,8 @@ __global__ void __launch_bounds__(TPB) k_colsum_slices(const double* __restrict_
 __global__ void __launch_bounds__(TPB) k_norm2_Jv_part(const double* __restrict__ J,
                                                        const double* __restrict__ v, int M, int N,
                                                        double* __restrict__ part,
-                                                       const double* __restrict__ psrc, double* __restrict__ pdst, int pn)
+                                                       const double* __restrict__ psrc, double* __restrict__ pdst, int pn,
+                                                       const double* __restrict__ skipf)
 {
   __shared__ double sh[4];
   // (behind the decision point, dlg_take_step: p_new goes to its page-locked destination with this pass, a slice a workgroup)
@@ -98,6 +99,8 @@ __global__ void __launch_bounds__(TPB) k_norm2_Jv_part(const double* __restrict_
     const int per = (pn + (int)gridDim.x - 1)/(int)gridDim.x, i0 = (int)blockIdx.x*per, i1 = min(i0 + per, pn);
     for(int i = i0 + (int)threadIdx.x; i < i1; i += TPB) pdst[i] = psrc[i];
   }
+  // K8 of a step whose |J step|^2 the host takes from the solved system (the step kernel's word, k_part_take_step)
+  if(skipf && *skipf != 0.0) return;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int wave = blockIdx.x*4 + w, nwaves = gridDim.x*4;
   double acc = 0;
@@ -839,7 +842,7 @@ int dense_norm2_Jv(dlg_backend* b, int s, const double* v, double* out_dev)
     if(double* hp = dlg_tail_partials(b, g))
     {
       hipLaunchKernelGGL(k_norm2_Jv_part, dim3(g), dim3(TPB), 0, b->stream, S.Jin(), v, M, b->N, hp,
-                         b->fold_p_src, b->fold_p_dst, (int)b->N);
+                         b->fold_p_src, b->fold_p_dst, (int)b->N, b->k8_skip);
       DLG_LAUNCH_CHECK();
       b->p_copied = b->fold_p_src != nullptr;
       return DLG_OK;
@@ -847,7 +850,7 @@ int dense_norm2_Jv(dlg_backend* b, int s, const double* v, double* out_dev)
   DLG_CHECK(dlg_ensure_partials(b, 8192));
   double* part = b->d_part + 5120;          // behind the regions of the vector reductions (kernels_vec.hip)
   hipLaunchKernelGGL(k_norm2_Jv_part, dim3(g), dim3(TPB), 0, b->stream, S.Jin(), v, M, b->N, part,
-                     (const double*)nullptr, (double*)nullptr, 0);
+                     (const double*)nullptr, (double*)nullptr, 0, b->k8_skip);
   DLG_LAUNCH_CHECK();
   return k_reduce_sum(b, part, g, out_dev);
 }

@@ -51,6 +51,19 @@ __device__ __forceinline__ double block_max(double v, double* sh)
   return r;
 }
 
+__device__ __forceinline__ double block_min(double v, double* sh)
+{
+#pragma unroll
+  for(int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_down(v, o, 64));
+  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+  __syncthreads();
+  if(l == 0) sh[w] = v;
+  __syncthreads();
+  double r = 1e300;
+  if(threadIdx.x == 0) for(int i = 0; i < (int)(blockDim.x >> 6); i++) r = fmin(r, sh[i]);
+  return r;
+}
+
 // partial layout: part[k*nb + blk] for output k
 __global__ void __launch_bounds__(TPB) k_part_norm2_absmax(const double* __restrict__ x, int n,
                                                            double* __restrict__ part)
@@ -203,11 +216,27 @@ __global__ void __launch_bounds__(TPB) k_part_take_step(const double* __restrict
                                                         double* __restrict__ out3,
                                                         const double* __restrict__ g,
                                                         double* __restrict__ gpart,
-                                                        const double* __restrict__ dsc, double* __restrict__ hsc, int nsc)
+                                                        const double* __restrict__ dsc, double* __restrict__ hsc, int nsc,
+                                                        double* __restrict__ gbpart, const double* __restrict__ mmpart, int nbm,
+                                                        int ident_enable, double ratio_max, double* __restrict__ ident_out)
 {
   __shared__ double sh[4];
-  __shared__ double s_l2, s_negc, s_n2g;
+  __shared__ double s_l2, s_negc, s_n2g, s_skip, s_ratio;
   __shared__ double s_gn[MAXB];
+  // The expected improvement from the solved system (K8 without its pass over J, backend.hip: ident_value): allowed by
+  // the host (lambda == 0, one rank) and by the factor itself -- the ratio of its largest to its smallest pivot, from
+  // the pairs the backward solve left per supernode (mmpart: their partial minima / maxima, k_part_negate_interp1).
+  // ident_out[0] = 1: the pass over J that follows on the stream returns at once (k_norm2_Jv: skipf); [1] = the ratio.
+  double ratio = 0.0;
+  if(ident_out && blockIdx.x == 0)
+  {
+    double lo = 1e300, hi = 0.0;
+    for(int i = threadIdx.x; i < nbm; i += TPB) { lo = fmin(lo, mmpart[i]); hi = fmax(hi, mmpart[nbm + i]); }
+    lo = block_min(lo, sh); __syncthreads();
+    hi = block_max(hi, sh);
+    if(threadIdx.x == 0) { ratio = (nbm > 0 && lo > 0.0) ? hi/lo : INFINITY; s_ratio = ratio; }
+    __syncthreads();
+  }
   {
     double v0 = 0, v1 = 0;
     for(int i = threadIdx.x; i < nb1; i += TPB) { v0 += part1[i]; v1 += part1[nb1 + i]; }
@@ -245,26 +274,41 @@ __global__ void __launch_bounds__(TPB) k_part_take_step(const double* __restrict
     if(disc < 0.0) disc = 0.0;
     k = (neg_c + sqrt(disc))/l2;
   }
-  double s2 = 0, m = 0, gs = 0;
+  double s2 = 0, m = 0, gs = 0, gb = 0;
   for(int i = blockIdx.x*TPB + threadIdx.x; i < n; i += gridDim.x*TPB)
   {
-    const double st = (kind == 0) ? sc*a[i] : ((kind == 1) ? b[i] : a[i] + k*(b[i] - a[i]));
+    const double bi = b[i], gi = g[i];
+    const double st = (kind == 0) ? sc*a[i] : ((kind == 1) ? bi : a[i] + k*(bi - a[i]));
     step[i] = st; pnew[i] = p[i] + st; s2 += st*st; m = fmax(m, fabs(st));
-    gs += g[i]*st;                                               // <Jt x, step> for the expected improvement
+    gs += gi*st;                                                 // <Jt x, step> for the expected improvement
+    gb += gi*bi;                                                 // <Jt x, gn>: |J gn|^2 of the solved system
   }
   const double S = block_sum(s2, sh);
   const double Mx = block_max(m, sh);
   __syncthreads();
   const double Gs = block_sum(gs, sh);
-  if(threadIdx.x == 0) { part[blockIdx.x] = S; part[gridDim.x + blockIdx.x] = Mx; gpart[blockIdx.x] = Gs; }
-  if(blockIdx.x == 0 && threadIdx.x == 0) { out3[0] = (double)kind; out3[1] = (kind == 2) ? k : NAN; out3[2] = n2g; }
+  __syncthreads();
+  const double Gb = block_sum(gb, sh);
+  if(threadIdx.x == 0) { part[blockIdx.x] = S; part[gridDim.x + blockIdx.x] = Mx; gpart[blockIdx.x] = Gs; if(gbpart) gbpart[blockIdx.x] = Gb; }
+  if(blockIdx.x == 0 && threadIdx.x == 0)
+  {
+    out3[0] = (double)kind; out3[1] = (kind == 2) ? k : NAN; out3[2] = n2g;
+    if(ident_out)
+    {
+      // (the Cauchy step to the edge needs no factor: its |J step|^2 is a multiple of K3's own scalar)
+      const double skip = (ident_enable && (kind == 0 || ratio <= ratio_max)) ? 1.0 : 0.0;
+      ident_out[0] = skip; ident_out[1] = ratio; s_skip = skip;
+    }
+  }
   // the step's last kernel on the main stream (K8 follows on the second one, dlg_step_tail): the device scalars of the
   // step -- written by the kernels before this one, and out3 from here -- go to the page-locked host array with it
+  if(dsc && blockIdx.x == 0) __syncthreads();                    // (s_skip, s_ratio: thread 0's, above)
   if(dsc && blockIdx.x == 0 && (int)threadIdx.x < nsc)
   {
     const double* o3 = out3;
-    const int t = threadIdx.x, d = (int)(o3 - dsc);
-    hsc[t] = (t == d) ? (double)kind : (t == d + 1) ? ((kind == 2) ? k : NAN) : (t == d + 2) ? n2g : dsc[t];
+    const int t = threadIdx.x, d = (int)(o3 - dsc), f = ident_out ? (int)(ident_out - dsc) : -8;
+    hsc[t] = (t == d) ? (double)kind : (t == d + 1) ? ((kind == 2) ? k : NAN) : (t == d + 2) ? n2g :
+             (t == f) ? s_skip : (t == f + 1) ? s_ratio : dsc[t];
   }
 }
 
@@ -274,9 +318,22 @@ __global__ void __launch_bounds__(TPB) k_part_negate_interp1(double* __restrict_
                                                              const double* __restrict__ a, int n,
                                                              double* __restrict__ gnpart,
                                                              double* __restrict__ part1,
-                                                             const int* __restrict__ gate, int epoch, int* __restrict__ status)
+                                                             const int* __restrict__ gate, int epoch, int* __restrict__ status,
+                                                             const double* __restrict__ mm, int nmm, double* __restrict__ mmpart,
+                                                             long mm_stride, int mm_hi)
 {
   __shared__ double sh[4];
+  // (the factor's smallest / largest pivot: a partial minimum / maximum per workgroup of the pairs the backward solve left
+  // per supernode -- k_part_take_step finishes them)
+  if(mmpart)
+  {
+    double lo = 1e300, hi = 0.0;
+    for(int i = blockIdx.x*TPB + threadIdx.x; i < nmm; i += gridDim.x*TPB) { lo = fmin(lo, mm[i*mm_stride]); hi = fmax(hi, mm[i*mm_stride + mm_hi]); }
+    lo = block_min(lo, sh); __syncthreads();
+    hi = block_max(hi, sh);
+    if(threadIdx.x == 0) { mmpart[blockIdx.x] = lo; mmpart[gridDim.x + blockIdx.x] = hi; }
+    __syncthreads();
+  }
   // (the Cauchy step a comes from the second stream: its word instead of an event between two kernels of this stream,
   // dlg_backend::d_join)
   if(gate)
@@ -481,22 +538,28 @@ int k_interpolate(dlg_backend* b, const double* a, const double* bb, double norm
   return DLG_OK;
 }
 // gn = -u (in place); its |.|^2 partials -> gnpart, the interpolation's pass-1 partials -> d_part[0 .. 2g)
-int k_negate_interp1(dlg_backend* b, double* gn, const double* cauchy, int n, double* gnpart, int* nb)
+// (mm / nmm: the pairs [min, max] of the factor's pivots per supernode -- or, mm_stride != 2, the diagonal of a dense factor,
+// one entry serving as both --, or null; their partials go to gnpart + 2*MAXB)
+int k_negate_interp1(dlg_backend* b, double* gn, const double* cauchy, int n, double* gnpart, int* nb, const double* mm, int nmm, long mm_stride)
 {
   const int g = grid_for(n);
   DLG_CHECK(dlg_ensure_partials(b, 5*MAXB));      // k_take_step's layout: no reallocation between the two
   const int ep = b->join_pending;
   b->join_pending = 0;
   hipLaunchKernelGGL(k_part_negate_interp1, dim3(g), dim3(TPB), 0, b->stream, gn, cauchy, n, gnpart, b->d_part,
-                     ep ? (const int*)b->d_join : (const int*)nullptr, ep, reinterpret_cast<int*>(b->d_scal + (dlg_backend::NSCAL - 2)));
+                     ep ? (const int*)b->d_join : (const int*)nullptr, ep, reinterpret_cast<int*>(b->d_scal + (dlg_backend::NSCAL - 2)),
+                     mm, nmm, mm ? gnpart + 2*MAXB : (double*)nullptr, mm_stride, mm_stride == 2 ? 1 : 0);
   DLG_LAUNCH_CHECK();
   *nb = g;
   return DLG_OK;
 }
 // after k_negate_interp1: the step (kind chosen on the device) and <Jtx, step> -> out_inner
+// out_gb: <Jt x, gn>; ident_out (two device scalars inside d_scal, or null): {the pass over J may be skipped, pivot ratio},
+// ident_gn: the Gauss-Newton system was solved at lambda = 0 (its identity holds), ratio_max: the largest pivot ratio trusted
 int k_take_step(dlg_backend* b, const double* cauchy, const double* gn, const double* gnpart, int nbg,
                 const double* n2c_dev, double trustregion, const double* p, double* step, double* p_new, int n,
-                double* out_n2_max, double* out3, const double* Jtx, double* out_inner)
+                double* out_n2_max, double* out3, const double* Jtx, double* out_inner,
+                double* out_gb, double* ident_out, bool have_mm, bool ident_gn, double ratio_max)
 {
   const int g = grid_for(n);
   // d_part: [0, 2g) pass-1 partials (k_negate_interp1), [2g, 4g) |step|^2 and max|step|, and the
@@ -506,12 +569,17 @@ int k_take_step(dlg_backend* b, const double* cauchy, const double* gn, const do
   double* hp = dlg_host_partials(b, out_n2_max, g, 1, 1, 2);
   double* hg = hp ? dlg_host_partials(b, out_inner, g, 1, 0, 1) : nullptr;
   double* gp = hg ? hg : b->d_part + 4*MAXB;
+  // (<Jt x, gn> only where the host adds the partial sums: the identity is a single-rank matter)
+  double* hb = (hg && out_gb) ? dlg_host_partials(b, out_gb, g, 1, 0, 1) : nullptr;
+  if(!hb) ident_out = nullptr;
   // (fold_scal_k7: this is the launch the host waits for -- it takes the scalars along and carries the event)
   const bool fold = hp && hg && b->fold_scal_k7 > 0 && b->fold_scal_k7 <= TPB && b->h_scal && out3 >= b->d_scal && out3 + 3 <= b->d_scal + b->fold_scal_k7;
   if(!fold) b->attach_stop = nullptr;
   DLG_LAUNCH_LAST(b, k_part_take_step, dim3(g), dim3(TPB), 0, b->stream, cauchy, gn, (const double*)b->d_part, g, gnpart, nbg,
                   n2c_dev, trustregion, p, step, p_new, n, hp ? hp : part2, out3, Jtx, gp,
-                  fold ? (const double*)b->d_scal : (const double*)nullptr, b->h_scal, fold ? b->fold_scal_k7 : 0);
+                  fold ? (const double*)b->d_scal : (const double*)nullptr, b->h_scal, fold ? b->fold_scal_k7 : 0,
+                  hb, have_mm ? gnpart + 2*MAXB : (const double*)nullptr, have_mm ? nbg : 0, ident_gn ? 1 : 0, ratio_max, ident_out);
+  b->ident_launched = ident_out != nullptr;
   if(fold) b->scal_copied = true;
   if(!hp) hipLaunchKernelGGL(k_final, dim3(1), dim3(TPB), 0, b->stream, part2, g, 1, 1, out_n2_max, 2);
   if(!hg) hipLaunchKernelGGL(k_final, dim3(1), dim3(TPB), 0, b->stream, gp, g, 1, 0, out_inner, 1);

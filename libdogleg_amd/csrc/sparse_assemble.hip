@@ -871,7 +871,8 @@ __global__ void __launch_bounds__(TPB) k_norm2_Jv(const int* __restrict__ chunk_
                                                   double* __restrict__ part, const int* __restrict__ info,
                                                   const double* __restrict__ kind, int nnz,
                                                   const double* __restrict__ dsc, double* __restrict__ hsc, int nsc,
-                                                  const double* __restrict__ psrc, double* __restrict__ pdst, int pn)
+                                                  const double* __restrict__ psrc, double* __restrict__ pdst, int pn,
+                                                  const double* __restrict__ skipf)
 {
   __shared__ __attribute__((aligned(16))) double prod[NV_CHUNK + 4];
   __shared__ double sh[4];
@@ -887,6 +888,8 @@ __global__ void __launch_bounds__(TPB) k_norm2_Jv(const int* __restrict__ chunk_
   // K8 behind a speculative factorisation (dlg_take_step): a step built on a failed factorisation is
   // never used -- unless it is the Cauchy step to the edge of the trust region, which needs no factor
   if(info && *info != 0x7fffffff && (int)*kind != DLG_KIND_CAUCHY_TO_EDGE) { if(threadIdx.x == 0) part[blockIdx.x] = 0.0; return; }
+  // ... and K8 of a step whose |J step|^2 the host takes from the solved system (the step kernel's word, k_part_take_step)
+  if(skipf && *skipf != 0.0) return;
   const int4 rec = reinterpret_cast<const int4*>(chunk_row)[blockIdx.x];      // {r0, r1, q0, n}
   const int r0 = rec.x, r1 = rec.y, q0 = rec.z, n = rec.w;
   const int tid = threadIdx.x;
@@ -995,7 +998,7 @@ int sparse_norm2_Jv(dlg_backend* b, int s, const double* v, double* out_dev, con
       DLG_LAUNCH_LAST(b, k_norm2_Jv, dim3(g), dim3(TPB), 0, b->stream, Y->nv_chunk, Y->Jp, Y->Ji, S.Jin(), v, hp,
                       kind_if_factor_failed ? (const int*)Y->d_info : (const int*)nullptr, kind_if_factor_failed, (int)Y->nnz_loc,
                       fold ? (const double*)b->d_scal : (const double*)nullptr, b->h_scal, (int)b->fold_scal,
-                      (fold || b->tail_mode) ? b->fold_p_src : (const double*)nullptr, b->fold_p_dst, (int)b->N);
+                      (fold || b->tail_mode) ? b->fold_p_src : (const double*)nullptr, b->fold_p_dst, (int)b->N, b->k8_skip);
       DLG_LAUNCH_CHECK();
       if(fold) b->scal_copied = true;
       if(fold || b->tail_mode) b->p_copied = b->fold_p_src != nullptr;
@@ -1005,7 +1008,7 @@ int sparse_norm2_Jv(dlg_backend* b, int s, const double* v, double* out_dev, con
   double* part = b->d_part + 5120;          // behind the regions of the vector reductions (kernels_vec.hip)
   hipLaunchKernelGGL(k_norm2_Jv, dim3(g), dim3(TPB), 0, b->stream, Y->nv_chunk, Y->Jp, Y->Ji, S.Jin(), v, part,
                      kind_if_factor_failed ? (const int*)Y->d_info : (const int*)nullptr, kind_if_factor_failed, (int)Y->nnz_loc,
-                     (const double*)nullptr, (double*)nullptr, 0, (const double*)nullptr, (double*)nullptr, 0);
+                     (const double*)nullptr, (double*)nullptr, 0, (const double*)nullptr, (double*)nullptr, 0, (const double*)nullptr);
   DLG_LAUNCH_CHECK();
   return k_reduce_sum(b, part, g, out_dev);
 }

@@ -118,6 +118,10 @@ void sparse_reset(dlg_backend* b)
   Y->info_armed = false; Y->info_clean = false; Y->spec_gen = -1;
   Y->held_Lx = nullptr;
   Y->fin_side_owed = 0; Y->fin_main = nullptr;            // (dlg_backend_reset waits for both streams first)
+  // (another solve, other values: what the last one learnt about its lambda = 0 factorisations -- the look at the diagonal
+  // and its synchronisation, panels left intact by a stopped attempt, a factorisation owed in part -- does not carry over)
+  Y->zero_fail_seen = false; Y->intact_Lx = nullptr; Y->intact_J = nullptr; Y->intact_slot = -1;
+  Y->fac_pending = false; Y->fac_J = nullptr; Y->fac_slot = -1;
 }
 
 int sparse_set_pattern(dlg_backend* b, const int* colptr, const int* rowidx)
@@ -588,6 +592,12 @@ int sparse_factorize_rest(dlg_backend* b, bool* was_pending)
   return sparse_factor_levels(b, 2);
 }
 double sparse_current_lambda(const dlg_backend* b) { return b->sym ? b->sym->cur_lambda : 0.0; }
+// [supernode][min, max] of the diagonal of L as the last backward solve saw it (k_solve_bwd_level: mm), or null
+const double* sparse_pivot_minmax(const dlg_backend* b, int* n)
+{
+  *n = b->sym ? b->sym->n_diag_mm : 0;
+  return (b->sym && b->sym->n_diag_mm > 0) ? b->sym->diag_mm : nullptr;
+}
 // A factorisation enqueued ahead of the caller's decision (backend.hip, step_prepare) takes the place of the held
 // one: the held panels stay in the other buffer (sparse_assemble swaps, the buffer is cleared only behind the
 // next step) and come back if the caller turns to the held factor after all (a rejected trial point).

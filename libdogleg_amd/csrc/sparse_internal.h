@@ -165,6 +165,7 @@ struct SparseSym
   // say which launch (at which lambda) filled the second panel buffer
   long lf_gen = 0, spec_gen = -1; double spec_lambda = 0.0;
   int bwd_xb_cap = 12288;       // below rows of a supernode staged in LDS by the backward solve
+  double* diag_mm = nullptr; int n_diag_mm = 0;   // [supernode][min, max] of the diagonal of L (k_solve_bwd_level), read by the step kernels
   std::vector<void*> allocs;
 };
 

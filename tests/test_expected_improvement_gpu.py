@@ -1,0 +1,201 @@
+"""K8, computeExpectedImprovement (dogleg.c:1085-1165): -2 <Jt x, step> - |J step|^2.
+
+Round 6: where the Gauss-Newton system was solved at lambda = 0 with a factor whose pivots span less than 212x,
+|J step|^2 comes from the solved system (backend.hip: ident_norm2_Jstep) -- no pass over J.  These tests hold that value
+against the pass over J (DOGLEG_AMD_EI_JPASS=1, read when a backend is created) and against the oracle's loop, show that
+every other case falls back to the pass, and pin the driver's `expected improvement < 0` stop (dogleg.c:1403-1408) in both
+placements of the value."""
+import numpy as np
+import pytest
+
+from libdogleg_amd import capi
+from libdogleg_amd.ctypes_defs import dptr, iptr
+from tests import oracle_api as oa
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-9      # relative, on the expected improvement (VERDICT r5 "next" #2)
+
+
+def _oracle_step(prob, p, x, Jx, lam=0.0):
+    O = oa.oracle()
+    Jp, Ji = prob.pattern()
+    F = O.orc_sparse_analyze(prob.N, prob.M, iptr(Jp), iptr(Ji))
+    work, o8 = np.zeros(5 * prob.N), np.zeros(8)
+    rc = O.orc_step_sparse(F, prob.N, prob.M, iptr(Jp), iptr(Ji), dptr(Jx), dptr(x), dptr(p), lam, dptr(work), dptr(o8))
+    O.orc_sparse_free(F)
+    assert rc == 0
+    return o8       # {|x|^2, |cauchy|^2, |gn|^2, k, |step|^2, expected improvement, ...}
+
+
+def _sparse_backend(prob, monkeypatch, jpass):
+    if jpass:
+        monkeypatch.setenv("DOGLEG_AMD_EI_JPASS", "1")
+    else:
+        monkeypatch.delenv("DOGLEG_AMD_EI_JPASS", raising=False)
+    be = capi.Backend(capi.DLG_SPARSE, prob.N, prob.M, prob.nnz)
+    be.set_pattern(*prob.pattern())
+    be.set_speculation(True)
+    return be
+
+
+SHAPES = {"tiny": dict(Nc=12, Np=120, Nobs=720), "medium": dict(Nc=49, Np=900, Nobs=10000), "ragged": dict(Nc=37, Np=411, Nobs=5003),
+          "config3": dict(Nc=499, Np=9000, Nobs=100000), "config4": dict(Nc=2499, Np=45000, Nobs=500000)}
+
+
+@pytest.mark.parametrize("shape", list(SHAPES))
+@pytest.mark.parametrize("defer", [False, True], ids=["inline", "behind"])
+def test_the_value_from_the_solved_system_is_the_pass_over_J(gpu, monkeypatch, shape, defer):
+    """all three kinds of step (trust regions that cut the Cauchy step, sit between the two, hold the Gauss-Newton step), a
+    fresh point through dlg_take_step and a retry from the cached vectors through dlg_step: the value without a pass over J
+    against the one with it and -- the interpolated step of a fresh point at the oracle's trust region -- the oracle's"""
+    prob = oa.BAProblem(**SHAPES[shape], seed=21)
+    p = prob.p0()
+    x, Jx = prob.eval(p)
+    o8 = _oracle_step(prob, p, x, Jx)
+    tr_o = 0.5 * (np.sqrt(o8[1]) + np.sqrt(o8[2]))           # orc_step_sparse's own choice: between the two steps
+    res = {}
+    for jpass in (True, False):
+        be = _sparse_backend(prob, monkeypatch, jpass)
+        be.set_p(0, p)
+        be.set_defer_tail(defer)
+        rows = []
+        for trf in (1e-3, None, 1e3):
+            be.upload(0, x, Jx)
+            be.eval(0)
+            tr = tr_o if trf is None else trf * np.sqrt(o8[2])
+            lam, r, pn = be.take_step(0, 1, tr, 0.0)
+            src, ratio = be.ei_source()
+            rows.append(("take_step", r["kind"], r["ei"], src, ratio))
+            # the retry of a rejected trial point: a smaller trust region, the cached vectors (dogleg.c:1455-1468)
+            kind = capi.KIND_CAUCHY if r["n2c"] >= (0.5 * tr) ** 2 else (capi.KIND_GN if r["n2g"] <= (0.5 * tr) ** 2 else capi.KIND_INTERP)
+            n2s, k, am, ei, pn = be.step(0, 1, kind, 0.5 * tr)
+            src2, _ = be.ei_source()
+            rows.append(("step", kind, ei, src2, ratio))
+        be.close()
+        res[jpass] = rows
+    kinds = set()
+    for a, b in zip(res[False], res[True]):
+        assert a[0] == b[0] and a[1] == b[1]
+        kinds.add(a[1])
+        assert b[3] is False, "DOGLEG_AMD_EI_JPASS=1 must take the pass over J"
+        assert a[3] is True, f"{a[0]} kind {a[1]}: the value did not come from the solved system (pivot ratio {a[4]})"
+        assert abs(a[2] - b[2]) <= TOL * abs(b[2]), (a, b)
+    assert kinds == {capi.KIND_CAUCHY, capi.KIND_GN, capi.KIND_INTERP}
+    # the oracle's step: interpolated, at tr_o
+    got = res[False][2]
+    assert got[1] == capi.KIND_INTERP
+    assert abs(got[2] - o8[5]) <= TOL * abs(o8[5]), (got[2], o8[5])
+    assert 1.0 <= got[4] <= 212.0, f"pivot ratio {got[4]}"
+    print(f"{shape}: pivot ratio {got[4]:.2f}; rel. difference to the pass over J "
+          f"{max(abs(a[2] - b[2]) / abs(b[2]) for a, b in zip(res[False], res[True])):.2e}, to the oracle {abs(got[2] - o8[5]) / abs(o8[5]):.2e}")
+
+
+def test_a_damped_or_ill_conditioned_factor_keeps_the_pass_over_J(gpu, monkeypatch):
+    """lambda > 0 (the reference's lambda loop, dogleg.c:656-677): the Gauss-Newton and the interpolated step take the pass
+    over J whatever the pivots look like; the Cauchy step to the edge never needs it.  A Jacobian whose columns are scaled
+    over four decades at lambda = 0: the pivot ratio is past the bound, the pass over J again.  Same numbers as the
+    oracle's either way."""
+    monkeypatch.delenv("DOGLEG_AMD_EI_JPASS", raising=False)
+    prob = oa.BAProblem(49, 900, 10000, seed=5)
+    p = prob.p0()
+    x, Jx = prob.eval(p)
+    for lam in (1e-6, 1.0):
+        o8 = _oracle_step(prob, p, x, Jx, lam)
+        be = _sparse_backend(prob, monkeypatch, False)
+        be.set_p(0, p)
+        for trf, want_src in ((1e-3, True), (None, False), (1e3, False)):
+            be.upload(0, x, Jx); be.eval(0)
+            tr = 0.5 * (np.sqrt(o8[1]) + np.sqrt(o8[2])) if trf is None else trf * np.sqrt(o8[2])
+            lam_out, r, _ = be.take_step(0, 1, tr, lam)
+            assert lam_out == lam
+            src, ratio = be.ei_source()
+            assert src is want_src, (lam, trf, r["kind"], src)
+            if trf is None:
+                assert abs(r["ei"] - o8[5]) <= TOL * abs(o8[5])
+        be.close()
+    # columns over four decades (config #5's shape, scaled down; no exactly-zero columns: lambda stays 0)
+    prob = oa.BAProblem(49, 900, 10000, seed=5, scale_decades=4.0)
+    p = prob.p0()
+    x, Jx = prob.eval(p)
+    o8 = _oracle_step(prob, p, x, Jx)
+    be = _sparse_backend(prob, monkeypatch, False)
+    be.set_p(0, p); be.upload(0, x, Jx); be.eval(0)
+    lam_out, r, _ = be.take_step(0, 1, 0.5 * (np.sqrt(o8[1]) + np.sqrt(o8[2])), 0.0)
+    src, ratio = be.ei_source()
+    be.close()
+    assert lam_out == 0.0 and r["kind"] == capi.KIND_INTERP
+    assert ratio > 212.0 and src is False, (ratio, src)
+    assert abs(r["ei"] - o8[5]) <= 1e-7 * abs(o8[5])          # (cond ~ 1e8 here: the two loops themselves differ by rounding x cond)
+
+
+def test_dense_value_from_the_solved_system(gpu, monkeypatch):
+    """the dense path (LAPACK's place, dogleg.c:782-803, 875-891): the pivots are the diagonal of the factor itself"""
+    dp = oa.DenseProblem(M=3000, N=256, seed=7)
+    p = dp.p0()
+    x, J = dp.eval(p)
+    res = {}
+    for jpass in (True, False):
+        if jpass:
+            monkeypatch.setenv("DOGLEG_AMD_EI_JPASS", "1")
+        else:
+            monkeypatch.delenv("DOGLEG_AMD_EI_JPASS", raising=False)
+        be = capi.Backend(capi.DLG_DENSE, dp.N, dp.M)
+        be.set_p(0, p); be.upload(0, x, J); be.eval(0)
+        lam, n2c, n2g = be.cauchy_gauss_newton(0, 0.0)
+        rows = []
+        for defer in (False, True):
+            be.set_defer_tail(defer)
+            for trf in (1e-3, 0.5, 1e3):
+                be.upload(0, x, J); be.eval(0)
+                tr = trf * (np.sqrt(n2c) + np.sqrt(n2g))
+                lam, r, _ = be.take_step(0, 1, tr, 0.0)
+                rows.append((r["kind"], r["ei"], be.ei_source()))
+        be.close()
+        res[jpass] = rows
+    for a, b in zip(res[False], res[True]):
+        assert a[0] == b[0]
+        assert a[2][0] is True and b[2][0] is False
+        assert abs(a[1] - b[1]) <= TOL * abs(b[1]), (a, b)
+    assert {a[0] for a in res[False]} == {capi.KIND_CAUCHY, capi.KIND_GN, capi.KIND_INTERP}
+
+
+@pytest.mark.parametrize("which", [1, 2, 3])
+def test_a_negative_expected_improvement_stops_the_solve_with_the_step_not_applied(gpu, monkeypatch, which):
+    """dogleg.c:1403-1408: `if(expectedImprovement < 0.0) return stepCount;` in front of the evaluation of the trial point --
+    the step is NOT applied.  In exact arithmetic the value is a positive definite form of Jt x for every kind of step, so the
+    test hook DOGLEG_AMD_DEBUG_EI_FLIP=n negates the n-th value a backend hands out.  The host-callback solve makes the test
+    where the reference makes it; the device-callback solve has the value behind the evaluation of the trial point
+    (dlg_backend_set_defer_tail) and makes it there (it used to divide by the negative value and accept a step
+    that RAISED the cost).  Both end where the oracle's un-hooked solve stood in front of its n-th trial: same p, same
+    |x|^2; the device solve has made exactly one evaluation more."""
+    monkeypatch.setenv("DOGLEG_AMD_NO_BACKEND_CACHE", "1")
+    prob = oa.BAProblem(20, 300, 3000, seed=9, eps=0.3, p0_spread=0.5)
+    twin = oa.DeviceTwin(prob)
+    Jp, Ji = prob.pattern()
+    prm = oa.default_params()
+    prm.max_iterations = 10
+    prm.trustregion0 = 2.0
+    p0 = prob.p0()
+    ro, po, tro = oa.oracle_solve("sparse", p0, prob.N, prob.M, prob.nnz, prob.cb, prob.cookie, prm)
+    trials = tro.trials()
+    assert len(trials) > which + 1
+    # the state in front of the n-th trial: the last accepted trial point among the first n - 1
+    p_want = np.array(p0, dtype=np.float64)
+    for i, t in enumerate(trials[:which - 1]):
+        if t["accepted"] == 1:
+            p_want = tro.p_trial[i].copy()
+    x_want, _ = prob.eval(p_want)
+    monkeypatch.setenv("DOGLEG_AMD_DEBUG_EI_FLIP", str(which))
+    n0 = twin.neval()
+    rh, ph, trh = capi.optimize("sparse", p0, prob.N, prob.M, prob.nnz, prob.cb, prob.cookie, prm)
+    rd, pd, trd = capi.optimize_device(p0, prob.N, prob.M, prob.nnz, Jp, Ji, twin.cb, twin.cookie, prm)
+    monkeypatch.delenv("DOGLEG_AMD_DEBUG_EI_FLIP")
+    for r, p, name in ((rh, ph, "host callback"), (rd, pd, "device callback")):
+        assert r >= 0, name
+        assert np.max(np.abs(p - p_want)) <= 1e-10, name
+        assert abs(r - float(x_want @ x_want)) <= 1e-10 * max(1.0, r), name
+    assert trh.ntrials == which and trd.ntrials == which
+    assert trh.trials()[-1]["accepted"] == 2 and trd.trials()[-1]["accepted"] == 2
+    assert trh.ncallbacks == which                         # the first point + one per trial before the n-th
+    assert twin.neval() - n0 == which + 1                  # the one evaluation the deferred value costs before it can stop
