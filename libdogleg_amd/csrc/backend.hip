@@ -252,6 +252,7 @@ extern "C" int dlg_backend_create(dlg_backend_t** out, int solve_type, int Nstat
     k.no_split = getenv("DOGLEG_AMD_NO_SPLIT_PRESOLVE") != nullptr;
     k.no_reject_run = getenv("DOGLEG_AMD_NO_REJECT_RUN") != nullptr;
     k.ei_jpass = getenv("DOGLEG_AMD_EI_JPASS") != nullptr;
+    k.no_p_side = getenv("DOGLEG_AMD_NO_P_SIDE") != nullptr;
     // test hook of the driver's `expected improvement < 0` stop (dogleg.c:1403-1408; exact arithmetic never gets there: the
     // value is a positive definite form of Jt x for all three kinds of step): the n-th value this backend hands out is negated
     if(const char* e = getenv("DOGLEG_AMD_DEBUG_EI_FLIP")) b->ei_flip = atoi(e);
@@ -410,13 +411,19 @@ static double ei_out(dlg_backend* b, double v)
   if(b->ei_flip > 0 && ++b->ei_count == b->ei_flip) return -fabs(v);
   return v;
 }
-static int tail_guard(dlg_backend*) { return DLG_OK; }
+// ... p_new of such a step travels on the copy stream behind the step kernel's event (dlg_take_step): what writes the
+// slot's p or the caller's buffer next waits for it here (long over by then: the copy starts when the step kernel ends)
+static int tail_guard(dlg_backend* b)
+{
+  if(b->p_side_pending) { b->p_side_pending = false; DLG_HIP(hipEventSynchronize(b->ev_copy)); }
+  return DLG_OK;
+}
 extern "C" int dlg_step_tail(dlg_backend_t* b, double* expected_improvement)
 {
   if(!b) return DLG_ERR_ARG;
   if(b->tail_pending)
   {
-    if(b->tail_mark == b->sync_mark) DLG_HIP(hipStreamSynchronize(b->stream));      // (nobody has waited for anything behind K8 yet)
+    if(b->tail_mark == b->sync_mark && !(b->tail_ident && b->tail_no_fold)) DLG_HIP(hipStreamSynchronize(b->stream));      // (nobody has waited for anything behind K8 yet -- and K8 carries something: sums or p_new)
     double v = 0.0;
     if(b->tail_ident) v = b->tail_nJs;                                // (from the solved system: that K8 returned at once)
     else for(int i = 0; i < b->tail_nb; i++) v += b->h_tail[i];     // in index order, as dlg_resolve_pending adds them
@@ -424,6 +431,7 @@ extern "C" int dlg_step_tail(dlg_backend_t* b, double* expected_improvement)
     b->ei_from_system = b->tail_ident;
     b->tail_pending = false; b->tail_ident = false;
   }
+  DLG_CHECK(tail_guard(b));                                          // (p_new on the copy stream)
   if(expected_improvement) *expected_improvement = b->tail_value;
   return DLG_OK;
 }
@@ -1538,7 +1546,19 @@ extern "C" int dlg_take_step(dlg_backend_t* b, int from, int to, double trustreg
       // (On the second stream beside the next evaluation it gained nothing: that evaluation's pass over J is bound by HBM
       // as K8 is -- 131 + 0 us against 98 + 38 -- and the wait for the event between the queues cost 18 us.)
       const bool k7_attached = b->stop_attached;
-      if(p_fold) { b->fold_p_src = T.p; b->fold_p_dst = (double*)p_attr.devicePointer; }
+      // p_new: on the copy stream behind the step kernel's own event (the one the host listens to: no event more on the main
+      // stream) -- the pass over J, which may return at once (k8_skip), does not have to carry 8 N bytes over PCIe on the
+      // critical queue (1.2 MB, ~25 us on config #4); dlg_step_tail / tail_guard wait for the copy
+      const bool p_side = p_fold && k7_attached && b->copy_stream && !b->knobs.no_p_side;
+      if(p_side)
+      {
+        DLG_HIP(hipStreamWaitEvent(b->copy_stream, b->ev_fetch, 0));
+        DLG_HIP(hipMemcpyAsync(p_new_host, T.p, sizeof(double)*(size_t)b->N, hipMemcpyDeviceToHost, b->copy_stream));
+        DLG_HIP(hipEventRecord(b->ev_copy, b->copy_stream));
+        b->p_side_pending = true;
+      }
+      else if(p_fold) { b->fold_p_src = T.p; b->fold_p_dst = (double*)p_attr.devicePointer; }
+      b->tail_no_fold = p_side || !p_fold;
       // No event of its own (a launch somebody listens to holds the next dispatch back by ~5 us): the evaluation that
       // follows is waited for on this stream behind it -- dlg_step_tail only waits itself if nothing was (sync_mark).
       b->tail_mode = true; b->fold_scal = 0; b->attach_stop = nullptr; b->stop_attached = false;

@@ -114,7 +114,7 @@ struct dlg_backend
   bool ident_launched = false; const double* k8_skip = nullptr;
   bool ei_from_system = false; double pivot_ratio = NAN;   // dlg_backend_ei_source: how the last value handed out was formed
   int ei_flip = 0, ei_count = 0;                           // DOGLEG_AMD_DEBUG_EI_FLIP (test hook)
-  bool tail_ident = false; double tail_nJs = 0.0;
+  bool tail_ident = false, tail_no_fold = false; double tail_nJs = 0.0;     // (tail_no_fold: the K8 on the stream carries no p_new)
   bool p_side_pending = false;          // p_new of a step behind the decision point is on its way on the copy stream (ev_copy)
   static constexpr int NSCAL = 16;
   // hand-offs inside the one-launch regions (flags between workgroups): a wait that gives up raises a bit in
@@ -127,7 +127,7 @@ struct dlg_backend
   {
     bool join_event = false;
     bool no_k3_fork = false, no_potrf_fuse = false, potrf_steps = false,
-         trsv_steps = false, no_touch = false, no_abandon = false, no_split = false, no_reject_run = false, no_defer_tail = false, ei_jpass = false;
+         trsv_steps = false, no_touch = false, no_abandon = false, no_split = false, no_reject_run = false, no_defer_tail = false, ei_jpass = false, no_p_side = false;
     int touch_wg = 512;
   } knobs;
   int ncu = 256;              // compute units of b->device

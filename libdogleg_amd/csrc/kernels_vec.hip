@@ -296,7 +296,7 @@ __global__ void __launch_bounds__(TPB) k_part_take_step(const double* __restrict
     if(ident_out)
     {
       // (the Cauchy step to the edge needs no factor: its |J step|^2 is a multiple of K3's own scalar)
-      const double skip = (ident_enable && (kind == 0 || ratio <= ratio_max)) ? 1.0 : 0.0;
+      const double skip = (kind == 0 || (ident_enable && ratio <= ratio_max)) ? 1.0 : 0.0;
       ident_out[0] = skip; ident_out[1] = ratio; s_skip = skip;
     }
   }

@@ -120,9 +120,9 @@ __global__ void __launch_bounds__(BWD_NT, BD_ONLY ? 4 : 1) k_solve_bwd_level(con
 {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   __shared__ int s_skip;
-  // (mm: smallest / largest diagonal entry of this supernode's part of L, a pair per workgroup -- the step kernel turns
-  // them into the pivot ratio that decides whether the expected improvement may come from the solved system, backend.hip)
-  __shared__ double s_mm[2*(BWD_NT/64)];
+  // (mm: smallest / largest diagonal entry of this supernode's part of L, a pair per WAVE that holds diagonal entries
+  // ([workgroup][8][2]; no LDS, no barrier: the waves store their own) -- the step kernel turns them into the pivot ratio
+  // that decides whether the expected improvement may come from the solved system, backend.hip)
   double dmin = 1e300, dmax = 0.0;
   if(threadIdx.x == 0) s_skip = *info != 0x7fffffff;      // the factor is that of a failed factorisation: its solution is never used
   constexpr int NW = BWD_NT/64;
@@ -264,11 +264,11 @@ __global__ void __launch_bounds__(BWD_NT, BD_ONLY ? 4 : 1) k_solve_bwd_level(con
       for(int a = 0; a < 8; a++) if(a < nbm) { dmin = fmin(dmin, Lm[a][a]); dmax = fmax(dmax, Lm[a][a]); }
     }
   }
-  if(mm)
+  if(mm && (nmem > 0 ? 64*wv < nmem : wv < nblk))
   {
 #pragma unroll
     for(int o = 32; o > 0; o >>= 1) { dmin = fmin(dmin, __shfl_down(dmin, o, 64)); dmax = fmax(dmax, __shfl_down(dmax, o, 64)); }
-    if(lane == 0) { s_mm[wv] = dmin; s_mm[NW + wv] = dmax; }
+    if(lane == 0) { mm[(8*blockIdx.x + wv)*2] = dmin; mm[(8*blockIdx.x + wv)*2 + 1] = dmax; }
   }
   BW_STAMP(1);
   // (rsv: the supernode's level has LDS room for it, sparse_solve_setup; only where there is a wait to
@@ -364,13 +364,6 @@ __global__ void __launch_bounds__(BWD_NT, BD_ONLY ? 4 : 1) k_solve_bwd_level(con
     for(int i = tid + BWD_NT; i < r; i += BWD_NT) xb[i] = ldx(ywork + rows[w + i]);
   }
   __syncthreads();
-  if(mm && tid == 0)
-  {
-    double lo = s_mm[0], hi = s_mm[NW];
-#pragma unroll
-    for(int k = 1; k < NW; k++) { lo = fmin(lo, s_mm[k]); hi = fmax(hi, s_mm[NW + k]); }
-    mm[2*blockIdx.x] = lo; mm[2*blockIdx.x + 1] = hi;
-  }
   if(s_skip)
   {
     if(tid < w) put_xh(c0 + tid, 0.0);              // (the children must not wait for values that never come)
@@ -778,10 +771,12 @@ int sparse_solve_setup(dlg_backend* b)
       }
     }
     DLG_CHECK(upload(Y->slv_item, items)); Y->allocs.push_back(Y->slv_item);
-    // smallest / largest diagonal entry of L per supernode, left behind by every backward solve (k_solve_bwd_level: mm)
-    std::vector<double> ones(2*std::max<size_t>(items.size(), 1), 1.0);
-    DLG_CHECK(upload(Y->diag_mm, ones)); Y->allocs.push_back(Y->diag_mm);
-    Y->n_diag_mm = (int)items.size();
+    // smallest / largest diagonal entry of L per supernode and wave, left behind by every backward solve (k_solve_bwd_level:
+    // mm); a wave without diagonal entries never writes its pair: (huge, 0) changes no minimum and no maximum
+    std::vector<double> none(16*std::max<size_t>(items.size(), 1));
+    for(size_t i = 0; i < none.size(); i += 2) { none[i] = 1e300; none[i + 1] = 0.0; }
+    DLG_CHECK(upload(Y->diag_mm, none)); Y->allocs.push_back(Y->diag_mm);
+    Y->n_diag_mm = 8*(int)items.size();
   }
   // Persistent top region of the backward solve: the last levels of the tree hold a few supernodes each
   // and every level waits for the one above.  They go out as ONE launch, workgroups ordered from the
@@ -895,7 +890,7 @@ int sparse_solve(dlg_backend* b, const double* rhs, double* out)
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_solve_bwd_level<512, false>), dim3(Y->bw_n), dim3(512), Y->bw_lds, st,
                        Y->slv_item_pr, Y->sn_rows, Y->perm, Y->Lx, Y->ywork, out, use_aug, Y->sn_bd_col,
                        256*Y->bw_level0, Y->bwd_xb_cap, Y->bwd_flag, ++Y->bwd_epoch, Y->d_info, dlg_handoff(b, 1 << 21), Y->bwd_xh, H.N,
-                       Y->diag_mm ? Y->diag_mm + 2*(size_t)H.xl_ptr[Y->bw_level0] : (double*)nullptr);
+                       (Y->diag_mm && !b->knobs.ei_jpass) ? Y->diag_mm + 16*(size_t)H.xl_ptr[Y->bw_level0] : (double*)nullptr);
     ltop = Y->bw_level0 - 1;
   }
   for(int l = ltop; l >= 0; l--)
@@ -907,17 +902,17 @@ int sparse_solve(dlg_backend* b, const double* rhs, double* out)
       hipLaunchKernelGGL(HIP_KERNEL_NAME(k_solve_bwd_level<256, true>), dim3(n), dim3(256), Y->bwd_lds[l], st,
                          Y->slv_item + H.xl_ptr[l], Y->sn_rows, Y->perm, Y->Lx, Y->ywork, out, use_aug, Y->sn_bd_col,
                          Y->bwd_top[l] + 256*l, Y->bwd_xb_cap, (int*)nullptr, 0, Y->d_info, dlg_handoff(b, 1 << 21), (double*)nullptr, 0,
-                         Y->diag_mm ? Y->diag_mm + 2*(size_t)H.xl_ptr[l] : (double*)nullptr);
+                         (Y->diag_mm && !b->knobs.ei_jpass) ? Y->diag_mm + 16*(size_t)H.xl_ptr[l] : (double*)nullptr);
     else if(n > 0 && Y->bwd_nt[l] == 256)
       hipLaunchKernelGGL(HIP_KERNEL_NAME(k_solve_bwd_level<256, false>), dim3(n), dim3(256), Y->bwd_lds[l], st,
                          Y->slv_item + H.xl_ptr[l], Y->sn_rows, Y->perm, Y->Lx, Y->ywork, out, use_aug, Y->sn_bd_col,
                          Y->bwd_top[l] + 256*l, Y->bwd_xb_cap, (int*)nullptr, 0, Y->d_info, dlg_handoff(b, 1 << 21), (double*)nullptr, 0,
-                         Y->diag_mm ? Y->diag_mm + 2*(size_t)H.xl_ptr[l] : (double*)nullptr);
+                         (Y->diag_mm && !b->knobs.ei_jpass) ? Y->diag_mm + 16*(size_t)H.xl_ptr[l] : (double*)nullptr);
     else if(n > 0)
       hipLaunchKernelGGL(HIP_KERNEL_NAME(k_solve_bwd_level<512, false>), dim3(n), dim3(512), Y->bwd_lds[l], st,
                          Y->slv_item + H.xl_ptr[l], Y->sn_rows, Y->perm, Y->Lx, Y->ywork, out, use_aug, Y->sn_bd_col,
                          Y->bwd_top[l] + 256*l, Y->bwd_xb_cap, (int*)nullptr, 0, Y->d_info, dlg_handoff(b, 1 << 21), (double*)nullptr, 0,
-                         Y->diag_mm ? Y->diag_mm + 2*(size_t)H.xl_ptr[l] : (double*)nullptr);
+                         (Y->diag_mm && !b->knobs.ei_jpass) ? Y->diag_mm + 16*(size_t)H.xl_ptr[l] : (double*)nullptr);
   }
   DLG_LAUNCH_CHECK();
   if(H.part_nranks > 1)

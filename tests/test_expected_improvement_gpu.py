@@ -198,4 +198,6 @@ def test_a_negative_expected_improvement_stops_the_solve_with_the_step_not_appli
     assert trh.ntrials == which and trd.ntrials == which
     assert trh.trials()[-1]["accepted"] == 2 and trd.trials()[-1]["accepted"] == 2
     assert trh.ncallbacks == which                         # the first point + one per trial before the n-th
-    assert twin.neval() - n0 == which + 1                  # the one evaluation the deferred value costs before it can stop
+    # the one evaluation a deferred value costs before it can stop (a value that needed no pass over J was handed out with
+    # the step: then the device solve stops where the reference does)
+    assert twin.neval() - n0 in (which, which + 1)

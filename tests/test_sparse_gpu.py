@@ -1056,8 +1056,12 @@ def test_a_retry_with_the_expected_improvement_behind_the_decision_point(gpu, de
             be.upload(1, *ev[1])
             be.eval(1)                              # the evaluation of the trial point (rejected: the next retry follows)
             if defer and late:
-                assert rec[3] != rec[3]
-                rec[3] = be.step_tail()
+                # (a value that needs no pass over J -- the Cauchy step's, round 6 -- is handed out at once: nothing pending)
+                if be.step_tail_pending():
+                    assert rec[3] != rec[3]
+                    rec[3] = be.step_tail()
+                else:
+                    assert kind == capi.KIND_CAUCHY and np.isfinite(rec[3])
                 rec[4] = pn.copy()
             res.append(rec)
         be.close()
