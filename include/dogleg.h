@@ -280,6 +280,10 @@ int  dogleg_amd_id_file_wait(const char* path, void* id128_out, const char* run_
  * once (the reference redoes all of it per solve, dogleg.c:1479-1562, 1633-1753: its solves take seconds).
  * dogleg_amd_release_cache gives everything back; DOGLEG_AMD_NO_BACKEND_CACHE=1 never keeps anything. */
 void dogleg_amd_release_cache(void);
+/* measurement: where the calling thread's last solve spent its wall time, if DOGLEG_AMD_TIMING=1 was set for it (the same
+ * numbers it printed on stderr): ms7 / calls7 = {pattern, model callback, inputs to the backend, dlg_point_eval,
+ * dlg_take_step + dlg_step, trace records, run_optimizer as a whole}.  Returns the number of entries (7). */
+int  dogleg_amd_last_solve_timing(double* ms7, int* calls7);
 
 /* the device backend (include/dlg_backend.h) behind a returned context, and the backend slot of
  * one of its operating points: what dlg_solve_with_factor / dlg_solve_multi /

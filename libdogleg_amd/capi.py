@@ -53,7 +53,7 @@ DOGLEG_SYMBOLS = [
     "dogleg_optimize_device2", "dogleg_amd_backend", "dogleg_amd_point_slot",
     "dogleg_amd_set_communicator", "dogleg_amd_set_allreduce", "dogleg_amd_clear_communicator",
     "dogleg_amd_rccl_unique_id", "dogleg_amd_rank", "dogleg_amd_release_cache",
-    "dogleg_amd_id_file_publish", "dogleg_amd_id_file_wait",
+    "dogleg_amd_id_file_publish", "dogleg_amd_id_file_wait", "dogleg_amd_last_solve_timing",
 ]
 
 _lib = None
@@ -182,6 +182,7 @@ def lib():
     L.dlg_sparse_pattern_matches.argtypes = [V, I, I]
     L.dlg_sparse_drop_pattern.argtypes = [V]
     L.dogleg_amd_release_cache.restype = None
+    L.dogleg_amd_last_solve_timing.argtypes = [D, I]
     L.dlg_point_gather_device.argtypes = [V, C.c_int, V, V, I]
     L.dogleg_setMaxIterations.argtypes = [C.c_int]
     L.dogleg_setDebug.argtypes = [C.c_int]
@@ -203,15 +204,15 @@ def default_parameters():
     return p
 
 
-def optimize(kind, p0, N, M, nnz, cb, cookie, params=None, capacity=256):
-    """dogleg_optimize2 / _dense2 / _dense_products with a per-trial trace.
+def optimize(kind, p0, N, M, nnz, cb, cookie, params=None, capacity=256, trace=True):
+    """dogleg_optimize2 / _dense2 / _dense_products with a per-trial trace (trace=False: without, as a user calls it).
     kind in {'sparse','dense','products'}; cb is a function address (c_void_p).
     Returns (norm2x, p_final, TraceBuffer)."""
     L = lib()
     p = np.array(p0, dtype=np.float64, copy=True)
-    tr = TraceBuffer(N, capacity)
+    tr = TraceBuffer(N, capacity) if trace else None
     prm = C.byref(params) if params is not None else None
-    L.dlg_set_trace(C.cast(tr.byref(), C.c_void_p))
+    L.dlg_set_trace(C.cast(tr.byref(), C.c_void_p) if trace else None)
     try:
         if kind == "sparse":
             r = L.dogleg_optimize2(dptr(p), N, M, nnz, cb, cookie, prm, None)
@@ -644,3 +645,11 @@ class Backend:
         out = np.zeros(n)
         _ck(self.L.dlg_factor_download_dense(self.h, dptr(out), n), "factor download")
         return out
+
+
+def last_solve_timing():
+    """{phase: (ms, calls)} of the calling thread's last dogleg_optimize* solve (DOGLEG_AMD_TIMING=1 must have been set)"""
+    ms, n = (C.c_double * 7)(), (C.c_int * 7)()
+    lib().dogleg_amd_last_solve_timing(ms, n)
+    keys = ("pattern", "callback", "inputs", "point_eval", "take_step", "trace", "run_optimizer")
+    return {k: (ms[i], n[i]) for i, k in enumerate(keys)}

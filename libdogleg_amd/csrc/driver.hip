@@ -104,6 +104,7 @@ struct Driver
   double tm_ms[8]; int tm_n[8];
 };
 enum { TM_PATTERN, TM_CALLBACK, TM_UPLOAD, TM_EVAL, TM_STEP, TM_TRACE, TM_COUNT };
+thread_local double t_last_tm_ms[TM_COUNT + 1]; thread_local int t_last_tm_n[TM_COUNT + 1];      // dogleg_amd_last_solve_timing
 const char* const k_tm_names[TM_COUNT] = { "pattern (symbolic phase or comparison with the parked one)", "model callback (host: evaluation; device: enqueue)",
                                            "inputs to the backend (upload / bind / gather)", "dlg_point_eval (K1 [+ K4, leaf level ahead], norms fetched)",
                                            "dlg_take_step / dlg_step (K3 .. K8, p_new fetched)", "trace / vnlog records (test harness, debug)" };
@@ -1120,6 +1121,8 @@ double optimize(double* p, unsigned int Nstate, unsigned int Nmeas, unsigned int
       acc += d->tm_ms[k];
     }
     MSG("timing:   %-62s %8.3f ms", "host logic between them (trust region, bookkeeping)", run_ms - acc);
+    for(int k = 0; k < TM_COUNT; k++) { t_last_tm_ms[k] = d->tm_ms[k]; t_last_tm_n[k] = d->tm_n[k]; }
+    t_last_tm_ms[TM_COUNT] = run_ms; t_last_tm_n[TM_COUNT] = 1;
   }
   lap("run_optimizer (incl. symbolic phase)");
   const double norm2_x = ctx->beforeStep->norm2_x;
@@ -1270,6 +1273,14 @@ void dogleg_amd_release_cache(void)
   }
   if(be) dlg_backend_destroy(be);
   for(const PinnedBuf& b : pool) (void)hipHostFree(b.p);
+}
+// where the calling thread's last solve spent its wall time (DOGLEG_AMD_TIMING=1 must have been set for it): milliseconds and
+// calls of {pattern, model callback, inputs to the backend, dlg_point_eval, dlg_take_step / dlg_step, trace records,
+// run_optimizer as a whole} -- everything but the second entry is the library's share of a trial (tools/e2e_bench.py)
+int dogleg_amd_last_solve_timing(double* ms7, int* calls7)
+{
+  for(int k = 0; k <= TM_COUNT; k++) { if(ms7) ms7[k] = t_last_tm_ms[k]; if(calls7) calls7[k] = t_last_tm_n[k]; }
+  return TM_COUNT + 1;
 }
 int dogleg_amd_rccl_unique_id(void* out128) { return dlg_rccl_unique_id(out128) == DLG_OK ? 0 : -1; }
 int dogleg_amd_rank(const dogleg_solverContext_t* ctx, int* nranks)

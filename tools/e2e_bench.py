@@ -68,6 +68,29 @@ prm.max_iterations = 20
 td20, (rd20, pd20, trd20) = timed(dev)
 th20, (rh20, ph20, trh20) = timed(host)
 prm.max_iterations = a.iters
+# What the LIBRARY costs a re-linked user per trial step with a host callback (VERDICT r5 "next" #6): the solve's own clock
+# around its calls (DOGLEG_AMD_TIMING=1), everything but the callback -- the H2D of x and the Jacobian values (128 MB on
+# config #4: PCIe), dlg_point_eval, dlg_take_step / dlg_step, the host logic.  "trial steps/s with a free callback" = trials
+# over that share: the ceiling of the literal drop-in, whatever the user's model costs.
+os.environ["DOGLEG_AMD_TIMING"] = "1"
+_devnull = os.open(os.devnull, os.O_WRONLY); _saved = os.dup(2); os.dup2(_devnull, 2)
+try:
+    th_t, (rh_t, ph_t, trh_t) = timed(lambda: capi.optimize("sparse", p0, prob.N, prob.M, prob.nnz, prob.cb, prob.cookie, prm, trace=False))
+    tm_host = capi.last_solve_timing()
+    td_t, _ = timed(dev_plain)
+    tm_dev = capi.last_solve_timing()
+finally:
+    os.dup2(_saved, 2); os.close(_devnull); os.close(_saved)
+del os.environ["DOGLEG_AMD_TIMING"]
+def _share(tm, wall):
+    cb = tm["callback"][0]
+    lib_ms = wall*1e3 - cb
+    return {"wall_ms": wall*1e3, "callback_ms": cb, "library_ms": lib_ms,
+            "phases_ms": {k: v[0] for k, v in tm.items()}, "calls": {k: v[1] for k, v in tm.items()}}
+host_share = _share(tm_host, th_t)
+host_share["trials"] = trh.ntrials
+host_share["library_ms_per_trial"] = host_share["library_ms"]/max(trh.ntrials, 1)
+host_share["trial_steps_per_s_with_a_free_callback"] = trh.ntrials/(host_share["library_ms"]*1e-3)
 out = {"workload": a.workload, "Nmeas": prob.M, "Nstate": prob.N, "nnz": prob.nnz,
        "trials": trh.ntrials, "callbacks": trh.ncallbacks, "symbolic_analysis_s": t_sym,
        "host_callback": {"first_call_s": th1, "second_call_s": th2, "callback_s_each": t_cb,
@@ -80,6 +103,7 @@ out = {"workload": a.workload, "Nmeas": prob.M, "Nstate": prob.N, "nnz": prob.nn
                            "untraced_steps_per_s": trd.ntrials / tdp[2]},
        "device_callback_20_iterations": {"solve_s": td20, "trials": trd20.ntrials, "steps_per_s": trd20.ntrials / td20},
        "host_callback_20_iterations": {"solve_s": th20, "trials": trh20.ntrials, "steps_per_s": trh20.ntrials / th20},
+       "host_callback_library_share": host_share, "device_callback_library_share": _share(tm_dev, td_t),
        "max_abs_p_diff_device_vs_host": float(np.max(np.abs(pd - ph))),
        "norm2x": rh, "step_types": [t["step_type"] for t in trh.trials()]}
 if a.oracle:
