@@ -255,104 +255,6 @@ __device__ __forceinline__ void mf_add_two_pipelined(double* P, double* Wt, int 
   __syncthreads();
 }
 
-// The root of an elimination tree solved where it is factored (round 6).  K6 is top-down: its root has no parent to hide
-// its loads behind, so the 126 x 126 root of config #4 cost the backward solve 19 of its 46 us before its children could
-// start (profiles/r05_step_trace.txt).  Here the factored panel is still in LDS and row w of it IS the forward-solved
-// right-hand side (the augmented row): x = L^-T y by blocks of 16 columns from the bottom,
-//   x_J = L_JJ^-T (y_J - sum_{i below block J} L(i, J)' x_i)
-// -- the sums as dot products down the columns (lanes = rows: consecutive LDS addresses), a wave a column; L_JJ^-1 of every
-// block formed up front by all waves at once (lane = column of the inverse, a substitution whose operands are LDS
-// broadcasts) and parked, transposed, in the block's own strict UPPER triangle of the panel (never stored: the caller
-// writes back the lower triangle only), its diagonal in rdiag.  scr: w + 16 doubles of LDS behind the panel.
-// x goes to ywork (the backward solve's own vector: the children gather it there) and, a sentinel-armed copy, to xh
-// (k_solve_bwd_level: x of the ancestors as its own arrival signal).  The pivots' range goes out with it (mm: a pair).
-template <int NT>
-__device__ __forceinline__ void root_backsolve(double* P, int ldp, int w, int tid, double* rdiag, double* scr,
-                                               double* __restrict__ ywork_c0, unsigned long long* __restrict__ xh_c0,
-                                               double* __restrict__ mm)
-{
-  constexpr int NW = NT/64;
-  const int lane = tid & 63, wv = tid >> 6;
-  const int nb16 = (w + 15) >> 4;
-  double* xs = scr;            // [w]
-  double* rb = scr + w;        // [16]
-  // inverses of the diagonal blocks: wave -> blocks wv, wv + NW, ...; lanes 0 .. 15 = columns of the inverse
-  for(int blk = wv; blk < nb16; blk += NW)
-  {
-    const int kb = 16*blk, nbk = min(16, w - kb), c = lane & 15;
-    const double dc = (c < nbk) ? P[(kb + c) + (kb + c)*ldp] : 1.0;
-    const double rd = 1.0/dc;
-    double sx[16];
-#pragma unroll
-    for(int i = 0; i < 16; i++) sx[i] = (i == c) ? 1.0 : 0.0;
-#pragma unroll
-    for(int k = 0; k < 16; k++)
-    {
-      const double xk = sx[k]*pf_readlane64(rd, k);
-      sx[k] = xk;
-#pragma unroll
-      for(int i = k + 1; i < 16; i++)
-      {
-        const double lik = (i < nbk) ? P[(kb + i) + (kb + k)*ldp] : 0.0;      // (the same address in every lane: a broadcast)
-        sx[i] = __builtin_fma(-lik, xk, sx[i]);
-      }
-    }
-    if(lane < 16 && c < nbk)
-    {
-      rdiag[kb + c] = sx[c];
-#pragma unroll
-      for(int i = 1; i < 16; i++) if(i > c && i < nbk) P[(kb + c) + (kb + i)*ldp] = sx[i];      // Inv(i, c) at (row c, column i)
-    }
-    if(mm && blk == 0 && NW >= nb16) { /* (the pivots' range: below, from rdiag) */ }
-  }
-  __syncthreads();
-  for(int J = nb16 - 1; J >= 0; J--)
-  {
-    const int kb = 16*J, nbk = min(16, w - kb);
-    for(int c = wv; c < 16; c += NW)
-    {
-      double sum = 0.0;
-      if(c < nbk)
-      {
-        const double* col = P + (size_t)(kb + c)*ldp;
-        for(int i = kb + 16 + lane; i < w; i += 64) sum = __builtin_fma(col[i], xs[i], sum);
-      }
-      sum = wave_sum(sum);
-      if(lane == 0) rb[c] = (c < nbk) ? P[w + (kb + c)*ldp] - sum : 0.0;       // y = the augmented row
-    }
-    __syncthreads();
-    if(tid < 16 && tid < nbk)
-    {
-      const int k = tid;
-      double a0 = rdiag[kb + k]*rb[k], a1 = 0.0;
-      const double* row = P + (kb + k) + (size_t)kb*ldp;
-#pragma unroll
-      for(int j = 1; j < 16; j += 2)
-      {
-        if(j > k && j < nbk) a0 = __builtin_fma(row[j*ldp], rb[j], a0);
-        if(j + 1 > k && j + 1 < nbk) a1 = __builtin_fma(row[(j + 1)*ldp], rb[j + 1], a1);
-      }
-      xs[kb + k] = a0 + a1;
-    }
-    __syncthreads();
-  }
-  if(tid < w)
-  {
-    const double x = xs[tid];
-    ywork_c0[tid] = x;
-    if(xh_c0) xh_c0[tid] = (unsigned long long)__double_as_longlong(x);
-  }
-  if(mm && wv == 0)
-  {
-    // 1 / L_ii of every column is in rdiag: the smallest pivot is the largest reciprocal
-    double lo = 1e300, hi = 0.0;
-    for(int i = lane; i < w; i += 64) { const double d = 1.0/rdiag[i]; lo = fmin(lo, d); hi = fmax(hi, d); }
-#pragma unroll
-    for(int o = 32; o > 0; o >>= 1) { lo = fmin(lo, __shfl_down(lo, o, 64)); hi = fmax(hi, __shfl_down(hi, o, 64)); }
-    if(lane == 0) { mm[0] = lo; mm[1] = hi; }
-  }
-}
-
 // factor one supernode panel per workgroup in LDS (column-major, even leading dimension).
 // One workgroup per work item (FwItem) = (supernode, slice [r0,r1) of its below rows): the LDS
 // panel holds the w x w top block plus the slice (up to ~160 KB); slices of one supernode factor
@@ -382,8 +284,7 @@ __global__ void __launch_bounds__(NT, LEAF ? 4 : 1) k_factor_level(const FwItem*
                                                      double* __restrict__ top_scr,
                                                      int* __restrict__ info,
                                                      double* uscr, int mode,
-                                                     int* pr_flag, int pr_epoch, DlgHandoff ho, int64_t pr_acc,
-                                                     double* root_y, unsigned long long* root_xh, double* root_mm)
+                                                     int* pr_flag, int pr_epoch, DlgHandoff ho, int64_t pr_acc)
 {
   extern __shared__ __attribute__((aligned(16))) double P[];
   __shared__ int sbad, s_skip;
@@ -507,13 +408,6 @@ __global__ void __launch_bounds__(NT, LEAF ? 4 : 1) k_factor_level(const FwItem*
   else         panel_factor<NT, true, true>(P, ldp, nloc, w, tid, &sbad, it.col0);
   FL_STAMP(3);
   if(r0 == 0 && it.rep == 0 && tid == 0 && sbad != 0x7fffffff) atomicMin(info, sbad);
-  // a root of the elimination tree, the right-hand side riding in its augmented row: solved here, off the backward
-  // solve's critical path (the host flagged the item -- its LDS has the room, the upper triangle of its top block is free --
-  // and passes root_y only where the backward solve's one-launch region knows that it need not solve it again)
-  const bool root_solve = !LEAF && root_y != nullptr && (it.pad & (1 << 16)) != 0;
-  if(!LEAF && root_solve)
-    root_backsolve<(NT >= 128 ? NT : 128)>(P, ldp, w, tid, s_rdiag, Dg, root_y + it.col0, root_xh ? root_xh + it.col0 : nullptr,
-                                            root_mm ? root_mm + 16*(it.pad >> 17) : nullptr);
   // U = B B' (mode 2: W = children's sum - B B'): lower 16x16 tiles on the matrix cores, both
   // operands read from the panel (factor_tail_tiles above).  The lower triangle of tiles is dealt
   // out in column-major tile order, in chunks of consecutive tiles: every round gives each wave one
@@ -622,7 +516,7 @@ __global__ void __launch_bounds__(NT, LEAF ? 4 : 1) k_factor_level(const FwItem*
     else if(r0 == 0)  { gp = top_scr + top + i; gs = (size_t)w; }
     else continue;
     // (where the top block's upper triangle held part of W, only its lower triangle goes back)
-    const int jend = ((usp < mb || root_solve) && i < w) ? i + 1 : w;
+    const int jend = (usp < mb && i < w) ? i + 1 : w;
     for(int j0 = cp_g; j0 < jend; j0 += 16*cp_ng)
     {
       double v[16];
@@ -1690,13 +1584,13 @@ int sparse_factor_levels(dlg_backend* b, int part)
         DlgRegionTurn turn(b);            // (held for the launch only: the sum over the ranks behind it blocks in the caller's hook)
         if(Y->fac_nt[l] == 128)
           hipLaunchKernelGGL(HIP_KERNEL_NAME(k_factor_level<128>), dim3(np), dim3(128), Y->pr2_lds, st,
-                             Y->pr2_item, Y->pr2_rec, Y->sn_bd_col, Y->pr2_dst, Y->Lx, Y->top_scr, Y->d_info, Y->uscr, fmode, fl, ep, ho, pacc, ry, rxh, rmm);
+                             Y->pr2_item, Y->pr2_rec, Y->sn_bd_col, Y->pr2_dst, Y->Lx, Y->top_scr, Y->d_info, Y->uscr, fmode, fl, ep, ho, pacc);
         else if(Y->fac_nt[l] == 256)
           hipLaunchKernelGGL(HIP_KERNEL_NAME(k_factor_level<256>), dim3(np), dim3(256), Y->pr2_lds, st,
-                             Y->pr2_item, Y->pr2_rec, Y->sn_bd_col, Y->pr2_dst, Y->Lx, Y->top_scr, Y->d_info, Y->uscr, fmode, fl, ep, ho, pacc, ry, rxh, rmm);
+                             Y->pr2_item, Y->pr2_rec, Y->sn_bd_col, Y->pr2_dst, Y->Lx, Y->top_scr, Y->d_info, Y->uscr, fmode, fl, ep, ho, pacc);
         else
           hipLaunchKernelGGL(HIP_KERNEL_NAME(k_factor_level<512>), dim3(np), dim3(512), Y->pr2_lds, st,
-                             Y->pr2_item, Y->pr2_rec, Y->sn_bd_col, Y->pr2_dst, Y->Lx, Y->top_scr, Y->d_info, Y->uscr, fmode, fl, ep, ho, pacc, ry, rxh, rmm);
+                             Y->pr2_item, Y->pr2_rec, Y->sn_bd_col, Y->pr2_dst, Y->Lx, Y->top_scr, Y->d_info, Y->uscr, fmode, fl, ep, ho, pacc);
       }
       l = Y->pr2_level1;                                 // (= the cut: everything below it is done)
       if(H.part_nranks > 1 && l == H.cut_level) { DLG_LAUNCH_CHECK(); DLG_CHECK(sparse_partition_reduce(b)); }
@@ -1714,13 +1608,13 @@ int sparse_factor_levels(dlg_backend* b, int part)
       DlgRegionTurn turn(b);
       if(Y->fac_nt[l] == 128)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_factor_level<128>), dim3(np), dim3(128), Y->pr_lds, st,
-                           Y->pr_item, Y->pr_rec, Y->sn_bd_col, Y->pr_dst, Y->Lx, Y->top_scr, Y->d_info, Y->uscr, fmode, fl, ep, ho, pacc, ry, rxh, rmm);
+                           Y->pr_item, Y->pr_rec, Y->sn_bd_col, Y->pr_dst, Y->Lx, Y->top_scr, Y->d_info, Y->uscr, fmode, fl, ep, ho, pacc);
       else if(Y->fac_nt[l] == 256)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_factor_level<256>), dim3(np), dim3(256), Y->pr_lds, st,
-                           Y->pr_item, Y->pr_rec, Y->sn_bd_col, Y->pr_dst, Y->Lx, Y->top_scr, Y->d_info, Y->uscr, fmode, fl, ep, ho, pacc, ry, rxh, rmm);
+                           Y->pr_item, Y->pr_rec, Y->sn_bd_col, Y->pr_dst, Y->Lx, Y->top_scr, Y->d_info, Y->uscr, fmode, fl, ep, ho, pacc);
       else
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_factor_level<512>), dim3(np), dim3(512), Y->pr_lds, st,
-                           Y->pr_item, Y->pr_rec, Y->sn_bd_col, Y->pr_dst, Y->Lx, Y->top_scr, Y->d_info, Y->uscr, fmode, fl, ep, ho, pacc, ry, rxh, rmm);
+                           Y->pr_item, Y->pr_rec, Y->sn_bd_col, Y->pr_dst, Y->Lx, Y->top_scr, Y->d_info, Y->uscr, fmode, fl, ep, ho, pacc);
       break;
     }
     if(n > 0 && !(l == 0 && Y->lf_on) && !launched_before)      // (leaf fronts: level 0 was factored with the assembly, sparse_leaf.hip)
@@ -1730,16 +1624,16 @@ int sparse_factor_levels(dlg_backend* b, int part)
       const int fmode = ((l >= H.mf_level0) ? 2 : Y->syrk_fused[l]) + 4*Y->fac_stage[l] + sweep_bits + 256*(l & 31);
       if(Y->fac_nt[l] == 128)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_factor_level<128>), dim3(n), dim3(128), Y->fac_lds[l], st,
-                           Y->fw_item + o, Y->mf_rec, Y->sn_bd_col, Y->mf_dst, Y->Lx, Y->top_scr, Y->d_info, Y->uscr, fmode, (int*)nullptr, 0, DlgHandoff{nullptr, 0, 0}, (int64_t)0, (double*)nullptr, (unsigned long long*)nullptr, (double*)nullptr);
+                           Y->fw_item + o, Y->mf_rec, Y->sn_bd_col, Y->mf_dst, Y->Lx, Y->top_scr, Y->d_info, Y->uscr, fmode, (int*)nullptr, 0, DlgHandoff{nullptr, 0, 0}, (int64_t)0);
       else if(Y->fac_nt[l] == 256 && Y->fac_leaf[l])
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_factor_level<256, true>), dim3(n), dim3(256), Y->fac_lds[l], st,
-                           Y->fw_item + o, Y->mf_rec, Y->sn_bd_col, Y->mf_dst, Y->Lx, Y->top_scr, Y->d_info, Y->uscr, fmode, (int*)nullptr, 0, DlgHandoff{nullptr, 0, 0}, (int64_t)0, (double*)nullptr, (unsigned long long*)nullptr, (double*)nullptr);
+                           Y->fw_item + o, Y->mf_rec, Y->sn_bd_col, Y->mf_dst, Y->Lx, Y->top_scr, Y->d_info, Y->uscr, fmode, (int*)nullptr, 0, DlgHandoff{nullptr, 0, 0}, (int64_t)0);
       else if(Y->fac_nt[l] == 256)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_factor_level<256>), dim3(n), dim3(256), Y->fac_lds[l], st,
-                           Y->fw_item + o, Y->mf_rec, Y->sn_bd_col, Y->mf_dst, Y->Lx, Y->top_scr, Y->d_info, Y->uscr, fmode, (int*)nullptr, 0, DlgHandoff{nullptr, 0, 0}, (int64_t)0, (double*)nullptr, (unsigned long long*)nullptr, (double*)nullptr);
+                           Y->fw_item + o, Y->mf_rec, Y->sn_bd_col, Y->mf_dst, Y->Lx, Y->top_scr, Y->d_info, Y->uscr, fmode, (int*)nullptr, 0, DlgHandoff{nullptr, 0, 0}, (int64_t)0);
       else
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_factor_level<512>), dim3(n), dim3(512), Y->fac_lds[l], st,
-                           Y->fw_item + o, Y->mf_rec, Y->sn_bd_col, Y->mf_dst, Y->Lx, Y->top_scr, Y->d_info, Y->uscr, fmode, (int*)nullptr, 0, DlgHandoff{nullptr, 0, 0}, (int64_t)0, (double*)nullptr, (unsigned long long*)nullptr, (double*)nullptr);
+                           Y->fw_item + o, Y->mf_rec, Y->sn_bd_col, Y->mf_dst, Y->Lx, Y->top_scr, Y->d_info, Y->uscr, fmode, (int*)nullptr, 0, DlgHandoff{nullptr, 0, 0}, (int64_t)0);
     }
     if(part == 1 && split && l == 0) { Y->fac_pending = true; DLG_LAUNCH_CHECK(); return DLG_OK; }
     // (behind the leaf level's factor kernel, in front of its updates: the gather kernel looks at the word itself,
