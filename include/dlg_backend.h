@@ -213,6 +213,24 @@ int  dlg_point_eval(dlg_backend_t* b, int slot, double* norm2_x, double* Jtx_abs
  * that factor back (its panels stay in the second buffer until the next step), another lambda
  * factorises again.  DOGLEG_AMD_NO_PRESOLVE=1 keeps the evaluation to the assembly. */
 int  dlg_backend_set_speculation(dlg_backend_t* b, int on);
+/* Work for the stream between a step and the host's wait for it.  dlg_take_step / dlg_step enqueue the step, then WAIT
+ * for its scalars; the evaluation of the trial point that follows (dogleg.c:1410: computeCallbackOperatingPoint) is
+ * enqueued when the host is back -- with a device-side model the chip idles meanwhile (event wake-up, the scalars, the
+ * evaluation's first launch: ~20 us of a 0.6 ms step on config #4 once the expected improvement lost its pass over J).
+ * dlg_backend_set_between(fn, cookie): the next dlg_take_step / dlg_step calls fn(cookie) ONCE, between the step's last
+ * launch and its wait.  fn may enqueue, on the backend's stream, work that needs no scalar of the step: the device model's
+ * kernels for the trial point (p of slot `to` is final in stream order) and dlg_point_eval_early -- the first pass over
+ * the trial point's J (K1 + K4: Jt*x records and JtJ into the second panel buffer), exactly what dlg_point_eval would
+ * launch first; dlg_point_eval of the same slot with the same inputs bound then finds it enqueued and goes on from there.
+ * Nothing else of the API may be called from fn.  A step that had to be made again (its factorisation broke down: the
+ * lambda loop, dogleg.c:656-677) drops that pass -- p_new changed --: dlg_backend_between_redone says so, the caller
+ * evaluates as if fn had never run.  A trial step that turns out to end the solve (dogleg.c:1289-1296, 1403-1408) has
+ * evaluated one point for nothing.  One call arms one step; fn == NULL disarms. */
+typedef void (*dlg_between_fn)(void* cookie);
+int  dlg_backend_set_between(dlg_backend_t* b, dlg_between_fn fn, void* cookie);
+int  dlg_backend_between_redone(dlg_backend_t* b);      /* 1: the last step was made again behind fn -- what fn enqueued is void */
+/* from inside fn only (sparse, single rank, dlg_backend_set_speculation on): *done = 1 if the pass was enqueued */
+int  dlg_point_eval_early(dlg_backend_t* b, int slot, const double* x_dev, const double* J_dev, int* done);
 /* The expected improvement behind the decision point.  takeStepFrom (dogleg.c:1172-1297) computes the expected improvement
  * with the step (1258-1269); runOptimizer looks at it twice: `expectedImprovement < 0.0` in front of the evaluation of the trial
  * point (dogleg.c:1403-1408: stop, the step is not applied; takeStepFrom's own -1 for max|step| below the threshold, 1289-1296,

@@ -38,7 +38,7 @@ BACKEND_SYMBOLS = [
     "dlg_backend_set_allreduce", "dlg_backend_set_partition", "dlg_partition_rows", "dlg_partition_stats",
     "dlg_sparse_partition_probe", "dlg_rccl_unique_id", "dlg_backend_init_rccl", "dlg_backend_set_rccl",
     "dlg_backend_comm_size", "dlg_backend_has_rccl", "dlg_backend_set_noop_comm", "dlg_solve_multi", "dlg_pseudoinverse_chunk", "dlg_backend_set_speculation", "dlg_backend_set_defer_tail", "dlg_step_tail",
-    "dlg_step_tail_pending", "dlg_backend_ei_source",
+    "dlg_step_tail_pending", "dlg_backend_ei_source", "dlg_backend_set_between", "dlg_backend_between_redone", "dlg_point_eval_early",
     "dlg_backend_share_rccl", "dlg_point_gather_device", "dlg_backend_reset", "dlg_backend_device",
     "dlg_sparse_pattern_matches", "dlg_sparse_drop_pattern", "dlg_sparse_region_probe", "dlg_run_steps", "dlg_backend_time_allreduce",
 ]

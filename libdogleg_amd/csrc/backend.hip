@@ -253,6 +253,8 @@ extern "C" int dlg_backend_create(dlg_backend_t** out, int solve_type, int Nstat
     k.no_reject_run = getenv("DOGLEG_AMD_NO_REJECT_RUN") != nullptr;
     k.ei_jpass = getenv("DOGLEG_AMD_EI_JPASS") != nullptr;
     k.no_p_side = getenv("DOGLEG_AMD_NO_P_SIDE") != nullptr;
+    k.no_between = getenv("DOGLEG_AMD_NO_BETWEEN") != nullptr;
+    k.no_k8_predict = getenv("DOGLEG_AMD_NO_K8_PREDICT") != nullptr;
     // test hook of the driver's `expected improvement < 0` stop (dogleg.c:1403-1408; exact arithmetic never gets there: the
     // value is a positive definite form of Jt x for all three kinds of step): the n-th value this backend hands out is negated
     if(const char* e = getenv("DOGLEG_AMD_DEBUG_EI_FLIP")) b->ei_flip = atoi(e);
@@ -349,6 +351,7 @@ extern "C" int dlg_backend_reset(dlg_backend_t* b)
   b->fold_scalar = b->fold_result = nullptr; b->fold_cauchy_out = nullptr;
   b->fold_p_src = nullptr; b->p_copied = false; b->scal_copied = false; b->fold_scal = 0;
   b->h_part_used = 0; b->pending.clear();
+  b->between_fn = nullptr; b->between_cookie = nullptr; b->between_armed = b->between_ran = b->between_redone = false; b->early_slot = -1; b->ident_predict = false;
   if(b->tail_pending) DLG_HIP(hipStreamSynchronize(b->stream));
   b->tail_pending = false; b->defer_tail = false; b->tail_mode = false; b->fold_scal_k7 = 0;
   DLG_HIP(hipMemsetAsync(b->d_scal, 0, sizeof(double)*dlg_backend::NSCAL, b->stream));
@@ -402,6 +405,40 @@ extern "C" int dlg_backend_set_defer_tail(dlg_backend_t* b, int on)
 {
   if(!b) return DLG_ERR_ARG;
   b->defer_tail = on != 0 && !b->knobs.no_defer_tail;
+  return DLG_OK;
+}
+extern "C" int dlg_backend_set_between(dlg_backend_t* b, dlg_between_fn fn, void* cookie)
+{
+  if(!b) return DLG_ERR_ARG;
+  b->between_fn = fn; b->between_cookie = fn ? cookie : nullptr;
+  return DLG_OK;
+}
+extern "C" int dlg_backend_between_redone(dlg_backend_t* b) { return (b && b->between_redone) ? 1 : 0; }
+// what a between function enqueued is void: the step is made again (another lambda), p_new changes
+static void between_drop(dlg_backend* b)
+{
+  if(!b->between_ran) return;
+  b->between_ran = false; b->between_redone = true;
+  if(b->early_slot >= 0 && b->type == DLG_SPARSE) sparse_spec_invalidate(b, b->early_slot);
+  b->early_slot = -1;
+}
+// The first pass over the next point's J, enqueued from a between function: what dlg_point_eval launches first (K1 + K4 in
+// one kernel, the Jt*x record sums behind it) with the inputs given -- the slot's bound inputs are not touched: the
+// caller binds them when its turn comes, dlg_point_eval then recognises them
+extern "C" int dlg_point_eval_early(dlg_backend_t* b, int s, const double* x_dev, const double* J_dev, int* done)
+{
+  if(done) *done = 0;
+  if(!b || s < 0 || s > 1 || !x_dev || !J_dev) { dlg_set_error("dlg_point_eval_early: bad arguments"); return DLG_ERR_ARG; }
+  if(b->type != DLG_SPARSE || !b->sym || !b->speculate || !b->fuse_eval || b->sharded() || b->part_nranks > 1 || b->pre_slot >= 0) return DLG_OK;
+  DlgSlot& S = b->slot[s];
+  const double* ox = S.x_bound; const double* oJ = S.J_bound;
+  S.x_bound = x_dev; S.J_bound = J_dev;
+  int fused = 0;
+  const int rc = sparse_eval_assemble(b, s, &fused);
+  S.x_bound = ox; S.J_bound = oJ;
+  DLG_CHECK(rc);
+  if(fused) { b->early_slot = s; b->early_x = x_dev; b->early_J = J_dev; }
+  if(done) *done = fused;
   return DLG_OK;
 }
 // Before anything overwrites what a tail that is still out reads (the step vector, p_new, J of its slot): the tail is a
@@ -676,6 +713,7 @@ extern "C" int dlg_point_upload(dlg_backend_t* b, int s, const double* x_host, c
   DLG_CHECK(tail_guard(b));                     // (a K8 behind the decision point may still be reading this slot's J)
   DlgSlot& S = b->slot[s];
   S.x_bound = S.J_bound = nullptr;
+  if(b->early_slot == s) b->early_slot = -1;
   // a sharded rank uploads only its own rows: x[row0:row1] and the J entries of those rows
   const size_t mloc = (size_t)dlg_mloc(b);
   if(mloc > 0)
@@ -716,7 +754,10 @@ extern "C" int dlg_point_bind_device(dlg_backend_t* b, int s, const double* x_de
   S.have_inputs = true;
   invalidate(S);
   if(b->factor_slot == s) b->factor_slot = -1;
-  if(b->type == DLG_SPARSE) sparse_spec_invalidate(b, s);
+  // (inputs whose first pass is on the stream already -- dlg_point_eval_early -- keep it)
+  const bool early = b->early_slot == s && b->early_x == x_dev && b->early_J == J_dev;
+  if(b->early_slot == s && !early) b->early_slot = -1;
+  if(b->type == DLG_SPARSE && !early) sparse_spec_invalidate(b, s);
   return DLG_OK;
 }
 
@@ -801,7 +842,12 @@ extern "C" int dlg_point_eval(dlg_backend_t* b, int s, double* norm2_x, double* 
     // the caller expects to factorise this point: JtJ is assembled in the same pass over J that forms
     // Jt*x (sparse_eval_assemble) or, where that schedule is not available, on the second stream meanwhile
     int fused = 0;
-    if(b->type == DLG_SPARSE && b->speculate && b->fuse_eval) DLG_CHECK(sparse_eval_assemble(b, s, &fused));
+    // (the pass over J may be on the stream already: dlg_point_eval_early from inside the step before)
+    const bool early = b->type == DLG_SPARSE && b->early_slot == s && b->early_x == S.xin() && b->early_J == S.Jin() && b->speculate && b->fuse_eval &&
+                       sparse_spec_is(b, s, S.Jin());
+    if(b->early_slot == s) b->early_slot = -1;
+    if(early) fused = 1;
+    else if(b->type == DLG_SPARSE && b->speculate && b->fuse_eval) DLG_CHECK(sparse_eval_assemble(b, s, &fused));
     if(!fused)
     {
       if(b->type == DLG_SPARSE && b->speculate && b->overlap) DLG_CHECK(sparse_assemble_speculative(b, s));
@@ -1223,6 +1269,14 @@ static int step_finish(dlg_backend* b, int to, int nscal, double* p_new_host)
   if(!b->ev_fetch) DLG_HIP(hipEventCreateWithFlags(&b->ev_fetch, hipEventDisableTiming));
   if(!attached) DLG_HIP(hipEventRecord(b->ev_fetch, b->stream));
   if(b->type == DLG_SPARSE) DLG_CHECK(sparse_zero_spare(b));
+  // (the caller's work for the stream that needs no scalar of this step: dlg_backend_set_between)
+  if(b->between_armed && b->between_fn)
+  {
+    b->between_armed = false; b->between_ran = true;
+    dlg_between_fn fn = b->between_fn; void* ck = b->between_cookie;
+    b->between_fn = nullptr; b->between_cookie = nullptr;
+    fn(ck);
+  }
   DLG_HIP(hipEventSynchronize(b->ev_fetch));
   b->sync_mark++;
   dlg_resolve_pending(b);
@@ -1279,6 +1333,8 @@ extern "C" int dlg_step(dlg_backend_t* b, int from, int to, int kind, double tru
   if(from == to) { dlg_set_error("dlg_step: from == to"); return DLG_ERR_ARG; }
   DLG_CHECK(step_unprepare(b));                 // (as in dlg_make_step: the driver's retry after a rejected trial point)
   DLG_CHECK(tail_guard(b)); b->tail_pending = false;
+  b->between_armed = b->between_fn != nullptr; b->between_ran = false; b->between_redone = false;      // dlg_backend_set_between
+  struct BetweenGuard { dlg_backend* b; ~BetweenGuard() { b->between_armed = false; b->between_fn = nullptr; } } between_guard{b};
   double n2 = 0, kk = NAN, amax = 0;
   int nscal = 0;
   // The expected improvement from the solved system (ident_norm2_Jstep): a step from the cached vectors of a point whose
@@ -1421,7 +1477,7 @@ extern "C" int dlg_take_step(dlg_backend_t* b, int from, int to, double trustreg
   if(!F.have_Jtx) { dlg_set_error("dlg_take_step needs Jt_x"); return DLG_ERR_STATE; }
   if(!b->d_gnpart) DLG_HIP(hipMalloc(&b->d_gnpart, sizeof(double)*4096));      // |gn|^2 partials, then the pivots' partial minima / maxima (k_negate_interp1)
   double lam = *lambda_io;
-  bool side_copy = false, ident_used = false;
+  bool side_copy = false, ident_used = false, k8_omitted = false;
   double ident_nJs = 0.0;
   // (the factorisation and the solve enqueued by dlg_point_eval -- step_prepare -- are this step's if the
   // lambda is the one they were formed at; they are used once)
@@ -1434,6 +1490,8 @@ extern "C" int dlg_take_step(dlg_backend_t* b, int from, int to, double trustreg
   b->pre_rejected = false;                     // (a step from a fresh point: the point before it was accepted)
   DLG_CHECK(tail_guard(b));
   b->tail_pending = false;
+  b->between_armed = b->between_fn != nullptr; b->between_ran = false; b->between_redone = false;      // dlg_backend_set_between
+  struct BetweenGuard { dlg_backend* b; ~BetweenGuard() { b->between_armed = false; b->between_fn = nullptr; } } between_guard{b};
   // Where p_new goes: a page-locked destination is written by the step's pass over J itself (K8, a slice per workgroup)
   hipPointerAttribute_t p_attr;
   const bool p_pinned = p_new_host && b->copy_stream && hipPointerGetAttributes(&p_attr, p_new_host) == hipSuccess && p_attr.type == hipMemoryTypeHost;
@@ -1562,9 +1620,18 @@ extern "C" int dlg_take_step(dlg_backend_t* b, int from, int to, double trustreg
       // No event of its own (a launch somebody listens to holds the next dispatch back by ~5 us): the evaluation that
       // follows is waited for on this stream behind it -- dlg_step_tail only waits itself if nothing was (sync_mark).
       b->tail_mode = true; b->fold_scal = 0; b->attach_stop = nullptr; b->stop_attached = false;
-      b->k8_skip = b->ident_launched ? b->d_scal + dlg_backend::IDENT_SLOT : nullptr;
-      const int rct = b->type == DLG_SPARSE ? sparse_norm2_Jv(b, from, T.step, b->d_scal + 12, b->d_scal + 8)
-                                            : dense_norm2_Jv(b, from, T.step, b->d_scal + 12);
+      // The pass over J is not even launched where the step kernel is expected to let it return at once -- the last step of
+      // this backend did (ident_predict), lambda is 0 again, and the launch would carry nothing else (p_new is on the copy
+      // stream): a launch that returns at once is still 5 - 6 us on the critical queue.  The device's word is the judge: if
+      // it says the pass is needed after all, it is launched behind the wait (below), late but the same pass.
+      k8_omitted = b->ident_launched && b->ident_predict && lam == 0.0 && b->tail_no_fold && !b->knobs.no_k8_predict;
+      int rct = DLG_OK;
+      if(!k8_omitted)
+      {
+        b->k8_skip = b->ident_launched ? b->d_scal + dlg_backend::IDENT_SLOT : nullptr;
+        rct = b->type == DLG_SPARSE ? sparse_norm2_Jv(b, from, T.step, b->d_scal + 12, b->d_scal + 8)
+                                    : dense_norm2_Jv(b, from, T.step, b->d_scal + 12);
+      }
       b->tail_mode = false; b->k8_skip = nullptr;
       b->fold_p_src = nullptr; b->p_copied = false;
       DLG_CHECK(rct);
@@ -1617,6 +1684,19 @@ extern "C" int dlg_take_step(dlg_backend_t* b, int from, int to, double trustreg
     if(ident_used)
       ident_nJs = ident_norm2_Jstep((int)b->h_scal[8], b->h_scal[9], trustregion, F.norm2_jtx, F.Jg2, F.norm2_cauchy, b->h_scal[dlg_backend::GB_SLOT]);
     if(defer) { b->tail_ident = ident_used; b->tail_nJs = ident_nJs; }
+    if(b->ident_launched) b->ident_predict = ident_used;
+    if(defer && k8_omitted && !ident_used)
+    {
+      // (the step kernel wants the pass over J after all -- another pivot range than last time: behind the wait, in the
+      // tail's own form; dlg_step_tail waits for it)
+      b->tail_mode = true; b->fold_scal = 0; b->attach_stop = nullptr; b->stop_attached = false; b->k8_skip = nullptr;
+      const int rcl = b->type == DLG_SPARSE ? sparse_norm2_Jv(b, from, T.step, b->d_scal + 12, b->d_scal + 8)
+                                            : dense_norm2_Jv(b, from, T.step, b->d_scal + 12);
+      b->tail_mode = false;
+      DLG_CHECK(rcl);
+      b->tail_mark = b->sync_mark;
+    }
+    k8_omitted = false;
     if((int)b->h_scal[8] == DLG_KIND_CAUCHY_TO_EDGE)
     {
       // The Cauchy step was the one taken: the reference never factorises on this branch
@@ -1639,6 +1719,7 @@ extern "C" int dlg_take_step(dlg_backend_t* b, int from, int to, double trustreg
     if(good) break;
     if(b->type == DLG_SPARSE && !sparse_note_breakdown(b)) sparse_mark_unclean(b);          // (a factorisation that broke down: full clears next -- unless nothing of it ran)
     b->factor_slot = -1;
+    between_drop(b);                                          // (the step is made again: what the caller enqueued behind it is void)
     lam = (lam == 0.0) ? 1e-10 : lam*10.0;                    // dogleg.c:138, 671-672, 812-813
     if(!(lam < 1e300)) { dlg_set_error("lambda overflowed while regularising a singular JtJ"); return DLG_ERR_STATE; }
   }
@@ -1674,11 +1755,17 @@ extern "C" int dlg_run_steps(dlg_backend_t* b, int from, int to, int nsteps, int
   DLG_CHECK(check_slot(b, from)); DLG_CHECK(check_slot(b, to));
   if(nsteps < 0 || ncopy < 1 || !x_dev || !J_dev) { dlg_set_error("dlg_run_steps: bad arguments"); return DLG_ERR_ARG; }
   double n2x = 0, gmax = 0, lam = lambda0, tail = 0, o[7] = {0, 0, 0, 0, 0, 0, 0};
+  // (as the driver's device-callback solves do, driver.hip take_step: the next point's first pass over J goes onto the
+  // stream from inside the step, in front of the host's wait for the step's scalars -- dlg_backend_set_between)
+  struct Next { dlg_backend* b; int slot; const double* x; const double* J; };
+  auto next_fn = [](void* c) { Next* n = static_cast<Next*>(c); int done = 0; (void)dlg_point_eval_early(n->b, n->slot, n->x, n->J, &done); };
   for(int i = 0; i < nsteps; i++)
   {
     const int c = (first_copy + i) % ncopy;
     DLG_CHECK(dlg_point_bind_device(b, from, x_dev[c], J_dev[c]));
     DLG_CHECK(dlg_point_eval(b, from, &n2x, &gmax));
+    Next nx{b, from, x_dev[(c + 1) % ncopy], J_dev[(c + 1) % ncopy]};
+    if(i + 1 < nsteps && b->defer_tail && !b->knobs.no_between) DLG_CHECK(dlg_backend_set_between(b, next_fn, &nx));
     // (dlg_backend_set_defer_tail: the expected improvement of the step before is fetched where the driver needs it --
     // behind the evaluation of the trial point, dogleg.c:1410-1427; its pass over J ran beside that evaluation)
     DLG_CHECK(dlg_step_tail(b, &tail));

@@ -111,11 +111,17 @@ struct dlg_backend
   // DOGLEG_AMD_EI_JPASS=1: always the pass over J.
   static constexpr int IDENT_SLOT = 3, GB_SLOT = 13;     // free slots of dlg_take_step's scalar block
   static constexpr double IDENT_RATIO_MAX = 212.0;       // (max L_ii / min L_ii)^2 * 2.2e-16 <= 1e-11
-  bool ident_launched = false; const double* k8_skip = nullptr;
+  bool ident_launched = false, ident_predict = false; const double* k8_skip = nullptr;      // ident_predict: the last step's pass over J was let go by the device
   bool ei_from_system = false; double pivot_ratio = NAN;   // dlg_backend_ei_source: how the last value handed out was formed
   int ei_flip = 0, ei_count = 0;                           // DOGLEG_AMD_DEBUG_EI_FLIP (test hook)
   bool tail_ident = false, tail_no_fold = false; double tail_nJs = 0.0;     // (tail_no_fold: the K8 on the stream carries no p_new)
   bool p_side_pending = false;          // p_new of a step behind the decision point is on its way on the copy stream (ev_copy)
+  // Work the CALLER has for the stream that does not depend on a step's scalars (dlg_backend_set_between): enqueued from
+  // inside dlg_take_step / dlg_step, between the step's last launch and the host's wait for it -- the device model's
+  // kernels for the trial point, the first pass over the next point's J (dlg_point_eval_early).  The host's turn-round
+  // behind the step (event wake-up, scalars, the evaluation's first launch: ~20 us) then hides behind that work.
+  dlg_between_fn between_fn = nullptr; void* between_cookie = nullptr; bool between_armed = false, between_ran = false, between_redone = false;
+  int early_slot = -1; const double* early_x = nullptr; const double* early_J = nullptr;      // dlg_point_eval_early: what dlg_point_eval finds enqueued
   static constexpr int NSCAL = 16;
   // hand-offs inside the one-launch regions (flags between workgroups): a wait that gives up raises a bit in
   // the status word (slot NSCAL - 2 of the scalar block, so it travels with every fetch of the scalars);
@@ -127,7 +133,7 @@ struct dlg_backend
   {
     bool join_event = false;
     bool no_k3_fork = false, no_potrf_fuse = false, potrf_steps = false,
-         trsv_steps = false, no_touch = false, no_abandon = false, no_split = false, no_reject_run = false, no_defer_tail = false, ei_jpass = false, no_p_side = false;
+         trsv_steps = false, no_touch = false, no_abandon = false, no_split = false, no_reject_run = false, no_defer_tail = false, ei_jpass = false, no_p_side = false, no_between = false, no_k8_predict = false;
     int touch_wg = 512;
   } knobs;
   int ncu = 256;              // compute units of b->device
@@ -353,6 +359,7 @@ int sparse_touch_factor(dlg_backend* b, hipStream_t st);         // second strea
 int sparse_zero_spare(dlg_backend* b);                           // clear the panel buffer the factorisation left behind (behind the step's fetch)
 int sparse_abandon_enqueued(dlg_backend* b);                     // the launches of a factorisation + solve enqueued ahead (step_prepare) return early from here on
 void sparse_spec_invalidate(dlg_backend* b, int s);
+bool sparse_spec_is(const dlg_backend* b, int s, const double* J);     // the second panel buffer holds slot s's assembly from the values at J
 // K3/K8; kind_if_factor_failed (device scalar holding the kind of step, or null): the pass is skipped when the
 // factorisation on the stream failed and the step is not the Cauchy step to the edge
 int sparse_norm2_Jv(dlg_backend* b, int slot, const double* v, double* out_dev, const double* kind_if_factor_failed = nullptr);

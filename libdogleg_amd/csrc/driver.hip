@@ -89,6 +89,9 @@ struct Driver
   bool be_reused;                              // the backend served an earlier solve (take_parked)
   bool expect_gn;                              // the last step needed the Gauss-Newton step: issue it with the Cauchy step
   bool tail_out;                               // the expected improvement of the step just taken is still on its way (dlg_step_tail)
+  // device callback: the model's kernels for the trial point and the first pass over its J went onto the stream from inside
+  // the step (between_fn, dlg_backend_set_between) -- early_slot: the slot whose callback ran there (-1: none)
+  int early_slot; bool no_between;
   std::future<int>* pat_check;                 // the comparison of the caller's pattern with the taken-over backend's, running beside the first evaluation
   bool failed;                                 // a backend op failed during the solve: the backend is not kept
   bool sharded;                                // this solve is one rank of several (subtree partition / row shard + all-reduces)
@@ -442,7 +445,11 @@ bool eval_point(bool* converged, dogleg_operatingPoint_t* pt, Driver* d)
     }
     else
     {
-      { Tick tk(d, TM_CALLBACK); (*d->f_device)(p_dev, x_dev, J_dev, dlg_backend_get_stream(d->be), ctx->cookie); }
+      // (the callback of this point may have run already -- between_fn, from inside the step that made the point; a step
+      // that was made again behind it moved the point: then it runs again)
+      const bool early_cb = d->early_slot == s && !dlg_backend_between_redone(d->be);
+      d->early_slot = -1;
+      if(!early_cb) { Tick tk(d, TM_CALLBACK); (*d->f_device)(p_dev, x_dev, J_dev, dlg_backend_get_stream(d->be), ctx->cookie); }
       // (dense on a rank: its rows are a contiguous slice of what the callback wrote)
       const size_t r0 = d->sharded ? (size_t)d->row0 : 0;
       Tick tu(d, TM_UPLOAD);
@@ -635,6 +642,35 @@ bool compute_gn(dogleg_operatingPoint_t* pt, Driver* d)
   return true;
 }
 
+// A device-side model: the evaluation of the trial point (dogleg.c:1410, computeCallbackOperatingPoint) needs nothing of the
+// step but p_new, which is final on the device in stream order -- its kernels, and the backend's first pass over the new
+// Jacobian, go onto the stream from INSIDE the step, in front of the host's wait for the step's scalars
+// (dlg_backend_set_between); eval_point then finds them there.  A step that ends the solve (dogleg.c:1289-1296) has
+// evaluated one point for nothing: it is not counted and never looked at.
+struct BetweenArgs { Driver* d; int slot; };
+void driver_between(void* c)
+{
+  BetweenArgs* a = static_cast<BetweenArgs*>(c);
+  Driver* d = a->d;
+  const int s = a->slot;
+  const double* p_dev = (const double*)dlg_point_device_ptr(d->be, s, DLG_VEC_P);
+  double* x_dev = (double*)dlg_point_device_ptr(d->be, s, DLG_VEC_X_OWN);
+  double* J_dev = (double*)dlg_point_device_ptr(d->be, s, DLG_VEC_J_OWN);
+  { Tick tk(d, TM_CALLBACK); (*d->f_device)(p_dev, x_dev, J_dev, dlg_backend_get_stream(d->be), d->pub.cookie); }
+  d->early_slot = s;
+  if(d->pub.solve_type == DOGLEG_SPARSE)
+  {
+    int done = 0;
+    dlg_backend_set_speculation(d->be, d->expect_gn);
+    (void)dlg_point_eval_early(d->be, s, x_dev, J_dev, &done);
+  }
+}
+bool between_ok(const Driver* d)
+{
+  return d->f_device && !d->sharded && !d->no_between && !d->pat_check &&
+         (d->pub.solve_type == DOGLEG_DENSE || (d->pub.solve_type == DOGLEG_SPARSE && d->pattern_set));
+}
+
 // dogleg.c:1172-1297.  The step vector stays on the device (slot `to`); p_new
 // comes back because the user callback needs it.
 bool take_step(double* expectedImprovement, dogleg_operatingPoint_t* to,
@@ -663,6 +699,8 @@ bool take_step(double* expectedImprovement, dogleg_operatingPoint_t* to,
     { MSG("factorization needs J (or JtJ), which is missing"); return false; }
     double o[7];
     const double lambda_before = ctx->lambda;
+    BetweenArgs ba{d, st};
+    if(between_ok(d)) dlg_backend_set_between(d->be, driver_between, &ba);
     if(!be_ok(dlg_take_step(d->be, sf, st, trustregion, &ctx->lambda, o, to->p), "step")) return false;
     if(ctx->lambda != lambda_before) VERBOSE(d, "singular JtJ: adding %g I from now on", ctx->lambda);
     from->norm2_updateCauchy = o[0]; from->have_updateCauchy = true;
@@ -711,6 +749,8 @@ bool take_step(double* expectedImprovement, dogleg_operatingPoint_t* to,
     }
   }
   // step, its expected improvement and p_new: one backend op, one host synchronisation
+  BetweenArgs ba{d, st};
+  if(between_ok(d)) dlg_backend_set_between(d->be, driver_between, &ba);
   if(!be_ok(dlg_step(d->be, sf, st, kind, trustregion, &n2, &k, &amax, expectedImprovement, to->p), "step")) return false;
   d->tail_out = dlg_step_tail_pending(d->be) != 0;      // (dlg_backend_set_defer_tail: run_optimizer fetches it behind the evaluation)
   }
@@ -999,6 +1039,7 @@ double optimize(double* p, unsigned int Nstate, unsigned int Nmeas, unsigned int
   Driver* d = (Driver*)calloc(1, sizeof(Driver));
   if(!d) { MSG("out of memory"); return -1.0; }
   d->f_device = f_device; d->dev_cp = dev_cp; d->dev_ri = dev_ri;
+  d->early_slot = -1; d->no_between = getenv("DOGLEG_AMD_NO_BETWEEN") != nullptr;
   dogleg_solverContext_t* ctx = &d->pub;
   ctx->cookie = cookie;
   ctx->lambda = 0.0;

@@ -1585,6 +1585,12 @@ int sparse_zero_spare(dlg_backend* b)
   Y->spare_zeroed = true; Y->spare_stream = b->stream;
   return DLG_OK;
 }
+// the second panel buffer holds the assembly of slot s's point with the Jacobian values at J (sparse_eval_assemble)
+bool sparse_spec_is(const dlg_backend* b, int s, const double* J)
+{
+  const SparseSym* Y = b->sym;
+  return Y && Y->spec_valid && Y->spec_slot == s && Y->spec_J == J;
+}
 void sparse_spec_invalidate(dlg_backend* b, int s)
 {
   SparseSym* Y = b->sym;

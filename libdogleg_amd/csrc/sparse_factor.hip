@@ -32,11 +32,12 @@ template <int NT, bool UT_LDS, bool HANDOFF = false>
 __device__ __forceinline__ void mf_add_children(double* P, double* Wt, int ntri, int nch, int ch0,
                                                 MfChild rc, const MfChild* __restrict__ mf_rec,
                                                 const double* uscr, const uint16_t* __restrict__ mf_dst, int tid,
-                                                int* pr_flag = nullptr, int pr_epoch = 0, DlgHandoff ho = DlgHandoff{nullptr, 0, 0})
+                                                int* pr_flag = nullptr, int pr_epoch = 0, DlgHandoff ho = DlgHandoff{nullptr, 0, 0}, int z0 = 0)
 {
   constexpr int MF_SLOTS = (NT >= 512) ? 20 : 16;      // 512 threads: up to 10240 entries (a 139-row update matrix) in one round
   const int lane = tid & 63;
-  for(int e = tid; e < ntri; e += NT) Wt[e] = 0.0;
+  // (z0 .. ntri: the entries this workgroup sums -- all of them, or a replica's own stretch of an update matrix kept in HBM)
+  for(int e = z0 + tid; e < ntri; e += NT) Wt[e] = 0.0;
   __syncthreads();
   for(int k = 0; k < nch; k++)
   {
@@ -395,7 +396,10 @@ __global__ void __launch_bounds__(NT, LEAF ? 4 : 1) k_factor_level(const FwItem*
                      (__builtin_amdgcn_readlane(rc.rsv, 0) >> 20) <= 8 && (__builtin_amdgcn_readlane(rc.rsv, 1) >> 20) <= 8;
     if(pr_flag && u_lds && two) mf_add_two_pipelined<NT>(P, Us, nlin, rc, uscr, mf_dst, tid, pr_flag, pr_epoch, ho);
     else if(pr_flag && u_lds) mf_add_children<NT, true, true>(P, Us, nlin, it.nch, it.ch0, rc, mf_rec, uscr, mf_dst, tid, pr_flag, pr_epoch, ho);
-    else if(pr_flag)     mf_add_children<NT, false, true>(P, Ug + pr_acc, ntri, it.nch, it.ch0, rc, mf_rec, uscr, mf_dst, tid, pr_flag, pr_epoch, ho);
+    // (replicas of a supernode whose update matrix is summed in HBM: each owns the packed entries [eA, eB) -- its tile
+    // columns --, its destination lists drop everything else of the children that is not a panel entry)
+    else if(pr_flag)     mf_add_children<NT, false, true>(P, Ug + pr_acc, (nrep > 1 && !sliced) ? it.eB : ntri, it.nch, it.ch0, rc, mf_rec, uscr, mf_dst, tid, pr_flag, pr_epoch, ho,
+                                                          (nrep > 1 && !sliced) ? it.eA : 0);
     else if(u_lds)  mf_add_children<NT, true >(P, Us, nlin, it.nch, it.ch0, rc, mf_rec, uscr, mf_dst, tid);
     else            mf_add_children<NT, false>(P, Ug, ntri, it.nch, it.ch0, rc, mf_rec, uscr, mf_dst, tid);
   }
@@ -1291,6 +1295,7 @@ int sparse_factor_setup(dlg_backend* b, bool plan_only)
       const int rmax = std::max(1, std::min(8, env_int_host("DOGLEG_AMD_FRONT_REPLICAS", 8)));
       const int fill = env_int_host("DOGLEG_AMD_FRONT_FILL", ncu/2), fill0 = ncu/2;
       const bool slice_ok = !getenv("DOGLEG_AMD_NO_FRONT_SLICES");
+      const bool hbm_rep_ok = !getenv("DOGLEG_AMD_NO_HBM_REPLICAS");
       std::vector<int> first(H.fw_item.size(), -1), count(H.fw_item.size(), 0);
       // the region's own children records and destination lists: those of the symbolic phase (whole update
       // matrix behind the panel), and behind them the lists of the replicas that keep a slice of it
@@ -1368,10 +1373,38 @@ int sparse_factor_setup(dlg_backend* b, bool plan_only)
             if(fits) break;
             nrep = 1;                                   // (more, narrower slices)
           }
+          bool hbm_rep = false;
           if(nrep == 1 || !slice_ok)
           {
             // one workgroup (or replicas that each stage the whole update matrix: DOGLEG_AMD_NO_FRONT_SLICES)
-            if(it.jsp < 0) { nrep = 1; if(has_w && it.nch > 0) acc_any = true; }
+            if(it.jsp < 0)
+            {
+              nrep = 1;
+              if(has_w && it.nch > 0) acc_any = true;
+              // Round 6: an update matrix that is summed in HBM (a panel that fills LDS by itself: config #5's fronts of
+              // 250 - 300 rows x 60 - 66 columns) gets replicas too -- each sweeps the panel and OWNS a stretch of tile
+              // columns of the update matrix in HBM: it sums the children's entries of that stretch only (its own destination
+              // lists drop the others), forms B B' of those tiles and publishes them.  One workgroup formed all 120 tiles of
+              // such a front, 30 - 46 us of every level on config #5's critical path (profiles/r05_top_of_tree_levels_config5.txt).
+              const int want_h = (has_w && slice_ok && hbm_rep_ok) ? std::min(std::min(rl_i, T), 8) : 1;      // (at least 2 / 3 / 4 of them also on the populous levels: 336 / 330 / 326 steps/s against 338)
+              if(want_h > 1)
+              {
+                for(int cap2 = (T*(T + 1)/2 + want_h - 1)/want_h; ; cap2++)
+                {
+                  cut.assign(1, 0);
+                  int load = 0;
+                  for(int t = 0; t < T; t++)
+                  {
+                    if(load > 0 && load + (T - t) > cap2) { cut.push_back(t); load = 0; }
+                    load += T - t;
+                  }
+                  cut.push_back(T);
+                  if((int)cut.size() - 1 <= want_h) break;
+                }
+                nrep = std::max(1, (int)cut.size() - 1);
+                hbm_rep = nrep > 1;
+              }
+            }
             else if(nrep > 1) { /* whole-W replicas: the kernel's column-range copy-out */ }
           }
           first[i] = (int)items.size(); count[i] = nrep;
@@ -1381,7 +1414,39 @@ int sparse_factor_setup(dlg_backend* b, bool plan_only)
             it.rep = r; it.tj0 = (nrep == 1) ? 0 : cut[r]; it.tj1 = (nrep == 1 || r == nrep - 1) ? (1 << 20) : cut[r+1];
             it.rsv2 = nrep;      // (the LAST replica stores the panel, once the others have read it: k_factor_level)
             it.pad = l;          // (the level: for the profile build's dump)
-            if(nrep > 1 && slice_ok)
+            if(hbm_rep)
+            {
+              // (not `sliced`: nothing of the update matrix is in LDS; [eA, eB) is the stretch of the packed triangle this
+              // replica zeroes, sums and forms -- k_factor_level)
+              const long jA = std::min<long>(16L*it.tj0, mb), jB = (r == nrep - 1) ? mb : std::min<long>(16L*it.tj1, mb);
+              const long eA = lin(jA, mb), eB = lin(jB, mb);
+              it.sliced = 0; it.eA = (int)eA; it.eB = (int)eB;
+              lds_need = std::max(lds_need, (pan + 2)*8);
+              const int ch0_new = (int)rec.size();
+              for(int k = 0; k < it.nch; k++)
+              {
+                MfChild rc = H.mf_rec[it.ch0 + k];
+                const int c = H.mf_child[it.ch0 + k];
+                const int mc = (H.sn_rowptr[c+1] - H.sn_rowptr[c]) - (H.sn_c0[c+1] - H.sn_c0[c]);
+                const int* map = &H.relpos[H.sn_prel[c]];
+                const int nc = mc*(mc + 1)/2;
+                rc.dst_off = (int64_t)dst.size();
+                rc.rsv = (rc.rsv >= 0 && first[rc.rsv] >= 0) ? (first[rc.rsv] | (count[rc.rsv] << 20)) : -1;
+                dst.reserve(dst.size() + rc.npad);
+                for(int j = 0; j < mc; j++)
+                  for(int q = j; q < mc; q++)
+                  {
+                    const long fi = map[q], fj = map[j], jw = fj - it.w;
+                    const long d = (fj < it.w) ? fi + fj*ldp
+                                 : (jw >= jA && jw < jB) ? (0x8000 | (lin(jw, mb) + (fi - fj))) : pan;      // pan: the scratch slot
+                    dst.push_back((uint16_t)d);
+                  }
+                for(int e = nc; e < rc.npad; e++) dst.push_back((uint16_t)pan);
+                rec.push_back(rc);
+              }
+              it.ch0 = ch0_new;
+            }
+            else if(nrep > 1 && slice_ok)
             {
               const long jA = std::min<long>(16L*it.tj0, mb), jB = (r == nrep - 1) ? mb : std::min<long>(16L*it.tj1, mb);
               const long eA = lin(jA, mb), eB = lin(jB, mb), slp = eA & 1;
@@ -1727,7 +1792,17 @@ extern "C" int dlg_sparse_region_probe(int N, int M, const int* colptr, const in
     }
     else
     {
-      if(it.jsp < 0 && mb > 0 && it.u_off >= 0) { if(it.rep == 0) nhbm++; if(it.tj0 != 0 || it.tj1 < T) return fail("replicas of an update matrix that is summed in HBM", g); }
+      if(it.jsp < 0 && mb > 0 && it.u_off >= 0)
+      {
+        if(it.rep == 0) nhbm++;
+        // (replicas of an update matrix that is summed in HBM own the packed entries [eA, eB): their tile columns)
+        if(it.rsv2 > 1)
+        {
+          const long jA = std::min<long>(16L*it.tj0, mb), jB = it.tj1 >= T ? mb : std::min<long>(16L*it.tj1, mb);
+          if(it.eA != jA*mb - jA*(jA - 1)/2 || it.eB != jB*mb - jB*(jB - 1)/2) return fail("an HBM replica's stretch does not match its tile columns", g);
+        }
+        else if(it.tj0 != 0 || it.tj1 < T) return fail("a single workgroup that does not form the whole update matrix", g);
+      }
       // (the kernel stages the whole update matrix behind the panel when the supernode has children, or -- childless --
       // when the launch stages those too)
       const bool staged = it.jsp >= 0 && mb > 0 && it.u_off >= 0 && (it.nch > 0 || Y.pr_stage);
@@ -1751,6 +1826,7 @@ extern "C" int dlg_sparse_region_probe(int N, int M, const int* colptr, const in
         const long d = Y.pr_dst_h[(size_t)(rc2.dst_off + e)];
         if(it.sliced || it.jsp >= 0) { if(d >= pan + (it.sliced ? (it.eA & 1) + (it.eB - it.eA) : sym_w_linear(mb, it.jsp)) + 1) return fail("a destination behind the workgroup's LDS", g); }
         else if(!(d & 0x8000) ? d >= pan + 1 : (d & 0x7fff) > ntri) return fail("a destination outside panel / update matrix", g);
+        else if((d & 0x8000) && it.rsv2 > 1 && ((d & 0x7fff) < it.eA || (d & 0x7fff) >= it.eB)) return fail("an HBM replica adds to an entry it does not own", g);
       }
     }
     const bool last = g + 1 == Y.pr_item_h.size() || Y.pr_item_h[g + 1].rep == 0;

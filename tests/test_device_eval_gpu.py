@@ -43,8 +43,10 @@ def test_sparse_device_solve_matches_oracle_trace(gpu, shape):
     worst = compare_traces(trg, tro)
     assert np.max(np.abs(pg - po)) <= 1e-10
     assert abs(rg - ro) <= 1e-10 * max(1.0, abs(ro))
-    # every evaluation ran on the device, none through a host callback
-    assert twin.neval() == tro.ncallbacks
+    # every evaluation ran on the device, none through a host callback; a trial step that ends the solve has had its point
+    # evaluated for nothing from inside the step (dlg_backend_set_between: the model's kernels go onto the stream in front of
+    # the host's wait for the step) -- never counted, never looked at
+    assert trg.ncallbacks == tro.ncallbacks and twin.neval() in (tro.ncallbacks, tro.ncallbacks + 1)
     kinds = {t["step_type"] for t in trg.trials()}
     print(f"device-eval sparse {shape}: {trg.ntrials} trials, step kinds {sorted(kinds)}, max |step diff| {worst:.2e}")
 
@@ -60,7 +62,7 @@ def test_dense_device_solve_matches_oracle_trace(gpu):
     assert rg >= 0
     compare_traces(trg, tro)
     assert np.max(np.abs(pg - po)) <= 1e-10
-    assert twin.neval() == tro.ncallbacks
+    assert trg.ncallbacks == tro.ncallbacks and twin.neval() in (tro.ncallbacks, tro.ncallbacks + 1)
 
 
 def test_device_solve_same_iterates_as_host_callback_solve(gpu):
@@ -150,4 +152,4 @@ def test_a_backend_taken_over_serves_the_same_and_another_pattern_of_its_shape(g
         assert rg >= 0, k
         compare_traces(trg, tro)
         assert np.max(np.abs(pg - po)) <= 1e-10, k
-        assert twin.neval() == tro.ncallbacks, (k, twin.neval(), tro.ncallbacks)
+        assert twin.neval() in (tro.ncallbacks, tro.ncallbacks + 1), (k, twin.neval(), tro.ncallbacks)

@@ -129,6 +129,47 @@ def test_a_damped_or_ill_conditioned_factor_keeps_the_pass_over_J(gpu, monkeypat
     assert abs(r["ei"] - o8[5]) <= 1e-7 * abs(o8[5])          # (cond ~ 1e8 here: the two loops themselves differ by rounding x cond)
 
 
+def test_a_pass_over_J_that_was_not_even_launched_is_made_when_the_factor_asks_for_it(gpu, monkeypatch):
+    """Behind the decision point the pass over J is not launched at all where the last step's was let go by the device
+    (backend.hip: ident_predict) -- the device's word stays the judge: values whose factor has a pivot range past the bound
+    right behind well-conditioned ones (same pattern, same backend) get their pass behind the wait, and the oracle's value;
+    and the other way round the prediction recovers.  DOGLEG_AMD_NO_K8_PREDICT=1: always launched -- the same numbers."""
+    monkeypatch.delenv("DOGLEG_AMD_EI_JPASS", raising=False)
+    good = oa.BAProblem(49, 900, 10000, seed=5)
+    bad = oa.BAProblem(49, 900, 10000, seed=5, scale_decades=4.0)
+    assert np.array_equal(good.pattern()[0], bad.pattern()[0]) and np.array_equal(good.pattern()[1], bad.pattern()[1])
+    p = good.p0()
+    ev = {"good": good.eval(p), "bad": bad.eval(bad.p0())}
+    o8 = {"good": _oracle_step(good, p, *ev["good"]), "bad": _oracle_step(bad, bad.p0(), *ev["bad"])}
+    seq = ["good", "good", "bad", "bad", "good", "bad", "good"]
+    out = {}
+    for knob in (False, True):
+        if knob:
+            monkeypatch.setenv("DOGLEG_AMD_NO_K8_PREDICT", "1")
+        be = _sparse_backend(good, monkeypatch, False)
+        be.set_p(0, p)
+        be.set_defer_tail(True)
+        rows = []
+        for which in seq:
+            x, Jx = ev[which]
+            be.upload(0, x, Jx); be.eval(0)
+            tr = 0.5 * (np.sqrt(o8[which][1]) + np.sqrt(o8[which][2]))
+            lam, r, _ = be.take_step(0, 1, tr, 0.0, tail=False)
+            assert be.step_tail_pending() and r["ei"] != r["ei"]
+            ei = be.step_tail()
+            src, ratio = be.ei_source()
+            rows.append((which, r["kind"], ei, src, ratio))
+        be.close()
+        out[knob] = rows
+        monkeypatch.delenv("DOGLEG_AMD_NO_K8_PREDICT", raising=False)
+    for rows in out.values():
+        for which, kind, ei, src, ratio in rows:
+            assert kind == capi.KIND_INTERP
+            assert src is (which == "good"), (which, src, ratio)
+            assert abs(ei - o8[which][5]) <= (TOL if which == "good" else 1e-7) * abs(o8[which][5]), (which, ei, o8[which][5])
+    assert [r[2] for r in out[False]] == [r[2] for r in out[True]]
+
+
 def test_dense_value_from_the_solved_system(gpu, monkeypatch):
     """the dense path (LAPACK's place, dogleg.c:782-803, 875-891): the pivots are the diagonal of the factor itself"""
     dp = oa.DenseProblem(M=3000, N=256, seed=7)
@@ -200,4 +241,4 @@ def test_a_negative_expected_improvement_stops_the_solve_with_the_step_not_appli
     assert trh.ncallbacks == which                         # the first point + one per trial before the n-th
     # the one evaluation a deferred value costs before it can stop (a value that needed no pass over J was handed out with
     # the step: then the device solve stops where the reference does)
-    assert twin.neval() - n0 in (which, which + 1)
+    assert twin.neval() - n0 in (which, which + 1, which + 2)      # (+ the point evaluated from inside the last step: dlg_backend_set_between)
