@@ -208,7 +208,7 @@ def main():
         # ... and the expected improvement's pass over J (K8) behind the decision point (dlg_backend_set_defer_tail, as the
         # driver runs device-callback solves): the reference uses the value behind the NEXT evaluation (dogleg.c:1427), so
         # K8 of step i runs beside the evaluation of step i + 1 and dlg_run_steps fetches it there (dlg_step_tail);
-        # the last step's tail is waited for inside the timed region.  DOGLEG_AMD_NO_DEFER_TAIL=1: K8 in line, as in rounds 1-4
+        # the last step's tail is waited for inside the timed region.  `inline_tail` below: K8 in line, as in rounds 1-4
         if not use_dist and not logical:
             be.set_defer_tail(True)
     elif kind == "dense" and not use_dist and not logical:
@@ -448,7 +448,7 @@ def main():
                                               "from_solved_system: |J step|^2 came from (JtJ) gn = -Jt x instead of a pass over J (lambda = 0, pivot ratio "
                                               "<= 212: include/dlg_backend.h; DOGLEG_AMD_EI_JPASS=1: always the pass).  `inline_tail`: the value in front of the "
                                               "synchronisation, as in rounds 1-4"}
-                                     if (not use_dist and not logical and os.environ.get("DOGLEG_AMD_NO_DEFER_TAIL") is None and kind in ("sparse", "dense"))
+                                     if (not use_dist and not logical and kind in ("sparse", "dense"))
                                      else {"placement": "in front of the step's synchronisation"}),
             "inline_tail": ({"ms_per_step": inline_ms, "steps_per_s": 1e3 / inline_ms,
                              "what": "the same step with the expected improvement and p_new in front of the synchronisation the host decides "

@@ -160,16 +160,6 @@ int  dlg_sparse_stats(dlg_backend_t* b, long* nnz_JtJ_lower, long* nnz_L,
  * whose update matrix is summed in HBM} */
 int  dlg_sparse_region_probe(int N, int M, const int* colptr, const int* rowidx, int ncu, long* stats, int nstats);
 
-/* host-only (no GPU): the leaf-front schedules of a pattern (libdogleg_amd/csrc/sparse_leaf.hip, switched on with
- * DOGLEG_AMD_LEAF_FRONT=1: JtJ assembly, Jt*x and the leaf level of the factorisation in one kernel) EXECUTED on the
- * CPU the way the kernel reads them, with the Jacobian values Jv[NJnnz] and x[Nmeas] given; what every leaf forms
- * (panel rows, member blocks, direct contributions to its update matrix, shares of Jt*x) is compared with the same
- * sums taken straight from the pattern.  stats[] = {leaf fronts available (0/1), leaves, strip tasks, strips without
- * a row list, strips carrying a rider, LDS bytes of the largest leaf}; *max_err relative to the largest sum.
- * Returns 0, or 1 with dlg_last_error() saying why the pattern gets no leaf fronts / what is inconsistent. */
-int  dlg_sparse_leaf_probe(int N, int M, const int* colptr, const int* rowidx, const double* Jv, const double* x,
-                           long* stats, int nstats, double* max_err);
-
 /* launch schedule of the factorisation: the number of levels of the supernodal
  * elimination tree; the first level of the persistent top region (all levels from
  * there on are ONE launch whose workgroups hand their update matrices to their
@@ -245,7 +235,6 @@ int  dlg_point_eval_early(dlg_backend_t* b, int slot, const double* x_dev, const
  * the J arrays of the slot the step was taken from alone (binding other arrays to the slot is fine).  dlg_step_tail with
  * nothing outstanding returns the value of the last step, whichever way it was formed; dlg_step_tail_pending says whether a
  * value is outstanding (NaN in out7[6] is how dlg_take_step says so, but a computed NaN looks the same).
- * DOGLEG_AMD_NO_DEFER_TAIL=1: the switch does nothing.
  *
  * The value itself needs no pass over J where the Gauss-Newton system was solved at lambda = 0 with a factor whose pivots
  * span less than 212x ((max L_ii / min L_ii)^2 eps <= 1e-11): |J gn|^2 = -<Jt x, gn>, <J cauchy, J gn> = -<cauchy, Jt x>,

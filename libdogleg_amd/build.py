@@ -38,8 +38,7 @@ def headers():
 # default heuristic the compiler parks them in AGPRs and copies all of them to VGPRs and back in
 # every loop iteration, the VGPR form of the instruction avoids that.
 _VGPR_MFMA = ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]
-EXTRA = {"sparse_assemble.hip": _VGPR_MFMA, "sparse_factor.hip": _VGPR_MFMA, "dense_diag.hip": _VGPR_MFMA,
-         "sparse_leaf.hip": _VGPR_MFMA}
+EXTRA = {"sparse_assemble.hip": _VGPR_MFMA, "sparse_factor.hip": _VGPR_MFMA, "dense_diag.hip": _VGPR_MFMA}
 
 
 def _compile(src, newest_hdr, verbose):

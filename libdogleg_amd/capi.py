@@ -33,7 +33,7 @@ BACKEND_SYMBOLS = [
     "dlg_kernel_syrk_lower", "dlg_kernel_potrf_lower", "dlg_probe_mfma_f64", "dlg_probe_mfma_f64_clock", "dlg_probe_mfma_f64_waves",
     "dlg_probe_hbm_copy", "dlg_set_trace", "dlg_mem_alloc", "dlg_mem_free", "dlg_host_alloc",
     "dlg_host_free", "dlg_mem_upload",
-    "dlg_mem_download", "dlg_mem_zero", "dlg_device_sync", "dlg_sparse_symbolic_probe", "dlg_sparse_leaf_probe",
+    "dlg_mem_download", "dlg_mem_zero", "dlg_device_sync", "dlg_sparse_symbolic_probe",
     "dlg_backend_set_profiling", "dlg_backend_get_profile", "dlg_backend_get_profile_early",
     "dlg_backend_set_allreduce", "dlg_backend_set_partition", "dlg_partition_rows", "dlg_partition_stats",
     "dlg_sparse_partition_probe", "dlg_rccl_unique_id", "dlg_backend_init_rccl", "dlg_backend_set_rccl",
@@ -144,7 +144,6 @@ def lib():
     L.dlg_backend_get_profile.argtypes = [V, D, C.POINTER(C.c_long), C.c_int]
     L.dlg_sparse_symbolic_probe.argtypes = [C.c_int, C.c_int, I, I, C.c_int, C.c_int,
                                             C.POINTER(C.c_long), C.c_int, I]
-    L.dlg_sparse_leaf_probe.argtypes = [C.c_int, C.c_int, I, I, D, D, C.POINTER(C.c_long), C.c_int, C.POINTER(C.c_double)]
     # dogleg.h
     PP = C.POINTER(Parameters2)
     L.dogleg_getDefaultParameters.argtypes = [PP]
@@ -249,7 +248,7 @@ def optimize_device(p0, N, M, nnz, Jp, Ji, cb, cookie, params=None, capacity=256
 SYM_STAT_NAMES = ["var_blocks", "supernodes", "levels", "nnz_JtJ_lower", "nnz_L", "panel_doubles",
                   "factor_flops", "max_panel", "asm_tasks", "update_items", "relpos", "out_blocks",
                   "contribs", "update_subtasks", "solve_scratch", "jtx_tasks", "asm_mfma_tasks",
-                  "asm_kgroups", "asm_shapes", "leaf_fronts", "lf_leaves", "lf_lds", "lf_blob_bytes", "lf_jtx_record"]
+                  "asm_kgroups", "asm_shapes"]
 
 
 def symbolic_probe(N, M, Jp, Ji, row0=0, row1=None, want_perm=False):
@@ -284,26 +283,6 @@ def partition_probe(N, M, Jp, Ji, rank, nranks):
 
 
 REGION_STAT_NAMES = ["level0", "supernodes", "workgroups", "lds_bytes", "sliced_workgroups", "hbm_update_matrices"]
-
-
-LEAF_STAT_NAMES = ["leaf_fronts", "leaves", "strips", "strips_without_list", "strips_with_rider", "lds_bytes"]
-
-
-def leaf_probe(N, M, Jp, Ji, Jv, x):
-    """Host-only: run the leaf-front schedules (DOGLEG_AMD_LEAF_FRONT=1) of a pattern on the CPU and compare what they
-    form with the sums taken straight from the pattern.  Returns (dict of statistics, relative max error)."""
-    L = lib()
-    Jp = np.ascontiguousarray(Jp, dtype=np.int32)
-    Ji = np.ascontiguousarray(Ji, dtype=np.int32)
-    Jv = np.ascontiguousarray(Jv, dtype=np.float64)
-    x = np.ascontiguousarray(x, dtype=np.float64)
-    st = (C.c_long * len(LEAF_STAT_NAMES))()
-    err = C.c_double(0.0)
-    rc = L.dlg_sparse_leaf_probe(N, M, iptr(Jp), iptr(Ji), dptr(Jv), dptr(x), st, len(LEAF_STAT_NAMES), C.byref(err))
-    d = {k: st[i] for i, k in enumerate(LEAF_STAT_NAMES)}
-    if rc != 0:
-        d["error"] = L.dlg_last_error().decode()
-    return d, err.value
 
 
 def region_probe(N, M, Jp, Ji, ncu=256):

@@ -420,141 +420,17 @@ __global__ void __launch_bounds__(TPB) k_potrf_tiles(double* A, int lda, int n, 
   if(t == 0) __hip_atomic_store(flags + ti*T + tj, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+
 // ---- both triangular solves in ONE launch: a workgroup per 64 rows -------------------------------
 // forward  y_i = Linv_i (b_i - sum_{k<i} L(i,k) y_k), backward  x_i = Linv_i' (y_i - sum_{k>i} L(k,i)' x_k).
 // Workgroup i waits for y_k (k < i) going down and for x_k (k > i) coming back up.  The vectors ARE the signal: a
 // block of y (x) is handed over in a buffer that holds a sentinel (a NaN no computation produces) until its owner
 // stores the values -- write-through, 8 bytes a lane --, and the 64 lanes that need a block each poll their own
 // element until it is not the sentinel: one trip through L2 per block instead of flag, barrier, load of the
-// block (and no drain + barrier + flag store on the owner's side): 3.5 -> 2 us a block, 32 + 32 of them in a row
-// on config #2.  Two sets of buffers, used by launches of even / odd epoch; a launch re-arms the set of the NEXT
-// launch (the launch before this one, which used it, is over).  The tile of L a product needs does not depend on
-// the vector it waits for: it is on its way (forward: in registers, backward: staged in LDS) before the poll.
+// block (and no drain + barrier + flag store on the owner's side).  Two sets of buffers, used by launches of even /
+// odd epoch; a launch re-arms the set of the NEXT launch (the launch before this one, which used it, is over).
 // All T workgroups must be resident (they wait for higher-numbered ones on the way back): T <= #CUs / 2.
 constexpr unsigned long long TRSV_EMPTY = 0x7FF8DEADBEEF0001ull;
-__global__ void __launch_bounds__(TPB) k_trsv_tiles_plain(const double* __restrict__ A, int lda, int n, int T,
-                                                    const double* __restrict__ Linv, const double* __restrict__ rhs,
-                                                    double* Yh, double* X, double* Xh, int epoch, DlgHandoff ho)
-{
-  extern __shared__ __attribute__((aligned(16))) double sm[];
-  typedef __attribute__((address_space(1))) unsigned long long* gu_t;
-  constexpr int LDT = NB + 1;
-  double (*Lt)[LDT] = reinterpret_cast<double (*)[LDT]>(sm);                 // a tile of L: Lt[row][col]
-  double* Li = sm + NB*LDT;                                                  // [NB*LDT] this block's inverse, Li[r + c*LDT] = Linv(r, c) (padded: its transpose is read too)
-  double* v = Li + NB*LDT;                                                    // [NB]  the vector waited for
-  double* part = v + NB;                                                     // [4][NB] partial sums
-  const int t = threadIdx.x, r = t & 63, g = t >> 6;
-  const int i = blockIdx.x, row0 = NB*i;
-  const int npad = T*NB, par = epoch & 1;
-  unsigned long long* ycur = reinterpret_cast<unsigned long long*>(Yh) + (size_t)par*npad;
-  unsigned long long* xcur = reinterpret_cast<unsigned long long*>(Xh) + (size_t)par*npad;
-  // (ho.skew != 0, the tests' forced time-out: the consumers look at a third set that nobody ever fills)
-  unsigned long long* ytake = ho.skew ? reinterpret_cast<unsigned long long*>(Yh) + (size_t)2*npad : ycur;
-  unsigned long long* xtake = ho.skew ? reinterpret_cast<unsigned long long*>(Xh) + (size_t)2*npad : xcur;
-  // the next launch's set, this block's part
-  if(t < NB)
-  {
-    reinterpret_cast<unsigned long long*>(Yh)[(size_t)(1 - (epoch & 1))*npad + row0 + t] = TRSV_EMPTY;
-    reinterpret_cast<unsigned long long*>(Xh)[(size_t)(1 - (epoch & 1))*npad + row0 + t] = TRSV_EMPTY;
-  }
-  // (lanes 0..NB-1: element t of block k, once it is there)
-  auto take = [&](unsigned long long* buf, int k) -> double {
-    unsigned long long u; int spins = 0;
-    while((u = __hip_atomic_load((gu_t)(buf + NB*k + t), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == TRSV_EMPTY)
-    { __builtin_amdgcn_s_sleep(1); if(++spins > ho.spins) { atomicOr(ho.status, DLG_HANDOFF_TRSV); u = 0; break; } }
-    return __longlong_as_double((long long)u);
-  };
-  for(int e = t; e < NB*NB; e += TPB) Li[(e & (NB - 1)) + (e/NB)*LDT] = Linv[(size_t)i*NB*NB + e];
-  const double rhs_t = (t < NB && row0 + t < n) ? rhs[row0 + t] : 0.0;      // (fetched now: behind the last block of y it would sit on everybody's path)
-  // ---- forward: thread (row r, column group g) keeps 16 values of the tile in registers
-  double acc = 0.0;
-  double cur[16];
-  auto load_row_tile = [&](int k, double (&d)[16]) {
-#pragma unroll
-    for(int c = 0; c < 16; c++)
-    {
-      const int row = row0 + r, col = NB*k + 16*g + c;
-      d[c] = (row < n && k < i) ? A[(size_t)col*lda + row] : 0.0;
-    }
-  };
-  load_row_tile(0, cur);
-  for(int k = 0; k < i; k++)
-  {
-    double nxt[16];
-    load_row_tile(k + 1, nxt);                       // (k + 1 == i: zeros, no loads)
-    __syncthreads();                                 // (v of the step before is done with)
-    if(t < NB) v[t] = take(ytake, k);
-    __syncthreads();
-#pragma unroll
-    for(int c = 0; c < 16; c++) acc += cur[c]*v[16*g + c];
-#pragma unroll
-    for(int c = 0; c < 16; c++) cur[c] = nxt[c];
-  }
-  __syncthreads();
-  part[g*NB + r] = acc;
-  __syncthreads();
-  if(t < NB)
-  {
-    const double s = (part[t] + part[NB + t]) + (part[2*NB + t] + part[3*NB + t]);
-    v[t] = (row0 + t < n) ? rhs_t - s : 0.0;
-  }
-  __syncthreads();
-  // y_i = Linv * v: every thread a quarter of a row's 64 terms (a chain of 16, not 64, on everybody's path), then the
-  // four quarters in a fixed order
-  {
-    double q4 = 0.0;
-#pragma unroll
-    for(int k = 0; k < 16; k++) q4 += Li[r + (16*g + k)*LDT]*v[16*g + k];          // Linv is zero above the diagonal
-    part[g*NB + r] = q4;
-  }
-  __syncthreads();
-  double yi = 0.0;
-  if(t < NB)
-  {
-    yi = (part[t] + part[NB + t]) + (part[2*NB + t] + part[3*NB + t]);
-    // (rows past the end hand over zeros: a block is NB values, and none of them may stay the sentinel)
-    __hip_atomic_store((gu_t)(ycur + row0 + t), (unsigned long long)__double_as_longlong(row0 + t < n ? yi : 0.0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  // ---- backward: the tile L(k, i) goes through LDS (thread = column afterwards)
-  double bacc = 0.0;
-  for(int k = T - 1; k > i; k--)
-  {
-    __syncthreads();
-    for(int e = t; e < NB*NB; e += TPB)
-    {
-      const int rr = e % NB, cc = e / NB;
-      const int row = NB*k + rr, col = row0 + cc;
-      Lt[rr][cc] = (row < n && col < n) ? A[(size_t)col*lda + row] : 0.0;
-    }
-    if(t < NB) v[t] = take(xtake, k);
-    __syncthreads();
-#pragma unroll
-    for(int q = 0; q < 16; q++) bacc += Lt[16*g + q][r]*v[16*g + q];      // thread (column r, row group g)
-  }
-  __syncthreads();
-  part[g*NB + r] = bacc;
-  __syncthreads();
-  if(t < NB)
-  {
-    const double s = (part[t] + part[NB + t]) + (part[2*NB + t] + part[3*NB + t]);
-    v[t] = yi - s;                                   // (rows past the end: yi = 0, s = 0)
-  }
-  __syncthreads();
-  {
-    double q4 = 0.0;
-#pragma unroll
-    for(int k = 0; k < 16; k++) q4 += Li[(16*g + k) + r*LDT]*v[16*g + k];         // Linv' : column r of Linv
-    part[g*NB + r] = q4;
-  }
-  __syncthreads();
-  if(t < NB)
-  {
-    const double xi = (part[t] + part[NB + t]) + (part[2*NB + t] + part[3*NB + t]);
-    if(row0 + t < n) X[row0 + t] = xi;
-    __hip_atomic_store((gu_t)(xcur + row0 + t), (unsigned long long)__double_as_longlong(row0 + t < n ? xi : 0.0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-}
-
 
 #ifdef DLG_TRSV_PROFILE
 __device__ long long g_trsv_dbg[64*8];
@@ -849,16 +725,8 @@ static void dlg_func_lds_once(bool (&done)[DLG_MAX_DEV], const void* fn, int byt
 void dense_launch_trsv_tiles(hipStream_t st, const double* A, int lda, int n, const double* Linv, const double* rhs,
                              double* Yh, double* X, double* Xh, int epoch, const DlgHandoff& ho)
 {
-  static bool attr[DLG_MAX_DEV] = {}, attr_plain[DLG_MAX_DEV] = {};       // a function attribute is a property of (function, device)
+  static bool attr[DLG_MAX_DEV] = {};       // a function attribute is a property of (function, device)
   const int T = (n + NB - 1)/NB;
-  static const bool plain = getenv("DOGLEG_AMD_TRSV_PLAIN") != nullptr;      // (the form of rounds 2b - 4: two products a hop; tests)
-  if(plain)
-  {
-    constexpr int LDSB = 88*1024;           // > half of the CU's LDS: one workgroup per CU
-    dlg_func_lds_once(attr_plain, reinterpret_cast<const void*>(&k_trsv_tiles_plain), LDSB);
-    hipLaunchKernelGGL(k_trsv_tiles_plain, dim3(T), dim3(TPB), LDSB, st, A, lda, n, T, Linv, rhs, Yh, X, Xh, epoch, ho);
-    return;
-  }
   constexpr int LDSB = (3*NB*(NB + 1) + 10*NB + 16)*(int)sizeof(double);           // three 64 x 65 tiles + the vectors: 102 KB, one workgroup per CU
   dlg_func_lds_once(attr, reinterpret_cast<const void*>(&k_trsv_tiles), LDSB);
   hipLaunchKernelGGL(k_trsv_tiles, dim3(T), dim3(TPB), LDSB, st, A, lda, n, T, Linv, rhs, Yh, X, Xh, epoch, ho);
@@ -899,7 +767,7 @@ void dense_launch_potrf_tiles(hipStream_t st, double* A, int lda, int n, int* in
   constexpr int LDSB = (2*NB*(NB + 1) + 2*NB*NB)*8;      // two staging tiles + the panel [A; I] of a diagonal tile (130 KB: one workgroup per CU)
   dlg_func_lds_once(attr, reinterpret_cast<const void*>(&k_potrf_tiles), LDSB);
   const int T = (n + NB - 1)/NB;
-  const int self_x = getenv("DOGLEG_AMD_NO_POTRF_SELF") ? 0 : 1;      // (the form of rounds 2 - 3: every block of L comes from its owner)
+  const int self_x = 1;      // (0, the form of rounds 2 - 3: every block of L comes from its owner)
   hipLaunchKernelGGL(k_potrf_tiles, dim3(T*(T + 1)/2), dim3(TPB), LDSB, st, A, lda, n, T, info_dev, Linv, flags, epoch, ho, self_x, gate);
 }
 

@@ -70,7 +70,7 @@ struct dlg_backend
   hipEvent_t  ev_fork = nullptr, ev_join = nullptr;
   // the join without an event: the second stream raises d_join to join_epoch behind the Cauchy step, the first kernel of the
   // main stream that reads that step (k_negate_interp1) polls the word itself -- a wait for an event of another stream costs
-  // the main stream ~6 us between two kernels even when the event is long complete (DOGLEG_AMD_JOIN_EVENT: the event)
+  // the main stream ~6 us between two kernels even when the event is long complete
   int* d_join = nullptr; int join_epoch = 0, join_pending = 0;
   hipEvent_t ev_region = nullptr;    // behind this backend's last one-launch region (DlgRegionTurn)
   bool turn_registered = false;
@@ -131,9 +131,7 @@ struct dlg_backend
   // environment knobs that steer per-step paths, read ONCE when the backend is created (dlg_backend_create)
   struct Knobs
   {
-    bool join_event = false;
-    bool no_k3_fork = false, no_potrf_fuse = false, potrf_steps = false,
-         trsv_steps = false, no_touch = false, no_abandon = false, no_split = false, no_reject_run = false, no_defer_tail = false, ei_jpass = false, no_p_side = false, no_between = false, no_k8_predict = false;
+    bool potrf_steps = false, trsv_steps = false, no_abandon = false, ei_jpass = false, no_between = false, no_k8_predict = false;
     int touch_wg = 512;
   } knobs;
   int ncu = 256;              // compute units of b->device
@@ -167,6 +165,7 @@ struct dlg_backend
   bool    defer_factor_sync = false;   // dlg_gauss_newton: the *_factorize calls enqueue only; the pivot
                                        // flag is read after the solve's synchronisation
   double* d_work = nullptr;   // N-vector scratch
+  double* d_solve_scr = nullptr; size_t solve_scr_cap = 0;   // scratch of the post-solve entry points (backend.hip: solve_scratch)
 
   // sparse
   SparseSym* sym = nullptr;

@@ -1,5 +1,5 @@
 // factor_tail.h -- the update matrix U = B B' of a supernode panel held in LDS, on the matrix cores
-// (shared by the level kernels of sparse_factor.hip and the leaf fronts of sparse_leaf.hip)
+// (the level kernels of sparse_factor.hip)
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstdint>
@@ -19,7 +19,6 @@ __device__ __forceinline__ int tri_col(int j, int mb) { return j*mb - j*(j - 1)/
 // columns).  Rows / columns past the end are clamped (their results are never written);
 // KD k-steps with their own operand registers, so the loads of the next ones are in flight
 // during the products of one.  mode 2: the multifrontal region keeps W = (children) - U;
-// mode 3 (leaf fronts): U - (what Ud holds).
 template <int NCH, int KD = 4>
 __device__ __forceinline__ void factor_tail_tiles(const double* Pb, int ldp, int w, int mb, int T, int first,
                                                   double* Ud, int mode, bool w_hbm, bool mf_acc, int lane,
@@ -133,7 +132,6 @@ __device__ __forceinline__ void factor_tail_tiles(const double* Pb, int ldp, int
           __hip_atomic_store((gwptr_t)(Ud + jtri + i), (w_hbm ? w0[q][r] : 0.0) - c4[q][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         else if(mode == 2) Uc[i] = (w_hbm ? w0[q][r] : (mf_acc ? Uc[i] : 0.0)) - c4[q][r];     // the region keeps W = -U
-        else if(mode == 3) Uc[i] = c4[q][r] - Uc[i];       // a leaf front: Uc holds its rows' direct contributions to these blocks
         else Uc[i] = c4[q][r];
       }
     }

@@ -893,7 +893,7 @@ static int run_potrf(dlg_backend* b)
     return DLG_OK;
   }
   return potrf_lower(b->stream, b->G, b->N, b->N, b->d_info, b->Linv, b->potrf_flag + (size_t)T*T, &b->potrf_epoch,
-                     !b->knobs.no_potrf_fuse, &ho);
+                     true, &ho);
 }
 
 static int finish_potrf(dlg_backend* b, int* ok)

@@ -736,11 +736,10 @@ __device__ __forceinline__ bool phase_has(const int* __restrict__ sn_owner, int 
 __global__ void __launch_bounds__(TPB) k_add_lambda(double* __restrict__ Lx,
                                                     const int64_t* __restrict__ diagpos, int n,
                                                     double lambda, const int* __restrict__ col_sn,
-                                                    const int* __restrict__ sn_owner, int phase,
-                                                    const char* __restrict__ skip)
+                                                    const int* __restrict__ sn_owner, int phase)
 {
   const int i = blockIdx.x*TPB + threadIdx.x;
-  if(i < n && phase_has(sn_owner, col_sn[i], phase) && !(skip && skip[i])) Lx[diagpos[i]] += lambda;      // (skip: columns of the leaf fronts, which took lambda themselves)
+  if(i < n && phase_has(sn_owner, col_sn[i], phase)) Lx[diagpos[i]] += lambda;
 }
 
 // augmented row: panel(last row, column k) += rhs[perm[k]]   (the row is zero after the assembly;
@@ -751,14 +750,12 @@ __global__ void __launch_bounds__(TPB) k_set_aug_row(double* __restrict__ Lx, co
                                                      const int* __restrict__ perm,
                                                      const double* __restrict__ rhs, int n,
                                                      int* __restrict__ info,
-                                                     const int* __restrict__ sn_owner, int phase,
-                                                     const char* __restrict__ skip)
+                                                     const int* __restrict__ sn_owner, int phase)
 {
   const int k = blockIdx.x*TPB + threadIdx.x;
   if(k == 0 && phase <= 0) *info = 0x7fffffff;          // re-arm the pivot flag of the factorisation that follows
   if(k >= n) return;
   if(phase >= 0 && !phase_has(sn_owner, col_sn[k], phase)) return;
-  if(skip && skip[k]) return;                           // (a column of a leaf front: its right-hand side went in with the front)
   // (single rank: nothing but this kernel ever writes a last row between two assemblies, and a partially cleared
   // buffer -- clear_panels -- holds the previous factorisation's there; the phases of a partition add behind the sum over the ranks)
   if(phase < 0) Lx[augpos[k]] = rhs[perm[k]]; else Lx[augpos[k]] += rhs[perm[k]];
@@ -1026,13 +1023,13 @@ int sparse_assemble_finish(dlg_backend* b)
   // augmented row now, and the pivot flag is re-armed: nothing left to launch between the caller's
   // decision to factorise and the first factor kernel.  It rides in the first partial-sum launch.
   bool aug_done = false;
-  if(!Y->lf_on) DLG_CHECK(assemble_fin_launch(b, Lx, Y->fin_pending_rhs, &aug_done));     // (leaf fronts: no partial sums, the fronts ARE the assembly)
+  DLG_CHECK(assemble_fin_launch(b, Lx, Y->fin_pending_rhs, &aug_done));
   if(Y->fin_pending_rhs)
   {
     const SymHost& H = Y->H;
     if(!aug_done)
       hipLaunchKernelGGL(k_set_aug_row, dim3(dlg_cdiv(H.N, TPB)), dim3(TPB), 0, b->stream, Lx, Y->col_sn, Y->augpos,
-                         Y->perm, Y->fin_pending_rhs, H.N, Y->d_info, Y->sn_owner, -1, Y->lf_on ? Y->lf_col : (const char*)nullptr);
+                         Y->perm, Y->fin_pending_rhs, H.N, Y->d_info, Y->sn_owner, -1);
     DLG_LAUNCH_CHECK();
     Y->spec_aug_rhs = Y->fin_pending_rhs; Y->info_clean = true;
     Y->fin_pending_rhs = nullptr;
@@ -1059,7 +1056,7 @@ __global__ void k_fin_flag(int* flag, int epoch)
 bool sparse_fin_side_ok(const dlg_backend* b)
 {
   const SparseSym* Y = b->sym;
-  return Y && Y->fin_side_sched_ok && Y->fin_flag && b->aux_stream && !Y->lf_on && Y->fin_pending_Lx && (Y->fin_pending_rhs || Y->aug_fused_epoch) &&
+  return Y && Y->fin_side_sched_ok && Y->fin_flag && b->aux_stream && Y->fin_pending_Lx && (Y->fin_pending_rhs || Y->aug_fused_epoch) &&
          !Y->fin_main && b->stream != b->aux_stream;
 }
 int sparse_fin_side_begin(dlg_backend* b)
@@ -1130,7 +1127,7 @@ static int clear_panels(dlg_backend* b, double* Lx, hipStream_t st)
   SparseSym* Y = b->sym;
   const SymHost& H = Y->H;
   const bool known = Lx == Y->lz_ok[0] || Lx == Y->lz_ok[1];
-  if(known && Y->clr_partial_ok && !Y->lf_on && !b->sharded() && H.part_nranks <= 1)
+  if(known && Y->clr_partial_ok && !b->sharded() && H.part_nranks <= 1)
   {
     hipLaunchKernelGGL(k_clear_ranges, dim3(64, Y->n_clr), dim3(TPB), 0, st, Lx, Y->clr_off, Y->clr_len);
     DLG_LAUNCH_CHECK();
@@ -1145,7 +1142,7 @@ static int clear_panels(dlg_backend* b, double* Lx, hipStream_t st)
        if(timed_single && dlg_prof_pair(b, DLG_PROF_K4_KERNEL, &e0, &e1)) hipExtLaunchKernelGGL(kernel, grid, block, shm, st, e0, e1, 0, __VA_ARGS__); \
        else { DlgProfScope pk1(b, DLG_PROF_K4_KERNEL, timed_single && !b->ext_events); hipLaunchKernelGGL(kernel, grid, block, shm, st, __VA_ARGS__); } } while(0)
 static int assemble_launch(dlg_backend* b, const double* Jv, double* Lx = nullptr, const double* xvec = nullptr, double* Jt_x = nullptr,
-                           bool zeroed = false, bool defer_fin = false, const double* lf_rhs = nullptr, double lf_lambda = 0.0)
+                           bool zeroed = false, bool defer_fin = false)
 {
   SparseSym* Y = b->sym;
   const SymHost& H = Y->H;
@@ -1154,30 +1151,6 @@ static int assemble_launch(dlg_backend* b, const double* Jv, double* Lx = nullpt
   DLG_CHECK(sparse_fin_side_gate(b));               // (... and stages still running on the second stream read them)
   if(!Lx) Lx = Y->Lx;
   if(!zeroed) DLG_CHECK(clear_panels(b, Lx, st));
-  if(Y->lf_on)
-  {
-    // leaf fronts: JtJ, Jt*x and the leaves' factorisation in one pass over J (sparse_leaf.hip); the panels of the
-    // ancestors stay zero until the update gather brings them everything
-    {
-      DlgProfScope pk(b, DLG_PROF_K4_KERNEL);
-      DLG_CHECK(sparse_leaf_front(b, Jv, Lx, xvec, Jt_x, xvec ? nullptr : lf_rhs, lf_lambda));
-    }
-    Y->lf_gen++;
-    if(xvec)
-    {
-      const int ns = (int)H.lf_jf_short.size(), nl = (int)H.lf_jf_long.size();
-      if(ns > 0)
-        hipLaunchKernelGGL(k_jtx_fin2_short, dim3(dlg_cdiv(ns, TPB/16)), dim3(TPB), 0, st, Y->lf_jf_short, ns, Y->lf_jf_ptr,
-                           Y->lf_jf_ent, Y->lf_jf_var0, Y->lf_jf_w, Y->lf_jtp, Jt_x);
-      if(nl > 0)
-        hipLaunchKernelGGL(k_jtx_fin2_long, dim3(nl*JFL_SEG), dim3(1024), 0, st, Y->lf_jf_long, Y->lf_jf_ptr, Y->lf_jf_ent,
-                           Y->lf_jf_var0, Y->lf_jf_w, Y->lf_jtp, Jt_x, Y->lf_jf_lpart, Y->lf_jf_lcnt,
-                           JfAug{nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, 0, nl*JFL_SEG});
-    }
-    if(defer_fin) { Y->fin_pending_Lx = Lx; Y->fin_pending_rhs = Jt_x; }
-    DLG_LAUNCH_CHECK();
-    return DLG_OK;
-  }
   const int nt = (int)H.asm_ctask.size(), nmt = (int)H.asm_mtask.size();
   if(nt > 0 || nmt > 0)
   {
@@ -1371,7 +1344,7 @@ int sparse_assemble(dlg_backend* b, int s, double lambda)
     {
       DLG_CHECK(sparse_fin_side_gate(b));
       hipLaunchKernelGGL(k_add_lambda, dim3(dlg_cdiv(H.N, TPB)), dim3(TPB), 0, st, Y->Lx, Y->diagpos, H.N,
-                         dl, Y->col_sn, Y->sn_owner, -1, (const char*)nullptr);
+                         dl, Y->col_sn, Y->sn_owner, -1);
       DLG_LAUNCH_CHECK();
     }
     Y->info_armed = false;            // (sparse_factorize arms the pivot word with a copy)
@@ -1379,10 +1352,7 @@ int sparse_assemble(dlg_backend* b, int s, double lambda)
   }
   Y->intact_Lx = nullptr;
   bool adopted = false;
-  // (leaf fronts: the second buffer holds FACTORED leaf panels -- they are this factorisation's only if they were
-  // formed at this lambda and the leaves' update matrices in the scratch are still that launch's)
-  const bool lf_fits = !Y->lf_on || (Y->spec_lambda == lambda && Y->spec_gen == Y->lf_gen);
-  if(Y->spec_valid && Y->spec_slot == s && Y->spec_J == S.Jin() && lf_fits)
+  if(Y->spec_valid && Y->spec_slot == s && Y->spec_J == S.Jin())
   {
     std::swap(Y->Lx, Y->Lx_spec);           // the panels assembled beside K1 become the factor's panels
     Y->spec_valid = false;
@@ -1395,7 +1365,7 @@ int sparse_assemble(dlg_backend* b, int s, double lambda)
   {
     DlgProfScope pt(b, DLG_PROF_K4_TOTAL);
     Y->spec_valid = Y->spec_valid && !(Y->spec_slot == s);      // (a second buffer that did not fit is of no further use)
-    DLG_CHECK(assemble_launch(b, S.Jin(), nullptr, nullptr, nullptr, false, false, S.have_Jtx ? S.Jt_x : (const double*)nullptr, lambda));
+    DLG_CHECK(assemble_launch(b, S.Jin()));
   }
   // contiguous row sharding: sum the partial JtJ of all ranks before factorising
   {
@@ -1413,7 +1383,7 @@ int sparse_assemble(dlg_backend* b, int s, double lambda)
   if(lambda != 0.0) DLG_CHECK(sparse_fin_side_gate(b));      // (lambda goes onto diagonal entries the stages on the second stream store)
   if(lambda != 0.0)
     hipLaunchKernelGGL(k_add_lambda, dim3(dlg_cdiv(H.N, TPB)), dim3(TPB), 0, st, Y->Lx, Y->diagpos, H.N,
-                       lambda, Y->col_sn, Y->sn_owner, phase, Y->lf_on ? Y->lf_col : (const char*)nullptr);
+                       lambda, Y->col_sn, Y->sn_owner, phase);
   // the right-hand side rides along as the last row of every panel: y = L^-1 P Jt_x falls out
   Y->aug_rhs = nullptr;
   Y->info_armed = false;
@@ -1426,7 +1396,7 @@ int sparse_assemble(dlg_backend* b, int s, double lambda)
   else if(S.have_Jtx)
   {
     hipLaunchKernelGGL(k_set_aug_row, dim3(dlg_cdiv(H.N, TPB)), dim3(TPB), 0, st, Y->Lx, Y->col_sn, Y->augpos,
-                       Y->perm, S.Jt_x, H.N, Y->d_info, Y->sn_owner, phase, Y->lf_on ? Y->lf_col : (const char*)nullptr);
+                       Y->perm, S.Jt_x, H.N, Y->d_info, Y->sn_owner, phase);
     Y->aug_rhs = S.Jt_x;
     Y->info_armed = true;
   }
@@ -1486,10 +1456,10 @@ int sparse_partition_reduce(dlg_backend* b)
   }
   if(Y->cur_lambda != 0.0)
     hipLaunchKernelGGL(k_add_lambda, dim3(dlg_cdiv(H.N, TPB)), dim3(TPB), 0, st, Y->Lx, Y->diagpos, H.N,
-                       Y->cur_lambda, Y->col_sn, Y->sn_owner, 1, (const char*)nullptr);
+                       Y->cur_lambda, Y->col_sn, Y->sn_owner, 1);
   if(Y->aug_rhs)
     hipLaunchKernelGGL(k_set_aug_row, dim3(dlg_cdiv(H.N, TPB)), dim3(TPB), 0, st, Y->Lx, Y->col_sn, Y->augpos,
-                       Y->perm, Y->aug_rhs, H.N, Y->d_info, Y->sn_owner, 1, (const char*)nullptr);
+                       Y->perm, Y->aug_rhs, H.N, Y->d_info, Y->sn_owner, 1);
   DLG_LAUNCH_CHECK();
   return DLG_OK;
 }
@@ -1504,7 +1474,7 @@ int sparse_partition_reduce(dlg_backend* b)
 int sparse_assemble_speculative(dlg_backend* b, int s)
 {
   SparseSym* Y = b->sym;
-  if(!Y || !b->aux_stream || b->sharded() || Y->H.part_nranks > 1 || Y->lf_on) return DLG_OK;
+  if(!Y || !b->aux_stream || b->sharded() || Y->H.part_nranks > 1) return DLG_OK;
   const SymHost& H = Y->H;
   DlgSlot& S = b->slot[s];
   if(!Y->Lx_spec)
@@ -1542,7 +1512,7 @@ int sparse_eval_assemble(dlg_backend* b, int s, int* done)
   SparseSym* Y = b->sym;
   if(!Y) { dlg_set_error("dlg_sparse_set_pattern must be called first"); return DLG_ERR_STATE; }
   const SymHost& H = Y->H;
-  if(!Y->lf_on && (!H.asm_jtx_ok || !Y->jtp)) return DLG_OK;
+  if(!H.asm_jtx_ok || !Y->jtp) return DLG_OK;
   // (sharded rows / subtree partition: the rank's rows give its share of Jt*x and of JtJ as the separate
   // kernels would; the sums over the ranks follow where they always did)
   DlgSlot& S = b->slot[s];
@@ -1560,10 +1530,7 @@ int sparse_eval_assemble(dlg_backend* b, int s, int* done)
   {
     DlgProfScope pt(b, DLG_PROF_K4_TOTAL);
     // (the partial-sum stages of JtJ wait until the caller has Jt*x on its way to the host: sparse_assemble_finish)
-    // (leaf fronts: the leaves are factored in this pass, at the lambda of the last factorisation -- the driver's
-    // lambda only ever changes when a factorisation fails, and then the point is assembled again)
-    DLG_CHECK(assemble_launch(b, S.Jin(), Y->Lx_spec, S.xin(), S.Jt_x, zeroed, true, nullptr, Y->cur_lambda));
-    Y->spec_lambda = Y->cur_lambda; Y->spec_gen = Y->lf_gen;
+    DLG_CHECK(assemble_launch(b, S.Jin(), Y->Lx_spec, S.xin(), S.Jt_x, zeroed, true));
     if(b->sharded()) Y->fin_pending_rhs = nullptr;     // Jt*x is not summed over the ranks yet: the augmented row waits for the factorisation
   }
   Y->spec_valid = true; Y->spec_slot = s; Y->spec_J = S.Jin(); Y->spec_aug_rhs = nullptr;

@@ -712,7 +712,7 @@ __global__ void __launch_bounds__(NT) k_update_gather(int unit0, const GatherUni
                                                        double* __restrict__ Lx,
                                                        double* __restrict__ upart,
                                                        const double* __restrict__ uscr, int nw,
-                                                       int* __restrict__ info, const int* __restrict__ lf_word,
+                                                       int* __restrict__ info,
                                                        const int* __restrict__ fin_gate = nullptr, int fin_epoch = 0, int* fin_status = nullptr)
 {
   extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -723,11 +723,7 @@ __global__ void __launch_bounds__(NT) k_update_gather(int unit0, const GatherUni
   if(fin_gate && threadIdx.x == 0) fin_seen = __hip_atomic_load(fin_gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if(threadIdx.x == 0)
   {
-    // (leaf fronts: the leaves were factored with the assembly, their pivot word sits behind the panels -- zero
-    // if every pivot was positive; it joins the factorisation's flag here, in front of the levels above)
-    const int lw = lf_word ? *lf_word : 0;
-    if(lw != 0 && blockIdx.x == 0) atomicMin(info, 0x7fffffff - lw);
-    s_skip = *info != 0x7fffffff || lw != 0;      // a failed factorisation is not worth finishing
+    s_skip = *info != 0x7fffffff;      // a failed factorisation is not worth finishing
   }
   // (one flat record: the chain unit -> item -> target supernode -> its rows cost three dependent loads
   // in front of the first barrier)
@@ -1106,7 +1102,7 @@ int sparse_factor_setup(dlg_backend* b, bool plan_only)
 {
   SparseSym* Y = b->sym;
   const SymHost& H = Y->H;
-  Y->fac_b16 = getenv("DOGLEG_AMD_NO_B16") == nullptr;
+  Y->fac_b16 = true;
   Y->fac_lds.assign(H.nlevels, 0); Y->fac_nt.assign(H.nlevels, 512); Y->upd_coop.assign(H.nlevels, 0);
   Y->upd_lds.assign(H.nlevels, 0); Y->upd_nw.assign(H.nlevels, 0);
   Y->syrk_lds.assign(H.nlevels, 0); Y->syrk_nt.assign(H.nlevels, 256); Y->syrk_kc.assign(H.nlevels, 4);
@@ -1147,7 +1143,7 @@ int sparse_factor_setup(dlg_backend* b, bool plan_only)
       // layout that never stages the top block (k_factor_level: cmp)
       const bool cmp = H.sn_bd_ptr[s+1] > H.sn_bd_ptr[s] && H.sn_top[s] < 0;
       const long mbl = nloc - wv;
-      const long p = (cmp && !getenv("DOGLEG_AMD_LEAF_LDS_FULL")) ? ((mbl + 1) & ~1L)*wv + (Y->fac_leaf[l] ? 4 : 8)*wv + 1 : ((nloc + 1) & ~1L)*wv;
+      const long p = cmp ? ((mbl + 1) & ~1L)*wv + (Y->fac_leaf[l] ? 4 : 8)*wv + 1 : ((nloc + 1) & ~1L)*wv;
       if(p > maxp) maxp = p;
       if(nloc > maxr) maxr = nloc;
     }
@@ -1293,9 +1289,8 @@ int sparse_factor_setup(dlg_backend* b, bool plan_only)
     // (a workgroup that finds no CU starts late and pays its panel load on the critical path).
     {
       const int rmax = std::max(1, std::min(8, env_int_host("DOGLEG_AMD_FRONT_REPLICAS", 8)));
-      const int fill = env_int_host("DOGLEG_AMD_FRONT_FILL", ncu/2), fill0 = ncu/2;
+      const int fill = ncu/2, fill0 = ncu/2;
       const bool slice_ok = !getenv("DOGLEG_AMD_NO_FRONT_SLICES");
-      const bool hbm_rep_ok = !getenv("DOGLEG_AMD_NO_HBM_REPLICAS");
       std::vector<int> first(H.fw_item.size(), -1), count(H.fw_item.size(), 0);
       // the region's own children records and destination lists: those of the symbolic phase (whole update
       // matrix behind the panel), and behind them the lists of the replicas that keep a slice of it
@@ -1310,7 +1305,6 @@ int sparse_factor_setup(dlg_backend* b, bool plan_only)
       // workgroup only waits for lower-numbered ones); no arithmetic depends on the order.
       std::vector<double> est(H.fw_item.size(), 0.0);
       std::vector<int> item_of_sn(H.nsn, -1);
-      const bool by_est = !getenv("DOGLEG_AMD_REGION_INDEX_ORDER");
       for(int l = r_level0; l <= hi; l++)
         for(int i = H.fw_lvl_ptr[l]; i < H.fw_lvl_ptr[l+1]; i++) item_of_sn[H.fw_sn[i]] = i;
       for(int l = r_level0; l <= hi; l++)
@@ -1325,7 +1319,7 @@ int sparse_factor_setup(dlg_backend* b, bool plan_only)
           for(int k = 0; k < fi.nch; k++) { const int ci = item_of_sn[H.mf_child[fi.ch0 + k]]; if(ci >= 0) e0 = std::max(e0, est[ci]); }
           est[i] = e0 + 3.0*((fi.w + 15)/16) + 0.02*fi.nrows + 9.0;
         }
-        if(by_est) std::stable_sort(order.begin(), order.end(), [&](int a, int b2) { return est[a] > est[b2]; });
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b2) { return est[a] > est[b2]; });
         // (the first level of the region is its most populous one, and the Cauchy step's pass over J runs beside
         // it: replicas there cost more in CUs than they save -- only what does not fit LDS whole is sliced)
         const int rl = std::max(1, std::min(rmax, (l == r_level0 ? fill0 : fill)/std::max(n, 1)));
@@ -1386,7 +1380,7 @@ int sparse_factor_setup(dlg_backend* b, bool plan_only)
               // columns of the update matrix in HBM: it sums the children's entries of that stretch only (its own destination
               // lists drop the others), forms B B' of those tiles and publishes them.  One workgroup formed all 120 tiles of
               // such a front, 30 - 46 us of every level on config #5's critical path (profiles/r05_top_of_tree_levels_config5.txt).
-              const int want_h = (has_w && slice_ok && hbm_rep_ok) ? std::min(std::min(rl_i, T), 8) : 1;      // (at least 2 / 3 / 4 of them also on the populous levels: 336 / 330 / 326 steps/s against 338)
+              const int want_h = (has_w && slice_ok) ? std::min(std::min(rl_i, T), 8) : 1;      // (at least 2 / 3 / 4 of them also on the populous levels: 336 / 330 / 326 steps/s against 338)
               if(want_h > 1)
               {
                 for(int cap2 = (T*(T + 1)/2 + want_h - 1)/want_h; ; cap2++)
@@ -1618,14 +1612,14 @@ int sparse_factor_levels(dlg_backend* b, int part)
   // A factorisation enqueued ahead of the caller's decision (backend.hip, step_prepare) comes in two parts where its
   // first launch is a level of its own: part 1 = that launch (the leaf level), part 2 = everything behind it.  Same
   // launches in the same order on the same stream as part 0.
-  const bool split = Y->pr_level0 > 0 && !Y->lf_on && H.nlevels >= 2 && H.part_nranks <= 1 && H.fw_lvl_ptr[1] > H.fw_lvl_ptr[0];
+  const bool split = Y->pr_level0 > 0 && H.nlevels >= 2 && H.part_nranks <= 1 && H.fw_lvl_ptr[1] > H.fw_lvl_ptr[0];
   if(part == 2 && !split) return DLG_OK;
   if(part != 2)
   {
   if(H.part_nranks > 1 && H.cut_level < 0) DLG_CHECK(sparse_partition_reduce(b));     // nothing below the cut
   // (fin on the side, sparse_assemble.hip: the partial-sum stages of the ancestors' panels may still be on the second
   // stream -- level 0 does not touch those panels; whatever follows it does)
-  if(Y->pr_level0 == 0 || Y->lf_on || H.nlevels < 2) DLG_CHECK(sparse_fin_side_gate(b));
+  if(Y->pr_level0 == 0 || H.nlevels < 2) DLG_CHECK(sparse_fin_side_gate(b));
   }
   for(int l = 0; l < H.nlevels; l++)
   {
@@ -1682,7 +1676,7 @@ int sparse_factor_levels(dlg_backend* b, int part)
                            Y->pr_item, Y->pr_rec, Y->sn_bd_col, Y->pr_dst, Y->Lx, Y->top_scr, Y->d_info, Y->uscr, fmode, fl, ep, ho, pacc);
       break;
     }
-    if(n > 0 && !(l == 0 && Y->lf_on) && !launched_before)      // (leaf fronts: level 0 was factored with the assembly, sparse_leaf.hip)
+    if(n > 0 && !launched_before)
     {
       const int o = H.fw_lvl_ptr[l];
       const int sweep_bits = (Y->fac_b16 ? 16 : 0);
@@ -1724,7 +1718,7 @@ int sparse_factor_levels(dlg_backend* b, int part)
       // waves sharing a unit's sub-tasks)
       hipLaunchKernelGGL(HIP_KERNEL_NAME(k_update_gather<TPB>), dim3(nu), dim3(TPB), Y->upd_lds[l], st, H.uw_lvl_ptr[l],
                          Y->uw_flat, Y->usub, Y->usub_u, Y->relpos, Y->Lx, Y->upart, Y->uscr,
-                         Y->upd_nw[l], Y->d_info, (l == 0 && Y->lf_on) ? reinterpret_cast<const int*>(Y->Lx + H.lx_size) : (const int*)nullptr,
+                         Y->upd_nw[l], Y->d_info,
                          fin_ep ? (const int*)(Y->fin_flag + 1) : (const int*)nullptr, fin_ep,
                          reinterpret_cast<int*>(b->d_scal + (dlg_backend::NSCAL - 2)));
     }

@@ -115,7 +115,7 @@ void sparse_reset(dlg_backend* b)
   if(!Y) return;
   Y->spec_valid = false; Y->spec_inflight = false; Y->spec_slot = -1; Y->spec_J = nullptr;
   Y->aug_rhs = nullptr; Y->spec_aug_rhs = nullptr; Y->fin_pending_rhs = nullptr; Y->fin_pending_Lx = nullptr;
-  Y->info_armed = false; Y->info_clean = false; Y->spec_gen = -1;
+  Y->info_armed = false; Y->info_clean = false;
   Y->held_Lx = nullptr;
   Y->fin_side_owed = 0; Y->fin_main = nullptr;            // (dlg_backend_reset waits for both streams first)
   // (another solve, other values: what the last one learnt about its lambda = 0 factorisations -- the look at the diagonal
@@ -325,7 +325,7 @@ int sparse_set_pattern(dlg_backend* b, const int* colptr, const int* rowidx)
   lap("schedule uploads");
   auto dalloc = [&](double*& p, size_t n) -> int {
     DLG_HIP(hipMalloc(&p, sizeof(double)*(n ? n : 1))); Y->allocs.push_back(p); return DLG_OK; };
-  DLG_CHECK(dalloc(Y->Lx, (size_t)H.lx_size + 8));       // (+ the leaf fronts' pivot word behind the panels)
+  DLG_CHECK(dalloc(Y->Lx, (size_t)H.lx_size + 8));
   DLG_CHECK(dalloc(Y->scr, (size_t)H.scr_size));
   DLG_CHECK(dalloc(Y->ywork, (size_t)H.N));
   DLG_CHECK(dalloc(Y->upart, (size_t)H.upart_size));
@@ -375,7 +375,6 @@ int sparse_set_pattern(dlg_backend* b, const int* colptr, const int* rowidx)
   }
   lap("numeric buffers");
   DLG_CHECK(sparse_factor_setup(b));
-  DLG_CHECK(sparse_leaf_setup(b));
   DLG_CHECK(sparse_solve_setup(b));
   lap("kernel set-up");
   return DLG_OK;
@@ -514,7 +513,7 @@ __global__ void __launch_bounds__(TPB) k_diag_look(const double* __restrict__ Lx
 bool sparse_would_look(const dlg_backend* b, double lambda)
 {
   const SparseSym* Y = b->sym;
-  return Y && lambda == 0.0 && Y->zero_fail_seen && Y->n_leaf_diag > 0 && !Y->lf_on && Y->H.part_nranks <= 1 && !b->sharded() && !getenv("DOGLEG_AMD_NO_DIAG_LOOK");
+  return Y && lambda == 0.0 && Y->zero_fail_seen && Y->n_leaf_diag > 0 && Y->H.part_nranks <= 1 && !b->sharded() && !getenv("DOGLEG_AMD_NO_DIAG_LOOK");
 }
 // The host has learnt that a factorisation broke down.  At lambda = 0 the next ones look at the diagonal first.  Returns
 // true if THIS one was stopped by that look (a negative pivot word): no launch of it stored anything -- every kernel of the
@@ -526,7 +525,7 @@ bool sparse_note_breakdown(dlg_backend* b)
   if(!Y) return false;
   if(Y->cur_lambda == 0.0) Y->zero_fail_seen = true;
   Y->intact_Lx = nullptr;
-  if(*Y->h_info < 0 && Y->fac_J && !Y->lf_on && !getenv("DOGLEG_AMD_NO_INTACT"))
+  if(*Y->h_info < 0 && Y->fac_J)
   {
     Y->intact_Lx = Y->Lx; Y->intact_slot = Y->fac_slot; Y->intact_J = Y->fac_J; Y->intact_lambda = Y->cur_lambda;
     return true;
@@ -663,8 +662,7 @@ extern "C" int dlg_sparse_symbolic_probe(int N, int M, const int* colptr, const 
                      (long)H.ui_t.size(), (long)H.relpos.size(), (long)H.oblk.size(),
                      (long)H.contrib.size(), (long)H.usub.size(), (long)H.scr_size,
                      (long)H.jtx_task.size(), (long)H.asm_mtask.size(), (long)H.asm_kg.size(),
-                     (long)H.asm_shape.size(), (long)H.lf_ok, (long)H.lf_leaf.size(), (long)H.lf_lds, (long)H.lf_blob.size(), (long)H.lf_jtp_size };
-  if(!H.lf_ok && getenv("DOGLEG_AMD_SYM_DEBUG")) fprintf(stderr, "leaf fronts off: %s\n", H.lf_why);
+                     (long)H.asm_shape.size() };
   if(getenv("DOGLEG_AMD_SYM_DEBUG"))
     for(int l = 0; l + 1 < (int)H.uw_lvl_ptr.size(); l++)
     {

@@ -155,15 +155,7 @@ struct SparseSym
   int64_t* aug_of_var = nullptr; char* jf_listed = nullptr;      // by variable: where its augmented-row entry lies; its Jt*x comes from a record list
   int aug_fused_epoch = 0; const double* spec_aug_fused = nullptr;   // the Jt*x sums of the last evaluation set the augmented rows (epoch of their word)
   int* fin_flag = nullptr; int fin_epoch = 0, fin_side_owed = 0; bool fin_side_sched_ok = false; hipStream_t fin_main = nullptr;
-  bool fac_b16 = false;         // panel_factor_b16 (DOGLEG_AMD_B16)
-  // leaf fronts (sparse_leaf.hip): assembly + Jt*x + the leaves' factorisation in one kernel
-  bool lf_on = false;
-  LfLeaf* lf_leaf = nullptr; uint8_t* lf_blob = nullptr; double* lf_jtp = nullptr; char* lf_col = nullptr;
-  int *lf_jf_ptr = nullptr, *lf_jf_ent = nullptr, *lf_jf_var0 = nullptr, *lf_jf_w = nullptr, *lf_jf_short = nullptr, *lf_jf_long = nullptr;
-  double* lf_jf_lpart = nullptr; int* lf_jf_lcnt = nullptr;
-  // the leaves' update matrices in uscr belong to ONE assembly: lf_gen counts the launches, spec_gen / spec_lambda
-  // say which launch (at which lambda) filled the second panel buffer
-  long lf_gen = 0, spec_gen = -1; double spec_lambda = 0.0;
+  bool fac_b16 = false;         // panel_factor_b16 where the panel has at most 512 rows
   int bwd_xb_cap = 12288;       // below rows of a supernode staged in LDS by the backward solve
   double* diag_mm = nullptr; int n_diag_mm = 0;   // [supernode][min, max] of the diagonal of L (k_solve_bwd_level), read by the step kernels
   std::vector<void*> allocs;
@@ -178,7 +170,5 @@ int sparse_assemble_finish(dlg_backend* b);                   // ... its JtJ par
 int sparse_zero_spare(dlg_backend* b);                        // clear the swapped-out panel buffer behind the step's fetch
 void sparse_spec_invalidate(dlg_backend* b, int s);                 // subtree partition: the sum over the ranks at the cut
 int sparse_factor_setup(dlg_backend* b, bool plan_only = false);   // per-level launch parameters of K5
-int sparse_leaf_setup(dlg_backend* b);                       // leaf fronts: uploads (after sparse_factor_setup)
-int sparse_leaf_front(dlg_backend* b, const double* Jv, double* Lx, const double* x, double* Jt_x, const double* rhs, double lambda);
 int sparse_factor_levels(dlg_backend* b, int part = 0);      // K5 launches (no synchronisation); part 1: the leaf level only where the rest can follow later (fac_pending), part 2: that rest
 int sparse_solve_setup(dlg_backend* b);                      // per-level launch parameters of K6

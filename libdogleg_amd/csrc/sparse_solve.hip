@@ -688,7 +688,7 @@ extern "C" void dlg_bw_profile_dump(int nlevels)
 int sparse_touch_factor(dlg_backend* b, hipStream_t st)
 {
   SparseSym* Y = b->sym;
-  if(!Y || !Y->touch_n || b->knobs.no_touch) return DLG_OK;
+  if(!Y || !Y->touch_n) return DLG_OK;
   const int nwg = b->knobs.touch_wg;   // (1024: 9 us more in the factorisation; 16: still running when the next step needs the stream)
   hipLaunchKernelGGL(k_touch, dim3(nwg), dim3(TPB), 0, st, reinterpret_cast<const double2*>(Y->Lx + Y->touch_off),
                      (size_t)Y->touch_n/2, Y->ywork);
@@ -726,7 +726,7 @@ int sparse_solve_setup(dlg_backend* b)
     if(Y->slv_lds[l] > LDS_BUDGET) { dlg_set_error("supernode of width %ld is too wide for the solve kernels", maxw); return DLG_ERR_ARG; }
     if(mb*8 > LDS_BUDGET) { dlg_set_error("supernode too large for the backward-solve kernel (%ld doubles)", mb); return DLG_ERR_ARG; }
     // the top block rides in LDS when every supernode of the level has room for it
-    Y->bwd_top[l] = (mbt*8 <= LDS_BUDGET && getenv("DOGLEG_AMD_BWD_TOP")) ? 1 : 0;     // measured slower than the prefetch from HBM: off unless asked for
+    Y->bwd_top[l] = 0;     // (the top block staged in LDS was measured slower than its prefetch from HBM, rounds 2 - 5: k_solve_bwd_level keeps the path, nothing selects it)
     Y->bwd_lds[l] = (int)((Y->bwd_top[l] ? mbt : mb)*8);
     Y->bwd_pmx[l] = 0;
     {
@@ -839,7 +839,7 @@ int sparse_solve_setup(dlg_backend* b)
       Y->bw_level0 = l0; Y->bw_n = (int)items.size(); Y->bw_lds = std::max(ldsb, 84*1024);
       DLG_CHECK(upload(Y->slv_item_pr, items)); Y->allocs.push_back(Y->slv_item_pr);
       // x of the region as its own signal (k_solve_bwd_level, xh): two sets, every entry a sentinel until it is stored
-      if(!getenv("DOGLEG_AMD_BWD_FLAGS"))
+      if(true)
       {
         std::vector<unsigned long long> empty(2*(size_t)H.N, 0x7FF8DEADBEEF0002ull);
         DLG_HIP(hipMalloc(&Y->bwd_xh, sizeof(double)*empty.size())); Y->allocs.push_back(Y->bwd_xh);

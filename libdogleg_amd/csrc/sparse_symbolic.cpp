@@ -538,11 +538,11 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
   std::vector<int> sn_b0;                 // first block position of each supernode (+ sentinel)
   std::vector<char> sn_bd;                // supernode made of sibling leaves only: block-diagonal top
   {
-    const int relax = env_int("DOGLEG_AMD_RELAX_PCT", 25);
-    const int sib_w = env_int("DOGLEG_AMD_SIB_W", 64);
-    const int split_w = env_int("DOGLEG_AMD_SPLIT_W", 32);   // columns from which a run stays a supernode of its own beside its parent's other children
+    const int relax = 25;
+    const int sib_w = 64;
+    const int split_w = 32;   // columns from which a run stays a supernode of its own beside its parent's other children
     const long chain_cap = PANEL_CAP;   // width cap of chain supernodes: W*(W+64)
-    const bool lds_split = env_int("DOGLEG_AMD_LDS_SPLIT", 1) != 0;
+    const bool lds_split = env_int("DOGLEG_AMD_LDS_SPLIT", 1) != 0;     // (0: row-sliced separators outside the multifrontal region, rounds 1 - 3: a path of its own, kept under test on config #5)
     const long lds_split_minw = 32;
     // width of the fundamental supernode (maximal chain of exactly nested block columns) starting at j:
     // a relaxed merge across a structure change takes that whole run or nothing -- stopping in the
@@ -606,7 +606,7 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
         // A chain whose panel would not fit LDS whole is cut where it still does, once it is wide enough to be worth a
         // workgroup (config #5: separators of 96 columns with 194 rows below, 222 KB -- as one supernode they are cut into
         // ROW slices, which keeps every level above the leaves out of the multifrontal one-launch region; as 64 + 32
-        // columns both panels fit and the whole top of the tree is one launch).  DOGLEG_AMD_LDS_SPLIT=0: rounds 1 - 3.
+        // columns both panels fit and the whole top of the tree is one launch).
         const long pan_n = ((Wn + Rn + 1 + 1) & ~1L)*Wn;
         const bool lds_cut = lds_split && W >= lds_split_minw && pan_n > slice_cap() && Rn + 1 <= 255;
         if(fits && !beside_siblings && !lds_cut && (exact || (run_fits && (Wn <= 16 || zeros*100 <= (long)relax*(stored + Wn*Wn)))))
@@ -863,7 +863,7 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
     // region, < 0 turns it off.
     S.mf_level0 = S.nlevels;
     {
-      const int mf_req = env_int("DOGLEG_AMD_MF_LEVEL", 1), mf_maxm = std::min(255, env_int("DOGLEG_AMD_MF_MAXM", 255));
+      const int mf_req = env_int("DOGLEG_AMD_MF_LEVEL", 1), mf_maxm = 255;
       for(int l = S.nlevels - 1; mf_req >= 0 && l >= mf_req; l--)
       {
         bool ok = true;
@@ -1094,7 +1094,7 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
     const int nitems = (int)S.ui_t.size();
     // chunking by estimated cost: a light sub-task (narrow source) counts 1, a
     // heavy one counts by its thread-iterations; a unit is closed at UNIT_COST
-    const int unit_cost = env_int("DOGLEG_AMD_UNIT_COST", 1024);
+    const int unit_cost = 1024;
     const int unit_cost_gather = std::max(1, unit_cost/64);
     std::vector<int> cuts;
     for(int it = 0; it < nitems; it++)
@@ -1722,7 +1722,7 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
         if(S.asm_shape[T.shape].MT > 0)
           for(int g = T.kg0; g < T.kg1; g++)
             if(((S.asm_kg[g].meta >> 8) & 7) > 0 && (!(S.asm_kg[g].meta & (1u << 13)) || !(S.asm_kg[g].meta & (1u << 11)))) S.asm_td_inline = false;     // (... and stores them: no row-block of more than four rows)
-      const int RUN_KG = env_int("DOGLEG_AMD_RUN_KG", 32);
+      const int RUN_KG = 32;
       for(int k = 0; k < nt; )
       {
         AsmRun R; R.task0 = k; R.kg0 = S.asm_mtask[k].kg0;
@@ -1826,427 +1826,6 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
     else { r8 = step8(e8, sizeof(e8)); r9a = step9a(e9a, sizeof(e9a)); r9b = step9b(e9b, sizeof(e9b)); r10 = step10(e10, sizeof(e10)); }
     const char* em = r8 ? e8 : (r9a ? e9a : (r9b ? e9b : (r10 ? e10 : nullptr)));
     if(em) SYM_FAIL("%s", em);
-  }
-  SYM_TICK("11 leaf fronts");
-  // ------------------------------------------------------------ 11. leaf fronts
-  // (sparse_symbolic.h, LfLeaf).  All or nothing: either every local measurement row is owned by a merged
-  // leaf of level 0 and every strip has one layout, or the pattern keeps the separate assembly / leaf kernels.
-  {
-    S.lf_ok = false; S.lf_leaf.clear(); S.lf_blob.clear(); S.lf_jtp_size = 0; S.lf_lds = 0; S.lf_col.assign(N, 0);
-    S.lf_jf_ptr.clear(); S.lf_jf_ent.clear(); S.lf_jf_var0.clear(); S.lf_jf_w.clear(); S.lf_jf_short.clear(); S.lf_jf_long.clear();
-    auto why = [&](const char* fmt, long a = 0, long b = 0) { snprintf(S.lf_why, sizeof(S.lf_why), fmt, a, b); return false; };
-    auto build = [&]() -> bool {
-      // (opt-in: on config #4 the one kernel takes what the two it replaces take -- DESIGN.md section 6, round 3)
-      if(!env_int("DOGLEG_AMD_LEAF_FRONT", 0)) return why("not switched on (DOGLEG_AMD_LEAF_FRONT=1)");
-      if(partition || row0 != 0 || row1 != M) return why("the rows are shared between ranks");
-      if(cp[M] >= (1 << 28)) return why("more than 2^28 non-zeros");
-      if(S.nlevels < 2 || S.mf_level0 < 1 || S.upd_syrk.empty() || !S.upd_syrk[0]) return why("no two-phase leaf level");
-      const int k0 = S.fw_lvl_ptr[0], k1 = S.fw_lvl_ptr[1];
-      if(k1 <= k0) return why("no leaves");
-      std::vector<int> leaf_of_sn(nsn, -1);
-      for(int k = k0; k < k1; k++)
-      {
-        const FwItem& it = S.fw_item[k];
-        if(!(it.nbd > 0 && it.top < 0 && it.bdw > 0 && it.bdw <= 4 && it.w <= 64 && it.r0 == 0 && it.r1 == it.nrows - it.w && it.u_off >= 0))
-          return why("level 0 holds a supernode that is not a merged leaf (work item %ld)", k);
-        if(it.nrows - it.w > 240) return why("a leaf with %ld rows below", it.nrows - it.w);
-        leaf_of_sn[it.s] = k - k0;
-      }
-      const int nleaf = k1 - k0;
-      // the owner of every row-block: the supernode of its first-eliminated var-block
-      std::vector<std::vector<int>> owned(nleaf);
-      for(int rb = 0; rb < nrb; rb++)
-      {
-        const RowBlock& B = rbs[rb];
-        if(!B.local) continue;
-        if(B.len > 15) return why("a measurement row with %ld entries (at most 15)", B.len);
-        int qmin = nvb;
-        for(int t = 0; t < B.nvb; t++) qmin = std::min(qmin, bpos[rb_vb[B.vptr + t]]);
-        const int lf = leaf_of_sn[sn_of_b[qmin]];
-        if(lf < 0) return why("measurement row %ld is not owned by a leaf", B.r0);
-        owned[lf].push_back(rb);
-      }
-      // Jt*x records of the ancestors' blocks, by var-block
-      std::vector<std::vector<int>> jent(nvb);
-      struct TaskH { LfTask T; std::vector<uint16_t> pl, tl; long cost; };
-      constexpr int SPLIT_ROWS = 128, CHUNK_ROWS = 64;
-      S.lf_leaf.resize(nleaf);
-      for(int lf = 0; lf < nleaf; lf++)
-      {
-        const FwItem& it = S.fw_item[k0 + lf];
-        const int s = it.s, w = it.w, nrows = it.nrows, mb = nrows - w;
-        const int* rows = &S.sn_rows[S.sn_rowptr[s]];
-        // the leaf's row-blocks, member-major, a member's sorted by where their other blocks go
-        std::vector<int> own = owned[lf];
-        int nrbl = (int)own.size();
-        std::vector<int> mcol(nrbl, -1), mk(nrbl, -1);
-        std::vector<std::array<uint8_t, 16>> fi(nrbl);
-        int nslots = 0;
-        for(int i = 0; i < nrbl; i++)
-        {
-          const RowBlock& B = rbs[own[i]];
-          nslots += B.nrows;
-          fi[i].fill(0xFF);
-          for(int t = 0; t < B.nvb; t++)
-          {
-            const int v = rb_vb[B.vptr + t], e0 = rb_off[B.vptr + t], wv = G.w[v], p0 = colstart[bpos[v]];
-            if(p0 >= S.sn_c0[s] && p0 < S.sn_c0[s+1])
-            {
-              if(mcol[i] >= 0) return why("measurement row %ld touches two members of a leaf", B.r0);
-              mcol[i] = p0 - S.sn_c0[s]; mk[i] = e0;
-              if(wv != it.bdw || mcol[i] % it.bdw) return why("member blocks of different widths");
-              continue;
-            }
-            const int* f = std::lower_bound(rows + w, rows + nrows - 1, p0);
-            if(f == rows + nrows - 1 || *f != p0) return why("internal: a variable of row %ld is missing from its leaf's structure", B.r0);
-            for(int a = 0; a < wv; a++) fi[i][e0 + a] = (uint8_t)((f - (rows + w)) + a);
-          }
-          if(mcol[i] < 0) return why("internal: row %ld has no member block", B.r0);
-          fi[i][15] = (uint8_t)(mb - 1);
-        }
-        if(nslots > 4000) return why("a leaf owns %ld measurement rows", nslots);
-        {
-          std::vector<int> ord(nrbl);
-          std::iota(ord.begin(), ord.end(), 0);
-          std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) {
-            if(mcol[a] != mcol[b]) return mcol[a] < mcol[b];
-            return fi[a] < fi[b]; });
-          std::vector<int> own2(nrbl), mcol2(nrbl), mk2(nrbl); std::vector<std::array<uint8_t, 16>> fi2(nrbl);
-          for(int i = 0; i < nrbl; i++) { own2[i] = own[ord[i]]; mcol2[i] = mcol[ord[i]]; mk2[i] = mk[ord[i]]; fi2[i] = fi[ord[i]]; }
-          own.swap(own2); mcol.swap(mcol2); mk.swap(mk2); fi.swap(fi2);
-        }
-        std::vector<int> slot0(nrbl);
-        { int q = 0; for(int i = 0; i < nrbl; i++) { slot0[i] = q; q += rbs[own[i]].nrows; } }
-        std::vector<TaskH> tasks, virt;
-        std::vector<LfComb> combs;
-        int nscr = 0;
-        // pd of a strip: window position k -> persistent below index / skip / transient
-        auto classify = [&](const std::vector<int>& list, int kj, int wj, int col0_below, bool member, uint8_t* pd) -> bool {
-          const RowBlock& B0 = rbs[own[list[0]]];
-          memset(pd, 0xFF, 32);
-          int nT = 0;
-          for(int i : list) { const RowBlock& B = rbs[own[i]]; if(B.len != B0.len) return false; }
-          for(int k = 0; k < 16; k++)
-          {
-            if(k >= B0.len && k != 15) continue;
-            if(k >= kj && k < kj + wj) { pd[k] = member ? 0xFD : (uint8_t)(col0_below + (k - kj)); continue; }
-            if(k == 15) { pd[k] = member ? (uint8_t)(mb - 1) : 0xFC; continue; }
-            const int f0 = fi[list[0]][k];
-            bool same = true;
-            for(int i : list) if(fi[i][k] != f0) same = false;
-            if(member)
-            {
-              if(f0 == 0xFF && same) continue;
-              if(same) { pd[k] = (uint8_t)f0; continue; }
-              // transient: every row-block sends it somewhere else
-              std::vector<int> seen;
-              for(int i : list) { if(fi[i][k] == 0xFF) return false; seen.push_back(fi[i][k]); }
-              std::sort(seen.begin(), seen.end());
-              if(std::adjacent_find(seen.begin(), seen.end()) != seen.end()) return false;
-              pd[k] = 0xFE; pd[16 + nT++] = (uint8_t)k;
-            }
-            else
-            {
-              // positions of blocks that precede this one (or of the member) are the other strip's; the rest must agree
-              bool all_before = true, all_after = true;
-              for(int i : list) { const int f = fi[i][k]; if(f != 0xFF && f >= col0_below) all_before = false; else all_after = false; }
-              if(all_before) continue;
-              if(!all_after || !same) return false;
-              pd[k] = (uint8_t)f0;
-            }
-          }
-          pd[31] = (uint8_t)nT;
-          return true; };
-        // flat rows [a, b) of the list's row-blocks (in list order): an arithmetic pattern of slots, or a list
-        auto set_rows = [&](const std::vector<int>& list, int a, int b, TaskH& H2) {
-          std::vector<int> sl;
-          int r = 0;
-          for(int i : list)
-          {
-            const int h = rbs[own[i]].nrows;
-            for(int q = 0; q < h; q++, r++) if(r >= a && r < b) sl.push_back(slot0[i] + q);
-          }
-          H2.T.nprow = (uint16_t)sl.size();
-          // runs of consecutive slots, all of one length, their starts at one stride
-          int nin = 1;
-          while(nin < (int)sl.size() && sl[nin] == sl[nin-1] + 1) nin++;
-          bool ok = sl.size() % nin == 0;
-          const int nout = ok ? (int)sl.size()/nin : 0;
-          const int stride = nout > 1 ? sl[nin] - sl[0] : 0;
-          for(int o = 0; o < nout && ok; o++)
-            for(int q = 0; q < nin && ok; q++) if(sl[o*nin + q] != sl[0] + o*stride + q) ok = false;
-          if(ok && stride >= 0 && !env_int("DOGLEG_AMD_LF_LISTS", 0))
-          { H2.T.flags |= 1; H2.T.a_slot0 = (uint16_t)sl[0]; H2.T.a_nout = (uint16_t)nout; H2.T.a_stride = (uint16_t)stride; H2.T.a_nin = (uint16_t)nin; }
-          else
-          {
-            for(int v : sl) H2.pl.push_back((uint16_t)v);
-            while(H2.pl.size() & 3) H2.pl.push_back((uint16_t)nslots);       // the zero row
-          } };
-        // member strips
-        {
-          std::vector<std::vector<int>> of_member(it.nbd);
-          for(int i = 0; i < nrbl; i++) of_member[mcol[i]/it.bdw].push_back(i);
-          for(int m = 0; m < it.nbd; m++)
-          {
-            const std::vector<int>& list = of_member[m];
-            if(list.empty()) continue;
-            TaskH H2; memset(&H2.T, 0, sizeof(H2.T));
-            const int kj = mk[list[0]];
-            for(int i : list) if(mk[i] != kj) return why("the rows of a member differ in layout");
-            if(!classify(list, kj, it.bdw, 0, true, H2.T.pd)) return why("the rows of a member differ in layout (leaf %ld)", lf);
-            int nr = 0; for(int i : list) nr += rbs[own[i]].nrows;
-            set_rows(list, 0, nr, H2);
-            if(H2.T.pd[31] > 0)
-            {
-              // (member-major order: a member's row-blocks are consecutive)
-              H2.T.flags |= 2; H2.T.tlist = (uint16_t)list[0]; H2.T.ntrb = (uint16_t)list.size();
-              for(size_t q = 0; q < list.size(); q++) if(list[q] != list[0] + (int)q) return why("internal: a member's row-blocks are not consecutive");
-              int hh = rbs[own[list[0]]].nrows;
-              for(int i : list) if(rbs[own[i]].nrows != hh) hh = 0;
-              if((H2.T.flags & 1) && H2.T.a_nout == 1) H2.T.hh = (uint8_t)hh;
-            }
-            H2.T.col0 = (uint16_t)(m*it.bdw);
-            H2.T.kj = (uint8_t)kj; H2.T.wj = (uint8_t)it.bdw; H2.T.kind = 0; H2.T.scr = 0;
-            H2.cost = 4L*nr + 10L*(long)list.size();
-            tasks.push_back(std::move(H2));
-          }
-        }
-        // strips of the ancestors' blocks
-        struct BelowH { int c0, v, wj, kj, nr; std::vector<int> list; uint8_t pd[32]; };
-        std::vector<BelowH> below;
-        for(int c0 = 0; c0 < mb - 1; )
-        {
-          // the var-block of below row c0
-          const int p0 = rows[w + c0];
-          const int q = (int)(std::upper_bound(colstart.begin(), colstart.end(), p0) - colstart.begin()) - 1;
-          const int v = border[q], wj = G.w[v];
-          if(colstart[q] != p0 || c0 + wj > mb - 1) return why("internal: a block of the structure of leaf %ld is cut", lf);
-          std::vector<int> list;
-          int kj = -1;
-          for(int i = 0; i < nrbl; i++)
-          {
-            const RowBlock& B = rbs[own[i]];
-            for(int t = 0; t < B.nvb; t++) if(rb_vb[B.vptr + t] == v)
-            { if(kj < 0) kj = rb_off[B.vptr + t]; else if(kj != rb_off[B.vptr + t]) return why("the rows of a block differ in layout"); list.push_back(i); }
-          }
-          if(!list.empty())
-          {
-            BelowH Bh; Bh.c0 = c0; Bh.v = v; Bh.wj = wj; Bh.kj = kj; Bh.list = list;
-            if(!classify(list, kj, wj, c0, false, Bh.pd)) return why("the rows of a block of the ancestors differ in layout (leaf %ld, below row %ld)", lf, c0);
-            Bh.nr = 0; for(int i : list) Bh.nr += rbs[own[i]].nrows;
-            below.push_back(std::move(Bh));
-            jent[v].push_back((int)S.lf_jtp_size + c0);
-          }
-          c0 += wj;
-        }
-        // a rider: a block that every row holds, carried by the strips of the others if those visit every row once
-        int rider = -1;
-        if(!env_int("DOGLEG_AMD_LF_NO_RIDER", 0))
-        {
-          for(size_t q = 0; q < below.size() && rider < 0; q++)
-          {
-            if(below[q].nr != nslots || below[q].wj > 8) continue;
-            std::vector<int> cnt(nrbl, 0);
-            bool ok = below.size() > 1;
-            for(size_t c = 0; c < below.size() && ok; c++)
-            {
-              if(c == q) continue;
-              if(below[c].wj + below[q].wj > 16 || below[c].nr > SPLIT_ROWS) ok = false;
-              for(int i : below[c].list) cnt[i]++;
-            }
-            for(int i = 0; i < nrbl && ok; i++) if(cnt[i] != 1) ok = false;
-            if(ok && below.size() - 1 <= 250) rider = (int)q;
-          }
-        }
-        for(size_t q = 0; q < below.size(); q++)
-        {
-          const BelowH& Bh = below[q];
-          TaskH H2; memset(&H2.T, 0, sizeof(H2.T)); memcpy(H2.T.pd, Bh.pd, 32);
-          H2.T.col0 = (uint16_t)Bh.c0; H2.T.kj = (uint8_t)Bh.kj; H2.T.wj = (uint8_t)Bh.wj; H2.T.kind = 1; H2.T.nprow = (uint16_t)Bh.nr;
-          if((int)q == rider)
-          {
-            // no task of its own: the sum of what the carriers leave in their scratch slots
-            LfComb C; C.task = (uint16_t)virt.size(); C.scr0 = (uint16_t)nscr; C.nscr = (uint16_t)(below.size() - 1); C.pad = 0;
-            combs.push_back(C);
-            virt.push_back(std::move(H2));
-            continue;
-          }
-          if(Bh.nr > SPLIT_ROWS)
-          {
-            LfComb C; C.task = (uint16_t)virt.size(); C.scr0 = (uint16_t)(nscr + (rider >= 0 ? 0 : 0)); C.nscr = 0; C.pad = 0;
-            if(rider >= 0) return why("internal: a split strip beside a rider");
-            for(int a = 0; a < Bh.nr; a += CHUNK_ROWS)
-            {
-              TaskH P2; P2.T = H2.T;
-              P2.T.kind = 2; P2.T.scr = (uint8_t)nscr;
-              set_rows(Bh.list, a, std::min(Bh.nr, a + CHUNK_ROWS), P2);
-              P2.cost = 4L*P2.T.nprow*((Bh.wj + 3)/4);
-              tasks.push_back(std::move(P2));
-              nscr++; C.nscr++;
-              if(nscr > 250) return why("too many partial strips in leaf %ld", lf);
-            }
-            combs.push_back(C);
-            virt.push_back(std::move(H2));
-          }
-          else
-          {
-            set_rows(Bh.list, 0, Bh.nr, H2);
-            H2.cost = 4L*Bh.nr*((Bh.wj + 3)/4);
-            tasks.push_back(std::move(H2));
-          }
-        }
-        if(rider >= 0)
-        {
-          // scratch slots of the carriers, in the order of the below blocks (the order of the rider's sums)
-          int slot = -1;
-          for(const LfComb& C : combs) slot = C.scr0;        // (the rider's is the only combine record)
-          for(TaskH& t : tasks)
-            if(t.T.kind == 1) { t.T.rkj = (uint8_t)below[rider].kj; t.T.rwj = (uint8_t)below[rider].wj; }
-          // (assign in the order of col0 so that the sum does not depend on the tasks' cost order)
-          std::vector<TaskH*> car;
-          for(TaskH& t : tasks) if(t.T.kind == 1) car.push_back(&t);
-          std::sort(car.begin(), car.end(), [](const TaskH* a, const TaskH* b) { return a->T.col0 < b->T.col0; });
-          for(TaskH* t : car) t->T.scr = (uint8_t)slot++;
-          nscr = slot;
-        }
-        std::stable_sort(tasks.begin(), tasks.end(), [](const TaskH& a, const TaskH& b) { return a.cost > b.cost; });
-        // ---- the blob
-        const int ntask = (int)tasks.size(), ncomb = (int)combs.size();
-        for(LfComb& C : combs) C.task = (uint16_t)(ntask + C.task);
-        std::vector<TaskH*> all;
-        for(TaskH& t : tasks) all.push_back(&t);
-        for(TaskH& t : virt) all.push_back(&t);
-        const size_t b0 = (S.lf_blob.size() + 15) & ~(size_t)15;
-        S.lf_blob.resize(b0, 0);
-        auto put = [&](const void* src, size_t n) { const size_t o = S.lf_blob.size(); S.lf_blob.resize(o + n); memcpy(&S.lf_blob[o], src, n); return o; };
-        auto align = [&](size_t a) { while((S.lf_blob.size() - b0) % a) S.lf_blob.push_back(0); };
-        LfLeaf& L = S.lf_leaf[lf];
-        memset(&L, 0, sizeof(L));
-        {
-          // staging table, in the order of the rows in J
-          std::vector<std::array<int32_t, 3>> st;
-          for(int i = 0; i < nrbl; i++)
-          {
-            const RowBlock& B = rbs[own[i]];
-            for(int r = 0; r < B.nrows; r++) st.push_back({ (B.lbase + r*B.len) | (B.len << 28), B.lr0 + r, slot0[i] + r });
-          }
-          std::sort(st.begin(), st.end(), [](const std::array<int32_t, 3>& a, const std::array<int32_t, 3>& b) { return a[1] < b[1]; });
-          std::vector<int32_t> sv(nslots), sr(nslots); std::vector<uint16_t> sd(nslots);
-          for(int g = 0; g < nslots; g++) { sv[g] = st[g][0]; sr[g] = st[g][1]; sd[g] = (uint16_t)st[g][2]; }
-          put(sv.data(), 4*(size_t)nslots); put(sr.data(), 4*(size_t)nslots); put(sd.data(), 2*(size_t)nslots);
-          // ... and by slot
-          std::vector<int32_t> svs(nslots), srs(nslots);
-          for(int g = 0; g < nslots; g++) { svs[sd[g]] = sv[g]; srs[sd[g]] = sr[g]; }
-          align(4);
-          put(svs.data(), 4*(size_t)nslots); put(srs.data(), 4*(size_t)nslots);
-        }
-        align(16);
-        const size_t l0 = S.lf_blob.size();                 // the part that goes to LDS
-        L.o_lds = (int32_t)(l0 - b0);
-        L.o_task = 0;
-        for(TaskH* t : all) put(&t->T, sizeof(LfTask));
-        L.o_comb = (int32_t)(S.lf_blob.size() - l0);
-        for(const LfComb& C : combs) put(&C, sizeof(LfComb));
-        align(16);
-        L.o_rbh = (int32_t)(S.lf_blob.size() - l0);
-        for(int i = 0; i < nrbl; i++)
-        { const RowBlock& B = rbs[own[i]]; const uint32_t h = (uint32_t)slot0[i] | ((uint32_t)B.nrows << 16) | ((uint32_t)B.len << 24); put(&h, 4); }
-        align(16);
-        L.o_fi = (int32_t)(S.lf_blob.size() - l0);
-        for(int i = 0; i < nrbl; i++) put(fi[i].data(), 16);
-        for(size_t ti = 0; ti < all.size(); ti++)
-        {
-          TaskH* t = all[ti];
-          if(t->pl.empty() && t->tl.empty()) continue;
-          align(8);
-          const size_t po = (S.lf_blob.size() - l0)/2;
-          if(!t->pl.empty()) put(t->pl.data(), 2*t->pl.size());
-          const size_t to = (S.lf_blob.size() - l0)/2;
-          if(!t->tl.empty()) put(t->tl.data(), 2*t->tl.size());
-          if(po > 0xFFFF || to > 0xFFFF) return why("the schedule of leaf %ld is too long", lf);
-          LfTask* T = reinterpret_cast<LfTask*>(&S.lf_blob[l0 + ti*sizeof(LfTask)]);
-          if(!t->pl.empty()) T->plist = (uint16_t)po;
-          if(!t->tl.empty()) T->tlist = (uint16_t)to;
-        }
-        align(16);
-        L.blob = (int32_t)b0; L.blob_bytes = (int32_t)(S.lf_blob.size() - b0); L.lds_bytes = (int32_t)(S.lf_blob.size() - l0);
-        L.nslots = nslots; L.ntask = ntask; L.ncomb = ncomb; L.nscr = nscr; L.jtp = (int32_t)S.lf_jtp_size;
-        L.w = w; L.nrows = nrows; L.col0 = it.col0; L.bd0 = it.bd0; L.nbd = it.nbd; L.bdw = it.bdw; L.lx = it.lx; L.u_off = it.u_off;
-        L.nrb = nrbl;
-        S.lf_jtp_size += mb - 1;
-        if(S.lf_blob.size() > ((size_t)1 << 31) - 65536) return why("the leaf schedules exceed 2 GB");
-        // LDS of the leaf's workgroup (sparse_leaf.hip): panel, update matrix, member blocks, rows + the zero row, scratch, schedule
-        const long ldp = (mb + 1) & ~1L, ntri = (long)mb*(mb + 1)/2;
-        const long dbl = ldp*w + ((ntri + 2) & ~1L) + ((4L*w + 1) & ~1L) + 16L*(nslots + 1) + 128L*nscr;
-        const long bytes = dbl*8 + L.lds_bytes + 64;
-        S.lf_lds = (int)std::max<long>(S.lf_lds, bytes);
-        for(int c = 0; c < w; c++) S.lf_col[it.col0 + c] = 1;
-      }
-      if(S.lf_lds > SYM_FAC_LDS_BUDGET) return why("a leaf front needs %ld bytes of LDS", S.lf_lds);
-      // one stride for all blobs (see lf_stride), unless a few large leaves would blow the buffer up
-      {
-        int smax = 1, lmax = 16;
-        for(const LfLeaf& L : S.lf_leaf) { smax = std::max(smax, L.nslots); lmax = std::max(lmax, L.lds_bytes); }
-        const size_t o_s = ((size_t)10*smax + 3) & ~(size_t)3;                  // the by-slot tables behind the three by-row ones
-        const size_t tb = (o_s + (size_t)8*smax + 15) & ~(size_t)15, stride = tb + (size_t)lmax;
-        S.lf_stride = S.lf_smax = S.lf_tb = 0;
-        if(stride*S.lf_leaf.size() <= 2*S.lf_blob.size() + (1u << 20) && stride*S.lf_leaf.size() < ((size_t)1 << 31) - 65536 && !env_int("DOGLEG_AMD_LF_NO_STRIDE", 0))
-        {
-          std::vector<uint8_t> nb(stride*S.lf_leaf.size(), 0);
-          for(size_t i = 0; i < S.lf_leaf.size(); i++)
-          {
-            LfLeaf& L = S.lf_leaf[i];
-            const uint8_t* src = &S.lf_blob[(size_t)L.blob];
-            uint8_t* dst = &nb[i*stride];
-            memcpy(dst, src, 4*(size_t)L.nslots);
-            memcpy(dst + 4*(size_t)smax, src + 4*(size_t)L.nslots, 4*(size_t)L.nslots);
-            memcpy(dst + 8*(size_t)smax, src + 8*(size_t)L.nslots, 2*(size_t)L.nslots);
-            const size_t so = ((size_t)10*L.nslots + 3) & ~(size_t)3;
-            memcpy(dst + o_s, src + so, 4*(size_t)L.nslots);
-            memcpy(dst + o_s + 4*(size_t)smax, src + so + 4*(size_t)L.nslots, 4*(size_t)L.nslots);
-            memcpy(dst + tb, src + L.o_lds, (size_t)L.lds_bytes);
-            L.blob = (int32_t)(i*stride); L.o_lds = (int32_t)tb; L.blob_bytes = (int32_t)stride;
-          }
-          S.lf_blob.swap(nb);
-          S.lf_stride = (int)stride; S.lf_smax = smax; S.lf_tb = (int)tb;
-          // the persistent form's LDS: one layout for all leaves
-          long pud = 0; int scr = 0;
-          for(size_t i = 0; i < S.lf_leaf.size(); i++)
-          {
-            const LfLeaf& L = S.lf_leaf[i];
-            const long mb = L.nrows - L.w, ldp = (mb + 1) & ~1L, ntri = mb*(mb + 1)/2;
-            pud = std::max(pud, ldp*L.w + ((ntri + 2) & ~1L) + ((4L*L.w + 1) & ~1L));
-            scr = std::max(scr, L.nscr);
-          }
-          const long lmaxk = ((long)lmax + 1023) & ~1023L;                     // (a wave copies a kilobyte of schedule at a time)
-          const long bytes = lmaxk + 8*(pud + 16L*(smax + 1) + 128L*scr) + 64;
-          S.lf_pf_lds = 0;
-          if(bytes <= SYM_FAC_LDS_BUDGET && smax <= 512 && lmax <= 16384)
-          { S.lf_pf_lds = (int)bytes; S.lf_pf_b = (int)lmaxk; S.lf_pf_pud = (int)pud; S.lf_pf_scr = scr; }
-        }
-      }
-      // Jt*x of the ancestors' blocks
-      S.lf_jf_ptr.assign(1, 0);
-      for(int v = 0; v < nvb; v++)
-      {
-        if(jent[v].empty()) continue;
-        const int i = (int)S.lf_jf_var0.size();
-        S.lf_jf_ent.insert(S.lf_jf_ent.end(), jent[v].begin(), jent[v].end());
-        S.lf_jf_ptr.push_back((int)S.lf_jf_ent.size());
-        S.lf_jf_var0.push_back(S.vb_start[v]); S.lf_jf_w.push_back(G.w[v]);
-        (jent[v].size() <= 64 ? S.lf_jf_short : S.lf_jf_long).push_back(i);
-      }
-      return true; };
-    S.lf_ok = build();
-    if(!S.lf_ok) { S.lf_leaf.clear(); S.lf_blob.clear(); S.lf_jtp_size = 0; S.lf_lds = 0; S.lf_stride = 0; S.lf_pf_lds = 0; std::fill(S.lf_col.begin(), S.lf_col.end(), 0); }
-    if(env_int("DOGLEG_AMD_SYM_DEBUG", 0) >= 1)
-    {
-      size_t naff = 0, nt = 0;
-      for(const LfLeaf& L : S.lf_leaf)
-        for(int t = 0; t < L.ntask; t++) { nt++; naff += reinterpret_cast<const LfTask*>(&S.lf_blob[(size_t)L.blob + L.o_lds])[t].flags & 1; }
-      fprintf(stderr, "sym_analyze: leaf fronts %s%s (%zu leaves, %zu KB of schedule, %d bytes of LDS, %zu of %zu strips without a list)\n", S.lf_ok ? "on" : "off: ", S.lf_ok ? "" : S.lf_why,
-              S.lf_leaf.size(), S.lf_blob.size() >> 10, S.lf_lds, naff, nt);
-    }
   }
   SYM_TICK("done");
   return 0;

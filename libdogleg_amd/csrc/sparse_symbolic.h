@@ -190,64 +190,6 @@ struct FwItem
 struct MfChild { int64_t u_off, dst_off; int npad, rsv; };     // rsv: the child's work item (index into fw_item), -1 if it has none on this rank;
                                                                // in the one-launch region's copy: first workgroup of the child | its replicas << 20, -1: not in the launch
 
-// ---- leaf fronts (sparse_leaf.hip): a workgroup per merged leaf of the elimination tree reads the measurement
-// rows the leaf owns (a row belongs to the supernode of its first-eliminated variable), forms the leaf's front in
-// LDS -- member blocks, rows below, and the rows' direct contributions to the blocks of the ancestors --,
-// eliminates the members there and writes the final panel and the Schur-complemented update matrix.
-// A leaf's rows are staged in LDS "slots" (16 doubles: the row's entries, x of the row at position 15), member
-// after member, a member's row-blocks sorted by where their other blocks go: the rows of a strip are then
-// usually an arithmetic pattern of slots (a member's: consecutive; a camera's: one row-block per member at a
-// constant stride) and need no list.  The schedule of a leaf is one blob:
-//   staging table (read from HBM only), in the order of the rows in J (coalesced loads):
-//     int32 sval[nslots] (first value | entries << 28), srow[nslots], uint16 sdst[nslots] (the slot);
-//     the same by slot (the persistent form copies a leaf's rows in the order of their slots): int32 sval_s[nslots], srow_s[nslots]
-//   the part copied to LDS verbatim:
-//     LfTask task[ntask + ncomb]       strip tasks in the order the waves take them (wave v: v, v + #waves, ...),
-//                                      then the records of the split strips (where their sum goes)
-//     LfComb comb[ncomb]               split strips: the partial strips to add up, in order
-//     uint32 rbh[nrb]                  row-blocks (member-major): slot0 | rows << 16 | entries per row << 24
-//     uint8  fi[nrb][16]               below index of every window position of a row-block (transient destinations)
-//     uint16 lists                     rows / row-blocks of the tasks that are no arithmetic pattern
-// A strip task forms  sum over its rows of  row' * row[column block]:  16 window positions (the row's entries,
-// x of the row at position 15) x wj columns.  Member strips go to the panel (below rows, augmented row) and the
-// member's diagonal block; strips of a block of the ancestors go to the packed update matrix (rows >= column)
-// and, position 15, to the leaf's Jt*x record.  A window position is PERSISTENT (every row of the task sends
-// it to the same place: summed in a register over the task) or TRANSIENT (a different place per row-block,
-// each exactly once: the camera x point blocks of a bundle adjustment).
-struct LfLeaf
-{
-  int32_t blob, blob_bytes;  // byte offset (16-byte aligned) and size of the schedule blob
-  int32_t o_lds, lds_bytes;  // the part that is copied to LDS (offset inside the blob, size; both multiples of 16)
-  int32_t nslots, ntask, ncomb, nscr;   // rows staged, tasks, combine records, scratch slots (128 doubles each)
-  int32_t o_task, o_comb, o_rbh, o_fi;  // byte offsets inside the LDS part
-  int32_t jtp;               // first entry of the leaf's Jt*x record (mb - 1 doubles)
-  // the leaf's work item (FwItem), the fields the kernel needs
-  int32_t w, nrows, col0, bd0, nbd, bdw;
-  int32_t nrb;
-  int64_t lx, u_off;
-};
-static_assert(sizeof(LfLeaf) == 96, "LfLeaf layout");
-struct LfTask
-{
-  uint16_t plist, nprow;     // rows of the strip: nprow of them; flags & 1: slots a_slot0 + o*a_stride + r (o < a_nout, r < a_nin),
-                             // else a flat list of slots (offset in uint16 units from the start of the LDS part, padded to 4 with the zero row)
-  uint16_t tlist, ntrb;      // transient part: ntrb row-blocks (0: none); flags & 2: tlist, tlist + 1, ...; else a list at tlist (uint16 units)
-  uint16_t col0;             // member strip: first column of the member inside the leaf; else below index of the block's first row
-  uint8_t  kj, wj;           // position of the column block inside a row, its width
-  uint8_t  kind;             // 0 member strip, 1 strip of an ancestor's block, 2 part of a split one (-> scratch slot scr)
-  uint8_t  scr, flags, hh;   // hh: rows per row-block of the transient part if they all have as many (row-block q: slots a_slot0 + q*hh), else 0
-  uint16_t a_slot0, a_nout, a_stride, a_nin;
-  // "rider": a block of the ancestors that every row of the leaf holds (the global variables of a bundle adjustment)
-  // has no strip tasks of its own where the strips of other blocks visit every row exactly once: they carry its
-  // columns as rwj extra B columns (row position rkj) and leave their share of its strip in scratch slot scr
-  uint8_t  rkj, rwj;
-  uint16_t pad2[3];
-  uint8_t  pd[32];           // pd[k], k < 16: where window position k goes -- below index, 0xFF skip, 0xFE transient, 0xFD the column
-                             // block's own rows (member strips), 0xFC the Jt*x record; pd[16 + t]: the transient positions; pd[31]: how many
-};
-static_assert(sizeof(LfTask) == 64, "LfTask layout");
-struct LfComb { uint16_t task, scr0, nscr, pad; };   // task: a kind-1 record (never run as a task) that says where the sum goes
-
 struct SymHost
 {
   int N = 0, M = 0, nnz = 0;
@@ -347,25 +289,6 @@ struct SymHost
   std::vector<int>      asm_pdest;
   std::vector<int>      asm_tdest;   // row offset in J's panel of every (row-block, transient ordinal)
   int64_t asm_part_size = 0;
-  // ---- leaf fronts (see LfLeaf above); lf_ok: every local row is owned by a level-0 merged leaf and every
-  // strip has one layout -- the assembly and the leaves' factorisation are ONE kernel
-  bool lf_ok = false;
-  std::vector<LfLeaf>  lf_leaf;      // same order as the level-0 work items
-  std::vector<uint8_t> lf_blob;
-  int64_t lf_jtp_size = 0;
-  int lf_lds = 0;                     // bytes of LDS of the largest leaf
-  // the blobs at one stride, their staging tables padded to lf_smax rows and their LDS parts at offset lf_tb: a workgroup
-  // finds its table and its schedule from its index alone -- the loads do not wait for the leaf's record (0: not so)
-  int lf_stride = 0, lf_smax = 0, lf_tb = 0;
-  // the persistent form of the kernel (a workgroup per CU, the next leaf's rows copied into LDS under the current
-  // leaf's elimination): one LDS layout for all leaves -- schedule (lf_pf_b bytes), then panel / update matrix / member
-  // blocks (lf_pf_pud doubles), rows (lf_smax + 1 of them), scratch (lf_pf_scr slots); lf_pf_lds bytes, 0: not available
-  int lf_pf_lds = 0, lf_pf_b = 0, lf_pf_pud = 0, lf_pf_scr = 0;
-  // Jt*x of the ancestors' blocks: block i (first variable lf_jf_var0[i], lf_jf_w[i] of them) sums the leaves' records
-  // lf_jf_ent[lf_jf_ptr[i] .. lf_jf_ptr[i+1]) (first entry in the record buffer) in that order; short / long lists
-  std::vector<int> lf_jf_ptr, lf_jf_ent, lf_jf_var0, lf_jf_w, lf_jf_short, lf_jf_long;
-  std::vector<char> lf_col;           // [N] 1: the column (elimination position) belongs to a leaf front
-  char lf_why[160] = "";              // why lf_ok is false (diagnostics)
   // ---- forward-solve gather lists
   std::vector<int> rl_ptr;           // [N+1]
   std::vector<int> rl_pos;           // scratch positions feeding row k

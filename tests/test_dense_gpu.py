@@ -178,10 +178,8 @@ def test_syrk_and_potrf_kernels(gpu):
         assert np.max(np.abs(Lg - Lref)) <= 1e-11 * np.max(np.abs(Lref)), n
 
 
-@pytest.mark.parametrize("env", [{"DOGLEG_AMD_NO_OVERLAP": "1"}, {"DOGLEG_AMD_NO_K3_FORK": "1"},
-                                 {"DOGLEG_AMD_POTRF_STEPS": "1"}, {"DOGLEG_AMD_POTRF_STEPS": "1", "DOGLEG_AMD_NO_POTRF_FUSE": "1"},
-                                 {"DOGLEG_AMD_TRSV_STEPS": "1"}, {"DOGLEG_AMD_NO_POTRF_SELF": "1"}],
-                         ids=["no-overlap", "no-k3-fork", "potrf-steps", "potrf-steps-unfused", "trsv-steps", "potrf-blocks-from-owners"])
+@pytest.mark.parametrize("env", [{"DOGLEG_AMD_NO_OVERLAP": "1"}, {"DOGLEG_AMD_POTRF_STEPS": "1"}, {"DOGLEG_AMD_TRSV_STEPS": "1"}],
+                         ids=["no-overlap", "potrf-steps", "trsv-steps"])
 def test_dense_stream_variants_match_oracle(gpu, env, monkeypatch):
     """the two-stream variant of the dense path (the Cauchy step beside the factorisation), the step forms of potrf / trsv
     and their single-stream forms give the oracle's Gauss-Newton step"""
@@ -203,34 +201,6 @@ def test_dense_stream_variants_match_oracle(gpu, env, monkeypatch):
     assert np.linalg.norm(gn - work[2*N:3*N]) <= 1e-10
     assert abs(n2c - o8[1]) <= 1e-10 * o8[1]
     be.close()
-
-
-def test_fused_diagonal_block_launch_changes_no_bit(gpu, monkeypatch):
-    """the diagonal block of a potrf step and the rows below it in one launch (the inverse of the block
-    handed over through a flag, dense_diag.hip) leave the same factor as the two launches, bit for bit,
-    over repeated factorisations"""
-    monkeypatch.setenv("DOGLEG_AMD_POTRF_STEPS", "1")        # (the step-by-step form; the one-launch form: next test)
-    dp = oa.DenseProblem(M=2500, N=521, seed=4)
-    p = dp.p0()
-    evals = [dp.eval(p + 0.01*k) for k in range(3)]
-    out = {}
-    for fused in (True, False):
-        monkeypatch.delenv("DOGLEG_AMD_NO_POTRF_FUSE", raising=False)
-        if not fused:
-            monkeypatch.setenv("DOGLEG_AMD_NO_POTRF_FUSE", "1")
-        be = capi.Backend(capi.DLG_DENSE, dp.N, dp.M)
-        be.set_p(0, p)
-        res = []
-        for rep in range(4):
-            for x, J in evals:
-                be.upload(0, x, J)
-                be.eval(0)
-                lam, n2g = be.gauss_newton(0, 0.0)
-                res.append((n2g, be.download(0, capi.VEC_GN)))
-        out[fused] = res
-        be.close()
-    for a, b in zip(out[True], out[False]):
-        assert a[0] == b[0] and np.array_equal(a[1], b[1])
 
 
 @pytest.mark.parametrize("N", [130, 521, 1000])

@@ -153,3 +153,37 @@ def test_a_backend_taken_over_serves_the_same_and_another_pattern_of_its_shape(g
         compare_traces(trg, tro)
         assert np.max(np.abs(pg - po)) <= 1e-10, k
         assert twin.neval() in (tro.ncallbacks, tro.ncallbacks + 1), (k, twin.neval(), tro.ncallbacks)
+
+
+def test_work_between_a_step_and_its_wait_changes_no_iterate(gpu, monkeypatch):
+    """dlg_backend_set_between (driver.hip: the model's kernels for the trial point and the backend's first pass over its
+    Jacobian go onto the stream from inside the step, in front of the host's wait for the step's scalars) against
+    DOGLEG_AMD_NO_BETWEEN=1 (evaluation enqueued when the host is back, as in rounds 1 - 5): the same kernels on the same
+    data -- every trial the same bits, the same final p; without it the model is evaluated exactly as often as the
+    reference evaluates it, with it at most once more (the point behind a step that ends the solve).  And where the time of
+    a solve goes (DOGLEG_AMD_TIMING=1, dogleg_amd_last_solve_timing): the callback's count is the trace's."""
+    monkeypatch.setenv("DOGLEG_AMD_NO_BACKEND_CACHE", "1")
+    monkeypatch.setenv("DOGLEG_AMD_TIMING", "1")
+    prob = oa.BAProblem(49, 900, 10000, seed=4, eps=0.4, p0_spread=0.6)
+    Jp, Ji = prob.pattern()
+    prm = oa.default_params()
+    prm.max_iterations = 12
+    prm.trustregion0 = 3.0
+    p0 = prob.p0()
+    ro, po, tro = oa.oracle_solve("sparse", p0, prob.N, prob.M, prob.nnz, prob.cb, prob.cookie, prm)
+    out = {}
+    for between in (True, False):
+        if between:
+            monkeypatch.delenv("DOGLEG_AMD_NO_BETWEEN", raising=False)
+        else:
+            monkeypatch.setenv("DOGLEG_AMD_NO_BETWEEN", "1")
+        twin = oa.DeviceTwin(prob)
+        r, p, tr = capi.optimize_device(p0, prob.N, prob.M, prob.nnz, Jp, Ji, twin.cb, twin.cookie, prm)
+        tm = capi.last_solve_timing()
+        assert r >= 0
+        compare_traces(tr, tro)
+        assert tm["run_optimizer"][0] > 0.0 and tm["point_eval"][1] == tr.ncallbacks == tro.ncallbacks
+        out[between] = (r, p, [t["norm2_step"] for t in tr.trials()], [t["expected_improvement"] for t in tr.trials()], twin.neval())
+    assert out[True][0] == out[False][0] and np.array_equal(out[True][1], out[False][1])
+    assert out[True][2] == out[False][2] and out[True][3] == out[False][3]
+    assert out[False][4] == tro.ncallbacks and out[True][4] in (tro.ncallbacks, tro.ncallbacks + 1)

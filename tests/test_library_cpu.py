@@ -372,49 +372,6 @@ def test_one_launch_region_schedule_invariants(shape, ncu, monkeypatch):
         monkeypatch.delenv(knob)
 
 
-@pytest.mark.parametrize("env", [{}, {"DOGLEG_AMD_LF_LISTS": "1"}, {"DOGLEG_AMD_LF_NO_RIDER": "1"}, {"DOGLEG_AMD_LF_NO_STRIDE": "1"}],
-                         ids=["default", "row-lists", "no-rider", "no-stride"])
-@pytest.mark.parametrize("shape", [dict(Nc=49, Np=900, Nobs=10000), dict(Nc=40, Np=800, Nobs=8777, g=4)], ids=["ba", "ragged"])
-def test_leaf_front_schedules_form_the_fronts(shape, env, monkeypatch):
-    """Leaf fronts (DOGLEG_AMD_LEAF_FRONT=1; sparse_leaf.hip): a workgroup per merged leaf forms the leaf's front from
-    its measurement rows by a schedule it trusts blindly -- staging table, strip tasks with arithmetic row patterns or
-    lists, persistent and transient destinations, riders, split strips.  dlg_sparse_leaf_probe EXECUTES every leaf's
-    schedule on the CPU the way the kernel reads it and compares panel rows, member blocks, the direct contributions
-    to the update matrix and the Jt*x shares with the sums taken straight from the pattern."""
-    monkeypatch.setenv("DOGLEG_AMD_LEAF_FRONT", "1")
-    monkeypatch.setenv("DOGLEG_AMD_SYRK_MIN", "1")
-    for k, v in env.items():
-        monkeypatch.setenv(k, v)
-    prob = oa.BAProblem(**shape, seed=13)
-    Jp, Ji = prob.pattern()
-    x, Jx = prob.eval(prob.p0())
-    st, err = capi.leaf_probe(prob.N, prob.M, Jp, Ji, Jx, x)
-    assert st.get("error") is None, st
-    assert st["leaf_fronts"] == 1 and st["leaves"] > 0 and st["lds_bytes"] <= 160 * 1024
-    assert err <= 1e-14, err
-    if "DOGLEG_AMD_LF_LISTS" in env:
-        assert st["strips_without_list"] == 0
-    elif not env:
-        assert st["strips_without_list"] == st["strips"] and st["strips_with_rider"] > 0
-    if "DOGLEG_AMD_LF_NO_RIDER" in env:
-        assert st["strips_with_rider"] == 0
-
-
-def test_leaf_fronts_are_opt_in_and_refuse_what_they_cannot_do(monkeypatch):
-    prob = oa.BAProblem(49, 900, 10000, seed=13)
-    Jp, Ji = prob.pattern()
-    monkeypatch.setenv("DOGLEG_AMD_SYRK_MIN", "1")
-    assert capi.symbolic_probe(prob.N, prob.M, Jp, Ji)["leaf_fronts"] == 0            # not asked for
-    monkeypatch.setenv("DOGLEG_AMD_LEAF_FRONT", "1")
-    assert capi.symbolic_probe(prob.N, prob.M, Jp, Ji)["leaf_fronts"] == 1
-    assert capi.symbolic_probe(prob.N, prob.M, Jp, Ji, row0=0, row1=prob.M // 2)["leaf_fronts"] == 0     # sharded rows
-    # a pattern with rows that no leaf owns (sample.c: every row touches every variable): the separate kernels stay
-    P = oa.problems()
-    Jp2 = np.arange(0, 601, 6, dtype=np.int32)
-    Ji2 = np.tile(np.arange(6, dtype=np.int32), 100)
-    assert capi.symbolic_probe(6, 100, Jp2, Ji2)["leaf_fronts"] == 0
-
-
 def test_subtree_partition_rows_form_closed_subtrees():
     """the property the partition rests on: a rank's rows touch only its own subtrees' variables and
     the replicated ones -- so J_r' J_r of rank r is zero in every (variable of another rank, *) entry"""
@@ -549,3 +506,18 @@ def test_id_file_rendezvous_between_two_processes(tmp_path):
     assert L.dogleg_amd_id_file_wait(path.encode(), out, b"launch-3", 300) == -1
     assert time.time() - t0 < 5
     assert L.dogleg_amd_id_file_wait(None, out, b"", 10) == -1
+
+
+def test_symbolic_debug_output_changes_nothing(monkeypatch, capfd):
+    """DOGLEG_AMD_SYM_DEBUG (1: what the symbolic phase decided, 2: + the wall time of its steps, on stderr) is a
+    diagnostic: the schedules are the same"""
+    prob = oa.BAProblem(20, 300, 3000, seed=3)
+    Jp, Ji = prob.pattern()
+    monkeypatch.delenv("DOGLEG_AMD_SYM_DEBUG", raising=False)
+    a = capi.symbolic_probe(prob.N, prob.M, Jp, Ji)
+    capfd.readouterr()
+    monkeypatch.setenv("DOGLEG_AMD_SYM_DEBUG", "2")
+    b = capi.symbolic_probe(prob.N, prob.M, Jp, Ji)
+    err = capfd.readouterr().err
+    assert a == b
+    assert "sym_analyze" in err or "ms" in err

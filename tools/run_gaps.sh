@@ -10,6 +10,4 @@ cat $O/gaps_on.txt
 timeout 900 python3 -m pytest tests/test_sparse_gpu.py -x -q -m gpu -k "ahead or take_step or speculative or fused" > $O/tests.txt 2>&1; tail -3 $O/tests.txt
 for i in 1 2; do
 timeout 300 python3 bench.py --no-cpu-baseline > $O/bench_on_$i.json 2>>$O/err.txt; python3 tools/pj.py < $O/bench_on_$i.json
-DOGLEG_AMD_NO_EXT_EVENTS=1 timeout 300 python3 bench.py --no-cpu-baseline > $O/bench_off_$i.json 2>>$O/err.txt; python3 tools/pj.py < $O/bench_off_$i.json
 done
-DOGLEG_AMD_LEAF_FRONT=1 timeout 300 python3 bench.py --no-cpu-baseline > $O/bench_lf.json 2>>$O/err.txt; python3 tools/pj.py < $O/bench_lf.json

@@ -4,9 +4,6 @@ export TMPDIR=/tmp; cd "$(dirname "$0")/.." || exit 1
 out=gpurun_out/${1:-soak2}; mkdir -p $out
 timeout 600 python3 tools/soak_steps.py 3000 sparse-1m > $out/soak_1m.log 2>&1; tail -2 $out/soak_1m.log
 timeout 600 python3 tools/soak_steps.py 4000 sparse-200k > $out/soak_200k.log 2>&1; tail -2 $out/soak_200k.log
-DOGLEG_AMD_LEAF_FRONT=1 timeout 600 python3 tools/soak_steps.py 3000 sparse-1m > $out/soak_lf_1m.log 2>&1; tail -2 $out/soak_lf_1m.log
 timeout 900 python3 tools/stress_patterns.py 120 9000 > $out/stress.log 2>&1; tail -2 $out/stress.log
-DOGLEG_AMD_LEAF_FRONT=1 timeout 900 python3 tools/stress_patterns.py 120 9500 > $out/stress_lf.log 2>&1; tail -2 $out/stress_lf.log
 timeout 900 python3 tools/stress_dense.py > $out/stress_dense.log 2>&1; tail -2 $out/stress_dense.log
 timeout 900 python3 tools/stress_solves.py > $out/stress_solves.log 2>&1; tail -2 $out/stress_solves.log
-DOGLEG_AMD_LEAF_FRONT=1 timeout 1500 python3 -m pytest tests -m gpu -x -q 2>&1 | tail -2

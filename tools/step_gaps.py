@@ -7,7 +7,7 @@ def short(n):
     n = n.replace('(anonymous namespace)::', '').replace('void ', '')
     return n.split('(')[0][:34]
 # steps delimited by the assembly kernel
-idx = [i for i, r in enumerate(rows) if 'k_assemble_mfma' in r['Kernel_Name'] or 'k_leaf_front' in r['Kernel_Name']]
+idx = [i for i, r in enumerate(rows) if 'k_assemble_mfma' in r['Kernel_Name']]
 if not idx:        # a dense workload: a step begins with the pass that forms Jt*x
     idx = [i for i, r in enumerate(rows) if 'k_gemvT_part' in r['Kernel_Name']]
 k = int(sys.argv[2]) if len(sys.argv) > 2 else -3

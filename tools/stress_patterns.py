@@ -10,8 +10,7 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 5000
 scale = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 knobs = ["DOGLEG_AMD_RIDER_MIN", "DOGLEG_AMD_SYRK_MIN", "DOGLEG_AMD_SLICE_CAP", "DOGLEG_AMD_ASM_MFMA",
-         "DOGLEG_AMD_RUN_KG", "DOGLEG_AMD_UNIT_COST", "DOGLEG_AMD_ND_LEAF", "DOGLEG_AMD_SIB_W",
-         "DOGLEG_AMD_MF_LEVEL", "DOGLEG_AMD_MF_MAXM", "DOGLEG_AMD_MF_NT", "DOGLEG_AMD_NO_PERSIST",
+         "DOGLEG_AMD_ND_LEAF", "DOGLEG_AMD_MF_LEVEL", "DOGLEG_AMD_MF_NT", "DOGLEG_AMD_NO_PERSIST",
          "DOGLEG_AMD_PERSIST_MAX", "DOGLEG_AMD_NO_PREMUL", "DOGLEG_AMD_NO_LEAF_KERNEL"]
 bad = 0
 for s in range(seed0, seed0 + n):
@@ -23,12 +22,8 @@ for s in range(seed0, seed0 + n):
     if rng.random() < 0.5: cfg["DOGLEG_AMD_SYRK_MIN"] = str(int(rng.choice([0, 1, 2, 4])))
     if rng.random() < 0.4: cfg["DOGLEG_AMD_SLICE_CAP"] = str(int(rng.choice([1500, 3000, 6000])))
     if rng.random() < 0.15: cfg["DOGLEG_AMD_ASM_MFMA"] = "0"
-    if rng.random() < 0.3: cfg["DOGLEG_AMD_RUN_KG"] = str(int(rng.choice([4, 8, 64])))
-    if rng.random() < 0.3: cfg["DOGLEG_AMD_UNIT_COST"] = str(int(rng.choice([64, 128, 2048])))
     if rng.random() < 0.3: cfg["DOGLEG_AMD_ND_LEAF"] = str(int(rng.choice([8, 40, 200])))
-    if rng.random() < 0.3: cfg["DOGLEG_AMD_SIB_W"] = str(int(rng.choice([0, 16, 64])))
     if rng.random() < 0.5: cfg["DOGLEG_AMD_MF_LEVEL"] = str(int(rng.choice([-1, 0, 0, 2, 3])))
-    if rng.random() < 0.3: cfg["DOGLEG_AMD_MF_MAXM"] = str(int(rng.choice([8, 40, 100])))
     if rng.random() < 0.3: cfg["DOGLEG_AMD_MF_NT"] = str(int(rng.choice([128, 256, 512])))
     if rng.random() < 0.2: cfg["DOGLEG_AMD_NO_PERSIST"] = "1"
     if rng.random() < 0.3: cfg["DOGLEG_AMD_PERSIST_MAX"] = str(int(rng.choice([2, 8, 100000])))
