@@ -31,6 +31,9 @@
 #ifndef DLG_PF_EVT           // tools/micro/bench_panel: time stamps of the hand-overs between the waves of panel_factor_b16
 #define DLG_PF_EVT(J, e)
 #endif
+#ifndef DLG_PF_WLOG          // tools/micro/bench_panel -DBP_WLOG: every wave's own log of (block, tile, event, clock)
+#define DLG_PF_WLOG(J, t, e)
+#endif
 
 // 1/sqrt(d) for d > 0: hardware v_rsq_f64 seed (about 1e-8 relative) + two Newton
 // steps (relative error ~1e-16).  The pivot sqrt(d) = d * rsqrt(d) and its reciprocal
@@ -598,6 +601,103 @@ __device__ __forceinline__ void pf_b16_vector_finish(double* P, int ldp, int nro
   __syncthreads();
   DLG_PF_STAMP(11);
 }
+// One to THREE row tiles of a helper wave in block J (tiles t1, t1 + dt, t1 + 2 dt -- all strictly below the next diagonal
+// tile): brought up to date against the columns before the block, multiplied with L_JJ^-T, stored.  Round 6: a wave with
+// two tiles used to finish one before it began the other -- every k-step four LDS reads, a round trip, two MFMAs -- and
+// such waves, not wave 0's pivot chain, set the pace of a 187 x 60 sweep (they ran a whole block behind:
+// tools/micro/bench_panel -DBP_WLOG).  All tiles of the wave in ONE loop: the diagonal tile's rows (the A operand) are
+// read once for all, 2 NTL MFMAs hide a round trip instead of two.  Every tile keeps its own accumulator chain with the
+// same products in the same order: the same bits as one tile at a time.  foreign: the tiles belonged to other waves in the
+// blocks before this one: their rows are waited for.  (Tried with it, round 6: the LAST block's tiles dealt out anew over all
+// eight waves, wave 4 and -- behind its last step -- wave 0 included: wave 4's products slow wave 0's chain by more than
+// the end of the sweep gains, 18.9 against 18.5 us on 187 x 60, 22.0 against 21.1 on 193 x 66.  Not kept.)
+template <int NTL>
+__device__ __forceinline__ void pf_b16_normal_tiles(double* P, int ldp, int nrows, pf_b16_lds& S, int J, int kb, int nb, int t1, int dt,
+                                                    int lane, int mm, int kq, bool foreign = false)
+{
+  const dlg_pf_v4d zero4 = {0.0, 0.0, 0.0, 0.0};
+  int r0[NTL], rowc[NTL];
+#pragma unroll
+  for(int q = 0; q < NTL; q++) { r0[q] = 16*(t1 + q*dt); rowc[q] = min(r0[q] + mm, nrows - 1); }
+  DLG_PF_WLOG(J, t1, 0);
+  if(foreign && J > 0)
+  {
+#pragma unroll
+    for(int q = 0; q < NTL; q++) pf_wait(&S.tdone[t1 + q*dt], J);
+  }
+  dlg_pf_v4d acc[NTL];
+#pragma unroll
+  for(int r = 0; r < 4; r++)
+  {
+    const int col = kq + 4*r, cc = kb + (col < nb ? col : 0);
+#pragma unroll
+    for(int q = 0; q < NTL; q++) { const double v = P[rowc[q] + cc*ldp]; acc[q][r] = (col < nb) ? v : 0.0; }
+  }
+  if(J > 0)
+  {
+    pf_wait(&S.tdone[J], J);
+    const double* ap = P + kb + (mm < nb ? mm : 0) + kq*ldp;        // rows of the diagonal tile
+    double a0 = ap[0], a1 = ap[4*ldp], b0[NTL], b1[NTL];
+#pragma unroll
+    for(int q = 0; q < NTL; q++) { const double* bp = P + rowc[q] + kq*ldp; b0[q] = bp[0]; b1[q] = bp[4*ldp]; }
+    for(int k0 = 0; k0 < kb; k0 += 8)
+    {
+      const int kn = (k0 + 8 < kb) ? k0 + 8 : k0;
+      const double na0 = ap[kn*ldp], na1 = ap[(kn + 4)*ldp];
+      double nb0[NTL], nb1[NTL];
+#pragma unroll
+      for(int q = 0; q < NTL; q++) { const double* bp = P + rowc[q] + kq*ldp; nb0[q] = bp[kn*ldp]; nb1[q] = bp[(kn + 4)*ldp]; }
+      __builtin_amdgcn_sched_barrier(0);
+      const double va0 = (mm < nb) ? a0 : 0.0, va1 = (mm < nb) ? a1 : 0.0;
+#pragma unroll
+      for(int q = 0; q < NTL; q++) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(va0, b0[q], acc[q], 0, 0, PF_NEG_A);
+#pragma unroll
+      for(int q = 0; q < NTL; q++) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(va1, b1[q], acc[q], 0, 0, PF_NEG_A);
+      __builtin_amdgcn_sched_barrier(0);
+      a0 = na0; a1 = na1;
+#pragma unroll
+      for(int q = 0; q < NTL; q++) { b0[q] = nb0[q]; b1[q] = nb1[q]; }
+    }
+  }
+  DLG_PF_WLOG(J, t1, 1);
+  // times L_JJ^-T: Y'[i][j] = sum_c W[i][c] S[r0 + j][kb + c]
+  pf_wait(&S.wdone, J + 1);
+  DLG_PF_WLOG(J, t1, 2);
+  const double* Wr = S.W[J & 1] + mm*PF_B16_WS + kq;
+  const double w0 = Wr[0], w1 = Wr[4], w2 = Wr[8], w3 = Wr[12];
+  dlg_pf_v4d y0[NTL], y1[NTL];
+#pragma unroll
+  for(int q = 0; q < NTL; q++) { y0[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(w0, acc[q][0], zero4, 0, 0, 0); y1[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(w2, acc[q][2], zero4, 0, 0, 0); }
+#pragma unroll
+  for(int q = 0; q < NTL; q++) { y0[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(w1, acc[q][1], y0[q], 0, 0, 0); y1[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(w3, acc[q][3], y1[q], 0, 0, 0); }
+#pragma unroll
+  for(int r = 0; r < 4; r++)
+  {
+    const int col = kq + 4*r;
+#pragma unroll
+    for(int q = 0; q < NTL; q++) if(r0[q] + mm < nrows && col < nb) P[(r0[q] + mm) + (kb + col)*ldp] = y0[q][r] + y1[q][r];
+  }
+  pf_wave_sync();
+  if(lane == 0)
+  {
+#pragma unroll
+    for(int q = 0; q < NTL; q++) __hip_atomic_store(&S.tdone[t1 + q*dt], J + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
+  DLG_PF_WLOG(J, t1, 3);
+}
+// a wave's tiles t, t + dt, ... < tend of block J, three / two / one at a time
+__device__ __forceinline__ void pf_b16_tile_run(double* P, int ldp, int nrows, pf_b16_lds& S, int J, int kb, int nb, int t, int dt, int tend,
+                                                int lane, int mm, int kq, bool foreign)
+{
+  while(t < tend)
+  {
+#ifndef DLG_PF_NO_PAIRS
+    if(t + 2*dt < tend) { pf_b16_normal_tiles<3>(P, ldp, nrows, S, J, kb, nb, t, dt, lane, mm, kq, foreign); t += 3*dt; continue; }
+    if(t + dt < tend)   { pf_b16_normal_tiles<2>(P, ldp, nrows, S, J, kb, nb, t, dt, lane, mm, kq, foreign); t += 2*dt; continue; }
+#endif
+    pf_b16_normal_tiles<1>(P, ldp, nrows, S, J, kb, nb, t, dt, lane, mm, kq, foreign); t += dt;
+  }
+}
 template <int NT>
 __device__ __forceinline__ void panel_factor_b16(double* P, int ldp, int nrows, int w_all, int tid,
                                                  int* __restrict__ info, int col0)
@@ -696,6 +796,7 @@ __device__ __forceinline__ void panel_factor_b16(double* P, int ldp, int nrows, 
       if(lane == 0) __hip_atomic_store(&S.wdone, J + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
       DLG_PF_STAMP(1);
       DLG_PF_EVT(J, 1);
+      DLG_PF_WLOG(J, 0, 5);
       if(J + 1 < nblk)
       {
         // the next diagonal tile: its rows in the columns of this block times L_JJ^-T, here, in registers -- the
@@ -725,6 +826,7 @@ __device__ __forceinline__ void panel_factor_b16(double* P, int ldp, int nrows, 
         pf_wave_sync();
         if(lane == 0) __hip_atomic_store(&S.tdone[J + 1], J + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         DLG_PF_EVT(J, 3);
+        DLG_PF_WLOG(J, J + 1, 6);
         // (for the check in front of the next block's first store into the other buffer: tiles > J - 1 at >= J)
         tv_ahead = (lane < ntr && lane > J - 1) ? __hip_atomic_load(&S.tdone[lane], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) : 0x7fffffff;
       }
@@ -738,15 +840,25 @@ __device__ __forceinline__ void panel_factor_b16(double* P, int ldp, int nrows, 
     for(int J = 0; J < nblk; J++)
     {
       const int kb = 16*J, nb = min(16, w - kb);
-      for(int t = (h + 1) % NH; t < ntr; t += NH)
+      // The wave's tiles of this block in increasing order.  The special ones -- the block's own tile below a short top block,
+      // the next diagonal tile (handed to wave 0 half-finished: it is waited for) -- one at a time, as before; the others two
+      // at a time (pf_b16_normal_tiles)
+      int t = (h + 1) % NH;
+      while(t < ntr && t < J) t += NH;
+      for(; t < ntr; )
       {
-        // tiles below the block; in a short (last) block also the rows of the block's own tile below the top block
         const bool own = t == J && nb < 16 && nrows > kb + nb;
-        if(t < J || (t == J && !own)) continue;
         const bool next = t == J + 1 && J + 1 < nblk;        // the next diagonal tile: wave 0 finishes it
+        if(t == J && !own) { t += NH; continue; }
+        if(!own && !next)
+        {
+          pf_b16_tile_run(P, ldp, nrows, S, J, kb, nb, t, NH, ntr, lane, mm, kq, false);
+          break;
+        }
         const int r0 = 16*t, rowc = min(r0 + mm, nrows - 1);
         const int nb1 = min(16, w - r0);
         if(next) { DLG_PF_EVT(J, 4); }
+        DLG_PF_WLOG(J, t, 0);
         // the tile TRANSPOSED: register r, lane (n, kq) = S[r0 + n][kb + kq + 4 r]
         dlg_pf_v4d acc, E = zero4;
 #pragma unroll
@@ -782,6 +894,7 @@ __device__ __forceinline__ void panel_factor_b16(double* P, int ldp, int nrows, 
             a0 = na0; b0 = nb0; a1 = na1; b1 = nb1v;
           }
         }
+        DLG_PF_WLOG(J, t, 1);
         if(next)
         {
 #pragma unroll
@@ -789,10 +902,13 @@ __device__ __forceinline__ void panel_factor_b16(double* P, int ldp, int nrows, 
           pf_wave_sync();
           if(lane == 0) __hip_atomic_store(&S.adone, J + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
           DLG_PF_EVT(J, 6);
+          DLG_PF_WLOG(J, t, 4);
+          t += NH;
           continue;
         }
         // times L_JJ^-T: Y'[i][j] = sum_c W[i][c] S[r0 + j][kb + c]
         pf_wait(&S.wdone, J + 1);
+        DLG_PF_WLOG(J, t, 2);
         const double* Wr = S.W[J & 1] + mm*PF_B16_WS + kq;
         const double w0 = Wr[0], w1 = Wr[4], w2 = Wr[8], w3 = Wr[12];
         dlg_pf_v4d y0 = __builtin_amdgcn_mfma_f64_16x16x4f64(w0, acc[0], zero4, 0, 0, 0);
@@ -807,6 +923,8 @@ __device__ __forceinline__ void panel_factor_b16(double* P, int ldp, int nrows, 
         }
         pf_wave_sync();
         if(lane == 0 && !own) __hip_atomic_store(&S.tdone[t], J + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        DLG_PF_WLOG(J, t, 3);
+        t += NH;
       }
     }
   }

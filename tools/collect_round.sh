@@ -21,7 +21,11 @@ DOGLEG_AMD_TIMING=1 timeout 600 python3 tools/e2e_bench.py --workload sparse-1m 
 # SQ counters of the assembly kernel (three passes of eight), the per-workgroup timeline of the one-launch factor region
 bash tools/run_sq.sh $tag/sq > $out/sq.log 2>&1
 cp gpurun_out/$tag/sq/sq_k4.txt $out/sq_k4.txt 2>/dev/null
+# round 6: the same counters for the dense JtJ kernel k_syrk_lower<64> (78 % of config #2's step)
+bash tools/run_sq_dense.sh $tag/sqd > $out/sqd.log 2>&1
+cp gpurun_out/$tag/sqd/sq_syrk.txt $out/sq_syrk.txt 2>/dev/null
 bash tools/run_prof.sh $tag/prof env > $out/top_of_tree_levels.txt 2>&1
+mkdir -p $out/prof5; DLG_FL_DUMP_ALL=1 DLG_FL_DUMP_N=32 bash tools/prof_factor.sh run --workload sparse-5m > $out/prof5/raw.txt 2>&1; python3 tools/pr_timeline.py $out/prof5/raw.txt > $out/top_of_tree_levels_config5.txt 2>&1
 python3 tools/k4_split.py > $out/k4_split.txt 2>&1; DLG_ASM_ONLY_SHAPE=0 python3 tools/k4_split.py >> $out/k4_split.txt 2>&1; DLG_ASM_ONLY_SHAPE=1 python3 tools/k4_split.py >> $out/k4_split.txt 2>&1
 timeout 300 python3 tools/gpu_probe.py > $out/probe.txt 2>&1
 # round 5: RCCL's cost per all-reduce at world size 1 (a process of its own), the dense triangular solves' hop timeline, the

@@ -14,6 +14,11 @@ __shared__ long long s_pf[16];
 #define DLG_PF_DONE if(threadIdx.x == 0 && g_pf_out) { for(int _i = 0; _i < 12; _i++) g_pf_out[_i] = s_pf[_i]; }
 __device__ long long g_evt[64*8];
 #define DLG_PF_EVT(J, e) do { if((threadIdx.x & 63) == 0 && blockIdx.x == 0) g_evt[(J)*8 + (e)] = clock64(); } while(0)
+#ifdef BP_WLOG
+// every wave's own log of the block-16 sweep: (block << 16 | tile << 8 | event, clock), workgroup 0 only
+__device__ long long g_wlog[8*512]; __device__ int g_wlog_n[8];
+#define DLG_PF_WLOG(J, t, e) do { if((threadIdx.x & 63) == 0 && blockIdx.x == 0) { const int _w = threadIdx.x >> 6; const int _n = g_wlog_n[_w]; if(_n < 255) { g_wlog[_w*512 + 2*_n] = ((long long)(J) << 16) | ((long long)(t) << 8) | (e); g_wlog[_w*512 + 2*_n + 1] = clock64(); g_wlog_n[_w] = _n + 1; } } } while(0)
+#endif
 #ifndef BP_LDP_EXTRA
 #define BP_LDP_EXTRA 0      // -DBP_LDP_EXTRA=16: the leading dimension of the LDS panel padded (bank layout experiments)
 #endif
@@ -128,6 +133,25 @@ void run(int nrows, int w, int G, int iters)
       if(i >= j) { if(dd > worst || dd != dd) { worst = dd; wi = i; wj = j; } big = fmax(big, fabs(r0[i + (size_t)j*nrows])); }
       else up = fmax(up, fabs(h[i + (size_t)j*nrows] - r5[i + (size_t)j*nrows]));
     }
+#ifdef BP_WLOG
+    {
+      // one more launch of workgroup 0 alone with the logs cleared, then every wave's events in time order
+      int zero[8] = {0,0,0,0,0,0,0,0}; hipMemcpyToSymbol(HIP_SYMBOL(g_wlog_n), zero, sizeof(zero));
+      hipMemcpy(d, h.data(), n*8, hipMemcpyHostToDevice);
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_panel<NT, 5>), dim3(1), dim3(NT), lds, 0, d, nrows, w, info, st);
+      hipDeviceSynchronize();
+      static long long lg[8*512]; int ln[8];
+      hipMemcpyFromSymbol(lg, HIP_SYMBOL(g_wlog), sizeof(lg)); hipMemcpyFromSymbol(ln, HIP_SYMBOL(g_wlog_n), sizeof(ln));
+      long long t0 = 0; for(int wv = 0; wv < 8; wv++) for(int k = 0; k < ln[wv]; k++) if(t0 == 0 || lg[wv*512 + 2*k + 1] < t0) t0 = lg[wv*512 + 2*k + 1];
+      const char* en[] = {"tile start", "updated", "inverse seen", "stored", "handed to wave 0", "inverse out", "next tile done"};
+      for(int wv = 0; wv < 8; wv++)
+        for(int k = 0; k < ln[wv]; k++)
+        {
+          const long long c = lg[wv*512 + 2*k]; const int J = (int)(c >> 16), t = (int)((c >> 8) & 255), e = (int)(c & 255);
+          printf("        wlog wave %d block %d tile %2d %-16s %7lld\n", wv, J, t, en[e], lg[wv*512 + 2*k + 1] - t0);
+        }
+    }
+#endif
     if(getenv("DLG_PF_EVENTS"))
     {
       long long ev[64*8]; hipMemcpyFromSymbol(ev, HIP_SYMBOL(g_evt), sizeof(ev));

@@ -16,7 +16,8 @@ for wl, short in names.items():
 for a, b in (("e2e_sparse1m.json", f"{tag}_e2e_sparse1m.json"), ("bench_dist_world1_rccl.log", f"{tag}_bench_dist_world1_rccl.log"),
              ("probe.txt", f"{tag}_probe.txt"), ("sq_k4.txt", f"{tag}_sq_k_assemble_mfma.txt"), ("k4_split.txt", f"{tag}_k4_split.txt"),
              ("top_of_tree_levels.txt", f"{tag}_top_of_tree_levels.txt"), ("e2e.err", f"{tag}_e2e_timing.txt"),
-             ("scaling_projection.md", f"{tag}_scaling_projection.md"), ("rccl_floor.json", f"{tag}_rccl_floor.json"), ("trsv_hops.txt", f"{tag}_trsv_hops.txt"), ("potrf_diag.txt", f"{tag}_potrf_diag.txt"), ("panel_sweep.txt", f"{tag}_panel_sweep.txt"), ("xcd_probe.txt", f"{tag}_xcd_probe.txt"), ("scaling_projection_sparse5m.md", f"{tag}_scaling_projection_sparse5m.md"), ("step_trace.txt", f"{tag}_step_trace.txt")):
+             ("scaling_projection.md", f"{tag}_scaling_projection.md"), ("rccl_floor.json", f"{tag}_rccl_floor.json"), ("trsv_hops.txt", f"{tag}_trsv_hops.txt"), ("potrf_diag.txt", f"{tag}_potrf_diag.txt"), ("panel_sweep.txt", f"{tag}_panel_sweep.txt"), ("xcd_probe.txt", f"{tag}_xcd_probe.txt"), ("scaling_projection_sparse5m.md", f"{tag}_scaling_projection_sparse5m.md"), ("step_trace.txt", f"{tag}_step_trace.txt"),
+             ("sq_syrk.txt", f"{tag}_sq_k_syrk_lower.txt"), ("top_of_tree_levels_config5.txt", f"{tag}_top_of_tree_levels_config5.txt")):
     if os.path.exists(os.path.join(src, a)):
         # (profiles/r04_sq_k_assemble_mfma.txt was published EMPTY and a text computed from it -- an empty source
         # is a failed collection step, not an artifact)
