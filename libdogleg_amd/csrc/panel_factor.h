@@ -613,8 +613,10 @@ __device__ __forceinline__ void pf_b16_vector_finish(double* P, int ldp, int nro
 // the end of the sweep gains, 18.9 against 18.5 us on 187 x 60, 22.0 against 21.1 on 193 x 66.  Not kept.)
 template <int NTL>
 __device__ __forceinline__ void pf_b16_normal_tiles(double* P, int ldp, int nrows, pf_b16_lds& S, int J, int kb, int nb, int t1, int dt,
-                                                    int lane, int mm, int kq, bool foreign = false)
+                                                    int lane, int mm, int kq, bool foreign = false, bool own_first = false)
 {
+  // (own_first: the first tile is the block's own tile below a short top block -- only its rows past the block are stored,
+  // and it is nobody's tile to wait for)
   const dlg_pf_v4d zero4 = {0.0, 0.0, 0.0, 0.0};
   int r0[NTL], rowc[NTL];
 #pragma unroll
@@ -675,27 +677,28 @@ __device__ __forceinline__ void pf_b16_normal_tiles(double* P, int ldp, int nrow
   {
     const int col = kq + 4*r;
 #pragma unroll
-    for(int q = 0; q < NTL; q++) if(r0[q] + mm < nrows && col < nb) P[(r0[q] + mm) + (kb + col)*ldp] = y0[q][r] + y1[q][r];
+    for(int q = 0; q < NTL; q++)
+      if(r0[q] + mm < nrows && col < nb && !(q == 0 && own_first && r0[q] + mm < kb + nb)) P[(r0[q] + mm) + (kb + col)*ldp] = y0[q][r] + y1[q][r];
   }
   pf_wave_sync();
   if(lane == 0)
   {
 #pragma unroll
-    for(int q = 0; q < NTL; q++) __hip_atomic_store(&S.tdone[t1 + q*dt], J + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    for(int q = 0; q < NTL; q++) if(!(q == 0 && own_first)) __hip_atomic_store(&S.tdone[t1 + q*dt], J + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
   }
   DLG_PF_WLOG(J, t1, 3);
 }
 // a wave's tiles t, t + dt, ... < tend of block J, three / two / one at a time
 __device__ __forceinline__ void pf_b16_tile_run(double* P, int ldp, int nrows, pf_b16_lds& S, int J, int kb, int nb, int t, int dt, int tend,
-                                                int lane, int mm, int kq, bool foreign)
+                                                int lane, int mm, int kq, bool foreign, bool own_first = false)
 {
   while(t < tend)
   {
 #ifndef DLG_PF_NO_PAIRS
-    if(t + 2*dt < tend) { pf_b16_normal_tiles<3>(P, ldp, nrows, S, J, kb, nb, t, dt, lane, mm, kq, foreign); t += 3*dt; continue; }
-    if(t + dt < tend)   { pf_b16_normal_tiles<2>(P, ldp, nrows, S, J, kb, nb, t, dt, lane, mm, kq, foreign); t += 2*dt; continue; }
+    if(t + 2*dt < tend) { pf_b16_normal_tiles<3>(P, ldp, nrows, S, J, kb, nb, t, dt, lane, mm, kq, foreign, own_first); t += 3*dt; own_first = false; continue; }
+    if(t + dt < tend)   { pf_b16_normal_tiles<2>(P, ldp, nrows, S, J, kb, nb, t, dt, lane, mm, kq, foreign, own_first); t += 2*dt; own_first = false; continue; }
 #endif
-    pf_b16_normal_tiles<1>(P, ldp, nrows, S, J, kb, nb, t, dt, lane, mm, kq, foreign); t += dt;
+    pf_b16_normal_tiles<1>(P, ldp, nrows, S, J, kb, nb, t, dt, lane, mm, kq, foreign, own_first); t += dt; own_first = false;
   }
 }
 template <int NT>
@@ -850,9 +853,9 @@ __device__ __forceinline__ void panel_factor_b16(double* P, int ldp, int nrows, 
         const bool own = t == J && nb < 16 && nrows > kb + nb;
         const bool next = t == J + 1 && J + 1 < nblk;        // the next diagonal tile: wave 0 finishes it
         if(t == J && !own) { t += NH; continue; }
-        if(!own && !next)
+        if(!next)
         {
-          pf_b16_tile_run(P, ldp, nrows, S, J, kb, nb, t, NH, ntr, lane, mm, kq, false);
+          pf_b16_tile_run(P, ldp, nrows, S, J, kb, nb, t, NH, ntr, lane, mm, kq, false, own);
           break;
         }
         const int r0 = 16*t, rowc = min(r0 + mm, nrows - 1);
