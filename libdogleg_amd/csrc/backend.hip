@@ -995,6 +995,12 @@ static int cauchy_fork_enqueue(dlg_backend* b, int s, double* sc)
     b->fold_scalar = sc + 1; b->fold_result = nullptr; b->fold_cauchy_out = sc + 2;
   }
   else rc = cauchy_enqueue(b, s, sc);
+  // The panel buffer the factorisation of this step swapped out (the previous factor: nobody's any more once the step is
+  // being taken) is cleared HERE, on the second stream behind the Cauchy step -- behind the fork, so behind everything the
+  // main stream had enqueued before the factorisation's one-launch region; in front of the join, so in front of the step
+  // kernels and of the next assembly on the main stream.  Behind the step kernel (step_finish) the clear sat between a
+  // step and the next evaluation's pass over J: 8 us of the critical queue, 13 with the gap in front of it.
+  if(rc == DLG_OK && b->type == DLG_SPARSE && !b->sharded() && b->part_nranks <= 1) rc = sparse_zero_spare(b, main_stream);
   b->stream = main_stream;
   DLG_CHECK(rc);
   if(b->d_join && !b->sharded())
@@ -1329,9 +1335,20 @@ extern "C" int dlg_step(dlg_backend_t* b, int from, int to, int kind, double tru
   struct BetweenGuard { dlg_backend* b; ~BetweenGuard() { b->between_armed = false; b->between_fn = nullptr; } } between_guard{b};
   double n2 = 0, kk = NAN, amax = 0;
   int nscal = 0;
+  // The deferred form (dlg_backend_set_defer_tail): the host waits for the kernel that forms <Jt x, step> -- every scalar of the
+  // step reaches it through page-locked partial sums, nothing is copied on the main stream
+  hipPointerAttribute_t pa;
+  const bool pin = p_new_host && hipPointerGetAttributes(&pa, p_new_host) == hipSuccess && pa.type == hipMemoryTypeHost && pa.devicePointer;
+  if(p_new_host && !pin) (void)hipGetLastError();
+  const int chunks = b->type == DLG_SPARSE ? sparse_norm2_chunks(b) : (b->type == DLG_DENSE ? dense_norm2_chunks(b) : 0);
+  const bool defer = b->defer_tail && expected_improvement && b->host_finals && b->h_part && !b->sharded() && (!p_new_host || pin) &&
+                     !(b->prof_mask >> DLG_PROF_K3K8_NORM2JV & 1u) && !(b->prof_mask >> DLG_PROF_K7_STEP & 1u) && b->ext_events &&
+                     chunks > 0 && b->slot[from].have_Jtx && b->h_part_used + 4096 <= dlg_backend::HPART_CAP &&      // (room for the step's partial sums: 4 x 1024 at most)
+                     dlg_tail_partials(b, chunks) != nullptr;
   // The expected improvement from the solved system (ident_norm2_Jstep): a step from the cached vectors of a point whose
   // dlg_take_step left <Jt x, gn> and the factor's verdict behind -- or the Cauchy step, which needs K3's scalar only --
-  // has no pass over J at all: step, <Jt x, step>, one synchronisation, the value at once (nothing deferred)
+  // has no pass over J at all: step, <Jt x, step>, one synchronisation.  In the deferred form p_new travels on the copy
+  // stream behind that kernel's event and dlg_step_tail hands the value out (it is complete, the copy may not be).
   {
     DlgSlot& F = b->slot[from];
     const bool ident = expected_improvement && !b->knobs.ei_jpass && b->host_finals && !b->sharded() && b->part_nranks <= 1 &&
@@ -1339,15 +1356,59 @@ extern "C" int dlg_step(dlg_backend_t* b, int from, int to, int kind, double tru
                        (kind == DLG_KIND_CAUCHY_TO_EDGE || (F.ident_ok && F.have_gn));
     if(ident)
     {
-      DLG_CHECK(make_step_enqueue(b, from, to, kind, trustregion, &nscal));
+      const bool deferred = defer && (!p_new_host || b->copy_stream);
+      b->kout_host = deferred;
+      const int rcm = make_step_enqueue(b, from, to, kind, trustregion, &nscal);
+      b->kout_host = false;
+      DLG_CHECK(rcm);
       if(!b->ev_fetch) DLG_HIP(hipEventCreateWithFlags(&b->ev_fetch, hipEventDisableTiming));
-      DLG_CHECK(k_inner(b, F.Jt_x, b->slot[to].step, b->N, b->d_scal + 4));
-      DLG_CHECK(step_finish(b, to, 6, p_new_host));
+      if(deferred) { b->attach_stop = b->ev_fetch; b->stop_attached = false; }
+      const int rci = k_inner(b, F.Jt_x, b->slot[to].step, b->N, b->d_scal + 4);
+      const bool attached = deferred && b->stop_attached;
+      b->attach_stop = nullptr; b->stop_attached = false;
+      DLG_CHECK(rci);
+      if(attached)
+      {
+        if(p_new_host)
+        {
+          DLG_HIP(hipStreamWaitEvent(b->copy_stream, b->ev_fetch, 0));
+          DLG_HIP(hipMemcpyAsync(p_new_host, b->slot[to].p, sizeof(double)*(size_t)b->N, hipMemcpyDeviceToHost, b->copy_stream));
+          DLG_HIP(hipEventRecord(b->ev_copy, b->copy_stream));
+          b->p_side_pending = true;
+        }
+        b->stop_attached = true; b->scal_copied = true;          // (nothing to copy: every scalar is a sum of page-locked partials)
+        DLG_CHECK(step_finish(b, to, 0, nullptr));
+      }
+      else
+      {
+        if(deferred)
+        {
+          // (no room for the partial sums in page-locked memory: the in-line form; an interpolation whose partial sums DID
+          // find room has written k to the page-locked block itself)
+          b->scal_copied = false;
+          bool k_on_host = false;
+          for(const dlg_backend::PendingFinal& f : b->pending) if(f.dst == 0 && f.stride == 2) k_on_host = true;
+          if(k_on_host && kind == DLG_KIND_INTERPOLATED)
+          {
+            DLG_HIP(hipMemcpyAsync(b->h_scal + 2, b->d_scal + 2, sizeof(double)*4, hipMemcpyDeviceToHost, b->stream));
+            b->scal_copied = true;
+          }
+        }
+        DLG_CHECK(step_finish(b, to, 6, p_new_host));
+      }
       make_step_read(b, from, kind, &n2, &kk, &amax);
       if(norm2_step) *norm2_step = n2;
       if(k_cauchy_to_gn) *k_cauchy_to_gn = kk;
       if(step_absmax) *step_absmax = amax;
-      *expected_improvement = ei_out(b, -2.0*b->h_scal[4] - ident_norm2_Jstep(kind, kk, trustregion, F.norm2_jtx, F.Jg2, F.norm2_cauchy, F.g_dot_gn));
+      const double nJs = ident_norm2_Jstep(kind, kk, trustregion, F.norm2_jtx, F.Jg2, F.norm2_cauchy, F.g_dot_gn);
+      if(attached)
+      {
+        b->tail_pending = true; b->tail_ident = true; b->tail_nJs = nJs; b->tail_no_fold = true;
+        b->tail_inner = b->h_scal[4]; b->tail_mark = b->sync_mark;
+        *expected_improvement = NAN;                             // (dlg_step_tail has it, and p_new complete)
+        return DLG_OK;
+      }
+      *expected_improvement = ei_out(b, -2.0*b->h_scal[4] - nJs);
       b->tail_value = *expected_improvement; b->ei_from_system = true;
       return DLG_OK;
     }
@@ -1356,14 +1417,6 @@ extern "C" int dlg_step(dlg_backend_t* b, int from, int to, int kind, double tru
   // forms <Jt x, step> -- every scalar of the step reaches it through page-locked partial sums, nothing is copied --,
   // the pass over J and p_new follow on the stream, dlg_step_tail has the value
   {
-    hipPointerAttribute_t pa;
-    const bool pin = p_new_host && hipPointerGetAttributes(&pa, p_new_host) == hipSuccess && pa.type == hipMemoryTypeHost && pa.devicePointer;
-    if(p_new_host && !pin) (void)hipGetLastError();
-    const int chunks = b->type == DLG_SPARSE ? sparse_norm2_chunks(b) : (b->type == DLG_DENSE ? dense_norm2_chunks(b) : 0);
-    const bool defer = b->defer_tail && expected_improvement && b->host_finals && b->h_part && !b->sharded() && (!p_new_host || pin) &&
-                       !(b->prof_mask >> DLG_PROF_K3K8_NORM2JV & 1u) && !(b->prof_mask >> DLG_PROF_K7_STEP & 1u) && b->ext_events &&
-                       chunks > 0 && b->slot[from].have_Jtx && b->h_part_used + 4096 <= dlg_backend::HPART_CAP &&      // (room for the step's partial sums: 4 x 1024 at most)
-                       dlg_tail_partials(b, chunks) != nullptr;
     if(defer)
     {
       DlgSlot& F = b->slot[from];

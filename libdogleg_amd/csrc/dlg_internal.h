@@ -355,7 +355,7 @@ int sparse_assemble_speculative(dlg_backend* b, int s);         // K4 beside K1 
 int sparse_eval_assemble(dlg_backend* b, int s, int* done);      // K1 + K4 in one pass over J (the assembly kernel forms Jt*x too)
 int sparse_assemble_finish(dlg_backend* b);                      // ... the deferred partial-sum stages of that JtJ
 int sparse_touch_factor(dlg_backend* b, hipStream_t st);         // second stream: pull the leaf panels into the Infinity Cache
-int sparse_zero_spare(dlg_backend* b);                           // clear the panel buffer the factorisation left behind (behind the step's fetch)
+int sparse_zero_spare(dlg_backend* b, hipStream_t ordered_for = nullptr);                           // clear the panel buffer the factorisation left behind (behind the step's fetch)
 int sparse_abandon_enqueued(dlg_backend* b);                     // the launches of a factorisation + solve enqueued ahead (step_prepare) return early from here on
 void sparse_spec_invalidate(dlg_backend* b, int s);
 bool sparse_spec_is(const dlg_backend* b, int s, const double* J);     // the second panel buffer holds slot s's assembly from the values at J

@@ -1540,7 +1540,9 @@ int sparse_eval_assemble(dlg_backend* b, int s, int* done)
 }
 // the panel buffer that a factorisation just left behind (sparse_assemble swapped it out) is cleared
 // behind the point the host waits for (step_finish): in stream order before the next assembly
-int sparse_zero_spare(dlg_backend* b)
+// (ordered_for: the stream whose later work is ordered behind this clear by other means -- the Cauchy step's join, when
+// the clear runs on the second stream beside the factorisation: cauchy_fork_enqueue)
+int sparse_zero_spare(dlg_backend* b, hipStream_t ordered_for)
 {
   SparseSym* Y = b->sym;
   if(!Y || !Y->spare_dirty || !Y->Lx_spec) return DLG_OK;
@@ -1549,7 +1551,7 @@ int sparse_zero_spare(dlg_backend* b)
   if(Y->held_Lx && Y->held_Lx == Y->Lx_spec) return DLG_OK;
   Y->spare_dirty = false;
   DLG_CHECK(clear_panels(b, Y->Lx_spec, b->stream));
-  Y->spare_zeroed = true; Y->spare_stream = b->stream;
+  Y->spare_zeroed = true; Y->spare_stream = ordered_for ? ordered_for : b->stream;
   return DLG_OK;
 }
 // the second panel buffer holds the assembly of slot s's point with the Jacobian values at J (sparse_eval_assemble)

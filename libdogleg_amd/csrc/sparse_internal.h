@@ -167,7 +167,7 @@ int sparse_partition_reduce(dlg_backend* b);
 int sparse_assemble_speculative(dlg_backend* b, int s);     // K4 on the second stream, beside K1
 int sparse_eval_assemble(dlg_backend* b, int s, int* done);   // K1 + K4 in one pass over J
 int sparse_assemble_finish(dlg_backend* b);                   // ... its JtJ partial-sum stages (deferred behind the fetch of Jt*x)
-int sparse_zero_spare(dlg_backend* b);                        // clear the swapped-out panel buffer behind the step's fetch
+int sparse_zero_spare(dlg_backend* b, hipStream_t ordered_for);                        // clear the swapped-out panel buffer behind the step's fetch
 void sparse_spec_invalidate(dlg_backend* b, int s);                 // subtree partition: the sum over the ranks at the cut
 int sparse_factor_setup(dlg_backend* b, bool plan_only = false);   // per-level launch parameters of K5
 int sparse_factor_levels(dlg_backend* b, int part = 0);      // K5 launches (no synchronisation); part 1: the leaf level only where the rest can follow later (fac_pending), part 2: that rest
