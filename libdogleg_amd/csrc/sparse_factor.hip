@@ -1661,7 +1661,10 @@ int sparse_factor_levels(dlg_backend* b, int part)
       const int np = Y->pr_nwg;           // the region's own work items (replicas) and children records
       const int fmode = 2 + 4*Y->pr_stage + (Y->fac_b16 ? 16 : 0) + 256*(l & 31);
       int* fl = Y->fac_flag; const int ep = ++Y->fac_epoch;
-      if(gate_here && l > 0 && n < 256) dlg_fork_gate(b, fl + np, ep);
+      // (the gate goes up with the region's LAST workgroup -- the top of the tree, on the chip once the populous levels below
+      // it have drained --, however many supernodes the region's first level has: with `n < 256` asked for here too, config #5
+      // -- 285 supernodes on level 1 -- never forked, and its Cauchy pass ran beside the backward solve instead)
+      if(gate_here && l > 0) dlg_fork_gate(b, fl + np, ep);
       const int64_t pacc = Y->pr_acc ? (int64_t)(Y->pr_acc - Y->uscr) : 0;
       const DlgHandoff ho = dlg_handoff(b, 1 << 21);
       DlgRegionTurn turn(b);
