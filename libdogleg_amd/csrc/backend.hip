@@ -346,6 +346,7 @@ extern "C" int dlg_backend_reset(dlg_backend_t* b)
   b->between_fn = nullptr; b->between_cookie = nullptr; b->between_armed = b->between_ran = b->between_redone = false; b->early_slot = -1; b->ident_predict = false;
   if(b->tail_pending) DLG_HIP(hipStreamSynchronize(b->stream));
   b->tail_pending = false; b->defer_tail = false; b->tail_mode = false; b->fold_scal_k7 = 0;
+  b->ei_count = 0; b->p_side_pending = false;      // (the test hook counts the values of ONE solve; the copy stream was waited for above)
   DLG_HIP(hipMemsetAsync(b->d_scal, 0, sizeof(double)*dlg_backend::NSCAL, b->stream));
   if(b->type == DLG_SPARSE) sparse_reset(b);
   DLG_HIP(hipStreamSynchronize(b->stream));

@@ -215,6 +215,7 @@ typedef double dlg_v4d __attribute__((ext_vector_type(4)));
 #define DLG_ASM_U 4
 #endif
 constexpr int ASM_U = DLG_ASM_U;
+constexpr int ASM_TLD = 17;             // doubles a row of the wave-private square the transient product turns through (asm_mfma_run: ts_ok)
 // One wave per RUN = consecutive tasks of one shape whose k-groups are contiguous: the shape's
 // lane constants are loaded once and the k-group stream is software-pipelined across the
 // task boundaries (bit 12 of a k-group's meta: last of its task -> store the persistent blocks,
@@ -229,7 +230,7 @@ constexpr int ASM_U = DLG_ASM_U;
 // J(row, column of the task's block / of the rider), so one multiply-add per k-group with x(row)
 // gives the task's share of (Jt x)[block]; it leaves a 16-double record per task (jtp), summed per
 // var-block by k_jtx_fin2_* in task order.  K1's own pass over J is not needed then.
-template <bool HAS_T, int CLEN, bool JTX, bool XT = false>
+template <bool HAS_T, int CLEN, bool JTX, bool XT = false, bool TS = false>
 __device__ __forceinline__ void asm_mfma_run(const AsmRun& R, const AsmMTask* __restrict__ tasks,
                                              const AsmShape* __restrict__ SH,
                                              const AsmKG* __restrict__ kgs, const int* __restrict__ tdest,
@@ -237,7 +238,7 @@ __device__ __forceinline__ void asm_mfma_run(const AsmRun& R, const AsmMTask* __
                                              double* __restrict__ Lx, double* __restrict__ part, int lane,
                                              double* __restrict__ tile, int LEN_rt,
                                              const double* __restrict__ xvec, double* __restrict__ jtp,
-                                             double* __restrict__ jtx_out)
+                                             double* __restrict__ jtx_out, double* __restrict__ tbuf, uint32_t trash_off)
 {
   constexpr int KD = ASM_KG_DW;
   // CLEN > 0: the tile row stride is a compile-time constant (the usual 16-column window), so the
@@ -276,6 +277,34 @@ __device__ __forceinline__ void asm_mfma_run(const AsmRun& R, const AsmMTask* __
 #define PA(r)  (int)(pk1[r] >> 24)
 #define PAO(r) (int)(pk2[r] & 0xFF)
 #define PNI(r) (int)(pk2[r] >> 8)
+  // XT, the transient blocks of a k-group: the 16 x 16 product turns through a wave-private LDS square (ASM_TLD doubles
+  // a row) and leaves ONE entry per lane, consecutive lanes = consecutive rows of one destination column -- entry L is
+  // (slot, column of J, transient row) in that order.  As the product comes out of the matrix core a lane holds
+  // rows kq + 4 r of column m: four masked stores a lane, each with a row offset of its own fetched across the wave,
+  // 37 of the ~100 instructions of such a k-group, for 54 of 256 entries (config #4).  ts_ok: the shape's entries fit one
+  // round of 64 lanes (else the four stores, below).  A property of the whole schedule, checked by the host (TS): the two
+  // forms in one kernel would keep the waits for the prefetched values as blind as before.
+  constexpr bool ts_ok = HAS_T && XT && TS;
+  int ts_rd = 0, ts_td4 = 0, ts_bs = 99, ts_cb = 0;      // LDS index read; 4 * (entry of td holding the row offset); slot; ta + bb * ld needs ld: (ta, bb) packed
+  if(ts_ok)
+  {
+    int nrt = 0;
+    for(int q = 0; q < 16; q++) if(SH->tj[q] != 0xFF) nrt++;
+    // (XT: a k-group's destinations came in its record -- two at most --, so it has at most 2 / nT row-block slots)
+    const int smax = min((int)SH->smax, max(1, 2/max(nT, 1)));
+    if(lane < smax*nJ*nrt)
+    {
+      const int q = lane / nrt, i = lane - q*nrt;
+      const int sbs = q / nJ, sbb = q - sbs*nJ;
+      int mmL = 0, seen = 0;
+      for(int qq = 0; qq < 16; qq++) if(SH->tj[qq] != 0xFF) { if(seen == i) mmL = qq; seen++; }
+      ts_rd = mmL*ASM_TLD + sbs*nJ + sbb;
+      ts_td4 = 4*(sbs*nT + SH->tj[mmL]);
+      ts_bs = sbs;
+      ts_cb = (int)SH->ta[mmL] | sbb << 8;
+    }
+  }
+  double* const tb_wr = tbuf + (kq*ASM_TLD + m);
   dlg_v4d accP = {0.0, 0.0, 0.0, 0.0}, accT = {0.0, 0.0, 0.0, 0.0};
   // task records: current + next (fetched ahead, as ONE vector load each: lane l holds dword l of
   // the record, fields are broadcast with readlane; vector loads return in order, so prefetches
@@ -287,6 +316,7 @@ __device__ __forceinline__ void asm_mfma_run(const AsmRun& R, const AsmMTask* __
   int tcv = task_fetch(tix), tnv = task_fetch(tix + 1);
   int pdc = pdest[16*(int64_t)min(tix, tlast) + m], pdn = pdest[16*(int64_t)min(tix + 1, tlast) + m];
   int64_t Tpart, Trpart, colT, colP;     // current task: partial offsets; Lx offset of this lane's column
+  uint32_t colTs = 0;                    // (ts_ok: Lx offset of the entry this lane stores, its row-block's offset aside)
   int Tjvar = -1;                        // ... first variable of J if the task writes Jt*x itself
   auto task_unpack = [&](int v) {
     if(JTX) Tjvar = __builtin_amdgcn_readlane(v, 12);
@@ -294,7 +324,8 @@ __device__ __forceinline__ void asm_mfma_run(const AsmRun& R, const AsmMTask* __
     const int64_t panel = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readlane(v, 7) << 32) | (uint32_t)__builtin_amdgcn_readlane(v, 6));
     Tpart  = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readlane(v, 9) << 32) | (uint32_t)__builtin_amdgcn_readlane(v, 8));
     Trpart = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readlane(v, 11) << 32) | (uint32_t)__builtin_amdgcn_readlane(v, 10));
-    colT = panel + (int64_t)bb*ld; colP = panel + (int64_t)m*ld; };
+    colT = panel + (int64_t)bb*ld; colP = panel + (int64_t)m*ld;
+    if(ts_ok) colTs = (uint32_t)panel + (uint32_t)((ts_cb >> 8)*ld + (ts_cb & 0xFF)); };
   task_unpack(tcv);
   // k-group records of one iteration: ASM_U*KD dwords, one vector load, prefetched one iteration ahead
   static_assert(ASM_U*KD <= 64, "k-group records of an iteration must fit one wave load");
@@ -418,19 +449,36 @@ __device__ __forceinline__ void asm_mfma_run(const AsmRun& R, const AsmMTask* __
         // the panels end below 4 GB (checked too): 32-bit offsets from the scalar base)
         const int myslot = (meta[u] >> (2*kq)) & 3;
         const bool mine = bs < (int)((meta[u] >> 8) & 7);
-        int ro[4];
-#pragma unroll
-        for(int r = 0; r < 4; r++) ro[r] = __builtin_amdgcn_ds_bpermute(4*(bs*nT + TJ(r)), td[u]);
         const dlg_v4d t4 = __builtin_amdgcn_mfma_f64_16x16x4f64(row[tc], row[bs == myslot ? bcol : ZC], (dlg_v4d){0.0, 0.0, 0.0, 0.0}, 0, 0, 0);
-#pragma unroll
-        for(int r = 0; r < 4; r++)
+        if(ts_ok)
         {
+          const int ro1 = __builtin_amdgcn_ds_bpermute(ts_td4, td[u]);
+#pragma unroll
+          for(int r = 0; r < 4; r++) tb_wr[4*r*ASM_TLD] = t4[r];
+          __builtin_amdgcn_wave_barrier();
+          const double tv = tbuf[ts_rd];
+          // (EVERY lane stores, the ones without an entry into the words behind the panels: a store under a branch is one
+          // the compiler cannot count, and the waits for the prefetched values -- one counter, in order, stores included --
+          // then assume the fewest and wait for stores they need not wait for)
+          const uint32_t off = (ts_bs < (int)((meta[u] >> 8) & 7)) ? colTs + (uint32_t)ro1 : trash_off + (uint32_t)(lane & 7);
+          *reinterpret_cast<double*>(reinterpret_cast<char*>(Lx) + (off << 3)) = tv;
+          __builtin_amdgcn_wave_barrier();
+        }
+        else
+        {
+          int ro[4];
+#pragma unroll
+          for(int r = 0; r < 4; r++) ro[r] = __builtin_amdgcn_ds_bpermute(4*(bs*nT + TJ(r)), td[u]);
+#pragma unroll
+          for(int r = 0; r < 4; r++)
+          {
 #ifndef DLG_ASM_NO_TSTORE                     // (tools/variant_lib.sh: the kernel without its transient stores)
-          if(mine && TJ(r) != 0xFF)
+            if(mine && TJ(r) != 0xFF)
 #else
-          if(mine && TJ(r) != 0xFF && t4[r] == 1.2345e300)
+            if(mine && TJ(r) != 0xFF && t4[r] == 1.2345e300)
 #endif
-            *reinterpret_cast<double*>(reinterpret_cast<char*>(Lx) + (((uint32_t)colT + (uint32_t)(ro[r] + TA(r))) << 3)) = t4[r];
+              *reinterpret_cast<double*>(reinterpret_cast<char*>(Lx) + (((uint32_t)colT + (uint32_t)(ro[r] + TA(r))) << 3)) = t4[r];
+          }
         }
       }
       else if(HAS_T)
@@ -501,7 +549,7 @@ __device__ __forceinline__ void asm_mfma_run(const AsmRun& R, const AsmMTask* __
 #else
 #define ASM_WPE_ATTR
 #endif
-template <int CLEN, bool JTX, bool XT = false>
+template <int CLEN, bool JTX, bool XT = false, bool TS = false>
 __global__ void __launch_bounds__(TPB) ASM_WPE_ATTR k_assemble_mfma(const AsmRun* __restrict__ runs, int nruns,
                                                        const AsmMTask* __restrict__ tasks,
                                                        const AsmKG* __restrict__ kgs,
@@ -510,7 +558,7 @@ __global__ void __launch_bounds__(TPB) ASM_WPE_ATTR k_assemble_mfma(const AsmRun
                                                        const double* __restrict__ vals,
                                                        double* __restrict__ Lx, double* __restrict__ part, int LEN,
                                                        const double* __restrict__ xvec, double* __restrict__ jtp,
-                                                       double* __restrict__ jtx_out, int only_shape)
+                                                       double* __restrict__ jtx_out, int only_shape, uint32_t trash_off)
 {
   extern __shared__ double asm_tiles[];
   const int lane = threadIdx.x & 63;
@@ -520,8 +568,10 @@ __global__ void __launch_bounds__(TPB) ASM_WPE_ATTR k_assemble_mfma(const AsmRun
   if(only_shape >= 0 && tasks[R.task0].shape != only_shape) return;      // (tools/k4_split.py: the time of one kind of task)
   const AsmShape* SH = shapes + tasks[R.task0].shape;
   double* tile = asm_tiles + (threadIdx.x >> 6)*(ASM_U*4*LEN);
-  if(SH->MT > 0) asm_mfma_run<true, CLEN, JTX, XT>(R, tasks, SH, kgs, tdest, pdest, vals, Lx, part, lane, tile, LEN, xvec, jtp, jtx_out);
-  else           asm_mfma_run<false, CLEN, JTX, XT>(R, tasks, SH, kgs, tdest, pdest, vals, Lx, part, lane, tile, LEN, xvec, jtp, jtx_out);
+  // (XT: the launch sized the LDS for a 16-row square a wave behind the tiles)
+  double* tbuf = TS ? asm_tiles + (TPB/64)*(ASM_U*4*LEN) + (threadIdx.x >> 6)*(16*ASM_TLD) : nullptr;
+  if(SH->MT > 0) asm_mfma_run<true, CLEN, JTX, XT, TS>(R, tasks, SH, kgs, tdest, pdest, vals, Lx, part, lane, tile, LEN, xvec, jtp, jtx_out, tbuf, trash_off);
+  else           asm_mfma_run<false, CLEN, JTX, XT, TS>(R, tasks, SH, kgs, tdest, pdest, vals, Lx, part, lane, tile, LEN, xvec, jtp, jtx_out, tbuf, trash_off);
 }
 // Jt*x from the records the assembly kernel left (JTX): var-block v = blks[...] sums its list in order.
 // short lists: 16 threads per var-block (thread = entry of the block); long ones (a dense block that
@@ -1167,28 +1217,44 @@ static int assemble_launch(dlg_backend* b, const double* Jv, double* Lx = nullpt
       for(const AsmShape& sh : H.asm_shape) if(sh.ncopy > 15) xt = false;
       if(xt) xt = H.asm_td_inline;                  // ... and every k-group carries its transient destinations
       if(xt) xt = (uint64_t)H.lx_size + (1u << 20) < (1ull << 29);      // ... and the panels end below 4 GB (32-bit store offsets)
-      if(H.asm_lds_len == 18 && xvec && xt)
+      // (TS: every shape's transient entries of a k-group fit one round of 64 lanes -- asm_mfma_run, ts_ok)
+      bool ts = xt;
+      for(const AsmShape& sh : H.asm_shape)
+        if(sh.MT > 0)
+        {
+          int nrt = 0;
+          for(int q = 0; q < 16; q++) if(sh.tj[q] != 0xFF) nrt++;
+          const int smax = std::min((int)sh.smax, std::max(1, 2/std::max((int)sh.nT, 1)));
+          if(!(nrt > 0 && smax*sh.nJ*nrt <= 64 && smax*sh.nJ <= 16)) ts = false;
+        }
+      static const bool old_ts = getenv("DLG_ASM_OLD_TSTORE") != nullptr;      // (A/B only)
+      if(old_ts) ts = false;
+      if(H.asm_lds_len == 18 && xvec && xt && ts)
+        ASM_LAUNCH((k_assemble_mfma<18, true, true, true>), dim3(dlg_cdiv(nruns, TPB/64)), dim3(TPB),
+                           sizeof(double)*(TPB/64)*(ASM_U*4*18 + 16*ASM_TLD), st, Y->asm_run, nruns, Y->asm_mtask,
+                           Y->asm_kg, Y->asm_shape, Y->asm_tdest, Y->asm_pdest, Jv, Lx, Y->asm_part, 18, xvec, Y->jtp, Jt_x, only_shape, (uint32_t)H.lx_size);
+      else if(H.asm_lds_len == 18 && xvec && xt)
         ASM_LAUNCH((k_assemble_mfma<18, true, true>), dim3(dlg_cdiv(nruns, TPB/64)), dim3(TPB),
                            sizeof(double)*(TPB/64)*ASM_U*4*18, st, Y->asm_run, nruns, Y->asm_mtask,
-                           Y->asm_kg, Y->asm_shape, Y->asm_tdest, Y->asm_pdest, Jv, Lx, Y->asm_part, 18, xvec, Y->jtp, Jt_x, only_shape);
+                           Y->asm_kg, Y->asm_shape, Y->asm_tdest, Y->asm_pdest, Jv, Lx, Y->asm_part, 18, xvec, Y->jtp, Jt_x, only_shape, (uint32_t)H.lx_size);
       else if(H.asm_lds_len == 18 && xvec)
         ASM_LAUNCH((k_assemble_mfma<18, true>), dim3(dlg_cdiv(nruns, TPB/64)), dim3(TPB),
                            sizeof(double)*(TPB/64)*ASM_U*4*18, st, Y->asm_run, nruns, Y->asm_mtask,
-                           Y->asm_kg, Y->asm_shape, Y->asm_tdest, Y->asm_pdest, Jv, Lx, Y->asm_part, 18, xvec, Y->jtp, Jt_x, only_shape);
+                           Y->asm_kg, Y->asm_shape, Y->asm_tdest, Y->asm_pdest, Jv, Lx, Y->asm_part, 18, xvec, Y->jtp, Jt_x, only_shape, (uint32_t)H.lx_size);
       else if(xvec)
         ASM_LAUNCH((k_assemble_mfma<0, true>), dim3(dlg_cdiv(nruns, TPB/64)), dim3(TPB),
                            sizeof(double)*(TPB/64)*ASM_U*4*H.asm_lds_len, st, Y->asm_run, nruns, Y->asm_mtask,
                            Y->asm_kg, Y->asm_shape, Y->asm_tdest, Y->asm_pdest, Jv, Lx, Y->asm_part,
-                           H.asm_lds_len, xvec, Y->jtp, Jt_x, only_shape);
+                           H.asm_lds_len, xvec, Y->jtp, Jt_x, only_shape, (uint32_t)H.lx_size);
       else if(H.asm_lds_len == 18)
         ASM_LAUNCH((k_assemble_mfma<18, false>), dim3(dlg_cdiv(nruns, TPB/64)), dim3(TPB),
                            sizeof(double)*(TPB/64)*ASM_U*4*18, st, Y->asm_run, nruns, Y->asm_mtask,
-                           Y->asm_kg, Y->asm_shape, Y->asm_tdest, Y->asm_pdest, Jv, Lx, Y->asm_part, 18, nox, nojt, nojt, only_shape);
+                           Y->asm_kg, Y->asm_shape, Y->asm_tdest, Y->asm_pdest, Jv, Lx, Y->asm_part, 18, nox, nojt, nojt, only_shape, (uint32_t)H.lx_size);
       else
         ASM_LAUNCH((k_assemble_mfma<0, false>), dim3(dlg_cdiv(nruns, TPB/64)), dim3(TPB),
                            sizeof(double)*(TPB/64)*ASM_U*4*H.asm_lds_len, st, Y->asm_run, nruns, Y->asm_mtask,
                            Y->asm_kg, Y->asm_shape, Y->asm_tdest, Y->asm_pdest, Jv, Lx, Y->asm_part,
-                           H.asm_lds_len, nox, nojt, nojt, only_shape);
+                           H.asm_lds_len, nox, nojt, nojt, only_shape, (uint32_t)H.lx_size);
     }
     if(nt > 0)
       hipLaunchKernelGGL(k_assemble, dim3(dlg_cdiv(nt, TPB/64)), dim3(TPB), 0, st, Y->asm_ctask, nt,
