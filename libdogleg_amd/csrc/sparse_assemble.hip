@@ -349,18 +349,17 @@ __device__ __forceinline__ void asm_mfma_run(const AsmRun& R, const AsmMTask* __
   // (JTX, a window of at most 15 columns: lane 15 of every row fetches x(row) instead of a duplicate of the
   // window's last column -- it lands in column 15 of the tile row, and the Jt*x product reads it from there:
   // no gather of x between the records and the products, no load of its own)
+  // (one fetch across the wave per row: lane 15 of an x_in_tile row asks for the record's x row, the others for the row's
+  // first value -- the word it asks for and the base it adds to are the lane's own constants)
+  const int vf_sel = 4*(kq + ((x_in_tile && m == 15) ? 6 : 0));
+  const double* const vf_base = (x_in_tile && m == 15) ? xvec : vals + (col0 + min(m, ncopy - 1));
   auto vals_fetch = [&](int rec, int kgi) {
 #pragma unroll
     for(int u = 0; u < ASM_U; u++)
     {
-      bpre[u] = __builtin_amdgcn_ds_bpermute(4*(KD*u + kq), rec);
-      if(kgi + u > kglast) bpre[u] = -1;
-      const double* src = vals + (max(bpre[u], 0) + col0 + min(m, ncopy - 1));
-      if(x_in_tile)
-      {
-        const int xrow = __builtin_amdgcn_ds_bpermute(4*(KD*u + 6 + kq), rec);
-        if(m == 15) src = xvec + xrow;
-      }
+      bpre[u] = __builtin_amdgcn_ds_bpermute(vf_sel + 4*KD*u, rec);
+      if(kgi + u > kglast && !(x_in_tile && m == 15)) bpre[u] = -1;
+      const double* src = vf_base + (uint32_t)max(bpre[u], 0);
 #ifdef DLG_ASM_NO_VLOAD
       vpre[u] = (double)(((long)src >> 3) & 7);
 #else
