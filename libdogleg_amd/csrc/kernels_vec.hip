@@ -64,6 +64,43 @@ __device__ __forceinline__ double block_min(double v, double* sh)
   return r;
 }
 
+// Several block-wide reductions behind ONE pair of barriers, their shuffle chains interleaved: value k is combined with
+// OPS[k] (0 sum, 1 max, 2 min) exactly as block_sum / block_max / block_min combine it -- the same operations in the same
+// order, the same bits --; results valid in thread 0.  sh: 4 doubles per value.
+template <int... OPS>
+__device__ __forceinline__ void block_reduce(double (&v)[sizeof...(OPS)], double* sh)
+{
+  constexpr int K = sizeof...(OPS);
+  constexpr int op[K] = { OPS... };
+#pragma unroll
+  for(int o = 32; o > 0; o >>= 1)
+  {
+    double t[K];
+#pragma unroll
+    for(int k = 0; k < K; k++) t[k] = __shfl_down(v[k], o, 64);
+#pragma unroll
+    for(int k = 0; k < K; k++) v[k] = op[k] == 0 ? v[k] + t[k] : (op[k] == 1 ? fmax(v[k], t[k]) : fmin(v[k], t[k]));
+  }
+  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+  __syncthreads();
+  if(l == 0)
+  {
+#pragma unroll
+    for(int k = 0; k < K; k++) sh[4*k + w] = v[k];
+  }
+  __syncthreads();
+  if(threadIdx.x == 0)
+  {
+#pragma unroll
+    for(int k = 0; k < K; k++)
+    {
+      double r = op[k] == 0 ? 0.0 : (op[k] == 1 ? 0.0 : 1e300);
+      for(int i = 0; i < (int)(blockDim.x >> 6); i++) r = op[k] == 0 ? r + sh[4*k + i] : (op[k] == 1 ? fmax(r, sh[4*k + i]) : fmin(r, sh[4*k + i]));
+      v[k] = r;
+    }
+  }
+}
+
 // partial layout: part[k*nb + blk] for output k
 __global__ void __launch_bounds__(TPB) k_part_norm2_absmax(const double* __restrict__ x, int n,
                                                            double* __restrict__ part)
@@ -220,7 +257,7 @@ __global__ void __launch_bounds__(TPB) k_part_take_step(const double* __restrict
                                                         double* __restrict__ gbpart, const double* __restrict__ mmpart, int nbm,
                                                         int ident_enable, double ratio_max, double* __restrict__ ident_out)
 {
-  __shared__ double sh[4];
+  __shared__ double sh[16];
   __shared__ double s_l2, s_negc, s_n2g, s_skip, s_ratio;
   __shared__ double s_gn[MAXB];
   // The expected improvement from the solved system (K8 without its pass over J, backend.hip: ident_value): allowed by
@@ -232,8 +269,7 @@ __global__ void __launch_bounds__(TPB) k_part_take_step(const double* __restrict
   {
     double lo = 1e300, hi = 0.0;
     for(int i = threadIdx.x; i < nbm; i += TPB) { lo = fmin(lo, mmpart[i]); hi = fmax(hi, mmpart[nbm + i]); }
-    lo = block_min(lo, sh); __syncthreads();
-    hi = block_max(hi, sh);
+    { double r2[2] = { lo, hi }; block_reduce<2, 1>(r2, sh); lo = r2[0]; hi = r2[1]; }
     if(threadIdx.x == 0) { ratio = (nbm > 0 && lo > 0.0) ? hi/lo : INFINITY; s_ratio = ratio; }
     __syncthreads();
   }
@@ -241,8 +277,7 @@ __global__ void __launch_bounds__(TPB) k_part_take_step(const double* __restrict
     double v0 = 0, v1 = 0;
     for(int i = threadIdx.x; i < nb1; i += TPB) { v0 += part1[i]; v1 += part1[nb1 + i]; }
     for(int i = threadIdx.x; i < nbg; i += TPB) s_gn[i] = gnpart[i];      // one round of loads, summed in order below
-    v0 = block_sum(v0, sh); __syncthreads();
-    v1 = block_sum(v1, sh);
+    { double r2[2] = { v0, v1 }; block_reduce<0, 0>(r2, sh); v0 = r2[0]; v1 = r2[1]; }
     if(threadIdx.x == 0)
     {
       s_l2 = v0; s_negc = v1;
@@ -283,12 +318,9 @@ __global__ void __launch_bounds__(TPB) k_part_take_step(const double* __restrict
     gs += gi*st;                                                 // <Jt x, step> for the expected improvement
     gb += gi*bi;                                                 // <Jt x, gn>: |J gn|^2 of the solved system
   }
-  const double S = block_sum(s2, sh);
-  const double Mx = block_max(m, sh);
-  __syncthreads();
-  const double Gs = block_sum(gs, sh);
-  __syncthreads();
-  const double Gb = block_sum(gb, sh);
+  double r4[4] = { s2, m, gs, gb };
+  block_reduce<0, 1, 0, 0>(r4, sh);
+  const double S = r4[0], Mx = r4[1], Gs = r4[2], Gb = r4[3];
   if(threadIdx.x == 0) { part[blockIdx.x] = S; part[gridDim.x + blockIdx.x] = Mx; gpart[blockIdx.x] = Gs; if(gbpart) gbpart[blockIdx.x] = Gb; }
   if(blockIdx.x == 0 && threadIdx.x == 0)
   {
@@ -322,15 +354,14 @@ __global__ void __launch_bounds__(TPB) k_part_negate_interp1(double* __restrict_
                                                              const double* __restrict__ mm, int nmm, double* __restrict__ mmpart,
                                                              long mm_stride, int mm_hi)
 {
-  __shared__ double sh[4];
+  __shared__ double sh[12];
   // (the factor's smallest / largest pivot: a partial minimum / maximum per workgroup of the pairs the backward solve left
   // per supernode -- k_part_take_step finishes them)
   if(mmpart)
   {
     double lo = 1e300, hi = 0.0;
     for(int i = blockIdx.x*TPB + threadIdx.x; i < nmm; i += gridDim.x*TPB) { lo = fmin(lo, mm[i*mm_stride]); hi = fmax(hi, mm[i*mm_stride + mm_hi]); }
-    lo = block_min(lo, sh); __syncthreads();
-    hi = block_max(hi, sh);
+    { double r2[2] = { lo, hi }; block_reduce<2, 1>(r2, sh); lo = r2[0]; hi = r2[1]; }
     if(threadIdx.x == 0) { mmpart[blockIdx.x] = lo; mmpart[gridDim.x + blockIdx.x] = hi; }
     __syncthreads();
   }
@@ -352,9 +383,9 @@ __global__ void __launch_bounds__(TPB) k_part_negate_interp1(double* __restrict_
     const double t = -v[i]; v[i] = t; s += t*t;
     const double ai = a[i], d = ai - t; l2 += d*d; nc += d*ai;
   }
-  const double S = block_sum(s, sh); __syncthreads();
-  const double L = block_sum(l2, sh); __syncthreads();
-  const double Cn = block_sum(nc, sh);
+  double r3[3] = { s, l2, nc };
+  block_reduce<0, 0, 0>(r3, sh);
+  const double S = r3[0], L = r3[1], Cn = r3[2];
   if(threadIdx.x == 0) { gnpart[blockIdx.x] = S; part1[blockIdx.x] = L; part1[gridDim.x + blockIdx.x] = Cn; }
 }
 __global__ void __launch_bounds__(TPB) k_part_negate_norm2(double* __restrict__ v, int n,

@@ -454,14 +454,14 @@ __device__ __forceinline__ void asm_mfma_run(const AsmRun& R, const AsmMTask* __
           const int ro1 = __builtin_amdgcn_ds_bpermute(ts_td4, td[u]);
 #pragma unroll
           for(int r = 0; r < 4; r++) tb_wr[4*r*ASM_TLD] = t4[r];
-          __builtin_amdgcn_wave_barrier();
+          // (no barrier of the wave's own: the LDS takes a wave's accesses in order, and the compiler keeps a load behind
+          // stores it may alias -- the products of the next k-group need not wait for this round trip)
           const double tv = tbuf[ts_rd];
           // (EVERY lane stores, the ones without an entry into the words behind the panels: a store under a branch is one
           // the compiler cannot count, and the waits for the prefetched values -- one counter, in order, stores included --
           // then assume the fewest and wait for stores they need not wait for)
           const uint32_t off = (ts_bs < (int)((meta[u] >> 8) & 7)) ? colTs + (uint32_t)ro1 : trash_off + (uint32_t)(lane & 7);
           *reinterpret_cast<double*>(reinterpret_cast<char*>(Lx) + (off << 3)) = tv;
-          __builtin_amdgcn_wave_barrier();
         }
         else
         {
