@@ -356,9 +356,35 @@ __global__ void __launch_bounds__(NT, LEAF ? 4 : 1) k_factor_level(const FwItem*
     }
     bd_compact_members<NT, DS>(G, nrows, w, tid, sn_bd_col + it.bd0, it.nbd, it.bdw, s_mcol, s_rdiag, Dg, &sbad, it.col0);
   }
-  // thread = (panel row, column group): rows padded to whole waves, the remaining threads take
-  // further columns
+  // LEAF: the rows below the top block are ONE linear image in LDS (column j at P + j ldp, ldp even): they come in by
+  // loads that write LDS themselves (16 bytes a lane, a wave-instruction fills 128 consecutive doubles of the image, the
+  // lane's source address is its own) -- all of a panel's loads are in flight at once and no register holds a value.
+  // Through registers, sixteen columns a thread at a time, the copy was two dependent round trips and 9.8 of a leaf
+  // workgroup's 26.8 us (tools/prof_factor.sh).  (A pad row reads the first entry of the next column: never used.)
+  // (thread = (panel row, column group) of the copies through registers: rows padded to whole waves, the remaining threads
+  // take further columns)
   const int cp_rows = min(NT, (nloc - row0c + 63) & ~63), cp_ng = NT/cp_rows, cp_g = tid/cp_rows;
+  // The same for a whole unsliced panel (rows 0 .. nloc of every column, column j at P + j ldp): the first level of the
+  // one-launch region waits for nothing but this copy (8.2 us of its 28, profiles/r05_top_of_tree_levels.txt).
+#ifndef DLG_LEAF_NO_GLDS
+  if((LEAF && cmp) || (!LEAF && !cmp && !sliced && shift == 0))
+  {
+    const int ntot = ldp*w;
+    const double* g0 = cmp ? G + (w + shift) : G;
+    for(int k = tid >> 6; 128*k < ntot; k += NT/64)
+    {
+      const int e = 128*k + 2*lane;
+      if(e < ntot)
+      {
+        const int j = e / ldp, r = e - j*ldp;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g0 + (size_t)j*nrows + r),
+                                         (__attribute__((address_space(3))) void*)(P + 128*k), 16, 0, 0);
+      }
+    }
+  }
+  else
+#endif
+  {
   for(int i = row0c + tid - cp_g*cp_rows; i < nloc && cp_g < cp_ng; i += cp_rows)
   {
     const double* gp = G + (i < w ? i : i + shift);
@@ -370,6 +396,7 @@ __global__ void __launch_bounds__(NT, LEAF ? 4 : 1) k_factor_level(const FwItem*
 #pragma unroll
       for(int u = 0; u < CP_FLIGHT; u++) if(j0 + u*cp_ng < w) Pb[i + (j0 + u*cp_ng)*ldp] = v[u];
     }
+  }
   }
   // (persistent top region: the panel is in LDS already; the children's flags are awaited one by one in
   // mf_add_children)
