@@ -1278,10 +1278,43 @@ __device__ __forceinline__ void bd_compact_members(double* __restrict__ G, int l
     if(badcol >= 0) atomicMin(info, col0 + c0 + badcol);
   }
 }
+template <int NT, int NB, int DS>
+__device__ __forceinline__ void bd_compact_rows_flat(double* Pb, int ldp, int nr, int w, int tid, int nmem,
+                                                     const double* rdiag, const double* __restrict__ Dg)
+{
+  // thread = (row, member) pairs tid, tid + NT, ... of the nr x nmem of them, member-major (a wave's lanes on consecutive
+  // rows of a column): one division, then steps of NT = q nr + rem
+  const int q = NT / nr, rem = NT - q*nr;
+  int m = tid / nr, r = tid - m*nr;
+  while(m < nmem)
+  {
+    bd_solve_row_c<NB, DS>(Pb, ldp, w + r, m*NB, rdiag, Dg);
+    r += rem; m += q;
+    if(r >= nr) { r -= nr; m++; }
+  }
+}
+// bdw > 0 with w == nmem * bdw: every member has bdw columns (merged point leaves) -- the (row, member) pairs are
+// independent and are dealt to ALL threads (thread = row left 73 of a leaf workgroup's 256 threads with 18 members each
+// in turn: 6.1 of its 26.8 us, tools/prof_factor.sh); the same arithmetic per pair, the same bits
 template <int NT, int DS = 8>
 __device__ __forceinline__ void bd_compact_rows(double* Pb, int ldp, int nrows, int w, int tid, int nmem,
-                                                const int* mcol, const double* rdiag, const double* __restrict__ Dg)
+                                                const int* mcol, const double* rdiag, const double* __restrict__ Dg, int bdw = 0)
 {
+#ifndef DLG_BD_ROWS_BY_THREAD
+  if(bdw > 0 && bdw <= 4 && w == nmem*bdw && nrows > w)
+  {
+    const int nr = nrows - w;
+    switch(bdw)
+    {
+      case 1: bd_compact_rows_flat<NT, 1, DS>(Pb, ldp, nr, w, tid, nmem, rdiag, Dg); break;
+      case 2: bd_compact_rows_flat<NT, 2, DS>(Pb, ldp, nr, w, tid, nmem, rdiag, Dg); break;
+      case 3: bd_compact_rows_flat<NT, 3, DS>(Pb, ldp, nr, w, tid, nmem, rdiag, Dg); break;
+      default: bd_compact_rows_flat<NT, 4, DS>(Pb, ldp, nr, w, tid, nmem, rdiag, Dg); break;
+    }
+    __syncthreads();
+    return;
+  }
+#endif
   for(int r = w + tid; r < nrows; r += NT)
   {
     for(int m = 0; m < nmem; m++)

@@ -431,7 +431,7 @@ __global__ void __launch_bounds__(NT, LEAF ? 4 : 1) k_factor_level(const FwItem*
     else            mf_add_children<NT, false>(P, Ug, ntri, it.nch, it.ch0, rc, mf_rec, uscr, mf_dst, tid);
   }
   FL_STAMP(2);
-  if(cmp) bd_compact_rows<NT, DS>(Pb, ldp, nloc, w, tid, it.nbd, s_mcol, s_rdiag, Dg);
+  if(cmp) bd_compact_rows<NT, DS>(Pb, ldp, nloc, w, tid, it.nbd, s_mcol, s_rdiag, Dg, it.bdw);
   else if(LEAF) { }
   else if(it.nbd > 0) panel_factor_blockdiag<NT>(P, ldp, nloc, w, tid, sn_bd_col + it.bd0, it.nbd, &sbad, it.col0, s_mcol, s_rdiag);
   else if(NT >= 256 && b16 && nloc <= 16*PF_B16_MAXT) panel_factor_b16<(NT >= 256 ? NT : 256)>(P, ldp, nloc, w, tid, &sbad, it.col0);
