@@ -236,11 +236,12 @@ int  dlg_point_eval_early(dlg_backend_t* b, int slot, const double* x_dev, const
  * nothing outstanding returns the value of the last step, whichever way it was formed; dlg_step_tail_pending says whether a
  * value is outstanding (NaN in out7[6] is how dlg_take_step says so, but a computed NaN looks the same).
  *
- * The value itself needs no pass over J where the Gauss-Newton system was solved at lambda = 0 with a factor whose pivots
- * span less than 212x ((max L_ii / min L_ii)^2 eps <= 1e-11): |J gn|^2 = -<Jt x, gn>, <J cauchy, J gn> = -<cauchy, Jt x>,
- * |J cauchy|^2 is the Cauchy step's own scalar (backend.hip: ident_norm2_Jstep; to rounding the number of
- * computeExpectedImprovement, dogleg.c:1085-1165).  The step kernel decides on the device, the pass over J that is on the
- * stream returns at once.  Any lambda > 0, a wider pivot range, several ranks: the pass over J, as before.
+ * The value itself needs no pass over J where the Gauss-Newton system (JtJ + lambda I) gn = -Jt x was solved with a factor
+ * whose pivots span less than 212x ((max L_ii / min L_ii)^2 eps <= 1e-11): |J gn|^2 = -<Jt x, gn> - lambda |gn|^2,
+ * <J cauchy, J gn> = -<cauchy, Jt x> - lambda <cauchy, gn>, |J cauchy|^2 is the Cauchy step's own scalar (backend.hip:
+ * ident_norm2_Jstep; to rounding the number of computeExpectedImprovement, dogleg.c:1085-1165).  The step kernel decides on
+ * the device, the pass over J that is on the stream returns at once.  A wider pivot range (config #5: 3.5e6 at
+ * lambda = 1e-10), several ranks: the pass over J, as before.
  * DOGLEG_AMD_EI_JPASS=1: always the pass over J. */
 int  dlg_backend_set_defer_tail(dlg_backend_t* b, int on);
 int  dlg_step_tail_pending(dlg_backend_t* b);

@@ -670,20 +670,24 @@ static void invalidate(DlgSlot& S)
 }
 
 // |J step|^2 without a pass over J.  The Cauchy step is a = kappa g with kappa = -|g|^2 / |J g|^2 (dogleg.c:605): |J a|^2 =
-// kappa^2 |J g|^2, K3's own scalar.  The Gauss-Newton step b solves (JtJ + lambda I) b = -g, so at lambda = 0
-// |J b|^2 = b' JtJ b = -<g, b> and <J a, J b> = a' JtJ b = -<a, g> = -kappa |g|^2; the interpolated step is
-// (1 - k) a + k b (dogleg.c:964-987).  The error of the last two against the pass over J is b' r with r the residual of
-// the solve, i.e. eps * cond(JtJ) relative: the caller uses them only where the factor's pivot ratio says cond is small
-// (k_part_take_step) -- the value agrees with computeExpectedImprovement (dogleg.c:1085-1165) to rounding there.
-static double ident_norm2_Jstep(int kind, double k, double trustregion, double g2, double Jg2, double n2c, double g_dot_gn)
+// kappa^2 |J g|^2, K3's own scalar.  The Gauss-Newton step b solves (JtJ + lambda I) b = -g, so
+// |J b|^2 = b' JtJ b = -<g, b> - lambda |b|^2 and <J a, J b> = a' JtJ b = -<a, g> - lambda <a, b> = -kappa |g|^2 - lambda <a, b>;
+// the interpolated step is (1 - k) a + k b (dogleg.c:964-987).  The error of the last two against the pass over J is b' r
+// with r the residual of the solve, i.e. eps * cond(JtJ + lambda I) relative to <g, b>: the caller uses them only where the
+// (damped) factor's pivot ratio says cond is small (k_part_take_step) -- the value agrees with
+// computeExpectedImprovement (dogleg.c:1085-1165) to rounding there.  (lambda > 0: -<g, b> and lambda |b|^2 may cancel in
+// |J b|^2 alone, but not in the expected improvement, which carries -2 <g, step> beside it.)
+static double ident_norm2_Jstep(int kind, double k, double trustregion, double g2, double Jg2, double n2c, double g_dot_gn,
+                                double lambda, double n2g, double a_dot_gn)
 {
   const double kappa = -g2/Jg2;
   const double Ja2 = kappa*kappa*Jg2;
+  const double Jb2 = -g_dot_gn - lambda*n2g, JaJb = -kappa*g2 - lambda*a_dot_gn;
   switch(kind)
   {
   case DLG_KIND_CAUCHY_TO_EDGE: { const double sc = trustregion/sqrt(n2c); return sc*sc*Ja2; }      // dogleg.c:1204-1207
-  case DLG_KIND_GAUSSNEWTON:    return -g_dot_gn;
-  default:                      return (1.0 - k)*(1.0 - k)*Ja2 - 2.0*k*(1.0 - k)*kappa*g2 - k*k*g_dot_gn;
+  case DLG_KIND_GAUSSNEWTON:    return Jb2;
+  default:                      return (1.0 - k)*(1.0 - k)*Ja2 + 2.0*k*(1.0 - k)*JaJb + k*k*Jb2;
   }
 }
 
@@ -1401,7 +1405,7 @@ extern "C" int dlg_step(dlg_backend_t* b, int from, int to, int kind, double tru
       if(norm2_step) *norm2_step = n2;
       if(k_cauchy_to_gn) *k_cauchy_to_gn = kk;
       if(step_absmax) *step_absmax = amax;
-      const double nJs = ident_norm2_Jstep(kind, kk, trustregion, F.norm2_jtx, F.Jg2, F.norm2_cauchy, F.g_dot_gn);
+      const double nJs = ident_norm2_Jstep(kind, kk, trustregion, F.norm2_jtx, F.Jg2, F.norm2_cauchy, F.g_dot_gn, F.ident_lam, F.norm2_gn, F.a_dot_gn);
       if(attached)
       {
         b->tail_pending = true; b->tail_ident = true; b->tail_nJs = nJs; b->tail_no_fold = true;
@@ -1629,7 +1633,7 @@ extern "C" int dlg_take_step(dlg_backend_t* b, int from, int to, double trustreg
                                   b->d_scal, b->d_scal + 8, F.Jt_x, b->d_scal + 11,
                                   ident_try ? b->d_scal + dlg_backend::GB_SLOT : (double*)nullptr,
                                   ident_try ? b->d_scal + dlg_backend::IDENT_SLOT : (double*)nullptr,
-                                  ident_mm != nullptr, lam == 0.0, dlg_backend::IDENT_RATIO_MAX);
+                                  ident_mm != nullptr, true, dlg_backend::IDENT_RATIO_MAX);
       b->fold_scal_k7 = 0; b->attach_stop = nullptr;
       DLG_CHECK(rc7);
     }
@@ -1670,7 +1674,7 @@ extern "C" int dlg_take_step(dlg_backend_t* b, int from, int to, double trustreg
       // this backend did (ident_predict), lambda is 0 again, and the launch would carry nothing else (p_new is on the copy
       // stream): a launch that returns at once is still 5 - 6 us on the critical queue.  The device's word is the judge: if
       // it says the pass is needed after all, it is launched behind the wait (below), late but the same pass.
-      k8_omitted = b->ident_launched && b->ident_predict && lam == 0.0 && b->tail_no_fold && !b->knobs.no_k8_predict;
+      k8_omitted = b->ident_launched && b->ident_predict && b->tail_no_fold && !b->knobs.no_k8_predict;
       int rct = DLG_OK;
       if(!k8_omitted)
       {
@@ -1728,7 +1732,8 @@ extern "C" int dlg_take_step(dlg_backend_t* b, int from, int to, double trustreg
     if(b->ident_launched && !ident_used && b->h_scal[dlg_backend::IDENT_SLOT] != 0.0)
     { dlg_set_error("internal error: the expected improvement's pass over J was skipped without |J Jt_x|^2 at hand"); return DLG_ERR_STATE; }
     if(ident_used)
-      ident_nJs = ident_norm2_Jstep((int)b->h_scal[8], b->h_scal[9], trustregion, F.norm2_jtx, F.Jg2, F.norm2_cauchy, b->h_scal[dlg_backend::GB_SLOT]);
+      ident_nJs = ident_norm2_Jstep((int)b->h_scal[8], b->h_scal[9], trustregion, F.norm2_jtx, F.Jg2, F.norm2_cauchy, b->h_scal[dlg_backend::GB_SLOT],
+                                    lam, b->h_scal[10], F.norm2_cauchy - b->h_scal[dlg_backend::IDENT_SLOT + 4]);
     if(defer) { b->tail_ident = ident_used; b->tail_nJs = ident_nJs; }
     if(b->ident_launched) b->ident_predict = ident_used;
     if(defer && k8_omitted && !ident_used)
@@ -1784,7 +1789,8 @@ extern "C" int dlg_take_step(dlg_backend_t* b, int from, int to, double trustreg
   b->pivot_ratio = b->ident_launched ? b->h_scal[dlg_backend::IDENT_SLOT + 1] : NAN;
   // (a retry from the cached vectors of this point, dlg_step, takes the same route: <Jt x, gn> and the factor's verdict)
   F.g_dot_gn = b->h_scal[dlg_backend::GB_SLOT];
-  F.ident_ok = b->ident_launched && lam == 0.0 && ident_mm != nullptr && b->h_scal[dlg_backend::IDENT_SLOT + 1] <= dlg_backend::IDENT_RATIO_MAX;
+  F.ident_ok = b->ident_launched && ident_mm != nullptr && b->h_scal[dlg_backend::IDENT_SLOT + 1] <= dlg_backend::IDENT_RATIO_MAX;
+  F.ident_lam = lam; F.a_dot_gn = F.norm2_cauchy - b->h_scal[dlg_backend::IDENT_SLOT + 4];
   return DLG_OK;
 }
 

@@ -47,8 +47,8 @@ struct DlgSlot
   const double* J_bound = nullptr;
   double  norm2_x = 0, norm2_cauchy = 0, norm2_gn = 0, norm2_jtx = 0;
   // the expected improvement from the solved system (backend.hip, ident_norm2_Jstep): |J Jt_x|^2 of the Cauchy step, <Jt_x, gn>,
-  // and whether the factor the Gauss-Newton step came from allows it (lambda == 0, pivot ratio)
-  double  Jg2 = 0, g_dot_gn = 0; bool ident_ok = false;
+  // and whether the factor the Gauss-Newton step came from allows it (pivot ratio)
+  double  Jg2 = 0, g_dot_gn = 0, a_dot_gn = 0, ident_lam = 0; bool ident_ok = false;      // (ident_norm2_Jstep: <Jt x, gn>, <cauchy, gn>, the lambda gn was solved at)
   bool    have_inputs = false, have_Jtx = false, have_cauchy = false, have_gn = false;
   const double* xin() const { return x_bound ? x_bound : x; }
   const double* Jin() const { return J_bound ? J_bound : J; }
@@ -106,7 +106,7 @@ struct dlg_backend
   bool kout_host = false;     // (dlg_step behind the decision point: k_interpolate's k straight into the page-locked scalars)
   // The expected improvement WITHOUT its pass over J (K8): with (JtJ + lambda I) gn = -Jt_x solved, |J step|^2 of all three
   // kinds of step is a combination of N-vector dot products (ident_norm2_Jstep).  The step kernel decides on the device
-  // (lambda == 0 and the factor's pivot ratio small enough -- d_scal[IDENT_SLOT] = 1, [IDENT_SLOT + 1] = the ratio) and the
+  // (the factor's pivot ratio small enough -- d_scal[IDENT_SLOT] = 1, [IDENT_SLOT + 1] = the ratio, [IDENT_SLOT + 4] = <cauchy - gn, cauchy>) and the
   // pass over J that is on the stream behind it returns at once (k8_skip); the host reads the same word and forms the value.
   // DOGLEG_AMD_EI_JPASS=1: always the pass over J.
   static constexpr int IDENT_SLOT = 3, GB_SLOT = 13;     // free slots of dlg_take_step's scalar block

@@ -330,6 +330,7 @@ __global__ void __launch_bounds__(TPB) k_part_take_step(const double* __restrict
       // (the Cauchy step to the edge needs no factor: its |J step|^2 is a multiple of K3's own scalar)
       const double skip = (kind == 0 || (ident_enable && ratio <= ratio_max)) ? 1.0 : 0.0;
       ident_out[0] = skip; ident_out[1] = ratio; s_skip = skip;
+      ident_out[4] = s_negc;                                     // <cauchy - gn, cauchy>: with lambda > 0 the identity needs <cauchy, gn>
     }
   }
   // the step's last kernel on the main stream (K8 follows on the second one, dlg_step_tail): the device scalars of the
@@ -340,7 +341,7 @@ __global__ void __launch_bounds__(TPB) k_part_take_step(const double* __restrict
     const double* o3 = out3;
     const int t = threadIdx.x, d = (int)(o3 - dsc), f = ident_out ? (int)(ident_out - dsc) : -8;
     hsc[t] = (t == d) ? (double)kind : (t == d + 1) ? ((kind == 2) ? k : NAN) : (t == d + 2) ? n2g :
-             (t == f) ? s_skip : (t == f + 1) ? s_ratio : dsc[t];
+             (t == f) ? s_skip : (t == f + 1) ? s_ratio : (t == f + 4) ? s_negc : dsc[t];
   }
 }
 

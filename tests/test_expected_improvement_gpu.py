@@ -91,29 +91,47 @@ def test_the_value_from_the_solved_system_is_the_pass_over_J(gpu, monkeypatch, s
           f"{max(abs(a[2] - b[2]) / abs(b[2]) for a, b in zip(res[False], res[True])):.2e}, to the oracle {abs(got[2] - o8[5]) / abs(o8[5]):.2e}")
 
 
-def test_a_damped_or_ill_conditioned_factor_keeps_the_pass_over_J(gpu, monkeypatch):
-    """lambda > 0 (the reference's lambda loop, dogleg.c:656-677): the Gauss-Newton and the interpolated step take the pass
-    over J whatever the pivots look like; the Cauchy step to the edge never needs it.  A Jacobian whose columns are scaled
-    over four decades at lambda = 0: the pivot ratio is past the bound, the pass over J again.  Same numbers as the
-    oracle's either way."""
-    monkeypatch.delenv("DOGLEG_AMD_EI_JPASS", raising=False)
+def test_a_damped_factor_gives_the_value_too_and_an_ill_conditioned_one_keeps_the_pass_over_J(gpu, monkeypatch):
+    """lambda > 0 (the reference's lambda loop, dogleg.c:656-677) with a well-conditioned damped factor: (JtJ + lambda I) gn =
+    -Jt x gives |J gn|^2 = -<Jt x, gn> - lambda |gn|^2 and <J cauchy, J gn> = -<cauchy, Jt x> - lambda <cauchy, gn> -- all
+    three kinds of step and the retry from the cached vectors against the pass over J, the interpolated step against the
+    oracle's.  A Jacobian whose columns are scaled over four decades at lambda = 0: the pivot ratio is past the bound, the
+    pass over J.  Same numbers as the oracle's either way."""
     prob = oa.BAProblem(49, 900, 10000, seed=5)
     p = prob.p0()
     x, Jx = prob.eval(p)
-    for lam in (1e-6, 1.0):
+    kinds_seen = {}
+    for lam in (1e-6, 1.0, 1e3):
         o8 = _oracle_step(prob, p, x, Jx, lam)
-        be = _sparse_backend(prob, monkeypatch, False)
-        be.set_p(0, p)
-        for trf, want_src in ((1e-3, True), (None, False), (1e3, False)):
-            be.upload(0, x, Jx); be.eval(0)
-            tr = 0.5 * (np.sqrt(o8[1]) + np.sqrt(o8[2])) if trf is None else trf * np.sqrt(o8[2])
-            lam_out, r, _ = be.take_step(0, 1, tr, lam)
-            assert lam_out == lam
-            src, ratio = be.ei_source()
-            assert src is want_src, (lam, trf, r["kind"], src)
-            if trf is None:
-                assert abs(r["ei"] - o8[5]) <= TOL * abs(o8[5])
-        be.close()
+        res = {}
+        for jpass in (True, False):
+            be = _sparse_backend(prob, monkeypatch, jpass)
+            be.set_p(0, p)
+            rows = []
+            for trf in (1e-3, None, 1e3):
+                be.upload(0, x, Jx); be.eval(0)
+                tr = 0.5 * (np.sqrt(o8[1]) + np.sqrt(o8[2])) if trf is None else trf * np.sqrt(o8[2])
+                lam_out, r, _ = be.take_step(0, 1, tr, lam)
+                assert lam_out == lam
+                src, ratio = be.ei_source()
+                rows.append((r["kind"], r["ei"], src, ratio))
+                kind = capi.KIND_CAUCHY if r["n2c"] >= (0.5 * tr) ** 2 else (capi.KIND_GN if r["n2g"] <= (0.5 * tr) ** 2 else capi.KIND_INTERP)
+                n2s, k, am, ei, pn = be.step(0, 1, kind, 0.5 * tr)
+                rows.append((kind, ei, be.ei_source()[0], ratio))
+            be.close()
+            res[jpass] = rows
+        for a_, b_ in zip(res[False], res[True]):
+            assert a_[0] == b_[0]
+            assert a_[2] is True and b_[2] is False, (lam, a_, b_)
+            assert abs(a_[1] - b_[1]) <= TOL * abs(b_[1]), (lam, a_, b_)
+        kinds_seen[lam] = {a_[0] for a_ in res[False]}
+        # (a heavily damped Gauss-Newton step is shorter than the Cauchy step: no interpolation there)
+        got = res[False][2]
+        if o8[2] > o8[1]:
+            assert got[0] == capi.KIND_INTERP and abs(got[1] - o8[5]) <= TOL * abs(o8[5]), (lam, got, o8[5])
+    assert kinds_seen[1e-6] == {capi.KIND_CAUCHY, capi.KIND_GN, capi.KIND_INTERP}, kinds_seen
+    assert all(capi.KIND_GN in k for k in kinds_seen.values()), kinds_seen
+    monkeypatch.delenv("DOGLEG_AMD_EI_JPASS", raising=False)
     # columns over four decades (config #5's shape, scaled down; no exactly-zero columns: lambda stays 0)
     prob = oa.BAProblem(49, 900, 10000, seed=5, scale_decades=4.0)
     p = prob.p0()
