@@ -1226,8 +1226,7 @@ static int assemble_launch(dlg_backend* b, const double* Jv, double* Lx = nullpt
           const int smax = std::min((int)sh.smax, std::max(1, 2/std::max((int)sh.nT, 1)));
           if(!(nrt > 0 && smax*sh.nJ*nrt <= 64 && smax*sh.nJ <= 16)) ts = false;
         }
-      static const bool old_ts = getenv("DLG_ASM_OLD_TSTORE") != nullptr;      // (A/B only)
-      if(old_ts) ts = false;
+      if(H.asm_ts_off) ts = false;
       if(H.asm_lds_len == 18 && xvec && xt && ts)
         ASM_LAUNCH((k_assemble_mfma<18, true, true, true>), dim3(dlg_cdiv(nruns, TPB/64)), dim3(TPB),
                            sizeof(double)*(TPB/64)*(ASM_U*4*18 + 16*ASM_TLD), st, Y->asm_run, nruns, Y->asm_mtask,

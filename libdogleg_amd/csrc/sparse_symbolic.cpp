@@ -1219,6 +1219,7 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
     // (same I in every row-block) or transient (all I different).  J qualifies when every
     // transient block receives exactly one contribution overall.
     const bool use_mfma = env_int("DOGLEG_AMD_ASM_MFMA", 1) != 0;
+    S.asm_ts_off = env_int("DOGLEG_AMD_ASM_MFMA", 1) == 2;
     const int KG_PER_TASK_T = 64, KG_PER_TASK_P = 256;
     std::map<std::vector<int>, int> shape_ids;
     std::vector<int> tseen(nvb, -1), pseen(nvb, -1), fin_of(nvb, -1);

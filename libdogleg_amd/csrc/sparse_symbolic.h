@@ -279,6 +279,7 @@ struct SymHost
   std::vector<int64_t>  asm_fin2_list;
   int asm_lds_len = 0;                // LDS row stride (doubles) of the MFMA assembly kernel
   bool asm_td_inline = false;         // every k-group with transient blocks carries their destinations in its record (AsmKG::td) and stores them (meta bit 11)
+  bool asm_ts_off = false;          // DOGLEG_AMD_ASM_MFMA=2: the MFMA assembly with the four masked transient stores a k-group (the form that serves shapes whose entries do not fit 64 lanes)
   // Jt*x out of the assembly kernel: every MFMA task leaves a 16-double record (lanes 0..nJ-1: its own
   // column block, nJ..: the rider it carries); var-block v sums the records jf_ent[jf_ptr[v] .. jf_ptr[v+1])
   // (entry = 16*task + first lane) in that order.  asm_jtx_ok: every var-block with rows is covered.

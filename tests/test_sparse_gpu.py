@@ -138,6 +138,7 @@ def test_ba_lambda_path(gpu):
 
 @pytest.mark.parametrize("env", [
     {"DOGLEG_AMD_ASM_MFMA": "0"},                                   # LDS assembly kernel k_assemble for every column block
+    {"DOGLEG_AMD_ASM_MFMA": "2"},                                   # MFMA assembly with the masked transient stores (shapes that do not fit one round of lanes)
     {"DOGLEG_AMD_SYRK_MIN": "0", "DOGLEG_AMD_NO_UPDATE_MFMA": "1"},  # k_update_coop instead of SYRK+gather / MFMA updates
     {"DOGLEG_AMD_SYRK_MIN": "0"},                                   # k_update_mfma at every level
     {"DOGLEG_AMD_SYRK_MIN": "1", "DOGLEG_AMD_NO_SYRK_FUSE": "1"},    # stand-alone SYRK kernel at every level
@@ -156,7 +157,7 @@ def test_ba_lambda_path(gpu):
     {"DOGLEG_AMD_NO_PREMUL": "1"},                                  # backward block sweep with the operands multiplied in the loop
     {"DOGLEG_AMD_NO_LEAF_KERNEL": "1"},                             # merged leaves through the general factor kernel
     {"DOGLEG_AMD_FRONT_REPLICAS": "3"},                             # another replica count in the one-launch region
-], ids=["lds-assembly", "coop-update", "mfma-update", "syrk-unfused", "no-rider", "small-slices", "no-multifrontal",
+], ids=["lds-assembly", "mfma-assembly-masked-stores", "coop-update", "mfma-update", "syrk-unfused", "no-rider", "small-slices", "no-multifrontal",
         "multifrontal-from-leaves", "multifrontal-128", "multifrontal-256", "device-finals",
         "bwd-x-from-hbm", "no-overlap", "no-persistent-top", "deep-persistent-top",
         "separate-jtx", "no-premul", "no-leaf-kernel", "replica-counts"])
