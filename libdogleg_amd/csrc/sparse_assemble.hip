@@ -215,6 +215,7 @@ typedef double dlg_v4d __attribute__((ext_vector_type(4)));
 #define DLG_ASM_U 4
 #endif
 constexpr int ASM_U = DLG_ASM_U;
+constexpr int ASM_TBUF = 16*17 + 64;    // doubles of that square plus the four rows' Jt*x sums of a task's end (te_ok)
 constexpr int ASM_TLD = 17;             // doubles a row of the wave-private square the transient product turns through (asm_mfma_run: ts_ok)
 // One wave per RUN = consecutive tasks of one shape whose k-groups are contiguous: the shape's
 // lane constants are loaded once and the k-group stream is software-pipelined across the
@@ -238,7 +239,8 @@ __device__ __forceinline__ void asm_mfma_run(const AsmRun& R, const AsmMTask* __
                                              double* __restrict__ Lx, double* __restrict__ part, int lane,
                                              double* __restrict__ tile, int LEN_rt,
                                              const double* __restrict__ xvec, double* __restrict__ jtp,
-                                             double* __restrict__ jtx_out, double* __restrict__ tbuf, uint32_t trash_off)
+                                             double* __restrict__ jtx_out, double* __restrict__ tbuf, uint32_t trash_off,
+                                             const uint32_t* __restrict__ pent)
 {
   constexpr int KD = ASM_KG_DW;
   // CLEN > 0: the tile row stride is a compile-time constant (the usual 16-column window), so the
@@ -304,6 +306,21 @@ __device__ __forceinline__ void asm_mfma_run(const AsmRun& R, const AsmMTask* __
       ts_cb = (int)SH->ta[mmL] | sbb << 8;
     }
   }
+  // TS, the END of a task: its persistent blocks and its Jt*x record leave the same way -- the accumulator and the four
+  // rows' Jt*x sums through the wave's LDS square, ONE entry a lane (the table of the shape: sparse_host.hip, asm_pent),
+  // one unconditional store.  In four masked rounds with nested cases (a block of J's panel or its partial, the rider's
+  // partial, the lower triangle of (J, J) only) plus two shuffles and two masked stores for Jt*x the end of a task was
+  // ~70 instructions -- every third k-group of config #4's point tasks.  te_ok: the shape's entries fit 64 lanes.
+  // (a property of the whole schedule, with ts_ok: the host found every shape's entries in at most two rounds of 64 lanes;
+  // the second round's words -- the camera blocks' 81 entries -- are fetched at the task's end, such tasks are long)
+  constexpr bool te_ok = ts_ok && JTX;
+  uint32_t te_w0 = 0;
+  bool te_two = false;
+  if(te_ok)
+  {
+    te_w0 = pent[lane];
+    te_two = __builtin_amdgcn_readfirstlane((int)pent[64]) != 0;
+  }
   double* const tb_wr = tbuf + (kq*ASM_TLD + m);
   dlg_v4d accP = {0.0, 0.0, 0.0, 0.0}, accT = {0.0, 0.0, 0.0, 0.0};
   // task records: current + next (fetched ahead, as ONE vector load each: lane l holds dword l of
@@ -317,14 +334,17 @@ __device__ __forceinline__ void asm_mfma_run(const AsmRun& R, const AsmMTask* __
   int pdc = pdest[16*(int64_t)min(tix, tlast) + m], pdn = pdest[16*(int64_t)min(tix + 1, tlast) + m];
   int64_t Tpart, Trpart, colT, colP;     // current task: partial offsets; Lx offset of this lane's column
   uint32_t colTs = 0;                    // (ts_ok: Lx offset of the entry this lane stores, its row-block's offset aside)
+  int64_t Tpanel = 0;                    // (te_ok: the task's panel)
   int Tjvar = -1;                        // ... first variable of J if the task writes Jt*x itself
+  int Tld = 0;                           // ... rows of J's panel
   auto task_unpack = [&](int v) {
     if(JTX) Tjvar = __builtin_amdgcn_readlane(v, 12);
     const int ld = __builtin_amdgcn_readlane(v, 4);
+    Tld = ld;
     const int64_t panel = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readlane(v, 7) << 32) | (uint32_t)__builtin_amdgcn_readlane(v, 6));
     Tpart  = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readlane(v, 9) << 32) | (uint32_t)__builtin_amdgcn_readlane(v, 8));
     Trpart = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readlane(v, 11) << 32) | (uint32_t)__builtin_amdgcn_readlane(v, 10));
-    colT = panel + (int64_t)bb*ld; colP = panel + (int64_t)m*ld;
+    colT = panel + (int64_t)bb*ld; colP = panel + (int64_t)m*ld; Tpanel = panel;
     if(ts_ok) colTs = (uint32_t)panel + (uint32_t)((ts_cb >> 8)*ld + (ts_cb & 0xFF)); };
   task_unpack(tcv);
   // k-group records of one iteration: ASM_U*KD dwords, one vector load, prefetched one iteration ahead
@@ -500,6 +520,39 @@ __device__ __forceinline__ void asm_mfma_run(const AsmRun& R, const AsmMTask* __
       }
       if(meta[u] & (1u << 12))           // end of a task: its persistent blocks
       {
+        if(te_ok)
+        {
+          double* const tbj = tbuf + 16*ASM_TLD;               // [4][16] the rows' Jt*x sums
+#pragma unroll
+          for(int r = 0; r < 4; r++) tb_wr[4*r*ASM_TLD] = accP[r];
+          tbj[16*kq + m] = jacc;
+          for(int rd = 0; rd < (te_two ? 2 : 1); rd++)
+          {
+            const uint32_t te_w = rd == 0 ? te_w0 : pent[64 + lane];
+            const int te_kind = te_w & 3, te_n = (te_w >> 6) & 15;
+            const int ro = __builtin_amdgcn_ds_bpermute((int)((te_w >> 10) & 15) << 2, pdc);
+            double val = tbuf[(te_kind == 3 ? 0 : (int)((te_w >> 2) & 15)*ASM_TLD) + (te_kind == 3 ? 0 : te_n)];
+            const int te_c = te_kind == 3 ? te_n : 0;
+            // the four rows of the k-groups: (0 + 1) + (2 + 3), as the shuffles added them
+            const double tj = (tbj[te_c] + tbj[16 + te_c]) + (tbj[32 + te_c] + tbj[48 + te_c]);
+            const int pa = (int)((te_w >> 14) & 15);
+            double* dst = Lx + (size_t)trash_off + (lane & 7);
+            if(te_kind == 1)
+            {
+              if(Tpart < 0) { if(!(te_w >> 30 & 1)) dst = Lx + (Tpanel + (int64_t)te_n*Tld + (ro + pa)); }
+              else dst = part + (Tpart + ((int)((te_w >> 18) & 255) + te_n*(int)((te_w >> 26) & 15)));
+            }
+            else if(te_kind == 2) dst = part + (Trpart + ((te_n - nJ)*nJr + pa));
+            else if(te_kind == 3)
+            {
+              val = tj;
+              dst = (Tjvar >= 0 && te_n < nJ) ? jtx_out + (Tjvar + te_n) : jtp + (16*(int64_t)tix + te_n);
+            }
+            *dst = val;
+          }
+        }
+        else
+        {
 #pragma unroll
         for(int r = 0; r < 4; r++)
           if(4*r < MP)
@@ -515,7 +568,6 @@ __device__ __forceinline__ void asm_mfma_run(const AsmRun& R, const AsmMTask* __
               else if(pn && PS(r) == rslot) part[Trpart + ((m - nJ)*nJr + PA(r))] = accP[r];
             }
           }
-        accP = (dlg_v4d){0.0, 0.0, 0.0, 0.0};
         if(JTX)
         {
           // the four rows of the k-groups sit in the four lane groups: (0 + 1) + (2 + 3)
@@ -526,8 +578,10 @@ __device__ __forceinline__ void asm_mfma_run(const AsmRun& R, const AsmMTask* __
             if(Tjvar >= 0 && m < nJ) jtx_out[Tjvar + m] = t;     // the only task of its block: (Jt x)[J] is complete
             else jtp[16*(int64_t)tix + m] = t;                   // (a rider on board still leaves its part of the record)
           }
-          jacc = 0.0;
         }
+        }
+        accP = (dlg_v4d){0.0, 0.0, 0.0, 0.0};
+        jacc = 0.0;
         tix++;
         task_unpack(tnv); pdc = pdn;
         tnv = task_fetch(tix + 1);
@@ -557,7 +611,8 @@ __global__ void __launch_bounds__(TPB) ASM_WPE_ATTR k_assemble_mfma(const AsmRun
                                                        const double* __restrict__ vals,
                                                        double* __restrict__ Lx, double* __restrict__ part, int LEN,
                                                        const double* __restrict__ xvec, double* __restrict__ jtp,
-                                                       double* __restrict__ jtx_out, int only_shape, uint32_t trash_off)
+                                                       double* __restrict__ jtx_out, int only_shape, uint32_t trash_off,
+                                                       const uint32_t* __restrict__ pent)
 {
   extern __shared__ double asm_tiles[];
   const int lane = threadIdx.x & 63;
@@ -568,9 +623,10 @@ __global__ void __launch_bounds__(TPB) ASM_WPE_ATTR k_assemble_mfma(const AsmRun
   const AsmShape* SH = shapes + tasks[R.task0].shape;
   double* tile = asm_tiles + (threadIdx.x >> 6)*(ASM_U*4*LEN);
   // (XT: the launch sized the LDS for a 16-row square a wave behind the tiles)
-  double* tbuf = TS ? asm_tiles + (TPB/64)*(ASM_U*4*LEN) + (threadIdx.x >> 6)*(16*ASM_TLD) : nullptr;
-  if(SH->MT > 0) asm_mfma_run<true, CLEN, JTX, XT, TS>(R, tasks, SH, kgs, tdest, pdest, vals, Lx, part, lane, tile, LEN, xvec, jtp, jtx_out, tbuf, trash_off);
-  else           asm_mfma_run<false, CLEN, JTX, XT, TS>(R, tasks, SH, kgs, tdest, pdest, vals, Lx, part, lane, tile, LEN, xvec, jtp, jtx_out, tbuf, trash_off);
+  double* tbuf = TS ? asm_tiles + (TPB/64)*(ASM_U*4*LEN) + (threadIdx.x >> 6)*ASM_TBUF : nullptr;
+  const uint32_t* pe = pent + 128*tasks[R.task0].shape;
+  if(SH->MT > 0) asm_mfma_run<true, CLEN, JTX, XT, TS>(R, tasks, SH, kgs, tdest, pdest, vals, Lx, part,  lane, tile, LEN, xvec, jtp, jtx_out, tbuf, trash_off, pe);
+  else           asm_mfma_run<false, CLEN, JTX, XT, TS>(R, tasks, SH, kgs, tdest, pdest, vals, Lx, part, lane, tile, LEN, xvec, jtp, jtx_out, tbuf, trash_off, pe);
 }
 // Jt*x from the records the assembly kernel left (JTX): var-block v = blks[...] sums its list in order.
 // short lists: 16 threads per var-block (thread = entry of the block); long ones (a dense block that
@@ -1226,33 +1282,33 @@ static int assemble_launch(dlg_backend* b, const double* Jv, double* Lx = nullpt
           const int smax = std::min((int)sh.smax, std::max(1, 2/std::max((int)sh.nT, 1)));
           if(!(nrt > 0 && smax*sh.nJ*nrt <= 64 && smax*sh.nJ <= 16)) ts = false;
         }
-      if(H.asm_ts_off) ts = false;
+      if(H.asm_ts_off || !Y->asm_pent_ok) ts = false;
       if(H.asm_lds_len == 18 && xvec && xt && ts)
         ASM_LAUNCH((k_assemble_mfma<18, true, true, true>), dim3(dlg_cdiv(nruns, TPB/64)), dim3(TPB),
-                           sizeof(double)*(TPB/64)*(ASM_U*4*18 + 16*ASM_TLD), st, Y->asm_run, nruns, Y->asm_mtask,
-                           Y->asm_kg, Y->asm_shape, Y->asm_tdest, Y->asm_pdest, Jv, Lx, Y->asm_part, 18, xvec, Y->jtp, Jt_x, only_shape, (uint32_t)H.lx_size);
+                           sizeof(double)*(TPB/64)*(ASM_U*4*18 + ASM_TBUF), st, Y->asm_run, nruns, Y->asm_mtask,
+                           Y->asm_kg, Y->asm_shape, Y->asm_tdest, Y->asm_pdest, Jv, Lx, Y->asm_part, 18, xvec, Y->jtp, Jt_x, only_shape, (uint32_t)H.lx_size, Y->asm_pent);
       else if(H.asm_lds_len == 18 && xvec && xt)
         ASM_LAUNCH((k_assemble_mfma<18, true, true>), dim3(dlg_cdiv(nruns, TPB/64)), dim3(TPB),
                            sizeof(double)*(TPB/64)*ASM_U*4*18, st, Y->asm_run, nruns, Y->asm_mtask,
-                           Y->asm_kg, Y->asm_shape, Y->asm_tdest, Y->asm_pdest, Jv, Lx, Y->asm_part, 18, xvec, Y->jtp, Jt_x, only_shape, (uint32_t)H.lx_size);
+                           Y->asm_kg, Y->asm_shape, Y->asm_tdest, Y->asm_pdest, Jv, Lx, Y->asm_part, 18, xvec, Y->jtp, Jt_x, only_shape, (uint32_t)H.lx_size, Y->asm_pent);
       else if(H.asm_lds_len == 18 && xvec)
         ASM_LAUNCH((k_assemble_mfma<18, true>), dim3(dlg_cdiv(nruns, TPB/64)), dim3(TPB),
                            sizeof(double)*(TPB/64)*ASM_U*4*18, st, Y->asm_run, nruns, Y->asm_mtask,
-                           Y->asm_kg, Y->asm_shape, Y->asm_tdest, Y->asm_pdest, Jv, Lx, Y->asm_part, 18, xvec, Y->jtp, Jt_x, only_shape, (uint32_t)H.lx_size);
+                           Y->asm_kg, Y->asm_shape, Y->asm_tdest, Y->asm_pdest, Jv, Lx, Y->asm_part, 18, xvec, Y->jtp, Jt_x, only_shape, (uint32_t)H.lx_size, Y->asm_pent);
       else if(xvec)
         ASM_LAUNCH((k_assemble_mfma<0, true>), dim3(dlg_cdiv(nruns, TPB/64)), dim3(TPB),
                            sizeof(double)*(TPB/64)*ASM_U*4*H.asm_lds_len, st, Y->asm_run, nruns, Y->asm_mtask,
                            Y->asm_kg, Y->asm_shape, Y->asm_tdest, Y->asm_pdest, Jv, Lx, Y->asm_part,
-                           H.asm_lds_len, xvec, Y->jtp, Jt_x, only_shape, (uint32_t)H.lx_size);
+                           H.asm_lds_len, xvec, Y->jtp, Jt_x, only_shape, (uint32_t)H.lx_size, Y->asm_pent);
       else if(H.asm_lds_len == 18)
         ASM_LAUNCH((k_assemble_mfma<18, false>), dim3(dlg_cdiv(nruns, TPB/64)), dim3(TPB),
                            sizeof(double)*(TPB/64)*ASM_U*4*18, st, Y->asm_run, nruns, Y->asm_mtask,
-                           Y->asm_kg, Y->asm_shape, Y->asm_tdest, Y->asm_pdest, Jv, Lx, Y->asm_part, 18, nox, nojt, nojt, only_shape, (uint32_t)H.lx_size);
+                           Y->asm_kg, Y->asm_shape, Y->asm_tdest, Y->asm_pdest, Jv, Lx, Y->asm_part, 18, nox, nojt, nojt, only_shape, (uint32_t)H.lx_size, Y->asm_pent);
       else
         ASM_LAUNCH((k_assemble_mfma<0, false>), dim3(dlg_cdiv(nruns, TPB/64)), dim3(TPB),
                            sizeof(double)*(TPB/64)*ASM_U*4*H.asm_lds_len, st, Y->asm_run, nruns, Y->asm_mtask,
                            Y->asm_kg, Y->asm_shape, Y->asm_tdest, Y->asm_pdest, Jv, Lx, Y->asm_part,
-                           H.asm_lds_len, nox, nojt, nojt, only_shape, (uint32_t)H.lx_size);
+                           H.asm_lds_len, nox, nojt, nojt, only_shape, (uint32_t)H.lx_size, Y->asm_pent);
     }
     if(nt > 0)
       hipLaunchKernelGGL(k_assemble, dim3(dlg_cdiv(nt, TPB/64)), dim3(TPB), 0, st, Y->asm_ctask, nt,

@@ -199,6 +199,39 @@ int sparse_set_pattern(dlg_backend* b, const int* colptr, const int* rowidx)
   }
   UP(asm_shape); UP(asm_kg); UP(asm_mtask); UP(asm_tdest); UP(asm_fin2); UP(asm_fin2_list); UP(asm_run); UP(asm_pdest);
   {
+    // What the END of a task stores (asm_mfma_run, TS): the persistent blocks' entries -- rows of the task's accumulator that
+    // belong to a block (I, J), columns of J; the rider's diagonal block --, then the sixteen entries of the task's Jt*x
+    // record, ONE entry a lane in the order that puts consecutive rows of a destination column on consecutive lanes.
+    // word: bits 0-1 kind (1 block of J's panel, 2 rider's diagonal, 3 Jt*x; 0 no entry), 2-5 accumulator row, 6-9 column,
+    // 10-13 slot ordinal, 14-17 row in its block, 18-25 offset of its block in a partial, 26-29 rows of its block,
+    // 30 strictly above the diagonal of (J, J).  Up to two rounds of 64 (camera blocks: 81 entries); more, or fields that do not
+    // fit: asm_pent_ok is false and the launch takes the kernel with the four masked rounds.
+    std::vector<uint32_t> pent(128*std::max<size_t>(1, H.asm_shape.size()), 0u);
+    Y->asm_pent_ok = true;
+    for(size_t q = 0; q < H.asm_shape.size(); q++)
+    {
+      const AsmShape& sh = H.asm_shape[q];
+      std::vector<uint32_t> e;
+      bool fits = true;
+      auto word = [&](int kind, int mm, int n) {
+        if(sh.pa[mm] > 15 || sh.pnI[mm] > 15 || sh.pslot[mm] > 15) fits = false;
+        return (uint32_t)kind | (uint32_t)mm << 2 | (uint32_t)n << 6 | (uint32_t)(sh.pslot[mm] & 15) << 10 | (uint32_t)(sh.pa[mm] & 15) << 14 |
+               (uint32_t)sh.paccoff[mm] << 18 | (uint32_t)(sh.pnI[mm] & 15) << 26 |
+               (uint32_t)((sh.pslot[mm] == sh.dslot && sh.pa[mm] < n) ? 1u : 0u) << 30; };
+      for(int n = 0; n < sh.nJ; n++)
+        for(int mm = 0; mm < sh.MP && mm < 16; mm++)
+          if(sh.pslot[mm] != 0xFF) e.push_back(word(1, mm, n));
+      for(int n = sh.nJ; n < sh.nJ + sh.nJr && n < 16; n++)
+        for(int mm = 0; mm < sh.MP && mm < 16; mm++)
+          if(sh.pslot[mm] != 0xFF && sh.pslot[mm] == sh.rslot) e.push_back(word(2, mm, n));
+      for(int c = 0; c < 16; c++) e.push_back(3u | (uint32_t)c << 6);
+      // (two rounds of 64 lanes at most; the second round's first word is non-zero exactly if there is one: an entry's kind is)
+      if(!fits || e.size() > 128) { Y->asm_pent_ok = false; continue; }
+      for(size_t k = 0; k < e.size(); k++) pent[128*q + k] = e[k];
+    }
+    DLG_CHECK(upload(Y->asm_pent, pent)); Y->allocs.push_back(Y->asm_pent);
+  }
+  {
     // fin on the side (sparse_assemble.hip): allowed where every block the partial-sum stages store lies in a panel
     // above level 0 (the leaf level's factor kernel runs beside them) and no LDS-kernel group has partial sums
     std::vector<std::pair<int64_t, int>> by_lx((size_t)H.nsn);

@@ -85,6 +85,8 @@ struct SparseSym
   int *jtx_fin_short = nullptr, *jtx_fin_long = nullptr; int n_fin_short = 0, n_fin_long = 0;   // entries by list length
   AsmRho* asm_rho = nullptr; AsmPair* asm_pair = nullptr; AsmSlot* asm_slot = nullptr;
   AsmBatch* asm_batch = nullptr; AsmTask* asm_ctask = nullptr; AsmFin* asm_cfin = nullptr;
+  bool asm_pent_ok = false;
+  uint32_t* asm_pent = nullptr;       // [shape][128] what the end of a task stores, one entry a lane (sparse_host.hip; asm_mfma_run: TS)
   AsmShape* asm_shape = nullptr; AsmKG* asm_kg = nullptr; AsmMTask* asm_mtask = nullptr; int* asm_tdest = nullptr;
   int *jf_ptr = nullptr, *jf_ent = nullptr, *jf_var0 = nullptr, *jf_w = nullptr, *jf_short = nullptr, *jf_long = nullptr;
   double* jf_lpart = nullptr; int* jf_lcnt = nullptr;      // k_jtx_fin2_long: [long block][JFL_SEG][16] segment sums, arrival counters
