@@ -215,6 +215,9 @@ typedef double dlg_v4d __attribute__((ext_vector_type(4)));
 #define DLG_ASM_U 4
 #endif
 constexpr int ASM_U = DLG_ASM_U;
+// (a run's k-groups are a multiple of ASM_KG_ALIGN, sparse_symbolic.cpp: with the default unroll no k-group of an iteration
+// lies past the end of its run, and nothing in the loop asks)
+constexpr bool ASM_RUN_ALIGNED = ASM_KG_ALIGN % ASM_U == 0;
 constexpr int ASM_TBUF = 16*17 + 64;    // doubles of that square plus the four rows' Jt*x sums of a task's end (te_ok)
 constexpr int ASM_TLD = 17;             // doubles a row of the wave-private square the transient product turns through (asm_mfma_run: ts_ok)
 // One wave per RUN = consecutive tasks of one shape whose k-groups are contiguous: the shape's
@@ -378,7 +381,7 @@ __device__ __forceinline__ void asm_mfma_run(const AsmRun& R, const AsmMTask* __
     for(int u = 0; u < ASM_U; u++)
     {
       bpre[u] = __builtin_amdgcn_ds_bpermute(vf_sel + 4*KD*u, rec);
-      if(kgi + u > kglast && !(x_in_tile && m == 15)) bpre[u] = -1;
+      if(!ASM_RUN_ALIGNED && kgi + u > kglast && !(x_in_tile && m == 15)) bpre[u] = -1;
       const double* src = vf_base + (uint32_t)max(bpre[u], 0);
 #ifdef DLG_ASM_NO_VLOAD
       vpre[u] = (double)(((long)src >> 3) & 7);
@@ -397,7 +400,7 @@ __device__ __forceinline__ void asm_mfma_run(const AsmRun& R, const AsmMTask* __
     uint32_t meta[ASM_U];
     int td[ASM_U];
 #pragma unroll
-    for(int u = 0; u < ASM_U; u++) meta[u] = kg + u <= kglast ? (uint32_t)__builtin_amdgcn_readlane(gv, KD*u + 5) : 0u;
+    for(int u = 0; u < ASM_U; u++) meta[u] = (ASM_RUN_ALIGNED || kg + u <= kglast) ? (uint32_t)__builtin_amdgcn_readlane(gv, KD*u + 5) : 0u;
     double xv[ASM_U];
     if(JTX && !x_in_tile)
     {
@@ -425,7 +428,7 @@ __device__ __forceinline__ void asm_mfma_run(const AsmRun& R, const AsmMTask* __
       for(int u = 0; u < ASM_U; u++)
       {
         b[u] = __builtin_amdgcn_ds_bpermute(4*(KD*u + kq), gv);
-        if(kg + u > kglast) b[u] = -1;
+        if(!ASM_RUN_ALIGNED && kg + u > kglast) b[u] = -1;
         v[u] = vals[max(b[u], 0) + col0 + min(c0 + m, ncopy - 1)];
       }
 #pragma unroll

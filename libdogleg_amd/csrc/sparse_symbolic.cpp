@@ -1672,16 +1672,40 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
       std::vector<int> order(nt);
       std::iota(order.begin(), order.end(), 0);
       std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return S.asm_mtask[a].shape < S.asm_mtask[b].shape; });
+      // (the runs are cut first -- consecutive tasks of one shape, at most RUN_KG k-groups --, and every run's k-groups are
+      // padded with empty ones to a multiple of the kernel's unroll: the kernel then never looks past the end of its run
+      // inside an iteration (four scalar compares and a select a k-group).  An empty k-group behind a task's last one has
+      // no rows, no slots and no end: it costs a product of zeros.)
+      const int RUN_KG = 32;
       std::vector<AsmMTask> tasks2; tasks2.reserve(nt);
-      std::vector<AsmKG> kg2; kg2.reserve(S.asm_kg.size());
-      for(int k : order)
+      std::vector<AsmKG> kg2; kg2.reserve(S.asm_kg.size() + S.asm_kg.size()/8);
+      S.asm_run.clear();
+      for(int q = 0; q < nt; )
       {
-        AsmMTask T = S.asm_mtask[k];
-        const int k0 = (int)kg2.size();
-        kg2.insert(kg2.end(), S.asm_kg.begin() + T.kg0, S.asm_kg.begin() + T.kg1);
-        kg2.back().meta |= 1u << 12;             // last k-group of its task
-        T.kg0 = k0; T.kg1 = (int)kg2.size();
-        tasks2.push_back(T);
+        AsmRun R; R.task0 = q; R.kg0 = (int)kg2.size();
+        const int shape0 = S.asm_mtask[order[q]].shape;
+        int nkg = 0;
+        do
+        {
+          AsmMTask T = S.asm_mtask[order[q]];
+          const int k0 = (int)kg2.size();
+          kg2.insert(kg2.end(), S.asm_kg.begin() + T.kg0, S.asm_kg.begin() + T.kg1);
+          kg2.back().meta |= 1u << 12;             // last k-group of its task
+          nkg += T.kg1 - T.kg0;
+          T.kg0 = k0; T.kg1 = (int)kg2.size();
+          tasks2.push_back(T);
+          q++;
+        }
+        while(q < nt && S.asm_mtask[order[q]].shape == shape0 &&
+              nkg + (S.asm_mtask[order[q]].kg1 - S.asm_mtask[order[q]].kg0) <= RUN_KG);
+        while(((int)kg2.size() - R.kg0) % ASM_KG_ALIGN != 0)
+        {
+          AsmKG g; g.base[0] = g.base[1] = g.base[2] = g.base[3] = -1; g.tq = 0; g.meta = 1u << 13;      // (no slots; "destinations in the record": none)
+          g.xr[0] = g.xr[1] = g.xr[2] = g.xr[3] = 0; g.td[0] = g.td[1] = 0;
+          kg2.push_back(g);
+        }
+        R.task1 = q; R.kg1 = (int)kg2.size();
+        S.asm_run.push_back(R);
       }
       S.asm_mtask.swap(tasks2); S.asm_kg.swap(kg2);
       // Jt*x beside JtJ: which task records every var-block sums (task order)
@@ -1723,17 +1747,6 @@ int sym_analyze(SymHost& S, int N, int M, const int* cp, const int* ri, int row0
         if(S.asm_shape[T.shape].MT > 0)
           for(int g = T.kg0; g < T.kg1; g++)
             if(((S.asm_kg[g].meta >> 8) & 7) > 0 && (!(S.asm_kg[g].meta & (1u << 13)) || !(S.asm_kg[g].meta & (1u << 11)))) S.asm_td_inline = false;     // (... and stores them: no row-block of more than four rows)
-      const int RUN_KG = 32;
-      for(int k = 0; k < nt; )
-      {
-        AsmRun R; R.task0 = k; R.kg0 = S.asm_mtask[k].kg0;
-        int nkg = 0;
-        do { nkg += S.asm_mtask[k].kg1 - S.asm_mtask[k].kg0; k++; }
-        while(k < nt && S.asm_mtask[k].shape == S.asm_mtask[R.task0].shape &&
-              nkg + (S.asm_mtask[k].kg1 - S.asm_mtask[k].kg0) <= RUN_KG);
-        R.task1 = k; R.kg1 = S.asm_mtask[k-1].kg1;
-        S.asm_run.push_back(R);
-      }
       // (Tried: an XCD-aware launch order -- runs sorted by the position in J of the first row they
       // read, the sorted list cut into 8 segments laid out on the workgroups s, s + 8, ..., so that the
       // two readers of a stretch of J, its points' tasks and its cameras' tasks, meet in one XCD's L2.

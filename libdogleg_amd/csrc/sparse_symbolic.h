@@ -123,6 +123,7 @@ struct AsmKG
 };
 static_assert(sizeof(AsmKG) == 48, "AsmKG layout");
 constexpr int ASM_KG_DW = 12;   // dwords per record
+constexpr int ASM_KG_ALIGN = 4; // a run's k-groups are padded to a multiple of this (the kernel's unroll, ASM_U)
 struct AsmMTask
 {
   int32_t kg0, kg1, slot0, shape;
