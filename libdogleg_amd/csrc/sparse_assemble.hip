@@ -367,7 +367,7 @@ __device__ __forceinline__ void asm_mfma_run(const AsmRun& R, const AsmMTask* __
 #ifdef DLG_ASM_PREFETCH
   // the values of the first 16 columns of an iteration's rows are fetched one iteration ahead (their
   // records two ahead): the copy into the tile finds them in registers
-  int gnn = kg_fetch(R.kg0 + ASM_U);
+  int gnn;
   double vpre[ASM_U]; int bpre[ASM_U];
   // (JTX, a window of at most 15 columns: lane 15 of every row fetches x(row) instead of a duplicate of the
   // window's last column -- it lands in column 15 of the tile row, and the Jt*x product reads it from there:
@@ -390,11 +390,29 @@ __device__ __forceinline__ void asm_mfma_run(const AsmRun& R, const AsmMTask* __
 #endif
     } };
   vals_fetch(gnv, R.kg0);
+  // Loads and stores share ONE in-order counter, and a wait for the prefetched values is written as "at most N younger
+  // operations outstanding".  At the loop's head the compiler has to be right for both ways in: over the back edge the
+  // prefetch is followed by the next records' load and (TS) the iteration's four transient stores, from here by nothing -- it
+  // took the smaller N, and every iteration's waits drained that iteration's stores (s_waitcnt vmcnt(3) .. (0) in front of
+  // the copies of the prefetched rows: profiles/r06_experiments.md section 21).  So the way in from here issues the same
+  // operations behind the prefetch as an iteration does: the records' load, and four stores into the words behind the panels.
+  gnn = kg_fetch(R.kg0 + ASM_U);
+  __builtin_amdgcn_sched_barrier(0);       // (behind the loads above, as in an iteration)
+  if(HAS_T && XT && TS)
+  {
+#pragma unroll
+    for(int u = 0; u < ASM_U; u++)
+      *reinterpret_cast<double*>(reinterpret_cast<char*>(Lx) + ((trash_off + (uint32_t)((lane + u) & 7)) << 3)) = 0.0;
+    asm volatile("" ::: "memory");
+  }
+#else
+  int gnn_unused = 0; (void)gnn_unused;
 #endif
   double* myrow = tile + kq*LEN;
 #pragma unroll
   for(int u = 0; u < ASM_U; u++) myrow[u*4*LEN + ZC] = 0.0;
-  for(int kg = R.kg0; kg < R.kg1; kg += ASM_U)
+  int kg = R.kg0;                       // (a run has at least one k-group: no test in front of the first iteration, the prefetch above stays above)
+  do
   {
     const int gv = gnv;
     uint32_t meta[ASM_U];
@@ -592,7 +610,9 @@ __device__ __forceinline__ void asm_mfma_run(const AsmRun& R, const AsmMTask* __
       }
     }
     __builtin_amdgcn_wave_barrier();
+    kg += ASM_U;
   }
+  while(kg < R.kg1);
 #undef TJ
 #undef TA
 #undef PS
