@@ -207,6 +207,10 @@ __global__ void __launch_bounds__(TPB) k_assemble(const AsmTask* __restrict__ ta
 //   transient:   n = slot*nJ + b,  B is masked to the rows of row-block `slot`, so each
 //                row-block of the k-group gets its own columns; D is stored and cleared
 typedef double dlg_v4d __attribute__((ext_vector_type(4)));
+#ifdef DLG_ASM_PROFILE
+// (tools only: cycles a wave spends [shape class][0 head of an iteration up to the tile writes, 1 the rest, 2 iterations, 3 waves])
+__device__ unsigned long long g_asm_prof[2][4];
+#endif
 // (-DDLG_ASM_NO_PREFETCH: the values of an iteration's rows fetched inside it -- tools/variant_lib.sh A/B)
 #ifndef DLG_ASM_NO_PREFETCH
 #define DLG_ASM_PREFETCH 1
@@ -412,8 +416,14 @@ __device__ __forceinline__ void asm_mfma_run(const AsmRun& R, const AsmMTask* __
 #pragma unroll
   for(int u = 0; u < ASM_U; u++) myrow[u*4*LEN + ZC] = 0.0;
   int kg = R.kg0;                       // (a run has at least one k-group: no test in front of the first iteration, the prefetch above stays above)
+#ifdef DLG_ASM_PROFILE
+  unsigned long long pf_head = 0, pf_rest = 0, pf_it = 0, pf_t0 = clock64();
+#endif
   do
   {
+#ifdef DLG_ASM_PROFILE
+    pf_t0 = clock64();
+#endif
     const int gv = gnv;
     uint32_t meta[ASM_U];
     int td[ASM_U];
@@ -469,6 +479,10 @@ __device__ __forceinline__ void asm_mfma_run(const AsmRun& R, const AsmMTask* __
     }
 #ifdef DLG_ASM_PREFETCH
     gnv = gnn; gnn = kg_fetch(kg + 2*ASM_U);
+#ifdef DLG_ASM_PROFILE
+    __builtin_amdgcn_wave_barrier();
+    { const unsigned long long t1 = clock64(); pf_head += t1 - pf_t0; pf_t0 = t1; }
+#endif
 #else
     gnv = kg_fetch(kg + ASM_U);
 #endif
@@ -610,9 +624,19 @@ __device__ __forceinline__ void asm_mfma_run(const AsmRun& R, const AsmMTask* __
       }
     }
     __builtin_amdgcn_wave_barrier();
+#ifdef DLG_ASM_PROFILE
+    { const unsigned long long t1 = clock64(); pf_rest += t1 - pf_t0; pf_it++; }
+#endif
     kg += ASM_U;
   }
   while(kg < R.kg1);
+#ifdef DLG_ASM_PROFILE
+  if(lane == 0)
+  {
+    const int c = HAS_T ? 1 : 0;
+    atomicAdd(&g_asm_prof[c][0], pf_head); atomicAdd(&g_asm_prof[c][1], pf_rest); atomicAdd(&g_asm_prof[c][2], pf_it); atomicAdd(&g_asm_prof[c][3], 1ull);
+  }
+#endif
 #undef TJ
 #undef TA
 #undef PS
@@ -1709,3 +1733,18 @@ void sparse_spec_invalidate(dlg_backend* b, int s)
   if(Y && Y->spec_valid && Y->spec_slot == s) Y->spec_valid = false;
   if(Y && Y->intact_slot == s) Y->intact_Lx = nullptr;      // (new inputs: panels assembled from the old ones are nobody's)
 }
+
+#ifdef DLG_ASM_PROFILE
+extern "C" void dlg_asm_profile_dump()
+{
+  unsigned long long h[2][4];
+  hipDeviceSynchronize();
+  hipMemcpyFromSymbol(h, HIP_SYMBOL(g_asm_prof), sizeof(h));
+  for(int c = 0; c < 2; c++)
+    if(h[c][3])
+      fprintf(stderr, "assembly kernel, %s tasks: %llu waves, %llu iterations, per iteration %.0f clocks at the head (prefetch consumed, next issued, tile written) + %.0f in the products and stores\n",
+              c ? "point (transient)" : "camera", h[c][3], h[c][2], (double)h[c][0]/h[c][2], (double)h[c][1]/h[c][2]);
+  memset(h, 0, sizeof(h));
+  hipMemcpyToSymbol(HIP_SYMBOL(g_asm_prof), h, sizeof(h));
+}
+#endif
